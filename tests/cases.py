@@ -1,0 +1,124 @@
+"""Shared case matrix for differential tests: (name, array, kwargs) tuples that force every encoder
+branch listed in SURVEY.md App. D-2 (LUT / const / raw blocks, 16x16 retry, TryRaiseMaxZError,
+bIsInt promotion, integer lossy, bit-plane cheat code, one-sweep, Huffman / DeltaHuffman, masks,
+nDepth > 1 with slice-difference encoding, multi band, NaN)."""
+import numpy as np
+
+ALL_DTYPES = [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.float32, np.float64]
+
+
+def _cast(x, dt):
+    dt = np.dtype(dt)
+    if dt.kind in "iu":
+        info = np.iinfo(dt)
+        return np.clip(np.rint(x), info.min, info.max).astype(dt)
+    return x.astype(dt)
+
+
+def terrain(rows, cols, rng, amp=500.0, base=1000.0, sigma=1.0):
+    i = np.arange(rows, dtype=np.float64)[:, None]
+    j = np.arange(cols, dtype=np.float64)[None, :]
+    return base + amp * np.sin(j / 37.0) * np.cos(i / 23.0) + sigma * rng.standard_normal((rows, cols))
+
+
+def mixed_regions(rows, cols, rng, dt):
+    """flat | stepped | noisy thirds -> const, LUT, bit-stuffed and (lossless float) raw blocks."""
+    x = terrain(rows, cols, rng, amp=300.0, base=400.0, sigma=3.0)
+    c1, c2 = cols // 3, 2 * cols // 3
+    x[:, :c1] = 77.0
+    x[:, c1:c2] = np.floor(x[:, c1:c2] / 64.0) * 64.0
+    x[: rows // 4, :c1] = 0.0
+    return _cast(x, dt)
+
+
+def basic_cases():
+    """Small but branch-complete; used by the CPU differential tests and (subset) GPU parity tests."""
+    rng = np.random.default_rng(7)
+    cases = []
+    shapes = [(8, 8), (64, 64), (129, 257), (1, 257), (257, 1), (5, 3), (100, 100), (16, 24)]
+    for dt in ALL_DTYPES:
+        kind = np.dtype(dt).kind
+        small = np.dtype(dt).itemsize == 1
+        for (r, c) in shapes:
+            amp, base = (40.0, 60.0) if small else (500.0, 1000.0)
+            x = terrain(r, c, rng, amp=amp, base=base, sigma=1.0 if kind == "f" else 2.0)
+            errs = [0.01, 0.5, 5.0] if kind == "f" else [0, 1, 5]
+            for e in errs:
+                cases.append((f"terrain-{np.dtype(dt).name}-{r}x{c}-e{e}", _cast(x, dt), dict(max_z_err=e)))
+        cases.append((f"mixed-{np.dtype(dt).name}", mixed_regions(100, 143, rng, dt), dict(max_z_err=0 if kind != "f" else 0.01)))
+        cases.append((f"mixed-lossy-{np.dtype(dt).name}", mixed_regions(77, 143, rng, dt), dict(max_z_err=2.0)))
+        cases.append((f"const-{np.dtype(dt).name}", np.full((33, 47), 5, dt), dict(max_z_err=0.5)))
+        cases.append((f"zeros-{np.dtype(dt).name}", np.zeros((33, 47), dt), dict(max_z_err=0.5)))
+    # ---- float specials
+    f = np.float32
+    x = terrain(256, 256, rng)
+    cases.append(("f32-allint", np.rint(x).astype(f), dict(max_z_err=0.01)))
+    cases.append(("f32-allint-e2.7", np.rint(x).astype(f), dict(max_z_err=2.7)))
+    cases.append(("f32-round1", np.round(1000 + 50 * np.sin(np.arange(256)[None, :] / 30.0) + rng.standard_normal((256, 256)), 1).astype(f), dict(max_z_err=0.01)))
+    cases.append(("f32-round2", np.round(1000 + 50 * np.sin(np.arange(256)[None, :] / 30.0) + rng.standard_normal((256, 256)), 2).astype(f), dict(max_z_err=0.001)))
+    cases.append(("f64-round1", np.round(terrain(100, 120, rng), 1), dict(max_z_err=0.01)))
+    y = np.full((256, 256), 100.0, f)
+    y[rng.random((256, 256)) < 0.05] += 0.02
+    cases.append(("f32-mb16", y, dict(max_z_err=0.01)))
+    cases.append(("f32-smooth-mb16", (100 + 0.001 * np.arange(256)[None, :] * np.ones((256, 1))).astype(f), dict(max_z_err=0.01)))
+    z = terrain(64, 80, rng).astype(f)
+    z[3, 5] = np.nan
+    z[10:20, 30:40] = np.nan
+    cases.append(("f32-nan", z, dict(max_z_err=0.01)))
+    cases.append(("f32-huge-range", (terrain(64, 64, rng) * 1e30).astype(f), dict(max_z_err=0.01)))
+    cases.append(("f32-tiny-err", terrain(64, 64, rng).astype(f), dict(max_z_err=1e-7)))
+    cases.append(("f64-wide", terrain(64, 64, rng) * 1e6, dict(max_z_err=1e-4)))
+    zr = terrain(64, 96, rng).astype(f)
+    zr[5, 7] = 3e30
+    zr[40:43, 50:70] *= 1e25
+    cases.append(("f32-some-raw", zr, dict(max_z_err=0.01)))
+    cases.append(("f32-neg", (-terrain(70, 90, rng)).astype(f), dict(max_z_err=0.1)))
+    cases.append(("f32-int16-offsets", (np.rint(terrain(64, 64, rng, amp=100, base=0, sigma=0) / 8) * 8 + 0.25 * rng.integers(0, 3, (64, 64))).astype(f), dict(max_z_err=0.01)))
+    # ---- integer specials
+    cases.append(("u16-lossy5", _cast(terrain(128, 128, rng), np.uint16), dict(max_z_err=5)))
+    cases.append(("u16-777", rng.integers(0, 65535, (128, 128)).astype(np.uint16), dict(max_z_err=777)))
+    cases.append(("i32-777", (rng.integers(-1000, 1000, (128, 128)) * 16 + rng.integers(0, 16, (128, 128))).astype(np.int32), dict(max_z_err=777)))
+    cases.append(("i32-wide", rng.integers(-2**31, 2**31 - 1, (64, 64)).astype(np.int32), dict(max_z_err=0)))
+    cases.append(("u32-wide", rng.integers(0, 2**32 - 1, (64, 64)).astype(np.uint32), dict(max_z_err=0)))
+    cases.append(("u32-big-offsets", (rng.integers(0, 1000, (64, 64)) + 3_000_000_000).astype(np.uint32), dict(max_z_err=0)))
+    cases.append(("i16-neg-offsets", (rng.integers(0, 100, (64, 64)) - 100).astype(np.int16), dict(max_z_err=0)))
+    # ---- 8-bit: Huffman / DeltaHuffman / one sweep
+    i = np.arange(96)[:, None]; j = np.arange(128)[None, :]
+    smooth = 128 + 100 * np.sin(j / 40.0) * np.cos(i / 31.0)
+    rgb = np.stack([_cast(smooth + 4 * rng.standard_normal(smooth.shape) + 5 * k, np.uint8) for k in range(3)], axis=-1)
+    cases.append(("u8-rgb-deltahuff", rgb, dict(max_z_err=0, n_depth=3)))
+    cases.append(("u8-rgb-lossy", rgb, dict(max_z_err=2, n_depth=3)))
+    cases.append(("u8-random-onesweep", rng.integers(0, 256, (64, 64, 3)).astype(np.uint8), dict(max_z_err=0, n_depth=3)))
+    cases.append(("u8-fewvals-huff", rng.choice(np.array([3, 50, 51, 200], np.uint8), (80, 90), p=[0.7, 0.1, 0.1, 0.1]), dict(max_z_err=0)))
+    cases.append(("i8-smooth", _cast(smooth - 128 + 3 * rng.standard_normal(smooth.shape), np.int8), dict(max_z_err=0)))
+    cases.append(("i8-rand30", (rng.integers(0, 30, (257, 713 // 8, 3))).astype(np.int8), dict(max_z_err=0, n_depth=3)))
+    cases.append(("u8-twovals", rng.choice(np.array([0, 255], np.uint8), (64, 64)), dict(max_z_err=0)))
+    # ---- nDepth > 1 (slice difference encoding for integer lossless)
+    base = terrain(70, 90, rng)
+    cube = np.stack([base + 3 * k + rng.standard_normal(base.shape) for k in range(4)], axis=-1)
+    cases.append(("u16-depth4", _cast(cube, np.uint16), dict(max_z_err=0, n_depth=4)))
+    cases.append(("i32-depth4", _cast(cube * 1000, np.int32), dict(max_z_err=0, n_depth=4)))
+    cases.append(("i16-depth2-lossy", _cast(cube[..., :2], np.int16), dict(max_z_err=3, n_depth=2)))
+    cases.append(("f32-depth3", cube[..., :3].astype(f), dict(max_z_err=0.01, n_depth=3)))
+    cube_same = np.repeat(_cast(base, np.uint16)[..., None], 3, axis=-1)
+    cases.append(("u16-depth3-identical", cube_same, dict(max_z_err=0, n_depth=3)))
+    # ---- masks
+    m = np.ones((129, 257), np.uint8)
+    m[::10, :] = 0
+    m[:, ::13] = 0
+    cases.append(("f32-mask-grid", terrain(129, 257, rng).astype(f), dict(max_z_err=0.01, mask=m)))
+    mr = (rng.random((129, 257)) > 0.3).astype(np.uint8)
+    cases.append(("u16-mask-random", _cast(terrain(129, 257, rng), np.uint16), dict(max_z_err=0, mask=mr)))
+    cases.append(("u8-mask-random", _cast(smooth[:96, :128], np.uint8), dict(max_z_err=0, mask=mr[:96, :128].copy())))
+    mh = np.ones((64, 64), np.uint8); mh[20:50, 10:60] = 0
+    cases.append(("f32-mask-hole", terrain(64, 64, rng).astype(f), dict(max_z_err=0.1, mask=mh)))
+    cases.append(("f32-mask-allinvalid", terrain(64, 64, rng).astype(f), dict(max_z_err=0.1, mask=np.zeros((64, 64), np.uint8))))
+    cases.append(("u16-depth3-mask", _cast(cube[..., :3], np.uint16), dict(max_z_err=0, n_depth=3, mask=(rng.random((70, 90)) > 0.2).astype(np.uint8))))
+    # ---- multi band
+    bands = np.stack([terrain(50, 60, rng, base=1000 + 100 * b) for b in range(3)]).astype(f)
+    cases.append(("f32-3bands", bands, dict(max_z_err=0.01, n_bands=3)))
+    mb = np.stack([(rng.random((50, 60)) > 0.2).astype(np.uint8) for _ in range(3)])
+    cases.append(("f32-3bands-3masks", bands, dict(max_z_err=0.01, n_bands=3, mask=mb)))
+    cases.append(("f32-3bands-1mask", bands, dict(max_z_err=0.01, n_bands=3, mask=mb[0].copy())))
+    cases.append(("u8-3bands", _cast(bands / 8, np.uint8), dict(max_z_err=0, n_bands=3)))
+    return cases
