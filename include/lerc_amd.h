@@ -1,0 +1,122 @@
+/*
+ * lerc_amd.h -- C ABI of liblerc_amd.so, the MI355X-native LERC (Lerc2 v6) encode / decode path.
+ *
+ * Part 1 is the stock LERC C API: the twelve entry points below have exactly the names, argument
+ * order, argument meaning and status codes of Esri/lerc's src/LercLib/include/Lerc_c_api.h, so a
+ * host that binds libLerc (ctypes / P/Invoke / cgo / GDAL) binds this library unchanged
+ * (INTEGRATION.md shows the bindings).  Every pointer is a HOST pointer owned by the caller; the
+ * library stages through HBM, runs the HIP kernels and copies the result back.  There is no CPU
+ * codec path inside: without a working HIP device every call returns lerc_status 1 (Failed) and
+ * says so on stderr.
+ *
+ * Part 2 is new surface (not in the reference): the same codec on DEVICE pointers, for callers
+ * that already hold rasters in HBM (bench.py, tile mosaics sharded over several GPUs).
+ *
+ * Data layout (reference Lerc_c_api.h:113-124): raw pixels are row-major, top-left first,
+ * [nBands][nRows][nCols][nDepth], little endian; masks are nMasks x nRows x nCols bytes, 1 = valid.
+ * dataType: 0 char, 1 uchar, 2 short, 3 ushort, 4 int, 5 uint, 6 float, 7 double (Lerc_types.h:22-32).
+ * lerc_status: 0 Ok, 1 Failed, 2 WrongParam, 3 BufferTooSmall, 4 NaN, 5 HasNoData,
+ *              6 DimensionsTooLarge (Lerc_types.h:11-20).
+ */
+#ifndef LERC_AMD_H
+#define LERC_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LERC_AMD_API __attribute__((visibility("default")))
+
+typedef unsigned int lerc_status;
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 1 -- stock API (replaces the reference implementation file src/LercLib/Lerc_c_api_impl.cpp)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* reference Lerc_c_api.h:126-137 -- exact size lerc_encode() will write ("accurate to the byte") */
+LERC_AMD_API lerc_status lerc_computeCompressedSize(const void* pData, unsigned int dataType, int nDepth, int nCols,
+    int nRows, int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr, unsigned int* numBytes);
+
+/* reference Lerc_c_api.h:141-154 -- zero-fills pOutBuffer, writes the blob, sets *nBytesWritten */
+LERC_AMD_API lerc_status lerc_encode(const void* pData, unsigned int dataType, int nDepth, int nCols, int nRows,
+    int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr, unsigned char* pOutBuffer,
+    unsigned int outBufferSize, unsigned int* nBytesWritten);
+
+/* reference Lerc_c_api.h:159-171 and :175-189 -- codecVersion -1 or 6; older codec versions (2..5)
+ * are encode targets this library does not produce: WrongParam(2) */
+LERC_AMD_API lerc_status lerc_computeCompressedSizeForVersion(const void* pData, int codecVersion, unsigned int dataType,
+    int nDepth, int nCols, int nRows, int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr,
+    unsigned int* numBytes);
+LERC_AMD_API lerc_status lerc_encodeForVersion(const void* pData, int codecVersion, unsigned int dataType, int nDepth,
+    int nCols, int nRows, int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr,
+    unsigned char* pOutBuffer, unsigned int outBufferSize, unsigned int* nBytesWritten);
+
+/* reference Lerc_c_api.h:203-210 -- header walk only, runs on the host.
+ * infoArray: version, dataType, nDepth, nCols, nRows, nBands, nValidPixels(band 0), blobSize, nMasks,
+ *            nDepth, nUsesNoDataValue;  dataRangeArray: zMin, zMax, maxZErrUsed (Lerc_types.h:34-56) */
+LERC_AMD_API lerc_status lerc_getBlobInfo(const unsigned char* pLercBlob, unsigned int blobSize,
+    unsigned int* infoArray, double* dataRangeArray, int infoArraySize, int dataRangeArraySize);
+
+/* reference Lerc_c_api.h:221-228 */
+LERC_AMD_API lerc_status lerc_getDataRanges(const unsigned char* pLercBlob, unsigned int blobSize, int nDepth,
+    int nBands, double* pMins, double* pMaxs);
+
+/* reference Lerc_c_api.h:238-252 -- pData / pValidBytes pre-allocated by the caller */
+LERC_AMD_API lerc_status lerc_decode(const unsigned char* pLercBlob, unsigned int blobSize, int nMasks,
+    unsigned char* pValidBytes, int nDepth, int nCols, int nRows, int nBands, unsigned int dataType, void* pData);
+
+/* reference Lerc_c_api.h:258-270 */
+LERC_AMD_API lerc_status lerc_decodeToDouble(const unsigned char* pLercBlob, unsigned int blobSize, int nMasks,
+    unsigned char* pValidBytes, int nDepth, int nCols, int nRows, int nBands, double* pData);
+
+/* reference Lerc_c_api.h:300-380 -- the _4D variants add a per-band noData value.  With
+ * pUsesNoData == NULL (or all zero) they are the calls above; a non-zero noData request is not
+ * implemented on the device yet and returns Failed(1). */
+LERC_AMD_API lerc_status lerc_computeCompressedSize_4D(const void* pData, unsigned int dataType, int nDepth, int nCols,
+    int nRows, int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr, unsigned int* numBytes,
+    const unsigned char* pUsesNoData, const double* noDataValues);
+LERC_AMD_API lerc_status lerc_encode_4D(const void* pData, unsigned int dataType, int nDepth, int nCols, int nRows,
+    int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr, unsigned char* pOutBuffer,
+    unsigned int outBufferSize, unsigned int* nBytesWritten, const unsigned char* pUsesNoData,
+    const double* noDataValues);
+LERC_AMD_API lerc_status lerc_decode_4D(const unsigned char* pLercBlob, unsigned int blobSize, int nMasks,
+    unsigned char* pValidBytes, int nDepth, int nCols, int nRows, int nBands, unsigned int dataType, void* pData,
+    unsigned char* pUsesNoData, double* noDataValues);
+LERC_AMD_API lerc_status lerc_decodeToDouble_4D(const unsigned char* pLercBlob, unsigned int blobSize, int nMasks,
+    unsigned char* pValidBytes, int nDepth, int nCols, int nRows, int nBands, double* pData,
+    unsigned char* pUsesNoData, double* noDataValues);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 2 -- device-pointer extension (new; no reference counterpart)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lerc_amd_context lerc_amd_context;
+
+/* hipStream: a hipStream_t cast to void* on which all work is enqueued, or NULL for a private
+ * stream.  A context owns its scratch HBM; use one context per host thread. */
+LERC_AMD_API lerc_amd_context* lerc_amd_create(void* hipStream);
+LERC_AMD_API void lerc_amd_destroy(lerc_amd_context* ctx);
+LERC_AMD_API void lerc_amd_set_stream(lerc_amd_context* ctx, void* hipStream);
+LERC_AMD_API const char* lerc_amd_last_error(lerc_amd_context* ctx);
+
+/* Same contracts as lerc_encode / lerc_decode, but pData, pValidBytes, pOutBuffer / pLercBlob are
+ * DEVICE pointers.  dOutBuffer == NULL turns lerc_amd_encode_device into the exact size query.
+ * The calls return after the stream has been synchronised (the blob size is a host-visible result). */
+LERC_AMD_API lerc_status lerc_amd_encode_device(lerc_amd_context* ctx, const void* dData, unsigned int dataType,
+    int nDepth, int nCols, int nRows, int nBands, int nMasks, const unsigned char* dValidBytes, double maxZErr,
+    unsigned char* dOutBuffer, unsigned int outBufferSize, unsigned int* nBytesWritten);
+LERC_AMD_API lerc_status lerc_amd_decode_device(lerc_amd_context* ctx, const unsigned char* dLercBlob,
+    unsigned int blobSize, int nMasks, unsigned char* dValidBytes, int nDepth, int nCols, int nRows, int nBands,
+    unsigned int dataType, void* dData);
+
+/* Per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline of the
+ * dominant kernel).  lerc_amd_profile_read writes lines "kernel_group total_ms launches" into buf. */
+LERC_AMD_API void lerc_amd_profile_enable(lerc_amd_context* ctx, int on);
+LERC_AMD_API int lerc_amd_profile_read(lerc_amd_context* ctx, char* buf, int cap, int reset);
+
+/* library / build identification: "lerc_amd <version> gfx950 hip" (or "... hipsim" for the CPU test build) */
+LERC_AMD_API const char* lerc_amd_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

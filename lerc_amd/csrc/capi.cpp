@@ -1,0 +1,340 @@
+// capi.cpp -- extern "C" boundary of liblerc_amd.so (include/lerc_amd.h).
+// Argument validation and status codes follow the reference's Lerc_c_api_impl.cpp:33-304; host
+// buffers are staged through HBM, all codec work happens in codec_encode.cpp / codec_decode.cpp.
+#include "../../include/lerc_amd.h"
+#include "codec.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <new>
+
+using namespace lerc;
+
+struct lerc_amd_context
+{
+  Context ctx;
+  // staging buffers for the host-pointer API (grown on demand, owned by the context)
+  void* io[3] = { nullptr, nullptr, nullptr };
+  size_t ioCap[3] = { 0, 0, 0 };
+  ~lerc_amd_context() { for (void* p : io) if (p) hipFree(p); }
+  void* stage(int slot, size_t bytes)
+  {
+    if (bytes <= ioCap[slot]) return io[slot];
+    if (io[slot]) { hipStreamSynchronize(ctx.activeStream()); hipFree(io[slot]); io[slot] = nullptr; ioCap[slot] = 0; }
+    const size_t want = bytes + bytes / 16 + 4096;
+    if (hipMalloc(&io[slot], want) != hipSuccess) return nullptr;
+    ioCap[slot] = want;
+    return io[slot];
+  }
+};
+
+namespace {
+
+lerc_amd_context* threadHandle()
+{
+  static thread_local lerc_amd_context* h = nullptr;
+  if (!h) h = new (std::nothrow) lerc_amd_context();
+  return (h && h->ctx.ok()) ? h : nullptr;
+}
+
+bool masksArgOk(int nMasks, int nBands, const void* pValidBytes)
+{
+  return (nMasks == 0 || nMasks == 1 || nMasks == nBands) && !(nMasks > 0 && !pValidBytes);
+}
+
+bool dimsOk(int nDepth, int nCols, int nRows, size_t elemSize)    // Lerc.cpp:1622-1639
+{
+  if (nDepth <= 0 || nCols <= 0 || nRows <= 0) return false;
+  const u64 nPix = (u64)nRows * nCols, lim = INT_MAX, bpp = elemSize;
+  return !(nPix > lim || bpp > lim || bpp * nDepth > lim || bpp * nDepth * nPix > lim);
+}
+
+bool usesNoData(const unsigned char* pUsesNoData, int nBands)
+{
+  if (!pUsesNoData) return false;
+  for (int i = 0; i < nBands; i++) if (pUsesNoData[i]) return true;
+  return false;
+}
+
+// shared by lerc_encode / lerc_computeCompressedSize: host pointers in, blob (optionally) out
+lerc_status encodeHost(const void* pData, unsigned dataType, int nDepth, int nCols, int nRows, int nBands, int nMasks,
+                       const unsigned char* pValidBytes, double maxZErr, unsigned char* pOut, unsigned outSize,
+                       unsigned* result, bool sizeOnly)
+{
+  lerc_amd_context* h = threadHandle();
+  if (!h) return kFailed;
+  Context& ctx = h->ctx;
+  hipStream_t st = ctx.activeStream();
+  const size_t tb = (size_t)dtSize((int)dataType);
+  if (!dimsOk(nDepth, nCols, nRows, tb)) return kDimsTooLarge;
+  const size_t nPix = (size_t)nRows * nCols;
+  const size_t dataBytes = nPix * nDepth * tb * nBands, maskBytes = (size_t)nMasks * nPix;
+  u8* dData = (u8*)h->stage(0, dataBytes);
+  u8* dMask = nMasks ? (u8*)h->stage(1, maskBytes) : nullptr;
+  if (!dData || (nMasks && !dMask)) return kFailed;
+  hipMemcpyAsync(dData, pData, dataBytes, hipMemcpyHostToDevice, st);
+  if (nMasks) hipMemcpyAsync(dMask, pValidBytes, maskBytes, hipMemcpyHostToDevice, st);
+
+  EncodeRequest rq;
+  rq.dData = dData; rq.dValidBytes = dMask; rq.dt = (int)dataType; rq.nDepth = nDepth; rq.nCols = nCols; rq.nRows = nRows;
+  rq.nBands = nBands; rq.nMasks = nMasks; rq.maxZErr = maxZErr;
+  u32 needed = 0, written = 0;
+  if (sizeOnly)
+  {
+    const u32 rc = encodeDevice(ctx, rq, needed, written);
+    if (rc == kOk) *result = needed;
+    return rc;
+  }
+  // a blob never exceeds raw pixels + mask + a few hundred bytes per band (one-sweep fallback)
+  const u64 bound = (u64)nBands * (nPix * nDepth * tb + nPix / 4 + 4096);
+  const u32 cap = (u32)std::min<u64>(outSize, bound);
+  u8* dOut = (u8*)h->stage(2, cap);
+  if (!dOut) return kFailed;
+  rq.dOut = dOut; rq.outCapacity = cap;
+  memset(pOut, 0, outSize);    // Lerc.cpp:374
+  const u32 rc = encodeDevice(ctx, rq, needed, written);
+  if (rc != kOk) return rc;
+  if (hipMemcpyAsync(pOut, dOut, written, hipMemcpyDeviceToHost, st) != hipSuccess) return kFailed;
+  if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
+  *result = written;
+  return kOk;
+}
+
+lerc_status decodeHost(const unsigned char* blob, unsigned blobSize, int nMasks, unsigned char* pValidBytes, int nDepth,
+                       int nCols, int nRows, int nBands, unsigned dataType, void* pData, bool toDouble)
+{
+  lerc_amd_context* h = threadHandle();
+  if (!h) return kFailed;
+  Context& ctx = h->ctx;
+  hipStream_t st = ctx.activeStream();
+  const size_t tb = (size_t)dtSize((int)dataType);
+  if (!dimsOk(nDepth, nCols, nRows, tb)) return kDimsTooLarge;
+  const size_t nPix = (size_t)nRows * nCols, nVals = nPix * nDepth * nBands;
+  const size_t outBytes = nVals * tb, maskBytes = (size_t)nMasks * nPix;
+  const bool widen = toDouble && dataType != DT_Double;
+  u8* dOut = (u8*)h->stage(0, outBytes + (widen ? nVals * 8 + 256 : 0));
+  u8* dMask = nMasks ? (u8*)h->stage(1, maskBytes) : nullptr;
+  if (!dOut || (nMasks && !dMask)) return kFailed;
+
+  DecodeRequest rq;
+  rq.hBlob = blob; rq.blobSize = blobSize; rq.dt = (int)dataType; rq.nDepth = nDepth; rq.nCols = nCols; rq.nRows = nRows;
+  rq.nBands = nBands; rq.nMasks = nMasks; rq.dOut = dOut; rq.dValidBytes = dMask;
+  const u32 rc = decodeDevice(ctx, rq);
+  if (rc != kOk) return rc;
+  if (widen)
+  {
+    double* dWide = (double*)(dOut + ((outBytes + 255) / 256) * 256);
+    launchWidenToDouble((int)dataType, dOut, dWide, (i64)nVals, st);
+    hipMemcpyAsync(pData, dWide, nVals * 8, hipMemcpyDeviceToHost, st);
+  }
+  else hipMemcpyAsync(pData, dOut, outBytes, hipMemcpyDeviceToHost, st);
+  if (nMasks) hipMemcpyAsync(pValidBytes, dMask, maskBytes, hipMemcpyDeviceToHost, st);
+  return hipStreamSynchronize(st) == hipSuccess ? (lerc_status)kOk : (lerc_status)kFailed;
+}
+
+}    // namespace
+
+extern "C" {
+
+lerc_status lerc_computeCompressedSize_4D(const void* pData, unsigned int dataType, int nDepth, int nCols, int nRows,
+  int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr, unsigned int* numBytes,
+  const unsigned char* pUsesNoData, const double* noDataValues)
+{
+  if (!numBytes) return kWrongParam;
+  *numBytes = 0;
+  if (!pData || dataType >= DT_Undefined || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0 || maxZErr < 0) return kWrongParam;
+  if (!masksArgOk(nMasks, nBands, pValidBytes)) return kWrongParam;
+  if (usesNoData(pUsesNoData, nBands)) return noDataValues ? kFailed : kWrongParam;    // noData: not on the device yet
+  return encodeHost(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, nullptr, 0, numBytes, true);
+}
+
+lerc_status lerc_encode_4D(const void* pData, unsigned int dataType, int nDepth, int nCols, int nRows, int nBands,
+  int nMasks, const unsigned char* pValidBytes, double maxZErr, unsigned char* pOutBuffer, unsigned int outBufferSize,
+  unsigned int* nBytesWritten, const unsigned char* pUsesNoData, const double* noDataValues)
+{
+  if (!nBytesWritten) return kWrongParam;
+  *nBytesWritten = 0;
+  if (!pData || dataType >= DT_Undefined || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0 || maxZErr < 0
+    || !pOutBuffer || !outBufferSize)
+    return kWrongParam;
+  if (!masksArgOk(nMasks, nBands, pValidBytes)) return kWrongParam;
+  if (usesNoData(pUsesNoData, nBands)) return noDataValues ? kFailed : kWrongParam;
+  return encodeHost(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, pOutBuffer, outBufferSize,
+                    nBytesWritten, false);
+}
+
+lerc_status lerc_computeCompressedSizeForVersion(const void* pData, int codecVersion, unsigned int dataType, int nDepth,
+  int nCols, int nRows, int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr, unsigned int* numBytes)
+{
+  if (!numBytes) return kWrongParam;
+  *numBytes = 0;
+  if (codecVersion >= 0 && codecVersion != kCodecVersion) return kWrongParam;
+  return lerc_computeCompressedSize_4D(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, numBytes,
+                                       nullptr, nullptr);
+}
+
+lerc_status lerc_encodeForVersion(const void* pData, int codecVersion, unsigned int dataType, int nDepth, int nCols,
+  int nRows, int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr, unsigned char* pOutBuffer,
+  unsigned int outBufferSize, unsigned int* nBytesWritten)
+{
+  if (!nBytesWritten) return kWrongParam;
+  *nBytesWritten = 0;
+  if (codecVersion >= 0 && codecVersion != kCodecVersion) return kWrongParam;
+  return lerc_encode_4D(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, pOutBuffer,
+                        outBufferSize, nBytesWritten, nullptr, nullptr);
+}
+
+lerc_status lerc_computeCompressedSize(const void* pData, unsigned int dataType, int nDepth, int nCols, int nRows,
+  int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr, unsigned int* numBytes)
+{
+  return lerc_computeCompressedSizeForVersion(pData, -1, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes,
+                                              maxZErr, numBytes);
+}
+
+lerc_status lerc_encode(const void* pData, unsigned int dataType, int nDepth, int nCols, int nRows, int nBands,
+  int nMasks, const unsigned char* pValidBytes, double maxZErr, unsigned char* pOutBuffer, unsigned int outBufferSize,
+  unsigned int* nBytesWritten)
+{
+  return lerc_encodeForVersion(pData, -1, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, pOutBuffer,
+                               outBufferSize, nBytesWritten);
+}
+
+lerc_status lerc_getBlobInfo(const unsigned char* pLercBlob, unsigned int blobSize, unsigned int* infoArray,
+  double* dataRangeArray, int infoArraySize, int dataRangeArraySize)
+{
+  if (!pLercBlob || !blobSize || (!infoArray && !dataRangeArray) || ((infoArraySize <= 0) && (dataRangeArraySize <= 0)))
+    return kWrongParam;
+  BlobInfo li;
+  const u32 e = getBlobInfo(pLercBlob, blobSize, li);
+  if (e != kOk) return e;
+  if (infoArray)
+  {
+    const unsigned v[11] = { (unsigned)li.version, (unsigned)li.dt, (unsigned)li.nDepth, (unsigned)li.nCols, (unsigned)li.nRows,
+      (unsigned)li.nBands, (unsigned)li.numValid, li.blobSize, (unsigned)li.nMasks, (unsigned)li.nDepth, (unsigned)li.nUsesNoData };
+    if (infoArraySize > 0) memset(infoArray, 0, infoArraySize * sizeof(unsigned));
+    for (int i = 0; i < infoArraySize && i < 11; i++) infoArray[i] = v[i];
+  }
+  if (dataRangeArray)
+  {
+    if (dataRangeArraySize > 0) memset(dataRangeArray, 0, dataRangeArraySize * sizeof(double));
+    const bool nd = (li.nDepth > 1) && (li.nUsesNoData > 0);
+    const double v[3] = { !nd ? li.zMin : -1, !nd ? li.zMax : -1, li.maxZErr };
+    for (int i = 0; i < dataRangeArraySize && i < 3; i++) dataRangeArray[i] = v[i];
+  }
+  return kOk;
+}
+
+lerc_status lerc_getDataRanges(const unsigned char* pLercBlob, unsigned int blobSize, int nDepth, int nBands,
+  double* pMins, double* pMaxs)
+{
+  if (!pLercBlob || !blobSize || !pMins || !pMaxs || nDepth <= 0 || nBands <= 0) return kWrongParam;
+  BlobInfo li;
+  return getBlobInfo(pLercBlob, blobSize, li, pMins, pMaxs, (size_t)nDepth * (size_t)nBands);
+}
+
+lerc_status lerc_decode_4D(const unsigned char* pLercBlob, unsigned int blobSize, int nMasks, unsigned char* pValidBytes,
+  int nDepth, int nCols, int nRows, int nBands, unsigned int dataType, void* pData, unsigned char* pUsesNoData,
+  double* noDataValues)
+{
+  if (!pLercBlob || !blobSize || !pData || dataType >= DT_Undefined || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0)
+    return kWrongParam;
+  if (!masksArgOk(nMasks, nBands, pValidBytes)) return kWrongParam;
+  (void)pUsesNoData; (void)noDataValues;    // only written for blobs that carry noData, which decodeDevice refuses
+  return decodeHost(pLercBlob, blobSize, nMasks, pValidBytes, nDepth, nCols, nRows, nBands, dataType, pData, false);
+}
+
+lerc_status lerc_decode(const unsigned char* pLercBlob, unsigned int blobSize, int nMasks, unsigned char* pValidBytes,
+  int nDepth, int nCols, int nRows, int nBands, unsigned int dataType, void* pData)
+{
+  return lerc_decode_4D(pLercBlob, blobSize, nMasks, pValidBytes, nDepth, nCols, nRows, nBands, dataType, pData, nullptr, nullptr);
+}
+
+lerc_status lerc_decodeToDouble_4D(const unsigned char* pLercBlob, unsigned int blobSize, int nMasks,
+  unsigned char* pValidBytes, int nDepth, int nCols, int nRows, int nBands, double* pData, unsigned char* pUsesNoData,
+  double* noDataValues)
+{
+  if (!pLercBlob || !blobSize || !pData || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0) return kWrongParam;
+  if (!masksArgOk(nMasks, nBands, pValidBytes)) return kWrongParam;
+  BlobInfo li;
+  const u32 e = getBlobInfo(pLercBlob, blobSize, li);
+  if (e != kOk) return e;
+  if (li.nDepth != nDepth || li.nCols != nCols || li.nRows != nRows || li.nBands != nBands) return kFailed;
+  (void)pUsesNoData; (void)noDataValues;
+  return decodeHost(pLercBlob, blobSize, nMasks, pValidBytes, nDepth, nCols, nRows, nBands, (unsigned)li.dt, pData, true);
+}
+
+lerc_status lerc_decodeToDouble(const unsigned char* pLercBlob, unsigned int blobSize, int nMasks,
+  unsigned char* pValidBytes, int nDepth, int nCols, int nRows, int nBands, double* pData)
+{
+  return lerc_decodeToDouble_4D(pLercBlob, blobSize, nMasks, pValidBytes, nDepth, nCols, nRows, nBands, pData, nullptr, nullptr);
+}
+
+// ---- device-pointer extension -------------------------------------------------------------------
+lerc_amd_context* lerc_amd_create(void* hipStream)
+{
+  lerc_amd_context* h = new (std::nothrow) lerc_amd_context();
+  if (!h) return nullptr;
+  if (!h->ctx.ok()) { delete h; return nullptr; }
+  h->ctx.setStream((hipStream_t)hipStream);
+  return h;
+}
+
+void lerc_amd_destroy(lerc_amd_context* h) { delete h; }
+
+void lerc_amd_set_stream(lerc_amd_context* h, void* hipStream) { if (h) h->ctx.setStream((hipStream_t)hipStream); }
+
+const char* lerc_amd_last_error(lerc_amd_context* h) { return h ? h->ctx.lastError.c_str() : "no context"; }
+
+lerc_status lerc_amd_encode_device(lerc_amd_context* h, const void* dData, unsigned int dataType, int nDepth, int nCols,
+  int nRows, int nBands, int nMasks, const unsigned char* dValidBytes, double maxZErr, unsigned char* dOutBuffer,
+  unsigned int outBufferSize, unsigned int* nBytesWritten)
+{
+  if (!h || !nBytesWritten) return kWrongParam;
+  *nBytesWritten = 0;
+  if (!dData || dataType >= DT_Undefined || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0 || maxZErr < 0) return kWrongParam;
+  if (!masksArgOk(nMasks, nBands, dValidBytes)) return kWrongParam;
+  if (!dimsOk(nDepth, nCols, nRows, (size_t)dtSize((int)dataType))) return kDimsTooLarge;
+  EncodeRequest rq;
+  rq.dData = dData; rq.dValidBytes = dValidBytes; rq.dt = (int)dataType; rq.nDepth = nDepth; rq.nCols = nCols; rq.nRows = nRows;
+  rq.nBands = nBands; rq.nMasks = nMasks; rq.maxZErr = maxZErr; rq.dOut = dOutBuffer; rq.outCapacity = outBufferSize;
+  u32 needed = 0, written = 0;
+  const u32 rc = encodeDevice(h->ctx, rq, needed, written);
+  if (rc == kOk) *nBytesWritten = dOutBuffer ? written : needed;
+  return rc;
+}
+
+lerc_status lerc_amd_decode_device(lerc_amd_context* h, const unsigned char* dLercBlob, unsigned int blobSize, int nMasks,
+  unsigned char* dValidBytes, int nDepth, int nCols, int nRows, int nBands, unsigned int dataType, void* dData)
+{
+  if (!h || !dLercBlob || !blobSize || !dData || dataType >= DT_Undefined || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0)
+    return kWrongParam;
+  if (!masksArgOk(nMasks, nBands, dValidBytes)) return kWrongParam;
+  if (!dimsOk(nDepth, nCols, nRows, (size_t)dtSize((int)dataType))) return kDimsTooLarge;
+  DecodeRequest rq;
+  rq.dBlob = dLercBlob; rq.blobSize = blobSize; rq.dt = (int)dataType; rq.nDepth = nDepth; rq.nCols = nCols; rq.nRows = nRows;
+  rq.nBands = nBands; rq.nMasks = nMasks; rq.dOut = dData; rq.dValidBytes = dValidBytes;
+  return decodeDevice(h->ctx, rq);
+}
+
+void lerc_amd_profile_enable(lerc_amd_context* h, int on) { if (h) h->ctx.profEnable(on != 0); }
+
+int lerc_amd_profile_read(lerc_amd_context* h, char* buf, int cap, int reset)
+{
+  if (!h || !buf || cap <= 0) return -1;
+  const std::string r = h->ctx.profReport(reset != 0);
+  const int n = (int)std::min<size_t>(r.size(), (size_t)cap - 1);
+  memcpy(buf, r.data(), n);
+  buf[n] = 0;
+  return n;
+}
+
+const char* lerc_amd_build_info(void)
+{
+#ifdef HIPSIM
+  return "lerc_amd 0.1 hipsim (CPU SIMT emulator -- test build, not the product)";
+#else
+  return "lerc_amd 0.1 gfx950 hip";
+#endif
+}
+
+}    // extern "C"

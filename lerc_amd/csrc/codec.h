@@ -1,0 +1,122 @@
+// codec.h -- host side of the MI355X LERC path: per-call context, header / mask / mode-decision logic
+// and the kernel pipelines behind lerc_encode() / lerc_decode().
+//
+// Reference counterparts: Lerc::EncodeInternal (Lerc.cpp:628-789), Lerc::DecodeTempl (:397-521),
+// Lerc2::ComputeNumBytesNeededToWrite (Lerc2.cpp:179-381), Lerc2::Encode (:396-480), Lerc2::Decode
+// (:577-694).  Pixel-touching work is never done here: it is enqueued as HIP kernels (kernels.h).
+#pragma once
+#include "kernels.h"
+
+#include <string>
+#include <vector>
+
+namespace lerc {
+
+// Lerc2::HeaderInfo (Lerc2.h:102-131)
+struct Header
+{
+  int version = kCodecVersion;
+  u32 checksum = 0;
+  int nRows = 0, nCols = 0, nDepth = 1, numValid = 0, mbSize = 8, blobSize = 0, dt = DT_Undefined, nBlobsMore = 0;
+  u8 passNoData = 0, isInt = 0, rsv3 = 0, rsv4 = 0;
+  double maxZErr = 0, zMin = 0, zMax = 0, noDataVal = 0, noDataValOrig = 0;
+  bool tryHuffmanInt() const { return version >= 2 && (dt == DT_Byte || dt == DT_Char) && maxZErr == 0.5; }
+  bool tryHuffmanFlt() const { return version >= 6 && (dt == DT_Float || dt == DT_Double) && maxZErr == 0; }
+};
+u32 headerBytes(int version);
+void writeHeader(u8* dst, const Header& h);
+bool readHeader(const u8* src, size_t n, Header& h, size_t& used);
+
+// RLE of the validity bit mask (host; the mask is << 1 % of the bytes and inherently sequential)
+void rleEncode(const u8* src, size_t n, std::vector<u8>& out);
+bool rleDecode(const u8* src, size_t left, u8* dst, size_t dstSize);
+
+// ---- growable device workspace + stream, one per host thread (C API) or per handle (device API)
+class Context
+{
+public:
+  Context();
+  ~Context();
+  bool ok() const { return m_ok; }
+  hipStream_t stream() const { return m_stream; }
+  void setStream(hipStream_t s) { m_userStream = s; }
+  hipStream_t activeStream() const { return m_userStream ? m_userStream : m_stream; }
+
+  // bump allocation out of one device slab; reserve() may re-allocate (invalidates earlier pointers)
+  bool reserve(size_t bytes);
+  void reset() { m_used = 0; }
+  void* alloc(size_t bytes, size_t align = 256);
+  template<class T> T* allocT(size_t n) { return (T*)alloc(n * sizeof(T)); }
+
+  // small pinned host mirror for results read back after a sync
+  void* pinned(size_t bytes);
+
+  std::string lastError;
+
+  // optional per-kernel timing with HIP events on the active stream (bench.py: roofline of the dominant kernel)
+  void profEnable(bool on) { m_prof = on; }
+  bool profOn() const { return m_prof; }
+  void profBegin(const char* name);
+  void profEnd();
+  void profCollect();                        // call after a stream sync
+  std::string profReport(bool reset);        // "name total_ms launches" per line
+
+private:
+  struct ProfEntry { const char* name; hipEvent_t a, b; };
+  struct ProfAcc { std::string name; double ms; int n; };
+  bool m_prof = false;
+  std::vector<ProfEntry> m_pending;
+  std::vector<hipEvent_t> m_eventPool;
+  std::vector<ProfAcc> m_acc;
+  hipEvent_t profEvent();
+
+  bool m_ok = false;
+  hipStream_t m_stream = nullptr, m_userStream = nullptr;
+  u8* m_slab = nullptr;
+  size_t m_cap = 0, m_used = 0;
+  void* m_pinned = nullptr;
+  size_t m_pinnedCap = 0;
+};
+
+// RAII bracket around one kernel launch (or a short group of launches)
+struct ProfScope
+{
+  Context& c;
+  ProfScope(Context& ctx, const char* name) : c(ctx) { if (c.profOn()) c.profBegin(name); }
+  ~ProfScope() { if (c.profOn()) c.profEnd(); }
+};
+
+// ---- whole-call entry points on DEVICE-resident pixel data -------------------------------------
+struct EncodeRequest
+{
+  const void* dData = nullptr;        // device: [nBands][nRows][nCols][nDepth]
+  const u8* dValidBytes = nullptr;    // device byte masks (nMasks of them) or nullptr
+  int dt = DT_Undefined, nDepth = 1, nCols = 0, nRows = 0, nBands = 1, nMasks = 0;
+  double maxZErr = 0;
+  u8* dOut = nullptr;                 // device output buffer (nullptr: size only)
+  u32 outCapacity = 0;
+};
+// returns an ErrCode; numBytesNeeded is always the exact blob size on kOk
+u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32& numBytesWritten);
+
+struct DecodeRequest
+{
+  const u8* hBlob = nullptr;          // host copy of the blob (may be nullptr when only dBlob is known)
+  const u8* dBlob = nullptr;          // device copy of the blob (nullptr: staged from hBlob)
+  u32 blobSize = 0;
+  int dt = DT_Undefined, nDepth = 1, nCols = 0, nRows = 0, nBands = 1, nMasks = 0;
+  void* dOut = nullptr;               // device: decoded pixels
+  u8* dValidBytes = nullptr;          // device: nMasks byte masks, or nullptr
+};
+u32 decodeDevice(Context& ctx, const DecodeRequest& rq);
+
+// header-only queries (host)
+struct BlobInfo
+{
+  int version = 0, nDepth = 0, nCols = 0, nRows = 0, numValid = 0, nBands = 0, nMasks = 0, nUsesNoData = 0, dt = 0;
+  u32 blobSize = 0;
+  double zMin = 0, zMax = 0, maxZErr = 0;
+};
+u32 getBlobInfo(const u8* blob, u32 n, BlobInfo& info, double* mins = nullptr, double* maxs = nullptr, size_t nElem = 0);
+
+}    // namespace lerc

@@ -1,0 +1,317 @@
+// codec_common.cpp -- wire-format pieces that stay on the host (a few hundred bytes per band):
+// header (Lerc2.cpp:724-917), mask RLE (RLE.cpp:32-331), blob info walk (Lerc.cpp:92-182), and the
+// per-thread device context.
+#include "codec.h"
+
+#include <algorithm>
+#include <cstdio>
+
+namespace lerc {
+
+// ------------------------------------------------------------------------------------------------
+// header
+// ------------------------------------------------------------------------------------------------
+u32 headerBytes(int v)
+{
+  return 6 + 4 + (v >= 3 ? 4 : 0) + 4 * (v >= 4 ? 7 : 6) + (v >= 6 ? 8 : 0) + 8 * (v >= 6 ? 5 : 3);
+}
+
+namespace {
+struct Out
+{
+  u8* p;
+  template<class T> void put(const T& v) { memcpy(p, &v, sizeof(T)); p += sizeof(T); }
+};
+struct In
+{
+  const u8* p;
+  size_t left;
+  template<class T> bool get(T& v) { if (left < sizeof(T)) return false; memcpy(&v, p, sizeof(T)); p += sizeof(T); left -= sizeof(T); return true; }
+};
+}
+
+void writeHeader(u8* dst, const Header& h)
+{
+  Out o{ dst };
+  memcpy(o.p, "Lerc2 ", 6); o.p += 6;
+  o.put(h.version);
+  if (h.version >= 3) o.put((u32)0);    // checksum slot, patched after the payload exists
+  o.put(h.nRows); o.put(h.nCols);
+  if (h.version >= 4) o.put(h.nDepth);
+  o.put(h.numValid); o.put(h.mbSize); o.put(h.blobSize); o.put(h.dt);
+  if (h.version >= 6) { o.put(h.nBlobsMore); o.put(h.passNoData); o.put(h.isInt); o.put(h.rsv3); o.put(h.rsv4); }
+  o.put(h.maxZErr); o.put(h.zMin); o.put(h.zMax);
+  if (h.version >= 6) { o.put(h.noDataVal); o.put(h.noDataValOrig); }
+}
+
+bool readHeader(const u8* src, size_t n, Header& h, size_t& used)
+{
+  h = Header();
+  In in{ src, n };
+  if (n < 6 || memcmp(src, "Lerc2 ", 6)) return false;
+  in.p += 6; in.left -= 6;
+  if (!in.get(h.version) || h.version < 0 || h.version > kCodecVersion) return false;
+  if (h.version >= 3 && !in.get(h.checksum)) return false;
+  h.nDepth = 1;
+  bool ok = in.get(h.nRows) && in.get(h.nCols);
+  if (ok && h.version >= 4) ok = in.get(h.nDepth);
+  ok = ok && in.get(h.numValid) && in.get(h.mbSize) && in.get(h.blobSize) && in.get(h.dt);
+  if (ok && h.version >= 6) ok = in.get(h.nBlobsMore) && in.get(h.passNoData) && in.get(h.isInt) && in.get(h.rsv3) && in.get(h.rsv4);
+  ok = ok && in.get(h.maxZErr) && in.get(h.zMin) && in.get(h.zMax);
+  if (ok && h.version >= 6) ok = in.get(h.noDataVal) && in.get(h.noDataValOrig);
+  if (!ok) return false;
+  if (h.nRows <= 0 || h.nCols <= 0 || h.nDepth <= 0 || h.numValid < 0 || h.mbSize <= 0 || h.blobSize <= 0
+    || h.dt < DT_Char || h.dt > DT_Double)
+    return false;
+  const u64 nPix = (u64)h.nRows * h.nCols, lim = (u64)INT_MAX, bpp = (u64)dtSize(h.dt);
+  if (nPix > lim || (u64)h.numValid > nPix) return false;
+  if (h.mbSize > 32 || bpp * h.nDepth > lim || bpp * h.nDepth * nPix > lim) return false;
+  used = (size_t)(in.p - src);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RLE of the mask bytes.  Stream: [int16 n][payload] ...; n > 0: n literal bytes; n < 0: one byte
+// repeated -n times; -32768 ends the stream.  A run is opened only where at least 5 equal bytes
+// start and one more byte follows (RLE.cpp:166-172, RLE.h:45); segments are cut at 32767.
+// ------------------------------------------------------------------------------------------------
+void rleEncode(const u8* b, size_t n, std::vector<u8>& out)
+{
+  out.clear();
+  auto count = [&](int v) { short s = (short)v; out.push_back((u8)(s & 0xff)); out.push_back((u8)((s >> 8) & 0xff)); };
+  size_t i = 0;
+  while (i < n)
+  {
+    const size_t litBeg = i;
+    while (i < n)
+    {
+      const bool runStarts = (i + 5 < n) && b[i] == b[i + 1] && b[i] == b[i + 2] && b[i] == b[i + 3] && b[i] == b[i + 4];
+      if (runStarts) break;
+      i++;
+    }
+    for (size_t at = litBeg; at < i;)
+    {
+      const size_t len = std::min<size_t>(32767, i - at);
+      count((int)len);
+      out.insert(out.end(), b + at, b + at + len);
+      at += len;
+    }
+    if (i >= n) break;
+    size_t t = i;
+    while (t + 1 < n && b[t + 1] == b[i]) t++;
+    for (size_t left = t - i + 1; left > 0;)
+    {
+      const size_t len = std::min<size_t>(32767, left);
+      count(-(int)len);
+      out.push_back(b[i]);
+      left -= len;
+    }
+    i = t + 1;
+  }
+  count(-32768);
+}
+
+bool rleDecode(const u8* src, size_t left, u8* dst, size_t dstSize)
+{
+  if (!src || !dst || left < 2) return false;
+  size_t at = 0;
+  for (;;)
+  {
+    if (left < 2) return false;
+    const short cnt = (short)(src[0] | (src[1] << 8));
+    src += 2; left -= 2;
+    if (cnt == -32768) return true;
+    const size_t n = (size_t)(cnt < 0 ? -cnt : cnt), payload = cnt > 0 ? n : 1;
+    if (left < payload + 2 || at + n > dstSize) return false;    // + 2: a count always follows (RLE.cpp:310)
+    if (cnt > 0) memcpy(dst + at, src, n); else memset(dst + at, src[0], n);
+    at += n; src += payload; left -= payload;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// blob info: hop over concatenated band blobs (Lerc.cpp:92-182, :1012-1042)
+// ------------------------------------------------------------------------------------------------
+static bool peekBand(const u8* p, size_t n, Header& h, bool& hasMask, size_t& hdrLen)
+{
+  if (!p || !readHeader(p, n, h, hdrLen)) return false;
+  int nm = 0;
+  if (n - hdrLen < 4) return false;
+  memcpy(&nm, p + hdrLen, 4);
+  if (nm < 0) return false;
+  hasMask = nm > 0;
+  return true;
+}
+
+// per-depth ranges of one band (Lerc2::GetRanges, Lerc2.cpp:516-573); host-side header parsing only
+static u32 bandRanges(const u8* p, size_t n, int iBand, const Header& h, size_t hdrLen, double* mins, double* maxs, size_t nElem)
+{
+  const int nD = h.nDepth;
+  if (nD <= 0 || iBand < 0 || !mins || !maxs) return kWrongParam;
+  if (nElem < ((size_t)iBand + 1) * (size_t)nD) return kBufferTooSmall;
+  if (nD == 1) { mins[iBand] = h.zMin; maxs[iBand] = h.zMax; return kOk; }
+  if (h.passNoData) return kHasNoData;
+  if (h.version < 4) return kFailed;
+  double* lo = mins + (size_t)iBand * nD;
+  double* hi = maxs + (size_t)iBand * nD;
+  if (h.numValid == 0) { for (int m = 0; m < nD; m++) lo[m] = hi[m] = 0; return kOk; }
+  if (h.zMin == h.zMax) { for (int m = 0; m < nD; m++) lo[m] = hi[m] = h.zMin; return kOk; }
+  int nm = 0;
+  memcpy(&nm, p + hdrLen, 4);
+  const size_t at = hdrLen + 4 + (size_t)nm, sz = (size_t)dtSize(h.dt);
+  if (nm < 0 || n < at + 2 * sz * nD) return kFailed;
+  for (int m = 0; m < nD; m++)
+  {
+    lo[m] = typedFromBits(getBytes(p + at + m * sz, (int)sz), h.dt);
+    hi[m] = typedFromBits(getBytes(p + at + (nD + m) * sz, (int)sz), h.dt);
+  }
+  return kOk;
+}
+
+u32 getBlobInfo(const u8* blob, u32 n, BlobInfo& info, double* mins, double* maxs, size_t nElem)
+{
+  info = BlobInfo();
+  Header h;
+  bool hasMask = false;
+  size_t hdrLen = 0;
+  int nMasks = 0;
+  if (!peekBand(blob, n, h, hasMask, hdrLen)) return kFailed;    // Lerc1 legacy blobs are not handled by this library
+  info.version = h.version; info.nDepth = h.nDepth; info.nCols = h.nCols; info.nRows = h.nRows;
+  info.numValid = h.numValid; info.blobSize = (u32)h.blobSize; info.dt = h.dt;
+  info.zMin = h.zMin; info.zMax = h.zMax; info.maxZErr = h.maxZErr; info.nUsesNoData = h.passNoData ? 1 : 0;
+  bool more = (h.version <= 5) || (h.nBlobsMore > 0);
+  if (hasMask || info.numValid == 0) nMasks = 1;
+  if (mins && maxs) { const u32 e = bandRanges(blob, n, 0, h, hdrLen, mins, maxs, nElem); if (e != kOk) return e; }
+  info.nBands = 1;
+  if (info.blobSize > n) return kFailed;
+  Header hn;
+  while (more && peekBand(blob + info.blobSize, n - info.blobSize, hn, hasMask, hdrLen))
+  {
+    if (hn.nDepth != info.nDepth || hn.nCols != info.nCols || hn.nRows != info.nRows || hn.dt != info.dt) return kFailed;
+    more = (hn.version <= 5) || (hn.nBlobsMore > 0);
+    if (hn.passNoData) info.nUsesNoData++;
+    if (hasMask || hn.numValid != info.numValid) nMasks = 2;
+    if ((size_t)info.blobSize > (size_t)UINT_MAX - (size_t)hn.blobSize) return kFailed;
+    if ((size_t)info.blobSize + (size_t)hn.blobSize > (size_t)n) return kFailed;
+    info.zMin = std::min(info.zMin, hn.zMin);
+    info.zMax = std::max(info.zMax, hn.zMax);
+    info.maxZErr = std::max(info.maxZErr, hn.maxZErr);
+    if (mins && maxs)
+    {
+      const u32 e = bandRanges(blob + info.blobSize, n - info.blobSize, info.nBands, hn, hdrLen, mins, maxs, nElem);
+      if (e != kOk) return e;
+    }
+    info.blobSize += (u32)hn.blobSize;
+    info.nBands++;
+  }
+  info.nMasks = nMasks > 1 ? info.nBands : nMasks;
+  if (info.nUsesNoData > 0) info.nUsesNoData = info.nBands;
+  return kOk;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+Context::Context()
+{
+  int nDev = 0;
+  if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
+  {
+    lastError = "lerc_amd: no HIP device available -- this library has no CPU path";
+    fprintf(stderr, "%s\n", lastError.c_str());
+    return;
+  }
+  if (hipStreamCreateWithFlags(&m_stream, hipStreamNonBlocking) != hipSuccess)
+  {
+    lastError = "lerc_amd: hipStreamCreate failed";
+    fprintf(stderr, "%s\n", lastError.c_str());
+    return;
+  }
+  m_ok = true;
+}
+
+Context::~Context()
+{
+  if (m_slab) hipFree(m_slab);
+  if (m_pinned) hipHostFree(m_pinned);
+  for (hipEvent_t e : m_eventPool) hipEventDestroy(e);
+  if (m_stream) hipStreamDestroy(m_stream);
+}
+
+bool Context::reserve(size_t bytes)
+{
+  m_used = 0;
+  if (bytes <= m_cap) return true;
+  if (m_slab) { hipStreamSynchronize(activeStream()); hipFree(m_slab); m_slab = nullptr; m_cap = 0; }
+  const size_t want = bytes + bytes / 8 + (1u << 20);
+  if (hipMalloc((void**)&m_slab, want) != hipSuccess) { lastError = "lerc_amd: hipMalloc failed"; return false; }
+  m_cap = want;
+  return true;
+}
+
+void* Context::alloc(size_t bytes, size_t align)
+{
+  size_t at = (m_used + align - 1) / align * align;
+  if (at + bytes > m_cap) return nullptr;
+  m_used = at + bytes;
+  return m_slab + at;
+}
+
+void* Context::pinned(size_t bytes)
+{
+  if (bytes <= m_pinnedCap) return m_pinned;
+  if (m_pinned) hipHostFree(m_pinned);
+  for (hipEvent_t e : m_eventPool) hipEventDestroy(e);
+  m_pinned = nullptr; m_pinnedCap = 0;
+  if (hipHostMalloc(&m_pinned, bytes + 4096, hipHostMallocDefault) != hipSuccess) return nullptr;
+  m_pinnedCap = bytes + 4096;
+  return m_pinned;
+}
+
+hipEvent_t Context::profEvent()
+{
+  if (!m_eventPool.empty()) { hipEvent_t e = m_eventPool.back(); m_eventPool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  hipEventCreate(&e);
+  return e;
+}
+
+void Context::profBegin(const char* name)
+{
+  ProfEntry pe{ name, profEvent(), profEvent() };
+  hipEventRecord(pe.a, activeStream());
+  m_pending.push_back(pe);
+}
+
+void Context::profEnd()
+{
+  if (!m_pending.empty()) hipEventRecord(m_pending.back().b, activeStream());
+}
+
+void Context::profCollect()
+{
+  for (ProfEntry& pe : m_pending)
+  {
+    float ms = 0;
+    if (hipEventSynchronize(pe.b) == hipSuccess && hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess)
+    {
+      bool found = false;
+      for (ProfAcc& a : m_acc) if (a.name == pe.name) { a.ms += ms; a.n++; found = true; break; }
+      if (!found) m_acc.push_back(ProfAcc{ pe.name, ms, 1 });
+    }
+    m_eventPool.push_back(pe.a);
+    m_eventPool.push_back(pe.b);
+  }
+  m_pending.clear();
+}
+
+std::string Context::profReport(bool reset)
+{
+  profCollect();
+  std::string out;
+  char line[256];
+  for (const ProfAcc& a : m_acc) { snprintf(line, sizeof(line), "%s %.6f %d\n", a.name.c_str(), a.ms, a.n); out += line; }
+  if (reset) m_acc.clear();
+  return out;
+}
+
+}    // namespace lerc

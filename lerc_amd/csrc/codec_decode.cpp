@@ -1,0 +1,314 @@
+// codec_decode.cpp -- lerc_decode() pipeline producing device-resident pixels.
+//
+// Host logic mirrors Lerc::DecodeTempl (Lerc.cpp:397-521) and Lerc2::Decode (Lerc2.cpp:577-694):
+// header + mask + ranges + mode bytes are parsed on the host (tens of bytes; the mask RLE is the
+// only sequential piece), everything that touches pixels or the block stream is a HIP kernel.
+#include "codec.h"
+#include "huffman.h"
+
+#include <algorithm>
+#include <cstdio>
+
+namespace lerc {
+
+namespace {
+
+// reads small pieces of a blob that lives on the host, the device, or both
+struct BlobReader
+{
+  const u8* h;
+  const u8* d;
+  u32 n;
+  hipStream_t st;
+  bool read(u64 off, size_t len, u8* dst) const
+  {
+    if (off + len > n) return false;
+    if (h) { memcpy(dst, h + off, len); return true; }
+    if (hipMemcpyAsync(dst, d + off, len, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+    return hipStreamSynchronize(st) == hipSuccess;
+  }
+};
+
+struct BandDesc
+{
+  u64 offset = 0;
+  Header hd;
+  size_t hdrLen = 0;
+  int numBytesMask = 0;
+};
+
+bool readBandHeader(const BlobReader& rd, u64 off, BandDesc& b)
+{
+  u8 buf[128];
+  const size_t want = std::min<size_t>(sizeof(buf), rd.n - off);
+  if (off >= rd.n || !rd.read(off, want, buf)) return false;
+  if (!readHeader(buf, want, b.hd, b.hdrLen)) return false;
+  if (want < b.hdrLen + 4) return false;
+  memcpy(&b.numBytesMask, buf + b.hdrLen, 4);
+  if (b.numBytesMask < 0) return false;
+  b.offset = off;
+  return true;
+}
+
+}    // namespace
+
+u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
+{
+  hipStream_t st = ctx.activeStream();
+  const int dt = rq.dt, nD = rq.nDepth, nCols = rq.nCols, nRows = rq.nRows;
+  const int tb = dtSize(dt);
+  const i64 nPix = (i64)nRows * nCols;
+  const size_t maskBytes = (size_t)((nPix + 7) >> 3);
+  BlobReader rd{ rq.hBlob, rq.dBlob, rq.blobSize, st };
+
+  // ---- walk the band headers (Lerc::GetLercInfo) and check the caller's request against them
+  std::vector<BandDesc> bands;
+  {
+    BandDesc b;
+    if (!readBandHeader(rd, 0, b) || b.hd.version < 1) return kFailed;    // not Lerc2 (Lerc1 is out of scope)
+    bands.push_back(b);
+    u64 total = (u64)b.hd.blobSize;
+    if (total > rq.blobSize) return kFailed;
+    bool more = (b.hd.version <= 5) || (b.hd.nBlobsMore > 0);
+    BandDesc nb;
+    while (more && total < rq.blobSize && readBandHeader(rd, total, nb))
+    {
+      if (nb.hd.nDepth != b.hd.nDepth || nb.hd.nCols != b.hd.nCols || nb.hd.nRows != b.hd.nRows || nb.hd.dt != b.hd.dt) return kFailed;
+      if (total + (u64)nb.hd.blobSize > rq.blobSize) return kFailed;
+      more = (nb.hd.version <= 5) || (nb.hd.nBlobsMore > 0);
+      bands.push_back(nb);
+      total += (u64)nb.hd.blobSize;
+    }
+  }
+  int infoMasks = 0, usesNoData = 0;
+  for (size_t i = 0; i < bands.size(); i++)
+  {
+    const BandDesc& b = bands[i];
+    if (i == 0) { if (b.numBytesMask > 0 || b.hd.numValid == 0) infoMasks = 1; }
+    else if (b.numBytesMask > 0 || b.hd.numValid != bands[0].hd.numValid) infoMasks = 2;
+    if (b.hd.passNoData) usesNoData++;
+  }
+  if (infoMasks > 1) infoMasks = (int)bands.size();
+  if (rq.nMasks < infoMasks) return kWrongParam;
+  if (rq.nBands > (int)bands.size()) return kWrongParam;
+  if (usesNoData && nD > 1)
+  {
+    ctx.lastError = "blobs carrying a noData value (nDepth > 1) are not supported by the device decoder";
+    return kHasNoData;
+  }
+
+  // ---- workspace
+  const u32 nPosMin = (u32)(((nRows + 31) / 32) * ((nCols + 31) / 32));
+  (void)nPosMin;
+  size_t need = (rq.dBlob ? 0 : (size_t)rq.blobSize + 256) + 2 * (maskBytes + 64) + (1u << 16)
+    + (size_t)nD * 8 + 4 * ((size_t)(nPix >> 5) + 1024) * 4;
+  // block offsets: one per sub-block for the smallest legal block size we may meet (decided per band below)
+  size_t maxSub = 0, maxChunks = 0;
+  for (int i = 0; i < rq.nBands; i++)
+  {
+    const Header& h = bands[i].hd;
+    const size_t sub = (size_t)((nRows + h.mbSize - 1) / h.mbSize) * ((nCols + h.mbSize - 1) / h.mbSize) * nD;
+    maxSub = std::max(maxSub, sub);
+    maxChunks = std::max(maxChunks, (size_t)h.blobSize / 4096 + 2);
+  }
+  need += maxSub * 4 + maxSub / nD * 2 + 5 * (maxChunks + 1024) * 4 + huffmanScratchBytes(nPix, nD);
+  if (!ctx.reserve(need)) return kFailed;
+
+  const u8* dBlob = rq.dBlob;
+  if (!dBlob)
+  {
+    u8* stage = ctx.allocT<u8>((size_t)rq.blobSize + 16);
+    if (!stage) return kFailed;
+    hipMemcpyAsync(stage, rq.hBlob, rq.blobSize, hipMemcpyHostToDevice, st);
+    dBlob = stage;
+  }
+  u8* dBits = ctx.allocT<u8>(maskBytes + 64);
+  DeviceStatus* dStatus = ctx.allocT<DeviceStatus>(1);
+  double* dZMax = ctx.allocT<double>(nD);
+  u64* dFl = ctx.allocT<u64>((size_t)kFletcherPartials * rq.nBands);
+  u8* dPixel = ctx.allocT<u8>((size_t)nD * 8);
+  if (!dBits || !dStatus || !dZMax || !dFl || !dPixel) return kFailed;
+  hipMemsetAsync(dStatus, 0, sizeof(DeviceStatus), st);
+
+  std::vector<u8> hBits;       // current mask (persists across bands: "use previous", Lerc2.cpp:1002)
+  bool haveMask = false, maskAllValid = true;
+  std::vector<u32> expectChecksum(rq.nBands, 0);
+  std::vector<u32> checksumLen(rq.nBands, 0);
+  std::vector<u8> small;
+
+  for (int iBand = 0; iBand < rq.nBands; iBand++)
+  {
+    const BandDesc& bd = bands[iBand];
+    const Header& hd = bd.hd;
+    if (hd.nDepth != nD || hd.nCols != nCols || hd.nRows != nRows) return kFailed;
+    if (hd.dt != dt) { ctx.lastError = "data type of the blob differs from the requested one"; return kFailed; }
+    const u8* dBand = dBlob + bd.offset;
+    const u32 blobEnd = (u32)hd.blobSize;
+    u8* dOutBand = (u8*)rq.dOut + (size_t)iBand * nPix * nD * tb;
+
+    if (hd.version >= 3)
+    {
+      if (hd.blobSize < 14) return kFailed;
+      { ProfScope ps(ctx, "fletcher_dec"); launchFletcher(dBand + 14, blobEnd - 14, dFl + (size_t)iBand * kFletcherPartials, st); }
+      expectChecksum[iBand] = hd.checksum;
+      checksumLen[iBand] = blobEnd - 14;
+    }
+
+    // ---- mask (Lerc2::ReadMask, Lerc2.cpp:961-1008)
+    u64 at = bd.offset + bd.hdrLen + 4;
+    const int nv = hd.numValid;
+    if ((nv == 0 || nv == (int)nPix) && bd.numBytesMask != 0) return kFailed;
+    if (nv == 0) { hBits.assign(maskBytes, 0); haveMask = true; maskAllValid = false; hipMemsetAsync(dBits, 0, maskBytes, st); }
+    else if (nv == (int)nPix) { haveMask = true; maskAllValid = true; hBits.clear(); }
+    else if (bd.numBytesMask > 0)
+    {
+      small.resize((size_t)bd.numBytesMask);
+      if (!rd.read(at, small.size(), small.data())) return kFailed;
+      hBits.assign(maskBytes, 0);
+      if (!rleDecode(small.data(), small.size(), hBits.data(), maskBytes)) return kFailed;
+      haveMask = true; maskAllValid = false;
+      hipMemcpyAsync(dBits, hBits.data(), maskBytes, hipMemcpyHostToDevice, st);
+      hipStreamSynchronize(st);    // hBits may be reused by the next band before the copy ran
+    }
+    else if (!haveMask || maskAllValid) return kFailed;    // "use previous mask" without a usable one
+    at += (u64)bd.numBytesMask;
+    const u8* dMask = maskAllValid ? nullptr : dBits;
+
+    if (iBand < rq.nMasks && rq.dValidBytes)
+      launchBitsToBytes(dMask, rq.dValidBytes + (size_t)iBand * nPix, nPix, st);
+
+    // ---- pixels
+    if (nv == 0) { hipMemsetAsync(dOutBand, 0, (size_t)nPix * nD * tb, st); continue; }
+
+    std::vector<double> zMinVec(nD, hd.zMin), zMaxVec(nD, hd.zMax);
+    std::vector<u8> pixel((size_t)nD * tb);
+    auto fillConst = [&](bool perDepth)
+    {
+      for (int m = 0; m < nD; m++)
+      {
+        // (T)hd.zMin resp. (T)m_zMinVec[m] (Lerc2.cpp:2681-2721)
+        const u64 bits = typedBits(perDepth ? zMinVec[m] : hd.zMin, dt);
+        putBytes(&pixel[(size_t)m * tb], bits, tb);
+      }
+      hipMemcpyAsync(dPixel, pixel.data(), pixel.size(), hipMemcpyHostToDevice, st);
+      launchFill(dOutBand, dPixel, nD * tb, dMask, nPix, st);
+      hipStreamSynchronize(st);    // `pixel` dies with this scope
+    };
+    if (hd.zMin == hd.zMax) { fillConst(false); continue; }
+
+    if (hd.version >= 4)
+    {
+      small.resize(2 * (size_t)nD * tb);
+      if (!rd.read(at, small.size(), small.data())) return kFailed;
+      for (int m = 0; m < nD; m++)
+      {
+        zMinVec[m] = typedFromBits(getBytes(&small[(size_t)m * tb], tb), dt);
+        zMaxVec[m] = typedFromBits(getBytes(&small[(size_t)(nD + m) * tb], tb), dt);
+      }
+      at += small.size();
+      if (0 == memcmp(zMinVec.data(), zMaxVec.data(), nD * sizeof(double))) { fillConst(true); continue; }
+    }
+    u8 flags[2] = { 0, 0 };
+    if (at - bd.offset >= blobEnd || !rd.read(at, 1, flags)) return kFailed;
+    at += 1;
+    if (flags[0])
+    {
+      // one sweep: valid pixels stored raw in order (Lerc2.cpp:1368-1400)
+      if ((u64)(at - bd.offset) + (u64)nv * nD * tb > blobEnd) return kFailed;
+      const u8* src = dBlob + at;
+      if (maskAllValid) hipMemcpyAsync(dOutBand, src, (size_t)nPix * nD * tb, hipMemcpyDeviceToDevice, st);
+      else
+      {
+        const i64 nGroups = (nPix + 31) >> 5;
+        u32* dCounts = ctx.allocT<u32>((size_t)nGroups + 4);
+        u32* dBase = ctx.allocT<u32>((size_t)nGroups + 4);
+        u32* dScr = ctx.allocT<u32>((size_t)nGroups / 1024 + 8);
+        if (!dCounts || !dBase || !dScr) return kFailed;
+        hipMemsetAsync(dOutBand, 0, (size_t)nPix * nD * tb, st);
+        launchMaskGroupCounts(dMask, nPix, dCounts, st);
+        launchExclusiveScan(dCounts, dBase, (u32)nGroups, dScr, st);
+        launchOneSweep(false, src, dOutBand, dMask, dBase, nPix, nD * tb, st);
+      }
+      continue;
+    }
+    int imageMode = IEM_Tiling;
+    if (hd.tryHuffmanInt() || hd.tryHuffmanFlt())
+    {
+      if (at - bd.offset >= blobEnd || !rd.read(at, 1, flags + 1)) return kFailed;
+      at += 1;
+      const int f = flags[1];
+      if (f > 3 || (f > 2 && hd.version < 6) || (f > 1 && hd.version < 4)) return kFailed;
+      imageMode = f;
+    }
+    if (imageMode != IEM_Tiling)
+    {
+      if (!hd.tryHuffmanInt() || !(imageMode == IEM_DeltaHuffman || (hd.version >= 4 && imageMode == IEM_Huffman)))
+      {
+        ctx.lastError = "lossless float / double stream (IEM_DeltaDeltaHuffman) is outside this library's scope";
+        return kFailed;
+      }
+      const u32 rc = decodeHuffman(ctx, dt, rq.hBlob ? rq.hBlob + bd.offset : nullptr, dBand, (u32)(at - bd.offset), blobEnd,
+                                   imageMode, dMask, nRows, nCols, nD, hd.version, dOutBand, dStatus);
+      if (rc != kOk) return rc;
+      continue;
+    }
+    if (hd.version < 3) { ctx.lastError = "codec version 2 bit layout is not supported"; return kFailed; }
+
+    // ---- tiling mode: discover the block offsets, then decode
+    BandParams bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.nRows = nRows; bp.nCols = nCols; bp.nDepth = nD; bp.dt = dt; bp.version = hd.version;
+    bp.mb = hd.mbSize; bp.nTV = (nRows + bp.mb - 1) / bp.mb; bp.nTH = (nCols + bp.mb - 1) / bp.mb;
+    bp.allValid = maskAllValid ? 1 : 0;
+    bp.maxQ = maxValToQuantize(dt);
+    bp.maxZErr = hd.maxZErr;
+    bp.scale = hd.maxZErr > 0 ? 1 / (2 * hd.maxZErr) : 0;
+    bp.invScale = 2 * hd.maxZErr;
+    bp.zMaxHdr = hd.zMax;
+    hipMemcpyAsync(dZMax, zMaxVec.data(), (size_t)nD * 8, hipMemcpyHostToDevice, st);
+    hipStreamSynchronize(st);    // zMaxVec is a per-band temporary
+
+    DecodeArgs da;
+    da.blob = dBand; da.dataBegin = (u32)(at - bd.offset); da.blobEnd = blobEnd;
+    da.maskBits = dMask; da.zMaxVec = dZMax; da.out = dOutBand;
+    const WalkPlan wp = makeWalkPlan(bp, da.dataBegin, da.blobEnd, nv);
+    WalkBuffers wb;
+    wb.chunkExit = ctx.allocT<u32>(wp.nChunks + 4);
+    wb.chunkEntry = ctx.allocT<u32>(wp.nChunks + 4);
+    wb.chunkCount = ctx.allocT<u32>(wp.nChunks + 4);
+    wb.chunkBase = ctx.allocT<u32>(wp.nChunks + 8);
+    wb.blockOff = ctx.allocT<u32>((size_t)wp.nSub + 4);
+    wb.scratch = ctx.allocT<u32>(wp.nChunks / 1024 + 8);
+    u16* nValidBlk = nullptr;
+    if (wp.uniformN == 0)
+    {
+      nValidBlk = ctx.allocT<u16>((size_t)bp.nTV * bp.nTH + 4);
+      if (!nValidBlk) return kFailed;
+      launchBlockValidCounts(dMask, bp, nValidBlk, st);
+    }
+    wb.nValidBlk = nValidBlk;
+    if (!wb.chunkExit || !wb.chunkEntry || !wb.chunkCount || !wb.chunkBase || !wb.blockOff || !wb.scratch) return kFailed;
+    { ProfScope ps(ctx, "walk_offsets"); launchWalk(bp, wp, da, wb, dStatus, st); }
+    da.blockOff = wb.blockOff;
+    { ProfScope ps(ctx, "tile_decode"); launchTileDecode(dt, bp, da, dStatus, st); }
+  }
+
+  // ---- one sync: kernel status + checksums
+  DeviceStatus hs;
+  std::vector<u64> hFl((size_t)kFletcherPartials * rq.nBands);
+  hipMemcpyAsync(&hs, dStatus, sizeof(hs), hipMemcpyDeviceToHost, st);
+  hipMemcpyAsync(hFl.data(), dFl, hFl.size() * 8, hipMemcpyDeviceToHost, st);
+  if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
+  if (ctx.profOn()) ctx.profCollect();
+  for (int iBand = 0; iBand < rq.nBands; iBand++)
+  {
+    if (bands[iBand].hd.version < 3) continue;
+    u64 A = 0, B = 0;
+    for (int i = 0; i < kFletcherPartials; i += 2) { A += hFl[(size_t)iBand * kFletcherPartials + i]; B += hFl[(size_t)iBand * kFletcherPartials + i + 1]; }
+    if (fletcherFinish(A, B, checksumLen[iBand]) != expectChecksum[iBand]) return kFailed;
+  }
+  if (hs.error) { ctx.lastError = "device kernel reported an error"; return hs.error; }
+  return kOk;
+}
+
+}    // namespace lerc

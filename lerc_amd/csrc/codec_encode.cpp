@@ -1,0 +1,412 @@
+// codec_encode.cpp -- lerc_encode() pipeline on device-resident pixels.
+//
+// Host logic mirrors Lerc::EncodeInternal (Lerc.cpp:628-789: band loop, mask reuse, flags) and
+// Lerc2::ComputeNumBytesNeededToWrite / Lerc2::Encode (Lerc2.cpp:179-480: mode decision, section
+// order).  Every sweep over pixels is a HIP kernel; the host only sees a few scalars per band.
+#include "codec.h"
+#include "huffman.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+
+namespace lerc {
+
+namespace {
+
+struct MaskState    // what the reference keeps inside its Lerc2 object between bands
+{
+  bool allValid = true;
+  int numValid = 0;
+  u8* dBits = nullptr;          // device bit mask (valid when !allValid)
+  std::vector<u8> hBits;        // host copy, for RLE and band-to-band comparison
+};
+
+struct Sync
+{
+  hipStream_t s;
+  bool wait() const { return hipStreamSynchronize(s) == hipSuccess; }
+};
+
+bool isIntegral(double z) { return z == floor(z + 0.5); }
+
+}    // namespace
+
+static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskState& ms, std::vector<u8>& prevByteValid,
+                      bool& anyMaskModified, u8* dBandOut, u32 capacityLeft, u32& bandBytes)
+{
+  hipStream_t st = ctx.activeStream();
+  Sync sync{ st };
+  const int dt = rq.dt, nD = rq.nDepth, nCols = rq.nCols, nRows = rq.nRows;
+  const int tb = dtSize(dt);
+  const i64 nPix = (i64)nRows * nCols, nElem = nPix * nD;
+  const bool isFlt = dt >= DT_Float;
+  const u8* dData = (const u8*)rq.dData + (size_t)iBand * nElem * tb;
+  const u8* dByteMask = (rq.nMasks > 0) ? rq.dValidBytes + ((rq.nMasks > 1) ? (size_t)iBand * nPix : 0) : nullptr;
+  bandBytes = 0;
+  if (nD > kStatsMaxDepth) { ctx.lastError = "nDepth above the device statistics limit"; return kFailed; }
+
+  // ---- device scratch of this band
+  DeviceStatus* dStatus = ctx.allocT<DeviceStatus>(1);
+  BandStats* dStats = ctx.allocT<BandStats>(1);
+  u64* dMins = ctx.allocT<u64>(nD);
+  u64* dMaxs = ctx.allocT<u64>(nD);
+  u8* dNewBits = ctx.allocT<u8>((size_t)((nPix + 7) >> 3) + 16);
+  if (!dStatus || !dStats || !dMins || !dMaxs || !dNewBits) return kFailed;
+  hipMemsetAsync(dStatus, 0, sizeof(DeviceStatus), st);
+  hipMemsetAsync(dStats, 0, sizeof(BandStats), st);
+
+  struct HostRes { BandStats stats; DeviceStatus status; };
+  std::vector<u64> hMins(nD), hMaxs(nD);
+  HostRes hr;
+
+  // ---- 1. validity: caller's byte mask, minus pixels that are NaN in every depth (Lerc.cpp:1440-1476)
+  bool bandAllValid = true;
+  int bandNumValid = (int)nPix;
+  bool modifiedMask = false;
+  bool haveBits = false;    // dNewBits holds this band's bit mask
+  auto buildMask = [&]() -> bool
+  {
+    hipMemsetAsync(dStats, 0, sizeof(BandStats), st);
+    { ProfScope ps(ctx, "build_mask"); launchBuildMask(dt, dData, dByteMask, nRows, nCols, nD, dNewBits, dStats, st); }
+    hipMemcpyAsync(&hr.stats, dStats, sizeof(BandStats), hipMemcpyDeviceToHost, st);
+    if (!sync.wait()) return false;
+    bandNumValid = (int)hr.stats.numValid;
+    bandAllValid = (bandNumValid == (int)nPix);
+    haveBits = true;
+    return true;
+  };
+  if (dByteMask && !buildMask()) return kFailed;
+  bool nanSeen = dByteMask ? (hr.stats.hasNaN != 0) : false;
+  bool mixedNaN = dByteMask ? (hr.stats.mixedNaN != 0) : false;
+
+  // ---- 2. statistics: per-depth min / max; float: NaN, all-integer, TryRaiseMaxZError candidates
+  double maxZErr = rq.maxZErr;
+  u32 raiseMask = 0;
+  static const double errCand[9] = { 1, 0.5, 0.1, 0.05, 0.01, 0.005, 0.001, 0.0005, 0.0001 };
+  static const int facCand[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
+  auto runStats = [&](int rows, u32 mask) -> bool
+  {
+    for (int m = 0; m < nD; m++) { hMins[m] = statKeyInitMin(); hMaxs[m] = statKeyInitMax(); }
+    hipMemcpyAsync(dMins, hMins.data(), nD * 8, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(dMaxs, hMaxs.data(), nD * 8, hipMemcpyHostToDevice, st);
+    hipMemsetAsync(dStats, 0, sizeof(BandStats), st);
+    { ProfScope ps(ctx, rows == nRows ? "band_stats" : "band_stats_row0"); launchBandStats(dt, dData, (haveBits && !bandAllValid) ? dNewBits : nullptr, rows, nCols, nD, mask, dMins, dMaxs, dStats, st); }
+    hipMemcpyAsync(&hr.stats, dStats, sizeof(BandStats), hipMemcpyDeviceToHost, st);
+    hipMemcpyAsync(hMins.data(), dMins, nD * 8, hipMemcpyDeviceToHost, st);
+    hipMemcpyAsync(hMaxs.data(), dMaxs, nD * 8, hipMemcpyDeviceToHost, st);
+    return sync.wait();
+  };
+  if (isFlt && maxZErr > 0)
+  {
+    // candidates whose error bound beats the request (Lerc2.cpp:1244-1253), pruned on the first row the
+    // way the reference prunes after every row (:1277); survivors are then measured over the whole band
+    u32 cand = 0;
+    for (int c = 0; c < 9; c++) if (errCand[c] / 2 > maxZErr) cand |= 1u << c;
+    if (cand)
+    {
+      if (!runStats(1, cand)) return kFailed;
+      for (int c = 0; c < 9; c++)
+        if (((cand >> c) & 1u) && hr.stats.raiseErr[c] / facCand[c] > maxZErr / 2) cand &= ~(1u << c);
+      raiseMask = cand;
+    }
+  }
+  if (bandNumValid > 0)
+  {
+    if (!runStats(nRows, raiseMask)) return kFailed;
+    if (isFlt && hr.stats.hasNaN && !haveBits)
+    {
+      // NaNs present and no mask yet: derive the mask (NaN in every depth -> invalid) and redo the stats
+      if (!buildMask()) return kFailed;
+      nanSeen = true;
+      mixedNaN = hr.stats.mixedNaN != 0;
+      if (bandNumValid > 0 && !runStats(nRows, raiseMask)) return kFailed;
+    }
+  }
+  if (isFlt && nanSeen)
+  {
+    modifiedMask = true;    // conservative: the reference only flags bands whose mask really changed
+    if (mixedNaN && nD > 1) return kNaN;    // Lerc.cpp:1498-1501 (no noData value to stand in)
+  }
+  (void)modifiedMask;
+
+  // ---- mask bookkeeping across bands (Lerc.cpp:717-741)
+  std::vector<u8> hBandBits;
+  if (haveBits && !bandAllValid)
+  {
+    hBandBits.resize((size_t)((nPix + 7) >> 3));
+    hipMemcpyAsync(hBandBits.data(), dNewBits, hBandBits.size(), hipMemcpyDeviceToHost, st);
+    if (!sync.wait()) return kFailed;
+  }
+  if (nanSeen) anyMaskModified = true;
+  bool encMask = (iBand == 0);
+  {
+    // the reference compares the (filtered) byte masks of consecutive bands; validity bits are equivalent
+    std::vector<u8> cur = hBandBits;    // empty == all valid
+    const bool compare = (rq.nMasks > 1) || anyMaskModified;
+    if (compare && iBand > 0 && cur != prevByteValid) encMask = true;
+    if (rq.nBands > 1 && iBand < rq.nBands - 1) prevByteValid = cur;
+  }
+  if (encMask)
+  {
+    ms.allValid = bandAllValid;
+    ms.numValid = bandNumValid;
+    ms.hBits = hBandBits;
+    if (!bandAllValid)
+    {
+      if (!ms.dBits) return kFailed;
+      hipMemcpyAsync(ms.dBits, dNewBits, hBandBits.size(), hipMemcpyDeviceToDevice, st);
+    }
+  }
+  const u8* dBits = ms.allValid ? nullptr : ms.dBits;
+  const int numValid = ms.numValid;
+
+  // ---- 3. what Lerc::FilterNoDataAndNaN + Lerc2::ComputeNumBytesNeededToWrite decide from the stats
+  Header hd;
+  hd.nRows = nRows; hd.nCols = nCols; hd.nDepth = nD; hd.numValid = numValid; hd.dt = dt;
+  hd.nBlobsMore = rq.nBands - 1 - iBand;
+  std::vector<double> zMinVec(nD, 0), zMaxVec(nD, 0);
+  bool allInt = false;
+  if (bandNumValid > 0)
+  {
+    for (int m = 0; m < nD; m++) { zMinVec[m] = statKeyToDouble(dt, hMins[m]); zMaxVec[m] = statKeyToDouble(dt, hMaxs[m]); }
+  }
+  if (isFlt)
+  {
+    if (bandNumValid == 0) maxZErr = 0;    // "tile has no valid data" (Lerc.cpp:1479-1484)
+    else
+    {
+      const double lo = *std::min_element(zMinVec.begin(), zMinVec.end());
+      const double hi = *std::max_element(zMaxVec.begin(), zMaxVec.end());
+      const double lim = (dt == DT_Float) ? (double)(1L << 23) : (double)((i64)1 << 53);
+      allInt = !hr.stats.notAllInt && lo >= -lim && lo <= lim && hi >= -lim && hi <= lim;
+      if (allInt) maxZErr = std::max(0.5, floor(maxZErr));
+    }
+    hd.isInt = allInt ? 1 : 0;
+  }
+  if (maxZErr == 777) maxZErr = -0.01;    // Lerc2.cpp:210-211
+  if (!isFlt)
+  {
+    if (maxZErr < 0)
+    {
+      // bit plane mode (Lerc2.cpp:1071-1229) is not implemented on the device yet: lossless is the
+      // reference's own fallback whenever the statistics are inconclusive
+      ctx.lastError = "bit-plane compression (maxZErr 777) not supported";
+      return kFailed;
+    }
+    maxZErr = std::max(0.5, floor(maxZErr));
+  }
+  else
+  {
+    if (maxZErr < 0) return kFailed;
+    if (maxZErr > 0 && raiseMask && !allInt)
+    {
+      for (int c = 0; c < 9; c++)
+        if (((raiseMask >> c) & 1u) && hr.stats.raiseErr[c] / facCand[c] <= maxZErr / 2) { maxZErr = errCand[c] / 2; break; }
+    }
+  }
+  hd.maxZErr = maxZErr;
+  hd.zMin = hd.zMax = 0;
+  hd.mbSize = 8;
+
+  // ---- sections before the pixel data
+  const bool needMask = numValid > 0 && numValid < (int)nPix;
+  std::vector<u8> rle;
+  if (needMask && encMask) rleEncode(ms.hBits.data(), ms.hBits.size(), rle);
+  u32 blobSize = headerBytes(hd.version) + 4 + (u32)rle.size();
+
+  enum Payload { P_NONE, P_TILING, P_ONESWEEP, P_HUFFMAN } payload = P_NONE;
+  bool writeRanges = false;
+  int imageMode = IEM_Tiling;
+  HuffmanPlan huff;
+  u32 nBytesData = 0;
+
+  BandParams bp;
+  memset(&bp, 0, sizeof(bp));
+  bp.nRows = nRows; bp.nCols = nCols; bp.nDepth = nD; bp.dt = dt; bp.version = hd.version;
+  bp.allValid = ms.allValid ? 1 : 0;
+  bp.maxQ = maxValToQuantize(dt);
+  bp.maxZErr = maxZErr;
+  bp.scale = maxZErr > 0 ? 1 / (2 * maxZErr) : 0;
+  bp.invScale = 2 * maxZErr;
+  bp.intLossless = (!isFlt && maxZErr == 0.5) ? 1 : 0;
+  bp.tryDiff = (hd.version >= 5 && nD > 1 && bp.intLossless) ? 1 : 0;
+
+  u32* dSizes = nullptr;
+  u32* dOffsets = nullptr;
+  u32* dScratch = nullptr;
+  const int nPos8 = ((nRows + 7) / 8) * ((nCols + 7) / 8);
+  auto tilingBytes = [&](int mb, u32& total) -> bool
+  {
+    bp.mb = mb; bp.nTV = (nRows + mb - 1) / mb; bp.nTH = (nCols + mb - 1) / mb;
+    const u32 nPos = (u32)bp.nTV * (u32)bp.nTH;
+    { ProfScope ps(ctx, "tile_sizes"); launchTileSizes(dt, mb, dData, dBits, bp, dSizes, dStatus, st); }
+    { ProfScope ps(ctx, "scan_block_sizes"); launchExclusiveScan(dSizes, dOffsets, nPos, dScratch, st); }
+    hipMemcpyAsync(&total, dOffsets + nPos, 4, hipMemcpyDeviceToHost, st);
+    return sync.wait();
+  };
+
+  if (numValid > 0)
+  {
+    hd.zMin = *std::min_element(zMinVec.begin(), zMinVec.end());
+    hd.zMax = *std::max_element(zMaxVec.begin(), zMaxVec.end());
+    bp.zMaxHdr = hd.zMax;
+    bp.checkOverflow = ((dt == DT_Int || dt == DT_UInt) && (hd.zMax - hd.zMin >= 0x7FFFFFFF)) ? 1 : 0;
+    if (hd.zMin != hd.zMax)
+    {
+      writeRanges = true;
+      blobSize += 2u * (u32)nD * (u32)tb;
+      const bool constDepths = (0 == memcmp(zMinVec.data(), zMaxVec.data(), nD * sizeof(double)));
+      if (!constDepths)
+      {
+        dSizes = ctx.allocT<u32>((size_t)nPos8 + 4);
+        dOffsets = ctx.allocT<u32>((size_t)nPos8 + 4);
+        dScratch = ctx.allocT<u32>((size_t)nPos8 / 1024 + 8);
+        if (!dSizes || !dOffsets || !dScratch) return kFailed;
+
+        u32 nBytesTiling = 0;
+        if (!tilingBytes(8, nBytesTiling)) return kFailed;
+        payload = P_TILING;
+        nBytesData = nBytesTiling;
+        u32 nBytesHuffman = 0;
+
+        if (hd.tryHuffmanInt())
+        {
+          if (!planHuffman(ctx, dt, dData, dBits, nRows, nCols, nD, hd.version, huff)) return kFailed;
+          nBytesHuffman = huff.ok ? huff.nBytes : 0;
+          if (huff.ok && nBytesHuffman < nBytesTiling) { payload = P_HUFFMAN; imageMode = huff.imageMode; nBytesData = nBytesHuffman; }
+          else huff.ok = false;
+        }
+        else if (hd.tryHuffmanFlt())
+        {
+          ctx.lastError = "lossless float / double (maxZErr == 0) is outside this library's scope";
+          return kFailed;
+        }
+
+        const size_t nBytesOneSweep = (size_t)tb * nD * (size_t)numValid;
+        // retry with 16 x 16 blocks at low bit rates (Lerc2.cpp:333-357)
+        if (((size_t)nBytesTiling * 8 < (size_t)nPix * nD * 1.5)
+          && ((size_t)nBytesTiling < 4 * nBytesOneSweep)
+          && (nBytesHuffman == 0 || (size_t)nBytesTiling < (size_t)2 * nBytesHuffman)
+          && (nRows > 8 || nCols > 8))
+        {
+          u32 nBytes16 = 0;
+          if (!tilingBytes(16, nBytes16)) return kFailed;
+          if (nBytes16 <= nBytesData) { nBytesData = nBytes16; payload = P_TILING; imageMode = IEM_Tiling; huff.ok = false; hd.mbSize = 16; }
+          else if (payload == P_TILING && !tilingBytes(8, nBytesTiling)) return kFailed;    // restore the 8x8 offsets
+          if (hd.mbSize == 8) { bp.mb = 8; bp.nTV = (nRows + 7) / 8; bp.nTH = (nCols + 7) / 8; }
+        }
+        if (hd.tryHuffmanInt() || hd.tryHuffmanFlt()) nBytesData += 1;
+        if (nBytesOneSweep <= (size_t)nBytesData) { payload = P_ONESWEEP; blobSize += 1 + (u32)nBytesOneSweep; }
+        else blobSize += 1 + nBytesData;
+      }
+    }
+  }
+  if ((size_t)blobSize > (size_t)INT_MAX) return kFailed;
+  hd.blobSize = (int)blobSize;
+  bandBytes = blobSize;
+  if (!dBandOut) return kOk;    // size query
+  if (blobSize > capacityLeft) return kBufferTooSmall;
+
+  // ---- 4. emit: small sections from the host, pixel payload by kernels
+  std::vector<u8> prefix(headerBytes(hd.version) + 4 + rle.size() + (writeRanges ? 2 * (size_t)nD * tb : 0) + 2);
+  size_t at = 0;
+  writeHeader(prefix.data(), hd);
+  at = headerBytes(hd.version);
+  const int nm = (int)rle.size();
+  memcpy(&prefix[at], &nm, 4); at += 4;
+  if (nm) { memcpy(&prefix[at], rle.data(), rle.size()); at += rle.size(); }
+  if (writeRanges)
+  {
+    for (int m = 0; m < nD; m++) { const u64 raw = statKeyToRawBits(dt, hMins[m]); putBytes(&prefix[at], raw, tb); at += tb; }
+    for (int m = 0; m < nD; m++) { const u64 raw = statKeyToRawBits(dt, hMaxs[m]); putBytes(&prefix[at], raw, tb); at += tb; }
+  }
+  if (payload != P_NONE)
+  {
+    prefix[at++] = (payload == P_ONESWEEP) ? 1 : 0;
+    if (payload != P_ONESWEEP && (hd.tryHuffmanInt() || hd.tryHuffmanFlt())) prefix[at++] = (u8)imageMode;
+  }
+  hipMemcpyAsync(dBandOut, prefix.data(), at, hipMemcpyHostToDevice, st);
+  u8* dPayload = dBandOut + at;
+
+  if (payload == P_TILING)
+  {
+    ProfScope ps(ctx, "tile_write");
+    launchTileWrite(dt, hd.mbSize, dData, dBits, bp, dOffsets, dPayload, dStatus, st);
+  }
+  else if (payload == P_ONESWEEP)
+  {
+    if (ms.allValid) hipMemcpyAsync(dPayload, dData, (size_t)nElem * tb, hipMemcpyDeviceToDevice, st);
+    else
+    {
+      const i64 nGroups = (nPix + 31) >> 5;
+      u32* dCounts = ctx.allocT<u32>((size_t)nGroups + 4);
+      u32* dBase = ctx.allocT<u32>((size_t)nGroups + 4);
+      u32* dScr = ctx.allocT<u32>((size_t)nGroups / 1024 + 8);
+      if (!dCounts || !dBase || !dScr) return kFailed;
+      launchMaskGroupCounts(dBits, nPix, dCounts, st);
+      launchExclusiveScan(dCounts, dBase, (u32)nGroups, dScr, st);
+      launchOneSweep(true, dData, dPayload, dBits, dBase, nPix, nD * tb, st);
+    }
+  }
+  else if (payload == P_HUFFMAN)
+  {
+    if (!emitHuffman(ctx, dt, dData, dBits, nRows, nCols, nD, huff, dPayload, dStatus)) return kFailed;
+  }
+
+  // ---- 5. checksum over blob[14 ..) (Lerc2.cpp:1012-1030), patched into the header
+  u64* dFl = ctx.allocT<u64>(kFletcherPartials);
+  if (!dFl) return kFailed;
+  { ProfScope ps(ctx, "fletcher_enc"); launchFletcher(dBandOut + 14, blobSize - 14, dFl, st); }
+  std::vector<u64> hFl(kFletcherPartials);
+  hipMemcpyAsync(hFl.data(), dFl, kFletcherPartials * 8, hipMemcpyDeviceToHost, st);
+  hipMemcpyAsync(&hr.status, dStatus, sizeof(DeviceStatus), hipMemcpyDeviceToHost, st);
+  if (!sync.wait()) return kFailed;
+  if (hr.status.error) { ctx.lastError = "device kernel reported an error"; return hr.status.error; }
+  u64 A = 0, B = 0;
+  for (int i = 0; i < kFletcherPartials; i += 2) { A += hFl[i]; B += hFl[i + 1]; }
+  const u32 cs = fletcherFinish(A, B, blobSize - 14);
+  hipMemcpyAsync(dBandOut + 10, &cs, 4, hipMemcpyHostToDevice, st);
+  if (!sync.wait()) return kFailed;
+  if (ctx.profOn()) ctx.profCollect();
+  return kOk;
+}
+
+u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32& numBytesWritten)
+{
+  numBytesNeeded = numBytesWritten = 0;
+  const int tb = dtSize(rq.dt);
+  const i64 nPix = (i64)rq.nRows * rq.nCols;
+  const size_t maskBytes = (size_t)((nPix + 7) >> 3) + 64;
+  const size_t nPos8 = (size_t)((rq.nRows + 7) / 8) * ((rq.nCols + 7) / 8);
+  // workspace: two bit masks, block sizes + offsets + scan scratch, one-sweep ranks, Huffman scratch, small stuff
+  size_t need = 2 * maskBytes + 3 * (nPos8 + 1024) * 4 + 3 * ((size_t)(nPix >> 5) + 1024) * 4
+    + huffmanScratchBytes(nPix, rq.nDepth) + (size_t)rq.nDepth * 16 + (1u << 16);
+  if (!ctx.reserve(need)) return kFailed;
+  (void)tb;
+
+  MaskState ms;
+  ms.dBits = ctx.allocT<u8>(maskBytes);
+  std::vector<u8> prevValid;
+  bool anyMaskModified = false;
+  u32 total = 0;
+  const size_t persistent = maskBytes + 512;    // keep ms.dBits across bands
+  for (int iBand = 0; iBand < rq.nBands; iBand++)
+  {
+    // band scratch is re-used: rewind the bump pointer to just behind the persistent mask
+    ctx.reset();
+    ctx.alloc(persistent);
+    u32 bandBytes = 0;
+    u8* dst = rq.dOut ? rq.dOut + total : nullptr;
+    const u32 left = rq.dOut ? (rq.outCapacity > total ? rq.outCapacity - total : 0) : 0;
+    const u32 rc = encodeBand(ctx, rq, iBand, ms, prevValid, anyMaskModified, dst, left, bandBytes);
+    if (rc != kOk) return rc;
+    if ((size_t)total + bandBytes > (size_t)UINT_MAX) return kDimsTooLarge;
+    total += bandBytes;
+  }
+  numBytesNeeded = total;
+  if (rq.dOut) numBytesWritten = total;
+  return kOk;
+}
+
+}    // namespace lerc

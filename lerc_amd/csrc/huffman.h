@@ -1,0 +1,31 @@
+// huffman.h -- 8-bit Huffman image mode (Lerc2::ComputeHuffmanCodes / EncodeHuffman / DecodeHuffman,
+// Lerc2.cpp:2270-2606; Huffman.cpp): histograms and bit packing on the device, the 256-entry code
+// book on the host.
+#pragma once
+#include "codec.h"
+
+namespace lerc {
+
+struct HuffmanPlan
+{
+  bool ok = false;             // a Huffman code book exists (false: fall back to tiling)
+  int imageMode = IEM_Tiling;  // IEM_Huffman or IEM_DeltaHuffman
+  u32 nBytes = 0;              // table + pixel stream + read-ahead word (Huffman.cpp:85-111)
+  std::vector<std::pair<u16, u32> > codes;    // (length, code) per symbol, 256 entries
+  std::vector<u8> table;       // serialised code table (Huffman.cpp:126-166)
+  u64 nBits = 0;               // bits of the pixel stream
+};
+
+size_t huffmanScratchBytes(i64 nPix, int nDepth);
+
+// histograms on the device, code books + sizes on the host; returns false only on a runtime error
+bool planHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth,
+                 int version, HuffmanPlan& plan);
+// writes table + pixel stream + padding at dOut
+bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth,
+                 const HuffmanPlan& plan, u8* dOut, DeviceStatus* dStatus);
+// decodes a Huffman payload starting at blob + dataBegin; returns an ErrCode
+u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 dataBegin, u32 blobEnd, int imageMode,
+                  const u8* dMaskBits, int nRows, int nCols, int nDepth, int version, void* dOut, DeviceStatus* dStatus);
+
+}    // namespace lerc

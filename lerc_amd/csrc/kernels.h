@@ -1,0 +1,90 @@
+// kernels.h -- launch wrappers of the HIP kernels (defined in the *.hip files of this directory).
+// Every wrapper enqueues on `stream` and returns immediately.
+#pragma once
+#include "lerc_common.h"
+
+namespace lerc {
+
+// ---- tile_encode.hip ---------------------------------------------------------------------------
+// Size-only dry run (Lerc2::WriteTiles with *ppByte == nullptr, Lerc2.cpp:1474-1668): one u32 per
+// micro-block position = bytes of all its depth slices.
+void launchTileSizes(int dt, int mb, const void* data, const u8* maskBits, const BandParams& p, u32* sizes,
+                     DeviceStatus* st, hipStream_t stream);
+// Real write: offsets[pos] = byte offset of block position pos relative to `out`.
+void launchTileWrite(int dt, int mb, const void* data, const u8* maskBits, const BandParams& p, const u32* offsets,
+                     u8* out, DeviceStatus* st, hipStream_t stream);
+
+// ---- tile_decode.hip ---------------------------------------------------------------------------
+struct DecodeArgs
+{
+  const u8* blob;        // start of the band blob (device)
+  u32 dataBegin;         // offset of the first block (after header / mask / ranges / flag bytes)
+  u32 blobEnd;           // == blobSize of the band
+  const u8* maskBits;    // device bit mask or nullptr when all valid
+  const double* zMaxVec; // per-depth clamp values (device, nDepth entries)
+  const u32* blockOff;   // absolute offset of every sub-block, index = pos * nDepth + iDepth
+  void* out;             // decoded pixels
+};
+void launchTileDecode(int dt, const BandParams& p, const DecodeArgs& a, DeviceStatus* st, hipStream_t stream);
+
+// Block-offset discovery (the stream stores no offsets; SURVEY.md section 7 "hard part 1").
+struct WalkPlan
+{
+  u32 chunkBytes;        // power of two
+  u32 window;            // upper bound of a block's byte length for this header
+  u32 nChunks;
+  u32 nSub;              // number of sub-blocks = nTV * nTH * nDepth
+  int uniformN;          // > 0: every block has exactly this many valid pixels; 0: varies (mask / edges)
+};
+struct WalkBuffers
+{
+  u32* chunkExit;        // [nChunks]   agreed first-block offset of chunk c+1 relative to blob, or ~0u
+  u32* chunkEntry;       // [nChunks+1] resolved entry offset of every chunk
+  u32* chunkCount;       // [nChunks]   number of sub-blocks that START inside the chunk
+  u32* chunkBase;        // [nChunks+1] exclusive scan of chunkCount
+  u32* blockOff;         // [nSub]
+  const u16* nValidBlk;  // [nTV*nTH]   valid pixels per block position (nullptr when uniformN > 0)
+  u32* scratch;          // scan scratch, >= nChunks/1024 + 2 words
+};
+WalkPlan makeWalkPlan(const BandParams& p, u32 dataBegin, u32 blobEnd, int numValid);
+void launchWalk(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, DeviceStatus* st,
+                hipStream_t stream);
+
+// ---- misc_kernels.hip --------------------------------------------------------------------------
+// exclusive scan of n u32 values; out[n] receives the total.  scratch >= n/1024 + 2 words.
+void launchExclusiveScan(const u32* in, u32* out, u32 n, u32* scratch, hipStream_t stream);
+
+// Fletcher32 partial sums over bytes [begin, begin + len) of `blob`; result words: acc[0] = sum of
+// big-endian 16-bit words, acc[1] = position-weighted sum, both mod 65535 (Lerc2.cpp:1037-1064,
+// closed form in DESIGN.md).  acc must be zeroed by the caller.
+void launchFletcher(const u8* bytes, u32 len, u64* partials /* kFletcherPartials words */, hipStream_t stream);
+u32 fletcherFinish(u64 sumWords, u64 sumWeighted, u32 len);
+
+// byte mask (1 = valid) [+ NaN test on float data] -> bit mask, numValid; nValidBlk per block position
+void launchBuildMask(int dt, const void* data, const u8* byteMask, int nRows, int nCols, int nDepth, u8* maskBits,
+                     BandStats* stats, hipStream_t stream);
+void launchBlockValidCounts(const u8* maskBits, const BandParams& p, u16* nValidBlk, hipStream_t stream);
+void launchBitsToBytes(const u8* maskBits, u8* byteMask, i64 nPix, hipStream_t stream);
+
+// per-depth min / max over valid pixels as raw T values (mins[nDepth], maxs[nDepth] device arrays of
+// 8-byte slots), plus float diagnostics in BandStats (NaN, all-integer, TryRaiseMaxZError errors)
+// raiseMask: bit c set = evaluate TryRaiseMaxZError candidate c (factors 1,2,10,20,100,200,1000,2000,10000).
+// mins / maxs hold order-preserving keys (init statKeyInitMin / statKeyInitMax); decode with statKeyTo*.
+// nDepth must be <= kStatsMaxDepth.
+static const int kStatsMaxDepth = 256;
+void launchBandStats(int dt, const void* data, const u8* maskBits, int nRows, int nCols, int nDepth, u32 raiseMask,
+                     u64* mins, u64* maxs, BandStats* stats, hipStream_t stream);
+u64 statKeyInitMin();
+u64 statKeyInitMax();
+u64 statKeyToRawBits(int dt, u64 key);
+double statKeyToDouble(int dt, u64 key);
+static const int kFletcherPartials = 2 * 512;    // u64 words written by launchFletcher
+void launchMaskGroupCounts(const u8* maskBits, i64 nPix, u32* counts, hipStream_t stream);
+
+// raw fallback ("one sweep", Lerc2.cpp:1343-1400): valid pixels copied in order
+void launchOneSweep(bool encode, const void* src, void* dst, const u8* maskBits, const u32* groupBase, i64 nPix,
+                    int pixelBytes, hipStream_t stream);
+void launchFill(void* dst, const void* pixel, int pixelBytes, const u8* maskBits, i64 nPix, hipStream_t stream);
+void launchWidenToDouble(int dt, const void* src, double* dst, i64 n, hipStream_t stream);
+
+}    // namespace lerc

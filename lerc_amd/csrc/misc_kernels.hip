@@ -1,0 +1,459 @@
+// misc_kernels.hip -- the full-image sweeps around the block loop, as HBM-bound HIP kernels:
+//   exclusive scan (block sizes -> block offsets), Fletcher32 partial sums, validity-mask
+//   construction, per-depth min / max + float diagnostics, raw "one sweep" copy, const fill, widen.
+// Reference counterparts: Lerc2::ComputeChecksumFletcher32 (Lerc2.cpp:1037-1064),
+// Lerc::FilterNoDataAndNaN (Lerc.cpp:1378-1552, the noData-free part), Lerc2::ComputeMinMaxRanges
+// (Lerc2.cpp:1404-1470), Lerc2::TryRaiseMaxZError (:1233-1318), Write/ReadDataOneSweep (:1343-1400),
+// FillConstImage (:2681-2721), Lerc::Convert byte<->bit mask (Lerc.cpp:959-995).
+#include "kernels.h"
+#include "wave_utils.h"
+
+namespace lerc {
+
+// ================================================================================================
+// exclusive scan
+// ================================================================================================
+__device__ __forceinline__ u32 waveInclusiveScan(u32 v)
+{
+  const int lane = laneId();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { u32 t = __shfl_up(v, (unsigned)d); if (lane >= d) v += t; }
+  return v;
+}
+
+// returns the exclusive prefix of `v` over the 256 threads of the workgroup; total in `total`
+__device__ __forceinline__ u32 blockExclusiveScan256(u32 v, u32& total)
+{
+  __shared__ u32 s_w[4];
+  const u32 inc = waveInclusiveScan(v);
+  if (laneId() == 63) s_w[waveId()] = inc;
+  __syncthreads();
+  u32 base = 0;
+  for (int i = 0; i < waveId(); i++) base += s_w[i];
+  total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  __syncthreads();
+  return base + inc - v;
+}
+
+__global__ void __launch_bounds__(256) k_scan_local(const u32* __restrict__ in, u32* __restrict__ out, u32 n, u32* __restrict__ partial)
+{
+  const u32 base = blockIdx.x * 1024u + threadIdx.x * 4u;
+  u32 a[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) a[i] = (base + i < n) ? in[base + i] : 0u;
+  const u32 s = a[0] + a[1] + a[2] + a[3];
+  u32 total;
+  u32 ex = blockExclusiveScan256(s, total);
+#pragma unroll
+  for (int i = 0; i < 4; i++) { if (base + i < n) out[base + i] = ex; ex += a[i]; }
+  if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256) k_scan_partials(u32* __restrict__ partial, u32 nPartials, u32* __restrict__ totalOut)
+{
+  u32 carry = 0;
+  for (u32 b = 0; b < nPartials; b += 256)
+  {
+    const u32 i = b + threadIdx.x;
+    const u32 v = (i < nPartials) ? partial[i] : 0u;
+    u32 total;
+    const u32 ex = blockExclusiveScan256(v, total);
+    if (i < nPartials) partial[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) *totalOut = carry;
+}
+
+__global__ void __launch_bounds__(256) k_scan_add(u32* __restrict__ out, u32 n, const u32* __restrict__ partial)
+{
+  const u32 add = partial[blockIdx.x];
+  const u32 base = blockIdx.x * 1024u + threadIdx.x * 4u;
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (base + i < n) out[base + i] += add;
+}
+
+void launchExclusiveScan(const u32* in, u32* out, u32 n, u32* scratch, hipStream_t stream)
+{
+  if (n == 0) { hipMemsetAsync(out, 0, 4, stream); return; }
+  const u32 nPart = (n + 1023) / 1024;
+  hipLaunchKernelGGL(k_scan_local, dim3(nPart), dim3(256), 0, stream, in, out, n, scratch);
+  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, stream, scratch, nPart, out + n);
+  hipLaunchKernelGGL(k_scan_add, dim3(nPart), dim3(256), 0, stream, out, n, (const u32*)scratch);
+}
+
+// ================================================================================================
+// Fletcher32 (Lerc2.cpp:1037-1064) as two linear sums mod 65535.
+//   words w_i = b[2i] << 8 | b[2i+1] (odd tail byte counts as b << 8), N = ceil(len / 2)
+//   s1 = 0xffff + sum w_i,   s2 = 0xffff (N + 1) + sum (N - i) w_i      (mod 65535, 0 -> 0xffff)
+// Every byte contributes independently: c = (p even ? 256 : 1) * b to A = sum w and (p >> 1) * c to
+// B = sum i * w, so the kernel is a plain streaming reduction; partials are combined on the host.
+// ================================================================================================
+static const int kFletcherBlocks = 512;
+
+__global__ void __launch_bounds__(256) k_fletcher(const u8* __restrict__ bytes, u32 len, u64* __restrict__ partials)
+{
+  __shared__ u64 s_a[4], s_b[4];
+  u64 A = 0, B = 0;
+  const u32 stride = gridDim.x * 256u;
+  for (u32 p = blockIdx.x * 256u + threadIdx.x; p < len; p += stride)
+  {
+    const u32 c = (u32)bytes[p] << ((p & 1u) ? 0 : 8);
+    A += c;
+    B += (u64)(p >> 1) * c;
+  }
+  A %= 65535u; B %= 65535u;
+  A = waveSum(A); B = waveSum(B);
+  if (laneId() == 0) { s_a[waveId()] = A; s_b[waveId()] = B; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    partials[2 * blockIdx.x] = (s_a[0] + s_a[1] + s_a[2] + s_a[3]) % 65535u;
+    partials[2 * blockIdx.x + 1] = (s_b[0] + s_b[1] + s_b[2] + s_b[3]) % 65535u;
+  }
+}
+
+// acc: 2 * kFletcherBlocks u64 words
+void launchFletcher(const u8* blob, u32 len, u64* acc, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_fletcher, dim3(kFletcherBlocks), dim3(256), 0, stream, blob, len, acc);
+}
+
+u32 fletcherFinish(u64 A, u64 B, u32 len)
+{
+  const u64 N = ((u64)len + 1) / 2;
+  A %= 65535u; B %= 65535u;
+  u64 s1 = A;
+  u64 s2 = ((N % 65535u) * A + 65535u - B) % 65535u;
+  if (s1 == 0) s1 = 0xffff;
+  if (s2 == 0) s2 = 0xffff;
+  return (u32)((s2 << 16) | s1);
+}
+
+// ================================================================================================
+// validity mask
+// ================================================================================================
+template<class T> __device__ __forceinline__ bool isNaNT(T) { return false; }
+template<> __device__ __forceinline__ bool isNaNT<float>(float v) { return v != v; }
+template<> __device__ __forceinline__ bool isNaNT<double>(double v) { return v != v; }
+
+// one thread per mask byte (8 pixels)
+template<class T>
+__global__ void __launch_bounds__(256) k_build_mask(const T* __restrict__ data, const u8* __restrict__ byteMask, i64 nPix,
+                                                    int nDepth, u8* __restrict__ maskBits, BandStats* stats)
+{
+  const i64 byteIdx = (i64)blockIdx.x * 256 + threadIdx.x;
+  const i64 nBytes = (nPix + 7) >> 3;
+  u32 bits = 0, cnt = 0;
+  bool sawNaN = false, sawMixed = false;
+  if (byteIdx < nBytes)
+  {
+    for (int j = 0; j < 8; j++)
+    {
+      const i64 k = byteIdx * 8 + j;
+      if (k >= nPix) { bits |= 0x80u >> j; continue; }    // tail bits stay set, like BitMask::SetAllValid + SetInvalid (Lerc.cpp:959-975)
+      bool valid = byteMask ? (byteMask[k] != 0) : true;
+      if (valid && (DtOf<T>::v >= DT_Float))
+      {
+        int nBad = 0;
+        for (int m = 0; m < nDepth; m++) nBad += isNaNT(data[k * nDepth + m]) ? 1 : 0;
+        if (nBad > 0) sawNaN = true;
+        if (nBad == nDepth) valid = false;
+        else if (nBad > 0) sawMixed = true;
+      }
+      if (valid) { bits |= 0x80u >> j; cnt++; }
+    }
+    maskBits[byteIdx] = (u8)bits;
+  }
+  cnt = waveSum(cnt);
+  const bool anyNaN = __any(sawNaN), anyMixed = __any(sawMixed);
+  if (laneId() == 0)
+  {
+    if (cnt) atomicAdd(&stats->numValid, cnt);
+    if (anyNaN) atomicOr(&stats->hasNaN, 1u);
+    if (anyMixed) atomicOr(&stats->mixedNaN, 1u);
+  }
+}
+
+void launchBuildMask(int dt, const void* data, const u8* byteMask, int nRows, int nCols, int nDepth, u8* maskBits,
+                     BandStats* stats, hipStream_t stream)
+{
+  const i64 nPix = (i64)nRows * nCols, nBytes = (nPix + 7) >> 3;
+  const dim3 grid((unsigned)((nBytes + 255) / 256)), block(256);
+  switch (dt)
+  {
+    case DT_Float: hipLaunchKernelGGL(k_build_mask<float>, grid, block, 0, stream, (const float*)data, byteMask, nPix, nDepth, maskBits, stats); break;
+    case DT_Double: hipLaunchKernelGGL(k_build_mask<double>, grid, block, 0, stream, (const double*)data, byteMask, nPix, nDepth, maskBits, stats); break;
+    default: hipLaunchKernelGGL(k_build_mask<u8>, grid, block, 0, stream, (const u8*)data, byteMask, nPix, 1, maskBits, stats); break;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_block_valid_counts(const u8* __restrict__ maskBits, BandParams p, u16* __restrict__ nValidBlk)
+{
+  const int pos = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (pos >= p.nTV * p.nTH) return;
+  const int it = pos / p.nTH, jt = pos - it * p.nTH;
+  const int i0 = it * p.mb, j0 = jt * p.mb;
+  const int i1 = min(p.nRows, i0 + p.mb), j1 = min(p.nCols, j0 + p.mb);
+  int n = 0;
+  for (int i = i0; i < i1; i++)
+    for (int j = j0; j < j1; j++) n += (!maskBits || maskBit(maskBits, (i64)i * p.nCols + j)) ? 1 : 0;
+  nValidBlk[pos] = (u16)n;
+}
+
+void launchBlockValidCounts(const u8* maskBits, const BandParams& p, u16* nValidBlk, hipStream_t stream)
+{
+  const int nPos = p.nTV * p.nTH;
+  hipLaunchKernelGGL(k_block_valid_counts, dim3((nPos + 255) / 256), dim3(256), 0, stream, maskBits, p, nValidBlk);
+}
+
+__global__ void __launch_bounds__(256) k_bits_to_bytes(const u8* __restrict__ maskBits, u8* __restrict__ byteMask, i64 nPix)
+{
+  const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (k < nPix) byteMask[k] = maskBits ? (maskBit(maskBits, k) ? 1 : 0) : 1;
+}
+
+void launchBitsToBytes(const u8* maskBits, u8* byteMask, i64 nPix, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_bits_to_bytes, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, stream, maskBits, byteMask, nPix);
+}
+
+// ================================================================================================
+// per-depth min / max (+ float diagnostics)
+// Order-preserving 64-bit keys so that integer atomics implement min / max for every type.
+// ================================================================================================
+template<class T> struct Key;
+template<> struct Key<signed char>    { static __device__ __host__ u64 enc(signed char v) { return (u64)((i64)v + (1ll << 62)); } };
+template<> struct Key<unsigned char>  { static __device__ __host__ u64 enc(unsigned char v) { return (u64)v + (1ull << 62); } };
+template<> struct Key<short>          { static __device__ __host__ u64 enc(short v) { return (u64)((i64)v + (1ll << 62)); } };
+template<> struct Key<unsigned short> { static __device__ __host__ u64 enc(unsigned short v) { return (u64)v + (1ull << 62); } };
+template<> struct Key<int>            { static __device__ __host__ u64 enc(int v) { return (u64)((i64)v + (1ll << 62)); } };
+template<> struct Key<unsigned int>   { static __device__ __host__ u64 enc(unsigned int v) { return (u64)v + (1ull << 62); } };
+template<> struct Key<float>
+{
+  static __device__ __host__ u64 enc(float v) { u32 b; memcpy(&b, &v, 4); b = (b & 0x80000000u) ? ~b : (b | 0x80000000u); return b; }
+};
+template<> struct Key<double>
+{
+  static __device__ __host__ u64 enc(double v) { u64 b; memcpy(&b, &v, 8); return (b >> 63) ? ~b : (b | (1ull << 63)); }
+};
+
+u64 statKeyInitMin() { return ~0ull; }
+u64 statKeyInitMax() { return 0ull; }
+
+// inverse of Key<T>::enc: returns the raw little-endian bits of the T value (low dtSize bytes)
+u64 statKeyToRawBits(int dt, u64 key)
+{
+  switch (dt)
+  {
+    case DT_Float: { u32 b = (u32)key; b = (b & 0x80000000u) ? (b & 0x7fffffffu) : ~b; return b; }
+    case DT_Double: { return (key >> 63) ? (key & ~(1ull << 63)) : ~key; }
+    default: { const i64 v = (i64)key - (1ll << 62); return (u64)v; }
+  }
+}
+
+double statKeyToDouble(int dt, u64 key)
+{
+  const u64 raw = statKeyToRawBits(dt, key);
+  switch (dt)
+  {
+    case DT_Float: { u32 b = (u32)raw; float f; memcpy(&f, &b, 4); return (double)f; }
+    case DT_Double: { double d; memcpy(&d, &raw, 8); return d; }
+    default: return (double)(i64)raw;
+  }
+}
+
+static const int kStatsMaxDepthLds = 256;
+
+template<class T>
+__global__ void __launch_bounds__(256)
+k_band_stats(const T* __restrict__ data, const u8* __restrict__ maskBits, i64 nPix, int nDepth, double maxZErr, u32 raiseMask,
+             u64* __restrict__ mins, u64* __restrict__ maxs, BandStats* stats)
+{
+  __shared__ u64 s_min[kStatsMaxDepthLds], s_max[kStatsMaxDepthLds];
+  __shared__ u64 s_raise[9];
+  constexpr bool isFlt = (DtOf<T>::v >= DT_Float);
+  const int facCand[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
+  for (int i = threadIdx.x; i < nDepth; i += 256) { s_min[i] = ~0ull; s_max[i] = 0ull; }
+  if (threadIdx.x < 9) s_raise[threadIdx.x] = 0ull;
+  __syncthreads();
+
+  const i64 nElem = nPix * nDepth;
+  const i64 stride = (i64)gridDim.x * 256;
+  bool sawNaN = false, sawFrac = false;
+  u64 kMin = ~0ull, kMax = 0ull;    // nDepth == 1 fast path: registers
+  double rerr[9];
+#pragma unroll
+  for (int c = 0; c < 9; c++) rerr[c] = 0;
+
+  for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < nElem; t += stride)
+  {
+    const i64 k = (nDepth == 1) ? t : t / nDepth;
+    if (maskBits && !maskBit(maskBits, k)) continue;
+    const T v = data[t];
+    if (isFlt && isNaNT(v)) { sawNaN = true; continue; }
+    const u64 key = Key<T>::enc(v);
+    if (nDepth == 1) { kMin = key < kMin ? key : kMin; kMax = key > kMax ? key : kMax; }
+    else
+    {
+      const int m = (int)(t - k * nDepth);
+      atomicMin(&s_min[m], key);
+      atomicMax(&s_max[m], key);
+    }
+    if (isFlt)
+    {
+      const double x = (double)v;
+      if (!sawFrac && !(v == (T)floor(x + 0.5))) sawFrac = true;    // Lerc.h:271 IsInt
+      if (raiseMask)
+      {
+        // Lerc2.cpp:1269-1276: candidates in increasing factor order, stop at the first exact hit
+#pragma unroll
+        for (int c = 0; c < 9; c++)
+        {
+          if (!((raiseMask >> c) & 1u)) continue;
+          const double z = x * facCand[c];
+          if (z == (double)(int)z) break;
+          const double dlt = fabs(floor(z + 0.5) - z);
+          rerr[c] = dlt > rerr[c] ? dlt : rerr[c];
+        }
+      }
+    }
+  }
+  if (nDepth == 1)
+  {
+    kMin = waveMin(kMin); kMax = waveMax(kMax);
+    if (laneId() == 0) { atomicMin(&s_min[0], kMin); atomicMax(&s_max[0], kMax); }
+  }
+  if (isFlt && raiseMask)
+  {
+#pragma unroll
+    for (int c = 0; c < 9; c++)
+    {
+      u64 b; double r = rerr[c]; memcpy(&b, &r, 8);    // non-negative doubles order like their bit patterns
+      b = waveMax(b);
+      if (laneId() == 0 && b) atomicMax(&s_raise[c], b);
+    }
+  }
+  const bool anyNaN = __any(sawNaN), anyFrac = __any(sawFrac);
+  if (laneId() == 0)
+  {
+    if (anyNaN) atomicOr(&stats->hasNaN, 1u);
+    if (anyFrac) atomicOr(&stats->notAllInt, 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nDepth; i += 256)
+  {
+    if (s_min[i] != ~0ull) atomicMin(&mins[i], s_min[i]);
+    if (s_max[i] != 0ull) atomicMax(&maxs[i], s_max[i]);
+  }
+  if (threadIdx.x < 9 && s_raise[threadIdx.x])
+    atomicMax(reinterpret_cast<u64*>(&stats->raiseErr[threadIdx.x]), s_raise[threadIdx.x]);
+  (void)maxZErr;
+}
+
+void launchBandStats(int dt, const void* data, const u8* maskBits, int nRows, int nCols, int nDepth, u32 raiseMask,
+                     u64* mins, u64* maxs, BandStats* stats, hipStream_t stream)
+{
+  const double maxZErr = 0;
+  const i64 nPix = (i64)nRows * nCols;
+  const i64 nElem = nPix * nDepth;
+  i64 nBlocks = (nElem + 256 * 16 - 1) / (256 * 16);
+  if (nBlocks > 4096) nBlocks = 4096;
+  if (nBlocks < 1) nBlocks = 1;
+  const dim3 grid((unsigned)nBlocks), block(256);
+  switch (dt)
+  {
+    case DT_Char:   hipLaunchKernelGGL(k_band_stats<signed char>, grid, block, 0, stream, (const signed char*)data, maskBits, nPix, nDepth, maxZErr, raiseMask, mins, maxs, stats); break;
+    case DT_Byte:   hipLaunchKernelGGL(k_band_stats<unsigned char>, grid, block, 0, stream, (const unsigned char*)data, maskBits, nPix, nDepth, maxZErr, raiseMask, mins, maxs, stats); break;
+    case DT_Short:  hipLaunchKernelGGL(k_band_stats<short>, grid, block, 0, stream, (const short*)data, maskBits, nPix, nDepth, maxZErr, raiseMask, mins, maxs, stats); break;
+    case DT_UShort: hipLaunchKernelGGL(k_band_stats<unsigned short>, grid, block, 0, stream, (const unsigned short*)data, maskBits, nPix, nDepth, maxZErr, raiseMask, mins, maxs, stats); break;
+    case DT_Int:    hipLaunchKernelGGL(k_band_stats<int>, grid, block, 0, stream, (const int*)data, maskBits, nPix, nDepth, maxZErr, raiseMask, mins, maxs, stats); break;
+    case DT_UInt:   hipLaunchKernelGGL(k_band_stats<unsigned int>, grid, block, 0, stream, (const unsigned int*)data, maskBits, nPix, nDepth, maxZErr, raiseMask, mins, maxs, stats); break;
+    case DT_Float:  hipLaunchKernelGGL(k_band_stats<float>, grid, block, 0, stream, (const float*)data, maskBits, nPix, nDepth, maxZErr, raiseMask, mins, maxs, stats); break;
+    case DT_Double: hipLaunchKernelGGL(k_band_stats<double>, grid, block, 0, stream, (const double*)data, maskBits, nPix, nDepth, maxZErr, raiseMask, mins, maxs, stats); break;
+    default: break;
+  }
+}
+
+// ================================================================================================
+// raw one-sweep copy / const fill / widen
+// ================================================================================================
+// wordBase[g] = number of valid pixels before pixel 32 * g (exclusive scan of per-group popcounts)
+__global__ void __launch_bounds__(256) k_mask_group_counts(const u8* __restrict__ maskBits, i64 nPix, u32* __restrict__ counts)
+{
+  const i64 g = (i64)blockIdx.x * 256 + threadIdx.x;
+  const i64 nGroups = (nPix + 31) >> 5;
+  if (g >= nGroups) return;
+  u32 c = 0;
+  for (int j = 0; j < 32; j++) { const i64 k = g * 32 + j; if (k < nPix && maskBit(maskBits, k)) c++; }
+  counts[g] = c;
+}
+
+__global__ void __launch_bounds__(256)
+k_one_sweep(bool encode, const u8* __restrict__ src, u8* __restrict__ dst, const u8* __restrict__ maskBits,
+            const u32* __restrict__ groupBase, i64 nPix, int pixelBytes)
+{
+  const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nPix) return;
+  i64 r = k;
+  if (maskBits)
+  {
+    if (!maskBit(maskBits, k)) return;
+    r = groupBase[k >> 5];
+    for (i64 j = (k >> 5) << 5; j < k; j++) r += maskBit(maskBits, j) ? 1 : 0;
+  }
+  const u8* s = src + (encode ? k : r) * pixelBytes;
+  u8* d = dst + (encode ? r : k) * pixelBytes;
+  for (int b = 0; b < pixelBytes; b++) d[b] = s[b];
+}
+
+void launchOneSweep(bool encode, const void* src, void* dst, const u8* maskBits, const u32* groupBase, i64 nPix,
+                    int pixelBytes, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_one_sweep, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, stream, encode, (const u8*)src, (u8*)dst,
+                     maskBits, groupBase, nPix, pixelBytes);
+}
+
+void launchMaskGroupCounts(const u8* maskBits, i64 nPix, u32* counts, hipStream_t stream)
+{
+  const i64 nGroups = (nPix + 31) >> 5;
+  hipLaunchKernelGGL(k_mask_group_counts, dim3((unsigned)((nGroups + 255) / 256)), dim3(256), 0, stream, maskBits, nPix, counts);
+}
+
+__global__ void __launch_bounds__(256)
+k_fill(u8* __restrict__ dst, const u8* __restrict__ pixel, int pixelBytes, const u8* __restrict__ maskBits, i64 nPix)
+{
+  const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nPix) return;
+  const bool valid = !maskBits || maskBit(maskBits, k);
+  for (int b = 0; b < pixelBytes; b++) dst[k * pixelBytes + b] = valid ? pixel[b] : (u8)0;
+}
+
+void launchFill(void* dst, const void* pixel, int pixelBytes, const u8* maskBits, i64 nPix, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, stream, (u8*)dst, (const u8*)pixel, pixelBytes, maskBits, nPix);
+}
+
+template<class T>
+__global__ void __launch_bounds__(256) k_widen(const T* __restrict__ src, double* __restrict__ dst, i64 n)
+{
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (double)src[i];
+}
+
+void launchWidenToDouble(int dt, const void* src, double* dst, i64 n, hipStream_t stream)
+{
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  switch (dt)
+  {
+    case DT_Char:   hipLaunchKernelGGL(k_widen<signed char>, grid, block, 0, stream, (const signed char*)src, dst, n); break;
+    case DT_Byte:   hipLaunchKernelGGL(k_widen<unsigned char>, grid, block, 0, stream, (const unsigned char*)src, dst, n); break;
+    case DT_Short:  hipLaunchKernelGGL(k_widen<short>, grid, block, 0, stream, (const short*)src, dst, n); break;
+    case DT_UShort: hipLaunchKernelGGL(k_widen<unsigned short>, grid, block, 0, stream, (const unsigned short*)src, dst, n); break;
+    case DT_Int:    hipLaunchKernelGGL(k_widen<int>, grid, block, 0, stream, (const int*)src, dst, n); break;
+    case DT_UInt:   hipLaunchKernelGGL(k_widen<unsigned int>, grid, block, 0, stream, (const unsigned int*)src, dst, n); break;
+    case DT_Float:  hipLaunchKernelGGL(k_widen<float>, grid, block, 0, stream, (const float*)src, dst, n); break;
+    default: break;
+  }
+}
+
+}    // namespace lerc

@@ -1,0 +1,447 @@
+// tile_decode.hip -- Lerc2 "tiling" decoder on CDNA4.
+//
+// Replaces Lerc2::ReadTiles / ReadTile (Lerc2.cpp:1672-1713, :2025-2230) and BitStuffer2::Decode /
+// BitUnStuff (BitStuffer2.cpp:159-258, :476-540).
+//
+// 1. Block-offset discovery.  The stream stores no block offsets: block k+1 starts where block k
+//    ends and a block's length is only known from its own first bytes.  The blob is cut into chunks;
+//    for every chunk all positions of its first `window` bytes (window = longest possible block)
+//    are tried as block starts and walked to the chunk end, dropping walks that hit an impossible
+//    block header or an inconsistent column signature.  The true first block of the chunk is always
+//    among the survivors; if all survivors leave the chunk at the same offset, that offset IS the
+//    first block of the next chunk, whatever this chunk's own entry was.  Chunks therefore resolve
+//    independently (self-synchronisation); the rare disagreeing chunk is re-walked from its
+//    resolved predecessor, and blobs whose raw blocks have position dependent lengths (masks /
+//    partial edge blocks) fall back to a single sequential walk on the device.
+// 2. Decode: one wave64 per micro-block position, lane = element (rank by __ballot / __popcll for
+//    masked blocks), bit extraction straight from the blob, dequantise in double precision in the
+//    reference's expression order (compile with -ffp-contract=off), clamp, cast, store.
+#include "kernels.h"
+#include "wave_utils.h"
+
+namespace lerc {
+
+struct BlkInfo
+{
+  u32 len;        // total bytes of the block
+  u32 cnt;        // element count stored in the bit stuffer header
+  u32 nLut;       // LUT entries without the implicit 0
+  u32 payload;    // offset of the first payload byte relative to the block start
+  u8 flag, mode, diff, tc, offBytes, nb, lut, dtUsed;
+};
+
+// 0 = ok, 1 = not a valid block here, 2 = raw block whose valid count is not known to the caller.
+// Mirrors the checks of Lerc2::ReadTile and BitStuffer2::Decode; additionally refuses element counts
+// that differ from the block's valid pixel count (the reference would read past its buffer there).
+template<int TBYTES>
+__device__ __forceinline__ int parseBlock(const u8* __restrict__ blob, u32 pos, u32 end, const BandParams& p, int nValid,
+                                          u32 maxCount, BlkInfo& b)
+{
+  if (pos >= end) return 1;
+  const u32 flag = blob[pos];
+  b.flag = (u8)flag;
+  b.diff = (p.version >= 5 && (flag & 4u)) ? 1 : 0;
+  b.mode = (u8)(flag & 3u);
+  b.tc = (u8)(flag >> 6);
+  b.offBytes = 0; b.nb = 0; b.lut = 0; b.cnt = 0; b.nLut = 0; b.payload = 1; b.dtUsed = (u8)p.dt;
+  u64 len = 1;
+  if (b.mode == 2) { b.len = 1; return 0; }
+  if (b.mode == 0)
+  {
+    if (b.diff) return 1;
+    if (nValid < 0) return 2;
+    len = 1 + (u64)nValid * TBYTES;
+  }
+  else
+  {
+    const int dtU = typeUsed((b.diff && p.dt < DT_Float) ? (int)DT_Int : p.dt, b.tc);
+    if (dtU == DT_Undefined) return 1;
+    b.dtUsed = (u8)dtU;
+    b.offBytes = (u8)dtSize(dtU);
+    len = 1 + b.offBytes;
+    if (b.mode == 1)
+    {
+      u64 at = (u64)pos + len;
+      if (at >= end) return 1;
+      const u32 b0 = blob[at];
+      const u32 code = b0 >> 6;
+      const int cb = (code == 0) ? 4 : 3 - (int)code;
+      if (cb == 0) return 1;
+      b.lut = (b0 & 32u) ? 1 : 0;
+      b.nb = (u8)(b0 & 31u);
+      if (at + 1 + cb > end) return 1;
+      u32 cnt = 0;
+      for (int i = 0; i < cb; i++) cnt |= (u32)blob[at + 1 + i] << (8 * i);
+      b.cnt = cnt;
+      if (cnt == 0 || cnt > maxCount || b.nb == 0) return 1;
+      if (nValid >= 0 && cnt != (u32)nValid) return 1;
+      len += 1 + cb;
+      if (!b.lut) { b.payload = (u32)len; len += ((u64)cnt * b.nb + 7) >> 3; }
+      else
+      {
+        if ((u64)pos + len >= end) return 1;
+        const int nLut = (int)blob[(u64)pos + len] - 1;
+        if (nLut < 1) return 1;
+        b.nLut = (u32)nLut;
+        len += 1;
+        b.payload = (u32)len;
+        len += ((u64)nLut * b.nb + 7) >> 3;
+        len += ((u64)cnt * bitLen((u32)nLut) + 7) >> 3;
+      }
+    }
+  }
+  if ((u64)pos + len > end) return 1;
+  b.len = (u32)len;
+  return 0;
+}
+
+// little-endian bit field read with a hard upper bound on the bytes touched
+__device__ __forceinline__ u32 readBits(const u8* __restrict__ blob, u64 bitPos, int nbits, u32 end)
+{
+  const u64 byte = bitPos >> 3;
+  const int sh = (int)(bitPos & 7);
+  const int need = (sh + nbits + 7) >> 3;    // <= 5
+  u64 v = 0;
+  for (int i = 0; i < need; i++)
+    if (byte + i < end) v |= (u64)blob[byte + i] << (8 * i);
+  return (u32)((v >> sh) & ((nbits >= 32) ? 0xFFFFFFFFull : ((1ull << nbits) - 1)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode kernel
+// ------------------------------------------------------------------------------------------------
+template<class T>
+__global__ void __launch_bounds__(256) k_decode_tiles(BandParams p, DecodeArgs a, DeviceStatus* st)
+{
+  __shared__ u32 s_lut[4][256];
+  const int w = waveId(), lane = laneId();
+  const int pos = (int)blockIdx.x * 4 + w;
+  if (pos >= p.nTV * p.nTH) return;
+  const int mb = p.mb, nD = p.nDepth;
+  const int it = pos / p.nTH, jt = pos - it * p.nTH;
+  const int i0 = it * mb, j0 = jt * mb;
+  const int tileH = min(mb, p.nRows - i0), tileW = min(mb, p.nCols - j0);
+  const int nElem = tileH * tileW;
+  const int E = (nElem + 63) >> 6;
+  const u64 lt = laneMaskLt();
+  T* __restrict__ out = (T*)a.out;
+  const u8* __restrict__ blob = a.blob;
+
+  int nValid = 0;
+  for (int k = 0; k < E; k++)
+  {
+    const int e = k * 64 + lane;
+    const bool inb = e < nElem;
+    const int r = inb ? e / tileW : 0, c = inb ? e - r * tileW : 0;
+    const i64 px = (i64)(i0 + r) * p.nCols + (j0 + c);
+    const bool valid = inb && (p.allValid || maskBit(a.maskBits, px));
+    nValid += __popcll(__ballot(valid));
+  }
+
+  const u32 pattern = (p.version >= 5) ? 14u : 15u;
+  bool failed = false;
+
+  for (int iD = 0; iD < nD; iD++)
+  {
+    const u32 off = a.blockOff[(i64)pos * nD + iD];
+    BlkInfo b;
+    const int rc = parseBlock<(int)sizeof(T)>(blob, off, a.blobEnd, p, nValid, (u32)nElem, b);
+    if (rc != 0 || (((u32)b.flag >> 2) & pattern) != (((u32)j0 >> 3) & pattern) || (b.diff && iD == 0))
+    {
+      failed = true;
+      break;
+    }
+    double offset = 0;
+    if (b.mode == 1 || b.mode == 3) offset = typedFromBits(getBytes(blob + off + 1, b.offBytes), b.dtUsed);
+    const double zMax = (p.version >= 4 && nD > 1) ? a.zMaxVec[iD] : p.zMaxHdr;
+    const u64 payloadBit = 8ull * ((u64)off + b.payload);
+    const int nbIdx = b.lut ? bitLen(b.nLut) : 0;
+    u64 idxBit = 0;
+    if (b.mode == 1 && b.lut)
+    {
+      s_lut[w][0] = 0;
+      for (u32 i = (u32)lane; i < b.nLut; i += 64) s_lut[w][i + 1] = readBits(blob, payloadBit + (u64)i * b.nb, b.nb, a.blobEnd);
+      idxBit = payloadBit + 8ull * (((u64)b.nLut * b.nb + 7) >> 3);
+      waveSync();
+    }
+
+    int base = 0;
+    bool badIdx = false;
+    for (int k = 0; k < E; k++)
+    {
+      const int e = k * 64 + lane;
+      const bool inb = e < nElem;
+      const int r = inb ? e / tileW : 0, c = inb ? e - r * tileW : 0;
+      const i64 px = (i64)(i0 + r) * p.nCols + (j0 + c);
+      const bool valid = inb && (p.allValid || maskBit(a.maskBits, px));
+      const u64 bal = __ballot(valid);
+      const int rank = base + __popcll(bal & lt);
+      base += __popcll(bal);
+      if (!inb) continue;
+      const i64 m = px * nD + iD;
+      T val = T(0);
+      if (valid)
+      {
+        if (b.mode == 2) val = b.diff ? out[m - 1] : T(0);
+        else if (b.mode == 0)
+        {
+          const u64 bits = getBytes(blob + off + 1 + (u64)rank * sizeof(T), (int)sizeof(T));
+          memcpy(&val, &bits, sizeof(T));
+        }
+        else if (b.mode == 3)
+        {
+          if (!b.diff) val = (T)offset;
+          else { const double z = offset + (double)out[m - 1]; val = (T)(z < zMax ? z : zMax); }
+        }
+        else
+        {
+          u32 q;
+          if (!b.lut) q = readBits(blob, payloadBit + (u64)rank * b.nb, b.nb, a.blobEnd);
+          else
+          {
+            const u32 ix = readBits(blob, idxBit + (u64)rank * nbIdx, nbIdx, a.blobEnd);
+            if (ix > b.nLut) { badIdx = true; q = 0; } else q = s_lut[w][ix];
+          }
+          double z = offset + (double)q * p.invScale;
+          if (b.diff) z = z + (double)out[m - 1];
+          val = (T)(z < zMax ? z : zMax);    // std::min(z, zMax)
+        }
+      }
+      out[m] = val;
+    }
+    if (__any(badIdx)) { failed = true; break; }
+    waveSync();
+  }
+  if (failed && lane == 0) raiseError(st, kFailed, (u32)pos);
+}
+
+void launchTileDecode(int dt, const BandParams& p, const DecodeArgs& a, DeviceStatus* st, hipStream_t stream)
+{
+  const int nPos = p.nTV * p.nTH;
+  const dim3 grid((nPos + 3) / 4), block(256);
+  switch (dt)
+  {
+    case DT_Char:   hipLaunchKernelGGL(k_decode_tiles<signed char>, grid, block, 0, stream, p, a, st); break;
+    case DT_Byte:   hipLaunchKernelGGL(k_decode_tiles<unsigned char>, grid, block, 0, stream, p, a, st); break;
+    case DT_Short:  hipLaunchKernelGGL(k_decode_tiles<short>, grid, block, 0, stream, p, a, st); break;
+    case DT_UShort: hipLaunchKernelGGL(k_decode_tiles<unsigned short>, grid, block, 0, stream, p, a, st); break;
+    case DT_Int:    hipLaunchKernelGGL(k_decode_tiles<int>, grid, block, 0, stream, p, a, st); break;
+    case DT_UInt:   hipLaunchKernelGGL(k_decode_tiles<unsigned int>, grid, block, 0, stream, p, a, st); break;
+    case DT_Float:  hipLaunchKernelGGL(k_decode_tiles<float>, grid, block, 0, stream, p, a, st); break;
+    case DT_Double: hipLaunchKernelGGL(k_decode_tiles<double>, grid, block, 0, stream, p, a, st); break;
+    default: break;
+  }
+}
+
+// ================================================================================================
+// block-offset discovery
+// ================================================================================================
+static const u32 kNone = 0xFFFFFFFFu;
+
+WalkPlan makeWalkPlan(const BandParams& p, u32 dataBegin, u32 blobEnd, int numValid)
+{
+  WalkPlan wp;
+  const u32 n = (u32)p.mb * (u32)p.mb;
+  const u32 tb = (u32)dtSize(p.dt);
+  const u32 raw = 1 + n * tb;
+  const u32 simple = 1 + 8 + 1 + 4 + ((n * 31 + 7) >> 3);
+  const u32 lut = 1 + 8 + 1 + 4 + 1 + ((254u * 31 + 7) >> 3) + n;
+  u32 win = raw > simple ? raw : simple;
+  win = lut > win ? lut : win;
+  wp.window = win + 1;
+  u32 cb = 4096;
+  while (cb < 2 * wp.window) cb <<= 1;
+  wp.chunkBytes = cb;
+  const u32 span = blobEnd > dataBegin ? blobEnd - dataBegin : 0;
+  wp.nChunks = span ? (span + cb - 1) / cb : 1;
+  wp.nSub = (u32)p.nTV * (u32)p.nTH * (u32)p.nDepth;
+  const bool uniform = (numValid == p.nRows * p.nCols) && (p.nRows % p.mb == 0) && (p.nCols % p.mb == 0);
+  wp.uniformN = uniform ? (int)n : 0;
+  return wp;
+}
+
+// Column-signature progression between two consecutive sub-blocks of the stream (flag bits 2-5,
+// Lerc2.cpp:1955-1958 / :2042-2046): same position (next depth slice), next column, or column 0 of
+// the next block row.  Only checked for the standard block sizes.
+__device__ __forceinline__ bool sigFollows(u32 prev, u32 cur, int mb, u32 pattern)
+{
+  if (mb != 8 && mb != 16 && mb != 32) return true;
+  u32 step = (u32)mb >> 3;
+  if (step == 1 && pattern == 14u) step = 2;
+  return cur == prev || cur == ((prev + step) & pattern) || cur == 0;
+}
+
+// D1: one wave per chunk.
+template<int TBYTES>
+__global__ void __launch_bounds__(64) k_walk_chunks(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin,
+                                                    u32 blobEnd, u32* __restrict__ chunkExit)
+{
+  const u32 c = blockIdx.x;
+  const int lane = laneId();
+  const u32 chunkStart = dataBegin + c * wp.chunkBytes;
+  const u32 chunkEnd = min(chunkStart + wp.chunkBytes, blobEnd);
+  const u32 winEnd = (c == 0) ? chunkStart + 1 : min(chunkStart + wp.window, chunkEnd);
+  const u32 pattern = (p.version >= 5) ? 14u : 15u;
+  const u32 maxCount = (u32)p.mb * (u32)p.mb;
+  const u32 kUnknown = 0xFFFFFFFEu;
+
+  u32 agreed = kNone;
+  bool conflict = false;
+  for (u32 r0 = chunkStart; r0 < winEnd; r0 += 64)
+  {
+    u32 cur = r0 + (u32)lane;
+    bool alive = cur < winEnd;
+    bool unknown = false;
+    u32 prevSig = kNone;
+    while (__any(alive && !unknown && cur < chunkEnd))
+    {
+      if (alive && !unknown && cur < chunkEnd)
+      {
+        BlkInfo b;
+        const int rc = parseBlock<TBYTES>(blob, cur, blobEnd, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b);
+        if (rc == 1) alive = false;
+        else if (rc == 2) unknown = true;
+        else
+        {
+          const u32 sig = ((u32)b.flag >> 2) & pattern;
+          if (prevSig != kNone && !sigFollows(prevSig, sig, p.mb, pattern)) alive = false;
+          else { prevSig = sig; cur += b.len; }
+        }
+      }
+    }
+    const u32 e = unknown ? kUnknown : cur;
+    const u32 lo = waveMin(alive ? e : kNone);
+    const u32 hi = waveMax(alive ? e : 0u);
+    if (lo != kNone)    // at least one survivor in this round
+    {
+      if (lo != hi) conflict = true;
+      else if (agreed == kNone) agreed = lo;
+      else if (agreed != lo) conflict = true;
+    }
+  }
+  if (lane == 0) chunkExit[c] = (!conflict && agreed != kNone && agreed != kUnknown) ? agreed : kNone;
+}
+
+// D2: entry[c] = agreed exit of chunk c-1; unresolved chunks are re-walked from their predecessor
+// (uniform blobs) or the whole band is handed to the sequential walk (flag in needSerial).
+template<int TBYTES>
+__global__ void __launch_bounds__(256) k_resolve_entries(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin,
+                                                         u32 blobEnd, const u32* __restrict__ chunkExit,
+                                                         u32* __restrict__ chunkEntry, u32* __restrict__ needSerial)
+{
+  __shared__ u32 s_bad;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  for (u32 c = threadIdx.x; c <= wp.nChunks; c += 256)
+  {
+    const u32 e = (c == 0) ? dataBegin : chunkExit[c - 1];
+    chunkEntry[c] = e;
+    // the exit of the last chunk is only needed to prove that it holds no raw block of unknown length
+    if (e == kNone && (c < wp.nChunks || wp.uniformN == 0)) atomicAdd(&s_bad, 1u);
+  }
+  __syncthreads();
+  if (s_bad == 0 || threadIdx.x != 0) return;
+  if (wp.uniformN == 0) { *needSerial = 1; return; }
+  const u32 maxCount = (u32)p.mb * (u32)p.mb;
+  for (u32 c = 1; c < wp.nChunks; c++)
+  {
+    if (chunkEntry[c] != kNone) continue;
+    u32 cur = chunkEntry[c - 1];
+    const u32 chunkEnd = min(dataBegin + c * wp.chunkBytes, blobEnd);
+    bool ok = cur != kNone;
+    while (ok && cur < chunkEnd)
+    {
+      BlkInfo b;
+      if (parseBlock<TBYTES>(blob, cur, blobEnd, p, wp.uniformN, maxCount, b) != 0) ok = false; else cur += b.len;
+    }
+    if (!ok) { *needSerial = 1; return; }
+    chunkEntry[c] = cur;
+  }
+}
+
+// D3: one lane per chunk walks from the resolved entry; pass 0 counts sub-blocks, pass 1 emits offsets.
+template<int TBYTES, bool EMIT>
+__global__ void __launch_bounds__(256) k_walk_emit(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
+                                                   const u32* __restrict__ chunkEntry, u32* __restrict__ chunkCount,
+                                                   const u32* __restrict__ chunkBase, u32* __restrict__ blockOff,
+                                                   const u32* __restrict__ needSerial, DeviceStatus* st)
+{
+  if (*needSerial) return;
+  const u32 c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= wp.nChunks) return;
+  const u32 chunkEnd = min(dataBegin + (c + 1) * wp.chunkBytes, blobEnd);
+  const u32 maxCount = (u32)p.mb * (u32)p.mb;
+  u32 cur = chunkEntry[c];
+  u32 n = 0;
+  u32 base = EMIT ? chunkBase[c] : 0u;
+  while (cur < chunkEnd)
+  {
+    BlkInfo b;
+    if (parseBlock<TBYTES>(blob, cur, blobEnd, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b) != 0) { raiseError(st, kFailed, 0x80000000u | c); break; }
+    if (EMIT) { if (base + n < wp.nSub) blockOff[base + n] = cur; }
+    n++;
+    cur += b.len;
+  }
+  if (!EMIT) chunkCount[c] = n;
+  else if (c == wp.nChunks - 1 && base + n != wp.nSub) raiseError(st, kFailed, 0x40000000u | c);
+}
+
+// Fallback: a single lane walks every sub-block in order (needed when raw blocks have position
+// dependent lengths, i.e. masks or partial edge blocks, or when chunk resolution failed).
+template<int TBYTES>
+__global__ void __launch_bounds__(64) k_walk_serial(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
+                                                    const u16* __restrict__ nValidBlk, u32* __restrict__ blockOff,
+                                                    const u32* __restrict__ needSerial, DeviceStatus* st)
+{
+  if (!*needSerial || threadIdx.x != 0) return;
+  u32 cur = dataBegin;
+  const u32 nPos = (u32)p.nTV * (u32)p.nTH;
+  const u32 maxCount = (u32)p.mb * (u32)p.mb;
+  for (u32 pos = 0; pos < nPos; pos++)
+  {
+    const int nValid = wp.uniformN > 0 ? wp.uniformN : (nValidBlk ? (int)nValidBlk[pos] : -1);
+    for (int iD = 0; iD < p.nDepth; iD++)
+    {
+      BlkInfo b;
+      if (parseBlock<TBYTES>(blob, cur, blobEnd, p, nValid, maxCount, b) != 0) { raiseError(st, kFailed, pos); return; }
+      blockOff[(u64)pos * p.nDepth + iD] = cur;
+      cur += b.len;
+    }
+  }
+}
+
+template<int TBYTES>
+static void launchWalkT(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, DeviceStatus* st,
+                        hipStream_t stream)
+{
+  u32* needSerial = wb.chunkBase + (wp.nChunks + 1);    // one extra word behind the scan output
+  hipMemsetAsync(needSerial, 0, 4, stream);
+  // With position dependent block sizes (masks / partial edge blocks, uniformN == 0) the chunk walk
+  // cannot size raw blocks; it still resolves every blob without raw blocks -- the common case for
+  // lossy and integer data -- and otherwise flags the band for the sequential walk.
+  hipLaunchKernelGGL(k_walk_chunks<TBYTES>, dim3(wp.nChunks), dim3(64), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit);
+  hipLaunchKernelGGL(k_resolve_entries<TBYTES>, dim3(1), dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd,
+                     (const u32*)wb.chunkExit, wb.chunkEntry, needSerial);
+  const dim3 gridC((wp.nChunks + 255) / 256);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_emit<TBYTES, false>), gridC, dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd,
+                     (const u32*)wb.chunkEntry, wb.chunkCount, (const u32*)nullptr, (u32*)nullptr, (const u32*)needSerial, st);
+  launchExclusiveScan(wb.chunkCount, wb.chunkBase, wp.nChunks, wb.scratch, stream);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_emit<TBYTES, true>), gridC, dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd,
+                     (const u32*)wb.chunkEntry, wb.chunkCount, (const u32*)wb.chunkBase, wb.blockOff, (const u32*)needSerial, st);
+  hipLaunchKernelGGL(k_walk_serial<TBYTES>, dim3(1), dim3(64), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.nValidBlk,
+                     wb.blockOff, (const u32*)needSerial, st);
+}
+
+void launchWalk(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, DeviceStatus* st,
+                hipStream_t stream)
+{
+  switch (dtSize(p.dt))
+  {
+    case 1: launchWalkT<1>(p, wp, a, wb, st, stream); break;
+    case 2: launchWalkT<2>(p, wp, a, wb, st, stream); break;
+    case 4: launchWalkT<4>(p, wp, a, wb, st, stream); break;
+    default: launchWalkT<8>(p, wp, a, wb, st, stream); break;
+  }
+}
+
+}    // namespace lerc

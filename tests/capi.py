@@ -192,3 +192,8 @@ def oracle():
 
 def product():
     return _load("product", os.path.join(ROOT, "lerc_amd", "csrc", "liblerc_amd.so"))
+
+
+def sim():
+    """The product sources compiled for the CPU SIMT emulator (tools/hipsim) -- kernel-logic tests only."""
+    return _load("sim", os.path.join(ROOT, "tests", "_sim", "liblerc_amd_sim.so"))

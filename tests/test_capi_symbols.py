@@ -1,0 +1,70 @@
+"""The product library must build, load without a GPU, export every symbol include/lerc_amd.h declares
+and FAIL LOUDLY (status 1, no CPU fallback) when no HIP device exists."""
+import ctypes as ct
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import capi
+
+HDR = os.path.join(capi.ROOT, "include", "lerc_amd.h")
+LIB = os.path.join(capi.ROOT, "lerc_amd", "csrc", "liblerc_amd.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(LIB), "-j8"])
+    return ct.CDLL(LIB, mode=ct.RTLD_LOCAL)
+
+
+def declared_symbols():
+    txt = open(HDR).read()
+    return sorted(set(re.findall(r"LERC_AMD_API[^;]*?\b(lerc_\w+)\s*\(", txt, flags=re.S)))
+
+
+def test_header_declares_stock_api():
+    syms = declared_symbols()
+    stock = ["lerc_computeCompressedSize", "lerc_encode", "lerc_computeCompressedSizeForVersion", "lerc_encodeForVersion",
+             "lerc_getBlobInfo", "lerc_getDataRanges", "lerc_decode", "lerc_decodeToDouble", "lerc_computeCompressedSize_4D",
+             "lerc_encode_4D", "lerc_decode_4D", "lerc_decodeToDouble_4D"]
+    for s in stock:
+        assert s in syms
+    assert "lerc_amd_encode_device" in syms and "lerc_amd_decode_device" in syms
+
+
+def test_exports_every_declared_symbol(lib):
+    for s in declared_symbols():
+        assert hasattr(lib, s), s
+
+
+def test_header_only_queries_run_on_host(lib):
+    """lerc_getBlobInfo / lerc_getDataRanges never touch the device."""
+    blob = open(os.path.join(capi.ROOT, "tests", "golden", "california_400_400_1_float.lerc2"), "rb").read()
+    P = capi.product()
+    rc, info, rng = P.blob_info(blob)
+    assert rc == 0 and info == [3, 6, 1, 400, 400, 1, 58515, 176451, 1, 1, 0]
+    assert rng == [-82.97209167480469, 4080.61376953125, 7.5e-05]
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    P = capi.product()
+    a = np.arange(64, dtype=np.float32).reshape(8, 8)
+    rc, size = P.compute_size(a, 0.01)
+    assert rc == 1 and size == 0    # Failed, loudly (stderr), never a CPU result
+    lib.lerc_amd_create.restype = ct.c_void_p
+    assert not lib.lerc_amd_create(None)
+
+
+def test_product_does_not_link_oracle():
+    out = subprocess.check_output(["ldd", LIB]).decode()
+    assert "oracle" not in out and "LercRef" not in out
+    for f in os.listdir(os.path.dirname(LIB)):
+        if f.endswith((".cpp", ".hip", ".h")):
+            assert "oracle/" not in open(os.path.join(os.path.dirname(LIB), f)).read(), f

@@ -1,0 +1,74 @@
+"""CPU-only check of the REAL kernel sources: lerc_amd/csrc/*.hip compiled for the SIMT emulator in
+tools/hipsim (tests/_sim/liblerc_amd_sim.so) and driven through the same C ABI as the product.
+This is test infrastructure: it proves indexing / protocol logic of the kernels before GPU time is
+spent; the product library itself is only ever run on a GPU (tests marked `gpu`)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import capi
+import cases
+
+
+@pytest.fixture(scope="module")
+def libs():
+    csrc = os.path.join(capi.ROOT, "lerc_amd", "csrc")
+    subprocess.check_call(["make", "-s", "-C", csrc, "sim", "-j8"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(capi.ROOT, "oracle")])
+    return capi.oracle(), capi.sim()
+
+
+def _same(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+
+
+# cases the device path does not cover yet (tracked in DESIGN.md "not yet on the device")
+def _unsupported(name):
+    return "777" in name
+
+
+_CASES = [c for c in cases.basic_cases() if c[1].size <= 36000 and not _unsupported(c[0])]
+# keep the emulator run short: every 3rd plain terrain case, all special cases
+_CASES = [c for i, c in enumerate(_CASES) if not c[0].startswith("terrain") or i % 3 == 0]
+
+
+@pytest.mark.parametrize("idx", range(len(_CASES)), ids=[c[0] for c in _CASES])
+def test_sim_matches_oracle(libs, idx):
+    O, S = libs
+    name, arr, kw = _CASES[idx]
+    kw = dict(kw)
+    e = kw.pop("max_z_err")
+    assert S.compute_size(arr, e, **kw) == O.compute_size(arr, e, **kw)
+    r1, b1 = O.encode(arr, e, **kw)
+    r2, b2 = S.encode(arr, e, **kw)
+    assert r1 == r2
+    assert b1 == b2, "blob differs from the oracle"
+    if r1 == 0:
+        d1, d2 = O.decode(b1), S.decode(b1)
+        assert d1[0] == d2[0] == 0
+        assert _same(d1[1], d2[1]) and _same(d1[2], d2[2])
+        assert O.blob_info(b1) == S.blob_info(b1)
+
+
+def test_sim_decodes_reference_blobs(libs):
+    O, S = libs
+    d = os.path.join(capi.ROOT, "tests", "golden")
+    names = ["california_400_400_1_float.lerc2", "js_sanity_v5.lerc2"]
+    names += [os.path.join("blobs", f) for f in sorted(os.listdir(os.path.join(d, "blobs")))]
+    for f in names:
+        blob = open(os.path.join(d, f), "rb").read()
+        d1, d2 = O.decode(blob), S.decode(blob)
+        assert d1[0] == d2[0] == 0, f
+        assert _same(d1[1], d2[1]) and _same(d1[2], d2[2]), f
+
+
+def test_sim_rejects_corruption(libs):
+    O, S = libs
+    blob = bytearray(open(os.path.join(capi.ROOT, "tests", "golden", "blobs", "mixed-float32.lerc2"), "rb").read())
+    blob[len(blob) // 2] ^= 0x40
+    assert S.decode(bytes(blob))[0] == 1
+    assert S.decode(bytes(blob[:300]))[0] != 0
