@@ -1,0 +1,39 @@
+// huffman_dev.h -- types and launch wrappers shared by huffman_host.cpp and huffman_kernels.hip
+#pragma once
+#include "lerc_common.h"
+
+namespace lerc {
+
+struct HuffGeom { int nRows, nCols, nDepth; };
+
+static const int kHuffRun = 128;         // stream elements per encoder thread
+static const int kHuffSubBits = 2048;    // bits per speculative decode sub-sequence
+static const int kHuffLutBits = 12;      // Huffman.h:37 uses the same look-up width
+
+struct HuffDecodeTable
+{
+  u32 lut[1 << kHuffLutBits];    // (length << 16) | symbol for codes of <= 12 bits, 0xFFFFFFFF otherwise
+  int nLong;                     // codes longer than the LUT width, sorted by length
+  u32 longCode[256];
+  u8 longLen[256];
+  u16 longSym[256];
+};
+
+void launchHuffHisto(int dt, const void* data, const u8* maskBits, const HuffGeom& g, u32* histos /* 2 x 256, zeroed */, hipStream_t st);
+void launchHuffRunBits(int dt, const void* data, const u8* maskBits, const HuffGeom& g, int mode, const u64* codes, u32* runBits,
+                       hipStream_t st);
+void launchHuffPack(int dt, const void* data, const u8* maskBits, const HuffGeom& g, int mode, const u64* codes, const u64* runBase,
+                    u32* stream /* zeroed */, hipStream_t st);
+void launchScan64(const u32* in, u64* out /* n + 1 */, u32 n, u64* scratch /* n/256 + 2 */, hipStream_t st);
+
+void launchHuffInitStarts(u64* starts, u64* prevStarts, u32 nSub, hipStream_t st);
+void launchHuffSync(const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, const u64* starts,
+                    u64* prevStarts, u64* exits, u32* counts, u32* bad, hipStream_t st);
+void launchHuffChain(u32 nSub, u64* starts, const u64* exits, u32* changed, hipStream_t st);
+void launchValidIndex(const u8* maskBits, const u32* groupBase, i64 nPix, u32* validIdx, hipStream_t st);
+void launchHuffEmit(int dt, const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, const u64* starts,
+                    const u64* symBase, const HuffGeom& g, int mode, u64 nSymbols, u32 numValid, const u32* validIdx, void* out,
+                    hipStream_t st);
+void launchHuffUndelta(int dt, void* data, const u8* maskBits, const HuffGeom& g, hipStream_t st);
+
+}    // namespace lerc

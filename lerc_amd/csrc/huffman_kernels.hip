@@ -1,0 +1,411 @@
+// huffman_kernels.hip -- device side of the 8-bit Huffman image mode.
+//
+// Reference counterparts: Lerc2::ComputeHistoForHuffman (Lerc2.cpp:2311-2380), EncodeHuffman
+// (:2384-2468) with Huffman::PushValue (Huffman.h:218-255), DecodeHuffman (:2472-2606) with
+// Huffman::DecodeOneValue (Huffman.h:144-214).
+//
+// The pixel stream is one long bit string without sync markers.  Encode: every element of the
+// (virtual, mask-agnostic) stream order gets its code length, an exclusive scan over runs of elements
+// gives bit offsets, and each thread ORs its run's codes into the stream.  Decode: the stream is cut
+// into sub-sequences decoded speculatively in parallel; a sub-sequence's start is corrected to its
+// predecessor's exit until nothing changes (Huffman codes self-synchronise after a few symbols), then
+// symbols are written by rank and the delta predictor is undone with wave-level segmented scans.
+#include "huffman_dev.h"
+#include "wave_utils.h"
+
+namespace lerc {
+
+// index of the last valid pixel before k, or -1
+__device__ __forceinline__ i64 prevValidPixel(const u8* __restrict__ bits, i64 k)
+{
+  i64 j = k - 1;
+  while (j >= 0)
+  {
+    if ((j & 7) == 7 && bits[j >> 3] == 0) { j -= 8; continue; }
+    if (maskBit(bits, j)) return j;
+    j--;
+  }
+  return -1;
+}
+
+// Symbol of virtual stream element v (delta mode: plane major; plain mode: pixel major), or -1 when
+// the pixel is invalid.  T is signed char or unsigned char.
+template<class T>
+__device__ __forceinline__ int huffSymbol(const T* __restrict__ data, const u8* __restrict__ maskBits, const HuffGeom& g, int mode, i64 v)
+{
+  const int off = (DtOf<T>::v == DT_Char) ? 128 : 0;
+  if (mode == IEM_Huffman)
+  {
+    const i64 k = v / g.nDepth;
+    if (maskBits && !maskBit(maskBits, k)) return -1;
+    return off + (int)data[v];
+  }
+  const i64 nPix = (i64)g.nRows * g.nCols;
+  const int iD = (int)(v / nPix);
+  const i64 k = v - (i64)iD * nPix;
+  if (maskBits && !maskBit(maskBits, k)) return -1;
+  const int i = (int)(k / g.nCols), j = (int)(k - (i64)i * g.nCols);
+  const T val = data[k * g.nDepth + iD];
+  T pred = 0;
+  if (j > 0 && (!maskBits || maskBit(maskBits, k - 1))) pred = data[(k - 1) * g.nDepth + iD];
+  else if (i > 0 && (!maskBits || maskBit(maskBits, k - g.nCols))) pred = data[(k - g.nCols) * g.nDepth + iD];
+  else if (maskBits)
+  {
+    const i64 kp = prevValidPixel(maskBits, k);
+    if (kp >= 0) pred = data[kp * g.nDepth + iD];
+  }
+  const T delta = (T)(val - pred);
+  return off + (int)delta;
+}
+
+// ---- histograms ---------------------------------------------------------------------------------
+template<class T>
+__global__ void __launch_bounds__(256) k_huff_histo(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffGeom g, u32* __restrict__ histos)
+{
+  __shared__ u32 s_h[2][256];
+  s_h[0][threadIdx.x] = 0; s_h[1][threadIdx.x] = 0;
+  __syncthreads();
+  const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
+  const i64 stride = (i64)gridDim.x * 256;
+  for (i64 v = (i64)blockIdx.x * 256 + threadIdx.x; v < n; v += stride)
+  {
+    const int s0 = huffSymbol<T>(data, maskBits, g, IEM_Huffman, v);
+    if (s0 >= 0) atomicAdd(&s_h[0][s0], 1u);
+    const int s1 = huffSymbol<T>(data, maskBits, g, IEM_DeltaHuffman, v);
+    if (s1 >= 0) atomicAdd(&s_h[1][s1], 1u);
+  }
+  __syncthreads();
+  if (s_h[0][threadIdx.x]) atomicAdd(&histos[threadIdx.x], s_h[0][threadIdx.x]);
+  if (s_h[1][threadIdx.x]) atomicAdd(&histos[256 + threadIdx.x], s_h[1][threadIdx.x]);
+}
+
+void launchHuffHisto(int dt, const void* data, const u8* maskBits, const HuffGeom& g, u32* histos, hipStream_t st)
+{
+  const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
+  i64 nb = (n + 256 * 32 - 1) / (256 * 32);
+  nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+  if (dt == DT_Char) hipLaunchKernelGGL(k_huff_histo<signed char>, dim3((unsigned)nb), dim3(256), 0, st, (const signed char*)data, maskBits, g, histos);
+  else hipLaunchKernelGGL(k_huff_histo<unsigned char>, dim3((unsigned)nb), dim3(256), 0, st, (const unsigned char*)data, maskBits, g, histos);
+}
+
+// ---- encode -------------------------------------------------------------------------------------
+// codes[s] = (length << 32) | code bits
+template<class T, bool PACK>
+__global__ void __launch_bounds__(256)
+k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffGeom g, int mode, const u64* __restrict__ codes,
+              u32* __restrict__ runBits, const u64* __restrict__ runBase, u32* __restrict__ stream)
+{
+  __shared__ u64 s_codes[256];
+  s_codes[threadIdx.x] = codes[threadIdx.x];
+  __syncthreads();
+  const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
+  const i64 run = (i64)blockIdx.x * 256 + threadIdx.x;
+  const i64 v0 = run * kHuffRun;
+  if (v0 >= n) return;
+  const i64 v1 = (v0 + kHuffRun < n) ? v0 + kHuffRun : n;
+  if (!PACK)
+  {
+    u32 bits = 0;
+    for (i64 v = v0; v < v1; v++)
+    {
+      const int s = huffSymbol<T>(data, maskBits, g, mode, v);
+      if (s >= 0) bits += (u32)(s_codes[s] >> 32);
+    }
+    runBits[run] = bits;
+    return;
+  }
+  // MSB-first packing into little-endian u32 words (Huffman.h:218-255): keep a 64-bit window whose top
+  // bits are the oldest; flush whole words with atomicOr (neighbouring runs share boundary words)
+  u64 pos = runBase[run];
+  u64 w = pos >> 5;
+  int fill = (int)(pos & 31);    // bits already used in the current word (by the previous run)
+  u64 acc = 0;                   // bits of this run for the current word(s), left aligned at bit 63 - fill
+  int have = fill;
+  for (i64 v = v0; v < v1; v++)
+  {
+    const int s = huffSymbol<T>(data, maskBits, g, mode, v);
+    if (s < 0) continue;
+    const u64 c = s_codes[s];
+    const int len = (int)(c >> 32);
+    const u64 code = c & 0xFFFFFFFFull;
+    acc |= code << (64 - have - len);
+    have += len;
+    if (have >= 32)
+    {
+      atomicOr(&stream[w], (u32)(acc >> 32));
+      acc <<= 32;
+      have -= 32;
+      w++;
+    }
+  }
+  if (have > 0) atomicOr(&stream[w], (u32)(acc >> 32));
+  (void)fill;
+}
+
+void launchHuffRunBits(int dt, const void* data, const u8* maskBits, const HuffGeom& g, int mode, const u64* codes, u32* runBits,
+                       hipStream_t st)
+{
+  const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
+  const i64 nRuns = (n + kHuffRun - 1) / kHuffRun;
+  const dim3 grid((unsigned)((nRuns + 255) / 256)), block(256);
+  if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, false>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, runBits, (const u64*)nullptr, (u32*)nullptr);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, false>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, runBits, (const u64*)nullptr, (u32*)nullptr);
+}
+
+void launchHuffPack(int dt, const void* data, const u8* maskBits, const HuffGeom& g, int mode, const u64* codes, const u64* runBase,
+                    u32* stream, hipStream_t st)
+{
+  const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
+  const i64 nRuns = (n + kHuffRun - 1) / kHuffRun;
+  const dim3 grid((unsigned)((nRuns + 255) / 256)), block(256);
+  if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, true>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, true>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream);
+}
+
+// u32 -> u64 exclusive scan (bit offsets can exceed 2^32); out[n] = total
+__global__ void __launch_bounds__(256) k_scan64_local(const u32* __restrict__ in, u64* __restrict__ out, u32 n, u64* __restrict__ partial)
+{
+  __shared__ u64 s_w[4];
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  const u64 v = i < n ? in[i] : 0;
+  u64 inc = v;
+  const int lane = laneId();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const u64 t = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += t; }
+  if (lane == 63) s_w[waveId()] = inc;
+  __syncthreads();
+  u64 base = 0;
+  for (int k = 0; k < waveId(); k++) base += s_w[k];
+  if (i < n) out[i] = base + inc - v;
+  if (threadIdx.x == 255) partial[blockIdx.x] = base + inc;
+}
+
+__global__ void __launch_bounds__(64) k_scan64_partials(u64* __restrict__ partial, u32 nPartials, u64* __restrict__ totalOut)
+{
+  // one wave, sequential over chunks of 64 with a carry
+  u64 carry = 0;
+  const int lane = laneId();
+  for (u32 b = 0; b < nPartials; b += 64)
+  {
+    const u32 i = b + (u32)lane;
+    const u64 v = i < nPartials ? partial[i] : 0;
+    u64 inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u64 t = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += t; }
+    if (i < nPartials) partial[i] = carry + inc - v;
+    carry += __shfl(inc, 63);
+  }
+  if (lane == 0) *totalOut = carry;
+}
+
+__global__ void __launch_bounds__(256) k_scan64_add(u64* __restrict__ out, u32 n, const u64* __restrict__ partial)
+{
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) out[i] += partial[blockIdx.x];
+}
+
+void launchScan64(const u32* in, u64* out, u32 n, u64* scratch, hipStream_t st)
+{
+  if (n == 0) { hipMemsetAsync(out, 0, 8, st); return; }
+  const u32 nPart = (n + 255) / 256;
+  hipLaunchKernelGGL(k_scan64_local, dim3(nPart), dim3(256), 0, st, in, out, n, scratch);
+  hipLaunchKernelGGL(k_scan64_partials, dim3(1), dim3(64), 0, st, scratch, nPart, out + n);
+  hipLaunchKernelGGL(k_scan64_add, dim3(nPart), dim3(256), 0, st, out, n, (const u64*)scratch);
+}
+
+// ---- decode -------------------------------------------------------------------------------------
+// 32 stream bits starting at bit position p, MSB first (words beyond `nWords` read as zero)
+__device__ __forceinline__ u32 peek32(const u32* __restrict__ stream, u64 nWords, u64 p)
+{
+  const u64 w = p >> 5;
+  const int sh = (int)(p & 31);
+  const u32 w0 = w < nWords ? stream[w] : 0u;
+  const u32 w1 = (w + 1) < nWords ? stream[w + 1] : 0u;
+  return sh ? ((w0 << sh) | (w1 >> (32 - sh))) : w0;
+}
+
+// returns the code length (0 = no code matches), symbol in sym
+__device__ __forceinline__ int decodeOne(const HuffDecodeTable* __restrict__ t, u32 top, int& sym)
+{
+  const u32 e = t->lut[top >> (32 - kHuffLutBits)];
+  if (e != 0xFFFFFFFFu) { sym = (int)(e & 0xFFFFu); return (int)(e >> 16); }
+  for (int i = 0; i < t->nLong; i++)
+  {
+    const int len = t->longLen[i];
+    if ((top >> (32 - len)) == t->longCode[i]) { sym = t->longSym[i]; return len; }
+  }
+  return 0;
+}
+
+// one thread per sub-sequence of kHuffSubBits bits: decode from starts[t] up to the end of the
+// sub-sequence; exits[t] = first code word position at or beyond it, counts[t] = symbols decoded
+__global__ void __launch_bounds__(256)
+k_huff_sync(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const HuffDecodeTable* __restrict__ table, u32 nSub,
+            const u64* __restrict__ starts, u64* __restrict__ prevStarts, u64* __restrict__ exits, u32* __restrict__ counts,
+            u32* __restrict__ bad)
+{
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= nSub) return;
+  const u64 s = starts[t];
+  if (prevStarts[t] == s) return;    // unchanged since the last round
+  prevStarts[t] = s;
+  const u64 end = min((u64)(t + 1) * kHuffSubBits, streamBits);
+  u64 p = s;
+  u32 n = 0;
+  while (p < end)
+  {
+    int sym;
+    const int len = decodeOne(table, peek32(stream, nWords, p), sym);
+    if (len == 0) { atomicOr(bad, 1u); break; }
+    p += (u64)len;
+    n++;
+  }
+  exits[t] = p;
+  counts[t] = n;
+}
+
+__global__ void __launch_bounds__(256)
+k_huff_chain(u32 nSub, u64* __restrict__ starts, const u64* __restrict__ exits, u32* __restrict__ changed)
+{
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t + 1 >= nSub) return;
+  const u64 e = exits[t];
+  if (starts[t + 1] != e) { starts[t + 1] = e; atomicOr(changed, 1u); }
+}
+
+// pixel index of every valid pixel, in scan order (rank -> pixel)
+__global__ void __launch_bounds__(256) k_valid_index(const u8* __restrict__ maskBits, const u32* __restrict__ groupBase, i64 nPix, u32* __restrict__ validIdx)
+{
+  const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nPix || !maskBit(maskBits, k)) return;
+  u32 r = groupBase[k >> 5];
+  for (i64 j = (k >> 5) << 5; j < k; j++) r += maskBit(maskBits, j) ? 1u : 0u;
+  validIdx[r] = (u32)k;
+}
+
+void launchValidIndex(const u8* maskBits, const u32* groupBase, i64 nPix, u32* validIdx, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_valid_index, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, st, maskBits, groupBase, nPix, validIdx);
+}
+
+// second pass: write symbol r of the stream to its pixel (raw deltas in delta mode)
+template<class T>
+__global__ void __launch_bounds__(256)
+k_huff_emit(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const HuffDecodeTable* __restrict__ table, u32 nSub,
+            const u64* __restrict__ starts, const u64* __restrict__ symBase, HuffGeom g, int mode, u64 nSymbols, u32 numValid,
+            const u32* __restrict__ validIdx, T* __restrict__ out)
+{
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= nSub) return;
+  const int off = (DtOf<T>::v == DT_Char) ? 128 : 0;
+  const u64 end = min((u64)(t + 1) * kHuffSubBits, streamBits);
+  u64 p = starts[t];
+  u64 r = symBase[t];
+  while (p < end && r < nSymbols)
+  {
+    int sym;
+    const int len = decodeOne(table, peek32(stream, nWords, p), sym);
+    if (len == 0) break;
+    p += (u64)len;
+    i64 at;
+    if (mode == IEM_Huffman)
+    {
+      const u64 q = r / (u64)g.nDepth;
+      const i64 k = validIdx ? (i64)validIdx[q] : (i64)q;
+      at = k * g.nDepth + (i64)(r - q * (u64)g.nDepth);
+    }
+    else
+    {
+      const u64 iD = r / numValid, q = r - iD * numValid;
+      const i64 k = validIdx ? (i64)validIdx[q] : (i64)q;
+      at = k * g.nDepth + (i64)iD;
+    }
+    out[at] = (T)(sym - off);
+    r++;
+  }
+}
+
+// Undo of the delta predictor (Lerc2.cpp:2499-2524 / :2555-2583): one wave per depth plane walks the
+// plane in scan order 64 pixels at a time.  A valid pixel continues from the nearest valid pixel
+// before it (left neighbour, or the "previous value" rule) unless its left neighbour is missing and
+// the pixel above is valid, in which case it restarts from the pixel above.
+template<class T>
+__global__ void __launch_bounds__(64) k_huff_undelta(T* __restrict__ data, const u8* __restrict__ maskBits, HuffGeom g)
+{
+  const int iD = (int)blockIdx.x;
+  const int lane = laneId();
+  const u64 le = laneMaskLt() | (1ull << lane);
+  u32 carry = 0;    // value of the last valid pixel so far (prevVal starts at 0)
+  // row by row, so that a pixel and the pixel above it never share a 64-lane chunk
+  for (int i = 0; i < g.nRows; i++)
+    for (int j0 = 0; j0 < g.nCols; j0 += 64)
+    {
+      const int j = j0 + lane;
+      const bool inb = j < g.nCols;
+      const i64 k = (i64)i * g.nCols + j;
+      const bool valid = inb && (!maskBits || maskBit(maskBits, k));
+      const bool leftOk = valid && j > 0 && (!maskBits || maskBit(maskBits, k - 1));
+      const bool fromAbove = valid && !leftOk && i > 0 && (!maskBits || maskBit(maskBits, k - g.nCols));
+      const u32 d = valid ? (u32)(u8)data[k * g.nDepth + iD] : 0u;
+      const u32 above = fromAbove ? (u32)(u8)data[(k - g.nCols) * g.nDepth + iD] : 0u;
+      // inclusive prefix sum of the deltas over the lanes
+      u32 s = d;
+#pragma unroll
+      for (int dd = 1; dd < 64; dd <<= 1) { const u32 tt = __shfl_up(s, (unsigned)dd); if (lane >= dd) s += tt; }
+      const u64 heads = __ballot(fromAbove);
+      const u64 mine = heads & le;
+      const int h = mine ? 63 - __clzll((long long)mine) : 0;
+      const u32 sH = __shfl(s, h), dH = __shfl(d, h), aH = __shfl(above, h);
+      u32 val = mine ? (aH + s - (sH - dH)) : (carry + s);
+      val &= 0xFFu;
+      if (valid) data[k * g.nDepth + iD] = (T)(u8)val;
+      const u64 vmask = __ballot(valid);
+      if (vmask)
+      {
+        const int last = 63 - __clzll((long long)vmask);
+        carry = __shfl(val, last);
+      }
+    }
+}
+
+void launchHuffUndelta(int dt, void* data, const u8* maskBits, const HuffGeom& g, hipStream_t st)
+{
+  if (dt == DT_Char) hipLaunchKernelGGL(k_huff_undelta<signed char>, dim3(g.nDepth), dim3(64), 0, st, (signed char*)data, maskBits, g);
+  else hipLaunchKernelGGL(k_huff_undelta<unsigned char>, dim3(g.nDepth), dim3(64), 0, st, (unsigned char*)data, maskBits, g);
+}
+
+void launchHuffSync(const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, const u64* starts,
+                    u64* prevStarts, u64* exits, u32* counts, u32* bad, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_huff_sync, dim3((nSub + 255) / 256), dim3(256), 0, st, stream, nWords, streamBits, table, nSub, starts, prevStarts,
+                     exits, counts, bad);
+}
+
+void launchHuffChain(u32 nSub, u64* starts, const u64* exits, u32* changed, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_huff_chain, dim3((nSub + 255) / 256), dim3(256), 0, st, nSub, starts, exits, changed);
+}
+
+void launchHuffEmit(int dt, const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, const u64* starts,
+                    const u64* symBase, const HuffGeom& g, int mode, u64 nSymbols, u32 numValid, const u32* validIdx, void* out,
+                    hipStream_t st)
+{
+  const dim3 grid((nSub + 255) / 256), block(256);
+  if (dt == DT_Char) hipLaunchKernelGGL(k_huff_emit<signed char>, grid, block, 0, st, stream, nWords, streamBits, table, nSub, starts, symBase, g, mode, nSymbols, numValid, validIdx, (signed char*)out);
+  else hipLaunchKernelGGL(k_huff_emit<unsigned char>, grid, block, 0, st, stream, nWords, streamBits, table, nSub, starts, symBase, g, mode, nSymbols, numValid, validIdx, (unsigned char*)out);
+}
+
+__global__ void __launch_bounds__(256) k_init_starts(u64* __restrict__ starts, u64* __restrict__ prevStarts, u32 nSub)
+{
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= nSub) return;
+  starts[t] = (u64)t * kHuffSubBits;
+  prevStarts[t] = ~0ull;
+}
+
+void launchHuffInitStarts(u64* starts, u64* prevStarts, u32 nSub, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_init_starts, dim3((nSub + 255) / 256), dim3(256), 0, st, starts, prevStarts, nSub);
+}
+
+}    // namespace lerc

@@ -163,7 +163,7 @@ def test_against_real_reference_fuzz(P):
 def _device_roundtrip(x, max_z_err):
     import torch
     from lerc_amd import api
-    codec = api.DeviceCodec()
+    codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)    # same stream as the tensor producers
     out = torch.empty(x.numel() * x.element_size() + (1 << 20), dtype=torch.uint8, device=x.device)
     y = torch.empty_like(x)
     rc, nb = api.encode_device(codec, x, max_z_err, out)
