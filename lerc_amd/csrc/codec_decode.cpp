@@ -5,8 +5,10 @@
 // only sequential piece), everything that touches pixels or the block stream is a HIP kernel.
 #include "codec.h"
 #include "huffman.h"
+#include "tile_fast.h"
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 
 namespace lerc {
@@ -35,12 +37,15 @@ struct BandDesc
   Header hd;
   size_t hdrLen = 0;
   int numBytesMask = 0;
+  u8 head[128];          // first bytes of the band (header, and for unmasked bands ranges + mode bytes)
+  size_t headLen = 0;
 };
 
 bool readBandHeader(const BlobReader& rd, u64 off, BandDesc& b)
 {
-  u8 buf[128];
-  const size_t want = std::min<size_t>(sizeof(buf), rd.n - off);
+  u8* buf = b.head;
+  const size_t want = std::min<size_t>(sizeof(b.head), rd.n - off);
+  b.headLen = want;
   if (off >= rd.n || !rd.read(off, want, buf)) return false;
   if (!readHeader(buf, want, b.hd, b.hdrLen)) return false;
   if (want < b.hdrLen + 4) return false;
@@ -52,8 +57,9 @@ bool readBandHeader(const BlobReader& rd, u64 off, BandDesc& b)
 
 }    // namespace
 
-u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
+static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, bool& fellBack)
 {
+  fellBack = false;
   hipStream_t st = ctx.activeStream();
   const int dt = rq.dt, nD = rq.nDepth, nCols = rq.nCols, nRows = rq.nRows;
   const int tb = dtSize(dt);
@@ -111,7 +117,8 @@ u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
     maxSub = std::max(maxSub, sub);
     maxChunks = std::max(maxChunks, (size_t)h.blobSize / 4096 + 2);
   }
-  need += maxSub * 4 + maxSub / nD * 2 + 5 * (maxChunks + 1024) * 4 + huffmanScratchBytes(nPix, nD);
+  need += maxSub * 4 + maxSub / nD * 2 + 5 * (maxChunks + 1024) * 4 + (dt <= DT_Byte ? huffmanScratchBytes(nPix, nD) : 0);
+  need += (maxChunks + 16) * (size_t)kFastWindow(8) * 2 + (size_t)(nPix / 4096 + 64) * 16 + 4096;    // streaming path tables
   if (!ctx.reserve(need)) return kFailed;
 
   const u8* dBlob = rq.dBlob;
@@ -135,6 +142,9 @@ u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
   std::vector<u32> expectChecksum(rq.nBands, 0);
   std::vector<u32> checksumLen(rq.nBands, 0);
   std::vector<u8> small;
+  // bands decoded by the streaming kernels: their checksum comes out of the decode kernel itself
+  struct FastBand { bool used = false; u64* dFletcher2 = nullptr; u32* dFallback = nullptr; u64 prefixA = 0, prefixB = 0; };
+  std::vector<FastBand> fast(rq.nBands);
 
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
@@ -146,10 +156,32 @@ u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
     const u32 blobEnd = (u32)hd.blobSize;
     u8* dOutBand = (u8*)rq.dOut + (size_t)iBand * nPix * nD * tb;
 
+    // Can the streaming kernels take this band?  (unmasked, nDepth 1, 8 x 8 tiling mode, friendly dimensions;
+    // for such bands the ranges and mode bytes sit inside the header bytes we already hold)
+    u32 fastDataBegin = 0;
+    bool fastBand = false;
+    if (allowFast && bd.numBytesMask == 0 && hd.numValid == (int)nPix && hd.zMin != hd.zMax && hd.version >= 3
+      && fastDecodeEligible(dt, hd.version, hd.mbSize, nRows, nCols, nD, true)
+      && ((uintptr_t)dBand & 15) == 0 && ((uintptr_t)dOutBand & 15) == 0)
+    {
+      size_t at0 = bd.hdrLen + 4;
+      bool rangesDiffer = true;
+      if (hd.version >= 4)
+      {
+        if (at0 + 2 * (size_t)tb < bd.headLen) rangesDiffer = memcmp(bd.head + at0, bd.head + at0 + tb, tb) != 0;
+        at0 += 2 * (size_t)tb;
+      }
+      if (rangesDiffer && at0 < bd.headLen && bd.head[at0] == 0 && at0 + 1 < (size_t)hd.blobSize)
+      {
+        fastBand = true;
+        fastDataBegin = (u32)(at0 + 1);
+      }
+    }
+
     if (hd.version >= 3)
     {
       if (hd.blobSize < 14) return kFailed;
-      { ProfScope ps(ctx, "fletcher_dec"); launchFletcher(dBand + 14, blobEnd - 14, dFl + (size_t)iBand * kFletcherPartials, st); }
+      if (!fastBand) { ProfScope ps(ctx, "fletcher_dec"); launchFletcher(dBand + 14, blobEnd - 14, dFl + (size_t)iBand * kFletcherPartials, st); }
       expectChecksum[iBand] = hd.checksum;
       checksumLen[iBand] = blobEnd - 14;
     }
@@ -268,6 +300,45 @@ u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
     hipMemcpyAsync(dZMax, zMaxVec.data(), (size_t)nD * 8, hipMemcpyHostToDevice, st);
     hipStreamSynchronize(st);    // zMaxVec is a per-band temporary
 
+    if (fastBand && fastDataBegin == (u32)(at - bd.offset))
+    {
+      const FastWalkPlan fwp = makeFastWalkPlan(nRows, nCols, fastDataBegin, blobEnd);
+      const u32 nWG = fastEncodeNumWG(nRows, nCols);
+      FastDecodeBuffers fbuf;
+      fbuf.chunkExit = ctx.allocT<u32>(fwp.nChunks + 4);
+      fbuf.countAt = ctx.allocT<u16>((size_t)fwp.nChunks * kFastWindow(tb) + 8);
+      fbuf.chunkEntry = ctx.allocT<u32>(fwp.nChunks + 4);
+      fbuf.chunkCount = ctx.allocT<u32>(fwp.nChunks + 4);
+      fbuf.chunkBase = ctx.allocT<u32>(fwp.nChunks + 4);
+      fbuf.blockOff = ctx.allocT<u32>((size_t)fwp.nBlocks + 4);
+      fbuf.wgFletcher = ctx.allocT<u64>((size_t)2 * nWG);
+      fbuf.fletcherOut = ctx.allocT<u64>(2);
+      fbuf.scanScratch = ctx.allocT<u32>(fwp.nChunks / 1024 + 8);
+      fbuf.fallback = ctx.allocT<u32>(4);
+      if (!fbuf.chunkExit || !fbuf.countAt || !fbuf.chunkEntry || !fbuf.chunkCount || !fbuf.chunkBase || !fbuf.blockOff
+        || !fbuf.wgFletcher || !fbuf.fletcherOut || !fbuf.scanScratch || !fbuf.fallback) return kFailed;
+      hipMemsetAsync(fbuf.fallback, 0, 16, st);
+      static const char* kStage[4] = { "fast_walk", "fast_resolve_scan", "fast_emit_offsets", "fast_decode" };
+      for (int stage = 0; stage < 4; stage++)
+      {
+        ProfScope ps(ctx, kStage[stage]);
+        launchFastDecode(stage, bp, fwp, dBand, fastDataBegin, blobEnd, fbuf, dOutBand, dStatus, st);
+      }
+      FastBand& f = fast[iBand];
+      f.used = true; f.dFletcher2 = fbuf.fletcherOut; f.dFallback = fbuf.fallback;
+      for (u32 pos = 0; pos + 14 < fastDataBegin; pos++)    // Fletcher terms of the bytes before the first block
+      {
+        const u32 cw = (u32)bd.head[14 + pos] << ((pos & 1u) ? 0 : 8);
+        f.prefixA += cw; f.prefixB += (u64)(pos >> 1) * cw;
+      }
+      continue;
+    }
+    if (fastBand)    // launched without its checksum kernel, but did not qualify after all
+    {
+      ProfScope ps(ctx, "fletcher_dec");
+      launchFletcher(dBand + 14, blobEnd - 14, dFl + (size_t)iBand * kFletcherPartials, st);
+    }
+
     DecodeArgs da;
     da.blob = dBand; da.dataBegin = (u32)(at - bd.offset); da.blobEnd = blobEnd;
     da.maskBits = dMask; da.zMaxVec = dZMax; da.out = dOutBand;
@@ -298,17 +369,41 @@ u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
   std::vector<u64> hFl((size_t)kFletcherPartials * rq.nBands);
   hipMemcpyAsync(&hs, dStatus, sizeof(hs), hipMemcpyDeviceToHost, st);
   hipMemcpyAsync(hFl.data(), dFl, hFl.size() * 8, hipMemcpyDeviceToHost, st);
+  std::vector<u64> hFast((size_t)2 * rq.nBands, 0);
+  std::vector<u32> hFallback(rq.nBands, 0);
+  for (int iBand = 0; iBand < rq.nBands; iBand++)
+    if (fast[iBand].used)
+    {
+      hipMemcpyAsync(&hFast[(size_t)2 * iBand], fast[iBand].dFletcher2, 16, hipMemcpyDeviceToHost, st);
+      hipMemcpyAsync(&hFallback[iBand], fast[iBand].dFallback, 4, hipMemcpyDeviceToHost, st);
+    }
   if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
   if (ctx.profOn()) ctx.profCollect();
   for (int iBand = 0; iBand < rq.nBands; iBand++)
+    if (fast[iBand].used && hFallback[iBand]) { fellBack = true; return kOk; }    // caller repeats with the general kernels
+  for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
     if (bands[iBand].hd.version < 3) continue;
+    if (fast[iBand].used)
+    {
+      const u64 A = hFast[(size_t)2 * iBand] + fast[iBand].prefixA, B = hFast[(size_t)2 * iBand + 1] + fast[iBand].prefixB;
+      if (fletcherFinish(A, B, checksumLen[iBand]) != expectChecksum[iBand]) return kFailed;
+      continue;
+    }
     u64 A = 0, B = 0;
     for (int i = 0; i < kFletcherPartials; i += 2) { A += hFl[(size_t)iBand * kFletcherPartials + i]; B += hFl[(size_t)iBand * kFletcherPartials + i + 1]; }
     if (fletcherFinish(A, B, checksumLen[iBand]) != expectChecksum[iBand]) return kFailed;
   }
   if (hs.error) { ctx.lastError = "device kernel reported an error"; return hs.error; }
   return kOk;
+}
+
+u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
+{
+  bool fellBack = false;
+  u32 rc = decodeImpl(ctx, rq, true, fellBack);
+  if (rc == kOk && fellBack) rc = decodeImpl(ctx, rq, false, fellBack);
+  return rc;
 }
 
 }    // namespace lerc

@@ -5,9 +5,11 @@
 // order).  Every sweep over pixels is a HIP kernel; the host only sees a few scalars per band.
 #include "codec.h"
 #include "huffman.h"
+#include "tile_fast.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 
 namespace lerc {
@@ -381,9 +383,76 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   const size_t nPos8 = (size_t)((rq.nRows + 7) / 8) * ((rq.nCols + 7) / 8);
   // workspace: two bit masks, block sizes + offsets + scan scratch, one-sweep ranks, Huffman scratch, small stuff
   size_t need = 2 * maskBytes + 3 * (nPos8 + 1024) * 4 + 3 * ((size_t)(nPix >> 5) + 1024) * 4
-    + huffmanScratchBytes(nPix, rq.nDepth) + (size_t)rq.nDepth * 16 + (1u << 16);
+    + (rq.dt <= DT_Byte ? huffmanScratchBytes(nPix, rq.nDepth) : 0) + (size_t)rq.nDepth * 16 + (1u << 16);
+  const bool fastOk = rq.nBands == 1 && rq.dOut && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
+    && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, rq.nDepth, rq.nMasks > 0, rq.maxZErr);
+  const u32 nWG = fastOk ? fastEncodeNumWG(rq.nRows, rq.nCols) : 0;
+  need += (size_t)nWG * 48 + 8192;
   if (!ctx.reserve(need)) return kFailed;
   (void)tb;
+
+  // ---- streaming path: everything is decided on the device, one synchronisation at the end.  If an
+  // assumption fails (NaN, all-integer floats, raisable error bound, constant image, 16 x 16 retry,
+  // raw fallback) the device says so and the general path below redoes the band.
+  if (fastOk)
+  {
+    hipStream_t st = ctx.activeStream();
+    const bool isFlt = rq.dt >= DT_Float;
+    FastEncodeBuffers fb;
+    fb.wgSize = ctx.allocT<u32>(nWG + 4);
+    fb.wgBase = ctx.allocT<u32>(nWG + 4);
+    fb.wgMinKey = ctx.allocT<u64>(nWG);
+    fb.wgMaxKey = ctx.allocT<u64>(nWG);
+    fb.wgFlags = ctx.allocT<u32>(nWG);
+    fb.wgFletcher = ctx.allocT<u64>((size_t)2 * nWG);
+    fb.scanScratch = ctx.allocT<u32>(nWG / 1024 + 8);
+    fb.result = ctx.allocT<FastEncodeResult>(1);
+    BandStats* dRow0 = ctx.allocT<BandStats>(1);
+    u64* dKeys = ctx.allocT<u64>(2);
+    if (!fb.wgSize || !fb.wgBase || !fb.wgMinKey || !fb.wgMaxKey || !fb.wgFlags || !fb.wgFletcher || !fb.scanScratch || !fb.result || !dRow0 || !dKeys)
+      return kFailed;
+    u32 cand = 0;
+    fb.row0RaiseErr = nullptr;
+    if (isFlt)
+    {
+      static const double errCand[9] = { 1, 0.5, 0.1, 0.05, 0.01, 0.005, 0.001, 0.0005, 0.0001 };
+      for (int c = 0; c < 9; c++) if (errCand[c] / 2 > rq.maxZErr) cand |= 1u << c;
+      if (cand)
+      {
+        hipMemsetAsync(dRow0, 0, sizeof(BandStats), st);
+        ProfScope ps(ctx, "band_stats_row0");
+        launchBandStats(rq.dt, rq.dData, nullptr, 1, rq.nCols, 1, cand, dKeys, dKeys + 1, dRow0, st);
+        fb.row0RaiseErr = dRow0->raiseErr;
+      }
+    }
+    BandParams bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.nRows = rq.nRows; bp.nCols = rq.nCols; bp.nDepth = 1; bp.dt = rq.dt; bp.version = kCodecVersion;
+    bp.mb = 8; bp.nTV = rq.nRows / 8; bp.nTH = rq.nCols / 8;
+    bp.allValid = 1;
+    bp.maxQ = maxValToQuantize(rq.dt);
+    bp.maxZErr = isFlt ? rq.maxZErr : std::max(0.5, floor(rq.maxZErr));
+    bp.scale = 1 / (2 * bp.maxZErr);
+    bp.invScale = 2 * bp.maxZErr;
+    bp.intLossless = (!isFlt && bp.maxZErr == 0.5) ? 1 : 0;
+    static const char* kStage[4] = { "fast_stats_sizes", "fast_scan_decide", "fast_pack", "fast_checksum" };
+    for (int stage = 0; stage < 4; stage++)
+    {
+      ProfScope ps(ctx, kStage[stage]);
+      launchFastEncode(stage, bp, rq.maxZErr, cand, rq.dData, rq.dOut, rq.outCapacity, fb, st);
+    }
+    FastEncodeResult hres;
+    hipMemcpyAsync(&hres, fb.result, sizeof(hres), hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
+    if (ctx.profOn()) ctx.profCollect();
+    if (!hres.redo)
+    {
+      numBytesNeeded = numBytesWritten = hres.blobSize;
+      return kOk;
+    }
+    if (hres.redoReason == 64u && hres.blobSize > rq.outCapacity) return kBufferTooSmall;
+    ctx.reset();
+  }
 
   MaskState ms;
   ms.dBits = ctx.allocT<u8>(maskBytes);

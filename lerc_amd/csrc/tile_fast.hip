@@ -1,0 +1,594 @@
+// tile_fast.hip -- streaming encoder kernels for the common case (see tile_fast.h for the conditions).
+//
+// Same arithmetic and the same bytes as the general wave-per-block kernel in tile_encode.hip, arranged
+// for HBM bandwidth instead of generality:
+//   * a lane owns V consecutive pixels of one raster row (one 16-byte global load); 8 / V lanes form a
+//     block row, 64 / V lanes an 8 x 8 block, so a wave64 covers 8 raster rows x 128 bytes -- whole
+//     cache lines per row -- and holds V blocks' worth of work in registers, no LDS staging of input
+//   * block statistics are butterfly reductions over the lanes of a block (xor 1/2 and 8/16/32)
+//   * a workgroup owns 64 consecutive blocks of a block row = one contiguous span of the output
+//     stream: it assembles the span in LDS with ds_or_b32 and flushes it with 16-byte stores
+//   * pass 1 (k_fast_stats) fuses the global statistics of Lerc::FilterNoDataAndNaN /
+//     Lerc2::ComputeMinMaxRanges with the size-only dry run of Lerc2::WriteTiles; pass 2
+//     (k_fast_pack) fuses the real write with the Fletcher32 sums of the bytes it stores
+//   * every decision the reference takes between its sweeps is taken by a one-workgroup kernel on the
+//     device (k_fast_decide), so an encode costs one host synchronisation
+// Reference: Lerc2.cpp:1474-1668, :1717-1799, :1949-2021; Lerc2.h:337-453; BitStuffer2.cpp:35-153.
+#include "tile_fast.h"
+#include "kernels.h"
+#include "wave_utils.h"
+#include "block_plan.h"
+
+namespace lerc {
+
+enum FastRedo : u32
+{
+  kRedoNaN = 1, kRedoAllInt = 2, kRedoRaise = 4, kRedoConst = 8, kRedoMb16 = 16, kRedoOneSweep = 32, kRedoCapacity = 64
+};
+
+template<class T> struct FastCfg
+{
+  static constexpr int V = (sizeof(T) >= 4) ? 16 / (int)sizeof(T) : 8;    // pixels per lane: f32 4, f64 2, 16-bit 8, 8-bit 8
+  static constexpr int LPR = 8 / V;                                      // lanes per block row
+  static constexpr int BPW = 8 / LPR;                                    // blocks per wave tile
+  static constexpr int TILE_COLS = 8 * V;                                // raster columns per wave tile
+  static constexpr int IT = kFastBlocksPerWG / (4 * BPW);                // wave tiles per wave
+};
+
+// butterfly reductions over the lanes of one block
+template<int LPR, class X> __device__ __forceinline__ X groupMin(X v)
+{
+  if (LPR > 1) { X o = __shfl_xor(v, 1); v = o < v ? o : v; }
+  if (LPR > 2) { X o = __shfl_xor(v, 2); v = o < v ? o : v; }
+#pragma unroll
+  for (int m = 8; m < 64; m <<= 1) { X o = __shfl_xor(v, m); v = o < v ? o : v; }
+  return v;
+}
+template<int LPR, class X> __device__ __forceinline__ X groupMax(X v)
+{
+  if (LPR > 1) { X o = __shfl_xor(v, 1); v = o > v ? o : v; }
+  if (LPR > 2) { X o = __shfl_xor(v, 2); v = o > v ? o : v; }
+#pragma unroll
+  for (int m = 8; m < 64; m <<= 1) { X o = __shfl_xor(v, m); v = o > v ? o : v; }
+  return v;
+}
+template<int LPR> __device__ __forceinline__ int groupSum(int v)
+{
+  if (LPR > 1) v += __shfl_xor(v, 1);
+  if (LPR > 2) v += __shfl_xor(v, 2);
+#pragma unroll
+  for (int m = 8; m < 64; m <<= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+template<class T> __device__ __forceinline__ T shflT(T v, int src) { return (T)__shfl((typename ShflT<T>::type)v, src); }
+template<class T> __device__ __forceinline__ T gMinT(T v);
+
+template<class T> __device__ __forceinline__ bool notIntegral(T) { return false; }
+template<> __device__ __forceinline__ bool notIntegral<float>(float v) { return !(v == truncf(v)); }    // == !IsInt (Lerc.h:271) for finite v
+template<> __device__ __forceinline__ bool notIntegral<double>(double v) { return !(v == trunc(v)); }
+template<class T> __device__ __forceinline__ bool isNaNv(T) { return false; }
+template<> __device__ __forceinline__ bool isNaNv<float>(float v) { return v != v; }
+template<> __device__ __forceinline__ bool isNaNv<double>(double v) { return v != v; }
+
+template<class T> struct FBlock
+{
+  Plan pl;
+  T mn, mx;
+  u32 qMax;
+  bool quantOk;
+};
+
+// loads the V pixels of this lane (one aligned vector load)
+template<class T, int V>
+__device__ __forceinline__ void loadLane(const T* __restrict__ p, T (&v)[V])
+{
+  struct alignas(sizeof(T) * V) Vec { T e[V]; };
+  const Vec x = *reinterpret_cast<const Vec*>(p);
+#pragma unroll
+  for (int k = 0; k < V; k++) v[k] = x.e[k];
+}
+
+template<class T, int V>
+__device__ __forceinline__ void quantizeLane(const BandParams& p, const T (&v)[V], T mn, u32 (&q)[V])
+{
+  const double z0 = (double)mn;
+#pragma unroll
+  for (int k = 0; k < V; k++)
+    q[k] = p.intLossless ? quantLossless<T>(v[k], mn) : (u32)(((double)v[k] - z0) * p.scale + 0.5);
+}
+
+// number of distinct quantised values in each block of the wave (only meaningful where `need`)
+template<int LPR, int V>
+__device__ __forceinline__ u32 groupDistinct(const u32 (&q)[V], bool need)
+{
+  u32 count = 0, last = 0;
+  bool active = need;
+  for (;;)
+  {
+    u32 m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < V; k++)
+      if ((count == 0 || q[k] > last) && q[k] < m) m = q[k];
+    m = groupMin<LPR>(m);
+    if (m == 0xFFFFFFFFu) active = false;
+    if (!__any(active)) break;
+    if (active) { last = m; count++; }
+  }
+  return count;
+}
+
+// statistics + encoding decision of the block this lane belongs to (GetValidDataAndStats + NumBytesTile)
+template<class T, int V, int LPR>
+__device__ __forceinline__ FBlock<T> analyzeBlock(const BandParams& p, const T (&v)[V], int r, int h, int lane)
+{
+  FBlock<T> fb;
+  T mn = v[0], mx = v[0];
+#pragma unroll
+  for (int k = 1; k < V; k++) { mn = v[k] < mn ? v[k] : mn; mx = v[k] > mx ? v[k] : mx; }
+  typedef typename ShflT<T>::type ST;
+  mn = (T)groupMin<LPR>((ST)mn);
+  mx = (T)groupMax<LPR>((ST)mx);
+  // "same as previous" count in row-major block order, prevVal starts at 0 (Lerc2.cpp:1729-1758)
+  const int src = (h > 0) ? lane - 1 : lane - 8 + (LPR - 1);
+  T prev = shflT<T>(v[V - 1], src & 63);
+  if (r == 0 && h == 0) prev = T(0);
+  int same = (v[0] == prev) ? 1 : 0;
+#pragma unroll
+  for (int k = 1; k < V; k++) same += (v[k] == v[k - 1]) ? 1 : 0;
+  same = groupSum<LPR>(same);
+  const bool tryLut = ((double)mx > (double)mn + 3 * p.maxZErr) && (2 * same > 64);
+
+  double mv = 0;
+  bool quantOk = false;
+  if (p.maxZErr > 0)
+  {
+    mv = ((double)mx - (double)mn) * p.scale;
+    quantOk = !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
+  }
+  u32 qMax = quantOk ? (u32)(mv + 0.5) : 0u;    // == the largest quantised element (same expression as Quantize)
+  u32 nDistinct = 0;
+  const bool needLut = tryLut && quantOk;
+  if (__any(needLut))
+  {
+    u32 q[V];
+    quantizeLane<T, V>(p, v, mn, q);
+    nDistinct = groupDistinct<LPR, V>(q, needLut);
+  }
+  fb.pl = planBlock<T>(p, 64, mn, mx, p.dt, tryLut, mv, qMax, nDistinct);
+  fb.mn = mn; fb.mx = mx; fb.qMax = qMax; fb.quantOk = quantOk;
+  return fb;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 1: global statistics + block sizes
+// ------------------------------------------------------------------------------------------------
+template<class T> struct FKey;
+template<> struct FKey<float> { static __device__ u64 enc(float v) { u32 b; memcpy(&b, &v, 4); b = (b & 0x80000000u) ? ~b : (b | 0x80000000u); return b; } };
+template<> struct FKey<double> { static __device__ u64 enc(double v) { u64 b; memcpy(&b, &v, 8); return (b >> 63) ? ~b : (b | (1ull << 63)); } };
+template<> struct FKey<int> { static __device__ u64 enc(int v) { return (u64)((i64)v + (1ll << 62)); } };
+template<> struct FKey<unsigned int> { static __device__ u64 enc(unsigned int v) { return (u64)v + (1ull << 62); } };
+template<> struct FKey<short> { static __device__ u64 enc(short v) { return (u64)((i64)v + (1ll << 62)); } };
+template<> struct FKey<unsigned short> { static __device__ u64 enc(unsigned short v) { return (u64)v + (1ull << 62); } };
+template<> struct FKey<signed char> { static __device__ u64 enc(signed char v) { return (u64)((i64)v + (1ll << 62)); } };
+template<> struct FKey<unsigned char> { static __device__ u64 enc(unsigned char v) { return (u64)v + (1ull << 62); } };
+
+template<class T>
+__global__ void __launch_bounds__(256)
+k_fast_stats(const T* __restrict__ data, BandParams p, u32* __restrict__ wgSize, u64* __restrict__ wgMinKey, u64* __restrict__ wgMaxKey,
+             u32* __restrict__ wgFlags)
+{
+  typedef FastCfg<T> C;
+  constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
+  __shared__ u32 s_sz[4];
+  __shared__ u64 s_mn[4], s_mx[4];
+  __shared__ u32 s_fl[4];
+  const int w = waveId(), lane = laneId();
+  const int r = lane >> 3, c = lane & 7, h = c % LPR;
+  const int wgPerRow = p.nCols / (kFastBlocksPerWG * 8);
+  const int it = (int)blockIdx.x / wgPerRow, wgc = (int)blockIdx.x - it * wgPerRow;
+  const i64 rowBase = (i64)(it * 8 + r) * p.nCols + (i64)wgc * (kFastBlocksPerWG * 8);
+
+  u32 bytes = 0, flags = 0;
+  u64 kMin = ~0ull, kMax = 0ull;
+#pragma unroll
+  for (int t = 0; t < C::IT; t++)
+  {
+    const int tile = t * 4 + w;
+    T v[V];
+    loadLane<T, V>(data + rowBase + tile * C::TILE_COLS + c * V, v);
+    if (DtOf<T>::v >= DT_Float)
+    {
+#pragma unroll
+      for (int k = 0; k < V; k++) { if (isNaNv(v[k])) flags |= 1u; if (notIntegral(v[k])) flags |= 2u; }
+    }
+    const FBlock<T> fb = analyzeBlock<T, V, LPR>(p, v, r, h, lane);
+    if (r == 0 && h == 0) bytes += (u32)fb.pl.nBytes;    // one lane per block contributes
+    const u64 a = FKey<T>::enc(fb.mn), b = FKey<T>::enc(fb.mx);
+    kMin = a < kMin ? a : kMin;
+    kMax = b > kMax ? b : kMax;
+  }
+  bytes = waveSum(bytes);
+  kMin = waveMin(kMin); kMax = waveMax(kMax);
+  const bool f1 = __any(flags & 1u), f2 = __any(flags & 2u);
+  if (lane == 0) { s_sz[w] = bytes; s_mn[w] = kMin; s_mx[w] = kMax; s_fl[w] = (f1 ? 1u : 0u) | (f2 ? 2u : 0u); }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    wgSize[blockIdx.x] = s_sz[0] + s_sz[1] + s_sz[2] + s_sz[3];
+    u64 a = s_mn[0], b = s_mx[0];
+    for (int i = 1; i < 4; i++) { a = s_mn[i] < a ? s_mn[i] : a; b = s_mx[i] > b ? s_mx[i] : b; }
+    wgMinKey[blockIdx.x] = a; wgMaxKey[blockIdx.x] = b;
+    wgFlags[blockIdx.x] = s_fl[0] | s_fl[1] | s_fl[2] | s_fl[3];
+  }
+  (void)BPW;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decisions between the passes (Lerc.cpp:1486-1502, Lerc2.cpp:205-373) + header (Lerc2.cpp:724-786)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double keyToDouble(int dt, u64 key, u64& raw)
+{
+  if (dt == DT_Float) { u32 b = (u32)key; b = (b & 0x80000000u) ? (b & 0x7fffffffu) : ~b; raw = b; float f; memcpy(&f, &b, 4); return (double)f; }
+  if (dt == DT_Double) { const u64 b = (key >> 63) ? (key & ~(1ull << 63)) : ~key; raw = b; double d; memcpy(&d, &b, 8); return d; }
+  const i64 v = (i64)key - (1ll << 62);
+  raw = (u64)v;
+  return (double)v;
+}
+
+__global__ void __launch_bounds__(256)
+k_fast_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgBase,
+              const u64* __restrict__ wgMinKey, const u64* __restrict__ wgMaxKey, const u32* __restrict__ wgFlags,
+              const double* __restrict__ row0RaiseErr, u8* __restrict__ out, u32 outCapacity, FastEncodeResult* res)
+{
+  __shared__ u64 s_mn[256], s_mx[256];
+  __shared__ u32 s_fl[256];
+  u64 a = ~0ull, b = 0ull;
+  u32 f = 0;
+  for (u32 i = threadIdx.x; i < nWG; i += 256)
+  {
+    const u64 x = wgMinKey[i], y = wgMaxKey[i];
+    a = x < a ? x : a; b = y > b ? y : b; f |= wgFlags[i];
+  }
+  s_mn[threadIdx.x] = a; s_mx[threadIdx.x] = b; s_fl[threadIdx.x] = f;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int i = 1; i < 256; i++) { a = s_mn[i] < a ? s_mn[i] : a; b = s_mx[i] > b ? s_mx[i] : b; f |= s_fl[i]; }
+
+  u64 rawMin = 0, rawMax = 0;
+  const double zMin = keyToDouble(p.dt, a, rawMin), zMax = keyToDouble(p.dt, b, rawMax);
+  const u32 nBytesTiling = wgBase[nWG];
+  const int tb = dtSize(p.dt);
+  const u64 nPix = (u64)p.nRows * (u64)p.nCols;
+  u32 redo = 0;
+  const bool isFlt = p.dt >= DT_Float;
+  if (isFlt)
+  {
+    if (f & 1u) redo |= kRedoNaN;
+    const double lim = (p.dt == DT_Float) ? 8388608.0 : 9007199254740992.0;
+    const bool allInt = !(f & 2u) && zMin >= -lim && zMin <= lim && zMax >= -lim && zMax <= lim;
+    if (allInt) redo |= kRedoAllInt;    // maxZErr becomes max(0.5, floor(.)) and the header says bIsInt
+    if (raiseCandidates && row0RaiseErr)
+    {
+      const int fac[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
+      for (int c = 0; c < 9; c++)
+        if (((raiseCandidates >> c) & 1u) && !(row0RaiseErr[c] / fac[c] > requestedMaxZErr / 2)) redo |= kRedoRaise;
+    }
+  }
+  if (zMin == zMax) redo |= kRedoConst;
+  const u64 nBytesOneSweep = (u64)tb * nPix;
+  if (((double)((u64)nBytesTiling * 8) < (double)nPix * 1.5) && ((u64)nBytesTiling < 4 * nBytesOneSweep)) redo |= kRedoMb16;
+  if (nBytesOneSweep <= (u64)nBytesTiling) redo |= kRedoOneSweep;
+  const u32 prefixLen = 90u + 4u + 2u * (u32)tb + 1u;
+  const u64 blobSize = (u64)prefixLen + nBytesTiling;
+  if (blobSize > outCapacity || blobSize > 0x7FFFFFFFull) redo |= kRedoCapacity;
+
+  res->redoReason = redo;
+  res->redo = redo ? 1u : 0u;
+  res->blobSize = (u32)blobSize;
+  res->nBytesTiling = nBytesTiling;
+  res->zMin = zMin; res->zMax = zMax;
+  res->minKey = a; res->maxKey = b;
+  res->prefixLen = prefixLen;
+  res->checksum = 0;
+  if (redo) return;
+
+  // header + "no mask" + ranges + "not one sweep" (Lerc2.cpp:396-430)
+  u8* o = out;
+  const char key[6] = { 'L', 'e', 'r', 'c', '2', ' ' };
+  for (int i = 0; i < 6; i++) o[i] = (u8)key[i];
+  putBytes(o + 6, (u64)(u32)kCodecVersion, 4);
+  putBytes(o + 10, 0, 4);
+  const int ints[8] = { p.nRows, p.nCols, 1, (int)nPix, 8, (int)blobSize, p.dt, 0 };
+  for (int i = 0; i < 8; i++) putBytes(o + 14 + 4 * i, (u64)(u32)ints[i], 4);
+  putBytes(o + 46, 0, 4);
+  const double dbl[5] = { p.maxZErr, zMin, zMax, 0.0, 0.0 };
+  for (int i = 0; i < 5; i++) { u64 bits; memcpy(&bits, &dbl[i], 8); putBytes(o + 50 + 8 * i, bits, 8); }
+  putBytes(o + 90, 0, 4);
+  putBytes(o + 94, rawMin, tb);
+  putBytes(o + 94 + tb, rawMax, tb);
+  o[94 + 2 * tb] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 2: pack + checksum
+// ------------------------------------------------------------------------------------------------
+// OR up to 64 bits into the LDS bit stream
+__device__ __forceinline__ void orBits64(u32* words, u32 bitPos, u64 value, int nbits)
+{
+  const u32 w = bitPos >> 5, sh = bitPos & 31;
+  const u32 lo = (u32)value, hi = (u32)(value >> 32);
+  atomicOr(&words[w], lo << sh);
+  const u32 mid = (sh ? (lo >> (32 - sh)) : 0u) | (hi << sh);
+  if (sh + (u32)nbits > 32) atomicOr(&words[w + 1], mid);
+  if (sh + (u32)nbits > 64) atomicOr(&words[w + 2], sh ? (hi >> (32 - sh)) : 0u);
+}
+
+template<class T>
+__global__ void __launch_bounds__(256)
+k_fast_pack(const T* __restrict__ data, BandParams p, const u32* __restrict__ wgBase, u8* __restrict__ out,
+            u64* __restrict__ wgFletcher, const FastEncodeResult* __restrict__ res)
+{
+  typedef FastCfg<T> C;
+  constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW, IT = C::IT;
+  constexpr int kMaxBlockBytes = 1 + 64 * (int)sizeof(T);
+  constexpr int kSpanWords = (kFastBlocksPerWG * kMaxBlockBytes + 16) / 4 + 8;
+  __shared__ __align__(16) u32 s_out[kSpanWords];
+  __shared__ u32 s_size[kFastBlocksPerWG];
+  __shared__ u32 s_off[kFastBlocksPerWG + 1];
+  __shared__ u64 s_fa[4], s_fb[4];
+  if (res->redo) return;
+
+  const int w = waveId(), lane = laneId();
+  const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
+  const int wgPerRow = p.nCols / (kFastBlocksPerWG * 8);
+  const int it = (int)blockIdx.x / wgPerRow, wgc = (int)blockIdx.x - it * wgPerRow;
+  const i64 rowBase = (i64)(it * 8 + r) * p.nCols + (i64)wgc * (kFastBlocksPerWG * 8);
+  const u32 g0 = res->prefixLen + wgBase[blockIdx.x];        // absolute offset of this workgroup's span
+  const u32 spanLen = wgBase[blockIdx.x + 1] - wgBase[blockIdx.x];
+  const u32 ldsShift = g0 & 15u;                            // LDS byte i <-> blob byte (g0 & ~15) + i
+
+  for (int i = threadIdx.x; i < kSpanWords; i += 256) s_out[i] = 0;
+
+  // ---- phase A: load, analyse, sizes
+  T v[IT][V];
+  FBlock<T> fb[IT];
+#pragma unroll
+  for (int t = 0; t < IT; t++)
+  {
+    const int tile = t * 4 + w;
+    loadLane<T, V>(data + rowBase + tile * C::TILE_COLS + c * V, v[t]);
+    fb[t] = analyzeBlock<T, V, LPR>(p, v[t], r, h, lane);
+    if (r == 0 && h == 0) s_size[tile * BPW + b] = (u32)fb[t].pl.nBytes;
+  }
+  __syncthreads();
+  if (w == 0)
+  {
+    const u32 sz = s_size[lane];
+    u32 inc = sz;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += o; }
+    s_off[lane] = inc - sz;
+    if (lane == 63) s_off[64] = inc;
+  }
+  __syncthreads();
+
+  // ---- phase B: write every block's bytes into the LDS image of the span
+#pragma unroll
+  for (int t = 0; t < IT; t++)
+  {
+    const int tile = t * 4 + w;
+    const int blk = tile * BPW + b;
+    const Plan& pl = fb[t].pl;
+    const int j0 = (wgc * kFastBlocksPerWG + blk) * 8;
+    u32 flag = (u32)(((j0 >> 3) & 15) << 2) & 0x38u;    // version 6, no slice difference
+    const u32 at0 = 8u * (ldsShift + s_off[blk]);        // bit position of the block inside s_out
+    const bool leader = (r == 0 && h == 0);
+    const int e0 = r * 8 + h * V;
+    if (pl.kind == 0) { if (leader) orBits(s_out, at0, flag | 2u, 8); }
+    else if (pl.kind == 1)
+    {
+      if (leader) orBits(s_out, at0, flag, 8);
+#pragma unroll
+      for (int k = 0; k < V; k++)
+      {
+        u64 bits = 0;
+        const T tmp = v[t][k];
+        memcpy(&bits, &tmp, sizeof(T));
+        orBits64(s_out, at0 + 8u + (u32)(e0 + k) * 8u * (u32)sizeof(T), bits, 8 * (int)sizeof(T));
+      }
+    }
+    else
+    {
+      flag |= (pl.kind == 2) ? 3u : 1u;
+      flag |= (u32)pl.tc << 6;
+      const int offBytes = dtSize(pl.dtRed);
+      if (leader)
+      {
+        orBits(s_out, at0, flag, 8);
+        orBits64(s_out, at0 + 8, typedBits((double)fb[t].mn, pl.dtRed), 8 * offBytes);
+      }
+      if (pl.kind >= 3)
+      {
+        u32 q[V];
+        quantizeLane<T, V>(p, v[t], fb[t].mn, q);
+        const int nb = bitLen(fb[t].qMax);
+        u32 at = at0 + 8u * (1u + (u32)offBytes);
+        if (pl.kind == 3)
+        {
+          if (leader) orBits(s_out, at, (u32)nb | (2u << 6) | (64u << 8), 16);    // numBits byte, 1-byte count = 64
+          at += 16;
+          // V consecutive elements form one V * nb bit string
+          if (V * nb <= 64)
+          {
+            u64 s = 0;
+#pragma unroll
+            for (int k = 0; k < V; k++) s |= (u64)q[k] << (k * nb);
+            orBits64(s_out, at + (u32)e0 * (u32)nb, s, V * nb);
+          }
+          else
+          {
+#pragma unroll
+            for (int k = 0; k < V; k += 2)
+              orBits64(s_out, at + (u32)(e0 + k) * (u32)nb, (u64)q[k] | ((u64)q[k + 1] << nb), 2 * nb);
+          }
+        }
+      }
+    }
+    // LUT blocks (kind 4): all blocks of the wave take part in the group reductions
+    if (__any(pl.kind == 4))
+    {
+      const bool mine = (pl.kind == 4);
+      u32 q[V], idx[V];
+      quantizeLane<T, V>(p, v[t], fb[t].mn, q);
+#pragma unroll
+      for (int k = 0; k < V; k++) idx[k] = 0;
+      const int nb = bitLen(fb[t].qMax);
+      const int offBytes = dtSize(pl.dtRed);
+      const u32 hdr = at0 + 8u * (1u + (u32)offBytes);
+      const u32 lutAt = hdr + 24;    // numBits byte, count byte, nLut + 1 byte
+      u32 count = 0, last = 0;
+      bool active = mine;
+      for (;;)
+      {
+        u32 m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < V; k++)
+          if ((count == 0 || q[k] > last) && q[k] < m) m = q[k];
+        m = groupMin<LPR>(m);
+        if (m == 0xFFFFFFFFu) active = false;
+        if (!__any(active)) break;
+        if (active)
+        {
+#pragma unroll
+          for (int k = 0; k < V; k++) if (q[k] == m) idx[k] = count;
+          if (leader && count > 0) orBits(s_out, lutAt + (count - 1) * (u32)nb, m, nb);
+          last = m; count++;
+        }
+      }
+      if (mine)
+      {
+        const u32 nLut = count - 1;
+        const int nbIdx = bitLen(nLut);
+        if (leader) orBits(s_out, hdr, (u32)nb | (2u << 6) | 32u | (64u << 8) | ((nLut + 1) << 16), 24);
+        const u32 idxAt = lutAt + 8u * ((nLut * (u32)nb + 7) >> 3);
+        u64 s = 0;
+#pragma unroll
+        for (int k = 0; k < V; k++) s |= (u64)idx[k] << (k * nbIdx);    // nbIdx <= 6
+        orBits64(s_out, idxAt + (u32)e0 * (u32)nbIdx, s, V * nbIdx);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- flush: 16-byte chunks, byte granular at the two ends; Fletcher sums of the bytes we own
+  u64 A = 0, B = 0;
+  const u32 gAligned = g0 & ~15u;
+  const u32 nChunks = (ldsShift + spanLen + 15) >> 4;
+  const u8* lds8 = reinterpret_cast<const u8*>(s_out);
+  for (u32 ch = threadIdx.x; ch < nChunks; ch += 256)
+  {
+    const u32 lo = ch * 16, hi = lo + 16;                                  // LDS byte range of this chunk
+    const u32 first = lo < ldsShift ? ldsShift : lo;
+    const u32 last = hi > ldsShift + spanLen ? ldsShift + spanLen : hi;    // owned bytes: [first, last)
+    const uint4 x = *reinterpret_cast<const uint4*>(&s_out[ch * 4]);
+    if (first == lo && last == hi) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;
+    else for (u32 i = first; i < last; i++) out[gAligned + i] = lds8[i];
+    const u32 wd[4] = { x.x, x.y, x.z, x.w };
+    for (u32 i = first; i < last; i++)
+    {
+      const u32 byte = (wd[(i - lo) >> 2] >> (8 * ((i - lo) & 3))) & 0xFFu;
+      const u32 pos = gAligned + i - 14;                                    // position inside the checksummed range
+      const u32 cw = byte << ((pos & 1u) ? 0 : 8);
+      A += cw;
+      B += (u64)(pos >> 1) * cw;
+    }
+  }
+  A %= 65535u; B %= 65535u;
+  A = waveSum(A); B = waveSum(B);
+  if (lane == 0) { s_fa[w] = A; s_fb[w] = B; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    wgFletcher[2 * blockIdx.x] = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u;
+    wgFletcher[2 * blockIdx.x + 1] = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
+  }
+}
+
+// checksum = Fletcher32 over blob[14 ..): the prefix bytes written by k_fast_decide + the workgroup sums
+__global__ void __launch_bounds__(256)
+k_fast_checksum(u32 nWG, const u64* __restrict__ wgFletcher, u8* __restrict__ out, FastEncodeResult* res)
+{
+  __shared__ u64 s_a[256], s_b[256];
+  if (res->redo) return;
+  u64 A = 0, B = 0;
+  for (u32 i = threadIdx.x; i < nWG; i += 256) { A += wgFletcher[2 * i]; B += wgFletcher[2 * i + 1]; }
+  for (u32 pos = threadIdx.x; pos + 14 < res->prefixLen; pos += 256)
+  {
+    const u32 cw = (u32)out[14 + pos] << ((pos & 1u) ? 0 : 8);
+    A += cw; B += (u64)(pos >> 1) * cw;
+  }
+  s_a[threadIdx.x] = A % 65535u; s_b[threadIdx.x] = B % 65535u;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  A = 0; B = 0;
+  for (int i = 0; i < 256; i++) { A += s_a[i]; B += s_b[i]; }
+  const u32 len = res->blobSize - 14;
+  const u64 N = ((u64)len + 1) / 2;
+  A %= 65535u; B %= 65535u;
+  u64 s1 = A, s2 = ((N % 65535u) * A + 65535u - B) % 65535u;
+  if (s1 == 0) s1 = 0xffff;
+  if (s2 == 0) s2 = 0xffff;
+  const u32 cs = (u32)((s2 << 16) | s1);
+  putBytes(out + 10, cs, 4);
+  res->checksum = cs;
+}
+
+// ------------------------------------------------------------------------------------------------
+bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, double maxZErr)
+{
+  if (hasMask || nDepth != 1) return false;
+  if (nRows % 8 != 0 || nCols % (kFastBlocksPerWG * 8) != 0) return false;
+  if (dt == DT_Char || dt == DT_Byte) return false;    // 8-bit: the Huffman decision needs the general path
+  if (dt >= DT_Float && maxZErr == 0) return false;    // lossless float is out of scope altogether
+  return true;
+}
+
+u32 fastEncodeNumWG(int nRows, int nCols) { return (u32)(nRows / 8) * (u32)(nCols / (kFastBlocksPerWG * 8)); }
+
+template<class T>
+static void launchFastEncodeT(int stage, const BandParams& p, double requested, u32 raiseCand, const void* data, u8* out, u32 cap,
+                              const FastEncodeBuffers& b, hipStream_t st)
+{
+  const u32 nWG = fastEncodeNumWG(p.nRows, p.nCols);
+  if (stage == 0)
+    hipLaunchKernelGGL(k_fast_stats<T>, dim3(nWG), dim3(256), 0, st, (const T*)data, p, b.wgSize, b.wgMinKey, b.wgMaxKey, b.wgFlags);
+  else if (stage == 1)
+  {
+    launchExclusiveScan(b.wgSize, b.wgBase, nWG, b.scanScratch, st);
+    hipLaunchKernelGGL(k_fast_decide, dim3(1), dim3(256), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgBase,
+                       (const u64*)b.wgMinKey, (const u64*)b.wgMaxKey, (const u32*)b.wgFlags, (const double*)b.row0RaiseErr, out, cap, b.result);
+  }
+  else if (stage == 2)
+    hipLaunchKernelGGL(k_fast_pack<T>, dim3(nWG), dim3(256), 0, st, (const T*)data, p, (const u32*)b.wgBase, out, b.wgFletcher,
+                       (const FastEncodeResult*)b.result);
+  else
+    hipLaunchKernelGGL(k_fast_checksum, dim3(1), dim3(256), 0, st, nWG, (const u64*)b.wgFletcher, out, b.result);
+}
+
+void launchFastEncode(int stage, const BandParams& assumed, double requestedMaxZErr, u32 raiseCandidates, const void* data, u8* out,
+                      u32 outCapacity, const FastEncodeBuffers& b, hipStream_t st)
+{
+  switch (assumed.dt)
+  {
+    case DT_Short:  launchFastEncodeT<short>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, b, st); break;
+    case DT_UShort: launchFastEncodeT<unsigned short>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, b, st); break;
+    case DT_Int:    launchFastEncodeT<int>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, b, st); break;
+    case DT_UInt:   launchFastEncodeT<unsigned int>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, b, st); break;
+    case DT_Float:  launchFastEncodeT<float>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, b, st); break;
+    case DT_Double: launchFastEncodeT<double>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, b, st); break;
+    default: break;
+  }
+}
+
+}    // namespace lerc

@@ -1,0 +1,479 @@
+// tile_fast_decode.hip -- streaming decoder kernels for the common case (one band, nDepth == 1, every
+// pixel valid, 8 x 8 blocks, nRows % 8 == 0, nCols % 512 == 0).  Same results as tile_decode.hip.
+//
+//   k_fast_walk     block-offset discovery, LDS staged: a workgroup stages 16 chunks of 4 KiB, tries every
+//                   position of each chunk's first `window` bytes as a block start (a few steps filter
+//                   out almost all of them), walks the survivors to the chunk end in LDS and records the
+//                   agreed exit plus (start, #blocks) of up to 8 survivors per chunk
+//   k_fast_resolve  entry of chunk c = agreed exit of chunk c-1; #blocks of the survivor that starts there
+//   k_fast_emit     one lane per chunk re-walks from the resolved entry and writes the block offsets
+//   k_fast_decode   a workgroup owns 64 consecutive blocks (8 rows x 512 columns): it stages their byte
+//                   span in LDS (accumulating the Fletcher32 sums of those bytes on the way), then every
+//                   lane extracts V consecutive pixels of one raster row, dequantises in double
+//                   precision (reference expression order) and stores one 16-byte vector
+// Whenever a precondition fails (a block longer than its raw size, disagreeing survivors, ...) the
+// kernels raise `fallback`, and the host repeats the band with the general kernels.
+#include "tile_fast.h"
+#include "kernels.h"
+#include "wave_utils.h"
+
+namespace lerc {
+
+static const u32 kNoOffset = 0xFFFFFFFFu;
+
+struct BlkLite
+{
+  u32 len, payload;
+  u8 flag, mode, tc, offBytes, nb, lut, dtUsed;
+  u32 nLut;
+};
+
+// Block header parser for all-valid 8 x 8 blocks (64 elements); `mem[pos]` may be LDS or global.
+// Returns false if no valid block starts at pos.  Mirrors Lerc2::ReadTile / BitStuffer2::Decode.
+template<int TBYTES>
+__device__ __forceinline__ bool parseLite(const u8* mem, u32 pos, u32 end, int dt, int version, BlkLite& b)
+{
+  if (pos >= end) return false;
+  const u32 flag = mem[pos];
+  b.flag = (u8)flag;
+  if (version >= 5 && (flag & 4u)) return false;    // slice difference needs nDepth > 1
+  b.mode = (u8)(flag & 3u);
+  b.tc = (u8)(flag >> 6);
+  b.offBytes = 0; b.nb = 0; b.lut = 0; b.nLut = 0; b.payload = 1; b.dtUsed = (u8)dt;
+  u32 len = 1;
+  if (b.mode == 2) { b.len = 1; return true; }
+  if (b.mode == 0) len = 1 + 64 * TBYTES;
+  else
+  {
+    const int dtU = typeUsed(dt, b.tc);
+    if (dtU == DT_Undefined) return false;
+    b.dtUsed = (u8)dtU;
+    b.offBytes = (u8)dtSize(dtU);
+    len = 1 + b.offBytes;
+    if (b.mode == 1)
+    {
+      const u32 at = pos + len;
+      if (at + 2 > end) return false;
+      const u32 b0 = mem[at];
+      if ((b0 >> 6) != 2u) return false;            // 64 elements -> one-byte count field
+      if (mem[at + 1] != 64u) return false;
+      b.lut = (b0 & 32u) ? 1 : 0;
+      b.nb = (u8)(b0 & 31u);
+      if (b.nb == 0) return false;
+      len += 2;
+      if (!b.lut) { b.payload = len; len += 8u * b.nb; }
+      else
+      {
+        if (pos + len >= end) return false;
+        const int nLut = (int)mem[pos + len] - 1;
+        if (nLut < 1) return false;
+        b.nLut = (u32)nLut;
+        len += 1;
+        b.payload = len;
+        len += ((u32)nLut * b.nb + 7) >> 3;
+        len += (64u * (u32)bitLen((u32)nLut) + 7) >> 3;
+      }
+    }
+  }
+  if (pos + len > end) return false;
+  b.len = len;
+  return true;
+}
+
+__device__ __forceinline__ bool sigOk(u32 prev, u32 cur, u32 pattern)
+{
+  const u32 step = (pattern == 14u) ? 2u : 1u;    // 8 x 8 blocks: signature = (j0 >> 3) & pattern
+  return cur == prev || cur == ((prev + step) & pattern) || cur == 0;
+}
+
+static const int kWalkChunksPerWG = 16;
+static const int kFilterSteps = 4;
+static const int kMaxSurvivors = 1024;
+
+template<int TBYTES>
+__global__ void __launch_bounds__(256)
+k_fast_walk(int dt, int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
+            u32* __restrict__ chunkExit, u16* __restrict__ countAt, u32* __restrict__ fallback)
+{
+  constexpr u32 W = kFastWindow(TBYTES);
+  constexpr u32 kStage = kWalkChunksPerWG * kFastChunkBytes + W + 48;
+  __shared__ __align__(16) u32 s_in[kStage / 4 + 4];
+  __shared__ u32 s_svStart[kMaxSurvivors], s_svCur[kMaxSurvivors], s_svMeta[kMaxSurvivors];    // meta: chunk | count << 8 | sig << 24
+  __shared__ u32 s_nSv, s_over;
+  __shared__ u32 s_min[kWalkChunksPerWG], s_max[kWalkChunksPerWG], s_n[kWalkChunksPerWG];
+
+  const u32 c0 = blockIdx.x * kWalkChunksPerWG;
+  const u32 groupStart = dataBegin + c0 * kFastChunkBytes;
+  const u32 a0 = groupStart & ~15u;
+  const u32 stageEnd = min(a0 + kStage, blobEnd);
+  for (u32 i = threadIdx.x * 16u; a0 + i < stageEnd; i += 256u * 16u)
+  {
+    if (a0 + i + 16 <= stageEnd)
+      *reinterpret_cast<uint4*>(reinterpret_cast<u8*>(s_in) + i) = *reinterpret_cast<const uint4*>(blob + a0 + i);
+    else
+      for (u32 k = 0; a0 + i + k < stageEnd; k++) reinterpret_cast<u8*>(s_in)[i + k] = blob[a0 + i + k];    // never read past the blob
+  }
+  if (threadIdx.x == 0) { s_nSv = 0; s_over = 0; }
+  if (threadIdx.x < kWalkChunksPerWG) { s_min[threadIdx.x] = kNoOffset; s_max[threadIdx.x] = 0; s_n[threadIdx.x] = 0; }
+  __syncthreads();
+
+  const u8* mem = reinterpret_cast<const u8*>(s_in) - a0;    // mem[absolute offset]
+  const u32 readEnd = min(stageEnd, blobEnd);
+  const u32 pattern = (version >= 5) ? 14u : 15u;
+  const u32 nChunksHere = min((u32)kWalkChunksPerWG, wp.nChunks - c0);
+
+  // ---- phase 1: every window position, a few steps
+  for (u32 f = threadIdx.x; f < nChunksHere * W; f += 256)
+  {
+    const u32 g = f / W, o = f - g * W;
+    const u32 chunkStart = groupStart + g * kFastChunkBytes;
+    const u32 chunkEnd = min(chunkStart + kFastChunkBytes, blobEnd);
+    if (c0 + g == 0 && o != 0) continue;    // the very first block of the stream is known
+    u32 cur = chunkStart + o;
+    if (cur >= chunkEnd) continue;
+    u32 sig = kNoOffset, count = 0;
+    bool alive = true;
+    for (int s = 0; s < kFilterSteps && cur < chunkEnd; s++)
+    {
+      BlkLite b;
+      if (!parseLite<TBYTES>(mem, cur, min(readEnd, blobEnd), dt, version, b)) { alive = false; break; }
+      const u32 sg = ((u32)b.flag >> 2) & pattern;
+      if (sig != kNoOffset && !sigOk(sig, sg, pattern)) { alive = false; break; }
+      sig = sg; cur += b.len; count++;
+    }
+    if (!alive) continue;
+    const u32 slot = atomicAdd(&s_nSv, 1u);
+    if (slot >= (u32)kMaxSurvivors) { s_over = 1; continue; }
+    s_svStart[slot] = chunkStart + o; s_svCur[slot] = cur; s_svMeta[slot] = g | (count << 8) | ((sig & 15u) << 24);
+  }
+  __syncthreads();
+
+  // ---- phase 2: survivors walk to the end of their chunk
+  const u32 nSv = min(s_nSv, (u32)kMaxSurvivors);
+  for (u32 s = threadIdx.x; s < nSv; s += 256)
+  {
+    const u32 meta = s_svMeta[s];
+    const u32 g = meta & 0xFFu;
+    u32 count = (meta >> 8) & 0xFFFFu, sig = meta >> 24;
+    const u32 chunkStart = groupStart + g * kFastChunkBytes;
+    const u32 chunkEnd = min(chunkStart + kFastChunkBytes, blobEnd);
+    u32 cur = s_svCur[s];
+    bool alive = true;
+    while (cur < chunkEnd)
+    {
+      BlkLite b;
+      if (!parseLite<TBYTES>(mem, cur, readEnd, dt, version, b)) { alive = false; break; }
+      const u32 sg = ((u32)b.flag >> 2) & pattern;
+      if (!sigOk(sig, sg, pattern)) { alive = false; break; }
+      sig = sg; cur += b.len; count++;
+    }
+    if (!alive) continue;
+    atomicMin(&s_min[g], cur);
+    atomicMax(&s_max[g], cur);
+    atomicAdd(&s_n[g], 1u);
+    countAt[(size_t)(c0 + g) * W + (s_svStart[s] - chunkStart)] = (u16)count;    // #blocks from this start to the chunk end
+  }
+  __syncthreads();
+  if (threadIdx.x < nChunksHere)
+  {
+    const u32 g = threadIdx.x;
+    const bool ok = !s_over && s_n[g] > 0 && s_min[g] == s_max[g];
+    chunkExit[c0 + g] = ok ? s_min[g] : kNoOffset;
+    if (!ok && c0 + g + 1 < wp.nChunks) atomicOr(fallback, 1u);    // the exit of the last chunk is not needed
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_fast_resolve(FastWalkPlan wp, u32 window, u32 dataBegin, const u32* __restrict__ chunkExit, const u16* __restrict__ countAt,
+               u32* __restrict__ chunkEntry, u32* __restrict__ chunkCount, u32* __restrict__ fallback)
+{
+  const u32 c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= wp.nChunks) return;
+  const u32 e = (c == 0) ? dataBegin : chunkExit[c - 1];
+  chunkEntry[c] = e;
+  const u32 chunkStart = dataBegin + c * kFastChunkBytes;
+  u32 n = 0xFFFFu;
+  if (e != kNoOffset && e >= chunkStart && e - chunkStart < window) n = countAt[(size_t)c * window + (e - chunkStart)];
+  if (n == 0xFFFFu) { atomicOr(fallback, 2u); n = 0; }
+  chunkCount[c] = n;
+}
+
+template<int TBYTES>
+__global__ void __launch_bounds__(256)
+k_fast_emit(int dt, int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
+            const u32* __restrict__ chunkEntry, const u32* __restrict__ chunkBase, u32* __restrict__ blockOff, u32* __restrict__ fallback)
+{
+  if (*fallback) return;
+  const u32 c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= wp.nChunks) return;
+  if (c == 0 && chunkBase[wp.nChunks] != wp.nBlocks) { atomicOr(fallback, 4u); return; }
+  const u32 chunkEnd = min(dataBegin + (c + 1) * kFastChunkBytes, blobEnd);
+  u32 cur = chunkEntry[c];
+  u32 i = chunkBase[c];
+  while (cur < chunkEnd)
+  {
+    BlkLite b;
+    if (!parseLite<TBYTES>(blob, cur, blobEnd, dt, version, b) || i >= wp.nBlocks) { atomicOr(fallback, 8u); return; }
+    blockOff[i++] = cur;
+    cur += b.len;
+  }
+  if (c == wp.nChunks - 1) blockOff[wp.nBlocks] = cur;    // sentinel: end of the last block
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------------
+template<class T> struct DCfg
+{
+  static constexpr int V = (sizeof(T) >= 4) ? 16 / (int)sizeof(T) : 8;
+  static constexpr int LPR = 8 / V;
+  static constexpr int BPW = 8 / LPR;
+  static constexpr int TILE_COLS = 8 * V;
+  static constexpr int IT = kFastBlocksPerWG / (4 * BPW);
+};
+
+// nbits (<= 32) at bit position bitPos of the LDS word stream
+__device__ __forceinline__ u32 ldsBits(const u32* words, u32 bitPos, int nbits)
+{
+  const u32 w = bitPos >> 5, sh = bitPos & 31;
+  const u64 x = ((u64)words[w + 1] << 32) | words[w];
+  return (u32)(x >> sh) & (nbits >= 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1u));
+}
+
+template<class T>
+__global__ void __launch_bounds__(256)
+k_fast_decode(BandParams p, const u8* __restrict__ blob, u32 blobEnd, const u32* __restrict__ blockOff, T* __restrict__ outPix,
+              u64* __restrict__ wgFletcher, const u32* __restrict__ fallback, DeviceStatus* st)
+{
+  typedef DCfg<T> C;
+  constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW, IT = C::IT;
+  constexpr int kSpanWords = (kFastBlocksPerWG * (1 + 64 * (int)sizeof(T)) + 32) / 4 + 8;
+  __shared__ __align__(16) u32 s_in[kSpanWords];
+  __shared__ u32 s_off[kFastBlocksPerWG + 1];
+  __shared__ u64 s_fa[4], s_fb[4];
+  __shared__ u32 s_bad;
+  if (*fallback) return;
+
+  const int w = waveId(), lane = laneId();
+  const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
+  const int wgPerRow = p.nCols / (kFastBlocksPerWG * 8);
+  const int it = (int)blockIdx.x / wgPerRow, wgc = (int)blockIdx.x - it * wgPerRow;
+  const u32 firstBlk = blockIdx.x * kFastBlocksPerWG;
+
+  if (threadIdx.x <= kFastBlocksPerWG) s_off[threadIdx.x] = blockOff[firstBlk + threadIdx.x];
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  const u32 g0 = s_off[0], g1 = s_off[kFastBlocksPerWG];
+  const u32 spanLen = g1 - g0;
+  if (g1 < g0 || spanLen > (u32)(kFastBlocksPerWG * (1 + 64 * (int)sizeof(T))) || g1 > blobEnd)
+  {
+    if (threadIdx.x == 0) raiseError(st, kFailed, blockIdx.x);
+    return;
+  }
+  // ---- stage the span (16-byte loads from the aligned-down start) + Fletcher sums of the owned bytes
+  const u32 a0 = g0 & ~15u;
+  const u32 shift = g0 - a0;
+  const u32 nChunks = (shift + spanLen + 15) >> 4;
+  u64 A = 0, B = 0;
+  for (u32 ch = threadIdx.x; ch < nChunks; ch += 256)
+  {
+    uint4 x;
+    if (a0 + ch * 16 + 16 <= blobEnd) x = *reinterpret_cast<const uint4*>(blob + a0 + ch * 16);
+    else
+    {
+      u32 t4[4] = { 0, 0, 0, 0 };
+      for (u32 k = 0; a0 + ch * 16 + k < blobEnd; k++) t4[k >> 2] |= (u32)blob[a0 + ch * 16 + k] << (8 * (k & 3));    // never read past the blob
+      x = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+    }
+    *reinterpret_cast<uint4*>(&s_in[ch * 4]) = x;
+    const u32 lo = ch * 16;
+    const u32 first = lo < shift ? shift : lo;
+    const u32 last = (lo + 16 > shift + spanLen) ? shift + spanLen : lo + 16;
+    const u32 wd[4] = { x.x, x.y, x.z, x.w };
+    for (u32 i = first; i < last; i++)
+    {
+      const u32 byte = (wd[(i - lo) >> 2] >> (8 * ((i - lo) & 3))) & 0xFFu;
+      const u32 pos = a0 + i - 14;
+      const u32 cw = byte << ((pos & 1u) ? 0 : 8);
+      A += cw;
+      B += (u64)(pos >> 1) * cw;
+    }
+  }
+  A %= 65535u; B %= 65535u;
+  A = waveSum(A); B = waveSum(B);
+  if (lane == 0) { s_fa[w] = A; s_fb[w] = B; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    wgFletcher[2 * blockIdx.x] = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u;
+    wgFletcher[2 * blockIdx.x + 1] = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
+  }
+
+  const u8* mem = reinterpret_cast<const u8*>(s_in) - a0;    // mem[absolute blob offset]
+  const u32 pattern = (p.version >= 5) ? 14u : 15u;
+  const i64 rowBase = (i64)(it * 8 + r) * p.nCols + (i64)wgc * (kFastBlocksPerWG * 8);
+  bool bad = false;
+#pragma unroll
+  for (int t = 0; t < IT; t++)
+  {
+    const int tile = t * 4 + w;
+    const int blk = tile * BPW + b;
+    const u32 off = s_off[blk];
+    const int j0 = (wgc * kFastBlocksPerWG + blk) * 8;
+    BlkLite bl;
+    bool ok = parseLite<(int)sizeof(T)>(mem, off, g1, p.dt, p.version, bl);
+    ok = ok && (off + bl.len == s_off[blk + 1]) && ((((u32)bl.flag >> 2) & pattern) == (((u32)j0 >> 3) & pattern));
+    T v[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) v[k] = T(0);
+    if (ok)
+    {
+      const int e0 = r * 8 + h * V;
+      if (bl.mode == 0)
+      {
+#pragma unroll
+        for (int k = 0; k < V; k++)
+        {
+          const u64 bits = getBytes(mem + off + 1 + (u32)(e0 + k) * (u32)sizeof(T), (int)sizeof(T));
+          memcpy(&v[k], &bits, sizeof(T));
+        }
+      }
+      else if (bl.mode != 2)
+      {
+        const double offset = typedFromBits(getBytes(mem + off + 1, bl.offBytes), bl.dtUsed);
+        if (bl.mode == 3)
+        {
+#pragma unroll
+          for (int k = 0; k < V; k++) v[k] = (T)offset;
+        }
+        else
+        {
+          const u32 payloadBit = 8u * (off - a0 + bl.payload);
+          const int nb = bl.nb;
+          if (!bl.lut)
+          {
+#pragma unroll
+            for (int k = 0; k < V; k++)
+            {
+              const u32 q = ldsBits(s_in, payloadBit + (u32)(e0 + k) * (u32)nb, nb);
+              const double z = offset + (double)q * p.invScale;
+              v[k] = (T)(z < p.zMaxHdr ? z : p.zMaxHdr);
+            }
+          }
+          else
+          {
+            const int nbIdx = bitLen(bl.nLut);
+            const u32 idxBit = payloadBit + 8u * ((bl.nLut * (u32)nb + 7) >> 3);
+#pragma unroll
+            for (int k = 0; k < V; k++)
+            {
+              const u32 ix = ldsBits(s_in, idxBit + (u32)(e0 + k) * (u32)nbIdx, nbIdx);
+              if (ix > bl.nLut) { ok = false; continue; }
+              const u32 q = ix ? ldsBits(s_in, payloadBit + (ix - 1) * (u32)nb, nb) : 0u;
+              const double z = offset + (double)q * p.invScale;
+              v[k] = (T)(z < p.zMaxHdr ? z : p.zMaxHdr);
+            }
+          }
+        }
+      }
+    }
+    if (!ok) bad = true;
+    struct alignas(sizeof(T) * V) Vec { T e[V]; };
+    Vec o;
+#pragma unroll
+    for (int k = 0; k < V; k++) o.e[k] = v[k];
+    *reinterpret_cast<Vec*>(outPix + rowBase + tile * C::TILE_COLS + c * V) = o;
+  }
+  if (__any(bad) && lane == 0) raiseError(st, kFailed, blockIdx.x);
+}
+
+// sums the per-workgroup Fletcher partials; the host adds the prefix bytes it already holds
+__global__ void __launch_bounds__(256) k_fast_fletcher_sum(u32 nWG, const u64* __restrict__ wgFletcher, u64* __restrict__ out2)
+{
+  __shared__ u64 s_a[256], s_b[256];
+  u64 A = 0, B = 0;
+  for (u32 i = threadIdx.x; i < nWG; i += 256) { A += wgFletcher[2 * i]; B += wgFletcher[2 * i + 1]; }
+  s_a[threadIdx.x] = A % 65535u; s_b[threadIdx.x] = B % 65535u;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  A = 0; B = 0;
+  for (int i = 0; i < 256; i++) { A += s_a[i]; B += s_b[i]; }
+  out2[0] = A % 65535u; out2[1] = B % 65535u;
+}
+
+// ------------------------------------------------------------------------------------------------
+bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid)
+{
+  if (!allValid || nDepth != 1 || mb != 8 || version < 3) return false;
+  if (nRows % 8 != 0 || nCols % (kFastBlocksPerWG * 8) != 0) return false;
+  if (dt == DT_Char || dt == DT_Byte) return false;
+  return true;
+}
+
+FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 dataBegin, u32 blobEnd)
+{
+  FastWalkPlan wp;
+  const u32 span = blobEnd > dataBegin ? blobEnd - dataBegin : 0;
+  wp.nChunks = span ? (span + kFastChunkBytes - 1) / kFastChunkBytes : 1;
+  wp.nBlocks = (u32)(nRows / 8) * (u32)(nCols / 8);
+  return wp;
+}
+
+template<int TBYTES>
+static void launchFastWalkT(int stage, const BandParams& p, const FastWalkPlan& wp, const u8* blob, u32 dataBegin, u32 blobEnd,
+                            const FastDecodeBuffers& b, hipStream_t st)
+{
+  if (stage == 0)
+  {
+    const u32 nWG = (wp.nChunks + kWalkChunksPerWG - 1) / kWalkChunksPerWG;
+    hipMemsetAsync(b.countAt, 0xFF, (size_t)wp.nChunks * kFastWindow(TBYTES) * 2, st);
+    hipLaunchKernelGGL(k_fast_walk<TBYTES>, dim3(nWG), dim3(256), 0, st, p.dt, p.version, wp, blob, dataBegin, blobEnd, b.chunkExit,
+                       b.countAt, b.fallback);
+  }
+  else if (stage == 1)
+  {
+    hipLaunchKernelGGL(k_fast_resolve, dim3((wp.nChunks + 255) / 256), dim3(256), 0, st, wp, (u32)kFastWindow(TBYTES), dataBegin,
+                       (const u32*)b.chunkExit, (const u16*)b.countAt, b.chunkEntry, b.chunkCount, b.fallback);
+    launchExclusiveScan(b.chunkCount, b.chunkBase, wp.nChunks, b.scanScratch, st);
+  }
+  else
+    hipLaunchKernelGGL(k_fast_emit<TBYTES>, dim3((wp.nChunks + 255) / 256), dim3(256), 0, st, p.dt, p.version, wp, blob, dataBegin, blobEnd,
+                       (const u32*)b.chunkEntry, (const u32*)b.chunkBase, b.blockOff, b.fallback);
+}
+
+template<class T>
+static void launchFastDecodeT(const BandParams& p, const u8* blob, u32 blobEnd, const FastDecodeBuffers& b, void* out, DeviceStatus* status,
+                              hipStream_t st)
+{
+  const u32 nWG = fastEncodeNumWG(p.nRows, p.nCols);
+  hipLaunchKernelGGL(k_fast_decode<T>, dim3(nWG), dim3(256), 0, st, p, blob, blobEnd, (const u32*)b.blockOff, (T*)out, b.wgFletcher,
+                     (const u32*)b.fallback, status);
+  hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1), dim3(256), 0, st, nWG, (const u64*)b.wgFletcher, b.fletcherOut);
+}
+
+void launchFastDecode(int stage, const BandParams& p, const FastWalkPlan& wp, const u8* blob, u32 dataBegin, u32 blobEnd,
+                      const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st)
+{
+  if (stage < 3)
+  {
+    switch (dtSize(p.dt))
+    {
+      case 2: launchFastWalkT<2>(stage, p, wp, blob, dataBegin, blobEnd, b, st); break;
+      case 4: launchFastWalkT<4>(stage, p, wp, blob, dataBegin, blobEnd, b, st); break;
+      default: launchFastWalkT<8>(stage, p, wp, blob, dataBegin, blobEnd, b, st); break;
+    }
+    return;
+  }
+  switch (p.dt)
+  {
+    case DT_Short:  launchFastDecodeT<short>(p, blob, blobEnd, b, out, status, st); break;
+    case DT_UShort: launchFastDecodeT<unsigned short>(p, blob, blobEnd, b, out, status, st); break;
+    case DT_Int:    launchFastDecodeT<int>(p, blob, blobEnd, b, out, status, st); break;
+    case DT_UInt:   launchFastDecodeT<unsigned int>(p, blob, blobEnd, b, out, status, st); break;
+    case DT_Float:  launchFastDecodeT<float>(p, blob, blobEnd, b, out, status, st); break;
+    case DT_Double: launchFastDecodeT<double>(p, blob, blobEnd, b, out, status, st); break;
+    default: break;
+  }
+}
+
+}    // namespace lerc

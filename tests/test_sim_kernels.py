@@ -72,3 +72,47 @@ def test_sim_rejects_corruption(libs):
     blob[len(blob) // 2] ^= 0x40
     assert S.decode(bytes(blob))[0] == 1
     assert S.decode(bytes(blob[:300]))[0] != 0
+
+
+def _fast_cases():
+    """Rasters that qualify for the streaming kernels (unmasked, nDepth 1, rows % 8 == 0, cols % 512 == 0),
+    plus the inputs that make the device-side decisions bail out to the general path."""
+    rng = np.random.default_rng(11)
+    out = []
+    for dt in (np.float32, np.uint16, np.int16, np.int32, np.uint32, np.float64):
+        kind = np.dtype(dt).kind
+        for (r, c) in ((8, 512), (16, 1024)):
+            x = cases.terrain(r, c, rng, amp=300, base=1000, sigma=1.5)
+            for e in ([0.01, 3.0] if kind == "f" else [0, 2]):
+                out.append((f"fast-terrain-{np.dtype(dt).name}-{r}x{c}-e{e}", cases._cast(x, dt), e))
+            out.append((f"fast-mixed-{np.dtype(dt).name}-{r}x{c}", cases.mixed_regions(r, c, rng, dt), 0.01 if kind == "f" else 0))
+    f = np.float32
+    out.append(("fast-f32-allint", np.rint(cases.terrain(16, 512, rng)).astype(f), 0.01))
+    out.append(("fast-f32-round1", np.round(cases.terrain(16, 512, rng), 1).astype(f), 0.01))
+    out.append(("fast-f32-const", np.full((16, 512), 3.5, f), 0.01))
+    y = np.full((16, 512), 100.0, f)
+    y[rng.random((16, 512)) < 0.05] += 0.02
+    out.append(("fast-f32-mb16", y, 0.01))
+    z = cases.terrain(16, 512, rng).astype(f)
+    z[3, 5] = np.nan
+    out.append(("fast-f32-nan", z, 0.01))
+    zr = cases.terrain(16, 512, rng).astype(f)
+    zr[5, 7] = 3e30
+    out.append(("fast-f32-some-raw", zr, 0.01))
+    out.append(("fast-f32-huge", (cases.terrain(16, 512, rng) * 1e30).astype(f), 0.01))
+    return out
+
+
+_FAST = _fast_cases()
+
+
+@pytest.mark.parametrize("idx", range(len(_FAST)), ids=[c[0] for c in _FAST])
+def test_sim_streaming_path(libs, idx):
+    O, S = libs
+    name, arr, e = _FAST[idx]
+    r1, b1 = O.encode(arr, e)
+    r2, b2 = S.encode(arr, e)
+    assert r1 == r2 and b1 == b2
+    if r1 == 0:
+        d1, d2 = O.decode(b1), S.decode(b1)
+        assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1])
