@@ -303,7 +303,6 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     if (fastBand && fastDataBegin == (u32)(at - bd.offset))
     {
       const FastWalkPlan fwp = makeFastWalkPlan(nRows, nCols, fastDataBegin, blobEnd);
-      const u32 nWG = fastEncodeNumWG(nRows, nCols);
       FastDecodeBuffers fbuf;
       fbuf.chunkExit = ctx.allocT<u32>(fwp.nChunks + 4);
       fbuf.countAt = ctx.allocT<u16>((size_t)fwp.nChunks * kFastWindow(tb) + 8);
@@ -311,12 +310,12 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
       fbuf.chunkCount = ctx.allocT<u32>(fwp.nChunks + 4);
       fbuf.chunkBase = ctx.allocT<u32>(fwp.nChunks + 4);
       fbuf.blockOff = ctx.allocT<u32>((size_t)fwp.nBlocks + 4);
-      fbuf.wgFletcher = ctx.allocT<u64>((size_t)2 * nWG);
+      fbuf.slotFletcher = ctx.allocT<u64>(2 * kFastSlots);
       fbuf.fletcherOut = ctx.allocT<u64>(2);
       fbuf.scanScratch = ctx.allocT<u32>(fwp.nChunks / 1024 + 8);
       fbuf.fallback = ctx.allocT<u32>(4);
       if (!fbuf.chunkExit || !fbuf.countAt || !fbuf.chunkEntry || !fbuf.chunkCount || !fbuf.chunkBase || !fbuf.blockOff
-        || !fbuf.wgFletcher || !fbuf.fletcherOut || !fbuf.scanScratch || !fbuf.fallback) return kFailed;
+        || !fbuf.slotFletcher || !fbuf.fletcherOut || !fbuf.scanScratch || !fbuf.fallback) return kFailed;
       hipMemsetAsync(fbuf.fallback, 0, 16, st);
       static const char* kStage[4] = { "fast_walk", "fast_resolve_scan", "fast_emit_offsets", "fast_decode" };
       for (int stage = 0; stage < 4; stage++)

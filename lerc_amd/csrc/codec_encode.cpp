@@ -387,7 +387,7 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   const bool fastOk = rq.nBands == 1 && rq.dOut && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
     && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, rq.nDepth, rq.nMasks > 0, rq.maxZErr);
   const u32 nWG = fastOk ? fastEncodeNumWG(rq.nRows, rq.nCols) : 0;
-  need += (size_t)nWG * 48 + 8192;
+  need += (size_t)nWG * (kFastBlocksPerWG * sizeof(FastBlockDesc) + 16) + 16384;
   if (!ctx.reserve(need)) return kFailed;
   (void)tb;
 
@@ -399,17 +399,18 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
     hipStream_t st = ctx.activeStream();
     const bool isFlt = rq.dt >= DT_Float;
     FastEncodeBuffers fb;
+    fb.desc = ctx.allocT<FastBlockDesc>((size_t)nWG * kFastBlocksPerWG);
     fb.wgSize = ctx.allocT<u32>(nWG + 4);
     fb.wgBase = ctx.allocT<u32>(nWG + 4);
-    fb.wgMinKey = ctx.allocT<u64>(nWG);
-    fb.wgMaxKey = ctx.allocT<u64>(nWG);
-    fb.wgFlags = ctx.allocT<u32>(nWG);
-    fb.wgFletcher = ctx.allocT<u64>((size_t)2 * nWG);
+    fb.slotMinKey = ctx.allocT<u64>(kFastSlots);
+    fb.slotMaxKey = ctx.allocT<u64>(kFastSlots);
+    fb.slotFlags = ctx.allocT<u32>(kFastSlots);
+    fb.slotFletcher = ctx.allocT<u64>(2 * kFastSlots);
     fb.scanScratch = ctx.allocT<u32>(nWG / 1024 + 8);
     fb.result = ctx.allocT<FastEncodeResult>(1);
     BandStats* dRow0 = ctx.allocT<BandStats>(1);
     u64* dKeys = ctx.allocT<u64>(2);
-    if (!fb.wgSize || !fb.wgBase || !fb.wgMinKey || !fb.wgMaxKey || !fb.wgFlags || !fb.wgFletcher || !fb.scanScratch || !fb.result || !dRow0 || !dKeys)
+    if (!fb.desc || !fb.wgSize || !fb.wgBase || !fb.slotMinKey || !fb.slotMaxKey || !fb.slotFlags || !fb.slotFletcher || !fb.scanScratch || !fb.result || !dRow0 || !dKeys)
       return kFailed;
     u32 cand = 0;
     fb.row0RaiseErr = nullptr;

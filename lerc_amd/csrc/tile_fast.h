@@ -21,14 +21,24 @@ struct FastEncodeResult
   u32 checksum;
 };
 
+static const int kFastSlots = 64;          // atomics of the workgroups are spread over this many global slots
+
+struct FastBlockDesc      // what pass 1 decided for one block; pass 2 packs from it
+{
+  u64 mnBits;             // block minimum (raw bits of T)
+  u32 w1;                 // nBytes | kind << 16 | tc << 19 | dtRed << 21 | numBits << 24
+  u32 pad;
+};
+
 struct FastEncodeBuffers
 {
+  FastBlockDesc* desc; // [nWG * 64]
   u32* wgSize;         // [nWG] bytes of each workgroup's 64 blocks
   u32* wgBase;         // [nWG + 1] exclusive scan
-  u64* wgMinKey;       // [nWG]
-  u64* wgMaxKey;       // [nWG]
-  u32* wgFlags;        // [nWG] bit 0 NaN seen, bit 1 non-integer value seen
-  u64* wgFletcher;     // [2 * nWG] Fletcher partial sums of the bytes each workgroup wrote
+  u64* slotMinKey;     // [kFastSlots]
+  u64* slotMaxKey;     // [kFastSlots]
+  u32* slotFlags;      // [kFastSlots] bit 0 NaN seen, bit 1 non-integer value seen
+  u64* slotFletcher;   // [2 * kFastSlots] Fletcher partial sums of the bytes the workgroups wrote
   u32* scanScratch;
   double* row0RaiseErr;    // [9] TryRaiseMaxZError rounding errors of the first row (float types), or nullptr
   FastEncodeResult* result;
@@ -55,7 +65,7 @@ struct FastDecodeBuffers
   u32* chunkCount;     // [nChunks]
   u32* chunkBase;      // [nChunks + 1]
   u32* blockOff;       // [nBlocks + 1]
-  u64* wgFletcher;     // [2 * nWG]
+  u64* slotFletcher;   // [2 * kFastSlots]
   u64* fletcherOut;    // [2]
   u32* scanScratch;
   u32* fallback;       // != 0: the general path must redo the band

@@ -1,18 +1,21 @@
 // tile_fast.hip -- streaming encoder kernels for the common case (see tile_fast.h for the conditions).
 //
 // Same arithmetic and the same bytes as the general wave-per-block kernel in tile_encode.hip, arranged
-// for HBM bandwidth instead of generality:
+// for HBM bandwidth instead of generality (measured: the first version of these kernels was VALU-issue
+// bound at ~420 instructions per 4-block tile, profiles/r01_pmc_fast_v1.txt; this layout cuts that ~3x):
 //   * a lane owns V consecutive pixels of one raster row (one 16-byte global load); 8 / V lanes form a
 //     block row, 64 / V lanes an 8 x 8 block, so a wave64 covers 8 raster rows x 128 bytes -- whole
-//     cache lines per row -- and holds V blocks' worth of work in registers, no LDS staging of input
-//   * block statistics are butterfly reductions over the lanes of a block (xor 1/2 and 8/16/32)
-//   * a workgroup owns 64 consecutive blocks of a block row = one contiguous span of the output
-//     stream: it assembles the span in LDS with ds_or_b32 and flushes it with 16-byte stores
-//   * pass 1 (k_fast_stats) fuses the global statistics of Lerc::FilterNoDataAndNaN /
-//     Lerc2::ComputeMinMaxRanges with the size-only dry run of Lerc2::WriteTiles; pass 2
-//     (k_fast_pack) fuses the real write with the Fletcher32 sums of the bytes it stores
-//   * every decision the reference takes between its sweeps is taken by a one-workgroup kernel on the
-//     device (k_fast_decide), so an encode costs one host synchronisation
+//     cache lines per row -- with the pixels in registers (no LDS staging of the input)
+//   * per block only min / max / "same as previous" are reduced across lanes (butterflies over lane
+//     bits 0-1 and 3-5); everything the reference decides per block (NeedToQuantize, NumBytesTile,
+//     ReduceDataType) is evaluated ONCE per block with lane = block over the workgroup's 64 blocks
+//   * pass 1 (k_fast_stats) = global statistics of Lerc::FilterNoDataAndNaN / ComputeMinMaxRanges + the
+//     size-only dry run of Lerc2::WriteTiles; it leaves a 16-byte descriptor per block
+//   * pass 2 (k_fast_pack) reads pixels + descriptors, assembles the workgroup's contiguous output span
+//     in LDS with ds_or_b32 and flushes it with 16-byte stores, accumulating the Fletcher32 sums of the
+//     bytes it stores (word-wise)
+//   * the decisions the reference takes between its sweeps are taken on the device (k_fast_decide), so
+//     an encode costs one host synchronisation
 // Reference: Lerc2.cpp:1474-1668, :1717-1799, :1949-2021; Lerc2.h:337-453; BitStuffer2.cpp:35-153.
 #include "tile_fast.h"
 #include "kernels.h"
@@ -28,7 +31,7 @@ enum FastRedo : u32
 
 template<class T> struct FastCfg
 {
-  static constexpr int V = (sizeof(T) >= 4) ? 16 / (int)sizeof(T) : 8;    // pixels per lane: f32 4, f64 2, 16-bit 8, 8-bit 8
+  static constexpr int V = (sizeof(T) >= 4) ? 16 / (int)sizeof(T) : 8;    // pixels per lane: f32 4, f64 2, 16-bit 8
   static constexpr int LPR = 8 / V;                                      // lanes per block row
   static constexpr int BPW = 8 / LPR;                                    // blocks per wave tile
   static constexpr int TILE_COLS = 8 * V;                                // raster columns per wave tile
@@ -62,7 +65,6 @@ template<int LPR> __device__ __forceinline__ int groupSum(int v)
 }
 
 template<class T> __device__ __forceinline__ T shflT(T v, int src) { return (T)__shfl((typename ShflT<T>::type)v, src); }
-template<class T> __device__ __forceinline__ T gMinT(T v);
 
 template<class T> __device__ __forceinline__ bool notIntegral(T) { return false; }
 template<> __device__ __forceinline__ bool notIntegral<float>(float v) { return !(v == truncf(v)); }    // == !IsInt (Lerc.h:271) for finite v
@@ -70,14 +72,6 @@ template<> __device__ __forceinline__ bool notIntegral<double>(double v) { retur
 template<class T> __device__ __forceinline__ bool isNaNv(T) { return false; }
 template<> __device__ __forceinline__ bool isNaNv<float>(float v) { return v != v; }
 template<> __device__ __forceinline__ bool isNaNv<double>(double v) { return v != v; }
-
-template<class T> struct FBlock
-{
-  Plan pl;
-  T mn, mx;
-  u32 qMax;
-  bool quantOk;
-};
 
 // loads the V pixels of this lane (one aligned vector load)
 template<class T, int V>
@@ -90,12 +84,12 @@ __device__ __forceinline__ void loadLane(const T* __restrict__ p, T (&v)[V])
 }
 
 template<class T, int V>
-__device__ __forceinline__ void quantizeLane(const BandParams& p, const T (&v)[V], T mn, u32 (&q)[V])
+__device__ __forceinline__ void quantizeLane(int intLossless, double scale, const T (&v)[V], T mn, u32 (&q)[V])
 {
   const double z0 = (double)mn;
 #pragma unroll
   for (int k = 0; k < V; k++)
-    q[k] = p.intLossless ? quantLossless<T>(v[k], mn) : (u32)(((double)v[k] - z0) * p.scale + 0.5);
+    q[k] = intLossless ? quantLossless<T>(v[k], mn) : (u32)(((double)v[k] - z0) * scale + 0.5);
 }
 
 // number of distinct quantised values in each block of the wave (only meaningful where `need`)
@@ -118,51 +112,6 @@ __device__ __forceinline__ u32 groupDistinct(const u32 (&q)[V], bool need)
   return count;
 }
 
-// statistics + encoding decision of the block this lane belongs to (GetValidDataAndStats + NumBytesTile)
-template<class T, int V, int LPR>
-__device__ __forceinline__ FBlock<T> analyzeBlock(const BandParams& p, const T (&v)[V], int r, int h, int lane)
-{
-  FBlock<T> fb;
-  T mn = v[0], mx = v[0];
-#pragma unroll
-  for (int k = 1; k < V; k++) { mn = v[k] < mn ? v[k] : mn; mx = v[k] > mx ? v[k] : mx; }
-  typedef typename ShflT<T>::type ST;
-  mn = (T)groupMin<LPR>((ST)mn);
-  mx = (T)groupMax<LPR>((ST)mx);
-  // "same as previous" count in row-major block order, prevVal starts at 0 (Lerc2.cpp:1729-1758)
-  const int src = (h > 0) ? lane - 1 : lane - 8 + (LPR - 1);
-  T prev = shflT<T>(v[V - 1], src & 63);
-  if (r == 0 && h == 0) prev = T(0);
-  int same = (v[0] == prev) ? 1 : 0;
-#pragma unroll
-  for (int k = 1; k < V; k++) same += (v[k] == v[k - 1]) ? 1 : 0;
-  same = groupSum<LPR>(same);
-  const bool tryLut = ((double)mx > (double)mn + 3 * p.maxZErr) && (2 * same > 64);
-
-  double mv = 0;
-  bool quantOk = false;
-  if (p.maxZErr > 0)
-  {
-    mv = ((double)mx - (double)mn) * p.scale;
-    quantOk = !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
-  }
-  u32 qMax = quantOk ? (u32)(mv + 0.5) : 0u;    // == the largest quantised element (same expression as Quantize)
-  u32 nDistinct = 0;
-  const bool needLut = tryLut && quantOk;
-  if (__any(needLut))
-  {
-    u32 q[V];
-    quantizeLane<T, V>(p, v, mn, q);
-    nDistinct = groupDistinct<LPR, V>(q, needLut);
-  }
-  fb.pl = planBlock<T>(p, 64, mn, mx, p.dt, tryLut, mv, qMax, nDistinct);
-  fb.mn = mn; fb.mx = mx; fb.qMax = qMax; fb.quantOk = quantOk;
-  return fb;
-}
-
-// ------------------------------------------------------------------------------------------------
-// pass 1: global statistics + block sizes
-// ------------------------------------------------------------------------------------------------
 template<class T> struct FKey;
 template<> struct FKey<float> { static __device__ u64 enc(float v) { u32 b; memcpy(&b, &v, 4); b = (b & 0x80000000u) ? ~b : (b | 0x80000000u); return b; } };
 template<> struct FKey<double> { static __device__ u64 enc(double v) { u64 b; memcpy(&b, &v, 8); return (b >> 63) ? ~b : (b | (1ull << 63)); } };
@@ -170,27 +119,36 @@ template<> struct FKey<int> { static __device__ u64 enc(int v) { return (u64)((i
 template<> struct FKey<unsigned int> { static __device__ u64 enc(unsigned int v) { return (u64)v + (1ull << 62); } };
 template<> struct FKey<short> { static __device__ u64 enc(short v) { return (u64)((i64)v + (1ll << 62)); } };
 template<> struct FKey<unsigned short> { static __device__ u64 enc(unsigned short v) { return (u64)v + (1ull << 62); } };
-template<> struct FKey<signed char> { static __device__ u64 enc(signed char v) { return (u64)((i64)v + (1ll << 62)); } };
-template<> struct FKey<unsigned char> { static __device__ u64 enc(unsigned char v) { return (u64)v + (1ull << 62); } };
 
+template<class T> __device__ __forceinline__ u64 rawBits(T v) { u64 b = 0; memcpy(&b, &v, sizeof(T)); return b; }
+template<class T> __device__ __forceinline__ T fromRawBits(u64 b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
+
+// descriptor word 1: nBytes (16) | kind (3) << 16 | tc (2) << 19 | dtRed (3) << 21 | numBits (5) << 24
+__device__ __forceinline__ u32 packDesc(const Plan& pl, int nb) { return (u32)pl.nBytes | ((u32)pl.kind << 16) | ((u32)pl.tc << 19) | ((u32)pl.dtRed << 21) | ((u32)nb << 24); }
+
+// ------------------------------------------------------------------------------------------------
+// pass 1: global statistics + block decisions + sizes
+// ------------------------------------------------------------------------------------------------
 template<class T>
 __global__ void __launch_bounds__(256)
-k_fast_stats(const T* __restrict__ data, BandParams p, u32* __restrict__ wgSize, u64* __restrict__ wgMinKey, u64* __restrict__ wgMaxKey,
-             u32* __restrict__ wgFlags)
+k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict__ desc, u32* __restrict__ wgSize,
+             u64* __restrict__ slotMinKey, u64* __restrict__ slotMaxKey, u32* __restrict__ slotFlags)
 {
   typedef FastCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
-  __shared__ u32 s_sz[4];
-  __shared__ u64 s_mn[4], s_mx[4];
+  typedef typename ShflT<T>::type ST;
+  __shared__ T s_mn[kFastBlocksPerWG], s_mx[kFastBlocksPerWG];
+  __shared__ u32 s_same[kFastBlocksPerWG], s_nd[kFastBlocksPerWG];
   __shared__ u32 s_fl[4];
   const int w = waveId(), lane = laneId();
-  const int r = lane >> 3, c = lane & 7, h = c % LPR;
+  const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
   const int wgPerRow = p.nCols / (kFastBlocksPerWG * 8);
   const int it = (int)blockIdx.x / wgPerRow, wgc = (int)blockIdx.x - it * wgPerRow;
   const i64 rowBase = (i64)(it * 8 + r) * p.nCols + (i64)wgc * (kFastBlocksPerWG * 8);
+  const bool leader = (r == 0 && h == 0);
+  const int src = ((h > 0) ? lane - 1 : lane - 8 + (LPR - 1)) & 63;
 
-  u32 bytes = 0, flags = 0;
-  u64 kMin = ~0ull, kMax = 0ull;
+  u32 flags = 0;
 #pragma unroll
   for (int t = 0; t < C::IT; t++)
   {
@@ -202,26 +160,69 @@ k_fast_stats(const T* __restrict__ data, BandParams p, u32* __restrict__ wgSize,
 #pragma unroll
       for (int k = 0; k < V; k++) { if (isNaNv(v[k])) flags |= 1u; if (notIntegral(v[k])) flags |= 2u; }
     }
-    const FBlock<T> fb = analyzeBlock<T, V, LPR>(p, v, r, h, lane);
-    if (r == 0 && h == 0) bytes += (u32)fb.pl.nBytes;    // one lane per block contributes
-    const u64 a = FKey<T>::enc(fb.mn), b = FKey<T>::enc(fb.mx);
-    kMin = a < kMin ? a : kMin;
-    kMax = b > kMax ? b : kMax;
+    T mn = v[0], mx = v[0];
+#pragma unroll
+    for (int k = 1; k < V; k++) { mn = v[k] < mn ? v[k] : mn; mx = v[k] > mx ? v[k] : mx; }
+    mn = (T)groupMin<LPR>((ST)mn);
+    mx = (T)groupMax<LPR>((ST)mx);
+    // "same as previous" in row-major block order, prevVal starts at 0 (Lerc2.cpp:1729-1758)
+    T prev = shflT<T>(v[V - 1], src);
+    if (leader) prev = T(0);
+    int same = (v[0] == prev) ? 1 : 0;
+#pragma unroll
+    for (int k = 1; k < V; k++) same += (v[k] == v[k - 1]) ? 1 : 0;
+    same = groupSum<LPR>(same);
+    // LUT candidates need the number of distinct quantised values, which only the pixel owners can count
+    u32 nd = 0;
+    const bool tryLut = (2 * same > 64) && ((double)mx > (double)mn + 3 * p.maxZErr);
+    if (__any(tryLut))
+    {
+      const double mv = ((double)mx - (double)mn) * p.scale;
+      const bool need = tryLut && !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
+      u32 q[V];
+      quantizeLane<T, V>(p.intLossless, p.scale, v, mn, q);
+      nd = groupDistinct<LPR, V>(q, need);
+    }
+    if (leader)
+    {
+      const int blk = tile * BPW + b;
+      s_mn[blk] = mn; s_mx[blk] = mx; s_same[blk] = (u32)same; s_nd[blk] = nd;
+    }
   }
-  bytes = waveSum(bytes);
-  kMin = waveMin(kMin); kMax = waveMax(kMax);
   const bool f1 = __any(flags & 1u), f2 = __any(flags & 2u);
-  if (lane == 0) { s_sz[w] = bytes; s_mn[w] = kMin; s_mx[w] = kMax; s_fl[w] = (f1 ? 1u : 0u) | (f2 ? 2u : 0u); }
+  if (lane == 0) s_fl[w] = (f1 ? 1u : 0u) | (f2 ? 2u : 0u);
   __syncthreads();
-  if (threadIdx.x == 0)
+  if (w != 0) return;
+
+  // ---- lane = block: the per-block decisions of Lerc2::NumBytesTile, once
+  const T mn = s_mn[lane], mx = s_mx[lane];
+  const int same = (int)s_same[lane];
+  const bool tryLut = (2 * same > 64) && ((double)mx > (double)mn + 3 * p.maxZErr);
+  double mv = 0;
+  bool quantOk = false;
+  if (p.maxZErr > 0)
   {
-    wgSize[blockIdx.x] = s_sz[0] + s_sz[1] + s_sz[2] + s_sz[3];
-    u64 a = s_mn[0], b = s_mx[0];
-    for (int i = 1; i < 4; i++) { a = s_mn[i] < a ? s_mn[i] : a; b = s_mx[i] > b ? s_mx[i] : b; }
-    wgMinKey[blockIdx.x] = a; wgMaxKey[blockIdx.x] = b;
-    wgFlags[blockIdx.x] = s_fl[0] | s_fl[1] | s_fl[2] | s_fl[3];
+    mv = ((double)mx - (double)mn) * p.scale;
+    quantOk = !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
   }
-  (void)BPW;
+  const u32 qMax = quantOk ? (u32)(mv + 0.5) : 0u;    // == largest quantised element (same expression as Quantize)
+  const Plan pl = planBlock<T>(p, 64, mn, mx, p.dt, tryLut, mv, qMax, s_nd[lane]);
+  FastBlockDesc d;
+  d.mnBits = rawBits<T>(mn);
+  d.w1 = packDesc(pl, bitLen(qMax));
+  d.pad = 0;
+  desc[(size_t)blockIdx.x * kFastBlocksPerWG + lane] = d;
+  const u32 total = waveSum((u32)pl.nBytes);
+  const u64 kMin = waveMin(FKey<T>::enc(mn)), kMax = waveMax(FKey<T>::enc(mx));
+  if (lane == 0)
+  {
+    wgSize[blockIdx.x] = total;
+    const u32 slot = blockIdx.x & (kFastSlots - 1);
+    atomicMin(&slotMinKey[slot], kMin);
+    atomicMax(&slotMaxKey[slot], kMax);
+    const u32 fl = s_fl[0] | s_fl[1] | s_fl[2] | s_fl[3];
+    if (fl) atomicOr(&slotFlags[slot], fl);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -236,24 +237,17 @@ __device__ __forceinline__ double keyToDouble(int dt, u64 key, u64& raw)
   return (double)v;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 k_fast_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgBase,
-              const u64* __restrict__ wgMinKey, const u64* __restrict__ wgMaxKey, const u32* __restrict__ wgFlags,
+              const u64* __restrict__ slotMinKey, const u64* __restrict__ slotMaxKey, const u32* __restrict__ slotFlags,
               const double* __restrict__ row0RaiseErr, u8* __restrict__ out, u32 outCapacity, FastEncodeResult* res)
 {
-  __shared__ u64 s_mn[256], s_mx[256];
-  __shared__ u32 s_fl[256];
-  u64 a = ~0ull, b = 0ull;
-  u32 f = 0;
-  for (u32 i = threadIdx.x; i < nWG; i += 256)
-  {
-    const u64 x = wgMinKey[i], y = wgMaxKey[i];
-    a = x < a ? x : a; b = y > b ? y : b; f |= wgFlags[i];
-  }
-  s_mn[threadIdx.x] = a; s_mx[threadIdx.x] = b; s_fl[threadIdx.x] = f;
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  for (int i = 1; i < 256; i++) { a = s_mn[i] < a ? s_mn[i] : a; b = s_mx[i] > b ? s_mx[i] : b; f |= s_fl[i]; }
+  const int lane = laneId();
+  const u64 a = waveMin(slotMinKey[lane]), b = waveMax(slotMaxKey[lane]);
+  u32 f = slotFlags[lane];
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) f |= __shfl_xor(f, m);
+  if (lane != 0) return;
 
   u64 rawMin = 0, rawMax = 0;
   const double zMin = keyToDouble(p.dt, a, rawMin), zMax = keyToDouble(p.dt, b, rawMax);
@@ -324,18 +318,29 @@ __device__ __forceinline__ void orBits64(u32* words, u32 bitPos, u64 value, int 
   if (sh + (u32)nbits > 64) atomicOr(&words[w + 2], sh ? (hi >> (32 - sh)) : 0u);
 }
 
+// Fletcher terms of one little-endian 32-bit word whose first byte sits at an EVEN position `pos` of
+// the checksummed range: two big-endian 16-bit words w0 = b0 b1, w1 = b2 b3 with indices pos/2, pos/2 + 1
+__device__ __forceinline__ void fletcherWord(u32 x, u32 pos, u64& A, u64& B)
+{
+  const u32 w0 = ((x & 0xFFu) << 8) | ((x >> 8) & 0xFFu), w1 = ((x >> 8) & 0xFF00u) | (x >> 24);
+  const u32 k = pos >> 1;
+  A += w0 + w1;
+  B += (u64)k * w0 + (u64)(k + 1) * w1;
+}
+
 template<class T>
 __global__ void __launch_bounds__(256)
-k_fast_pack(const T* __restrict__ data, BandParams p, const u32* __restrict__ wgBase, u8* __restrict__ out,
-            u64* __restrict__ wgFletcher, const FastEncodeResult* __restrict__ res)
+k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __restrict__ desc, const u32* __restrict__ wgBase,
+            u8* __restrict__ out, u64* __restrict__ slotFletcher, const FastEncodeResult* __restrict__ res)
 {
   typedef FastCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW, IT = C::IT;
   constexpr int kMaxBlockBytes = 1 + 64 * (int)sizeof(T);
   constexpr int kSpanWords = (kFastBlocksPerWG * kMaxBlockBytes + 16) / 4 + 8;
   __shared__ __align__(16) u32 s_out[kSpanWords];
-  __shared__ u32 s_size[kFastBlocksPerWG];
-  __shared__ u32 s_off[kFastBlocksPerWG + 1];
+  __shared__ u64 s_mn[kFastBlocksPerWG];
+  __shared__ u32 s_w1[kFastBlocksPerWG];
+  __shared__ u32 s_bit[kFastBlocksPerWG];    // bit position of each block inside s_out
   __shared__ u64 s_fa[4], s_fb[4];
   if (res->redo) return;
 
@@ -348,103 +353,95 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const u32* __restrict__ wg
   const u32 spanLen = wgBase[blockIdx.x + 1] - wgBase[blockIdx.x];
   const u32 ldsShift = g0 & 15u;                            // LDS byte i <-> blob byte (g0 & ~15) + i
 
-  for (int i = threadIdx.x; i < kSpanWords; i += 256) s_out[i] = 0;
-
-  // ---- phase A: load, analyse, sizes
+  // pixels first (long latency), descriptors by wave 0, zero the span image meanwhile
   T v[IT][V];
-  FBlock<T> fb[IT];
 #pragma unroll
-  for (int t = 0; t < IT; t++)
-  {
-    const int tile = t * 4 + w;
-    loadLane<T, V>(data + rowBase + tile * C::TILE_COLS + c * V, v[t]);
-    fb[t] = analyzeBlock<T, V, LPR>(p, v[t], r, h, lane);
-    if (r == 0 && h == 0) s_size[tile * BPW + b] = (u32)fb[t].pl.nBytes;
-  }
-  __syncthreads();
+  for (int t = 0; t < IT; t++) loadLane<T, V>(data + rowBase + (t * 4 + w) * C::TILE_COLS + c * V, v[t]);
+  FastBlockDesc d;
+  if (w == 0) d = desc[(size_t)blockIdx.x * kFastBlocksPerWG + lane];
+  for (int i = threadIdx.x; i < kSpanWords; i += 256) s_out[i] = 0;
   if (w == 0)
   {
-    const u32 sz = s_size[lane];
+    const u32 sz = d.w1 & 0xFFFFu;
     u32 inc = sz;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += o; }
-    s_off[lane] = inc - sz;
-    if (lane == 63) s_off[64] = inc;
+    for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(inc, (unsigned)dd); if (lane >= dd) inc += o; }
+    s_mn[lane] = d.mnBits; s_w1[lane] = d.w1;
+    s_bit[lane] = 8u * (ldsShift + inc - sz);
   }
   __syncthreads();
 
-  // ---- phase B: write every block's bytes into the LDS image of the span
+  // ---- block headers: lane = block (Lerc2::WriteTile, BitStuffer2 stream header)
+  if (w == 0)
+  {
+    const u32 w1 = d.w1;
+    const int kind = (int)((w1 >> 16) & 7u), tc = (int)((w1 >> 19) & 3u), dtRed = (int)((w1 >> 21) & 7u), nb = (int)(w1 >> 24);
+    const int j0 = (wgc * kFastBlocksPerWG + lane) * 8;
+    u32 flag = (u32)(((j0 >> 3) & 15) << 2) & 0x38u;    // version 6, no slice difference
+    const u32 at0 = 8u * (ldsShift) + (s_bit[lane] - 8u * ldsShift);
+    if (kind == 0) orBits(s_out, at0, flag | 2u, 8);
+    else if (kind == 1) orBits(s_out, at0, flag, 8);
+    else
+    {
+      flag |= (kind == 2) ? 3u : 1u;
+      flag |= (u32)tc << 6;
+      const int offBytes = dtSize(dtRed);
+      orBits(s_out, at0, flag, 8);
+      orBits64(s_out, at0 + 8, typedBits((double)fromRawBits<T>(d.mnBits), dtRed), 8 * offBytes);
+      if (kind == 3) orBits(s_out, at0 + 8u * (1u + (u32)offBytes), (u32)nb | (2u << 6) | (64u << 8), 16);    // numBits byte, count 64
+    }
+  }
+
+  // ---- payloads
 #pragma unroll
   for (int t = 0; t < IT; t++)
   {
     const int tile = t * 4 + w;
     const int blk = tile * BPW + b;
-    const Plan& pl = fb[t].pl;
-    const int j0 = (wgc * kFastBlocksPerWG + blk) * 8;
-    u32 flag = (u32)(((j0 >> 3) & 15) << 2) & 0x38u;    // version 6, no slice difference
-    const u32 at0 = 8u * (ldsShift + s_off[blk]);        // bit position of the block inside s_out
-    const bool leader = (r == 0 && h == 0);
+    const u32 w1 = s_w1[blk];
+    const int kind = (int)((w1 >> 16) & 7u);
+    const u32 at0 = s_bit[blk];
     const int e0 = r * 8 + h * V;
-    if (pl.kind == 0) { if (leader) orBits(s_out, at0, flag | 2u, 8); }
-    else if (pl.kind == 1)
+    if (kind == 3)
     {
-      if (leader) orBits(s_out, at0, flag, 8);
+      const int nb = (int)(w1 >> 24);
+      const int offBytes = dtSize((int)((w1 >> 21) & 7u));
+      const T mn = fromRawBits<T>(s_mn[blk]);
+      u32 q[V];
+      quantizeLane<T, V>(p.intLossless, p.scale, v[t], mn, q);
+      const u32 at = at0 + 8u * (3u + (u32)offBytes);
+      if (V * nb <= 64)
+      {
+        u64 s = 0;
+#pragma unroll
+        for (int k = 0; k < V; k++) s |= (u64)q[k] << (k * nb);
+        orBits64(s_out, at + (u32)e0 * (u32)nb, s, V * nb);
+      }
+      else
+      {
+#pragma unroll
+        for (int k = 0; k < V; k += 2)
+          orBits64(s_out, at + (u32)(e0 + k) * (u32)nb, (u64)q[k] | ((u64)q[k + 1] << nb), 2 * nb);
+      }
+    }
+    else if (kind == 1)
+    {
 #pragma unroll
       for (int k = 0; k < V; k++)
-      {
-        u64 bits = 0;
-        const T tmp = v[t][k];
-        memcpy(&bits, &tmp, sizeof(T));
-        orBits64(s_out, at0 + 8u + (u32)(e0 + k) * 8u * (u32)sizeof(T), bits, 8 * (int)sizeof(T));
-      }
-    }
-    else
-    {
-      flag |= (pl.kind == 2) ? 3u : 1u;
-      flag |= (u32)pl.tc << 6;
-      const int offBytes = dtSize(pl.dtRed);
-      if (leader)
-      {
-        orBits(s_out, at0, flag, 8);
-        orBits64(s_out, at0 + 8, typedBits((double)fb[t].mn, pl.dtRed), 8 * offBytes);
-      }
-      if (pl.kind >= 3)
-      {
-        u32 q[V];
-        quantizeLane<T, V>(p, v[t], fb[t].mn, q);
-        const int nb = bitLen(fb[t].qMax);
-        u32 at = at0 + 8u * (1u + (u32)offBytes);
-        if (pl.kind == 3)
-        {
-          if (leader) orBits(s_out, at, (u32)nb | (2u << 6) | (64u << 8), 16);    // numBits byte, 1-byte count = 64
-          at += 16;
-          // V consecutive elements form one V * nb bit string
-          if (V * nb <= 64)
-          {
-            u64 s = 0;
-#pragma unroll
-            for (int k = 0; k < V; k++) s |= (u64)q[k] << (k * nb);
-            orBits64(s_out, at + (u32)e0 * (u32)nb, s, V * nb);
-          }
-          else
-          {
-#pragma unroll
-            for (int k = 0; k < V; k += 2)
-              orBits64(s_out, at + (u32)(e0 + k) * (u32)nb, (u64)q[k] | ((u64)q[k + 1] << nb), 2 * nb);
-          }
-        }
-      }
+        orBits64(s_out, at0 + 8u + (u32)(e0 + k) * 8u * (u32)sizeof(T), rawBits<T>(v[t][k]), 8 * (int)sizeof(T));
     }
     // LUT blocks (kind 4): all blocks of the wave take part in the group reductions
-    if (__any(pl.kind == 4))
+    if (__any(kind == 4))
     {
-      const bool mine = (pl.kind == 4);
+      const bool mine = (kind == 4);
+      const bool leader = (r == 0 && h == 0);
+      const T mn = fromRawBits<T>(s_mn[blk]);
       u32 q[V], idx[V];
-      quantizeLane<T, V>(p, v[t], fb[t].mn, q);
+      quantizeLane<T, V>(p.intLossless, p.scale, v[t], mn, q);
 #pragma unroll
       for (int k = 0; k < V; k++) idx[k] = 0;
-      const int nb = bitLen(fb[t].qMax);
-      const int offBytes = dtSize(pl.dtRed);
+      const int nb = (int)(w1 >> 24);
+      const int offBytes = dtSize((int)((w1 >> 21) & 7u));
       const u32 hdr = at0 + 8u * (1u + (u32)offBytes);
       const u32 lutAt = hdr + 24;    // numBits byte, count byte, nLut + 1 byte
       u32 count = 0, last = 0;
@@ -481,28 +478,36 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const u32* __restrict__ wg
   }
   __syncthreads();
 
-  // ---- flush: 16-byte chunks, byte granular at the two ends; Fletcher sums of the bytes we own
+  // ---- flush: 16-byte chunks, byte granular at the two ends; Fletcher sums of the bytes we own.
+  // Absolute blob offsets of chunk starts are multiples of 16, so positions inside blob[14 ..) are even.
   u64 A = 0, B = 0;
   const u32 gAligned = g0 & ~15u;
   const u32 nChunks = (ldsShift + spanLen + 15) >> 4;
-  const u8* lds8 = reinterpret_cast<const u8*>(s_out);
   for (u32 ch = threadIdx.x; ch < nChunks; ch += 256)
   {
     const u32 lo = ch * 16, hi = lo + 16;                                  // LDS byte range of this chunk
     const u32 first = lo < ldsShift ? ldsShift : lo;
     const u32 last = hi > ldsShift + spanLen ? ldsShift + spanLen : hi;    // owned bytes: [first, last)
-    const uint4 x = *reinterpret_cast<const uint4*>(&s_out[ch * 4]);
+    uint4 x = *reinterpret_cast<const uint4*>(&s_out[ch * 4]);
     if (first == lo && last == hi) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;
-    else for (u32 i = first; i < last; i++) out[gAligned + i] = lds8[i];
-    const u32 wd[4] = { x.x, x.y, x.z, x.w };
-    for (u32 i = first; i < last; i++)
+    else
     {
-      const u32 byte = (wd[(i - lo) >> 2] >> (8 * ((i - lo) & 3))) & 0xFFu;
-      const u32 pos = gAligned + i - 14;                                    // position inside the checksummed range
-      const u32 cw = byte << ((pos & 1u) ? 0 : 8);
-      A += cw;
-      B += (u64)(pos >> 1) * cw;
+      // partial chunk: store byte-wise and blank the bytes we do not own before summing
+      u32 wd[4] = { x.x, x.y, x.z, x.w };
+      for (u32 i = lo; i < hi; i++)
+      {
+        const u32 byte = (wd[(i - lo) >> 2] >> (8 * ((i - lo) & 3))) & 0xFFu;
+        if (i >= first && i < last) out[gAligned + i] = (u8)byte;
+        else wd[(i - lo) >> 2] &= ~(0xFFu << (8 * ((i - lo) & 3)));
+      }
+      x = make_uint4(wd[0], wd[1], wd[2], wd[3]);
     }
+    const u32 pos = gAligned + lo - 14 + 0;    // position of the chunk's first byte; may be "negative" only for lo < 14 of the first span
+    // gAligned + lo >= 16 > 14 always holds here because spans start behind the >= 95-byte prefix
+    fletcherWord(x.x, pos, A, B);
+    fletcherWord(x.y, pos + 4, A, B);
+    fletcherWord(x.z, pos + 8, A, B);
+    fletcherWord(x.w, pos + 12, A, B);
   }
   A %= 65535u; B %= 65535u;
   A = waveSum(A); B = waveSum(B);
@@ -510,29 +515,26 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const u32* __restrict__ wg
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    wgFletcher[2 * blockIdx.x] = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u;
-    wgFletcher[2 * blockIdx.x + 1] = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
+    const u32 slot = blockIdx.x & (kFastSlots - 1);
+    atomicAdd(&slotFletcher[2 * slot], (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u);
+    atomicAdd(&slotFletcher[2 * slot + 1], (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u);
   }
 }
 
-// checksum = Fletcher32 over blob[14 ..): the prefix bytes written by k_fast_decide + the workgroup sums
-__global__ void __launch_bounds__(256)
-k_fast_checksum(u32 nWG, const u64* __restrict__ wgFletcher, u8* __restrict__ out, FastEncodeResult* res)
+// checksum = Fletcher32 over blob[14 ..): the prefix bytes written by k_fast_decide + the slot sums
+__global__ void __launch_bounds__(64)
+k_fast_checksum(const u64* __restrict__ slotFletcher, u8* __restrict__ out, FastEncodeResult* res)
 {
-  __shared__ u64 s_a[256], s_b[256];
   if (res->redo) return;
-  u64 A = 0, B = 0;
-  for (u32 i = threadIdx.x; i < nWG; i += 256) { A += wgFletcher[2 * i]; B += wgFletcher[2 * i + 1]; }
-  for (u32 pos = threadIdx.x; pos + 14 < res->prefixLen; pos += 256)
+  const int lane = laneId();
+  u64 A = slotFletcher[2 * lane] % 65535u, B = slotFletcher[2 * lane + 1] % 65535u;
+  for (u32 pos = (u32)lane; pos + 14 < res->prefixLen; pos += 64)
   {
     const u32 cw = (u32)out[14 + pos] << ((pos & 1u) ? 0 : 8);
     A += cw; B += (u64)(pos >> 1) * cw;
   }
-  s_a[threadIdx.x] = A % 65535u; s_b[threadIdx.x] = B % 65535u;
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  A = 0; B = 0;
-  for (int i = 0; i < 256; i++) { A += s_a[i]; B += s_b[i]; }
+  A = waveSum(A % 65535u); B = waveSum(B % 65535u);
+  if (lane != 0) return;
   const u32 len = res->blobSize - 14;
   const u64 N = ((u64)len + 1) / 2;
   A %= 65535u; B %= 65535u;
@@ -542,6 +544,13 @@ k_fast_checksum(u32 nWG, const u64* __restrict__ wgFletcher, u8* __restrict__ ou
   const u32 cs = (u32)((s2 << 16) | s1);
   putBytes(out + 10, cs, 4);
   res->checksum = cs;
+}
+
+__global__ void __launch_bounds__(64) k_fast_init_slots(u64* slotMinKey, u64* slotMaxKey, u32* slotFlags, u64* slotFletcher)
+{
+  const int lane = laneId();
+  slotMinKey[lane] = ~0ull; slotMaxKey[lane] = 0ull; slotFlags[lane] = 0u;
+  slotFletcher[2 * lane] = 0ull; slotFletcher[2 * lane + 1] = 0ull;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -562,18 +571,21 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
 {
   const u32 nWG = fastEncodeNumWG(p.nRows, p.nCols);
   if (stage == 0)
-    hipLaunchKernelGGL(k_fast_stats<T>, dim3(nWG), dim3(256), 0, st, (const T*)data, p, b.wgSize, b.wgMinKey, b.wgMaxKey, b.wgFlags);
+  {
+    hipLaunchKernelGGL(k_fast_init_slots, dim3(1), dim3(64), 0, st, b.slotMinKey, b.slotMaxKey, b.slotFlags, b.slotFletcher);
+    hipLaunchKernelGGL(k_fast_stats<T>, dim3(nWG), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.slotMinKey, b.slotMaxKey, b.slotFlags);
+  }
   else if (stage == 1)
   {
     launchExclusiveScan(b.wgSize, b.wgBase, nWG, b.scanScratch, st);
-    hipLaunchKernelGGL(k_fast_decide, dim3(1), dim3(256), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgBase,
-                       (const u64*)b.wgMinKey, (const u64*)b.wgMaxKey, (const u32*)b.wgFlags, (const double*)b.row0RaiseErr, out, cap, b.result);
+    hipLaunchKernelGGL(k_fast_decide, dim3(1), dim3(64), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgBase,
+                       (const u64*)b.slotMinKey, (const u64*)b.slotMaxKey, (const u32*)b.slotFlags, (const double*)b.row0RaiseErr, out, cap, b.result);
   }
   else if (stage == 2)
-    hipLaunchKernelGGL(k_fast_pack<T>, dim3(nWG), dim3(256), 0, st, (const T*)data, p, (const u32*)b.wgBase, out, b.wgFletcher,
-                       (const FastEncodeResult*)b.result);
+    hipLaunchKernelGGL(k_fast_pack<T>, dim3(nWG), dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc, (const u32*)b.wgBase, out,
+                       b.slotFletcher, (const FastEncodeResult*)b.result);
   else
-    hipLaunchKernelGGL(k_fast_checksum, dim3(1), dim3(256), 0, st, nWG, (const u64*)b.wgFletcher, out, b.result);
+    hipLaunchKernelGGL(k_fast_checksum, dim3(1), dim3(64), 0, st, (const u64*)b.slotFletcher, out, b.result);
 }
 
 void launchFastEncode(int stage, const BandParams& assumed, double requestedMaxZErr, u32 raiseCandidates, const void* data, u8* out,

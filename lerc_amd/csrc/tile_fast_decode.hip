@@ -1,16 +1,17 @@
 // tile_fast_decode.hip -- streaming decoder kernels for the common case (one band, nDepth == 1, every
 // pixel valid, 8 x 8 blocks, nRows % 8 == 0, nCols % 512 == 0).  Same results as tile_decode.hip.
 //
-//   k_fast_walk     block-offset discovery, LDS staged: a workgroup stages 16 chunks of 4 KiB, tries every
+//   k_fast_walk     block-offset discovery, LDS staged: a workgroup stages a few 4 KiB chunks, tries every
 //                   position of each chunk's first `window` bytes as a block start (a few steps filter
 //                   out almost all of them), walks the survivors to the chunk end in LDS and records the
-//                   agreed exit plus (start, #blocks) of up to 8 survivors per chunk
+//                   agreed exit plus, per surviving start, the number of blocks up to the chunk end
 //   k_fast_resolve  entry of chunk c = agreed exit of chunk c-1; #blocks of the survivor that starts there
 //   k_fast_emit     one lane per chunk re-walks from the resolved entry and writes the block offsets
 //   k_fast_decode   a workgroup owns 64 consecutive blocks (8 rows x 512 columns): it stages their byte
-//                   span in LDS (accumulating the Fletcher32 sums of those bytes on the way), then every
-//                   lane extracts V consecutive pixels of one raster row, dequantises in double
-//                   precision (reference expression order) and stores one 16-byte vector
+//                   span in LDS (accumulating the Fletcher32 sums of those bytes word-wise), parses the 64
+//                   block headers once (lane = block), then every lane extracts V consecutive pixels of one
+//                   raster row, dequantises (double precision in the reference's expression order for
+//                   float types, exact integer arithmetic for integer types) and stores one 16-byte vector
 // Whenever a precondition fails (a block longer than its raw size, disagreeing survivors, ...) the
 // kernels raise `fallback`, and the host repeats the band with the general kernels.
 #include "tile_fast.h"
@@ -24,28 +25,30 @@ static const u32 kNoOffset = 0xFFFFFFFFu;
 struct BlkLite
 {
   u32 len, payload;
-  u8 flag, mode, tc, offBytes, nb, lut, dtUsed;
   u32 nLut;
+  u8 flag, mode, offBytes, nb, lut, dtUsed;
 };
 
-// Block header parser for all-valid 8 x 8 blocks (64 elements); `mem[pos]` may be LDS or global.
-// Returns false if no valid block starts at pos.  Mirrors Lerc2::ReadTile / BitStuffer2::Decode.
-template<int TBYTES>
-__device__ __forceinline__ bool parseLite(const u8* mem, u32 pos, u32 end, int dt, int version, BlkLite& b)
+// Block header parser for all-valid 8 x 8 blocks (64 elements) of data type DT; `mem[pos]` may be LDS
+// or global.  Returns false if no valid block starts at pos.  Mirrors Lerc2::ReadTile (Lerc2.cpp:2025-2110)
+// and BitStuffer2::Decode (BitStuffer2.cpp:159-258).
+template<int DT>
+__device__ __forceinline__ bool parseLite(const u8* mem, u32 pos, u32 end, int version, BlkLite& b)
 {
+  constexpr int TBYTES = (DT <= DT_Byte) ? 1 : (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
   if (pos >= end) return false;
   const u32 flag = mem[pos];
   b.flag = (u8)flag;
   if (version >= 5 && (flag & 4u)) return false;    // slice difference needs nDepth > 1
   b.mode = (u8)(flag & 3u);
-  b.tc = (u8)(flag >> 6);
-  b.offBytes = 0; b.nb = 0; b.lut = 0; b.nLut = 0; b.payload = 1; b.dtUsed = (u8)dt;
+  const int tc = (int)(flag >> 6);
+  b.offBytes = 0; b.nb = 0; b.lut = 0; b.nLut = 0; b.payload = 1; b.dtUsed = (u8)DT;
   u32 len = 1;
   if (b.mode == 2) { b.len = 1; return true; }
   if (b.mode == 0) len = 1 + 64 * TBYTES;
   else
   {
-    const int dtU = typeUsed(dt, b.tc);
+    const int dtU = typeUsed(DT, tc);
     if (dtU == DT_Undefined) return false;
     b.dtUsed = (u8)dtU;
     b.offBytes = (u8)dtSize(dtU);
@@ -86,15 +89,16 @@ __device__ __forceinline__ bool sigOk(u32 prev, u32 cur, u32 pattern)
   return cur == prev || cur == ((prev + step) & pattern) || cur == 0;
 }
 
-static const int kWalkChunksPerWG = 16;
+static const int kWalkChunksPerWG = 4;
 static const int kFilterSteps = 4;
-static const int kMaxSurvivors = 1024;
+static const int kMaxSurvivors = 448;
 
-template<int TBYTES>
+template<int DT>
 __global__ void __launch_bounds__(256)
-k_fast_walk(int dt, int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
+k_fast_walk(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
             u32* __restrict__ chunkExit, u16* __restrict__ countAt, u32* __restrict__ fallback)
 {
+  constexpr int TBYTES = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
   constexpr u32 W = kFastWindow(TBYTES);
   constexpr u32 kStage = kWalkChunksPerWG * kFastChunkBytes + W + 48;
   __shared__ __align__(16) u32 s_in[kStage / 4 + 4];
@@ -118,7 +122,7 @@ k_fast_walk(int dt, int version, FastWalkPlan wp, const u8* __restrict__ blob, u
   __syncthreads();
 
   const u8* mem = reinterpret_cast<const u8*>(s_in) - a0;    // mem[absolute offset]
-  const u32 readEnd = min(stageEnd, blobEnd);
+  const u32 readEnd = stageEnd;
   const u32 pattern = (version >= 5) ? 14u : 15u;
   const u32 nChunksHere = min((u32)kWalkChunksPerWG, wp.nChunks - c0);
 
@@ -136,7 +140,7 @@ k_fast_walk(int dt, int version, FastWalkPlan wp, const u8* __restrict__ blob, u
     for (int s = 0; s < kFilterSteps && cur < chunkEnd; s++)
     {
       BlkLite b;
-      if (!parseLite<TBYTES>(mem, cur, min(readEnd, blobEnd), dt, version, b)) { alive = false; break; }
+      if (!parseLite<DT>(mem, cur, readEnd, version, b)) { alive = false; break; }
       const u32 sg = ((u32)b.flag >> 2) & pattern;
       if (sig != kNoOffset && !sigOk(sig, sg, pattern)) { alive = false; break; }
       sig = sg; cur += b.len; count++;
@@ -162,7 +166,7 @@ k_fast_walk(int dt, int version, FastWalkPlan wp, const u8* __restrict__ blob, u
     while (cur < chunkEnd)
     {
       BlkLite b;
-      if (!parseLite<TBYTES>(mem, cur, readEnd, dt, version, b)) { alive = false; break; }
+      if (!parseLite<DT>(mem, cur, readEnd, version, b)) { alive = false; break; }
       const u32 sg = ((u32)b.flag >> 2) & pattern;
       if (!sigOk(sig, sg, pattern)) { alive = false; break; }
       sig = sg; cur += b.len; count++;
@@ -198,9 +202,9 @@ k_fast_resolve(FastWalkPlan wp, u32 window, u32 dataBegin, const u32* __restrict
   chunkCount[c] = n;
 }
 
-template<int TBYTES>
+template<int DT>
 __global__ void __launch_bounds__(256)
-k_fast_emit(int dt, int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
+k_fast_emit(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
             const u32* __restrict__ chunkEntry, const u32* __restrict__ chunkBase, u32* __restrict__ blockOff, u32* __restrict__ fallback)
 {
   if (*fallback) return;
@@ -213,7 +217,7 @@ k_fast_emit(int dt, int version, FastWalkPlan wp, const u8* __restrict__ blob, u
   while (cur < chunkEnd)
   {
     BlkLite b;
-    if (!parseLite<TBYTES>(blob, cur, blobEnd, dt, version, b) || i >= wp.nBlocks) { atomicOr(fallback, 8u); return; }
+    if (!parseLite<DT>(blob, cur, blobEnd, version, b) || i >= wp.nBlocks) { atomicOr(fallback, 8u); return; }
     blockOff[i++] = cur;
     cur += b.len;
   }
@@ -240,18 +244,41 @@ __device__ __forceinline__ u32 ldsBits(const u32* words, u32 bitPos, int nbits)
   return (u32)(x >> sh) & (nbits >= 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1u));
 }
 
+__device__ __forceinline__ void fletcherWordD(u32 x, u32 pos, u64& A, u64& B)
+{
+  const u32 w0 = ((x & 0xFFu) << 8) | ((x >> 8) & 0xFFu), w1 = ((x >> 8) & 0xFF00u) | (x >> 24);
+  const u32 k = pos >> 1;
+  A += w0 + w1;
+  B += (u64)k * w0 + (u64)(k + 1) * w1;
+}
+
+template<class T> __device__ __forceinline__ T dequant(double offset, u32 q, double invScale, double zMax, i64 offI, i64 invI, i64 zMaxI)
+{
+  if (DtOf<T>::v >= DT_Float)
+  {
+    const double z = offset + (double)q * invScale;    // Lerc2.cpp:2159-2160, no contraction
+    return (T)(z < zMax ? z : zMax);
+  }
+  // integer types: offset, 2 * maxZError and zMax are integers, the double expression is exact
+  const i64 z = offI + (i64)q * invI;
+  return (T)(z < zMaxI ? z : zMaxI);
+}
+
 template<class T>
 __global__ void __launch_bounds__(256)
 k_fast_decode(BandParams p, const u8* __restrict__ blob, u32 blobEnd, const u32* __restrict__ blockOff, T* __restrict__ outPix,
-              u64* __restrict__ wgFletcher, const u32* __restrict__ fallback, DeviceStatus* st)
+              u64* __restrict__ slotFletcher, const u32* __restrict__ fallback, DeviceStatus* st)
 {
   typedef DCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW, IT = C::IT;
+  constexpr int DT = DtOf<T>::v;
   constexpr int kSpanWords = (kFastBlocksPerWG * (1 + 64 * (int)sizeof(T)) + 32) / 4 + 8;
   __shared__ __align__(16) u32 s_in[kSpanWords];
   __shared__ u32 s_off[kFastBlocksPerWG + 1];
+  __shared__ u32 s_pbit[kFastBlocksPerWG];     // LDS bit position of the payload (bit stuffed) / first raw value
+  __shared__ u32 s_meta[kFastBlocksPerWG];     // mode | lut << 2 | numBits << 3 | nLut << 8 | ok << 31
+  __shared__ double s_offs[kFastBlocksPerWG];
   __shared__ u64 s_fa[4], s_fb[4];
-  __shared__ u32 s_bad;
   if (*fallback) return;
 
   const int w = waveId(), lane = laneId();
@@ -261,7 +288,6 @@ k_fast_decode(BandParams p, const u8* __restrict__ blob, u32 blobEnd, const u32*
   const u32 firstBlk = blockIdx.x * kFastBlocksPerWG;
 
   if (threadIdx.x <= kFastBlocksPerWG) s_off[threadIdx.x] = blockOff[firstBlk + threadIdx.x];
-  if (threadIdx.x == 0) s_bad = 0;
   __syncthreads();
   const u32 g0 = s_off[0], g1 = s_off[kFastBlocksPerWG];
   const u32 spanLen = g1 - g0;
@@ -287,17 +313,19 @@ k_fast_decode(BandParams p, const u8* __restrict__ blob, u32 blobEnd, const u32*
     }
     *reinterpret_cast<uint4*>(&s_in[ch * 4]) = x;
     const u32 lo = ch * 16;
-    const u32 first = lo < shift ? shift : lo;
-    const u32 last = (lo + 16 > shift + spanLen) ? shift + spanLen : lo + 16;
-    const u32 wd[4] = { x.x, x.y, x.z, x.w };
-    for (u32 i = first; i < last; i++)
+    if (lo < shift || lo + 16 > shift + spanLen)
     {
-      const u32 byte = (wd[(i - lo) >> 2] >> (8 * ((i - lo) & 3))) & 0xFFu;
-      const u32 pos = a0 + i - 14;
-      const u32 cw = byte << ((pos & 1u) ? 0 : 8);
-      A += cw;
-      B += (u64)(pos >> 1) * cw;
+      // first / last chunk: blank the neighbours' bytes before summing
+      u32 wd[4] = { x.x, x.y, x.z, x.w };
+      for (u32 i = lo; i < lo + 16; i++)
+        if (i < shift || i >= shift + spanLen) wd[(i - lo) >> 2] &= ~(0xFFu << (8 * ((i - lo) & 3)));
+      x = make_uint4(wd[0], wd[1], wd[2], wd[3]);
     }
+    const u32 pos = a0 + lo - 14;    // a0 + lo is a multiple of 16 and >= 16: even position inside blob[14 ..)
+    fletcherWordD(x.x, pos, A, B);
+    fletcherWordD(x.y, pos + 4, A, B);
+    fletcherWordD(x.z, pos + 8, A, B);
+    fletcherWordD(x.w, pos + 12, A, B);
   }
   A %= 65535u; B %= 65535u;
   A = waveSum(A); B = waveSum(B);
@@ -305,79 +333,91 @@ k_fast_decode(BandParams p, const u8* __restrict__ blob, u32 blobEnd, const u32*
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    wgFletcher[2 * blockIdx.x] = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u;
-    wgFletcher[2 * blockIdx.x + 1] = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
+    const u32 slot = blockIdx.x & (kFastSlots - 1);
+    atomicAdd(&slotFletcher[2 * slot], (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u);
+    atomicAdd(&slotFletcher[2 * slot + 1], (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u);
   }
 
+  // ---- parse the 64 block headers once: lane = block
   const u8* mem = reinterpret_cast<const u8*>(s_in) - a0;    // mem[absolute blob offset]
   const u32 pattern = (p.version >= 5) ? 14u : 15u;
+  if (w == 0)
+  {
+    const u32 off = s_off[lane];
+    const int j0 = (wgc * kFastBlocksPerWG + lane) * 8;
+    BlkLite bl;
+    bool ok = parseLite<DT>(mem, off, g1, p.version, bl);
+    ok = ok && (off + bl.len == s_off[lane + 1]) && ((((u32)bl.flag >> 2) & pattern) == (((u32)j0 >> 3) & pattern));
+    double offset = 0;
+    if (ok && (bl.mode == 1 || bl.mode == 3)) offset = typedFromBits(getBytes(mem + off + 1, bl.offBytes), bl.dtUsed);
+    s_offs[lane] = offset;
+    s_pbit[lane] = 8u * (off - a0 + bl.payload);
+    s_meta[lane] = ok ? ((u32)bl.mode | ((u32)bl.lut << 2) | ((u32)bl.nb << 3) | (bl.nLut << 8) | 0x80000000u) : 0u;
+    if (__any(!ok) && lane == 0) raiseError(st, kFailed, blockIdx.x);
+  }
+  __syncthreads();
+
   const i64 rowBase = (i64)(it * 8 + r) * p.nCols + (i64)wgc * (kFastBlocksPerWG * 8);
+  const i64 invI = (i64)p.invScale, zMaxI = (i64)p.zMaxHdr;
   bool bad = false;
 #pragma unroll
   for (int t = 0; t < IT; t++)
   {
     const int tile = t * 4 + w;
     const int blk = tile * BPW + b;
-    const u32 off = s_off[blk];
-    const int j0 = (wgc * kFastBlocksPerWG + blk) * 8;
-    BlkLite bl;
-    bool ok = parseLite<(int)sizeof(T)>(mem, off, g1, p.dt, p.version, bl);
-    ok = ok && (off + bl.len == s_off[blk + 1]) && ((((u32)bl.flag >> 2) & pattern) == (((u32)j0 >> 3) & pattern));
+    const u32 meta = s_meta[blk];
+    const u32 pbit = s_pbit[blk];
+    const double offset = s_offs[blk];
+    const int mode = (int)(meta & 3u);
+    const int e0 = r * 8 + h * V;
     T v[V];
 #pragma unroll
     for (int k = 0; k < V; k++) v[k] = T(0);
-    if (ok)
+    if (meta >> 31)
     {
-      const int e0 = r * 8 + h * V;
-      if (bl.mode == 0)
+      if (mode == 0)
       {
 #pragma unroll
         for (int k = 0; k < V; k++)
         {
-          const u64 bits = getBytes(mem + off + 1 + (u32)(e0 + k) * (u32)sizeof(T), (int)sizeof(T));
+          const u32 bp = pbit + (u32)(e0 + k) * 8u * (u32)sizeof(T);
+          u64 bits = ldsBits(s_in, bp, 32);
+          if (sizeof(T) == 8) bits |= (u64)ldsBits(s_in, bp + 32, 32) << 32;
+          else if (sizeof(T) < 4) bits &= (1ull << (8 * sizeof(T))) - 1;
           memcpy(&v[k], &bits, sizeof(T));
         }
       }
-      else if (bl.mode != 2)
+      else if (mode == 3)
       {
-        const double offset = typedFromBits(getBytes(mem + off + 1, bl.offBytes), bl.dtUsed);
-        if (bl.mode == 3)
+#pragma unroll
+        for (int k = 0; k < V; k++) v[k] = (T)offset;
+      }
+      else if (mode == 1)
+      {
+        const int nb = (int)((meta >> 3) & 31u);
+        const i64 offI = (i64)offset;
+        if (!((meta >> 2) & 1u))
         {
 #pragma unroll
-          for (int k = 0; k < V; k++) v[k] = (T)offset;
+          for (int k = 0; k < V; k++)
+            v[k] = dequant<T>(offset, ldsBits(s_in, pbit + (u32)(e0 + k) * (u32)nb, nb), p.invScale, p.zMaxHdr, offI, invI, zMaxI);
         }
         else
         {
-          const u32 payloadBit = 8u * (off - a0 + bl.payload);
-          const int nb = bl.nb;
-          if (!bl.lut)
-          {
+          const u32 nLut = (meta >> 8) & 0xFFu;
+          const int nbIdx = bitLen(nLut);
+          const u32 idxBit = pbit + 8u * ((nLut * (u32)nb + 7) >> 3);
 #pragma unroll
-            for (int k = 0; k < V; k++)
-            {
-              const u32 q = ldsBits(s_in, payloadBit + (u32)(e0 + k) * (u32)nb, nb);
-              const double z = offset + (double)q * p.invScale;
-              v[k] = (T)(z < p.zMaxHdr ? z : p.zMaxHdr);
-            }
-          }
-          else
+          for (int k = 0; k < V; k++)
           {
-            const int nbIdx = bitLen(bl.nLut);
-            const u32 idxBit = payloadBit + 8u * ((bl.nLut * (u32)nb + 7) >> 3);
-#pragma unroll
-            for (int k = 0; k < V; k++)
-            {
-              const u32 ix = ldsBits(s_in, idxBit + (u32)(e0 + k) * (u32)nbIdx, nbIdx);
-              if (ix > bl.nLut) { ok = false; continue; }
-              const u32 q = ix ? ldsBits(s_in, payloadBit + (ix - 1) * (u32)nb, nb) : 0u;
-              const double z = offset + (double)q * p.invScale;
-              v[k] = (T)(z < p.zMaxHdr ? z : p.zMaxHdr);
-            }
+            u32 ix = ldsBits(s_in, idxBit + (u32)(e0 + k) * (u32)nbIdx, nbIdx);
+            if (ix > nLut) { ix = 0; bad = true; }    // the reference would read outside its table here
+            const u32 q = ix ? ldsBits(s_in, pbit + (ix - 1) * (u32)nb, nb) : 0u;
+            v[k] = dequant<T>(offset, q, p.invScale, p.zMaxHdr, offI, invI, zMaxI);
           }
         }
       }
     }
-    if (!ok) bad = true;
     struct alignas(sizeof(T) * V) Vec { T e[V]; };
     Vec o;
 #pragma unroll
@@ -387,18 +427,11 @@ k_fast_decode(BandParams p, const u8* __restrict__ blob, u32 blobEnd, const u32*
   if (__any(bad) && lane == 0) raiseError(st, kFailed, blockIdx.x);
 }
 
-// sums the per-workgroup Fletcher partials; the host adds the prefix bytes it already holds
-__global__ void __launch_bounds__(256) k_fast_fletcher_sum(u32 nWG, const u64* __restrict__ wgFletcher, u64* __restrict__ out2)
+__global__ void __launch_bounds__(64) k_fast_fletcher_sum(u64* __restrict__ slotFletcher, u64* __restrict__ out2)
 {
-  __shared__ u64 s_a[256], s_b[256];
-  u64 A = 0, B = 0;
-  for (u32 i = threadIdx.x; i < nWG; i += 256) { A += wgFletcher[2 * i]; B += wgFletcher[2 * i + 1]; }
-  s_a[threadIdx.x] = A % 65535u; s_b[threadIdx.x] = B % 65535u;
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  A = 0; B = 0;
-  for (int i = 0; i < 256; i++) { A += s_a[i]; B += s_b[i]; }
-  out2[0] = A % 65535u; out2[1] = B % 65535u;
+  const int lane = laneId();
+  const u64 A = waveSum(slotFletcher[2 * lane] % 65535u), B = waveSum(slotFletcher[2 * lane + 1] % 65535u);
+  if (lane == 0) { out2[0] = A % 65535u; out2[1] = B % 65535u; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -419,16 +452,16 @@ FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 dataBegin, u32 blobEnd)
   return wp;
 }
 
-template<int TBYTES>
+template<int DT>
 static void launchFastWalkT(int stage, const BandParams& p, const FastWalkPlan& wp, const u8* blob, u32 dataBegin, u32 blobEnd,
                             const FastDecodeBuffers& b, hipStream_t st)
 {
+  constexpr int TBYTES = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
   if (stage == 0)
   {
     const u32 nWG = (wp.nChunks + kWalkChunksPerWG - 1) / kWalkChunksPerWG;
     hipMemsetAsync(b.countAt, 0xFF, (size_t)wp.nChunks * kFastWindow(TBYTES) * 2, st);
-    hipLaunchKernelGGL(k_fast_walk<TBYTES>, dim3(nWG), dim3(256), 0, st, p.dt, p.version, wp, blob, dataBegin, blobEnd, b.chunkExit,
-                       b.countAt, b.fallback);
+    hipLaunchKernelGGL(k_fast_walk<DT>, dim3(nWG), dim3(256), 0, st, p.version, wp, blob, dataBegin, blobEnd, b.chunkExit, b.countAt, b.fallback);
   }
   else if (stage == 1)
   {
@@ -437,41 +470,33 @@ static void launchFastWalkT(int stage, const BandParams& p, const FastWalkPlan& 
     launchExclusiveScan(b.chunkCount, b.chunkBase, wp.nChunks, b.scanScratch, st);
   }
   else
-    hipLaunchKernelGGL(k_fast_emit<TBYTES>, dim3((wp.nChunks + 255) / 256), dim3(256), 0, st, p.dt, p.version, wp, blob, dataBegin, blobEnd,
+    hipLaunchKernelGGL(k_fast_emit<DT>, dim3((wp.nChunks + 255) / 256), dim3(256), 0, st, p.version, wp, blob, dataBegin, blobEnd,
                        (const u32*)b.chunkEntry, (const u32*)b.chunkBase, b.blockOff, b.fallback);
 }
 
 template<class T>
-static void launchFastDecodeT(const BandParams& p, const u8* blob, u32 blobEnd, const FastDecodeBuffers& b, void* out, DeviceStatus* status,
-                              hipStream_t st)
+static void launchFastDecodeT(int stage, const BandParams& p, const FastWalkPlan& wp, const u8* blob, u32 dataBegin, u32 blobEnd,
+                              const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st)
 {
+  if (stage < 3) { launchFastWalkT<DtOf<T>::v>(stage, p, wp, blob, dataBegin, blobEnd, b, st); return; }
   const u32 nWG = fastEncodeNumWG(p.nRows, p.nCols);
-  hipLaunchKernelGGL(k_fast_decode<T>, dim3(nWG), dim3(256), 0, st, p, blob, blobEnd, (const u32*)b.blockOff, (T*)out, b.wgFletcher,
+  hipMemsetAsync(b.slotFletcher, 0, 2 * kFastSlots * 8, st);
+  hipLaunchKernelGGL(k_fast_decode<T>, dim3(nWG), dim3(256), 0, st, p, blob, blobEnd, (const u32*)b.blockOff, (T*)out, b.slotFletcher,
                      (const u32*)b.fallback, status);
-  hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1), dim3(256), 0, st, nWG, (const u64*)b.wgFletcher, b.fletcherOut);
+  hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1), dim3(64), 0, st, b.slotFletcher, b.fletcherOut);
 }
 
 void launchFastDecode(int stage, const BandParams& p, const FastWalkPlan& wp, const u8* blob, u32 dataBegin, u32 blobEnd,
                       const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st)
 {
-  if (stage < 3)
-  {
-    switch (dtSize(p.dt))
-    {
-      case 2: launchFastWalkT<2>(stage, p, wp, blob, dataBegin, blobEnd, b, st); break;
-      case 4: launchFastWalkT<4>(stage, p, wp, blob, dataBegin, blobEnd, b, st); break;
-      default: launchFastWalkT<8>(stage, p, wp, blob, dataBegin, blobEnd, b, st); break;
-    }
-    return;
-  }
   switch (p.dt)
   {
-    case DT_Short:  launchFastDecodeT<short>(p, blob, blobEnd, b, out, status, st); break;
-    case DT_UShort: launchFastDecodeT<unsigned short>(p, blob, blobEnd, b, out, status, st); break;
-    case DT_Int:    launchFastDecodeT<int>(p, blob, blobEnd, b, out, status, st); break;
-    case DT_UInt:   launchFastDecodeT<unsigned int>(p, blob, blobEnd, b, out, status, st); break;
-    case DT_Float:  launchFastDecodeT<float>(p, blob, blobEnd, b, out, status, st); break;
-    case DT_Double: launchFastDecodeT<double>(p, blob, blobEnd, b, out, status, st); break;
+    case DT_Short:  launchFastDecodeT<short>(stage, p, wp, blob, dataBegin, blobEnd, b, out, status, st); break;
+    case DT_UShort: launchFastDecodeT<unsigned short>(stage, p, wp, blob, dataBegin, blobEnd, b, out, status, st); break;
+    case DT_Int:    launchFastDecodeT<int>(stage, p, wp, blob, dataBegin, blobEnd, b, out, status, st); break;
+    case DT_UInt:   launchFastDecodeT<unsigned int>(stage, p, wp, blob, dataBegin, blobEnd, b, out, status, st); break;
+    case DT_Float:  launchFastDecodeT<float>(stage, p, wp, blob, dataBegin, blobEnd, b, out, status, st); break;
+    case DT_Double: launchFastDecodeT<double>(stage, p, wp, blob, dataBegin, blobEnd, b, out, status, st); break;
     default: break;
   }
 }
