@@ -91,8 +91,8 @@ LERC_AMD_API lerc_status lerc_decodeToDouble_4D(const unsigned char* pLercBlob, 
  * ---------------------------------------------------------------------------------------------- */
 typedef struct lerc_amd_context lerc_amd_context;
 
-/* hipStream: a hipStream_t cast to void* on which all work is enqueued, or NULL for a private
- * stream.  A context owns its scratch HBM; use one context per host thread. */
+/* hipStream: a hipStream_t cast to void* on which all work is enqueued; NULL is the HIP default
+ * (NULL) stream, with its usual ordering against other blocking streams.  A context owns its scratch HBM; use one context per host thread. */
 LERC_AMD_API lerc_amd_context* lerc_amd_create(void* hipStream);
 LERC_AMD_API void lerc_amd_destroy(lerc_amd_context* ctx);
 LERC_AMD_API void lerc_amd_set_stream(lerc_amd_context* ctx, void* hipStream);

@@ -165,7 +165,7 @@ def decode(lercBlob):
 
 # ---- device-pointer extension (torch tensors or raw device addresses) --------------------------------
 class DeviceCodec:
-    """One lerc_amd context bound to a HIP stream (default: the library's private stream)."""
+    """One lerc_amd context bound to a HIP stream (None / 0 = the HIP default stream)."""
 
     def __init__(self, stream_ptr=None):
         self.lib = load_library()

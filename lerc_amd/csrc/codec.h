@@ -39,8 +39,9 @@ public:
   ~Context();
   bool ok() const { return m_ok; }
   hipStream_t stream() const { return m_stream; }
-  void setStream(hipStream_t s) { m_userStream = s; }
-  hipStream_t activeStream() const { return m_userStream ? m_userStream : m_stream; }
+  // a caller-provided stream; nullptr means the HIP default (NULL) stream, exactly like a HIP API call would
+  void setStream(hipStream_t s) { m_userStream = s; m_userSet = true; }
+  hipStream_t activeStream() const { return m_userSet ? m_userStream : m_stream; }
 
   // bump allocation out of one device slab; reserve() may re-allocate (invalidates earlier pointers)
   bool reserve(size_t bytes);
@@ -72,6 +73,7 @@ private:
 
   bool m_ok = false;
   hipStream_t m_stream = nullptr, m_userStream = nullptr;
+  bool m_userSet = false;
   u8* m_slab = nullptr;
   size_t m_cap = 0, m_used = 0;
   void* m_pinned = nullptr;

@@ -22,10 +22,15 @@ struct BlobReader
   const u8* d;
   u32 n;
   hipStream_t st;
+  // bytes already fetched (the head of the current band): served without another device round trip
+  const u8* cache = nullptr;
+  u64 cacheOff = 0;
+  size_t cacheLen = 0;
   bool read(u64 off, size_t len, u8* dst) const
   {
     if (off + len > n) return false;
     if (h) { memcpy(dst, h + off, len); return true; }
+    if (cache && off >= cacheOff && off + len <= cacheOff + cacheLen) { memcpy(dst, cache + (off - cacheOff), len); return true; }
     if (hipMemcpyAsync(dst, d + off, len, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
     return hipStreamSynchronize(st) == hipSuccess;
   }
@@ -65,7 +70,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   const int tb = dtSize(dt);
   const i64 nPix = (i64)nRows * nCols;
   const size_t maskBytes = (size_t)((nPix + 7) >> 3);
-  BlobReader rd{ rq.hBlob, rq.dBlob, rq.blobSize, st };
+  BlobReader rd{ rq.hBlob, rq.dBlob, rq.blobSize, st, nullptr, 0, 0 };
 
   // ---- walk the band headers (Lerc::GetLercInfo) and check the caller's request against them
   std::vector<BandDesc> bands;
@@ -154,6 +159,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     if (hd.dt != dt) { ctx.lastError = "data type of the blob differs from the requested one"; return kFailed; }
     const u8* dBand = dBlob + bd.offset;
     const u32 blobEnd = (u32)hd.blobSize;
+    rd.cache = bd.head; rd.cacheOff = bd.offset; rd.cacheLen = bd.headLen;
     u8* dOutBand = (u8*)rq.dOut + (size_t)iBand * nPix * nD * tb;
 
     // Can the streaming kernels take this band?  (unmasked, nDepth 1, 8 x 8 tiling mode, friendly dimensions;
@@ -297,8 +303,6 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     bp.scale = hd.maxZErr > 0 ? 1 / (2 * hd.maxZErr) : 0;
     bp.invScale = 2 * hd.maxZErr;
     bp.zMaxHdr = hd.zMax;
-    hipMemcpyAsync(dZMax, zMaxVec.data(), (size_t)nD * 8, hipMemcpyHostToDevice, st);
-    hipStreamSynchronize(st);    // zMaxVec is a per-band temporary
 
     if (fastBand && fastDataBegin == (u32)(at - bd.offset))
     {
@@ -338,6 +342,9 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
       launchFletcher(dBand + 14, blobEnd - 14, dFl + (size_t)iBand * kFletcherPartials, st);
     }
 
+    hipMemcpyAsync(dZMax, zMaxVec.data(), (size_t)nD * 8, hipMemcpyHostToDevice, st);
+    hipStreamSynchronize(st);    // zMaxVec is a per-band temporary
+
     DecodeArgs da;
     da.blob = dBand; da.dataBegin = (u32)(at - bd.offset); da.blobEnd = blobEnd;
     da.maskBits = dMask; da.zMaxVec = dZMax; da.out = dOutBand;
@@ -364,28 +371,36 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   }
 
   // ---- one sync: kernel status + checksums
-  DeviceStatus hs;
-  std::vector<u64> hFl((size_t)kFletcherPartials * rq.nBands);
+  bool anyGeneric = false;
+  for (int iBand = 0; iBand < rq.nBands; iBand++) if (!fast[iBand].used) anyGeneric = true;
+  u8* pin = (u8*)ctx.pinned(sizeof(DeviceStatus) + (size_t)rq.nBands * 32 + 64);
+  if (!pin) return kFailed;
+  DeviceStatus& hs = *reinterpret_cast<DeviceStatus*>(pin);
+  u64* hFastPin = reinterpret_cast<u64*>(pin + 64);
+  std::vector<u64> hFl(anyGeneric ? (size_t)kFletcherPartials * rq.nBands : 0);
   hipMemcpyAsync(&hs, dStatus, sizeof(hs), hipMemcpyDeviceToHost, st);
-  hipMemcpyAsync(hFl.data(), dFl, hFl.size() * 8, hipMemcpyDeviceToHost, st);
-  std::vector<u64> hFast((size_t)2 * rq.nBands, 0);
-  std::vector<u32> hFallback(rq.nBands, 0);
+  if (anyGeneric) hipMemcpyAsync(hFl.data(), dFl, hFl.size() * 8, hipMemcpyDeviceToHost, st);
+  // per band 4 pinned u64: Fletcher A, B, fallback flag
+  u64* hFast = hFastPin;
   for (int iBand = 0; iBand < rq.nBands; iBand++)
+  {
+    hFast[4 * iBand] = hFast[4 * iBand + 1] = hFast[4 * iBand + 2] = 0;
     if (fast[iBand].used)
     {
-      hipMemcpyAsync(&hFast[(size_t)2 * iBand], fast[iBand].dFletcher2, 16, hipMemcpyDeviceToHost, st);
-      hipMemcpyAsync(&hFallback[iBand], fast[iBand].dFallback, 4, hipMemcpyDeviceToHost, st);
+      hipMemcpyAsync(&hFast[4 * iBand], fast[iBand].dFletcher2, 16, hipMemcpyDeviceToHost, st);
+      hipMemcpyAsync(&hFast[4 * iBand + 2], fast[iBand].dFallback, 4, hipMemcpyDeviceToHost, st);
     }
+  }
   if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
   if (ctx.profOn()) ctx.profCollect();
   for (int iBand = 0; iBand < rq.nBands; iBand++)
-    if (fast[iBand].used && hFallback[iBand]) { fellBack = true; return kOk; }    // caller repeats with the general kernels
+    if (fast[iBand].used && (u32)hFast[4 * iBand + 2]) { fellBack = true; return kOk; }    // caller repeats with the general kernels
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
     if (bands[iBand].hd.version < 3) continue;
     if (fast[iBand].used)
     {
-      const u64 A = hFast[(size_t)2 * iBand] + fast[iBand].prefixA, B = hFast[(size_t)2 * iBand + 1] + fast[iBand].prefixB;
+      const u64 A = hFast[4 * iBand] + fast[iBand].prefixA, B = hFast[4 * iBand + 1] + fast[iBand].prefixB;
       if (fletcherFinish(A, B, checksumLen[iBand]) != expectChecksum[iBand]) return kFailed;
       continue;
     }

@@ -442,7 +442,9 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
       ProfScope ps(ctx, kStage[stage]);
       launchFastEncode(stage, bp, rq.maxZErr, cand, rq.dData, rq.dOut, rq.outCapacity, fb, st);
     }
-    FastEncodeResult hres;
+    FastEncodeResult* pinRes = (FastEncodeResult*)ctx.pinned(sizeof(FastEncodeResult));
+    if (!pinRes) return kFailed;
+    FastEncodeResult& hres = *pinRes;
     hipMemcpyAsync(&hres, fb.result, sizeof(hres), hipMemcpyDeviceToHost, st);
     if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
     if (ctx.profOn()) ctx.profCollect();

@@ -356,7 +356,8 @@ void launchBandStats(int dt, const void* data, const u8* maskBits, int nRows, in
   const double maxZErr = 0;
   const i64 nPix = (i64)nRows * nCols;
   const i64 nElem = nPix * nDepth;
-  i64 nBlocks = (nElem + 256 * 16 - 1) / (256 * 16);
+  const i64 perBlock = nElem < (1 << 20) ? 256 : 256 * 16;    // small inputs (e.g. one row): one element per thread
+  i64 nBlocks = (nElem + perBlock - 1) / perBlock;
   if (nBlocks > 4096) nBlocks = 4096;
   if (nBlocks < 1) nBlocks = 1;
   const dim3 grid((unsigned)nBlocks), block(256);
