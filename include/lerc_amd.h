@@ -113,6 +113,11 @@ LERC_AMD_API lerc_status lerc_amd_decode_device(lerc_amd_context* ctx, const uns
 LERC_AMD_API void lerc_amd_profile_enable(lerc_amd_context* ctx, int on);
 LERC_AMD_API int lerc_amd_profile_read(lerc_amd_context* ctx, char* buf, int cap, int reset);
 
+/* Which kernels served the successful calls of a context so far: out[0] encodes by the streaming kernels, out[1]
+ * encodes by the general kernels, out[2] / out[3] the same for decodes.  ctx == NULL: the calling thread's context
+ * behind lerc_encode / lerc_decode.  Diagnostics only (tests assert that the streaming path really ran). */
+LERC_AMD_API void lerc_amd_path_counters(lerc_amd_context* ctx, unsigned long long out[4]);
+
 /* library / build identification: "lerc_amd <version> gfx950 hip" (or "... hipsim" for the CPU test build) */
 LERC_AMD_API const char* lerc_amd_build_info(void);
 

@@ -328,6 +328,12 @@ int lerc_amd_profile_read(lerc_amd_context* h, char* buf, int cap, int reset)
   return n;
 }
 
+void lerc_amd_path_counters(lerc_amd_context* h, unsigned long long out[4])
+{
+  if (!h) h = threadHandle();    // the context behind the stock host-pointer entry points of this thread
+  for (int i = 0; i < 4; i++) out[i] = h ? h->ctx.pathCount[i] : 0;
+}
+
 const char* lerc_amd_build_info(void)
 {
 #ifdef HIPSIM

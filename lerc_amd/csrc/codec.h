@@ -54,6 +54,10 @@ public:
 
   std::string lastError;
 
+  // which kernels served the calls so far: [0] encode streaming, [1] encode general, [2] decode streaming, [3] decode general
+  unsigned long long pathCount[4] = { 0, 0, 0, 0 };
+  bool lastDecodeStreamed = false;
+
   // optional per-kernel timing with HIP events on the active stream (bench.py: roofline of the dominant kernel)
   void profEnable(bool on) { m_prof = on; }
   bool profOn() const { return m_prof; }

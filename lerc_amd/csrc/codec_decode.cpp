@@ -65,6 +65,7 @@ bool readBandHeader(const BlobReader& rd, u64 off, BandDesc& b)
 static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, bool& fellBack)
 {
   fellBack = false;
+  ctx.lastDecodeStreamed = false;
   hipStream_t st = ctx.activeStream();
   const int dt = rq.dt, nD = rq.nDepth, nCols = rq.nCols, nRows = rq.nRows;
   const int tb = dtSize(dt);
@@ -123,7 +124,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     maxChunks = std::max(maxChunks, (size_t)h.blobSize / 4096 + 2);
   }
   need += maxSub * 4 + maxSub / nD * 2 + 5 * (maxChunks + 1024) * 4 + (dt <= DT_Byte ? huffmanScratchBytes(nPix, nD) : 0);
-  need += (maxChunks + 16) * (size_t)kFastWindow(8) * 2 + (size_t)(nPix / 4096 + 64) * 16 + 4096;    // streaming path tables
+  need += (maxChunks + 16) * ((size_t)kFastWindow(8) * 2 + kFastSubPerChunk * 4) + (size_t)(nPix / 4096 + 64) * 16 + 4096;    // streaming path tables
   if (!ctx.reserve(need)) return kFailed;
 
   const u8* dBlob = rq.dBlob;
@@ -313,21 +314,22 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
       fbuf.chunkEntry = ctx.allocT<u32>(fwp.nChunks + 4);
       fbuf.chunkCount = ctx.allocT<u32>(fwp.nChunks + 4);
       fbuf.chunkBase = ctx.allocT<u32>(fwp.nChunks + 4);
-      fbuf.blockOff = ctx.allocT<u32>((size_t)fwp.nBlocks + 4);
+      fbuf.subEntry = ctx.allocT<u32>((size_t)fwp.nChunks * kFastSubPerChunk + 4);
       fbuf.slotFletcher = ctx.allocT<u64>(2 * kFastSlots);
       fbuf.fletcherOut = ctx.allocT<u64>(2);
       fbuf.scanScratch = ctx.allocT<u32>(fwp.nChunks / 1024 + 8);
       fbuf.fallback = ctx.allocT<u32>(4);
-      if (!fbuf.chunkExit || !fbuf.countAt || !fbuf.chunkEntry || !fbuf.chunkCount || !fbuf.chunkBase || !fbuf.blockOff
+      if (!fbuf.chunkExit || !fbuf.countAt || !fbuf.chunkEntry || !fbuf.chunkCount || !fbuf.chunkBase || !fbuf.subEntry
         || !fbuf.slotFletcher || !fbuf.fletcherOut || !fbuf.scanScratch || !fbuf.fallback) return kFailed;
       hipMemsetAsync(fbuf.fallback, 0, 16, st);
-      static const char* kStage[4] = { "fast_walk", "fast_resolve_scan", "fast_emit_offsets", "fast_decode" };
-      for (int stage = 0; stage < 4; stage++)
+      static const char* kStage[3] = { "fast_walk", "fast_resolve_scan", "fast_decode" };
+      for (int stage = 0; stage < 3; stage++)
       {
         ProfScope ps(ctx, kStage[stage]);
         launchFastDecode(stage, bp, fwp, dBand, fastDataBegin, blobEnd, fbuf, dOutBand, dStatus, st);
       }
       FastBand& f = fast[iBand];
+      ctx.lastDecodeStreamed = true;
       f.used = true; f.dFletcher2 = fbuf.fletcherOut; f.dFallback = fbuf.fallback;
       for (u32 pos = 0; pos + 14 < fastDataBegin; pos++)    // Fletcher terms of the bytes before the first block
       {
@@ -416,7 +418,9 @@ u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
 {
   bool fellBack = false;
   u32 rc = decodeImpl(ctx, rq, true, fellBack);
-  if (rc == kOk && fellBack) rc = decodeImpl(ctx, rq, false, fellBack);
+  const bool repeated = (rc == kOk && fellBack);
+  if (repeated) rc = decodeImpl(ctx, rq, false, fellBack);
+  if (rc == kOk) ctx.pathCount[(repeated || !ctx.lastDecodeStreamed) ? 3 : 2]++;
   return rc;
 }
 

@@ -450,6 +450,7 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
     if (ctx.profOn()) ctx.profCollect();
     if (!hres.redo)
     {
+      ctx.pathCount[0]++;
       numBytesNeeded = numBytesWritten = hres.blobSize;
       return kOk;
     }
@@ -457,6 +458,7 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
     ctx.reset();
   }
 
+  ctx.pathCount[1]++;
   MaskState ms;
   ms.dBits = ctx.allocT<u8>(maskBytes);
   std::vector<u8> prevValid;

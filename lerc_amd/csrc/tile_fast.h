@@ -52,6 +52,8 @@ void launchFastEncode(int stage, const BandParams& assumed, double requestedMaxZ
 
 // ---- decode side ---------------------------------------------------------------------------------
 static const u32 kFastChunkBytes = 4096;
+static const u32 kFastSubBytes = 512;      // the walk also records the first block start behind every sub-chunk boundary
+static const int kFastSubPerChunk = (int)(kFastChunkBytes / kFastSubBytes);
 // longest block the streaming walk accepts: the raw form (the reference encoder never emits a longer one)
 constexpr u32 kFastWindow(int typeBytes) { return 2u + 64u * (u32)typeBytes; }
 
@@ -64,7 +66,7 @@ struct FastDecodeBuffers
   u32* chunkEntry;     // [nChunks]
   u32* chunkCount;     // [nChunks]
   u32* chunkBase;      // [nChunks + 1]
-  u32* blockOff;       // [nBlocks + 1]
+  u32* subEntry;       // [nChunks * kFastSubPerChunk] agreed first block start at / behind a sub-chunk boundary, or ~0
   u64* slotFletcher;   // [2 * kFastSlots]
   u64* fletcherOut;    // [2]
   u32* scanScratch;
@@ -73,7 +75,7 @@ struct FastDecodeBuffers
 
 bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid);
 FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 dataBegin, u32 blobEnd);
-// stage 0: chunk walk; 1: resolve + scan; 2: emit block offsets; 3: decode + Fletcher sums
+// stage 0: chunk walk; 1: resolve + scan; 2: decode + Fletcher sums
 void launchFastDecode(int stage, const BandParams& p, const FastWalkPlan& wp, const u8* blob, u32 dataBegin, u32 blobEnd,
                       const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st);
 

@@ -53,6 +53,15 @@ class LercLib:
                      "lerc_decodeToDouble_4D"):
             getattr(L, name).restype = ct.c_uint
 
+    def path_counters(self):
+        """lerc_amd only: (encode streaming, encode general, decode streaming, decode general) call counts of
+        this thread's context behind the stock entry points."""
+        out = (ct.c_ulonglong * 4)()
+        self.lib.lerc_amd_path_counters.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+        self.lib.lerc_amd_path_counters.restype = None
+        self.lib.lerc_amd_path_counters(None, out)
+        return tuple(int(v) for v in out)
+
     # ------------------------------------------------------------------ helpers
     @staticmethod
     def _dims(arr, n_depth, n_bands):

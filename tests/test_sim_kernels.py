@@ -116,3 +116,40 @@ def test_sim_streaming_path(libs, idx):
     if r1 == 0:
         d1, d2 = O.decode(b1), S.decode(b1)
         assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1])
+
+
+def _multi_chunk_cases():
+    """Streams of many 4 KiB chunks: the walk has to agree on chunk exits and sub-chunk entries."""
+    rng = np.random.default_rng(5)
+    out = []
+    for dt in (np.float32, np.uint16, np.int32, np.float64):
+        kind = np.dtype(dt).kind
+        x = cases.terrain(64, 1024, rng, amp=300, base=1000, sigma=1.5)
+        out.append((f"chunks-terrain-{np.dtype(dt).name}", cases._cast(x, dt), 0.01 if kind == "f" else 0, True))
+        out.append((f"chunks-mixed-{np.dtype(dt).name}", cases.mixed_regions(64, 1024, rng, dt), 2.0, True))
+    z = np.zeros((128, 1024), np.float32)
+    z[40:56, 100:400] = cases.terrain(16, 300, rng).astype(np.float32)
+    out.append(("chunks-sparse-f32", z, 0.01, False))       # thousands of 1-byte blocks per chunk: general kernels
+    zr = cases.terrain(64, 1024, rng).astype(np.float32)
+    zr[::8, ::8] *= 1e20
+    out.append(("chunks-raw-f32", zr, 0.01, False))          # raw blocks: too many plausible block starts
+    return out
+
+
+_CHUNKS = _multi_chunk_cases()
+
+
+@pytest.mark.parametrize("idx", range(len(_CHUNKS)), ids=[c[0] for c in _CHUNKS])
+def test_sim_streaming_decode_many_chunks(libs, idx):
+    O, S = libs
+    name, arr, e, expect_streamed = _CHUNKS[idx]
+    r1, b1 = O.encode(arr, e)
+    r2, b2 = S.encode(arr, e)
+    assert r1 == r2 == 0 and b1 == b2
+    c0 = S.path_counters()
+    d2 = S.decode(b1)
+    c1 = S.path_counters()
+    d1 = O.decode(b1)
+    assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1])
+    if expect_streamed:
+        assert c1[2] == c0[2] + 1, "the streaming decode kernels fell back to the general path"
