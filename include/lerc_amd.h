@@ -117,6 +117,8 @@ LERC_AMD_API int lerc_amd_profile_read(lerc_amd_context* ctx, char* buf, int cap
  * encodes by the general kernels, out[2] / out[3] the same for decodes.  ctx == NULL: the calling thread's context
  * behind lerc_encode / lerc_decode.  Diagnostics only (tests assert that the streaming path really ran). */
 LERC_AMD_API void lerc_amd_path_counters(lerc_amd_context* ctx, unsigned long long out[4]);
+/* why the last call that left the streaming kernels did so ("" if none did); same ctx convention */
+LERC_AMD_API const char* lerc_amd_last_note(lerc_amd_context* ctx);
 
 /* library / build identification: "lerc_amd <version> gfx950 hip" (or "... hipsim" for the CPU test build) */
 LERC_AMD_API const char* lerc_amd_build_info(void);

@@ -27,7 +27,8 @@ class LercError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "csrc", "liblerc_amd.so")
+    # LERC_AMD_LIBRARY: another build of the same HIP sources (e.g. csrc/_probe/liblerc_amd_probe.so, the tuning build)
+    return os.environ.get("LERC_AMD_LIBRARY") or os.path.join(_HERE, "csrc", "liblerc_amd.so")
 
 
 def load_library():

@@ -328,6 +328,12 @@ int lerc_amd_profile_read(lerc_amd_context* h, char* buf, int cap, int reset)
   return n;
 }
 
+const char* lerc_amd_last_note(lerc_amd_context* h)
+{
+  if (!h) h = threadHandle();
+  return h ? h->ctx.lastNote.c_str() : "";
+}
+
 void lerc_amd_path_counters(lerc_amd_context* h, unsigned long long out[4])
 {
   if (!h) h = threadHandle();    // the context behind the stock host-pointer entry points of this thread

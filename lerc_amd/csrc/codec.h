@@ -53,6 +53,7 @@ public:
   void* pinned(size_t bytes);
 
   std::string lastError;
+  std::string lastNote;      // diagnostics that are not errors (why a call left the streaming path)
 
   // which kernels served the calls so far: [0] encode streaming, [1] encode general, [2] decode streaming, [3] decode general
   unsigned long long pathCount[4] = { 0, 0, 0, 0 };

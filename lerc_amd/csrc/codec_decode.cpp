@@ -124,7 +124,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     maxChunks = std::max(maxChunks, (size_t)h.blobSize / 4096 + 2);
   }
   need += maxSub * 4 + maxSub / nD * 2 + 5 * (maxChunks + 1024) * 4 + (dt <= DT_Byte ? huffmanScratchBytes(nPix, nD) : 0);
-  need += (maxChunks + 16) * ((size_t)kFastWindow(8) * 2 + kFastSubPerChunk * 4) + (size_t)(nPix / 4096 + 64) * 16 + 4096;    // streaming path tables
+  need += (maxChunks + 16) * ((size_t)kFastListCap * 8 + kFastSubPerChunk * 8 + kFastChainsPerChunk * sizeof(FastChain) + 64) + (size_t)(nPix / 4096 + 64) * 16 + 4096;    // streaming path tables
   if (!ctx.reserve(need)) return kFailed;
 
   const u8* dBlob = rq.dBlob;
@@ -309,21 +309,26 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     {
       const FastWalkPlan fwp = makeFastWalkPlan(nRows, nCols, fastDataBegin, blobEnd);
       FastDecodeBuffers fbuf;
-      fbuf.chunkExit = ctx.allocT<u32>(fwp.nChunks + 4);
-      fbuf.countAt = ctx.allocT<u16>((size_t)fwp.nChunks * kFastWindow(tb) + 8);
+      fbuf.chunkListN = ctx.allocT<u32>(fwp.nChunks + 4);
+      fbuf.chunkList = ctx.allocT<u64>((size_t)fwp.nChunks * kFastListCap + 4);
+      fbuf.chains = ctx.allocT<FastChain>((size_t)fwp.chainCap + 4);
+      fbuf.chainCount = ctx.allocT<u32>(4);
       fbuf.chunkEntry = ctx.allocT<u32>(fwp.nChunks + 4);
       fbuf.chunkCount = ctx.allocT<u32>(fwp.nChunks + 4);
       fbuf.chunkBase = ctx.allocT<u32>(fwp.nChunks + 4);
       fbuf.subEntry = ctx.allocT<u32>((size_t)fwp.nChunks * kFastSubPerChunk + 4);
+      fbuf.subIndex = ctx.allocT<u32>((size_t)fwp.nChunks * kFastSubPerChunk + 4);
+      fbuf.blockOff = ctx.allocT<u32>((size_t)fwp.nBlocks + 4);
       fbuf.slotFletcher = ctx.allocT<u64>(2 * kFastSlots);
       fbuf.fletcherOut = ctx.allocT<u64>(2);
       fbuf.scanScratch = ctx.allocT<u32>(fwp.nChunks / 1024 + 8);
       fbuf.fallback = ctx.allocT<u32>(4);
-      if (!fbuf.chunkExit || !fbuf.countAt || !fbuf.chunkEntry || !fbuf.chunkCount || !fbuf.chunkBase || !fbuf.subEntry
-        || !fbuf.slotFletcher || !fbuf.fletcherOut || !fbuf.scanScratch || !fbuf.fallback) return kFailed;
+      if (!fbuf.chunkListN || !fbuf.chunkList || !fbuf.chains || !fbuf.chainCount || !fbuf.chunkEntry || !fbuf.chunkCount
+        || !fbuf.chunkBase || !fbuf.subEntry || !fbuf.subIndex || !fbuf.blockOff || !fbuf.slotFletcher || !fbuf.fletcherOut || !fbuf.scanScratch
+        || !fbuf.fallback) return kFailed;
       hipMemsetAsync(fbuf.fallback, 0, 16, st);
-      static const char* kStage[3] = { "fast_walk", "fast_resolve_scan", "fast_decode" };
-      for (int stage = 0; stage < 3; stage++)
+      static const char* kStage[kFastDecodeStages] = { "fast_candidates", "fast_chains", "fast_resolve_scan", "fast_emit_offsets", "fast_decode" };
+      for (int stage = 0; stage < kFastDecodeStages; stage++)
       {
         ProfScope ps(ctx, kStage[stage]);
         launchFastDecode(stage, bp, fwp, dBand, fastDataBegin, blobEnd, fbuf, dOutBand, dStatus, st);
@@ -396,7 +401,14 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
   if (ctx.profOn()) ctx.profCollect();
   for (int iBand = 0; iBand < rq.nBands; iBand++)
-    if (fast[iBand].used && (u32)hFast[4 * iBand + 2]) { fellBack = true; return kOk; }    // caller repeats with the general kernels
+    if (fast[iBand].used && (u32)hFast[4 * iBand + 2])    // caller repeats with the general kernels
+    {
+      char msg[96];
+      snprintf(msg, sizeof(msg), "streaming decode handed band %d to the general kernels (reason bits 0x%x)", iBand, (u32)hFast[4 * iBand + 2]);
+      ctx.lastNote = msg;
+      fellBack = true;
+      return kOk;
+    }
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
     if (bands[iBand].hd.version < 3) continue;

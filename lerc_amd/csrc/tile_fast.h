@@ -52,21 +52,39 @@ void launchFastEncode(int stage, const BandParams& assumed, double requestedMaxZ
 
 // ---- decode side ---------------------------------------------------------------------------------
 static const u32 kFastChunkBytes = 4096;
-static const u32 kFastSubBytes = 512;      // the walk also records the first block start behind every sub-chunk boundary
+static const u32 kFastSubBytes = 512;      // the chains also note the first block start behind every sub-chunk boundary
 static const int kFastSubPerChunk = (int)(kFastChunkBytes / kFastSubBytes);
+static const int kFastListCap = 64;        // surviving block-start candidates listed per chunk
+static const int kFastChainsPerChunk = 16; // capacity of the chain array per chunk (a handful in practice)
 // longest block the streaming walk accepts: the raw form (the reference encoder never emits a longer one)
 constexpr u32 kFastWindow(int typeBytes) { return 2u + 64u * (u32)typeBytes; }
 
-struct FastWalkPlan { u32 nChunks, nBlocks; };
+struct FastWalkPlan { u32 nChunks, nBlocks, chainCap; };
+
+// one speculative walk through a chunk, shared by all the candidates that merged into it
+struct FastChain
+{
+  u32 cur;             // where it starts (absolute)
+  u32 chunkSig;        // chunk index | signature of the block before `cur` << 28
+  u32 exit;            // out: first block start at / behind the chunk end
+  u16 count;           // out: blocks from cur to exit
+  u16 alive;           // out: 0 if it ran into something that is not a block
+  u16 marks[8];        // out: first block start at / behind sub-chunk boundary j (relative to the chunk start), 0 = not passed
+  u16 markCount[8];    // out: blocks from cur to that block start
+};
 
 struct FastDecodeBuffers
 {
-  u32* chunkExit;      // [nChunks]
-  u16* countAt;        // [nChunks * window] #blocks from a surviving start to the end of its chunk, 0xFFFF elsewhere
-  u32* chunkEntry;     // [nChunks]
+  u32* chunkListN;     // [nChunks] entries of chunkList in use
+  u64* chunkList;      // [nChunks * kFastListCap] start offset in the chunk | steps taken << 16 | chain index << 32
+  FastChain* chains;   // [chainCap]
+  u32* chainCount;     // [1]
+  u32* chunkEntry;     // [nChunks + 1]
   u32* chunkCount;     // [nChunks]
   u32* chunkBase;      // [nChunks + 1]
-  u32* subEntry;       // [nChunks * kFastSubPerChunk] agreed first block start at / behind a sub-chunk boundary, or ~0
+  u32* subEntry;       // [nChunks * kFastSubPerChunk] first block start at / behind a sub-chunk boundary ([0] = the chunk entry), or ~0
+  u32* subIndex;       // [nChunks * kFastSubPerChunk] index of that block within the chunk
+  u32* blockOff;       // [nBlocks + 1]
   u64* slotFletcher;   // [2 * kFastSlots]
   u64* fletcherOut;    // [2]
   u32* scanScratch;
@@ -75,7 +93,8 @@ struct FastDecodeBuffers
 
 bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid);
 FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 dataBegin, u32 blobEnd);
-// stage 0: chunk walk; 1: resolve + scan; 2: decode + Fletcher sums
+static const int kFastDecodeStages = 5;
+// stage 0: candidates; 1: chains; 2: resolve + scan; 3: block offsets; 4: decode + Fletcher sums
 void launchFastDecode(int stage, const BandParams& p, const FastWalkPlan& wp, const u8* blob, u32 dataBegin, u32 blobEnd,
                       const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st);
 

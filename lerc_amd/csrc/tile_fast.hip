@@ -24,6 +24,8 @@
 
 namespace lerc {
 
+PROBE_DEFINE(fast_encode)
+
 enum FastRedo : u32
 {
   kRedoNaN = 1, kRedoAllInt = 2, kRedoRaise = 4, kRedoConst = 8, kRedoMb16 = 16, kRedoOneSweep = 32, kRedoCapacity = 64
@@ -140,6 +142,7 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
   __shared__ T s_mn[kFastBlocksPerWG], s_mx[kFastBlocksPerWG];
   __shared__ u32 s_same[kFastBlocksPerWG], s_nd[kFastBlocksPerWG];
   __shared__ u32 s_fl[4];
+  PROBE_BEGIN;
   const int w = waveId(), lane = laneId();
   const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
   const int wgPerRow = p.nCols / (kFastBlocksPerWG * 8);
@@ -192,6 +195,7 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
   const bool f1 = __any(flags & 1u), f2 = __any(flags & 2u);
   if (lane == 0) s_fl[w] = (f1 ? 1u : 0u) | (f2 ? 2u : 0u);
   __syncthreads();
+  PROBE(0);
   if (w != 0) return;
 
   // ---- lane = block: the per-block decisions of Lerc2::NumBytesTile, once
@@ -223,6 +227,7 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
     const u32 fl = s_fl[0] | s_fl[1] | s_fl[2] | s_fl[3];
     if (fl) atomicOr(&slotFlags[slot], fl);
   }
+  PROBE(1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -344,6 +349,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
   __shared__ u64 s_fa[4], s_fb[4];
   if (res->redo) return;
 
+  PROBE_BEGIN;
   const int w = waveId(), lane = laneId();
   const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
   const int wgPerRow = p.nCols / (kFastBlocksPerWG * 8);
@@ -370,6 +376,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
     s_bit[lane] = 8u * (ldsShift + inc - sz);
   }
   __syncthreads();
+  PROBE(4);
 
   // ---- block headers: lane = block (Lerc2::WriteTile, BitStuffer2 stream header)
   if (w == 0)
@@ -392,6 +399,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
     }
   }
 
+  PROBE(5);
   // ---- payloads
 #pragma unroll
   for (int t = 0; t < IT; t++)
@@ -477,6 +485,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
     }
   }
   __syncthreads();
+  PROBE(6);
 
   // ---- flush: 16-byte chunks, byte granular at the two ends; Fletcher sums of the bytes we own.
   // Absolute blob offsets of chunk starts are multiples of 16, so positions inside blob[14 ..) are even.
@@ -519,6 +528,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
     atomicAdd(&slotFletcher[2 * slot], (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u);
     atomicAdd(&slotFletcher[2 * slot + 1], (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u);
   }
+  PROBE(7);
 }
 
 // checksum = Fletcher32 over blob[14 ..): the prefix bytes written by k_fast_decide + the slot sums

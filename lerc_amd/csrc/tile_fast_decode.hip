@@ -2,25 +2,30 @@
 // pixel valid, 8 x 8 blocks, nRows % 8 == 0, nCols % 512 == 0).  Same results as tile_decode.hip.
 //
 // The block stream stores no offsets (block k+1 starts where block k ends), so decoding starts with a
-// discovery pass:
-//   k_fast_walk     LDS staged.  A workgroup stages a few 4 KiB chunks, tries every position of each chunk's
-//                   first `window` bytes as a block start (a few steps filter out almost all of them) and
-//                   walks the survivors to the chunk end.  The true first block of the chunk is always among
-//                   the survivors, so whatever ALL survivors agree on is true without knowing which survivor
-//                   is the real one: the chunk's exit (= entry of the next chunk) and the first block start
-//                   behind every 512-byte sub-chunk boundary.  Per surviving start it also records the
-//                   number of blocks up to the chunk end.
-//   k_fast_resolve  entry of chunk c = agreed exit of chunk c-1; #blocks of chunk c = count recorded for the
-//                   survivor that starts exactly there; an exclusive scan turns counts into block indices.
-//   k_fast_decode   a workgroup owns 2 chunks: it stages their bytes (accumulating the Fletcher32 sums of the
-//                   bytes it owns, word-wise), re-walks them from the resolved entry with one lane per
-//                   512-byte sub-chunk, parses every block header once (thread = block), then every lane
-//                   extracts V consecutive pixels of one raster row, dequantises (double precision in the
-//                   reference's expression order for float types, exact integer arithmetic for integer
-//                   types) and stores one 16-byte vector; a wave covers 8 raster rows x 128 bytes.
-// Whenever a precondition fails (a block longer than its raw size, disagreeing survivors, more than
-// kMaxBlocksPerWG blocks in two chunks, ...) the kernels raise `fallback`, and the host repeats the band
-// with the general kernels.  Reference: Lerc2.cpp:1672-1713, :2025-2230; BitStuffer2.cpp:159-258, :476-540.
+// discovery pass over 4 KiB chunks of the stream.  Serial walking is latency bound, so the serial parts run
+// as plain one-lane-per-chain kernels straight from global memory (L2 / MALL hits) with every chain of the
+// whole stream in flight at once, and only the wide, throughput bound part is staged through LDS:
+//   k_fast_candidates  LDS staged.  A workgroup takes a few chunks and tries every position of each chunk's
+//                      first `window` bytes as a block start.  Candidates are filtered for a few steps through
+//                      compacting queues (most die at once) and the survivors are merged into distinct
+//                      chains (a hash on position + signature).  The true first block of a chunk is always
+//                      among the survivors.
+//   k_fast_chains      one lane per chain walks to the end of its chunk: exit, #blocks, and the first block
+//                      start behind every 512-byte sub-chunk boundary it passes.
+//   k_fast_resolve     whatever ALL live chains of a chunk agree on is true without knowing which one is
+//                      real: entry of chunk c = agreed exit of chunk c-1; #blocks of chunk c = steps + count
+//                      of the survivor that starts exactly there; agreed sub-chunk entries.  An exclusive
+//                      scan turns the counts into block indices.
+//   k_fast_emit        one lane per sub-chunk walks from its agreed entry to the next one and writes the
+//                      block offsets.
+//   k_fast_decode      a workgroup owns 64 consecutive blocks (8 rows x 512 columns): it stages their byte
+//                      span in LDS (accumulating the Fletcher32 sums of those bytes word-wise), parses the 64
+//                      block headers once (lane = block), then every lane extracts V consecutive pixels of one
+//                      raster row, dequantises (double precision in the reference's expression order for
+//                      float types, exact integer arithmetic for integer types) and stores one 16-byte vector.
+// Whenever a precondition fails (a block longer than its raw size, disagreeing chains, too many survivors,
+// ...) the kernels raise `fallback`, and the host repeats the band with the general kernels.
+// Reference: Lerc2.cpp:1672-1713, :2025-2230; BitStuffer2.cpp:159-258, :476-540.
 #include "tile_fast.h"
 #include "kernels.h"
 #include "wave_utils.h"
@@ -28,218 +33,481 @@
 namespace lerc {
 
 static const u32 kNoOffset = 0xFFFFFFFFu;
+PROBE_DEFINE(fast_decode)
 
-struct BlkLite
-{
-  u32 len, payload;
-  u32 nLut;
-  u8 flag, mode, offBytes, nb, lut, dtUsed;
-};
+// ------------------------------------------------------------------------------------------------
+// block header parsing, branch free
+// ------------------------------------------------------------------------------------------------
+// code word of one block: len (10) | mode (2) << 10 | lut << 12 | numBits (5) << 13 | nLut (8) << 18 | offBytes (4) << 26
+__device__ __forceinline__ u32 codeLen(u32 c) { return c & 1023u; }
+__device__ __forceinline__ u32 codeMode(u32 c) { return (c >> 10) & 3u; }
+__device__ __forceinline__ u32 codeLut(u32 c) { return (c >> 12) & 1u; }
+__device__ __forceinline__ u32 codeBits(u32 c) { return (c >> 13) & 31u; }
+__device__ __forceinline__ u32 codeNLut(u32 c) { return (c >> 18) & 255u; }
+__device__ __forceinline__ u32 codeOffBytes(u32 c) { return (c >> 26) & 15u; }
 
-// Header parser for all-valid 8 x 8 blocks (64 elements) of data type DT from an LDS word image whose
-// byte 0 is blob byte `a0`.  All header bytes come out of one group of aligned word reads (a single LDS
-// round trip per block).  Returns false if no valid block starts at pos.  Mirrors Lerc2::ReadTile
-// (Lerc2.cpp:2025-2110) and BitStuffer2::Decode (BitStuffer2.cpp:159-258).
-template<int DT>
-__device__ __forceinline__ bool parseLds(const u32* words, u32 a0, u32 pos, u32 end, int version, BlkLite& b)
+// bytes of the block offset for each of the 4 type codes, a nibble each (0 = no such type); Lerc2.h:528-542
+template<int DT> __device__ __forceinline__ u32 offBytesTable()
 {
-  constexpr int TBYTES = (DT <= DT_Byte) ? 1 : (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
-  if (pos >= end) return false;
-  const u32 rel = pos - a0, w = rel >> 2, sh = 8u * (rel & 3u);
-  const u32 x0 = words[w], x1 = words[w + 1], x2 = words[w + 2], x3 = (DT == DT_Double) ? words[w + 3] : 0u;
-  const u32 h0 = sh ? ((x0 >> sh) | (x1 << (32 - sh))) : x0;
-  const u32 h1 = sh ? ((x1 >> sh) | (x2 << (32 - sh))) : x1;
-  const u32 h2 = sh ? ((x2 >> sh) | (x3 << (32 - sh))) : x2;
-  const u64 lo = ((u64)h1 << 32) | h0;    // header bytes 0..7; h2 = bytes 8..11
-  const u32 flag = h0 & 0xFFu;
-  b.flag = (u8)flag;
-  if (version >= 5 && (flag & 4u)) return false;    // slice difference needs nDepth > 1
-  b.mode = (u8)(flag & 3u);
-  const int tc = (int)(flag >> 6);
-  b.offBytes = 0; b.nb = 0; b.lut = 0; b.nLut = 0; b.payload = 1; b.dtUsed = (u8)DT;
-  u32 len = 1;
-  if (b.mode == 2) { b.len = 1; return true; }
-  if (b.mode == 0) len = 1 + 64 * TBYTES;
-  else
+  u32 t = 0;
+#pragma unroll
+  for (int tc = 0; tc < 4; tc++)
   {
     const int dtU = typeUsed(DT, tc);
-    if (dtU == DT_Undefined) return false;
-    b.dtUsed = (u8)dtU;
-    b.offBytes = (u8)dtSize(dtU);
-    len = 1 + b.offBytes;
-    if (b.mode == 1)
-    {
-      // bytes len, len + 1, len + 2 of the header: numBits byte, count, (LUT size)
-      const u32 t3 = (len < 8) ? (u32)(lo >> (8 * len)) | ((len > 4) ? (h2 << (8 * (8 - len))) : 0u) : (h2 >> (8 * (len - 8)));
-      if (pos + len + 2 > end) return false;
-      const u32 b0 = t3 & 0xFFu;
-      if ((b0 >> 6) != 2u) return false;            // 64 elements -> one-byte count field
-      if (((t3 >> 8) & 0xFFu) != 64u) return false;
-      b.lut = (b0 & 32u) ? 1 : 0;
-      b.nb = (u8)(b0 & 31u);
-      if (b.nb == 0) return false;
-      len += 2;
-      if (!b.lut) { b.payload = len; len += 8u * b.nb; }
-      else
-      {
-        if (pos + len >= end) return false;
-        const int nLut = (int)((t3 >> 16) & 0xFFu) - 1;
-        if (nLut < 1) return false;
-        b.nLut = (u32)nLut;
-        len += 1;
-        b.payload = len;
-        len += ((u32)nLut * b.nb + 7) >> 3;
-        len += (64u * (u32)bitLen((u32)nLut) + 7) >> 3;
-      }
-    }
+    t |= (u32)(dtU == DT_Undefined ? 0 : dtSize(dtU)) << (4 * tc);
   }
-  if (pos + len > end) return false;
-  b.len = len;
-  return true;
+  return t;
+}
+
+// the first 12 bytes at LDS byte offset rel: one round of aligned word reads + funnel shifts
+template<int DT>
+__device__ __forceinline__ void ldsHeader(const u32* words, u32 rel, u32& h0, u32& h1, u32& h2)
+{
+  const u32 w = rel >> 2, sh = 8u * (rel & 3u);
+  const u32 x0 = words[w], x1 = words[w + 1], x2 = words[w + 2];
+  h0 = (u32)((((u64)x1 << 32) | x0) >> sh);
+  h1 = (u32)((((u64)x2 << 32) | x1) >> sh);
+  h2 = 0;
+  if (DT == DT_Double) { const u32 x3 = words[w + 3]; h2 = (u32)((((u64)x3 << 32) | x2) >> sh); }
+}
+
+// Code word of the all-valid 8 x 8 block (64 elements) of data type DT whose first 12 bytes are h0 h1 h2, or 0
+// if no valid block starts there.  The caller checks that the block ends inside the stream.  Mirrors
+// Lerc2::ReadTile (Lerc2.cpp:2025-2110) and BitStuffer2::Decode (BitStuffer2.cpp:159-258); blocks longer than
+// the raw form are refused (the reference encoder never writes one; the general kernels take such blobs).
+template<int DT>
+__device__ __forceinline__ u32 parseCode(u32 h0, u32 h1, u32 h2, int version)
+{
+  constexpr u32 TB = (DT <= DT_Byte) ? 1 : (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
+  constexpr u32 RAW = 1 + 64 * TB;
+  const u32 flag = h0 & 0xFFu, mode = flag & 3u;
+  const u32 offB = (offBytesTable<DT>() >> ((flag >> 4) & 12u)) & 15u;
+  const u64 hdr = ((u64)h1 << 32) | h0;
+  u32 t = (u32)(hdr >> ((8u + 8u * offB) & 63u));    // bytes 1 + offB ...: numBits byte, count, LUT size
+  if (DT == DT_Double) t = (offB == 8u) ? (h2 >> 8) : t;
+  const u32 nb = t & 31u, lut = (t >> 5) & 1u;
+  const u32 nLut = ((t >> 16) & 0xFFu) - 1u;                           // valid: 1 ... 254
+  const bool okBits = ((t & 0xFFC0u) == 0x4080u) & (nb != 0u);         // 64 elements: one-byte count field == 64
+  const bool okLut = (nLut - 1u) < 254u;
+  const u32 lenSimple = 3u + offB + 8u * nb;
+  const u32 lenLut = 4u + offB + (((nLut & 0xFFu) * nb + 7u) >> 3) + 8u * (u32)bitLen(nLut & 0xFFu);
+  const u32 len = (mode == 0u) ? RAW : (mode == 2u) ? 1u : (mode == 3u) ? 1u + offB : (lut ? lenLut : lenSimple);
+  bool ok = (mode == 0u) | (mode == 2u) | ((offB != 0u) & ((mode == 3u) | (okBits & ((lut == 0u) | okLut))));
+  ok = ok & !((version >= 5) & ((flag & 4u) != 0u)) & (len <= RAW);    // slice difference needs nDepth > 1
+  const u32 code = len | (mode << 10) | (lut << 12) | (nb << 13) | ((nLut & 0xFFu) << 18) | (offB << 26);
+  return ok ? code : 0u;
 }
 
 __device__ __forceinline__ bool sigOk(u32 prev, u32 cur, u32 pattern)
 {
   const u32 step = (pattern == 14u) ? 2u : 1u;    // 8 x 8 blocks: signature = (j0 >> 3) & pattern
-  return cur == prev || cur == ((prev + step) & pattern) || cur == 0;
+  return (cur == prev) | (cur == ((prev + step) & pattern)) | (cur == 0u);
 }
 
-static const int kWalkChunksPerWG = 4;
+// one step of a walk: the block at `cur` (absolute), or 0
+template<int DT>
+__device__ __forceinline__ u32 stepAt(const u32* words, u32 a0, u32 cur, u32 end, int version, u32& sig, u32 pattern)
+{
+  u32 h0, h1, h2;
+  ldsHeader<DT>(words, cur - a0, h0, h1, h2);
+  const u32 code = parseCode<DT>(h0, h1, h2, version);
+  const u32 sg = (h0 >> 2) & pattern;
+  const bool ok = (code != 0u) & (cur + codeLen(code) <= end) & ((sig == kNoOffset) | sigOk(sig, sg, pattern));
+  sig = sg;
+  return ok ? code : 0u;
+}
+
+// the first 12 bytes at blob offset pos, straight from global memory.  Never touches a word behind the one that
+// holds the last blob byte (device allocations are at least 4-byte granular; blob itself is 16-byte aligned).
+struct __attribute__((packed, aligned(4))) Words4 { u32 x0, x1, x2, x3; };    // a 16-byte load that is only 4-byte aligned
+
+template<int DT>
+__device__ __forceinline__ void globalHeader(const u8* __restrict__ blob, u32 pos, u32 blobEnd, u32& h0, u32& h1, u32& h2)
+{
+  const u32 w = pos & ~3u, sh = 8u * (pos & 3u), last = (blobEnd - 1u) & ~3u;
+  u32 x0, x1, x2, x3;
+  if (w + 12u <= last)    // one request per lane
+  {
+    const Words4 v = *reinterpret_cast<const Words4*>(blob + w);
+    x0 = v.x0; x1 = v.x1; x2 = v.x2; x3 = v.x3;
+  }
+  else                    // the last bytes of the blob
+  {
+    x0 = *reinterpret_cast<const u32*>(blob + w);
+    x1 = *reinterpret_cast<const u32*>(blob + min(w + 4u, last));
+    x2 = *reinterpret_cast<const u32*>(blob + min(w + 8u, last));
+    x3 = *reinterpret_cast<const u32*>(blob + min(w + 12u, last));
+  }
+  h0 = (u32)((((u64)x1 << 32) | x0) >> sh);
+  h1 = (u32)((((u64)x2 << 32) | x1) >> sh);
+  h2 = (DT == DT_Double) ? (u32)((((u64)x3 << 32) | x2) >> sh) : 0u;
+}
+
+// one step of a walk through global memory: the block at `cur`, or 0
+template<int DT>
+__device__ __forceinline__ u32 stepGlobal(const u8* __restrict__ blob, u32 cur, u32 blobEnd, int version, u32& sig, u32 pattern)
+{
+  u32 h0, h1, h2;
+  globalHeader<DT>(blob, cur, blobEnd, h0, h1, h2);
+  const u32 code = parseCode<DT>(h0, h1, h2, version);
+  const u32 sg = (h0 >> 2) & pattern;
+  const bool ok = (code != 0u) & (cur + codeLen(code) <= blobEnd) & ((sig == kNoOffset) | sigOk(sig, sg, pattern));
+  sig = sg;
+  return ok ? code : 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// candidates
+// ------------------------------------------------------------------------------------------------
+static const int kWalkG = 4;                 // chunks per workgroup
 static const int kFilterSteps = 4;
-static const int kMaxSurvivors = 448;
+static const u32 kSurvivorCap = 512;         // survivors of a workgroup after the last filter step
+static const u32 kHashSize = 1024;
+static const u32 kChainCap = 128;            // distinct chains of a workgroup
+
+// appends e for the lanes with p; call in wave-uniform control flow
+__device__ __forceinline__ void queuePush(bool p, u64 e, u64* q, u32* qn, u32 cap, u32* over)
+{
+  const u64 m = __ballot(p);
+  if (!m) return;
+  const int lane = laneId(), leader = __ffsll((long long)m) - 1;
+  u32 base = 0;
+  if (lane == leader) base = atomicAdd(qn, (u32)__popcll(m));
+  base = __shfl(base, leader);
+  if (p)
+  {
+    const u32 idx = base + (u32)__popcll(m & laneMaskLt());
+    if (idx < cap) q[idx] = e; else *over = 1;
+  }
+}
+
+// queue entry: candidate index g * W + o (16) | position relative to the group start (16) << 16 | signature (4) << 32 | steps (4) << 36 | hash slot (16) << 40 | chain owner << 56
+__device__ __forceinline__ u64 qMake(u32 f, u32 curRel, u32 sig, u32 steps) { return (u64)f | ((u64)curRel << 16) | ((u64)(sig & 15u) << 32) | ((u64)steps << 36); }
 
 template<int DT>
 __global__ void __launch_bounds__(256)
-k_fast_walk(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
-            u32* __restrict__ chunkExit, u16* __restrict__ countAt, u32* __restrict__ subEntry, u32* __restrict__ fallback)
+k_fast_candidates(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
+                  u32* __restrict__ chunkListN, u64* __restrict__ chunkList, FastChain* __restrict__ chains, u32* __restrict__ chainCount,
+                  u32 chainCap, u32* __restrict__ fallback)
 {
   constexpr int TBYTES = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
   constexpr u32 W = kFastWindow(TBYTES);
-  constexpr u32 kStage = kWalkChunksPerWG * kFastChunkBytes + W + 48;
-  constexpr int NS = kFastSubPerChunk;
+  constexpr u32 kStage = kWalkG * kFastChunkBytes + W + 48;
+  constexpr u32 kQueueCap = (kWalkG * W * 3) / 4;    // live candidates after the first filter step (about 3/8 on noise)
   __shared__ __align__(16) u32 s_in[kStage / 4 + 8];
-  __shared__ u32 s_svStart[kMaxSurvivors];
-  __shared__ u32 s_nSv, s_over;
-  __shared__ u32 s_min[kWalkChunksPerWG], s_max[kWalkChunksPerWG], s_n[kWalkChunksPerWG];
-  __shared__ u32 s_subMin[kWalkChunksPerWG][NS], s_subMax[kWalkChunksPerWG][NS];
+  __shared__ u64 s_qa[kQueueCap], s_qb[kQueueCap];
+  __shared__ u32 s_hkey[kHashSize];
+  __shared__ u16 s_hval[kHashSize];
+  __shared__ u32 s_nq[2], s_nChains, s_over, s_chainBase;
+  __shared__ u32 s_listN[kWalkG];
 
-  const u32 c0 = blockIdx.x * kWalkChunksPerWG;
+  PROBE_BEGIN;
+  const u32 c0 = blockIdx.x * kWalkG;
   const u32 groupStart = dataBegin + c0 * kFastChunkBytes;
   const u32 a0 = groupStart & ~15u;
   const u32 stageEnd = min(a0 + kStage, blobEnd);
-  for (u32 i = threadIdx.x * 16u; a0 + i < stageEnd; i += 256u * 16u)
   {
-    if (a0 + i + 16 <= stageEnd)
-      *reinterpret_cast<uint4*>(reinterpret_cast<u8*>(s_in) + i) = *reinterpret_cast<const uint4*>(blob + a0 + i);
-    else
+    constexpr int kRounds = (int)((kStage + 4095) / 4096);
+    uint4 x[kRounds];
+#pragma unroll
+    for (int k = 0; k < kRounds; k++)    // all loads in flight before the first LDS store
     {
-      u32 t4[4] = { 0, 0, 0, 0 };
-      for (u32 k = 0; a0 + i + k < stageEnd; k++) t4[k >> 2] |= (u32)blob[a0 + i + k] << (8 * (k & 3));    // never read past the blob
-      *reinterpret_cast<uint4*>(reinterpret_cast<u8*>(s_in) + i) = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+      const u32 i = ((u32)k * 256u + threadIdx.x) * 16u;
+      x[k] = make_uint4(0, 0, 0, 0);
+      if (a0 + i + 16 <= stageEnd) x[k] = *reinterpret_cast<const uint4*>(blob + a0 + i);
+      else if (a0 + i < stageEnd)
+      {
+        u32 t4[4] = { 0, 0, 0, 0 };
+        for (u32 b = 0; a0 + i + b < stageEnd; b++) t4[b >> 2] |= (u32)blob[a0 + i + b] << (8 * (b & 3));    // never read past the blob
+        x[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kRounds; k++)
+    {
+      const u32 i = ((u32)k * 256u + threadIdx.x) * 16u;
+      if (i < kStage + 16) *reinterpret_cast<uint4*>(reinterpret_cast<u8*>(s_in) + i) = x[k];
     }
   }
-  if (threadIdx.x == 0) { s_nSv = 0; s_over = 0; }
-  if (threadIdx.x < kWalkChunksPerWG) { s_min[threadIdx.x] = kNoOffset; s_max[threadIdx.x] = 0; s_n[threadIdx.x] = 0; }
-  if (threadIdx.x < kWalkChunksPerWG * NS) { (&s_subMin[0][0])[threadIdx.x] = kNoOffset; (&s_subMax[0][0])[threadIdx.x] = 0; }
+  for (u32 i = threadIdx.x; i < kHashSize; i += 256) s_hkey[i] = 0;
+  if (threadIdx.x == 0) { s_nq[0] = 0; s_nq[1] = 0; s_nChains = 0; s_over = 0; }
+  if (threadIdx.x < kWalkG) s_listN[threadIdx.x] = 0;
   __syncthreads();
+  PROBE(0);
 
   const u32 pattern = (version >= 5) ? 14u : 15u;
-  const u32 nChunksHere = min((u32)kWalkChunksPerWG, wp.nChunks - c0);
+  const u32 nChunksHere = min((u32)kWalkG, wp.nChunks - c0);
 
-  // ---- phase 1: every window position, a few steps
-  for (u32 f = threadIdx.x; f < nChunksHere * W; f += 256)
+  // ---- filter step 1: every window position of every chunk
+  const u32 nCand = nChunksHere * W;
+  for (u32 base = 0; base < nCand; base += 256)
   {
+    const u32 f = base + threadIdx.x;
     const u32 g = f / W, o = f - g * W;
     const u32 chunkStart = groupStart + g * kFastChunkBytes;
     const u32 chunkEnd = min(chunkStart + kFastChunkBytes, blobEnd);
-    if (c0 + g == 0 && o != 0) continue;    // the very first block of the stream is known
-    u32 cur = chunkStart + o;
-    if (cur >= chunkEnd) continue;
-    u32 sig = kNoOffset;
-    bool alive = true;
-    for (int s = 0; s < kFilterSteps && cur < chunkEnd; s++)
-    {
-      BlkLite b;
-      if (!parseLds<DT>(s_in, a0, cur, stageEnd, version, b)) { alive = false; break; }
-      const u32 sg = ((u32)b.flag >> 2) & pattern;
-      if (sig != kNoOffset && !sigOk(sig, sg, pattern)) { alive = false; break; }
-      sig = sg; cur += b.len;
-    }
-    if (!alive) continue;
-    const u32 slot = atomicAdd(&s_nSv, 1u);
-    if (slot >= (u32)kMaxSurvivors) { s_over = 1; continue; }
-    s_svStart[slot] = (chunkStart + o) | 0u;
+    const u32 cur = chunkStart + o;
+    bool live = (f < nCand) & (cur < chunkEnd) & ((c0 + g != 0) | (o == 0));    // the very first block of the stream is known
+    u32 sig = kNoOffset, code = 0;
+    if (live) code = stepAt<DT>(s_in, a0, cur, stageEnd, version, sig, pattern);
+    live = live & (code != 0u);
+    queuePush(live, qMake(f, cur + codeLen(code) - groupStart, sig, 1), s_qa, &s_nq[0], kQueueCap, &s_over);
   }
   __syncthreads();
 
-  // ---- phase 2: survivors walk (again from their start) to the end of their chunk, noting where they
-  // pass every sub-chunk boundary
-  const u32 nSv = min(s_nSv, (u32)kMaxSurvivors);
-  for (u32 s = threadIdx.x; s < nSv; s += 256)
+  // ---- filter steps 2 ..: compacted queues (a candidate that reaches its chunk end early just stays)
+  u64* qIn = s_qa;
+  u64* qOut = s_qb;
+  for (int s = 1; s < kFilterSteps; s++)
   {
-    const u32 start = s_svStart[s];
-    const u32 g = (start - groupStart) / kFastChunkBytes;
-    const u32 chunkStart = groupStart + g * kFastChunkBytes;
-    const u32 chunkEnd = min(chunkStart + kFastChunkBytes, blobEnd);
-    u32 cur = start, count = 0, sig = kNoOffset;
-    u32 nextSub = 1;    // sub-chunk boundaries passed so far + 1
-    bool alive = true;
-    while (cur < chunkEnd)
+    const u32 nIn = min(s_nq[(s - 1) & 1], kQueueCap);
+    __syncthreads();
+    if (threadIdx.x == 0) s_nq[s & 1] = 0;
+    __syncthreads();
+    for (u32 base = 0; base < nIn; base += 256)
     {
-      while (nextSub < (u32)NS && cur >= chunkStart + nextSub * kFastSubBytes)
+      const u32 i = base + threadIdx.x;
+      const u64 e = (i < nIn) ? qIn[i] : 0;
+      const u32 f = (u32)(e & 0xFFFFu), curRel = (u32)(e >> 16) & 0xFFFFu;
+      const u32 g = f / W;
+      const u32 chunkEnd = min(groupStart + (g + 1) * kFastChunkBytes, blobEnd);
+      const u32 cur = groupStart + curRel;
+      bool live = i < nIn;
+      u64 out = e;
+      if (live && cur < chunkEnd)
       {
-        atomicMin(&s_subMin[g][nextSub], cur);
-        atomicMax(&s_subMax[g][nextSub], cur);
-        nextSub++;
+        u32 sig = (u32)(e >> 32) & 15u;
+        const u32 code = stepAt<DT>(s_in, a0, cur, stageEnd, version, sig, pattern);
+        live = code != 0u;
+        out = qMake(f, curRel + codeLen(code), sig, ((u32)(e >> 36) & 15u) + 1);
       }
-      BlkLite b;
-      if (!parseLds<DT>(s_in, a0, cur, stageEnd, version, b)) { alive = false; break; }
-      const u32 sg = ((u32)b.flag >> 2) & pattern;
-      if (sig != kNoOffset && !sigOk(sig, sg, pattern)) { alive = false; break; }
-      sig = sg; cur += b.len; count++;
+      queuePush(live, out, qOut, &s_nq[s & 1], kQueueCap, &s_over);
     }
-    if (!alive)
+    __syncthreads();
+    u64* t = qIn; qIn = qOut; qOut = t;
+  }
+  u64* qs = qIn;                                                   // the survivors
+  const u32 nSvAll = s_nq[(kFilterSteps - 1) & 1];
+  const u32 nSv = min(nSvAll, kSurvivorCap);
+  PROBE(1);
+
+  // ---- merge the survivors into distinct chains: same chunk, position and signature behave alike from here on
+  for (u32 i = threadIdx.x; i < nSv; i += 256)
+  {
+    const u64 e = qs[i];
+    const u32 g = (u32)(e & 0xFFFFu) / W;
+    const u32 key = ((u32)(e >> 16) & 0xFFFFu) | (((u32)(e >> 32) & 15u) << 16) | (g << 20) | 0x80000000u;
+    u32 h = (key * 2654435761u) >> 22;                             // 10 bits
+    u64 owner = 0;
+    for (;;)
     {
-      // a chain that died after leaving marks: its marks must not count as agreement
-      for (u32 j = 1; j < nextSub; j++) { atomicMin(&s_subMin[g][j], 0u); atomicMax(&s_subMax[g][j], kNoOffset - 1); }
-      continue;
+      const u32 old = atomicCAS(&s_hkey[h], 0u, key);
+      if (old == 0u) { s_hval[h] = (u16)atomicAdd(&s_nChains, 1u); owner = 1; break; }
+      if (old == key) break;
+      h = (h + 1) & (kHashSize - 1);
     }
-    for (; nextSub < (u32)NS; nextSub++) { atomicMin(&s_subMin[g][nextSub], cur); atomicMax(&s_subMax[g][nextSub], cur); }
-    atomicMin(&s_min[g], cur);
-    atomicMax(&s_max[g], cur);
-    atomicAdd(&s_n[g], 1u);
-    countAt[(size_t)(c0 + g) * W + (start - chunkStart)] = (u16)count;    // #blocks from this start to the chunk end
+    qs[i] = e | ((u64)h << 40) | (owner << 56);
+  }
+  __syncthreads();
+  const u32 nChains = s_nChains;
+  if (threadIdx.x == 0) s_chainBase = atomicAdd(chainCount, nChains);
+  __syncthreads();
+  const u32 chainBase = s_chainBase;
+  const bool over = (s_over != 0u) | (nSvAll > kSurvivorCap) | (nChains > kChainCap) | (chainBase + nChains > chainCap);
+
+  // ---- hand the chains and the survivor lists (start, steps so far, chain) of every chunk over
+  if (!over)
+  {
+    for (u32 i = threadIdx.x; i < nSv; i += 256)
+    {
+      const u64 e = qs[i];
+      const u32 f = (u32)(e & 0xFFFFu), g = f / W, o = f - g * W;
+      const u32 chain = chainBase + s_hval[(u32)(e >> 40) & 0xFFFFu];
+      const u32 slot = atomicAdd(&s_listN[g], 1u);
+      if (slot < (u32)kFastListCap)
+        chunkList[(size_t)(c0 + g) * kFastListCap + slot] = (u64)(o | (((u32)(e >> 36) & 15u) << 16)) | ((u64)chain << 32);
+      if ((e >> 56) & 1u)
+      {
+        FastChain ch;
+        ch.cur = groupStart + ((u32)(e >> 16) & 0xFFFFu);
+        ch.chunkSig = (c0 + g) | (((u32)(e >> 32) & 15u) << 28);
+        ch.exit = 0; ch.count = 0; ch.alive = 0;
+        for (int j = 0; j < kFastSubPerChunk; j++) { ch.marks[j] = 0; ch.markCount[j] = 0; }
+        chains[chain] = ch;
+      }
+    }
   }
   __syncthreads();
   if (threadIdx.x < nChunksHere)
   {
-    const u32 g = threadIdx.x;
-    const bool ok = !s_over && s_n[g] > 0 && s_min[g] == s_max[g];
-    chunkExit[c0 + g] = ok ? s_min[g] : kNoOffset;
-    if (!ok && c0 + g + 1 < wp.nChunks) atomicOr(fallback, 1u);    // the exit of the last chunk is not needed
+    const bool ok = !over && s_listN[threadIdx.x] <= (u32)kFastListCap && s_listN[threadIdx.x] > 0;
+    chunkListN[c0 + threadIdx.x] = ok ? s_listN[threadIdx.x] : 0u;
+    if (!ok) atomicOr(fallback, 1u);
   }
-  if (threadIdx.x < nChunksHere * NS)
-  {
-    const u32 g = threadIdx.x / NS, j = threadIdx.x % NS;
-    const bool ok = j > 0 && s_subMin[g][j] == s_subMax[g][j] && s_subMin[g][j] != kNoOffset;
-    subEntry[(size_t)(c0 + g) * NS + j] = ok ? s_subMin[g][j] : kNoOffset;
-  }
+  PROBE(2);
 }
 
+// ------------------------------------------------------------------------------------------------
+// chains
+// ------------------------------------------------------------------------------------------------
+template<int DT>
 __global__ void __launch_bounds__(256)
-k_fast_resolve(FastWalkPlan wp, u32 window, u32 dataBegin, u32 blobEnd, const u32* __restrict__ chunkExit, const u16* __restrict__ countAt,
-               u32* __restrict__ chunkEntry, u32* __restrict__ chunkCount, u32* __restrict__ fallback)
+k_fast_chains(int version, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd, FastChain* __restrict__ chains,
+              const u32* __restrict__ chainCount, u32 chainCap)
 {
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= min(*chainCount, chainCap)) return;
+  constexpr int NS = kFastSubPerChunk;
+  const u32 pattern = (version >= 5) ? 14u : 15u;
+  const FastChain ch = chains[t];
+  const u32 chunk = ch.chunkSig & 0x0FFFFFFFu;
+  const u32 chunkStart = dataBegin + chunk * kFastChunkBytes;
+  const u32 chunkEnd = min(chunkStart + kFastChunkBytes, blobEnd);
+  u32 cur = ch.cur, sig = ch.chunkSig >> 28, count = 0;
+  u32 nextSub = (cur - chunkStart) / kFastSubBytes + 1;    // boundaries at or before the chain start are nobody's
+  u32 nextBoundary = chunkStart + nextSub * kFastSubBytes;
+  u16 marks[NS], markCount[NS];
+#pragma unroll
+  for (int j = 0; j < NS; j++) { marks[j] = 0; markCount[j] = 0; }
+  bool alive = true;
+  while (cur < chunkEnd)
+  {
+    const u32 code = stepGlobal<DT>(blob, cur, blobEnd, version, sig, pattern);
+    if (code == 0u) { alive = false; break; }
+    cur += codeLen(code); count++;
+    while (nextSub < (u32)NS && cur >= nextBoundary)
+    {
+#pragma unroll
+      for (int j = 1; j < NS; j++) if ((u32)j == nextSub) { marks[j] = (u16)(cur - chunkStart); markCount[j] = (u16)count; }
+      nextSub++; nextBoundary += kFastSubBytes;
+    }
+  }
+  FastChain out = ch;
+  out.exit = cur; out.count = (u16)count; out.alive = alive ? 1 : 0;
+#pragma unroll
+  for (int j = 0; j < NS; j++) { out.marks[j] = marks[j]; out.markCount[j] = markCount[j]; }
+  chains[t] = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// resolve
+// ------------------------------------------------------------------------------------------------
+// the exit every live chain of chunk c agrees on, or kNoOffset
+__device__ __forceinline__ u32 agreedExit(u32 c, const u32* __restrict__ chunkListN, const u64* __restrict__ chunkList,
+                                          const FastChain* __restrict__ chains)
+{
+  const u32 n = min(chunkListN[c], (u32)kFastListCap);
+  u32 ex = kNoOffset;
+  bool any = false, same = true;
+  for (u32 i = 0; i < n; i++)
+  {
+    const FastChain& ch = chains[(u32)(chunkList[(size_t)c * kFastListCap + i] >> 32)];
+    if (!ch.alive) continue;
+    if (!any) { ex = ch.exit; any = true; }
+    else if (ch.exit != ex) same = false;
+  }
+  return (any && same) ? ex : kNoOffset;
+}
+
+template<int DT>
+__global__ void __launch_bounds__(256)
+k_fast_resolve(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd, const u32* __restrict__ chunkListN,
+               const u64* __restrict__ chunkList, const FastChain* __restrict__ chains, u32* __restrict__ chunkEntry,
+               u32* __restrict__ chunkCount, u32* __restrict__ subEntry, u32* __restrict__ subIndex, u32* __restrict__ fallback)
+{
+  constexpr int NS = kFastSubPerChunk;
   const u32 c = blockIdx.x * 256u + threadIdx.x;
   if (c > wp.nChunks) return;
   if (c == wp.nChunks) { chunkEntry[c] = blobEnd; return; }
-  const u32 e = (c == 0) ? dataBegin : chunkExit[c - 1];
+  // Only the exits need agreement (they break the chunk-to-chunk dependency).  Once the entry of this chunk is
+  // known, the survivor that starts there IS the true path, and so is the chain it merged into.
+  const u32 e = (c == 0) ? dataBegin : agreedExit(c - 1, chunkListN, chunkList, chains);
   chunkEntry[c] = e;
   const u32 chunkStart = dataBegin + c * kFastChunkBytes;
-  u32 n = 0xFFFFu;
-  if (e != kNoOffset && e >= chunkStart && e - chunkStart < window) n = countAt[(size_t)c * window + (e - chunkStart)];
-  if (n == 0xFFFFu) { atomicOr(fallback, 2u); n = 0; }
-  chunkCount[c] = n;
+  const u32 n = min(chunkListN[c], (u32)kFastListCap);
+  u32 steps = 0, chainIdx = kNoOffset;
+  for (u32 i = 0; i < n; i++)
+  {
+    const u64 rec = chunkList[(size_t)c * kFastListCap + i];
+    if (e != kNoOffset && ((u32)rec & 0xFFFFu) == e - chunkStart) { steps = ((u32)rec >> 16) & 15u; chainIdx = (u32)(rec >> 32); }
+  }
+  u32 pos[NS], idx[NS];
+#pragma unroll
+  for (int j = 0; j < NS; j++) { pos[j] = kNoOffset; idx[j] = 0; }
+  u32 count = 0;
+  bool ok = chainIdx != kNoOffset;
+  if (ok)
+  {
+    const FastChain ch = chains[chainIdx];
+    ok = ch.alive != 0;
+    // the first steps, before the survivor joined its chain
+    const u32 pattern = (version >= 5) ? 14u : 15u;
+    u32 cur = e, sig = kNoOffset, nextSub = 1;
+    pos[0] = e;
+    for (u32 s = 0; s < steps && ok; s++)
+    {
+      const u32 code = stepGlobal<DT>(blob, cur, blobEnd, version, sig, pattern);
+      if (code == 0u) { ok = false; break; }
+      cur += codeLen(code);
+      while (nextSub < (u32)NS && cur >= chunkStart + nextSub * kFastSubBytes)
+      {
+#pragma unroll
+        for (int j = 1; j < NS; j++) if ((u32)j == nextSub) { pos[j] = cur; idx[j] = s + 1; }
+        nextSub++;
+      }
+    }
+    ok = ok && cur == ch.cur;
+#pragma unroll
+    for (int j = 1; j < NS; j++)
+      if ((u32)j >= nextSub && ch.marks[j] != 0) { pos[j] = chunkStart + ch.marks[j]; idx[j] = steps + ch.markCount[j]; }    // 0: behind the end of the blob
+    count = steps + ch.count;
+  }
+  if (!ok) { atomicOr(fallback, 2u); count = 0; }
+  chunkCount[c] = count;
+#pragma unroll
+  for (int j = 0; j < NS; j++) { subEntry[(size_t)c * NS + j] = ok ? pos[j] : kNoOffset; subIndex[(size_t)c * NS + j] = idx[j]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// block offsets
+// ------------------------------------------------------------------------------------------------
+template<int DT>
+__global__ void __launch_bounds__(256)
+k_fast_emit(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 blobEnd, const u32* __restrict__ chunkEntry,
+            const u32* __restrict__ chunkCount, const u32* __restrict__ chunkBase, const u32* __restrict__ subEntry,
+            const u32* __restrict__ subIndex, u32* __restrict__ blockOff, u32* __restrict__ fallback)
+{
+  constexpr int NS = kFastSubPerChunk;
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  const u32 c = t / NS, j = t % NS;
+  if (t == 0)
+  {
+    blockOff[wp.nBlocks] = blobEnd;    // sentinel: end of the last block
+    if (chunkBase[wp.nChunks] != wp.nBlocks) atomicOr(fallback, 4u);
+  }
+  if (c >= wp.nChunks || *fallback != 0u) return;    // raised by an earlier kernel: nothing below can be trusted
+  const u32 start = subEntry[(size_t)c * NS + j];
+  if (start == kNoOffset) return;
+  // this lane walks [start, limit): up to the next sub-chunk entry, or the entry of the next chunk.  Entries never
+  // decrease from lane to lane (positions on one path); equal ones (a block spanning two boundaries) leave nothing.
+  u32 limit = chunkEntry[c + 1], endIdx = chunkCount[c];
+  if (j + 1 < (u32)NS)
+  {
+    const u32 nx = subEntry[(size_t)c * NS + j + 1];
+    if (nx != kNoOffset) { limit = nx; endIdx = subIndex[(size_t)c * NS + j + 1]; }
+  }
+  const u32 base = chunkBase[c];
+  u32 at = base + subIndex[(size_t)c * NS + j];
+  u32 cur = start, sig = kNoOffset;
+  bool bad = false;
+  while (cur < limit)
+  {
+    const u32 code = stepGlobal<DT>(blob, cur, blobEnd, version, sig, 0u);    // signatures are checked by the decoder
+    if (code == 0u || at >= wp.nBlocks) { bad = true; break; }
+    blockOff[at++] = cur;
+    cur += codeLen(code);
+  }
+  if (bad || cur != limit || at != base + endIdx) atomicOr(fallback, 8u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -249,7 +517,9 @@ template<class T> struct DCfg
 {
   static constexpr int V = (sizeof(T) >= 4) ? 16 / (int)sizeof(T) : 8;
   static constexpr int LPR = 8 / V;
-  static constexpr int BPW = 8 / LPR;    // blocks per wave tile
+  static constexpr int BPW = 8 / LPR;
+  static constexpr int TILE_COLS = 8 * V;
+  static constexpr int IT = kFastBlocksPerWG / (4 * BPW);
 };
 
 // nbits (<= 32) at bit position bitPos of the LDS word stream
@@ -280,47 +550,45 @@ template<class T> __device__ __forceinline__ T dequant(double offset, u32 q, dou
   return (T)(z < zMaxI ? z : zMaxI);
 }
 
-static const int kDecodeChunksPerWG = 2;
-static const int kMaxBlocksPerWG = 1024;
-
 template<class T>
 __global__ void __launch_bounds__(256)
-k_fast_decode(BandParams p, FastWalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
-              const u32* __restrict__ chunkEntry, const u32* __restrict__ chunkBase, const u32* __restrict__ subEntry,
-              T* __restrict__ outPix, u64* __restrict__ slotFletcher, u32* __restrict__ fallback, DeviceStatus* st)
+k_fast_decode(BandParams p, const u8* __restrict__ blob, u32 blobEnd, const u32* __restrict__ blockOff, T* __restrict__ outPix,
+              u64* __restrict__ slotFletcher, const u32* __restrict__ fallback, DeviceStatus* st)
 {
   typedef DCfg<T> C;
-  constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
+  constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW, IT = C::IT;
   constexpr int DT = DtOf<T>::v;
-  constexpr int NS = kFastSubPerChunk, NL = kDecodeChunksPerWG * NS;
-  constexpr u32 kStage = kDecodeChunksPerWG * kFastChunkBytes + kFastWindow((int)sizeof(T)) + 48;
-  __shared__ __align__(16) u32 s_in[kStage / 4 + 8];
-  __shared__ u16 s_boff[kMaxBlocksPerWG];      // block start, relative to a0
-  __shared__ u32 s_pbit[kMaxBlocksPerWG];      // LDS bit position of the payload (bit stuffed) / first raw value
-  __shared__ u32 s_meta[kMaxBlocksPerWG];      // mode | lut << 2 | numBits << 3 | nLut << 8 | ok << 31
-  __shared__ double s_offs[kMaxBlocksPerWG];
+  constexpr int kSpanWords = (kFastBlocksPerWG * (1 + 64 * (int)sizeof(T)) + 32) / 4 + 8;
+  __shared__ __align__(16) u32 s_in[kSpanWords];
+  __shared__ u32 s_off[kFastBlocksPerWG + 1];
+  __shared__ u32 s_code[kFastBlocksPerWG];     // parseCode of the block, 0 = bad
+  __shared__ double s_offs[kFastBlocksPerWG];
   __shared__ u64 s_fa[4], s_fb[4];
-  __shared__ u32 s_nB, s_bad, s_skip;
-  // the earlier kernels gave up?  (read once per workgroup: other workgroups of this launch may raise it too)
-  if (threadIdx.x == 0) s_skip = *fallback;
-  __syncthreads();
-  if (s_skip) return;
+  if (*fallback) return;    // only earlier kernels raise it
 
+  PROBE_BEGIN;
   const int w = waveId(), lane = laneId();
-  const u32 c0 = blockIdx.x * kDecodeChunksPerWG;
-  const u32 c1 = min(c0 + (u32)kDecodeChunksPerWG, wp.nChunks);
-  const u32 g0 = chunkEntry[c0], g1 = chunkEntry[c1];    // chunkEntry[nChunks] = blobEnd
-  if (g0 == kNoOffset || g1 < g0 || g1 - g0 > kStage - 48 || g1 > blobEnd)
+  const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
+  const int wgPerRow = p.nCols / (kFastBlocksPerWG * 8);
+  const int it = (int)blockIdx.x / wgPerRow, wgc = (int)blockIdx.x - it * wgPerRow;
+  const u32 firstBlk = blockIdx.x * kFastBlocksPerWG;
+
+  if (threadIdx.x <= kFastBlocksPerWG) s_off[threadIdx.x] = blockOff[firstBlk + threadIdx.x];
+  __syncthreads();
+  const u32 g0 = s_off[0], g1 = s_off[kFastBlocksPerWG];
+  const u32 spanLen = g1 - g0;
+  if (g1 < g0 || spanLen > (u32)(kFastBlocksPerWG * (1 + 64 * (int)sizeof(T))) || g1 > blobEnd)
   {
-    if (threadIdx.x == 0) atomicOr(fallback, 16u);
+    if (threadIdx.x == 0) raiseError(st, kFailed, blockIdx.x);
     return;
   }
+  PROBE(8);
   // ---- stage the span (16-byte loads from the aligned-down start) + Fletcher sums of the owned bytes
   const u32 a0 = g0 & ~15u;
-  const u32 shift = g0 - a0, spanLen = g1 - g0;
-  const u32 nChunks16 = (shift + spanLen + 15) >> 4;
+  const u32 shift = g0 - a0;
+  const u32 nChunks = (shift + spanLen + 15) >> 4;
   u64 A = 0, B = 0;
-  for (u32 ch = threadIdx.x; ch < nChunks16; ch += 256)
+  for (u32 ch = threadIdx.x; ch < nChunks; ch += 256)
   {
     uint4 x;
     if (a0 + ch * 16 + 16 <= blobEnd) x = *reinterpret_cast<const uint4*>(blob + a0 + ch * 16);
@@ -349,7 +617,6 @@ k_fast_decode(BandParams p, FastWalkPlan wp, const u8* __restrict__ blob, u32 da
   A %= 65535u; B %= 65535u;
   A = waveSum(A); B = waveSum(B);
   if (lane == 0) { s_fa[w] = A; s_fb[w] = B; }
-  if (threadIdx.x == 0) { s_nB = 0; s_bad = 0; }
   __syncthreads();
   if (threadIdx.x == 0)
   {
@@ -357,111 +624,53 @@ k_fast_decode(BandParams p, FastWalkPlan wp, const u8* __restrict__ blob, u32 da
     atomicAdd(&slotFletcher[2 * slot], (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u);
     atomicAdd(&slotFletcher[2 * slot + 1], (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u);
   }
+  PROBE(9);
 
-  // ---- block starts: one lane per sub-chunk walks from its (agreed) entry to the next known entry
+  // ---- parse the 64 block headers once: lane = block
   const u32 pattern = (p.version >= 5) ? 14u : 15u;
   if (w == 0)
   {
-    u32 start = kNoOffset;
-    if (lane < NL)
-    {
-      const u32 g = (u32)lane / NS, j = (u32)lane % NS;
-      if (c0 + g < c1) start = (j == 0) ? chunkEntry[c0 + g] : subEntry[(size_t)(c0 + g) * NS + j];
-      // an entry that is not behind the previous known one cannot be right (never happens for agreed values)
-      if (start != kNoOffset && (start < g0 || start >= g1)) start = kNoOffset;    // nothing left to walk from there
-    }
-    const u64 known = __ballot(start != kNoOffset);
-    // limit = start of the next lane with a known start, or the end of the span
-    const u64 later = (lane < 63) ? (known >> (lane + 1)) : 0ull;
-    const int nextLane = later ? lane + 1 + (__ffsll((long long)later) - 1) : -1;
-    const u32 nextStart = __shfl(start, nextLane < 0 ? lane : nextLane);
-    const u32 limit = (nextLane < 0) ? g1 : nextStart;
-    // a later lane may name a start inside an earlier lane's range only if both are on the same chain;
-    // duplicates (two boundaries passed by one block) are dropped: a lane whose start equals the previous
-    // known start would emit the same blocks twice
-    u32 n = 0;
-    bool bad = false;
-    if (start != kNoOffset && start < limit)
-    {
-      u32 cur = start;
-      while (cur < limit)
-      {
-        BlkLite b;
-        if (!parseLds<DT>(s_in, a0, cur, g1, p.version, b)) { bad = true; break; }
-        cur += b.len; n++;
-      }
-      if (cur != limit) bad = true;
-    }
-    u32 inc = n;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += o; }
-    const u32 total = __shfl(inc, 63);
-    u32 at = inc - n;
-    if (total > (u32)kMaxBlocksPerWG) bad = true;
-    if (!__any(bad) && start != kNoOffset && start < limit)
-    {
-      u32 cur = start;
-      while (cur < limit)
-      {
-        BlkLite b;
-        parseLds<DT>(s_in, a0, cur, g1, p.version, b);
-        s_boff[at++] = (u16)(cur - a0);
-        cur += b.len;
-      }
-    }
-    if (lane == 0) { s_nB = total; s_bad = __any(bad) ? 1u : 0u; }
-    else (void)__any(bad);
-  }
-  __syncthreads();
-  const u32 nB = s_nB;
-  if (s_bad || nB != chunkBase[c1] - chunkBase[c0])
-  {
-    if (threadIdx.x == 0) atomicOr(fallback, 32u);
-    return;
-  }
-
-  // ---- parse every block header once: thread = block
-  const u32 B0 = chunkBase[c0];
-  bool anyBad = false;
-  for (u32 i = threadIdx.x; i < nB; i += 256)
-  {
-    const u32 off = a0 + s_boff[i];
-    const u32 blkIdx = B0 + i;
-    const int jt = (int)(blkIdx % (u32)p.nTH);
-    const int j0 = jt * 8;
-    BlkLite bl;
-    bool ok = parseLds<DT>(s_in, a0, off, g1, p.version, bl);
-    ok = ok && ((((u32)bl.flag >> 2) & pattern) == (((u32)j0 >> 3) & pattern));
+    const u32 off = s_off[lane];
+    const u32 jt = (u32)(wgc * kFastBlocksPerWG + lane);
+    u32 h0, h1, h2;
+    ldsHeader<DT>(s_in, off - a0, h0, h1, h2);
+    u32 code = parseCode<DT>(h0, h1, h2, p.version);
+    if (off + codeLen(code) != s_off[lane + 1]) code = 0;
+    if (((h0 >> 2) & pattern) != (jt & pattern)) code = 0;    // signature = (j0 >> 3) & pattern, j0 = 8 jt
     double offset = 0;
-    if (ok && (bl.mode == 1 || bl.mode == 3))
-      offset = typedFromBits(getBytes(reinterpret_cast<const u8*>(s_in) + (off - a0) + 1, bl.offBytes), bl.dtUsed);
-    s_offs[i] = offset;
-    s_pbit[i] = 8u * (off - a0 + bl.payload);
-    s_meta[i] = ok ? ((u32)bl.mode | ((u32)bl.lut << 2) | ((u32)bl.nb << 3) | (bl.nLut << 8) | 0x80000000u) : 0u;
-    if (!ok) anyBad = true;
+    const u32 mode = codeMode(code);
+    if (code && (mode == 1 || mode == 3))
+    {
+      const u32 offB = codeOffBytes(code);
+      u64 bits = (((u64)h1 << 32) | h0) >> 8;
+      if (DT == DT_Double) bits |= (u64)h2 << 56;
+      if (offB < 8) bits &= (1ull << (8 * offB)) - 1;
+      offset = typedFromBits(bits, typeUsed(DT, (int)((h0 >> 6) & 3u)));
+    }
+    s_offs[lane] = offset;
+    s_code[lane] = code;
+    if (__any(code == 0u) && lane == 0) raiseError(st, kFailed, blockIdx.x);
   }
-  if (anyBad) raiseError(st, kFailed, blockIdx.x);
   __syncthreads();
+  PROBE(10);
 
-  // ---- pixels: wave tiles of BPW adjacent blocks (global block index / BPW), 8 rows x 128 bytes per wave
-  const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
+  const i64 rowBase = (i64)(it * 8 + r) * p.nCols + (i64)wgc * (kFastBlocksPerWG * 8);
   const i64 invI = (i64)p.invScale, zMaxI = (i64)p.zMaxHdr;
-  const u32 firstTile = B0 / BPW, lastTile = (B0 + nB - 1) / BPW;
   bool bad = false;
-  for (u32 tile = firstTile + (u32)w; tile <= lastTile && nB > 0; tile += 4)
+#pragma unroll
+  for (int t = 0; t < IT; t++)
   {
-    const u32 blkIdx = tile * BPW + (u32)b;
-    if (blkIdx < B0 || blkIdx >= B0 + nB) continue;    // that block belongs to a neighbouring workgroup
-    const u32 i = blkIdx - B0;
-    const u32 meta = s_meta[i];
-    const u32 pbit = s_pbit[i];
-    const double offset = s_offs[i];
-    const int mode = (int)(meta & 3u);
+    const int tile = t * 4 + w;
+    const int blk = tile * BPW + b;
+    const u32 code = s_code[blk];
+    const double offset = s_offs[blk];
+    const u32 mode = codeMode(code), lut = codeLut(code), offB = codeOffBytes(code);
+    const u32 pbit = 8u * (s_off[blk] - a0 + ((mode == 1u) ? 3u + offB + lut : 1u));    // payload / first raw value
     const int e0 = r * 8 + h * V;
     T v[V];
 #pragma unroll
     for (int k = 0; k < V; k++) v[k] = T(0);
-    if (meta >> 31)
+    if (code)
     {
       if (mode == 0)
       {
@@ -482,9 +691,9 @@ k_fast_decode(BandParams p, FastWalkPlan wp, const u8* __restrict__ blob, u32 da
       }
       else if (mode == 1)
       {
-        const int nb = (int)((meta >> 3) & 31u);
+        const int nb = (int)codeBits(code);
         const i64 offI = (i64)offset;
-        if (!((meta >> 2) & 1u))
+        if (!lut)
         {
 #pragma unroll
           for (int k = 0; k < V; k++)
@@ -492,7 +701,7 @@ k_fast_decode(BandParams p, FastWalkPlan wp, const u8* __restrict__ blob, u32 da
         }
         else
         {
-          const u32 nLut = (meta >> 8) & 0xFFu;
+          const u32 nLut = codeNLut(code);
           const int nbIdx = bitLen(nLut);
           const u32 idxBit = pbit + 8u * ((nLut * (u32)nb + 7) >> 3);
 #pragma unroll
@@ -506,16 +715,14 @@ k_fast_decode(BandParams p, FastWalkPlan wp, const u8* __restrict__ blob, u32 da
         }
       }
     }
-    const u32 it = blkIdx / (u32)p.nTH, jt = blkIdx - it * (u32)p.nTH;
     struct alignas(sizeof(T) * V) Vec { T e[V]; };
     Vec o;
 #pragma unroll
     for (int k = 0; k < V; k++) o.e[k] = v[k];
-    *reinterpret_cast<Vec*>(outPix + (i64)(it * 8 + (u32)r) * p.nCols + (i64)jt * 8 + h * V) = o;
+    *reinterpret_cast<Vec*>(outPix + rowBase + tile * C::TILE_COLS + c * V) = o;
   }
-  if (bad) raiseError(st, kFailed, blockIdx.x);
-  // the last workgroup proves that the stream holds exactly the expected number of blocks
-  if (c1 == wp.nChunks && threadIdx.x == 0 && B0 + nB != wp.nBlocks) atomicOr(fallback, 64u);
+  PROBE(11);
+  if (__any(bad) && lane == 0) raiseError(st, kFailed, blockIdx.x);
 }
 
 __global__ void __launch_bounds__(64) k_fast_fletcher_sum(u64* __restrict__ slotFletcher, u64* __restrict__ out2)
@@ -540,6 +747,7 @@ FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 dataBegin, u32 blobEnd)
   const u32 span = blobEnd > dataBegin ? blobEnd - dataBegin : 0;
   wp.nChunks = span ? (span + kFastChunkBytes - 1) / kFastChunkBytes : 1;
   wp.nBlocks = (u32)(nRows / 8) * (u32)(nCols / 8);
+  wp.chainCap = wp.nChunks * (u32)kFastChainsPerChunk;
   return wp;
 }
 
@@ -548,27 +756,34 @@ static void launchFastDecodeT(int stage, const BandParams& p, const FastWalkPlan
                               const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st)
 {
   constexpr int DT = DtOf<T>::v;
-  constexpr int TBYTES = (int)sizeof(T);
-  if (stage == 0)
+  switch (stage)
   {
-    const u32 nWG = (wp.nChunks + kWalkChunksPerWG - 1) / kWalkChunksPerWG;
-    hipMemsetAsync(b.countAt, 0xFF, (size_t)wp.nChunks * kFastWindow(TBYTES) * 2, st);
-    hipLaunchKernelGGL(k_fast_walk<DT>, dim3(nWG), dim3(256), 0, st, p.version, wp, blob, dataBegin, blobEnd, b.chunkExit, b.countAt,
-                       b.subEntry, b.fallback);
-  }
-  else if (stage == 1)
-  {
-    hipLaunchKernelGGL(k_fast_resolve, dim3((wp.nChunks + 256) / 256), dim3(256), 0, st, wp, (u32)kFastWindow(TBYTES), dataBegin, blobEnd,
-                       (const u32*)b.chunkExit, (const u16*)b.countAt, b.chunkEntry, b.chunkCount, b.fallback);
-    launchExclusiveScan(b.chunkCount, b.chunkBase, wp.nChunks, b.scanScratch, st);
-  }
-  else
-  {
-    const u32 nWG = (wp.nChunks + kDecodeChunksPerWG - 1) / kDecodeChunksPerWG;
-    hipMemsetAsync(b.slotFletcher, 0, 2 * kFastSlots * 8, st);
-    hipLaunchKernelGGL(k_fast_decode<T>, dim3(nWG), dim3(256), 0, st, p, wp, blob, dataBegin, blobEnd, (const u32*)b.chunkEntry,
-                       (const u32*)b.chunkBase, (const u32*)b.subEntry, (T*)out, b.slotFletcher, b.fallback, status);
-    hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1), dim3(64), 0, st, b.slotFletcher, b.fletcherOut);
+    case 0:
+      hipMemsetAsync(b.chainCount, 0, 4, st);
+      hipLaunchKernelGGL(k_fast_candidates<DT>, dim3((wp.nChunks + kWalkG - 1) / kWalkG), dim3(256), 0, st, p.version, wp, blob, dataBegin,
+                         blobEnd, b.chunkListN, b.chunkList, b.chains, b.chainCount, wp.chainCap, b.fallback);
+      break;
+    case 1:
+      hipLaunchKernelGGL(k_fast_chains<DT>, dim3((wp.chainCap + 255) / 256), dim3(256), 0, st, p.version, blob, dataBegin, blobEnd, b.chains,
+                         (const u32*)b.chainCount, wp.chainCap);
+      break;
+    case 2:
+      hipLaunchKernelGGL(k_fast_resolve<DT>, dim3((wp.nChunks + 256) / 256), dim3(256), 0, st, p.version, wp, blob, dataBegin, blobEnd,
+                         (const u32*)b.chunkListN, (const u64*)b.chunkList, (const FastChain*)b.chains, b.chunkEntry, b.chunkCount,
+                         b.subEntry, b.subIndex, b.fallback);
+      launchExclusiveScan(b.chunkCount, b.chunkBase, wp.nChunks, b.scanScratch, st);
+      break;
+    case 3:
+      hipLaunchKernelGGL(k_fast_emit<DT>, dim3((wp.nChunks * kFastSubPerChunk + 255) / 256), dim3(256), 0, st, p.version, wp, blob, blobEnd,
+                         (const u32*)b.chunkEntry, (const u32*)b.chunkCount, (const u32*)b.chunkBase, (const u32*)b.subEntry,
+                         (const u32*)b.subIndex, b.blockOff, b.fallback);
+      break;
+    default:
+      hipMemsetAsync(b.slotFletcher, 0, 2 * kFastSlots * 8, st);
+      hipLaunchKernelGGL(k_fast_decode<T>, dim3(fastEncodeNumWG(p.nRows, p.nCols)), dim3(256), 0, st, p, blob, blobEnd, (const u32*)b.blockOff,
+                         (T*)out, b.slotFletcher, (const u32*)b.fallback, status);
+      hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1), dim3(64), 0, st, b.slotFletcher, b.fletcherOut);
+      break;
   }
 }
 

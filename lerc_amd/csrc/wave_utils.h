@@ -2,6 +2,23 @@
 #pragma once
 #include "lerc_common.h"
 
+// Phase probes (tuning tool, `make probe` only): thread 0 of every workgroup adds the shader cycles between
+// consecutive PROBE(i) points to slot i of a per-file device array; tools/probe_phases.py prints the totals.
+// The product build compiles them to nothing.
+#if defined(LERC_PROBE) && !defined(HIPSIM)
+#define PROBE_DEFINE(tag) \
+  static __device__ unsigned long long g_probe[32]; \
+  extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_##tag(unsigned long long* out, int reset) \
+  { hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof(g_probe)); \
+    if (reset) { unsigned long long z[32] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)); } }
+#define PROBE_BEGIN unsigned long long probeT_ = clock64()
+#define PROBE(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = clock64(); atomicAdd(&g_probe[i], n_ - probeT_); probeT_ = n_; } } while (0)
+#else
+#define PROBE_DEFINE(tag)
+#define PROBE_BEGIN
+#define PROBE(i)
+#endif
+
 namespace lerc {
 
 __device__ __forceinline__ int laneId() { return (int)(threadIdx.x & 63); }

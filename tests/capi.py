@@ -62,6 +62,11 @@ class LercLib:
         self.lib.lerc_amd_path_counters(None, out)
         return tuple(int(v) for v in out)
 
+    def last_note(self):
+        self.lib.lerc_amd_last_note.argtypes = [ct.c_void_p]
+        self.lib.lerc_amd_last_note.restype = ct.c_char_p
+        return self.lib.lerc_amd_last_note(None).decode()
+
     # ------------------------------------------------------------------ helpers
     @staticmethod
     def _dims(arr, n_depth, n_bands):
