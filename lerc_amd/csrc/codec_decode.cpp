@@ -312,21 +312,22 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
       fbuf.chunkListN = ctx.allocT<u32>(fwp.nChunks + 4);
       fbuf.chunkList = ctx.allocT<u64>((size_t)fwp.nChunks * kFastListCap + 4);
       fbuf.chains = ctx.allocT<FastChain>((size_t)fwp.chainCap + 4);
-      fbuf.chainCount = ctx.allocT<u32>(4);
+      fbuf.chainCount = ctx.allocT<u32>(fwp.nChunks / kFastCandChunks + 4);
       fbuf.chunkEntry = ctx.allocT<u32>(fwp.nChunks + 4);
       fbuf.chunkCount = ctx.allocT<u32>(fwp.nChunks + 4);
       fbuf.chunkBase = ctx.allocT<u32>(fwp.nChunks + 4);
       fbuf.subEntry = ctx.allocT<u32>((size_t)fwp.nChunks * kFastSubPerChunk + 4);
       fbuf.subIndex = ctx.allocT<u32>((size_t)fwp.nChunks * kFastSubPerChunk + 4);
       fbuf.blockOff = ctx.allocT<u32>((size_t)fwp.nBlocks + 4);
-      fbuf.slotFletcher = ctx.allocT<u64>(2 * kFastSlots);
       fbuf.fletcherOut = ctx.allocT<u64>(2);
       fbuf.scanScratch = ctx.allocT<u32>(fwp.nChunks / 1024 + 8);
-      fbuf.fallback = ctx.allocT<u32>(4);
-      if (!fbuf.chunkListN || !fbuf.chunkList || !fbuf.chains || !fbuf.chainCount || !fbuf.chunkEntry || !fbuf.chunkCount
-        || !fbuf.chunkBase || !fbuf.subEntry || !fbuf.subIndex || !fbuf.blockOff || !fbuf.slotFletcher || !fbuf.fletcherOut || !fbuf.scanScratch
-        || !fbuf.fallback) return kFailed;
-      hipMemsetAsync(fbuf.fallback, 0, 16, st);
+      // the small cells the kernels accumulate into sit together: one memset clears them
+      u8* cells = ctx.allocT<u8>(32 + 2 * kFastSlots * 8);
+      fbuf.fallback = reinterpret_cast<u32*>(cells);
+      fbuf.slotFletcher = reinterpret_cast<u64*>(cells + 32);
+      if (!fbuf.chunkListN || !fbuf.chunkList || !fbuf.chains || !fbuf.chainCount || !cells || !fbuf.chunkEntry || !fbuf.chunkCount
+        || !fbuf.chunkBase || !fbuf.subEntry || !fbuf.subIndex || !fbuf.blockOff || !fbuf.fletcherOut || !fbuf.scanScratch) return kFailed;
+      if (cells) hipMemsetAsync(cells, 0, 32 + 2 * kFastSlots * 8, st);
       static const char* kStage[kFastDecodeStages] = { "fast_candidates", "fast_chains", "fast_resolve_scan", "fast_emit_offsets", "fast_decode" };
       for (int stage = 0; stage < kFastDecodeStages; stage++)
       {

@@ -408,9 +408,8 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
     fb.slotFletcher = ctx.allocT<u64>(2 * kFastSlots);
     fb.scanScratch = ctx.allocT<u32>(nWG / 1024 + 8);
     fb.result = ctx.allocT<FastEncodeResult>(1);
-    BandStats* dRow0 = ctx.allocT<BandStats>(1);
-    u64* dKeys = ctx.allocT<u64>(2);
-    if (!fb.desc || !fb.wgSize || !fb.wgBase || !fb.slotMinKey || !fb.slotMaxKey || !fb.slotFlags || !fb.slotFletcher || !fb.scanScratch || !fb.result || !dRow0 || !dKeys)
+    double* dRow0Raise = ctx.allocT<double>(kFastRow0WG * 9);
+    if (!fb.desc || !fb.wgSize || !fb.wgBase || !fb.slotMinKey || !fb.slotMaxKey || !fb.slotFlags || !fb.slotFletcher || !fb.scanScratch || !fb.result || !dRow0Raise)
       return kFailed;
     u32 cand = 0;
     fb.row0RaiseErr = nullptr;
@@ -418,13 +417,7 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
     {
       static const double errCand[9] = { 1, 0.5, 0.1, 0.05, 0.01, 0.005, 0.001, 0.0005, 0.0001 };
       for (int c = 0; c < 9; c++) if (errCand[c] / 2 > rq.maxZErr) cand |= 1u << c;
-      if (cand)
-      {
-        hipMemsetAsync(dRow0, 0, sizeof(BandStats), st);
-        ProfScope ps(ctx, "band_stats_row0");
-        launchBandStats(rq.dt, rq.dData, nullptr, 1, rq.nCols, 1, cand, dKeys, dKeys + 1, dRow0, st);
-        fb.row0RaiseErr = dRow0->raiseErr;
-      }
+      if (cand) fb.row0RaiseErr = dRow0Raise;    // filled by the prepare kernel
     }
     BandParams bp;
     memset(&bp, 0, sizeof(bp));

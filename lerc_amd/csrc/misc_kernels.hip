@@ -72,9 +72,54 @@ __global__ void __launch_bounds__(256) k_scan_add(u32* __restrict__ out, u32 n, 
   for (int i = 0; i < 4; i++) if (base + i < n) out[base + i] += add;
 }
 
+// one launch for moderate n: thread t owns a contiguous run of 4 * ceil(n / 4096) elements, moved as 16-byte vectors
+// (in and out are 16-byte aligned and hold at least that many rounded-up elements: the callers' arrays have slack)
+__global__ void __launch_bounds__(1024) k_scan_single(const u32* __restrict__ in, u32* __restrict__ out, u32 n)
+{
+  __shared__ u32 s_w[16];
+  const u32 per4 = (n + 4095u) / 4096u;                   // vectors per thread
+  const u32 begin = threadIdx.x * per4 * 4u;
+  u32 sum = 0;
+#pragma unroll 4
+  for (u32 q = 0; q < per4; q++)
+  {
+    const u32 i = begin + q * 4u;
+    if (i >= n) break;
+    const uint4 x = *reinterpret_cast<const uint4*>(in + i);
+    sum += x.x + (i + 1 < n ? x.y : 0u) + (i + 2 < n ? x.z : 0u) + (i + 3 < n ? x.w : 0u);
+  }
+  const u32 inc = waveInclusiveScan(sum);
+  if (laneId() == 63) s_w[waveId()] = inc;
+  __syncthreads();
+  u32 run = inc - sum;
+  for (int i = 0; i < waveId(); i++) run += s_w[i];
+#pragma unroll 4
+  for (u32 q = 0; q < per4; q++)
+  {
+    const u32 i = begin + q * 4u;
+    if (i >= n) break;
+    const uint4 x = *reinterpret_cast<const uint4*>(in + i);
+    uint4 o;
+    o.x = run; run += x.x;
+    o.y = run; run += (i + 1 < n ? x.y : 0u);
+    o.z = run; run += (i + 2 < n ? x.z : 0u);
+    o.w = run; run += (i + 3 < n ? x.w : 0u);
+    if (i + 3 < n) *reinterpret_cast<uint4*>(out + i) = o;
+    else { out[i] = o.x; if (i + 1 < n) out[i + 1] = o.y; if (i + 2 < n) out[i + 2] = o.z; }
+  }
+  // the thread that holds element n - 1 (or the last one with none left of it) knows the total
+  const u32 lastOwner = min((n - 1u) / (per4 * 4u), 1023u);
+  if (threadIdx.x == lastOwner) out[n] = run;
+}
+
 void launchExclusiveScan(const u32* in, u32* out, u32 n, u32* scratch, hipStream_t stream)
 {
   if (n == 0) { hipMemsetAsync(out, 0, 4, stream); return; }
+  if (n <= (1u << 18) && in != out && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0)
+  {
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, in, out, n);
+    return;
+  }
   const u32 nPart = (n + 1023) / 1024;
   hipLaunchKernelGGL(k_scan_local, dim3(nPart), dim3(256), 0, stream, in, out, n, scratch);
   hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, stream, scratch, nPart, out + n);

@@ -21,6 +21,7 @@ struct FastEncodeResult
   u32 checksum;
 };
 
+static const int kFastRow0WG = 16;         // workgroups that look at the first raster row (TryRaiseMaxZError)
 static const int kFastSlots = 64;          // atomics of the workgroups are spread over this many global slots
 
 struct FastBlockDesc      // what pass 1 decided for one block; pass 2 packs from it
@@ -40,7 +41,7 @@ struct FastEncodeBuffers
   u32* slotFlags;      // [kFastSlots] bit 0 NaN seen, bit 1 non-integer value seen
   u64* slotFletcher;   // [2 * kFastSlots] Fletcher partial sums of the bytes the workgroups wrote
   u32* scanScratch;
-  double* row0RaiseErr;    // [9] TryRaiseMaxZError rounding errors of the first row (float types), or nullptr
+  double* row0RaiseErr;    // [kFastRow0WG * 9] TryRaiseMaxZError rounding errors of the first row, one set per workgroup (float types), or nullptr
   FastEncodeResult* result;
 };
 
@@ -56,6 +57,7 @@ static const u32 kFastSubBytes = 512;      // the chains also note the first blo
 static const int kFastSubPerChunk = (int)(kFastChunkBytes / kFastSubBytes);
 static const int kFastListCap = 64;        // surviving block-start candidates listed per chunk
 static const int kFastChainsPerChunk = 16; // capacity of the chain array per chunk (a handful in practice)
+static const int kFastCandChunks = 8;      // chunks per workgroup of the candidate filter
 // longest block the streaming walk accepts: the raw form (the reference encoder never emits a longer one)
 constexpr u32 kFastWindow(int typeBytes) { return 2u + 64u * (u32)typeBytes; }
 
@@ -78,7 +80,7 @@ struct FastDecodeBuffers
   u32* chunkListN;     // [nChunks] entries of chunkList in use
   u64* chunkList;      // [nChunks * kFastListCap] start offset in the chunk | steps taken << 16 | chain index << 32
   FastChain* chains;   // [chainCap]
-  u32* chainCount;     // [1]
+  u32* chainCount;     // [ceil(nChunks / kFastCandChunks)] chains in use in each workgroup's slice of `chains`
   u32* chunkEntry;     // [nChunks + 1]
   u32* chunkCount;     // [nChunks]
   u32* chunkBase;      // [nChunks + 1]

@@ -271,7 +271,11 @@ k_fast_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u32 nW
     {
       const int fac[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
       for (int c = 0; c < 9; c++)
-        if (((raiseCandidates >> c) & 1u) && !(row0RaiseErr[c] / fac[c] > requestedMaxZErr / 2)) redo |= kRedoRaise;
+      {
+        double e = 0;
+        for (u32 w = 0; w < kFastRow0WG; w++) { const double x = row0RaiseErr[w * 9 + c]; e = x > e ? x : e; }
+        if (((raiseCandidates >> c) & 1u) && !(e / fac[c] > requestedMaxZErr / 2)) redo |= kRedoRaise;
+      }
     }
   }
   if (zMin == zMax) redo |= kRedoConst;
@@ -556,11 +560,55 @@ k_fast_checksum(const u64* __restrict__ slotFletcher, u8* __restrict__ out, Fast
   res->checksum = cs;
 }
 
-__global__ void __launch_bounds__(64) k_fast_init_slots(u64* slotMinKey, u64* slotMaxKey, u32* slotFlags, u64* slotFletcher)
+// Before the passes: clear the accumulation slots and, for float types, look at the first raster row the way
+// Lerc2::TryRaiseMaxZError does (Lerc2.cpp:1245-1290): per candidate factor the largest rounding error, one partial
+// result per workgroup (k_fast_decide folds them).
+template<class T>
+__global__ void __launch_bounds__(256)
+k_fast_prepare(const T* __restrict__ data, int nCols, u32 raiseCand, double* __restrict__ row0Partial, u64* slotMinKey, u64* slotMaxKey,
+               u32* slotFlags, u64* slotFletcher)
 {
-  const int lane = laneId();
-  slotMinKey[lane] = ~0ull; slotMaxKey[lane] = 0ull; slotFlags[lane] = 0u;
-  slotFletcher[2 * lane] = 0ull; slotFletcher[2 * lane + 1] = 0ull;
+  __shared__ u64 s_r[4][9];
+  const int lane = laneId(), w = waveId();
+  if (blockIdx.x == 0 && w == 0)
+  {
+    slotMinKey[lane] = ~0ull; slotMaxKey[lane] = 0ull; slotFlags[lane] = 0u;
+    slotFletcher[2 * lane] = 0ull; slotFletcher[2 * lane + 1] = 0ull;
+  }
+  if (!row0Partial) return;
+  double rerr[9];
+#pragma unroll
+  for (int c = 0; c < 9; c++) rerr[c] = 0;
+  const int facCand[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
+  for (int i = (int)(blockIdx.x * 256u + threadIdx.x); i < nCols; i += (int)(gridDim.x * 256u))
+  {
+    const double x = (double)data[i];
+    if (x != x) continue;    // a NaN sends the band to the general path anyway
+#pragma unroll
+    for (int c = 0; c < 9; c++)    // candidates in increasing factor order, stop at the first exact hit
+    {
+      if (!((raiseCand >> c) & 1u)) continue;
+      const double z = x * facCand[c];
+      if (z == (double)(int)z) break;
+      const double dlt = fabs(floor(z + 0.5) - z);
+      rerr[c] = dlt > rerr[c] ? dlt : rerr[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 9; c++)
+  {
+    u64 bits; const double e = rerr[c]; memcpy(&bits, &e, 8);    // non-negative doubles order like their bit patterns
+    bits = waveMax(bits);
+    if (lane == 0) s_r[w][c] = bits;
+  }
+  __syncthreads();
+  if (threadIdx.x < 9)
+  {
+    u64 m = s_r[0][threadIdx.x];
+    for (int i = 1; i < 4; i++) m = s_r[i][threadIdx.x] > m ? s_r[i][threadIdx.x] : m;
+    double e; memcpy(&e, &m, 8);
+    row0Partial[blockIdx.x * 9 + threadIdx.x] = e;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -582,7 +630,8 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
   const u32 nWG = fastEncodeNumWG(p.nRows, p.nCols);
   if (stage == 0)
   {
-    hipLaunchKernelGGL(k_fast_init_slots, dim3(1), dim3(64), 0, st, b.slotMinKey, b.slotMaxKey, b.slotFlags, b.slotFletcher);
+    hipLaunchKernelGGL(k_fast_prepare<T>, dim3(b.row0RaiseErr ? kFastRow0WG : 1), dim3(256), 0, st, (const T*)data, p.nCols, raiseCand,
+                       b.row0RaiseErr, b.slotMinKey, b.slotMaxKey, b.slotFlags, b.slotFletcher);
     hipLaunchKernelGGL(k_fast_stats<T>, dim3(nWG), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.slotMinKey, b.slotMaxKey, b.slotFlags);
   }
   else if (stage == 1)

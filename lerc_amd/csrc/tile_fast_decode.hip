@@ -159,14 +159,14 @@ __device__ __forceinline__ u32 stepGlobal(const u8* __restrict__ blob, u32 cur, 
 // ------------------------------------------------------------------------------------------------
 // candidates
 // ------------------------------------------------------------------------------------------------
-static const int kWalkG = 4;                 // chunks per workgroup
+static const int kWalkG = kFastCandChunks;    // chunks per workgroup
 static const int kFilterSteps = 4;
 static const u32 kSurvivorCap = 512;         // survivors of a workgroup after the last filter step
 static const u32 kHashSize = 1024;
-static const u32 kChainCap = 128;            // distinct chains of a workgroup
+static const u32 kChainCap = kFastCandChunks * kFastChainsPerChunk;    // distinct chains of a workgroup (its slice of the chain array)
 
 // appends e for the lanes with p; call in wave-uniform control flow
-__device__ __forceinline__ void queuePush(bool p, u64 e, u64* q, u32* qn, u32 cap, u32* over)
+__device__ __forceinline__ void queuePush(bool p, u32 e, u32* q, u32* qn, u32 cap, u32* over)
 {
   const u64 m = __ballot(p);
   if (!m) return;
@@ -181,62 +181,74 @@ __device__ __forceinline__ void queuePush(bool p, u64 e, u64* q, u32* qn, u32 ca
   }
 }
 
-// queue entry: candidate index g * W + o (16) | position relative to the group start (16) << 16 | signature (4) << 32 | steps (4) << 36 | hash slot (16) << 40 | chain owner << 56
-__device__ __forceinline__ u64 qMake(u32 f, u32 curRel, u32 sig, u32 steps) { return (u64)f | ((u64)curRel << 16) | ((u64)(sig & 15u) << 32) | ((u64)steps << 36); }
+// queue entry: candidate index g * W + o (13) | position relative to the chunk start (12) << 13 | signature (4) << 25 | steps (3) << 29
+__device__ __forceinline__ u32 qMake(u32 f, u32 rel, u32 sig, u32 steps) { return f | (rel << 13) | ((sig & 15u) << 25) | (steps << 29); }
+__device__ __forceinline__ u32 qCand(u32 e) { return e & 0x1FFFu; }
+__device__ __forceinline__ u32 qRel(u32 e) { return (e >> 13) & 0xFFFu; }
+__device__ __forceinline__ u32 qSig(u32 e) { return (e >> 25) & 15u; }
+__device__ __forceinline__ u32 qSteps(u32 e) { return e >> 29; }
 
+// Only the head of every chunk is needed here: a candidate starts inside the window and takes kFilterSteps - 1
+// steps before the header of its last block is read.
 template<int DT>
 __global__ void __launch_bounds__(256)
 k_fast_candidates(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
                   u32* __restrict__ chunkListN, u64* __restrict__ chunkList, FastChain* __restrict__ chains, u32* __restrict__ chainCount,
-                  u32 chainCap, u32* __restrict__ fallback)
+                  u32* __restrict__ fallback)
 {
   constexpr int TBYTES = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
-  constexpr u32 W = kFastWindow(TBYTES);
-  constexpr u32 kStage = kWalkG * kFastChunkBytes + W + 48;
-  constexpr u32 kQueueCap = (kWalkG * W * 3) / 4;    // live candidates after the first filter step (about 3/8 on noise)
-  __shared__ __align__(16) u32 s_in[kStage / 4 + 8];
-  __shared__ u64 s_qa[kQueueCap], s_qb[kQueueCap];
+  constexpr u32 W = kFastWindow(TBYTES), RAW = 1 + 64 * TBYTES;
+  constexpr u32 kHead = (W + (kFilterSteps - 1) * RAW + 16 + 15) & ~15u;    // staged bytes per chunk, from its 16-byte aligned start
+  constexpr u32 kSlice = kHead + 32;                                        // LDS bytes per chunk
+  constexpr u32 kQueueCap = (kWalkG * W * 3) / 4;                           // live candidates after the first filter step (about 3/8 on noise)
+  constexpr int kRounds = (int)((kWalkG * (kSlice / 16) + 255) / 256);
+  static_assert(kWalkG * W <= 0x2000 && W - 1 + (kFilterSteps - 1) * RAW <= 0xFFF, "queue entry fields");
+  __shared__ __align__(16) u32 s_in[kWalkG * kSlice / 4];
+  __shared__ u32 s_qa[kQueueCap], s_qb[kQueueCap];
   __shared__ u32 s_hkey[kHashSize];
   __shared__ u16 s_hval[kHashSize];
-  __shared__ u32 s_nq[2], s_nChains, s_over, s_chainBase;
+  __shared__ u16 s_slot[kSurvivorCap];       // hash slot | owner << 15 of every survivor
+  __shared__ u32 s_nq[kFilterSteps], s_nChains, s_over;
   __shared__ u32 s_listN[kWalkG];
 
   PROBE_BEGIN;
   const u32 c0 = blockIdx.x * kWalkG;
-  const u32 groupStart = dataBegin + c0 * kFastChunkBytes;
-  const u32 a0 = groupStart & ~15u;
-  const u32 stageEnd = min(a0 + kStage, blobEnd);
+  const u32 nChunksHere = min((u32)kWalkG, wp.nChunks - c0);
   {
-    constexpr int kRounds = (int)((kStage + 4095) / 4096);
     uint4 x[kRounds];
 #pragma unroll
     for (int k = 0; k < kRounds; k++)    // all loads in flight before the first LDS store
     {
-      const u32 i = ((u32)k * 256u + threadIdx.x) * 16u;
+      const u32 i = (u32)k * 256u + threadIdx.x;
+      const u32 g = i / (kSlice / 16), q = i - g * (kSlice / 16);
+      const u32 src = ((dataBegin + (c0 + g) * kFastChunkBytes) & ~15u) + q * 16u;
       x[k] = make_uint4(0, 0, 0, 0);
-      if (a0 + i + 16 <= stageEnd) x[k] = *reinterpret_cast<const uint4*>(blob + a0 + i);
-      else if (a0 + i < stageEnd)
+      if (g < nChunksHere)
       {
-        u32 t4[4] = { 0, 0, 0, 0 };
-        for (u32 b = 0; a0 + i + b < stageEnd; b++) t4[b >> 2] |= (u32)blob[a0 + i + b] << (8 * (b & 3));    // never read past the blob
-        x[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+        if (src + 16 <= blobEnd) x[k] = *reinterpret_cast<const uint4*>(blob + src);
+        else if (src < blobEnd)
+        {
+          u32 t4[4] = { 0, 0, 0, 0 };
+          for (u32 b = 0; src + b < blobEnd; b++) t4[b >> 2] |= (u32)blob[src + b] << (8 * (b & 3));    // never read past the blob
+          x[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+        }
       }
     }
 #pragma unroll
     for (int k = 0; k < kRounds; k++)
     {
-      const u32 i = ((u32)k * 256u + threadIdx.x) * 16u;
-      if (i < kStage + 16) *reinterpret_cast<uint4*>(reinterpret_cast<u8*>(s_in) + i) = x[k];
+      const u32 i = (u32)k * 256u + threadIdx.x;
+      if (i < kWalkG * (kSlice / 16)) *reinterpret_cast<uint4*>(&s_in[i * 4]) = x[k];
     }
   }
   for (u32 i = threadIdx.x; i < kHashSize; i += 256) s_hkey[i] = 0;
-  if (threadIdx.x == 0) { s_nq[0] = 0; s_nq[1] = 0; s_nChains = 0; s_over = 0; }
+  if (threadIdx.x < kFilterSteps) s_nq[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { s_nChains = 0; s_over = 0; }
   if (threadIdx.x < kWalkG) s_listN[threadIdx.x] = 0;
   __syncthreads();
   PROBE(0);
 
   const u32 pattern = (version >= 5) ? 14u : 15u;
-  const u32 nChunksHere = min((u32)kWalkG, wp.nChunks - c0);
 
   // ---- filter step 1: every window position of every chunk
   const u32 nCand = nChunksHere * W;
@@ -244,61 +256,57 @@ k_fast_candidates(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32
   {
     const u32 f = base + threadIdx.x;
     const u32 g = f / W, o = f - g * W;
-    const u32 chunkStart = groupStart + g * kFastChunkBytes;
+    const u32 chunkStart = dataBegin + (c0 + g) * kFastChunkBytes;
     const u32 chunkEnd = min(chunkStart + kFastChunkBytes, blobEnd);
     const u32 cur = chunkStart + o;
     bool live = (f < nCand) & (cur < chunkEnd) & ((c0 + g != 0) | (o == 0));    // the very first block of the stream is known
     u32 sig = kNoOffset, code = 0;
-    if (live) code = stepAt<DT>(s_in, a0, cur, stageEnd, version, sig, pattern);
+    if (live) code = stepAt<DT>(s_in + g * (kSlice / 4), chunkStart & ~15u, cur, blobEnd, version, sig, pattern);
     live = live & (code != 0u);
-    queuePush(live, qMake(f, cur + codeLen(code) - groupStart, sig, 1), s_qa, &s_nq[0], kQueueCap, &s_over);
+    queuePush(live, qMake(f, o + codeLen(code), sig, 1), s_qa, &s_nq[0], kQueueCap, &s_over);
   }
   __syncthreads();
 
   // ---- filter steps 2 ..: compacted queues (a candidate that reaches its chunk end early just stays)
-  u64* qIn = s_qa;
-  u64* qOut = s_qb;
+  u32* qIn = s_qa;
+  u32* qOut = s_qb;
   for (int s = 1; s < kFilterSteps; s++)
   {
-    const u32 nIn = min(s_nq[(s - 1) & 1], kQueueCap);
-    __syncthreads();
-    if (threadIdx.x == 0) s_nq[s & 1] = 0;
-    __syncthreads();
+    const u32 nIn = min(s_nq[s - 1], kQueueCap);
     for (u32 base = 0; base < nIn; base += 256)
     {
       const u32 i = base + threadIdx.x;
-      const u64 e = (i < nIn) ? qIn[i] : 0;
-      const u32 f = (u32)(e & 0xFFFFu), curRel = (u32)(e >> 16) & 0xFFFFu;
-      const u32 g = f / W;
-      const u32 chunkEnd = min(groupStart + (g + 1) * kFastChunkBytes, blobEnd);
-      const u32 cur = groupStart + curRel;
+      const u32 e = (i < nIn) ? qIn[i] : 0;
+      const u32 g = qCand(e) / W;
+      const u32 chunkStart = dataBegin + (c0 + g) * kFastChunkBytes;
+      const u32 chunkEnd = min(chunkStart + kFastChunkBytes, blobEnd);
+      const u32 cur = chunkStart + qRel(e);
       bool live = i < nIn;
-      u64 out = e;
+      u32 out = e;
       if (live && cur < chunkEnd)
       {
-        u32 sig = (u32)(e >> 32) & 15u;
-        const u32 code = stepAt<DT>(s_in, a0, cur, stageEnd, version, sig, pattern);
+        u32 sig = qSig(e);
+        const u32 code = stepAt<DT>(s_in + g * (kSlice / 4), chunkStart & ~15u, cur, blobEnd, version, sig, pattern);
         live = code != 0u;
-        out = qMake(f, curRel + codeLen(code), sig, ((u32)(e >> 36) & 15u) + 1);
+        out = qMake(qCand(e), qRel(e) + codeLen(code), sig, qSteps(e) + 1);
       }
-      queuePush(live, out, qOut, &s_nq[s & 1], kQueueCap, &s_over);
+      queuePush(live, out, qOut, &s_nq[s], kQueueCap, &s_over);
     }
     __syncthreads();
-    u64* t = qIn; qIn = qOut; qOut = t;
+    u32* t = qIn; qIn = qOut; qOut = t;
   }
-  u64* qs = qIn;                                                   // the survivors
-  const u32 nSvAll = s_nq[(kFilterSteps - 1) & 1];
+  const u32* qs = qIn;                                             // the survivors
+  const u32 nSvAll = s_nq[kFilterSteps - 1];
   const u32 nSv = min(nSvAll, kSurvivorCap);
   PROBE(1);
 
   // ---- merge the survivors into distinct chains: same chunk, position and signature behave alike from here on
   for (u32 i = threadIdx.x; i < nSv; i += 256)
   {
-    const u64 e = qs[i];
-    const u32 g = (u32)(e & 0xFFFFu) / W;
-    const u32 key = ((u32)(e >> 16) & 0xFFFFu) | (((u32)(e >> 32) & 15u) << 16) | (g << 20) | 0x80000000u;
+    const u32 e = qs[i];
+    const u32 key = (e >> 13 & 0xFFFFu) | ((qCand(e) / W) << 16) | 0x80000000u;    // position + signature, chunk
     u32 h = (key * 2654435761u) >> 22;                             // 10 bits
-    u64 owner = 0;
+    u32 owner = 0;
     for (;;)
     {
       const u32 old = atomicCAS(&s_hkey[h], 0u, key);
@@ -306,31 +314,30 @@ k_fast_candidates(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32
       if (old == key) break;
       h = (h + 1) & (kHashSize - 1);
     }
-    qs[i] = e | ((u64)h << 40) | (owner << 56);
+    s_slot[i] = (u16)(h | (owner << 15));
   }
   __syncthreads();
   const u32 nChains = s_nChains;
-  if (threadIdx.x == 0) s_chainBase = atomicAdd(chainCount, nChains);
-  __syncthreads();
-  const u32 chainBase = s_chainBase;
-  const bool over = (s_over != 0u) | (nSvAll > kSurvivorCap) | (nChains > kChainCap) | (chainBase + nChains > chainCap);
+  const u32 chainBase = blockIdx.x * kChainCap;
+  const bool over = (s_over != 0u) | (nSvAll > kSurvivorCap) | (nChains > kChainCap);
+  if (threadIdx.x == 0) chainCount[blockIdx.x] = over ? 0u : nChains;
 
   // ---- hand the chains and the survivor lists (start, steps so far, chain) of every chunk over
   if (!over)
   {
     for (u32 i = threadIdx.x; i < nSv; i += 256)
     {
-      const u64 e = qs[i];
-      const u32 f = (u32)(e & 0xFFFFu), g = f / W, o = f - g * W;
-      const u32 chain = chainBase + s_hval[(u32)(e >> 40) & 0xFFFFu];
+      const u32 e = qs[i];
+      const u32 f = qCand(e), g = f / W, o = f - g * W;
+      const u32 slot16 = s_slot[i];
+      const u32 chain = chainBase + s_hval[slot16 & 0x7FFFu];
       const u32 slot = atomicAdd(&s_listN[g], 1u);
-      if (slot < (u32)kFastListCap)
-        chunkList[(size_t)(c0 + g) * kFastListCap + slot] = (u64)(o | (((u32)(e >> 36) & 15u) << 16)) | ((u64)chain << 32);
-      if ((e >> 56) & 1u)
+      if (slot < (u32)kFastListCap) chunkList[(size_t)(c0 + g) * kFastListCap + slot] = (u64)(o | (qSteps(e) << 16)) | ((u64)chain << 32);
+      if (slot16 >> 15)
       {
         FastChain ch;
-        ch.cur = groupStart + ((u32)(e >> 16) & 0xFFFFu);
-        ch.chunkSig = (c0 + g) | (((u32)(e >> 32) & 15u) << 28);
+        ch.cur = dataBegin + (c0 + g) * kFastChunkBytes + qRel(e);
+        ch.chunkSig = (c0 + g) | (qSig(e) << 28);
         ch.exit = 0; ch.count = 0; ch.alive = 0;
         for (int j = 0; j < kFastSubPerChunk; j++) { ch.marks[j] = 0; ch.markCount[j] = 0; }
         chains[chain] = ch;
@@ -355,8 +362,8 @@ __global__ void __launch_bounds__(256)
 k_fast_chains(int version, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd, FastChain* __restrict__ chains,
               const u32* __restrict__ chainCount, u32 chainCap)
 {
-  const u32 t = blockIdx.x * 256u + threadIdx.x;
-  if (t >= min(*chainCount, chainCap)) return;
+  const u32 t = blockIdx.x * 256u + threadIdx.x;    // chain slot: kChainCap per candidates workgroup
+  if (t >= chainCap || t % kChainCap >= chainCount[t / kChainCap]) return;
   constexpr int NS = kFastSubPerChunk;
   const u32 pattern = (version >= 5) ? 14u : 15u;
   const FastChain ch = chains[t];
@@ -747,7 +754,7 @@ FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 dataBegin, u32 blobEnd)
   const u32 span = blobEnd > dataBegin ? blobEnd - dataBegin : 0;
   wp.nChunks = span ? (span + kFastChunkBytes - 1) / kFastChunkBytes : 1;
   wp.nBlocks = (u32)(nRows / 8) * (u32)(nCols / 8);
-  wp.chainCap = wp.nChunks * (u32)kFastChainsPerChunk;
+  wp.chainCap = ((wp.nChunks + kFastCandChunks - 1) / kFastCandChunks) * (u32)(kFastCandChunks * kFastChainsPerChunk);
   return wp;
 }
 
@@ -759,9 +766,8 @@ static void launchFastDecodeT(int stage, const BandParams& p, const FastWalkPlan
   switch (stage)
   {
     case 0:
-      hipMemsetAsync(b.chainCount, 0, 4, st);
       hipLaunchKernelGGL(k_fast_candidates<DT>, dim3((wp.nChunks + kWalkG - 1) / kWalkG), dim3(256), 0, st, p.version, wp, blob, dataBegin,
-                         blobEnd, b.chunkListN, b.chunkList, b.chains, b.chainCount, wp.chainCap, b.fallback);
+                         blobEnd, b.chunkListN, b.chunkList, b.chains, b.chainCount, b.fallback);
       break;
     case 1:
       hipLaunchKernelGGL(k_fast_chains<DT>, dim3((wp.chainCap + 255) / 256), dim3(256), 0, st, p.version, blob, dataBegin, blobEnd, b.chains,
@@ -779,7 +785,6 @@ static void launchFastDecodeT(int stage, const BandParams& p, const FastWalkPlan
                          (const u32*)b.subIndex, b.blockOff, b.fallback);
       break;
     default:
-      hipMemsetAsync(b.slotFletcher, 0, 2 * kFastSlots * 8, st);
       hipLaunchKernelGGL(k_fast_decode<T>, dim3(fastEncodeNumWG(p.nRows, p.nCols)), dim3(256), 0, st, p, blob, blobEnd, (const u32*)b.blockOff,
                          (T*)out, b.slotFletcher, (const u32*)b.fallback, status);
       hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1), dim3(64), 0, st, b.slotFletcher, b.fletcherOut);
