@@ -23,4 +23,7 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   rocprofv3 --kernel-trace --pmc $SET -d /tmp/prof_pmc$i -o pmc -- $BENCH > /dev/null 2> "$OUT/${TAG}_pmc$i.err"
   DB=$(find /tmp/prof_pmc$i -name '*.db' | head -1)
   { echo "# counters: $SET"; python "$OLDPWD/tools/rocpd_summary.py" "$DB" fast; } > "$OUT/${TAG}_pmc$i.txt" 2>&1
+  [ "$SET" = "FETCH_SIZE" ] && FETCH_DB=$DB
+  [ "$SET" = "WRITE_SIZE" ] && WRITE_DB=$DB
 done
+python "$OLDPWD/tools/rocpd_summary.py" --traffic "$FETCH_DB" "$WRITE_DB" 8192 "$OUT/${TAG}_hbm_traffic.json"
