@@ -51,6 +51,7 @@ public:
 
   // small pinned host mirror for results read back after a sync
   void* pinned(size_t bytes);
+  bool sync();                               // wait for the active stream (polls first: see codec_common.cpp)
 
   std::string lastError;
   std::string lastNote;      // diagnostics that are not errors (why a call left the streaming path)

@@ -260,11 +260,24 @@ void* Context::pinned(size_t bytes)
 {
   if (bytes <= m_pinnedCap) return m_pinned;
   if (m_pinned) hipHostFree(m_pinned);
-  for (hipEvent_t e : m_eventPool) hipEventDestroy(e);
   m_pinned = nullptr; m_pinnedCap = 0;
   if (hipHostMalloc(&m_pinned, bytes + 4096, hipHostMallocDefault) != hipSuccess) return nullptr;
   m_pinnedCap = bytes + 4096;
   return m_pinned;
+}
+
+// Waits for the stream.  A blocking hipStreamSynchronize wakes the thread up tens of microseconds late, which is
+// a tenth of a whole 8192 x 8192 call; calls this short are worth polling for.
+bool Context::sync()
+{
+  hipStream_t st = activeStream();
+  for (int i = 0; i < 20000; i++)
+  {
+    const hipError_t e = hipStreamQuery(st);
+    if (e == hipSuccess) return true;
+    if (e != hipErrorNotReady) return false;
+  }
+  return hipStreamSynchronize(st) == hipSuccess;
 }
 
 hipEvent_t Context::profEvent()

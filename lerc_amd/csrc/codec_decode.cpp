@@ -26,13 +26,17 @@ struct BlobReader
   const u8* cache = nullptr;
   u64 cacheOff = 0;
   size_t cacheLen = 0;
+  Context* ctx = nullptr;    // small device reads go through its pinned mirror (a pageable target costs a staging copy)
   bool read(u64 off, size_t len, u8* dst) const
   {
     if (off + len > n) return false;
     if (h) { memcpy(dst, h + off, len); return true; }
     if (cache && off >= cacheOff && off + len <= cacheOff + cacheLen) { memcpy(dst, cache + (off - cacheOff), len); return true; }
-    if (hipMemcpyAsync(dst, d + off, len, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
-    return hipStreamSynchronize(st) == hipSuccess;
+    u8* pin = (ctx && len <= 4096) ? (u8*)ctx->pinned(4096) : nullptr;
+    if (hipMemcpyAsync(pin ? pin : dst, d + off, len, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+    if (!(ctx ? ctx->sync() : hipStreamSynchronize(st) == hipSuccess)) return false;
+    if (pin) memcpy(dst, pin, len);
+    return true;
   }
 };
 
@@ -71,7 +75,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   const int tb = dtSize(dt);
   const i64 nPix = (i64)nRows * nCols;
   const size_t maskBytes = (size_t)((nPix + 7) >> 3);
-  BlobReader rd{ rq.hBlob, rq.dBlob, rq.blobSize, st, nullptr, 0, 0 };
+  BlobReader rd{ rq.hBlob, rq.dBlob, rq.blobSize, st, nullptr, 0, 0, &ctx };
 
   // ---- walk the band headers (Lerc::GetLercInfo) and check the caller's request against them
   std::vector<BandDesc> bands;
@@ -136,12 +140,17 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     dBlob = stage;
   }
   u8* dBits = ctx.allocT<u8>(maskBytes + 64);
-  DeviceStatus* dStatus = ctx.allocT<DeviceStatus>(1);
+  // everything the host reads back at the end sits together: [status 64 B] then per band
+  // [Fletcher A, B 16 B | fallback bits 16 B | 32 B | 64 Fletcher slot pairs]; one memset before, one copy after
+  const size_t kCellBytes = 64 + 2 * kFastSlots * 8;
+  const size_t cellsBytes = 64 + (size_t)rq.nBands * kCellBytes;
+  u8* dCells = ctx.allocT<u8>(cellsBytes);
+  DeviceStatus* dStatus = reinterpret_cast<DeviceStatus*>(dCells);
   double* dZMax = ctx.allocT<double>(nD);
   u64* dFl = ctx.allocT<u64>((size_t)kFletcherPartials * rq.nBands);
   u8* dPixel = ctx.allocT<u8>((size_t)nD * 8);
-  if (!dBits || !dStatus || !dZMax || !dFl || !dPixel) return kFailed;
-  hipMemsetAsync(dStatus, 0, sizeof(DeviceStatus), st);
+  if (!dBits || !dCells || !dZMax || !dFl || !dPixel) return kFailed;
+  hipMemsetAsync(dCells, 0, cellsBytes, st);
 
   std::vector<u8> hBits;       // current mask (persists across bands: "use previous", Lerc2.cpp:1002)
   bool haveMask = false, maskAllValid = true;
@@ -149,7 +158,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   std::vector<u32> checksumLen(rq.nBands, 0);
   std::vector<u8> small;
   // bands decoded by the streaming kernels: their checksum comes out of the decode kernel itself
-  struct FastBand { bool used = false; u64* dFletcher2 = nullptr; u32* dFallback = nullptr; u64 prefixA = 0, prefixB = 0; };
+  struct FastBand { bool used = false; u64 prefixA = 0, prefixB = 0; };
   std::vector<FastBand> fast(rq.nBands);
 
   for (int iBand = 0; iBand < rq.nBands; iBand++)
@@ -319,15 +328,13 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
       fbuf.subEntry = ctx.allocT<u32>((size_t)fwp.nChunks * kFastSubPerChunk + 4);
       fbuf.subIndex = ctx.allocT<u32>((size_t)fwp.nChunks * kFastSubPerChunk + 4);
       fbuf.blockOff = ctx.allocT<u32>((size_t)fwp.nBlocks + 4);
-      fbuf.fletcherOut = ctx.allocT<u64>(2);
       fbuf.scanScratch = ctx.allocT<u32>(fwp.nChunks / 1024 + 8);
-      // the small cells the kernels accumulate into sit together: one memset clears them
-      u8* cells = ctx.allocT<u8>(32 + 2 * kFastSlots * 8);
-      fbuf.fallback = reinterpret_cast<u32*>(cells);
-      fbuf.slotFletcher = reinterpret_cast<u64*>(cells + 32);
-      if (!fbuf.chunkListN || !fbuf.chunkList || !fbuf.chains || !fbuf.chainCount || !cells || !fbuf.chunkEntry || !fbuf.chunkCount
-        || !fbuf.chunkBase || !fbuf.subEntry || !fbuf.subIndex || !fbuf.blockOff || !fbuf.fletcherOut || !fbuf.scanScratch) return kFailed;
-      if (cells) hipMemsetAsync(cells, 0, 32 + 2 * kFastSlots * 8, st);
+      u8* cells = dCells + 64 + (size_t)iBand * kCellBytes;
+      fbuf.fletcherOut = reinterpret_cast<u64*>(cells);
+      fbuf.fallback = reinterpret_cast<u32*>(cells + 16);
+      fbuf.slotFletcher = reinterpret_cast<u64*>(cells + 64);
+      if (!fbuf.chunkListN || !fbuf.chunkList || !fbuf.chains || !fbuf.chainCount || !fbuf.chunkEntry || !fbuf.chunkCount
+        || !fbuf.chunkBase || !fbuf.subEntry || !fbuf.subIndex || !fbuf.blockOff || !fbuf.scanScratch) return kFailed;
       static const char* kStage[kFastDecodeStages] = { "fast_candidates", "fast_chains", "fast_resolve_scan", "fast_emit_offsets", "fast_decode" };
       for (int stage = 0; stage < kFastDecodeStages; stage++)
       {
@@ -336,7 +343,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
       }
       FastBand& f = fast[iBand];
       ctx.lastDecodeStreamed = true;
-      f.used = true; f.dFletcher2 = fbuf.fletcherOut; f.dFallback = fbuf.fallback;
+      f.used = true;
       for (u32 pos = 0; pos + 14 < fastDataBegin; pos++)    // Fletcher terms of the bytes before the first block
       {
         const u32 cw = (u32)bd.head[14 + pos] << ((pos & 1u) ? 0 : 8);
@@ -381,25 +388,23 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   // ---- one sync: kernel status + checksums
   bool anyGeneric = false;
   for (int iBand = 0; iBand < rq.nBands; iBand++) if (!fast[iBand].used) anyGeneric = true;
-  u8* pin = (u8*)ctx.pinned(sizeof(DeviceStatus) + (size_t)rq.nBands * 32 + 64);
+  u8* pin = (u8*)ctx.pinned(cellsBytes);
   if (!pin) return kFailed;
-  DeviceStatus& hs = *reinterpret_cast<DeviceStatus*>(pin);
-  u64* hFastPin = reinterpret_cast<u64*>(pin + 64);
   std::vector<u64> hFl(anyGeneric ? (size_t)kFletcherPartials * rq.nBands : 0);
-  hipMemcpyAsync(&hs, dStatus, sizeof(hs), hipMemcpyDeviceToHost, st);
+  hipMemcpyAsync(pin, dCells, cellsBytes, hipMemcpyDeviceToHost, st);
   if (anyGeneric) hipMemcpyAsync(hFl.data(), dFl, hFl.size() * 8, hipMemcpyDeviceToHost, st);
-  // per band 4 pinned u64: Fletcher A, B, fallback flag
-  u64* hFast = hFastPin;
+  if (!ctx.sync()) return kFailed;
+  const DeviceStatus hs = *reinterpret_cast<const DeviceStatus*>(pin);
+  // per band: Fletcher A, B, fallback bits (copied out of the pinned mirror, which later calls reuse)
+  std::vector<u64> hFast((size_t)rq.nBands * 4, 0);
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
-    hFast[4 * iBand] = hFast[4 * iBand + 1] = hFast[4 * iBand + 2] = 0;
-    if (fast[iBand].used)
-    {
-      hipMemcpyAsync(&hFast[4 * iBand], fast[iBand].dFletcher2, 16, hipMemcpyDeviceToHost, st);
-      hipMemcpyAsync(&hFast[4 * iBand + 2], fast[iBand].dFallback, 4, hipMemcpyDeviceToHost, st);
-    }
+    if (!fast[iBand].used) continue;
+    const u8* cell = pin + 64 + (size_t)iBand * kCellBytes;
+    memcpy(&hFast[4 * iBand], cell, 16);
+    u32 fb; memcpy(&fb, cell + 16, 4);
+    hFast[4 * iBand + 2] = fb;
   }
-  if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
   if (ctx.profOn()) ctx.profCollect();
   for (int iBand = 0; iBand < rq.nBands; iBand++)
     if (fast[iBand].used && (u32)hFast[4 * iBand + 2])    // caller repeats with the general kernels

@@ -439,7 +439,7 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
     if (!pinRes) return kFailed;
     FastEncodeResult& hres = *pinRes;
     hipMemcpyAsync(&hres, fb.result, sizeof(hres), hipMemcpyDeviceToHost, st);
-    if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
+    if (!ctx.sync()) return kFailed;
     if (ctx.profOn()) ctx.profCollect();
     if (!hres.redo)
     {

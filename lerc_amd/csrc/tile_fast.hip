@@ -95,7 +95,7 @@ __device__ __forceinline__ void quantizeLane(int intLossless, double scale, cons
 }
 
 // number of distinct quantised values in each block of the wave (only meaningful where `need`)
-template<int LPR, int V>
+template<int LB, int V>
 __device__ __forceinline__ u32 groupDistinct(const u32 (&q)[V], bool need)
 {
   u32 count = 0, last = 0;
@@ -106,7 +106,7 @@ __device__ __forceinline__ u32 groupDistinct(const u32 (&q)[V], bool need)
 #pragma unroll
     for (int k = 0; k < V; k++)
       if ((count == 0 || q[k] > last) && q[k] < m) m = q[k];
-    m = groupMin<LPR>(m);
+    m = groupReduce<LB>(m, OpMin());
     if (m == 0xFFFFFFFFu) active = false;
     if (!__any(active)) break;
     if (active) { last = m; count++; }
@@ -143,21 +143,28 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
   __shared__ u32 s_same[kFastBlocksPerWG], s_nd[kFastBlocksPerWG];
   __shared__ u32 s_fl[4];
   PROBE_BEGIN;
+  // a block is LB consecutive lanes (a DPP row for 32-bit types), so that its reductions never leave the VALU:
+  // lane = b * LB + r * LPR + h  (block of the wave tile, raster row of the block, lane of that row)
+  constexpr int LB = 8 * LPR;
   const int w = waveId(), lane = laneId();
-  const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
+  const int b = lane / LB, r = (lane % LB) / LPR, h = lane % LPR, c = b * LPR + h;
   const int wgPerRow = p.nCols / (kFastBlocksPerWG * 8);
   const int it = (int)blockIdx.x / wgPerRow, wgc = (int)blockIdx.x - it * wgPerRow;
   const i64 rowBase = (i64)(it * 8 + r) * p.nCols + (i64)wgc * (kFastBlocksPerWG * 8);
-  const bool leader = (r == 0 && h == 0);
-  const int src = ((h > 0) ? lane - 1 : lane - 8 + (LPR - 1)) & 63;
+  const bool leader = (lane % LB == 0);
+
+  // all loads of the wave in flight before the first use (the data-dependent LUT branch below keeps the compiler
+  // from hoisting them itself)
+  T vAll[C::IT][V];
+#pragma unroll
+  for (int t = 0; t < C::IT; t++) loadLane<T, V>(data + rowBase + (t * 4 + w) * C::TILE_COLS + c * V, vAll[t]);
 
   u32 flags = 0;
 #pragma unroll
   for (int t = 0; t < C::IT; t++)
   {
     const int tile = t * 4 + w;
-    T v[V];
-    loadLane<T, V>(data + rowBase + tile * C::TILE_COLS + c * V, v);
+    T (&v)[V] = vAll[t];
     if (DtOf<T>::v >= DT_Float)
     {
 #pragma unroll
@@ -166,15 +173,16 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
     T mn = v[0], mx = v[0];
 #pragma unroll
     for (int k = 1; k < V; k++) { mn = v[k] < mn ? v[k] : mn; mx = v[k] > mx ? v[k] : mx; }
-    mn = (T)groupMin<LPR>((ST)mn);
-    mx = (T)groupMax<LPR>((ST)mx);
-    // "same as previous" in row-major block order, prevVal starts at 0 (Lerc2.cpp:1729-1758)
-    T prev = shflT<T>(v[V - 1], src);
+    mn = (T)groupReduce<LB>((ST)mn, OpMin());
+    mx = (T)groupReduce<LB>((ST)mx, OpMax());
+    // "same as previous" in row-major block order, prevVal starts at 0 (Lerc2.cpp:1729-1758): the previous
+    // pixel vector of the block lives in the previous lane
+    T prev = (T)dppMovT<kDppWaveShr1>((ST)v[V - 1]);
     if (leader) prev = T(0);
     int same = (v[0] == prev) ? 1 : 0;
 #pragma unroll
     for (int k = 1; k < V; k++) same += (v[k] == v[k - 1]) ? 1 : 0;
-    same = groupSum<LPR>(same);
+    same = groupReduce<LB>(same, OpSum());
     // LUT candidates need the number of distinct quantised values, which only the pixel owners can count
     u32 nd = 0;
     const bool tryLut = (2 * same > 64) && ((double)mx > (double)mn + 3 * p.maxZErr);
@@ -184,7 +192,7 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
       const bool need = tryLut && !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
       u32 q[V];
       quantizeLane<T, V>(p.intLossless, p.scale, v, mn, q);
-      nd = groupDistinct<LPR, V>(q, need);
+      nd = groupDistinct<LB, V>(q, need);
     }
     if (leader)
     {
@@ -196,7 +204,9 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
   if (lane == 0) s_fl[w] = (f1 ? 1u : 0u) | (f2 ? 2u : 0u);
   __syncthreads();
   PROBE(0);
-  if (w != 0) return;
+  // the serial per-block phase rotates over the waves (= SIMDs) from workgroup to workgroup, or one SIMD of the CU
+  // would carry it for every resident workgroup
+  if (w != (int)((blockIdx.x * 2654435761u) >> 30)) return;
 
   // ---- lane = block: the per-block decisions of Lerc2::NumBytesTile, once
   const T mn = s_mn[lane], mx = s_mx[lane];
@@ -368,9 +378,10 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
 #pragma unroll
   for (int t = 0; t < IT; t++) loadLane<T, V>(data + rowBase + (t * 4 + w) * C::TILE_COLS + c * V, v[t]);
   FastBlockDesc d;
-  if (w == 0) d = desc[(size_t)blockIdx.x * kFastBlocksPerWG + lane];
+  const int wPlan = (int)((blockIdx.x * 2654435761u) >> 30);    // the wave that does the per-block work rotates (see k_fast_stats)
+  if (w == wPlan) d = desc[(size_t)blockIdx.x * kFastBlocksPerWG + lane];
   for (int i = threadIdx.x; i < kSpanWords; i += 256) s_out[i] = 0;
-  if (w == 0)
+  if (w == wPlan)
   {
     const u32 sz = d.w1 & 0xFFFFu;
     u32 inc = sz;
@@ -383,7 +394,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
   PROBE(4);
 
   // ---- block headers: lane = block (Lerc2::WriteTile, BitStuffer2 stream header)
-  if (w == 0)
+  if (w == wPlan)
   {
     const u32 w1 = d.w1;
     const int kind = (int)((w1 >> 16) & 7u), tc = (int)((w1 >> 19) & 3u), dtRed = (int)((w1 >> 21) & 7u), nb = (int)(w1 >> 24);

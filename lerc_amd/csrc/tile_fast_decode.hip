@@ -635,7 +635,7 @@ k_fast_decode(BandParams p, const u8* __restrict__ blob, u32 blobEnd, const u32*
 
   // ---- parse the 64 block headers once: lane = block
   const u32 pattern = (p.version >= 5) ? 14u : 15u;
-  if (w == 0)
+  if (w == (int)((blockIdx.x * 2654435761u) >> 30))    // rotates over the waves (= SIMDs) from workgroup to workgroup
   {
     const u32 off = s_off[lane];
     const u32 jt = (u32)(wgc * kFastBlocksPerWG + lane);

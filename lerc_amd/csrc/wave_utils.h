@@ -34,24 +34,98 @@ __device__ __forceinline__ void waveSync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template<class T> __device__ __forceinline__ T waveMin(T v)
+// ------------------------------------------------------------------------------------------------
+// Cross-lane moves that stay in the VALU (no LDS traffic, unlike ds_bpermute behind __shfl*):
+// DPP (data parallel primitives) inside a row of 16 lanes, v_permlane{16,32}_swap across rows (gfx950).
+// A lane whose DPP source does not exist keeps its own value.
+// ------------------------------------------------------------------------------------------------
+enum : int
 {
+  kDppQuadXor1 = 0xB1,         // quad_perm [1,0,3,2]
+  kDppQuadXor2 = 0x4E,         // quad_perm [2,3,0,1]
+  kDppRowShr1 = 0x111,         // lane i <- lane i - 1 inside its row
+  kDppRowRor1 = 0x121, kDppRowRor2 = 0x122, kDppRowRor4 = 0x124, kDppRowRor8 = 0x128,
+  kDppWaveShr1 = 0x138,        // lane i <- lane i - 1 across the whole wave
+  kDppRowMirror = 0x140, kDppRowHalfMirror = 0x141
+};
+
+template<int CTRL> __device__ __forceinline__ u32 dppMov(u32 v)
+{
+#ifdef HIPSIM
+  const int lane = laneId();
+  int src = lane;
+  if (CTRL < 0x100) src = (lane & ~3) | ((CTRL >> (2 * (lane & 3))) & 3);
+  else if (CTRL >= 0x111 && CTRL <= 0x11F) src = ((lane & 15) >= (CTRL - 0x110)) ? lane - (CTRL - 0x110) : lane;
+  else if (CTRL >= 0x121 && CTRL <= 0x12F) src = (lane & ~15) | ((lane - (CTRL - 0x120)) & 15);
+  else if (CTRL == kDppWaveShr1) src = lane > 0 ? lane - 1 : lane;
+  else if (CTRL == kDppRowMirror) src = (lane & ~15) | (15 - (lane & 15));
+  else if (CTRL == kDppRowHalfMirror) src = (lane & ~7) | (7 - (lane & 7));
+  return __shfl(v, src);
+#else
+  return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+#endif
+}
+
+template<int CTRL, class X> __device__ __forceinline__ X dppMovT(X v)
+{
+  static_assert(sizeof(X) == 4 || sizeof(X) == 8, "32- or 64-bit payloads");
+  u32 w[sizeof(X) / 4];
+  memcpy(w, &v, sizeof(X));
 #pragma unroll
-  for (int m = 1; m < 64; m <<= 1) { T o = __shfl_xor(v, m); v = (o < v) ? o : v; }
+  for (int i = 0; i < (int)(sizeof(X) / 4); i++) w[i] = dppMov<CTRL>(w[i]);
+  memcpy(&v, w, sizeof(X));
   return v;
 }
-template<class T> __device__ __forceinline__ T waveMax(T v)
+
+// op(v of this lane, v of lane ^ 16) resp. lane ^ 32 for a symmetric op
+template<int DIST, class X, class Op> __device__ __forceinline__ X combineXor(X v, Op op)
 {
+#ifdef HIPSIM
+  return op(v, __shfl_xor(v, DIST));
+#else
+  u32 w[sizeof(X) / 4], a[sizeof(X) / 4], b[sizeof(X) / 4];
+  memcpy(w, &v, sizeof(X));
 #pragma unroll
-  for (int m = 1; m < 64; m <<= 1) { T o = __shfl_xor(v, m); v = (o > v) ? o : v; }
+  for (int i = 0; i < (int)(sizeof(X) / 4); i++)
+  {
+    // both copies hold v; the swap leaves this lane's value in one result and its partner's in the other
+    if (DIST == 16) { auto r = __builtin_amdgcn_permlane16_swap(w[i], w[i], false, false); a[i] = r[0]; b[i] = r[1]; }
+    else { auto r = __builtin_amdgcn_permlane32_swap(w[i], w[i], false, false); a[i] = r[0]; b[i] = r[1]; }
+  }
+  X xa, xb;
+  memcpy(&xa, a, sizeof(X)); memcpy(&xb, b, sizeof(X));
+  return op(xa, xb);
+#endif
+}
+
+// all-reduce over groups of G consecutive lanes (G = 8, 16, 32 or 64), result in every lane of the group
+template<int G, class X, class Op> __device__ __forceinline__ X groupReduce(X v, Op op)
+{
+  static_assert(G == 8 || G == 16 || G == 32 || G == 64, "group size");
+  if (G == 8)
+  {
+    v = op(v, dppMovT<kDppQuadXor1>(v));
+    v = op(v, dppMovT<kDppQuadXor2>(v));
+    v = op(v, dppMovT<kDppRowHalfMirror>(v));
+    return v;
+  }
+  v = op(v, dppMovT<kDppRowRor8>(v));
+  v = op(v, dppMovT<kDppRowRor4>(v));
+  v = op(v, dppMovT<kDppRowRor2>(v));
+  v = op(v, dppMovT<kDppRowRor1>(v));
+  if (G >= 32) v = combineXor<16>(v, op);
+  if (G >= 64) v = combineXor<32>(v, op);
   return v;
 }
-template<class T> __device__ __forceinline__ T waveSum(T v)
-{
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
-  return v;
-}
+
+struct OpMin { template<class X> __device__ __forceinline__ X operator()(X a, X b) const { return b < a ? b : a; } };
+struct OpMax { template<class X> __device__ __forceinline__ X operator()(X a, X b) const { return b > a ? b : a; } };
+struct OpSum { template<class X> __device__ __forceinline__ X operator()(X a, X b) const { return a + b; } };
+
+// whole-wave all-reduces (32- and 64-bit payloads)
+template<class T> __device__ __forceinline__ T waveMin(T v) { return groupReduce<64>(v, OpMin()); }
+template<class T> __device__ __forceinline__ T waveMax(T v) { return groupReduce<64>(v, OpMax()); }
+template<class T> __device__ __forceinline__ T waveSum(T v) { return groupReduce<64>(v, OpSum()); }
 
 // signed char is not a shuffle payload type everywhere: widen small integers
 template<class T> struct ShflT { typedef T type; };
