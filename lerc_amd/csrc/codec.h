@@ -69,7 +69,8 @@ public:
   std::string profReport(bool reset);        // "name total_ms launches" per line
 
 private:
-  struct ProfEntry { const char* name; hipEvent_t a, b; };
+  struct ProfEntry { const char* name; hipEvent_t a, b; bool ownsA, ownsB; };
+  bool m_lastEndFresh = false;               // nothing was enqueued since the last profEnd()
   struct ProfAcc { std::string name; double ms; int n; };
   bool m_prof = false;
   std::vector<ProfEntry> m_pending;

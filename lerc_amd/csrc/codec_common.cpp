@@ -284,20 +284,32 @@ hipEvent_t Context::profEvent()
 {
   if (!m_eventPool.empty()) { hipEvent_t e = m_eventPool.back(); m_eventPool.pop_back(); return e; }
   hipEvent_t e = nullptr;
+#ifdef hipEventDisableSystemFence
+  // a plain event record carries a system-scope release (cache write-back) and costs ~10 us between two kernels
+  if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) == hipSuccess) return e;
+#endif
   hipEventCreate(&e);
   return e;
 }
 
+// Consecutive groups share their boundary event: when a group begins right after the previous one ended (nothing
+// enqueued in between by this library), the previous end event is the new begin event.
 void Context::profBegin(const char* name)
 {
-  ProfEntry pe{ name, profEvent(), profEvent() };
-  hipEventRecord(pe.a, activeStream());
+  ProfEntry pe{ name, nullptr, nullptr, true, true };
+  if (m_lastEndFresh && !m_pending.empty() && m_pending.back().b) { pe.a = m_pending.back().b; pe.ownsA = false; }
+  else { pe.a = profEvent(); hipEventRecord(pe.a, activeStream()); }
+  m_lastEndFresh = false;
   m_pending.push_back(pe);
 }
 
 void Context::profEnd()
 {
-  if (!m_pending.empty()) hipEventRecord(m_pending.back().b, activeStream());
+  if (m_pending.empty()) return;
+  ProfEntry& pe = m_pending.back();
+  pe.b = profEvent();
+  hipEventRecord(pe.b, activeStream());
+  m_lastEndFresh = true;
 }
 
 void Context::profCollect()
@@ -305,16 +317,20 @@ void Context::profCollect()
   for (ProfEntry& pe : m_pending)
   {
     float ms = 0;
-    if (hipEventSynchronize(pe.b) == hipSuccess && hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess)
+    if (pe.a && pe.b && hipEventSynchronize(pe.b) == hipSuccess && hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess)
     {
       bool found = false;
       for (ProfAcc& a : m_acc) if (a.name == pe.name) { a.ms += ms; a.n++; found = true; break; }
       if (!found) m_acc.push_back(ProfAcc{ pe.name, ms, 1 });
     }
-    m_eventPool.push_back(pe.a);
-    m_eventPool.push_back(pe.b);
+  }
+  for (ProfEntry& pe : m_pending)
+  {
+    if (pe.a && pe.ownsA) m_eventPool.push_back(pe.a);
+    if (pe.b) m_eventPool.push_back(pe.b);
   }
   m_pending.clear();
+  m_lastEndFresh = false;
 }
 
 std::string Context::profReport(bool reset)
