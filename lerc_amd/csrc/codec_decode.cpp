@@ -66,6 +66,100 @@ bool readBandHeader(const BlobReader& rd, u64 off, BandDesc& b)
 
 }    // namespace
 
+// ------------------------------------------------------------------------------------------------
+// streaming kernels for one band
+// ------------------------------------------------------------------------------------------------
+// layout of a band's result cell (device, zeroed before the launches, copied back in one piece):
+//   [FastDecodeParams, 128 B reserved][fallback bits 16 B][pad to 192][64 Fletcher slot pairs]
+static const size_t kCellParams = 0, kCellFallback = 128, kCellSlots = 192, kCellBytes = 192 + 2 * kFastSlots * 8;
+static_assert(sizeof(FastDecodeParams) <= 128, "cell layout");
+
+static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven)
+{
+  const FastWalkPlan wp = makeFastWalkPlan(nRows, nCols, sizeGiven);
+  return (size_t)wp.nChunks * ((size_t)kFastListCap * 8 + kFastSubPerChunk * 8 + 64) + (size_t)wp.chainCap * sizeof(FastChain)
+    + (size_t)wp.nBlocks * 4 + (1u << 16);
+}
+
+// enqueues header check, discovery and decode of one band; nothing is read back here
+static bool launchFastBand(Context& ctx, int dt, int nRows, int nCols, const u8* dBand, u32 sizeGiven, void* dOutBand,
+                           DeviceStatus* dStatus, u8* dCell)
+{
+  hipStream_t st = ctx.activeStream();
+  const FastWalkPlan fwp = makeFastWalkPlan(nRows, nCols, sizeGiven);
+  FastDecodeBuffers fbuf;
+  fbuf.chunkListN = ctx.allocT<u32>(fwp.nChunks + 4);
+  fbuf.chunkList = ctx.allocT<u64>((size_t)fwp.nChunks * kFastListCap + 4);
+  fbuf.chains = ctx.allocT<FastChain>((size_t)fwp.chainCap + 4);
+  fbuf.chainCount = ctx.allocT<u32>(fwp.nChunks / kFastCandChunks + 4);
+  fbuf.chunkEntry = ctx.allocT<u32>(fwp.nChunks + 4);
+  fbuf.chunkCount = ctx.allocT<u32>(fwp.nChunks + 4);
+  fbuf.subEntry = ctx.allocT<u32>((size_t)fwp.nChunks * kFastSubPerChunk + 4);
+  fbuf.subIndex = ctx.allocT<u32>((size_t)fwp.nChunks * kFastSubPerChunk + 4);
+  fbuf.blockOff = ctx.allocT<u32>((size_t)fwp.nBlocks + 4);
+  fbuf.params = reinterpret_cast<FastDecodeParams*>(dCell + kCellParams);
+  fbuf.fallback = reinterpret_cast<u32*>(dCell + kCellFallback);
+  fbuf.slotFletcher = reinterpret_cast<u64*>(dCell + kCellSlots);
+  if (!fbuf.chunkListN || !fbuf.chunkList || !fbuf.chains || !fbuf.chainCount || !fbuf.chunkEntry || !fbuf.chunkCount
+    || !fbuf.subEntry || !fbuf.subIndex || !fbuf.blockOff) return false;
+  static const char* kStage[kFastDecodeStages] = { "fast_candidates", "fast_chains", "fast_resolve", "fast_emit_offsets", "fast_decode" };
+  for (int stage = 0; stage < kFastDecodeStages; stage++)
+  {
+    ProfScope ps(ctx, kStage[stage]);
+    launchFastDecode(stage, dt, nRows, nCols, fwp, dBand, sizeGiven, fbuf, dOutBand, dStatus, st);
+  }
+  return true;
+}
+
+// what the host makes of a band's cell after the sync: 0 = decoded and checksum good, else the reason bits
+static u32 fastBandVerdict(const u8* hCell)
+{
+  FastDecodeParams hp;
+  memcpy(&hp, hCell + kCellParams, sizeof(hp));
+  u32 fb;
+  memcpy(&fb, hCell + kCellFallback, 4);
+  if (!hp.ok) fb |= 0x100u;
+  else if (!fb && !hp.checksumOk) fb |= 0x200u;
+  return fb;
+}
+
+// Device-resident single-band blobs: everything is enqueued before a single byte of the blob has been seen by the
+// host (the header is checked by k_fast_header); one synchronisation.  handled == false: nothing was decided,
+// the caller goes the long way (header read, general kernels, exact status codes).
+static u32 decodeSpeculative(Context& ctx, const DecodeRequest& rq, bool& handled)
+{
+  handled = false;
+  const int dt = rq.dt, nRows = rq.nRows, nCols = rq.nCols;
+  if (!rq.dBlob || rq.hBlob || rq.nBands != 1 || rq.nDepth != 1 || rq.blobSize < 70 || !rq.dOut) return kOk;
+  if (!fastDecodeEligible(dt, 6, 8, nRows, nCols, 1, true)) return kOk;
+  if (((uintptr_t)rq.dBlob & 15) || ((uintptr_t)rq.dOut & 15)) return kOk;
+  hipStream_t st = ctx.activeStream();
+  if (!ctx.reserve(fastBandWorkspace(nRows, nCols, rq.blobSize) + 4096)) return kOk;
+  const size_t cellsBytes = 64 + kCellBytes;
+  u8* dCells = ctx.allocT<u8>(cellsBytes);
+  if (!dCells) return kOk;
+  hipMemsetAsync(dCells, 0, cellsBytes, st);
+  if (!launchFastBand(ctx, dt, nRows, nCols, rq.dBlob, rq.blobSize, rq.dOut, reinterpret_cast<DeviceStatus*>(dCells), dCells + 64))
+    return kOk;
+  if (rq.nMasks > 0 && rq.dValidBytes) hipMemsetAsync(rq.dValidBytes, 1, (size_t)nRows * nCols, st);    // numValid == nPix or no verdict
+  u8* pin = (u8*)ctx.pinned(cellsBytes);
+  if (!pin) return kOk;
+  hipMemcpyAsync(pin, dCells, cellsBytes, hipMemcpyDeviceToHost, st);
+  if (!ctx.sync()) return kFailed;
+  if (ctx.profOn()) ctx.profCollect();
+  const DeviceStatus hs = *reinterpret_cast<const DeviceStatus*>(pin);
+  const u32 verdict = fastBandVerdict(pin + 64);
+  if (verdict || hs.error)
+  {
+    char msg[112];
+    snprintf(msg, sizeof(msg), "streaming decode handed the blob to the general path (reason bits 0x%x, kernel status %u)", verdict, hs.error);
+    ctx.lastNote = msg;
+    return kOk;
+  }
+  handled = true;
+  return kOk;
+}
+
 static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, bool& fellBack)
 {
   fellBack = false;
@@ -128,7 +222,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     maxChunks = std::max(maxChunks, (size_t)h.blobSize / 4096 + 2);
   }
   need += maxSub * 4 + maxSub / nD * 2 + 5 * (maxChunks + 1024) * 4 + (dt <= DT_Byte ? huffmanScratchBytes(nPix, nD) : 0);
-  need += (maxChunks + 16) * ((size_t)kFastListCap * 8 + kFastSubPerChunk * 8 + kFastChainsPerChunk * sizeof(FastChain) + 64) + (size_t)(nPix / 4096 + 64) * 16 + 4096;    // streaming path tables
+  need += fastBandWorkspace(nRows, nCols, rq.blobSize) + 4096;    // streaming path tables
   if (!ctx.reserve(need)) return kFailed;
 
   const u8* dBlob = rq.dBlob;
@@ -140,9 +234,8 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     dBlob = stage;
   }
   u8* dBits = ctx.allocT<u8>(maskBytes + 64);
-  // everything the host reads back at the end sits together: [status 64 B] then per band
-  // [Fletcher A, B 16 B | fallback bits 16 B | 32 B | 64 Fletcher slot pairs]; one memset before, one copy after
-  const size_t kCellBytes = 64 + 2 * kFastSlots * 8;
+  // everything the host reads back at the end sits together: [status 64 B] then one cell per band (see above);
+  // one memset before, one copy after
   const size_t cellsBytes = 64 + (size_t)rq.nBands * kCellBytes;
   u8* dCells = ctx.allocT<u8>(cellsBytes);
   DeviceStatus* dStatus = reinterpret_cast<DeviceStatus*>(dCells);
@@ -158,7 +251,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   std::vector<u32> checksumLen(rq.nBands, 0);
   std::vector<u8> small;
   // bands decoded by the streaming kernels: their checksum comes out of the decode kernel itself
-  struct FastBand { bool used = false; u64 prefixA = 0, prefixB = 0; };
+  struct FastBand { bool used = false; };
   std::vector<FastBand> fast(rq.nBands);
 
   for (int iBand = 0; iBand < rq.nBands; iBand++)
@@ -316,39 +409,10 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
 
     if (fastBand && fastDataBegin == (u32)(at - bd.offset))
     {
-      const FastWalkPlan fwp = makeFastWalkPlan(nRows, nCols, fastDataBegin, blobEnd);
-      FastDecodeBuffers fbuf;
-      fbuf.chunkListN = ctx.allocT<u32>(fwp.nChunks + 4);
-      fbuf.chunkList = ctx.allocT<u64>((size_t)fwp.nChunks * kFastListCap + 4);
-      fbuf.chains = ctx.allocT<FastChain>((size_t)fwp.chainCap + 4);
-      fbuf.chainCount = ctx.allocT<u32>(fwp.nChunks / kFastCandChunks + 4);
-      fbuf.chunkEntry = ctx.allocT<u32>(fwp.nChunks + 4);
-      fbuf.chunkCount = ctx.allocT<u32>(fwp.nChunks + 4);
-      fbuf.chunkBase = ctx.allocT<u32>(fwp.nChunks + 4);
-      fbuf.subEntry = ctx.allocT<u32>((size_t)fwp.nChunks * kFastSubPerChunk + 4);
-      fbuf.subIndex = ctx.allocT<u32>((size_t)fwp.nChunks * kFastSubPerChunk + 4);
-      fbuf.blockOff = ctx.allocT<u32>((size_t)fwp.nBlocks + 4);
-      fbuf.scanScratch = ctx.allocT<u32>(fwp.nChunks / 1024 + 8);
-      u8* cells = dCells + 64 + (size_t)iBand * kCellBytes;
-      fbuf.fletcherOut = reinterpret_cast<u64*>(cells);
-      fbuf.fallback = reinterpret_cast<u32*>(cells + 16);
-      fbuf.slotFletcher = reinterpret_cast<u64*>(cells + 64);
-      if (!fbuf.chunkListN || !fbuf.chunkList || !fbuf.chains || !fbuf.chainCount || !fbuf.chunkEntry || !fbuf.chunkCount
-        || !fbuf.chunkBase || !fbuf.subEntry || !fbuf.subIndex || !fbuf.blockOff || !fbuf.scanScratch) return kFailed;
-      static const char* kStage[kFastDecodeStages] = { "fast_candidates", "fast_chains", "fast_resolve_scan", "fast_emit_offsets", "fast_decode" };
-      for (int stage = 0; stage < kFastDecodeStages; stage++)
-      {
-        ProfScope ps(ctx, kStage[stage]);
-        launchFastDecode(stage, bp, fwp, dBand, fastDataBegin, blobEnd, fbuf, dOutBand, dStatus, st);
-      }
+      if (!launchFastBand(ctx, dt, nRows, nCols, dBand, blobEnd, dOutBand, dStatus, dCells + 64 + (size_t)iBand * kCellBytes)) return kFailed;
       FastBand& f = fast[iBand];
       ctx.lastDecodeStreamed = true;
       f.used = true;
-      for (u32 pos = 0; pos + 14 < fastDataBegin; pos++)    // Fletcher terms of the bytes before the first block
-      {
-        const u32 cw = (u32)bd.head[14 + pos] << ((pos & 1u) ? 0 : 8);
-        f.prefixA += cw; f.prefixB += (u64)(pos >> 1) * cw;
-      }
       continue;
     }
     if (fastBand)    // launched without its checksum kernel, but did not qualify after all
@@ -395,35 +459,24 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   if (anyGeneric) hipMemcpyAsync(hFl.data(), dFl, hFl.size() * 8, hipMemcpyDeviceToHost, st);
   if (!ctx.sync()) return kFailed;
   const DeviceStatus hs = *reinterpret_cast<const DeviceStatus*>(pin);
-  // per band: Fletcher A, B, fallback bits (copied out of the pinned mirror, which later calls reuse)
-  std::vector<u64> hFast((size_t)rq.nBands * 4, 0);
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
     if (!fast[iBand].used) continue;
-    const u8* cell = pin + 64 + (size_t)iBand * kCellBytes;
-    memcpy(&hFast[4 * iBand], cell, 16);
-    u32 fb; memcpy(&fb, cell + 16, 4);
-    hFast[4 * iBand + 2] = fb;
-  }
-  if (ctx.profOn()) ctx.profCollect();
-  for (int iBand = 0; iBand < rq.nBands; iBand++)
-    if (fast[iBand].used && (u32)hFast[4 * iBand + 2])    // caller repeats with the general kernels
+    const u32 verdict = fastBandVerdict(pin + 64 + (size_t)iBand * kCellBytes);
+    if (verdict & 0x200u) return kFailed;    // decoded, but the checksum is wrong
+    if (verdict)                             // caller repeats with the general kernels
     {
       char msg[96];
-      snprintf(msg, sizeof(msg), "streaming decode handed band %d to the general kernels (reason bits 0x%x)", iBand, (u32)hFast[4 * iBand + 2]);
+      snprintf(msg, sizeof(msg), "streaming decode handed band %d to the general kernels (reason bits 0x%x)", iBand, verdict);
       ctx.lastNote = msg;
       fellBack = true;
       return kOk;
     }
+  }
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
     if (bands[iBand].hd.version < 3) continue;
-    if (fast[iBand].used)
-    {
-      const u64 A = hFast[4 * iBand] + fast[iBand].prefixA, B = hFast[4 * iBand + 1] + fast[iBand].prefixB;
-      if (fletcherFinish(A, B, checksumLen[iBand]) != expectChecksum[iBand]) return kFailed;
-      continue;
-    }
+    if (fast[iBand].used) continue;    // checked on the device
     u64 A = 0, B = 0;
     for (int i = 0; i < kFletcherPartials; i += 2) { A += hFl[(size_t)iBand * kFletcherPartials + i]; B += hFl[(size_t)iBand * kFletcherPartials + i + 1]; }
     if (fletcherFinish(A, B, checksumLen[iBand]) != expectChecksum[iBand]) return kFailed;
@@ -434,6 +487,10 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
 
 u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
 {
+  bool handled = false;
+  const u32 src = decodeSpeculative(ctx, rq, handled);
+  if (src != kOk) return src;
+  if (handled) { ctx.pathCount[2]++; return kOk; }
   bool fellBack = false;
   u32 rc = decodeImpl(ctx, rq, true, fellBack);
   const bool repeated = (rc == kOk && fellBack);

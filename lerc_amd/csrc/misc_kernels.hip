@@ -79,37 +79,35 @@ __global__ void __launch_bounds__(1024) k_scan_single(const u32* __restrict__ in
   __shared__ u32 s_w[16];
   const u32 per4 = (n + 4095u) / 4096u;                   // vectors per thread
   const u32 begin = threadIdx.x * per4 * 4u;
+  const u32 lastVec = (n - 1u) & ~3u;                      // clamped loads: no data-dependent exit, so they batch
   u32 sum = 0;
-#pragma unroll 4
+#pragma unroll 8
   for (u32 q = 0; q < per4; q++)
   {
     const u32 i = begin + q * 4u;
-    if (i >= n) break;
-    const uint4 x = *reinterpret_cast<const uint4*>(in + i);
-    sum += x.x + (i + 1 < n ? x.y : 0u) + (i + 2 < n ? x.z : 0u) + (i + 3 < n ? x.w : 0u);
+    const uint4 x = *reinterpret_cast<const uint4*>(in + min(i, lastVec));
+    sum += (i < n ? x.x : 0u) + (i + 1 < n ? x.y : 0u) + (i + 2 < n ? x.z : 0u) + (i + 3 < n ? x.w : 0u);
   }
   const u32 inc = waveInclusiveScan(sum);
   if (laneId() == 63) s_w[waveId()] = inc;
   __syncthreads();
   u32 run = inc - sum;
   for (int i = 0; i < waveId(); i++) run += s_w[i];
-#pragma unroll 4
+#pragma unroll 8
   for (u32 q = 0; q < per4; q++)
   {
     const u32 i = begin + q * 4u;
-    if (i >= n) break;
-    const uint4 x = *reinterpret_cast<const uint4*>(in + i);
+    const uint4 x = *reinterpret_cast<const uint4*>(in + min(i, lastVec));
     uint4 o;
-    o.x = run; run += x.x;
+    o.x = run; run += (i < n ? x.x : 0u);
     o.y = run; run += (i + 1 < n ? x.y : 0u);
     o.z = run; run += (i + 2 < n ? x.z : 0u);
     o.w = run; run += (i + 3 < n ? x.w : 0u);
     if (i + 3 < n) *reinterpret_cast<uint4*>(out + i) = o;
-    else { out[i] = o.x; if (i + 1 < n) out[i + 1] = o.y; if (i + 2 < n) out[i + 2] = o.z; }
+    else if (i < n) { out[i] = o.x; if (i + 1 < n) out[i + 1] = o.y; if (i + 2 < n) out[i + 2] = o.z; }
   }
-  // the thread that holds element n - 1 (or the last one with none left of it) knows the total
-  const u32 lastOwner = min((n - 1u) / (per4 * 4u), 1023u);
-  if (threadIdx.x == lastOwner) out[n] = run;
+  // every thread behind the one that holds element n - 1 carries the total too
+  if (threadIdx.x == 1023) out[n] = run;
 }
 
 void launchExclusiveScan(const u32* in, u32* out, u32 n, u32* scratch, hipStream_t stream)

@@ -61,7 +61,23 @@ static const int kFastCandChunks = 8;      // chunks per workgroup of the candid
 // longest block the streaming walk accepts: the raw form (the reference encoder never emits a longer one)
 constexpr u32 kFastWindow(int typeBytes) { return 2u + 64u * (u32)typeBytes; }
 
+// sizes the host can bound without reading the blob (grids and buffers); the true values are in FastDecodeParams
 struct FastWalkPlan { u32 nChunks, nBlocks, chainCap; };
+
+// what k_fast_header reads out of the band header for the other kernels, and what the host reads back at the end
+struct FastDecodeParams
+{
+  u32 ok;                // the band qualifies for the streaming kernels
+  u32 version;
+  u32 dataBegin, blobEnd;
+  u32 nChunks, nBlocks;
+  u32 nTH, nCols, nRows;
+  u32 expectChecksum;    // from the header
+  u32 checksumOk;        // set by k_fast_fletcher_sum
+  u32 pad;
+  u64 prefixA, prefixB;  // Fletcher terms of the bytes in front of the first block
+  double invScale, zMaxHdr;
+};
 
 // one speculative walk through a chunk, shared by all the candidates that merged into it
 struct FastChain
@@ -83,21 +99,19 @@ struct FastDecodeBuffers
   u32* chainCount;     // [ceil(nChunks / kFastCandChunks)] chains in use in each workgroup's slice of `chains`
   u32* chunkEntry;     // [nChunks + 1]
   u32* chunkCount;     // [nChunks]
-  u32* chunkBase;      // [nChunks + 1]
   u32* subEntry;       // [nChunks * kFastSubPerChunk] first block start at / behind a sub-chunk boundary ([0] = the chunk entry), or ~0
   u32* subIndex;       // [nChunks * kFastSubPerChunk] index of that block within the chunk
   u32* blockOff;       // [nBlocks + 1]
   u64* slotFletcher;   // [2 * kFastSlots]
-  u64* fletcherOut;    // [2]
-  u32* scanScratch;
+  FastDecodeParams* params;
   u32* fallback;       // != 0: the general path must redo the band
 };
 
 bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid);
-FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 dataBegin, u32 blobEnd);
+FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven);
 static const int kFastDecodeStages = 5;
-// stage 0: candidates; 1: chains; 2: resolve + scan; 3: block offsets; 4: decode + Fletcher sums
-void launchFastDecode(int stage, const BandParams& p, const FastWalkPlan& wp, const u8* blob, u32 dataBegin, u32 blobEnd,
+// stage 0: header + candidates; 1: chains; 2: resolve; 3: block offsets; 4: decode + checksum
+void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastWalkPlan& wp, const u8* blob, u32 sizeGiven,
                       const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st);
 
 }    // namespace lerc

@@ -157,6 +157,85 @@ __device__ __forceinline__ u32 stepGlobal(const u8* __restrict__ blob, u32 cur, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// header
+// ------------------------------------------------------------------------------------------------
+// One lane reads the band header the way Lerc2::ReadHeader / ReadMask / ReadMinMaxRanges do (Lerc2.cpp:790-1008,
+// :2642-2677) and decides whether the streaming kernels may take the band.  Everything the later kernels need is
+// left in *P, so the host can enqueue the whole decode without having seen a single byte of the blob; it checks
+// P->ok (and the fallback bits) when it reads the results back.
+__device__ __forceinline__ u32 rdU32(const u8* b, u32 at) { return (u32)b[at] | ((u32)b[at + 1] << 8) | ((u32)b[at + 2] << 16) | ((u32)b[at + 3] << 24); }
+__device__ __forceinline__ double rdF64(const u8* b, u32 at) { const u64 v = (u64)rdU32(b, at) | ((u64)rdU32(b, at + 4) << 32); double d; memcpy(&d, &v, 8); return d; }
+
+template<int DT>
+__global__ void __launch_bounds__(64)
+k_fast_header(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols, FastDecodeParams* __restrict__ P)
+{
+  constexpr u32 TB = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
+  __shared__ u8 s_h[128];
+  const int lane = laneId();
+  for (u32 i = (u32)lane; i < 128u; i += 64u) s_h[i] = (i < sizeGiven) ? blob[i] : (u8)0;
+  waveSync();
+  if (lane != 0) return;
+  FastDecodeParams hp;
+  memset(&hp, 0, sizeof(hp));
+  const u8* h = s_h;
+  bool ok = sizeGiven >= 70u && h[0] == 'L' && h[1] == 'e' && h[2] == 'r' && h[3] == 'c' && h[4] == '2' && h[5] == ' ';
+  const u32 version = rdU32(h, 6);
+  ok = ok && version >= 3u && version <= 6u;
+  u32 at = 14;    // magic, version, checksum
+  hp.version = version;
+  hp.expectChecksum = rdU32(h, 10);
+  if (ok)
+  {
+    const u32 hRows = rdU32(h, at), hCols = rdU32(h, at + 4);
+    at += 8;
+    u32 nDepth = 1;
+    if (version >= 4u) { nDepth = rdU32(h, at); at += 4; }
+    const u32 numValid = rdU32(h, at), mb = rdU32(h, at + 4), blobSize = rdU32(h, at + 8), dt = rdU32(h, at + 12);
+    at += 16;
+    u32 passNoData = 0;
+    if (version >= 6u) { passNoData = h[at + 4]; at += 8; }    // nBlobsMore, then 4 flag bytes
+    const double maxZErr = rdF64(h, at), zMin = rdF64(h, at + 8), zMax = rdF64(h, at + 16);
+    at += 24;
+    if (version >= 6u) at += 16;                                // noData values
+    const u32 numBytesMask = rdU32(h, at);
+    at += 4;
+    ok = hRows == (u32)nRows && hCols == (u32)nCols && nDepth == 1u && numValid == (u32)nRows * (u32)nCols && mb == 8u
+      && dt == (u32)DT && passNoData == 0u && numBytesMask == 0u && blobSize <= sizeGiven && zMin != zMax
+      && maxZErr > 0 && maxZErr == maxZErr;
+    if (ok && version >= 4u)                                    // ranges: min then max, raw T (nDepth == 1)
+    {
+      bool differ = false;
+      for (u32 i = 0; i < TB; i++) differ = differ || (h[at + i] != h[at + TB + i]);
+      ok = differ;
+      at += 2 * TB;
+    }
+    ok = ok && h[at] == 0;                                      // not the one-sweep raw form
+    at += 1;
+    ok = ok && at < blobSize;
+    hp.dataBegin = at;
+    hp.blobEnd = blobSize;
+    hp.nChunks = ok ? (blobSize - at + kFastChunkBytes - 1) / kFastChunkBytes : 0u;
+    hp.nBlocks = (u32)(nRows / 8) * (u32)(nCols / 8);
+    hp.nTH = (u32)nCols / 8u;
+    hp.nCols = (u32)nCols;
+    hp.nRows = (u32)nRows;
+    hp.invScale = 2 * maxZErr;
+    hp.zMaxHdr = zMax;
+    // Fletcher terms of the bytes in front of the first block (Lerc2.cpp:1037-1064; word k of blob[14 ..))
+    u64 A = 0, B = 0;
+    for (u32 pos = 0; ok && pos + 14u < at; pos++)
+    {
+      const u32 cw = (u32)h[14 + pos] << ((pos & 1u) ? 0 : 8);
+      A += cw; B += (u64)(pos >> 1) * cw;
+    }
+    hp.prefixA = A; hp.prefixB = B;
+  }
+  hp.ok = ok ? 1u : 0u;
+  *P = hp;
+}
+
+// ------------------------------------------------------------------------------------------------
 // candidates
 // ------------------------------------------------------------------------------------------------
 static const int kWalkG = kFastCandChunks;    // chunks per workgroup
@@ -192,10 +271,20 @@ __device__ __forceinline__ u32 qSteps(u32 e) { return e >> 29; }
 // steps before the header of its last block is read.
 template<int DT>
 __global__ void __launch_bounds__(256)
-k_fast_candidates(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
+k_fast_candidates(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob,
                   u32* __restrict__ chunkListN, u64* __restrict__ chunkList, FastChain* __restrict__ chains, u32* __restrict__ chainCount,
                   u32* __restrict__ fallback)
 {
+  const FastDecodeParams hp = *P;
+  if (!hp.ok) return;
+  const int version = (int)hp.version;
+  const u32 dataBegin = hp.dataBegin, blobEnd = hp.blobEnd;
+  const FastWalkPlan wp = { hp.nChunks, hp.nBlocks, 0u };
+  if (blockIdx.x * kWalkG >= wp.nChunks)    // the grid is sized for the largest stream the blob could hold
+  {
+    if (threadIdx.x == 0) chainCount[blockIdx.x] = 0u;
+    return;
+  }
   constexpr int TBYTES = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
   constexpr u32 W = kFastWindow(TBYTES), RAW = 1 + 64 * TBYTES;
   constexpr u32 kHead = (W + (kFilterSteps - 1) * RAW + 16 + 15) & ~15u;    // staged bytes per chunk, from its 16-byte aligned start
@@ -359,9 +448,13 @@ k_fast_candidates(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32
 // ------------------------------------------------------------------------------------------------
 template<int DT>
 __global__ void __launch_bounds__(256)
-k_fast_chains(int version, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd, FastChain* __restrict__ chains,
+k_fast_chains(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, FastChain* __restrict__ chains,
               const u32* __restrict__ chainCount, u32 chainCap)
 {
+  const FastDecodeParams hp = *P;
+  if (!hp.ok) return;
+  const int version = (int)hp.version;
+  const u32 dataBegin = hp.dataBegin, blobEnd = hp.blobEnd;
   const u32 t = blockIdx.x * 256u + threadIdx.x;    // chain slot: kChainCap per candidates workgroup
   if (t >= chainCap || t % kChainCap >= chainCount[t / kChainCap]) return;
   constexpr int NS = kFastSubPerChunk;
@@ -418,10 +511,15 @@ __device__ __forceinline__ u32 agreedExit(u32 c, const u32* __restrict__ chunkLi
 
 template<int DT>
 __global__ void __launch_bounds__(256)
-k_fast_resolve(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd, const u32* __restrict__ chunkListN,
+k_fast_resolve(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ chunkListN,
                const u64* __restrict__ chunkList, const FastChain* __restrict__ chains, u32* __restrict__ chunkEntry,
                u32* __restrict__ chunkCount, u32* __restrict__ subEntry, u32* __restrict__ subIndex, u32* __restrict__ fallback)
 {
+  const FastDecodeParams hp = *P;
+  if (!hp.ok) return;
+  const int version = (int)hp.version;
+  const u32 dataBegin = hp.dataBegin, blobEnd = hp.blobEnd;
+  const FastWalkPlan wp = { hp.nChunks, hp.nBlocks, 0u };
   constexpr int NS = kFastSubPerChunk;
   const u32 c = blockIdx.x * 256u + threadIdx.x;
   if (c > wp.nChunks) return;
@@ -480,18 +578,49 @@ k_fast_resolve(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 da
 // ------------------------------------------------------------------------------------------------
 template<int DT>
 __global__ void __launch_bounds__(256)
-k_fast_emit(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 blobEnd, const u32* __restrict__ chunkEntry,
-            const u32* __restrict__ chunkCount, const u32* __restrict__ chunkBase, const u32* __restrict__ subEntry,
-            const u32* __restrict__ subIndex, u32* __restrict__ blockOff, u32* __restrict__ fallback)
+k_fast_emit(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ chunkEntry,
+            const u32* __restrict__ chunkCount, const u32* __restrict__ subEntry, const u32* __restrict__ subIndex,
+            u32* __restrict__ blockOff, u32* __restrict__ fallback)
 {
   constexpr int NS = kFastSubPerChunk;
+  constexpr u32 kChunksPerWG = 256 / NS;
+  __shared__ u32 s_part[4], s_cbase[kChunksPerWG];
+  const FastDecodeParams hp = *P;
+  if (!hp.ok) return;
+  const int version = (int)hp.version;
+  const u32 blobEnd = hp.blobEnd;
+  const FastWalkPlan wp = { hp.nChunks, hp.nBlocks, 0u };
+  const u32 c0 = blockIdx.x * kChunksPerWG;
+  if (c0 >= wp.nChunks) return;              // the grid is sized for the largest stream the blob could hold
+  const int lane = laneId(), w = waveId();
+
+  // index of this workgroup's first block: every workgroup adds up the counts of the chunks before its own
+  // (about 100 workgroups x 100 KB out of L2 -- cheaper than a scan kernel in between)
+  u32 sum = 0;
+  for (u32 i = threadIdx.x; i < c0; i += 256u) sum += chunkCount[i];
+  sum = waveSum(sum);
+  if (lane == 0) s_part[w] = sum;
+  __syncthreads();
+  if (w == 0)
+  {
+    const u32 cc = c0 + (u32)lane;
+    const u32 cnt = (lane < (int)kChunksPerWG && cc < wp.nChunks) ? chunkCount[cc] : 0u;
+    u32 inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += o; }
+    const u32 before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (lane < (int)kChunksPerWG) s_cbase[lane] = before + inc - cnt;
+    const u32 total = before + __shfl(inc, 63);
+    if (lane == 0 && c0 + kChunksPerWG >= wp.nChunks)
+    {
+      blockOff[wp.nBlocks] = blobEnd;        // sentinel: end of the last block
+      if (total != wp.nBlocks) atomicOr(fallback, 4u);
+    }
+  }
+  __syncthreads();
+
   const u32 t = blockIdx.x * 256u + threadIdx.x;
   const u32 c = t / NS, j = t % NS;
-  if (t == 0)
-  {
-    blockOff[wp.nBlocks] = blobEnd;    // sentinel: end of the last block
-    if (chunkBase[wp.nChunks] != wp.nBlocks) atomicOr(fallback, 4u);
-  }
   if (c >= wp.nChunks || *fallback != 0u) return;    // raised by an earlier kernel: nothing below can be trusted
   const u32 start = subEntry[(size_t)c * NS + j];
   if (start == kNoOffset) return;
@@ -503,7 +632,7 @@ k_fast_emit(int version, FastWalkPlan wp, const u8* __restrict__ blob, u32 blobE
     const u32 nx = subEntry[(size_t)c * NS + j + 1];
     if (nx != kNoOffset) { limit = nx; endIdx = subIndex[(size_t)c * NS + j + 1]; }
   }
-  const u32 base = chunkBase[c];
+  const u32 base = s_cbase[c - c0];
   u32 at = base + subIndex[(size_t)c * NS + j];
   u32 cur = start, sig = kNoOffset;
   bool bad = false;
@@ -559,9 +688,13 @@ template<class T> __device__ __forceinline__ T dequant(double offset, u32 q, dou
 
 template<class T>
 __global__ void __launch_bounds__(256)
-k_fast_decode(BandParams p, const u8* __restrict__ blob, u32 blobEnd, const u32* __restrict__ blockOff, T* __restrict__ outPix,
-              u64* __restrict__ slotFletcher, const u32* __restrict__ fallback, DeviceStatus* st)
+k_fast_decode(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ blockOff,
+              T* __restrict__ outPix, u64* __restrict__ slotFletcher, const u32* __restrict__ fallback, DeviceStatus* st)
 {
+  const FastDecodeParams hp = *P;
+  if (!hp.ok) return;
+  const u32 blobEnd = hp.blobEnd;
+  const struct { int nCols, version; double invScale, zMaxHdr; } p = { (int)hp.nCols, (int)hp.version, hp.invScale, hp.zMaxHdr };
   typedef DCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW, IT = C::IT;
   constexpr int DT = DtOf<T>::v;
@@ -732,11 +865,19 @@ k_fast_decode(BandParams p, const u8* __restrict__ blob, u32 blobEnd, const u32*
   if (__any(bad) && lane == 0) raiseError(st, kFailed, blockIdx.x);
 }
 
-__global__ void __launch_bounds__(64) k_fast_fletcher_sum(u64* __restrict__ slotFletcher, u64* __restrict__ out2)
+// folds the slots and the prefix bytes into the checksum and compares it with the header's (Lerc2.cpp:1037-1064)
+__global__ void __launch_bounds__(64) k_fast_fletcher_sum(FastDecodeParams* __restrict__ P, const u64* __restrict__ slotFletcher)
 {
   const int lane = laneId();
-  const u64 A = waveSum(slotFletcher[2 * lane] % 65535u), B = waveSum(slotFletcher[2 * lane + 1] % 65535u);
-  if (lane == 0) { out2[0] = A % 65535u; out2[1] = B % 65535u; }
+  if (!P->ok) return;
+  u64 A = waveSum(slotFletcher[2 * lane] % 65535u), B = waveSum(slotFletcher[2 * lane + 1] % 65535u);
+  if (lane != 0) return;
+  A = (A + P->prefixA) % 65535u; B = (B + P->prefixB) % 65535u;
+  const u64 N = ((u64)(P->blobEnd - 14u) + 1) / 2;
+  u64 s1 = A, s2 = ((N % 65535u) * A + 65535u - B) % 65535u;
+  if (s1 == 0) s1 = 0xffff;
+  if (s2 == 0) s2 = 0xffff;
+  P->checksumOk = ((u32)((s2 << 16) | s1) == P->expectChecksum) ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -748,61 +889,63 @@ bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int n
   return true;
 }
 
-FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 dataBegin, u32 blobEnd)
+FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven)
 {
+  // upper bounds from what the caller knows without reading the blob: the shortest header in front of a block
+  // stream is 67 bytes (codec 3: 62-byte header, mask length, one-sweep flag)
   FastWalkPlan wp;
-  const u32 span = blobEnd > dataBegin ? blobEnd - dataBegin : 0;
-  wp.nChunks = span ? (span + kFastChunkBytes - 1) / kFastChunkBytes : 1;
+  const u32 span = sizeGiven > 67u ? sizeGiven - 67u : 1u;
+  wp.nChunks = (span + kFastChunkBytes - 1) / kFastChunkBytes;
   wp.nBlocks = (u32)(nRows / 8) * (u32)(nCols / 8);
   wp.chainCap = ((wp.nChunks + kFastCandChunks - 1) / kFastCandChunks) * (u32)(kFastCandChunks * kFastChainsPerChunk);
   return wp;
 }
 
 template<class T>
-static void launchFastDecodeT(int stage, const BandParams& p, const FastWalkPlan& wp, const u8* blob, u32 dataBegin, u32 blobEnd,
+static void launchFastDecodeT(int stage, int nRows, int nCols, const FastWalkPlan& wp, const u8* blob, u32 sizeGiven,
                               const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st)
 {
   constexpr int DT = DtOf<T>::v;
   switch (stage)
   {
     case 0:
-      hipLaunchKernelGGL(k_fast_candidates<DT>, dim3((wp.nChunks + kWalkG - 1) / kWalkG), dim3(256), 0, st, p.version, wp, blob, dataBegin,
-                         blobEnd, b.chunkListN, b.chunkList, b.chains, b.chainCount, b.fallback);
+      hipLaunchKernelGGL(k_fast_header<DT>, dim3(1), dim3(64), 0, st, blob, sizeGiven, nRows, nCols, b.params);
+      hipLaunchKernelGGL(k_fast_candidates<DT>, dim3((wp.nChunks + kWalkG - 1) / kWalkG), dim3(256), 0, st, (const FastDecodeParams*)b.params,
+                         blob, b.chunkListN, b.chunkList, b.chains, b.chainCount, b.fallback);
       break;
     case 1:
-      hipLaunchKernelGGL(k_fast_chains<DT>, dim3((wp.chainCap + 255) / 256), dim3(256), 0, st, p.version, blob, dataBegin, blobEnd, b.chains,
+      hipLaunchKernelGGL(k_fast_chains<DT>, dim3((wp.chainCap + 255) / 256), dim3(256), 0, st, (const FastDecodeParams*)b.params, blob, b.chains,
                          (const u32*)b.chainCount, wp.chainCap);
       break;
     case 2:
-      hipLaunchKernelGGL(k_fast_resolve<DT>, dim3((wp.nChunks + 256) / 256), dim3(256), 0, st, p.version, wp, blob, dataBegin, blobEnd,
+      hipLaunchKernelGGL(k_fast_resolve<DT>, dim3((wp.nChunks + 256) / 256), dim3(256), 0, st, (const FastDecodeParams*)b.params, blob,
                          (const u32*)b.chunkListN, (const u64*)b.chunkList, (const FastChain*)b.chains, b.chunkEntry, b.chunkCount,
                          b.subEntry, b.subIndex, b.fallback);
-      launchExclusiveScan(b.chunkCount, b.chunkBase, wp.nChunks, b.scanScratch, st);
       break;
     case 3:
-      hipLaunchKernelGGL(k_fast_emit<DT>, dim3((wp.nChunks * kFastSubPerChunk + 255) / 256), dim3(256), 0, st, p.version, wp, blob, blobEnd,
-                         (const u32*)b.chunkEntry, (const u32*)b.chunkCount, (const u32*)b.chunkBase, (const u32*)b.subEntry,
+      hipLaunchKernelGGL(k_fast_emit<DT>, dim3((wp.nChunks * kFastSubPerChunk + 255) / 256), dim3(256), 0, st,
+                         (const FastDecodeParams*)b.params, blob, (const u32*)b.chunkEntry, (const u32*)b.chunkCount, (const u32*)b.subEntry,
                          (const u32*)b.subIndex, b.blockOff, b.fallback);
       break;
     default:
-      hipLaunchKernelGGL(k_fast_decode<T>, dim3(fastEncodeNumWG(p.nRows, p.nCols)), dim3(256), 0, st, p, blob, blobEnd, (const u32*)b.blockOff,
-                         (T*)out, b.slotFletcher, (const u32*)b.fallback, status);
-      hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1), dim3(64), 0, st, b.slotFletcher, b.fletcherOut);
+      hipLaunchKernelGGL(k_fast_decode<T>, dim3(fastEncodeNumWG(nRows, nCols)), dim3(256), 0, st, (const FastDecodeParams*)b.params, blob,
+                         (const u32*)b.blockOff, (T*)out, b.slotFletcher, (const u32*)b.fallback, status);
+      hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1), dim3(64), 0, st, b.params, (const u64*)b.slotFletcher);
       break;
   }
 }
 
-void launchFastDecode(int stage, const BandParams& p, const FastWalkPlan& wp, const u8* blob, u32 dataBegin, u32 blobEnd,
+void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastWalkPlan& wp, const u8* blob, u32 sizeGiven,
                       const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st)
 {
-  switch (p.dt)
+  switch (dt)
   {
-    case DT_Short:  launchFastDecodeT<short>(stage, p, wp, blob, dataBegin, blobEnd, b, out, status, st); break;
-    case DT_UShort: launchFastDecodeT<unsigned short>(stage, p, wp, blob, dataBegin, blobEnd, b, out, status, st); break;
-    case DT_Int:    launchFastDecodeT<int>(stage, p, wp, blob, dataBegin, blobEnd, b, out, status, st); break;
-    case DT_UInt:   launchFastDecodeT<unsigned int>(stage, p, wp, blob, dataBegin, blobEnd, b, out, status, st); break;
-    case DT_Float:  launchFastDecodeT<float>(stage, p, wp, blob, dataBegin, blobEnd, b, out, status, st); break;
-    case DT_Double: launchFastDecodeT<double>(stage, p, wp, blob, dataBegin, blobEnd, b, out, status, st); break;
+    case DT_Short:  launchFastDecodeT<short>(stage, nRows, nCols, wp, blob, sizeGiven, b, out, status, st); break;
+    case DT_UShort: launchFastDecodeT<unsigned short>(stage, nRows, nCols, wp, blob, sizeGiven, b, out, status, st); break;
+    case DT_Int:    launchFastDecodeT<int>(stage, nRows, nCols, wp, blob, sizeGiven, b, out, status, st); break;
+    case DT_UInt:   launchFastDecodeT<unsigned int>(stage, nRows, nCols, wp, blob, sizeGiven, b, out, status, st); break;
+    case DT_Float:  launchFastDecodeT<float>(stage, nRows, nCols, wp, blob, sizeGiven, b, out, status, st); break;
+    case DT_Double: launchFastDecodeT<double>(stage, nRows, nCols, wp, blob, sizeGiven, b, out, status, st); break;
     default: break;
   }
 }
