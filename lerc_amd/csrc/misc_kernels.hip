@@ -13,14 +13,6 @@ namespace lerc {
 // ================================================================================================
 // exclusive scan
 // ================================================================================================
-__device__ __forceinline__ u32 waveInclusiveScan(u32 v)
-{
-  const int lane = laneId();
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { u32 t = __shfl_up(v, (unsigned)d); if (lane >= d) v += t; }
-  return v;
-}
-
 // returns the exclusive prefix of `v` over the 256 threads of the workgroup; total in `total`
 __device__ __forceinline__ u32 blockExclusiveScan256(u32 v, u32& total)
 {
@@ -76,38 +68,7 @@ __global__ void __launch_bounds__(256) k_scan_add(u32* __restrict__ out, u32 n, 
 // (in and out are 16-byte aligned and hold at least that many rounded-up elements: the callers' arrays have slack)
 __global__ void __launch_bounds__(1024) k_scan_single(const u32* __restrict__ in, u32* __restrict__ out, u32 n)
 {
-  __shared__ u32 s_w[16];
-  const u32 per4 = (n + 4095u) / 4096u;                   // vectors per thread
-  const u32 begin = threadIdx.x * per4 * 4u;
-  const u32 lastVec = (n - 1u) & ~3u;                      // clamped loads: no data-dependent exit, so they batch
-  u32 sum = 0;
-#pragma unroll 8
-  for (u32 q = 0; q < per4; q++)
-  {
-    const u32 i = begin + q * 4u;
-    const uint4 x = *reinterpret_cast<const uint4*>(in + min(i, lastVec));
-    sum += (i < n ? x.x : 0u) + (i + 1 < n ? x.y : 0u) + (i + 2 < n ? x.z : 0u) + (i + 3 < n ? x.w : 0u);
-  }
-  const u32 inc = waveInclusiveScan(sum);
-  if (laneId() == 63) s_w[waveId()] = inc;
-  __syncthreads();
-  u32 run = inc - sum;
-  for (int i = 0; i < waveId(); i++) run += s_w[i];
-#pragma unroll 8
-  for (u32 q = 0; q < per4; q++)
-  {
-    const u32 i = begin + q * 4u;
-    const uint4 x = *reinterpret_cast<const uint4*>(in + min(i, lastVec));
-    uint4 o;
-    o.x = run; run += (i < n ? x.x : 0u);
-    o.y = run; run += (i + 1 < n ? x.y : 0u);
-    o.z = run; run += (i + 2 < n ? x.z : 0u);
-    o.w = run; run += (i + 3 < n ? x.w : 0u);
-    if (i + 3 < n) *reinterpret_cast<uint4*>(out + i) = o;
-    else if (i < n) { out[i] = o.x; if (i + 1 < n) out[i + 1] = o.y; if (i + 2 < n) out[i + 2] = o.z; }
-  }
-  // every thread behind the one that holds element n - 1 carries the total too
-  if (threadIdx.x == 1023) out[n] = run;
+  scanSingleWorkgroup(in, out, n);
 }
 
 void launchExclusiveScan(const u32* in, u32* out, u32 n, u32* scratch, hipStream_t stream)

@@ -91,7 +91,7 @@ __device__ __forceinline__ void quantizeLane(int intLossless, double scale, cons
   const double z0 = (double)mn;
 #pragma unroll
   for (int k = 0; k < V; k++)
-    q[k] = intLossless ? quantLossless<T>(v[k], mn) : (u32)(((double)v[k] - z0) * scale + 0.5);
+    q[k] = (DtOf<T>::v < DT_Float && intLossless) ? quantLossless<T>(v[k], mn) : (u32)(((double)v[k] - z0) * scale + 0.5);
 }
 
 // number of distinct quantised values in each block of the wave (only meaningful where `need`)
@@ -168,7 +168,12 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
     if (DtOf<T>::v >= DT_Float)
     {
 #pragma unroll
-      for (int k = 0; k < V; k++) { if (isNaNv(v[k])) flags |= 1u; if (notIntegral(v[k])) flags |= 2u; }
+      for (int k = 0; k < V; k++) if (isNaNv(v[k])) flags |= 1u;
+      if (!(flags & 2u))    // one fractional value settles "not all integers" for good (skipped once every lane has one)
+      {
+#pragma unroll
+        for (int k = 0; k < V; k++) if (notIntegral(v[k])) flags |= 2u;
+      }
     }
     T mn = v[0], mx = v[0];
 #pragma unroll
@@ -182,7 +187,9 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
     int same = (v[0] == prev) ? 1 : 0;
 #pragma unroll
     for (int k = 1; k < V; k++) same += (v[k] == v[k - 1]) ? 1 : 0;
-    same = groupReduce<LB>(same, OpSum());
+    // only "more than half of the 64" matters (tryLut); that needs a lane above the average of 32 / LB
+    if (__any(same > 32 / LB)) same = groupReduce<LB>(same, OpSum());
+    else same = 0;
     // LUT candidates need the number of distinct quantised values, which only the pixel owners can count
     u32 nd = 0;
     const bool tryLut = (2 * same > 64) && ((double)mx > (double)mn + 3 * p.maxZErr);
@@ -252,10 +259,10 @@ __device__ __forceinline__ double keyToDouble(int dt, u64 key, u64& raw)
   return (double)v;
 }
 
-__global__ void __launch_bounds__(64)
-k_fast_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgBase,
-              const u64* __restrict__ slotMinKey, const u64* __restrict__ slotMaxKey, const u32* __restrict__ slotFlags,
-              const double* __restrict__ row0RaiseErr, u8* __restrict__ out, u32 outCapacity, FastEncodeResult* res)
+__device__ __forceinline__ void
+fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgBase,
+           const u64* __restrict__ slotMinKey, const u64* __restrict__ slotMaxKey, const u32* __restrict__ slotFlags,
+           const double* __restrict__ row0RaiseErr, u8* __restrict__ out, u32 outCapacity, FastEncodeResult* res)
 {
   const int lane = laneId();
   const u64 a = waveMin(slotMinKey[lane]), b = waveMax(slotMaxKey[lane]);
@@ -321,6 +328,27 @@ k_fast_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u32 nW
   putBytes(o + 94, rawMin, tb);
   putBytes(o + 94 + tb, rawMax, tb);
   o[94 + 2 * tb] = 0;
+}
+
+// the scan of the workgroup sizes and the decisions in one launch (1024 threads; the first wave decides)
+__global__ void __launch_bounds__(1024)
+k_fast_scan_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgSize,
+                   u32* __restrict__ wgBase, const u64* __restrict__ slotMinKey, const u64* __restrict__ slotMaxKey,
+                   const u32* __restrict__ slotFlags, const double* __restrict__ row0RaiseErr, u8* __restrict__ out, u32 outCapacity,
+                   FastEncodeResult* res)
+{
+  scanSingleWorkgroup(wgSize, wgBase, nWG);
+  __syncthreads();
+  if (waveId() == 0)
+    fastDecide(p, requestedMaxZErr, raiseCandidates, nWG, wgBase, slotMinKey, slotMaxKey, slotFlags, row0RaiseErr, out, outCapacity, res);
+}
+
+__global__ void __launch_bounds__(64)
+k_fast_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgBase,
+              const u64* __restrict__ slotMinKey, const u64* __restrict__ slotMaxKey, const u32* __restrict__ slotFlags,
+              const double* __restrict__ row0RaiseErr, u8* __restrict__ out, u32 outCapacity, FastEncodeResult* res)
+{
+  fastDecide(p, requestedMaxZErr, raiseCandidates, nWG, wgBase, slotMinKey, slotMaxKey, slotFlags, row0RaiseErr, out, outCapacity, res);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -647,9 +675,16 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
   }
   else if (stage == 1)
   {
-    launchExclusiveScan(b.wgSize, b.wgBase, nWG, b.scanScratch, st);
-    hipLaunchKernelGGL(k_fast_decide, dim3(1), dim3(64), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgBase,
-                       (const u64*)b.slotMinKey, (const u64*)b.slotMaxKey, (const u32*)b.slotFlags, (const double*)b.row0RaiseErr, out, cap, b.result);
+    if (nWG <= (1u << 18))
+      hipLaunchKernelGGL(k_fast_scan_decide, dim3(1), dim3(1024), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgSize, b.wgBase,
+                         (const u64*)b.slotMinKey, (const u64*)b.slotMaxKey, (const u32*)b.slotFlags, (const double*)b.row0RaiseErr, out, cap,
+                         b.result);
+    else
+    {
+      launchExclusiveScan(b.wgSize, b.wgBase, nWG, b.scanScratch, st);
+      hipLaunchKernelGGL(k_fast_decide, dim3(1), dim3(64), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgBase,
+                         (const u64*)b.slotMinKey, (const u64*)b.slotMaxKey, (const u32*)b.slotFlags, (const double*)b.row0RaiseErr, out, cap, b.result);
+    }
   }
   else if (stage == 2)
     hipLaunchKernelGGL(k_fast_pack<T>, dim3(nWG), dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc, (const u32*)b.wgBase, out,

@@ -145,6 +145,53 @@ __device__ __forceinline__ void orBits(u32* words, u32 bitPos, u32 value, int nb
   if (sh + (u32)nbits > 32) atomicOr(&words[w + 1], value >> (32 - sh));
 }
 
+__device__ __forceinline__ u32 waveInclusiveScan(u32 v)
+{
+  const int lane = laneId();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { u32 t = __shfl_up(v, (unsigned)d); if (lane >= d) v += t; }
+  return v;
+}
+
+// Exclusive scan of in[0 .. n) into out[0 .. n], out[n] = total, by ONE workgroup of 1024 threads: thread t owns a
+// contiguous run of 4 * ceil(n / 4096) elements, moved as 16-byte vectors (in and out are 16-byte aligned and
+// readable up to the next multiple of 4 elements: the callers' arrays have slack)
+__device__ __forceinline__ void scanSingleWorkgroup(const u32* __restrict__ in, u32* __restrict__ out, u32 n)
+{
+  __shared__ u32 s_w[16];
+  const u32 per4 = (n + 4095u) / 4096u;                   // vectors per thread
+  const u32 begin = threadIdx.x * per4 * 4u;
+  const u32 lastVec = (n - 1u) & ~3u;                      // clamped loads: no data-dependent exit, so they batch
+  u32 sum = 0;
+#pragma unroll 8
+  for (u32 q = 0; q < per4; q++)
+  {
+    const u32 i = begin + q * 4u;
+    const uint4 x = *reinterpret_cast<const uint4*>(in + min(i, lastVec));
+    sum += (i < n ? x.x : 0u) + (i + 1 < n ? x.y : 0u) + (i + 2 < n ? x.z : 0u) + (i + 3 < n ? x.w : 0u);
+  }
+  const u32 inc = waveInclusiveScan(sum);
+  if (laneId() == 63) s_w[waveId()] = inc;
+  __syncthreads();
+  u32 run = inc - sum;
+  for (int i = 0; i < waveId(); i++) run += s_w[i];
+#pragma unroll 8
+  for (u32 q = 0; q < per4; q++)
+  {
+    const u32 i = begin + q * 4u;
+    const uint4 x = *reinterpret_cast<const uint4*>(in + min(i, lastVec));
+    uint4 o;
+    o.x = run; run += (i < n ? x.x : 0u);
+    o.y = run; run += (i + 1 < n ? x.y : 0u);
+    o.z = run; run += (i + 2 < n ? x.z : 0u);
+    o.w = run; run += (i + 3 < n ? x.w : 0u);
+    if (i + 3 < n) *reinterpret_cast<uint4*>(out + i) = o;
+    else if (i < n) { out[i] = o.x; if (i + 1 < n) out[i + 1] = o.y; if (i + 2 < n) out[i + 2] = o.z; }
+  }
+  // every thread behind the one that holds element n - 1 carries the total too
+  if (threadIdx.x == 1023) out[n] = run;
+}
+
 // first error wins
 __device__ __forceinline__ void raiseError(DeviceStatus* st, u32 code, u32 where)
 {
