@@ -70,15 +70,15 @@ bool readBandHeader(const BlobReader& rd, u64 off, BandDesc& b)
 // streaming kernels for one band
 // ------------------------------------------------------------------------------------------------
 // layout of a band's result cell (device, zeroed before the launches, copied back in one piece):
-//   [FastDecodeParams, 128 B reserved][fallback bits 16 B][pad to 192][64 Fletcher slot pairs]
-static const size_t kCellParams = 0, kCellFallback = 128, kCellSlots = 192, kCellBytes = 192 + 2 * kFastSlots * 8;
+//   [FastDecodeParams, 128 B reserved][fallback bits 16 B][pad to 192]
+static const size_t kCellParams = 0, kCellFallback = 128, kCellBytes = 192;
 static_assert(sizeof(FastDecodeParams) <= 128, "cell layout");
 
 static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven)
 {
   const FastWalkPlan wp = makeFastWalkPlan(nRows, nCols, sizeGiven);
   return (size_t)wp.nChunks * ((size_t)kFastListCap * 8 + kFastSubPerChunk * 8 + 64) + (size_t)wp.chainCap * sizeof(FastChain)
-    + (size_t)wp.nBlocks * 4 + (1u << 16);
+    + (size_t)wp.nBlocks * 4 + (size_t)(wp.nBlocks / kFastBlocksPerWG) * 16 + (1u << 16);
 }
 
 // enqueues header check, discovery and decode of one band; nothing is read back here
@@ -99,9 +99,9 @@ static bool launchFastBand(Context& ctx, int dt, int nRows, int nCols, const u8*
   fbuf.blockOff = ctx.allocT<u32>((size_t)fwp.nBlocks + 4);
   fbuf.params = reinterpret_cast<FastDecodeParams*>(dCell + kCellParams);
   fbuf.fallback = reinterpret_cast<u32*>(dCell + kCellFallback);
-  fbuf.slotFletcher = reinterpret_cast<u64*>(dCell + kCellSlots);
+  fbuf.wgFletcher = ctx.allocT<u64>(2 * (size_t)(fwp.nBlocks / kFastBlocksPerWG) + 4);
   if (!fbuf.chunkListN || !fbuf.chunkList || !fbuf.chains || !fbuf.chainCount || !fbuf.chunkEntry || !fbuf.chunkCount
-    || !fbuf.subEntry || !fbuf.subIndex || !fbuf.blockOff) return false;
+    || !fbuf.subEntry || !fbuf.subIndex || !fbuf.blockOff || !fbuf.wgFletcher) return false;
   static const char* kStage[kFastDecodeStages] = { "fast_candidates", "fast_chains", "fast_resolve", "fast_emit_offsets", "fast_decode" };
   for (int stage = 0; stage < kFastDecodeStages; stage++)
   {

@@ -402,14 +402,13 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
     fb.desc = ctx.allocT<FastBlockDesc>((size_t)nWG * kFastBlocksPerWG);
     fb.wgSize = ctx.allocT<u32>(nWG + 4);
     fb.wgBase = ctx.allocT<u32>(nWG + 4);
-    fb.slotMinKey = ctx.allocT<u64>(kFastSlots);
-    fb.slotMaxKey = ctx.allocT<u64>(kFastSlots);
-    fb.slotFlags = ctx.allocT<u32>(kFastSlots);
-    fb.slotFletcher = ctx.allocT<u64>(2 * kFastSlots);
-    fb.scanScratch = ctx.allocT<u32>(nWG / 1024 + 8);
+    fb.wgMinKey = ctx.allocT<u64>(nWG + 4);
+    fb.wgMaxKey = ctx.allocT<u64>(nWG + 4);
+    fb.wgFlags = ctx.allocT<u32>(nWG + 4);
+    fb.wgFletcher = ctx.allocT<u64>(2 * (size_t)nWG + 4);
     fb.result = ctx.allocT<FastEncodeResult>(1);
     double* dRow0Raise = ctx.allocT<double>(kFastRow0WG * 9);
-    if (!fb.desc || !fb.wgSize || !fb.wgBase || !fb.slotMinKey || !fb.slotMaxKey || !fb.slotFlags || !fb.slotFletcher || !fb.scanScratch || !fb.result || !dRow0Raise)
+    if (!fb.desc || !fb.wgSize || !fb.wgBase || !fb.wgMinKey || !fb.wgMaxKey || !fb.wgFlags || !fb.wgFletcher || !fb.result || !dRow0Raise)
       return kFailed;
     u32 cand = 0;
     fb.row0RaiseErr = nullptr;

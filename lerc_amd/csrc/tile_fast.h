@@ -22,7 +22,6 @@ struct FastEncodeResult
 };
 
 static const int kFastRow0WG = 16;         // workgroups that look at the first raster row (TryRaiseMaxZError)
-static const int kFastSlots = 64;          // atomics of the workgroups are spread over this many global slots
 
 struct FastBlockDesc      // what pass 1 decided for one block; pass 2 packs from it
 {
@@ -36,11 +35,10 @@ struct FastEncodeBuffers
   FastBlockDesc* desc; // [nWG * 64]
   u32* wgSize;         // [nWG] bytes of each workgroup's 64 blocks
   u32* wgBase;         // [nWG + 1] exclusive scan
-  u64* slotMinKey;     // [kFastSlots]
-  u64* slotMaxKey;     // [kFastSlots]
-  u32* slotFlags;      // [kFastSlots] bit 0 NaN seen, bit 1 non-integer value seen
-  u64* slotFletcher;   // [2 * kFastSlots] Fletcher partial sums of the bytes the workgroups wrote
-  u32* scanScratch;
+  u64* wgMinKey;       // [nWG] order-preserving key of each workgroup's smallest / largest pixel
+  u64* wgMaxKey;       // [nWG]
+  u32* wgFlags;        // [nWG] bit 0 NaN seen, bit 1 non-integer value seen
+  u64* wgFletcher;     // [2 * nWG] Fletcher partial sums (mod 65535) of the bytes each workgroup wrote
   double* row0RaiseErr;    // [kFastRow0WG * 9] TryRaiseMaxZError rounding errors of the first row, one set per workgroup (float types), or nullptr
   FastEncodeResult* result;
 };
@@ -102,7 +100,7 @@ struct FastDecodeBuffers
   u32* subEntry;       // [nChunks * kFastSubPerChunk] first block start at / behind a sub-chunk boundary ([0] = the chunk entry), or ~0
   u32* subIndex;       // [nChunks * kFastSubPerChunk] index of that block within the chunk
   u32* blockOff;       // [nBlocks + 1]
-  u64* slotFletcher;   // [2 * kFastSlots]
+  u64* wgFletcher;     // [2 * nBlocks / 64] Fletcher partial sums (mod 65535) of the bytes each decode workgroup staged
   FastDecodeParams* params;
   u32* fallback;       // != 0: the general path must redo the band
 };

@@ -134,7 +134,7 @@ __device__ __forceinline__ u32 packDesc(const Plan& pl, int nb) { return (u32)pl
 template<class T>
 __global__ void __launch_bounds__(256)
 k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict__ desc, u32* __restrict__ wgSize,
-             u64* __restrict__ slotMinKey, u64* __restrict__ slotMaxKey, u32* __restrict__ slotFlags)
+             u64* __restrict__ wgMinKey, u64* __restrict__ wgMaxKey, u32* __restrict__ wgFlags)
 {
   typedef FastCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
@@ -237,12 +237,12 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
   const u64 kMin = waveMin(FKey<T>::enc(mn)), kMax = waveMax(FKey<T>::enc(mx));
   if (lane == 0)
   {
+    // per-workgroup partial results, folded by k_fast_scan_decide (thousands of workgroups hammering a few
+    // addresses with atomics cost more than the whole pass)
     wgSize[blockIdx.x] = total;
-    const u32 slot = blockIdx.x & (kFastSlots - 1);
-    atomicMin(&slotMinKey[slot], kMin);
-    atomicMax(&slotMaxKey[slot], kMax);
-    const u32 fl = s_fl[0] | s_fl[1] | s_fl[2] | s_fl[3];
-    if (fl) atomicOr(&slotFlags[slot], fl);
+    wgMinKey[blockIdx.x] = kMin;
+    wgMaxKey[blockIdx.x] = kMax;
+    wgFlags[blockIdx.x] = s_fl[0] | s_fl[1] | s_fl[2] | s_fl[3];
   }
   PROBE(1);
 }
@@ -330,25 +330,34 @@ fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u3
   o[94 + 2 * tb] = 0;
 }
 
-// the scan of the workgroup sizes and the decisions in one launch (1024 threads; the first wave decides)
+// the scan of the workgroup sizes, the fold of the per-workgroup statistics and the decisions in one launch
+// (1024 threads; the first wave decides)
 __global__ void __launch_bounds__(1024)
 k_fast_scan_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgSize,
-                   u32* __restrict__ wgBase, const u64* __restrict__ slotMinKey, const u64* __restrict__ slotMaxKey,
-                   const u32* __restrict__ slotFlags, const double* __restrict__ row0RaiseErr, u8* __restrict__ out, u32 outCapacity,
+                   u32* __restrict__ wgBase, const u64* __restrict__ wgMinKey, const u64* __restrict__ wgMaxKey,
+                   const u32* __restrict__ wgFlags, const double* __restrict__ row0RaiseErr, u8* __restrict__ out, u32 outCapacity,
                    FastEncodeResult* res)
 {
+  __shared__ u64 s_min[64], s_max[64];
+  __shared__ u32 s_fl[64];
+  u64 kMin = ~0ull, kMax = 0ull;
+  u32 fl = 0;
+  for (u32 i = threadIdx.x; i < nWG; i += 1024u)
+  {
+    const u64 a = wgMinKey[i], b = wgMaxKey[i];
+    kMin = a < kMin ? a : kMin; kMax = b > kMax ? b : kMax;
+    fl |= wgFlags[i];
+  }
+  kMin = waveMin(kMin); kMax = waveMax(kMax);
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) fl |= __shfl_xor(fl, m);
+  if (threadIdx.x < 64) { s_min[threadIdx.x] = ~0ull; s_max[threadIdx.x] = 0ull; s_fl[threadIdx.x] = 0u; }
+  __syncthreads();
+  if (laneId() == 0) { s_min[waveId()] = kMin; s_max[waveId()] = kMax; s_fl[waveId()] = fl; }
   scanSingleWorkgroup(wgSize, wgBase, nWG);
   __syncthreads();
   if (waveId() == 0)
-    fastDecide(p, requestedMaxZErr, raiseCandidates, nWG, wgBase, slotMinKey, slotMaxKey, slotFlags, row0RaiseErr, out, outCapacity, res);
-}
-
-__global__ void __launch_bounds__(64)
-k_fast_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgBase,
-              const u64* __restrict__ slotMinKey, const u64* __restrict__ slotMaxKey, const u32* __restrict__ slotFlags,
-              const double* __restrict__ row0RaiseErr, u8* __restrict__ out, u32 outCapacity, FastEncodeResult* res)
-{
-  fastDecide(p, requestedMaxZErr, raiseCandidates, nWG, wgBase, slotMinKey, slotMaxKey, slotFlags, row0RaiseErr, out, outCapacity, res);
+    fastDecide(p, requestedMaxZErr, raiseCandidates, nWG, wgBase, s_min, s_max, s_fl, row0RaiseErr, out, outCapacity, res);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -378,7 +387,7 @@ __device__ __forceinline__ void fletcherWord(u32 x, u32 pos, u64& A, u64& B)
 template<class T>
 __global__ void __launch_bounds__(256)
 k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __restrict__ desc, const u32* __restrict__ wgBase,
-            u8* __restrict__ out, u64* __restrict__ slotFletcher, const FastEncodeResult* __restrict__ res)
+            u8* __restrict__ out, u64* __restrict__ wgFletcher, const FastEncodeResult* __restrict__ res)
 {
   typedef FastCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW, IT = C::IT;
@@ -567,27 +576,32 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    const u32 slot = blockIdx.x & (kFastSlots - 1);
-    atomicAdd(&slotFletcher[2 * slot], (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u);
-    atomicAdd(&slotFletcher[2 * slot + 1], (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u);
+    wgFletcher[2 * (size_t)blockIdx.x] = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u;    // folded by k_fast_checksum
+    wgFletcher[2 * (size_t)blockIdx.x + 1] = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
   }
   PROBE(7);
 }
 
-// checksum = Fletcher32 over blob[14 ..): the prefix bytes written by k_fast_decide + the slot sums
-__global__ void __launch_bounds__(64)
-k_fast_checksum(const u64* __restrict__ slotFletcher, u8* __restrict__ out, FastEncodeResult* res)
+// checksum = Fletcher32 over blob[14 ..): the prefix bytes written by the decide step + the workgroups' partial sums
+__global__ void __launch_bounds__(1024)
+k_fast_checksum(const u64* __restrict__ wgFletcher, u32 nWG, u8* __restrict__ out, FastEncodeResult* res)
 {
+  __shared__ u64 s_a[16], s_b[16];
   if (res->redo) return;
-  const int lane = laneId();
-  u64 A = slotFletcher[2 * lane] % 65535u, B = slotFletcher[2 * lane + 1] % 65535u;
-  for (u32 pos = (u32)lane; pos + 14 < res->prefixLen; pos += 64)
+  const int lane = laneId(), w = waveId();
+  u64 A = 0, B = 0;
+  for (u32 i = threadIdx.x; i < nWG; i += 1024u) { A += wgFletcher[2 * (size_t)i]; B += wgFletcher[2 * (size_t)i + 1]; }    // each < 65535
+  for (u32 pos = threadIdx.x; pos + 14 < res->prefixLen; pos += 1024u)
   {
     const u32 cw = (u32)out[14 + pos] << ((pos & 1u) ? 0 : 8);
     A += cw; B += (u64)(pos >> 1) * cw;
   }
   A = waveSum(A % 65535u); B = waveSum(B % 65535u);
-  if (lane != 0) return;
+  if (lane == 0) { s_a[w] = A; s_b[w] = B; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  A = 0; B = 0;
+  for (int i = 0; i < 16; i++) { A += s_a[i]; B += s_b[i]; }
   const u32 len = res->blobSize - 14;
   const u64 N = ((u64)len + 1) / 2;
   A %= 65535u; B %= 65535u;
@@ -599,22 +613,15 @@ k_fast_checksum(const u64* __restrict__ slotFletcher, u8* __restrict__ out, Fast
   res->checksum = cs;
 }
 
-// Before the passes: clear the accumulation slots and, for float types, look at the first raster row the way
+// Before the passes, for float types: look at the first raster row the way
 // Lerc2::TryRaiseMaxZError does (Lerc2.cpp:1245-1290): per candidate factor the largest rounding error, one partial
 // result per workgroup (k_fast_decide folds them).
 template<class T>
 __global__ void __launch_bounds__(256)
-k_fast_prepare(const T* __restrict__ data, int nCols, u32 raiseCand, double* __restrict__ row0Partial, u64* slotMinKey, u64* slotMaxKey,
-               u32* slotFlags, u64* slotFletcher)
+k_fast_prepare(const T* __restrict__ data, int nCols, u32 raiseCand, double* __restrict__ row0Partial)
 {
   __shared__ u64 s_r[4][9];
   const int lane = laneId(), w = waveId();
-  if (blockIdx.x == 0 && w == 0)
-  {
-    slotMinKey[lane] = ~0ull; slotMaxKey[lane] = 0ull; slotFlags[lane] = 0u;
-    slotFletcher[2 * lane] = 0ull; slotFletcher[2 * lane + 1] = 0ull;
-  }
-  if (!row0Partial) return;
   double rerr[9];
 #pragma unroll
   for (int c = 0; c < 9; c++) rerr[c] = 0;
@@ -669,28 +676,18 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
   const u32 nWG = fastEncodeNumWG(p.nRows, p.nCols);
   if (stage == 0)
   {
-    hipLaunchKernelGGL(k_fast_prepare<T>, dim3(b.row0RaiseErr ? kFastRow0WG : 1), dim3(256), 0, st, (const T*)data, p.nCols, raiseCand,
-                       b.row0RaiseErr, b.slotMinKey, b.slotMaxKey, b.slotFlags, b.slotFletcher);
-    hipLaunchKernelGGL(k_fast_stats<T>, dim3(nWG), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.slotMinKey, b.slotMaxKey, b.slotFlags);
+    if (b.row0RaiseErr)
+      hipLaunchKernelGGL(k_fast_prepare<T>, dim3(kFastRow0WG), dim3(256), 0, st, (const T*)data, p.nCols, raiseCand, b.row0RaiseErr);
+    hipLaunchKernelGGL(k_fast_stats<T>, dim3(nWG), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.wgMinKey, b.wgMaxKey, b.wgFlags);
   }
   else if (stage == 1)
-  {
-    if (nWG <= (1u << 18))
-      hipLaunchKernelGGL(k_fast_scan_decide, dim3(1), dim3(1024), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgSize, b.wgBase,
-                         (const u64*)b.slotMinKey, (const u64*)b.slotMaxKey, (const u32*)b.slotFlags, (const double*)b.row0RaiseErr, out, cap,
-                         b.result);
-    else
-    {
-      launchExclusiveScan(b.wgSize, b.wgBase, nWG, b.scanScratch, st);
-      hipLaunchKernelGGL(k_fast_decide, dim3(1), dim3(64), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgBase,
-                         (const u64*)b.slotMinKey, (const u64*)b.slotMaxKey, (const u32*)b.slotFlags, (const double*)b.row0RaiseErr, out, cap, b.result);
-    }
-  }
+    hipLaunchKernelGGL(k_fast_scan_decide, dim3(1), dim3(1024), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgSize, b.wgBase,
+                       (const u64*)b.wgMinKey, (const u64*)b.wgMaxKey, (const u32*)b.wgFlags, (const double*)b.row0RaiseErr, out, cap, b.result);
   else if (stage == 2)
     hipLaunchKernelGGL(k_fast_pack<T>, dim3(nWG), dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc, (const u32*)b.wgBase, out,
-                       b.slotFletcher, (const FastEncodeResult*)b.result);
+                       b.wgFletcher, (const FastEncodeResult*)b.result);
   else
-    hipLaunchKernelGGL(k_fast_checksum, dim3(1), dim3(64), 0, st, (const u64*)b.slotFletcher, out, b.result);
+    hipLaunchKernelGGL(k_fast_checksum, dim3(1), dim3(1024), 0, st, (const u64*)b.wgFletcher, nWG, out, b.result);
 }
 
 void launchFastEncode(int stage, const BandParams& assumed, double requestedMaxZErr, u32 raiseCandidates, const void* data, u8* out,

@@ -689,7 +689,7 @@ template<class T> __device__ __forceinline__ T dequant(double offset, u32 q, dou
 template<class T>
 __global__ void __launch_bounds__(256)
 k_fast_decode(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ blockOff,
-              T* __restrict__ outPix, u64* __restrict__ slotFletcher, const u32* __restrict__ fallback, DeviceStatus* st)
+              T* __restrict__ outPix, u64* __restrict__ wgFletcher, const u32* __restrict__ fallback, DeviceStatus* st)
 {
   const FastDecodeParams hp = *P;
   if (!hp.ok) return;
@@ -760,9 +760,8 @@ k_fast_decode(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blo
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    const u32 slot = blockIdx.x & (kFastSlots - 1);
-    atomicAdd(&slotFletcher[2 * slot], (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u);
-    atomicAdd(&slotFletcher[2 * slot + 1], (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u);
+    wgFletcher[2 * (size_t)blockIdx.x] = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u;    // folded by k_fast_fletcher_sum
+    wgFletcher[2 * (size_t)blockIdx.x + 1] = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
   }
   PROBE(9);
 
@@ -865,14 +864,21 @@ k_fast_decode(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blo
   if (__any(bad) && lane == 0) raiseError(st, kFailed, blockIdx.x);
 }
 
-// folds the slots and the prefix bytes into the checksum and compares it with the header's (Lerc2.cpp:1037-1064)
-__global__ void __launch_bounds__(64) k_fast_fletcher_sum(FastDecodeParams* __restrict__ P, const u64* __restrict__ slotFletcher)
+// folds the workgroups' partial sums and the prefix bytes into the checksum and compares it with the header's
+// (Lerc2.cpp:1037-1064)
+__global__ void __launch_bounds__(1024) k_fast_fletcher_sum(FastDecodeParams* __restrict__ P, const u64* __restrict__ wgFletcher, u32 nWG)
 {
-  const int lane = laneId();
+  __shared__ u64 s_a[16], s_b[16];
   if (!P->ok) return;
-  u64 A = waveSum(slotFletcher[2 * lane] % 65535u), B = waveSum(slotFletcher[2 * lane + 1] % 65535u);
-  if (lane != 0) return;
-  A = (A + P->prefixA) % 65535u; B = (B + P->prefixB) % 65535u;
+  u64 A = 0, B = 0;
+  for (u32 i = threadIdx.x; i < nWG; i += 1024u) { A += wgFletcher[2 * (size_t)i]; B += wgFletcher[2 * (size_t)i + 1]; }    // each < 65535
+  A = waveSum(A % 65535u); B = waveSum(B % 65535u);
+  if (laneId() == 0) { s_a[waveId()] = A; s_b[waveId()] = B; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  A = P->prefixA; B = P->prefixB;
+  for (int i = 0; i < 16; i++) { A += s_a[i]; B += s_b[i]; }
+  A %= 65535u; B %= 65535u;
   const u64 N = ((u64)(P->blobEnd - 14u) + 1) / 2;
   u64 s1 = A, s2 = ((N % 65535u) * A + 65535u - B) % 65535u;
   if (s1 == 0) s1 = 0xffff;
@@ -929,8 +935,8 @@ static void launchFastDecodeT(int stage, int nRows, int nCols, const FastWalkPla
       break;
     default:
       hipLaunchKernelGGL(k_fast_decode<T>, dim3(fastEncodeNumWG(nRows, nCols)), dim3(256), 0, st, (const FastDecodeParams*)b.params, blob,
-                         (const u32*)b.blockOff, (T*)out, b.slotFletcher, (const u32*)b.fallback, status);
-      hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1), dim3(64), 0, st, b.params, (const u64*)b.slotFletcher);
+                         (const u32*)b.blockOff, (T*)out, b.wgFletcher, (const u32*)b.fallback, status);
+      hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1), dim3(1024), 0, st, b.params, (const u64*)b.wgFletcher, fastEncodeNumWG(nRows, nCols));
       break;
   }
 }
