@@ -163,75 +163,103 @@ __device__ __forceinline__ u32 stepGlobal(const u8* __restrict__ blob, u32 cur, 
 // :2642-2677) and decides whether the streaming kernels may take the band.  Everything the later kernels need is
 // left in *P, so the host can enqueue the whole decode without having seen a single byte of the blob; it checks
 // P->ok (and the fallback bits) when it reads the results back.
-__device__ __forceinline__ u32 rdU32(const u8* b, u32 at) { return (u32)b[at] | ((u32)b[at + 1] << 8) | ((u32)b[at + 2] << 16) | ((u32)b[at + 3] << 24); }
-__device__ __forceinline__ double rdF64(const u8* b, u32 at) { const u64 v = (u64)rdU32(b, at) | ((u64)rdU32(b, at + 4) << 32); double d; memcpy(&d, &v, 8); return d; }
+// The first 128 bytes of the band sit in 32 registers of the parsing lane; all field offsets are compile-time
+// constants per codec version, so the parse is a handful of funnel shifts instead of a chain of byte loads.
+struct Head128
+{
+  u32 w[32];
+  __device__ __forceinline__ u32 u32At(u32 at) const    // at: constant after inlining
+  {
+    const u32 i = at >> 2, sh = 8u * (at & 3u);
+    return sh ? ((w[i] >> sh) | (w[i + 1] << (32u - sh))) : w[i];
+  }
+  __device__ __forceinline__ u32 byteAt(u32 at) const { return (w[at >> 2] >> (8u * (at & 3u))) & 0xFFu; }
+  __device__ __forceinline__ double f64At(u32 at) const
+  {
+    const u64 v = (u64)u32At(at) | ((u64)u32At(at + 4) << 32);
+    double d; memcpy(&d, &v, 8);
+    return d;
+  }
+};
+
+template<int DT, int VER>
+__device__ __forceinline__ void parseHead(const Head128& h, u32 sizeGiven, int nRows, int nCols, FastDecodeParams& hp)
+{
+  constexpr u32 TB = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
+  // byte offsets of the fields for this codec version (Lerc2.cpp:790-917)
+  constexpr u32 oRows = 14, oCols = 18, oDepth = 22;
+  constexpr u32 oValid = (VER >= 4) ? 26 : 22, oMb = oValid + 4, oSize = oValid + 8, oDt = oValid + 12;
+  constexpr u32 oFlags = oValid + 20;                              // v6: nBlobsMore at oValid + 16, then 4 flag bytes
+  constexpr u32 oDbl = (VER >= 6) ? oValid + 24 : oValid + 16;     // maxZError, zMin, zMax
+  constexpr u32 oMask = oDbl + 24 + ((VER >= 6) ? 16 : 0);         // numBytesMask
+  constexpr u32 oRanges = oMask + 4;
+  constexpr u32 oSweep = oRanges + ((VER >= 4) ? 2 * TB : 0);
+  constexpr u32 oData = oSweep + 1;
+  static_assert(oData + 4 <= 124, "the parsed part of the header fits the 128 bytes read");
+  const u32 nDepth = (VER >= 4) ? h.u32At(oDepth) : 1u;
+  const u32 blobSize = h.u32At(oSize);
+  const double maxZErr = h.f64At(oDbl), zMin = h.f64At(oDbl + 8), zMax = h.f64At(oDbl + 16);
+  bool ok = h.u32At(oRows) == (u32)nRows && h.u32At(oCols) == (u32)nCols && nDepth == 1u
+    && h.u32At(oValid) == (u32)nRows * (u32)nCols && h.u32At(oMb) == 8u && h.u32At(oDt) == (u32)DT
+    && ((VER < 6) || h.byteAt(oFlags) == 0u) && h.u32At(oMask) == 0u && blobSize <= sizeGiven && zMin != zMax
+    && maxZErr > 0 && maxZErr == maxZErr;
+  if (VER >= 4)                                                    // ranges: min then max, raw T (nDepth == 1)
+  {
+    bool differ = false;
+#pragma unroll
+    for (u32 i = 0; i < TB; i += 4) differ = differ || (h.u32At(oRanges + i) != h.u32At(oRanges + TB + i));
+    if (TB == 2) differ = (h.u32At(oRanges) & 0xFFFFu) != (h.u32At(oRanges + 2) & 0xFFFFu);
+    ok = ok && differ;
+  }
+  ok = ok && h.byteAt(oSweep) == 0u && oData < blobSize;          // not the one-sweep raw form
+  hp.dataBegin = oData;
+  hp.blobEnd = blobSize;
+  hp.nChunks = ok ? (blobSize - oData + kFastChunkBytes - 1) / kFastChunkBytes : 0u;
+  hp.invScale = 2 * maxZErr;
+  hp.zMaxHdr = zMax;
+  // Fletcher terms of the bytes in front of the first block (Lerc2.cpp:1037-1064; word k of blob[14 ..))
+  u64 A = 0, B = 0;
+#pragma unroll
+  for (u32 pos = 0; pos + 14u < oData; pos++)
+  {
+    const u32 cw = h.byteAt(14 + pos) << ((pos & 1u) ? 0 : 8);
+    A += cw; B += (u64)(pos >> 1) * cw;
+  }
+  hp.prefixA = A; hp.prefixB = B;
+  hp.ok = ok ? 1u : 0u;
+}
 
 template<int DT>
 __global__ void __launch_bounds__(64)
 k_fast_header(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols, FastDecodeParams* __restrict__ P)
 {
-  constexpr u32 TB = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
-  __shared__ u8 s_h[128];
-  const int lane = laneId();
-  for (u32 i = (u32)lane; i < 128u; i += 64u) s_h[i] = (i < sizeGiven) ? blob[i] : (u8)0;
-  waveSync();
-  if (lane != 0) return;
+  if (threadIdx.x != 0) return;
   FastDecodeParams hp;
   memset(&hp, 0, sizeof(hp));
-  const u8* h = s_h;
-  bool ok = sizeGiven >= 70u && h[0] == 'L' && h[1] == 'e' && h[2] == 'r' && h[3] == 'c' && h[4] == '2' && h[5] == ' ';
-  const u32 version = rdU32(h, 6);
-  ok = ok && version >= 3u && version <= 6u;
-  u32 at = 14;    // magic, version, checksum
-  hp.version = version;
-  hp.expectChecksum = rdU32(h, 10);
-  if (ok)
+  Head128 h;
+  const uint4* src = reinterpret_cast<const uint4*>(blob);    // the band is 16-byte aligned and at least 70 bytes long
+#pragma unroll
+  for (int i = 0; i < 8; i++)
   {
-    const u32 hRows = rdU32(h, at), hCols = rdU32(h, at + 4);
-    at += 8;
-    u32 nDepth = 1;
-    if (version >= 4u) { nDepth = rdU32(h, at); at += 4; }
-    const u32 numValid = rdU32(h, at), mb = rdU32(h, at + 4), blobSize = rdU32(h, at + 8), dt = rdU32(h, at + 12);
-    at += 16;
-    u32 passNoData = 0;
-    if (version >= 6u) { passNoData = h[at + 4]; at += 8; }    // nBlobsMore, then 4 flag bytes
-    const double maxZErr = rdF64(h, at), zMin = rdF64(h, at + 8), zMax = rdF64(h, at + 16);
-    at += 24;
-    if (version >= 6u) at += 16;                                // noData values
-    const u32 numBytesMask = rdU32(h, at);
-    at += 4;
-    ok = hRows == (u32)nRows && hCols == (u32)nCols && nDepth == 1u && numValid == (u32)nRows * (u32)nCols && mb == 8u
-      && dt == (u32)DT && passNoData == 0u && numBytesMask == 0u && blobSize <= sizeGiven && zMin != zMax
-      && maxZErr > 0 && maxZErr == maxZErr;
-    if (ok && version >= 4u)                                    // ranges: min then max, raw T (nDepth == 1)
-    {
-      bool differ = false;
-      for (u32 i = 0; i < TB; i++) differ = differ || (h[at + i] != h[at + TB + i]);
-      ok = differ;
-      at += 2 * TB;
-    }
-    ok = ok && h[at] == 0;                                      // not the one-sweep raw form
-    at += 1;
-    ok = ok && at < blobSize;
-    hp.dataBegin = at;
-    hp.blobEnd = blobSize;
-    hp.nChunks = ok ? (blobSize - at + kFastChunkBytes - 1) / kFastChunkBytes : 0u;
-    hp.nBlocks = (u32)(nRows / 8) * (u32)(nCols / 8);
-    hp.nTH = (u32)nCols / 8u;
-    hp.nCols = (u32)nCols;
-    hp.nRows = (u32)nRows;
-    hp.invScale = 2 * maxZErr;
-    hp.zMaxHdr = zMax;
-    // Fletcher terms of the bytes in front of the first block (Lerc2.cpp:1037-1064; word k of blob[14 ..))
-    u64 A = 0, B = 0;
-    for (u32 pos = 0; ok && pos + 14u < at; pos++)
-    {
-      const u32 cw = (u32)h[14 + pos] << ((pos & 1u) ? 0 : 8);
-      A += cw; B += (u64)(pos >> 1) * cw;
-    }
-    hp.prefixA = A; hp.prefixB = B;
+    uint4 x = make_uint4(0, 0, 0, 0);
+    if ((u32)(16 * i + 16) <= sizeGiven) x = src[i];
+    else for (u32 k = 0; 16u * i + k < sizeGiven && k < 16u; k++) (&x.x)[k >> 2] |= (u32)blob[16 * i + k] << (8 * (k & 3));
+    h.w[4 * i] = x.x; h.w[4 * i + 1] = x.y; h.w[4 * i + 2] = x.z; h.w[4 * i + 3] = x.w;
   }
-  hp.ok = ok ? 1u : 0u;
+  const u32 version = h.u32At(6);
+  const bool magic = sizeGiven >= 70u && h.u32At(0) == 0x6372654Cu && (h.u32At(4) & 0xFFFFu) == 0x2032u;    // "Lerc2 "
+  hp.version = version;
+  hp.expectChecksum = h.u32At(10);
+  hp.nBlocks = (u32)(nRows / 8) * (u32)(nCols / 8);
+  hp.nTH = (u32)nCols / 8u;
+  hp.nCols = (u32)nCols;
+  hp.nRows = (u32)nRows;
+  if (magic)
+  {
+    if (version == 6u) parseHead<DT, 6>(h, sizeGiven, nRows, nCols, hp);
+    else if (version == 5u || version == 4u) parseHead<DT, 4>(h, sizeGiven, nRows, nCols, hp);
+    else if (version == 3u) parseHead<DT, 3>(h, sizeGiven, nRows, nCols, hp);
+  }
   *P = hp;
 }
 
@@ -239,7 +267,8 @@ k_fast_header(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols, 
 // candidates
 // ------------------------------------------------------------------------------------------------
 static const int kWalkG = kFastCandChunks;    // chunks per workgroup
-static const int kFilterSteps = 4;
+static const int kMinSteps = 4;               // every candidate is filtered for at least this many blocks
+static const int kMaxRounds = 40;            // steps a candidate may need to leave the window; more -> its chain stays apart
 static const u32 kSurvivorCap = 512;         // survivors of a workgroup after the last filter step
 static const u32 kHashSize = 1024;
 static const u32 kChainCap = kFastCandChunks * kFastChainsPerChunk;    // distinct chains of a workgroup (its slice of the chain array)
@@ -260,15 +289,16 @@ __device__ __forceinline__ void queuePush(bool p, u32 e, u32* q, u32* qn, u32 ca
   }
 }
 
-// queue entry: candidate index g * W + o (13) | position relative to the chunk start (12) << 13 | signature (4) << 25 | steps (3) << 29
-__device__ __forceinline__ u32 qMake(u32 f, u32 rel, u32 sig, u32 steps) { return f | (rel << 13) | ((sig & 15u) << 25) | (steps << 29); }
+// queue entry: candidate index g * W + o (13) | position relative to the chunk start (12) << 13 | signature (4) << 25
+__device__ __forceinline__ u32 qMake(u32 f, u32 rel, u32 sig) { return f | (rel << 13) | ((sig & 15u) << 25); }
 __device__ __forceinline__ u32 qCand(u32 e) { return e & 0x1FFFu; }
 __device__ __forceinline__ u32 qRel(u32 e) { return (e >> 13) & 0xFFFu; }
 __device__ __forceinline__ u32 qSig(u32 e) { return (e >> 25) & 15u; }
-__device__ __forceinline__ u32 qSteps(u32 e) { return e >> 29; }
 
-// Only the head of every chunk is needed here: a candidate starts inside the window and takes kFilterSteps - 1
-// steps before the header of its last block is read.
+// Every candidate walks until it has left the window (and for at least kMinSteps blocks).  Candidates that sit on one
+// path (the true path crosses the window in several blocks, each of them a candidate) arrive at the same block start
+// there and merge into one chain, however short the blocks are -- except the last few, which stop up to kMinSteps - 1
+// blocks further.  Only the head of every chunk is needed for that: window + kMinSteps blocks + one header.
 template<int DT>
 __global__ void __launch_bounds__(256)
 k_fast_candidates(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob,
@@ -287,17 +317,19 @@ k_fast_candidates(const FastDecodeParams* __restrict__ P, const u8* __restrict__
   }
   constexpr int TBYTES = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
   constexpr u32 W = kFastWindow(TBYTES), RAW = 1 + 64 * TBYTES;
-  constexpr u32 kHead = (W + (kFilterSteps - 1) * RAW + 16 + 15) & ~15u;    // staged bytes per chunk, from its 16-byte aligned start
+  constexpr u32 kHead = (W + kMinSteps * RAW + 16 + 15) & ~15u;             // staged bytes per chunk, from its 16-byte aligned start
   constexpr u32 kSlice = kHead + 32;                                        // LDS bytes per chunk
-  constexpr u32 kQueueCap = (kWalkG * W * 3) / 4;                           // live candidates after the first filter step (about 3/8 on noise)
+  constexpr u32 kQueueCap = (kWalkG * W) / 2;                               // live candidates after the first step (about 3/8 on noise)
   constexpr int kRounds = (int)((kWalkG * (kSlice / 16) + 255) / 256);
-  static_assert(kWalkG * W <= 0x2000 && W - 1 + (kFilterSteps - 1) * RAW <= 0xFFF, "queue entry fields");
+  static_assert(kWalkG * W <= 0x2000 && W - 1 + (kMinSteps + 1) * RAW <= 0xFFF, "queue entry fields");
   __shared__ __align__(16) u32 s_in[kWalkG * kSlice / 4];
   __shared__ u32 s_qa[kQueueCap], s_qb[kQueueCap];
   __shared__ u32 s_hkey[kHashSize];
   __shared__ u16 s_hval[kHashSize];
   __shared__ u16 s_slot[kSurvivorCap];       // hash slot | owner << 15 of every survivor
-  __shared__ u32 s_nq[kFilterSteps], s_nChains, s_over;
+  __shared__ u32 s_done[kSurvivorCap];       // survivors: queue entry ...
+  __shared__ u8 s_doneSteps[kSurvivorCap];   // ... and the steps it took
+  __shared__ u32 s_nq[3], s_nDone, s_nChains, s_over;    // three queue counters in rotation: one barrier per round
   __shared__ u32 s_listN[kWalkG];
 
   PROBE_BEGIN;
@@ -331,15 +363,14 @@ k_fast_candidates(const FastDecodeParams* __restrict__ P, const u8* __restrict__
     }
   }
   for (u32 i = threadIdx.x; i < kHashSize; i += 256) s_hkey[i] = 0;
-  if (threadIdx.x < kFilterSteps) s_nq[threadIdx.x] = 0;
-  if (threadIdx.x == 0) { s_nChains = 0; s_over = 0; }
+  if (threadIdx.x == 0) { s_nq[0] = 0; s_nq[1] = 0; s_nq[2] = 0; s_nDone = 0; s_nChains = 0; s_over = 0; }
   if (threadIdx.x < kWalkG) s_listN[threadIdx.x] = 0;
   __syncthreads();
   PROBE(0);
 
   const u32 pattern = (version >= 5) ? 14u : 15u;
 
-  // ---- filter step 1: every window position of every chunk
+  // ---- step 1: every window position of every chunk
   const u32 nCand = nChunksHere * W;
   for (u32 base = 0; base < nCand; base += 256)
   {
@@ -352,16 +383,20 @@ k_fast_candidates(const FastDecodeParams* __restrict__ P, const u8* __restrict__
     u32 sig = kNoOffset, code = 0;
     if (live) code = stepAt<DT>(s_in + g * (kSlice / 4), chunkStart & ~15u, cur, blobEnd, version, sig, pattern);
     live = live & (code != 0u);
-    queuePush(live, qMake(f, o + codeLen(code), sig, 1), s_qa, &s_nq[0], kQueueCap, &s_over);
+    queuePush(live, qMake(f, o + codeLen(code), sig), s_qa, &s_nq[0], kQueueCap, &s_over);
   }
   __syncthreads();
 
-  // ---- filter steps 2 ..: compacted queues (a candidate that reaches its chunk end early just stays)
+  // ---- further steps through compacting queues (most candidates die at once); who has left the window (or the
+  // chunk) is a survivor
   u32* qIn = s_qa;
   u32* qOut = s_qb;
-  for (int s = 1; s < kFilterSteps; s++)
+  for (int round = 1; ; round++)
   {
-    const u32 nIn = min(s_nq[s - 1], kQueueCap);
+    const u32 nIn = min(s_nq[(round - 1) % 3], kQueueCap);
+    if (nIn == 0) break;
+    if (threadIdx.x == 0) s_nq[(round + 1) % 3] = 0;    // read for the last time two barriers ago
+    const bool lastRound = round >= kMaxRounds;
     for (u32 base = 0; base < nIn; base += 256)
     {
       const u32 i = base + threadIdx.x;
@@ -370,22 +405,34 @@ k_fast_candidates(const FastDecodeParams* __restrict__ P, const u8* __restrict__
       const u32 chunkStart = dataBegin + (c0 + g) * kFastChunkBytes;
       const u32 chunkEnd = min(chunkStart + kFastChunkBytes, blobEnd);
       const u32 cur = chunkStart + qRel(e);
-      bool live = i < nIn;
+      const bool have = i < nIn;
+      const bool done = have & (((qRel(e) >= W) & (round >= kMinSteps)) | (cur >= chunkEnd) | lastRound);
+      bool live = have & !done;
       u32 out = e;
-      if (live && cur < chunkEnd)
+      if (live)
       {
         u32 sig = qSig(e);
         const u32 code = stepAt<DT>(s_in + g * (kSlice / 4), chunkStart & ~15u, cur, blobEnd, version, sig, pattern);
         live = code != 0u;
-        out = qMake(qCand(e), qRel(e) + codeLen(code), sig, qSteps(e) + 1);
+        out = qMake(qCand(e), qRel(e) + codeLen(code), sig);
       }
-      queuePush(live, out, qOut, &s_nq[s], kQueueCap, &s_over);
+      queuePush(live, out, qOut, &s_nq[round % 3], kQueueCap, &s_over);
+      // survivors: wave-aggregated append, like queuePush
+      const u64 m = __ballot(done);
+      if (m)
+      {
+        const int lane = laneId(), leader = __ffsll((long long)m) - 1;
+        u32 at = 0;
+        if (lane == leader) at = atomicAdd(&s_nDone, (u32)__popcll(m));
+        at = __shfl(at, leader) + (u32)__popcll(m & laneMaskLt());
+        if (done) { if (at < kSurvivorCap) { s_done[at] = e; s_doneSteps[at] = (u8)round; } else s_over = 1; }
+      }
     }
     __syncthreads();
     u32* t = qIn; qIn = qOut; qOut = t;
   }
-  const u32* qs = qIn;                                             // the survivors
-  const u32 nSvAll = s_nq[kFilterSteps - 1];
+  const u32* qs = s_done;                                          // the survivors
+  const u32 nSvAll = s_nDone;
   const u32 nSv = min(nSvAll, kSurvivorCap);
   PROBE(1);
 
@@ -421,7 +468,7 @@ k_fast_candidates(const FastDecodeParams* __restrict__ P, const u8* __restrict__
       const u32 slot16 = s_slot[i];
       const u32 chain = chainBase + s_hval[slot16 & 0x7FFFu];
       const u32 slot = atomicAdd(&s_listN[g], 1u);
-      if (slot < (u32)kFastListCap) chunkList[(size_t)(c0 + g) * kFastListCap + slot] = (u64)(o | (qSteps(e) << 16)) | ((u64)chain << 32);
+      if (slot < (u32)kFastListCap) chunkList[(size_t)(c0 + g) * kFastListCap + slot] = (u64)(o | ((u32)s_doneSteps[i] << 16)) | ((u64)chain << 32);
       if (slot16 >> 15)
       {
         FastChain ch;
@@ -534,7 +581,7 @@ k_fast_resolve(const FastDecodeParams* __restrict__ P, const u8* __restrict__ bl
   for (u32 i = 0; i < n; i++)
   {
     const u64 rec = chunkList[(size_t)c * kFastListCap + i];
-    if (e != kNoOffset && ((u32)rec & 0xFFFFu) == e - chunkStart) { steps = ((u32)rec >> 16) & 15u; chainIdx = (u32)(rec >> 32); }
+    if (e != kNoOffset && ((u32)rec & 0xFFFFu) == e - chunkStart) { steps = ((u32)rec >> 16) & 0xFFFFu; chainIdx = (u32)(rec >> 32); }
   }
   u32 pos[NS], idx[NS];
 #pragma unroll

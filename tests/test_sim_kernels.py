@@ -217,3 +217,29 @@ def test_sim_device_decode_without_reading_the_header_on_the_host(libs):
     rc2, got, valid, cnt = _device_decode(S, blob, arr.shape, np.float32, mask=True)
     assert rc2 == 0 and cnt[3] == 1 and np.array_equal(valid.reshape(m.shape), m)
     assert _same(want[1].reshape(arr.shape) * m, got * m)
+
+
+@pytest.mark.ref
+def test_sim_streaming_decode_of_older_codec_versions(libs):
+    """Header layouts of codec 3, 4 and 5 (no nDepth / no nBlobsMore / no noData fields) through k_fast_header."""
+    import ctypes as ct
+    R = capi.ref()
+    if R is None:
+        pytest.skip("reference library not built")
+    O, S = libs
+    rng = np.random.default_rng(17)
+    for dt, e in ((np.float32, 0.01), (np.uint16, 0), (np.float64, 0.1)):
+        arr = cases._cast(cases.terrain(16, 1024, rng, amp=300, base=1000, sigma=1.5), dt)
+        for ver in (3, 4, 5):
+            buf = np.empty(arr.nbytes + 4096, np.uint8)
+            n = ct.c_uint(0)
+            rc = R.lib.lerc_encodeForVersion(arr.ctypes.data, ver, capi.dt_code(dt), 1, arr.shape[1], arr.shape[0], 1, 0, None,
+                                             float(e), buf.ctypes.data, buf.size, ct.byref(n))
+            assert rc == 0
+            blob = buf[:n.value].tobytes()
+            want = R.decode(blob)
+            c0 = S.path_counters()
+            got = S.decode(blob)
+            c1 = S.path_counters()
+            assert want[0] == got[0] == 0 and _same(want[1], got[1])
+            assert c1[2] == c0[2] + 1, (np.dtype(dt).name, ver, S.last_note())
