@@ -83,7 +83,7 @@ static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven)
 
 // enqueues header check, discovery and decode of one band; nothing is read back here
 static bool launchFastBand(Context& ctx, int dt, int nRows, int nCols, const u8* dBand, u32 sizeGiven, void* dOutBand,
-                           DeviceStatus* dStatus, u8* dCell)
+                           DeviceStatus* dStatus, u8* dCell, bool clearCells)
 {
   hipStream_t st = ctx.activeStream();
   const FastWalkPlan fwp = makeFastWalkPlan(nRows, nCols, sizeGiven);
@@ -99,6 +99,7 @@ static bool launchFastBand(Context& ctx, int dt, int nRows, int nCols, const u8*
   fbuf.blockOff = ctx.allocT<u32>((size_t)fwp.nBlocks + 4);
   fbuf.params = reinterpret_cast<FastDecodeParams*>(dCell + kCellParams);
   fbuf.fallback = reinterpret_cast<u32*>(dCell + kCellFallback);
+  fbuf.clearCells = clearCells;
   fbuf.wgFletcher = ctx.allocT<u64>(2 * (size_t)(fwp.nBlocks / kFastBlocksPerWG) + 4);
   if (!fbuf.chunkListN || !fbuf.chunkList || !fbuf.chains || !fbuf.chainCount || !fbuf.chunkEntry || !fbuf.chunkCount
     || !fbuf.subEntry || !fbuf.subIndex || !fbuf.blockOff || !fbuf.wgFletcher) return false;
@@ -138,8 +139,7 @@ static u32 decodeSpeculative(Context& ctx, const DecodeRequest& rq, bool& handle
   const size_t cellsBytes = 64 + kCellBytes;
   u8* dCells = ctx.allocT<u8>(cellsBytes);
   if (!dCells) return kOk;
-  hipMemsetAsync(dCells, 0, cellsBytes, st);
-  if (!launchFastBand(ctx, dt, nRows, nCols, rq.dBlob, rq.blobSize, rq.dOut, reinterpret_cast<DeviceStatus*>(dCells), dCells + 64))
+  if (!launchFastBand(ctx, dt, nRows, nCols, rq.dBlob, rq.blobSize, rq.dOut, reinterpret_cast<DeviceStatus*>(dCells), dCells + 64, true))
     return kOk;
   if (rq.nMasks > 0 && rq.dValidBytes) hipMemsetAsync(rq.dValidBytes, 1, (size_t)nRows * nCols, st);    // numValid == nPix or no verdict
   u8* pin = (u8*)ctx.pinned(cellsBytes);
@@ -409,7 +409,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
 
     if (fastBand && fastDataBegin == (u32)(at - bd.offset))
     {
-      if (!launchFastBand(ctx, dt, nRows, nCols, dBand, blobEnd, dOutBand, dStatus, dCells + 64 + (size_t)iBand * kCellBytes)) return kFailed;
+      if (!launchFastBand(ctx, dt, nRows, nCols, dBand, blobEnd, dOutBand, dStatus, dCells + 64 + (size_t)iBand * kCellBytes, false)) return kFailed;
       FastBand& f = fast[iBand];
       ctx.lastDecodeStreamed = true;
       f.used = true;

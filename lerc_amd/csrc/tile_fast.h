@@ -103,6 +103,7 @@ struct FastDecodeBuffers
   u64* wgFletcher;     // [2 * nBlocks / 64] Fletcher partial sums (mod 65535) of the bytes each decode workgroup staged
   FastDecodeParams* params;
   u32* fallback;       // != 0: the general path must redo the band
+  bool clearCells;     // the header kernel zeroes *status and fallback[0..3] itself (no memset before the launches)
 };
 
 bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid);

@@ -231,8 +231,12 @@ __device__ __forceinline__ void parseHead(const Head128& h, u32 sizeGiven, int n
 
 template<int DT>
 __global__ void __launch_bounds__(64)
-k_fast_header(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols, FastDecodeParams* __restrict__ P)
+k_fast_header(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols, FastDecodeParams* __restrict__ P,
+              u32* __restrict__ clearStatus, u32* __restrict__ clearFallback)
 {
+  // first kernel of a decode: it also clears the cells the later kernels raise flags in (saves a memset launch)
+  if (threadIdx.x < 4 && clearStatus) clearStatus[threadIdx.x] = 0u;
+  if (threadIdx.x >= 4 && threadIdx.x < 8 && clearFallback) clearFallback[threadIdx.x - 4] = 0u;
   if (threadIdx.x != 0) return;
   FastDecodeParams hp;
   memset(&hp, 0, sizeof(hp));
@@ -319,7 +323,7 @@ k_fast_candidates(const FastDecodeParams* __restrict__ P, const u8* __restrict__
   constexpr u32 W = kFastWindow(TBYTES), RAW = 1 + 64 * TBYTES;
   constexpr u32 kHead = (W + kMinSteps * RAW + 16 + 15) & ~15u;             // staged bytes per chunk, from its 16-byte aligned start
   constexpr u32 kSlice = kHead + 32;                                        // LDS bytes per chunk
-  constexpr u32 kQueueCap = (kWalkG * W) / 2;                               // live candidates after the first step (about 3/8 on noise)
+  constexpr u32 kQueueCap = (kWalkG * W * 3) / 4;    // live candidates after the first step (noise: 3/8 with codec >= 5, 3/4 before)
   constexpr int kRounds = (int)((kWalkG * (kSlice / 16) + 255) / 256);
   static_assert(kWalkG * W <= 0x2000 && W - 1 + (kMinSteps + 1) * RAW <= 0xFFF, "queue entry fields");
   __shared__ __align__(16) u32 s_in[kWalkG * kSlice / 4];
@@ -962,7 +966,8 @@ static void launchFastDecodeT(int stage, int nRows, int nCols, const FastWalkPla
   switch (stage)
   {
     case 0:
-      hipLaunchKernelGGL(k_fast_header<DT>, dim3(1), dim3(64), 0, st, blob, sizeGiven, nRows, nCols, b.params);
+      hipLaunchKernelGGL(k_fast_header<DT>, dim3(1), dim3(64), 0, st, blob, sizeGiven, nRows, nCols, b.params,
+                         b.clearCells ? reinterpret_cast<u32*>(status) : nullptr, b.clearCells ? b.fallback : nullptr);
       hipLaunchKernelGGL(k_fast_candidates<DT>, dim3((wp.nChunks + kWalkG - 1) / kWalkG), dim3(256), 0, st, (const FastDecodeParams*)b.params,
                          blob, b.chunkListN, b.chunkList, b.chains, b.chainCount, b.fallback);
       break;
