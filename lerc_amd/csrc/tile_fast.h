@@ -49,6 +49,33 @@ u32 fastEncodeNumWG(int nRows, int nCols);
 void launchFastEncode(int stage, const BandParams& assumed, double requestedMaxZErr, u32 raiseCandidates, const void* data, u8* out,
                       u32 outCapacity, const FastEncodeBuffers& b, hipStream_t st);
 
+// ---- where a workgroup's 64 consecutive blocks lie in the raster -----------------------------------------------
+// Block k of the stream is block (k / nTH, k % nTH) of the raster (nTH = nCols / 8 blocks per block row).  The streaming
+// kernels take rasters in which either a block row holds a whole number of workgroups (nTH % 64 == 0) or a
+// workgroup holds a whole number of block rows (nTH a power of two <= 64: 64 ... 512 columns, e.g. 256 x 256 tiles),
+// so the split into row and column is one division per workgroup or none.
+struct FastSpan { u32 it0, jt0, shift, mask; };
+LERC_HD FastSpan fastSpanOf(u32 wg, u32 nTH)
+{
+  FastSpan s;
+  const u32 k0 = wg * 64u;
+  if ((nTH & 63u) == 0u) { s.it0 = k0 / nTH; s.jt0 = k0 - s.it0 * nTH; s.shift = 31; s.mask = 0xFFFFFFFFu; }
+  else { u32 sh = 0; while ((1u << (sh + 1)) <= nTH) sh++; s.shift = sh; s.it0 = k0 >> sh; s.jt0 = 0; s.mask = nTH - 1u; }
+  return s;
+}
+LERC_HD u32 fastSpanRow(const FastSpan& s, u32 j) { return s.it0 + ((s.jt0 + j) >> s.shift); }    // block j of the workgroup
+LERC_HD u32 fastSpanCol(const FastSpan& s, u32 j) { return (s.jt0 + j) & s.mask; }
+// dimensions the streaming kernels accept (blocksPerWaveTile: 4 for 32-bit types, 8 for 16-bit, 2 for 64-bit)
+LERC_HD bool fastDimsOk(int dt, int nRows, int nCols)
+{
+  if (nRows <= 0 || nCols <= 0 || nRows % 8 != 0 || nCols % 8 != 0) return false;
+  const u32 nTH = (u32)nCols / 8u, nTV = (u32)nRows / 8u;
+  const u32 bpw = (dt == DT_Short || dt == DT_UShort) ? 8u : (dt == DT_Double) ? 2u : 4u;
+  const bool pow2 = (nTH & (nTH - 1u)) == 0u;
+  if (!((nTH % 64u == 0u) || (pow2 && nTH <= 64u && nTH >= bpw))) return false;
+  return ((u64)nTH * nTV) % 64u == 0u;
+}
+
 // ---- decode side ---------------------------------------------------------------------------------
 static const u32 kFastChunkBytes = 4096;
 static const u32 kFastSubBytes = 512;      // the chains also note the first block start behind every sub-chunk boundary

@@ -122,6 +122,17 @@ template<> struct FKey<unsigned int> { static __device__ u64 enc(unsigned int v)
 template<> struct FKey<short> { static __device__ u64 enc(short v) { return (u64)((i64)v + (1ll << 62)); } };
 template<> struct FKey<unsigned short> { static __device__ u64 enc(unsigned short v) { return (u64)v + (1ull << 62); } };
 
+// Raster offset of the first pixel a lane owns in wave tile `tl` (0 .. 15) of its workgroup.  WIDE: the 64 blocks of
+// the workgroup lie in one block row (nTH % 64 == 0), the tiles are a constant stride apart and the compiler folds the
+// stride into the load / store instruction; otherwise the workgroup spans several block rows (fastSpanOf).
+template<bool WIDE, int BPW, int V>
+__device__ __forceinline__ i64 laneOrigin(const FastSpan& span, int tl, int r, int c, int nCols)
+{
+  if (WIDE) return (i64)(span.it0 * 8u + (u32)r) * nCols + (i64)span.jt0 * 8 + tl * (BPW * 8) + c * V;
+  const u32 j = (u32)tl * BPW;
+  return (i64)(fastSpanRow(span, j) * 8u + (u32)r) * nCols + (i64)fastSpanCol(span, j) * 8 + c * V;
+}
+
 template<class T> __device__ __forceinline__ u64 rawBits(T v) { u64 b = 0; memcpy(&b, &v, sizeof(T)); return b; }
 template<class T> __device__ __forceinline__ T fromRawBits(u64 b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
 
@@ -131,7 +142,7 @@ __device__ __forceinline__ u32 packDesc(const Plan& pl, int nb) { return (u32)pl
 // ------------------------------------------------------------------------------------------------
 // pass 1: global statistics + block decisions + sizes
 // ------------------------------------------------------------------------------------------------
-template<class T>
+template<class T, bool WIDE>
 __global__ void __launch_bounds__(256)
 k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict__ desc, u32* __restrict__ wgSize,
              u64* __restrict__ wgMinKey, u64* __restrict__ wgMaxKey, u32* __restrict__ wgFlags)
@@ -148,16 +159,14 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
   constexpr int LB = 8 * LPR;
   const int w = waveId(), lane = laneId();
   const int b = lane / LB, r = (lane % LB) / LPR, h = lane % LPR, c = b * LPR + h;
-  const int wgPerRow = p.nCols / (kFastBlocksPerWG * 8);
-  const int it = (int)blockIdx.x / wgPerRow, wgc = (int)blockIdx.x - it * wgPerRow;
-  const i64 rowBase = (i64)(it * 8 + r) * p.nCols + (i64)wgc * (kFastBlocksPerWG * 8);
+  const FastSpan span = fastSpanOf(blockIdx.x, (u32)p.nTH);
   const bool leader = (lane % LB == 0);
 
   // all loads of the wave in flight before the first use (the data-dependent LUT branch below keeps the compiler
   // from hoisting them itself)
   T vAll[C::IT][V];
 #pragma unroll
-  for (int t = 0; t < C::IT; t++) loadLane<T, V>(data + rowBase + (t * 4 + w) * C::TILE_COLS + c * V, vAll[t]);
+  for (int t = 0; t < C::IT; t++) loadLane<T, V>(data + laneOrigin<WIDE, BPW, V>(span, t * 4 + w, r, c, p.nCols), vAll[t]);
 
   u32 flags = 0;
 #pragma unroll
@@ -384,7 +393,7 @@ __device__ __forceinline__ void fletcherWord(u32 x, u32 pos, u64& A, u64& B)
   B += (u64)k * w0 + (u64)(k + 1) * w1;
 }
 
-template<class T>
+template<class T, bool WIDE>
 __global__ void __launch_bounds__(256)
 k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __restrict__ desc, const u32* __restrict__ wgBase,
             u8* __restrict__ out, u64* __restrict__ wgFletcher, const FastEncodeResult* __restrict__ res)
@@ -403,9 +412,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
   PROBE_BEGIN;
   const int w = waveId(), lane = laneId();
   const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
-  const int wgPerRow = p.nCols / (kFastBlocksPerWG * 8);
-  const int it = (int)blockIdx.x / wgPerRow, wgc = (int)blockIdx.x - it * wgPerRow;
-  const i64 rowBase = (i64)(it * 8 + r) * p.nCols + (i64)wgc * (kFastBlocksPerWG * 8);
+  const FastSpan span = fastSpanOf(blockIdx.x, (u32)p.nTH);
   const u32 g0 = res->prefixLen + wgBase[blockIdx.x];        // absolute offset of this workgroup's span
   const u32 spanLen = wgBase[blockIdx.x + 1] - wgBase[blockIdx.x];
   const u32 ldsShift = g0 & 15u;                            // LDS byte i <-> blob byte (g0 & ~15) + i
@@ -413,7 +420,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
   // pixels first (long latency), descriptors by wave 0, zero the span image meanwhile
   T v[IT][V];
 #pragma unroll
-  for (int t = 0; t < IT; t++) loadLane<T, V>(data + rowBase + (t * 4 + w) * C::TILE_COLS + c * V, v[t]);
+  for (int t = 0; t < IT; t++) loadLane<T, V>(data + laneOrigin<WIDE, BPW, V>(span, t * 4 + w, r, c, p.nCols), v[t]);
   FastBlockDesc d;
   const int wPlan = (int)((blockIdx.x * 2654435761u) >> 30);    // the wave that does the per-block work rotates (see k_fast_stats)
   if (w == wPlan) d = desc[(size_t)blockIdx.x * kFastBlocksPerWG + lane];
@@ -435,7 +442,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
   {
     const u32 w1 = d.w1;
     const int kind = (int)((w1 >> 16) & 7u), tc = (int)((w1 >> 19) & 3u), dtRed = (int)((w1 >> 21) & 7u), nb = (int)(w1 >> 24);
-    const int j0 = (wgc * kFastBlocksPerWG + lane) * 8;
+    const int j0 = (int)fastSpanCol(span, (u32)lane) * 8;
     u32 flag = (u32)(((j0 >> 3) & 15) << 2) & 0x38u;    // version 6, no slice difference
     const u32 at0 = 8u * (ldsShift) + (s_bit[lane] - 8u * ldsShift);
     if (kind == 0) orBits(s_out, at0, flag | 2u, 8);
@@ -661,13 +668,13 @@ k_fast_prepare(const T* __restrict__ data, int nCols, u32 raiseCand, double* __r
 bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, double maxZErr)
 {
   if (hasMask || nDepth != 1) return false;
-  if (nRows % 8 != 0 || nCols % (kFastBlocksPerWG * 8) != 0) return false;
   if (dt == DT_Char || dt == DT_Byte) return false;    // 8-bit: the Huffman decision needs the general path
+  if (!fastDimsOk(dt, nRows, nCols)) return false;
   if (dt >= DT_Float && maxZErr == 0) return false;    // lossless float is out of scope altogether
   return true;
 }
 
-u32 fastEncodeNumWG(int nRows, int nCols) { return (u32)(nRows / 8) * (u32)(nCols / (kFastBlocksPerWG * 8)); }
+u32 fastEncodeNumWG(int nRows, int nCols) { return (u32)(((u64)(nRows / 8) * (u64)(nCols / 8)) / kFastBlocksPerWG); }
 
 template<class T>
 static void launchFastEncodeT(int stage, const BandParams& p, double requested, u32 raiseCand, const void* data, u8* out, u32 cap,
@@ -678,14 +685,23 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
   {
     if (b.row0RaiseErr)
       hipLaunchKernelGGL(k_fast_prepare<T>, dim3(kFastRow0WG), dim3(256), 0, st, (const T*)data, p.nCols, raiseCand, b.row0RaiseErr);
-    hipLaunchKernelGGL(k_fast_stats<T>, dim3(nWG), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.wgMinKey, b.wgMaxKey, b.wgFlags);
+    if (p.nTH % 64 == 0)
+      hipLaunchKernelGGL((k_fast_stats<T, true>), dim3(nWG), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.wgMinKey, b.wgMaxKey, b.wgFlags);
+    else
+      hipLaunchKernelGGL((k_fast_stats<T, false>), dim3(nWG), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.wgMinKey, b.wgMaxKey, b.wgFlags);
   }
   else if (stage == 1)
     hipLaunchKernelGGL(k_fast_scan_decide, dim3(1), dim3(1024), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgSize, b.wgBase,
                        (const u64*)b.wgMinKey, (const u64*)b.wgMaxKey, (const u32*)b.wgFlags, (const double*)b.row0RaiseErr, out, cap, b.result);
   else if (stage == 2)
-    hipLaunchKernelGGL(k_fast_pack<T>, dim3(nWG), dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc, (const u32*)b.wgBase, out,
-                       b.wgFletcher, (const FastEncodeResult*)b.result);
+  {
+    if (p.nTH % 64 == 0)
+      hipLaunchKernelGGL((k_fast_pack<T, true>), dim3(nWG), dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc, (const u32*)b.wgBase,
+                         out, b.wgFletcher, (const FastEncodeResult*)b.result);
+    else
+      hipLaunchKernelGGL((k_fast_pack<T, false>), dim3(nWG), dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc, (const u32*)b.wgBase,
+                         out, b.wgFletcher, (const FastEncodeResult*)b.result);
+  }
   else
     hipLaunchKernelGGL(k_fast_checksum, dim3(1), dim3(1024), 0, st, (const u64*)b.wgFletcher, nWG, out, b.result);
 }

@@ -737,7 +737,7 @@ template<class T> __device__ __forceinline__ T dequant(double offset, u32 q, dou
   return (T)(z < zMaxI ? z : zMaxI);
 }
 
-template<class T>
+template<class T, bool WIDE>
 __global__ void __launch_bounds__(256)
 k_fast_decode(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ blockOff,
               T* __restrict__ outPix, u64* __restrict__ wgFletcher, const u32* __restrict__ fallback, DeviceStatus* st)
@@ -760,8 +760,7 @@ k_fast_decode(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blo
   PROBE_BEGIN;
   const int w = waveId(), lane = laneId();
   const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
-  const int wgPerRow = p.nCols / (kFastBlocksPerWG * 8);
-  const int it = (int)blockIdx.x / wgPerRow, wgc = (int)blockIdx.x - it * wgPerRow;
+  const FastSpan span = fastSpanOf(blockIdx.x, hp.nTH);
   const u32 firstBlk = blockIdx.x * kFastBlocksPerWG;
 
   if (threadIdx.x <= kFastBlocksPerWG) s_off[threadIdx.x] = blockOff[firstBlk + threadIdx.x];
@@ -821,7 +820,7 @@ k_fast_decode(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blo
   if (w == (int)((blockIdx.x * 2654435761u) >> 30))    // rotates over the waves (= SIMDs) from workgroup to workgroup
   {
     const u32 off = s_off[lane];
-    const u32 jt = (u32)(wgc * kFastBlocksPerWG + lane);
+    const u32 jt = fastSpanCol(span, (u32)lane);
     u32 h0, h1, h2;
     ldsHeader<DT>(s_in, off - a0, h0, h1, h2);
     u32 code = parseCode<DT>(h0, h1, h2, p.version);
@@ -844,7 +843,6 @@ k_fast_decode(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blo
   __syncthreads();
   PROBE(10);
 
-  const i64 rowBase = (i64)(it * 8 + r) * p.nCols + (i64)wgc * (kFastBlocksPerWG * 8);
   const i64 invI = (i64)p.invScale, zMaxI = (i64)p.zMaxHdr;
   bool bad = false;
 #pragma unroll
@@ -909,7 +907,10 @@ k_fast_decode(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blo
     Vec o;
 #pragma unroll
     for (int k = 0; k < V; k++) o.e[k] = v[k];
-    *reinterpret_cast<Vec*>(outPix + rowBase + tile * C::TILE_COLS + c * V) = o;
+    i64 at;
+    if (WIDE) at = (i64)(span.it0 * 8u + (u32)r) * p.nCols + (i64)span.jt0 * 8 + tile * (BPW * 8) + c * V;    // one block row: constant stride
+    else { const u32 j = (u32)tile * BPW; at = (i64)(fastSpanRow(span, j) * 8u + (u32)r) * p.nCols + (i64)fastSpanCol(span, j) * 8 + c * V; }
+    *reinterpret_cast<Vec*>(outPix + at) = o;
   }
   PROBE(11);
   if (__any(bad) && lane == 0) raiseError(st, kFailed, blockIdx.x);
@@ -941,8 +942,8 @@ __global__ void __launch_bounds__(1024) k_fast_fletcher_sum(FastDecodeParams* __
 bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid)
 {
   if (!allValid || nDepth != 1 || mb != 8 || version < 3) return false;
-  if (nRows % 8 != 0 || nCols % (kFastBlocksPerWG * 8) != 0) return false;
   if (dt == DT_Char || dt == DT_Byte) return false;
+  if (!fastDimsOk(dt, nRows, nCols)) return false;
   return true;
 }
 
@@ -986,8 +987,12 @@ static void launchFastDecodeT(int stage, int nRows, int nCols, const FastWalkPla
                          (const u32*)b.subIndex, b.blockOff, b.fallback);
       break;
     default:
-      hipLaunchKernelGGL(k_fast_decode<T>, dim3(fastEncodeNumWG(nRows, nCols)), dim3(256), 0, st, (const FastDecodeParams*)b.params, blob,
-                         (const u32*)b.blockOff, (T*)out, b.wgFletcher, (const u32*)b.fallback, status);
+      if ((nCols / 8) % 64 == 0)
+        hipLaunchKernelGGL((k_fast_decode<T, true>), dim3(fastEncodeNumWG(nRows, nCols)), dim3(256), 0, st, (const FastDecodeParams*)b.params, blob,
+                           (const u32*)b.blockOff, (T*)out, b.wgFletcher, (const u32*)b.fallback, status);
+      else
+        hipLaunchKernelGGL((k_fast_decode<T, false>), dim3(fastEncodeNumWG(nRows, nCols)), dim3(256), 0, st, (const FastDecodeParams*)b.params, blob,
+                           (const u32*)b.blockOff, (T*)out, b.wgFletcher, (const u32*)b.fallback, status);
       hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1), dim3(1024), 0, st, b.params, (const u64*)b.wgFletcher, fastEncodeNumWG(nRows, nCols));
       break;
   }

@@ -86,6 +86,11 @@ def _fast_cases():
             for e in ([0.01, 3.0] if kind == "f" else [0, 2]):
                 out.append((f"fast-terrain-{np.dtype(dt).name}-{r}x{c}-e{e}", cases._cast(x, dt), e))
             out.append((f"fast-mixed-{np.dtype(dt).name}-{r}x{c}", cases.mixed_regions(r, c, rng, dt), 0.01 if kind == "f" else 0))
+    # narrow rasters: a workgroup's 64 blocks span several block rows (e.g. the 256 x 256 tiles of a mosaic)
+    for dt in (np.float32, np.uint16, np.float64):
+        for (r, c) in ((256, 256), (64, 128), (128, 64)):
+            x = cases.terrain(r, c, rng, amp=300, base=1000, sigma=1.5)
+            out.append((f"fast-narrow-{np.dtype(dt).name}-{r}x{c}", cases._cast(x, dt), 0.01 if np.dtype(dt).kind == "f" else 0))
     f = np.float32
     out.append(("fast-f32-allint", np.rint(cases.terrain(16, 512, rng)).astype(f), 0.01))
     out.append(("fast-f32-round1", np.round(cases.terrain(16, 512, rng), 1).astype(f), 0.01))
