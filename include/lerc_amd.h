@@ -108,6 +108,18 @@ LERC_AMD_API lerc_status lerc_amd_decode_device(lerc_amd_context* ctx, const uns
     unsigned int blobSize, int nMasks, unsigned char* dValidBytes, int nDepth, int nCols, int nRows, int nBands,
     unsigned int dataType, void* dData);
 
+/* Tile mosaics: nTiles rasters of one shape, contiguous on the device ([nTiles][nRows][nCols], 1 band, nDepth 1,
+ * no masks), in ONE call (tiles are independent blobs; ranks of a multi-GPU job take tile ranges).
+ * Tile t becomes exactly the blob lerc_encode() would make of it, at dArena + offsets[t] (16-byte aligned), sizes[t]
+ * bytes long; offsets / sizes / arenaUsed are HOST arrays the caller provides.  BufferTooSmall(3) if the arena is
+ * too small (lerc_computeCompressedSize bounds a tile; nRows * nCols * sizeof(T) + 128 per tile always suffices).
+ * Decoding takes the same description back.  Blobs that need the general kernels are handled inside, one by one. */
+LERC_AMD_API lerc_status lerc_amd_encode_tiles_device(lerc_amd_context* ctx, const void* dTiles, unsigned int dataType, int nCols,
+    int nRows, int nTiles, double maxZErr, unsigned char* dArena, unsigned long long arenaCapacity, unsigned long long* offsets,
+    unsigned int* sizes, unsigned long long* arenaUsed);
+LERC_AMD_API lerc_status lerc_amd_decode_tiles_device(lerc_amd_context* ctx, const unsigned char* dArena,
+    const unsigned long long* offsets, const unsigned int* sizes, int nTiles, int nCols, int nRows, unsigned int dataType, void* dTiles);
+
 /* Per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline of the
  * dominant kernel).  lerc_amd_profile_read writes lines "kernel_group total_ms launches" into buf. */
 LERC_AMD_API void lerc_amd_profile_enable(lerc_amd_context* ctx, int on);

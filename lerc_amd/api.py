@@ -58,9 +58,13 @@ def load_library():
     lib.lerc_amd_encode_device.argtypes = [ct.c_void_p] + enc + [ct.c_void_p, ct.c_uint, u32p]
     lib.lerc_amd_decode_device.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int,
                                            ct.c_int, ct.c_int, ct.c_uint, ct.c_void_p]
+    lib.lerc_amd_encode_tiles_device.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_int, ct.c_int, ct.c_int, ct.c_double, ct.c_void_p,
+                                                 ct.c_ulonglong, ct.c_void_p, ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+    lib.lerc_amd_decode_tiles_device.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_uint,
+                                                 ct.c_void_p]
     lib.lerc_amd_build_info.restype = ct.c_char_p
     for n in ("lerc_computeCompressedSize", "lerc_encode", "lerc_getBlobInfo", "lerc_getDataRanges", "lerc_decode",
-              "lerc_amd_encode_device", "lerc_amd_decode_device"):
+              "lerc_amd_encode_device", "lerc_amd_decode_device", "lerc_amd_encode_tiles_device", "lerc_amd_decode_tiles_device"):
         getattr(lib, n).restype = ct.c_uint
     _LIB = lib
     return lib
@@ -223,3 +227,24 @@ def encode_device(codec, tensor, max_z_err, out, n_depth=1):
 def decode_device(codec, blob, n_bytes, out, n_depth=1):
     n_rows, n_cols = int(out.shape[0]), int(out.shape[1])
     return codec.decode(blob.data_ptr(), int(n_bytes), _torch_dt_code(out), n_depth, n_cols, n_rows, 1, out.data_ptr())
+
+
+def encode_tiles_device(codec, tiles, max_z_err, arena):
+    """tiles: CUDA(HIP) tensor [nTiles, nRows, nCols]; arena: uint8 CUDA tensor.  One blob per tile, each exactly what
+    encode() makes of that tile.  -> (status, offsets uint64[nTiles], sizes uint32[nTiles], arena bytes used)"""
+    n_tiles, n_rows, n_cols = (int(v) for v in tiles.shape)
+    offsets = np.zeros(n_tiles, np.uint64)
+    sizes = np.zeros(n_tiles, np.uint32)
+    used = ct.c_ulonglong(0)
+    rc = codec.lib.lerc_amd_encode_tiles_device(codec.h, tiles.data_ptr(), _torch_dt_code(tiles), n_cols, n_rows, n_tiles, float(max_z_err),
+                                                arena.data_ptr(), arena.numel(), offsets.ctypes.data, sizes.ctypes.data, ct.byref(used))
+    return rc, offsets, sizes, int(used.value)
+
+
+def decode_tiles_device(codec, arena, offsets, sizes, out):
+    """out: CUDA(HIP) tensor [nTiles, nRows, nCols] to fill from the blobs arena[offsets[t] : offsets[t] + sizes[t]]."""
+    n_tiles, n_rows, n_cols = (int(v) for v in out.shape)
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    sizes = np.ascontiguousarray(sizes, np.uint32)
+    return codec.lib.lerc_amd_decode_tiles_device(codec.h, arena.data_ptr(), offsets.ctypes.data, sizes.ctypes.data, n_tiles, n_cols, n_rows,
+                                                  _torch_dt_code(out), out.data_ptr())

@@ -316,6 +316,33 @@ lerc_status lerc_amd_decode_device(lerc_amd_context* h, const unsigned char* dLe
   return decodeDevice(h->ctx, rq);
 }
 
+lerc_status lerc_amd_encode_tiles_device(lerc_amd_context* h, const void* dTiles, unsigned int dataType, int nCols, int nRows, int nTiles,
+  double maxZErr, unsigned char* dArena, unsigned long long arenaCapacity, unsigned long long* offsets, unsigned int* sizes,
+  unsigned long long* arenaUsed)
+{
+  if (!h || !dTiles || !dArena || !offsets || !sizes || dataType >= DT_Undefined || nCols <= 0 || nRows <= 0 || nTiles <= 0 || maxZErr < 0)
+    return kWrongParam;
+  if (!dimsOk(1, nCols, nRows, (size_t)dtSize((int)dataType))) return kDimsTooLarge;
+  TilesEncodeRequest rq;
+  rq.dData = dTiles; rq.dt = (int)dataType; rq.nCols = nCols; rq.nRows = nRows; rq.nTiles = nTiles; rq.maxZErr = maxZErr;
+  rq.dArena = dArena; rq.arenaCapacity = arenaCapacity; rq.hOffsets = offsets; rq.hSizes = sizes;
+  u64 used = 0;
+  const u32 rc = encodeTilesDevice(h->ctx, rq, used);
+  if (arenaUsed) *arenaUsed = used;
+  return rc;
+}
+
+lerc_status lerc_amd_decode_tiles_device(lerc_amd_context* h, const unsigned char* dArena, const unsigned long long* offsets,
+  const unsigned int* sizes, int nTiles, int nCols, int nRows, unsigned int dataType, void* dTiles)
+{
+  if (!h || !dArena || !offsets || !sizes || !dTiles || dataType >= DT_Undefined || nCols <= 0 || nRows <= 0 || nTiles <= 0) return kWrongParam;
+  if (!dimsOk(1, nCols, nRows, (size_t)dtSize((int)dataType))) return kDimsTooLarge;
+  TilesDecodeRequest rq;
+  rq.dArena = dArena; rq.hOffsets = offsets; rq.hSizes = sizes; rq.dt = (int)dataType; rq.nCols = nCols; rq.nRows = nRows; rq.nTiles = nTiles;
+  rq.dOut = dTiles;
+  return decodeTilesDevice(h->ctx, rq);
+}
+
 void lerc_amd_profile_enable(lerc_amd_context* h, int on) { if (h) h->ctx.profEnable(on != 0); }
 
 int lerc_amd_profile_read(lerc_amd_context* h, char* buf, int cap, int reset)

@@ -108,6 +108,26 @@ struct EncodeRequest
 // returns an ErrCode; numBytesNeeded is always the exact blob size on kOk
 u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32& numBytesWritten);
 
+// nTiles rasters of one shape, contiguous on the device, each to become (or coming from) its own blob in an arena
+struct TilesEncodeRequest
+{
+  const void* dData = nullptr;        // device: [nTiles][nRows][nCols]
+  int dt = 0, nCols = 0, nRows = 0, nTiles = 0;
+  double maxZErr = 0;
+  u8* dArena = nullptr;               // device
+  u64 arenaCapacity = 0;
+  u64* hOffsets = nullptr;            // host [nTiles]: where tile t's blob starts in the arena (16-byte aligned)
+  u32* hSizes = nullptr;              // host [nTiles]
+};
+struct TilesDecodeRequest
+{
+  const u8* dArena = nullptr;         // device
+  const u64* hOffsets = nullptr;      // host [nTiles]
+  const u32* hSizes = nullptr;        // host [nTiles]
+  int dt = 0, nCols = 0, nRows = 0, nTiles = 0;
+  void* dOut = nullptr;               // device: [nTiles][nRows][nCols]
+};
+
 struct DecodeRequest
 {
   const u8* hBlob = nullptr;          // host copy of the blob (may be nullptr when only dBlob is known)
@@ -116,8 +136,11 @@ struct DecodeRequest
   int dt = DT_Undefined, nDepth = 1, nCols = 0, nRows = 0, nBands = 1, nMasks = 0;
   void* dOut = nullptr;               // device: decoded pixels
   u8* dValidBytes = nullptr;          // device: nMasks byte masks, or nullptr
+  bool noStreaming = false;            // go straight to the general kernels (a batch has already tried the streaming ones)
 };
 u32 decodeDevice(Context& ctx, const DecodeRequest& rq);
+u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed);
+u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq);
 
 // header-only queries (host)
 struct BlobInfo

@@ -74,42 +74,56 @@ bool readBandHeader(const BlobReader& rd, u64 off, BandDesc& b)
 static const size_t kCellParams = 0, kCellFallback = 128, kCellBytes = 192;
 static_assert(sizeof(FastDecodeParams) <= 128, "cell layout");
 
-static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven)
+static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven, u32 nTiles = 1)
 {
   const FastWalkPlan wp = makeFastWalkPlan(nRows, nCols, sizeGiven);
-  return (size_t)wp.nChunks * ((size_t)kFastListCap * 8 + kFastSubPerChunk * 8 + 64) + (size_t)wp.chainCap * sizeof(FastChain)
-    + (size_t)wp.nBlocks * 4 + (size_t)(wp.nBlocks / kFastBlocksPerWG) * 16 + (1u << 16);
+  const size_t perTile = (size_t)wp.nChunks * ((size_t)kFastListCap * 8 + kFastSubPerChunk * 8 + 64) + (size_t)wp.chainCap * sizeof(FastChain)
+    + (size_t)wp.nBlocks * 4 + (size_t)(wp.nBlocks / kFastBlocksPerWG) * 16 + 4096;
+  return perTile * nTiles + (1u << 16);
 }
 
-// enqueues header check, discovery and decode of one band; nothing is read back here
-static bool launchFastBand(Context& ctx, int dt, int nRows, int nCols, const u8* dBand, u32 sizeGiven, void* dOutBand,
-                           DeviceStatus* dStatus, u8* dCell, bool clearCells)
+// Enqueues header check, discovery and decode of nTiles blobs (one band: nTiles == 1, dTileOffset == nullptr);
+// nothing is read back here.  dParams [nTiles] and dFallback [4 * nTiles] receive the verdicts.
+static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8* dBlobs, u32 sizeBound, u32 nTiles, const u64* dTileOffset,
+                            const u32* dTileSize, void* dOut, DeviceStatus* dStatus, FastDecodeParams* dParams, u32* dFallback,
+                            bool clearCells)
 {
   hipStream_t st = ctx.activeStream();
-  const FastWalkPlan fwp = makeFastWalkPlan(nRows, nCols, sizeGiven);
+  const FastWalkPlan fwp = makeFastWalkPlan(nRows, nCols, sizeBound);
+  const size_t nT = nTiles, sChunk = fastChunkStride(fwp.nChunks);
+  FastDecodeBatch tb;
+  tb.nTiles = nTiles; tb.nChunks = fwp.nChunks; tb.nBlocks = fwp.nBlocks; tb.chainCap = fwp.chainCap;
+  tb.tileElems = (u64)nRows * (u64)nCols; tb.tileOffset = dTileOffset; tb.tileSize = dTileSize;
   FastDecodeBuffers fbuf;
-  fbuf.chunkListN = ctx.allocT<u32>(fwp.nChunks + 4);
-  fbuf.chunkList = ctx.allocT<u64>((size_t)fwp.nChunks * kFastListCap + 4);
-  fbuf.chains = ctx.allocT<FastChain>((size_t)fwp.chainCap + 4);
-  fbuf.chainCount = ctx.allocT<u32>(fwp.nChunks / kFastCandChunks + 4);
-  fbuf.chunkEntry = ctx.allocT<u32>(fwp.nChunks + 4);
-  fbuf.chunkCount = ctx.allocT<u32>(fwp.nChunks + 4);
-  fbuf.subEntry = ctx.allocT<u32>((size_t)fwp.nChunks * kFastSubPerChunk + 4);
-  fbuf.subIndex = ctx.allocT<u32>((size_t)fwp.nChunks * kFastSubPerChunk + 4);
-  fbuf.blockOff = ctx.allocT<u32>((size_t)fwp.nBlocks + 4);
-  fbuf.params = reinterpret_cast<FastDecodeParams*>(dCell + kCellParams);
-  fbuf.fallback = reinterpret_cast<u32*>(dCell + kCellFallback);
+  fbuf.chunkListN = ctx.allocT<u32>(nT * sChunk);
+  fbuf.chunkList = ctx.allocT<u64>(nT * fwp.nChunks * kFastListCap + 4);
+  fbuf.chains = ctx.allocT<FastChain>(nT * fwp.chainCap + 4);
+  fbuf.chainCount = ctx.allocT<u32>(nT * ((fwp.nChunks + kFastCandChunks - 1) / kFastCandChunks) + 4);
+  fbuf.chunkEntry = ctx.allocT<u32>(nT * sChunk);
+  fbuf.chunkCount = ctx.allocT<u32>(nT * sChunk);
+  fbuf.subEntry = ctx.allocT<u32>(nT * fwp.nChunks * kFastSubPerChunk + 4);
+  fbuf.subIndex = ctx.allocT<u32>(nT * fwp.nChunks * kFastSubPerChunk + 4);
+  fbuf.blockOff = ctx.allocT<u32>(nT * ((size_t)fwp.nBlocks + 4));
+  fbuf.params = dParams;
+  fbuf.fallback = dFallback;
   fbuf.clearCells = clearCells;
-  fbuf.wgFletcher = ctx.allocT<u64>(2 * (size_t)(fwp.nBlocks / kFastBlocksPerWG) + 4);
+  fbuf.wgFletcher = ctx.allocT<u64>(2 * nT * (fwp.nBlocks / kFastBlocksPerWG) + 4);
   if (!fbuf.chunkListN || !fbuf.chunkList || !fbuf.chains || !fbuf.chainCount || !fbuf.chunkEntry || !fbuf.chunkCount
     || !fbuf.subEntry || !fbuf.subIndex || !fbuf.blockOff || !fbuf.wgFletcher) return false;
   static const char* kStage[kFastDecodeStages] = { "fast_candidates", "fast_chains", "fast_resolve", "fast_emit_offsets", "fast_decode" };
   for (int stage = 0; stage < kFastDecodeStages; stage++)
   {
     ProfScope ps(ctx, kStage[stage]);
-    launchFastDecode(stage, dt, nRows, nCols, fwp, dBand, sizeGiven, fbuf, dOutBand, dStatus, st);
+    launchFastDecode(stage, dt, nRows, nCols, tb, dBlobs, sizeBound, fbuf, dOut, dStatus, st);
   }
   return true;
+}
+
+static bool launchFastBand(Context& ctx, int dt, int nRows, int nCols, const u8* dBand, u32 sizeGiven, void* dOutBand,
+                           DeviceStatus* dStatus, u8* dCell, bool clearCells)
+{
+  return launchFastBands(ctx, dt, nRows, nCols, dBand, sizeGiven, 1, nullptr, nullptr, dOutBand, dStatus,
+                         reinterpret_cast<FastDecodeParams*>(dCell + kCellParams), reinterpret_cast<u32*>(dCell + kCellFallback), clearCells);
 }
 
 // what the host makes of a band's cell after the sync: 0 = decoded and checksum good, else the reason bits
@@ -488,15 +502,107 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
 u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
 {
   bool handled = false;
-  const u32 src = decodeSpeculative(ctx, rq, handled);
-  if (src != kOk) return src;
-  if (handled) { ctx.pathCount[2]++; return kOk; }
+  if (!rq.noStreaming)
+  {
+    const u32 src = decodeSpeculative(ctx, rq, handled);
+    if (src != kOk) return src;
+    if (handled) { ctx.pathCount[2]++; return kOk; }
+  }
   bool fellBack = false;
-  u32 rc = decodeImpl(ctx, rq, true, fellBack);
+  u32 rc = decodeImpl(ctx, rq, !rq.noStreaming, fellBack);
   const bool repeated = (rc == kOk && fellBack);
   if (repeated) rc = decodeImpl(ctx, rq, false, fellBack);
   if (rc == kOk) ctx.pathCount[(repeated || !ctx.lastDecodeStreamed) ? 3 : 2]++;
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A mosaic's worth of independent blobs (one per tile, all of one shape and type) in one call.  Blobs the
+// streaming kernels refuse (masked, constant, other shapes, damaged ...) are decoded one by one afterwards, which
+// also produces the exact status for a bad one.
+// ------------------------------------------------------------------------------------------------
+u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
+{
+  if (!rq.dArena || !rq.hOffsets || !rq.hSizes || !rq.dOut || rq.nTiles <= 0 || rq.nRows <= 0 || rq.nCols <= 0 || rq.dt < 0 || rq.dt > DT_Double)
+    return kWrongParam;
+  const int tbytes = dtSize(rq.dt);
+  const u64 tileElems = (u64)rq.nRows * (u64)rq.nCols;
+  auto decodeOne = [&](int t) -> u32
+  {
+    DecodeRequest one;
+    one.dBlob = rq.dArena + rq.hOffsets[t]; one.blobSize = rq.hSizes[t]; one.dt = rq.dt; one.nDepth = 1; one.nCols = rq.nCols;
+    one.nRows = rq.nRows; one.nBands = 1; one.nMasks = 0; one.dValidBytes = nullptr;
+    one.dOut = (u8*)rq.dOut + (size_t)t * tileElems * tbytes;
+    one.noStreaming = true;    // it has just been tried
+    return decodeDevice(ctx, one);
+  };
+  bool fastOk = fastDecodeEligible(rq.dt, 6, 8, rq.nRows, rq.nCols, 1, true) && ((uintptr_t)rq.dArena & 15) == 0
+    && ((uintptr_t)rq.dOut & 15) == 0 && (tileElems * tbytes) % 16 == 0;
+  u32 maxSize = 0;
+  for (int t = 0; t < rq.nTiles; t++)
+  {
+    if (rq.hOffsets[t] % 16 != 0 || rq.hSizes[t] < 70) fastOk = false;
+    maxSize = std::max(maxSize, rq.hSizes[t]);
+  }
+  if (!fastOk)
+  {
+    for (int t = 0; t < rq.nTiles; t++) { const u32 rc = decodeOne(t); if (rc != kOk) return rc; }
+    return kOk;
+  }
+
+  hipStream_t st = ctx.activeStream();
+  const size_t perTile = fastBandWorkspace(rq.nRows, rq.nCols, maxSize, 1) - (1u << 16) + sizeof(FastDecodeParams) + 64;
+  const int maxBatch = (int)std::max<size_t>(1, std::min<size_t>((size_t)rq.nTiles, ((size_t)256 << 20) / perTile));
+  std::vector<int> redo;
+  for (int t0 = 0; t0 < rq.nTiles; t0 += maxBatch)
+  {
+    const int n = std::min(maxBatch, rq.nTiles - t0);
+    if (!ctx.reserve(fastBandWorkspace(rq.nRows, rq.nCols, maxSize, (u32)n) + (size_t)n * (sizeof(FastDecodeParams) + 64) + 8192)) return kFailed;
+    // verdict cells [status 64][params n][fallback 16 n], then the offsets / sizes the kernels index by tile
+    const size_t cellsBytes = 64 + (size_t)n * (sizeof(FastDecodeParams) + 16);
+    u8* dCells = ctx.allocT<u8>(cellsBytes);
+    u64* dOff = ctx.allocT<u64>((size_t)n + 1);
+    u32* dSize = ctx.allocT<u32>((size_t)n + 1);
+    u8* pin = (u8*)ctx.pinned(std::max(cellsBytes, (size_t)n * 12 + 64));
+    if (!dCells || !dOff || !dSize || !pin) return kFailed;
+    u64* hOff = reinterpret_cast<u64*>(pin);
+    u32* hSize = reinterpret_cast<u32*>(pin + (size_t)n * 8);
+    for (int i = 0; i < n; i++) { hOff[i] = rq.hOffsets[t0 + i]; hSize[i] = rq.hSizes[t0 + i]; }
+    hipMemcpyAsync(dOff, hOff, (size_t)n * 8, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(dSize, hSize, (size_t)n * 4, hipMemcpyHostToDevice, st);
+    if (!ctx.sync()) return kFailed;    // the pinned mirror is reused for the read-back below
+    DeviceStatus* dStatus = reinterpret_cast<DeviceStatus*>(dCells);
+    FastDecodeParams* dParams = reinterpret_cast<FastDecodeParams*>(dCells + 64);
+    u32* dFallback = reinterpret_cast<u32*>(dCells + 64 + (size_t)n * sizeof(FastDecodeParams));
+    if (!launchFastBands(ctx, rq.dt, rq.nRows, rq.nCols, rq.dArena, maxSize, (u32)n, dOff, dSize,
+                         (u8*)rq.dOut + (size_t)t0 * tileElems * tbytes, dStatus, dParams, dFallback, true))
+      return kFailed;
+    hipMemcpyAsync(pin, dCells, cellsBytes, hipMemcpyDeviceToHost, st);
+    if (!ctx.sync()) return kFailed;
+    if (ctx.profOn()) ctx.profCollect();
+    const FastDecodeParams* hp = reinterpret_cast<const FastDecodeParams*>(pin + 64);
+    const u32* hfb = reinterpret_cast<const u32*>(pin + 64 + (size_t)n * sizeof(FastDecodeParams));
+    const DeviceStatus hs = *reinterpret_cast<const DeviceStatus*>(pin);
+    redo.clear();
+    for (int i = 0; i < n; i++)
+    {
+      const bool good = hp[i].ok && !hfb[4 * i] && hp[i].checksumOk && !hs.error;
+      if (good) ctx.pathCount[2]++;
+      else
+      {
+        if (redo.empty())
+        {
+          char msg[160];
+          snprintf(msg, sizeof(msg), "tile %d of the batch went to the general path (header ok %u, reason bits 0x%x, checksum ok %u, kernel status %u)",
+                   t0 + i, hp[i].ok, hfb[4 * i], hp[i].checksumOk, hs.error);
+          ctx.lastNote = msg;
+        }
+        redo.push_back(t0 + i);
+      }
+    }
+    for (int t : redo) { const u32 rc = decodeOne(t); if (rc != kOk) return rc; }    // (reuses the workspace: the batch is done with it)
+  }
+  return kOk;
 }
 
 }    // namespace lerc

@@ -374,6 +374,80 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   return kOk;
 }
 
+// ------------------------------------------------------------------------------------------------
+// streaming kernels: buffers + launches for nTiles rasters of one shape (a single raster is nTiles == 1)
+// ------------------------------------------------------------------------------------------------
+struct FastEncodeLaunch
+{
+  FastEncodeBuffers fb;
+  FastBatch batch;
+  BandParams bp;
+  u32 cand;
+  double maxZErr;
+};
+
+static size_t fastEncodeWorkspace(int nRows, int nCols, u32 nTiles)
+{
+  const size_t nWG = fastEncodeNumWG(nRows, nCols);
+  return (size_t)nTiles * (nWG * (kFastBlocksPerWG * sizeof(FastBlockDesc) + 64) + 16 * 9 * 8 + kFastPrefixStage + sizeof(FastEncodeResult) + 256)
+    + 65536;
+}
+
+static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double maxZErr, u32 nTiles, u64 tileElems, bool arena,
+                              FastEncodeLaunch& fl)
+{
+  const u32 nWG = fastEncodeNumWG(nRows, nCols);
+  const bool isFlt = dt >= DT_Float;
+  const size_t nT = nTiles;
+  FastEncodeBuffers& fb = fl.fb;
+  fl.batch.nTiles = nTiles; fl.batch.nWG = nWG; fl.batch.tileElems = tileElems;
+  fl.batch.nRaiseSets = (nTiles > 1) ? 1u : 16u;    // a batch has tiles enough to fill the chip
+  fb.desc = ctx.allocT<FastBlockDesc>(nT * nWG * kFastBlocksPerWG);
+  fb.wgSize = ctx.allocT<u32>(nT * fastWgStride(nWG) + 4);
+  fb.wgBase = ctx.allocT<u32>(nT * fastWgStride(nWG) + 4);
+  fb.wgMinKey = ctx.allocT<u64>(nT * nWG + 4);
+  fb.wgMaxKey = ctx.allocT<u64>(nT * nWG + 4);
+  fb.wgFlags = ctx.allocT<u32>(nT * nWG + 4);
+  fb.wgFletcher = ctx.allocT<u64>(2 * nT * nWG + 4);
+  fb.result = ctx.allocT<FastEncodeResult>(nT);
+  fb.prefixStage = ctx.allocT<u8>(nT * kFastPrefixStage);
+  fb.tileOffset = arena ? ctx.allocT<u64>(nT + 1) : nullptr;
+  double* dRow0Raise = ctx.allocT<double>(nT * fl.batch.nRaiseSets * 9);
+  if (!fb.desc || !fb.wgSize || !fb.wgBase || !fb.wgMinKey || !fb.wgMaxKey || !fb.wgFlags || !fb.wgFletcher || !fb.result
+    || !fb.prefixStage || (arena && !fb.tileOffset) || !dRow0Raise)
+    return false;
+  fl.cand = 0;
+  fb.row0RaiseErr = nullptr;
+  if (isFlt)
+  {
+    static const double errCand[9] = { 1, 0.5, 0.1, 0.05, 0.01, 0.005, 0.001, 0.0005, 0.0001 };
+    for (int c = 0; c < 9; c++) if (errCand[c] / 2 > maxZErr) fl.cand |= 1u << c;
+    if (fl.cand) fb.row0RaiseErr = dRow0Raise;    // filled by the prepare kernel
+  }
+  BandParams& bp = fl.bp;
+  memset(&bp, 0, sizeof(bp));
+  bp.nRows = nRows; bp.nCols = nCols; bp.nDepth = 1; bp.dt = dt; bp.version = kCodecVersion;
+  bp.mb = 8; bp.nTV = nRows / 8; bp.nTH = nCols / 8;
+  bp.allValid = 1;
+  bp.maxQ = maxValToQuantize(dt);
+  bp.maxZErr = isFlt ? maxZErr : std::max(0.5, floor(maxZErr));
+  bp.scale = 1 / (2 * bp.maxZErr);
+  bp.invScale = 2 * bp.maxZErr;
+  bp.intLossless = (!isFlt && bp.maxZErr == 0.5) ? 1 : 0;
+  fl.maxZErr = maxZErr;
+  return true;
+}
+
+static void runFastEncode(Context& ctx, const FastEncodeLaunch& fl, const void* dData, u8* dOut, u64 capacity, u64 arenaBase)
+{
+  static const char* kStage[4] = { "fast_stats_sizes", "fast_scan_decide", "fast_pack", "fast_checksum" };
+  for (int stage = 0; stage < 4; stage++)
+  {
+    ProfScope ps(ctx, kStage[stage]);
+    launchFastEncode(stage, fl.bp, fl.maxZErr, fl.cand, dData, dOut, capacity, arenaBase, fl.fb, fl.batch, ctx.activeStream());
+  }
+}
+
 u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32& numBytesWritten)
 {
   numBytesNeeded = numBytesWritten = 0;
@@ -387,7 +461,8 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   const bool fastOk = rq.nBands == 1 && rq.dOut && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
     && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, rq.nDepth, rq.nMasks > 0, rq.maxZErr);
   const u32 nWG = fastOk ? fastEncodeNumWG(rq.nRows, rq.nCols) : 0;
-  need += (size_t)nWG * (kFastBlocksPerWG * sizeof(FastBlockDesc) + 16) + 16384;
+  need += fastOk ? fastEncodeWorkspace(rq.nRows, rq.nCols, 1) : 0;
+  (void)nWG;
   if (!ctx.reserve(need)) return kFailed;
   (void)tb;
 
@@ -397,47 +472,13 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   if (fastOk)
   {
     hipStream_t st = ctx.activeStream();
-    const bool isFlt = rq.dt >= DT_Float;
-    FastEncodeBuffers fb;
-    fb.desc = ctx.allocT<FastBlockDesc>((size_t)nWG * kFastBlocksPerWG);
-    fb.wgSize = ctx.allocT<u32>(nWG + 4);
-    fb.wgBase = ctx.allocT<u32>(nWG + 4);
-    fb.wgMinKey = ctx.allocT<u64>(nWG + 4);
-    fb.wgMaxKey = ctx.allocT<u64>(nWG + 4);
-    fb.wgFlags = ctx.allocT<u32>(nWG + 4);
-    fb.wgFletcher = ctx.allocT<u64>(2 * (size_t)nWG + 4);
-    fb.result = ctx.allocT<FastEncodeResult>(1);
-    double* dRow0Raise = ctx.allocT<double>(kFastRow0WG * 9);
-    if (!fb.desc || !fb.wgSize || !fb.wgBase || !fb.wgMinKey || !fb.wgMaxKey || !fb.wgFlags || !fb.wgFletcher || !fb.result || !dRow0Raise)
-      return kFailed;
-    u32 cand = 0;
-    fb.row0RaiseErr = nullptr;
-    if (isFlt)
-    {
-      static const double errCand[9] = { 1, 0.5, 0.1, 0.05, 0.01, 0.005, 0.001, 0.0005, 0.0001 };
-      for (int c = 0; c < 9; c++) if (errCand[c] / 2 > rq.maxZErr) cand |= 1u << c;
-      if (cand) fb.row0RaiseErr = dRow0Raise;    // filled by the prepare kernel
-    }
-    BandParams bp;
-    memset(&bp, 0, sizeof(bp));
-    bp.nRows = rq.nRows; bp.nCols = rq.nCols; bp.nDepth = 1; bp.dt = rq.dt; bp.version = kCodecVersion;
-    bp.mb = 8; bp.nTV = rq.nRows / 8; bp.nTH = rq.nCols / 8;
-    bp.allValid = 1;
-    bp.maxQ = maxValToQuantize(rq.dt);
-    bp.maxZErr = isFlt ? rq.maxZErr : std::max(0.5, floor(rq.maxZErr));
-    bp.scale = 1 / (2 * bp.maxZErr);
-    bp.invScale = 2 * bp.maxZErr;
-    bp.intLossless = (!isFlt && bp.maxZErr == 0.5) ? 1 : 0;
-    static const char* kStage[4] = { "fast_stats_sizes", "fast_scan_decide", "fast_pack", "fast_checksum" };
-    for (int stage = 0; stage < 4; stage++)
-    {
-      ProfScope ps(ctx, kStage[stage]);
-      launchFastEncode(stage, bp, rq.maxZErr, cand, rq.dData, rq.dOut, rq.outCapacity, fb, st);
-    }
+    FastEncodeLaunch fl;
+    if (!prepareFastEncode(ctx, rq.dt, rq.nRows, rq.nCols, rq.maxZErr, 1, 0, false, fl)) return kFailed;
+    runFastEncode(ctx, fl, rq.dData, rq.dOut, rq.outCapacity, 0);
     FastEncodeResult* pinRes = (FastEncodeResult*)ctx.pinned(sizeof(FastEncodeResult));
     if (!pinRes) return kFailed;
     FastEncodeResult& hres = *pinRes;
-    hipMemcpyAsync(&hres, fb.result, sizeof(hres), hipMemcpyDeviceToHost, st);
+    hipMemcpyAsync(&hres, fl.fb.result, sizeof(hres), hipMemcpyDeviceToHost, st);
     if (!ctx.sync()) return kFailed;
     if (ctx.profOn()) ctx.profCollect();
     if (!hres.redo)
@@ -472,6 +513,89 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   }
   numBytesNeeded = total;
   if (rq.dOut) numBytesWritten = total;
+  return kOk;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A mosaic's worth of independent tiles in one call: every tile becomes its own blob (own header, ranges,
+// checksum), byte for byte what encodeDevice() makes of it; the blobs go into one arena at 16-byte aligned offsets.
+// Tiles the streaming kernels hand back (constant tiles, NaNs, ...) are encoded one by one behind their sub-batch.
+// ------------------------------------------------------------------------------------------------
+u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed)
+{
+  arenaUsed = 0;
+  if (!rq.dData || !rq.dArena || !rq.hOffsets || !rq.hSizes || rq.nTiles <= 0 || rq.nRows <= 0 || rq.nCols <= 0 || rq.dt < 0 || rq.dt > DT_Double
+    || rq.maxZErr < 0)
+    return kWrongParam;
+  const int tb = dtSize(rq.dt);
+  const u64 tileElems = (u64)rq.nRows * (u64)rq.nCols;
+  const bool fastOk = rq.maxZErr != 777 && ((uintptr_t)rq.dArena & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0 && (tileElems * tb) % 16 == 0
+    && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, 1, false, rq.maxZErr);
+  u64 end = 0;    // arena bytes in use
+
+  auto encodeOne = [&](int t) -> u32
+  {
+    end = (end + 15) & ~15ull;
+    EncodeRequest one;
+    one.dData = (const u8*)rq.dData + (size_t)t * tileElems * tb;
+    one.dt = rq.dt; one.nDepth = 1; one.nCols = rq.nCols; one.nRows = rq.nRows; one.nBands = 1; one.nMasks = 0; one.dValidBytes = nullptr;
+    one.maxZErr = rq.maxZErr;
+    one.dOut = rq.dArena + end;
+    one.outCapacity = (u32)std::min<u64>(rq.arenaCapacity > end ? rq.arenaCapacity - end : 0, 0xFFFFFFFFull);
+    u32 needed = 0, written = 0;
+    const u32 rc = encodeDevice(ctx, one, needed, written);
+    if (rc != kOk) return rc;
+    rq.hOffsets[t] = end; rq.hSizes[t] = written;
+    end += written;
+    return kOk;
+  };
+
+  if (!fastOk)
+  {
+    for (int t = 0; t < rq.nTiles; t++) { const u32 rc = encodeOne(t); if (rc != kOk) return rc; }
+    arenaUsed = end;
+    return kOk;
+  }
+
+  // sub-batches keep the workspace bounded (block descriptors are 1/16 of the pixels)
+  const size_t perTile = fastEncodeWorkspace(rq.nRows, rq.nCols, 1) - 65536;
+  const int maxBatch = (int)std::max<size_t>(1, std::min<size_t>((size_t)rq.nTiles, ((size_t)256 << 20) / perTile));
+  hipStream_t st = ctx.activeStream();
+  std::vector<int> redo;
+  for (int t0 = 0; t0 < rq.nTiles; t0 += maxBatch)
+  {
+    const int n = std::min(maxBatch, rq.nTiles - t0);
+    if (!ctx.reserve(fastEncodeWorkspace(rq.nRows, rq.nCols, (u32)n))) return kFailed;
+    FastEncodeLaunch fl;
+    if (!prepareFastEncode(ctx, rq.dt, rq.nRows, rq.nCols, rq.maxZErr, (u32)n, tileElems, true, fl)) return kFailed;
+    end = (end + 15) & ~15ull;
+    runFastEncode(ctx, fl, (const u8*)rq.dData + (size_t)t0 * tileElems * tb, rq.dArena, rq.arenaCapacity, end);
+    const size_t resBytes = (size_t)n * sizeof(FastEncodeResult), offBytes = ((size_t)n + 1) * 8;
+    u8* pin = (u8*)ctx.pinned(resBytes + offBytes);
+    if (!pin) return kFailed;
+    hipMemcpyAsync(pin, fl.fb.result, resBytes, hipMemcpyDeviceToHost, st);
+    hipMemcpyAsync(pin + resBytes, fl.fb.tileOffset, offBytes, hipMemcpyDeviceToHost, st);
+    if (!ctx.sync()) return kFailed;
+    if (ctx.profOn()) ctx.profCollect();
+    const FastEncodeResult* res = reinterpret_cast<const FastEncodeResult*>(pin);
+    const u64* off = reinterpret_cast<const u64*>(pin + resBytes);
+    redo.clear();
+    for (int i = 0; i < n; i++)
+    {
+      if (res[i].redo)
+      {
+        if (res[i].redoReason == 64u) return kBufferTooSmall;    // the arena is full
+        redo.push_back(t0 + i);
+        continue;
+      }
+      rq.hOffsets[t0 + i] = off[i];
+      rq.hSizes[t0 + i] = res[i].blobSize;
+      ctx.pathCount[0]++;
+    }
+    end = off[n];
+    for (int t : redo) { const u32 rc = encodeOne(t); if (rc != kOk) return rc; }    // (reuses the workspace: the batch is done with it)
+  }
+  arenaUsed = end;
   return kOk;
 }
 

@@ -30,24 +30,39 @@ struct FastBlockDesc      // what pass 1 decided for one block; pass 2 packs fro
   u32 pad;
 };
 
+// A launch covers nTiles independent rasters of one shape (blockIdx.y = tile; a single raster is nTiles == 1).
+// Every per-raster array below then holds nTiles consecutive sets.
+struct FastBatch
+{
+  u32 nTiles;
+  u32 nWG;             // workgroups (64 blocks each) per tile
+  u64 tileElems;       // pixels from one tile to the next
+  u32 nRaiseSets;      // workgroups per tile that look at the first raster row
+};
+LERC_HD u32 fastWgStride(u32 nWG) { return (nWG + 7u) & ~3u; }    // elements from one tile's wgSize / wgBase set to the next (16-byte aligned)
+static const int kFastPrefixStage = 128;   // bytes reserved per tile for header + mask count + ranges + mode byte
+
 struct FastEncodeBuffers
 {
   FastBlockDesc* desc; // [nWG * 64]
-  u32* wgSize;         // [nWG] bytes of each workgroup's 64 blocks
-  u32* wgBase;         // [nWG + 1] exclusive scan
+  u32* wgSize;         // [nWG + 4] bytes of each workgroup's 64 blocks
+  u32* wgBase;         // [nWG + 4] exclusive scan, [nWG] = total
   u64* wgMinKey;       // [nWG] order-preserving key of each workgroup's smallest / largest pixel
   u64* wgMaxKey;       // [nWG]
   u32* wgFlags;        // [nWG] bit 0 NaN seen, bit 1 non-integer value seen
   u64* wgFletcher;     // [2 * nWG] Fletcher partial sums (mod 65535) of the bytes each workgroup wrote
-  double* row0RaiseErr;    // [kFastRow0WG * 9] TryRaiseMaxZError rounding errors of the first row, one set per workgroup (float types), or nullptr
+  double* row0RaiseErr;    // [nRaiseSets * 9] TryRaiseMaxZError rounding errors of the first row, one set per workgroup (float types), or nullptr
+  u8* prefixStage;     // [kFastPrefixStage] the bytes in front of the first block, written by the decide step, copied by the pack step
+  u64* tileOffset;     // [nTiles + 1] where each tile's blob starts in the output arena; nullptr: a single raster at offset 0
   FastEncodeResult* result;
 };
 
 bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, double maxZErr);
 u32 fastEncodeNumWG(int nRows, int nCols);
 // stage 0: statistics + block sizes; 1: scan + decisions + header; 2: pack + Fletcher sums; 3: checksum patch
+// (batches: stage 1 also places the tiles in the arena, from `arenaBase` on; tiles that need the general path take no room)
 void launchFastEncode(int stage, const BandParams& assumed, double requestedMaxZErr, u32 raiseCandidates, const void* data, u8* out,
-                      u32 outCapacity, const FastEncodeBuffers& b, hipStream_t st);
+                      u64 outCapacity, u64 arenaBase, const FastEncodeBuffers& b, const FastBatch& batch, hipStream_t st);
 
 // ---- where a workgroup's 64 consecutive blocks lie in the raster -----------------------------------------------
 // Block k of the stream is block (k / nTH, k % nTH) of the raster (nTH = nCols / 8 blocks per block row).  The streaming
@@ -128,16 +143,28 @@ struct FastDecodeBuffers
   u32* subIndex;       // [nChunks * kFastSubPerChunk] index of that block within the chunk
   u32* blockOff;       // [nBlocks + 1]
   u64* wgFletcher;     // [2 * nBlocks / 64] Fletcher partial sums (mod 65535) of the bytes each decode workgroup staged
-  FastDecodeParams* params;
-  u32* fallback;       // != 0: the general path must redo the band
+  FastDecodeParams* params;   // [nTiles]
+  u32* fallback;       // [4 * nTiles] [0] != 0: the general path must redo the band
   bool clearCells;     // the header kernel zeroes *status and fallback[0..3] itself (no memset before the launches)
 };
+
+// A launch covers nTiles independent blobs of rasters of one shape (blockIdx.y = tile; one raster is nTiles == 1).
+// Every buffer above then holds nTiles consecutive slices, sized by the bounds below.
+struct FastDecodeBatch
+{
+  u32 nTiles;
+  u32 nChunks, nBlocks, chainCap;    // per tile; nChunks / chainCap are upper bounds (largest blob of the batch)
+  u64 tileElems;                     // pixels from one tile's output to the next
+  const u64* tileOffset;             // device [nTiles]: start of each blob in the arena; nullptr: `blob` itself
+  const u32* tileSize;               // device [nTiles]
+};
+LERC_HD u32 fastChunkStride(u32 nChunks) { return nChunks + 4u; }    // elements per tile of the per-chunk u32 arrays
 
 bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid);
 FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven);
 static const int kFastDecodeStages = 5;
 // stage 0: header + candidates; 1: chains; 2: resolve; 3: block offsets; 4: decode + checksum
-void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastWalkPlan& wp, const u8* blob, u32 sizeGiven,
+void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
                       const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st);
 
 }    // namespace lerc

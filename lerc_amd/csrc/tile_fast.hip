@@ -145,8 +145,13 @@ __device__ __forceinline__ u32 packDesc(const Plan& pl, int nb) { return (u32)pl
 template<class T, bool WIDE>
 __global__ void __launch_bounds__(256)
 k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict__ desc, u32* __restrict__ wgSize,
-             u64* __restrict__ wgMinKey, u64* __restrict__ wgMaxKey, u32* __restrict__ wgFlags)
+             u64* __restrict__ wgMinKey, u64* __restrict__ wgMaxKey, u32* __restrict__ wgFlags, FastBatch batch)
 {
+  {
+    const size_t tile = blockIdx.y;    // this tile's slice of every array
+    data += tile * batch.tileElems; desc += tile * batch.nWG * kFastBlocksPerWG; wgSize += tile * fastWgStride(batch.nWG);
+    wgMinKey += tile * batch.nWG; wgMaxKey += tile * batch.nWG; wgFlags += tile * batch.nWG;
+  }
   typedef FastCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
   typedef typename ShflT<T>::type ST;
@@ -271,7 +276,7 @@ __device__ __forceinline__ double keyToDouble(int dt, u64 key, u64& raw)
 __device__ __forceinline__ void
 fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgBase,
            const u64* __restrict__ slotMinKey, const u64* __restrict__ slotMaxKey, const u32* __restrict__ slotFlags,
-           const double* __restrict__ row0RaiseErr, u8* __restrict__ out, u32 outCapacity, FastEncodeResult* res)
+           const double* __restrict__ row0RaiseErr, u32 nRaiseSets, u8* __restrict__ out, u64 outCapacity, FastEncodeResult* res)
 {
   const int lane = laneId();
   const u64 a = waveMin(slotMinKey[lane]), b = waveMax(slotMaxKey[lane]);
@@ -299,7 +304,7 @@ fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u3
       for (int c = 0; c < 9; c++)
       {
         double e = 0;
-        for (u32 w = 0; w < kFastRow0WG; w++) { const double x = row0RaiseErr[w * 9 + c]; e = x > e ? x : e; }
+        for (u32 w = 0; w < nRaiseSets; w++) { const double x = row0RaiseErr[w * 9 + c]; e = x > e ? x : e; }
         if (((raiseCandidates >> c) & 1u) && !(e / fac[c] > requestedMaxZErr / 2)) redo |= kRedoRaise;
       }
     }
@@ -344,11 +349,18 @@ fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u3
 __global__ void __launch_bounds__(1024)
 k_fast_scan_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgSize,
                    u32* __restrict__ wgBase, const u64* __restrict__ wgMinKey, const u64* __restrict__ wgMaxKey,
-                   const u32* __restrict__ wgFlags, const double* __restrict__ row0RaiseErr, u8* __restrict__ out, u32 outCapacity,
-                   FastEncodeResult* res)
+                   const u32* __restrict__ wgFlags, const double* __restrict__ row0RaiseErr, u8* __restrict__ prefixStage, u64 outCapacity,
+                   FastEncodeResult* res, FastBatch batch)
 {
   __shared__ u64 s_min[64], s_max[64];
   __shared__ u32 s_fl[64];
+  {
+    const size_t tile = blockIdx.y;
+    wgSize += tile * fastWgStride(batch.nWG); wgBase += tile * fastWgStride(batch.nWG);
+    wgMinKey += tile * batch.nWG; wgMaxKey += tile * batch.nWG; wgFlags += tile * batch.nWG;
+    if (row0RaiseErr) row0RaiseErr += tile * batch.nRaiseSets * 9;
+    prefixStage += tile * kFastPrefixStage; res += tile;
+  }
   u64 kMin = ~0ull, kMax = 0ull;
   u32 fl = 0;
   for (u32 i = threadIdx.x; i < nWG; i += 1024u)
@@ -366,7 +378,7 @@ k_fast_scan_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u
   scanSingleWorkgroup(wgSize, wgBase, nWG);
   __syncthreads();
   if (waveId() == 0)
-    fastDecide(p, requestedMaxZErr, raiseCandidates, nWG, wgBase, s_min, s_max, s_fl, row0RaiseErr, out, outCapacity, res);
+    fastDecide(p, requestedMaxZErr, raiseCandidates, nWG, wgBase, s_min, s_max, s_fl, row0RaiseErr, batch.nRaiseSets, prefixStage, outCapacity, res);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -396,8 +408,15 @@ __device__ __forceinline__ void fletcherWord(u32 x, u32 pos, u64& A, u64& B)
 template<class T, bool WIDE>
 __global__ void __launch_bounds__(256)
 k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __restrict__ desc, const u32* __restrict__ wgBase,
-            u8* __restrict__ out, u64* __restrict__ wgFletcher, const FastEncodeResult* __restrict__ res)
+            u8* __restrict__ out, u64* __restrict__ wgFletcher, const FastEncodeResult* __restrict__ res,
+            const u8* __restrict__ prefixStage, const u64* __restrict__ tileOffset, FastBatch batch)
 {
+  {
+    const size_t tile = blockIdx.y;
+    data += tile * batch.tileElems; desc += tile * batch.nWG * kFastBlocksPerWG; wgBase += tile * fastWgStride(batch.nWG);
+    wgFletcher += tile * batch.nWG * 2; res += tile; prefixStage += tile * kFastPrefixStage;
+    if (tileOffset) out += tileOffset[tile];
+  }
   typedef FastCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW, IT = C::IT;
   constexpr int kMaxBlockBytes = 1 + 64 * (int)sizeof(T);
@@ -408,6 +427,8 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
   __shared__ u32 s_bit[kFastBlocksPerWG];    // bit position of each block inside s_out
   __shared__ u64 s_fa[4], s_fb[4];
   if (res->redo) return;
+  // the bytes in front of the first block (header, mask count, ranges, mode byte) come from the decide step
+  if (blockIdx.x == 0 && threadIdx.x < res->prefixLen) out[threadIdx.x] = prefixStage[threadIdx.x];
 
   PROBE_BEGIN;
   const int w = waveId(), lane = laneId();
@@ -590,17 +611,23 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
 }
 
 // checksum = Fletcher32 over blob[14 ..): the prefix bytes written by the decide step + the workgroups' partial sums
-__global__ void __launch_bounds__(1024)
-k_fast_checksum(const u64* __restrict__ wgFletcher, u32 nWG, u8* __restrict__ out, FastEncodeResult* res)
+__global__ void __launch_bounds__(256)
+k_fast_checksum(const u64* __restrict__ wgFletcher, u32 nWG, u8* __restrict__ out, FastEncodeResult* res,
+                const u8* __restrict__ prefixStage, const u64* __restrict__ tileOffset, FastBatch batch)
 {
-  __shared__ u64 s_a[16], s_b[16];
+  __shared__ u64 s_a[4], s_b[4];
+  {
+    const size_t tile = blockIdx.y;
+    wgFletcher += tile * batch.nWG * 2; res += tile; prefixStage += tile * kFastPrefixStage;
+    if (tileOffset) out += tileOffset[tile];
+  }
   if (res->redo) return;
   const int lane = laneId(), w = waveId();
   u64 A = 0, B = 0;
-  for (u32 i = threadIdx.x; i < nWG; i += 1024u) { A += wgFletcher[2 * (size_t)i]; B += wgFletcher[2 * (size_t)i + 1]; }    // each < 65535
-  for (u32 pos = threadIdx.x; pos + 14 < res->prefixLen; pos += 1024u)
+  for (u32 i = threadIdx.x; i < nWG; i += 256u) { A += wgFletcher[2 * (size_t)i]; B += wgFletcher[2 * (size_t)i + 1]; }    // each < 65535
+  for (u32 pos = threadIdx.x; pos + 14 < res->prefixLen; pos += 256u)
   {
-    const u32 cw = (u32)out[14 + pos] << ((pos & 1u) ? 0 : 8);
+    const u32 cw = (u32)prefixStage[14 + pos] << ((pos & 1u) ? 0 : 8);
     A += cw; B += (u64)(pos >> 1) * cw;
   }
   A = waveSum(A % 65535u); B = waveSum(B % 65535u);
@@ -608,7 +635,7 @@ k_fast_checksum(const u64* __restrict__ wgFletcher, u32 nWG, u8* __restrict__ ou
   __syncthreads();
   if (threadIdx.x != 0) return;
   A = 0; B = 0;
-  for (int i = 0; i < 16; i++) { A += s_a[i]; B += s_b[i]; }
+  for (int i = 0; i < 4; i++) { A += s_a[i]; B += s_b[i]; }
   const u32 len = res->blobSize - 14;
   const u64 N = ((u64)len + 1) / 2;
   A %= 65535u; B %= 65535u;
@@ -620,13 +647,46 @@ k_fast_checksum(const u64* __restrict__ wgFletcher, u32 nWG, u8* __restrict__ ou
   res->checksum = cs;
 }
 
+// Batches: where each tile's blob goes in the arena.  One workgroup of 1024 threads; a tile that the general path has
+// to redo takes no room here (the host appends it behind the batch).  Starts are 16-byte aligned.
+__global__ void __launch_bounds__(1024)
+k_fast_tile_offsets(FastEncodeResult* __restrict__ res, u32 nTiles, u64 arenaBase, u64 arenaCapacity, u64* __restrict__ tileOffset)
+{
+  __shared__ u64 s_w[16];
+  const u32 per = (nTiles + 1023u) / 1024u;
+  const u32 begin = min(threadIdx.x * per, nTiles), end = min(begin + per, nTiles);
+  u64 sum = 0;
+  for (u32 t = begin; t < end; t++) sum += res[t].redo ? 0ull : (((u64)res[t].blobSize + 15ull) & ~15ull);
+  u64 inc = sum;
+  const int lane = laneId();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const u64 o = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += o; }
+  if (lane == 63) s_w[waveId()] = inc;
+  __syncthreads();
+  u64 run = arenaBase + inc - sum;
+  for (int i = 0; i < waveId(); i++) run += s_w[i];
+  for (u32 t = begin; t < end; t++)
+  {
+    tileOffset[t] = run;
+    if (!res[t].redo)
+    {
+      const u64 sz = ((u64)res[t].blobSize + 15ull) & ~15ull;
+      if (run + sz > arenaCapacity) { res[t].redo = 1u; res[t].redoReason = kRedoCapacity; }    // does not fit: nothing is written
+      run += sz;
+    }
+  }
+  if (threadIdx.x == 1023) tileOffset[nTiles] = run;
+}
+
 // Before the passes, for float types: look at the first raster row the way
 // Lerc2::TryRaiseMaxZError does (Lerc2.cpp:1245-1290): per candidate factor the largest rounding error, one partial
 // result per workgroup (k_fast_decide folds them).
 template<class T>
 __global__ void __launch_bounds__(256)
-k_fast_prepare(const T* __restrict__ data, int nCols, u32 raiseCand, double* __restrict__ row0Partial)
+k_fast_prepare(const T* __restrict__ data, int nCols, u32 raiseCand, double* __restrict__ row0Partial, FastBatch batch)
 {
+  data += (size_t)blockIdx.y * batch.tileElems;
+  row0Partial += (size_t)blockIdx.y * batch.nRaiseSets * 9;
   __shared__ u64 s_r[4][9];
   const int lane = laneId(), w = waveId();
   double rerr[9];
@@ -677,46 +737,57 @@ bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, 
 u32 fastEncodeNumWG(int nRows, int nCols) { return (u32)(((u64)(nRows / 8) * (u64)(nCols / 8)) / kFastBlocksPerWG); }
 
 template<class T>
-static void launchFastEncodeT(int stage, const BandParams& p, double requested, u32 raiseCand, const void* data, u8* out, u32 cap,
-                              const FastEncodeBuffers& b, hipStream_t st)
+static void launchFastEncodeT(int stage, const BandParams& p, double requested, u32 raiseCand, const void* data, u8* out, u64 cap,
+                              u64 arenaBase, const FastEncodeBuffers& b, const FastBatch& batch, hipStream_t st)
 {
-  const u32 nWG = fastEncodeNumWG(p.nRows, p.nCols);
+  const u32 nWG = batch.nWG, nT = batch.nTiles;
   if (stage == 0)
   {
     if (b.row0RaiseErr)
-      hipLaunchKernelGGL(k_fast_prepare<T>, dim3(kFastRow0WG), dim3(256), 0, st, (const T*)data, p.nCols, raiseCand, b.row0RaiseErr);
+      hipLaunchKernelGGL(k_fast_prepare<T>, dim3(batch.nRaiseSets, nT), dim3(256), 0, st, (const T*)data, p.nCols, raiseCand, b.row0RaiseErr, batch);
     if (p.nTH % 64 == 0)
-      hipLaunchKernelGGL((k_fast_stats<T, true>), dim3(nWG), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.wgMinKey, b.wgMaxKey, b.wgFlags);
+      hipLaunchKernelGGL((k_fast_stats<T, true>), dim3(nWG, nT), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.wgMinKey, b.wgMaxKey,
+                         b.wgFlags, batch);
     else
-      hipLaunchKernelGGL((k_fast_stats<T, false>), dim3(nWG), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.wgMinKey, b.wgMaxKey, b.wgFlags);
+      hipLaunchKernelGGL((k_fast_stats<T, false>), dim3(nWG, nT), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.wgMinKey, b.wgMaxKey,
+                         b.wgFlags, batch);
   }
   else if (stage == 1)
-    hipLaunchKernelGGL(k_fast_scan_decide, dim3(1), dim3(1024), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgSize, b.wgBase,
-                       (const u64*)b.wgMinKey, (const u64*)b.wgMaxKey, (const u32*)b.wgFlags, (const double*)b.row0RaiseErr, out, cap, b.result);
+  {
+    // a tile of a batch may be as large as it likes here; whether the arena holds it is decided by the placement
+    hipLaunchKernelGGL(k_fast_scan_decide, dim3(1, nT), dim3(1024), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgSize, b.wgBase,
+                       (const u64*)b.wgMinKey, (const u64*)b.wgMaxKey, (const u32*)b.wgFlags, (const double*)b.row0RaiseErr, b.prefixStage,
+                       b.tileOffset ? ~0ull : cap, b.result, batch);
+    if (b.tileOffset)
+      hipLaunchKernelGGL(k_fast_tile_offsets, dim3(1), dim3(1024), 0, st, b.result, nT, arenaBase, cap, b.tileOffset);
+  }
   else if (stage == 2)
   {
     if (p.nTH % 64 == 0)
-      hipLaunchKernelGGL((k_fast_pack<T, true>), dim3(nWG), dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc, (const u32*)b.wgBase,
-                         out, b.wgFletcher, (const FastEncodeResult*)b.result);
+      hipLaunchKernelGGL((k_fast_pack<T, true>), dim3(nWG, nT), dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc,
+                         (const u32*)b.wgBase, out, b.wgFletcher, (const FastEncodeResult*)b.result, (const u8*)b.prefixStage,
+                         (const u64*)b.tileOffset, batch);
     else
-      hipLaunchKernelGGL((k_fast_pack<T, false>), dim3(nWG), dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc, (const u32*)b.wgBase,
-                         out, b.wgFletcher, (const FastEncodeResult*)b.result);
+      hipLaunchKernelGGL((k_fast_pack<T, false>), dim3(nWG, nT), dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc,
+                         (const u32*)b.wgBase, out, b.wgFletcher, (const FastEncodeResult*)b.result, (const u8*)b.prefixStage,
+                         (const u64*)b.tileOffset, batch);
   }
   else
-    hipLaunchKernelGGL(k_fast_checksum, dim3(1), dim3(1024), 0, st, (const u64*)b.wgFletcher, nWG, out, b.result);
+    hipLaunchKernelGGL(k_fast_checksum, dim3(1, nT), dim3(256), 0, st, (const u64*)b.wgFletcher, nWG, out, b.result, (const u8*)b.prefixStage,
+                       (const u64*)b.tileOffset, batch);
 }
 
 void launchFastEncode(int stage, const BandParams& assumed, double requestedMaxZErr, u32 raiseCandidates, const void* data, u8* out,
-                      u32 outCapacity, const FastEncodeBuffers& b, hipStream_t st)
+                      u64 outCapacity, u64 arenaBase, const FastEncodeBuffers& b, const FastBatch& batch, hipStream_t st)
 {
   switch (assumed.dt)
   {
-    case DT_Short:  launchFastEncodeT<short>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, b, st); break;
-    case DT_UShort: launchFastEncodeT<unsigned short>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, b, st); break;
-    case DT_Int:    launchFastEncodeT<int>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, b, st); break;
-    case DT_UInt:   launchFastEncodeT<unsigned int>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, b, st); break;
-    case DT_Float:  launchFastEncodeT<float>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, b, st); break;
-    case DT_Double: launchFastEncodeT<double>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, b, st); break;
+    case DT_Short:  launchFastEncodeT<short>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, arenaBase, b, batch, st); break;
+    case DT_UShort: launchFastEncodeT<unsigned short>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, arenaBase, b, batch, st); break;
+    case DT_Int:    launchFastEncodeT<int>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, arenaBase, b, batch, st); break;
+    case DT_UInt:   launchFastEncodeT<unsigned int>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, arenaBase, b, batch, st); break;
+    case DT_Float:  launchFastEncodeT<float>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, arenaBase, b, batch, st); break;
+    case DT_Double: launchFastEncodeT<double>(stage, assumed, requestedMaxZErr, raiseCandidates, data, out, outCapacity, arenaBase, b, batch, st); break;
     default: break;
   }
 }

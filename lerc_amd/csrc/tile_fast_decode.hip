@@ -230,8 +230,8 @@ __device__ __forceinline__ void parseHead(const Head128& h, u32 sizeGiven, int n
 }
 
 template<int DT>
-__global__ void __launch_bounds__(64)
-k_fast_header(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols, FastDecodeParams* __restrict__ P,
+__device__ __forceinline__ void
+fastHeaderBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols, FastDecodeParams* __restrict__ P,
               u32* __restrict__ clearStatus, u32* __restrict__ clearFallback)
 {
   // first kernel of a decode: it also clears the cells the later kernels raise flags in (saves a memset launch)
@@ -304,8 +304,8 @@ __device__ __forceinline__ u32 qSig(u32 e) { return (e >> 25) & 15u; }
 // there and merge into one chain, however short the blocks are -- except the last few, which stop up to kMinSteps - 1
 // blocks further.  Only the head of every chunk is needed for that: window + kMinSteps blocks + one header.
 template<int DT>
-__global__ void __launch_bounds__(256)
-k_fast_candidates(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob,
+__device__ __forceinline__ void
+fastCandidatesBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob,
                   u32* __restrict__ chunkListN, u64* __restrict__ chunkList, FastChain* __restrict__ chains, u32* __restrict__ chainCount,
                   u32* __restrict__ fallback)
 {
@@ -487,7 +487,9 @@ k_fast_candidates(const FastDecodeParams* __restrict__ P, const u8* __restrict__
   __syncthreads();
   if (threadIdx.x < nChunksHere)
   {
-    const bool ok = !over && s_listN[threadIdx.x] <= (u32)kFastListCap && s_listN[threadIdx.x] > 0;
+    // (no survivor at all is fine for the last chunk of a stream when the last block begins before it: k_fast_resolve
+    // tells a chunk without its true entry from an empty one)
+    const bool ok = !over && s_listN[threadIdx.x] <= (u32)kFastListCap;
     chunkListN[c0 + threadIdx.x] = ok ? s_listN[threadIdx.x] : 0u;
     if (!ok) atomicOr(fallback, 1u);
   }
@@ -498,8 +500,8 @@ k_fast_candidates(const FastDecodeParams* __restrict__ P, const u8* __restrict__
 // chains
 // ------------------------------------------------------------------------------------------------
 template<int DT>
-__global__ void __launch_bounds__(256)
-k_fast_chains(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, FastChain* __restrict__ chains,
+__device__ __forceinline__ void
+fastChainsBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, FastChain* __restrict__ chains,
               const u32* __restrict__ chainCount, u32 chainCap)
 {
   const FastDecodeParams hp = *P;
@@ -561,8 +563,8 @@ __device__ __forceinline__ u32 agreedExit(u32 c, const u32* __restrict__ chunkLi
 }
 
 template<int DT>
-__global__ void __launch_bounds__(256)
-k_fast_resolve(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ chunkListN,
+__device__ __forceinline__ void
+fastResolveBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ chunkListN,
                const u64* __restrict__ chunkList, const FastChain* __restrict__ chains, u32* __restrict__ chunkEntry,
                u32* __restrict__ chunkCount, u32* __restrict__ subEntry, u32* __restrict__ subIndex, u32* __restrict__ fallback)
 {
@@ -592,7 +594,10 @@ k_fast_resolve(const FastDecodeParams* __restrict__ P, const u8* __restrict__ bl
   for (int j = 0; j < NS; j++) { pos[j] = kNoOffset; idx[j] = 0; }
   u32 count = 0;
   bool ok = chainIdx != kNoOffset;
-  if (ok)
+  // the last block of the stream may begin before the last chunk and end with it: nothing starts in that chunk
+  const bool emptyTail = e != kNoOffset && e >= min(chunkStart + kFastChunkBytes, blobEnd);
+  if (emptyTail) ok = (e == blobEnd);
+  else if (ok)
   {
     const FastChain ch = chains[chainIdx];
     ok = ch.alive != 0;
@@ -621,15 +626,15 @@ k_fast_resolve(const FastDecodeParams* __restrict__ P, const u8* __restrict__ bl
   if (!ok) { atomicOr(fallback, 2u); count = 0; }
   chunkCount[c] = count;
 #pragma unroll
-  for (int j = 0; j < NS; j++) { subEntry[(size_t)c * NS + j] = ok ? pos[j] : kNoOffset; subIndex[(size_t)c * NS + j] = idx[j]; }
+  for (int j = 0; j < NS; j++) { subEntry[(size_t)c * NS + j] = (ok && !emptyTail) ? pos[j] : kNoOffset; subIndex[(size_t)c * NS + j] = idx[j]; }
 }
 
 // ------------------------------------------------------------------------------------------------
 // block offsets
 // ------------------------------------------------------------------------------------------------
 template<int DT>
-__global__ void __launch_bounds__(256)
-k_fast_emit(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ chunkEntry,
+__device__ __forceinline__ void
+fastEmitBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ chunkEntry,
             const u32* __restrict__ chunkCount, const u32* __restrict__ subEntry, const u32* __restrict__ subIndex,
             u32* __restrict__ blockOff, u32* __restrict__ fallback)
 {
@@ -738,8 +743,8 @@ template<class T> __device__ __forceinline__ T dequant(double offset, u32 q, dou
 }
 
 template<class T, bool WIDE>
-__global__ void __launch_bounds__(256)
-k_fast_decode(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ blockOff,
+__device__ __forceinline__ void
+fastDecodeBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ blockOff,
               T* __restrict__ outPix, u64* __restrict__ wgFletcher, const u32* __restrict__ fallback, DeviceStatus* st)
 {
   const FastDecodeParams hp = *P;
@@ -918,13 +923,15 @@ k_fast_decode(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blo
 
 // folds the workgroups' partial sums and the prefix bytes into the checksum and compares it with the header's
 // (Lerc2.cpp:1037-1064)
-__global__ void __launch_bounds__(1024) k_fast_fletcher_sum(FastDecodeParams* __restrict__ P, const u64* __restrict__ wgFletcher, u32 nWG)
+__device__ __forceinline__ void fastFletcherSumBody(FastDecodeParams* __restrict__ P, const u64* __restrict__ wgFletcher, u32 nWG)
 {
   __shared__ u64 s_a[16], s_b[16];
   if (!P->ok) return;
   u64 A = 0, B = 0;
-  for (u32 i = threadIdx.x; i < nWG; i += 1024u) { A += wgFletcher[2 * (size_t)i]; B += wgFletcher[2 * (size_t)i + 1]; }    // each < 65535
+  for (u32 i = threadIdx.x; i < nWG; i += blockDim.x) { A += wgFletcher[2 * (size_t)i]; B += wgFletcher[2 * (size_t)i + 1]; }    // each < 65535
   A = waveSum(A % 65535u); B = waveSum(B % 65535u);
+  if (threadIdx.x < 16) { s_a[threadIdx.x] = 0; s_b[threadIdx.x] = 0; }
+  __syncthreads();
   if (laneId() == 0) { s_a[waveId()] = A; s_b[waveId()] = B; }
   __syncthreads();
   if (threadIdx.x != 0) return;
@@ -959,56 +966,120 @@ FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven)
   return wp;
 }
 
+// ------------------------------------------------------------------------------------------------
+// kernels: blockIdx.y = tile of a batch (one raster: a batch of 1).  Each tile has its own slice of every buffer.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tileSlice(FastDecodeBuffers& b, const FastDecodeBatch& t, const u8*& blob, u32& sizeGiven)
+{
+  const size_t tile = blockIdx.y;
+  const size_t sChunk = fastChunkStride(t.nChunks);
+  b.params += tile; b.fallback += 4 * tile;
+  b.chunkListN += tile * sChunk; b.chunkList += tile * t.nChunks * kFastListCap;
+  b.chains += tile * t.chainCap; b.chainCount += tile * ((t.nChunks + kFastCandChunks - 1) / kFastCandChunks);
+  b.chunkEntry += tile * sChunk; b.chunkCount += tile * sChunk;
+  b.subEntry += tile * t.nChunks * kFastSubPerChunk; b.subIndex += tile * t.nChunks * kFastSubPerChunk;
+  b.blockOff += tile * ((size_t)t.nBlocks + 4); b.wgFletcher += tile * 2 * (t.nBlocks / kFastBlocksPerWG);
+  if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
+}
+
+template<int DT>
+__global__ void __launch_bounds__(64)
+k_fast_header(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 sizeGiven, int nRows, int nCols, u32* clearStatus)
+{
+  tileSlice(b, t, blob, sizeGiven);
+  fastHeaderBody<DT>(blob, sizeGiven, nRows, nCols, b.params, (b.clearCells && blockIdx.y == 0) ? clearStatus : nullptr,
+                     b.clearCells ? b.fallback : nullptr);
+}
+template<int DT>
+__global__ void __launch_bounds__(256)
+k_fast_candidates(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob)
+{
+  u32 sizeGiven = 0;
+  tileSlice(b, t, blob, sizeGiven);
+  fastCandidatesBody<DT>(b.params, blob, b.chunkListN, b.chunkList, b.chains, b.chainCount, b.fallback);
+}
+template<int DT>
+__global__ void __launch_bounds__(256)
+k_fast_chains(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob)
+{
+  u32 sizeGiven = 0;
+  tileSlice(b, t, blob, sizeGiven);
+  fastChainsBody<DT>(b.params, blob, b.chains, b.chainCount, t.chainCap);
+}
+template<int DT>
+__global__ void __launch_bounds__(256)
+k_fast_resolve(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob)
+{
+  u32 sizeGiven = 0;
+  tileSlice(b, t, blob, sizeGiven);
+  fastResolveBody<DT>(b.params, blob, b.chunkListN, b.chunkList, b.chains, b.chunkEntry, b.chunkCount, b.subEntry, b.subIndex, b.fallback);
+}
+template<int DT>
+__global__ void __launch_bounds__(256)
+k_fast_emit(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob)
+{
+  u32 sizeGiven = 0;
+  tileSlice(b, t, blob, sizeGiven);
+  fastEmitBody<DT>(b.params, blob, b.chunkEntry, b.chunkCount, b.subEntry, b.subIndex, b.blockOff, b.fallback);
+}
+template<class T, bool WIDE>
+__global__ void __launch_bounds__(256)
+k_fast_decode(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, T* __restrict__ outPix, DeviceStatus* st)
+{
+  u32 sizeGiven = 0;
+  tileSlice(b, t, blob, sizeGiven);
+  fastDecodeBody<T, WIDE>(b.params, blob, b.blockOff, outPix + (size_t)blockIdx.y * t.tileElems, b.wgFletcher, b.fallback, st);
+}
+__global__ void __launch_bounds__(1024) k_fast_fletcher_sum(FastDecodeBuffers b, FastDecodeBatch t)
+{
+  const u8* blob = nullptr;
+  u32 sizeGiven = 0;
+  tileSlice(b, t, blob, sizeGiven);
+  fastFletcherSumBody(b.params, b.wgFletcher, t.nBlocks / kFastBlocksPerWG);
+}
+
 template<class T>
-static void launchFastDecodeT(int stage, int nRows, int nCols, const FastWalkPlan& wp, const u8* blob, u32 sizeGiven,
+static void launchFastDecodeT(int stage, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
                               const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st)
 {
   constexpr int DT = DtOf<T>::v;
+  const u32 nT = t.nTiles;
   switch (stage)
   {
     case 0:
-      hipLaunchKernelGGL(k_fast_header<DT>, dim3(1), dim3(64), 0, st, blob, sizeGiven, nRows, nCols, b.params,
-                         b.clearCells ? reinterpret_cast<u32*>(status) : nullptr, b.clearCells ? b.fallback : nullptr);
-      hipLaunchKernelGGL(k_fast_candidates<DT>, dim3((wp.nChunks + kWalkG - 1) / kWalkG), dim3(256), 0, st, (const FastDecodeParams*)b.params,
-                         blob, b.chunkListN, b.chunkList, b.chains, b.chainCount, b.fallback);
+      hipLaunchKernelGGL(k_fast_header<DT>, dim3(1, nT), dim3(64), 0, st, b, t, blob, sizeGiven, nRows, nCols, reinterpret_cast<u32*>(status));
+      hipLaunchKernelGGL(k_fast_candidates<DT>, dim3((t.nChunks + kWalkG - 1) / kWalkG, nT), dim3(256), 0, st, b, t, blob);
       break;
     case 1:
-      hipLaunchKernelGGL(k_fast_chains<DT>, dim3((wp.chainCap + 255) / 256), dim3(256), 0, st, (const FastDecodeParams*)b.params, blob, b.chains,
-                         (const u32*)b.chainCount, wp.chainCap);
+      hipLaunchKernelGGL(k_fast_chains<DT>, dim3((t.chainCap + 255) / 256, nT), dim3(256), 0, st, b, t, blob);
       break;
     case 2:
-      hipLaunchKernelGGL(k_fast_resolve<DT>, dim3((wp.nChunks + 256) / 256), dim3(256), 0, st, (const FastDecodeParams*)b.params, blob,
-                         (const u32*)b.chunkListN, (const u64*)b.chunkList, (const FastChain*)b.chains, b.chunkEntry, b.chunkCount,
-                         b.subEntry, b.subIndex, b.fallback);
+      hipLaunchKernelGGL(k_fast_resolve<DT>, dim3((t.nChunks + 256) / 256, nT), dim3(256), 0, st, b, t, blob);
       break;
     case 3:
-      hipLaunchKernelGGL(k_fast_emit<DT>, dim3((wp.nChunks * kFastSubPerChunk + 255) / 256), dim3(256), 0, st,
-                         (const FastDecodeParams*)b.params, blob, (const u32*)b.chunkEntry, (const u32*)b.chunkCount, (const u32*)b.subEntry,
-                         (const u32*)b.subIndex, b.blockOff, b.fallback);
+      hipLaunchKernelGGL(k_fast_emit<DT>, dim3((t.nChunks * kFastSubPerChunk + 255) / 256, nT), dim3(256), 0, st, b, t, blob);
       break;
     default:
       if ((nCols / 8) % 64 == 0)
-        hipLaunchKernelGGL((k_fast_decode<T, true>), dim3(fastEncodeNumWG(nRows, nCols)), dim3(256), 0, st, (const FastDecodeParams*)b.params, blob,
-                           (const u32*)b.blockOff, (T*)out, b.wgFletcher, (const u32*)b.fallback, status);
+        hipLaunchKernelGGL((k_fast_decode<T, true>), dim3(t.nBlocks / kFastBlocksPerWG, nT), dim3(256), 0, st, b, t, blob, (T*)out, status);
       else
-        hipLaunchKernelGGL((k_fast_decode<T, false>), dim3(fastEncodeNumWG(nRows, nCols)), dim3(256), 0, st, (const FastDecodeParams*)b.params, blob,
-                           (const u32*)b.blockOff, (T*)out, b.wgFletcher, (const u32*)b.fallback, status);
-      hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1), dim3(1024), 0, st, b.params, (const u64*)b.wgFletcher, fastEncodeNumWG(nRows, nCols));
+        hipLaunchKernelGGL((k_fast_decode<T, false>), dim3(t.nBlocks / kFastBlocksPerWG, nT), dim3(256), 0, st, b, t, blob, (T*)out, status);
+      hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1, nT), dim3(nT > 1 ? 256 : 1024), 0, st, b, t);
       break;
   }
 }
 
-void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastWalkPlan& wp, const u8* blob, u32 sizeGiven,
+void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
                       const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st)
 {
   switch (dt)
   {
-    case DT_Short:  launchFastDecodeT<short>(stage, nRows, nCols, wp, blob, sizeGiven, b, out, status, st); break;
-    case DT_UShort: launchFastDecodeT<unsigned short>(stage, nRows, nCols, wp, blob, sizeGiven, b, out, status, st); break;
-    case DT_Int:    launchFastDecodeT<int>(stage, nRows, nCols, wp, blob, sizeGiven, b, out, status, st); break;
-    case DT_UInt:   launchFastDecodeT<unsigned int>(stage, nRows, nCols, wp, blob, sizeGiven, b, out, status, st); break;
-    case DT_Float:  launchFastDecodeT<float>(stage, nRows, nCols, wp, blob, sizeGiven, b, out, status, st); break;
-    case DT_Double: launchFastDecodeT<double>(stage, nRows, nCols, wp, blob, sizeGiven, b, out, status, st); break;
+    case DT_Short:  launchFastDecodeT<short>(stage, nRows, nCols, t, blob, sizeGiven, b, out, status, st); break;
+    case DT_UShort: launchFastDecodeT<unsigned short>(stage, nRows, nCols, t, blob, sizeGiven, b, out, status, st); break;
+    case DT_Int:    launchFastDecodeT<int>(stage, nRows, nCols, t, blob, sizeGiven, b, out, status, st); break;
+    case DT_UInt:   launchFastDecodeT<unsigned int>(stage, nRows, nCols, t, blob, sizeGiven, b, out, status, st); break;
+    case DT_Float:  launchFastDecodeT<float>(stage, nRows, nCols, t, blob, sizeGiven, b, out, status, st); break;
+    case DT_Double: launchFastDecodeT<double>(stage, nRows, nCols, t, blob, sizeGiven, b, out, status, st); break;
     default: break;
   }
 }

@@ -4,6 +4,7 @@
   * the real reference build (oracle/_ref/libLercRef.so) when it travelled to the GPU box,
 plus size-independent properties at the full BASELINE sizes.  Bar: byte-identical blobs, bit-identical
 decodes; float pixels within MaxZError (+ 1/2 ulp of the f32 result)."""
+import ctypes as ct
 import hashlib
 import json
 import os
@@ -213,3 +214,40 @@ def test_c5_tiles_are_independent_blobs(P, O):
         r1, b1 = P.encode(t, 0.01)
         r2, b2 = O.encode(t, 0.01)
         assert r1 == r2 == 0 and b1 == b2
+
+
+def test_c5_tile_batch_in_one_call(P, O):
+    """BASELINE configs[4]: a rank's share of the mosaic goes through lerc_amd_encode_tiles_device /
+    lerc_amd_decode_tiles_device in one call.  Every blob equals the per-tile lerc_encode() blob (oracle on a sample),
+    all tiles round-trip within the bound, and tiles the streaming kernels hand back are still right."""
+    import torch
+    from lerc_amd import api, synth
+    dev = torch.device("cuda:0")
+    n_side = 16                                                    # 256 tiles = a 4096 x 4096 window of the virtual raster
+    big = synth.c2_float32(256 * n_side, 256 * n_side, virt_cols=65536, device=dev)
+    tiles = big.reshape(n_side, 256, n_side, 256).permute(0, 2, 1, 3).contiguous().reshape(n_side * n_side, 256, 256)
+    tiles[5] = 7.25                                                # a constant tile (ocean): general path inside the batch
+    tiles[9] = torch.round(tiles[9])                               # all-integer floats: bIsInt promotion
+    n_tiles = tiles.shape[0]
+    codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
+    arena = torch.empty(tiles.numel() * 4 + n_tiles * 256, dtype=torch.uint8, device=dev)
+    rc, offs, sizes, used = api.encode_tiles_device(codec, tiles, 0.01, arena)
+    assert rc == 0, (rc, codec.last_error())
+    assert (offs % 16 == 0).all() and int(offs.max()) < used <= arena.numel()
+    ah = arena[:used].cpu().numpy()
+    th = tiles.cpu().numpy()
+    for t in (0, 1, 5, 9, 100, n_tiles - 1):
+        r1, b1 = O.encode(th[t], 0.01)
+        assert r1 == 0 and ah[int(offs[t]):int(offs[t]) + int(sizes[t])].tobytes() == b1, t
+    out = torch.empty_like(tiles)
+    rc = api.decode_tiles_device(codec, arena, offs, sizes, out)
+    assert rc == 0, (rc, codec.last_error())
+    torch.cuda.synchronize()
+    assert float((out.double() - tiles.double()).abs().max().item()) <= 0.01 + 6.2e-5
+    for t in (0, 5, 9, n_tiles - 1):
+        want = O.decode(ah[int(offs[t]):int(offs[t]) + int(sizes[t])].tobytes())
+        assert np.array_equal(want[1].reshape(256, 256), out[t].cpu().numpy())
+    cnt = (ct.c_ulonglong * 4)()
+    codec.lib.lerc_amd_path_counters.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+    codec.lib.lerc_amd_path_counters(codec.h, cnt)
+    assert cnt[0] == n_tiles - 2 and cnt[2] >= n_tiles - 4, list(cnt)    # the batch really went through the streaming kernels

@@ -248,3 +248,61 @@ def test_sim_streaming_decode_of_older_codec_versions(libs):
             c1 = S.path_counters()
             assert want[0] == got[0] == 0 and _same(want[1], got[1])
             assert c1[2] == c0[2] + 1, (np.dtype(dt).name, ver, S.last_note())
+
+
+def test_sim_tile_batches(libs):
+    """lerc_amd_encode_tiles_device / decode_tiles_device: one launch sequence for a batch of tiles, every blob byte
+    for byte what the per-tile call makes; tiles the streaming kernels hand back (constant, all-integer floats) are
+    redone inside the call."""
+    import ctypes as ct
+    O, S = libs
+    L = S.lib
+    L.lerc_amd_create.restype = ct.c_void_p
+    L.lerc_amd_create.argtypes = [ct.c_void_p]
+    L.lerc_amd_destroy.argtypes = [ct.c_void_p]
+    L.lerc_amd_encode_tiles_device.restype = ct.c_uint
+    L.lerc_amd_encode_tiles_device.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_int, ct.c_int, ct.c_int, ct.c_double, ct.c_void_p,
+                                               ct.c_ulonglong, ct.c_void_p, ct.c_void_p, ct.c_void_p]
+    L.lerc_amd_decode_tiles_device.restype = ct.c_uint
+    L.lerc_amd_decode_tiles_device.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_uint,
+                                               ct.c_void_p]
+    h = L.lerc_amd_create(None)
+    assert h
+    rng = np.random.default_rng(4)
+    try:
+        for dt, e in ((np.float32, 0.01), (np.uint16, 0), (np.float64, 0.05)):
+            for (r, c, n_t) in ((256, 256, 5), (64, 128, 6), (24, 40, 3)):    # the last shape is not streamable at all
+                tiles = np.stack([cases._cast(cases.terrain(r, c, rng, amp=300, base=1000 + 10 * t, sigma=1.5), dt) for t in range(n_t)])
+                if n_t >= 5:
+                    tiles[2] = tiles[2].flat[0]
+                    if np.dtype(dt).kind == "f":
+                        tiles[3] = np.rint(tiles[3])
+                src = _aligned(tiles.nbytes).view(dt).reshape(tiles.shape)
+                src[...] = tiles
+                arena = _aligned(tiles.nbytes + n_t * 256)
+                offs, sizes, used = np.zeros(n_t, np.uint64), np.zeros(n_t, np.uint32), ct.c_ulonglong(0)
+                rc = L.lerc_amd_encode_tiles_device(h, src.ctypes.data, capi.dt_code(dt), c, r, n_t, float(e), arena.ctypes.data, arena.size,
+                                                    offs.ctypes.data, sizes.ctypes.data, ct.byref(used))
+                assert rc == 0
+                for t in range(n_t):
+                    r1, b1 = O.encode(tiles[t], e)
+                    assert r1 == 0 and offs[t] % 16 == 0 and int(offs[t]) + int(sizes[t]) <= used.value
+                    assert arena[int(offs[t]):int(offs[t]) + int(sizes[t])].tobytes() == b1, (np.dtype(dt).name, r, c, t)
+                out = _aligned(tiles.nbytes).view(dt).reshape(tiles.shape)
+                rc = L.lerc_amd_decode_tiles_device(h, arena.ctypes.data, offs.ctypes.data, sizes.ctypes.data, n_t, c, r, capi.dt_code(dt),
+                                                    out.ctypes.data)
+                assert rc == 0
+                for t in range(n_t):
+                    want = O.decode(arena[int(offs[t]):int(offs[t]) + int(sizes[t])].tobytes())
+                    assert _same(want[1].reshape(r, c), out[t])
+        # an arena that is too small
+        tiles = np.stack([cases.terrain(64, 128, rng).astype(np.float32) for _ in range(4)])
+        src = _aligned(tiles.nbytes).view(np.float32).reshape(tiles.shape)
+        src[...] = tiles
+        arena = _aligned(4096)
+        offs, sizes, used = np.zeros(4, np.uint64), np.zeros(4, np.uint32), ct.c_ulonglong(0)
+        rc = L.lerc_amd_encode_tiles_device(h, src.ctypes.data, 6, 128, 64, 4, 0.01, arena.ctypes.data, arena.size, offs.ctypes.data,
+                                            sizes.ctypes.data, ct.byref(used))
+        assert rc == 3
+    finally:
+        L.lerc_amd_destroy(h)
