@@ -304,7 +304,12 @@ fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u3
       for (int c = 0; c < 9; c++)
       {
         double e = 0;
-        for (u32 w = 0; w < nRaiseSets; w++) { const double x = row0RaiseErr[w * 9 + c]; e = x > e ? x : e; }
+#pragma unroll
+        for (u32 w = 0; w < 16u; w++)    // nRaiseSets <= 16; a fixed trip count lets the loads go out together
+        {
+          const double x = (w < nRaiseSets) ? row0RaiseErr[w * 9 + c] : 0.0;
+          e = x > e ? x : e;
+        }
         if (((raiseCandidates >> c) & 1u) && !(e / fac[c] > requestedMaxZErr / 2)) redo |= kRedoRaise;
       }
     }
@@ -611,11 +616,11 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
 }
 
 // checksum = Fletcher32 over blob[14 ..): the prefix bytes written by the decide step + the workgroups' partial sums
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_fast_checksum(const u64* __restrict__ wgFletcher, u32 nWG, u8* __restrict__ out, FastEncodeResult* res,
                 const u8* __restrict__ prefixStage, const u64* __restrict__ tileOffset, FastBatch batch)
 {
-  __shared__ u64 s_a[4], s_b[4];
+  __shared__ u64 s_a[16], s_b[16];
   {
     const size_t tile = blockIdx.y;
     wgFletcher += tile * batch.nWG * 2; res += tile; prefixStage += tile * kFastPrefixStage;
@@ -624,8 +629,10 @@ k_fast_checksum(const u64* __restrict__ wgFletcher, u32 nWG, u8* __restrict__ ou
   if (res->redo) return;
   const int lane = laneId(), w = waveId();
   u64 A = 0, B = 0;
-  for (u32 i = threadIdx.x; i < nWG; i += 256u) { A += wgFletcher[2 * (size_t)i]; B += wgFletcher[2 * (size_t)i + 1]; }    // each < 65535
-  for (u32 pos = threadIdx.x; pos + 14 < res->prefixLen; pos += 256u)
+  if (threadIdx.x < 16) { s_a[threadIdx.x] = 0; s_b[threadIdx.x] = 0; }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < nWG; i += blockDim.x) { A += wgFletcher[2 * (size_t)i]; B += wgFletcher[2 * (size_t)i + 1]; }    // each < 65535
+  for (u32 pos = threadIdx.x; pos + 14 < res->prefixLen; pos += blockDim.x)
   {
     const u32 cw = (u32)prefixStage[14 + pos] << ((pos & 1u) ? 0 : 8);
     A += cw; B += (u64)(pos >> 1) * cw;
@@ -635,7 +642,7 @@ k_fast_checksum(const u64* __restrict__ wgFletcher, u32 nWG, u8* __restrict__ ou
   __syncthreads();
   if (threadIdx.x != 0) return;
   A = 0; B = 0;
-  for (int i = 0; i < 4; i++) { A += s_a[i]; B += s_b[i]; }
+  for (int i = 0; i < 16; i++) { A += s_a[i]; B += s_b[i]; }
   const u32 len = res->blobSize - 14;
   const u64 N = ((u64)len + 1) / 2;
   A %= 65535u; B %= 65535u;
@@ -773,7 +780,7 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
                          (const u64*)b.tileOffset, batch);
   }
   else
-    hipLaunchKernelGGL(k_fast_checksum, dim3(1, nT), dim3(256), 0, st, (const u64*)b.wgFletcher, nWG, out, b.result, (const u8*)b.prefixStage,
+    hipLaunchKernelGGL(k_fast_checksum, dim3(1, nT), dim3(nT > 1 ? 256 : 1024), 0, st, (const u64*)b.wgFletcher, nWG, out, b.result, (const u8*)b.prefixStage,
                        (const u64*)b.tileOffset, batch);
 }
 
