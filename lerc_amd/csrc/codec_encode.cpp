@@ -191,10 +191,39 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   {
     if (maxZErr < 0)
     {
-      // bit plane mode (Lerc2.cpp:1071-1229) is not implemented on the device yet: lossless is the
-      // reference's own fallback whenever the statistics are inconclusive
-      ctx.lastError = "bit-plane compression (maxZErr 777) not supported";
-      return kFailed;
+      // bit plane mode (Lerc2::TryBitPlaneCompression, Lerc2.cpp:1071-1229): drop the low bit planes whose XOR with
+      // the neighbours looks like coin flips (|1 - 2 p| < eps); lossless whenever the statistics are inconclusive
+      const double eps = -maxZErr;
+      maxZErr = 0;
+      const int nBits = 8 * dtSize(dt), minCnt = 5000;
+      if (bandNumValid >= minCnt)
+      {
+        u32* dCounts = ctx.allocT<u32>((size_t)nD * 32 + 1);
+        if (!dCounts) return kFailed;
+        std::vector<u32> hCounts((size_t)nD * 32 + 1);
+        { ProfScope ps(ctx, "bitplane_counts"); launchBitPlaneCounts(dt, dData, (haveBits && !bandAllValid) ? dNewBits : nullptr, nRows, nCols, nD, dCounts, st); }
+        hipMemcpyAsync(hCounts.data(), dCounts, hCounts.size() * 4, hipMemcpyDeviceToHost, st);
+        if (!sync.wait()) return kFailed;
+        const double cnt = (double)hCounts[(size_t)nD * 32];
+        if (cnt >= minCnt)
+        {
+          int nCut = 0, lastKept = 0;
+          for (int s2 = nBits - 1; s2 >= 0; s2--)
+          {
+            bool crit = true;
+            for (int m = 0; m < nD; m++)
+              if (fabs(1 - 2 * ((double)hCounts[(size_t)m * 32 + s2] / cnt)) >= eps) crit = false;
+            if (crit && nCut < 2)
+            {
+              if (nCut == 0) lastKept = s2;
+              if (nCut == 1 && s2 < lastKept - 1) { lastKept = s2; nCut = 0; }
+              nCut++;
+            }
+          }
+          lastKept = std::max(0, lastKept);
+          maxZErr = (double)((1 << lastKept) >> 1);
+        }
+      }
     }
     maxZErr = std::max(0.5, floor(maxZErr));
   }

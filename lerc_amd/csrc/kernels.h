@@ -78,6 +78,8 @@ u64 statKeyInitMin();
 u64 statKeyInitMax();
 u64 statKeyToRawBits(int dt, u64 key);
 double statKeyToDouble(int dt, u64 key);
+// bit plane mode (Lerc2.cpp:1071-1229): counts[nDepth * 32 + 1] u32 on the device, see misc_kernels.hip
+void launchBitPlaneCounts(int dt, const void* data, const u8* maskBits, int nRows, int nCols, int nDepth, u32* counts, hipStream_t stream);
 static const int kFletcherPartials = 2 * 512;    // u64 words written by launchFletcher
 void launchMaskGroupCounts(const u8* maskBits, i64 nPix, u32* counts, hipStream_t stream);
 

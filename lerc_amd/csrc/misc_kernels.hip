@@ -6,6 +6,7 @@
 // (Lerc2.cpp:1404-1470), Lerc2::TryRaiseMaxZError (:1233-1318), Write/ReadDataOneSweep (:1343-1400),
 // FillConstImage (:2681-2721), Lerc::Convert byte<->bit mask (Lerc.cpp:959-995).
 #include "kernels.h"
+#include <algorithm>
 #include "wave_utils.h"
 
 namespace lerc {
@@ -375,6 +376,71 @@ void launchBandStats(int dt, const void* data, const u8* maskBits, int nRows, in
     case DT_UInt:   hipLaunchKernelGGL(k_band_stats<unsigned int>, grid, block, 0, stream, (const unsigned int*)data, maskBits, nPix, nDepth, maxZErr, raiseMask, mins, maxs, stats); break;
     case DT_Float:  hipLaunchKernelGGL(k_band_stats<float>, grid, block, 0, stream, (const float*)data, maskBits, nPix, nDepth, maxZErr, raiseMask, mins, maxs, stats); break;
     case DT_Double: hipLaunchKernelGGL(k_band_stats<double>, grid, block, 0, stream, (const double*)data, maskBits, nPix, nDepth, maxZErr, raiseMask, mins, maxs, stats); break;
+    default: break;
+  }
+}
+
+// ================================================================================================
+// bit plane statistics for the integer "bit plane" mode (Lerc2::TryBitPlaneCompression, Lerc2.cpp:1071-1229):
+// for every valid pixel and its valid right / lower neighbour, per depth, how often each bit of a XOR b is set.
+// counts[m * 32 + s] = tally of bit s in depth m, counts[nDepth * 32] = number of neighbour pairs.
+// The all-valid nDepth == 1 case of the reference leaves the last row and column out altogether (:1091-1103).
+// ================================================================================================
+template<class T>
+__global__ void __launch_bounds__(256)
+k_bitplane_counts(const T* __restrict__ data, const u8* __restrict__ maskBits, int nRows, int nCols, int nDepth, u32* __restrict__ counts)
+{
+  constexpr int nBits = 8 * (int)sizeof(T);
+  const i64 nPix = (i64)nRows * nCols;
+  const bool simple = (nDepth == 1 && !maskBits);
+  const int lane = laneId();
+  u32 pairs = 0;
+  for (i64 base = (i64)blockIdx.x * 256; base < nPix; base += (i64)gridDim.x * 256)    // uniform trip count: ballots inside
+  {
+    const i64 k = base + threadIdx.x;
+    const bool in = k < nPix;
+    const int i = in ? (int)(k / nCols) : 0, j = in ? (int)(k - (i64)i * nCols) : 0;
+    bool hori, vert;
+    if (simple) hori = vert = in && i < nRows - 1 && j < nCols - 1;
+    else
+    {
+      const bool valid = in && (!maskBits || maskBit(maskBits, k));
+      hori = valid && j < nCols - 1 && (!maskBits || maskBit(maskBits, k + 1));
+      vert = valid && i < nRows - 1 && (!maskBits || maskBit(maskBits, k + nCols));
+    }
+    pairs += (hori ? 1u : 0u) + (vert ? 1u : 0u);
+    for (int m = 0; m < nDepth; m++)
+    {
+      const i64 at = k * nDepth + m;
+      const u32 a = (hori || vert) ? (u32)data[at] : 0u;
+      const u32 xh = hori ? (a ^ (u32)data[at + nDepth]) : 0u;
+      const u32 xv = vert ? (a ^ (u32)data[at + (i64)nDepth * nCols]) : 0u;
+#pragma unroll
+      for (int s = 0; s < nBits; s++)
+      {
+        const u32 c = (u32)__popcll(__ballot((xh >> s) & 1u)) + (u32)__popcll(__ballot((xv >> s) & 1u));
+        if (lane == 0 && c) atomicAdd(&counts[m * 32 + s], c);
+      }
+    }
+  }
+  pairs = waveSum(pairs);
+  if (lane == 0 && pairs) atomicAdd(&counts[nDepth * 32], pairs);
+}
+
+void launchBitPlaneCounts(int dt, const void* data, const u8* maskBits, int nRows, int nCols, int nDepth, u32* counts, hipStream_t stream)
+{
+  hipMemsetAsync(counts, 0, ((size_t)nDepth * 32 + 1) * 4, stream);
+  const i64 nPix = (i64)nRows * nCols;
+  const unsigned nBlocks = (unsigned)std::min<i64>((nPix + 255) / 256, 4096);
+  const dim3 grid(nBlocks), block(256);
+  switch (dt)
+  {
+    case DT_Char:   hipLaunchKernelGGL(k_bitplane_counts<signed char>, grid, block, 0, stream, (const signed char*)data, maskBits, nRows, nCols, nDepth, counts); break;
+    case DT_Byte:   hipLaunchKernelGGL(k_bitplane_counts<unsigned char>, grid, block, 0, stream, (const unsigned char*)data, maskBits, nRows, nCols, nDepth, counts); break;
+    case DT_Short:  hipLaunchKernelGGL(k_bitplane_counts<short>, grid, block, 0, stream, (const short*)data, maskBits, nRows, nCols, nDepth, counts); break;
+    case DT_UShort: hipLaunchKernelGGL(k_bitplane_counts<unsigned short>, grid, block, 0, stream, (const unsigned short*)data, maskBits, nRows, nCols, nDepth, counts); break;
+    case DT_Int:    hipLaunchKernelGGL(k_bitplane_counts<int>, grid, block, 0, stream, (const int*)data, maskBits, nRows, nCols, nDepth, counts); break;
+    case DT_UInt:   hipLaunchKernelGGL(k_bitplane_counts<unsigned int>, grid, block, 0, stream, (const unsigned int*)data, maskBits, nRows, nCols, nDepth, counts); break;
     default: break;
   }
 }
