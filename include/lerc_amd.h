@@ -70,8 +70,9 @@ LERC_AMD_API lerc_status lerc_decodeToDouble(const unsigned char* pLercBlob, uns
     unsigned char* pValidBytes, int nDepth, int nCols, int nRows, int nBands, double* pData);
 
 /* reference Lerc_c_api.h:300-380 -- the _4D variants add a per-band noData value.  With
- * pUsesNoData == NULL (or all zero) they are the calls above; a non-zero noData request is not
- * implemented on the device yet and returns Failed(1). */
+ * pUsesNoData == NULL (or all zero) they are the calls above.  A noData value turns pixels that hold it in every
+ * depth into invalid ones and, for nDepth > 1, travels in the blob (remapped below the data range if need be);
+ * lerc_decode_4D hands it back.  (Where the filter has to make a float band lossless: Failed(1), no lossless float.) */
 LERC_AMD_API lerc_status lerc_computeCompressedSize_4D(const void* pData, unsigned int dataType, int nDepth, int nCols,
     int nRows, int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr, unsigned int* numBytes,
     const unsigned char* pUsesNoData, const double* noDataValues);

@@ -59,7 +59,7 @@ bool usesNoData(const unsigned char* pUsesNoData, int nBands)
 // shared by lerc_encode / lerc_computeCompressedSize: host pointers in, blob (optionally) out
 lerc_status encodeHost(const void* pData, unsigned dataType, int nDepth, int nCols, int nRows, int nBands, int nMasks,
                        const unsigned char* pValidBytes, double maxZErr, unsigned char* pOut, unsigned outSize,
-                       unsigned* result, bool sizeOnly)
+                       unsigned* result, bool sizeOnly, const unsigned char* pUsesNoData = nullptr, const double* noDataValues = nullptr)
 {
   lerc_amd_context* h = threadHandle();
   if (!h) return kFailed;
@@ -78,6 +78,7 @@ lerc_status encodeHost(const void* pData, unsigned dataType, int nDepth, int nCo
   EncodeRequest rq;
   rq.dData = dData; rq.dValidBytes = dMask; rq.dt = (int)dataType; rq.nDepth = nDepth; rq.nCols = nCols; rq.nRows = nRows;
   rq.nBands = nBands; rq.nMasks = nMasks; rq.maxZErr = maxZErr;
+  rq.hUsesNoData = pUsesNoData; rq.hNoDataValues = noDataValues;
   u32 needed = 0, written = 0;
   if (sizeOnly)
   {
@@ -101,7 +102,8 @@ lerc_status encodeHost(const void* pData, unsigned dataType, int nDepth, int nCo
 }
 
 lerc_status decodeHost(const unsigned char* blob, unsigned blobSize, int nMasks, unsigned char* pValidBytes, int nDepth,
-                       int nCols, int nRows, int nBands, unsigned dataType, void* pData, bool toDouble)
+                       int nCols, int nRows, int nBands, unsigned dataType, void* pData, bool toDouble,
+                       unsigned char* pUsesNoData = nullptr, double* noDataValues = nullptr)
 {
   lerc_amd_context* h = threadHandle();
   if (!h) return kFailed;
@@ -119,6 +121,7 @@ lerc_status decodeHost(const unsigned char* blob, unsigned blobSize, int nMasks,
   DecodeRequest rq;
   rq.hBlob = blob; rq.blobSize = blobSize; rq.dt = (int)dataType; rq.nDepth = nDepth; rq.nCols = nCols; rq.nRows = nRows;
   rq.nBands = nBands; rq.nMasks = nMasks; rq.dOut = dOut; rq.dValidBytes = dMask;
+  rq.hUsesNoData = pUsesNoData; rq.hNoDataValues = noDataValues;
   const u32 rc = decodeDevice(ctx, rq);
   if (rc != kOk) return rc;
   if (widen)
@@ -144,8 +147,9 @@ lerc_status lerc_computeCompressedSize_4D(const void* pData, unsigned int dataTy
   *numBytes = 0;
   if (!pData || dataType >= DT_Undefined || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0 || maxZErr < 0) return kWrongParam;
   if (!masksArgOk(nMasks, nBands, pValidBytes)) return kWrongParam;
-  if (usesNoData(pUsesNoData, nBands)) return noDataValues ? kFailed : kWrongParam;    // noData: not on the device yet
-  return encodeHost(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, nullptr, 0, numBytes, true);
+  if (usesNoData(pUsesNoData, nBands) && !noDataValues) return kWrongParam;
+  return encodeHost(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, nullptr, 0, numBytes, true, pUsesNoData,
+                    noDataValues);
 }
 
 lerc_status lerc_encode_4D(const void* pData, unsigned int dataType, int nDepth, int nCols, int nRows, int nBands,
@@ -158,9 +162,9 @@ lerc_status lerc_encode_4D(const void* pData, unsigned int dataType, int nDepth,
     || !pOutBuffer || !outBufferSize)
     return kWrongParam;
   if (!masksArgOk(nMasks, nBands, pValidBytes)) return kWrongParam;
-  if (usesNoData(pUsesNoData, nBands)) return noDataValues ? kFailed : kWrongParam;
+  if (usesNoData(pUsesNoData, nBands) && !noDataValues) return kWrongParam;
   return encodeHost(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, pOutBuffer, outBufferSize,
-                    nBytesWritten, false);
+                    nBytesWritten, false, pUsesNoData, noDataValues);
 }
 
 lerc_status lerc_computeCompressedSizeForVersion(const void* pData, int codecVersion, unsigned int dataType, int nDepth,
@@ -239,8 +243,7 @@ lerc_status lerc_decode_4D(const unsigned char* pLercBlob, unsigned int blobSize
   if (!pLercBlob || !blobSize || !pData || dataType >= DT_Undefined || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0)
     return kWrongParam;
   if (!masksArgOk(nMasks, nBands, pValidBytes)) return kWrongParam;
-  (void)pUsesNoData; (void)noDataValues;    // only written for blobs that carry noData, which decodeDevice refuses
-  return decodeHost(pLercBlob, blobSize, nMasks, pValidBytes, nDepth, nCols, nRows, nBands, dataType, pData, false);
+  return decodeHost(pLercBlob, blobSize, nMasks, pValidBytes, nDepth, nCols, nRows, nBands, dataType, pData, false, pUsesNoData, noDataValues);
 }
 
 lerc_status lerc_decode(const unsigned char* pLercBlob, unsigned int blobSize, int nMasks, unsigned char* pValidBytes,
@@ -259,8 +262,8 @@ lerc_status lerc_decodeToDouble_4D(const unsigned char* pLercBlob, unsigned int 
   const u32 e = getBlobInfo(pLercBlob, blobSize, li);
   if (e != kOk) return e;
   if (li.nDepth != nDepth || li.nCols != nCols || li.nRows != nRows || li.nBands != nBands) return kFailed;
-  (void)pUsesNoData; (void)noDataValues;
-  return decodeHost(pLercBlob, blobSize, nMasks, pValidBytes, nDepth, nCols, nRows, nBands, (unsigned)li.dt, pData, true);
+  return decodeHost(pLercBlob, blobSize, nMasks, pValidBytes, nDepth, nCols, nRows, nBands, (unsigned)li.dt, pData, true, pUsesNoData,
+                    noDataValues);
 }
 
 lerc_status lerc_decodeToDouble(const unsigned char* pLercBlob, unsigned int blobSize, int nMasks,

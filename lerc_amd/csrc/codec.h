@@ -104,6 +104,8 @@ struct EncodeRequest
   double maxZErr = 0;
   u8* dOut = nullptr;                 // device output buffer (nullptr: size only)
   u32 outCapacity = 0;
+  const u8* hUsesNoData = nullptr;    // host [nBands] or nullptr: band carries a noData value (lerc_encode_4D)
+  const double* hNoDataValues = nullptr;
 };
 // returns an ErrCode; numBytesNeeded is always the exact blob size on kOk
 u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32& numBytesWritten);
@@ -137,6 +139,8 @@ struct DecodeRequest
   void* dOut = nullptr;               // device: decoded pixels
   u8* dValidBytes = nullptr;          // device: nMasks byte masks, or nullptr
   bool noStreaming = false;            // go straight to the general kernels (a batch has already tried the streaming ones)
+  u8* hUsesNoData = nullptr;           // host [nBands] out (lerc_decode_4D), or nullptr
+  double* hNoDataValues = nullptr;
 };
 u32 decodeDevice(Context& ctx, const DecodeRequest& rq);
 u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed);

@@ -6,6 +6,7 @@
 #include "codec.h"
 #include "huffman.h"
 #include "tile_fast.h"
+#include <functional>
 
 #include <algorithm>
 #include <cstdint>
@@ -215,10 +216,12 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   if (infoMasks > 1) infoMasks = (int)bands.size();
   if (rq.nMasks < infoMasks) return kWrongParam;
   if (rq.nBands > (int)bands.size()) return kWrongParam;
-  if (usesNoData && nD > 1)
+  const bool passNoData = usesNoData && nD > 1;    // Lerc.cpp:430-441: only the _4D entry points can hand the values out
+  if (passNoData)
   {
-    ctx.lastError = "blobs carrying a noData value (nDepth > 1) are not supported by the device decoder";
-    return kHasNoData;
+    if (!rq.hUsesNoData || !rq.hNoDataValues) return kHasNoData;
+    memset(rq.hUsesNoData, 0, (size_t)rq.nBands);
+    memset(rq.hNoDataValues, 0, (size_t)rq.nBands * sizeof(double));
   }
 
   // ---- workspace
@@ -328,6 +331,21 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     else if (!haveMask || maskAllValid) return kFailed;    // "use previous mask" without a usable one
     at += (u64)bd.numBytesMask;
     const u8* dMask = maskAllValid ? nullptr : dBits;
+
+    // noData value of this band: handed out, and the remapped value in the decoded pixels turned back into the
+    // caller's original one (Lerc.cpp:488-510) -- enqueued when the iteration is left, behind the band's kernels
+    struct BandEpilogue
+    {
+      std::function<void()> fn;
+      ~BandEpilogue() { if (fn) fn(); }
+    } epilogue;
+    if (passNoData)
+    {
+      rq.hUsesNoData[iBand] = hd.passNoData ? 1 : 0;
+      rq.hNoDataValues[iBand] = hd.noDataValOrig;
+      if (hd.passNoData && hd.noDataVal != hd.noDataValOrig)
+        epilogue.fn = [&, dMask, dOutBand]() { launchNoDataRemap(dt, dOutBand, nullptr, dMask, nPix, nD, hd.noDataVal, hd.noDataValOrig, st); };
+    }
 
     if (iBand < rq.nMasks && rq.dValidBytes)
       launchBitsToBytes(dMask, rq.dValidBytes + (size_t)iBand * nPix, nPix, st);

@@ -6,6 +6,8 @@
 #include "codec.h"
 #include "huffman.h"
 #include "tile_fast.h"
+#include <cfloat>
+#include <functional>
 
 #include <algorithm>
 #include <cmath>
@@ -34,6 +36,171 @@ bool isIntegral(double z) { return z == floor(z + 0.5); }
 
 }    // namespace
 
+// ------------------------------------------------------------------------------------------------
+// noData values: what Lerc::FilterNoDataAndNaN (float, Lerc.cpp:1378-1552) and its integer sibling (:1241-1374)
+// decide once the sweep over the band (k_nodata_scan) is done.  In: the requested error bound and noData value;
+// out: the bound to encode with, whether the blob has to carry a noData value, and the value it is remapped to.
+// ------------------------------------------------------------------------------------------------
+struct NoDataDecision
+{
+  bool active = false;       // this band came with a noData value
+  bool needNoData = false;   // some valid pixels keep noData in some depths: the header carries the value
+  bool allInt = false;       // float types: header flag bIsInt
+  bool remap = false;
+  double maxZErr = 0, noDataOrig = 0, noDataNew = 0, remapFrom = 0, remapTo = 0;
+  const u8* dData = nullptr; // the filtered copy of the band
+  const u8* dMask = nullptr; // ... and of its byte mask
+  bool modifiedMask = false;
+  bool empty = false;        // no value left at all
+};
+
+template<class T> static bool isIntValT(T z) { return z == (T)floor((double)z + 0.5); }    // Lerc.h:271
+
+// Lerc.cpp:1558-1618
+template<class T>
+static bool findNoDataBelowMin(double minVal, double maxZErr, bool allInt, double lowIntLimit, T& out)
+{
+  std::vector<T> cand;
+  if (allInt)
+  {
+    const double dist[] = { 4 * maxZErr, 1, 10, 100, 1000, 10000 };
+    for (double d : dist) cand.push_back((T)(minVal - d));
+    cand.push_back((T)(minVal > 0 ? floor(minVal / 2) : minVal * 2));
+    std::sort(cand.begin(), cand.end(), std::greater<double>());
+    for (T v : cand)
+      if ((v > (T)lowIntLimit) && (v < (T)(minVal - 2 * maxZErr)) && isIntValT(v)) { out = v; return true; }
+  }
+  else
+  {
+    const double dist[] = { 4 * maxZErr, 0.0001, 0.001, 0.01, 0.1, 1, 10, 100, 1000, 10000 };
+    for (double d : dist) cand.push_back((T)(minVal - d));
+    cand.push_back((T)(minVal > 0 ? minVal / 2 : minVal * 2));
+    std::sort(cand.begin(), cand.end(), std::greater<double>());
+    const T lowest = (T)(std::is_same<T, float>::value ? -FLT_MAX : -DBL_MAX);
+    for (T v : cand)
+      if ((v > lowest) && (v < (T)(minVal - 2 * maxZErr))) { out = v; return true; }
+  }
+  return false;
+}
+
+template<class T>
+static u32 decideNoDataFloat(const NoDataScan& sc, bool any, double minVal, double maxVal, int nDepth, double maxZErr, double noDataValue,
+                             NoDataDecision& d)
+{
+  const bool isF32 = std::is_same<T, float>::value;
+  const T origNoData = (T)noDataValue;
+  const bool noDataLeft = (sc.flags & 2u) != 0;
+  bool allInt = !(sc.flags & 8u);
+  const double lowInt = isF32 ? -(double)(1L << 23) : -(double)((i64)1 << 53), highInt = -lowInt;
+  d.maxZErr = maxZErr; d.noDataNew = noDataValue;
+  if (!any) { d.empty = true; d.maxZErr = 0; return kOk; }
+  d.needNoData = noDataLeft;
+  (void)nDepth;
+  double e = maxZErr;
+  if (allInt)
+  {
+    allInt = allInt && (minVal >= lowInt) && (minVal <= highInt) && (maxVal >= lowInt) && (maxVal <= highInt);
+    if (noDataLeft) allInt = allInt && isIntValT(origNoData) && (origNoData >= lowInt) && (origNoData <= highInt);
+    if (allInt) e = std::max(0.5, floor(maxZErr));
+  }
+  d.allInt = allInt;
+  if (e == 0) { d.maxZErr = maxZErr; return kOk; }
+  {
+    const double dist = allInt ? floor(e) : 2 * e;
+    if ((origNoData >= minVal - dist) && (origNoData <= maxVal + dist)) { d.maxZErr = allInt ? 0.5 : 0; return kOk; }
+  }
+  if (noDataLeft)
+  {
+    T remap = origNoData;
+    if (findNoDataBelowMin<T>(minVal, e, allInt, lowInt, remap))
+    {
+      if (remap != origNoData) { d.remap = true; d.remapFrom = (double)origNoData; d.remapTo = (double)remap; d.noDataNew = (double)remap; }
+    }
+    else if ((double)origNoData >= minVal) e = allInt ? 0.5 : 0;
+  }
+  d.maxZErr = e;
+  return kOk;
+}
+
+template<class T>
+static u32 decideNoDataInt(const NoDataScan& sc, bool any, double minVal, double maxVal, double lo, double hi, double maxZErr,
+                           double noDataValue, NoDataDecision& d)
+{
+  const T orig = (T)noDataValue;
+  d.needNoData = (sc.flags & 2u) != 0;
+  d.noDataNew = noDataValue;
+  double e = std::max(0.5, floor(maxZErr));
+  const double dist = floor(e);
+  if (!any) { d.empty = true; d.maxZErr = 0.5; return kOk; }
+  if (((double)orig >= minVal - dist) && ((double)orig <= maxVal + dist)) { d.maxZErr = 0.5; return kOk; }
+  if (d.needNoData)
+  {
+    const double minDist = floor(e) + 1;
+    double remap = minVal - minDist;
+    T nd = orig;
+    if (remap >= lo) nd = (T)remap;
+    else
+    {
+      e = 0.5;
+      remap = minVal - 1;
+      if (remap >= lo) nd = (T)remap;
+      else
+      {
+        remap = maxVal + 1;
+        if ((remap <= hi) && (remap < (double)orig)) nd = (T)remap;
+      }
+    }
+    if (nd != orig) { d.remap = true; d.remapFrom = (double)orig; d.remapTo = (double)nd; d.noDataNew = (double)nd; }
+  }
+  d.maxZErr = e;
+  return kOk;
+}
+
+// sweeps a private copy of band iBand and fills `d`; workspace comes from ctx (behind whatever is allocated so far)
+static u32 filterNoData(Context& ctx, const EncodeRequest& rq, int iBand, NoDataDecision& d)
+{
+  hipStream_t st = ctx.activeStream();
+  const int dt = rq.dt, nD = rq.nDepth;
+  const int tb = dtSize(dt);
+  const i64 nPix = (i64)rq.nRows * rq.nCols, nElem = nPix * nD;
+  const double noData = rq.hNoDataValues[iBand];
+  static const double tlo[6] = { -128, 0, -32768, 0, -2147483648.0, 0 }, thi[6] = { 127, 255, 32767, 65535, 2147483647.0, 4294967295.0 };
+  if (dt == DT_Float && (noData < -FLT_MAX || noData > FLT_MAX)) return kWrongParam;
+  if (dt < DT_Float && (noData < tlo[dt] || noData > thi[dt])) return kWrongParam;
+  if (noData != noData) return kWrongParam;
+  u8* dCopy = ctx.allocT<u8>((size_t)nElem * tb + 256);
+  u8* dMask = ctx.allocT<u8>((size_t)nPix + 256);
+  NoDataScan* dScan = ctx.allocT<NoDataScan>(1);
+  if (!dCopy || !dMask || !dScan) return kFailed;
+  const u8* src = (const u8*)rq.dData + (size_t)iBand * nElem * tb;
+  hipMemcpyAsync(dCopy, src, (size_t)nElem * tb, hipMemcpyDeviceToDevice, st);
+  if (rq.nMasks > 0) hipMemcpyAsync(dMask, rq.dValidBytes + ((rq.nMasks > 1) ? (size_t)iBand * nPix : 0), (size_t)nPix, hipMemcpyDeviceToDevice, st);
+  else hipMemsetAsync(dMask, 1, (size_t)nPix, st);
+  launchNoDataScan(dt, dCopy, dMask, nPix, nD, noData, dScan, st);
+  NoDataScan sc;
+  hipMemcpyAsync(&sc, dScan, sizeof(sc), hipMemcpyDeviceToHost, st);
+  if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
+  const bool any = sc.minKey != statKeyInitMin() || sc.maxKey != statKeyInitMax();
+  const double minVal = any ? statKeyToDouble(dt, sc.minKey) : 0, maxVal = any ? statKeyToDouble(dt, sc.maxKey) : 0;
+  d = NoDataDecision();
+  d.active = true; d.noDataOrig = noData; d.dData = dCopy; d.dMask = dMask; d.modifiedMask = (sc.flags & 4u) != 0;
+  u32 rc = kOk;
+  switch (dt)
+  {
+    case DT_Float:  rc = decideNoDataFloat<float>(sc, any, minVal, maxVal, nD, rq.maxZErr, noData, d); break;
+    case DT_Double: rc = decideNoDataFloat<double>(sc, any, minVal, maxVal, nD, rq.maxZErr, noData, d); break;
+    case DT_Char:   rc = decideNoDataInt<signed char>(sc, any, minVal, maxVal, tlo[dt], thi[dt], rq.maxZErr, noData, d); break;
+    case DT_Byte:   rc = decideNoDataInt<unsigned char>(sc, any, minVal, maxVal, tlo[dt], thi[dt], rq.maxZErr, noData, d); break;
+    case DT_Short:  rc = decideNoDataInt<short>(sc, any, minVal, maxVal, tlo[dt], thi[dt], rq.maxZErr, noData, d); break;
+    case DT_UShort: rc = decideNoDataInt<unsigned short>(sc, any, minVal, maxVal, tlo[dt], thi[dt], rq.maxZErr, noData, d); break;
+    case DT_Int:    rc = decideNoDataInt<int>(sc, any, minVal, maxVal, tlo[dt], thi[dt], rq.maxZErr, noData, d); break;
+    default:        rc = decideNoDataInt<unsigned int>(sc, any, minVal, maxVal, tlo[dt], thi[dt], rq.maxZErr, noData, d); break;
+  }
+  if (rc != kOk) return rc;
+  if (d.remap) launchNoDataRemap(dt, dCopy, dMask, nullptr, nPix, nD, d.remapFrom, d.remapTo, st);
+  return kOk;
+}
+
 static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskState& ms, std::vector<u8>& prevByteValid,
                       bool& anyMaskModified, u8* dBandOut, u32 capacityLeft, u32& bandBytes)
 {
@@ -47,6 +214,16 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   const u8* dByteMask = (rq.nMasks > 0) ? rq.dValidBytes + ((rq.nMasks > 1) ? (size_t)iBand * nPix : 0) : nullptr;
   bandBytes = 0;
   if (nD > kStatsMaxDepth) { ctx.lastError = "nDepth above the device statistics limit"; return kFailed; }
+  // a noData value: the band is filtered into a private copy first (pixels that are noData throughout leave the
+  // mask, the value may move below the data range), and the decisions below come from that filter
+  NoDataDecision nd;
+  if (rq.hUsesNoData && rq.hUsesNoData[iBand])
+  {
+    const u32 rc = filterNoData(ctx, rq, iBand, nd);
+    if (rc != kOk) return rc;
+    dData = nd.dData;
+    dByteMask = nd.dMask;
+  }
 
   // ---- device scratch of this band
   DeviceStatus* dStatus = ctx.allocT<DeviceStatus>(1);
@@ -140,7 +317,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     hipMemcpyAsync(hBandBits.data(), dNewBits, hBandBits.size(), hipMemcpyDeviceToHost, st);
     if (!sync.wait()) return kFailed;
   }
-  if (nanSeen) anyMaskModified = true;
+  if (nanSeen || nd.modifiedMask) anyMaskModified = true;
   bool encMask = (iBand == 0);
   {
     // the reference compares the (filtered) byte masks of consecutive bands; validity bits are equivalent
@@ -184,8 +361,13 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
       allInt = !hr.stats.notAllInt && lo >= -lim && lo <= lim && hi >= -lim && hi <= lim;
       if (allInt) maxZErr = std::max(0.5, floor(maxZErr));
     }
+    if (nd.active) { allInt = nd.allInt; maxZErr = nd.maxZErr; }    // decided by the noData filter (it knows the original values)
     hd.isInt = allInt ? 1 : 0;
   }
+  else if (nd.active) maxZErr = nd.maxZErr;
+  hd.passNoData = nd.needNoData ? 1 : 0;
+  hd.noDataVal = nd.needNoData ? nd.noDataNew : 0;
+  hd.noDataValOrig = nd.needNoData ? nd.noDataOrig : 0;
   if (maxZErr == 777) maxZErr = -0.01;    // Lerc2.cpp:210-211
   if (!isFlt)
   {
@@ -487,7 +669,11 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   // workspace: two bit masks, block sizes + offsets + scan scratch, one-sweep ranks, Huffman scratch, small stuff
   size_t need = 2 * maskBytes + 3 * (nPos8 + 1024) * 4 + 3 * ((size_t)(nPix >> 5) + 1024) * 4
     + (rq.dt <= DT_Byte ? huffmanScratchBytes(nPix, rq.nDepth) : 0) + (size_t)rq.nDepth * 16 + (1u << 16);
-  const bool fastOk = rq.nBands == 1 && rq.dOut && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
+  bool anyNoData = false;
+  if (rq.hUsesNoData) for (int i = 0; i < rq.nBands; i++) anyNoData = anyNoData || rq.hUsesNoData[i] != 0;
+  if (anyNoData && !rq.hNoDataValues) return kWrongParam;
+  if (anyNoData) need += (size_t)nPix * rq.nDepth * tb + (size_t)nPix + 8192;
+  const bool fastOk = !anyNoData && rq.nBands == 1 && rq.dOut && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
     && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, rq.nDepth, rq.nMasks > 0, rq.maxZErr);
   const u32 nWG = fastOk ? fastEncodeNumWG(rq.nRows, rq.nCols) : 0;
   need += fastOk ? fastEncodeWorkspace(rq.nRows, rq.nCols, 1) : 0;

@@ -78,6 +78,10 @@ u64 statKeyInitMin();
 u64 statKeyInitMax();
 u64 statKeyToRawBits(int dt, u64 key);
 double statKeyToDouble(int dt, u64 key);
+// noData values (Lerc.cpp:1241-1552): scan of a private copy of a band (modifies the copy and its byte mask), remap
+struct NoDataScan { u64 minKey, maxKey; u32 flags, pad; };    // flags: 1 NaN seen, 2 noData left, 4 mask modified, 8 fractional value
+void launchNoDataScan(int dt, void* data, u8* maskBytes, i64 nPix, int nDepth, double orig, NoDataScan* res, hipStream_t stream);
+void launchNoDataRemap(int dt, void* data, const u8* maskBytes, const u8* maskBits, i64 nPix, int nDepth, double from, double to, hipStream_t stream);
 // bit plane mode (Lerc2.cpp:1071-1229): counts[nDepth * 32 + 1] u32 on the device, see misc_kernels.hip
 void launchBitPlaneCounts(int dt, const void* data, const u8* maskBits, int nRows, int nCols, int nDepth, u32* counts, hipStream_t stream);
 static const int kFletcherPartials = 2 * 512;    // u64 words written by launchFletcher

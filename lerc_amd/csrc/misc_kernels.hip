@@ -381,6 +381,103 @@ void launchBandStats(int dt, const void* data, const u8* maskBits, int nRows, in
 }
 
 // ================================================================================================
+// noData values (Lerc::FilterNoDataAndNaN with a noData value, Lerc.cpp:1378-1552; integer types :1241-1374):
+// one sweep over a private copy of the band.  Per valid pixel: count the depth values that are the noData value (or
+// NaN); all of them -> the pixel leaves the mask; some -> the blob will have to carry a noData value.  NaNs turn into
+// the noData value (nDepth > 1) or 0 (nDepth 1).  Min / max / "all integers" over the remaining values.
+// ================================================================================================
+template<class T>
+__global__ void __launch_bounds__(256)
+k_nodata_scan(T* __restrict__ data, u8* __restrict__ maskBytes, i64 nPix, int nDepth, T orig, NoDataScan* res)
+{
+  constexpr bool isFlt = (DtOf<T>::v >= DT_Float);
+  u64 kMin = ~0ull, kMax = 0ull;
+  u32 flags = 0;    // 1 NaN seen, 2 noData left in a valid pixel, 4 mask modified, 8 a fractional value seen
+  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < nPix; k += (i64)gridDim.x * 256)
+  {
+    if (!maskBytes[k]) continue;
+    int bad = 0;
+    for (int m = 0; m < nDepth; m++)
+    {
+      const T z = data[k * nDepth + m];
+      if (isFlt && isNaNT(z))
+      {
+        flags |= 1u; bad++;
+        if (nDepth > 1) data[k * nDepth + m] = orig; else data[k * nDepth + m] = T(0);
+      }
+      else if (z == orig) bad++;
+      else
+      {
+        const u64 key = Key<T>::enc(z);
+        kMin = key < kMin ? key : kMin; kMax = key > kMax ? key : kMax;
+        if (isFlt && !(z == (T)floor((double)z + 0.5))) flags |= 8u;    // Lerc.h:271 IsInt
+      }
+    }
+    if (bad == nDepth) { maskBytes[k] = 0; flags |= 4u; }
+    else if (bad > 0) flags |= 2u;
+  }
+  kMin = waveMin(kMin); kMax = waveMax(kMax);
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) flags |= __shfl_xor(flags, d);
+  if (laneId() == 0)
+  {
+    if (kMin != ~0ull) atomicMin(&res->minKey, kMin);
+    if (kMax != 0ull) atomicMax(&res->maxKey, kMax);
+    if (flags) atomicOr(&res->flags, flags);
+  }
+}
+
+// data == from -> to, in valid pixels only (byte mask, bit mask, or neither)
+template<class T>
+__global__ void __launch_bounds__(256)
+k_nodata_remap(T* __restrict__ data, const u8* __restrict__ maskBytes, const u8* __restrict__ maskBits, i64 nPix, int nDepth, T from, T to)
+{
+  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < nPix; k += (i64)gridDim.x * 256)
+  {
+    if (maskBytes && !maskBytes[k]) continue;
+    if (maskBits && !maskBit(maskBits, k)) continue;
+    for (int m = 0; m < nDepth; m++) if (data[k * nDepth + m] == from) data[k * nDepth + m] = to;
+  }
+}
+
+void launchNoDataScan(int dt, void* data, u8* maskBytes, i64 nPix, int nDepth, double orig, NoDataScan* res, hipStream_t stream)
+{
+  NoDataScan init; init.minKey = ~0ull; init.maxKey = 0ull; init.flags = 0; init.pad = 0;
+  hipMemcpyAsync(res, &init, sizeof(init), hipMemcpyHostToDevice, stream);
+  hipStreamSynchronize(stream);    // `init` is a local
+  const dim3 grid((unsigned)std::min<i64>((nPix + 255) / 256, 8192)), block(256);
+  switch (dt)
+  {
+    case DT_Char:   hipLaunchKernelGGL(k_nodata_scan<signed char>, grid, block, 0, stream, (signed char*)data, maskBytes, nPix, nDepth, (signed char)orig, res); break;
+    case DT_Byte:   hipLaunchKernelGGL(k_nodata_scan<unsigned char>, grid, block, 0, stream, (unsigned char*)data, maskBytes, nPix, nDepth, (unsigned char)orig, res); break;
+    case DT_Short:  hipLaunchKernelGGL(k_nodata_scan<short>, grid, block, 0, stream, (short*)data, maskBytes, nPix, nDepth, (short)orig, res); break;
+    case DT_UShort: hipLaunchKernelGGL(k_nodata_scan<unsigned short>, grid, block, 0, stream, (unsigned short*)data, maskBytes, nPix, nDepth, (unsigned short)orig, res); break;
+    case DT_Int:    hipLaunchKernelGGL(k_nodata_scan<int>, grid, block, 0, stream, (int*)data, maskBytes, nPix, nDepth, (int)orig, res); break;
+    case DT_UInt:   hipLaunchKernelGGL(k_nodata_scan<unsigned int>, grid, block, 0, stream, (unsigned int*)data, maskBytes, nPix, nDepth, (unsigned int)orig, res); break;
+    case DT_Float:  hipLaunchKernelGGL(k_nodata_scan<float>, grid, block, 0, stream, (float*)data, maskBytes, nPix, nDepth, (float)orig, res); break;
+    case DT_Double: hipLaunchKernelGGL(k_nodata_scan<double>, grid, block, 0, stream, (double*)data, maskBytes, nPix, nDepth, orig, res); break;
+    default: break;
+  }
+}
+
+void launchNoDataRemap(int dt, void* data, const u8* maskBytes, const u8* maskBits, i64 nPix, int nDepth, double from, double to, hipStream_t stream)
+{
+  const dim3 grid((unsigned)std::min<i64>((nPix + 255) / 256, 8192)), block(256);
+  switch (dt)
+  {
+    case DT_Char:   hipLaunchKernelGGL(k_nodata_remap<signed char>, grid, block, 0, stream, (signed char*)data, maskBytes, maskBits, nPix, nDepth, (signed char)from, (signed char)to); break;
+    case DT_Byte:   hipLaunchKernelGGL(k_nodata_remap<unsigned char>, grid, block, 0, stream, (unsigned char*)data, maskBytes, maskBits, nPix, nDepth, (unsigned char)from, (unsigned char)to); break;
+    case DT_Short:  hipLaunchKernelGGL(k_nodata_remap<short>, grid, block, 0, stream, (short*)data, maskBytes, maskBits, nPix, nDepth, (short)from, (short)to); break;
+    case DT_UShort: hipLaunchKernelGGL(k_nodata_remap<unsigned short>, grid, block, 0, stream, (unsigned short*)data, maskBytes, maskBits, nPix, nDepth, (unsigned short)from, (unsigned short)to); break;
+    case DT_Int:    hipLaunchKernelGGL(k_nodata_remap<int>, grid, block, 0, stream, (int*)data, maskBytes, maskBits, nPix, nDepth, (int)from, (int)to); break;
+    case DT_UInt:   hipLaunchKernelGGL(k_nodata_remap<unsigned int>, grid, block, 0, stream, (unsigned int*)data, maskBytes, maskBits, nPix, nDepth, (unsigned int)from, (unsigned int)to); break;
+    case DT_Float:  hipLaunchKernelGGL(k_nodata_remap<float>, grid, block, 0, stream, (float*)data, maskBytes, maskBits, nPix, nDepth, (float)from, (float)to); break;
+    case DT_Double: hipLaunchKernelGGL(k_nodata_remap<double>, grid, block, 0, stream, (double*)data, maskBytes, maskBits, nPix, nDepth, from, to); break;
+    default: break;
+  }
+}
+
+// ================================================================================================
 // bit plane statistics for the integer "bit plane" mode (Lerc2::TryBitPlaneCompression, Lerc2.cpp:1071-1229):
 // for every valid pixel and its valid right / lower neighbour, per depth, how often each bit of a XOR b is set.
 // counts[m * 32 + s] = tally of bit s in depth m, counts[nDepth * 32] = number of neighbour pairs.

@@ -122,3 +122,67 @@ def basic_cases():
     cases.append(("f32-3bands-1mask", bands, dict(max_z_err=0.01, n_bands=3, mask=mb[0].copy())))
     cases.append(("u8-3bands", _cast(bands / 8, np.uint8), dict(max_z_err=0, n_bands=3)))
     return cases
+
+
+def nodata_fuzz_cases(n_iter, seed=33):
+    """Rasters with a noData value (lerc_encode_4D): inside / below / above the data range or absent from the data,
+    single pixels and whole pixels (all depths), with NaNs, masks, nDepth 1..3.  -> [(name, arr, maxZErr, kw)]"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for it in range(n_iter):
+        dt = [np.float32, np.float64, np.uint8, np.int16, np.uint16, np.int32][rng.integers(0, 6)]
+        nd = int(rng.choice([1, 1, 2, 3]))
+        r, c = int(rng.integers(8, 60)), int(rng.integers(8, 60))
+        kind = np.dtype(dt).kind
+        x = terrain(r, c, rng, amp=float(rng.choice([5, 100])), base=float(rng.choice([0, 100, 1000])), sigma=float(rng.choice([0, 0.5, 3])))
+        x = np.stack([x + k for k in range(nd)], axis=-1) if nd > 1 else x
+        if kind == "f" and rng.random() < 0.4:
+            x = np.round(x)
+        x = _cast(x, dt)
+        style = rng.integers(0, 5)
+        flat = x.reshape(-1)
+        if style == 0:
+            nod = float(flat[rng.integers(0, flat.size)])
+        elif style == 1:
+            nod = float(-9999 if kind != "u" else 0)
+        elif style == 2:
+            nod = float(32000 if np.dtype(dt).itemsize > 1 else 250)
+        elif style == 3:
+            nod = float(np.float32(-3.4e38)) if kind == "f" else float(np.iinfo(dt).min)
+        else:
+            nod = float(np.iinfo(dt).max) if kind != "f" else 1e30
+        sel = rng.random(x.shape) < rng.choice([0.0, 0.05, 0.3])
+        x = x.copy()
+        x[sel] = np.array(nod).astype(dt)
+        if nd > 1 and rng.random() < 0.5:
+            x[rng.random((r, c)) < 0.1] = np.array(nod).astype(dt)
+        if kind == "f" and rng.random() < 0.3:
+            x[rng.random(x.shape) < 0.02] = np.nan
+        e = float(rng.choice([0.01, 0.5, 2])) if kind == "f" else float(rng.choice([0, 1, 3]))
+        kw = dict(n_depth=nd, no_data=nod)
+        if rng.random() < 0.3:
+            kw["mask"] = (rng.random((r, c)) > 0.2).astype(np.uint8)
+        out.append((f"nodata{it}-{np.dtype(dt).name}-{r}x{c}x{nd}-e{e}-style{style}", x, e, kw))
+    x = np.stack([terrain(20, 30, rng) for _ in range(2)])[..., None].repeat(2, axis=-1).astype(np.float32)
+    x[0, 3:5, 4:9, 1] = -9999
+    out.append(("nodata-two-bands", x, 0.1, dict(n_depth=2, n_bands=2, no_data=[-9999, None])))
+    return out
+
+
+def check_nodata_case(T, P, name, arr, e, kw, same):
+    """T: trusted library (reference or oracle), P: the library under test.  Float rasters whose error bound the
+    noData filter drops to 0 need the lossless float codec, which P does not have: Failed(1) is the contract there."""
+    s1, s2 = T.compute_size(arr, e, **kw), P.compute_size(arr, e, **kw)
+    r1, b1 = T.encode(arr, e, **kw)
+    r2, b2 = P.encode(arr, e, **kw)
+    if r1 == 0 and arr.dtype.kind == "f" and T.blob_info(b1)[2][2] == 0:
+        assert r2 == 1 and s2[0] == 1, name
+        return
+    assert s1 == s2 and r1 == r2 and b1 == b2, name
+    if r1 != 0:
+        return
+    d1, d2 = T.decode(b1, with_nodata=True), P.decode(b1, with_nodata=True)
+    assert d1[0] == d2[0], name
+    for a, b in zip(d1[1:], d2[1:]):
+        assert same(a, b), name
+    assert T.decode(b1)[0] == P.decode(b1)[0], name    # the plain entry point refuses blobs that carry a noData value

@@ -251,3 +251,11 @@ def test_c5_tile_batch_in_one_call(P, O):
     codec.lib.lerc_amd_path_counters.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
     codec.lib.lerc_amd_path_counters(codec.h, cnt)
     assert cnt[0] == n_tiles - 2 and cnt[2] >= n_tiles - 4, list(cnt)    # the batch really went through the streaming kernels
+
+
+def test_nodata_values(P, O):
+    """lerc_encode_4D / lerc_decode_4D with per-band noData values, differential against the real reference (or the
+    oracle): sizes, blobs, decoded pixels, masks and the noData values handed back."""
+    T = capi.ref() or O
+    for name, arr, e, kw in cases.nodata_fuzz_cases(120):
+        cases.check_nodata_case(T, P, name, arr, e, kw, _same)

@@ -329,3 +329,11 @@ def test_sim_bit_plane_mode(libs):
     assert O.encode(small, 777) == S.encode(small, 777)
     f = rng.random((64, 64)).astype(np.float32)
     assert S.encode(f, 777)[0] == O.encode(f, 777)[0] == 1
+
+
+def test_sim_nodata_values(libs):
+    """lerc_encode_4D / lerc_decode_4D with per-band noData values (Lerc.cpp:1241-1552)."""
+    O, S = libs
+    T = capi.ref() or O
+    for name, arr, e, kw in cases.nodata_fuzz_cases(50):
+        cases.check_nodata_case(T, S, name, arr, e, kw, _same)
