@@ -652,7 +652,8 @@ static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double
 static void runFastEncode(Context& ctx, const FastEncodeLaunch& fl, const void* dData, u8* dOut, u64 capacity, u64 arenaBase)
 {
   static const char* kStage[4] = { "fast_stats_sizes", "fast_scan_decide", "fast_pack", "fast_checksum" };
-  for (int stage = 0; stage < 4; stage++)
+  const int nStages = dOut ? 4 : 2;    // no output buffer: the size is known after the decisions
+  for (int stage = 0; stage < nStages; stage++)
   {
     ProfScope ps(ctx, kStage[stage]);
     launchFastEncode(stage, fl.bp, fl.maxZErr, fl.cand, dData, dOut, capacity, arenaBase, fl.fb, fl.batch, ctx.activeStream());
@@ -673,7 +674,8 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   if (rq.hUsesNoData) for (int i = 0; i < rq.nBands; i++) anyNoData = anyNoData || rq.hUsesNoData[i] != 0;
   if (anyNoData && !rq.hNoDataValues) return kWrongParam;
   if (anyNoData) need += (size_t)nPix * rq.nDepth * tb + (size_t)nPix + 8192;
-  const bool fastOk = !anyNoData && rq.nBands == 1 && rq.dOut && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
+  // (a size query, dOut == nullptr, takes the first two steps of the streaming path: statistics and decisions)
+  const bool fastOk = !anyNoData && rq.nBands == 1 && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
     && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, rq.nDepth, rq.nMasks > 0, rq.maxZErr);
   const u32 nWG = fastOk ? fastEncodeNumWG(rq.nRows, rq.nCols) : 0;
   need += fastOk ? fastEncodeWorkspace(rq.nRows, rq.nCols, 1) : 0;
@@ -689,7 +691,7 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
     hipStream_t st = ctx.activeStream();
     FastEncodeLaunch fl;
     if (!prepareFastEncode(ctx, rq.dt, rq.nRows, rq.nCols, rq.maxZErr, 1, 0, false, fl)) return kFailed;
-    runFastEncode(ctx, fl, rq.dData, rq.dOut, rq.outCapacity, 0);
+    runFastEncode(ctx, fl, rq.dData, rq.dOut, rq.dOut ? (u64)rq.outCapacity : ~0ull, 0);
     FastEncodeResult* pinRes = (FastEncodeResult*)ctx.pinned(sizeof(FastEncodeResult));
     if (!pinRes) return kFailed;
     FastEncodeResult& hres = *pinRes;
@@ -699,10 +701,11 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
     if (!hres.redo)
     {
       ctx.pathCount[0]++;
-      numBytesNeeded = numBytesWritten = hres.blobSize;
+      numBytesNeeded = hres.blobSize;
+      numBytesWritten = rq.dOut ? hres.blobSize : 0;
       return kOk;
     }
-    if (hres.redoReason == 64u && hres.blobSize > rq.outCapacity) return kBufferTooSmall;
+    if (rq.dOut && hres.redoReason == 64u && hres.blobSize > rq.outCapacity) return kBufferTooSmall;
     ctx.reset();
   }
 
