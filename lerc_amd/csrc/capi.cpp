@@ -59,7 +59,8 @@ bool usesNoData(const unsigned char* pUsesNoData, int nBands)
 // shared by lerc_encode / lerc_computeCompressedSize: host pointers in, blob (optionally) out
 lerc_status encodeHost(const void* pData, unsigned dataType, int nDepth, int nCols, int nRows, int nBands, int nMasks,
                        const unsigned char* pValidBytes, double maxZErr, unsigned char* pOut, unsigned outSize,
-                       unsigned* result, bool sizeOnly, const unsigned char* pUsesNoData = nullptr, const double* noDataValues = nullptr)
+                       unsigned* result, bool sizeOnly, const unsigned char* pUsesNoData = nullptr, const double* noDataValues = nullptr,
+                       int version = kCodecVersion)
 {
   lerc_amd_context* h = threadHandle();
   if (!h) return kFailed;
@@ -79,6 +80,7 @@ lerc_status encodeHost(const void* pData, unsigned dataType, int nDepth, int nCo
   rq.dData = dData; rq.dValidBytes = dMask; rq.dt = (int)dataType; rq.nDepth = nDepth; rq.nCols = nCols; rq.nRows = nRows;
   rq.nBands = nBands; rq.nMasks = nMasks; rq.maxZErr = maxZErr;
   rq.hUsesNoData = pUsesNoData; rq.hNoDataValues = noDataValues;
+  rq.version = version;
   u32 needed = 0, written = 0;
   if (sizeOnly)
   {
@@ -172,7 +174,15 @@ lerc_status lerc_computeCompressedSizeForVersion(const void* pData, int codecVer
 {
   if (!numBytes) return kWrongParam;
   *numBytes = 0;
-  if (codecVersion >= 0 && codecVersion != kCodecVersion) return kWrongParam;
+  if (codecVersion > kCodecVersion) return kWrongParam;
+  if (codecVersion >= 0 && codecVersion < kCodecVersion)    // Lerc.cpp:339-347 -> EncodeInternal_v5; codec 2 (pre-v3 bit layout) is not built
+  {
+    if (!pData || dataType >= DT_Undefined || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0 || maxZErr < 0) return kWrongParam;
+    if (!masksArgOk(nMasks, nBands, pValidBytes)) return kWrongParam;
+    if (codecVersion < 3) return kWrongParam;
+    return encodeHost(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, nullptr, 0, numBytes, true, nullptr,
+                      nullptr, codecVersion);
+  }
   return lerc_computeCompressedSize_4D(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, numBytes,
                                        nullptr, nullptr);
 }
@@ -183,7 +193,17 @@ lerc_status lerc_encodeForVersion(const void* pData, int codecVersion, unsigned 
 {
   if (!nBytesWritten) return kWrongParam;
   *nBytesWritten = 0;
-  if (codecVersion >= 0 && codecVersion != kCodecVersion) return kWrongParam;
+  if (codecVersion > kCodecVersion) return kWrongParam;
+  if (codecVersion >= 0 && codecVersion < kCodecVersion)    // Lerc.cpp:378-386
+  {
+    if (!pData || dataType >= DT_Undefined || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0 || maxZErr < 0
+      || !pOutBuffer || !outBufferSize)
+      return kWrongParam;
+    if (!masksArgOk(nMasks, nBands, pValidBytes)) return kWrongParam;
+    if (codecVersion < 3) return kWrongParam;
+    return encodeHost(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, pOutBuffer, outBufferSize,
+                      nBytesWritten, false, nullptr, nullptr, codecVersion);
+  }
   return lerc_encode_4D(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, pOutBuffer,
                         outBufferSize, nBytesWritten, nullptr, nullptr);
 }

@@ -106,6 +106,7 @@ struct EncodeRequest
   u32 outCapacity = 0;
   const u8* hUsesNoData = nullptr;    // host [nBands] or nullptr: band carries a noData value (lerc_encode_4D)
   const double* hNoDataValues = nullptr;
+  int version = kCodecVersion;        // codec version of the blobs to write: 3..6 (lerc_encodeForVersion)
 };
 // returns an ErrCode; numBytesNeeded is always the exact blob size on kOk
 u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32& numBytesWritten);

@@ -305,7 +305,12 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   if (isFlt && nanSeen)
   {
     modifiedMask = true;    // conservative: the reference only flags bands whose mask really changed
-    if (mixedNaN && nD > 1) return kNaN;    // Lerc.cpp:1498-1501 (no noData value to stand in)
+    if (mixedNaN && nD > 1)
+    {
+      if (rq.version >= 6) return kNaN;    // Lerc.cpp:1498-1501 (no noData value to stand in)
+      ctx.lastError = "codec < 6 with NaN in some depths of a pixel only (-FLT_MAX stand-ins) is not built";
+      return kFailed;
+    }
   }
   (void)modifiedMask;
 
@@ -342,6 +347,8 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
 
   // ---- 3. what Lerc::FilterNoDataAndNaN + Lerc2::ComputeNumBytesNeededToWrite decide from the stats
   Header hd;
+  hd.version = rq.version;
+  const bool oldCodec = rq.version < 6;    // Lerc::EncodeInternal_v5 (Lerc.cpp:526-624): no all-integer promotion, no noData
   hd.nRows = nRows; hd.nCols = nCols; hd.nDepth = nD; hd.numValid = numValid; hd.dt = dt;
   hd.nBlobsMore = rq.nBands - 1 - iBand;
   std::vector<double> zMinVec(nD, 0), zMaxVec(nD, 0);
@@ -350,7 +357,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   {
     for (int m = 0; m < nD; m++) { zMinVec[m] = statKeyToDouble(dt, hMins[m]); zMaxVec[m] = statKeyToDouble(dt, hMaxs[m]); }
   }
-  if (isFlt)
+  if (isFlt && !oldCodec)
   {
     if (bandNumValid == 0) maxZErr = 0;    // "tile has no valid data" (Lerc.cpp:1479-1484)
     else
@@ -412,7 +419,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   else
   {
     if (maxZErr < 0) return kFailed;
-    if (maxZErr > 0 && raiseMask && !allInt)
+    if (maxZErr > 0 && raiseMask && !allInt && numValid > 0)    // (numValid: Lerc2.cpp:1236)
     {
       for (int c = 0; c < 9; c++)
         if (((raiseMask >> c) & 1u) && hr.stats.raiseErr[c] / facCand[c] <= maxZErr / 2) { maxZErr = errCand[c] / 2; break; }
@@ -467,9 +474,9 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     bp.checkOverflow = ((dt == DT_Int || dt == DT_UInt) && (hd.zMax - hd.zMin >= 0x7FFFFFFF)) ? 1 : 0;
     if (hd.zMin != hd.zMax)
     {
-      writeRanges = true;
-      blobSize += 2u * (u32)nD * (u32)tb;
-      const bool constDepths = (0 == memcmp(zMinVec.data(), zMaxVec.data(), nD * sizeof(double)));
+      writeRanges = hd.version >= 4;    // Lerc2.cpp:260
+      if (writeRanges) blobSize += 2u * (u32)nD * (u32)tb;
+      const bool constDepths = writeRanges && (0 == memcmp(zMinVec.data(), zMaxVec.data(), nD * sizeof(double)));
       if (!constDepths)
       {
         dSizes = ctx.allocT<u32>((size_t)nPos8 + 4);
@@ -675,7 +682,10 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   if (anyNoData && !rq.hNoDataValues) return kWrongParam;
   if (anyNoData) need += (size_t)nPix * rq.nDepth * tb + (size_t)nPix + 8192;
   // (a size query, dOut == nullptr, takes the first two steps of the streaming path: statistics and decisions)
-  const bool fastOk = !anyNoData && rq.nBands == 1 && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
+  if (rq.version < 3 || rq.version > kCodecVersion) return kWrongParam;
+  if (rq.version < 6 && anyNoData) return kWrongParam;    // Lerc.cpp:341-344
+  if (rq.version < 4 && rq.nDepth > 1) return kFailed;    // Lerc2::Set refuses (Lerc2.cpp:85-86)
+  const bool fastOk = !anyNoData && rq.version == kCodecVersion && rq.nBands == 1 && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
     && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, rq.nDepth, rq.nMasks > 0, rq.maxZErr);
   const u32 nWG = fastOk ? fastEncodeNumWG(rq.nRows, rq.nCols) : 0;
   need += fastOk ? fastEncodeWorkspace(rq.nRows, rq.nCols, 1) : 0;

@@ -2003,7 +2003,7 @@ static Err encodeBands(const T* pData, int version, int nDepth, int nCols, int n
   unsigned& numBytesWritten, const u8* pUsesNoData, const double* noDataValues)
 {
   numBytesNeeded = numBytesWritten = 0;
-  if (version >= 0 && version != kCurrentVersion) return WRONG_PARAM;    // only v6 is restated
+  if (version >= 0 && version != kCurrentVersion) return WRONG_PARAM;    // older codecs: encodeBandsOld() below
   if (pUsesNoData && !noDataValues)
     for (int i = 0; i < nBands; i++) if (pUsesNoData[i]) return WRONG_PARAM;
 
@@ -2058,6 +2058,70 @@ static Err encodeBands(const T* pData, int version, int nDepth, int nCols, int n
       band.zMinVec.assign(1, minVal); band.zMaxVec.assign(1, maxVal); band.minMaxSet = true;
     }
     unsigned nBytes = band.plan(data.data(), e, encMask);
+    if (nBytes == 0) return FAILED;
+    if ((size_t)numBytesNeeded + nBytes > (size_t)UINT_MAX) return DIMS_TOO_LARGE;
+    numBytesNeeded += nBytes;
+    if (pBuffer)
+    {
+      if ((size_t)(dst - pBuffer) + nBytes > numBytesBuffer) return BUFFER_TOO_SMALL;
+      Writer w{ dst };
+      if (!band.emit(data.data(), w)) return FAILED;
+      dst = w.p;
+    }
+  }
+  numBytesWritten = (unsigned)(dst - pBuffer);
+  return OK;
+}
+
+// Lerc::EncodeInternal_v5 (Lerc.cpp:526-624): what lerc_encodeForVersion does for codec versions 3..5.  No noData
+// filter and no all-integer promotion; a NaN becomes -FLT_MAX / -DBL_MAX, and a pixel that is NaN in every depth
+// leaves the mask (CheckForNaN :861-897, ReplaceNaNValues :901-938).  Lossless float has no Huffman mode before
+// codec 6 (Lerc2.h:130): it goes through the tiling with raw blocks.  (Codec 2 -- the pre-v3 bit layout,
+// BitStuffer2.cpp:292-425 -- is not restated.)
+template<class T>
+static Err encodeBandsOld(const T* pData, int version, int nDepth, int nCols, int nRows, int nBands, int nMasks,
+  const u8* pValidBytes, double maxZErr, unsigned& numBytesNeeded, u8* pBuffer, unsigned numBytesBuffer, unsigned& numBytesWritten)
+{
+  numBytesNeeded = numBytesWritten = 0;
+  if (version < 3 || version > 5) return WRONG_PARAM;              // Lerc2.cpp:52-62 (2 would be legal there)
+  if (version < 4 && nDepth > 1) return FAILED;                   // Lerc2::Set refuses (Lerc2.cpp:85-86)
+  Band band;
+  band.hd.version = version;
+  u8* dst = pBuffer;
+  const size_t nPix = (size_t)nCols * nRows, nElem = nPix * nDepth;
+  std::vector<T> data(nElem);
+  std::vector<u8> mask(nPix), prevMask;
+  bool havePrev = false;
+  Mask bitMask;
+  const bool isFlt = std::is_floating_point<T>::value;
+  const T nanStandIn = (T)(std::is_same<T, float>::value ? -FLT_MAX : -DBL_MAX);
+
+  for (int iBand = 0; iBand < nBands; iBand++)
+  {
+    bool encMask = (iBand == 0);
+    const T* arr = pData + nElem * iBand;
+    const u8* bm = (nMasks > 0) ? (pValidBytes + ((nMasks > 1) ? nPix * iBand : 0)) : nullptr;
+    memcpy(data.data(), arr, nElem * sizeof(T));
+    if (bm) memcpy(mask.data(), bm, nPix); else memset(mask.data(), 1, nPix);
+    if (isFlt)
+      for (size_t k = 0; k < nPix; k++)
+      {
+        if (!mask[k]) continue;
+        int cntNaN = 0;
+        for (int m = 0; m < nDepth; m++)
+          if (std::isnan((double)data[k * nDepth + m])) { cntNaN++; data[k * nDepth + m] = nanStandIn; }
+        if (cntNaN == nDepth) mask[k] = 0;
+      }
+    if (iBand > 0 && havePrev && memcmp(mask.data(), prevMask.data(), nPix)) encMask = true;    // MasksDiffer, Lerc.cpp:572,586
+    if (iBand < nBands - 1) { prevMask = mask; havePrev = true; }
+    if (encMask)
+    {
+      const bool allValid = !memchr(mask.data(), 0, nPix);
+      if (!allValid) bytesToBits(mask.data(), nCols, nRows, bitMask);
+      if (!band.setDims(nDepth, nCols, nRows, allValid ? nullptr : bitMask.bits.data())) return FAILED;
+    }
+    band.zMinVec.clear(); band.zMaxVec.clear(); band.minMaxSet = false;
+    unsigned nBytes = band.plan(data.data(), maxZErr, encMask);
     if (nBytes == 0) return FAILED;
     if ((size_t)numBytesNeeded + nBytes > (size_t)UINT_MAX) return DIMS_TOO_LARGE;
     numBytesNeeded += nBytes;
@@ -2260,7 +2324,17 @@ lerc_status lerc_computeCompressedSizeForVersion(const void* pData, int codecVer
 {
   if (!numBytes) return WRONG_PARAM;
   *numBytes = 0;
-  if (codecVersion >= 0 && codecVersion != kCurrentVersion) return WRONG_PARAM;    // old codec versions: not restated
+  if (codecVersion >= 0 && codecVersion <= 5)    // Lerc.cpp:339-347
+  {
+    if (!pData || dataType >= DT_UNDEF || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0 || maxZErr < 0) return WRONG_PARAM;
+    if (!masksArgOk(nMasks, nBands, pValidBytes)) return WRONG_PARAM;
+    unsigned written = 0;
+    ORC_DISPATCH(dataType,
+      if (!dimsOk(nDepth, nCols, nRows, sizeof(TT))) return DIMS_TOO_LARGE;
+      return encodeBandsOld((const TT*)pData, codecVersion, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, *numBytes,
+        nullptr, 0, written))
+  }
+  if (codecVersion > kCurrentVersion) return WRONG_PARAM;
   return lerc_computeCompressedSize_4D(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr,
     numBytes, nullptr, nullptr);
 }
@@ -2271,7 +2345,20 @@ lerc_status lerc_encodeForVersion(const void* pData, int codecVersion, unsigned 
 {
   if (!nBytesWritten) return WRONG_PARAM;
   *nBytesWritten = 0;
-  if (codecVersion >= 0 && codecVersion != kCurrentVersion) return WRONG_PARAM;
+  if (codecVersion >= 0 && codecVersion <= 5)    // Lerc.cpp:378-386
+  {
+    if (!pData || dataType >= DT_UNDEF || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0 || maxZErr < 0
+      || !pOutBuffer || !outBufferSize)
+      return WRONG_PARAM;
+    if (!masksArgOk(nMasks, nBands, pValidBytes)) return WRONG_PARAM;
+    unsigned needed = 0;
+    ORC_DISPATCH(dataType,
+      if (!dimsOk(nDepth, nCols, nRows, sizeof(TT))) return DIMS_TOO_LARGE;
+      memset(pOutBuffer, 0, outBufferSize);
+      return encodeBandsOld((const TT*)pData, codecVersion, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, needed,
+        pOutBuffer, outBufferSize, *nBytesWritten))
+  }
+  if (codecVersion > kCurrentVersion) return WRONG_PARAM;
   return lerc_encode_4D(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, pOutBuffer,
     outBufferSize, nBytesWritten, nullptr, nullptr);
 }

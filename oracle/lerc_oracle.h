@@ -18,8 +18,7 @@
  *
  * Not restated (returns Failed / WrongParam, documented in DESIGN.md "out of scope"):
  *   - lossless float/double (maxZError == 0 on DT_Float/DT_Double -> fpl_* path, Lerc2.cpp:305-328)
- *   - Lerc1 "CntZImage" legacy blobs, codec versions < 3 bit layout (BitStuffer2.cpp:291-425)
- *   - lerc_encodeForVersion with codecVersion in [2,5]
+ *   - Lerc1 "CntZImage" legacy blobs, codec version 2 (no checksum, pre-v3 bit layout, BitStuffer2.cpp:291-425)
  */
 #ifndef LERC_ORACLE_H
 #define LERC_ORACLE_H

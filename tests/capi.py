@@ -136,6 +136,20 @@ class LercLib:
                                          uses.ctypes.data, vals.ctypes.data)
         return rc, buf[:written.value].tobytes()
 
+    def encode_for_version(self, arr, version, max_z_err, n_depth=1, n_bands=1, mask=None):
+        """lerc_computeCompressedSizeForVersion + lerc_encodeForVersion; returns (status, size status, size, blob bytes)"""
+        a, n_rows, n_cols = self._dims(arr, n_depth, n_bands)
+        n_masks, mptr, m = self._mask(mask, n_bands)
+        size = ct.c_uint(0)
+        rc0 = self.lib.lerc_computeCompressedSizeForVersion(a.ctypes.data, int(version), dt_code(a.dtype), n_depth, n_cols,
+                                                            n_rows, n_bands, n_masks, mptr, float(max_z_err), ct.byref(size))
+        cap = int(size.value) if rc0 == 0 else a.nbytes + 4096
+        buf = np.empty(max(cap, 1), np.uint8)
+        written = ct.c_uint(0)
+        rc = self.lib.lerc_encodeForVersion(a.ctypes.data, int(version), dt_code(a.dtype), n_depth, n_cols, n_rows, n_bands,
+                                            n_masks, mptr, float(max_z_err), buf.ctypes.data, cap, ct.byref(written))
+        return rc, rc0, size.value, buf[:written.value].tobytes()
+
     def blob_info(self, blob):
         b = np.frombuffer(blob, np.uint8)
         info = (ct.c_uint * 11)()

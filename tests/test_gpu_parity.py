@@ -259,3 +259,15 @@ def test_nodata_values(P, O):
     T = capi.ref() or O
     for name, arr, e, kw in cases.nodata_fuzz_cases(120):
         cases.check_nodata_case(T, P, name, arr, e, kw, _same)
+
+
+def test_encode_for_older_codec_versions(P, O):
+    """lerc_encodeForVersion / lerc_computeCompressedSizeForVersion, codec 3..5 (Lerc.cpp:526-624): status, size and
+    blob bytes as the oracle's (itself pinned on the real reference by tests/test_oracle_vs_reference.py), and against
+    the real reference when it travelled."""
+    for name, arr, ver, e, kw in cases.old_codec_cases(200):
+        cases.check_old_codec_case(O, P, name, arr, ver, e, kw, _same)
+    R = capi.ref()
+    if R is not None:
+        for name, arr, ver, e, kw in cases.old_codec_cases(100, seed=72):
+            cases.check_old_codec_case(R, P, name, arr, ver, e, kw, _same)

@@ -123,3 +123,9 @@ def test_fletcher32(O):
         b = np.frombuffer(blob, np.uint8)
         stored = int(np.frombuffer(blob[10:14], np.uint32)[0])
         assert O.lib.orc_fletcher32(b[14:].ctypes.data, len(blob) - 14) == stored
+
+
+def test_old_codec_versions(O):
+    """lerc_encodeForVersion / lerc_computeCompressedSizeForVersion for codec 3..5 (Lerc.cpp:526-624)."""
+    for name, arr, ver, e, kw in cases.old_codec_cases(250):
+        cases.check_old_codec_case(R, O, name, arr, ver, e, kw, _same)

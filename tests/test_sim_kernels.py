@@ -337,3 +337,11 @@ def test_sim_nodata_values(libs):
     T = capi.ref() or O
     for name, arr, e, kw in cases.nodata_fuzz_cases(50):
         cases.check_nodata_case(T, S, name, arr, e, kw, _same)
+
+
+def test_sim_encode_for_older_codec_versions(libs):
+    """lerc_encodeForVersion, codec 3..5: header layouts, no ranges before 4, no slice differences before 5,
+    raw Huffman only from 4, lossless float as raw blocks, NaN -> mask, no all-integer promotion."""
+    O, S = libs
+    for name, arr, ver, e, kw in cases.old_codec_cases(60):
+        cases.check_old_codec_case(O, S, name, arr, ver, e, kw, _same)
