@@ -306,7 +306,11 @@ void lerc_amd_destroy(lerc_amd_context* h) { delete h; }
 
 void lerc_amd_set_stream(lerc_amd_context* h, void* hipStream) { if (h) h->ctx.setStream((hipStream_t)hipStream); }
 
-const char* lerc_amd_last_error(lerc_amd_context* h) { return h ? h->ctx.lastError.c_str() : "no context"; }
+const char* lerc_amd_last_error(lerc_amd_context* h)
+{
+  if (!h) h = threadHandle();    // nullptr: the calling thread's context behind the stock entry points
+  return h ? h->ctx.lastError.c_str() : "no context";
+}
 
 lerc_status lerc_amd_encode_device(lerc_amd_context* h, const void* dData, unsigned int dataType, int nDepth, int nCols,
   int nRows, int nBands, int nMasks, const unsigned char* dValidBytes, double maxZErr, unsigned char* dOutBuffer,

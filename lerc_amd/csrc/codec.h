@@ -46,6 +46,8 @@ public:
   // bump allocation out of one device slab; reserve() may re-allocate (invalidates earlier pointers)
   bool reserve(size_t bytes);
   void reset() { m_used = 0; }
+  size_t used() const { return m_used; }
+  void rewind(size_t mark) { m_used = mark; }    // gives back everything allocated since used() returned mark
   void* alloc(size_t bytes, size_t align = 256);
   template<class T> T* allocT(size_t n) { return (T*)alloc(n * sizeof(T)); }
 

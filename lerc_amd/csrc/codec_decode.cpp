@@ -5,6 +5,7 @@
 // only sequential piece), everything that touches pixels or the block stream is a HIP kernel.
 #include "codec.h"
 #include "huffman.h"
+#include "fpl.h"
 #include "tile_fast.h"
 #include <functional>
 
@@ -240,6 +241,8 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   }
   need += maxSub * 4 + maxSub / nD * 2 + 5 * (maxChunks + 1024) * 4 + (dt <= DT_Byte ? huffmanScratchBytes(nPix, nD) : 0);
   need += fastBandWorkspace(nRows, nCols, rq.blobSize) + 4096;    // streaming path tables
+  for (int i = 0; i < rq.nBands; i++)
+    if (bands[i].hd.tryHuffmanFlt()) { need += fplDecodeScratchBytes(nPix * nD, tb); break; }
   if (!ctx.reserve(need)) return kFailed;
 
   const u8* dBlob = rq.dBlob;
@@ -286,7 +289,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     // for such bands the ranges and mode bytes sit inside the header bytes we already hold)
     u32 fastDataBegin = 0;
     bool fastBand = false;
-    if (allowFast && bd.numBytesMask == 0 && hd.numValid == (int)nPix && hd.zMin != hd.zMax && hd.version >= 3
+    if (allowFast && bd.numBytesMask == 0 && hd.numValid == (int)nPix && hd.zMin != hd.zMax && hd.version >= 3 && hd.maxZErr > 0
       && fastDecodeEligible(dt, hd.version, hd.mbSize, nRows, nCols, nD, true)
       && ((uintptr_t)dBand & 15) == 0 && ((uintptr_t)dOutBand & 15) == 0)
     {
@@ -415,11 +418,15 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     }
     if (imageMode != IEM_Tiling)
     {
-      if (!hd.tryHuffmanInt() || !(imageMode == IEM_DeltaHuffman || (hd.version >= 4 && imageMode == IEM_Huffman)))
+      if (hd.tryHuffmanFlt())
       {
-        ctx.lastError = "lossless float / double stream (IEM_DeltaDeltaHuffman) is outside this library's scope";
-        return kFailed;
+        if (imageMode != IEM_DeltaDeltaHuffman) return kFailed;    // Lerc2.cpp:674-678
+        const u32 rc = decodeLosslessFloat(ctx, dt, rq.hBlob ? rq.hBlob + bd.offset : nullptr, dBand, (u32)(at - bd.offset), blobEnd,
+                                           nRows, nCols, nD, dOutBand);
+        if (rc != kOk) return rc;
+        continue;
       }
+      if (!(imageMode == IEM_DeltaHuffman || (hd.version >= 4 && imageMode == IEM_Huffman))) return kFailed;
       const u32 rc = decodeHuffman(ctx, dt, rq.hBlob ? rq.hBlob + bd.offset : nullptr, dBand, (u32)(at - bd.offset), blobEnd,
                                    imageMode, dMask, nRows, nCols, nD, hd.version, dOutBand, dStatus);
       if (rc != kOk) return rc;

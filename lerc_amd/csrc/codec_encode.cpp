@@ -5,6 +5,7 @@
 // order).  Every sweep over pixels is a HIP kernel; the host only sees a few scalars per band.
 #include "codec.h"
 #include "huffman.h"
+#include "fpl.h"
 #include "tile_fast.h"
 #include <cfloat>
 #include <functional>
@@ -20,6 +21,7 @@ namespace {
 
 struct MaskState    // what the reference keeps inside its Lerc2 object between bands
 {
+  u32 fplStale = 0;    // bytes of lossless float planes that were coded but not written (see encodeBand)
   bool allValid = true;
   int numValid = 0;
   u8* dBits = nullptr;          // device bit mask (valid when !allValid)
@@ -435,7 +437,9 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   if (needMask && encMask) rleEncode(ms.hBits.data(), ms.hBits.size(), rle);
   u32 blobSize = headerBytes(hd.version) + 4 + (u32)rle.size();
 
-  enum Payload { P_NONE, P_TILING, P_ONESWEEP, P_HUFFMAN } payload = P_NONE;
+  enum Payload { P_NONE, P_TILING, P_ONESWEEP, P_HUFFMAN, P_FLOAT } payload = P_NONE;
+  FplPlan fpl;
+  u32 fplPlanes = 0;    // bytes of this band's coded planes, if they were made
   bool writeRanges = false;
   int imageMode = IEM_Tiling;
   HuffmanPlan huff;
@@ -499,8 +503,16 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
         }
         else if (hd.tryHuffmanFlt())
         {
-          ctx.lastError = "lossless float / double (maxZErr == 0) is outside this library's scope";
-          return kFailed;
+          // lossless float / double: predictor + byte planes + entropy coding, kept if it beats the (raw) blocks by 10 % (Lerc2.cpp:305-328)
+          if (nd.active) { ctx.lastError = "lossless float / double together with a noData value is not built"; return kFailed; }
+          if (!planLosslessFloat(ctx, dt, dData, dByteMask, nRows, nCols, nD, fpl)) return kFailed;
+          // The reference keeps the coded planes inside its Lerc2 object until a band writes them, and only the
+          // nDepth == 1 entry drops planes left over from a band that did not (fpl_Lerc2Ext.cpp:432-452): with
+          // nDepth > 1 they count into the next band's length (every later band of a size query, :391-403).
+          if (nD == 1) ms.fplStale = 0;
+          fplPlanes = fpl.nBytes - 1;
+          nBytesHuffman = 1 + ms.fplStale + fplPlanes;
+          if ((double)nBytesHuffman < (double)nBytesTiling * 0.9) { payload = P_FLOAT; imageMode = IEM_DeltaDeltaHuffman; nBytesData = nBytesHuffman; }
         }
 
         const size_t nBytesOneSweep = (size_t)tb * nD * (size_t)numValid;
@@ -525,6 +537,14 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   if ((size_t)blobSize > (size_t)INT_MAX) return kFailed;
   hd.blobSize = (int)blobSize;
   bandBytes = blobSize;
+  if (fplPlanes)
+  {
+    if (dBandOut && payload == P_FLOAT)
+    {
+      if (ms.fplStale) { ctx.lastError = "lossless float: planes of an earlier band would be written again (reference quirk, not reproduced)"; return kFailed; }
+    }
+    else ms.fplStale += fplPlanes;
+  }
   if (!dBandOut) return kOk;    // size query
   if (blobSize > capacityLeft) return kBufferTooSmall;
 
@@ -568,6 +588,10 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
       launchExclusiveScan(dCounts, dBase, (u32)nGroups, dScr, st);
       launchOneSweep(true, dData, dPayload, dBits, dBase, nPix, nD * tb, st);
     }
+  }
+  else if (payload == P_FLOAT)
+  {
+    if (!emitLosslessFloat(ctx, fpl, dPayload)) return kFailed;
   }
   else if (payload == P_HUFFMAN)
   {
@@ -681,6 +705,7 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   if (rq.hUsesNoData) for (int i = 0; i < rq.nBands; i++) anyNoData = anyNoData || rq.hUsesNoData[i] != 0;
   if (anyNoData && !rq.hNoDataValues) return kWrongParam;
   if (anyNoData) need += (size_t)nPix * rq.nDepth * tb + (size_t)nPix + 8192;
+  if (rq.dt >= DT_Float && rq.maxZErr == 0 && rq.version >= 6) need += fplEncodeScratchBytes(nPix * rq.nDepth, tb);
   // (a size query, dOut == nullptr, takes the first two steps of the streaming path: statistics and decisions)
   if (rq.version < 3 || rq.version > kCodecVersion) return kWrongParam;
   if (rq.version < 6 && anyNoData) return kWrongParam;    // Lerc.cpp:341-344

@@ -1,0 +1,612 @@
+// fpl_kernels.hip -- device side of the lossless float / double image mode (IEM_DeltaDeltaHuffman).
+//
+// Reference counterparts: UnitTypes::doFloatTransform / setRowsDerivative / setCrossDerivative / restoreBlockSequence /
+// restoreCrossBytes (fpl_UnitTypes.cpp:34-150, :302-357, :436-517, :626-697, :775-849), testBlocksSize and getBestLevel2
+// (fpl_Lerc2Ext.cpp:167-322), setDerivative / restoreSequence (:112-165), encodePackBits / decodePackBits /
+// getPackBitsSize (fpl_EsriHuffman.cpp:37-236).
+//
+// The reference walks every array front to back (or back to front); here each of those walks is either elementwise
+// (a difference only needs the ORIGINAL neighbours) or a prefix sum (the inverse), so it runs as one thread per element
+// resp. as a scan.  The two "which predictor / which level is best" decisions are taken on the host from histograms of
+// exactly the bytes the reference samples (every 7th byte of its test blocks / snippets).
+#include "fpl_dev.h"
+#include "wave_utils.h"
+
+namespace lerc {
+
+namespace {
+
+template<int U> struct UnitOf;
+template<> struct UnitOf<4> { typedef u32 T; };
+template<> struct UnitOf<8> { typedef u64 T; };
+
+// float bits: sign | exponent | mantissa  ->  exponent | sign | mantissa (fpl_UnitTypes.cpp:39-65); doubles stay as they are
+__device__ __forceinline__ u32 fplForward(u32 a) { return (a & 0x007FFFFFu) | (((a >> 23) & 0xFFu) << 24) | ((a >> 31) << 23); }
+__device__ __forceinline__ u32 fplBackward(u32 a) { return (a & 0x007FFFFFu) | (((a >> 24) & 0xFFu) << 23) | (((a >> 23) & 1u) << 31); }
+__device__ __forceinline__ u64 fplForward(u64 a) { return a; }
+__device__ __forceinline__ u64 fplBackward(u64 a) { return a; }
+
+// mantissa and the bits above it are differenced apart (SUB32_BIT_FLT / ADD32_BIT_FLT, SUB64_BIT_DBL / ADD64_BIT_DBL)
+__device__ __forceinline__ u32 fplSub(u32 a, u32 b) { return ((a - b) & 0x007FFFFFu) | ((((a >> 23) - (b >> 23)) & 0x1FFu) << 23); }
+__device__ __forceinline__ u32 fplAdd(u32 a, u32 b) { return ((a + b) & 0x007FFFFFu) | ((((a >> 23) + (b >> 23)) & 0x1FFu) << 23); }
+__device__ __forceinline__ u64 fplSub(u64 a, u64 b)
+{
+  return ((a - b) & 0x000FFFFFFFFFFFFFull) | ((((a >> 52) - (b >> 52)) & 0xFFFull) << 52);
+}
+__device__ __forceinline__ u64 fplAdd(u64 a, u64 b)
+{
+  return ((a + b) & 0x000FFFFFFFFFFFFFull) | ((((a >> 52) + (b >> 52)) & 0xFFFull) << 52);
+}
+
+__device__ __forceinline__ bool isNaNBits(u32 a) { return (a & 0x7FFFFFFFu) > 0x7F800000u; }
+__device__ __forceinline__ bool isNaNBits(u64 a) { return (a & 0x7FFFFFFFFFFFFFFFull) > 0x7FF0000000000000ull; }
+
+template<int U>
+__device__ __forceinline__ typename UnitOf<U>::T loadUnit(const void* __restrict__ data, const u8* __restrict__ byteMask, const FplGeom& g, i64 e)
+{
+  typedef typename UnitOf<U>::T T;
+  T x = ((const T*)data)[e];
+  if (g.nanToZero && isNaNBits(x) && (!byteMask || byteMask[e])) x = 0;
+  return fplForward(x);
+}
+
+// the element at e under the three predictors: none, difference along the row, difference along row and column
+template<int U>
+__device__ __forceinline__ void predictAll(const void* __restrict__ data, const u8* __restrict__ byteMask, const FplGeom& g, i64 e,
+                                           typename UnitOf<U>::T out[3])
+{
+  typedef typename UnitOf<U>::T T;
+  const i64 r = e / g.cols, c = e - r * g.cols;
+  const T u = loadUnit<U>(data, byteMask, g, e);
+  const T d1 = (c >= 1) ? fplSub(u, loadUnit<U>(data, byteMask, g, e - 1)) : u;
+  T d2 = d1;
+  if (r >= 1)
+  {
+    const T ua = loadUnit<U>(data, byteMask, g, e - g.cols);
+    const T d1a = (c >= 1) ? fplSub(ua, loadUnit<U>(data, byteMask, g, e - g.cols - 1)) : ua;
+    d2 = fplSub(d1, d1a);
+  }
+  out[0] = u; out[1] = d1; out[2] = d2;
+}
+
+// finite difference of order o (0..5) of a byte sequence, x[j] = the byte j places back
+__device__ __forceinline__ u32 byteDifference(const u32 x[6], int o)
+{
+  switch (o)
+  {
+    case 0: return x[0] & 255u;
+    case 1: return (x[0] - x[1]) & 255u;
+    case 2: return (x[0] - 2u * x[1] + x[2]) & 255u;
+    case 3: return (x[0] - 3u * x[1] + 3u * x[2] - x[3]) & 255u;
+    case 4: return (x[0] - 4u * x[1] + 6u * x[2] - 4u * x[3] + x[4]) & 255u;
+    default: return (x[0] - 5u * x[1] + 10u * x[2] - 10u * x[3] + 5u * x[4] - x[5]) & 255u;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// which predictor: histograms over the reference's test blocks (fpl_Lerc2Ext.cpp:57-101, :167-232)
+// ------------------------------------------------------------------------------------------------
+template<int U>
+__global__ void __launch_bounds__(256)
+k_fpl_predictor_samples(const void* __restrict__ data, const u8* __restrict__ byteMask, FplGeom g, const FplSpan* __restrict__ blocks,
+                        u32* __restrict__ histos)
+{
+  typedef typename UnitOf<U>::T T;
+  __shared__ u32 s_h[3 * 2 * U * 256];
+  for (int i = threadIdx.x; i < 3 * 2 * U * 256; i += 256) s_h[i] = 0;
+  __syncthreads();
+  const FplSpan sp = blocks[blockIdx.x];
+  const i64 nSamples = (sp.len + kFplPrime - 1) / kFplPrime;
+  for (i64 k = threadIdx.x; k < nSamples; k += 256)
+  {
+    const i64 i = k * kFplPrime, e = sp.start + i;
+    T v[3], w[3] = { 0, 0, 0 };
+    predictAll<U>(data, byteMask, g, e, v);
+    if (i > 0) predictAll<U>(data, byteMask, g, e - 1, w);
+    for (int p = 0; p < 3; p++)
+      for (int b = 0; b < U; b++)
+      {
+        const u32 x = (u32)(v[p] >> (8 * b)) & 255u;
+        const u32 y = (i > 0) ? (x - ((u32)(w[p] >> (8 * b)) & 255u)) & 255u : x;    // setDerivativePrime (:81-95)
+        atomicAdd(&s_h[((p * 2 + 0) * U + b) * 256 + x], 1u);
+        atomicAdd(&s_h[((p * 2 + 1) * U + b) * 256 + y], 1u);
+      }
+  }
+  __syncthreads();
+  u32* out = histos + (size_t)blockIdx.x * (3 * 2 * U * 256);
+  for (int i = threadIdx.x; i < 3 * 2 * U * 256; i += 256) out[i] = s_h[i];
+}
+
+template<int U>
+__global__ void __launch_bounds__(256)
+k_fpl_predict(const void* __restrict__ data, const u8* __restrict__ byteMask, FplGeom g, int predictor, typename UnitOf<U>::T* __restrict__ units)
+{
+  typedef typename UnitOf<U>::T T;
+  const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (e >= g.nElem) return;
+  T v[3];
+  predictAll<U>(data, byteMask, g, e, v);
+  units[e] = v[predictor];
+}
+
+// ------------------------------------------------------------------------------------------------
+// which extra difference order per byte plane: histograms over the reference's snippets (:237-322)
+// ------------------------------------------------------------------------------------------------
+template<int U>
+__global__ void __launch_bounds__(256)
+k_fpl_level_samples(const typename UnitOf<U>::T* __restrict__ units, FplGeom g, const FplSpan* __restrict__ snippets, u32 nSnippets,
+                    u32* __restrict__ histos)
+{
+  __shared__ u32 s_h[kFplLevels * 256];
+  for (int i = threadIdx.x; i < kFplLevels * 256; i += 256) s_h[i] = 0;
+  __syncthreads();
+  const FplSpan sp = snippets[blockIdx.x];
+  const int b = (int)blockIdx.y;
+  const i64 nSamples = (sp.len + kFplPrime - 1) / kFplPrime;
+  for (i64 k = threadIdx.x; k < nSamples; k += 256)
+  {
+    const i64 off = k * kFplPrime, i = sp.start + off;
+    u32 x[6];
+    for (int j = 0; j < 6; j++) x[j] = (j <= off) ? (u32)(units[i - j] >> (8 * b)) & 255u : 0u;
+    for (int l = 0; l < kFplLevels; l++)
+    {
+      const int o = (off < l) ? (int)off : l;    // the first bytes of a snippet keep their lower order
+      atomicAdd(&s_h[l * 256 + byteDifference(x, o)], 1u);
+    }
+  }
+  __syncthreads();
+  u32* out = histos + ((size_t)b * nSnippets + blockIdx.x) * (kFplLevels * 256);
+  for (int i = threadIdx.x; i < kFplLevels * 256; i += 256) out[i] = s_h[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// the byte planes as they are entropy coded (:557-567 + setDerivative), and their histograms
+// ------------------------------------------------------------------------------------------------
+template<int U>
+__global__ void __launch_bounds__(256)
+k_fpl_symbols(const typename UnitOf<U>::T* __restrict__ units, FplGeom g, FplLevels lv, i64 planeStride, u8* __restrict__ planes,
+              u32* __restrict__ histos)
+{
+  typedef typename UnitOf<U>::T T;
+  __shared__ u32 s_h[U * 256];
+  for (int i = threadIdx.x; i < U * 256; i += 256) s_h[i] = 0;
+  __syncthreads();
+  const i64 i0 = ((i64)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 < g.nElem)
+  {
+    T p[9];    // p[5 + k] = element i0 + k
+    for (int k = -5; k < 4; k++) p[5 + k] = (i0 + k >= 0 && i0 + k < g.nElem) ? units[i0 + k] : (T)0;
+    for (int b = 0; b < U; b++)
+    {
+      const int L = lv.level[b];
+      u32 word = 0;
+      for (int k = 0; k < 4; k++)
+      {
+        const i64 i = i0 + k;
+        if (i >= g.nElem) break;
+        u32 x[6];
+        for (int j = 0; j < 6; j++) x[j] = (u32)(p[5 + k - j] >> (8 * b)) & 255u;
+        const u32 s = byteDifference(x, (i < L) ? (int)i : L);
+        word |= s << (8 * k);
+        atomicAdd(&s_h[b * 256 + s], 1u);
+      }
+      u8* dst = planes + (size_t)b * planeStride + i0;    // planeStride is a multiple of 16
+      if (i0 + 3 < g.nElem) *reinterpret_cast<u32*>(dst) = word;
+      else for (int k = 0; i0 + k < g.nElem; k++) dst[k] = (u8)(word >> (8 * k));
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < U * 256; i += 256) if (s_h[i]) atomicAdd(&histos[i], s_h[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// inclusive scans (identity 0 for both operators): 1024 elements per workgroup, three kernels
+// ------------------------------------------------------------------------------------------------
+struct ScanMax { template<class X> __device__ __forceinline__ X operator()(X a, X b) const { return a > b ? a : b; } };
+struct ScanSum { template<class X> __device__ __forceinline__ X operator()(X a, X b) const { return (X)(a + b); } };
+
+// inclusive scan of one value per thread over the 256 threads of a workgroup; returns the EXCLUSIVE prefix of the thread
+template<class X, class Op>
+__device__ __forceinline__ X workgroupExclusive(X v, Op op, X* s_wave /* [4] */, X& total)
+{
+  const int lane = laneId(), w = waveId();
+  X inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const X t = __shfl_up(inc, (unsigned)d); if (lane >= d) inc = op(t, inc); }
+  X exc = __shfl_up(inc, 1u);
+  if (lane == 0) exc = 0;
+  if (lane == 63) s_wave[w] = inc;
+  __syncthreads();
+  X before = 0;
+  for (int i = 0; i < w; i++) before = op(before, s_wave[i]);
+  total = op(op(op(s_wave[0], s_wave[1]), s_wave[2]), s_wave[3]);
+  __syncthreads();
+  return op(before, exc);
+}
+
+template<class T, class Op>
+__global__ void __launch_bounds__(256) k_gscan_local(T* __restrict__ data, u32 n, T* __restrict__ partial)
+{
+  __shared__ u32 s_wave[4];
+  const Op op;
+  const u32 i0 = blockIdx.x * 1024u + threadIdx.x * 4u;
+  u32 v[4];
+  for (int k = 0; k < 4; k++) v[k] = (i0 + k < n) ? (u32)data[i0 + k] : 0u;
+  for (int k = 1; k < 4; k++) v[k] = (u32)(T)op(v[k - 1], v[k]);
+  u32 total;
+  const u32 before = workgroupExclusive<u32, Op>(v[3], op, s_wave, total);
+  for (int k = 0; k < 4; k++) if (i0 + k < n) data[i0 + k] = (T)op(before, v[k]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (T)total;
+}
+
+template<class T, class Op>
+__global__ void __launch_bounds__(256) k_gscan_partials(T* __restrict__ partial, u32 nPart)
+{
+  __shared__ u32 s_wave[4];
+  const Op op;
+  u32 carry = 0;
+  for (u32 base = 0; base < nPart; base += 256u)
+  {
+    const u32 i = base + threadIdx.x;
+    const u32 v = (i < nPart) ? (u32)partial[i] : 0u;
+    u32 total;
+    const u32 before = workgroupExclusive<u32, Op>(v, op, s_wave, total);
+    if (i < nPart) partial[i] = (T)op(carry, before);
+    carry = (u32)(T)op(carry, total);
+  }
+}
+
+template<class T, class Op>
+__global__ void __launch_bounds__(256) k_gscan_add(T* __restrict__ data, u32 n, const T* __restrict__ partial)
+{
+  const Op op;
+  const u32 i0 = blockIdx.x * 1024u + threadIdx.x * 4u;
+  const T before = partial[blockIdx.x];
+  for (int k = 0; k < 4; k++) if (i0 + k < n) data[i0 + k] = (T)op(before, data[i0 + k]);
+}
+
+template<class T, class Op>
+void inclusiveScan(T* data, u32 n, T* scratch, hipStream_t st)
+{
+  if (n == 0) return;
+  const u32 nPart = (n + 1023u) / 1024u;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gscan_local<T, Op>), dim3(nPart), dim3(256), 0, st, data, n, scratch);
+  if (nPart == 1) return;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gscan_partials<T, Op>), dim3(1), dim3(256), 0, st, scratch, nPart);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gscan_add<T, Op>), dim3(nPart), dim3(256), 0, st, data, n, (const T*)scratch);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PackBits.  The reference's greedy scan (fpl_EsriHuffman.cpp:79-236) cuts every run of equal bytes, counted from
+// the run's first byte, into tokens of 129 and a remainder: 2 .. 128 bytes make one more run token, a single byte is
+// a literal; literals that touch are grouped by 128 behind a count byte.  Everything a position emits therefore
+// follows from where its run starts and where its stretch of literals starts -- two max-scans -- and the stream
+// offsets are a sum-scan.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool pbRunEnd(const u8* __restrict__ s, u32 n, u32 i) { return i + 1u >= n || s[i] != s[i + 1u]; }
+__device__ __forceinline__ bool pbLiteral(const u8* __restrict__ s, u32 n, const u32* __restrict__ runStart, u32 i)
+{
+  return pbRunEnd(s, n, i) && ((i - runStart[i] + 1u) % 129u) == 1u;
+}
+
+__global__ void __launch_bounds__(256) k_pb_run_start(const u8* __restrict__ s, u32 n, u32* __restrict__ runStart)
+{
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) runStart[i] = (i > 0 && s[i] != s[i - 1u]) ? i : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_pb_lit_start(const u8* __restrict__ s, u32 n, const u32* __restrict__ runStart, u32* __restrict__ litStart)
+{
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const bool lit = pbLiteral(s, n, runStart, i);
+  litStart[i] = (lit && i > 0 && !pbLiteral(s, n, runStart, i - 1u)) ? i : 0u;
+}
+
+__device__ __forceinline__ u32 pbCost(const u8* __restrict__ s, u32 n, const u32* __restrict__ runStart, const u32* __restrict__ litStart, u32 i)
+{
+  const u32 len = i - runStart[i] + 1u, rem = len % 129u;
+  u32 c = (rem == 0u) ? 2u : 0u;
+  if (pbRunEnd(s, n, i))
+  {
+    if (rem >= 2u) c += 2u;
+    if (rem == 1u) c += 1u + (((i - litStart[i]) % 128u) == 0u ? 1u : 0u);
+  }
+  return c;
+}
+
+__global__ void __launch_bounds__(256) k_pb_cost(const u8* __restrict__ s, u32 n, const u32* __restrict__ runStart,
+                                                 const u32* __restrict__ litStart, u32* __restrict__ offset)
+{
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) offset[i] = pbCost(s, n, runStart, litStart, i);
+}
+
+__global__ void __launch_bounds__(256) k_pb_total(u32* __restrict__ offset, u32 n) { if (threadIdx.x == 0 && blockIdx.x == 0) offset[n] = offset[n - 1u]; }
+
+__global__ void __launch_bounds__(256) k_pb_emit(const u8* __restrict__ s, u32 n, const u32* __restrict__ runStart,
+                                                 const u32* __restrict__ litStart, const u32* __restrict__ offset, u8* __restrict__ out)
+{
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  u32 at = (i > 0) ? offset[i - 1u] : 0u;    // offset[] holds the inclusive sums
+  const u32 len = i - runStart[i] + 1u, rem = len % 129u;
+  const u8 v = s[i];
+  if (rem == 0u) { out[at] = 255; out[at + 1u] = v; return; }    // 127 + 128 repeats
+  if (!pbRunEnd(s, n, i)) return;
+  if (rem >= 2u) { out[at] = (u8)(126u + rem); out[at + 1u] = v; return; }
+  const u32 first = litStart[i];
+  if (((i - first) % 128u) == 0u)
+  {
+    // count byte of this group of literals: 128, or what is left of the stretch
+    u32 cnt = 128u;
+    if (!(i + 127u < n && pbLiteral(s, n, runStart, i + 127u) && litStart[i + 127u] == first))
+    {
+      cnt = 1u;
+      while (cnt < 128u && i + cnt < n && pbLiteral(s, n, runStart, i + cnt)) cnt++;
+    }
+    out[at++] = (u8)(cnt - 1u);
+  }
+  out[at] = v;
+}
+
+// decode: the tokens can only be found one after the other; one lane walks them out of LDS
+static const u32 kPbChunk = 8192, kPbOverlap = 160;
+
+__global__ void __launch_bounds__(256) k_pb_walk(const u8* __restrict__ in, u32 n, u32 expected, u32* __restrict__ tokSrc,
+                                                 u32* __restrict__ tokDst, u32* __restrict__ result)
+{
+  __shared__ u8 s_buf[kPbChunk + kPbOverlap];
+  __shared__ u32 s_state[4];    // src, dst, nTokens, status (0 running, 1 done, 2 bad)
+  if (threadIdx.x == 0) { s_state[0] = 0; s_state[1] = 0; s_state[2] = 0; s_state[3] = (n == 0) ? 1u : 0u; }
+  __syncthreads();
+  for (u32 base = 0; base < n; base += kPbChunk)
+  {
+    if (s_state[3] != 0u) break;    // (uniform: read between barriers)
+    for (u32 i = threadIdx.x; i < kPbChunk + kPbOverlap; i += 256u) s_buf[i] = (base + i < n) ? in[base + i] : (u8)0;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      u32 src = s_state[0], dst = s_state[1], k = s_state[2], status = 0;
+      while (src < n && src < base + kPbChunk)
+      {
+        const u32 b = s_buf[src - base];
+        const u32 produced = (b <= 127u) ? b + 1u : b - 126u;
+        const u32 consumed = (b <= 127u) ? b + 2u : 2u;
+        if (dst + produced > expected || src + consumed > n) { status = 2u; break; }    // fpl_EsriHuffman.cpp:58, :68
+        tokSrc[k] = src; tokDst[k] = dst; k++;
+        src += consumed; dst += produced;
+      }
+      if (status == 0u && src >= n) status = (dst == expected) ? 1u : 2u;
+      s_state[0] = src; s_state[1] = dst; s_state[2] = k; s_state[3] = status;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { result[0] = s_state[2]; result[1] = (s_state[3] == 1u && s_state[1] == expected) ? 1u : 0u; }
+}
+
+__global__ void __launch_bounds__(256) k_pb_expand(const u8* __restrict__ in, const u32* __restrict__ tokSrc, const u32* __restrict__ tokDst,
+                                                   const u32* __restrict__ result, u8* __restrict__ out)
+{
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= result[0] || result[1] == 0u) return;
+  const u32 src = tokSrc[t], dst = tokDst[t];
+  const u32 b = in[src];
+  if (b <= 127u) for (u32 j = 0; j <= b; j++) out[dst + j] = in[src + 1u + j];
+  else { const u8 v = in[src + 1u]; for (u32 j = 0; j < b - 126u; j++) out[dst + j] = v; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode: planes -> units, predictor undone by prefix sums
+// ------------------------------------------------------------------------------------------------
+struct FplByteIndex { int idx[8]; };
+
+template<int U>
+__global__ void __launch_bounds__(256)
+k_fpl_gather(const u8* __restrict__ planes, i64 planeStride, FplByteIndex bi, i64 nElem, int finish, typename UnitOf<U>::T* __restrict__ out)
+{
+  typedef typename UnitOf<U>::T T;
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nElem) return;
+  T x = 0;
+  for (int b = 0; b < U; b++) x |= (T)planes[(size_t)b * planeStride + i] << (8 * bi.idx[b]);
+  out[i] = finish ? fplBackward(x) : x;
+}
+
+// column sums in three steps: totals of row segments, their running totals down the column, the segments themselves
+template<int U>
+__global__ void __launch_bounds__(256)
+k_fpl_col_partial(const typename UnitOf<U>::T* __restrict__ x, i64 cols, i64 rows, u32 segRows, u32 nSeg, typename UnitOf<U>::T* __restrict__ partial)
+{
+  typedef typename UnitOf<U>::T T;
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (i64)nSeg * cols) return;
+  const i64 seg = t / cols, c = t - seg * cols;
+  const i64 r0 = seg * segRows, r1 = (r0 + segRows < rows) ? r0 + segRows : rows;
+  T sum = 0;
+  for (i64 r = r0; r < r1; r++) sum = fplAdd(sum, x[r * cols + c]);
+  partial[t] = sum;
+}
+
+template<int U>
+__global__ void __launch_bounds__(256)
+k_fpl_col_scan(typename UnitOf<U>::T* __restrict__ partial, i64 cols, u32 nSeg)
+{
+  typedef typename UnitOf<U>::T T;
+  const i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  T run = 0;
+  for (u32 s = 0; s < nSeg; s++) { const T v = partial[(size_t)s * cols + c]; partial[(size_t)s * cols + c] = run; run = fplAdd(run, v); }
+}
+
+template<int U>
+__global__ void __launch_bounds__(256)
+k_fpl_col_apply(typename UnitOf<U>::T* __restrict__ x, i64 cols, i64 rows, u32 segRows, u32 nSeg, const typename UnitOf<U>::T* __restrict__ partial)
+{
+  typedef typename UnitOf<U>::T T;
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (i64)nSeg * cols) return;
+  const i64 seg = t / cols, c = t - seg * cols;
+  const i64 r0 = seg * segRows, r1 = (r0 + segRows < rows) ? r0 + segRows : rows;
+  T run = partial[t];
+  for (i64 r = r0; r < r1; r++) { run = fplAdd(run, x[r * cols + c]); x[r * cols + c] = run; }
+}
+
+struct ScanFpl { template<class X> __device__ __forceinline__ X operator()(X a, X b) const { return fplAdd(a, b); } };
+
+// row sums, one workgroup per row; the result goes back to IEEE bit order
+template<int U>
+__global__ void __launch_bounds__(256)
+k_fpl_row_sums_wide(typename UnitOf<U>::T* __restrict__ x, i64 cols)
+{
+  typedef typename UnitOf<U>::T T;
+  __shared__ T s_wave[4];
+  const ScanFpl op;
+  T* row = x + (size_t)blockIdx.x * cols;
+  T carry = 0;
+  for (i64 base = 0; base < cols; base += 1024)
+  {
+    const i64 i0 = base + threadIdx.x * 4;
+    T v[4];
+    for (int k = 0; k < 4; k++) v[k] = (i0 + k < cols) ? row[i0 + k] : (T)0;
+    for (int k = 1; k < 4; k++) v[k] = fplAdd(v[k - 1], v[k]);
+    T total;
+    const T before = fplAdd(carry, workgroupExclusive<T, ScanFpl>(v[3], op, s_wave, total));
+    for (int k = 0; k < 4; k++) if (i0 + k < cols) row[i0 + k] = fplBackward(fplAdd(before, v[k]));
+    carry = fplAdd(carry, total);
+  }
+}
+
+template<int U>
+__global__ void __launch_bounds__(256)
+k_fpl_row_sums_narrow(typename UnitOf<U>::T* __restrict__ x, i64 cols, i64 rows)
+{
+  typedef typename UnitOf<U>::T T;
+  const i64 r = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  T* row = x + (size_t)r * cols;
+  T run = 0;
+  for (i64 c = 0; c < cols; c++) { run = fplAdd(run, row[c]); row[c] = fplBackward(run); }
+}
+
+unsigned gridFor(i64 n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}    // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+void launchFplPredictorSamples(const void* data, const u8* byteMask, const FplGeom& g, const FplSpan* blocks, u32 nBlocks, u32* histos,
+                               hipStream_t st)
+{
+  if (g.unit == 4) hipLaunchKernelGGL(k_fpl_predictor_samples<4>, dim3(nBlocks), dim3(256), 0, st, data, byteMask, g, blocks, histos);
+  else hipLaunchKernelGGL(k_fpl_predictor_samples<8>, dim3(nBlocks), dim3(256), 0, st, data, byteMask, g, blocks, histos);
+}
+
+void launchFplPredict(const void* data, const u8* byteMask, const FplGeom& g, int predictor, void* units, hipStream_t st)
+{
+  const dim3 grid(gridFor(g.nElem, 256));
+  if (g.unit == 4) hipLaunchKernelGGL(k_fpl_predict<4>, grid, dim3(256), 0, st, data, byteMask, g, predictor, (u32*)units);
+  else hipLaunchKernelGGL(k_fpl_predict<8>, grid, dim3(256), 0, st, data, byteMask, g, predictor, (u64*)units);
+}
+
+void launchFplLevelSamples(const void* units, const FplGeom& g, const FplSpan* snippets, u32 nSnippets, u32* histos, hipStream_t st)
+{
+  if (nSnippets == 0) return;
+  const dim3 grid(nSnippets, (unsigned)g.unit);
+  if (g.unit == 4) hipLaunchKernelGGL(k_fpl_level_samples<4>, grid, dim3(256), 0, st, (const u32*)units, g, snippets, nSnippets, histos);
+  else hipLaunchKernelGGL(k_fpl_level_samples<8>, grid, dim3(256), 0, st, (const u64*)units, g, snippets, nSnippets, histos);
+}
+
+void launchFplSymbols(const void* units, const FplGeom& g, const FplLevels& lv, u8* planes, u32* histos, hipStream_t st)
+{
+  const dim3 grid(gridFor(g.nElem, 1024));
+  const i64 stride = fplPlaneStride(g.nElem);
+  if (g.unit == 4) hipLaunchKernelGGL(k_fpl_symbols<4>, grid, dim3(256), 0, st, (const u32*)units, g, lv, stride, planes, histos);
+  else hipLaunchKernelGGL(k_fpl_symbols<8>, grid, dim3(256), 0, st, (const u64*)units, g, lv, stride, planes, histos);
+}
+
+void launchPackBitsPlan(const u8* plane, u32 n, const PackBitsBuffers& b, hipStream_t st)
+{
+  const dim3 grid((n + 255u) / 256u), block(256);
+  hipLaunchKernelGGL(k_pb_run_start, grid, block, 0, st, plane, n, b.runStart);
+  inclusiveScan<u32, ScanMax>(b.runStart, n, b.scratch, st);
+  hipLaunchKernelGGL(k_pb_lit_start, grid, block, 0, st, plane, n, (const u32*)b.runStart, b.litStart);
+  inclusiveScan<u32, ScanMax>(b.litStart, n, b.scratch, st);
+  hipLaunchKernelGGL(k_pb_cost, grid, block, 0, st, plane, n, (const u32*)b.runStart, (const u32*)b.litStart, b.offset);
+  inclusiveScan<u32, ScanSum>(b.offset, n, b.scratch, st);
+  hipLaunchKernelGGL(k_pb_total, dim3(1), dim3(64), 0, st, b.offset, n);
+}
+
+void launchPackBitsEmit(const u8* plane, u32 n, const PackBitsBuffers& b, u8* out, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_pb_emit, dim3((n + 255u) / 256u), dim3(256), 0, st, plane, n, (const u32*)b.runStart, (const u32*)b.litStart,
+                     (const u32*)b.offset, out);
+}
+
+void launchPackBitsWalk(const u8* in, u32 n, u32 expected, u32* tokSrc, u32* tokDst, u32* result, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_pb_walk, dim3(1), dim3(256), 0, st, in, n, expected, tokSrc, tokDst, result);
+}
+
+void launchPackBitsExpand(const u8* in, const u32* tokSrc, const u32* tokDst, const u32* result, u32 maxTokens, u8* out, hipStream_t st)
+{
+  if (maxTokens == 0) return;
+  hipLaunchKernelGGL(k_pb_expand, dim3((maxTokens + 255u) / 256u), dim3(256), 0, st, in, tokSrc, tokDst, result, out);
+}
+
+void launchBytePrefixSum(u8* p, u32 n, u32* scratch, hipStream_t st)
+{
+  inclusiveScan<u8, ScanSum>(p, n, (u8*)scratch, st);
+}
+
+void launchFplGather(const u8* planes, const int* byteIndex, const FplGeom& g, bool finish, void* out, hipStream_t st)
+{
+  FplByteIndex bi;
+  for (int b = 0; b < 8; b++) bi.idx[b] = (b < g.unit) ? byteIndex[b] : 0;
+  const dim3 grid(gridFor(g.nElem, 256));
+  const i64 stride = fplPlaneStride(g.nElem);
+  if (g.unit == 4) hipLaunchKernelGGL(k_fpl_gather<4>, grid, dim3(256), 0, st, planes, stride, bi, g.nElem, finish ? 1 : 0, (u32*)out);
+  else hipLaunchKernelGGL(k_fpl_gather<8>, grid, dim3(256), 0, st, planes, stride, bi, g.nElem, finish ? 1 : 0, (u64*)out);
+}
+
+u32 fplColumnSegments(i64 rows)
+{
+  const i64 segRows = fplColumnSegmentRows(rows);
+  return (u32)((rows + segRows - 1) / segRows);
+}
+
+void launchFplColumnSums(void* units, const FplGeom& g, void* partial, u32 nSeg, hipStream_t st)
+{
+  const u32 segRows = (u32)fplColumnSegmentRows(g.rows);
+  const dim3 grid(gridFor((i64)nSeg * g.cols, 256)), gridC(gridFor(g.cols, 256));
+  if (g.unit == 4)
+  {
+    hipLaunchKernelGGL(k_fpl_col_partial<4>, grid, dim3(256), 0, st, (const u32*)units, g.cols, g.rows, segRows, nSeg, (u32*)partial);
+    hipLaunchKernelGGL(k_fpl_col_scan<4>, gridC, dim3(256), 0, st, (u32*)partial, g.cols, nSeg);
+    hipLaunchKernelGGL(k_fpl_col_apply<4>, grid, dim3(256), 0, st, (u32*)units, g.cols, g.rows, segRows, nSeg, (const u32*)partial);
+  }
+  else
+  {
+    hipLaunchKernelGGL(k_fpl_col_partial<8>, grid, dim3(256), 0, st, (const u64*)units, g.cols, g.rows, segRows, nSeg, (u64*)partial);
+    hipLaunchKernelGGL(k_fpl_col_scan<8>, gridC, dim3(256), 0, st, (u64*)partial, g.cols, nSeg);
+    hipLaunchKernelGGL(k_fpl_col_apply<8>, grid, dim3(256), 0, st, (u64*)units, g.cols, g.rows, segRows, nSeg, (const u64*)partial);
+  }
+}
+
+void launchFplRowSums(void* units, const FplGeom& g, hipStream_t st)
+{
+  if (g.cols > 32)
+  {
+    if (g.unit == 4) hipLaunchKernelGGL(k_fpl_row_sums_wide<4>, dim3((unsigned)g.rows), dim3(256), 0, st, (u32*)units, g.cols);
+    else hipLaunchKernelGGL(k_fpl_row_sums_wide<8>, dim3((unsigned)g.rows), dim3(256), 0, st, (u64*)units, g.cols);
+  }
+  else
+  {
+    const dim3 grid(gridFor(g.rows, 256));
+    if (g.unit == 4) hipLaunchKernelGGL(k_fpl_row_sums_narrow<4>, grid, dim3(256), 0, st, (u32*)units, g.cols, g.rows);
+    else hipLaunchKernelGGL(k_fpl_row_sums_narrow<8>, grid, dim3(256), 0, st, (u64*)units, g.cols, g.rows);
+  }
+}
+
+}    // namespace lerc

@@ -18,6 +18,11 @@ struct HuffmanPlan
 
 size_t huffmanScratchBytes(i64 nPix, int nDepth);
 
+// code book + sizes for a plain byte stream with this histogram (the lossless float planes, fpl_EsriHuffman.cpp:238-283);
+// false: no code book can be built (fewer than two symbols, or a code longer than 32 bits)
+bool planHuffmanFromHisto(const std::vector<int>& histo, HuffmanPlan& plan);
+
+
 // histograms on the device, code books + sizes on the host; returns false only on a runtime error
 bool planHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth,
                  int version, HuffmanPlan& plan);

@@ -270,6 +270,25 @@ size_t huffmanScratchBytes(i64 nPix, int nDepth)
   return nElem * 3 + (size_t)nPix * 6 + (2u << 20);
 }
 
+bool planHuffmanFromHisto(const std::vector<int>& histo, HuffmanPlan& plan)
+{
+  plan = HuffmanPlan();
+  std::vector<HCode> t;
+  std::vector<u8> ser;
+  u32 n = 0;
+  u64 bits = 0;
+  if (!buildCodes(histo, t)) return false;
+  serialiseTable(t, ser);
+  if (!compressedBytes(t, histo, (u32)ser.size(), n, bits)) return false;
+  plan.ok = true;
+  plan.imageMode = IEM_Huffman;
+  plan.codes = t;
+  plan.table = ser;
+  plan.nBytes = n;
+  plan.nBits = bits;
+  return true;
+}
+
 bool planHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth, int version,
                  HuffmanPlan& plan)
 {

@@ -735,6 +735,425 @@ struct HuffDecoder
 };
 
 // ---------------------------------------------------------------------------------------------
+// Lossless float / double (image mode IEM_DeltaDeltaHuffman) -- fpl_Lerc2Ext.cpp, fpl_UnitTypes.cpp,
+// fpl_Predictor.cpp, fpl_Compression.cpp, fpl_EsriHuffman.cpp.  Float bits are reordered to
+// exponent|sign|mantissa, a predictor (none / row differences / row + column differences, mantissa and the bits
+// above it differenced apart) is picked from entropy estimates over sample blocks, the result is split into byte
+// planes, every plane gets a byte-wise difference order picked the same way, and is then stored as one value,
+// PackBits, raw bytes or Huffman codes -- whichever is smallest.
+// ---------------------------------------------------------------------------------------------
+static const int kFplPrime = 7;      // fpl_Compression.h:33
+static const int kFplMaxDelta = 5;   // fpl_Predictor.h:33
+
+static uint32_t fplFwd32(uint32_t a) { return (a & 0x007FFFFFu) | (((a >> 23) & 0xFFu) << 24) | ((a >> 31) << 23); }              // fpl_UnitTypes.cpp:39-51
+static uint32_t fplBack32(uint32_t a) { return (a & 0x007FFFFFu) | (((a >> 24) & 0xFFu) << 23) | (((a >> 23) & 1u) << 31); }      // :53-65
+static uint32_t fplSub(uint32_t a, uint32_t b) { return ((a - b) & 0x007FFFFFu) | ((((a >> 23) - (b >> 23)) & 0x1FFu) << 23); }  // :83-97
+static uint32_t fplAdd(uint32_t a, uint32_t b) { return ((a + b) & 0x007FFFFFu) | ((((a >> 23) + (b >> 23)) & 0x1FFu) << 23); }  // :99-113
+static uint64_t fplSub(uint64_t a, uint64_t b)    // :119-136
+{
+  return ((a - b) & 0x000FFFFFFFFFFFFFull) | ((((a >> 52) - (b >> 52)) & 0xFFFull) << 52);
+}
+static uint64_t fplAdd(uint64_t a, uint64_t b)    // :138-155
+{
+  return ((a + b) & 0x000FFFFFFFFFFFFFull) | ((((a >> 52) + (b >> 52)) & 0xFFFull) << 52);
+}
+
+// fpl_Compression.cpp:85-113
+static long fplEntropy(const u8* p, size_t size)
+{
+  unsigned long table[256];
+  memset(table, 0, sizeof(table));
+  int total = 0;
+  for (size_t i = 0; i < size; i += kFplPrime) { table[p[i]]++; total++; }
+  double totalBits = 0;
+  for (int i = 0; i < 256; i++)
+  {
+    if (table[i] == 0) continue;
+    double q = (double)total / table[i];
+    double bits = log2(q);
+    totalBits += (bits * table[i]);
+  }
+  return (long)((totalBits + 7) / 8);
+}
+
+// row differences (setRowsDerivative phase 1, fpl_UnitTypes.cpp:302-357) / column differences (setCrossDerivative phase 2, :436-517)
+template<class W> static void fplRowDiff(W* d, size_t cols, size_t rows)
+{
+  for (size_t r = 0; r < rows; r++)
+    for (size_t i = cols - 1; i >= 1; i--) d[r * cols + i] = fplSub(d[r * cols + i], d[r * cols + i - 1]);
+}
+template<class W> static void fplColDiff(W* d, size_t cols, size_t rows)
+{
+  for (size_t c = 0; c < cols; c++)
+    for (size_t r = rows - 1; r >= 1; r--) d[r * cols + c] = fplSub(d[r * cols + c], d[(r - 1) * cols + c]);
+}
+
+struct FplBlock { long top, height; };
+
+// fpl_Lerc2Ext.cpp:57-101
+static void fplTestBlocks(int width, int height, std::vector<FplBlock>& blocks)
+{
+  size_t size = (size_t)width * height;
+  const int target = 8 * 1024;
+  double t = round((double)size / target);
+  int count = (int)round(sqrt(t + 1));
+  int blockHeight = target / width;
+  if (blockHeight < 4) blockHeight = 4;
+  while ((count * blockHeight > height) && (count > 1)) count--;
+  float topMargin = (float)((height - count * blockHeight) / (2.0 * count));
+  float delta = 2.0f * topMargin + blockHeight;
+  for (int i = 0; i < count; i++)
+  {
+    FplBlock tb;
+    tb.top = (long)(topMargin + delta * i);
+    tb.height = blockHeight;
+    if (tb.top < 0) tb.top = 0;
+    if (tb.top + tb.height > height) tb.height = height - tb.top;
+    if (tb.height > 0) blocks.push_back(tb);
+  }
+}
+
+// fpl_Lerc2Ext.cpp:167-232 (test_first_byte_delta is always on)
+static size_t fplTestBlocksSize(const std::vector<FplBlock>& blocks, size_t unit, const u8* data, long width)
+{
+  size_t ret = 0;
+  std::vector<u8> plane;
+  for (const FplBlock& tb : blocks)
+  {
+    size_t start = unit * tb.top * width, length = (size_t)tb.height * width;
+    plane.resize(length);
+    for (size_t byte = 0; byte < unit; byte++)
+    {
+      for (size_t i = 0; i < length; i++) plane[i] = data[start + byte + i * unit];
+      size_t plain = (size_t)fplEntropy(plane.data(), length);
+      // setDerivativePrime (:81-95): only the sampled bytes are differenced
+      for (long i = kFplPrime * (((long)length - 1) / kFplPrime); i >= 1; i -= kFplPrime) plane[i] = (u8)(plane[i] - plane[i - 1]);
+      size_t prime = (size_t)fplEntropy(plane.data(), length);
+      ret += std::min(plain, prime);
+    }
+  }
+  return ret;
+}
+
+// fpl_Lerc2Ext.cpp:237-322
+static int fplBestLevel(const u8* p, size_t size, int maxOrder)
+{
+  if (maxOrder == 0) return 0;
+  std::vector<std::pair<size_t, int> > snippets;
+  const unsigned target = 1024 * 8;
+  double t = round((double)size / target);
+  int count = (int)round(sqrt(t + 1));
+  while (count * target > size && (count > 0)) count--;
+  if (count > 0)    // (the reference divides by zero otherwise and likewise ends up without snippets)
+  {
+    float topMargin = (float)(((int)size - count * target) / (2.0 * count));
+    float delta = 2.0f * topMargin + target;
+    for (int i = 0; i < count; i++)
+    {
+      long start = (long)(topMargin + delta * i);
+      int len = (int)target;
+      if (start < 0) start = 0;
+      if (start + len > (int)size) len = (int)size - start;
+      if (len > 0) snippets.push_back(std::make_pair((size_t)start, len));
+    }
+  }
+  std::vector<u8> copy(p, p + size);
+  size_t best = 0;
+  int ret = 0;
+  for (int l = 0; l <= maxOrder; l++)
+  {
+    if (l > 0)
+      for (const auto& sn : snippets)
+        for (int i = (int)sn.first + sn.second - 1; i >= (int)sn.first + l; i--) copy[i] = (u8)(copy[i] - copy[i - 1]);
+    size_t comp = 0;
+    for (const auto& sn : snippets) comp += (size_t)fplEntropy(copy.data() + sn.first, sn.second);
+    if (comp < best || l == 0) { best = comp; ret = l; }
+    else break;
+  }
+  return ret;
+}
+
+// fpl_EsriHuffman.cpp:164-236 (the limit only shortens the reference's loop; the caller's comparisons decide the same)
+static long fplPackBitsSize(const u8* ptr, size_t size, long limit)
+{
+  long curr = 0;
+  int literalCount = 0, literalPos = -1;
+  for (size_t i = 0; i <= size; )
+  {
+    int b = (i == size) ? -1 : ptr[i];
+    if (curr > limit) return -1;
+    int repeat = 0;
+    while (i < size - 1 && b == ptr[i + 1] && repeat < 128) { i++; repeat++; }
+    i++;
+    if (repeat == 0 && b >= 0)
+    {
+      if (literalPos < 0) { literalPos = (int)curr; curr++; }
+      curr++;
+      literalCount++;
+      if (literalCount == 128) { literalCount = 0; literalPos = -1; }
+    }
+    else
+    {
+      if (literalCount > 0) { literalPos = -1; literalCount = 0; }
+      if (repeat > 0) curr += 2;
+    }
+  }
+  return curr;
+}
+
+// fpl_EsriHuffman.cpp:79-161
+static long fplPackBitsEncode(const u8* ptr, size_t size, u8* out)
+{
+  int literalCount = 0, curr = 0, literalPos = -1;
+  for (size_t i = 0; i <= size; )
+  {
+    int b = (i == size) ? -1 : ptr[i];
+    int repeat = 0;
+    while (i < size - 1 && b == ptr[i + 1] && repeat < 128) { i++; repeat++; }
+    i++;
+    if (repeat == 0 && b >= 0)
+    {
+      if (literalPos < 0) { literalPos = curr; curr++; }
+      out[curr++] = (u8)b;
+      literalCount++;
+      if (literalCount == 128) { out[literalPos] = (u8)(literalCount - 1); literalCount = 0; literalPos = -1; }
+    }
+    else
+    {
+      if (literalCount > 0) { out[literalPos] = (u8)(literalCount - 1); literalPos = -1; literalCount = 0; }
+      if (repeat > 0) { out[curr++] = (u8)(127 + repeat); out[curr++] = (u8)b; }
+    }
+  }
+  return curr;
+}
+
+// fpl_EsriHuffman.cpp:37-77
+static bool fplPackBitsDecode(const u8* ptr, size_t size, size_t expected, u8* out)
+{
+  size_t curr = 0;
+  for (size_t i = 0; i < size; )
+  {
+    int b = ptr[i++];
+    if (b <= 127)
+    {
+      if (curr + b >= expected || i + b + 1 > size) return false;
+      memcpy(&out[curr], &ptr[i], b + 1);
+      curr += b + 1; i += b + 1;
+    }
+    else
+    {
+      if (curr + b - 127 >= expected || i >= size) return false;
+      memset(&out[curr], ptr[i], b - 127 + 1);
+      curr += b - 127 + 1; i++;
+    }
+  }
+  return curr == expected;
+}
+
+// fpl_EsriHuffman.cpp:306-437; the read-ahead word behind the codes is left uninitialised by the reference, 0 here
+static bool fplCompressPlane(const u8* in, size_t len, std::vector<u8>& out)
+{
+  std::vector<int> histo(256, 0);
+  for (size_t i = 0; i < len; i++) histo[in[i]]++;
+  int distinct = 0;
+  for (int i = 0; i < 256; i++) if (histo[i] > 0) distinct++;
+  if (distinct < 2)
+  {
+    out.assign(6, 0);
+    out[0] = 1; out[1] = in[0];
+    uint32_t n = (uint32_t)len;
+    memcpy(&out[2], &n, 4);
+    return true;
+  }
+  std::vector<HCode> codes;
+  int numBytes = 0;
+  if (!huffBuild(histo, codes) || !huffCompressedBytes(codes, histo, numBytes) || numBytes <= 0) return false;
+  long limit = std::min(numBytes, (int)len);
+  long rle = fplPackBitsSize(in, len, limit);
+  if (rle > 0 && rle < numBytes && rle < (long)len)
+  {
+    out.assign((size_t)rle + 1, 0);
+    out[0] = 3;
+    fplPackBitsEncode(in, len, &out[1]);
+    return true;
+  }
+  if (numBytes >= (int)len)
+  {
+    out.resize(len + 1);
+    out[0] = 2;
+    memcpy(&out[1], in, len);
+    return true;
+  }
+  out.assign((size_t)numBytes + 1 + 8, 0);
+  out[0] = 0;
+  Writer w{ &out[1] };
+  if (!huffWriteTable(w, codes)) return false;
+  HuffSink sink{ w.p, 0 };
+  for (size_t m = 0; m < len; m++)
+  {
+    const HCode& c = codes[in[m]];
+    if (c.first <= 0) return false;
+    sink.push(c.second, c.first);
+  }
+  size_t used = (size_t)(sink.p - out.data()) + 4 * ((sink.bitPos > 0 ? 1 : 0) + 1);
+  out.resize(used);
+  return true;
+}
+
+// fpl_EsriHuffman.cpp:439-560
+static bool fplExtractPlane(const u8* in, size_t inCount, size_t expected, u8* out)
+{
+  if (inCount < 1) return false;
+  if (in[0] == 1)
+  {
+    if (inCount < 6) return false;
+    uint32_t n;
+    memcpy(&n, in + 2, 4);
+    if (n != expected) return false;
+    memset(out, in[1], expected);
+    return true;
+  }
+  if (in[0] == 2)
+  {
+    if (inCount < expected + 1) return false;
+    memcpy(out, in + 1, expected);
+    return true;
+  }
+  if (in[0] == 3) return fplPackBitsDecode(in + 1, inCount - 1, expected, out);
+  if (in[0] != 0) return false;
+  Reader r{ in + 1, inCount - 1 };
+  std::vector<HCode> table;
+  if (!huffReadTable(r, table, 5)) return false;
+  HuffDecoder dec;
+  if (!dec.init(table)) return false;
+  const u8* p = r.p;
+  size_t left = r.left;
+  int bitPos = 0;
+  for (size_t m = 0; m < expected; m++)
+  {
+    int sym = 0;
+    if (!dec.next(p, left, bitPos, sym)) return false;
+    out[m] = (u8)sym;
+  }
+  return true;
+}
+
+struct FplPlane { u8 byteIndex, level; std::vector<u8> bytes; };
+
+// what the reference's LosslessFPCompression object holds between ComputeHuffmanCodesFlt and EncodeHuffmanFlt
+struct FplState
+{
+  std::vector<FplPlane> planes;
+  u8 predictor = 0;
+  int compressedLength() const    // fpl_Lerc2Ext.cpp:391-403
+  {
+    int ret = 1;
+    for (const FplPlane& b : planes) ret += (int)b.bytes.size() + 6;
+    return ret;
+  }
+};
+
+// fpl_Lerc2Ext.cpp:456-606
+template<class W>
+static bool fplComputeSlice(const W* input, int cols, int rows, FplState& st)
+{
+  const size_t unit = sizeof(W), size = (size_t)cols * rows;
+  std::vector<W> values(input, input + size);
+  if (unit == 4) for (size_t i = 0; i < size; i++) values[i] = (W)fplFwd32((uint32_t)values[i]);
+  size_t stats[3] = { 0, 0, 0 };
+  {
+    std::vector<W> copy(values);    // selectInitialLinearOrCrossDelta (:337-389)
+    std::vector<FplBlock> blocks;
+    fplTestBlocks(cols, rows, blocks);
+    stats[0] = fplTestBlocksSize(blocks, unit, (const u8*)copy.data(), cols);
+    fplRowDiff(copy.data(), cols, rows);
+    stats[1] = fplTestBlocksSize(blocks, unit, (const u8*)copy.data(), cols);
+    fplColDiff(copy.data(), cols, rows);
+    stats[2] = fplTestBlocksSize(blocks, unit, (const u8*)copy.data(), cols);
+  }
+  int predictor = 0;
+  for (int i = 1; i < 3; i++) if (stats[i] < stats[predictor]) predictor = i;
+  if (predictor >= 1) fplRowDiff(values.data(), cols, rows);
+  if (predictor == 2) fplColDiff(values.data(), cols, rows);
+  const int maxDelta = kFplMaxDelta - predictor;    // Predictor::getMaxByteDelta
+  std::vector<u8> plane(size);
+  const u8* bytes = (const u8*)values.data();
+  for (size_t byte = 0; byte < unit; byte++)
+  {
+    for (size_t i = 0; i < size; i++) plane[i] = bytes[i * unit + byte];
+    const int level = fplBestLevel(plane.data(), size, maxDelta);
+    for (int l = 1; l <= level; l++)    // setDerivative (:97-110)
+      for (int i = (int)size - 1; i >= l; i--) plane[i] = (u8)(plane[i] - plane[i - 1]);
+    FplPlane out;
+    out.byteIndex = (u8)byte; out.level = (u8)level;
+    if (!fplCompressPlane(plane.data(), size, out.bytes)) return false;
+    st.predictor = (u8)predictor;
+    st.planes.push_back(out);
+  }
+  return true;
+}
+
+// fpl_Lerc2Ext.cpp:423-452: nDepth > 1 is coded as an (nDepth x nPixels) raster, and -- unlike the nDepth == 1 entry --
+// does not drop planes a previous band computed but never wrote
+template<class T>
+static bool fplCompute(const T* data, int nCols, int nRows, int nDepth, FplState& st)
+{
+  typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type W;
+  if (nDepth == 1) { st.planes.clear(); return fplComputeSlice((const W*)data, nCols, nRows, st); }
+  return fplComputeSlice((const W*)data, nDepth, nCols * nRows, st);
+}
+
+// fpl_Lerc2Ext.cpp:405-421
+static void fplWrite(FplState& st, Writer& w)
+{
+  w.byte(st.predictor);
+  for (const FplPlane& b : st.planes)
+  {
+    w.byte(b.byteIndex); w.byte(b.level);
+    uint32_t n = (uint32_t)b.bytes.size();
+    w.put(&n, 4);
+    w.put(b.bytes.data(), b.bytes.size());
+  }
+  st.planes.clear();
+}
+
+// fpl_Lerc2Ext.cpp:723-866
+template<class T>
+static bool fplDecode(Reader& r, T* data, int nCols, int nRows, int nDepth)
+{
+  typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type W;
+  const size_t unit = sizeof(W);
+  const size_t cols = (nDepth == 1) ? nCols : nDepth, rows = (nDepth == 1) ? nRows : (size_t)nCols * nRows, size = cols * rows;
+  u8 pred = 0;
+  if (!r.get(&pred, 1) || pred > 2) return false;
+  std::vector<W> values(size, 0);
+  u8* bytes = (u8*)values.data();
+  std::vector<u8> plane(size);
+  for (size_t b = 0; b < unit; b++)
+  {
+    u8 byteIndex = 0, level = 0;
+    uint32_t csize = 0;
+    if (r.left < 6) return false;
+    r.get(&byteIndex, 1); r.get(&level, 1); r.get(&csize, 4);
+    if (byteIndex >= unit || level > kFplMaxDelta || r.left < csize) return false;
+    if (!fplExtractPlane(r.p, csize, size, plane.data())) return false;
+    r.skip(csize);
+    for (int l = level; l > 0; l--)    // restoreSequence (:128-165)
+      for (size_t i = l; i < size; i++) plane[i] = (u8)(plane[i] + plane[i - 1]);
+    for (size_t i = 0; i < size; i++) bytes[i * unit + byteIndex] = plane[i];
+  }
+  if (pred == 2)    // restoreCrossBytes (fpl_UnitTypes.cpp:775-849)
+    for (size_t c = 0; c < cols; c++)
+      for (size_t i = 1; i < rows; i++) values[i * cols + c] = fplAdd(values[i * cols + c], values[(i - 1) * cols + c]);
+  if (pred >= 1)    // ... and restoreBlockSequence (:626-697)
+    for (size_t i = 0; i < rows; i++)
+      for (size_t c = 1; c < cols; c++) values[i * cols + c] = fplAdd(values[i * cols + c], values[i * cols + c - 1]);
+  if (unit == 4) for (size_t i = 0; i < size; i++) values[i] = (W)fplBack32((uint32_t)values[i]);
+  memcpy(data, values.data(), size * unit);
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // per-block helpers -- Lerc2.h:337-353 (ComputeMaxVal / NeedToQuantize), :357-376 (Quantize),
 // :457-515 (ReduceDataType), :528-542 (GetDataTypeUsed), :546-681 (variable-type offset I/O)
 // ---------------------------------------------------------------------------------------------
@@ -858,6 +1277,7 @@ struct Band
   unsigned maxQ = 0;
   std::vector<double> zMinVec, zMaxVec;
   std::vector<HCode> huffCodes;
+  FplState fpl;                       // lossless float planes between plan() and emit() (m_lfpc, Lerc2.h)
 
   // Lerc2.cpp:85-114
   bool setDims(int nDepth, int nCols, int nRows, const u8* maskBits)
@@ -1504,8 +1924,14 @@ template<class T> unsigned Band::plan(const T* data, double maxZErr, bool encMas
     if (!huffCodes.empty() && nBytesHuff < nBytesTiling) { imageMode = hm; nBytesData = nBytesHuff; }
     else huffCodes.clear();
   }
-  else if (hd.tryHuffmanFlt())
-    return 0;    // lossless float (fpl_*) is not restated -- see header comment
+  else if (hd.tryHuffmanFlt())    // Lerc2.cpp:305-328
+  {
+    huffCodes.clear();
+    if (!fplCompute(data, hd.nCols, hd.nRows, hd.nDepth, fpl)) return 0;
+    nBytesHuff = fpl.compressedLength();
+    if (nBytesHuff < 0) nBytesHuff = INT_MAX;
+    if (nBytesHuff < nBytesTiling * 0.9) { nBytesData = nBytesHuff; imageMode = IEM_DELTADELTA_HUFFMAN; }    // at least 10 % better
+  }
 
   oneSweep = false;
   const size_t nBytesOneSweep = sizeof(T) * nD * (size_t)numValid;
@@ -1581,7 +2007,13 @@ template<class T> bool Band::emit(const T* data, Writer& w)
     w.byte((u8)imageMode);
     if (imageMode != IEM_TILING)
     {
-      if (hd.tryHuffmanFlt() || huffCodes.empty()) return false;
+      if (hd.tryHuffmanFlt())
+      {
+        if (imageMode != IEM_DELTADELTA_HUFFMAN) return false;
+        fplWrite(fpl, w);
+        return finish();
+      }
+      if (huffCodes.empty()) return false;
       if (!huffEncode(data, w)) return false;
       return finish();
     }
@@ -1774,7 +2206,9 @@ template<class T> bool Band::decode(Reader& r, T* data, u8* maskBitsOut)
         if (imageMode == IEM_DELTA_HUFFMAN || (hd.version >= 4 && imageMode == IEM_HUFFMAN)) return huffDecode(r, data);
         return false;
       }
-      return false;    // lossless float stream: not restated
+      if (hd.tryHuffmanFlt() && imageMode == IEM_DELTADELTA_HUFFMAN)    // Lerc2.cpp:674-678
+        return fplDecode(r, data, hd.nCols, hd.nRows, hd.nDepth);
+      return false;
     }
   }
   return readTiles(r, data);

@@ -16,8 +16,10 @@
  * data-shape matrix, and tests/test_golden.py checks it against the committed golden vectors
  * (doc/MORE.md worked example, JS sanity blob, testData digests).
  *
+ * Lossless float / double is restated too (fpl_*); there the reference leaves the read-ahead word behind every
+ * Huffman coded byte plane uninitialised (heap garbage), this restatement writes 0 (tests/cases.py: lossless_float_dont_care).
+ *
  * Not restated (returns Failed / WrongParam, documented in DESIGN.md "out of scope"):
- *   - lossless float/double (maxZError == 0 on DT_Float/DT_Double -> fpl_* path, Lerc2.cpp:305-328)
  *   - Lerc1 "CntZImage" legacy blobs, codec version 2 (no checksum, pre-v3 bit layout, BitStuffer2.cpp:291-425)
  */
 #ifndef LERC_ORACLE_H

@@ -10,6 +10,7 @@ Outputs (data only -- inputs and expected outputs, never reference source text):
   ref_vectors.json          for every case of tests/cases.py: reference status, blob size, sha256(blob),
                             sha256(decoded bytes), sha256(mask), getBlobInfo arrays
   blobs/<case>.lerc2        full reference blobs for a handful of cases (decode fixtures)
+  fpl_vectors.json, blobs/fpl-*.lerc2   the same for lossless float / double rasters (cases.lossless_float_cases)
 """
 import hashlib
 import json
@@ -80,5 +81,40 @@ def main():
     print("wrote", len(vec), "vectors")
 
 
+def masked_sha(blob, itemsize):
+    """sha256 of a blob with the bytes the reference leaves uninitialised (cases.lossless_float_dont_care) set to 0"""
+    a = bytearray(blob)
+    for k in cases.lossless_float_dont_care(blob, itemsize):
+        a[k] = 0
+    return sha(a)
+
+
+def main_lossless_float():
+    """fpl_vectors.json + blobs/fpl-*.lerc2: lossless float / double (maxZErr 0) cases of cases.lossless_float_cases"""
+    R = capi.ref()
+    assert R is not None, "build oracle/_ref first (make -C oracle ref)"
+    vec = {}
+    kept = 0
+    for i, (name, arr, kw) in enumerate(cases.lossless_float_cases(60, max_side=90)):
+        rc_s, size = R.compute_size(arr, 0, **kw)
+        rc, b = R.encode(arr, 0, **kw)
+        ent = {"rc_size": rc_s, "size": size, "rc": rc}
+        if rc == 0:
+            drc, dec, dm = R.decode(b)
+            ent.update(blob_len=len(b), blob_sha_masked=masked_sha(b, arr.dtype.itemsize), dec_rc=drc, dec_sha=sha(dec.tobytes()),
+                       mask_sha=sha(dm.tobytes()) if dm is not None else None)
+            if len(b) < 40000 and kept < 16 and i % 3 == 0:
+                open(os.path.join(HERE, "blobs", "fpl-%s.lerc2" % name), "wb").write(b)
+                ent["blob_file"] = "fpl-%s.lerc2" % name
+                kept += 1
+        vec[name] = ent
+    json.dump(vec, open(os.path.join(HERE, "fpl_vectors.json"), "w"), indent=0, sort_keys=True)
+    print("wrote", len(vec), "lossless float vectors,", kept, "blobs")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "lossless-float":
+        main_lossless_float()
+    else:
+        main()
+        main_lossless_float()

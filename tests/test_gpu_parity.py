@@ -271,3 +271,33 @@ def test_encode_for_older_codec_versions(P, O):
     if R is not None:
         for name, arr, ver, e, kw in cases.old_codec_cases(100, seed=72):
             cases.check_old_codec_case(R, P, name, arr, ver, e, kw, _same)
+
+
+def test_lossless_float(P, O):
+    """maxZErr == 0 on float / double rasters (Lerc2 IEM_DeltaDeltaHuffman): golden vectors of the real reference, the
+    oracle, the real reference itself when it travelled, and rasters large enough for every scan to span many workgroups."""
+    vec = json.load(open(os.path.join(GOLD, "fpl_vectors.json")))
+    cases.check_lossless_float_golden(P, vec, os.path.join(GOLD, "blobs"), sha)
+    for name, arr, kw in cases.lossless_float_cases(150, seed=93, max_side=300):
+        cases.check_lossless_float_case(O, P, name, arr, kw, _same)
+    rng = np.random.default_rng(8)
+    R = capi.ref()
+    for dt, shape in ((np.float32, (2048, 3000)), (np.float64, (1500, 1111))):
+        x = (cases.terrain(shape[0], shape[1], rng, sigma=0.02) + np.cumsum(rng.standard_normal(shape), axis=1) * 1e-3).astype(dt)
+        x[100:400, 200:900] = 7.25
+        cases.check_lossless_float_case(O, P, "large-" + np.dtype(dt).name, x, {}, _same)
+        if R is not None:
+            cases.check_lossless_float_case(R, P, "large-" + np.dtype(dt).name, x, {}, _same)
+    if R is not None:
+        for name, arr, kw in cases.lossless_float_cases(60, seed=95, max_side=300):
+            cases.check_lossless_float_case(R, P, name, arr, kw, _same)
+
+
+def test_lossless_float_round_trip_full_size(P):
+    """8192 x 8192 float32, maxZErr 0: decode(encode(x)) == x bit for bit, and the blob is smaller than the raster."""
+    from lerc_amd import synth
+    x = synth.c2_float32().numpy()
+    rc, blob = P.encode(x, 0)
+    assert rc == 0 and len(blob) < x.nbytes
+    d = P.decode(blob)
+    assert d[0] == 0 and _same(d[1].reshape(x.shape), x)

@@ -129,3 +129,10 @@ def test_old_codec_versions(O):
     """lerc_encodeForVersion / lerc_computeCompressedSizeForVersion for codec 3..5 (Lerc.cpp:526-624)."""
     for name, arr, ver, e, kw in cases.old_codec_cases(250):
         cases.check_old_codec_case(R, O, name, arr, ver, e, kw, _same)
+
+
+def test_lossless_float(O):
+    """maxZErr == 0 on float / double: the restated fpl_* codec against the real one (blobs equal up to the bytes the
+    reference leaves uninitialised), including the multi-band nDepth > 1 size query quirk."""
+    for name, arr, kw in cases.lossless_float_cases(150, seed=94, max_side=200):
+        cases.check_lossless_float_case(R, O, name, arr, kw, _same)

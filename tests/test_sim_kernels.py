@@ -345,3 +345,25 @@ def test_sim_encode_for_older_codec_versions(libs):
     O, S = libs
     for name, arr, ver, e, kw in cases.old_codec_cases(60):
         cases.check_old_codec_case(O, S, name, arr, ver, e, kw, _same)
+
+
+def test_sim_lossless_float_against_golden(libs):
+    """maxZErr == 0 on float / double (IEM_DeltaDeltaHuffman): predictor and difference-order choices,
+    plane coding (Huffman / one value / stored / PackBits), decode by scans -- against the reference's vectors."""
+    import hashlib
+    import json
+    import os
+    O, S = libs
+    gold = os.path.join(capi.ROOT, "tests", "golden")
+    vec = json.load(open(os.path.join(gold, "fpl_vectors.json")))
+    cases.check_lossless_float_golden(S, vec, os.path.join(gold, "blobs"), lambda b: hashlib.sha256(bytes(b)).hexdigest())
+
+
+@pytest.mark.ref
+def test_sim_lossless_float_against_reference(libs):
+    R = capi.ref()
+    if R is None:
+        pytest.skip("reference library not built")
+    O, S = libs
+    for name, arr, kw in cases.lossless_float_cases(40, seed=92):
+        cases.check_lossless_float_case(R, S, name, arr, kw, _same)
