@@ -72,7 +72,7 @@ LERC_AMD_API lerc_status lerc_decodeToDouble(const unsigned char* pLercBlob, uns
 /* reference Lerc_c_api.h:300-380 -- the _4D variants add a per-band noData value.  With
  * pUsesNoData == NULL (or all zero) they are the calls above.  A noData value turns pixels that hold it in every
  * depth into invalid ones and, for nDepth > 1, travels in the blob (remapped below the data range if need be);
- * lerc_decode_4D hands it back.  (Where the filter has to make a float band lossless: Failed(1), no lossless float.) */
+ * lerc_decode_4D hands it back.  (Where the filter has to make a float band lossless, the band goes through the lossless float mode.) */
 LERC_AMD_API lerc_status lerc_computeCompressedSize_4D(const void* pData, unsigned int dataType, int nDepth, int nCols,
     int nRows, int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr, unsigned int* numBytes,
     const unsigned char* pUsesNoData, const double* noDataValues);

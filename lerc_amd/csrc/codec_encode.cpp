@@ -504,8 +504,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
         else if (hd.tryHuffmanFlt())
         {
           // lossless float / double: predictor + byte planes + entropy coding, kept if it beats the (raw) blocks by 10 % (Lerc2.cpp:305-328)
-          if (nd.active) { ctx.lastError = "lossless float / double together with a noData value is not built"; return kFailed; }
-          if (!planLosslessFloat(ctx, dt, dData, dByteMask, nRows, nCols, nD, fpl)) return kFailed;
+          if (!planLosslessFloat(ctx, dt, dData, dByteMask, nd.active, nRows, nCols, nD, fpl)) return kFailed;
           // The reference keeps the coded planes inside its Lerc2 object until a band writes them, and only the
           // nDepth == 1 entry drops planes left over from a band that did not (fpl_Lerc2Ext.cpp:432-452): with
           // nDepth > 1 they count into the next band's length (every later band of a size query, :391-403).
@@ -705,7 +704,7 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   if (rq.hUsesNoData) for (int i = 0; i < rq.nBands; i++) anyNoData = anyNoData || rq.hUsesNoData[i] != 0;
   if (anyNoData && !rq.hNoDataValues) return kWrongParam;
   if (anyNoData) need += (size_t)nPix * rq.nDepth * tb + (size_t)nPix + 8192;
-  if (rq.dt >= DT_Float && rq.maxZErr == 0 && rq.version >= 6) need += fplEncodeScratchBytes(nPix * rq.nDepth, tb);
+  if (rq.dt >= DT_Float && (rq.maxZErr == 0 || anyNoData) && rq.version >= 6) need += fplEncodeScratchBytes(nPix * rq.nDepth, tb);
   // (a size query, dOut == nullptr, takes the first two steps of the streaming path: statistics and decisions)
   if (rq.version < 3 || rq.version > kCodecVersion) return kWrongParam;
   if (rq.version < 6 && anyNoData) return kWrongParam;    // Lerc.cpp:341-344

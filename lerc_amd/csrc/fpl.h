@@ -31,7 +31,10 @@ size_t fplEncodeScratchBytes(i64 nElem, int unit);
 size_t fplDecodeScratchBytes(i64 nElem, int unit);
 
 // statistics on the device, decisions on the host; false on a runtime error or when the reference would give up
-bool planLosslessFloat(Context& ctx, int dt, const void* dData, const u8* dByteMask, int nRows, int nCols, int nDepth, FplPlan& plan);
+// (nansFiltered: dData is the noData filter's private copy, NaNs of valid pixels are already replaced there; otherwise a NaN
+// in a valid pixel of an nDepth == 1 band counts as 0, the way Lerc::FilterNoDataAndNaN leaves it, Lerc.cpp:1439-1442)
+bool planLosslessFloat(Context& ctx, int dt, const void* dData, const u8* dByteMask, bool nansFiltered, int nRows, int nCols, int nDepth,
+                       FplPlan& plan);
 // writes plan.nBytes bytes at dOut
 bool emitLosslessFloat(Context& ctx, const FplPlan& plan, u8* dOut);
 // decodes the stream at band + dataBegin into dOut (all pixels, valid or not: fpl_Lerc2Ext.cpp:858); returns an ErrCode

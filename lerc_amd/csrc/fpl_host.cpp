@@ -109,12 +109,14 @@ size_t fplDecodeScratchBytes(i64 nElem, int unit)
   return (size_t)unit * (size_t)fplPlaneStride(nElem) + 6 * n + n * unit / 64 + (8u << 20);
 }
 
-bool planLosslessFloat(Context& ctx, int dt, const void* dData, const u8* dByteMask, int nRows, int nCols, int nDepth, FplPlan& plan)
+bool planLosslessFloat(Context& ctx, int dt, const void* dData, const u8* dByteMask, bool nansFiltered, int nRows, int nCols, int nDepth,
+                       FplPlan& plan)
 {
   hipStream_t st = ctx.activeStream();
   plan = FplPlan();
   const int U = (dt == DT_Double) ? 8 : 4;
-  const FplGeom g = geomOf(U, nRows, nCols, nDepth);
+  FplGeom g = geomOf(U, nRows, nCols, nDepth);
+  if (nansFiltered) g.nanToZero = 0;
   plan.unit = U; plan.nElem = g.nElem; plan.nRows = nRows; plan.nCols = nCols; plan.nDepth = nDepth;
   if (g.nElem <= 0 || g.nElem > (i64)INT_MAX) return false;
   const u32 n = (u32)g.nElem;

@@ -158,7 +158,7 @@ def nodata_fuzz_cases(n_iter, seed=33):
             x[rng.random((r, c)) < 0.1] = np.array(nod).astype(dt)
         if kind == "f" and rng.random() < 0.3:
             x[rng.random(x.shape) < 0.02] = np.nan
-        e = float(rng.choice([0.01, 0.5, 2])) if kind == "f" else float(rng.choice([0, 1, 3]))
+        e = float(rng.choice([0, 0.01, 0.5, 2])) if kind == "f" else float(rng.choice([0, 1, 3]))
         kw = dict(n_depth=nd, no_data=nod)
         if rng.random() < 0.3:
             kw["mask"] = (rng.random((r, c)) > 0.2).astype(np.uint8)
@@ -170,15 +170,17 @@ def nodata_fuzz_cases(n_iter, seed=33):
 
 
 def check_nodata_case(T, P, name, arr, e, kw, same):
-    """T: trusted library (reference or oracle), P: the library under test.  Float rasters whose error bound the
-    noData filter drops to 0 need the lossless float codec, which P does not have: Failed(1) is the contract there."""
+    """T: trusted library (reference or oracle), P: the library under test.  (Float rasters whose error bound the
+    noData filter drops to 0 go through the lossless float codec.)"""
     s1, s2 = T.compute_size(arr, e, **kw), P.compute_size(arr, e, **kw)
     r1, b1 = T.encode(arr, e, **kw)
     r2, b2 = P.encode(arr, e, **kw)
-    if r1 == 0 and arr.dtype.kind == "f" and T.blob_info(b1)[2][2] == 0:
-        assert r2 == 1 and s2[0] == 1, name
-        return
-    assert s1 == s2 and r1 == r2 and b1 == b2, name
+    assert s1 == s2 and r1 == r2 and len(b1) == len(b2), name
+    if b1 != b2:    # a float band the filter made lossless: the reference leaves a few padding bytes to chance
+        a1, a2 = bytearray(b1), bytearray(b2)
+        for k in lossless_float_dont_care(b1, arr.dtype.itemsize):
+            a1[k] = a2[k] = 0
+        assert a1 == a2, name
     if r1 != 0:
         return
     d1, d2 = T.decode(b1, with_nodata=True), P.decode(b1, with_nodata=True)

@@ -136,3 +136,9 @@ def test_lossless_float(O):
     reference leaves uninitialised), including the multi-band nDepth > 1 size query quirk."""
     for name, arr, kw in cases.lossless_float_cases(150, seed=94, max_side=200):
         cases.check_lossless_float_case(R, O, name, arr, kw, _same)
+
+
+def test_nodata_fuzz(O):
+    """the shared noData case generator (also used against the product), lossless float bands included"""
+    for name, arr, e, kw in cases.nodata_fuzz_cases(250, seed=34):
+        cases.check_nodata_case(R, O, name, arr, e, kw, _same)
