@@ -367,3 +367,25 @@ def test_sim_lossless_float_against_reference(libs):
     O, S = libs
     for name, arr, kw in cases.lossless_float_cases(40, seed=92):
         cases.check_lossless_float_case(R, S, name, arr, kw, _same)
+
+
+def test_sim_lossless_float_damaged_blobs(libs):
+    """flipped / overwritten bytes and truncation in lossless float blobs: same verdict as the oracle, no out-of-bounds walk
+    (the emulator runs the kernels as host code, so a stray access would crash the test)"""
+    O, S = libs
+    rng = np.random.default_rng(5)
+    for name, arr, kw in cases.lossless_float_cases(8, seed=7, max_side=60):
+        rc, blob = O.encode(arr, 0, **kw)
+        assert rc == 0
+        for t in range(12):
+            b = bytearray(blob)
+            k = int(rng.integers(0, len(b)))
+            how = int(rng.integers(0, 3))
+            if how == 0:
+                b[k] ^= 1 << int(rng.integers(0, 8))
+            elif how == 1:
+                b[k] = int(rng.integers(0, 256))
+            else:
+                b = b[:max(20, k)]
+            b = bytes(b)
+            assert (O.decode(b)[0] == 0) == (S.decode(b)[0] == 0), (name, k, how)
