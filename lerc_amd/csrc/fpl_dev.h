@@ -32,7 +32,7 @@ void launchFplPredict(const void* data, const u8* byteMask, const FplGeom& g, in
 void launchFplLevelSamples(const void* units, const FplGeom& g, const FplSpan* snippets, u32 nSnippets,
                            u32* histos /* [unit][nSnippets][kFplLevels][256] */, hipStream_t st);
 void launchFplSymbols(const void* units, const FplGeom& g, const FplLevels& lv, u8* planes /* [unit][nElem] */,
-                      u32* histos /* [unit][256], zeroed */, hipStream_t st);
+                      u32* histos /* [unit][256] + [8]: bytes per plane that equal their successor; zeroed */, hipStream_t st);
 
 // PackBits (fpl_EsriHuffman.cpp:79-236) of one byte plane: size, then the stream itself
 struct PackBitsBuffers
@@ -46,9 +46,9 @@ void launchPackBitsPlan(const u8* plane, u32 n, const PackBitsBuffers& b, hipStr
 void launchPackBitsEmit(const u8* plane, u32 n, const PackBitsBuffers& b, u8* out, hipStream_t st);
 
 // ---- decode
-// tokens of a PackBits stream, walked by one lane; tokSrc / tokDst have room for n / 2 + 2 entries, result = { nTokens, ok }
-void launchPackBitsWalk(const u8* in, u32 n, u32 expected, u32* tokSrc, u32* tokDst, u32* result, hipStream_t st);
-void launchPackBitsExpand(const u8* in, const u32* tokSrc, const u32* tokDst, const u32* result, u32 maxTokens, u8* out, hipStream_t st);
+// PackBits stream -> plane; scratch holds packBitsDecodeScratchBytes(n) bytes (256-byte aligned), result = { bytes produced, ok }
+size_t packBitsDecodeScratchBytes(u32 n);
+bool launchPackBitsDecode(const u8* in, u32 n, u32 expected, u8* scratch, u32* result, u8* out, hipStream_t st);
 // restoreSequence (fpl_Lerc2Ext.cpp:128-165), one level: p[i] += p[i - 1] for i = 1 .. n - 1
 void launchBytePrefixSum(u8* p, u32 n, u32* scratch /* n / 1024 + 8 */, hipStream_t st);
 // planes -> units -> predictor undone -> float bits back in place (fpl_Lerc2Ext.cpp:608-721)

@@ -131,8 +131,10 @@ bool planLosslessFloat(Context& ctx, int dt, const void* dData, const u8* dByteM
   if (!dBlocks || !dH1) return false;
   hipMemcpyAsync(dBlocks, blocks.data(), blocks.size() * sizeof(FplSpan), hipMemcpyHostToDevice, st);
   { ProfScope ps(ctx, "fpl_predictor_samples"); launchFplPredictorSamples(dData, dByteMask, g, dBlocks, (u32)blocks.size(), dH1, st); }
-  std::vector<u32> h1(blocks.size() * h1Len);
-  hipMemcpyAsync(h1.data(), dH1, h1.size() * 4, hipMemcpyDeviceToHost, st);
+  // (histograms come back through the context's pinned mirror: a pageable target costs a staging copy at ~1 GB/s)
+  const u32* h1 = (const u32*)ctx.pinned(blocks.size() * h1Len * 4);
+  if (!h1) return false;
+  hipMemcpyAsync((void*)h1, dH1, blocks.size() * h1Len * 4, hipMemcpyDeviceToHost, st);
   if (!waitFor(ctx)) return false;
   size_t est[3] = { 0, 0, 0 };
   for (int p = 0; p < 3; p++)
@@ -165,8 +167,9 @@ bool planLosslessFloat(Context& ctx, int dt, const void* dData, const u8* dByteM
     if (!dSnips || !dH2) return false;
     hipMemcpyAsync(dSnips, snips.data(), snips.size() * sizeof(FplSpan), hipMemcpyHostToDevice, st);
     { ProfScope ps(ctx, "fpl_level_samples"); launchFplLevelSamples(dUnits, g, dSnips, (u32)snips.size(), dH2, st); }
-    std::vector<u32> h2((size_t)U * snips.size() * h2Len);
-    hipMemcpyAsync(h2.data(), dH2, h2.size() * 4, hipMemcpyDeviceToHost, st);
+    const u32* h2 = (const u32*)ctx.pinned((size_t)U * snips.size() * h2Len * 4);
+    if (!h2) return false;
+    hipMemcpyAsync((void*)h2, dH2, (size_t)U * snips.size() * h2Len * 4, hipMemcpyDeviceToHost, st);
     if (!waitFor(ctx)) return false;
     for (int b = 0; b < U; b++)
     {
@@ -183,34 +186,25 @@ bool planLosslessFloat(Context& ctx, int dt, const void* dData, const u8* dByteM
     }
   }
 
-  // ---- 3. the planes as they get coded, their histograms, their PackBits sizes
+  // ---- 3. the planes as they get coded, their histograms
   const i64 stride = fplPlaneStride(g.nElem);
   plan.dPlanes = ctx.allocT<u8>((size_t)U * stride);
-  u32* dH3 = ctx.allocT<u32>((size_t)U * 256 + 8);
+  const size_t h3Len = (size_t)U * 256 + 8 + 8;    // histograms, "equals its successor" counts, PackBits sizes
+  u32* dH3 = ctx.allocT<u32>(h3Len);
   if (!plan.dPlanes || !dH3) return false;
-  hipMemsetAsync(dH3, 0, ((size_t)U * 256 + 8) * 4, st);
+  hipMemsetAsync(dH3, 0, h3Len * 4, st);
   { ProfScope ps(ctx, "fpl_symbols"); launchFplSymbols(dUnits, g, lv, plan.dPlanes, dH3, st); }
-  const size_t mark = ctx.used();
-  PackBitsBuffers pb;
-  pb.runStart = ctx.allocT<u32>((size_t)n + 4);
-  pb.litStart = ctx.allocT<u32>((size_t)n + 4);
-  pb.offset = ctx.allocT<u32>((size_t)n + 4);
-  pb.scratch = ctx.allocT<u32>((size_t)n / 1024 + 8);
-  u32* dPbSize = dH3 + (size_t)U * 256;
-  if (!pb.runStart || !pb.litStart || !pb.offset || !pb.scratch) return false;
-  for (int b = 0; b < U; b++)
+  std::vector<u32> h3(h3Len);
   {
-    ProfScope ps(ctx, "fpl_packbits_size");
-    launchPackBitsPlan(plan.dPlanes + (size_t)b * stride, n, pb, st);
-    hipMemcpyAsync(dPbSize + b, pb.offset + n, 4, hipMemcpyDeviceToDevice, st);
+    u32* pin = (u32*)ctx.pinned(h3Len * 4);
+    if (!pin) return false;
+    hipMemcpyAsync(pin, dH3, h3Len * 4, hipMemcpyDeviceToHost, st);
+    if (!waitFor(ctx)) return false;
+    memcpy(h3.data(), pin, h3Len * 4);
   }
-  std::vector<u32> h3((size_t)U * 256 + 8);
-  hipMemcpyAsync(h3.data(), dH3, h3.size() * 4, hipMemcpyDeviceToHost, st);
-  if (!waitFor(ctx)) return false;
-  ctx.rewind(mark);
 
-  // ---- 4. how every plane is coded (fpl_EsriHuffman.cpp:306-381)
-  u32 total = 1;    // predictor code
+  // code books; PackBits is sized only where it can win
+  bool needPackBits[8] = { false, false, false, false, false, false, false, false }, anyPackBits = false;
   for (int b = 0; b < U; b++)
   {
     FplPlanePlan& pp = plan.plane[b];
@@ -218,11 +212,47 @@ bool planLosslessFloat(Context& ctx, int dt, const void* dData, const u8* dByteM
     std::vector<int> histo(256);
     int distinct = 0, firstSym = 0;
     for (int i = 0; i < 256; i++) { histo[i] = (int)h3[(size_t)b * 256 + i]; if (histo[i] > 0 && distinct++ == 0) firstSym = i; }
-    if (distinct < 2) { pp.mode = 1; pp.value = (u8)firstSym; pp.size = 6; }
-    else
+    if (distinct < 2) { pp.mode = 1; pp.value = (u8)firstSym; pp.size = 6; continue; }
+    if (!planHuffmanFromHisto(histo, pp.huff)) { ctx.lastError = "lossless float: no Huffman code book for a byte plane"; return false; }
+    // every run of equal bytes emits at least one byte, every 128 single bytes one count byte more; at most `eq` runs are
+    // longer than one byte, so at least n - 2 eq are single
+    const u64 eq = h3[(size_t)U * 256 + b], runs = (u64)n - eq, singles = (2 * eq < n) ? (u64)n - 2 * eq : 0;
+    needPackBits[b] = runs + singles / 128 < std::min<u64>(pp.huff.nBytes, n);
+    anyPackBits = anyPackBits || needPackBits[b];
+  }
+  if (anyPackBits)
+  {
+    const size_t mark = ctx.used();
+    PackBitsBuffers pb;
+    pb.runStart = ctx.allocT<u32>((size_t)n + 4);
+    pb.litStart = ctx.allocT<u32>((size_t)n + 4);
+    pb.offset = ctx.allocT<u32>((size_t)n + 4);
+    pb.scratch = ctx.allocT<u32>((size_t)n / 1024 + 8);
+    u32* dPbSize = dH3 + (size_t)U * 256 + 8;
+    if (!pb.runStart || !pb.litStart || !pb.offset || !pb.scratch) return false;
+    for (int b = 0; b < U; b++)
     {
-      if (!planHuffmanFromHisto(histo, pp.huff)) { ctx.lastError = "lossless float: no Huffman code book for a byte plane"; return false; }
-      const long numBytes = (long)pp.huff.nBytes, rle = (long)h3[(size_t)U * 256 + b];
+      if (!needPackBits[b]) continue;
+      ProfScope ps(ctx, "fpl_packbits_size");
+      launchPackBitsPlan(plan.dPlanes + (size_t)b * stride, n, pb, st);
+      hipMemcpyAsync(dPbSize + b, pb.offset + n, 4, hipMemcpyDeviceToDevice, st);
+    }
+    u32* pin = (u32*)ctx.pinned(64);
+    if (!pin) return false;
+    hipMemcpyAsync(pin, dPbSize, 8 * 4, hipMemcpyDeviceToHost, st);
+    if (!waitFor(ctx)) return false;
+    memcpy(h3.data() + (size_t)U * 256 + 8, pin, 8 * 4);
+    ctx.rewind(mark);
+  }
+
+  // ---- 4. how every plane is coded (fpl_EsriHuffman.cpp:306-381)
+  u32 total = 1;    // predictor code
+  for (int b = 0; b < U; b++)
+  {
+    FplPlanePlan& pp = plan.plane[b];
+    if (pp.mode != 1)
+    {
+      const long numBytes = (long)pp.huff.nBytes, rle = needPackBits[b] ? (long)h3[(size_t)U * 256 + 8 + b] : 0;
       if (rle > 0 && rle < numBytes && rle < (long)n) { pp.mode = 3; pp.size = (u32)rle + 1; }
       else if (numBytes >= (long)n) { pp.mode = 2; pp.size = n + 1; }
       else { pp.mode = 0; pp.size = (u32)numBytes + 1; }
@@ -364,14 +394,12 @@ u32 decodeLosslessFloat(Context& ctx, int dt, const u8* hBand, const u8* dBand, 
     }
     else if (mode == 3)
     {
-      const u32 nIn = size - 1, maxTok = nIn / 2 + 2;
-      u32* tokSrc = ctx.allocT<u32>(maxTok);
-      u32* tokDst = ctx.allocT<u32>(maxTok);
+      const u32 nIn = size - 1;
+      u8* scratch = (u8*)ctx.alloc(nIn ? packBitsDecodeScratchBytes(nIn) : 256);
       u32* dRes = ctx.allocT<u32>(4);
-      if (!tokSrc || !tokDst || !dRes) return failAt(ctx, 11);
+      if (!scratch || !dRes || nIn == 0) return failAt(ctx, 100);
       ProfScope ps(ctx, "fpl_packbits_decode");
-      launchPackBitsWalk(dBand + at + 1, nIn, n, tokSrc, tokDst, dRes, st);
-      launchPackBitsExpand(dBand + at + 1, tokSrc, tokDst, dRes, maxTok, dPlane, st);
+      launchPackBitsDecode(dBand + at + 1, nIn, n, scratch, dRes, dPlane, st);
       u32* pin = (u32*)ctx.pinned(64);
       if (!pin) return failAt(ctx, 12);
       hipMemcpyAsync(pin, dRes, 8, hipMemcpyDeviceToHost, st);

@@ -56,7 +56,8 @@ __device__ __forceinline__ void predictAll(const void* __restrict__ data, const 
                                            typename UnitOf<U>::T out[3])
 {
   typedef typename UnitOf<U>::T T;
-  const i64 r = e / g.cols, c = e - r * g.cols;
+  const u32 r32 = (u32)e / (u32)g.cols;    // (elements and columns fit 31 bits: a 32-bit division is a fraction of a 64-bit one)
+  const i64 r = r32, c = e - r * g.cols;
   const T u = loadUnit<U>(data, byteMask, g, e);
   const T d1 = (c >= 1) ? fplSub(u, loadUnit<U>(data, byteMask, g, e - 1)) : u;
   T d2 = d1;
@@ -126,7 +127,7 @@ k_fpl_predict(const void* __restrict__ data, const u8* __restrict__ byteMask, Fp
   if (e >= g.nElem) return;
   T v[3];
   predictAll<U>(data, byteMask, g, e, v);
-  units[e] = v[predictor];
+  units[e] = (predictor == 0) ? v[0] : (predictor == 1 ? v[1] : v[2]);    // (no indexed access: that would put v[] in scratch)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -168,35 +169,47 @@ k_fpl_symbols(const typename UnitOf<U>::T* __restrict__ units, FplGeom g, FplLev
               u32* __restrict__ histos)
 {
   typedef typename UnitOf<U>::T T;
-  __shared__ u32 s_h[U * 256];
-  for (int i = threadIdx.x; i < U * 256; i += 256) s_h[i] = 0;
+  __shared__ u32 s_h[U * 256 + 8];    // histograms, then per plane: how many bytes equal their successor
+  for (int i = threadIdx.x; i < U * 256 + 8; i += 256) s_h[i] = 0;
   __syncthreads();
   const i64 i0 = ((i64)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i0 < g.nElem)
-  {
-    T p[9];    // p[5 + k] = element i0 + k
-    for (int k = -5; k < 4; k++) p[5 + k] = (i0 + k >= 0 && i0 + k < g.nElem) ? units[i0 + k] : (T)0;
+  {    // (threads behind the last element run along with nothing to count: the ballots below want whole waves)
+    T p[10];    // p[5 + k] = element i0 + k  (all loops below unroll: p[] and x[] stay in registers)
+#pragma unroll
+    for (int k = -5; k < 5; k++) p[5 + k] = (i0 + k >= 0 && i0 + k < g.nElem) ? units[i0 + k] : (T)0;
+#pragma unroll
     for (int b = 0; b < U; b++)
     {
       const int L = lv.level[b];
-      u32 word = 0;
-      for (int k = 0; k < 4; k++)
+      u32 word = 0, prev = 0, equal = 0;
+#pragma unroll
+      for (int k = 0; k < 5; k++)    // (the fifth symbol belongs to the next thread: only compared)
       {
         const i64 i = i0 + k;
-        if (i >= g.nElem) break;
+        const bool in = i < g.nElem;
         u32 x[6];
+#pragma unroll
         for (int j = 0; j < 6; j++) x[j] = (u32)(p[5 + k - j] >> (8 * b)) & 255u;
         const u32 s = byteDifference(x, (i < L) ? (int)i : L);
-        word |= s << (8 * k);
-        atomicAdd(&s_h[b * 256 + s], 1u);
+        if (in && k > 0 && s == prev) equal++;
+        prev = s;
+        if (in && k < 4) word |= s << (8 * k);
+        // histogram: the high planes hold one or two values almost everywhere -- when the whole wave agrees, one add
+        const bool count = in && k < 4;
+        const u64 voters = __ballot(count);
+        const u32 s0 = __shfl(s, voters ? __ffsll((long long)voters) - 1 : 0);
+        const bool same = __ballot(count && s == s0) == voters;
+        if (same) { if (voters && laneId() == __ffsll((long long)voters) - 1) atomicAdd(&s_h[b * 256 + s0], (u32)__popcll(voters)); }
+        else if (count) atomicAdd(&s_h[b * 256 + s], 1u);
       }
+      if (equal) atomicAdd(&s_h[U * 256 + b], equal);
       u8* dst = planes + (size_t)b * planeStride + i0;    // planeStride is a multiple of 16
       if (i0 + 3 < g.nElem) *reinterpret_cast<u32*>(dst) = word;
-      else for (int k = 0; i0 + k < g.nElem; k++) dst[k] = (u8)(word >> (8 * k));
+      else for (int k = 0; k < 4 && i0 + k < g.nElem; k++) dst[k] = (u8)(word >> (8 * k));
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < U * 256; i += 256) if (s_h[i]) atomicAdd(&histos[i], s_h[i]);
+  for (int i = threadIdx.x; i < U * 256 + 8; i += 256) if (s_h[i]) atomicAdd(&histos[i], s_h[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -350,50 +363,118 @@ __global__ void __launch_bounds__(256) k_pb_emit(const u8* __restrict__ s, u32 n
   out[at] = v;
 }
 
-// decode: the tokens can only be found one after the other; one lane walks them out of LDS
-static const u32 kPbChunk = 8192, kPbOverlap = 160;
+// decode.  Where a token starts depends on every token before it, but a token is at most 129 bytes long: the first
+// token start at or behind any stream position p lies in [p, p + 128].  So the stream is cut into segments of 512
+// bytes, and for each segment and EACH of the 129 possible entries a lane walks to the segment's end: exit (= entry
+// into the next segment) and bytes produced.  Entry -> exit is a function on 129 states; functions compose, so groups
+// of 256 segments are folded by 129 lanes, the few groups by one lane, and then every segment knows its true entry.
+// States 254 / 255: the stream ended exactly on a token boundary / the walk ran past the stream's end (damaged).
+static const u32 kPbSeg = 512, kPbStates = 129, kPbGroup = 256;
+static const u32 kPbEnd = 254, kPbBad = 255;
 
-__global__ void __launch_bounds__(256) k_pb_walk(const u8* __restrict__ in, u32 n, u32 expected, u32* __restrict__ tokSrc,
-                                                 u32* __restrict__ tokDst, u32* __restrict__ result)
+__device__ __forceinline__ u32 pbConsumed(u32 b) { return (b <= 127u) ? b + 2u : 2u; }
+__device__ __forceinline__ u32 pbProduced(u32 b) { return (b <= 127u) ? b + 1u : b - 126u; }
+
+__global__ void __launch_bounds__(256) k_pb_seg_tables(const u8* __restrict__ in, u32 n, u8* __restrict__ exitT, u32* __restrict__ outT)
 {
-  __shared__ u8 s_buf[kPbChunk + kPbOverlap];
-  __shared__ u32 s_state[4];    // src, dst, nTokens, status (0 running, 1 done, 2 bad)
-  if (threadIdx.x == 0) { s_state[0] = 0; s_state[1] = 0; s_state[2] = 0; s_state[3] = (n == 0) ? 1u : 0u; }
+  __shared__ u8 s_buf[kPbSeg];
+  const u32 seg = blockIdx.x, base = seg * kPbSeg;
+  for (u32 i = threadIdx.x; i < kPbSeg; i += 256u) s_buf[i] = (base + i < n) ? in[base + i] : (u8)0;
   __syncthreads();
-  for (u32 base = 0; base < n; base += kPbChunk)
+  const u32 o = threadIdx.x;
+  if (o >= kPbStates) return;
+  u32 pos = o, out = 0, state = 0;
+  if (base + pos > n) state = kPbBad;
+  while (state == 0u && pos < kPbSeg && base + pos < n)
   {
-    if (s_state[3] != 0u) break;    // (uniform: read between barriers)
-    for (u32 i = threadIdx.x; i < kPbChunk + kPbOverlap; i += 256u) s_buf[i] = (base + i < n) ? in[base + i] : (u8)0;
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-      u32 src = s_state[0], dst = s_state[1], k = s_state[2], status = 0;
-      while (src < n && src < base + kPbChunk)
-      {
-        const u32 b = s_buf[src - base];
-        const u32 produced = (b <= 127u) ? b + 1u : b - 126u;
-        const u32 consumed = (b <= 127u) ? b + 2u : 2u;
-        if (dst + produced > expected || src + consumed > n) { status = 2u; break; }    // fpl_EsriHuffman.cpp:58, :68
-        tokSrc[k] = src; tokDst[k] = dst; k++;
-        src += consumed; dst += produced;
-      }
-      if (status == 0u && src >= n) status = (dst == expected) ? 1u : 2u;
-      s_state[0] = src; s_state[1] = dst; s_state[2] = k; s_state[3] = status;
-    }
-    __syncthreads();
+    const u32 b = s_buf[pos];
+    if (base + pos + pbConsumed(b) > n) { state = kPbBad; break; }
+    out += pbProduced(b);
+    pos += pbConsumed(b);
   }
-  if (threadIdx.x == 0) { result[0] = s_state[2]; result[1] = (s_state[3] == 1u && s_state[1] == expected) ? 1u : 0u; }
+  if (state == 0u) state = (base + pos == n) ? kPbEnd : pos - kPbSeg;
+  exitT[(size_t)seg * kPbStates + o] = (u8)state;
+  outT[(size_t)seg * kPbStates + o] = out;
 }
 
-__global__ void __launch_bounds__(256) k_pb_expand(const u8* __restrict__ in, const u32* __restrict__ tokSrc, const u32* __restrict__ tokDst,
+__device__ __forceinline__ u32 pbNext(const u8* table, u32 state) { return state < kPbStates ? (u32)table[state] : state; }
+
+__global__ void __launch_bounds__(256) k_pb_group_compose(const u8* __restrict__ exitT, u32 nSeg, u8* __restrict__ groupExit)
+{
+  __shared__ u8 s_t[kPbGroup * kPbStates];
+  const u32 s0 = blockIdx.x * kPbGroup, cnt = min(kPbGroup, nSeg - s0);
+  for (u32 i = threadIdx.x; i < cnt * kPbStates; i += 256u) s_t[i] = exitT[(size_t)s0 * kPbStates + i];
+  __syncthreads();
+  if (threadIdx.x >= kPbStates) return;
+  u32 cur = threadIdx.x;
+  for (u32 s = 0; s < cnt; s++) cur = pbNext(s_t + s * kPbStates, cur);
+  groupExit[(size_t)blockIdx.x * kPbStates + threadIdx.x] = (u8)cur;
+}
+
+__global__ void __launch_bounds__(64) k_pb_group_entries(const u8* __restrict__ groupExit, u32 nGroups, u8* __restrict__ groupEntry)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  u32 cur = 0;
+  for (u32 g = 0; g < nGroups; g++) { groupEntry[g] = (u8)cur; cur = pbNext(groupExit + (size_t)g * kPbStates, cur); }
+  groupEntry[nGroups] = (u8)cur;    // state behind the last segment: kPbEnd for an intact stream
+}
+
+__global__ void __launch_bounds__(256) k_pb_seg_entries(const u8* __restrict__ exitT, const u32* __restrict__ outT, u32 nSeg,
+                                                         const u8* __restrict__ groupEntry, u8* __restrict__ entry, u32* __restrict__ segOut)
+{
+  __shared__ u8 s_t[kPbGroup * kPbStates];
+  const u32 s0 = blockIdx.x * kPbGroup, cnt = min(kPbGroup, nSeg - s0);
+  for (u32 i = threadIdx.x; i < cnt * kPbStates; i += 256u) s_t[i] = exitT[(size_t)s0 * kPbStates + i];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  u32 cur = groupEntry[blockIdx.x];
+  for (u32 s = 0; s < cnt; s++)
+  {
+    entry[s0 + s] = (u8)cur;
+    segOut[s0 + s] = (cur < kPbStates) ? outT[(size_t)(s0 + s) * kPbStates + cur] : 0u;
+    cur = pbNext(s_t + s * kPbStates, cur);
+  }
+}
+
+__global__ void __launch_bounds__(64) k_pb_verdict(const u8* __restrict__ groupEntry, u32 nGroups, const u32* __restrict__ segOut, u32 nSeg,
+                                                   u32 expected, u32* __restrict__ result)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  result[0] = segOut[nSeg - 1u];    // inclusive sums: bytes the whole stream produces
+  result[1] = (groupEntry[nGroups] == kPbEnd && segOut[nSeg - 1u] == expected) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_pb_expand(const u8* __restrict__ in, u32 n, const u8* __restrict__ entry, const u32* __restrict__ segOut,
                                                    const u32* __restrict__ result, u8* __restrict__ out)
 {
-  const u32 t = blockIdx.x * 256u + threadIdx.x;
-  if (t >= result[0] || result[1] == 0u) return;
-  const u32 src = tokSrc[t], dst = tokDst[t];
-  const u32 b = in[src];
-  if (b <= 127u) for (u32 j = 0; j <= b; j++) out[dst + j] = in[src + 1u + j];
-  else { const u8 v = in[src + 1u]; for (u32 j = 0; j < b - 126u; j++) out[dst + j] = v; }
+  __shared__ u8 s_buf[kPbSeg + 132];
+  __shared__ u32 s_src[kPbSeg / 2 + 2], s_dst[kPbSeg / 2 + 2], s_count;
+  const u32 seg = blockIdx.x, base = seg * kPbSeg;
+  for (u32 i = threadIdx.x; i < kPbSeg + 132u; i += 256u) s_buf[i] = (base + i < n) ? in[base + i] : (u8)0;
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    u32 k = 0;
+    const u32 e = entry[seg];
+    if (result[1] == 1u && e < kPbStates)
+    {
+      u32 pos = e, dst = (seg > 0) ? segOut[seg - 1u] : 0u;    // segOut[] holds the inclusive sums
+      while (pos < kPbSeg && base + pos < n)
+      {
+        const u32 b = s_buf[pos];
+        s_src[k] = pos; s_dst[k] = dst; k++;
+        dst += pbProduced(b);
+        pos += pbConsumed(b);
+      }
+    }
+    s_count = k;
+  }
+  __syncthreads();
+  const u32 t = threadIdx.x;
+  if (t >= s_count) return;
+  const u32 pos = s_src[t], dst = s_dst[t], b = s_buf[pos];
+  if (b <= 127u) for (u32 j = 0; j <= b; j++) out[dst + j] = s_buf[pos + 1u + j];
+  else { const u8 v = s_buf[pos + 1u]; for (u32 j = 0; j < b - 126u; j++) out[dst + j] = v; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -544,15 +625,34 @@ void launchPackBitsEmit(const u8* plane, u32 n, const PackBitsBuffers& b, u8* ou
                      (const u32*)b.offset, out);
 }
 
-void launchPackBitsWalk(const u8* in, u32 n, u32 expected, u32* tokSrc, u32* tokDst, u32* result, hipStream_t st)
+size_t packBitsDecodeScratchBytes(u32 n)
 {
-  hipLaunchKernelGGL(k_pb_walk, dim3(1), dim3(256), 0, st, in, n, expected, tokSrc, tokDst, result);
+  const size_t nSeg = ((size_t)n + kPbSeg - 1) / kPbSeg, nGroups = (nSeg + kPbGroup - 1) / kPbGroup;
+  return nSeg * kPbStates * 5 + nSeg * 5 + nGroups * (kPbStates + 1) + (nSeg / 1024 + 16) * 4 + 8192;
 }
 
-void launchPackBitsExpand(const u8* in, const u32* tokSrc, const u32* tokDst, const u32* result, u32 maxTokens, u8* out, hipStream_t st)
+// result[0] = bytes the stream produces, result[1] = 1 if the stream is intact and produces exactly `expected` bytes
+// (only then is anything written to out)
+bool launchPackBitsDecode(const u8* in, u32 n, u32 expected, u8* scratch, u32* result, u8* out, hipStream_t st)
 {
-  if (maxTokens == 0) return;
-  hipLaunchKernelGGL(k_pb_expand, dim3((maxTokens + 255u) / 256u), dim3(256), 0, st, in, tokSrc, tokDst, result, out);
+  if (n == 0) return false;
+  const u32 nSeg = (n + kPbSeg - 1u) / kPbSeg, nGroups = (nSeg + kPbGroup - 1u) / kPbGroup;
+  auto take = [&](size_t bytes) { u8* p = scratch; scratch += (bytes + 255) & ~(size_t)255; return p; };
+  u32* outT = (u32*)take((size_t)nSeg * kPbStates * 4);
+  u32* segOut = (u32*)take((size_t)nSeg * 4 + 16);
+  u32* scanScratch = (u32*)take(((size_t)nSeg / 1024 + 16) * 4);
+  u8* exitT = take((size_t)nSeg * kPbStates);
+  u8* entry = take(nSeg);
+  u8* groupExit = take((size_t)nGroups * kPbStates);
+  u8* groupEntry = take(nGroups + 1);
+  hipLaunchKernelGGL(k_pb_seg_tables, dim3(nSeg), dim3(256), 0, st, in, n, exitT, outT);
+  hipLaunchKernelGGL(k_pb_group_compose, dim3(nGroups), dim3(256), 0, st, (const u8*)exitT, nSeg, groupExit);
+  hipLaunchKernelGGL(k_pb_group_entries, dim3(1), dim3(64), 0, st, (const u8*)groupExit, nGroups, groupEntry);
+  hipLaunchKernelGGL(k_pb_seg_entries, dim3(nGroups), dim3(256), 0, st, (const u8*)exitT, (const u32*)outT, nSeg, (const u8*)groupEntry, entry, segOut);
+  inclusiveScan<u32, ScanSum>(segOut, nSeg, scanScratch, st);
+  hipLaunchKernelGGL(k_pb_verdict, dim3(1), dim3(64), 0, st, (const u8*)groupEntry, nGroups, (const u32*)segOut, nSeg, expected, result);
+  hipLaunchKernelGGL(k_pb_expand, dim3(nSeg), dim3(256), 0, st, in, n, (const u8*)entry, (const u32*)segOut, (const u32*)result, out);
+  return true;
 }
 
 void launchBytePrefixSum(u8* p, u32 n, u32* scratch, hipStream_t st)

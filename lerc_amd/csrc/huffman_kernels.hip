@@ -368,8 +368,78 @@ __global__ void __launch_bounds__(64) k_huff_undelta(T* __restrict__ data, const
     }
 }
 
+// All pixels valid: a pixel continues from its left neighbour and the first pixel of a row from the one above it
+// (the first pixel of the plane from 0), so column 0 is a running sum down the rows and every row then a running sum
+// of its own -- one workgroup per depth plane resp. per (row, plane), 8-bit wrap-around arithmetic.
+__device__ __forceinline__ u32 undeltaWorkgroupScan(u32 v, u32* s_wave, u32& total)
+{
+  const int lane = laneId(), w = waveId();
+  u32 inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += t; }
+  if (lane == 63) s_wave[w] = inc;
+  __syncthreads();
+  u32 before = 0;
+  for (int i = 0; i < w; i++) before += s_wave[i];
+  total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  __syncthreads();
+  return before + inc - v;    // exclusive
+}
+
+template<class T>
+__global__ void __launch_bounds__(256) k_huff_undelta_col0(T* __restrict__ data, HuffGeom g)
+{
+  __shared__ u32 s_wave[4];
+  const int iD = (int)blockIdx.x;
+  u32 carry = 0;
+  for (int i0 = 0; i0 < g.nRows; i0 += 256)
+  {
+    const int i = i0 + (int)threadIdx.x;
+    const i64 at = (i64)i * g.nCols * g.nDepth + iD;
+    const u32 d = (i < g.nRows) ? (u32)(u8)data[at] : 0u;
+    u32 total;
+    const u32 before = undeltaWorkgroupScan(d, s_wave, total);
+    if (i < g.nRows) data[at] = (T)(u8)(carry + before + d);
+    carry += total;
+  }
+}
+
+template<class T>
+__global__ void __launch_bounds__(256) k_huff_undelta_rows(T* __restrict__ data, HuffGeom g)
+{
+  __shared__ u32 s_wave[4];
+  const int iD = (int)blockIdx.y;
+  T* row = data + (i64)blockIdx.x * g.nCols * g.nDepth + iD;
+  u32 carry = 0;
+  for (int j0 = 0; j0 < g.nCols; j0 += 1024)
+  {
+    const int j = j0 + (int)threadIdx.x * 4;
+    u32 v[4];
+    for (int k = 0; k < 4; k++) v[k] = (j + k < g.nCols) ? (u32)(u8)row[(i64)(j + k) * g.nDepth] : 0u;
+    for (int k = 1; k < 4; k++) v[k] += v[k - 1];
+    u32 total;
+    const u32 before = carry + undeltaWorkgroupScan(v[3], s_wave, total);
+    for (int k = 0; k < 4; k++) if (j + k < g.nCols) row[(i64)(j + k) * g.nDepth] = (T)(u8)(before + v[k]);
+    carry += total;
+  }
+}
+
 void launchHuffUndelta(int dt, void* data, const u8* maskBits, const HuffGeom& g, hipStream_t st)
 {
+  if (!maskBits)
+  {
+    if (dt == DT_Char)
+    {
+      hipLaunchKernelGGL(k_huff_undelta_col0<signed char>, dim3(g.nDepth), dim3(256), 0, st, (signed char*)data, g);
+      hipLaunchKernelGGL(k_huff_undelta_rows<signed char>, dim3(g.nRows, g.nDepth), dim3(256), 0, st, (signed char*)data, g);
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_huff_undelta_col0<unsigned char>, dim3(g.nDepth), dim3(256), 0, st, (unsigned char*)data, g);
+      hipLaunchKernelGGL(k_huff_undelta_rows<unsigned char>, dim3(g.nRows, g.nDepth), dim3(256), 0, st, (unsigned char*)data, g);
+    }
+    return;
+  }
   if (dt == DT_Char) hipLaunchKernelGGL(k_huff_undelta<signed char>, dim3(g.nDepth), dim3(64), 0, st, (signed char*)data, maskBits, g);
   else hipLaunchKernelGGL(k_huff_undelta<unsigned char>, dim3(g.nDepth), dim3(64), 0, st, (unsigned char*)data, maskBits, g);
 }

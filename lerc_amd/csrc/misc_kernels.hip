@@ -100,11 +100,32 @@ __global__ void __launch_bounds__(256) k_fletcher(const u8* __restrict__ bytes, 
   __shared__ u64 s_a[4], s_b[4];
   u64 A = 0, B = 0;
   const u32 stride = gridDim.x * 256u;
-  for (u32 p = blockIdx.x * 256u + threadIdx.x; p < len; p += stride)
+  // 16 bytes per load from the first 16-byte aligned address on; byte p counts as (byte << 8) when p is even, with
+  // weight p >> 1 -- inside a vector the weights are (q >> 1) + small constants, so the 64-bit product is paid once
+  const u32 head = min(len, (u32)((16u - ((u32)(uintptr_t)bytes & 15u)) & 15u));
+  const u32 nVec = (len - head) >> 4;
+  const uint4* vec = reinterpret_cast<const uint4*>(bytes + head);
+  for (u32 i = blockIdx.x * 256u + threadIdx.x; i < nVec; i += stride)
   {
-    const u32 c = (u32)bytes[p] << ((p & 1u) ? 0 : 8);
-    A += c;
-    B += (u64)(p >> 1) * c;
+    const u32 q = head + (i << 4), odd = q & 1u;
+    const uint4 x = vec[i];
+    const u32 w[4] = { x.x, x.y, x.z, x.w };
+    u32 sumC = 0, inner = 0;
+#pragma unroll
+    for (u32 j = 0; j < 16u; j++)
+    {
+      const u32 byte = (w[j >> 2] >> (8u * (j & 3u))) & 255u;
+      const u32 c = byte << (((odd + j) & 1u) ? 0u : 8u);
+      sumC += c;
+      inner += ((odd + j) >> 1) * c;
+    }
+    A += sumC;
+    B += (u64)(q >> 1) * sumC + inner;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    for (u32 p = 0; p < head; p++) { const u32 c = (u32)bytes[p] << ((p & 1u) ? 0 : 8); A += c; B += (u64)(p >> 1) * c; }
+    for (u32 p = head + (nVec << 4); p < len; p++) { const u32 c = (u32)bytes[p] << ((p & 1u) ? 0 : 8); A += c; B += (u64)(p >> 1) * c; }
   }
   A %= 65535u; B %= 65535u;
   A = waveSum(A); B = waveSum(B);
