@@ -58,6 +58,50 @@ __device__ __forceinline__ int huffSymbol(const T* __restrict__ data, const u8* 
   return off + (int)delta;
 }
 
+// The same symbol for consecutive stream elements without dividing again: where element v sits (depth plane, pixel,
+// row, column) is worked out once and then stepped.
+struct HuffCursor
+{
+  i64 v, nPix;
+  i64 k;        // pixel
+  int iD, i, j; // depth plane (delta mode) resp. depth index (plain mode), row, column
+  int mode;
+  __device__ __forceinline__ void init(const HuffGeom& g, int mode_, i64 v0)
+  {
+    mode = mode_; v = v0; nPix = (i64)g.nRows * g.nCols;
+    if (mode == IEM_Huffman) { k = v0 / g.nDepth; iD = (int)(v0 - k * g.nDepth); }
+    else { iD = (int)(v0 / nPix); k = v0 - (i64)iD * nPix; }
+    i = (int)(k / g.nCols); j = (int)(k - (i64)i * g.nCols);
+  }
+  __device__ __forceinline__ void step(const HuffGeom& g)
+  {
+    v++;
+    if (mode == IEM_Huffman) { if (++iD < g.nDepth) return; iD = 0; }
+    k++;
+    if (++j == g.nCols) { j = 0; i++; }
+    if (mode != IEM_Huffman && k == nPix) { k = 0; i = 0; j = 0; iD++; }
+  }
+};
+
+template<class T>
+__device__ __forceinline__ int huffSymbolAt(const T* __restrict__ data, const u8* __restrict__ maskBits, const HuffGeom& g, const HuffCursor& c)
+{
+  const int off = (DtOf<T>::v == DT_Char) ? 128 : 0;
+  if (maskBits && !maskBit(maskBits, c.k)) return -1;
+  const T val = data[c.k * g.nDepth + c.iD];
+  if (c.mode == IEM_Huffman) return off + (int)val;
+  T pred = 0;
+  if (c.j > 0 && (!maskBits || maskBit(maskBits, c.k - 1))) pred = data[(c.k - 1) * g.nDepth + c.iD];
+  else if (c.i > 0 && (!maskBits || maskBit(maskBits, c.k - g.nCols))) pred = data[(c.k - g.nCols) * g.nDepth + c.iD];
+  else if (maskBits)
+  {
+    const i64 kp = prevValidPixel(maskBits, c.k);
+    if (kp >= 0) pred = data[kp * g.nDepth + c.iD];
+  }
+  const T delta = (T)(val - pred);
+  return off + (int)delta;
+}
+
 // ---- histograms ---------------------------------------------------------------------------------
 template<class T>
 __global__ void __launch_bounds__(256) k_huff_histo(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffGeom g, u32* __restrict__ histos)
@@ -65,14 +109,24 @@ __global__ void __launch_bounds__(256) k_huff_histo(const T* __restrict__ data, 
   __shared__ u32 s_h[2][256];
   s_h[0][threadIdx.x] = 0; s_h[1][threadIdx.x] = 0;
   __syncthreads();
-  const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
+  // thread t of the grid takes pixels t, t + T, ... ; both symbols of a (pixel, depth) come from the same bytes
+  const i64 nPix = (i64)g.nRows * g.nCols;
   const i64 stride = (i64)gridDim.x * 256;
-  for (i64 v = (i64)blockIdx.x * 256 + threadIdx.x; v < n; v += stride)
+  const int off = (DtOf<T>::v == DT_Char) ? 128 : 0;
+  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < nPix; k += stride)
   {
-    const int s0 = huffSymbol<T>(data, maskBits, g, IEM_Huffman, v);
-    if (s0 >= 0) atomicAdd(&s_h[0][s0], 1u);
-    const int s1 = huffSymbol<T>(data, maskBits, g, IEM_DeltaHuffman, v);
-    if (s1 >= 0) atomicAdd(&s_h[1][s1], 1u);
+    if (maskBits && !maskBit(maskBits, k)) continue;
+    const int i = (int)(k / g.nCols), j = (int)(k - (i64)i * g.nCols);
+    const bool left = j > 0 && (!maskBits || maskBit(maskBits, k - 1));
+    const bool up = !left && i > 0 && (!maskBits || maskBit(maskBits, k - g.nCols));
+    const i64 kp = left ? k - 1 : (up ? k - g.nCols : (maskBits ? prevValidPixel(maskBits, k) : -1));
+    for (int m = 0; m < g.nDepth; m++)
+    {
+      const T val = data[k * g.nDepth + m];
+      const T pred = (kp >= 0) ? data[kp * g.nDepth + m] : (T)0;
+      atomicAdd(&s_h[0][off + (int)val], 1u);
+      atomicAdd(&s_h[1][off + (int)(T)(val - pred)], 1u);
+    }
   }
   __syncthreads();
   if (s_h[0][threadIdx.x]) atomicAdd(&histos[threadIdx.x], s_h[0][threadIdx.x]);
@@ -96,21 +150,61 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
               u32* __restrict__ runBits, const u64* __restrict__ runBase, u32* __restrict__ stream)
 {
   __shared__ u64 s_codes[256];
+  // all pixels valid: the workgroup's 256 x 128 stream elements are turned into symbols with coalesced loads first and
+  // parked in LDS, element e of run r at [e][r] (rows 260 bytes apart: conflict-free both ways); a thread walking its
+  // run straight from global memory touches a different cache line in every lane
+  __shared__ u8 s_sym[kHuffRun * 260];
   s_codes[threadIdx.x] = codes[threadIdx.x];
-  __syncthreads();
   const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
+  const bool staged = (maskBits == nullptr);
+  if (staged)
+  {
+    const int off = (DtOf<T>::v == DT_Char) ? 128 : 0;
+    const i64 vBase = (i64)blockIdx.x * 256 * kHuffRun, nPix = (i64)g.nRows * g.nCols;
+    i64 v = vBase + threadIdx.x;
+    // delta mode walks plane by plane: (plane, pixel, row, column) of this thread's first element, then 256 further each time
+    i64 k = 0;
+    int iD = 0, i = 0, j = 0;
+    if (mode != IEM_Huffman && v < n) { iD = (int)(v / nPix); k = v - (i64)iD * nPix; i = (int)(k / g.nCols); j = (int)(k - (i64)i * g.nCols); }
+    for (int q = 0; q < kHuffRun; q++, v += 256)
+    {
+      const int idx = (int)threadIdx.x + 256 * q;
+      int sym = 0;
+      if (v < n)
+      {
+        if (mode == IEM_Huffman) sym = off + (int)data[v];
+        else
+        {
+          const T val = data[k * g.nDepth + iD];
+          T pred = 0;
+          if (j > 0) pred = data[(k - 1) * g.nDepth + iD];
+          else if (i > 0) pred = data[(k - g.nCols) * g.nDepth + iD];
+          sym = off + (int)(T)(val - pred);
+          k += 256; j += 256;
+          while (j >= g.nCols) { j -= g.nCols; i++; }
+          if (k >= nPix) { while (k >= nPix) { k -= nPix; iD++; } i = (int)(k / g.nCols); j = (int)(k - (i64)i * g.nCols); }
+        }
+      }
+      s_sym[(idx & (kHuffRun - 1)) * 260 + (idx >> 7)] = (u8)sym;
+    }
+  }
+  __syncthreads();
   const i64 run = (i64)blockIdx.x * 256 + threadIdx.x;
   const i64 v0 = run * kHuffRun;
   if (v0 >= n) return;
   const i64 v1 = (v0 + kHuffRun < n) ? v0 + kHuffRun : n;
+  HuffCursor cur;
+  if (!staged) cur.init(g, mode, v0);
   if (!PACK)
   {
     u32 bits = 0;
-    for (i64 v = v0; v < v1; v++)
-    {
-      const int s = huffSymbol<T>(data, maskBits, g, mode, v);
-      if (s >= 0) bits += (u32)(s_codes[s] >> 32);
-    }
+    if (staged) for (int e = 0; e < (int)(v1 - v0); e++) bits += (u32)(s_codes[s_sym[e * 260 + threadIdx.x]] >> 32);
+    else
+      for (i64 v = v0; v < v1; v++, cur.step(g))
+      {
+        const int s = huffSymbolAt<T>(data, maskBits, g, cur);
+        if (s >= 0) bits += (u32)(s_codes[s] >> 32);
+      }
     runBits[run] = bits;
     return;
   }
@@ -123,7 +217,9 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
   int have = fill;
   for (i64 v = v0; v < v1; v++)
   {
-    const int s = huffSymbol<T>(data, maskBits, g, mode, v);
+    int s;
+    if (staged) s = s_sym[(int)(v - v0) * 260 + threadIdx.x];
+    else { s = huffSymbolAt<T>(data, maskBits, g, cur); cur.step(g); }
     if (s < 0) continue;
     const u64 c = s_codes[s];
     const int len = (int)(c >> 32);
@@ -224,10 +320,39 @@ __device__ __forceinline__ u32 peek32(const u32* __restrict__ stream, u64 nWords
   return sh ? ((w0 << sh) | (w1 >> (32 - sh))) : w0;
 }
 
-// returns the code length (0 = no code matches), symbol in sym
-__device__ __forceinline__ int decodeOne(const HuffDecodeTable* __restrict__ t, u32 top, int& sym)
+// The decoders run one thread per sub-sequence; read straight from global memory every lane would sit in a cache line
+// of its own.  A workgroup of kHuffDecThreads threads therefore stages its slice of the stream (its sub-sequences + 2
+// words of the next) in LDS with coalesced loads, word w of sub-sequence t at [w][t] (rows one word longer than the
+// thread count, so that the staging stores and the decoders' loads both spread over the banks).
+static const int kHuffDecThreads = 128;
+static const int kHuffSubWords = kHuffSubBits / 32;
+static const int kHuffStagePitch = kHuffDecThreads + 1;
+
+__device__ __forceinline__ void stageStream(const u32* __restrict__ stream, u64 nWords, u32* s_str)
 {
-  const u32 e = t->lut[top >> (32 - kHuffLutBits)];
+  const u64 gw0 = (u64)blockIdx.x * kHuffDecThreads * kHuffSubWords;
+  for (u32 g = threadIdx.x; g < (u32)(kHuffDecThreads * kHuffSubWords + 2); g += kHuffDecThreads)
+  {
+    const u64 w = gw0 + g;
+    s_str[(g % kHuffSubWords) * kHuffStagePitch + g / kHuffSubWords] = (w < nWords) ? stream[w] : 0u;
+  }
+}
+
+// 32 stream bits from bit position p (inside this workgroup's slice), MSB first
+__device__ __forceinline__ u32 peek32Staged(const u32* s_str, u64 p)
+{
+  const u32 g = (u32)((p >> 5) - (u64)blockIdx.x * kHuffDecThreads * kHuffSubWords);
+  const int sh = (int)(p & 31);
+  const u32 w0 = s_str[(g % kHuffSubWords) * kHuffStagePitch + g / kHuffSubWords];
+  const u32 g1 = g + 1u;
+  const u32 w1 = s_str[(g1 % kHuffSubWords) * kHuffStagePitch + g1 / kHuffSubWords];
+  return sh ? ((w0 << sh) | (w1 >> (32 - sh))) : w0;
+}
+
+// returns the code length (0 = no code matches), symbol in sym; lut = the workgroup's LDS copy of t->lut
+__device__ __forceinline__ int decodeOne(const HuffDecodeTable* __restrict__ t, const u32* lut, u32 top, int& sym)
+{
+  const u32 e = lut[top >> (32 - kHuffLutBits)];
   if (e != 0xFFFFFFFFu) { sym = (int)(e & 0xFFFFu); return (int)(e >> 16); }
   for (int i = 0; i < t->nLong; i++)
   {
@@ -239,15 +364,26 @@ __device__ __forceinline__ int decodeOne(const HuffDecodeTable* __restrict__ t, 
 
 // one thread per sub-sequence of kHuffSubBits bits: decode from starts[t] up to the end of the
 // sub-sequence; exits[t] = first code word position at or beyond it, counts[t] = symbols decoded
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kHuffDecThreads)
 k_huff_sync(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const HuffDecodeTable* __restrict__ table, u32 nSub,
             const u64* __restrict__ starts, u64* __restrict__ prevStarts, u64* __restrict__ exits, u32* __restrict__ counts,
             u32* __restrict__ bad)
 {
-  const u32 t = blockIdx.x * 256u + threadIdx.x;
-  if (t >= nSub) return;
-  const u64 s = starts[t];
-  if (prevStarts[t] == s) return;    // unchanged since the last round
+  __shared__ u32 s_lut[1 << kHuffLutBits];
+  __shared__ u32 s_str[kHuffSubWords * kHuffStagePitch];
+  __shared__ u32 s_any;
+  const u32 t = blockIdx.x * (u32)kHuffDecThreads + threadIdx.x;
+  const u64 s = (t < nSub) ? starts[t] : 0;
+  const bool todo = t < nSub && prevStarts[t] != s;    // else: unchanged since the last round
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  if (todo) s_any = 1;
+  __syncthreads();
+  if (!s_any) return;    // (after the first round most workgroups have nothing to redo)
+  for (int i = threadIdx.x; i < (1 << kHuffLutBits); i += kHuffDecThreads) s_lut[i] = table->lut[i];
+  stageStream(stream, nWords, s_str);
+  __syncthreads();
+  if (!todo) return;
   prevStarts[t] = s;
   const u64 end = min((u64)(t + 1) * kHuffSubBits, streamBits);
   u64 p = s;
@@ -255,7 +391,7 @@ k_huff_sync(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const Hu
   while (p < end)
   {
     int sym;
-    const int len = decodeOne(table, peek32(stream, nWords, p), sym);
+    const int len = decodeOne(table, s_lut, peek32Staged(s_str, p), sym);
     if (len == 0) { atomicOr(bad, 1u); break; }
     p += (u64)len;
     n++;
@@ -290,38 +426,37 @@ void launchValidIndex(const u8* maskBits, const u32* groupBase, i64 nPix, u32* v
 
 // second pass: write symbol r of the stream to its pixel (raw deltas in delta mode)
 template<class T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kHuffDecThreads)
 k_huff_emit(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const HuffDecodeTable* __restrict__ table, u32 nSub,
             const u64* __restrict__ starts, const u64* __restrict__ symBase, HuffGeom g, int mode, u64 nSymbols, u32 numValid,
             const u32* __restrict__ validIdx, T* __restrict__ out)
 {
-  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  __shared__ u32 s_lut[1 << kHuffLutBits];
+  __shared__ u32 s_str[kHuffSubWords * kHuffStagePitch];
+  for (int i = threadIdx.x; i < (1 << kHuffLutBits); i += kHuffDecThreads) s_lut[i] = table->lut[i];
+  stageStream(stream, nWords, s_str);
+  __syncthreads();
+  const u32 t = blockIdx.x * (u32)kHuffDecThreads + threadIdx.x;
   if (t >= nSub) return;
   const int off = (DtOf<T>::v == DT_Char) ? 128 : 0;
   const u64 end = min((u64)(t + 1) * kHuffSubBits, streamBits);
   u64 p = starts[t];
   u64 r = symBase[t];
+  // rank r -> (valid pixel q, depth m): divided once, then stepped
+  u64 q, m;
+  if (mode == IEM_Huffman) { q = r / (u64)g.nDepth; m = r - q * (u64)g.nDepth; }
+  else { m = r / numValid; q = r - m * numValid; }
   while (p < end && r < nSymbols)
   {
     int sym;
-    const int len = decodeOne(table, peek32(stream, nWords, p), sym);
+    const int len = decodeOne(table, s_lut, peek32Staged(s_str, p), sym);
     if (len == 0) break;
     p += (u64)len;
-    i64 at;
-    if (mode == IEM_Huffman)
-    {
-      const u64 q = r / (u64)g.nDepth;
-      const i64 k = validIdx ? (i64)validIdx[q] : (i64)q;
-      at = k * g.nDepth + (i64)(r - q * (u64)g.nDepth);
-    }
-    else
-    {
-      const u64 iD = r / numValid, q = r - iD * numValid;
-      const i64 k = validIdx ? (i64)validIdx[q] : (i64)q;
-      at = k * g.nDepth + (i64)iD;
-    }
-    out[at] = (T)(sym - off);
+    const i64 k = validIdx ? (i64)validIdx[q] : (i64)q;
+    out[k * g.nDepth + (i64)m] = (T)(sym - off);
     r++;
+    if (mode == IEM_Huffman) { if (++m == (u64)g.nDepth) { m = 0; q++; } }
+    else if (++q == numValid) { q = 0; m++; }
   }
 }
 
@@ -447,7 +582,7 @@ void launchHuffUndelta(int dt, void* data, const u8* maskBits, const HuffGeom& g
 void launchHuffSync(const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, const u64* starts,
                     u64* prevStarts, u64* exits, u32* counts, u32* bad, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_huff_sync, dim3((nSub + 255) / 256), dim3(256), 0, st, stream, nWords, streamBits, table, nSub, starts, prevStarts,
+  hipLaunchKernelGGL(k_huff_sync, dim3((nSub + kHuffDecThreads - 1) / kHuffDecThreads), dim3(kHuffDecThreads), 0, st, stream, nWords, streamBits, table, nSub, starts, prevStarts,
                      exits, counts, bad);
 }
 
@@ -460,7 +595,7 @@ void launchHuffEmit(int dt, const u32* stream, u64 nWords, u64 streamBits, const
                     const u64* symBase, const HuffGeom& g, int mode, u64 nSymbols, u32 numValid, const u32* validIdx, void* out,
                     hipStream_t st)
 {
-  const dim3 grid((nSub + 255) / 256), block(256);
+  const dim3 grid((nSub + kHuffDecThreads - 1) / kHuffDecThreads), block(kHuffDecThreads);
   if (dt == DT_Char) hipLaunchKernelGGL(k_huff_emit<signed char>, grid, block, 0, st, stream, nWords, streamBits, table, nSub, starts, symBase, g, mode, nSymbols, numValid, validIdx, (signed char*)out);
   else hipLaunchKernelGGL(k_huff_emit<unsigned char>, grid, block, 0, st, stream, nWords, streamBits, table, nSub, starts, symBase, g, mode, nSymbols, numValid, validIdx, (unsigned char*)out);
 }
