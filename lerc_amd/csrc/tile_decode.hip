@@ -300,7 +300,14 @@ __global__ void __launch_bounds__(64) k_walk_chunks(BandParams p, WalkPlan wp, c
         BlkInfo b;
         const int rc = parseBlock<TBYTES>(blob, cur, blobEnd, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b);
         if (rc == 1) alive = false;
-        else if (rc == 2) unknown = true;
+        else if (rc == 2)
+        {
+          // a raw block of a masked / ragged band: its length is the block's valid pixel count, which takes the block
+          // index.  The candidate drops out -- one random byte in eight looks like such a block, so counting it as
+          // "undecided" would leave no chunk decided.  If the true path goes with it, what the others agree on may be
+          // wrong; the sweep (D3) only ever takes over walks that started where it arrives, so that costs time, not truth.
+          if (wp.uniformN == 0) alive = false; else unknown = true;
+        }
         else
         {
           const u32 sig = ((u32)b.flag >> 2) & pattern;
@@ -322,91 +329,159 @@ __global__ void __launch_bounds__(64) k_walk_chunks(BandParams p, WalkPlan wp, c
   if (lane == 0) chunkExit[c] = (!conflict && agreed != kNone && agreed != kUnknown) ? agreed : kNone;
 }
 
-// D2: entry[c] = agreed exit of chunk c-1; unresolved chunks are re-walked from their predecessor
-// (uniform blobs) or the whole band is handed to the sequential walk (flag in needSerial).
+// D2: one lane per chunk whose entry is known (= the agreed exit of its predecessor) walks it: number of sub-blocks
+// that start in the chunk and the true exit.  A raw block of a masked / ragged band cannot be sized without the block's
+// index (its length is the block's valid pixel count), such a chunk is left to D3.
 template<int TBYTES>
-__global__ void __launch_bounds__(256) k_resolve_entries(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin,
-                                                         u32 blobEnd, const u32* __restrict__ chunkExit,
-                                                         u32* __restrict__ chunkEntry, u32* __restrict__ needSerial)
+__global__ void __launch_bounds__(256) k_walk_counts(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
+                                                     const u32* __restrict__ chunkExit, u32* __restrict__ chunkCount, u32* __restrict__ exitOut)
 {
-  __shared__ u32 s_bad;
-  if (threadIdx.x == 0) s_bad = 0;
-  __syncthreads();
-  for (u32 c = threadIdx.x; c <= wp.nChunks; c += 256)
-  {
-    const u32 e = (c == 0) ? dataBegin : chunkExit[c - 1];
-    chunkEntry[c] = e;
-    // the exit of the last chunk is only needed to prove that it holds no raw block of unknown length
-    if (e == kNone && (c < wp.nChunks || wp.uniformN == 0)) atomicAdd(&s_bad, 1u);
-  }
-  __syncthreads();
-  if (s_bad == 0 || threadIdx.x != 0) return;
-  if (wp.uniformN == 0) { *needSerial = 1; return; }
-  const u32 maxCount = (u32)p.mb * (u32)p.mb;
-  for (u32 c = 1; c < wp.nChunks; c++)
-  {
-    if (chunkEntry[c] != kNone) continue;
-    u32 cur = chunkEntry[c - 1];
-    const u32 chunkEnd = min(dataBegin + c * wp.chunkBytes, blobEnd);
-    bool ok = cur != kNone;
-    while (ok && cur < chunkEnd)
-    {
-      BlkInfo b;
-      if (parseBlock<TBYTES>(blob, cur, blobEnd, p, wp.uniformN, maxCount, b) != 0) ok = false; else cur += b.len;
-    }
-    if (!ok) { *needSerial = 1; return; }
-    chunkEntry[c] = cur;
-  }
-}
-
-// D3: one lane per chunk walks from the resolved entry; pass 0 counts sub-blocks, pass 1 emits offsets.
-template<int TBYTES, bool EMIT>
-__global__ void __launch_bounds__(256) k_walk_emit(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
-                                                   const u32* __restrict__ chunkEntry, u32* __restrict__ chunkCount,
-                                                   const u32* __restrict__ chunkBase, u32* __restrict__ blockOff,
-                                                   const u32* __restrict__ needSerial, DeviceStatus* st)
-{
-  if (*needSerial) return;
   const u32 c = blockIdx.x * 256u + threadIdx.x;
   if (c >= wp.nChunks) return;
   const u32 chunkEnd = min(dataBegin + (c + 1) * wp.chunkBytes, blobEnd);
   const u32 maxCount = (u32)p.mb * (u32)p.mb;
-  u32 cur = chunkEntry[c];
+  u32 cur = (c == 0) ? dataBegin : chunkExit[c - 1];
   u32 n = 0;
-  u32 base = EMIT ? chunkBase[c] : 0u;
-  while (cur < chunkEnd)
+  bool ok = cur != kNone;
+  while (ok && cur < chunkEnd)
   {
     BlkInfo b;
-    if (parseBlock<TBYTES>(blob, cur, blobEnd, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b) != 0) { raiseError(st, kFailed, 0x80000000u | c); break; }
-    if (EMIT) { if (base + n < wp.nSub) blockOff[base + n] = cur; }
-    n++;
-    cur += b.len;
+    if (parseBlock<TBYTES>(blob, cur, blobEnd, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b) != 0) ok = false;
+    else { n++; cur += b.len; }
   }
-  if (!EMIT) chunkCount[c] = n;
-  else if (c == wp.nChunks - 1 && base + n != wp.nSub) raiseError(st, kFailed, 0x40000000u | c);
+  chunkCount[c] = ok ? n : kNone;
+  exitOut[c] = ok ? cur : kNone;
 }
 
-// Fallback: a single lane walks every sub-block in order (needed when raw blocks have position
-// dependent lengths, i.e. masks or partial edge blocks, or when chunk resolution failed).
+// D3: one workgroup sweeps over the chunks in order and fixes, for every chunk, where its first block starts and which
+// sub-block that is.  Chunks that D2 walked from the position the sweep arrives at are skipped in one step (their count
+// and exit are taken over); the others -- raw blocks of a masked band, chunks behind a chunk whose candidates did not
+// agree -- are staged in LDS by all threads and walked by one, now that the block index (and with it the valid pixel
+// count of every block) is known.  entryExit[] holds D2's exits on entry and the chunks' entries on exit.
+static const u32 kSweepChunkMax = 16384, kSweepWindowMax = 8208;
+
 template<int TBYTES>
-__global__ void __launch_bounds__(64) k_walk_serial(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
-                                                    const u16* __restrict__ nValidBlk, u32* __restrict__ blockOff,
-                                                    const u32* __restrict__ needSerial, DeviceStatus* st)
+__global__ void __launch_bounds__(256) k_walk_sweep(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
+                                                    const u32* __restrict__ chunkExit, const u32* __restrict__ chunkCount,
+                                                    u32* __restrict__ entryExit, const u16* __restrict__ nValidBlk,
+                                                    u32* __restrict__ chunkBase, DeviceStatus* st)
 {
-  if (!*needSerial || threadIdx.x != 0) return;
-  u32 cur = dataBegin;
-  const u32 nPos = (u32)p.nTV * (u32)p.nTH;
+  __shared__ u32 s_from[256], s_cnt[256], s_exit[256];
+  __shared__ u32 s_cur, s_pos, s_todo, s_bad, s_run[4], s_wsum[4];
+  __shared__ u8 s_chunk[kSweepChunkMax + kSweepWindowMax];
+  __shared__ u16 s_nv[kSweepChunkMax];
   const u32 maxCount = (u32)p.mb * (u32)p.mb;
-  for (u32 pos = 0; pos < nPos; pos++)
+  const u32 nPos = (u32)p.nTV * (u32)p.nTH;
+  if (threadIdx.x == 0) { s_cur = dataBegin; s_pos = 0; s_bad = 0; }
+  if (wp.chunkBytes > kSweepChunkMax || wp.window > kSweepWindowMax) { if (threadIdx.x == 0) raiseError(st, kFailed, 0x20000000u); return; }
+  __syncthreads();
+  for (u32 base = 0; base < wp.nChunks; base += 256u)
   {
-    const int nValid = wp.uniformN > 0 ? wp.uniformN : (nValidBlk ? (int)nValidBlk[pos] : -1);
-    for (int iD = 0; iD < p.nDepth; iD++)
+    const u32 batchEnd = min(base + 256u, wp.nChunks);
     {
-      BlkInfo b;
-      if (parseBlock<TBYTES>(blob, cur, blobEnd, p, nValid, maxCount, b) != 0) { raiseError(st, kFailed, pos); return; }
-      blockOff[(u64)pos * p.nDepth + iD] = cur;
-      cur += b.len;
+      const u32 c = base + threadIdx.x;
+      const bool in = c < wp.nChunks;
+      s_from[threadIdx.x] = !in ? kNone : (c == 0 ? dataBegin : chunkExit[c - 1]);
+      s_cnt[threadIdx.x] = in ? chunkCount[c] : kNone;
+      s_exit[threadIdx.x] = in ? entryExit[c] : kNone;
     }
+    __syncthreads();
+    u32 c = base;    // first chunk of the batch that is not placed yet (same in every thread)
+    for (;;)
+    {
+      // chunks c, c + 1, ... can be taken over from D2 as long as each was walked from where its predecessor ended
+      // (the first one: from where the sweep stands); their bases are a running sum of the counts
+      const u32 t = threadIdx.x, k = c + t;    // this thread looks at chunk k
+      const bool in = k < batchEnd;
+      const u32 cntK = in ? s_cnt[k - base] : kNone;
+      const u32 prevEnd = (t == 0) ? s_cur : ((k - 1 < batchEnd) ? s_exit[k - 1 - base] : kNone);
+      const bool ok = in && cntK != kNone && s_from[k - base] == prevEnd;
+      // length of the run of ok's from thread 0, and the counts' prefix sums over it
+      const u64 bad = __ballot(!ok);
+      if (laneId() == 0) s_run[waveId()] = bad ? (u32)(__ffsll((long long)bad) - 1) : 64u;
+      u32 inc = ok ? cntK : 0u;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, (unsigned)d); if (laneId() >= d) inc += o; }
+      if (laneId() == 63) s_wsum[waveId()] = inc;
+      __syncthreads();
+      u32 run = 0, before = 0;
+      for (int w2 = 0; w2 < 4; w2++) { run += s_run[w2]; if (s_run[w2] < 64u) break; }
+      for (int w2 = 0; w2 < waveId(); w2++) before += s_wsum[w2];
+      const u32 pos0 = s_pos, cur0 = s_cur;
+      if (t < run) { entryExit[k] = (t == 0) ? cur0 : prevEnd; chunkBase[k] = pos0 + before + inc - cntK; }
+      __syncthreads();
+      if (run > 0 && t == run - 1) { s_cur = s_exit[k - base]; s_pos = pos0 + before + inc; }
+      if (t == 0) s_todo = c + run;
+      c += run;
+      __syncthreads();
+      const u32 todo = s_todo;
+      if (todo >= batchEnd || s_bad) break;
+      // stage chunk `todo` (from its start: the entry lies at or behind it) and the valid counts of the blocks from s_pos on
+      const u32 chunkStart = dataBegin + todo * wp.chunkBytes;
+      const u32 chunkEnd = min(chunkStart + wp.chunkBytes, blobEnd);
+      const u32 stageEnd = min(chunkEnd + wp.window, blobEnd);
+      for (u32 i = threadIdx.x; chunkStart + i < stageEnd; i += 256u) s_chunk[i] = blob[chunkStart + i];
+      if (nValidBlk)
+      {
+        const u32 pos0 = s_pos / (u32)p.nDepth;
+        for (u32 i = threadIdx.x; i < wp.chunkBytes && pos0 + i < nPos; i += 256u) s_nv[i] = nValidBlk[pos0 + i];
+      }
+      __syncthreads();
+      if (threadIdx.x == 0)
+      {
+        u32 cur = s_cur, pos = s_pos;
+        const u32 pos0 = pos / (u32)p.nDepth;
+        entryExit[todo] = cur; chunkBase[todo] = pos;
+        bool ok = cur >= chunkStart;
+        while (ok && cur < chunkEnd)
+        {
+          const u32 blk = pos / (u32)p.nDepth;
+          const int nValid = wp.uniformN > 0 ? wp.uniformN : ((nValidBlk && blk < nPos) ? (int)s_nv[blk - pos0] : -1);
+          BlkInfo b;
+          if (blk >= nPos || parseBlock<TBYTES>(s_chunk, cur - chunkStart, stageEnd - chunkStart, p, nValid, maxCount, b) != 0) ok = false;
+          else { pos++; cur += b.len; }
+        }
+        if (!ok) { raiseError(st, kFailed, 0x10000000u | todo); s_bad = 1; }
+        s_cur = cur; s_pos = pos;
+      }
+      c = todo + 1;
+      __syncthreads();
+      if (s_bad) break;
+    }
+    if (s_bad) break;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+  {
+    entryExit[wp.nChunks] = s_cur; chunkBase[wp.nChunks] = s_pos;
+    if (!s_bad && (s_pos != wp.nSub || s_cur != blobEnd)) raiseError(st, kFailed, 0x40000000u);
+  }
+}
+
+// D4: one lane per chunk walks from the resolved entry and writes the offsets of the sub-blocks that start in it
+template<int TBYTES>
+__global__ void __launch_bounds__(256) k_walk_emit(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
+                                                   const u32* __restrict__ chunkEntry, const u32* __restrict__ chunkBase,
+                                                   const u16* __restrict__ nValidBlk, u32* __restrict__ blockOff, DeviceStatus* st)
+{
+  if (st->error) return;    // raised by the sweep: the entries cannot be trusted
+  const u32 c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= wp.nChunks) return;
+  const u32 chunkEnd = min(dataBegin + (c + 1) * wp.chunkBytes, blobEnd);
+  const u32 maxCount = (u32)p.mb * (u32)p.mb;
+  const u32 nPos = (u32)p.nTV * (u32)p.nTH;
+  u32 cur = chunkEntry[c];
+  u32 pos = chunkBase[c];
+  const u32 posEnd = chunkBase[c + 1];
+  while (cur < chunkEnd && pos < posEnd)
+  {
+    const u32 blk = pos / (u32)p.nDepth;
+    const int nValid = wp.uniformN > 0 ? wp.uniformN : ((nValidBlk && blk < nPos) ? (int)nValidBlk[blk] : -1);
+    BlkInfo b;
+    if (parseBlock<TBYTES>(blob, cur, blobEnd, p, nValid, maxCount, b) != 0) { raiseError(st, kFailed, 0x80000000u | c); break; }
+    if (pos < wp.nSub) blockOff[pos] = cur;
+    pos++;
+    cur += b.len;
   }
 }
 
@@ -414,22 +489,16 @@ template<int TBYTES>
 static void launchWalkT(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, DeviceStatus* st,
                         hipStream_t stream)
 {
-  u32* needSerial = wb.chunkBase + (wp.nChunks + 1);    // one extra word behind the scan output
-  hipMemsetAsync(needSerial, 0, 4, stream);
-  // With position dependent block sizes (masks / partial edge blocks, uniformN == 0) the chunk walk
-  // cannot size raw blocks; it still resolves every blob without raw blocks -- the common case for
-  // lossy and integer data -- and otherwise flags the band for the sequential walk.
-  hipLaunchKernelGGL(k_walk_chunks<TBYTES>, dim3(wp.nChunks), dim3(64), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit);
-  hipLaunchKernelGGL(k_resolve_entries<TBYTES>, dim3(1), dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd,
-                     (const u32*)wb.chunkExit, wb.chunkEntry, needSerial);
+  // candidates per chunk -> exits the candidates agree on -> counts where the entry is known -> one sweep that closes
+  // the gaps (and sizes the raw blocks of masked / ragged bands, whose length hangs on the block index) -> offsets
   const dim3 gridC((wp.nChunks + 255) / 256);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_emit<TBYTES, false>), gridC, dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd,
-                     (const u32*)wb.chunkEntry, wb.chunkCount, (const u32*)nullptr, (u32*)nullptr, (const u32*)needSerial, st);
-  launchExclusiveScan(wb.chunkCount, wb.chunkBase, wp.nChunks, wb.scratch, stream);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_emit<TBYTES, true>), gridC, dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd,
-                     (const u32*)wb.chunkEntry, wb.chunkCount, (const u32*)wb.chunkBase, wb.blockOff, (const u32*)needSerial, st);
-  hipLaunchKernelGGL(k_walk_serial<TBYTES>, dim3(1), dim3(64), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.nValidBlk,
-                     wb.blockOff, (const u32*)needSerial, st);
+  hipLaunchKernelGGL(k_walk_chunks<TBYTES>, dim3(wp.nChunks), dim3(64), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit);
+  hipLaunchKernelGGL(k_walk_counts<TBYTES>, gridC, dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, (const u32*)wb.chunkExit,
+                     wb.chunkCount, wb.chunkEntry);
+  hipLaunchKernelGGL(k_walk_sweep<TBYTES>, dim3(1), dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, (const u32*)wb.chunkExit,
+                     (const u32*)wb.chunkCount, wb.chunkEntry, wb.nValidBlk, wb.chunkBase, st);
+  hipLaunchKernelGGL(k_walk_emit<TBYTES>, gridC, dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, (const u32*)wb.chunkEntry,
+                     (const u32*)wb.chunkBase, wb.nValidBlk, wb.blockOff, st);
 }
 
 void launchWalk(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, DeviceStatus* st,
