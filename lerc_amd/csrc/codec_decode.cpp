@@ -80,7 +80,7 @@ static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven, u32 nTiles 
 {
   const FastWalkPlan wp = makeFastWalkPlan(nRows, nCols, sizeGiven);
   const size_t perTile = (size_t)wp.nChunks * ((size_t)kFastListCap * 8 + kFastSubPerChunk * 8 + 64) + (size_t)wp.chainCap * sizeof(FastChain)
-    + (size_t)wp.nBlocks * 4 + (size_t)(wp.nBlocks / kFastBlocksPerWG) * 16 + 4096;
+    + (size_t)wp.nBlocks * 4 + (size_t)(wp.nBlocks / kFastBlocksPerWG + 1) * 16 + 4096;
   return perTile * nTiles + (1u << 16);
 }
 
@@ -109,7 +109,7 @@ static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8
   fbuf.params = dParams;
   fbuf.fallback = dFallback;
   fbuf.clearCells = clearCells;
-  fbuf.wgFletcher = ctx.allocT<u64>(2 * nT * (fwp.nBlocks / kFastBlocksPerWG) + 4);
+  fbuf.wgFletcher = ctx.allocT<u64>(2 * nT * (fwp.nBlocks / kFastBlocksPerWG + 1) + 4);
   if (!fbuf.chunkListN || !fbuf.chunkList || !fbuf.chains || !fbuf.chainCount || !fbuf.chunkEntry || !fbuf.chunkCount
     || !fbuf.subEntry || !fbuf.subIndex || !fbuf.blockOff || !fbuf.wgFletcher) return false;
   static const char* kStage[kFastDecodeStages] = { "fast_candidates", "fast_chains", "fast_resolve", "fast_emit_offsets", "fast_decode" };

@@ -1,12 +1,12 @@
 // tile_fast.h -- streaming ("fast") kernels for the common case: one band, nDepth == 1, every pixel
-// valid, 8 x 8 micro blocks, nRows % 8 == 0 and nCols % 64 == 0.  Everything else takes the general
+// valid, 8 x 8 micro blocks, rows and columns multiples of 8.  Everything else takes the general
 // wave-per-block kernels (tile_encode.hip / tile_decode.hip); both produce identical bytes.
 #pragma once
 #include "lerc_common.h"
 
 namespace lerc {
 
-static const int kFastBlocksPerWG = 64;    // one workgroup = 64 consecutive blocks of a block row (8 rows x 512 cols)
+static const int kFastBlocksPerWG = 64;    // one workgroup = 64 consecutive blocks of the stream (8 rows x 512 cols where a block row is long enough)
 
 // written by the device, read by the host after the single sync of an encode call
 struct FastEncodeResult
@@ -65,31 +65,47 @@ void launchFastEncode(int stage, const BandParams& assumed, double requestedMaxZ
                       u64 outCapacity, u64 arenaBase, const FastEncodeBuffers& b, const FastBatch& batch, hipStream_t st);
 
 // ---- where a workgroup's 64 consecutive blocks lie in the raster -----------------------------------------------
-// Block k of the stream is block (k / nTH, k % nTH) of the raster (nTH = nCols / 8 blocks per block row).  The streaming
-// kernels take rasters in which either a block row holds a whole number of workgroups (nTH % 64 == 0) or a
-// workgroup holds a whole number of block rows (nTH a power of two <= 64: 64 ... 512 columns, e.g. 256 x 256 tiles),
-// so the split into row and column is one division per workgroup or none.
-struct FastSpan { u32 it0, jt0, shift, mask; };
-LERC_HD FastSpan fastSpanOf(u32 wg, u32 nTH)
+// Block k of the stream is block (k / nTH, k % nTH) of the raster (nTH = nCols / 8 blocks per block row).  Three cases:
+// a block row holds a whole number of workgroups (nTH % 64 == 0: one division per workgroup, constant strides inside);
+// a workgroup holds a whole number of block rows (nTH a power of two <= 64, e.g. 256 x 256 tiles: shifts and masks);
+// anything else (any width that is a multiple of 8): a division per block, the workgroup's blocks wrap around the end of
+// a block row wherever it falls, and the last workgroup may hold fewer than 64 blocks (nBlocks).
+struct FastSpan { u32 it0, jt0, shift, mask, nTH, nBlocks, k0; };
+LERC_HD FastSpan fastSpanOf(u32 wg, u32 nTH, u32 nTV)
 {
   FastSpan s;
   const u32 k0 = wg * 64u;
+  s.nTH = nTH; s.nBlocks = nTH * nTV; s.k0 = k0;
+  const bool pow2 = (nTH & (nTH - 1u)) == 0u;
   if ((nTH & 63u) == 0u) { s.it0 = k0 / nTH; s.jt0 = k0 - s.it0 * nTH; s.shift = 31; s.mask = 0xFFFFFFFFu; }
-  else { u32 sh = 0; while ((1u << (sh + 1)) <= nTH) sh++; s.shift = sh; s.it0 = k0 >> sh; s.jt0 = 0; s.mask = nTH - 1u; }
+  else if (pow2 && nTH <= 64u && (s.nBlocks & 63u) == 0u)
+  {
+    u32 sh = 0;
+    while ((1u << (sh + 1)) <= nTH) sh++;
+    s.shift = sh; s.it0 = k0 >> sh; s.jt0 = 0; s.mask = nTH - 1u;
+  }
+  else { s.it0 = k0 / nTH; s.jt0 = k0 - s.it0 * nTH; s.shift = 32; s.mask = 0xFFFFFFFFu; }
   return s;
 }
-LERC_HD u32 fastSpanRow(const FastSpan& s, u32 j) { return s.it0 + ((s.jt0 + j) >> s.shift); }    // block j of the workgroup
-LERC_HD u32 fastSpanCol(const FastSpan& s, u32 j) { return (s.jt0 + j) & s.mask; }
-// dimensions the streaming kernels accept (blocksPerWaveTile: 4 for 32-bit types, 8 for 16-bit, 2 for 64-bit)
+// block j of the workgroup (behind the raster's last block: that last block, so that loads stay inside the raster)
+LERC_HD u32 fastSpanRow(const FastSpan& s, u32 j)
+{
+  if (s.shift == 32u) { const u32 k = (s.k0 + j < s.nBlocks) ? s.k0 + j : s.nBlocks - 1u; return k / s.nTH; }
+  return s.it0 + ((s.jt0 + j) >> s.shift);
+}
+LERC_HD u32 fastSpanCol(const FastSpan& s, u32 j)
+{
+  if (s.shift == 32u) { const u32 k = (s.k0 + j < s.nBlocks) ? s.k0 + j : s.nBlocks - 1u; return k % s.nTH; }
+  return (s.jt0 + j) & s.mask;
+}
+LERC_HD bool fastSpanHas(const FastSpan& s, u32 j) { return s.k0 + j < s.nBlocks; }    // block j of the workgroup exists
+// dimensions the streaming kernels accept: whole 8 x 8 blocks
 LERC_HD bool fastDimsOk(int dt, int nRows, int nCols)
 {
-  if (nRows <= 0 || nCols <= 0 || nRows % 8 != 0 || nCols % 8 != 0) return false;
-  const u32 nTH = (u32)nCols / 8u, nTV = (u32)nRows / 8u;
-  const u32 bpw = (dt == DT_Short || dt == DT_UShort) ? 8u : (dt == DT_Double) ? 2u : 4u;
-  const bool pow2 = (nTH & (nTH - 1u)) == 0u;
-  if (!((nTH % 64u == 0u) || (pow2 && nTH <= 64u && nTH >= bpw))) return false;
-  return ((u64)nTH * nTV) % 64u == 0u;
+  (void)dt;
+  return nRows > 0 && nCols > 0 && nRows % 8 == 0 && nCols % 8 == 0 && (u64)(nRows / 8) * (u64)(nCols / 8) < 0x7FFFFFC0ull;
 }
+LERC_HD u32 fastNumWG(int nRows, int nCols) { return (u32)(((u64)(nRows / 8) * (u64)(nCols / 8) + 63u) / 64u); }
 
 // ---- decode side ---------------------------------------------------------------------------------
 static const u32 kFastChunkBytes = 4096;

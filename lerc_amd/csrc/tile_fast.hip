@@ -129,8 +129,9 @@ template<bool WIDE, int BPW, int V>
 __device__ __forceinline__ i64 laneOrigin(const FastSpan& span, int tl, int r, int c, int nCols)
 {
   if (WIDE) return (i64)(span.it0 * 8u + (u32)r) * nCols + (i64)span.jt0 * 8 + tl * (BPW * 8) + c * V;
-  const u32 j = (u32)tl * BPW;
-  return (i64)(fastSpanRow(span, j) * 8u + (u32)r) * nCols + (i64)fastSpanCol(span, j) * 8 + c * V;
+  constexpr int LPR = 8 / V;    // lanes per block row; c = block of the wave tile * LPR + lane of the row
+  const u32 j = (u32)tl * BPW + (u32)(c / LPR);
+  return (i64)(fastSpanRow(span, j) * 8u + (u32)r) * nCols + (i64)fastSpanCol(span, j) * 8 + (c % LPR) * V;
 }
 
 template<class T> __device__ __forceinline__ u64 rawBits(T v) { u64 b = 0; memcpy(&b, &v, sizeof(T)); return b; }
@@ -164,7 +165,7 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
   constexpr int LB = 8 * LPR;
   const int w = waveId(), lane = laneId();
   const int b = lane / LB, r = (lane % LB) / LPR, h = lane % LPR, c = b * LPR + h;
-  const FastSpan span = fastSpanOf(blockIdx.x, (u32)p.nTH);
+  const FastSpan span = fastSpanOf(blockIdx.x, (u32)p.nTH, (u32)p.nTV);
   const bool leader = (lane % LB == 0);
 
   // all loads of the wave in flight before the first use (the data-dependent LUT branch below keeps the compiler
@@ -241,7 +242,8 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
     quantOk = !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
   }
   const u32 qMax = quantOk ? (u32)(mv + 0.5) : 0u;    // == largest quantised element (same expression as Quantize)
-  const Plan pl = planBlock<T>(p, 64, mn, mx, p.dt, tryLut, mv, qMax, s_nd[lane]);
+  Plan pl = planBlock<T>(p, 64, mn, mx, p.dt, tryLut, mv, qMax, s_nd[lane]);
+  if (!fastSpanHas(span, (u32)lane)) { pl.nBytes = 0; pl.kind = 7; }    // behind the raster's last block: nothing to write
   FastBlockDesc d;
   d.mnBits = rawBits<T>(mn);
   d.w1 = packDesc(pl, bitLen(qMax));
@@ -438,7 +440,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
   PROBE_BEGIN;
   const int w = waveId(), lane = laneId();
   const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
-  const FastSpan span = fastSpanOf(blockIdx.x, (u32)p.nTH);
+  const FastSpan span = fastSpanOf(blockIdx.x, (u32)p.nTH, (u32)p.nTV);
   const u32 g0 = res->prefixLen + wgBase[blockIdx.x];        // absolute offset of this workgroup's span
   const u32 spanLen = wgBase[blockIdx.x + 1] - wgBase[blockIdx.x];
   const u32 ldsShift = g0 & 15u;                            // LDS byte i <-> blob byte (g0 & ~15) + i
@@ -471,7 +473,8 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
     const int j0 = (int)fastSpanCol(span, (u32)lane) * 8;
     u32 flag = (u32)(((j0 >> 3) & 15) << 2) & 0x38u;    // version 6, no slice difference
     const u32 at0 = 8u * (ldsShift) + (s_bit[lane] - 8u * ldsShift);
-    if (kind == 0) orBits(s_out, at0, flag | 2u, 8);
+    if (kind == 7) { }    // no such block (last workgroup of a raster whose block count is no multiple of 64)
+    else if (kind == 0) orBits(s_out, at0, flag | 2u, 8);
     else if (kind == 1) orBits(s_out, at0, flag, 8);
     else
     {
@@ -741,7 +744,7 @@ bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, 
   return true;
 }
 
-u32 fastEncodeNumWG(int nRows, int nCols) { return (u32)(((u64)(nRows / 8) * (u64)(nCols / 8)) / kFastBlocksPerWG); }
+u32 fastEncodeNumWG(int nRows, int nCols) { return fastNumWG(nRows, nCols); }
 
 template<class T>
 static void launchFastEncodeT(int stage, const BandParams& p, double requested, u32 raiseCand, const void* data, u8* out, u64 cap,

@@ -765,10 +765,10 @@ fastDecodeBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ bl
   PROBE_BEGIN;
   const int w = waveId(), lane = laneId();
   const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
-  const FastSpan span = fastSpanOf(blockIdx.x, hp.nTH);
+  const FastSpan span = fastSpanOf(blockIdx.x, hp.nTH, hp.nRows / 8u);
   const u32 firstBlk = blockIdx.x * kFastBlocksPerWG;
 
-  if (threadIdx.x <= kFastBlocksPerWG) s_off[threadIdx.x] = blockOff[firstBlk + threadIdx.x];
+  if (threadIdx.x <= kFastBlocksPerWG) s_off[threadIdx.x] = blockOff[min(firstBlk + threadIdx.x, hp.nBlocks)];    // [nBlocks] = end of the stream
   __syncthreads();
   const u32 g0 = s_off[0], g1 = s_off[kFastBlocksPerWG];
   const u32 spanLen = g1 - g0;
@@ -829,8 +829,10 @@ fastDecodeBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ bl
     u32 h0, h1, h2;
     ldsHeader<DT>(s_in, off - a0, h0, h1, h2);
     u32 code = parseCode<DT>(h0, h1, h2, p.version);
+    const bool exists = fastSpanHas(span, (u32)lane);    // (the last workgroup may hold fewer than 64 blocks)
     if (off + codeLen(code) != s_off[lane + 1]) code = 0;
     if (((h0 >> 2) & pattern) != (jt & pattern)) code = 0;    // signature = (j0 >> 3) & pattern, j0 = 8 jt
+    if (!exists) code = 0;
     double offset = 0;
     const u32 mode = codeMode(code);
     if (code && (mode == 1 || mode == 3))
@@ -843,7 +845,7 @@ fastDecodeBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ bl
     }
     s_offs[lane] = offset;
     s_code[lane] = code;
-    if (__any(code == 0u) && lane == 0) raiseError(st, kFailed, blockIdx.x);
+    if (__any(code == 0u && exists) && lane == 0) raiseError(st, kFailed, blockIdx.x);
   }
   __syncthreads();
   PROBE(10);
@@ -914,8 +916,8 @@ fastDecodeBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ bl
     for (int k = 0; k < V; k++) o.e[k] = v[k];
     i64 at;
     if (WIDE) at = (i64)(span.it0 * 8u + (u32)r) * p.nCols + (i64)span.jt0 * 8 + tile * (BPW * 8) + c * V;    // one block row: constant stride
-    else { const u32 j = (u32)tile * BPW; at = (i64)(fastSpanRow(span, j) * 8u + (u32)r) * p.nCols + (i64)fastSpanCol(span, j) * 8 + c * V; }
-    *reinterpret_cast<Vec*>(outPix + at) = o;
+    else { const u32 j = (u32)blk; at = (i64)(fastSpanRow(span, j) * 8u + (u32)r) * p.nCols + (i64)fastSpanCol(span, j) * 8 + h * V; }
+    if (fastSpanHas(span, (u32)blk)) *reinterpret_cast<Vec*>(outPix + at) = o;
   }
   PROBE(11);
   if (__any(bad) && lane == 0) raiseError(st, kFailed, blockIdx.x);
@@ -978,7 +980,7 @@ __device__ __forceinline__ void tileSlice(FastDecodeBuffers& b, const FastDecode
   b.chains += tile * t.chainCap; b.chainCount += tile * ((t.nChunks + kFastCandChunks - 1) / kFastCandChunks);
   b.chunkEntry += tile * sChunk; b.chunkCount += tile * sChunk;
   b.subEntry += tile * t.nChunks * kFastSubPerChunk; b.subIndex += tile * t.nChunks * kFastSubPerChunk;
-  b.blockOff += tile * ((size_t)t.nBlocks + 4); b.wgFletcher += tile * 2 * (t.nBlocks / kFastBlocksPerWG);
+  b.blockOff += tile * ((size_t)t.nBlocks + 4); b.wgFletcher += tile * 2 * ((t.nBlocks + kFastBlocksPerWG - 1) / kFastBlocksPerWG);
   if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
 }
 
@@ -1035,7 +1037,7 @@ __global__ void __launch_bounds__(1024) k_fast_fletcher_sum(FastDecodeBuffers b,
   const u8* blob = nullptr;
   u32 sizeGiven = 0;
   tileSlice(b, t, blob, sizeGiven);
-  fastFletcherSumBody(b.params, b.wgFletcher, t.nBlocks / kFastBlocksPerWG);
+  fastFletcherSumBody(b.params, b.wgFletcher, (t.nBlocks + kFastBlocksPerWG - 1) / kFastBlocksPerWG);
 }
 
 template<class T>
@@ -1061,9 +1063,9 @@ static void launchFastDecodeT(int stage, int nRows, int nCols, const FastDecodeB
       break;
     default:
       if ((nCols / 8) % 64 == 0)
-        hipLaunchKernelGGL((k_fast_decode<T, true>), dim3(t.nBlocks / kFastBlocksPerWG, nT), dim3(256), 0, st, b, t, blob, (T*)out, status);
+        hipLaunchKernelGGL((k_fast_decode<T, true>), dim3((t.nBlocks + kFastBlocksPerWG - 1) / kFastBlocksPerWG, nT), dim3(256), 0, st, b, t, blob, (T*)out, status);
       else
-        hipLaunchKernelGGL((k_fast_decode<T, false>), dim3(t.nBlocks / kFastBlocksPerWG, nT), dim3(256), 0, st, b, t, blob, (T*)out, status);
+        hipLaunchKernelGGL((k_fast_decode<T, false>), dim3((t.nBlocks + kFastBlocksPerWG - 1) / kFastBlocksPerWG, nT), dim3(256), 0, st, b, t, blob, (T*)out, status);
       hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1, nT), dim3(nT > 1 ? 256 : 1024), 0, st, b, t);
       break;
   }

@@ -301,3 +301,22 @@ def test_lossless_float_round_trip_full_size(P):
     assert rc == 0 and len(blob) < x.nbytes
     d = P.decode(blob)
     assert d[0] == 0 and _same(d[1].reshape(x.shape), x)
+
+
+def test_any_width_takes_the_streaming_kernels(P, O):
+    """unmasked rasters of whole 8 x 8 blocks, any width: a workgroup's blocks wrap around block row ends, the last
+    workgroup is partly empty -- still the streaming kernels, still the oracle's bytes"""
+    rng = np.random.default_rng(12)
+    for dt, shape, e in ((np.float32, (4000, 3000), 0.01), (np.uint16, (1000, 1000), 0), (np.float64, (808, 1208), 0.001),
+                         (np.int32, (2048, 1032), 0), (np.float32, (8, 8), 0.01), (np.float32, (1600, 8), 0.01)):
+        x = cases._cast(cases.terrain(shape[0], shape[1], rng, amp=300, base=1000, sigma=1.5), dt)
+        r1, b1 = O.encode(x, e)
+        c0 = P.path_counters()
+        r2, b2 = P.encode(x, e)
+        c1 = P.path_counters()
+        assert r1 == r2 == 0 and b1 == b2, (np.dtype(dt).name, shape)
+        assert c1[0] > c0[0], (np.dtype(dt).name, shape, P.last_note())
+        d1, d2 = O.decode(b1), P.decode(b1)
+        assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1])
+        if len(b1) > 8192:
+            assert P.path_counters()[2] > c1[2], (np.dtype(dt).name, shape, P.last_note())

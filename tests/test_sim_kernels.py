@@ -91,6 +91,14 @@ def _fast_cases():
         for (r, c) in ((256, 256), (64, 128), (128, 64)):
             x = cases.terrain(r, c, rng, amp=300, base=1000, sigma=1.5)
             out.append((f"fast-narrow-{np.dtype(dt).name}-{r}x{c}", cases._cast(x, dt), 0.01 if np.dtype(dt).kind == "f" else 0))
+    # any width that is a multiple of 8: a workgroup's blocks wrap around block row ends wherever they fall, and the
+    # last workgroup holds fewer than 64 blocks
+    for dt in (np.float32, np.uint16, np.float64, np.int32):
+        for (r, c) in ((8, 1000), (24, 200), (16, 8), (40, 328), (8, 8), (72, 520), (256, 24)):
+            x = cases.terrain(r, c, rng, amp=300, base=1000, sigma=1.5)
+            out.append((f"fast-anywidth-{np.dtype(dt).name}-{r}x{c}", cases._cast(x, dt), 0.01 if np.dtype(dt).kind == "f" else 0))
+    out.append(("fast-anywidth-mixed-f32-48x1048", cases.mixed_regions(48, 1048, rng, np.float32), 0.01))
+    out.append(("fast-anywidth-mixed-u16-200x120", cases.mixed_regions(200, 120, rng, np.uint16), 0))
     f = np.float32
     out.append(("fast-f32-allint", np.rint(cases.terrain(16, 512, rng)).astype(f), 0.01))
     out.append(("fast-f32-round1", np.round(cases.terrain(16, 512, rng), 1).astype(f), 0.01))
@@ -116,11 +124,17 @@ def test_sim_streaming_path(libs, idx):
     O, S = libs
     name, arr, e = _FAST[idx]
     r1, b1 = O.encode(arr, e)
+    c0 = S.path_counters()
     r2, b2 = S.encode(arr, e)
+    c1 = S.path_counters()
     assert r1 == r2 and b1 == b2
+    if "anywidth" in name and "mixed" not in name:
+        assert c1[0] > c0[0], (name, "the encode did not take the streaming kernels", S.last_note())
     if r1 == 0:
         d1, d2 = O.decode(b1), S.decode(b1)
         assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1])
+        if "anywidth" in name and "mixed" not in name and len(b1) > 4096:
+            assert S.path_counters()[2] > c1[2], (name, "the decode did not take the streaming kernels", S.last_note())
 
 
 def _multi_chunk_cases():
