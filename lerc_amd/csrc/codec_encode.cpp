@@ -321,8 +321,11 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   if (haveBits && !bandAllValid)
   {
     hBandBits.resize((size_t)((nPix + 7) >> 3));
-    hipMemcpyAsync(hBandBits.data(), dNewBits, hBandBits.size(), hipMemcpyDeviceToHost, st);
+    u8* pin = (u8*)ctx.pinned(hBandBits.size());    // (a pageable target costs a staging copy at ~1 GB/s)
+    if (!pin) return kFailed;
+    hipMemcpyAsync(pin, dNewBits, hBandBits.size(), hipMemcpyDeviceToHost, st);
     if (!sync.wait()) return kFailed;
+    memcpy(hBandBits.data(), pin, hBandBits.size());
   }
   if (nanSeen || nd.modifiedMask) anyMaskModified = true;
   bool encMask = (iBand == 0);

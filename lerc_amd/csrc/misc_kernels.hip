@@ -162,37 +162,44 @@ template<class T> __device__ __forceinline__ bool isNaNT(T) { return false; }
 template<> __device__ __forceinline__ bool isNaNT<float>(float v) { return v != v; }
 template<> __device__ __forceinline__ bool isNaNT<double>(double v) { return v != v; }
 
-// one thread per mask byte (8 pixels)
+// one lane per pixel (coalesced loads), a ballot per wave = 8 mask bytes; a fixed grid strides over the raster so that
+// the valid pixel count costs one atomic per wave of the grid, not one per 64 pixels
 template<class T>
 __global__ void __launch_bounds__(256) k_build_mask(const T* __restrict__ data, const u8* __restrict__ byteMask, i64 nPix,
                                                     int nDepth, u8* __restrict__ maskBits, BandStats* stats)
 {
-  const i64 byteIdx = (i64)blockIdx.x * 256 + threadIdx.x;
   const i64 nBytes = (nPix + 7) >> 3;
-  u32 bits = 0, cnt = 0;
+  const int lane = laneId();
+  u32 cnt = 0;
   bool sawNaN = false, sawMixed = false;
-  if (byteIdx < nBytes)
+  for (i64 base = (i64)blockIdx.x * 256; base < nBytes * 8; base += (i64)gridDim.x * 256)    // whole waves: uniform trip count
   {
-    for (int j = 0; j < 8; j++)
+    const i64 k = base + threadIdx.x;
+    const bool inb = k < nPix;
+    bool valid = inb ? (byteMask ? (byteMask[k] != 0) : true) : false;
+    if (valid && (DtOf<T>::v >= DT_Float))
     {
-      const i64 k = byteIdx * 8 + j;
-      if (k >= nPix) { bits |= 0x80u >> j; continue; }    // tail bits stay set, like BitMask::SetAllValid + SetInvalid (Lerc.cpp:959-975)
-      bool valid = byteMask ? (byteMask[k] != 0) : true;
-      if (valid && (DtOf<T>::v >= DT_Float))
-      {
-        int nBad = 0;
-        for (int m = 0; m < nDepth; m++) nBad += isNaNT(data[k * nDepth + m]) ? 1 : 0;
-        if (nBad > 0) sawNaN = true;
-        if (nBad == nDepth) valid = false;
-        else if (nBad > 0) sawMixed = true;
-      }
-      if (valid) { bits |= 0x80u >> j; cnt++; }
+      int nBad = 0;
+      for (int m = 0; m < nDepth; m++) nBad += isNaNT(data[k * nDepth + m]) ? 1 : 0;
+      if (nBad > 0) sawNaN = true;
+      if (nBad == nDepth) valid = false;
+      else if (nBad > 0) sawMixed = true;
     }
-    maskBits[byteIdx] = (u8)bits;
+    const u64 bal = __ballot(valid);
+    const u64 tail = __ballot(!inb);    // tail bits stay set, like BitMask::SetAllValid + SetInvalid (Lerc.cpp:959-975)
+    if (lane < 8)
+    {
+      const i64 byteIdx = ((k - lane) >> 3) + lane;    // the wave's first pixel is a multiple of 64
+      if (byteIdx < nBytes)
+      {
+        const u32 eight = (u32)(((bal | tail) >> (8 * lane)) & 0xFFull);
+        maskBits[byteIdx] = (u8)(__brev(eight) >> 24);    // pixel 8 j + i is bit 0x80 >> i of byte j
+      }
+    }
+    cnt += (u32)__popcll(bal);
   }
-  cnt = waveSum(cnt);
   const bool anyNaN = __any(sawNaN), anyMixed = __any(sawMixed);
-  if (laneId() == 0)
+  if (lane == 0)
   {
     if (cnt) atomicAdd(&stats->numValid, cnt);
     if (anyNaN) atomicOr(&stats->hasNaN, 1u);
@@ -203,8 +210,8 @@ __global__ void __launch_bounds__(256) k_build_mask(const T* __restrict__ data, 
 void launchBuildMask(int dt, const void* data, const u8* byteMask, int nRows, int nCols, int nDepth, u8* maskBits,
                      BandStats* stats, hipStream_t stream)
 {
-  const i64 nPix = (i64)nRows * nCols, nBytes = (nPix + 7) >> 3;
-  const dim3 grid((unsigned)((nBytes + 255) / 256)), block(256);
+  const i64 nPix = (i64)nRows * nCols;
+  const dim3 grid((unsigned)std::min<i64>((nPix + 255) / 256, 4096)), block(256);
   switch (dt)
   {
     case DT_Float: hipLaunchKernelGGL(k_build_mask<float>, grid, block, 0, stream, (const float*)data, byteMask, nPix, nDepth, maskBits, stats); break;

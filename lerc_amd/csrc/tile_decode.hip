@@ -329,6 +329,117 @@ __global__ void __launch_bounds__(64) k_walk_chunks(BandParams p, WalkPlan wp, c
   if (lane == 0) chunkExit[c] = (!conflict && agreed != kNone && agreed != kUnknown) ? agreed : kNone;
 }
 
+// D1 for chunks of 4 KiB (every 8 x 8 raster, 16 x 16 up to 32-bit types): the same agreement, but the chunk is staged in
+// LDS and every position is parsed at most once -- s_next[] remembers length and signature of the block that starts
+// there, so the few hundred candidates, which fall onto a handful of common paths within a step or two, follow those
+// paths by table look-up instead of parsing ~40 blocks each out of global memory.
+static const u32 kMemoChunk = 4096, kMemoWindowMax = 1100;
+
+template<int TBYTES>
+__global__ void __launch_bounds__(64) k_walk_chunks_memo(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin,
+                                                         u32 blobEnd, u32* __restrict__ chunkExit)
+{
+  __shared__ __align__(16) u8 s_bytes[kMemoChunk + kMemoWindowMax + 48];
+  __shared__ __align__(16) u32 s_next[kMemoChunk];    // 0 = not parsed yet; else len | sig << 16 | kind << 30 (1 block, 2 no block here, 3 raw of unknown size)
+  __shared__ __align__(16) u32 s_exitOf[kMemoChunk];  // 0 = unknown; else where a walk that passes through this block start leaves the chunk
+  const u32 c = blockIdx.x;
+  const int lane = laneId();
+  const u32 chunkStart = dataBegin + c * wp.chunkBytes;
+  const u32 chunkEnd = min(chunkStart + wp.chunkBytes, blobEnd);
+  const u32 stageEnd = min(chunkEnd + wp.window, blobEnd);
+  // candidates: every byte up to one raw block + 1 behind the chunk start.  Encoders never write a longer block (they fall
+  // back to raw); should a blob hold one, the exits agreed on here may be wrong, which D3 notices (it only takes over walks
+  // that started where it arrives) and pays for with its own walk.
+  const u32 candWindow = min(wp.window, 2u + (u32)p.mb * (u32)p.mb * (u32)TBYTES);
+  const u32 winEnd = (c == 0) ? chunkStart + 1 : min(chunkStart + candWindow, chunkEnd);
+  const u32 pattern = (p.version >= 5) ? 14u : 15u;
+  const u32 maxCount = (u32)p.mb * (u32)p.mb;
+  const u32 kUnknown = 0xFFFFFFFEu;
+  // stage with 16-byte loads from the aligned-down start (never past the blob's end); LDS byte i + shift <-> blob byte chunkStart + i
+  const u32 a0 = chunkStart & ~15u, shift = chunkStart - a0;
+  for (u32 v = (u32)lane; a0 + 16u * v < stageEnd; v += 64u)
+  {
+    const u32 g = a0 + 16u * v;
+    uint4 x = make_uint4(0, 0, 0, 0);
+    if (g + 16u <= blobEnd && ((uintptr_t)(blob + g) & 15u) == 0u) x = *reinterpret_cast<const uint4*>(blob + g);
+    else for (u32 k2 = 0; k2 < 16u && g + k2 < blobEnd; k2++) (&x.x)[k2 >> 2] |= (u32)blob[g + k2] << (8u * (k2 & 3u));
+    *reinterpret_cast<uint4*>(&s_bytes[16u * v]) = x;
+  }
+  for (u32 i = (u32)lane; i < kMemoChunk / 4u; i += 64u)
+  {
+    reinterpret_cast<uint4*>(s_next)[i] = make_uint4(0, 0, 0, 0);
+    reinterpret_cast<uint4*>(s_exitOf)[i] = make_uint4(0, 0, 0, 0);
+  }
+  waveSync();
+  const u8* s_chunk = s_bytes + shift;
+
+  u32 agreed = kNone;
+  bool conflict = false;
+  for (u32 r0 = chunkStart; r0 < winEnd; r0 += 64)
+  {
+    u32 cur = r0 + (u32)lane;
+    bool alive = cur < winEnd;
+    bool unknown = false;
+    u32 prevSig = kNone;
+    while (__any(alive && !unknown && cur < chunkEnd))
+    {
+      if (alive && !unknown && cur < chunkEnd)
+      {
+        const u32 rel = cur - chunkStart;
+        u32 e = s_next[rel];
+        if (e == 0u)
+        {
+          BlkInfo b;
+          const int rc = parseBlock<TBYTES>(s_chunk, rel, stageEnd - chunkStart, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b);
+          if (rc == 1) e = 2u << 30;
+          else if (rc == 2) e = 3u << 30;
+          else e = b.len | ((((u32)b.flag >> 2) & pattern) << 16) | (1u << 30);
+          s_next[rel] = e;    // (lanes that race here store the same word)
+        }
+        const u32 kind = e >> 30;
+        if (kind == 2u) alive = false;
+        else if (kind == 3u) { if (wp.uniformN == 0) alive = false; else unknown = true; }    // see k_walk_chunks
+        else
+        {
+          const u32 sig = (e >> 16) & 15u;
+          if (prevSig != kNone && !sigFollows(prevSig, sig, p.mb, pattern)) alive = false;
+          else
+          {
+            const u32 known = s_exitOf[rel];    // an earlier walk came through here and made it to the chunk's end
+            prevSig = sig;
+            cur = known ? known : cur + (e & 0xFFFFu);
+          }
+        }
+      }
+    }
+    // walks that made it leave their exit at every block start they passed, so that later candidates can stop there
+    {
+      u32 at = r0 + (u32)lane;
+      bool go = alive && !unknown && at < winEnd;
+      while (__any(go))
+      {
+        if (go)
+        {
+          const u32 rel = at - chunkStart;
+          if (at >= chunkEnd || s_exitOf[rel] != 0u) go = false;
+          else { s_exitOf[rel] = cur; at += s_next[rel] & 0xFFFFu; }
+        }
+      }
+    }
+    waveSync();
+    const u32 ex = unknown ? kUnknown : cur;
+    const u32 lo = waveMin(alive ? ex : kNone);
+    const u32 hi = waveMax(alive ? ex : 0u);
+    if (lo != kNone)
+    {
+      if (lo != hi) conflict = true;
+      else if (agreed == kNone) agreed = lo;
+      else if (agreed != lo) conflict = true;
+    }
+  }
+  if (lane == 0) chunkExit[c] = (!conflict && agreed != kNone && agreed != kUnknown) ? agreed : kNone;
+}
+
 // D2: one lane per chunk whose entry is known (= the agreed exit of its predecessor) walks it: number of sub-blocks
 // that start in the chunk and the true exit.  A raw block of a masked / ragged band cannot be sized without the block's
 // index (its length is the block's valid pixel count), such a chunk is left to D3.
@@ -492,7 +603,10 @@ static void launchWalkT(const BandParams& p, const WalkPlan& wp, const DecodeArg
   // candidates per chunk -> exits the candidates agree on -> counts where the entry is known -> one sweep that closes
   // the gaps (and sizes the raw blocks of masked / ragged bands, whose length hangs on the block index) -> offsets
   const dim3 gridC((wp.nChunks + 255) / 256);
-  hipLaunchKernelGGL(k_walk_chunks<TBYTES>, dim3(wp.nChunks), dim3(64), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit);
+  if (wp.chunkBytes <= kMemoChunk && wp.window <= kMemoWindowMax)
+    hipLaunchKernelGGL(k_walk_chunks_memo<TBYTES>, dim3(wp.nChunks), dim3(64), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit);
+  else
+    hipLaunchKernelGGL(k_walk_chunks<TBYTES>, dim3(wp.nChunks), dim3(64), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit);
   hipLaunchKernelGGL(k_walk_counts<TBYTES>, gridC, dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, (const u32*)wb.chunkExit,
                      wb.chunkCount, wb.chunkEntry);
   hipLaunchKernelGGL(k_walk_sweep<TBYTES>, dim3(1), dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, (const u32*)wb.chunkExit,
