@@ -363,3 +363,52 @@ def check_lossless_float_golden(P, vec, blob_dir, sha, n_iter=60, max_side=90):
             assert d[0] == v["dec_rc"] and sha(d[1].tobytes()) == v["dec_sha"], name
             n_checked += 1
     assert n_checked >= 10
+
+
+def damaged_blob_cases(T, n_damage, seed=123):
+    """Blobs of every path (streaming, any-width streaming, masked, ragged, nDepth, 8-bit Huffman, lossless float, raw
+    blocks, tiny) with one byte flipped / overwritten, a short stretch zeroed, or the end cut off.  -> [(name, blob, n_bands hint)]
+    T encodes the intact blobs."""
+    rng = np.random.default_rng(seed)
+    blobs = []
+    f = np.float32
+    blobs.append(("stream-f32", T.encode(_cast(terrain(64, 512, rng, sigma=1.5), f), 0.01)[1]))
+    blobs.append(("stream-u16", T.encode(_cast(terrain(32, 512, rng, sigma=1.5), np.uint16), 0)[1]))
+    blobs.append(("anywidth-f32", T.encode(_cast(terrain(40, 328, rng, sigma=1.5), f), 0.01)[1]))
+    blobs.append(("anywidth-f64", T.encode(_cast(terrain(24, 200, rng, sigma=1.5), np.float64), 0.001)[1]))
+    m = (rng.random((70, 90)) > 0.2).astype(np.uint8)
+    blobs.append(("masked-f32", T.encode(_cast(terrain(70, 90, rng), f), 0.01, mask=m)[1]))
+    blobs.append(("ragged-i16", T.encode(_cast(terrain(37, 53, rng), np.int16), 0)[1]))
+    blobs.append(("depth3-u16", T.encode(_cast(np.stack([terrain(40, 48, rng) + k for k in range(3)], -1), np.uint16), 0, n_depth=3)[1]))
+    blobs.append(("huffman-u8", T.encode(_cast(terrain(80, 96, rng, amp=50, base=100, sigma=2), np.uint8), 0)[1]))
+    blobs.append(("lossless-f32", T.encode(_cast(terrain(48, 64, rng, sigma=0.01), f), 0)[1]))
+    zr = _cast(terrain(32, 512, rng), f)
+    zr[::8, ::8] *= 1e20
+    blobs.append(("raw-blocks-f32", T.encode(zr, 0.01)[1]))
+    blobs.append(("two-bands-f32", T.encode(np.stack([_cast(terrain(24, 32, rng), f)] * 2), 0.01, n_bands=2)[1]))
+    out = []
+    for name, blob in blobs:
+        assert len(blob) > 100, name
+        for t in range(n_damage):
+            b = bytearray(blob)
+            how = int(rng.integers(0, 4))
+            k = int(rng.integers(0, len(b)))
+            if how == 0:
+                b[k] ^= 1 << int(rng.integers(0, 8))
+            elif how == 1:
+                b[k] = int(rng.integers(0, 256))
+            elif how == 2:
+                n_zero = min(len(b) - k, int(rng.integers(2, 40)))
+                b[k:k + n_zero] = bytes(n_zero)
+            else:
+                b = b[:max(24, k)]
+            out.append((f"{name}-{t}-how{how}-at{k}", bytes(b)))
+    return out
+
+
+def check_damaged_blob(T, P, name, blob, same):
+    """same verdict as the trusted decoder; where both accept the blob (damage in bytes nobody reads), the same pixels"""
+    d1, d2 = T.decode(blob), P.decode(blob)
+    assert (d1[0] == 0) == (d2[0] == 0), (name, d1[0], d2[0])
+    if d1[0] == 0:
+        assert same(d1[1], d2[1]) and same(d1[2], d2[2]), name

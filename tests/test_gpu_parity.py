@@ -320,3 +320,9 @@ def test_any_width_takes_the_streaming_kernels(P, O):
         assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1])
         if len(b1) > 8192:
             assert P.path_counters()[2] > c1[2], (np.dtype(dt).name, shape, P.last_note())
+
+
+def test_damaged_blobs_of_every_path(P, O):
+    """flipped / overwritten / zeroed bytes and truncation in blobs of every path: the oracle's verdict, no fault on the device"""
+    for name, blob in cases.damaged_blob_cases(O, 40):
+        cases.check_damaged_blob(O, P, name, blob, _same)

@@ -404,3 +404,10 @@ def test_sim_lossless_float_damaged_blobs(libs):
                 b = b[:max(20, k)]
             b = bytes(b)
             assert (O.decode(b)[0] == 0) == (S.decode(b)[0] == 0), (name, k, how)
+
+
+def test_sim_damaged_blobs_of_every_path(libs):
+    """no stray access, no endless walk, the oracle's verdict -- whichever kernels the blob goes to"""
+    O, S = libs
+    for name, blob in cases.damaged_blob_cases(O, 6):
+        cases.check_damaged_blob(O, S, name, blob, _same)
