@@ -644,7 +644,7 @@ static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double
   const bool isFlt = dt >= DT_Float;
   const size_t nT = nTiles;
   FastEncodeBuffers& fb = fl.fb;
-  fl.batch.nTiles = nTiles; fl.batch.nWG = nWG; fl.batch.tileElems = tileElems;
+  fl.batch.nTiles = nTiles; fl.batch.nWG = nWG; fl.batch.tileElems = tileElems; fl.batch.nBlobsMore = 0;
   fl.batch.nRaiseSets = (nTiles > 1) ? 1u : 16u;    // a batch has tiles enough to fill the chip
   fb.desc = ctx.allocT<FastBlockDesc>(nT * nWG * kFastBlocksPerWG);
   fb.wgSize = ctx.allocT<u32>(nT * fastWgStride(nWG) + 4);
@@ -712,10 +712,12 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   if (rq.version < 3 || rq.version > kCodecVersion) return kWrongParam;
   if (rq.version < 6 && anyNoData) return kWrongParam;    // Lerc.cpp:341-344
   if (rq.version < 4 && rq.nDepth > 1) return kFailed;    // Lerc2::Set refuses (Lerc2.cpp:85-86)
-  const bool fastOk = !anyNoData && rq.version == kCodecVersion && rq.nBands == 1 && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
+  const bool fastOk = !anyNoData && rq.version == kCodecVersion && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
     && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, rq.nDepth, rq.nMasks > 0, rq.maxZErr);
   const u32 nWG = fastOk ? fastEncodeNumWG(rq.nRows, rq.nCols) : 0;
   need += fastOk ? fastEncodeWorkspace(rq.nRows, rq.nCols, 1) : 0;
+  const size_t bandCap = (size_t)nPix * tb + 4096;    // a band's blob never exceeds its raw form by more than the small sections
+  if (fastOk && rq.nBands > 1 && rq.dOut) need += bandCap + 256;
   (void)nWG;
   if (!ctx.reserve(need)) return kFailed;
   (void)tb;
@@ -723,7 +725,47 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   // ---- streaming path: everything is decided on the device, one synchronisation at the end.  If an
   // assumption fails (NaN, all-integer floats, raisable error bound, constant image, 16 x 16 retry,
   // raw fallback) the device says so and the general path below redoes the band.
-  if (fastOk)
+  if (fastOk && rq.nBands > 1)
+  {
+    // several bands: each is a blob of its own with "bands to follow" in its header (Lerc.cpp:628-789); a band is packed
+    // into 16-byte aligned scratch (its place in the output is wherever the band before it ended) and copied over
+    hipStream_t st = ctx.activeStream();
+    FastEncodeLaunch fl;
+    if (!prepareFastEncode(ctx, rq.dt, rq.nRows, rq.nCols, rq.maxZErr, 1, 0, false, fl)) return kFailed;
+    u8* dBandBlob = rq.dOut ? ctx.allocT<u8>(bandCap) : nullptr;
+    FastEncodeResult* pinRes = (FastEncodeResult*)ctx.pinned(sizeof(FastEncodeResult));
+    if (!pinRes || (rq.dOut && !dBandBlob)) return kFailed;
+    u64 total = 0;
+    bool redo = false;
+    for (int iBand = 0; iBand < rq.nBands && !redo; iBand++)
+    {
+      fl.batch.nBlobsMore = (u32)(rq.nBands - 1 - iBand);
+      const u8* dBand = (const u8*)rq.dData + (size_t)iBand * nPix * tb;
+      runFastEncode(ctx, fl, dBand, dBandBlob, dBandBlob ? (u64)bandCap : ~0ull, 0);
+      hipMemcpyAsync(pinRes, fl.fb.result, sizeof(FastEncodeResult), hipMemcpyDeviceToHost, st);
+      if (!ctx.sync()) return kFailed;
+      if (pinRes->redo) { redo = true; break; }
+      const u32 bandBytes = pinRes->blobSize;
+      if (total + bandBytes > (u64)UINT_MAX) return kDimsTooLarge;
+      if (rq.dOut)
+      {
+        if (total + bandBytes > rq.outCapacity) return kBufferTooSmall;
+        hipMemcpyAsync(rq.dOut + total, dBandBlob, bandBytes, hipMemcpyDeviceToDevice, st);
+      }
+      total += bandBytes;
+    }
+    if (ctx.profOn()) ctx.profCollect();
+    if (!redo)
+    {
+      if (rq.dOut && !ctx.sync()) return kFailed;
+      ctx.pathCount[0]++;
+      numBytesNeeded = (u32)total;
+      numBytesWritten = rq.dOut ? (u32)total : 0;
+      return kOk;
+    }
+    ctx.reset();
+  }
+  else if (fastOk)
   {
     hipStream_t st = ctx.activeStream();
     FastEncodeLaunch fl;

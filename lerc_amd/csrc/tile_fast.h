@@ -38,6 +38,7 @@ struct FastBatch
   u32 nWG;             // workgroups (64 blocks each) per tile
   u64 tileElems;       // pixels from one tile to the next
   u32 nRaiseSets;      // workgroups per tile that look at the first raster row
+  u32 nBlobsMore;      // header field: bands that follow this one in the blob (0 for a single band / a tile)
 };
 LERC_HD u32 fastWgStride(u32 nWG) { return (nWG + 7u) & ~3u; }    // elements from one tile's wgSize / wgBase set to the next (16-byte aligned)
 static const int kFastPrefixStage = 128;   // bytes reserved per tile for header + mask count + ranges + mode byte

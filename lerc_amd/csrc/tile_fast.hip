@@ -278,7 +278,7 @@ __device__ __forceinline__ double keyToDouble(int dt, u64 key, u64& raw)
 __device__ __forceinline__ void
 fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgBase,
            const u64* __restrict__ slotMinKey, const u64* __restrict__ slotMaxKey, const u32* __restrict__ slotFlags,
-           const double* __restrict__ row0RaiseErr, u32 nRaiseSets, u8* __restrict__ out, u64 outCapacity, FastEncodeResult* res)
+           const double* __restrict__ row0RaiseErr, u32 nRaiseSets, u32 nBlobsMore, u8* __restrict__ out, u64 outCapacity, FastEncodeResult* res)
 {
   const int lane = laneId();
   const u64 a = waveMin(slotMinKey[lane]), b = waveMax(slotMaxKey[lane]);
@@ -340,7 +340,7 @@ fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u3
   for (int i = 0; i < 6; i++) o[i] = (u8)key[i];
   putBytes(o + 6, (u64)(u32)kCodecVersion, 4);
   putBytes(o + 10, 0, 4);
-  const int ints[8] = { p.nRows, p.nCols, 1, (int)nPix, 8, (int)blobSize, p.dt, 0 };
+  const int ints[8] = { p.nRows, p.nCols, 1, (int)nPix, 8, (int)blobSize, p.dt, (int)nBlobsMore };
   for (int i = 0; i < 8; i++) putBytes(o + 14 + 4 * i, (u64)(u32)ints[i], 4);
   putBytes(o + 46, 0, 4);
   const double dbl[5] = { p.maxZErr, zMin, zMax, 0.0, 0.0 };
@@ -385,7 +385,7 @@ k_fast_scan_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u
   scanSingleWorkgroup(wgSize, wgBase, nWG);
   __syncthreads();
   if (waveId() == 0)
-    fastDecide(p, requestedMaxZErr, raiseCandidates, nWG, wgBase, s_min, s_max, s_fl, row0RaiseErr, batch.nRaiseSets, prefixStage, outCapacity, res);
+    fastDecide(p, requestedMaxZErr, raiseCandidates, nWG, wgBase, s_min, s_max, s_fl, row0RaiseErr, batch.nRaiseSets, batch.nBlobsMore, prefixStage, outCapacity, res);
 }
 
 // ------------------------------------------------------------------------------------------------

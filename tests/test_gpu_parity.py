@@ -326,3 +326,16 @@ def test_damaged_blobs_of_every_path(P, O):
     """flipped / overwritten / zeroed bytes and truncation in blobs of every path: the oracle's verdict, no fault on the device"""
     for name, blob in cases.damaged_blob_cases(O, 40):
         cases.check_damaged_blob(O, P, name, blob, _same)
+
+
+def test_several_bands_take_the_streaming_kernels(P, O):
+    rng = np.random.default_rng(32)
+    for dt, e, shape in ((np.uint16, 0, (3, 1024, 1024)), (np.float32, 0.01, (2, 1000, 1200)), (np.float64, 0.001, (4, 256, 512))):
+        x = np.stack([cases._cast(cases.terrain(shape[1], shape[2], rng, amp=300, base=1000 + 50 * b, sigma=1.5), dt) for b in range(shape[0])])
+        c0 = P.path_counters()
+        r1, b1 = O.encode(x, e, n_bands=shape[0])
+        r2, b2 = P.encode(x, e, n_bands=shape[0])
+        assert r1 == r2 == 0 and b1 == b2, np.dtype(dt).name
+        assert P.path_counters()[0] >= c0[0] + 2, (np.dtype(dt).name, P.last_note())
+        d1, d2 = O.decode(b1), P.decode(b1)
+        assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1])

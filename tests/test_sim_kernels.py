@@ -411,3 +411,26 @@ def test_sim_damaged_blobs_of_every_path(libs):
     O, S = libs
     for name, blob in cases.damaged_blob_cases(O, 6):
         cases.check_damaged_blob(O, S, name, blob, _same)
+
+
+def test_sim_streaming_encode_of_several_bands(libs):
+    """unmasked multi-band rasters: every band through the streaming kernels, "bands to follow" in each header"""
+    O, S = libs
+    rng = np.random.default_rng(31)
+    for dt, e, shape in ((np.uint16, 0, (3, 16, 512)), (np.float32, 0.01, (2, 24, 200)), (np.float64, 0.001, (4, 8, 64)), (np.int32, 0, (2, 40, 328))):
+        x = np.stack([cases._cast(cases.terrain(shape[1], shape[2], rng, amp=300, base=1000 + 50 * b, sigma=1.5), dt) for b in range(shape[0])])
+        c0 = S.path_counters()
+        assert O.compute_size(x, e, n_bands=shape[0]) == S.compute_size(x, e, n_bands=shape[0])
+        r1, b1 = O.encode(x, e, n_bands=shape[0])
+        r2, b2 = S.encode(x, e, n_bands=shape[0])
+        assert r1 == r2 == 0 and b1 == b2, np.dtype(dt).name
+        assert S.path_counters()[0] >= c0[0] + 2, (np.dtype(dt).name, S.last_note())
+        d1, d2 = O.decode(b1), S.decode(b1)
+        assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1])
+    # one band that the streaming kernels hand back (constant): the whole call goes the general way, same bytes
+    x = np.stack([cases._cast(cases.terrain(16, 512, rng), np.float32), np.full((16, 512), 2.5, np.float32)])
+    assert O.encode(x, 0.01, n_bands=2) == S.encode(x, 0.01, n_bands=2)
+    # output buffer too small for the second band
+    x = np.stack([cases._cast(cases.terrain(16, 512, rng), np.float32)] * 2)
+    rc, size = O.compute_size(x, 0.01, n_bands=2)
+    assert S.encode(x, 0.01, n_bands=2, buf_size=size - 10)[0] == O.encode(x, 0.01, n_bands=2, buf_size=size - 10)[0] == 3
