@@ -98,7 +98,8 @@ lerc_status encodeHost(const void* pData, unsigned dataType, int nDepth, int nCo
   const u32 rc = encodeDevice(ctx, rq, needed, written);
   if (rc != kOk) return rc;
   if (hipMemcpyAsync(pOut, dOut, written, hipMemcpyDeviceToHost, st) != hipSuccess) return kFailed;
-  if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
+  if (hipStreamSynchronize(st) != hipSuccess) return kFailed;    // (not the polling Context::sync(): the copy into the caller's pageable
+                                                                 // buffer is driven by this wait)
   *result = written;
   return kOk;
 }

@@ -265,7 +265,10 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   if (!dBits || !dCells || !dZMax || !dFl || !dPixel) return kFailed;
   hipMemsetAsync(dCells, 0, cellsBytes, st);
 
-  std::vector<u8> hBits;       // current mask (persists across bands: "use previous", Lerc2.cpp:1002)
+  // host buffers the enqueued copies read from: kept until the call's final synchronisation instead of waiting per band
+  std::vector<std::vector<u8> > keepBits;
+  std::vector<std::vector<double> > keepZMax;
+  struct Drain { Context& c; ~Drain() { c.sync(); } } drain{ ctx };    // (destroyed before the buffers above, on every way out)
   bool haveMask = false, maskAllValid = true;
   std::vector<u32> expectChecksum(rq.nBands, 0);
   std::vector<u32> checksumLen(rq.nBands, 0);
@@ -319,17 +322,16 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     u64 at = bd.offset + bd.hdrLen + 4;
     const int nv = hd.numValid;
     if ((nv == 0 || nv == (int)nPix) && bd.numBytesMask != 0) return kFailed;
-    if (nv == 0) { hBits.assign(maskBytes, 0); haveMask = true; maskAllValid = false; hipMemsetAsync(dBits, 0, maskBytes, st); }
-    else if (nv == (int)nPix) { haveMask = true; maskAllValid = true; hBits.clear(); }
+    if (nv == 0) { haveMask = true; maskAllValid = false; hipMemsetAsync(dBits, 0, maskBytes, st); }
+    else if (nv == (int)nPix) { haveMask = true; maskAllValid = true; }
     else if (bd.numBytesMask > 0)
     {
       small.resize((size_t)bd.numBytesMask);
       if (!rd.read(at, small.size(), small.data())) return kFailed;
-      hBits.assign(maskBytes, 0);
-      if (!rleDecode(small.data(), small.size(), hBits.data(), maskBytes)) return kFailed;
+      keepBits.emplace_back(maskBytes, (u8)0);
+      if (!rleDecode(small.data(), small.size(), keepBits.back().data(), maskBytes)) return kFailed;
       haveMask = true; maskAllValid = false;
-      hipMemcpyAsync(dBits, hBits.data(), maskBytes, hipMemcpyHostToDevice, st);
-      hipStreamSynchronize(st);    // hBits may be reused by the next band before the copy ran
+      hipMemcpyAsync(dBits, keepBits.back().data(), maskBytes, hipMemcpyHostToDevice, st);
     }
     else if (!haveMask || maskAllValid) return kFailed;    // "use previous mask" without a usable one
     at += (u64)bd.numBytesMask;
@@ -460,8 +462,8 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
       launchFletcher(dBand + 14, blobEnd - 14, dFl + (size_t)iBand * kFletcherPartials, st);
     }
 
-    hipMemcpyAsync(dZMax, zMaxVec.data(), (size_t)nD * 8, hipMemcpyHostToDevice, st);
-    hipStreamSynchronize(st);    // zMaxVec is a per-band temporary
+    keepZMax.push_back(zMaxVec);
+    hipMemcpyAsync(dZMax, keepZMax.back().data(), (size_t)nD * 8, hipMemcpyHostToDevice, st);
 
     DecodeArgs da;
     da.blob = dBand; da.dataBegin = (u32)(at - bd.offset); da.blobEnd = blobEnd;
