@@ -78,14 +78,20 @@ bool readHeader(const u8* src, size_t n, Header& h, size_t& used)
 void rleEncode(const u8* b, size_t n, std::vector<u8>& out)
 {
   out.clear();
+  out.reserve(n / 8 + 64);
   auto count = [&](int v) { short s = (short)v; out.push_back((u8)(s & 0xff)); out.push_back((u8)((s >> 8) & 0xff)); };
+  // eight bytes at a time (a validity mask of a large raster is megabytes): five equal bytes from i on <=> the low
+  // 32 bits of x ^ (x >> 8) are zero, x = the 8 bytes at i
+  auto load8 = [&](size_t at) { u64 x; memcpy(&x, b + at, 8); return x; };
   size_t i = 0;
   while (i < n)
   {
     const size_t litBeg = i;
     while (i < n)
     {
-      const bool runStarts = (i + 5 < n) && b[i] == b[i + 1] && b[i] == b[i + 2] && b[i] == b[i + 3] && b[i] == b[i + 4];
+      bool runStarts;
+      if (i + 8 <= n) { const u64 x = load8(i); runStarts = (i + 5 < n) && (u32)(x ^ (x >> 8)) == 0u; }
+      else runStarts = (i + 5 < n) && b[i] == b[i + 1] && b[i] == b[i + 2] && b[i] == b[i + 3] && b[i] == b[i + 4];
       if (runStarts) break;
       i++;
     }
@@ -98,6 +104,8 @@ void rleEncode(const u8* b, size_t n, std::vector<u8>& out)
     }
     if (i >= n) break;
     size_t t = i;
+    const u64 same = 0x0101010101010101ull * b[i];
+    while (t + 9 <= n && load8(t + 1) == same) t += 8;    // b[t + 1 .. t + 8] all equal b[i]
     while (t + 1 < n && b[t + 1] == b[i]) t++;
     for (size_t left = t - i + 1; left > 0;)
     {

@@ -331,20 +331,20 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   bool encMask = (iBand == 0);
   {
     // the reference compares the (filtered) byte masks of consecutive bands; validity bits are equivalent
-    std::vector<u8> cur = hBandBits;    // empty == all valid
-    const bool compare = (rq.nMasks > 1) || anyMaskModified;
-    if (compare && iBand > 0 && cur != prevByteValid) encMask = true;
-    if (rq.nBands > 1 && iBand < rq.nBands - 1) prevByteValid = cur;
+    const bool compare = (rq.nMasks > 1) || anyMaskModified;    // (an empty vector == all valid)
+    if (compare && iBand > 0 && hBandBits != prevByteValid) encMask = true;
+    if (rq.nBands > 1 && iBand < rq.nBands - 1) prevByteValid = hBandBits;
   }
   if (encMask)
   {
     ms.allValid = bandAllValid;
     ms.numValid = bandNumValid;
-    ms.hBits = hBandBits;
+    const size_t nMaskBytes = hBandBits.size();
+    ms.hBits = std::move(hBandBits);    // (megabytes for a large raster: moved, not copied)
     if (!bandAllValid)
     {
       if (!ms.dBits) return kFailed;
-      hipMemcpyAsync(ms.dBits, dNewBits, hBandBits.size(), hipMemcpyDeviceToDevice, st);
+      hipMemcpyAsync(ms.dBits, dNewBits, nMaskBytes, hipMemcpyDeviceToDevice, st);
     }
   }
   const u8* dBits = ms.allValid ? nullptr : ms.dBits;
