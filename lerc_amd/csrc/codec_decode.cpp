@@ -112,7 +112,8 @@ static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8
   fbuf.wgFletcher = ctx.allocT<u64>(2 * nT * (fwp.nBlocks / kFastBlocksPerWG + 1) + 4);
   if (!fbuf.chunkListN || !fbuf.chunkList || !fbuf.chains || !fbuf.chainCount || !fbuf.chunkEntry || !fbuf.chunkCount
     || !fbuf.subEntry || !fbuf.subIndex || !fbuf.blockOff || !fbuf.wgFletcher) return false;
-  static const char* kStage[kFastDecodeStages] = { "fast_candidates", "fast_chains", "fast_resolve", "fast_emit_offsets", "fast_decode" };
+  static const char* kStage[kFastDecodeStages] = { "fast_header", "fast_candidates", "fast_chains", "fast_resolve", "fast_emit_offsets", "fast_decode",
+                                                   "fast_fletcher_sum" };
   for (int stage = 0; stage < kFastDecodeStages; stage++)
   {
     ProfScope ps(ctx, kStage[stage]);

@@ -684,12 +684,15 @@ static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double
 
 static void runFastEncode(Context& ctx, const FastEncodeLaunch& fl, const void* dData, u8* dOut, u64 capacity, u64 arenaBase)
 {
-  static const char* kStage[4] = { "fast_stats_sizes", "fast_scan_decide", "fast_pack", "fast_checksum" };
-  const int nStages = dOut ? 4 : 2;    // no output buffer: the size is known after the decisions
+  // one kernel per stage (and per profiling group): prepare (float types with raise candidates only), statistics, scan + decide
+  // (+ tile placement for batches), pack, checksum
+  static const char* kStage[5] = { "fast_prepare", "fast_stats_sizes", "fast_scan_decide", "fast_pack", "fast_checksum" };
+  const int nStages = dOut ? 5 : 3;    // no output buffer: the size is known after the decisions
   for (int stage = 0; stage < nStages; stage++)
   {
+    if (stage == 0 && !fl.fb.row0RaiseErr) continue;
     ProfScope ps(ctx, kStage[stage]);
-    launchFastEncode(stage, fl.bp, fl.maxZErr, fl.cand, dData, dOut, capacity, arenaBase, fl.fb, fl.batch, ctx.activeStream());
+    launchFastEncode(stage - 1, fl.bp, fl.maxZErr, fl.cand, dData, dOut, capacity, arenaBase, fl.fb, fl.batch, ctx.activeStream());
   }
 }
 

@@ -60,7 +60,8 @@ struct FastEncodeBuffers
 
 bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, double maxZErr);
 u32 fastEncodeNumWG(int nRows, int nCols);
-// stage 0: statistics + block sizes; 1: scan + decisions + header; 2: pack + Fletcher sums; 3: checksum patch
+// stage -1: first-row rounding errors (float types); 0: statistics + block sizes; 1: scan + decisions + header; 2: pack +
+// Fletcher sums; 3: checksum patch
 // (batches: stage 1 also places the tiles in the arena, from `arenaBase` on; tiles that need the general path take no room)
 void launchFastEncode(int stage, const BandParams& assumed, double requestedMaxZErr, u32 raiseCandidates, const void* data, u8* out,
                       u64 outCapacity, u64 arenaBase, const FastEncodeBuffers& b, const FastBatch& batch, hipStream_t st);
@@ -179,8 +180,8 @@ LERC_HD u32 fastChunkStride(u32 nChunks) { return nChunks + 4u; }    // elements
 
 bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid);
 FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven);
-static const int kFastDecodeStages = 5;
-// stage 0: header + candidates; 1: chains; 2: resolve; 3: block offsets; 4: decode + checksum
+static const int kFastDecodeStages = 7;    // one kernel each: header, candidates, chains, resolve, emit, decode, checksum fold
+// stage 0: header; 1: candidates; 2: chains; 3: resolve; 4: block offsets; 5: decode; 6: checksum fold
 void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
                       const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st);
 

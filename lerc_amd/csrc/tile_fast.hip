@@ -751,10 +751,13 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
                               u64 arenaBase, const FastEncodeBuffers& b, const FastBatch& batch, hipStream_t st)
 {
   const u32 nWG = batch.nWG, nT = batch.nTiles;
-  if (stage == 0)
+  if (stage == -1)
   {
     if (b.row0RaiseErr)
       hipLaunchKernelGGL(k_fast_prepare<T>, dim3(batch.nRaiseSets, nT), dim3(256), 0, st, (const T*)data, p.nCols, raiseCand, b.row0RaiseErr, batch);
+  }
+  else if (stage == 0)
+  {
     if (p.nTH % 64 == 0)
       hipLaunchKernelGGL((k_fast_stats<T, true>), dim3(nWG, nT), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.wgMinKey, b.wgMaxKey,
                          b.wgFlags, batch);

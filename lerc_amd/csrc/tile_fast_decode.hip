@@ -1050,22 +1050,26 @@ static void launchFastDecodeT(int stage, int nRows, int nCols, const FastDecodeB
   {
     case 0:
       hipLaunchKernelGGL(k_fast_header<DT>, dim3(1, nT), dim3(64), 0, st, b, t, blob, sizeGiven, nRows, nCols, reinterpret_cast<u32*>(status));
-      hipLaunchKernelGGL(k_fast_candidates<DT>, dim3((t.nChunks + kWalkG - 1) / kWalkG, nT), dim3(256), 0, st, b, t, blob);
       break;
     case 1:
-      hipLaunchKernelGGL(k_fast_chains<DT>, dim3((t.chainCap + 255) / 256, nT), dim3(256), 0, st, b, t, blob);
+      hipLaunchKernelGGL(k_fast_candidates<DT>, dim3((t.nChunks + kWalkG - 1) / kWalkG, nT), dim3(256), 0, st, b, t, blob);
       break;
     case 2:
-      hipLaunchKernelGGL(k_fast_resolve<DT>, dim3((t.nChunks + 256) / 256, nT), dim3(256), 0, st, b, t, blob);
+      hipLaunchKernelGGL(k_fast_chains<DT>, dim3((t.chainCap + 255) / 256, nT), dim3(256), 0, st, b, t, blob);
       break;
     case 3:
+      hipLaunchKernelGGL(k_fast_resolve<DT>, dim3((t.nChunks + 256) / 256, nT), dim3(256), 0, st, b, t, blob);
+      break;
+    case 4:
       hipLaunchKernelGGL(k_fast_emit<DT>, dim3((t.nChunks * kFastSubPerChunk + 255) / 256, nT), dim3(256), 0, st, b, t, blob);
       break;
-    default:
+    case 5:
       if ((nCols / 8) % 64 == 0)
         hipLaunchKernelGGL((k_fast_decode<T, true>), dim3((t.nBlocks + kFastBlocksPerWG - 1) / kFastBlocksPerWG, nT), dim3(256), 0, st, b, t, blob, (T*)out, status);
       else
         hipLaunchKernelGGL((k_fast_decode<T, false>), dim3((t.nBlocks + kFastBlocksPerWG - 1) / kFastBlocksPerWG, nT), dim3(256), 0, st, b, t, blob, (T*)out, status);
+      break;
+    default:
       hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1, nT), dim3(nT > 1 ? 256 : 1024), 0, st, b, t);
       break;
   }
