@@ -42,8 +42,8 @@ LERC_AMD_API lerc_status lerc_encode(const void* pData, unsigned int dataType, i
     int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr, unsigned char* pOutBuffer,
     unsigned int outBufferSize, unsigned int* nBytesWritten);
 
-/* reference Lerc_c_api.h:159-171 and :175-189 -- codecVersion -1 (latest) or 3..6; codec 3..5 blobs come out as
- * Lerc::EncodeInternal_v5 writes them (Lerc.cpp:526-624).  Codec 2 (pre-v3 bit layout) is not produced: WrongParam(2) */
+/* reference Lerc_c_api.h:159-171 and :175-189 -- codecVersion -1 (latest) or 2..6; codec 2..5 blobs come out as
+ * Lerc::EncodeInternal_v5 writes them (Lerc.cpp:526-624) */
 LERC_AMD_API lerc_status lerc_computeCompressedSizeForVersion(const void* pData, int codecVersion, unsigned int dataType,
     int nDepth, int nCols, int nRows, int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr,
     unsigned int* numBytes);

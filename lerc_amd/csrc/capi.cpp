@@ -176,11 +176,11 @@ lerc_status lerc_computeCompressedSizeForVersion(const void* pData, int codecVer
   if (!numBytes) return kWrongParam;
   *numBytes = 0;
   if (codecVersion > kCodecVersion) return kWrongParam;
-  if (codecVersion >= 0 && codecVersion < kCodecVersion)    // Lerc.cpp:339-347 -> EncodeInternal_v5; codec 2 (pre-v3 bit layout) is not built
+  if (codecVersion >= 0 && codecVersion < kCodecVersion)    // Lerc.cpp:339-347 -> EncodeInternal_v5
   {
     if (!pData || dataType >= DT_Undefined || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0 || maxZErr < 0) return kWrongParam;
     if (!masksArgOk(nMasks, nBands, pValidBytes)) return kWrongParam;
-    if (codecVersion < 3) return kWrongParam;
+    if (codecVersion < 2) return kWrongParam;    // Lerc2::SetEncoderToOldVersion (Lerc2.cpp:52-62)
     return encodeHost(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, nullptr, 0, numBytes, true, nullptr,
                       nullptr, codecVersion);
   }
@@ -201,7 +201,7 @@ lerc_status lerc_encodeForVersion(const void* pData, int codecVersion, unsigned 
       || !pOutBuffer || !outBufferSize)
       return kWrongParam;
     if (!masksArgOk(nMasks, nBands, pValidBytes)) return kWrongParam;
-    if (codecVersion < 3) return kWrongParam;
+    if (codecVersion < 2) return kWrongParam;    // Lerc2::SetEncoderToOldVersion (Lerc2.cpp:52-62)
     return encodeHost(pData, dataType, nDepth, nCols, nRows, nBands, nMasks, pValidBytes, maxZErr, pOutBuffer, outBufferSize,
                       nBytesWritten, false, nullptr, nullptr, codecVersion);
   }

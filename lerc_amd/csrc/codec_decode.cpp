@@ -435,7 +435,6 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
       if (rc != kOk) return rc;
       continue;
     }
-    if (hd.version < 3) { ctx.lastError = "codec version 2 bit layout is not supported"; return kFailed; }
 
     // ---- tiling mode: discover the block offsets, then decode
     BandParams bp;

@@ -600,7 +600,15 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     if (!emitHuffman(ctx, dt, dData, dBits, nRows, nCols, nD, huff, dPayload, dStatus)) return kFailed;
   }
 
-  // ---- 5. checksum over blob[14 ..) (Lerc2.cpp:1012-1030), patched into the header
+  // ---- 5. checksum over blob[14 ..) (Lerc2.cpp:1012-1030), patched into the header (codec 2 has none)
+  if (hd.version < 3)
+  {
+    hipMemcpyAsync(&hr.status, dStatus, sizeof(DeviceStatus), hipMemcpyDeviceToHost, st);
+    if (!sync.wait()) return kFailed;
+    if (hr.status.error) { ctx.lastError = "device kernel reported an error"; return hr.status.error; }
+    if (ctx.profOn()) ctx.profCollect();
+    return kOk;
+  }
   u64* dFl = ctx.allocT<u64>(kFletcherPartials);
   if (!dFl) return kFailed;
   { ProfScope ps(ctx, "fletcher_enc"); launchFletcher(dBandOut + 14, blobSize - 14, dFl, st); }
@@ -712,7 +720,7 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   if (anyNoData) need += (size_t)nPix * rq.nDepth * tb + (size_t)nPix + 8192;
   if (rq.dt >= DT_Float && (rq.maxZErr == 0 || anyNoData) && rq.version >= 6) need += fplEncodeScratchBytes(nPix * rq.nDepth, tb);
   // (a size query, dOut == nullptr, takes the first two steps of the streaming path: statistics and decisions)
-  if (rq.version < 3 || rq.version > kCodecVersion) return kWrongParam;
+  if (rq.version < 2 || rq.version > kCodecVersion) return kWrongParam;
   if (rq.version < 6 && anyNoData) return kWrongParam;    // Lerc.cpp:341-344
   if (rq.version < 4 && rq.nDepth > 1) return kFailed;    // Lerc2::Set refuses (Lerc2.cpp:85-86)
   const bool fastOk = !anyNoData && rq.version == kCodecVersion && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0

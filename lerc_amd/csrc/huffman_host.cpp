@@ -127,7 +127,7 @@ struct WordSink
   void finish() { if (used > 0) flushWord(); }
 };
 
-void serialiseTable(const std::vector<HCode>& t, std::vector<u8>& out)
+void serialiseTable(const std::vector<HCode>& t, std::vector<u8>& out, int lercVersion = kCodecVersion)
 {
   out.clear();
   int i0 = 0, i1 = 0, maxLen = 0;
@@ -144,11 +144,22 @@ void serialiseTable(const std::vector<HCode>& t, std::vector<u8>& out)
   for (int i = 0; i < cb; i++) out.push_back((u8)(n >> (8 * i)));
   const size_t at = out.size();
   out.resize(at + ((n * nb + 7) >> 3), 0);
+  auto orAt = [&](u32 bitPos, u32 value)    // value's bits into the little-endian bit stream that starts at out[at]
+  {
+    const u64 v = (u64)value << (bitPos & 7);
+    const size_t b = at + (bitPos >> 3);
+    for (int k = 0; k < 5 && (v >> (8 * k)); k++) out[b + k] |= (u8)(v >> (8 * k));
+  };
   for (u32 i = 0; i < n; i++)
   {
-    const u64 v = (u64)t[wrapIdx(i0 + (int)i, size)].first << ((i * nb) & 7);
-    const size_t b = at + ((i * nb) >> 3);
-    for (int k = 0; k < 3 && (v >> (8 * k)); k++) out[b + k] |= (u8)(v >> (8 * k));
+    const u32 len = t[wrapIdx(i0 + (int)i, size)].first;
+    if (lercVersion >= 3) orAt(i * nb, len);
+    else    // codec 2 bit layout (lerc_common.h: oldBitLayout)
+    {
+      const OldBitLayout o = oldBitLayout(i, nb, n);
+      orAt(o.pos0, len >> o.n1);
+      if (o.n1) orAt(o.pos1, len & ((1u << o.n1) - 1u));
+    }
   }
   WordSink sink(out);
   for (int i = i0; i < i1; i++)
@@ -173,7 +184,7 @@ bool compressedBytes(const std::vector<HCode>& t, const std::vector<int>& histo,
 // parses the code table at p; `used` = bytes consumed
 bool parseTable(const u8* p, size_t n, int lercVersion, std::vector<HCode>& t, size_t& used)
 {
-  if (lercVersion < 3 || n < 16) return false;
+  if (lercVersion < 2 || n < 16) return false;
   int hdr[4];
   memcpy(hdr, p, 16);
   if (hdr[0] < 2) return false;
@@ -195,12 +206,23 @@ bool parseTable(const u8* p, size_t n, int lercVersion, std::vector<HCode>& t, s
   {
     const size_t nBytes = ((size_t)cnt * nb + 7) >> 3;
     if (n < at + nBytes) return false;
+    auto bitsAt = [&](size_t bit, u32 nbits) -> u32
+    {
+      u64 v = 0;
+      for (int k = 0; k < 5; k++) if ((bit >> 3) + k < nBytes) v |= (u64)p[at + (bit >> 3) + k] << (8 * k);
+      return (u32)(v >> (bit & 7)) & ((1u << nbits) - 1);
+    };
     for (u32 i = 0; i < cnt; i++)
     {
-      const size_t bit = (size_t)i * nb;
-      u32 v = 0;
-      for (int k = 0; k < 3; k++) if ((bit >> 3) + k < nBytes) v |= (u32)p[at + (bit >> 3) + k] << (8 * k);
-      t[wrapIdx(i0 + (int)i, size)].first = (u16)((v >> (bit & 7)) & ((1u << nb) - 1));
+      u32 len;
+      if (lercVersion >= 3) len = bitsAt((size_t)i * nb, (u32)nb);
+      else
+      {
+        const OldBitLayout o = oldBitLayout(i, nb, cnt);
+        len = bitsAt(o.pos0, o.n0) << o.n1;
+        if (o.n1) len |= bitsAt(o.pos1, o.n1);
+      }
+      t[wrapIdx(i0 + (int)i, size)].first = (u16)len;
     }
     at += nBytes;
   }
@@ -310,12 +332,12 @@ bool planHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
   u64 bits0 = 0, bits1 = 0;
   if (version >= 4 && buildCodes(h0, t0))
   {
-    serialiseTable(t0, s0);
+    serialiseTable(t0, s0, version);
     if (!compressedBytes(t0, h0, (u32)s0.size(), n0, bits0)) n0 = 0;
   }
   if (buildCodes(h1, t1))
   {
-    serialiseTable(t1, s1);
+    serialiseTable(t1, s1, version);
     if (!compressedBytes(t1, h1, (u32)s1.size(), n1, bits1)) n1 = 0;
   }
   // Lerc2.cpp:2289-2306

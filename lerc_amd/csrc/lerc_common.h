@@ -58,6 +58,32 @@ LERC_HD int bitLen(u32 v)    // number of bits of the largest element (BitStuffe
 LERC_HD int countFieldBytes(u32 n) { return n < 256 ? 1 : (n < 65536 ? 2 : 4); }    // BitStuffer2.h:64
 
 // bytes of a BitStuffer2 "simple" stream: header byte + count field + ceil(n * numBits / 8)
+// Codec 2 packs the n elements of nb bits MSB first into 32-bit words, shifts the last word down by the bytes it does
+// not need and stores only the bytes in use (BitStuff_Before_Lerc2v3, BitStuffer2.cpp:292-351; same byte count as the later
+// layout).  Seen as the little-endian bit stream of those bytes, element i is one or two runs of bits: its top n0 bits at
+// bit pos0 and -- when it straddles two words -- its low n1 bits at pos1.
+struct OldBitLayout { u32 pos0, n0, pos1, n1; };
+LERC_HD OldBitLayout oldBitLayout(u32 i, int nb, u32 n)
+{
+  const u32 total = n * (u32)nb, lastWord = (total + 31u) / 32u - 1u;
+  const u32 tailBits = total & 31u, tailBytes = (tailBits + 7u) >> 3;
+  const u32 drop = tailBytes ? 8u * (4u - tailBytes) : 0u;    // NumTailBytesNotNeeded, BitStuffer2.h:127-132
+  const u32 b = i * (u32)nb, w = b >> 5, s = b & 31u;
+  OldBitLayout o;
+  if (s + (u32)nb <= 32u)
+  {
+    o.n0 = (u32)nb; o.n1 = 0; o.pos1 = 0;
+    o.pos0 = 32u * w + (32u - s - (u32)nb) - (w == lastWord ? drop : 0u);
+  }
+  else
+  {
+    o.n0 = 32u - s; o.pos0 = 32u * w;
+    o.n1 = (u32)nb - o.n0;
+    o.pos1 = 32u * (w + 1u) + (32u - o.n1) - (w + 1u == lastWord ? drop : 0u);
+  }
+  return o;
+}
+
 LERC_HD u32 sizeSimple(u32 n, u32 maxElem) { return 1 + countFieldBytes(n) + ((n * (u32)bitLen(maxElem) + 7) >> 3); }
 // bytes of a LUT stream (BitStuffer2.cpp:262-287); nLut = number of distinct values minus one
 LERC_HD u32 sizeLut(u32 n, u32 maxElem, u32 nLut, bool& doLut)

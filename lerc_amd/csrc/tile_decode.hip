@@ -107,6 +107,17 @@ __device__ __forceinline__ u32 readBits(const u8* __restrict__ blob, u64 bitPos,
   return (u32)((v >> sh) & ((nbits >= 32) ? 0xFFFFFFFFull : ((1ull << nbits) - 1)));
 }
 
+// element i of a bit-stuffed field of n elements, nb bits each, that starts at bit `at` of the blob
+// (BitStuffer2::BitUnStuff, BitStuffer2.cpp:476-540; codec 2: BitUnStuff_Before_Lerc2v3, :355-425)
+__device__ __forceinline__ u32 unstuffElement(const u8* __restrict__ blob, u64 at, u32 i, int nb, u32 n, u32 end, int version)
+{
+  if (version >= 3) return readBits(blob, at + (u64)i * nb, nb, end);
+  const OldBitLayout o = oldBitLayout(i, nb, n);
+  u32 v = readBits(blob, at + o.pos0, (int)o.n0, end) << o.n1;
+  if (o.n1) v |= readBits(blob, at + o.pos1, (int)o.n1, end);
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // decode kernel
 // ------------------------------------------------------------------------------------------------
@@ -160,7 +171,7 @@ __global__ void __launch_bounds__(256) k_decode_tiles(BandParams p, DecodeArgs a
     if (b.mode == 1 && b.lut)
     {
       s_lut[w][0] = 0;
-      for (u32 i = (u32)lane; i < b.nLut; i += 64) s_lut[w][i + 1] = readBits(blob, payloadBit + (u64)i * b.nb, b.nb, a.blobEnd);
+      for (u32 i = (u32)lane; i < b.nLut; i += 64) s_lut[w][i + 1] = unstuffElement(blob, payloadBit, i, b.nb, b.nLut, a.blobEnd, p.version);
       idxBit = payloadBit + 8ull * (((u64)b.nLut * b.nb + 7) >> 3);
       waveSync();
     }
@@ -196,10 +207,10 @@ __global__ void __launch_bounds__(256) k_decode_tiles(BandParams p, DecodeArgs a
         else
         {
           u32 q;
-          if (!b.lut) q = readBits(blob, payloadBit + (u64)rank * b.nb, b.nb, a.blobEnd);
+          if (!b.lut) q = unstuffElement(blob, payloadBit, (u32)rank, b.nb, b.cnt, a.blobEnd, p.version);
           else
           {
-            const u32 ix = readBits(blob, idxBit + (u64)rank * nbIdx, nbIdx, a.blobEnd);
+            const u32 ix = unstuffElement(blob, idxBit, (u32)rank, nbIdx, b.cnt, a.blobEnd, p.version);
             if (ix > b.nLut) { badIdx = true; q = 0; } else q = s_lut[w][ix];
           }
           double z = offset + (double)q * p.invScale;

@@ -24,6 +24,16 @@
 
 namespace lerc {
 
+// element i of a bit-stuffed field of n elements, nb bits each, that starts at bit `at` of the block image
+// (BitStuffer2::BitStuff, BitStuffer2.cpp:432-472; codec 2: BitStuff_Before_Lerc2v3, :292-351)
+__device__ __forceinline__ void stuffElement(u32* obuf, u32 at, u32 i, u32 v, int nb, u32 n, int version)
+{
+  if (version >= 3) { orBits(obuf, at + i * (u32)nb, v, nb); return; }
+  const OldBitLayout o = oldBitLayout(i, nb, n);
+  orBits(obuf, at + o.pos0, v >> o.n1, (int)o.n0);
+  if (o.n1) orBits(obuf, at + o.pos1, v & ((1u << o.n1) - 1u), (int)o.n1);
+}
+
 // Distinct values of the block in increasing order (what the reference gets from SortQuantArray,
 // Lerc2.cpp:2255-2266): repeated wave-min extraction.  Returns the number of distinct values, stores
 // them to lutOut (if not null) and the per-element index into idx.
@@ -107,7 +117,7 @@ __device__ __forceinline__ void composeBlock(u32* obuf, u32* lutBuf, const BandP
         at += 8u * (1u + (u32)cb);
 #pragma unroll
         for (int k = 0; k < E; k++)
-          if (rank[k] >= 0) orBits(obuf, at + (u32)rank[k] * (u32)nb, q[k], nb);
+          if (rank[k] >= 0) stuffElement(obuf, at, (u32)rank[k], q[k], nb, (u32)n, p.version);
       }
       else
       {
@@ -125,11 +135,11 @@ __device__ __forceinline__ void composeBlock(u32* obuf, u32* lutBuf, const BandP
           orBits(obuf, at + 8u * (1u + (u32)cb), nLut + 1, 8);
         }
         at += 8u * (2u + (u32)cb);
-        for (u32 i = (u32)lane; i < nLut; i += 64) orBits(obuf, at + i * (u32)nb, lutBuf[i + 1], nb);
+        for (u32 i = (u32)lane; i < nLut; i += 64) stuffElement(obuf, at, i, lutBuf[i + 1], nb, nLut, p.version);
         at += 8u * ((nLut * (u32)nb + 7) >> 3);
 #pragma unroll
         for (int k = 0; k < E; k++)
-          if (rank[k] >= 0) orBits(obuf, at + (u32)rank[k] * (u32)nbIdx, idx[k], nbIdx);
+          if (rank[k] >= 0) stuffElement(obuf, at, (u32)rank[k], idx[k], nbIdx, (u32)n, p.version);
       }
     }
   }

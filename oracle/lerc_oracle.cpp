@@ -330,8 +330,79 @@ static void stuffBits(Writer& w, const unsigned* v, unsigned n, int nb)
   w.p += nBytes;
 }
 
-static bool unstuffBits(Reader& r, std::vector<unsigned>& v, unsigned n, int nb)
+// Codec 2 (BitStuff_Before_Lerc2v3 / BitUnStuff_Before_Lerc2v3, BitStuffer2.cpp:292-425): the elements are packed MSB
+// first into 32-bit words, the last word is shifted down by the bytes it does not need and only its used bytes are kept.
+static unsigned tailBytesNotNeeded(unsigned n, int nb)    // BitStuffer2.h:127-132
 {
+  int numBitsTail = (int)(((unsigned long long)n * nb) & 31);
+  int numBytesTail = (numBitsTail + 7) >> 3;
+  return (numBytesTail > 0) ? 4 - numBytesTail : 0;
+}
+
+static void stuffBitsOld(Writer& w, const unsigned* v, unsigned n, int nb)
+{
+  const unsigned numUInts = (unsigned)(((unsigned long long)n * nb + 31) / 32);
+  std::vector<unsigned> arr(numUInts, 0u);
+  unsigned* dst = arr.data();
+  int bitPos = 0;
+  for (unsigned i = 0; i < n; i++)
+  {
+    if (32 - bitPos >= nb)
+    {
+      *dst |= v[i] << (32 - bitPos - nb);
+      bitPos += nb;
+      if (bitPos == 32) { bitPos = 0; dst++; }
+    }
+    else
+    {
+      const int k = nb - (32 - bitPos);
+      *dst++ |= v[i] >> k;
+      *dst |= v[i] << (32 - k);
+      bitPos = k;
+    }
+  }
+  const unsigned drop = tailBytesNotNeeded(n, nb);
+  for (unsigned k = drop; k; --k) arr[numUInts - 1] >>= 8;
+  const size_t nBytes = (size_t)numUInts * 4 - drop;
+  memcpy(w.p, arr.data(), nBytes);
+  w.p += nBytes;
+}
+
+static bool unstuffBitsOld(Reader& r, std::vector<unsigned>& v, unsigned n, int nb)
+{
+  if (n == 0 || nb >= 32) return false;
+  const size_t numUInts = (size_t)(((unsigned long long)n * nb + 31) / 32);
+  const unsigned drop = tailBytesNotNeeded(n, nb);
+  const size_t nBytes = ((size_t)n * nb + 7) / 8;
+  if (r.left + drop < numUInts * 4 || r.left < nBytes) return false;
+  std::vector<unsigned> arr(numUInts, 0u);
+  memcpy(arr.data(), r.p, nBytes);
+  for (unsigned k = drop; k; --k) arr[numUInts - 1] <<= 8;
+  v.assign(n, 0u);
+  const unsigned* src = arr.data();
+  int bitPos = 0;
+  for (unsigned i = 0; i < n; i++)
+  {
+    if (32 - bitPos >= nb)
+    {
+      v[i] = (*src << bitPos) >> (32 - nb);
+      bitPos += nb;
+      if (bitPos == 32) { bitPos = 0; src++; }
+    }
+    else
+    {
+      v[i] = (*src++ << bitPos) >> (32 - nb);
+      bitPos -= (32 - nb);
+      v[i] |= *src >> (32 - bitPos);
+    }
+  }
+  r.skip(nBytes);
+  return true;
+}
+
+static bool unstuffBits(Reader& r, std::vector<unsigned>& v, unsigned n, int nb, int lercVersion = kCurrentVersion)
+{
+  if (lercVersion < 3) return unstuffBitsOld(r, v, n, nb);
   if (n == 0 || nb >= 32) return false;
   size_t nBytes = ((size_t)n * nb + 7) >> 3;
   if (r.left < nBytes) return false;
@@ -361,7 +432,7 @@ static void putCountField(Writer& w, unsigned k, int nBytes)
   else w.put(&k, 4);
 }
 
-static bool encodeSimple(Writer& w, const std::vector<unsigned>& v)
+static bool encodeSimple(Writer& w, const std::vector<unsigned>& v, int lercVersion = kCurrentVersion)
 {
   if (v.empty()) return false;
   unsigned mx = *std::max_element(v.begin(), v.end());
@@ -372,7 +443,7 @@ static bool encodeSimple(Writer& w, const std::vector<unsigned>& v)
   int code = (cb == 4) ? 0 : 3 - cb;
   w.byte((u8)(nb | (code << 6)));
   putCountField(w, n, cb);
-  if (nb > 0) stuffBits(w, v.data(), n, nb);
+  if (nb > 0) { if (lercVersion >= 3) stuffBits(w, v.data(), n, nb); else stuffBitsOld(w, v.data(), n, nb); }
   return true;
 }
 
@@ -394,7 +465,7 @@ static unsigned sizeLut(const std::vector<QIdx>& sorted, bool& doLut)
 }
 
 // BitStuffer2.cpp:79-153
-static bool encodeLut(Writer& w, const std::vector<QIdx>& sorted)
+static bool encodeLut(Writer& w, const std::vector<QIdx>& sorted, int lercVersion = kCurrentVersion)
 {
   if (sorted.empty() || sorted[0].first != 0) return false;
   unsigned n = (unsigned)sorted.size();
@@ -416,10 +487,10 @@ static bool encodeLut(Writer& w, const std::vector<QIdx>& sorted)
   unsigned nLut = (unsigned)lut.size();
   if (nLut < 1 || nLut >= 255) return false;
   w.byte((u8)(nLut + 1));
-  stuffBits(w, lut.data(), nLut, nb);
+  if (lercVersion >= 3) stuffBits(w, lut.data(), nLut, nb); else stuffBitsOld(w, lut.data(), nLut, nb);
   int nbIdx = 0;
   while (nLut >> nbIdx) nbIdx++;
-  stuffBits(w, idx.data(), n, nbIdx);
+  if (lercVersion >= 3) stuffBits(w, idx.data(), n, nbIdx); else stuffBitsOld(w, idx.data(), n, nbIdx);
   return true;
 }
 
@@ -427,7 +498,6 @@ static bool encodeLut(Writer& w, const std::vector<QIdx>& sorted)
 // exactly like the reference's reused buffer.
 static bool decodeBitStuffer(Reader& r, std::vector<unsigned>& out, size_t maxCount, int lercVersion)
 {
-  if (lercVersion < 3) return false;    // pre-v3 bit layout not restated
   u8 b0;
   if (!r.get(&b0, 1)) return false;
   int code = b0 >> 6;
@@ -443,7 +513,7 @@ static bool decodeBitStuffer(Reader& r, std::vector<unsigned>& out, size_t maxCo
 
   if (!lutMode)
   {
-    if (nb > 0 && !unstuffBits(r, out, n, nb)) return false;
+    if (nb > 0 && !unstuffBits(r, out, n, nb, lercVersion)) return false;
     return true;
   }
   if (nb == 0) return false;
@@ -451,11 +521,12 @@ static bool decodeBitStuffer(Reader& r, std::vector<unsigned>& out, size_t maxCo
   if (!r.get(&lb, 1)) return false;
   int nLut = lb - 1;
   std::vector<unsigned> lut;
-  if (!unstuffBits(r, lut, (unsigned)nLut, nb)) return false;
+  if (nLut < 1) return false;
+  if (!unstuffBits(r, lut, (unsigned)nLut, nb, lercVersion)) return false;
   int nbIdx = 0;
   while (nLut >> nbIdx) nbIdx++;
   if (nbIdx == 0) return false;
-  if (!unstuffBits(r, out, n, nbIdx)) return false;
+  if (!unstuffBits(r, out, n, nbIdx, lercVersion)) return false;
   lut.insert(lut.begin(), 0u);
   for (unsigned i = 0; i < n; i++)
   {
@@ -618,7 +689,7 @@ static bool huffCompressedBytes(const std::vector<HCode>& t, const std::vector<i
   return true;
 }
 
-static bool huffWriteTable(Writer& w, const std::vector<HCode>& t)
+static bool huffWriteTable(Writer& w, const std::vector<HCode>& t, int lercVersion = kCurrentVersion)
 {
   int i0, i1, maxLen;
   if (!huffRange(t, i0, i1, maxLen)) return false;
@@ -627,7 +698,7 @@ static bool huffWriteTable(Writer& w, const std::vector<HCode>& t)
   for (int i = i0; i < i1; i++) lens[i - i0] = t[wrapIdx(i, size)].first;
   int hdr[4] = { 4, size, i0, i1 };
   w.put(hdr, 16);
-  if (!encodeSimple(w, lens)) return false;
+  if (!encodeSimple(w, lens, lercVersion)) return false;
   HuffSink s{ w.p, 0 };
   for (int i = i0; i < i1; i++)
   {
@@ -1575,8 +1646,8 @@ template<class Z> bool Band::writeBlock(const Z* buf, int n, Writer& w, int& nWr
     if (maxElem > 0)
     {
       if ((int)q.size() != n) return false;
-      if (mode == BEM_SIMPLE) { if (!encodeSimple(w, q)) return false; }
-      else if (mode == BEM_LUT) { if (!encodeLut(w, sorted)) return false; }
+      if (mode == BEM_SIMPLE) { if (!encodeSimple(w, q, hd.version)) return false; }
+      else if (mode == BEM_LUT) { if (!encodeLut(w, sorted, hd.version)) return false; }
       else return false;
     }
   }
@@ -1763,7 +1834,7 @@ template<class T> void Band::huffChoose(const T* data, int& nBytes, int& mode, s
 // Lerc2.cpp:2384-2468
 template<class T> bool Band::huffEncode(const T* data, Writer& w) const
 {
-  if (!huffWriteTable(w, huffCodes)) return false;
+  if (!huffWriteTable(w, huffCodes, hd.version)) return false;
   const int off = (hd.dt == DT_CHAR) ? 128 : 0, H = hd.nRows, W = hd.nCols, nD = hd.nDepth;
   const bool all = allValid();
   HuffSink s{ w.p, 0 };
@@ -2510,14 +2581,14 @@ static Err encodeBands(const T* pData, int version, int nDepth, int nCols, int n
 // Lerc::EncodeInternal_v5 (Lerc.cpp:526-624): what lerc_encodeForVersion does for codec versions 3..5.  No noData
 // filter and no all-integer promotion; a NaN becomes -FLT_MAX / -DBL_MAX, and a pixel that is NaN in every depth
 // leaves the mask (CheckForNaN :861-897, ReplaceNaNValues :901-938).  Lossless float has no Huffman mode before
-// codec 6 (Lerc2.h:130): it goes through the tiling with raw blocks.  (Codec 2 -- the pre-v3 bit layout,
-// BitStuffer2.cpp:292-425 -- is not restated.)
+// codec 6 (Lerc2.h:130): it goes through the tiling with raw blocks.  Codec 2 has no checksum and packs bits the old
+// way (stuffBitsOld).
 template<class T>
 static Err encodeBandsOld(const T* pData, int version, int nDepth, int nCols, int nRows, int nBands, int nMasks,
   const u8* pValidBytes, double maxZErr, unsigned& numBytesNeeded, u8* pBuffer, unsigned numBytesBuffer, unsigned& numBytesWritten)
 {
   numBytesNeeded = numBytesWritten = 0;
-  if (version < 3 || version > 5) return WRONG_PARAM;              // Lerc2.cpp:52-62 (2 would be legal there)
+  if (version < 2 || version > 5) return WRONG_PARAM;              // Lerc2.cpp:52-62
   if (version < 4 && nDepth > 1) return FAILED;                   // Lerc2::Set refuses (Lerc2.cpp:85-86)
   Band band;
   band.hd.version = version;

@@ -20,7 +20,7 @@
  * Huffman coded byte plane uninitialised (heap garbage), this restatement writes 0 (tests/cases.py: lossless_float_dont_care).
  *
  * Not restated (returns Failed / WrongParam, documented in DESIGN.md "out of scope"):
- *   - Lerc1 "CntZImage" legacy blobs, codec version 2 (no checksum, pre-v3 bit layout, BitStuffer2.cpp:291-425)
+ *   - Lerc1 "CntZImage" legacy blobs (decode only in the reference; it has no encoder to make test vectors with)
  */
 #ifndef LERC_ORACLE_H
 #define LERC_ORACLE_H

@@ -143,7 +143,9 @@ class LercLib:
         size = ct.c_uint(0)
         rc0 = self.lib.lerc_computeCompressedSizeForVersion(a.ctypes.data, int(version), dt_code(a.dtype), n_depth, n_cols,
                                                             n_rows, n_bands, n_masks, mptr, float(max_z_err), ct.byref(size))
-        cap = int(size.value) if rc0 == 0 else a.nbytes + 4096
+        # (64 bytes of slack: the reference's codec 2 packer clears whole 32-bit words and so writes up to 3 bytes behind
+        # the blob it announced, BitStuffer2.cpp:292-300 -- with an exact-size buffer that is a heap overrun)
+        cap = (int(size.value) if rc0 == 0 else a.nbytes + 4096) + 64
         buf = np.empty(max(cap, 1), np.uint8)
         written = ct.c_uint(0)
         rc = self.lib.lerc_encodeForVersion(a.ctypes.data, int(version), dt_code(a.dtype), n_depth, n_cols, n_rows, n_bands,

@@ -191,13 +191,13 @@ def check_nodata_case(T, P, name, arr, e, kw, same):
 
 
 def old_codec_cases(n_iter, seed=71):
-    """lerc_encodeForVersion with codec 3, 4, 5 (Lerc::EncodeInternal_v5): all dtypes, lossless float included (raw
+    """lerc_encodeForVersion with codec 2, 3, 4, 5 (Lerc::EncodeInternal_v5; codec 2: no checksum, old bit layout): all dtypes, lossless float included (raw
     blocks before codec 6), NaNs (-> mask), masks, nDepth (codec >= 4), several bands.  -> [(name, arr, version, e, kw)]"""
     rng = np.random.default_rng(seed)
     out = []
     for it in range(n_iter):
         dt = ALL_DTYPES[rng.integers(0, 8)]
-        ver = int(rng.choice([3, 4, 5]))
+        ver = int(rng.choice([2, 3, 4, 5]))
         nd = int(rng.choice([1, 1, 2, 3])) if ver >= 4 else 1
         nb = int(rng.choice([1, 1, 2]))
         r, c = int(rng.integers(1, 70)), int(rng.integers(1, 70))
