@@ -121,6 +121,13 @@ lerc_status decodeHost(const unsigned char* blob, unsigned blobSize, int nMasks,
   u8* dMask = nMasks ? (u8*)h->stage(1, maskBytes) : nullptr;
   if (!dOut || (nMasks && !dMask)) return kFailed;
 
+  if (isLerc1(blob, blobSize))
+  {
+    // Lerc1 leaves pixels that are not valid as the caller's buffer had them (Lerc::Convert, Lerc.cpp:795-845): the staging
+    // buffer starts out as a copy of it (lerc_decodeToDouble decodes into the tail of the double buffer, Lerc_c_api_impl.cpp:288-300)
+    const u8* src = (const u8*)pData + (widen ? nVals * (8 - tb) : 0);
+    hipMemcpyAsync(dOut, src, outBytes, hipMemcpyHostToDevice, st);
+  }
   DecodeRequest rq;
   rq.hBlob = blob; rq.blobSize = blobSize; rq.dt = (int)dataType; rq.nDepth = nDepth; rq.nCols = nCols; rq.nRows = nRows;
   rq.nBands = nBands; rq.nMasks = nMasks; rq.dOut = dOut; rq.dValidBytes = dMask;
@@ -230,7 +237,13 @@ lerc_status lerc_getBlobInfo(const unsigned char* pLercBlob, unsigned int blobSi
   if (!pLercBlob || !blobSize || (!infoArray && !dataRangeArray) || ((infoArraySize <= 0) && (dataRangeArraySize <= 0)))
     return kWrongParam;
   BlobInfo li;
-  const u32 e = getBlobInfo(pLercBlob, blobSize, li);
+  u32 e = getBlobInfo(pLercBlob, blobSize, li);
+  if (e != kOk && isLerc1(pLercBlob, blobSize))    // legacy Lerc1: the bands have to be decoded to know their ranges (Lerc.cpp:184-266)
+  {
+    lerc_amd_context* h = threadHandle();
+    if (!h) return kFailed;
+    e = lerc1BlobInfo(h->ctx, pLercBlob, blobSize, li, nullptr, nullptr, 0);
+  }
   if (e != kOk) return e;
   if (infoArray)
   {
@@ -254,7 +267,14 @@ lerc_status lerc_getDataRanges(const unsigned char* pLercBlob, unsigned int blob
 {
   if (!pLercBlob || !blobSize || !pMins || !pMaxs || nDepth <= 0 || nBands <= 0) return kWrongParam;
   BlobInfo li;
-  return getBlobInfo(pLercBlob, blobSize, li, pMins, pMaxs, (size_t)nDepth * (size_t)nBands);
+  const u32 e = getBlobInfo(pLercBlob, blobSize, li, pMins, pMaxs, (size_t)nDepth * (size_t)nBands);
+  if (e != kOk && isLerc1(pLercBlob, blobSize))
+  {
+    lerc_amd_context* h = threadHandle();
+    if (!h) return kFailed;
+    return lerc1BlobInfo(h->ctx, pLercBlob, blobSize, li, pMins, pMaxs, (size_t)nDepth * (size_t)nBands);
+  }
+  return e;
 }
 
 lerc_status lerc_decode_4D(const unsigned char* pLercBlob, unsigned int blobSize, int nMasks, unsigned char* pValidBytes,
@@ -280,7 +300,13 @@ lerc_status lerc_decodeToDouble_4D(const unsigned char* pLercBlob, unsigned int 
   if (!pLercBlob || !blobSize || !pData || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0) return kWrongParam;
   if (!masksArgOk(nMasks, nBands, pValidBytes)) return kWrongParam;
   BlobInfo li;
-  const u32 e = getBlobInfo(pLercBlob, blobSize, li);
+  u32 e = getBlobInfo(pLercBlob, blobSize, li);
+  if (e != kOk && isLerc1(pLercBlob, blobSize))
+  {
+    lerc_amd_context* h = threadHandle();
+    if (!h) return kFailed;
+    e = lerc1BlobInfo(h->ctx, pLercBlob, blobSize, li, nullptr, nullptr, 0);
+  }
   if (e != kOk) return e;
   if (li.nDepth != nDepth || li.nCols != nCols || li.nRows != nRows || li.nBands != nBands) return kFailed;
   return decodeHost(pLercBlob, blobSize, nMasks, pValidBytes, nDepth, nCols, nRows, nBands, (unsigned)li.dt, pData, true, pUsesNoData,

@@ -158,4 +158,9 @@ struct BlobInfo
 };
 u32 getBlobInfo(const u8* blob, u32 n, BlobInfo& info, double* mins = nullptr, double* maxs = nullptr, size_t nElem = 0);
 
+// legacy Lerc1 ("CntZImage") blobs: decode only, on the device (lerc1_host.cpp)
+bool isLerc1(const u8* hBlob, u32 n);
+u32 decodeLerc1(Context& ctx, const DecodeRequest& rq);
+u32 lerc1BlobInfo(Context& ctx, const u8* hBlob, u32 n, BlobInfo& info, double* mins, double* maxs, size_t nElem);
+
 }    // namespace lerc

@@ -192,7 +192,12 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   std::vector<BandDesc> bands;
   {
     BandDesc b;
-    if (!readBandHeader(rd, 0, b) || b.hd.version < 1) return kFailed;    // not Lerc2 (Lerc1 is out of scope)
+    if (!readBandHeader(rd, 0, b) || b.hd.version < 1)
+    {
+      u8 magic[10];
+      if (rq.blobSize >= 10 && rd.read(0, 10, magic) && memcmp(magic, "CntZImage ", 10) == 0) return decodeLerc1(ctx, rq);    // legacy Lerc1
+      return kFailed;    // neither Lerc2 nor Lerc1
+    }
     bands.push_back(b);
     u64 total = (u64)b.hd.blobSize;
     if (total > rq.blobSize) return kFailed;

@@ -46,6 +46,22 @@ struct WalkBuffers
   const u16* nValidBlk;  // [nTV*nTH]   valid pixels per block position (nullptr when uniformN > 0)
   u32* scratch;          // scan scratch, >= nChunks/1024 + 2 words
 };
+// ---- legacy Lerc1 z part (lerc1_kernels.hip)
+struct Lerc1Geom
+{
+  int width, height;
+  int nTV, nTH;          // numTilesVert / numTilesHori of the part header; a remainder row / column follows when the size does not divide
+  u32 tilesAcross, nTiles;
+  int allValid;          // the count part is a positive constant (m_bDecoderCanIgnoreMask)
+  float maxZInImg;
+  double maxZErr;
+};
+void launchLerc1TileValid(const Lerc1Geom& g, const u8* maskBits, u32* nValid, hipStream_t st);
+void launchLerc1Walk(const Lerc1Geom& g, const u8* part, u32 partBytes, const u32* nValid, u32* tileOff /* nTiles + 1 */, DeviceStatus* status,
+                     hipStream_t st);
+void launchLerc1Decode(int dt, const Lerc1Geom& g, const u8* part, u32 partBytes, const u8* maskBits, const u32* nValid, const u32* tileOff,
+                       void* out, DeviceStatus* status, hipStream_t st);
+
 WalkPlan makeWalkPlan(const BandParams& p, u32 dataBegin, u32 blobEnd, int numValid);
 void launchWalk(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, DeviceStatus* st,
                 hipStream_t stream);

@@ -2660,13 +2660,221 @@ static Err bandRanges(const u8* p, unsigned n, int iBand, const Header& h, doubl
   return b.ranges(p, n, mins + (size_t)iBand * nD, maxs + (size_t)iBand * nD) ? OK : FAILED;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Lerc1 ("CntZImage", decode only) -- Lerc1Decode/CntZImage.cpp:74-480, Lerc1Decode/BitStuffer.cpp:32-157.
+// Blob = "CntZImage " | version 11 | type 8 | height | width | maxZError | count part | z part; every further band is
+// header + z part only.  A part = numTilesVert | numTilesHori | numBytes | maxValInImg | tiles.  Counts are, in practice, a
+// validity mask (RLE of the bit mask) or constant; z tiles are raw floats, a constant, or offset + bit-stuffed integers
+// (the MSB-first word layout codec 2 inherited).  Unlike the reference, every read is bounds checked.
+// ---------------------------------------------------------------------------------------------
+struct Lerc1Image
+{
+  int width = 0, height = 0;
+  double maxZErr = 0;
+  std::vector<float> cnt, z;
+  bool ignoreMask = false;    // m_bDecoderCanIgnoreMask
+};
+
+static bool lerc1ReadFlt(Reader& r, float& z, int numBytes)    // CntZImage.cpp:449-477
+{
+  if (numBytes == 1) { signed char c; if (!r.get(&c, 1)) return false; z = c; return true; }
+  if (numBytes == 2) { short v; if (!r.get(&v, 2)) return false; z = v; return true; }
+  if (numBytes == 4) return r.get(&z, 4);
+  return false;
+}
+
+static bool lerc1BitStuffer(Reader& r, std::vector<unsigned>& data)    // BitStuffer.cpp:32-112
+{
+  u8 b0;
+  if (!r.get(&b0, 1)) return false;
+  const int bits67 = b0 >> 6, nb = b0 & 63;
+  const int nCount = (bits67 == 0) ? 4 : 3 - bits67;
+  unsigned n = 0;
+  if (nCount == 1) { u8 c; if (!r.get(&c, 1)) return false; n = c; }
+  else if (nCount == 2) { unsigned short v; if (!r.get(&v, 2)) return false; n = v; }
+  else if (nCount == 4) { if (!r.get(&n, 4)) return false; }
+  else return false;
+  if (nb >= 32) return false;
+  data.assign(n, 0u);
+  if (n == 0 || nb == 0) return true;
+  std::vector<unsigned> tmp;
+  if (!unstuffBitsOld(r, tmp, n, nb)) return false;
+  data.swap(tmp);
+  return true;
+}
+
+static bool lerc1ReadCntTile(Reader& r, Lerc1Image& img, int i0, int i1, int j0, int j1)    // CntZImage.cpp:262-337
+{
+  u8 flag;
+  if (i0 >= i1 || j0 >= j1 || !r.get(&flag, 1)) return false;
+  if (flag == 2) return true;    // all 0 (the image was cleared)
+  if (flag == 3 || flag == 4)
+  {
+    for (int i = i0; i < i1; i++) for (int j = j0; j < j1; j++) { img.cnt[(size_t)i * img.width + j] = (flag == 3) ? -1.0f : 1.0f; img.z[(size_t)i * img.width + j] = 0; }
+    return true;
+  }
+  if ((flag & 63) > 4) return false;
+  if (flag == 0)
+  {
+    for (int i = i0; i < i1; i++) for (int j = j0; j < j1; j++) if (!r.get(&img.cnt[(size_t)i * img.width + j], 4)) return false;
+    return true;
+  }
+  const int bits67 = flag >> 6, n = (bits67 == 0) ? 4 : 3 - bits67;
+  float offset = 0;
+  std::vector<unsigned> data;
+  if (!lerc1ReadFlt(r, offset, n) || !lerc1BitStuffer(r, data) || data.size() < (size_t)(i1 - i0) * (j1 - j0)) return false;
+  size_t k = 0;
+  for (int i = i0; i < i1; i++) for (int j = j0; j < j1; j++) img.cnt[(size_t)i * img.width + j] = offset + (float)data[k++];
+  return true;
+}
+
+static bool lerc1ReadZTile(Reader& r, Lerc1Image& img, int i0, int i1, int j0, int j1, float maxZInImg)    // CntZImage.cpp:341-438
+{
+  u8 flag;
+  if (!r.get(&flag, 1)) return false;
+  const int bits67 = flag >> 6;
+  flag &= 63;
+  auto at = [&](int i, int j) { return (size_t)i * img.width + j; };
+  if (flag == 2)
+  {
+    for (int i = i0; i < i1; i++) for (int j = j0; j < j1; j++) if (img.cnt[at(i, j)] > 0) img.z[at(i, j)] = 0;
+    return true;
+  }
+  if (flag > 3) return false;
+  if (flag == 0)
+  {
+    for (int i = i0; i < i1; i++) for (int j = j0; j < j1; j++) if (img.cnt[at(i, j)] > 0 && !r.get(&img.z[at(i, j)], 4)) return false;
+    return true;
+  }
+  const int n = (bits67 == 0) ? 4 : 3 - bits67;
+  float offset = 0;
+  if (!lerc1ReadFlt(r, offset, n)) return false;
+  if (flag == 3)
+  {
+    for (int i = i0; i < i1; i++) for (int j = j0; j < j1; j++) if (img.cnt[at(i, j)] > 0) img.z[at(i, j)] = offset;
+    return true;
+  }
+  std::vector<unsigned> data;
+  if (!lerc1BitStuffer(r, data)) return false;
+  const double invScale = 2 * img.maxZErr;
+  size_t k = 0;
+  for (int i = i0; i < i1; i++)
+    for (int j = j0; j < j1; j++)
+      if (img.ignoreMask || img.cnt[at(i, j)] > 0)
+      {
+        if (k >= data.size()) return false;
+        const float z = (float)(offset + data[k++] * invScale);
+        img.z[at(i, j)] = std::min(z, maxZInImg);
+      }
+  return true;
+}
+
+static const size_t kLerc1HeaderBytes = 10 + 4 * 4 + 8;
+
+// CntZImage::read (CntZImage.cpp:74-215)
+static bool lerc1Read(Reader& r, Lerc1Image& img, bool onlyHeader, bool onlyZPart)
+{
+  if (r.left < kLerc1HeaderBytes || memcmp(r.p, "CntZImage ", 10)) return false;
+  r.skip(10);
+  int version = 0, type = 0, width = 0, height = 0;
+  double maxZErr = 0;
+  r.get(&version, 4); r.get(&type, 4); r.get(&height, 4); r.get(&width, 4); r.get(&maxZErr, 8);
+  if (version != 11 || type != 8) return false;
+  if (height < 0 || width < 0 || height > 40000 || width > 40000) return false;
+  if ((size_t)8 * height * width > (size_t)INT_MAX) return false;
+  if (maxZErr > 1e12) return false;
+  if (onlyHeader) { img.width = width; img.height = height; img.maxZErr = maxZErr; return true; }
+  if (!onlyZPart) { img.width = width; img.height = height; img.cnt.assign((size_t)width * height, 0.f); img.z.assign((size_t)width * height, 0.f); }
+  else if (width != img.width || height != img.height) return false;
+  img.maxZErr = maxZErr;
+  if (!onlyZPart) img.ignoreMask = false;
+  for (int iPart = onlyZPart ? 1 : 0; iPart < 2; iPart++)
+  {
+    const bool zPart = iPart == 1;
+    int nTV = 0, nTH = 0, numBytes = 0;
+    float maxVal = 0;
+    if (r.left < 16) return false;
+    r.get(&nTV, 4); r.get(&nTH, 4); r.get(&numBytes, 4); r.get(&maxVal, 4);
+    if (numBytes < 0 || (size_t)numBytes > r.left) return false;
+    Reader part{ r.p, (size_t)numBytes };
+    if (!zPart && nTV == 0 && nTH == 0)
+    {
+      if (numBytes == 0)
+      {
+        std::fill(img.cnt.begin(), img.cnt.end(), maxVal);
+        if (maxVal > 0) img.ignoreMask = true;
+      }
+      else
+      {
+        Mask m;
+        m.resize(width, height);
+        if (!rleDecode(part.p, part.left, m.bits.data(), m.nBytes())) return false;
+        for (int64_t k = 0, nPix = (int64_t)width * height; k < nPix; k++) img.cnt[k] = m.valid(k) ? 1.0f : 0.0f;
+      }
+    }
+    else
+    {
+      if (nTV <= 0 || nTH <= 0 || nTV > height || nTH > width) return false;    // readTiles, CntZImage.cpp:219-258
+      for (int it = 0; it <= nTV; it++)
+      {
+        int tileH = height / nTV;
+        const int i0 = it * tileH;
+        if (it == nTV) tileH = height % nTV;
+        if (tileH == 0) continue;
+        for (int jt = 0; jt <= nTH; jt++)
+        {
+          int tileW = width / nTH;
+          const int j0 = jt * tileW;
+          if (jt == nTH) tileW = width % nTH;
+          if (tileW == 0) continue;
+          const bool ok = zPart ? lerc1ReadZTile(part, img, i0, i0 + tileH, j0, j0 + tileW, maxVal)
+                                : lerc1ReadCntTile(part, img, i0, i0 + tileH, j0, j0 + tileW);
+          if (!ok) return false;
+        }
+      }
+    }
+    r.skip((size_t)numBytes);
+  }
+  return true;
+}
+
+// Lerc::GetLercInfo, Lerc1 branch (Lerc.cpp:184-266): the bands are decoded to find valid counts and ranges
+static Err getInfoLerc1(const u8* blob, unsigned n, Info& info, double* mins, double* maxs)
+{
+  const size_t hdr0 = kLerc1HeaderBytes + 2 * 16 + 1, hdr1 = kLerc1HeaderBytes + 16 + 1;
+  Reader r{ blob, n };
+  Lerc1Image img;
+  if (hdr0 > n || !lerc1Read(r, img, true, false)) return FAILED;
+  info.zMin = FLT_MAX; info.zMax = -FLT_MAX;
+  info.nDepth = 1; info.nCols = img.width; info.nRows = img.height; info.dt = DT_FLOAT; info.maxZErr = img.maxZErr;
+  r = Reader{ blob, n };
+  bool onlyZ = false;
+  while ((size_t)info.blobSize + hdr1 < n)
+  {
+    if (!lerc1Read(r, img, false, onlyZ)) return info.nBands > 0 ? OK : FAILED;
+    onlyZ = true;
+    info.blobSize = (unsigned)(r.p - blob);
+    int numValid = 0;
+    float zMin = FLT_MAX, zMax = -FLT_MAX;
+    for (size_t k = 0; k < img.cnt.size(); k++)
+      if (img.cnt[k] > 0) { numValid++; zMax = std::max(zMax, img.z[k]); zMin = std::min(zMin, img.z[k]); }
+    info.numValid = numValid;
+    info.zMin = std::min(info.zMin, (double)zMin);
+    info.zMax = std::max(info.zMax, (double)zMax);
+    info.nMasks = numValid < img.width * img.height ? 1 : 0;
+    if (mins && maxs) { mins[info.nBands] = zMin; maxs[info.nBands] = zMax; }
+    info.nBands++;
+  }
+  return OK;
+}
+
 static Err getInfo(const u8* blob, unsigned n, Info& info, double* mins = nullptr, double* maxs = nullptr, size_t nElem = 0)
 {
   info = Info();
   Header h;
   bool hasMask = false;
   int nMasks = 0;
-  if (!peekHeader(blob, n, h, hasMask)) return FAILED;    // (Lerc1 not restated)
+  if (!peekHeader(blob, n, h, hasMask)) return getInfoLerc1(blob, n, info, mins, maxs);
   if (h.blobSize < 0) return FAILED;
   info.version = h.version; info.nDepth = h.nDepth; info.nCols = h.nCols; info.nRows = h.nRows;
   info.numValid = h.numValid; info.blobSize = (unsigned)h.blobSize; info.dt = h.dt;
@@ -2721,7 +2929,30 @@ static Err decodeBands(T* pData, const u8* blob, unsigned nBytesBlob, int nDepth
   if (!dimsOk(nDepth, nCols, nRows, sizeof(T))) return DIMS_TOO_LARGE;
   Header h;
   bool hasMask = false;
-  if (!peekHeader(blob, nBytesBlob, h, hasMask) || h.version < 1) return FAILED;    // Lerc1 not restated
+  if (!peekHeader(blob, nBytesBlob, h, hasMask) || h.version < 1)
+  {
+    // Lerc1 (Lerc.cpp:487-516 + Lerc::Convert :795-845): pixels that are not valid keep what the caller's buffer held
+    const size_t hdr0 = kLerc1HeaderBytes + 2 * 16 + 1, hdr1 = kLerc1HeaderBytes + 16 + 1;
+    Reader r{ blob, nBytesBlob };
+    Lerc1Image img;
+    const bool flt = std::is_floating_point<T>::value;
+    for (int iBand = 0; iBand < nBands; iBand++)
+    {
+      if ((size_t)(r.p - blob) + (iBand == 0 ? hdr0 : hdr1) > nBytesBlob) return FAILED;
+      if (!lerc1Read(r, img, false, iBand > 0)) return FAILED;
+      if (img.width != nCols || img.height != nRows) return FAILED;
+      const size_t nPix = (size_t)nRows * nCols;
+      T* arr = pData + (size_t)iBand * nPix;
+      u8* msk = iBand < nMasks ? pValidBytes + (size_t)iBand * nPix : nullptr;
+      if (msk) memset(msk, 0, nPix);
+      for (size_t k = 0; k < nPix; k++)
+      {
+        if (img.cnt[k] > 0) { arr[k] = flt ? (T)img.z[k] : (T)floor(img.z[k] + 0.5); if (msk) msk[k] = 1; }
+        else if (!msk && iBand == 0) return FAILED;
+      }
+    }
+    return OK;
+  }
   Info info;
   Err e = getInfo(blob, nBytesBlob, info);
   if (e != OK) return e;

@@ -19,8 +19,7 @@
  * Lossless float / double is restated too (fpl_*); there the reference leaves the read-ahead word behind every
  * Huffman coded byte plane uninitialised (heap garbage), this restatement writes 0 (tests/cases.py: lossless_float_dont_care).
  *
- * Not restated (returns Failed / WrongParam, documented in DESIGN.md "out of scope"):
- *   - Lerc1 "CntZImage" legacy blobs (decode only in the reference; it has no encoder to make test vectors with)
+ * Legacy Lerc1 ("CntZImage") blobs are restated too (decode only, like the reference) and pinned on testData/world.lerc1.
  */
 #ifndef LERC_ORACLE_H
 #define LERC_ORACLE_H

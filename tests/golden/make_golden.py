@@ -5,7 +5,7 @@ Run in the build container only:   make -C oracle ref && python tests/golden/mak
 
 Outputs (data only -- inputs and expected outputs, never reference source text):
   js_sanity_v5.lerc2        the inline golden blob of OtherLanguages/js/tests/sanity.mjs:6 (number list -> bytes)
-  california_400_400_1_float.lerc2, bluemarble_256_256_3_byte.lerc2   the reference's own testData blobs
+  california_400_400_1_float.lerc2, bluemarble_256_256_3_byte.lerc2, world.lerc1   the reference's own testData blobs
   kat_more_md.json          doc/MORE.md:5-41 worked 4x4 example: inputs + reference blobs (hex) at maxZErr 0.01 / 1.0
   ref_vectors.json          for every case of tests/cases.py: reference status, blob size, sha256(blob),
                             sha256(decoded bytes), sha256(mask), getBlobInfo arrays
@@ -43,7 +43,7 @@ def main():
     blob = bytes(int(x) for x in m.group(1).split(","))
     open(os.path.join(HERE, "js_sanity_v5.lerc2"), "wb").write(blob)
     # 2. testData blobs
-    for f in ("california_400_400_1_float.lerc2", "bluemarble_256_256_3_byte.lerc2"):
+    for f in ("california_400_400_1_float.lerc2", "bluemarble_256_256_3_byte.lerc2", "world.lerc1"):
         shutil.copyfile(os.path.join(REF_ROOT, "testData", f), os.path.join(HERE, f))
     # 3. MORE.md worked example
     vals = [1234.1234, 1241.8741, 1256.2759, 1267.2950, 1280.8725, 1248.2917, 1272.7511, 1279.3802,

@@ -339,3 +339,27 @@ def test_several_bands_take_the_streaming_kernels(P, O):
         assert P.path_counters()[0] >= c0[0] + 2, (np.dtype(dt).name, P.last_note())
         d1, d2 = O.decode(b1), P.decode(b1)
         assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1])
+
+
+def test_lerc1_world(P, O):
+    """the reference's legacy Lerc1 fixture (decode only): info, ranges, pixels, mask -- and damaged copies"""
+    blob = open(os.path.join(GOLD, "world.lerc1"), "rb").read()
+    assert P.blob_info(blob) == O.blob_info(blob) == (0, [0, 6, 1, 257, 257, 1, 65025, 63518, 1, 1, 0], [-27.458635330200195, 5474.1728515625, 0.1])
+    assert P.data_ranges(blob, 1, 1) == O.data_ranges(blob, 1, 1)
+    for kw in ({}, {"to_double": True}):
+        d1, d2 = O.decode(blob, **kw), P.decode(blob, **kw)
+        assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1]) and _same(d1[2], d2[2])
+    m = d2[2].reshape(257, 257).astype(bool)
+    assert sha(P.decode(blob)[1].reshape(257, 257)[m].tobytes()) == "74f626d1a4fcf78f1eae5b7cb07f7690a8a0bf76d5d77315b3737a2bae5aae09"
+    rng = np.random.default_rng(3)
+    for t in range(150):
+        x = bytearray(blob)
+        k = int(rng.integers(0, len(x)))
+        x[k] ^= 1 << int(rng.integers(0, 8))
+        if t % 4 == 0:
+            x = x[:max(40, k)]
+        x = bytes(x)
+        g1, g2 = O.decode(x), P.decode(x)
+        assert (g1[0] == 0) == (g2[0] == 0), (t, k)
+        if g1[0] == 0:
+            assert _same(g1[1], g2[1]) and _same(g1[2], g2[2]), (t, k)

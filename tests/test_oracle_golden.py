@@ -149,3 +149,15 @@ def test_lossless_float_vectors(O):
     import hashlib
     vec = json.load(open(os.path.join(GOLD, "fpl_vectors.json")))
     cases.check_lossless_float_golden(O, vec, os.path.join(GOLD, "blobs"), lambda b: hashlib.sha256(bytes(b)).hexdigest())
+
+
+def test_lerc1_world(O):
+    """testData/world.lerc1, the reference's legacy-format fixture: info array and ranges as the reference reports them,
+    sha256 of the valid pixels as the reference decodes them (tests/golden/make_golden.py copies the file)"""
+    blob = open(os.path.join(GOLD, "world.lerc1"), "rb").read()
+    assert O.blob_info(blob) == (0, [0, 6, 1, 257, 257, 1, 65025, 63518, 1, 1, 0], [-27.458635330200195, 5474.1728515625, 0.1])
+    rc, dec, mask = O.decode(blob)
+    assert rc == 0
+    m = mask.reshape(257, 257).astype(bool)
+    assert int(m.sum()) == 65025
+    assert sha(dec.reshape(257, 257)[m].tobytes()) == "74f626d1a4fcf78f1eae5b7cb07f7690a8a0bf76d5d77315b3737a2bae5aae09"

@@ -142,3 +142,14 @@ def test_nodata_fuzz(O):
     """the shared noData case generator (also used against the product), lossless float bands included"""
     for name, arr, e, kw in cases.nodata_fuzz_cases(250, seed=34):
         cases.check_nodata_case(R, O, name, arr, e, kw, _same)
+
+
+def test_lerc1_world(O):
+    """the legacy Lerc1 fixture: info, ranges, pixels (as float, double and int16) and mask as the real reference gives them"""
+    import os
+    blob = open(os.path.join(capi.ROOT, "tests", "golden", "world.lerc1"), "rb").read()
+    assert R.blob_info(blob) == O.blob_info(blob)
+    assert R.data_ranges(blob, 1, 1) == O.data_ranges(blob, 1, 1)
+    for kw in ({}, {"to_double": True}):
+        d1, d2 = R.decode(blob, **kw), O.decode(blob, **kw)
+        assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1]) and _same(d1[2], d2[2])

@@ -434,3 +434,37 @@ def test_sim_streaming_encode_of_several_bands(libs):
     x = np.stack([cases._cast(cases.terrain(16, 512, rng), np.float32)] * 2)
     rc, size = O.compute_size(x, 0.01, n_bands=2)
     assert S.encode(x, 0.01, n_bands=2, buf_size=size - 10)[0] == O.encode(x, 0.01, n_bands=2, buf_size=size - 10)[0] == 3
+
+
+def test_sim_lerc1_world(libs):
+    """the reference's Lerc1 fixture (testData/world.lerc1, 257 x 257 float, RLE mask, 33 x 33 tiles): info, ranges, pixels
+    as float / double / int16, the mask, the refusal when the caller takes no mask, damaged copies"""
+    import ctypes as ct
+    O, S = libs
+    blob = open(os.path.join(capi.ROOT, "tests", "golden", "world.lerc1"), "rb").read()
+    assert O.blob_info(blob) == S.blob_info(blob) == (0, [0, 6, 1, 257, 257, 1, 65025, 63518, 1, 1, 0], [-27.458635330200195, 5474.1728515625, 0.1])
+    assert O.data_ranges(blob, 1, 1) == S.data_ranges(blob, 1, 1)
+    d1, d2 = O.decode(blob), S.decode(blob)
+    assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1]) and _same(d1[2], d2[2])    # (pixels that are not valid keep the harness's fill)
+    d1, d2 = O.decode(blob, to_double=True), S.decode(blob, to_double=True)
+    assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1])
+    b = np.frombuffer(blob, np.uint8)
+    outs = []
+    for L in (O, S):
+        out, m = np.full((257, 257), -7, np.int16), np.zeros((257, 257), np.uint8)
+        assert L.lib.lerc_decode(b.ctypes.data, len(blob), 1, m.ctypes.data, 1, 257, 257, 1, 2, out.ctypes.data) == 0
+        assert L.lib.lerc_decode(b.ctypes.data, len(blob), 0, None, 1, 257, 257, 1, 2, out.ctypes.data) == 1    # has a mask: the caller must take it
+        outs.append((out, m))
+    assert _same(outs[0][0], outs[1][0]) and _same(outs[0][1], outs[1][1]) and int(outs[1][1].sum()) == 65025
+    rng = np.random.default_rng(3)
+    for t in range(40):
+        x = bytearray(blob)
+        k = int(rng.integers(0, len(x)))
+        x[k] ^= 1 << int(rng.integers(0, 8))
+        if t % 4 == 0:
+            x = x[:max(40, k)]
+        x = bytes(x)
+        g1, g2 = O.decode(x), S.decode(x)    # Lerc1 has no checksum: a flipped payload bit decodes to other pixels in both
+        assert (g1[0] == 0) == (g2[0] == 0), (t, k)
+        if g1[0] == 0:
+            assert _same(g1[1], g2[1]) and _same(g1[2], g2[2]), (t, k)
