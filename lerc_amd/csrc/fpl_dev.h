@@ -34,15 +34,17 @@ void launchFplLevelSamples(const void* units, const FplGeom& g, const FplSpan* s
 void launchFplSymbols(const void* units, const FplGeom& g, const FplLevels& lv, u8* planes /* [unit][nElem] */,
                       u32* histos /* [unit][256] + [8]: bytes per plane that equal their successor; zeroed */, hipStream_t st);
 
+// entropy estimates (fpl_Compression.cpp:85-113) of nHist byte histograms -> out[nHist].  log2Tables holds, for every
+// histogram total t that occurs (total[k], from index at[k] on), log2((double)t / c) for c = 0 .. t as the host's libm
+// gives them (index 0 unused); a histogram whose total has no table yields -1.
+struct FplEntropyTables { u32 nTables; u32 total[4]; u32 at[4]; };
+void launchFplEntropy(const u32* histos, u32 nHist, const double* log2Tables, const FplEntropyTables& tb, i64* out, hipStream_t st);
+
 // PackBits (fpl_EsriHuffman.cpp:79-236) of one byte plane: size, then the stream itself
-struct PackBitsBuffers
-{
-  u32* runStart;     // [n + 4] start of the run of equal bytes a position lies in
-  u32* litStart;     // [n + 4] start of the stretch of literal bytes a position lies in
-  u32* offset;       // [n + 4] stream offset of what a position emits; [n] = stream size
-  u32* scratch;      // [n / 1024 + 8]
-};
+struct PackBitsBuffers { u32 *carry1, *carry2, *carry3; };    // packBitsCarryCount(n) words each
+size_t packBitsCarryCount(u32 n);
 void launchPackBitsPlan(const u8* plane, u32 n, const PackBitsBuffers& b, hipStream_t st);
+const u32* packBitsSize(const PackBitsBuffers& b, u32 n);    // where the stream's size stands after launchPackBitsPlan
 void launchPackBitsEmit(const u8* plane, u32 n, const PackBitsBuffers& b, u8* out, hipStream_t st);
 
 // ---- decode

@@ -91,6 +91,50 @@ FplGeom geomOf(int unit, int nRows, int nCols, int nDepth)
 
 bool waitFor(Context& ctx) { return ctx.sync(); }
 
+// log2((double)total / c), c = 1 .. total, by this host's libm -- the numbers fpl_Compression.cpp:98-104 works with.
+// The sample counts of test blocks and snippets repeat from call to call, so the few tables are kept.
+const std::vector<double>& log2Table(u32 total)
+{
+  static thread_local std::vector<std::pair<u32, std::vector<double> > > kept;
+  for (auto& e : kept) if (e.first == total) return e.second;
+  if (kept.size() >= 8) kept.erase(kept.begin());
+  kept.emplace_back(total, std::vector<double>((size_t)total + 1, 0.0));
+  std::vector<double>& t = kept.back().second;
+  for (u32 c = 1; c <= total; c++) t[c] = log2((double)total / (unsigned long)c);
+  return t;
+}
+
+static const u32 kTableMax = 1u << 16;    // entries over all tables; more (test blocks of > 450 000 elements): the host does the sums
+
+// The entropy estimates of nHist histograms on the device -> pinned host array (valid after the next sync), or nullptr
+// if the sample counts do not fit the tables (then the caller reads the histograms back and uses entropyBytes)
+const i64* enqueueEntropies(Context& ctx, const u32* dHistos, size_t nHist, const std::vector<FplSpan>& spans)
+{
+  hipStream_t st = ctx.activeStream();
+  FplEntropyTables tb;
+  memset(&tb, 0, sizeof(tb));
+  std::vector<double> image;
+  for (const FplSpan& sp : spans)
+  {
+    const u32 total = (u32)((sp.len + kFplPrime - 1) / kFplPrime);
+    bool have = false;
+    for (u32 t = 0; t < tb.nTables; t++) have = have || tb.total[t] == total;
+    if (have || total == 0) continue;
+    if (tb.nTables == 4 || image.size() + total + 1 > kTableMax) return nullptr;
+    const std::vector<double>& t = log2Table(total);
+    tb.total[tb.nTables] = total; tb.at[tb.nTables] = (u32)image.size(); tb.nTables++;
+    image.insert(image.end(), t.begin(), t.end());
+  }
+  double* dTables = ctx.allocT<double>(image.size() + 1);
+  i64* dOut = ctx.allocT<i64>(nHist);
+  i64* hOut = (i64*)ctx.pinned(nHist * sizeof(i64));
+  if (!dTables || !dOut || !hOut) return nullptr;
+  if (!image.empty()) hipMemcpyAsync(dTables, image.data(), image.size() * sizeof(double), hipMemcpyHostToDevice, st);    // (pageable: staged before the call returns)
+  launchFplEntropy(dHistos, (u32)nHist, dTables, tb, dOut, st);
+  hipMemcpyAsync(hOut, dOut, nHist * sizeof(i64), hipMemcpyDeviceToHost, st);
+  return hOut;
+}
+
 }    // namespace
 
 size_t fplEncodeScratchBytes(i64 nElem, int unit)
@@ -98,7 +142,7 @@ size_t fplEncodeScratchBytes(i64 nElem, int unit)
   const size_t n = (size_t)nElem;
   const size_t nSpans = (size_t)sqrt((double)n / 8192 + 2) + 4;
   return n * unit + (size_t)unit * (size_t)fplPlaneStride(nElem)        // units, planes
-    + 3 * (n + 1024) * 4 + (n / 1024 + 64) * 4                              // PackBits tables
+    + 3 * (n / 4096 + 64) * 4 + (1u << 20)                                  // PackBits carries, entropy tables
     + n + n / 8 + (4u << 20)                                                 // Huffman stream + run tables of one plane
     + nSpans * (6 * 8 * 256 * 4 + 8 * kFplLevels * 256 * 4 + 64) + (1u << 20);
 }
@@ -130,22 +174,42 @@ bool planLosslessFloat(Context& ctx, int dt, const void* dData, const u8* dByteM
   u32* dH1 = ctx.allocT<u32>(blocks.size() * h1Len);
   if (!dBlocks || !dH1) return false;
   hipMemcpyAsync(dBlocks, blocks.data(), blocks.size() * sizeof(FplSpan), hipMemcpyHostToDevice, st);
-  { ProfScope ps(ctx, "fpl_predictor_samples"); launchFplPredictorSamples(dData, dByteMask, g, dBlocks, (u32)blocks.size(), dH1, st); }
-  // (histograms come back through the context's pinned mirror: a pageable target costs a staging copy at ~1 GB/s)
-  const u32* h1 = (const u32*)ctx.pinned(blocks.size() * h1Len * 4);
-  if (!h1) return false;
-  hipMemcpyAsync((void*)h1, dH1, blocks.size() * h1Len * 4, hipMemcpyDeviceToHost, st);
-  if (!waitFor(ctx)) return false;
   size_t est[3] = { 0, 0, 0 };
-  for (int p = 0; p < 3; p++)
-    for (size_t blk = 0; blk < blocks.size(); blk++)
-      for (int b = 0; b < U; b++)
-      {
-        const u32* hp = &h1[blk * h1Len + ((size_t)(p * 2 + 0) * U + b) * 256];
-        const u32* hq = &h1[blk * h1Len + ((size_t)(p * 2 + 1) * U + b) * 256];
-        const size_t plain = (size_t)entropyBytes(hp), prime = (size_t)entropyBytes(hq);
-        est[p] += std::min(plain, prime);
-      }
+  {
+    ProfScope ps(ctx, "fpl_predictor_samples");
+    launchFplPredictorSamples(dData, dByteMask, g, dBlocks, (u32)blocks.size(), dH1, st);
+    // histogram index: (block * 6 + predictor * 2 + plain / differenced) * U + byte
+    const i64* ent = enqueueEntropies(ctx, dH1, blocks.size() * 6 * U, blocks);
+    if (ent)
+    {
+      if (!waitFor(ctx)) return false;
+      for (int p = 0; p < 3; p++)
+        for (size_t blk = 0; blk < blocks.size(); blk++)
+          for (int b = 0; b < U; b++)
+          {
+            const i64 plain = ent[(blk * 6 + (size_t)p * 2 + 0) * U + b], prime = ent[(blk * 6 + (size_t)p * 2 + 1) * U + b];
+            if (plain < 0 || prime < 0) { ctx.lastError = "lossless float: entropy table missing"; return false; }
+            est[p] += (size_t)std::min(plain, prime);
+          }
+    }
+    else
+    {
+      // (histograms come back through the context's pinned mirror: a pageable target costs a staging copy at ~1 GB/s)
+      const u32* h1 = (const u32*)ctx.pinned(blocks.size() * h1Len * 4);
+      if (!h1) return false;
+      hipMemcpyAsync((void*)h1, dH1, blocks.size() * h1Len * 4, hipMemcpyDeviceToHost, st);
+      if (!waitFor(ctx)) return false;
+      for (int p = 0; p < 3; p++)
+        for (size_t blk = 0; blk < blocks.size(); blk++)
+          for (int b = 0; b < U; b++)
+          {
+            const u32* hp = &h1[blk * h1Len + ((size_t)(p * 2 + 0) * U + b) * 256];
+            const u32* hq = &h1[blk * h1Len + ((size_t)(p * 2 + 1) * U + b) * 256];
+            const size_t plain = (size_t)entropyBytes(hp), prime = (size_t)entropyBytes(hq);
+            est[p] += std::min(plain, prime);
+          }
+    }
+  }
   int predictor = 0;
   for (int p = 1; p < 3; p++) if (est[p] < est[predictor]) predictor = p;
   plan.predictor = predictor;
@@ -166,10 +230,17 @@ bool planLosslessFloat(Context& ctx, int dt, const void* dData, const u8* dByteM
     u32* dH2 = ctx.allocT<u32>((size_t)U * snips.size() * h2Len);
     if (!dSnips || !dH2) return false;
     hipMemcpyAsync(dSnips, snips.data(), snips.size() * sizeof(FplSpan), hipMemcpyHostToDevice, st);
-    { ProfScope ps(ctx, "fpl_level_samples"); launchFplLevelSamples(dUnits, g, dSnips, (u32)snips.size(), dH2, st); }
-    const u32* h2 = (const u32*)ctx.pinned((size_t)U * snips.size() * h2Len * 4);
-    if (!h2) return false;
-    hipMemcpyAsync((void*)h2, dH2, (size_t)U * snips.size() * h2Len * 4, hipMemcpyDeviceToHost, st);
+    ProfScope ps(ctx, "fpl_level_samples");
+    launchFplLevelSamples(dUnits, g, dSnips, (u32)snips.size(), dH2, st);
+    // histogram index: (byte * snippets + snippet) * levels + level
+    const i64* ent = enqueueEntropies(ctx, dH2, (size_t)U * snips.size() * kFplLevels, snips);
+    const u32* h2 = nullptr;
+    if (!ent)
+    {
+      h2 = (const u32*)ctx.pinned((size_t)U * snips.size() * h2Len * 4);
+      if (!h2) return false;
+      hipMemcpyAsync((void*)h2, dH2, (size_t)U * snips.size() * h2Len * 4, hipMemcpyDeviceToHost, st);
+    }
     if (!waitFor(ctx)) return false;
     for (int b = 0; b < U; b++)
     {
@@ -178,7 +249,12 @@ bool planLosslessFloat(Context& ctx, int dt, const void* dData, const u8* dByteM
       for (int l = 0; l <= maxDelta; l++)
       {
         size_t comp = 0;
-        for (size_t s = 0; s < snips.size(); s++) comp += (size_t)entropyBytes(&h2[(((size_t)b * snips.size() + s) * kFplLevels + l) * 256]);
+        for (size_t s = 0; s < snips.size(); s++)
+        {
+          const size_t hi = ((size_t)b * snips.size() + s) * kFplLevels + l;
+          if (ent && ent[hi] < 0) { ctx.lastError = "lossless float: entropy table missing"; return false; }
+          comp += ent ? (size_t)ent[hi] : (size_t)entropyBytes(&h2[hi * 256]);
+        }
         if (comp < best || l == 0) { best = comp; ret = l; }
         else break;
       }
@@ -224,18 +300,17 @@ bool planLosslessFloat(Context& ctx, int dt, const void* dData, const u8* dByteM
   {
     const size_t mark = ctx.used();
     PackBitsBuffers pb;
-    pb.runStart = ctx.allocT<u32>((size_t)n + 4);
-    pb.litStart = ctx.allocT<u32>((size_t)n + 4);
-    pb.offset = ctx.allocT<u32>((size_t)n + 4);
-    pb.scratch = ctx.allocT<u32>((size_t)n / 1024 + 8);
+    pb.carry1 = ctx.allocT<u32>(packBitsCarryCount(n));
+    pb.carry2 = ctx.allocT<u32>(packBitsCarryCount(n));
+    pb.carry3 = ctx.allocT<u32>(packBitsCarryCount(n));
     u32* dPbSize = dH3 + (size_t)U * 256 + 8;
-    if (!pb.runStart || !pb.litStart || !pb.offset || !pb.scratch) return false;
+    if (!pb.carry1 || !pb.carry2 || !pb.carry3) return false;
     for (int b = 0; b < U; b++)
     {
       if (!needPackBits[b]) continue;
       ProfScope ps(ctx, "fpl_packbits_size");
       launchPackBitsPlan(plan.dPlanes + (size_t)b * stride, n, pb, st);
-      hipMemcpyAsync(dPbSize + b, pb.offset + n, 4, hipMemcpyDeviceToDevice, st);
+      hipMemcpyAsync(dPbSize + b, packBitsSize(pb, n), 4, hipMemcpyDeviceToDevice, st);
     }
     u32* pin = (u32*)ctx.pinned(64);
     if (!pin) return false;
@@ -306,11 +381,10 @@ bool emitLosslessFloat(Context& ctx, const FplPlan& plan, u8* dOut)
     else if (pp.mode == 3)
     {
       PackBitsBuffers pb;
-      pb.runStart = ctx.allocT<u32>((size_t)n + 4);
-      pb.litStart = ctx.allocT<u32>((size_t)n + 4);
-      pb.offset = ctx.allocT<u32>((size_t)n + 4);
-      pb.scratch = ctx.allocT<u32>((size_t)n / 1024 + 8);
-      if (!pb.runStart || !pb.litStart || !pb.offset || !pb.scratch) return false;
+      pb.carry1 = ctx.allocT<u32>(packBitsCarryCount(n));
+      pb.carry2 = ctx.allocT<u32>(packBitsCarryCount(n));
+      pb.carry3 = ctx.allocT<u32>(packBitsCarryCount(n));
+      if (!pb.carry1 || !pb.carry2 || !pb.carry3) return false;
       ProfScope ps(ctx, "fpl_packbits_emit");
       launchPackBitsPlan(dPlane, n, pb, st);
       launchPackBitsEmit(dPlane, n, pb, dst, st);

@@ -130,6 +130,54 @@ k_fpl_predict(const void* __restrict__ data, const u8* __restrict__ byteMask, Fp
   units[e] = (predictor == 0) ? v[0] : (predictor == 1 ? v[1] : v[2]);    // (no indexed access: that would put v[] in scratch)
 }
 
+// four elements of one row per thread, for rasters whose rows are whole quads (cols % 4 == 0, base 16-byte aligned)
+template<int U> struct alignas(16) Quad { typename UnitOf<U>::T v[4]; };
+
+template<int U>
+__global__ void __launch_bounds__(256)
+k_fpl_predict_quads(const void* __restrict__ data, const u8* __restrict__ byteMask, FplGeom g, int predictor,
+                    typename UnitOf<U>::T* __restrict__ units)
+{
+  typedef typename UnitOf<U>::T T;
+  const i64 e0 = ((i64)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e0 >= g.nElem) return;
+  const u32 r = (u32)e0 / (u32)g.cols, c = (u32)e0 - r * (u32)g.cols;
+  T cur[5], out[4];    // cur[k] = element e0 - 1 + k
+  {
+    const Quad<U> q = *reinterpret_cast<const Quad<U>*>((const T*)data + e0);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      T x = q.v[k];
+      if (g.nanToZero && isNaNBits(x) && (!byteMask || byteMask[e0 + k])) x = 0;
+      cur[k + 1] = fplForward(x);
+    }
+    cur[0] = (c >= 1u) ? loadUnit<U>(data, byteMask, g, e0 - 1) : (T)0;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) out[k] = (predictor == 0 || c + k == 0u) ? cur[k + 1] : fplSub(cur[k + 1], cur[k]);
+  if (predictor == 2 && r >= 1u)
+  {
+    T abv[5];
+    const i64 a0 = e0 - g.cols;
+    const Quad<U> q = *reinterpret_cast<const Quad<U>*>((const T*)data + a0);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      T x = q.v[k];
+      if (g.nanToZero && isNaNBits(x) && (!byteMask || byteMask[a0 + k])) x = 0;
+      abv[k + 1] = fplForward(x);
+    }
+    abv[0] = (c >= 1u) ? loadUnit<U>(data, byteMask, g, a0 - 1) : (T)0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = fplSub(out[k], (c + k == 0u) ? abv[k + 1] : fplSub(abv[k + 1], abv[k]));
+  }
+  Quad<U> o;
+#pragma unroll
+  for (int k = 0; k < 4; k++) o.v[k] = out[k];
+  *reinterpret_cast<Quad<U>*>(units + e0) = o;
+}
+
 // ------------------------------------------------------------------------------------------------
 // which extra difference order per byte plane: histograms over the reference's snippets (:237-322)
 // ------------------------------------------------------------------------------------------------
@@ -161,8 +209,41 @@ k_fpl_level_samples(const typename UnitOf<U>::T* __restrict__ units, FplGeom g, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// entropy estimate of a byte histogram (fpl_Compression.cpp:85-113): sum over the bins, in bin order, of
+// log2(total / count) * count in double precision, then (long)((bits + 7) / 8).  The logarithms come out of a table
+// the host made with its libm (one per histogram total: the totals are sample counts the host knows), products and
+// the running sum are IEEE operations in the reference's order (this file is compiled with -ffp-contract=off), so the
+// numbers are the reference's.  One wave per histogram; adding the 0.0 of an empty bin changes nothing.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_fpl_entropy(const u32* __restrict__ histos, u32 nHist, const double* __restrict__ tables, FplEntropyTables tb, i64* __restrict__ out)
+{
+  __shared__ double s_term[4][256];
+  const int w = waveId(), lane = laneId();
+  const u32 h = blockIdx.x * 4u + (u32)w;
+  const bool live = h < nHist;
+  u32 c[4] = { 0, 0, 0, 0 }, total = 0;
+  if (live)
+    for (int k = 0; k < 4; k++) { c[k] = histos[(size_t)h * 256 + lane + 64 * k]; total += c[k]; }
+  for (int d = 1; d < 64; d <<= 1) total += __shfl_xor(total, d);
+  i64 at = -1;
+  for (u32 t = 0; t < tb.nTables; t++) if (tb.total[t] == total) at = (i64)tb.at[t];
+  for (int k = 0; k < 4; k++)
+    s_term[w][lane + 64 * k] = (c[k] != 0u && at >= 0) ? tables[at + c[k]] * (double)c[k] : 0.0;
+  __syncthreads();
+  if (live && lane == 0)
+  {
+    double bits = 0;
+    for (int i = 0; i < 256; i++) bits += s_term[w][i];
+    out[h] = (total != 0u && at < 0) ? (i64)-1 : (i64)((bits + 7) / 8);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // the byte planes as they are entropy coded (:557-567 + setDerivative), and their histograms
 // ------------------------------------------------------------------------------------------------
+static const int kFplSymbolTiles = 16;    // tiles of 1024 elements per workgroup: 16 times fewer histogram flushes
+
 template<int U>
 __global__ void __launch_bounds__(256)
 k_fpl_symbols(const typename UnitOf<U>::T* __restrict__ units, FplGeom g, FplLevels lv, i64 planeStride, u8* __restrict__ planes,
@@ -172,8 +253,12 @@ k_fpl_symbols(const typename UnitOf<U>::T* __restrict__ units, FplGeom g, FplLev
   __shared__ u32 s_h[U * 256 + 8];    // histograms, then per plane: how many bytes equal their successor
   for (int i = threadIdx.x; i < U * 256 + 8; i += 256) s_h[i] = 0;
   __syncthreads();
-  const i64 i0 = ((i64)blockIdx.x * 256 + threadIdx.x) * 4;
-  {    // (threads behind the last element run along with nothing to count: the ballots below want whole waves)
+  const int lane = laneId();
+  for (int tile = 0; tile < kFplSymbolTiles; tile++)
+  {
+    const i64 i0 = (((i64)blockIdx.x * kFplSymbolTiles + tile) * 256 + threadIdx.x) * 4;
+    if (i0 - 4 * (i64)threadIdx.x >= g.nElem) break;    // (whole workgroup)
+    // (threads behind the last element run along with nothing to count: the ballots below want whole waves)
     T p[10];    // p[5 + k] = element i0 + k  (all loops below unroll: p[] and x[] stay in registers)
 #pragma unroll
     for (int k = -5; k < 5; k++) p[5 + k] = (i0 + k >= 0 && i0 + k < g.nElem) ? units[i0 + k] : (T)0;
@@ -194,15 +279,24 @@ k_fpl_symbols(const typename UnitOf<U>::T* __restrict__ units, FplGeom g, FplLev
         if (in && k > 0 && s == prev) equal++;
         prev = s;
         if (in && k < 4) word |= s << (8 * k);
-        // histogram: the high planes hold one or two values almost everywhere -- when the whole wave agrees, one add
-        const bool count = in && k < 4;
-        const u64 voters = __ballot(count);
-        const u32 s0 = __shfl(s, voters ? __ffsll((long long)voters) - 1 : 0);
-        const bool same = __ballot(count && s == s0) == voters;
-        if (same) { if (voters && laneId() == __ffsll((long long)voters) - 1) atomicAdd(&s_h[b * 256 + s0], (u32)__popcll(voters)); }
-        else if (count) atomicAdd(&s_h[b * 256 + s], 1u);
+        // histogram.  The high planes hold a few values almost everywhere, and 64 lanes adding to one LDS word take 64
+        // turns: lanes that agree are counted by ballot and added once, as long as the groups are big
+        bool mine = in && k < 4;
+        u64 rest = __ballot(mine);
+        for (int round = 0; round < 4 && rest; round++)
+        {
+          const int leader = __ffsll((long long)rest) - 1;
+          const u32 sL = __shfl(s, leader);
+          const u64 m = __ballot(mine && s == sL);
+          if (__popcll(m) < 6) break;
+          if (lane == leader) atomicAdd(&s_h[b * 256 + sL], (u32)__popcll(m));
+          if (s == sL) mine = false;
+          rest &= ~m;
+        }
+        if (mine) atomicAdd(&s_h[b * 256 + s], 1u);
       }
-      if (equal) atomicAdd(&s_h[U * 256 + b], equal);
+      equal = waveSum(equal);
+      if (lane == 0 && equal) atomicAdd(&s_h[U * 256 + b], equal);
       u8* dst = planes + (size_t)b * planeStride + i0;    // planeStride is a multiple of 16
       if (i0 + 3 < g.nElem) *reinterpret_cast<u32*>(dst) = word;
       else for (int k = 0; k < 4 && i0 + k < g.nElem; k++) dst[k] = (u8)(word >> (8 * k));
@@ -253,18 +347,23 @@ __global__ void __launch_bounds__(256) k_gscan_local(T* __restrict__ data, u32 n
 }
 
 template<class T, class Op>
-__global__ void __launch_bounds__(256) k_gscan_partials(T* __restrict__ partial, u32 nPart)
+__global__ void __launch_bounds__(256) k_gscan_partials(T* __restrict__ partial, u32 nPart)    // -> exclusive, one workgroup
 {
   __shared__ u32 s_wave[4];
   const Op op;
   u32 carry = 0;
-  for (u32 base = 0; base < nPart; base += 256u)
+  for (u32 base = 0; base < nPart; base += 4096u)
   {
-    const u32 i = base + threadIdx.x;
-    const u32 v = (i < nPart) ? (u32)partial[i] : 0u;
+    const u32 i0 = base + threadIdx.x * 16u;
+    u32 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = (i0 + k < nPart) ? (u32)partial[i0 + k] : 0u;
+#pragma unroll
+    for (int k = 1; k < 16; k++) v[k] = (u32)(T)op(v[k - 1], v[k]);
     u32 total;
-    const u32 before = workgroupExclusive<u32, Op>(v, op, s_wave, total);
-    if (i < nPart) partial[i] = (T)op(carry, before);
+    const u32 before = (u32)(T)op(carry, workgroupExclusive<u32, Op>(v[15], op, s_wave, total));
+#pragma unroll
+    for (int k = 0; k < 16; k++) if (i0 + k < nPart) partial[i0 + k] = (k == 0) ? (T)before : (T)op(before, v[k - 1]);
     carry = (u32)(T)op(carry, total);
   }
 }
@@ -295,72 +394,129 @@ void inclusiveScan(T* data, u32 n, T* scratch, hipStream_t st)
 // a literal; literals that touch are grouped by 128 behind a count byte.  Everything a position emits therefore
 // follows from where its run starts and where its stretch of literals starts -- two max-scans -- and the stream
 // offsets are a sum-scan.
+// Nothing per position is stored: a workgroup takes 4096 bytes (16 per thread) and recomputes what it needs from the
+// bytes and three carries per workgroup -- pass 1 finds where the last run begins, pass 2 (with the run carries) where
+// the last stretch of literals begins, pass 3 (with both) the bytes emitted; pass 4 writes the stream.  The plane is
+// read four times (67 MB each for 8192^2) instead of 5 GB of u32 tables moved.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool pbRunEnd(const u8* __restrict__ s, u32 n, u32 i) { return i + 1u >= n || s[i] != s[i + 1u]; }
-__device__ __forceinline__ bool pbLiteral(const u8* __restrict__ s, u32 n, const u32* __restrict__ runStart, u32 i)
-{
-  return pbRunEnd(s, n, i) && ((i - runStart[i] + 1u) % 129u) == 1u;
-}
+static const u32 kPbChunk = 4096;
 
-__global__ void __launch_bounds__(256) k_pb_run_start(const u8* __restrict__ s, u32 n, u32* __restrict__ runStart)
+template<class Op>
+__global__ void __launch_bounds__(256) k_pb_carries(u32* __restrict__ partial, u32 nPart)    // exclusive scan in place, total behind
 {
-  const u32 i = blockIdx.x * 256u + threadIdx.x;
-  if (i < n) runStart[i] = (i > 0 && s[i] != s[i - 1u]) ? i : 0u;
-}
-
-__global__ void __launch_bounds__(256) k_pb_lit_start(const u8* __restrict__ s, u32 n, const u32* __restrict__ runStart, u32* __restrict__ litStart)
-{
-  const u32 i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const bool lit = pbLiteral(s, n, runStart, i);
-  litStart[i] = (lit && i > 0 && !pbLiteral(s, n, runStart, i - 1u)) ? i : 0u;
-}
-
-__device__ __forceinline__ u32 pbCost(const u8* __restrict__ s, u32 n, const u32* __restrict__ runStart, const u32* __restrict__ litStart, u32 i)
-{
-  const u32 len = i - runStart[i] + 1u, rem = len % 129u;
-  u32 c = (rem == 0u) ? 2u : 0u;
-  if (pbRunEnd(s, n, i))
+  __shared__ u32 s_wave[4];
+  const Op op;
+  u32 carry = 0;
+  for (u32 base = 0; base < nPart; base += 1024u)
   {
-    if (rem >= 2u) c += 2u;
-    if (rem == 1u) c += 1u + (((i - litStart[i]) % 128u) == 0u ? 1u : 0u);
+    const u32 i0 = base + threadIdx.x * 4u;
+    u32 v[4], inc[4];
+    for (int k = 0; k < 4; k++) v[k] = (i0 + k < nPart) ? partial[i0 + k] : 0u;
+    inc[0] = v[0];
+    for (int k = 1; k < 4; k++) inc[k] = op(inc[k - 1], v[k]);
+    u32 total;
+    const u32 before = op(carry, workgroupExclusive<u32, Op>(inc[3], op, s_wave, total));
+    for (int k = 0; k < 4; k++) if (i0 + k < nPart) partial[i0 + k] = (k == 0) ? before : op(before, inc[k - 1]);
+    carry = op(carry, total);
   }
-  return c;
+  if (threadIdx.x == 0) partial[nPart] = carry;
 }
 
-__global__ void __launch_bounds__(256) k_pb_cost(const u8* __restrict__ s, u32 n, const u32* __restrict__ runStart,
-                                                 const u32* __restrict__ litStart, u32* __restrict__ offset)
+// PASS 1: carry1[wg] = start of the last run that begins in this chunk (0: none);  PASS 2: carry2[wg] = start of the last
+// stretch of literals that begins in it;  PASS 3: carry3[wg] = bytes it emits;  PASS 4: the stream.  Passes > 1 read the
+// carries of the passes before, scanned (exclusive) by k_pb_carries.
+template<int PASS>
+__global__ void __launch_bounds__(256) k_pb_pass(const u8* __restrict__ s, u32 n, u32* __restrict__ carry1, u32* __restrict__ carry2,
+                                                 u32* __restrict__ carry3, u8* __restrict__ out)
 {
-  const u32 i = blockIdx.x * 256u + threadIdx.x;
-  if (i < n) offset[i] = pbCost(s, n, runStart, litStart, i);
-}
-
-__global__ void __launch_bounds__(256) k_pb_total(u32* __restrict__ offset, u32 n) { if (threadIdx.x == 0 && blockIdx.x == 0) offset[n] = offset[n - 1u]; }
-
-__global__ void __launch_bounds__(256) k_pb_emit(const u8* __restrict__ s, u32 n, const u32* __restrict__ runStart,
-                                                 const u32* __restrict__ litStart, const u32* __restrict__ offset, u8* __restrict__ out)
-{
-  const u32 i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  u32 at = (i > 0) ? offset[i - 1u] : 0u;    // offset[] holds the inclusive sums
-  const u32 len = i - runStart[i] + 1u, rem = len % 129u;
-  const u8 v = s[i];
-  if (rem == 0u) { out[at] = 255; out[at + 1u] = v; return; }    // 127 + 128 repeats
-  if (!pbRunEnd(s, n, i)) return;
-  if (rem >= 2u) { out[at] = (u8)(126u + rem); out[at + 1u] = v; return; }
-  const u32 first = litStart[i];
-  if (((i - first) % 128u) == 0u)
+  __shared__ u32 s_wave[4];
+  const u32 i0 = blockIdx.x * kPbChunk + threadIdx.x * 16u;
+  // b[k] = byte i0 + k, k = 0 .. 17; 256: behind the plane's end (differs from every byte); prev = byte i0 - 1
+  u32 b[18], prev = 256u;
+  if (i0 + 16u <= n && (((size_t)s) & 15u) == 0u)
   {
-    // count byte of this group of literals: 128, or what is left of the stretch
-    u32 cnt = 128u;
-    if (!(i + 127u < n && pbLiteral(s, n, runStart, i + 127u) && litStart[i + 127u] == first))
+    const uint4 q = *reinterpret_cast<const uint4*>(s + i0);
+    const u32 w[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+    for (int k = 0; k < 16; k++) b[k] = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+  }
+  else
+  {
+#pragma unroll
+    for (int k = 0; k < 16; k++) b[k] = (i0 + k < n) ? (u32)s[i0 + k] : 256u;
+  }
+  b[16] = (i0 + 16u < n) ? (u32)s[i0 + 16u] : 256u;
+  b[17] = (i0 + 17u < n) ? (u32)s[i0 + 17u] : 256u;
+  if (i0 > 0u && i0 < n) prev = s[i0 - 1u];
+
+  // where the run a position lies in starts
+  u32 local = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) if (i0 + k < n && b[k] != (k ? b[k - 1] : prev)) local = i0 + k;
+  u32 total;
+  u32 runBefore = workgroupExclusive<u32, ScanMax>(local, ScanMax(), s_wave, total);    // = run start of position i0 - 1
+  if (PASS == 1) { if (threadIdx.x == 0) carry1[blockIdx.x] = total; return; }
+  runBefore = max(runBefore, carry1[blockIdx.x]);
+  u32 rem[16];    // (length of the run up to and including the position) mod 129
+  {
+    u32 rs = runBefore;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
     {
-      cnt = 1u;
-      while (cnt < 128u && i + cnt < n && pbLiteral(s, n, runStart, i + cnt)) cnt++;
+      if (b[k] != (k ? b[k - 1] : prev)) rs = i0 + k;
+      rem[k] = (i0 + k - rs + 1u) % 129u;
     }
-    out[at++] = (u8)(cnt - 1u);
   }
-  out[at] = v;
+  // literal: a run's last byte that is left over after the tokens of 129;  where the stretch of literals it lies in starts
+  u32 litMask = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) if (i0 + k < n && b[k] != b[k + 1] && rem[k] == 1u) litMask |= 1u << k;
+  const bool litPrev = i0 > 0u && i0 < n && prev != b[0] && ((i0 - runBefore) % 129u) == 1u;
+  local = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+    if (((litMask >> k) & 1u) && i0 + k > 0u && !(k ? ((litMask >> (k - 1)) & 1u) != 0u : litPrev)) local = i0 + k;
+  u32 litBefore = workgroupExclusive<u32, ScanMax>(local, ScanMax(), s_wave, total);
+  if (PASS == 2) { if (threadIdx.x == 0) carry2[blockIdx.x] = total; return; }
+  litBefore = max(litBefore, carry2[blockIdx.x]);
+  u32 inGroup[16];    // literals: place in their group of 128
+  {
+    u32 ls = litBefore;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+    {
+      const bool lit = (litMask >> k) & 1u;
+      if (lit && i0 + k > 0u && !(k ? ((litMask >> (k - 1)) & 1u) != 0u : litPrev)) ls = i0 + k;
+      inGroup[k] = lit ? (i0 + k - ls) % 128u : 0u;
+    }
+  }
+  // bytes emitted
+  u32 cost = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+  {
+    if (i0 + k >= n) continue;
+    if (rem[k] == 0u) cost += 2u;
+    else if (b[k] != b[k + 1]) cost += (rem[k] >= 2u) ? 2u : (inGroup[k] == 0u ? 2u : 1u);
+  }
+  u32 at = workgroupExclusive<u32, ScanSum>(cost, ScanSum(), s_wave, total);
+  if (PASS == 3) { if (threadIdx.x == 0) carry3[blockIdx.x] = total; return; }
+  at += carry3[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+  {
+    if (i0 + k >= n) continue;
+    const u8 v = (u8)b[k];
+    if (rem[k] == 0u) { out[at] = 255; out[at + 1u] = v; at += 2u; continue; }    // 127 + 128 repeats
+    if (b[k] == b[k + 1]) continue;
+    if (rem[k] >= 2u) { out[at] = (u8)(126u + rem[k]); out[at + 1u] = v; at += 2u; continue; }
+    // a literal; the group's count byte sits in front of the group's first literal and is written by its last one
+    const u32 pos = at + (inGroup[k] == 0u ? 1u : 0u);
+    out[pos] = v;
+    at = pos + 1u;
+    const bool nextIsLiteral = i0 + k + 1u < n && b[k + 1] != b[k + 2];    // (it begins a run: length 1)
+    if (inGroup[k] == 127u || !nextIsLiteral) out[pos - inGroup[k] - 1u] = (u8)inGroup[k];
+  }
 }
 
 // decode.  Where a token starts depends on every token before it, but a token is at most 129 bytes long: the first
@@ -586,6 +742,13 @@ void launchFplPredictorSamples(const void* data, const u8* byteMask, const FplGe
 
 void launchFplPredict(const void* data, const u8* byteMask, const FplGeom& g, int predictor, void* units, hipStream_t st)
 {
+  if (g.cols % 4 == 0 && (((size_t)data | (size_t)units) & 15u) == 0)
+  {
+    const dim3 grid(gridFor(g.nElem, 1024));
+    if (g.unit == 4) hipLaunchKernelGGL(k_fpl_predict_quads<4>, grid, dim3(256), 0, st, data, byteMask, g, predictor, (u32*)units);
+    else hipLaunchKernelGGL(k_fpl_predict_quads<8>, grid, dim3(256), 0, st, data, byteMask, g, predictor, (u64*)units);
+    return;
+  }
   const dim3 grid(gridFor(g.nElem, 256));
   if (g.unit == 4) hipLaunchKernelGGL(k_fpl_predict<4>, grid, dim3(256), 0, st, data, byteMask, g, predictor, (u32*)units);
   else hipLaunchKernelGGL(k_fpl_predict<8>, grid, dim3(256), 0, st, data, byteMask, g, predictor, (u64*)units);
@@ -601,28 +764,36 @@ void launchFplLevelSamples(const void* units, const FplGeom& g, const FplSpan* s
 
 void launchFplSymbols(const void* units, const FplGeom& g, const FplLevels& lv, u8* planes, u32* histos, hipStream_t st)
 {
-  const dim3 grid(gridFor(g.nElem, 1024));
+  const dim3 grid(gridFor(g.nElem, 1024 * kFplSymbolTiles));
   const i64 stride = fplPlaneStride(g.nElem);
   if (g.unit == 4) hipLaunchKernelGGL(k_fpl_symbols<4>, grid, dim3(256), 0, st, (const u32*)units, g, lv, stride, planes, histos);
   else hipLaunchKernelGGL(k_fpl_symbols<8>, grid, dim3(256), 0, st, (const u64*)units, g, lv, stride, planes, histos);
 }
 
+size_t packBitsCarryCount(u32 n) { return (size_t)(n + kPbChunk - 1u) / kPbChunk + 8; }
+
 void launchPackBitsPlan(const u8* plane, u32 n, const PackBitsBuffers& b, hipStream_t st)
 {
-  const dim3 grid((n + 255u) / 256u), block(256);
-  hipLaunchKernelGGL(k_pb_run_start, grid, block, 0, st, plane, n, b.runStart);
-  inclusiveScan<u32, ScanMax>(b.runStart, n, b.scratch, st);
-  hipLaunchKernelGGL(k_pb_lit_start, grid, block, 0, st, plane, n, (const u32*)b.runStart, b.litStart);
-  inclusiveScan<u32, ScanMax>(b.litStart, n, b.scratch, st);
-  hipLaunchKernelGGL(k_pb_cost, grid, block, 0, st, plane, n, (const u32*)b.runStart, (const u32*)b.litStart, b.offset);
-  inclusiveScan<u32, ScanSum>(b.offset, n, b.scratch, st);
-  hipLaunchKernelGGL(k_pb_total, dim3(1), dim3(64), 0, st, b.offset, n);
+  const u32 nWG = (n + kPbChunk - 1u) / kPbChunk;
+  const dim3 grid(nWG), block(256);
+  hipLaunchKernelGGL(k_pb_pass<1>, grid, block, 0, st, plane, n, b.carry1, b.carry2, b.carry3, (u8*)nullptr);
+  hipLaunchKernelGGL(k_pb_carries<ScanMax>, dim3(1), block, 0, st, b.carry1, nWG);
+  hipLaunchKernelGGL(k_pb_pass<2>, grid, block, 0, st, plane, n, b.carry1, b.carry2, b.carry3, (u8*)nullptr);
+  hipLaunchKernelGGL(k_pb_carries<ScanMax>, dim3(1), block, 0, st, b.carry2, nWG);
+  hipLaunchKernelGGL(k_pb_pass<3>, grid, block, 0, st, plane, n, b.carry1, b.carry2, b.carry3, (u8*)nullptr);
+  hipLaunchKernelGGL(k_pb_carries<ScanSum>, dim3(1), block, 0, st, b.carry3, nWG);
 }
+
+const u32* packBitsSize(const PackBitsBuffers& b, u32 n) { return b.carry3 + (n + kPbChunk - 1u) / kPbChunk; }
 
 void launchPackBitsEmit(const u8* plane, u32 n, const PackBitsBuffers& b, u8* out, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_pb_emit, dim3((n + 255u) / 256u), dim3(256), 0, st, plane, n, (const u32*)b.runStart, (const u32*)b.litStart,
-                     (const u32*)b.offset, out);
+  hipLaunchKernelGGL(k_pb_pass<4>, dim3((n + kPbChunk - 1u) / kPbChunk), dim3(256), 0, st, plane, n, b.carry1, b.carry2, b.carry3, out);
+}
+
+void launchFplEntropy(const u32* histos, u32 nHist, const double* log2Tables, const FplEntropyTables& tb, i64* out, hipStream_t st)
+{
+  if (nHist) hipLaunchKernelGGL(k_fpl_entropy, dim3((nHist + 3u) / 4u), dim3(256), 0, st, histos, nHist, log2Tables, tb, out);
 }
 
 size_t packBitsDecodeScratchBytes(u32 n)
