@@ -215,7 +215,6 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   const u8* dData = (const u8*)rq.dData + (size_t)iBand * nElem * tb;
   const u8* dByteMask = (rq.nMasks > 0) ? rq.dValidBytes + ((rq.nMasks > 1) ? (size_t)iBand * nPix : 0) : nullptr;
   bandBytes = 0;
-  if (nD > kStatsMaxDepth) { ctx.lastError = "nDepth above the device statistics limit"; return kFailed; }
   // a noData value: the band is filtered into a private copy first (pixels that are noData throughout leave the
   // mask, the value may move below the data range), and the decisions below come from that filter
   NoDataDecision nd;

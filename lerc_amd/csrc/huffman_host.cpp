@@ -423,8 +423,11 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
     if (!dCounts || !dBase || !dScr) { delete hTab; return kFailed; }
     launchMaskGroupCounts(dMaskBits, nPix, dCounts, st);
     launchExclusiveScan(dCounts, dBase, (u32)nGroups, dScr, st);
-    hipMemcpyAsync(&numValid, dBase + nGroups, 4, hipMemcpyDeviceToHost, st);
-    if (hipStreamSynchronize(st) != hipSuccess) { delete hTab; return kFailed; }
+    u32* pin = (u32*)ctx.pinned(64);
+    if (!pin) { delete hTab; return kFailed; }
+    hipMemcpyAsync(pin, dBase + nGroups, 4, hipMemcpyDeviceToHost, st);
+    if (!ctx.sync()) { delete hTab; return kFailed; }
+    numValid = pin[0];
     dValidIdx = ctx.allocT<u32>((size_t)numValid + 4);
     if (!dValidIdx) { delete hTab; return kFailed; }
     launchValidIndex(dMaskBits, dBase, nPix, dValidIdx, st);
@@ -445,33 +448,42 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
   hipMemcpyAsync(dStream, dBlob + streamBegin, (size_t)nWords * 4, hipMemcpyDeviceToDevice, st);    // word aligned copy
   hipMemsetAsync(dFlags, 0, 16, st);
   launchHuffInitStarts(dStarts, dPrev, nSub, st);
-  hipStreamSynchronize(st);
-  delete hTab;
 
-  // ---- synchronise the sub-sequence starts (speculative decode until the chain of exits is stable)
-  u32 flags[4] = { 0, 0, 0, 0 };
+  // ---- synchronise the sub-sequence starts (speculative decode until the chain of exits is stable); the symbol counts
+  // are summed right behind every round, so that the usual single round costs one wait
+  u32* pin = (u32*)ctx.pinned(64);    // [0] chain changed, [1] bad code seen, [2..3] symbols in the stream
+  if (!pin) { delete hTab; return kFailed; }
   const int kMaxRounds = 4096;
   int round = 0;
+  u64 total = 0;
   for (; round < kMaxRounds; round++)
   {
-    ProfScope ps(ctx, "huff_sync");
-    hipMemsetAsync(dFlags, 0, 4, st);
-    launchHuffSync(dStream, nWords, streamBits, dTab, nSub, dStarts, dPrev, dExits, dCounts, dFlags + 1, st);
-    launchHuffChain(nSub, dStarts, dExits, dFlags, st);
-    hipMemcpyAsync(flags, dFlags, 8, hipMemcpyDeviceToHost, st);
-    if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
-    if (!flags[0]) break;
+    { ProfScope ps(ctx, "huff_sync");
+      hipMemsetAsync(dFlags, 0, 4, st);
+      launchHuffSync(dStream, nWords, streamBits, dTab, nSub, dStarts, dPrev, dExits, dCounts, dFlags + 1, round == 0, st);
+      launchHuffChain(nSub, dStarts, dExits, dFlags, st); }
+    { ProfScope ps(ctx, "huff_scan"); launchScan64(dCounts, dSymBase, nSub, dScr64, st); }
+    hipMemcpyAsync(pin, dFlags, 8, hipMemcpyDeviceToHost, st);
+    hipMemcpyAsync(pin + 2, dSymBase + nSub, 8, hipMemcpyDeviceToHost, st);
+    const bool ok = ctx.sync();
+    if (hTab) { delete hTab; hTab = nullptr; }    // (the table's upload has certainly happened now)
+    if (!ok) return kFailed;
+    memcpy(&total, pin + 2, 8);
+    if (!pin[0]) break;
   }
   if (round == kMaxRounds) { ctx.lastError = "Huffman stream did not synchronise"; return kFailed; }
-
-  { ProfScope ps(ctx, "huff_scan"); launchScan64(dCounts, dSymBase, nSub, dScr64, st); }
-  u64 total = 0;
-  hipMemcpyAsync(&total, dSymBase + nSub, 8, hipMemcpyDeviceToHost, st);
-  if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
   if (total < nSymbols) { ctx.lastError = "Huffman stream holds fewer symbols than pixels"; return kFailed; }
 
   if (dMaskBits) hipMemsetAsync(dOut, 0, (size_t)nPix * nDepth, st);    // invalid pixels stay 0
-  { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, nWords, streamBits, dTab, nSub, dStarts, dSymBase, g, imageMode, nSymbols, numValid, dValidIdx, dOut, st); }
+  if (huffPlanarDecode(imageMode, dMaskBits, nDepth))
+  {
+    u8* dPlanar = ctx.allocT<u8>((size_t)nSymbols + 16);
+    if (!dPlanar) return kFailed;
+    { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, nWords, streamBits, dTab, nSub, dStarts, dSymBase, g, imageMode, nSymbols, numValid, nullptr, true, dPlanar, st); }
+    { ProfScope ps(ctx, "huff_undelta"); launchHuffUndeltaPlanar(dPlanar, dOut, g, st); }
+    return kOk;
+  }
+  { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, nWords, streamBits, dTab, nSub, dStarts, dSymBase, g, imageMode, nSymbols, numValid, dValidIdx, false, dOut, st); }
   if (imageMode == IEM_DeltaHuffman) { ProfScope ps(ctx, "huff_undelta"); launchHuffUndelta(dt, dOut, dMaskBits, g, st); }
   return kOk;
 }

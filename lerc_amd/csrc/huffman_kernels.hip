@@ -321,39 +321,71 @@ __device__ __forceinline__ u32 peek32(const u32* __restrict__ stream, u64 nWords
 }
 
 // The decoders run one thread per sub-sequence; read straight from global memory every lane would sit in a cache line
-// of its own.  A workgroup of kHuffDecThreads threads therefore stages its slice of the stream (its sub-sequences + 2
-// words of the next) in LDS with coalesced loads, word w of sub-sequence t at [w][t] (rows one word longer than the
+// of its own.  A workgroup of kHuffDecThreads threads therefore stages its slice of the stream in LDS with coalesced
+// loads -- kHuffWarmWords words in front of its first sub-sequence (the warm-up of the first round, below), its
+// sub-sequences, kHuffTailWords of the next -- word j of sub-sequence t at [j][t] (rows one word longer than the
 // thread count, so that the staging stores and the decoders' loads both spread over the banks).
-static const int kHuffDecThreads = 128;
+static const int kHuffDecThreads = 256;
 static const int kHuffSubWords = kHuffSubBits / 32;
 static const int kHuffStagePitch = kHuffDecThreads + 1;
+static const int kHuffWarmWords = 8, kHuffTailWords = 4;
+static_assert(kHuffWarmWords + kHuffTailWords <= kHuffSubWords, "the slice must fit kHuffSubWords rows of kHuffStagePitch words");
+
+__device__ __forceinline__ i64 stageOriginWord() { return (i64)blockIdx.x * kHuffDecThreads * kHuffSubWords - kHuffWarmWords; }
 
 __device__ __forceinline__ void stageStream(const u32* __restrict__ stream, u64 nWords, u32* s_str)
 {
-  const u64 gw0 = (u64)blockIdx.x * kHuffDecThreads * kHuffSubWords;
-  for (u32 g = threadIdx.x; g < (u32)(kHuffDecThreads * kHuffSubWords + 2); g += kHuffDecThreads)
+  const i64 o = stageOriginWord();
+  for (u32 l = threadIdx.x; l < (u32)(kHuffDecThreads * kHuffSubWords + kHuffWarmWords + kHuffTailWords); l += kHuffDecThreads)
   {
-    const u64 w = gw0 + g;
-    s_str[(g % kHuffSubWords) * kHuffStagePitch + g / kHuffSubWords] = (w < nWords) ? stream[w] : 0u;
+    const i64 w = o + l;
+    s_str[(l % kHuffSubWords) * kHuffStagePitch + l / kHuffSubWords] = (w >= 0 && (u64)w < nWords) ? stream[w] : 0u;
   }
 }
 
-// 32 stream bits from bit position p (inside this workgroup's slice), MSB first
-__device__ __forceinline__ u32 peek32Staged(const u32* s_str, u64 p)
+// the workgroup's LDS copy of the look-up table: (length << 8) | symbol in 16 bits, 0xFFFF = longer than the LUT width
+__device__ __forceinline__ void stageLut(const HuffDecodeTable* __restrict__ t, u16* s_lut)
 {
-  const u32 g = (u32)((p >> 5) - (u64)blockIdx.x * kHuffDecThreads * kHuffSubWords);
-  const int sh = (int)(p & 31);
-  const u32 w0 = s_str[(g % kHuffSubWords) * kHuffStagePitch + g / kHuffSubWords];
-  const u32 g1 = g + 1u;
-  const u32 w1 = s_str[(g1 % kHuffSubWords) * kHuffStagePitch + g1 / kHuffSubWords];
-  return sh ? ((w0 << sh) | (w1 >> (32 - sh))) : w0;
+  for (int i = threadIdx.x; i < (1 << kHuffLutBits); i += kHuffDecThreads)
+  {
+    const u32 e = t->lut[i];
+    s_lut[i] = (e == 0xFFFFFFFFu) ? (u16)0xFFFFu : (u16)(((e >> 16) << 8) | (e & 0xFFu));
+  }
 }
 
+// Bit reader over the staged slice: 64-bit window (next bit = bit 63), refilled a word at a time, so that the only
+// LDS access a symbol waits for is its table look-up.
+struct StagedBits
+{
+  const u32* s_str;
+  u64 window;
+  u32 pos;     // bit position of the window's first bit, counted from the slice's first staged word
+  u32 next;    // staged word the next refill takes
+  int have;    // bits in the window
+
+  __device__ __forceinline__ u32 word(u32 l) const { return s_str[(l % kHuffSubWords) * kHuffStagePitch + l / kHuffSubWords]; }
+  __device__ __forceinline__ void start(const u32* str, u32 at)
+  {
+    s_str = str; pos = at;
+    const u32 l = at >> 5;
+    const int sh = (int)(at & 31u);
+    window = (((u64)word(l) << 32) | word(l + 1u)) << sh;
+    have = 64 - sh;
+    next = l + 2u;
+  }
+  __device__ __forceinline__ u32 top() const { return (u32)(window >> 32); }
+  __device__ __forceinline__ void skip(int len)
+  {
+    window <<= len; have -= len; pos += (u32)len;
+    if (have <= 32) { window |= (u64)word(next++) << (32 - have); have += 32; }
+  }
+};
+
 // returns the code length (0 = no code matches), symbol in sym; lut = the workgroup's LDS copy of t->lut
-__device__ __forceinline__ int decodeOne(const HuffDecodeTable* __restrict__ t, const u32* lut, u32 top, int& sym)
+__device__ __forceinline__ int decodeOne(const HuffDecodeTable* __restrict__ t, const u16* lut, u32 top, int& sym)
 {
   const u32 e = lut[top >> (32 - kHuffLutBits)];
-  if (e != 0xFFFFFFFFu) { sym = (int)(e & 0xFFFFu); return (int)(e >> 16); }
+  if (e != 0xFFFFu) { sym = (int)(e & 0xFFu); return (int)(e >> 8); }
   for (int i = 0; i < t->nLong; i++)
   {
     const int len = t->longLen[i];
@@ -363,40 +395,61 @@ __device__ __forceinline__ int decodeOne(const HuffDecodeTable* __restrict__ t, 
 }
 
 // one thread per sub-sequence of kHuffSubBits bits: decode from starts[t] up to the end of the
-// sub-sequence; exits[t] = first code word position at or beyond it, counts[t] = symbols decoded
+// sub-sequence; exits[t] = first code word position at or beyond it, counts[t] = symbols decoded.
+// First round (warm != 0): nobody knows where a code word starts near the sub-sequence's first bit, but a decoder set
+// down anywhere falls into step with the true code words within a few symbols -- so the thread starts kHuffWarmWords
+// words early and takes the first code word boundary at or behind its first bit as starts[t].  If the chain of exits
+// (k_huff_chain) then fits everywhere, which is the normal case, that was the only round.
 __global__ void __launch_bounds__(kHuffDecThreads)
 k_huff_sync(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const HuffDecodeTable* __restrict__ table, u32 nSub,
-            const u64* __restrict__ starts, u64* __restrict__ prevStarts, u64* __restrict__ exits, u32* __restrict__ counts,
-            u32* __restrict__ bad)
+            u64* __restrict__ starts, u64* __restrict__ prevStarts, u64* __restrict__ exits, u32* __restrict__ counts,
+            u32* __restrict__ bad, int warm)
 {
-  __shared__ u32 s_lut[1 << kHuffLutBits];
+  __shared__ u16 s_lut[1 << kHuffLutBits];
   __shared__ u32 s_str[kHuffSubWords * kHuffStagePitch];
   __shared__ u32 s_any;
   const u32 t = blockIdx.x * (u32)kHuffDecThreads + threadIdx.x;
-  const u64 s = (t < nSub) ? starts[t] : 0;
+  u64 s = (t < nSub) ? starts[t] : 0;
   const bool todo = t < nSub && prevStarts[t] != s;    // else: unchanged since the last round
   if (threadIdx.x == 0) s_any = 0;
   __syncthreads();
   if (todo) s_any = 1;
   __syncthreads();
   if (!s_any) return;    // (after the first round most workgroups have nothing to redo)
-  for (int i = threadIdx.x; i < (1 << kHuffLutBits); i += kHuffDecThreads) s_lut[i] = table->lut[i];
+  stageLut(table, s_lut);
   stageStream(stream, nWords, s_str);
   __syncthreads();
   if (!todo) return;
+  const u64 origin = (u64)(stageOriginWord() + kHuffWarmWords) * 32u;    // bit position of the slice's first sub-sequence
+  StagedBits in;
+  if (warm && t > 0)
+  {
+    const u32 first = (u32)(s - origin) + kHuffWarmWords * 32u;
+    in.start(s_str, first - kHuffWarmWords * 32u);
+    while (in.pos < first)
+    {
+      int sym;
+      const int len = decodeOne(table, s_lut, in.top(), sym);
+      if (len == 0) { in.start(s_str, first); break; }
+      in.skip(len);
+    }
+    s = origin + in.pos - kHuffWarmWords * 32u;
+    starts[t] = s;
+  }
+  else in.start(s_str, (u32)(s - origin) + kHuffWarmWords * 32u);
   prevStarts[t] = s;
   const u64 end = min((u64)(t + 1) * kHuffSubBits, streamBits);
-  u64 p = s;
+  const u32 endLocal = (u32)(end - origin) + kHuffWarmWords * 32u;
   u32 n = 0;
-  while (p < end)
+  while (in.pos < endLocal)
   {
     int sym;
-    const int len = decodeOne(table, s_lut, peek32Staged(s_str, p), sym);
+    const int len = decodeOne(table, s_lut, in.top(), sym);
     if (len == 0) { atomicOr(bad, 1u); break; }
-    p += (u64)len;
+    in.skip(len);
     n++;
   }
-  exits[t] = p;
+  exits[t] = origin + in.pos - kHuffWarmWords * 32u;
   counts[t] = n;
 }
 
@@ -429,29 +482,56 @@ template<class T>
 __global__ void __launch_bounds__(kHuffDecThreads)
 k_huff_emit(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const HuffDecodeTable* __restrict__ table, u32 nSub,
             const u64* __restrict__ starts, const u64* __restrict__ symBase, HuffGeom g, int mode, u64 nSymbols, u32 numValid,
-            const u32* __restrict__ validIdx, T* __restrict__ out)
+            const u32* __restrict__ validIdx, int rankOrder, T* __restrict__ out)
 {
-  __shared__ u32 s_lut[1 << kHuffLutBits];
+  __shared__ u16 s_lut[1 << kHuffLutBits];
   __shared__ u32 s_str[kHuffSubWords * kHuffStagePitch];
-  for (int i = threadIdx.x; i < (1 << kHuffLutBits); i += kHuffDecThreads) s_lut[i] = table->lut[i];
+  stageLut(table, s_lut);
   stageStream(stream, nWords, s_str);
   __syncthreads();
   const u32 t = blockIdx.x * (u32)kHuffDecThreads + threadIdx.x;
   if (t >= nSub) return;
   const int off = (DtOf<T>::v == DT_Char) ? 128 : 0;
+  const u64 origin = (u64)(stageOriginWord() + kHuffWarmWords) * 32u;
   const u64 end = min((u64)(t + 1) * kHuffSubBits, streamBits);
-  u64 p = starts[t];
+  const u32 endLocal = (u32)(end - origin) + kHuffWarmWords * 32u;
+  StagedBits in;
+  in.start(s_str, (u32)(starts[t] - origin) + kHuffWarmWords * 32u);
   u64 r = symBase[t];
+  if (rankOrder)
+  {
+    // symbol r is byte r of the output: whole words once r is a multiple of 4
+    const bool words = ((size_t)out & 3u) == 0;
+    u32 acc = 0;
+    int pending = 0;    // bytes r - pending .. r - 1 wait in acc
+    while (in.pos < endLocal && r < nSymbols)
+    {
+      int sym;
+      const int len = decodeOne(table, s_lut, in.top(), sym);
+      if (len == 0) break;
+      in.skip(len);
+      const u32 v = (u32)(sym - off) & 255u;
+      if (!words || (pending == 0 && (r & 3u) != 0)) out[r] = (T)(u8)v;
+      else
+      {
+        acc |= v << (8 * pending);
+        if (++pending == 4) { *reinterpret_cast<u32*>(out + (r - 3)) = acc; acc = 0; pending = 0; }
+      }
+      r++;
+    }
+    for (int j = 0; j < pending; j++) out[r - (u64)pending + j] = (T)(u8)(acc >> (8 * j));
+    return;
+  }
   // rank r -> (valid pixel q, depth m): divided once, then stepped
   u64 q, m;
   if (mode == IEM_Huffman) { q = r / (u64)g.nDepth; m = r - q * (u64)g.nDepth; }
   else { m = r / numValid; q = r - m * numValid; }
-  while (p < end && r < nSymbols)
+  while (in.pos < endLocal && r < nSymbols)
   {
     int sym;
-    const int len = decodeOne(table, s_lut, peek32Staged(s_str, p), sym);
+    const int len = decodeOne(table, s_lut, in.top(), sym);
     if (len == 0) break;
-    p += (u64)len;
+    in.skip(len);
     const i64 k = validIdx ? (i64)validIdx[q] : (i64)q;
     out[k * g.nDepth + (i64)m] = (T)(sym - off);
     r++;
@@ -559,6 +639,77 @@ __global__ void __launch_bounds__(256) k_huff_undelta_rows(T* __restrict__ data,
   }
 }
 
+// Delta mode, every pixel valid, 1 < nDepth <= kHuffInterleaveMax: the decoder leaves the deltas plane by plane
+// ([nDepth][nPix], the order of the stream) -- scattering them to their pixels from the decoder's threads would keep more
+// half-written cache lines open than the L2 holds.  Column 0 is summed in the planes; then a workgroup per row sums
+// the row of every plane and writes the interleaved pixels out of LDS in whole words.
+static const int kHuffInterleaveMax = 16;
+
+__global__ void __launch_bounds__(256) k_huff_undelta_col0_planar(u8* __restrict__ planar, HuffGeom g)
+{
+  __shared__ u32 s_wave[4];
+  u8* plane = planar + (i64)blockIdx.x * g.nRows * g.nCols;
+  u32 carry = 0;
+  for (int i0 = 0; i0 < g.nRows; i0 += 256)
+  {
+    const int i = i0 + (int)threadIdx.x;
+    const i64 at = (i64)i * g.nCols;
+    const u32 d = (i < g.nRows) ? (u32)plane[at] : 0u;
+    u32 total;
+    const u32 before = undeltaWorkgroupScan(d, s_wave, total);
+    if (i < g.nRows) plane[at] = (u8)(carry + before + d);
+    carry += total;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_huff_undelta_rows_interleave(const u8* __restrict__ planar, u8* __restrict__ out, HuffGeom g)
+{
+  __shared__ u32 s_wave[4];
+  __shared__ u32 s_carry[kHuffInterleaveMax];
+  __shared__ u32 s_out[1024 * kHuffInterleaveMax / 4];
+  u8* s_bytes = reinterpret_cast<u8*>(s_out);
+  const i64 nPix = (i64)g.nRows * g.nCols, row0 = (i64)blockIdx.x * g.nCols;
+  if (threadIdx.x < (u32)kHuffInterleaveMax) s_carry[threadIdx.x] = 0;
+  __syncthreads();
+  for (int j0 = 0; j0 < g.nCols; j0 += 1024)
+  {
+    const int j = j0 + (int)threadIdx.x * 4;
+    for (int iD = 0; iD < g.nDepth; iD++)
+    {
+      const u8* src = planar + (i64)iD * nPix + row0;
+      u32 v[4];
+      for (int k = 0; k < 4; k++) v[k] = (j + k < g.nCols) ? (u32)src[j + k] : 0u;
+      for (int k = 1; k < 4; k++) v[k] += v[k - 1];
+      const u32 carry = s_carry[iD];
+      u32 total;
+      const u32 before = carry + undeltaWorkgroupScan(v[3], s_wave, total);
+      for (int k = 0; k < 4; k++) s_bytes[((int)threadIdx.x * 4 + k) * g.nDepth + iD] = (u8)(before + v[k]);
+      if (threadIdx.x == 0) s_carry[iD] = carry + total;
+    }
+    __syncthreads();
+    const int nBytes = min(1024, g.nCols - j0) * g.nDepth;
+    u8* dst = out + (row0 + j0) * g.nDepth;
+    if ((((size_t)dst) & 3u) == 0)
+    {
+      for (int w = threadIdx.x; w < nBytes / 4; w += 256) reinterpret_cast<u32*>(dst)[w] = s_out[w];
+      for (int b = (nBytes & ~3) + (int)threadIdx.x; b < nBytes; b += 256) dst[b] = s_bytes[b];
+    }
+    else for (int b = threadIdx.x; b < nBytes; b += 256) dst[b] = s_bytes[b];
+    __syncthreads();
+  }
+}
+
+bool huffPlanarDecode(int imageMode, const u8* maskBits, int nDepth)
+{
+  return imageMode == IEM_DeltaHuffman && !maskBits && nDepth > 1 && nDepth <= kHuffInterleaveMax;
+}
+
+void launchHuffUndeltaPlanar(u8* planar, void* out, const HuffGeom& g, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_huff_undelta_col0_planar, dim3(g.nDepth), dim3(256), 0, st, planar, g);
+  hipLaunchKernelGGL(k_huff_undelta_rows_interleave, dim3(g.nRows), dim3(256), 0, st, (const u8*)planar, (u8*)out, g);
+}
+
 void launchHuffUndelta(int dt, void* data, const u8* maskBits, const HuffGeom& g, hipStream_t st)
 {
   if (!maskBits)
@@ -579,11 +730,11 @@ void launchHuffUndelta(int dt, void* data, const u8* maskBits, const HuffGeom& g
   else hipLaunchKernelGGL(k_huff_undelta<unsigned char>, dim3(g.nDepth), dim3(64), 0, st, (unsigned char*)data, maskBits, g);
 }
 
-void launchHuffSync(const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, const u64* starts,
-                    u64* prevStarts, u64* exits, u32* counts, u32* bad, hipStream_t st)
+void launchHuffSync(const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u64* starts,
+                    u64* prevStarts, u64* exits, u32* counts, u32* bad, bool firstRound, hipStream_t st)
 {
   hipLaunchKernelGGL(k_huff_sync, dim3((nSub + kHuffDecThreads - 1) / kHuffDecThreads), dim3(kHuffDecThreads), 0, st, stream, nWords, streamBits, table, nSub, starts, prevStarts,
-                     exits, counts, bad);
+                     exits, counts, bad, firstRound ? 1 : 0);
 }
 
 void launchHuffChain(u32 nSub, u64* starts, const u64* exits, u32* changed, hipStream_t st)
@@ -592,12 +743,14 @@ void launchHuffChain(u32 nSub, u64* starts, const u64* exits, u32* changed, hipS
 }
 
 void launchHuffEmit(int dt, const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, const u64* starts,
-                    const u64* symBase, const HuffGeom& g, int mode, u64 nSymbols, u32 numValid, const u32* validIdx, void* out,
-                    hipStream_t st)
+                    const u64* symBase, const HuffGeom& g, int mode, u64 nSymbols, u32 numValid, const u32* validIdx, bool planar,
+                    void* out, hipStream_t st)
 {
   const dim3 grid((nSub + kHuffDecThreads - 1) / kHuffDecThreads), block(kHuffDecThreads);
-  if (dt == DT_Char) hipLaunchKernelGGL(k_huff_emit<signed char>, grid, block, 0, st, stream, nWords, streamBits, table, nSub, starts, symBase, g, mode, nSymbols, numValid, validIdx, (signed char*)out);
-  else hipLaunchKernelGGL(k_huff_emit<unsigned char>, grid, block, 0, st, stream, nWords, streamBits, table, nSub, starts, symBase, g, mode, nSymbols, numValid, validIdx, (unsigned char*)out);
+  // symbol r goes to byte r: one value per pixel, or pixel-interleaved symbols (not delta mode), or planes wanted
+  const int rankOrder = (!validIdx && (g.nDepth == 1 || mode == IEM_Huffman || planar)) ? 1 : 0;
+  if (dt == DT_Char) hipLaunchKernelGGL(k_huff_emit<signed char>, grid, block, 0, st, stream, nWords, streamBits, table, nSub, starts, symBase, g, mode, nSymbols, numValid, validIdx, rankOrder, (signed char*)out);
+  else hipLaunchKernelGGL(k_huff_emit<unsigned char>, grid, block, 0, st, stream, nWords, streamBits, table, nSub, starts, symBase, g, mode, nSymbols, numValid, validIdx, rankOrder, (unsigned char*)out);
 }
 
 __global__ void __launch_bounds__(256) k_init_starts(u64* __restrict__ starts, u64* __restrict__ prevStarts, u32 nSub)

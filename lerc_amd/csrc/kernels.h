@@ -86,8 +86,6 @@ void launchBitsToBytes(const u8* maskBits, u8* byteMask, i64 nPix, hipStream_t s
 // 8-byte slots), plus float diagnostics in BandStats (NaN, all-integer, TryRaiseMaxZError errors)
 // raiseMask: bit c set = evaluate TryRaiseMaxZError candidate c (factors 1,2,10,20,100,200,1000,2000,10000).
 // mins / maxs hold order-preserving keys (init statKeyInitMin / statKeyInitMax); decode with statKeyTo*.
-// nDepth must be <= kStatsMaxDepth.
-static const int kStatsMaxDepth = 256;
 void launchBandStats(int dt, const void* data, const u8* maskBits, int nRows, int nCols, int nDepth, u32 raiseMask,
                      u64* mins, u64* maxs, BandStats* stats, hipStream_t stream);
 u64 statKeyInitMin();

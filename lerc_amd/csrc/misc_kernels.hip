@@ -75,7 +75,8 @@ __global__ void __launch_bounds__(1024) k_scan_single(const u32* __restrict__ in
 void launchExclusiveScan(const u32* in, u32* out, u32 n, u32* scratch, hipStream_t stream)
 {
   if (n == 0) { hipMemsetAsync(out, 0, 4, stream); return; }
-  if (n <= (1u << 18) && in != out && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0)
+  if (n <= (1u << 14) && in != out    /* one workgroup: ~0.45 us per 1024 elements; the three launches cost ~15 us */
+      && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0)
   {
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, stream, in, out, n);
     return;
@@ -306,32 +307,33 @@ k_band_stats(const T* __restrict__ data, const u8* __restrict__ maskBits, i64 nP
   __shared__ u64 s_raise[9];
   constexpr bool isFlt = (DtOf<T>::v >= DT_Float);
   const int facCand[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
-  for (int i = threadIdx.x; i < nDepth; i += 256) { s_min[i] = ~0ull; s_max[i] = 0ull; }
+  const bool ldsRanges = nDepth <= kStatsMaxDepthLds;    // (more values per pixel than that: straight to the global ranges)
+  for (int i = threadIdx.x; i < nDepth && ldsRanges; i += 256) { s_min[i] = ~0ull; s_max[i] = 0ull; }
   if (threadIdx.x < 9) s_raise[threadIdx.x] = 0ull;
   __syncthreads();
 
+  // The grid's stride is cut to a multiple of nDepth (the few threads beyond it idle), so that a thread stays with one
+  // of the nDepth values of a pixel and keeps its range in registers; its pixel index advances by a constant.
   const i64 nElem = nPix * nDepth;
-  const i64 stride = (i64)gridDim.x * 256;
+  const i64 first = (i64)blockIdx.x * 256 + threadIdx.x;
+  i64 stride = (i64)gridDim.x * 256;
+  if (nDepth > 1) stride -= stride % nDepth;    // (the launch has at least nDepth threads)
+  const int m = (nDepth > 1) ? (int)(first % nDepth) : 0;
+  const i64 kStep = stride / nDepth;
   bool sawNaN = false, sawFrac = false;
-  u64 kMin = ~0ull, kMax = 0ull;    // nDepth == 1 fast path: registers
+  u64 kMin = ~0ull, kMax = 0ull;
   double rerr[9];
 #pragma unroll
   for (int c = 0; c < 9; c++) rerr[c] = 0;
 
-  for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < nElem; t += stride)
+  i64 k = (nDepth > 1) ? first / nDepth : first;
+  for (i64 t = first; t < nElem && first < stride; t += stride, k += kStep)
   {
-    const i64 k = (nDepth == 1) ? t : t / nDepth;
     if (maskBits && !maskBit(maskBits, k)) continue;
     const T v = data[t];
     if (isFlt && isNaNT(v)) { sawNaN = true; continue; }
     const u64 key = Key<T>::enc(v);
-    if (nDepth == 1) { kMin = key < kMin ? key : kMin; kMax = key > kMax ? key : kMax; }
-    else
-    {
-      const int m = (int)(t - k * nDepth);
-      atomicMin(&s_min[m], key);
-      atomicMax(&s_max[m], key);
-    }
+    kMin = key < kMin ? key : kMin; kMax = key > kMax ? key : kMax;
     if (isFlt)
     {
       const double x = (double)v;
@@ -356,6 +358,11 @@ k_band_stats(const T* __restrict__ data, const u8* __restrict__ maskBits, i64 nP
     kMin = waveMin(kMin); kMax = waveMax(kMax);
     if (laneId() == 0) { atomicMin(&s_min[0], kMin); atomicMax(&s_max[0], kMax); }
   }
+  else if (kMin <= kMax)
+  {
+    if (ldsRanges) { atomicMin(&s_min[m], kMin); atomicMax(&s_max[m], kMax); }
+    else { atomicMin(&mins[m], kMin); atomicMax(&maxs[m], kMax); }
+  }
   if (isFlt && raiseMask)
   {
 #pragma unroll
@@ -373,7 +380,7 @@ k_band_stats(const T* __restrict__ data, const u8* __restrict__ maskBits, i64 nP
     if (anyFrac) atomicOr(&stats->notAllInt, 1u);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nDepth; i += 256)
+  for (int i = threadIdx.x; i < nDepth && ldsRanges; i += 256)
   {
     if (s_min[i] != ~0ull) atomicMin(&mins[i], s_min[i]);
     if (s_max[i] != 0ull) atomicMax(&maxs[i], s_max[i]);
@@ -392,6 +399,7 @@ void launchBandStats(int dt, const void* data, const u8* maskBits, int nRows, in
   const i64 perBlock = nElem < (1 << 20) ? 256 : 256 * 16;    // small inputs (e.g. one row): one element per thread
   i64 nBlocks = (nElem + perBlock - 1) / perBlock;
   if (nBlocks > 4096) nBlocks = 4096;
+  if (nBlocks < ((i64)nDepth + 255) / 256) nBlocks = ((i64)nDepth + 255) / 256;    // a thread per value of a pixel at least
   if (nBlocks < 1) nBlocks = 1;
   const dim3 grid((unsigned)nBlocks), block(256);
   switch (dt)

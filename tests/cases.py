@@ -242,6 +242,40 @@ def check_old_codec_case(T, P, name, arr, ver, e, kw, same):
         assert d1[0] == d2[0] == 0 and same(d1[1], d2[1]) and same(d1[2], d2[2]), name
 
 
+def deep_pixel_cases(seed=17):
+    """Hyperspectral-like rasters: more values per pixel than a workgroup has threads (the per-depth ranges of
+    Lerc2 v4+, Lerc2.cpp:1095-1166, are then gathered without the LDS table), masks, lossy and lossless.
+    -> [(name, arr, max_z_err, kw)]"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for dt, (r, c, nd), e in [(np.uint8, (8, 8, 300), 0), (np.float32, (9, 11, 300), 0.01), (np.int16, (16, 16, 257), 1),
+                              (np.uint8, (1, 1, 300), 0), (np.float64, (3, 2, 1000), 0.5), (np.uint16, (24, 40, 256), 0),
+                              (np.float32, (5, 7, 513), 0)]:
+        x = np.stack([terrain(r, c, rng, amp=40, base=100, sigma=1.0) + 3 * k for k in range(nd)], axis=-1)
+        x = _cast(x, dt)
+        m = (rng.random((r, c)) > 0.2).astype(np.uint8)
+        out.append((f"deep-{np.dtype(dt).name}-{r}x{c}x{nd}", x, float(e), dict(n_depth=nd)))
+        out.append((f"deep-{np.dtype(dt).name}-{r}x{c}x{nd}-mask", x, float(e), dict(n_depth=nd, mask=m)))
+    return out
+
+
+def check_deep_pixel_case(T, P, name, arr, e, kw, same):
+    """T: trusted library, P: library under test: same blob, same pixels / mask / ranges back"""
+    r1, b1 = T.encode(arr, e, **kw)
+    r2, b2 = P.encode(arr, e, **kw)
+    lossless_float = arr.dtype.kind == "f" and e == 0
+    assert r1 == r2 == 0 and len(b1) == len(b2), (name, r1, r2, len(b1), len(b2))
+    if not lossless_float:    # (there the reference leaves pad bytes undefined)
+        assert bytes(b1) == bytes(b2), name
+    d1, d2 = T.decode(b1), P.decode(b1)
+    assert d1[0] == d2[0] == 0 and same(d1[1], d2[1]) and same(d1[2], d2[2]), name
+    d3 = P.decode(b2)
+    assert d3[0] == 0 and same(d1[1], d3[1]), name
+    assert T.blob_info(b1) == P.blob_info(b1), name
+    nd = kw["n_depth"]
+    assert T.data_ranges(b1, nd, 1) == P.data_ranges(b1, nd, 1), name
+
+
 def lossless_float_cases(n_iter, seed=91, max_side=150):
     """maxZErr == 0 on float / double rasters (Lerc2 IEM_DeltaDeltaHuffman, fpl_*): smooth, noisy, stepped and random
     data so that every predictor (none / rows / rows + columns), difference order and plane coding (Huffman, one value,

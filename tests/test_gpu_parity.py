@@ -261,6 +261,12 @@ def test_nodata_values(P, O):
         cases.check_nodata_case(T, P, name, arr, e, kw, _same)
 
 
+def test_many_values_per_pixel(P, O):
+    """nDepth of several hundred (hyperspectral cubes): blobs, pixels, masks, info and ranges as the oracle's"""
+    for name, arr, e, kw in cases.deep_pixel_cases():
+        cases.check_deep_pixel_case(O, P, name, arr, e, kw, _same)
+
+
 def test_encode_for_older_codec_versions(P, O):
     """lerc_encodeForVersion / lerc_computeCompressedSizeForVersion, codec 3..5 (Lerc.cpp:526-624): status, size and
     blob bytes as the oracle's (itself pinned on the real reference by tests/test_oracle_vs_reference.py), and against

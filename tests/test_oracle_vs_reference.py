@@ -125,6 +125,12 @@ def test_fletcher32(O):
         assert O.lib.orc_fletcher32(b[14:].ctypes.data, len(blob) - 14) == stored
 
 
+def test_many_values_per_pixel(O):
+    """nDepth of several hundred: the restatement against the real reference"""
+    for name, arr, e, kw in cases.deep_pixel_cases():
+        cases.check_deep_pixel_case(R, O, name, arr, e, kw, _same)
+
+
 def test_old_codec_versions(O):
     """lerc_encodeForVersion / lerc_computeCompressedSizeForVersion for codec 3..5 (Lerc.cpp:526-624)."""
     for name, arr, ver, e, kw in cases.old_codec_cases(250):

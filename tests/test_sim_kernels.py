@@ -354,6 +354,13 @@ def test_sim_nodata_values(libs):
         cases.check_nodata_case(T, S, name, arr, e, kw, _same)
 
 
+def test_sim_many_values_per_pixel(libs):
+    """nDepth of several hundred (hyperspectral cubes): per-depth ranges, tiles, masks as the oracle's"""
+    O, S = libs
+    for name, arr, e, kw in cases.deep_pixel_cases():
+        cases.check_deep_pixel_case(O, S, name, arr, e, kw, _same)
+
+
 def test_sim_encode_for_older_codec_versions(libs):
     """lerc_encodeForVersion, codec 3..5: header layouts, no ranges before 4, no slice differences before 5,
     raw Huffman only from 4, lossless float as raw blocks, NaN -> mask, no all-integer promotion."""
