@@ -29,7 +29,7 @@ bool readHeader(const u8* src, size_t n, Header& h, size_t& used);
 
 // RLE of the validity bit mask (host; the mask is << 1 % of the bytes and inherently sequential)
 void rleEncode(const u8* src, size_t n, std::vector<u8>& out);
-bool rleDecode(const u8* src, size_t left, u8* dst, size_t dstSize);
+bool rleDecode(const u8* src, size_t n, u8* dst, size_t dstSize, size_t* written = nullptr);    // (what the stream does not fill stays as it was)
 
 // ---- growable device workspace + stream, one per host thread (C API) or per handle (device API)
 class Context
@@ -53,6 +53,9 @@ public:
 
   // small pinned host mirror for results read back after a sync
   void* pinned(size_t bytes);
+  // a second pinned area (the validity bits of a band on their way to the host while kernels run) and its event
+  void* pinnedAux(size_t bytes);
+  hipEvent_t auxEvent();
   bool sync();                               // wait for the active stream (polls first: see codec_common.cpp)
 
   std::string lastError;
@@ -87,6 +90,9 @@ private:
   size_t m_cap = 0, m_used = 0;
   void* m_pinned = nullptr;
   size_t m_pinnedCap = 0;
+  void* m_pinnedAux = nullptr;
+  size_t m_pinnedAuxCap = 0;
+  hipEvent_t m_auxEvent = nullptr;
 };
 
 // RAII bracket around one kernel launch (or a short group of launches)

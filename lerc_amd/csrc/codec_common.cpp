@@ -119,8 +119,9 @@ void rleEncode(const u8* b, size_t n, std::vector<u8>& out)
   count(-32768);
 }
 
-bool rleDecode(const u8* src, size_t left, u8* dst, size_t dstSize)
+bool rleDecode(const u8* src, size_t left, u8* dst, size_t dstSize, size_t* written)
 {
+  if (written) *written = 0;
   if (!src || !dst || left < 2) return false;
   size_t at = 0;
   for (;;)
@@ -128,7 +129,7 @@ bool rleDecode(const u8* src, size_t left, u8* dst, size_t dstSize)
     if (left < 2) return false;
     const short cnt = (short)(src[0] | (src[1] << 8));
     src += 2; left -= 2;
-    if (cnt == -32768) return true;
+    if (cnt == -32768) { if (written) *written = at; return true; }
     const size_t n = (size_t)(cnt < 0 ? -cnt : cnt), payload = cnt > 0 ? n : 1;
     if (left < payload + 2 || at + n > dstSize) return false;    // + 2: a count always follows (RLE.cpp:310)
     if (cnt > 0) memcpy(dst + at, src, n); else memset(dst + at, src[0], n);
@@ -241,6 +242,8 @@ Context::~Context()
 {
   if (m_slab) hipFree(m_slab);
   if (m_pinned) hipHostFree(m_pinned);
+  if (m_pinnedAux) hipHostFree(m_pinnedAux);
+  if (m_auxEvent) hipEventDestroy(m_auxEvent);
   for (hipEvent_t e : m_eventPool) hipEventDestroy(e);
   if (m_stream) hipStreamDestroy(m_stream);
 }
@@ -272,6 +275,22 @@ void* Context::pinned(size_t bytes)
   if (hipHostMalloc(&m_pinned, bytes + 4096, hipHostMallocDefault) != hipSuccess) return nullptr;
   m_pinnedCap = bytes + 4096;
   return m_pinned;
+}
+
+void* Context::pinnedAux(size_t bytes)
+{
+  if (bytes <= m_pinnedAuxCap) return m_pinnedAux;
+  if (m_pinnedAux) hipHostFree(m_pinnedAux);
+  m_pinnedAux = nullptr; m_pinnedAuxCap = 0;
+  if (hipHostMalloc(&m_pinnedAux, bytes + 4096, hipHostMallocDefault) != hipSuccess) return nullptr;
+  m_pinnedAuxCap = bytes + 4096;
+  return m_pinnedAux;
+}
+
+hipEvent_t Context::auxEvent()
+{
+  if (!m_auxEvent && hipEventCreateWithFlags(&m_auxEvent, hipEventDisableTiming) != hipSuccess) m_auxEvent = nullptr;
+  return m_auxEvent;
 }
 
 // Waits for the stream.  A blocking hipStreamSynchronize wakes the thread up tens of microseconds late, which is

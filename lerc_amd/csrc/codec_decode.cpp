@@ -34,7 +34,7 @@ struct BlobReader
     if (off + len > n) return false;
     if (h) { memcpy(dst, h + off, len); return true; }
     if (cache && off >= cacheOff && off + len <= cacheOff + cacheLen) { memcpy(dst, cache + (off - cacheOff), len); return true; }
-    u8* pin = (ctx && len <= 4096) ? (u8*)ctx->pinned(4096) : nullptr;
+    u8* pin = ctx ? (u8*)ctx->pinned(len < 4096 ? 4096 : len) : nullptr;    // (a pageable target is staged at ~1 GB/s)
     if (hipMemcpyAsync(pin ? pin : dst, d + off, len, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
     if (!(ctx ? ctx->sync() : hipStreamSynchronize(st) == hipSuccess)) return false;
     if (pin) memcpy(dst, pin, len);
@@ -273,6 +273,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
 
   // host buffers the enqueued copies read from: kept until the call's final synchronisation instead of waiting per band
   std::vector<std::vector<u8> > keepBits;
+  bool auxInFlight = false;    // the pinned mask area is the source of a copy that may not have run yet
   std::vector<std::vector<double> > keepZMax;
   struct Drain { Context& c; ~Drain() { c.sync(); } } drain{ ctx };    // (destroyed before the buffers above, on every way out)
   bool haveMask = false, maskAllValid = true;
@@ -334,10 +335,23 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     {
       small.resize((size_t)bd.numBytesMask);
       if (!rd.read(at, small.size(), small.data())) return kFailed;
-      keepBits.emplace_back(maskBytes, (u8)0);
-      if (!rleDecode(small.data(), small.size(), keepBits.back().data(), maskBytes)) return kFailed;
+      // the bits are put together in pinned memory and travel while the host goes on (the area is free again once its
+      // event has passed); without it: a pageable vector that lives until the final sync
+      u8* hostBits = nullptr;
+      if (ctx.auxEvent())
+      {
+        if (auxInFlight && hipEventSynchronize(ctx.auxEvent()) != hipSuccess) return kFailed;
+        auxInFlight = false;
+        hostBits = (u8*)ctx.pinnedAux(maskBytes);
+      }
+      const bool pinnedBits = hostBits != nullptr;
+      if (!pinnedBits) { keepBits.emplace_back(maskBytes, (u8)0); hostBits = keepBits.back().data(); }
+      size_t written = 0;
+      if (!rleDecode(small.data(), small.size(), hostBits, maskBytes, &written)) return kFailed;
+      if (pinnedBits && written < maskBytes) memset(hostBits + written, 0, maskBytes - written);
       haveMask = true; maskAllValid = false;
-      hipMemcpyAsync(dBits, keepBits.back().data(), maskBytes, hipMemcpyHostToDevice, st);
+      hipMemcpyAsync(dBits, hostBits, maskBytes, hipMemcpyHostToDevice, st);
+      if (pinnedBits) { hipEventRecord(ctx.auxEvent(), st); auxInFlight = true; }
     }
     else if (!haveMask || maskAllValid) return kFailed;    // "use previous mask" without a usable one
     at += (u64)bd.numBytesMask;

@@ -317,14 +317,28 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
 
   // ---- mask bookkeeping across bands (Lerc.cpp:717-741)
   std::vector<u8> hBandBits;
+  const u8* bitsOnTheWay = nullptr;    // single band: the bits travel while the tile kernels run, the host picks them up for the RLE
+  size_t nBitsOnTheWay = 0;
   if (haveBits && !bandAllValid)
   {
-    hBandBits.resize((size_t)((nPix + 7) >> 3));
-    u8* pin = (u8*)ctx.pinned(hBandBits.size());    // (a pageable target costs a staging copy at ~1 GB/s)
-    if (!pin) return kFailed;
-    hipMemcpyAsync(pin, dNewBits, hBandBits.size(), hipMemcpyDeviceToHost, st);
-    if (!sync.wait()) return kFailed;
-    memcpy(hBandBits.data(), pin, hBandBits.size());
+    const size_t nb = (size_t)((nPix + 7) >> 3);
+    if (rq.nBands == 1 && ctx.auxEvent())
+    {
+      u8* pin = (u8*)ctx.pinnedAux(nb);
+      if (!pin) return kFailed;
+      hipMemcpyAsync(pin, dNewBits, nb, hipMemcpyDeviceToHost, st);
+      hipEventRecord(ctx.auxEvent(), st);
+      bitsOnTheWay = pin; nBitsOnTheWay = nb;
+    }
+    else
+    {
+      hBandBits.resize(nb);
+      u8* pin = (u8*)ctx.pinned(nb);    // (a pageable target costs a staging copy at ~1 GB/s)
+      if (!pin) return kFailed;
+      hipMemcpyAsync(pin, dNewBits, nb, hipMemcpyDeviceToHost, st);
+      if (!sync.wait()) return kFailed;
+      memcpy(hBandBits.data(), pin, nb);
+    }
   }
   if (nanSeen || nd.modifiedMask) anyMaskModified = true;
   bool encMask = (iBand == 0);
@@ -338,7 +352,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   {
     ms.allValid = bandAllValid;
     ms.numValid = bandNumValid;
-    const size_t nMaskBytes = hBandBits.size();
+    const size_t nMaskBytes = bitsOnTheWay ? nBitsOnTheWay : hBandBits.size();
     ms.hBits = std::move(hBandBits);    // (megabytes for a large raster: moved, not copied)
     if (!bandAllValid)
     {
@@ -436,8 +450,22 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   // ---- sections before the pixel data
   const bool needMask = numValid > 0 && numValid < (int)nPix;
   std::vector<u8> rle;
-  if (needMask && encMask) rleEncode(ms.hBits.data(), ms.hBits.size(), rle);
-  u32 blobSize = headerBytes(hd.version) + 4 + (u32)rle.size();
+  u32 blobSize = headerBytes(hd.version) + 4;
+  bool maskCoded = false;
+  auto codeMask = [&]() -> bool    // (called with kernels in flight where there are any: the RLE of 8 MB of bits takes the host a millisecond)
+  {
+    if (maskCoded) return true;
+    maskCoded = true;
+    if (!(needMask && encMask)) return true;
+    if (bitsOnTheWay)
+    {
+      if (hipEventSynchronize(ctx.auxEvent()) != hipSuccess) return false;
+      rleEncode(bitsOnTheWay, nBitsOnTheWay, rle);
+    }
+    else rleEncode(ms.hBits.data(), ms.hBits.size(), rle);
+    blobSize += (u32)rle.size();
+    return true;
+  };
 
   enum Payload { P_NONE, P_TILING, P_ONESWEEP, P_HUFFMAN, P_FLOAT } payload = P_NONE;
   FplPlan fpl;
@@ -469,6 +497,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     { ProfScope ps(ctx, "tile_sizes"); launchTileSizes(dt, mb, dData, dBits, bp, dSizes, dStatus, st); }
     { ProfScope ps(ctx, "scan_block_sizes"); launchExclusiveScan(dSizes, dOffsets, nPos, dScratch, st); }
     hipMemcpyAsync(&total, dOffsets + nPos, 4, hipMemcpyDeviceToHost, st);
+    if (!codeMask()) return false;
     return sync.wait();
   };
 
@@ -535,6 +564,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
       }
     }
   }
+  if (!codeMask()) return kFailed;
   if ((size_t)blobSize > (size_t)INT_MAX) return kFailed;
   hd.blobSize = (int)blobSize;
   bandBytes = blobSize;
@@ -550,9 +580,13 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   if (blobSize > capacityLeft) return kBufferTooSmall;
 
   // ---- 4. emit: small sections from the host, pixel payload by kernels
-  std::vector<u8> prefix(headerBytes(hd.version) + 4 + rle.size() + (writeRanges ? 2 * (size_t)nD * tb : 0) + 2);
+  // (put together in pinned memory -- the mask's RLE can be megabytes, and a pageable source is staged at ~1 GB/s with the
+  // stream waiting; the area held the mask bits, which codeMask() has consumed by now)
+  const size_t prefixCap = headerBytes(hd.version) + 4 + rle.size() + (writeRanges ? 2 * (size_t)nD * tb : 0) + 2;
+  u8* prefix = (u8*)ctx.pinnedAux(prefixCap);
+  if (!prefix) return kFailed;
   size_t at = 0;
-  writeHeader(prefix.data(), hd);
+  writeHeader(prefix, hd);
   at = headerBytes(hd.version);
   const int nm = (int)rle.size();
   memcpy(&prefix[at], &nm, 4); at += 4;
@@ -567,7 +601,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     prefix[at++] = (payload == P_ONESWEEP) ? 1 : 0;
     if (payload != P_ONESWEEP && (hd.tryHuffmanInt() || hd.tryHuffmanFlt())) prefix[at++] = (u8)imageMode;
   }
-  hipMemcpyAsync(dBandOut, prefix.data(), at, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(dBandOut, prefix, at, hipMemcpyHostToDevice, st);
   u8* dPayload = dBandOut + at;
 
   if (payload == P_TILING)

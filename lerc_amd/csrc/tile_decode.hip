@@ -351,8 +351,10 @@ __global__ void __launch_bounds__(64) k_walk_chunks_memo(BandParams p, WalkPlan 
                                                          u32 blobEnd, u32* __restrict__ chunkExit)
 {
   __shared__ __align__(16) u8 s_bytes[kMemoChunk + kMemoWindowMax + 48];
-  __shared__ __align__(16) u32 s_next[kMemoChunk];    // 0 = not parsed yet; else len | sig << 16 | kind << 30 (1 block, 2 no block here, 3 raw of unknown size)
-  __shared__ __align__(16) u32 s_exitOf[kMemoChunk];  // 0 = unknown; else where a walk that passes through this block start leaves the chunk
+  // 16-bit tables (21 KB with the bytes: seven of these one-wave workgroups per CU instead of four)
+  __shared__ __align__(16) u16 s_next[kMemoChunk];    // 0 = not parsed yet; kNoBlock / kRawUnknown; else len (< 4096) | sig << 12
+  __shared__ __align__(16) u16 s_exitOf[kMemoChunk];  // 0 = unknown; else 1 + (where a walk through this block start leaves the chunk - chunkStart)
+  const u32 kNoBlock = 0xFFFFu, kRawUnknown = 0xFFFEu;
   const u32 c = blockIdx.x;
   const int lane = laneId();
   const u32 chunkStart = dataBegin + c * wp.chunkBytes;
@@ -376,7 +378,7 @@ __global__ void __launch_bounds__(64) k_walk_chunks_memo(BandParams p, WalkPlan 
     else for (u32 k2 = 0; k2 < 16u && g + k2 < blobEnd; k2++) (&x.x)[k2 >> 2] |= (u32)blob[g + k2] << (8u * (k2 & 3u));
     *reinterpret_cast<uint4*>(&s_bytes[16u * v]) = x;
   }
-  for (u32 i = (u32)lane; i < kMemoChunk / 4u; i += 64u)
+  for (u32 i = (u32)lane; i < kMemoChunk / 8u; i += 64u)
   {
     reinterpret_cast<uint4*>(s_next)[i] = make_uint4(0, 0, 0, 0);
     reinterpret_cast<uint4*>(s_exitOf)[i] = make_uint4(0, 0, 0, 0);
@@ -402,23 +404,22 @@ __global__ void __launch_bounds__(64) k_walk_chunks_memo(BandParams p, WalkPlan 
         {
           BlkInfo b;
           const int rc = parseBlock<TBYTES>(s_chunk, rel, stageEnd - chunkStart, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b);
-          if (rc == 1) e = 2u << 30;
-          else if (rc == 2) e = 3u << 30;
-          else e = b.len | ((((u32)b.flag >> 2) & pattern) << 16) | (1u << 30);
-          s_next[rel] = e;    // (lanes that race here store the same word)
+          if (rc == 1 || b.len >= 4094u) e = kNoBlock;    // (no block of a chunk this size is that long; 0xFFFE, 0xFFFF are taken)
+          else if (rc == 2) e = kRawUnknown;
+          else e = b.len | ((((u32)b.flag >> 2) & pattern) << 12);
+          s_next[rel] = (u16)e;    // (lanes that race here store the same value)
         }
-        const u32 kind = e >> 30;
-        if (kind == 2u) alive = false;
-        else if (kind == 3u) { if (wp.uniformN == 0) alive = false; else unknown = true; }    // see k_walk_chunks
+        if (e == kNoBlock) alive = false;
+        else if (e == kRawUnknown) { if (wp.uniformN == 0) alive = false; else unknown = true; }    // see k_walk_chunks
         else
         {
-          const u32 sig = (e >> 16) & 15u;
+          const u32 sig = e >> 12;
           if (prevSig != kNone && !sigFollows(prevSig, sig, p.mb, pattern)) alive = false;
           else
           {
             const u32 known = s_exitOf[rel];    // an earlier walk came through here and made it to the chunk's end
             prevSig = sig;
-            cur = known ? known : cur + (e & 0xFFFFu);
+            cur = known ? chunkStart + known - 1u : cur + (e & 0xFFFu);
           }
         }
       }
@@ -433,7 +434,7 @@ __global__ void __launch_bounds__(64) k_walk_chunks_memo(BandParams p, WalkPlan 
         {
           const u32 rel = at - chunkStart;
           if (at >= chunkEnd || s_exitOf[rel] != 0u) go = false;
-          else { s_exitOf[rel] = cur; at += s_next[rel] & 0xFFFFu; }
+          else { s_exitOf[rel] = (u16)(cur - chunkStart + 1u); at += s_next[rel] & 0xFFFu; }
         }
       }
     }
