@@ -456,12 +456,10 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   {
     if (maskCoded) return true;
     maskCoded = true;
+    // (the copy must have landed in any case: the pinned area takes the blob's prefix next)
+    if (bitsOnTheWay && hipEventSynchronize(ctx.auxEvent()) != hipSuccess) return false;
     if (!(needMask && encMask)) return true;
-    if (bitsOnTheWay)
-    {
-      if (hipEventSynchronize(ctx.auxEvent()) != hipSuccess) return false;
-      rleEncode(bitsOnTheWay, nBitsOnTheWay, rle);
-    }
+    if (bitsOnTheWay) rleEncode(bitsOnTheWay, nBitsOnTheWay, rle);
     else rleEncode(ms.hBits.data(), ms.hBits.size(), rle);
     blobSize += (u32)rle.size();
     return true;
