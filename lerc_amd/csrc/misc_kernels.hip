@@ -163,42 +163,64 @@ template<class T> __device__ __forceinline__ bool isNaNT(T) { return false; }
 template<> __device__ __forceinline__ bool isNaNT<float>(float v) { return v != v; }
 template<> __device__ __forceinline__ bool isNaNT<double>(double v) { return v != v; }
 
-// one lane per pixel (coalesced loads), a ballot per wave = 8 mask bytes; a fixed grid strides over the raster so that
-// the valid pixel count costs one atomic per wave of the grid, not one per 64 pixels
+// four pixels per lane (one 32-bit load of the byte mask, one 128-bit load of a float raster), two lanes make a mask
+// byte; a fixed grid strides over the raster so that the valid pixel count costs one atomic per wave of the grid
 template<class T>
 __global__ void __launch_bounds__(256) k_build_mask(const T* __restrict__ data, const u8* __restrict__ byteMask, i64 nPix,
                                                     int nDepth, u8* __restrict__ maskBits, BandStats* stats)
 {
+  constexpr bool isFlt = DtOf<T>::v >= DT_Float;
   const i64 nBytes = (nPix + 7) >> 3;
   const int lane = laneId();
+  const bool maskWords = byteMask && (((size_t)byteMask) & 3u) == 0;
+  const bool dataQuads = isFlt && nDepth == 1 && (((size_t)data) & (4 * sizeof(T) - 1)) == 0;
   u32 cnt = 0;
   bool sawNaN = false, sawMixed = false;
-  for (i64 base = (i64)blockIdx.x * 256; base < nBytes * 8; base += (i64)gridDim.x * 256)    // whole waves: uniform trip count
+  for (i64 base = (i64)blockIdx.x * 1024; base < nBytes * 8; base += (i64)gridDim.x * 1024)    // whole waves: uniform trip count
   {
-    const i64 k = base + threadIdx.x;
-    const bool inb = k < nPix;
-    bool valid = inb ? (byteMask ? (byteMask[k] != 0) : true) : false;
-    if (valid && (DtOf<T>::v >= DT_Float))
+    const i64 k0 = base + (i64)threadIdx.x * 4;
+    const bool whole = k0 + 3 < nPix;
+    u32 mask4 = 0x01010101u;    // byte q = pixel k0 + q is valid so far
+    if (byteMask)
     {
-      int nBad = 0;
-      for (int m = 0; m < nDepth; m++) nBad += isNaNT(data[k * nDepth + m]) ? 1 : 0;
-      if (nBad > 0) sawNaN = true;
-      if (nBad == nDepth) valid = false;
-      else if (nBad > 0) sawMixed = true;
+      if (whole && maskWords) mask4 = *reinterpret_cast<const u32*>(byteMask + k0);
+      else { mask4 = 0; for (int q = 0; q < 4; q++) if (k0 + q < nPix && byteMask[k0 + q]) mask4 |= 1u << (8 * q); }
     }
-    const u64 bal = __ballot(valid);
-    const u64 tail = __ballot(!inb);    // tail bits stay set, like BitMask::SetAllValid + SetInvalid (Lerc.cpp:959-975)
-    if (lane < 8)
+    T vals[4] = { T(0), T(0), T(0), T(0) };
+    if (dataQuads && whole && mask4)
     {
-      const i64 byteIdx = ((k - lane) >> 3) + lane;    // the wave's first pixel is a multiple of 64
-      if (byteIdx < nBytes)
+      struct alignas(4 * sizeof(T)) Quad { T v[4]; };
+      const Quad qd = *reinterpret_cast<const Quad*>(data + k0);
+      for (int q = 0; q < 4; q++) vals[q] = qd.v[q];
+    }
+    u32 nib = 0, tailNib = 0;    // bit 8 >> q: pixel k0 + q valid resp. behind the raster's end
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+      const i64 k = k0 + q;
+      const bool inb = k < nPix;
+      bool valid = inb && ((mask4 >> (8 * q)) & 0xFFu) != 0;
+      if (valid && isFlt)
       {
-        const u32 eight = (u32)(((bal | tail) >> (8 * lane)) & 0xFFull);
-        maskBits[byteIdx] = (u8)(__brev(eight) >> 24);    // pixel 8 j + i is bit 0x80 >> i of byte j
+        int nBad = 0;
+        if (dataQuads && whole) nBad = isNaNT(vals[q]) ? 1 : 0;
+        else for (int m = 0; m < nDepth; m++) nBad += isNaNT(data[k * nDepth + m]) ? 1 : 0;
+        if (nBad > 0) sawNaN = true;
+        if (nBad == nDepth) valid = false;
+        else if (nBad > 0) sawMixed = true;
       }
+      if (valid) nib |= 8u >> q;
+      if (!inb) tailNib |= 8u >> q;    // tail bits stay set, like BitMask::SetAllValid + SetInvalid (Lerc.cpp:959-975)
     }
-    cnt += (u32)__popcll(bal);
+    const u32 mine = nib | tailNib, other = __shfl_xor(mine, 1);
+    if (!(lane & 1))
+    {
+      const i64 byteIdx = k0 >> 3;    // pixel 8 j + i is bit 0x80 >> i of byte j
+      if (byteIdx < nBytes) maskBits[byteIdx] = (u8)((mine << 4) | other);
+    }
+    cnt += (u32)__popc(nib);
   }
+  cnt = waveSum(cnt);
   const bool anyNaN = __any(sawNaN), anyMixed = __any(sawMixed);
   if (lane == 0)
   {
@@ -212,7 +234,7 @@ void launchBuildMask(int dt, const void* data, const u8* byteMask, int nRows, in
                      BandStats* stats, hipStream_t stream)
 {
   const i64 nPix = (i64)nRows * nCols;
-  const dim3 grid((unsigned)std::min<i64>((nPix + 255) / 256, 4096)), block(256);
+  const dim3 grid((unsigned)std::min<i64>((nPix + 1023) / 1024, 4096)), block(256);
   switch (dt)
   {
     case DT_Float: hipLaunchKernelGGL(k_build_mask<float>, grid, block, 0, stream, (const float*)data, byteMask, nPix, nDepth, maskBits, stats); break;

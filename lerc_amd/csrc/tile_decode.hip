@@ -125,6 +125,7 @@ template<class T>
 __global__ void __launch_bounds__(256) k_decode_tiles(BandParams p, DecodeArgs a, DeviceStatus* st)
 {
   __shared__ u32 s_lut[4][256];
+  __shared__ u8 s_head[4][64];
   const int w = waveId(), lane = laneId();
   const int pos = (int)blockIdx.x * 4 + w;
   if (pos >= p.nTV * p.nTH) return;
@@ -155,15 +156,21 @@ __global__ void __launch_bounds__(256) k_decode_tiles(BandParams p, DecodeArgs a
   for (int iD = 0; iD < nD; iD++)
   {
     const u32 off = a.blockOff[(i64)pos * nD + iD];
+    // the block's first 64 bytes in one coalesced load: parsed lane by lane from global memory, the header's fields
+    // (flag -> offset type -> bit width -> count) are half a dozen dependent round trips.  parseBlock looks at no byte
+    // beyond the 15th of a block, so it is handed a view whose byte `off` is s_head[0].
+    s_head[w][lane] = ((u64)off + (u64)lane < (u64)a.blobEnd) ? blob[(u64)off + lane] : (u8)0;
+    waveSync();
+    const u8* headView = s_head[w] - (size_t)off;
     BlkInfo b;
-    const int rc = parseBlock<(int)sizeof(T)>(blob, off, a.blobEnd, p, nValid, (u32)nElem, b);
+    const int rc = parseBlock<(int)sizeof(T)>(headView, off, a.blobEnd, p, nValid, (u32)nElem, b);
     if (rc != 0 || (((u32)b.flag >> 2) & pattern) != (((u32)j0 >> 3) & pattern) || (b.diff && iD == 0))
     {
       failed = true;
       break;
     }
     double offset = 0;
-    if (b.mode == 1 || b.mode == 3) offset = typedFromBits(getBytes(blob + off + 1, b.offBytes), b.dtUsed);
+    if (b.mode == 1 || b.mode == 3) offset = typedFromBits(getBytes(s_head[w] + 1, b.offBytes), b.dtUsed);
     const double zMax = (p.version >= 4 && nD > 1) ? a.zMaxVec[iD] : p.zMaxHdr;
     const u64 payloadBit = 8ull * ((u64)off + b.payload);
     const int nbIdx = b.lut ? bitLen(b.nLut) : 0;
