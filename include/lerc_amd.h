@@ -51,7 +51,8 @@ LERC_AMD_API lerc_status lerc_encodeForVersion(const void* pData, int codecVersi
     int nCols, int nRows, int nBands, int nMasks, const unsigned char* pValidBytes, double maxZErr,
     unsigned char* pOutBuffer, unsigned int outBufferSize, unsigned int* nBytesWritten);
 
-/* reference Lerc_c_api.h:203-210 -- header walk only, runs on the host.
+/* reference Lerc_c_api.h:203-210 -- header walk only, runs on the host (legacy Lerc1 "CntZImage" blobs: the bands are
+ * decoded on the device to count valid pixels and find the range, as Lerc.cpp:184-266 does on the CPU).
  * infoArray: version, dataType, nDepth, nCols, nRows, nBands, nValidPixels(band 0), blobSize, nMasks,
  *            nDepth, nUsesNoDataValue;  dataRangeArray: zMin, zMax, maxZErrUsed (Lerc_types.h:34-56) */
 LERC_AMD_API lerc_status lerc_getBlobInfo(const unsigned char* pLercBlob, unsigned int blobSize,
@@ -61,7 +62,8 @@ LERC_AMD_API lerc_status lerc_getBlobInfo(const unsigned char* pLercBlob, unsign
 LERC_AMD_API lerc_status lerc_getDataRanges(const unsigned char* pLercBlob, unsigned int blobSize, int nDepth,
     int nBands, double* pMins, double* pMaxs);
 
-/* reference Lerc_c_api.h:238-252 -- pData / pValidBytes pre-allocated by the caller */
+/* reference Lerc_c_api.h:238-252 -- pData / pValidBytes pre-allocated by the caller.  Lerc2 codec 2..6 and Lerc1 blobs
+ * (Lerc1: pixels that are not valid keep what pData held, Lerc.cpp:2063-2107) */
 LERC_AMD_API lerc_status lerc_decode(const unsigned char* pLercBlob, unsigned int blobSize, int nMasks,
     unsigned char* pValidBytes, int nDepth, int nCols, int nRows, int nBands, unsigned int dataType, void* pData);
 
