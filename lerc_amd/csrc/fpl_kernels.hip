@@ -279,8 +279,21 @@ k_fpl_symbols(const typename UnitOf<U>::T* __restrict__ units, FplGeom g, FplLev
         if (in && k > 0 && s == prev) equal++;
         prev = s;
         if (in && k < 4) word |= s << (8 * k);
-        // histogram (the high planes hold a few values almost everywhere: see histogramAdd)
-        histogramAdd(&s_h[b * 256], s, in && k < 4);
+        // histogram.  The high planes hold a few values almost everywhere, and 64 lanes adding to one LDS word take 64
+        // turns: lanes that agree are counted by ballot and added once, as long as the groups are big
+        bool mine = in && k < 4;
+        u64 rest = __ballot(mine);
+        for (int round = 0; round < 4 && rest; round++)
+        {
+          const int leader = __ffsll((long long)rest) - 1;
+          const u32 sL = __shfl(s, leader);
+          const u64 m = __ballot(mine && s == sL);
+          if (__popcll(m) < 6) break;
+          if (lane == leader) atomicAdd(&s_h[b * 256 + sL], (u32)__popcll(m));
+          if (s == sL) mine = false;
+          rest &= ~m;
+        }
+        if (mine) atomicAdd(&s_h[b * 256 + s], 1u);
       }
       equal = waveSum(equal);
       if (lane == 0 && equal) atomicAdd(&s_h[U * 256 + b], equal);

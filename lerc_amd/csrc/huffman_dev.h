@@ -38,9 +38,6 @@ void launchHuffEmit(int dt, const u32* stream, u64 nWords, u64 streamBits, const
 // summed and interleaved by launchHuffUndeltaPlanar
 bool huffPlanarDecode(int imageMode, const u8* maskBits, int nDepth);
 void launchHuffUndeltaPlanar(u8* planar, void* out, const HuffGeom& g, hipStream_t st);
-// the encoder's counterpart (same condition): delta symbols plane by plane, which the run-bit and pack kernels then
-// take as a plain byte stream (DT_Byte, IEM_Huffman)
-void launchHuffDeltaSymbols(int dt, const void* data, const HuffGeom& g, u8* planar, hipStream_t st);
 void launchHuffUndelta(int dt, void* data, const u8* maskBits, const HuffGeom& g, hipStream_t st);
 
 }    // namespace lerc

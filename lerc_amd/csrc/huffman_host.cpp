@@ -375,17 +375,9 @@ bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
   hipMemcpyAsync(dCodes, hCodes, sizeof(hCodes), hipMemcpyHostToDevice, st);
   hipMemcpyAsync(dOut, plan.table.data(), plan.table.size(), hipMemcpyHostToDevice, st);
   hipMemsetAsync(dStream, 0, (size_t)nWords * 4, st);
-  int dtUse = dt, modeUse = plan.imageMode;
-  if (huffPlanarDecode(plan.imageMode, dMaskBits, nDepth))    // (the decoder's condition: delta mode, no mask, a few values per pixel)
-  {
-    u8* dSym = ctx.allocT<u8>((size_t)nElem + 16);
-    if (!dSym) return false;
-    { ProfScope ps(ctx, "huff_symbols"); launchHuffDeltaSymbols(dt, dData, g, dSym, st); }
-    dData = dSym; dtUse = DT_Byte; modeUse = IEM_Huffman;
-  }
-  { ProfScope ps(ctx, "huff_runbits"); launchHuffRunBits(dtUse, dData, dMaskBits, g, modeUse, dCodes, dRunBits, st); }
+  { ProfScope ps(ctx, "huff_runbits"); launchHuffRunBits(dt, dData, dMaskBits, g, plan.imageMode, dCodes, dRunBits, st); }
   { ProfScope ps(ctx, "huff_scan"); launchScan64(dRunBits, dRunBase, nRuns, dScr, st); }
-  { ProfScope ps(ctx, "huff_pack"); launchHuffPack(dtUse, dData, dMaskBits, g, modeUse, dCodes, dRunBase, dStream, st); }
+  { ProfScope ps(ctx, "huff_pack"); launchHuffPack(dt, dData, dMaskBits, g, plan.imageMode, dCodes, dRunBase, dStream, st); }
   hipMemcpyAsync(dOut + plan.table.size(), dStream, (size_t)nWords * 4, hipMemcpyDeviceToDevice, st);
   return hipStreamSynchronize(st) == hipSuccess;    // hCodes / plan.table are host temporaries
 }

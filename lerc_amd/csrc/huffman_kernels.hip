@@ -113,24 +113,19 @@ __global__ void __launch_bounds__(256) k_huff_histo(const T* __restrict__ data, 
   const i64 nPix = (i64)g.nRows * g.nCols;
   const i64 stride = (i64)gridDim.x * 256;
   const int off = (DtOf<T>::v == DT_Char) ? 128 : 0;
-  for (i64 k0 = (i64)blockIdx.x * 256; k0 < nPix; k0 += stride)    // (whole waves all the way: histogramAdd votes)
+  for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < nPix; k += stride)
   {
-    const i64 k = k0 + threadIdx.x;
-    const bool live = k < nPix && (!maskBits || maskBit(maskBits, k));
-    i64 kp = -1;
-    if (live)
-    {
-      const int i = (int)(k / g.nCols), j = (int)(k - (i64)i * g.nCols);
-      const bool left = j > 0 && (!maskBits || maskBit(maskBits, k - 1));
-      const bool up = !left && i > 0 && (!maskBits || maskBit(maskBits, k - g.nCols));
-      kp = left ? k - 1 : (up ? k - g.nCols : (maskBits ? prevValidPixel(maskBits, k) : -1));
-    }
+    if (maskBits && !maskBit(maskBits, k)) continue;
+    const int i = (int)(k / g.nCols), j = (int)(k - (i64)i * g.nCols);
+    const bool left = j > 0 && (!maskBits || maskBit(maskBits, k - 1));
+    const bool up = !left && i > 0 && (!maskBits || maskBit(maskBits, k - g.nCols));
+    const i64 kp = left ? k - 1 : (up ? k - g.nCols : (maskBits ? prevValidPixel(maskBits, k) : -1));
     for (int m = 0; m < g.nDepth; m++)
     {
-      const T val = live ? data[k * g.nDepth + m] : (T)0;
-      const T pred = (live && kp >= 0) ? data[kp * g.nDepth + m] : (T)0;
-      histogramAdd(s_h[0], (u32)(off + (int)val), live);
-      histogramAdd(s_h[1], (u32)(off + (int)(T)(val - pred)), live);
+      const T val = data[k * g.nDepth + m];
+      const T pred = (kp >= 0) ? data[kp * g.nDepth + m] : (T)0;
+      atomicAdd(&s_h[0][off + (int)val], 1u);
+      atomicAdd(&s_h[1][off + (int)(T)(val - pred)], 1u);
     }
   }
   __syncthreads();
@@ -702,64 +697,6 @@ __global__ void __launch_bounds__(256) k_huff_undelta_rows_interleave(const u8* 
     else for (int b = threadIdx.x; b < nBytes; b += 256) dst[b] = s_bytes[b];
     __syncthreads();
   }
-}
-
-// The encoder's side of the same detour: the delta symbols of a pixel-interleaved raster, plane by plane (the order of
-// the stream), made by a workgroup per 1024 pixels of a row out of one coalesced read -- histogram, run bits and packer
-// then see a plain byte stream instead of bytes nDepth apart.
-template<class T>
-__global__ void __launch_bounds__(256) k_huff_delta_symbols(const T* __restrict__ data, HuffGeom g, u8* __restrict__ planar)
-{
-  __shared__ u32 s_in[(1025 * kHuffInterleaveMax) / 4 + 4];
-  u8* s_bytes = reinterpret_cast<u8*>(s_in);    // pixel p of the chunk at (p + 1) * nDepth; slot 0: the pixel the first one is predicted from
-  const int nD = g.nDepth, i = (int)blockIdx.y, j0 = (int)blockIdx.x * 1024;
-  const int n = min(1024, g.nCols - j0);
-  const i64 nPix = (i64)g.nRows * g.nCols, row0 = (i64)i * g.nCols;
-  const u8* src = reinterpret_cast<const u8*>(data) + (row0 + j0) * nD;
-  const int nBytes = n * nD;
-  if ((((size_t)src) & 3u) == 0)
-    for (int b = (int)threadIdx.x * 4; b < nBytes; b += 1024)
-    {
-      if (b + 4 <= nBytes)
-      {
-        const u32 w = *reinterpret_cast<const u32*>(src + b);
-        for (int k = 0; k < 4; k++) s_bytes[nD + b + k] = (u8)(w >> (8 * k));
-      }
-      else for (int k = 0; b + k < nBytes; k++) s_bytes[nD + b + k] = src[b + k];
-    }
-  else for (int b = threadIdx.x; b < nBytes; b += 256) s_bytes[nD + b] = src[b];
-  if ((int)threadIdx.x < nD)
-  {
-    // left neighbour; first pixel of a row: the pixel above; first pixel of the plane: 0 (Lerc2.cpp:2355-2362)
-    u8 prev = 0;
-    if (j0 > 0) prev = src[(int)threadIdx.x - nD];
-    else if (i > 0) prev = reinterpret_cast<const u8*>(data)[(row0 - g.nCols) * nD + threadIdx.x];
-    s_bytes[threadIdx.x] = prev;
-  }
-  __syncthreads();
-  const u32 flip = (DtOf<T>::v == DT_Char) ? 0x80u : 0u;    // symbol = delta + 128 for signed bytes
-  const int p0 = (int)threadIdx.x * 4;
-  if (p0 >= n) return;
-  for (int iD = 0; iD < nD; iD++)
-  {
-    u32 word = 0;
-    int cnt = 0;
-    for (int k = 0; k < 4 && p0 + k < n; k++, cnt++)
-    {
-      const u32 val = s_bytes[(p0 + k + 1) * nD + iD], pred = s_bytes[(p0 + k) * nD + iD];
-      word |= (((val - pred) & 255u) ^ flip) << (8 * k);
-    }
-    u8* dst = planar + (i64)iD * nPix + row0 + j0 + p0;
-    if (cnt == 4 && (((size_t)dst) & 3u) == 0) *reinterpret_cast<u32*>(dst) = word;
-    else for (int k = 0; k < cnt; k++) dst[k] = (u8)(word >> (8 * k));
-  }
-}
-
-void launchHuffDeltaSymbols(int dt, const void* data, const HuffGeom& g, u8* planar, hipStream_t st)
-{
-  const dim3 grid((unsigned)((g.nCols + 1023) / 1024), (unsigned)g.nRows);
-  if (dt == DT_Char) hipLaunchKernelGGL(k_huff_delta_symbols<signed char>, grid, dim3(256), 0, st, (const signed char*)data, g, planar);
-  else hipLaunchKernelGGL(k_huff_delta_symbols<unsigned char>, grid, dim3(256), 0, st, (const unsigned char*)data, g, planar);
 }
 
 bool huffPlanarDecode(int imageMode, const u8* maskBits, int nDepth)

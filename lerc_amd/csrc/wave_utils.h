@@ -138,25 +138,6 @@ template<class T> __device__ __forceinline__ T waveMinT(T v) { return (T)waveMin
 template<class T> __device__ __forceinline__ T waveMaxT(T v) { return (T)waveMax((typename ShflT<T>::type)v); }
 
 // OR `nbits` (<= 32) of `value` into a little-endian bit stream held in 32-bit words (LDS).
-// One count for `sym` in an LDS histogram from every lane with `mine` set (call with whole waves).  64 lanes adding to one
-// LDS word take 64 turns, and smooth data puts most of a wave on two or three symbols: lanes that agree are counted by
-// ballot and added once, as long as the groups are big; scattered symbols go the plain way.
-__device__ __forceinline__ void histogramAdd(u32* hist, u32 sym, bool mine)
-{
-  u64 rest = __ballot(mine);
-  for (int round = 0; round < 4 && rest; round++)
-  {
-    const int leader = __ffsll((long long)rest) - 1;
-    const u32 sL = __shfl(sym, leader);
-    const u64 m = __ballot(mine && sym == sL);
-    if (__popcll(m) < 6) break;
-    if (laneId() == leader) atomicAdd(&hist[sL], (u32)__popcll(m));
-    if (sym == sL) mine = false;
-    rest &= ~m;
-  }
-  if (mine) atomicAdd(&hist[sym], 1u);
-}
-
 __device__ __forceinline__ void orBits(u32* words, u32 bitPos, u32 value, int nbits)
 {
   u32 w = bitPos >> 5, sh = bitPos & 31;
