@@ -274,6 +274,8 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   // host buffers the enqueued copies read from: kept until the call's final synchronisation instead of waiting per band
   std::vector<std::vector<u8> > keepBits;
   bool auxInFlight = false;    // the pinned mask area is the source of a copy that may not have run yet
+  bool maskPending = false;    // a band's mask bytes are fetched (maskRle) but not decoded / sent yet: finishMask()
+  std::vector<u8> maskRle;
   std::vector<std::vector<double> > keepZMax;
   struct Drain { Context& c; ~Drain() { c.sync(); } } drain{ ctx };    // (destroyed before the buffers above, on every way out)
   bool haveMask = false, maskAllValid = true;
@@ -333,29 +335,45 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     else if (nv == (int)nPix) { haveMask = true; maskAllValid = true; }
     else if (bd.numBytesMask > 0)
     {
-      small.resize((size_t)bd.numBytesMask);
-      if (!rd.read(at, small.size(), small.data())) return kFailed;
-      // the bits are put together in pinned memory and travel while the host goes on (the area is free again once its
-      // event has passed); without it: a pageable vector that lives until the final sync
-      u8* hostBits = nullptr;
-      if (ctx.auxEvent())
-      {
-        if (auxInFlight && hipEventSynchronize(ctx.auxEvent()) != hipSuccess) return kFailed;
-        auxInFlight = false;
-        hostBits = (u8*)ctx.pinnedAux(maskBytes);
-      }
-      const bool pinnedBits = hostBits != nullptr;
-      if (!pinnedBits) { keepBits.emplace_back(maskBytes, (u8)0); hostBits = keepBits.back().data(); }
-      size_t written = 0;
-      if (!rleDecode(small.data(), small.size(), hostBits, maskBytes, &written)) return kFailed;
-      if (pinnedBits && written < maskBytes) memset(hostBits + written, 0, maskBytes - written);
+      // fetched now (with the few header bytes behind it, so that the reads further down cost no round trip), decoded
+      // and sent to the device by finishMask() -- in tiling mode behind the launch of the chunk walk, which needs no mask
+      if (at + (u64)bd.numBytesMask > bd.offset + (u64)blobEnd) return kFailed;
+      const size_t extra = std::min<size_t>((size_t)2 * nD * tb + 2, (size_t)(bd.offset + (u64)blobEnd - (at + (u64)bd.numBytesMask)));
+      maskRle.resize((size_t)bd.numBytesMask + extra);
+      if (!rd.read(at, maskRle.size(), maskRle.data())) return kFailed;
+      rd.cache = maskRle.data(); rd.cacheOff = at; rd.cacheLen = maskRle.size();
       haveMask = true; maskAllValid = false;
-      hipMemcpyAsync(dBits, hostBits, maskBytes, hipMemcpyHostToDevice, st);
-      if (pinnedBits) { hipEventRecord(ctx.auxEvent(), st); auxInFlight = true; }
+      maskPending = true;
     }
     else if (!haveMask || maskAllValid) return kFailed;    // "use previous mask" without a usable one
     at += (u64)bd.numBytesMask;
     const u8* dMask = maskAllValid ? nullptr : dBits;
+    bool wantMaskBytes = iBand < rq.nMasks && rq.dValidBytes;
+    auto finishMask = [&]() -> bool
+    {
+      if (maskPending)
+      {
+        maskPending = false;
+        // the bits are put together in pinned memory and travel while the host goes on (the area is free again once its
+        // event has passed); without it: a pageable vector that lives until the final sync
+        u8* hostBits = nullptr;
+        if (ctx.auxEvent())
+        {
+          if (auxInFlight && hipEventSynchronize(ctx.auxEvent()) != hipSuccess) return false;
+          auxInFlight = false;
+          hostBits = (u8*)ctx.pinnedAux(maskBytes);
+        }
+        const bool pinnedBits = hostBits != nullptr;
+        if (!pinnedBits) { keepBits.emplace_back(maskBytes, (u8)0); hostBits = keepBits.back().data(); }
+        size_t written = 0;
+        if (!rleDecode(maskRle.data(), (size_t)bd.numBytesMask, hostBits, maskBytes, &written)) return false;
+        if (pinnedBits && written < maskBytes) memset(hostBits + written, 0, maskBytes - written);
+        hipMemcpyAsync(dBits, hostBits, maskBytes, hipMemcpyHostToDevice, st);
+        if (pinnedBits) { hipEventRecord(ctx.auxEvent(), st); auxInFlight = true; }
+      }
+      if (wantMaskBytes) { wantMaskBytes = false; launchBitsToBytes(dMask, rq.dValidBytes + (size_t)iBand * nPix, nPix, st); }
+      return true;
+    };
 
     // noData value of this band: handed out, and the remapped value in the decoded pixels turned back into the
     // caller's original one (Lerc.cpp:488-510) -- enqueued when the iteration is left, behind the band's kernels
@@ -372,10 +390,9 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
         epilogue.fn = [&, dMask, dOutBand]() { launchNoDataRemap(dt, dOutBand, nullptr, dMask, nPix, nD, hd.noDataVal, hd.noDataValOrig, st); };
     }
 
-    if (iBand < rq.nMasks && rq.dValidBytes)
-      launchBitsToBytes(dMask, rq.dValidBytes + (size_t)iBand * nPix, nPix, st);
 
     // ---- pixels
+    if (nv == 0 && !finishMask()) return kFailed;
     if (nv == 0) { hipMemsetAsync(dOutBand, 0, (size_t)nPix * nD * tb, st); continue; }
 
     std::vector<double> zMinVec(nD, hd.zMin), zMaxVec(nD, hd.zMax);
@@ -392,7 +409,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
       launchFill(dOutBand, dPixel, nD * tb, dMask, nPix, st);
       hipStreamSynchronize(st);    // `pixel` dies with this scope
     };
-    if (hd.zMin == hd.zMax) { fillConst(false); continue; }
+    if (hd.zMin == hd.zMax) { if (!finishMask()) return kFailed; fillConst(false); continue; }
 
     if (hd.version >= 4)
     {
@@ -404,13 +421,14 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
         zMaxVec[m] = typedFromBits(getBytes(&small[(size_t)(nD + m) * tb], tb), dt);
       }
       at += small.size();
-      if (0 == memcmp(zMinVec.data(), zMaxVec.data(), nD * sizeof(double))) { fillConst(true); continue; }
+      if (0 == memcmp(zMinVec.data(), zMaxVec.data(), nD * sizeof(double))) { if (!finishMask()) return kFailed; fillConst(true); continue; }
     }
     u8 flags[2] = { 0, 0 };
     if (at - bd.offset >= blobEnd || !rd.read(at, 1, flags)) return kFailed;
     at += 1;
     if (flags[0])
     {
+      if (!finishMask()) return kFailed;
       // one sweep: valid pixels stored raw in order (Lerc2.cpp:1368-1400)
       if ((u64)(at - bd.offset) + (u64)nv * nD * tb > blobEnd) return kFailed;
       const u8* src = dBlob + at;
@@ -440,6 +458,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     }
     if (imageMode != IEM_Tiling)
     {
+      if (!finishMask()) return kFailed;
       if (hd.tryHuffmanFlt())
       {
         if (imageMode != IEM_DeltaDeltaHuffman) return kFailed;    // Lerc2.cpp:674-678
@@ -500,11 +519,14 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     {
       nValidBlk = ctx.allocT<u16>((size_t)bp.nTV * bp.nTH + 4);
       if (!nValidBlk) return kFailed;
-      launchBlockValidCounts(dMask, bp, nValidBlk, st);
     }
     wb.nValidBlk = nValidBlk;
     if (!wb.chunkExit || !wb.chunkEntry || !wb.chunkCount || !wb.chunkBase || !wb.blockOff || !wb.scratch) return kFailed;
-    { ProfScope ps(ctx, "walk_offsets"); launchWalk(bp, wp, da, wb, dStatus, st); }
+    // the chunk candidates need no mask: they run while the host decodes the mask's RLE and sends the bits
+    { ProfScope ps(ctx, "walk_chunks"); launchWalkChunks(bp, wp, da, wb, st); }
+    if (!finishMask()) return kFailed;
+    if (nValidBlk) launchBlockValidCounts(dMask, bp, nValidBlk, st);
+    { ProfScope ps(ctx, "walk_offsets"); launchWalkRest(bp, wp, da, wb, dStatus, st); }
     da.blockOff = wb.blockOff;
     { ProfScope ps(ctx, "tile_decode"); launchTileDecode(dt, bp, da, dStatus, st); }
   }

@@ -65,6 +65,10 @@ void launchLerc1Decode(int dt, const Lerc1Geom& g, const u8* part, u32 partBytes
 WalkPlan makeWalkPlan(const BandParams& p, u32 dataBegin, u32 blobEnd, int numValid);
 void launchWalk(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, DeviceStatus* st,
                 hipStream_t stream);
+// the same in two parts: the chunk candidates (no mask, no valid counts needed), then the rest
+void launchWalkChunks(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, hipStream_t stream);
+void launchWalkRest(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, DeviceStatus* st,
+                    hipStream_t stream);
 
 // ---- misc_kernels.hip --------------------------------------------------------------------------
 // exclusive scan of n u32 values; out[n] receives the total.  scratch >= n/1024 + 2 words.

@@ -615,17 +615,23 @@ __global__ void __launch_bounds__(256) k_walk_emit(BandParams p, WalkPlan wp, co
   }
 }
 
+// candidates per chunk -> exits the candidates agree on -> counts where the entry is known -> one sweep that closes
+// the gaps (and sizes the raw blocks of masked / ragged bands, whose length hangs on the block index) -> offsets.
+// The first step needs neither the mask nor the blocks' valid counts and is launched on its own.
 template<int TBYTES>
-static void launchWalkT(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, DeviceStatus* st,
-                        hipStream_t stream)
+static void launchWalkChunksT(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, hipStream_t stream)
 {
-  // candidates per chunk -> exits the candidates agree on -> counts where the entry is known -> one sweep that closes
-  // the gaps (and sizes the raw blocks of masked / ragged bands, whose length hangs on the block index) -> offsets
-  const dim3 gridC((wp.nChunks + 255) / 256);
   if (wp.chunkBytes <= kMemoChunk && wp.window <= kMemoWindowMax)
     hipLaunchKernelGGL(k_walk_chunks_memo<TBYTES>, dim3(wp.nChunks), dim3(64), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit);
   else
     hipLaunchKernelGGL(k_walk_chunks<TBYTES>, dim3(wp.nChunks), dim3(64), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit);
+}
+
+template<int TBYTES>
+static void launchWalkRestT(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, DeviceStatus* st,
+                            hipStream_t stream)
+{
+  const dim3 gridC((wp.nChunks + 255) / 256);
   hipLaunchKernelGGL(k_walk_counts<TBYTES>, gridC, dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, (const u32*)wb.chunkExit,
                      wb.chunkCount, wb.chunkEntry);
   hipLaunchKernelGGL(k_walk_sweep<TBYTES>, dim3(1), dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, (const u32*)wb.chunkExit,
@@ -634,16 +640,34 @@ static void launchWalkT(const BandParams& p, const WalkPlan& wp, const DecodeArg
                      (const u32*)wb.chunkBase, wb.nValidBlk, wb.blockOff, st);
 }
 
-void launchWalk(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, DeviceStatus* st,
-                hipStream_t stream)
+void launchWalkChunks(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, hipStream_t stream)
 {
   switch (dtSize(p.dt))
   {
-    case 1: launchWalkT<1>(p, wp, a, wb, st, stream); break;
-    case 2: launchWalkT<2>(p, wp, a, wb, st, stream); break;
-    case 4: launchWalkT<4>(p, wp, a, wb, st, stream); break;
-    default: launchWalkT<8>(p, wp, a, wb, st, stream); break;
+    case 1: launchWalkChunksT<1>(p, wp, a, wb, stream); break;
+    case 2: launchWalkChunksT<2>(p, wp, a, wb, stream); break;
+    case 4: launchWalkChunksT<4>(p, wp, a, wb, stream); break;
+    default: launchWalkChunksT<8>(p, wp, a, wb, stream); break;
   }
+}
+
+void launchWalkRest(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, DeviceStatus* st,
+                    hipStream_t stream)
+{
+  switch (dtSize(p.dt))
+  {
+    case 1: launchWalkRestT<1>(p, wp, a, wb, st, stream); break;
+    case 2: launchWalkRestT<2>(p, wp, a, wb, st, stream); break;
+    case 4: launchWalkRestT<4>(p, wp, a, wb, st, stream); break;
+    default: launchWalkRestT<8>(p, wp, a, wb, st, stream); break;
+  }
+}
+
+void launchWalk(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, DeviceStatus* st,
+                hipStream_t stream)
+{
+  launchWalkChunks(p, wp, a, wb, stream);
+  launchWalkRest(p, wp, a, wb, st, stream);
 }
 
 }    // namespace lerc
