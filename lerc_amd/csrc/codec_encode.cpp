@@ -9,6 +9,7 @@
 #include "tile_fast.h"
 #include <cfloat>
 #include <functional>
+#include <future>
 
 #include <algorithm>
 #include <cmath>
@@ -245,6 +246,28 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   int bandNumValid = (int)nPix;
   bool modifiedMask = false;
   bool haveBits = false;    // dNewBits holds this band's bit mask
+  // single band: the bits travel to pinned host memory as soon as they are final, and a helper thread codes their RLE
+  // (a millisecond for the 8 MB of an 8192 x 8192 mask) while this thread goes on launching and waiting for kernels
+  const u8* bitsOnTheWay = nullptr;
+  size_t nBitsOnTheWay = 0;
+  std::future<std::vector<u8> > rleFuture;
+  auto sendBitsHome = [&]() -> bool
+  {
+    const size_t nb = (size_t)((nPix + 7) >> 3);
+    u8* pin = (u8*)ctx.pinnedAux(nb);
+    if (!pin) return false;
+    hipMemcpyAsync(pin, dNewBits, nb, hipMemcpyDeviceToHost, st);
+    hipEvent_t ev = ctx.auxEvent();
+    hipEventRecord(ev, st);
+    bitsOnTheWay = pin; nBitsOnTheWay = nb;
+    rleFuture = std::async(std::launch::async, [pin, nb, ev]()
+    {
+      std::vector<u8> out;
+      if (hipEventSynchronize(ev) == hipSuccess) rleEncode(pin, nb, out);
+      return out;    // (empty: the copy failed; an RLE stream is never empty)
+    });
+    return true;
+  };
   auto buildMask = [&]() -> bool
   {
     hipMemsetAsync(dStats, 0, sizeof(BandStats), st);
@@ -254,6 +277,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     bandNumValid = (int)hr.stats.numValid;
     bandAllValid = (bandNumValid == (int)nPix);
     haveBits = true;
+    if (rq.nBands == 1 && !bandAllValid && bandNumValid > 0 && ctx.auxEvent() && !sendBitsHome()) return false;
     return true;
   };
   if (dByteMask && !buildMask()) return kFailed;
@@ -317,20 +341,9 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
 
   // ---- mask bookkeeping across bands (Lerc.cpp:717-741)
   std::vector<u8> hBandBits;
-  const u8* bitsOnTheWay = nullptr;    // single band: the bits travel while the tile kernels run, the host picks them up for the RLE
-  size_t nBitsOnTheWay = 0;
-  if (haveBits && !bandAllValid)
+  if (haveBits && !bandAllValid && !bitsOnTheWay)
   {
     const size_t nb = (size_t)((nPix + 7) >> 3);
-    if (rq.nBands == 1 && ctx.auxEvent())
-    {
-      u8* pin = (u8*)ctx.pinnedAux(nb);
-      if (!pin) return kFailed;
-      hipMemcpyAsync(pin, dNewBits, nb, hipMemcpyDeviceToHost, st);
-      hipEventRecord(ctx.auxEvent(), st);
-      bitsOnTheWay = pin; nBitsOnTheWay = nb;
-    }
-    else
     {
       hBandBits.resize(nb);
       u8* pin = (u8*)ctx.pinned(nb);    // (a pageable target costs a staging copy at ~1 GB/s)
@@ -456,11 +469,10 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   {
     if (maskCoded) return true;
     maskCoded = true;
-    // (the copy must have landed in any case: the pinned area takes the blob's prefix next)
-    if (bitsOnTheWay && hipEventSynchronize(ctx.auxEvent()) != hipSuccess) return false;
-    if (!(needMask && encMask)) return true;
-    if (bitsOnTheWay) rleEncode(bitsOnTheWay, nBitsOnTheWay, rle);
-    else rleEncode(ms.hBits.data(), ms.hBits.size(), rle);
+    // (the helper must be through in any case: the pinned area takes the blob's prefix next)
+    if (rleFuture.valid()) { rle = rleFuture.get(); if (rle.empty()) return false; }
+    if (!(needMask && encMask)) { rle.clear(); return true; }
+    if (!bitsOnTheWay) rleEncode(ms.hBits.data(), ms.hBits.size(), rle);
     blobSize += (u32)rle.size();
     return true;
   };
