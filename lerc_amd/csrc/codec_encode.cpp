@@ -260,6 +260,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     hipEvent_t ev = ctx.auxEvent();
     hipEventRecord(ev, st);
     bitsOnTheWay = pin; nBitsOnTheWay = nb;
+    if (nb < (256u << 10)) return true;    // small masks: codeMask() does it in line (starting a thread costs ~30 us)
     rleFuture = std::async(std::launch::async, [pin, nb, ev]()
     {
       std::vector<u8> out;
@@ -470,9 +471,15 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     if (maskCoded) return true;
     maskCoded = true;
     // (the helper must be through in any case: the pinned area takes the blob's prefix next)
-    if (rleFuture.valid()) { rle = rleFuture.get(); if (rle.empty()) return false; }
+    const bool helped = rleFuture.valid();
+    if (helped) { rle = rleFuture.get(); if (rle.empty()) return false; }
+    else if (bitsOnTheWay && hipEventSynchronize(ctx.auxEvent()) != hipSuccess) return false;
     if (!(needMask && encMask)) { rle.clear(); return true; }
-    if (!bitsOnTheWay) rleEncode(ms.hBits.data(), ms.hBits.size(), rle);
+    if (!helped)
+    {
+      if (bitsOnTheWay) rleEncode(bitsOnTheWay, nBitsOnTheWay, rle);
+      else rleEncode(ms.hBits.data(), ms.hBits.size(), rle);
+    }
     blobSize += (u32)rle.size();
     return true;
   };
