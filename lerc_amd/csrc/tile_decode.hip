@@ -353,17 +353,21 @@ __global__ void __launch_bounds__(64) k_walk_chunks(BandParams p, WalkPlan wp, c
 // paths by table look-up instead of parsing ~40 blocks each out of global memory.
 static const u32 kMemoChunk = 4096, kMemoWindowMax = 1100;
 
+// Four waves share a chunk's tables and take every fourth round of 64 candidates: four times the waves per CU for the
+// same LDS, and a chunk is through after little more than its most expensive round.  (A wave may miss an exit another
+// wave is just writing -- it then walks on as it would have.)
 template<int TBYTES>
-__global__ void __launch_bounds__(64) k_walk_chunks_memo(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin,
+__global__ void __launch_bounds__(256) k_walk_chunks_memo(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin,
                                                          u32 blobEnd, u32* __restrict__ chunkExit)
 {
   __shared__ __align__(16) u8 s_bytes[kMemoChunk + kMemoWindowMax + 48];
   // 16-bit tables (21 KB with the bytes: seven of these one-wave workgroups per CU instead of four)
   __shared__ __align__(16) u16 s_next[kMemoChunk];    // 0 = not parsed yet; kNoBlock / kRawUnknown; else len (< 4096) | sig << 12
   __shared__ __align__(16) u16 s_exitOf[kMemoChunk];  // 0 = unknown; else 1 + (where a walk through this block start leaves the chunk - chunkStart)
+  __shared__ u32 s_agreed[4], s_conflict[4];
   const u32 kNoBlock = 0xFFFFu, kRawUnknown = 0xFFFEu;
   const u32 c = blockIdx.x;
-  const int lane = laneId();
+  const int lane = laneId(), wv = waveId();
   const u32 chunkStart = dataBegin + c * wp.chunkBytes;
   const u32 chunkEnd = min(chunkStart + wp.chunkBytes, blobEnd);
   const u32 stageEnd = min(chunkEnd + wp.window, blobEnd);
@@ -377,7 +381,7 @@ __global__ void __launch_bounds__(64) k_walk_chunks_memo(BandParams p, WalkPlan 
   const u32 kUnknown = 0xFFFFFFFEu;
   // stage with 16-byte loads from the aligned-down start (never past the blob's end); LDS byte i + shift <-> blob byte chunkStart + i
   const u32 a0 = chunkStart & ~15u, shift = chunkStart - a0;
-  for (u32 v = (u32)lane; a0 + 16u * v < stageEnd; v += 64u)
+  for (u32 v = threadIdx.x; a0 + 16u * v < stageEnd; v += 256u)
   {
     const u32 g = a0 + 16u * v;
     uint4 x = make_uint4(0, 0, 0, 0);
@@ -385,17 +389,17 @@ __global__ void __launch_bounds__(64) k_walk_chunks_memo(BandParams p, WalkPlan 
     else for (u32 k2 = 0; k2 < 16u && g + k2 < blobEnd; k2++) (&x.x)[k2 >> 2] |= (u32)blob[g + k2] << (8u * (k2 & 3u));
     *reinterpret_cast<uint4*>(&s_bytes[16u * v]) = x;
   }
-  for (u32 i = (u32)lane; i < kMemoChunk / 8u; i += 64u)
+  for (u32 i = threadIdx.x; i < kMemoChunk / 8u; i += 256u)
   {
     reinterpret_cast<uint4*>(s_next)[i] = make_uint4(0, 0, 0, 0);
     reinterpret_cast<uint4*>(s_exitOf)[i] = make_uint4(0, 0, 0, 0);
   }
-  waveSync();
+  __syncthreads();
   const u8* s_chunk = s_bytes + shift;
 
   u32 agreed = kNone;
   bool conflict = false;
-  for (u32 r0 = chunkStart; r0 < winEnd; r0 += 64)
+  for (u32 r0 = chunkStart + 64u * (u32)wv; r0 < winEnd; r0 += 256u)
   {
     u32 cur = r0 + (u32)lane;
     bool alive = cur < winEnd;
@@ -456,7 +460,19 @@ __global__ void __launch_bounds__(64) k_walk_chunks_memo(BandParams p, WalkPlan 
       else if (agreed != lo) conflict = true;
     }
   }
-  if (lane == 0) chunkExit[c] = (!conflict && agreed != kNone && agreed != kUnknown) ? agreed : kNone;
+  if (lane == 0) { s_agreed[wv] = agreed; s_conflict[wv] = conflict ? 1u : 0u; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    for (int k = 1; k < 4; k++)
+    {
+      if (s_conflict[k]) conflict = true;
+      if (s_agreed[k] == kNone) continue;
+      if (agreed == kNone) agreed = s_agreed[k];
+      else if (agreed != s_agreed[k]) conflict = true;
+    }
+    chunkExit[c] = (!conflict && agreed != kNone && agreed != kUnknown) ? agreed : kNone;
+  }
 }
 
 // D2: one lane per chunk whose entry is known (= the agreed exit of its predecessor) walks it: number of sub-blocks
@@ -622,7 +638,7 @@ template<int TBYTES>
 static void launchWalkChunksT(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, hipStream_t stream)
 {
   if (wp.chunkBytes <= kMemoChunk && wp.window <= kMemoWindowMax)
-    hipLaunchKernelGGL(k_walk_chunks_memo<TBYTES>, dim3(wp.nChunks), dim3(64), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit);
+    hipLaunchKernelGGL(k_walk_chunks_memo<TBYTES>, dim3(wp.nChunks), dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit);
   else
     hipLaunchKernelGGL(k_walk_chunks<TBYTES>, dim3(wp.nChunks), dim3(64), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit);
 }
