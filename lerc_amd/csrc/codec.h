@@ -45,6 +45,7 @@ public:
 
   // bump allocation out of one device slab; reserve() may re-allocate (invalidates earlier pointers)
   bool reserve(size_t bytes);
+  void poisonScratch(size_t bytes);          // test aid, see codec_common.cpp
   void reset() { m_used = 0; }
   size_t used() const { return m_used; }
   void rewind(size_t mark) { m_used = mark; }    // gives back everything allocated since used() returned mark

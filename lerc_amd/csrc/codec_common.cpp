@@ -251,12 +251,23 @@ Context::~Context()
 bool Context::reserve(size_t bytes)
 {
   m_used = 0;
-  if (bytes <= m_cap) return true;
+  if (bytes <= m_cap) { poisonScratch(bytes); return true; }
   if (m_slab) { hipStreamSynchronize(activeStream()); hipFree(m_slab); m_slab = nullptr; m_cap = 0; }
   const size_t want = bytes + bytes / 8 + (1u << 20);
   if (hipMalloc((void**)&m_slab, want) != hipSuccess) { lastError = "lerc_amd: hipMalloc failed"; return false; }
   m_cap = want;
+  poisonScratch(bytes);
   return true;
+}
+
+// Test aid: LERC_AMD_POISON=<byte> fills the scratch a call is about to use with that byte, so that a kernel reading what
+// nobody wrote (block offsets of a damaged blob, say) meets 0xA5A5A5A5 or 0xFFFFFFFF instead of the zeros of a fresh
+// allocation or the plausible leftovers of the call before (tests/test_sim_kernels.py runs the damaged-blob cases that way).
+void Context::poisonScratch(size_t bytes)
+{
+  static const char* env = getenv("LERC_AMD_POISON");
+  if (!env || !m_slab) return;
+  hipMemsetAsync(m_slab, (int)strtol(env, nullptr, 0) & 255, bytes < m_cap ? bytes : m_cap, activeStream());
 }
 
 void* Context::alloc(size_t bytes, size_t align)

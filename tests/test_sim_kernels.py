@@ -475,3 +475,16 @@ def test_sim_lerc1_world(libs):
         assert (g1[0] == 0) == (g2[0] == 0), (t, k)
         if g1[0] == 0:
             assert _same(g1[1], g2[1]) and _same(g1[2], g2[2]), (t, k)
+
+
+def test_sim_poisoned_scratch():
+    """The damaged-blob cases once more in a process whose scratch memory is filled with 0xFF before every call
+    (LERC_AMD_POISON, codec_common.cpp): a kernel that trusts what nobody wrote -- the block offsets a refused walk
+    leaves unwritten, say -- meets 0xFFFFFFFF here instead of the zeros of a fresh allocation.  (On the GPU such a read
+    once made a staging loop run away for minutes; the emulator, whose scratch starts zeroed, had not shown it.)"""
+    import subprocess
+    import sys
+    env = dict(os.environ, LERC_AMD_POISON="0xFF")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "damaged or lerc1_world"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
