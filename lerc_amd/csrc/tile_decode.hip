@@ -125,10 +125,7 @@ template<class T>
 __global__ void __launch_bounds__(256) k_decode_tiles(BandParams p, DecodeArgs a, DeviceStatus* st)
 {
   __shared__ u32 s_lut[4][256];
-  // the wave's block, staged with aligned 32-bit loads: header fields and bit fields are then LDS reads instead of
-  // up to five predicated byte loads per element from global memory
-  constexpr u32 kStageMax = 1u + 256u * (u32)sizeof(T) + 16u;
-  __shared__ __align__(16) u8 s_blk[4][(kStageMax + 8u + 15u) & ~15u];
+  __shared__ u8 s_head[4][64];
   const int w = waveId(), lane = laneId();
   const int pos = (int)blockIdx.x * 4 + w;
   if (pos >= p.nTV * p.nTH) return;
@@ -159,37 +156,20 @@ __global__ void __launch_bounds__(256) k_decode_tiles(BandParams p, DecodeArgs a
   for (int iD = 0; iD < nD; iD++)
   {
     const u32 off = a.blockOff[(i64)pos * nD + iD];
-    // the block (as long as any encoder writes one) is staged with coalesced aligned loads and read through a view whose
-    // byte `off` is the block's first byte: parsed lane by lane from global memory, the header's fields (flag -> offset
-    // type -> bit width -> count) alone are half a dozen dependent round trips
-    const u32 a0 = off & ~3u;    // (the blob's base is 4-byte aligned for every caller; if not, the loads below go byte by byte)
-    const u32 want = (off < a.blobEnd) ? min(1u + (u32)nElem * (u32)sizeof(T) + 16u, a.blobEnd - off) : 0u;
-    const u32 staged = want;
-    {
-      const bool words = (((size_t)blob) & 3u) == 0;
-      // (counted from the block's start: `off` may be anything when a damaged blob left its offset unwritten)
-      const u32 nStage = want ? (off - a0) + want : 0u;    // <= kStageMax + 3
-      for (u32 i = 4u * (u32)lane; i < nStage; i += 256u)
-      {
-        const u32 g = a0 + i;
-        u32 x = 0;
-        if (words && (u64)g + 4u <= (u64)a.blobEnd) x = *reinterpret_cast<const u32*>(blob + g);
-        else for (u32 k = 0; k < 4u && (u64)g + k < (u64)a.blobEnd; k++) x |= (u32)blob[g + k] << (8u * k);
-        *reinterpret_cast<u32*>(&s_blk[w][i]) = x;
-      }
-    }
+    // the block's first 64 bytes in one coalesced load: parsed lane by lane from global memory, the header's fields
+    // (flag -> offset type -> bit width -> count) are half a dozen dependent round trips.  parseBlock looks at no byte
+    // beyond the 15th of a block.
+    s_head[w][lane] = ((u64)off + (u64)lane < (u64)a.blobEnd) ? blob[(u64)off + lane] : (u8)0;
     waveSync();
-    const u8* ldsView = s_blk[w] + (off - a0) - (size_t)off;    // byte `off` of the view is the block's first byte
-    BlkInfo b;
-    const int rc = parseBlock<(int)sizeof(T)>(ldsView, off, a.blobEnd, p, nValid, (u32)nElem, b);
+    BlkInfo b;    // (parsed relative to the block's start: position 0, the blob's end as seen from there)
+    const int rc = (off < a.blobEnd) ? parseBlock<(int)sizeof(T)>(s_head[w], 0u, a.blobEnd - off, p, nValid, (u32)nElem, b) : 1;
     if (rc != 0 || (((u32)b.flag >> 2) & pattern) != (((u32)j0 >> 3) & pattern) || (b.diff && iD == 0))
     {
       failed = true;
       break;
     }
     double offset = 0;
-    const u8* view = (rc == 0 && b.len <= staged) ? ldsView : blob;    // (a block longer than any encoder writes: from global memory)
-    if (b.mode == 1 || b.mode == 3) offset = typedFromBits(getBytes(ldsView + off + 1, b.offBytes), b.dtUsed);
+    if (b.mode == 1 || b.mode == 3) offset = typedFromBits(getBytes(s_head[w] + 1, b.offBytes), b.dtUsed);
     const double zMax = (p.version >= 4 && nD > 1) ? a.zMaxVec[iD] : p.zMaxHdr;
     const u64 payloadBit = 8ull * ((u64)off + b.payload);
     const int nbIdx = b.lut ? bitLen(b.nLut) : 0;
@@ -197,7 +177,7 @@ __global__ void __launch_bounds__(256) k_decode_tiles(BandParams p, DecodeArgs a
     if (b.mode == 1 && b.lut)
     {
       s_lut[w][0] = 0;
-      for (u32 i = (u32)lane; i < b.nLut; i += 64) s_lut[w][i + 1] = unstuffElement(view, payloadBit, i, b.nb, b.nLut, a.blobEnd, p.version);
+      for (u32 i = (u32)lane; i < b.nLut; i += 64) s_lut[w][i + 1] = unstuffElement(blob, payloadBit, i, b.nb, b.nLut, a.blobEnd, p.version);
       idxBit = payloadBit + 8ull * (((u64)b.nLut * b.nb + 7) >> 3);
       waveSync();
     }
@@ -222,7 +202,7 @@ __global__ void __launch_bounds__(256) k_decode_tiles(BandParams p, DecodeArgs a
         if (b.mode == 2) val = b.diff ? out[m - 1] : T(0);
         else if (b.mode == 0)
         {
-          const u64 bits = getBytes(view + off + 1 + (u64)rank * sizeof(T), (int)sizeof(T));
+          const u64 bits = getBytes(blob + off + 1 + (u64)rank * sizeof(T), (int)sizeof(T));
           memcpy(&val, &bits, sizeof(T));
         }
         else if (b.mode == 3)
@@ -233,10 +213,10 @@ __global__ void __launch_bounds__(256) k_decode_tiles(BandParams p, DecodeArgs a
         else
         {
           u32 q;
-          if (!b.lut) q = unstuffElement(view, payloadBit, (u32)rank, b.nb, b.cnt, a.blobEnd, p.version);
+          if (!b.lut) q = unstuffElement(blob, payloadBit, (u32)rank, b.nb, b.cnt, a.blobEnd, p.version);
           else
           {
-            const u32 ix = unstuffElement(view, idxBit, (u32)rank, nbIdx, b.cnt, a.blobEnd, p.version);
+            const u32 ix = unstuffElement(blob, idxBit, (u32)rank, nbIdx, b.cnt, a.blobEnd, p.version);
             if (ix > b.nLut) { badIdx = true; q = 0; } else q = s_lut[w][ix];
           }
           double z = offset + (double)q * p.invScale;
