@@ -276,6 +276,46 @@ def check_deep_pixel_case(T, P, name, arr, e, kw, same):
     assert T.data_ranges(b1, nd, 1) == P.data_ranges(b1, nd, 1), name
 
 
+def lerc1_cases(seed=23):
+    """Legacy Lerc1 blobs from tests/lerc1_writer.py (the reference has a Lerc1 decoder, no encoder, and one fixture):
+    masks and none, tile grids with remainder rows / columns, raw / constant / zero / bit-stuffed tiles with float, int16 and
+    int8 offsets, several bands.  -> [(name, blob, n_bands)]"""
+    import lerc1_writer
+    rng = np.random.default_rng(seed)
+    out = []
+    for it, (h, w, tiles, e, masked, nb, raw_every) in enumerate([
+            (40, 56, (5, 7), 0.1, True, 1, 0), (33, 47, (4, 5), 0.01, True, 1, 3), (64, 64, (8, 8), 0.5, False, 1, 0),
+            (17, 300, (2, 9), 1.0, True, 2, 5), (100, 90, (1, 1), 0.05, False, 1, 0), (57, 61, (7, 6), 0.25, True, 3, 4),
+            (8, 8, (1, 1), 0.0, False, 1, 0), (129, 130, (16, 16), 0.1, True, 1, 7), (23, 5, (23, 5), 0.1, True, 1, 2)]):
+        bands = []
+        for b in range(nb):
+            z = terrain(h, w, rng, amp=float(rng.choice([5, 300, 3000])), base=float(rng.choice([-50, 0, 1000])), sigma=0.3)
+            if it % 3 == 1:
+                z = np.floor(z)                      # integer offsets -> int8 / int16 offset types
+            z[: h // 4, : w // 3] = 0.0              # all-zero tiles
+            z[h // 2:, w // 2:] = 17.0 if it % 2 else -1234.5    # constant tiles
+            bands.append(z.astype(np.float32))
+        mask = None
+        if masked:
+            mask = (rng.random((h, w)) > 0.15).astype(np.uint8)
+            mask[h // 3: h // 3 + 6, :] = 0
+            mask[:, w // 5: w // 5 + 3] = 1
+        out.append((f"lerc1-{h}x{w}-t{tiles[0]}x{tiles[1]}-e{e}-b{nb}-{'mask' if masked else 'full'}",
+                    lerc1_writer.write(bands, mask, e, tiles, rng, raw_every), nb))
+    return out
+
+
+def check_lerc1_case(T, P, name, blob, n_bands, same):
+    """T: trusted library, P: library under test: info, ranges, pixels (float and double) and mask"""
+    ti, pi = T.blob_info(blob), P.blob_info(blob)
+    assert ti == pi and ti[0] == 0 and ti[1][0] == 0 and ti[1][5] == n_bands, (name, ti, pi)
+    assert T.data_ranges(blob, 1, n_bands) == P.data_ranges(blob, 1, n_bands), name
+    for dbl in (False, True):
+        d1, d2 = T.decode(blob, to_double=dbl), P.decode(blob, to_double=dbl)
+        assert d1[0] == d2[0] == 0, (name, d1[0], d2[0])
+        assert same(d1[1], d2[1]) and same(d1[2], d2[2]), name
+
+
 def lossless_float_cases(n_iter, seed=91, max_side=150):
     """maxZErr == 0 on float / double rasters (Lerc2 IEM_DeltaDeltaHuffman, fpl_*): smooth, noisy, stepped and random
     data so that every predictor (none / rows / rows + columns), difference order and plane coding (Huffman, one value,

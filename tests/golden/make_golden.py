@@ -11,6 +11,7 @@ Outputs (data only -- inputs and expected outputs, never reference source text):
                             sha256(decoded bytes), sha256(mask), getBlobInfo arrays
   blobs/<case>.lerc2        full reference blobs for a handful of cases (decode fixtures)
   fpl_vectors.json, blobs/fpl-*.lerc2   the same for lossless float / double rasters (cases.lossless_float_cases)
+  lerc1_vectors.json                    the reference's reading of the Lerc1 blobs of cases.lerc1_cases (tests/lerc1_writer.py)
 """
 import hashlib
 import json
@@ -112,9 +113,32 @@ def main_lossless_float():
     print("wrote", len(vec), "lossless float vectors,", kept, "blobs")
 
 
+def main_lerc1():
+    """lerc1_vectors.json: what the real reference makes of the Lerc1 blobs of cases.lerc1_cases (written by
+    tests/lerc1_writer.py: the reference has a Lerc1 decoder and no encoder) -- blob digest (so that a drifting writer
+    is noticed), info, ranges, digests of the decoded pixels (float and double; the harness presets the output, so pixels
+    that are not valid are the same everywhere) and of the mask"""
+    R = capi.ref()
+    assert R is not None, "build oracle/_ref first (make -C oracle ref)"
+    vec = {}
+    for name, blob, nb in cases.lerc1_cases():
+        rc, info, rng = R.blob_info(blob)
+        d = R.decode(blob)
+        dd = R.decode(blob, to_double=True)
+        assert rc == 0 and d[0] == 0 and dd[0] == 0, name
+        vec[name] = {"blob_sha": sha(blob), "info": info, "range": rng, "ranges": list(R.data_ranges(blob, 1, nb)),
+                     "dec_sha": sha(d[1].tobytes()), "dec_double_sha": sha(dd[1].tobytes()),
+                     "mask_sha": sha(d[2].tobytes()) if d[2] is not None else None}
+    json.dump(vec, open(os.path.join(HERE, "lerc1_vectors.json"), "w"), indent=0, sort_keys=True)
+    print("wrote", len(vec), "Lerc1 vectors")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "lossless-float":
         main_lossless_float()
+    elif len(sys.argv) > 1 and sys.argv[1] == "lerc1":
+        main_lerc1()
     else:
         main()
         main_lossless_float()
+        main_lerc1()

@@ -161,3 +161,18 @@ def test_lerc1_world(O):
     m = mask.reshape(257, 257).astype(bool)
     assert int(m.sum()) == 65025
     assert sha(dec.reshape(257, 257)[m].tobytes()) == "74f626d1a4fcf78f1eae5b7cb07f7690a8a0bf76d5d77315b3737a2bae5aae09"
+
+
+def test_lerc1_written_blobs(O):
+    """tests/golden/lerc1_vectors.json: the real reference's reading of the Lerc1 blobs of cases.lerc1_cases"""
+    vec = json.load(open(os.path.join(GOLD, "lerc1_vectors.json")))
+    for name, blob, nb in cases.lerc1_cases():
+        v = vec[name]
+        assert sha(blob) == v["blob_sha"], "tests/lerc1_writer.py drifted; regenerate golden (make_golden.py lerc1)"
+        rc, info, rng = O.blob_info(blob)
+        assert rc == 0 and info == v["info"] and rng == v["range"], name
+        assert json.loads(json.dumps(list(O.data_ranges(blob, 1, nb)))) == v["ranges"], name    # (tuples become lists)
+        d, dd = O.decode(blob), O.decode(blob, to_double=True)
+        assert d[0] == 0 and dd[0] == 0
+        assert sha(d[1].tobytes()) == v["dec_sha"] and sha(dd[1].tobytes()) == v["dec_double_sha"], name
+        assert (sha(d[2].tobytes()) if d[2] is not None else None) == v["mask_sha"], name

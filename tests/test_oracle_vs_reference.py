@@ -159,3 +159,9 @@ def test_lerc1_world(O):
     for kw in ({}, {"to_double": True}):
         d1, d2 = R.decode(blob, **kw), O.decode(blob, **kw)
         assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1]) and _same(d1[2], d2[2])
+
+
+def test_lerc1_written_blobs(O):
+    """Lerc1 blobs written by tests/lerc1_writer.py: the real reference reads them, and the restatement reads the same"""
+    for name, blob, nb in cases.lerc1_cases():
+        cases.check_lerc1_case(R, O, name, blob, nb, _same)

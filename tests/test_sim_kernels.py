@@ -477,6 +477,24 @@ def test_sim_lerc1_world(libs):
             assert _same(g1[1], g2[1]) and _same(g1[2], g2[2]), (t, k)
 
 
+def test_sim_lerc1_written_blobs(libs):
+    """Lerc1 blobs of tests/lerc1_writer.py (masks, remainder tiles, raw / constant / zero / bit-stuffed tiles, int8 / int16 /
+    float offsets, several bands): info, ranges, pixels, masks as the oracle's; damaged copies: the oracle's verdict"""
+    O, S = libs
+    rng = np.random.default_rng(4)
+    for name, blob, nb in cases.lerc1_cases():
+        cases.check_lerc1_case(O, S, name, blob, nb, _same)
+        for t in range(6):
+            x = bytearray(blob)
+            k = int(rng.integers(0, len(x)))
+            x[k] ^= 1 << int(rng.integers(0, 8))
+            x = bytes(x[:max(40, k)] if t % 3 == 0 else x)
+            g1, g2 = O.decode(x), S.decode(x)
+            assert (g1[0] == 0) == (g2[0] == 0), (name, t, k)
+            if g1[0] == 0:
+                assert _same(g1[1], g2[1]) and _same(g1[2], g2[2]), (name, t, k)
+
+
 def test_sim_poisoned_scratch():
     """The damaged-blob cases once more in a process whose scratch memory is filled with 0xFF before every call
     (LERC_AMD_POISON, codec_common.cpp): a kernel that trusts what nobody wrote -- the block offsets a refused walk
