@@ -372,7 +372,6 @@ def test_lerc1_world(P, O):
 
 
 def test_lerc1_written_blobs(P, O):
-    """(last in the file: new in round 1's final hours, run on the emulator only before the round's GPU budget ran out)
-    Lerc1 blobs of tests/lerc1_writer.py: info, ranges, pixels and masks as the oracle's"""
+    """Lerc1 blobs of tests/lerc1_writer.py: info, ranges, pixels and masks as the oracle's"""
     for name, blob, nb in cases.lerc1_cases():
         cases.check_lerc1_case(O, P, name, blob, nb, _same)
