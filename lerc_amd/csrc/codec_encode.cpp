@@ -261,12 +261,16 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     hipEventRecord(ev, st);
     bitsOnTheWay = pin; nBitsOnTheWay = nb;
     if (nb < (256u << 10)) return true;    // small masks: codeMask() does it in line (starting a thread costs ~30 us)
-    rleFuture = std::async(std::launch::async, [pin, nb, ev]()
+    try
     {
-      std::vector<u8> out;
-      if (hipEventSynchronize(ev) == hipSuccess) rleEncode(pin, nb, out);
-      return out;    // (empty: the copy failed; an RLE stream is never empty)
-    });
+      rleFuture = std::async(std::launch::async, [pin, nb, ev]()
+      {
+        std::vector<u8> out;
+        if (hipEventSynchronize(ev) == hipSuccess) rleEncode(pin, nb, out);
+        return out;    // (empty: the copy failed; an RLE stream is never empty)
+      });
+    }
+    catch (...) { rleFuture = std::future<std::vector<u8> >(); }    // no thread to be had: codeMask() codes the mask in line
     return true;
   };
   auto buildMask = [&]() -> bool

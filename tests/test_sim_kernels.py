@@ -495,6 +495,22 @@ def test_sim_lerc1_written_blobs(libs):
                 assert _same(g1[1], g2[1]) and _same(g1[2], g2[2]), (name, t, k)
 
 
+def test_sim_large_mask_helper_thread(libs):
+    """A single-band raster whose validity bits make 256 KB and more: the mask's RLE is coded by a helper thread while the
+    calling thread launches kernels (codec_encode.cpp: sendBitsHome) -- same blob as the oracle's, and it decodes"""
+    O, S = libs
+    rng = np.random.default_rng(1)
+    r, c = 1460, 1448
+    x = cases._cast(cases.terrain(r, c, rng, amp=40, base=100, sigma=1.0), np.uint8)
+    m = (rng.random((r, c)) > 0.1).astype(np.uint8)
+    m[100:300, 200:900] = 0
+    r1, b1 = O.encode(x, 1.0, mask=m)
+    r2, b2 = S.encode(x, 1.0, mask=m)
+    assert r1 == r2 == 0 and bytes(b1) == bytes(b2)
+    d1, d2 = O.decode(b1), S.decode(b1)
+    assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1]) and _same(d1[2], d2[2])
+
+
 def test_sim_poisoned_scratch():
     """The damaged-blob cases once more in a process whose scratch memory is filled with 0xFF before every call
     (LERC_AMD_POISON, codec_common.cpp): a kernel that trusts what nobody wrote -- the block offsets a refused walk
