@@ -289,7 +289,14 @@ inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8)
 inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
 
 // ---- host runtime subset ----
-inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipMalloc(void** p, size_t n)
+{
+  *p = malloc(n ? n : 1);
+  // (LERC_AMD_POISON: fresh device memory is not zero on the real thing either)
+  static const char* poison = getenv("LERC_AMD_POISON");
+  if (*p && poison) memset(*p, (int)strtol(poison, nullptr, 0) & 255, n ? n : 1);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 template<class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
