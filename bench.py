@@ -188,7 +188,7 @@ def main():
         b_dec = blob_bytes + raw_bytes
         # an encode-side launch is priced at B_enc = raw + blob bytes, a decode-side launch at
         # B_dec = blob + raw bytes, whatever part of them that launch really touches (extra passes only lower frac)
-        dec_side = ("decode", "header", "candidates", "chains", "resolve", "emit", "fletcher_sum", "walk", "fletcher_dec", "huff_dec")
+        dec_side = ("decode", "discover", "resolve", "gather", "walk", "fletcher_dec", "huff_dec")
         alg = {k: (b_dec if any(t in k for t in dec_side) else b_enc) for k in prof}
         kernels = {k: {"avg_ms": round(v[0] / max(v[1], 1), 5), "launches": v[1]} for k, v in prof.items()}
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else None

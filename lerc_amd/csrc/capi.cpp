@@ -30,11 +30,21 @@ struct lerc_amd_context
 
 namespace {
 
+// The stock entry points are re-entrant across host threads like the reference's (Lerc.cpp:448,640: no global state):
+// every thread that calls them owns one context -- workspace slab, three staging buffers, pinned mirror, events --
+// and gives it back when the thread ends.  At process exit the HIP runtime may already be gone by the time the main
+// thread's holder is destroyed; the context's destructor frees through calls that then merely return an error.
+struct ThreadHolder
+{
+  lerc_amd_context* h = nullptr;
+  ~ThreadHolder() { delete h; h = nullptr; }
+};
+
 lerc_amd_context* threadHandle()
 {
-  static thread_local lerc_amd_context* h = nullptr;
-  if (!h) h = new (std::nothrow) lerc_amd_context();
-  return (h && h->ctx.ok()) ? h : nullptr;
+  static thread_local ThreadHolder holder;
+  if (!holder.h) holder.h = new (std::nothrow) lerc_amd_context();
+  return (holder.h && holder.h->ctx.ok()) ? holder.h : nullptr;
 }
 
 bool masksArgOk(int nMasks, int nBands, const void* pValidBytes)
@@ -88,8 +98,9 @@ lerc_status encodeHost(const void* pData, unsigned dataType, int nDepth, int nCo
     if (rc == kOk) *result = needed;
     return rc;
   }
-  // a blob never exceeds raw pixels + mask + a few hundred bytes per band (one-sweep fallback)
-  const u64 bound = (u64)nBands * (nPix * nDepth * tb + nPix / 4 + 4096);
+  // a blob never exceeds raw pixels + mask RLE + header + the per-depth ranges of codec >= 4 (2 * nDepth values) + a few
+  // hundred bytes per band (one-sweep fallback, Lerc2.cpp:364)
+  const u64 bound = (u64)nBands * (nPix * nDepth * tb + nPix / 4 + 2 * (u64)nDepth * tb + 4096);
   const u32 cap = (u32)std::min<u64>(outSize, bound);
   u8* dOut = (u8*)h->stage(2, cap);
   if (!dOut) return kFailed;

@@ -58,6 +58,9 @@ public:
   void* pinnedAux(size_t bytes);
   hipEvent_t auxEvent();
   bool sync();                               // wait for the active stream (polls first: see codec_common.cpp)
+  // a value no earlier call of this context has used and that no fill pattern looks like: kernels raise flags by
+  // writing it into cells that are never cleared (tile_fast.h)
+  u32 nextEpoch() { m_epoch += 0x9E3779B9u; if ((m_epoch & 0xFFFFu) == (m_epoch >> 16) || m_epoch == 0u) m_epoch += 0x9E3779B9u; return m_epoch; }
 
   std::string lastError;
   std::string lastNote;      // diagnostics that are not errors (why a call left the streaming path)
@@ -85,6 +88,7 @@ private:
   hipEvent_t profEvent();
 
   bool m_ok = false;
+  u32 m_epoch = 0x1234567u;
   hipStream_t m_stream = nullptr, m_userStream = nullptr;
   bool m_userSet = false;
   u8* m_slab = nullptr;

@@ -79,63 +79,68 @@ static_assert(sizeof(FastDecodeParams) <= 128, "cell layout");
 static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven, u32 nTiles = 1)
 {
   const FastWalkPlan wp = makeFastWalkPlan(nRows, nCols, sizeGiven);
-  const size_t perTile = (size_t)wp.nChunks * ((size_t)kFastListCap * 8 + kFastSubPerChunk * 8 + 64) + (size_t)wp.chainCap * sizeof(FastChain)
-    + (size_t)wp.nBlocks * 4 + (size_t)(wp.nBlocks / kFastBlocksPerWG + 1) * 16 + 4096;
-  return perTile * nTiles + (1u << 16);
+  const size_t perTile = (size_t)wp.nChunks * (sizeof(FastChunkRec) + (size_t)kDiscWalks * kFastListCap * 2 + 12) + (size_t)wp.nBlocks * 4
+    + (size_t)wp.nWaves * 16 + (size_t)(wp.nChunks / kResolveWG + 2) * 4 + 4096;
+  return perTile * nTiles + (size_t)kGatherChunks * kDiscWalks * kFastListCap * 2 + (1u << 16);
 }
 
 // Enqueues header check, discovery and decode of nTiles blobs (one band: nTiles == 1, dTileOffset == nullptr);
-// nothing is read back here.  dParams [nTiles] and dFallback [4 * nTiles] receive the verdicts.
+// nothing is read back here.  dParams [nTiles] and dFallback [4 * nTiles] receive the verdicts; the flags in dFallback
+// are raised by writing `epoch` (tile_fast.h), so the cells need no clearing.
 static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8* dBlobs, u32 sizeBound, u32 nTiles, const u64* dTileOffset,
-                            const u32* dTileSize, void* dOut, DeviceStatus* dStatus, FastDecodeParams* dParams, u32* dFallback,
-                            bool clearCells)
+                            const u32* dTileSize, void* dOut, FastDecodeParams* dParams, u32* dFallback, u32 epoch)
 {
   hipStream_t st = ctx.activeStream();
   const FastWalkPlan fwp = makeFastWalkPlan(nRows, nCols, sizeBound);
   const size_t nT = nTiles, sChunk = fastChunkStride(fwp.nChunks);
   FastDecodeBatch tb;
-  tb.nTiles = nTiles; tb.nChunks = fwp.nChunks; tb.nBlocks = fwp.nBlocks; tb.chainCap = fwp.chainCap;
+  tb.nTiles = nTiles; tb.nChunks = fwp.nChunks; tb.nBlocks = fwp.nBlocks; tb.nWaves = fwp.nWaves;
   tb.tileElems = (u64)nRows * (u64)nCols; tb.tileOffset = dTileOffset; tb.tileSize = dTileSize;
   FastDecodeBuffers fbuf;
-  fbuf.chunkListN = ctx.allocT<u32>(nT * sChunk);
-  fbuf.chunkList = ctx.allocT<u64>(nT * fwp.nChunks * kFastListCap + 4);
-  fbuf.chains = ctx.allocT<FastChain>(nT * fwp.chainCap + 4);
-  fbuf.chainCount = ctx.allocT<u32>(nT * ((fwp.nChunks + kFastCandChunks - 1) / kFastCandChunks) + 4);
-  fbuf.chunkEntry = ctx.allocT<u32>(nT * sChunk);
+  fbuf.recs = ctx.allocT<FastChunkRec>(nT * fwp.nChunks + 1);
+  fbuf.lists = ctx.allocT<u16>((nT * fwp.nChunks + kGatherChunks) * (size_t)(kDiscWalks * kFastListCap) + 8);    // (+ what the gather step's clamped loads may touch)
   fbuf.chunkCount = ctx.allocT<u32>(nT * sChunk);
-  fbuf.subEntry = ctx.allocT<u32>(nT * fwp.nChunks * kFastSubPerChunk + 4);
-  fbuf.subIndex = ctx.allocT<u32>(nT * fwp.nChunks * kFastSubPerChunk + 4);
+  fbuf.chunkLane = ctx.allocT<u32>(nT * sChunk);
+  fbuf.chunkLocal = ctx.allocT<u32>(nT * sChunk);
+  fbuf.groupSum = ctx.allocT<u32>(nT * ((fwp.nChunks + kResolveWG - 1) / kResolveWG + 1) + 4);
   fbuf.blockOff = ctx.allocT<u32>(nT * ((size_t)fwp.nBlocks + 4));
+  fbuf.waveFletcher = ctx.allocT<u64>(2 * nT * (size_t)fwp.nWaves + 4);
   fbuf.params = dParams;
   fbuf.fallback = dFallback;
-  fbuf.clearCells = clearCells;
-  fbuf.wgFletcher = ctx.allocT<u64>(2 * nT * (fwp.nBlocks / kFastBlocksPerWG + 1) + 4);
-  if (!fbuf.chunkListN || !fbuf.chunkList || !fbuf.chains || !fbuf.chainCount || !fbuf.chunkEntry || !fbuf.chunkCount
-    || !fbuf.subEntry || !fbuf.subIndex || !fbuf.blockOff || !fbuf.wgFletcher) return false;
-  static const char* kStage[kFastDecodeStages] = { "fast_header", "fast_candidates", "fast_chains", "fast_resolve", "fast_emit_offsets", "fast_decode",
-                                                   "fast_fletcher_sum" };
+  fbuf.epoch = epoch;
+  if (!fbuf.recs || !fbuf.lists || !fbuf.chunkCount || !fbuf.chunkLane || !fbuf.chunkLocal || !fbuf.groupSum || !fbuf.blockOff || !fbuf.waveFletcher)
+    return false;
+  static const char* kStage[kFastDecodeStages] = { "fast_discover", "fast_resolve", "fast_gather_offsets", "fast_decode" };
   for (int stage = 0; stage < kFastDecodeStages; stage++)
   {
     ProfScope ps(ctx, kStage[stage]);
-    launchFastDecode(stage, dt, nRows, nCols, tb, dBlobs, sizeBound, fbuf, dOut, dStatus, st);
+    launchFastDecode(stage, dt, nRows, nCols, tb, dBlobs, sizeBound, fbuf, dOut, st);
   }
   return true;
 }
 
-static bool launchFastBand(Context& ctx, int dt, int nRows, int nCols, const u8* dBand, u32 sizeGiven, void* dOutBand,
-                           DeviceStatus* dStatus, u8* dCell, bool clearCells)
+static bool launchFastBand(Context& ctx, int dt, int nRows, int nCols, const u8* dBand, u32 sizeGiven, void* dOutBand, u8* dCell, u32 epoch)
 {
-  return launchFastBands(ctx, dt, nRows, nCols, dBand, sizeGiven, 1, nullptr, nullptr, dOutBand, dStatus,
-                         reinterpret_cast<FastDecodeParams*>(dCell + kCellParams), reinterpret_cast<u32*>(dCell + kCellFallback), clearCells);
+  return launchFastBands(ctx, dt, nRows, nCols, dBand, sizeGiven, 1, nullptr, nullptr, dOutBand,
+                         reinterpret_cast<FastDecodeParams*>(dCell + kCellParams), reinterpret_cast<u32*>(dCell + kCellFallback), epoch);
+}
+
+// reason bits of a tile's / band's four epoch tagged flag cells
+static u32 fastFlagBits(const u32* cells, u32 epoch)
+{
+  u32 bits = 0;
+  for (int k = 0; k < 4; k++) if (cells[k] == epoch) bits |= 1u << k;
+  return bits;
 }
 
 // what the host makes of a band's cell after the sync: 0 = decoded and checksum good, else the reason bits
-static u32 fastBandVerdict(const u8* hCell)
+static u32 fastBandVerdict(const u8* hCell, u32 epoch)
 {
   FastDecodeParams hp;
   memcpy(&hp, hCell + kCellParams, sizeof(hp));
-  u32 fb;
-  memcpy(&fb, hCell + kCellFallback, 4);
+  u32 cells[4];
+  memcpy(cells, hCell + kCellFallback, 16);
+  u32 fb = fastFlagBits(cells, epoch);
   if (!hp.ok) fb |= 0x100u;
   else if (!fb && !hp.checksumOk) fb |= 0x200u;
   return fb;
@@ -156,20 +161,19 @@ static u32 decodeSpeculative(Context& ctx, const DecodeRequest& rq, bool& handle
   const size_t cellsBytes = 64 + kCellBytes;
   u8* dCells = ctx.allocT<u8>(cellsBytes);
   if (!dCells) return kOk;
-  if (!launchFastBand(ctx, dt, nRows, nCols, rq.dBlob, rq.blobSize, rq.dOut, reinterpret_cast<DeviceStatus*>(dCells), dCells + 64, true))
-    return kOk;
+  const u32 epoch = ctx.nextEpoch();
+  if (!launchFastBand(ctx, dt, nRows, nCols, rq.dBlob, rq.blobSize, rq.dOut, dCells + 64, epoch)) return kOk;
   if (rq.nMasks > 0 && rq.dValidBytes) hipMemsetAsync(rq.dValidBytes, 1, (size_t)nRows * nCols, st);    // numValid == nPix or no verdict
   u8* pin = (u8*)ctx.pinned(cellsBytes);
   if (!pin) return kOk;
   hipMemcpyAsync(pin, dCells, cellsBytes, hipMemcpyDeviceToHost, st);
   if (!ctx.sync()) return kFailed;
   if (ctx.profOn()) ctx.profCollect();
-  const DeviceStatus hs = *reinterpret_cast<const DeviceStatus*>(pin);
-  const u32 verdict = fastBandVerdict(pin + 64);
-  if (verdict || hs.error)
+  const u32 verdict = fastBandVerdict(pin + 64, epoch);
+  if (verdict)
   {
     char msg[112];
-    snprintf(msg, sizeof(msg), "streaming decode handed the blob to the general path (reason bits 0x%x, kernel status %u)", verdict, hs.error);
+    snprintf(msg, sizeof(msg), "streaming decode handed the blob to the general path (reason bits 0x%x)", verdict);
     ctx.lastNote = msg;
     return kOk;
   }
@@ -283,6 +287,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   std::vector<u32> checksumLen(rq.nBands, 0);
   std::vector<u8> small;
   // bands decoded by the streaming kernels: their checksum comes out of the decode kernel itself
+  const u32 fastEpoch = ctx.nextEpoch();
   struct FastBand { bool used = false; };
   std::vector<FastBand> fast(rq.nBands);
 
@@ -488,10 +493,11 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
 
     if (fastBand && fastDataBegin == (u32)(at - bd.offset))
     {
-      if (!launchFastBand(ctx, dt, nRows, nCols, dBand, blobEnd, dOutBand, dStatus, dCells + 64 + (size_t)iBand * kCellBytes, false)) return kFailed;
+      if (!launchFastBand(ctx, dt, nRows, nCols, dBand, blobEnd, dOutBand, dCells + 64 + (size_t)iBand * kCellBytes, fastEpoch)) return kFailed;
       FastBand& f = fast[iBand];
       ctx.lastDecodeStreamed = true;
       f.used = true;
+      if (!finishMask()) return kFailed;    // all valid: the caller's mask bytes become 1s (Lerc.cpp:464-488 always writes them)
       continue;
     }
     if (fastBand)    // launched without its checksum kernel, but did not qualify after all
@@ -544,7 +550,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
     if (!fast[iBand].used) continue;
-    const u32 verdict = fastBandVerdict(pin + 64 + (size_t)iBand * kCellBytes);
+    const u32 verdict = fastBandVerdict(pin + 64 + (size_t)iBand * kCellBytes, fastEpoch);
     if (verdict & 0x200u) return kFailed;    // decoded, but the checksum is wrong
     if (verdict)                             // caller repeats with the general kernels
     {
@@ -620,7 +626,7 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
 
   hipStream_t st = ctx.activeStream();
   const size_t perTile = fastBandWorkspace(rq.nRows, rq.nCols, maxSize, 1) - (1u << 16) + sizeof(FastDecodeParams) + 64;
-  const int maxBatch = (int)std::max<size_t>(1, std::min<size_t>((size_t)rq.nTiles, ((size_t)256 << 20) / perTile));
+  const int maxBatch = (int)std::max<size_t>(1, std::min<size_t>((size_t)rq.nTiles, ((size_t)1024 << 20) / perTile));
   std::vector<int> redo;
   for (int t0 = 0; t0 < rq.nTiles; t0 += maxBatch)
   {
@@ -639,30 +645,30 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
     hipMemcpyAsync(dOff, hOff, (size_t)n * 8, hipMemcpyHostToDevice, st);
     hipMemcpyAsync(dSize, hSize, (size_t)n * 4, hipMemcpyHostToDevice, st);
     if (!ctx.sync()) return kFailed;    // the pinned mirror is reused for the read-back below
-    DeviceStatus* dStatus = reinterpret_cast<DeviceStatus*>(dCells);
     FastDecodeParams* dParams = reinterpret_cast<FastDecodeParams*>(dCells + 64);
     u32* dFallback = reinterpret_cast<u32*>(dCells + 64 + (size_t)n * sizeof(FastDecodeParams));
+    const u32 epoch = ctx.nextEpoch();
     if (!launchFastBands(ctx, rq.dt, rq.nRows, rq.nCols, rq.dArena, maxSize, (u32)n, dOff, dSize,
-                         (u8*)rq.dOut + (size_t)t0 * tileElems * tbytes, dStatus, dParams, dFallback, true))
+                         (u8*)rq.dOut + (size_t)t0 * tileElems * tbytes, dParams, dFallback, epoch))
       return kFailed;
     hipMemcpyAsync(pin, dCells, cellsBytes, hipMemcpyDeviceToHost, st);
     if (!ctx.sync()) return kFailed;
     if (ctx.profOn()) ctx.profCollect();
     const FastDecodeParams* hp = reinterpret_cast<const FastDecodeParams*>(pin + 64);
     const u32* hfb = reinterpret_cast<const u32*>(pin + 64 + (size_t)n * sizeof(FastDecodeParams));
-    const DeviceStatus hs = *reinterpret_cast<const DeviceStatus*>(pin);
     redo.clear();
     for (int i = 0; i < n; i++)
     {
-      const bool good = hp[i].ok && !hfb[4 * i] && hp[i].checksumOk && !hs.error;
+      const u32 bits = fastFlagBits(hfb + 4 * i, epoch);
+      const bool good = hp[i].ok && !bits && hp[i].checksumOk;
       if (good) ctx.pathCount[2]++;
       else
       {
         if (redo.empty())
         {
           char msg[160];
-          snprintf(msg, sizeof(msg), "tile %d of the batch went to the general path (header ok %u, reason bits 0x%x, checksum ok %u, kernel status %u)",
-                   t0 + i, hp[i].ok, hfb[4 * i], hp[i].checksumOk, hs.error);
+          snprintf(msg, sizeof(msg), "tile %d of the batch went to the general path (header ok %u, reason bits 0x%x, checksum ok %u)",
+                   t0 + i, hp[i].ok, bits, hp[i].checksumOk);
           ctx.lastNote = msg;
         }
         redo.push_back(t0 + i);

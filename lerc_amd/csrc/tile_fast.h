@@ -110,19 +110,32 @@ LERC_HD bool fastDimsOk(int dt, int nRows, int nCols)
 LERC_HD u32 fastNumWG(int nRows, int nCols) { return (u32)(((u64)(nRows / 8) * (u64)(nCols / 8) + 63u) / 64u); }
 
 // ---- decode side ---------------------------------------------------------------------------------
+// The block stream stores no offsets.  Discovery works on 4 KiB chunks of the blob (chunk c = blob bytes
+// [c * 4096, (c + 1) * 4096), so every chunk start is 16-byte aligned like the blob itself):
+//   k_fast_discover  a workgroup stages kDiscChunks consecutive chunks in LDS (summing their Fletcher32 terms on the way),
+//                    filters every position of each chunk's first `window` bytes as a block start (kFilterSteps valid
+//                    blocks in a row with the right signature sequence), then up to kDiscWalks survivors per chunk walk
+//                    to the chunk's end in lockstep, listing the block starts they pass
+//   k_fast_resolve   entry of chunk c = the exit all surviving walks of chunk c - 1 agree on; the walk that starts
+//                    there is the true path: its block count, scanned, is the index of the chunk's first block
+//   k_fast_gather    copies the true walks' lists into blockOff[]
+//   k_fast_decode    a workgroup decodes 64 consecutive blocks and checks that they tile their span exactly
 static const u32 kFastChunkBytes = 4096;
-static const u32 kFastSubBytes = 512;      // the chains also note the first block start behind every sub-chunk boundary
-static const int kFastSubPerChunk = (int)(kFastChunkBytes / kFastSubBytes);
-static const int kFastListCap = 64;        // surviving block-start candidates listed per chunk
-static const int kFastChainsPerChunk = 16; // capacity of the chain array per chunk (a handful in practice)
-static const int kFastCandChunks = 8;      // chunks per workgroup of the candidate filter
+static const int kDiscLanes = 16;          // lanes of the discovery wave that own a chunk
+static const int kDiscWalks = 8;           // walks per chunk (path heads among the filter's survivors; more: general path)
+static const int kDiscChunks = 16;         // chunks per workgroup of k_fast_discover (four per wave while candidates are filtered)
+static const int kFilterSteps = 4;         // valid blocks in a row that make a window position a walk start
+static const int kFastListCap = 256;       // block starts a walk can list per chunk (more, i.e. blocks of < 16 bytes on average: general path)
+static const int kRecPrefix = 4;           // block starts of a walk kept in its chunk record (the rest is in its list)
+static const u32 kResolveWG = 256;         // chunks per workgroup of k_fast_resolve
+static const u32 kGatherChunks = 16;       // chunks per workgroup of k_fast_gather (divides kResolveWG)
 // longest block the streaming walk accepts: the raw form (the reference encoder never emits a longer one)
 constexpr u32 kFastWindow(int typeBytes) { return 2u + 64u * (u32)typeBytes; }
 
 // sizes the host can bound without reading the blob (grids and buffers); the true values are in FastDecodeParams
-struct FastWalkPlan { u32 nChunks, nBlocks, chainCap; };
+struct FastWalkPlan { u32 nChunks, nBlocks, nWaves; };
 
-// what k_fast_header reads out of the band header for the other kernels, and what the host reads back at the end
+// what the header parse leaves for the other kernels, and what the host reads back at the end
 struct FastDecodeParams
 {
   u32 ok;                // the band qualifies for the streaming kernels
@@ -131,39 +144,36 @@ struct FastDecodeParams
   u32 nChunks, nBlocks;
   u32 nTH, nCols, nRows;
   u32 expectChecksum;    // from the header
-  u32 checksumOk;        // set by k_fast_fletcher_sum
+  u32 checksumOk;        // set by k_fast_resolve
   u32 pad;
-  u64 prefixA, prefixB;  // Fletcher terms of the bytes in front of the first block
   double invScale, zMaxHdr;
 };
 
-// one speculative walk through a chunk, shared by all the candidates that merged into it
-struct FastChain
+// what the walks of one chunk found
+struct FastChunkRec
 {
-  u32 cur;             // where it starts (absolute)
-  u32 chunkSig;        // chunk index | signature of the block before `cur` << 28
-  u32 exit;            // out: first block start at / behind the chunk end
-  u16 count;           // out: blocks from cur to exit
-  u16 alive;           // out: 0 if it ran into something that is not a block
-  u16 marks[8];        // out: first block start at / behind sub-chunk boundary j (relative to the chunk start), 0 = not passed
-  u16 markCount[8];    // out: blocks from cur to that block start
+  u32 exit;                    // first block start at / behind the chunk's end that all live walks agree on, or ~0
+  u32 nLive;
+  u16 first[kDiscWalks][kRecPrefix];    // the first block starts of walk l, relative to the chunk (0xFFFF: none)
+  u16 count[kDiscWalks];       // blocks from its start to `exit`; 0xFFFF: no such walk / it ran into something that is no block
 };
 
+// Flags the kernels raise are epoch tagged: cell k == epoch means "raised during this call", so nothing has to be
+// cleared between calls (a stale or never written cell matching the epoch by accident only costs a detour through
+// the general path).  k: 0 discovery, 1 resolve, 2 gather, 3 decode.
 struct FastDecodeBuffers
 {
-  u32* chunkListN;     // [nChunks] entries of chunkList in use
-  u64* chunkList;      // [nChunks * kFastListCap] start offset in the chunk | steps taken << 16 | chain index << 32
-  FastChain* chains;   // [chainCap]
-  u32* chainCount;     // [ceil(nChunks / kFastCandChunks)] chains in use in each workgroup's slice of `chains`
-  u32* chunkEntry;     // [nChunks + 1]
-  u32* chunkCount;     // [nChunks]
-  u32* subEntry;       // [nChunks * kFastSubPerChunk] first block start at / behind a sub-chunk boundary ([0] = the chunk entry), or ~0
-  u32* subIndex;       // [nChunks * kFastSubPerChunk] index of that block within the chunk
+  FastChunkRec* recs;  // [nChunks]
+  u16* lists;          // [nChunks * kDiscWalks * kFastListCap] block starts relative to the chunk, per walk
+  u32* chunkCount;     // [nChunks] blocks that start in the chunk
+  u32* chunkLane;      // [nChunks] the walk that is the true path
+  u32* chunkLocal;     // [nChunks] exclusive scan of chunkCount inside a resolve workgroup
+  u32* groupSum;       // [ceil(nChunks / kResolveWG)] blocks per resolve workgroup
   u32* blockOff;       // [nBlocks + 1]
-  u64* wgFletcher;     // [2 * nBlocks / 64] Fletcher partial sums (mod 65535) of the bytes each decode workgroup staged
+  u64* waveFletcher;   // [2 * nWaves] Fletcher partial sums (mod 65535) of the bytes each discovery workgroup staged
   FastDecodeParams* params;   // [nTiles]
-  u32* fallback;       // [4 * nTiles] [0] != 0: the general path must redo the band
-  bool clearCells;     // the header kernel zeroes *status and fallback[0..3] itself (no memset before the launches)
+  u32* fallback;       // [4 * nTiles] epoch tagged, see above
+  u32 epoch;
 };
 
 // A launch covers nTiles independent blobs of rasters of one shape (blockIdx.y = tile; one raster is nTiles == 1).
@@ -171,7 +181,7 @@ struct FastDecodeBuffers
 struct FastDecodeBatch
 {
   u32 nTiles;
-  u32 nChunks, nBlocks, chainCap;    // per tile; nChunks / chainCap are upper bounds (largest blob of the batch)
+  u32 nChunks, nBlocks, nWaves;      // per tile; nChunks / nWaves are upper bounds (largest blob of the batch)
   u64 tileElems;                     // pixels from one tile's output to the next
   const u64* tileOffset;             // device [nTiles]: start of each blob in the arena; nullptr: `blob` itself
   const u32* tileSize;               // device [nTiles]
@@ -180,9 +190,8 @@ LERC_HD u32 fastChunkStride(u32 nChunks) { return nChunks + 4u; }    // elements
 
 bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid);
 FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven);
-static const int kFastDecodeStages = 7;    // one kernel each: header, candidates, chains, resolve, emit, decode, checksum fold
-// stage 0: header; 1: candidates; 2: chains; 3: resolve; 4: block offsets; 5: decode; 6: checksum fold
+static const int kFastDecodeStages = 4;    // one kernel each: discover (+ header + checksum terms), resolve, gather, decode
 void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
-                      const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st);
+                      const FastDecodeBuffers& b, void* out, hipStream_t st);
 
 }    // namespace lerc

@@ -1,31 +1,29 @@
 // tile_fast_decode.hip -- streaming decoder kernels for the common case (one band, nDepth == 1, every
-// pixel valid, 8 x 8 blocks, nRows % 8 == 0, nCols % 512 == 0).  Same results as tile_decode.hip.
+// pixel valid, 8 x 8 blocks, rows and columns multiples of 8).  Same results as tile_decode.hip.
 //
 // The block stream stores no offsets (block k+1 starts where block k ends), so decoding starts with a
-// discovery pass over 4 KiB chunks of the stream.  Serial walking is latency bound, so the serial parts run
-// as plain one-lane-per-chain kernels straight from global memory (L2 / MALL hits) with every chain of the
-// whole stream in flight at once, and only the wide, throughput bound part is staged through LDS:
-//   k_fast_candidates  LDS staged.  A workgroup takes a few chunks and tries every position of each chunk's
-//                      first `window` bytes as a block start.  Candidates are filtered for a few steps through
-//                      compacting queues (most die at once) and the survivors are merged into distinct
-//                      chains (a hash on position + signature).  The true first block of a chunk is always
-//                      among the survivors.
-//   k_fast_chains      one lane per chain walks to the end of its chunk: exit, #blocks, and the first block
-//                      start behind every 512-byte sub-chunk boundary it passes.
-//   k_fast_resolve     whatever ALL live chains of a chunk agree on is true without knowing which one is
-//                      real: entry of chunk c = agreed exit of chunk c-1; #blocks of chunk c = steps + count
-//                      of the survivor that starts exactly there; agreed sub-chunk entries.  An exclusive
-//                      scan turns the counts into block indices.
-//   k_fast_emit        one lane per sub-chunk walks from its agreed entry to the next one and writes the
-//                      block offsets.
-//   k_fast_decode      a workgroup owns 64 consecutive blocks (8 rows x 512 columns): it stages their byte
-//                      span in LDS (accumulating the Fletcher32 sums of those bytes word-wise), parses the 64
-//                      block headers once (lane = block), then every lane extracts V consecutive pixels of one
-//                      raster row, dequantises (double precision in the reference's expression order for
-//                      float types, exact integer arithmetic for integer types) and stores one 16-byte vector.
-// Whenever a precondition fails (a block longer than its raw size, disagreeing chains, too many survivors,
-// ...) the kernels raise `fallback`, and the host repeats the band with the general kernels.
-// Reference: Lerc2.cpp:1672-1713, :2025-2230; BitStuffer2.cpp:159-258, :476-540.
+// discovery pass over 4 KiB chunks of the blob (tile_fast.h).  Everything serial about it runs out of LDS:
+//   k_fast_discover    one wave = kDiscChunks chunks staged with 16-byte loads (their Fletcher32 terms are summed
+//                      on the way, so the decode kernel does not look at the checksum at all).  Every wave parses
+//                      the band header itself (the host has not seen a byte of the blob when it enqueues the four
+//                      kernels).  Each chunk belongs to kDiscLanes lanes: they try every position of the chunk's
+//                      first `window` bytes as a block start, keep the ones that stay valid for kFilterSteps blocks
+//                      (compacting LDS queues: most die at once) and walk the survivors to the chunk's end in
+//                      lockstep, writing down the block starts they pass.  The true first block of a chunk is
+//                      always among the survivors.
+//   k_fast_resolve     whatever ALL live walks of a chunk agree on is true without knowing which one is real:
+//                      entry of chunk c = agreed exit of chunk c-1; the walk that starts exactly there is the true
+//                      path and its length the chunk's block count.  Also folds the checksum terms.
+//   k_fast_gather      block offsets = the true walks' lists, placed by a scan of the counts.
+//   k_fast_decode      a workgroup owns 64 consecutive blocks (8 rows x 512 columns where a block row is that
+//                      long): it stages their byte span in LDS, parses the 64 block headers once (lane = block;
+//                      signature and contiguity checks = ReadTile's integrity checks), then every lane extracts V
+//                      consecutive pixels of one raster row, dequantises (double precision in the reference's
+//                      expression order for float types, exact integer arithmetic for integer types) and stores
+//                      one 16-byte vector.
+// Whenever a precondition fails (a block longer than its raw size, disagreeing walks, too many survivors,
+// ...) the kernels raise an epoch tagged flag, and the host repeats the band with the general kernels.
+// Reference: Lerc2.cpp:1672-1713, :2025-2230; BitStuffer2.cpp:159-258, :476-540; Lerc2.cpp:1037-1064 (checksum).
 #include "tile_fast.h"
 #include "kernels.h"
 #include "wave_utils.h"
@@ -117,54 +115,56 @@ __device__ __forceinline__ u32 stepAt(const u32* words, u32 a0, u32 cur, u32 end
   return ok ? code : 0u;
 }
 
-// the first 12 bytes at blob offset pos, straight from global memory.  Never touches a word behind the one that
-// holds the last blob byte (device allocations are at least 4-byte granular; blob itself is 16-byte aligned).
-struct __attribute__((packed, aligned(4))) Words4 { u32 x0, x1, x2, x3; };    // a 16-byte load that is only 4-byte aligned
-
+// The same step written for the walks' critical path: everything is computed for every lane and selected at the end,
+// so a step is one LDS round trip and a dozen dependent VALU operations, with no branch.  `rel` must lie inside the
+// staged bytes (the caller clamps it for lanes that are not walking); returns the block's length or 0.
 template<int DT>
-__device__ __forceinline__ void globalHeader(const u8* __restrict__ blob, u32 pos, u32 blobEnd, u32& h0, u32& h1, u32& h2)
+__device__ __forceinline__ u32 stepLean(const u32* words, u32 rel, u32 remaining, bool v5, u32 prevSig, u32 pattern, u32& sigOut)
 {
-  const u32 w = pos & ~3u, sh = 8u * (pos & 3u), last = (blobEnd - 1u) & ~3u;
-  u32 x0, x1, x2, x3;
-  if (w + 12u <= last)    // one request per lane
+  constexpr u32 TB = (DT <= DT_Byte) ? 1 : (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
+  constexpr u32 RAW = 1 + 64 * TB;
+  const u32 wi = rel >> 2, sh = 8u * rel;    // (alignbit takes the shift mod 32)
+  const u32 x0 = words[wi], x1 = words[wi + 1], x2 = words[wi + 2];
+  const u32 h0 = __builtin_amdgcn_alignbit(x1, x0, sh), h1 = __builtin_amdgcn_alignbit(x2, x1, sh);
+  const u32 mode = h0 & 3u;
+  const u32 offB = (offBytesTable<DT>() >> ((h0 >> 4) & 12u)) & 15u;
+  u32 t;    // bytes 1 + offB ...: numBits byte, count, LUT size
+  if (DT == DT_Double)
   {
-    const Words4 v = *reinterpret_cast<const Words4*>(blob + w);
-    x0 = v.x0; x1 = v.x1; x2 = v.x2; x3 = v.x3;
+    const u32 x3 = words[wi + 3];
+    const u32 h2 = __builtin_amdgcn_alignbit(x3, x2, sh);
+    t = (offB == 8u) ? (h2 >> 8) : (u32)((((u64)h1 << 32) | h0) >> ((8u + 8u * offB) & 63u));
   }
-  else                    // the last bytes of the blob
-  {
-    x0 = *reinterpret_cast<const u32*>(blob + w);
-    x1 = *reinterpret_cast<const u32*>(blob + min(w + 4u, last));
-    x2 = *reinterpret_cast<const u32*>(blob + min(w + 8u, last));
-    x3 = *reinterpret_cast<const u32*>(blob + min(w + 12u, last));
-  }
-  h0 = (u32)((((u64)x1 << 32) | x0) >> sh);
-  h1 = (u32)((((u64)x2 << 32) | x1) >> sh);
-  h2 = (DT == DT_Double) ? (u32)((((u64)x3 << 32) | x2) >> sh) : 0u;
-}
-
-// one step of a walk through global memory: the block at `cur`, or 0
-template<int DT>
-__device__ __forceinline__ u32 stepGlobal(const u8* __restrict__ blob, u32 cur, u32 blobEnd, int version, u32& sig, u32 pattern)
-{
-  u32 h0, h1, h2;
-  globalHeader<DT>(blob, cur, blobEnd, h0, h1, h2);
-  const u32 code = parseCode<DT>(h0, h1, h2, version);
+  else t = (u32)((((u64)h1 << 32) | h0) >> ((8u + 8u * offB) & 63u));
+  const u32 nb = t & 31u, lut = (t >> 5) & 1u;
+  const u32 nLut = (((t >> 16) & 0xFFu) - 1u) & 0xFFu;                     // valid: 1 ... 254
+  const u32 okBits = (u32)((t & 0xFFC0u) == 0x4080u) & (u32)(nb != 0u);    // 64 elements: one-byte count field == 64
+  const u32 okLut = (u32)((nLut - 1u) < 254u);
+  const u32 lenSimple = 3u + offB + 8u * nb;
+  const u32 lenLut = 4u + offB + ((nLut * nb + 7u) >> 3) + 8u * (u32)bitLen(nLut);
+  const u32 lenStuffed = lut ? lenLut : lenSimple;
+  const u32 lenOther = (mode == 0u) ? RAW : (mode == 2u) ? 1u : 1u + offB;
+  const u32 len = (mode == 1u) ? lenStuffed : lenOther;
+  const u32 okStuffed = okBits & (u32)(offB != 0u) & ((lut ^ 1u) | okLut);
+  const u32 okOther = (u32)(mode != 3u) | (u32)(offB != 0u);
+  u32 ok = (mode == 1u) ? okStuffed : okOther;
+  ok &= (u32)!(v5 && (h0 & 4u)) & (u32)(len <= RAW) & (u32)(len <= remaining);    // slice difference needs nDepth > 1
   const u32 sg = (h0 >> 2) & pattern;
-  const bool ok = (code != 0u) & (cur + codeLen(code) <= blobEnd) & ((sig == kNoOffset) | sigOk(sig, sg, pattern));
-  sig = sg;
-  return ok ? code : 0u;
+  ok &= (u32)(prevSig == kNoOffset) | (u32)sigOk(prevSig, sg, pattern);
+  sigOut = sg;
+  return ok ? len : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
 // header
 // ------------------------------------------------------------------------------------------------
-// One lane reads the band header the way Lerc2::ReadHeader / ReadMask / ReadMinMaxRanges do (Lerc2.cpp:790-1008,
-// :2642-2677) and decides whether the streaming kernels may take the band.  Everything the later kernels need is
-// left in *P, so the host can enqueue the whole decode without having seen a single byte of the blob; it checks
-// P->ok (and the fallback bits) when it reads the results back.
-// The first 128 bytes of the band sit in 32 registers of the parsing lane; all field offsets are compile-time
-// constants per codec version, so the parse is a handful of funnel shifts instead of a chain of byte loads.
+// The band header is read the way Lerc2::ReadHeader / ReadMask / ReadMinMaxRanges do (Lerc2.cpp:790-1008,
+// :2642-2677) to decide whether the streaming kernels may take the band.  Every discovery wave does it for itself
+// (all lanes alike: the same 128 bytes, no divergence, so it costs what one lane would); the first one leaves the
+// result in *P for the later kernels and the host, which can therefore enqueue the whole decode without having seen a
+// single byte of the blob; it checks P->ok (and the fallback flags) when it reads the results back.
+// The first 128 bytes of the band sit in 32 registers; all field offsets are compile-time constants per codec
+// version, so the parse is a handful of funnel shifts instead of a chain of byte loads.
 struct Head128
 {
   u32 w[32];
@@ -214,30 +214,15 @@ __device__ __forceinline__ void parseHead(const Head128& h, u32 sizeGiven, int n
   ok = ok && h.byteAt(oSweep) == 0u && oData < blobSize;          // not the one-sweep raw form
   hp.dataBegin = oData;
   hp.blobEnd = blobSize;
-  hp.nChunks = ok ? (blobSize - oData + kFastChunkBytes - 1) / kFastChunkBytes : 0u;
+  hp.nChunks = ok ? (blobSize + kFastChunkBytes - 1) / kFastChunkBytes : 0u;    // chunk c = blob bytes [c * 4096, (c + 1) * 4096)
   hp.invScale = 2 * maxZErr;
   hp.zMaxHdr = zMax;
-  // Fletcher terms of the bytes in front of the first block (Lerc2.cpp:1037-1064; word k of blob[14 ..))
-  u64 A = 0, B = 0;
-#pragma unroll
-  for (u32 pos = 0; pos + 14u < oData; pos++)
-  {
-    const u32 cw = h.byteAt(14 + pos) << ((pos & 1u) ? 0 : 8);
-    A += cw; B += (u64)(pos >> 1) * cw;
-  }
-  hp.prefixA = A; hp.prefixB = B;
   hp.ok = ok ? 1u : 0u;
 }
 
 template<int DT>
-__device__ __forceinline__ void
-fastHeaderBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols, FastDecodeParams* __restrict__ P,
-              u32* __restrict__ clearStatus, u32* __restrict__ clearFallback)
+__device__ __forceinline__ FastDecodeParams parseBandHeader(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols)
 {
-  // first kernel of a decode: it also clears the cells the later kernels raise flags in (saves a memset launch)
-  if (threadIdx.x < 4 && clearStatus) clearStatus[threadIdx.x] = 0u;
-  if (threadIdx.x >= 4 && threadIdx.x < 8 && clearFallback) clearFallback[threadIdx.x - 4] = 0u;
-  if (threadIdx.x != 0) return;
   FastDecodeParams hp;
   memset(&hp, 0, sizeof(hp));
   Head128 h;
@@ -247,7 +232,13 @@ fastHeaderBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols,
   {
     uint4 x = make_uint4(0, 0, 0, 0);
     if ((u32)(16 * i + 16) <= sizeGiven) x = src[i];
-    else for (u32 k = 0; 16u * i + k < sizeGiven && k < 16u; k++) (&x.x)[k >> 2] |= (u32)blob[16 * i + k] << (8 * (k & 3));
+    else
+    {
+      u32 t4[4] = { 0, 0, 0, 0 };
+#pragma unroll
+      for (u32 k = 0; k < 16u; k++) if (16u * i + k < sizeGiven) t4[k >> 2] |= (u32)blob[16 * i + k] << (8 * (k & 3));
+      x = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+    }
     h.w[4 * i] = x.x; h.w[4 * i + 1] = x.y; h.w[4 * i + 2] = x.z; h.w[4 * i + 3] = x.w;
   }
   const u32 version = h.u32At(6);
@@ -264,442 +255,483 @@ fastHeaderBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols,
     else if (version == 5u || version == 4u) parseHead<DT, 4>(h, sizeGiven, nRows, nCols, hp);
     else if (version == 3u) parseHead<DT, 3>(h, sizeGiven, nRows, nCols, hp);
   }
-  *P = hp;
+  return hp;
 }
 
-// ------------------------------------------------------------------------------------------------
-// candidates
-// ------------------------------------------------------------------------------------------------
-static const int kWalkG = kFastCandChunks;    // chunks per workgroup
-static const int kMinSteps = 4;               // every candidate is filtered for at least this many blocks
-static const int kMaxRounds = 40;            // steps a candidate may need to leave the window; more -> its chain stays apart
-static const u32 kSurvivorCap = 512;         // survivors of a workgroup after the last filter step
-static const u32 kHashSize = 1024;
-static const u32 kChainCap = kFastCandChunks * kFastChainsPerChunk;    // distinct chains of a workgroup (its slice of the chain array)
-
-// appends e for the lanes with p; call in wave-uniform control flow
-__device__ __forceinline__ void queuePush(bool p, u32 e, u32* q, u32* qn, u32 cap, u32* over)
+__device__ __forceinline__ bool fastRaised(const u32* __restrict__ fallback, u32 epoch)
 {
-  const u64 m = __ballot(p);
-  if (!m) return;
-  const int lane = laneId(), leader = __ffsll((long long)m) - 1;
-  u32 base = 0;
-  if (lane == leader) base = atomicAdd(qn, (u32)__popcll(m));
-  base = __shfl(base, leader);
-  if (p)
-  {
-    const u32 idx = base + (u32)__popcll(m & laneMaskLt());
-    if (idx < cap) q[idx] = e; else *over = 1;
-  }
+  return fallback[0] == epoch || fallback[1] == epoch || fallback[2] == epoch || fallback[3] == epoch;
 }
 
-// queue entry: candidate index g * W + o (13) | position relative to the chunk start (12) << 13 | signature (4) << 25
-__device__ __forceinline__ u32 qMake(u32 f, u32 rel, u32 sig) { return f | (rel << 13) | ((sig & 15u) << 25); }
-__device__ __forceinline__ u32 qCand(u32 e) { return e & 0x1FFFu; }
-__device__ __forceinline__ u32 qRel(u32 e) { return (e >> 13) & 0xFFFu; }
-__device__ __forceinline__ u32 qSig(u32 e) { return (e >> 25) & 15u; }
+// ------------------------------------------------------------------------------------------------
+// discovery
+// ------------------------------------------------------------------------------------------------
+// Fletcher32 terms (Lerc2.cpp:1037-1064) of one 16-byte unit whose first byte is byte 2 * k0 of the checksummed range
+// blob[14 ..): the checksum works on big-endian 16-bit words w, A = sum w, B = sum index * w.  Bytes at even positions
+// weigh 256: four byte dot products per dword, the word index inside the unit (0 .. 7) rides in the weights.
+__device__ __forceinline__ void fletcherUnit(const uint4& x, u64 k0, u32& A, u64& B)
+{
+  u32 ae = 0, ao = 0, be = 0, bo = 0;
+  ae = __builtin_amdgcn_udot4(x.x, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.x, 0x01000100u, ao, false);
+  be = __builtin_amdgcn_udot4(x.x, 0x00010000u, be, false); bo = __builtin_amdgcn_udot4(x.x, 0x01000000u, bo, false);
+  ae = __builtin_amdgcn_udot4(x.y, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.y, 0x01000100u, ao, false);
+  be = __builtin_amdgcn_udot4(x.y, 0x00030002u, be, false); bo = __builtin_amdgcn_udot4(x.y, 0x03000200u, bo, false);
+  ae = __builtin_amdgcn_udot4(x.z, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.z, 0x01000100u, ao, false);
+  be = __builtin_amdgcn_udot4(x.z, 0x00050004u, be, false); bo = __builtin_amdgcn_udot4(x.z, 0x05000400u, bo, false);
+  ae = __builtin_amdgcn_udot4(x.w, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.w, 0x01000100u, ao, false);
+  be = __builtin_amdgcn_udot4(x.w, 0x00070006u, be, false); bo = __builtin_amdgcn_udot4(x.w, 0x07000600u, bo, false);
+  const u32 a = 256u * ae + ao;    // < 2^19
+  A += a;
+  B += k0 * a + (256u * be + bo);
+}
 
-// Every candidate walks until it has left the window (and for at least kMinSteps blocks).  Candidates that sit on one
-// path (the true path crosses the window in several blocks, each of them a candidate) arrive at the same block start
-// there and merge into one chain, however short the blocks are -- except the last few, which stop up to kMinSteps - 1
-// blocks further.  Only the head of every chunk is needed for that: window + kMinSteps blocks + one header.
+// queue entry of the candidate filter: start in the window (10) | current position relative to the chunk (13) << 10 |
+// signature of the last block (4) << 23 | valid blocks so far (3) << 27
+__device__ __forceinline__ u32 qMake(u32 start, u32 rel, u32 sig, u32 steps) { return start | (rel << 10) | ((sig & 15u) << 23) | (steps << 27); }
+__device__ __forceinline__ u32 qStart(u32 e) { return e & 0x3FFu; }
+__device__ __forceinline__ u32 qRel(u32 e) { return (e >> 10) & 0x1FFFu; }
+__device__ __forceinline__ u32 qSig(u32 e) { return (e >> 23) & 15u; }
+__device__ __forceinline__ u32 qSteps(u32 e) { return e >> 27; }
+
+// What a discovery workgroup needs of the band header; every workgroup reads it for itself (three 16-byte loads of
+// the same address in all lanes).  The full check is done once, by parseBandHeader in workgroup 0: if that one says
+// "not ours" nobody looks at what the others did.
+struct HeadLite { u32 ok, version, dataBegin, blobEnd; };
+template<int DT>
+__device__ __forceinline__ HeadLite parseHeadLite(const u8* __restrict__ blob, u32 sizeGiven)
+{
+  constexpr u32 TB = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
+  HeadLite h = { 0u, 0u, 0u, 0u };
+  if (sizeGiven < 70u) return h;
+  const uint4* src = reinterpret_cast<const uint4*>(blob);
+  const uint4 a = src[0], c = src[1], d = src[2];
+  const u32 version = (a.y >> 16) | (a.z << 16);                    // bytes 6 .. 9
+  // blob size: byte 30 (codec 3) or 34 (codec >= 4), Lerc2.cpp:790-917
+  const u32 size3 = (c.w >> 16) | (d.x << 16), size4 = (d.x >> 16) | (d.y << 16);
+  h.version = version;
+  const u32 hdr = (version >= 6u) ? 90u : (version >= 4u) ? 66u : 62u;
+  h.dataBegin = hdr + 4u + ((version >= 4u) ? 2u * TB : 0u) + 1u;   // mask byte count, ranges, one-sweep flag
+  h.blobEnd = min((version >= 4u) ? size4 : size3, sizeGiven);
+  h.ok = (version >= 3u && version <= 6u && h.blobEnd > h.dataBegin) ? 1u : 0u;
+  return h;
+}
+
 template<int DT>
 __device__ __forceinline__ void
-fastCandidatesBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob,
-                  u32* __restrict__ chunkListN, u64* __restrict__ chunkList, FastChain* __restrict__ chains, u32* __restrict__ chainCount,
-                  u32* __restrict__ fallback)
+fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols, const FastDecodeBuffers& b)
 {
-  const FastDecodeParams hp = *P;
-  if (!hp.ok) return;
-  const int version = (int)hp.version;
-  const u32 dataBegin = hp.dataBegin, blobEnd = hp.blobEnd;
-  const FastWalkPlan wp = { hp.nChunks, hp.nBlocks, 0u };
-  if (blockIdx.x * kWalkG >= wp.nChunks)    // the grid is sized for the largest stream the blob could hold
-  {
-    if (threadIdx.x == 0) chainCount[blockIdx.x] = 0u;
-    return;
-  }
   constexpr int TBYTES = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
-  constexpr u32 W = kFastWindow(TBYTES), RAW = 1 + 64 * TBYTES;
-  constexpr u32 kHead = (W + kMinSteps * RAW + 16 + 15) & ~15u;             // staged bytes per chunk, from its 16-byte aligned start
-  constexpr u32 kSlice = kHead + 32;                                        // LDS bytes per chunk
-  constexpr u32 kQueueCap = (kWalkG * W * 3) / 4;    // live candidates after the first step (noise: 3/8 with codec >= 5, 3/4 before)
-  constexpr int kRounds = (int)((kWalkG * (kSlice / 16) + 255) / 256);
-  static_assert(kWalkG * W <= 0x2000 && W - 1 + (kMinSteps + 1) * RAW <= 0xFFF, "queue entry fields");
-  __shared__ __align__(16) u32 s_in[kWalkG * kSlice / 4];
-  __shared__ u32 s_qa[kQueueCap], s_qb[kQueueCap];
-  __shared__ u32 s_hkey[kHashSize];
-  __shared__ u16 s_hval[kHashSize];
-  __shared__ u16 s_slot[kSurvivorCap];       // hash slot | owner << 15 of every survivor
-  __shared__ u32 s_done[kSurvivorCap];       // survivors: queue entry ...
-  __shared__ u8 s_doneSteps[kSurvivorCap];   // ... and the steps it took
-  __shared__ u32 s_nq[3], s_nDone, s_nChains, s_over;    // three queue counters in rotation: one barrier per round
-  __shared__ u32 s_listN[kWalkG];
+  constexpr u32 W = kFastWindow(TBYTES);
+  constexpr u32 CH = kFastChunkBytes, NCH = (u32)kDiscChunks, LPC = (u32)kDiscLanes, NW = (u32)kDiscWalks;
+  constexpr u32 kUnits = NCH * CH / 16;                    // 16-byte units a workgroup owns
+  constexpr u32 kStageUnits = kUnits + 1;                  // + the first bytes of the block that may start right before the end
+  constexpr u32 QCAP = (TBYTES == 8 || W < 200u) ? W : 200u;    // positions of a chunk's window whose flag byte passes (7 of 16 on noise; all four offset types of float64 are valid: half)
+  constexpr u32 kBitWords = (W + 31) / 32;
+  static_assert(NCH * LPC == 256 && NW == 8 && W < 1024 && CH + 64 * TBYTES + 1 < 8192, "lane layout / queue entry fields");
+  __shared__ __align__(16) u32 s_in[kStageUnits * 4];
+  __shared__ u32 s_q[NCH][QCAP];
+  __shared__ u32 s_bits[NCH][kBitWords];
+  __shared__ u16 s_final[NCH][NW];
+  __shared__ u32 s_nFinal[NCH];
+  __shared__ u32 s_exit[NCH][NW];
+  __shared__ u64 s_fa[4], s_fb[4];
+  __shared__ u32 s_over;
 
   PROBE_BEGIN;
-  const u32 c0 = blockIdx.x * kWalkG;
-  const u32 nChunksHere = min((u32)kWalkG, wp.nChunks - c0);
-  {
-    uint4 x[kRounds];
+  const int lane = laneId(), w = waveId();
+  const u32 c0 = blockIdx.x * NCH;                         // first chunk of this workgroup
+  const u32 r0 = c0 * CH;                                  // blob offset of LDS byte 0
+
+  // ---- all loads in flight first: the workgroup's chunks (clipped to what the caller says is readable) ...
+  constexpr int kRounds = (int)((kStageUnits + 255) / 256);
+  uint4 x[kRounds];
 #pragma unroll
-    for (int k = 0; k < kRounds; k++)    // all loads in flight before the first LDS store
+  for (int k = 0; k < kRounds; k++)
+  {
+    const u32 i = (u32)k * 256u + threadIdx.x;
+    const u64 a = (u64)r0 + 16ull * i;
+    x[k] = make_uint4(0, 0, 0, 0);
+    if (i < kStageUnits)
     {
-      const u32 i = (u32)k * 256u + threadIdx.x;
-      const u32 g = i / (kSlice / 16), q = i - g * (kSlice / 16);
-      const u32 src = ((dataBegin + (c0 + g) * kFastChunkBytes) & ~15u) + q * 16u;
-      x[k] = make_uint4(0, 0, 0, 0);
-      if (g < nChunksHere)
+      if (a + 16 <= sizeGiven) x[k] = *reinterpret_cast<const uint4*>(blob + a);
+      else if (a < sizeGiven)    // never read past the blob
       {
-        if (src + 16 <= blobEnd) x[k] = *reinterpret_cast<const uint4*>(blob + src);
-        else if (src < blobEnd)
-        {
-          u32 t4[4] = { 0, 0, 0, 0 };
-          for (u32 b = 0; src + b < blobEnd; b++) t4[b >> 2] |= (u32)blob[src + b] << (8 * (b & 3));    // never read past the blob
-          x[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-        }
+        u32 t4[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (u32 q = 0; q < 16; q++) if (a + q < sizeGiven) t4[q >> 2] |= (u32)blob[a + q] << (8 * (q & 3));
+        x[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
       }
     }
+  }
+  // ... and the band header
+  HeadLite hl;
+  if (blockIdx.x == 0)
+  {
+    const FastDecodeParams hp = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
+    if (threadIdx.x == 0) *b.params = hp;
+    hl.ok = hp.ok; hl.version = hp.version; hl.dataBegin = hp.dataBegin; hl.blobEnd = hp.blobEnd;
+  }
+  else hl = parseHeadLite<DT>(blob, sizeGiven);
+  const u32 nChunks = (hl.blobEnd + CH - 1) / CH;
+  if (!hl.ok || c0 >= nChunks) return;    // (the grid is sized for the largest stream the blob could hold)
+  const int version = (int)hl.version;
+  const u32 dataBegin = hl.dataBegin, blobEnd = hl.blobEnd;
+
+  // ---- stage + Fletcher terms of the units this workgroup owns (bytes 14 ... blobEnd - 1 of the blob are checksummed)
+  u32 fA = 0;
+  u64 fB = 0;
 #pragma unroll
-    for (int k = 0; k < kRounds; k++)
+  for (int k = 0; k < kRounds; k++)
+  {
+    const u32 i = (u32)k * 256u + threadIdx.x;
+    if (i < kStageUnits) *reinterpret_cast<uint4*>(&s_in[i * 4]) = x[k];
+    const u64 a = (u64)r0 + 16ull * i;
+    if (i < kUnits && a < blobEnd)
     {
-      const u32 i = (u32)k * 256u + threadIdx.x;
-      if (i < kWalkG * (kSlice / 16)) *reinterpret_cast<uint4*>(&s_in[i * 4]) = x[k];
+      uint4 y = x[k];
+      if (a == 0 || a + 16 > blobEnd)    // blank what is not checksummed: the first 14 bytes, whatever lies behind the blob
+      {
+        u32 wd[4] = { y.x, y.y, y.z, y.w };
+#pragma unroll
+        for (u32 q = 0; q < 16; q++)
+          if (a + q < 14u || a + q >= blobEnd) wd[q >> 2] &= ~(0xFFu << (8 * (q & 3)));
+        y = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+      }
+      // unit at blob offset a holds words (a - 14) / 2 ...; the first unit's index -7 as its residue mod 65535
+      fletcherUnit(y, a ? (a - 14u) / 2u : 65528ull, fA, fB);
     }
   }
-  for (u32 i = threadIdx.x; i < kHashSize; i += 256) s_hkey[i] = 0;
-  if (threadIdx.x == 0) { s_nq[0] = 0; s_nq[1] = 0; s_nq[2] = 0; s_nDone = 0; s_nChains = 0; s_over = 0; }
-  if (threadIdx.x < kWalkG) s_listN[threadIdx.x] = 0;
-  __syncthreads();
-  PROBE(0);
-
-  const u32 pattern = (version >= 5) ? 14u : 15u;
-
-  // ---- step 1: every window position of every chunk
-  const u32 nCand = nChunksHere * W;
-  for (u32 base = 0; base < nCand; base += 256)
   {
-    const u32 f = base + threadIdx.x;
-    const u32 g = f / W, o = f - g * W;
-    const u32 chunkStart = dataBegin + (c0 + g) * kFastChunkBytes;
-    const u32 chunkEnd = min(chunkStart + kFastChunkBytes, blobEnd);
+    const u64 A = waveSum((u64)fA % 65535u), B = waveSum(fB % 65535u);
+    if (lane == 0) { s_fa[w] = A; s_fb[w] = B; }
+  }
+  if (threadIdx.x == 0) s_over = 0u;
+  __syncthreads();
+  PROBE(16);
+  if (threadIdx.x == 0)
+  {
+    b.waveFletcher[2 * (size_t)blockIdx.x] = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u;
+    b.waveFletcher[2 * (size_t)blockIdx.x + 1] = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
+  }
+
+  // ---- candidates.  Lanes g * LPC ... of wave w own chunk c0 + 4 w + g.
+  const u32 g = (u32)lane / LPC, sl = (u32)lane % LPC;
+  const u32 cl = (u32)w * 4u + g;                                         // chunk inside the workgroup
+  const u32 chunk = c0 + cl;
+  const u32 chunkStart = chunk * CH;                                      // (no overflow: chunk < nChunks)
+  const bool chunkLive = chunk < nChunks;
+  const u32 chunkEnd = chunkLive ? min(chunkStart + CH, blobEnd) : chunkStart;
+  const u32 pattern = (version >= 5) ? 14u : 15u;
+  const u32 groupShift = g * LPC;
+  const u32 belowMe = (1u << sl) - 1u;
+  bool overflow = false;
+  u32* __restrict__ q = s_q[cl];
+
+  // step 0: window positions whose first byte can be a block's flag byte (Lerc2.cpp:1961-1973: bits 0-1 how the block
+  // is coded, bit 2 -- codec >= 5 -- "difference to the previous slice", never set with nDepth == 1, bits 6-7 the type of
+  // the offset, which only bit-stuffed and constant blocks have); the chunk that holds the first block: that block only.
+  // Before codec 5 bit 2 belongs to the signature and 7 of 8 bytes pass, more than the queue holds: those take their
+  // first two blocks at once.
+  u32 nq = 0;                                                             // entries in this chunk's queue (the same in all its lanes)
+  for (u32 o0 = 0; o0 < W; o0 += LPC)
+  {
+    const u32 o = o0 + sl;
     const u32 cur = chunkStart + o;
-    bool live = (f < nCand) & (cur < chunkEnd) & ((c0 + g != 0) | (o == 0));    // the very first block of the stream is known
-    u32 sig = kNoOffset, code = 0;
-    if (live) code = stepAt<DT>(s_in + g * (kSlice / 4), chunkStart & ~15u, cur, blobEnd, version, sig, pattern);
-    live = live & (code != 0u);
-    queuePush(live, qMake(f, o + codeLen(code), sig), s_qa, &s_nq[0], kQueueCap, &s_over);
-  }
-  __syncthreads();
-
-  // ---- further steps through compacting queues (most candidates die at once); who has left the window (or the
-  // chunk) is a survivor
-  u32* qIn = s_qa;
-  u32* qOut = s_qb;
-  for (int round = 1; ; round++)
-  {
-    const u32 nIn = min(s_nq[(round - 1) % 3], kQueueCap);
-    if (nIn == 0) break;
-    if (threadIdx.x == 0) s_nq[(round + 1) % 3] = 0;    // read for the last time two barriers ago
-    const bool lastRound = round >= kMaxRounds;
-    for (u32 base = 0; base < nIn; base += 256)
+    bool live = chunkLive && o < W && cur < chunkEnd && (chunkStart <= dataBegin ? cur == dataBegin : true);
+    u32 entry = qMake(o, o, kNoOffset, 0u);
+    if (live && version >= 5)
     {
-      const u32 i = base + threadIdx.x;
-      const u32 e = (i < nIn) ? qIn[i] : 0;
-      const u32 g = qCand(e) / W;
-      const u32 chunkStart = dataBegin + (c0 + g) * kFastChunkBytes;
-      const u32 chunkEnd = min(chunkStart + kFastChunkBytes, blobEnd);
-      const u32 cur = chunkStart + qRel(e);
-      const bool have = i < nIn;
-      const bool done = have & (((qRel(e) >= W) & (round >= kMinSteps)) | (cur >= chunkEnd) | lastRound);
-      bool live = have & !done;
-      u32 out = e;
-      if (live)
+      const u32 rel = cur - r0;
+      const u32 flag = (s_in[rel >> 2] >> (8u * (rel & 3u))) & 0xFFu;
+      const bool hasOffset = (flag & 1u) != 0u;                           // bit-stuffed or constant
+      live = !(flag & 4u) && !(hasOffset && ((offBytesTable<DT>() >> ((flag >> 4) & 12u)) & 15u) == 0u);
+    }
+    else if (live)
+    {
+      u32 sig = kNoOffset, rel = o, steps = 0;
+      for (int k = 0; k < 2 && live && chunkStart + rel < chunkEnd; k++)
       {
-        u32 sig = qSig(e);
-        const u32 code = stepAt<DT>(s_in + g * (kSlice / 4), chunkStart & ~15u, cur, blobEnd, version, sig, pattern);
+        const u32 code = stepAt<DT>(s_in, r0, chunkStart + rel, blobEnd, version, sig, pattern);
         live = code != 0u;
-        out = qMake(qCand(e), qRel(e) + codeLen(code), sig);
+        rel += codeLen(code); steps++;
       }
-      queuePush(live, out, qOut, &s_nq[round % 3], kQueueCap, &s_over);
-      // survivors: wave-aggregated append, like queuePush
-      const u64 m = __ballot(done);
-      if (m)
-      {
-        const int lane = laneId(), leader = __ffsll((long long)m) - 1;
-        u32 at = 0;
-        if (lane == leader) at = atomicAdd(&s_nDone, (u32)__popcll(m));
-        at = __shfl(at, leader) + (u32)__popcll(m & laneMaskLt());
-        if (done) { if (at < kSurvivorCap) { s_done[at] = e; s_doneSteps[at] = (u8)round; } else s_over = 1; }
-      }
+      entry = qMake(o, rel, sig, steps);
     }
-    __syncthreads();
-    u32* t = qIn; qIn = qOut; qOut = t;
+    const u32 gm = (u32)(__ballot(live) >> groupShift) & ((1u << LPC) - 1u);
+    const u32 at = nq + (u32)__popc(gm & belowMe);
+    if (live) { if (at < QCAP) q[at] = entry; else overflow = true; }
+    nq = min(nq + (u32)__popc(gm), QCAP);
   }
-  const u32* qs = s_done;                                          // the survivors
-  const u32 nSvAll = s_nDone;
-  const u32 nSv = min(nSvAll, kSurvivorCap);
-  PROBE(1);
+  waveSync();
+  PROBE(17);
 
-  // ---- merge the survivors into distinct chains: same chunk, position and signature behave alike from here on
-  for (u32 i = threadIdx.x; i < nSv; i += 256)
+  // further blocks through the queues, compacted in place (a round reads LPC entries before it writes at most LPC at
+  // or before them); who is still valid after kFilterSteps blocks (or has reached the chunk's end) is a survivor
+  const bool v5 = version >= 5;
+  constexpr u32 kMaxRel = NCH * CH - 1;                                   // last staged byte a block may start at
+  for (int pass = 0; pass < kFilterSteps; pass++)
   {
-    const u32 e = qs[i];
-    const u32 key = (e >> 13 & 0xFFFFu) | ((qCand(e) / W) << 16) | 0x80000000u;    // position + signature, chunk
-    u32 h = (key * 2654435761u) >> 22;                             // 10 bits
-    u32 owner = 0;
-    for (;;)
+    u32 nOut = 0;
+    bool pending = false;
+    for (u32 i0 = 0; __any(i0 < nq); i0 += LPC)
     {
-      const u32 old = atomicCAS(&s_hkey[h], 0u, key);
-      if (old == 0u) { s_hval[h] = (u16)atomicAdd(&s_nChains, 1u); owner = 1; break; }
-      if (old == key) break;
-      h = (h + 1) & (kHashSize - 1);
+      const u32 i = i0 + sl;
+      const bool have = i < nq;
+      const u32 e = have ? q[i] : 0u;
+      const u32 rel = qRel(e), steps = qSteps(e);
+      const u32 cur = chunkStart + rel;
+      const bool doStep = have && steps < (u32)kFilterSteps && cur < chunkEnd;
+      u32 sg;
+      const u32 len = stepLean<DT>(s_in, min(cur - r0, kMaxRel), blobEnd - min(cur, blobEnd), v5, steps ? qSig(e) : kNoOffset, pattern, sg);
+      const bool live = have && (!doStep || len != 0u);
+      const u32 rel2 = doStep ? rel + len : rel, steps2 = doStep ? steps + 1u : steps, sig2 = doStep ? sg : qSig(e);
+      pending = pending || (live && steps2 < (u32)kFilterSteps && chunkStart + rel2 < chunkEnd);
+      waveSync();    // every lane has read its entry
+      const u32 gm = (u32)(__ballot(live) >> groupShift) & ((1u << LPC) - 1u);
+      if (live) q[nOut + (u32)__popc(gm & belowMe)] = qMake(qStart(e), rel2, sig2, steps2);
+      nOut += (u32)__popc(gm);
+      waveSync();
     }
-    s_slot[i] = (u16)(h | (owner << 15));
+    nq = nOut;
+    if (!__any(pending)) break;
   }
+  PROBE(18);
+  // Survivors that sit on one path (the true path crosses the window in several blocks, each of them a survivor; a run
+  // of constant blocks makes every byte one) need one walk, from the first of them: a survivor that is the block
+  // right behind another survivor is dropped (its predecessor is valid for kFilterSteps blocks too, hence a survivor).
+  for (u32 i = sl; i < kBitWords; i += LPC) s_bits[cl][i] = 0u;
+  waveSync();
+  for (u32 i0 = 0; __any(i0 < nq); i0 += LPC)
+    if (i0 + sl < nq) { const u32 st = qStart(q[i0 + sl]); atomicOr(&s_bits[cl][st >> 5], 1u << (st & 31u)); }
+  waveSync();
+  for (u32 i0 = 0; __any(i0 < nq); i0 += LPC)
+  {
+    if (i0 + sl < nq)
+    {
+      const u32 st = qStart(q[i0 + sl]);
+      u32 sg;
+      const u32 nx = st + stepLean<DT>(s_in, chunkStart + st - r0, blobEnd - (chunkStart + st), v5, kNoOffset, pattern, sg);    // valid: it was a moment ago
+      if (nx < W) atomicAnd(&s_bits[cl][nx >> 5], ~(1u << (nx & 31u)));
+    }
+  }
+  waveSync();
+  u32 nFinal = 0;
+  for (u32 i0 = 0; __any(i0 < nq); i0 += LPC)
+  {
+    const u32 st = (i0 + sl < nq) ? qStart(q[i0 + sl]) : 0u;
+    const bool head = i0 + sl < nq && ((s_bits[cl][st >> 5] >> (st & 31u)) & 1u) != 0u;
+    const u32 gd = (u32)(__ballot(head) >> groupShift) & ((1u << LPC) - 1u);
+    if (head)
+    {
+      const u32 at = nFinal + (u32)__popc(gd & belowMe);
+      if (at < NW) s_final[cl][at] = (u16)st; else overflow = true;
+    }
+    nFinal = min(nFinal + (u32)__popc(gd), NW);
+  }
+  if (sl == 0) s_nFinal[cl] = chunkLive ? nFinal : 0u;
+  if (__any(overflow) && lane == 0) s_over = 1u;
+  PROBE(19);
   __syncthreads();
-  const u32 nChains = s_nChains;
-  const u32 chainBase = blockIdx.x * kChainCap;
-  const bool over = (s_over != 0u) | (nSvAll > kSurvivorCap) | (nChains > kChainCap);
-  if (threadIdx.x == 0) chainCount[blockIdx.x] = over ? 0u : nChains;
+  PROBE(20);
 
-  // ---- hand the chains and the survivor lists (start, steps so far, chain) of every chunk over
-  if (!over)
+  // ---- walks: the path heads of all 16 chunks, lane = (chunk, head); waves 0 and 1 take heads 0-3 and 4-7 (there are
+  // seldom more than two), the other waves are done
+  if (w < 2)
   {
-    for (u32 i = threadIdx.x; i < nSv; i += 256)
+    const u32 wc = (u32)lane >> 2, slot = ((u32)lane & 3u) + 4u * (u32)w;    // chunk inside the workgroup, head
+    const u32 wChunk = c0 + wc;
+    const u32 wStart = wChunk * CH;
+    const bool wLive = wChunk < nChunks;
+    const u32 wEnd = wLive ? min(wStart + CH, blobEnd) : wStart;
+    const bool walker = wLive && slot < s_nFinal[wc];
+    u32 cur = wStart + (walker ? (u32)s_final[wc][slot] : 0u);
+    u32 sig = kNoOffset, count = 0;
+    bool alive = walker, tooMany = false;
+    u16 first[kRecPrefix];
+#pragma unroll
+    for (int k = 0; k < kRecPrefix; k++) first[k] = (u16)0xFFFFu;
+    u16* __restrict__ list = b.lists + ((size_t)wChunk * NW + slot) * kFastListCap;
+    bool active = alive && cur < wEnd;
+    while (__any(active))
     {
-      const u32 e = qs[i];
-      const u32 f = qCand(e), g = f / W, o = f - g * W;
-      const u32 slot16 = s_slot[i];
-      const u32 chain = chainBase + s_hval[slot16 & 0x7FFFu];
-      const u32 slot = atomicAdd(&s_listN[g], 1u);
-      if (slot < (u32)kFastListCap) chunkList[(size_t)(c0 + g) * kFastListCap + slot] = (u64)(o | ((u32)s_doneSteps[i] << 16)) | ((u64)chain << 32);
-      if (slot16 >> 15)
-      {
-        FastChain ch;
-        ch.cur = dataBegin + (c0 + g) * kFastChunkBytes + qRel(e);
-        ch.chunkSig = (c0 + g) | (qSig(e) << 28);
-        ch.exit = 0; ch.count = 0; ch.alive = 0;
-        for (int j = 0; j < kFastSubPerChunk; j++) { ch.marks[j] = 0; ch.markCount[j] = 0; }
-        chains[chain] = ch;
-      }
+      u32 sg;
+      const u32 len = stepLean<DT>(s_in, min(cur - r0, kMaxRel), blobEnd - min(cur, blobEnd), v5, sig, pattern, sg);
+      const bool room = count < (u32)kFastListCap;
+      const bool ok = active && len != 0u && room;
+      tooMany = tooMany || (active && len != 0u && !room);
+      const u16 at = (u16)(cur - wStart);
+      if (ok) list[count] = at;
+#pragma unroll
+      for (int k = 0; k < kRecPrefix; k++) first[k] = (ok && count == (u32)k) ? at : first[k];
+      alive = alive && (!active || ok);
+      cur += ok ? len : 0u;
+      count += ok ? 1u : 0u;
+      sig = ok ? sg : sig;
+      active = alive && cur < wEnd;
     }
+    s_exit[wc][slot] = alive ? cur : kNoOffset;
+    if (wLive)
+    {
+      FastChunkRec* rec = b.recs + wChunk;
+#pragma unroll
+      for (int k = 0; k < kRecPrefix; k++) rec->first[slot][k] = first[k];
+      rec->count[slot] = alive ? (u16)count : (u16)0xFFFFu;
+    }
+    if (__any(tooMany) && lane == 0) s_over = 1u;
   }
+  PROBE(21);
   __syncthreads();
-  if (threadIdx.x < nChunksHere)
+  // what all live walks of a chunk agree on
+  if (threadIdx.x < NCH && c0 + threadIdx.x < nChunks)
   {
-    // (no survivor at all is fine for the last chunk of a stream when the last block begins before it: k_fast_resolve
-    // tells a chunk without its true entry from an empty one)
-    const bool ok = !over && s_listN[threadIdx.x] <= (u32)kFastListCap;
-    chunkListN[c0 + threadIdx.x] = ok ? s_listN[threadIdx.x] : 0u;
-    if (!ok) atomicOr(fallback, 1u);
-  }
-  PROBE(2);
-}
-
-// ------------------------------------------------------------------------------------------------
-// chains
-// ------------------------------------------------------------------------------------------------
-template<int DT>
-__device__ __forceinline__ void
-fastChainsBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, FastChain* __restrict__ chains,
-              const u32* __restrict__ chainCount, u32 chainCap)
-{
-  const FastDecodeParams hp = *P;
-  if (!hp.ok) return;
-  const int version = (int)hp.version;
-  const u32 dataBegin = hp.dataBegin, blobEnd = hp.blobEnd;
-  const u32 t = blockIdx.x * 256u + threadIdx.x;    // chain slot: kChainCap per candidates workgroup
-  if (t >= chainCap || t % kChainCap >= chainCount[t / kChainCap]) return;
-  constexpr int NS = kFastSubPerChunk;
-  const u32 pattern = (version >= 5) ? 14u : 15u;
-  const FastChain ch = chains[t];
-  const u32 chunk = ch.chunkSig & 0x0FFFFFFFu;
-  const u32 chunkStart = dataBegin + chunk * kFastChunkBytes;
-  const u32 chunkEnd = min(chunkStart + kFastChunkBytes, blobEnd);
-  u32 cur = ch.cur, sig = ch.chunkSig >> 28, count = 0;
-  u32 nextSub = (cur - chunkStart) / kFastSubBytes + 1;    // boundaries at or before the chain start are nobody's
-  u32 nextBoundary = chunkStart + nextSub * kFastSubBytes;
-  u16 marks[NS], markCount[NS];
+    u32 lo = kNoOffset, hi = 0u, n = 0u;
 #pragma unroll
-  for (int j = 0; j < NS; j++) { marks[j] = 0; markCount[j] = 0; }
-  bool alive = true;
-  while (cur < chunkEnd)
-  {
-    const u32 code = stepGlobal<DT>(blob, cur, blobEnd, version, sig, pattern);
-    if (code == 0u) { alive = false; break; }
-    cur += codeLen(code); count++;
-    while (nextSub < (u32)NS && cur >= nextBoundary)
+    for (u32 k = 0; k < NW; k++)
     {
-#pragma unroll
-      for (int j = 1; j < NS; j++) if ((u32)j == nextSub) { marks[j] = (u16)(cur - chunkStart); markCount[j] = (u16)count; }
-      nextSub++; nextBoundary += kFastSubBytes;
+      const u32 e = s_exit[threadIdx.x][k];
+      if (e != kNoOffset) { lo = min(lo, e); hi = max(hi, e); n++; }
     }
+    FastChunkRec* rec = b.recs + c0 + threadIdx.x;
+    rec->exit = (n != 0u && lo == hi) ? lo : kNoOffset;
+    rec->nLive = n;
   }
-  FastChain out = ch;
-  out.exit = cur; out.count = (u16)count; out.alive = alive ? 1 : 0;
-#pragma unroll
-  for (int j = 0; j < NS; j++) { out.marks[j] = marks[j]; out.markCount[j] = markCount[j]; }
-  chains[t] = out;
+  if (threadIdx.x == 0 && s_over) b.fallback[0] = b.epoch;
 }
 
 // ------------------------------------------------------------------------------------------------
 // resolve
 // ------------------------------------------------------------------------------------------------
-// the exit every live chain of chunk c agrees on, or kNoOffset
-__device__ __forceinline__ u32 agreedExit(u32 c, const u32* __restrict__ chunkListN, const u64* __restrict__ chunkList,
-                                          const FastChain* __restrict__ chains)
+// One thread per chunk.  Only the exits need agreement (they break the chunk-to-chunk dependency): once the entry of
+// a chunk is known, the walk that starts there IS the true path.  The counts are scanned inside the workgroup; the
+// gather step adds the sums of the workgroups before its own.  Workgroup 0 also folds the checksum terms.
+__device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 nWavesBound)
 {
-  const u32 n = min(chunkListN[c], (u32)kFastListCap);
-  u32 ex = kNoOffset;
-  bool any = false, same = true;
-  for (u32 i = 0; i < n; i++)
-  {
-    const FastChain& ch = chains[(u32)(chunkList[(size_t)c * kFastListCap + i] >> 32)];
-    if (!ch.alive) continue;
-    if (!any) { ex = ch.exit; any = true; }
-    else if (ch.exit != ex) same = false;
-  }
-  return (any && same) ? ex : kNoOffset;
-}
-
-template<int DT>
-__device__ __forceinline__ void
-fastResolveBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ chunkListN,
-               const u64* __restrict__ chunkList, const FastChain* __restrict__ chains, u32* __restrict__ chunkEntry,
-               u32* __restrict__ chunkCount, u32* __restrict__ subEntry, u32* __restrict__ subIndex, u32* __restrict__ fallback)
-{
-  const FastDecodeParams hp = *P;
+  __shared__ u32 s_w[kResolveWG / 64];
+  __shared__ u64 s_a[kResolveWG / 64], s_b[kResolveWG / 64];
+  const FastDecodeParams hp = *b.params;
   if (!hp.ok) return;
-  const int version = (int)hp.version;
-  const u32 dataBegin = hp.dataBegin, blobEnd = hp.blobEnd;
-  const FastWalkPlan wp = { hp.nChunks, hp.nBlocks, 0u };
-  constexpr int NS = kFastSubPerChunk;
-  const u32 c = blockIdx.x * 256u + threadIdx.x;
-  if (c > wp.nChunks) return;
-  if (c == wp.nChunks) { chunkEntry[c] = blobEnd; return; }
-  // Only the exits need agreement (they break the chunk-to-chunk dependency).  Once the entry of this chunk is
-  // known, the survivor that starts there IS the true path, and so is the chain it merged into.
-  const u32 e = (c == 0) ? dataBegin : agreedExit(c - 1, chunkListN, chunkList, chains);
-  chunkEntry[c] = e;
-  const u32 chunkStart = dataBegin + c * kFastChunkBytes;
-  const u32 n = min(chunkListN[c], (u32)kFastListCap);
-  u32 steps = 0, chainIdx = kNoOffset;
-  for (u32 i = 0; i < n; i++)
+  const u32 blobEnd = hp.blobEnd;
+  const u32 c = blockIdx.x * kResolveWG + threadIdx.x;
+  const int lane = laneId(), w = waveId();
+  u32 count = 0, laneOfPath = kNoOffset;
+  bool bad = false;
+  if (c < hp.nChunks)
   {
-    const u64 rec = chunkList[(size_t)c * kFastListCap + i];
-    if (e != kNoOffset && ((u32)rec & 0xFFFFu) == e - chunkStart) { steps = ((u32)rec >> 16) & 0xFFFFu; chainIdx = (u32)(rec >> 32); }
-  }
-  u32 pos[NS], idx[NS];
-#pragma unroll
-  for (int j = 0; j < NS; j++) { pos[j] = kNoOffset; idx[j] = 0; }
-  u32 count = 0;
-  bool ok = chainIdx != kNoOffset;
-  // the last block of the stream may begin before the last chunk and end with it: nothing starts in that chunk
-  const bool emptyTail = e != kNoOffset && e >= min(chunkStart + kFastChunkBytes, blobEnd);
-  if (emptyTail) ok = (e == blobEnd);
-  else if (ok)
-  {
-    const FastChain ch = chains[chainIdx];
-    ok = ch.alive != 0;
-    // the first steps, before the survivor joined its chain
-    const u32 pattern = (version >= 5) ? 14u : 15u;
-    u32 cur = e, sig = kNoOffset, nextSub = 1;
-    pos[0] = e;
-    for (u32 s = 0; s < steps && ok; s++)
+    const u32 chunkStart = c * kFastChunkBytes, chunkEnd = min(chunkStart + kFastChunkBytes, blobEnd);
+    const u32 e = (chunkStart <= hp.dataBegin) ? hp.dataBegin : b.recs[c - 1].exit;
+    if (e == kNoOffset || e < chunkStart) bad = true;
+    else if (e >= chunkEnd) bad = (e != blobEnd);    // the last block may begin before the last chunk and end with it
+    else
     {
-      const u32 code = stepGlobal<DT>(blob, cur, blobEnd, version, sig, pattern);
-      if (code == 0u) { ok = false; break; }
-      cur += codeLen(code);
-      while (nextSub < (u32)NS && cur >= chunkStart + nextSub * kFastSubBytes)
+      const FastChunkRec rec = b.recs[c];
+      const u32 rel = e - chunkStart;
+      // the walk the entry lies on: normally a walk starts there; else it is one of the first blocks of a walk that
+      // began a little earlier (a stray byte in front of the entry that looks like a one byte block), or -- long runs
+      // of tiny blocks -- somewhere in its list
+#pragma unroll
+      for (int l = 0; l < kDiscWalks; l++)
+#pragma unroll
+        for (int k = 0; k < kRecPrefix; k++)
+          if ((u32)rec.first[l][k] == rel && rec.count[l] != 0xFFFFu && laneOfPath == kNoOffset) { laneOfPath = (u32)l | ((u32)k << 8); count = rec.count[l] - (u32)k; }
+      if (laneOfPath == kNoOffset && rec.exit != kNoOffset)
       {
 #pragma unroll
-        for (int j = 1; j < NS; j++) if ((u32)j == nextSub) { pos[j] = cur; idx[j] = s + 1; }
-        nextSub++;
+        for (int l = 0; l < kDiscWalks; l++)
+        {
+          const u32 n = rec.count[l];
+          if (laneOfPath != kNoOffset || n == 0xFFFFu || n <= (u32)kRecPrefix || (u32)rec.first[l][0] > rel) continue;
+          const u16* __restrict__ list = b.lists + ((size_t)c * kDiscWalks + l) * kFastListCap;
+          u32 lo = kRecPrefix, hi = n;    // first index with list[i] >= rel
+          while (lo < hi) { const u32 mid = (lo + hi) >> 1; if ((u32)list[mid] < rel) lo = mid + 1; else hi = mid; }
+          if (lo < n && (u32)list[lo] == rel) { laneOfPath = (u32)l | (lo << 8); count = n - lo; }
+        }
       }
+      if (laneOfPath == kNoOffset || rec.exit == kNoOffset) bad = true;    // (no agreement on the exit: the next chunk says so too)
     }
-    ok = ok && cur == ch.cur;
-#pragma unroll
-    for (int j = 1; j < NS; j++)
-      if ((u32)j >= nextSub && ch.marks[j] != 0) { pos[j] = chunkStart + ch.marks[j]; idx[j] = steps + ch.markCount[j]; }    // 0: behind the end of the blob
-    count = steps + ch.count;
+    if (bad) count = 0;
+    b.chunkCount[c] = count;
+    b.chunkLane[c] = laneOfPath;
   }
-  if (!ok) { atomicOr(fallback, 2u); count = 0; }
-  chunkCount[c] = count;
+  if (__any(bad) && lane == 0) b.fallback[1] = b.epoch;
+  // exclusive scan of the counts inside the workgroup
+  u32 inc = count;
 #pragma unroll
-  for (int j = 0; j < NS; j++) { subEntry[(size_t)c * NS + j] = (ok && !emptyTail) ? pos[j] : kNoOffset; subIndex[(size_t)c * NS + j] = idx[j]; }
+  for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += o; }
+  if (lane == 63) s_w[w] = inc;
+  __syncthreads();
+  u32 before = 0;
+  for (int i = 0; i < w; i++) before += s_w[i];
+  if (c < hp.nChunks) b.chunkLocal[c] = before + inc - count;
+  if (threadIdx.x == kResolveWG - 1) b.groupSum[blockIdx.x] = before + inc;
+
+  if (blockIdx.x != 0) return;
+  // checksum: Fletcher32 over blob[14 ..) from the discovery waves' partial sums (Lerc2.cpp:1037-1064)
+  const u32 nWaves = min((hp.nChunks + (u32)kDiscChunks - 1u) / (u32)kDiscChunks, nWavesBound);
+  u64 A = 0, B = 0;
+  for (u32 i = threadIdx.x; i < nWaves; i += kResolveWG) { A += b.waveFletcher[2 * (size_t)i]; B += b.waveFletcher[2 * (size_t)i + 1]; }    // each < 65535
+  A = waveSum(A % 65535u); B = waveSum(B % 65535u);
+  if (lane == 0) { s_a[w] = A; s_b[w] = B; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  A = 0; B = 0;
+  for (u32 i = 0; i < kResolveWG / 64; i++) { A += s_a[i]; B += s_b[i]; }
+  A %= 65535u; B %= 65535u;
+  const u64 N = ((u64)(blobEnd - 14u) + 1) / 2;
+  u64 s1 = A, s2 = ((N % 65535u) * A + 65535u - B) % 65535u;
+  if (s1 == 0) s1 = 0xffff;
+  if (s2 == 0) s2 = 0xffff;
+  b.params->checksumOk = ((u32)((s2 << 16) | s1) == hp.expectChecksum) ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
 // block offsets
 // ------------------------------------------------------------------------------------------------
-template<int DT>
-__device__ __forceinline__ void
-fastEmitBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ chunkEntry,
-            const u32* __restrict__ chunkCount, const u32* __restrict__ subEntry, const u32* __restrict__ subIndex,
-            u32* __restrict__ blockOff, u32* __restrict__ fallback)
+__device__ __forceinline__ void fastGatherBody(const FastDecodeBuffers& b)
 {
-  constexpr int NS = kFastSubPerChunk;
-  constexpr u32 kChunksPerWG = 256 / NS;
-  __shared__ u32 s_part[4], s_cbase[kChunksPerWG];
-  const FastDecodeParams hp = *P;
+  static_assert(kFastListCap == 256, "one thread per list entry");
+  __shared__ u32 s_part[4], s_n[kGatherChunks], s_loc[kGatherChunks], s_lane[kGatherChunks];
+  const FastDecodeParams hp = *b.params;
   if (!hp.ok) return;
-  const int version = (int)hp.version;
-  const u32 blobEnd = hp.blobEnd;
-  const FastWalkPlan wp = { hp.nChunks, hp.nBlocks, 0u };
-  const u32 c0 = blockIdx.x * kChunksPerWG;
-  if (c0 >= wp.nChunks) return;              // the grid is sized for the largest stream the blob could hold
+  const u32 cFirst = blockIdx.x * kGatherChunks;
+  if (cFirst >= hp.nChunks) return;          // the grid is sized for the largest stream the blob could hold
   const int lane = laneId(), w = waveId();
-
-  // index of this workgroup's first block: every workgroup adds up the counts of the chunks before its own
-  // (about 100 workgroups x 100 KB out of L2 -- cheaper than a scan kernel in between)
+  if (threadIdx.x < kGatherChunks)
+  {
+    const u32 c = cFirst + threadIdx.x;
+    const bool have = c < hp.nChunks;
+    s_n[threadIdx.x] = have ? b.chunkCount[c] : 0u;
+    s_loc[threadIdx.x] = have ? b.chunkLocal[c] : 0u;
+    s_lane[threadIdx.x] = have ? b.chunkLane[c] : 0u;
+  }
+  // blocks before this workgroup's resolve group
+  const u32 grp = cFirst / kResolveWG;
   u32 sum = 0;
-  for (u32 i = threadIdx.x; i < c0; i += 256u) sum += chunkCount[i];
+  for (u32 i = threadIdx.x; i < grp; i += 256u) sum += b.groupSum[i];
   sum = waveSum(sum);
   if (lane == 0) s_part[w] = sum;
   __syncthreads();
-  if (w == 0)
+  const u32 before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  if (cFirst + kGatherChunks >= hp.nChunks && threadIdx.x == 0)
   {
-    const u32 cc = c0 + (u32)lane;
-    const u32 cnt = (lane < (int)kChunksPerWG && cc < wp.nChunks) ? chunkCount[cc] : 0u;
-    u32 inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += o; }
-    const u32 before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    if (lane < (int)kChunksPerWG) s_cbase[lane] = before + inc - cnt;
-    const u32 total = before + __shfl(inc, 63);
-    if (lane == 0 && c0 + kChunksPerWG >= wp.nChunks)
-    {
-      blockOff[wp.nBlocks] = blobEnd;        // sentinel: end of the last block
-      if (total != wp.nBlocks) atomicOr(fallback, 4u);
-    }
+    // the workgroup that holds the last chunk: sentinel + total
+    const u32 last = hp.nChunks - 1u - cFirst;
+    const u32 total = before + s_loc[last] + s_n[last];
+    b.blockOff[hp.nBlocks] = hp.blobEnd;     // end of the last block
+    if (total != hp.nBlocks) b.fallback[2] = b.epoch;
   }
-  __syncthreads();
-
-  const u32 t = blockIdx.x * 256u + threadIdx.x;
-  const u32 c = t / NS, j = t % NS;
-  if (c >= wp.nChunks || *fallback != 0u) return;    // raised by an earlier kernel: nothing below can be trusted
-  const u32 start = subEntry[(size_t)c * NS + j];
-  if (start == kNoOffset) return;
-  // this lane walks [start, limit): up to the next sub-chunk entry, or the entry of the next chunk.  Entries never
-  // decrease from lane to lane (positions on one path); equal ones (a block spanning two boundaries) leave nothing.
-  u32 limit = chunkEntry[c + 1], endIdx = chunkCount[c];
-  if (j + 1 < (u32)NS)
-  {
-    const u32 nx = subEntry[(size_t)c * NS + j + 1];
-    if (nx != kNoOffset) { limit = nx; endIdx = subIndex[(size_t)c * NS + j + 1]; }
-  }
-  const u32 base = s_cbase[c - c0];
-  u32 at = base + subIndex[(size_t)c * NS + j];
-  u32 cur = start, sig = kNoOffset;
+  if (fastRaised(b.fallback, b.epoch)) return;    // raised by an earlier kernel: nothing below can be trusted
+  const u32 i = threadIdx.x;                       // entry of each chunk's list
   bool bad = false;
-  while (cur < limit)
+#pragma unroll
+  for (u32 k = 0; k < kGatherChunks; k++)
   {
-    const u32 code = stepGlobal<DT>(blob, cur, blobEnd, version, sig, 0u);    // signatures are checked by the decoder
-    if (code == 0u || at >= wp.nBlocks) { bad = true; break; }
-    blockOff[at++] = cur;
-    cur += codeLen(code);
+    const u32 c = cFirst + k, ls = s_lane[k];      // walk | index of the chunk's first block in its list << 8
+    const u32 src = min((ls >> 8) + i, (u32)kFastListCap - 1u);
+    const u32 v = b.lists[((size_t)c * kDiscWalks + (ls & 7u)) * kFastListCap + src];    // (chunks behind the last one: inside the buffer's slack)
+    const u32 at = before + s_loc[k] + i;
+    if (i < s_n[k]) { if (at < hp.nBlocks) b.blockOff[at] = c * kFastChunkBytes + v; else bad = true; }
   }
-  if (bad || cur != limit || at != base + endIdx) atomicOr(fallback, 8u);
+  if (__any(bad) && lane == 0) b.fallback[2] = b.epoch;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -722,14 +754,6 @@ __device__ __forceinline__ u32 ldsBits(const u32* words, u32 bitPos, int nbits)
   return (u32)(x >> sh) & (nbits >= 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1u));
 }
 
-__device__ __forceinline__ void fletcherWordD(u32 x, u32 pos, u64& A, u64& B)
-{
-  const u32 w0 = ((x & 0xFFu) << 8) | ((x >> 8) & 0xFFu), w1 = ((x >> 8) & 0xFF00u) | (x >> 24);
-  const u32 k = pos >> 1;
-  A += w0 + w1;
-  B += (u64)k * w0 + (u64)(k + 1) * w1;
-}
-
 template<class T> __device__ __forceinline__ T dequant(double offset, u32 q, double invScale, double zMax, i64 offI, i64 invI, i64 zMaxI)
 {
   if (DtOf<T>::v >= DT_Float)
@@ -745,7 +769,7 @@ template<class T> __device__ __forceinline__ T dequant(double offset, u32 q, dou
 template<class T, bool WIDE>
 __device__ __forceinline__ void
 fastDecodeBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ blockOff,
-              T* __restrict__ outPix, u64* __restrict__ wgFletcher, const u32* __restrict__ fallback, DeviceStatus* st)
+              T* __restrict__ outPix, u32* __restrict__ fallback, u32 epoch)
 {
   const FastDecodeParams hp = *P;
   if (!hp.ok) return;
@@ -759,8 +783,7 @@ fastDecodeBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ bl
   __shared__ u32 s_off[kFastBlocksPerWG + 1];
   __shared__ u32 s_code[kFastBlocksPerWG];     // parseCode of the block, 0 = bad
   __shared__ double s_offs[kFastBlocksPerWG];
-  __shared__ u64 s_fa[4], s_fb[4];
-  if (*fallback) return;    // only earlier kernels raise it
+  if (fallback[0] == epoch || fallback[1] == epoch || fallback[2] == epoch) return;    // raised by an earlier kernel
 
   PROBE_BEGIN;
   const int w = waveId(), lane = laneId();
@@ -774,15 +797,14 @@ fastDecodeBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ bl
   const u32 spanLen = g1 - g0;
   if (g1 < g0 || spanLen > (u32)(kFastBlocksPerWG * (1 + 64 * (int)sizeof(T))) || g1 > blobEnd)
   {
-    if (threadIdx.x == 0) raiseError(st, kFailed, blockIdx.x);
+    if (threadIdx.x == 0) fallback[3] = epoch;
     return;
   }
   PROBE(8);
-  // ---- stage the span (16-byte loads from the aligned-down start) + Fletcher sums of the owned bytes
+  // ---- stage the span (16-byte loads from the aligned-down start; the checksum was taken care of by the discovery waves)
   const u32 a0 = g0 & ~15u;
   const u32 shift = g0 - a0;
   const u32 nChunks = (shift + spanLen + 15) >> 4;
-  u64 A = 0, B = 0;
   for (u32 ch = threadIdx.x; ch < nChunks; ch += 256)
   {
     uint4 x;
@@ -794,30 +816,8 @@ fastDecodeBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ bl
       x = make_uint4(t4[0], t4[1], t4[2], t4[3]);
     }
     *reinterpret_cast<uint4*>(&s_in[ch * 4]) = x;
-    const u32 lo = ch * 16;
-    if (lo < shift || lo + 16 > shift + spanLen)
-    {
-      // first / last chunk: blank the neighbours' bytes before summing
-      u32 wd[4] = { x.x, x.y, x.z, x.w };
-      for (u32 i = lo; i < lo + 16; i++)
-        if (i < shift || i >= shift + spanLen) wd[(i - lo) >> 2] &= ~(0xFFu << (8 * ((i - lo) & 3)));
-      x = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-    }
-    const u32 pos = a0 + lo - 14;    // a0 + lo is a multiple of 16 and >= 16: even position inside blob[14 ..)
-    fletcherWordD(x.x, pos, A, B);
-    fletcherWordD(x.y, pos + 4, A, B);
-    fletcherWordD(x.z, pos + 8, A, B);
-    fletcherWordD(x.w, pos + 12, A, B);
   }
-  A %= 65535u; B %= 65535u;
-  A = waveSum(A); B = waveSum(B);
-  if (lane == 0) { s_fa[w] = A; s_fb[w] = B; }
   __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    wgFletcher[2 * (size_t)blockIdx.x] = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u;    // folded by k_fast_fletcher_sum
-    wgFletcher[2 * (size_t)blockIdx.x + 1] = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
-  }
   PROBE(9);
 
   // ---- parse the 64 block headers once: lane = block
@@ -845,7 +845,7 @@ fastDecodeBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ bl
     }
     s_offs[lane] = offset;
     s_code[lane] = code;
-    if (__any(code == 0u && exists) && lane == 0) raiseError(st, kFailed, blockIdx.x);
+    if (__any(code == 0u && exists) && lane == 0) fallback[3] = epoch;
   }
   __syncthreads();
   PROBE(10);
@@ -920,31 +920,7 @@ fastDecodeBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ bl
     if (fastSpanHas(span, (u32)blk)) *reinterpret_cast<Vec*>(outPix + at) = o;
   }
   PROBE(11);
-  if (__any(bad) && lane == 0) raiseError(st, kFailed, blockIdx.x);
-}
-
-// folds the workgroups' partial sums and the prefix bytes into the checksum and compares it with the header's
-// (Lerc2.cpp:1037-1064)
-__device__ __forceinline__ void fastFletcherSumBody(FastDecodeParams* __restrict__ P, const u64* __restrict__ wgFletcher, u32 nWG)
-{
-  __shared__ u64 s_a[16], s_b[16];
-  if (!P->ok) return;
-  u64 A = 0, B = 0;
-  for (u32 i = threadIdx.x; i < nWG; i += blockDim.x) { A += wgFletcher[2 * (size_t)i]; B += wgFletcher[2 * (size_t)i + 1]; }    // each < 65535
-  A = waveSum(A % 65535u); B = waveSum(B % 65535u);
-  if (threadIdx.x < 16) { s_a[threadIdx.x] = 0; s_b[threadIdx.x] = 0; }
-  __syncthreads();
-  if (laneId() == 0) { s_a[waveId()] = A; s_b[waveId()] = B; }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  A = P->prefixA; B = P->prefixB;
-  for (int i = 0; i < 16; i++) { A += s_a[i]; B += s_b[i]; }
-  A %= 65535u; B %= 65535u;
-  const u64 N = ((u64)(P->blobEnd - 14u) + 1) / 2;
-  u64 s1 = A, s2 = ((N % 65535u) * A + 65535u - B) % 65535u;
-  if (s1 == 0) s1 = 0xffff;
-  if (s2 == 0) s2 = 0xffff;
-  P->checksumOk = ((u32)((s2 << 16) | s1) == P->expectChecksum) ? 1u : 0u;
+  if (__any(bad) && lane == 0) fallback[3] = epoch;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -958,13 +934,11 @@ bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int n
 
 FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven)
 {
-  // upper bounds from what the caller knows without reading the blob: the shortest header in front of a block
-  // stream is 67 bytes (codec 3: 62-byte header, mask length, one-sweep flag)
+  // upper bounds from what the caller knows without reading the blob
   FastWalkPlan wp;
-  const u32 span = sizeGiven > 67u ? sizeGiven - 67u : 1u;
-  wp.nChunks = (span + kFastChunkBytes - 1) / kFastChunkBytes;
+  wp.nChunks = ((sizeGiven ? sizeGiven : 1u) + kFastChunkBytes - 1) / kFastChunkBytes;
   wp.nBlocks = (u32)(nRows / 8) * (u32)(nCols / 8);
-  wp.chainCap = ((wp.nChunks + kFastCandChunks - 1) / kFastCandChunks) * (u32)(kFastCandChunks * kFastChainsPerChunk);
+  wp.nWaves = (wp.nChunks + (u32)kDiscChunks - 1) / (u32)kDiscChunks;
   return wp;
 }
 
@@ -976,116 +950,80 @@ __device__ __forceinline__ void tileSlice(FastDecodeBuffers& b, const FastDecode
   const size_t tile = blockIdx.y;
   const size_t sChunk = fastChunkStride(t.nChunks);
   b.params += tile; b.fallback += 4 * tile;
-  b.chunkListN += tile * sChunk; b.chunkList += tile * t.nChunks * kFastListCap;
-  b.chains += tile * t.chainCap; b.chainCount += tile * ((t.nChunks + kFastCandChunks - 1) / kFastCandChunks);
-  b.chunkEntry += tile * sChunk; b.chunkCount += tile * sChunk;
-  b.subEntry += tile * t.nChunks * kFastSubPerChunk; b.subIndex += tile * t.nChunks * kFastSubPerChunk;
-  b.blockOff += tile * ((size_t)t.nBlocks + 4); b.wgFletcher += tile * 2 * ((t.nBlocks + kFastBlocksPerWG - 1) / kFastBlocksPerWG);
+  b.recs += tile * t.nChunks; b.lists += tile * t.nChunks * (size_t)(kDiscWalks * kFastListCap);
+  b.chunkCount += tile * sChunk; b.chunkLane += tile * sChunk; b.chunkLocal += tile * sChunk;
+  b.groupSum += tile * ((t.nChunks + kResolveWG - 1) / kResolveWG + 1);
+  b.blockOff += tile * ((size_t)t.nBlocks + 4); b.waveFletcher += tile * 2 * (size_t)t.nWaves;
   if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
 }
 
 template<int DT>
-__global__ void __launch_bounds__(64)
-k_fast_header(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 sizeGiven, int nRows, int nCols, u32* clearStatus)
-{
-  tileSlice(b, t, blob, sizeGiven);
-  fastHeaderBody<DT>(blob, sizeGiven, nRows, nCols, b.params, (b.clearCells && blockIdx.y == 0) ? clearStatus : nullptr,
-                     b.clearCells ? b.fallback : nullptr);
-}
-template<int DT>
 __global__ void __launch_bounds__(256)
-k_fast_candidates(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob)
+k_fast_discover(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 sizeGiven, int nRows, int nCols)
 {
-  u32 sizeGiven = 0;
   tileSlice(b, t, blob, sizeGiven);
-  fastCandidatesBody<DT>(b.params, blob, b.chunkListN, b.chunkList, b.chains, b.chainCount, b.fallback);
+  fastDiscoverBody<DT>(blob, sizeGiven, nRows, nCols, b);
 }
-template<int DT>
-__global__ void __launch_bounds__(256)
-k_fast_chains(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob)
-{
-  u32 sizeGiven = 0;
-  tileSlice(b, t, blob, sizeGiven);
-  fastChainsBody<DT>(b.params, blob, b.chains, b.chainCount, t.chainCap);
-}
-template<int DT>
-__global__ void __launch_bounds__(256)
-k_fast_resolve(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob)
-{
-  u32 sizeGiven = 0;
-  tileSlice(b, t, blob, sizeGiven);
-  fastResolveBody<DT>(b.params, blob, b.chunkListN, b.chunkList, b.chains, b.chunkEntry, b.chunkCount, b.subEntry, b.subIndex, b.fallback);
-}
-template<int DT>
-__global__ void __launch_bounds__(256)
-k_fast_emit(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob)
-{
-  u32 sizeGiven = 0;
-  tileSlice(b, t, blob, sizeGiven);
-  fastEmitBody<DT>(b.params, blob, b.chunkEntry, b.chunkCount, b.subEntry, b.subIndex, b.blockOff, b.fallback);
-}
-template<class T, bool WIDE>
-__global__ void __launch_bounds__(256)
-k_fast_decode(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, T* __restrict__ outPix, DeviceStatus* st)
-{
-  u32 sizeGiven = 0;
-  tileSlice(b, t, blob, sizeGiven);
-  fastDecodeBody<T, WIDE>(b.params, blob, b.blockOff, outPix + (size_t)blockIdx.y * t.tileElems, b.wgFletcher, b.fallback, st);
-}
-__global__ void __launch_bounds__(1024) k_fast_fletcher_sum(FastDecodeBuffers b, FastDecodeBatch t)
+__global__ void __launch_bounds__(kResolveWG) k_fast_resolve(FastDecodeBuffers b, FastDecodeBatch t)
 {
   const u8* blob = nullptr;
   u32 sizeGiven = 0;
   tileSlice(b, t, blob, sizeGiven);
-  fastFletcherSumBody(b.params, b.wgFletcher, (t.nBlocks + kFastBlocksPerWG - 1) / kFastBlocksPerWG);
+  fastResolveBody(b, t.nWaves);
+}
+__global__ void __launch_bounds__(256) k_fast_gather(FastDecodeBuffers b, FastDecodeBatch t)
+{
+  const u8* blob = nullptr;
+  u32 sizeGiven = 0;
+  tileSlice(b, t, blob, sizeGiven);
+  fastGatherBody(b);
+}
+template<class T, bool WIDE>
+__global__ void __launch_bounds__(256)
+k_fast_decode(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, T* __restrict__ outPix)
+{
+  u32 sizeGiven = 0;
+  tileSlice(b, t, blob, sizeGiven);
+  fastDecodeBody<T, WIDE>(b.params, blob, b.blockOff, outPix + (size_t)blockIdx.y * t.tileElems, b.fallback, b.epoch);
 }
 
 template<class T>
 static void launchFastDecodeT(int stage, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
-                              const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st)
+                              const FastDecodeBuffers& b, void* out, hipStream_t st)
 {
   constexpr int DT = DtOf<T>::v;
   const u32 nT = t.nTiles;
   switch (stage)
   {
     case 0:
-      hipLaunchKernelGGL(k_fast_header<DT>, dim3(1, nT), dim3(64), 0, st, b, t, blob, sizeGiven, nRows, nCols, reinterpret_cast<u32*>(status));
+      hipLaunchKernelGGL(k_fast_discover<DT>, dim3(t.nWaves, nT), dim3(256), 0, st, b, t, blob, sizeGiven, nRows, nCols);
       break;
     case 1:
-      hipLaunchKernelGGL(k_fast_candidates<DT>, dim3((t.nChunks + kWalkG - 1) / kWalkG, nT), dim3(256), 0, st, b, t, blob);
+      hipLaunchKernelGGL(k_fast_resolve, dim3((t.nChunks + kResolveWG - 1) / kResolveWG, nT), dim3(kResolveWG), 0, st, b, t);
       break;
     case 2:
-      hipLaunchKernelGGL(k_fast_chains<DT>, dim3((t.chainCap + 255) / 256, nT), dim3(256), 0, st, b, t, blob);
-      break;
-    case 3:
-      hipLaunchKernelGGL(k_fast_resolve<DT>, dim3((t.nChunks + 256) / 256, nT), dim3(256), 0, st, b, t, blob);
-      break;
-    case 4:
-      hipLaunchKernelGGL(k_fast_emit<DT>, dim3((t.nChunks * kFastSubPerChunk + 255) / 256, nT), dim3(256), 0, st, b, t, blob);
-      break;
-    case 5:
-      if ((nCols / 8) % 64 == 0)
-        hipLaunchKernelGGL((k_fast_decode<T, true>), dim3((t.nBlocks + kFastBlocksPerWG - 1) / kFastBlocksPerWG, nT), dim3(256), 0, st, b, t, blob, (T*)out, status);
-      else
-        hipLaunchKernelGGL((k_fast_decode<T, false>), dim3((t.nBlocks + kFastBlocksPerWG - 1) / kFastBlocksPerWG, nT), dim3(256), 0, st, b, t, blob, (T*)out, status);
+      hipLaunchKernelGGL(k_fast_gather, dim3((t.nChunks + kGatherChunks - 1) / kGatherChunks, nT), dim3(256), 0, st, b, t);
       break;
     default:
-      hipLaunchKernelGGL(k_fast_fletcher_sum, dim3(1, nT), dim3(nT > 1 ? 256 : 1024), 0, st, b, t);
+      if ((nCols / 8) % 64 == 0)
+        hipLaunchKernelGGL((k_fast_decode<T, true>), dim3((t.nBlocks + kFastBlocksPerWG - 1) / kFastBlocksPerWG, nT), dim3(256), 0, st, b, t, blob, (T*)out);
+      else
+        hipLaunchKernelGGL((k_fast_decode<T, false>), dim3((t.nBlocks + kFastBlocksPerWG - 1) / kFastBlocksPerWG, nT), dim3(256), 0, st, b, t, blob, (T*)out);
       break;
   }
 }
 
 void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
-                      const FastDecodeBuffers& b, void* out, DeviceStatus* status, hipStream_t st)
+                      const FastDecodeBuffers& b, void* out, hipStream_t st)
 {
   switch (dt)
   {
-    case DT_Short:  launchFastDecodeT<short>(stage, nRows, nCols, t, blob, sizeGiven, b, out, status, st); break;
-    case DT_UShort: launchFastDecodeT<unsigned short>(stage, nRows, nCols, t, blob, sizeGiven, b, out, status, st); break;
-    case DT_Int:    launchFastDecodeT<int>(stage, nRows, nCols, t, blob, sizeGiven, b, out, status, st); break;
-    case DT_UInt:   launchFastDecodeT<unsigned int>(stage, nRows, nCols, t, blob, sizeGiven, b, out, status, st); break;
-    case DT_Float:  launchFastDecodeT<float>(stage, nRows, nCols, t, blob, sizeGiven, b, out, status, st); break;
-    case DT_Double: launchFastDecodeT<double>(stage, nRows, nCols, t, blob, sizeGiven, b, out, status, st); break;
+    case DT_Short:  launchFastDecodeT<short>(stage, nRows, nCols, t, blob, sizeGiven, b, out, st); break;
+    case DT_UShort: launchFastDecodeT<unsigned short>(stage, nRows, nCols, t, blob, sizeGiven, b, out, st); break;
+    case DT_Int:    launchFastDecodeT<int>(stage, nRows, nCols, t, blob, sizeGiven, b, out, st); break;
+    case DT_UInt:   launchFastDecodeT<unsigned int>(stage, nRows, nCols, t, blob, sizeGiven, b, out, st); break;
+    case DT_Float:  launchFastDecodeT<float>(stage, nRows, nCols, t, blob, sizeGiven, b, out, st); break;
+    case DT_Double: launchFastDecodeT<double>(stage, nRows, nCols, t, blob, sizeGiven, b, out, st); break;
     default: break;
   }
 }

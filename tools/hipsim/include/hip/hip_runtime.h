@@ -253,6 +253,12 @@ inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
 inline unsigned __funnelshift_r(unsigned lo, unsigned hi, unsigned sh) { return (unsigned)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
 inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
+// v_dot4_u32_u8: sum of the four byte products + c
+inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool)
+{
+  for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
+  return c;
+}
 inline unsigned __builtin_amdgcn_ubfe(unsigned v, unsigned off, unsigned w) { return w == 0 ? 0 : (v >> (off & 31)) & (w >= 32 ? ~0u : ((1u << w) - 1)); }
 
 // ---- atomics (single host thread: plain read-modify-write) ----
