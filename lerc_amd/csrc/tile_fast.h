@@ -110,23 +110,20 @@ LERC_HD bool fastDimsOk(int dt, int nRows, int nCols)
 LERC_HD u32 fastNumWG(int nRows, int nCols) { return (u32)(((u64)(nRows / 8) * (u64)(nCols / 8) + 63u) / 64u); }
 
 // ---- decode side ---------------------------------------------------------------------------------
-// The block stream stores no offsets.  Discovery works on 4 KiB chunks of the blob (chunk c = blob bytes
-// [c * 4096, (c + 1) * 4096), so every chunk start is 16-byte aligned like the blob itself):
+// The block stream stores no offsets.  Discovery works on 2 KiB chunks of the blob (chunk c = blob bytes
+// [c * 2048, (c + 1) * 2048), so every chunk start is 16-byte aligned like the blob itself):
 //   k_fast_discover  a workgroup stages kDiscChunks consecutive chunks in LDS (summing their Fletcher32 terms on the way),
-//                    filters every position of each chunk's first `window` bytes as a block start (kFilterSteps valid
-//                    blocks in a row with the right signature sequence), then up to kDiscWalks survivors per chunk walk
-//                    to the chunk's end in lockstep, listing the block starts they pass
+//                    finds the bit-stuffed block headers in each chunk's first `window` bytes by their byte pattern, and
+//                    lets up to kDiscWalks of them per chunk walk -- in lockstep, listing the block starts they pass --
+//                    until they land on a header found in the next chunk's window
 //   k_fast_resolve   entry of chunk c = the exit all surviving walks of chunk c - 1 agree on; the walk that starts
 //                    there is the true path: its block count, scanned, is the index of the chunk's first block
 //   k_fast_gather    copies the true walks' lists into blockOff[]
 //   k_fast_decode    a workgroup decodes 64 consecutive blocks and checks that they tile their span exactly
-static const u32 kFastChunkBytes = 4096;
-static const int kDiscLanes = 16;          // lanes of the discovery wave that own a chunk
+static const u32 kFastChunkBytes = 2048;
 static const int kDiscWalks = 8;           // walks per chunk (path heads among the filter's survivors; more: general path)
 static const int kDiscChunks = 16;         // chunks per workgroup of k_fast_discover (four per wave while candidates are filtered)
-static const int kFilterSteps = 4;         // valid blocks in a row that make a window position a walk start
-static const int kFastListCap = 256;       // block starts a walk can list per chunk (more, i.e. blocks of < 16 bytes on average: general path)
-static const int kRecPrefix = 4;           // block starts of a walk kept in its chunk record (the rest is in its list)
+static const int kFastListCap = 128;       // block starts a walk can list per chunk (more, i.e. blocks of < 16 bytes on average: general path)
 static const u32 kResolveWG = 256;         // chunks per workgroup of k_fast_resolve
 static const u32 kGatherChunks = 16;       // chunks per workgroup of k_fast_gather (divides kResolveWG)
 // longest block the streaming walk accepts: the raw form (the reference encoder never emits a longer one)
@@ -152,10 +149,9 @@ struct FastDecodeParams
 // what the walks of one chunk found
 struct FastChunkRec
 {
-  u32 exit;                    // first block start at / behind the chunk's end that all live walks agree on, or ~0
+  u32 exit;                    // the block header of the next chunk's window that all live walks end on (or the blob's end), or ~0
   u32 nLive;
-  u16 first[kDiscWalks][kRecPrefix];    // the first block starts of walk l, relative to the chunk (0xFFFF: none)
-  u16 count[kDiscWalks];       // blocks from its start to `exit`; 0xFFFF: no such walk / it ran into something that is no block
+  u16 count[kDiscWalks];       // blocks from walk l's start to `exit`; 0xFFFF: no such walk / it ran into something that is no block
 };
 
 // Flags the kernels raise are epoch tagged: cell k == epoch means "raised during this call", so nothing has to be

@@ -2,18 +2,21 @@
 // pixel valid, 8 x 8 blocks, rows and columns multiples of 8).  Same results as tile_decode.hip.
 //
 // The block stream stores no offsets (block k+1 starts where block k ends), so decoding starts with a
-// discovery pass over 4 KiB chunks of the blob (tile_fast.h).  Everything serial about it runs out of LDS:
-//   k_fast_discover    one wave = kDiscChunks chunks staged with 16-byte loads (their Fletcher32 terms are summed
-//                      on the way, so the decode kernel does not look at the checksum at all).  Every wave parses
+// discovery pass over 2 KiB chunks of the blob (tile_fast.h).  Everything serial about it runs out of LDS:
+//   k_fast_discover    a workgroup = kDiscChunks chunks staged with 16-byte loads (their Fletcher32 terms are summed
+//                      on the way, so the decode kernel does not look at the checksum at all).  Every workgroup reads
 //                      the band header itself (the host has not seen a byte of the blob when it enqueues the four
-//                      kernels).  Each chunk belongs to kDiscLanes lanes: they try every position of the chunk's
-//                      first `window` bytes as a block start, keep the ones that stay valid for kFilterSteps blocks
-//                      (compacting LDS queues: most die at once) and walk the survivors to the chunk's end in
-//                      lockstep, writing down the block starts they pass.  The true first block of a chunk is
-//                      always among the survivors.
+//                      kernels).  A bit-stuffed block reads flag byte, offset, 10?nnnnn, count 64: "64 behind
+//                      10?nnnnn" is found four positions per lane and step in each chunk's first `window` bytes and is
+//                      true for one position in a thousand of anything else.  Of the blocks found, those that are
+//                      not the block right behind another one start a walk: one wave walks all chunks' heads in
+//                      lockstep (lane = chunk x head), fetching the words of the next block as soon as its start is
+//                      known, until each has landed on a header found in the NEXT chunk's window.  Walks that are
+//                      not on the path end within a few steps (signature sequence).
 //   k_fast_resolve     whatever ALL live walks of a chunk agree on is true without knowing which one is real:
-//                      entry of chunk c = agreed exit of chunk c-1; the walk that starts exactly there is the true
-//                      path and its length the chunk's block count.  Also folds the checksum terms.
+//                      entry of chunk c = agreed exit of chunk c-1; the walk that starts exactly there (or passes
+//                      it with one of its first blocks) is the true path and its length the chunk's block count.
+//                      Also folds the checksum terms.
 //   k_fast_gather      block offsets = the true walks' lists, placed by a scan of the counts.
 //   k_fast_decode      a workgroup owns 64 consecutive blocks (8 rows x 512 columns where a block row is that
 //                      long): it stages their byte span in LDS, parses the 64 block headers once (lane = block;
@@ -21,8 +24,9 @@
 //                      consecutive pixels of one raster row, dequantises (double precision in the reference's
 //                      expression order for float types, exact integer arithmetic for integer types) and stores
 //                      one 16-byte vector.
-// Whenever a precondition fails (a block longer than its raw size, disagreeing walks, too many survivors,
-// ...) the kernels raise an epoch tagged flag, and the host repeats the band with the general kernels.
+// Streams the scan cannot follow (a chunk whose window holds no bit-stuffed block on the path: long runs of constant
+// or raw blocks) and anything else unexpected raise an epoch tagged flag; the host then repeats the band with the
+// general kernels.
 // Reference: Lerc2.cpp:1672-1713, :2025-2230; BitStuffer2.cpp:159-258, :476-540; Lerc2.cpp:1037-1064 (checksum).
 #include "tile_fast.h"
 #include "kernels.h"
@@ -115,44 +119,91 @@ __device__ __forceinline__ u32 stepAt(const u32* words, u32 a0, u32 cur, u32 end
   return ok ? code : 0u;
 }
 
-// The same step written for the walks' critical path: everything is computed for every lane and selected at the end,
-// so a step is one LDS round trip and a dozen dependent VALU operations, with no branch.  `rel` must lie inside the
-// staged bytes (the caller clamps it for lanes that are not walking); returns the block's length or 0.
-template<int DT>
-__device__ __forceinline__ u32 stepLean(const u32* words, u32 rel, u32 remaining, bool v5, u32 prevSig, u32 pattern, u32& sigOut)
+// The same step written for the walks' critical path, in three parts: the LDS words a block's first bytes lie in, the
+// block's length from them (a dozen dependent operations, no branch), and whether it is a block at all with a signature
+// that follows the previous one's (off the critical path: a walk fetches the words of the NEXT block before it looks at
+// that).  UNIFORM: all lanes of the wave are here (the look-up table arithmetic is then skipped unless some lane has
+// such a block).
+template<int DT> struct LeanWords { u32 x0, x1, x2, x3; };
+template<int DT> __device__ __forceinline__ LeanWords<DT> leanFetch(const u32* words, u32 rel)    // rel: inside the staged bytes
+{
+  const u32 wi = rel >> 2;
+  LeanWords<DT> v;
+  v.x0 = words[wi]; v.x1 = words[wi + 1]; v.x2 = words[wi + 2];
+  v.x3 = (DT == DT_Double) ? words[wi + 3] : 0u;
+  return v;
+}
+struct LeanBlock { u32 h0, t, offB, len, okLut; };
+template<int DT, bool UNIFORM>
+__device__ __forceinline__ LeanBlock leanLength(const LeanWords<DT>& v, u32 rel)
 {
   constexpr u32 TB = (DT <= DT_Byte) ? 1 : (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
   constexpr u32 RAW = 1 + 64 * TB;
-  const u32 wi = rel >> 2, sh = 8u * rel;    // (alignbit takes the shift mod 32)
-  const u32 x0 = words[wi], x1 = words[wi + 1], x2 = words[wi + 2];
-  const u32 h0 = __builtin_amdgcn_alignbit(x1, x0, sh), h1 = __builtin_amdgcn_alignbit(x2, x1, sh);
+  const u32 sh = 8u * rel;    // (alignbit takes the shift mod 32)
+  LeanBlock k;
+  const u32 h0 = __builtin_amdgcn_alignbit(v.x1, v.x0, sh), h1 = __builtin_amdgcn_alignbit(v.x2, v.x1, sh);
   const u32 mode = h0 & 3u;
   const u32 offB = (offBytesTable<DT>() >> ((h0 >> 4) & 12u)) & 15u;
   u32 t;    // bytes 1 + offB ...: numBits byte, count, LUT size
   if (DT == DT_Double)
   {
-    const u32 x3 = words[wi + 3];
-    const u32 h2 = __builtin_amdgcn_alignbit(x3, x2, sh);
+    const u32 h2 = __builtin_amdgcn_alignbit(v.x3, v.x2, sh);
     t = (offB == 8u) ? (h2 >> 8) : (u32)((((u64)h1 << 32) | h0) >> ((8u + 8u * offB) & 63u));
   }
   else t = (u32)((((u64)h1 << 32) | h0) >> ((8u + 8u * offB) & 63u));
   const u32 nb = t & 31u, lut = (t >> 5) & 1u;
-  const u32 nLut = (((t >> 16) & 0xFFu) - 1u) & 0xFFu;                     // valid: 1 ... 254
-  const u32 okBits = (u32)((t & 0xFFC0u) == 0x4080u) & (u32)(nb != 0u);    // 64 elements: one-byte count field == 64
-  const u32 okLut = (u32)((nLut - 1u) < 254u);
-  const u32 lenSimple = 3u + offB + 8u * nb;
-  const u32 lenLut = 4u + offB + ((nLut * nb + 7u) >> 3) + 8u * (u32)bitLen(nLut);
-  const u32 lenStuffed = lut ? lenLut : lenSimple;
+  u32 lenStuffed = 3u + offB + 8u * nb;
+  k.okLut = 1u;
+  if (!UNIFORM || __any(lut && mode == 1u))
+  {
+    const u32 nLut = (((t >> 16) & 0xFFu) - 1u) & 0xFFu;                   // valid: 1 ... 254
+    k.okLut = (lut ^ 1u) | (u32)((nLut - 1u) < 254u);
+    const u32 lenLut = 4u + offB + ((nLut * nb + 7u) >> 3) + 8u * (u32)bitLen(nLut);
+    lenStuffed = lut ? lenLut : lenStuffed;
+  }
   const u32 lenOther = (mode == 0u) ? RAW : (mode == 2u) ? 1u : 1u + offB;
-  const u32 len = (mode == 1u) ? lenStuffed : lenOther;
-  const u32 okStuffed = okBits & (u32)(offB != 0u) & ((lut ^ 1u) | okLut);
-  const u32 okOther = (u32)(mode != 3u) | (u32)(offB != 0u);
+  k.h0 = h0; k.t = t; k.offB = offB;
+  k.len = (mode == 1u) ? lenStuffed : lenOther;
+  return k;
+}
+template<int DT>
+__device__ __forceinline__ bool leanValid(const LeanBlock& k, u32 remaining, bool v5, u32 prevSig, u32 pattern, u32& sigOut)
+{
+  constexpr u32 TB = (DT <= DT_Byte) ? 1 : (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
+  constexpr u32 RAW = 1 + 64 * TB;
+  const u32 mode = k.h0 & 3u, nb = k.t & 31u;
+  const u32 okBits = (u32)((k.t & 0xFFC0u) == 0x4080u) & (u32)(nb != 0u);  // 64 elements: one-byte count field == 64
+  const u32 okStuffed = okBits & (u32)(k.offB != 0u) & k.okLut;
+  const u32 okOther = (u32)(mode != 3u) | (u32)(k.offB != 0u);
   u32 ok = (mode == 1u) ? okStuffed : okOther;
-  ok &= (u32)!(v5 && (h0 & 4u)) & (u32)(len <= RAW) & (u32)(len <= remaining);    // slice difference needs nDepth > 1
-  const u32 sg = (h0 >> 2) & pattern;
+  ok &= (u32)!(v5 && (k.h0 & 4u)) & (u32)(k.len <= remaining);             // slice difference needs nDepth > 1
+  if (3u + 8u + 8u * 31u > RAW) ok &= (u32)(k.len <= RAW);                 // (32-bit and wider types: no stuffed block is that long)
+  const u32 sg = (k.h0 >> 2) & pattern;
   ok &= (u32)(prevSig == kNoOffset) | (u32)sigOk(prevSig, sg, pattern);
   sigOut = sg;
-  return ok ? len : 0u;
+  return ok != 0u;
+}
+// What a walk needs to know of that: enough to end a walk that is not on the path within a few steps (the signature
+// sequence alone ends 5 of 8 per step; "bit-stuffed" with anything but a header byte and the count 64 behind the offset
+// nearly all the rest) and to stay inside the blob.  Everything else about a block is checked, in full, by the decode
+// kernel (parseCode, contiguity, the column signature), which sends a damaged blob to the general path.
+__device__ __forceinline__ bool leanPlausible(const LeanBlock& k, u32 remaining, u32 prevSig, u32 pattern, u32& sigOut)
+{
+  const u32 mode = k.h0 & 3u;
+  const u32 okBits = (u32)((k.t & 0xFFC0u) == 0x4080u) & (u32)((k.t & 31u) != 0u);
+  u32 ok = (u32)(mode != 1u) | okBits;
+  ok &= (u32)(k.len <= remaining);
+  const u32 sg = (k.h0 >> 2) & pattern;
+  ok &= (u32)(prevSig == kNoOffset) | (u32)sigOk(prevSig, sg, pattern);
+  sigOut = sg;
+  return ok != 0u;
+}
+// all three at once: the block's length or 0
+template<int DT, bool UNIFORM>
+__device__ __forceinline__ u32 stepLean(const u32* words, u32 rel, u32 remaining, bool v5, u32 prevSig, u32 pattern, u32& sigOut)
+{
+  const LeanBlock k = leanLength<DT, UNIFORM>(leanFetch<DT>(words, rel), rel);
+  return leanValid<DT>(k, remaining, v5, prevSig, pattern, sigOut) ? k.len : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -214,7 +265,7 @@ __device__ __forceinline__ void parseHead(const Head128& h, u32 sizeGiven, int n
   ok = ok && h.byteAt(oSweep) == 0u && oData < blobSize;          // not the one-sweep raw form
   hp.dataBegin = oData;
   hp.blobEnd = blobSize;
-  hp.nChunks = ok ? (blobSize + kFastChunkBytes - 1) / kFastChunkBytes : 0u;    // chunk c = blob bytes [c * 4096, (c + 1) * 4096)
+  hp.nChunks = ok ? (blobSize + kFastChunkBytes - 1) / kFastChunkBytes : 0u;    // chunk c = blob bytes [c * kFastChunkBytes, (c + 1) * kFastChunkBytes)
   hp.invScale = 2 * maxZErr;
   hp.zMaxHdr = zMax;
   hp.ok = ok ? 1u : 0u;
@@ -285,14 +336,6 @@ __device__ __forceinline__ void fletcherUnit(const uint4& x, u64 k0, u32& A, u64
   B += k0 * a + (256u * be + bo);
 }
 
-// queue entry of the candidate filter: start in the window (10) | current position relative to the chunk (13) << 10 |
-// signature of the last block (4) << 23 | valid blocks so far (3) << 27
-__device__ __forceinline__ u32 qMake(u32 start, u32 rel, u32 sig, u32 steps) { return start | (rel << 10) | ((sig & 15u) << 23) | (steps << 27); }
-__device__ __forceinline__ u32 qStart(u32 e) { return e & 0x3FFu; }
-__device__ __forceinline__ u32 qRel(u32 e) { return (e >> 10) & 0x1FFFu; }
-__device__ __forceinline__ u32 qSig(u32 e) { return (e >> 23) & 15u; }
-__device__ __forceinline__ u32 qSteps(u32 e) { return e >> 27; }
-
 // What a discovery workgroup needs of the band header; every workgroup reads it for itself (three 16-byte loads of
 // the same address in all lanes).  The full check is done once, by parseBandHeader in workgroup 0: if that one says
 // "not ours" nobody looks at what the others did.
@@ -316,21 +359,28 @@ __device__ __forceinline__ HeadLite parseHeadLite(const u8* __restrict__ blob, u
   return h;
 }
 
+// 0x80 in every byte of v that is zero (exact per byte, unlike the borrow trick)
+__device__ __forceinline__ u32 zeroBytes(u32 v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu); }
+
 template<int DT>
 __device__ __forceinline__ void
 fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols, const FastDecodeBuffers& b)
 {
   constexpr int TBYTES = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
   constexpr u32 W = kFastWindow(TBYTES);
-  constexpr u32 CH = kFastChunkBytes, NCH = (u32)kDiscChunks, LPC = (u32)kDiscLanes, NW = (u32)kDiscWalks;
+  constexpr u32 CH = kFastChunkBytes, NCH = (u32)kDiscChunks, NW = (u32)kDiscWalks;
   constexpr u32 kUnits = NCH * CH / 16;                    // 16-byte units a workgroup owns
-  constexpr u32 kStageUnits = kUnits + 1;                  // + the first bytes of the block that may start right before the end
-  constexpr u32 QCAP = (TBYTES == 8 || W < 200u) ? W : 200u;    // positions of a chunk's window whose flag byte passes (7 of 16 on noise; all four offset types of float64 are valid: half)
+  constexpr u32 kOverhang = (W + 16 + 15) / 16;            // + the next workgroup's first window (walks end on a block start there)
+  constexpr u32 kStageUnits = kUnits + kOverhang;
   constexpr u32 kBitWords = (W + 31) / 32;
-  static_assert(NCH * LPC == 256 && NW == 8 && W < 1024 && CH + 64 * TBYTES + 1 < 8192, "lane layout / queue entry fields");
+  constexpr u32 kFoundCap = 512, kHitCap = 512;            // count bytes / block headers found in the workgroup's 17 windows (a few dozen)
+  constexpr u32 kScanWords = (W + 2 + 8 + 3) / 4 + 1;      // dwords of a window that can hold the count byte of a block starting in it
+  static_assert(NCH == 16 && NW == 8 && W < 1024 && CH + 2 * W < 65536, "lane layout / 16-bit list entries");
   __shared__ __align__(16) u32 s_in[kStageUnits * 4];
-  __shared__ u32 s_q[NCH][QCAP];
-  __shared__ u32 s_bits[NCH][kBitWords];
+  __shared__ u32 s_hits[NCH + 1][kBitWords];               // window positions where a bit-stuffed block header stands
+  __shared__ u32 s_heads[NCH][kBitWords];                  // ... that are not the block right behind another one
+  __shared__ u16 s_found[kFoundCap], s_hit[kHitCap];        // window (5) << 11 | position
+  __shared__ u32 s_nFound, s_nHit;
   __shared__ u16 s_final[NCH][NW];
   __shared__ u32 s_nFinal[NCH];
   __shared__ u32 s_exit[NCH][NW];
@@ -375,18 +425,25 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   const u32 nChunks = (hl.blobEnd + CH - 1) / CH;
   if (!hl.ok || c0 >= nChunks) return;    // (the grid is sized for the largest stream the blob could hold)
   const int version = (int)hl.version;
+  const bool v5 = version >= 5;
   const u32 dataBegin = hl.dataBegin, blobEnd = hl.blobEnd;
+  const u32 pattern = v5 ? 14u : 15u;
 
   // ---- stage + Fletcher terms of the units this workgroup owns (bytes 14 ... blobEnd - 1 of the blob are checksummed)
   u32 fA = 0;
   u64 fB = 0;
+  const bool inner = r0 != 0u && (u64)r0 + 16ull * kUnits <= blobEnd;    // no unit of this workgroup needs blanking
 #pragma unroll
   for (int k = 0; k < kRounds; k++)
   {
     const u32 i = (u32)k * 256u + threadIdx.x;
     if (i < kStageUnits) *reinterpret_cast<uint4*>(&s_in[i * 4]) = x[k];
-    const u64 a = (u64)r0 + 16ull * i;
-    if (i < kUnits && a < blobEnd)
+    const u32 a = r0 + 16u * i;                                           // (< 2^32: the blob is)
+    if (inner)
+    {
+      if (i < kUnits) fletcherUnit(x[k], (a - 14u) / 2u, fA, fB);         // unit at blob offset a holds words (a - 14) / 2 ...
+    }
+    else if (i < kUnits && a < blobEnd)
     {
       uint4 y = x[k];
       if (a == 0 || a + 16 > blobEnd)    // blank what is not checksummed: the first 14 bytes, whatever lies behind the blob
@@ -397,8 +454,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
           if (a + q < 14u || a + q >= blobEnd) wd[q >> 2] &= ~(0xFFu << (8 * (q & 3)));
         y = make_uint4(wd[0], wd[1], wd[2], wd[3]);
       }
-      // unit at blob offset a holds words (a - 14) / 2 ...; the first unit's index -7 as its residue mod 65535
-      fletcherUnit(y, a ? (a - 14u) / 2u : 65528ull, fA, fB);
+      fletcherUnit(y, a ? (a - 14u) / 2u : 65528ull, fA, fB);             // (the first unit's index -7 as its residue mod 65535)
     }
   }
   {
@@ -406,6 +462,8 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     if (lane == 0) { s_fa[w] = A; s_fb[w] = B; }
   }
   if (threadIdx.x == 0) s_over = 0u;
+  for (u32 i = threadIdx.x; i < (NCH + 1) * kBitWords; i += 256u) (&s_hits[0][0])[i] = 0u;
+  if (threadIdx.x == 0) { s_nFound = 0u; s_nHit = 0u; }
   __syncthreads();
   PROBE(16);
   if (threadIdx.x == 0)
@@ -414,128 +472,106 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     b.waveFletcher[2 * (size_t)blockIdx.x + 1] = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
   }
 
-  // ---- candidates.  Lanes g * LPC ... of wave w own chunk c0 + 4 w + g.
-  const u32 g = (u32)lane / LPC, sl = (u32)lane % LPC;
-  const u32 cl = (u32)w * 4u + g;                                         // chunk inside the workgroup
-  const u32 chunk = c0 + cl;
-  const u32 chunkStart = chunk * CH;                                      // (no overflow: chunk < nChunks)
-  const bool chunkLive = chunk < nChunks;
-  const u32 chunkEnd = chunkLive ? min(chunkStart + CH, blobEnd) : chunkStart;
-  const u32 pattern = (version >= 5) ? 14u : 15u;
-  const u32 groupShift = g * LPC;
-  const u32 belowMe = (1u << sl) - 1u;
-  bool overflow = false;
-  u32* __restrict__ q = s_q[cl];
-
-  // step 0: window positions whose first byte can be a block's flag byte (Lerc2.cpp:1961-1973: bits 0-1 how the block
-  // is coded, bit 2 -- codec >= 5 -- "difference to the previous slice", never set with nDepth == 1, bits 6-7 the type of
-  // the offset, which only bit-stuffed and constant blocks have); the chunk that holds the first block: that block only.
-  // Before codec 5 bit 2 belongs to the signature and 7 of 8 bytes pass, more than the queue holds: those take their
-  // first two blocks at once.
-  u32 nq = 0;                                                             // entries in this chunk's queue (the same in all its lanes)
-  for (u32 o0 = 0; o0 < W; o0 += LPC)
+  // ---- bit-stuffed block headers in the first `window` bytes of every chunk (+ the next workgroup's first one).
+  // Such a block reads: flag byte (bits 0-1 == 1, bits 6-7 the type of the offset, bit 2 clear from codec 5 on), the
+  // offset in that type, then 10?nnnnn (bits per element n != 0, bit 5: look-up table, bits 6-7: the count field
+  // is one byte) and the count 64 (Lerc2.cpp:1961-2021, BitStuffer2.cpp:35-77).  "a byte 64 behind a byte 10?nnnnn" is
+  // true for one position in a thousand of anything else, so the scan finds the path's blocks almost alone; whatever
+  // else it finds dies within a few steps of its walk.  Four positions per lane and step.
+  for (u32 f0 = 0; f0 < (NCH + 1) * kScanWords; f0 += 256u)
   {
-    const u32 o = o0 + sl;
-    const u32 cur = chunkStart + o;
-    bool live = chunkLive && o < W && cur < chunkEnd && (chunkStart <= dataBegin ? cur == dataBegin : true);
-    u32 entry = qMake(o, o, kNoOffset, 0u);
-    if (live && version >= 5)
+    const u32 f = f0 + threadIdx.x;
+    const u32 win = f / kScanWords, d = f - win * kScanWords;
+    const u32 chunk = c0 + win;
+    const bool scan = win <= NCH && chunk < nChunks && chunk * CH > dataBegin;    // (the chunk that holds the first block: that block only)
+    u32 m = 0;
+    if (scan)
     {
-      const u32 rel = cur - r0;
-      const u32 flag = (s_in[rel >> 2] >> (8u * (rel & 3u))) & 0xFFu;
-      const bool hasOffset = (flag & 1u) != 0u;                           // bit-stuffed or constant
-      live = !(flag & 4u) && !(hasOffset && ((offBytesTable<DT>() >> ((flag >> 4) & 12u)) & 15u) == 0u);
+      const u32 wAt = win * (CH / 4) + d;
+      const u32 cur4 = s_in[wAt], prev4 = d ? s_in[wAt - 1] : 0u;
+      const u32 hdr4 = __builtin_amdgcn_alignbit(cur4, prev4, 24);        // the bytes in front of cur4's
+      m = zeroBytes(cur4 ^ 0x40404040u) & zeroBytes((hdr4 & 0xC0C0C0C0u) ^ 0x80808080u) & ~zeroBytes(hdr4 & 0x1F1F1F1Fu);
     }
-    else if (live)
+    // the few count bytes found (one lane in a hundred has any) go to a queue: window (5) << 11 | position
+    while (m)
     {
-      u32 sig = kNoOffset, rel = o, steps = 0;
-      for (int k = 0; k < 2 && live && chunkStart + rel < chunkEnd; k++)
-      {
-        const u32 code = stepAt<DT>(s_in, r0, chunkStart + rel, blobEnd, version, sig, pattern);
-        live = code != 0u;
-        rel += codeLen(code); steps++;
-      }
-      entry = qMake(o, rel, sig, steps);
+      const u32 j = (u32)(__ffs((int)m) - 1) >> 3;
+      m &= m - 1u;
+      const u32 at = atomicAdd(&s_nFound, 1u);
+      if (at < kFoundCap) s_found[at] = (u16)((win << 11) | (4u * d + j)); else s_over = 1u;
     }
-    const u32 gm = (u32)(__ballot(live) >> groupShift) & ((1u << LPC) - 1u);
-    const u32 at = nq + (u32)__popc(gm & belowMe);
-    if (live) { if (at < QCAP) q[at] = entry; else overflow = true; }
-    nq = min(nq + (u32)__popc(gm), QCAP);
   }
-  waveSync();
+  __syncthreads();
+  // a count byte stands 2 + (bytes of the offset) behind the block's flag byte: try each offset type, one lane each
+  {
+    const u32 nFound = min(s_nFound, kFoundCap);
+    for (u32 h = threadIdx.x; h < 4u * nFound; h += 256u)
+    {
+      const u32 e = s_found[h >> 2], tc = h & 3u;
+      const u32 win = e >> 11, q = e & 0x7FFu;
+      const u32 offB = (offBytesTable<DT>() >> (4u * tc)) & 15u;
+      if (offB == 0u || q < 2u + offB) continue;
+      const u32 p = q - 2u - offB;
+      if (p >= W || (c0 + win) * CH + p >= blobEnd) continue;
+      const u32 rel = win * CH + p;
+      const u32 flag = (s_in[rel >> 2] >> (8u * (rel & 3u))) & 0xFFu;
+      if ((flag & 3u) != 1u || (flag >> 6) != tc || (v5 && (flag & 4u))) continue;
+      atomicOr(&s_hits[win][p >> 5], 1u << (p & 31u));
+      if (win < NCH) { const u32 at = atomicAdd(&s_nHit, 1u); if (at < kHitCap) s_hit[at] = (u16)((win << 11) | p); else s_over = 1u; }
+    }
+  }
+  if (threadIdx.x == 0 && c0 * CH <= dataBegin)    // the stream's first block, whatever it is
+  {
+    const u32 p = dataBegin - c0 * CH;
+    atomicOr(&s_hits[0][p >> 5], 1u << (p & 31u));
+    const u32 at = atomicAdd(&s_nHit, 1u);
+    if (at < kHitCap) s_hit[at] = (u16)p; else s_over = 1u;
+  }
+  __syncthreads();
   PROBE(17);
 
-  // further blocks through the queues, compacted in place (a round reads LPC entries before it writes at most LPC at
-  // or before them); who is still valid after kFilterSteps blocks (or has reached the chunk's end) is a survivor
-  const bool v5 = version >= 5;
-  constexpr u32 kMaxRel = NCH * CH - 1;                                   // last staged byte a block may start at
-  for (int pass = 0; pass < kFilterSteps; pass++)
+  // ---- of the blocks found, those that are not the block right behind another one start a walk (the true path crosses
+  // a window in several blocks, each of them found)
+  for (u32 i = threadIdx.x; i < NCH * kBitWords; i += 256u) (&s_heads[0][0])[i] = (&s_hits[0][0])[i];
+  if (threadIdx.x < NCH) s_nFinal[threadIdx.x] = 0u;
+  __syncthreads();
+  constexpr u32 kMaxRel = NCH * CH + W - 1;                               // last staged byte a block may start at
+  const u32 nHit = min(s_nHit, kHitCap);
+  for (u32 h = threadIdx.x; h < nHit; h += 256u)
   {
-    u32 nOut = 0;
-    bool pending = false;
-    for (u32 i0 = 0; __any(i0 < nq); i0 += LPC)
-    {
-      const u32 i = i0 + sl;
-      const bool have = i < nq;
-      const u32 e = have ? q[i] : 0u;
-      const u32 rel = qRel(e), steps = qSteps(e);
-      const u32 cur = chunkStart + rel;
-      const bool doStep = have && steps < (u32)kFilterSteps && cur < chunkEnd;
-      u32 sg;
-      const u32 len = stepLean<DT>(s_in, min(cur - r0, kMaxRel), blobEnd - min(cur, blobEnd), v5, steps ? qSig(e) : kNoOffset, pattern, sg);
-      const bool live = have && (!doStep || len != 0u);
-      const u32 rel2 = doStep ? rel + len : rel, steps2 = doStep ? steps + 1u : steps, sig2 = doStep ? sg : qSig(e);
-      pending = pending || (live && steps2 < (u32)kFilterSteps && chunkStart + rel2 < chunkEnd);
-      waveSync();    // every lane has read its entry
-      const u32 gm = (u32)(__ballot(live) >> groupShift) & ((1u << LPC) - 1u);
-      if (live) q[nOut + (u32)__popc(gm & belowMe)] = qMake(qStart(e), rel2, sig2, steps2);
-      nOut += (u32)__popc(gm);
-      waveSync();
-    }
-    nq = nOut;
-    if (!__any(pending)) break;
+    const u32 e = s_hit[h];
+    const u32 hWin = e >> 11, hPos = e & 0x7FFu;
+    u32 sg;
+    const u32 cur = (c0 + hWin) * CH + hPos;
+    const u32 len = stepLean<DT, false>(s_in, cur - r0, blobEnd - cur, v5, kNoOffset, pattern, sg);
+    // (only where the walk from here would pass the block behind: its signature has to follow this one's -- then both
+    // walks are the same from there on, and the earlier one lists the later one's blocks)
+    const u32 nx = hPos + len;
+    const u32 relNx = cur - r0 + len;
+    const u32 sgNx = ((s_in[relNx >> 2] >> (8u * (relNx & 3u))) >> 2) & pattern;
+    const bool follows = sigOk(sg, sgNx, pattern);
+    if (len != 0u && nx < W && follows) atomicAnd(&s_heads[hWin][nx >> 5], ~(1u << (nx & 31u)));
+    // what is no block, or is followed by something that cannot be the next block, would end its walk at once: a byte of
+    // a block's offset often looks like a flag byte in front of the same header (one such twin per block)
+    if (len == 0u || (!follows && cur + len < blobEnd)) atomicAnd(&s_heads[hWin][hPos >> 5], ~(1u << (hPos & 31u)));
   }
-  PROBE(18);
-  // Survivors that sit on one path (the true path crosses the window in several blocks, each of them a survivor; a run
-  // of constant blocks makes every byte one) need one walk, from the first of them: a survivor that is the block
-  // right behind another survivor is dropped (its predecessor is valid for kFilterSteps blocks too, hence a survivor).
-  for (u32 i = sl; i < kBitWords; i += LPC) s_bits[cl][i] = 0u;
-  waveSync();
-  for (u32 i0 = 0; __any(i0 < nq); i0 += LPC)
-    if (i0 + sl < nq) { const u32 st = qStart(q[i0 + sl]); atomicOr(&s_bits[cl][st >> 5], 1u << (st & 31u)); }
-  waveSync();
-  for (u32 i0 = 0; __any(i0 < nq); i0 += LPC)
+  __syncthreads();
+  for (u32 h = threadIdx.x; h < nHit; h += 256u)
   {
-    if (i0 + sl < nq)
+    const u32 e = s_hit[h];
+    const u32 hWin = e >> 11, hPos = e & 0x7FFu;
+    if ((s_heads[hWin][hPos >> 5] >> (hPos & 31u)) & 1u)
     {
-      const u32 st = qStart(q[i0 + sl]);
-      u32 sg;
-      const u32 nx = st + stepLean<DT>(s_in, chunkStart + st - r0, blobEnd - (chunkStart + st), v5, kNoOffset, pattern, sg);    // valid: it was a moment ago
-      if (nx < W) atomicAnd(&s_bits[cl][nx >> 5], ~(1u << (nx & 31u)));
+      const u32 at = atomicAdd(&s_nFinal[hWin], 1u);
+      if (at < NW) s_final[hWin][at] = (u16)hPos; else s_over = 1u;
     }
   }
-  waveSync();
-  u32 nFinal = 0;
-  for (u32 i0 = 0; __any(i0 < nq); i0 += LPC)
-  {
-    const u32 st = (i0 + sl < nq) ? qStart(q[i0 + sl]) : 0u;
-    const bool head = i0 + sl < nq && ((s_bits[cl][st >> 5] >> (st & 31u)) & 1u) != 0u;
-    const u32 gd = (u32)(__ballot(head) >> groupShift) & ((1u << LPC) - 1u);
-    if (head)
-    {
-      const u32 at = nFinal + (u32)__popc(gd & belowMe);
-      if (at < NW) s_final[cl][at] = (u16)st; else overflow = true;
-    }
-    nFinal = min(nFinal + (u32)__popc(gd), NW);
-  }
-  if (sl == 0) s_nFinal[cl] = chunkLive ? nFinal : 0u;
-  if (__any(overflow) && lane == 0) s_over = 1u;
   PROBE(19);
   __syncthreads();
   PROBE(20);
 
-  // ---- walks: the path heads of all 16 chunks, lane = (chunk, head); waves 0 and 1 take heads 0-3 and 4-7 (there are
-  // seldom more than two), the other waves are done
+  // ---- walks: lane = (chunk, head); waves 0 and 1 take heads 0-3 and 4-7 (there are seldom more than two), the other
+  // waves are done.  A walk ends on the first block header of the next chunk's window it lands on (or with the blob).
   if (w < 2)
   {
     const u32 wc = (u32)lane >> 2, slot = ((u32)lane & 3u) + 4u * (u32)w;    // chunk inside the workgroup, head
@@ -543,40 +579,61 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     const u32 wStart = wChunk * CH;
     const bool wLive = wChunk < nChunks;
     const u32 wEnd = wLive ? min(wStart + CH, blobEnd) : wStart;
-    const bool walker = wLive && slot < s_nFinal[wc];
+    const bool walker = wLive && slot < min(s_nFinal[wc], NW);
     u32 cur = wStart + (walker ? (u32)s_final[wc][slot] : 0u);
     u32 sig = kNoOffset, count = 0;
     bool alive = walker, tooMany = false;
-    u16 first[kRecPrefix];
-#pragma unroll
-    for (int k = 0; k < kRecPrefix; k++) first[k] = (u16)0xFFFFu;
     u16* __restrict__ list = b.lists + ((size_t)wChunk * NW + slot) * kFastListCap;
-    bool active = alive && cur < wEnd;
-    while (__any(active))
+    const u32* __restrict__ nextHits = s_hits[wc + 1];
+    // (the words of the next block are fetched as soon as its start is known; what is not on the way from one start to
+    // the next -- is this a block, does its signature follow, the list -- fills the wait)
+    LeanWords<DT> xw = leanFetch<DT>(s_in, cur - r0);
+    while (__any(alive && cur < wEnd))
     {
+      const bool active = alive && cur < wEnd;
+      const LeanBlock k = leanLength<DT, true>(xw, cur - r0);
+      const u32 nxt = min(cur + k.len, r0 + kMaxRel);                     // (a length that is none stays inside the staged bytes)
+      xw = leanFetch<DT>(s_in, nxt - r0);
       u32 sg;
-      const u32 len = stepLean<DT>(s_in, min(cur - r0, kMaxRel), blobEnd - min(cur, blobEnd), v5, sig, pattern, sg);
+#ifdef LERC_WALK_FULLCHECK
+      const bool valid = leanValid<DT>(k, blobEnd - cur, v5, sig, pattern, sg);
+#else
+      const bool valid = leanPlausible(k, blobEnd - cur, sig, pattern, sg);
+#endif
+      const bool room = count < (u32)kFastListCap;
+      const bool ok = active && valid && room;
+      tooMany = tooMany || (active && valid && !room);
+#ifndef LERC_WALK_NOSTORE
+      if (ok) list[count] = (u16)(cur - wStart);
+#endif
+      alive = alive && (!active || ok);
+      cur = ok ? nxt : cur;
+      count += ok ? 1u : 0u;
+      sig = ok ? sg : sig;
+    }
+    // behind the chunk: done on a block header of the next window (or at the end of the blob), lost behind that window
+    bool landed = false;
+    for (;;)
+    {
+      const u32 past = cur - wEnd;                                        // (alive lanes have cur >= wEnd now)
+      const u32 pb = min(past, W - 1u);
+      landed = landed || (alive && (cur == blobEnd || (past < W && ((nextHits[pb >> 5] >> (pb & 31u)) & 1u))));
+      alive = alive && (landed || past < W);
+      const bool active = alive && !landed;
+      if (!__any(active)) break;
+      u32 sg;
+      const u32 len = stepLean<DT, true>(s_in, min(cur - r0, kMaxRel), blobEnd - min(cur, blobEnd), v5, sig, pattern, sg);
       const bool room = count < (u32)kFastListCap;
       const bool ok = active && len != 0u && room;
       tooMany = tooMany || (active && len != 0u && !room);
-      const u16 at = (u16)(cur - wStart);
-      if (ok) list[count] = at;
-#pragma unroll
-      for (int k = 0; k < kRecPrefix; k++) first[k] = (ok && count == (u32)k) ? at : first[k];
+      if (ok) list[count] = (u16)(cur - wStart);
       alive = alive && (!active || ok);
       cur += ok ? len : 0u;
       count += ok ? 1u : 0u;
       sig = ok ? sg : sig;
-      active = alive && cur < wEnd;
     }
     s_exit[wc][slot] = alive ? cur : kNoOffset;
-    if (wLive)
-    {
-      FastChunkRec* rec = b.recs + wChunk;
-#pragma unroll
-      for (int k = 0; k < kRecPrefix; k++) rec->first[slot][k] = first[k];
-      rec->count[slot] = alive ? (u16)count : (u16)0xFFFFu;
-    }
+    if (wLive) b.recs[wChunk].count[slot] = alive ? (u16)count : (u16)0xFFFFu;
     if (__any(tooMany) && lane == 0) s_over = 1u;
   }
   PROBE(21);
@@ -626,25 +683,16 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
       const FastChunkRec rec = b.recs[c];
       const u32 rel = e - chunkStart;
       // the walk the entry lies on: normally a walk starts there; else it is one of the first blocks of a walk that
-      // began a little earlier (a stray byte in front of the entry that looks like a one byte block), or -- long runs
-      // of tiny blocks -- somewhere in its list
+      // began a little earlier (something in front of the entry that looks like a block ending right there)
 #pragma unroll
       for (int l = 0; l < kDiscWalks; l++)
-#pragma unroll
-        for (int k = 0; k < kRecPrefix; k++)
-          if ((u32)rec.first[l][k] == rel && rec.count[l] != 0xFFFFu && laneOfPath == kNoOffset) { laneOfPath = (u32)l | ((u32)k << 8); count = rec.count[l] - (u32)k; }
-      if (laneOfPath == kNoOffset && rec.exit != kNoOffset)
       {
+        if (rec.count[l] == 0xFFFFu) continue;
+        const uint2 pre = *reinterpret_cast<const uint2*>(b.lists + ((size_t)c * kDiscWalks + l) * kFastListCap);    // its first four block starts
+        const u32 st[4] = { pre.x & 0xFFFFu, pre.x >> 16, pre.y & 0xFFFFu, pre.y >> 16 };
 #pragma unroll
-        for (int l = 0; l < kDiscWalks; l++)
-        {
-          const u32 n = rec.count[l];
-          if (laneOfPath != kNoOffset || n == 0xFFFFu || n <= (u32)kRecPrefix || (u32)rec.first[l][0] > rel) continue;
-          const u16* __restrict__ list = b.lists + ((size_t)c * kDiscWalks + l) * kFastListCap;
-          u32 lo = kRecPrefix, hi = n;    // first index with list[i] >= rel
-          while (lo < hi) { const u32 mid = (lo + hi) >> 1; if ((u32)list[mid] < rel) lo = mid + 1; else hi = mid; }
-          if (lo < n && (u32)list[lo] == rel) { laneOfPath = (u32)l | (lo << 8); count = n - lo; }
-        }
+        for (u32 k = 0; k < 4; k++)
+          if (st[k] == rel && k < (u32)rec.count[l] && laneOfPath == kNoOffset) { laneOfPath = (u32)l | (k << 8); count = rec.count[l] - k; }
       }
       if (laneOfPath == kNoOffset || rec.exit == kNoOffset) bad = true;    // (no agreement on the exit: the next chunk says so too)
     }
@@ -688,7 +736,8 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void fastGatherBody(const FastDecodeBuffers& b)
 {
-  static_assert(kFastListCap == 256, "one thread per list entry");
+  constexpr u32 kPerPass = 256u / (u32)kFastListCap;      // chunks whose lists the 256 threads copy at once
+  static_assert(256 % kFastListCap == 0 && kGatherChunks % kPerPass == 0, "threads per list entry");
   __shared__ u32 s_part[4], s_n[kGatherChunks], s_loc[kGatherChunks], s_lane[kGatherChunks];
   const FastDecodeParams hp = *b.params;
   if (!hp.ok) return;
@@ -720,11 +769,12 @@ __device__ __forceinline__ void fastGatherBody(const FastDecodeBuffers& b)
     if (total != hp.nBlocks) b.fallback[2] = b.epoch;
   }
   if (fastRaised(b.fallback, b.epoch)) return;    // raised by an earlier kernel: nothing below can be trusted
-  const u32 i = threadIdx.x;                       // entry of each chunk's list
+  const u32 i = threadIdx.x % (u32)kFastListCap, sub = threadIdx.x / (u32)kFastListCap;    // entry of a chunk's list
   bool bad = false;
 #pragma unroll
-  for (u32 k = 0; k < kGatherChunks; k++)
+  for (u32 k0 = 0; k0 < kGatherChunks; k0 += kPerPass)
   {
+    const u32 k = k0 + sub;
     const u32 c = cFirst + k, ls = s_lane[k];      // walk | index of the chunk's first block in its list << 8
     const u32 src = min((ls >> 8) + i, (u32)kFastListCap - 1u);
     const u32 v = b.lists[((size_t)c * kDiscWalks + (ls & 7u)) * kFastListCap + src];    // (chunks behind the last one: inside the buffer's slack)

@@ -11,7 +11,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["LERC_AMD_LIBRARY"] = os.path.join(ROOT, "lerc_amd", "csrc", "_probe", "liblerc_amd_probe.so")
+os.environ["LERC_AMD_LIBRARY"] = os.environ.get("PROBE_LIB") or os.path.join(ROOT, "lerc_amd", "csrc", "_probe", "liblerc_amd_probe.so")
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from lerc_amd import api, synth  # noqa: E402
