@@ -21,7 +21,13 @@ struct FastEncodeResult
   u32 checksum;
 };
 
-static const int kFastRow0WG = 16;         // workgroups that look at the first raster row (TryRaiseMaxZError)
+#ifdef LERC_SMALL_GROUPS                   // (emulator builds: small rasters then take the multi-group hand-offs too)
+static const u32 kFastScanGroup = 16, kFastPackGroup = 4;
+#else
+static const u32 kFastScanGroup = 4096;    // workgroup sizes one workgroup of the scan step takes (1024 threads x 4)
+static const u32 kFastPackGroup = 16;      // pack workgroups that add their checksum terms to one accumulator (256 on one address
+                                           // made the atomics queue up: k_fast_pack 124 us against 81)
+#endif
 
 struct FastBlockDesc      // what pass 1 decided for one block; pass 2 packs from it
 {
@@ -37,9 +43,12 @@ struct FastBatch
   u32 nTiles;
   u32 nWG;             // workgroups (64 blocks each) per tile
   u64 tileElems;       // pixels from one tile to the next
-  u32 nRaiseSets;      // workgroups per tile that look at the first raster row
+  u32 nRaiseSets;      // workgroups per tile that hold pixels of the first raster row (TryRaiseMaxZError looks at that row)
   u32 nBlobsMore;      // header field: bands that follow this one in the blob (0 for a single band / a tile)
 };
+LERC_HD u32 fastScanGroups(u32 nWG) { return (nWG + kFastScanGroup - 1u) / kFastScanGroup; }
+LERC_HD u32 fastPackGroups(u32 nWG) { return (nWG + kFastPackGroup - 1u) / kFastPackGroup; }
+LERC_HD u32 fastTicketStride(u32 nWG) { (void)nWG; return 4u; }
 LERC_HD u32 fastWgStride(u32 nWG) { return (nWG + 7u) & ~3u; }    // elements from one tile's wgSize / wgBase set to the next (16-byte aligned)
 static const int kFastPrefixStage = 128;   // bytes reserved per tile for header + mask count + ranges + mode byte
 
@@ -47,12 +56,18 @@ struct FastEncodeBuffers
 {
   FastBlockDesc* desc; // [nWG * 64]
   u32* wgSize;         // [nWG + 4] bytes of each workgroup's 64 blocks
-  u32* wgBase;         // [nWG + 4] exclusive scan, [nWG] = total
+  u32* wgBase;         // [nWG + 4] exclusive scan inside a scan group of kFastScanGroup workgroups
+  u32* groupBase;      // [nScanGroups + 1] bytes in front of each scan group
+  u64* scanPart;       // [3 * nScanGroups] what a scan workgroup found: bytes | flags << 32, min key, max key
+  u64* packPart;       // [nPackGroups] Fletcher sums of a pack group's workgroups and how many have arrived: A | B << 24 | n << 48
+  u32* tickets;        // [fastTicketStride] [0] arrival counter of the scan workgroups
+                       // (each kernel zeroes what the next one counts in: the statistics step the scan's ticket, the scan's last
+                       // workgroup the pack step's accumulators)
   u64* wgMinKey;       // [nWG] order-preserving key of each workgroup's smallest / largest pixel
   u64* wgMaxKey;       // [nWG]
   u32* wgFlags;        // [nWG] bit 0 NaN seen, bit 1 non-integer value seen
-  u64* wgFletcher;     // [2 * nWG] Fletcher partial sums (mod 65535) of the bytes each workgroup wrote
-  double* row0RaiseErr;    // [nRaiseSets * 9] TryRaiseMaxZError rounding errors of the first row, one set per workgroup (float types), or nullptr
+  double* row0RaiseErr;    // [nRaiseSets * 9] TryRaiseMaxZError rounding errors of the first row, one set per workgroup that holds
+                           // some of it (float types), or nullptr
   u8* prefixStage;     // [kFastPrefixStage] the bytes in front of the first block, written by the decide step, copied by the pack step
   u64* tileOffset;     // [nTiles + 1] where each tile's blob starts in the output arena; nullptr: a single raster at offset 0
   FastEncodeResult* result;
@@ -60,8 +75,8 @@ struct FastEncodeBuffers
 
 bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, double maxZErr);
 u32 fastEncodeNumWG(int nRows, int nCols);
-// stage -1: first-row rounding errors (float types); 0: statistics + block sizes; 1: scan + decisions + header; 2: pack +
-// Fletcher sums; 3: checksum patch
+// stage 0: statistics + block sizes (+ first-row rounding errors, float types); 1: scan + decisions + header; 2: pack +
+// checksum
 // (batches: stage 1 also places the tiles in the arena, from `arenaBase` on; tiles that need the general path take no room)
 void launchFastEncode(int stage, const BandParams& assumed, double requestedMaxZErr, u32 raiseCandidates, const void* data, u8* out,
                       u64 outCapacity, u64 arenaBase, const FastEncodeBuffers& b, const FastBatch& batch, hipStream_t st);

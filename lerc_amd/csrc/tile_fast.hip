@@ -146,19 +146,24 @@ __device__ __forceinline__ u32 packDesc(const Plan& pl, int nb) { return (u32)pl
 template<class T, bool WIDE>
 __global__ void __launch_bounds__(256)
 k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict__ desc, u32* __restrict__ wgSize,
-             u64* __restrict__ wgMinKey, u64* __restrict__ wgMaxKey, u32* __restrict__ wgFlags, FastBatch batch)
+             u64* __restrict__ wgMinKey, u64* __restrict__ wgMaxKey, u32* __restrict__ wgFlags, u32 raiseCand,
+             double* __restrict__ row0RaiseErr, u32* __restrict__ tickets, FastBatch batch)
 {
   {
     const size_t tile = blockIdx.y;    // this tile's slice of every array
     data += tile * batch.tileElems; desc += tile * batch.nWG * kFastBlocksPerWG; wgSize += tile * fastWgStride(batch.nWG);
     wgMinKey += tile * batch.nWG; wgMaxKey += tile * batch.nWG; wgFlags += tile * batch.nWG;
+    if (row0RaiseErr) row0RaiseErr += tile * batch.nRaiseSets * 9;
+    tickets += tile * fastTicketStride(batch.nWG);
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) tickets[0] = 0u;    // the scan step counts its workgroups here
   typedef FastCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
   typedef typename ShflT<T>::type ST;
   __shared__ T s_mn[kFastBlocksPerWG], s_mx[kFastBlocksPerWG];
   __shared__ u32 s_same[kFastBlocksPerWG], s_nd[kFastBlocksPerWG];
   __shared__ u32 s_fl[4];
+  __shared__ u64 s_raise[4][9];
   PROBE_BEGIN;
   // a block is LB consecutive lanes (a DPP row for 32-bit types), so that its reductions never leave the VALU:
   // lane = b * LB + r * LPR + h  (block of the wave tile, raster row of the block, lane of that row)
@@ -174,12 +179,36 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
 #pragma unroll
   for (int t = 0; t < C::IT; t++) loadLane<T, V>(data + laneOrigin<WIDE, BPW, V>(span, t * 4 + w, r, c, p.nCols), vAll[t]);
 
+  // float types: the pixels of the first raster row the way Lerc2::TryRaiseMaxZError looks at them (Lerc2.cpp:1245-1290):
+  // per candidate factor the largest rounding error; the decide step folds the workgroups' partial results
+  const bool doRaise = DtOf<T>::v >= DT_Float && raiseCand != 0u && row0RaiseErr != nullptr && blockIdx.x < batch.nRaiseSets;
+  double rerr[9];
+#pragma unroll
+  for (int cnd = 0; cnd < 9; cnd++) rerr[cnd] = 0;
   u32 flags = 0;
 #pragma unroll
   for (int t = 0; t < C::IT; t++)
   {
     const int tile = t * 4 + w;
     T (&v)[V] = vAll[t];
+    if (doRaise && r == 0 && fastSpanRow(span, (u32)(tile * BPW + b)) == 0u && fastSpanHas(span, (u32)(tile * BPW + b)))
+    {
+      const int facCand[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
+#pragma unroll
+      for (int k = 0; k < V; k++)
+      {
+        const double x = (double)v[k];
+        if (x != x) continue;    // a NaN sends the band to the general path anyway
+        for (int cnd = 0; cnd < 9; cnd++)    // candidates in increasing factor order, stop at the first exact hit
+        {
+          if (!((raiseCand >> cnd) & 1u)) continue;
+          const double z = x * facCand[cnd];
+          if (z == (double)(int)z) break;
+          const double dlt = fabs(floor(z + 0.5) - z);
+          rerr[cnd] = dlt > rerr[cnd] ? dlt : rerr[cnd];
+        }
+      }
+    }
     if (DtOf<T>::v >= DT_Float)
     {
 #pragma unroll
@@ -224,6 +253,16 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
   }
   const bool f1 = __any(flags & 1u), f2 = __any(flags & 2u);
   if (lane == 0) s_fl[w] = (f1 ? 1u : 0u) | (f2 ? 2u : 0u);
+  if (doRaise)
+  {
+#pragma unroll
+    for (int cnd = 0; cnd < 9; cnd++)
+    {
+      u64 bits; const double e = rerr[cnd]; memcpy(&bits, &e, 8);    // non-negative doubles order like their bit patterns
+      bits = waveMax(bits);
+      if (lane == 0) s_raise[w][cnd] = bits;
+    }
+  }
   __syncthreads();
   PROBE(0);
   // the serial per-block phase rotates over the waves (= SIMDs) from workgroup to workgroup, or one SIMD of the CU
@@ -260,6 +299,13 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
     wgMaxKey[blockIdx.x] = kMax;
     wgFlags[blockIdx.x] = s_fl[0] | s_fl[1] | s_fl[2] | s_fl[3];
   }
+  if (doRaise && lane < 9)
+  {
+    u64 m = s_raise[0][lane];
+    for (int i = 1; i < 4; i++) m = s_raise[i][lane] > m ? s_raise[i][lane] : m;
+    double e; memcpy(&e, &m, 8);
+    row0RaiseErr[blockIdx.x * 9 + lane] = e;
+  }
   PROBE(1);
 }
 
@@ -275,21 +321,16 @@ __device__ __forceinline__ double keyToDouble(int dt, u64 key, u64& raw)
   return (double)v;
 }
 
+// lane 0 of a wave decides; `prefix` (LDS) receives the bytes in front of the first block
 __device__ __forceinline__ void
-fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgBase,
-           const u64* __restrict__ slotMinKey, const u64* __restrict__ slotMaxKey, const u32* __restrict__ slotFlags,
-           const double* __restrict__ row0RaiseErr, u32 nRaiseSets, u32 nBlobsMore, u8* __restrict__ out, u64 outCapacity, FastEncodeResult* res)
+fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u32 nBytesTiling, u64 minKey, u64 maxKey, u32 flags,
+           const u64* raiseBits /* [9] largest first-row rounding error per candidate, as bit patterns */, u32 nBlobsMore, u8* prefix,
+           u64 outCapacity, FastEncodeResult* res)
 {
-  const int lane = laneId();
-  const u64 a = waveMin(slotMinKey[lane]), b = waveMax(slotMaxKey[lane]);
-  u32 f = slotFlags[lane];
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) f |= __shfl_xor(f, m);
-  if (lane != 0) return;
-
+  const u64 a = minKey, b = maxKey;
+  const u32 f = flags;
   u64 rawMin = 0, rawMax = 0;
   const double zMin = keyToDouble(p.dt, a, rawMin), zMax = keyToDouble(p.dt, b, rawMax);
-  const u32 nBytesTiling = wgBase[nWG];
   const int tb = dtSize(p.dt);
   const u64 nPix = (u64)p.nRows * (u64)p.nCols;
   u32 redo = 0;
@@ -300,18 +341,12 @@ fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u3
     const double lim = (p.dt == DT_Float) ? 8388608.0 : 9007199254740992.0;
     const bool allInt = !(f & 2u) && zMin >= -lim && zMin <= lim && zMax >= -lim && zMax <= lim;
     if (allInt) redo |= kRedoAllInt;    // maxZErr becomes max(0.5, floor(.)) and the header says bIsInt
-    if (raiseCandidates && row0RaiseErr)
+    if (raiseCandidates && raiseBits)
     {
       const int fac[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
       for (int c = 0; c < 9; c++)
       {
-        double e = 0;
-#pragma unroll
-        for (u32 w = 0; w < 16u; w++)    // nRaiseSets <= 16; a fixed trip count lets the loads go out together
-        {
-          const double x = (w < nRaiseSets) ? row0RaiseErr[w * 9 + c] : 0.0;
-          e = x > e ? x : e;
-        }
+        double e; const u64 bits = raiseBits[c]; memcpy(&e, &bits, 8);
         if (((raiseCandidates >> c) & 1u) && !(e / fac[c] > requestedMaxZErr / 2)) redo |= kRedoRaise;
       }
     }
@@ -335,7 +370,7 @@ fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u3
   if (redo) return;
 
   // header + "no mask" + ranges + "not one sweep" (Lerc2.cpp:396-430)
-  u8* o = out;
+  u8* o = prefix;
   const char key[6] = { 'L', 'e', 'r', 'c', '2', ' ' };
   for (int i = 0; i < 6; i++) o[i] = (u8)key[i];
   putBytes(o + 6, (u64)(u32)kCodecVersion, 4);
@@ -351,41 +386,132 @@ fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u3
   o[94 + 2 * tb] = 0;
 }
 
-// the scan of the workgroup sizes, the fold of the per-workgroup statistics and the decisions in one launch
-// (1024 threads; the first wave decides)
+// The scan of the workgroup sizes, the fold of the per-workgroup statistics and the decisions in one launch: every
+// workgroup (1024 threads) scans kFastScanGroup sizes and publishes what it found; the one that arrives last scans the
+// groups' totals, decides, writes the bytes in front of the first block and resets the pack step's arrival counters.
 __global__ void __launch_bounds__(1024)
 k_fast_scan_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgSize,
                    u32* __restrict__ wgBase, const u64* __restrict__ wgMinKey, const u64* __restrict__ wgMaxKey,
                    const u32* __restrict__ wgFlags, const double* __restrict__ row0RaiseErr, u8* __restrict__ prefixStage, u64 outCapacity,
-                   FastEncodeResult* res, FastBatch batch)
+                   FastEncodeResult* res, u32* __restrict__ groupBase, u64* __restrict__ scanPart, u64* __restrict__ packPart,
+                   u32* __restrict__ tickets, FastBatch batch)
 {
-  __shared__ u64 s_min[64], s_max[64];
-  __shared__ u32 s_fl[64];
+  __shared__ u64 s_min[16], s_max[16], s_raise[9];
+  __shared__ u32 s_fl[16], s_w[16];
+  __shared__ u32 s_last;
+  __shared__ __align__(16) u8 s_prefix[kFastPrefixStage];
+  const u32 nGroups = fastScanGroups(nWG);
   {
     const size_t tile = blockIdx.y;
     wgSize += tile * fastWgStride(batch.nWG); wgBase += tile * fastWgStride(batch.nWG);
     wgMinKey += tile * batch.nWG; wgMaxKey += tile * batch.nWG; wgFlags += tile * batch.nWG;
     if (row0RaiseErr) row0RaiseErr += tile * batch.nRaiseSets * 9;
     prefixStage += tile * kFastPrefixStage; res += tile;
+    groupBase += tile * (nGroups + 1); scanPart += tile * 3 * nGroups; tickets += tile * fastTicketStride(batch.nWG);
+    packPart += tile * fastPackGroups(batch.nWG);
   }
+  const int lane = laneId(), w = waveId();
+  // ---- this group's kFastScanGroup entries: four per thread, all loads in flight first
+  const u32 g = blockIdx.x;
+  const u32 i0 = g * kFastScanGroup + 4u * threadIdx.x;
+  const u32 lastVec = (nWG - 1u) & ~3u;                      // clamped loads (the arrays have slack up to a multiple of 4)
+  const uint4 sz = *reinterpret_cast<const uint4*>(wgSize + min(i0, lastVec));
   u64 kMin = ~0ull, kMax = 0ull;
   u32 fl = 0;
-  for (u32 i = threadIdx.x; i < nWG; i += 1024u)
+  u32 e[4] = { sz.x, sz.y, sz.z, sz.w };
+#pragma unroll
+  for (u32 k = 0; k < 4; k++)
   {
+    const u32 i = min(i0 + k, nWG - 1u);
     const u64 a = wgMinKey[i], b = wgMaxKey[i];
-    kMin = a < kMin ? a : kMin; kMax = b > kMax ? b : kMax;
-    fl |= wgFlags[i];
+    const u32 f = wgFlags[i];
+    const bool have = i0 + k < nWG && 4u * threadIdx.x + k < kFastScanGroup;
+    kMin = (have && a < kMin) ? a : kMin; kMax = (have && b > kMax) ? b : kMax;
+    fl |= have ? f : 0u;
+    e[k] = have ? e[k] : 0u;
   }
+  const u32 sum = e[0] + e[1] + e[2] + e[3];
+  const u32 inc = waveInclusiveScan(sum);
   kMin = waveMin(kMin); kMax = waveMax(kMax);
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) fl |= __shfl_xor(fl, m);
-  if (threadIdx.x < 64) { s_min[threadIdx.x] = ~0ull; s_max[threadIdx.x] = 0ull; s_fl[threadIdx.x] = 0u; }
+  if (lane == 63) s_w[w] = inc;
+  if (lane == 0) { s_min[w] = kMin; s_max[w] = kMax; s_fl[w] = fl; }
   __syncthreads();
-  if (laneId() == 0) { s_min[waveId()] = kMin; s_max[waveId()] = kMax; s_fl[waveId()] = fl; }
-  scanSingleWorkgroup(wgSize, wgBase, nWG);
+  u32 run = inc - sum;
+  for (int i = 0; i < w; i++) run += s_w[i];
+  {
+    uint4 o;
+    o.x = run; o.y = run + e[0]; o.z = o.y + e[1]; o.w = o.z + e[2];
+    if (4u * threadIdx.x >= kFastScanGroup) { }
+    else if (i0 + 3 < nWG) *reinterpret_cast<uint4*>(wgBase + i0) = o;
+    else if (i0 < nWG) { wgBase[i0] = o.x; if (i0 + 1 < nWG) wgBase[i0 + 1] = o.y; if (i0 + 2 < nWG) wgBase[i0 + 2] = o.z; }
+  }
+  if (threadIdx.x == 0)
+  {
+    u32 total = 0, f = 0;
+    u64 a = ~0ull, b = 0ull;
+    for (int i = 0; i < 16; i++) { total += s_w[i]; f |= s_fl[i]; a = s_min[i] < a ? s_min[i] : a; b = s_max[i] > b ? s_max[i] : b; }
+    publish64(scanPart + 3 * (size_t)g, (u64)total | ((u64)f << 32));
+    publish64(scanPart + 3 * (size_t)g + 1, a);
+    publish64(scanPart + 3 * (size_t)g + 2, b);
+    drainVmem();
+    s_last = (nGroups == 1u || lastArrival(&tickets[0], nGroups)) ? 1u : 0u;
+  }
   __syncthreads();
-  if (waveId() == 0)
-    fastDecide(p, requestedMaxZErr, raiseCandidates, nWG, wgBase, s_min, s_max, s_fl, row0RaiseErr, batch.nRaiseSets, batch.nBlobsMore, prefixStage, outCapacity, res);
+  if (!s_last) return;
+
+  // ---- the last workgroup: the groups' totals, the decisions, the header
+  const u32 nPackGroups = fastPackGroups(nWG);
+  for (u32 i = threadIdx.x; i < nPackGroups; i += 1024u) packPart[i] = 0ull;    // the pack step adds up its checksum terms here
+  if (threadIdx.x < 9)
+  {
+    u64 m = 0;    // (+0.0)
+    if (row0RaiseErr)
+      for (u32 i = 0; i < batch.nRaiseSets; i++)
+      {
+        u64 bits; const double er = row0RaiseErr[i * 9 + threadIdx.x]; memcpy(&bits, &er, 8);
+        m = bits > m ? bits : m;
+      }
+    s_raise[threadIdx.x] = m;
+  }
+  u64 aMin = ~0ull, aMax = 0ull;
+  u32 aFl = 0, carry = 0;
+  for (u32 g0 = 0; g0 < nGroups; g0 += 1024u)    // (one round unless the raster has more than 2^28 blocks)
+  {
+    const u32 gi = g0 + threadIdx.x;
+    const bool have = gi < nGroups;
+    const u64 tf = have ? observe64(scanPart + 3 * (size_t)gi) : 0ull;
+    const u64 a = have ? observe64(scanPart + 3 * (size_t)gi + 1) : ~0ull, b = have ? observe64(scanPart + 3 * (size_t)gi + 2) : 0ull;
+    const u32 tot = (u32)tf;
+    aFl |= (u32)(tf >> 32); aMin = a < aMin ? a : aMin; aMax = b > aMax ? b : aMax;
+    __syncthreads();
+    const u32 inc2 = waveInclusiveScan(tot);
+    if (lane == 63) s_w[w] = inc2;
+    __syncthreads();
+    u32 before = carry + inc2 - tot;
+    for (int i = 0; i < w; i++) before += s_w[i];
+    if (have) groupBase[gi] = before;
+    u32 all = 0;
+    for (int i = 0; i < 16; i++) all += s_w[i];
+    carry += all;
+  }
+  aMin = waveMin(aMin); aMax = waveMax(aMax);
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) aFl |= __shfl_xor(aFl, m);
+  __syncthreads();
+  if (lane == 0) { s_min[w] = aMin; s_max[w] = aMax; s_fl[w] = aFl; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    groupBase[nGroups] = carry;
+    u32 f = 0;
+    u64 a = ~0ull, b = 0ull;
+    for (int i = 0; i < 16; i++) { f |= s_fl[i]; a = s_min[i] < a ? s_min[i] : a; b = s_max[i] > b ? s_max[i] : b; }
+    fastDecide(p, requestedMaxZErr, raiseCandidates, carry, a, b, f, row0RaiseErr ? s_raise : nullptr, batch.nBlobsMore, s_prefix, outCapacity, res);
+  }
+  __syncthreads();
+  if (threadIdx.x < kFastPrefixStage / 4) reinterpret_cast<u32*>(prefixStage)[threadIdx.x] = reinterpret_cast<const u32*>(s_prefix)[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -414,14 +540,17 @@ __device__ __forceinline__ void fletcherWord(u32 x, u32 pos, u64& A, u64& B)
 
 template<class T, bool WIDE>
 __global__ void __launch_bounds__(256)
-k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __restrict__ desc, const u32* __restrict__ wgBase,
-            u8* __restrict__ out, u64* __restrict__ wgFletcher, const FastEncodeResult* __restrict__ res,
+k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __restrict__ desc, const u32* __restrict__ wgSize,
+            const u32* __restrict__ wgBase, const u32* __restrict__ groupBase, u8* __restrict__ out,
+            u64* __restrict__ packPart, FastEncodeResult* __restrict__ res,
             const u8* __restrict__ prefixStage, const u64* __restrict__ tileOffset, FastBatch batch)
 {
   {
     const size_t tile = blockIdx.y;
     data += tile * batch.tileElems; desc += tile * batch.nWG * kFastBlocksPerWG; wgBase += tile * fastWgStride(batch.nWG);
-    wgFletcher += tile * batch.nWG * 2; res += tile; prefixStage += tile * kFastPrefixStage;
+    wgSize += tile * fastWgStride(batch.nWG); groupBase += tile * (fastScanGroups(batch.nWG) + 1);
+    packPart += tile * fastPackGroups(batch.nWG);
+    res += tile; prefixStage += tile * kFastPrefixStage;
     if (tileOffset) out += tileOffset[tile];
   }
   typedef FastCfg<T> C;
@@ -435,14 +564,16 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
   __shared__ u64 s_fa[4], s_fb[4];
   if (res->redo) return;
   // the bytes in front of the first block (header, mask count, ranges, mode byte) come from the decide step
-  if (blockIdx.x == 0 && threadIdx.x < res->prefixLen) out[threadIdx.x] = prefixStage[threadIdx.x];
+  // (without the checksum, bytes 10 .. 13: the workgroup that arrives last writes it, possibly through another XCD's L2, and
+  // a second dirty copy of those bytes here could reach memory after it)
+  if (blockIdx.x == 0 && threadIdx.x < res->prefixLen && (threadIdx.x < 10 || threadIdx.x >= 14)) out[threadIdx.x] = prefixStage[threadIdx.x];
 
   PROBE_BEGIN;
   const int w = waveId(), lane = laneId();
   const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
   const FastSpan span = fastSpanOf(blockIdx.x, (u32)p.nTH, (u32)p.nTV);
-  const u32 g0 = res->prefixLen + wgBase[blockIdx.x];        // absolute offset of this workgroup's span
-  const u32 spanLen = wgBase[blockIdx.x + 1] - wgBase[blockIdx.x];
+  const u32 g0 = res->prefixLen + groupBase[blockIdx.x / kFastScanGroup] + wgBase[blockIdx.x];    // absolute offset of this workgroup's span
+  const u32 spanLen = wgSize[blockIdx.x];
   const u32 ldsShift = g0 & 15u;                            // LDS byte i <-> blob byte (g0 & ~15) + i
 
   // pixels first (long latency), descriptors by wave 0, zero the span image meanwhile
@@ -575,81 +706,86 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
   __syncthreads();
   PROBE(6);
 
-  // ---- flush: 16-byte chunks, byte granular at the two ends; Fletcher sums of the bytes we own.
-  // Absolute blob offsets of chunk starts are multiples of 16, so positions inside blob[14 ..) are even.
-  u64 A = 0, B = 0;
+  // ---- Fletcher sums of the bytes this workgroup owns (16-byte units of the span image; absolute blob offsets of unit
+  // starts are multiples of 16, so positions inside blob[14 ..) are even), before the bytes themselves leave: the sums
+  // are handed on below while the stores are still under way
   const u32 gAligned = g0 & ~15u;
   const u32 nChunks = (ldsShift + spanLen + 15) >> 4;
+  {
+    u32 A = 0;
+    u64 B = 0;
+    for (u32 ch = threadIdx.x; ch < nChunks; ch += 256)
+    {
+      const u32 lo = ch * 16, hi = lo + 16;                                  // LDS byte range of this unit
+      uint4 x = *reinterpret_cast<const uint4*>(&s_out[ch * 4]);
+      if (lo < ldsShift || hi > ldsShift + spanLen)                          // blank the bytes we do not own
+      {
+        u32 wd[4] = { x.x, x.y, x.z, x.w };
+#pragma unroll
+        for (u32 i = 0; i < 16; i++)
+          if (lo + i < ldsShift || lo + i >= ldsShift + spanLen) wd[i >> 2] &= ~(0xFFu << (8 * (i & 3)));
+        x = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+      }
+      // (gAligned + lo >= 16 > 14 always holds here because spans start behind the >= 95-byte prefix)
+      fletcherUnit(x, (u64)((gAligned + lo - 14u) >> 1), A, B);
+    }
+    const u64 a = waveSum((u64)A % 65535u), b2 = waveSum(B % 65535u);
+    if (lane == 0) { s_fa[w] = a; s_fb[w] = b2; }
+  }
+  __syncthreads();
+  // ---- checksum = Fletcher32 over blob[14 ..) (Lerc2.cpp:1037-1064).  Every workgroup adds its two sums (each < 65535)
+  // and a 1 to its group's accumulator with ONE 64-bit atomic that it does not wait for: A in bits 0-23, B in bits 24-47,
+  // arrivals in bits 48-63.  Only the workgroup with the highest index waits: it is dispatched last, so all the others
+  // are resident or done, and it polls the accumulators until every group is complete, folds them and patches the header.
+  const u32 nWG = batch.nWG, nGroups = fastPackGroups(nWG);
+  if (threadIdx.x == 0)
+  {
+    const u64 a = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u, b2 = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
+    __hip_atomic_fetch_add(packPart + blockIdx.x / kFastPackGroup, a | (b2 << 24) | (1ull << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- flush: 16-byte units, byte granular at the two ends
   for (u32 ch = threadIdx.x; ch < nChunks; ch += 256)
   {
-    const u32 lo = ch * 16, hi = lo + 16;                                  // LDS byte range of this chunk
+    const u32 lo = ch * 16, hi = lo + 16;
     const u32 first = lo < ldsShift ? ldsShift : lo;
     const u32 last = hi > ldsShift + spanLen ? ldsShift + spanLen : hi;    // owned bytes: [first, last)
-    uint4 x = *reinterpret_cast<const uint4*>(&s_out[ch * 4]);
+    const uint4 x = *reinterpret_cast<const uint4*>(&s_out[ch * 4]);
     if (first == lo && last == hi) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;
     else
     {
-      // partial chunk: store byte-wise and blank the bytes we do not own before summing
-      u32 wd[4] = { x.x, x.y, x.z, x.w };
-      for (u32 i = lo; i < hi; i++)
-      {
-        const u32 byte = (wd[(i - lo) >> 2] >> (8 * ((i - lo) & 3))) & 0xFFu;
-        if (i >= first && i < last) out[gAligned + i] = (u8)byte;
-        else wd[(i - lo) >> 2] &= ~(0xFFu << (8 * ((i - lo) & 3)));
-      }
-      x = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+      const u32 wd[4] = { x.x, x.y, x.z, x.w };
+#pragma unroll
+      for (u32 i = 0; i < 16; i++)
+        if (lo + i >= first && lo + i < last) out[gAligned + lo + i] = (u8)(wd[i >> 2] >> (8 * (i & 3)));
     }
-    const u32 pos = gAligned + lo - 14 + 0;    // position of the chunk's first byte; may be "negative" only for lo < 14 of the first span
-    // gAligned + lo >= 16 > 14 always holds here because spans start behind the >= 95-byte prefix
-    fletcherWord(x.x, pos, A, B);
-    fletcherWord(x.y, pos + 4, A, B);
-    fletcherWord(x.z, pos + 8, A, B);
-    fletcherWord(x.w, pos + 12, A, B);
-  }
-  A %= 65535u; B %= 65535u;
-  A = waveSum(A); B = waveSum(B);
-  if (lane == 0) { s_fa[w] = A; s_fb[w] = B; }
-  __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    wgFletcher[2 * (size_t)blockIdx.x] = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u;    // folded by k_fast_checksum
-    wgFletcher[2 * (size_t)blockIdx.x + 1] = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
   }
   PROBE(7);
-}
-
-// checksum = Fletcher32 over blob[14 ..): the prefix bytes written by the decide step + the workgroups' partial sums
-__global__ void __launch_bounds__(1024)
-k_fast_checksum(const u64* __restrict__ wgFletcher, u32 nWG, u8* __restrict__ out, FastEncodeResult* res,
-                const u8* __restrict__ prefixStage, const u64* __restrict__ tileOffset, FastBatch batch)
-{
-  __shared__ u64 s_a[16], s_b[16];
+  if (blockIdx.x != nWG - 1u || w != 0) return;
+  u64 fA = 0, fB = 0;
+  for (u32 g0i = 0; g0i < nGroups; g0i += 64u)
   {
-    const size_t tile = blockIdx.y;
-    wgFletcher += tile * batch.nWG * 2; res += tile; prefixStage += tile * kFastPrefixStage;
-    if (tileOffset) out += tileOffset[tile];
+    const u32 gi = g0i + (u32)lane;
+    const u32 want = gi < nGroups ? min(kFastPackGroup, nWG - gi * kFastPackGroup) : 0u;
+    u64 acc = 0;
+    for (u32 spin = 0; ; spin++)
+    {
+      acc = gi < nGroups ? observe64(packPart + gi) : 0ull;
+      if (!__any((u32)(acc >> 48) != want)) break;
+      if (spin > (1u << 22)) break;          // (never: every other workgroup was dispatched before this one)
+      __builtin_amdgcn_s_sleep(8);
+    }
+    fA += acc & 0xFFFFFFull; fB += (acc >> 24) & 0xFFFFFFull;
   }
-  if (res->redo) return;
-  const int lane = laneId(), w = waveId();
-  u64 A = 0, B = 0;
-  if (threadIdx.x < 16) { s_a[threadIdx.x] = 0; s_b[threadIdx.x] = 0; }
-  __syncthreads();
-  for (u32 i = threadIdx.x; i < nWG; i += blockDim.x) { A += wgFletcher[2 * (size_t)i]; B += wgFletcher[2 * (size_t)i + 1]; }    // each < 65535
-  for (u32 pos = threadIdx.x; pos + 14 < res->prefixLen; pos += blockDim.x)
+  for (u32 pos = (u32)lane; pos + 14 < res->prefixLen; pos += 64u)    // + the bytes in front of the first block
   {
     const u32 cw = (u32)prefixStage[14 + pos] << ((pos & 1u) ? 0 : 8);
-    A += cw; B += (u64)(pos >> 1) * cw;
+    fA += cw; fB += (u64)(pos >> 1) * cw;
   }
-  A = waveSum(A % 65535u); B = waveSum(B % 65535u);
-  if (lane == 0) { s_a[w] = A; s_b[w] = B; }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  A = 0; B = 0;
-  for (int i = 0; i < 16; i++) { A += s_a[i]; B += s_b[i]; }
+  fA = waveSum(fA % 65535u) % 65535u; fB = waveSum(fB % 65535u) % 65535u;
+  if (lane != 0) return;
   const u32 len = res->blobSize - 14;
   const u64 N = ((u64)len + 1) / 2;
-  A %= 65535u; B %= 65535u;
-  u64 s1 = A, s2 = ((N % 65535u) * A + 65535u - B) % 65535u;
+  u64 s1 = fA, s2 = ((N % 65535u) * fA + 65535u - fB) % 65535u;
   if (s1 == 0) s1 = 0xffff;
   if (s2 == 0) s2 = 0xffff;
   const u32 cs = (u32)((s2 << 16) | s1);
@@ -688,52 +824,6 @@ k_fast_tile_offsets(FastEncodeResult* __restrict__ res, u32 nTiles, u64 arenaBas
   if (threadIdx.x == 1023) tileOffset[nTiles] = run;
 }
 
-// Before the passes, for float types: look at the first raster row the way
-// Lerc2::TryRaiseMaxZError does (Lerc2.cpp:1245-1290): per candidate factor the largest rounding error, one partial
-// result per workgroup (k_fast_decide folds them).
-template<class T>
-__global__ void __launch_bounds__(256)
-k_fast_prepare(const T* __restrict__ data, int nCols, u32 raiseCand, double* __restrict__ row0Partial, FastBatch batch)
-{
-  data += (size_t)blockIdx.y * batch.tileElems;
-  row0Partial += (size_t)blockIdx.y * batch.nRaiseSets * 9;
-  __shared__ u64 s_r[4][9];
-  const int lane = laneId(), w = waveId();
-  double rerr[9];
-#pragma unroll
-  for (int c = 0; c < 9; c++) rerr[c] = 0;
-  const int facCand[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
-  for (int i = (int)(blockIdx.x * 256u + threadIdx.x); i < nCols; i += (int)(gridDim.x * 256u))
-  {
-    const double x = (double)data[i];
-    if (x != x) continue;    // a NaN sends the band to the general path anyway
-#pragma unroll
-    for (int c = 0; c < 9; c++)    // candidates in increasing factor order, stop at the first exact hit
-    {
-      if (!((raiseCand >> c) & 1u)) continue;
-      const double z = x * facCand[c];
-      if (z == (double)(int)z) break;
-      const double dlt = fabs(floor(z + 0.5) - z);
-      rerr[c] = dlt > rerr[c] ? dlt : rerr[c];
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 9; c++)
-  {
-    u64 bits; const double e = rerr[c]; memcpy(&bits, &e, 8);    // non-negative doubles order like their bit patterns
-    bits = waveMax(bits);
-    if (lane == 0) s_r[w][c] = bits;
-  }
-  __syncthreads();
-  if (threadIdx.x < 9)
-  {
-    u64 m = s_r[0][threadIdx.x];
-    for (int i = 1; i < 4; i++) m = s_r[i][threadIdx.x] > m ? s_r[i][threadIdx.x] : m;
-    double e; memcpy(&e, &m, 8);
-    row0Partial[blockIdx.x * 9 + threadIdx.x] = e;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, double maxZErr)
 {
@@ -751,43 +841,35 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
                               u64 arenaBase, const FastEncodeBuffers& b, const FastBatch& batch, hipStream_t st)
 {
   const u32 nWG = batch.nWG, nT = batch.nTiles;
-  if (stage == -1)
-  {
-    if (b.row0RaiseErr)
-      hipLaunchKernelGGL(k_fast_prepare<T>, dim3(batch.nRaiseSets, nT), dim3(256), 0, st, (const T*)data, p.nCols, raiseCand, b.row0RaiseErr, batch);
-  }
-  else if (stage == 0)
+  if (stage == 0)
   {
     if (p.nTH % 64 == 0)
       hipLaunchKernelGGL((k_fast_stats<T, true>), dim3(nWG, nT), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.wgMinKey, b.wgMaxKey,
-                         b.wgFlags, batch);
+                         b.wgFlags, raiseCand, b.row0RaiseErr, b.tickets, batch);
     else
       hipLaunchKernelGGL((k_fast_stats<T, false>), dim3(nWG, nT), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.wgMinKey, b.wgMaxKey,
-                         b.wgFlags, batch);
+                         b.wgFlags, raiseCand, b.row0RaiseErr, b.tickets, batch);
   }
   else if (stage == 1)
   {
     // a tile of a batch may be as large as it likes here; whether the arena holds it is decided by the placement
-    hipLaunchKernelGGL(k_fast_scan_decide, dim3(1, nT), dim3(1024), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgSize, b.wgBase,
+    hipLaunchKernelGGL(k_fast_scan_decide, dim3(fastScanGroups(nWG), nT), dim3(1024), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgSize, b.wgBase,
                        (const u64*)b.wgMinKey, (const u64*)b.wgMaxKey, (const u32*)b.wgFlags, (const double*)b.row0RaiseErr, b.prefixStage,
-                       b.tileOffset ? ~0ull : cap, b.result, batch);
+                       b.tileOffset ? ~0ull : cap, b.result, b.groupBase, b.scanPart, b.packPart, b.tickets, batch);
     if (b.tileOffset)
       hipLaunchKernelGGL(k_fast_tile_offsets, dim3(1), dim3(1024), 0, st, b.result, nT, arenaBase, cap, b.tileOffset);
   }
-  else if (stage == 2)
+  else
   {
     if (p.nTH % 64 == 0)
       hipLaunchKernelGGL((k_fast_pack<T, true>), dim3(nWG, nT), dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc,
-                         (const u32*)b.wgBase, out, b.wgFletcher, (const FastEncodeResult*)b.result, (const u8*)b.prefixStage,
-                         (const u64*)b.tileOffset, batch);
+                         (const u32*)b.wgSize, (const u32*)b.wgBase, (const u32*)b.groupBase, out, b.packPart,
+                         b.result, (const u8*)b.prefixStage, (const u64*)b.tileOffset, batch);
     else
       hipLaunchKernelGGL((k_fast_pack<T, false>), dim3(nWG, nT), dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc,
-                         (const u32*)b.wgBase, out, b.wgFletcher, (const FastEncodeResult*)b.result, (const u8*)b.prefixStage,
-                         (const u64*)b.tileOffset, batch);
+                         (const u32*)b.wgSize, (const u32*)b.wgBase, (const u32*)b.groupBase, out, b.packPart,
+                         b.result, (const u8*)b.prefixStage, (const u64*)b.tileOffset, batch);
   }
-  else
-    hipLaunchKernelGGL(k_fast_checksum, dim3(1, nT), dim3(nT > 1 ? 256 : 1024), 0, st, (const u64*)b.wgFletcher, nWG, out, b.result, (const u8*)b.prefixStage,
-                       (const u64*)b.tileOffset, batch);
 }
 
 void launchFastEncode(int stage, const BandParams& assumed, double requestedMaxZErr, u32 raiseCandidates, const void* data, u8* out,

@@ -317,25 +317,6 @@ __device__ __forceinline__ bool fastRaised(const u32* __restrict__ fallback, u32
 // ------------------------------------------------------------------------------------------------
 // discovery
 // ------------------------------------------------------------------------------------------------
-// Fletcher32 terms (Lerc2.cpp:1037-1064) of one 16-byte unit whose first byte is byte 2 * k0 of the checksummed range
-// blob[14 ..): the checksum works on big-endian 16-bit words w, A = sum w, B = sum index * w.  Bytes at even positions
-// weigh 256: four byte dot products per dword, the word index inside the unit (0 .. 7) rides in the weights.
-__device__ __forceinline__ void fletcherUnit(const uint4& x, u64 k0, u32& A, u64& B)
-{
-  u32 ae = 0, ao = 0, be = 0, bo = 0;
-  ae = __builtin_amdgcn_udot4(x.x, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.x, 0x01000100u, ao, false);
-  be = __builtin_amdgcn_udot4(x.x, 0x00010000u, be, false); bo = __builtin_amdgcn_udot4(x.x, 0x01000000u, bo, false);
-  ae = __builtin_amdgcn_udot4(x.y, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.y, 0x01000100u, ao, false);
-  be = __builtin_amdgcn_udot4(x.y, 0x00030002u, be, false); bo = __builtin_amdgcn_udot4(x.y, 0x03000200u, bo, false);
-  ae = __builtin_amdgcn_udot4(x.z, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.z, 0x01000100u, ao, false);
-  be = __builtin_amdgcn_udot4(x.z, 0x00050004u, be, false); bo = __builtin_amdgcn_udot4(x.z, 0x05000400u, bo, false);
-  ae = __builtin_amdgcn_udot4(x.w, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.w, 0x01000100u, ao, false);
-  be = __builtin_amdgcn_udot4(x.w, 0x00070006u, be, false); bo = __builtin_amdgcn_udot4(x.w, 0x07000600u, bo, false);
-  const u32 a = 256u * ae + ao;    // < 2^19
-  A += a;
-  B += k0 * a + (256u * be + bo);
-}
-
 // What a discovery workgroup needs of the band header; every workgroup reads it for itself (three 16-byte loads of
 // the same address in all lanes).  The full check is done once, by parseBandHeader in workgroup 0: if that one says
 // "not ours" nobody looks at what the others did.

@@ -34,6 +34,26 @@ __device__ __forceinline__ void waveSync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Waits until this wave's stores (and loads) have been acknowledged.  Between write-through (agent scope) stores of a
+// partial result and the arrival ticket that lets another workgroup read them: inline assembly, because the compiler
+// drops a builtin wait it believes redundant (MI355X_MICROARCH.md, hand-off rules).
+__device__ __forceinline__ void drainVmem()
+{
+#ifndef HIPSIM
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+// partial results handed from workgroup to workgroup inside one launch: write-through stores / loads that bypass the
+// (per XCD, not coherent) L2, so that no release fence -- which would write back every dirty line of the L2 -- is needed
+__device__ __forceinline__ void publish64(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 observe64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// draws an arrival ticket; true for the workgroup that draws the last of `expected` (call by ONE thread, after
+// drainVmem() + __syncthreads())
+__device__ __forceinline__ bool lastArrival(u32* ticket, u32 expected)
+{
+  return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1u;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Cross-lane moves that stay in the VALU (no LDS traffic, unlike ds_bpermute behind __shfl*):
 // DPP (data parallel primitives) inside a row of 16 lanes, v_permlane{16,32}_swap across rows (gfx950).
@@ -190,6 +210,25 @@ __device__ __forceinline__ void scanSingleWorkgroup(const u32* __restrict__ in, 
   }
   // every thread behind the one that holds element n - 1 carries the total too
   if (threadIdx.x == 1023) out[n] = run;
+}
+
+// Fletcher32 terms (Lerc2.cpp:1037-1064) of one 16-byte unit whose first byte is byte 2 * k0 of the checksummed range
+// blob[14 ..): the checksum works on big-endian 16-bit words w, A = sum w, B = sum index * w.  Bytes at even positions
+// weigh 256: four byte dot products per dword, the word index inside the unit (0 .. 7) rides in the weights.
+__device__ __forceinline__ void fletcherUnit(const uint4& x, u64 k0, u32& A, u64& B)
+{
+  u32 ae = 0, ao = 0, be = 0, bo = 0;
+  ae = __builtin_amdgcn_udot4(x.x, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.x, 0x01000100u, ao, false);
+  be = __builtin_amdgcn_udot4(x.x, 0x00010000u, be, false); bo = __builtin_amdgcn_udot4(x.x, 0x01000000u, bo, false);
+  ae = __builtin_amdgcn_udot4(x.y, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.y, 0x01000100u, ao, false);
+  be = __builtin_amdgcn_udot4(x.y, 0x00030002u, be, false); bo = __builtin_amdgcn_udot4(x.y, 0x03000200u, bo, false);
+  ae = __builtin_amdgcn_udot4(x.z, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.z, 0x01000100u, ao, false);
+  be = __builtin_amdgcn_udot4(x.z, 0x00050004u, be, false); bo = __builtin_amdgcn_udot4(x.z, 0x05000400u, bo, false);
+  ae = __builtin_amdgcn_udot4(x.w, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.w, 0x01000100u, ao, false);
+  be = __builtin_amdgcn_udot4(x.w, 0x00070006u, be, false); bo = __builtin_amdgcn_udot4(x.w, 0x07000600u, bo, false);
+  const u32 a = 256u * ae + ao;    // < 2^19
+  A += a;
+  B += k0 * a + (256u * be + bo);
 }
 
 // first error wins
