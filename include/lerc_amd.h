@@ -27,6 +27,15 @@ extern "C" {
 
 #define LERC_AMD_API __attribute__((visibility("default")))
 
+/* Version of the stock API this library implements (reference Lerc_c_api.h:39-52: callers test features with
+ * LERC_AT_LEAST_VERSION).  The shared object carries the reference's soname, libLerc.so.4 (CMakeLists.txt:27-29). */
+#define LERC_VERSION_MAJOR 4
+#define LERC_VERSION_MINOR 2
+#define LERC_VERSION_PATCH 0
+#define LERC_COMPUTE_VERSION(maj, min, patch) ((maj) * 10000 + (min) * 100 + (patch))
+#define LERC_VERSION_NUMBER LERC_COMPUTE_VERSION(LERC_VERSION_MAJOR, LERC_VERSION_MINOR, LERC_VERSION_PATCH)
+#define LERC_AT_LEAST_VERSION(maj, min, patch) (LERC_VERSION_NUMBER >= LERC_COMPUTE_VERSION(maj, min, patch))
+
 typedef unsigned int lerc_status;
 
 /* ------------------------------------------------------------------------------------------------

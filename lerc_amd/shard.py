@@ -2,10 +2,15 @@
 
 A band blob is ONE sequential block stream with one global zMin / zMax and one checksum, so a single raster does
 not split across GPUs.  What shards is the unit above it: independent rasters / mosaic tiles, each its own blob.
-Ranks take contiguous tile ranges and never exchange pixel or blob data; the only collectives are metadata:
-the per-tile blob sizes (4 bytes per tile) that turn into the offsets of a mosaic container, and the
-max-over-ranks of the elapsed time that bench.py reports.  One process per GPU, torch.distributed ("nccl" is RCCL
-on ROCm; the CPU tests run the same code over "gloo").
+Ranks take contiguous tile ranges and compress them without talking to each other; the one exchange step of a
+mosaic job is the GATHER OF THE COMPRESSED BLOBS on the rank that writes the container (gather_arenas below):
+an all-gather of the arena lengths (8 bytes per rank), then every rank sends its arena -- the blobs of its tiles as
+lerc_amd_encode_tiles_device left them, device memory -- straight into its slice of the root's buffer with one
+grouped send / receive batch (RCCL: one ncclGroup of point-to-point transfers, each rank's bytes travelling over
+its own xGMI link to the root; no padding to the longest arena, no staging on the host), and the per-tile
+(offset, size) tables follow the same way.  The other collective is the max-over-ranks of the elapsed time that
+bench.py reports.  One process per GPU, torch.distributed ("nccl" is RCCL on ROCm; the CPU tests run the same code
+over "gloo").
 """
 import torch
 import torch.distributed as dist
@@ -50,3 +55,71 @@ def gather_manifest(local_sizes, n_tiles, device="cpu"):
     offsets = torch.zeros(n_tiles + 1, dtype=torch.int64)
     offsets[1:] = torch.cumsum(sizes, 0)
     return sizes, offsets
+
+
+def gather_arenas(arena, used, offsets, sizes, root=0):
+    """The exchange step of a mosaic job: the blobs of all ranks' tiles end up on `root`, in rank (= tile) order.
+
+    arena    this rank's blob arena (uint8 tensor on the job's device: HBM under RCCL, host memory under gloo)
+    used     bytes of it in use
+    offsets  int64 / uint64 array-like [nLocalTiles]: where each local tile's blob starts in `arena`
+    sizes    array-like [nLocalTiles]: its length
+
+    Returns on root (mosaic, tile_offsets, tile_sizes, rank_bases): `mosaic` a uint8 tensor on the same device holding
+    the ranks' arenas back to back (each starting at a multiple of 16 bytes, as inside an arena), tile_offsets /
+    tile_sizes int64 CPU tensors over ALL tiles in tile order (offsets into `mosaic`), rank_bases where each rank's
+    arena starts.  Other ranks get (None, None, None, None).  Works for a single process (no process group) too.
+    """
+    import numpy as np
+    world = _world()
+    rank = dist.get_rank() if world > 1 else 0
+    dev = arena.device
+    offsets = torch.as_tensor(np.asarray(offsets).astype(np.int64), dtype=torch.int64)
+    sizes = torch.as_tensor(np.asarray(sizes).astype(np.int64), dtype=torch.int64)
+    n_local = int(offsets.numel())
+    used = int(used)
+    if world == 1:
+        return arena[:used], offsets.clone(), sizes.clone(), [0]
+
+    # 1. how much everybody has: [bytes in use, tiles] (on the device under RCCL; gloo moves host memory)
+    tdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.tensor([used, n_local], dtype=torch.int64, device=tdev)
+    table = torch.empty(2 * world, dtype=torch.int64, device=tdev)
+    dist.all_gather_into_tensor(table, mine)
+    table = table.cpu().view(world, 2)
+    lens = [int(v) for v in table[:, 0]]
+    tiles = [int(v) for v in table[:, 1]]
+    bases, at = [], 0
+    for n in lens:
+        bases.append(at)
+        at += (n + 15) & ~15
+    total = at
+
+    # 2. the arenas and the per-tile tables, rank -> root, one grouped batch of point-to-point transfers
+    meta = torch.stack([offsets, sizes]).to(dev).contiguous() if n_local else torch.empty((2, 0), dtype=torch.int64, device=dev)
+    ops = []
+    if rank == root:
+        mosaic = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+        metas = [torch.empty((2, tiles[r]), dtype=torch.int64, device=dev) for r in range(world)]
+        for r in range(world):
+            if r == root:
+                continue
+            if lens[r]:
+                ops.append(dist.P2POp(dist.irecv, mosaic[bases[r]:bases[r] + lens[r]], r))
+            if tiles[r]:
+                ops.append(dist.P2POp(dist.irecv, metas[r], r))
+        mosaic[bases[root]:bases[root] + used].copy_(arena[:used])
+        metas[root] = meta
+    else:
+        if used:
+            ops.append(dist.P2POp(dist.isend, arena[:used], root))
+        if n_local:
+            ops.append(dist.P2POp(dist.isend, meta, root))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if rank != root:
+        return None, None, None, None
+    all_off = torch.cat([metas[r][0].cpu() + bases[r] for r in range(world)]) if sum(tiles) else torch.zeros(0, dtype=torch.int64)
+    all_size = torch.cat([metas[r][1].cpu() for r in range(world)]) if sum(tiles) else torch.zeros(0, dtype=torch.int64)
+    return mosaic[:total], all_off, all_size, bases

@@ -68,3 +68,21 @@ def test_product_does_not_link_oracle():
     for f in os.listdir(os.path.dirname(LIB)):
         if f.endswith((".cpp", ".hip", ".h")):
             assert "oracle/" not in open(os.path.join(os.path.dirname(LIB), f)).read(), f
+
+
+def test_soname_and_version_macros():
+    """Consumers of the reference find the library as libLerc.so.4 (CMakeLists.txt:27-29, _lerc.py:127) and test
+    features with LERC_AT_LEAST_VERSION (Lerc_c_api.h:39-52)."""
+    import re
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "lerc_amd.h")).read()
+    for macro in ("LERC_VERSION_MAJOR", "LERC_VERSION_MINOR", "LERC_VERSION_PATCH", "LERC_VERSION_NUMBER", "LERC_AT_LEAST_VERSION"):
+        assert re.search(r"#define\s+" + macro + r"\b", hdr), macro
+    assert re.search(r"#define\s+LERC_VERSION_MAJOR\s+4\b", hdr)
+    so = os.path.join(root, "lerc_amd", "csrc", "liblerc_amd.so")
+    if not os.path.exists(so) or not shutil.which("readelf"):
+        pytest.skip("library not built / no readelf")
+    dyn = subprocess.run(["readelf", "-d", so], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert "libLerc.so.4" in [m for m in re.findall(r"soname: \[(.*?)\]", dyn)], dyn

@@ -375,3 +375,53 @@ def test_lerc1_written_blobs(P, O):
     """Lerc1 blobs of tests/lerc1_writer.py: info, ranges, pixels and masks as the oracle's"""
     for name, blob, nb in cases.lerc1_cases():
         cases.check_lerc1_case(O, P, name, blob, nb, _same)
+
+
+def test_reference_test_driver_runs_against_the_product():
+    """The reference's own caller, src/LercTest/main.cpp, compiled from where it lies (`make -C oracle reftest`, test
+    infrastructure under oracle/_ref/) and linked against liblerc_amd.so under the reference's soname libLerc.so.4: its
+    encode / decode / getBlobInfo sequences check themselves, the exit code is the number of failed checks != 0."""
+    exe = os.path.join(capi.ROOT, "oracle", "_ref", "LercTest_amd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/LercTest_amd not built (needs /root/reference at build time)")
+    csrc = os.path.join(capi.ROOT, "lerc_amd", "csrc")
+    link = os.path.join(csrc, "libLerc.so.4")
+    if not os.path.exists(link):
+        os.symlink("liblerc_amd.so", link)
+    out = subprocess.run([exe], cwd=capi.ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    tail = out.stdout.decode(errors="replace")[-2000:]
+    assert out.returncode == 0, tail
+    assert "failed" not in tail.lower(), tail
+
+
+def test_mask_bytes_of_an_all_valid_band(P, O):
+    """lerc_decode with nMasks >= 1 on a blob that stores no mask (all pixels valid): the caller's mask bytes become 1s on
+    every path (Lerc.cpp:464-488), including the streaming kernels (the harness pre-fills the mask with 0xCD)."""
+    rng = np.random.default_rng(41)
+    for shape, n_bands in (((64, 1024), 1), ((2, 40, 520), 2), ((33, 47), 1)):
+        arr = cases.terrain(*shape[-2:], rng).astype(np.float32)
+        if n_bands > 1:
+            arr = np.stack([arr + i for i in range(n_bands)])
+        rc, blob = O.encode(arr, 0.01, n_bands=n_bands)
+        assert rc == 0
+        for want in (1, n_bands):
+            rc, dec, mask = P.decode(blob, want_masks=want, n_bands=n_bands)
+            assert rc == 0 and mask is not None and mask.shape[0] == want
+            assert (mask == 1).all(), (shape, want, np.unique(mask))
+            want_dec = O.decode(blob)[1]
+            assert _same(dec, want_dec)
+
+
+def test_c4_full_size_4096_rgb_uint8_huffman(P, O):
+    """BASELINE configs[3] at full size: 4096 x 4096 x 3 bytes, lossless -> 8-bit Huffman mode.  Blob == oracle blob,
+    decode == input (the self-synchronising Huffman decoder and the multi-level scans depend on the size)."""
+    from lerc_amd import synth
+    x = synth.c4_rgb_u8().numpy() if hasattr(synth, "c4_rgb_u8") else None
+    if x is None:
+        pytest.skip("synth.c4_rgb_u8 missing")
+    rc, blob = P.encode(x, 0, n_depth=3)
+    assert rc == 0
+    rc_o, blob_o = O.encode(x, 0, n_depth=3)
+    assert rc_o == 0 and len(blob) == len(blob_o) and sha(blob) == sha(blob_o)
+    rc, dec, _ = P.decode(blob)
+    assert rc == 0 and np.array_equal(dec.reshape(x.shape), x)

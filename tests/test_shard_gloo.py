@@ -42,6 +42,22 @@ def _worker(rank, world, port, out_dir):
         blobs = [_encode(t) for t in range(first, first + count)]
         sizes, offsets = shard.gather_manifest([len(b) for b in blobs], N_TILES)
         slowest = shard.max_over_ranks(0.25 + rank)
+        # the exchange step proper: every rank's arena (blobs at 16-byte aligned offsets, as the tile batch call leaves
+        # them) travels to rank 0 through the collective; rank 0 keeps the gathered mosaic for the parent to check
+        loc_off, at = [], 0
+        for b in blobs:
+            loc_off.append(at)
+            at += (len(b) + 15) & ~15
+        arena = torch.zeros(max(at, 1), dtype=torch.uint8)
+        for o, b in zip(loc_off, blobs):
+            arena[o:o + len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+        mosaic, t_off, t_size, bases = shard.gather_arenas(arena, at, loc_off, [len(b) for b in blobs], root=0)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "mosaic.npy"), mosaic.numpy())
+            np.save(os.path.join(out_dir, "mosaic_off.npy"), t_off.numpy())
+            np.save(os.path.join(out_dir, "mosaic_size.npy"), t_size.numpy())
+        else:
+            assert mosaic is None and t_off is None
         np.save(os.path.join(out_dir, f"sizes{rank}.npy"), sizes.numpy())
         np.save(os.path.join(out_dir, f"offsets{rank}.npy"), offsets.numpy())
         with open(os.path.join(out_dir, f"blobs{rank}.bin"), "wb") as f:
@@ -88,3 +104,20 @@ def test_two_ranks_over_gloo(tmp_path):
     # the ranks' arenas, concatenated in rank order, are the single-process mosaic byte for byte
     mosaic = open(tmp_path / "blobs0.bin", "rb").read() + open(tmp_path / "blobs1.bin", "rb").read()
     assert mosaic == b"".join(want)
+    # ... and so is what rank 0 holds after the gather collective: every tile's blob, cut out of the GATHERED tensor by the
+    # gathered offset / size tables, is the blob a single process makes of that tile; it decodes to the tile
+    g = np.load(tmp_path / "mosaic.npy")
+    g_off, g_size = np.load(tmp_path / "mosaic_off.npy"), np.load(tmp_path / "mosaic_size.npy")
+    assert g_size.tolist() == want_sizes and len(g_off) == N_TILES and (g_off % 16 == 0).all()
+    assert (np.diff(g_off) >= g_size[:-1]).all()                      # tile order, no overlap
+    for t in range(N_TILES):
+        blob = g[int(g_off[t]):int(g_off[t]) + int(g_size[t])].tobytes()
+        assert blob == want[t], t
+    rc, dec, _ = capi.oracle().decode(g[int(g_off[7]):int(g_off[7]) + int(g_size[7])].tobytes())
+    assert rc == 0 and float(np.abs(dec.reshape(TILE, TILE).astype(np.float64) - _tile(7)).max()) <= 0.0101
+
+
+def test_single_process_gather_is_the_arena_itself():
+    arena = torch.arange(64, dtype=torch.uint8)
+    mosaic, off, size, bases = shard.gather_arenas(arena, 40, [0, 16], [10, 24])
+    assert mosaic.tolist() == list(range(40)) and off.tolist() == [0, 16] and size.tolist() == [10, 24] and bases == [0]

@@ -522,3 +522,19 @@ def test_sim_poisoned_scratch():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
                         "-k", "damaged or lerc1_world"], env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_sim_mask_bytes_of_an_all_valid_band(libs):
+    """nMasks >= 1 on a blob without a mask: 1s everywhere, on the streaming path too (the harness pre-fills 0xCD)."""
+    O, S = libs
+    rng = np.random.default_rng(41)
+    for shape, n_bands in (((16, 1024), 1), ((2, 16, 520), 2), ((33, 47), 1)):
+        arr = cases.terrain(*shape[-2:], rng).astype(np.float32)
+        if n_bands > 1:
+            arr = np.stack([arr + i for i in range(n_bands)])
+        rc, blob = O.encode(arr, 0.01, n_bands=n_bands)
+        assert rc == 0
+        for want in (1, n_bands):
+            rc, dec, mask = S.decode(blob, want_masks=want, n_bands=n_bands)
+            assert rc == 0 and mask is not None and (mask == 1).all(), (shape, want)
+            assert _same(dec, O.decode(blob)[1])
