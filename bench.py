@@ -54,6 +54,11 @@ def parse_args():
                          "mosaic sharded over the ranks with the RCCL gather of the blobs (BASELINE configs[4])")
     ap.add_argument("--tiles", type=int, default=0, help="tiles of the whole mosaic for --workload c5 (default 65536; on one GPU 4096)")
     ap.add_argument("--rotate", type=int, default=3, help="buffer sets of the cache-cold pass (0: skip it)")
+    ap.add_argument("--mode", choices=("async", "sync"), default="async",
+                    help="c2: async (default) -- every step's encode and decode are ENQUEUED on the HIP stream (lerc_amd_*_device_async; the decode "
+                         "reads the blob's size from its header on the device) and the host waits once, at the end of the K steps, the way any "
+                         "stream of GPU work is driven; sync -- lerc_amd_encode_device / lerc_amd_decode_device, each waiting for its own result "
+                         "(reported beside it as `sync_per_call` in async mode)")
     return ap.parse_args()
 
 
@@ -211,7 +216,8 @@ def main():
     n_pix = sets[0][0].numel()
     torch.cuda.synchronize()
 
-    state = {"blob_bytes": 0, "gather_s": 0.0, "gather_bytes": 0, "gather_steps": 0}
+    state = {"blob_bytes": 0, "gather_s": 0.0, "gather_bytes": 0, "gather_steps": 0, "tickets": [],
+             "async": args.mode == "async" and not tiles_mode}
 
     def step(k=0):
         x, out, y = sets[k]
@@ -236,6 +242,15 @@ def main():
             if rc != 0:
                 raise RuntimeError(f"tile decode failed: status {rc}: {codec.last_error()}")
             return
+        if state["async"]:
+            rc, t1 = api.encode_device_async(codec, x, args.max_z_err, out)
+            rc2, t2 = api.decode_device_async(codec, out, out.numel(), y)
+            if rc != 0 or rc2 != 0:
+                raise RuntimeError(f"enqueue failed: status {rc} / {rc2}: {codec.last_error()}")
+            state["tickets"].append((t1, t2))
+            if len(state["tickets"]) >= 24:
+                drain()
+            return
         rc, nb = api.encode_device(codec, x, args.max_z_err, out)
         if rc != 0:
             raise RuntimeError(f"encode failed: status {rc}: {codec.last_error()}")
@@ -243,6 +258,16 @@ def main():
         rc = api.decode_device(codec, out, nb, y)
         if rc != 0:
             raise RuntimeError(f"decode failed: status {rc}: {codec.last_error()}")
+
+    def drain():
+        """async mode: wait for what is in flight and look at every operation's status"""
+        for t1, t2 in state["tickets"]:
+            rc, nb = codec.finish(t1)
+            rc2, _ = codec.finish(t2)
+            if rc != 0 or rc2 != 0:
+                raise RuntimeError(f"encode / decode failed: status {rc} / {rc2}: {codec.last_error()}")
+            state["blob_bytes"] = nb
+        state["tickets"] = []
 
     def barrier():
         if world > 1:
@@ -256,6 +281,7 @@ def main():
         """W warm-up steps, then exactly K timed steps between barriers; per-kernel HIP-event times of the timed steps."""
         for i in range(args.warmup):
             step(i % n_sets)
+        drain()
         state["gather_s"], state["gather_steps"] = 0.0, 0
         barrier()
         codec.lib.lerc_amd_profile_enable(codec.h, 1)
@@ -264,6 +290,7 @@ def main():
             step(i % n_sets)
         barrier()
         elapsed = time.perf_counter() - t0
+        drain()    # (the stream is idle: this only reads the verdicts)
         codec.lib.lerc_amd_profile_enable(codec.h, 0)
         buf = ct.create_string_buffer(1 << 16)
         codec.lib.lerc_amd_profile_read(codec.h, buf, len(buf), 1)
@@ -275,6 +302,11 @@ def main():
 
     elapsed, prof = timed(1)
     gather = dict(state)
+    sync_run = None
+    if state["async"]:
+        state["async"] = False
+        sync_run = timed(1)
+        state["async"] = True
 
     # correctness of what was timed (outside the timed region)
     x0, _, y0 = sets[0]
@@ -352,6 +384,13 @@ def main():
             res["gather"] = {"bytes_into_root": gather["gather_bytes"], "ms_per_step": round(g_s * 1e3, 4), "GBps": round(gbps, 2),
                              "links": world - 1, "frac_of_xgmi": round(gbps / ((world - 1) * XGMI_LINK_GBS), 4),
                              "peak": f"{world - 1} links x {XGMI_LINK_GBS} GB/s into the root"}
+        res["config"]["host"] = ("K steps enqueued on the stream, one wait at the end (lerc_amd_encode_device_async / lerc_amd_decode_device_async)"
+                                 if state["async"] else "every call waits for its own result")
+        if sync_run is not None:
+            s_ms = sync_run[0] / args.steps * 1e3
+            s_kms = sum(v[0] for v in sync_run[1].values()) / max(args.steps, 1)
+            res["sync_per_call"] = {"value": round(world * n_pix * args.steps / sync_run[0] / 1e6, 2), "roundtrip": roundtrip(s_ms, s_kms),
+                                    "note": "lerc_amd_encode_device + lerc_amd_decode_device, the host waits for each call's result"}
         if cold is not None:
             c_ms = cold[0] / args.steps * 1e3
             c_kms = sum(v[0] for v in cold[1].values()) / max(args.steps, 1)

@@ -120,6 +120,24 @@ LERC_AMD_API lerc_status lerc_amd_decode_device(lerc_amd_context* ctx, const uns
     unsigned int blobSize, int nMasks, unsigned char* dValidBytes, int nDepth, int nCols, int nRows, int nBands,
     unsigned int dataType, void* dData);
 
+/* The same two calls without the wait: the operation is enqueued on the context's stream and the call returns a ticket.
+ * Operations of one context run in the order they were enqueued, so a decode may be enqueued right behind the encode
+ * that writes its blob: pass the CAPACITY of the blob buffer as blobSizeBound, the true size is read from the header on
+ * the device.  lerc_amd_finish(ctx, ticket, &n) waits for the stream, returns that operation's lerc_status (and, for an
+ * encode, the bytes written / needed) and forgets it; ticket 0 waits for everything and drops all results.  Requests
+ * the streaming kernels do not take blind (masks, several bands, nDepth > 1, ...) are carried out inside the _async call
+ * itself, in order.  If the device hands an operation back to the general path (a constant raster, a damaged blob,
+ * ...), lerc_amd_finish repeats it and everything enqueued behind it synchronously -- results are the same as with
+ * the synchronous calls, only later.  Buffers must stay untouched until the operation has been finished.  At most 31
+ * unfinished results are kept; older ones are completed and dropped. */
+LERC_AMD_API lerc_status lerc_amd_encode_device_async(lerc_amd_context* ctx, const void* dData, unsigned int dataType,
+    int nDepth, int nCols, int nRows, int nBands, int nMasks, const unsigned char* dValidBytes, double maxZErr,
+    unsigned char* dOutBuffer, unsigned int outBufferSize, unsigned int* ticket);
+LERC_AMD_API lerc_status lerc_amd_decode_device_async(lerc_amd_context* ctx, const unsigned char* dLercBlob,
+    unsigned int blobSizeBound, int nMasks, unsigned char* dValidBytes, int nDepth, int nCols, int nRows, int nBands,
+    unsigned int dataType, void* dData, unsigned int* ticket);
+LERC_AMD_API lerc_status lerc_amd_finish(lerc_amd_context* ctx, unsigned int ticket, unsigned int* nBytes);
+
 /* Tile mosaics: nTiles rasters of one shape, contiguous on the device ([nTiles][nRows][nCols], 1 band, nDepth 1,
  * no masks), in ONE call (tiles are independent blobs; ranks of a multi-GPU job take tile ranges).
  * Tile t becomes exactly the blob lerc_encode() would make of it, at dArena + offsets[t] (16-byte aligned), sizes[t]

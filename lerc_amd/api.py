@@ -63,8 +63,13 @@ def load_library():
     lib.lerc_amd_decode_tiles_device.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_uint,
                                                  ct.c_void_p]
     lib.lerc_amd_build_info.restype = ct.c_char_p
+    lib.lerc_amd_encode_device_async.argtypes = [ct.c_void_p] + enc + [ct.c_void_p, ct.c_uint, u32p]
+    lib.lerc_amd_decode_device_async.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int,
+                                                 ct.c_int, ct.c_int, ct.c_uint, ct.c_void_p, u32p]
+    lib.lerc_amd_finish.argtypes = [ct.c_void_p, ct.c_uint, u32p]
     for n in ("lerc_computeCompressedSize", "lerc_encode", "lerc_getBlobInfo", "lerc_getDataRanges", "lerc_decode",
-              "lerc_amd_encode_device", "lerc_amd_decode_device", "lerc_amd_encode_tiles_device", "lerc_amd_decode_tiles_device"):
+              "lerc_amd_encode_device", "lerc_amd_decode_device", "lerc_amd_encode_tiles_device", "lerc_amd_decode_tiles_device",
+              "lerc_amd_encode_device_async", "lerc_amd_decode_device_async", "lerc_amd_finish"):
         getattr(lib, n).restype = ct.c_uint
     _LIB = lib
     return lib
@@ -198,6 +203,24 @@ class DeviceCodec:
                                              d_mask or None, float(max_z_err), d_out or None, out_cap, ct.byref(written))
         return rc, written.value
 
+    def encode_async(self, d_data, dt_code, n_depth, n_cols, n_rows, n_bands, max_z_err, d_out, out_cap, d_mask=0, n_masks=0):
+        """-> (status, ticket): enqueued on the context's stream; finish(ticket) waits and returns (status, nBytes)"""
+        ticket = ct.c_uint(0)
+        rc = self.lib.lerc_amd_encode_device_async(self.h, d_data, dt_code, n_depth, n_cols, n_rows, n_bands, n_masks,
+                                                   d_mask or None, float(max_z_err), d_out or None, out_cap, ct.byref(ticket))
+        return rc, ticket.value
+
+    def decode_async(self, d_blob, size_bound, dt_code, n_depth, n_cols, n_rows, n_bands, d_out, d_mask=0, n_masks=0):
+        ticket = ct.c_uint(0)
+        rc = self.lib.lerc_amd_decode_device_async(self.h, d_blob, size_bound, n_masks, d_mask or None, n_depth, n_cols, n_rows,
+                                                   n_bands, dt_code, d_out, ct.byref(ticket))
+        return rc, ticket.value
+
+    def finish(self, ticket=0):
+        n = ct.c_uint(0)
+        rc = self.lib.lerc_amd_finish(self.h, int(ticket), ct.byref(n))
+        return rc, n.value
+
     def decode(self, d_blob, blob_size, dt_code, n_depth, n_cols, n_rows, n_bands, d_out, d_mask=0, n_masks=0):
         return self.lib.lerc_amd_decode_device(self.h, d_blob, blob_size, n_masks, d_mask or None, n_depth, n_cols, n_rows,
                                                n_bands, dt_code, d_out)
@@ -227,6 +250,18 @@ def encode_device(codec, tensor, max_z_err, out, n_depth=1):
 def decode_device(codec, blob, n_bytes, out, n_depth=1):
     n_rows, n_cols = int(out.shape[0]), int(out.shape[1])
     return codec.decode(blob.data_ptr(), int(n_bytes), _torch_dt_code(out), n_depth, n_cols, n_rows, 1, out.data_ptr())
+
+
+def encode_device_async(codec, tensor, max_z_err, out, n_depth=1):
+    """Like encode_device, without the wait -> (status, ticket); codec.finish(ticket) -> (status, nBytes)."""
+    n_rows, n_cols = int(tensor.shape[0]), int(tensor.shape[1])
+    return codec.encode_async(tensor.data_ptr(), _torch_dt_code(tensor), n_depth, n_cols, n_rows, 1, max_z_err, out.data_ptr(), out.numel())
+
+
+def decode_device_async(codec, blob, size_bound, out, n_depth=1):
+    """Like decode_device, without the wait; size_bound: the blob's size or the capacity of its buffer."""
+    n_rows, n_cols = int(out.shape[0]), int(out.shape[1])
+    return codec.decode_async(blob.data_ptr(), int(size_bound), _torch_dt_code(out), n_depth, n_cols, n_rows, 1, out.data_ptr())
 
 
 def encode_tiles_device(codec, tiles, max_z_err, arena):

@@ -6,13 +6,29 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <deque>
 #include <new>
 
 using namespace lerc;
 
+// an operation of the asynchronous device API that has been enqueued but not waited for
+struct AsyncOp
+{
+  unsigned ticket = 0;
+  bool isEncode = false;
+  EncodeRequest er;
+  DecodeRequest dr;
+  bool streamed = false;    // its streaming kernels and the copy of their verdict are on the stream
+  u32 epoch = 0;
+  bool done = false;
+  u32 status = kOk, bytes = 0;
+};
+
 struct lerc_amd_context
 {
   Context ctx;
+  std::deque<AsyncOp> ops;  // in enqueue order; results stay until lerc_amd_finish has handed them out
+  unsigned nextTicket = 1;
   // staging buffers for the host-pointer API (grown on demand, owned by the context)
   void* io[3] = { nullptr, nullptr, nullptr };
   size_t ioCap[3] = { 0, 0, 0 };
@@ -379,6 +395,135 @@ lerc_status lerc_amd_decode_device(lerc_amd_context* h, const unsigned char* dLe
   rq.dBlob = dLercBlob; rq.blobSize = blobSize; rq.dt = (int)dataType; rq.nDepth = nDepth; rq.nCols = nCols; rq.nRows = nRows;
   rq.nBands = nBands; rq.nMasks = nMasks; rq.dOut = dData; rq.dValidBytes = dValidBytes;
   return decodeDevice(h->ctx, rq);
+}
+
+// ---- asynchronous device API: operations queue up on the context's stream, the host runs ahead -------------------------
+namespace {
+
+// Brings every operation of the context to its result.  The stream is waited for once; verdicts are then read in enqueue
+// order.  An operation the streaming kernels handed back (or that never was theirs) is repeated through the synchronous
+// path -- and so is everything enqueued behind it, which may have worked on what it had not produced yet.
+void completeAll(lerc_amd_context* h)
+{
+  bool pending = false;
+  for (const AsyncOp& op : h->ops) pending = pending || !op.done;
+  if (!pending) return;
+  Context& ctx = h->ctx;
+  const bool synced = ctx.sync();
+  bool rerun = !synced;
+  for (AsyncOp& op : h->ops)
+  {
+    if (op.done) continue;
+    if (!rerun && op.streamed)
+    {
+      const u8* slot = ctx.asyncSlot(op.ticket);
+      if (op.isEncode)
+      {
+        bool redo = false;
+        u32 needed = 0, written = 0;
+        encodeStreamingVerdict(ctx, op.er, slot, redo, op.status, needed, written);
+        op.bytes = op.er.dOut ? written : needed;
+        rerun = redo;
+      }
+      else rerun = !decodeStreamingVerdict(ctx, slot, op.epoch);
+      if (!rerun) { if (!op.isEncode) ctx.pathCount[2]++; op.done = true; continue; }
+    }
+    rerun = true;
+    if (op.isEncode)
+    {
+      u32 needed = 0, written = 0;
+      op.status = encodeDevice(ctx, op.er, needed, written);
+      op.bytes = op.er.dOut ? written : needed;
+    }
+    else
+    {
+      // (the blob's true length: an asynchronous decode may have been given the capacity of the buffer an encode still
+      // in flight was writing to; the synchronous path wants the blob's own size)
+      if (op.dr.dBlob && !op.dr.hBlob && op.dr.blobSize >= 70)
+      {
+        u8 head[64];
+        if (hipMemcpy(head, op.dr.dBlob, sizeof(head), hipMemcpyDeviceToHost) == hipSuccess)
+        {
+          BlobInfo info;
+          if (getBlobInfo(head, sizeof(head), info) == kOk && info.blobSize >= 70 && info.blobSize <= op.dr.blobSize) op.dr.blobSize = info.blobSize;
+        }
+      }
+      op.status = decodeDevice(ctx, op.dr);
+    }
+    op.done = true;
+  }
+}
+
+unsigned pushOp(lerc_amd_context* h, AsyncOp& op)
+{
+  // results nobody asked for do not pile up: beyond the pinned slots' number the oldest are brought to their end and dropped
+  if (h->ops.size() >= (size_t)Context::kAsyncSlots - 1) { completeAll(h); while (h->ops.size() >= (size_t)Context::kAsyncSlots / 2) h->ops.pop_front(); }
+  op.ticket = h->nextTicket++;
+  if (h->nextTicket == 0) h->nextTicket = 1;
+  h->ops.push_back(op);
+  return op.ticket;
+}
+
+}    // namespace
+
+lerc_status lerc_amd_encode_device_async(lerc_amd_context* h, const void* dData, unsigned int dataType, int nDepth, int nCols,
+  int nRows, int nBands, int nMasks, const unsigned char* dValidBytes, double maxZErr, unsigned char* dOutBuffer,
+  unsigned int outBufferSize, unsigned int* ticket)
+{
+  if (!h || !ticket) return kWrongParam;
+  *ticket = 0;
+  if (!dData || dataType >= DT_Undefined || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0 || maxZErr < 0) return kWrongParam;
+  if (!masksArgOk(nMasks, nBands, dValidBytes)) return kWrongParam;
+  if (!dimsOk(nDepth, nCols, nRows, (size_t)dtSize((int)dataType))) return kDimsTooLarge;
+  AsyncOp op;
+  op.isEncode = true;
+  EncodeRequest& rq = op.er;
+  rq.dData = dData; rq.dValidBytes = dValidBytes; rq.dt = (int)dataType; rq.nDepth = nDepth; rq.nCols = nCols; rq.nRows = nRows;
+  rq.nBands = nBands; rq.nMasks = nMasks; rq.maxZErr = maxZErr; rq.dOut = dOutBuffer; rq.outCapacity = outBufferSize;
+  const unsigned t = pushOp(h, op);
+  AsyncOp& q = h->ops.back();
+  q.streamed = encodeEnqueueStreaming(h->ctx, q.er, h->ctx.asyncSlot(t));
+  if (!q.streamed) completeAll(h);    // not a request the streaming kernels take: done on the spot (in order, behind what is in flight)
+  *ticket = t;
+  return kOk;
+}
+
+lerc_status lerc_amd_decode_device_async(lerc_amd_context* h, const unsigned char* dLercBlob, unsigned int blobSizeBound, int nMasks,
+  unsigned char* dValidBytes, int nDepth, int nCols, int nRows, int nBands, unsigned int dataType, void* dData, unsigned int* ticket)
+{
+  if (!h || !ticket) return kWrongParam;
+  *ticket = 0;
+  if (!dLercBlob || !blobSizeBound || !dData || dataType >= DT_Undefined || nDepth <= 0 || nCols <= 0 || nRows <= 0 || nBands <= 0)
+    return kWrongParam;
+  if (!masksArgOk(nMasks, nBands, dValidBytes)) return kWrongParam;
+  if (!dimsOk(nDepth, nCols, nRows, (size_t)dtSize((int)dataType))) return kDimsTooLarge;
+  AsyncOp op;
+  DecodeRequest& rq = op.dr;
+  rq.dBlob = dLercBlob; rq.blobSize = blobSizeBound; rq.dt = (int)dataType; rq.nDepth = nDepth; rq.nCols = nCols; rq.nRows = nRows;
+  rq.nBands = nBands; rq.nMasks = nMasks; rq.dOut = dData; rq.dValidBytes = dValidBytes;
+  const unsigned t = pushOp(h, op);
+  AsyncOp& q = h->ops.back();
+  q.streamed = decodeEnqueueStreaming(h->ctx, q.dr, h->ctx.asyncSlot(t), q.epoch);
+  if (!q.streamed) completeAll(h);
+  *ticket = t;
+  return kOk;
+}
+
+lerc_status lerc_amd_finish(lerc_amd_context* h, unsigned int ticket, unsigned int* nBytes)
+{
+  if (!h) return kWrongParam;
+  if (nBytes) *nBytes = 0;
+  completeAll(h);
+  if (ticket == 0) { h->ops.clear(); return kOk; }    // "everything": results are dropped
+  for (auto it = h->ops.begin(); it != h->ops.end(); ++it)
+    if (it->ticket == ticket)
+    {
+      const u32 rc = it->status;
+      if (nBytes) *nBytes = it->bytes;
+      h->ops.erase(it);
+      return rc;
+    }
+  return kWrongParam;    // no such operation (handed out before, or dropped behind more than kAsyncSlots / 2 newer ones)
 }
 
 lerc_status lerc_amd_encode_tiles_device(lerc_amd_context* h, const void* dTiles, unsigned int dataType, int nCols, int nRows, int nTiles,

@@ -54,6 +54,10 @@ public:
 
   // small pinned host mirror for results read back after a sync
   void* pinned(size_t bytes);
+  // pinned result slots of operations that are enqueued but not waited for yet (asynchronous device API)
+  static const int kAsyncSlots = 64;
+  static const size_t kAsyncSlotBytes = 512;
+  u8* asyncSlot(unsigned ticket);
   // a second pinned area (the validity bits of a band on their way to the host while kernels run) and its event
   void* pinnedAux(size_t bytes);
   hipEvent_t auxEvent();
@@ -87,6 +91,7 @@ private:
   std::vector<ProfAcc> m_acc;
   hipEvent_t profEvent();
 
+  u8* m_asyncPinned = nullptr;
   bool m_ok = false;
   u32 m_epoch = 0x1234567u;
   hipStream_t m_stream = nullptr, m_userStream = nullptr;
@@ -157,6 +162,16 @@ struct DecodeRequest
   double* hNoDataValues = nullptr;
 };
 u32 decodeDevice(Context& ctx, const DecodeRequest& rq);
+
+// The same two calls in two halves, for callers that keep several operations in flight on the stream (the asynchronous
+// device API, capi.cpp): the enqueue half puts the streaming kernels and the copy of their verdict into `slot` (pinned,
+// Context::kAsyncSlotBytes) on the stream and returns true -- or false when the request is not one the streaming kernels
+// take blind (then nothing was enqueued); the verdict half is called once the stream has passed that point.
+bool encodeEnqueueStreaming(Context& ctx, const EncodeRequest& rq, u8* slot);
+// redo: the general path has to repeat the request; else status / sizes are final
+void encodeStreamingVerdict(Context& ctx, const EncodeRequest& rq, const u8* slot, bool& redo, u32& status, u32& numBytesNeeded, u32& numBytesWritten);
+bool decodeEnqueueStreaming(Context& ctx, const DecodeRequest& rq, u8* slot, u32& epoch);
+bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch);    // true: decoded, checksum good
 u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed);
 u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq);
 

@@ -243,6 +243,7 @@ Context::~Context()
   if (m_slab) hipFree(m_slab);
   if (m_pinned) hipHostFree(m_pinned);
   if (m_pinnedAux) hipHostFree(m_pinnedAux);
+  if (m_asyncPinned) hipHostFree(m_asyncPinned);
   if (m_auxEvent) hipEventDestroy(m_auxEvent);
   for (hipEvent_t e : m_eventPool) hipEventDestroy(e);
   if (m_stream) hipStreamDestroy(m_stream);
@@ -286,6 +287,13 @@ void* Context::pinned(size_t bytes)
   if (hipHostMalloc(&m_pinned, bytes + 4096, hipHostMallocDefault) != hipSuccess) return nullptr;
   m_pinnedCap = bytes + 4096;
   return m_pinned;
+}
+
+u8* Context::asyncSlot(unsigned ticket)
+{
+  if (!m_asyncPinned && hipHostMalloc((void**)&m_asyncPinned, (size_t)kAsyncSlots * kAsyncSlotBytes, hipHostMallocDefault) != hipSuccess)
+    m_asyncPinned = nullptr;
+  return m_asyncPinned ? m_asyncPinned + (size_t)(ticket % kAsyncSlots) * kAsyncSlotBytes : nullptr;
 }
 
 void* Context::pinnedAux(size_t bytes)

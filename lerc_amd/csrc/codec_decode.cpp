@@ -149,35 +149,50 @@ static u32 fastBandVerdict(const u8* hCell, u32 epoch)
 // Device-resident single-band blobs: everything is enqueued before a single byte of the blob has been seen by the
 // host (the header is checked by k_fast_header); one synchronisation.  handled == false: nothing was decided,
 // the caller goes the long way (header read, general kernels, exact status codes).
-static u32 decodeSpeculative(Context& ctx, const DecodeRequest& rq, bool& handled)
+bool decodeEnqueueStreaming(Context& ctx, const DecodeRequest& rq, u8* slot, u32& epoch)
 {
-  handled = false;
   const int dt = rq.dt, nRows = rq.nRows, nCols = rq.nCols;
-  if (!rq.dBlob || rq.hBlob || rq.nBands != 1 || rq.nDepth != 1 || rq.blobSize < 70 || !rq.dOut) return kOk;
-  if (!fastDecodeEligible(dt, 6, 8, nRows, nCols, 1, true)) return kOk;
-  if (((uintptr_t)rq.dBlob & 15) || ((uintptr_t)rq.dOut & 15)) return kOk;
+  if (!slot || !rq.dBlob || rq.hBlob || rq.nBands != 1 || rq.nDepth != 1 || rq.blobSize < 70 || !rq.dOut) return false;
+  if (!fastDecodeEligible(dt, 6, 8, nRows, nCols, 1, true)) return false;
+  if (((uintptr_t)rq.dBlob & 15) || ((uintptr_t)rq.dOut & 15)) return false;
   hipStream_t st = ctx.activeStream();
-  if (!ctx.reserve(fastBandWorkspace(nRows, nCols, rq.blobSize) + 4096)) return kOk;
+  ctx.reset();
+  if (!ctx.reserve(fastBandWorkspace(nRows, nCols, rq.blobSize) + 4096)) return false;
   const size_t cellsBytes = 64 + kCellBytes;
+  static_assert(64 + kCellBytes <= Context::kAsyncSlotBytes, "a verdict fits a pinned slot");
   u8* dCells = ctx.allocT<u8>(cellsBytes);
-  if (!dCells) return kOk;
-  const u32 epoch = ctx.nextEpoch();
-  if (!launchFastBand(ctx, dt, nRows, nCols, rq.dBlob, rq.blobSize, rq.dOut, dCells + 64, epoch)) return kOk;
+  if (!dCells) return false;
+  epoch = ctx.nextEpoch();
+  if (!launchFastBand(ctx, dt, nRows, nCols, rq.dBlob, rq.blobSize, rq.dOut, dCells + 64, epoch)) return false;
   if (rq.nMasks > 0 && rq.dValidBytes) hipMemsetAsync(rq.dValidBytes, 1, (size_t)nRows * nCols, st);    // numValid == nPix or no verdict
-  u8* pin = (u8*)ctx.pinned(cellsBytes);
-  if (!pin) return kOk;
-  hipMemcpyAsync(pin, dCells, cellsBytes, hipMemcpyDeviceToHost, st);
-  if (!ctx.sync()) return kFailed;
+  return hipMemcpyAsync(slot, dCells, cellsBytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+}
+
+bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch)
+{
   if (ctx.profOn()) ctx.profCollect();
-  const u32 verdict = fastBandVerdict(pin + 64, epoch);
+  const u32 verdict = fastBandVerdict(slot + 64, epoch);
   if (verdict)
   {
     char msg[112];
     snprintf(msg, sizeof(msg), "streaming decode handed the blob to the general path (reason bits 0x%x)", verdict);
     ctx.lastNote = msg;
-    return kOk;
+    return false;
   }
-  handled = true;
+  return true;
+}
+
+// Device-resident single-band blobs: everything is enqueued before a single byte of the blob has been seen by the
+// host (the header is checked on the device); one synchronisation.  handled == false: nothing was decided,
+// the caller goes the long way (header read, general kernels, exact status codes).
+static u32 decodeSpeculative(Context& ctx, const DecodeRequest& rq, bool& handled)
+{
+  handled = false;
+  u8* pin = (u8*)ctx.pinned(64 + kCellBytes);
+  u32 epoch = 0;
+  if (!pin || !decodeEnqueueStreaming(ctx, rq, pin, epoch)) return kOk;
+  if (!ctx.sync()) return kFailed;
+  handled = decodeStreamingVerdict(ctx, pin, epoch);
   return kOk;
 }
 

@@ -763,6 +763,43 @@ static void runFastEncode(Context& ctx, const FastEncodeLaunch& fl, const void* 
   }
 }
 
+// single band requests the streaming kernels can take (the same test encodeDevice makes)
+static bool encodeStreamingOk(const EncodeRequest& rq)
+{
+  bool anyNoData = false;
+  if (rq.hUsesNoData) for (int i = 0; i < rq.nBands; i++) anyNoData = anyNoData || rq.hUsesNoData[i] != 0;
+  return !anyNoData && rq.version == kCodecVersion && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
+    && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, rq.nDepth, rq.nMasks > 0, rq.maxZErr);
+}
+
+bool encodeEnqueueStreaming(Context& ctx, const EncodeRequest& rq, u8* slot)
+{
+  if (!slot || rq.nBands != 1 || !encodeStreamingOk(rq)) return false;
+  ctx.reset();
+  if (!ctx.reserve(fastEncodeWorkspace(rq.nRows, rq.nCols, 1) + (1u << 16))) return false;
+  FastEncodeLaunch fl;
+  if (!prepareFastEncode(ctx, rq.dt, rq.nRows, rq.nCols, rq.maxZErr, 1, 0, false, fl)) return false;
+  runFastEncode(ctx, fl, rq.dData, rq.dOut, rq.dOut ? (u64)rq.outCapacity : ~0ull, 0);
+  return hipMemcpyAsync(slot, fl.fb.result, sizeof(FastEncodeResult), hipMemcpyDeviceToHost, ctx.activeStream()) == hipSuccess;
+}
+
+void encodeStreamingVerdict(Context& ctx, const EncodeRequest& rq, const u8* slot, bool& redo, u32& status, u32& numBytesNeeded, u32& numBytesWritten)
+{
+  FastEncodeResult hres;
+  memcpy(&hres, slot, sizeof(hres));
+  if (ctx.profOn()) ctx.profCollect();
+  redo = false; status = kOk;
+  if (!hres.redo)
+  {
+    ctx.pathCount[0]++;
+    numBytesNeeded = hres.blobSize;
+    numBytesWritten = rq.dOut ? hres.blobSize : 0;
+    return;
+  }
+  if (rq.dOut && hres.redoReason == 64u && hres.blobSize > rq.outCapacity) { status = kBufferTooSmall; return; }
+  redo = true;
+}
+
 u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32& numBytesWritten)
 {
   numBytesNeeded = numBytesWritten = 0;
@@ -837,24 +874,14 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   }
   else if (fastOk)
   {
-    hipStream_t st = ctx.activeStream();
-    FastEncodeLaunch fl;
-    if (!prepareFastEncode(ctx, rq.dt, rq.nRows, rq.nCols, rq.maxZErr, 1, 0, false, fl)) return kFailed;
-    runFastEncode(ctx, fl, rq.dData, rq.dOut, rq.dOut ? (u64)rq.outCapacity : ~0ull, 0);
     FastEncodeResult* pinRes = (FastEncodeResult*)ctx.pinned(sizeof(FastEncodeResult));
     if (!pinRes) return kFailed;
-    FastEncodeResult& hres = *pinRes;
-    hipMemcpyAsync(&hres, fl.fb.result, sizeof(hres), hipMemcpyDeviceToHost, st);
+    if (!encodeEnqueueStreaming(ctx, rq, reinterpret_cast<u8*>(pinRes))) return kFailed;
     if (!ctx.sync()) return kFailed;
-    if (ctx.profOn()) ctx.profCollect();
-    if (!hres.redo)
-    {
-      ctx.pathCount[0]++;
-      numBytesNeeded = hres.blobSize;
-      numBytesWritten = rq.dOut ? hres.blobSize : 0;
-      return kOk;
-    }
-    if (rq.dOut && hres.redoReason == 64u && hres.blobSize > rq.outCapacity) return kBufferTooSmall;
+    bool redo = false;
+    u32 status = kOk;
+    encodeStreamingVerdict(ctx, rq, reinterpret_cast<const u8*>(pinRes), redo, status, numBytesNeeded, numBytesWritten);
+    if (!redo) return status;
     ctx.reset();
   }
 

@@ -373,7 +373,25 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   const u32 c0 = blockIdx.x * NCH;                         // first chunk of this workgroup
   const u32 r0 = c0 * CH;                                  // blob offset of LDS byte 0
 
-  // ---- all loads in flight first: the workgroup's chunks (clipped to what the caller says is readable) ...
+  // ---- the band header first: a caller that only knows the capacity of the blob's buffer (a decode enqueued behind the
+  // encode that writes it) launches workgroups for all of it, and those behind the stream's end must not drag a third of a
+  // raster's worth of bytes through the chip before they find out
+  HeadLite hl;
+  if (blockIdx.x == 0)
+  {
+    const FastDecodeParams hp = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
+    if (threadIdx.x == 0) *b.params = hp;
+    hl.ok = hp.ok; hl.version = hp.version; hl.dataBegin = hp.dataBegin; hl.blobEnd = hp.blobEnd;
+  }
+  else hl = parseHeadLite<DT>(blob, sizeGiven);
+  const u32 nChunks = (hl.blobEnd + CH - 1) / CH;
+  if (!hl.ok || c0 >= nChunks) return;    // (the grid is sized for the largest stream the blob could hold)
+  const int version = (int)hl.version;
+  const bool v5 = version >= 5;
+  const u32 dataBegin = hl.dataBegin, blobEnd = hl.blobEnd;
+  const u32 pattern = v5 ? 14u : 15u;
+
+  // ---- the workgroup's chunks, all loads in flight at once (clipped to what the caller says is readable)
   constexpr int kRounds = (int)((kStageUnits + 255) / 256);
   uint4 x[kRounds];
 #pragma unroll
@@ -394,21 +412,6 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
       }
     }
   }
-  // ... and the band header
-  HeadLite hl;
-  if (blockIdx.x == 0)
-  {
-    const FastDecodeParams hp = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
-    if (threadIdx.x == 0) *b.params = hp;
-    hl.ok = hp.ok; hl.version = hp.version; hl.dataBegin = hp.dataBegin; hl.blobEnd = hp.blobEnd;
-  }
-  else hl = parseHeadLite<DT>(blob, sizeGiven);
-  const u32 nChunks = (hl.blobEnd + CH - 1) / CH;
-  if (!hl.ok || c0 >= nChunks) return;    // (the grid is sized for the largest stream the blob could hold)
-  const int version = (int)hl.version;
-  const bool v5 = version >= 5;
-  const u32 dataBegin = hl.dataBegin, blobEnd = hl.blobEnd;
-  const u32 pattern = v5 ? 14u : 15u;
 
   // ---- stage + Fletcher terms of the units this workgroup owns (bytes 14 ... blobEnd - 1 of the blob are checksummed)
   u32 fA = 0;

@@ -538,3 +538,73 @@ def test_sim_mask_bytes_of_an_all_valid_band(libs):
             rc, dec, mask = S.decode(blob, want_masks=want, n_bands=n_bands)
             assert rc == 0 and mask is not None and (mask == 1).all(), (shape, want)
             assert _same(dec, O.decode(blob)[1])
+
+
+def _async_lib(S):
+    import ctypes as ct
+    L = S.lib
+    L.lerc_amd_create.restype = ct.c_void_p
+    L.lerc_amd_create.argtypes = [ct.c_void_p]
+    L.lerc_amd_destroy.argtypes = [ct.c_void_p]
+    enc = [ct.c_void_p, ct.c_uint, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p, ct.c_double]
+    L.lerc_amd_encode_device_async.restype = ct.c_uint
+    L.lerc_amd_encode_device_async.argtypes = [ct.c_void_p] + enc + [ct.c_void_p, ct.c_uint, ct.POINTER(ct.c_uint)]
+    L.lerc_amd_decode_device_async.restype = ct.c_uint
+    L.lerc_amd_decode_device_async.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int,
+                                               ct.c_uint, ct.c_void_p, ct.POINTER(ct.c_uint)]
+    L.lerc_amd_finish.restype = ct.c_uint
+    L.lerc_amd_finish.argtypes = [ct.c_void_p, ct.c_uint, ct.POINTER(ct.c_uint)]
+    return L
+
+
+def test_sim_async_device_api(libs):
+    """lerc_amd_encode_device_async / decode_device_async / finish: operations queue up in order; a decode enqueued right
+    behind the encode that writes its blob gets the buffer's capacity as size bound; what the device hands back to the
+    general path (a constant raster) is repeated at finish time, and so is whatever was enqueued behind it."""
+    import ctypes as ct
+    O, S = libs
+    L = _async_lib(S)
+    h = L.lerc_amd_create(None)
+    assert h
+    rng = np.random.default_rng(8)
+    try:
+        rasters = [cases.terrain(32, 1024, rng, amp=300, base=1000, sigma=1.5).astype(np.float32),
+                   np.full((16, 512), 3.5, np.float32),                                  # constant: the device says "redo"
+                   cases._cast(cases.terrain(24, 200, rng, amp=300, base=1000, sigma=1.5), np.uint16),
+                   cases.terrain(33, 47, rng).astype(np.float32)]                        # no whole blocks: never a streaming request
+        errs = [0.01, 0.01, 0, 0.01]
+        keep, tickets = [], []
+        for arr, e in zip(rasters, errs):
+            src = _aligned(arr.nbytes).view(arr.dtype).reshape(arr.shape)
+            src[...] = arr
+            blob = _aligned(arr.nbytes + 4096)
+            out = _aligned(arr.nbytes).view(arr.dtype).reshape(arr.shape)
+            t1, t2 = ct.c_uint(0), ct.c_uint(0)
+            rc = L.lerc_amd_encode_device_async(h, src.ctypes.data, capi.dt_code(arr.dtype), 1, arr.shape[1], arr.shape[0], 1, 0, None, float(e),
+                                                blob.ctypes.data, blob.size, ct.byref(t1))
+            assert rc == 0 and t1.value
+            rc = L.lerc_amd_decode_device_async(h, blob.ctypes.data, blob.size, 0, None, 1, arr.shape[1], arr.shape[0], 1, capi.dt_code(arr.dtype),
+                                                out.ctypes.data, ct.byref(t2))
+            assert rc == 0 and t2.value
+            keep.append((src, blob, out))
+            tickets.append((t1.value, t2.value))
+        for (arr, e, (src, blob, out), (t1, t2)) in zip(rasters, errs, keep, tickets):
+            n = ct.c_uint(0)
+            assert L.lerc_amd_finish(h, t1, ct.byref(n)) == 0
+            r0, b0 = O.encode(arr, e)
+            assert r0 == 0 and blob[:n.value].tobytes() == b0
+            assert L.lerc_amd_finish(h, t2, ct.byref(n)) == 0
+            assert _same(O.decode(b0)[1].reshape(arr.shape), out)
+        assert L.lerc_amd_finish(h, tickets[0][0], None) == 2                            # handed out already
+        # more operations than result slots: the oldest are completed and dropped, the newest still answer
+        arr = rasters[0]
+        src, blob, out = keep[0]
+        last = ct.c_uint(0)
+        for _ in range(80):
+            assert L.lerc_amd_encode_device_async(h, src.ctypes.data, 6, 1, arr.shape[1], arr.shape[0], 1, 0, None, 0.01, blob.ctypes.data, blob.size,
+                                                  ct.byref(last)) == 0
+        n = ct.c_uint(0)
+        assert L.lerc_amd_finish(h, last.value, ct.byref(n)) == 0 and blob[:n.value].tobytes() == O.encode(arr, 0.01)[1]
+        assert L.lerc_amd_finish(h, 0, None) == 0
+    finally:
+        L.lerc_amd_destroy(h)
