@@ -80,8 +80,8 @@ static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven, u32 nTiles 
 {
   const FastWalkPlan wp = makeFastWalkPlan(nRows, nCols, sizeGiven);
   const size_t perTile = (size_t)wp.nChunks * (sizeof(FastChunkRec) + (size_t)kDiscWalks * kFastListCap * 2 + 12) + (size_t)wp.nBlocks * 4
-    + (size_t)wp.nWaves * 16 + (size_t)(wp.nChunks / kResolveWG + 2) * 4 + 4096;
-  return perTile * nTiles + (size_t)kGatherChunks * kDiscWalks * kFastListCap * 2 + (1u << 16);
+    + (size_t)wp.nWaves * 16 + (size_t)(wp.nChunks / kResolveWG + 2) * 4 + 4096 + kResolveWG * sizeof(FastChunkRec);
+  return perTile * nTiles + (size_t)kDecodeChunks * kDiscWalks * kFastListCap * 2 + (1u << 16);
 }
 
 // Enqueues header check, discovery and decode of nTiles blobs (one band: nTiles == 1, dTileOffset == nullptr);
@@ -97,20 +97,19 @@ static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8
   tb.nTiles = nTiles; tb.nChunks = fwp.nChunks; tb.nBlocks = fwp.nBlocks; tb.nWaves = fwp.nWaves;
   tb.tileElems = (u64)nRows * (u64)nCols; tb.tileOffset = dTileOffset; tb.tileSize = dTileSize;
   FastDecodeBuffers fbuf;
-  fbuf.recs = ctx.allocT<FastChunkRec>(nT * fwp.nChunks + 1);
-  fbuf.lists = ctx.allocT<u16>((nT * fwp.nChunks + kGatherChunks) * (size_t)(kDiscWalks * kFastListCap) + 8);    // (+ what the gather step's clamped loads may touch)
+  fbuf.recs = ctx.allocT<FastChunkRec>(nT * fwp.nChunks + kResolveWG);    // (+ what the resolve step's unconditional loads may touch)
+  fbuf.lists = ctx.allocT<u16>((nT * fwp.nChunks + kDecodeChunks) * (size_t)(kDiscWalks * kFastListCap) + 8);    // (+ what the gather step's clamped loads may touch)
   fbuf.chunkCount = ctx.allocT<u32>(nT * sChunk);
   fbuf.chunkLane = ctx.allocT<u32>(nT * sChunk);
   fbuf.chunkLocal = ctx.allocT<u32>(nT * sChunk);
   fbuf.groupSum = ctx.allocT<u32>(nT * ((fwp.nChunks + kResolveWG - 1) / kResolveWG + 1) + 4);
-  fbuf.blockOff = ctx.allocT<u32>(nT * ((size_t)fwp.nBlocks + 4));
   fbuf.waveFletcher = ctx.allocT<u64>(2 * nT * (size_t)fwp.nWaves + 4);
   fbuf.params = dParams;
   fbuf.fallback = dFallback;
   fbuf.epoch = epoch;
-  if (!fbuf.recs || !fbuf.lists || !fbuf.chunkCount || !fbuf.chunkLane || !fbuf.chunkLocal || !fbuf.groupSum || !fbuf.blockOff || !fbuf.waveFletcher)
+  if (!fbuf.recs || !fbuf.lists || !fbuf.chunkCount || !fbuf.chunkLane || !fbuf.chunkLocal || !fbuf.groupSum || !fbuf.waveFletcher)
     return false;
-  static const char* kStage[kFastDecodeStages] = { "fast_discover", "fast_resolve", "fast_gather_offsets", "fast_decode" };
+  static const char* kStage[kFastDecodeStages] = { "fast_discover", "fast_resolve", "fast_decode" };
   for (int stage = 0; stage < kFastDecodeStages; stage++)
   {
     ProfScope ps(ctx, kStage[stage]);

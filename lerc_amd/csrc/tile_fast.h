@@ -133,14 +133,14 @@ LERC_HD u32 fastNumWG(int nRows, int nCols) { return (u32)(((u64)(nRows / 8) * (
 //                    until they land on a header found in the next chunk's window
 //   k_fast_resolve   entry of chunk c = the exit all surviving walks of chunk c - 1 agree on; the walk that starts
 //                    there is the true path: its block count, scanned, is the index of the chunk's first block
-//   k_fast_gather    copies the true walks' lists into blockOff[]
-//   k_fast_decode    a workgroup decodes 64 consecutive blocks and checks that they tile their span exactly
+//   k_fast_decode    a workgroup decodes the blocks that start in kDecodeChunks chunks, from the true walks' lists, and checks
+//                    that they tile the stream exactly
 static const u32 kFastChunkBytes = 2048;
 static const int kDiscWalks = 8;           // walks per chunk (path heads among the filter's survivors; more: general path)
 static const int kDiscChunks = 16;         // chunks per workgroup of k_fast_discover (four per wave while candidates are filtered)
 static const int kFastListCap = 128;       // block starts a walk can list per chunk (more, i.e. blocks of < 16 bytes on average: general path)
 static const u32 kResolveWG = 256;         // chunks per workgroup of k_fast_resolve
-static const u32 kGatherChunks = 16;       // chunks per workgroup of k_fast_gather (divides kResolveWG)
+static const u32 kDecodeChunks = 4;        // chunks whose blocks a workgroup of k_fast_decode decodes (divides kResolveWG)
 // longest block the streaming walk accepts: the raw form (the reference encoder never emits a longer one)
 constexpr u32 kFastWindow(int typeBytes) { return 2u + 64u * (u32)typeBytes; }
 
@@ -180,7 +180,6 @@ struct FastDecodeBuffers
   u32* chunkLane;      // [nChunks] the walk that is the true path
   u32* chunkLocal;     // [nChunks] exclusive scan of chunkCount inside a resolve workgroup
   u32* groupSum;       // [ceil(nChunks / kResolveWG)] blocks per resolve workgroup
-  u32* blockOff;       // [nBlocks + 1]
   u64* waveFletcher;   // [2 * nWaves] Fletcher partial sums (mod 65535) of the bytes each discovery workgroup staged
   FastDecodeParams* params;   // [nTiles]
   u32* fallback;       // [4 * nTiles] epoch tagged, see above
@@ -201,7 +200,7 @@ LERC_HD u32 fastChunkStride(u32 nChunks) { return nChunks + 4u; }    // elements
 
 bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid);
 FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven);
-static const int kFastDecodeStages = 4;    // one kernel each: discover (+ header + checksum terms), resolve, gather, decode
+static const int kFastDecodeStages = 3;    // one kernel each: discover (+ header + checksum terms), resolve, decode
 void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
                       const FastDecodeBuffers& b, void* out, hipStream_t st);
 

@@ -17,7 +17,6 @@
 //                      entry of chunk c = agreed exit of chunk c-1; the walk that starts exactly there (or passes
 //                      it with one of its first blocks) is the true path and its length the chunk's block count.
 //                      Also folds the checksum terms.
-//   k_fast_gather      block offsets = the true walks' lists, placed by a scan of the counts.
 //   k_fast_decode      a workgroup owns 64 consecutive blocks (8 rows x 512 columns where a block row is that
 //                      long): it stages their byte span in LDS, parses the 64 block headers once (lane = block;
 //                      signature and contiguity checks = ReadTile's integrity checks), then every lane extracts V
@@ -540,14 +539,18 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     if (len == 0u || (!follows && cur + len < blobEnd)) atomicAnd(&s_heads[hWin][hPos >> 5], ~(1u << (hPos & 31u)));
   }
   __syncthreads();
+  // (walk slots in the order of the heads' positions: the path's head is nearly always the first one, so that the decode
+  // kernel can fetch "walk 0 of the chunk" before it has been told which walk it is)
   for (u32 h = threadIdx.x; h < nHit; h += 256u)
   {
     const u32 e = s_hit[h];
     const u32 hWin = e >> 11, hPos = e & 0x7FFu;
     if ((s_heads[hWin][hPos >> 5] >> (hPos & 31u)) & 1u)
     {
-      const u32 at = atomicAdd(&s_nFinal[hWin], 1u);
+      u32 at = (u32)__popc(s_heads[hWin][hPos >> 5] & ((1u << (hPos & 31u)) - 1u));
+      for (u32 k = 0; k < (hPos >> 5); k++) at += (u32)__popc(s_heads[hWin][k]);
       if (at < NW) s_final[hWin][at] = (u16)hPos; else s_over = 1u;
+      atomicAdd(&s_nFinal[hWin], 1u);
     }
   }
   PROBE(19);
@@ -650,16 +653,19 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
   __shared__ u32 s_w[kResolveWG / 64];
   __shared__ u64 s_a[kResolveWG / 64], s_b[kResolveWG / 64];
   const FastDecodeParams hp = *b.params;
-  if (!hp.ok) return;
   const u32 blobEnd = hp.blobEnd;
   const u32 c = blockIdx.x * kResolveWG + threadIdx.x;
+  // (the records first: their addresses do not hang on the header)
+  const u32 cPrev = c ? c - 1u : 0u;
+  const u32 prevExit = b.recs[cPrev].exit;
+  if (!hp.ok) return;
   const int lane = laneId(), w = waveId();
   u32 count = 0, laneOfPath = kNoOffset;
   bool bad = false;
   if (c < hp.nChunks)
   {
     const u32 chunkStart = c * kFastChunkBytes, chunkEnd = min(chunkStart + kFastChunkBytes, blobEnd);
-    const u32 e = (chunkStart <= hp.dataBegin) ? hp.dataBegin : b.recs[c - 1].exit;
+    const u32 e = (chunkStart <= hp.dataBegin) ? hp.dataBegin : prevExit;
     if (e == kNoOffset || e < chunkStart) bad = true;
     else if (e >= chunkEnd) bad = (e != blobEnd);    // the last block may begin before the last chunk and end with it
     else
@@ -716,59 +722,6 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
 }
 
 // ------------------------------------------------------------------------------------------------
-// block offsets
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fastGatherBody(const FastDecodeBuffers& b)
-{
-  constexpr u32 kPerPass = 256u / (u32)kFastListCap;      // chunks whose lists the 256 threads copy at once
-  static_assert(256 % kFastListCap == 0 && kGatherChunks % kPerPass == 0, "threads per list entry");
-  __shared__ u32 s_part[4], s_n[kGatherChunks], s_loc[kGatherChunks], s_lane[kGatherChunks];
-  const FastDecodeParams hp = *b.params;
-  if (!hp.ok) return;
-  const u32 cFirst = blockIdx.x * kGatherChunks;
-  if (cFirst >= hp.nChunks) return;          // the grid is sized for the largest stream the blob could hold
-  const int lane = laneId(), w = waveId();
-  if (threadIdx.x < kGatherChunks)
-  {
-    const u32 c = cFirst + threadIdx.x;
-    const bool have = c < hp.nChunks;
-    s_n[threadIdx.x] = have ? b.chunkCount[c] : 0u;
-    s_loc[threadIdx.x] = have ? b.chunkLocal[c] : 0u;
-    s_lane[threadIdx.x] = have ? b.chunkLane[c] : 0u;
-  }
-  // blocks before this workgroup's resolve group
-  const u32 grp = cFirst / kResolveWG;
-  u32 sum = 0;
-  for (u32 i = threadIdx.x; i < grp; i += 256u) sum += b.groupSum[i];
-  sum = waveSum(sum);
-  if (lane == 0) s_part[w] = sum;
-  __syncthreads();
-  const u32 before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-  if (cFirst + kGatherChunks >= hp.nChunks && threadIdx.x == 0)
-  {
-    // the workgroup that holds the last chunk: sentinel + total
-    const u32 last = hp.nChunks - 1u - cFirst;
-    const u32 total = before + s_loc[last] + s_n[last];
-    b.blockOff[hp.nBlocks] = hp.blobEnd;     // end of the last block
-    if (total != hp.nBlocks) b.fallback[2] = b.epoch;
-  }
-  if (fastRaised(b.fallback, b.epoch)) return;    // raised by an earlier kernel: nothing below can be trusted
-  const u32 i = threadIdx.x % (u32)kFastListCap, sub = threadIdx.x / (u32)kFastListCap;    // entry of a chunk's list
-  bool bad = false;
-#pragma unroll
-  for (u32 k0 = 0; k0 < kGatherChunks; k0 += kPerPass)
-  {
-    const u32 k = k0 + sub;
-    const u32 c = cFirst + k, ls = s_lane[k];      // walk | index of the chunk's first block in its list << 8
-    const u32 src = min((ls >> 8) + i, (u32)kFastListCap - 1u);
-    const u32 v = b.lists[((size_t)c * kDiscWalks + (ls & 7u)) * kFastListCap + src];    // (chunks behind the last one: inside the buffer's slack)
-    const u32 at = before + s_loc[k] + i;
-    if (i < s_n[k]) { if (at < hp.nBlocks) b.blockOff[at] = c * kFastChunkBytes + v; else bad = true; }
-  }
-  if (__any(bad) && lane == 0) b.fallback[2] = b.epoch;
-}
-
-// ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
 template<class T> struct DCfg
@@ -800,73 +753,149 @@ template<class T> __device__ __forceinline__ T dequant(double offset, u32 q, dou
   return (T)(z < zMaxI ? z : zMaxI);
 }
 
-template<class T, bool WIDE>
+// A workgroup decodes the blocks that start in kDecodeChunks consecutive chunks: their bytes lie in a range known
+// beforehand (the chunks, plus the blocks a walk passed behind its chunk before it landed), so the bytes, the chunks'
+// counts and -- as soon as it is known which walk of a chunk is the path -- the walks' lists travel together; block i
+// of chunk c is block base(c) + i of the raster (base: the scan the resolve step left in pieces).
+template<class T>
 __device__ __forceinline__ void
-fastDecodeBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ blob, const u32* __restrict__ blockOff,
-              T* __restrict__ outPix, u32* __restrict__ fallback, u32 epoch)
+fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __restrict__ outPix)
 {
-  const FastDecodeParams hp = *P;
-  if (!hp.ok) return;
-  const u32 blobEnd = hp.blobEnd;
-  const struct { int nCols, version; double invScale, zMaxHdr; } p = { (int)hp.nCols, (int)hp.version, hp.invScale, hp.zMaxHdr };
+  const FastDecodeParams hp = *b.params;
+  const u32 raised0 = b.fallback[0], raised1 = b.fallback[1];    // (read together with the parameters: one round trip, not three)
   typedef DCfg<T> C;
-  constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW, IT = C::IT;
+  constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
   constexpr int DT = DtOf<T>::v;
-  constexpr int kSpanWords = (kFastBlocksPerWG * (1 + 64 * (int)sizeof(T)) + 32) / 4 + 8;
-  __shared__ __align__(16) u32 s_in[kSpanWords];
-  __shared__ u32 s_off[kFastBlocksPerWG + 1];
-  __shared__ u32 s_code[kFastBlocksPerWG];     // parseCode of the block, 0 = bad
-  __shared__ double s_offs[kFastBlocksPerWG];
-  if (fallback[0] == epoch || fallback[1] == epoch || fallback[2] == epoch) return;    // raised by an earlier kernel
-
+  constexpr u32 CH = kFastChunkBytes, CPD = kDecodeChunks, CAP = (u32)kFastListCap;
+  constexpr u32 TB = (u32)sizeof(T), RAW = 1 + 64 * TB, W = kFastWindow((int)sizeof(T));
+  constexpr u32 kStageUnits = (CPD * CH + W + RAW + 16 + 15) / 16;
+  constexpr u32 kMaxBlocks = CPD * CAP;
+  __shared__ __align__(16) u32 s_in[kStageUnits * 4];
+  __shared__ u16 s_pos[kMaxBlocks + 1];          // block starts relative to the workgroup's first byte
+  __shared__ u32 s_code[kMaxBlocks];             // parseCode of the block, 0 = bad
+  __shared__ u32 s_at[kMaxBlocks];               // raster offset (pixels) of the block's first pixel, ~0: no such block
+  __shared__ double s_offs[kMaxBlocks];
+  __shared__ u32 s_n[CPD + 1], s_first[CPD], s_lane[CPD], s_part[4], s_bad;
+  __shared__ __align__(16) u16 s_spec[CPD][CAP];   // the list of each chunk's walk 0, fetched before anybody knows which walk is the path
+  const u32 blobEnd = hp.blobEnd, epoch = b.epoch;
+  const struct { int nCols, version; double invScale, zMaxHdr; } p = { (int)hp.nCols, (int)hp.version, hp.invScale, hp.zMaxHdr };
   PROBE_BEGIN;
   const int w = waveId(), lane = laneId();
-  const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
-  const FastSpan span = fastSpanOf(blockIdx.x, hp.nTH, hp.nRows / 8u);
-  const u32 firstBlk = blockIdx.x * kFastBlocksPerWG;
+  const u32 c0 = blockIdx.x * CPD;
+  // not ours, given up by an earlier kernel, or behind the stream's end (the grid is sized for the largest stream the blob could hold)
+  if (!hp.ok || raised0 == epoch || raised1 == epoch || c0 >= hp.nChunks) return;
+  const u32 r0 = c0 * CH;
 
-  if (threadIdx.x <= kFastBlocksPerWG) s_off[threadIdx.x] = blockOff[min(firstBlk + threadIdx.x, hp.nBlocks)];    // [nBlocks] = end of the stream
-  __syncthreads();
-  const u32 g0 = s_off[0], g1 = s_off[kFastBlocksPerWG];
-  const u32 spanLen = g1 - g0;
-  if (g1 < g0 || spanLen > (u32)(kFastBlocksPerWG * (1 + 64 * (int)sizeof(T))) || g1 > blobEnd)
+  // ---- everything whose address is known goes out at once: the bytes ...
+  constexpr int kRounds = (int)((kStageUnits + 255) / 256);
+  uint4 x[kRounds];
+#pragma unroll
+  for (int k = 0; k < kRounds; k++)
   {
-    if (threadIdx.x == 0) fallback[3] = epoch;
-    return;
-  }
-  PROBE(8);
-  // ---- stage the span (16-byte loads from the aligned-down start; the checksum was taken care of by the discovery waves)
-  const u32 a0 = g0 & ~15u;
-  const u32 shift = g0 - a0;
-  const u32 nChunks = (shift + spanLen + 15) >> 4;
-  for (u32 ch = threadIdx.x; ch < nChunks; ch += 256)
-  {
-    uint4 x;
-    if (a0 + ch * 16 + 16 <= blobEnd) x = *reinterpret_cast<const uint4*>(blob + a0 + ch * 16);
-    else
+    const u32 i = (u32)k * 256u + threadIdx.x;
+    const u64 a = (u64)r0 + 16ull * i;
+    x[k] = make_uint4(0, 0, 0, 0);
+    if (i < kStageUnits)
     {
-      u32 t4[4] = { 0, 0, 0, 0 };
-      for (u32 k = 0; a0 + ch * 16 + k < blobEnd; k++) t4[k >> 2] |= (u32)blob[a0 + ch * 16 + k] << (8 * (k & 3));    // never read past the blob
-      x = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+      if (a + 16 <= blobEnd) x[k] = *reinterpret_cast<const uint4*>(blob + a);
+      else if (a < blobEnd)    // never read past the blob
+      {
+        u32 t4[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (u32 q = 0; q < 16; q++) if (a + q < blobEnd) t4[q >> 2] |= (u32)blob[a + q] << (8 * (q & 3));
+        x[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+      }
     }
-    *reinterpret_cast<uint4*>(&s_in[ch * 4]) = x;
+  }
+  // ... walk 0's lists ...
+  static_assert(CPD * CAP * 2 / 16 <= 256, "one 16-byte load per thread");
+  if (threadIdx.x < CPD * CAP / 8)
+  {
+    const u32 q = threadIdx.x / (CAP / 8), part = threadIdx.x % (CAP / 8);
+    const uint4 l = *reinterpret_cast<const uint4*>(b.lists + ((size_t)(c0 + q) * kDiscWalks) * kFastListCap + 8u * part);    // (chunks behind the last one: the buffer's slack)
+    *reinterpret_cast<uint4*>(&s_spec[q][8u * part]) = l;
+  }
+  // ... the chunks' counts, and the blocks in front of this workgroup's resolve group
+  if (threadIdx.x < CPD)
+  {
+    const u32 c = c0 + threadIdx.x;
+    const bool have = c < hp.nChunks;
+    s_n[threadIdx.x] = have ? b.chunkCount[c] : 0u;
+    s_first[threadIdx.x] = have ? b.chunkLocal[c] : 0u;
+    s_lane[threadIdx.x] = have ? b.chunkLane[c] : 0u;
+  }
+  if (threadIdx.x == 0) s_bad = 0u;
+  const u32 grp = c0 / kResolveWG;
+  u32 sum = 0;
+  for (u32 i = threadIdx.x; i < grp; i += 256u) sum += b.groupSum[i];
+  if (blockIdx.x == 0)    // (one workgroup checks that the chunks hold all the raster's blocks)
+  {
+    u32 all = 0;
+    const u32 nGroups = (hp.nChunks + kResolveWG - 1) / kResolveWG;
+    for (u32 i = threadIdx.x; i < nGroups; i += 256u) all += b.groupSum[i];
+    all = waveSum(all);
+    if (lane == 0) s_part[w] = all;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_part[0] + s_part[1] + s_part[2] + s_part[3] != hp.nBlocks) b.fallback[2] = epoch;
+    __syncthreads();
+  }
+  sum = waveSum(sum);
+  if (lane == 0) s_part[w] = sum;
+  __syncthreads();
+  const u32 before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  PROBE(8);
+  // ---- the lists of the walks that are the path: flat index f = blocks of chunk 0, then of chunk 1, ...
+  u32 nAll = 0, cum[CPD + 1];
+#pragma unroll
+  for (u32 q = 0; q < CPD; q++) { cum[q] = nAll; nAll += min(s_n[q], CAP); }
+  cum[CPD] = nAll;
+  for (u32 f = threadIdx.x; f < nAll; f += 256u)
+  {
+    u32 q = 0;
+#pragma unroll
+    for (u32 k = 1; k < CPD; k++) q += (f >= cum[k]) ? 1u : 0u;
+    const u32 i = f - cum[q], ls = s_lane[q];      // walk | index of the chunk's first block in its list << 8
+    const u32 src = min((ls >> 8) + i, CAP - 1u);
+    const u32 v = (ls & 7u) == 0u ? (u32)s_spec[q][src] : (u32)b.lists[((size_t)(c0 + q) * kDiscWalks + (ls & 7u)) * kFastListCap + src];
+    s_pos[f] = (u16)(q * CH + v);
+  }
+  // (the end of the last block: the next chunk's entry, which is the exit its walks agreed on)
+  if (threadIdx.x == 0 && nAll)
+  {
+    u32 last = CPD - 1;
+    while (last > 0 && s_n[last] == 0u) last--;    // (a last chunk in which no block starts has no walks and no exit)
+    const u32 ex = b.recs[c0 + last].exit;
+    s_pos[nAll] = (u16)min(ex - min(ex, r0), 0xFFFFu);
+  }
+  // ---- stage the bytes
+#pragma unroll
+  for (int k = 0; k < kRounds; k++)
+  {
+    const u32 i = (u32)k * 256u + threadIdx.x;
+    if (i < kStageUnits) *reinterpret_cast<uint4*>(&s_in[i * 4]) = x[k];
   }
   __syncthreads();
   PROBE(9);
 
-  // ---- parse the 64 block headers once: lane = block
+  // ---- parse the block headers once: lane = block
   const u32 pattern = (p.version >= 5) ? 14u : 15u;
-  if (w == (int)((blockIdx.x * 2654435761u) >> 30))    // rotates over the waves (= SIMDs) from workgroup to workgroup
+  constexpr u32 kMaxRel = kStageUnits * 16 - 16;
+  const bool pow2 = (hp.nTH & (hp.nTH - 1u)) == 0u;
+  const u32 thShift = 31u - (u32)__clz((int)hp.nTH);
+  for (u32 f = threadIdx.x; f < nAll; f += 256u)
   {
-    const u32 off = s_off[lane];
-    const u32 jt = fastSpanCol(span, (u32)lane);
+    u32 q = 0;
+#pragma unroll
+    for (u32 k = 1; k < CPD; k++) q += (f >= cum[k]) ? 1u : 0u;
+    const u32 blk = before + s_first[q] + (f - cum[q]);          // index of the block in the raster
+    const u32 off = min((u32)s_pos[f], kMaxRel);
     u32 h0, h1, h2;
-    ldsHeader<DT>(s_in, off - a0, h0, h1, h2);
+    ldsHeader<DT>(s_in, off, h0, h1, h2);
     u32 code = parseCode<DT>(h0, h1, h2, p.version);
-    const bool exists = fastSpanHas(span, (u32)lane);    // (the last workgroup may hold fewer than 64 blocks)
-    if (off + codeLen(code) != s_off[lane + 1]) code = 0;
-    if (((h0 >> 2) & pattern) != (jt & pattern)) code = 0;    // signature = (j0 >> 3) & pattern, j0 = 8 jt
-    if (!exists) code = 0;
+    const u32 it = pow2 ? (blk >> thShift) : blk / hp.nTH, jt = blk - it * hp.nTH;
+    if ((u32)s_pos[f] + codeLen(code) != (u32)s_pos[f + 1]) code = 0;      // the blocks tile the stream
+    if (((h0 >> 2) & pattern) != (jt & pattern)) code = 0;                // signature = (j0 >> 3) & pattern, j0 = 8 jt
+    if (blk >= hp.nBlocks) code = 0;
     double offset = 0;
     const u32 mode = codeMode(code);
     if (code && (mode == 1 || mode == 3))
@@ -877,29 +906,73 @@ fastDecodeBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ bl
       if (offB < 8) bits &= (1ull << (8 * offB)) - 1;
       offset = typedFromBits(bits, typeUsed(DT, (int)((h0 >> 6) & 3u)));
     }
-    s_offs[lane] = offset;
-    s_code[lane] = code;
-    if (__any(code == 0u && exists) && lane == 0) fallback[3] = epoch;
+    // bit 30: not even the largest value nb bits can hold reaches the header's zMax, so the pixels need no clamp
+    // (the dequantiser is monotone in q)
+    if (code && mode == 1)
+    {
+      const u32 qTop = codeBits(code) >= 32u ? 0xFFFFFFFFu : ((1u << codeBits(code)) - 1u);
+      const bool below = (DT >= DT_Float) ? (offset + (double)qTop * p.invScale < p.zMaxHdr)
+                                          : ((i64)offset + (i64)qTop * (i64)p.invScale < (i64)p.zMaxHdr);
+      if (below) code |= 1u << 30;
+    }
+    s_offs[f] = offset;
+    s_code[f] = code;
+    s_at[f] = code ? (it * 8u) * (u32)p.nCols + jt * 8u : kNoOffset;
+    if (code == 0u) s_bad = 1u;
   }
   __syncthreads();
   PROBE(10);
 
+  // ---- pixels: a wave takes BPW blocks at a time, a lane V consecutive pixels of one raster row of one block
+  const int r = lane >> 3, c = lane & 7, bb = c / LPR, h = c % LPR;
   const i64 invI = (i64)p.invScale, zMaxI = (i64)p.zMaxHdr;
   bool bad = false;
-#pragma unroll
-  for (int t = 0; t < IT; t++)
+  // (wave tiles lie on multiples of BPW blocks of the RASTER, not of this workgroup's first block: a tile row is then a
+  // whole 128-byte line of the output, written by one instruction; only the first and last tile may be partial)
+  const u32 blk0 = before + s_first[0];            // the workgroup's blocks are blk0 ... blk0 + nAll - 1
+  const u32 g1 = (blk0 + nAll + BPW - 1) / BPW;
+  for (u32 g = blk0 / BPW + (u32)w; g < g1; g += 4u)
   {
-    const int tile = t * 4 + w;
-    const int blk = tile * BPW + b;
-    const u32 code = s_code[blk];
-    const double offset = s_offs[blk];
+    const u32 blk = g * BPW + (u32)bb;
+    const u32 f = blk - blk0;                      // (wraps for the blocks in front of the workgroup's first one)
+    const bool have = blk >= blk0 && f < nAll;
+    const u32 code = have ? s_code[f] : 0u;
+    const double offset = have ? s_offs[f] : 0.0;
+    const u32 at0 = have ? s_at[f] : kNoOffset;
     const u32 mode = codeMode(code), lut = codeLut(code), offB = codeOffBytes(code);
-    const u32 pbit = 8u * (s_off[blk] - a0 + ((mode == 1u) ? 3u + offB + lut : 1u));    // payload / first raw value
+    const u32 pbit = 8u * ((have ? (u32)s_pos[f] : 0u) + ((mode == 1u) ? 3u + offB + lut : 1u));    // payload / first raw value
     const int e0 = r * 8 + h * V;
     T v[V];
 #pragma unroll
     for (int k = 0; k < V; k++) v[k] = T(0);
-    if (code)
+    // the common case, all blocks of the wave alike: bit-stuffed without a table, the lane's V values inside 64 bits, no
+    // clamp -- three words of the stream, one funnel shift each way, V shifts
+    const bool plain = mode == 1u && !lut && (code >> 30) != 0u && (u32)V * codeBits(code) <= 64u;
+    if (__all(plain || !code))
+    {
+      if (code)
+      {
+        const u32 nb = codeBits(code);
+        const u32 bit0 = pbit + (u32)e0 * nb, wi = bit0 >> 5;
+        const u32 x0 = s_in[wi], x1 = s_in[wi + 1], x2 = s_in[wi + 2];
+        const u64 all = ((u64)__builtin_amdgcn_alignbit(x2, x1, bit0) << 32) | __builtin_amdgcn_alignbit(x1, x0, bit0);
+        const u32 mask = nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+        const i64 offI = (i64)offset;
+#pragma unroll
+        for (int k = 0; k < V; k++)
+        {
+          const u32 q = (u32)(all >> ((u32)k * nb)) & mask;
+          if (DT >= DT_Float) v[k] = (T)(offset + (double)q * p.invScale);    // Lerc2.cpp:2159-2160, no contraction
+          else v[k] = (T)(offI + (i64)q * invI);
+        }
+        struct alignas(sizeof(T) * V) Vec { T e[V]; };
+        Vec o;
+#pragma unroll
+        for (int k = 0; k < V; k++) o.e[k] = v[k];
+        *reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)) = o;
+      }
+    }
+    else if (code)
     {
       if (mode == 0)
       {
@@ -943,18 +1016,15 @@ fastDecodeBody(const FastDecodeParams* __restrict__ P, const u8* __restrict__ bl
           }
         }
       }
-    }
-    struct alignas(sizeof(T) * V) Vec { T e[V]; };
-    Vec o;
+      struct alignas(sizeof(T) * V) Vec { T e[V]; };
+      Vec o;
 #pragma unroll
-    for (int k = 0; k < V; k++) o.e[k] = v[k];
-    i64 at;
-    if (WIDE) at = (i64)(span.it0 * 8u + (u32)r) * p.nCols + (i64)span.jt0 * 8 + tile * (BPW * 8) + c * V;    // one block row: constant stride
-    else { const u32 j = (u32)blk; at = (i64)(fastSpanRow(span, j) * 8u + (u32)r) * p.nCols + (i64)fastSpanCol(span, j) * 8 + h * V; }
-    if (fastSpanHas(span, (u32)blk)) *reinterpret_cast<Vec*>(outPix + at) = o;
+      for (int k = 0; k < V; k++) o.e[k] = v[k];
+      *reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)) = o;
+    }
   }
   PROBE(11);
-  if (__any(bad) && lane == 0) fallback[3] = epoch;
+  if ((__any(bad) && lane == 0) || (threadIdx.x == 0 && s_bad)) b.fallback[3] = epoch;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -987,7 +1057,7 @@ __device__ __forceinline__ void tileSlice(FastDecodeBuffers& b, const FastDecode
   b.recs += tile * t.nChunks; b.lists += tile * t.nChunks * (size_t)(kDiscWalks * kFastListCap);
   b.chunkCount += tile * sChunk; b.chunkLane += tile * sChunk; b.chunkLocal += tile * sChunk;
   b.groupSum += tile * ((t.nChunks + kResolveWG - 1) / kResolveWG + 1);
-  b.blockOff += tile * ((size_t)t.nBlocks + 4); b.waveFletcher += tile * 2 * (size_t)t.nWaves;
+  b.waveFletcher += tile * 2 * (size_t)t.nWaves;
   if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
 }
 
@@ -1005,20 +1075,13 @@ __global__ void __launch_bounds__(kResolveWG) k_fast_resolve(FastDecodeBuffers b
   tileSlice(b, t, blob, sizeGiven);
   fastResolveBody(b, t.nWaves);
 }
-__global__ void __launch_bounds__(256) k_fast_gather(FastDecodeBuffers b, FastDecodeBatch t)
-{
-  const u8* blob = nullptr;
-  u32 sizeGiven = 0;
-  tileSlice(b, t, blob, sizeGiven);
-  fastGatherBody(b);
-}
-template<class T, bool WIDE>
+template<class T>
 __global__ void __launch_bounds__(256)
 k_fast_decode(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, T* __restrict__ outPix)
 {
   u32 sizeGiven = 0;
   tileSlice(b, t, blob, sizeGiven);
-  fastDecodeBody<T, WIDE>(b.params, blob, b.blockOff, outPix + (size_t)blockIdx.y * t.tileElems, b.fallback, b.epoch);
+  fastDecodeBody<T>(b, blob, outPix + (size_t)blockIdx.y * t.tileElems);
 }
 
 template<class T>
@@ -1035,14 +1098,8 @@ static void launchFastDecodeT(int stage, int nRows, int nCols, const FastDecodeB
     case 1:
       hipLaunchKernelGGL(k_fast_resolve, dim3((t.nChunks + kResolveWG - 1) / kResolveWG, nT), dim3(kResolveWG), 0, st, b, t);
       break;
-    case 2:
-      hipLaunchKernelGGL(k_fast_gather, dim3((t.nChunks + kGatherChunks - 1) / kGatherChunks, nT), dim3(256), 0, st, b, t);
-      break;
     default:
-      if ((nCols / 8) % 64 == 0)
-        hipLaunchKernelGGL((k_fast_decode<T, true>), dim3((t.nBlocks + kFastBlocksPerWG - 1) / kFastBlocksPerWG, nT), dim3(256), 0, st, b, t, blob, (T*)out);
-      else
-        hipLaunchKernelGGL((k_fast_decode<T, false>), dim3((t.nBlocks + kFastBlocksPerWG - 1) / kFastBlocksPerWG, nT), dim3(256), 0, st, b, t, blob, (T*)out);
+      hipLaunchKernelGGL((k_fast_decode<T>), dim3((t.nChunks + kDecodeChunks - 1) / kDecodeChunks, nT), dim3(256), 0, st, b, t, blob, (T*)out);
       break;
   }
 }
