@@ -695,9 +695,8 @@ struct FastEncodeLaunch
 static size_t fastEncodeWorkspace(int nRows, int nCols, u32 nTiles)
 {
   const size_t nWG = fastEncodeNumWG(nRows, nCols);
-  const size_t nRaise = ((size_t)(nCols / 8) + 63) / 64;
-  return (size_t)nTiles * (nWG * (kFastBlocksPerWG * sizeof(FastBlockDesc) + 64) + nRaise * 9 * 8 + kFastPrefixStage + sizeof(FastEncodeResult)
-                           + (fastScanGroups((u32)nWG) + 1) * 28 + fastPackGroups((u32)nWG) * 16 + fastTicketStride((u32)nWG) * 4 + 256)
+  return (size_t)nTiles * (nWG * (kFastBlocksPerWG * sizeof(FastBlockDesc) + 64) + kFastPrefixStage + sizeof(FastEncodeResult)
+                           + (fastScanGroups((u32)nWG) + 1) * (4 + 8 * kScanPartWords) + fastPackGroups((u32)nWG) * 16 + fastTicketStride((u32)nWG) * 4 + 256)
     + 65536;
 }
 
@@ -709,7 +708,6 @@ static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double
   const size_t nT = nTiles;
   FastEncodeBuffers& fb = fl.fb;
   fl.batch.nTiles = nTiles; fl.batch.nWG = nWG; fl.batch.tileElems = tileElems; fl.batch.nBlobsMore = 0;
-  fl.batch.nRaiseSets = ((u32)(nCols / 8) + 63u) / 64u;    // workgroups that hold blocks of the first block row
   fb.desc = ctx.allocT<FastBlockDesc>(nT * nWG * kFastBlocksPerWG);
   fb.wgSize = ctx.allocT<u32>(nT * fastWgStride(nWG) + 4);
   fb.wgBase = ctx.allocT<u32>(nT * fastWgStride(nWG) + 4);
@@ -717,24 +715,21 @@ static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double
   fb.wgMaxKey = ctx.allocT<u64>(nT * nWG + 4);
   fb.wgFlags = ctx.allocT<u32>(nT * nWG + 4);
   fb.groupBase = ctx.allocT<u32>(nT * (fastScanGroups(nWG) + 1) + 4);
-  fb.scanPart = ctx.allocT<u64>(3 * nT * fastScanGroups(nWG) + 4);
+  fb.scanPart = ctx.allocT<u64>(kScanPartWords * nT * fastScanGroups(nWG) + 4);
   fb.packPart = ctx.allocT<u64>(nT * fastPackGroups(nWG) + 4);
   fb.tickets = ctx.allocT<u32>(nT * fastTicketStride(nWG) + 4);
   fb.result = ctx.allocT<FastEncodeResult>(nT);
   fb.prefixStage = ctx.allocT<u8>(nT * kFastPrefixStage);
   fb.tileOffset = arena ? ctx.allocT<u64>(nT + 1) : nullptr;
-  double* dRow0Raise = ctx.allocT<double>(nT * fl.batch.nRaiseSets * 9);
   if (!fb.desc || !fb.wgSize || !fb.wgBase || !fb.wgMinKey || !fb.wgMaxKey || !fb.wgFlags || !fb.result
     || !fb.groupBase || !fb.scanPart || !fb.packPart || !fb.tickets
-    || !fb.prefixStage || (arena && !fb.tileOffset) || !dRow0Raise)
+    || !fb.prefixStage || (arena && !fb.tileOffset))
     return false;
   fl.cand = 0;
-  fb.row0RaiseErr = nullptr;
   if (isFlt)
   {
     static const double errCand[9] = { 1, 0.5, 0.1, 0.05, 0.01, 0.005, 0.001, 0.0005, 0.0001 };
     for (int c = 0; c < 9; c++) if (errCand[c] / 2 > maxZErr) fl.cand |= 1u << c;
-    if (fl.cand) fb.row0RaiseErr = dRow0Raise;    // filled by the statistics kernel
   }
   BandParams& bp = fl.bp;
   memset(&bp, 0, sizeof(bp));

@@ -43,13 +43,13 @@ struct FastBatch
   u32 nTiles;
   u32 nWG;             // workgroups (64 blocks each) per tile
   u64 tileElems;       // pixels from one tile to the next
-  u32 nRaiseSets;      // workgroups per tile that hold pixels of the first raster row (TryRaiseMaxZError looks at that row)
   u32 nBlobsMore;      // header field: bands that follow this one in the blob (0 for a single band / a tile)
 };
 LERC_HD u32 fastScanGroups(u32 nWG) { return (nWG + kFastScanGroup - 1u) / kFastScanGroup; }
 LERC_HD u32 fastPackGroups(u32 nWG) { return (nWG + kFastPackGroup - 1u) / kFastPackGroup; }
 LERC_HD u32 fastTicketStride(u32 nWG) { (void)nWG; return 4u; }
 LERC_HD u32 fastWgStride(u32 nWG) { return (nWG + 7u) & ~3u; }    // elements from one tile's wgSize / wgBase set to the next (16-byte aligned)
+static const u32 kScanPartWords = 12;
 static const int kFastPrefixStage = 128;   // bytes reserved per tile for header + mask count + ranges + mode byte
 
 struct FastEncodeBuffers
@@ -58,7 +58,8 @@ struct FastEncodeBuffers
   u32* wgSize;         // [nWG + 4] bytes of each workgroup's 64 blocks
   u32* wgBase;         // [nWG + 4] exclusive scan inside a scan group of kFastScanGroup workgroups
   u32* groupBase;      // [nScanGroups + 1] bytes in front of each scan group
-  u64* scanPart;       // [3 * nScanGroups] what a scan workgroup found: bytes | flags << 32, min key, max key
+  u64* scanPart;       // [kScanPartWords * nScanGroups] what a scan workgroup found: bytes | flags << 32, min key, max key, and (float
+                       // types) the largest rounding error of its share of the first raster row per TryRaiseMaxZError candidate
   u64* packPart;       // [nPackGroups] Fletcher sums of a pack group's workgroups and how many have arrived: A | B << 24 | n << 48
   u32* tickets;        // [fastTicketStride] [0] arrival counter of the scan workgroups
                        // (each kernel zeroes what the next one counts in: the statistics step the scan's ticket, the scan's last
@@ -66,8 +67,6 @@ struct FastEncodeBuffers
   u64* wgMinKey;       // [nWG] order-preserving key of each workgroup's smallest / largest pixel
   u64* wgMaxKey;       // [nWG]
   u32* wgFlags;        // [nWG] bit 0 NaN seen, bit 1 non-integer value seen
-  double* row0RaiseErr;    // [nRaiseSets * 9] TryRaiseMaxZError rounding errors of the first row, one set per workgroup that holds
-                           // some of it (float types), or nullptr
   u8* prefixStage;     // [kFastPrefixStage] the bytes in front of the first block, written by the decide step, copied by the pack step
   u64* tileOffset;     // [nTiles + 1] where each tile's blob starts in the output arena; nullptr: a single raster at offset 0
   FastEncodeResult* result;

@@ -146,14 +146,12 @@ __device__ __forceinline__ u32 packDesc(const Plan& pl, int nb) { return (u32)pl
 template<class T, bool WIDE>
 __global__ void __launch_bounds__(256)
 k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict__ desc, u32* __restrict__ wgSize,
-             u64* __restrict__ wgMinKey, u64* __restrict__ wgMaxKey, u32* __restrict__ wgFlags, u32 raiseCand,
-             double* __restrict__ row0RaiseErr, u32* __restrict__ tickets, FastBatch batch)
+             u64* __restrict__ wgMinKey, u64* __restrict__ wgMaxKey, u32* __restrict__ wgFlags, u32* __restrict__ tickets, FastBatch batch)
 {
   {
     const size_t tile = blockIdx.y;    // this tile's slice of every array
     data += tile * batch.tileElems; desc += tile * batch.nWG * kFastBlocksPerWG; wgSize += tile * fastWgStride(batch.nWG);
     wgMinKey += tile * batch.nWG; wgMaxKey += tile * batch.nWG; wgFlags += tile * batch.nWG;
-    if (row0RaiseErr) row0RaiseErr += tile * batch.nRaiseSets * 9;
     tickets += tile * fastTicketStride(batch.nWG);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) tickets[0] = 0u;    // the scan step counts its workgroups here
@@ -163,7 +161,6 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
   __shared__ T s_mn[kFastBlocksPerWG], s_mx[kFastBlocksPerWG];
   __shared__ u32 s_same[kFastBlocksPerWG], s_nd[kFastBlocksPerWG];
   __shared__ u32 s_fl[4];
-  __shared__ u64 s_raise[4][9];
   PROBE_BEGIN;
   // a block is LB consecutive lanes (a DPP row for 32-bit types), so that its reductions never leave the VALU:
   // lane = b * LB + r * LPR + h  (block of the wave tile, raster row of the block, lane of that row)
@@ -179,36 +176,12 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
 #pragma unroll
   for (int t = 0; t < C::IT; t++) loadLane<T, V>(data + laneOrigin<WIDE, BPW, V>(span, t * 4 + w, r, c, p.nCols), vAll[t]);
 
-  // float types: the pixels of the first raster row the way Lerc2::TryRaiseMaxZError looks at them (Lerc2.cpp:1245-1290):
-  // per candidate factor the largest rounding error; the decide step folds the workgroups' partial results
-  const bool doRaise = DtOf<T>::v >= DT_Float && raiseCand != 0u && row0RaiseErr != nullptr && blockIdx.x < batch.nRaiseSets;
-  double rerr[9];
-#pragma unroll
-  for (int cnd = 0; cnd < 9; cnd++) rerr[cnd] = 0;
   u32 flags = 0;
 #pragma unroll
   for (int t = 0; t < C::IT; t++)
   {
     const int tile = t * 4 + w;
     T (&v)[V] = vAll[t];
-    if (doRaise && r == 0 && fastSpanRow(span, (u32)(tile * BPW + b)) == 0u && fastSpanHas(span, (u32)(tile * BPW + b)))
-    {
-      const int facCand[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
-#pragma unroll
-      for (int k = 0; k < V; k++)
-      {
-        const double x = (double)v[k];
-        if (x != x) continue;    // a NaN sends the band to the general path anyway
-        for (int cnd = 0; cnd < 9; cnd++)    // candidates in increasing factor order, stop at the first exact hit
-        {
-          if (!((raiseCand >> cnd) & 1u)) continue;
-          const double z = x * facCand[cnd];
-          if (z == (double)(int)z) break;
-          const double dlt = fabs(floor(z + 0.5) - z);
-          rerr[cnd] = dlt > rerr[cnd] ? dlt : rerr[cnd];
-        }
-      }
-    }
     if (DtOf<T>::v >= DT_Float)
     {
 #pragma unroll
@@ -253,16 +226,6 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
   }
   const bool f1 = __any(flags & 1u), f2 = __any(flags & 2u);
   if (lane == 0) s_fl[w] = (f1 ? 1u : 0u) | (f2 ? 2u : 0u);
-  if (doRaise)
-  {
-#pragma unroll
-    for (int cnd = 0; cnd < 9; cnd++)
-    {
-      u64 bits; const double e = rerr[cnd]; memcpy(&bits, &e, 8);    // non-negative doubles order like their bit patterns
-      bits = waveMax(bits);
-      if (lane == 0) s_raise[w][cnd] = bits;
-    }
-  }
   __syncthreads();
   PROBE(0);
   // the serial per-block phase rotates over the waves (= SIMDs) from workgroup to workgroup, or one SIMD of the CU
@@ -298,13 +261,6 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
     wgMinKey[blockIdx.x] = kMin;
     wgMaxKey[blockIdx.x] = kMax;
     wgFlags[blockIdx.x] = s_fl[0] | s_fl[1] | s_fl[2] | s_fl[3];
-  }
-  if (doRaise && lane < 9)
-  {
-    u64 m = s_raise[0][lane];
-    for (int i = 1; i < 4; i++) m = s_raise[i][lane] > m ? s_raise[i][lane] : m;
-    double e; memcpy(&e, &m, 8);
-    row0RaiseErr[blockIdx.x * 9 + lane] = e;
   }
   PROBE(1);
 }
@@ -389,14 +345,15 @@ fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u3
 // The scan of the workgroup sizes, the fold of the per-workgroup statistics and the decisions in one launch: every
 // workgroup (1024 threads) scans kFastScanGroup sizes and publishes what it found; the one that arrives last scans the
 // groups' totals, decides, writes the bytes in front of the first block and resets the pack step's arrival counters.
+template<class T>
 __global__ void __launch_bounds__(1024)
-k_fast_scan_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgSize,
+k_fast_scan_decide(const T* __restrict__ data, BandParams p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, const u32* __restrict__ wgSize,
                    u32* __restrict__ wgBase, const u64* __restrict__ wgMinKey, const u64* __restrict__ wgMaxKey,
-                   const u32* __restrict__ wgFlags, const double* __restrict__ row0RaiseErr, u8* __restrict__ prefixStage, u64 outCapacity,
+                   const u32* __restrict__ wgFlags, u8* __restrict__ prefixStage, u64 outCapacity,
                    FastEncodeResult* res, u32* __restrict__ groupBase, u64* __restrict__ scanPart, u64* __restrict__ packPart,
                    u32* __restrict__ tickets, FastBatch batch)
 {
-  __shared__ u64 s_min[16], s_max[16], s_raise[9];
+  __shared__ u64 s_min[16], s_max[16], s_raise[9], s_rw[16][9];
   __shared__ u32 s_fl[16], s_w[16];
   __shared__ u32 s_last;
   __shared__ __align__(16) u8 s_prefix[kFastPrefixStage];
@@ -405,14 +362,40 @@ k_fast_scan_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u
     const size_t tile = blockIdx.y;
     wgSize += tile * fastWgStride(batch.nWG); wgBase += tile * fastWgStride(batch.nWG);
     wgMinKey += tile * batch.nWG; wgMaxKey += tile * batch.nWG; wgFlags += tile * batch.nWG;
-    if (row0RaiseErr) row0RaiseErr += tile * batch.nRaiseSets * 9;
+    data += tile * batch.tileElems;
     prefixStage += tile * kFastPrefixStage; res += tile;
-    groupBase += tile * (nGroups + 1); scanPart += tile * 3 * nGroups; tickets += tile * fastTicketStride(batch.nWG);
+    groupBase += tile * (nGroups + 1); scanPart += tile * kScanPartWords * nGroups; tickets += tile * fastTicketStride(batch.nWG);
     packPart += tile * fastPackGroups(batch.nWG);
   }
   const int lane = laneId(), w = waveId();
-  // ---- this group's kFastScanGroup entries: four per thread, all loads in flight first
   const u32 g = blockIdx.x;
+  // ---- float types: this group's share of the first raster row the way Lerc2::TryRaiseMaxZError looks at it
+  // (Lerc2.cpp:1245-1290): per candidate factor the largest rounding error (the last workgroup folds the groups' results)
+  const bool doRaise = DtOf<T>::v >= DT_Float && raiseCandidates != 0u;
+  double rerr[9];
+#pragma unroll
+  for (int cnd = 0; cnd < 9; cnd++) rerr[cnd] = 0;
+  if (doRaise)
+  {
+    const int facCand[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
+    const u32 per = ((u32)p.nCols + nGroups - 1u) / nGroups;
+    for (u32 col = g * per + threadIdx.x; col < min((g + 1u) * per, (u32)p.nCols); col += 1024u)
+    {
+      const double x = (double)data[col];
+      if (x != x) continue;    // a NaN sends the band to the general path anyway
+      bool exact = false;
+#pragma unroll
+      for (int cnd = 0; cnd < 9; cnd++)    // candidates in increasing factor order, stop at the first exact hit
+      {
+        if (exact || !((raiseCandidates >> cnd) & 1u)) continue;
+        const double z = x * facCand[cnd];
+        if (z == (double)(int)z) { exact = true; continue; }
+        const double dlt = fabs(floor(z + 0.5) - z);
+        rerr[cnd] = dlt > rerr[cnd] ? dlt : rerr[cnd];
+      }
+    }
+  }
+  // ---- this group's kFastScanGroup entries: four per thread, all loads in flight first
   const u32 i0 = g * kFastScanGroup + 4u * threadIdx.x;
   const u32 lastVec = (nWG - 1u) & ~3u;                      // clamped loads (the arrays have slack up to a multiple of 4)
   const uint4 sz = *reinterpret_cast<const uint4*>(wgSize + min(i0, lastVec));
@@ -437,6 +420,16 @@ k_fast_scan_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u
   for (int m = 1; m < 64; m <<= 1) fl |= __shfl_xor(fl, m);
   if (lane == 63) s_w[w] = inc;
   if (lane == 0) { s_min[w] = kMin; s_max[w] = kMax; s_fl[w] = fl; }
+  if (doRaise)
+  {
+#pragma unroll
+    for (int cnd = 0; cnd < 9; cnd++)
+    {
+      u64 bits; const double e = rerr[cnd]; memcpy(&bits, &e, 8);    // non-negative doubles order like their bit patterns
+      bits = waveMax(bits);
+      if (lane == 0) s_rw[w][cnd] = bits;
+    }
+  }
   __syncthreads();
   u32 run = inc - sum;
   for (int i = 0; i < w; i++) run += s_w[i];
@@ -452,9 +445,15 @@ k_fast_scan_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u
     u32 total = 0, f = 0;
     u64 a = ~0ull, b = 0ull;
     for (int i = 0; i < 16; i++) { total += s_w[i]; f |= s_fl[i]; a = s_min[i] < a ? s_min[i] : a; b = s_max[i] > b ? s_max[i] : b; }
-    publish64(scanPart + 3 * (size_t)g, (u64)total | ((u64)f << 32));
-    publish64(scanPart + 3 * (size_t)g + 1, a);
-    publish64(scanPart + 3 * (size_t)g + 2, b);
+    publish64(scanPart + kScanPartWords * (size_t)g, (u64)total | ((u64)f << 32));
+    publish64(scanPart + kScanPartWords * (size_t)g + 1, a);
+    publish64(scanPart + kScanPartWords * (size_t)g + 2, b);
+    for (int cnd = 0; cnd < 9; cnd++)
+    {
+      u64 m = 0;    // (+0.0)
+      if (doRaise) for (int i = 0; i < 16; i++) m = s_rw[i][cnd] > m ? s_rw[i][cnd] : m;
+      publish64(scanPart + kScanPartWords * (size_t)g + 3 + cnd, m);
+    }
     drainVmem();
     s_last = (nGroups == 1u || lastArrival(&tickets[0], nGroups)) ? 1u : 0u;
   }
@@ -467,12 +466,7 @@ k_fast_scan_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u
   if (threadIdx.x < 9)
   {
     u64 m = 0;    // (+0.0)
-    if (row0RaiseErr)
-      for (u32 i = 0; i < batch.nRaiseSets; i++)
-      {
-        u64 bits; const double er = row0RaiseErr[i * 9 + threadIdx.x]; memcpy(&bits, &er, 8);
-        m = bits > m ? bits : m;
-      }
+    for (u32 i = 0; i < nGroups; i++) { const u64 bits = observe64(scanPart + kScanPartWords * (size_t)i + 3 + threadIdx.x); m = bits > m ? bits : m; }
     s_raise[threadIdx.x] = m;
   }
   u64 aMin = ~0ull, aMax = 0ull;
@@ -481,8 +475,8 @@ k_fast_scan_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u
   {
     const u32 gi = g0 + threadIdx.x;
     const bool have = gi < nGroups;
-    const u64 tf = have ? observe64(scanPart + 3 * (size_t)gi) : 0ull;
-    const u64 a = have ? observe64(scanPart + 3 * (size_t)gi + 1) : ~0ull, b = have ? observe64(scanPart + 3 * (size_t)gi + 2) : 0ull;
+    const u64 tf = have ? observe64(scanPart + kScanPartWords * (size_t)gi) : 0ull;
+    const u64 a = have ? observe64(scanPart + kScanPartWords * (size_t)gi + 1) : ~0ull, b = have ? observe64(scanPart + kScanPartWords * (size_t)gi + 2) : 0ull;
     const u32 tot = (u32)tf;
     aFl |= (u32)(tf >> 32); aMin = a < aMin ? a : aMin; aMax = b > aMax ? b : aMax;
     __syncthreads();
@@ -508,7 +502,7 @@ k_fast_scan_decide(BandParams p, double requestedMaxZErr, u32 raiseCandidates, u
     u32 f = 0;
     u64 a = ~0ull, b = 0ull;
     for (int i = 0; i < 16; i++) { f |= s_fl[i]; a = s_min[i] < a ? s_min[i] : a; b = s_max[i] > b ? s_max[i] : b; }
-    fastDecide(p, requestedMaxZErr, raiseCandidates, carry, a, b, f, row0RaiseErr ? s_raise : nullptr, batch.nBlobsMore, s_prefix, outCapacity, res);
+    fastDecide(p, requestedMaxZErr, raiseCandidates, carry, a, b, f, doRaise ? s_raise : nullptr, batch.nBlobsMore, s_prefix, outCapacity, res);
   }
   __syncthreads();
   if (threadIdx.x < kFastPrefixStage / 4) reinterpret_cast<u32*>(prefixStage)[threadIdx.x] = reinterpret_cast<const u32*>(s_prefix)[threadIdx.x];
@@ -850,16 +844,16 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
   {
     if (p.nTH % 64 == 0)
       hipLaunchKernelGGL((k_fast_stats<T, true>), dim3(nWG, nT), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.wgMinKey, b.wgMaxKey,
-                         b.wgFlags, raiseCand, b.row0RaiseErr, b.tickets, batch);
+                         b.wgFlags, b.tickets, batch);
     else
       hipLaunchKernelGGL((k_fast_stats<T, false>), dim3(nWG, nT), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.wgMinKey, b.wgMaxKey,
-                         b.wgFlags, raiseCand, b.row0RaiseErr, b.tickets, batch);
+                         b.wgFlags, b.tickets, batch);
   }
   else if (stage == 1)
   {
     // a tile of a batch may be as large as it likes here; whether the arena holds it is decided by the placement
-    hipLaunchKernelGGL(k_fast_scan_decide, dim3(fastScanGroups(nWG), nT), dim3(1024), 0, st, p, requested, raiseCand, nWG, (const u32*)b.wgSize, b.wgBase,
-                       (const u64*)b.wgMinKey, (const u64*)b.wgMaxKey, (const u32*)b.wgFlags, (const double*)b.row0RaiseErr, b.prefixStage,
+    hipLaunchKernelGGL(k_fast_scan_decide<T>, dim3(fastScanGroups(nWG), nT), dim3(1024), 0, st, (const T*)data, p, requested, raiseCand, nWG, (const u32*)b.wgSize, b.wgBase,
+                       (const u64*)b.wgMinKey, (const u64*)b.wgMaxKey, (const u32*)b.wgFlags, b.prefixStage,
                        b.tileOffset ? ~0ull : cap, b.result, b.groupBase, b.scanPart, b.packPart, b.tickets, batch);
     if (b.tileOffset)
       hipLaunchKernelGGL(k_fast_tile_offsets, dim3(1), dim3(1024), 0, st, b.result, nT, arenaBase, cap, b.tileOffset);

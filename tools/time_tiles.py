@@ -19,21 +19,21 @@ def main():
     arena = torch.empty(tiles.numel() * 4 + n_tiles * 256, dtype=torch.uint8, device=dev)
     out = torch.empty_like(tiles)
     for _ in range(2):
-        rc, offs, sizes, used = api.encode_tiles_device(codec, tiles, 0.01, arena)
+        rc, offs, sizes, used = api.encode_tiles_device(codec, tiles, float(os.environ.get("MZE", "0.01")), arena)
         assert rc == 0
         assert api.decode_tiles_device(codec, arena, offs, sizes, out) == 0
     torch.cuda.synchronize()
     reps = 5
     t0 = time.perf_counter()
     for _ in range(reps):
-        rc, offs, sizes, used = api.encode_tiles_device(codec, tiles, 0.01, arena)
+        rc, offs, sizes, used = api.encode_tiles_device(codec, tiles, float(os.environ.get("MZE", "0.01")), arena)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(reps):
         api.decode_tiles_device(codec, arena, offs, sizes, out)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    assert float((out - tiles).abs().max()) <= 0.0101
+    assert float((out - tiles).abs().max()) <= float(os.environ.get("MZE", "0.01")) * 1.01
     import ctypes as ct
     lib = codec.lib
     lib.lerc_amd_profile_enable.argtypes = [ct.c_void_p, ct.c_int]
@@ -42,7 +42,7 @@ def main():
     c0 = (ct.c_ulonglong * 4)()
     lib.lerc_amd_path_counters(codec.h, c0)
     lib.lerc_amd_profile_enable(codec.h, 1)
-    api.encode_tiles_device(codec, tiles, 0.01, arena)
+    api.encode_tiles_device(codec, tiles, float(os.environ.get("MZE", "0.01")), arena)
     api.decode_tiles_device(codec, arena, offs, sizes, out)
     lib.lerc_amd_profile_enable(codec.h, 0)
     buf = ct.create_string_buffer(1 << 16)
@@ -64,7 +64,7 @@ def main():
     m = min(n_tiles, 256)
     t0 = time.perf_counter()
     for t in range(m):
-        rc, nb = api.encode_device(codec, tiles[t], 0.01, one)
+        rc, nb = api.encode_device(codec, tiles[t], float(os.environ.get("MZE", "0.01")), one)
         api.decode_device(codec, one, nb, y)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
