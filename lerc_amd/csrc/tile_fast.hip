@@ -368,6 +368,8 @@ k_fast_scan_decide(const T* __restrict__ data, BandParams p, double requestedMax
     packPart += tile * fastPackGroups(batch.nWG);
   }
   const int lane = laneId(), w = waveId();
+  const int nWaves = (int)(blockDim.x >> 6);    // 16, or 4 where a raster has at most 1024 workgroups (mosaic tiles)
+  const u32 nThreads = blockDim.x;
   const u32 g = blockIdx.x;
   // ---- float types: this group's share of the first raster row the way Lerc2::TryRaiseMaxZError looks at it
   // (Lerc2.cpp:1245-1290): per candidate factor the largest rounding error (the last workgroup folds the groups' results)
@@ -379,7 +381,7 @@ k_fast_scan_decide(const T* __restrict__ data, BandParams p, double requestedMax
   {
     const int facCand[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
     const u32 per = ((u32)p.nCols + nGroups - 1u) / nGroups;
-    for (u32 col = g * per + threadIdx.x; col < min((g + 1u) * per, (u32)p.nCols); col += 1024u)
+    for (u32 col = g * per + threadIdx.x; col < min((g + 1u) * per, (u32)p.nCols); col += nThreads)
     {
       const double x = (double)data[col];
       if (x != x) continue;    // a NaN sends the band to the general path anyway
@@ -444,14 +446,14 @@ k_fast_scan_decide(const T* __restrict__ data, BandParams p, double requestedMax
   {
     u32 total = 0, f = 0;
     u64 a = ~0ull, b = 0ull;
-    for (int i = 0; i < 16; i++) { total += s_w[i]; f |= s_fl[i]; a = s_min[i] < a ? s_min[i] : a; b = s_max[i] > b ? s_max[i] : b; }
+    for (int i = 0; i < nWaves; i++) { total += s_w[i]; f |= s_fl[i]; a = s_min[i] < a ? s_min[i] : a; b = s_max[i] > b ? s_max[i] : b; }
     publish64(scanPart + kScanPartWords * (size_t)g, (u64)total | ((u64)f << 32));
     publish64(scanPart + kScanPartWords * (size_t)g + 1, a);
     publish64(scanPart + kScanPartWords * (size_t)g + 2, b);
     for (int cnd = 0; cnd < 9; cnd++)
     {
       u64 m = 0;    // (+0.0)
-      if (doRaise) for (int i = 0; i < 16; i++) m = s_rw[i][cnd] > m ? s_rw[i][cnd] : m;
+      if (doRaise) for (int i = 0; i < nWaves; i++) m = s_rw[i][cnd] > m ? s_rw[i][cnd] : m;
       publish64(scanPart + kScanPartWords * (size_t)g + 3 + cnd, m);
     }
     drainVmem();
@@ -462,7 +464,7 @@ k_fast_scan_decide(const T* __restrict__ data, BandParams p, double requestedMax
 
   // ---- the last workgroup: the groups' totals, the decisions, the header
   const u32 nPackGroups = fastPackGroups(nWG);
-  for (u32 i = threadIdx.x; i < nPackGroups; i += 1024u) packPart[i] = 0ull;    // the pack step adds up its checksum terms here
+  for (u32 i = threadIdx.x; i < nPackGroups; i += nThreads) packPart[i] = 0ull;    // the pack step adds up its checksum terms here
   if (threadIdx.x < 9)
   {
     u64 m = 0;    // (+0.0)
@@ -471,7 +473,7 @@ k_fast_scan_decide(const T* __restrict__ data, BandParams p, double requestedMax
   }
   u64 aMin = ~0ull, aMax = 0ull;
   u32 aFl = 0, carry = 0;
-  for (u32 g0 = 0; g0 < nGroups; g0 += 1024u)    // (one round unless the raster has more than 2^28 blocks)
+  for (u32 g0 = 0; g0 < nGroups; g0 += nThreads)    // (one round unless the raster has more than 2^28 blocks)
   {
     const u32 gi = g0 + threadIdx.x;
     const bool have = gi < nGroups;
@@ -487,7 +489,7 @@ k_fast_scan_decide(const T* __restrict__ data, BandParams p, double requestedMax
     for (int i = 0; i < w; i++) before += s_w[i];
     if (have) groupBase[gi] = before;
     u32 all = 0;
-    for (int i = 0; i < 16; i++) all += s_w[i];
+    for (int i = 0; i < nWaves; i++) all += s_w[i];
     carry += all;
   }
   aMin = waveMin(aMin); aMax = waveMax(aMax);
@@ -501,7 +503,7 @@ k_fast_scan_decide(const T* __restrict__ data, BandParams p, double requestedMax
     groupBase[nGroups] = carry;
     u32 f = 0;
     u64 a = ~0ull, b = 0ull;
-    for (int i = 0; i < 16; i++) { f |= s_fl[i]; a = s_min[i] < a ? s_min[i] : a; b = s_max[i] > b ? s_max[i] : b; }
+    for (int i = 0; i < nWaves; i++) { f |= s_fl[i]; a = s_min[i] < a ? s_min[i] : a; b = s_max[i] > b ? s_max[i] : b; }
     fastDecide(p, requestedMaxZErr, raiseCandidates, carry, a, b, f, doRaise ? s_raise : nullptr, batch.nBlobsMore, s_prefix, outCapacity, res);
   }
   __syncthreads();
@@ -852,7 +854,7 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
   else if (stage == 1)
   {
     // a tile of a batch may be as large as it likes here; whether the arena holds it is decided by the placement
-    hipLaunchKernelGGL(k_fast_scan_decide<T>, dim3(fastScanGroups(nWG), nT), dim3(1024), 0, st, (const T*)data, p, requested, raiseCand, nWG, (const u32*)b.wgSize, b.wgBase,
+    hipLaunchKernelGGL(k_fast_scan_decide<T>, dim3(fastScanGroups(nWG), nT), dim3(nWG <= 1024u ? 256 : 1024), 0, st, (const T*)data, p, requested, raiseCand, nWG, (const u32*)b.wgSize, b.wgBase,
                        (const u64*)b.wgMinKey, (const u64*)b.wgMaxKey, (const u32*)b.wgFlags, b.prefixStage,
                        b.tileOffset ? ~0ull : cap, b.result, b.groupBase, b.scanPart, b.packPart, b.tickets, batch);
     if (b.tileOffset)

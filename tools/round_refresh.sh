@@ -1,0 +1,17 @@
+#!/bin/bash
+# Everything the round's profiles/ files come from, in one GPU-box call:
+#   gpurun --timeout 2400 -- 'bash tools/round_refresh.sh r02'
+set -u
+TAG=${1:-rXX}
+OUT=$PWD/gpurun_out; mkdir -p "$OUT"
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -q > "$OUT/${TAG}_pytest_gpu.txt" 2>&1; tail -3 "$OUT/${TAG}_pytest_gpu.txt"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/${TAG}_smoke.txt" 2>&1; tail -2 "$OUT/${TAG}_smoke.txt"
+timeout 600 python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"; cut -c1-400 "$OUT/${TAG}_bench.json"
+bash tools/profile_run.sh $TAG
+timeout 300 python tools/time_configs.py c3 c4 general c2lossless > "$OUT/${TAG}_time_configs.txt" 2>&1
+timeout 200 python tools/time_tiles.py > "$OUT/${TAG}_time_tiles.txt" 2>&1
+timeout 200 python tools/time_small.py > "$OUT/${TAG}_time_small.txt" 2>&1
+timeout 200 python tools/time_host_api.py > "$OUT/${TAG}_time_host_api.txt" 2>&1
+timeout 400 python bench.py --workload c5 --tiles 4096 --steps 5 --warmup 2 > "$OUT/${TAG}_bench_c5_1gpu.json" 2> "$OUT/${TAG}_bench_c5_1gpu.err"; cut -c1-300 "$OUT/${TAG}_bench_c5_1gpu.json"
+ls -la "$OUT" | grep $TAG | wc -l
