@@ -136,7 +136,11 @@ LERC_HD u32 fastNumWG(int nRows, int nCols) { return (u32)(((u64)(nRows / 8) * (
 //                    that they tile the stream exactly
 static const u32 kFastChunkBytes = 2048;
 static const int kDiscWalks = 8;           // walks per chunk (path heads among the filter's survivors; more: general path)
-static const int kDiscChunks = 16;         // chunks per workgroup of k_fast_discover (four per wave while candidates are filtered)
+#ifndef LERC_DISC_CHUNKS
+#define LERC_DISC_CHUNKS 16
+#endif
+static const int kDiscChunks = LERC_DISC_CHUNKS;    // chunks per workgroup of k_fast_discover: 8 or 16 (16 threads each; 8 is 8 % slower)
+static const int kDiscThreads = 16 * kDiscChunks;
 static const int kFastListCap = 128;       // block starts a walk can list per chunk (more, i.e. blocks of < 16 bytes on average: general path)
 static const u32 kResolveWG = 256;         // chunks per workgroup of k_fast_resolve
 static const u32 kDecodeChunks = 4;        // chunks whose blocks a workgroup of k_fast_decode decodes (divides kResolveWG)

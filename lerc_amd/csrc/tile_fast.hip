@@ -77,10 +77,10 @@ template<> __device__ __forceinline__ bool isNaNv<double>(double v) { return v !
 
 // loads the V pixels of this lane (one aligned vector load)
 template<class T, int V>
-__device__ __forceinline__ void loadLane(const T* __restrict__ p, T (&v)[V])
+__device__ __forceinline__ void loadLane(const T* __restrict__ p, T (&v)[V], bool streaming = false)
 {
   struct alignas(sizeof(T) * V) Vec { T e[V]; };
-  const Vec x = *reinterpret_cast<const Vec*>(p);
+  const Vec x = streaming ? loadStreaming(reinterpret_cast<const Vec*>(p)) : *reinterpret_cast<const Vec*>(p);
 #pragma unroll
   for (int k = 0; k < V; k++) v[k] = x.e[k];
 }
@@ -173,8 +173,10 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
   // all loads of the wave in flight before the first use (the data-dependent LUT branch below keeps the compiler
   // from hoisting them itself)
   T vAll[C::IT][V];
+  // (the raster is read with the non-temporal hint here and in k_fast_pack: 268 MB do not fit the 256 MiB Infinity Cache,
+  // so nothing of the first pass survives for the second one anyway, and ordinary loads only displace what does get re-used)
 #pragma unroll
-  for (int t = 0; t < C::IT; t++) loadLane<T, V>(data + laneOrigin<WIDE, BPW, V>(span, t * 4 + w, r, c, p.nCols), vAll[t]);
+  for (int t = 0; t < C::IT; t++) loadLane<T, V>(data + laneOrigin<WIDE, BPW, V>(span, t * 4 + w, r, c, p.nCols), vAll[t], true);
 
   u32 flags = 0;
 #pragma unroll
@@ -194,9 +196,13 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
     }
     T mn = v[0], mx = v[0];
 #pragma unroll
-    for (int k = 1; k < V; k++) { mn = v[k] < mn ? v[k] : mn; mx = v[k] > mx ? v[k] : mx; }
-    mn = (T)groupReduce<LB>((ST)mn, OpMin());
-    mx = (T)groupReduce<LB>((ST)mx, OpMax());
+    for (int k = 1; k < V; k++) { mn = OpMin()(mn, v[k]); mx = OpMax()(mx, v[k]); }
+    if constexpr (std::is_same<T, float>::value) rowMinMax(mn, mx);    // (LB == 16)
+    else
+    {
+      mn = (T)groupReduce<LB>((ST)mn, OpMin());
+      mx = (T)groupReduce<LB>((ST)mx, OpMax());
+    }
     // "same as previous" in row-major block order, prevVal starts at 0 (Lerc2.cpp:1729-1758): the previous
     // pixel vector of the block lives in the previous lane
     T prev = (T)dppMovT<kDppWaveShr1>((ST)v[V - 1]);
@@ -204,20 +210,23 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
     int same = (v[0] == prev) ? 1 : 0;
 #pragma unroll
     for (int k = 1; k < V; k++) same += (v[k] == v[k - 1]) ? 1 : 0;
-    // only "more than half of the 64" matters (tryLut); that needs a lane above the average of 32 / LB
-    if (__any(same > 32 / LB)) same = groupReduce<LB>(same, OpSum());
-    else same = 0;
-    // LUT candidates need the number of distinct quantised values, which only the pixel owners can count
+    // only "more than half of the 64" matters (tryLut); that needs a lane above the average of 32 / LB.  LUT candidates
+    // need the number of distinct quantised values, which only the pixel owners can count
     u32 nd = 0;
-    const bool tryLut = (2 * same > 64) && ((double)mx > (double)mn + 3 * p.maxZErr);
-    if (__any(tryLut))
+    if (__any(same > 32 / LB))
     {
-      const double mv = ((double)mx - (double)mn) * p.scale;
-      const bool need = tryLut && !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
-      u32 q[V];
-      quantizeLane<T, V>(p.intLossless, p.scale, v, mn, q);
-      nd = groupDistinct<LB, V>(q, need);
+      same = groupReduce<LB>(same, OpSum());
+      const bool tryLut = (2 * same > 64) && ((double)mx > (double)mn + 3 * p.maxZErr);
+      if (__any(tryLut))
+      {
+        const double mv = ((double)mx - (double)mn) * p.scale;
+        const bool need = tryLut && !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
+        u32 q[V];
+        quantizeLane<T, V>(p.intLossless, p.scale, v, mn, q);
+        nd = groupDistinct<LB, V>(q, need);
+      }
     }
+    else same = 0;
     if (leader)
     {
       const int blk = tile * BPW + b;
@@ -570,7 +579,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
   // one round trip per question -- what the decide step left: is this band ours at all, where does the span go
   T v[IT][V];
 #pragma unroll
-  for (int t = 0; t < IT; t++) loadLane<T, V>(data + laneOrigin<WIDE, BPW, V>(span, t * 4 + w, r, c, p.nCols), v[t]);
+  for (int t = 0; t < IT; t++) loadLane<T, V>(data + laneOrigin<WIDE, BPW, V>(span, t * 4 + w, r, c, p.nCols), v[t], true);
   FastBlockDesc d;
   const int wPlan = (int)((wg * 2654435761u) >> 30);    // the wave that does the per-block work rotates (see k_fast_stats)
   if (w == wPlan) d = desc[(size_t)wg * kFastBlocksPerWG + lane];
@@ -751,7 +760,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
     const u32 first = lo < ldsShift ? ldsShift : lo;
     const u32 last = hi > ldsShift + spanLen ? ldsShift + spanLen : hi;    // owned bytes: [first, last)
     const uint4 x = *reinterpret_cast<const uint4*>(&s_out[ch * 4]);
-    if (first == lo && last == hi) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;
+    if (first == lo && last == hi) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;    // (k_fast_discover reads them next: no streaming hint)
     else
     {
       const u32 wd[4] = { x.x, x.y, x.z, x.w };

@@ -35,6 +35,11 @@ namespace lerc {
 
 static const u32 kNoOffset = 0xFFFFFFFFu;
 PROBE_DEFINE(fast_decode)
+// The decoded pixels leave with the non-temporal hint: nothing in the call reads them again, and written the ordinary
+// way they sit dirty in L2 / the Infinity Cache until the NEXT kernel's traffic pushes them out (measured on C2: this
+// kernel 79 -> 71 us, the statistics pass of the following encode 77 -> 53 us).  The same hint on the blob loads here or in
+// k_fast_discover costs 5-8 us: those bytes were just written by the kernel in front and are still on the die.
+#define DECODE_STORE(ptr, val) storeStreaming(ptr, val)
 
 // ------------------------------------------------------------------------------------------------
 // block header parsing, branch free
@@ -348,14 +353,15 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
 {
   constexpr int TBYTES = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
   constexpr u32 W = kFastWindow(TBYTES);
-  constexpr u32 CH = kFastChunkBytes, NCH = (u32)kDiscChunks, NW = (u32)kDiscWalks;
+  constexpr u32 CH = kFastChunkBytes, NCH = (u32)kDiscChunks, NW = (u32)kDiscWalks, NT = (u32)kDiscThreads;
+  constexpr u32 kWaves = NT / 64, kHeadsPerWave = 64 / NCH;    // walks: lane = (chunk, head), a wave takes kHeadsPerWave heads of every chunk
   constexpr u32 kUnits = NCH * CH / 16;                    // 16-byte units a workgroup owns
   constexpr u32 kOverhang = (W + 16 + 15) / 16;            // + the next workgroup's first window (walks end on a block start there)
   constexpr u32 kStageUnits = kUnits + kOverhang;
   constexpr u32 kBitWords = (W + 31) / 32;
   constexpr u32 kFoundCap = 512, kHitCap = 512;            // count bytes / block headers found in the workgroup's 17 windows (a few dozen)
   constexpr u32 kScanWords = (W + 2 + 8 + 3) / 4 + 1;      // dwords of a window that can hold the count byte of a block starting in it
-  static_assert(NCH == 16 && NW == 8 && W < 1024 && CH + 2 * W < 65536, "lane layout / 16-bit list entries");
+  static_assert((NCH == 16 || NCH == 8) && NW == 8 && NT >= NCH * NW && W < 1024 && CH + 2 * W < 65536, "lane layout / 16-bit list entries");
   __shared__ __align__(16) u32 s_in[kStageUnits * 4];
   __shared__ u32 s_hits[NCH + 1][kBitWords];               // window positions where a bit-stuffed block header stands
   __shared__ u32 s_heads[NCH][kBitWords];                  // ... that are not the block right behind another one
@@ -364,7 +370,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   __shared__ u16 s_final[NCH][NW];
   __shared__ u32 s_nFinal[NCH];
   __shared__ u32 s_exit[NCH][NW];
-  __shared__ u64 s_fa[4], s_fb[4];
+  __shared__ u64 s_fa[kWaves], s_fb[kWaves];
   __shared__ u32 s_over;
 
   PROBE_BEGIN;
@@ -389,14 +395,15 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   const bool v5 = version >= 5;
   const u32 dataBegin = hl.dataBegin, blobEnd = hl.blobEnd;
   const u32 pattern = v5 ? 14u : 15u;
+  PROBE(12);
 
   // ---- the workgroup's chunks, all loads in flight at once (clipped to what the caller says is readable)
-  constexpr int kRounds = (int)((kStageUnits + 255) / 256);
+  constexpr int kRounds = (int)((kStageUnits + NT - 1) / NT);
   uint4 x[kRounds];
 #pragma unroll
   for (int k = 0; k < kRounds; k++)
   {
-    const u32 i = (u32)k * 256u + threadIdx.x;
+    const u32 i = (u32)k * NT + threadIdx.x;
     const u64 a = (u64)r0 + 16ull * i;
     x[k] = make_uint4(0, 0, 0, 0);
     if (i < kStageUnits)
@@ -415,11 +422,14 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   // ---- stage + Fletcher terms of the units this workgroup owns (bytes 14 ... blobEnd - 1 of the blob are checksummed)
   u32 fA = 0;
   u64 fB = 0;
+  PROBE(13);
+  PROBE_DRAIN;
+  PROBE(15);
   const bool inner = r0 != 0u && (u64)r0 + 16ull * kUnits <= blobEnd;    // no unit of this workgroup needs blanking
 #pragma unroll
   for (int k = 0; k < kRounds; k++)
   {
-    const u32 i = (u32)k * 256u + threadIdx.x;
+    const u32 i = (u32)k * NT + threadIdx.x;
     if (i < kStageUnits) *reinterpret_cast<uint4*>(&s_in[i * 4]) = x[k];
     const u32 a = r0 + 16u * i;                                           // (< 2^32: the blob is)
     if (inner)
@@ -440,19 +450,23 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
       fletcherUnit(y, a ? (a - 14u) / 2u : 65528ull, fA, fB);             // (the first unit's index -7 as its residue mod 65535)
     }
   }
+  PROBE(14);
   {
     const u64 A = waveSum((u64)fA % 65535u), B = waveSum(fB % 65535u);
     if (lane == 0) { s_fa[w] = A; s_fb[w] = B; }
   }
   if (threadIdx.x == 0) s_over = 0u;
-  for (u32 i = threadIdx.x; i < (NCH + 1) * kBitWords; i += 256u) (&s_hits[0][0])[i] = 0u;
+  for (u32 i = threadIdx.x; i < (NCH + 1) * kBitWords; i += NT) (&s_hits[0][0])[i] = 0u;
   if (threadIdx.x == 0) { s_nFound = 0u; s_nHit = 0u; }
   __syncthreads();
   PROBE(16);
   if (threadIdx.x == 0)
   {
-    b.waveFletcher[2 * (size_t)blockIdx.x] = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u;
-    b.waveFletcher[2 * (size_t)blockIdx.x + 1] = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
+    u64 A = 0, B = 0;
+#pragma unroll
+    for (u32 k = 0; k < kWaves; k++) { A += s_fa[k]; B += s_fb[k]; }
+    b.waveFletcher[2 * (size_t)blockIdx.x] = A % 65535u;
+    b.waveFletcher[2 * (size_t)blockIdx.x + 1] = B % 65535u;
   }
 
   // ---- bit-stuffed block headers in the first `window` bytes of every chunk (+ the next workgroup's first one).
@@ -461,7 +475,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   // is one byte) and the count 64 (Lerc2.cpp:1961-2021, BitStuffer2.cpp:35-77).  "a byte 64 behind a byte 10?nnnnn" is
   // true for one position in a thousand of anything else, so the scan finds the path's blocks almost alone; whatever
   // else it finds dies within a few steps of its walk.  Four positions per lane and step.
-  for (u32 f0 = 0; f0 < (NCH + 1) * kScanWords; f0 += 256u)
+  for (u32 f0 = 0; f0 < (NCH + 1) * kScanWords; f0 += NT)
   {
     const u32 f = f0 + threadIdx.x;
     const u32 win = f / kScanWords, d = f - win * kScanWords;
@@ -488,7 +502,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   // a count byte stands 2 + (bytes of the offset) behind the block's flag byte: try each offset type, one lane each
   {
     const u32 nFound = min(s_nFound, kFoundCap);
-    for (u32 h = threadIdx.x; h < 4u * nFound; h += 256u)
+    for (u32 h = threadIdx.x; h < 4u * nFound; h += NT)
     {
       const u32 e = s_found[h >> 2], tc = h & 3u;
       const u32 win = e >> 11, q = e & 0x7FFu;
@@ -515,12 +529,12 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
 
   // ---- of the blocks found, those that are not the block right behind another one start a walk (the true path crosses
   // a window in several blocks, each of them found)
-  for (u32 i = threadIdx.x; i < NCH * kBitWords; i += 256u) (&s_heads[0][0])[i] = (&s_hits[0][0])[i];
+  for (u32 i = threadIdx.x; i < NCH * kBitWords; i += NT) (&s_heads[0][0])[i] = (&s_hits[0][0])[i];
   if (threadIdx.x < NCH) s_nFinal[threadIdx.x] = 0u;
   __syncthreads();
   constexpr u32 kMaxRel = NCH * CH + W - 1;                               // last staged byte a block may start at
   const u32 nHit = min(s_nHit, kHitCap);
-  for (u32 h = threadIdx.x; h < nHit; h += 256u)
+  for (u32 h = threadIdx.x; h < nHit; h += NT)
   {
     const u32 e = s_hit[h];
     const u32 hWin = e >> 11, hPos = e & 0x7FFu;
@@ -541,7 +555,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   __syncthreads();
   // (walk slots in the order of the heads' positions: the path's head is nearly always the first one, so that the decode
   // kernel can fetch "walk 0 of the chunk" before it has been told which walk it is)
-  for (u32 h = threadIdx.x; h < nHit; h += 256u)
+  for (u32 h = threadIdx.x; h < nHit; h += NT)
   {
     const u32 e = s_hit[h];
     const u32 hWin = e >> 11, hPos = e & 0x7FFu;
@@ -557,11 +571,12 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   __syncthreads();
   PROBE(20);
 
-  // ---- walks: lane = (chunk, head); waves 0 and 1 take heads 0-3 and 4-7 (there are seldom more than two), the other
-  // waves are done.  A walk ends on the first block header of the next chunk's window it lands on (or with the blob).
-  if (w < 2)
+  // ---- walks: lane = (chunk, head); the first wave takes the first heads of every chunk (there are seldom more than two).
+  // A walk ends on the first block header of the next chunk's window it lands on (or with the blob).
+  // (rotating the walking waves over the workgroup's waves, as the encoder's statistics pass does, changes nothing here)
+  if ((u32)w < NW / kHeadsPerWave)
   {
-    const u32 wc = (u32)lane >> 2, slot = ((u32)lane & 3u) + 4u * (u32)w;    // chunk inside the workgroup, head
+    const u32 wc = (u32)lane / kHeadsPerWave, slot = ((u32)lane % kHeadsPerWave) + kHeadsPerWave * (u32)w;    // chunk inside the workgroup, head
     const u32 wChunk = c0 + wc;
     const u32 wStart = wChunk * CH;
     const bool wLive = wChunk < nChunks;
@@ -598,6 +613,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
       count += ok ? 1u : 0u;
       sig = ok ? sg : sig;
     }
+    PROBE(22);
     // behind the chunk: done on a block header of the next window (or at the end of the blob), lost behind that window
     bool landed = false;
     for (;;)
@@ -969,7 +985,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
         Vec o;
 #pragma unroll
         for (int k = 0; k < V; k++) o.e[k] = v[k];
-        *reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)) = o;
+        DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
       }
     }
     else if (code)
@@ -1020,7 +1036,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
       Vec o;
 #pragma unroll
       for (int k = 0; k < V; k++) o.e[k] = v[k];
-      *reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)) = o;
+      DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
     }
   }
   PROBE(11);
@@ -1062,7 +1078,7 @@ __device__ __forceinline__ void tileSlice(FastDecodeBuffers& b, const FastDecode
 }
 
 template<int DT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kDiscThreads)
 k_fast_discover(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 sizeGiven, int nRows, int nCols)
 {
   tileSlice(b, t, blob, sizeGiven);
@@ -1093,7 +1109,7 @@ static void launchFastDecodeT(int stage, int nRows, int nCols, const FastDecodeB
   switch (stage)
   {
     case 0:
-      hipLaunchKernelGGL(k_fast_discover<DT>, dim3(t.nWaves, nT), dim3(256), 0, st, b, t, blob, sizeGiven, nRows, nCols);
+      hipLaunchKernelGGL(k_fast_discover<DT>, dim3(t.nWaves, nT), dim3(kDiscThreads), 0, st, b, t, blob, sizeGiven, nRows, nCols);
       break;
     case 1:
       hipLaunchKernelGGL(k_fast_resolve, dim3((t.nChunks + kResolveWG - 1) / kResolveWG, nT), dim3(kResolveWG), 0, st, b, t);

@@ -13,10 +13,12 @@
     if (reset) { unsigned long long z[32] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)); } }
 #define PROBE_BEGIN unsigned long long probeT_ = clock64()
 #define PROBE(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = clock64(); atomicAdd(&g_probe[i], n_ - probeT_); probeT_ = n_; } } while (0)
+#define PROBE_DRAIN asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")    // so that a phase is charged its own loads
 #else
 #define PROBE_DEFINE(tag)
 #define PROBE_BEGIN
 #define PROBE(i)
+#define PROBE_DRAIN
 #endif
 
 namespace lerc {
@@ -55,6 +57,35 @@ __device__ __forceinline__ bool lastArrival(u32* ticket, u32 expected)
 }
 
 // ------------------------------------------------------------------------------------------------
+// 8- and 16-byte vector accesses with the "non-temporal" hint (streamed once: do not displace what other kernels of the
+// call still want from the caches)
+// ------------------------------------------------------------------------------------------------
+typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+template<class Vec> __device__ __forceinline__ void storeStreaming(Vec* dst, const Vec& v)
+{
+  static_assert(sizeof(Vec) == 8 || sizeof(Vec) == 16, "vector store");
+#ifdef HIPSIM
+  *dst = v;
+#else
+  if (sizeof(Vec) == 16) { u32x4_t x; memcpy(&x, &v, 16); __builtin_nontemporal_store(x, reinterpret_cast<u32x4_t*>(dst)); }
+  else { u32x2_t x; memcpy(&x, &v, 8); __builtin_nontemporal_store(x, reinterpret_cast<u32x2_t*>(dst)); }
+#endif
+}
+template<class Vec> __device__ __forceinline__ Vec loadStreaming(const Vec* src)
+{
+  static_assert(sizeof(Vec) == 8 || sizeof(Vec) == 16, "vector load");
+#ifdef HIPSIM
+  return *src;
+#else
+  Vec v;
+  if (sizeof(Vec) == 16) { const u32x4_t x = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(src)); memcpy(&v, &x, 16); }
+  else { const u32x2_t x = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(src)); memcpy(&v, &x, 8); }
+  return v;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // Cross-lane moves that stay in the VALU (no LDS traffic, unlike ds_bpermute behind __shfl*):
 // DPP (data parallel primitives) inside a row of 16 lanes, v_permlane{16,32}_swap across rows (gfx950).
 // A lane whose DPP source does not exist keeps its own value.
@@ -82,7 +113,10 @@ template<int CTRL> __device__ __forceinline__ u32 dppMov(u32 v)
   else if (CTRL == kDppRowHalfMirror) src = (lane & ~7) | (7 - (lane & 7));
   return __shfl(v, src);
 #else
-  return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+  // the shifts keep a lane's own value where its source lane does not exist; the permutations (every lane has a
+  // source) are written with "bound_ctrl", the form hipcc folds into the consuming VALU instruction (v_add_u32_dpp ...)
+  if (CTRL == kDppRowShr1 || CTRL == kDppWaveShr1) return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+  return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 #endif
 }
 
@@ -138,9 +172,39 @@ template<int G, class X, class Op> __device__ __forceinline__ X groupReduce(X v,
   return v;
 }
 
-struct OpMin { template<class X> __device__ __forceinline__ X operator()(X a, X b) const { return b < a ? b : a; } };
-struct OpMax { template<class X> __device__ __forceinline__ X operator()(X a, X b) const { return b > a ? b : a; } };
+// Floating point minima / maxima go through v_min_f32 / v_max_f32 (one instruction, and the DPP move of a reduction
+// step folds into it) instead of compare + select.  The two differ only where a NaN is involved, and a band with a
+// NaN in it leaves the streaming kernels for the general path before any of these results is used.
+struct OpMin
+{
+  template<class X> __device__ __forceinline__ X operator()(X a, X b) const { return b < a ? b : a; }
+  __device__ __forceinline__ float operator()(float a, float b) const { return __builtin_fminf(a, b); }
+  __device__ __forceinline__ double operator()(double a, double b) const { return __builtin_fmin(a, b); }
+};
+struct OpMax
+{
+  template<class X> __device__ __forceinline__ X operator()(X a, X b) const { return b > a ? b : a; }
+  __device__ __forceinline__ float operator()(float a, float b) const { return __builtin_fmaxf(a, b); }
+  __device__ __forceinline__ double operator()(double a, double b) const { return __builtin_fmax(a, b); }
+};
 struct OpSum { template<class X> __device__ __forceinline__ X operator()(X a, X b) const { return a + b; } };
+
+// minimum and maximum of float values over groups of 16 lanes (a DPP row) in one go: v_min_f32 / v_max_f32 with the
+// lane permutation as an operand modifier, four steps of two instructions (hipcc does not fold the move into a
+// floating point minimum itself, because it wants to quiet signalling NaNs first)
+__device__ __forceinline__ void rowMinMax(float& mn, float& mx)
+{
+#ifdef HIPSIM
+  mn = groupReduce<16>(mn, OpMin()); mx = groupReduce<16>(mx, OpMax());
+#else
+  // s_nop 1: a DPP operand must not have been written by the VALU instruction right in front (2 wait states)
+  asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\tv_min_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\tv_min_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\tv_min_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf"
+      : "+v"(mn), "+v"(mx));
+#endif
+}
 
 // whole-wave all-reduces (32- and 64-bit payloads)
 template<class T> __device__ __forceinline__ T waveMin(T v) { return groupReduce<64>(v, OpMin()); }
