@@ -62,6 +62,10 @@ public:
   void* pinnedAux(size_t bytes);
   hipEvent_t auxEvent();
   bool sync();                               // wait for the active stream (polls first: see codec_common.cpp)
+  // Device memory that keeps its contents from call to call (the two-launch encoder's arrival counters and cells,
+  // tile_fast.h): zero when handed out for the first time and whenever it had to grow.  Two areas: [0] counters, which the
+  // kernels leave zero, and [1] cells tagged with the call's epoch, which they leave as they are.
+  u8* persistentState(int area, size_t bytes);
   // a value no earlier call of this context has used and that no fill pattern looks like: kernels raise flags by
   // writing it into cells that are never cleared (tile_fast.h)
   u32 nextEpoch() { m_epoch += 0x9E3779B9u; if ((m_epoch & 0xFFFFu) == (m_epoch >> 16) || m_epoch == 0u) m_epoch += 0x9E3779B9u; return m_epoch; }
@@ -92,6 +96,9 @@ private:
   hipEvent_t profEvent();
 
   u8* m_asyncPinned = nullptr;
+  u8* m_state[2] = { nullptr, nullptr };
+  size_t m_stateCap[2] = { 0, 0 };
+  unsigned long long m_stateCalls = 0;
   bool m_ok = false;
   u32 m_epoch = 0x1234567u;
   hipStream_t m_stream = nullptr, m_userStream = nullptr;

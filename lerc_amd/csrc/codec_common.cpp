@@ -244,6 +244,7 @@ Context::~Context()
   if (m_pinned) hipHostFree(m_pinned);
   if (m_pinnedAux) hipHostFree(m_pinnedAux);
   if (m_asyncPinned) hipHostFree(m_asyncPinned);
+  for (u8* st : m_state) if (st) hipFree(st);
   if (m_auxEvent) hipEventDestroy(m_auxEvent);
   for (hipEvent_t e : m_eventPool) hipEventDestroy(e);
   if (m_stream) hipStreamDestroy(m_stream);
@@ -287,6 +288,24 @@ void* Context::pinned(size_t bytes)
   if (hipHostMalloc(&m_pinned, bytes + 4096, hipHostMallocDefault) != hipSuccess) return nullptr;
   m_pinnedCap = bytes + 4096;
   return m_pinned;
+}
+
+u8* Context::persistentState(int area, size_t bytes)
+{
+  // (the cells of area 1 carry the call's 32-bit epoch: long before a tag can come round again, wipe them)
+  const bool wipe = area == 1 && (++m_stateCalls & ((1ull << 30) - 1)) == 0;
+  if (bytes <= m_stateCap[area] && !wipe) return m_state[area];
+  hipStreamSynchronize(activeStream());
+  if (bytes > m_stateCap[area])
+  {
+    if (m_state[area]) hipFree(m_state[area]);
+    m_state[area] = nullptr; m_stateCap[area] = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipMalloc((void**)&m_state[area], want) != hipSuccess) { lastError = "lerc_amd: hipMalloc failed"; return nullptr; }
+    m_stateCap[area] = want;
+  }
+  if (hipMemset(m_state[area], 0, m_stateCap[area]) != hipSuccess) return nullptr;
+  return m_state[area];
 }
 
 u8* Context::asyncSlot(unsigned ticket)

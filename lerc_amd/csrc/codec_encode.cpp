@@ -708,23 +708,47 @@ static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double
   const size_t nT = nTiles;
   FastEncodeBuffers& fb = fl.fb;
   fl.batch.nTiles = nTiles; fl.batch.nWG = nWG; fl.batch.tileElems = tileElems; fl.batch.nBlobsMore = 0;
-  fb.desc = ctx.allocT<FastBlockDesc>(nT * nWG * kFastBlocksPerWG);
-  fb.wgSize = ctx.allocT<u32>(nT * fastWgStride(nWG) + 4);
-  fb.wgBase = ctx.allocT<u32>(nT * fastWgStride(nWG) + 4);
-  fb.wgMinKey = ctx.allocT<u64>(nT * nWG + 4);
-  fb.wgMaxKey = ctx.allocT<u64>(nT * nWG + 4);
-  fb.wgFlags = ctx.allocT<u32>(nT * nWG + 4);
-  fb.groupBase = ctx.allocT<u32>(nT * (fastScanGroups(nWG) + 1) + 4);
-  fb.scanPart = ctx.allocT<u64>(kScanPartWords * nT * fastScanGroups(nWG) + 4);
-  fb.packPart = ctx.allocT<u64>(nT * fastPackGroups(nWG) + 4);
-  fb.tickets = ctx.allocT<u32>(nT * fastTicketStride(nWG) + 4);
-  fb.result = ctx.allocT<FastEncodeResult>(nT);
-  fb.prefixStage = ctx.allocT<u8>(nT * kFastPrefixStage);
-  fb.tileOffset = arena ? ctx.allocT<u64>(nT + 1) : nullptr;
-  if (!fb.desc || !fb.wgSize || !fb.wgBase || !fb.wgMinKey || !fb.wgMaxKey || !fb.wgFlags || !fb.result
-    || !fb.groupBase || !fb.scanPart || !fb.packPart || !fb.tickets
-    || !fb.prefixStage || (arena && !fb.tileOffset))
-    return false;
+  memset(&fb.solo, 0, sizeof(fb.solo));
+  if (nTiles == 1 && !arena && fastSoloOk(dt, nRows, nCols))
+  {
+    // one raster: two launches, the pack step's first blocks scan and decide (tile_fast.h)
+    memset(&fb, 0, sizeof(fb));
+    const size_t nGroups = fastPackGroups(nWG);
+    u8* counters = ctx.persistentState(0, (nGroups + 1) * 8 + 256);
+    u8* cells = ctx.persistentState(1, (size_t)nWG * 8 + 256);
+    fb.desc = ctx.allocT<FastBlockDesc>((size_t)nWG * kFastBlocksPerWG);
+    fb.wgSize = ctx.allocT<u32>(fastWgStride(nWG) + 4);
+    fb.wgMinKey = ctx.allocT<u64>(nWG + 4);
+    fb.wgMaxKey = ctx.allocT<u64>(nWG + 4);
+    fb.wgFlags = ctx.allocT<u32>(nWG + 4);
+    fb.tickets = ctx.allocT<u32>(fastTicketStride(nWG) + 4);
+    fb.result = ctx.allocT<FastEncodeResult>(1);
+    fb.prefixStage = ctx.allocT<u8>(kFastPrefixStage);
+    if (!counters || !cells || !fb.desc || !fb.wgSize || !fb.wgMinKey || !fb.wgMaxKey || !fb.wgFlags || !fb.tickets || !fb.result || !fb.prefixStage)
+      return false;
+    fb.packPart = (u64*)counters;
+    fb.solo.cells = (u64*)cells;
+  }
+  else
+  {
+    fb.desc = ctx.allocT<FastBlockDesc>(nT * nWG * kFastBlocksPerWG);
+    fb.wgSize = ctx.allocT<u32>(nT * fastWgStride(nWG) + 4);
+    fb.wgBase = ctx.allocT<u32>(nT * fastWgStride(nWG) + 4);
+    fb.wgMinKey = ctx.allocT<u64>(nT * nWG + 4);
+    fb.wgMaxKey = ctx.allocT<u64>(nT * nWG + 4);
+    fb.wgFlags = ctx.allocT<u32>(nT * nWG + 4);
+    fb.groupBase = ctx.allocT<u32>(nT * (fastScanGroups(nWG) + 1) + 4);
+    fb.scanPart = ctx.allocT<u64>(kScanPartWords * nT * fastScanGroups(nWG) + 4);
+    fb.packPart = ctx.allocT<u64>(nT * fastPackGroups(nWG) + 4);
+    fb.tickets = ctx.allocT<u32>(nT * fastTicketStride(nWG) + 4);
+    fb.result = ctx.allocT<FastEncodeResult>(nT);
+    fb.prefixStage = ctx.allocT<u8>(nT * kFastPrefixStage);
+    fb.tileOffset = arena ? ctx.allocT<u64>(nT + 1) : nullptr;
+    if (!fb.desc || !fb.wgSize || !fb.wgBase || !fb.wgMinKey || !fb.wgMaxKey || !fb.wgFlags || !fb.result
+      || !fb.groupBase || !fb.scanPart || !fb.packPart || !fb.tickets
+      || !fb.prefixStage || (arena && !fb.tileOffset))
+      return false;
+  }
   fl.cand = 0;
   if (isFlt)
   {
@@ -750,11 +774,15 @@ static void runFastEncode(Context& ctx, const FastEncodeLaunch& fl, const void* 
   // one kernel per stage (and per profiling group): statistics (+ first-row rounding errors), scan + decide (+ tile
   // placement for batches), pack + checksum
   static const char* kStage[3] = { "fast_stats_sizes", "fast_scan_decide", "fast_pack" };
-  const int nStages = dOut ? 3 : 2;    // no output buffer: the size is known after the decisions
+  // (no output buffer: the size is known after the decisions -- one raster: the pack step's last workgroup takes them)
+  const int nStages = (dOut || fl.fb.solo.cells) ? 3 : 2;
   for (int stage = 0; stage < nStages; stage++)
   {
+    if (stage == 1 && fl.fb.solo.cells) continue;    // (one raster: the pack step scans and decides itself)
     ProfScope ps(ctx, kStage[stage]);
-    launchFastEncode(stage, fl.bp, fl.maxZErr, fl.cand, dData, dOut, capacity, arenaBase, fl.fb, fl.batch, ctx.activeStream());
+    FastEncodeBuffers fb = fl.fb;
+    if (stage == 2 && fb.solo.cells) fb.solo.epoch = ctx.nextEpoch();    // (never 0, the tag of a cell nobody has written yet)
+    launchFastEncode(stage, fl.bp, fl.maxZErr, fl.cand, dData, dOut, capacity, arenaBase, fb, fl.batch, ctx.activeStream());
   }
 }
 

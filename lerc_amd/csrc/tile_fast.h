@@ -52,6 +52,21 @@ LERC_HD u32 fastWgStride(u32 nWG) { return (nWG + 7u) & ~3u; }    // elements fr
 static const u32 kScanPartWords = 12;
 static const int kFastPrefixStage = 128;   // bytes reserved per tile for header + mask count + ranges + mode byte
 
+// One raster (no batch) is encoded in two launches: the statistics step, then a pack step whose first blocks do the scan and
+// take the decisions while the others pack (k_fast_pack<SOLO>).  The cells live as long as the codec context.
+static const u32 kSoloSlice = 4096;        // workgroups one scan block places (16 per thread)
+struct FastSolo
+{
+  u64* cells;          // [nWG] epoch (32) | where the workgroup's span starts behind the header (32); nullptr: not this mode
+  u32 epoch;
+};
+// rasters that mode takes: its byte counts are 32 bits wide
+LERC_HD bool fastSoloOk(int dt, int nRows, int nCols)
+{
+  const u64 nBlocks = (u64)(nRows / 8) * (u64)(nCols / 8);
+  return nBlocks * (1 + 64 * (u64)dtSize(dt)) + 256 < 0xFFFFFFFFull;
+}
+
 struct FastEncodeBuffers
 {
   FastBlockDesc* desc; // [nWG * 64]
@@ -60,7 +75,7 @@ struct FastEncodeBuffers
   u32* groupBase;      // [nScanGroups + 1] bytes in front of each scan group
   u64* scanPart;       // [kScanPartWords * nScanGroups] what a scan workgroup found: bytes | flags << 32, min key, max key, and (float
                        // types) the largest rounding error of its share of the first raster row per TryRaiseMaxZError candidate
-  u64* packPart;       // [nPackGroups] Fletcher sums of a pack group's workgroups and how many have arrived: A | B << 24 | n << 48
+  u64* packPart;       // [nPackGroups (+ 1 one raster: the deciding block)] Fletcher sums of a pack group's workgroups and how many have arrived: A | B << 24 | n << 48
   u32* tickets;        // [fastTicketStride] [0] arrival counter of the scan workgroups
                        // (each kernel zeroes what the next one counts in: the statistics step the scan's ticket, the scan's last
                        // workgroup the pack step's accumulators)
@@ -70,6 +85,7 @@ struct FastEncodeBuffers
   u8* prefixStage;     // [kFastPrefixStage] the bytes in front of the first block, written by the decide step, copied by the pack step
   u64* tileOffset;     // [nTiles + 1] where each tile's blob starts in the output arena; nullptr: a single raster at offset 0
   FastEncodeResult* result;
+  FastSolo solo;
 };
 
 bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, double maxZErr);

@@ -264,8 +264,8 @@ k_fast_stats(const T* __restrict__ data, BandParams p, FastBlockDesc* __restrict
   const u64 kMin = waveMin(FKey<T>::enc(mn)), kMax = waveMax(FKey<T>::enc(mx));
   if (lane == 0)
   {
-    // per-workgroup partial results, folded by k_fast_scan_decide (thousands of workgroups hammering a few
-    // addresses with atomics cost more than the whole pass)
+    // per-workgroup partial results, folded by k_fast_scan_decide resp. the first blocks of k_fast_pack<SOLO> (thousands of
+    // workgroups hammering a few addresses with atomics cost more than the whole pass)
     wgSize[blockIdx.x] = total;
     wgMinKey[blockIdx.x] = kMin;
     wgMaxKey[blockIdx.x] = kMax;
@@ -287,7 +287,7 @@ __device__ __forceinline__ double keyToDouble(int dt, u64 key, u64& raw)
 }
 
 // lane 0 of a wave decides; `prefix` (LDS) receives the bytes in front of the first block
-__device__ __forceinline__ void
+__device__ __forceinline__ u32
 fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u32 nBytesTiling, u64 minKey, u64 maxKey, u32 flags,
            const u64* raiseBits /* [9] largest first-row rounding error per candidate, as bit patterns */, u32 nBlobsMore, u8* prefix,
            u64 outCapacity, FastEncodeResult* res)
@@ -332,7 +332,7 @@ fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u3
   res->minKey = a; res->maxKey = b;
   res->prefixLen = prefixLen;
   res->checksum = 0;
-  if (redo) return;
+  if (redo) return redo;
 
   // header + "no mask" + ranges + "not one sweep" (Lerc2.cpp:396-430)
   u8* o = prefix;
@@ -349,6 +349,7 @@ fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u3
   putBytes(o + 94, rawMin, tb);
   putBytes(o + 94 + tb, rawMax, tb);
   o[94 + 2 * tb] = 0;
+  return 0u;
 }
 
 // The scan of the workgroup sizes, the fold of the per-workgroup statistics and the decisions in one launch: every
@@ -543,13 +544,147 @@ __device__ __forceinline__ void fletcherWord(u32 x, u32 pos, u64& A, u64& B)
   B += (u64)k * w0 + (u64)(k + 1) * w1;
 }
 
-template<class T, bool WIDE>
+// One raster (k_fast_pack<SOLO>): the first blocks of the launch are no pack workgroups.  Block s places the workgroups
+// s * kSoloSlice ... of the stream -- the sum of all sizes in front of its slice, then a scan of the slice; no block needs
+// another -- and publishes a cell per workgroup, epoch (32) | first byte behind the header (32), with write-through
+// stores; a pack workgroup polls its own cell only (a word that every workgroup polls was tried: memory serves one
+// address at about 90 reads per microsecond), and only the workgroups of the first round ever wait, with their pixels
+// loaded and packed by then.  Block 0 also takes the decisions the reference takes between its sweeps, out of what the
+// statistics step left: the largest first-row rounding errors (Lerc2::TryRaiseMaxZError), the fold of the per-workgroup
+// statistics, fastDecide.  The bytes in front of the first block and the verdict go to `prefixStage`, write-through too;
+// the last pack workgroup picks them up for the checksum.
+template<class T>
+__device__ __forceinline__ void
+soloScanDecide(u32 s, const T* __restrict__ data, const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u32 nWG, u32 nBlobsMore,
+               const u32* __restrict__ wgSize, const u64* __restrict__ wgMinKey, const u64* __restrict__ wgMaxKey, const u32* __restrict__ wgFlags,
+               u64* __restrict__ cells, u32 epoch, u8* __restrict__ prefixStage, u64 outCapacity, FastEncodeResult* __restrict__ res,
+               u64* __restrict__ arrived, bool pack)
+{
+  __shared__ u64 s_min[4], s_max[4], s_rw[4][9], s_raise[9];
+  __shared__ u32 s_fl[4], s_sum[4], s_w[4], s_redo;
+  __shared__ __align__(16) u8 s_prefix[kFastPrefixStage];
+  const int w = waveId(), lane = laneId();
+  const u32 lastVec = (nWG - 1u) & ~3u;                      // clamped loads (the array has slack up to a multiple of 4)
+  // ---- the sizes in front of the slice (block 0: all of them, that is the total)
+  const u32 sliceBegin = s * kSoloSlice, sumEnd = s ? sliceBegin : nWG;
+  u32 sum = 0;
+#pragma unroll 4
+  for (u32 i = 4u * threadIdx.x; i < sumEnd; i += 1024u)
+  {
+    const uint4 x = *reinterpret_cast<const uint4*>(wgSize + min(i, lastVec));
+    sum += x.x + (i + 1u < sumEnd ? x.y : 0u) + (i + 2u < sumEnd ? x.z : 0u) + (i + 3u < sumEnd ? x.w : 0u);
+  }
+  sum = waveSum(sum);
+  if (lane == 0) s_sum[w] = sum;
+  // ---- the slice: 16 sizes per thread
+  u32 e[16], mine = 0;
+  const u32 i0 = sliceBegin + 16u * threadIdx.x;
+#pragma unroll
+  for (u32 q = 0; q < 4; q++)
+  {
+    const uint4 x = *reinterpret_cast<const uint4*>(wgSize + min(i0 + 4u * q, lastVec));
+    e[4 * q] = x.x; e[4 * q + 1] = x.y; e[4 * q + 2] = x.z; e[4 * q + 3] = x.w;
+  }
+#pragma unroll
+  for (u32 k = 0; k < 16; k++) { e[k] = (i0 + k < nWG) ? e[k] : 0u; mine += e[k]; }
+  const u32 inc = waveInclusiveScan(mine);
+  if (lane == 63) s_w[w] = inc;
+  __syncthreads();
+  const u32 total = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];    // in front of the slice; block 0: of the whole stream
+  u32 run = (s ? total : 0u) + inc - mine;
+  for (int i = 0; i < w; i++) run += s_w[i];
+#pragma unroll
+  for (u32 k = 0; k < 16; k++)
+  {
+    if (i0 + k < nWG) publish64(cells + i0 + k, ((u64)epoch << 32) | run);
+    run += e[k];
+  }
+  if (s != 0u) return;
+
+  // ---- block 0: the decisions
+  const bool doRaise = DtOf<T>::v >= DT_Float && raiseCandidates != 0u;
+  if (doRaise)
+  {
+    const int facCand[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
+    double rerr[9];
+#pragma unroll
+    for (int cnd = 0; cnd < 9; cnd++) rerr[cnd] = 0;
+#pragma unroll 2
+    for (u32 col = threadIdx.x; col < (u32)p.nCols; col += 256u)
+    {
+      const double x = (double)data[col];
+      if (x != x) continue;    // a NaN sends the band to the general path anyway
+      bool exact = false;
+#pragma unroll
+      for (int cnd = 0; cnd < 9; cnd++)    // candidates in increasing factor order, stop at the first exact hit
+      {
+        if (exact || !((raiseCandidates >> cnd) & 1u)) continue;
+        const double z = x * facCand[cnd];
+        if (z == (double)(int)z) { exact = true; continue; }
+        const double dlt = fabs(floor(z + 0.5) - z);
+        rerr[cnd] = dlt > rerr[cnd] ? dlt : rerr[cnd];
+      }
+    }
+#pragma unroll
+    for (int cnd = 0; cnd < 9; cnd++)
+    {
+      u64 bits; const double er = rerr[cnd]; memcpy(&bits, &er, 8);    // non-negative doubles order like their bit patterns
+      bits = waveMax(bits);
+      if (lane == 0) s_rw[w][cnd] = bits;
+    }
+  }
+  u64 kMin = ~0ull, kMax = 0ull;
+  u32 fl = 0;
+#pragma unroll 4
+  for (u32 i = threadIdx.x; i < nWG; i += 256u)
+  {
+    const u64 x = wgMinKey[i], y = wgMaxKey[i];
+    kMin = x < kMin ? x : kMin; kMax = y > kMax ? y : kMax; fl |= wgFlags[i];
+  }
+  kMin = waveMin(kMin); kMax = waveMax(kMax);
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) fl |= __shfl_xor(fl, m);
+  if (lane == 0) { s_min[w] = kMin; s_max[w] = kMax; s_fl[w] = fl; }
+  __syncthreads();
+  if (threadIdx.x < 9)
+  {
+    u64 m = 0;    // (+0.0)
+    if (doRaise) for (int i = 0; i < 4; i++) m = s_rw[i][threadIdx.x] > m ? s_rw[i][threadIdx.x] : m;
+    s_raise[threadIdx.x] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    u64 a = ~0ull, b = 0ull;
+    u32 f = 0;
+    for (int i = 0; i < 4; i++) { a = s_min[i] < a ? s_min[i] : a; b = s_max[i] > b ? s_max[i] : b; f |= s_fl[i]; }
+    s_redo = fastDecide(p, requestedMaxZErr, raiseCandidates, total, a, b, f, doRaise ? s_raise : nullptr, nBlobsMore, s_prefix, outCapacity, res);
+  }
+  __syncthreads();
+  if (!pack) return;    // (a size query)
+  if (threadIdx.x < kFastPrefixStage / 8 - 1) publish64(reinterpret_cast<u64*>(prefixStage) + threadIdx.x, reinterpret_cast<const u64*>(s_prefix)[threadIdx.x]);
+  if (threadIdx.x == kFastPrefixStage / 8 - 1) publish64(reinterpret_cast<u64*>(prefixStage) + threadIdx.x, (u64)s_redo);    // (the prefix is at most 111 bytes long)
+  drainVmem();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(arrived, 1ull << 48, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// SOLO (one raster, no batch; right behind k_fast_stats, no scan step in between): the first blocks scan and decide
+// (soloScanDecide), the others pack.  A pack workgroup assembles its span in LDS at byte 16 -- where it goes in the blob
+// is only needed when the bytes leave -- and then reads its cell; the last one, once everybody has arrived, adds the
+// header to the checksum, writes both and leaves the arrival counters zero for the next call.  If a decision says "not
+// this path" (NaN, all-integer floats, ...) the bytes written are garbage and the host redoes the band on the general
+// path.  out == nullptr: a size query, launched with block 0 alone.
+template<class T, bool WIDE, bool SOLO>
 __global__ void __launch_bounds__(256)
 k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __restrict__ desc, const u32* __restrict__ wgSize,
             const u32* __restrict__ wgBase, const u32* __restrict__ groupBase, u8* __restrict__ out,
             u64* __restrict__ packPart, FastEncodeResult* __restrict__ res,
-            const u8* __restrict__ prefixStage, const u64* __restrict__ tileOffset, FastBatch batch)
+            u8* __restrict__ prefixStage, const u64* __restrict__ tileOffset, FastBatch batch,
+            FastSolo solo, const u64* __restrict__ wgMinKey, const u64* __restrict__ wgMaxKey, const u32* __restrict__ wgFlags,
+            double requestedMaxZErr, u32 raiseCandidates, u64 outCapacity)
 {
+  if (!SOLO)
   {
     const size_t tile = blockIdx.y;
     data += tile * batch.tileElems; desc += tile * batch.nWG * kFastBlocksPerWG; wgBase += tile * fastWgStride(batch.nWG);
@@ -561,18 +696,27 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
   typedef FastCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW, IT = C::IT;
   constexpr int kMaxBlockBytes = 1 + 64 * (int)sizeof(T);
-  constexpr int kSpanWords = (kFastBlocksPerWG * kMaxBlockBytes + 16) / 4 + 8;
+  constexpr u32 kLead = 16;                  // SOLO: zero bytes in front of the image (the flush reads up to 15 bytes before it)
+  constexpr int kSpanWords = (kFastBlocksPerWG * kMaxBlockBytes + 16) / 4 + 8 + (SOLO ? (int)kLead / 4 : 0);
   __shared__ __align__(16) u32 s_out[kSpanWords];
   __shared__ u64 s_mn[kFastBlocksPerWG];
   __shared__ u32 s_w1[kFastBlocksPerWG];
   __shared__ u32 s_bit[kFastBlocksPerWG];    // bit position of each block inside s_out
   __shared__ u64 s_fa[4], s_fb[4];
+  __shared__ u32 s_spanBase;
   PROBE_BEGIN;
   const int w = waveId(), lane = laneId();
   const int r = lane >> 3, c = lane & 7, b = c / LPR, h = c % LPR;
+  const u32 nScanBlocks = SOLO ? (batch.nWG + kSoloSlice - 1u) / kSoloSlice : 0u;
+  if (SOLO && blockIdx.x < nScanBlocks)
+  {
+    soloScanDecide<T>(blockIdx.x, data, p, requestedMaxZErr, raiseCandidates, batch.nWG, batch.nBlobsMore, wgSize, wgMinKey, wgMaxKey, wgFlags,
+                      solo.cells, solo.epoch, prefixStage, outCapacity, res, packPart + fastPackGroups(batch.nWG), out != nullptr);
+    return;
+  }
   // (tried: back to front, so that the workgroups dispatched first meet the end of the raster, which the statistics kernel
   // read last and the Infinity Cache might still hold -- no difference, 81.7 against 81.4 us)
-  const u32 wg = blockIdx.x;
+  const u32 wg = blockIdx.x - nScanBlocks;
   const FastSpan span = fastSpanOf(wg, (u32)p.nTH, (u32)p.nTV);
 
   // pixels first (long latency; nothing they need comes out of memory), descriptors by one wave, then -- in one go, not
@@ -583,16 +727,24 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
   FastBlockDesc d;
   const int wPlan = (int)((wg * 2654435761u) >> 30);    // the wave that does the per-block work rotates (see k_fast_stats)
   if (w == wPlan) d = desc[(size_t)wg * kFastBlocksPerWG + lane];
-  const u32 redo = res->redo, prefixLen = res->prefixLen;
-  const u32 spanBase = groupBase[wg / kFastScanGroup] + wgBase[wg];
+  u32 prefixLen, spanBase = 0;    // (SOLO: known when the span leaves)
   const u32 spanLen = wgSize[wg];
-  if (redo) return;
-  // the bytes in front of the first block (header, mask count, ranges, mode byte) come from the decide step
-  // (without the checksum, bytes 10 .. 13: the workgroup that arrives last writes it, possibly through another XCD's L2, and
-  // a second dirty copy of those bytes here could reach memory after it)
-  if (wg == 0 && threadIdx.x < prefixLen && (threadIdx.x < 10 || threadIdx.x >= 14)) out[threadIdx.x] = prefixStage[threadIdx.x];
-  const u32 g0 = prefixLen + spanBase;                      // absolute offset of this workgroup's span
-  const u32 ldsShift = g0 & 15u;                            // LDS byte i <-> blob byte (g0 & ~15) + i
+  // SOLO: where the span goes is in this workgroup's cell -- asked for now, looked at when the span is packed (it has been
+  // there long before, except for the workgroups of the launch's first round)
+  u64 cell = 0;
+  if (SOLO && threadIdx.x == 0) cell = observe64(solo.cells + wg);
+  if (SOLO) prefixLen = 90u + 4u + 2u * (u32)sizeof(T) + 1u;    // header, mask byte count, ranges, "not one sweep" (fastDecide)
+  else
+  {
+    const u32 redo = res->redo;
+    prefixLen = res->prefixLen;
+    spanBase = groupBase[wg / kFastScanGroup] + wgBase[wg];
+    if (redo) return;
+    // the bytes in front of the first block (header, mask count, ranges, mode byte) come from the decide step
+    // (without the checksum, bytes 10 .. 13: the workgroup that arrives last writes it, possibly through another XCD's L2, and
+    // a second dirty copy of those bytes here could reach memory after it)
+    if (wg == 0 && threadIdx.x < prefixLen && (threadIdx.x < 10 || threadIdx.x >= 14)) out[threadIdx.x] = prefixStage[threadIdx.x];
+  }
   for (int i = threadIdx.x; i < kSpanWords; i += 256) s_out[i] = 0;
   if (w == wPlan)
   {
@@ -601,7 +753,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
 #pragma unroll
     for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(inc, (unsigned)dd); if (lane >= dd) inc += o; }
     s_mn[lane] = d.mnBits; s_w1[lane] = d.w1;
-    s_bit[lane] = 8u * (ldsShift + inc - sz);
+    s_bit[lane] = 8u * ((SOLO ? kLead : ((prefixLen + spanBase) & 15u)) + inc - sz);
   }
   __syncthreads();
   PROBE(4);
@@ -613,7 +765,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
     const int kind = (int)((w1 >> 16) & 7u), tc = (int)((w1 >> 19) & 3u), dtRed = (int)((w1 >> 21) & 7u), nb = (int)(w1 >> 24);
     const int j0 = (int)fastSpanCol(span, (u32)lane) * 8;
     u32 flag = (u32)(((j0 >> 3) & 15) << 2) & 0x38u;    // version 6, no slice difference
-    const u32 at0 = 8u * (ldsShift) + (s_bit[lane] - 8u * ldsShift);
+    const u32 at0 = s_bit[lane];
     if (kind == 7) { }    // no such block (last workgroup of a raster whose block count is no multiple of 64)
     else if (kind == 0) orBits(s_out, at0, flag | 2u, 8);
     else if (kind == 1) orBits(s_out, at0, flag, 8);
@@ -713,14 +865,59 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
       }
     }
   }
+  if (SOLO && threadIdx.x == 0)
+  {
+    for (u32 spin = 0; (u32)(cell >> 32) != solo.epoch && spin < (1u << 22); spin++)    // (never that long: the scan blocks were dispatched before this one)
+    {
+      __builtin_amdgcn_s_sleep(8);
+      cell = observe64(solo.cells + wg);
+    }
+    s_spanBase = (u32)cell;
+  }
   __syncthreads();
   PROBE(6);
+  if (SOLO) spanBase = s_spanBase;
+  const u32 g0 = prefixLen + spanBase;                      // absolute offset of this workgroup's span
+  const bool fits = !SOLO || (u64)g0 + spanLen <= outCapacity;    // (SOLO: the last workgroup reports what does not fit)
+  const u32 ldsShift = g0 & 15u;                            // non-SOLO: LDS byte i <-> blob byte (g0 & ~15) + i
 
   // ---- Fletcher sums of the bytes this workgroup owns (16-byte units of the span image; absolute blob offsets of unit
   // starts are multiples of 16, so positions inside blob[14 ..) are even), before the bytes themselves leave: the sums
   // are handed on below while the stores are still under way
   const u32 gAligned = g0 & ~15u;
   const u32 nChunks = (ldsShift + spanLen + 15) >> 4;
+  if constexpr (SOLO)
+  {
+    // Fletcher sums and flush in one go, in 16-byte units of the BLOB: unit u holds the image bytes from 16 u - (g0 & 15) on,
+    // fetched as five words and funnel shifted; what lies outside the span is zero in LDS, adds nothing to the sums and
+    // is not stored
+    u32 A = 0;
+    u64 B = 0;
+    for (u32 u = threadIdx.x; u < nChunks; u += 256)
+    {
+      const u32 at = kLead + 16u * u - ldsShift;            // LDS byte of the unit's first byte (>= 1)
+      const u32 wd0 = at >> 2, sh = 8u * (at & 3u);
+      const u32 x0 = s_out[wd0], x1 = s_out[wd0 + 1], x2 = s_out[wd0 + 2], x3 = s_out[wd0 + 3], x4 = s_out[wd0 + 4];
+      uint4 x;
+      x.x = __builtin_amdgcn_alignbit(x1, x0, sh); x.y = __builtin_amdgcn_alignbit(x2, x1, sh);
+      x.z = __builtin_amdgcn_alignbit(x3, x2, sh); x.w = __builtin_amdgcn_alignbit(x4, x3, sh);
+      // (gAligned + 16 u >= 16 > 14 always holds here because spans start behind the >= 95-byte prefix)
+      fletcherUnit(x, (u64)((gAligned + 16u * u - 14u) >> 1), A, B);
+      if (!fits) continue;
+      const u32 lo = 16u * u, first = lo < ldsShift ? ldsShift : lo, last = min(lo + 16u, ldsShift + spanLen);    // owned bytes of the unit
+      if (first == lo && last == lo + 16u) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;    // (k_fast_discover reads them next: no streaming hint)
+      else
+      {
+        const u32 xs[4] = { x.x, x.y, x.z, x.w };
+#pragma unroll
+        for (u32 i = 0; i < 16; i++)
+          if (lo + i >= first && lo + i < last) out[gAligned + lo + i] = (u8)(xs[i >> 2] >> (8 * (i & 3)));
+      }
+    }
+    const u64 a = waveSum((u64)A % 65535u), b2 = waveSum(B % 65535u);
+    if (lane == 0) { s_fa[w] = a; s_fb[w] = b2; }
+  }
+  else
   {
     u32 A = 0;
     u64 B = 0;
@@ -753,54 +950,107 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
     const u64 a = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u, b2 = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
     __hip_atomic_fetch_add(packPart + wg / kFastPackGroup, a | (b2 << 24) | (1ull << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // ---- flush: 16-byte units, byte granular at the two ends
-  for (u32 ch = threadIdx.x; ch < nChunks; ch += 256)
+  if constexpr (!SOLO)
   {
-    const u32 lo = ch * 16, hi = lo + 16;
-    const u32 first = lo < ldsShift ? ldsShift : lo;
-    const u32 last = hi > ldsShift + spanLen ? ldsShift + spanLen : hi;    // owned bytes: [first, last)
-    const uint4 x = *reinterpret_cast<const uint4*>(&s_out[ch * 4]);
-    if (first == lo && last == hi) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;    // (k_fast_discover reads them next: no streaming hint)
-    else
+    // ---- flush: 16-byte units, byte granular at the two ends
+    for (u32 ch = threadIdx.x; ch < nChunks; ch += 256)
     {
-      const u32 wd[4] = { x.x, x.y, x.z, x.w };
-#pragma unroll
-      for (u32 i = 0; i < 16; i++)
-        if (lo + i >= first && lo + i < last) out[gAligned + lo + i] = (u8)(wd[i >> 2] >> (8 * (i & 3)));
+      const u32 lo = ch * 16, hi = lo + 16;
+      const u32 first = lo < ldsShift ? ldsShift : lo;
+      const u32 last = hi > ldsShift + spanLen ? ldsShift + spanLen : hi;    // owned bytes: [first, last)
+      const uint4 x = *reinterpret_cast<const uint4*>(&s_out[ch * 4]);
+      if (first == lo && last == hi) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;    // (k_fast_discover reads them next: no streaming hint)
+      else
+      {
+        const u32 wd[4] = { x.x, x.y, x.z, x.w };
+  #pragma unroll
+        for (u32 i = 0; i < 16; i++)
+          if (lo + i >= first && lo + i < last) out[gAligned + lo + i] = (u8)(wd[i >> 2] >> (8 * (i & 3)));
+      }
     }
   }
   PROBE(7);
-  if (blockIdx.x != nWG - 1u || w != 0) return;
-  u64 fA = 0, fB = 0;
-  for (u32 g0i = 0; g0i < nGroups; g0i += 64u)
+  if (wg != nWG - 1u) return;
+  if (!SOLO)
   {
-    const u32 gi = g0i + (u32)lane;
-    const u32 want = gi < nGroups ? min(kFastPackGroup, nWG - gi * kFastPackGroup) : 0u;
-    u64 acc = 0;
-    for (u32 spin = 0; ; spin++)
+    if (w != 0) return;
+    u64 fA = 0, fB = 0;
+    for (u32 g0i = 0; g0i < nGroups; g0i += 64u)
     {
-      acc = gi < nGroups ? observe64(packPart + gi) : 0ull;
-      if (!__any((u32)(acc >> 48) != want)) break;
-      if (spin > (1u << 22)) break;          // (never: every other workgroup was dispatched before this one)
-      __builtin_amdgcn_s_sleep(8);
+      const u32 gi = g0i + (u32)lane;
+      const u32 want = gi < nGroups ? min(kFastPackGroup, nWG - gi * kFastPackGroup) : 0u;
+      u64 acc = 0;
+      for (u32 spin = 0; ; spin++)
+      {
+        acc = gi < nGroups ? observe64(packPart + gi) : 0ull;
+        if (!__any((u32)(acc >> 48) != want)) break;
+        if (spin > (1u << 22)) break;          // (never: every other workgroup was dispatched before this one)
+        __builtin_amdgcn_s_sleep(8);
+      }
+      fA += acc & 0xFFFFFFull; fB += (acc >> 24) & 0xFFFFFFull;
     }
-    fA += acc & 0xFFFFFFull; fB += (acc >> 24) & 0xFFFFFFull;
+    for (u32 pos = (u32)lane; pos + 14 < res->prefixLen; pos += 64u)    // + the bytes in front of the first block
+    {
+      const u32 cw = (u32)prefixStage[14 + pos] << ((pos & 1u) ? 0 : 8);
+      fA += cw; fB += (u64)(pos >> 1) * cw;
+    }
+    fA = waveSum(fA % 65535u) % 65535u; fB = waveSum(fB % 65535u) % 65535u;
+    if (lane != 0) return;
+    const u32 len = res->blobSize - 14;
+    const u64 N = ((u64)len + 1) / 2;
+    u64 s1 = fA, s2 = ((N % 65535u) * fA + 65535u - fB) % 65535u;
+    if (s1 == 0) s1 = 0xffff;
+    if (s2 == 0) s2 = 0xffff;
+    const u32 cs = (u32)((s2 << 16) | s1);
+    putBytes(out + 10, cs, 4);
+    res->checksum = cs;
+    return;
   }
-  for (u32 pos = (u32)lane; pos + 14 < res->prefixLen; pos += 64u)    // + the bytes in front of the first block
+
+  // ---- SOLO, the last workgroup: wait for everybody (block 0 included), header + checksum
+  __shared__ u32 s_redo, s_cs;
+  __shared__ __align__(16) u64 s_prefix[kFastPrefixStage / 8];
+  const u32 nBytesTiling = spanBase + spanLen;
+  if (w == 0)
   {
-    const u32 cw = (u32)prefixStage[14 + pos] << ((pos & 1u) ? 0 : 8);
-    fA += cw; fB += (u64)(pos >> 1) * cw;
+    u64 fA = 0, fB = 0;
+    for (u32 g0i = 0; g0i <= nGroups; g0i += 64u)
+    {
+      const u32 gi = g0i + (u32)lane;
+      const u32 want = gi < nGroups ? min(kFastPackGroup, nWG - gi * kFastPackGroup) : gi == nGroups ? 1u : 0u;    // (+ block 0)
+      u64 acc = 0;
+      for (u32 spin = 0; ; spin++)
+      {
+        acc = gi <= nGroups ? observe64(packPart + gi) : 0ull;
+        if (!__any((u32)(acc >> 48) != want)) break;
+        if (spin > (1u << 22)) break;          // (never: every other workgroup was dispatched before this one)
+        __builtin_amdgcn_s_sleep(8);
+      }
+      fA += acc & 0xFFFFFFull; fB += (acc >> 24) & 0xFFFFFFull;
+      if (gi <= nGroups) publish64(packPart + gi, 0ull);    // clean for the next call
+    }
+    if (lane < kFastPrefixStage / 8) s_prefix[lane] = observe64(reinterpret_cast<const u64*>(prefixStage) + lane);
+    __builtin_amdgcn_wave_barrier();
+    const u8* pre = reinterpret_cast<const u8*>(s_prefix);
+    for (u32 pos = (u32)lane; pos + 14 < prefixLen; pos += 64u)    // + the Fletcher terms of the bytes in front of the first block
+    {
+      const u32 cw = (u32)pre[14 + pos] << ((pos & 1u) ? 0 : 8);
+      fA += cw; fB += (u64)(pos >> 1) * cw;
+    }
+    fA = waveSum(fA % 65535u) % 65535u; fB = waveSum(fB % 65535u) % 65535u;
+    const u32 len = prefixLen + nBytesTiling - 14u;
+    const u64 N = ((u64)len + 1) / 2;
+    u64 s1 = fA, s2 = ((N % 65535u) * fA + 65535u - fB) % 65535u;
+    if (s1 == 0) s1 = 0xffff;
+    if (s2 == 0) s2 = 0xffff;
+    if (lane == 0) { s_cs = (u32)((s2 << 16) | s1); s_redo = (u32)s_prefix[kFastPrefixStage / 8 - 1]; }
   }
-  fA = waveSum(fA % 65535u) % 65535u; fB = waveSum(fB % 65535u) % 65535u;
-  if (lane != 0) return;
-  const u32 len = res->blobSize - 14;
-  const u64 N = ((u64)len + 1) / 2;
-  u64 s1 = fA, s2 = ((N % 65535u) * fA + 65535u - fB) % 65535u;
-  if (s1 == 0) s1 = 0xffff;
-  if (s2 == 0) s2 = 0xffff;
-  const u32 cs = (u32)((s2 << 16) | s1);
-  putBytes(out + 10, cs, 4);
-  res->checksum = cs;
+  __syncthreads();
+  if (s_redo) return;
+  const u32 cs = s_cs;
+  if (threadIdx.x < prefixLen && threadIdx.x < outCapacity)
+    out[threadIdx.x] = (threadIdx.x >= 10u && threadIdx.x < 14u) ? (u8)(cs >> (8u * (threadIdx.x - 10u))) : reinterpret_cast<const u8*>(s_prefix)[threadIdx.x];
+  if (threadIdx.x == 0) res->checksum = cs;
 }
 
 // Batches: where each tile's blob goes in the arena.  One workgroup of 1024 threads; a tile that the general path has
@@ -846,14 +1096,15 @@ bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, 
 
 u32 fastEncodeNumWG(int nRows, int nCols) { return fastNumWG(nRows, nCols); }
 
-template<class T>
+template<class T, bool SOLO>
 static void launchFastEncodeT(int stage, const BandParams& p, double requested, u32 raiseCand, const void* data, u8* out, u64 cap,
                               u64 arenaBase, const FastEncodeBuffers& b, const FastBatch& batch, hipStream_t st)
 {
   const u32 nWG = batch.nWG, nT = batch.nTiles;
+  const bool wide = p.nTH % 64 == 0;
   if (stage == 0)
   {
-    if (p.nTH % 64 == 0)
+    if (wide)
       hipLaunchKernelGGL((k_fast_stats<T, true>), dim3(nWG, nT), dim3(256), 0, st, (const T*)data, p, b.desc, b.wgSize, b.wgMinKey, b.wgMaxKey,
                          b.wgFlags, b.tickets, batch);
     else
@@ -862,6 +1113,7 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
   }
   else if (stage == 1)
   {
+    if (SOLO) return;    // (k_fast_pack<SOLO> scans and decides itself)
     // a tile of a batch may be as large as it likes here; whether the arena holds it is decided by the placement
     hipLaunchKernelGGL(k_fast_scan_decide<T>, dim3(fastScanGroups(nWG), nT), dim3(nWG <= 1024u ? 256 : 1024), 0, st, (const T*)data, p, requested, raiseCand, nWG, (const u32*)b.wgSize, b.wgBase,
                        (const u64*)b.wgMinKey, (const u64*)b.wgMaxKey, (const u32*)b.wgFlags, b.prefixStage,
@@ -871,15 +1123,26 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
   }
   else
   {
-    if (p.nTH % 64 == 0)
-      hipLaunchKernelGGL((k_fast_pack<T, true>), dim3(nWG, nT), dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc,
+    const dim3 grid = SOLO ? dim3(out ? nWG + (nWG + kSoloSlice - 1u) / kSoloSlice : 1u) : dim3(nWG, nT);    // (SOLO: + the scan blocks; a size query needs block 0 only)
+    if (wide)
+      hipLaunchKernelGGL((k_fast_pack<T, true, SOLO>), grid, dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc,
                          (const u32*)b.wgSize, (const u32*)b.wgBase, (const u32*)b.groupBase, out, b.packPart,
-                         b.result, (const u8*)b.prefixStage, (const u64*)b.tileOffset, batch);
+                         b.result, b.prefixStage, (const u64*)b.tileOffset, batch, b.solo, (const u64*)b.wgMinKey, (const u64*)b.wgMaxKey,
+                         (const u32*)b.wgFlags, requested, raiseCand, cap);
     else
-      hipLaunchKernelGGL((k_fast_pack<T, false>), dim3(nWG, nT), dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc,
+      hipLaunchKernelGGL((k_fast_pack<T, false, SOLO>), grid, dim3(256), 0, st, (const T*)data, p, (const FastBlockDesc*)b.desc,
                          (const u32*)b.wgSize, (const u32*)b.wgBase, (const u32*)b.groupBase, out, b.packPart,
-                         b.result, (const u8*)b.prefixStage, (const u64*)b.tileOffset, batch);
+                         b.result, b.prefixStage, (const u64*)b.tileOffset, batch, b.solo, (const u64*)b.wgMinKey, (const u64*)b.wgMaxKey,
+                         (const u32*)b.wgFlags, requested, raiseCand, cap);
   }
+}
+
+template<class T>
+static void launchFastEncodeT(int stage, const BandParams& p, double requested, u32 raiseCand, const void* data, u8* out, u64 cap,
+                              u64 arenaBase, const FastEncodeBuffers& b, const FastBatch& batch, hipStream_t st)
+{
+  if (b.solo.cells) launchFastEncodeT<T, true>(stage, p, requested, raiseCand, data, out, cap, arenaBase, b, batch, st);
+  else launchFastEncodeT<T, false>(stage, p, requested, raiseCand, data, out, cap, arenaBase, b, batch, st);
 }
 
 void launchFastEncode(int stage, const BandParams& assumed, double requestedMaxZErr, u32 raiseCandidates, const void* data, u8* out,
