@@ -914,7 +914,8 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
           if (lo + i >= first && lo + i < last) out[gAligned + lo + i] = (u8)(xs[i >> 2] >> (8 * (i & 3)));
       }
     }
-    const u64 a = waveSum((u64)A % 65535u), b2 = waveSum(B % 65535u);
+    // (no reduction mod 65535 before the sums: a lane holds at most 5 units, A < 2^22 and B < 2^53 per lane)
+    const u64 a = waveSum(A), b2 = waveSum(B);
     if (lane == 0) { s_fa[w] = a; s_fb[w] = b2; }
   }
   else
@@ -936,7 +937,8 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
       // (gAligned + lo >= 16 > 14 always holds here because spans start behind the >= 95-byte prefix)
       fletcherUnit(x, (u64)((gAligned + lo - 14u) >> 1), A, B);
     }
-    const u64 a = waveSum((u64)A % 65535u), b2 = waveSum(B % 65535u);
+    // (no reduction mod 65535 before the sums: a lane holds at most 5 units, A < 2^22 and B < 2^53 per lane)
+    const u64 a = waveSum(A), b2 = waveSum(B);
     if (lane == 0) { s_fa[w] = a; s_fb[w] = b2; }
   }
   __syncthreads();

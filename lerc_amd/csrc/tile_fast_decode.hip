@@ -452,7 +452,8 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   }
   PROBE(14);
   {
-    const u64 A = waveSum((u64)fA % 65535u), B = waveSum(fB % 65535u);
+    // (no reduction mod 65535 before the sums: a lane holds 9 units, A < 2^23 and B < 2^54 per lane)
+    const u64 A = waveSum(fA), B = waveSum(fB);
     if (lane == 0) { s_fa[w] = A; s_fb[w] = B; }
   }
   if (threadIdx.x == 0) s_over = 0u;
