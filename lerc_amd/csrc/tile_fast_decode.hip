@@ -154,11 +154,11 @@ __device__ __forceinline__ LeanBlock leanLength(const LeanWords<DT>& v, u32 rel)
     const u32 h2 = __builtin_amdgcn_alignbit(v.x3, v.x2, sh);
     t = (offB == 8u) ? (h2 >> 8) : (u32)((((u64)h1 << 32) | h0) >> ((8u + 8u * offB) & 63u));
   }
-  else t = (u32)((((u64)h1 << 32) | h0) >> ((8u + 8u * offB) & 63u));
+  else t = (u32)((((u64)h1 << 32) | h0) >> (8u + 8u * offB));    // (offsets of at most 4 bytes: no shift beyond 40)
   const u32 nb = t & 31u, lut = (t >> 5) & 1u;
   u32 lenStuffed = 3u + offB + 8u * nb;
   k.okLut = 1u;
-  if (!UNIFORM || __any(lut && mode == 1u))
+  if (!UNIFORM || __builtin_amdgcn_ballot_w64((t & 32u) != 0u && mode == 1u) != 0ull)
   {
     const u32 nLut = (((t >> 16) & 0xFFu) - 1u) & 0xFFu;                   // valid: 1 ... 254
     k.okLut = (lut ^ 1u) | (u32)((nLut - 1u) < 254u);
@@ -583,38 +583,44 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     const bool wLive = wChunk < nChunks;
     const u32 wEnd = wLive ? min(wStart + CH, blobEnd) : wStart;
     const bool walker = wLive && slot < min(s_nFinal[wc], NW);
-    u32 cur = wStart + (walker ? (u32)s_final[wc][slot] : 0u);
-    u32 sig = kNoOffset, count = 0;
-    bool alive = walker, tooMany = false;
     u16* __restrict__ list = b.lists + ((size_t)wChunk * NW + slot) * kFastListCap;
     const u32* __restrict__ nextHits = s_hits[wc + 1];
-    // (the words of the next block are fetched as soon as its start is known; what is not on the way from one start to
-    // the next -- is this a block, does its signature follow, the list -- fills the wait)
-    LeanWords<DT> xw = leanFetch<DT>(s_in, cur - r0);
-    while (__any(alive && cur < wEnd))
+    // Inside the chunk.  A lone wave issues an instruction every seven cycles or so whatever it depends on, and this loop
+    // is what the kernel waits for, so it is written for few instructions: positions relative to the staged bytes, a walk
+    // that is over is a position no chunk reaches (no flag beside it), the signature of the walk's first block stands in
+    // for "the block before" at the first step, and "bit-stuffed with a one-byte count of 64 and 1 .. 31 bits" is one
+    // range test.  The words of the next block are fetched as soon as its start is known; what is not on the way from
+    // one start to the next -- is this a block, does its signature follow, the list -- fills the wait.
+    constexpr u32 kOver = 0xFFFFFFFFu;
+    const u32 startRel = wc * CH, endRel = wEnd - r0, blobRel = blobEnd - r0;
+    const u32 sigStep = (pattern == 14u) ? 2u : 1u;
+    u32 rel = walker ? startRel + (u32)s_final[wc][slot] : kOver;
+    u32 count = 0;
+    LeanWords<DT> xw = leanFetch<DT>(s_in, min(rel, kMaxRel));
+    u32 sig = (__builtin_amdgcn_alignbit(xw.x1, xw.x0, 8u * rel) >> 2) & pattern;
+    bool active = rel < endRel;
+    while (__builtin_amdgcn_ballot_w64(active) != 0ull)
     {
-      const bool active = alive && cur < wEnd;
-      const LeanBlock k = leanLength<DT, true>(xw, cur - r0);
-      const u32 nxt = min(cur + k.len, r0 + kMaxRel);                     // (a length that is none stays inside the staged bytes)
-      xw = leanFetch<DT>(s_in, nxt - r0);
-      u32 sg;
-#ifdef LERC_WALK_FULLCHECK
-      const bool valid = leanValid<DT>(k, blobEnd - cur, v5, sig, pattern, sg);
-#else
-      const bool valid = leanPlausible(k, blobEnd - cur, sig, pattern, sg);
-#endif
-      const bool room = count < (u32)kFastListCap;
-      const bool ok = active && valid && room;
-      tooMany = tooMany || (active && valid && !room);
+      const LeanBlock k = leanLength<DT, true>(xw, rel);
+      const u32 behind = rel + k.len;
+      const u32 nxt = min(behind, kMaxRel);                               // (a length that is none stays inside the staged bytes)
+      xw = leanFetch<DT>(s_in, nxt);
+      const u32 sg = (k.h0 >> 2) & pattern, d = (sg - sig) & pattern;
+      const bool valid = (((k.h0 & 3u) != 1u) | (((k.t & 0xFFDFu) - 0x4081u) <= 30u)) & (behind <= blobRel)
+        & ((d == 0u) | (d == sigStep) | (sg == 0u));
+      const bool ok = active & valid & (count < (u32)kFastListCap);
 #ifndef LERC_WALK_NOSTORE
-      if (ok) list[count] = (u16)(cur - wStart);
+      if (ok) list[count] = (u16)(rel - startRel);
 #endif
-      alive = alive && (!active || ok);
-      cur = ok ? nxt : cur;
+      rel = active ? (ok ? nxt : kOver) : rel;
       count += ok ? 1u : 0u;
       sig = ok ? sg : sig;
+      active = rel < endRel;
     }
     PROBE(22);
+    bool alive = rel != kOver;
+    u32 cur = r0 + rel;                                                   // (absolute from here on: a few steps at most)
+    bool tooMany = count == (u32)kFastListCap;                            // (a walk that filled its list: it may have been cut short)
     // behind the chunk: done on a block header of the next window (or at the end of the blob), lost behind that window
     bool landed = false;
     for (;;)

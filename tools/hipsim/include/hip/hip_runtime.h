@@ -218,6 +218,7 @@ inline unsigned long long __ballot(int pred)
   return m;
 }
 inline int __any(int p) { return __ballot(p) != 0; }
+inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return __ballot(p ? 1 : 0); }
 inline int __all(int p)
 {
   unsigned long long act = __ballot(1);
