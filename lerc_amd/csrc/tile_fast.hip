@@ -524,15 +524,19 @@ k_fast_scan_decide(const T* __restrict__ data, BandParams p, double requestedMax
 // pass 2: pack + checksum
 // ------------------------------------------------------------------------------------------------
 // OR up to 64 bits into the LDS bit stream
+// (three words whatever the length: an OR of nothing costs less than the branches around it; the image has slack behind it)
 __device__ __forceinline__ void orBits64(u32* words, u32 bitPos, u64 value, int nbits)
 {
+  (void)nbits;
   const u32 w = bitPos >> 5, sh = bitPos & 31;
-  const u32 lo = (u32)value, hi = (u32)(value >> 32);
-  atomicOr(&words[w], lo << sh);
-  const u32 mid = (sh ? (lo >> (32 - sh)) : 0u) | (hi << sh);
-  if (sh + (u32)nbits > 32) atomicOr(&words[w + 1], mid);
-  if (sh + (u32)nbits > 64) atomicOr(&words[w + 2], sh ? (hi >> (32 - sh)) : 0u);
+  const u64 lo = value << sh;
+  const u32 hi = (u32)((value >> 1) >> (63u - sh));    // bits 64 .. 95 of the shifted value (0 for sh == 0)
+  atomicOr(&words[w], (u32)lo);
+  atomicOr(&words[w + 1], (u32)(lo >> 32));
+  atomicOr(&words[w + 2], hi);
 }
+// bytes of a data type whose code is known to be 0 .. 7 (dtSize without the comparisons)
+__device__ __forceinline__ int dtSize3(u32 dt) { return (int)((0x84442211u >> (4u * dt)) & 15u); }
 
 // Fletcher terms of one little-endian 32-bit word whose first byte sits at an EVEN position `pos` of
 // the checksummed range: two big-endian 16-bit words w0 = b0 b1, w1 = b2 b3 with indices pos/2, pos/2 + 1
@@ -773,7 +777,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
     {
       flag |= (kind == 2) ? 3u : 1u;
       flag |= (u32)tc << 6;
-      const int offBytes = dtSize(dtRed);
+      const int offBytes = dtSize3((u32)dtRed);
       orBits(s_out, at0, flag, 8);
       orBits64(s_out, at0 + 8, typedBits((double)fromRawBits<T>(d.mnBits), dtRed), 8 * offBytes);
       if (kind == 3) orBits(s_out, at0 + 8u * (1u + (u32)offBytes), (u32)nb | (2u << 6) | (64u << 8), 16);    // numBits byte, count 64
@@ -794,7 +798,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
     if (kind == 3)
     {
       const int nb = (int)(w1 >> 24);
-      const int offBytes = dtSize((int)((w1 >> 21) & 7u));
+      const int offBytes = dtSize3((w1 >> 21) & 7u);
       const T mn = fromRawBits<T>(s_mn[blk]);
       u32 q[V];
       quantizeLane<T, V>(p.intLossless, p.scale, v[t], mn, q);
@@ -830,7 +834,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
 #pragma unroll
       for (int k = 0; k < V; k++) idx[k] = 0;
       const int nb = (int)(w1 >> 24);
-      const int offBytes = dtSize((int)((w1 >> 21) & 7u));
+      const int offBytes = dtSize3((w1 >> 21) & 7u);
       const u32 hdr = at0 + 8u * (1u + (u32)offBytes);
       const u32 lutAt = hdr + 24;    // numBits byte, count byte, nLut + 1 byte
       u32 count = 0, last = 0;
