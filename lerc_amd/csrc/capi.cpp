@@ -159,6 +159,29 @@ lerc_status decodeHost(const unsigned char* blob, unsigned blobSize, int nMasks,
   rq.hBlob = blob; rq.blobSize = blobSize; rq.dt = (int)dataType; rq.nDepth = nDepth; rq.nCols = nCols; rq.nRows = nRows;
   rq.nBands = nBands; rq.nMasks = nMasks; rq.dOut = dOut; rq.dValidBytes = dMask;
   rq.hUsesNoData = pUsesNoData; rq.hNoDataValues = noDataValues;
+  // What the streaming kernels can take -- the header says so: one band, every pixel valid, 8 x 8 blocks, nDepth 1 -- goes
+  // up, through the kernels and back in one go: upload, kernels, verdict and the pixels' way back are enqueued together
+  // and this thread waits once (two waits and the gap between them are a quarter of a small raster's call).
+  {
+    Header hd;
+    size_t used = 0;
+    const size_t nPixHd = (size_t)nRows * nCols;
+    if (!widen && nBands == 1 && nDepth == 1 && !pUsesNoData && readHeader(blob, blobSize, hd, used) && hd.version >= 3 && hd.nRows == nRows
+      && hd.nCols == nCols && hd.nDepth == 1 && hd.dt == (int)dataType && hd.mbSize == 8 && hd.nBlobsMore == 0
+      && (size_t)hd.numValid == nPixHd && (unsigned)hd.blobSize <= blobSize && hd.maxZErr > 0 && hd.zMin != hd.zMax)
+    {
+      u8* dBlob = (u8*)h->stage(2, (size_t)blobSize + 256);
+      if (dBlob && hipMemcpyAsync(dBlob, blob, blobSize, hipMemcpyHostToDevice, st) == hipSuccess)
+      {
+        DecodeRequest rs = rq;
+        rs.hBlob = nullptr; rs.dBlob = dBlob;
+        bool handled = false;
+        const u32 src = decodeSpeculativeToHost(ctx, rs, pData, outBytes, nMasks ? pValidBytes : nullptr, maskBytes, handled);
+        if (src != kOk) return src;
+        if (handled) return kOk;
+      }
+    }
+  }
   const u32 rc = decodeDevice(ctx, rq);
   if (rc != kOk) return rc;
   if (widen)

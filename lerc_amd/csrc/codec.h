@@ -179,6 +179,8 @@ bool encodeEnqueueStreaming(Context& ctx, const EncodeRequest& rq, u8* slot);
 void encodeStreamingVerdict(Context& ctx, const EncodeRequest& rq, const u8* slot, bool& redo, u32& status, u32& numBytesNeeded, u32& numBytesWritten);
 bool decodeEnqueueStreaming(Context& ctx, const DecodeRequest& rq, u8* slot, u32& epoch);
 bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch);    // true: decoded, checksum good
+// host-pointer calls: streaming kernels + the results' way back to the host enqueued together, one wait (rq holds a device copy of the blob)
+u32 decodeSpeculativeToHost(Context& ctx, const DecodeRequest& rq, void* hOut, size_t outBytes, u8* hMask, size_t maskBytes, bool& handled);
 u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed);
 u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq);
 

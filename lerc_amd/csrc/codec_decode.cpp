@@ -587,6 +587,24 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   return kOk;
 }
 
+// Host-pointer calls on a device copy of the blob: the same, with the pixels' (and the mask bytes') way back to the host
+// enqueued behind the kernels, so that the calling thread waits once.  handled == false: the device did not vouch for
+// what it wrote (the caller goes the long way and overwrites it).
+u32 decodeSpeculativeToHost(Context& ctx, const DecodeRequest& rq, void* hOut, size_t outBytes, u8* hMask, size_t maskBytes, bool& handled)
+{
+  handled = false;
+  u8* pin = (u8*)ctx.pinned(64 + kCellBytes);
+  u32 epoch = 0;
+  if (!pin || !decodeEnqueueStreaming(ctx, rq, pin, epoch)) return kOk;
+  hipStream_t st = ctx.activeStream();
+  hipMemcpyAsync(hOut, rq.dOut, outBytes, hipMemcpyDeviceToHost, st);
+  if (hMask && rq.dValidBytes) hipMemcpyAsync(hMask, rq.dValidBytes, maskBytes, hipMemcpyDeviceToHost, st);
+  if (!ctx.sync()) return kFailed;
+  handled = decodeStreamingVerdict(ctx, pin, epoch);
+  if (handled) { ctx.pathCount[2]++; ctx.lastDecodeStreamed = true; }
+  return kOk;
+}
+
 u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
 {
   bool handled = false;

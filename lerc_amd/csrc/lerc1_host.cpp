@@ -155,7 +155,8 @@ u32 decodeLerc1(Context& ctx, const DecodeRequest& rq)
   hipStream_t st = ctx.activeStream();
   const i64 nPix = (i64)rq.nRows * rq.nCols;
   const int tb = dtSize(rq.dt);
-  if (!ctx.reserve((rq.dBlob ? 0 : (size_t)rq.blobSize + 256) + (size_t)((nPix + 7) >> 3) + 4096 + 8 * ((size_t)nPix / 4 + 4096)))
+  // (two u32 arrays of one entry per tile; a legal blob may have tiles of a single pixel, so size them for nPix tiles)
+  if (!ctx.reserve((rq.dBlob ? 0 : (size_t)rq.blobSize + 256) + (size_t)((nPix + 7) >> 3) + 4096 + 8 * ((size_t)nPix + 4096)))
     return kFailed;
   const u8* dBlob = rq.dBlob;
   if (!dBlob)
@@ -205,7 +206,7 @@ u32 lerc1BlobInfo(Context& ctx, const u8* hBlob, u32 n, BlobInfo& info, double* 
   const i64 nPix = (i64)b0.width * b0.height;
   info.nDepth = 1; info.nCols = b0.width; info.nRows = b0.height; info.dt = DT_Float; info.maxZErr = b0.maxZErr;
   info.zMin = FLT_MAX; info.zMax = -FLT_MAX;
-  if (!ctx.reserve((size_t)n + 256 + (size_t)nPix * 4 + (size_t)((nPix + 7) >> 3) + 8 * ((size_t)nPix / 4 + 4096) + 65536)) return kFailed;
+  if (!ctx.reserve((size_t)n + 256 + (size_t)nPix * 4 + (size_t)((nPix + 7) >> 3) + 8 * ((size_t)nPix + 4096) + 65536)) return kFailed;
   u8* dBlob = ctx.allocT<u8>((size_t)n + 16);
   float* dZ = ctx.allocT<float>((size_t)nPix + 4);
   u64* dMin = ctx.allocT<u64>(1);
