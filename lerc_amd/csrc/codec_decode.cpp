@@ -99,17 +99,17 @@ static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8
   FastDecodeBuffers fbuf;
   fbuf.recs = ctx.allocT<FastChunkRec>(nT * fwp.nChunks + kResolveWG);    // (+ what the resolve step's unconditional loads may touch)
   fbuf.lists = ctx.allocT<u16>((nT * fwp.nChunks + kDecodeChunks) * (size_t)(kDiscWalks * kFastListCap) + 8);    // (+ what the gather step's clamped loads may touch)
-  fbuf.chunkCount = ctx.allocT<u32>(nT * sChunk);
-  fbuf.chunkLane = ctx.allocT<u32>(nT * sChunk);
-  fbuf.chunkLocal = ctx.allocT<u32>(nT * sChunk);
-  fbuf.groupSum = ctx.allocT<u32>(nT * ((fwp.nChunks + kResolveWG - 1) / kResolveWG + 1) + 4);
+  // (epoch-tagged cells, never cleared: they live as long as the context and share its area with the encoder's)
+  const size_t cellWords = nT * (2 * sChunk + fastGroupStride(fwp.nChunks)) + 8;
+  fbuf.chunkCell = (u64*)ctx.persistentState(1, cellWords * 8);
+  fbuf.groupCell = fbuf.chunkCell ? fbuf.chunkCell + nT * 2 * sChunk : nullptr;
   fbuf.waveFletcher = ctx.allocT<u64>(2 * nT * (size_t)fwp.nWaves + 4);
   fbuf.params = dParams;
   fbuf.fallback = dFallback;
   fbuf.epoch = epoch;
-  if (!fbuf.recs || !fbuf.lists || !fbuf.chunkCount || !fbuf.chunkLane || !fbuf.chunkLocal || !fbuf.groupSum || !fbuf.waveFletcher)
+  if (!fbuf.recs || !fbuf.lists || !fbuf.chunkCell || !fbuf.waveFletcher)
     return false;
-  static const char* kStage[kFastDecodeStages] = { "fast_discover", "fast_resolve", "fast_decode" };
+  static const char* kStage[kFastDecodeStages] = { "fast_discover", "fast_decode" };
   for (int stage = 0; stage < kFastDecodeStages; stage++)
   {
     ProfScope ps(ctx, kStage[stage]);

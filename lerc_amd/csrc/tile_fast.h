@@ -146,10 +146,10 @@ LERC_HD u32 fastNumWG(int nRows, int nCols) { return (u32)(((u64)(nRows / 8) * (
 //                    finds the bit-stuffed block headers in each chunk's first `window` bytes by their byte pattern, and
 //                    lets up to kDiscWalks of them per chunk walk -- in lockstep, listing the block starts they pass --
 //                    until they land on a header found in the next chunk's window
-//   k_fast_resolve   entry of chunk c = the exit all surviving walks of chunk c - 1 agree on; the walk that starts
-//                    there is the true path: its block count, scanned, is the index of the chunk's first block
-//   k_fast_decode    a workgroup decodes the blocks that start in kDecodeChunks chunks, from the true walks' lists, and checks
-//                    that they tile the stream exactly
+//   k_fast_decode    its first blocks resolve: entry of chunk c = the exit all surviving walks of chunk c - 1 agree on; the
+//                    walk that starts there is the true path: its block count, scanned, is the index of the chunk's first
+//                    block -- left in an epoch-tagged cell per chunk.  The other workgroups decode the blocks that start in
+//                    kDecodeChunks chunks each, from the true walks' lists, and check that they tile the stream exactly
 static const u32 kFastChunkBytes = 2048;
 static const int kDiscWalks = 8;           // walks per chunk (path heads among the filter's survivors; more: general path)
 #ifndef LERC_DISC_CHUNKS
@@ -158,7 +158,7 @@ static const int kDiscWalks = 8;           // walks per chunk (path heads among 
 static const int kDiscChunks = LERC_DISC_CHUNKS;    // chunks per workgroup of k_fast_discover: 8 or 16 (16 threads each; 8 is 8 % slower)
 static const int kDiscThreads = 16 * kDiscChunks;
 static const int kFastListCap = 128;       // block starts a walk can list per chunk (more, i.e. blocks of < 16 bytes on average: general path)
-static const u32 kResolveWG = 256;         // chunks per workgroup of k_fast_resolve
+static const u32 kResolveWG = 256;         // chunks per resolving block of k_fast_decode
 static const u32 kDecodeChunks = 4;        // chunks whose blocks a workgroup of k_fast_decode decodes (divides kResolveWG)
 // longest block the streaming walk accepts: the raw form (the reference encoder never emits a longer one)
 constexpr u32 kFastWindow(int typeBytes) { return 2u + 64u * (u32)typeBytes; }
@@ -195,10 +195,9 @@ struct FastDecodeBuffers
 {
   FastChunkRec* recs;  // [nChunks]
   u16* lists;          // [nChunks * kDiscWalks * kFastListCap] block starts relative to the chunk, per walk
-  u32* chunkCount;     // [nChunks] blocks that start in the chunk
-  u32* chunkLane;      // [nChunks] the walk that is the true path
-  u32* chunkLocal;     // [nChunks] exclusive scan of chunkCount inside a resolve workgroup
-  u32* groupSum;       // [ceil(nChunks / kResolveWG)] blocks per resolve workgroup
+  u64* chunkCell;      // [2 * nChunks] what the resolving blocks found: epoch (32) | index of the chunk's first block (32), and
+                       // blocks that start in the chunk (32) | the walk that is the true path, ~0: none (32)
+  u64* groupCell;      // [ceil(nChunks / kResolveWG)] epoch (32) | blocks of a resolving block's chunks (32)
   u64* waveFletcher;   // [2 * nWaves] Fletcher partial sums (mod 65535) of the bytes each discovery workgroup staged
   FastDecodeParams* params;   // [nTiles]
   u32* fallback;       // [4 * nTiles] epoch tagged, see above
@@ -215,11 +214,12 @@ struct FastDecodeBatch
   const u64* tileOffset;             // device [nTiles]: start of each blob in the arena; nullptr: `blob` itself
   const u32* tileSize;               // device [nTiles]
 };
-LERC_HD u32 fastChunkStride(u32 nChunks) { return nChunks + 4u; }    // elements per tile of the per-chunk u32 arrays
+LERC_HD u32 fastChunkStride(u32 nChunks) { return nChunks + 4u; }    // chunk cells per tile
+LERC_HD u32 fastGroupStride(u32 nChunks) { return (nChunks + kResolveWG - 1u) / kResolveWG + 1u; }    // group cells per tile
 
 bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid);
 FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven);
-static const int kFastDecodeStages = 3;    // one kernel each: discover (+ header + checksum terms), resolve, decode
+static const int kFastDecodeStages = 2;    // one kernel each: discover (+ header + checksum terms), resolve + decode
 void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
                       const FastDecodeBuffers& b, void* out, hipStream_t st);
 

@@ -671,17 +671,17 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
 // One thread per chunk.  Only the exits need agreement (they break the chunk-to-chunk dependency): once the entry of
 // a chunk is known, the walk that starts there IS the true path.  The counts are scanned inside the workgroup; the
 // gather step adds the sums of the workgroups before its own.  Workgroup 0 also folds the checksum terms.
-__device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 nWavesBound)
+__device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 nWavesBound, u32 group)
 {
   __shared__ u32 s_w[kResolveWG / 64];
   __shared__ u64 s_a[kResolveWG / 64], s_b[kResolveWG / 64];
   const FastDecodeParams hp = *b.params;
   const u32 blobEnd = hp.blobEnd;
-  const u32 c = blockIdx.x * kResolveWG + threadIdx.x;
+  const u32 c = group * kResolveWG + threadIdx.x;
   // (the records first: their addresses do not hang on the header)
   const u32 cPrev = c ? c - 1u : 0u;
   const u32 prevExit = b.recs[cPrev].exit;
-  if (!hp.ok) return;
+  if (!hp.ok || group * kResolveWG >= hp.nChunks) return;    // (the grid is sized for the largest stream the blob could hold)
   const int lane = laneId(), w = waveId();
   u32 count = 0, laneOfPath = kNoOffset;
   bool bad = false;
@@ -709,9 +709,7 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
       }
       if (laneOfPath == kNoOffset || rec.exit == kNoOffset) bad = true;    // (no agreement on the exit: the next chunk says so too)
     }
-    if (bad) count = 0;
-    b.chunkCount[c] = count;
-    b.chunkLane[c] = laneOfPath;
+    if (bad) { count = 0; laneOfPath = kNoOffset; }
   }
   if (__any(bad) && lane == 0) b.fallback[1] = b.epoch;
   // exclusive scan of the counts inside the workgroup
@@ -722,10 +720,40 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
   __syncthreads();
   u32 before = 0;
   for (int i = 0; i < w; i++) before += s_w[i];
-  if (c < hp.nChunks) b.chunkLocal[c] = before + inc - count;
-  if (threadIdx.x == kResolveWG - 1) b.groupSum[blockIdx.x] = before + inc;
+  // this block's total goes out at once; the blocks in front of it -- dispatched earlier, waiting for nobody before they
+  // publish theirs -- are read in one go (a cell is read by the few hundred resolving blocks behind it, no more)
+  const u32 epoch = b.epoch;
+  const u32 nGroups = (hp.nChunks + kResolveWG - 1u) / kResolveWG;
+  __shared__ u32 s_base[kResolveWG / 64];
+  if (threadIdx.x == kResolveWG - 1) publish64(b.groupCell + group, ((u64)epoch << 32) | (before + inc));
+  u32 base = 0;
+  for (u32 g0 = 0; g0 < group; g0 += kResolveWG)
+  {
+    const u32 g = g0 + threadIdx.x;
+    u64 cell = g < group ? observe64(b.groupCell + g) : 0ull;
+    for (u32 spin = 0; __any(g < group && (u32)(cell >> 32) != epoch) && spin < (1u << 22); spin++)    // (never that long)
+    {
+      __builtin_amdgcn_s_sleep(4);
+      if (g < group && (u32)(cell >> 32) != epoch) cell = observe64(b.groupCell + g);
+    }
+    base += g < group ? (u32)cell : 0u;
+  }
+  base = waveSum(base);
+  __syncthreads();    // (s_w has been read)
+  if (lane == 0) s_base[w] = base;
+  __syncthreads();
+  base = 0;
+  for (u32 i = 0; i < kResolveWG / 64; i++) base += s_base[i];
+  if (c < hp.nChunks)
+  {
+    publish64(b.chunkCell + 2 * (size_t)c + 1, (u64)count | ((u64)laneOfPath << 32));
+    drainVmem();    // (the tagged word last: who sees it sees the other one)
+    publish64(b.chunkCell + 2 * (size_t)c, ((u64)epoch << 32) | (base + before + inc - count));
+  }
+  // the chunks hold all the raster's blocks, or the band goes the long way
+  if (group == nGroups - 1u && threadIdx.x == kResolveWG - 1 && base + before + inc != hp.nBlocks) b.fallback[2] = epoch;
 
-  if (blockIdx.x != 0) return;
+  if (group != 0) return;
   // checksum: Fletcher32 over blob[14 ..) from the discovery waves' partial sums (Lerc2.cpp:1037-1064)
   const u32 nWaves = min((hp.nChunks + (u32)kDiscChunks - 1u) / (u32)kDiscChunks, nWavesBound);
   u64 A = 0, B = 0;
@@ -782,10 +810,10 @@ template<class T> __device__ __forceinline__ T dequant(double offset, u32 q, dou
 // of chunk c is block base(c) + i of the raster (base: the scan the resolve step left in pieces).
 template<class T>
 __device__ __forceinline__ void
-fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __restrict__ outPix)
+fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __restrict__ outPix, u32 wgIndex)
 {
   const FastDecodeParams hp = *b.params;
-  const u32 raised0 = b.fallback[0], raised1 = b.fallback[1];    // (read together with the parameters: one round trip, not three)
+  const u32 raised0 = b.fallback[0];    // (read together with the parameters: one round trip, not two)
   typedef DCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
   constexpr int DT = DtOf<T>::v;
@@ -798,15 +826,15 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
   __shared__ u32 s_code[kMaxBlocks];             // parseCode of the block, 0 = bad
   __shared__ u32 s_at[kMaxBlocks];               // raster offset (pixels) of the block's first pixel, ~0: no such block
   __shared__ double s_offs[kMaxBlocks];
-  __shared__ u32 s_n[CPD + 1], s_first[CPD], s_lane[CPD], s_part[4], s_bad;
+  __shared__ u32 s_n[CPD + 1], s_first[CPD], s_lane[CPD], s_bad;
   __shared__ __align__(16) u16 s_spec[CPD][CAP];   // the list of each chunk's walk 0, fetched before anybody knows which walk is the path
   const u32 blobEnd = hp.blobEnd, epoch = b.epoch;
   const struct { int nCols, version; double invScale, zMaxHdr; } p = { (int)hp.nCols, (int)hp.version, hp.invScale, hp.zMaxHdr };
   PROBE_BEGIN;
   const int w = waveId(), lane = laneId();
-  const u32 c0 = blockIdx.x * CPD;
+  const u32 c0 = wgIndex * CPD;
   // not ours, given up by an earlier kernel, or behind the stream's end (the grid is sized for the largest stream the blob could hold)
-  if (!hp.ok || raised0 == epoch || raised1 == epoch || c0 >= hp.nChunks) return;
+  if (!hp.ok || raised0 == epoch || c0 >= hp.nChunks) return;
   const u32 r0 = c0 * CH;
 
   // ---- everything whose address is known goes out at once: the bytes ...
@@ -838,34 +866,29 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
     const uint4 l = *reinterpret_cast<const uint4*>(b.lists + ((size_t)(c0 + q) * kDiscWalks) * kFastListCap + 8u * part);    // (chunks behind the last one: the buffer's slack)
     *reinterpret_cast<uint4*>(&s_spec[q][8u * part]) = l;
   }
-  // ... the chunks' counts, and the blocks in front of this workgroup's resolve group
+  // ... and the chunks' cells: which walk is the path, how many blocks, the index of the first one (the resolving blocks of
+  // this launch leave them; only the workgroups of the launch's first round ever wait)
   if (threadIdx.x < CPD)
   {
     const u32 c = c0 + threadIdx.x;
-    const bool have = c < hp.nChunks;
-    s_n[threadIdx.x] = have ? b.chunkCount[c] : 0u;
-    s_first[threadIdx.x] = have ? b.chunkLocal[c] : 0u;
-    s_lane[threadIdx.x] = have ? b.chunkLane[c] : 0u;
+    u32 n = 0, first = 0, ln = 0;
+    if (c < hp.nChunks)
+    {
+      u64 tagged = observe64(b.chunkCell + 2 * (size_t)c);
+      for (u32 spin = 0; (u32)(tagged >> 32) != epoch && spin < (1u << 22); spin++)    // (never that long: the resolving blocks were dispatched first)
+      {
+        __builtin_amdgcn_s_sleep(4);
+        tagged = observe64(b.chunkCell + 2 * (size_t)c);
+      }
+      const u64 other = observe64(b.chunkCell + 2 * (size_t)c + 1);
+      first = (u32)tagged; n = (u32)other; ln = (u32)(other >> 32);
+      if (ln == kNoOffset) { n = 0; ln = 0; }    // (no path through this chunk: the resolving block has raised the flag)
+    }
+    s_n[threadIdx.x] = n; s_first[threadIdx.x] = first; s_lane[threadIdx.x] = ln;
   }
   if (threadIdx.x == 0) s_bad = 0u;
-  const u32 grp = c0 / kResolveWG;
-  u32 sum = 0;
-  for (u32 i = threadIdx.x; i < grp; i += 256u) sum += b.groupSum[i];
-  if (blockIdx.x == 0)    // (one workgroup checks that the chunks hold all the raster's blocks)
-  {
-    u32 all = 0;
-    const u32 nGroups = (hp.nChunks + kResolveWG - 1) / kResolveWG;
-    for (u32 i = threadIdx.x; i < nGroups; i += 256u) all += b.groupSum[i];
-    all = waveSum(all);
-    if (lane == 0) s_part[w] = all;
-    __syncthreads();
-    if (threadIdx.x == 0 && s_part[0] + s_part[1] + s_part[2] + s_part[3] != hp.nBlocks) b.fallback[2] = epoch;
-    __syncthreads();
-  }
-  sum = waveSum(sum);
-  if (lane == 0) s_part[w] = sum;
   __syncthreads();
-  const u32 before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  const u32 before = 0u;    // (the cells hold raster indices)
   PROBE(8);
   // ---- the lists of the walks that are the path: flat index f = blocks of chunk 0, then of chunk 1, ...
   u32 nAll = 0, cum[CPD + 1];
@@ -1078,8 +1101,8 @@ __device__ __forceinline__ void tileSlice(FastDecodeBuffers& b, const FastDecode
   const size_t sChunk = fastChunkStride(t.nChunks);
   b.params += tile; b.fallback += 4 * tile;
   b.recs += tile * t.nChunks; b.lists += tile * t.nChunks * (size_t)(kDiscWalks * kFastListCap);
-  b.chunkCount += tile * sChunk; b.chunkLane += tile * sChunk; b.chunkLocal += tile * sChunk;
-  b.groupSum += tile * ((t.nChunks + kResolveWG - 1) / kResolveWG + 1);
+  b.chunkCell += tile * 2 * sChunk;
+  b.groupCell += tile * fastGroupStride(t.nChunks);
   b.waveFletcher += tile * 2 * (size_t)t.nWaves;
   if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
 }
@@ -1091,20 +1114,17 @@ k_fast_discover(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 size
   tileSlice(b, t, blob, sizeGiven);
   fastDiscoverBody<DT>(blob, sizeGiven, nRows, nCols, b);
 }
-__global__ void __launch_bounds__(kResolveWG) k_fast_resolve(FastDecodeBuffers b, FastDecodeBatch t)
-{
-  const u8* blob = nullptr;
-  u32 sizeGiven = 0;
-  tileSlice(b, t, blob, sizeGiven);
-  fastResolveBody(b, t.nWaves);
-}
+// The first blocks of the launch resolve (kResolveWG chunks each), the others decode (kDecodeChunks chunks each).
 template<class T>
 __global__ void __launch_bounds__(256)
 k_fast_decode(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, T* __restrict__ outPix)
 {
+  static_assert(kResolveWG == 256, "a resolving block is a block of this launch");
   u32 sizeGiven = 0;
   tileSlice(b, t, blob, sizeGiven);
-  fastDecodeBody<T>(b, blob, outPix + (size_t)blockIdx.y * t.tileElems);
+  const u32 nResolve = (t.nChunks + kResolveWG - 1u) / kResolveWG;
+  if (blockIdx.x < nResolve) fastResolveBody(b, t.nWaves, blockIdx.x);
+  else fastDecodeBody<T>(b, blob, outPix + (size_t)blockIdx.y * t.tileElems, blockIdx.x - nResolve);
 }
 
 template<class T>
@@ -1118,11 +1138,9 @@ static void launchFastDecodeT(int stage, int nRows, int nCols, const FastDecodeB
     case 0:
       hipLaunchKernelGGL(k_fast_discover<DT>, dim3(t.nWaves, nT), dim3(kDiscThreads), 0, st, b, t, blob, sizeGiven, nRows, nCols);
       break;
-    case 1:
-      hipLaunchKernelGGL(k_fast_resolve, dim3((t.nChunks + kResolveWG - 1) / kResolveWG, nT), dim3(kResolveWG), 0, st, b, t);
-      break;
     default:
-      hipLaunchKernelGGL((k_fast_decode<T>), dim3((t.nChunks + kDecodeChunks - 1) / kDecodeChunks, nT), dim3(256), 0, st, b, t, blob, (T*)out);
+      hipLaunchKernelGGL((k_fast_decode<T>), dim3((t.nChunks + kResolveWG - 1) / kResolveWG + (t.nChunks + kDecodeChunks - 1) / kDecodeChunks, nT),
+                         dim3(256), 0, st, b, t, blob, (T*)out);
       break;
   }
 }
