@@ -196,7 +196,7 @@ struct FastDecodeBuffers
   FastChunkRec* recs;  // [nChunks]
   u16* lists;          // [nChunks * kDiscWalks * kFastListCap] block starts relative to the chunk, per walk
   u64* chunkCell;      // [2 * nChunks] what the resolving blocks found: epoch (32) | index of the chunk's first block (32), and
-                       // blocks that start in the chunk (32) | the walk that is the true path, ~0: none (32)
+                       // epoch (32) | the walk that is the true path, 0xFFFF: none (16) | blocks that start in the chunk (16)
   u64* groupCell;      // [ceil(nChunks / kResolveWG)] epoch (32) | blocks of a resolving block's chunks (32)
   u64* waveFletcher;   // [2 * nWaves] Fletcher partial sums (mod 65535) of the bytes each discovery workgroup staged
   FastDecodeParams* params;   // [nTiles]

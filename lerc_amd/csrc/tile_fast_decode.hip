@@ -710,6 +710,9 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
       if (laneOfPath == kNoOffset || rec.exit == kNoOffset) bad = true;    // (no agreement on the exit: the next chunk says so too)
     }
     if (bad) { count = 0; laneOfPath = kNoOffset; }
+    // which walk and how many blocks: out at once (the decode workgroups gather the block starts with it while this block
+    // still waits for the totals in front of it); epoch (32) | walk (16, 0xFFFF: none) | count (16)
+    publish64(b.chunkCell + 2 * (size_t)c + 1, ((u64)b.epoch << 32) | ((u64)(laneOfPath & 0xFFFFu) << 16) | (count & 0xFFFFu));
   }
   if (__any(bad) && lane == 0) b.fallback[1] = b.epoch;
   // exclusive scan of the counts inside the workgroup
@@ -744,12 +747,7 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
   __syncthreads();
   base = 0;
   for (u32 i = 0; i < kResolveWG / 64; i++) base += s_base[i];
-  if (c < hp.nChunks)
-  {
-    publish64(b.chunkCell + 2 * (size_t)c + 1, (u64)count | ((u64)laneOfPath << 32));
-    drainVmem();    // (the tagged word last: who sees it sees the other one)
-    publish64(b.chunkCell + 2 * (size_t)c, ((u64)epoch << 32) | (base + before + inc - count));
-  }
+  if (c < hp.nChunks) publish64(b.chunkCell + 2 * (size_t)c, ((u64)epoch << 32) | (base + before + inc - count));
   // the chunks hold all the raster's blocks, or the band goes the long way
   if (group == nGroups - 1u && threadIdx.x == kResolveWG - 1 && base + before + inc != hp.nBlocks) b.fallback[2] = epoch;
 
@@ -871,20 +869,19 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
   if (threadIdx.x < CPD)
   {
     const u32 c = c0 + threadIdx.x;
-    u32 n = 0, first = 0, ln = 0;
+    u32 n = 0, ln = 0;
     if (c < hp.nChunks)
     {
-      u64 tagged = observe64(b.chunkCell + 2 * (size_t)c);
-      for (u32 spin = 0; (u32)(tagged >> 32) != epoch && spin < (1u << 22); spin++)    // (never that long: the resolving blocks were dispatched first)
+      u64 cell = observe64(b.chunkCell + 2 * (size_t)c + 1);
+      for (u32 spin = 0; (u32)(cell >> 32) != epoch && spin < (1u << 22); spin++)    // (never that long: the resolving blocks were dispatched first)
       {
         __builtin_amdgcn_s_sleep(4);
-        tagged = observe64(b.chunkCell + 2 * (size_t)c);
+        cell = observe64(b.chunkCell + 2 * (size_t)c + 1);
       }
-      const u64 other = observe64(b.chunkCell + 2 * (size_t)c + 1);
-      first = (u32)tagged; n = (u32)other; ln = (u32)(other >> 32);
-      if (ln == kNoOffset) { n = 0; ln = 0; }    // (no path through this chunk: the resolving block has raised the flag)
+      n = (u32)cell & 0xFFFFu; ln = ((u32)cell >> 16) & 0xFFFFu;
+      if (ln == 0xFFFFu) { n = 0; ln = 0; }    // (no path through this chunk: the resolving block has raised the flag)
     }
-    s_n[threadIdx.x] = n; s_first[threadIdx.x] = first; s_lane[threadIdx.x] = ln;
+    s_n[threadIdx.x] = n; s_lane[threadIdx.x] = ln;
   }
   if (threadIdx.x == 0) s_bad = 0u;
   __syncthreads();
@@ -919,6 +916,23 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
   {
     const u32 i = (u32)k * 256u + threadIdx.x;
     if (i < kStageUnits) *reinterpret_cast<uint4*>(&s_in[i * 4]) = x[k];
+  }
+  // ... and, by now, where the chunks' blocks lie in the raster
+  if (threadIdx.x < CPD)
+  {
+    const u32 c = c0 + threadIdx.x;
+    u32 first = 0;
+    if (c < hp.nChunks)
+    {
+      u64 cell = observe64(b.chunkCell + 2 * (size_t)c);
+      for (u32 spin = 0; (u32)(cell >> 32) != epoch && spin < (1u << 22); spin++)
+      {
+        __builtin_amdgcn_s_sleep(4);
+        cell = observe64(b.chunkCell + 2 * (size_t)c);
+      }
+      first = (u32)cell;
+    }
+    s_first[threadIdx.x] = first;
   }
   __syncthreads();
   PROBE(9);
