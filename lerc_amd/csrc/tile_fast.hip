@@ -749,7 +749,11 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
     // a second dirty copy of those bytes here could reach memory after it)
     if (wg == 0 && threadIdx.x < prefixLen && (threadIdx.x < 10 || threadIdx.x >= 14)) out[threadIdx.x] = prefixStage[threadIdx.x];
   }
-  for (int i = threadIdx.x; i < kSpanWords; i += 256) s_out[i] = 0;
+  // (only what the span can touch: 16-byte stores up to a few words behind its end -- the ORs of three words reach that far)
+  {
+    const u32 nZero = min((u32)kSpanWords / 4u, ((SOLO ? kLead : 16u) + spanLen + 48u) / 16u + 1u);
+    for (u32 i = threadIdx.x; i < nZero; i += 256u) reinterpret_cast<uint4*>(s_out)[i] = make_uint4(0, 0, 0, 0);
+  }
   if (w == wPlan)
   {
     const u32 sz = d.w1 & 0xFFFFu;
