@@ -1109,9 +1109,9 @@ FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven)
 // ------------------------------------------------------------------------------------------------
 // kernels: blockIdx.y = tile of a batch (one raster: a batch of 1).  Each tile has its own slice of every buffer.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void tileSlice(FastDecodeBuffers& b, const FastDecodeBatch& t, const u8*& blob, u32& sizeGiven)
+__device__ __forceinline__ void tileSlice(FastDecodeBuffers& b, const FastDecodeBatch& t, const u8*& blob, u32& sizeGiven, u32 tileIndex)
 {
-  const size_t tile = blockIdx.y;
+  const size_t tile = tileIndex;
   const size_t sChunk = fastChunkStride(t.nChunks);
   b.params += tile; b.fallback += 4 * tile;
   b.recs += tile * t.nChunks; b.lists += tile * t.nChunks * (size_t)(kDiscWalks * kFastListCap);
@@ -1125,20 +1125,24 @@ template<int DT>
 __global__ void __launch_bounds__(kDiscThreads)
 k_fast_discover(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 sizeGiven, int nRows, int nCols)
 {
-  tileSlice(b, t, blob, sizeGiven);
+  tileSlice(b, t, blob, sizeGiven, blockIdx.y);
   fastDiscoverBody<DT>(blob, sizeGiven, nRows, nCols, b);
 }
-// The first blocks of the launch resolve (kResolveWG chunks each), the others decode (kDecodeChunks chunks each).
+// The first blocks of the launch resolve (kResolveWG chunks each; all tiles' resolving blocks first, so that a batch's decode
+// workgroups find the cells of their tile ready like those of a single raster do), the others decode (kDecodeChunks chunks each).
 template<class T>
 __global__ void __launch_bounds__(256)
 k_fast_decode(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, T* __restrict__ outPix)
 {
   static_assert(kResolveWG == 256, "a resolving block is a block of this launch");
+  const u32 nResolve = (t.nChunks + kResolveWG - 1u) / kResolveWG, nDecode = (t.nChunks + kDecodeChunks - 1u) / kDecodeChunks;
+  const bool resolving = blockIdx.x < t.nTiles * nResolve;
+  const u32 rest = resolving ? blockIdx.x : blockIdx.x - t.nTiles * nResolve, per = resolving ? nResolve : nDecode;
+  const u32 tile = rest / per, index = rest - tile * per;
   u32 sizeGiven = 0;
-  tileSlice(b, t, blob, sizeGiven);
-  const u32 nResolve = (t.nChunks + kResolveWG - 1u) / kResolveWG;
-  if (blockIdx.x < nResolve) fastResolveBody(b, t.nWaves, blockIdx.x);
-  else fastDecodeBody<T>(b, blob, outPix + (size_t)blockIdx.y * t.tileElems, blockIdx.x - nResolve);
+  tileSlice(b, t, blob, sizeGiven, tile);
+  if (resolving) fastResolveBody(b, t.nWaves, index);
+  else fastDecodeBody<T>(b, blob, outPix + (size_t)tile * t.tileElems, index);
 }
 
 template<class T>
@@ -1153,7 +1157,7 @@ static void launchFastDecodeT(int stage, int nRows, int nCols, const FastDecodeB
       hipLaunchKernelGGL(k_fast_discover<DT>, dim3(t.nWaves, nT), dim3(kDiscThreads), 0, st, b, t, blob, sizeGiven, nRows, nCols);
       break;
     default:
-      hipLaunchKernelGGL((k_fast_decode<T>), dim3((t.nChunks + kResolveWG - 1) / kResolveWG + (t.nChunks + kDecodeChunks - 1) / kDecodeChunks, nT),
+      hipLaunchKernelGGL((k_fast_decode<T>), dim3(nT * ((t.nChunks + kResolveWG - 1) / kResolveWG + (t.nChunks + kDecodeChunks - 1) / kDecodeChunks)),
                          dim3(256), 0, st, b, t, blob, (T*)out);
       break;
   }
