@@ -175,7 +175,7 @@ struct FastDecodeParams
   u32 nChunks, nBlocks;
   u32 nTH, nCols, nRows;
   u32 expectChecksum;    // from the header
-  u32 checksumOk;        // set by k_fast_resolve
+  u32 checksumOk;        // set by the first resolving block of k_fast_decode
   u32 pad;
   double invScale, zMaxHdr;
 };

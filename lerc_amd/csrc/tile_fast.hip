@@ -14,8 +14,9 @@
 //   * pass 2 (k_fast_pack) reads pixels + descriptors, assembles the workgroup's contiguous output span
 //     in LDS with ds_or_b32 and flushes it with 16-byte stores, accumulating the Fletcher32 sums of the
 //     bytes it stores (word-wise)
-//   * the decisions the reference takes between its sweeps are taken on the device (k_fast_decide), so
-//     an encode costs one host synchronisation
+//   * the scan of the sizes and the decisions the reference takes between its sweeps are taken on the device: for one
+//     raster by the first blocks of the pack launch (k_fast_pack<SOLO>, soloScanDecide), for tile batches by a launch of
+//     their own (k_fast_scan_decide); an encode costs one host synchronisation, a queued one none
 // Reference: Lerc2.cpp:1474-1668, :1717-1799, :1949-2021; Lerc2.h:337-453; BitStuffer2.cpp:35-153.
 #include "tile_fast.h"
 #include "kernels.h"

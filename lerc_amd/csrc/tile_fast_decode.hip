@@ -5,7 +5,7 @@
 // discovery pass over 2 KiB chunks of the blob (tile_fast.h).  Everything serial about it runs out of LDS:
 //   k_fast_discover    a workgroup = kDiscChunks chunks staged with 16-byte loads (their Fletcher32 terms are summed
 //                      on the way, so the decode kernel does not look at the checksum at all).  Every workgroup reads
-//                      the band header itself (the host has not seen a byte of the blob when it enqueues the four
+//                      the band header itself (the host has not seen a byte of the blob when it enqueues the two
 //                      kernels).  A bit-stuffed block reads flag byte, offset, 10?nnnnn, count 64: "64 behind
 //                      10?nnnnn" is found four positions per lane and step in each chunk's first `window` bytes and is
 //                      true for one position in a thousand of anything else.  Of the blocks found, those that are
@@ -13,16 +13,18 @@
 //                      lockstep (lane = chunk x head), fetching the words of the next block as soon as its start is
 //                      known, until each has landed on a header found in the NEXT chunk's window.  Walks that are
 //                      not on the path end within a few steps (signature sequence).
-//   k_fast_resolve     whatever ALL live walks of a chunk agree on is true without knowing which one is real:
-//                      entry of chunk c = agreed exit of chunk c-1; the walk that starts exactly there (or passes
-//                      it with one of its first blocks) is the true path and its length the chunk's block count.
-//                      Also folds the checksum terms.
-//   k_fast_decode      a workgroup owns 64 consecutive blocks (8 rows x 512 columns where a block row is that
-//                      long): it stages their byte span in LDS, parses the 64 block headers once (lane = block;
-//                      signature and contiguity checks = ReadTile's integrity checks), then every lane extracts V
-//                      consecutive pixels of one raster row, dequantises (double precision in the reference's
-//                      expression order for float types, exact integer arithmetic for integer types) and stores
-//                      one 16-byte vector.
+//   k_fast_decode      its first blocks resolve, 256 chunks each: whatever ALL live walks of a chunk agree on is true
+//                      without knowing which one is real: entry of chunk c = agreed exit of chunk c-1; the walk that
+//                      starts exactly there (or passes it with one of its first blocks) is the true path and its
+//                      length the chunk's block count; scanned -- inside the block, then over the totals of the blocks
+//                      in front -- it is the index of the chunk's first block, left in an epoch-tagged cell per chunk.
+//                      Block 0 also folds the checksum terms.
+//                      The other workgroups decode the blocks that start in kDecodeChunks chunks: they stage the byte
+//                      span in LDS, read their chunks' cells, gather the block starts from the true walks' lists, parse
+//                      the block headers once (lane = block; signature and contiguity checks = ReadTile's integrity
+//                      checks), then every lane extracts V consecutive pixels of one raster row, dequantises (double
+//                      precision in the reference's expression order for float types, exact integer arithmetic for
+//                      integer types) and stores one 16-byte vector.
 // Streams the scan cannot follow (a chunk whose window holds no bit-stuffed block on the path: long runs of constant
 // or raw blocks) and anything else unexpected raise an epoch tagged flag; the host then repeats the band with the
 // general kernels.

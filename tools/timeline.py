@@ -10,8 +10,8 @@ def main():
     step = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     cur = con.cursor()
     rows = cur.execute("select name, start, end from kernels order by start").fetchall()
-    # one step starts at every k_fast_prepare
-    starts = [i for i, r in enumerate(rows) if "k_fast_prepare" in r[0]]
+    # one step starts at every k_fast_stats
+    starts = [i for i, r in enumerate(rows) if "k_fast_stats" in r[0]]
     if len(starts) <= step + 1:
         step = max(0, len(starts) - 2)
     a, b = starts[step], starts[step + 1]
