@@ -812,7 +812,7 @@ void encodeStreamingVerdict(Context& ctx, const EncodeRequest& rq, const u8* slo
   memcpy(&hres, slot, sizeof(hres));
   if (ctx.profOn()) ctx.profCollect();
   redo = false; status = kOk;
-  if (!hres.redo)
+  if (!hres.redo && !hres.stuck)
   {
     ctx.pathCount[0]++;
     numBytesNeeded = hres.blobSize;
@@ -874,7 +874,7 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
       runFastEncode(ctx, fl, dBand, dBandBlob, dBandBlob ? (u64)bandCap : ~0ull, 0);
       hipMemcpyAsync(pinRes, fl.fb.result, sizeof(FastEncodeResult), hipMemcpyDeviceToHost, st);
       if (!ctx.sync()) return kFailed;
-      if (pinRes->redo) { redo = true; break; }
+      if (pinRes->redo || pinRes->stuck) { redo = true; break; }
       const u32 bandBytes = pinRes->blobSize;
       if (total + bandBytes > (u64)UINT_MAX) return kDimsTooLarge;
       if (rq.dOut)
@@ -999,7 +999,7 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
     redo.clear();
     for (int i = 0; i < n; i++)
     {
-      if (res[i].redo)
+      if (res[i].redo || res[i].stuck)
       {
         if (res[i].redoReason == 64u) return kBufferTooSmall;    // the arena is full
         redo.push_back(t0 + i);

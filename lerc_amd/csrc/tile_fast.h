@@ -19,6 +19,8 @@ struct FastEncodeResult
   u64 minKey, maxKey;
   u32 prefixLen;       // bytes before the first block
   u32 checksum;
+  u32 stuck;           // != 0: a workgroup gave up waiting for another one (never seen; the host then takes the general path)
+  u32 pad;
 };
 
 #ifdef LERC_SMALL_GROUPS                   // (emulator builds: small rasters then take the multi-group hand-offs too)

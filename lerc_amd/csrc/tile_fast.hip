@@ -333,6 +333,7 @@ fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u3
   res->minKey = a; res->maxKey = b;
   res->prefixLen = prefixLen;
   res->checksum = 0;
+  __hip_atomic_store(&res->stuck, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (written through: a workgroup that gives up much later says so the same way)
   if (redo) return redo;
 
   // header + "no mask" + ranges + "not one sweep" (Lerc2.cpp:396-430)
@@ -881,6 +882,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
       __builtin_amdgcn_s_sleep(8);
       cell = observe64(solo.cells + wg);
     }
+    if ((u32)(cell >> 32) != solo.epoch) __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_spanBase = (u32)cell;
   }
   __syncthreads();
@@ -995,7 +997,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
       {
         acc = gi < nGroups ? observe64(packPart + gi) : 0ull;
         if (!__any((u32)(acc >> 48) != want)) break;
-        if (spin > (1u << 22)) break;          // (never: every other workgroup was dispatched before this one)
+        if (spin > (1u << 22)) { if (lane == 0) __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }    // (never: every other workgroup was dispatched before this one)
         __builtin_amdgcn_s_sleep(8);
       }
       fA += acc & 0xFFFFFFull; fB += (acc >> 24) & 0xFFFFFFull;
@@ -1034,7 +1036,7 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
       {
         acc = gi <= nGroups ? observe64(packPart + gi) : 0ull;
         if (!__any((u32)(acc >> 48) != want)) break;
-        if (spin > (1u << 22)) break;          // (never: every other workgroup was dispatched before this one)
+        if (spin > (1u << 22)) { if (lane == 0) __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }    // (never: every other workgroup was dispatched before this one)
         __builtin_amdgcn_s_sleep(8);
       }
       fA += acc & 0xFFFFFFull; fB += (acc >> 24) & 0xFFFFFFull;

@@ -741,6 +741,7 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
       __builtin_amdgcn_s_sleep(4);
       if (g < group && (u32)(cell >> 32) != epoch) cell = observe64(b.groupCell + g);
     }
+    if (g < group && (u32)(cell >> 32) != epoch) b.fallback[1] = epoch;    // (gave up waiting: never seen; the general path takes the band)
     base += g < group ? (u32)cell : 0u;
   }
   base = waveSum(base);
@@ -880,6 +881,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
         __builtin_amdgcn_s_sleep(4);
         cell = observe64(b.chunkCell + 2 * (size_t)c + 1);
       }
+      if ((u32)(cell >> 32) != epoch) { b.fallback[3] = epoch; cell = 0xFFFFull << 16; }    // (gave up waiting: never seen)
       n = (u32)cell & 0xFFFFu; ln = ((u32)cell >> 16) & 0xFFFFu;
       if (ln == 0xFFFFu) { n = 0; ln = 0; }    // (no path through this chunk: the resolving block has raised the flag)
     }
@@ -932,6 +934,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
         __builtin_amdgcn_s_sleep(4);
         cell = observe64(b.chunkCell + 2 * (size_t)c);
       }
+      if ((u32)(cell >> 32) != epoch) b.fallback[3] = epoch;    // (gave up waiting: never seen)
       first = (u32)cell;
     }
     s_first[threadIdx.x] = first;
