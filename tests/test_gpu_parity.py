@@ -425,3 +425,42 @@ def test_c4_full_size_4096_rgb_uint8_huffman(P, O):
     assert rc_o == 0 and len(blob) == len(blob_o) and sha(blob) == sha(blob_o)
     rc, dec, _ = P.decode(blob)
     assert rc == 0 and np.array_equal(dec.reshape(x.shape), x)
+
+
+def test_queued_device_calls(O):
+    """lerc_amd_encode_device_async / lerc_amd_decode_device_async / lerc_amd_finish on device tensors: operations queue up
+    on the stream; a decode enqueued right behind the encode that writes its blob gets the buffer's capacity as size bound
+    (the grids are sized for that, the stream's true end is read from the header on the device); what the device hands
+    back to the general path (a constant raster) is repeated at finish time."""
+    import torch
+    from lerc_amd import api
+    dev = torch.device("cuda:0")
+    codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(8)
+    try:
+        rasters = [cases.terrain(1024, 2048, rng, amp=300, base=1000, sigma=1.5).astype(np.float32),
+                   np.full((64, 512), 3.5, np.float32),                                           # constant: the device says "redo"
+                   cases.terrain(264, 1000, rng, amp=300, base=1000, sigma=1.5).astype(np.int32),
+                   cases.terrain(2048, 4096, rng, amp=50, base=100, sigma=0.3).astype(np.float32)]
+        errs = [0.01, 0.01, 0, 0.001]
+        keep, tickets = [], []
+        for arr, e in zip(rasters, errs):
+            x = torch.from_numpy(arr).to(dev)
+            blob = torch.empty(arr.nbytes + 4096, dtype=torch.uint8, device=dev)
+            y = torch.empty_like(x)
+            rc, t1 = api.encode_device_async(codec, x, e, blob)
+            assert rc == 0 and t1
+            rc, t2 = api.decode_device_async(codec, blob, blob.numel(), y)
+            assert rc == 0 and t2
+            keep.append((x, blob, y))
+            tickets.append((t1, t2))
+        for arr, e, (x, blob, y), (t1, t2) in zip(rasters, errs, keep, tickets):
+            rc, n = codec.finish(t1)
+            assert rc == 0
+            r0, b0 = O.encode(arr, e)
+            assert r0 == 0 and blob[:n].cpu().numpy().tobytes() == b0, arr.shape
+            rc, _ = codec.finish(t2)
+            assert rc == 0
+            assert _same(O.decode(b0)[1].reshape(arr.shape), y.cpu().numpy()), arr.shape
+    finally:
+        codec.close()
