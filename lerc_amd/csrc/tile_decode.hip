@@ -750,7 +750,7 @@ static void launchWalkRestT(const BandParams& p, const WalkPlan& wp, const Decod
 {
   const dim3 gridC((wp.nChunks + 255) / 256), gridL((wp.nChunks + kLdsWalkChunks - 1) / kLdsWalkChunks);
   // Small streams walk out of LDS (eight lanes per workgroup, 0.3 us a step instead of 2); large ones have tens of thousands
-  // of lanes in flight to hide the round trips and are faster one lane per chunk (8192^2 with a 10 % mask: 0.93 against 1.69 ms)
+  // of lanes in flight to hide the round trips and are faster one lane per chunk (8192^2 with a 10 % mask, same box: 1.52 against 1.84 ms)
   const bool lds = wp.chunkBytes <= kMemoChunk && wp.window <= kMemoWindowMax && wp.nChunks <= 1024u;
   if (lds)
     hipLaunchKernelGGL(k_walk_counts_lds<TBYTES>, gridL, dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, (const u32*)wb.chunkExit,
