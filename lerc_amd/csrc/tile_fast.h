@@ -159,7 +159,6 @@ static const int kDiscWalks = 8;           // walks per chunk (path heads among 
 #endif
 static const int kDiscChunks = LERC_DISC_CHUNKS;    // chunks per workgroup of k_fast_discover: 8 or 16 (16 threads each; 8 is 8 % slower)
 static const int kDiscThreads = 16 * kDiscChunks;
-static const u32 kDiscResident = 1024;     // discovery workgroups one launch holds for a single raster (256 CUs x 4 by LDS)
 static const int kFastListCap = 128;       // block starts a walk can list per chunk (more, i.e. blocks of < 16 bytes on average: general path)
 static const u32 kResolveWG = 256;         // chunks per resolving block of k_fast_decode
 static const u32 kDecodeChunks = 4;        // chunks whose blocks a workgroup of k_fast_decode decodes (divides kResolveWG)

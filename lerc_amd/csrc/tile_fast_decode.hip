@@ -377,6 +377,8 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
 
   PROBE_BEGIN;
   const int lane = laneId(), w = waveId();
+  const u32 c0 = blockIdx.x * NCH;                         // first chunk of this workgroup
+  const u32 r0 = c0 * CH;                                  // blob offset of LDS byte 0
 
   // ---- the band header first: a caller that only knows the capacity of the blob's buffer (a decode enqueued behind the
   // encode that writes it) launches workgroups for all of it, and those behind the stream's end must not drag a third of a
@@ -390,47 +392,34 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   }
   else hl = parseHeadLite<DT>(blob, sizeGiven);
   const u32 nChunks = (hl.blobEnd + CH - 1) / CH;
-  const u32 nGroups = (nChunks + NCH - 1) / NCH;
-  // A workgroup takes the groups of NCH chunks blockIdx.x, blockIdx.x + gridDim.x, ...: the launch holds as many workgroups as
-  // the chip keeps resident, and the bytes of a workgroup's NEXT group are asked for as soon as this group's are in LDS,
-  // so that they arrive while this group's blocks are found and walked (a third of a group's time was waiting for them).
-  u32 grp = blockIdx.x;
-  if (!hl.ok || grp >= nGroups) return;    // (the grid is sized for the largest stream the blob could hold)
+  if (!hl.ok || c0 >= nChunks) return;    // (the grid is sized for the largest stream the blob could hold)
   const int version = (int)hl.version;
   const bool v5 = version >= 5;
   const u32 dataBegin = hl.dataBegin, blobEnd = hl.blobEnd;
   const u32 pattern = v5 ? 14u : 15u;
   PROBE(12);
 
-  // ---- a group's chunks, all loads in flight at once (clipped to what the caller says is readable)
+  // ---- the workgroup's chunks, all loads in flight at once (clipped to what the caller says is readable)
   constexpr int kRounds = (int)((kStageUnits + NT - 1) / NT);
   uint4 x[kRounds];
-  auto fetchGroup = [&](u32 g)
+#pragma unroll
+  for (int k = 0; k < kRounds; k++)
   {
-#pragma unroll
-    for (int k = 0; k < kRounds; k++)
+    const u32 i = (u32)k * NT + threadIdx.x;
+    const u64 a = (u64)r0 + 16ull * i;
+    x[k] = make_uint4(0, 0, 0, 0);
+    if (i < kStageUnits)
     {
-      const u32 i = (u32)k * NT + threadIdx.x;
-      const u64 a = (u64)g * (NCH * CH) + 16ull * i;
-      x[k] = make_uint4(0, 0, 0, 0);
-      if (i < kStageUnits)
+      if (a + 16 <= sizeGiven) x[k] = *reinterpret_cast<const uint4*>(blob + a);
+      else if (a < sizeGiven)    // never read past the blob
       {
-        if (a + 16 <= sizeGiven) x[k] = *reinterpret_cast<const uint4*>(blob + a);
-        else if (a < sizeGiven)    // never read past the blob
-        {
-          u32 t4[4] = { 0, 0, 0, 0 };
+        u32 t4[4] = { 0, 0, 0, 0 };
 #pragma unroll
-          for (u32 q = 0; q < 16; q++) if (a + q < sizeGiven) t4[q >> 2] |= (u32)blob[a + q] << (8 * (q & 3));
-          x[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-        }
+        for (u32 q = 0; q < 16; q++) if (a + q < sizeGiven) t4[q >> 2] |= (u32)blob[a + q] << (8 * (q & 3));
+        x[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
       }
     }
-  };
-  fetchGroup(grp);
-  for (;;)
-  {
-  const u32 c0 = grp * NCH;                                // first chunk of this group
-  const u32 r0 = c0 * CH;                                  // blob offset of LDS byte 0
+  }
 
   // ---- stage + Fletcher terms of the units this workgroup owns (bytes 14 ... blobEnd - 1 of the blob are checksummed)
   u32 fA = 0;
@@ -464,8 +453,6 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     }
   }
   PROBE(14);
-  const u32 grpNext = grp + gridDim.x;
-  if (grpNext < nGroups) fetchGroup(grpNext);    // (x is free again; the loads land while this group is worked on)
   {
     // (no reduction mod 65535 before the sums: a lane holds 9 units, A < 2^23 and B < 2^54 per lane)
     const u64 A = waveSum(fA), B = waveSum(fB);
@@ -474,15 +461,15 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   if (threadIdx.x == 0) s_over = 0u;
   for (u32 i = threadIdx.x; i < (NCH + 1) * kBitWords; i += NT) (&s_hits[0][0])[i] = 0u;
   if (threadIdx.x == 0) { s_nFound = 0u; s_nHit = 0u; }
-  ldsBarrier();
+  __syncthreads();
   PROBE(16);
   if (threadIdx.x == 0)
   {
     u64 A = 0, B = 0;
 #pragma unroll
     for (u32 k = 0; k < kWaves; k++) { A += s_fa[k]; B += s_fb[k]; }
-    b.waveFletcher[2 * (size_t)grp] = A % 65535u;
-    b.waveFletcher[2 * (size_t)grp + 1] = B % 65535u;
+    b.waveFletcher[2 * (size_t)blockIdx.x] = A % 65535u;
+    b.waveFletcher[2 * (size_t)blockIdx.x + 1] = B % 65535u;
   }
 
   // ---- bit-stuffed block headers in the first `window` bytes of every chunk (+ the next workgroup's first one).
@@ -514,7 +501,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
       if (at < kFoundCap) s_found[at] = (u16)((win << 11) | (4u * d + j)); else s_over = 1u;
     }
   }
-  ldsBarrier();
+  __syncthreads();
   // a count byte stands 2 + (bytes of the offset) behind the block's flag byte: try each offset type, one lane each
   {
     const u32 nFound = min(s_nFound, kFoundCap);
@@ -540,14 +527,14 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     const u32 at = atomicAdd(&s_nHit, 1u);
     if (at < kHitCap) s_hit[at] = (u16)p; else s_over = 1u;
   }
-  ldsBarrier();
+  __syncthreads();
   PROBE(17);
 
   // ---- of the blocks found, those that are not the block right behind another one start a walk (the true path crosses
   // a window in several blocks, each of them found)
   for (u32 i = threadIdx.x; i < NCH * kBitWords; i += NT) (&s_heads[0][0])[i] = (&s_hits[0][0])[i];
   if (threadIdx.x < NCH) s_nFinal[threadIdx.x] = 0u;
-  ldsBarrier();
+  __syncthreads();
   constexpr u32 kMaxRel = NCH * CH + W - 1;                               // last staged byte a block may start at
   const u32 nHit = min(s_nHit, kHitCap);
   for (u32 h = threadIdx.x; h < nHit; h += NT)
@@ -568,7 +555,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     // a block's offset often looks like a flag byte in front of the same header (one such twin per block)
     if (len == 0u || (!follows && cur + len < blobEnd)) atomicAnd(&s_heads[hWin][hPos >> 5], ~(1u << (hPos & 31u)));
   }
-  ldsBarrier();
+  __syncthreads();
   // (walk slots in the order of the heads' positions: the path's head is nearly always the first one, so that the decode
   // kernel can fetch "walk 0 of the chunk" before it has been told which walk it is)
   for (u32 h = threadIdx.x; h < nHit; h += NT)
@@ -584,7 +571,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     }
   }
   PROBE(19);
-  ldsBarrier();
+  __syncthreads();
   PROBE(20);
 
   // ---- walks: lane = (chunk, head); the first wave takes the first heads of every chunk (there are seldom more than two).
@@ -662,7 +649,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     if (__any(tooMany) && lane == 0) s_over = 1u;
   }
   PROBE(21);
-  ldsBarrier();
+  __syncthreads();
   // what all live walks of a chunk agree on
   if (threadIdx.x < NCH && c0 + threadIdx.x < nChunks)
   {
@@ -678,10 +665,6 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     rec->nLive = n;
   }
   if (threadIdx.x == 0 && s_over) b.fallback[0] = b.epoch;
-  if (grpNext >= nGroups) break;
-  grp = grpNext;
-  ldsBarrier();    // (the tables above are read before the next group overwrites them)
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1143,10 +1126,8 @@ __device__ __forceinline__ void tileSlice(FastDecodeBuffers& b, const FastDecode
   if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
 }
 
-// (four waves per SIMD -- four workgroups per CU, what the LDS allows -- need the registers kept at 128: with the next
-// group's bytes in flight in registers the compiler would take one more)
 template<int DT>
-__global__ void __launch_bounds__(kDiscThreads, 4)
+__global__ void __launch_bounds__(kDiscThreads)
 k_fast_discover(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 sizeGiven, int nRows, int nCols)
 {
   tileSlice(b, t, blob, sizeGiven, blockIdx.y);
@@ -1178,9 +1159,7 @@ static void launchFastDecodeT(int stage, int nRows, int nCols, const FastDecodeB
   switch (stage)
   {
     case 0:
-      // (as many workgroups as stay resident -- four per CU by their LDS -- each taking several groups of chunks; batches:
-      // a tile's few groups one workgroup each)
-      hipLaunchKernelGGL(k_fast_discover<DT>, dim3(std::min<u32>(t.nWaves, kDiscResident), nT), dim3(kDiscThreads), 0, st, b, t, blob, sizeGiven, nRows, nCols);
+      hipLaunchKernelGGL(k_fast_discover<DT>, dim3(t.nWaves, nT), dim3(kDiscThreads), 0, st, b, t, blob, sizeGiven, nRows, nCols);
       break;
     default:
       hipLaunchKernelGGL((k_fast_decode<T>), dim3(nT * ((t.nChunks + kResolveWG - 1) / kResolveWG + (t.nChunks + kDecodeChunks - 1) / kDecodeChunks)),

@@ -49,17 +49,6 @@ __device__ __forceinline__ void drainVmem()
 // (per XCD, not coherent) L2, so that no release fence -- which would write back every dirty line of the L2 -- is needed
 __device__ __forceinline__ void publish64(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 observe64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// A workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also waits for every global load the
-// wave has in flight, which is exactly what a kernel that fetches its next piece of work ahead of time does not want.
-// For phases that hand data over through LDS alone.
-__device__ __forceinline__ void ldsBarrier()
-{
-#ifdef HIPSIM
-  __syncthreads();
-#else
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-}
 // draws an arrival ticket; true for the workgroup that draws the last of `expected` (call by ONE thread, after
 // drainVmem() + __syncthreads())
 __device__ __forceinline__ bool lastArrival(u32* ticket, u32 expected)
