@@ -56,7 +56,11 @@ static const int kFastPrefixStage = 128;   // bytes reserved per tile for header
 
 // One raster (no batch) is encoded in two launches: the statistics step, then a pack step whose first blocks do the scan and
 // take the decisions while the others pack (k_fast_pack<SOLO>).  The cells live as long as the codec context.
+#ifdef LERC_SMALL_GROUPS                   // (emulator builds: small rasters then take several scan blocks)
+static const u32 kSoloSlice = 4;
+#else
 static const u32 kSoloSlice = 4096;        // workgroups one scan block places (16 per thread)
+#endif
 struct FastSolo
 {
   u64* cells;          // [nWG] epoch (32) | where the workgroup's span starts behind the header (32); nullptr: not this mode
@@ -160,7 +164,12 @@ static const int kDiscWalks = 8;           // walks per chunk (path heads among 
 static const int kDiscChunks = LERC_DISC_CHUNKS;    // chunks per workgroup of k_fast_discover: 8 or 16 (16 threads each; 8 is 8 % slower)
 static const int kDiscThreads = 16 * kDiscChunks;
 static const int kFastListCap = 128;       // block starts a walk can list per chunk (more, i.e. blocks of < 16 bytes on average: general path)
-static const u32 kResolveWG = 256;         // chunks per resolving block of k_fast_decode
+static const u32 kResolveWG = 256;         // threads of a resolving block of k_fast_decode (= of any block of that launch)
+#ifdef LERC_SMALL_GROUPS                   // (emulator builds: small streams then take several resolving blocks)
+static const u32 kResolveChunks = 4;
+#else
+static const u32 kResolveChunks = 256;     // chunks a resolving block takes, one per thread
+#endif
 static const u32 kDecodeChunks = 4;        // chunks whose blocks a workgroup of k_fast_decode decodes (divides kResolveWG)
 // longest block the streaming walk accepts: the raw form (the reference encoder never emits a longer one)
 constexpr u32 kFastWindow(int typeBytes) { return 2u + 64u * (u32)typeBytes; }
@@ -199,7 +208,7 @@ struct FastDecodeBuffers
   u16* lists;          // [nChunks * kDiscWalks * kFastListCap] block starts relative to the chunk, per walk
   u64* chunkCell;      // [2 * nChunks] what the resolving blocks found: epoch (32) | index of the chunk's first block (32), and
                        // epoch (32) | the walk that is the true path, 0xFFFF: none (16) | blocks that start in the chunk (16)
-  u64* groupCell;      // [ceil(nChunks / kResolveWG)] epoch (32) | blocks of a resolving block's chunks (32)
+  u64* groupCell;      // [ceil(nChunks / kResolveChunks)] epoch (32) | blocks of a resolving block's chunks (32)
   u64* waveFletcher;   // [2 * nWaves] Fletcher partial sums (mod 65535) of the bytes each discovery workgroup staged
   FastDecodeParams* params;   // [nTiles]
   u32* fallback;       // [4 * nTiles] epoch tagged, see above
@@ -217,7 +226,7 @@ struct FastDecodeBatch
   const u32* tileSize;               // device [nTiles]
 };
 LERC_HD u32 fastChunkStride(u32 nChunks) { return nChunks + 4u; }    // chunk cells per tile
-LERC_HD u32 fastGroupStride(u32 nChunks) { return (nChunks + kResolveWG - 1u) / kResolveWG + 1u; }    // group cells per tile
+LERC_HD u32 fastGroupStride(u32 nChunks) { return (nChunks + kResolveChunks - 1u) / kResolveChunks + 1u; }    // group cells per tile
 
 bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid);
 FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven);

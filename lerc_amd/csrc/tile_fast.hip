@@ -582,17 +582,27 @@ soloScanDecide(u32 s, const T* __restrict__ data, const BandParams& p, double re
   }
   sum = waveSum(sum);
   if (lane == 0) s_sum[w] = sum;
-  // ---- the slice: 16 sizes per thread
-  u32 e[16], mine = 0;
-  const u32 i0 = sliceBegin + 16u * threadIdx.x;
-#pragma unroll
-  for (u32 q = 0; q < 4; q++)
+  // ---- the slice: kPer sizes per thread (16; emulator builds: 1, most threads idle)
+  constexpr u32 kPer = (kSoloSlice + 255u) / 256u;
+  const u32 sliceEnd = min(sliceBegin + kSoloSlice, nWG);
+  u32 e[kPer], mine = 0;
+  const u32 i0 = sliceBegin + kPer * threadIdx.x;
+  if constexpr (kPer % 4u == 0u)
   {
-    const uint4 x = *reinterpret_cast<const uint4*>(wgSize + min(i0 + 4u * q, lastVec));
-    e[4 * q] = x.x; e[4 * q + 1] = x.y; e[4 * q + 2] = x.z; e[4 * q + 3] = x.w;
+#pragma unroll
+    for (u32 q = 0; q < kPer / 4u; q++)
+    {
+      const uint4 x = *reinterpret_cast<const uint4*>(wgSize + min(i0 + 4u * q, lastVec));
+      e[4 * q] = x.x; e[4 * q + 1] = x.y; e[4 * q + 2] = x.z; e[4 * q + 3] = x.w;
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (u32 k = 0; k < kPer; k++) e[k] = wgSize[min(i0 + k, nWG - 1u)];
   }
 #pragma unroll
-  for (u32 k = 0; k < 16; k++) { e[k] = (i0 + k < nWG) ? e[k] : 0u; mine += e[k]; }
+  for (u32 k = 0; k < kPer; k++) { e[k] = (i0 + k < sliceEnd) ? e[k] : 0u; mine += e[k]; }
   const u32 inc = waveInclusiveScan(mine);
   if (lane == 63) s_w[w] = inc;
   __syncthreads();
@@ -600,9 +610,9 @@ soloScanDecide(u32 s, const T* __restrict__ data, const BandParams& p, double re
   u32 run = (s ? total : 0u) + inc - mine;
   for (int i = 0; i < w; i++) run += s_w[i];
 #pragma unroll
-  for (u32 k = 0; k < 16; k++)
+  for (u32 k = 0; k < kPer; k++)
   {
-    if (i0 + k < nWG) publish64(cells + i0 + k, ((u64)epoch << 32) | run);
+    if (i0 + k < sliceEnd) publish64(cells + i0 + k, ((u64)epoch << 32) | run);
     run += e[k];
   }
   if (s != 0u) return;

@@ -679,15 +679,16 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
   __shared__ u64 s_a[kResolveWG / 64], s_b[kResolveWG / 64];
   const FastDecodeParams hp = *b.params;
   const u32 blobEnd = hp.blobEnd;
-  const u32 c = group * kResolveWG + threadIdx.x;
+  const u32 c = group * kResolveChunks + threadIdx.x;
   // (the records first: their addresses do not hang on the header)
   const u32 cPrev = c ? c - 1u : 0u;
   const u32 prevExit = b.recs[cPrev].exit;
-  if (!hp.ok || group * kResolveWG >= hp.nChunks) return;    // (the grid is sized for the largest stream the blob could hold)
+  if (!hp.ok || group * kResolveChunks >= hp.nChunks) return;    // (the grid is sized for the largest stream the blob could hold)
   const int lane = laneId(), w = waveId();
   u32 count = 0, laneOfPath = kNoOffset;
   bool bad = false;
-  if (c < hp.nChunks)
+  const bool mine = threadIdx.x < kResolveChunks && c < hp.nChunks;
+  if (mine)
   {
     const u32 chunkStart = c * kFastChunkBytes, chunkEnd = min(chunkStart + kFastChunkBytes, blobEnd);
     const u32 e = (chunkStart <= hp.dataBegin) ? hp.dataBegin : prevExit;
@@ -728,7 +729,7 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
   // this block's total goes out at once; the blocks in front of it -- dispatched earlier, waiting for nobody before they
   // publish theirs -- are read in one go (a cell is read by the few hundred resolving blocks behind it, no more)
   const u32 epoch = b.epoch;
-  const u32 nGroups = (hp.nChunks + kResolveWG - 1u) / kResolveWG;
+  const u32 nGroups = (hp.nChunks + kResolveChunks - 1u) / kResolveChunks;
   __shared__ u32 s_base[kResolveWG / 64];
   if (threadIdx.x == kResolveWG - 1) publish64(b.groupCell + group, ((u64)epoch << 32) | (before + inc));
   u32 base = 0;
@@ -750,7 +751,7 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
   __syncthreads();
   base = 0;
   for (u32 i = 0; i < kResolveWG / 64; i++) base += s_base[i];
-  if (c < hp.nChunks) publish64(b.chunkCell + 2 * (size_t)c, ((u64)epoch << 32) | (base + before + inc - count));
+  if (mine) publish64(b.chunkCell + 2 * (size_t)c, ((u64)epoch << 32) | (base + before + inc - count));
   // the chunks hold all the raster's blocks, or the band goes the long way
   if (group == nGroups - 1u && threadIdx.x == kResolveWG - 1 && base + before + inc != hp.nBlocks) b.fallback[2] = epoch;
 
@@ -1133,14 +1134,14 @@ k_fast_discover(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 size
   tileSlice(b, t, blob, sizeGiven, blockIdx.y);
   fastDiscoverBody<DT>(blob, sizeGiven, nRows, nCols, b);
 }
-// The first blocks of the launch resolve (kResolveWG chunks each; all tiles' resolving blocks first, so that a batch's decode
+// The first blocks of the launch resolve (kResolveChunks chunks each; all tiles' resolving blocks first, so that a batch's decode
 // workgroups find the cells of their tile ready like those of a single raster do), the others decode (kDecodeChunks chunks each).
 template<class T>
 __global__ void __launch_bounds__(256)
 k_fast_decode(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, T* __restrict__ outPix)
 {
   static_assert(kResolveWG == 256, "a resolving block is a block of this launch");
-  const u32 nResolve = (t.nChunks + kResolveWG - 1u) / kResolveWG, nDecode = (t.nChunks + kDecodeChunks - 1u) / kDecodeChunks;
+  const u32 nResolve = (t.nChunks + kResolveChunks - 1u) / kResolveChunks, nDecode = (t.nChunks + kDecodeChunks - 1u) / kDecodeChunks;
   const bool resolving = blockIdx.x < t.nTiles * nResolve;
   const u32 rest = resolving ? blockIdx.x : blockIdx.x - t.nTiles * nResolve, per = resolving ? nResolve : nDecode;
   const u32 tile = rest / per, index = rest - tile * per;
@@ -1162,7 +1163,7 @@ static void launchFastDecodeT(int stage, int nRows, int nCols, const FastDecodeB
       hipLaunchKernelGGL(k_fast_discover<DT>, dim3(t.nWaves, nT), dim3(kDiscThreads), 0, st, b, t, blob, sizeGiven, nRows, nCols);
       break;
     default:
-      hipLaunchKernelGGL((k_fast_decode<T>), dim3(nT * ((t.nChunks + kResolveWG - 1) / kResolveWG + (t.nChunks + kDecodeChunks - 1) / kDecodeChunks)),
+      hipLaunchKernelGGL((k_fast_decode<T>), dim3(nT * ((t.nChunks + kResolveChunks - 1) / kResolveChunks + (t.nChunks + kDecodeChunks - 1) / kDecodeChunks)),
                          dim3(256), 0, st, b, t, blob, (T*)out);
       break;
   }
