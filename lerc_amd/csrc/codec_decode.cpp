@@ -88,7 +88,7 @@ static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven, u32 nTiles 
 // nothing is read back here.  dParams [nTiles] and dFallback [4 * nTiles] receive the verdicts; the flags in dFallback
 // are raised by writing `epoch` (tile_fast.h), so the cells need no clearing.
 static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8* dBlobs, u32 sizeBound, u32 nTiles, const u64* dTileOffset,
-                            const u32* dTileSize, void* dOut, FastDecodeParams* dParams, u32* dFallback, u32 epoch)
+                            const u32* dTileSize, void* dOut, FastDecodeParams* dParams, u32* dFallback, u32 epoch, u8* hCell = nullptr)
 {
   hipStream_t st = ctx.activeStream();
   const FastWalkPlan fwp = makeFastWalkPlan(nRows, nCols, sizeBound);
@@ -106,6 +106,8 @@ static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8
   fbuf.waveFletcher = ctx.allocT<u64>(2 * nT * (size_t)fwp.nWaves + 4);
   fbuf.params = dParams;
   fbuf.fallback = dFallback;
+  fbuf.hostParams = hCell ? reinterpret_cast<FastDecodeParams*>(hCell + kCellParams) : nullptr;
+  fbuf.hostFallback = hCell ? reinterpret_cast<u32*>(hCell + kCellFallback) : nullptr;
   fbuf.epoch = epoch;
   if (!fbuf.recs || !fbuf.lists || !fbuf.chunkCell || !fbuf.waveFletcher)
     return false;
@@ -118,10 +120,11 @@ static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8
   return true;
 }
 
-static bool launchFastBand(Context& ctx, int dt, int nRows, int nCols, const u8* dBand, u32 sizeGiven, void* dOutBand, u8* dCell, u32 epoch)
+static bool launchFastBand(Context& ctx, int dt, int nRows, int nCols, const u8* dBand, u32 sizeGiven, void* dOutBand, u8* dCell, u32 epoch,
+                           u8* hCell = nullptr)
 {
   return launchFastBands(ctx, dt, nRows, nCols, dBand, sizeGiven, 1, nullptr, nullptr, dOutBand,
-                         reinterpret_cast<FastDecodeParams*>(dCell + kCellParams), reinterpret_cast<u32*>(dCell + kCellFallback), epoch);
+                         reinterpret_cast<FastDecodeParams*>(dCell + kCellParams), reinterpret_cast<u32*>(dCell + kCellFallback), epoch, hCell);
 }
 
 // reason bits of a tile's / band's four epoch tagged flag cells
@@ -162,9 +165,11 @@ bool decodeEnqueueStreaming(Context& ctx, const DecodeRequest& rq, u8* slot, u32
   u8* dCells = ctx.allocT<u8>(cellsBytes);
   if (!dCells) return false;
   epoch = ctx.nextEpoch();
-  if (!launchFastBand(ctx, dt, nRows, nCols, rq.dBlob, rq.blobSize, rq.dOut, dCells + 64, epoch)) return false;
+  // (the kernels write the verdict -- header check, checksum, flags -- through to `slot`, pinned host memory, as well as to
+  // the device cell they read it back from: a copy kernel behind the decode would cost every call 4 us)
+  if (!launchFastBand(ctx, dt, nRows, nCols, rq.dBlob, rq.blobSize, rq.dOut, dCells + 64, epoch, slot + 64)) return false;
   if (rq.nMasks > 0 && rq.dValidBytes) hipMemsetAsync(rq.dValidBytes, 1, (size_t)nRows * nCols, st);    // numValid == nPix or no verdict
-  return hipMemcpyAsync(slot, dCells, cellsBytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+  return true;
 }
 
 bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch)

@@ -802,8 +802,12 @@ bool encodeEnqueueStreaming(Context& ctx, const EncodeRequest& rq, u8* slot)
   if (!ctx.reserve(fastEncodeWorkspace(rq.nRows, rq.nCols, 1) + (1u << 16))) return false;
   FastEncodeLaunch fl;
   if (!prepareFastEncode(ctx, rq.dt, rq.nRows, rq.nCols, rq.maxZErr, 1, 0, false, fl)) return false;
+  // (one raster: the deciding block and the last workgroup write the result straight into `slot`, pinned host memory -- no
+  // kernel reads it, and a copy kernel behind the encode would cost every call 4 us)
+  const bool direct = fl.fb.solo.cells != nullptr;
+  if (direct) fl.fb.result = reinterpret_cast<FastEncodeResult*>(slot);
   runFastEncode(ctx, fl, rq.dData, rq.dOut, rq.dOut ? (u64)rq.outCapacity : ~0ull, 0);
-  return hipMemcpyAsync(slot, fl.fb.result, sizeof(FastEncodeResult), hipMemcpyDeviceToHost, ctx.activeStream()) == hipSuccess;
+  return direct || hipMemcpyAsync(slot, fl.fb.result, sizeof(FastEncodeResult), hipMemcpyDeviceToHost, ctx.activeStream()) == hipSuccess;
 }
 
 void encodeStreamingVerdict(Context& ctx, const EncodeRequest& rq, const u8* slot, bool& redo, u32& status, u32& numBytesNeeded, u32& numBytesWritten)
@@ -871,8 +875,10 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
     {
       fl.batch.nBlobsMore = (u32)(rq.nBands - 1 - iBand);
       const u8* dBand = (const u8*)rq.dData + (size_t)iBand * nPix * tb;
+      const bool direct = fl.fb.solo.cells != nullptr;    // (the kernels write the result into pinned memory themselves)
+      if (direct) fl.fb.result = pinRes;
       runFastEncode(ctx, fl, dBand, dBandBlob, dBandBlob ? (u64)bandCap : ~0ull, 0);
-      hipMemcpyAsync(pinRes, fl.fb.result, sizeof(FastEncodeResult), hipMemcpyDeviceToHost, st);
+      if (!direct) hipMemcpyAsync(pinRes, fl.fb.result, sizeof(FastEncodeResult), hipMemcpyDeviceToHost, st);
       if (!ctx.sync()) return kFailed;
       if (pinRes->redo || pinRes->stuck) { redo = true; break; }
       const u32 bandBytes = pinRes->blobSize;

@@ -212,6 +212,8 @@ struct FastDecodeBuffers
   u64* waveFletcher;   // [2 * nWaves] Fletcher partial sums (mod 65535) of the bytes each discovery workgroup staged
   FastDecodeParams* params;   // [nTiles]
   u32* fallback;       // [4 * nTiles] epoch tagged, see above
+  FastDecodeParams* hostParams;    // one band: the same two in pinned host memory (written through by the kernels, so that the
+  u32* hostFallback;               // verdict needs no copy kernel behind the decode); nullptr for batches
   u32 epoch;
 };
 

@@ -36,6 +36,13 @@
 namespace lerc {
 
 static const u32 kNoOffset = 0xFFFFFFFFu;
+// raises flag k of the call (tile_fast.h): in the device cell, and -- one band, whose verdict the host reads straight out of
+// pinned memory -- in the host's
+__device__ __forceinline__ void raiseFlag(const FastDecodeBuffers& b, int k)
+{
+  b.fallback[k] = b.epoch;
+  if (b.hostFallback) b.hostFallback[k] = b.epoch;
+}
 PROBE_DEFINE(fast_decode)
 // The decoded pixels leave with the non-temporal hint: nothing in the call reads them again, and written the ordinary
 // way they sit dirty in L2 / the Infinity Cache until the NEXT kernel's traffic pushes them out (measured on C2: this
@@ -387,7 +394,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   if (blockIdx.x == 0)
   {
     const FastDecodeParams hp = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
-    if (threadIdx.x == 0) *b.params = hp;
+    if (threadIdx.x == 0) { *b.params = hp; if (b.hostParams) *b.hostParams = hp; }
     hl.ok = hp.ok; hl.version = hp.version; hl.dataBegin = hp.dataBegin; hl.blobEnd = hp.blobEnd;
   }
   else hl = parseHeadLite<DT>(blob, sizeGiven);
@@ -664,7 +671,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     rec->exit = (n != 0u && lo == hi) ? lo : kNoOffset;
     rec->nLive = n;
   }
-  if (threadIdx.x == 0 && s_over) b.fallback[0] = b.epoch;
+  if (threadIdx.x == 0 && s_over) raiseFlag(b, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -717,7 +724,7 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
     // still waits for the totals in front of it); epoch (32) | walk (16, 0xFFFF: none) | count (16)
     publish64(b.chunkCell + 2 * (size_t)c + 1, ((u64)b.epoch << 32) | ((u64)(laneOfPath & 0xFFFFu) << 16) | (count & 0xFFFFu));
   }
-  if (__any(bad) && lane == 0) b.fallback[1] = b.epoch;
+  if (__any(bad) && lane == 0) raiseFlag(b, 1);
   // exclusive scan of the counts inside the workgroup
   u32 inc = count;
 #pragma unroll
@@ -742,7 +749,7 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
       __builtin_amdgcn_s_sleep(4);
       if (g < group && (u32)(cell >> 32) != epoch) cell = observe64(b.groupCell + g);
     }
-    if (g < group && (u32)(cell >> 32) != epoch) b.fallback[1] = epoch;    // (gave up waiting: never seen; the general path takes the band)
+    if (g < group && (u32)(cell >> 32) != epoch) raiseFlag(b, 1);    // (gave up waiting: never seen; the general path takes the band)
     base += g < group ? (u32)cell : 0u;
   }
   base = waveSum(base);
@@ -753,7 +760,7 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
   for (u32 i = 0; i < kResolveWG / 64; i++) base += s_base[i];
   if (mine) publish64(b.chunkCell + 2 * (size_t)c, ((u64)epoch << 32) | (base + before + inc - count));
   // the chunks hold all the raster's blocks, or the band goes the long way
-  if (group == nGroups - 1u && threadIdx.x == kResolveWG - 1 && base + before + inc != hp.nBlocks) b.fallback[2] = epoch;
+  if (group == nGroups - 1u && threadIdx.x == kResolveWG - 1 && base + before + inc != hp.nBlocks) raiseFlag(b, 2);
 
   if (group != 0) return;
   // checksum: Fletcher32 over blob[14 ..) from the discovery waves' partial sums (Lerc2.cpp:1037-1064)
@@ -771,7 +778,9 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
   u64 s1 = A, s2 = ((N % 65535u) * A + 65535u - B) % 65535u;
   if (s1 == 0) s1 = 0xffff;
   if (s2 == 0) s2 = 0xffff;
-  b.params->checksumOk = ((u32)((s2 << 16) | s1) == hp.expectChecksum) ? 1u : 0u;
+  const u32 good = ((u32)((s2 << 16) | s1) == hp.expectChecksum) ? 1u : 0u;
+  b.params->checksumOk = good;
+  if (b.hostParams) b.hostParams->checksumOk = good;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -882,7 +891,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
         __builtin_amdgcn_s_sleep(4);
         cell = observe64(b.chunkCell + 2 * (size_t)c + 1);
       }
-      if ((u32)(cell >> 32) != epoch) { b.fallback[3] = epoch; cell = 0xFFFFull << 16; }    // (gave up waiting: never seen)
+      if ((u32)(cell >> 32) != epoch) { raiseFlag(b, 3); cell = 0xFFFFull << 16; }    // (gave up waiting: never seen)
       n = (u32)cell & 0xFFFFu; ln = ((u32)cell >> 16) & 0xFFFFu;
       if (ln == 0xFFFFu) { n = 0; ln = 0; }    // (no path through this chunk: the resolving block has raised the flag)
     }
@@ -935,7 +944,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
         __builtin_amdgcn_s_sleep(4);
         cell = observe64(b.chunkCell + 2 * (size_t)c);
       }
-      if ((u32)(cell >> 32) != epoch) b.fallback[3] = epoch;    // (gave up waiting: never seen)
+      if ((u32)(cell >> 32) != epoch) raiseFlag(b, 3);    // (gave up waiting: never seen)
       first = (u32)cell;
     }
     s_first[threadIdx.x] = first;
@@ -1090,7 +1099,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
     }
   }
   PROBE(11);
-  if ((__any(bad) && lane == 0) || (threadIdx.x == 0 && s_bad)) b.fallback[3] = epoch;
+  if ((__any(bad) && lane == 0) || (threadIdx.x == 0 && s_bad)) raiseFlag(b, 3);
 }
 
 // ------------------------------------------------------------------------------------------------
