@@ -7,7 +7,7 @@ namespace lerc {
 struct HuffGeom { int nRows, nCols, nDepth; };
 
 static const int kHuffRun = 128;         // stream elements per encoder thread
-static const int kHuffSubBits = 1024;    // bits per speculative decode sub-sequence
+static const int kHuffSubWordsMin = 33, kHuffSubWordsMax = 41;    // 32-bit words per speculative decode sub-sequence (odd; huffSubWords picks)
 static const int kHuffLutBits = 12;      // Huffman.h:37 uses the same look-up width
 
 struct HuffDecodeTable
@@ -26,12 +26,13 @@ void launchHuffPack(int dt, const void* data, const u8* maskBits, const HuffGeom
                     u32* stream /* zeroed */, hipStream_t st);
 void launchScan64(const u32* in, u64* out /* n + 1 */, u32 n, u64* scratch /* n/256 + 2 */, hipStream_t st);
 
-void launchHuffInitStarts(u64* starts, u64* prevStarts, u32 nSub, hipStream_t st);
-void launchHuffSync(const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u64* starts,
+u32 huffSubWords(u64 streamBits, u32 slots);
+void launchHuffInitStarts(u64* starts, u64* prevStarts, u32 nSub, u32 subWords, hipStream_t st);
+void launchHuffSync(const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u32 subWords, u64* starts,
                     u64* prevStarts, u64* exits, u32* counts, u32* bad, bool firstRound, hipStream_t st);
 void launchHuffChain(u32 nSub, u64* starts, const u64* exits, u32* changed, hipStream_t st);
 void launchValidIndex(const u8* maskBits, const u32* groupBase, i64 nPix, u32* validIdx, hipStream_t st);
-void launchHuffEmit(int dt, const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, const u64* starts,
+void launchHuffEmit(int dt, const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u32 subWords, const u64* starts,
                     const u64* symBase, const HuffGeom& g, int mode, u64 nSymbols, u32 numValid, const u32* validIdx, bool planar,
                     void* out, hipStream_t st);
 // delta mode without a mask and a few values per pixel: symbols decoded plane by plane (planar = [nDepth][nPix] scratch),

@@ -409,7 +409,11 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
   const u64 streamBytes = blobEnd - streamBegin;
   const u64 nWords = streamBytes / 4;
   const u64 streamBits = nWords * 32;
-  const u32 nSub = (u32)((streamBits + kHuffSubBits - 1) / kHuffSubBits);
+  // sub-sequence length: the decoders' workgroups hold ~52 KB of LDS, three of them share a compute unit
+  static const int computeUnits = []() { hipDeviceProp_t pr; int dev = 0; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+  const u32 subWords = huffSubWords(streamBits, 3u * (u32)computeUnits);
+  const u64 subBits = (u64)subWords * 32u;
+  const u32 nSub = (u32)((streamBits + subBits - 1) / subBits);
 
   // ---- how many symbols, and which pixel each rank maps to
   u32 numValid = (u32)nPix;
@@ -447,7 +451,7 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
   hipMemcpyAsync(dTab, hTab, sizeof(HuffDecodeTable), hipMemcpyHostToDevice, st);
   hipMemcpyAsync(dStream, dBlob + streamBegin, (size_t)nWords * 4, hipMemcpyDeviceToDevice, st);    // word aligned copy
   hipMemsetAsync(dFlags, 0, 16, st);
-  launchHuffInitStarts(dStarts, dPrev, nSub, st);
+  launchHuffInitStarts(dStarts, dPrev, nSub, subWords, st);
 
   // ---- synchronise the sub-sequence starts (speculative decode until the chain of exits is stable); the symbol counts
   // are summed right behind every round, so that the usual single round costs one wait
@@ -460,7 +464,7 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
   {
     { ProfScope ps(ctx, "huff_sync");
       hipMemsetAsync(dFlags, 0, 4, st);
-      launchHuffSync(dStream, nWords, streamBits, dTab, nSub, dStarts, dPrev, dExits, dCounts, dFlags + 1, round == 0, st);
+      launchHuffSync(dStream, nWords, streamBits, dTab, nSub, subWords, dStarts, dPrev, dExits, dCounts, dFlags + 1, round == 0, st);
       launchHuffChain(nSub, dStarts, dExits, dFlags, st); }
     { ProfScope ps(ctx, "huff_scan"); launchScan64(dCounts, dSymBase, nSub, dScr64, st); }
     hipMemcpyAsync(pin, dFlags, 8, hipMemcpyDeviceToHost, st);
@@ -479,11 +483,11 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
   {
     u8* dPlanar = ctx.allocT<u8>((size_t)nSymbols + 16);
     if (!dPlanar) return kFailed;
-    { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, nWords, streamBits, dTab, nSub, dStarts, dSymBase, g, imageMode, nSymbols, numValid, nullptr, true, dPlanar, st); }
+    { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, nWords, streamBits, dTab, nSub, subWords, dStarts, dSymBase, g, imageMode, nSymbols, numValid, nullptr, true, dPlanar, st); }
     { ProfScope ps(ctx, "huff_undelta"); launchHuffUndeltaPlanar(dPlanar, dOut, g, st); }
     return kOk;
   }
-  { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, nWords, streamBits, dTab, nSub, dStarts, dSymBase, g, imageMode, nSymbols, numValid, dValidIdx, false, dOut, st); }
+  { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, nWords, streamBits, dTab, nSub, subWords, dStarts, dSymBase, g, imageMode, nSymbols, numValid, dValidIdx, false, dOut, st); }
   if (imageMode == IEM_DeltaHuffman) { ProfScope ps(ctx, "huff_undelta"); launchHuffUndelta(dt, dOut, dMaskBits, g, st); }
   return kOk;
 }

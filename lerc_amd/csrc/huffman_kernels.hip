@@ -144,19 +144,42 @@ void launchHuffHisto(int dt, const void* data, const u8* maskBits, const HuffGeo
 
 // ---- encode -------------------------------------------------------------------------------------
 // codes[s] = (length << 32) | code bits
+//
+// A workgroup owns 256 runs of kHuffRun stream elements.  All pixels valid: the elements are turned into symbols with the
+// loads of eight steps in flight at a time (a thread walking its run straight from global memory touches a different cache
+// line in every lane, and a loop that waits for each byte load spends its time on memory latency) and parked in LDS,
+// element e of run r at [e][r] (rows 260 bytes apart: conflict-free both ways).  Packing assembles the workgroup's part of
+// the bit stream in LDS (ds_or) and stores it in whole words -- only the first and the last word of the span are shared
+// with the neighbouring workgroups and go out with an atomic OR; a span longer than the LDS area (more than ten bits per
+// symbol on average) is ORed into global memory word by word as the masked path does.
+static const int kHuffSpanWords = 10240;
+static const int kHuffStageBatch = 8;
+
 template<class T, bool PACK>
 __global__ void __launch_bounds__(256)
 k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffGeom g, int mode, const u64* __restrict__ codes,
               u32* __restrict__ runBits, const u64* __restrict__ runBase, u32* __restrict__ stream)
 {
   __shared__ u64 s_codes[256];
-  // all pixels valid: the workgroup's 256 x 128 stream elements are turned into symbols with coalesced loads first and
-  // parked in LDS, element e of run r at [e][r] (rows 260 bytes apart: conflict-free both ways); a thread walking its
-  // run straight from global memory touches a different cache line in every lane
   __shared__ u8 s_sym[kHuffRun * 260];
+  __shared__ u32 s_span[PACK ? kHuffSpanWords : 1];
   s_codes[threadIdx.x] = codes[threadIdx.x];
   const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
+  const i64 nRuns = (n + kHuffRun - 1) / kHuffRun;
   const bool staged = (maskBits == nullptr);
+  // this workgroup's words of the stream
+  u64 spanWord0 = 0;
+  u32 spanWords = 0;
+  bool inLds = false;
+  if (PACK)
+  {
+    const i64 r0 = (i64)blockIdx.x * 256, r1 = (r0 + 256 < nRuns) ? r0 + 256 : nRuns;
+    const u64 bit0 = runBase[r0], bit1 = runBase[r1];
+    spanWord0 = bit0 >> 5;
+    spanWords = (u32)(((bit1 + 31) >> 5) - spanWord0);
+    inLds = staged && spanWords <= (u32)kHuffSpanWords;
+    if (inLds) for (u32 x = threadIdx.x; x < spanWords; x += 256) s_span[x] = 0u;
+  }
   if (staged)
   {
     const int off = (DtOf<T>::v == DT_Char) ? 128 : 0;
@@ -166,37 +189,49 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
     i64 k = 0;
     int iD = 0, i = 0, j = 0;
     if (mode != IEM_Huffman && v < n) { iD = (int)(v / nPix); k = v - (i64)iD * nPix; i = (int)(k / g.nCols); j = (int)(k - (i64)i * g.nCols); }
-    for (int q = 0; q < kHuffRun; q++, v += 256)
+    for (int q0 = 0; q0 < kHuffRun; q0 += kHuffStageBatch)
     {
-      const int idx = (int)threadIdx.x + 256 * q;
-      int sym = 0;
-      if (v < n)
+      i64 aVal[kHuffStageBatch], aPred[kHuffStageBatch];    // byte offsets; -1: no such byte (value 0)
+#pragma unroll
+      for (int b = 0; b < kHuffStageBatch; b++, v += 256)
       {
-        if (mode == IEM_Huffman) sym = off + (int)data[v];
-        else
-        {
-          const T val = data[k * g.nDepth + iD];
-          T pred = 0;
-          if (j > 0) pred = data[(k - 1) * g.nDepth + iD];
-          else if (i > 0) pred = data[(k - g.nCols) * g.nDepth + iD];
-          sym = off + (int)(T)(val - pred);
-          k += 256; j += 256;
-          while (j >= g.nCols) { j -= g.nCols; i++; }
-          if (k >= nPix) { while (k >= nPix) { k -= nPix; iD++; } i = (int)(k / g.nCols); j = (int)(k - (i64)i * g.nCols); }
-        }
+        aVal[b] = -1; aPred[b] = -1;
+        if (v >= n) continue;
+        if (mode == IEM_Huffman) { aVal[b] = v; continue; }
+        aVal[b] = k * g.nDepth + iD;
+        if (j > 0) aPred[b] = aVal[b] - g.nDepth;
+        else if (i > 0) aPred[b] = aVal[b] - (i64)g.nCols * g.nDepth;
+        k += 256; j += 256;
+        while (j >= g.nCols) { j -= g.nCols; i++; }
+        if (k >= nPix) { while (k >= nPix) { k -= nPix; iD++; } i = (int)(k / g.nCols); j = (int)(k - (i64)i * g.nCols); }
       }
-      s_sym[(idx & (kHuffRun - 1)) * 260 + (idx >> 7)] = (u8)sym;
+      T val[kHuffStageBatch], pred[kHuffStageBatch];
+#pragma unroll
+      for (int b = 0; b < kHuffStageBatch; b++)    // (unconditional loads of a clamped address: all of them leave before the first use)
+      {
+        val[b] = data[aVal[b] < 0 ? 0 : aVal[b]];
+        pred[b] = data[aPred[b] < 0 ? 0 : aPred[b]];
+      }
+#pragma unroll
+      for (int b = 0; b < kHuffStageBatch; b++)
+      {
+        const int idx = (int)threadIdx.x + 256 * (q0 + b);
+        const T vv = aVal[b] < 0 ? (T)0 : val[b], pp = aPred[b] < 0 ? (T)0 : pred[b];
+        const int sym = (aVal[b] < 0) ? 0 : off + (int)(T)(vv - pp);
+        s_sym[(idx & (kHuffRun - 1)) * 260 + (idx >> 7)] = (u8)sym;
+      }
     }
   }
   __syncthreads();
   const i64 run = (i64)blockIdx.x * 256 + threadIdx.x;
   const i64 v0 = run * kHuffRun;
-  if (v0 >= n) return;
+  const bool active = v0 < n;
   const i64 v1 = (v0 + kHuffRun < n) ? v0 + kHuffRun : n;
   HuffCursor cur;
-  if (!staged) cur.init(g, mode, v0);
+  if (active && !staged) cur.init(g, mode, v0);
   if (!PACK)
   {
+    if (!active) return;
     u32 bits = 0;
     if (staged) for (int e = 0; e < (int)(v1 - v0); e++) bits += (u32)(s_codes[s_sym[e * 260 + threadIdx.x]] >> 32);
     else
@@ -209,33 +244,47 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
     return;
   }
   // MSB-first packing into little-endian u32 words (Huffman.h:218-255): keep a 64-bit window whose top
-  // bits are the oldest; flush whole words with atomicOr (neighbouring runs share boundary words)
-  u64 pos = runBase[run];
-  u64 w = pos >> 5;
-  int fill = (int)(pos & 31);    // bits already used in the current word (by the previous run)
-  u64 acc = 0;                   // bits of this run for the current word(s), left aligned at bit 63 - fill
-  int have = fill;
-  for (i64 v = v0; v < v1; v++)
+  // bits are the oldest; whole words are ORed into the span (neighbouring runs share boundary words)
+  if (active)
   {
-    int s;
-    if (staged) s = s_sym[(int)(v - v0) * 260 + threadIdx.x];
-    else { s = huffSymbolAt<T>(data, maskBits, g, cur); cur.step(g); }
-    if (s < 0) continue;
-    const u64 c = s_codes[s];
-    const int len = (int)(c >> 32);
-    const u64 code = c & 0xFFFFFFFFull;
-    acc |= code << (64 - have - len);
-    have += len;
-    if (have >= 32)
+    const u64 pos = runBase[run];
+    u64 w = pos >> 5;
+    u64 acc = 0;                   // bits of this run for the current word(s), left aligned behind the previous run's bits
+    int have = (int)(pos & 31);    // bits already used in the current word (by the previous run)
+    for (i64 v = v0; v < v1; v++)
     {
-      atomicOr(&stream[w], (u32)(acc >> 32));
-      acc <<= 32;
-      have -= 32;
-      w++;
+      int s;
+      if (staged) s = s_sym[(int)(v - v0) * 260 + threadIdx.x];
+      else { s = huffSymbolAt<T>(data, maskBits, g, cur); cur.step(g); }
+      if (s < 0) continue;
+      const u64 c = s_codes[s];
+      const int len = (int)(c >> 32);
+      const u64 code = c & 0xFFFFFFFFull;
+      acc |= code << (64 - have - len);
+      have += len;
+      if (have >= 32)
+      {
+        if (inLds) atomicOr(&s_span[(u32)(w - spanWord0)], (u32)(acc >> 32));
+        else atomicOr(&stream[w], (u32)(acc >> 32));
+        acc <<= 32;
+        have -= 32;
+        w++;
+      }
+    }
+    if (have > 0 && (u32)(acc >> 32) != 0u)
+    {
+      if (inLds) atomicOr(&s_span[(u32)(w - spanWord0)], (u32)(acc >> 32));
+      else atomicOr(&stream[w], (u32)(acc >> 32));
     }
   }
-  if (have > 0) atomicOr(&stream[w], (u32)(acc >> 32));
-  (void)fill;
+  if (!inLds) return;    // (uniform over the workgroup)
+  __syncthreads();
+  for (u32 x = threadIdx.x; x < spanWords; x += 256)
+  {
+    const u32 word = s_span[x];
+    if (x == 0u || x + 1u == spanWords) { if (word) atomicOr(&stream[spanWord0 + x], word); }
+    else stream[spanWord0 + x] = word;
+  }
 }
 
 void launchHuffRunBits(int dt, const void* data, const u8* maskBits, const HuffGeom& g, int mode, const u64* codes, u32* runBits,
@@ -320,37 +369,52 @@ __device__ __forceinline__ u32 peek32(const u32* __restrict__ stream, u64 nWords
   return sh ? ((w0 << sh) | (w1 >> (32 - sh))) : w0;
 }
 
-// The decoders run one thread per sub-sequence; read straight from global memory every lane would sit in a cache line
-// of its own.  A workgroup of kHuffDecThreads threads therefore stages its slice of the stream in LDS with coalesced
-// loads -- kHuffWarmWords words in front of its first sub-sequence (the warm-up of the first round, below), its
-// sub-sequences, kHuffTailWords of the next -- word j of sub-sequence t at [j][t] (rows one word longer than the
-// thread count, so that the staging stores and the decoders' loads both spread over the banks).
+// The decoders run one thread per sub-sequence of subWords 32-bit words; read straight from global memory every lane would
+// sit in a cache line of its own.  A workgroup of kHuffDecThreads threads therefore stages its slice of the stream in LDS
+// with coalesced loads -- kHuffWarmWords words in front of its first sub-sequence (the warm-up of the first round, below),
+// its sub-sequences, kHuffTailWords of the next -- as it lies in memory: subWords is odd (huffSubWords), so that the
+// lanes of a wave, each reading its own sub-sequence, spread over the banks without any transposition.  The host picks
+// subWords such that the workgroups fill the machine in whole rounds (853 workgroups on 768 slots take as long as 1536).
 static const int kHuffDecThreads = 256;
-static const int kHuffSubWords = kHuffSubBits / 32;
-static const int kHuffStagePitch = kHuffDecThreads + 1;
 static const int kHuffWarmWords = 8, kHuffTailWords = 4;
-static_assert(kHuffWarmWords + kHuffTailWords <= kHuffSubWords, "the slice must fit kHuffSubWords rows of kHuffStagePitch words");
+static const int kHuffStageWords = kHuffDecThreads * kHuffSubWordsMax + kHuffWarmWords + kHuffTailWords;
 
-__device__ __forceinline__ i64 stageOriginWord() { return (i64)blockIdx.x * kHuffDecThreads * kHuffSubWords - kHuffWarmWords; }
+__device__ __forceinline__ i64 stageOriginWord(u32 subWords) { return (i64)blockIdx.x * kHuffDecThreads * subWords - kHuffWarmWords; }
 
-__device__ __forceinline__ void stageStream(const u32* __restrict__ stream, u64 nWords, u32* s_str)
+__device__ __forceinline__ void stageStream(const u32* __restrict__ stream, u64 nWords, u32 subWords, u32* s_str)
 {
-  const i64 o = stageOriginWord();
-  for (u32 l = threadIdx.x; l < (u32)(kHuffDecThreads * kHuffSubWords + kHuffWarmWords + kHuffTailWords); l += kHuffDecThreads)
+  const i64 o = stageOriginWord(subWords);
+  for (u32 l = threadIdx.x; l < (u32)kHuffDecThreads * subWords + (u32)(kHuffWarmWords + kHuffTailWords); l += kHuffDecThreads)
   {
     const i64 w = o + l;
-    s_str[(l % kHuffSubWords) * kHuffStagePitch + l / kHuffSubWords] = (w >= 0 && (u64)w < nWords) ? stream[w] : 0u;
+    s_str[l] = (w >= 0 && (u64)w < nWords) ? stream[w] : 0u;
   }
 }
 
-// the workgroup's LDS copy of the look-up table: (length << 8) | symbol in 16 bits, 0xFFFF = longer than the LUT width
-__device__ __forceinline__ void stageLut(const HuffDecodeTable* __restrict__ t, u16* s_lut)
+// the workgroup's LDS copy of the tables: the look-up table as (length << 8) | symbol in 16 bits, 0xFFFF = longer than
+// the LUT width; the longer codes (sorted by length) as code word and (length << 8) | symbol
+struct HuffLdsTable
+{
+  u16 lut[1 << kHuffLutBits];
+  u32 longCode[256];
+  u16 longLenSym[256];
+  int nLong;
+};
+
+__device__ __forceinline__ void stageLut(const HuffDecodeTable* __restrict__ t, HuffLdsTable& s)
 {
   for (int i = threadIdx.x; i < (1 << kHuffLutBits); i += kHuffDecThreads)
   {
     const u32 e = t->lut[i];
-    s_lut[i] = (e == 0xFFFFFFFFu) ? (u16)0xFFFFu : (u16)(((e >> 16) << 8) | (e & 0xFFu));
+    s.lut[i] = (e == 0xFFFFFFFFu) ? (u16)0xFFFFu : (u16)(((e >> 16) << 8) | (e & 0xFFu));
   }
+  const int nLong = t->nLong;
+  for (int i = threadIdx.x; i < nLong; i += kHuffDecThreads)
+  {
+    s.longCode[i] = t->longCode[i];
+    s.longLenSym[i] = (u16)(((u32)t->longLen[i] << 8) | ((u32)t->longSym[i] & 0xFFu));
+  }
+  if (threadIdx.x == 0) s.nLong = nLong;
 }
 
 // Bit reader over the staged slice: 64-bit window (next bit = bit 63), refilled a word at a time, so that the only
@@ -363,13 +427,12 @@ struct StagedBits
   u32 next;    // staged word the next refill takes
   int have;    // bits in the window
 
-  __device__ __forceinline__ u32 word(u32 l) const { return s_str[(l % kHuffSubWords) * kHuffStagePitch + l / kHuffSubWords]; }
   __device__ __forceinline__ void start(const u32* str, u32 at)
   {
     s_str = str; pos = at;
     const u32 l = at >> 5;
     const int sh = (int)(at & 31u);
-    window = (((u64)word(l) << 32) | word(l + 1u)) << sh;
+    window = (((u64)s_str[l] << 32) | s_str[l + 1u]) << sh;
     have = 64 - sh;
     next = l + 2u;
   }
@@ -377,80 +440,112 @@ struct StagedBits
   __device__ __forceinline__ void skip(int len)
   {
     window <<= len; have -= len; pos += (u32)len;
-    if (have <= 32) { window |= (u64)word(next++) << (32 - have); have += 32; }
+    if (have <= 32) { window |= (u64)s_str[next++] << (32 - have); have += 32; }
   }
 };
 
-// returns the code length (0 = no code matches), symbol in sym; lut = the workgroup's LDS copy of t->lut
-__device__ __forceinline__ int decodeOne(const HuffDecodeTable* __restrict__ t, const u16* lut, u32 top, int& sym)
+// returns the code length (0 = no code matches), symbol in sym
+__device__ __forceinline__ int decodeOne(const HuffLdsTable& s, u32 top, int& sym)
 {
-  const u32 e = lut[top >> (32 - kHuffLutBits)];
+  const u32 e = s.lut[top >> (32 - kHuffLutBits)];
   if (e != 0xFFFFu) { sym = (int)(e & 0xFFu); return (int)(e >> 8); }
-  for (int i = 0; i < t->nLong; i++)
+  const int nLong = s.nLong;
+  for (int i = 0; i < nLong; i++)
   {
-    const int len = t->longLen[i];
-    if ((top >> (32 - len)) == t->longCode[i]) { sym = t->longSym[i]; return len; }
+    const u32 ls = s.longLenSym[i];
+    const int len = (int)(ls >> 8);
+    if ((top >> (32 - len)) == s.longCode[i]) { sym = (int)(ls & 0xFFu); return len; }
   }
   return 0;
 }
 
-// one thread per sub-sequence of kHuffSubBits bits: decode from starts[t] up to the end of the
+// one thread per sub-sequence of subWords * 32 bits: decode from starts[t] up to the end of the
 // sub-sequence; exits[t] = first code word position at or beyond it, counts[t] = symbols decoded.
 // First round (warm != 0): nobody knows where a code word starts near the sub-sequence's first bit, but a decoder set
 // down anywhere falls into step with the true code words within a few symbols -- so the thread starts kHuffWarmWords
-// words early and takes the first code word boundary at or behind its first bit as starts[t].  If the chain of exits
-// (k_huff_chain) then fits everywhere, which is the normal case, that was the only round.
+// words early and takes the first code word boundary at or behind its first bit as starts[t].  Where the warm-up did not
+// catch on, the sub-sequence in front ends somewhere else than this one begins: the workgroup sees that in LDS and lets
+// such threads start over from their predecessor's exit until its sub-sequences fit together.  If the chain of exits
+// (k_huff_chain) then fits across the workgroups as well, which is the normal case, that was the only round.
 __global__ void __launch_bounds__(kHuffDecThreads)
-k_huff_sync(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const HuffDecodeTable* __restrict__ table, u32 nSub,
+k_huff_sync(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const HuffDecodeTable* __restrict__ table, u32 nSub, u32 subWords,
             u64* __restrict__ starts, u64* __restrict__ prevStarts, u64* __restrict__ exits, u32* __restrict__ counts,
             u32* __restrict__ bad, int warm)
 {
-  __shared__ u16 s_lut[1 << kHuffLutBits];
-  __shared__ u32 s_str[kHuffSubWords * kHuffStagePitch];
+  __shared__ HuffLdsTable s_tab;
+  __shared__ u32 s_str[kHuffStageWords];
+  __shared__ u32 s_exit[kHuffDecThreads];
   __shared__ u32 s_any;
   const u32 t = blockIdx.x * (u32)kHuffDecThreads + threadIdx.x;
   u64 s = (t < nSub) ? starts[t] : 0;
-  const bool todo = t < nSub && prevStarts[t] != s;    // else: unchanged since the last round
+  bool todo = t < nSub && prevStarts[t] != s;    // else: unchanged since the last round
   if (threadIdx.x == 0) s_any = 0;
   __syncthreads();
   if (todo) s_any = 1;
   __syncthreads();
   if (!s_any) return;    // (after the first round most workgroups have nothing to redo)
-  stageLut(table, s_lut);
-  stageStream(stream, nWords, s_str);
+  stageLut(table, s_tab);
+  stageStream(stream, nWords, subWords, s_str);
   __syncthreads();
-  if (!todo) return;
-  const u64 origin = (u64)(stageOriginWord() + kHuffWarmWords) * 32u;    // bit position of the slice's first sub-sequence
-  StagedBits in;
-  if (warm && t > 0)
+  const u64 origin = (u64)(stageOriginWord(subWords) + kHuffWarmWords) * 32u;    // bit position of the slice's first sub-sequence
+  const u64 subBits = (u64)subWords * 32u;
+  const u64 end = min((u64)(t + 1) * subBits, streamBits);
+  const u32 endLocal = (t < nSub) ? (u32)(end - origin) + kHuffWarmWords * 32u : 0u;
+  u32 exitLocal = 0;    // (local positions count from the slice's first staged word)
+  bool broken = false;
+  for (int pass = 0; ; pass++)
   {
-    const u32 first = (u32)(s - origin) + kHuffWarmWords * 32u;
-    in.start(s_str, first - kHuffWarmWords * 32u);
-    while (in.pos < first)
+    if (todo)
     {
-      int sym;
-      const int len = decodeOne(table, s_lut, in.top(), sym);
-      if (len == 0) { in.start(s_str, first); break; }
-      in.skip(len);
+      StagedBits in;
+      if (warm && t > 0 && pass == 0)
+      {
+        const u32 first = (u32)(s - origin) + kHuffWarmWords * 32u;
+        in.start(s_str, first - kHuffWarmWords * 32u);
+        while (in.pos < first)
+        {
+          int sym;
+          const int len = decodeOne(s_tab, in.top(), sym);
+          if (len == 0) { in.start(s_str, first); break; }
+          in.skip(len);
+        }
+        s = origin + in.pos - kHuffWarmWords * 32u;
+      }
+      else in.start(s_str, (u32)(s - origin) + kHuffWarmWords * 32u);
+      u32 n = 0;
+      broken = false;
+      while (in.pos < endLocal)
+      {
+        int sym;
+        const int len = decodeOne(s_tab, in.top(), sym);
+        if (len == 0) { broken = true; break; }
+        in.skip(len);
+        n++;
+      }
+      exitLocal = in.pos;
+      starts[t] = s;
+      prevStarts[t] = s;
+      exits[t] = origin + in.pos - kHuffWarmWords * 32u;
+      counts[t] = n;
     }
-    s = origin + in.pos - kHuffWarmWords * 32u;
-    starts[t] = s;
+    else if (t < nSub && pass == 0) exitLocal = (u32)(exits[t] - origin) + kHuffWarmWords * 32u;
+    // does every sub-sequence of the workgroup begin where the one in front ended?
+    __syncthreads();
+    s_exit[threadIdx.x] = exitLocal;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    todo = false;
+    if (threadIdx.x > 0 && t < nSub)
+    {
+      const u32 mine = (u32)(s - origin) + kHuffWarmWords * 32u;
+      const u32 before = s_exit[threadIdx.x - 1];
+      // (a predecessor that ran far beyond its end -- a broken stream -- is left to the chain check)
+      if (before != mine && before < endLocal) { todo = true; s = origin + before - kHuffWarmWords * 32u; s_any = 1; }
+    }
+    __syncthreads();
+    if (!s_any || pass >= 64) break;
   }
-  else in.start(s_str, (u32)(s - origin) + kHuffWarmWords * 32u);
-  prevStarts[t] = s;
-  const u64 end = min((u64)(t + 1) * kHuffSubBits, streamBits);
-  const u32 endLocal = (u32)(end - origin) + kHuffWarmWords * 32u;
-  u32 n = 0;
-  while (in.pos < endLocal)
-  {
-    int sym;
-    const int len = decodeOne(table, s_lut, in.top(), sym);
-    if (len == 0) { atomicOr(bad, 1u); break; }
-    in.skip(len);
-    n++;
-  }
-  exits[t] = origin + in.pos - kHuffWarmWords * 32u;
-  counts[t] = n;
+  if (broken) atomicOr(bad, 1u);    // (no code word matched: the symbol count comes out short and the host refuses the blob)
 }
 
 __global__ void __launch_bounds__(256)
@@ -480,20 +575,20 @@ void launchValidIndex(const u8* maskBits, const u32* groupBase, i64 nPix, u32* v
 // second pass: write symbol r of the stream to its pixel (raw deltas in delta mode)
 template<class T>
 __global__ void __launch_bounds__(kHuffDecThreads)
-k_huff_emit(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const HuffDecodeTable* __restrict__ table, u32 nSub,
+k_huff_emit(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const HuffDecodeTable* __restrict__ table, u32 nSub, u32 subWords,
             const u64* __restrict__ starts, const u64* __restrict__ symBase, HuffGeom g, int mode, u64 nSymbols, u32 numValid,
             const u32* __restrict__ validIdx, int rankOrder, T* __restrict__ out)
 {
-  __shared__ u16 s_lut[1 << kHuffLutBits];
-  __shared__ u32 s_str[kHuffSubWords * kHuffStagePitch];
-  stageLut(table, s_lut);
-  stageStream(stream, nWords, s_str);
+  __shared__ HuffLdsTable s_tab;
+  __shared__ u32 s_str[kHuffStageWords];
+  stageLut(table, s_tab);
+  stageStream(stream, nWords, subWords, s_str);
   __syncthreads();
   const u32 t = blockIdx.x * (u32)kHuffDecThreads + threadIdx.x;
   if (t >= nSub) return;
   const int off = (DtOf<T>::v == DT_Char) ? 128 : 0;
-  const u64 origin = (u64)(stageOriginWord() + kHuffWarmWords) * 32u;
-  const u64 end = min((u64)(t + 1) * kHuffSubBits, streamBits);
+  const u64 origin = (u64)(stageOriginWord(subWords) + kHuffWarmWords) * 32u;
+  const u64 end = min((u64)(t + 1) * (u64)subWords * 32u, streamBits);
   const u32 endLocal = (u32)(end - origin) + kHuffWarmWords * 32u;
   StagedBits in;
   in.start(s_str, (u32)(starts[t] - origin) + kHuffWarmWords * 32u);
@@ -507,7 +602,7 @@ k_huff_emit(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const Hu
     while (in.pos < endLocal && r < nSymbols)
     {
       int sym;
-      const int len = decodeOne(table, s_lut, in.top(), sym);
+      const int len = decodeOne(s_tab, in.top(), sym);
       if (len == 0) break;
       in.skip(len);
       const u32 v = (u32)(sym - off) & 255u;
@@ -529,7 +624,7 @@ k_huff_emit(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const Hu
   while (in.pos < endLocal && r < nSymbols)
   {
     int sym;
-    const int len = decodeOne(table, s_lut, in.top(), sym);
+    const int len = decodeOne(s_tab, in.top(), sym);
     if (len == 0) break;
     in.skip(len);
     const i64 k = validIdx ? (i64)validIdx[q] : (i64)q;
@@ -730,11 +825,28 @@ void launchHuffUndelta(int dt, void* data, const u8* maskBits, const HuffGeom& g
   else hipLaunchKernelGGL(k_huff_undelta<unsigned char>, dim3(g.nDepth), dim3(64), 0, st, (unsigned char*)data, maskBits, g);
 }
 
-void launchHuffSync(const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u64* starts,
+void launchHuffSync(const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u32 subWords, u64* starts,
                     u64* prevStarts, u64* exits, u32* counts, u32* bad, bool firstRound, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_huff_sync, dim3((nSub + kHuffDecThreads - 1) / kHuffDecThreads), dim3(kHuffDecThreads), 0, st, stream, nWords, streamBits, table, nSub, starts, prevStarts,
-                     exits, counts, bad, firstRound ? 1 : 0);
+  hipLaunchKernelGGL(k_huff_sync, dim3((nSub + kHuffDecThreads - 1) / kHuffDecThreads), dim3(kHuffDecThreads), 0, st, stream, nWords, streamBits, table, nSub, subWords,
+                     starts, prevStarts, exits, counts, bad, firstRound ? 1 : 0);
+}
+
+// Words per sub-sequence for a stream of that many bits: odd (LDS banks, see above), between kHuffSubWordsMin and
+// kHuffSubWordsMax, and such that the workgroups -- `slots` of them run at the same time -- come in full rounds.
+u32 huffSubWords(u64 streamBits, u32 slots)
+{
+  const u64 words = (streamBits + 31) / 32;
+  if (slots == 0) slots = 1;
+  u32 best = (u32)kHuffSubWordsMin;
+  u64 bestCost = ~0ull;
+  for (u32 w = (u32)kHuffSubWordsMin; w <= (u32)kHuffSubWordsMax; w += 2)
+  {
+    const u64 nSub = (words + w - 1) / w, nWG = (nSub + kHuffDecThreads - 1) / kHuffDecThreads;
+    const u64 cost = ((nWG + slots - 1) / slots) * w;
+    if (cost < bestCost) { bestCost = cost; best = w; }
+  }
+  return best;
 }
 
 void launchHuffChain(u32 nSub, u64* starts, const u64* exits, u32* changed, hipStream_t st)
@@ -742,28 +854,28 @@ void launchHuffChain(u32 nSub, u64* starts, const u64* exits, u32* changed, hipS
   hipLaunchKernelGGL(k_huff_chain, dim3((nSub + 255) / 256), dim3(256), 0, st, nSub, starts, exits, changed);
 }
 
-void launchHuffEmit(int dt, const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, const u64* starts,
+void launchHuffEmit(int dt, const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u32 subWords, const u64* starts,
                     const u64* symBase, const HuffGeom& g, int mode, u64 nSymbols, u32 numValid, const u32* validIdx, bool planar,
                     void* out, hipStream_t st)
 {
   const dim3 grid((nSub + kHuffDecThreads - 1) / kHuffDecThreads), block(kHuffDecThreads);
   // symbol r goes to byte r: one value per pixel, or pixel-interleaved symbols (not delta mode), or planes wanted
   const int rankOrder = (!validIdx && (g.nDepth == 1 || mode == IEM_Huffman || planar)) ? 1 : 0;
-  if (dt == DT_Char) hipLaunchKernelGGL(k_huff_emit<signed char>, grid, block, 0, st, stream, nWords, streamBits, table, nSub, starts, symBase, g, mode, nSymbols, numValid, validIdx, rankOrder, (signed char*)out);
-  else hipLaunchKernelGGL(k_huff_emit<unsigned char>, grid, block, 0, st, stream, nWords, streamBits, table, nSub, starts, symBase, g, mode, nSymbols, numValid, validIdx, rankOrder, (unsigned char*)out);
+  if (dt == DT_Char) hipLaunchKernelGGL(k_huff_emit<signed char>, grid, block, 0, st, stream, nWords, streamBits, table, nSub, subWords, starts, symBase, g, mode, nSymbols, numValid, validIdx, rankOrder, (signed char*)out);
+  else hipLaunchKernelGGL(k_huff_emit<unsigned char>, grid, block, 0, st, stream, nWords, streamBits, table, nSub, subWords, starts, symBase, g, mode, nSymbols, numValid, validIdx, rankOrder, (unsigned char*)out);
 }
 
-__global__ void __launch_bounds__(256) k_init_starts(u64* __restrict__ starts, u64* __restrict__ prevStarts, u32 nSub)
+__global__ void __launch_bounds__(256) k_init_starts(u64* __restrict__ starts, u64* __restrict__ prevStarts, u32 nSub, u32 subWords)
 {
   const u32 t = blockIdx.x * 256u + threadIdx.x;
   if (t >= nSub) return;
-  starts[t] = (u64)t * kHuffSubBits;
+  starts[t] = (u64)t * subWords * 32u;
   prevStarts[t] = ~0ull;
 }
 
-void launchHuffInitStarts(u64* starts, u64* prevStarts, u32 nSub, hipStream_t st)
+void launchHuffInitStarts(u64* starts, u64* prevStarts, u32 nSub, u32 subWords, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_init_starts, dim3((nSub + 255) / 256), dim3(256), 0, st, starts, prevStarts, nSub);
+  hipLaunchKernelGGL(k_init_starts, dim3((nSub + 255) / 256), dim3(256), 0, st, starts, prevStarts, nSub, subWords);
 }
 
 }    // namespace lerc

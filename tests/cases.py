@@ -486,3 +486,27 @@ def check_damaged_blob(T, P, name, blob, same):
     assert (d1[0] == 0) == (d2[0] == 0), (name, d1[0], d2[0])
     if d1[0] == 0:
         assert same(d1[1], d2[1]) and same(d1[2], d2[2]), name
+
+
+def huffman_stress_cases(scale=1):
+    """8-bit rasters whose Huffman code books hold code words longer than the decoders' 12-bit look-up table, in streams
+    of many speculative sub-sequences: a smooth signal with rare large steps (delta mode, long codes for the steps), a
+    geometric value distribution (plain mode), three values per pixel, and stretches of a single very short code next to
+    noise (sub-sequences that hold hundreds of symbols next to ones that hold few)."""
+    rng = np.random.default_rng(77)
+    out = []
+    h, w = 192 * scale, 256 * scale
+    walk = np.cumsum(rng.choice([-1, 0, 0, 0, 1], size=(h, w)), axis=1)
+    jump = (rng.random((h, w)) < 0.02) * np.minimum(rng.geometric(0.07, (h, w)), 120) * rng.choice([-1, 1], (h, w))
+    out.append(("huff-steps-u8", ((walk + np.cumsum(jump, axis=1)) & 255).astype(np.uint8), {}))
+    out.append(("huff-steps-i8", (((walk + np.cumsum(jump, axis=1)) & 255) - 128).astype(np.int8), {}))
+    geo = np.minimum(rng.geometric(0.45, (h, w)) - 1, 255)
+    perm = rng.permutation(256)
+    out.append(("huff-geometric-u8", perm[geo].astype(np.uint8), {}))
+    x3 = np.stack([(walk + 7 * c + np.cumsum(jump, axis=1) * (c + 1)) & 255 for c in range(3)], axis=-1).astype(np.uint8)
+    out.append(("huff-steps-u8-depth3", x3, dict(n_depth=3)))
+    flat = np.full((h, w), 9, np.uint8)
+    flat[:, w // 3: w // 2] = rng.integers(0, 256, (h, w // 2 - w // 3))
+    flat[rng.random((h, w)) < 0.0005] = 200
+    out.append(("huff-flat-and-noise-u8", flat, {}))
+    return out

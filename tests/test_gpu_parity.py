@@ -427,6 +427,16 @@ def test_c4_full_size_4096_rgb_uint8_huffman(P, O):
     assert rc == 0 and np.array_equal(dec.reshape(x.shape), x)
 
 
+def test_huffman_long_codes_and_many_subsequences(P, O):
+    """The cases of tests/test_sim_kernels.py's Huffman stress test at four times the edge length, on the device."""
+    for name, arr, kw in cases.huffman_stress_cases(scale=4):
+        rc, blob = P.encode(arr, 0, **kw)
+        rc_o, blob_o = O.encode(arr, 0, **kw)
+        assert rc == rc_o == 0 and blob == blob_o, name
+        rc, dec, _ = P.decode(blob)
+        assert rc == 0 and np.array_equal(dec.reshape(arr.shape), arr), name
+
+
 def test_queued_device_calls(O):
     """lerc_amd_encode_device_async / lerc_amd_decode_device_async / lerc_amd_finish on device tensors: operations queue up
     on the stream; a decode enqueued right behind the encode that writes its blob gets the buffer's capacity as size bound

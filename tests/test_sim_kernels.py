@@ -369,6 +369,18 @@ def test_sim_encode_for_older_codec_versions(libs):
         cases.check_old_codec_case(O, S, name, arr, ver, e, kw, _same)
 
 
+def test_sim_huffman_long_codes_and_many_subsequences(libs):
+    """Code words beyond the look-up table, sub-sequences whose warm-up does not catch on (the workgroup chains them in
+    LDS), spans assembled in LDS by the packer: blob == oracle blob, decode == input."""
+    O, S = libs
+    for name, arr, kw in cases.huffman_stress_cases():
+        r1, b1 = O.encode(arr, 0, **kw)
+        r2, b2 = S.encode(arr, 0, **kw)
+        assert r1 == r2 == 0 and b1 == b2, name
+        d = S.decode(b1)
+        assert d[0] == 0 and np.array_equal(np.asarray(d[1]).reshape(arr.shape), arr), name
+
+
 def test_sim_lossless_float_against_golden(libs):
     """maxZErr == 0 on float / double (IEM_DeltaDeltaHuffman): predictor and difference-order choices,
     plane coding (Huffman / one value / stored / PackBits), decode by scans -- against the reference's vectors."""
