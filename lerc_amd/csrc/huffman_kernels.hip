@@ -133,8 +133,75 @@ __global__ void __launch_bounds__(256) k_huff_histo(const T* __restrict__ data, 
   if (s_h[1][threadIdx.x]) atomicAdd(&histos[256 + threadIdx.x], s_h[1][threadIdx.x]);
 }
 
+// Every pixel valid, at most four values per pixel, rows of a multiple of 8 pixels: a thread takes 8 consecutive pixels
+// (8-byte loads; the predecessors of pixels 1 .. 7 are in its registers, the one of pixel 0 comes with one more load) and
+// counts into one of 16 copies of the histograms (a smooth image sends most lanes of a wave to the same few delta
+// bins: same-address LDS atomics are served one after the other).
+static const int kHistoCopies = 16;
+
+template<class T, int D>
+__global__ void __launch_bounds__(256) k_huff_histo_dense(const T* __restrict__ data, HuffGeom g, u32* __restrict__ histos)
+{
+  __shared__ u32 s_h[2][256 * kHistoCopies];
+  for (int i = threadIdx.x; i < 256 * kHistoCopies; i += 256) { s_h[0][i] = 0; s_h[1][i] = 0; }
+  __syncthreads();
+  const u8* bytes = reinterpret_cast<const u8*>(data);
+  const i64 nGroups = ((i64)g.nRows * g.nCols) >> 3;
+  const int off = (DtOf<T>::v == DT_Char) ? 128 : 0;
+  const u32 copy = threadIdx.x & (u32)(kHistoCopies - 1);
+  for (i64 grp = (i64)blockIdx.x * 256 + threadIdx.x; grp < nGroups; grp += (i64)gridDim.x * 256)
+  {
+    const i64 k0 = grp << 3;
+    const int i = (int)(k0 / g.nCols), j = (int)(k0 - (i64)i * g.nCols);
+    u64 w[D];
+#pragma unroll
+    for (int x = 0; x < D; x++) w[x] = *reinterpret_cast<const u64*>(bytes + k0 * D + 8 * x);
+    // the pixel in front of pixel 0: its left neighbour (the last D bytes in front of the group), in column 0 the pixel
+    // above (the first D bytes of the group one row up), for the first pixel of all: 0
+    const bool left = j > 0, up = !left && i > 0;
+    const u64 pw = *reinterpret_cast<const u64*>(bytes + (left ? k0 * D - 8 : (up ? (k0 - g.nCols) * D : k0 * D)));
+    const u64 pbits = (left || up) ? (pw >> (left ? 8 * (8 - D) : 0)) : 0ull;
+#define LERC_PX(c, d) ((T)(u8)(w[((c) * D + (d)) >> 3] >> (8 * (((c) * D + (d)) & 7))))
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+#pragma unroll
+      for (int m = 0; m < D; m++)
+      {
+        const T val = LERC_PX(c, m);
+        const T pred = (c > 0) ? LERC_PX(c > 0 ? c - 1 : 0, m) : (T)(u8)(pbits >> (8 * m));
+        atomicAdd(&s_h[0][(u32)(off + (int)val) * kHistoCopies + copy], 1u);
+        atomicAdd(&s_h[1][(u32)(off + (int)(T)(val - pred)) * kHistoCopies + copy], 1u);
+      }
+#undef LERC_PX
+  }
+  __syncthreads();
+  u32 n0 = 0, n1 = 0;
+  for (int c = 0; c < kHistoCopies; c++) { n0 += s_h[0][threadIdx.x * kHistoCopies + c]; n1 += s_h[1][threadIdx.x * kHistoCopies + c]; }
+  if (n0) atomicAdd(&histos[threadIdx.x], n0);
+  if (n1) atomicAdd(&histos[256 + threadIdx.x], n1);
+}
+
+template<class T>
+static bool launchHistoDense(const void* data, const u8* maskBits, const HuffGeom& g, u32* histos, hipStream_t st)
+{
+  if (maskBits || g.nDepth > 4 || (g.nCols & 7) || ((uintptr_t)data & 7)) return false;
+  const i64 nGroups = ((i64)g.nRows * g.nCols) >> 3;
+  i64 nb = (nGroups + 256 * 4 - 1) / (256 * 4);
+  nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+  const dim3 grid((unsigned)nb), block(256);
+  switch (g.nDepth)
+  {
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_histo_dense<T, 1>), grid, block, 0, st, (const T*)data, g, histos); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_histo_dense<T, 2>), grid, block, 0, st, (const T*)data, g, histos); break;
+    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_histo_dense<T, 3>), grid, block, 0, st, (const T*)data, g, histos); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_histo_dense<T, 4>), grid, block, 0, st, (const T*)data, g, histos); break;
+  }
+  return true;
+}
+
 void launchHuffHisto(int dt, const void* data, const u8* maskBits, const HuffGeom& g, u32* histos, hipStream_t st)
 {
+  if (dt == DT_Char ? launchHistoDense<signed char>(data, maskBits, g, histos, st) : launchHistoDense<unsigned char>(data, maskBits, g, histos, st)) return;
   const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
   i64 nb = (n + 256 * 32 - 1) / (256 * 32);
   nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);

@@ -347,6 +347,144 @@ k_encode_tiles(const T* __restrict__ data, const u8* __restrict__ maskBits, Band
   (void)st;
 }
 
+// ---- sizes only, 8-bit values, every pixel valid, lossless, whole 8 x 8 blocks, a few values per pixel -----------------
+// One LANE per block position instead of one wave: the block's 8 rows of 8 * D bytes sit in the lane's registers (8-byte
+// loads; the lanes of a wave read neighbouring blocks, so whole cache lines are used), and what k_encode_tiles gets from wave
+// reductions -- range, "same as the previous element", distinct values, the same for the difference to the previous depth
+// slice -- is plain serial arithmetic over 64 bytes.  This is the dry run behind the choice between tiling and Huffman
+// coding for 8-bit imagery (Lerc2.cpp:317-373), where the general kernel's ~9 000 cycles per position were the largest
+// single item of the encode.  Same decisions, same sums: tests compare the two kernels' totals.
+struct DistinctBits
+{
+  u64 bm[8];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int i = 0; i < 8; i++) bm[i] = 0ull; }
+  __device__ __forceinline__ void set(u32 q)    // q < 512
+  {
+    const u32 hi = q >> 6;
+    const u64 bit = 1ull << (q & 63u);
+#pragma unroll
+    for (int i = 0; i < 8; i++) if ((u32)i == hi) bm[i] |= bit;
+  }
+  __device__ __forceinline__ u32 count() const
+  {
+    u32 n = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) n += (u32)__popcll(bm[i]);
+    return n;
+  }
+};
+
+template<class T, int D>
+__global__ void __launch_bounds__(256)
+k_tile_sizes_bytes(const T* __restrict__ data, BandParams p, u32* __restrict__ sizes)
+{
+  const int pos = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (pos >= p.nTV * p.nTH) return;
+  const int it = pos / p.nTH, jt = pos - it * p.nTH;
+  const i64 rowBytes = (i64)p.nCols * D;
+  const u8* base = reinterpret_cast<const u8*>(data) + ((i64)it * 8 * p.nCols + (i64)jt * 8) * D;
+#define LERC_PX(c, d) ((int)(T)(u8)(w[((c) * D + (d)) >> 3] >> (8 * (((c) * D + (d)) & 7))))
+  // ---- first sweep over the rows: ranges and "same as the previous element" counts of every slice and of its
+  // difference to the slice in front (GetValidDataAndStats, all-valid branch: prevVal starts at 0; ComputeDiffSliceInt,
+  // Lerc2.cpp:1803-1874)
+  int mn[D], mx[D], same[D], prev[D], lo[D], hi[D], sameD[D], prevD[D];
+#pragma unroll
+  for (int d = 0; d < D; d++) { mn[d] = 0x7FFFFFFF; mx[d] = -0x7FFFFFFF; same[d] = 0; prev[d] = 0; lo[d] = 0x7FFFFFFF; hi[d] = -0x7FFFFFFF; sameD[d] = 0; prevD[d] = 0; }
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+  {
+    u64 w[D];
+#pragma unroll
+    for (int x = 0; x < D; x++) w[x] = *reinterpret_cast<const u64*>(base + r * rowBytes + 8 * x);
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+#pragma unroll
+      for (int d = 0; d < D; d++)
+      {
+        const int v = LERC_PX(c, d);
+        mn[d] = v < mn[d] ? v : mn[d]; mx[d] = v > mx[d] ? v : mx[d];
+        same[d] += (v == prev[d]) ? 1 : 0;
+        prev[d] = v;
+        if (d > 0)
+        {
+          const int dv = v - LERC_PX(c, d > 0 ? d - 1 : 0);
+          lo[d] = dv < lo[d] ? dv : lo[d]; hi[d] = dv > hi[d] ? dv : hi[d];
+          sameD[d] += (dv == prevD[d]) ? 1 : 0;
+          prevD[d] = dv;
+        }
+      }
+  }
+  u32 total = 0;
+#pragma unroll
+  for (int d = 0; d < D; d++)
+  {
+    const bool tryLut = ((double)mx[d] > (double)mn[d] + 3 * p.maxZErr) && (2 * same[d] > 64);
+    double mv = 0;
+    bool quantOk = false;
+    if (p.maxZErr > 0)
+    {
+      mv = ((double)mx[d] - (double)mn[d]) * p.scale;
+      quantOk = !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
+    }
+    const u32 qMax = quantOk ? (u32)(mx[d] - mn[d]) : 0u;    // lossless: the quantised value is v - mn
+    const bool diff = d > 0 && p.tryDiff;
+    const bool tryLutD = diff && ((double)hi[d] > (double)lo[d] + 3 * p.maxZErr) && (2 * sameD[d] > 64);
+    const double mvD = diff ? ((double)hi[d] - (double)lo[d]) * p.scale : 0;
+    const bool quantOkD = diff && !(mvD > (double)p.maxQ || (u32)(mvD + 0.5) == 0);
+    const u32 qMaxD = quantOkD ? (u32)(hi[d] - lo[d]) : 0u;
+    // ---- second sweep where a look-up table is on the cards: the number of distinct values
+    u32 nDistinct = 0, nDistinctD = 0;
+    if ((tryLut && quantOk) || (tryLutD && quantOkD))
+    {
+      DistinctBits plain, delta;
+      plain.clear(); delta.clear();
+      for (int r = 0; r < 8; r++)
+      {
+        u64 w[D];
+#pragma unroll
+        for (int x = 0; x < D; x++) w[x] = *reinterpret_cast<const u64*>(base + r * rowBytes + 8 * x);
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+        {
+          const int v = LERC_PX(c, d);
+          plain.set((u32)(v - mn[d]));
+          if (d > 0) delta.set((u32)(v - LERC_PX(c, d > 0 ? d - 1 : 0) - lo[d]));
+        }
+      }
+      nDistinct = plain.count(); nDistinctD = delta.count();
+    }
+    const Plan plan = planBlock<T>(p, 64, (T)mn[d], (T)mx[d], p.dt, tryLut, mv, qMax, nDistinct);
+    int nBytes = plan.nBytes;
+    if (diff)
+    {
+      const Plan planD = planBlock<int>(p, 64, lo[d], hi[d], DT_Int, tryLutD, mvD, qMaxD, nDistinctD);
+      if (plan.nBytes > planD.nBytes) nBytes = planD.nBytes;
+    }
+    total += (u32)nBytes;
+  }
+#undef LERC_PX
+  sizes[pos] = total;
+}
+
+template<class T>
+static bool launchSizesBytes(int mb, const void* data, const u8* maskBits, const BandParams& p, u32* sizes, hipStream_t stream)
+{
+  if (sizeof(T) != 1 || mb != 8 || maskBits || !p.allValid || !p.intLossless || p.checkOverflow || p.nDepth > 4
+      || (p.nRows & 7) || (p.nCols & 7) || ((uintptr_t)data & 7)) return false;
+  const int nPos = p.nTV * p.nTH;
+  const dim3 grid((nPos + 255) / 256), block(256);
+  switch (p.nDepth)
+  {
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_sizes_bytes<T, 1>), grid, block, 0, stream, (const T*)data, p, sizes); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_sizes_bytes<T, 2>), grid, block, 0, stream, (const T*)data, p, sizes); break;
+    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_sizes_bytes<T, 3>), grid, block, 0, stream, (const T*)data, p, sizes); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_sizes_bytes<T, 4>), grid, block, 0, stream, (const T*)data, p, sizes); break;
+  }
+  return true;
+}
+
 template<class T>
 static void launchSizesT(int mb, const void* data, const u8* maskBits, const BandParams& p, u32* sizes, DeviceStatus* st,
                          hipStream_t stream)
@@ -391,6 +529,8 @@ static void launchWriteT(int mb, const void* data, const u8* maskBits, const Ban
 void launchTileSizes(int dt, int mb, const void* data, const u8* maskBits, const BandParams& p, u32* sizes,
                      DeviceStatus* st, hipStream_t stream)
 {
+  if (dt == DT_Char && launchSizesBytes<signed char>(mb, data, maskBits, p, sizes, stream)) return;
+  if (dt == DT_Byte && launchSizesBytes<unsigned char>(mb, data, maskBits, p, sizes, stream)) return;
   LERC_DT_SWITCH(dt, launchSizesT<TT>(mb, data, maskBits, p, sizes, st, stream))
 }
 

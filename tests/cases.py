@@ -510,3 +510,44 @@ def huffman_stress_cases(scale=1):
     flat[rng.random((h, w)) < 0.0005] = 200
     out.append(("huff-flat-and-noise-u8", flat, {}))
     return out
+
+
+def byte_tiling_cases():
+    """8-bit rasters of whole 8 x 8 blocks, every pixel valid, 1 .. 4 values per pixel: the encoder prices the tiling with a
+    lane per block position (k_tile_sizes_bytes).  Content that makes blocks constant, bit-stuffed, LUT coded (long runs of
+    equal values), raw, and -- for more than one value per pixel -- cheaper as a difference to the slice in front."""
+    rng = np.random.default_rng(123)
+    out = []
+    for dt in (np.uint8, np.int8):
+        for nd in (1, 2, 3, 4):
+            h, w = 64, 96 + 8 * nd
+            base = np.cumsum(rng.integers(-2, 3, (h, w)), axis=1) + np.cumsum(rng.integers(-1, 2, (h, 1)), axis=0) * 3
+            planes = []
+            for m in range(nd):
+                kind = (m + (0 if dt is np.uint8 else 1)) % 4
+                if kind == 0: x = base + 11 * m                                             # tracks the slice in front: differences are small
+                elif kind == 1: x = np.repeat(rng.integers(0, 9, (h, w // 8)), 8, axis=1) * 20 + (rng.random((h, w)) < 0.03) * 7    # runs: LUT
+                elif kind == 2: x = rng.integers(0, 256, (h, w))                              # noise: raw blocks
+                else: x = base // 4 + (rng.random((h, w)) < 0.5)                               # few bits
+                planes.append(x)
+            a = np.stack(planes, axis=-1)
+            a[:16, :32] = 5                                                                  # constant blocks
+            a[16:24, :32] = 0                                                                # all zero blocks
+            arr = (a & 255).astype(np.uint8).view(dt) if dt is np.int8 else (a & 255).astype(np.uint8)
+            out.append((f"bytes-{np.dtype(dt).name}-depth{nd}", arr if nd > 1 else arr[:, :, 0], dict(n_depth=nd) if nd > 1 else {}))
+            # regions with code books of their own: here the tiling beats one Huffman code for the whole raster, so the
+            # sizes per block position end up as offsets in the blob
+            h, w = 64, 128
+            planes = []
+            for m in range(nd):
+                x = np.zeros((h, w), np.int64)
+                x[:, :w // 4] = rng.integers(0, 4, (h, w // 4)) + 40 * m
+                x[:, w // 4:w // 2] = rng.integers(0, 256, (h, w // 4))
+                x[:, w // 2:3 * w // 4] = 77
+                x[:, 3 * w // 4:] = np.repeat(rng.integers(0, 6, (h, w // 32)), 8, axis=1) * 37 + (rng.random((h, w // 4)) < 0.04) * 3
+                if m % 2 == 1: x[:, w // 4:w // 2] = planes[m - 1][:, w // 4:w // 2] + rng.integers(0, 3, (h, w // 4))
+                planes.append(x)
+            a = np.stack(planes, axis=-1)
+            arr = (a & 255).astype(np.uint8).view(dt) if dt is np.int8 else (a & 255).astype(np.uint8)
+            out.append((f"bytes-regions-{np.dtype(dt).name}-depth{nd}", arr if nd > 1 else arr[:, :, 0], dict(n_depth=nd) if nd > 1 else {}))
+    return out

@@ -437,6 +437,15 @@ def test_huffman_long_codes_and_many_subsequences(P, O):
         assert rc == 0 and np.array_equal(dec.reshape(arr.shape), arr), name
 
 
+def test_byte_rasters_priced_by_the_lane_per_block_kernel(P, O):
+    for name, arr, kw in cases.byte_tiling_cases():
+        rc, blob = P.encode(arr, 0, **kw)
+        rc_o, blob_o = O.encode(arr, 0, **kw)
+        assert rc == rc_o == 0 and blob == blob_o, name
+        rc, dec, _ = P.decode(blob)
+        assert rc == 0 and np.array_equal(dec.reshape(arr.shape), arr), name
+
+
 def test_queued_device_calls(O):
     """lerc_amd_encode_device_async / lerc_amd_decode_device_async / lerc_amd_finish on device tensors: operations queue up
     on the stream; a decode enqueued right behind the encode that writes its blob gets the buffer's capacity as size bound

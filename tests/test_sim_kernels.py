@@ -381,6 +381,16 @@ def test_sim_huffman_long_codes_and_many_subsequences(libs):
         assert d[0] == 0 and np.array_equal(np.asarray(d[1]).reshape(arr.shape), arr), name
 
 
+def test_sim_byte_rasters_priced_by_the_lane_per_block_kernel(libs):
+    O, S = libs
+    for name, arr, kw in cases.byte_tiling_cases():
+        r1, b1 = O.encode(arr, 0, **kw)
+        r2, b2 = S.encode(arr, 0, **kw)
+        assert r1 == r2 == 0 and b1 == b2, name
+        d = S.decode(b1)
+        assert d[0] == 0 and np.array_equal(np.asarray(d[1]).reshape(arr.shape), arr), name
+
+
 def test_sim_lossless_float_against_golden(libs):
     """maxZErr == 0 on float / double (IEM_DeltaDeltaHuffman): predictor and difference-order choices,
     plane coding (Huffman / one value / stored / PackBits), decode by scans -- against the reference's vectors."""
