@@ -294,6 +294,41 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   u32 raiseMask = 0;
   static const double errCand[9] = { 1, 0.5, 0.1, 0.05, 0.01, 0.005, 0.001, 0.0005, 0.0001 };
   static const int facCand[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
+  // 8-bit values without a mask, lossless: what the choice between tiling and Huffman coding is made from -- the sizes
+  // of the 8 x 8 blocks and the two histograms -- depends on nothing the statistics decide, so both are enqueued right
+  // behind the statistics kernel and arrive with the same wait (every wait costs the stream ~50 us of idling)
+  struct Speculated
+  {
+    bool on = false, sizesFresh = false;
+    u32* dSizes = nullptr; u32* dOffsets = nullptr; u32* dScratch = nullptr;
+    u32 total = 0;
+    u32 histo[512];
+    BandParams bp;
+  } spec;
+  const bool specWanted = !isFlt && tb == 1 && !dByteMask && !nd.active && rq.maxZErr >= 0 && rq.maxZErr < 1 && rq.version >= 4
+    && (nRows > 8 || nCols > 8);
+  auto speculate = [&]() -> void
+  {
+    const int nPos8 = ((nRows + 7) / 8) * ((nCols + 7) / 8);
+    spec.dSizes = ctx.allocT<u32>((size_t)nPos8 + 4);
+    spec.dOffsets = ctx.allocT<u32>((size_t)nPos8 + 4);
+    spec.dScratch = ctx.allocT<u32>((size_t)nPos8 / 1024 + 8);
+    if (!spec.dSizes || !spec.dOffsets || !spec.dScratch) return;
+    BandParams& b = spec.bp;
+    memset(&b, 0, sizeof(b));
+    b.nRows = nRows; b.nCols = nCols; b.nDepth = nD; b.dt = dt; b.version = rq.version;
+    b.allValid = 1;
+    b.maxQ = maxValToQuantize(dt);
+    b.maxZErr = 0.5; b.scale = 1; b.invScale = 1;
+    b.intLossless = 1;
+    b.tryDiff = (rq.version >= 5 && nD > 1) ? 1 : 0;
+    b.mb = 8; b.nTV = (nRows + 7) / 8; b.nTH = (nCols + 7) / 8;
+    { ProfScope ps(ctx, "tile_sizes"); launchTileSizes(dt, 8, dData, nullptr, b, spec.dSizes, dStatus, st); }
+    { ProfScope ps(ctx, "scan_block_sizes"); launchExclusiveScan(spec.dSizes, spec.dOffsets, (u32)nPos8, spec.dScratch, st); }
+    hipMemcpyAsync(&spec.total, spec.dOffsets + nPos8, 4, hipMemcpyDeviceToHost, st);
+    if (!enqueueHuffmanHisto(ctx, dt, dData, nullptr, nRows, nCols, nD, spec.histo)) return;
+    spec.on = spec.sizesFresh = true;
+  };
   auto runStats = [&](int rows, u32 mask) -> bool
   {
     for (int m = 0; m < nD; m++) { hMins[m] = statKeyInitMin(); hMaxs[m] = statKeyInitMax(); }
@@ -304,6 +339,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     hipMemcpyAsync(&hr.stats, dStats, sizeof(BandStats), hipMemcpyDeviceToHost, st);
     hipMemcpyAsync(hMins.data(), dMins, nD * 8, hipMemcpyDeviceToHost, st);
     hipMemcpyAsync(hMaxs.data(), dMaxs, nD * 8, hipMemcpyDeviceToHost, st);
+    if (specWanted && rows == nRows && !spec.on && !haveBits) speculate();
     return sync.wait();
   };
   if (isFlt && maxZErr > 0)
@@ -515,6 +551,12 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   {
     bp.mb = mb; bp.nTV = (nRows + mb - 1) / mb; bp.nTH = (nCols + mb - 1) / mb;
     const u32 nPos = (u32)bp.nTV * (u32)bp.nTH;
+    if (mb == 8 && spec.sizesFresh)    // priced behind the statistics already (see above): dSizes / dOffsets hold the result
+    {
+      spec.sizesFresh = false;
+      total = spec.total;
+      return codeMask();
+    }
     { ProfScope ps(ctx, "tile_sizes"); launchTileSizes(dt, mb, dData, dBits, bp, dSizes, dStatus, st); }
     { ProfScope ps(ctx, "scan_block_sizes"); launchExclusiveScan(dSizes, dOffsets, nPos, dScratch, st); }
     hipMemcpyAsync(&total, dOffsets + nPos, 4, hipMemcpyDeviceToHost, st);
@@ -535,9 +577,16 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
       const bool constDepths = writeRanges && (0 == memcmp(zMinVec.data(), zMaxVec.data(), nD * sizeof(double)));
       if (!constDepths)
       {
-        dSizes = ctx.allocT<u32>((size_t)nPos8 + 4);
-        dOffsets = ctx.allocT<u32>((size_t)nPos8 + 4);
-        dScratch = ctx.allocT<u32>((size_t)nPos8 / 1024 + 8);
+        // (what was enqueued ahead of the decisions only counts if they came out as assumed)
+        if (spec.on && !(bp.allValid && bp.intLossless && bp.maxZErr == 0.5 && bp.tryDiff == spec.bp.tryDiff && bp.version == spec.bp.version && !dBits))
+          spec.on = spec.sizesFresh = false;
+        if (spec.on) { dSizes = spec.dSizes; dOffsets = spec.dOffsets; dScratch = spec.dScratch; }
+        else
+        {
+          dSizes = ctx.allocT<u32>((size_t)nPos8 + 4);
+          dOffsets = ctx.allocT<u32>((size_t)nPos8 + 4);
+          dScratch = ctx.allocT<u32>((size_t)nPos8 / 1024 + 8);
+        }
         if (!dSizes || !dOffsets || !dScratch) return kFailed;
 
         u32 nBytesTiling = 0;
@@ -548,7 +597,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
 
         if (hd.tryHuffmanInt())
         {
-          if (!planHuffman(ctx, dt, dData, dBits, nRows, nCols, nD, hd.version, huff)) return kFailed;
+          if (!planHuffman(ctx, dt, dData, dBits, nRows, nCols, nD, hd.version, huff, spec.on ? spec.histo : nullptr)) return kFailed;
           nBytesHuffman = huff.ok ? huff.nBytes : 0;
           if (huff.ok && nBytesHuffman < nBytesTiling) { payload = P_HUFFMAN; imageMode = huff.imageMode; nBytesData = nBytesHuffman; }
           else huff.ok = false;

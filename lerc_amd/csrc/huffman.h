@@ -14,6 +14,7 @@ struct HuffmanPlan
   std::vector<std::pair<u16, u32> > codes;    // (length, code) per symbol, 256 entries
   std::vector<u8> table;       // serialised code table (Huffman.cpp:126-166)
   u64 nBits = 0;               // bits of the pixel stream
+  mutable std::vector<u64> deviceCodes;    // emitHuffman: what the kernels read, kept here until the caller's next synchronisation
 };
 
 size_t huffmanScratchBytes(i64 nPix, int nDepth);
@@ -24,9 +25,12 @@ bool planHuffmanFromHisto(const std::vector<int>& histo, HuffmanPlan& plan);
 
 
 // histograms on the device, code books + sizes on the host; returns false only on a runtime error
+// (readyHisto: the 2 x 256 counts, where enqueueHuffmanHisto ran earlier and the stream has been waited for since)
 bool planHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth,
-                 int version, HuffmanPlan& plan);
-// writes table + pixel stream + padding at dOut
+                 int version, HuffmanPlan& plan, const u32* readyHisto = nullptr);
+// the histograms only: counts into hHisto[512] once the stream has been waited for (hHisto must live until then)
+bool enqueueHuffmanHisto(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth, u32* hHisto);
+// writes table + pixel stream + padding at dOut; enqueues only -- `plan` must outlive the caller's next synchronisation
 bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth,
                  const HuffmanPlan& plan, u8* dOut, DeviceStatus* dStatus);
 // decodes a Huffman payload starting at blob + dataBegin; returns an ErrCode

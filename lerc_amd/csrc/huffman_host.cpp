@@ -311,19 +311,29 @@ bool planHuffmanFromHisto(const std::vector<int>& histo, HuffmanPlan& plan)
   return true;
 }
 
-bool planHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth, int version,
-                 HuffmanPlan& plan)
+bool enqueueHuffmanHisto(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth, u32* hHisto)
 {
-  plan = HuffmanPlan();
   hipStream_t st = ctx.activeStream();
   u32* dHisto = ctx.allocT<u32>(512);
   if (!dHisto) return false;
   hipMemsetAsync(dHisto, 0, 512 * 4, st);
   const HuffGeom g{ nRows, nCols, nDepth };
   { ProfScope ps(ctx, "huff_histo"); launchHuffHisto(dt, dData, dMaskBits, g, dHisto, st); }
-  u32 h[512];
-  hipMemcpyAsync(h, dHisto, sizeof(h), hipMemcpyDeviceToHost, st);
-  if (hipStreamSynchronize(st) != hipSuccess) return false;
+  return hipMemcpyAsync(hHisto, dHisto, 512 * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+}
+
+bool planHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth, int version,
+                 HuffmanPlan& plan, const u32* readyHisto)
+{
+  plan = HuffmanPlan();
+  u32 hOwn[512];
+  const u32* h = readyHisto;
+  if (!h)
+  {
+    if (!enqueueHuffmanHisto(ctx, dt, dData, dMaskBits, nRows, nCols, nDepth, hOwn)) return false;
+    if (hipStreamSynchronize(ctx.activeStream()) != hipSuccess) return false;
+    h = hOwn;
+  }
   std::vector<int> h0(h, h + 256), h1(h + 256, h + 512);
 
   std::vector<HCode> t0, t1;
@@ -364,7 +374,8 @@ bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
   const u32 nRuns = (u32)((nElem + kHuffRun - 1) / kHuffRun);
   const u64 nWords = ((plan.nBits + 31) >> 5) + 1;    // one extra word: the decoder's LUT may read ahead (Lerc2.cpp:2464)
 
-  u64 hCodes[256];
+  plan.deviceCodes.resize(256);
+  u64* hCodes = plan.deviceCodes.data();
   for (int i = 0; i < 256; i++) hCodes[i] = ((u64)plan.codes[i].first << 32) | plan.codes[i].second;
   u64* dCodes = ctx.allocT<u64>(256);
   u32* dRunBits = ctx.allocT<u32>((size_t)nRuns + 4);
@@ -372,14 +383,13 @@ bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
   u64* dScr = ctx.allocT<u64>((size_t)nRuns / 256 + 8);
   u32* dStream = ctx.allocT<u32>((size_t)nWords + 4);
   if (!dCodes || !dRunBits || !dRunBase || !dScr || !dStream) return false;
-  hipMemcpyAsync(dCodes, hCodes, sizeof(hCodes), hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(dCodes, hCodes, 256 * sizeof(u64), hipMemcpyHostToDevice, st);
   hipMemcpyAsync(dOut, plan.table.data(), plan.table.size(), hipMemcpyHostToDevice, st);
   hipMemsetAsync(dStream, 0, (size_t)nWords * 4, st);
   { ProfScope ps(ctx, "huff_runbits"); launchHuffRunBits(dt, dData, dMaskBits, g, plan.imageMode, dCodes, dRunBits, st); }
   { ProfScope ps(ctx, "huff_scan"); launchScan64(dRunBits, dRunBase, nRuns, dScr, st); }
   { ProfScope ps(ctx, "huff_pack"); launchHuffPack(dt, dData, dMaskBits, g, plan.imageMode, dCodes, dRunBase, dStream, st); }
-  hipMemcpyAsync(dOut + plan.table.size(), dStream, (size_t)nWords * 4, hipMemcpyDeviceToDevice, st);
-  return hipStreamSynchronize(st) == hipSuccess;    // hCodes / plan.table are host temporaries
+  return hipMemcpyAsync(dOut + plan.table.size(), dStream, (size_t)nWords * 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
 }
 
 u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 dataBegin, u32 blobEnd, int imageMode,
@@ -454,9 +464,30 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
   launchHuffInitStarts(dStarts, dPrev, nSub, subWords, st);
 
   // ---- synchronise the sub-sequence starts (speculative decode until the chain of exits is stable); the symbol counts
-  // are summed right behind every round, so that the usual single round costs one wait
+  // are summed right behind every round.  The usual case is a single round, so the second pass -- symbols to their
+  // pixels, predictor undone -- is enqueued behind the first round without waiting for its verdict and repeated in the
+  // rare case that the chain had to be corrected: one wait, no idle stream in between.
   u32* pin = (u32*)ctx.pinned(64);    // [0] chain changed, [1] bad code seen, [2..3] symbols in the stream
   if (!pin) { delete hTab; return kFailed; }
+  u8* dPlanar = nullptr;
+  const bool planar = huffPlanarDecode(imageMode, dMaskBits, nDepth);
+  if (planar)
+  {
+    dPlanar = ctx.allocT<u8>((size_t)nSymbols + 16);
+    if (!dPlanar) { delete hTab; return kFailed; }
+  }
+  auto secondPass = [&]()
+  {
+    if (dMaskBits) hipMemsetAsync(dOut, 0, (size_t)nPix * nDepth, st);    // invalid pixels stay 0
+    if (planar)
+    {
+      { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, nWords, streamBits, dTab, nSub, subWords, dStarts, dSymBase, g, imageMode, nSymbols, numValid, nullptr, true, dPlanar, st); }
+      { ProfScope ps(ctx, "huff_undelta"); launchHuffUndeltaPlanar(dPlanar, dOut, g, st); }
+      return;
+    }
+    { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, nWords, streamBits, dTab, nSub, subWords, dStarts, dSymBase, g, imageMode, nSymbols, numValid, dValidIdx, false, dOut, st); }
+    if (imageMode == IEM_DeltaHuffman) { ProfScope ps(ctx, "huff_undelta"); launchHuffUndelta(dt, dOut, dMaskBits, g, st); }
+  };
   const int kMaxRounds = 4096;
   int round = 0;
   u64 total = 0;
@@ -469,6 +500,7 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
     { ProfScope ps(ctx, "huff_scan"); launchScan64(dCounts, dSymBase, nSub, dScr64, st); }
     hipMemcpyAsync(pin, dFlags, 8, hipMemcpyDeviceToHost, st);
     hipMemcpyAsync(pin + 2, dSymBase + nSub, 8, hipMemcpyDeviceToHost, st);
+    if (round == 0) secondPass();
     const bool ok = ctx.sync();
     if (hTab) { delete hTab; hTab = nullptr; }    // (the table's upload has certainly happened now)
     if (!ok) return kFailed;
@@ -477,18 +509,7 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
   }
   if (round == kMaxRounds) { ctx.lastError = "Huffman stream did not synchronise"; return kFailed; }
   if (total < nSymbols) { ctx.lastError = "Huffman stream holds fewer symbols than pixels"; return kFailed; }
-
-  if (dMaskBits) hipMemsetAsync(dOut, 0, (size_t)nPix * nDepth, st);    // invalid pixels stay 0
-  if (huffPlanarDecode(imageMode, dMaskBits, nDepth))
-  {
-    u8* dPlanar = ctx.allocT<u8>((size_t)nSymbols + 16);
-    if (!dPlanar) return kFailed;
-    { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, nWords, streamBits, dTab, nSub, subWords, dStarts, dSymBase, g, imageMode, nSymbols, numValid, nullptr, true, dPlanar, st); }
-    { ProfScope ps(ctx, "huff_undelta"); launchHuffUndeltaPlanar(dPlanar, dOut, g, st); }
-    return kOk;
-  }
-  { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, nWords, streamBits, dTab, nSub, subWords, dStarts, dSymBase, g, imageMode, nSymbols, numValid, dValidIdx, false, dOut, st); }
-  if (imageMode == IEM_DeltaHuffman) { ProfScope ps(ctx, "huff_undelta"); launchHuffUndelta(dt, dOut, dMaskBits, g, st); }
+  if (round > 0) secondPass();    // (the first one worked from starts that were corrected afterwards)
   return kOk;
 }
 

@@ -442,8 +442,13 @@ __device__ __forceinline__ u32 peek32(const u32* __restrict__ stream, u64 nWords
 // its sub-sequences, kHuffTailWords of the next -- as it lies in memory: subWords is odd (huffSubWords), so that the
 // lanes of a wave, each reading its own sub-sequence, spread over the banks without any transposition.  The host picks
 // subWords such that the workgroups fill the machine in whole rounds (853 workgroups on 768 slots take as long as 1536).
+#ifdef LERC_SMALL_GROUPS    // (emulator builds: small rasters still give several workgroups, and warm-ups that do not catch on)
+static const int kHuffDecThreads = 16;
+static const int kHuffWarmWords = 1, kHuffTailWords = 4;
+#else
 static const int kHuffDecThreads = 256;
 static const int kHuffWarmWords = 8, kHuffTailWords = 4;
+#endif
 static const int kHuffStageWords = kHuffDecThreads * kHuffSubWordsMax + kHuffWarmWords + kHuffTailWords;
 
 __device__ __forceinline__ i64 stageOriginWord(u32 subWords) { return (i64)blockIdx.x * kHuffDecThreads * subWords - kHuffWarmWords; }
