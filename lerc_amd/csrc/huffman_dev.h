@@ -22,8 +22,11 @@ struct HuffDecodeTable
 void launchHuffHisto(int dt, const void* data, const u8* maskBits, const HuffGeom& g, u32* histos /* 2 x 256, zeroed */, hipStream_t st);
 void launchHuffRunBits(int dt, const void* data, const u8* maskBits, const HuffGeom& g, int mode, const u64* codes, u32* runBits,
                        hipStream_t st);
+// runBase: bit offset of every run (launchHuffRunBits + launchScan64) -- or, every pixel valid, nullptr and `cells` (one
+// zeroed u64 per 256 runs, huffPackCells): the packer finds its offsets itself, in one pass
 void launchHuffPack(int dt, const void* data, const u8* maskBits, const HuffGeom& g, int mode, const u64* codes, const u64* runBase,
-                    u32* stream /* zeroed */, hipStream_t st);
+                    u32* stream /* zeroed */, u64* cells, DeviceStatus* status, hipStream_t st);
+inline size_t huffPackCells(i64 nElem) { return (size_t)(((nElem + kHuffRun - 1) / kHuffRun + 255) / 256); }
 void launchScan64(const u32* in, u64* out /* n + 1 */, u32 n, u64* scratch /* n/256 + 2 */, hipStream_t st);
 
 u32 huffSubWords(u64 streamBits, u32 slots);

@@ -367,7 +367,6 @@ bool planHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
 bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth,
                  const HuffmanPlan& plan, u8* dOut, DeviceStatus* dStatus)
 {
-  (void)dStatus;
   hipStream_t st = ctx.activeStream();
   const HuffGeom g{ nRows, nCols, nDepth };
   const i64 nElem = (i64)nRows * nCols * nDepth;
@@ -386,9 +385,22 @@ bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
   hipMemcpyAsync(dCodes, hCodes, 256 * sizeof(u64), hipMemcpyHostToDevice, st);
   hipMemcpyAsync(dOut, plan.table.data(), plan.table.size(), hipMemcpyHostToDevice, st);
   hipMemsetAsync(dStream, 0, (size_t)nWords * 4, st);
-  { ProfScope ps(ctx, "huff_runbits"); launchHuffRunBits(dt, dData, dMaskBits, g, plan.imageMode, dCodes, dRunBits, st); }
-  { ProfScope ps(ctx, "huff_scan"); launchScan64(dRunBits, dRunBase, nRuns, dScr, st); }
-  { ProfScope ps(ctx, "huff_pack"); launchHuffPack(dt, dData, dMaskBits, g, plan.imageMode, dCodes, dRunBase, dStream, st); }
+  if (!dMaskBits && dStatus)
+  {
+    // every pixel valid: one pass (the packer's workgroups chain their bit counts themselves)
+    const size_t nCells = huffPackCells(nElem);
+    u64* dCells = ctx.allocT<u64>(nCells + 4);
+    if (!dCells) return false;
+    hipMemsetAsync(dCells, 0, nCells * 8, st);
+    ProfScope ps(ctx, "huff_pack");
+    launchHuffPack(dt, dData, nullptr, g, plan.imageMode, dCodes, nullptr, dStream, dCells, dStatus, st);
+  }
+  else
+  {
+    { ProfScope ps(ctx, "huff_runbits"); launchHuffRunBits(dt, dData, dMaskBits, g, plan.imageMode, dCodes, dRunBits, st); }
+    { ProfScope ps(ctx, "huff_scan"); launchScan64(dRunBits, dRunBase, nRuns, dScr, st); }
+    { ProfScope ps(ctx, "huff_pack"); launchHuffPack(dt, dData, dMaskBits, g, plan.imageMode, dCodes, dRunBase, dStream, nullptr, nullptr, st); }
+  }
   return hipMemcpyAsync(dOut + plan.table.size(), dStream, (size_t)nWords * 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
 }
 

@@ -225,11 +225,12 @@ static const int kHuffStageBatch = 8;
 template<class T, bool PACK>
 __global__ void __launch_bounds__(256)
 k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffGeom g, int mode, const u64* __restrict__ codes,
-              u32* __restrict__ runBits, const u64* __restrict__ runBase, u32* __restrict__ stream)
+              u32* __restrict__ runBits, const u64* __restrict__ runBase, u32* __restrict__ stream, u64* __restrict__ cells, DeviceStatus* status)
 {
   __shared__ u64 s_codes[256];
   __shared__ u8 s_sym[kHuffRun * 260];
   __shared__ u32 s_span[PACK ? kHuffSpanWords : 1];
+  __shared__ u64 s_wave[4], s_base;
   s_codes[threadIdx.x] = codes[threadIdx.x];
   const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
   const i64 nRuns = (n + kHuffRun - 1) / kHuffRun;
@@ -238,7 +239,8 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
   u64 spanWord0 = 0;
   u32 spanWords = 0;
   bool inLds = false;
-  if (PACK)
+  const bool selfScan = PACK && cells != nullptr;    // positions from a look-back over the workgroups instead of a scan pass
+  if (PACK && !selfScan)
   {
     const i64 r0 = (i64)blockIdx.x * 256, r1 = (r0 + 256 < nRuns) ? r0 + 256 : nRuns;
     const u64 bit0 = runBase[r0], bit1 = runBase[r1];
@@ -312,9 +314,66 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
   }
   // MSB-first packing into little-endian u32 words (Huffman.h:218-255): keep a 64-bit window whose top
   // bits are the oldest; whole words are ORed into the span (neighbouring runs share boundary words)
+  u64 pos = 0;
+  if (selfScan)
+  {
+    // One pass (all pixels valid): the bits of this thread's run, their prefix over the workgroup, and the workgroup's
+    // place in the stream from the cells of the workgroups in front -- each publishes the bits it holds ("aggregate", tag
+    // 1) as soon as it knows them and the sum up to and including itself ("inclusive", tag 2) once it has looked back far
+    // enough to meet an inclusive cell.  Workgroups start in the order of their index, so the ones looked at are running
+    // or done; the cells are zeroed by the host before the launch.
+    u64 mine = 0;
+    if (active) for (int e = 0; e < (int)(v1 - v0); e++) mine += (u32)(s_codes[s_sym[e * 260 + threadIdx.x]] >> 32);
+    u64 inc = mine;
+    const int lane = laneId(), wv = waveId();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u64 t = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += t; }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    u64 before = 0;
+    for (int k = 0; k < wv; k++) before += s_wave[k];
+    const u64 total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (wv == 0)
+    {
+      const u64 kTag = 62, kValue = (1ull << 62) - 1ull;
+      const i64 b = (i64)blockIdx.x;
+      if (lane == 0) publish64(&cells[b], ((b == 0 ? 2ull : 1ull) << kTag) | total);
+      u64 excl = 0;
+      u32 spins = 0;
+      for (i64 j = b - 1; j >= 0; )
+      {
+        const u64 c = (j - lane >= 0) ? observe64(&cells[j - lane]) : (2ull << kTag);    // (in front of workgroup 0: nothing)
+        const u32 tag = (u32)(c >> kTag);
+        const u64 empty = __ballot(tag == 0u), incl = __ballot(tag == 2u);
+        const int firstIncl = incl ? __ffsll((long long)incl) - 1 : 64, firstEmpty = empty ? __ffsll((long long)empty) - 1 : 64;
+        if (firstEmpty < firstIncl)
+        {
+          if (++spins > (1u << 24)) { if (lane == 0) raiseError(status, kFailed, (u32)b); break; }
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        excl += waveSum((lane <= firstIncl) ? (c & kValue) : 0ull);
+        if (firstIncl < 64) break;
+        j -= 64;
+      }
+      if (lane == 0)
+      {
+        if (b > 0) publish64(&cells[b], (2ull << kTag) | (excl + total));
+        s_base = excl;
+      }
+    }
+    __syncthreads();
+    const u64 bit0 = s_base, bit1 = bit0 + total;
+    pos = bit0 + before + inc - mine;
+    spanWord0 = bit0 >> 5;
+    spanWords = (u32)(((bit1 + 31) >> 5) - spanWord0);
+    inLds = spanWords <= (u32)kHuffSpanWords;
+    if (inLds) for (u32 x = threadIdx.x; x < spanWords; x += 256) s_span[x] = 0u;
+    __syncthreads();
+  }
+  else if (active) pos = runBase[run];
   if (active)
   {
-    const u64 pos = runBase[run];
     u64 w = pos >> 5;
     u64 acc = 0;                   // bits of this run for the current word(s), left aligned behind the previous run's bits
     int have = (int)(pos & 31);    // bits already used in the current word (by the previous run)
@@ -360,18 +419,18 @@ void launchHuffRunBits(int dt, const void* data, const u8* maskBits, const HuffG
   const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
   const i64 nRuns = (n + kHuffRun - 1) / kHuffRun;
   const dim3 grid((unsigned)((nRuns + 255) / 256)), block(256);
-  if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, false>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, runBits, (const u64*)nullptr, (u32*)nullptr);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, false>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, runBits, (const u64*)nullptr, (u32*)nullptr);
+  if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, false>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, runBits, (const u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (DeviceStatus*)nullptr);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, false>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, runBits, (const u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (DeviceStatus*)nullptr);
 }
 
 void launchHuffPack(int dt, const void* data, const u8* maskBits, const HuffGeom& g, int mode, const u64* codes, const u64* runBase,
-                    u32* stream, hipStream_t st)
+                    u32* stream, u64* cells, DeviceStatus* status, hipStream_t st)
 {
   const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
   const i64 nRuns = (n + kHuffRun - 1) / kHuffRun;
   const dim3 grid((unsigned)((nRuns + 255) / 256)), block(256);
-  if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, true>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, true>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream);
+  if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, true>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, cells, status);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, true>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, cells, status);
 }
 
 // u32 -> u64 exclusive scan (bit offsets can exceed 2^32); out[n] = total

@@ -412,6 +412,44 @@ k_band_stats(const T* __restrict__ data, const u8* __restrict__ maskBits, i64 nP
   (void)maxZErr;
 }
 
+// 8-bit values, every pixel valid: 16 bytes per load; a thread's loads are a multiple of nDepth vectors apart, so byte b
+// of every vector it sees belongs to the same value of a pixel, and it keeps sixteen running ranges that are sorted into
+// the per-depth ranges once at the end.
+template<class T>
+__global__ void __launch_bounds__(256)
+k_band_stats_bytes(const T* __restrict__ data, i64 nVec, int nDepth, u64* __restrict__ mins, u64* __restrict__ maxs)
+{
+  __shared__ int s_min[kStatsMaxDepthLds], s_max[kStatsMaxDepthLds];
+  for (int i = threadIdx.x; i < nDepth; i += 256) { s_min[i] = 0x7FFFFFFF; s_max[i] = -0x7FFFFFFF; }
+  __syncthreads();
+  const i64 first = (i64)blockIdx.x * 256 + threadIdx.x;
+  i64 stride = (i64)gridDim.x * 256;
+  stride -= stride % nDepth;    // (the launch has at least nDepth threads)
+  int mn[16], mx[16];
+#pragma unroll
+  for (int b = 0; b < 16; b++) { mn[b] = 0x7FFFFFFF; mx[b] = -0x7FFFFFFF; }
+  const uint4* vec = reinterpret_cast<const uint4*>(data);
+  if (first < stride)
+    for (i64 t = first; t < nVec; t += stride)
+    {
+      const uint4 x = vec[t];
+      const u32 w[4] = { x.x, x.y, x.z, x.w };
+#pragma unroll
+      for (int b = 0; b < 16; b++)
+      {
+        const int v = (int)(T)(u8)(w[b >> 2] >> (8 * (b & 3)));
+        mn[b] = v < mn[b] ? v : mn[b]; mx[b] = v > mx[b] ? v : mx[b];
+      }
+    }
+  const int phase = (int)((first * 16) % nDepth);
+#pragma unroll
+  for (int b = 0; b < 16; b++)
+    if (mn[b] <= mx[b]) { const int m = (phase + b) % nDepth; atomicMin(&s_min[m], mn[b]); atomicMax(&s_max[m], mx[b]); }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nDepth; i += 256)
+    if (s_min[i] <= s_max[i]) { atomicMin(&mins[i], Key<T>::enc((T)s_min[i])); atomicMax(&maxs[i], Key<T>::enc((T)s_max[i])); }
+}
+
 void launchBandStats(int dt, const void* data, const u8* maskBits, int nRows, int nCols, int nDepth, u32 raiseMask,
                      u64* mins, u64* maxs, BandStats* stats, hipStream_t stream)
 {
@@ -424,6 +462,16 @@ void launchBandStats(int dt, const void* data, const u8* maskBits, int nRows, in
   if (nBlocks < ((i64)nDepth + 255) / 256) nBlocks = ((i64)nDepth + 255) / 256;    // a thread per value of a pixel at least
   if (nBlocks < 1) nBlocks = 1;
   const dim3 grid((unsigned)nBlocks), block(256);
+  if ((dt == DT_Char || dt == DT_Byte) && !maskBits && nDepth <= kStatsMaxDepthLds && (nElem & 15) == 0 && nElem >= (1 << 12) && ((uintptr_t)data & 15) == 0
+      && nBlocks * 256 >= nDepth)
+  {
+    const i64 nVec = nElem >> 4;
+    i64 nb = (nVec + 256 * 8 - 1) / (256 * 8);
+    nb = nb > 4096 ? 4096 : (nb < ((i64)nDepth + 255) / 256 ? ((i64)nDepth + 255) / 256 : nb);
+    if (dt == DT_Char) hipLaunchKernelGGL(k_band_stats_bytes<signed char>, dim3((unsigned)nb), block, 0, stream, (const signed char*)data, nVec, nDepth, mins, maxs);
+    else hipLaunchKernelGGL(k_band_stats_bytes<unsigned char>, dim3((unsigned)nb), block, 0, stream, (const unsigned char*)data, nVec, nDepth, mins, maxs);
+    return;
+  }
   switch (dt)
   {
     case DT_Char:   hipLaunchKernelGGL(k_band_stats<signed char>, grid, block, 0, stream, (const signed char*)data, maskBits, nPix, nDepth, maxZErr, raiseMask, mins, maxs, stats); break;
