@@ -6,7 +6,8 @@ namespace lerc {
 
 struct HuffGeom { int nRows, nCols, nDepth; };
 
-static const int kHuffRun = 128;         // stream elements per encoder thread
+static const int kHuffRun = 128;         // stream elements per encoder thread (runs with a table of bit offsets)
+static const int kHuffSelfRun = 64;      // ... where the packer finds its offsets itself (launchHuffPack with cells)
 static const int kHuffSubWordsMin = 33, kHuffSubWordsMax = 41;    // 32-bit words per speculative decode sub-sequence (odd; huffSubWords picks)
 static const int kHuffLutBits = 12;      // Huffman.h:37 uses the same look-up width
 
@@ -26,7 +27,7 @@ void launchHuffRunBits(int dt, const void* data, const u8* maskBits, const HuffG
 // zeroed u64 per 256 runs, huffPackCells): the packer finds its offsets itself, in one pass
 void launchHuffPack(int dt, const void* data, const u8* maskBits, const HuffGeom& g, int mode, const u64* codes, const u64* runBase,
                     u32* stream /* zeroed */, u64* cells, DeviceStatus* status, hipStream_t st);
-inline size_t huffPackCells(i64 nElem) { return (size_t)(((nElem + kHuffRun - 1) / kHuffRun + 255) / 256); }
+inline size_t huffPackCells(i64 nElem) { return (size_t)(((nElem + kHuffSelfRun - 1) / kHuffSelfRun + 255) / 256); }
 void launchScan64(const u32* in, u64* out /* n + 1 */, u32 n, u64* scratch /* n/256 + 2 */, hipStream_t st);
 
 u32 huffSubWords(u64 streamBits, u32 slots);

@@ -222,18 +222,20 @@ void launchHuffHisto(int dt, const void* data, const u8* maskBits, const HuffGeo
 static const int kHuffSpanWords = 10240;
 static const int kHuffStageBatch = 8;
 
-template<class T, bool PACK>
+template<class T, bool PACK, int RUN>
 __global__ void __launch_bounds__(256)
 k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffGeom g, int mode, const u64* __restrict__ codes,
               u32* __restrict__ runBits, const u64* __restrict__ runBase, u32* __restrict__ stream, u64* __restrict__ cells, DeviceStatus* status)
 {
   __shared__ u64 s_codes[256];
-  __shared__ u8 s_sym[kHuffRun * 260];
-  __shared__ u32 s_span[PACK ? kHuffSpanWords : 1];
+  __shared__ u8 s_sym[RUN * 260];
+  constexpr int kRunShift = (RUN == 128) ? 7 : 6;
+  static_assert(RUN == 128 || RUN == 64, "elements per thread");
+  __shared__ u32 s_span[PACK ? kHuffSpanWords * RUN / 128 : 1];
   __shared__ u64 s_wave[4], s_base;
   s_codes[threadIdx.x] = codes[threadIdx.x];
   const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
-  const i64 nRuns = (n + kHuffRun - 1) / kHuffRun;
+  const i64 nRuns = (n + RUN - 1) / RUN;
   const bool staged = (maskBits == nullptr);
   // this workgroup's words of the stream
   u64 spanWord0 = 0;
@@ -246,19 +248,19 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
     const u64 bit0 = runBase[r0], bit1 = runBase[r1];
     spanWord0 = bit0 >> 5;
     spanWords = (u32)(((bit1 + 31) >> 5) - spanWord0);
-    inLds = staged && spanWords <= (u32)kHuffSpanWords;
+    inLds = staged && spanWords <= (u32)(kHuffSpanWords * RUN / 128);
     if (inLds) for (u32 x = threadIdx.x; x < spanWords; x += 256) s_span[x] = 0u;
   }
   if (staged)
   {
     const int off = (DtOf<T>::v == DT_Char) ? 128 : 0;
-    const i64 vBase = (i64)blockIdx.x * 256 * kHuffRun, nPix = (i64)g.nRows * g.nCols;
+    const i64 vBase = (i64)blockIdx.x * 256 * RUN, nPix = (i64)g.nRows * g.nCols;
     i64 v = vBase + threadIdx.x;
     // delta mode walks plane by plane: (plane, pixel, row, column) of this thread's first element, then 256 further each time
     i64 k = 0;
     int iD = 0, i = 0, j = 0;
     if (mode != IEM_Huffman && v < n) { iD = (int)(v / nPix); k = v - (i64)iD * nPix; i = (int)(k / g.nCols); j = (int)(k - (i64)i * g.nCols); }
-    for (int q0 = 0; q0 < kHuffRun; q0 += kHuffStageBatch)
+    for (int q0 = 0; q0 < RUN; q0 += kHuffStageBatch)
     {
       i64 aVal[kHuffStageBatch], aPred[kHuffStageBatch];    // byte offsets; -1: no such byte (value 0)
 #pragma unroll
@@ -268,7 +270,7 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
         if (v >= n) continue;
         if (mode == IEM_Huffman) { aVal[b] = v; continue; }
         aVal[b] = k * g.nDepth + iD;
-        if (j > 0) aPred[b] = aVal[b] - g.nDepth;
+        if (j > 0) aPred[b] = (threadIdx.x & 63u) ? -2 : aVal[b] - g.nDepth;    // (-2: the value the lane in front has just loaded)
         else if (i > 0) aPred[b] = aVal[b] - (i64)g.nCols * g.nDepth;
         k += 256; j += 256;
         while (j >= g.nCols) { j -= g.nCols; i++; }
@@ -276,26 +278,28 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
       }
       T val[kHuffStageBatch], pred[kHuffStageBatch];
 #pragma unroll
-      for (int b = 0; b < kHuffStageBatch; b++)    // (unconditional loads of a clamped address: all of them leave before the first use)
+      for (int b = 0; b < kHuffStageBatch; b++)    // (loads of a clamped address: all of them leave before the first use)
       {
         val[b] = data[aVal[b] < 0 ? 0 : aVal[b]];
-        pred[b] = data[aPred[b] < 0 ? 0 : aPred[b]];
+        pred[b] = (T)0;
+        if (aPred[b] >= 0) pred[b] = data[aPred[b]];    // (first lane of a wave, first column of a row: few lanes)
       }
 #pragma unroll
       for (int b = 0; b < kHuffStageBatch; b++)
       {
         const int idx = (int)threadIdx.x + 256 * (q0 + b);
-        const T vv = aVal[b] < 0 ? (T)0 : val[b], pp = aPred[b] < 0 ? (T)0 : pred[b];
+        const T left = (T)__shfl_up((int)val[b], 1u);
+        const T vv = aVal[b] < 0 ? (T)0 : val[b], pp = aPred[b] == -2 ? left : (aPred[b] < 0 ? (T)0 : pred[b]);
         const int sym = (aVal[b] < 0) ? 0 : off + (int)(T)(vv - pp);
-        s_sym[(idx & (kHuffRun - 1)) * 260 + (idx >> 7)] = (u8)sym;
+        s_sym[(idx & (RUN - 1)) * 260 + (idx >> kRunShift)] = (u8)sym;
       }
     }
   }
   __syncthreads();
   const i64 run = (i64)blockIdx.x * 256 + threadIdx.x;
-  const i64 v0 = run * kHuffRun;
+  const i64 v0 = run * RUN;
   const bool active = v0 < n;
-  const i64 v1 = (v0 + kHuffRun < n) ? v0 + kHuffRun : n;
+  const i64 v1 = (v0 + RUN < n) ? v0 + RUN : n;
   HuffCursor cur;
   if (active && !staged) cur.init(g, mode, v0);
   if (!PACK)
@@ -367,7 +371,7 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
     pos = bit0 + before + inc - mine;
     spanWord0 = bit0 >> 5;
     spanWords = (u32)(((bit1 + 31) >> 5) - spanWord0);
-    inLds = spanWords <= (u32)kHuffSpanWords;
+    inLds = spanWords <= (u32)(kHuffSpanWords * RUN / 128);
     if (inLds) for (u32 x = threadIdx.x; x < spanWords; x += 256) s_span[x] = 0u;
     __syncthreads();
   }
@@ -419,18 +423,25 @@ void launchHuffRunBits(int dt, const void* data, const u8* maskBits, const HuffG
   const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
   const i64 nRuns = (n + kHuffRun - 1) / kHuffRun;
   const dim3 grid((unsigned)((nRuns + 255) / 256)), block(256);
-  if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, false>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, runBits, (const u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (DeviceStatus*)nullptr);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, false>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, runBits, (const u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (DeviceStatus*)nullptr);
+  if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, false, kHuffRun>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, runBits, (const u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (DeviceStatus*)nullptr);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, false, kHuffRun>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, runBits, (const u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (DeviceStatus*)nullptr);
 }
 
 void launchHuffPack(int dt, const void* data, const u8* maskBits, const HuffGeom& g, int mode, const u64* codes, const u64* runBase,
                     u32* stream, u64* cells, DeviceStatus* status, hipStream_t st)
 {
   const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
+  if (cells)    // one pass: no table of runs, so a thread takes kHuffSelfRun elements -- half the LDS, twice the workgroups per CU
+  {
+    const dim3 grid((unsigned)huffPackCells(n)), block(256);
+    if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, true, kHuffSelfRun>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, cells, status);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, true, kHuffSelfRun>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, cells, status);
+    return;
+  }
   const i64 nRuns = (n + kHuffRun - 1) / kHuffRun;
   const dim3 grid((unsigned)((nRuns + 255) / 256)), block(256);
-  if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, true>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, cells, status);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, true>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, cells, status);
+  if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, true, kHuffRun>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, cells, status);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, true, kHuffRun>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, cells, status);
 }
 
 // u32 -> u64 exclusive scan (bit offsets can exceed 2^32); out[n] = total
@@ -726,10 +737,11 @@ k_huff_emit(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const Hu
   u64 r = symBase[t];
   if (rankOrder)
   {
-    // symbol r is byte r of the output: whole words once r is a multiple of 4
-    const bool words = ((size_t)out & 3u) == 0;
-    u32 acc = 0;
-    int pending = 0;    // bytes r - pending .. r - 1 wait in acc
+    // symbol r is byte r of the output: eight at a time once r is a multiple of 8 (every lane writes a stream of its own,
+    // a cache line apart from its neighbours': the fewer, wider stores the better)
+    const bool wide = ((size_t)out & 7u) == 0;
+    u64 acc = 0;        // the pending bytes, oldest lowest -- once eight have come in
+    int pending = 0;    // bytes r - pending .. r - 1 wait in acc's top bytes
     while (in.pos < endLocal && r < nSymbols)
     {
       int sym;
@@ -737,15 +749,15 @@ k_huff_emit(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const Hu
       if (len == 0) break;
       in.skip(len);
       const u32 v = (u32)(sym - off) & 255u;
-      if (!words || (pending == 0 && (r & 3u) != 0)) out[r] = (T)(u8)v;
+      if (!wide || (pending == 0 && (r & 7u) != 0)) out[r] = (T)(u8)v;
       else
       {
-        acc |= v << (8 * pending);
-        if (++pending == 4) { *reinterpret_cast<u32*>(out + (r - 3)) = acc; acc = 0; pending = 0; }
+        acc = (acc >> 8) | ((u64)v << 56);
+        if (++pending == 8) { *reinterpret_cast<u64*>(out + (r - 7)) = acc; pending = 0; }
       }
       r++;
     }
-    for (int j = 0; j < pending; j++) out[r - (u64)pending + j] = (T)(u8)(acc >> (8 * j));
+    for (int j = 0; j < pending; j++) out[r - (u64)pending + j] = (T)(u8)(acc >> (8 * (8 - pending + j)));
     return;
   }
   // rank r -> (valid pixel q, depth m): divided once, then stepped
