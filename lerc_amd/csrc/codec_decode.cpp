@@ -48,7 +48,7 @@ struct BandDesc
   Header hd;
   size_t hdrLen = 0;
   int numBytesMask = 0;
-  u8 head[128];          // first bytes of the band (header, and for unmasked bands ranges + mode bytes)
+  u8 head[2048];         // first bytes of the band (header, and for unmasked bands ranges + mode bytes + a Huffman code table)
   size_t headLen = 0;
 };
 
@@ -493,7 +493,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
       }
       if (!(imageMode == IEM_DeltaHuffman || (hd.version >= 4 && imageMode == IEM_Huffman))) return kFailed;
       const u32 rc = decodeHuffman(ctx, dt, rq.hBlob ? rq.hBlob + bd.offset : nullptr, dBand, (u32)(at - bd.offset), blobEnd,
-                                   imageMode, dMask, nRows, nCols, nD, hd.version, dOutBand, dStatus);
+                                   imageMode, dMask, nRows, nCols, nD, hd.version, dOutBand, dStatus, bd.head, bd.headLen);
       if (rc != kOk) return rc;
       continue;
     }

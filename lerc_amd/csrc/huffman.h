@@ -35,6 +35,7 @@ bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
                  const HuffmanPlan& plan, u8* dOut, DeviceStatus* dStatus);
 // decodes a Huffman payload starting at blob + dataBegin; returns an ErrCode
 u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 dataBegin, u32 blobEnd, int imageMode,
-                  const u8* dMaskBits, int nRows, int nCols, int nDepth, int version, void* dOut, DeviceStatus* dStatus);
+                  const u8* dMaskBits, int nRows, int nCols, int nDepth, int version, void* dOut, DeviceStatus* dStatus,
+                  const u8* bandHead = nullptr, size_t bandHeadLen = 0);    // (the band's first bytes, where the caller holds them already)
 
 }    // namespace lerc

@@ -405,24 +405,33 @@ bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
 }
 
 u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 dataBegin, u32 blobEnd, int imageMode,
-                  const u8* dMaskBits, int nRows, int nCols, int nDepth, int version, void* dOut, DeviceStatus* dStatus)
+                  const u8* dMaskBits, int nRows, int nCols, int nDepth, int version, void* dOut, DeviceStatus* dStatus,
+                  const u8* bandHead, size_t bandHeadLen)
 {
   (void)dStatus;
   hipStream_t st = ctx.activeStream();
   const HuffGeom g{ nRows, nCols, nDepth };
   const i64 nPix = (i64)nRows * nCols;
 
-  // ---- code table: a few hundred bytes, parsed on the host
-  std::vector<u8> head(std::min<size_t>(blobEnd - dataBegin, 4096));
-  if (hBlob) memcpy(head.data(), hBlob + dataBegin, head.size());
-  else
-  {
-    hipMemcpyAsync(head.data(), dBlob + dataBegin, head.size(), hipMemcpyDeviceToHost, st);
-    if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
-  }
+  // ---- code table: a few hundred bytes, parsed on the host (out of the bytes the caller fetched with the header where
+  // they reach that far: a read from the device costs a wait)
   std::vector<HCode> table;
   size_t used = 0;
-  if (!parseTable(head.data(), head.size(), version, table, used)) return kFailed;
+  bool parsed = false;
+  if (!hBlob && bandHead && bandHeadLen > dataBegin)
+    parsed = parseTable(bandHead + dataBegin, std::min<size_t>(bandHeadLen, blobEnd) - dataBegin, version, table, used);
+  if (!parsed)
+  {
+    std::vector<u8> head(std::min<size_t>(blobEnd - dataBegin, 4096));
+    if (hBlob) memcpy(head.data(), hBlob + dataBegin, head.size());
+    else
+    {
+      hipMemcpyAsync(head.data(), dBlob + dataBegin, head.size(), hipMemcpyDeviceToHost, st);
+      if (hipStreamSynchronize(st) != hipSuccess) return kFailed;
+    }
+    table.clear(); used = 0;
+    if (!parseTable(head.data(), head.size(), version, table, used)) return kFailed;
+  }
   HuffDecodeTable* hTab = new HuffDecodeTable();
   if (!buildDecodeTable(table, *hTab)) { delete hTab; return kFailed; }
 
