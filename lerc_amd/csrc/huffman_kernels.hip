@@ -559,31 +559,24 @@ __device__ __forceinline__ void stageLut(const HuffDecodeTable* __restrict__ t, 
   if (threadIdx.x == 0) s.nLong = nLong;
 }
 
-// Bit reader over the staged slice: 64-bit window (next bit = bit 63), refilled a word at a time, so that the only
-// LDS access a symbol waits for is its table look-up.
+// Bit reader over the staged slice.  It keeps no window: the 32 bits at the current position are put together from two
+// neighbouring LDS words every time (one ds_read2 and a funnel shift).  A 64-bit window refilled "when needed" looks
+// cheaper per symbol, but the refill is a branch that some lane of the wave takes in nearly every step, and the
+// compiler's mask bookkeeping for it (plus the window's own shifts) came to more instructions than the decoding itself --
+// the loop is issue bound, not latency bound (twelve waves per CU hide the two dependent LDS reads).
 struct StagedBits
 {
   const u32* s_str;
-  u64 window;
-  u32 pos;     // bit position of the window's first bit, counted from the slice's first staged word
-  u32 next;    // staged word the next refill takes
-  int have;    // bits in the window
+  u32 pos;     // bit position, counted from the slice's first staged word
 
-  __device__ __forceinline__ void start(const u32* str, u32 at)
+  __device__ __forceinline__ void start(const u32* str, u32 at) { s_str = str; pos = at; }
+  __device__ __forceinline__ u32 top() const
   {
-    s_str = str; pos = at;
-    const u32 l = at >> 5;
-    const int sh = (int)(at & 31u);
-    window = (((u64)s_str[l] << 32) | s_str[l + 1u]) << sh;
-    have = 64 - sh;
-    next = l + 2u;
+    const u32 w = pos >> 5;
+    const u64 x = ((u64)s_str[w] << 32) | s_str[w + 1u];
+    return (u32)((x << (pos & 31u)) >> 32);
   }
-  __device__ __forceinline__ u32 top() const { return (u32)(window >> 32); }
-  __device__ __forceinline__ void skip(int len)
-  {
-    window <<= len; have -= len; pos += (u32)len;
-    if (have <= 32) { window |= (u64)s_str[next++] << (32 - have); have += 32; }
-  }
+  __device__ __forceinline__ void skip(int len) { pos += (u32)len; }
 };
 
 // returns the code length (0 = no code matches), symbol in sym
