@@ -325,8 +325,8 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     b.mb = 8; b.nTV = (nRows + 7) / 8; b.nTH = (nCols + 7) / 8;
     { ProfScope ps(ctx, "tile_sizes"); launchTileSizes(dt, 8, dData, nullptr, b, spec.dSizes, dStatus, st); }
     { ProfScope ps(ctx, "scan_block_sizes"); launchExclusiveScan(spec.dSizes, spec.dOffsets, (u32)nPos8, spec.dScratch, st); }
-    hipMemcpyAsync(&spec.total, spec.dOffsets + nPos8, 4, hipMemcpyDeviceToHost, st);
     if (!enqueueHuffmanHisto(ctx, dt, dData, nullptr, nRows, nCols, nD, spec.histo)) return;
+    hipMemcpyAsync(&spec.total, spec.dOffsets + nPos8, 4, hipMemcpyDeviceToHost, st);    // (copies behind all the kernels, see runStats)
     spec.on = spec.sizesFresh = true;
   };
   auto runStats = [&](int rows, u32 mask) -> bool
@@ -336,10 +336,11 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     hipMemcpyAsync(dMaxs, hMaxs.data(), nD * 8, hipMemcpyHostToDevice, st);
     hipMemsetAsync(dStats, 0, sizeof(BandStats), st);
     { ProfScope ps(ctx, rows == nRows ? "band_stats" : "band_stats_row0"); launchBandStats(dt, dData, (haveBits && !bandAllValid) ? dNewBits : nullptr, rows, nCols, nD, mask, dMins, dMaxs, dStats, st); }
+    // (in front of the copies: a copy into pageable memory keeps the host until everything enqueued so far is through)
+    if (specWanted && rows == nRows && !spec.on && !haveBits) speculate();
     hipMemcpyAsync(&hr.stats, dStats, sizeof(BandStats), hipMemcpyDeviceToHost, st);
     hipMemcpyAsync(hMins.data(), dMins, nD * 8, hipMemcpyDeviceToHost, st);
     hipMemcpyAsync(hMaxs.data(), dMaxs, nD * 8, hipMemcpyDeviceToHost, st);
-    if (specWanted && rows == nRows && !spec.on && !haveBits) speculate();
     return sync.wait();
   };
   if (isFlt && maxZErr > 0)
@@ -714,17 +715,11 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   }
   u64* dFl = ctx.allocT<u64>(kFletcherPartials);
   if (!dFl) return kFailed;
-  { ProfScope ps(ctx, "fletcher_enc"); launchFletcher(dBandOut + 14, blobSize - 14, dFl, st); }
-  std::vector<u64> hFl(kFletcherPartials);
-  hipMemcpyAsync(hFl.data(), dFl, kFletcherPartials * 8, hipMemcpyDeviceToHost, st);
+  // (the sums are folded and the header field is written on the device: one wait at the end of the band instead of two)
+  { ProfScope ps(ctx, "fletcher_enc"); launchFletcher(dBandOut + 14, blobSize - 14, dFl, st); launchFletcherPatch(dFl, blobSize - 14, dBandOut + 10, st); }
   hipMemcpyAsync(&hr.status, dStatus, sizeof(DeviceStatus), hipMemcpyDeviceToHost, st);
   if (!sync.wait()) return kFailed;
   if (hr.status.error) { ctx.lastError = "device kernel reported an error"; return hr.status.error; }
-  u64 A = 0, B = 0;
-  for (int i = 0; i < kFletcherPartials; i += 2) { A += hFl[i]; B += hFl[i + 1]; }
-  const u32 cs = fletcherFinish(A, B, blobSize - 14);
-  hipMemcpyAsync(dBandOut + 10, &cs, 4, hipMemcpyHostToDevice, st);
-  if (!sync.wait()) return kFailed;
   if (ctx.profOn()) ctx.profCollect();
   return kOk;
 }

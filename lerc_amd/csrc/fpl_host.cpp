@@ -371,6 +371,11 @@ bool emitLosslessFloat(Context& ctx, const FplPlan& plan, u8* dOut)
   memcpy(pin, small.data(), small.size());
   for (const auto& c : copies) hipMemcpyAsync(dOut + c.first, pin + c.second.first, c.second.second, hipMemcpyHostToDevice, st);
 
+  // (the one-pass Huffman packer reports here if it ever gives up on its look-back; allocated in front of the planes'
+  // scratch, which is rewound plane by plane)
+  DeviceStatus* dPackStatus = ctx.allocT<DeviceStatus>(1);
+  if (!dPackStatus) return false;
+  hipMemsetAsync(dPackStatus, 0, sizeof(DeviceStatus), st);
   for (const Body& body : bodies)
   {
     const FplPlanePlan& pp = plan.plane[body.b];
@@ -392,11 +397,16 @@ bool emitLosslessFloat(Context& ctx, const FplPlan& plan, u8* dOut)
     else if (pp.mode == 0)
     {
       // (the planes are plain byte streams: the 8-bit image mode's packer in its "no predictor" form)
-      if (!emitHuffman(ctx, DT_Byte, dPlane, nullptr, plan.nRows, plan.nCols, plan.nDepth, pp.huff, dst, nullptr)) return false;
+      if (!emitHuffman(ctx, DT_Byte, dPlane, nullptr, plan.nRows, plan.nCols, plan.nDepth, pp.huff, dst, dPackStatus)) return false;
     }
     ctx.rewind(mark);
   }
-  return ctx.sync();    // the pinned image must outlive the copies
+  DeviceStatus hs;
+  memset(&hs, 0, sizeof(hs));
+  hipMemcpyAsync(&hs, dPackStatus, sizeof(hs), hipMemcpyDeviceToHost, st);
+  if (!ctx.sync()) return false;    // the pinned image must outlive the copies
+  if (hs.error) { ctx.lastError = "lossless float: the Huffman packer gave up"; return false; }
+  return true;
 }
 
 namespace {

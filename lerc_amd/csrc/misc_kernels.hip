@@ -145,6 +145,29 @@ void launchFletcher(const u8* blob, u32 len, u64* acc, hipStream_t stream)
   hipLaunchKernelGGL(k_fletcher, dim3(kFletcherBlocks), dim3(256), 0, stream, blob, len, acc);
 }
 
+// folds launchFletcher's partials and writes the finished checksum (four bytes, any alignment) -- so that an encoder need
+// not bring the sums to the host and send the header field back
+__global__ void __launch_bounds__(64) k_fletcher_patch(const u64* __restrict__ partials, u32 len, u8* __restrict__ dst)
+{
+  u64 A = 0, B = 0;
+  for (int i = laneId(); i < kFletcherPartials / 2; i += 64) { A += partials[2 * i]; B += partials[2 * i + 1]; }
+  A = waveSum(A); B = waveSum(B);
+  if (laneId() != 0) return;
+  const u64 N = ((u64)len + 1) / 2;
+  A %= 65535u; B %= 65535u;
+  u64 s1 = A;
+  u64 s2 = ((N % 65535u) * A + 65535u - B) % 65535u;
+  if (s1 == 0) s1 = 0xffff;
+  if (s2 == 0) s2 = 0xffff;
+  const u32 cs = (u32)((s2 << 16) | s1);
+  for (int i = 0; i < 4; i++) dst[i] = (u8)(cs >> (8 * i));
+}
+
+void launchFletcherPatch(const u64* partials, u32 len, u8* dst, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_fletcher_patch, dim3(1), dim3(64), 0, stream, partials, len, dst);
+}
+
 u32 fletcherFinish(u64 A, u64 B, u32 len)
 {
   const u64 N = ((u64)len + 1) / 2;
