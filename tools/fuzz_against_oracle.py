@@ -1,6 +1,6 @@
 """Soak test on the GPU box: random rasters of a few hundred to 1600 pixels a side (all data types, ragged sizes, masks, nDepth,
 raw blocks) through the product library and the oracle for 150 s; prints every mismatch.  Round 1: 7 600 cases, none.
-    gpurun -- 'python tools/fuzz_against_oracle.py [seed]'"""
+    gpurun -- 'python tools/fuzz_against_oracle.py [seed] [seconds] [bytes]'      (bytes: 8-bit data types only)"""
 import sys, os, time
 sys.path.insert(0,'tests'); sys.path.insert(0,'.')
 import numpy as np, capi, cases
@@ -10,8 +10,10 @@ def same(a,b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
 rng=np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 1)
 t0=time.time(); n=0
-while time.time()-t0 < 150:
-    dt=cases.ALL_DTYPES[rng.integers(0,8)]
+budget=float(sys.argv[2]) if len(sys.argv)>2 else 150
+only_bytes=len(sys.argv)>3 and sys.argv[3]=='bytes'
+while time.time()-t0 < budget:
+    dt=cases.ALL_DTYPES[rng.integers(0,8)] if not only_bytes else (np.uint8 if rng.random()<0.6 else np.int8)
     r,c=int(rng.integers(200,1600)),int(rng.integers(200,1600))
     if rng.random()<0.4: r-=r%8; c-=c%8
     nd=int(rng.choice([1,1,1,2,3]))
