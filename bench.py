@@ -52,7 +52,9 @@ def parse_args():
     ap.add_argument("--workload", choices=("auto", "c2", "c5"), default="auto",
                     help="auto (default): c2 on one GPU -- the BASELINE metric: one 8192^2 raster --, c5 on several: the 65 536-tile "
                          "mosaic sharded over the ranks with the RCCL gather of the blobs (BASELINE configs[4])")
-    ap.add_argument("--tiles", type=int, default=0, help="tiles of the whole mosaic for --workload c5 (default 65536; on one GPU 4096)")
+    ap.add_argument("--tiles", type=int, default=0, help="tiles of the whole mosaic for --workload c5 (default: all 65536, on one GPU too -- 17 GB of pixels)")
+    ap.add_argument("--no-c5-anchor", action="store_true",
+                    help="default c2 line on one GPU: leave out `c5_1gpu`, the N = 1 point of the mosaic's strong-scaling curve")
     ap.add_argument("--rotate", type=int, default=3, help="buffer sets of the cache-cold pass (0: skip it)")
     ap.add_argument("--mode", choices=("async", "sync"), default="async",
                     help="c2: async (default) -- every step's encode and decode are ENQUEUED on the HIP stream (lerc_amd_*_device_async; the decode "
@@ -82,11 +84,12 @@ def cpu_baseline(raster_np, max_z_err):
         assert rc == 0 and rc2 == 0
         if best is None or (t2 - t0) < best[0]:
             best = (t2 - t0, t1 - t0, t2 - t1)
+    import hashlib
     return {
         "value": round(n_pix / best[0] / 1e6, 2), "unit": "MPix/s", "cores": 1, "kind": kind,
         "sample": f"{raster_np.shape[0]}x{raster_np.shape[1]} float32 full raster, best of 2 round trips "
                   f"(lerc_computeCompressedSize+lerc_encode {best[1]*1e3:.0f} ms, lerc_decode {best[2]*1e3:.0f} ms)",
-        "blob_bytes": len(blob),
+        "blob_bytes": len(blob), "blob_sha256": hashlib.sha256(bytes(blob)).hexdigest(),
     }
 
 
@@ -162,6 +165,81 @@ def measured_traffic(kernel_group, size):
     return None
 
 
+def measured_traffic_table(size):
+    """All kernel groups of the newest committed traffic file for this raster size (see measured_traffic), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            if t.get("size") == size and t.get("bytes_per_launch"):
+                return os.path.basename(path), t["bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
+    return None
+
+
+def measured_ceiling(torch, x, y, reps=10):
+    """What this box's HBM delivers to the plainest streaming kernel there is, in the same process: a device-to-device copy
+    of the raster (hipMemcpyDtoD: every byte read once and written once), timed with events on the stream, best of `reps`."""
+    best = None
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        y.copy_(x)
+        b.record()
+        b.synchronize()
+        ms = a.elapsed_time(b)
+        best = ms if best is None or ms < best else best
+    nbytes = 2 * x.numel() * x.element_size()
+    return {"kind": "hipMemcpyDtoD of the raster (bytes read + bytes written), best of %d" % reps, "bytes": nbytes,
+            "ms": round(best, 5), "GBps": round(nbytes / (best / 1e3) / 1e9, 1)}
+
+
+def c5_single_gpu(torch, api, synth, codec, dev, max_z_err, total_tiles, steps=3, warmup=1):
+    """All tiles of the mosaic on ONE GPU (the N = 1 anchor of `bench.py --gpus N`'s strong-scaling curve): batched encode +
+    batched decode per step, in slabs of 8192 tiles (what one rank of eight holds) so that the buffers stay at 2 GB each."""
+    slab = 8192
+    n_slabs = (total_tiles + slab - 1) // slab
+    xs = []
+    for k in range(n_slabs):
+        count = min(slab, total_tiles - k * slab)
+        rows_of_tiles = (count + 255) // 256
+        big = synth.c2_float32(256 * rows_of_tiles, 65536, row0=256 * (k * (slab // 256)), col0=0, virt_cols=65536, device=dev)
+        xs.append(big.reshape(rows_of_tiles, 256, 256, 256).permute(0, 2, 1, 3).contiguous().reshape(rows_of_tiles * 256, 256, 256)[:count].contiguous())
+        del big
+    out = torch.empty(xs[0].numel() * 4 + slab * 256, dtype=torch.uint8, device=dev)
+    y = torch.empty_like(xs[0])
+
+    def one_pass():
+        nbytes = 0
+        for x in xs:
+            rc, offs, sizes, used = api.encode_tiles_device(codec, x, max_z_err, out)
+            if rc != 0:
+                raise RuntimeError(f"tile encode failed: status {rc}: {codec.last_error()}")
+            nbytes += int(sizes.sum())
+            rc = api.decode_tiles_device(codec, out, offs, sizes, y[:x.shape[0]])
+            if rc != 0:
+                raise RuntimeError(f"tile decode failed: status {rc}: {codec.last_error()}")
+        return nbytes
+
+    for _ in range(warmup):
+        one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nbytes = one_pass()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    err = float((y[:xs[-1].shape[0]].double() - xs[-1].double()).abs().max().item())
+    n_pix = total_tiles * 65536
+    b_rt = 2 * (n_pix * 4 + nbytes)
+    return {"tiles": total_tiles, "value": round(n_pix / el / 1e6, 2), "unit": "MPix/s", "ms_per_step": round(el * 1e3, 3), "steps": steps,
+            "blob_bytes": nbytes, "frac_of_hbm_peak_wall": round(b_rt / el / 1e9 / HBM_PEAK_GBS, 5), "max_abs_error": err,
+            "verified": bool(err <= max_z_err * (1 + 1e-6) + 6.2e-5),
+            "note": "the whole 65 536-tile mosaic on one GPU, %d batched calls of %d tiles each way per step, no gather" % (n_slabs, slab)}
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -197,7 +275,7 @@ def main():
     def make_set(k):
         """Input, blob buffer and output of one buffer set (set 0 is the plain loop's)."""
         if tiles_mode:
-            total = args.tiles or (MOSAIC_TILES if world > 1 else 4096)
+            total = args.tiles or MOSAIC_TILES
             first, count = shard.tile_range(rank, world, total)
             # this rank's tiles: rows of 256 tiles of the 65536-wide virtual raster, cut into 256 x 256 tiles
             rows_of_tiles = (count + 255) // 256
@@ -302,16 +380,39 @@ def main():
 
     elapsed, prof = timed(1)
     gather = dict(state)
-    sync_run = None
-    if state["async"]:
-        state["async"] = False
-        sync_run = timed(1)
-        state["async"] = True
+    timed_blob_bytes = int(state["blob_bytes"])    # of the TIMED pass (buffer set 0); later passes must not overwrite it
+    # the blob the timed pass left in set 0's buffer (its last step's), before anything else writes there
+    import hashlib
+    timed_blob_sha = None
+    if not tiles_mode:
+        timed_blob_sha = hashlib.sha256(sets[0][1][:timed_blob_bytes].cpu().numpy().tobytes()).hexdigest()
 
     # correctness of what was timed (outside the timed region)
     x0, _, y0 = sets[0]
     err = float((y0.double() - x0.double()).abs().max().item())
     verified = err <= args.max_z_err * (1 + 1e-6) + 6.2e-5    # + 1/2 ulp of an f32 near 1000
+
+    # the same steps once more with an event behind every step (outside the timed region: an event record between kernels is
+    # not free): the spread of the single steps -- median and fastest next to the timed region's mean
+    step_ms = None
+    if not tiles_mode:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        evs[0].record()
+        for i in range(args.steps):
+            step(0)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        drain()
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+        step_ms = {"median": round(per[len(per) // 2], 4), "min": round(per[0], 4), "max": round(per[-1], 4),
+                   "note": "one event per step on the stream, measured in a pass of its own behind the timed region"}
+
+    sync_run = None
+    if state["async"]:
+        state["async"] = False
+        sync_run = timed(1)
+        state["async"] = True
+    ceiling = measured_ceiling(torch, x0, torch.empty_like(x0)) if not tiles_mode else None
 
     cold = None
     if args.rotate >= 2:
@@ -324,8 +425,19 @@ def main():
         except torch.OutOfMemoryError:
             cold = None
 
+    # the N = 1 point of the mosaic's strong-scaling curve (BASELINE configs[4]: all 65 536 tiles on this one GPU), so that a
+    # driver record holds it next to the c2 line
+    c5_anchor = None
+    if world == 1 and not tiles_mode and not args.no_c5_anchor and n == 8192:
+        try:
+            del sets[1:]
+            torch.cuda.empty_cache()
+            c5_anchor = c5_single_gpu(torch, api, synth, codec, dev, args.max_z_err, MOSAIC_TILES)
+        except (torch.OutOfMemoryError, RuntimeError) as e:
+            c5_anchor = {"error": str(e)[:200]}
+
     if rank == 0:
-        blob_bytes = state["blob_bytes"]
+        blob_bytes = timed_blob_bytes
         raw_bytes = n_pix * 4
         b_enc = raw_bytes + blob_bytes
         b_dec = blob_bytes + raw_bytes
@@ -345,6 +457,16 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dom, n) if not tiles_mode else None,
                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": round(avg_s * 1e3, 5)}
+            if ceiling:
+                roofline["measured_ceiling"] = ceiling
+                roofline["frac_of_measured_ceiling"] = round(ach / ceiling["GBps"], 5)
+            tt = measured_traffic_table(n) if not tiles_mode else None
+            if tt and all(k in tt[1] for k in prof):
+                step_traffic = sum(tt[1][k] * prof[k][1] for k in prof) / max(args.steps, 1)
+                roofline["step_traffic"] = {"bytes": int(step_traffic), "algorithmic_bytes": b_enc + b_dec,
+                                            "ratio": round(step_traffic / (b_enc + b_dec), 4), "source": "profiles/" + tt[0],
+                                            "note": "HBM bytes all launches of one step move (PMC passes of the last profiled build) "
+                                                    "over the step's algorithmic bytes B_enc + B_dec"}
         ms_per_step = elapsed / args.steps * 1e3
         kernel_ms = sum(v[0] for v in prof.values()) / max(args.steps, 1)
 
@@ -375,7 +497,7 @@ def main():
             "config": {"workload": wl, "blob_bytes": blob_bytes, "compression_ratio": round(raw_bytes / max(blob_bytes, 1), 3),
                        "max_abs_error": err, "verified": bool(verified), "cache_state": "MALL-warm (one buffer set re-used every step)"},
             "roofline": roofline,
-            "roundtrip": roundtrip(ms_per_step, kernel_ms),
+            "roundtrip": dict(roundtrip(ms_per_step, kernel_ms), **({"step_ms": step_ms} if step_ms else {})),
             "kernels": table(prof),
         }
         if tiles_mode and world > 1 and gather["gather_steps"]:
@@ -406,6 +528,16 @@ def main():
             res["cache_cold"] = cc
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_tiles(x0[:64].cpu().numpy(), args.max_z_err) if tiles_mode else cpu_baseline(x0.cpu().numpy(), args.max_z_err)
+            cb = res["cpu_baseline"]
+            if cb and not tiles_mode and cb.get("blob_sha256"):
+                # the blob the TIMED (asynchronous) pass wrote against the reference's blob of the same raster: size and bytes
+                same = cb["blob_bytes"] == blob_bytes and cb["blob_sha256"] == timed_blob_sha
+                res["config"]["blob_matches_reference"] = bool(same)
+                res["config"]["blob_sha256"] = timed_blob_sha
+                if not same:
+                    res["config"]["verified"] = False
+        if c5_anchor is not None:
+            res["c5_1gpu"] = c5_anchor
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -4,6 +4,9 @@
 #include "../../include/lerc_amd.h"
 #include "codec.h"
 
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <deque>
@@ -48,12 +51,22 @@ namespace {
 
 // The stock entry points are re-entrant across host threads like the reference's (Lerc.cpp:448,640: no global state):
 // every thread that calls them owns one context -- workspace slab, three staging buffers, pinned mirror, events --
-// and gives it back when the thread ends.  At process exit the HIP runtime may already be gone by the time the main
-// thread's holder is destroyed; the context's destructor frees through calls that then merely return an error.
+// and gives it back when the thread ends.  The main thread's holder is destroyed while the process exits, when the HIP
+// runtime may be half gone already (hipFree / hipStreamDestroy have been seen to hang there on some ROCm versions): its
+// context is left to the operating system, like everything else the process owns.
 struct ThreadHolder
 {
   lerc_amd_context* h = nullptr;
-  ~ThreadHolder() { delete h; h = nullptr; }
+  ~ThreadHolder()
+  {
+    const bool mainThread = (long)syscall(SYS_gettid) == (long)getpid();
+    if (h && !mainThread)
+    {
+      hipStreamSynchronize(h->ctx.activeStream());    // (operations still queued: their buffers go away with the context)
+      delete h;
+    }
+    h = nullptr;
+  }
 };
 
 lerc_amd_context* threadHandle()

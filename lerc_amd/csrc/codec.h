@@ -66,6 +66,9 @@ public:
   // tile_fast.h): zero when handed out for the first time and whenever it had to grow.  Two areas: [0] counters, which the
   // kernels leave zero, and [1] cells tagged with the call's epoch, which they leave as they are.
   u8* persistentState(int area, size_t bytes);
+  // after a kernel has reported a hand-off it gave up on ("stuck"): late workgroups may have left residue in the counters,
+  // so both areas are wiped (after waiting for the stream) before the next call uses them
+  void wipePersistentState();
   // a value no earlier call of this context has used and that no fill pattern looks like: kernels raise flags by
   // writing it into cells that are never cleared (tile_fast.h)
   u32 nextEpoch() { m_epoch += 0x9E3779B9u; if ((m_epoch & 0xFFFFu) == (m_epoch >> 16) || m_epoch == 0u) m_epoch += 0x9E3779B9u; return m_epoch; }

@@ -308,6 +308,12 @@ u8* Context::persistentState(int area, size_t bytes)
   return m_state[area];
 }
 
+void Context::wipePersistentState()
+{
+  hipStreamSynchronize(activeStream());
+  for (int a = 0; a < 2; a++) if (m_state[a]) hipMemset(m_state[a], 0, m_stateCap[a]);
+}
+
 u8* Context::asyncSlot(unsigned ticket)
 {
   if (!m_asyncPinned && hipHostMalloc((void**)&m_asyncPinned, (size_t)kAsyncSlots * kAsyncSlotBytes, hipHostMallocDefault) != hipSuccess)

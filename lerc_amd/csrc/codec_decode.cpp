@@ -166,8 +166,12 @@ bool decodeEnqueueStreaming(Context& ctx, const DecodeRequest& rq, u8* slot, u32
   if (!dCells) return false;
   epoch = ctx.nextEpoch();
   // (the kernels write the verdict -- header check, checksum, flags -- through to `slot`, pinned host memory, as well as to
-  // the device cell they read it back from: a copy kernel behind the decode would cost every call 4 us)
+  // the device cell they read it back from: a copy kernel behind the decode would cost every call 4 us.  The slot is wiped
+  // first: if a launch fails, what the operation that had the slot before left there must not read as this one's "ok")
+  memset(slot + 64, 0, kCellBytes);
+  (void)hipGetLastError();
   if (!launchFastBand(ctx, dt, nRows, nCols, rq.dBlob, rq.blobSize, rq.dOut, dCells + 64, epoch, slot + 64)) return false;
+  if (hipGetLastError() != hipSuccess) { ctx.lastError = "lerc_amd: a streaming decode kernel could not be launched"; return false; }
   if (rq.nMasks > 0 && rq.dValidBytes) hipMemsetAsync(rq.dValidBytes, 1, (size_t)nRows * nCols, st);    // numValid == nPix or no verdict
   return true;
 }
@@ -306,8 +310,9 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   std::vector<u32> checksumLen(rq.nBands, 0);
   std::vector<u8> small;
   // bands decoded by the streaming kernels: their checksum comes out of the decode kernel itself
-  const u32 fastEpoch = ctx.nextEpoch();
-  struct FastBand { bool used = false; };
+  // (a band of its own epoch each: the bands share the context's epoch-tagged cells, and cells left by the band before must
+  // not look like this band's)
+  struct FastBand { bool used = false; u32 epoch = 0; };
   std::vector<FastBand> fast(rq.nBands);
 
   for (int iBand = 0; iBand < rq.nBands; iBand++)
@@ -512,8 +517,9 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
 
     if (fastBand && fastDataBegin == (u32)(at - bd.offset))
     {
-      if (!launchFastBand(ctx, dt, nRows, nCols, dBand, blobEnd, dOutBand, dCells + 64 + (size_t)iBand * kCellBytes, fastEpoch)) return kFailed;
       FastBand& f = fast[iBand];
+      f.epoch = ctx.nextEpoch();
+      if (!launchFastBand(ctx, dt, nRows, nCols, dBand, blobEnd, dOutBand, dCells + 64 + (size_t)iBand * kCellBytes, f.epoch)) return kFailed;
       ctx.lastDecodeStreamed = true;
       f.used = true;
       if (!finishMask()) return kFailed;    // all valid: the caller's mask bytes become 1s (Lerc.cpp:464-488 always writes them)
@@ -569,7 +575,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
     if (!fast[iBand].used) continue;
-    const u32 verdict = fastBandVerdict(pin + 64 + (size_t)iBand * kCellBytes, fastEpoch);
+    const u32 verdict = fastBandVerdict(pin + 64 + (size_t)iBand * kCellBytes, fast[iBand].epoch);
     if (verdict & 0x200u) return kFailed;    // decoded, but the checksum is wrong
     if (verdict)                             // caller repeats with the general kernels
     {

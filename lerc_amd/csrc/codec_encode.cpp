@@ -849,8 +849,19 @@ bool encodeEnqueueStreaming(Context& ctx, const EncodeRequest& rq, u8* slot)
   // (one raster: the deciding block and the last workgroup write the result straight into `slot`, pinned host memory -- no
   // kernel reads it, and a copy kernel behind the encode would cost every call 4 us)
   const bool direct = fl.fb.solo.cells != nullptr;
-  if (direct) fl.fb.result = reinterpret_cast<FastEncodeResult*>(slot);
+  if (direct)
+  {
+    // (wiped first: if a launch fails, what the operation that had the slot before left there must not read as this one's
+    // verdict -- "redo" sends the request to the general path, which reports what is wrong)
+    FastEncodeResult init;
+    memset(&init, 0, sizeof(init));
+    init.redo = 1u; init.redoReason = 0x80000000u;
+    memcpy(slot, &init, sizeof(init));
+    fl.fb.result = reinterpret_cast<FastEncodeResult*>(slot);
+  }
+  (void)hipGetLastError();
   runFastEncode(ctx, fl, rq.dData, rq.dOut, rq.dOut ? (u64)rq.outCapacity : ~0ull, 0);
+  if (hipGetLastError() != hipSuccess) { ctx.lastError = "lerc_amd: a streaming encode kernel could not be launched"; return false; }
   return direct || hipMemcpyAsync(slot, fl.fb.result, sizeof(FastEncodeResult), hipMemcpyDeviceToHost, ctx.activeStream()) == hipSuccess;
 }
 
@@ -867,6 +878,7 @@ void encodeStreamingVerdict(Context& ctx, const EncodeRequest& rq, const u8* slo
     numBytesWritten = rq.dOut ? hres.blobSize : 0;
     return;
   }
+  if (hres.stuck) ctx.wipePersistentState();
   if (rq.dOut && hres.redoReason == 64u && hres.blobSize > rq.outCapacity) { status = kBufferTooSmall; return; }
   redo = true;
 }
@@ -920,10 +932,11 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
       fl.batch.nBlobsMore = (u32)(rq.nBands - 1 - iBand);
       const u8* dBand = (const u8*)rq.dData + (size_t)iBand * nPix * tb;
       const bool direct = fl.fb.solo.cells != nullptr;    // (the kernels write the result into pinned memory themselves)
-      if (direct) fl.fb.result = pinRes;
+      if (direct) { memset(pinRes, 0, sizeof(*pinRes)); pinRes->redo = 1u; pinRes->redoReason = 0x80000000u; fl.fb.result = pinRes; }
       runFastEncode(ctx, fl, dBand, dBandBlob, dBandBlob ? (u64)bandCap : ~0ull, 0);
       if (!direct) hipMemcpyAsync(pinRes, fl.fb.result, sizeof(FastEncodeResult), hipMemcpyDeviceToHost, st);
       if (!ctx.sync()) return kFailed;
+      if (pinRes->stuck) ctx.wipePersistentState();
       if (pinRes->redo || pinRes->stuck) { redo = true; break; }
       const u32 bandBytes = pinRes->blobSize;
       if (total + bandBytes > (u64)UINT_MAX) return kDimsTooLarge;

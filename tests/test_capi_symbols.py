@@ -1,4 +1,4 @@
-"""The product library must build, load without a GPU, export every symbol include/lerc_amd.h declares
+"""The product library must build, load without a GPU, export every symbol include/*.h declares
 and FAIL LOUDLY (status 1, no CPU fallback) when no HIP device exists."""
 import ctypes as ct
 import os
@@ -10,7 +10,8 @@ import pytest
 
 import capi
 
-HDR = os.path.join(capi.ROOT, "include", "lerc_amd.h")
+HDR = os.path.join(capi.ROOT, "include", "lerc_amd.h")                  # the stock twelve (Lerc_c_api.h)
+HDR_DEVICE = os.path.join(capi.ROOT, "include", "lerc_amd_device.h")    # the surface without a reference counterpart
 LIB = os.path.join(capi.ROOT, "lerc_amd", "csrc", "liblerc_amd.so")
 
 
@@ -21,8 +22,8 @@ def lib():
     return ct.CDLL(LIB, mode=ct.RTLD_LOCAL)
 
 
-def declared_symbols():
-    txt = open(HDR).read()
+def declared_symbols(paths=(HDR, HDR_DEVICE)):
+    txt = "".join(open(p).read() for p in paths)
     return sorted(set(re.findall(r"LERC_AMD_API[^;]*?\b(lerc_\w+)\s*\(", txt, flags=re.S)))
 
 
@@ -34,6 +35,9 @@ def test_header_declares_stock_api():
     for s in stock:
         assert s in syms
     assert "lerc_amd_encode_device" in syms and "lerc_amd_decode_device" in syms
+    # the stock header holds the stock twelve and nothing else; everything lerc_amd_* sits in the header of its own
+    assert declared_symbols((HDR,)) == sorted(stock)
+    assert all(s.startswith("lerc_amd_") for s in declared_symbols((HDR_DEVICE,)))
 
 
 def test_exports_every_declared_symbol(lib):

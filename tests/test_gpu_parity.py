@@ -347,6 +347,34 @@ def test_several_bands_take_the_streaming_kernels(P, O):
         assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1])
 
 
+def test_later_bands_do_not_see_the_cells_of_earlier_ones(P, O):
+    """Several streamed bands of one decode call share the context's epoch-tagged cells: every band has to come with an
+    epoch of its own, or band k + 1 reads what band k left there (block indices, walks, group totals).  Band 0's blob must
+    be a multiple of 16 bytes long for band 1 to qualify for the streaming decoder at all, so the raster is searched for."""
+    import struct
+    rng = np.random.default_rng(77)
+    found = 0
+    for t in range(200):
+        n = 512
+        b0 = cases._cast(cases.terrain(n, n, rng, amp=300, base=1000, sigma=1.0 + 0.05 * t), np.uint16)
+        b1 = cases._cast(cases.terrain(n, n, rng, amp=30, base=200, sigma=12.0), np.uint16)    # other block sizes, other counts per chunk
+        x = np.stack([b0, b1, b0[::-1].copy()])
+        r1, blob = O.encode(x, 0, n_bands=3)
+        assert r1 == 0
+        size0 = struct.unpack_from("<i", blob, 34)[0]
+        if size0 % 16:
+            continue
+        found += 1
+        c0 = P.path_counters()
+        d1, d2 = O.decode(blob), P.decode(blob)
+        assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1]), t
+        assert P.path_counters()[2] > c0[2], P.last_note()
+        assert np.array_equal(d2[1].reshape(3, n, n), x)
+        if found == 3:
+            break
+    assert found >= 1
+
+
 def test_lerc1_world(P, O):
     """the reference's legacy Lerc1 fixture (decode only): info, ranges, pixels, mask -- and damaged copies"""
     blob = open(os.path.join(GOLD, "world.lerc1"), "rb").read()
