@@ -421,7 +421,7 @@ def main():
                 sets.append(make_set(len(sets)))
             torch.cuda.synchronize()
             cold_elapsed, cold_prof = timed(len(sets))
-            cold = (cold_elapsed, cold_prof)
+            cold = (cold_elapsed, cold_prof, len(sets))
         except torch.OutOfMemoryError:
             cold = None
 
@@ -517,7 +517,7 @@ def main():
             c_ms = cold[0] / args.steps * 1e3
             c_kms = sum(v[0] for v in cold[1].values()) / max(args.steps, 1)
             cdom = max(cold[1].items(), key=lambda kv: kv[1][0])[0] if cold[1] else None
-            cc = {"buffer_sets": len(sets), "value": round(world * n_pix * args.steps / cold[0] / 1e6, 2), "roundtrip": roundtrip(c_ms, c_kms),
+            cc = {"buffer_sets": cold[2], "value": round(world * n_pix * args.steps / cold[0] / 1e6, 2), "roundtrip": roundtrip(c_ms, c_kms),
                   "kernels": table(cold[1]),
                   "note": "inputs, blob buffers and outputs rotate over distinct allocations, so a step's input is in neither the "
                           "Infinity Cache nor an L2 when the step starts"}

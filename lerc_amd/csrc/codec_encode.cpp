@@ -736,6 +736,13 @@ struct FastEncodeLaunch
   double maxZErr;
 };
 
+// LERC_AMD_ENCODE_LAUNCHES=2 keeps the two-launch form (statistics, then scan + pack) for a single raster: a tuning / test knob
+static bool fastEncodeOneLaunch()
+{
+  static const bool one = []() { const char* e = getenv("LERC_AMD_ENCODE_LAUNCHES"); return !(e && e[0] == '2'); }();
+  return one;
+}
+
 static size_t fastEncodeWorkspace(int nRows, int nCols, u32 nTiles)
 {
   const size_t nWG = fastEncodeNumWG(nRows, nCols);
@@ -753,13 +760,16 @@ static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double
   FastEncodeBuffers& fb = fl.fb;
   fl.batch.nTiles = nTiles; fl.batch.nWG = nWG; fl.batch.tileElems = tileElems; fl.batch.nBlobsMore = 0;
   memset(&fb.solo, 0, sizeof(fb.solo));
+  memset(&fb.fused, 0, sizeof(fb.fused));
   if (nTiles == 1 && !arena && fastSoloOk(dt, nRows, nCols))
   {
     // one raster: two launches, the pack step's first blocks scan and decide (tile_fast.h)
     memset(&fb, 0, sizeof(fb));
-    const size_t nGroups = fastPackGroups(nWG);
-    u8* counters = ctx.persistentState(0, (nGroups + 1) * 8 + 256);
-    u8* cells = ctx.persistentState(1, (size_t)nWG * 8 + 256);
+    const size_t nGroups = fastPackGroups(nWG), nFused = fastFusedGroups(nWG);
+    // (counters: the pack accumulators, then the one-launch form's key cells; cells: a cell per workgroup, then the
+    // one-launch form's group cells and first-row errors)
+    u8* counters = ctx.persistentState(0, (nGroups + 1) * 8 + 2 * nGroups * 8 + 256);
+    u8* cells = ctx.persistentState(1, ((size_t)nWG + nFused + 16) * 8 + 256);
     fb.desc = ctx.allocT<FastBlockDesc>((size_t)nWG * kFastBlocksPerWG);
     fb.wgSize = ctx.allocT<u32>(fastWgStride(nWG) + 4);
     fb.wgMinKey = ctx.allocT<u64>(nWG + 4);
@@ -772,6 +782,14 @@ static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double
       return false;
     fb.packPart = (u64*)counters;
     fb.solo.cells = (u64*)cells;
+    if (fastEncodeOneLaunch())
+    {
+      fb.fused.sizeCell = (u64*)cells;
+      fb.fused.baseCell = (u64*)cells + nWG;
+      fb.fused.raise = (u64*)cells + nWG + nFused;
+      fb.fused.packPart = (u64*)counters;
+      fb.fused.keyPart = (u64*)counters + nGroups + 1;
+    }
   }
   else
   {
@@ -818,6 +836,14 @@ static void runFastEncode(Context& ctx, const FastEncodeLaunch& fl, const void* 
   // one kernel per stage (and per profiling group): statistics (+ first-row rounding errors), scan + decide (+ tile
   // placement for batches), pack + checksum
   static const char* kStage[3] = { "fast_stats_sizes", "fast_scan_decide", "fast_pack" };
+  if (fl.fb.fused.sizeCell && dOut)    // one raster, one launch
+  {
+    ProfScope ps(ctx, "fast_encode1");
+    FastEncodeBuffers fb = fl.fb;
+    fb.fused.epoch = ctx.nextEpoch();    // (never 0, the tag of a cell nobody has written yet)
+    launchFastEncode(0, fl.bp, fl.maxZErr, fl.cand, dData, dOut, capacity, arenaBase, fb, fl.batch, ctx.activeStream());
+    return;
+  }
   // (no output buffer: the size is known after the decisions -- one raster: the pack step's last workgroup takes them)
   const int nStages = (dOut || fl.fb.solo.cells) ? 3 : 2;
   for (int stage = 0; stage < nStages; stage++)

@@ -73,6 +73,26 @@ LERC_HD bool fastSoloOk(int dt, int nRows, int nCols)
   return nBlocks * (1 + 64 * (u64)dtSize(dt)) + 256 < 0xFFFFFFFFull;
 }
 
+// One raster, output wanted: ONE launch (k_fast_encode1) -- statistics, block decisions, pack and checksum from a single read
+// of the raster.  A workgroup publishes the size of its span in an epoch-tagged cell and adds up the cells of the
+// workgroups between the start of the group in front of its own and itself; aggregator blocks (one per kFusedGroup
+// workgroups, in front of their group in the grid) leave the bytes in front of each group.
+#ifdef LERC_SMALL_GROUPS                   // (emulator builds: small rasters then take several groups)
+static const u32 kFusedGroup = 4;
+#else
+static const u32 kFusedGroup = 256;        // (a thread reads at most two cells of the window of 2 * kFusedGroup - 1)
+#endif
+struct FastFused
+{
+  u64* sizeCell;       // [nWG] epoch (32) | bytes of the workgroup's span (32); nullptr: not this mode
+  u64* baseCell;       // [nGroups] epoch (32) | bytes in front of group k (32), k = 1 .. nGroups - 2
+  u64* raise;          // [9] largest first-row rounding error per TryRaiseMaxZError candidate (aggregator 0; read after its arrival)
+  u64* packPart;       // [nPackGroups + 1] as k_fast_pack's: A | B << 24 | arrivals << 48 | NaN seen << 53 | non-integer seen << 58; [nPackGroups]: aggregator 0
+  u64* keyPart;        // [2 * nPackGroups] largest key, largest complement of a key (zero between calls, like packPart)
+  u32 epoch;
+};
+LERC_HD u32 fastFusedGroups(u32 nWG) { return (nWG + kFusedGroup - 1u) / kFusedGroup; }
+
 struct FastEncodeBuffers
 {
   FastBlockDesc* desc; // [nWG * 64]
@@ -92,6 +112,7 @@ struct FastEncodeBuffers
   u64* tileOffset;     // [nTiles + 1] where each tile's blob starts in the output arena; nullptr: a single raster at offset 0
   FastEncodeResult* result;
   FastSolo solo;
+  FastFused fused;
 };
 
 bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, double maxZErr);

@@ -1076,6 +1076,531 @@ k_fast_pack(const T* __restrict__ data, BandParams p, const FastBlockDesc* __res
   if (threadIdx.x == 0) res->checksum = cs;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// ONE launch for one raster (k_fast_encode1): statistics, decisions per block, pack and checksum from a single read of the
+// raster.  A workgroup keeps its 64 blocks' pixels in registers from the first load to the last bit packed; what used to
+// travel through memory between the two passes (16-byte descriptors: 17 MB each way at 8192 x 8192, and the raster a
+// second time) stays in LDS.
+//
+// Where a workgroup's span goes in the blob is the sum of the sizes of all workgroups in front of it.  Every workgroup
+// publishes its size in an epoch-tagged cell as soon as its blocks are planned -- long before its span is packed -- and
+// adds up, itself, the cells of the workgroups between the start of the GROUP in front of its own (kFusedGroup workgroups
+// a group: at most 2 * kFusedGroup - 1 cells, two per thread, asked for before the payload is packed and looked at
+// behind it); what lies in front of that comes from one more cell, left by an AGGREGATOR block: block (kFusedGroup + 1) k
+// of the grid sums group k - 1 and adds the bytes in front of it (its predecessor's cell).  No chain through the pack
+// workgroups, no word that everybody reads (memory serves one address at about 90 reads per microsecond), and everything a
+// block waits for was published by blocks in front of it in the grid, which start first.  If that ever fails to hold a
+// workgroup gives up after 2^22 polls and says so (`stuck`): the host repeats the band on the general path.
+//
+// The band's statistics (range, NaN / non-integer flags) ride on fire-and-forget atomics into per-16-workgroup cells (the
+// checksum accumulators of k_fast_pack plus two key cells); the workgroup with the highest index waits for all arrivals,
+// takes the decisions the reference takes between its sweeps (fastDecide) and writes header and checksum.  A decision
+// that says "not this path" makes the bytes written so far garbage nobody reads, exactly as in the two-launch form.
+// Reference: Lerc2.cpp:1474-1668 (WriteTiles), :179-381 (ComputeNumBytesNeededToWrite), :1037-1064 (checksum).
+// ------------------------------------------------------------------------------------------------
+template<class T>
+__device__ __forceinline__ void
+fusedAggregate(u32 k, u32 nGroups, const T* __restrict__ data, const BandParams& p, u32 raiseCandidates, const FastFused& f, u32 nPackGroups,
+               FastEncodeResult* __restrict__ res)
+{
+  const int lane = laneId(), w = waveId();
+  if (k == 0u)
+  {
+    // ---- aggregator 0 has nothing to add up: it looks at the first raster row the way Lerc2::TryRaiseMaxZError does
+    // (Lerc2.cpp:1245-1290) and leaves the largest rounding error per candidate factor for the deciding workgroup
+    __shared__ u64 s_rw[4][9];
+    const bool doRaise = DtOf<T>::v >= DT_Float && raiseCandidates != 0u;
+    if (doRaise)
+    {
+      const int facCand[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
+      double rerr[9];
+#pragma unroll
+      for (int cnd = 0; cnd < 9; cnd++) rerr[cnd] = 0;
+#pragma unroll 2
+      for (u32 col = threadIdx.x; col < (u32)p.nCols; col += 256u)
+      {
+        const double x = (double)data[col];
+        if (x != x) continue;    // a NaN sends the band to the general path anyway
+        bool exact = false;
+#pragma unroll
+        for (int cnd = 0; cnd < 9; cnd++)    // candidates in increasing factor order, stop at the first exact hit
+        {
+          if (exact || !((raiseCandidates >> cnd) & 1u)) continue;
+          const double z = x * facCand[cnd];
+          if (z == (double)(int)z) { exact = true; continue; }
+          const double dlt = fabs(floor(z + 0.5) - z);
+          rerr[cnd] = dlt > rerr[cnd] ? dlt : rerr[cnd];
+        }
+      }
+#pragma unroll
+      for (int cnd = 0; cnd < 9; cnd++)
+      {
+        u64 bits; const double er = rerr[cnd]; memcpy(&bits, &er, 8);    // non-negative doubles order like their bit patterns
+        bits = waveMax(bits);
+        if (lane == 0) s_rw[w][cnd] = bits;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 9)
+    {
+      u64 m = 0;    // (+0.0)
+      if (doRaise) for (int i = 0; i < 4; i++) m = s_rw[i][threadIdx.x] > m ? s_rw[i][threadIdx.x] : m;
+      publish64(f.raise + threadIdx.x, m);
+    }
+    drainVmem();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(f.packPart + nPackGroups, 1ull << 48, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  // ---- aggregator k >= 1: bytes in front of group k = bytes in front of group k - 1 + the sizes of group k - 1.  Group
+  // k + 1 is the first one to ask for it, so the last two aggregators have nobody to work for
+  if (k + 1u >= nGroups) return;
+  __shared__ u32 s_sum[4];
+  u32 size = 0;
+  bool lost = false;
+  if (threadIdx.x < kFusedGroup)
+  {
+    const u64* cellAt = f.sizeCell + (size_t)(k - 1u) * kFusedGroup + threadIdx.x;    // (group k - 1 is a whole group)
+    u64 cell = observe64(cellAt);
+    for (u32 spin = 0; (u32)(cell >> 32) != f.epoch && spin < (1u << 22); spin++)
+    {
+      __builtin_amdgcn_s_sleep(2);
+      cell = observe64(cellAt);
+    }
+    lost = (u32)(cell >> 32) != f.epoch;
+    size = lost ? 0u : (u32)cell;
+  }
+  size = waveSum(size);
+  if (lane == 0) s_sum[w] = size;
+  if (__any(lost) && lane == 0) __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    u32 before = 0;
+    bool ok = true;
+    if (k >= 2u)
+    {
+      u64 cell = observe64(f.baseCell + (k - 1u));
+      for (u32 spin = 0; (u32)(cell >> 32) != f.epoch && spin < (1u << 22); spin++)
+      {
+        __builtin_amdgcn_s_sleep(2);
+        cell = observe64(f.baseCell + (k - 1u));
+      }
+      ok = (u32)(cell >> 32) == f.epoch;
+      before = (u32)cell;
+    }
+    if (!ok) __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else publish64(f.baseCell + k, ((u64)f.epoch << 32) | (u64)(before + s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]));
+  }
+}
+
+template<class T, bool WIDE>
+__global__ void __launch_bounds__(256)
+k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, FastEncodeResult* __restrict__ res, u32 nWG, u32 nBlobsMore,
+               FastFused f, double requestedMaxZErr, u32 raiseCandidates, u64 outCapacity)
+{
+  typedef FastCfg<T> C;
+  constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW, IT = C::IT;
+  constexpr int LB = 8 * LPR;                // lanes of a block: lane = b * LB + r * LPR + h (block of the wave tile, row, lane of the row)
+  typedef typename ShflT<T>::type ST;
+  constexpr int kMaxBlockBytes = 1 + 64 * (int)sizeof(T);
+  constexpr u32 kLead = 16;                  // zero bytes in front of the span image (the flush reads up to 15 bytes before it)
+  constexpr int kSpanWords = (kFastBlocksPerWG * kMaxBlockBytes + 16) / 4 + 8 + (int)kLead / 4;
+  __shared__ __align__(16) u32 s_out[kSpanWords];
+  __shared__ T s_mnT[kFastBlocksPerWG], s_mxT[kFastBlocksPerWG];
+  __shared__ u32 s_same[kFastBlocksPerWG], s_nd[kFastBlocksPerWG];
+  __shared__ u32 s_w1[kFastBlocksPerWG];
+  __shared__ u32 s_bit[kFastBlocksPerWG];    // bit position of each block inside s_out
+  __shared__ u32 s_fl[4];
+  __shared__ u64 s_fa[4], s_fb[4];
+  __shared__ u32 s_spanLen, s_base, s_retry;
+
+  const u32 nGroups = (nWG + kFusedGroup - 1u) / kFusedGroup, nPackGroups = fastPackGroups(nWG);
+  const u32 grp = blockIdx.x / (kFusedGroup + 1u), inGrp = blockIdx.x - grp * (kFusedGroup + 1u);
+  if (inGrp == 0u) { fusedAggregate<T>(grp, nGroups, data, p, raiseCandidates, f, nPackGroups, res); return; }
+  const u32 wg = grp * kFusedGroup + inGrp - 1u;    // (the grid has exactly nWG + nGroups blocks)
+  PROBE_BEGIN;
+  const int w = waveId(), lane = laneId();
+  const int b = lane / LB, r = (lane % LB) / LPR, h = lane % LPR, c = b * LPR + h;
+  const bool leader = (lane % LB == 0);
+  const FastSpan span = fastSpanOf(wg, (u32)p.nTH, (u32)p.nTV);
+
+  // ---- the pixels: all loads of the wave in flight first (non-temporal: nothing reads them again), the span image is
+  // zeroed while they travel
+  T v[IT][V];
+#pragma unroll
+  for (int t = 0; t < IT; t++) loadLane<T, V>(data + laneOrigin<WIDE, BPW, V>(span, t * 4 + w, r, c, p.nCols), v[t], true);
+  for (u32 i = threadIdx.x; i < (u32)kSpanWords / 4u; i += 256u) reinterpret_cast<uint4*>(s_out)[i] = make_uint4(0, 0, 0, 0);
+  if (threadIdx.x == 0) { s_base = 0u; s_retry = 0u; }
+
+  // ---- statistics per block (Lerc2::GetValidDataAndStats for an all-valid block + the tryLut count, Lerc2.cpp:1717-1799)
+  u32 flags = 0;
+#pragma unroll
+  for (int t = 0; t < IT; t++)
+  {
+    const int tile = t * 4 + w;
+    const T (&x)[V] = v[t];
+    if (DtOf<T>::v >= DT_Float)
+    {
+#pragma unroll
+      for (int k = 0; k < V; k++) if (isNaNv(x[k])) flags |= 1u;
+      if (!(flags & 2u))    // one fractional value settles "not all integers" for good
+      {
+#pragma unroll
+        for (int k = 0; k < V; k++) if (notIntegral(x[k])) flags |= 2u;
+      }
+    }
+    T mn = x[0], mx = x[0];
+#pragma unroll
+    for (int k = 1; k < V; k++) { mn = OpMin()(mn, x[k]); mx = OpMax()(mx, x[k]); }
+    if constexpr (std::is_same<T, float>::value) rowMinMax(mn, mx);    // (LB == 16)
+    else
+    {
+      mn = (T)groupReduce<LB>((ST)mn, OpMin());
+      mx = (T)groupReduce<LB>((ST)mx, OpMax());
+    }
+    T prev = (T)dppMovT<kDppWaveShr1>((ST)x[V - 1]);
+    if (leader) prev = T(0);
+    int same = (x[0] == prev) ? 1 : 0;
+#pragma unroll
+    for (int k = 1; k < V; k++) same += (x[k] == x[k - 1]) ? 1 : 0;
+    u32 nd = 0;
+    if (__any(same > 32 / LB))
+    {
+      same = groupReduce<LB>(same, OpSum());
+      const bool tryLut = (2 * same > 64) && ((double)mx > (double)mn + 3 * p.maxZErr);
+      if (__any(tryLut))
+      {
+        const double mv = ((double)mx - (double)mn) * p.scale;
+        const bool need = tryLut && !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
+        u32 q[V];
+        quantizeLane<T, V>(p.intLossless, p.scale, x, mn, q);
+        nd = groupDistinct<LB, V>(q, need);
+      }
+    }
+    else same = 0;
+    if (leader)
+    {
+      const int blk = tile * BPW + b;
+      s_mnT[blk] = mn; s_mxT[blk] = mx; s_same[blk] = (u32)same; s_nd[blk] = nd;
+    }
+  }
+  const bool f1 = __any(flags & 1u), f2 = __any(flags & 2u);
+  if (lane == 0) s_fl[w] = (f1 ? 1u : 0u) | (f2 ? 2u : 0u);
+  __syncthreads();
+  PROBE(0);
+
+  // ---- lane = block, one wave (it rotates over the SIMDs from workgroup to workgroup): the per-block decisions of
+  // Lerc2::NumBytesTile once per block, the size of the span, the block headers (Lerc2::WriteTile, BitStuffer2 stream header)
+  const int wPlan = (int)((wg * 2654435761u) >> 30);
+  if (w == wPlan)
+  {
+    const T mn = s_mnT[lane], mx = s_mxT[lane];
+    const int same = (int)s_same[lane];
+    const bool tryLut = (2 * same > 64) && ((double)mx > (double)mn + 3 * p.maxZErr);
+    double mv = 0;
+    bool quantOk = false;
+    if (p.maxZErr > 0)
+    {
+      mv = ((double)mx - (double)mn) * p.scale;
+      quantOk = !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
+    }
+    const u32 qMax = quantOk ? (u32)(mv + 0.5) : 0u;    // == largest quantised element (same expression as Quantize)
+    Plan pl = planBlock<T>(p, 64, mn, mx, p.dt, tryLut, mv, qMax, s_nd[lane]);
+    if (!fastSpanHas(span, (u32)lane)) { pl.nBytes = 0; pl.kind = 7; }    // behind the raster's last block: nothing to write
+    const int nb = bitLen(qMax);
+    const u32 w1 = packDesc(pl, nb);
+    const u32 sz = (u32)pl.nBytes;
+    u32 inc = sz;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(inc, (unsigned)dd); if (lane >= dd) inc += o; }
+    const u32 at0 = 8u * (kLead + inc - sz);
+    s_w1[lane] = w1; s_bit[lane] = at0;
+    const u32 total = (u32)__shfl((int)inc, 63);
+    const u64 kMin = waveMin(FKey<T>::enc(mn)), kMax = waveMax(FKey<T>::enc(mx));
+    if (lane == 0)
+    {
+      s_spanLen = total;
+      publish64(f.sizeCell + wg, ((u64)f.epoch << 32) | (u64)total);
+      // the band's range: fire and forget, both as maxima (the cells are zero between calls)
+      __hip_atomic_fetch_max(f.keyPart + 2 * (size_t)(wg / kFastPackGroup), kMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max(f.keyPart + 2 * (size_t)(wg / kFastPackGroup) + 1, ~kMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // block headers
+    const int kind = pl.kind, tc = pl.tc, dtRed = pl.dtRed;
+    const int j0 = (int)fastSpanCol(span, (u32)lane) * 8;
+    u32 flag = (u32)(((j0 >> 3) & 15) << 2) & 0x38u;    // version 6, no slice difference
+    if (kind == 7) { }
+    else if (kind == 0) orBits(s_out, at0, flag | 2u, 8);
+    else if (kind == 1) orBits(s_out, at0, flag, 8);
+    else
+    {
+      flag |= (kind == 2) ? 3u : 1u;
+      flag |= (u32)tc << 6;
+      const int offBytes = dtSize3((u32)dtRed);
+      orBits(s_out, at0, flag, 8);
+      orBits64(s_out, at0 + 8, typedBits((double)mn, dtRed), 8 * offBytes);
+      if (kind == 3) orBits(s_out, at0 + 8u * (1u + (u32)offBytes), (u32)nb | (2u << 6) | (64u << 8), 16);    // numBits byte, count 64
+    }
+  }
+  __syncthreads();
+  PROBE(1);
+  if (!out) return;    // (never: size queries take the two-launch form's first steps)
+
+  // ---- where the span goes: the cells of the workgroups from the start of the group in front of this one's up to this
+  // one (two per thread), and what lies in front of those.  Asked for now, looked at when the payload is packed.
+  const u32 winBegin = (grp ? grp - 1u : 0u) * kFusedGroup;
+  const u32 i0 = winBegin + threadIdx.x, i1 = i0 + 256u;
+  static_assert(2u * kFusedGroup <= 512u, "two cells per thread cover the window");
+  u64 c0 = 0, c1 = 0, cb = 0;
+  if (i0 < wg) c0 = observe64(f.sizeCell + i0);
+  if (i1 < wg) c1 = observe64(f.sizeCell + i1);
+  if (threadIdx.x == 0 && grp >= 2u) cb = observe64(f.baseCell + (grp - 1u));
+
+  // ---- payloads
+#pragma unroll
+  for (int t = 0; t < IT; t++)
+  {
+    const int tile = t * 4 + w;
+    const int blk = tile * BPW + b;
+    const u32 w1 = s_w1[blk];
+    const int kind = (int)((w1 >> 16) & 7u);
+    const u32 at0 = s_bit[blk];
+    const int e0 = r * 8 + h * V;
+    if (kind == 3)
+    {
+      const int nb = (int)(w1 >> 24);
+      const int offBytes = dtSize3((w1 >> 21) & 7u);
+      const T mn = s_mnT[blk];
+      u32 q[V];
+      quantizeLane<T, V>(p.intLossless, p.scale, v[t], mn, q);
+      const u32 at = at0 + 8u * (3u + (u32)offBytes);
+      if (V * nb <= 64)
+      {
+        u64 s = 0;
+#pragma unroll
+        for (int k = 0; k < V; k++) s |= (u64)q[k] << (k * nb);
+        orBits64(s_out, at + (u32)e0 * (u32)nb, s, V * nb);
+      }
+      else
+      {
+#pragma unroll
+        for (int k = 0; k < V; k += 2)
+          orBits64(s_out, at + (u32)(e0 + k) * (u32)nb, (u64)q[k] | ((u64)q[k + 1] << nb), 2 * nb);
+      }
+    }
+    else if (kind == 1)
+    {
+#pragma unroll
+      for (int k = 0; k < V; k++)
+        orBits64(s_out, at0 + 8u + (u32)(e0 + k) * 8u * (u32)sizeof(T), rawBits<T>(v[t][k]), 8 * (int)sizeof(T));
+    }
+    // LUT blocks (kind 4): all blocks of the wave take part in the group reductions
+    if (__any(kind == 4))
+    {
+      const bool mine = (kind == 4);
+      const T mn = s_mnT[blk];
+      u32 q[V], idx[V];
+      quantizeLane<T, V>(p.intLossless, p.scale, v[t], mn, q);
+#pragma unroll
+      for (int k = 0; k < V; k++) idx[k] = 0;
+      const int nb = (int)(w1 >> 24);
+      const int offBytes = dtSize3((w1 >> 21) & 7u);
+      const u32 hdr = at0 + 8u * (1u + (u32)offBytes);
+      const u32 lutAt = hdr + 24;    // numBits byte, count byte, nLut + 1 byte
+      u32 count = 0, last = 0;
+      bool active = mine;
+      for (;;)
+      {
+        u32 m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < V; k++)
+          if ((count == 0 || q[k] > last) && q[k] < m) m = q[k];
+        m = groupReduce<LB>(m, OpMin());
+        if (m == 0xFFFFFFFFu) active = false;
+        if (!__any(active)) break;
+        if (active)
+        {
+#pragma unroll
+          for (int k = 0; k < V; k++) if (q[k] == m) idx[k] = count;
+          if (leader && count > 0) orBits(s_out, lutAt + (count - 1) * (u32)nb, m, nb);
+          last = m; count++;
+        }
+      }
+      if (mine)
+      {
+        const u32 nLut = count - 1;
+        const int nbIdx = bitLen(nLut);
+        if (leader) orBits(s_out, hdr, (u32)nb | (2u << 6) | 32u | (64u << 8) | ((nLut + 1) << 16), 24);
+        const u32 idxAt = lutAt + 8u * ((nLut * (u32)nb + 7) >> 3);
+        u64 s = 0;
+#pragma unroll
+        for (int k = 0; k < V; k++) s |= (u64)idx[k] << (k * nbIdx);    // nbIdx <= 6
+        orBits64(s_out, idxAt + (u32)e0 * (u32)nbIdx, s, V * nbIdx);
+      }
+    }
+  }
+  PROBE(2);
+  // ---- the cells asked for above: nearly always all there
+  {
+    const bool need0 = i0 < wg, need1 = i1 < wg, needB = threadIdx.x == 0 && grp >= 2u;
+    const bool miss = (need0 && (u32)(c0 >> 32) != f.epoch) || (need1 && (u32)(c1 >> 32) != f.epoch) || (needB && (u32)(cb >> 32) != f.epoch);
+    u32 part = (need0 ? (u32)c0 : 0u) + (need1 ? (u32)c1 : 0u) + (needB ? (u32)cb : 0u);
+    part = waveSum(part);
+    if (lane == 0) atomicAdd(&s_base, part);
+    if (__any(miss) && lane == 0) s_retry = 1u;
+  }
+  __syncthreads();
+  if (s_retry)
+  {
+    // (a workgroup in front of this one was slower than this one: ask again, patiently)
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = 0u;
+    __syncthreads();
+    const bool need0 = i0 < wg, need1 = i1 < wg, needB = threadIdx.x == 0 && grp >= 2u;
+    bool lost = false;
+    for (u32 spin = 0; ; spin++)
+    {
+      if (need0 && (u32)(c0 >> 32) != f.epoch) c0 = observe64(f.sizeCell + i0);
+      if (need1 && (u32)(c1 >> 32) != f.epoch) c1 = observe64(f.sizeCell + i1);
+      if (needB && (u32)(cb >> 32) != f.epoch) cb = observe64(f.baseCell + (grp - 1u));
+      const bool miss = (need0 && (u32)(c0 >> 32) != f.epoch) || (need1 && (u32)(c1 >> 32) != f.epoch) || (needB && (u32)(cb >> 32) != f.epoch);
+      if (!miss) break;
+      if (spin >= (1u << 22)) { lost = true; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    u32 part = (need0 ? (u32)c0 : 0u) + (need1 ? (u32)c1 : 0u) + (needB ? (u32)cb : 0u);
+    part = waveSum(part);
+    if (lane == 0) atomicAdd(&s_base, part);
+    if (__any(lost) && lane == 0) __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  }
+  PROBE(3);
+  const u32 prefixLen = 90u + 4u + 2u * (u32)sizeof(T) + 1u;    // header, mask byte count, ranges, "not one sweep" (fastDecide)
+  const u32 spanBase = s_base, spanLen = s_spanLen;
+  const u32 g0 = prefixLen + spanBase;                      // absolute offset of this workgroup's span
+  const bool fits = (u64)g0 + spanLen <= outCapacity;       // (the last workgroup reports what does not fit)
+  const u32 ldsShift = g0 & 15u;
+  const u32 gAligned = g0 & ~15u;
+  const u32 nUnits = (ldsShift + spanLen + 15) >> 4;
+  {
+    // Fletcher sums and flush in one go, in 16-byte units of the BLOB: unit u holds the image bytes from 16 u - (g0 & 15) on,
+    // fetched as five words and funnel shifted; what lies outside the span is zero in LDS, adds nothing to the sums and
+    // is not stored
+    u32 A = 0;
+    u64 B = 0;
+    for (u32 u = threadIdx.x; u < nUnits; u += 256)
+    {
+      const u32 at = kLead + 16u * u - ldsShift;            // LDS byte of the unit's first byte (>= 1)
+      const u32 wd0 = at >> 2, sh = 8u * (at & 3u);
+      const u32 x0 = s_out[wd0], x1 = s_out[wd0 + 1], x2 = s_out[wd0 + 2], x3 = s_out[wd0 + 3], x4 = s_out[wd0 + 4];
+      uint4 x;
+      x.x = __builtin_amdgcn_alignbit(x1, x0, sh); x.y = __builtin_amdgcn_alignbit(x2, x1, sh);
+      x.z = __builtin_amdgcn_alignbit(x3, x2, sh); x.w = __builtin_amdgcn_alignbit(x4, x3, sh);
+      fletcherUnit(x, (u64)((gAligned + 16u * u - 14u) >> 1), A, B);
+      if (!fits) continue;
+      const u32 lo = 16u * u, first = lo < ldsShift ? ldsShift : lo, last = min(lo + 16u, ldsShift + spanLen);    // owned bytes of the unit
+      if (first == lo && last == lo + 16u) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;    // (k_fast_discover reads them next: no streaming hint)
+      else
+      {
+        const u32 xs[4] = { x.x, x.y, x.z, x.w };
+#pragma unroll
+        for (u32 i = 0; i < 16; i++)
+          if (lo + i >= first && lo + i < last) out[gAligned + lo + i] = (u8)(xs[i >> 2] >> (8 * (i & 3)));
+      }
+    }
+    const u64 a = waveSum(A), b2 = waveSum(B);
+    if (lane == 0) { s_fa[w] = a; s_fb[w] = b2; }
+  }
+  __syncthreads();
+  // ---- arrival: checksum terms (A bits 0-23, B bits 24-47), one arrival (bits 48-52), the two flags as counts (bits 53-57
+  // NaN seen, bits 58-62 a non-integer value seen) in ONE atomic nobody waits for; by the thread that sent the range
+  // atomics, behind a wait for those (the deciding workgroup reads the key cells once the arrivals are complete)
+  if (w == wPlan && lane == 0)
+  {
+    const u64 a = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u, b2 = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
+    const u32 fl = s_fl[0] | s_fl[1] | s_fl[2] | s_fl[3];
+    drainVmem();
+    __hip_atomic_fetch_add(f.packPart + wg / kFastPackGroup, a | (b2 << 24) | (1ull << 48) | ((u64)(fl & 1u) << 53) | ((u64)((fl >> 1) & 1u) << 58),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  PROBE(4);
+  if (wg != nWG - 1u) return;
+
+  // ---- the last workgroup: wait for everybody (aggregator 0 included), fold, decide, header + checksum
+  __shared__ u32 s_redo, s_cs;
+  __shared__ u64 s_kmax[4], s_kmin[4], s_A[4], s_B[4], s_raise[9];
+  __shared__ u32 s_flg[4];
+  __shared__ __align__(16) u8 s_prefix[kFastPrefixStage];
+  const u32 nBytesTiling = spanBase + spanLen;
+  {
+    u64 fA = 0, fB = 0, kMaxAll = 0, kMinInv = 0;
+    u32 flg = 0;
+    for (u32 gq = 0; gq <= nPackGroups; gq += 256u)
+    {
+      const u32 gi = gq + threadIdx.x;
+      const u32 want = gi < nPackGroups ? min(kFastPackGroup, nWG - gi * kFastPackGroup) : gi == nPackGroups ? 1u : 0u;    // (+ aggregator 0)
+      u64 acc = 0;
+      for (u32 spin = 0; ; spin++)
+      {
+        acc = gi <= nPackGroups ? observe64(f.packPart + gi) : 0ull;
+        if (!__any((u32)((acc >> 48) & 31u) != want)) break;
+        if (spin > (1u << 22)) { if (lane == 0) __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }    // (never: every other block was dispatched before this one)
+        __builtin_amdgcn_s_sleep(8);
+      }
+      fA += acc & 0xFFFFFFull; fB += (acc >> 24) & 0xFFFFFFull;
+      flg |= (((acc >> 53) & 31u) ? 1u : 0u) | (((acc >> 58) & 31u) ? 2u : 0u);
+      if (gi <= nPackGroups) publish64(f.packPart + gi, 0ull);    // clean for the next call
+      if (gi < nPackGroups)
+      {
+        const u64 a = observe64(f.keyPart + 2 * (size_t)gi), bInv = observe64(f.keyPart + 2 * (size_t)gi + 1);
+        kMaxAll = a > kMaxAll ? a : kMaxAll; kMinInv = bInv > kMinInv ? bInv : kMinInv;
+        publish64(f.keyPart + 2 * (size_t)gi, 0ull); publish64(f.keyPart + 2 * (size_t)gi + 1, 0ull);
+      }
+    }
+    fA = waveSum(fA % 65535u) % 65535u; fB = waveSum(fB % 65535u) % 65535u;
+    kMaxAll = waveMax(kMaxAll); kMinInv = waveMax(kMinInv);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) flg |= __shfl_xor(flg, m);
+    if (lane == 0) { s_A[w] = fA; s_B[w] = fB; s_kmax[w] = kMaxAll; s_kmin[w] = kMinInv; s_flg[w] = flg; }
+    if (threadIdx.x < 9) s_raise[threadIdx.x] = observe64(f.raise + threadIdx.x);    // (aggregator 0 has arrived)
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    u64 a = 0, bInv = 0;
+    u32 fl = 0;
+    for (int i = 0; i < 4; i++) { a = s_kmax[i] > a ? s_kmax[i] : a; bInv = s_kmin[i] > bInv ? s_kmin[i] : bInv; fl |= s_flg[i]; }
+    const bool doRaise = DtOf<T>::v >= DT_Float && raiseCandidates != 0u;
+    s_redo = fastDecide(p, requestedMaxZErr, raiseCandidates, nBytesTiling, ~bInv, a, fl, doRaise ? s_raise : nullptr, nBlobsMore, s_prefix, outCapacity, res);
+  }
+  __syncthreads();
+  if (s_redo) return;
+  if (w == 0)
+  {
+    u64 fA = s_A[0] + s_A[1] + s_A[2] + s_A[3], fB = s_B[0] + s_B[1] + s_B[2] + s_B[3];
+    fA = lane == 0 ? fA : 0ull; fB = lane == 0 ? fB : 0ull;
+    for (u32 pos = (u32)lane; pos + 14 < prefixLen; pos += 64u)    // + the Fletcher terms of the bytes in front of the first block
+    {
+      const u32 cw = (u32)s_prefix[14 + pos] << ((pos & 1u) ? 0 : 8);
+      fA += cw; fB += (u64)(pos >> 1) * cw;
+    }
+    fA = waveSum(fA % 65535u) % 65535u; fB = waveSum(fB % 65535u) % 65535u;
+    const u32 len = prefixLen + nBytesTiling - 14u;
+    const u64 N = ((u64)len + 1) / 2;
+    u64 s1 = fA, s2 = ((N % 65535u) * fA + 65535u - fB) % 65535u;
+    if (s1 == 0) s1 = 0xffff;
+    if (s2 == 0) s2 = 0xffff;
+    if (lane == 0) s_cs = (u32)((s2 << 16) | s1);
+  }
+  __syncthreads();
+  const u32 cs = s_cs;
+  if (threadIdx.x < prefixLen && threadIdx.x < outCapacity)
+    out[threadIdx.x] = (threadIdx.x >= 10u && threadIdx.x < 14u) ? (u8)(cs >> (8u * (threadIdx.x - 10u))) : s_prefix[threadIdx.x];
+  if (threadIdx.x == 0) res->checksum = cs;
+}
+
 // Batches: where each tile's blob goes in the arena.  One workgroup of 1024 threads; a tile that the general path has
 // to redo takes no room here (the host appends it behind the batch).  Starts are 16-byte aligned.
 __global__ void __launch_bounds__(1024)
@@ -1125,6 +1650,16 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
 {
   const u32 nWG = batch.nWG, nT = batch.nTiles;
   const bool wide = p.nTH % 64 == 0;
+  if (b.fused.sizeCell && out)    // one raster, one launch
+  {
+    if (stage != 0) return;
+    const dim3 grid(nWG + fastFusedGroups(nWG));
+    if (wide)
+      hipLaunchKernelGGL((k_fast_encode1<T, true>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nWG, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
+    else
+      hipLaunchKernelGGL((k_fast_encode1<T, false>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nWG, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
+    return;
+  }
   if (stage == 0)
   {
     if (wide)
