@@ -769,7 +769,7 @@ static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double
     // (counters: the pack accumulators, then the one-launch form's key cells; cells: a cell per workgroup, then the
     // one-launch form's group cells and first-row errors)
     u8* counters = ctx.persistentState(0, (nGroups + 1) * 8 + 2 * nGroups * 8 + 256);
-    u8* cells = ctx.persistentState(1, ((size_t)nWG + nFused + 16) * 8 + 256);
+    u8* cells = ctx.persistentState(1, ((size_t)nWG + 2 * nFused + 16) * 8 + 256);
     fb.desc = ctx.allocT<FastBlockDesc>((size_t)nWG * kFastBlocksPerWG);
     fb.wgSize = ctx.allocT<u32>(fastWgStride(nWG) + 4);
     fb.wgMinKey = ctx.allocT<u64>(nWG + 4);
@@ -786,7 +786,8 @@ static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double
     {
       fb.fused.sizeCell = (u64*)cells;
       fb.fused.baseCell = (u64*)cells + nWG;
-      fb.fused.raise = (u64*)cells + nWG + nFused;
+      fb.fused.totalCell = (u64*)cells + nWG + nFused;
+      fb.fused.raise = (u64*)cells + nWG + 2 * nFused;
       fb.fused.packPart = (u64*)counters;
       fb.fused.keyPart = (u64*)counters + nGroups + 1;
     }

@@ -80,12 +80,16 @@ LERC_HD bool fastSoloOk(int dt, int nRows, int nCols)
 #ifdef LERC_SMALL_GROUPS                   // (emulator builds: small rasters then take several groups)
 static const u32 kFusedGroup = 4;
 #else
-static const u32 kFusedGroup = 256;        // (a thread reads at most two cells of the window of 2 * kFusedGroup - 1)
+#ifndef LERC_FUSED_GROUP
+#define LERC_FUSED_GROUP 256
+#endif
+static const u32 kFusedGroup = LERC_FUSED_GROUP;    // (a thread reads at most two cells of the window of 2 * kFusedGroup - 1)
 #endif
 struct FastFused
 {
   u64* sizeCell;       // [nWG] epoch (32) | bytes of the workgroup's span (32); nullptr: not this mode
   u64* baseCell;       // [nGroups] epoch (32) | bytes in front of group k (32), k = 1 .. nGroups - 2
+  u64* totalCell;      // [nGroups] epoch (32) | bytes of group k (32)
   u64* raise;          // [9] largest first-row rounding error per TryRaiseMaxZError candidate (aggregator 0; read after its arrival)
   u64* packPart;       // [nPackGroups + 1] as k_fast_pack's: A | B << 24 | arrivals << 48 | NaN seen << 53 | non-integer seen << 58; [nPackGroups]: aggregator 0
   u64* keyPart;        // [2 * nPackGroups] largest key, largest complement of a key (zero between calls, like packPart)

@@ -25,7 +25,30 @@
 
 namespace lerc {
 
+// (a workgroup of 256 threads is admitted eight times per CU only if its kernel uses at most 80 scalar registers)
+#ifndef LERC_FUSED_SGPR80
+#define LERC_FUSED_SGPR80 1
+#endif
+#ifndef LERC_FUSED_PATIENT
+#define LERC_FUSED_PATIENT 0
+#endif
+#if defined(HIPSIM) || !LERC_FUSED_SGPR80
+#define LERC_SGPR_CAP
+#else
+#define LERC_SGPR_CAP __attribute__((amdgpu_num_sgpr(80)))
+#endif
 PROBE_DEFINE(fast_encode)
+#if defined(LERC_PROBE) && !defined(HIPSIM)
+// tuning: per-workgroup time line of the one-launch encoder (constant-rate counter), read by tools/trace_encode1.py
+static __device__ unsigned long long g_trace[8 * 32768];
+extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace(unsigned long long* out, int n)
+{ hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * (size_t)n); }
+#define TRACE(slot) do { if (threadIdx.x == 0 && wg < 32768u) g_trace[8 * wg + (slot)] = wall_clock64(); } while (0)
+#define TRACE_ID() do { if (threadIdx.x == 0 && wg < 32768u) { unsigned xcc, hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_trace[8 * wg + 7] = ((unsigned long long)xcc << 32) | hw; } } while (0)
+#else
+#define TRACE(slot)
+#define TRACE_ID()
+#endif
 
 enum FastRedo : u32
 {
@@ -1153,10 +1176,14 @@ fusedAggregate(u32 k, u32 nGroups, const T* __restrict__ data, const BandParams&
     if (threadIdx.x == 0) __hip_atomic_fetch_add(f.packPart + nPackGroups, 1ull << 48, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  // ---- aggregator k >= 1: bytes in front of group k = bytes in front of group k - 1 + the sizes of group k - 1.  Group
-  // k + 1 is the first one to ask for it, so the last two aggregators have nobody to work for
-  if (k + 1u >= nGroups) return;
-  __shared__ u32 s_sum[4];
+  // ---- aggregator k >= 1 adds up group k - 1 and publishes that total at once (it hangs on nothing but the group's own
+  // workgroups); the bytes in front of group k are the totals of all groups before it, which the aggregators in front of
+  // this one have published -- each for itself, so that no chain runs through the aggregators (a chain of 64 hops of 1.8 us
+  // was as long as the whole kernel).  Group k + 1 is the first one to ask for the bytes in front of group k.
+  if (k + 1u >= nGroups) return;    // (nobody asks for the bytes in front of the last group, nor for the total of the one before it)
+  __shared__ u32 s_sum[4], s_lost;
+  if (threadIdx.x == 0) s_lost = 0u;
+  __syncthreads();
   u32 size = 0;
   bool lost = false;
   if (threadIdx.x < kFusedGroup)
@@ -1172,31 +1199,39 @@ fusedAggregate(u32 k, u32 nGroups, const T* __restrict__ data, const BandParams&
     size = lost ? 0u : (u32)cell;
   }
   size = waveSum(size);
-  if (lane == 0) s_sum[w] = size;
-  if (__any(lost) && lane == 0) __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool lostWave = __any(lost);
+  if (lane == 0) { s_sum[w] = size; if (lostWave) s_lost = 1u; }
   __syncthreads();
-  if (threadIdx.x == 0)
+  const u32 total = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+  if (threadIdx.x == 0 && !s_lost) publish64(f.totalCell + (k - 1u), ((u64)f.epoch << 32) | (u64)total);
+  // the totals of groups 0 .. k - 2
+  u32 before = 0;
+  lost = false;
+  for (u32 j0 = 0; j0 + 1u < k; j0 += 256u)
   {
-    u32 before = 0;
-    bool ok = true;
-    if (k >= 2u)
+    const u32 j = j0 + threadIdx.x;
+    if (j + 1u >= k) continue;
+    u64 cell = observe64(f.totalCell + j);
+    for (u32 spin = 0; (u32)(cell >> 32) != f.epoch && spin < (1u << 22); spin++)
     {
-      u64 cell = observe64(f.baseCell + (k - 1u));
-      for (u32 spin = 0; (u32)(cell >> 32) != f.epoch && spin < (1u << 22); spin++)
-      {
-        __builtin_amdgcn_s_sleep(2);
-        cell = observe64(f.baseCell + (k - 1u));
-      }
-      ok = (u32)(cell >> 32) == f.epoch;
-      before = (u32)cell;
+      __builtin_amdgcn_s_sleep(2);
+      cell = observe64(f.totalCell + j);
     }
-    if (!ok) __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else publish64(f.baseCell + k, ((u64)f.epoch << 32) | (u64)(before + s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]));
+    lost = lost || (u32)(cell >> 32) != f.epoch;
+    before += (u32)cell;
   }
+  before = waveSum(before);
+  lostWave = __any(lost);
+  __syncthreads();    // (s_sum has been read)
+  if (lane == 0) { s_sum[w] = before; if (lostWave) s_lost = 1u; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (s_lost) __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else publish64(f.baseCell + k, ((u64)f.epoch << 32) | (u64)(total + s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]));
 }
 
 template<class T, bool WIDE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) LERC_SGPR_CAP
 k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, FastEncodeResult* __restrict__ res, u32 nWG, u32 nBlobsMore,
                FastFused f, double requestedMaxZErr, u32 raiseCandidates, u64 outCapacity)
 {
@@ -1221,6 +1256,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   if (inGrp == 0u) { fusedAggregate<T>(grp, nGroups, data, p, raiseCandidates, f, nPackGroups, res); return; }
   const u32 wg = grp * kFusedGroup + inGrp - 1u;    // (the grid has exactly nWG + nGroups blocks)
   PROBE_BEGIN;
+  TRACE(0); TRACE_ID();
   const int w = waveId(), lane = laneId();
   const int b = lane / LB, r = (lane % LB) / LPR, h = lane % LPR, c = b * LPR + h;
   const bool leader = (lane % LB == 0);
@@ -1307,7 +1343,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       quantOk = !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
     }
     const u32 qMax = quantOk ? (u32)(mv + 0.5) : 0u;    // == largest quantised element (same expression as Quantize)
-    Plan pl = planBlock<T>(p, 64, mn, mx, p.dt, tryLut, mv, qMax, s_nd[lane]);
+    Plan pl = planBlock<T>(p, 64, mn, mx, DtOf<T>::v, tryLut, mv, qMax, s_nd[lane]);    // (the data type as a constant: the other types' branches fold away)
     if (!fastSpanHas(span, (u32)lane)) { pl.nBytes = 0; pl.kind = 7; }    // behind the raster's last block: nothing to write
     const int nb = bitLen(qMax);
     const u32 w1 = packDesc(pl, nb);
@@ -1346,6 +1382,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   }
   __syncthreads();
   PROBE(1);
+  TRACE(1);
   if (!out) return;    // (never: size queries take the two-launch form's first steps)
 
   // ---- where the span goes: the cells of the workgroups from the start of the group in front of this one's up to this
@@ -1442,6 +1479,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
     }
   }
   PROBE(2);
+  TRACE(2);
   // ---- the cells asked for above: nearly always all there
   {
     const bool need0 = i0 < wg, need1 = i1 < wg, needB = threadIdx.x == 0 && grp >= 2u;
@@ -1450,11 +1488,78 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
     part = waveSum(part);
     if (lane == 0) atomicAdd(&s_base, part);
     if (__any(miss) && lane == 0) s_retry = 1u;
+#if defined(LERC_PROBE) && !defined(HIPSIM) && !defined(LERC_PROBE_TRACE_ONLY)
+    {
+      // tuning counters: how many workgroups miss a size cell / the base cell at the first look, how far back the misses lie
+      const bool missB = needB && (u32)(cb >> 32) != f.epoch;
+      const bool miss0 = (need0 && (u32)(c0 >> 32) != f.epoch), miss1 = (need1 && (u32)(c1 >> 32) != f.epoch);
+      const u64 mB = __builtin_amdgcn_ballot_w64(missB), mS = __builtin_amdgcn_ballot_w64(miss0 || miss1);
+      if (lane == 0 && mB) atomicAdd(&g_probe[8], 1ull);
+      if (lane == 0 && mS) atomicAdd(&g_probe[9], (unsigned long long)__popcll(mS));
+      // distance of the farthest missing size cell
+      u32 far = 0;
+      if (miss0) far = wg - i0;
+      if (miss1) far = max(far, wg - i1);
+      far = waveMax(far);
+      if (lane == 0 && far) atomicAdd(&g_probe[10 + min(5u, (u32)(31 - __clz((int)far)) / 2u)], 1ull);    // buckets 1, 4, 16, 64, 256
+    }
+#endif
   }
   __syncthreads();
+#if LERC_FUSED_PATIENT
   if (s_retry)
   {
-    // (a workgroup in front of this one was slower than this one: ask again, patiently)
+    // Some workgroup in front of this one has not published its size yet (the eight XCDs do not start their blocks in step).
+    // Waiting must cost the others nothing: ONE lane polls the oldest missing cell, with pauses -- a whole workgroup asking
+    // again and again for a hundred cells, in two thousand resident workgroups, takes the memory system away from those
+    // that are waited for -- and when it has arrived everybody looks once more at what he is still missing.
+    __shared__ u32 s_oldest;
+    const bool need0 = i0 < wg, need1 = i1 < wg, needB = threadIdx.x == 0 && grp >= 2u;
+    bool lost = false;
+    for (u32 round = 0; ; round++)
+    {
+      __syncthreads();
+      if (threadIdx.x == 0) { s_oldest = 0xFFFFFFFFu; s_base = 0u; }
+      __syncthreads();
+      u32 mine = 0xFFFFFFFFu;
+      if (need1 && (u32)(c1 >> 32) != f.epoch) mine = i1;
+      if (need0 && (u32)(c0 >> 32) != f.epoch) mine = i0;
+      mine = waveMin(mine);
+      if (lane == 0 && mine != 0xFFFFFFFFu) atomicMin(&s_oldest, mine);
+      __syncthreads();
+      const u32 oldest = s_oldest;
+      const bool baseMissing = needB && (u32)(cb >> 32) != f.epoch;    // (thread 0 only)
+      if (threadIdx.x == 0 && (oldest != 0xFFFFFFFFu || baseMissing))
+      {
+        u64 cell = 0;
+        for (u32 spin = 0; ; spin++)
+        {
+          bool ok = true;
+          if (oldest != 0xFFFFFFFFu) { cell = observe64(f.sizeCell + oldest); ok = (u32)(cell >> 32) == f.epoch; }
+          if (needB && (u32)(cb >> 32) != f.epoch) { cb = observe64(f.baseCell + (grp - 1u)); ok = ok && (u32)(cb >> 32) == f.epoch; }
+          if (ok) break;
+          if (spin >= (1u << 20)) { lost = true; break; }
+#if defined(LERC_PROBE) && !defined(HIPSIM) && !defined(LERC_PROBE_TRACE_ONLY)
+          atomicAdd(&g_probe[16], 1ull);    // polls of the patient lane
+#endif
+          __builtin_amdgcn_s_sleep(16);
+        }
+        if (lost) { __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_oldest = 0xFFFFFFFEu; }
+      }
+      __syncthreads();
+      if (oldest == 0xFFFFFFFFu || s_oldest == 0xFFFFFFFEu) break;    // nothing was missing any more (or: given up)
+      if (need0 && (u32)(c0 >> 32) != f.epoch) c0 = observe64(f.sizeCell + i0);
+      if (need1 && (u32)(c1 >> 32) != f.epoch) c1 = observe64(f.sizeCell + i1);
+    }
+    u32 part = (need0 ? (u32)c0 : 0u) + (need1 ? (u32)c1 : 0u) + (needB ? (u32)cb : 0u);
+    part = waveSum(part);
+    if (lane == 0) atomicAdd(&s_base, part);
+    __syncthreads();
+  }
+#else
+  if (s_retry)
+  {
+    // (a workgroup in front of this one was slower than this one: ask again)
     __syncthreads();
     if (threadIdx.x == 0) s_base = 0u;
     __syncthreads();
@@ -1476,7 +1581,9 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
     if (__any(lost) && lane == 0) __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
   }
+#endif
   PROBE(3);
+  TRACE(3);
   const u32 prefixLen = 90u + 4u + 2u * (u32)sizeof(T) + 1u;    // header, mask byte count, ranges, "not one sweep" (fastDecide)
   const u32 spanBase = s_base, spanLen = s_spanLen;
   const u32 g0 = prefixLen + spanBase;                      // absolute offset of this workgroup's span
@@ -1526,6 +1633,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   PROBE(4);
+  TRACE(4);
   if (wg != nWG - 1u) return;
 
   // ---- the last workgroup: wait for everybody (aggregator 0 included), fold, decide, header + checksum

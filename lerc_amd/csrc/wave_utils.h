@@ -11,8 +11,13 @@
   extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_##tag(unsigned long long* out, int reset) \
   { hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof(g_probe)); \
     if (reset) { unsigned long long z[32] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)); } }
+#ifdef LERC_PROBE_TRACE_ONLY    // (the per-workgroup time line alone: the phase sums' atomics on a few addresses distort it)
+#define PROBE_BEGIN
+#define PROBE(i)
+#else
 #define PROBE_BEGIN unsigned long long probeT_ = clock64()
 #define PROBE(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = clock64(); atomicAdd(&g_probe[i], n_ - probeT_); probeT_ = n_; } } while (0)
+#endif
 #define PROBE_DRAIN asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")    // so that a phase is charged its own loads
 #else
 #define PROBE_DEFINE(tag)
