@@ -765,11 +765,13 @@ static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double
   {
     // one raster: two launches, the pack step's first blocks scan and decide (tile_fast.h)
     memset(&fb, 0, sizeof(fb));
-    const size_t nGroups = fastPackGroups(nWG), nFused = fastFusedGroups(nWG);
+    const bool form = fastEncodeOneLaunch();
+    const u32 nWGf = form ? fastFusedNumWG(nRows, nCols) : nWG;    // (the one-launch form counts its own workgroups)
+    const size_t nGroups = std::max(fastPackGroups(nWG), fastPackGroups(nWGf)), nFused = fastFusedGroups(std::max(nWG, nWGf));
     // (counters: the pack accumulators, then the one-launch form's key cells; cells: a cell per workgroup, then the
     // one-launch form's group cells and first-row errors)
     u8* counters = ctx.persistentState(0, (nGroups + 1) * 8 + 2 * nGroups * 8 + 256);
-    u8* cells = ctx.persistentState(1, ((size_t)nWG + 2 * nFused + 16) * 8 + 256);
+    u8* cells = ctx.persistentState(1, ((size_t)std::max(nWG, nWGf) + 2 * nFused + 16) * 8 + 256);
     fb.desc = ctx.allocT<FastBlockDesc>((size_t)nWG * kFastBlocksPerWG);
     fb.wgSize = ctx.allocT<u32>(fastWgStride(nWG) + 4);
     fb.wgMinKey = ctx.allocT<u64>(nWG + 4);
@@ -782,14 +784,16 @@ static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double
       return false;
     fb.packPart = (u64*)counters;
     fb.solo.cells = (u64*)cells;
-    if (fastEncodeOneLaunch())
+    if (form)
     {
+      const size_t nCell = std::max(nWG, nWGf);
       fb.fused.sizeCell = (u64*)cells;
-      fb.fused.baseCell = (u64*)cells + nWG;
-      fb.fused.totalCell = (u64*)cells + nWG + nFused;
-      fb.fused.raise = (u64*)cells + nWG + 2 * nFused;
+      fb.fused.baseCell = (u64*)cells + nCell;
+      fb.fused.totalCell = (u64*)cells + nCell + nFused;
+      fb.fused.raise = (u64*)cells + nCell + 2 * nFused;
       fb.fused.packPart = (u64*)counters;
       fb.fused.keyPart = (u64*)counters + nGroups + 1;
+      fb.fused.nWG = nWGf;
     }
   }
   else

@@ -94,8 +94,18 @@ struct FastFused
   u64* packPart;       // [nPackGroups + 1] as k_fast_pack's: A | B << 24 | arrivals << 48 | NaN seen << 53 | non-integer seen << 58; [nPackGroups]: aggregator 0
   u64* keyPart;        // [2 * nPackGroups] largest key, largest complement of a key (zero between calls, like packPart)
   u32 epoch;
+  u32 nWG;             // workgroups of the launch (kFusedUnits units of 64 blocks each)
 };
 LERC_HD u32 fastFusedGroups(u32 nWG) { return (nWG + kFusedGroup - 1u) / kFusedGroup; }
+#ifndef LERC_FUSED_U
+#define LERC_FUSED_U 2
+#endif
+static const int kFusedUnits = LERC_FUSED_U;    // consecutive units of 64 blocks a workgroup of k_fast_encode1 takes
+LERC_HD u32 fastFusedNumWG(int nRows, int nCols)
+{
+  const u64 nUnits = ((u64)(nRows / 8) * (u64)(nCols / 8) + 63u) / 64u;
+  return (u32)((nUnits + kFusedUnits - 1u) / kFusedUnits);
+}
 
 struct FastEncodeBuffers
 {

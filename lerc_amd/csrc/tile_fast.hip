@@ -1230,418 +1230,72 @@ fusedAggregate(u32 k, u32 nGroups, const T* __restrict__ data, const BandParams&
   else publish64(f.baseCell + k, ((u64)f.epoch << 32) | (u64)(total + s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]));
 }
 
-template<class T, bool WIDE>
-__global__ void __launch_bounds__(256) LERC_SGPR_CAP
-k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, FastEncodeResult* __restrict__ res, u32 nWG, u32 nBlobsMore,
-               FastFused f, double requestedMaxZErr, u32 raiseCandidates, u64 outCapacity)
+// The tail of the one-launch encoders in three pieces.
+// (1) Fletcher sums + flush of a span image whose first byte is blob byte g0: 16-byte units of the BLOB -- unit u holds the image
+// bytes from 16 u - (g0 & 15) on, fetched as five words and funnel shifted; what lies outside the span is zero in LDS, adds
+// nothing to the sums and is not stored.  A and B collect this lane's Fletcher terms (no reduction mod 65535: a lane
+// holds a dozen units at most, A < 2^24 and B < 2^55).
+__device__ __forceinline__ void
+fusedFlush(const u32* s_out, u32 kLead, u32 g0, u32 spanLen, u8* __restrict__ out, u64 outCapacity, u32& A, u64& B)
 {
-  typedef FastCfg<T> C;
-  constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW, IT = C::IT;
-  constexpr int LB = 8 * LPR;                // lanes of a block: lane = b * LB + r * LPR + h (block of the wave tile, row, lane of the row)
-  typedef typename ShflT<T>::type ST;
-  constexpr int kMaxBlockBytes = 1 + 64 * (int)sizeof(T);
-  constexpr u32 kLead = 16;                  // zero bytes in front of the span image (the flush reads up to 15 bytes before it)
-  constexpr int kSpanWords = (kFastBlocksPerWG * kMaxBlockBytes + 16) / 4 + 8 + (int)kLead / 4;
-  __shared__ __align__(16) u32 s_out[kSpanWords];
-  __shared__ T s_mnT[kFastBlocksPerWG], s_mxT[kFastBlocksPerWG];
-  __shared__ u32 s_same[kFastBlocksPerWG], s_nd[kFastBlocksPerWG];
-  __shared__ u32 s_w1[kFastBlocksPerWG];
-  __shared__ u32 s_bit[kFastBlocksPerWG];    // bit position of each block inside s_out
-  __shared__ u32 s_fl[4];
-  __shared__ u64 s_fa[4], s_fb[4];
-  __shared__ u32 s_spanLen, s_base, s_retry;
-
-  const u32 nGroups = (nWG + kFusedGroup - 1u) / kFusedGroup, nPackGroups = fastPackGroups(nWG);
-  const u32 grp = blockIdx.x / (kFusedGroup + 1u), inGrp = blockIdx.x - grp * (kFusedGroup + 1u);
-  if (inGrp == 0u) { fusedAggregate<T>(grp, nGroups, data, p, raiseCandidates, f, nPackGroups, res); return; }
-  const u32 wg = grp * kFusedGroup + inGrp - 1u;    // (the grid has exactly nWG + nGroups blocks)
-  PROBE_BEGIN;
-  TRACE(0); TRACE_ID();
-  const int w = waveId(), lane = laneId();
-  const int b = lane / LB, r = (lane % LB) / LPR, h = lane % LPR, c = b * LPR + h;
-  const bool leader = (lane % LB == 0);
-  const FastSpan span = fastSpanOf(wg, (u32)p.nTH, (u32)p.nTV);
-
-  // ---- the pixels: all loads of the wave in flight first (non-temporal: nothing reads them again), the span image is
-  // zeroed while they travel
-  T v[IT][V];
-#pragma unroll
-  for (int t = 0; t < IT; t++) loadLane<T, V>(data + laneOrigin<WIDE, BPW, V>(span, t * 4 + w, r, c, p.nCols), v[t], true);
-  for (u32 i = threadIdx.x; i < (u32)kSpanWords / 4u; i += 256u) reinterpret_cast<uint4*>(s_out)[i] = make_uint4(0, 0, 0, 0);
-  if (threadIdx.x == 0) { s_base = 0u; s_retry = 0u; }
-
-  // ---- statistics per block (Lerc2::GetValidDataAndStats for an all-valid block + the tryLut count, Lerc2.cpp:1717-1799)
-  u32 flags = 0;
-#pragma unroll
-  for (int t = 0; t < IT; t++)
-  {
-    const int tile = t * 4 + w;
-    const T (&x)[V] = v[t];
-    if (DtOf<T>::v >= DT_Float)
-    {
-#pragma unroll
-      for (int k = 0; k < V; k++) if (isNaNv(x[k])) flags |= 1u;
-      if (!(flags & 2u))    // one fractional value settles "not all integers" for good
-      {
-#pragma unroll
-        for (int k = 0; k < V; k++) if (notIntegral(x[k])) flags |= 2u;
-      }
-    }
-    T mn = x[0], mx = x[0];
-#pragma unroll
-    for (int k = 1; k < V; k++) { mn = OpMin()(mn, x[k]); mx = OpMax()(mx, x[k]); }
-    if constexpr (std::is_same<T, float>::value) rowMinMax(mn, mx);    // (LB == 16)
-    else
-    {
-      mn = (T)groupReduce<LB>((ST)mn, OpMin());
-      mx = (T)groupReduce<LB>((ST)mx, OpMax());
-    }
-    T prev = (T)dppMovT<kDppWaveShr1>((ST)x[V - 1]);
-    if (leader) prev = T(0);
-    int same = (x[0] == prev) ? 1 : 0;
-#pragma unroll
-    for (int k = 1; k < V; k++) same += (x[k] == x[k - 1]) ? 1 : 0;
-    u32 nd = 0;
-    if (__any(same > 32 / LB))
-    {
-      same = groupReduce<LB>(same, OpSum());
-      const bool tryLut = (2 * same > 64) && ((double)mx > (double)mn + 3 * p.maxZErr);
-      if (__any(tryLut))
-      {
-        const double mv = ((double)mx - (double)mn) * p.scale;
-        const bool need = tryLut && !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
-        u32 q[V];
-        quantizeLane<T, V>(p.intLossless, p.scale, x, mn, q);
-        nd = groupDistinct<LB, V>(q, need);
-      }
-    }
-    else same = 0;
-    if (leader)
-    {
-      const int blk = tile * BPW + b;
-      s_mnT[blk] = mn; s_mxT[blk] = mx; s_same[blk] = (u32)same; s_nd[blk] = nd;
-    }
-  }
-  const bool f1 = __any(flags & 1u), f2 = __any(flags & 2u);
-  if (lane == 0) s_fl[w] = (f1 ? 1u : 0u) | (f2 ? 2u : 0u);
-  __syncthreads();
-  PROBE(0);
-
-  // ---- lane = block, one wave (it rotates over the SIMDs from workgroup to workgroup): the per-block decisions of
-  // Lerc2::NumBytesTile once per block, the size of the span, the block headers (Lerc2::WriteTile, BitStuffer2 stream header)
-  const int wPlan = (int)((wg * 2654435761u) >> 30);
-  if (w == wPlan)
-  {
-    const T mn = s_mnT[lane], mx = s_mxT[lane];
-    const int same = (int)s_same[lane];
-    const bool tryLut = (2 * same > 64) && ((double)mx > (double)mn + 3 * p.maxZErr);
-    double mv = 0;
-    bool quantOk = false;
-    if (p.maxZErr > 0)
-    {
-      mv = ((double)mx - (double)mn) * p.scale;
-      quantOk = !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
-    }
-    const u32 qMax = quantOk ? (u32)(mv + 0.5) : 0u;    // == largest quantised element (same expression as Quantize)
-    Plan pl = planBlock<T>(p, 64, mn, mx, DtOf<T>::v, tryLut, mv, qMax, s_nd[lane]);    // (the data type as a constant: the other types' branches fold away)
-    if (!fastSpanHas(span, (u32)lane)) { pl.nBytes = 0; pl.kind = 7; }    // behind the raster's last block: nothing to write
-    const int nb = bitLen(qMax);
-    const u32 w1 = packDesc(pl, nb);
-    const u32 sz = (u32)pl.nBytes;
-    u32 inc = sz;
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(inc, (unsigned)dd); if (lane >= dd) inc += o; }
-    const u32 at0 = 8u * (kLead + inc - sz);
-    s_w1[lane] = w1; s_bit[lane] = at0;
-    const u32 total = (u32)__shfl((int)inc, 63);
-    const u64 kMin = waveMin(FKey<T>::enc(mn)), kMax = waveMax(FKey<T>::enc(mx));
-    if (lane == 0)
-    {
-      s_spanLen = total;
-      publish64(f.sizeCell + wg, ((u64)f.epoch << 32) | (u64)total);
-      // the band's range: fire and forget, both as maxima (the cells are zero between calls)
-      __hip_atomic_fetch_max(f.keyPart + 2 * (size_t)(wg / kFastPackGroup), kMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_max(f.keyPart + 2 * (size_t)(wg / kFastPackGroup) + 1, ~kMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // block headers
-    const int kind = pl.kind, tc = pl.tc, dtRed = pl.dtRed;
-    const int j0 = (int)fastSpanCol(span, (u32)lane) * 8;
-    u32 flag = (u32)(((j0 >> 3) & 15) << 2) & 0x38u;    // version 6, no slice difference
-    if (kind == 7) { }
-    else if (kind == 0) orBits(s_out, at0, flag | 2u, 8);
-    else if (kind == 1) orBits(s_out, at0, flag, 8);
-    else
-    {
-      flag |= (kind == 2) ? 3u : 1u;
-      flag |= (u32)tc << 6;
-      const int offBytes = dtSize3((u32)dtRed);
-      orBits(s_out, at0, flag, 8);
-      orBits64(s_out, at0 + 8, typedBits((double)mn, dtRed), 8 * offBytes);
-      if (kind == 3) orBits(s_out, at0 + 8u * (1u + (u32)offBytes), (u32)nb | (2u << 6) | (64u << 8), 16);    // numBits byte, count 64
-    }
-  }
-  __syncthreads();
-  PROBE(1);
-  TRACE(1);
-  if (!out) return;    // (never: size queries take the two-launch form's first steps)
-
-  // ---- where the span goes: the cells of the workgroups from the start of the group in front of this one's up to this
-  // one (two per thread), and what lies in front of those.  Asked for now, looked at when the payload is packed.
-  const u32 winBegin = (grp ? grp - 1u : 0u) * kFusedGroup;
-  const u32 i0 = winBegin + threadIdx.x, i1 = i0 + 256u;
-  static_assert(2u * kFusedGroup <= 512u, "two cells per thread cover the window");
-  u64 c0 = 0, c1 = 0, cb = 0;
-  if (i0 < wg) c0 = observe64(f.sizeCell + i0);
-  if (i1 < wg) c1 = observe64(f.sizeCell + i1);
-  if (threadIdx.x == 0 && grp >= 2u) cb = observe64(f.baseCell + (grp - 1u));
-
-  // ---- payloads
-#pragma unroll
-  for (int t = 0; t < IT; t++)
-  {
-    const int tile = t * 4 + w;
-    const int blk = tile * BPW + b;
-    const u32 w1 = s_w1[blk];
-    const int kind = (int)((w1 >> 16) & 7u);
-    const u32 at0 = s_bit[blk];
-    const int e0 = r * 8 + h * V;
-    if (kind == 3)
-    {
-      const int nb = (int)(w1 >> 24);
-      const int offBytes = dtSize3((w1 >> 21) & 7u);
-      const T mn = s_mnT[blk];
-      u32 q[V];
-      quantizeLane<T, V>(p.intLossless, p.scale, v[t], mn, q);
-      const u32 at = at0 + 8u * (3u + (u32)offBytes);
-      if (V * nb <= 64)
-      {
-        u64 s = 0;
-#pragma unroll
-        for (int k = 0; k < V; k++) s |= (u64)q[k] << (k * nb);
-        orBits64(s_out, at + (u32)e0 * (u32)nb, s, V * nb);
-      }
-      else
-      {
-#pragma unroll
-        for (int k = 0; k < V; k += 2)
-          orBits64(s_out, at + (u32)(e0 + k) * (u32)nb, (u64)q[k] | ((u64)q[k + 1] << nb), 2 * nb);
-      }
-    }
-    else if (kind == 1)
-    {
-#pragma unroll
-      for (int k = 0; k < V; k++)
-        orBits64(s_out, at0 + 8u + (u32)(e0 + k) * 8u * (u32)sizeof(T), rawBits<T>(v[t][k]), 8 * (int)sizeof(T));
-    }
-    // LUT blocks (kind 4): all blocks of the wave take part in the group reductions
-    if (__any(kind == 4))
-    {
-      const bool mine = (kind == 4);
-      const T mn = s_mnT[blk];
-      u32 q[V], idx[V];
-      quantizeLane<T, V>(p.intLossless, p.scale, v[t], mn, q);
-#pragma unroll
-      for (int k = 0; k < V; k++) idx[k] = 0;
-      const int nb = (int)(w1 >> 24);
-      const int offBytes = dtSize3((w1 >> 21) & 7u);
-      const u32 hdr = at0 + 8u * (1u + (u32)offBytes);
-      const u32 lutAt = hdr + 24;    // numBits byte, count byte, nLut + 1 byte
-      u32 count = 0, last = 0;
-      bool active = mine;
-      for (;;)
-      {
-        u32 m = 0xFFFFFFFFu;
-#pragma unroll
-        for (int k = 0; k < V; k++)
-          if ((count == 0 || q[k] > last) && q[k] < m) m = q[k];
-        m = groupReduce<LB>(m, OpMin());
-        if (m == 0xFFFFFFFFu) active = false;
-        if (!__any(active)) break;
-        if (active)
-        {
-#pragma unroll
-          for (int k = 0; k < V; k++) if (q[k] == m) idx[k] = count;
-          if (leader && count > 0) orBits(s_out, lutAt + (count - 1) * (u32)nb, m, nb);
-          last = m; count++;
-        }
-      }
-      if (mine)
-      {
-        const u32 nLut = count - 1;
-        const int nbIdx = bitLen(nLut);
-        if (leader) orBits(s_out, hdr, (u32)nb | (2u << 6) | 32u | (64u << 8) | ((nLut + 1) << 16), 24);
-        const u32 idxAt = lutAt + 8u * ((nLut * (u32)nb + 7) >> 3);
-        u64 s = 0;
-#pragma unroll
-        for (int k = 0; k < V; k++) s |= (u64)idx[k] << (k * nbIdx);    // nbIdx <= 6
-        orBits64(s_out, idxAt + (u32)e0 * (u32)nbIdx, s, V * nbIdx);
-      }
-    }
-  }
-  PROBE(2);
-  TRACE(2);
-  // ---- the cells asked for above: nearly always all there
-  {
-    const bool need0 = i0 < wg, need1 = i1 < wg, needB = threadIdx.x == 0 && grp >= 2u;
-    const bool miss = (need0 && (u32)(c0 >> 32) != f.epoch) || (need1 && (u32)(c1 >> 32) != f.epoch) || (needB && (u32)(cb >> 32) != f.epoch);
-    u32 part = (need0 ? (u32)c0 : 0u) + (need1 ? (u32)c1 : 0u) + (needB ? (u32)cb : 0u);
-    part = waveSum(part);
-    if (lane == 0) atomicAdd(&s_base, part);
-    if (__any(miss) && lane == 0) s_retry = 1u;
-#if defined(LERC_PROBE) && !defined(HIPSIM) && !defined(LERC_PROBE_TRACE_ONLY)
-    {
-      // tuning counters: how many workgroups miss a size cell / the base cell at the first look, how far back the misses lie
-      const bool missB = needB && (u32)(cb >> 32) != f.epoch;
-      const bool miss0 = (need0 && (u32)(c0 >> 32) != f.epoch), miss1 = (need1 && (u32)(c1 >> 32) != f.epoch);
-      const u64 mB = __builtin_amdgcn_ballot_w64(missB), mS = __builtin_amdgcn_ballot_w64(miss0 || miss1);
-      if (lane == 0 && mB) atomicAdd(&g_probe[8], 1ull);
-      if (lane == 0 && mS) atomicAdd(&g_probe[9], (unsigned long long)__popcll(mS));
-      // distance of the farthest missing size cell
-      u32 far = 0;
-      if (miss0) far = wg - i0;
-      if (miss1) far = max(far, wg - i1);
-      far = waveMax(far);
-      if (lane == 0 && far) atomicAdd(&g_probe[10 + min(5u, (u32)(31 - __clz((int)far)) / 2u)], 1ull);    // buckets 1, 4, 16, 64, 256
-    }
-#endif
-  }
-  __syncthreads();
-#if LERC_FUSED_PATIENT
-  if (s_retry)
-  {
-    // Some workgroup in front of this one has not published its size yet (the eight XCDs do not start their blocks in step).
-    // Waiting must cost the others nothing: ONE lane polls the oldest missing cell, with pauses -- a whole workgroup asking
-    // again and again for a hundred cells, in two thousand resident workgroups, takes the memory system away from those
-    // that are waited for -- and when it has arrived everybody looks once more at what he is still missing.
-    __shared__ u32 s_oldest;
-    const bool need0 = i0 < wg, need1 = i1 < wg, needB = threadIdx.x == 0 && grp >= 2u;
-    bool lost = false;
-    for (u32 round = 0; ; round++)
-    {
-      __syncthreads();
-      if (threadIdx.x == 0) { s_oldest = 0xFFFFFFFFu; s_base = 0u; }
-      __syncthreads();
-      u32 mine = 0xFFFFFFFFu;
-      if (need1 && (u32)(c1 >> 32) != f.epoch) mine = i1;
-      if (need0 && (u32)(c0 >> 32) != f.epoch) mine = i0;
-      mine = waveMin(mine);
-      if (lane == 0 && mine != 0xFFFFFFFFu) atomicMin(&s_oldest, mine);
-      __syncthreads();
-      const u32 oldest = s_oldest;
-      const bool baseMissing = needB && (u32)(cb >> 32) != f.epoch;    // (thread 0 only)
-      if (threadIdx.x == 0 && (oldest != 0xFFFFFFFFu || baseMissing))
-      {
-        u64 cell = 0;
-        for (u32 spin = 0; ; spin++)
-        {
-          bool ok = true;
-          if (oldest != 0xFFFFFFFFu) { cell = observe64(f.sizeCell + oldest); ok = (u32)(cell >> 32) == f.epoch; }
-          if (needB && (u32)(cb >> 32) != f.epoch) { cb = observe64(f.baseCell + (grp - 1u)); ok = ok && (u32)(cb >> 32) == f.epoch; }
-          if (ok) break;
-          if (spin >= (1u << 20)) { lost = true; break; }
-#if defined(LERC_PROBE) && !defined(HIPSIM) && !defined(LERC_PROBE_TRACE_ONLY)
-          atomicAdd(&g_probe[16], 1ull);    // polls of the patient lane
-#endif
-          __builtin_amdgcn_s_sleep(16);
-        }
-        if (lost) { __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_oldest = 0xFFFFFFFEu; }
-      }
-      __syncthreads();
-      if (oldest == 0xFFFFFFFFu || s_oldest == 0xFFFFFFFEu) break;    // nothing was missing any more (or: given up)
-      if (need0 && (u32)(c0 >> 32) != f.epoch) c0 = observe64(f.sizeCell + i0);
-      if (need1 && (u32)(c1 >> 32) != f.epoch) c1 = observe64(f.sizeCell + i1);
-    }
-    u32 part = (need0 ? (u32)c0 : 0u) + (need1 ? (u32)c1 : 0u) + (needB ? (u32)cb : 0u);
-    part = waveSum(part);
-    if (lane == 0) atomicAdd(&s_base, part);
-    __syncthreads();
-  }
-#else
-  if (s_retry)
-  {
-    // (a workgroup in front of this one was slower than this one: ask again)
-    __syncthreads();
-    if (threadIdx.x == 0) s_base = 0u;
-    __syncthreads();
-    const bool need0 = i0 < wg, need1 = i1 < wg, needB = threadIdx.x == 0 && grp >= 2u;
-    bool lost = false;
-    for (u32 spin = 0; ; spin++)
-    {
-      if (need0 && (u32)(c0 >> 32) != f.epoch) c0 = observe64(f.sizeCell + i0);
-      if (need1 && (u32)(c1 >> 32) != f.epoch) c1 = observe64(f.sizeCell + i1);
-      if (needB && (u32)(cb >> 32) != f.epoch) cb = observe64(f.baseCell + (grp - 1u));
-      const bool miss = (need0 && (u32)(c0 >> 32) != f.epoch) || (need1 && (u32)(c1 >> 32) != f.epoch) || (needB && (u32)(cb >> 32) != f.epoch);
-      if (!miss) break;
-      if (spin >= (1u << 22)) { lost = true; break; }
-      __builtin_amdgcn_s_sleep(4);
-    }
-    u32 part = (need0 ? (u32)c0 : 0u) + (need1 ? (u32)c1 : 0u) + (needB ? (u32)cb : 0u);
-    part = waveSum(part);
-    if (lane == 0) atomicAdd(&s_base, part);
-    if (__any(lost) && lane == 0) __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-  }
-#endif
-  PROBE(3);
-  TRACE(3);
-  const u32 prefixLen = 90u + 4u + 2u * (u32)sizeof(T) + 1u;    // header, mask byte count, ranges, "not one sweep" (fastDecide)
-  const u32 spanBase = s_base, spanLen = s_spanLen;
-  const u32 g0 = prefixLen + spanBase;                      // absolute offset of this workgroup's span
   const bool fits = (u64)g0 + spanLen <= outCapacity;       // (the last workgroup reports what does not fit)
   const u32 ldsShift = g0 & 15u;
   const u32 gAligned = g0 & ~15u;
   const u32 nUnits = (ldsShift + spanLen + 15) >> 4;
+  for (u32 u = threadIdx.x; u < nUnits; u += 256)
   {
-    // Fletcher sums and flush in one go, in 16-byte units of the BLOB: unit u holds the image bytes from 16 u - (g0 & 15) on,
-    // fetched as five words and funnel shifted; what lies outside the span is zero in LDS, adds nothing to the sums and
-    // is not stored
-    u32 A = 0;
-    u64 B = 0;
-    for (u32 u = threadIdx.x; u < nUnits; u += 256)
+    const u32 at = kLead + 16u * u - ldsShift;              // LDS byte of the unit's first byte (>= 1)
+    const u32 wd0 = at >> 2, sh = 8u * (at & 3u);
+    const u32 x0 = s_out[wd0], x1 = s_out[wd0 + 1], x2 = s_out[wd0 + 2], x3 = s_out[wd0 + 3], x4 = s_out[wd0 + 4];
+    uint4 x;
+    x.x = __builtin_amdgcn_alignbit(x1, x0, sh); x.y = __builtin_amdgcn_alignbit(x2, x1, sh);
+    x.z = __builtin_amdgcn_alignbit(x3, x2, sh); x.w = __builtin_amdgcn_alignbit(x4, x3, sh);
+    // (gAligned + 16 u >= 16 > 14 always holds here because spans start behind the >= 95-byte prefix)
+    fletcherUnit(x, (u64)((gAligned + 16u * u - 14u) >> 1), A, B);
+    if (!fits) continue;
+    const u32 lo = 16u * u, first = lo < ldsShift ? ldsShift : lo, last = min(lo + 16u, ldsShift + spanLen);    // owned bytes of the unit
+    if (first == lo && last == lo + 16u) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;    // (k_fast_discover reads them next: no streaming hint)
+    else
     {
-      const u32 at = kLead + 16u * u - ldsShift;            // LDS byte of the unit's first byte (>= 1)
-      const u32 wd0 = at >> 2, sh = 8u * (at & 3u);
-      const u32 x0 = s_out[wd0], x1 = s_out[wd0 + 1], x2 = s_out[wd0 + 2], x3 = s_out[wd0 + 3], x4 = s_out[wd0 + 4];
-      uint4 x;
-      x.x = __builtin_amdgcn_alignbit(x1, x0, sh); x.y = __builtin_amdgcn_alignbit(x2, x1, sh);
-      x.z = __builtin_amdgcn_alignbit(x3, x2, sh); x.w = __builtin_amdgcn_alignbit(x4, x3, sh);
-      fletcherUnit(x, (u64)((gAligned + 16u * u - 14u) >> 1), A, B);
-      if (!fits) continue;
-      const u32 lo = 16u * u, first = lo < ldsShift ? ldsShift : lo, last = min(lo + 16u, ldsShift + spanLen);    // owned bytes of the unit
-      if (first == lo && last == lo + 16u) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;    // (k_fast_discover reads them next: no streaming hint)
-      else
-      {
-        const u32 xs[4] = { x.x, x.y, x.z, x.w };
+      const u32 xs[4] = { x.x, x.y, x.z, x.w };
 #pragma unroll
-        for (u32 i = 0; i < 16; i++)
-          if (lo + i >= first && lo + i < last) out[gAligned + lo + i] = (u8)(xs[i >> 2] >> (8 * (i & 3)));
-      }
+      for (u32 i = 0; i < 16; i++)
+        if (lo + i >= first && lo + i < last) out[gAligned + lo + i] = (u8)(xs[i >> 2] >> (8 * (i & 3)));
     }
-    const u64 a = waveSum(A), b2 = waveSum(B);
-    if (lane == 0) { s_fa[w] = a; s_fb[w] = b2; }
   }
+}
+
+// (2) the arrival: checksum terms (A bits 0-23, B bits 24-47), one arrival (bits 48-52), the two flags as counts (bits 53-57
+// NaN seen, bits 58-62 a non-integer value seen) in ONE atomic nobody waits for; by the thread that sent the range
+// atomics, behind a wait for those (the deciding workgroup reads the key cells once the arrivals are complete)
+__device__ __forceinline__ void
+fusedArrive(u32 A, u64 B, u64* s_fa, u64* s_fb, const u32* s_fl, u32 wg, int wPlan, const FastFused& f)
+{
+  const int w = waveId(), lane = laneId();
+  const u64 a = waveSum((u64)A), b2 = waveSum(B);
+  if (lane == 0) { s_fa[w] = a; s_fb[w] = b2; }
   __syncthreads();
-  // ---- arrival: checksum terms (A bits 0-23, B bits 24-47), one arrival (bits 48-52), the two flags as counts (bits 53-57
-  // NaN seen, bits 58-62 a non-integer value seen) in ONE atomic nobody waits for; by the thread that sent the range
-  // atomics, behind a wait for those (the deciding workgroup reads the key cells once the arrivals are complete)
   if (w == wPlan && lane == 0)
   {
-    const u64 a = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u, b2 = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
+    const u64 a4 = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u, b4 = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
     const u32 fl = s_fl[0] | s_fl[1] | s_fl[2] | s_fl[3];
     drainVmem();
-    __hip_atomic_fetch_add(f.packPart + wg / kFastPackGroup, a | (b2 << 24) | (1ull << 48) | ((u64)(fl & 1u) << 53) | ((u64)((fl >> 1) & 1u) << 58),
+    __hip_atomic_fetch_add(f.packPart + wg / kFastPackGroup, a4 | (b4 << 24) | (1ull << 48) | ((u64)(fl & 1u) << 53) | ((u64)((fl >> 1) & 1u) << 58),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  PROBE(4);
-  TRACE(4);
-  if (wg != nWG - 1u) return;
+}
 
-  // ---- the last workgroup: wait for everybody (aggregator 0 included), fold, decide, header + checksum
+// (3) the workgroup with the highest index: wait for everybody (aggregator 0 included), fold, decide, header + checksum
+template<class T>
+__device__ __forceinline__ void
+fusedFinish(u32 nBytesTiling, u32 prefixLen, u8* __restrict__ out, u64 outCapacity, u32 nWG, u32 nPackGroups, const BandParams& p, const FastFused& f,
+            FastEncodeResult* __restrict__ res, double requestedMaxZErr, u32 raiseCandidates, u32 nBlobsMore)
+{
+  const int w = waveId(), lane = laneId();
   __shared__ u32 s_redo, s_cs;
   __shared__ u64 s_kmax[4], s_kmin[4], s_A[4], s_B[4], s_raise[9];
   __shared__ u32 s_flg[4];
   __shared__ __align__(16) u8 s_prefix[kFastPrefixStage];
-  const u32 nBytesTiling = spanBase + spanLen;
   {
     u64 fA = 0, fB = 0, kMaxAll = 0, kMinInv = 0;
     u32 flg = 0;
@@ -1709,6 +1363,349 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   if (threadIdx.x == 0) res->checksum = cs;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_fast_encode1: the one-launch encoder with U consecutive units (64 blocks each) per workgroup.  All U units' pixels are
+// asked for at the start; statistics and plans of all of them come first, so the workgroup's size (ONE cell: its units are
+// consecutive in the stream, their spans lie back to back) is published long before the first span leaves, and the
+// second unit's pixels arrive while the first unit is being packed: the time line of k_fast_encode1 showed a workgroup
+// living 10.9 us of which 5.0 went by before its size was out (mostly waiting for its pixels) and 2.8 waiting for the
+// cells of the workgroups in front of it, which publish when it does.  Units go through ONE span image, one after the other.
+// ------------------------------------------------------------------------------------------------
+template<class T, bool WIDE, int U>
+__global__ void __launch_bounds__(256) LERC_SGPR_CAP
+k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, FastEncodeResult* __restrict__ res, u32 nWG, u32 nBlobsMore,
+                FastFused f, double requestedMaxZErr, u32 raiseCandidates, u64 outCapacity)
+{
+  typedef FastCfg<T> C;
+  constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW, IT = C::IT;
+  constexpr int LB = 8 * LPR;                // lanes of a block: lane = b * LB + r * LPR + h (block of the wave tile, row, lane of the row)
+  constexpr int DT = DtOf<T>::v;
+  typedef typename ShflT<T>::type ST;
+  static_assert(U >= 1 && U <= 4, "a plan wave per unit");
+  constexpr int kMaxBlockBytes = 1 + 64 * (int)sizeof(T);
+  constexpr u32 kLead = 16;                  // zero bytes in front of the span image (the flush reads up to 15 bytes before it)
+  constexpr int kSpanWords = (kFastBlocksPerWG * kMaxBlockBytes + 16) / 4 + 8 + (int)kLead / 4;
+  __shared__ __align__(16) u32 s_out[kSpanWords];
+  __shared__ T s_mnT[U][kFastBlocksPerWG], s_mxT[U][kFastBlocksPerWG];
+  __shared__ u32 s_same[U][kFastBlocksPerWG], s_nd[U][kFastBlocksPerWG];
+  __shared__ u32 s_w1[U][kFastBlocksPerWG];
+  __shared__ u32 s_bit[U][kFastBlocksPerWG]; // bit position of each block inside s_out
+  __shared__ u32 s_fl[4];
+  __shared__ u64 s_fa[4], s_fb[4], s_kmx[U], s_kmn[U];
+  __shared__ u32 s_len[U], s_base, s_retry;
+
+  const u32 nGroups = (nWG + kFusedGroup - 1u) / kFusedGroup, nPackGroups = fastPackGroups(nWG);
+  const u32 grp = blockIdx.x / (kFusedGroup + 1u), inGrp = blockIdx.x - grp * (kFusedGroup + 1u);
+  if (inGrp == 0u) { fusedAggregate<T>(grp, nGroups, data, p, raiseCandidates, f, nPackGroups, res); return; }
+  const u32 wg = grp * kFusedGroup + inGrp - 1u;    // (the grid has exactly nWG + nGroups blocks)
+  TRACE(0); TRACE_ID();
+  const int w = waveId(), lane = laneId();
+  const int b = lane / LB, r = (lane % LB) / LPR, h = lane % LPR, c = b * LPR + h;
+  const bool leader = (lane % LB == 0);
+  const u32 nUnits = fastNumWG(p.nRows, p.nCols);    // units of the raster (the last workgroup may hold fewer than U)
+  FastSpan span[U];
+#pragma unroll
+  for (int a = 0; a < U; a++) span[a] = fastSpanOf(min(wg * (u32)U + (u32)a, nUnits - 1u), (u32)p.nTH, (u32)p.nTV);
+
+  // ---- the pixels of all units: every load of the wave in flight first (non-temporal: nothing reads them again), the span
+  // image is zeroed while they travel
+  T v[U][IT][V];
+#pragma unroll
+  for (int a = 0; a < U; a++)
+#pragma unroll
+    for (int t = 0; t < IT; t++) loadLane<T, V>(data + laneOrigin<WIDE, BPW, V>(span[a], t * 4 + w, r, c, p.nCols), v[a][t], true);
+  for (u32 i = threadIdx.x; i < (u32)kSpanWords / 4u; i += 256u) reinterpret_cast<uint4*>(s_out)[i] = make_uint4(0, 0, 0, 0);
+  if (threadIdx.x == 0) { s_base = 0u; s_retry = 0u; }
+
+  // ---- statistics per block (Lerc2::GetValidDataAndStats for an all-valid block + the tryLut count, Lerc2.cpp:1717-1799)
+  u32 flags = 0;
+#pragma unroll
+  for (int a = 0; a < U; a++)
+  {
+#pragma unroll
+    for (int t = 0; t < IT; t++)
+    {
+      const int tile = t * 4 + w;
+      const T (&x)[V] = v[a][t];
+      if (DT >= DT_Float)
+      {
+#pragma unroll
+        for (int k = 0; k < V; k++) if (isNaNv(x[k])) flags |= 1u;
+        if (!(flags & 2u))    // one fractional value settles "not all integers" for good
+        {
+#pragma unroll
+          for (int k = 0; k < V; k++) if (notIntegral(x[k])) flags |= 2u;
+        }
+      }
+      T mn = x[0], mx = x[0];
+#pragma unroll
+      for (int k = 1; k < V; k++) { mn = OpMin()(mn, x[k]); mx = OpMax()(mx, x[k]); }
+      if constexpr (std::is_same<T, float>::value) rowMinMax(mn, mx);    // (LB == 16)
+      else
+      {
+        mn = (T)groupReduce<LB>((ST)mn, OpMin());
+        mx = (T)groupReduce<LB>((ST)mx, OpMax());
+      }
+      T prev = (T)dppMovT<kDppWaveShr1>((ST)x[V - 1]);
+      if (leader) prev = T(0);
+      int same = (x[0] == prev) ? 1 : 0;
+#pragma unroll
+      for (int k = 1; k < V; k++) same += (x[k] == x[k - 1]) ? 1 : 0;
+      u32 nd = 0;
+      if (__any(same > 32 / LB))
+      {
+        same = groupReduce<LB>(same, OpSum());
+        const bool tryLut = (2 * same > 64) && ((double)mx > (double)mn + 3 * p.maxZErr);
+        if (__any(tryLut))
+        {
+          const double mv = ((double)mx - (double)mn) * p.scale;
+          const bool need = tryLut && !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
+          u32 q[V];
+          quantizeLane<T, V>(p.intLossless, p.scale, x, mn, q);
+          nd = groupDistinct<LB, V>(q, need);
+        }
+      }
+      else same = 0;
+      if (leader)
+      {
+        const int blk = tile * BPW + b;
+        s_mnT[a][blk] = mn; s_mxT[a][blk] = mx; s_same[a][blk] = (u32)same; s_nd[a][blk] = nd;
+      }
+    }
+  }
+  const bool f1 = __any(flags & 1u), f2 = __any(flags & 2u);
+  if (lane == 0) s_fl[w] = (f1 ? 1u : 0u) | (f2 ? 2u : 0u);
+  __syncthreads();
+  TRACE(5);
+
+  // ---- lane = block, a wave per unit (they rotate over the SIMDs from workgroup to workgroup): the per-block decisions of
+  // Lerc2::NumBytesTile once per block and where each block starts in its unit's span
+  const int wPlan = (int)((wg * 2654435761u) >> 30);
+  const int myUnit = (w - wPlan) & 3;        // the unit this wave plans (and writes the block headers of), if < U
+#pragma unroll
+  for (int a = 0; a < U; a++)    // (unrolled: a unit's span stays in registers)
+  {
+    if (myUnit != a) continue;
+    const bool haveUnit = wg * (u32)U + (u32)a < nUnits;
+    const T mn = s_mnT[a][lane], mx = s_mxT[a][lane];
+    const int same = (int)s_same[a][lane];
+    const bool tryLut = (2 * same > 64) && ((double)mx > (double)mn + 3 * p.maxZErr);
+    double mv = 0;
+    bool quantOk = false;
+    if (p.maxZErr > 0)
+    {
+      mv = ((double)mx - (double)mn) * p.scale;
+      quantOk = !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
+    }
+    const u32 qMax = quantOk ? (u32)(mv + 0.5) : 0u;    // == largest quantised element (same expression as Quantize)
+    Plan pl = planBlock<T>(p, 64, mn, mx, DT, tryLut, mv, qMax, s_nd[a][lane]);    // (the data type as a constant: the other types' branches fold away)
+    if (!haveUnit || !fastSpanHas(span[a], (u32)lane)) { pl.nBytes = 0; pl.kind = 7; }    // behind the raster's last block: nothing to write
+    const int nb = bitLen(qMax);
+    const u32 sz = (u32)pl.nBytes;
+    u32 inc = sz;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(inc, (unsigned)dd); if (lane >= dd) inc += o; }
+    s_w1[a][lane] = packDesc(pl, nb); s_bit[a][lane] = 8u * (kLead + inc - sz);
+    const u32 total = (u32)__shfl((int)inc, 63);
+    // (blocks behind the raster's end repeat the last block's range: they change nothing)
+    const u64 kMin = waveMin(FKey<T>::enc(mn)), kMax = waveMax(FKey<T>::enc(mx));
+    if (lane == 0) { s_len[a] = total; s_kmx[a] = kMax; s_kmn[a] = kMin; }
+  }
+  __syncthreads();
+  u32 len[U], lenAll = 0;
+#pragma unroll
+  for (int a = 0; a < U; a++) { len[a] = s_len[a]; lenAll += len[a]; }
+  if (threadIdx.x == 0)
+  {
+    publish64(f.sizeCell + wg, ((u64)f.epoch << 32) | (u64)lenAll);
+    u64 kMax = s_kmx[0], kMin = s_kmn[0];
+#pragma unroll
+    for (int a = 1; a < U; a++) { kMax = s_kmx[a] > kMax ? s_kmx[a] : kMax; kMin = s_kmn[a] < kMin ? s_kmn[a] : kMin; }
+    // the band's range: fire and forget, both as maxima (the cells are zero between calls)
+    __hip_atomic_fetch_max(f.keyPart + 2 * (size_t)(wg / kFastPackGroup), kMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_max(f.keyPart + 2 * (size_t)(wg / kFastPackGroup) + 1, ~kMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  TRACE(1);
+  if (!out) return;    // (never: size queries take the two-launch form's first steps)
+
+  // ---- where the spans go: the cells of the workgroups from the start of the group in front of this one's up to this
+  // one (two per thread), and what lies in front of those.  Asked for now, looked at when the first unit is packed.
+  const u32 winBegin = (grp ? grp - 1u : 0u) * kFusedGroup;
+  const u32 i0 = winBegin + threadIdx.x, i1 = i0 + 256u;
+  static_assert(2u * kFusedGroup <= 512u, "two cells per thread cover the window");
+  u64 c0 = 0, c1 = 0, cb = 0;
+  if (i0 < wg) c0 = observe64(f.sizeCell + i0);
+  if (i1 < wg) c1 = observe64(f.sizeCell + i1);
+  if (threadIdx.x == 0 && grp >= 2u) cb = observe64(f.baseCell + (grp - 1u));
+
+  const u32 prefixLen = 90u + 4u + 2u * (u32)sizeof(T) + 1u;    // header, mask byte count, ranges, "not one sweep" (fastDecide)
+  u32 fA = 0, spanBase = 0, before = 0;
+  u64 fB = 0;
+#pragma unroll
+  for (int a = 0; a < U; a++)
+  {
+    if (a > 0)
+    {
+      // the image again, for the next unit (everybody is done reading the last one)
+      __syncthreads();
+      for (u32 i = threadIdx.x; i < min((u32)kSpanWords / 4u, (kLead + len[a] + 48u) / 16u + 1u); i += 256u) reinterpret_cast<uint4*>(s_out)[i] = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+    }
+    // ---- block headers: lane = block, the wave that planned the unit (Lerc2::WriteTile, BitStuffer2 stream header)
+    if (myUnit == a)
+    {
+      const u32 w1 = s_w1[a][lane];
+      const int kind = (int)((w1 >> 16) & 7u), tc = (int)((w1 >> 19) & 3u), dtRed = (int)((w1 >> 21) & 7u), nb = (int)(w1 >> 24);
+      const int j0 = (int)fastSpanCol(span[a], (u32)lane) * 8;
+      u32 flag = (u32)(((j0 >> 3) & 15) << 2) & 0x38u;    // version 6, no slice difference
+      const u32 at0 = s_bit[a][lane];
+      if (kind == 7) { }
+      else if (kind == 0) orBits(s_out, at0, flag | 2u, 8);
+      else if (kind == 1) orBits(s_out, at0, flag, 8);
+      else
+      {
+        flag |= (kind == 2) ? 3u : 1u;
+        flag |= (u32)tc << 6;
+        const int offBytes = dtSize3((u32)dtRed);
+        orBits(s_out, at0, flag, 8);
+        orBits64(s_out, at0 + 8, typedBits((double)s_mnT[a][lane], dtRed), 8 * offBytes);
+        if (kind == 3) orBits(s_out, at0 + 8u * (1u + (u32)offBytes), (u32)nb | (2u << 6) | (64u << 8), 16);    // numBits byte, count 64
+      }
+    }
+    // ---- payloads
+#pragma unroll
+    for (int t = 0; t < IT; t++)
+    {
+      const int tile = t * 4 + w;
+      const int blk = tile * BPW + b;
+      const u32 w1 = s_w1[a][blk];
+      const int kind = (int)((w1 >> 16) & 7u);
+      const u32 at0 = s_bit[a][blk];
+      const int e0 = r * 8 + h * V;
+      if (kind == 3)
+      {
+        const int nb = (int)(w1 >> 24);
+        const int offBytes = dtSize3((w1 >> 21) & 7u);
+        const T mn = s_mnT[a][blk];
+        u32 q[V];
+        quantizeLane<T, V>(p.intLossless, p.scale, v[a][t], mn, q);
+        const u32 at = at0 + 8u * (3u + (u32)offBytes);
+        if (V * nb <= 64)
+        {
+          u64 s = 0;
+#pragma unroll
+          for (int k = 0; k < V; k++) s |= (u64)q[k] << (k * nb);
+          orBits64(s_out, at + (u32)e0 * (u32)nb, s, V * nb);
+        }
+        else
+        {
+#pragma unroll
+          for (int k = 0; k < V; k += 2)
+            orBits64(s_out, at + (u32)(e0 + k) * (u32)nb, (u64)q[k] | ((u64)q[k + 1] << nb), 2 * nb);
+        }
+      }
+      else if (kind == 1)
+      {
+#pragma unroll
+        for (int k = 0; k < V; k++)
+          orBits64(s_out, at0 + 8u + (u32)(e0 + k) * 8u * (u32)sizeof(T), rawBits<T>(v[a][t][k]), 8 * (int)sizeof(T));
+      }
+      // LUT blocks (kind 4): all blocks of the wave take part in the group reductions
+      if (__any(kind == 4))
+      {
+        const bool mine = (kind == 4);
+        const T mn = s_mnT[a][blk];
+        u32 q[V], idx[V];
+        quantizeLane<T, V>(p.intLossless, p.scale, v[a][t], mn, q);
+#pragma unroll
+        for (int k = 0; k < V; k++) idx[k] = 0;
+        const int nb = (int)(w1 >> 24);
+        const int offBytes = dtSize3((w1 >> 21) & 7u);
+        const u32 hdr = at0 + 8u * (1u + (u32)offBytes);
+        const u32 lutAt = hdr + 24;    // numBits byte, count byte, nLut + 1 byte
+        u32 count = 0, last = 0;
+        bool active = mine;
+        for (;;)
+        {
+          u32 m = 0xFFFFFFFFu;
+#pragma unroll
+          for (int k = 0; k < V; k++)
+            if ((count == 0 || q[k] > last) && q[k] < m) m = q[k];
+          m = groupReduce<LB>(m, OpMin());
+          if (m == 0xFFFFFFFFu) active = false;
+          if (!__any(active)) break;
+          if (active)
+          {
+#pragma unroll
+            for (int k = 0; k < V; k++) if (q[k] == m) idx[k] = count;
+            if (leader && count > 0) orBits(s_out, lutAt + (count - 1) * (u32)nb, m, nb);
+            last = m; count++;
+          }
+        }
+        if (mine)
+        {
+          const u32 nLut = count - 1;
+          const int nbIdx = bitLen(nLut);
+          if (leader) orBits(s_out, hdr, (u32)nb | (2u << 6) | 32u | (64u << 8) | ((nLut + 1) << 16), 24);
+          const u32 idxAt = lutAt + 8u * ((nLut * (u32)nb + 7) >> 3);
+          u64 s = 0;
+#pragma unroll
+          for (int k = 0; k < V; k++) s |= (u64)idx[k] << (k * nbIdx);    // nbIdx <= 6
+          orBits64(s_out, idxAt + (u32)e0 * (u32)nbIdx, s, V * nbIdx);
+        }
+      }
+    }
+    if (a == 0)
+    {
+      TRACE(2);
+      // ---- the cells asked for above: nearly always all there
+      {
+        const bool need0 = i0 < wg, need1 = i1 < wg, needB = threadIdx.x == 0 && grp >= 2u;
+        const bool miss = (need0 && (u32)(c0 >> 32) != f.epoch) || (need1 && (u32)(c1 >> 32) != f.epoch) || (needB && (u32)(cb >> 32) != f.epoch);
+        u32 part = (need0 ? (u32)c0 : 0u) + (need1 ? (u32)c1 : 0u) + (needB ? (u32)cb : 0u);
+        part = waveSum(part);
+        if (lane == 0) atomicAdd(&s_base, part);
+        if (__any(miss) && lane == 0) s_retry = 1u;
+      }
+      __syncthreads();
+      if (s_retry)
+      {
+        // (a workgroup in front of this one was slower than this one: ask again)
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = 0u;
+        __syncthreads();
+        const bool need0 = i0 < wg, need1 = i1 < wg, needB = threadIdx.x == 0 && grp >= 2u;
+        bool lost = false;
+        for (u32 spin = 0; ; spin++)
+        {
+          if (need0 && (u32)(c0 >> 32) != f.epoch) c0 = observe64(f.sizeCell + i0);
+          if (need1 && (u32)(c1 >> 32) != f.epoch) c1 = observe64(f.sizeCell + i1);
+          if (needB && (u32)(cb >> 32) != f.epoch) cb = observe64(f.baseCell + (grp - 1u));
+          const bool miss = (need0 && (u32)(c0 >> 32) != f.epoch) || (need1 && (u32)(c1 >> 32) != f.epoch) || (needB && (u32)(cb >> 32) != f.epoch);
+          if (!miss) break;
+          if (spin >= (1u << 22)) { lost = true; break; }
+          __builtin_amdgcn_s_sleep(4);
+        }
+        u32 part = (need0 ? (u32)c0 : 0u) + (need1 ? (u32)c1 : 0u) + (needB ? (u32)cb : 0u);
+        part = waveSum(part);
+        if (lane == 0) atomicAdd(&s_base, part);
+        if (__any(lost) && lane == 0) __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+      }
+      TRACE(3);
+      spanBase = s_base;
+    }
+    else __syncthreads();    // (the image is complete)
+    fusedFlush(s_out, kLead, prefixLen + spanBase + before, len[a], out, outCapacity, fA, fB);
+    before += len[a];
+  }
+  fusedArrive(fA, fB, s_fa, s_fb, s_fl, wg, wPlan, f);
+  TRACE(4);
+  if (wg != nWG - 1u) return;
+  fusedFinish<T>(spanBase + lenAll, prefixLen, out, outCapacity, nWG, nPackGroups, p, f, res, requestedMaxZErr, raiseCandidates, nBlobsMore);
+}
+
 // Batches: where each tile's blob goes in the arena.  One workgroup of 1024 threads; a tile that the general path has
 // to redo takes no room here (the host appends it behind the batch).  Starts are 16-byte aligned.
 __global__ void __launch_bounds__(1024)
@@ -1761,11 +1758,12 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
   if (b.fused.sizeCell && out)    // one raster, one launch
   {
     if (stage != 0) return;
-    const dim3 grid(nWG + fastFusedGroups(nWG));
+    const u32 nW = b.fused.nWG;
+    const dim3 grid(nW + fastFusedGroups(nW));
     if (wide)
-      hipLaunchKernelGGL((k_fast_encode1<T, true>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nWG, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
+      hipLaunchKernelGGL((k_fast_encode1<T, true, kFusedUnits>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
     else
-      hipLaunchKernelGGL((k_fast_encode1<T, false>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nWG, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
+      hipLaunchKernelGGL((k_fast_encode1<T, false, kFusedUnits>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
     return;
   }
   if (stage == 0)

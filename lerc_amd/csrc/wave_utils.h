@@ -160,7 +160,14 @@ template<int DIST, class X, class Op> __device__ __forceinline__ X combineXor(X 
 // all-reduce over groups of G consecutive lanes (G = 8, 16, 32 or 64), result in every lane of the group
 template<int G, class X, class Op> __device__ __forceinline__ X groupReduce(X v, Op op)
 {
-  static_assert(G == 8 || G == 16 || G == 32 || G == 64, "group size");
+  static_assert(G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "group size");
+  if (G == 2) return op(v, dppMovT<kDppQuadXor1>(v));
+  if (G == 4)
+  {
+    v = op(v, dppMovT<kDppQuadXor1>(v));
+    v = op(v, dppMovT<kDppQuadXor2>(v));
+    return v;
+  }
   if (G == 8)
   {
     v = op(v, dppMovT<kDppQuadXor1>(v));

@@ -21,7 +21,7 @@ for _ in range(3):
     rc, n = api.encode_device(codec, x, 0.01, blob)
     assert rc == 0
 torch.cuda.synchronize()
-nwg = 16384
+nwg = int(os.environ.get('NWG', '8192'))
 buf = (ct.c_ulonglong * (8 * nwg))()
 lib.lerc_amd_probe_trace(buf, 8 * nwg)
 t = np.frombuffer(buf, dtype=np.uint64).reshape(nwg, 8).astype(np.int64)
@@ -33,10 +33,14 @@ cu = (hw >> 8) & 0xF
 se = (hw >> 13) & 0x7
 print("kernel span %.1f us" % us[:, 4].max())
 print("phase durations (us): mean / p50 / p90")
-names = ["start->size published", "payload", "wait for the base", "flush"]
+names = ["start->size published", "first payload", "wait for the base", "flush (+ other units)"]
 for k in range(4):
     d = us[:, k + 1] - us[:, k]
     print("  %-24s %6.2f %6.2f %6.2f" % (names[k], d.mean(), np.median(d), np.percentile(d, 90)))
+t5 = (t[:, 5] - t0) / 100.0
+if t[:, 5].max() > 0:
+    d = t5 - us[:, 0]
+    print("  %-24s %6.2f %6.2f %6.2f" % ("start->statistics done", d.mean(), np.median(d), np.percentile(d, 90)))
 print("life %.2f us mean" % (us[:, 4] - us[:, 0]).mean())
 print("xcc of blocks 0..23:", xcc[:24].tolist())
 # is the start order the index order?
