@@ -1242,6 +1242,7 @@ fusedFlush(const u32* s_out, u32 kLead, u32 g0, u32 spanLen, u8* __restrict__ ou
   const u32 ldsShift = g0 & 15u;
   const u32 gAligned = g0 & ~15u;
   const u32 nUnits = (ldsShift + spanLen + 15) >> 4;
+  const u32 spanEnd = ldsShift + spanLen;                   // (relative to gAligned)
   for (u32 u = threadIdx.x; u < nUnits; u += 256)
   {
     const u32 at = kLead + 16u * u - ldsShift;              // LDS byte of the unit's first byte (>= 1)
@@ -1252,15 +1253,20 @@ fusedFlush(const u32* s_out, u32 kLead, u32 g0, u32 spanLen, u8* __restrict__ ou
     x.z = __builtin_amdgcn_alignbit(x3, x2, sh); x.w = __builtin_amdgcn_alignbit(x4, x3, sh);
     // (gAligned + 16 u >= 16 > 14 always holds here because spans start behind the >= 95-byte prefix)
     fletcherUnit(x, (u64)((gAligned + 16u * u - 14u) >> 1), A, B);
-    if (!fits) continue;
-    const u32 lo = 16u * u, first = lo < ldsShift ? ldsShift : lo, last = min(lo + 16u, ldsShift + spanLen);    // owned bytes of the unit
-    if (first == lo && last == lo + 16u) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;    // (k_fast_discover reads them next: no streaming hint)
-    else
+    const u32 lo = 16u * u;
+    if (fits && lo >= ldsShift && lo + 16u <= spanEnd) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;    // (k_fast_discover reads them next: no streaming hint)
+  }
+  // the span's two ragged ends (units shared with the neighbouring spans), byte by byte: two lanes of one wave, outside the
+  // loop -- inside it every wave that holds such a unit paid for sixteen predicated byte stores
+  if (threadIdx.x < 2u && fits && nUnits != 0u)
+  {
+    const u32 u = threadIdx.x ? nUnits - 1u : 0u;
+    const u32 lo = 16u * u, first = lo < ldsShift ? ldsShift : lo, last = min(lo + 16u, spanEnd);    // owned bytes of the unit
+    const bool partial = !(first == lo && last == lo + 16u) && !(threadIdx.x == 1u && nUnits == 1u);    // (one unit in all: lane 0 takes it)
+    if (partial)
     {
-      const u32 xs[4] = { x.x, x.y, x.z, x.w };
-#pragma unroll
-      for (u32 i = 0; i < 16; i++)
-        if (lo + i >= first && lo + i < last) out[gAligned + lo + i] = (u8)(xs[i >> 2] >> (8 * (i & 3)));
+      const u8* img = reinterpret_cast<const u8*>(s_out) + kLead - ldsShift;    // image byte of blob byte gAligned
+      for (u32 i = first; i < last; i++) out[gAligned + i] = img[i];
     }
   }
 }
@@ -1540,12 +1546,18 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   if (threadIdx.x == 0 && grp >= 2u) cb = observe64(f.baseCell + (grp - 1u));
 
   const u32 prefixLen = 90u + 4u + 2u * (u32)sizeof(T) + 1u;    // header, mask byte count, ranges, "not one sweep" (fastDecide)
-  u32 fA = 0, spanBase = 0, before = 0;
+  // All units' spans lie back to back in the blob.  Where they fit the image together (it is sized for 64 raw blocks) they are
+  // packed one behind the other and leave in ONE piece: the cells asked for above then have the time of U payloads to
+  // arrive -- the workgroups in front publish their sizes when this one does, and a cell takes a microsecond or two to be
+  // seen -- and the flush runs once, over full rounds of lanes.  Else (mostly raw blocks) unit after unit through the image.
+  const bool together = U > 1 && kLead + lenAll + 64u <= (u32)kSpanWords * 4u;
+  u32 fA = 0, spanBase = 0, flushed = 0, bitBase = 0;
   u64 fB = 0;
+  bool resolved = false;
 #pragma unroll
   for (int a = 0; a < U; a++)
   {
-    if (a > 0)
+    if (a > 0 && !together)
     {
       // the image again, for the next unit (everybody is done reading the last one)
       __syncthreads();
@@ -1559,7 +1571,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       const int kind = (int)((w1 >> 16) & 7u), tc = (int)((w1 >> 19) & 3u), dtRed = (int)((w1 >> 21) & 7u), nb = (int)(w1 >> 24);
       const int j0 = (int)fastSpanCol(span[a], (u32)lane) * 8;
       u32 flag = (u32)(((j0 >> 3) & 15) << 2) & 0x38u;    // version 6, no slice difference
-      const u32 at0 = s_bit[a][lane];
+      const u32 at0 = s_bit[a][lane] + bitBase;
       if (kind == 7) { }
       else if (kind == 0) orBits(s_out, at0, flag | 2u, 8);
       else if (kind == 1) orBits(s_out, at0, flag, 8);
@@ -1581,7 +1593,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       const int blk = tile * BPW + b;
       const u32 w1 = s_w1[a][blk];
       const int kind = (int)((w1 >> 16) & 7u);
-      const u32 at0 = s_bit[a][blk];
+      const u32 at0 = s_bit[a][blk] + bitBase;
       const int e0 = r * 8 + h * V;
       if (kind == 3)
       {
@@ -1593,9 +1605,19 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         const u32 at = at0 + 8u * (3u + (u32)offBytes);
         if (V * nb <= 64)
         {
+          // (nb <= 16 here for V >= 4: pairs fit a 32-bit word, one 64-bit shift in all instead of one per value)
           u64 s = 0;
+          if (V == 4) s = (u64)(q[0] | (q[1] << nb)) | ((u64)(q[2] | (q[3] << nb)) << (2 * nb));
+          else if (V == 8)
+          {
+            const u32 p0 = q[0] | (q[1] << nb), p1 = q[2] | (q[3] << nb), p2 = q[4] | (q[5] << nb), p3 = q[6] | (q[7] << nb);    // nb <= 8
+            s = (u64)(p0 | (p1 << (2 * nb))) | ((u64)(p2 | (p3 << (2 * nb))) << (4 * nb));
+          }
+          else
+          {
 #pragma unroll
-          for (int k = 0; k < V; k++) s |= (u64)q[k] << (k * nb);
+            for (int k = 0; k < V; k++) s |= (u64)q[k] << (k * nb);
+          }
           orBits64(s_out, at + (u32)e0 * (u32)nb, s, V * nb);
         }
         else
@@ -1656,8 +1678,11 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         }
       }
     }
-    if (a == 0)
+    if (together) bitBase += 8u * len[a];
+    if (together && a < U - 1) continue;    // (more units go into this image)
+    if (!resolved)
     {
+      resolved = true;
       TRACE(2);
       // ---- the cells asked for above: nearly always all there
       {
@@ -1697,8 +1722,9 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       spanBase = s_base;
     }
     else __syncthreads();    // (the image is complete)
-    fusedFlush(s_out, kLead, prefixLen + spanBase + before, len[a], out, outCapacity, fA, fB);
-    before += len[a];
+    const u32 segLen = together ? lenAll : len[a];
+    fusedFlush(s_out, kLead, prefixLen + spanBase + flushed, segLen, out, outCapacity, fA, fB);
+    flushed += segLen;
   }
   fusedArrive(fA, fB, s_fa, s_fb, s_fl, wg, wPlan, f);
   TRACE(4);
