@@ -1541,9 +1541,6 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   const u32 i0 = winBegin + threadIdx.x, i1 = i0 + 256u;
   static_assert(2u * kFusedGroup <= 512u, "two cells per thread cover the window");
   u64 c0 = 0, c1 = 0, cb = 0;
-  if (i0 < wg) c0 = observe64(f.sizeCell + i0);
-  if (i1 < wg) c1 = observe64(f.sizeCell + i1);
-  if (threadIdx.x == 0 && grp >= 2u) cb = observe64(f.baseCell + (grp - 1u));
 
   const u32 prefixLen = 90u + 4u + 2u * (u32)sizeof(T) + 1u;    // header, mask byte count, ranges, "not one sweep" (fastDecide)
   // All units' spans lie back to back in the blob.  Where they fit the image together (it is sized for 64 raw blocks) they are
@@ -1551,6 +1548,15 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   // arrive -- the workgroups in front publish their sizes when this one does, and a cell takes a microsecond or two to be
   // seen -- and the flush runs once, over full rounds of lanes.  Else (mostly raw blocks) unit after unit through the image.
   const bool together = U > 1 && kLead + lenAll + 64u <= (u32)kSpanWords * 4u;
+  // (asked for now where a unit's flush comes right behind its payload; behind the first payload where all units are packed
+  // before anything leaves: the workgroups in front publish when this one does, and asking before their cells can be
+  // seen only means asking twice)
+  if (!together)
+  {
+    if (i0 < wg) c0 = observe64(f.sizeCell + i0);
+    if (i1 < wg) c1 = observe64(f.sizeCell + i1);
+    if (threadIdx.x == 0 && grp >= 2u) cb = observe64(f.baseCell + (grp - 1u));
+  }
   u32 fA = 0, spanBase = 0, flushed = 0, bitBase = 0;
   u64 fB = 0;
   bool resolved = false;
@@ -1679,6 +1685,12 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       }
     }
     if (together) bitBase += 8u * len[a];
+    if (together && a == 0)
+    {
+      if (i0 < wg) c0 = observe64(f.sizeCell + i0);
+      if (i1 < wg) c1 = observe64(f.sizeCell + i1);
+      if (threadIdx.x == 0 && grp >= 2u) cb = observe64(f.baseCell + (grp - 1u));
+    }
     if (together && a < U - 1) continue;    // (more units go into this image)
     if (!resolved)
     {
