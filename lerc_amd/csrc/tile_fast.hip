@@ -146,6 +146,24 @@ template<> struct FKey<unsigned int> { static __device__ u64 enc(unsigned int v)
 template<> struct FKey<short> { static __device__ u64 enc(short v) { return (u64)((i64)v + (1ll << 62)); } };
 template<> struct FKey<unsigned short> { static __device__ u64 enc(unsigned short v) { return (u64)v + (1ull << 62); } };
 
+// order-preserving 32-bit image of a value of a type of at most 32 bits (for wave reductions in one register)
+template<class T> struct FOrd
+{
+  static __device__ __forceinline__ u32 enc(T v)
+  {
+    if (std::is_same<T, float>::value) { u32 b; memcpy(&b, &v, 4); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+    if (std::is_signed<T>::value) return (u32)((i64)v + 0x80000000ll);
+    return (u32)v;
+  }
+  static __device__ __forceinline__ T dec(u32 k)
+  {
+    if (std::is_same<T, float>::value) { const u32 b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; T v; memcpy(&v, &b, 4); return v; }
+    if (std::is_signed<T>::value) return (T)((i64)k - 0x80000000ll);
+    return (T)k;
+  }
+};
+template<> struct FOrd<double> { static __device__ __forceinline__ u32 enc(double) { return 0u; } static __device__ __forceinline__ double dec(u32) { return 0; } };
+
 // Raster offset of the first pixel a lane owns in wave tile `tl` (0 .. 15) of its workgroup.  WIDE: the 64 blocks of
 // the workgroup lie in one block row (nTH % 64 == 0), the tiles are a constant stride apart and the compiler folds the
 // stride into the load / store instruction; otherwise the workgroup spans several block rows (fastSpanOf).
@@ -1378,8 +1396,10 @@ fusedFinish(u32 nBytesTiling, u32 prefixLen, u8* __restrict__ out, u64 outCapaci
 // living 10.9 us of which 5.0 went by before its size was out (mostly waiting for its pixels) and 2.8 waiting for the
 // cells of the workgroups in front of it, which publish when it does.  Units go through ONE span image, one after the other.
 // ------------------------------------------------------------------------------------------------
+// (32-bit types: eight workgroups per CU, i.e. at most 64 vector registers -- three values go to scratch and it is still
+// 4 us faster at 8192 x 8192 than seven workgroups per CU without)
 template<class T, bool WIDE, int U>
-__global__ void __launch_bounds__(256) LERC_SGPR_CAP
+__global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 8 : 1)) LERC_SGPR_CAP
 k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, FastEncodeResult* __restrict__ res, u32 nWG, u32 nBlobsMore,
                 FastFused f, double requestedMaxZErr, u32 raiseCandidates, u64 outCapacity)
 {
@@ -1515,7 +1535,12 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
     s_w1[a][lane] = packDesc(pl, nb); s_bit[a][lane] = 8u * (kLead + inc - sz);
     const u32 total = (u32)__shfl((int)inc, 63);
     // (blocks behind the raster's end repeat the last block's range: they change nothing)
-    const u64 kMin = waveMin(FKey<T>::enc(mn)), kMax = waveMax(FKey<T>::enc(mx));
+    u64 kMin, kMax;
+    if (sizeof(T) <= 4)    // (the keys of these types have 34 bits at most: reduce the value, order-preserving in 32 bits, encode once)
+    {
+      kMin = FKey<T>::enc(FOrd<T>::dec(waveMin(FOrd<T>::enc(mn)))); kMax = FKey<T>::enc(FOrd<T>::dec(waveMax(FOrd<T>::enc(mx))));
+    }
+    else { kMin = waveMin(FKey<T>::enc(mn)); kMax = waveMax(FKey<T>::enc(mx)); }
     if (lane == 0) { s_len[a] = total; s_kmx[a] = kMax; s_kmn[a] = kMin; }
   }
   __syncthreads();
