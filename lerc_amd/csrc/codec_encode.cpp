@@ -766,7 +766,7 @@ static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double
     // one raster: two launches, the pack step's first blocks scan and decide (tile_fast.h)
     memset(&fb, 0, sizeof(fb));
     const bool form = fastEncodeOneLaunch();
-    const u32 nWGf = form ? fastFusedNumWG(nRows, nCols) : nWG;    // (the one-launch form counts its own workgroups)
+    const u32 nWGf = form ? fastFusedNumWG(dt, nRows, nCols) : nWG;    // (the one-launch form counts its own workgroups)
     const size_t nGroups = std::max(fastPackGroups(nWG), fastPackGroups(nWGf)), nFused = fastFusedGroups(std::max(nWG, nWGf));
     // (counters: the pack accumulators, then the one-launch form's key cells; cells: a cell per workgroup, then the
     // one-launch form's group cells and first-row errors)

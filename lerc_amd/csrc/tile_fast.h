@@ -94,17 +94,16 @@ struct FastFused
   u64* packPart;       // [nPackGroups + 1] as k_fast_pack's: A | B << 24 | arrivals << 48 | NaN seen << 53 | non-integer seen << 58; [nPackGroups]: aggregator 0
   u64* keyPart;        // [2 * nPackGroups] largest key, largest complement of a key (zero between calls, like packPart)
   u32 epoch;
-  u32 nWG;             // workgroups of the launch (kFusedUnits units of 64 blocks each)
+  u32 nWG;             // workgroups of the launch (fastFusedUnits units of 64 blocks each)
 };
 LERC_HD u32 fastFusedGroups(u32 nWG) { return (nWG + kFusedGroup - 1u) / kFusedGroup; }
-#ifndef LERC_FUSED_U
-#define LERC_FUSED_U 2
-#endif
-static const int kFusedUnits = LERC_FUSED_U;    // consecutive units of 64 blocks a workgroup of k_fast_encode1 takes
-LERC_HD u32 fastFusedNumWG(int nRows, int nCols)
+// consecutive units of 64 blocks a workgroup of k_fast_encode1 takes: as many as usually fit its span image together (two units
+// of 32-bit pixels at a ratio of 2.5, three of 16-bit pixels at a ratio of 2), and 32 KB (24 KB) of pixels in flight per workgroup
+LERC_HD int fastFusedUnits(int dt) { return dtSize(dt) == 2 ? 3 : 2; }
+LERC_HD u32 fastFusedNumWG(int dt, int nRows, int nCols)
 {
-  const u64 nUnits = ((u64)(nRows / 8) * (u64)(nCols / 8) + 63u) / 64u;
-  return (u32)((nUnits + kFusedUnits - 1u) / kFusedUnits);
+  const u64 nUnits = ((u64)(nRows / 8) * (u64)(nCols / 8) + 63u) / 64u, per = (u64)fastFusedUnits(dt);
+  return (u32)((nUnits + per - 1u) / per);
 }
 
 struct FastEncodeBuffers

@@ -1399,7 +1399,7 @@ fusedFinish(u32 nBytesTiling, u32 prefixLen, u8* __restrict__ out, u64 outCapaci
 // (32-bit types: eight workgroups per CU, i.e. at most 64 vector registers -- three values go to scratch and it is still
 // 4 us faster at 8192 x 8192 than seven workgroups per CU without)
 template<class T, bool WIDE, int U>
-__global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 8 : 1)) LERC_SGPR_CAP
+__global__ void __launch_bounds__(256, (sizeof(T) <= 4 ? 8 : 1)) LERC_SGPR_CAP
 k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, FastEncodeResult* __restrict__ res, u32 nWG, u32 nBlobsMore,
                 FastFused f, double requestedMaxZErr, u32 raiseCandidates, u64 outCapacity)
 {
@@ -1411,7 +1411,9 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   static_assert(U >= 1 && U <= 4, "a plan wave per unit");
   constexpr int kMaxBlockBytes = 1 + 64 * (int)sizeof(T);
   constexpr u32 kLead = 16;                  // zero bytes in front of the span image (the flush reads up to 15 bytes before it)
-  constexpr int kSpanWords = (kFastBlocksPerWG * kMaxBlockBytes + 16) / 4 + 8 + (int)kLead / 4;
+  // (room for 64 raw blocks of the type -- or for what two units of 16-bit pixels usually come to: 16 KiB, the 32-bit types' size)
+  constexpr int kImgBytes = kFastBlocksPerWG * kMaxBlockBytes > 16448 ? kFastBlocksPerWG * kMaxBlockBytes : 16448;
+  constexpr int kSpanWords = (kImgBytes + 16) / 4 + 8 + (int)kLead / 4;
   __shared__ __align__(16) u32 s_out[kSpanWords];
   __shared__ T s_mnT[U][kFastBlocksPerWG], s_mxT[U][kFastBlocksPerWG];
   __shared__ u32 s_same[U][kFastBlocksPerWG], s_nd[U][kFastBlocksPerWG];
@@ -1824,9 +1826,9 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
     const u32 nW = b.fused.nWG;
     const dim3 grid(nW + fastFusedGroups(nW));
     if (wide)
-      hipLaunchKernelGGL((k_fast_encode1<T, true, kFusedUnits>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
+      hipLaunchKernelGGL((k_fast_encode1<T, true, (sizeof(T) == 2 ? 3 : 2)>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
     else
-      hipLaunchKernelGGL((k_fast_encode1<T, false, kFusedUnits>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
+      hipLaunchKernelGGL((k_fast_encode1<T, false, (sizeof(T) == 2 ? 3 : 2)>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
     return;
   }
   if (stage == 0)
