@@ -109,6 +109,8 @@ static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8
   fbuf.hostParams = hCell ? reinterpret_cast<FastDecodeParams*>(hCell + kCellParams) : nullptr;
   fbuf.hostFallback = hCell ? reinterpret_cast<u32*>(hCell + kCellFallback) : nullptr;
   fbuf.epoch = epoch;
+  fbuf.publishEpoch = (fastTestGiveUp() & 2u) ? epoch ^ 0x5A5A5A5Au : epoch;
+  fbuf.spinLimit = (fastTestGiveUp() & 2u) ? 8u : (1u << 22);
   if (!fbuf.recs || !fbuf.lists || !fbuf.chunkCell || !fbuf.waveFletcher)
     return false;
   static const char* kStage[kFastDecodeStages] = { "fast_discover", "fast_decode" };

@@ -846,6 +846,8 @@ static void runFastEncode(Context& ctx, const FastEncodeLaunch& fl, const void* 
     ProfScope ps(ctx, "fast_encode1");
     FastEncodeBuffers fb = fl.fb;
     fb.fused.epoch = ctx.nextEpoch();    // (never 0, the tag of a cell nobody has written yet)
+    fb.fused.publishEpoch = (fastTestGiveUp() & 1u) ? fb.fused.epoch ^ 0x5A5A5A5Au : fb.fused.epoch;
+    fb.fused.spinLimit = (fastTestGiveUp() & 1u) ? 8u : (1u << 22);
     launchFastEncode(0, fl.bp, fl.maxZErr, fl.cand, dData, dOut, capacity, arenaBase, fb, fl.batch, ctx.activeStream());
     return;
   }

@@ -94,6 +94,8 @@ struct FastFused
   u64* packPart;       // [nPackGroups + 1] as k_fast_pack's: A | B << 24 | arrivals << 48 | NaN seen << 53 | non-integer seen << 58; [nPackGroups]: aggregator 0
   u64* keyPart;        // [2 * nPackGroups] largest key, largest complement of a key (zero between calls, like packPart)
   u32 epoch;
+  u32 publishEpoch;    // == epoch; a test knob makes it differ, so that nobody ever sees a cell arrive and every waiter gives up
+  u32 spinLimit;       // polls before a waiter gives up (2^22; the test knob: a few)
   u32 nWG;             // workgroups of the launch (fastFusedUnits units of 64 blocks each)
 };
 LERC_HD u32 fastFusedGroups(u32 nWG) { return (nWG + kFusedGroup - 1u) / kFusedGroup; }
@@ -249,7 +251,12 @@ struct FastDecodeBuffers
   FastDecodeParams* hostParams;    // one band: the same two in pinned host memory (written through by the kernels, so that the
   u32* hostFallback;               // verdict needs no copy kernel behind the decode); nullptr for batches
   u32 epoch;
+  u32 publishEpoch;    // == epoch; a test knob makes it differ, so that nobody ever sees a cell arrive and every waiter gives up
+  u32 spinLimit;       // polls before a waiter gives up (2^22; the test knob: a few)
 };
+// LERC_AMD_TEST_GIVEUP (bit 0: the one-launch encoder, bit 1: the streaming decoder): hand-offs inside a launch never arrive
+// -- the path a workgroup takes when it gives up waiting is then the one every call takes (tests/test_gpu_parity.py)
+u32 fastTestGiveUp();
 
 // A launch covers nTiles independent blobs of rasters of one shape (blockIdx.y = tile; one raster is nTiles == 1).
 // Every buffer above then holds nTiles consecutive slices, sized by the bounds below.

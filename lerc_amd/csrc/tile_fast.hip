@@ -29,9 +29,6 @@ namespace lerc {
 #ifndef LERC_FUSED_SGPR80
 #define LERC_FUSED_SGPR80 1
 #endif
-#ifndef LERC_FUSED_PATIENT
-#define LERC_FUSED_PATIENT 0
-#endif
 #if defined(HIPSIM) || !LERC_FUSED_SGPR80
 #define LERC_SGPR_CAP
 #else
@@ -332,7 +329,7 @@ __device__ __forceinline__ double keyToDouble(int dt, u64 key, u64& raw)
 __device__ __forceinline__ u32
 fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u32 nBytesTiling, u64 minKey, u64 maxKey, u32 flags,
            const u64* raiseBits /* [9] largest first-row rounding error per candidate, as bit patterns */, u32 nBlobsMore, u8* prefix,
-           u64 outCapacity, FastEncodeResult* res)
+           u64 outCapacity, FastEncodeResult* res, bool resetStuck = true)
 {
   const u64 a = minKey, b = maxKey;
   const u32 f = flags;
@@ -374,7 +371,9 @@ fastDecide(const BandParams& p, double requestedMaxZErr, u32 raiseCandidates, u3
   res->minKey = a; res->maxKey = b;
   res->prefixLen = prefixLen;
   res->checksum = 0;
-  __hip_atomic_store(&res->stuck, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (written through: a workgroup that gives up much later says so the same way)
+  // (written through: a workgroup that gives up much later says so the same way.  The one-launch encoder decides LAST, when
+  // every workgroup has had its chance to give up: there the host clears the word before the launch)
+  if (resetStuck) __hip_atomic_store(&res->stuck, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (redo) return redo;
 
   // header + "no mask" + ranges + "not one sweep" (Lerc2.cpp:396-430)
@@ -1208,7 +1207,7 @@ fusedAggregate(u32 k, u32 nGroups, const T* __restrict__ data, const BandParams&
   {
     const u64* cellAt = f.sizeCell + (size_t)(k - 1u) * kFusedGroup + threadIdx.x;    // (group k - 1 is a whole group)
     u64 cell = observe64(cellAt);
-    for (u32 spin = 0; (u32)(cell >> 32) != f.epoch && spin < (1u << 22); spin++)
+    for (u32 spin = 0; (u32)(cell >> 32) != f.epoch && spin < f.spinLimit; spin++)
     {
       __builtin_amdgcn_s_sleep(2);
       cell = observe64(cellAt);
@@ -1221,7 +1220,7 @@ fusedAggregate(u32 k, u32 nGroups, const T* __restrict__ data, const BandParams&
   if (lane == 0) { s_sum[w] = size; if (lostWave) s_lost = 1u; }
   __syncthreads();
   const u32 total = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-  if (threadIdx.x == 0 && !s_lost) publish64(f.totalCell + (k - 1u), ((u64)f.epoch << 32) | (u64)total);
+  if (threadIdx.x == 0 && !s_lost) publish64(f.totalCell + (k - 1u), ((u64)f.publishEpoch << 32) | (u64)total);
   // the totals of groups 0 .. k - 2
   u32 before = 0;
   lost = false;
@@ -1230,7 +1229,7 @@ fusedAggregate(u32 k, u32 nGroups, const T* __restrict__ data, const BandParams&
     const u32 j = j0 + threadIdx.x;
     if (j + 1u >= k) continue;
     u64 cell = observe64(f.totalCell + j);
-    for (u32 spin = 0; (u32)(cell >> 32) != f.epoch && spin < (1u << 22); spin++)
+    for (u32 spin = 0; (u32)(cell >> 32) != f.epoch && spin < f.spinLimit; spin++)
     {
       __builtin_amdgcn_s_sleep(2);
       cell = observe64(f.totalCell + j);
@@ -1245,7 +1244,7 @@ fusedAggregate(u32 k, u32 nGroups, const T* __restrict__ data, const BandParams&
   __syncthreads();
   if (threadIdx.x != 0) return;
   if (s_lost) __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else publish64(f.baseCell + k, ((u64)f.epoch << 32) | (u64)(total + s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]));
+  else publish64(f.baseCell + k, ((u64)f.publishEpoch << 32) | (u64)(total + s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]));
 }
 
 // The tail of the one-launch encoders in three pieces.
@@ -1359,7 +1358,7 @@ fusedFinish(u32 nBytesTiling, u32 prefixLen, u8* __restrict__ out, u64 outCapaci
     u32 fl = 0;
     for (int i = 0; i < 4; i++) { a = s_kmax[i] > a ? s_kmax[i] : a; bInv = s_kmin[i] > bInv ? s_kmin[i] : bInv; fl |= s_flg[i]; }
     const bool doRaise = DtOf<T>::v >= DT_Float && raiseCandidates != 0u;
-    s_redo = fastDecide(p, requestedMaxZErr, raiseCandidates, nBytesTiling, ~bInv, a, fl, doRaise ? s_raise : nullptr, nBlobsMore, s_prefix, outCapacity, res);
+    s_redo = fastDecide(p, requestedMaxZErr, raiseCandidates, nBytesTiling, ~bInv, a, fl, doRaise ? s_raise : nullptr, nBlobsMore, s_prefix, outCapacity, res, false);
   }
   __syncthreads();
   if (s_redo) return;
@@ -1551,7 +1550,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   for (int a = 0; a < U; a++) { len[a] = s_len[a]; lenAll += len[a]; }
   if (threadIdx.x == 0)
   {
-    publish64(f.sizeCell + wg, ((u64)f.epoch << 32) | (u64)lenAll);
+    publish64(f.sizeCell + wg, ((u64)f.publishEpoch << 32) | (u64)lenAll);
     u64 kMax = s_kmx[0], kMin = s_kmn[0];
 #pragma unroll
     for (int a = 1; a < U; a++) { kMax = s_kmx[a] > kMax ? s_kmx[a] : kMax; kMin = s_kmn[a] < kMin ? s_kmn[a] : kMin; }
@@ -1748,7 +1747,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
           if (needB && (u32)(cb >> 32) != f.epoch) cb = observe64(f.baseCell + (grp - 1u));
           const bool miss = (need0 && (u32)(c0 >> 32) != f.epoch) || (need1 && (u32)(c1 >> 32) != f.epoch) || (needB && (u32)(cb >> 32) != f.epoch);
           if (!miss) break;
-          if (spin >= (1u << 22)) { lost = true; break; }
+          if (spin >= f.spinLimit) { lost = true; break; }
           __builtin_amdgcn_s_sleep(4);
         }
         u32 part = (need0 ? (u32)c0 : 0u) + (need1 ? (u32)c1 : 0u) + (needB ? (u32)cb : 0u);

@@ -722,7 +722,7 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
     if (bad) { count = 0; laneOfPath = kNoOffset; }
     // which walk and how many blocks: out at once (the decode workgroups gather the block starts with it while this block
     // still waits for the totals in front of it); epoch (32) | walk (16, 0xFFFF: none) | count (16)
-    publish64(b.chunkCell + 2 * (size_t)c + 1, ((u64)b.epoch << 32) | ((u64)(laneOfPath & 0xFFFFu) << 16) | (count & 0xFFFFu));
+    publish64(b.chunkCell + 2 * (size_t)c + 1, ((u64)b.publishEpoch << 32) | ((u64)(laneOfPath & 0xFFFFu) << 16) | (count & 0xFFFFu));
   }
   if (__any(bad) && lane == 0) raiseFlag(b, 1);
   // exclusive scan of the counts inside the workgroup
@@ -738,13 +738,13 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
   const u32 epoch = b.epoch;
   const u32 nGroups = (hp.nChunks + kResolveChunks - 1u) / kResolveChunks;
   __shared__ u32 s_base[kResolveWG / 64];
-  if (threadIdx.x == kResolveWG - 1) publish64(b.groupCell + group, ((u64)epoch << 32) | (before + inc));
+  if (threadIdx.x == kResolveWG - 1) publish64(b.groupCell + group, ((u64)b.publishEpoch << 32) | (before + inc));
   u32 base = 0;
   for (u32 g0 = 0; g0 < group; g0 += kResolveWG)
   {
     const u32 g = g0 + threadIdx.x;
     u64 cell = g < group ? observe64(b.groupCell + g) : 0ull;
-    for (u32 spin = 0; __any(g < group && (u32)(cell >> 32) != epoch) && spin < (1u << 22); spin++)    // (never that long)
+    for (u32 spin = 0; __any(g < group && (u32)(cell >> 32) != epoch) && spin < b.spinLimit; spin++)    // (never that long)
     {
       __builtin_amdgcn_s_sleep(4);
       if (g < group && (u32)(cell >> 32) != epoch) cell = observe64(b.groupCell + g);
@@ -758,7 +758,7 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
   __syncthreads();
   base = 0;
   for (u32 i = 0; i < kResolveWG / 64; i++) base += s_base[i];
-  if (mine) publish64(b.chunkCell + 2 * (size_t)c, ((u64)epoch << 32) | (base + before + inc - count));
+  if (mine) publish64(b.chunkCell + 2 * (size_t)c, ((u64)b.publishEpoch << 32) | (base + before + inc - count));
   // the chunks hold all the raster's blocks, or the band goes the long way
   if (group == nGroups - 1u && threadIdx.x == kResolveWG - 1 && base + before + inc != hp.nBlocks) raiseFlag(b, 2);
 
@@ -886,7 +886,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
     if (c < hp.nChunks)
     {
       u64 cell = observe64(b.chunkCell + 2 * (size_t)c + 1);
-      for (u32 spin = 0; (u32)(cell >> 32) != epoch && spin < (1u << 22); spin++)    // (never that long: the resolving blocks were dispatched first)
+      for (u32 spin = 0; (u32)(cell >> 32) != epoch && spin < b.spinLimit; spin++)    // (never that long: the resolving blocks were dispatched first)
       {
         __builtin_amdgcn_s_sleep(4);
         cell = observe64(b.chunkCell + 2 * (size_t)c + 1);
@@ -939,7 +939,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
     if (c < hp.nChunks)
     {
       u64 cell = observe64(b.chunkCell + 2 * (size_t)c);
-      for (u32 spin = 0; (u32)(cell >> 32) != epoch && spin < (1u << 22); spin++)
+      for (u32 spin = 0; (u32)(cell >> 32) != epoch && spin < b.spinLimit; spin++)
       {
         __builtin_amdgcn_s_sleep(4);
         cell = observe64(b.chunkCell + 2 * (size_t)c);
@@ -1103,6 +1103,12 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+u32 fastTestGiveUp()
+{
+  static const u32 bits = []() -> u32 { const char* e = getenv("LERC_AMD_TEST_GIVEUP"); return e ? (u32)strtoul(e, nullptr, 0) : 0u; }();
+  return bits;
+}
+
 bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid)
 {
   if (!allValid || nDepth != 1 || mb != 8 || version < 3) return false;

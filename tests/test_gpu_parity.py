@@ -375,6 +375,36 @@ def test_later_bands_do_not_see_the_cells_of_earlier_ones(P, O):
     assert found >= 2
 
 
+def test_workgroups_that_give_up_waiting_fall_back_to_the_general_path():
+    """The hand-offs inside the one-launch encoder and the streaming decoder (size cells, aggregator cells, the resolving
+    blocks' cells) rely on workgroups starting in index order.  LERC_AMD_TEST_GIVEUP makes every such cell arrive with a tag
+    nobody waits for, so every waiter runs into its poll limit: the calls must then come back through the general kernels
+    with the reference's bytes -- slower, never wrong, never hanging.  (A process of its own: the knob is read once.)"""
+    import subprocess
+    import sys
+    code = r"""
+import sys, os
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, capi, cases
+P, O = capi.product(), capi.oracle()
+rng = np.random.default_rng(5)
+for dt, e in ((np.float32, 0.01), (np.uint16, 0)):
+    x = cases._cast(cases.terrain(1024, 1536, rng, amp=300, base=1000, sigma=2.0), dt)
+    c0 = P.path_counters()
+    r1, b1 = O.encode(x, e)
+    r2, b2 = P.encode(x, e)
+    assert r1 == r2 == 0 and b1 == b2, "blob"
+    d1, d2 = O.decode(b1), P.decode(b1)
+    assert d1[0] == d2[0] == 0 and np.array_equal(d1[1].view(np.uint8), d2[1].view(np.uint8)), "pixels"
+    c1 = P.path_counters()
+    assert c1[1] > c0[1] and c1[3] > c0[3], (c0, c1)    # both went the long way
+print("gave up and recovered")
+""" % (capi.ROOT,)
+    env = dict(os.environ, LERC_AMD_TEST_GIVEUP="3")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert out.returncode == 0 and b"gave up and recovered" in out.stdout, out.stdout.decode()[-2000:]
+
+
 def test_lerc1_world(P, O):
     """the reference's legacy Lerc1 fixture (decode only): info, ranges, pixels, mask -- and damaged copies"""
     blob = open(os.path.join(GOLD, "world.lerc1"), "rb").read()

@@ -630,3 +630,32 @@ def test_sim_async_device_api(libs):
         assert L.lerc_amd_finish(h, 0, None) == 0
     finally:
         L.lerc_amd_destroy(h)
+
+
+def test_sim_workgroups_that_give_up_waiting(libs):
+    """LERC_AMD_TEST_GIVEUP: every hand-off inside the one-launch encoder and the streaming decoder arrives with a tag nobody
+    waits for; the waiters run into their poll limit, say so, and the host repeats the call on the general kernels --
+    same bytes, same pixels (the knob is read once: a process of its own).  The GPU suite runs the same on hardware."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, os
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, capi, cases
+S, O = capi.sim(), capi.oracle()
+rng = np.random.default_rng(5)
+for dt, e, shape in ((np.float32, 0.01, (64, 1024)), (np.uint16, 0, (128, 512))):
+    x = cases._cast(cases.terrain(shape[0], shape[1], rng, amp=300, base=1000, sigma=2.0), dt)
+    c0 = S.path_counters()
+    r1, b1 = O.encode(x, e)
+    r2, b2 = S.encode(x, e)
+    assert r1 == r2 == 0 and b1 == b2, "blob"
+    d1, d2 = O.decode(b1), S.decode(b1)
+    assert d1[0] == d2[0] == 0 and np.array_equal(d1[1].view(np.uint8), d2[1].view(np.uint8)), "pixels"
+    c1 = S.path_counters()
+    assert c1[1] > c0[1] and c1[3] > c0[3], (c0, c1)
+print("gave up and recovered")
+""" % (capi.ROOT,)
+    env = dict(os.environ, LERC_AMD_TEST_GIVEUP="3")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert out.returncode == 0 and b"gave up and recovered" in out.stdout, out.stdout.decode()[-2000:]
