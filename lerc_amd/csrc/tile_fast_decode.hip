@@ -44,6 +44,16 @@ __device__ __forceinline__ void raiseFlag(const FastDecodeBuffers& b, int k)
   if (b.hostFallback) b.hostFallback[k] = b.epoch;
 }
 PROBE_DEFINE(fast_decode)
+#if defined(LERC_PROBE) && !defined(HIPSIM)
+// tuning: per-workgroup time lines (constant-rate counter) of the discovery kernel (slots 0 .. 7 of row blockIdx.x) and of the
+// decode workgroups (rows behind 8192), read by tools/trace_decode.py
+static __device__ unsigned long long g_traceD[8 * 32768];
+extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_decode(unsigned long long* out, int n)
+{ hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_traceD), sizeof(unsigned long long) * (size_t)n); }
+#define TRACED(row, slot) do { if (threadIdx.x == 0 && (row) < 32768u) g_traceD[8 * (row) + (slot)] = wall_clock64(); } while (0)
+#else
+#define TRACED(row, slot)
+#endif
 // The decoded pixels leave with the non-temporal hint: nothing in the call reads them again, and written the ordinary
 // way they sit dirty in L2 / the Infinity Cache until the NEXT kernel's traffic pushes them out (measured on C2: this
 // kernel 79 -> 71 us, the statistics pass of the following encode 77 -> 53 us).  The same hint on the blob loads here or in
@@ -383,6 +393,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   __shared__ u32 s_over;
 
   PROBE_BEGIN;
+  TRACED(blockIdx.x, 0);
   const int lane = laneId(), w = waveId();
   const u32 c0 = blockIdx.x * NCH;                         // first chunk of this workgroup
   const u32 r0 = c0 * CH;                                  // blob offset of LDS byte 0
@@ -470,6 +481,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   if (threadIdx.x == 0) { s_nFound = 0u; s_nHit = 0u; }
   __syncthreads();
   PROBE(16);
+  TRACED(blockIdx.x, 1);
   if (threadIdx.x == 0)
   {
     u64 A = 0, B = 0;
@@ -536,6 +548,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   }
   __syncthreads();
   PROBE(17);
+  TRACED(blockIdx.x, 2);
 
   // ---- of the blocks found, those that are not the block right behind another one start a walk (the true path crosses
   // a window in several blocks, each of them found)
@@ -580,6 +593,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   PROBE(19);
   __syncthreads();
   PROBE(20);
+  TRACED(blockIdx.x, 3);
 
   // ---- walks: lane = (chunk, head); the first wave takes the first heads of every chunk (there are seldom more than two).
   // A walk ends on the first block header of the next chunk's window it lands on (or with the blob).
@@ -657,6 +671,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   }
   PROBE(21);
   __syncthreads();
+  TRACED(blockIdx.x, 4);
   // what all live walks of a chunk agree on
   if (threadIdx.x < NCH && c0 + threadIdx.x < nChunks)
   {
@@ -842,6 +857,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
   const u32 blobEnd = hp.blobEnd, epoch = b.epoch;
   const struct { int nCols, version; double invScale, zMaxHdr; } p = { (int)hp.nCols, (int)hp.version, hp.invScale, hp.zMaxHdr };
   PROBE_BEGIN;
+  TRACED(8192u + wgIndex, 0);
   const int w = waveId(), lane = laneId();
   const u32 c0 = wgIndex * CPD;
   // not ours, given up by an earlier kernel, or behind the stream's end (the grid is sized for the largest stream the blob could hold)
@@ -879,6 +895,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
   }
   // ... and the chunks' cells: which walk is the path, how many blocks, the index of the first one (the resolving blocks of
   // this launch leave them; only the workgroups of the launch's first round ever wait)
+  u64 firstCell = 0;    // (threads 0 .. CPD - 1: the chunk's other cell, asked for in the same breath and looked at further down)
   if (threadIdx.x < CPD)
   {
     const u32 c = c0 + threadIdx.x;
@@ -886,6 +903,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
     if (c < hp.nChunks)
     {
       u64 cell = observe64(b.chunkCell + 2 * (size_t)c + 1);
+      firstCell = observe64(b.chunkCell + 2 * (size_t)c);
       for (u32 spin = 0; (u32)(cell >> 32) != epoch && spin < b.spinLimit; spin++)    // (never that long: the resolving blocks were dispatched first)
       {
         __builtin_amdgcn_s_sleep(4);
@@ -901,6 +919,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
   __syncthreads();
   const u32 before = 0u;    // (the cells hold raster indices)
   PROBE(8);
+  TRACED(8192u + wgIndex, 1);
   // ---- the lists of the walks that are the path: flat index f = blocks of chunk 0, then of chunk 1, ...
   u32 nAll = 0, cum[CPD + 1];
 #pragma unroll
@@ -938,7 +957,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
     u32 first = 0;
     if (c < hp.nChunks)
     {
-      u64 cell = observe64(b.chunkCell + 2 * (size_t)c);
+      u64 cell = firstCell;    // (asked for at the start; only the workgroups of the launch's first round find it missing)
       for (u32 spin = 0; (u32)(cell >> 32) != epoch && spin < b.spinLimit; spin++)
       {
         __builtin_amdgcn_s_sleep(4);
@@ -951,6 +970,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
   }
   __syncthreads();
   PROBE(9);
+  TRACED(8192u + wgIndex, 2);
 
   // ---- parse the block headers once: lane = block
   const u32 pattern = (p.version >= 5) ? 14u : 15u;
@@ -997,6 +1017,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
   }
   __syncthreads();
   PROBE(10);
+  TRACED(8192u + wgIndex, 3);
 
   // ---- pixels: a wave takes BPW blocks at a time, a lane V consecutive pixels of one raster row of one block
   const int r = lane >> 3, c = lane & 7, bb = c / LPR, h = c % LPR;
@@ -1099,6 +1120,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
     }
   }
   PROBE(11);
+  TRACED(8192u + wgIndex, 4);
   if ((__any(bad) && lane == 0) || (threadIdx.x == 0 && s_bad)) raiseFlag(b, 3);
 }
 
