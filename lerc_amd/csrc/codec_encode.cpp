@@ -825,7 +825,7 @@ static bool prepareFastEncode(Context& ctx, int dt, int nRows, int nCols, double
   BandParams& bp = fl.bp;
   memset(&bp, 0, sizeof(bp));
   bp.nRows = nRows; bp.nCols = nCols; bp.nDepth = 1; bp.dt = dt; bp.version = kCodecVersion;
-  bp.mb = 8; bp.nTV = nRows / 8; bp.nTH = nCols / 8;
+  bp.mb = 8; bp.nTV = (nRows + 7) / 8; bp.nTH = (nCols + 7) / 8;
   bp.allValid = 1;
   bp.maxQ = maxValToQuantize(dt);
   bp.maxZErr = isFlt ? maxZErr : std::max(0.5, floor(maxZErr));
@@ -841,7 +841,8 @@ static void runFastEncode(Context& ctx, const FastEncodeLaunch& fl, const void* 
   // one kernel per stage (and per profiling group): statistics (+ first-row rounding errors), scan + decide (+ tile
   // placement for batches), pack + checksum
   static const char* kStage[3] = { "fast_stats_sizes", "fast_scan_decide", "fast_pack" };
-  if (fl.fb.fused.sizeCell && dOut)    // one raster, one launch
+  const bool ragged = fl.bp.nRows % 8 != 0 || fl.bp.nCols % 8 != 0;
+  if (fl.fb.fused.sizeCell && (dOut || ragged))    // one raster, one launch (size queries: only where the two-launch form cannot go)
   {
     ProfScope ps(ctx, "fast_encode1");
     FastEncodeBuffers fb = fl.fb;
@@ -869,7 +870,7 @@ static bool encodeStreamingOk(const EncodeRequest& rq)
   bool anyNoData = false;
   if (rq.hUsesNoData) for (int i = 0; i < rq.nBands; i++) anyNoData = anyNoData || rq.hUsesNoData[i] != 0;
   return !anyNoData && rq.version == kCodecVersion && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
-    && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, rq.nDepth, rq.nMasks > 0, rq.maxZErr);
+    && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, rq.nDepth, rq.nMasks > 0, rq.maxZErr, fastEncodeOneLaunch());
 }
 
 bool encodeEnqueueStreaming(Context& ctx, const EncodeRequest& rq, u8* slot)
@@ -936,7 +937,7 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   if (rq.version < 6 && anyNoData) return kWrongParam;    // Lerc.cpp:341-344
   if (rq.version < 4 && rq.nDepth > 1) return kFailed;    // Lerc2::Set refuses (Lerc2.cpp:85-86)
   const bool fastOk = !anyNoData && rq.version == kCodecVersion && rq.maxZErr != 777 && ((uintptr_t)rq.dOut & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
-    && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, rq.nDepth, rq.nMasks > 0, rq.maxZErr);
+    && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, rq.nDepth, rq.nMasks > 0, rq.maxZErr, fastEncodeOneLaunch());
   const u32 nWG = fastOk ? fastEncodeNumWG(rq.nRows, rq.nCols) : 0;
   need += fastOk ? fastEncodeWorkspace(rq.nRows, rq.nCols, 1) : 0;
   const size_t bandCap = (size_t)nPix * tb + 4096;    // a band's blob never exceeds its raw form by more than the small sections

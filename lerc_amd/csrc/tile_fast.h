@@ -69,7 +69,7 @@ struct FastSolo
 // rasters that mode takes: its byte counts are 32 bits wide
 LERC_HD bool fastSoloOk(int dt, int nRows, int nCols)
 {
-  const u64 nBlocks = (u64)(nRows / 8) * (u64)(nCols / 8);
+  const u64 nBlocks = (u64)((nRows + 7) / 8) * (u64)((nCols + 7) / 8);
   return nBlocks * (1 + 64 * (u64)dtSize(dt)) + 256 < 0xFFFFFFFFull;
 }
 
@@ -104,7 +104,7 @@ LERC_HD u32 fastFusedGroups(u32 nWG) { return (nWG + kFusedGroup - 1u) / kFusedG
 LERC_HD int fastFusedUnits(int dt) { return dtSize(dt) == 2 ? 3 : 2; }
 LERC_HD u32 fastFusedNumWG(int dt, int nRows, int nCols)
 {
-  const u64 nUnits = ((u64)(nRows / 8) * (u64)(nCols / 8) + 63u) / 64u, per = (u64)fastFusedUnits(dt);
+  const u64 nUnits = ((u64)((nRows + 7) / 8) * (u64)((nCols + 7) / 8) + 63u) / 64u, per = (u64)fastFusedUnits(dt);
   return (u32)((nUnits + per - 1u) / per);
 }
 
@@ -130,7 +130,8 @@ struct FastEncodeBuffers
   FastFused fused;
 };
 
-bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, double maxZErr);
+// ragged: rows / columns need not be multiples of 8 (the one-launch encoder for a single raster with an output buffer takes such rasters)
+bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, double maxZErr, bool ragged = false);
 u32 fastEncodeNumWG(int nRows, int nCols);
 // stage 0: statistics + block sizes (+ first-row rounding errors, float types); 1: scan + decisions + header; 2: pack +
 // checksum
@@ -179,7 +180,12 @@ LERC_HD bool fastDimsOk(int dt, int nRows, int nCols)
   (void)dt;
   return nRows > 0 && nCols > 0 && nRows % 8 == 0 && nCols % 8 == 0 && (u64)(nRows / 8) * (u64)(nCols / 8) < 0x7FFFFFC0ull;
 }
-LERC_HD u32 fastNumWG(int nRows, int nCols) { return (u32)(((u64)(nRows / 8) * (u64)(nCols / 8) + 63u) / 64u); }
+LERC_HD u32 fastNumWG(int nRows, int nCols) { return (u32)(((u64)((nRows + 7) / 8) * (u64)((nCols + 7) / 8) + 63u) / 64u); }
+// any dimensions (the blocks of the last block row / column are smaller): the one-launch encoder
+LERC_HD bool fastDimsOkRagged(int nRows, int nCols)
+{
+  return nRows > 0 && nCols > 0 && (u64)((nRows + 7) / 8) * (u64)((nCols + 7) / 8) < 0x7FFFFFC0ull;
+}
 
 // ---- decode side ---------------------------------------------------------------------------------
 // The block stream stores no offsets.  Discovery works on 2 KiB chunks of the blob (chunk c = blob bytes

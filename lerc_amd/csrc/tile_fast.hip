@@ -23,6 +23,8 @@
 #include "wave_utils.h"
 #include "block_plan.h"
 
+#include <limits>
+
 namespace lerc {
 
 // (a workgroup of 256 threads is admitted eight times per CU only if its kernel uses at most 80 scalar registers)
@@ -1255,7 +1257,7 @@ fusedAggregate(u32 k, u32 nGroups, const T* __restrict__ data, const BandParams&
 __device__ __forceinline__ void
 fusedFlush(const u32* s_out, u32 kLead, u32 g0, u32 spanLen, u8* __restrict__ out, u64 outCapacity, u32& A, u64& B)
 {
-  const bool fits = (u64)g0 + spanLen <= outCapacity;       // (the last workgroup reports what does not fit)
+  const bool fits = out != nullptr && (u64)g0 + spanLen <= outCapacity;       // (the last workgroup reports what does not fit)
   const u32 ldsShift = g0 & 15u;
   const u32 gAligned = g0 & ~15u;
   const u32 nUnits = (ldsShift + spanLen + 15) >> 4;
@@ -1381,7 +1383,7 @@ fusedFinish(u32 nBytesTiling, u32 prefixLen, u8* __restrict__ out, u64 outCapaci
   }
   __syncthreads();
   const u32 cs = s_cs;
-  if (threadIdx.x < prefixLen && threadIdx.x < outCapacity)
+  if (out && threadIdx.x < prefixLen && threadIdx.x < outCapacity)
     out[threadIdx.x] = (threadIdx.x >= 10u && threadIdx.x < 14u) ? (u8)(cs >> (8u * (threadIdx.x - 10u))) : s_prefix[threadIdx.x];
   if (threadIdx.x == 0) res->checksum = cs;
 }
@@ -1397,7 +1399,10 @@ fusedFinish(u32 nBytesTiling, u32 prefixLen, u8* __restrict__ out, u64 outCapaci
 // ------------------------------------------------------------------------------------------------
 // (32-bit types: eight workgroups per CU, i.e. at most 64 vector registers -- three values go to scratch and it is still
 // 4 us faster at 8192 x 8192 than seven workgroups per CU without)
-template<class T, bool WIDE, int U>
+// PART: rows or columns are no multiples of 8 -- the blocks of the raster's last block row / column are w x h pixels
+// (w, h < 8), Lerc2.cpp:1504-1519.  A lane then holds a PREFIX of its V pixels (or none), a block's element count is
+// w * h instead of 64, and an element's place in the block's bit stream is its row-major index among the w * h.
+template<class T, bool WIDE, int U, bool PART>
 __global__ void __launch_bounds__(256, (sizeof(T) <= 4 ? 8 : 1)) LERC_SGPR_CAP
 k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, FastEncodeResult* __restrict__ res, u32 nWG, u32 nBlobsMore,
                 FastFused f, double requestedMaxZErr, u32 raiseCandidates, u64 outCapacity)
@@ -1421,6 +1426,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   __shared__ u32 s_fl[4];
   __shared__ u64 s_fa[4], s_fb[4], s_kmx[U], s_kmn[U];
   __shared__ u32 s_len[U], s_base, s_retry;
+  static_assert(!(PART && WIDE), "ragged rasters take the per-block mapping");
 
   const u32 nGroups = (nWG + kFusedGroup - 1u) / kFusedGroup, nPackGroups = fastPackGroups(nWG);
   const u32 grp = blockIdx.x / (kFusedGroup + 1u), inGrp = blockIdx.x - grp * (kFusedGroup + 1u);
@@ -1430,7 +1436,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   const int w = waveId(), lane = laneId();
   const int b = lane / LB, r = (lane % LB) / LPR, h = lane % LPR, c = b * LPR + h;
   const bool leader = (lane % LB == 0);
-  const u32 nUnits = fastNumWG(p.nRows, p.nCols);    // units of the raster (the last workgroup may hold fewer than U)
+  const u32 nUnits = ((u32)p.nTH * (u32)p.nTV + 63u) / 64u;    // units of the raster (the last workgroup may hold fewer than U)
   FastSpan span[U];
 #pragma unroll
   for (int a = 0; a < U; a++) span[a] = fastSpanOf(min(wg * (u32)U + (u32)a, nUnits - 1u), (u32)p.nTH, (u32)p.nTV);
@@ -1438,10 +1444,34 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   // ---- the pixels of all units: every load of the wave in flight first (non-temporal: nothing reads them again), the span
   // image is zeroed while they travel
   T v[U][IT][V];
+  // PART: pixels of this lane that exist (a prefix of its V: 0 .. V) and the width of its block, per wave tile
+  int vcA[U][IT], bwA[U][IT];
 #pragma unroll
   for (int a = 0; a < U; a++)
 #pragma unroll
-    for (int t = 0; t < IT; t++) loadLane<T, V>(data + laneOrigin<WIDE, BPW, V>(span[a], t * 4 + w, r, c, p.nCols), v[a][t], true);
+    for (int t = 0; t < IT; t++)
+    {
+      if constexpr (!PART)
+      {
+        vcA[a][t] = V; bwA[a][t] = 8;
+        loadLane<T, V>(data + laneOrigin<WIDE, BPW, V>(span[a], t * 4 + w, r, c, p.nCols), v[a][t], true);
+      }
+      else
+      {
+        const u32 j = (u32)(t * 4 + w) * BPW + (u32)b;
+        const int bw = min(8, p.nCols - (int)fastSpanCol(span[a], j) * 8), bh = min(8, p.nRows - (int)fastSpanRow(span[a], j) * 8);
+        const int vc = r < bh ? max(0, min(V, bw - h * V)) : 0;
+        vcA[a][t] = vc; bwA[a][t] = bw;
+        const T* src = data + laneOrigin<WIDE, BPW, V>(span[a], t * 4 + w, r, c, p.nCols);
+        // (whole vectors where the raster's rows start on 16-byte boundaries; else, and at the ragged ends, pixel by pixel)
+        if (vc == V && (((size_t)p.nCols * sizeof(T)) & 15u) == 0u) loadLane<T, V>(src, v[a][t], true);
+        else
+        {
+#pragma unroll
+          for (int k = 0; k < V; k++) v[a][t][k] = k < vc ? src[k] : T(0);
+        }
+      }
+    }
   for (u32 i = threadIdx.x; i < (u32)kSpanWords / 4u; i += 256u) reinterpret_cast<uint4*>(s_out)[i] = make_uint4(0, 0, 0, 0);
   if (threadIdx.x == 0) { s_base = 0u; s_retry = 0u; }
 
@@ -1455,6 +1485,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
     {
       const int tile = t * 4 + w;
       const T (&x)[V] = v[a][t];
+      const int vc = vcA[a][t];    // (V unless PART; pixels that do not exist were loaded as 0: neither NaN nor fractional)
       if (DT >= DT_Float)
       {
 #pragma unroll
@@ -1465,31 +1496,68 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
           for (int k = 0; k < V; k++) if (notIntegral(x[k])) flags |= 2u;
         }
       }
-      T mn = x[0], mx = x[0];
+      T mn, mx;
+      if constexpr (!PART)
+      {
+        mn = x[0]; mx = x[0];
 #pragma unroll
-      for (int k = 1; k < V; k++) { mn = OpMin()(mn, x[k]); mx = OpMax()(mx, x[k]); }
+        for (int k = 1; k < V; k++) { mn = OpMin()(mn, x[k]); mx = OpMax()(mx, x[k]); }
+      }
+      else
+      {
+        mn = std::numeric_limits<T>::has_infinity ? std::numeric_limits<T>::infinity() : std::numeric_limits<T>::max();
+        mx = std::numeric_limits<T>::has_infinity ? -std::numeric_limits<T>::infinity() : std::numeric_limits<T>::lowest();
+#pragma unroll
+        for (int k = 0; k < V; k++) if (k < vc) { mn = OpMin()(mn, x[k]); mx = OpMax()(mx, x[k]); }
+      }
       if constexpr (std::is_same<T, float>::value) rowMinMax(mn, mx);    // (LB == 16)
       else
       {
         mn = (T)groupReduce<LB>((ST)mn, OpMin());
         mx = (T)groupReduce<LB>((ST)mx, OpMax());
       }
-      T prev = (T)dppMovT<kDppWaveShr1>((ST)x[V - 1]);
-      if (leader) prev = T(0);
-      int same = (x[0] == prev) ? 1 : 0;
+      // "same as previous" in row-major block order, prevVal starts at 0 (Lerc2.cpp:1729-1758)
+      int same, nElem = 64;
+      if constexpr (!PART)
+      {
+        T prev = (T)dppMovT<kDppWaveShr1>((ST)x[V - 1]);    // the previous pixel vector of the block lives in the previous lane
+        if (leader) prev = T(0);
+        same = (x[0] == prev) ? 1 : 0;
 #pragma unroll
-      for (int k = 1; k < V; k++) same += (x[k] == x[k - 1]) ? 1 : 0;
+        for (int k = 1; k < V; k++) same += (x[k] == x[k - 1]) ? 1 : 0;
+      }
+      else
+      {
+        // the pixel in front of this lane's first one: the last existing pixel of the lane to the left, or -- first lane of
+        // a row -- of the last lane of the row above that holds pixels
+        const int bw = bwA[a][t], hLast = (bw - 1) / V;
+        T lastMine = T(0);
+#pragma unroll
+        for (int k = 0; k < V; k++) if (k == vc - 1) lastMine = x[k];
+        const int src = (h > 0) ? lane - 1 : (lane - LPR + hLast);    // (row above: lane - LPR is its first lane)
+        T prev = shflT<T>(lastMine, src & 63);
+        if (leader) prev = T(0);
+        same = (vc > 0 && x[0] == prev) ? 1 : 0;
+#pragma unroll
+        for (int k = 1; k < V; k++) same += (k < vc && x[k] == x[k - 1]) ? 1 : 0;
+        nElem = groupReduce<LB>(vc, OpSum());
+      }
       u32 nd = 0;
-      if (__any(same > 32 / LB))
+      if (PART || __any(same > 32 / LB))
       {
         same = groupReduce<LB>(same, OpSum());
-        const bool tryLut = (2 * same > 64) && ((double)mx > (double)mn + 3 * p.maxZErr);
+        const bool tryLut = (nElem > 4) && (2 * same > nElem) && ((double)mx > (double)mn + 3 * p.maxZErr);
         if (__any(tryLut))
         {
           const double mv = ((double)mx - (double)mn) * p.scale;
           const bool need = tryLut && !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
           u32 q[V];
           quantizeLane<T, V>(p.intLossless, p.scale, x, mn, q);
+          if constexpr (PART)
+          {
+#pragma unroll
+            for (int k = 0; k < V; k++) if (k >= vc) q[k] = 0xFFFFFFFFu;    // (no such pixel: never the smallest value left)
+          }
           nd = groupDistinct<LB, V>(q, need);
         }
       }
@@ -1497,7 +1565,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       if (leader)
       {
         const int blk = tile * BPW + b;
-        s_mnT[a][blk] = mn; s_mxT[a][blk] = mx; s_same[a][blk] = (u32)same; s_nd[a][blk] = nd;
+        s_mnT[a][blk] = mn; s_mxT[a][blk] = mx; s_same[a][blk] = (u32)same | ((u32)nElem << 16); s_nd[a][blk] = nd;
       }
     }
   }
@@ -1516,8 +1584,8 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
     if (myUnit != a) continue;
     const bool haveUnit = wg * (u32)U + (u32)a < nUnits;
     const T mn = s_mnT[a][lane], mx = s_mxT[a][lane];
-    const int same = (int)s_same[a][lane];
-    const bool tryLut = (2 * same > 64) && ((double)mx > (double)mn + 3 * p.maxZErr);
+    const int same = (int)(s_same[a][lane] & 0xFFFFu), nElem = (int)(s_same[a][lane] >> 16);    // (nElem: 64 unless PART)
+    const bool tryLut = (nElem > 4) && (2 * same > nElem) && ((double)mx > (double)mn + 3 * p.maxZErr);
     double mv = 0;
     bool quantOk = false;
     if (p.maxZErr > 0)
@@ -1526,7 +1594,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       quantOk = !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
     }
     const u32 qMax = quantOk ? (u32)(mv + 0.5) : 0u;    // == largest quantised element (same expression as Quantize)
-    Plan pl = planBlock<T>(p, 64, mn, mx, DT, tryLut, mv, qMax, s_nd[a][lane]);    // (the data type as a constant: the other types' branches fold away)
+    Plan pl = planBlock<T>(p, nElem, mn, mx, DT, tryLut, mv, qMax, s_nd[a][lane]);    // (the data type as a constant: the other types' branches fold away)
     if (!haveUnit || !fastSpanHas(span[a], (u32)lane)) { pl.nBytes = 0; pl.kind = 7; }    // behind the raster's last block: nothing to write
     const int nb = bitLen(qMax);
     const u32 sz = (u32)pl.nBytes;
@@ -1559,7 +1627,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
     __hip_atomic_fetch_max(f.keyPart + 2 * (size_t)(wg / kFastPackGroup) + 1, ~kMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   TRACE(1);
-  if (!out) return;    // (never: size queries take the two-launch form's first steps)
+  const bool sizeOnly = out == nullptr;    // (a size query of a ragged raster: everything but payloads and stores)
 
   // ---- where the spans go: the cells of the workgroups from the start of the group in front of this one's up to this
   // one (two per thread), and what lies in front of those.  Asked for now, looked at when the first unit is packed.
@@ -1597,7 +1665,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       __syncthreads();
     }
     // ---- block headers: lane = block, the wave that planned the unit (Lerc2::WriteTile, BitStuffer2 stream header)
-    if (myUnit == a)
+    if (myUnit == a && !sizeOnly)
     {
       const u32 w1 = s_w1[a][lane];
       const int kind = (int)((w1 >> 16) & 7u), tc = (int)((w1 >> 19) & 3u), dtRed = (int)((w1 >> 21) & 7u), nb = (int)(w1 >> 24);
@@ -1614,7 +1682,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         const int offBytes = dtSize3((u32)dtRed);
         orBits(s_out, at0, flag, 8);
         orBits64(s_out, at0 + 8, typedBits((double)s_mnT[a][lane], dtRed), 8 * offBytes);
-        if (kind == 3) orBits(s_out, at0 + 8u * (1u + (u32)offBytes), (u32)nb | (2u << 6) | (64u << 8), 16);    // numBits byte, count 64
+        if (kind == 3) orBits(s_out, at0 + 8u * (1u + (u32)offBytes), (u32)nb | (2u << 6) | ((s_same[a][lane] >> 16) << 8), 16);    // numBits byte, count (64)
       }
     }
     // ---- payloads
@@ -1624,9 +1692,10 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       const int tile = t * 4 + w;
       const int blk = tile * BPW + b;
       const u32 w1 = s_w1[a][blk];
-      const int kind = (int)((w1 >> 16) & 7u);
+      const int kind = sizeOnly ? 7 : (int)((w1 >> 16) & 7u);
       const u32 at0 = s_bit[a][blk] + bitBase;
-      const int e0 = r * 8 + h * V;
+      const int vc = vcA[a][t];
+      const int e0 = PART ? r * bwA[a][t] + h * V : r * 8 + h * V;    // first element of this lane in the block's row-major order
       if (kind == 3)
       {
         const int nb = (int)(w1 >> 24);
@@ -1634,6 +1703,11 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         const T mn = s_mnT[a][blk];
         u32 q[V];
         quantizeLane<T, V>(p.intLossless, p.scale, v[a][t], mn, q);
+        if constexpr (PART)
+        {
+#pragma unroll
+          for (int k = 0; k < V; k++) if (k >= vc) q[k] = 0u;    // (no such pixel: no bits)
+        }
         const u32 at = at0 + 8u * (3u + (u32)offBytes);
         if (V * nb <= 64)
         {
@@ -1663,7 +1737,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       {
 #pragma unroll
         for (int k = 0; k < V; k++)
-          orBits64(s_out, at0 + 8u + (u32)(e0 + k) * 8u * (u32)sizeof(T), rawBits<T>(v[a][t][k]), 8 * (int)sizeof(T));
+          if (!PART || k < vc) orBits64(s_out, at0 + 8u + (u32)(e0 + k) * 8u * (u32)sizeof(T), rawBits<T>(v[a][t][k]), 8 * (int)sizeof(T));
       }
       // LUT blocks (kind 4): all blocks of the wave take part in the group reductions
       if (__any(kind == 4))
@@ -1674,6 +1748,12 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         quantizeLane<T, V>(p.intLossless, p.scale, v[a][t], mn, q);
 #pragma unroll
         for (int k = 0; k < V; k++) idx[k] = 0;
+        if constexpr (PART)
+        {
+#pragma unroll
+          for (int k = 0; k < V; k++) if (k >= vc) q[k] = 0xFFFFFFFFu;    // (no such pixel: never the smallest value left, index bits 0)
+        }
+        const u32 nElemB = s_same[a][blk] >> 16;
         const int nb = (int)(w1 >> 24);
         const int offBytes = dtSize3((w1 >> 21) & 7u);
         const u32 hdr = at0 + 8u * (1u + (u32)offBytes);
@@ -1701,7 +1781,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         {
           const u32 nLut = count - 1;
           const int nbIdx = bitLen(nLut);
-          if (leader) orBits(s_out, hdr, (u32)nb | (2u << 6) | 32u | (64u << 8) | ((nLut + 1) << 16), 24);
+          if (leader) orBits(s_out, hdr, (u32)nb | (2u << 6) | 32u | (nElemB << 8) | ((nLut + 1) << 16), 24);
           const u32 idxAt = lutAt + 8u * ((nLut * (u32)nb + 7) >> 3);
           u64 s = 0;
 #pragma unroll
@@ -1802,11 +1882,11 @@ k_fast_tile_offsets(FastEncodeResult* __restrict__ res, u32 nTiles, u64 arenaBas
 }
 
 // ------------------------------------------------------------------------------------------------
-bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, double maxZErr)
+bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, double maxZErr, bool ragged)
 {
   if (hasMask || nDepth != 1) return false;
   if (dt == DT_Char || dt == DT_Byte) return false;    // 8-bit: the Huffman decision needs the general path
-  if (!fastDimsOk(dt, nRows, nCols)) return false;
+  if (!(ragged ? fastDimsOkRagged(nRows, nCols) : fastDimsOk(dt, nRows, nCols))) return false;
   if (dt >= DT_Float && maxZErr == 0) return false;    // lossless float is out of scope altogether
   return true;
 }
@@ -1819,15 +1899,18 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
 {
   const u32 nWG = batch.nWG, nT = batch.nTiles;
   const bool wide = p.nTH % 64 == 0;
-  if (b.fused.sizeCell && out)    // one raster, one launch
+  if (b.fused.sizeCell && (out || p.nRows % 8 != 0 || p.nCols % 8 != 0))    // one raster, one launch
   {
     if (stage != 0) return;
     const u32 nW = b.fused.nWG;
     const dim3 grid(nW + fastFusedGroups(nW));
-    if (wide)
-      hipLaunchKernelGGL((k_fast_encode1<T, true, (sizeof(T) == 2 ? 3 : 2)>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
+    constexpr int U = sizeof(T) == 2 ? 3 : 2;
+    if (p.nRows % 8 != 0 || p.nCols % 8 != 0)
+      hipLaunchKernelGGL((k_fast_encode1<T, false, U, true>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
+    else if (wide)
+      hipLaunchKernelGGL((k_fast_encode1<T, true, U, false>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
     else
-      hipLaunchKernelGGL((k_fast_encode1<T, false, (sizeof(T) == 2 ? 3 : 2)>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
+      hipLaunchKernelGGL((k_fast_encode1<T, false, U, false>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
     return;
   }
   if (stage == 0)
