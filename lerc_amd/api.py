@@ -194,6 +194,14 @@ class DeviceCodec:
         except Exception:
             pass
 
+    def path_counters(self):
+        """[encodes by the streaming kernels, encodes by the general kernels, decodes streaming, decodes general] of this context"""
+        out = (ct.c_ulonglong * 4)()
+        self.lib.lerc_amd_path_counters.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+        self.lib.lerc_amd_path_counters.restype = None
+        self.lib.lerc_amd_path_counters(self.h, out)
+        return list(out)
+
     def last_error(self):
         return self.lib.lerc_amd_last_error(self.h).decode()
 

@@ -84,6 +84,22 @@ template<int DT> __device__ __forceinline__ u32 offBytesTable()
   return t;
 }
 
+// Rasters whose rows / columns are no multiples of 8 (RAG): the blocks of the last block column are wl = nCols % 8 pixels wide,
+// those of the last block row hl = nRows % 8 high (Lerc2.cpp:1504-1519), so a block holds 64, 8 wl, 8 hl or wl hl elements --
+// its count byte says which; the decode kernel, which knows where a block lies, checks that it is the right one.
+struct RagCounts
+{
+  u32 cR = 64u, cB = 64u, cC = 64u;    // right edge, bottom edge, corner (64 where there is no such edge)
+  __device__ __forceinline__ bool allowed(u32 c) const { return (c == 64u) | (c == cR) | (c == cB) | (c == cC); }
+};
+__device__ __forceinline__ RagCounts ragCounts(int nRows, int nCols)
+{
+  const u32 wl = (u32)nCols & 7u, hl = (u32)nRows & 7u;
+  RagCounts rc;
+  rc.cR = wl ? 8u * wl : 64u; rc.cB = hl ? 8u * hl : 64u; rc.cC = (wl ? wl : 8u) * (hl ? hl : 8u);
+  return rc;
+}
+
 // the first 12 bytes at LDS byte offset rel: one round of aligned word reads + funnel shifts
 template<int DT>
 __device__ __forceinline__ void ldsHeader(const u32* words, u32 rel, u32& h0, u32& h1, u32& h2)
@@ -101,10 +117,10 @@ __device__ __forceinline__ void ldsHeader(const u32* words, u32 rel, u32& h0, u3
 // Lerc2::ReadTile (Lerc2.cpp:2025-2110) and BitStuffer2::Decode (BitStuffer2.cpp:159-258); blocks longer than
 // the raw form are refused (the reference encoder never writes one; the general kernels take such blobs).
 template<int DT>
-__device__ __forceinline__ u32 parseCode(u32 h0, u32 h1, u32 h2, int version)
+__device__ __forceinline__ u32 parseCode(u32 h0, u32 h1, u32 h2, int version, u32 n = 64u)    // n: elements of the block (64 unless the raster is ragged)
 {
   constexpr u32 TB = (DT <= DT_Byte) ? 1 : (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
-  constexpr u32 RAW = 1 + 64 * TB;
+  const u32 RAW = 1 + n * TB;
   const u32 flag = h0 & 0xFFu, mode = flag & 3u;
   const u32 offB = (offBytesTable<DT>() >> ((flag >> 4) & 12u)) & 15u;
   const u64 hdr = ((u64)h1 << 32) | h0;
@@ -112,10 +128,10 @@ __device__ __forceinline__ u32 parseCode(u32 h0, u32 h1, u32 h2, int version)
   if (DT == DT_Double) t = (offB == 8u) ? (h2 >> 8) : t;
   const u32 nb = t & 31u, lut = (t >> 5) & 1u;
   const u32 nLut = ((t >> 16) & 0xFFu) - 1u;                           // valid: 1 ... 254
-  const bool okBits = ((t & 0xFFC0u) == 0x4080u) & (nb != 0u);         // 64 elements: one-byte count field == 64
+  const bool okBits = ((t & 0xFFC0u) == ((n << 8) | 0x80u)) & (nb != 0u);    // one-byte count field == n
   const bool okLut = (nLut - 1u) < 254u;
-  const u32 lenSimple = 3u + offB + 8u * nb;
-  const u32 lenLut = 4u + offB + (((nLut & 0xFFu) * nb + 7u) >> 3) + 8u * (u32)bitLen(nLut & 0xFFu);
+  const u32 lenSimple = 3u + offB + ((n * nb + 7u) >> 3);
+  const u32 lenLut = 4u + offB + (((nLut & 0xFFu) * nb + 7u) >> 3) + ((n * (u32)bitLen(nLut & 0xFFu) + 7u) >> 3);
   const u32 len = (mode == 0u) ? RAW : (mode == 2u) ? 1u : (mode == 3u) ? 1u + offB : (lut ? lenLut : lenSimple);
   bool ok = (mode == 0u) | (mode == 2u) | ((offB != 0u) & ((mode == 3u) | (okBits & ((lut == 0u) | okLut))));
   ok = ok & !((version >= 5) & ((flag & 4u) != 0u)) & (len <= RAW);    // slice difference needs nDepth > 1
@@ -157,8 +173,11 @@ template<int DT> __device__ __forceinline__ LeanWords<DT> leanFetch(const u32* w
   return v;
 }
 struct LeanBlock { u32 h0, t, offB, len, okLut; };
-template<int DT, bool UNIFORM>
-__device__ __forceinline__ LeanBlock leanLength(const LeanWords<DT>& v, u32 rel)
+// (RAG: toEnd = bytes from the block's start to the end of the blob.  A raw block's length hangs on where the block lies, which
+// a walk does not know: it takes raw blocks for whole ones -- except the raster's very last block, the corner, which is
+// one when it ends the blob exactly: a corner of one pixel is ALWAYS raw, 5 bytes either way and raw wins ties)
+template<int DT, bool UNIFORM, bool RAG = false>
+__device__ __forceinline__ LeanBlock leanLength(const LeanWords<DT>& v, u32 rel, u32 toEnd = 0u, const RagCounts& rc = RagCounts())
 {
   constexpr u32 TB = (DT <= DT_Byte) ? 1 : (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
   constexpr u32 RAW = 1 + 64 * TB;
@@ -175,27 +194,31 @@ __device__ __forceinline__ LeanBlock leanLength(const LeanWords<DT>& v, u32 rel)
   }
   else t = (u32)((((u64)h1 << 32) | h0) >> (8u + 8u * offB));    // (offsets of at most 4 bytes: no shift beyond 40)
   const u32 nb = t & 31u, lut = (t >> 5) & 1u;
-  u32 lenStuffed = 3u + offB + 8u * nb;
+  const u32 cnt = RAG ? ((t >> 8) & 0xFFu) : 64u;                          // (RAG: the stream says how many elements the block holds)
+  u32 lenStuffed = 3u + offB + (RAG ? ((cnt * nb + 7u) >> 3) : 8u * nb);
   k.okLut = 1u;
   if (!UNIFORM || __builtin_amdgcn_ballot_w64((t & 32u) != 0u && mode == 1u) != 0ull)
   {
     const u32 nLut = (((t >> 16) & 0xFFu) - 1u) & 0xFFu;                   // valid: 1 ... 254
     k.okLut = (lut ^ 1u) | (u32)((nLut - 1u) < 254u);
-    const u32 lenLut = 4u + offB + ((nLut * nb + 7u) >> 3) + 8u * (u32)bitLen(nLut);
+    const u32 lenLut = 4u + offB + ((nLut * nb + 7u) >> 3) + (RAG ? ((cnt * (u32)bitLen(nLut) + 7u) >> 3) : 8u * (u32)bitLen(nLut));
     lenStuffed = lut ? lenLut : lenStuffed;
   }
-  const u32 lenOther = (mode == 0u) ? RAW : (mode == 2u) ? 1u : 1u + offB;
+  u32 lenRaw = RAW;
+  if (RAG) lenRaw = (toEnd == 1u + rc.cC * TB) ? toEnd : RAW;
+  const u32 lenOther = (mode == 0u) ? lenRaw : (mode == 2u) ? 1u : 1u + offB;
   k.h0 = h0; k.t = t; k.offB = offB;
   k.len = (mode == 1u) ? lenStuffed : lenOther;
   return k;
 }
-template<int DT>
-__device__ __forceinline__ bool leanValid(const LeanBlock& k, u32 remaining, bool v5, u32 prevSig, u32 pattern, u32& sigOut)
+template<int DT, bool RAG = false>
+__device__ __forceinline__ bool leanValid(const LeanBlock& k, u32 remaining, bool v5, u32 prevSig, u32 pattern, u32& sigOut, const RagCounts& rc = RagCounts())
 {
   constexpr u32 TB = (DT <= DT_Byte) ? 1 : (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
   constexpr u32 RAW = 1 + 64 * TB;
   const u32 mode = k.h0 & 3u, nb = k.t & 31u;
-  const u32 okBits = (u32)((k.t & 0xFFC0u) == 0x4080u) & (u32)(nb != 0u);  // 64 elements: one-byte count field == 64
+  const u32 okBits = RAG ? ((u32)((k.t & 0xC0u) == 0x80u) & (u32)(nb != 0u) & (u32)rc.allowed((k.t >> 8) & 0xFFu))
+                         : ((u32)((k.t & 0xFFC0u) == 0x4080u) & (u32)(nb != 0u));  // one-byte count field == 64 (RAG: one of the block sizes)
   const u32 okStuffed = okBits & (u32)(k.offB != 0u) & k.okLut;
   const u32 okOther = (u32)(mode != 3u) | (u32)(k.offB != 0u);
   u32 ok = (mode == 1u) ? okStuffed : okOther;
@@ -222,11 +245,11 @@ __device__ __forceinline__ bool leanPlausible(const LeanBlock& k, u32 remaining,
   return ok != 0u;
 }
 // all three at once: the block's length or 0
-template<int DT, bool UNIFORM>
-__device__ __forceinline__ u32 stepLean(const u32* words, u32 rel, u32 remaining, bool v5, u32 prevSig, u32 pattern, u32& sigOut)
+template<int DT, bool UNIFORM, bool RAG = false>
+__device__ __forceinline__ u32 stepLean(const u32* words, u32 rel, u32 remaining, bool v5, u32 prevSig, u32 pattern, u32& sigOut, const RagCounts& rc = RagCounts())
 {
-  const LeanBlock k = leanLength<DT, UNIFORM>(leanFetch<DT>(words, rel), rel);
-  return leanValid<DT>(k, remaining, v5, prevSig, pattern, sigOut) ? k.len : 0u;
+  const LeanBlock k = leanLength<DT, UNIFORM, RAG>(leanFetch<DT>(words, rel), rel, remaining, rc);
+  return leanValid<DT, RAG>(k, remaining, v5, prevSig, pattern, sigOut, rc) ? k.len : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -319,8 +342,8 @@ __device__ __forceinline__ FastDecodeParams parseBandHeader(const u8* __restrict
   const bool magic = sizeGiven >= 70u && h.u32At(0) == 0x6372654Cu && (h.u32At(4) & 0xFFFFu) == 0x2032u;    // "Lerc2 "
   hp.version = version;
   hp.expectChecksum = h.u32At(10);
-  hp.nBlocks = (u32)(nRows / 8) * (u32)(nCols / 8);
-  hp.nTH = (u32)nCols / 8u;
+  hp.nBlocks = (u32)((nRows + 7) / 8) * (u32)((nCols + 7) / 8);    // (the blocks of the last block row / column may be smaller)
+  hp.nTH = ((u32)nCols + 7u) / 8u;
   hp.nCols = (u32)nCols;
   hp.nRows = (u32)nRows;
   if (magic)
@@ -366,10 +389,11 @@ __device__ __forceinline__ HeadLite parseHeadLite(const u8* __restrict__ blob, u
 // 0x80 in every byte of v that is zero (exact per byte, unlike the borrow trick)
 __device__ __forceinline__ u32 zeroBytes(u32 v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu); }
 
-template<int DT>
+template<int DT, bool RAG>
 __device__ __forceinline__ void
 fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols, const FastDecodeBuffers& b)
 {
+  const RagCounts rc = ragCounts(nRows, nCols);
   constexpr int TBYTES = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
   constexpr u32 W = kFastWindow(TBYTES);
   constexpr u32 CH = kFastChunkBytes, NCH = (u32)kDiscChunks, NW = (u32)kDiscWalks, NT = (u32)kDiscThreads;
@@ -509,7 +533,9 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
       const u32 wAt = win * (CH / 4) + d;
       const u32 cur4 = s_in[wAt], prev4 = d ? s_in[wAt - 1] : 0u;
       const u32 hdr4 = __builtin_amdgcn_alignbit(cur4, prev4, 24);        // the bytes in front of cur4's
-      m = zeroBytes(cur4 ^ 0x40404040u) & zeroBytes((hdr4 & 0xC0C0C0C0u) ^ 0x80808080u) & ~zeroBytes(hdr4 & 0x1F1F1F1Fu);
+      u32 isCount = zeroBytes(cur4 ^ 0x40404040u);
+      if (RAG) isCount |= zeroBytes(cur4 ^ (rc.cR * 0x01010101u)) | zeroBytes(cur4 ^ (rc.cB * 0x01010101u)) | zeroBytes(cur4 ^ (rc.cC * 0x01010101u));
+      m = isCount & zeroBytes((hdr4 & 0xC0C0C0C0u) ^ 0x80808080u) & ~zeroBytes(hdr4 & 0x1F1F1F1Fu);
     }
     // the few count bytes found (one lane in a hundred has any) go to a queue: window (5) << 11 | position
     while (m)
@@ -563,7 +589,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     const u32 hWin = e >> 11, hPos = e & 0x7FFu;
     u32 sg;
     const u32 cur = (c0 + hWin) * CH + hPos;
-    const u32 len = stepLean<DT, false>(s_in, cur - r0, blobEnd - cur, v5, kNoOffset, pattern, sg);
+    const u32 len = stepLean<DT, false, RAG>(s_in, cur - r0, blobEnd - cur, v5, kNoOffset, pattern, sg, rc);
     // (only where the walk from here would pass the block behind: its signature has to follow this one's -- then both
     // walks are the same from there on, and the earlier one lists the later one's blocks)
     const u32 nx = hPos + len;
@@ -624,12 +650,14 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     bool active = rel < endRel;
     while (__builtin_amdgcn_ballot_w64(active) != 0ull)
     {
-      const LeanBlock k = leanLength<DT, true>(xw, rel);
+      const LeanBlock k = leanLength<DT, true, RAG>(xw, rel, blobRel - min(rel, blobRel), rc);
       const u32 behind = rel + k.len;
       const u32 nxt = min(behind, kMaxRel);                               // (a length that is none stays inside the staged bytes)
       xw = leanFetch<DT>(s_in, nxt);
       const u32 sg = (k.h0 >> 2) & pattern, d = (sg - sig) & pattern;
-      const bool valid = (((k.h0 & 3u) != 1u) | (((k.t & 0xFFDFu) - 0x4081u) <= 30u)) & (behind <= blobRel)
+      const bool stuffedOk = RAG ? (((k.t & 0xC0u) == 0x80u) & ((k.t & 31u) != 0u) & rc.allowed((k.t >> 8) & 0xFFu))
+                                 : (((k.t & 0xFFDFu) - 0x4081u) <= 30u);
+      const bool valid = (((k.h0 & 3u) != 1u) | stuffedOk) & (behind <= blobRel)
         & ((d == 0u) | (d == sigStep) | (sg == 0u));
       const bool ok = active & valid & (count < (u32)kFastListCap);
 #ifndef LERC_WALK_NOSTORE
@@ -655,7 +683,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
       const bool active = alive && !landed;
       if (!__any(active)) break;
       u32 sg;
-      const u32 len = stepLean<DT, true>(s_in, min(cur - r0, kMaxRel), blobEnd - min(cur, blobEnd), v5, sig, pattern, sg);
+      const u32 len = stepLean<DT, true, RAG>(s_in, min(cur - r0, kMaxRel), blobEnd - min(cur, blobEnd), v5, sig, pattern, sg, rc);
       const bool room = count < (u32)kFastListCap;
       const bool ok = active && len != 0u && room;
       tooMany = tooMany || (active && len != 0u && !room);
@@ -834,7 +862,7 @@ template<class T> __device__ __forceinline__ T dequant(double offset, u32 q, dou
 // beforehand (the chunks, plus the blocks a walk passed behind its chunk before it landed), so the bytes, the chunks'
 // counts and -- as soon as it is known which walk of a chunk is the path -- the walks' lists travel together; block i
 // of chunk c is block base(c) + i of the raster (base: the scan the resolve step left in pieces).
-template<class T>
+template<class T, bool RAG>
 __device__ __forceinline__ void
 fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __restrict__ outPix, u32 wgIndex)
 {
@@ -853,6 +881,7 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
   __shared__ u32 s_at[kMaxBlocks];               // raster offset (pixels) of the block's first pixel, ~0: no such block
   __shared__ double s_offs[kMaxBlocks];
   __shared__ u32 s_n[CPD + 1], s_first[CPD], s_lane[CPD], s_bad;
+  __shared__ u8 s_dims[RAG ? kMaxBlocks : 1];    // RAG: width | height << 4 of each block (8 x 8 but for the raster's last block column / row)
   __shared__ __align__(16) u16 s_spec[CPD][CAP];   // the list of each chunk's walk 0, fetched before anybody knows which walk is the path
   const u32 blobEnd = hp.blobEnd, epoch = b.epoch;
   const struct { int nCols, version; double invScale, zMaxHdr; } p = { (int)hp.nCols, (int)hp.version, hp.invScale, hp.zMaxHdr };
@@ -986,8 +1015,14 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
     const u32 off = min((u32)s_pos[f], kMaxRel);
     u32 h0, h1, h2;
     ldsHeader<DT>(s_in, off, h0, h1, h2);
-    u32 code = parseCode<DT>(h0, h1, h2, p.version);
     const u32 it = pow2 ? (blk >> thShift) : blk / hp.nTH, jt = blk - it * hp.nTH;
+    u32 bw = 8u, bh = 8u;
+    if (RAG)
+    {
+      bw = min(8u, hp.nCols - 8u * min(jt, hp.nTH - 1u)); bh = min(8u, hp.nRows - 8u * min(it, (hp.nRows + 7u) / 8u - 1u));
+      s_dims[f] = (u8)(bw | (bh << 4));
+    }
+    u32 code = parseCode<DT>(h0, h1, h2, p.version, bw * bh);
     if ((u32)s_pos[f] + codeLen(code) != (u32)s_pos[f + 1]) code = 0;      // the blocks tile the stream
     if (((h0 >> 2) & pattern) != (jt & pattern)) code = 0;                // signature = (j0 >> 3) & pattern, j0 = 8 jt
     if (blk >= hp.nBlocks) code = 0;
@@ -1037,13 +1072,22 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
     const u32 at0 = have ? s_at[f] : kNoOffset;
     const u32 mode = codeMode(code), lut = codeLut(code), offB = codeOffBytes(code);
     const u32 pbit = 8u * ((have ? (u32)s_pos[f] : 0u) + ((mode == 1u) ? 3u + offB + lut : 1u));    // payload / first raw value
-    const int e0 = r * 8 + h * V;
+    // RAG: the block is bw x bh pixels, this lane holds the first vc of its V (or none), element = row-major index among them
+    int bw = 8, vc = V;
+    if (RAG)
+    {
+      const u32 dims = have ? (u32)s_dims[f] : 0x88u;
+      bw = (int)(dims & 15u);
+      vc = r < (int)(dims >> 4) ? max(0, min(V, bw - h * V)) : 0;
+    }
+    const bool rowsAligned = !RAG || (((size_t)p.nCols * sizeof(T)) & 15u) == 0u;    // (else: no 16-byte stores)
+    const int e0 = r * bw + h * V;
     T v[V];
 #pragma unroll
     for (int k = 0; k < V; k++) v[k] = T(0);
     // the common case, all blocks of the wave alike: bit-stuffed without a table, the lane's V values inside 64 bits, no
     // clamp -- three words of the stream, one funnel shift each way, V shifts
-    const bool plain = mode == 1u && !lut && (code >> 30) != 0u && (u32)V * codeBits(code) <= 64u;
+    const bool plain = mode == 1u && !lut && (code >> 30) != 0u && (u32)V * codeBits(code) <= 64u && (!RAG || (vc == V && bw == 8 && rowsAligned));
     if (__all(plain || !code))
     {
       if (code)
@@ -1106,17 +1150,26 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
           for (int k = 0; k < V; k++)
           {
             u32 ix = ldsBits(s_in, idxBit + (u32)(e0 + k) * (u32)nbIdx, nbIdx);
-            if (ix > nLut) { ix = 0; bad = true; }    // the reference would read outside its table here
+            if (ix > nLut) { ix = 0; bad = bad || !RAG || k < vc; }    // the reference would read outside its table here (RAG: pixels that do not exist have no index)
             const u32 q = ix ? ldsBits(s_in, pbit + (ix - 1) * (u32)nb, nb) : 0u;
             v[k] = dequant<T>(offset, q, p.invScale, p.zMaxHdr, offI, invI, zMaxI);
           }
         }
       }
-      struct alignas(sizeof(T) * V) Vec { T e[V]; };
-      Vec o;
+      if (RAG && !(vc == V && rowsAligned))
+      {
+        T* dst = outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V);
 #pragma unroll
-      for (int k = 0; k < V; k++) o.e[k] = v[k];
-      DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
+        for (int k = 0; k < V; k++) if (k < vc) dst[k] = v[k];
+      }
+      else
+      {
+        struct alignas(sizeof(T) * V) Vec { T e[V]; };
+        Vec o;
+#pragma unroll
+        for (int k = 0; k < V; k++) o.e[k] = v[k];
+        DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
+      }
     }
   }
   PROBE(11);
@@ -1135,7 +1188,7 @@ bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int n
 {
   if (!allValid || nDepth != 1 || mb != 8 || version < 3) return false;
   if (dt == DT_Char || dt == DT_Byte) return false;
-  if (!fastDimsOk(dt, nRows, nCols)) return false;
+  if (!fastDimsOkRagged(nRows, nCols)) return false;    // (rows / columns need not be multiples of 8)
   return true;
 }
 
@@ -1144,7 +1197,7 @@ FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven)
   // upper bounds from what the caller knows without reading the blob
   FastWalkPlan wp;
   wp.nChunks = ((sizeGiven ? sizeGiven : 1u) + kFastChunkBytes - 1) / kFastChunkBytes;
-  wp.nBlocks = (u32)(nRows / 8) * (u32)(nCols / 8);
+  wp.nBlocks = (u32)((nRows + 7) / 8) * (u32)((nCols + 7) / 8);
   wp.nWaves = (wp.nChunks + (u32)kDiscChunks - 1) / (u32)kDiscChunks;
   return wp;
 }
@@ -1164,16 +1217,16 @@ __device__ __forceinline__ void tileSlice(FastDecodeBuffers& b, const FastDecode
   if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
 }
 
-template<int DT>
+template<int DT, bool RAG>
 __global__ void __launch_bounds__(kDiscThreads)
 k_fast_discover(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 sizeGiven, int nRows, int nCols)
 {
   tileSlice(b, t, blob, sizeGiven, blockIdx.y);
-  fastDiscoverBody<DT>(blob, sizeGiven, nRows, nCols, b);
+  fastDiscoverBody<DT, RAG>(blob, sizeGiven, nRows, nCols, b);
 }
 // The first blocks of the launch resolve (kResolveChunks chunks each; all tiles' resolving blocks first, so that a batch's decode
 // workgroups find the cells of their tile ready like those of a single raster do), the others decode (kDecodeChunks chunks each).
-template<class T>
+template<class T, bool RAG>
 __global__ void __launch_bounds__(256)
 k_fast_decode(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, T* __restrict__ outPix)
 {
@@ -1185,7 +1238,7 @@ k_fast_decode(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, T* __restr
   u32 sizeGiven = 0;
   tileSlice(b, t, blob, sizeGiven, tile);
   if (resolving) fastResolveBody(b, t.nWaves, index);
-  else fastDecodeBody<T>(b, blob, outPix + (size_t)tile * t.tileElems, index);
+  else fastDecodeBody<T, RAG>(b, blob, outPix + (size_t)tile * t.tileElems, index);
 }
 
 template<class T>
@@ -1197,11 +1250,18 @@ static void launchFastDecodeT(int stage, int nRows, int nCols, const FastDecodeB
   switch (stage)
   {
     case 0:
-      hipLaunchKernelGGL(k_fast_discover<DT>, dim3(t.nWaves, nT), dim3(kDiscThreads), 0, st, b, t, blob, sizeGiven, nRows, nCols);
+      if (nRows % 8 != 0 || nCols % 8 != 0)
+        hipLaunchKernelGGL((k_fast_discover<DT, true>), dim3(t.nWaves, nT), dim3(kDiscThreads), 0, st, b, t, blob, sizeGiven, nRows, nCols);
+      else
+        hipLaunchKernelGGL((k_fast_discover<DT, false>), dim3(t.nWaves, nT), dim3(kDiscThreads), 0, st, b, t, blob, sizeGiven, nRows, nCols);
       break;
     default:
-      hipLaunchKernelGGL((k_fast_decode<T>), dim3(nT * ((t.nChunks + kResolveChunks - 1) / kResolveChunks + (t.nChunks + kDecodeChunks - 1) / kDecodeChunks)),
-                         dim3(256), 0, st, b, t, blob, (T*)out);
+      if (nRows % 8 != 0 || nCols % 8 != 0)
+        hipLaunchKernelGGL((k_fast_decode<T, true>), dim3(nT * ((t.nChunks + kResolveChunks - 1) / kResolveChunks + (t.nChunks + kDecodeChunks - 1) / kDecodeChunks)),
+                           dim3(256), 0, st, b, t, blob, (T*)out);
+      else
+        hipLaunchKernelGGL((k_fast_decode<T, false>), dim3(nT * ((t.nChunks + kResolveChunks - 1) / kResolveChunks + (t.nChunks + kDecodeChunks - 1) / kDecodeChunks)),
+                           dim3(256), 0, st, b, t, blob, (T*)out);
       break;
   }
 }

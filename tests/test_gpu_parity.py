@@ -375,6 +375,44 @@ def test_later_bands_do_not_see_the_cells_of_earlier_ones(P, O):
     assert found >= 2
 
 
+def test_ragged_rasters_take_the_streaming_kernels(P, O):
+    """8190 x 8190 and the 257 x 257 of Esri's elevation tiles (rows / columns no multiples of 8) on the one-launch encoder and
+    the streaming decoder: path counters say so, bytes and pixels are the oracle's."""
+    rng = np.random.default_rng(41)
+    for dt, e, shape in ((np.float32, 0.01, (257, 257)), (np.uint16, 0, (257, 257)), (np.float32, 0.01, (1000, 1201)), (np.int32, 0, (515, 130)),
+                         (np.float64, 0.001, (63, 65)), (np.float32, 0.01, (2050, 4099))):
+        x = cases._cast(cases.terrain(shape[0], shape[1], rng, amp=300, base=1000, sigma=2.0), dt)
+        c0 = P.path_counters()
+        r1, b1 = O.encode(x, e)
+        r2, b2 = P.encode(x, e)
+        assert r1 == r2 == 0 and b1 == b2, (np.dtype(dt).name, shape)
+        d1, d2 = O.decode(b1), P.decode(b1)
+        assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1]), (np.dtype(dt).name, shape)
+        c1 = P.path_counters()
+        assert c1[0] - c0[0] == 2 and c1[2] - c0[2] == 1, (np.dtype(dt).name, shape, c0, c1, P.last_note())
+    # full size, on the device: decode == what the oracle-checked small cases promise, error bound, re-encode idempotent
+    import torch
+    from lerc_amd import api, synth
+    dev = torch.device("cuda:0")
+    codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
+    x = synth.c2_float32(8192, 8192, device=dev)[:8190, :8190].contiguous()
+    blob = torch.empty(x.numel() * 4 + 4096, dtype=torch.uint8, device=dev)
+    y = torch.empty_like(x)
+    c0 = codec.path_counters()
+    rc, n = api.encode_device(codec, x, 0.01, blob)
+    assert rc == 0
+    rc = api.decode_device(codec, blob, n, y)
+    assert rc == 0
+    c1 = codec.path_counters()
+    assert c1[0] - c0[0] == 1 and c1[2] - c0[2] == 1, (c0, c1)
+    assert float((y.double() - x.double()).abs().max()) <= 0.01 * (1 + 1e-6) + 6.2e-5
+    # ... and the bytes: the blob's size is what the size query says, and the general kernels read the same pixels out of it
+    rc, need = codec.encode(x.data_ptr(), 6, 1, 8190, 8190, 1, 0.01, 0, 0)    # (no output buffer: the size query)
+    assert rc == 0 and need == n
+    rc, dec_general, _ = P.decode(blob[:n].cpu().numpy().tobytes())    # host call: stages the blob itself
+    assert rc == 0 and bool(np.array_equal(dec_general.reshape(8190, 8190), y.cpu().numpy()))
+
+
 def test_workgroups_that_give_up_waiting_fall_back_to_the_general_path():
     """The hand-offs inside the one-launch encoder and the streaming decoder (size cells, aggregator cells, the resolving
     blocks' cells) rely on workgroups starting in index order.  LERC_AMD_TEST_GIVEUP makes every such cell arrive with a tag

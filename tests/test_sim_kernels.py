@@ -659,3 +659,24 @@ print("gave up and recovered")
     env = dict(os.environ, LERC_AMD_TEST_GIVEUP="3")
     out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert out.returncode == 0 and b"gave up and recovered" in out.stdout, out.stdout.decode()[-2000:]
+
+
+def test_sim_ragged_rasters_take_the_streaming_kernels(libs):
+    """Rows / columns that are no multiples of 8: the blocks of the last block row / column hold w x h < 64 elements
+    (Lerc2.cpp:1504-1519).  The one-launch encoder and the streaming decoder take such rasters (path counters), bytes and
+    pixels are the oracle's -- 257 x 257 elevation tiles included, whose one-pixel corner block is always a raw one."""
+    O, S = libs
+    rng = np.random.default_rng(31)
+    for dt, e in ((np.float32, 0.01), (np.uint16, 0), (np.int32, 0), (np.float64, 0.001)):
+        for shape in ((9, 9), (17, 23), (63, 65), (100, 70), (257, 257), (3, 700), (64, 1027)):
+            for kind in ("terrain", "mixed"):
+                x = cases._cast(cases.terrain(shape[0], shape[1], rng, amp=300, base=1000, sigma=2.0), dt) if kind == "terrain" else cases.mixed_regions(shape[0], shape[1], rng, dt)
+                c0 = S.path_counters()
+                r1, b1 = O.encode(x, e)
+                r2, b2 = S.encode(x, e)
+                assert r1 == r2 == 0 and b1 == b2, (np.dtype(dt).name, shape, kind)
+                d1, d2 = O.decode(b1), S.decode(b1)
+                assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1]), (np.dtype(dt).name, shape, kind)
+                c1 = S.path_counters()
+                if kind == "terrain":
+                    assert c1[0] - c0[0] == 2 and c1[2] - c0[2] == 1, (np.dtype(dt).name, shape, c0, c1, S.last_note())    # size query + encode, decode
