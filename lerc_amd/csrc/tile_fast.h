@@ -101,7 +101,10 @@ struct FastFused
 LERC_HD u32 fastFusedGroups(u32 nWG) { return (nWG + kFusedGroup - 1u) / kFusedGroup; }
 // consecutive units of 64 blocks a workgroup of k_fast_encode1 takes: as many as usually fit its span image together (two units
 // of 32-bit pixels at a ratio of 2.5, three of 16-bit pixels at a ratio of 2), and 32 KB (24 KB) of pixels in flight per workgroup
-LERC_HD int fastFusedUnits(int dt) { return dtSize(dt) == 2 ? 3 : 2; }
+#ifndef LERC_U32
+#define LERC_U32 2
+#endif
+LERC_HD int fastFusedUnits(int dt) { return dtSize(dt) == 2 ? 3 : LERC_U32; }
 LERC_HD u32 fastFusedNumWG(int dt, int nRows, int nCols)
 {
   const u64 nUnits = ((u64)((nRows + 7) / 8) * (u64)((nCols + 7) / 8) + 63u) / 64u, per = (u64)fastFusedUnits(dt);

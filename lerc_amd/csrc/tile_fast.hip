@@ -1416,7 +1416,10 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   constexpr int kMaxBlockBytes = 1 + 64 * (int)sizeof(T);
   constexpr u32 kLead = 16;                  // zero bytes in front of the span image (the flush reads up to 15 bytes before it)
   // (room for 64 raw blocks of the type -- or for what two units of 16-bit pixels usually come to: 16 KiB, the 32-bit types' size)
-  constexpr int kImgBytes = kFastBlocksPerWG * kMaxBlockBytes > 16448 ? kFastBlocksPerWG * kMaxBlockBytes : 16448;
+#ifndef LERC_IMG_MIN
+#define LERC_IMG_MIN 16448
+#endif
+  constexpr int kImgBytes = kFastBlocksPerWG * kMaxBlockBytes > LERC_IMG_MIN ? kFastBlocksPerWG * kMaxBlockBytes : LERC_IMG_MIN;
   constexpr int kSpanWords = (kImgBytes + 16) / 4 + 8 + (int)kLead / 4;
   __shared__ __align__(16) u32 s_out[kSpanWords];
   __shared__ T s_mnT[U][kFastBlocksPerWG], s_mxT[U][kFastBlocksPerWG];
@@ -1904,7 +1907,10 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
     if (stage != 0) return;
     const u32 nW = b.fused.nWG;
     const dim3 grid(nW + fastFusedGroups(nW));
-    constexpr int U = sizeof(T) == 2 ? 3 : 2;
+#ifndef LERC_U32
+#define LERC_U32 2
+#endif
+    constexpr int U = sizeof(T) == 2 ? 3 : LERC_U32;
     if (p.nRows % 8 != 0 || p.nCols % 8 != 0)
       hipLaunchKernelGGL((k_fast_encode1<T, false, U, true>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
     else if (wide)
