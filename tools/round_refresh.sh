@@ -13,7 +13,8 @@ timeout 300 python tools/time_configs.py c3 c4 general c2lossless > "$OUT/${TAG}
 timeout 200 python tools/time_tiles.py > "$OUT/${TAG}_time_tiles.txt" 2>&1
 timeout 200 python tools/time_small.py > "$OUT/${TAG}_time_small.txt" 2>&1
 timeout 200 python tools/time_host_api.py > "$OUT/${TAG}_time_host_api.txt" 2>&1
-timeout 400 python bench.py --workload c5 --tiles 4096 --steps 5 --warmup 2 > "$OUT/${TAG}_bench_c5_1gpu.json" 2> "$OUT/${TAG}_bench_c5_1gpu.err"; cut -c1-300 "$OUT/${TAG}_bench_c5_1gpu.json"
+timeout 200 python tools/time_ragged.py > "$OUT/${TAG}_time_ragged.txt" 2>&1
+timeout 400 python bench.py --workload c5 --tiles 8192 --steps 5 --warmup 2 > "$OUT/${TAG}_bench_c5_1gpu.json" 2> "$OUT/${TAG}_bench_c5_1gpu.err"; cut -c1-300 "$OUT/${TAG}_bench_c5_1gpu.json"
 ROOT=$PWD
 cd /tmp && rm -rf /tmp/prof_c4
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_c4 -o kt -- python $ROOT/tools/time_configs.py c4 > /dev/null 2> "$OUT/${TAG}_c4_kt.err"
