@@ -1071,11 +1071,104 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
     return kOk;
   }
 
+  hipStream_t st = ctx.activeStream();
+  std::vector<int> redo;
+  if (fastEncodeOneLaunch())
+  {
+    // ---- the one-launch encoder, a tile per blockIdx.y: every tile's blob goes into a slot of its own (half the tile's raw
+    // size: a tile that needs more is encoded by itself afterwards), then the tiles are placed and moved into the arena
+    const u32 nWGt = fastFusedNumWG(rq.dt, rq.nRows, rq.nCols);
+    const size_t cellWords = fastFusedCellWords(nWGt), counterWords = fastFusedCounterWords(nWGt);
+    const u64 slotBytes = ((tileElems * tb / 2 + 4096) + 15) & ~15ull;
+    const int maxBatch = (int)std::max<size_t>(1, std::min<size_t>((size_t)rq.nTiles, ((size_t)2 << 30) / slotBytes));
+    const bool isFlt = rq.dt >= DT_Float;
+    for (int t0 = 0; t0 < rq.nTiles; t0 += maxBatch)
+    {
+      const int n = std::min(maxBatch, rq.nTiles - t0);
+      if (!ctx.reserve((size_t)n * (slotBytes + sizeof(FastEncodeResult) + 8) + (1u << 16))) return kFailed;
+      u8* cells = ctx.persistentState(1, (size_t)n * cellWords * 8 + 256);
+      u8* counters = ctx.persistentState(0, (size_t)n * counterWords * 8 + 256);
+      u8* slots = ctx.allocT<u8>((size_t)n * slotBytes);
+      FastEncodeResult* dRes = ctx.allocT<FastEncodeResult>(n);
+      u64* dOff = ctx.allocT<u64>((size_t)n + 1);
+      if (!cells || !counters || !slots || !dRes || !dOff) return kFailed;
+      FastEncodeLaunch fl;
+      memset(&fl.fb, 0, sizeof(fl.fb));
+      const u32 nG = fastFusedGroups(nWGt), nPG = fastPackGroups(nWGt);
+      FastFused& f = fl.fb.fused;
+      f.sizeCell = (u64*)cells; f.baseCell = f.sizeCell + nWGt; f.totalCell = f.baseCell + nG; f.raise = f.totalCell + nG;
+      f.packPart = (u64*)counters; f.keyPart = f.packPart + nPG + 1;
+      f.nWG = nWGt; f.nTiles = (u32)n; f.cellStride = (u32)cellWords; f.counterStride = (u32)counterWords;
+      f.tileElems = tileElems; f.outStride = slotBytes;
+      f.epoch = ctx.nextEpoch();
+      f.publishEpoch = (fastTestGiveUp() & 1u) ? f.epoch ^ 0x5A5A5A5Au : f.epoch;
+      f.spinLimit = (fastTestGiveUp() & 1u) ? 8u : (1u << 22);
+      fl.fb.result = dRes;
+      fl.batch.nTiles = (u32)n; fl.batch.nWG = nWGt; fl.batch.tileElems = tileElems; fl.batch.nBlobsMore = 0;
+      fl.cand = 0;
+      if (isFlt)
+      {
+        static const double errCand[9] = { 1, 0.5, 0.1, 0.05, 0.01, 0.005, 0.001, 0.0005, 0.0001 };
+        for (int c = 0; c < 9; c++) if (errCand[c] / 2 > rq.maxZErr) fl.cand |= 1u << c;
+      }
+      BandParams& bp = fl.bp;
+      memset(&bp, 0, sizeof(bp));
+      bp.nRows = rq.nRows; bp.nCols = rq.nCols; bp.nDepth = 1; bp.dt = rq.dt; bp.version = kCodecVersion;
+      bp.mb = 8; bp.nTV = (rq.nRows + 7) / 8; bp.nTH = (rq.nCols + 7) / 8;
+      bp.allValid = 1;
+      bp.maxQ = maxValToQuantize(rq.dt);
+      bp.maxZErr = isFlt ? rq.maxZErr : std::max(0.5, floor(rq.maxZErr));
+      bp.scale = 1 / (2 * bp.maxZErr);
+      bp.invScale = 2 * bp.maxZErr;
+      bp.intLossless = (!isFlt && bp.maxZErr == 0.5) ? 1 : 0;
+      fl.maxZErr = rq.maxZErr;
+      end = (end + 15) & ~15ull;
+      (void)hipGetLastError();
+      hipMemsetAsync(dRes, 0, (size_t)n * sizeof(FastEncodeResult), st);    // (the kernels raise `stuck`, nobody else clears it)
+      {
+        ProfScope ps(ctx, "fast_encode1");
+        launchFastEncode(0, fl.bp, fl.maxZErr, fl.cand, (const u8*)rq.dData + (size_t)t0 * tileElems * tb, slots, slotBytes, 0, fl.fb, fl.batch, st);
+      }
+      {
+        ProfScope ps(ctx, "fast_tile_move");
+        launchFastTileCopy(dRes, dOff, slots, slotBytes, slotBytes, rq.dArena, (u32)n, end, rq.arenaCapacity, st);
+      }
+      if (hipGetLastError() != hipSuccess) { ctx.lastError = "lerc_amd: a streaming encode kernel could not be launched"; return kFailed; }
+      const size_t resBytes = (size_t)n * sizeof(FastEncodeResult), offBytes = ((size_t)n + 1) * 8;
+      u8* pin = (u8*)ctx.pinned(resBytes + offBytes);
+      if (!pin) return kFailed;
+      hipMemcpyAsync(pin, dRes, resBytes, hipMemcpyDeviceToHost, st);
+      hipMemcpyAsync(pin + resBytes, dOff, offBytes, hipMemcpyDeviceToHost, st);
+      if (!ctx.sync()) return kFailed;
+      if (ctx.profOn()) ctx.profCollect();
+      const FastEncodeResult* res = reinterpret_cast<const FastEncodeResult*>(pin);
+      const u64* off = reinterpret_cast<const u64*>(pin + resBytes);
+      redo.clear();
+      bool anyStuck = false;
+      for (int i = 0; i < n; i++)
+      {
+        if (res[i].redo || res[i].stuck)
+        {
+          anyStuck = anyStuck || res[i].stuck != 0;
+          if (res[i].redoReason & 128u) return kBufferTooSmall;    // the arena is full
+          redo.push_back(t0 + i);
+          continue;
+        }
+        rq.hOffsets[t0 + i] = off[i];
+        rq.hSizes[t0 + i] = res[i].blobSize;
+        ctx.pathCount[0]++;
+      }
+      if (anyStuck) ctx.wipePersistentState();
+      end = off[n];
+      for (int t : redo) { const u32 rc = encodeOne(t); if (rc != kOk) return rc; }    // (reuses the workspace: the batch is done with it)
+    }
+    arenaUsed = end;
+    return kOk;
+  }
+
   // sub-batches keep the workspace bounded (block descriptors are 1/16 of the pixels)
   const size_t perTile = fastEncodeWorkspace(rq.nRows, rq.nCols, 1) - 65536;
   const int maxBatch = (int)std::max<size_t>(1, std::min<size_t>((size_t)rq.nTiles, ((size_t)256 << 20) / perTile));
-  hipStream_t st = ctx.activeStream();
-  std::vector<int> redo;
   for (int t0 = 0; t0 < rq.nTiles; t0 += maxBatch)
   {
     const int n = std::min(maxBatch, rq.nTiles - t0);
@@ -1098,7 +1191,7 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
     {
       if (res[i].redo || res[i].stuck)
       {
-        if (res[i].redoReason == 64u) return kBufferTooSmall;    // the arena is full
+        if (res[i].redoReason & 128u) return kBufferTooSmall;    // the arena is full
         redo.push_back(t0 + i);
         continue;
       }

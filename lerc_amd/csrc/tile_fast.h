@@ -96,9 +96,17 @@ struct FastFused
   u32 epoch;
   u32 publishEpoch;    // == epoch; a test knob makes it differ, so that nobody ever sees a cell arrive and every waiter gives up
   u32 spinLimit;       // polls before a waiter gives up (2^22; the test knob: a few)
-  u32 nWG;             // workgroups of the launch (fastFusedUnits units of 64 blocks each)
+  u32 nWG;             // workgroups per raster (fastFusedUnits units of 64 blocks each)
+  // a batch of nTiles rasters of one shape (blockIdx.y = tile): every tile has its own set of the arrays above, cellStride /
+  // counterStride words apart, reads its pixels tileElems apart and writes its blob into a slot of its own, outStride bytes apart
+  u32 nTiles, cellStride, counterStride;
+  u64 tileElems, outStride;
 };
 LERC_HD u32 fastFusedGroups(u32 nWG) { return (nWG + kFusedGroup - 1u) / kFusedGroup; }
+// words of a tile's cells (sizes, group bases, group totals, first-row errors) and counters (pack accumulators + aggregator 0, key cells)
+LERC_HD u32 fastFusedCellWords(u32 nWG) { return nWG + 2u * ((nWG + kFusedGroup - 1u) / kFusedGroup) + 16u; }
+LERC_HD u32 fastFusedCounterWords(u32 nWG) { return 3u * fastPackGroups(nWG) + 1u; }
+
 // consecutive units of 64 blocks a workgroup of k_fast_encode1 takes: as many as usually fit its span image together (two units
 // of 32-bit pixels at a ratio of 2.5, three of 16-bit pixels at a ratio of 2), and 32 KB (24 KB) of pixels in flight per workgroup
 #ifndef LERC_U32
@@ -135,6 +143,9 @@ struct FastEncodeBuffers
 
 // ragged: rows / columns need not be multiples of 8 (the one-launch encoder for a single raster with an output buffer takes such rasters)
 bool fastEncodeEligible(int dt, int nRows, int nCols, int nDepth, bool hasMask, double maxZErr, bool ragged = false);
+// batches through the one-launch encoder: tile placement (k_fast_tile_offsets) + the move from the tiles' slots into the arena
+void launchFastTileCopy(const FastEncodeResult* res, const u64* tileOffset, const u8* slots, u64 slotStride, u64 slotBytes, u8* arena, u32 nTiles,
+                        u64 arenaBase, u64 arenaCapacity, hipStream_t st);
 u32 fastEncodeNumWG(int nRows, int nCols);
 // stage 0: statistics + block sizes (+ first-row rounding errors, float types); 1: scan + decisions + header; 2: pack +
 // checksum

@@ -51,7 +51,8 @@ extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace(unsi
 
 enum FastRedo : u32
 {
-  kRedoNaN = 1, kRedoAllInt = 2, kRedoRaise = 4, kRedoConst = 8, kRedoMb16 = 16, kRedoOneSweep = 32, kRedoCapacity = 64
+  kRedoNaN = 1, kRedoAllInt = 2, kRedoRaise = 4, kRedoConst = 8, kRedoMb16 = 16, kRedoOneSweep = 32, kRedoCapacity = 64,
+  kRedoArena = 128    // (with kRedoCapacity: the ARENA of a batch is full, not a tile's own room)
 };
 
 template<class T> struct FastCfg
@@ -1432,6 +1433,14 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   static_assert(!(PART && WIDE), "ragged rasters take the per-block mapping");
 
   const u32 nGroups = (nWG + kFusedGroup - 1u) / kFusedGroup, nPackGroups = fastPackGroups(nWG);
+  if (f.nTiles > 1u)    // a batch: this tile's pixels, cells, counters, result and slot
+  {
+    const size_t tile = blockIdx.y;
+    data += tile * f.tileElems; res += tile;
+    if (out) out += tile * f.outStride;
+    f.sizeCell += tile * f.cellStride; f.baseCell += tile * f.cellStride; f.totalCell += tile * f.cellStride; f.raise += tile * f.cellStride;
+    f.packPart += tile * f.counterStride; f.keyPart += tile * f.counterStride;
+  }
   const u32 grp = blockIdx.x / (kFusedGroup + 1u), inGrp = blockIdx.x - grp * (kFusedGroup + 1u);
   if (inGrp == 0u) { fusedAggregate<T>(grp, nGroups, data, p, raiseCandidates, f, nPackGroups, res); return; }
   const u32 wg = grp * kFusedGroup + inGrp - 1u;    // (the grid has exactly nWG + nGroups blocks)
@@ -1877,11 +1886,32 @@ k_fast_tile_offsets(FastEncodeResult* __restrict__ res, u32 nTiles, u64 arenaBas
     if (!res[t].redo)
     {
       const u64 sz = ((u64)res[t].blobSize + 15ull) & ~15ull;
-      if (run + sz > arenaCapacity) { res[t].redo = 1u; res[t].redoReason = kRedoCapacity; }    // does not fit: nothing is written
+      if (run + sz > arenaCapacity) { res[t].redo = 1u; res[t].redoReason = kRedoCapacity | kRedoArena; }    // does not fit: nothing is written
       run += sz;
     }
   }
   if (threadIdx.x == 1023) tileOffset[nTiles] = run;
+}
+
+// Batches through the one-launch encoder: every tile's blob lies in a slot of its own (nobody knows where a tile goes in the
+// arena before the tiles in front of it are sized); k_fast_tile_offsets places the tiles, this moves them: 16-byte units,
+// both ends aligned.  A tile the general path has to redo is not moved.
+__global__ void __launch_bounds__(256)
+k_fast_tile_copy(const FastEncodeResult* __restrict__ res, const u64* __restrict__ tileOffset, const u8* __restrict__ slots, u64 slotStride,
+                 u8* __restrict__ arena)
+{
+  const size_t tile = blockIdx.y;
+  if (res[tile].redo) return;
+  const u32 nUnits = (res[tile].blobSize + 15u) >> 4;
+  const uint4* src = reinterpret_cast<const uint4*>(slots + tile * slotStride);
+  uint4* dst = reinterpret_cast<uint4*>(arena + tileOffset[tile]);
+  for (u32 u = blockIdx.x * 1024u + threadIdx.x; u < min(nUnits, (blockIdx.x + 1u) * 1024u); u += 256u) dst[u] = src[u];
+}
+void launchFastTileCopy(const FastEncodeResult* res, const u64* tileOffset, const u8* slots, u64 slotStride, u64 slotBytes, u8* arena, u32 nTiles,
+                        u64 arenaBase, u64 arenaCapacity, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_fast_tile_offsets, dim3(1), dim3(1024), 0, st, const_cast<FastEncodeResult*>(res), nTiles, arenaBase, arenaCapacity, const_cast<u64*>(tileOffset));
+  hipLaunchKernelGGL(k_fast_tile_copy, dim3((u32)((slotBytes / 16 + 1023) / 1024), nTiles), dim3(256), 0, st, res, tileOffset, slots, slotStride, arena);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1906,7 +1936,7 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
   {
     if (stage != 0) return;
     const u32 nW = b.fused.nWG;
-    const dim3 grid(nW + fastFusedGroups(nW));
+    const dim3 grid(nW + fastFusedGroups(nW), b.fused.nTiles > 1u ? b.fused.nTiles : 1u);
 #ifndef LERC_U32
 #define LERC_U32 2
 #endif
