@@ -73,7 +73,10 @@ LERC_AMD_API lerc_status lerc_getDataRanges(const unsigned char* pLercBlob, unsi
     int nBands, double* pMins, double* pMaxs);
 
 /* reference Lerc_c_api.h:238-252 -- pData / pValidBytes pre-allocated by the caller.  Lerc2 codec 2..6 and Lerc1 blobs
- * (Lerc1: pixels that are not valid keep what pData held, Lerc.cpp:2063-2107) */
+ * (Lerc1: pixels that are not valid keep what pData held, Lerc.cpp:2063-2107).
+ * When the call returns anything but Ok the contents of pData / pValidBytes are unspecified: the streaming kernels write
+ * pixels while the blob's checksum is still being summed and hand a bad blob to the general path afterwards (the
+ * reference, too, leaves a partly written image behind when a block fails to parse behind a good checksum). */
 LERC_AMD_API lerc_status lerc_decode(const unsigned char* pLercBlob, unsigned int blobSize, int nMasks,
     unsigned char* pValidBytes, int nDepth, int nCols, int nRows, int nBands, unsigned int dataType, void* pData);
 
