@@ -656,7 +656,7 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
     return decodeDevice(ctx, one);
   };
   bool fastOk = fastDecodeEligible(rq.dt, 6, 8, rq.nRows, rq.nCols, 1, true) && ((uintptr_t)rq.dArena & 15) == 0
-    && ((uintptr_t)rq.dOut & 15) == 0 && (tileElems * tbytes) % 16 == 0;
+    && ((uintptr_t)rq.dOut & 15) == 0 && ((tileElems * tbytes) % 16 == 0 || rq.nRows % 8 != 0 || rq.nCols % 8 != 0);    // (ragged tiles: pixel-wise stores)
   u32 maxSize = 0;
   for (int t = 0; t < rq.nTiles; t++)
   {

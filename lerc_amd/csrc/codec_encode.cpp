@@ -1043,8 +1043,12 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
     return kWrongParam;
   const int tb = dtSize(rq.dt);
   const u64 tileElems = (u64)rq.nRows * (u64)rq.nCols;
-  const bool fastOk = rq.maxZErr != 777 && ((uintptr_t)rq.dArena & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0 && (tileElems * tb) % 16 == 0
-    && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, 1, false, rq.maxZErr);
+  // (tiles whose sides are no multiples of 8 -- 257 x 257 elevation tiles -- go through the one-launch encoder's ragged form, pixel by
+  // pixel where rows do not start on 16-byte boundaries; whole-block tiles must lie 16 bytes apart)
+  const bool raggedTile = rq.nRows % 8 != 0 || rq.nCols % 8 != 0;
+  const bool fastOk = rq.maxZErr != 777 && ((uintptr_t)rq.dArena & 15) == 0 && ((uintptr_t)rq.dData & 15) == 0
+    && (raggedTile ? fastEncodeOneLaunch() : (tileElems * tb) % 16 == 0)
+    && fastEncodeEligible(rq.dt, rq.nRows, rq.nCols, 1, false, rq.maxZErr, raggedTile);
   u64 end = 0;    // arena bytes in use
 
   auto encodeOne = [&](int t) -> u32

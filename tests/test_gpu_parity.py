@@ -253,6 +253,36 @@ def test_c5_tile_batch_in_one_call(P, O):
     assert cnt[0] == n_tiles - 2 and cnt[2] >= n_tiles - 4, list(cnt)    # the batch really went through the streaming kernels
 
 
+def test_elevation_tile_batch_257(P, O):
+    """A mosaic of 257 x 257 tiles (Esri's elevation tile caches; rows / columns no multiples of 8, tiles 4 bytes off a 16-byte
+    grid) in one batched call each way: the ragged forms of the streaming kernels take them (path counters), blobs are the
+    per-tile oracle blobs."""
+    import torch
+    from lerc_amd import api, synth
+    dev = torch.device("cuda:0")
+    n_tiles = 96
+    big = synth.c2_float32(257 * 8, 257 * 12, virt_cols=65536, device=dev)
+    tiles = big.reshape(8, 257, 12, 257).permute(0, 2, 1, 3).contiguous().reshape(n_tiles, 257, 257)
+    codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
+    arena = torch.empty(tiles.numel() * 4 + n_tiles * 256, dtype=torch.uint8, device=dev)
+    rc, offs, sizes, used = api.encode_tiles_device(codec, tiles, 0.01, arena)
+    assert rc == 0, (rc, codec.last_error())
+    ah = arena[:used].cpu().numpy()
+    th = tiles.cpu().numpy()
+    for t in (0, 1, 50, n_tiles - 1):
+        r1, b1 = O.encode(th[t], 0.01)
+        assert r1 == 0 and offs[t] % 16 == 0 and ah[int(offs[t]):int(offs[t]) + int(sizes[t])].tobytes() == b1, t
+    out = torch.empty_like(tiles)
+    rc = api.decode_tiles_device(codec, arena, offs, sizes, out)
+    assert rc == 0, (rc, codec.last_error())
+    torch.cuda.synchronize()
+    assert float((out.double() - tiles.double()).abs().max().item()) <= 0.01 + 6.2e-5
+    for t in (0, 50, n_tiles - 1):
+        want = O.decode(ah[int(offs[t]):int(offs[t]) + int(sizes[t])].tobytes())
+        assert np.array_equal(want[1].reshape(257, 257), out[t].cpu().numpy())
+    assert codec.path_counters()[0] == n_tiles and codec.path_counters()[2] == n_tiles, codec.path_counters()
+
+
 def test_nodata_values(P, O):
     """lerc_encode_4D / lerc_decode_4D with per-band noData values, differential against the real reference (or the
     oracle): sizes, blobs, decoded pixels, masks and the noData values handed back."""

@@ -286,7 +286,8 @@ def test_sim_tile_batches(libs):
     try:
         for dt, e in ((np.float32, 0.01), (np.uint16, 0), (np.float64, 0.05)):
             # (24, 40): 15 blocks, one partly empty workgroup per tile; (20, 44): no whole blocks, tile by tile through the general kernels
-            for (r, c, n_t) in ((256, 256, 5), (64, 128, 6), (24, 40, 3), (200, 200, 4), (20, 44, 3)):
+            # (257, 257) / (33, 65): ragged tiles (Esri's elevation tiles are 257 x 257) through the batch kernels' ragged forms
+            for (r, c, n_t) in ((256, 256, 5), (64, 128, 6), (24, 40, 3), (200, 200, 4), (20, 44, 3), (257, 257, 3), (33, 65, 5)):
                 tiles = np.stack([cases._cast(cases.terrain(r, c, rng, amp=300, base=1000 + 10 * t, sigma=1.5), dt) for t in range(n_t)])
                 if n_t >= 5:
                     tiles[2] = tiles[2].flat[0]
