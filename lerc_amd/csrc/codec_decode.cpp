@@ -76,11 +76,13 @@ bool readBandHeader(const BlobReader& rd, u64 off, BandDesc& b)
 static const size_t kCellParams = 0, kCellFallback = 128, kCellBytes = 192;
 static_assert(sizeof(FastDecodeParams) <= 128, "cell layout");
 
+static bool fastDecodeOneLaunch();    // LERC_AMD_DECODE_LAUNCHES=1: the one-launch form for single rasters (an experiment, 5 % slower: DESIGN.md)
+
 static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven, u32 nTiles = 1)
 {
   const FastWalkPlan wp = makeFastWalkPlan(nRows, nCols, sizeGiven);
   const size_t perTile = (size_t)wp.nChunks * (sizeof(FastChunkRec) + (size_t)kDiscWalks * kFastListCap * 2 + 12) + (size_t)wp.nBlocks * 4
-    + (size_t)wp.nWaves * 16 + (size_t)(wp.nChunks / kResolveWG + 2) * 4 + 4096 + kResolveWG * sizeof(FastChunkRec);
+    + (size_t)(wp.nChunks / kOneDiscChunks + 1) * 16 + (size_t)(wp.nChunks / kResolveWG + 2) * 4 + 4096 + kResolveWG * sizeof(FastChunkRec);
   return perTile * nTiles + (size_t)kDecodeChunks * kDiscWalks * kFastListCap * 2 + (1u << 16);
 }
 
@@ -100,10 +102,13 @@ static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8
   fbuf.recs = ctx.allocT<FastChunkRec>(nT * fwp.nChunks + kResolveWG);    // (+ what the resolve step's unconditional loads may touch)
   fbuf.lists = ctx.allocT<u16>((nT * fwp.nChunks + kDecodeChunks) * (size_t)(kDiscWalks * kFastListCap) + 8);    // (+ what the gather step's clamped loads may touch)
   // (epoch-tagged cells, never cleared: they live as long as the context and share its area with the encoder's)
-  const size_t cellWords = nT * (2 * sChunk + fastGroupStride(fwp.nChunks)) + 8;
+  const bool one = nTiles == 1 && fastDecodeOneLaunch();    // a single raster: discovery, resolving and decoding workgroups in one grid
+  const size_t nDisc = (size_t)fwp.nChunks / kOneDiscChunks + 1;
+  const size_t cellWords = nT * (2 * sChunk + fastGroupStride(fwp.nChunks)) + (one ? nDisc : 0) + 8;
   fbuf.chunkCell = (u64*)ctx.persistentState(1, cellWords * 8);
   fbuf.groupCell = fbuf.chunkCell ? fbuf.chunkCell + nT * 2 * sChunk : nullptr;
-  fbuf.waveFletcher = ctx.allocT<u64>(2 * nT * (size_t)fwp.nWaves + 4);
+  fbuf.discCell = (fbuf.chunkCell && one) ? fbuf.groupCell + nT * fastGroupStride(fwp.nChunks) : nullptr;
+  fbuf.waveFletcher = ctx.allocT<u64>(2 * nT * (one ? nDisc : (size_t)fwp.nWaves) + 4);
   fbuf.params = dParams;
   fbuf.fallback = dFallback;
   fbuf.hostParams = hCell ? reinterpret_cast<FastDecodeParams*>(hCell + kCellParams) : nullptr;
@@ -113,6 +118,12 @@ static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8
   fbuf.spinLimit = (fastTestGiveUp() & 2u) ? 8u : (1u << 22);
   if (!fbuf.recs || !fbuf.lists || !fbuf.chunkCell || !fbuf.waveFletcher)
     return false;
+  if (one)
+  {
+    ProfScope ps(ctx, "fast_decode1");
+    launchFastDecode(2, dt, nRows, nCols, tb, dBlobs, sizeBound, fbuf, dOut, st);
+    return true;
+  }
   static const char* kStage[kFastDecodeStages] = { "fast_discover", "fast_decode" };
   for (int stage = 0; stage < kFastDecodeStages; stage++)
   {
@@ -127,6 +138,12 @@ static bool launchFastBand(Context& ctx, int dt, int nRows, int nCols, const u8*
 {
   return launchFastBands(ctx, dt, nRows, nCols, dBand, sizeGiven, 1, nullptr, nullptr, dOutBand,
                          reinterpret_cast<FastDecodeParams*>(dCell + kCellParams), reinterpret_cast<u32*>(dCell + kCellFallback), epoch, hCell);
+}
+
+static bool fastDecodeOneLaunch()
+{
+  static const bool one = []() { const char* e = getenv("LERC_AMD_DECODE_LAUNCHES"); return e && atoi(e) == 1; }();
+  return one;
 }
 
 // reason bits of a tile's / band's four epoch tagged flag cells

@@ -212,21 +212,36 @@ LERC_HD bool fastDimsOkRagged(int nRows, int nCols)
 //                    walk that starts there is the true path: its block count, scanned, is the index of the chunk's first
 //                    block -- left in an epoch-tagged cell per chunk.  The other workgroups decode the blocks that start in
 //                    kDecodeChunks chunks each, from the true walks' lists, and check that they tile the stream exactly
-static const u32 kFastChunkBytes = 2048;
+#ifndef LERC_CHUNK_BYTES
+#define LERC_CHUNK_BYTES 2048
+#endif
+static const u32 kFastChunkBytes = LERC_CHUNK_BYTES;
 static const int kDiscWalks = 8;           // walks per chunk (path heads among the filter's survivors; more: general path)
 #ifndef LERC_DISC_CHUNKS
 #define LERC_DISC_CHUNKS 16
 #endif
 static const int kDiscChunks = LERC_DISC_CHUNKS;    // chunks per workgroup of k_fast_discover: 8 or 16 (16 threads each; 8 is 8 % slower)
-static const int kDiscThreads = 16 * kDiscChunks;
-static const int kFastListCap = 128;       // block starts a walk can list per chunk (more, i.e. blocks of < 16 bytes on average: general path)
+static const int kDiscThreads = (int)((u32)kDiscChunks * kFastChunkBytes / 128u);    // 16 threads per 2 KiB
+#ifndef LERC_LIST_CAP
+#define LERC_LIST_CAP 128
+#endif
+static const int kFastListCap = LERC_LIST_CAP;       // block starts a walk can list per chunk (more, i.e. blocks of < 16 bytes on average: general path)
 static const u32 kResolveWG = 256;         // threads of a resolving block of k_fast_decode (= of any block of that launch)
 #ifdef LERC_SMALL_GROUPS                   // (emulator builds: small streams then take several resolving blocks)
 static const u32 kResolveChunks = 4;
 #else
 static const u32 kResolveChunks = 256;     // chunks a resolving block takes, one per thread
 #endif
-static const u32 kDecodeChunks = 4;        // chunks whose blocks a workgroup of k_fast_decode decodes (divides kResolveWG)
+static const int kOneDiscChunks = (int)(16384u / kFastChunkBytes);       // chunks per discovery workgroup of the one-launch decoder (256 threads; its LDS is then no more than a decoding workgroup's)
+#ifdef LERC_SMALL_GROUPS
+static const u32 kOneLead = 2;
+#else
+static const u32 kOneLead = 24;            // groups whose discovery workgroups are dispatched before the first resolving block
+#endif
+#ifndef LERC_DECODE_CHUNKS
+#define LERC_DECODE_CHUNKS 4
+#endif
+static const u32 kDecodeChunks = LERC_DECODE_CHUNKS;        // chunks whose blocks a workgroup of k_fast_decode decodes (divides kResolveWG)
 // longest block the streaming walk accepts: the raw form (the reference encoder never emits a longer one)
 constexpr u32 kFastWindow(int typeBytes) { return 2u + 64u * (u32)typeBytes; }
 
@@ -266,6 +281,7 @@ struct FastDecodeBuffers
                        // epoch (32) | the walk that is the true path, 0xFFFF: none (16) | blocks that start in the chunk (16)
   u64* groupCell;      // [ceil(nChunks / kResolveChunks)] epoch (32) | blocks of a resolving block's chunks (32)
   u64* waveFletcher;   // [2 * nWaves] Fletcher partial sums (mod 65535) of the bytes each discovery workgroup staged
+  u64* discCell;       // [ceil(nChunks / kOneDiscChunks)] one-launch decoder: epoch (32) | 1 -- all that discovery workgroup leaves has arrived
   FastDecodeParams* params;   // [nTiles]
   u32* fallback;       // [4 * nTiles] epoch tagged, see above
   FastDecodeParams* hostParams;    // one band: the same two in pinned host memory (written through by the kernels, so that the
@@ -277,6 +293,7 @@ struct FastDecodeBuffers
 // LERC_AMD_TEST_GIVEUP (bit 0: the one-launch encoder, bit 1: the streaming decoder): hand-offs inside a launch never arrive
 // -- the path a workgroup takes when it gives up waiting is then the one every call takes (tests/test_gpu_parity.py)
 u32 fastTestGiveUp();
+u32 fastOneLead();              // LERC_AMD_DECODE_LEAD: see k_fast_decode1
 
 // A launch covers nTiles independent blobs of rasters of one shape (blockIdx.y = tile; one raster is nTiles == 1).
 // Every buffer above then holds nTiles consecutive slices, sized by the bounds below.

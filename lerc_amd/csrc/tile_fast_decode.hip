@@ -360,6 +360,18 @@ __device__ __forceinline__ bool fastRaised(const u32* __restrict__ fallback, u32
   return fallback[0] == epoch || fallback[1] == epoch || fallback[2] == epoch || fallback[3] == epoch;
 }
 
+// (THROUGH: the one-launch decoder, where the checksum verdict is written into the same 64 bytes later in the launch by a
+// workgroup on another XCD -- both as write-through stores, so that neither L2 holds a dirty copy of the other's half)
+template<bool THROUGH> __device__ __forceinline__ void storeParams(FastDecodeParams* dst, const FastDecodeParams& hp)
+{
+  static_assert(sizeof(FastDecodeParams) == 64, "eight 8-byte stores");
+  if (!THROUGH) { *dst = hp; return; }
+  u64 wds[8];
+  memcpy(wds, &hp, 64);
+#pragma unroll
+  for (int i = 0; i < 8; i++) publish64(reinterpret_cast<u64*>(dst) + i, wds[i]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // discovery
 // ------------------------------------------------------------------------------------------------
@@ -389,47 +401,66 @@ __device__ __forceinline__ HeadLite parseHeadLite(const u8* __restrict__ blob, u
 // 0x80 in every byte of v that is zero (exact per byte, unlike the borrow trick)
 __device__ __forceinline__ u32 zeroBytes(u32 v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu); }
 
-template<int DT, bool RAG>
+// sizes of a discovery workgroup of NCH chunks
+template<int DT, u32 NCH> struct DiscGeom
+{
+  static constexpr int TBYTES = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
+  static constexpr u32 W = kFastWindow(TBYTES), CH = kFastChunkBytes, NW = (u32)kDiscWalks;
+  static constexpr u32 kUnits = NCH * CH / 16;                    // 16-byte units a workgroup owns
+  static constexpr u32 kOverhang = (W + 16 + 15) / 16;            // + the next workgroup's first window (walks end on a block start there)
+  static constexpr u32 kStageUnits = kUnits + kOverhang;
+  static constexpr u32 kBitWords = (W + 31) / 32;
+  static constexpr u32 kFoundCap = 512, kHitCap = 512;            // count bytes / block headers found in the workgroup's windows (a few dozen)
+  static constexpr u32 kScanWords = (W + 2 + 8 + 3) / 4 + 1;      // dwords of a window that can hold the count byte of a block starting in it
+};
+// ... and its LDS (a struct, so that the one-launch decoder can lay the three roles' LDS over each other)
+template<int DT, u32 NCH, u32 NT> struct DiscShared
+{
+  typedef DiscGeom<DT, NCH> G;
+  alignas(16) u32 in[G::kStageUnits * 4];
+  u32 hits[NCH + 1][G::kBitWords];               // window positions where a bit-stuffed block header stands
+  u32 heads[NCH][G::kBitWords];                  // ... that are not the block right behind another one
+  u16 found[G::kFoundCap], hit[G::kHitCap];      // window (6) << 10 | position
+  u32 nFound, nHit;
+  u16 fin[NCH][G::NW];
+  u32 nFinal[NCH];
+  u32 exit[NCH][G::NW];
+  u64 fa[NT / 64], fb[NT / 64];
+  u32 over;
+  u16 cnt[NCH][G::NW];                           // (ONE: the walks' counts on their way to the records)
+};
+
+// ONE: a workgroup of the one-launch decoder (k_fast_decode1): what it leaves is read by other workgroups of the SAME launch, on
+// other XCDs -- lists, records and checksum terms leave as write-through stores, and a tagged cell per workgroup says "all out"
+template<int DT, bool RAG, u32 NCH, u32 NT, bool ONE>
 __device__ __forceinline__ void
-fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols, const FastDecodeBuffers& b)
+fastDiscoverBody(DiscShared<DT, NCH, NT>& S, const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols, const FastDecodeBuffers& b, u32 wg)
 {
   const RagCounts rc = ragCounts(nRows, nCols);
-  constexpr int TBYTES = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
-  constexpr u32 W = kFastWindow(TBYTES);
-  constexpr u32 CH = kFastChunkBytes, NCH = (u32)kDiscChunks, NW = (u32)kDiscWalks, NT = (u32)kDiscThreads;
+  typedef DiscGeom<DT, NCH> G;
+  constexpr u32 W = G::W, CH = G::CH, NW = G::NW;
   constexpr u32 kWaves = NT / 64, kHeadsPerWave = 64 / NCH;    // walks: lane = (chunk, head), a wave takes kHeadsPerWave heads of every chunk
-  constexpr u32 kUnits = NCH * CH / 16;                    // 16-byte units a workgroup owns
-  constexpr u32 kOverhang = (W + 16 + 15) / 16;            // + the next workgroup's first window (walks end on a block start there)
-  constexpr u32 kStageUnits = kUnits + kOverhang;
-  constexpr u32 kBitWords = (W + 31) / 32;
-  constexpr u32 kFoundCap = 512, kHitCap = 512;            // count bytes / block headers found in the workgroup's 17 windows (a few dozen)
-  constexpr u32 kScanWords = (W + 2 + 8 + 3) / 4 + 1;      // dwords of a window that can hold the count byte of a block starting in it
-  static_assert((NCH == 16 || NCH == 8) && NW == 8 && NT >= NCH * NW && W < 1024 && CH + 2 * W < 65536, "lane layout / 16-bit list entries");
-  __shared__ __align__(16) u32 s_in[kStageUnits * 4];
-  __shared__ u32 s_hits[NCH + 1][kBitWords];               // window positions where a bit-stuffed block header stands
-  __shared__ u32 s_heads[NCH][kBitWords];                  // ... that are not the block right behind another one
-  __shared__ u16 s_found[kFoundCap], s_hit[kHitCap];        // window (5) << 11 | position
-  __shared__ u32 s_nFound, s_nHit;
-  __shared__ u16 s_final[NCH][NW];
-  __shared__ u32 s_nFinal[NCH];
-  __shared__ u32 s_exit[NCH][NW];
-  __shared__ u64 s_fa[kWaves], s_fb[kWaves];
-  __shared__ u32 s_over;
+  constexpr u32 kUnits = G::kUnits, kStageUnits = G::kStageUnits, kBitWords = G::kBitWords;
+  constexpr u32 kFoundCap = G::kFoundCap, kHitCap = G::kHitCap, kScanWords = G::kScanWords;
+  static_assert((NCH == 32 || NCH == 16 || NCH == 8) && NW == 8 && W + 16 < 1024 && NT >= NCH * NW && W < 1024 && CH + 2 * W < 65536, "lane layout / 16-bit list entries");
+  auto& s_in = S.in; auto& s_hits = S.hits; auto& s_heads = S.heads; auto& s_found = S.found; auto& s_hit = S.hit;
+  auto& s_nFound = S.nFound; auto& s_nHit = S.nHit; auto& s_final = S.fin; auto& s_nFinal = S.nFinal; auto& s_exit = S.exit;
+  auto& s_fa = S.fa; auto& s_fb = S.fb; auto& s_over = S.over;
 
   PROBE_BEGIN;
-  TRACED(blockIdx.x, 0);
+  TRACED(wg, 0);
   const int lane = laneId(), w = waveId();
-  const u32 c0 = blockIdx.x * NCH;                         // first chunk of this workgroup
+  const u32 c0 = wg * NCH;                         // first chunk of this workgroup
   const u32 r0 = c0 * CH;                                  // blob offset of LDS byte 0
 
   // ---- the band header first: a caller that only knows the capacity of the blob's buffer (a decode enqueued behind the
   // encode that writes it) launches workgroups for all of it, and those behind the stream's end must not drag a third of a
   // raster's worth of bytes through the chip before they find out
   HeadLite hl;
-  if (blockIdx.x == 0)
+  if (wg == 0)
   {
     const FastDecodeParams hp = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
-    if (threadIdx.x == 0) { *b.params = hp; if (b.hostParams) *b.hostParams = hp; }
+    if (threadIdx.x == 0) { storeParams<ONE>(b.params, hp); if (b.hostParams) *b.hostParams = hp; }
     hl.ok = hp.ok; hl.version = hp.version; hl.dataBegin = hp.dataBegin; hl.blobEnd = hp.blobEnd;
   }
   else hl = parseHeadLite<DT>(blob, sizeGiven);
@@ -505,14 +536,14 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   if (threadIdx.x == 0) { s_nFound = 0u; s_nHit = 0u; }
   __syncthreads();
   PROBE(16);
-  TRACED(blockIdx.x, 1);
+  TRACED(wg, 1);
   if (threadIdx.x == 0)
   {
     u64 A = 0, B = 0;
 #pragma unroll
     for (u32 k = 0; k < kWaves; k++) { A += s_fa[k]; B += s_fb[k]; }
-    b.waveFletcher[2 * (size_t)blockIdx.x] = A % 65535u;
-    b.waveFletcher[2 * (size_t)blockIdx.x + 1] = B % 65535u;
+    if (ONE) { publish64(b.waveFletcher + 2 * (size_t)wg, A % 65535u); publish64(b.waveFletcher + 2 * (size_t)wg + 1, B % 65535u); }
+    else { b.waveFletcher[2 * (size_t)wg] = A % 65535u; b.waveFletcher[2 * (size_t)wg + 1] = B % 65535u; }
   }
 
   // ---- bit-stuffed block headers in the first `window` bytes of every chunk (+ the next workgroup's first one).
@@ -537,23 +568,25 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
       if (RAG) isCount |= zeroBytes(cur4 ^ (rc.cR * 0x01010101u)) | zeroBytes(cur4 ^ (rc.cB * 0x01010101u)) | zeroBytes(cur4 ^ (rc.cC * 0x01010101u));
       m = isCount & zeroBytes((hdr4 & 0xC0C0C0C0u) ^ 0x80808080u) & ~zeroBytes(hdr4 & 0x1F1F1F1Fu);
     }
-    // the few count bytes found (one lane in a hundred has any) go to a queue: window (5) << 11 | position
+    // the few count bytes found (one lane in a hundred has any) go to a queue: window (6) << 10 | position
     while (m)
     {
       const u32 j = (u32)(__ffs((int)m) - 1) >> 3;
       m &= m - 1u;
       const u32 at = atomicAdd(&s_nFound, 1u);
-      if (at < kFoundCap) s_found[at] = (u16)((win << 11) | (4u * d + j)); else s_over = 1u;
+      if (at < kFoundCap) s_found[at] = (u16)((win << 10) | (4u * d + j)); else s_over = 1u;
     }
   }
+  TRACED(wg, 5);
   __syncthreads();
+  TRACED(wg, 6);
   // a count byte stands 2 + (bytes of the offset) behind the block's flag byte: try each offset type, one lane each
   {
     const u32 nFound = min(s_nFound, kFoundCap);
     for (u32 h = threadIdx.x; h < 4u * nFound; h += NT)
     {
       const u32 e = s_found[h >> 2], tc = h & 3u;
-      const u32 win = e >> 11, q = e & 0x7FFu;
+      const u32 win = e >> 10, q = e & 0x3FFu;
       const u32 offB = (offBytesTable<DT>() >> (4u * tc)) & 15u;
       if (offB == 0u || q < 2u + offB) continue;
       const u32 p = q - 2u - offB;
@@ -562,7 +595,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
       const u32 flag = (s_in[rel >> 2] >> (8u * (rel & 3u))) & 0xFFu;
       if ((flag & 3u) != 1u || (flag >> 6) != tc || (v5 && (flag & 4u))) continue;
       atomicOr(&s_hits[win][p >> 5], 1u << (p & 31u));
-      if (win < NCH) { const u32 at = atomicAdd(&s_nHit, 1u); if (at < kHitCap) s_hit[at] = (u16)((win << 11) | p); else s_over = 1u; }
+      if (win < NCH) { const u32 at = atomicAdd(&s_nHit, 1u); if (at < kHitCap) s_hit[at] = (u16)((win << 10) | p); else s_over = 1u; }
     }
   }
   if (threadIdx.x == 0 && c0 * CH <= dataBegin)    // the stream's first block, whatever it is
@@ -574,7 +607,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   }
   __syncthreads();
   PROBE(17);
-  TRACED(blockIdx.x, 2);
+  TRACED(wg, 2);
 
   // ---- of the blocks found, those that are not the block right behind another one start a walk (the true path crosses
   // a window in several blocks, each of them found)
@@ -586,7 +619,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   for (u32 h = threadIdx.x; h < nHit; h += NT)
   {
     const u32 e = s_hit[h];
-    const u32 hWin = e >> 11, hPos = e & 0x7FFu;
+    const u32 hWin = e >> 10, hPos = e & 0x3FFu;
     u32 sg;
     const u32 cur = (c0 + hWin) * CH + hPos;
     const u32 len = stepLean<DT, false, RAG>(s_in, cur - r0, blobEnd - cur, v5, kNoOffset, pattern, sg, rc);
@@ -607,7 +640,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   for (u32 h = threadIdx.x; h < nHit; h += NT)
   {
     const u32 e = s_hit[h];
-    const u32 hWin = e >> 11, hPos = e & 0x7FFu;
+    const u32 hWin = e >> 10, hPos = e & 0x3FFu;
     if ((s_heads[hWin][hPos >> 5] >> (hPos & 31u)) & 1u)
     {
       u32 at = (u32)__popc(s_heads[hWin][hPos >> 5] & ((1u << (hPos & 31u)) - 1u));
@@ -619,7 +652,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
   PROBE(19);
   __syncthreads();
   PROBE(20);
-  TRACED(blockIdx.x, 3);
+  TRACED(wg, 3);
 
   // ---- walks: lane = (chunk, head); the first wave takes the first heads of every chunk (there are seldom more than two).
   // A walk ends on the first block header of the next chunk's window it lands on (or with the blob).
@@ -645,6 +678,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
     const u32 sigStep = (pattern == 14u) ? 2u : 1u;
     u32 rel = walker ? startRel + (u32)s_final[wc][slot] : kOver;
     u32 count = 0;
+    u64 acc = 0ull;    // (ONE: the block starts of the current group of four)
     LeanWords<DT> xw = leanFetch<DT>(s_in, min(rel, kMaxRel));
     u32 sig = (__builtin_amdgcn_alignbit(xw.x1, xw.x0, 8u * rel) >> 2) & pattern;
     bool active = rel < endRel;
@@ -661,7 +695,13 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
         & ((d == 0u) | (d == sigStep) | (sg == 0u));
       const bool ok = active & valid & (count < (u32)kFastListCap);
 #ifndef LERC_WALK_NOSTORE
-      if (ok) list[count] = (u16)(rel - startRel);
+      if (ONE)
+      {
+        // (four block starts leave together: two-byte write-through stores would each be a memory transaction of their own)
+        if (ok) acc |= (u64)(rel - startRel) << (16u * (count & 3u));
+        if (ok && (count & 3u) == 3u) { publish64(reinterpret_cast<u64*>(list) + (count >> 2), acc); acc = 0ull; }
+      }
+      else if (ok) list[count] = (u16)(rel - startRel);
 #endif
       rel = active ? (ok ? nxt : kOver) : rel;
       count += ok ? 1u : 0u;
@@ -669,6 +709,7 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
       active = rel < endRel;
     }
     PROBE(22);
+    if (w == 0) TRACED(wg, 7);
     bool alive = rel != kOver;
     u32 cur = r0 + rel;                                                   // (absolute from here on: a few steps at most)
     bool tooMany = count == (u32)kFastListCap;                            // (a walk that filled its list: it may have been cut short)
@@ -687,19 +728,26 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
       const bool room = count < (u32)kFastListCap;
       const bool ok = active && len != 0u && room;
       tooMany = tooMany || (active && len != 0u && !room);
-      if (ok) list[count] = (u16)(cur - wStart);
+      if (ONE)
+      {
+        if (ok) acc |= (u64)(cur - wStart) << (16u * (count & 3u));
+        if (ok && (count & 3u) == 3u) { publish64(reinterpret_cast<u64*>(list) + (count >> 2), acc); acc = 0ull; }
+      }
+      else if (ok) list[count] = (u16)(cur - wStart);
       alive = alive && (!active || ok);
       cur += ok ? len : 0u;
       count += ok ? 1u : 0u;
       sig = ok ? sg : sig;
     }
     s_exit[wc][slot] = alive ? cur : kNoOffset;
-    if (wLive) b.recs[wChunk].count[slot] = alive ? (u16)count : (u16)0xFFFFu;
+    if (ONE && (count & 3u) != 0u) publish64(reinterpret_cast<u64*>(list) + (count >> 2), acc);
+    if (ONE) S.cnt[wc][slot] = alive ? (u16)count : (u16)0xFFFFu;
+    else if (wLive) b.recs[wChunk].count[slot] = alive ? (u16)count : (u16)0xFFFFu;
     if (__any(tooMany) && lane == 0) s_over = 1u;
   }
   PROBE(21);
   __syncthreads();
-  TRACED(blockIdx.x, 4);
+  TRACED(wg, 4);
   // what all live walks of a chunk agree on
   if (threadIdx.x < NCH && c0 + threadIdx.x < nChunks)
   {
@@ -711,10 +759,26 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
       if (e != kNoOffset) { lo = min(lo, e); hi = max(hi, e); n++; }
     }
     FastChunkRec* rec = b.recs + c0 + threadIdx.x;
-    rec->exit = (n != 0u && lo == hi) ? lo : kNoOffset;
-    rec->nLive = n;
+    const u32 ex = (n != 0u && lo == hi) ? lo : kNoOffset;
+    if (ONE)
+    {
+      static_assert(sizeof(FastChunkRec) == 24 && kDiscWalks == 8, "a record is three 8-byte stores");
+      u64* dst = reinterpret_cast<u64*>(rec);
+      const u16* cn = S.cnt[threadIdx.x];
+      publish64(dst, (u64)ex | ((u64)n << 32));
+      publish64(dst + 1, (u64)cn[0] | ((u64)cn[1] << 16) | ((u64)cn[2] << 32) | ((u64)cn[3] << 48));
+      publish64(dst + 2, (u64)cn[4] | ((u64)cn[5] << 16) | ((u64)cn[6] << 32) | ((u64)cn[7] << 48));
+    }
+    else { rec->exit = ex; rec->nLive = n; }
   }
   if (threadIdx.x == 0 && s_over) raiseFlag(b, 0);
+  if (ONE)
+  {
+    // everything this workgroup leaves is on its way: wait until it has arrived, then say so
+    drainVmem();
+    __syncthreads();
+    if (threadIdx.x == 0) publish64(b.discCell + wg, ((u64)b.publishEpoch << 32) | 1u);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -723,18 +787,47 @@ fastDiscoverBody(const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCol
 // One thread per chunk.  Only the exits need agreement (they break the chunk-to-chunk dependency): once the entry of
 // a chunk is known, the walk that starts there IS the true path.  The counts are scanned inside the workgroup; the
 // gather step adds the sums of the workgroups before its own.  Workgroup 0 also folds the checksum terms.
-__device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 nWavesBound, u32 group)
+struct ResolveShared
 {
-  __shared__ u32 s_w[kResolveWG / 64];
-  __shared__ u64 s_a[kResolveWG / 64], s_b[kResolveWG / 64];
-  const FastDecodeParams hp = *b.params;
+  u32 w[kResolveWG / 64];
+  u64 a[kResolveWG / 64], b[kResolveWG / 64];
+  u32 base[kResolveWG / 64];
+};
+// (ONE: a resolving block of the one-launch decoder.  It reads the band header itself, waits for the discovery workgroups of
+// its chunks -- and of the chunk in front of them -- to say "all out", and reads what they left past the L2; the LAST
+// resolving block folds the checksum terms: it is the one that has, by way of the totals in front of it, waited for everybody)
+template<int DT, bool ONE>
+__device__ __forceinline__ void fastResolveBody(ResolveShared& S, const FastDecodeBuffers& b, u32 nWavesBound, u32 group,
+                                                const u8* __restrict__ blob = nullptr, u32 sizeGiven = 0, int nRows = 0, int nCols = 0)
+{
+  auto& s_w = S.w; auto& s_a = S.a; auto& s_b = S.b; auto& s_base = S.base;
+  constexpr u32 kDiscPer = (u32)kOneDiscChunks;
+  const FastDecodeParams hp = ONE ? parseBandHeader<DT>(blob, sizeGiven, nRows, nCols) : *b.params;
   const u32 blobEnd = hp.blobEnd;
   const u32 c = group * kResolveChunks + threadIdx.x;
-  // (the records first: their addresses do not hang on the header)
   const u32 cPrev = c ? c - 1u : 0u;
-  const u32 prevExit = b.recs[cPrev].exit;
+  u32 prevExit = 0;
+  if (!ONE) prevExit = b.recs[cPrev].exit;    // (the records first: their addresses do not hang on the header)
   if (!hp.ok || group * kResolveChunks >= hp.nChunks) return;    // (the grid is sized for the largest stream the blob could hold)
   const int lane = laneId(), w = waveId();
+  if (ONE)
+  {
+    // the discovery workgroups of chunks [first - 1, last]: one thread each
+    const u32 first = group * kResolveChunks, last = min(first + kResolveChunks, hp.nChunks) - 1u;
+    const u32 d0 = (first ? first - 1u : 0u) / kDiscPer, d1 = last / kDiscPer;
+    static_assert(kResolveChunks / kOneDiscChunks + 2 <= kResolveWG, "one thread per discovery workgroup");
+    const u32 d = d0 + threadIdx.x;
+    const bool mineD = d <= d1;
+    u64 cell = mineD ? observe64(b.discCell + d) : 0ull;
+    for (u32 spin = 0; mineD && (u32)(cell >> 32) != b.epoch && spin < b.spinLimit; spin++)
+    {
+      __builtin_amdgcn_s_sleep(8);
+      cell = observe64(b.discCell + d);
+    }
+    if (mineD && (u32)(cell >> 32) != b.epoch) raiseFlag(b, 1);    // (gave up waiting: never seen; the general path takes the band)
+    __syncthreads();
+    prevExit = (u32)observe64(reinterpret_cast<const u64*>(b.recs + cPrev));
+  }
   u32 count = 0, laneOfPath = kNoOffset;
   bool bad = false;
   const bool mine = threadIdx.x < kResolveChunks && c < hp.nChunks;
@@ -746,7 +839,16 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
     else if (e >= chunkEnd) bad = (e != blobEnd);    // the last block may begin before the last chunk and end with it
     else
     {
-      const FastChunkRec rec = b.recs[c];
+      FastChunkRec rec;
+      if (ONE)
+      {
+        const u64* src = reinterpret_cast<const u64*>(b.recs + c);
+        const u64 r0 = observe64(src), r1 = observe64(src + 1), r2 = observe64(src + 2);
+        rec.exit = (u32)r0; rec.nLive = (u32)(r0 >> 32);
+#pragma unroll
+        for (int l = 0; l < 4; l++) { rec.count[l] = (u16)(r1 >> (16 * l)); rec.count[4 + l] = (u16)(r2 >> (16 * l)); }
+      }
+      else rec = b.recs[c];
       const u32 rel = e - chunkStart;
       // the walk the entry lies on: normally a walk starts there; else it is one of the first blocks of a walk that
       // began a little earlier (something in front of the entry that looks like a block ending right there)
@@ -754,7 +856,10 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
       for (int l = 0; l < kDiscWalks; l++)
       {
         if (rec.count[l] == 0xFFFFu) continue;
-        const uint2 pre = *reinterpret_cast<const uint2*>(b.lists + ((size_t)c * kDiscWalks + l) * kFastListCap);    // its first four block starts
+        const u16* lp = b.lists + ((size_t)c * kDiscWalks + l) * kFastListCap;    // its first four block starts
+        uint2 pre;
+        if (ONE) { const u64 v = observe64(reinterpret_cast<const u64*>(lp)); pre = make_uint2((u32)v, (u32)(v >> 32)); }
+        else pre = *reinterpret_cast<const uint2*>(lp);
         const u32 st[4] = { pre.x & 0xFFFFu, pre.x >> 16, pre.y & 0xFFFFu, pre.y >> 16 };
 #pragma unroll
         for (u32 k = 0; k < 4; k++)
@@ -780,7 +885,6 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
   // publish theirs -- are read in one go (a cell is read by the few hundred resolving blocks behind it, no more)
   const u32 epoch = b.epoch;
   const u32 nGroups = (hp.nChunks + kResolveChunks - 1u) / kResolveChunks;
-  __shared__ u32 s_base[kResolveWG / 64];
   if (threadIdx.x == kResolveWG - 1) publish64(b.groupCell + group, ((u64)b.publishEpoch << 32) | (before + inc));
   u32 base = 0;
   for (u32 g0 = 0; g0 < group; g0 += kResolveWG)
@@ -805,11 +909,16 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
   // the chunks hold all the raster's blocks, or the band goes the long way
   if (group == nGroups - 1u && threadIdx.x == kResolveWG - 1 && base + before + inc != hp.nBlocks) raiseFlag(b, 2);
 
-  if (group != 0) return;
+  if (group != (ONE ? nGroups - 1u : 0u)) return;
   // checksum: Fletcher32 over blob[14 ..) from the discovery waves' partial sums (Lerc2.cpp:1037-1064)
-  const u32 nWaves = min((hp.nChunks + (u32)kDiscChunks - 1u) / (u32)kDiscChunks, nWavesBound);
+  const u32 perWave = ONE ? (u32)kOneDiscChunks : (u32)kDiscChunks;
+  const u32 nWaves = min((hp.nChunks + perWave - 1u) / perWave, nWavesBound);
   u64 A = 0, B = 0;
-  for (u32 i = threadIdx.x; i < nWaves; i += kResolveWG) { A += b.waveFletcher[2 * (size_t)i]; B += b.waveFletcher[2 * (size_t)i + 1]; }    // each < 65535
+  for (u32 i = threadIdx.x; i < nWaves; i += kResolveWG)    // each < 65535
+  {
+    if (ONE) { A += observe64(b.waveFletcher + 2 * (size_t)i); B += observe64(b.waveFletcher + 2 * (size_t)i + 1); }
+    else { A += b.waveFletcher[2 * (size_t)i]; B += b.waveFletcher[2 * (size_t)i + 1]; }
+  }
   A = waveSum(A % 65535u); B = waveSum(B % 65535u);
   if (lane == 0) { s_a[w] = A; s_b[w] = B; }
   __syncthreads();
@@ -822,7 +931,7 @@ __device__ __forceinline__ void fastResolveBody(const FastDecodeBuffers& b, u32 
   if (s1 == 0) s1 = 0xffff;
   if (s2 == 0) s2 = 0xffff;
   const u32 good = ((u32)((s2 << 16) | s1) == hp.expectChecksum) ? 1u : 0u;
-  b.params->checksumOk = good;
+  if (ONE) publish32(&b.params->checksumOk, good); else b.params->checksumOk = good;
   if (b.hostParams) b.hostParams->checksumOk = good;
 }
 
@@ -862,27 +971,38 @@ template<class T> __device__ __forceinline__ T dequant(double offset, u32 q, dou
 // beforehand (the chunks, plus the blocks a walk passed behind its chunk before it landed), so the bytes, the chunks'
 // counts and -- as soon as it is known which walk of a chunk is the path -- the walks' lists travel together; block i
 // of chunk c is block base(c) + i of the raster (base: the scan the resolve step left in pieces).
-template<class T, bool RAG>
-__device__ __forceinline__ void
-fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __restrict__ outPix, u32 wgIndex)
+template<class T, bool RAG> struct DecodeShared
 {
-  const FastDecodeParams hp = *b.params;
-  const u32 raised0 = b.fallback[0];    // (read together with the parameters: one round trip, not two)
+  static constexpr u32 CH = kFastChunkBytes, CPD = kDecodeChunks, CAP = (u32)kFastListCap;
+  static constexpr u32 TB = (u32)sizeof(T), RAW = 1 + 64 * TB, W = kFastWindow((int)sizeof(T));
+  static constexpr u32 kStageUnits = (CPD * CH + W + RAW + 16 + 15) / 16;
+  static constexpr u32 kMaxBlocks = CPD * CAP;
+  alignas(16) u32 in[kStageUnits * 4];
+  alignas(16) u16 spec[CPD][CAP];      // the list of each chunk's walk 0, fetched before anybody knows which walk is the path
+  double offs[kMaxBlocks];
+  u32 code[kMaxBlocks];                // parseCode of the block, 0 = bad
+  u32 at[kMaxBlocks];                  // raster offset (pixels) of the block's first pixel, ~0: no such block
+  u32 n[CPD + 1], first[CPD], lane[CPD], bad;
+  u16 pos[kMaxBlocks + 1];             // block starts relative to the workgroup's first byte
+  u8 dims[RAG ? kMaxBlocks : 1];       // RAG: width | height << 4 of each block (8 x 8 but for the raster's last block column / row)
+};
+
+// (ONE: a decoding workgroup of the one-launch decoder: it reads the band header itself and, once its chunks' cells are
+// there, what the discovery workgroups left past the L2 -- not before: a line read too early would stay in this XCD's L2)
+template<class T, bool RAG, bool ONE>
+__device__ __forceinline__ void
+fastDecodeBody(DecodeShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __restrict__ outPix, u32 wgIndex,
+               u32 sizeGiven = 0, int nRows = 0, int nCols = 0)
+{
+  constexpr int DT = DtOf<T>::v;
+  const FastDecodeParams hp = ONE ? parseBandHeader<DT>(blob, sizeGiven, nRows, nCols) : *b.params;
+  const u32 raised0 = ONE ? ~b.epoch : b.fallback[0];    // (read together with the parameters: one round trip, not two)
   typedef DCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
-  constexpr int DT = DtOf<T>::v;
-  constexpr u32 CH = kFastChunkBytes, CPD = kDecodeChunks, CAP = (u32)kFastListCap;
-  constexpr u32 TB = (u32)sizeof(T), RAW = 1 + 64 * TB, W = kFastWindow((int)sizeof(T));
-  constexpr u32 kStageUnits = (CPD * CH + W + RAW + 16 + 15) / 16;
-  constexpr u32 kMaxBlocks = CPD * CAP;
-  __shared__ __align__(16) u32 s_in[kStageUnits * 4];
-  __shared__ u16 s_pos[kMaxBlocks + 1];          // block starts relative to the workgroup's first byte
-  __shared__ u32 s_code[kMaxBlocks];             // parseCode of the block, 0 = bad
-  __shared__ u32 s_at[kMaxBlocks];               // raster offset (pixels) of the block's first pixel, ~0: no such block
-  __shared__ double s_offs[kMaxBlocks];
-  __shared__ u32 s_n[CPD + 1], s_first[CPD], s_lane[CPD], s_bad;
-  __shared__ u8 s_dims[RAG ? kMaxBlocks : 1];    // RAG: width | height << 4 of each block (8 x 8 but for the raster's last block column / row)
-  __shared__ __align__(16) u16 s_spec[CPD][CAP];   // the list of each chunk's walk 0, fetched before anybody knows which walk is the path
+  typedef DecodeShared<T, RAG> G;
+  constexpr u32 CH = G::CH, CPD = G::CPD, CAP = G::CAP, TB = G::TB, RAW = G::RAW, W = G::W, kStageUnits = G::kStageUnits, kMaxBlocks = G::kMaxBlocks;
+  auto& s_in = S.in; auto& s_pos = S.pos; auto& s_code = S.code; auto& s_at = S.at; auto& s_offs = S.offs;
+  auto& s_n = S.n; auto& s_first = S.first; auto& s_lane = S.lane; auto& s_bad = S.bad; auto& s_dims = S.dims; auto& s_spec = S.spec;
   const u32 blobEnd = hp.blobEnd, epoch = b.epoch;
   const struct { int nCols, version; double invScale, zMaxHdr; } p = { (int)hp.nCols, (int)hp.version, hp.invScale, hp.zMaxHdr };
   PROBE_BEGIN;
@@ -916,10 +1036,20 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
   }
   // ... walk 0's lists ...
   static_assert(CPD * CAP * 2 / 16 <= 256, "one 16-byte load per thread");
+  // (ONE: past the L2, so that a list that is not there yet leaves nothing behind in it.  Such a list is only used by a workgroup
+  // that found its cells at the first look -- they are written microseconds after the lists have arrived -- and whatever is
+  // used is checked block by block against the stream: first start == the chunk's entry, every block ends where the next begins)
   if (threadIdx.x < CPD * CAP / 8)
   {
     const u32 q = threadIdx.x / (CAP / 8), part = threadIdx.x % (CAP / 8);
-    const uint4 l = *reinterpret_cast<const uint4*>(b.lists + ((size_t)(c0 + q) * kDiscWalks) * kFastListCap + 8u * part);    // (chunks behind the last one: the buffer's slack)
+    const u16* src = b.lists + ((size_t)(c0 + q) * kDiscWalks) * kFastListCap + 8u * part;    // (chunks behind the last one: the buffer's slack)
+    uint4 l;
+    if (ONE)
+    {
+      const u64 lo = observe64(reinterpret_cast<const u64*>(src)), hi = observe64(reinterpret_cast<const u64*>(src) + 1);
+      l = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+    }
+    else l = *reinterpret_cast<const uint4*>(src);
     *reinterpret_cast<uint4*>(&s_spec[q][8u * part]) = l;
   }
   // ... and the chunks' cells: which walk is the path, how many blocks, the index of the first one (the resolving blocks of
@@ -933,14 +1063,16 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
     {
       u64 cell = observe64(b.chunkCell + 2 * (size_t)c + 1);
       firstCell = observe64(b.chunkCell + 2 * (size_t)c);
+      const bool waited = (u32)(cell >> 32) != epoch;
       for (u32 spin = 0; (u32)(cell >> 32) != epoch && spin < b.spinLimit; spin++)    // (never that long: the resolving blocks were dispatched first)
       {
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(ONE ? 16 : 4);
         cell = observe64(b.chunkCell + 2 * (size_t)c + 1);
       }
       if ((u32)(cell >> 32) != epoch) { raiseFlag(b, 3); cell = 0xFFFFull << 16; }    // (gave up waiting: never seen)
       n = (u32)cell & 0xFFFFu; ln = ((u32)cell >> 16) & 0xFFFFu;
       if (ln == 0xFFFFu) { n = 0; ln = 0; }    // (no path through this chunk: the resolving block has raised the flag)
+      if (ONE && waited) ln |= 0x4000u;         // (the list fetched at the start may have been fetched too early)
     }
     s_n[threadIdx.x] = n; s_lane[threadIdx.x] = ln;
   }
@@ -960,8 +1092,12 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
 #pragma unroll
     for (u32 k = 1; k < CPD; k++) q += (f >= cum[k]) ? 1u : 0u;
     const u32 i = f - cum[q], ls = s_lane[q];      // walk | index of the chunk's first block in its list << 8
-    const u32 src = min((ls >> 8) + i, CAP - 1u);
-    const u32 v = (ls & 7u) == 0u ? (u32)s_spec[q][src] : (u32)b.lists[((size_t)(c0 + q) * kDiscWalks + (ls & 7u)) * kFastListCap + src];
+    const u32 src = min(((ls >> 8) & 3u) + i, CAP - 1u);
+    const u16* lp = b.lists + ((size_t)(c0 + q) * kDiscWalks + (ls & 7u)) * kFastListCap + src;
+    u32 v;
+    if ((ls & 0x4007u) == 0u) v = (u32)s_spec[q][src];
+    else if (ONE) v = (u32)(observe64(reinterpret_cast<const u64*>(lp - (src & 3u))) >> (16u * (src & 3u))) & 0xFFFFu;    // (written in groups of four)
+    else v = (u32)*lp;
     s_pos[f] = (u16)(q * CH + v);
   }
   // (the end of the last block: the next chunk's entry, which is the exit its walks agreed on)
@@ -969,7 +1105,14 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
   {
     u32 last = CPD - 1;
     while (last > 0 && s_n[last] == 0u) last--;    // (a last chunk in which no block starts has no walks and no exit)
-    const u32 ex = b.recs[c0 + last].exit;
+    const u32 ex = ONE ? (u32)observe64(reinterpret_cast<const u64*>(b.recs + c0 + last)) : b.recs[c0 + last].exit;
+    if (ONE)    // the first block starts at its chunk's entry: the exit of the chunk in front (the stream's first block: behind the header)
+    {
+      u32 qf = 0;
+      while (qf < CPD - 1 && s_n[qf] == 0u) qf++;
+      const u32 entry = (c0 + qf == 0u) ? hp.dataBegin : (u32)observe64(reinterpret_cast<const u64*>(b.recs + c0 + qf - 1u));
+      if (entry != r0 + (u32)s_pos[0]) s_bad = 1u;
+    }
     s_pos[nAll] = (u16)min(ex - min(ex, r0), 0xFFFFu);
   }
   // ---- stage the bytes
@@ -1178,6 +1321,11 @@ fastDecodeBody(const FastDecodeBuffers& b, const u8* __restrict__ blob, T* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+u32 fastOneLead()
+{
+  static const u32 lead = []() -> u32 { const char* e = getenv("LERC_AMD_DECODE_LEAD"); return e ? (u32)strtoul(e, nullptr, 0) : (u32)kOneLead; }();
+  return lead;
+}
 u32 fastTestGiveUp()
 {
   static const u32 bits = []() -> u32 { const char* e = getenv("LERC_AMD_TEST_GIVEUP"); return e ? (u32)strtoul(e, nullptr, 0) : 0u; }();
@@ -1222,7 +1370,8 @@ __global__ void __launch_bounds__(kDiscThreads)
 k_fast_discover(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 sizeGiven, int nRows, int nCols)
 {
   tileSlice(b, t, blob, sizeGiven, blockIdx.y);
-  fastDiscoverBody<DT, RAG>(blob, sizeGiven, nRows, nCols, b);
+  __shared__ DiscShared<DT, (u32)kDiscChunks, (u32)kDiscThreads> sm;
+  fastDiscoverBody<DT, RAG, (u32)kDiscChunks, (u32)kDiscThreads, false>(sm, blob, sizeGiven, nRows, nCols, b, blockIdx.x);
 }
 // The first blocks of the launch resolve (kResolveChunks chunks each; all tiles' resolving blocks first, so that a batch's decode
 // workgroups find the cells of their tile ready like those of a single raster do), the others decode (kDecodeChunks chunks each).
@@ -1237,8 +1386,48 @@ k_fast_decode(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, T* __restr
   const u32 tile = rest / per, index = rest - tile * per;
   u32 sizeGiven = 0;
   tileSlice(b, t, blob, sizeGiven, tile);
-  if (resolving) fastResolveBody(b, t.nWaves, index);
-  else fastDecodeBody<T, RAG>(b, blob, outPix + (size_t)tile * t.tileElems, index);
+  __shared__ union Sm { ResolveShared r; DecodeShared<T, RAG> x; } sm;
+  if (resolving) fastResolveBody<DtOf<T>::v, false>(sm.r, b, t.nWaves, index);
+  else fastDecodeBody<T, RAG, false>(sm.x, b, blob, outPix + (size_t)tile * t.tileElems, index);
+}
+
+// The one-launch decoder (one raster): discovery, resolving and decoding workgroups in ONE grid, ordered so that whatever a
+// workgroup waits for was dispatched before it -- the discovery workgroups of the first `lead` groups (a group: the
+// kResolveChunks chunks of one resolving block), then step by step: the discovery workgroups of group s + lead, the
+// resolving block of group s, the decoding workgroups of group s - 1.  While the walks of one part of the blob -- one wave
+// per workgroup, issuing an instruction every few cycles -- are under way, the chip's other waves decode an earlier part.
+LERC_HD u32 fastOneStep() { return (kResolveChunks + kOneDiscChunks - 1u) / kOneDiscChunks + 1u + kResolveChunks / kDecodeChunks; }
+LERC_HD u32 fastOneGrid(u32 nChunksBound, u32 lead)
+{
+  const u32 nG = (nChunksBound + kResolveChunks - 1u) / kResolveChunks;
+  const u32 dps = (kResolveChunks + kOneDiscChunks - 1u) / kOneDiscChunks;
+  return min(lead, nG) * dps + (nG + 1u) * fastOneStep();
+}
+template<class T, bool RAG>
+__global__ void __launch_bounds__(256)
+k_fast_decode1(FastDecodeBuffers b, const u8* blob, u32 sizeGiven, int nRows, int nCols, T* __restrict__ outPix, u32 nChunksBound, u32 nWavesBound, u32 lead)
+{
+  constexpr int DT = DtOf<T>::v;
+  constexpr u32 DPS = (kResolveChunks + kOneDiscChunks - 1u) / kOneDiscChunks, XPS = kResolveChunks / kDecodeChunks;
+  typedef DiscShared<DT, (u32)kOneDiscChunks, 256u> DS;
+  __shared__ union Sm { DS d; ResolveShared r; DecodeShared<T, RAG> x; } sm;
+  const u32 nG = (nChunksBound + kResolveChunks - 1u) / kResolveChunks;
+  const u32 pro = min(lead, nG) * DPS;
+  if (blockIdx.x < pro)
+  {
+    fastDiscoverBody<DT, RAG, (u32)kOneDiscChunks, 256u, true>(sm.d, blob, sizeGiven, nRows, nCols, b, blockIdx.x);
+    return;
+  }
+  const u32 rest = blockIdx.x - pro, s = rest / fastOneStep(), k = rest - s * fastOneStep();
+  if (k < DPS)
+  {
+    if (s + lead < nG) fastDiscoverBody<DT, RAG, (u32)kOneDiscChunks, 256u, true>(sm.d, blob, sizeGiven, nRows, nCols, b, (s + lead) * DPS + k);
+  }
+  else if (k == DPS)
+  {
+    if (s < nG) fastResolveBody<DT, true>(sm.r, b, nWavesBound, s, blob, sizeGiven, nRows, nCols);
+  }
+  else if (s != 0u) fastDecodeBody<T, RAG, true>(sm.x, b, blob, outPix, (s - 1u) * XPS + (k - DPS - 1u), sizeGiven, nRows, nCols);
 }
 
 template<class T>
@@ -1255,6 +1444,16 @@ static void launchFastDecodeT(int stage, int nRows, int nCols, const FastDecodeB
       else
         hipLaunchKernelGGL((k_fast_discover<DT, false>), dim3(t.nWaves, nT), dim3(kDiscThreads), 0, st, b, t, blob, sizeGiven, nRows, nCols);
       break;
+    case 2:
+    {
+      const u32 nWavesOne = (t.nChunks + (u32)kOneDiscChunks - 1u) / (u32)kOneDiscChunks;
+      const u32 lead = fastOneLead();
+      if (nRows % 8 != 0 || nCols % 8 != 0)
+        hipLaunchKernelGGL((k_fast_decode1<T, true>), dim3(fastOneGrid(t.nChunks, lead)), dim3(256), 0, st, b, blob, sizeGiven, nRows, nCols, (T*)out, t.nChunks, nWavesOne, lead);
+      else
+        hipLaunchKernelGGL((k_fast_decode1<T, false>), dim3(fastOneGrid(t.nChunks, lead)), dim3(256), 0, st, b, blob, sizeGiven, nRows, nCols, (T*)out, t.nChunks, nWavesOne, lead);
+      break;
+    }
     default:
       if (nRows % 8 != 0 || nCols % 8 != 0)
         hipLaunchKernelGGL((k_fast_decode<T, true>), dim3(nT * ((t.nChunks + kResolveChunks - 1) / kResolveChunks + (t.nChunks + kDecodeChunks - 1) / kDecodeChunks)),

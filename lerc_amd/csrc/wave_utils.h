@@ -54,6 +54,7 @@ __device__ __forceinline__ void drainVmem()
 // (per XCD, not coherent) L2, so that no release fence -- which would write back every dirty line of the L2 -- is needed
 __device__ __forceinline__ void publish64(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 observe64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void publish32(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // draws an arrival ticket; true for the workgroup that draws the last of `expected` (call by ONE thread, after
 // drainVmem() + __syncthreads())
 __device__ __forceinline__ bool lastArrival(u32* ticket, u32 expected)

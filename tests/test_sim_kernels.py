@@ -662,6 +662,46 @@ print("gave up and recovered")
     assert out.returncode == 0 and b"gave up and recovered" in out.stdout, out.stdout.decode()[-2000:]
 
 
+@pytest.mark.parametrize("giveup", ["0", "2"])
+def test_sim_one_launch_decoder_behind_its_knob(libs, giveup):
+    """LERC_AMD_DECODE_LAUNCHES=1: the one-launch decoder (k_fast_decode1: discovery, resolving and decoding workgroups in one
+    grid; kept behind the knob).  Emulator builds have groups of 4 chunks, so small rasters take several steps
+    of the grid.  Same pixels as the oracle; with the hand-offs made to fail the general path takes over."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, os
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, capi, cases
+S, O = capi.sim(), capi.oracle()
+giveup = os.environ.get("LERC_AMD_TEST_GIVEUP", "0") != "0"
+rng = np.random.default_rng(12)
+for dt, e, shape in ((np.float32, 0.01, (128, 1024)), (np.uint16, 0, (128, 512)), (np.float64, 0.001, (64, 256)), (np.int32, 0, (100, 70)),
+                     (np.float32, 0.5, (257, 257)), (np.int16, 0, (8, 8))):
+    for kind in ("terrain", "mixed"):
+        x = cases._cast(cases.terrain(shape[0], shape[1], rng, amp=300, base=1000, sigma=2.0), dt) if kind == "terrain" else cases.mixed_regions(shape[0], shape[1], rng, dt)
+        r1, b1 = O.encode(x, e)
+        assert r1 == 0
+        c0 = S.path_counters()
+        d1, d2 = O.decode(b1), S.decode(b1)
+        c1 = S.path_counters()
+        assert d1[0] == d2[0] == 0 and np.array_equal(d1[1].view(np.uint8), d2[1].view(np.uint8)), ("pixels", shape, kind)
+        if giveup: assert c1[3] > c0[3], (c0, c1, shape)
+        for t in range(6):
+            y = bytearray(b1)
+            k = int(rng.integers(0, len(y)))
+            y[k] ^= 1 << int(rng.integers(0, 8))
+            d1, d2 = O.decode(bytes(y)), S.decode(bytes(y))
+            assert (d1[0] == 0) == (d2[0] == 0), ("status", shape, k)
+            if d1[0] == 0:
+                assert np.array_equal(d1[1].view(np.uint8), d2[1].view(np.uint8)), ("damaged", shape, k)
+print("one launch ok")
+""" % (capi.ROOT,)
+    env = dict(os.environ, LERC_AMD_DECODE_LAUNCHES="1", LERC_AMD_TEST_GIVEUP=giveup)
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert out.returncode == 0 and b"one launch ok" in out.stdout, out.stdout.decode()[-2000:]
+
+
 def test_sim_ragged_rasters_take_the_streaming_kernels(libs):
     """Rows / columns that are no multiples of 8: the blocks of the last block row / column hold w x h < 64 elements
     (Lerc2.cpp:1504-1519).  The one-launch encoder and the streaming decoder take such rasters (path counters), bytes and

@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/bench_variants.sh lib1.so lib2.so ...'
 for L in "$@"; do
   echo "== $L"
-  LERC_AMD_LIBRARY=$PWD/$L python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+  LERC_AMD_LIBRARY=$PWD/$L python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-c5-anchor 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('ms_per_step', d['ms_per_step'], 'verified', d['config']['verified'])

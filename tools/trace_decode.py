@@ -37,3 +37,8 @@ for name, lo, cnt, names in (("discover", 0, (n_chunks + 15) // 16, ["start->sta
     for k, nm in enumerate(names):
         d = us[:, k + 1] - us[:, k]
         print("   %-30s mean %6.2f  p50 %6.2f  p90 %6.2f" % (nm, d.mean(), np.median(d), np.percentile(d, 90)))
+    if name == "discover" and (tt[:, 5] > 0).all():
+        al = (tt[:, :8] - t0) / 100.0
+        for nm, a, b in (("  scan loop (wave 0)", 1, 5), ("  barrier behind it", 5, 6), ("  offset types + barrier", 6, 2), ("  walk inside the chunk (wave 0)", 3, 7), ("  behind the chunk + barrier", 7, 4)):
+            d = al[:, b] - al[:, a]
+            print("   %-34s mean %6.2f  p50 %6.2f  p90 %6.2f" % (nm, d.mean(), np.median(d), np.percentile(d, 90)))
