@@ -64,6 +64,15 @@ LERC_AMD_API lerc_status lerc_amd_encode_tiles_device(lerc_amd_context* ctx, con
 LERC_AMD_API lerc_status lerc_amd_decode_tiles_device(lerc_amd_context* ctx, const unsigned char* dArena,
     const unsigned long long* offsets, const unsigned int* sizes, int nTiles, int nCols, int nRows, unsigned int dataType, void* dTiles);
 
+/* The same with a slot per tile, the way a caller of lerc_encode() hands every tile a buffer of its own: tile t's blob goes to
+ * dSlots + t * slotBytes (slotBytes: a multiple of 16, the capacity of every slot), sizes[t] bytes long -- nothing is moved
+ * behind the encode kernel (the packed form costs one more pass over the blobs).  BufferTooSmall(3) if a tile's blob does
+ * not fit its slot. */
+LERC_AMD_API lerc_status lerc_amd_encode_tiles_device_slots(lerc_amd_context* ctx, const void* dTiles, unsigned int dataType, int nCols,
+    int nRows, int nTiles, double maxZErr, unsigned char* dSlots, unsigned long long slotBytes, unsigned int* sizes);
+LERC_AMD_API lerc_status lerc_amd_decode_tiles_device_slots(lerc_amd_context* ctx, const unsigned char* dSlots, unsigned long long slotBytes,
+    const unsigned int* sizes, int nTiles, int nCols, int nRows, unsigned int dataType, void* dTiles);
+
 /* Per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline of the
  * dominant kernel).  lerc_amd_profile_read writes lines "kernel_group total_ms launches" into buf. */
 LERC_AMD_API void lerc_amd_profile_enable(lerc_amd_context* ctx, int on);

@@ -62,6 +62,10 @@ def load_library():
                                                  ct.c_ulonglong, ct.c_void_p, ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
     lib.lerc_amd_decode_tiles_device.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_uint,
                                                  ct.c_void_p]
+    lib.lerc_amd_encode_tiles_device_slots.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_int, ct.c_int, ct.c_int, ct.c_double, ct.c_void_p,
+                                                       ct.c_ulonglong, ct.c_void_p]
+    lib.lerc_amd_decode_tiles_device_slots.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_ulonglong, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_uint,
+                                                       ct.c_void_p]
     lib.lerc_amd_build_info.restype = ct.c_char_p
     lib.lerc_amd_encode_device_async.argtypes = [ct.c_void_p] + enc + [ct.c_void_p, ct.c_uint, u32p]
     lib.lerc_amd_decode_device_async.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int,
@@ -69,7 +73,8 @@ def load_library():
     lib.lerc_amd_finish.argtypes = [ct.c_void_p, ct.c_uint, u32p]
     for n in ("lerc_computeCompressedSize", "lerc_encode", "lerc_getBlobInfo", "lerc_getDataRanges", "lerc_decode",
               "lerc_amd_encode_device", "lerc_amd_decode_device", "lerc_amd_encode_tiles_device", "lerc_amd_decode_tiles_device",
-              "lerc_amd_encode_device_async", "lerc_amd_decode_device_async", "lerc_amd_finish"):
+              "lerc_amd_encode_device_async", "lerc_amd_decode_device_async", "lerc_amd_finish", "lerc_amd_encode_tiles_device_slots",
+              "lerc_amd_decode_tiles_device_slots"):
         getattr(lib, n).restype = ct.c_uint
     _LIB = lib
     return lib
@@ -282,6 +287,24 @@ def encode_tiles_device(codec, tiles, max_z_err, arena):
     rc = codec.lib.lerc_amd_encode_tiles_device(codec.h, tiles.data_ptr(), _torch_dt_code(tiles), n_cols, n_rows, n_tiles, float(max_z_err),
                                                 arena.data_ptr(), arena.numel(), offsets.ctypes.data, sizes.ctypes.data, ct.byref(used))
     return rc, offsets, sizes, int(used.value)
+
+
+def encode_tiles_device_slots(codec, tiles, max_z_err, slots, slot_bytes):
+    """The same with a slot per tile: tile t's blob at slots[t * slot_bytes :] (slot_bytes: a multiple of 16), nothing is packed
+    afterwards -- the way a caller of lerc_encode() hands every tile a buffer of its own.  -> (status, sizes uint32[nTiles])"""
+    n_tiles, n_rows, n_cols = (int(v) for v in tiles.shape)
+    assert slots.numel() >= n_tiles * slot_bytes
+    sizes = np.zeros(n_tiles, np.uint32)
+    rc = codec.lib.lerc_amd_encode_tiles_device_slots(codec.h, tiles.data_ptr(), _torch_dt_code(tiles), n_cols, n_rows, n_tiles, float(max_z_err),
+                                                      slots.data_ptr(), int(slot_bytes), sizes.ctypes.data)
+    return rc, sizes
+
+
+def decode_tiles_device_slots(codec, slots, slot_bytes, sizes, out):
+    n_tiles, n_rows, n_cols = (int(v) for v in out.shape)
+    sizes = np.ascontiguousarray(sizes, np.uint32)
+    return codec.lib.lerc_amd_decode_tiles_device_slots(codec.h, slots.data_ptr(), int(slot_bytes), sizes.ctypes.data, n_tiles, n_cols, n_rows,
+                                                        _torch_dt_code(out), out.data_ptr())
 
 
 def decode_tiles_device(codec, arena, offsets, sizes, out):

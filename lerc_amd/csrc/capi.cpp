@@ -2,6 +2,7 @@
 // Argument validation and status codes follow the reference's Lerc_c_api_impl.cpp:33-304; host
 // buffers are staged through HBM, all codec work happens in codec_encode.cpp / codec_decode.cpp.
 #include "../../include/lerc_amd.h"
+#include "../../include/lerc_amd_device.h"
 #include "codec.h"
 
 #include <sys/syscall.h>
@@ -11,6 +12,7 @@
 #include <cstdio>
 #include <deque>
 #include <new>
+#include <vector>
 
 using namespace lerc;
 
@@ -598,6 +600,35 @@ lerc_status lerc_amd_encode_tiles_device(lerc_amd_context* h, const void* dTiles
   const u32 rc = encodeTilesDevice(h->ctx, rq, used);
   if (arenaUsed) *arenaUsed = used;
   return rc;
+}
+
+lerc_status lerc_amd_encode_tiles_device_slots(lerc_amd_context* h, const void* dTiles, unsigned int dataType, int nCols, int nRows, int nTiles,
+  double maxZErr, unsigned char* dSlots, unsigned long long slotBytes, unsigned int* sizes)
+{
+  if (!h || !dTiles || !dSlots || !sizes || dataType >= DT_Undefined || nCols <= 0 || nRows <= 0 || nTiles <= 0 || maxZErr < 0
+    || slotBytes == 0 || (slotBytes & 15u) != 0)
+    return kWrongParam;
+  if (!dimsOk(1, nCols, nRows, (size_t)dtSize((int)dataType))) return kDimsTooLarge;
+  std::vector<u64> offsets((size_t)nTiles);
+  TilesEncodeRequest rq;
+  rq.dData = dTiles; rq.dt = (int)dataType; rq.nCols = nCols; rq.nRows = nRows; rq.nTiles = nTiles; rq.maxZErr = maxZErr;
+  rq.dArena = dSlots; rq.arenaCapacity = (u64)nTiles * slotBytes; rq.hOffsets = offsets.data(); rq.hSizes = sizes; rq.slotBytes = slotBytes;
+  u64 used = 0;
+  return encodeTilesDevice(h->ctx, rq, used);
+}
+
+lerc_status lerc_amd_decode_tiles_device_slots(lerc_amd_context* h, const unsigned char* dSlots, unsigned long long slotBytes,
+  const unsigned int* sizes, int nTiles, int nCols, int nRows, unsigned int dataType, void* dTiles)
+{
+  if (!h || !dSlots || !sizes || !dTiles || dataType >= DT_Undefined || nCols <= 0 || nRows <= 0 || nTiles <= 0 || slotBytes == 0 || (slotBytes & 15u) != 0)
+    return kWrongParam;
+  if (!dimsOk(1, nCols, nRows, (size_t)dtSize((int)dataType))) return kDimsTooLarge;
+  std::vector<u64> offsets((size_t)nTiles);
+  for (int t = 0; t < nTiles; t++) offsets[(size_t)t] = (u64)t * slotBytes;
+  TilesDecodeRequest rq;
+  rq.dArena = dSlots; rq.hOffsets = offsets.data(); rq.hSizes = sizes; rq.dt = (int)dataType; rq.nCols = nCols; rq.nRows = nRows; rq.nTiles = nTiles;
+  rq.dOut = dTiles;
+  return decodeTilesDevice(h->ctx, rq);
 }
 
 lerc_status lerc_amd_decode_tiles_device(lerc_amd_context* h, const unsigned char* dArena, const unsigned long long* offsets,

@@ -149,6 +149,7 @@ struct TilesEncodeRequest
   u64 arenaCapacity = 0;
   u64* hOffsets = nullptr;            // host [nTiles]: where tile t's blob starts in the arena (16-byte aligned)
   u32* hSizes = nullptr;              // host [nTiles]
+  u64 slotBytes = 0;                  // != 0: tile t's blob goes to dArena + t * slotBytes (a multiple of 16), nothing is moved afterwards
 };
 struct TilesDecodeRequest
 {

@@ -1039,8 +1039,9 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
 {
   arenaUsed = 0;
   if (!rq.dData || !rq.dArena || !rq.hOffsets || !rq.hSizes || rq.nTiles <= 0 || rq.nRows <= 0 || rq.nCols <= 0 || rq.dt < 0 || rq.dt > DT_Double
-    || rq.maxZErr < 0)
+    || rq.maxZErr < 0 || (rq.slotBytes & 15u) != 0)
     return kWrongParam;
+  const bool slotted = rq.slotBytes != 0;    // every tile has its place: no arena to fill front to back
   const int tb = dtSize(rq.dt);
   const u64 tileElems = (u64)rq.nRows * (u64)rq.nCols;
   // (tiles whose sides are no multiples of 8 -- 257 x 257 elevation tiles -- go through the one-launch encoder's ragged form, pixel by
@@ -1053,13 +1054,13 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
 
   auto encodeOne = [&](int t) -> u32
   {
-    end = (end + 15) & ~15ull;
+    end = slotted ? (u64)t * rq.slotBytes : (end + 15) & ~15ull;
     EncodeRequest one;
     one.dData = (const u8*)rq.dData + (size_t)t * tileElems * tb;
     one.dt = rq.dt; one.nDepth = 1; one.nCols = rq.nCols; one.nRows = rq.nRows; one.nBands = 1; one.nMasks = 0; one.dValidBytes = nullptr;
     one.maxZErr = rq.maxZErr;
     one.dOut = rq.dArena + end;
-    one.outCapacity = (u32)std::min<u64>(rq.arenaCapacity > end ? rq.arenaCapacity - end : 0, 0xFFFFFFFFull);
+    one.outCapacity = (u32)std::min<u64>(slotted ? rq.slotBytes : (rq.arenaCapacity > end ? rq.arenaCapacity - end : 0), 0xFFFFFFFFull);
     u32 needed = 0, written = 0;
     const u32 rc = encodeDevice(ctx, one, needed, written);
     if (rc != kOk) return rc;
@@ -1068,10 +1069,11 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
     return kOk;
   };
 
-  if (!fastOk)
+  if (slotted && rq.arenaCapacity < (u64)rq.nTiles * rq.slotBytes) return kBufferTooSmall;
+  if (!fastOk || (slotted && !fastEncodeOneLaunch()))
   {
     for (int t = 0; t < rq.nTiles; t++) { const u32 rc = encodeOne(t); if (rc != kOk) return rc; }
-    arenaUsed = end;
+    arenaUsed = slotted ? (u64)rq.nTiles * rq.slotBytes : end;
     return kOk;
   }
 
@@ -1083,16 +1085,16 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
     // size: a tile that needs more is encoded by itself afterwards), then the tiles are placed and moved into the arena
     const u32 nWGt = fastFusedNumWG(rq.dt, rq.nRows, rq.nCols);
     const size_t cellWords = fastFusedCellWords(nWGt), counterWords = fastFusedCounterWords(nWGt);
-    const u64 slotBytes = ((tileElems * tb / 2 + 4096) + 15) & ~15ull;
+    const u64 slotBytes = slotted ? rq.slotBytes : ((tileElems * tb / 2 + 4096) + 15) & ~15ull;
     const int maxBatch = (int)std::max<size_t>(1, std::min<size_t>((size_t)rq.nTiles, ((size_t)2 << 30) / slotBytes));
     const bool isFlt = rq.dt >= DT_Float;
     for (int t0 = 0; t0 < rq.nTiles; t0 += maxBatch)
     {
       const int n = std::min(maxBatch, rq.nTiles - t0);
-      if (!ctx.reserve((size_t)n * (slotBytes + sizeof(FastEncodeResult) + 8) + (1u << 16))) return kFailed;
+      if (!ctx.reserve((size_t)n * ((slotted ? 0 : slotBytes) + sizeof(FastEncodeResult) + 8) + (1u << 16))) return kFailed;
       u8* cells = ctx.persistentState(1, (size_t)n * cellWords * 8 + 256);
       u8* counters = ctx.persistentState(0, (size_t)n * counterWords * 8 + 256);
-      u8* slots = ctx.allocT<u8>((size_t)n * slotBytes);
+      u8* slots = slotted ? rq.dArena + (size_t)t0 * slotBytes : ctx.allocT<u8>((size_t)n * slotBytes);
       FastEncodeResult* dRes = ctx.allocT<FastEncodeResult>(n);
       u64* dOff = ctx.allocT<u64>((size_t)n + 1);
       if (!cells || !counters || !slots || !dRes || !dOff) return kFailed;
@@ -1133,6 +1135,7 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
         ProfScope ps(ctx, "fast_encode1");
         launchFastEncode(0, fl.bp, fl.maxZErr, fl.cand, (const u8*)rq.dData + (size_t)t0 * tileElems * tb, slots, slotBytes, 0, fl.fb, fl.batch, st);
       }
+      if (!slotted)
       {
         ProfScope ps(ctx, "fast_tile_move");
         launchFastTileCopy(dRes, dOff, slots, slotBytes, slotBytes, rq.dArena, (u32)n, end, rq.arenaCapacity, st);
@@ -1142,7 +1145,7 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
       u8* pin = (u8*)ctx.pinned(resBytes + offBytes);
       if (!pin) return kFailed;
       hipMemcpyAsync(pin, dRes, resBytes, hipMemcpyDeviceToHost, st);
-      hipMemcpyAsync(pin + resBytes, dOff, offBytes, hipMemcpyDeviceToHost, st);
+      if (!slotted) hipMemcpyAsync(pin + resBytes, dOff, offBytes, hipMemcpyDeviceToHost, st);
       if (!ctx.sync()) return kFailed;
       if (ctx.profOn()) ctx.profCollect();
       const FastEncodeResult* res = reinterpret_cast<const FastEncodeResult*>(pin);
@@ -1154,19 +1157,19 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
         if (res[i].redo || res[i].stuck)
         {
           anyStuck = anyStuck || res[i].stuck != 0;
-          if (res[i].redoReason & 128u) return kBufferTooSmall;    // the arena is full
-          redo.push_back(t0 + i);
+          if (!slotted && (res[i].redoReason & 128u)) return kBufferTooSmall;    // the arena is full
+          redo.push_back(t0 + i);    // (slotted: a tile that does not fit its slot says so when it is encoded by itself)
           continue;
         }
-        rq.hOffsets[t0 + i] = off[i];
+        rq.hOffsets[t0 + i] = slotted ? (u64)(t0 + i) * slotBytes : off[i];
         rq.hSizes[t0 + i] = res[i].blobSize;
         ctx.pathCount[0]++;
       }
       if (anyStuck) ctx.wipePersistentState();
-      end = off[n];
+      if (!slotted) end = off[n];
       for (int t : redo) { const u32 rc = encodeOne(t); if (rc != kOk) return rc; }    // (reuses the workspace: the batch is done with it)
     }
-    arenaUsed = end;
+    arenaUsed = slotted ? (u64)rq.nTiles * slotBytes : end;
     return kOk;
   }
 

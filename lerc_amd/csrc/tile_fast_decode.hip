@@ -1000,7 +1000,7 @@ fastDecodeBody(DecodeShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __
   typedef DCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
   typedef DecodeShared<T, RAG> G;
-  constexpr u32 CH = G::CH, CPD = G::CPD, CAP = G::CAP, TB = G::TB, RAW = G::RAW, W = G::W, kStageUnits = G::kStageUnits, kMaxBlocks = G::kMaxBlocks;
+  constexpr u32 CH = G::CH, CPD = G::CPD, CAP = G::CAP, kStageUnits = G::kStageUnits;
   auto& s_in = S.in; auto& s_pos = S.pos; auto& s_code = S.code; auto& s_at = S.at; auto& s_offs = S.offs;
   auto& s_n = S.n; auto& s_first = S.first; auto& s_lane = S.lane; auto& s_bad = S.bad; auto& s_dims = S.dims; auto& s_spec = S.spec;
   const u32 blobEnd = hp.blobEnd, epoch = b.epoch;

@@ -283,6 +283,40 @@ def test_elevation_tile_batch_257(P, O):
     assert codec.path_counters()[0] == n_tiles and codec.path_counters()[2] == n_tiles, codec.path_counters()
 
 
+@pytest.mark.parametrize("shape", [(256, 256), (257, 257)])
+def test_tile_batches_with_a_slot_per_tile(P, O, shape):
+    """lerc_amd_encode_tiles_device_slots: every tile's blob written straight into its slot (t * slotBytes) by the encode kernel --
+    no packing pass -- and decoded from there; blobs are the per-tile oracle blobs, both ways on the streaming kernels."""
+    import torch
+    from lerc_amd import api, synth
+    dev = torch.device("cuda:0")
+    r, c = shape
+    n_tiles = 96
+    big = synth.c2_float32(r * 8, c * 12, virt_cols=65536, device=dev)
+    tiles = big.reshape(8, r, 12, c).permute(0, 2, 1, 3).contiguous().reshape(n_tiles, r, c)
+    codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
+    slot = (r * c * 4 // 2 + 4096 + 15) // 16 * 16
+    slots = torch.full((n_tiles * slot,), 0xEE, dtype=torch.uint8, device=dev)
+    rc, sizes = api.encode_tiles_device_slots(codec, tiles, 0.01, slots, slot)
+    assert rc == 0, (rc, codec.last_error())
+    sh = slots.cpu().numpy()
+    th = tiles.cpu().numpy()
+    for t in (0, 1, 50, n_tiles - 1):
+        r1, b1 = O.encode(th[t], 0.01)
+        assert r1 == 0 and sh[t * slot:t * slot + int(sizes[t])].tobytes() == b1, t
+    out = torch.empty_like(tiles)
+    rc = api.decode_tiles_device_slots(codec, slots, slot, sizes, out)
+    assert rc == 0, (rc, codec.last_error())
+    torch.cuda.synchronize()
+    for t in (0, 50, n_tiles - 1):
+        want = O.decode(sh[t * slot:t * slot + int(sizes[t])].tobytes())
+        assert np.array_equal(want[1].reshape(r, c), out[t].cpu().numpy())
+    assert codec.path_counters()[0] == n_tiles and codec.path_counters()[2] == n_tiles, codec.path_counters()
+    # slots too small for the blobs
+    rc, _ = api.encode_tiles_device_slots(codec, tiles, 0.01, slots, 1024)
+    assert rc == 3
+
+
 def test_nodata_values(P, O):
     """lerc_encode_4D / lerc_decode_4D with per-band noData values, differential against the real reference (or the
     oracle): sizes, blobs, decoded pixels, masks and the noData values handed back."""

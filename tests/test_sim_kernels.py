@@ -324,6 +324,62 @@ def test_sim_tile_batches(libs):
         L.lerc_amd_destroy(h)
 
 
+def test_sim_tile_batches_with_a_slot_per_tile(libs):
+    """lerc_amd_encode_tiles_device_slots / decode_tiles_device_slots: tile t's blob at t * slotBytes, written there by the
+    encode kernel itself (no packing pass); bytes are the per-tile call's, tiles the streaming kernels hand back are redone
+    into their slot, a tile that does not fit its slot is BufferTooSmall."""
+    import ctypes as ct
+    O, S = libs
+    L = S.lib
+    L.lerc_amd_create.restype = ct.c_void_p
+    L.lerc_amd_create.argtypes = [ct.c_void_p]
+    L.lerc_amd_destroy.argtypes = [ct.c_void_p]
+    L.lerc_amd_encode_tiles_device_slots.restype = ct.c_uint
+    L.lerc_amd_encode_tiles_device_slots.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_int, ct.c_int, ct.c_int, ct.c_double, ct.c_void_p,
+                                                     ct.c_ulonglong, ct.c_void_p]
+    L.lerc_amd_decode_tiles_device_slots.restype = ct.c_uint
+    L.lerc_amd_decode_tiles_device_slots.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_ulonglong, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_uint,
+                                                     ct.c_void_p]
+    h = L.lerc_amd_create(None)
+    assert h
+    rng = np.random.default_rng(41)
+    try:
+        for dt, e in ((np.float32, 0.01), (np.uint16, 0), (np.float64, 0.05)):
+            for (r, c, n_t) in ((256, 256, 5), (64, 128, 6), (24, 40, 3), (20, 44, 3), (257, 257, 3), (33, 65, 5)):
+                tiles = np.stack([cases._cast(cases.terrain(r, c, rng, amp=300, base=1000 + 10 * t, sigma=1.5), dt) for t in range(n_t)])
+                if n_t >= 5:
+                    tiles[2] = tiles[2].flat[0]
+                    if np.dtype(dt).kind == "f":
+                        tiles[3] = np.rint(tiles[3])
+                src = _aligned(tiles.nbytes).view(dt).reshape(tiles.shape)
+                src[...] = tiles
+                slot = (tiles[0].nbytes + 256 + 15) // 16 * 16
+                slots = _aligned(n_t * slot)
+                slots[...] = 0xEE
+                sizes = np.zeros(n_t, np.uint32)
+                rc = L.lerc_amd_encode_tiles_device_slots(h, src.ctypes.data, capi.dt_code(dt), c, r, n_t, float(e), slots.ctypes.data, slot, sizes.ctypes.data)
+                assert rc == 0
+                for t in range(n_t):
+                    r1, b1 = O.encode(tiles[t], e)
+                    assert r1 == 0 and slots[t * slot:t * slot + int(sizes[t])].tobytes() == b1, (np.dtype(dt).name, r, c, t)
+                out = _aligned(tiles.nbytes).view(dt).reshape(tiles.shape)
+                rc = L.lerc_amd_decode_tiles_device_slots(h, slots.ctypes.data, slot, sizes.ctypes.data, n_t, c, r, capi.dt_code(dt), out.ctypes.data)
+                assert rc == 0
+                for t in range(n_t):
+                    want = O.decode(slots[t * slot:t * slot + int(sizes[t])].tobytes())
+                    assert _same(want[1].reshape(r, c), out[t])
+        # slots that are too small for the blobs, a slot size that is no multiple of 16
+        tiles = np.stack([cases.terrain(64, 128, rng).astype(np.float32) for _ in range(4)])
+        src = _aligned(tiles.nbytes).view(np.float32).reshape(tiles.shape)
+        src[...] = tiles
+        slots = _aligned(4 * 1024)
+        sizes = np.zeros(4, np.uint32)
+        assert L.lerc_amd_encode_tiles_device_slots(h, src.ctypes.data, 6, 128, 64, 4, 0.01, slots.ctypes.data, 1024, sizes.ctypes.data) == 3
+        assert L.lerc_amd_encode_tiles_device_slots(h, src.ctypes.data, 6, 128, 64, 4, 0.01, slots.ctypes.data, 1000, sizes.ctypes.data) == 2
+    finally:
+        L.lerc_amd_destroy(h)
+
+
 def test_sim_bit_plane_mode(libs):
     """maxZErr == 777: Lerc2::TryBitPlaneCompression picks the error bound from neighbour XOR statistics
     (Lerc2.cpp:1071-1229) -- all integer types, with a mask, with nDepth > 1, too few pixels, float (refused)."""

@@ -59,6 +59,25 @@ def main():
     px = tiles.numel()
     print(f"batched : {n_tiles} tiles, blobs {used} B; encode {(t1 - t0) / reps * 1e3:.3f} ms, decode {(t2 - t1) / reps * 1e3:.3f} ms, "
           f"round trip {px / ((t2 - t0) / reps) / 1e6:.0f} MPix/s")
+    # a slot per tile: the encode kernel writes every blob where it stays (no packing pass)
+    slot = (256 * 256 * 4 // 2 + 4096 + 15) // 16 * 16
+    mze = float(os.environ.get("MZE", "0.01"))
+    for _ in range(2):
+        rc, sz = api.encode_tiles_device_slots(codec, tiles, mze, arena, slot)
+        assert rc == 0 and api.decode_tiles_device_slots(codec, arena, slot, sz, out) == 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rc, sz = api.encode_tiles_device_slots(codec, tiles, mze, arena, slot)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        api.decode_tiles_device_slots(codec, arena, slot, sz, out)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    assert float((out - tiles).abs().max()) <= mze * 1.01
+    print(f"slotted : {n_tiles} tiles, a slot of {slot} B each; encode {(t1 - t0) / reps * 1e3:.3f} ms, decode {(t2 - t1) / reps * 1e3:.3f} ms, "
+          f"round trip {px / ((t2 - t0) / reps) / 1e6:.0f} MPix/s")
     one = torch.empty(256 * 256 * 4 + 4096, dtype=torch.uint8, device=dev)
     y = torch.empty_like(tiles[0])
     m = min(n_tiles, 256)
