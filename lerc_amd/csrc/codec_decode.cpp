@@ -80,7 +80,7 @@ static bool fastDecodeOneLaunch();    // LERC_AMD_DECODE_LAUNCHES=1: the one-lau
 
 static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven, u32 nTiles = 1)
 {
-  const FastWalkPlan wp = makeFastWalkPlan(nRows, nCols, sizeGiven);
+  const FastWalkPlan wp = makeFastWalkPlan(nRows, nCols, sizeGiven, nTiles);
   const size_t perTile = (size_t)wp.nChunks * (sizeof(FastChunkRec) + (size_t)kDiscWalks * kFastListCap * 2 + 12) + (size_t)wp.nBlocks * 4
     + (size_t)(wp.nChunks / kOneDiscChunks + 1) * 16 + (size_t)(wp.nChunks / kResolveWG + 2) * 4 + 4096 + kResolveWG * sizeof(FastChunkRec);
   return perTile * nTiles + (size_t)kDecodeChunks * kDiscWalks * kFastListCap * 2 + (1u << 16);
@@ -93,10 +93,10 @@ static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8
                             const u32* dTileSize, void* dOut, FastDecodeParams* dParams, u32* dFallback, u32 epoch, u8* hCell = nullptr)
 {
   hipStream_t st = ctx.activeStream();
-  const FastWalkPlan fwp = makeFastWalkPlan(nRows, nCols, sizeBound);
+  const FastWalkPlan fwp = makeFastWalkPlan(nRows, nCols, sizeBound, nTiles);
   const size_t nT = nTiles, sChunk = fastChunkStride(fwp.nChunks);
   FastDecodeBatch tb;
-  tb.nTiles = nTiles; tb.nChunks = fwp.nChunks; tb.nBlocks = fwp.nBlocks; tb.nWaves = fwp.nWaves;
+  tb.nTiles = nTiles; tb.nChunks = fwp.nChunks; tb.nBlocks = fwp.nBlocks; tb.nWaves = fwp.nWaves; tb.discChunks = fwp.discChunks;
   tb.tileElems = (u64)nRows * (u64)nCols; tb.tileOffset = dTileOffset; tb.tileSize = dTileSize;
   FastDecodeBuffers fbuf;
   fbuf.recs = ctx.allocT<FastChunkRec>(nT * fwp.nChunks + kResolveWG);    // (+ what the resolve step's unconditional loads may touch)

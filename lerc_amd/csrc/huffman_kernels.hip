@@ -222,6 +222,16 @@ void launchHuffHisto(int dt, const void* data, const u8* maskBits, const HuffGeo
 static const int kHuffSpanWords = 10240;
 static const int kHuffStageBatch = 8;
 
+#if defined(LERC_PROBE) && !defined(HIPSIM)
+// tuning: per-workgroup time lines (constant-rate counter) of the packing kernel, read by tools/trace_huff.py
+static __device__ unsigned long long g_traceH[8 * 8192];
+extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_huff(unsigned long long* out, int n)
+{ hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_traceH), sizeof(unsigned long long) * (size_t)n); }
+#define TRACEH(slot) do { if (PACK && threadIdx.x == 0 && blockIdx.x < 8192u) g_traceH[8 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
+#else
+#define TRACEH(slot)
+#endif
+
 template<class T, bool PACK, int RUN>
 __global__ void __launch_bounds__(256)
 k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffGeom g, int mode, const u64* __restrict__ codes,
@@ -233,6 +243,7 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
   static_assert(RUN == 128 || RUN == 64, "elements per thread");
   __shared__ u32 s_span[PACK ? kHuffSpanWords * RUN / 128 : 1];
   __shared__ u64 s_wave[4], s_base;
+  TRACEH(0);
   s_codes[threadIdx.x] = codes[threadIdx.x];
   const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
   const i64 nRuns = (n + RUN - 1) / RUN;
@@ -296,6 +307,7 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
     }
   }
   __syncthreads();
+  TRACEH(1);
   const i64 run = (i64)blockIdx.x * 256 + threadIdx.x;
   const i64 v0 = run * RUN;
   const bool active = v0 < n;
@@ -334,6 +346,7 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
     for (int d = 1; d < 64; d <<= 1) { const u64 t = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += t; }
     if (lane == 63) s_wave[wv] = inc;
     __syncthreads();
+    TRACEH(2);
     u64 before = 0;
     for (int k = 0; k < wv; k++) before += s_wave[k];
     const u64 total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
@@ -374,6 +387,7 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
     inLds = spanWords <= (u32)(kHuffSpanWords * RUN / 128);
     if (inLds) for (u32 x = threadIdx.x; x < spanWords; x += 256) s_span[x] = 0u;
     __syncthreads();
+    TRACEH(3);
   }
   else if (active) pos = runBase[run];
   if (active)
@@ -409,12 +423,14 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
   }
   if (!inLds) return;    // (uniform over the workgroup)
   __syncthreads();
+  TRACEH(4);
   for (u32 x = threadIdx.x; x < spanWords; x += 256)
   {
     const u32 word = s_span[x];
     if (x == 0u || x + 1u == spanWords) { if (word) atomicOr(&stream[spanWord0 + x], word); }
     else stream[spanWord0 + x] = word;
   }
+  TRACEH(5);
 }
 
 void launchHuffRunBits(int dt, const void* data, const u8* maskBits, const HuffGeom& g, int mode, const u64* codes, u32* runBits,

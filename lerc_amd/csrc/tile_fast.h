@@ -220,7 +220,7 @@ static const int kDiscWalks = 8;           // walks per chunk (path heads among 
 #ifndef LERC_DISC_CHUNKS
 #define LERC_DISC_CHUNKS 16
 #endif
-static const int kDiscChunks = LERC_DISC_CHUNKS;    // chunks per workgroup of k_fast_discover: 8 or 16 (16 threads each; 8 is 8 % slower)
+static const int kDiscChunks = LERC_DISC_CHUNKS;    // chunks per workgroup of k_fast_discover: 16 (16 threads each; 8 is 8 % slower on one large raster; batches of small blobs: makeFastWalkPlan)
 static const int kDiscThreads = (int)((u32)kDiscChunks * kFastChunkBytes / 128u);    // 16 threads per 2 KiB
 #ifndef LERC_LIST_CAP
 #define LERC_LIST_CAP 128
@@ -246,7 +246,7 @@ static const u32 kDecodeChunks = LERC_DECODE_CHUNKS;        // chunks whose bloc
 constexpr u32 kFastWindow(int typeBytes) { return 2u + 64u * (u32)typeBytes; }
 
 // sizes the host can bound without reading the blob (grids and buffers); the true values are in FastDecodeParams
-struct FastWalkPlan { u32 nChunks, nBlocks, nWaves; };
+struct FastWalkPlan { u32 nChunks, nBlocks, nWaves, discChunks; };    // discChunks: chunks per discovery workgroup of this launch
 
 // what the header parse leaves for the other kernels, and what the host reads back at the end
 struct FastDecodeParams
@@ -301,6 +301,7 @@ struct FastDecodeBatch
 {
   u32 nTiles;
   u32 nChunks, nBlocks, nWaves;      // per tile; nChunks / nWaves are upper bounds (largest blob of the batch)
+  u32 discChunks;                    // chunks per discovery workgroup: kDiscChunks, or half of it (see makeFastWalkPlan)
   u64 tileElems;                     // pixels from one tile's output to the next
   const u64* tileOffset;             // device [nTiles]: start of each blob in the arena; nullptr: `blob` itself
   const u32* tileSize;               // device [nTiles]
@@ -309,7 +310,7 @@ LERC_HD u32 fastChunkStride(u32 nChunks) { return nChunks + 4u; }    // chunk ce
 LERC_HD u32 fastGroupStride(u32 nChunks) { return (nChunks + kResolveChunks - 1u) / kResolveChunks + 1u; }    // group cells per tile
 
 bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid);
-FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven);
+FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven, u32 nTiles = 1);
 static const int kFastDecodeStages = 2;    // one kernel each: discover (+ header + checksum terms), resolve + decode
 void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
                       const FastDecodeBuffers& b, void* out, hipStream_t st);
