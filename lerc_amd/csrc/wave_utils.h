@@ -290,22 +290,30 @@ __device__ __forceinline__ void scanSingleWorkgroup(const u32* __restrict__ in, 
 }
 
 // Fletcher32 terms (Lerc2.cpp:1037-1064) of one 16-byte unit whose first byte is byte 2 * k0 of the checksummed range
-// blob[14 ..): the checksum works on big-endian 16-bit words w, A = sum w, B = sum index * w.  Bytes at even positions
-// weigh 256: four byte dot products per dword, the word index inside the unit (0 .. 7) rides in the weights.
+// blob[14 ..): the checksum works on big-endian 16-bit words w, A = sum w, B = sum index * w.  Per dword: the bytes of both
+// halves swapped (one v_perm), then two dot products of 16-bit pairs -- the words themselves, and the words weighted with
+// their index inside the unit (0 .. 7): 12 instructions a unit (byte dot products with even / odd masks took 16 + 6).
+__device__ __forceinline__ u32 dot2u16(u32 a, u32 b, u32 c)
+{
+#ifdef HIPSIM
+  return lercsim_udot2(a, b, c);
+#else
+  typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+  u16x2_t x, y;
+  __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
+  return __builtin_amdgcn_udot2(x, y, c, false);
+#endif
+}
 __device__ __forceinline__ void fletcherUnit(const uint4& x, u64 k0, u32& A, u64& B)
 {
-  u32 ae = 0, ao = 0, be = 0, bo = 0;
-  ae = __builtin_amdgcn_udot4(x.x, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.x, 0x01000100u, ao, false);
-  be = __builtin_amdgcn_udot4(x.x, 0x00010000u, be, false); bo = __builtin_amdgcn_udot4(x.x, 0x01000000u, bo, false);
-  ae = __builtin_amdgcn_udot4(x.y, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.y, 0x01000100u, ao, false);
-  be = __builtin_amdgcn_udot4(x.y, 0x00030002u, be, false); bo = __builtin_amdgcn_udot4(x.y, 0x03000200u, bo, false);
-  ae = __builtin_amdgcn_udot4(x.z, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.z, 0x01000100u, ao, false);
-  be = __builtin_amdgcn_udot4(x.z, 0x00050004u, be, false); bo = __builtin_amdgcn_udot4(x.z, 0x05000400u, bo, false);
-  ae = __builtin_amdgcn_udot4(x.w, 0x00010001u, ae, false); ao = __builtin_amdgcn_udot4(x.w, 0x01000100u, ao, false);
-  be = __builtin_amdgcn_udot4(x.w, 0x00070006u, be, false); bo = __builtin_amdgcn_udot4(x.w, 0x07000600u, bo, false);
-  const u32 a = 256u * ae + ao;    // < 2^19
+  const u32 w0 = __builtin_amdgcn_perm(x.x, x.x, 0x02030001u), w1 = __builtin_amdgcn_perm(x.y, x.y, 0x02030001u);
+  const u32 w2 = __builtin_amdgcn_perm(x.z, x.z, 0x02030001u), w3 = __builtin_amdgcn_perm(x.w, x.w, 0x02030001u);
+  u32 a = dot2u16(w0, 0x00010001u, 0u), bw = dot2u16(w0, 0x00010000u, 0u);
+  a = dot2u16(w1, 0x00010001u, a); bw = dot2u16(w1, 0x00030002u, bw);
+  a = dot2u16(w2, 0x00010001u, a); bw = dot2u16(w2, 0x00050004u, bw);
+  a = dot2u16(w3, 0x00010001u, a); bw = dot2u16(w3, 0x00070006u, bw);    // a < 2^19, bw < 2^21
   A += a;
-  B += k0 * a + (256u * be + bo);
+  B += k0 * a + bw;
 }
 
 // first error wins

@@ -255,6 +255,15 @@ inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 32; i++
 inline unsigned __funnelshift_r(unsigned lo, unsigned hi, unsigned sh) { return (unsigned)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
 inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
 // v_dot4_u32_u8: sum of the four byte products + c
+// (the two 16-bit halves of a and b multiplied pairwise: the product forms of fletcherUnit in wave_utils.h)
+inline unsigned lercsim_udot2(unsigned a, unsigned b, unsigned c) { return (a & 0xFFFFu) * (b & 0xFFFFu) + (a >> 16) * (b >> 16) + c; }
+inline unsigned __builtin_amdgcn_perm(unsigned a, unsigned b, unsigned sel)
+{
+  const uint64_t both = ((uint64_t)a << 32) | b;
+  unsigned r = 0;
+  for (int i = 0; i < 4; i++) r |= (unsigned)((both >> (8 * ((sel >> (8 * i)) & 7u))) & 0xFFu) << (8 * i);
+  return r;
+}
 inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool)
 {
   for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
