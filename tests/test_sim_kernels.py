@@ -14,9 +14,13 @@ import cases
 
 @pytest.fixture(scope="module")
 def libs():
+    import fcntl
     csrc = os.path.join(capi.ROOT, "lerc_amd", "csrc")
-    subprocess.check_call(["make", "-s", "-C", csrc, "sim", "-j8"])
-    subprocess.check_call(["make", "-s", "-C", os.path.join(capi.ROOT, "oracle")])
+    os.makedirs(os.path.join(capi.ROOT, "tests", "_sim"), exist_ok=True)
+    with open(os.path.join(capi.ROOT, "tests", "_sim", ".build.lock"), "w") as lock:    # (pytest-xdist workers: one make at a time)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "-C", csrc, "sim", "-j8"])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(capi.ROOT, "oracle")])
     return capi.oracle(), capi.sim()
 
 
