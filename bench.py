@@ -196,6 +196,9 @@ def measured_ceiling(torch, x, y, reps=10):
             "ms": round(best, 5), "GBps": round(nbytes / (best / 1e3) / 1e9, 1)}
 
 
+TILE_SLOT_BYTES = (256 * 256 * 4 // 2 + 4096 + 15) // 16 * 16    # a buffer per 256 x 256 float32 tile, as a caller of lerc_encode() would size it for lossy floats
+
+
 def c5_single_gpu(torch, api, synth, codec, dev, max_z_err, total_tiles, steps=3, warmup=1):
     """All tiles of the mosaic on ONE GPU (the N = 1 anchor of `bench.py --gpus N`'s strong-scaling curve): batched encode +
     batched decode per step, in slabs of 8192 tiles (what one rank of eight holds) so that the buffers stay at 2 GB each."""
@@ -210,7 +213,7 @@ def c5_single_gpu(torch, api, synth, codec, dev, max_z_err, total_tiles, steps=3
         del big
     out = torch.empty(xs[0].numel() * 4 + slab * 256, dtype=torch.uint8, device=dev)
     y = torch.empty_like(xs[0])
-    slot_bytes = (256 * 256 * 4 // 2 + 4096 + 15) // 16 * 16    # a buffer per tile, as a caller of lerc_encode() would size it for lossy floats
+    slot_bytes = TILE_SLOT_BYTES
     n_pix = total_tiles * 65536
 
     def one_pass(slots):
@@ -247,12 +250,13 @@ def c5_single_gpu(torch, api, synth, codec, dev, max_z_err, total_tiles, steps=3
                 "verified": bool(err <= max_z_err * (1 + 1e-6) + 6.2e-5)}
 
     res = {"tiles": total_tiles}
-    res.update(timed(False))
-    res["note"] = ("the whole 65 536-tile mosaic on one GPU, %d batched calls of %d tiles each way per step, blobs packed into one arena "
-                   "(what the ranks of a multi-GPU job gather), no gather" % (n_slabs, slab))
-    res["slot_per_tile"] = timed(True)
-    res["slot_per_tile"]["note"] = ("the same with a buffer of %d bytes per tile (lerc_amd_encode_tiles_device_slots): the encode kernel writes "
-                                    "every blob where it stays, no packing pass" % slot_bytes)
+    res.update(timed(True))
+    res["note"] = ("the whole 65 536-tile mosaic on one GPU, %d batched calls of %d tiles each way per step, a buffer of %d bytes per tile "
+                   "(lerc_amd_encode_tiles_device_slots: the encode kernel writes every blob where it stays) -- what `--workload c5` "
+                   "runs on one GPU; no exchange step" % (n_slabs, slab, slot_bytes))
+    res["packed"] = timed(False)
+    res["packed"]["note"] = ("the same with the blobs packed into one arena (lerc_amd_encode_tiles_device: one more pass over the blobs) -- "
+                             "what every rank of a multi-GPU job does before the gather")
     return res
 
 
@@ -315,6 +319,17 @@ def main():
 
     def step(k=0):
         x, out, y = sets[k]
+        if tiles_mode and world == 1:
+            # one GPU, no exchange step: every tile's blob stays in a slot of its own (a buffer per tile, as with lerc_encode());
+            # the ranks of a multi-GPU job pack theirs into an arena, which is what the gather sends
+            rc, sizes = api.encode_tiles_device_slots(codec, x, args.max_z_err, out, TILE_SLOT_BYTES)
+            if rc != 0:
+                raise RuntimeError(f"tile encode failed: status {rc}: {codec.last_error()}")
+            state["blob_bytes"] = int(sizes.sum())
+            rc = api.decode_tiles_device_slots(codec, out, TILE_SLOT_BYTES, sizes, y)
+            if rc != 0:
+                raise RuntimeError(f"tile decode failed: status {rc}: {codec.last_error()}")
+            return
         if tiles_mode:
             rc, offs, sizes, used = api.encode_tiles_device(codec, x, args.max_z_err, out)
             if rc != 0:
@@ -497,7 +512,9 @@ def main():
                       + (f" sharded across {world} GPUs, RCCL gather of the blobs" if world > 1 else " (batched calls, 1 GPU)"))
             wl = (f"{total_tiles} tiles of 256x256 float32, MaxZError={args.max_z_err}: {sets[0][0].shape[0]} per rank, one batched encode call, "
                   + ("gather of the compressed blobs on rank 0 (lengths all-gather + grouped send/recv over RCCL), " if world > 1 else "")
-                  + "one batched decode call per rank")
+                  + "one batched decode call per rank"
+                  + ("" if world > 1 else f"; every tile's blob in a slot of {TILE_SLOT_BYTES} bytes (a buffer per tile; the ranks of a multi-GPU job "
+                                          "pack theirs into one arena for the gather)"))
         else:
             metric = "MPix/s encode+decode round-trip, 8192^2 float32 MaxZError=0.01"
             wl = (f"{n}x{n} float32 1-band, MaxZError={args.max_z_err}, lerc encode+decode on HBM-resident data"

@@ -699,14 +699,16 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
     u8* dCells = ctx.allocT<u8>(cellsBytes);
     u64* dOff = ctx.allocT<u64>((size_t)n + 1);
     u32* dSize = ctx.allocT<u32>((size_t)n + 1);
-    u8* pin = (u8*)ctx.pinned(std::max(cellsBytes, (size_t)n * 12 + 64));
-    if (!dCells || !dOff || !dSize || !pin) return kFailed;
-    u64* hOff = reinterpret_cast<u64*>(pin);
-    u32* hSize = reinterpret_cast<u32*>(pin + (size_t)n * 8);
+    // (pinned: the tables on their way up, then -- a region of its own, so that nobody has to wait in between -- the verdicts' way back)
+    const size_t upBytes = ((size_t)n * 12 + 64 + 63) & ~(size_t)63;
+    u8* pinUp = (u8*)ctx.pinned(upBytes + cellsBytes);
+    if (!dCells || !dOff || !dSize || !pinUp) return kFailed;
+    u8* pin = pinUp + upBytes;
+    u64* hOff = reinterpret_cast<u64*>(pinUp);
+    u32* hSize = reinterpret_cast<u32*>(pinUp + (size_t)n * 8);
     for (int i = 0; i < n; i++) { hOff[i] = rq.hOffsets[t0 + i]; hSize[i] = rq.hSizes[t0 + i]; }
     hipMemcpyAsync(dOff, hOff, (size_t)n * 8, hipMemcpyHostToDevice, st);
     hipMemcpyAsync(dSize, hSize, (size_t)n * 4, hipMemcpyHostToDevice, st);
-    if (!ctx.sync()) return kFailed;    // the pinned mirror is reused for the read-back below
     FastDecodeParams* dParams = reinterpret_cast<FastDecodeParams*>(dCells + 64);
     u32* dFallback = reinterpret_cast<u32*>(dCells + 64 + (size_t)n * sizeof(FastDecodeParams));
     const u32 epoch = ctx.nextEpoch();

@@ -1351,7 +1351,9 @@ FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven, u32 nTiles)
   // raster is 8 % faster with the full ones
   const u32 full = (u32)kDiscChunks, half = full / 2u;
   const u32 slotsFull = (wp.nChunks + full - 1) / full * full, slotsHalf = (wp.nChunks + half - 1) / half * half;
+  static const int force = []() { const char* e = getenv("LERC_AMD_DISC_CHUNKS"); return e ? atoi(e) : 0; }();    // tuning knob: 8 or 16
   wp.discChunks = (nTiles > 1 && slotsHalf < slotsFull) ? half : full;
+  if (force == (int)half || force == (int)full) wp.discChunks = (u32)force;
   wp.nWaves = (wp.nChunks + wp.discChunks - 1) / wp.discChunks;
   return wp;
 }
