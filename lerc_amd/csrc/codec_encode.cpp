@@ -204,6 +204,32 @@ static u32 filterNoData(Context& ctx, const EncodeRequest& rq, int iBand, NoData
   return kOk;
 }
 
+// ------------------------------------------------------------------------------------------------
+// streaming kernels: buffers + launches for nTiles rasters of one shape (a single raster is nTiles == 1)
+// ------------------------------------------------------------------------------------------------
+struct FastEncodeLaunch
+{
+  FastEncodeBuffers fb;
+  FastBatch batch;
+  BandParams bp;
+  u32 cand;
+  double maxZErr;
+};
+
+// LERC_AMD_MASKED_STREAMING=0: masked bands keep the general kernels for their block stream (a test / tuning knob)
+static bool maskedStreamingOn()
+{
+  static const bool on = []() { const char* e = getenv("LERC_AMD_MASKED_STREAMING"); return !(e && atoi(e) == 0); }();
+  return on;
+}
+
+// LERC_AMD_ENCODE_LAUNCHES=2 keeps the two-launch form (statistics, then scan + pack) for a single raster: a tuning / test knob
+static bool fastEncodeOneLaunch()
+{
+  static const bool one = []() { const char* e = getenv("LERC_AMD_ENCODE_LAUNCHES"); return !(e && e[0] == '2'); }();
+  return one;
+}
+
 static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskState& ms, std::vector<u8>& prevByteValid,
                       bool& anyMaskModified, u8* dBandOut, u32 capacityLeft, u32& bandBytes)
 {
@@ -548,10 +574,70 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   u32* dOffsets = nullptr;
   u32* dScratch = nullptr;
   const int nPos8 = ((nRows + 7) / 8) * ((nCols + 7) / 8);
+  // A band with a validity mask, one value per pixel, whole 8 x 8 blocks, a type of 16 bits or more: its block stream is made by
+  // the one-launch encoder's masked form (tile_fast.hip) -- straight into the band's place behind mask and ranges, with the band's
+  // FINAL parameters, all decisions about the band having been made above -- instead of tile_sizes + scan + tile_write.  If the band
+  // ends up coded another way (16 x 16 blocks, one sweep) that writer comes later in the stream and overwrites it.
+  // dStreamed: that stream is in place; a launch that gave up waiting (never seen) leaves the band to the three kernels.
+  u8* dStreamed = nullptr;
+  u32 nBytesStreamed = 0;
+  bool streamedTried = false;
+  auto streamMasked = [&]() -> bool    // false: an error (not: "not applicable")
+  {
+    if (streamedTried) return true;
+    streamedTried = true;
+    const bool eligible = maskedStreamingOn() && dBits && !bp.allValid && nD == 1 && nRows % 8 == 0 && nCols % 8 == 0 && hd.version == kCodecVersion
+      && dt != DT_Char && dt != DT_Byte && !hd.tryHuffmanInt() && !hd.tryHuffmanFlt() && !nd.active && !bp.tryDiff && fastEncodeOneLaunch() && fastDimsOkRagged(nRows, nCols)
+      && ((uintptr_t)dData & 15) == 0 && (!dBandOut || ((uintptr_t)dBandOut & 15) == 0) && (u64)nPix * tb + (u64)nPos8 + 8192 < 0xFFFFFFFFull;
+    if (!eligible) return true;
+    if (!codeMask()) return false;    // (the mask's length says where the block stream begins; the statistics kernels have covered its coding)
+    const u32 nWGt = fastFusedNumWG(dt, nRows, nCols);
+    const size_t cellWords = fastFusedCellWords(nWGt), counterWords = fastFusedCounterWords(nWGt);
+    const u64 cap = capacityLeft;
+    const u32 payloadAt = (u32)(headerBytes(hd.version) + 4 + rle.size() + 2 * (size_t)tb + 1);    // header, mask, ranges, "not one sweep"
+    u8* cells = ctx.persistentState(1, cellWords * 8 + 256);
+    u8* counters = ctx.persistentState(0, counterWords * 8 + 256);
+    u8* dWs = dBandOut;    // (a size query: no payloads, no stores)
+    FastEncodeResult* dRes = ctx.allocT<FastEncodeResult>(1);
+    FastEncodeResult* hRes = (FastEncodeResult*)ctx.pinned(sizeof(FastEncodeResult));
+    if (!cells || !counters || (dBandOut && !dWs) || !dRes || !hRes) return false;
+    FastEncodeLaunch fl;
+    memset(&fl.fb, 0, sizeof(fl.fb));
+    const u32 nG = fastFusedGroups(nWGt), nPG = fastPackGroups(nWGt);
+    FastFused& f = fl.fb.fused;
+    f.sizeCell = (u64*)cells; f.baseCell = f.sizeCell + nWGt; f.totalCell = f.baseCell + nG; f.raise = f.totalCell + nG;
+    f.packPart = (u64*)counters; f.keyPart = f.packPart + nPG + 1;
+    f.nWG = nWGt; f.nTiles = 1; f.cellStride = (u32)cellWords; f.counterStride = (u32)counterWords;
+    f.tileElems = (u64)nPix; f.outStride = cap;
+    f.maskBits = dBits; f.payloadAt = payloadAt;
+    f.epoch = ctx.nextEpoch();
+    f.publishEpoch = (fastTestGiveUp() & 1u) ? f.epoch ^ 0x5A5A5A5Au : f.epoch;
+    f.spinLimit = (fastTestGiveUp() & 1u) ? 8u : (1u << 22);
+    fl.fb.result = dRes;
+    fl.batch.nTiles = 1; fl.batch.nWG = nWGt; fl.batch.tileElems = (u64)nPix; fl.batch.nBlobsMore = 0;
+    BandParams sp = bp;
+    sp.mb = 8; sp.nTV = nRows / 8; sp.nTH = nCols / 8;
+    (void)hipGetLastError();
+    hipMemsetAsync(dRes, 0, sizeof(FastEncodeResult), st);
+    { ProfScope ps(ctx, "masked_encode1"); launchFastEncode(0, sp, maxZErr, 0, dData, dWs, cap, 0, fl.fb, fl.batch, st); }
+    if (hipGetLastError() != hipSuccess) { ctx.lastError = "lerc_amd: a streaming encode kernel could not be launched"; return false; }
+    hipMemcpyAsync(hRes, dRes, sizeof(FastEncodeResult), hipMemcpyDeviceToHost, st);
+    if (!sync.wait()) return false;
+    if (hRes->stuck) { ctx.wipePersistentState(); return true; }    // (the three kernels take the band)
+    nBytesStreamed = hRes->nBytesTiling;    // (a stream that does not fit the buffer was cut off inside it; the size check below says BufferTooSmall)
+    dStreamed = dWs ? dWs + payloadAt : reinterpret_cast<u8*>(dRes);    // (size query: only != nullptr counts)
+    ctx.lastNote = "masked band: block stream by the one-launch encoder";
+    return true;
+  };
   auto tilingBytes = [&](int mb, u32& total) -> bool
   {
     bp.mb = mb; bp.nTV = (nRows + mb - 1) / mb; bp.nTH = (nCols + mb - 1) / mb;
     const u32 nPos = (u32)bp.nTV * (u32)bp.nTH;
+    if (mb == 8)
+    {
+      if (!streamMasked()) return false;
+      if (dStreamed) { total = nBytesStreamed; return codeMask(); }
+    }
     if (mb == 8 && spec.sizesFresh)    // priced behind the statistics already (see above): dSizes / dOffsets hold the result
     {
       spec.sizesFresh = false;
@@ -675,7 +761,11 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   hipMemcpyAsync(dBandOut, prefix, at, hipMemcpyHostToDevice, st);
   u8* dPayload = dBandOut + at;
 
-  if (payload == P_TILING)
+  if (payload == P_TILING && dStreamed && hd.mbSize == 8)    // (in place since streamMasked)
+  {
+    if (dStreamed != dPayload) { ctx.lastError = "lerc_amd: the masked band's block stream is not where the band's sections end"; return kFailed; }
+  }
+  else if (payload == P_TILING)
   {
     ProfScope ps(ctx, "tile_write");
     launchTileWrite(dt, hd.mbSize, dData, dBits, bp, dOffsets, dPayload, dStatus, st);
@@ -722,25 +812,6 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   if (hr.status.error) { ctx.lastError = "device kernel reported an error"; return hr.status.error; }
   if (ctx.profOn()) ctx.profCollect();
   return kOk;
-}
-
-// ------------------------------------------------------------------------------------------------
-// streaming kernels: buffers + launches for nTiles rasters of one shape (a single raster is nTiles == 1)
-// ------------------------------------------------------------------------------------------------
-struct FastEncodeLaunch
-{
-  FastEncodeBuffers fb;
-  FastBatch batch;
-  BandParams bp;
-  u32 cand;
-  double maxZErr;
-};
-
-// LERC_AMD_ENCODE_LAUNCHES=2 keeps the two-launch form (statistics, then scan + pack) for a single raster: a tuning / test knob
-static bool fastEncodeOneLaunch()
-{
-  static const bool one = []() { const char* e = getenv("LERC_AMD_ENCODE_LAUNCHES"); return !(e && e[0] == '2'); }();
-  return one;
 }
 
 static size_t fastEncodeWorkspace(int nRows, int nCols, u32 nTiles)

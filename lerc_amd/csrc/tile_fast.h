@@ -99,6 +99,8 @@ struct FastFused
   u32 nWG;             // workgroups per raster (fastFusedUnits units of 64 blocks each)
   // a batch of nTiles rasters of one shape (blockIdx.y = tile): every tile has its own set of the arrays above, cellStride /
   // counterStride words apart, reads its pixels tileElems apart and writes its blob into a slot of its own, outStride bytes apart
+  const u8* maskBits;      // != nullptr: the band's validity bits (k_fast_encode1<.., MASKED>)
+  u32 payloadAt;           // MASKED: where the block stream begins in `out` (header, mask, ranges and the sweep flag in front of it are the host's)
   u32 nTiles, cellStride, counterStride;
   u64 tileElems, outStride;
 };

@@ -1403,8 +1403,16 @@ fusedFinish(u32 nBytesTiling, u32 prefixLen, u8* __restrict__ out, u64 outCapaci
 // PART: rows or columns are no multiples of 8 -- the blocks of the raster's last block row / column are w x h pixels
 // (w, h < 8), Lerc2.cpp:1504-1519.  A lane then holds a PREFIX of its V pixels (or none), a block's element count is
 // w * h instead of 64, and an element's place in the block's bit stream is its row-major index among the w * h.
-template<class T, bool WIDE, int U, bool PART>
-__global__ void __launch_bounds__(256, (sizeof(T) <= 4 ? 8 : 1)) LERC_SGPR_CAP
+// MASKED: the band has a validity mask (f.maskBits, a bit per pixel as BitMask keeps them).  A lane holds ANY subset of its V
+// pixels, a block its valid pixels only -- 0 .. 64 of them, in row-major order (Lerc2::GetValidDataAndStats' masked branch,
+// Lerc2.cpp:1765-1792: the first valid pixel is not compared with a "value before") -- an element's place in the block's bit
+// stream is its rank among them, and a block without a valid pixel is one byte.  The general path runs this form for the block
+// stream of masked bands once all decisions about the band are made (codec_encode.cpp); header, mask and checksum are its.
+template<class T, bool WIDE, int U, bool PART, bool MASKED = false>
+#ifndef LERC_MASKED_WAVES
+#define LERC_MASKED_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, (sizeof(T) <= 4 ? (MASKED ? LERC_MASKED_WAVES : 8) : 1)) LERC_SGPR_CAP    // (MASKED at 64 registers: 208 bytes of scratch a lane)
 k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, FastEncodeResult* __restrict__ res, u32 nWG, u32 nBlobsMore,
                 FastFused f, double requestedMaxZErr, u32 raiseCandidates, u64 outCapacity)
 {
@@ -1431,6 +1439,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   __shared__ u64 s_fa[4], s_fb[4], s_kmx[U], s_kmn[U];
   __shared__ u32 s_len[U], s_base, s_retry;
   static_assert(!(PART && WIDE), "ragged rasters take the per-block mapping");
+  static_assert(!(MASKED && (WIDE || PART)), "masked bands: whole blocks, per-block mapping");
 
   const u32 nGroups = (nWG + kFusedGroup - 1u) / kFusedGroup, nPackGroups = fastPackGroups(nWG);
   if (f.nTiles > 1u)    // a batch: this tile's pixels, cells, counters, result and slot
@@ -1458,15 +1467,25 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   T v[U][IT][V];
   // PART: pixels of this lane that exist (a prefix of its V: 0 .. V) and the width of its block, per wave tile
   int vcA[U][IT], bwA[U][IT];
+  u32 vmA[U][IT];    // MASKED: bit k = pixel k of the lane is valid
+  const u64 blockLanes = (LB == 64) ? ~0ull : (((1ull << (LB & 63)) - 1ull) << (b * LB)), earlierLanes = laneMaskLt() & blockLanes;
 #pragma unroll
   for (int a = 0; a < U; a++)
 #pragma unroll
     for (int t = 0; t < IT; t++)
     {
+      vmA[a][t] = (1u << V) - 1u;
       if constexpr (!PART)
       {
         vcA[a][t] = V; bwA[a][t] = 8;
-        loadLane<T, V>(data + laneOrigin<WIDE, BPW, V>(span[a], t * 4 + w, r, c, p.nCols), v[a][t], true);
+        const i64 at = laneOrigin<WIDE, BPW, V>(span[a], t * 4 + w, r, c, p.nCols);
+        loadLane<T, V>(data + at, v[a][t], true);
+        if constexpr (MASKED)
+        {
+          // (columns are multiples of 8 and a lane's first column one of V: its V bits lie in one byte, most significant first)
+          const u32 byte = f.maskBits[at >> 3];
+          vmA[a][t] = (__brev((byte << ((u32)at & 7u)) & 0xFFu) >> 24) & ((1u << V) - 1u);
+        }
       }
       else
       {
@@ -1498,18 +1517,26 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       const int tile = t * 4 + w;
       const T (&x)[V] = v[a][t];
       const int vc = vcA[a][t];    // (V unless PART; pixels that do not exist were loaded as 0: neither NaN nor fractional)
+      const u32 vm = vmA[a][t];    // (all ones unless MASKED)
       if (DT >= DT_Float)
       {
 #pragma unroll
-        for (int k = 0; k < V; k++) if (isNaNv(x[k])) flags |= 1u;
+        for (int k = 0; k < V; k++) if ((!MASKED || ((vm >> k) & 1u)) && isNaNv(x[k])) flags |= 1u;
         if (!(flags & 2u))    // one fractional value settles "not all integers" for good
         {
 #pragma unroll
-          for (int k = 0; k < V; k++) if (notIntegral(x[k])) flags |= 2u;
+          for (int k = 0; k < V; k++) if ((!MASKED || ((vm >> k) & 1u)) && notIntegral(x[k])) flags |= 2u;
         }
       }
       T mn, mx;
-      if constexpr (!PART)
+      if constexpr (MASKED)
+      {
+        mn = std::numeric_limits<T>::has_infinity ? std::numeric_limits<T>::infinity() : std::numeric_limits<T>::max();
+        mx = std::numeric_limits<T>::has_infinity ? -std::numeric_limits<T>::infinity() : std::numeric_limits<T>::lowest();
+#pragma unroll
+        for (int k = 0; k < V; k++) if ((vm >> k) & 1u) { mn = OpMin()(mn, x[k]); mx = OpMax()(mx, x[k]); }
+      }
+      else if constexpr (!PART)
       {
         mn = x[0]; mx = x[0];
 #pragma unroll
@@ -1530,7 +1557,26 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       }
       // "same as previous" in row-major block order, prevVal starts at 0 (Lerc2.cpp:1729-1758)
       int same, nElem = 64;
-      if constexpr (!PART)
+      if constexpr (MASKED)
+      {
+        // the valid pixel in front of this lane's first valid one: the last valid pixel of the nearest lane before it in
+        // the block that holds any (lanes of a block are in row-major order); the block's first valid pixel has none
+        T lastMine = T(0);
+#pragma unroll
+        for (int k = 0; k < V; k++) if ((vm >> k) & 1u) lastMine = x[k];
+        const u64 have = __ballot(vm != 0u) & earlierLanes;
+        const int src = have ? 63 - __clzll((long long)have) : lane;
+        T pv = shflT<T>(lastMine, src);
+        bool seen = have != 0ull;
+        same = 0;
+#pragma unroll
+        for (int k = 0; k < V; k++)
+          if ((vm >> k) & 1u) { same += (seen && x[k] == pv) ? 1 : 0; pv = x[k]; seen = true; }
+        nElem = 0;
+#pragma unroll
+        for (int k = 0; k < V; k++) nElem += __popcll(__ballot((vm >> k) & 1u) & blockLanes);
+      }
+      else if constexpr (!PART)
       {
         T prev = (T)dppMovT<kDppWaveShr1>((ST)x[V - 1]);    // the previous pixel vector of the block lives in the previous lane
         if (leader) prev = T(0);
@@ -1555,7 +1601,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         nElem = groupReduce<LB>(vc, OpSum());
       }
       u32 nd = 0;
-      if (PART || __any(same > 32 / LB))
+      if (PART || MASKED || __any(same > 32 / LB))
       {
         same = groupReduce<LB>(same, OpSum());
         const bool tryLut = (nElem > 4) && (2 * same > nElem) && ((double)mx > (double)mn + 3 * p.maxZErr);
@@ -1569,6 +1615,11 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
           {
 #pragma unroll
             for (int k = 0; k < V; k++) if (k >= vc) q[k] = 0xFFFFFFFFu;    // (no such pixel: never the smallest value left)
+          }
+          if constexpr (MASKED)
+          {
+#pragma unroll
+            for (int k = 0; k < V; k++) if (!((vm >> k) & 1u)) q[k] = 0xFFFFFFFFu;
           }
           nd = groupDistinct<LB, V>(q, need);
         }
@@ -1707,7 +1758,14 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       const int kind = sizeOnly ? 7 : (int)((w1 >> 16) & 7u);
       const u32 at0 = s_bit[a][blk] + bitBase;
       const int vc = vcA[a][t];
-      const int e0 = PART ? r * bwA[a][t] + h * V : r * 8 + h * V;    // first element of this lane in the block's row-major order
+      int e0 = PART ? r * bwA[a][t] + h * V : r * 8 + h * V;    // first element of this lane in the block's row-major order
+      const u32 vm = vmA[a][t];
+      if constexpr (MASKED)    // ... its rank among the block's valid pixels
+      {
+        e0 = 0;
+#pragma unroll
+        for (int k = 0; k < V; k++) e0 += __popcll(__ballot((vm >> k) & 1u) & earlierLanes);
+      }
       if (kind == 3)
       {
         const int nb = (int)(w1 >> 24);
@@ -1721,7 +1779,24 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
           for (int k = 0; k < V; k++) if (k >= vc) q[k] = 0u;    // (no such pixel: no bits)
         }
         const u32 at = at0 + 8u * (3u + (u32)offBytes);
-        if (V * nb <= 64)
+        if constexpr (MASKED)
+        {
+          // the lane's valid values, closed up
+          int rk = 0;
+          if (V * nb <= 64)
+          {
+            u64 s = 0;
+#pragma unroll
+            for (int k = 0; k < V; k++) if ((vm >> k) & 1u) { s |= (u64)q[k] << (rk * nb); rk++; }
+            if (rk) orBits64(s_out, at + (u32)e0 * (u32)nb, s, rk * nb);
+          }
+          else
+          {
+#pragma unroll
+            for (int k = 0; k < V; k++) if ((vm >> k) & 1u) { orBits64(s_out, at + (u32)(e0 + rk) * (u32)nb, (u64)q[k], nb); rk++; }
+          }
+        }
+        else if (V * nb <= 64)
         {
           // (nb <= 16 here for V >= 4: pairs fit a 32-bit word, one 64-bit shift in all instead of one per value)
           u64 s = 0;
@@ -1747,9 +1822,19 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       }
       else if (kind == 1)
       {
+        if constexpr (MASKED)
+        {
+          int rk = 0;
 #pragma unroll
-        for (int k = 0; k < V; k++)
-          if (!PART || k < vc) orBits64(s_out, at0 + 8u + (u32)(e0 + k) * 8u * (u32)sizeof(T), rawBits<T>(v[a][t][k]), 8 * (int)sizeof(T));
+          for (int k = 0; k < V; k++)
+            if ((vm >> k) & 1u) { orBits64(s_out, at0 + 8u + (u32)(e0 + rk) * 8u * (u32)sizeof(T), rawBits<T>(v[a][t][k]), 8 * (int)sizeof(T)); rk++; }
+        }
+        else
+        {
+#pragma unroll
+          for (int k = 0; k < V; k++)
+            if (!PART || k < vc) orBits64(s_out, at0 + 8u + (u32)(e0 + k) * 8u * (u32)sizeof(T), rawBits<T>(v[a][t][k]), 8 * (int)sizeof(T));
+        }
       }
       // LUT blocks (kind 4): all blocks of the wave take part in the group reductions
       if (__any(kind == 4))
@@ -1764,6 +1849,11 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         {
 #pragma unroll
           for (int k = 0; k < V; k++) if (k >= vc) q[k] = 0xFFFFFFFFu;    // (no such pixel: never the smallest value left, index bits 0)
+        }
+        if constexpr (MASKED)
+        {
+#pragma unroll
+          for (int k = 0; k < V; k++) if (!((vm >> k) & 1u)) q[k] = 0xFFFFFFFFu;
         }
         const u32 nElemB = s_same[a][blk] >> 16;
         const int nb = (int)(w1 >> 24);
@@ -1796,9 +1886,19 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
           if (leader) orBits(s_out, hdr, (u32)nb | (2u << 6) | 32u | (nElemB << 8) | ((nLut + 1) << 16), 24);
           const u32 idxAt = lutAt + 8u * ((nLut * (u32)nb + 7) >> 3);
           u64 s = 0;
+          if constexpr (MASKED)
+          {
+            int rk = 0;
 #pragma unroll
-          for (int k = 0; k < V; k++) s |= (u64)idx[k] << (k * nbIdx);    // nbIdx <= 6
-          orBits64(s_out, idxAt + (u32)e0 * (u32)nbIdx, s, V * nbIdx);
+            for (int k = 0; k < V; k++) if ((vm >> k) & 1u) { s |= (u64)idx[k] << (rk * nbIdx); rk++; }
+            if (rk) orBits64(s_out, idxAt + (u32)e0 * (u32)nbIdx, s, rk * nbIdx);
+          }
+          else
+          {
+#pragma unroll
+            for (int k = 0; k < V; k++) s |= (u64)idx[k] << (k * nbIdx);    // nbIdx <= 6
+            orBits64(s_out, idxAt + (u32)e0 * (u32)nbIdx, s, V * nbIdx);
+          }
         }
       }
     }
@@ -1853,7 +1953,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
     }
     else __syncthreads();    // (the image is complete)
     const u32 segLen = together ? lenAll : len[a];
-    fusedFlush(s_out, kLead, prefixLen + spanBase + flushed, segLen, out, outCapacity, fA, fB);
+    fusedFlush(s_out, kLead, (MASKED ? f.payloadAt : prefixLen) + spanBase + flushed, segLen, out, outCapacity, fA, fB);    // (MASKED: behind the band's real sections, which the host writes)
     flushed += segLen;
   }
   fusedArrive(fA, fB, s_fa, s_fb, s_fl, wg, wPlan, f);
@@ -1932,7 +2032,7 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
 {
   const u32 nWG = batch.nWG, nT = batch.nTiles;
   const bool wide = p.nTH % 64 == 0;
-  if (b.fused.sizeCell && (out || p.nRows % 8 != 0 || p.nCols % 8 != 0))    // one raster, one launch
+  if (b.fused.sizeCell && (out || p.nRows % 8 != 0 || p.nCols % 8 != 0 || b.fused.maskBits))    // one raster, one launch
   {
     if (stage != 0) return;
     const u32 nW = b.fused.nWG;
@@ -1941,7 +2041,9 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
 #define LERC_U32 2
 #endif
     constexpr int U = sizeof(T) == 2 ? 3 : LERC_U32;
-    if (p.nRows % 8 != 0 || p.nCols % 8 != 0)
+    if (b.fused.maskBits)    // (whole-block rasters only: the caller sees to that)
+      hipLaunchKernelGGL((k_fast_encode1<T, false, U, false, true>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
+    else if (p.nRows % 8 != 0 || p.nCols % 8 != 0)
       hipLaunchKernelGGL((k_fast_encode1<T, false, U, true>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
     else if (wide)
       hipLaunchKernelGGL((k_fast_encode1<T, true, U, false>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);

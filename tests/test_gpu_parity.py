@@ -317,6 +317,38 @@ def test_tile_batches_with_a_slot_per_tile(P, O, shape):
     assert rc == 3
 
 
+def test_masked_bands_take_the_one_launch_encoder(P, O):
+    """Bands with a validity mask: the block stream comes from the one-launch encoder's masked form (the note says so), written in
+    place behind the band's mask and ranges; bytes are the oracle's, for blob-shaped masks, salt-and-pepper masks, masks that
+    leave whole block rows empty and a single valid pixel."""
+    rng = np.random.default_rng(21)
+    for dt, e, shape in ((np.float32, 0.01, (1024, 1536)), (np.uint16, 0, (512, 1024)), (np.float64, 0.001, (256, 512)), (np.int32, 2, (640, 640))):
+        r, c = shape
+        x = cases._cast(cases.terrain(r, c, rng, amp=300, base=1000, sigma=2.0), dt)
+        for style in range(4):
+            m = np.ones((r, c), np.uint8)
+            if style == 0:
+                for _ in range(12):
+                    i0, j0 = int(rng.integers(0, r)), int(rng.integers(0, c))
+                    m[i0:i0 + int(rng.integers(1, 200)), j0:j0 + int(rng.integers(1, 300))] = 0
+            elif style == 1:
+                m = (rng.random((r, c)) > 0.05).astype(np.uint8)
+            elif style == 2:
+                m[: r // 2] = 0
+                m[:, ::7] = 0
+            else:
+                m[:] = 0
+                m[r // 3, c // 5] = 1
+                m[r - 1, :] = 1
+            r1, b1 = O.encode(x, e, mask=m)
+            r2, b2 = P.encode(x, e, mask=m)
+            assert r1 == r2 == 0 and b1 == b2, (np.dtype(dt).name, style)
+            assert "one-launch encoder" in P.last_note(), P.last_note()
+            d1, d2 = O.decode(b1), P.decode(b1)
+            assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1]) and _same(d1[2], d2[2])
+        assert O.encode(x, e, mask=m, buf_size=len(b1) - 1)[0] == P.encode(x, e, mask=m, buf_size=len(b1) - 1)[0] == 3
+
+
 def test_nodata_values(P, O):
     """lerc_encode_4D / lerc_decode_4D with per-band noData values, differential against the real reference (or the
     oracle): sizes, blobs, decoded pixels, masks and the noData values handed back."""

@@ -384,6 +384,50 @@ def test_sim_tile_batches_with_a_slot_per_tile(libs):
         L.lerc_amd_destroy(h)
 
 
+def test_sim_masked_bands_take_the_one_launch_encoder(libs):
+    """A band with a validity mask (one value per pixel, whole 8 x 8 blocks, 16 bits a pixel or more): its block stream is made
+    by the one-launch encoder's masked form -- any subset of a lane's pixels valid, elements placed by their rank among the block's
+    valid pixels, blocks without a valid pixel one byte, the masked branch's "same as the value before" count -- straight into
+    the band's place behind mask and ranges.  Bytes are the oracle's; the note says which kernels ran; too small a buffer is the
+    oracle's status."""
+    O, S = libs
+    rng = np.random.default_rng(77)
+    streamed = 0
+    for dt, e in ((np.float32, 0.01), (np.uint16, 0), (np.float64, 0.001), (np.int32, 1)):
+        for shape in ((64, 64), (8, 8), (72, 1032)):
+            for style in range(6):
+                r, c = shape
+                x = cases._cast(cases.terrain(r, c, rng, amp=300, base=1000, sigma=2.0), dt) if style % 2 == 0 else cases.mixed_regions(r, c, rng, dt)
+                m = np.ones((r, c), np.uint8)
+                if style == 0:
+                    for _ in range(6):
+                        i0, j0 = int(rng.integers(0, r)), int(rng.integers(0, c))
+                        m[i0:i0 + int(rng.integers(1, 40)), j0:j0 + int(rng.integers(1, 60))] = 0
+                elif style == 1:
+                    m = (rng.random((r, c)) > 0.3).astype(np.uint8)
+                elif style == 2:
+                    m[:, :c // 2] = 0
+                elif style == 3:
+                    m = (rng.random((r, c)) > 0.97).astype(np.uint8)
+                elif style == 4:
+                    m[::3, ::5] = 0
+                else:
+                    m[:] = 0
+                    m[r // 2, c // 3] = 1
+                    m[0, :] = 1
+                if m.all() or not m.any():
+                    m[0, 0] ^= 1
+                r1, b1 = O.encode(x, e, mask=m)
+                r2, b2 = S.encode(x, e, mask=m)
+                assert r1 == r2 == 0 and b1 == b2, (np.dtype(dt).name, shape, style)
+                streamed += "one-launch encoder" in S.last_note()
+                d1, d2 = O.decode(b1), S.decode(b1)
+                assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1]) and _same(d1[2], d2[2])
+                if style == 0:
+                    assert O.encode(x, e, mask=m, buf_size=len(b1) - 1)[0] == S.encode(x, e, mask=m, buf_size=len(b1) - 1)[0] == 3
+    assert streamed >= 60
+
+
 def test_sim_bit_plane_mode(libs):
     """maxZErr == 777: Lerc2::TryBitPlaneCompression picks the error bound from neighbour XOR statistics
     (Lerc2.cpp:1071-1229) -- all integer types, with a mask, with nDepth > 1, too few pixels, float (refused)."""
