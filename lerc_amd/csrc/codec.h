@@ -8,6 +8,7 @@
 #include "kernels.h"
 
 #include <string>
+#include <functional>
 #include <vector>
 
 namespace lerc {
@@ -29,6 +30,7 @@ bool readHeader(const u8* src, size_t n, Header& h, size_t& used);
 
 // RLE of the validity bit mask (host; the mask is << 1 % of the bytes and inherently sequential)
 void rleEncode(const u8* src, size_t n, std::vector<u8>& out);
+bool rleEncodeWhenReady(const u8* b, size_t n, const std::function<bool()>& ready, std::vector<u8>& out);    // (pieces by several threads, started before the bytes are there)
 bool rleDecode(const u8* src, size_t n, u8* dst, size_t dstSize, size_t* written = nullptr);    // (what the stream does not fill stays as it was)
 
 // ---- growable device workspace + stream, one per host thread (C API) or per handle (device API)
@@ -61,6 +63,8 @@ public:
   // a second pinned area (the validity bits of a band on their way to the host while kernels run) and its event
   void* pinnedAux(size_t bytes);
   hipEvent_t auxEvent();
+  // a stream beside the active one for that copy (it branches off behind what is enqueued so far: forkSide()); nullptr: none to be had
+  hipStream_t forkSide();
   bool sync();                               // wait for the active stream (polls first: see codec_common.cpp)
   // Device memory that keeps its contents from call to call (the two-launch encoder's arrival counters and cells,
   // tile_fast.h): zero when handed out for the first time and whenever it had to grow.  Two areas: [0] counters, which the
@@ -112,7 +116,9 @@ private:
   size_t m_pinnedCap = 0;
   void* m_pinnedAux = nullptr;
   size_t m_pinnedAuxCap = 0;
-  hipEvent_t m_auxEvent = nullptr;
+  hipEvent_t m_auxEvent = nullptr, m_forkEvent = nullptr;
+  hipStream_t m_sideStream = nullptr;
+  bool m_sideUsed = false;
 };
 
 // RAII bracket around one kernel launch (or a short group of launches)

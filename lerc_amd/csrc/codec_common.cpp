@@ -5,6 +5,13 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <atomic>
+#include <chrono>
+#include <functional>
+#include <thread>
+#include <future>
+#include <vector>
 
 namespace lerc {
 
@@ -75,19 +82,20 @@ bool readHeader(const u8* src, size_t n, Header& h, size_t& used)
 // repeated -n times; -32768 ends the stream.  A run is opened only where at least 5 equal bytes
 // start and one more byte follows (RLE.cpp:166-172, RLE.h:45); segments are cut at 32767.
 // ------------------------------------------------------------------------------------------------
-void rleEncode(const u8* b, size_t n, std::vector<u8>& out)
+// bytes [begin, end) of b[0 .. n), appended to out without the end marker.  `end` is n, or the start of a run that follows a
+// run of five or more equal bytes -- so is `begin` (or 0): at such a place RLE.cpp's encoder has just closed a run and starts a
+// literal stretch with an empty count, whatever came before; what it writes from there on hangs on nothing in front of it.
+static void rleEncodeRange(const u8* b, size_t n, size_t begin, size_t end, std::vector<u8>& out)
 {
-  out.clear();
-  out.reserve(n / 8 + 64);
   auto count = [&](int v) { short s = (short)v; out.push_back((u8)(s & 0xff)); out.push_back((u8)((s >> 8) & 0xff)); };
   // eight bytes at a time (a validity mask of a large raster is megabytes): five equal bytes from i on <=> the low
   // 32 bits of x ^ (x >> 8) are zero, x = the 8 bytes at i
   auto load8 = [&](size_t at) { u64 x; memcpy(&x, b + at, 8); return x; };
-  size_t i = 0;
-  while (i < n)
+  size_t i = begin;
+  while (i < end)
   {
     const size_t litBeg = i;
-    while (i < n)
+    while (i < end)
     {
       bool runStarts;
       if (i + 8 <= n) { const u64 x = load8(i); runStarts = (i + 5 < n) && (u32)(x ^ (x >> 8)) == 0u; }
@@ -102,7 +110,7 @@ void rleEncode(const u8* b, size_t n, std::vector<u8>& out)
       out.insert(out.end(), b + at, b + at + len);
       at += len;
     }
-    if (i >= n) break;
+    if (i >= end) break;
     size_t t = i;
     const u64 same = 0x0101010101010101ull * b[i];
     while (t + 9 <= n && load8(t + 1) == same) t += 8;    // b[t + 1 .. t + 8] all equal b[i]
@@ -116,7 +124,93 @@ void rleEncode(const u8* b, size_t n, std::vector<u8>& out)
     }
     i = t + 1;
   }
-  count(-32768);
+}
+
+// A large mask (megabytes of bits) is cut where a long run ends -- see rleEncodeRange -- and the pieces are coded by a few
+// threads: the coding of 8 MB takes one core a millisecond (most of it reading what the copy engine has just written), and with
+// the block stream of a masked band down to a fifth of that (the one-launch encoder) it was what an encode call waited for.
+// Piece p of K begins at the first place in its window [p n / K, (p + 1) n / K) where a run begins right behind five equal
+// bytes -- a piece whose window holds no such place does not exist, the piece in front of it runs on -- so every worker finds
+// its own range without asking anybody.
+static size_t rleCutIn(const u8* b, size_t n, size_t K, size_t p)    // 0: none (p >= 1)
+{
+  const size_t from = std::max<size_t>(p * (n / K), 6), to = std::min(n, (p + 1) * (n / K));
+  for (size_t i = from; i < to; i++)
+    if (b[i] != b[i - 1] && b[i - 1] == b[i - 2] && b[i - 1] == b[i - 3] && b[i - 1] == b[i - 4] && b[i - 1] == b[i - 5]) return i;
+  return 0;
+}
+static void rlePiece(const u8* b, size_t n, size_t K, size_t p, std::vector<u8>& out)
+{
+  const size_t begin = p ? rleCutIn(b, n, K, p) : 0;
+  if (p && !begin) return;
+  size_t end = n;
+  for (size_t q = p + 1; q < K; q++) { const size_t c = rleCutIn(b, n, K, q); if (c) { end = c; break; } }
+  // (into a vector of this thread's own and handed over at the end: the pieces' vectors lie side by side, and every push_back
+  // writes its vector's header -- eight threads on one cache line ran four times slower than one)
+  std::vector<u8> mine;
+  mine.reserve((end - begin) / 8 + 64);
+  rleEncodeRange(b, n, begin, end, mine);
+  out.swap(mine);
+}
+static size_t rlePieces(size_t n)
+{
+  // (LERC_AMD_RLE_PIECE=<bytes>, LERC_AMD_RLE_THREADS=<n>: test knobs, so that small masks are cut too)
+  static const size_t kPiece = []() -> size_t { const char* e = getenv("LERC_AMD_RLE_PIECE"); const long v = e ? atol(e) : 0; return v >= 16 ? (size_t)v : (size_t)(512 << 10); }();
+  static const size_t kMaxPieces = []() -> size_t { const char* e = getenv("LERC_AMD_RLE_THREADS"); const long v = e ? atol(e) : 0; return v >= 1 ? (size_t)v : (size_t)8; }();
+  return std::max<size_t>(1, std::min<size_t>(kMaxPieces, n / kPiece));
+}
+
+// ready(): called by every worker before it looks at a byte (the bits may still be on their way from the device: the workers
+// are started while they travel, so that starting them costs the caller nothing); false: give up, out stays empty
+bool rleEncodeWhenReady(const u8* b, size_t n, const std::function<bool()>& ready, std::vector<u8>& out)
+{
+  out.clear();
+  const size_t K = rlePieces(n);
+  std::vector<std::vector<u8> > part(K);
+  // ready() is the caller's alone (a HIP event wait: eight threads waiting for one event took turns, a tenth of a millisecond
+  // each); the workers watch a flag
+  std::atomic<int> state(0);    // 1: the bytes are there, -1: they will not come
+  std::vector<std::future<void> > job;
+  std::vector<size_t> inLine;
+  for (size_t p = 1; p < K; p++)
+  {
+    try
+    {
+      job.push_back(std::async(std::launch::async, [&, p]()
+      {
+        int st;
+        while ((st = state.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+        if (st > 0) rlePiece(b, n, K, p, part[p]);
+      }));
+    }
+    catch (...) { inLine.push_back(p); }    // (no thread to be had)
+  }
+  static const bool kTL = getenv("LERC_AMD_HOST_TIMES") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+  const bool good = ready();
+  const double tReady = us();
+  state.store(good ? 1 : -1, std::memory_order_release);
+  if (good)
+  {
+    rlePiece(b, n, K, 0, part[0]);
+    for (size_t p : inLine) rlePiece(b, n, K, p, part[p]);
+  }
+  const double tMine = us();
+  for (auto& j : job) j.get();
+  if (kTL) fprintf(stderr, "  [tl] rle: %zu pieces, bytes there after %.1f us, own piece +%.1f, all pieces +%.1f\n", K, tReady, tMine - tReady, us() - tReady);
+  if (!good) return false;
+  size_t total = 2;
+  for (auto& v : part) total += v.size();
+  out.reserve(total);
+  for (auto& v : part) out.insert(out.end(), v.begin(), v.end());
+  out.push_back(0x00); out.push_back(0x80);    // -32768
+  return true;
+}
+
+void rleEncode(const u8* b, size_t n, std::vector<u8>& out)
+{
+  rleEncodeWhenReady(b, n, []() { return true; }, out);
 }
 
 bool rleDecode(const u8* src, size_t left, u8* dst, size_t dstSize, size_t* written)
@@ -246,12 +340,15 @@ Context::~Context()
   if (m_asyncPinned) hipHostFree(m_asyncPinned);
   for (u8* st : m_state) if (st) hipFree(st);
   if (m_auxEvent) hipEventDestroy(m_auxEvent);
+  if (m_forkEvent) hipEventDestroy(m_forkEvent);
+  if (m_sideStream) { hipStreamSynchronize(m_sideStream); hipStreamDestroy(m_sideStream); }
   for (hipEvent_t e : m_eventPool) hipEventDestroy(e);
   if (m_stream) hipStreamDestroy(m_stream);
 }
 
 bool Context::reserve(size_t bytes)
 {
+  if (m_sideUsed) { m_sideUsed = false; hipStreamSynchronize(m_sideStream); }    // (a call that ended early: its side copy reads the scratch)
   m_used = 0;
   if (bytes <= m_cap) { poisonScratch(bytes); return true; }
   if (m_slab) { hipStreamSynchronize(activeStream()); hipFree(m_slab); m_slab = nullptr; m_cap = 0; }
@@ -331,6 +428,15 @@ void* Context::pinnedAux(size_t bytes)
   return m_pinnedAux;
 }
 
+hipStream_t Context::forkSide()
+{
+  if (!m_sideStream && hipStreamCreateWithFlags(&m_sideStream, hipStreamNonBlocking) != hipSuccess) { m_sideStream = nullptr; return nullptr; }
+  if (!m_forkEvent && hipEventCreateWithFlags(&m_forkEvent, hipEventDisableTiming) != hipSuccess) { m_forkEvent = nullptr; return nullptr; }
+  if (hipEventRecord(m_forkEvent, activeStream()) != hipSuccess || hipStreamWaitEvent(m_sideStream, m_forkEvent, 0) != hipSuccess) return nullptr;
+  m_sideUsed = true;    // (sync() and reset() wait for it too from now on)
+  return m_sideStream;
+}
+
 hipEvent_t Context::auxEvent()
 {
   if (!m_auxEvent && hipEventCreateWithFlags(&m_auxEvent, hipEventDisableTiming) != hipSuccess) m_auxEvent = nullptr;
@@ -342,6 +448,11 @@ hipEvent_t Context::auxEvent()
 bool Context::sync()
 {
   hipStream_t st = activeStream();
+  if (m_sideUsed)    // (the copy beside the stream, forkSide(): nothing of the call may outlive the call)
+  {
+    m_sideUsed = false;
+    if (hipStreamSynchronize(m_sideStream) != hipSuccess) return false;
+  }
   for (int i = 0; i < 20000; i++)
   {
     const hipError_t e = hipStreamQuery(st);

@@ -12,6 +12,7 @@
 #include <future>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -233,6 +234,11 @@ static bool fastEncodeOneLaunch()
 static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskState& ms, std::vector<u8>& prevByteValid,
                       bool& anyMaskModified, u8* dBandOut, u32 capacityLeft, u32& bandBytes)
 {
+  // (LERC_AMD_HOST_TIMES: where the host is, microseconds into the band -- a tuning aid)
+  static const bool kTL = getenv("LERC_AMD_HOST_TIMES") != nullptr;
+  const auto tl0 = std::chrono::steady_clock::now();
+  auto TL = [&](const char* what) { if (kTL) fprintf(stderr, "  [tl] %8.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl0).count(), what); };
+
   hipStream_t st = ctx.activeStream();
   Sync sync{ st };
   const int dt = rq.dt, nD = rq.nDepth, nCols = rq.nCols, nRows = rq.nRows;
@@ -282,9 +288,11 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     const size_t nb = (size_t)((nPix + 7) >> 3);
     u8* pin = (u8*)ctx.pinnedAux(nb);
     if (!pin) return false;
-    hipMemcpyAsync(pin, dNewBits, nb, hipMemcpyDeviceToHost, st);
+    // (beside the stream, so that the statistics kernels do not wait behind 8 MB on their way over PCIe: a third of a millisecond)
+    hipStream_t side = nb >= (256u << 10) ? ctx.forkSide() : nullptr;
     hipEvent_t ev = ctx.auxEvent();
-    hipEventRecord(ev, st);
+    hipMemcpyAsync(pin, dNewBits, nb, hipMemcpyDeviceToHost, side ? side : st);
+    hipEventRecord(ev, side ? side : st);
     bitsOnTheWay = pin; nBitsOnTheWay = nb;
     if (nb < (256u << 10)) return true;    // small masks: codeMask() does it in line (starting a thread costs ~30 us)
     try
@@ -292,7 +300,10 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
       rleFuture = std::async(std::launch::async, [pin, nb, ev]()
       {
         std::vector<u8> out;
-        if (hipEventSynchronize(ev) == hipSuccess) rleEncode(pin, nb, out);
+        const auto t0 = std::chrono::steady_clock::now();
+        // (the workers are started now, while the bits travel, and wait for them one by one)
+        if (!rleEncodeWhenReady(pin, nb, [ev]() { return hipEventSynchronize(ev) == hipSuccess; }, out)) out.clear();
+        if (getenv("LERC_AMD_HOST_TIMES")) fprintf(stderr, "  [tl] helper: %zu -> %zu bytes, %.1f us after its start\n", nb, out.size(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
         return out;    // (empty: the copy failed; an RLE stream is never empty)
       });
     }
@@ -524,6 +535,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
         if (((raiseMask >> c) & 1u) && hr.stats.raiseErr[c] / facCand[c] <= maxZErr / 2) { maxZErr = errCand[c] / 2; break; }
     }
   }
+  TL("statistics read, decisions made");
   hd.maxZErr = maxZErr;
   hd.zMin = hd.zMax = 0;
   hd.mbSize = 8;
@@ -590,7 +602,9 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
       && dt != DT_Char && dt != DT_Byte && !hd.tryHuffmanInt() && !hd.tryHuffmanFlt() && !nd.active && !bp.tryDiff && fastEncodeOneLaunch() && fastDimsOkRagged(nRows, nCols)
       && ((uintptr_t)dData & 15) == 0 && (!dBandOut || ((uintptr_t)dBandOut & 15) == 0) && (u64)nPix * tb + (u64)nPos8 + 8192 < 0xFFFFFFFFull;
     if (!eligible) return true;
-    if (!codeMask()) return false;    // (the mask's length says where the block stream begins; the statistics kernels have covered its coding)
+    TL("streamMasked: before codeMask");
+    if (!codeMask()) return false;
+    TL("streamMasked: mask coded");    // (the mask's length says where the block stream begins; the statistics kernels have covered its coding)
     const u32 nWGt = fastFusedNumWG(dt, nRows, nCols);
     const size_t cellWords = fastFusedCellWords(nWGt), counterWords = fastFusedCounterWords(nWGt);
     const u64 cap = capacityLeft;
@@ -623,6 +637,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     if (hipGetLastError() != hipSuccess) { ctx.lastError = "lerc_amd: a streaming encode kernel could not be launched"; return false; }
     hipMemcpyAsync(hRes, dRes, sizeof(FastEncodeResult), hipMemcpyDeviceToHost, st);
     if (!sync.wait()) return false;
+    TL("streamMasked: kernel done");
     if (hRes->stuck) { ctx.wipePersistentState(); return true; }    // (the three kernels take the band)
     nBytesStreamed = hRes->nBytesTiling;    // (a stream that does not fit the buffer was cut off inside it; the size check below says BufferTooSmall)
     dStreamed = dWs ? dWs + payloadAt : reinterpret_cast<u8*>(dRes);    // (size query: only != nullptr counts)
@@ -758,6 +773,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     prefix[at++] = (payload == P_ONESWEEP) ? 1 : 0;
     if (payload != P_ONESWEEP && (hd.tryHuffmanInt() || hd.tryHuffmanFlt())) prefix[at++] = (u8)imageMode;
   }
+  TL("prefix assembled");
   hipMemcpyAsync(dBandOut, prefix, at, hipMemcpyHostToDevice, st);
   u8* dPayload = dBandOut + at;
 
@@ -809,6 +825,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   { ProfScope ps(ctx, "fletcher_enc"); launchFletcher(dBandOut + 14, blobSize - 14, dFl, st); launchFletcherPatch(dFl, blobSize - 14, dBandOut + 10, st); }
   hipMemcpyAsync(&hr.status, dStatus, sizeof(DeviceStatus), hipMemcpyDeviceToHost, st);
   if (!sync.wait()) return kFailed;
+  TL("band done");
   if (hr.status.error) { ctx.lastError = "device kernel reported an error"; return hr.status.error; }
   if (ctx.profOn()) ctx.profCollect();
   return kOk;

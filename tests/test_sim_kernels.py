@@ -428,6 +428,44 @@ def test_sim_masked_bands_take_the_one_launch_encoder(libs):
     assert streamed >= 60
 
 
+def test_sim_mask_coded_in_pieces(libs):
+    """The host codes a large mask in pieces, cut where a run of five or more equal bytes ends (RLE.cpp's encoder starts afresh
+    there), by several threads.  LERC_AMD_RLE_PIECE makes the pieces small, so that masks of test size are cut many times -- runs
+    longer than 32767 bytes across the cuts included; the blobs are the oracle's (the knob is read once: a process of its own)."""
+    import sys
+    code = r"""
+import sys, os
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, capi, cases
+S, O = capi.sim(), capi.oracle()
+rng = np.random.default_rng(5)
+for it in range(24):
+    r, c = int(rng.integers(1, 40)) * 8, int(rng.integers(1, 60)) * 8
+    if it %% 3 == 0: r += int(rng.integers(0, 8)); c += int(rng.integers(0, 8))
+    if it == 23: r, c = 384, 4096
+    x = cases._cast(cases.terrain(r, c, rng, amp=300, base=1000, sigma=2.0), np.uint16)
+    m = np.ones((r, c), np.uint8)
+    style = it %% 6
+    if style == 0:
+        for _ in range(8):
+            i0, j0 = int(rng.integers(0, r)), int(rng.integers(0, c)); m[i0:i0 + int(rng.integers(1, 60)), j0:j0 + int(rng.integers(1, 200))] = 0
+    elif style == 1: m = (rng.random((r, c)) > 0.3).astype(np.uint8)
+    elif style == 2: m[:, :c // 2] = 0
+    elif style == 3: m = (rng.random((r, c)) > 0.999).astype(np.uint8); m[0, 0] = 1
+    elif style == 4: m[r // 3:, :] = 0
+    else: m[:] = (np.arange(c)[None, :] // 41 + np.arange(r)[:, None] // 3) %% 2
+    if it == 23: m[:] = 1; m[: r // 2 + 3, :] = 0; m[5, 77] = 1
+    if m.all() or not m.any(): m[0, 0] ^= 1
+    r1, b1 = O.encode(x, 0, mask=m); r2, b2 = S.encode(x, 0, mask=m)
+    assert r1 == r2 == 0 and b1 == b2, (it, r, c, style)
+print("pieces ok")
+""" % (capi.ROOT,)
+    for piece in ("16", "4096"):
+        env = dict(os.environ, LERC_AMD_RLE_PIECE=piece)
+        out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert out.returncode == 0 and b"pieces ok" in out.stdout, out.stdout.decode()[-2000:]
+
+
 def test_sim_bit_plane_mode(libs):
     """maxZErr == 777: Lerc2::TryBitPlaneCompression picks the error bound from neighbour XOR statistics
     (Lerc2.cpp:1071-1229) -- all integer types, with a mask, with nDepth > 1, too few pixels, float (refused)."""

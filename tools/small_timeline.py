@@ -3,7 +3,7 @@
 last call's kernels and copies in time order with the idle gaps between them.
     rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/p -o t -- python tools/small_timeline.py run <case>
     python tools/small_timeline.py show /tmp/p/.../t_results.db
-cases: california (decode of the 400 x 400 masked float blob), dec256 / enc256 (256 x 256 float32)"""
+cases: california (decode of the 400 x 400 masked float blob), dec256 / enc256 (256 x 256 float32), masked (encode of the 8192 x 8192 raster with a 10 % mask)"""
 import os
 import sqlite3
 import sys
@@ -20,7 +20,19 @@ def run(case):
     import cases
     P = capi.product()
     rng = np.random.default_rng(1)
-    if case == "california":
+    if case == "masked":    # device-resident 8192 x 8192 float32 with a 10 % mask, one encode call
+        import ctypes as ct
+        import torch
+        from lerc_amd import api, synth
+        dev = torch.device("cuda:0")
+        x = synth.c2_float32().to(dev)
+        i = torch.arange(8192).view(-1, 1)
+        j = torch.arange(8192).view(1, -1)
+        m = (((i // 97) + (j // 131)) % 10 != 0).to(torch.uint8).contiguous().to(dev)
+        codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
+        out = torch.empty(x.numel() * 4 + (1 << 20), dtype=torch.uint8, device=dev)
+        f = lambda: codec.encode(x.data_ptr(), 6, 1, 8192, 8192, 1, 0.01, out.data_ptr(), out.numel(), m.data_ptr(), 1)
+    elif case == "california":
         blob = open(os.path.join(ROOT, "tests", "golden", "california_400_400_1_float.lerc2"), "rb").read()
         f = lambda: P.decode(blob)
     else:
