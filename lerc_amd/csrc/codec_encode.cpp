@@ -586,7 +586,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   u32* dOffsets = nullptr;
   u32* dScratch = nullptr;
   const int nPos8 = ((nRows + 7) / 8) * ((nCols + 7) / 8);
-  // A band with a validity mask, one value per pixel, whole 8 x 8 blocks, a type of 16 bits or more: its block stream is made by
+  // A band with a validity mask, one value per pixel, a type of 16 bits or more: its block stream is made by
   // the one-launch encoder's masked form (tile_fast.hip) -- straight into the band's place behind mask and ranges, with the band's
   // FINAL parameters, all decisions about the band having been made above -- instead of tile_sizes + scan + tile_write.  If the band
   // ends up coded another way (16 x 16 blocks, one sweep) that writer comes later in the stream and overwrites it.
@@ -598,7 +598,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   {
     if (streamedTried) return true;
     streamedTried = true;
-    const bool eligible = maskedStreamingOn() && dBits && !bp.allValid && nD == 1 && nRows % 8 == 0 && nCols % 8 == 0 && hd.version == kCodecVersion
+    const bool eligible = maskedStreamingOn() && dBits && !bp.allValid && nD == 1 && hd.version == kCodecVersion
       && dt != DT_Char && dt != DT_Byte && !hd.tryHuffmanInt() && !hd.tryHuffmanFlt() && !nd.active && !bp.tryDiff && fastEncodeOneLaunch() && fastDimsOkRagged(nRows, nCols)
       && ((uintptr_t)dData & 15) == 0 && (!dBandOut || ((uintptr_t)dBandOut & 15) == 0) && (u64)nPix * tb + (u64)nPos8 + 8192 < 0xFFFFFFFFull;
     if (!eligible) return true;
@@ -630,7 +630,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     fl.fb.result = dRes;
     fl.batch.nTiles = 1; fl.batch.nWG = nWGt; fl.batch.tileElems = (u64)nPix; fl.batch.nBlobsMore = 0;
     BandParams sp = bp;
-    sp.mb = 8; sp.nTV = nRows / 8; sp.nTH = nCols / 8;
+    sp.mb = 8; sp.nTV = (nRows + 7) / 8; sp.nTH = (nCols + 7) / 8;
     (void)hipGetLastError();
     hipMemsetAsync(dRes, 0, sizeof(FastEncodeResult), st);
     { ProfScope ps(ctx, "masked_encode1"); launchFastEncode(0, sp, maxZErr, 0, dData, dWs, cap, 0, fl.fb, fl.batch, st); }

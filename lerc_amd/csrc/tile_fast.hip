@@ -1439,7 +1439,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   __shared__ u64 s_fa[4], s_fb[4], s_kmx[U], s_kmn[U];
   __shared__ u32 s_len[U], s_base, s_retry;
   static_assert(!(PART && WIDE), "ragged rasters take the per-block mapping");
-  static_assert(!(MASKED && (WIDE || PART)), "masked bands: whole blocks, per-block mapping");
+  static_assert(!(MASKED && WIDE), "masked bands take the per-block mapping");
 
   const u32 nGroups = (nWG + kFusedGroup - 1u) / kFusedGroup, nPackGroups = fastPackGroups(nWG);
   if (f.nTiles > 1u)    // a batch: this tile's pixels, cells, counters, result and slot
@@ -1486,6 +1486,24 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
           const u32 byte = f.maskBits[at >> 3];
           vmA[a][t] = (__brev((byte << ((u32)at & 7u)) & 0xFFu) >> 24) & ((1u << V) - 1u);
         }
+      }
+      else if constexpr (MASKED)    // ragged AND masked: the pixels that exist, of those the valid ones (their bits may lie in two bytes)
+      {
+        const u32 j = (u32)(t * 4 + w) * BPW + (u32)b;
+        const int bw = min(8, p.nCols - (int)fastSpanCol(span[a], j) * 8), bh = min(8, p.nRows - (int)fastSpanRow(span[a], j) * 8);
+        const int vc = r < bh ? max(0, min(V, bw - h * V)) : 0;
+        vcA[a][t] = vc; bwA[a][t] = bw;
+        const i64 at = laneOrigin<WIDE, BPW, V>(span[a], t * 4 + w, r, c, p.nCols);
+        const T* src = data + at;
+#pragma unroll
+        for (int k = 0; k < V; k++) v[a][t][k] = k < vc ? src[k] : T(0);
+        u32 bits = 0;
+        if (vc > 0)
+        {
+          const u32 two = ((u32)f.maskBits[at >> 3] << 8) | (u32)f.maskBits[(at >> 3) + 1];    // (the mask has slack behind its last byte)
+          bits = (__brev((two << ((u32)at & 7u)) & 0xFF00u) >> 16) & ((1u << vc) - 1u);
+        }
+        vmA[a][t] = bits;
       }
       else
       {
@@ -2041,7 +2059,9 @@ static void launchFastEncodeT(int stage, const BandParams& p, double requested, 
 #define LERC_U32 2
 #endif
     constexpr int U = sizeof(T) == 2 ? 3 : LERC_U32;
-    if (b.fused.maskBits)    // (whole-block rasters only: the caller sees to that)
+    if (b.fused.maskBits && (p.nRows % 8 != 0 || p.nCols % 8 != 0))
+      hipLaunchKernelGGL((k_fast_encode1<T, false, U, true, true>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
+    else if (b.fused.maskBits)
       hipLaunchKernelGGL((k_fast_encode1<T, false, U, false, true>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);
     else if (p.nRows % 8 != 0 || p.nCols % 8 != 0)
       hipLaunchKernelGGL((k_fast_encode1<T, false, U, true>), grid, dim3(256), 0, st, (const T*)data, p, out, b.result, nW, batch.nBlobsMore, b.fused, requested, raiseCand, cap);

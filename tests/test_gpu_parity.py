@@ -322,7 +322,8 @@ def test_masked_bands_take_the_one_launch_encoder(P, O):
     place behind the band's mask and ranges; bytes are the oracle's, for blob-shaped masks, salt-and-pepper masks, masks that
     leave whole block rows empty and a single valid pixel."""
     rng = np.random.default_rng(21)
-    for dt, e, shape in ((np.float32, 0.01, (1024, 1536)), (np.uint16, 0, (512, 1024)), (np.float64, 0.001, (256, 512)), (np.int32, 2, (640, 640))):
+    for dt, e, shape in ((np.float32, 0.01, (1024, 1536)), (np.uint16, 0, (512, 1024)), (np.float64, 0.001, (256, 512)), (np.int32, 2, (640, 640)),
+                         (np.float32, 0.01, (1001, 1203)), (np.uint16, 0, (257, 257)), (np.float64, 0.5, (130, 1027))):    # (the last three: ragged)
         r, c = shape
         x = cases._cast(cases.terrain(r, c, rng, amp=300, base=1000, sigma=2.0), dt)
         for style in range(4):
