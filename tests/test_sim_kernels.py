@@ -393,9 +393,9 @@ def test_sim_masked_bands_take_the_one_launch_encoder(libs):
     O, S = libs
     rng = np.random.default_rng(77)
     streamed = 0
-    for dt, e in ((np.float32, 0.01), (np.uint16, 0), (np.float64, 0.001), (np.int32, 1)):
-        for shape in ((64, 64), (8, 8), (72, 1032), (63, 65), (257, 257), (3, 700)):    # (the last three: rows / columns no multiples of 8)
-            for style in range(6):
+    for dt, e in ((np.float32, 0.01), (np.uint16, 0), (np.float64, 0.001)):
+        for shape in ((64, 64), (8, 8), (40, 520), (63, 65), (130, 67), (3, 300)):    # (the last three: rows / columns no multiples of 8)
+            for style in (0, 1, 3, 5):
                 r, c = shape
                 x = cases._cast(cases.terrain(r, c, rng, amp=300, base=1000, sigma=2.0), dt) if style % 2 == 0 else cases.mixed_regions(r, c, rng, dt)
                 m = np.ones((r, c), np.uint8)
@@ -425,7 +425,7 @@ def test_sim_masked_bands_take_the_one_launch_encoder(libs):
                 assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1]) and _same(d1[2], d2[2])
                 if style == 0:
                     assert O.encode(x, e, mask=m, buf_size=len(b1) - 1)[0] == S.encode(x, e, mask=m, buf_size=len(b1) - 1)[0] == 3
-    assert streamed >= 120
+    assert streamed >= 60
 
 
 def test_sim_mask_coded_in_pieces(libs):
@@ -442,7 +442,7 @@ rng = np.random.default_rng(5)
 for it in range(24):
     r, c = int(rng.integers(1, 40)) * 8, int(rng.integers(1, 60)) * 8
     if it %% 3 == 0: r += int(rng.integers(0, 8)); c += int(rng.integers(0, 8))
-    if it == 23: r, c = 384, 4096
+    if it == 23: r, c = 160, 4096
     x = cases._cast(cases.terrain(r, c, rng, amp=300, base=1000, sigma=2.0), np.uint16)
     m = np.ones((r, c), np.uint8)
     style = it %% 6
@@ -829,7 +829,7 @@ for dt, e, shape in ((np.float32, 0.01, (128, 1024)), (np.uint16, 0, (128, 512))
         c1 = S.path_counters()
         assert d1[0] == d2[0] == 0 and np.array_equal(d1[1].view(np.uint8), d2[1].view(np.uint8)), ("pixels", shape, kind)
         if giveup: assert c1[3] > c0[3], (c0, c1, shape)
-        for t in range(6):
+        for t in range(3):
             y = bytearray(b1)
             k = int(rng.integers(0, len(y)))
             y[k] ^= 1 << int(rng.integers(0, 8))
