@@ -76,7 +76,7 @@ bool readBandHeader(const BlobReader& rd, u64 off, BandDesc& b)
 static const size_t kCellParams = 0, kCellFallback = 128, kCellBytes = 192;
 static_assert(sizeof(FastDecodeParams) <= 128, "cell layout");
 
-static bool fastDecodeOneLaunch();    // LERC_AMD_DECODE_LAUNCHES=1: the one-launch form for single rasters (an experiment, 5 % slower: DESIGN.md)
+static bool fastDecodeOneLaunch();    // the one-launch decoder (tile_fast_decode_one.hip); LERC_AMD_DECODE_LAUNCHES=2: discovery + decode as two launches
 
 static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven, u32 nTiles = 1)
 {
@@ -99,16 +99,6 @@ static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8
   tb.nTiles = nTiles; tb.nChunks = fwp.nChunks; tb.nBlocks = fwp.nBlocks; tb.nWaves = fwp.nWaves; tb.discChunks = fwp.discChunks;
   tb.tileElems = (u64)nRows * (u64)nCols; tb.tileOffset = dTileOffset; tb.tileSize = dTileSize;
   FastDecodeBuffers fbuf;
-  fbuf.recs = ctx.allocT<FastChunkRec>(nT * fwp.nChunks + kResolveWG);    // (+ what the resolve step's unconditional loads may touch)
-  fbuf.lists = ctx.allocT<u16>((nT * fwp.nChunks + kDecodeChunks) * (size_t)(kDiscWalks * kFastListCap) + 8);    // (+ what the gather step's clamped loads may touch)
-  // (epoch-tagged cells, never cleared: they live as long as the context and share its area with the encoder's)
-  const bool one = nTiles == 1 && fastDecodeOneLaunch();    // a single raster: discovery, resolving and decoding workgroups in one grid
-  const size_t nDisc = (size_t)fwp.nChunks / kOneDiscChunks + 1;
-  const size_t cellWords = nT * (2 * sChunk + fastGroupStride(fwp.nChunks)) + (one ? nDisc : 0) + 8;
-  fbuf.chunkCell = (u64*)ctx.persistentState(1, cellWords * 8);
-  fbuf.groupCell = fbuf.chunkCell ? fbuf.chunkCell + nT * 2 * sChunk : nullptr;
-  fbuf.discCell = (fbuf.chunkCell && one) ? fbuf.groupCell + nT * fastGroupStride(fwp.nChunks) : nullptr;
-  fbuf.waveFletcher = ctx.allocT<u64>(2 * nT * (one ? nDisc : (size_t)fwp.nWaves) + 4);
   fbuf.params = dParams;
   fbuf.fallback = dFallback;
   fbuf.hostParams = hCell ? reinterpret_cast<FastDecodeParams*>(hCell + kCellParams) : nullptr;
@@ -116,14 +106,32 @@ static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8
   fbuf.epoch = epoch;
   fbuf.publishEpoch = (fastTestGiveUp() & 2u) ? epoch ^ 0x5A5A5A5Au : epoch;
   fbuf.spinLimit = (fastTestGiveUp() & 2u) ? 8u : (1u << 22);
-  if (!fbuf.recs || !fbuf.lists || !fbuf.chunkCell || !fbuf.waveFletcher)
-    return false;
-  if (one)
+  fbuf.discCell = nullptr;
+  fbuf.testRewalk = (fastTestGiveUp() & 4u) ? 1u : 0u;
+  fbuf.wgCell = fbuf.wgGroupCell = fbuf.wgAcc = nullptr;
+  // (epoch-tagged cells, never cleared: they live as long as the context and share its area with the encoder's)
+  if (fastDecodeOneLaunch())
   {
-    ProfScope ps(ctx, "fast_decode1");
-    launchFastDecode(2, dt, nRows, nCols, tb, dBlobs, sizeBound, fbuf, dOut, st);
+    // everything in one launch: a cell per workgroup and per group of workgroups, and the groups' checksum accumulators
+    // (counters: left zero by the launch's last workgroup)
+    const size_t sWg = fastOneWgStride(fwp.nChunks), sGrp = fastOneGroupStride(fwp.nChunks);
+    fbuf.wgCell = (u64*)ctx.persistentState(1, (nT * (sWg + sGrp) + 8) * 8);
+    fbuf.wgGroupCell = fbuf.wgCell ? fbuf.wgCell + nT * sWg : nullptr;
+    fbuf.wgAcc = (u64*)ctx.persistentState(0, (nT * sGrp + 8) * 8);
+    if (!fbuf.wgCell || !fbuf.wgAcc) return false;
+    fbuf.recs = nullptr; fbuf.lists = nullptr; fbuf.chunkCell = fbuf.groupCell = fbuf.waveFletcher = nullptr;
+    ProfScope ps(ctx, "fast_decode_one");
+    launchFastDecodeOne(dt, nRows, nCols, tb, dBlobs, sizeBound, fbuf, dOut, st);
     return true;
   }
+  fbuf.recs = ctx.allocT<FastChunkRec>(nT * fwp.nChunks + kResolveWG);    // (+ what the resolve step's unconditional loads may touch)
+  fbuf.lists = ctx.allocT<u16>((nT * fwp.nChunks + kDecodeChunks) * (size_t)(kDiscWalks * kFastListCap) + 8);    // (+ what the gather step's clamped loads may touch)
+  const size_t cellWords = nT * (2 * sChunk + fastGroupStride(fwp.nChunks)) + 8;
+  fbuf.chunkCell = (u64*)ctx.persistentState(1, cellWords * 8);
+  fbuf.groupCell = fbuf.chunkCell ? fbuf.chunkCell + nT * 2 * sChunk : nullptr;
+  fbuf.waveFletcher = ctx.allocT<u64>(2 * nT * (size_t)fwp.nWaves + 4);
+  if (!fbuf.recs || !fbuf.lists || !fbuf.chunkCell || !fbuf.waveFletcher)
+    return false;
   static const char* kStage[kFastDecodeStages] = { "fast_discover", "fast_decode" };
   for (int stage = 0; stage < kFastDecodeStages; stage++)
   {
@@ -142,7 +150,7 @@ static bool launchFastBand(Context& ctx, int dt, int nRows, int nCols, const u8*
 
 static bool fastDecodeOneLaunch()
 {
-  static const bool one = []() { const char* e = getenv("LERC_AMD_DECODE_LAUNCHES"); return e && atoi(e) == 1; }();
+  static const bool one = []() { const char* e = getenv("LERC_AMD_DECODE_LAUNCHES"); return !e || atoi(e) != 2; }();
   return one;
 }
 
@@ -199,6 +207,7 @@ bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch)
 {
   if (ctx.profOn()) ctx.profCollect();
   const u32 verdict = fastBandVerdict(slot + 64, epoch);
+  if (verdict & 0x8u) ctx.wipePersistentState();    // (a workgroup gave up waiting: the checksum accumulators may hold residue)
   if (verdict)
   {
     char msg[112];
@@ -595,6 +604,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
   {
     if (!fast[iBand].used) continue;
     const u32 verdict = fastBandVerdict(pin + 64 + (size_t)iBand * kCellBytes, fast[iBand].epoch);
+    if (verdict & 0x8u) ctx.wipePersistentState();    // (a workgroup gave up waiting: the checksum accumulators may hold residue)
     if (verdict & 0x200u) return kFailed;    // decoded, but the checksum is wrong
     if (verdict)                             // caller repeats with the general kernels
     {
@@ -721,6 +731,9 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
     const FastDecodeParams* hp = reinterpret_cast<const FastDecodeParams*>(pin + 64);
     const u32* hfb = reinterpret_cast<const u32*>(pin + 64 + (size_t)n * sizeof(FastDecodeParams));
     redo.clear();
+    bool gaveUp = false;
+    for (int i = 0; i < n; i++) gaveUp = gaveUp || (fastFlagBits(hfb + 4 * i, epoch) & 0x8u) != 0u;
+    if (gaveUp) ctx.wipePersistentState();    // (a workgroup gave up waiting: the checksum accumulators may hold residue)
     for (int i = 0; i < n; i++)
     {
       const u32 bits = fastFlagBits(hfb + 4 * i, epoch);

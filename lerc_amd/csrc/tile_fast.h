@@ -234,12 +234,26 @@ static const u32 kResolveChunks = 4;
 #else
 static const u32 kResolveChunks = 256;     // chunks a resolving block takes, one per thread
 #endif
-static const int kOneDiscChunks = (int)(16384u / kFastChunkBytes);       // chunks per discovery workgroup of the one-launch decoder (256 threads; its LDS is then no more than a decoding workgroup's)
-#ifdef LERC_SMALL_GROUPS
-static const u32 kOneLead = 2;
-#else
-static const u32 kOneLead = 24;            // groups whose discovery workgroups are dispatched before the first resolving block
+static const int kOneDiscChunks = (int)(16384u / kFastChunkBytes);       // (kept for the two-launch kernels' templates; no launch uses it any more)
+// The one-launch decoder (tile_fast_decode_one.hip): a workgroup stages kOneChunks consecutive chunks, walks them all, and decodes
+// the blocks that start in all of them but the first -- that one is the last chunk of the workgroup in front, walked again
+// here so that the entry of this workgroup's first own chunk (= the exit that chunk's walks agree on) is known without asking
+// anybody.  Workgroup 0 owns its first chunk too.  What travels between workgroups is one number: how many blocks start in a
+// workgroup's chunks (an epoch-tagged cell each, and one per kOneGroup workgroups for the group's total).
+#ifndef LERC_ONE_CHUNKS
+#define LERC_ONE_CHUNKS 16
 #endif
+static const u32 kOneChunks = LERC_ONE_CHUNKS;
+static const u32 kOneThreads = 32u * kOneChunks;                         // 16 threads per KiB staged, like k_fast_discover
+#ifdef LERC_SMALL_GROUPS
+static const u32 kOneGroup = 2;
+#else
+static const u32 kOneGroup = 64;
+#endif
+LERC_HD u32 fastOneNumWG(u32 nChunks) { return nChunks <= kOneChunks ? 1u : 1u + (nChunks - kOneChunks + kOneChunks - 2u) / (kOneChunks - 1u); }
+LERC_HD u32 fastOneGroups(u32 nWG) { return (nWG + kOneGroup - 1u) / kOneGroup; }
+LERC_HD u32 fastOneWgStride(u32 nChunksBound) { return (fastOneNumWG(nChunksBound) + 3u) & ~1u; }        // cells per tile
+LERC_HD u32 fastOneGroupStride(u32 nChunksBound) { return (fastOneGroups(fastOneNumWG(nChunksBound)) + 3u) & ~1u; }    // group cells / accumulators per tile
 #ifndef LERC_DECODE_CHUNKS
 #define LERC_DECODE_CHUNKS 4
 #endif
@@ -283,7 +297,12 @@ struct FastDecodeBuffers
                        // epoch (32) | the walk that is the true path, 0xFFFF: none (16) | blocks that start in the chunk (16)
   u64* groupCell;      // [ceil(nChunks / kResolveChunks)] epoch (32) | blocks of a resolving block's chunks (32)
   u64* waveFletcher;   // [2 * nWaves] Fletcher partial sums (mod 65535) of the bytes each discovery workgroup staged
-  u64* discCell;       // [ceil(nChunks / kOneDiscChunks)] one-launch decoder: epoch (32) | 1 -- all that discovery workgroup leaves has arrived
+  u64* discCell;       // (unused)
+  // the one-launch decoder's hand-offs (tile_fast_decode_one.hip)
+  u64* wgCell;         // [fastOneWgStride] epoch (32) | blocks that start in the workgroup's own chunks (32)
+  u64* wgGroupCell;    // [fastOneGroupStride] epoch (32) | blocks of group g's workgroups (32), left by the group's last workgroup
+  u64* wgAcc;          // [fastOneGroupStride] checksum terms of a group's workgroups and how many have arrived: A | B << 24 | n << 48
+                       // (zero between calls: the launch's last workgroup folds and clears them)
   FastDecodeParams* params;   // [nTiles]
   u32* fallback;       // [4 * nTiles] epoch tagged, see above
   FastDecodeParams* hostParams;    // one band: the same two in pinned host memory (written through by the kernels, so that the
@@ -291,11 +310,12 @@ struct FastDecodeBuffers
   u32 epoch;
   u32 publishEpoch;    // == epoch; a test knob makes it differ, so that nobody ever sees a cell arrive and every waiter gives up
   u32 spinLimit;       // polls before a waiter gives up (2^22; the test knob: a few)
+  u32 testRewalk;      // test knob (LERC_AMD_TEST_GIVEUP bit 2): the one-launch decoder walks every chunk's path again, as it does
+                       // for the rare chunk whose path is not its walk 0
 };
 // LERC_AMD_TEST_GIVEUP (bit 0: the one-launch encoder, bit 1: the streaming decoder): hand-offs inside a launch never arrive
 // -- the path a workgroup takes when it gives up waiting is then the one every call takes (tests/test_gpu_parity.py)
 u32 fastTestGiveUp();
-u32 fastOneLead();              // LERC_AMD_DECODE_LEAD: see k_fast_decode1
 
 // A launch covers nTiles independent blobs of rasters of one shape (blockIdx.y = tile; one raster is nTiles == 1).
 // Every buffer above then holds nTiles consecutive slices, sized by the bounds below.
@@ -313,7 +333,9 @@ LERC_HD u32 fastGroupStride(u32 nChunks) { return (nChunks + kResolveChunks - 1u
 
 bool fastDecodeEligible(int dt, int version, int mb, int nRows, int nCols, int nDepth, bool allValid);
 FastWalkPlan makeFastWalkPlan(int nRows, int nCols, u32 sizeGiven, u32 nTiles = 1);
-static const int kFastDecodeStages = 2;    // one kernel each: discover (+ header + checksum terms), resolve + decode
+static const int kFastDecodeStages = 2;    // one kernel each: discover (+ header + checksum terms), resolve + decode; stage 2: all of it in one launch
+void launchFastDecodeOne(int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
+                         const FastDecodeBuffers& b, void* out, hipStream_t st);
 void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
                       const FastDecodeBuffers& b, void* out, hipStream_t st);
 

@@ -1,0 +1,25 @@
+#!/bin/bash
+# One GPU-box call while iterating: the decoder tests, then the bench for several builds / knobs, one line per run.
+#   gpurun --timeout 1500 -- 'bash tools/gpu_ab.sh [lib.so ...]'
+set -u
+OUT=$PWD/gpurun_out; mkdir -p "$OUT"
+run() {  # name, then env assignments
+  local name=$1; shift
+  env "$@" python bench.py --steps ${STEPS:-20} --warmup 5 --no-cpu-baseline --no-c5-anchor --rotate 0 2>"$OUT/ab_$name.err" | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('$name', 'ms_per_step', d['ms_per_step'], 'frac', d['roundtrip']['frac_of_hbm_peak_wall'], 'verified', d['config']['verified'], ' '.join(f\"{k}={v['avg_ms']*1000:.1f}\" for k,v in d['kernels'].items()))
+" || tail -3 "$OUT/ab_$name.err"
+}
+if [ "${TESTS:-1}" = "1" ]; then
+  timeout 900 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} > "$OUT/ab_pytest.txt" 2>&1; tail -4 "$OUT/ab_pytest.txt"
+fi
+run one LERC_AMD_DECODE_LAUNCHES=1
+run two LERC_AMD_DECODE_LAUNCHES=2
+run one_again LERC_AMD_DECODE_LAUNCHES=1
+for L in "$@"; do run "$(basename $L .so)" LERC_AMD_LIBRARY=$PWD/$L; done
+if [ -f lerc_amd/csrc/_var/trace.so ]; then
+  PROBE_LIB=$PWD/lerc_amd/csrc/_var/trace.so timeout 200 python tools/trace_decode_one.py 2>&1 | tail -12
+  PROBE_LIB=$PWD/lerc_amd/csrc/_var/trace.so timeout 200 python tools/trace_decode_one.py c3 2>&1 | tail -12
+fi
+timeout 300 python tools/time_configs.py c3 2>&1 | tail -8
