@@ -196,6 +196,7 @@ lerc_status decodeHost(const unsigned char* blob, unsigned blobSize, int nMasks,
   rq.hBlob = blob; rq.blobSize = blobSize; rq.dt = (int)dataType; rq.nDepth = nDepth; rq.nCols = nCols; rq.nRows = nRows;
   rq.nBands = nBands; rq.nMasks = nMasks; rq.dOut = dOut; rq.dValidBytes = dMask;
   rq.hUsesNoData = pUsesNoData; rq.hNoDataValues = noDataValues;
+  bool triedOne = false;
   // What the streaming kernels can take -- the header says so: one band, every pixel valid, 8 x 8 blocks, nDepth 1 -- goes
   // up, through the kernels and back in one go: upload, kernels, verdict and the pixels' way back are enqueued together
   // and this thread waits once (two waits and the gap between them are a quarter of a small raster's call).
@@ -216,9 +217,11 @@ lerc_status decodeHost(const unsigned char* blob, unsigned blobSize, int nMasks,
         const u32 src = decodeSpeculativeToHost(ctx, rs, pData, outBytes, nMasks ? pValidBytes : nullptr, maskBytes, handled);
         if (src != kOk) return src;
         if (handled) return kOk;
+        triedOne = true;
       }
     }
   }
+  rq.skipOne = triedOne;    // (the one-launch streaming decoder has just refused this blob)
   const u32 rc = decodeDevice(ctx, rq);
   if (rc != kOk) return rc;
   if (widen)
@@ -508,6 +511,7 @@ void completeAll(lerc_amd_context* h)
           if (getBlobInfo(head, sizeof(head), info) == kOk && info.blobSize >= 70 && info.blobSize <= op.dr.blobSize) op.dr.blobSize = info.blobSize;
         }
       }
+      op.dr.skipOne = op.streamed;    // (the one-launch streaming decoder has just refused this blob)
       op.status = decodeDevice(ctx, op.dr);
     }
     op.done = true;

@@ -175,6 +175,7 @@ struct DecodeRequest
   void* dOut = nullptr;               // device: decoded pixels
   u8* dValidBytes = nullptr;          // device: nMasks byte masks, or nullptr
   bool noStreaming = false;            // go straight to the general kernels (a batch has already tried the streaming ones)
+  bool skipOne = false;                // the one-launch streaming decoder has just been tried on this blob: start with the two-launch form
   u8* hUsesNoData = nullptr;           // host [nBands] out (lerc_decode_4D), or nullptr
   double* hNoDataValues = nullptr;
 };

@@ -89,7 +89,9 @@ static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven, u32 nTiles 
 // Enqueues header check, discovery and decode of nTiles blobs (one band: nTiles == 1, dTileOffset == nullptr);
 // nothing is read back here.  dParams [nTiles] and dFallback [4 * nTiles] receive the verdicts; the flags in dFallback
 // are raised by writing `epoch` (tile_fast.h), so the cells need no clearing.
-static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8* dBlobs, u32 sizeBound, u32 nTiles, const u64* dTileOffset,
+// (one: the one-launch decoder -- short walks over sub-chunks of 512 bytes; else discovery + decode as two launches over chunks of
+// 2 KiB, which follow streams the first cannot: more tiny blocks in a row, longer stretches without a bit-stuffed block)
+static bool launchFastBands(Context& ctx, bool one, int dt, int nRows, int nCols, const u8* dBlobs, u32 sizeBound, u32 nTiles, const u64* dTileOffset,
                             const u32* dTileSize, void* dOut, FastDecodeParams* dParams, u32* dFallback, u32 epoch, u8* hCell = nullptr)
 {
   hipStream_t st = ctx.activeStream();
@@ -109,12 +111,14 @@ static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8
   fbuf.discCell = nullptr;
   fbuf.testRewalk = (fastTestGiveUp() & 4u) ? 1u : 0u;
   fbuf.wgCell = fbuf.wgGroupCell = fbuf.wgAcc = nullptr;
+  fbuf.wgStride = fbuf.wgGroupStride = 0;
   // (epoch-tagged cells, never cleared: they live as long as the context and share its area with the encoder's)
-  if (fastDecodeOneLaunch())
+  if (one)
   {
     // everything in one launch: a cell per workgroup and per group of workgroups, and the groups' checksum accumulators
     // (counters: left zero by the launch's last workgroup)
-    const size_t sWg = fastOneWgStride(fwp.nChunks), sGrp = fastOneGroupStride(fwp.nChunks);
+    const size_t sWg = fastOneWgStride(sizeBound, dtSize(dt)), sGrp = fastOneGroupStride(sizeBound, dtSize(dt));
+    fbuf.wgStride = (u32)sWg; fbuf.wgGroupStride = (u32)sGrp;
     fbuf.wgCell = (u64*)ctx.persistentState(1, (nT * (sWg + sGrp) + 8) * 8);
     fbuf.wgGroupCell = fbuf.wgCell ? fbuf.wgCell + nT * sWg : nullptr;
     fbuf.wgAcc = (u64*)ctx.persistentState(0, (nT * sGrp + 8) * 8);
@@ -141,10 +145,10 @@ static bool launchFastBands(Context& ctx, int dt, int nRows, int nCols, const u8
   return true;
 }
 
-static bool launchFastBand(Context& ctx, int dt, int nRows, int nCols, const u8* dBand, u32 sizeGiven, void* dOutBand, u8* dCell, u32 epoch,
+static bool launchFastBand(Context& ctx, bool one, int dt, int nRows, int nCols, const u8* dBand, u32 sizeGiven, void* dOutBand, u8* dCell, u32 epoch,
                            u8* hCell = nullptr)
 {
-  return launchFastBands(ctx, dt, nRows, nCols, dBand, sizeGiven, 1, nullptr, nullptr, dOutBand,
+  return launchFastBands(ctx, one, dt, nRows, nCols, dBand, sizeGiven, 1, nullptr, nullptr, dOutBand,
                          reinterpret_cast<FastDecodeParams*>(dCell + kCellParams), reinterpret_cast<u32*>(dCell + kCellFallback), epoch, hCell);
 }
 
@@ -197,7 +201,7 @@ bool decodeEnqueueStreaming(Context& ctx, const DecodeRequest& rq, u8* slot, u32
   // first: if a launch fails, what the operation that had the slot before left there must not read as this one's "ok")
   memset(slot + 64, 0, kCellBytes);
   (void)hipGetLastError();
-  if (!launchFastBand(ctx, dt, nRows, nCols, rq.dBlob, rq.blobSize, rq.dOut, dCells + 64, epoch, slot + 64)) return false;
+  if (!launchFastBand(ctx, fastDecodeOneLaunch() && !rq.skipOne, dt, nRows, nCols, rq.dBlob, rq.blobSize, rq.dOut, dCells + 64, epoch, slot + 64)) return false;
   if (hipGetLastError() != hipSuccess) { ctx.lastError = "lerc_amd: a streaming decode kernel could not be launched"; return false; }
   if (rq.nMasks > 0 && rq.dValidBytes) hipMemsetAsync(rq.dValidBytes, 1, (size_t)nRows * nCols, st);    // numValid == nPix or no verdict
   return true;
@@ -221,19 +225,22 @@ bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch)
 // Device-resident single-band blobs: everything is enqueued before a single byte of the blob has been seen by the
 // host (the header is checked on the device); one synchronisation.  handled == false: nothing was decided,
 // the caller goes the long way (header read, general kernels, exact status codes).
-static u32 decodeSpeculative(Context& ctx, const DecodeRequest& rq, bool& handled)
+static u32 decodeSpeculative(Context& ctx, const DecodeRequest& rq, bool& handled, bool& tried)
 {
-  handled = false;
+  handled = false; tried = false;
   u8* pin = (u8*)ctx.pinned(64 + kCellBytes);
   u32 epoch = 0;
   if (!pin || !decodeEnqueueStreaming(ctx, rq, pin, epoch)) return kOk;
+  tried = true;
   if (!ctx.sync()) return kFailed;
   handled = decodeStreamingVerdict(ctx, pin, epoch);
   return kOk;
 }
 
-static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, bool& fellBack)
+// (fastLevel: 2 the one-launch streaming decoder where a band qualifies, 1 the two-launch form, 0 the general kernels only)
+static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool& fellBack)
 {
+  const bool allowFast = fastLevel > 0;
   fellBack = false;
   ctx.lastDecodeStreamed = false;
   hipStream_t st = ctx.activeStream();
@@ -547,7 +554,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, bool allowFast, boo
     {
       FastBand& f = fast[iBand];
       f.epoch = ctx.nextEpoch();
-      if (!launchFastBand(ctx, dt, nRows, nCols, dBand, blobEnd, dOutBand, dCells + 64 + (size_t)iBand * kCellBytes, f.epoch)) return kFailed;
+      if (!launchFastBand(ctx, fastLevel == 2, dt, nRows, nCols, dBand, blobEnd, dOutBand, dCells + 64 + (size_t)iBand * kCellBytes, f.epoch)) return kFailed;
       ctx.lastDecodeStreamed = true;
       f.used = true;
       if (!finishMask()) return kFailed;    // all valid: the caller's mask bytes become 1s (Lerc.cpp:464-488 always writes them)
@@ -647,17 +654,27 @@ u32 decodeSpeculativeToHost(Context& ctx, const DecodeRequest& rq, void* hOut, s
 
 u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
 {
-  bool handled = false;
-  if (!rq.noStreaming)
+  // tiers: the one-launch streaming decoder, the two-launch form (which follows streams the first cannot), the general kernels
+  int level = rq.noStreaming ? 0 : ((fastDecodeOneLaunch() && !rq.skipOne) ? 2 : 1);
+  while (level > 0)
   {
-    const u32 src = decodeSpeculative(ctx, rq, handled);
+    bool handled = false, tried = false;
+    DecodeRequest r = rq;
+    r.skipOne = level < 2;
+    const u32 src = decodeSpeculative(ctx, r, handled, tried);
     if (src != kOk) return src;
     if (handled) { ctx.pathCount[2]++; return kOk; }
+    if (!tried) break;    // (not a request the streaming kernels take blind: decodeImpl looks at every band)
+    level--;
   }
   bool fellBack = false;
-  u32 rc = decodeImpl(ctx, rq, !rq.noStreaming, fellBack);
-  const bool repeated = (rc == kOk && fellBack);
-  if (repeated) rc = decodeImpl(ctx, rq, false, fellBack);
+  u32 rc = decodeImpl(ctx, rq, level, fellBack);
+  bool repeated = false;
+  while (rc == kOk && fellBack && level > 0)
+  {
+    repeated = --level == 0;
+    rc = decodeImpl(ctx, rq, level, fellBack);
+  }
   if (rc == kOk) ctx.pathCount[(repeated || !ctx.lastDecodeStreamed) ? 3 : 2]++;
   return rc;
 }
@@ -679,7 +696,8 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
     one.dBlob = rq.dArena + rq.hOffsets[t]; one.blobSize = rq.hSizes[t]; one.dt = rq.dt; one.nDepth = 1; one.nCols = rq.nCols;
     one.nRows = rq.nRows; one.nBands = 1; one.nMasks = 0; one.dValidBytes = nullptr;
     one.dOut = (u8*)rq.dOut + (size_t)t * tileElems * tbytes;
-    one.noStreaming = true;    // it has just been tried
+    one.noStreaming = !fastDecodeOneLaunch();    // the batch's kernels have just been tried: the two-launch form next (or, if the batch was that, the general kernels)
+    one.skipOne = true;
     return decodeDevice(ctx, one);
   };
   bool fastOk = fastDecodeEligible(rq.dt, 6, 8, rq.nRows, rq.nCols, 1, true) && ((uintptr_t)rq.dArena & 15) == 0
@@ -722,7 +740,7 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
     FastDecodeParams* dParams = reinterpret_cast<FastDecodeParams*>(dCells + 64);
     u32* dFallback = reinterpret_cast<u32*>(dCells + 64 + (size_t)n * sizeof(FastDecodeParams));
     const u32 epoch = ctx.nextEpoch();
-    if (!launchFastBands(ctx, rq.dt, rq.nRows, rq.nCols, rq.dArena, maxSize, (u32)n, dOff, dSize,
+    if (!launchFastBands(ctx, fastDecodeOneLaunch(), rq.dt, rq.nRows, rq.nCols, rq.dArena, maxSize, (u32)n, dOff, dSize,
                          (u8*)rq.dOut + (size_t)t0 * tileElems * tbytes, dParams, dFallback, epoch))
       return kFailed;
     hipMemcpyAsync(pin, dCells, cellsBytes, hipMemcpyDeviceToHost, st);

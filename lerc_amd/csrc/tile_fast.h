@@ -235,25 +235,31 @@ static const u32 kResolveChunks = 4;
 static const u32 kResolveChunks = 256;     // chunks a resolving block takes, one per thread
 #endif
 static const int kOneDiscChunks = (int)(16384u / kFastChunkBytes);       // (kept for the two-launch kernels' templates; no launch uses it any more)
-// The one-launch decoder (tile_fast_decode_one.hip): a workgroup stages kOneChunks consecutive chunks, walks them all, and decodes
-// the blocks that start in all of them but the first -- that one is the last chunk of the workgroup in front, walked again
-// here so that the entry of this workgroup's first own chunk (= the exit that chunk's walks agree on) is known without asking
-// anybody.  Workgroup 0 owns its first chunk too.  What travels between workgroups is one number: how many blocks start in a
-// workgroup's chunks (an epoch-tagged cell each, and one per kOneGroup workgroups for the group's total).
-#ifndef LERC_ONE_CHUNKS
-#define LERC_ONE_CHUNKS 16
+// The one-launch decoder (tile_fast_decode_one.hip): a workgroup stages kOneStage bytes of the blob as sub-chunks of fastOneSub()
+// bytes (short walks: a quarter of a discovery chunk), walks them all, and decodes the blocks that start in all of them but the
+// first -- that one is the last sub-chunk of the workgroup in front, walked again here so that the entry of this workgroup's
+// first own sub-chunk (= the exit that sub-chunk's walks agree on) is known without asking anybody.  Workgroup 0 owns its first
+// sub-chunk too.  What travels between workgroups is one number: how many blocks start in a workgroup's own bytes (an
+// epoch-tagged cell each, and one per kOneGroup workgroups for the group's total).
+static const u32 kOneStage = 32768;
+static const u32 kOneThreads = 512;
+#ifndef LERC_ONE_SUB
+#define LERC_ONE_SUB 512
 #endif
-static const u32 kOneChunks = LERC_ONE_CHUNKS;
-static const u32 kOneThreads = 32u * kOneChunks;                         // 16 threads per KiB staged, like k_fast_discover
+constexpr LERC_HD u32 fastOneSub(int typeBytes) { return (typeBytes == 8 && LERC_ONE_SUB < 1024) ? 1024u : (u32)LERC_ONE_SUB; }    // (at least a raw block + 1: a window lies inside its sub-chunk)
 #ifdef LERC_SMALL_GROUPS
 static const u32 kOneGroup = 2;
 #else
 static const u32 kOneGroup = 64;
 #endif
-LERC_HD u32 fastOneNumWG(u32 nChunks) { return nChunks <= kOneChunks ? 1u : 1u + (nChunks - kOneChunks + kOneChunks - 2u) / (kOneChunks - 1u); }
+LERC_HD u32 fastOneNumWG(u32 blobBytes, int typeBytes)
+{
+  const u32 sub = fastOneSub(typeBytes), nch = kOneStage / sub, nSub = (blobBytes + sub - 1u) / sub;
+  return nSub <= nch ? 1u : 1u + (nSub - nch + nch - 2u) / (nch - 1u);
+}
 LERC_HD u32 fastOneGroups(u32 nWG) { return (nWG + kOneGroup - 1u) / kOneGroup; }
-LERC_HD u32 fastOneWgStride(u32 nChunksBound) { return (fastOneNumWG(nChunksBound) + 3u) & ~1u; }        // cells per tile
-LERC_HD u32 fastOneGroupStride(u32 nChunksBound) { return (fastOneGroups(fastOneNumWG(nChunksBound)) + 3u) & ~1u; }    // group cells / accumulators per tile
+LERC_HD u32 fastOneWgStride(u32 bytesBound, int typeBytes) { return (fastOneNumWG(bytesBound, typeBytes) + 3u) & ~1u; }        // cells per tile
+LERC_HD u32 fastOneGroupStride(u32 bytesBound, int typeBytes) { return (fastOneGroups(fastOneNumWG(bytesBound, typeBytes)) + 3u) & ~1u; }    // group cells / accumulators per tile
 #ifndef LERC_DECODE_CHUNKS
 #define LERC_DECODE_CHUNKS 4
 #endif
@@ -299,7 +305,8 @@ struct FastDecodeBuffers
   u64* waveFletcher;   // [2 * nWaves] Fletcher partial sums (mod 65535) of the bytes each discovery workgroup staged
   u64* discCell;       // (unused)
   // the one-launch decoder's hand-offs (tile_fast_decode_one.hip)
-  u64* wgCell;         // [fastOneWgStride] epoch (32) | blocks that start in the workgroup's own chunks (32)
+  u32 wgStride, wgGroupStride;    // cells / group cells (and accumulators) from one tile's set to the next
+  u64* wgCell;         // [fastOneWgStride] epoch (32) | where the path of the workgroup's last sub-chunk ends, relative to the next workgroup's first staged byte (16) | blocks of the workgroup's own sub-chunks (16)
   u64* wgGroupCell;    // [fastOneGroupStride] epoch (32) | blocks of group g's workgroups (32), left by the group's last workgroup
   u64* wgAcc;          // [fastOneGroupStride] checksum terms of a group's workgroups and how many have arrived: A | B << 24 | n << 48
                        // (zero between calls: the launch's last workgroup folds and clears them)

@@ -18,6 +18,19 @@ run one LERC_AMD_DECODE_LAUNCHES=1
 run two LERC_AMD_DECODE_LAUNCHES=2
 run one_again LERC_AMD_DECODE_LAUNCHES=1
 for L in "$@"; do run "$(basename $L .so)" LERC_AMD_LIBRARY=$PWD/$L; done
+# PMC=1: instruction counts (one pass) of the default build and of every variant given
+if [ "${PMC:-0}" = "1" ]; then
+  ROOT=$PWD
+  for L in default "$@"; do
+    LIB=""; [ "$L" != default ] && LIB="LERC_AMD_LIBRARY=$ROOT/$L"
+    for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" ${PMC2:+"SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"}; do
+      (cd /tmp && rm -rf /tmp/prof_pmc && TMPDIR=/tmp timeout 300 env $LIB rocprofv3 --kernel-trace --pmc $SET -d /tmp/prof_pmc -o pmc -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-c5-anchor --rotate 0 > /dev/null 2> "$OUT/ab_pmc.err")
+      DB=$(find /tmp/prof_pmc -name '*.db' | head -1)
+      echo "== PMC $L"
+      python "$ROOT/tools/rocpd_summary.py" "$DB" fast 2>&1 | grep -v "^$" | cut -c1-160 | tee -a "$OUT/ab_pmc.txt"
+    done
+  done
+fi
 if [ -f lerc_amd/csrc/_var/trace.so ]; then
   PROBE_LIB=$PWD/lerc_amd/csrc/_var/trace.so timeout 200 python tools/trace_decode_one.py 2>&1 | tail -12
   PROBE_LIB=$PWD/lerc_amd/csrc/_var/trace.so timeout 200 python tools/trace_decode_one.py c3 2>&1 | tail -12
