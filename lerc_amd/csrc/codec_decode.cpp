@@ -89,7 +89,7 @@ static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven, u32 nTiles 
 // Enqueues header check, discovery and decode of nTiles blobs (one band: nTiles == 1, dTileOffset == nullptr);
 // nothing is read back here.  dParams [nTiles] and dFallback [4 * nTiles] receive the verdicts; the flags in dFallback
 // are raised by writing `epoch` (tile_fast.h), so the cells need no clearing.
-// (one: the one-launch decoder -- short walks over sub-chunks of 512 bytes; else discovery + decode as two launches over chunks of
+// (one: the one-launch decoder -- short walks over sub-chunks of 1 KiB; else discovery + decode as two launches over chunks of
 // 2 KiB, which follow streams the first cannot: more tiny blocks in a row, longer stretches without a bit-stuffed block)
 static bool launchFastBands(Context& ctx, bool one, int dt, int nRows, int nCols, const u8* dBlobs, u32 sizeBound, u32 nTiles, const u64* dTileOffset,
                             const u32* dTileSize, void* dOut, FastDecodeParams* dParams, u32* dFallback, u32 epoch, u8* hCell = nullptr)

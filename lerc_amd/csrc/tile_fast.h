@@ -236,7 +236,7 @@ static const u32 kResolveChunks = 256;     // chunks a resolving block takes, on
 #endif
 static const int kOneDiscChunks = (int)(16384u / kFastChunkBytes);       // (kept for the two-launch kernels' templates; no launch uses it any more)
 // The one-launch decoder (tile_fast_decode_one.hip): a workgroup stages kOneStage bytes of the blob as sub-chunks of fastOneSub()
-// bytes (short walks: a quarter of a discovery chunk), walks them all, and decodes the blocks that start in all of them but the
+// bytes (short walks: half a discovery chunk), walks them all, and decodes the blocks that start in all of them but the
 // first -- that one is the last sub-chunk of the workgroup in front, walked again here so that the entry of this workgroup's
 // first own sub-chunk (= the exit that sub-chunk's walks agree on) is known without asking anybody.  Workgroup 0 owns its first
 // sub-chunk too.  What travels between workgroups is one number: how many blocks start in a workgroup's own bytes (an
@@ -244,7 +244,7 @@ static const int kOneDiscChunks = (int)(16384u / kFastChunkBytes);       // (kep
 static const u32 kOneStage = 32768;
 static const u32 kOneThreads = 512;
 #ifndef LERC_ONE_SUB
-#define LERC_ONE_SUB 512
+#define LERC_ONE_SUB 1024
 #endif
 constexpr LERC_HD u32 fastOneSub(int typeBytes) { return (typeBytes == 8 && LERC_ONE_SUB < 1024) ? 1024u : (u32)LERC_ONE_SUB; }    // (at least a raw block + 1: a window lies inside its sub-chunk)
 #ifdef LERC_SMALL_GROUPS

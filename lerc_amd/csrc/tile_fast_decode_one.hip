@@ -4,15 +4,15 @@
 // The block stream stores no offsets (block k+1 starts where block k ends).  The two-launch form (tile_fast_decode.hip) reads
 // the blob twice -- once to find the block starts (k_fast_discover: lists of starts per chunk go to memory), once to decode
 // (k_fast_decode, behind a resolving step that turns per-chunk counts into block indices).  Here a workgroup of 512 threads
-//   1. stages 32 KiB of the blob (+ the first window behind them) in LDS as 64 sub-chunks of 512 bytes (doubles: 32 of 1 KiB),
-//      summing the Fletcher32 terms of its own sub-chunks on the way -- all but the first: that one is the last sub-chunk of
-//      the workgroup in front, staged and walked again here, so that the entry of this workgroup's first own sub-chunk (the
-//      exit all live walks of the sub-chunk in front agree on) is known without asking anybody; 1/64 of the discovery work
-//      done twice buys a launch, a pass over the blob, and the lists' way through memory;
+//   1. stages 32 KiB of the blob (+ the first window behind them) in LDS as 32 sub-chunks of 1 KiB, summing the Fletcher32
+//      terms of its own sub-chunks on the way -- all but the first: that one is the last sub-chunk of the workgroup in front,
+//      staged and walked again here, so that the entry of this workgroup's first own sub-chunk (the exit all live walks of
+//      the sub-chunk in front agree on) is known without asking anybody; 1/32 of the discovery work done twice buys a launch,
+//      a pass over the blob, and the lists' way through memory;
 //   2. finds the bit-stuffed block headers in every sub-chunk's first window by their byte pattern ("a byte 64 behind a byte
-//      10?nnnnn", looked for in the registers the bytes arrived in) and lets the heads among them walk, lane = sub-chunk,
-//      wave = head -- k_fast_discover's steps on chunks a quarter as long, so a walk is half a dozen steps, and walk 0's list
-//      of block starts stays in LDS;
+//      10?nnnnn": a lane takes a 16-byte unit of a window) and lets the heads among them walk, lane = sub-chunk x head --
+//      k_fast_discover's steps on chunks half as long, so a walk is ten steps, and walk 0's list of block starts stays in LDS
+//      (sub-chunks of 512 bytes: walks of 2 us instead of 3.5, but twice the windows to scan: 149 against 119 us; of 2 KiB: 122);
 //   3. settles, per own sub-chunk, which walk is the path and how many blocks belong to it, publishes the workgroup's block
 //      count in an epoch-tagged cell, and closes the lists up into one flat list of block starts;
 //   4. adds up the cells of the workgroups in front of it (those of its group of 64, and one cell per group in front, left by
@@ -42,17 +42,18 @@ template<class T> struct OneGeom
 {
   static constexpr int DT = DtOf<T>::v;
   static constexpr u32 TB = (u32)sizeof(T), W = kFastWindow((int)sizeof(T)), CH = fastOneSub((int)sizeof(T));
-  static constexpr u32 NCH = kOneStage / CH, NW = (u32)kDiscWalks, NT = kOneThreads, CAP = CH / 8u;    // (list cap: blocks of 8 bytes on average; the last block row of a 257 x 257 tile has 14-byte blocks)
+  static constexpr u32 NCH = kOneStage / CH, NW = (u32)kDiscWalks, NT = kOneThreads, CAP = CH / 8u < 128u ? CH / 8u : 128u;    // (list cap: blocks of 8 bytes on average; the last block row of a 257 x 257 tile has 14-byte blocks)
   static constexpr u32 kUnits = kOneStage / 16;                   // 16-byte units of the staged sub-chunks
   static constexpr u32 kOverhang = (W + 16 + 15) / 16;            // + the next sub-chunk's first window (walks end on a block start there)
   static constexpr u32 kStageUnits = kUnits + kOverhang;
   static constexpr u32 kBitWords = (W + 31) / 32;
-  static constexpr u32 kHitCap = 768;                             // block headers found in the windows (a few hundred)
+  static constexpr u32 kFoundCap = 768, kHitCap = 768;            // count bytes / block headers found in the windows (a few hundred)
   static constexpr u32 R = NT;                                    // blocks per decode round: one header per thread
   static constexpr u32 kMaxRel = NCH * CH + W - 1;                // last staged byte a block may start at
   static constexpr u32 kSlotsPerWave = 64u / NCH ? 64u / NCH : 1u;    // walks: lane = sub-chunk; a wave takes one head (two: doubles) of every sub-chunk
   static constexpr u32 kWalkWaves = NW / kSlotsPerWave;
-  static constexpr u32 kChShift = CH == 512u ? 9u : 10u;
+  static constexpr u32 kChShift = CH == 512u ? 9u : CH == 1024u ? 10u : 11u;
+  static constexpr u32 kNchShift = NCH == 64u ? 6u : NCH == 32u ? 5u : 4u;
 };
 
 template<class T, bool RAG> struct OneShared
@@ -72,7 +73,7 @@ template<class T, bool RAG> struct OneShared
         {
           u32 removed[G::NCH][G::kBitWords];       // headers that are the block right behind another one (or no block at all): no heads
           u32 strong[G::NCH][G::kBitWords];        // heads that are followed, exactly where they end, by another header found
-          u16 hit[G::kHitCap];                     // block headers found: position in the staged bytes
+          u16 found[G::kFoundCap], hit[G::kHitCap];    // count bytes / block headers found: position in the staged bytes
         } a;
         struct B                                   // ... from the walks on
         {
@@ -98,7 +99,7 @@ template<class T, bool RAG> struct OneShared
   u32 cum[G::NCH + 1];
   u64 fa[G::NT / 64], fb[G::NT / 64];
   u64 part;                                        // sum of the cells: this group's in the low half, the groups' in front in the high half
-  u32 nHit, over, bad, rewalk, lost, maxCount;
+  u32 nFound, nHit, over, bad, rewalk, lost, maxCount;
   FastDecodeParams hp;                             // the band header, parsed in full by the first wave
 };
 
@@ -127,11 +128,11 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
   constexpr u32 W = G::W, CH = G::CH, NCH = G::NCH, NW = G::NW, NT = G::NT, CAP = G::CAP, SH = G::kChShift;
   constexpr u32 kWaves = NT / 64;
   constexpr u32 kUnits = G::kUnits, kStageUnits = G::kStageUnits, kBitWords = G::kBitWords;
-  constexpr u32 kHitCap = G::kHitCap, kMaxRel = G::kMaxRel;
-  static_assert((NCH == 64 || NCH == 32) && NW == 8 && W <= CH && NCH * CH + 2 * W < 65535 && CAP <= 254, "lane layout / 16-bit positions / 8-bit counts");
+  constexpr u32 kFoundCap = G::kFoundCap, kHitCap = G::kHitCap, kMaxRel = G::kMaxRel;
+  static_assert((NCH == 64 || NCH == 32 || NCH == 16) && NW == 8 && W <= CH && NCH * CH + 2 * W < 65535 && CAP <= 254, "lane layout / 16-bit positions / 8-bit counts");
   static_assert(NCH * NW <= NT, "a thread per walk when the path is picked");
   auto& s_in = S.in; auto& s_hits = S.u.d.hits; auto& s_removed = S.u.d.p.a.removed; auto& s_strong = S.u.d.p.a.strong;
-  auto& s_hit = S.u.d.p.a.hit; auto& s_fin = S.u.d.fin;
+  auto& s_found = S.u.d.p.a.found; auto& s_hit = S.u.d.p.a.hit; auto& s_fin = S.u.d.fin;
   auto& s_mini = S.u.d.p.b.mini; auto& s_exit = S.u.d.p.b.exit; auto& s_cnt = S.u.d.p.b.cnt; auto& s_key = S.u.d.p.b.key;
 
   const RagCounts rc = ragCounts(nRows, nCols);
@@ -193,7 +194,7 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
   for (u32 i = threadIdx.x; i < (NCH + 1) * kBitWords; i += NT) (&s_hits[0][0])[i] = 0u;
   for (u32 i = threadIdx.x; i < NCH * kBitWords; i += NT) { (&s_removed[0][0])[i] = 0u; (&s_strong[0][0])[i] = 0u; }
   if (threadIdx.x < NCH) S.nFinal[threadIdx.x] = 0u;
-  if (threadIdx.x == 0) { S.nHit = 0u; S.over = 0u; S.bad = 0u; S.rewalk = 0u; S.lost = 0u; S.part = 0ull; S.maxCount = 0u; }
+  if (threadIdx.x == 0) { S.nFound = 0u; S.nHit = 0u; S.over = 0u; S.bad = 0u; S.rewalk = 0u; S.lost = 0u; S.part = 0ull; S.maxCount = 0u; }
   __syncthreads();
   if (!S.hp.ok) return;    // (not a band the streaming kernels take: the header says so in full only)
 
@@ -270,24 +271,32 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
       // 0x80 in every byte of hdr4 that reads 10?nnnnn, n != 0: bit 7 set and bit 6 clear; the low five bits + 31 reach bit 5
       const u32 m10 = hdr4 & ~(hdr4 << 1), mN = ((hdr4 & 0x1F1F1F1Fu) + 0x1F1F1F1Fu) << 2;
       u32 m = isCount & m10 & mN;
-      while (m)    // (one lane in six has any)
+      // the few count bytes found (one lane in six has any) go to a queue
+      while (m)
       {
         const u32 q = 16u * i + 4u * j + ((u32)(__ffs((int)m) - 1) >> 3);
         m &= m - 1u;
-#pragma unroll
-        for (u32 tc = 0; tc < 4; tc++)
-        {
-          const u32 offB = (offBytesTable<DT>() >> (4u * tc)) & 15u;
-          if (offB == 0u || q < 2u + offB) continue;
-          const u32 p = q - 2u - offB;                                   // the flag byte (relative to the staged bytes)
-          const u32 pw = p - (win << SH);
-          if ((p >> SH) != win || pw >= W || r0 + p >= blobEnd) continue;
-          const u32 flag = (s_in[p >> 2] >> (8u * (p & 3u))) & 0xFFu;
-          if ((flag & 3u) != 1u || (flag >> 6) != tc || (v5 && (flag & 4u))) continue;
-          atomicOr(&s_hits[win][pw >> 5], 1u << (pw & 31u));
-          if (win < NCH) { const u32 at = atomicAdd(&S.nHit, 1u); if (at < kHitCap) s_hit[at] = (u16)p; else S.over = 1u; }
-        }
+        const u32 at = atomicAdd(&S.nFound, 1u);
+        if (at < kFoundCap) s_found[at] = (u16)q; else S.over = 1u;
       }
+    }
+  }
+  __syncthreads();
+  // a count byte stands 2 + (bytes of the offset) behind the block's flag byte: try each offset type, one lane each
+  {
+    const u32 nFound = min(S.nFound, kFoundCap);
+    for (u32 h = threadIdx.x; h < 4u * nFound; h += NT)
+    {
+      const u32 q = s_found[h >> 2], tc = h & 3u;
+      const u32 offB = (offBytesTable<DT>() >> (4u * tc)) & 15u;
+      if (offB == 0u || q < 2u + offB) continue;
+      const u32 p = q - 2u - offB;                                       // the flag byte (relative to the staged bytes)
+      const u32 win = p >> SH, pw = p & (CH - 1u);
+      if (pw >= W || r0 + p >= blobEnd || ((cs + win) << SH) <= dataBegin) continue;
+      const u32 flag = (s_in[p >> 2] >> (8u * (p & 3u))) & 0xFFu;
+      if ((flag & 3u) != 1u || (flag >> 6) != tc || (v5 && (flag & 4u))) continue;
+      atomicOr(&s_hits[win][pw >> 5], 1u << (pw & 31u));
+      if (win < NCH) { const u32 at = atomicAdd(&S.nHit, 1u); if (at < kHitCap) s_hit[at] = (u16)p; else S.over = 1u; }
     }
   }
   if (threadIdx.x == 0 && r0 <= dataBegin)    // the stream's first block, whatever it is
@@ -358,7 +367,7 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
   if (threadIdx.x < NCH) s_key[threadIdx.x] = 0xFFFFFFFFu;
   if ((u32)w < G::kWalkWaves)
   {
-    const u32 wc = (u32)lane & (NCH - 1u), slot = (u32)w * G::kSlotsPerWave + ((u32)lane >> (NCH == 64u ? 6 : 5));
+    const u32 wc = (u32)lane & (NCH - 1u), slot = (u32)w * G::kSlotsPerWave + ((u32)lane >> G::kNchShift);
     const u32 wChunk = cs + wc;
     const u32 wStart = wChunk << SH;
     const bool wLive = wChunk < nSub;
@@ -378,7 +387,7 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
     LeanWords<DT> xw = leanFetch<DT>(s_in, min(rel, kMaxRel));
     u32 sig = (__builtin_amdgcn_alignbit(xw.x1, xw.x0, 8u * rel) >> 2) & pattern;
     bool active = rel < endRel;
-#ifndef HIPSIM
+#if !defined(HIPSIM) && defined(LERC_ONE_WALK_PRIO)
     __builtin_amdgcn_s_setprio(3);    // (the walks are what the workgroup waits for; a walking wave issues an instruction every few cycles)
 #endif
     while (__builtin_amdgcn_ballot_w64(active) != 0ull)
@@ -423,7 +432,7 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
       count += ok ? 1u : 0u;
       sig = ok ? sg : sig;
     }
-#ifndef HIPSIM
+#if !defined(HIPSIM) && defined(LERC_ONE_WALK_PRIO)
     __builtin_amdgcn_s_setprio(0);
 #endif
     s_exit[wc][slot] = alive ? (u16)(cur - r0) : (u16)0xFFFFu;
