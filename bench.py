@@ -49,6 +49,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=8192, help="raster edge (default: the BASELINE 8192)")
     ap.add_argument("--max-z-err", type=float, default=0.01)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the c3 / c4 sub-objects (BASELINE configs[2], configs[3])")
     ap.add_argument("--workload", choices=("auto", "c2", "c5"), default="auto",
                     help="auto (default): c2 on one GPU -- the BASELINE metric: one 8192^2 raster --, c5 on several: the 65 536-tile "
                          "mosaic sharded over the ranks with the RCCL gather of the blobs (BASELINE configs[4])")
@@ -148,13 +149,100 @@ def cpu_baseline_tiles(tiles_np, max_z_err, seconds=8.0):
                       f"one process per core on {len(res)} cores, lerc_computeCompressedSize+lerc_encode+lerc_decode each"}
 
 
+def other_config(torch, api, codec, name, x, max_z_err, n_depth, steps=5, warmup=2, reference=True):
+    """BASELINE configs[2] / configs[3] on this GPU, device resident: `steps` round trips (lerc_amd_encode_device +
+    lerc_amd_decode_device, the host waits for each call), per-kernel HIP-event times, the blob compared with the reference's."""
+    import hashlib
+    L = codec.lib
+    out = torch.empty(x.numel() * x.element_size() + (1 << 20), dtype=torch.uint8, device=x.device)
+    dec = torch.empty_like(x)
+    n_pix = int(x.shape[0]) * int(x.shape[1])
+    raw = x.numel() * x.element_size()
+
+    def one():
+        rc, nb = api.encode_device(codec, x, max_z_err, out, n_depth)
+        rc2 = api.decode_device(codec, out, nb, dec, n_depth)
+        if rc != 0 or rc2 != 0:
+            raise RuntimeError(f"{name}: encode / decode failed: status {rc} / {rc2}: {codec.last_error()}")
+        return nb
+
+    for _ in range(warmup):
+        nb = one()
+    torch.cuda.synchronize()
+    L.lerc_amd_profile_enable(codec.h, 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nb = one()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    L.lerc_amd_profile_enable(codec.h, 0)
+    buf = ct.create_string_buffer(1 << 16)
+    L.lerc_amd_profile_read(codec.h, buf, len(buf), 1)
+    kern = {}
+    for line in buf.value.decode().splitlines():
+        k, ms, cnt = line.split()
+        kern[k] = {"avg_ms": round(float(ms) / max(int(cnt), 1), 5), "launches": int(cnt)}
+    ms = el / steps * 1e3
+    kms = sum(v["avg_ms"] * v["launches"] for v in kern.values()) / steps
+    b_rt = 2 * (raw + nb)
+    same = bool(torch.equal(dec.view(torch.uint8), x.view(torch.uint8))) if max_z_err == 0 else None
+    res = {"workload": name, "value": round(n_pix * steps / el / 1e6, 2), "unit": "MPix/s", "steps": steps, "ms_per_step": round(ms, 4),
+           "kernel_ms_per_step": round(kms, 4), "blob_bytes": int(nb), "compression_ratio": round(raw / max(nb, 1), 3),
+           "algorithmic_bytes": b_rt, "frac_of_hbm_peak_wall": round(b_rt / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+           "frac_of_hbm_peak_kernels": round(b_rt / (max(kms, 1e-9) / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+           "host": "every call waits for its own result", "lossless_round_trip": same, "kernels": kern}
+    sha = hashlib.sha256(out[:nb].cpu().numpy().tobytes()).hexdigest()
+    res["blob_sha256"] = sha
+    if reference:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import capi
+        lib = capi.ref() or capi.oracle()
+        if lib is not None:
+            xn = x.cpu().numpy()
+            t0 = time.perf_counter()
+            rc, blob = lib.encode(xn, max_z_err)
+            t1 = time.perf_counter()
+            res["blob_matches_reference"] = bool(rc == 0 and len(blob) == nb and hashlib.sha256(bytes(blob)).hexdigest() == sha)
+            res["reference_encode_s"] = round(t1 - t0, 3)
+    res["verified"] = bool((same is not False) and res.get("blob_matches_reference", True))
+    del out, dec
+    return res
+
+
+def csrc_digest():
+    """sha256 over the kernel and host sources of lerc_amd/csrc (what a committed HBM-traffic file was measured on)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "lerc_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".cpp", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def traffic_files():
+    """the committed HBM-traffic files, newest first -- only those measured on THESE sources (a file that carries no digest,
+    or another one, is stale: the kernels changed since the PMC passes)"""
+    import glob
+    good, stale = [], []
+    now = csrc_digest()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        (good if d.get("csrc_digest") == now else stale).append(path)
+    return good, stale
+
+
 def measured_traffic(kernel_group, size):
     """HBM bytes per launch of a kernel group from the committed PMC passes (profiles/*hbm_traffic.json, written
     by tools/profile_run.sh: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE).
     Counters cannot be read from inside the timed process, so this is the figure of the last profiled build of
     the same workload -- None when no such file or kernel group exists."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json")), reverse=True):
+    for path in traffic_files()[0]:
         try:
             with open(path) as f:
                 t = json.load(f)
@@ -168,7 +256,7 @@ def measured_traffic(kernel_group, size):
 def measured_traffic_table(size):
     """All kernel groups of the newest committed traffic file for this raster size (see measured_traffic), or None."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json")), reverse=True):
+    for path in traffic_files()[0]:
         try:
             with open(path) as f:
                 t = json.load(f)
@@ -331,25 +419,36 @@ def main():
                 raise RuntimeError(f"tile decode failed: status {rc}: {codec.last_error()}")
             return
         if tiles_mode:
+            te0 = time.perf_counter()
             rc, offs, sizes, used = api.encode_tiles_device(codec, x, args.max_z_err, out)
             if rc != 0:
                 raise RuntimeError(f"tile encode failed: status {rc}: {codec.last_error()}")
+            te1 = time.perf_counter()
             state["blob_bytes"] = int(sizes.sum())
+            flight = None
             if world > 1:
-                # the exchange step: all ranks' blobs on rank 0 (timed inside the step; its own share reported as well)
+                # the exchange step: all ranks' blobs on rank 0.  The transfers are enqueued here and run beside what this rank
+                # does next -- the decode of its own tiles does not hang on them (timed inside the step: start to arrival, and
+                # what of it was still to wait for behind the decode)
+                flight = shard.gather_arenas_start(out, used, offs, sizes, root=0)
+            tg0 = time.perf_counter()
+            rc = api.decode_tiles_device(codec, out, offs, sizes, y)
+            if rc != 0:
+                raise RuntimeError(f"tile decode failed: status {rc}: {codec.last_error()}")
+            td1 = time.perf_counter()
+            if flight is not None:
+                mosaic, t_off, t_size, _ = flight.finish()
                 torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                mosaic, t_off, t_size, _ = shard.gather_arenas(out, used, offs, sizes, root=0)
-                torch.cuda.synchronize()
-                state["gather_s"] += time.perf_counter() - t0
+                tg1 = time.perf_counter()
+                state["gather_s"] += tg1 - te1
+                state["gather_wait_s"] = state.get("gather_wait_s", 0.0) + (tg1 - td1)
                 state["gather_steps"] += 1
                 if rank == 0:
                     state["gather_bytes"] = int(mosaic.numel()) - int(used)    # what arrived over the links
                     state["mosaic_tiles"] = int(t_off.numel())
                 del mosaic
-            rc = api.decode_tiles_device(codec, out, offs, sizes, y)
-            if rc != 0:
-                raise RuntimeError(f"tile decode failed: status {rc}: {codec.last_error()}")
+            state["encode_s"] = state.get("encode_s", 0.0) + (te1 - te0)
+            state["decode_s"] = state.get("decode_s", 0.0) + (td1 - tg0)
             return
         if state["async"]:
             rc, t1 = api.encode_device_async(codec, x, args.max_z_err, out)
@@ -392,6 +491,7 @@ def main():
             step(i % n_sets)
         drain()
         state["gather_s"], state["gather_steps"] = 0.0, 0
+        state["gather_wait_s"], state["encode_s"], state["decode_s"] = 0.0, 0.0, 0.0
         barrier()
         codec.lib.lerc_amd_profile_enable(codec.h, 1)
         t0 = time.perf_counter()
@@ -411,6 +511,18 @@ def main():
 
     elapsed, prof = timed(1)
     gather = dict(state)
+    per_rank = None
+    if tiles_mode and world > 1:
+        # every rank's share of a step, so that the first run on hardware can be read from one line
+        mine = torch.tensor([state.get("encode_s", 0.0), state.get("decode_s", 0.0), state["gather_s"], state.get("gather_wait_s", 0.0),
+                             float(state["blob_bytes"]), float(sets[0][0].shape[0])], dtype=torch.float64, device=dev if not one_device else "cpu")
+        table = torch.empty(6 * world, dtype=torch.float64, device=mine.device)
+        dist.all_gather_into_tensor(table, mine)
+        table = table.cpu().view(world, 6)
+        k = max(args.steps, 1)
+        per_rank = [{"rank": r, "tiles": int(table[r, 5]), "blob_bytes": int(table[r, 4]), "encode_ms": round(float(table[r, 0]) / k * 1e3, 4),
+                     "decode_ms": round(float(table[r, 1]) / k * 1e3, 4), "gather_ms_start_to_arrival": round(float(table[r, 2]) / k * 1e3, 4),
+                     "gather_ms_waited_behind_decode": round(float(table[r, 3]) / k * 1e3, 4)} for r in range(world)]
     timed_blob_bytes = int(state["blob_bytes"])    # of the TIMED pass (buffer set 0); later passes must not overwrite it
     # the blob the timed pass left in set 0's buffer (its last step's), before anything else writes there
     import hashlib
@@ -467,6 +579,22 @@ def main():
         except (torch.OutOfMemoryError, RuntimeError) as e:
             c5_anchor = {"error": str(e)[:200]}
 
+    # BASELINE configs[2] and configs[3] beside it (parity-test cases with their own timing: not the line's value)
+    others = None
+    if world == 1 and not tiles_mode and not args.no_other_configs and n == 8192:
+        others = {}
+        del sets[1:]
+        torch.cuda.empty_cache()
+        for key, name, make, depth in (("c3", "16384x16384 uint16 DEM, MaxZError=0 (lossless bit-stuff path)", synth.c3_uint16, 1),
+                                       ("c4", "4096x4096 nDepth=3 byte RGB, MaxZError=0 (8-bit Huffman path)", synth.c4_rgb_u8, 3)):
+            try:
+                xo = make(device=dev)
+                others[key] = other_config(torch, api, codec, name, xo, 0, depth, reference=not args.no_cpu_baseline)
+                del xo
+                torch.cuda.empty_cache()
+            except (torch.OutOfMemoryError, RuntimeError) as e:
+                others[key] = {"error": str(e)[:200]}
+
     if rank == 0:
         blob_bytes = timed_blob_bytes
         raw_bytes = n_pix * 4
@@ -491,6 +619,10 @@ def main():
             if ceiling:
                 roofline["measured_ceiling"] = ceiling
                 roofline["frac_of_measured_ceiling"] = round(ach / ceiling["GBps"], 5)
+            if roofline["traffic"] is None and not tiles_mode:
+                stale = traffic_files()[1]
+                roofline["traffic_note"] = ("no committed PMC passes of these kernel sources (lerc_amd/csrc digest " + csrc_digest()
+                                            + (("; stale: " + ", ".join(os.path.basename(q) for q in stale[:2])) if stale else "") + ")")
             tt = measured_traffic_table(n) if not tiles_mode else None
             if tt and all(k in tt[1] for k in prof):
                 step_traffic = sum(tt[1][k] * prof[k][1] for k in prof) / max(args.steps, 1)
@@ -538,7 +670,12 @@ def main():
             gbps = gather["gather_bytes"] / max(g_s, 1e-9) / 1e9
             res["gather"] = {"bytes_into_root": gather["gather_bytes"], "ms_per_step": round(g_s * 1e3, 4), "GBps": round(gbps, 2),
                              "links": world - 1, "frac_of_xgmi": round(gbps / ((world - 1) * XGMI_LINK_GBS), 4),
-                             "peak": f"{world - 1} links x {XGMI_LINK_GBS} GB/s into the root"}
+                             "peak": f"{world - 1} links x {XGMI_LINK_GBS} GB/s into the root",
+                             "ms_waited_behind_decode": round(gather.get("gather_wait_s", 0.0) / gather["gather_steps"] * 1e3, 4),
+                             "note": "the transfers are enqueued behind the batched encode and run beside the rank's own batched decode; "
+                                     "ms_per_step is start to arrival on rank 0, ms_waited_behind_decode what was left to wait for"}
+        if per_rank is not None:
+            res["per_rank"] = per_rank
         res["config"]["host"] = ("K steps enqueued on the stream, one wait at the end (lerc_amd_encode_device_async / lerc_amd_decode_device_async)"
                                  if state["async"] else "every call waits for its own result")
         if sync_run is not None:
@@ -571,6 +708,8 @@ def main():
                     res["config"]["verified"] = False
         if c5_anchor is not None:
             res["c5_1gpu"] = c5_anchor
+        if others:
+            res.update(others)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -143,6 +143,8 @@ static void rlePiece(const u8* b, size_t n, size_t K, size_t p, std::vector<u8>&
 {
   const size_t begin = p ? rleCutIn(b, n, K, p) : 0;
   if (p && !begin) return;
+  // (where this piece ends: the first cut of a window behind it.  A mask without runs has no cut anywhere: each window is then
+  // looked through once here and once by its own worker, which gives up -- bytewise, but without coding anything)
   size_t end = n;
   for (size_t q = p + 1; q < K; q++) { const size_t c = rleCutIn(b, n, K, q); if (c) { end = c; break; } }
   // (into a vector of this thread's own and handed over at the end: the pieces' vectors lie side by side, and every push_back
@@ -172,6 +174,10 @@ bool rleEncodeWhenReady(const u8* b, size_t n, const std::function<bool()>& read
   std::atomic<int> state(0);    // 1: the bytes are there, -1: they will not come
   std::vector<std::future<void> > job;
   std::vector<size_t> inLine;
+  job.reserve(K); inLine.reserve(K);
+  // (whatever throws before the flag is set -- ready() itself, say --: the workers must not be left spinning on it, or the
+  // futures' destructors would wait for them for ever; declared behind the futures, so it goes first)
+  struct Release { std::atomic<int>& s; ~Release() { int zero = 0; s.compare_exchange_strong(zero, -1, std::memory_order_acq_rel); } } release{ state };
   for (size_t p = 1; p < K; p++)
   {
     try
@@ -179,7 +185,8 @@ bool rleEncodeWhenReady(const u8* b, size_t n, const std::function<bool()>& read
       job.push_back(std::async(std::launch::async, [&, p]()
       {
         int st;
-        while ((st = state.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+        for (unsigned spins = 0; (st = state.load(std::memory_order_acquire)) == 0; spins++)    // (the bits travel for a third of a millisecond: yield first, then sleep in short steps)
+          if (spins < 64) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
         if (st > 0) rlePiece(b, n, K, p, part[p]);
       }));
     }

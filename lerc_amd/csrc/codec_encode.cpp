@@ -1174,11 +1174,10 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
     const u32 nWGt = fastFusedNumWG(rq.dt, rq.nRows, rq.nCols);
     const size_t cellWords = fastFusedCellWords(nWGt), counterWords = fastFusedCounterWords(nWGt);
     const u64 slotBytes = slotted ? rq.slotBytes : ((tileElems * tb / 2 + 4096) + 15) & ~15ull;
-    const int maxBatch = (int)std::max<size_t>(1, std::min<size_t>((size_t)rq.nTiles, ((size_t)2 << 30) / slotBytes));
     const bool isFlt = rq.dt >= DT_Float;
-    for (int t0 = 0; t0 < rq.nTiles; t0 += maxBatch)
+    // one launch for tiles [t0, t0 + n), every blob in a slot of slotBytes; redoOut: the tiles it hands back, with the reason bits
+    auto runBatch = [&](int t0, int n, u64 slotBytes, std::vector<std::pair<int, u32> >& redoOut) -> u32
     {
-      const int n = std::min(maxBatch, rq.nTiles - t0);
       if (!ctx.reserve((size_t)n * ((slotted ? 0 : slotBytes) + sizeof(FastEncodeResult) + 8) + (1u << 16))) return kFailed;
       u8* cells = ctx.persistentState(1, (size_t)n * cellWords * 8 + 256);
       u8* counters = ctx.persistentState(0, (size_t)n * counterWords * 8 + 256);
@@ -1238,7 +1237,7 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
       if (ctx.profOn()) ctx.profCollect();
       const FastEncodeResult* res = reinterpret_cast<const FastEncodeResult*>(pin);
       const u64* off = reinterpret_cast<const u64*>(pin + resBytes);
-      redo.clear();
+      redoOut.clear();
       bool anyStuck = false;
       for (int i = 0; i < n; i++)
       {
@@ -1246,7 +1245,7 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
         {
           anyStuck = anyStuck || res[i].stuck != 0;
           if (!slotted && (res[i].redoReason & 128u)) return kBufferTooSmall;    // the arena is full
-          redo.push_back(t0 + i);    // (slotted: a tile that does not fit its slot says so when it is encoded by itself)
+          redoOut.push_back(std::make_pair(t0 + i, res[i].stuck ? 0u : res[i].redoReason));    // (slotted: a tile that does not fit its slot says so when it is encoded by itself)
           continue;
         }
         rq.hOffsets[t0 + i] = slotted ? (u64)(t0 + i) * slotBytes : off[i];
@@ -1255,7 +1254,37 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
       }
       if (anyStuck) ctx.wipePersistentState();
       if (!slotted) end = off[n];
-      for (int t : redo) { const u32 rc = encodeOne(t); if (rc != kOk) return rc; }    // (reuses the workspace: the batch is done with it)
+      return kOk;
+    };
+    // (a tile that compresses to more than half its raw size -- lossless noise, a small error bound -- does not fit the batch's
+    // slots.  A few such tiles are encoded one by one behind the batch; a batch full of them is encoded once more with slots
+    // that hold raw blocks, instead of tile after tile with a wait each)
+    const u64 slotBig = slotted ? slotBytes : ((tileElems * tb + tileElems / 64 + 4096) + 15) & ~15ull;
+    // (a tile is a blockIdx.y: at most 65535 of them per launch)
+    const int maxBatch = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)rq.nTiles, 65535), ((size_t)2 << 30) / slotBytes));
+    const int maxBig = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)rq.nTiles, 65535), ((size_t)2 << 30) / slotBig));
+    std::vector<std::pair<int, u32> > back;
+    for (int t0 = 0; t0 < rq.nTiles; t0 += maxBatch)
+    {
+      const int n = std::min(maxBatch, rq.nTiles - t0);
+      const u64 end0 = end;
+      const unsigned long long count0 = ctx.pathCount[0];
+      u32 rc = runBatch(t0, n, slotBytes, back);
+      if (rc != kOk) return rc;
+      size_t tooBig = 0;
+      for (const auto& r : back) if (r.second == 64u) tooBig++;    // (kRedoCapacity and nothing else)
+      if (!slotted && tooBig > (size_t)std::max(8, n / 32))
+      {
+        end = end0; ctx.pathCount[0] = count0;
+        for (int s0 = t0; s0 < t0 + n; s0 += maxBig)
+        {
+          rc = runBatch(s0, std::min(maxBig, t0 + n - s0), slotBig, back);
+          if (rc != kOk) return rc;
+          for (const auto& r : back) { rc = encodeOne(r.first); if (rc != kOk) return rc; }
+        }
+        continue;
+      }
+      for (const auto& r : back) { rc = encodeOne(r.first); if (rc != kOk) return rc; }    // (reuses the workspace: the batch is done with it)
     }
     arenaUsed = slotted ? (u64)rq.nTiles * slotBytes : end;
     return kOk;

@@ -8,7 +8,16 @@ struct HuffGeom { int nRows, nCols, nDepth; };
 
 static const int kHuffRun = 128;         // stream elements per encoder thread (runs with a table of bit offsets)
 static const int kHuffSelfRun = 64;      // ... where the packer finds its offsets itself (launchHuffPack with cells)
-static const int kHuffSubWordsMin = 33, kHuffSubWordsMax = 41;    // 32-bit words per speculative decode sub-sequence (odd; huffSubWords picks)
+// 32-bit words per speculative decode sub-sequence (odd; huffSubWords picks).  The decoders are bound by the latency of a
+// symbol's two dependent LDS reads, so what counts is how many threads a CU holds -- how little LDS a workgroup takes: its
+// slice of the stream (256 sub-sequences) + the table
+#ifndef LERC_HUFF_SUB_MIN
+#define LERC_HUFF_SUB_MIN 33
+#define LERC_HUFF_SUB_MAX 41
+#define LERC_HUFF_WG_PER_CU 3
+#endif
+static const int kHuffSubWordsMin = LERC_HUFF_SUB_MIN, kHuffSubWordsMax = LERC_HUFF_SUB_MAX;
+static const int kHuffWgPerCu = LERC_HUFF_WG_PER_CU;    // decoder workgroups a CU holds at that size (LDS)
 static const int kHuffLutBits = 12;      // Huffman.h:37 uses the same look-up width
 
 struct HuffDecodeTable

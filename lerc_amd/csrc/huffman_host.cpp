@@ -442,7 +442,7 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
   const u64 streamBits = nWords * 32;
   // sub-sequence length: the decoders' workgroups hold ~52 KB of LDS, three of them share a compute unit
   static const int computeUnits = []() { hipDeviceProp_t pr; int dev = 0; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
-  const u32 subWords = huffSubWords(streamBits, 3u * (u32)computeUnits);
+  const u32 subWords = huffSubWords(streamBits, (u32)kHuffWgPerCu * (u32)computeUnits);
   const u64 subBits = (u64)subWords * 32u;
   const u32 nSub = (u32)((streamBits + subBits - 1) / subBits);
 

@@ -578,7 +578,10 @@ static const int kHuffDecThreads = 16;
 static const int kHuffWarmWords = 1, kHuffTailWords = 4;
 #else
 static const int kHuffDecThreads = 256;
-static const int kHuffWarmWords = 8, kHuffTailWords = 4;
+#ifndef LERC_HUFF_WARM
+#define LERC_HUFF_WARM 8
+#endif
+static const int kHuffWarmWords = LERC_HUFF_WARM, kHuffTailWords = 4;
 #endif
 static const int kHuffStageWords = kHuffDecThreads * kHuffSubWordsMax + kHuffWarmWords + kHuffTailWords;
 

@@ -57,7 +57,29 @@ def gather_manifest(local_sizes, n_tiles, device="cpu"):
     return sizes, offsets
 
 
+class GatherInFlight:
+    """The exchange step between its two halves: the transfers are enqueued (under RCCL they run on the collective's own
+    stream, beside whatever the caller enqueues next -- a rank decodes its own tiles while its blobs travel), finish() waits
+    for them and returns what gather_arenas returns."""
+
+    def __init__(self, result=None, reqs=(), build=None):
+        self._result, self._reqs, self._build = result, list(reqs), build
+
+    def finish(self):
+        for req in self._reqs:
+            req.wait()
+        self._reqs = []
+        if self._build is not None:
+            self._result, self._build = self._build(), None
+        return self._result
+
+
 def gather_arenas(arena, used, offsets, sizes, root=0):
+    """The exchange step of a mosaic job in one call: gather_arenas_start(...).finish()."""
+    return gather_arenas_start(arena, used, offsets, sizes, root).finish()
+
+
+def gather_arenas_start(arena, used, offsets, sizes, root=0):
     """The exchange step of a mosaic job: the blobs of all ranks' tiles end up on `root`, in rank (= tile) order.
 
     arena    this rank's blob arena (uint8 tensor on the job's device: HBM under RCCL, host memory under gloo)
@@ -65,7 +87,10 @@ def gather_arenas(arena, used, offsets, sizes, root=0):
     offsets  int64 / uint64 array-like [nLocalTiles]: where each local tile's blob starts in `arena`
     sizes    array-like [nLocalTiles]: its length
 
-    Returns on root (mosaic, tile_offsets, tile_sizes, rank_bases): `mosaic` a uint8 tensor on the same device holding
+    offsets need not be monotonic (tiles a batch handed back to the general path sit behind the batch's own), a rank may
+    hold no tile at all.
+
+    finish() returns on root (mosaic, tile_offsets, tile_sizes, rank_bases): `mosaic` a uint8 tensor on the same device holding
     the ranks' arenas back to back (each starting at a multiple of 16 bytes, as inside an arena), tile_offsets /
     tile_sizes int64 CPU tensors over ALL tiles in tile order (offsets into `mosaic`), rank_bases where each rank's
     arena starts.  Other ranks get (None, None, None, None).  Works for a single process (no process group) too.
@@ -79,7 +104,7 @@ def gather_arenas(arena, used, offsets, sizes, root=0):
     n_local = int(offsets.numel())
     used = int(used)
     if world == 1:
-        return arena[:used], offsets.clone(), sizes.clone(), [0]
+        return GatherInFlight((arena[:used], offsets.clone(), sizes.clone(), [0]))
 
     # 1. how much everybody has: [bytes in use, tiles] (on the device under RCCL; gloo moves host memory)
     tdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -115,11 +140,13 @@ def gather_arenas(arena, used, offsets, sizes, root=0):
             ops.append(dist.P2POp(dist.isend, arena[:used], root))
         if n_local:
             ops.append(dist.P2POp(dist.isend, meta, root))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+    reqs = dist.batch_isend_irecv(ops) if ops else []
     if rank != root:
-        return None, None, None, None
-    all_off = torch.cat([metas[r][0].cpu() + bases[r] for r in range(world)]) if sum(tiles) else torch.zeros(0, dtype=torch.int64)
-    all_size = torch.cat([metas[r][1].cpu() for r in range(world)]) if sum(tiles) else torch.zeros(0, dtype=torch.int64)
-    return mosaic[:total], all_off, all_size, bases
+        keep = (arena, meta)    # (what is being sent stays alive until finish())
+        return GatherInFlight((None, None, None, None), reqs, lambda: (keep and None, None, None, None))
+
+    def build():
+        all_off = torch.cat([metas[r][0].cpu() + bases[r] for r in range(world)]) if sum(tiles) else torch.zeros(0, dtype=torch.int64)
+        all_size = torch.cat([metas[r][1].cpu() for r in range(world)]) if sum(tiles) else torch.zeros(0, dtype=torch.int64)
+        return mosaic[:total], all_off, all_size, bases
+    return GatherInFlight(None, reqs, build)

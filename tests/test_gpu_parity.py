@@ -585,6 +585,87 @@ print("decoder ok")
     assert out.returncode == 0 and b"decoder ok" in out.stdout, out.stdout.decode()[-2000:]
 
 
+def test_host_threads_call_the_stock_api_at_the_same_time(P, O):
+    """The reference's contract (Lerc.cpp:448, :640; Lerc_c_api.h:113): no global state, concurrent calls on different buffers
+    are fine.  Eight host threads call lerc_encode / lerc_decode at once -- every data type, a masked raster among them, every
+    thread its own context inside the library -- and each gets the oracle's bytes and pixels, again and again."""
+    import threading
+    rng = np.random.default_rng(77)
+    jobs = []
+    for k, (dt, e, shape) in enumerate(((np.float32, 0.01, (1024, 1536)), (np.uint16, 0, (1024, 1024)), (np.int32, 0, (777, 1001)),
+                                        (np.float64, 0.001, (512, 768)), (np.uint8, 0, (768, 1024)), (np.int16, 0.5, (640, 640)),
+                                        (np.float32, 0.1, (1000, 1000)), (np.uint32, 0, (512, 2048)))):
+        x = cases._cast(cases.terrain(shape[0], shape[1], rng, amp=300, base=1000, sigma=2.0), dt)
+        m = None
+        if k == 6:    # a mask with a hole and ragged edges
+            m = np.ones(shape, np.uint8)
+            m[100:300, 200:700] = 0
+            m[::7, ::13] = 0
+        r, blob = O.encode(x, e, mask=m)
+        assert r == 0
+        jobs.append((x, e, m, blob, O.decode(blob)))
+    errors = []
+
+    def work(k):
+        x, e, m, blob, want = jobs[k]
+        try:
+            for rep in range(6):
+                r, b = P.encode(x, e, mask=m)
+                assert r == 0 and b == blob, ("blob", k, rep)
+                d = P.decode(blob)
+                assert d[0] == 0 and _same(d[1], want[1]) and _same(d[2], want[2]), ("pixels", k, rep)
+        except BaseException as ex:    # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors and not any(t.is_alive() for t in threads), errors[:3]
+
+
+def test_two_codecs_on_two_streams_at_the_same_time(O):
+    """Two DeviceCodec contexts on two HIP streams, their one-launch encoders and decoders in flight together: the hand-offs
+    inside a launch (size cells, block-count cells, checksum accumulators) are per context, and a workgroup that waits for
+    a cell waits for a workgroup of its OWN launch -- which the other launch's workgroups may delay but not starve.  Bytes
+    are the oracle's, pixels within the bound, and no call came back through the general kernels."""
+    import torch
+    from lerc_amd import api, synth
+    dev = torch.device("cuda:0")
+    xs = [synth.c2_float32(4096, 4096, row0=4096 * k, device=dev) for k in range(2)]
+    want = []
+    for x in xs:
+        r, b = O.encode(x.cpu().numpy(), 0.01)
+        assert r == 0
+        want.append(b)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    codecs = [api.DeviceCodec(st.cuda_stream) for st in streams]
+    blobs = [torch.empty(x.numel() * 4 + 4096, dtype=torch.uint8, device=dev) for x in xs]
+    outs = [torch.empty_like(x) for x in xs]
+    torch.cuda.synchronize()
+    tickets = [[], []]
+    for rep in range(12):
+        for k in range(2):
+            rc, t1 = api.encode_device_async(codecs[k], xs[k], 0.01, blobs[k])
+            rc2, t2 = api.decode_device_async(codecs[k], blobs[k], blobs[k].numel(), outs[k])
+            assert rc == 0 and rc2 == 0, (rc, rc2, codecs[k].last_error())
+            tickets[k].append((t1, t2))
+        if rep % 4 == 3:
+            for k in range(2):
+                for t1, t2 in tickets[k]:
+                    rc, nb = codecs[k].finish(t1)
+                    rc2, _ = codecs[k].finish(t2)
+                    assert rc == 0 and rc2 == 0 and nb == len(want[k]), (rc, rc2, nb, len(want[k]), codecs[k].last_error())
+                tickets[k] = []
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert blobs[k][:len(want[k])].cpu().numpy().tobytes() == want[k], ("blob", k)
+        assert float((outs[k].double() - xs[k].double()).abs().max().item()) <= 0.01 * (1 + 1e-6) + 6.2e-5
+        c = codecs[k].path_counters()
+        assert c[0] == 12 and c[2] == 12 and c[1] == 0 and c[3] == 0, (k, c, codecs[k].last_note() if hasattr(codecs[k], "last_note") else "")
+
+
 def test_lerc1_world(P, O):
     """the reference's legacy Lerc1 fixture (decode only): info, ranges, pixels, mask -- and damaged copies"""
     blob = open(os.path.join(GOLD, "world.lerc1"), "rb").read()

@@ -33,25 +33,33 @@ def _encode(t):
     return blob
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, n_tiles=N_TILES, scramble=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        N_TILES = n_tiles    # noqa: N806 -- (shadows the module's default on purpose)
         first, count = shard.tile_range(rank, world, N_TILES)
         blobs = [_encode(t) for t in range(first, first + count)]
         sizes, offsets = shard.gather_manifest([len(b) for b in blobs], N_TILES)
         slowest = shard.max_over_ranks(0.25 + rank)
         # the exchange step proper: every rank's arena (blobs at 16-byte aligned offsets, as the tile batch call leaves
         # them) travels to rank 0 through the collective; rank 0 keeps the gathered mosaic for the parent to check
-        loc_off, at = [], 0
-        for b in blobs:
-            loc_off.append(at)
-            at += (len(b) + 15) & ~15
+        # (scramble: odd ranks place their blobs back to front, as a batch does with tiles it handed to the general path --
+        # offsets[] then is not monotonic)
+        order = list(range(len(blobs)))
+        if scramble and rank % 2 == 1:
+            order.reverse()
+        loc_off, at = [0] * len(blobs), 0
+        for i in order:
+            loc_off[i] = at
+            at += (len(blobs[i]) + 15) & ~15
         arena = torch.zeros(max(at, 1), dtype=torch.uint8)
         for o, b in zip(loc_off, blobs):
             arena[o:o + len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8)
-        mosaic, t_off, t_size, bases = shard.gather_arenas(arena, at, loc_off, [len(b) for b in blobs], root=0)
+        # the two halves of the step: what a rank does between them (decoding its own tiles) runs beside the transfers
+        flight = shard.gather_arenas_start(arena, at, loc_off, [len(b) for b in blobs], root=0)
+        mosaic, t_off, t_size, bases = flight.finish()
         if rank == 0:
             np.save(os.path.join(out_dir, "mosaic.npy"), mosaic.numpy())
             np.save(os.path.join(out_dir, "mosaic_off.npy"), t_off.numpy())
@@ -115,6 +123,32 @@ def test_two_ranks_over_gloo(tmp_path):
         assert blob == want[t], t
     rc, dec, _ = capi.oracle().decode(g[int(g_off[7]):int(g_off[7]) + int(g_size[7])].tobytes())
     assert rc == 0 and float(np.abs(dec.reshape(TILE, TILE).astype(np.float64) - _tile(7)).max()) <= 0.0101
+
+
+@pytest.mark.parametrize("world,n_tiles", [(3, 11), (8, 21), (8, 5)])
+def test_more_ranks_uneven_shares_empty_ranks_and_scrambled_arenas(tmp_path, world, n_tiles):
+    """World sizes 3 and 8 over gloo: tile counts that do not divide (the first ranks take one more), ranks without a tile
+    (5 tiles on 8 ranks), and arenas whose blobs do not lie in tile order (odd ranks place theirs back to front: offsets[] is
+    not monotonic, as after a batch that handed tiles to the general path).  What rank 0 holds after the gather is, tile by
+    tile, the blob a single process makes."""
+    import capi
+    if capi.oracle() is None:
+        pytest.skip("oracle not built")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(world, port, str(tmp_path), n_tiles, True), nprocs=world, join=True)
+    want = [_encode(t) for t in range(n_tiles)]
+    g = np.load(tmp_path / "mosaic.npy")
+    g_off, g_size = np.load(tmp_path / "mosaic_off.npy"), np.load(tmp_path / "mosaic_size.npy")
+    assert g_size.tolist() == [len(b) for b in want] and len(g_off) == n_tiles and (g_off % 16 == 0).all()
+    for t in range(n_tiles):
+        assert g[int(g_off[t]):int(g_off[t]) + int(g_size[t])].tobytes() == want[t], t
+    spans = sorted((int(o), int(o) + int(z)) for o, z in zip(g_off, g_size))
+    assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))    # no two blobs overlap
+    for r in range(world):
+        first, count, slowest = eval(open(tmp_path / f"t{r}.txt").read())
+        assert (first, count) == shard.tile_range(r, world, n_tiles) and slowest == 0.25 + world - 1
 
 
 def test_single_process_gather_is_the_arena_itself():

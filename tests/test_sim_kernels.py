@@ -328,6 +328,68 @@ def test_sim_tile_batches(libs):
         L.lerc_amd_destroy(h)
 
 
+def test_sim_tile_batches_that_compress_badly(libs):
+    """A batch whose tiles compress to more than half their raw size (lossless noise; a tiny error bound) does not fit the
+    one-launch encoder's first slots: the batch is then encoded once more with slots that hold raw blocks -- one launch again,
+    not tile after tile -- and every blob is the per-tile oracle blob; a batch with only a few such tiles keeps its slots and
+    encodes those few behind it."""
+    import ctypes as ct
+    O, S = libs
+    L = S.lib
+    L.lerc_amd_create.restype = ct.c_void_p
+    L.lerc_amd_create.argtypes = [ct.c_void_p]
+    L.lerc_amd_destroy.argtypes = [ct.c_void_p]
+    L.lerc_amd_path_counters.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+    L.lerc_amd_encode_tiles_device.restype = ct.c_uint
+    L.lerc_amd_encode_tiles_device.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_int, ct.c_int, ct.c_int, ct.c_double, ct.c_void_p,
+                                               ct.c_ulonglong, ct.c_void_p, ct.c_void_p, ct.c_void_p]
+    h = L.lerc_amd_create(None)
+    assert h
+    rng = np.random.default_rng(41)
+    try:
+        for dt, e, n_t, n_noisy in ((np.int16, 0, 24, 24), (np.float32, 1e-5, 16, 16), (np.uint16, 0, 40, 3)):
+            tiles = []
+            for t in range(n_t):
+                if t < n_noisy:
+                    x = rng.integers(0, 30000, size=(128, 128)) if np.dtype(dt).kind != "f" else rng.normal(1000, 300, size=(128, 128))
+                else:
+                    x = cases.terrain(128, 128, rng, amp=300, base=1000, sigma=1.5)
+                tiles.append(cases._cast(np.asarray(x, np.float64), dt))
+            tiles = np.stack(tiles)
+            src = _aligned(tiles.nbytes).view(dt).reshape(tiles.shape)
+            src[...] = tiles
+            arena = _aligned(2 * tiles.nbytes + n_t * 512)
+            offs, sizes, used = np.zeros(n_t, np.uint64), np.zeros(n_t, np.uint32), ct.c_ulonglong(0)
+            c0 = (ct.c_ulonglong * 4)()
+            L.lerc_amd_path_counters(h, c0)
+            L.lerc_amd_profile_enable.argtypes = [ct.c_void_p, ct.c_int]
+            L.lerc_amd_profile_read.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_int, ct.c_int]
+            L.lerc_amd_profile_enable(h, 1)
+            rc = L.lerc_amd_encode_tiles_device(h, src.ctypes.data, capi.dt_code(dt), 128, 128, n_t, float(e), arena.ctypes.data, arena.size,
+                                                offs.ctypes.data, sizes.ctypes.data, ct.byref(used))
+            assert rc == 0
+            L.lerc_amd_profile_enable(h, 0)
+            buf = ct.create_string_buffer(1 << 14)
+            L.lerc_amd_profile_read(h, buf, len(buf), 1)
+            launches = {ln.split()[0]: int(ln.split()[2]) for ln in buf.value.decode().splitlines()}
+            c1 = (ct.c_ulonglong * 4)()
+            L.lerc_amd_path_counters(h, c1)
+            spans = []
+            for t in range(n_t):
+                r1, b1 = O.encode(tiles[t], e)
+                assert r1 == 0 and arena[int(offs[t]):int(offs[t]) + int(sizes[t])].tobytes() == b1, (np.dtype(dt).name, t)
+                spans.append((int(offs[t]), int(offs[t]) + int(sizes[t])))
+            spans.sort()
+            assert all(spans[i][1] <= spans[i + 1][0] for i in range(n_t - 1)) and spans[-1][1] <= used.value
+            if n_noisy == n_t:    # the whole batch went through the batch kernels (second time round), none tile by tile
+                assert c1[0] - c0[0] == n_t and c1[1] == c0[1], (np.dtype(dt).name, list(c0), list(c1))
+                assert launches.get("fast_encode1") == 2, launches
+            else:                 # the batch, then the few tiles that did not fit
+                assert launches.get("fast_encode1") == 1 + n_noisy, launches
+    finally:
+        L.lerc_amd_destroy(h)
+
+
 def test_sim_tile_batches_with_a_slot_per_tile(libs):
     """lerc_amd_encode_tiles_device_slots / decode_tiles_device_slots: tile t's blob at t * slotBytes, written there by the
     encode kernel itself (no packing pass); bytes are the per-tile call's, tiles the streaming kernels hand back are redone
