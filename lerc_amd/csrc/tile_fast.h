@@ -241,8 +241,13 @@ static const int kOneDiscChunks = (int)(16384u / kFastChunkBytes);       // (kep
 // first own sub-chunk (= the exit that sub-chunk's walks agree on) is known without asking anybody.  Workgroup 0 owns its first
 // sub-chunk too.  What travels between workgroups is one number: how many blocks start in a workgroup's own bytes (an
 // epoch-tagged cell each, and one per kOneGroup workgroups for the group's total).
-static const u32 kOneStage = 32768;
-static const u32 kOneThreads = 512;
+#ifndef LERC_ONE_STAGE
+#define LERC_ONE_STAGE 32768
+#endif
+static const u32 kOneStage = LERC_ONE_STAGE;               // 32 KiB: three workgroups to a CU (53 KB of LDS each).  24 KiB -- four to a CU, 38 KB
+                                                           // each -- is slower, 150 against 117 us on C2: a third more workgroups, and what a
+                                                           // workgroup does before its pixels (header, scan, walks, hand-off) costs the same
+static const u32 kOneThreads = kOneStage / 64u;            // 16 threads per KiB staged, like k_fast_discover
 #ifndef LERC_ONE_SUB
 #define LERC_ONE_SUB 1024
 #endif

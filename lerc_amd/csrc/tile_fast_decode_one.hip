@@ -50,10 +50,8 @@ template<class T> struct OneGeom
   static constexpr u32 kFoundCap = 768, kHitCap = 768;            // count bytes / block headers found in the windows (a few hundred)
   static constexpr u32 R = NT;                                    // blocks per decode round: one header per thread
   static constexpr u32 kMaxRel = NCH * CH + W - 1;                // last staged byte a block may start at
-  static constexpr u32 kSlotsPerWave = 64u / NCH ? 64u / NCH : 1u;    // walks: lane = sub-chunk; a wave takes one head (two: doubles) of every sub-chunk
-  static constexpr u32 kWalkWaves = NW / kSlotsPerWave;
+  static constexpr u32 kWalkWaves = (NCH * NW + 63u) / 64u;          // walks: thread = sub-chunk + NCH * head
   static constexpr u32 kChShift = CH == 512u ? 9u : CH == 1024u ? 10u : 11u;
-  static constexpr u32 kNchShift = NCH == 64u ? 6u : NCH == 32u ? 5u : 4u;
 };
 
 template<class T, bool RAG> struct OneShared
@@ -129,7 +127,7 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
   constexpr u32 kWaves = NT / 64;
   constexpr u32 kUnits = G::kUnits, kStageUnits = G::kStageUnits, kBitWords = G::kBitWords;
   constexpr u32 kFoundCap = G::kFoundCap, kHitCap = G::kHitCap, kMaxRel = G::kMaxRel;
-  static_assert((NCH == 64 || NCH == 32 || NCH == 16) && NW == 8 && W <= CH && NCH * CH + 2 * W < 65535 && CAP <= 254, "lane layout / 16-bit positions / 8-bit counts");
+  static_assert(NCH <= 64 && NCH * NW <= NT && NT % 64 == 0 && NT % NCH == 0 && CAP % (NT / NCH) == 0 && NW == 8 && W <= CH && NCH * CH + 2 * W < 65535 && CAP <= 254, "lane layout / 16-bit positions / 8-bit counts");
   static_assert(NCH * NW <= NT, "a thread per walk when the path is picked");
   auto& s_in = S.in; auto& s_hits = S.u.d.hits; auto& s_removed = S.u.d.p.a.removed; auto& s_strong = S.u.d.p.a.strong;
   auto& s_found = S.u.d.p.a.found; auto& s_hit = S.u.d.p.a.hit; auto& s_fin = S.u.d.fin;
@@ -367,7 +365,8 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
   if (threadIdx.x < NCH) s_key[threadIdx.x] = 0xFFFFFFFFu;
   if ((u32)w < G::kWalkWaves)
   {
-    const u32 wc = (u32)lane & (NCH - 1u), slot = (u32)w * G::kSlotsPerWave + ((u32)lane >> G::kNchShift);
+    static_assert((NCH * NW) % 64u == 0u, "whole waves of walks");
+    const u32 wc = threadIdx.x % NCH, slot = threadIdx.x / NCH;
     const u32 wChunk = cs + wc;
     const u32 wStart = wChunk << SH;
     const bool wLive = wChunk < nSub;
@@ -604,7 +603,7 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
     const u32 c = (u32)lane < NCH ? S.count[lane] : 0u;
     u32 inc = c;
 #pragma unroll
-    for (int d = 1; d < (int)NCH; d <<= 1) { const u32 o = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += o; }
+    for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += o; }
     if ((u32)lane < NCH) S.cum[lane] = inc - c;
     const u32 cMax = waveMax(c);
     if ((u32)lane == NCH - 1u)
@@ -953,8 +952,15 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
 }
 
 // blockIdx.y = tile of a batch (one raster: a batch of 1); each tile has its own slice of every buffer
+// (80 scalar registers: the waves of four workgroups fit a CU only if a SIMD can hold eight -- 800 scalar registers per SIMD, 16
+// more than a wave asks for go with each; at 90 it is seven, and a workgroup of six waves puts two on two of the SIMDs)
+#ifdef HIPSIM
+#define LERC_ONE_SGPR_CAP
+#else
+#define LERC_ONE_SGPR_CAP __attribute__((amdgpu_num_sgpr(80)))
+#endif
 template<class T, bool RAG>
-__global__ void __launch_bounds__(kOneThreads)
+__global__ void __launch_bounds__(kOneThreads) LERC_ONE_SGPR_CAP
 k_fast_decode_one(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 sizeGiven, int nRows, int nCols, T* __restrict__ outPix)
 {
   const size_t tile = blockIdx.y;
@@ -976,6 +982,18 @@ static void launchFastDecodeOneT(int nRows, int nCols, const FastDecodeBatch& t,
     hipLaunchKernelGGL((k_fast_decode_one<T, true>), grid, block, 0, st, b, t, blob, sizeGiven, nRows, nCols, (T*)out);
   else
     hipLaunchKernelGGL((k_fast_decode_one<T, false>), grid, block, 0, st, b, t, blob, sizeGiven, nRows, nCols, (T*)out);
+}
+
+// diagnostic: workgroups of the float kernel a CU holds, by the runtime's count
+extern "C" __attribute__((visibility("default"))) int lerc_amd_probe_decode_one_residency()
+{
+#ifdef HIPSIM
+  return 0;
+#else
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fast_decode_one<float, false>, (int)kOneThreads, 0) != hipSuccess) return -1;
+  return n;
+#endif
 }
 
 void launchFastDecodeOne(int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
