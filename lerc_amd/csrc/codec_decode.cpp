@@ -207,10 +207,11 @@ bool decodeEnqueueStreaming(Context& ctx, const DecodeRequest& rq, u8* slot, u32
   return true;
 }
 
-bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch)
+bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits)
 {
   if (ctx.profOn()) ctx.profCollect();
   const u32 verdict = fastBandVerdict(slot + 64, epoch);
+  if (bits) *bits = verdict;
   if (verdict & 0x8u) ctx.wipePersistentState();    // (a workgroup gave up waiting: the checksum accumulators may hold residue)
   if (verdict)
   {
@@ -225,7 +226,7 @@ bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch)
 // Device-resident single-band blobs: everything is enqueued before a single byte of the blob has been seen by the
 // host (the header is checked on the device); one synchronisation.  handled == false: nothing was decided,
 // the caller goes the long way (header read, general kernels, exact status codes).
-static u32 decodeSpeculative(Context& ctx, const DecodeRequest& rq, bool& handled, bool& tried)
+static u32 decodeSpeculative(Context& ctx, const DecodeRequest& rq, bool& handled, bool& tried, u32* bits = nullptr)
 {
   handled = false; tried = false;
   u8* pin = (u8*)ctx.pinned(64 + kCellBytes);
@@ -233,7 +234,7 @@ static u32 decodeSpeculative(Context& ctx, const DecodeRequest& rq, bool& handle
   if (!pin || !decodeEnqueueStreaming(ctx, rq, pin, epoch)) return kOk;
   tried = true;
   if (!ctx.sync()) return kFailed;
-  handled = decodeStreamingVerdict(ctx, pin, epoch);
+  handled = decodeStreamingVerdict(ctx, pin, epoch, bits);
   return kOk;
 }
 
@@ -661,10 +662,12 @@ u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
     bool handled = false, tried = false;
     DecodeRequest r = rq;
     r.skipOne = level < 2;
-    const u32 src = decodeSpeculative(ctx, r, handled, tried);
+    u32 bits = 0;
+    const u32 src = decodeSpeculative(ctx, r, handled, tried, &bits);
     if (src != kOk) return src;
     if (handled) { ctx.pathCount[2]++; return kOk; }
     if (!tried) break;    // (not a request the streaming kernels take blind: decodeImpl looks at every band)
+    if (bits & 0x100u) break;    // (the header says it is no band for the streaming kernels -- a mask, another mode: the other form would say the same)
     level--;
   }
   bool fellBack = false;

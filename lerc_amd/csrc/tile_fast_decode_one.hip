@@ -25,6 +25,7 @@
 // the general kernels.
 // Reference: Lerc2.cpp:1672-1713, :2025-2230; BitStuffer2.cpp:159-258, :476-540; Lerc2.cpp:1037-1064 (checksum).
 #include "tile_fast_decode_dev.h"
+#include <cstddef>
 
 namespace lerc {
 
@@ -186,7 +187,21 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
     if (lane == 0)
     {
       S.hp = hpFull;
-      if (wg == 0u) { storeParams<true>(b.params, hpFull); if (b.hostParams) *b.hostParams = hpFull; }
+      if (wg == 0u)
+      {
+        // (the verdict on the checksum comes from the launch's last workgroup, microseconds later for a small blob: one writer
+        // per byte -- the host's copy, which travels over PCIe, gets everything BUT that word here (the host has zeroed it);
+        // the device's copy is complete before this thread sends its checksum terms off, which the last workgroup waits for)
+        storeParams<true>(b.params, hpFull);
+        if (b.hostParams)
+        {
+          u64 wds[8];
+          memcpy(wds, &hpFull, 64);
+          static_assert(offsetof(FastDecodeParams, checksumOk) == 40 && sizeof(FastDecodeParams) == 64, "word 5 holds the verdict");
+#pragma unroll
+          for (int i = 0; i < 8; i++) if (i != 5) reinterpret_cast<volatile u64*>(b.hostParams)[i] = wds[i];
+        }
+      }
     }
   }
   for (u32 i = threadIdx.x; i < (NCH + 1) * kBitWords; i += NT) (&s_hits[0][0])[i] = 0u;
@@ -239,6 +254,7 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
 #pragma unroll
     for (u32 k = 0; k < kWaves; k++) { A += S.fa[k]; B += S.fb[k]; }
     A %= 65535u; B %= 65535u;
+    if (wg == 0u) drainVmem();    // (the band's parameters have arrived)
     __hip_atomic_fetch_add(b.wgAcc + wg / kOneGroup, A | (B << 24) | (1ull << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- bit-stuffed block headers in every sub-chunk's first window.  Such a block reads: flag byte (bits 0-1 == 1, bits 6-7

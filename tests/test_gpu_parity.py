@@ -585,6 +585,35 @@ print("decoder ok")
     assert out.returncode == 0 and b"decoder ok" in out.stdout, out.stdout.decode()[-2000:]
 
 
+def test_small_blobs_decode_in_one_launch_every_time():
+    """A blob of a few workgroups, decoded again and again: the launch's last workgroup is through microseconds after the
+    first one has left the band's parameters for the host -- the verdict on the checksum must not be overtaken by them
+    (one writer per byte; it was, once: every decode but the first came back through the two-launch form, silently).  The
+    kernels that ran say which form served the calls."""
+    import torch
+    from lerc_amd import api, synth
+    dev = torch.device("cuda:0")
+    codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
+    L = codec.lib
+    L.lerc_amd_profile_enable.argtypes = [ct.c_void_p, ct.c_int]
+    L.lerc_amd_profile_read.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_int, ct.c_int]
+    for n in (64, 256, 600, 1024):
+        x = synth.c2_float32(n, n, device=dev)
+        blob = torch.empty(x.numel() * 4 + 4096, dtype=torch.uint8, device=dev)
+        y = torch.empty_like(x)
+        rc, nb = api.encode_device(codec, x, 0.01, blob)
+        assert rc == 0
+        L.lerc_amd_profile_enable(codec.h, 1)
+        for rep in range(8):
+            assert api.decode_device(codec, blob, nb, y) == 0
+        L.lerc_amd_profile_enable(codec.h, 0)
+        buf = ct.create_string_buffer(1 << 14)
+        L.lerc_amd_profile_read(codec.h, buf, len(buf), 1)
+        launches = {ln.split()[0]: int(ln.split()[2]) for ln in buf.value.decode().splitlines()}
+        assert launches == {"fast_decode_one": 8}, (n, launches)
+        assert float((y.double() - x.double()).abs().max().item()) <= 0.01 * (1 + 1e-6) + 6.2e-5
+
+
 def test_host_threads_call_the_stock_api_at_the_same_time(P, O):
     """The reference's contract (Lerc.cpp:448, :640; Lerc_c_api.h:113): no global state, concurrent calls on different buffers
     are fine.  Eight host threads call lerc_encode / lerc_decode at once -- every data type, a masked raster among them, every

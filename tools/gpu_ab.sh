@@ -5,7 +5,7 @@ set -u
 OUT=$PWD/gpurun_out; mkdir -p "$OUT"
 run() {  # name, then env assignments
   local name=$1; shift
-  env "$@" python bench.py --steps ${STEPS:-20} --warmup 5 --no-cpu-baseline --no-c5-anchor --rotate 0 2>"$OUT/ab_$name.err" | python -c "
+  env "$@" python bench.py --steps ${STEPS:-20} --warmup 5 --no-cpu-baseline --no-c5-anchor --no-other-configs --rotate 0 2>"$OUT/ab_$name.err" | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('$name', 'ms_per_step', d['ms_per_step'], 'frac', d['roundtrip']['frac_of_hbm_peak_wall'], 'verified', d['config']['verified'], ' '.join(f\"{k}={v['avg_ms']*1000:.1f}\" for k,v in d['kernels'].items()))
@@ -24,7 +24,7 @@ if [ "${PMC:-0}" = "1" ]; then
   for L in default "$@"; do
     LIB=""; [ "$L" != default ] && LIB="LERC_AMD_LIBRARY=$ROOT/$L"
     for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" ${PMC2:+"SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"}; do
-      (cd /tmp && rm -rf /tmp/prof_pmc && TMPDIR=/tmp timeout 300 env $LIB rocprofv3 --kernel-trace --pmc $SET -d /tmp/prof_pmc -o pmc -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-c5-anchor --rotate 0 > /dev/null 2> "$OUT/ab_pmc.err")
+      (cd /tmp && rm -rf /tmp/prof_pmc && TMPDIR=/tmp timeout 300 env $LIB rocprofv3 --kernel-trace --pmc $SET -d /tmp/prof_pmc -o pmc -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-c5-anchor --no-other-configs --rotate 0 > /dev/null 2> "$OUT/ab_pmc.err")
       DB=$(find /tmp/prof_pmc -name '*.db' | head -1)
       echo "== PMC $L"
       python "$ROOT/tools/rocpd_summary.py" "$DB" fast 2>&1 | grep -v "^$" | cut -c1-160 | tee -a "$OUT/ab_pmc.txt"

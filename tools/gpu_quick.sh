@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 ROOT=$PWD
 timeout 900 python -m pytest tests -m gpu -x -q "$@" > "$OUT/${TAG}_pytest_gpu.txt" 2>&1
 tail -5 "$OUT/${TAG}_pytest_gpu.txt"
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 cat "$OUT/${TAG}_bench.json"; tail -3 "$OUT/${TAG}_bench.err"
 cd /tmp && rm -rf /tmp/prof_kt
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_kt.err"

@@ -7,7 +7,7 @@ TAG=${1:-run}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-c5-anchor --rotate 0"
+BENCH="python $PWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-c5-anchor --no-other-configs --rotate 0"
 cd /tmp
 rm -rf /tmp/prof_kt /tmp/prof_pmc*
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $BENCH > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_kt.err"
