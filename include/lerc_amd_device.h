@@ -85,6 +85,12 @@ LERC_AMD_API void lerc_amd_path_counters(lerc_amd_context* ctx, unsigned long lo
 /* why the last call that left the streaming kernels did so ("" if none did); same ctx convention */
 LERC_AMD_API const char* lerc_amd_last_note(lerc_amd_context* ctx);
 
+/* The run-length coding of a validity BIT mask (the mask section of a Lerc2 blob, RLE.cpp:123-254: nBytes = (nPix + 7) / 8
+ * bytes, most significant bit first) on the device, as the masked encode uses it: dBits and dOut device pointers (dBits 16-byte
+ * aligned), *size = bytes written incl. the end marker.  Returns 0, or 3 (BufferTooSmall) if the stream does not fit cap. */
+LERC_AMD_API unsigned int lerc_amd_mask_rle_device(lerc_amd_context* ctx, const unsigned char* dBits, unsigned int nBytes,
+                                                   unsigned char* dOut, unsigned int cap, unsigned int* size);
+
 /* library / build identification: "lerc_amd <version> gfx950 hip" (or "... hipsim" for the CPU test build) */
 LERC_AMD_API const char* lerc_amd_build_info(void);
 

@@ -670,6 +670,25 @@ void lerc_amd_path_counters(lerc_amd_context* h, unsigned long long out[4])
   for (int i = 0; i < 4; i++) out[i] = h ? h->ctx.pathCount[i] : 0;
 }
 
+unsigned int lerc_amd_mask_rle_device(lerc_amd_context* h, const unsigned char* dBits, unsigned int nBytes, unsigned char* dOut,
+                                      unsigned int cap, unsigned int* size)
+{
+  if (!h || !dBits || !dOut || !size || nBytes == 0 || ((uintptr_t)dBits & 15)) return kWrongParam;
+  Context& ctx = h->ctx;
+  ctx.reset();
+  if (!ctx.reserve(maskRleScratchBytes(nBytes) + 4096)) return kFailed;
+  u8* scratch = ctx.allocT<u8>(maskRleScratchBytes(nBytes));
+  u32* dSize = ctx.allocT<u32>(4);
+  u32* pin = (u32*)ctx.pinned(64);
+  if (!scratch || !dSize || !pin) return kFailed;
+  launchMaskRle(dBits, nBytes, dOut, cap, dSize, scratch, ctx.activeStream());
+  hipMemcpyAsync(pin, dSize, 4, hipMemcpyDeviceToHost, ctx.activeStream());
+  if (!ctx.sync()) return kFailed;
+  if (pin[0] == 0xFFFFFFFFu) return kBufferTooSmall;
+  *size = pin[0];
+  return kOk;
+}
+
 const char* lerc_amd_build_info(void)
 {
 #ifdef HIPSIM

@@ -283,9 +283,37 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   const u8* bitsOnTheWay = nullptr;
   size_t nBitsOnTheWay = 0;
   std::future<std::vector<u8> > rleFuture;
+  // ... or, a large mask: coded on the device (rle_kernels.hip) -- the bits never leave it, the stream's size and its first
+  // kRleFirst bytes travel home beside the statistics kernels, and codeMask() below picks them up
+  // (LERC_AMD_DEVICE_RLE=0: never; =<bytes>: from masks of that many bytes on -- a test knob; default: 256 KB, as for the helper threads)
+  static const size_t kDeviceRleFrom = []() -> size_t { const char* e = getenv("LERC_AMD_DEVICE_RLE"); const long v = e ? atol(e) : 1; return v <= 0 ? ~(size_t)0 : v < 16 ? (size_t)(256u << 10) : (size_t)v; }();
+  static const u32 kRleCap = 4u << 20, kRleFirst = 64u << 10;
+  bool deviceRle = false;
+  u8* dRle = nullptr;
+  u32* pinRle = nullptr;        // [0]: the stream's size (~0: it did not fit kRleCap), from byte 16 on: its first kRleFirst bytes
+  size_t nBitsOnDevice = 0;
   auto sendBitsHome = [&]() -> bool
   {
     const size_t nb = (size_t)((nPix + 7) >> 3);
+    if (nb >= kDeviceRleFrom && nb < 0xFFFFFFF0ull)
+    {
+      u8* scratch = ctx.allocT<u8>(maskRleScratchBytes(nb));
+      dRle = ctx.allocT<u8>((size_t)kRleCap + 64);
+      u32* dSize = ctx.allocT<u32>(4);
+      pinRle = (u32*)ctx.pinnedAux((size_t)kRleCap + 64);
+      if (scratch && dRle && dSize && pinRle)
+      {
+        hipStream_t side = ctx.forkSide();
+        hipStream_t sr = side ? side : st;
+        ProfScope ps(ctx, "mask_rle");
+        launchMaskRle(dNewBits, (u32)nb, dRle, kRleCap, dSize, scratch, sr);
+        hipMemcpyAsync(pinRle, dSize, 4, hipMemcpyDeviceToHost, sr);
+        hipMemcpyAsync((u8*)pinRle + 16, dRle, kRleFirst, hipMemcpyDeviceToHost, sr);
+        hipEventRecord(ctx.auxEvent(), sr);
+        deviceRle = true; nBitsOnDevice = nb;
+        return true;
+      }
+    }
     u8* pin = (u8*)ctx.pinnedAux(nb);
     if (!pin) return false;
     // (beside the stream, so that the statistics kernels do not wait behind 8 MB on their way over PCIe: a third of a millisecond)
@@ -420,7 +448,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
 
   // ---- mask bookkeeping across bands (Lerc.cpp:717-741)
   std::vector<u8> hBandBits;
-  if (haveBits && !bandAllValid && !bitsOnTheWay)
+  if (haveBits && !bandAllValid && !bitsOnTheWay && !deviceRle)
   {
     const size_t nb = (size_t)((nPix + 7) >> 3);
     {
@@ -444,7 +472,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   {
     ms.allValid = bandAllValid;
     ms.numValid = bandNumValid;
-    const size_t nMaskBytes = bitsOnTheWay ? nBitsOnTheWay : hBandBits.size();
+    const size_t nMaskBytes = bitsOnTheWay ? nBitsOnTheWay : deviceRle ? nBitsOnDevice : hBandBits.size();
     ms.hBits = std::move(hBandBits);    // (megabytes for a large raster: moved, not copied)
     if (!bandAllValid)
     {
@@ -550,10 +578,29 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     if (maskCoded) return true;
     maskCoded = true;
     // (the helper must be through in any case: the pinned area takes the blob's prefix next)
-    const bool helped = rleFuture.valid();
+    bool helped = rleFuture.valid();
     if (helped) { rle = rleFuture.get(); if (rle.empty()) return false; }
-    else if (bitsOnTheWay && hipEventSynchronize(ctx.auxEvent()) != hipSuccess) return false;
+    else if ((bitsOnTheWay || deviceRle) && hipEventSynchronize(ctx.auxEvent()) != hipSuccess) return false;
     if (!(needMask && encMask)) { rle.clear(); return true; }
+    if (deviceRle)
+    {
+      const u32 size = pinRle[0];
+      if (size != 0xFFFFFFFFu && size >= 2u && size <= kRleCap)
+      {
+        if (size > kRleFirst)    // (a mask with many short runs: the rest of its stream)
+        {
+          if (hipMemcpy((u8*)pinRle + 16 + kRleFirst, dRle + kRleFirst, size - kRleFirst, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        }
+        rle.assign((const u8*)pinRle + 16, (const u8*)pinRle + 16 + size);
+        helped = true;
+      }
+      else
+      {
+        // (a mask that hardly compresses: its bits come home after all, and the host codes them)
+        ms.hBits.resize(nBitsOnDevice);
+        if (hipMemcpy(ms.hBits.data(), dNewBits, nBitsOnDevice, hipMemcpyDeviceToHost) != hipSuccess) return false;
+      }
+    }
     if (!helped)
     {
       if (bitsOnTheWay) rleEncode(bitsOnTheWay, nBitsOnTheWay, rle);
@@ -1019,6 +1066,7 @@ u32 encodeDevice(Context& ctx, const EncodeRequest& rq, u32& numBytesNeeded, u32
   if (rq.hUsesNoData) for (int i = 0; i < rq.nBands; i++) anyNoData = anyNoData || rq.hUsesNoData[i] != 0;
   if (anyNoData && !rq.hNoDataValues) return kWrongParam;
   if (anyNoData) need += (size_t)nPix * rq.nDepth * tb + (size_t)nPix + 8192;
+  if (rq.nMasks > 0 || rq.dt >= DT_Float) need += maskRleScratchBytes(maskBytes) + (4u << 20) + 8192;    // a large mask is run-length coded on the device
   if (rq.dt >= DT_Float && (rq.maxZErr == 0 || anyNoData) && rq.version >= 6) need += fplEncodeScratchBytes(nPix * rq.nDepth, tb);
   // (a size query, dOut == nullptr, takes the first two steps of the streaming path: statistics and decisions)
   if (rq.version < 2 || rq.version > kCodecVersion) return kWrongParam;

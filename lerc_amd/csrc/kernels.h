@@ -105,6 +105,10 @@ void launchNoDataRemap(int dt, void* data, const u8* maskBytes, const u8* maskBi
 void launchBitPlaneCounts(int dt, const void* data, const u8* maskBits, int nRows, int nCols, int nDepth, u32* counts, hipStream_t stream);
 static const int kFletcherPartials = 2 * 512;    // u64 words written by launchFletcher
 void launchMaskGroupCounts(const u8* maskBits, i64 nPix, u32* counts, hipStream_t stream);
+// ---- rle_kernels.hip: the run-length coding of a band's validity bits (RLE::compress, RLE.cpp:123-254) on the device.
+// out[0 .. *sizeOut) receives the stream with its end marker; *sizeOut = ~0 if it does not fit cap (nothing useful written)
+size_t maskRleScratchBytes(size_t nBytes);
+void launchMaskRle(const u8* bits, u32 nBytes, u8* out, u32 cap, u32* sizeOut, u8* scratch, hipStream_t stream);
 
 // raw fallback ("one sweep", Lerc2.cpp:1343-1400): valid pixels copied in order
 void launchOneSweep(bool encode, const void* src, void* dst, const u8* maskBits, const u32* groupBase, i64 nPix,

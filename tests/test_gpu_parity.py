@@ -585,6 +585,29 @@ print("decoder ok")
     assert out.returncode == 0 and b"decoder ok" in out.stdout, out.stdout.decode()[-2000:]
 
 
+def test_device_mask_rle():
+    """the run-length coding of validity bits on the device (rle_kernels.hip), against RLE::compress said plainly: the cases of
+    the emulator suite, on device memory"""
+    import torch
+    import test_sim_kernels as tsk
+    from lerc_amd import api
+    dev = torch.device("cuda:0")
+    codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
+    L = codec.lib
+    L.lerc_amd_mask_rle_device.restype = ct.c_uint
+    L.lerc_amd_mask_rle_device.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_void_p, ct.c_uint, ct.POINTER(ct.c_uint)]
+    rng = np.random.default_rng(9)
+    for k, b in enumerate(tsk.rle_cases(rng)):
+        n = len(b)
+        want = tsk._rle_restated(bytes(b))
+        src = torch.zeros(max(n, 16) + 16, dtype=torch.uint8, device=dev)
+        src[:n] = torch.from_numpy(b).to(dev)
+        out = torch.zeros(len(want) + 64, dtype=torch.uint8, device=dev)
+        size = ct.c_uint(0)
+        rc = L.lerc_amd_mask_rle_device(codec.h, src.data_ptr(), n, out.data_ptr(), out.numel(), ct.byref(size))
+        assert rc == 0 and out[:size.value].cpu().numpy().tobytes() == want, (k, n, rc, size.value, len(want))
+
+
 def test_small_blobs_decode_in_one_launch_every_time():
     """A blob of a few workgroups, decoded again and again: the launch's last workgroup is through microseconds after the
     first one has left the band's parameters for the host -- the verdict on the checksum must not be overtaken by them

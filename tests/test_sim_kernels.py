@@ -523,9 +523,107 @@ for it in range(24):
 print("pieces ok")
 """ % (capi.ROOT,)
     for piece in ("16", "4096"):
-        env = dict(os.environ, LERC_AMD_RLE_PIECE=piece)
+        env = dict(os.environ, LERC_AMD_RLE_PIECE=piece, LERC_AMD_DEVICE_RLE="0")
         out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
         assert out.returncode == 0 and b"pieces ok" in out.stdout, out.stdout.decode()[-2000:]
+    # ... and the same masks through the device's coder (rle_kernels.hip: every byte decides for itself whether it lies in a
+    # run, two scans say where its segment begins and ends) -- which takes masks of 256 KB and more; the knob makes it take all
+    env = dict(os.environ, LERC_AMD_DEVICE_RLE="16")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert out.returncode == 0 and b"pieces ok" in out.stdout, out.stdout.decode()[-2000:]
+
+
+def _rle_restated(b):
+    """RLE::compress (RLE.cpp:123-254) said plainly: in a literal stretch a run opens where five equal bytes start and one more
+    byte follows; it takes every byte equal to its first; stretches and runs are cut at 32767; -32768 ends the stream"""
+    n, out, i = len(b), bytearray(), 0
+
+    def cnt(v):
+        out.extend(int(v & 0xFFFF).to_bytes(2, "little"))
+    while i < n:
+        lit = i
+        while i < n and not (i + 5 < n and b[i] == b[i + 1] == b[i + 2] == b[i + 3] == b[i + 4]):
+            i += 1
+        while lit < i:
+            ln = min(32767, i - lit)
+            cnt(ln)
+            out.extend(b[lit:lit + ln])
+            lit += ln
+        if i >= n:
+            break
+        t = i
+        while t + 1 < n and b[t + 1] == b[i]:
+            t += 1
+        left = t - i + 1
+        while left > 0:
+            ln = min(32767, left)
+            cnt(-ln)
+            out.append(b[i])
+            left -= ln
+        i = t + 1
+    cnt(-32768)
+    return bytes(out)
+
+
+def rle_cases(rng):
+    out = []
+    for n in (1, 2, 5, 6, 7, 15, 16, 17, 31, 33, 100, 1000, 4096, 70000):
+        out.append(rng.integers(0, 256, n).astype(np.uint8))                      # noise: one long literal stretch
+        out.append(np.zeros(n, np.uint8))                                          # one run
+        k = max(1, n // 7 + 1)
+        x = np.repeat(rng.integers(0, 3, k).astype(np.uint8) * 127, rng.integers(1, 14, k))[:n]
+        out.append(np.concatenate([x, np.zeros(n - len(x), np.uint8)]).astype(np.uint8))    # short runs and literals mixed
+        y = np.zeros(n, np.uint8)
+        y[rng.integers(0, n, max(1, n // 50))] = rng.integers(1, 256, max(1, n // 50))
+        out.append(y)                                                              # runs with single bytes in between
+        z = rng.integers(0, 256, n).astype(np.uint8)
+        z[n // 3:n // 3 + n // 2] = 0xFF
+        out.append(z)
+        w = np.full(n, 7, np.uint8)
+        w[:max(0, n - 5)] = rng.integers(0, 256, max(0, n - 5))
+        out.append(w)                                                              # exactly five equal bytes at the end: no run
+    for n in (32767, 32768, 32767 * 2 + 5, 32767 * 3):
+        out.append(np.full(n, 0xAA, np.uint8))                                     # runs cut at 32767
+        c = (np.arange(n) % 3).astype(np.uint8)
+        out.append(c)                                                              # a literal stretch cut at 32767
+    return out
+
+
+def check_device_rle(L, h):
+    import ctypes as ct
+    L.lerc_amd_mask_rle_device.restype = ct.c_uint
+    L.lerc_amd_mask_rle_device.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_void_p, ct.c_uint, ct.POINTER(ct.c_uint)]
+    rng = np.random.default_rng(9)
+    for k, b in enumerate(rle_cases(rng)):
+        n = len(b)
+        src = _aligned(max(n, 16))
+        src[:n] = b
+        want = _rle_restated(bytes(b))
+        out = _aligned(len(want) + 64)
+        size = ct.c_uint(0)
+        rc = L.lerc_amd_mask_rle_device(h, src.ctypes.data, n, out.ctypes.data, out.size, ct.byref(size))
+        assert rc == 0 and out[:size.value].tobytes() == want, (k, n, rc, size.value, len(want))
+    src = _aligned(1000)
+    src[:] = rng.integers(0, 256, 1000).astype(np.uint8)
+    out = _aligned(100)
+    assert L.lerc_amd_mask_rle_device(h, src.ctypes.data, 1000, out.ctypes.data, 100, ct.byref(ct.c_uint(0))) == 3    # BufferTooSmall
+
+
+def test_sim_device_mask_rle(libs):
+    """lerc_amd_mask_rle_device: the run-length coding of validity bits on the device (rle_kernels.hip) against RLE::compress
+    said plainly -- noise, single runs, mixtures, runs and stretches longer than 32767, five equal bytes at the very end."""
+    import ctypes as ct
+    O, S = libs
+    L = S.lib
+    L.lerc_amd_create.restype = ct.c_void_p
+    L.lerc_amd_create.argtypes = [ct.c_void_p]
+    L.lerc_amd_destroy.argtypes = [ct.c_void_p]
+    h = L.lerc_amd_create(None)
+    assert h
+    try:
+        check_device_rle(L, h)
+    finally:
+        L.lerc_amd_destroy(h)
 
 
 def test_sim_bit_plane_mode(libs):
