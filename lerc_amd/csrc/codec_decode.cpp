@@ -572,7 +572,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
 
     DecodeArgs da;
     da.blob = dBand; da.dataBegin = (u32)(at - bd.offset); da.blobEnd = blobEnd;
-    da.maskBits = dMask; da.zMaxVec = dZMax; da.out = dOutBand;
+    da.maskBits = dMask; da.zMaxVec = dZMax; da.out = dOutBand; da.blockOff = nullptr; da.nValidBlk = nullptr;
     const WalkPlan wp = makeWalkPlan(bp, da.dataBegin, da.blobEnd, nv);
     WalkBuffers wb;
     wb.chunkExit = ctx.allocT<u32>(wp.nChunks + 4);
@@ -595,6 +595,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     if (nValidBlk) launchBlockValidCounts(dMask, bp, nValidBlk, st);
     { ProfScope ps(ctx, "walk_offsets"); launchWalkRest(bp, wp, da, wb, dStatus, st); }
     da.blockOff = wb.blockOff;
+    da.nValidBlk = nValidBlk;
     { ProfScope ps(ctx, "tile_decode"); launchTileDecode(dt, bp, da, dStatus, st); }
   }
 

@@ -23,6 +23,7 @@ struct DecodeArgs
   const u8* maskBits;    // device bit mask or nullptr when all valid
   const double* zMaxVec; // per-depth clamp values (device, nDepth entries)
   const u32* blockOff;   // absolute offset of every sub-block, index = pos * nDepth + iDepth
+  const u16* nValidBlk;  // valid pixels per block (device) or nullptr: every block has all its pixels
   void* out;             // decoded pixels
 };
 void launchTileDecode(int dt, const BandParams& p, const DecodeArgs& a, DeviceStatus* st, hipStream_t stream);

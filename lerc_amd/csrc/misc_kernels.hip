@@ -359,8 +359,28 @@ __global__ void __launch_bounds__(256) k_bits_to_bytes(const u8* __restrict__ ma
   if (k < nPix) byteMask[k] = maskBits ? (maskBit(maskBits, k) ? 1 : 0) : 1;
 }
 
+// eight pixels (one byte of bits) per thread and one 8-byte store, for byte masks that are 8-byte aligned
+__global__ void __launch_bounds__(256) k_bits_to_bytes8(const u8* __restrict__ maskBits, u8* __restrict__ byteMask, i64 nGroups)
+{
+  const i64 g = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (g >= nGroups) return;
+  const u32 x = maskBits[g];
+  u64 v = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) v |= (u64)((x >> (7 - i)) & 1u) << (8 * i);
+  reinterpret_cast<u64*>(byteMask)[g] = v;
+}
+
 void launchBitsToBytes(const u8* maskBits, u8* byteMask, i64 nPix, hipStream_t stream)
 {
+  if (maskBits && ((uintptr_t)byteMask & 7u) == 0u && nPix >= 8)
+  {
+    const i64 nGroups = nPix >> 3, done = nGroups << 3;
+    hipLaunchKernelGGL(k_bits_to_bytes8, dim3((unsigned)((nGroups + 255) / 256)), dim3(256), 0, stream, maskBits, byteMask, nGroups);
+    if (done < nPix)    // (the last byte's few pixels: pixel k of the tail is pixel done + k of the raster, done is a multiple of 8)
+      hipLaunchKernelGGL(k_bits_to_bytes, dim3(1), dim3(256), 0, stream, maskBits + (done >> 3), byteMask + done, nPix - done);
+    return;
+  }
   hipLaunchKernelGGL(k_bits_to_bytes, dim3((unsigned)((nPix + 255) / 256)), dim3(256), 0, stream, maskBits, byteMask, nPix);
 }
 

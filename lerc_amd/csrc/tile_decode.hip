@@ -232,9 +232,205 @@ __global__ void __launch_bounds__(256) k_decode_tiles(BandParams p, DecodeArgs a
   if (failed && lane == 0) raiseError(st, kFailed, (u32)pos);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same for 8 x 8 blocks of single-depth bands (every block one sub-block), codec >= 3: the shape of the masked and the
+// ragged rasters that the streaming kernels do not take.  k_decode_tiles gives a block a wave that waits three times on
+// global memory (offset -> header -> payload) and stores 64 scattered elements; here a workgroup takes kGroup blocks that
+// follow each other in the stream, stages their bytes -- one contiguous range -- in LDS, parses one header per thread,
+// and a wave then decodes V blocks side by side, a lane V pixels of a row, so that a row of the V blocks is one
+// contiguous store of up to 128 bytes.  Checks and arithmetic are k_decode_tiles' (the parse is the same function).
+// ------------------------------------------------------------------------------------------------
+static const u32 kGroup = 64;
+
+// nbits (<= 32) at bit position bitPos of an LDS word stream
+__device__ __forceinline__ u32 wordBits(const u32* words, u32 bitPos, u32 nbits)
+{
+  const u32 w = bitPos >> 5, sh = bitPos & 31u;
+  const u64 x = ((u64)words[w + 1] << 32) | words[w];
+  return (u32)(x >> sh) & (nbits >= 32u ? 0xFFFFFFFFu : ((1u << nbits) - 1u));
+}
+
+template<class T>
+__global__ void __launch_bounds__(256) k_decode_blocks8(BandParams p, DecodeArgs a, DeviceStatus* st)
+{
+  constexpr u32 TB = (u32)sizeof(T);
+  constexpr u32 V = (16u / TB) < 8u ? (16u / TB) : 8u;    // pixels of a row per lane
+  constexpr u32 LPB = 64u / V;                             // lanes per block
+  constexpr u32 kCap = kGroup * (64u * TB + 1u);           // no block is longer than a raw one
+  __shared__ __align__(16) u8 s_bytes[kCap + 48];
+  __shared__ double s_offset[kGroup];
+  __shared__ u32 s_info[kGroup];      // payload (relative to the staged range, 16 bits) | nb << 16 | mode << 22 | lut << 24 | ok << 31
+  __shared__ u32 s_lutBits[kGroup];   // LUT blocks: bits per index | entries << 8
+  __shared__ u32 s_i0[kGroup], s_j0[kGroup];
+  const u32 nPos = (u32)p.nTV * (u32)p.nTH;
+  const u32 pos0 = blockIdx.x * kGroup;
+  const u32 nHere = min(kGroup, nPos - pos0);
+  const u32 from = a.blockOff[pos0];
+  const u32 to = (pos0 + nHere < nPos) ? a.blockOff[pos0 + nHere] : a.blobEnd;
+  if (to < from || to - from > kCap || to > a.blobEnd)
+  {
+    if (threadIdx.x == 0) raiseError(st, kFailed, pos0);
+    return;
+  }
+  // stage with 16-byte loads from the aligned-down start; LDS byte i + shift <-> blob byte from + i
+  const u32 a0 = from & ~15u, shift = from - a0;
+  const u8* __restrict__ blob = a.blob;
+  for (u32 v = threadIdx.x; a0 + 16u * v < to; v += 256u)
+  {
+    const u32 g = a0 + 16u * v;
+    uint4 x = make_uint4(0, 0, 0, 0);
+    if (g + 16u <= a.blobEnd && ((uintptr_t)(blob + g) & 15u) == 0u) x = *reinterpret_cast<const uint4*>(blob + g);
+    else for (u32 k2 = 0; k2 < 16u && g + k2 < a.blobEnd; k2++) (&x.x)[k2 >> 2] |= (u32)blob[g + k2] << (8u * (k2 & 3u));
+    *reinterpret_cast<uint4*>(&s_bytes[16u * v]) = x;
+  }
+  __syncthreads();
+  const u8* s_range = s_bytes + shift;
+  const u32 pattern = (p.version >= 5) ? 14u : 15u;
+
+  if (threadIdx.x < nHere)
+  {
+    const u32 t = threadIdx.x, pos = pos0 + t;
+    const u32 it = pos / (u32)p.nTH, jt = pos - it * (u32)p.nTH;
+    const u32 i0 = it * 8u, j0 = jt * 8u;
+    s_i0[t] = i0; s_j0[t] = j0;
+    const u32 tileH = min(8u, (u32)p.nRows - i0), tileW = min(8u, (u32)p.nCols - j0);
+    const int nValid = a.nValidBlk ? (int)a.nValidBlk[pos] : (int)(tileH * tileW);
+    const u32 off = a.blockOff[pos];
+    const u32 next = (t + 1 < nHere) ? a.blockOff[pos + 1] : to;
+    BlkInfo b;
+    u32 info = 0;
+    double offset = 0;
+    int rc = 1;
+    if (off >= from && off < to && next > off && next <= to)
+      rc = parseBlock<(int)TB>(s_range, off - from, next - from, p, nValid, 64u, b);
+    const bool good = rc == 0 && b.len == next - off && (((u32)b.flag >> 2) & pattern) == ((j0 >> 3) & pattern) && !b.diff;
+    if (good)
+    {
+      if (b.mode == 1 || b.mode == 3) offset = typedFromBits(getBytes(s_range + (off - from) + 1, b.offBytes), b.dtUsed);
+      info = (off - from + b.payload) | ((u32)b.nb << 16) | ((u32)b.mode << 22) | ((u32)b.lut << 24) | (1u << 31);
+      s_lutBits[t] = b.lut ? ((u32)bitLen(b.nLut) | (b.nLut << 8)) : 0u;
+    }
+    else raiseError(st, kFailed, pos);
+    s_info[t] = info;
+    s_offset[t] = offset;
+  }
+  __syncthreads();
+
+  const u32 lane = (u32)laneId(), w = (u32)waveId();
+  const u32 sub = lane / LPB, li = lane - sub * LPB;     // block of the wave's V, lane in the block
+  const u32 r = li / (8u / V), h = li - r * (8u / V);    // row, segment of the row
+  const u64 groupLt = laneMaskLt() & (((LPB == 64u) ? ~0ull : ((1ull << LPB) - 1ull)) << (sub * LPB));
+  const u32* s_words = reinterpret_cast<const u32*>(s_bytes);
+  T* __restrict__ out = (T*)a.out;
+  const double zMax = p.zMaxHdr, invScale = p.invScale;
+  const u64 maskBytes = ((u64)p.nRows * (u64)p.nCols + 7ull) >> 3;
+  bool badIdx = false;
+  for (u32 t0 = w * V; t0 < nHere; t0 += 4u * V)
+  {
+    const u32 t = t0 + sub;
+    const bool have = t < nHere;
+    const u32 info = have ? s_info[t] : 0u;
+    const u32 i = (have ? s_i0[t] : 0u) + r, j = (have ? s_j0[t] : 0u) + h * V;
+    const bool rowIn = have && (info >> 31) && i < (u32)p.nRows;
+    // validity of the lane's V pixels, pixel k in bit k
+    u32 inb = 0u, vb = 0u;
+    if (rowIn)
+    {
+      const u32 nIn = j < (u32)p.nCols ? min(V, (u32)p.nCols - j) : 0u;
+      inb = (1u << nIn) - 1u;
+      vb = inb;
+      if (!p.allValid && nIn)
+      {
+        const u64 px = (u64)i * (u64)p.nCols + j;
+        const u64 by = px >> 3;
+        const u32 sh = (u32)(px & 7u);
+        u32 win = (u32)a.maskBits[by] << 8;
+        if (sh + nIn > 8u && by + 1 < maskBytes) win |= a.maskBits[by + 1];
+        const u32 msb = (win << sh) >> (16u - V) & ((1u << V) - 1u);    // pixel 0 in bit V - 1 ... (the window's bits 15 - sh downward)
+        const u32 field = msb & ((1u << V) - 1u);
+        u32 rev = 0u;
+#pragma unroll
+        for (u32 k = 0; k < V; k++) rev |= ((field >> (V - 1u - k)) & 1u) << k;
+        vb = rev & inb;
+      }
+    }
+    // rank of the lane's first valid pixel among the block's
+    u32 e0 = 0u;
+#pragma unroll
+    for (u32 k = 0; k < V; k++) e0 += (u32)__popcll(__ballot((vb >> k) & 1u) & groupLt);
+    if (!rowIn || !inb) continue;
+    const u32 mode = (info >> 22) & 3u, nb = (info >> 16) & 63u, payload = info & 0xFFFFu;
+    const double offset = s_offset[t];
+    T vals[V];
+    u32 e = e0;
+#pragma unroll
+    for (u32 k = 0; k < V; k++)
+    {
+      T val = T(0);
+      if ((vb >> k) & 1u)
+      {
+        if (mode == 0u)
+        {
+          u64 bits = 0;
+          for (u32 q = 0; q < TB; q++) bits |= (u64)s_range[payload + e * TB + q] << (8u * q);
+          memcpy(&val, &bits, sizeof(T));
+        }
+        else if (mode == 3u) val = (T)offset;
+        else if (mode == 1u)
+        {
+          const u32 bit0 = (shift + payload) * 8u;
+          u32 q;
+          if (!((info >> 24) & 1u)) q = wordBits(s_words, bit0 + e * nb, nb);
+          else
+          {
+            const u32 lb = s_lutBits[t], nbIdx = lb & 255u, nLut = lb >> 8;
+            const u32 idxBit = bit0 + 8u * ((nLut * nb + 7u) >> 3);
+            const u32 ix = wordBits(s_words, idxBit + e * nbIdx, nbIdx);
+            if (ix > nLut) { badIdx = true; q = 0u; }
+            else q = ix ? wordBits(s_words, bit0 + (ix - 1u) * nb, nb) : 0u;
+          }
+          const double z = offset + (double)q * invScale;
+          val = (T)(z < zMax ? z : zMax);    // std::min(z, zMax)
+        }
+        e++;
+      }
+      vals[k] = val;
+    }
+    T* dst = out + ((u64)i * (u64)p.nCols + j);
+    if (inb == (1u << V) - 1u && ((uintptr_t)dst & (V * TB - 1u)) == 0u)
+    {
+      if (V * TB == 16u) { uint4 x; memcpy(&x, vals, 16); *reinterpret_cast<uint4*>(dst) = x; }
+      else { uint2 x; memcpy(&x, vals, 8); *reinterpret_cast<uint2*>(dst) = x; }
+    }
+    else
+    {
+#pragma unroll
+      for (u32 k = 0; k < V; k++) if ((inb >> k) & 1u) dst[k] = vals[k];
+    }
+  }
+  if (__any(badIdx) && laneId() == 0) raiseError(st, kFailed, pos0);
+}
+
 void launchTileDecode(int dt, const BandParams& p, const DecodeArgs& a, DeviceStatus* st, hipStream_t stream)
 {
   const int nPos = p.nTV * p.nTH;
+  if (p.mb == 8 && p.nDepth == 1 && p.version >= 3 && nPos > 0)
+  {
+    const dim3 grid8((nPos + (int)kGroup - 1) / (int)kGroup), block8(256);
+    switch (dt)
+    {
+      case DT_Char:   hipLaunchKernelGGL(k_decode_blocks8<signed char>, grid8, block8, 0, stream, p, a, st); break;
+      case DT_Byte:   hipLaunchKernelGGL(k_decode_blocks8<unsigned char>, grid8, block8, 0, stream, p, a, st); break;
+      case DT_Short:  hipLaunchKernelGGL(k_decode_blocks8<short>, grid8, block8, 0, stream, p, a, st); break;
+      case DT_UShort: hipLaunchKernelGGL(k_decode_blocks8<unsigned short>, grid8, block8, 0, stream, p, a, st); break;
+      case DT_Int:    hipLaunchKernelGGL(k_decode_blocks8<int>, grid8, block8, 0, stream, p, a, st); break;
+      case DT_UInt:   hipLaunchKernelGGL(k_decode_blocks8<unsigned int>, grid8, block8, 0, stream, p, a, st); break;
+      case DT_Float:  hipLaunchKernelGGL(k_decode_blocks8<float>, grid8, block8, 0, stream, p, a, st); break;
+      case DT_Double: hipLaunchKernelGGL(k_decode_blocks8<double>, grid8, block8, 0, stream, p, a, st); break;
+      default: break;
+    }
+    return;
+  }
   const dim3 grid((nPos + 3) / 4), block(256);
   switch (dt)
   {
