@@ -91,6 +91,12 @@ LERC_AMD_API const char* lerc_amd_last_note(lerc_amd_context* ctx);
 LERC_AMD_API unsigned int lerc_amd_mask_rle_device(lerc_amd_context* ctx, const unsigned char* dBits, unsigned int nBytes,
                                                    unsigned char* dOut, unsigned int cap, unsigned int* size);
 
+/* The other way, as the masked decode uses it: nBytes mask bytes out of a stream of rleBytes bytes (RLE.cpp:259-330); what the
+ * stream does not hold stays zero.  Returns 0, or 1 (Failed) for a damaged stream (no end marker, a segment that runs over
+ * either end). */
+LERC_AMD_API unsigned int lerc_amd_mask_rle_decode_device(lerc_amd_context* ctx, const unsigned char* dRle, unsigned int rleBytes,
+                                                          unsigned char* dBits, unsigned int nBytes);
+
 /* library / build identification: "lerc_amd <version> gfx950 hip" (or "... hipsim" for the CPU test build) */
 LERC_AMD_API const char* lerc_amd_build_info(void);
 

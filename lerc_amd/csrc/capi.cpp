@@ -689,6 +689,25 @@ unsigned int lerc_amd_mask_rle_device(lerc_amd_context* h, const unsigned char* 
   return kOk;
 }
 
+unsigned int lerc_amd_mask_rle_decode_device(lerc_amd_context* h, const unsigned char* dRle, unsigned int rleBytes, unsigned char* dBits,
+                                             unsigned int nBytes)
+{
+  if (!h || !dRle || !dBits || rleBytes < 2 || nBytes == 0) return kWrongParam;
+  Context& ctx = h->ctx;
+  ctx.reset();
+  const size_t need = maskRleDecodeScratchBytes(rleBytes);
+  if (!ctx.reserve(need + 4096)) return kFailed;
+  u8* scratch = ctx.allocT<u8>(need);
+  DeviceStatus* dStatus = reinterpret_cast<DeviceStatus*>(ctx.allocT<u8>(64));
+  DeviceStatus* pin = (DeviceStatus*)ctx.pinned(64);
+  if (!scratch || !dStatus || !pin) return kFailed;
+  hipMemsetAsync(dStatus, 0, 64, ctx.activeStream());
+  launchMaskRleDecode(dRle, rleBytes, dBits, nBytes, scratch, dStatus, ctx.activeStream());
+  hipMemcpyAsync(pin, dStatus, sizeof(DeviceStatus), hipMemcpyDeviceToHost, ctx.activeStream());
+  if (!ctx.sync()) return kFailed;
+  return pin->error ? pin->error : kOk;
+}
+
 const char* lerc_amd_build_info(void)
 {
 #ifdef HIPSIM

@@ -312,6 +312,15 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
   need += fastBandWorkspace(nRows, nCols, rq.blobSize) + 4096;    // streaming path tables
   for (int i = 0; i < rq.nBands; i++)
     if (bands[i].hd.tryHuffmanFlt()) { need += fplDecodeScratchBytes(nPix * nD, tb); break; }
+  // masks of some size are decoded where the bits are needed (rle_kernels.hip) instead of on the host between a copy down and a
+  // copy up (LERC_AMD_DEVICE_RLE as for the encoder: 0 = never, <bytes> = from masks of that many bytes on; default 256 KB)
+  static const size_t kDeviceRleFrom = []() -> size_t { const char* e = getenv("LERC_AMD_DEVICE_RLE"); const long v = e ? atol(e) : 1; return v <= 0 ? ~(size_t)0 : v < 16 ? (size_t)(256u << 10) : (size_t)v; }();
+  const size_t kDeviceRleMax = (size_t)4 << 20;    // (16 bytes of tables per byte of the stream)
+  size_t rleScratch = 0;
+  for (int i = 0; i < rq.nBands; i++)
+    if (maskBytes >= kDeviceRleFrom && bands[i].numBytesMask >= 2 && (size_t)bands[i].numBytesMask <= kDeviceRleMax)
+      rleScratch = std::max(rleScratch, maskRleDecodeScratchBytes((size_t)bands[i].numBytesMask));
+  need += rleScratch + (rleScratch ? 256 : 0);
   if (!ctx.reserve(need)) return kFailed;
 
   const u8* dBlob = rq.dBlob;
@@ -404,11 +413,27 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
       // and sent to the device by finishMask() -- in tiling mode behind the launch of the chunk walk, which needs no mask
       if (at + (u64)bd.numBytesMask > bd.offset + (u64)blobEnd) return kFailed;
       const size_t extra = std::min<size_t>((size_t)2 * nD * tb + 2, (size_t)(bd.offset + (u64)blobEnd - (at + (u64)bd.numBytesMask)));
+      const bool onDevice = maskBytes >= kDeviceRleFrom && bd.numBytesMask >= 2 && (size_t)bd.numBytesMask <= kDeviceRleMax;
+      if (onDevice)
+      {
+        // decoded on the device, in front of the band's kernels; a damaged stream raises Failed in the status the call ends on.
+        // The host fetches the header bytes behind the mask only.
+        u8* scratch = ctx.allocT<u8>(maskRleDecodeScratchBytes((size_t)bd.numBytesMask));
+        if (!scratch) return kFailed;
+        maskRle.resize(extra);    // (read first: the copy waits for what the stream holds)
+        if (extra && !rd.read(at + (u64)bd.numBytesMask, extra, maskRle.data())) return kFailed;
+        rd.cache = maskRle.data(); rd.cacheOff = at + (u64)bd.numBytesMask; rd.cacheLen = maskRle.size();
+        { ProfScope ps(ctx, "mask_rle_decode"); launchMaskRleDecode(dBand + (at - bd.offset), (u32)bd.numBytesMask, dBits, (u32)maskBytes, scratch, dStatus, st); }
+        haveMask = true; maskAllValid = false;
+      }
+      else
+      {
       maskRle.resize((size_t)bd.numBytesMask + extra);
       if (!rd.read(at, maskRle.size(), maskRle.data())) return kFailed;
       rd.cache = maskRle.data(); rd.cacheOff = at; rd.cacheLen = maskRle.size();
       haveMask = true; maskAllValid = false;
       maskPending = true;
+      }
     }
     else if (!haveMask || maskAllValid) return kFailed;    // "use previous mask" without a usable one
     at += (u64)bd.numBytesMask;

@@ -110,6 +110,9 @@ void launchMaskGroupCounts(const u8* maskBits, i64 nPix, u32* counts, hipStream_
 // out[0 .. *sizeOut) receives the stream with its end marker; *sizeOut = ~0 if it does not fit cap (nothing useful written)
 size_t maskRleScratchBytes(size_t nBytes);
 void launchMaskRle(const u8* bits, u32 nBytes, u8* out, u32 cap, u32* sizeOut, u8* scratch, hipStream_t stream);
+// the other way (rle_kernels.hip): bits[0 .. outBytes) from a stream of rleBytes bytes in device memory
+size_t maskRleDecodeScratchBytes(size_t rleBytes);
+void launchMaskRleDecode(const u8* rle, u32 rleBytes, u8* bits, u32 outBytes, u8* scratch, DeviceStatus* status, hipStream_t stream);
 
 // raw fallback ("one sweep", Lerc2.cpp:1343-1400): valid pixels copied in order
 void launchOneSweep(bool encode, const void* src, void* dst, const u8* maskBits, const u32* groupBase, i64 nPix,

@@ -263,6 +263,223 @@ __global__ void __launch_bounds__(256) k_rle_write(const u8* __restrict__ b, u32
   });
 }
 
+// ================================================================================================
+// Decoding (RLE::decompress, RLE.cpp:259-330; the host's rleDecode in codec_common.cpp is the same loop)
+// ================================================================================================
+// Where a segment starts is known once the segment before it has been read: the same chain as in the block stream, and
+// without anything to tell a true segment start from a false one.  So nothing is guessed: every position p of the stream
+// gets the step it would make if a segment started there (one look at two bytes), and pointer doubling in LDS turns the steps
+// into hops -- first to the end of p's 256-byte sub-piece, then on to the end of its 8 KiB piece --, each with the number of
+// mask bytes produced on the way.  One thread then follows the 8 KiB hops from position 0 (a stream of 700 KB: 90 dependent
+// loads), one thread per piece the 256-byte hops inside it, and with that every sub-piece on the way knows where the chain
+// enters it and which mask byte comes next: a wave walks the sub-piece's twenty-odd segments and writes them, a lane a segment.
+constexpr u32 kPiece = 8192u, kSub = 256u;
+constexpr u32 kHopEnd = 0xFFFFFFFFu, kHopErr = 0xFFFFFFFEu;    // the stream's end mark was read / the stream is damaged
+constexpr u32 kRelEnd = 0xFFFFu, kRelErr = 0xFFFEu;
+
+struct Hop { u32 exit, sum; };    // first segment start at or behind the (sub-)piece's end, or kHopEnd / kHopErr; bytes produced up to there
+
+__global__ void __launch_bounds__(1024) k_rled_hops(const u8* __restrict__ rle, u32 L, Hop* __restrict__ hopSub, Hop* __restrict__ hopPiece)
+{
+  __shared__ __align__(16) u8 s_b[kPiece + 16];
+  __shared__ u16 s_nx[kPiece];    // relative to the piece's start; >= kPiece: outside; kRelEnd / kRelErr
+  __shared__ u32 s_sm[kPiece];
+  __shared__ u32 s_changed;
+  constexpr u32 E = kPiece / 1024u;    // entries per thread
+  const u32 B = blockIdx.x * kPiece;
+  const u32 nHere = min(kPiece, L - B);
+  for (u32 i = threadIdx.x; i < kPiece + 2u; i += 1024u) s_b[i] = (B + i < L) ? rle[B + i] : (u8)0;
+  __syncthreads();
+  // the single steps
+  for (u32 q = 0; q < E; q++)
+  {
+    const u32 r = q * 1024u + threadIdx.x;
+    u32 nx = kRelErr, sm = 0u;
+    const u32 p = B + r;
+    if (r < nHere && p + 2u <= L)
+    {
+      const int cnt = (int)(short)((u32)s_b[r] | ((u32)s_b[r + 1] << 8));
+      if (cnt == -32768) nx = kRelEnd;
+      else
+      {
+        const u32 n = (u32)(cnt < 0 ? -cnt : cnt), payload = cnt > 0 ? n : 1u;
+        if (L - (p + 2u) >= payload + 2u) { nx = r + 2u + payload; sm = n; }    // (+ 2: a count always follows, RLE.cpp:310)
+      }
+    }
+    s_nx[r] = (u16)nx; s_sm[r] = sm;    // (nx <= 8191 + 2 + 32767 < kRelErr)
+  }
+  __syncthreads();
+  // doubling, synchronous rounds: a hop that ends inside the limit is extended by the hop that starts where it ends
+  for (int phase = 0; phase < 2; phase++)
+  {
+    for (;;)
+    {
+      if (threadIdx.x == 0) s_changed = 0u;
+      u32 nx[E], sm[E];
+      bool ch = false;
+#pragma unroll
+      for (u32 q = 0; q < E; q++)
+      {
+        const u32 r = q * 1024u + threadIdx.x;
+        nx[q] = s_nx[r]; sm[q] = s_sm[r];
+        const u32 limit = phase == 0 ? min((r | (kSub - 1u)) + 1u, nHere) : nHere;
+        if (nx[q] < limit)    // (neither a mark nor outside)
+        {
+          const u32 j = nx[q];
+          nx[q] = s_nx[j]; sm[q] += s_sm[j];
+          ch = true;
+        }
+      }
+      __syncthreads();
+      if (ch)
+      {
+        s_changed = 1u;
+#pragma unroll
+        for (u32 q = 0; q < E; q++) { const u32 r = q * 1024u + threadIdx.x; s_nx[r] = (u16)nx[q]; s_sm[r] = sm[q]; }
+      }
+      __syncthreads();
+      if (!s_changed) break;
+      __syncthreads();
+    }
+    Hop* dst = phase == 0 ? hopSub : hopPiece;
+    for (u32 q = 0; q < E; q++)
+    {
+      const u32 r = q * 1024u + threadIdx.x;
+      if (r >= nHere) continue;
+      const u32 nx = s_nx[r];
+      Hop h;
+      h.exit = nx == kRelEnd ? kHopEnd : nx == kRelErr ? kHopErr : B + nx;
+      h.sum = s_sm[r];
+      dst[B + r] = h;
+    }
+    __syncthreads();
+  }
+}
+
+// entry of the chain into every piece it touches: (position, mask bytes produced before); untouched pieces keep kNone
+__global__ void __launch_bounds__(64) k_rled_chain(const Hop* __restrict__ hopPiece, u32 L, u32 outBytes, uint2* __restrict__ pieceEntry,
+                                                   DeviceStatus* st)
+{
+  if (threadIdx.x != 0) return;
+  u32 pos = 0;
+  u64 out = 0;
+  for (;;)
+  {
+    if (pos >= L) { raiseError(st, kFailed, 0x52000001u); return; }
+    pieceEntry[pos / kPiece] = make_uint2(pos, (u32)out);
+    const Hop h = hopPiece[pos];
+    out += h.sum;
+    if (out > outBytes || h.exit == kHopErr) { raiseError(st, kFailed, 0x52000002u); return; }
+    if (h.exit == kHopEnd) return;
+    pos = h.exit;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_rled_sub_entries(const Hop* __restrict__ hopSub, u32 L, const uint2* __restrict__ pieceEntry,
+                                                         uint2* __restrict__ subEntry, const DeviceStatus* st)
+{
+  const u32 b = blockIdx.x * 64u + threadIdx.x;
+  if (b >= (L + kPiece - 1u) / kPiece || st->error) return;
+  const uint2 e = pieceEntry[b];
+  if (e.x == kNone) return;
+  u32 pos = e.x, out = e.y;
+  const u32 end = min((b + 1u) * kPiece, L);
+  while (pos < end)
+  {
+    subEntry[pos / kSub] = make_uint2(pos, out);
+    const Hop h = hopSub[pos];
+    out += h.sum;
+    if (h.exit >= kHopErr) break;
+    pos = h.exit;
+  }
+}
+
+// a wave per sub-piece the chain enters
+__global__ void __launch_bounds__(64) k_rled_expand(const u8* __restrict__ rle, u32 L, const uint2* __restrict__ subEntry,
+                                                    u8* __restrict__ bits, u32 outBytes, const DeviceStatus* st)
+{
+  constexpr u32 kMaxSeg = kSub / 3u + 2u;    // (a segment is three bytes at least; one whose count is 0 too)
+  __shared__ u8 s_b[kSub + 8];
+  __shared__ u32 s_pos[kMaxSeg], s_out[kMaxSeg];
+  __shared__ int s_cnt[kMaxSeg];
+  __shared__ u32 s_n;
+  const u32 s = blockIdx.x, lane = threadIdx.x;
+  const uint2 e = subEntry[s];
+  if (e.x == kNone || st->error) return;
+  const u32 S = s * kSub, end = min(S + kSub, L);
+  for (u32 i = lane; i < kSub + 2u; i += 64u) s_b[i] = (S + i < L) ? rle[S + i] : (u8)0;
+  __syncthreads();
+  if (lane == 0)
+  {
+    u32 pos = e.x, out = e.y, n = 0;
+    while (pos < end && pos + 2u <= L && n < kMaxSeg)
+    {
+      const int cnt = (int)(short)((u32)s_b[pos - S] | ((u32)s_b[pos - S + 1] << 8));
+      if (cnt == -32768) break;
+      const u32 len = (u32)(cnt < 0 ? -cnt : cnt), payload = cnt > 0 ? len : 1u;
+      if (L - (pos + 2u) < payload + 2u) break;    // (k_rled_chain has raised the error)
+      s_pos[n] = pos + 2u; s_out[n] = out; s_cnt[n] = cnt; n++;
+      out += len; pos += 2u + payload;
+    }
+    s_n = n;
+  }
+  __syncthreads();
+  const u32 n = s_n;
+  constexpr u32 kBig = 256u;
+  // short segments: a lane each
+  for (u32 k = lane; k < n; k += 64u)
+  {
+    const int cnt = s_cnt[k];
+    const u32 len = (u32)(cnt < 0 ? -cnt : cnt);
+    const u32 o = s_out[k];
+    if (len == 0u || len >= kBig || (u64)o + len > outBytes) continue;
+    const u8* src = rle + s_pos[k];
+    u8* dst = bits + o;
+    if (cnt < 0)
+    {
+      const u8 v = src[0];
+      const u64 v8 = 0x0101010101010101ull * v;
+      u32 i = 0;
+      for (; i < len && (((uintptr_t)(dst + i)) & 7u); i++) dst[i] = v;
+      for (; i + 8u <= len; i += 8u) *reinterpret_cast<u64*>(dst + i) = v8;
+      for (; i < len; i++) dst[i] = v;
+    }
+    else for (u32 i = 0; i < len; i++) dst[i] = src[i];
+  }
+  // long ones: the wave together, 8 bytes a lane where the destination allows
+  for (u32 k = 0; k < n; k++)
+  {
+    const int cnt = s_cnt[k];
+    const u32 len = (u32)(cnt < 0 ? -cnt : cnt);
+    const u32 o = s_out[k];
+    if (len < kBig || (u64)o + len > outBytes) continue;
+    const u8* src = rle + s_pos[k];
+    u8* dst = bits + o;
+    const u32 head = min(len, (u32)((8u - ((uintptr_t)dst & 7u)) & 7u));
+    const u32 words = (len - head) / 8u, tail = len - head - 8u * words;
+    if (cnt < 0)
+    {
+      const u8 v = src[0];
+      const u64 v8 = 0x0101010101010101ull * v;
+      if (lane < head) dst[lane] = v;
+      for (u32 w = lane; w < words; w += 64u) *reinterpret_cast<u64*>(dst + head + 8u * w) = v8;
+      if (lane < tail) dst[head + 8u * words + lane] = v;
+    }
+    else
+    {
+      if (lane < head) dst[lane] = src[lane];
+      for (u32 w = lane; w < words; w += 64u)
+      {
+        u64 x = 0;
+#pragma unroll
+        for (u32 q = 0; q < 8u; q++) x |= (u64)src[head + 8u * w + q] << (8u * q);
+        *reinterpret_cast<u64*>(dst + head + 8u * w) = x;
+      }
+      if (lane < tail) dst[head + 8u * words + lane] = src[head + 8u * words + lane];
+    }
+  }
+}
+
 }    // namespace
 
 size_t maskRleScratchBytes(size_t nBytes)
@@ -293,6 +510,30 @@ void launchMaskRle(const u8* bits, u32 nBytes, u8* out, u32 cap, u32* sizeOut, u
   launchExclusiveScan(sizes, offs, nThreads, part + 2 * (nPart + 8), st);
   hipLaunchKernelGGL(k_rle_write, dim3(nWG), dim3(256), 0, st, bits, nBytes, nThreads, (const u32*)lastHead, (const u32*)firstTail,
                      (const u32*)offs, out, cap, sizeOut);
+}
+
+size_t maskRleDecodeScratchBytes(size_t rleBytes)
+{
+  const size_t nPiece = (rleBytes + kPiece - 1) / kPiece, nSub = (rleBytes + kSub - 1) / kSub;
+  return 2 * (rleBytes + 8) * sizeof(Hop) + (nPiece + nSub + 16) * sizeof(uint2) + 256;
+}
+
+// bits[0 .. outBytes) = the decoded stream, zeros behind what it holds; a damaged stream raises kFailed in *status
+void launchMaskRleDecode(const u8* rle, u32 rleBytes, u8* bits, u32 outBytes, u8* scratch, DeviceStatus* status, hipStream_t st)
+{
+  hipMemsetAsync(bits, 0, outBytes, st);
+  if (rleBytes < 2u) return;
+  const u32 nPiece = (rleBytes + kPiece - 1u) / kPiece, nSub = (rleBytes + kSub - 1u) / kSub;
+  Hop* hopSub = reinterpret_cast<Hop*>(((uintptr_t)scratch + 15u) & ~(uintptr_t)15u);
+  Hop* hopPiece = hopSub + rleBytes + 8;
+  uint2* pieceEntry = reinterpret_cast<uint2*>(hopPiece + rleBytes + 8);
+  uint2* subEntry = pieceEntry + nPiece + 8;
+  hipMemsetAsync(pieceEntry, 0xFF, ((size_t)nPiece + 8 + nSub + 8) * sizeof(uint2), st);
+  hipLaunchKernelGGL(k_rled_hops, dim3(nPiece), dim3(1024), 0, st, rle, rleBytes, hopSub, hopPiece);
+  hipLaunchKernelGGL(k_rled_chain, dim3(1), dim3(64), 0, st, (const Hop*)hopPiece, rleBytes, outBytes, pieceEntry, status);
+  hipLaunchKernelGGL(k_rled_sub_entries, dim3((nPiece + 63u) / 64u), dim3(64), 0, st, (const Hop*)hopSub, rleBytes, (const uint2*)pieceEntry,
+                     subEntry, (const DeviceStatus*)status);
+  hipLaunchKernelGGL(k_rled_expand, dim3(nSub), dim3(64), 0, st, rle, rleBytes, (const uint2*)subEntry, bits, outBytes, (const DeviceStatus*)status);
 }
 
 }    // namespace lerc

@@ -16,6 +16,8 @@
 // 2. Decode: one wave64 per micro-block position, lane = element (rank by __ballot / __popcll for
 //    masked blocks), bit extraction straight from the blob, dequantise in double precision in the
 //    reference's expression order (compile with -ffp-contract=off), clamp, cast, store.
+#include <cstdio>
+#include <cstdlib>
 #include "kernels.h"
 #include "wave_utils.h"
 
@@ -30,21 +32,72 @@ struct BlkInfo
   u8 flag, mode, diff, tc, offBytes, nb, lut, dtUsed;
 };
 
+// The first 16 bytes of a block, which hold every header field there is (flag, offset of up to 8 bytes, the bit stuffer's
+// first byte, a count of up to 4 bytes, the LUT size: 15 bytes) -- fetched with five aligned 32-bit loads that are all in
+// flight at once, where a parse that goes byte by byte waits for memory half a dozen times in a row (flag -> offset type
+// -> bit width -> count -> LUT size).  Bytes at or behind `end` read as zero; no load touches a 4-byte unit that lies
+// entirely outside [blob, blob + end).
+struct Win16
+{
+  u64 lo, hi;
+  __device__ __forceinline__ u32 byteAt(u32 k) const { return (u32)((k < 8u ? lo >> (8u * k) : hi >> (8u * (k - 8u))) & 255u); }
+};
+
+__device__ __forceinline__ Win16 funnel16(const u32 (&d)[5], u32 sh, u32 have)
+{
+  u32 x[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) x[k] = (u32)((((u64)d[k + 1] << 32) | d[k]) >> sh);
+  Win16 w;
+  w.lo = ((u64)x[1] << 32) | x[0];
+  w.hi = ((u64)x[3] << 32) | x[2];
+  // blank what lies at or behind the end (have = bytes of the window inside the blob)
+  if (have < 16u)
+  {
+    if (have <= 8u) { w.hi = 0; w.lo = have == 0u ? 0ull : (w.lo & (~0ull >> (64u - 8u * have))); }
+    else w.hi &= ~0ull >> (64u - 8u * (have - 8u));
+  }
+  return w;
+}
+
+// bytes pos ... pos + 15 of blob (any memory, any alignment)
+__device__ __forceinline__ Win16 loadWin16(const u8* __restrict__ blob, u32 pos, u32 end)
+{
+  const uintptr_t A = (uintptr_t)blob + pos, E = (uintptr_t)blob + end;
+  const u32* wp = reinterpret_cast<const u32*>(A & ~(uintptr_t)3);
+  u32 d[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) d[k] = ((uintptr_t)(wp + k) < E) ? wp[k] : 0u;
+  return funnel16(d, (u32)(A & 3u) * 8u, end > pos ? min(16u, end - pos) : 0u);
+}
+
+// the same out of an LDS array that starts on a 4-byte boundary (kept apart so that the loads stay LDS loads)
+__device__ __forceinline__ Win16 loadWin16Words(const u32* words, u32 pos, u32 end)
+{
+  const u32 w0 = pos >> 2;
+  u32 d[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) d[k] = (4u * (w0 + k) < end) ? words[w0 + k] : 0u;
+  return funnel16(d, (pos & 3u) * 8u, end > pos ? min(16u, end - pos) : 0u);
+}
+
 // 0 = ok, 1 = not a valid block here, 2 = raw block whose valid count is not known to the caller.
 // Mirrors the checks of Lerc2::ReadTile and BitStuffer2::Decode; additionally refuses element counts
 // that differ from the block's valid pixel count (the reference would read past its buffer there).
+// `h` holds the block's first 16 bytes, pos / end say where it lies in its stream.
 template<int TBYTES>
-__device__ __forceinline__ int parseBlock(const u8* __restrict__ blob, u32 pos, u32 end, const BandParams& p, int nValid,
-                                          u32 maxCount, BlkInfo& b)
+__device__ __forceinline__ int parseWindow(const Win16& h, u32 pos, u32 end, const BandParams& p, int nValid, u32 maxCount, BlkInfo& b)
 {
+  b.len = 0;
   if (pos >= end) return 1;
-  const u32 flag = blob[pos];
+  const u32 flag = h.byteAt(0);
   b.flag = (u8)flag;
   b.diff = (p.version >= 5 && (flag & 4u)) ? 1 : 0;
   b.mode = (u8)(flag & 3u);
   b.tc = (u8)(flag >> 6);
   b.offBytes = 0; b.nb = 0; b.lut = 0; b.cnt = 0; b.nLut = 0; b.payload = 1; b.dtUsed = (u8)p.dt;
   u64 len = 1;
+  if (b.diff && p.nDepth == 1) return 1;    // (difference to the slice before: there is none, Lerc2.cpp ReadTile refuses)
   if (b.mode == 2) { b.len = 1; return 0; }
   if (b.mode == 0)
   {
@@ -61,17 +114,19 @@ __device__ __forceinline__ int parseBlock(const u8* __restrict__ blob, u32 pos, 
     len = 1 + b.offBytes;
     if (b.mode == 1)
     {
-      u64 at = (u64)pos + len;
-      if (at >= end) return 1;
-      const u32 b0 = blob[at];
+      const u32 at = (u32)len;                      // (relative to the block's start from here on: <= 9)
+      if ((u64)pos + at >= end) return 1;
+      const u32 b0 = h.byteAt(at);
       const u32 code = b0 >> 6;
       const int cb = (code == 0) ? 4 : 3 - (int)code;
       if (cb == 0) return 1;
       b.lut = (b0 & 32u) ? 1 : 0;
       b.nb = (u8)(b0 & 31u);
-      if (at + 1 + cb > end) return 1;
-      u32 cnt = 0;
-      for (int i = 0; i < cb; i++) cnt |= (u32)blob[at + 1 + i] << (8 * i);
+      if ((u64)pos + at + 1 + cb > end) return 1;
+      // the count's cb bytes start at at + 1 <= 10: inside the window
+      const u32 sh = 8u * (at + 1u);
+      const u64 two = sh < 64u ? ((h.lo >> sh) | (sh ? h.hi << (64u - sh) : 0ull)) : (h.hi >> (sh - 64u));
+      const u32 cnt = (u32)two & (cb == 4 ? 0xFFFFFFFFu : ((1u << (8 * cb)) - 1u));
       b.cnt = cnt;
       if (cnt == 0 || cnt > maxCount || b.nb == 0) return 1;
       if (nValid >= 0 && cnt != (u32)nValid) return 1;
@@ -80,7 +135,7 @@ __device__ __forceinline__ int parseBlock(const u8* __restrict__ blob, u32 pos, 
       else
       {
         if ((u64)pos + len >= end) return 1;
-        const int nLut = (int)blob[(u64)pos + len] - 1;
+        const int nLut = (int)h.byteAt((u32)len) - 1;    // (at most byte 14)
         if (nLut < 1) return 1;
         b.nLut = (u32)nLut;
         len += 1;
@@ -93,6 +148,21 @@ __device__ __forceinline__ int parseBlock(const u8* __restrict__ blob, u32 pos, 
   if ((u64)pos + len > end) return 1;
   b.len = (u32)len;
   return 0;
+}
+
+template<int TBYTES>
+__device__ __forceinline__ int parseBlock(const u8* __restrict__ blob, u32 pos, u32 end, const BandParams& p, int nValid,
+                                          u32 maxCount, BlkInfo& b)
+{
+  return parseWindow<TBYTES>(loadWin16(blob, pos, end), pos, end, p, nValid, maxCount, b);
+}
+
+// the block at byte `pos` of an LDS array given as words
+template<int TBYTES>
+__device__ __forceinline__ int parseBlockWords(const u32* words, u32 pos, u32 end, const BandParams& p, int nValid,
+                                               u32 maxCount, BlkInfo& b)
+{
+  return parseWindow<TBYTES>(loadWin16Words(words, pos, end), pos, end, p, nValid, maxCount, b);
 }
 
 // little-endian bit field read with a hard upper bound on the bytes touched
@@ -125,7 +195,7 @@ template<class T>
 __global__ void __launch_bounds__(256) k_decode_tiles(BandParams p, DecodeArgs a, DeviceStatus* st)
 {
   __shared__ u32 s_lut[4][256];
-  __shared__ u8 s_head[4][64];
+  __shared__ __align__(16) u8 s_head[4][64];
   const int w = waveId(), lane = laneId();
   const int pos = (int)blockIdx.x * 4 + w;
   if (pos >= p.nTV * p.nTH) return;
@@ -162,7 +232,7 @@ __global__ void __launch_bounds__(256) k_decode_tiles(BandParams p, DecodeArgs a
     s_head[w][lane] = ((u64)off + (u64)lane < (u64)a.blobEnd) ? blob[(u64)off + lane] : (u8)0;
     waveSync();
     BlkInfo b;    // (parsed relative to the block's start: position 0, the blob's end as seen from there)
-    const int rc = (off < a.blobEnd) ? parseBlock<(int)sizeof(T)>(s_head[w], 0u, a.blobEnd - off, p, nValid, (u32)nElem, b) : 1;
+    const int rc = (off < a.blobEnd) ? parseBlockWords<(int)sizeof(T)>(reinterpret_cast<const u32*>(s_head[w]), 0u, a.blobEnd - off, p, nValid, (u32)nElem, b) : 1;
     if (rc != 0 || (((u32)b.flag >> 2) & pattern) != (((u32)j0 >> 3) & pattern) || (b.diff && iD == 0))
     {
       failed = true;
@@ -302,7 +372,7 @@ __global__ void __launch_bounds__(256) k_decode_blocks8(BandParams p, DecodeArgs
     double offset = 0;
     int rc = 1;
     if (off >= from && off < to && next > off && next <= to)
-      rc = parseBlock<(int)TB>(s_range, off - from, next - from, p, nValid, 64u, b);
+      rc = parseBlockWords<(int)TB>(reinterpret_cast<const u32*>(s_bytes), shift + off - from, shift + next - from, p, nValid, 64u, b);
     const bool good = rc == 0 && b.len == next - off && (((u32)b.flag >> 2) & pattern) == ((j0 >> 3) & pattern) && !b.diff;
     if (good)
     {
@@ -545,35 +615,39 @@ __global__ void __launch_bounds__(64) k_walk_chunks(BandParams p, WalkPlan wp, c
 // D1 for chunks of 4 KiB (every 8 x 8 raster, 16 x 16 up to 32-bit types): the same agreement, but the chunk is staged in
 // LDS and every position is parsed at most once -- s_next[] remembers length and signature of the block that starts
 // there, so the few hundred candidates, which fall onto a handful of common paths within a step or two, follow those
-// paths by table look-up instead of parsing ~40 blocks each out of global memory.
+// paths by table look-up instead of parsing every block each.
+//
+// A walk is a chain of dependent steps, one per block, and the kernel's time is the length of that chain.  So the chunk is
+// cut into up to four sub-chunks and each wave walks the candidates of one of them (every byte of the first window of
+// its sub-chunk) to that sub-chunk's end only, leaving in s_exitOf[] where a walk through a block start leaves the
+// SUB-chunk.  Where a walk lands in the next sub-chunk is one of that one's candidates, whatever it is, so afterwards a
+// candidate of the chunk's first window gets to the chunk's end in at most four look-ups -- having survived exactly the
+// blocks it would have had to survive walking there (8192^2 with a 10 % mask: 0.98 -> R ms).
 static const u32 kMemoChunk = 4096, kMemoWindowMax = 1100;
 
-// Four waves share a chunk's tables and take every fourth round of 64 candidates: four times the waves per CU for the
-// same LDS, and a chunk is through after little more than its most expensive round.  (A wave may miss an exit another
-// wave is just writing -- it then walks on as it would have.)
 template<int TBYTES>
 __global__ void __launch_bounds__(256) k_walk_chunks_memo(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin,
                                                          u32 blobEnd, u32* __restrict__ chunkExit)
 {
   __shared__ __align__(16) u8 s_bytes[kMemoChunk + kMemoWindowMax + 48];
-  // 16-bit tables (21 KB with the bytes: seven of these one-wave workgroups per CU instead of four)
-  __shared__ __align__(16) u16 s_next[kMemoChunk];    // 0 = not parsed yet; kNoBlock / kRawUnknown; else len (< 4096) | sig << 12
-  __shared__ __align__(16) u16 s_exitOf[kMemoChunk];  // 0 = unknown; else 1 + (where a walk through this block start leaves the chunk - chunkStart)
+  // 16-bit tables (21 KB with the bytes: seven workgroups per CU)
+  __shared__ __align__(16) u16 s_next[kMemoChunk];    // 0 = not parsed yet; kNoBlock; else len (< 4094) | sig << 12
+  __shared__ __align__(16) u16 s_exitOf[kMemoChunk];  // 0 = unknown; else 1 + (where a walk through this block start leaves its sub-chunk - chunkStart)
   __shared__ u32 s_agreed[4], s_conflict[4];
-  const u32 kNoBlock = 0xFFFFu, kRawUnknown = 0xFFFEu;
+  const u32 kNoBlock = 0xFFFFu;
   const u32 c = blockIdx.x;
   const int lane = laneId(), wv = waveId();
   const u32 chunkStart = dataBegin + c * wp.chunkBytes;
   const u32 chunkEnd = min(chunkStart + wp.chunkBytes, blobEnd);
   const u32 stageEnd = min(chunkEnd + wp.window, blobEnd);
-  // candidates: every byte up to one raw block + 1 behind the chunk start.  Encoders never write a longer block (they fall
-  // back to raw); should a blob hold one, the exits agreed on here may be wrong, which D3 notices (it only takes over walks
-  // that started where it arrives) and pays for with its own walk.
+  // candidates: every byte up to one raw block + 1 behind the (sub-)chunk's start.  Encoders never write a longer block (they
+  // fall back to raw); should a blob hold one, the exits agreed on here may be wrong or missing, which D3 notices (it only
+  // takes over walks that started where it arrives) and pays for with its own walk.
   const u32 candWindow = min(wp.window, 2u + (u32)p.mb * (u32)p.mb * (u32)TBYTES);
-  const u32 winEnd = (c == 0) ? chunkStart + 1 : min(chunkStart + candWindow, chunkEnd);
+  const u32 subs = (wp.chunkBytes >= 12u * candWindow) ? 4u : (wp.chunkBytes >= 6u * candWindow) ? 2u : 1u;    // (a sub-chunk: three windows at least)
+  const u32 subBytes = wp.chunkBytes / subs;          // (a power of two)
   const u32 pattern = (p.version >= 5) ? 14u : 15u;
   const u32 maxCount = (u32)p.mb * (u32)p.mb;
-  const u32 kUnknown = 0xFFFFFFFEu;
   // stage with 16-byte loads from the aligned-down start (never past the blob's end); LDS byte i + shift <-> blob byte chunkStart + i
   const u32 a0 = chunkStart & ~15u, shift = chunkStart - a0;
   for (u32 v = threadIdx.x; a0 + 16u * v < stageEnd; v += 256u)
@@ -590,69 +664,87 @@ __global__ void __launch_bounds__(256) k_walk_chunks_memo(BandParams p, WalkPlan
     reinterpret_cast<uint4*>(s_exitOf)[i] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
-  const u8* s_chunk = s_bytes + shift;
 
-  u32 agreed = kNone;
-  bool conflict = false;
-  for (u32 r0 = chunkStart + 64u * (u32)wv; r0 < winEnd; r0 += 256u)
+  // ---- the walks: wave wv takes sub-chunk wv % subs, and of its rounds of 64 candidates every (4 / subs)-th
   {
-    u32 cur = r0 + (u32)lane;
-    bool alive = cur < winEnd;
-    bool unknown = false;
-    u32 prevSig = kNone;
-    while (__any(alive && !unknown && cur < chunkEnd))
+    const u32 k = (u32)wv % subs;
+    const u32 subStart = chunkStart + k * subBytes;
+    const u32 subEnd = min(subStart + subBytes, chunkEnd);
+    const u32 winEnd = (subStart >= chunkEnd) ? subStart : (c == 0 && k == 0) ? subStart + 1 : min(subStart + candWindow, subEnd);    // (the stream's first block starts at dataBegin)
+    for (u32 r0 = subStart + 64u * ((u32)wv / subs); r0 < winEnd; r0 += 64u * (4u / subs))
     {
-      if (alive && !unknown && cur < chunkEnd)
+      u32 cur = r0 + (u32)lane;
+      bool alive = cur < winEnd;
+      u32 prevSig = kNone;
+      while (__any(alive && cur < subEnd))
       {
-        const u32 rel = cur - chunkStart;
-        u32 e = s_next[rel];
-        if (e == 0u)
+        if (alive && cur < subEnd)
         {
-          BlkInfo b;
-          const int rc = parseBlock<TBYTES>(s_chunk, rel, stageEnd - chunkStart, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b);
-          if (rc == 1 || b.len >= 4094u) e = kNoBlock;    // (no block of a chunk this size is that long; 0xFFFE, 0xFFFF are taken)
-          else if (rc == 2) e = kRawUnknown;
-          else e = b.len | ((((u32)b.flag >> 2) & pattern) << 12);
-          s_next[rel] = (u16)e;    // (lanes that race here store the same value)
-        }
-        if (e == kNoBlock) alive = false;
-        else if (e == kRawUnknown) { if (wp.uniformN == 0) alive = false; else unknown = true; }    // see k_walk_chunks
-        else
-        {
-          const u32 sig = e >> 12;
-          if (prevSig != kNone && !sigFollows(prevSig, sig, p.mb, pattern)) alive = false;
+          const u32 rel = cur - chunkStart;
+          u32 e = s_next[rel];
+          if (e == 0u)
+          {
+            BlkInfo b;
+            const int rc = parseBlockWords<TBYTES>(reinterpret_cast<const u32*>(s_bytes), rel + shift, stageEnd - chunkStart + shift, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b);
+            // a raw block of a masked / ragged band (rc 2): its length is the block's valid pixel count, which takes the
+            // block index -- the candidate drops out (see k_walk_chunks)
+            if (rc != 0 || b.len >= 4094u) e = kNoBlock;    // (no block of a chunk this size is that long; 0xFFFF is taken)
+            else e = b.len | ((((u32)b.flag >> 2) & pattern) << 12);
+            s_next[rel] = (u16)e;    // (lanes that race here store the same value)
+          }
+          if (e == kNoBlock) alive = false;
           else
           {
-            const u32 known = s_exitOf[rel];    // an earlier walk came through here and made it to the chunk's end
-            prevSig = sig;
-            cur = known ? chunkStart + known - 1u : cur + (e & 0xFFFu);
+            const u32 sig = e >> 12;
+            if (prevSig != kNone && !sigFollows(prevSig, sig, p.mb, pattern)) alive = false;
+            else
+            {
+              const u32 known = s_exitOf[rel];    // an earlier walk came through here and made it to the sub-chunk's end
+              prevSig = sig;
+              cur = known ? chunkStart + known - 1u : cur + (e & 0xFFFu);
+            }
           }
         }
       }
-    }
-    // walks that made it leave their exit at every block start they passed, so that later candidates can stop there
-    {
+      // walks that made it leave their exit at every block start they passed, so that later candidates can stop there
       u32 at = r0 + (u32)lane;
-      bool go = alive && !unknown && at < winEnd;
+      bool go = alive && at < winEnd;
       while (__any(go))
       {
         if (go)
         {
           const u32 rel = at - chunkStart;
-          if (at >= chunkEnd || s_exitOf[rel] != 0u) go = false;
+          if (at >= subEnd || s_exitOf[rel] != 0u) go = false;
           else { s_exitOf[rel] = (u16)(cur - chunkStart + 1u); at += s_next[rel] & 0xFFFu; }
         }
       }
+      waveSync();
     }
-    waveSync();
-    const u32 ex = unknown ? kUnknown : cur;
-    const u32 lo = waveMin(alive ? ex : kNone);
-    const u32 hi = waveMax(alive ? ex : 0u);
-    if (lo != kNone)
+  }
+  __syncthreads();
+
+  // ---- from the first window to the chunk's end, sub-chunk by sub-chunk; the candidates that get there have to agree
+  u32 agreed = kNone;
+  bool conflict = false;
+  {
+    const u32 winEnd = (c == 0) ? chunkStart + 1 : min(chunkStart + candWindow, min(chunkStart + subBytes, chunkEnd));
+    const u32 len = chunkEnd - chunkStart;
+    for (u32 r0 = chunkStart + 64u * (u32)wv; r0 < winEnd; r0 += 256u)
     {
-      if (lo != hi) conflict = true;
-      else if (agreed == kNone) agreed = lo;
-      else if (agreed != lo) conflict = true;
+      const u32 q = r0 + (u32)lane;
+      u32 e = (q < winEnd) ? (u32)s_exitOf[q - chunkStart] : 0u;
+      for (u32 k = 1; k < subs; k++)
+        if (e != 0u && e - 1u < len) e = s_exitOf[e - 1u];
+      const bool alive = e != 0u && e - 1u >= len;
+      const u32 ex = chunkStart + e - 1u;
+      const u32 lo = waveMin(alive ? ex : kNone);
+      const u32 hi = waveMax(alive ? ex : 0u);
+      if (lo != kNone)
+      {
+        if (lo != hi) conflict = true;
+        else if (agreed == kNone) agreed = lo;
+        else if (agreed != lo) conflict = true;
+      }
     }
   }
   if (lane == 0) { s_agreed[wv] = agreed; s_conflict[wv] = conflict ? 1u : 0u; }
@@ -666,7 +758,7 @@ __global__ void __launch_bounds__(256) k_walk_chunks_memo(BandParams p, WalkPlan
       if (agreed == kNone) agreed = s_agreed[k];
       else if (agreed != s_agreed[k]) conflict = true;
     }
-    chunkExit[c] = (!conflict && agreed != kNone && agreed != kUnknown) ? agreed : kNone;
+    chunkExit[c] = (!conflict && agreed != kNone) ? agreed : kNone;
   }
 }
 
@@ -739,14 +831,15 @@ __global__ void __launch_bounds__(256) k_walk_counts_lds(BandParams p, WalkPlan 
   const u32 chunkEnd = min(chunkStart + wp.chunkBytes, blobEnd);
   const u32 maxCount = (u32)p.mb * (u32)p.mb;
   u32 cur = (c == 0) ? dataBegin : chunkExit[c - 1];
-  const u8* s_chunk = s_bytes + threadIdx.x * kLdsWalkStride + s_shift[threadIdx.x];
+  const u32* s_mine = reinterpret_cast<const u32*>(s_bytes + threadIdx.x * kLdsWalkStride);
+  const u32 shift = s_shift[threadIdx.x];
   u32 n = 0;
   bool ok = cur != kNone;
   while (ok && cur < chunkEnd)
   {
     BlkInfo b;
     // (a block in front of the chunk -- an entry there has never been seen -- is read where it lies)
-    const int rc = cur >= chunkStart ? parseBlock<TBYTES>(s_chunk, cur - chunkStart, blobEnd - chunkStart, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b)
+    const int rc = cur >= chunkStart ? parseBlockWords<TBYTES>(s_mine, cur - chunkStart + shift, blobEnd - chunkStart + shift, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b)
                                      : parseBlock<TBYTES>(blob, cur, blobEnd, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b);
     if (rc != 0) ok = false;
     else { n++; cur += b.len; }
@@ -775,7 +868,8 @@ __global__ void __launch_bounds__(256) k_walk_emit_lds(BandParams p, WalkPlan wp
   u32 cur = chunkEntry[c];
   u32 pos = chunkBase[c];
   const u32 posEnd = chunkBase[c + 1];
-  const u8* s_chunk = s_bytes + threadIdx.x * kLdsWalkStride + s_shift[threadIdx.x];
+  const u32* s_mine = reinterpret_cast<const u32*>(s_bytes + threadIdx.x * kLdsWalkStride);
+  const u32 shift = s_shift[threadIdx.x];
   // (the valid count of the NEXT block is asked for while this one is parsed: it is the one load left on the way)
   const bool table = wp.uniformN <= 0 && nValidBlk != nullptr;
   u32 nvNext = (table && pos / (u32)p.nDepth < nPos) ? (u32)nValidBlk[pos / (u32)p.nDepth] : 0u;
@@ -787,7 +881,7 @@ __global__ void __launch_bounds__(256) k_walk_emit_lds(BandParams p, WalkPlan wp
     if (table && blkNext < nPos) nvNext = (u32)nValidBlk[blkNext];
     BlkInfo b;
     // (a block in front of the chunk -- an entry there has never been seen -- is read where it lies)
-    const int rc = cur >= chunkStart ? parseBlock<TBYTES>(s_chunk, cur - chunkStart, blobEnd - chunkStart, p, nValid, maxCount, b)
+    const int rc = cur >= chunkStart ? parseBlockWords<TBYTES>(s_mine, cur - chunkStart + shift, blobEnd - chunkStart + shift, p, nValid, maxCount, b)
                                      : parseBlock<TBYTES>(blob, cur, blobEnd, p, nValid, maxCount, b);
     if (rc != 0) { raiseError(st, kFailed, 0x80000000u | c); break; }
     if (pos < wp.nSub) blockOff[pos] = cur;
@@ -811,7 +905,7 @@ __global__ void __launch_bounds__(256) k_walk_sweep(BandParams p, WalkPlan wp, c
 {
   __shared__ u32 s_from[256], s_cnt[256], s_exit[256];
   __shared__ u32 s_cur, s_pos, s_todo, s_bad, s_run[4], s_wsum[4];
-  __shared__ u8 s_chunk[kSweepChunkMax + kSweepWindowMax];
+  __shared__ __align__(16) u8 s_chunk[kSweepChunkMax + kSweepWindowMax + 16];
   __shared__ u16 s_nv[kSweepChunkMax];
   const u32 maxCount = (u32)p.mb * (u32)p.mb;
   const u32 nPos = (u32)p.nTV * (u32)p.nTH;
@@ -881,7 +975,7 @@ __global__ void __launch_bounds__(256) k_walk_sweep(BandParams p, WalkPlan wp, c
           const u32 blk = pos / (u32)p.nDepth;
           const int nValid = wp.uniformN > 0 ? wp.uniformN : ((nValidBlk && blk < nPos) ? (int)s_nv[blk - pos0] : -1);
           BlkInfo b;
-          if (blk >= nPos || parseBlock<TBYTES>(s_chunk, cur - chunkStart, stageEnd - chunkStart, p, nValid, maxCount, b) != 0) ok = false;
+          if (blk >= nPos || parseBlockWords<TBYTES>(reinterpret_cast<const u32*>(s_chunk), cur - chunkStart, stageEnd - chunkStart, p, nValid, maxCount, b) != 0) ok = false;
           else { pos++; cur += b.len; }
         }
         if (!ok) { raiseError(st, kFailed, 0x10000000u | todo); s_bad = 1; }
@@ -956,6 +1050,19 @@ static void launchWalkRestT(const BandParams& p, const WalkPlan& wp, const Decod
                        wb.chunkCount, wb.chunkEntry);
   hipLaunchKernelGGL(k_walk_sweep<TBYTES>, dim3(1), dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, (const u32*)wb.chunkExit,
                      (const u32*)wb.chunkCount, wb.chunkEntry, wb.nValidBlk, wb.chunkBase, st);
+#ifdef HIPSIM
+  if (getenv("LERC_DEBUG_WALK"))
+  {
+    hipStreamSynchronize(stream);
+    u32 noExit = 0, noCount = 0, mism = 0;
+    for (u32 c = 0; c < wp.nChunks; c++)
+    {
+      if (wb.chunkExit[c] == kNone) { noExit++; fprintf(stderr, "  no exit: chunk %u (bytes %u .. %u)\n", c, a.dataBegin + c * wp.chunkBytes, a.dataBegin + (c + 1) * wp.chunkBytes); }
+      if (wb.chunkCount[c] == kNone) noCount++;
+    }
+    fprintf(stderr, "walk debug: %u chunks, %u without agreed exit, %u without count\n", wp.nChunks, noExit, noCount);
+  }
+#endif
   if (lds)
     hipLaunchKernelGGL(k_walk_emit_lds<TBYTES>, gridL, dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, (const u32*)wb.chunkEntry,
                        (const u32*)wb.chunkBase, wb.nValidBlk, wb.blockOff, st);

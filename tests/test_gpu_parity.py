@@ -608,6 +608,27 @@ def test_device_mask_rle():
         assert rc == 0 and out[:size.value].cpu().numpy().tobytes() == want, (k, n, rc, size.value, len(want))
 
 
+def test_device_mask_rle_decode():
+    """the way back (rle_kernels.hip: hops by pointer doubling, a chain over the pieces, a wave per 256 bytes of stream) against
+    RLE::decompress said plainly: the cases of the emulator suite incl. the damaged streams, on device memory"""
+    import torch
+    import test_sim_kernels as tsk
+    from lerc_amd import api
+    dev = torch.device("cuda:0")
+    codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
+    L = codec.lib
+
+    def run(stream, n_out):
+        src = torch.zeros(len(stream) + 16, dtype=torch.uint8, device=dev)
+        src[:len(stream)] = torch.frombuffer(bytearray(stream), dtype=torch.uint8).to(dev)
+        out = torch.full((n_out + 64,), 0xA5, dtype=torch.uint8, device=dev)
+        rc = L.lerc_amd_mask_rle_decode_device(codec.h, src.data_ptr(), len(stream), out.data_ptr(), n_out)
+        got = out.cpu().numpy()
+        assert (got[n_out:] == 0xA5).all()
+        return rc, got[:n_out].tobytes()
+    tsk.check_device_rle_decode(L, codec.h, run)
+
+
 def test_small_blobs_decode_in_one_launch_every_time():
     """A blob of a few workgroups, decoded again and again: the launch's last workgroup is through microseconds after the
     first one has left the band's parameters for the host -- the verdict on the checksum must not be overtaken by them

@@ -520,6 +520,8 @@ for it in range(24):
     if m.all() or not m.any(): m[0, 0] ^= 1
     r1, b1 = O.encode(x, 0, mask=m); r2, b2 = S.encode(x, 0, mask=m)
     assert r1 == r2 == 0 and b1 == b2, (it, r, c, style)
+    d1, d2 = O.decode(b1), S.decode(b1)    # (the mask's way back: on the host, or -- with the knob -- rle_kernels.hip's decoder)
+    assert d1[0] == d2[0] == 0 and np.array_equal(d1[2], d2[2]) and np.array_equal(d1[1].reshape(r, c) * (d1[2].reshape(r, c) != 0), d2[1].reshape(r, c) * (d2[2].reshape(r, c) != 0)), (it, r, c, style)
 print("pieces ok")
 """ % (capi.ROOT,)
     for piece in ("16", "4096"):
@@ -607,6 +609,93 @@ def check_device_rle(L, h):
     src[:] = rng.integers(0, 256, 1000).astype(np.uint8)
     out = _aligned(100)
     assert L.lerc_amd_mask_rle_device(h, src.ctypes.data, 1000, out.ctypes.data, 100, ct.byref(ct.c_uint(0))) == 3    # BufferTooSmall
+
+
+def _rle_decode_restated(src, n_out):
+    """RLE::decompress (RLE.cpp:259-330) said plainly; None for a stream the reference refuses"""
+    out, at, left, i = bytearray(n_out), 0, len(src), 0
+    while True:
+        if left < 2:
+            return None
+        cnt = int.from_bytes(src[i:i + 2], "little", signed=True)
+        i += 2
+        left -= 2
+        if cnt == -32768:
+            return bytes(out)
+        n = abs(cnt)
+        payload = n if cnt > 0 else 1
+        if left < payload + 2 or at + n > n_out:
+            return None
+        out[at:at + n] = src[i:i + n] if cnt > 0 else bytes([src[i]]) * n
+        at += n
+        i += payload
+        left -= payload
+
+
+def check_device_rle_decode(L, h, run=None):
+    """run(stream, n_out) -> (status, n_out decoded bytes); default: the emulator's, on host memory"""
+    import ctypes as ct
+    L.lerc_amd_mask_rle_decode_device.restype = ct.c_uint
+    L.lerc_amd_mask_rle_decode_device.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_void_p, ct.c_uint]
+    rng = np.random.default_rng(10)
+
+    def run_host(stream, n_out):
+        src = _aligned(len(stream) + 16)
+        src[:len(stream)] = np.frombuffer(stream, np.uint8)
+        out = _aligned(n_out + 64)
+        out[:] = 0xA5
+        rc = L.lerc_amd_mask_rle_decode_device(h, src.ctypes.data, len(stream), out.ctypes.data, n_out)
+        assert (out[n_out:] == 0xA5).all()
+        return rc, out[:n_out].tobytes()
+    run = run or run_host
+
+    cases_ = rle_cases(rng)
+    # masks as rasters make them: rectangles of invalid pixels (several pieces and sub-pieces of stream), and one stream of many MB
+    i = np.arange(1200).reshape(-1, 1)
+    j = np.arange(4096).reshape(1, -1)
+    cases_.append(np.packbits((((i // 97) + (j // 131)) % 10 != 0).astype(np.uint8)))
+    cases_.append(np.packbits((rng.random(300000) > 0.03).astype(np.uint8)))
+    for k, b in enumerate(cases_):
+        stream = _rle_restated(bytes(b))
+        rc, got = run(stream, len(b))
+        assert rc == 0 and got == bytes(b), (k, len(b), rc)
+        if len(b) > 8:    # a stream that holds less than the mask: the rest stays zero
+            rc, got = run(stream, len(b) + 37)
+            assert rc == 0 and got == bytes(b) + bytes(37), (k, len(b), rc)
+            rc, _ = run(stream, len(b) - 1)                      # ... and more: refused
+            assert rc == 1, (k, rc)
+    # damaged streams: the verdict is the restated decoder's (no end marker, a segment that runs over the end, garbage)
+    for k in range(60):
+        b = cases_[(7 * k) % len(cases_)]
+        stream = bytearray(_rle_restated(bytes(b)))
+        if k % 3 == 0:
+            stream = stream[:max(2, len(stream) - 1 - int(rng.integers(0, min(40, len(stream) - 1))))]
+        elif k % 3 == 1:
+            stream[int(rng.integers(0, len(stream)))] ^= 1 << int(rng.integers(0, 8))
+        else:
+            stream = bytearray(rng.integers(0, 256, int(rng.integers(2, 3000))).astype(np.uint8).tobytes())
+        want = _rle_decode_restated(bytes(stream), len(b))
+        rc, got = run(bytes(stream), len(b))
+        assert (rc == 0) == (want is not None), (k, rc, want is None)
+        if want is not None:
+            assert got == want, k
+
+
+def test_sim_device_mask_rle_decode(libs):
+    """lerc_amd_mask_rle_decode_device: the way back (rle_kernels.hip: hops by pointer doubling, a chain over 8 KiB pieces, a wave
+    per 256 bytes of stream) against RLE::decompress said plainly, incl. damaged streams."""
+    import ctypes as ct
+    O, S = libs
+    L = S.lib
+    L.lerc_amd_create.restype = ct.c_void_p
+    L.lerc_amd_create.argtypes = [ct.c_void_p]
+    L.lerc_amd_destroy.argtypes = [ct.c_void_p]
+    h = L.lerc_amd_create(None)
+    assert h
+    try:
+        check_device_rle_decode(L, h)
+    finally:
+        L.lerc_amd_destroy(h)
 
 
 def test_sim_device_mask_rle(libs):
