@@ -65,6 +65,8 @@ public:
   hipEvent_t auxEvent();
   // a stream beside the active one for that copy (it branches off behind what is enqueued so far: forkSide()); nullptr: none to be had
   hipStream_t forkSide();
+  // more work has gone onto that stream since the last sync(): the next sync() / reset() waits for it again
+  void sideInUse() { if (m_sideStream) m_sideUsed = true; }
   bool sync();                               // wait for the active stream (polls first: see codec_common.cpp)
   // Device memory that keeps its contents from call to call (the two-launch encoder's arrival counters and cells,
   // tile_fast.h): zero when handed out for the first time and whenever it had to grow.  Two areas: [0] counters, which the

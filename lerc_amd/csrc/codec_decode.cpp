@@ -309,6 +309,11 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     maxChunks = std::max(maxChunks, (size_t)h.blobSize / 4096 + 2);
   }
   need += maxSub * 4 + maxSub / nD * 2 + 5 * (maxChunks + 1024) * 4 + (dt <= DT_Byte ? huffmanScratchBytes(nPix, nD) : 0);
+  {
+    size_t cand = 0;    // (k_rank_chunks' table: a word per candidate -- one raw block + 1 of them, 1100 at most, to a chunk of 4 KiB)
+    for (int i = 0; i < rq.nBands; i++) cand = std::max(cand, std::min<size_t>(1100, 2 + (size_t)bands[i].hd.mbSize * bands[i].hd.mbSize * tb));
+    need += (maxChunks + 2) * cand * 4;
+  }
   need += fastBandWorkspace(nRows, nCols, rq.blobSize) + 4096;    // streaming path tables
   for (int i = 0; i < rq.nBands; i++)
     if (bands[i].hd.tryHuffmanFlt()) { need += fplDecodeScratchBytes(nPix * nD, tb); break; }
@@ -347,6 +352,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
   std::vector<std::vector<u8> > keepBits;
   bool auxInFlight = false;    // the pinned mask area is the source of a copy that may not have run yet
   bool maskPending = false;    // a band's mask bytes are fetched (maskRle) but not decoded / sent yet: finishMask()
+  hipStream_t maskSide = nullptr;    // the mask is being decoded on the device beside the call's stream: finishMask() joins the two
   std::vector<u8> maskRle;
   std::vector<std::vector<double> > keepZMax;
   struct Drain { Context& c; ~Drain() { c.sync(); } } drain{ ctx };    // (destroyed before the buffers above, on every way out)
@@ -423,7 +429,10 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
         maskRle.resize(extra);    // (read first: the copy waits for what the stream holds)
         if (extra && !rd.read(at + (u64)bd.numBytesMask, extra, maskRle.data())) return kFailed;
         rd.cache = maskRle.data(); rd.cacheOff = at + (u64)bd.numBytesMask; rd.cacheLen = maskRle.size();
-        { ProfScope ps(ctx, "mask_rle_decode"); launchMaskRleDecode(dBand + (at - bd.offset), (u32)bd.numBytesMask, dBits, (u32)maskBytes, scratch, dStatus, st); }
+        // (beside the stream: half a dozen small launches and a chain of dependent loads that keep no CU busy, while the
+        // stream goes on with the chunk tables, which need no mask)
+        maskSide = ctx.auxEvent() ? ctx.forkSide() : nullptr;
+        { ProfScope ps(ctx, "mask_rle_decode"); launchMaskRleDecode(dBand + (at - bd.offset), (u32)bd.numBytesMask, dBits, (u32)maskBytes, scratch, dStatus, maskSide ? maskSide : st); }
         haveMask = true; maskAllValid = false;
       }
       else
@@ -439,7 +448,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     at += (u64)bd.numBytesMask;
     const u8* dMask = maskAllValid ? nullptr : dBits;
     bool wantMaskBytes = iBand < rq.nMasks && rq.dValidBytes;
-    auto finishMask = [&]() -> bool
+    auto finishMask = [&](bool joinSide = true) -> bool
     {
       if (maskPending)
       {
@@ -461,7 +470,13 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
         hipMemcpyAsync(dBits, hostBits, maskBytes, hipMemcpyHostToDevice, st);
         if (pinnedBits) { hipEventRecord(ctx.auxEvent(), st); auxInFlight = true; }
       }
-      if (wantMaskBytes) { wantMaskBytes = false; launchBitsToBytes(dMask, rq.dValidBytes + (size_t)iBand * nPix, nPix, st); }
+      if (maskSide) ctx.sideInUse();
+      if (wantMaskBytes) { wantMaskBytes = false; launchBitsToBytes(dMask, rq.dValidBytes + (size_t)iBand * nPix, nPix, maskSide ? maskSide : st); }
+      if (maskSide && joinSide)
+      {
+        if (hipEventRecord(ctx.auxEvent(), maskSide) != hipSuccess || hipStreamWaitEvent(st, ctx.auxEvent(), 0) != hipSuccess) return false;
+        maskSide = nullptr;
+      }
       return true;
     };
 
@@ -606,6 +621,8 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     wb.chunkBase = ctx.allocT<u32>(wp.nChunks + 8);
     wb.blockOff = ctx.allocT<u32>((size_t)wp.nSub + 4);
     wb.scratch = ctx.allocT<u32>(wp.nChunks / 1024 + 8);
+    wb.candTab = wp.tabled ? ctx.allocT<u32>((size_t)wp.nChunks * wp.candWindow + 4) : nullptr;
+    if (wp.tabled && !wb.candTab) return kFailed;
     u16* nValidBlk = nullptr;
     if (wp.uniformN == 0)
     {
@@ -616,8 +633,9 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     if (!wb.chunkExit || !wb.chunkEntry || !wb.chunkCount || !wb.chunkBase || !wb.blockOff || !wb.scratch) return kFailed;
     // the chunk candidates need no mask: they run while the host decodes the mask's RLE and sends the bits
     { ProfScope ps(ctx, "walk_chunks"); launchWalkChunks(bp, wp, da, wb, st); }
-    if (!finishMask()) return kFailed;
-    if (nValidBlk) launchBlockValidCounts(dMask, bp, nValidBlk, st);
+    if (!finishMask(false)) return kFailed;
+    if (nValidBlk) launchBlockValidCounts(dMask, bp, nValidBlk, maskSide ? maskSide : st);
+    if (!finishMask()) return kFailed;    // (joins the side stream, if the mask went that way)
     { ProfScope ps(ctx, "walk_offsets"); launchWalkRest(bp, wp, da, wb, dStatus, st); }
     da.blockOff = wb.blockOff;
     da.nValidBlk = nValidBlk;

@@ -36,6 +36,8 @@ struct WalkPlan
   u32 nChunks;
   u32 nSub;              // number of sub-blocks = nTV * nTH * nDepth
   int uniformN;          // > 0: every block has exactly this many valid pixels; 0: varies (mask / edges)
+  u32 candWindow;        // a chunk's candidates: every byte of its first candWindow (one raw block + 1)
+  u32 tabled;            // 1: chunks small enough for the kernel that ranks every position (candTab is filled)
 };
 struct WalkBuffers
 {
@@ -46,6 +48,7 @@ struct WalkBuffers
   u32* blockOff;         // [nSub]
   const u16* nValidBlk;  // [nTV*nTH]   valid pixels per block position (nullptr when uniformN > 0)
   u32* scratch;          // scan scratch, >= nChunks/1024 + 2 words
+  u32* candTab;          // [nChunks * candWindow] per candidate: where it leaves the chunk (relative, 16 bits) | blocks on the way << 16; 0 = not a block start
 };
 // ---- legacy Lerc1 z part (lerc1_kernels.hip)
 struct Lerc1Geom

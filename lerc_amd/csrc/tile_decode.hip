@@ -16,6 +16,7 @@
 // 2. Decode: one wave64 per micro-block position, lane = element (rank by __ballot / __popcll for
 //    masked blocks), bit extraction straight from the blob, dequantise in double precision in the
 //    reference's expression order (compile with -ffp-contract=off), clamp, cast, store.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include "kernels.h"
@@ -148,6 +149,61 @@ __device__ __forceinline__ int parseWindow(const Win16& h, u32 pos, u32 end, con
   if ((u64)pos + len > end) return 1;
   b.len = (u32)len;
   return 0;
+}
+
+// What a walk needs of parseWindow -- the block's length, or that there is none -- without a branch: every lane of a wave looks
+// at another position, so every branch of the parse is taken by some lane, and the bookkeeping of who is in which costs more
+// than the arithmetic (k_rank_chunks parses every position of the stream: 480 instructions a position that way, R this way).
+// offPack: bytes of the offset for type code tc and difference flag d, 4 bits at (tc * 2 + d) * 4, 0 = no such type
+// (typeUsed, Lerc2.h:528-542), see offsetBytesPack.  Returns the length, 0 = no block, kLenRawUnknown = a raw block whose
+// valid count the caller does not know (nValid < 0).
+static const u32 kLenRawUnknown = 0xFFFFFFFFu;
+
+__device__ __forceinline__ u32 offsetBytesPack(const BandParams& p)
+{
+  u32 pack = 0;
+  for (int tc = 0; tc < 4; tc++)
+    for (int d = 0; d < 2; d++)
+    {
+      const int dtU = typeUsed((d && p.dt < DT_Float) ? (int)DT_Int : p.dt, tc);
+      const u32 n = (dtU == DT_Undefined) ? 0u : (u32)dtSize(dtU);
+      pack |= (n > 8u ? 0u : n) << ((tc * 2 + d) * 4);    // (8 fits 4 bits)
+    }
+  return pack;
+}
+
+template<int TBYTES>
+__device__ __forceinline__ u32 blockLength(const Win16& h, u32 pos, u32 end, const BandParams& p, u32 offPack, int nValid, u32 maxCount)
+{
+  const u32 flag = (u32)h.lo & 255u;
+  const u32 mode = flag & 3u, tc = flag >> 6;
+  const u32 diff = (p.version >= 5) ? ((flag >> 2) & 1u) : 0u;
+  const u32 offB = (offPack >> ((tc * 2u + diff) * 4u)) & 15u;
+  // the bit stuffer's header behind the offset: first byte, count (1, 2 or 4 bytes), LUT size -- bytes at + 0 ... at + 5
+  const u32 at = 1u + offB;                         // <= 9
+  const u32 sh = 8u * at;
+  const u64 six = sh < 64u ? ((h.lo >> sh) | ((h.hi << 1) << (63u - sh))) : h.hi >> (sh - 64u);    // (sh >= 8)
+  const u32 b0 = (u32)six & 255u;
+  const u32 code = b0 >> 6;
+  const u32 cb = (code == 0u) ? 4u : 3u - code;     // 0: no such code
+  const u32 nb = b0 & 31u, lut = (b0 >> 5) & 1u;
+  const u32 cnt = (u32)(six >> 8) & (cb == 4u ? 0xFFFFFFFFu : ((1u << (8u * cb)) - 1u));
+  const u32 hdr = at + 1u + cb;
+  const u32 nLut = ((u32)(six >> (8u * (1u + cb))) & 255u) - 1u;    // (the byte behind the count; 0xFFFFFFFF for a zero byte)
+  const u32 nbIdx = (u32)bitLen(nLut & 255u);
+  const u32 plain = hdr + ((cnt * nb + 7u) >> 3);
+  const u32 withLut = hdr + 1u + (((nLut & 255u) * nb + 7u) >> 3) + ((cnt * nbIdx + 7u) >> 3);
+  const bool okStuffed = (offB != 0u) & (cb != 0u) & (cnt != 0u) & (cnt <= maxCount) & (nb != 0u) & ((nValid < 0) | (cnt == (u32)nValid))
+                       & ((lut == 0u) | ((nLut >= 1u) & (nLut < 255u)));
+  u32 len = lut ? withLut : plain;
+  len = okStuffed ? len : 0u;
+  len = (mode == 3u) ? (offB ? 1u + offB : 0u) : len;
+  len = (mode == 2u) ? 1u : len;
+  const u32 raw = diff ? 0u : (nValid < 0 ? kLenRawUnknown : 1u + (u32)nValid * (u32)TBYTES);
+  len = (mode == 0u) ? raw : len;
+  if (diff && p.nDepth == 1) len = 0u;
+  if (len != kLenRawUnknown && ((u64)pos + len > end || pos >= end)) len = 0u;
+  return len;
 }
 
 template<int TBYTES>
@@ -540,6 +596,8 @@ WalkPlan makeWalkPlan(const BandParams& p, u32 dataBegin, u32 blobEnd, int numVa
   wp.nSub = (u32)p.nTV * (u32)p.nTH * (u32)p.nDepth;
   const bool uniform = (numValid == p.nRows * p.nCols) && (p.nRows % p.mb == 0) && (p.nCols % p.mb == 0);
   wp.uniformN = uniform ? (int)n : 0;
+  wp.candWindow = std::min(wp.window, 2u + n * tb);
+  wp.tabled = (wp.chunkBytes <= 4096u && wp.window <= 1100u) ? 1u : 0u;    // (kMemoChunk, kMemoWindowMax below)
   return wp;
 }
 
@@ -612,40 +670,31 @@ __global__ void __launch_bounds__(64) k_walk_chunks(BandParams p, WalkPlan wp, c
   if (lane == 0) chunkExit[c] = (!conflict && agreed != kNone && agreed != kUnknown) ? agreed : kNone;
 }
 
-// D1 for chunks of 4 KiB (every 8 x 8 raster, 16 x 16 up to 32-bit types): the same agreement, but the chunk is staged in
-// LDS and every position is parsed at most once -- s_next[] remembers length and signature of the block that starts
-// there, so the few hundred candidates, which fall onto a handful of common paths within a step or two, follow those
-// paths by table look-up instead of parsing every block each.
-//
-// A walk is a chain of dependent steps, one per block, and the kernel's time is the length of that chain.  So the chunk is
-// cut into up to four sub-chunks and each wave walks the candidates of one of them (every byte of the first window of
-// its sub-chunk) to that sub-chunk's end only, leaving in s_exitOf[] where a walk through a block start leaves the
-// SUB-chunk.  Where a walk lands in the next sub-chunk is one of that one's candidates, whatever it is, so afterwards a
-// candidate of the chunk's first window gets to the chunk's end in at most four look-ups -- having survived exactly the
-// blocks it would have had to survive walking there (8192^2 with a 10 % mask: 0.98 -> R ms).
+// D1 for chunks of 4 KiB (every 8 x 8 raster, 16 x 16 up to 32-bit types), without a walk.  A walk is a chain of dependent
+// steps, one per block, a few hundred to a chunk, and all a workgroup's other lanes do is wait for it.  Instead: EVERY
+// position of the chunk is parsed as if a block started there (one look at 16 bytes of LDS; most positions fail), which
+// gives every position its successor, and pointer doubling turns successors into "where the stream leaves the chunk
+// coming through here, and how many blocks that takes" in log2(blocks) rounds over all positions at once.  What the walks
+// agreed on falls out of the table -- the candidates of the first window that leave the chunk have to name one exit --, and
+// so does what D2 walked for: the number of blocks on the way from the chunk's entry, which is one of those candidates.
+// Per candidate the table goes to candTab (8192^2 float with a 10 % mask: walks 0.98 ms, four sub-chunk walks joined by
+// look-ups 0.55 ms, this R ms, and D2's 0.09 ms become a look-up).
 static const u32 kMemoChunk = 4096, kMemoWindowMax = 1100;
 
 template<int TBYTES>
-__global__ void __launch_bounds__(256) k_walk_chunks_memo(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin,
-                                                         u32 blobEnd, u32* __restrict__ chunkExit)
+__global__ void __launch_bounds__(256) k_rank_chunks(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin,
+                                                    u32 blobEnd, u32* __restrict__ chunkExit, u32* __restrict__ candTab)
 {
   __shared__ __align__(16) u8 s_bytes[kMemoChunk + kMemoWindowMax + 48];
-  // 16-bit tables (21 KB with the bytes: seven workgroups per CU)
-  __shared__ __align__(16) u16 s_next[kMemoChunk];    // 0 = not parsed yet; kNoBlock; else len (< 4094) | sig << 12
-  __shared__ __align__(16) u16 s_exitOf[kMemoChunk];  // 0 = unknown; else 1 + (where a walk through this block start leaves its sub-chunk - chunkStart)
-  __shared__ u32 s_agreed[4], s_conflict[4];
-  const u32 kNoBlock = 0xFFFFu;
+  __shared__ u32 s_nc[kMemoChunk];    // successor relative to the chunk's start (16 bits; >= the chunk's length: outside; kDead) | blocks from here to there << 16
+  __shared__ u32 s_changed, s_lo, s_hi;
+  constexpr u32 E = kMemoChunk / 256u;
+  const u32 kDead = 0xFFFFu;
   const u32 c = blockIdx.x;
-  const int lane = laneId(), wv = waveId();
   const u32 chunkStart = dataBegin + c * wp.chunkBytes;
   const u32 chunkEnd = min(chunkStart + wp.chunkBytes, blobEnd);
+  const u32 len = chunkEnd - chunkStart;
   const u32 stageEnd = min(chunkEnd + wp.window, blobEnd);
-  // candidates: every byte up to one raw block + 1 behind the (sub-)chunk's start.  Encoders never write a longer block (they
-  // fall back to raw); should a blob hold one, the exits agreed on here may be wrong or missing, which D3 notices (it only
-  // takes over walks that started where it arrives) and pays for with its own walk.
-  const u32 candWindow = min(wp.window, 2u + (u32)p.mb * (u32)p.mb * (u32)TBYTES);
-  const u32 subs = (wp.chunkBytes >= 12u * candWindow) ? 4u : (wp.chunkBytes >= 6u * candWindow) ? 2u : 1u;    // (a sub-chunk: three windows at least)
-  const u32 subBytes = wp.chunkBytes / subs;          // (a power of two)
   const u32 pattern = (p.version >= 5) ? 14u : 15u;
   const u32 maxCount = (u32)p.mb * (u32)p.mb;
   // stage with 16-byte loads from the aligned-down start (never past the blob's end); LDS byte i + shift <-> blob byte chunkStart + i
@@ -658,108 +707,101 @@ __global__ void __launch_bounds__(256) k_walk_chunks_memo(BandParams p, WalkPlan
     else for (u32 k2 = 0; k2 < 16u && g + k2 < blobEnd; k2++) (&x.x)[k2 >> 2] |= (u32)blob[g + k2] << (8u * (k2 & 3u));
     *reinterpret_cast<uint4*>(&s_bytes[16u * v]) = x;
   }
-  for (u32 i = threadIdx.x; i < kMemoChunk / 8u; i += 256u)
-  {
-    reinterpret_cast<uint4*>(s_next)[i] = make_uint4(0, 0, 0, 0);
-    reinterpret_cast<uint4*>(s_exitOf)[i] = make_uint4(0, 0, 0, 0);
-  }
+  if (threadIdx.x == 0) { s_lo = kNone; s_hi = 0u; }
   __syncthreads();
+  const u32* s_words = reinterpret_cast<const u32*>(s_bytes);
+  const u32 endRel = stageEnd - chunkStart;    // (what is staged of the stream, as seen from the chunk's start)
 
-  // ---- the walks: wave wv takes sub-chunk wv % subs, and of its rounds of 64 candidates every (4 / subs)-th
+  // ---- every position's block, if it is one.  A raw block of a masked / ragged band (rc 2) has the length of its valid
+  // pixel count, which takes the block index: no successor (the sweep, D3, walks such a chunk with the index in hand).
+  // The column signature has to go on from block to block (sigFollows); checked on the links inside the chunk.
+  u32 nc[E];    // (a thread's own positions stay in registers; LDS holds what the others look up)
+  const u32 offPack = offsetBytesPack(p);
+#pragma unroll
+  for (u32 q = 0; q < E; q++)
   {
-    const u32 k = (u32)wv % subs;
-    const u32 subStart = chunkStart + k * subBytes;
-    const u32 subEnd = min(subStart + subBytes, chunkEnd);
-    const u32 winEnd = (subStart >= chunkEnd) ? subStart : (c == 0 && k == 0) ? subStart + 1 : min(subStart + candWindow, subEnd);    // (the stream's first block starts at dataBegin)
-    for (u32 r0 = subStart + 64u * ((u32)wv / subs); r0 < winEnd; r0 += 64u * (4u / subs))
+    const u32 r = q * 256u + threadIdx.x;
+    u32 nx = kDead;
+    if (r < len)
     {
-      u32 cur = r0 + (u32)lane;
-      bool alive = cur < winEnd;
-      u32 prevSig = kNone;
-      while (__any(alive && cur < subEnd))
+      const Win16 h = loadWin16Words(s_words, r + shift, endRel + shift);
+      const u32 bl = blockLength<TBYTES>(h, r + shift, endRel + shift, p, offPack, wp.uniformN > 0 ? wp.uniformN : -1, maxCount);
+#ifdef HIPSIM
       {
-        if (alive && cur < subEnd)
-        {
-          const u32 rel = cur - chunkStart;
-          u32 e = s_next[rel];
-          if (e == 0u)
-          {
-            BlkInfo b;
-            const int rc = parseBlockWords<TBYTES>(reinterpret_cast<const u32*>(s_bytes), rel + shift, stageEnd - chunkStart + shift, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b);
-            // a raw block of a masked / ragged band (rc 2): its length is the block's valid pixel count, which takes the
-            // block index -- the candidate drops out (see k_walk_chunks)
-            if (rc != 0 || b.len >= 4094u) e = kNoBlock;    // (no block of a chunk this size is that long; 0xFFFF is taken)
-            else e = b.len | ((((u32)b.flag >> 2) & pattern) << 12);
-            s_next[rel] = (u16)e;    // (lanes that race here store the same value)
-          }
-          if (e == kNoBlock) alive = false;
-          else
-          {
-            const u32 sig = e >> 12;
-            if (prevSig != kNone && !sigFollows(prevSig, sig, p.mb, pattern)) alive = false;
-            else
-            {
-              const u32 known = s_exitOf[rel];    // an earlier walk came through here and made it to the sub-chunk's end
-              prevSig = sig;
-              cur = known ? chunkStart + known - 1u : cur + (e & 0xFFFu);
-            }
-          }
-        }
+        BlkInfo b;
+        const int rc = parseWindow<TBYTES>(h, r + shift, endRel + shift, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b);
+        const u32 want = rc == 0 ? b.len : rc == 2 ? kLenRawUnknown : 0u;
+        if (want != bl) { fprintf(stderr, "blockLength %u != parseWindow %u (rc %d) at chunk %u + %u\n", bl, want, rc, c, r); abort(); }
       }
-      // walks that made it leave their exit at every block start they passed, so that later candidates can stop there
-      u32 at = r0 + (u32)lane;
-      bool go = alive && at < winEnd;
-      while (__any(go))
+#endif
+      if (bl != 0u && bl < 4094u)    // (no block of a chunk this size is that long; a raw block of unknown length: no successor)
       {
-        if (go)
-        {
-          const u32 rel = at - chunkStart;
-          if (at >= subEnd || s_exitOf[rel] != 0u) go = false;
-          else { s_exitOf[rel] = (u16)(cur - chunkStart + 1u); at += s_next[rel] & 0xFFFu; }
-        }
+        nx = r + bl;
+        if (nx < len && !sigFollows(((u32)h.lo >> 2) & pattern, ((u32)s_bytes[nx + shift] >> 2) & pattern, p.mb, pattern)) nx = kDead;
       }
-      waveSync();
     }
+    nc[q] = nx | (1u << 16);
+    s_nc[r] = nc[q];
   }
   __syncthreads();
+  // ---- doubling, synchronous rounds: a hop that ends inside the chunk is extended by the hop that starts where it ends.
+  // Most positions are no block start or end in one after a hop or two; they cost nothing from then on.
+  for (;;)
+  {
+    if (threadIdx.x == 0) s_changed = 0u;
+    u32 ch = 0u;
+#pragma unroll
+    for (u32 q = 0; q < E; q++)
+    {
+      const u32 nx = nc[q] & 0xFFFFu;
+      if (nx < len)
+      {
+        const u32 v = s_nc[nx];
+        nc[q] = (v & 0xFFFFu) | ((nc[q] & 0xFFFF0000u) + (v & 0xFFFF0000u));
+        ch |= 1u << q;
+      }
+    }
+    __syncthreads();
+    if (ch)
+    {
+      s_changed = 1u;
+#pragma unroll
+      for (u32 q = 0; q < E; q++) if ((ch >> q) & 1u) s_nc[q * 256u + threadIdx.x] = nc[q];
+    }
+    __syncthreads();
+    if (!s_changed) break;
+    __syncthreads();
+  }
+  // ---- the candidates: every byte up to one raw block + 1 behind the chunk's start (the stream's first block starts at
+  // dataBegin).  Encoders never write a longer block (they fall back to raw); should a blob hold one, the exits agreed on
+  // here may be wrong or missing, which D3 notices (it only takes over walks that started where it arrives) and pays for
+  // with its own walk.
+  const u32 nCand = (c == 0) ? 1u : min(wp.candWindow, len);
+  u32 lo = kNone, hi = 0u;
+  for (u32 r = threadIdx.x; r < wp.candWindow; r += 256u)
+  {
+    u32 e = 0u;
+    if (r < nCand && (s_nc[r] & 0xFFFFu) != kDead) { e = s_nc[r]; const u32 x = e & 0xFFFFu; lo = min(lo, x); hi = max(hi, x); }
+    candTab[(size_t)c * wp.candWindow + r] = e;    // (a block is a byte at least: x >= 1, e != 0)
+  }
+  lo = waveMin(lo); hi = waveMax(hi);
+  if (laneId() == 0 && lo != kNone) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+  __syncthreads();
+  if (threadIdx.x == 0) chunkExit[c] = (s_lo != kNone && s_lo == s_hi) ? chunkStart + s_lo : kNone;
+}
 
-  // ---- from the first window to the chunk's end, sub-chunk by sub-chunk; the candidates that get there have to agree
-  u32 agreed = kNone;
-  bool conflict = false;
-  {
-    const u32 winEnd = (c == 0) ? chunkStart + 1 : min(chunkStart + candWindow, min(chunkStart + subBytes, chunkEnd));
-    const u32 len = chunkEnd - chunkStart;
-    for (u32 r0 = chunkStart + 64u * (u32)wv; r0 < winEnd; r0 += 256u)
-    {
-      const u32 q = r0 + (u32)lane;
-      u32 e = (q < winEnd) ? (u32)s_exitOf[q - chunkStart] : 0u;
-      for (u32 k = 1; k < subs; k++)
-        if (e != 0u && e - 1u < len) e = s_exitOf[e - 1u];
-      const bool alive = e != 0u && e - 1u >= len;
-      const u32 ex = chunkStart + e - 1u;
-      const u32 lo = waveMin(alive ? ex : kNone);
-      const u32 hi = waveMax(alive ? ex : 0u);
-      if (lo != kNone)
-      {
-        if (lo != hi) conflict = true;
-        else if (agreed == kNone) agreed = lo;
-        else if (agreed != lo) conflict = true;
-      }
-    }
-  }
-  if (lane == 0) { s_agreed[wv] = agreed; s_conflict[wv] = conflict ? 1u : 0u; }
-  __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    for (int k = 1; k < 4; k++)
-    {
-      if (s_conflict[k]) conflict = true;
-      if (s_agreed[k] == kNone) continue;
-      if (agreed == kNone) agreed = s_agreed[k];
-      else if (agreed != s_agreed[k]) conflict = true;
-    }
-    chunkExit[c] = (!conflict && agreed != kNone) ? agreed : kNone;
-  }
+// D2 for chunks that k_rank_chunks has tabled: the entry is a candidate, its count and exit are in the table
+__global__ void __launch_bounds__(256) k_walk_counts_tab(WalkPlan wp, u32 dataBegin, const u32* __restrict__ chunkExit,
+                                                         const u32* __restrict__ candTab, u32* __restrict__ chunkCount, u32* __restrict__ exitOut)
+{
+  const u32 c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= wp.nChunks) return;
+  const u32 chunkStart = dataBegin + c * wp.chunkBytes;
+  const u32 cur = (c == 0) ? dataBegin : chunkExit[c - 1];
+  u32 e = 0u;
+  if (cur != kNone && cur >= chunkStart && cur - chunkStart < wp.candWindow) e = candTab[(size_t)c * wp.candWindow + (cur - chunkStart)];
+  chunkCount[c] = e ? (e >> 16) : kNone;
+  exitOut[c] = e ? chunkStart + (e & 0xFFFFu) : kNone;
 }
 
 // D2: one lane per chunk whose entry is known (= the agreed exit of its predecessor) walks it: number of sub-blocks
@@ -1028,8 +1070,8 @@ __global__ void __launch_bounds__(256) k_walk_emit(BandParams p, WalkPlan wp, co
 template<int TBYTES>
 static void launchWalkChunksT(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, hipStream_t stream)
 {
-  if (wp.chunkBytes <= kMemoChunk && wp.window <= kMemoWindowMax)
-    hipLaunchKernelGGL(k_walk_chunks_memo<TBYTES>, dim3(wp.nChunks), dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit);
+  if (wp.tabled && wb.candTab)
+    hipLaunchKernelGGL(k_rank_chunks<TBYTES>, dim3(wp.nChunks), dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit, wb.candTab);
   else
     hipLaunchKernelGGL(k_walk_chunks<TBYTES>, dim3(wp.nChunks), dim3(64), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit);
 }
@@ -1042,7 +1084,10 @@ static void launchWalkRestT(const BandParams& p, const WalkPlan& wp, const Decod
   // Small streams walk out of LDS (eight lanes per workgroup, 0.3 us a step instead of 2); large ones have tens of thousands
   // of lanes in flight to hide the round trips and are faster one lane per chunk (8192^2 with a 10 % mask, same box: 1.52 against 1.84 ms)
   const bool lds = wp.chunkBytes <= kMemoChunk && wp.window <= kMemoWindowMax && wp.nChunks <= 1024u;
-  if (lds)
+  if (wp.tabled && wb.candTab)
+    hipLaunchKernelGGL(k_walk_counts_tab, gridC, dim3(256), 0, stream, wp, a.dataBegin, (const u32*)wb.chunkExit, (const u32*)wb.candTab,
+                       wb.chunkCount, wb.chunkEntry);
+  else if (lds)
     hipLaunchKernelGGL(k_walk_counts_lds<TBYTES>, gridL, dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, (const u32*)wb.chunkExit,
                        wb.chunkCount, wb.chunkEntry);
   else
