@@ -262,14 +262,15 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   // ---- device scratch of this band
   DeviceStatus* dStatus = ctx.allocT<DeviceStatus>(1);
   BandStats* dStats = ctx.allocT<BandStats>(1);
+  BandStats* dStatsRow0 = ctx.allocT<BandStats>(1);    // (the first row's TryRaiseMaxZError errors, measured beside the mask's statistics)
   u64* dMins = ctx.allocT<u64>(nD);
   u64* dMaxs = ctx.allocT<u64>(nD);
   u8* dNewBits = ctx.allocT<u8>((size_t)((nPix + 7) >> 3) + 16);
-  if (!dStatus || !dStats || !dMins || !dMaxs || !dNewBits) return kFailed;
+  if (!dStatus || !dStats || !dStatsRow0 || !dMins || !dMaxs || !dNewBits) return kFailed;
   hipMemsetAsync(dStatus, 0, sizeof(DeviceStatus), st);
   hipMemsetAsync(dStats, 0, sizeof(BandStats), st);
 
-  struct HostRes { BandStats stats; DeviceStatus status; };
+  struct HostRes { BandStats stats; BandStats row0; DeviceStatus status; };
   std::vector<u64> hMins(nD), hMaxs(nD);
   HostRes hr;
 
@@ -338,11 +339,30 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     catch (...) { rleFuture = std::future<std::vector<u8> >(); }    // no thread to be had: codeMask() codes the mask in line
     return true;
   };
+  // TryRaiseMaxZError's candidates whose error bound beats the request (Lerc2.cpp:1244-1253) are pruned on the raster's first
+  // row; where a mask is made first, that row is measured in the same wait (every wait costs the stream ~50 us of idling)
+  static const double errCand[9] = { 1, 0.5, 0.1, 0.05, 0.01, 0.005, 0.001, 0.0005, 0.0001 };
+  static const int facCand[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
+  u32 candAll = 0;
+  if (isFlt && rq.maxZErr > 0)
+    for (int c = 0; c < 9; c++) if (errCand[c] / 2 > rq.maxZErr) candAll |= 1u << c;
+  bool row0Measured = false;
   auto buildMask = [&]() -> bool
   {
     hipMemsetAsync(dStats, 0, sizeof(BandStats), st);
     { ProfScope ps(ctx, "build_mask"); launchBuildMask(dt, dData, dByteMask, nRows, nCols, nD, dNewBits, dStats, st); }
     hipMemcpyAsync(&hr.stats, dStats, sizeof(BandStats), hipMemcpyDeviceToHost, st);
+    row0Measured = false;
+    if (candAll)
+    {
+      for (int m = 0; m < nD; m++) { hMins[m] = statKeyInitMin(); hMaxs[m] = statKeyInitMax(); }
+      hipMemcpyAsync(dMins, hMins.data(), nD * 8, hipMemcpyHostToDevice, st);
+      hipMemcpyAsync(dMaxs, hMaxs.data(), nD * 8, hipMemcpyHostToDevice, st);
+      hipMemsetAsync(dStatsRow0, 0, sizeof(BandStats), st);
+      { ProfScope ps(ctx, "band_stats_row0"); launchBandStats(dt, dData, dNewBits, 1, nCols, nD, candAll, dMins, dMaxs, dStatsRow0, st); }    // (with the bits just made: all ones if nothing is invalid)
+      hipMemcpyAsync(&hr.row0, dStatsRow0, sizeof(BandStats), hipMemcpyDeviceToHost, st);
+      row0Measured = true;
+    }
     if (!sync.wait()) return false;
     bandNumValid = (int)hr.stats.numValid;
     bandAllValid = (bandNumValid == (int)nPix);
@@ -357,8 +377,6 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   // ---- 2. statistics: per-depth min / max; float: NaN, all-integer, TryRaiseMaxZError candidates
   double maxZErr = rq.maxZErr;
   u32 raiseMask = 0;
-  static const double errCand[9] = { 1, 0.5, 0.1, 0.05, 0.01, 0.005, 0.001, 0.0005, 0.0001 };
-  static const int facCand[9] = { 1, 2, 10, 20, 100, 200, 1000, 2000, 10000 };
   // 8-bit values without a mask, lossless: what the choice between tiling and Huffman coding is made from -- the sizes
   // of the 8 x 8 blocks and the two histograms -- depends on nothing the statistics decide, so both are enqueued right
   // behind the statistics kernel and arrive with the same wait (every wait costs the stream ~50 us of idling)
@@ -412,13 +430,16 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   {
     // candidates whose error bound beats the request (Lerc2.cpp:1244-1253), pruned on the first row the
     // way the reference prunes after every row (:1277); survivors are then measured over the whole band
-    u32 cand = 0;
-    for (int c = 0; c < 9; c++) if (errCand[c] / 2 > maxZErr) cand |= 1u << c;
+    u32 cand = candAll;
     if (cand)
     {
-      if (!runStats(1, cand)) return kFailed;
+      if (!row0Measured)
+      {
+        if (!runStats(1, cand)) return kFailed;
+        hr.row0 = hr.stats;
+      }
       for (int c = 0; c < 9; c++)
-        if (((cand >> c) & 1u) && hr.stats.raiseErr[c] / facCand[c] > maxZErr / 2) cand &= ~(1u << c);
+        if (((cand >> c) & 1u) && hr.row0.raiseErr[c] / facCand[c] > maxZErr / 2) cand &= ~(1u << c);
       raiseMask = cand;
     }
   }
@@ -639,7 +660,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   // ends up coded another way (16 x 16 blocks, one sweep) that writer comes later in the stream and overwrites it.
   // dStreamed: that stream is in place; a launch that gave up waiting (never seen) leaves the band to the three kernels.
   u8* dStreamed = nullptr;
-  u32 nBytesStreamed = 0;
+  u32 nBytesStreamed = 0, streamSums = 0;    // (streamSums: the stream's Fletcher terms, which the kernel collects as it writes)
   bool streamedTried = false;
   auto streamMasked = [&]() -> bool    // false: an error (not: "not applicable")
   {
@@ -686,6 +707,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     if (!sync.wait()) return false;
     TL("streamMasked: kernel done");
     if (hRes->stuck) { ctx.wipePersistentState(); return true; }    // (the three kernels take the band)
+    streamSums = hRes->streamSums;
     nBytesStreamed = hRes->nBytesTiling;    // (a stream that does not fit the buffer was cut off inside it; the size check below says BufferTooSmall)
     dStreamed = dWs ? dWs + payloadAt : reinterpret_cast<u8*>(dRes);    // (size query: only != nullptr counts)
     ctx.lastNote = "masked band: block stream by the one-launch encoder";
@@ -869,6 +891,14 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   u64* dFl = ctx.allocT<u64>(kFletcherPartials);
   if (!dFl) return kFailed;
   // (the sums are folded and the header field is written on the device: one wait at the end of the band instead of two)
+  if (payload == P_TILING && dStreamed && hd.mbSize == 8 && dStreamed == dPayload && (size_t)(dPayload - dBandOut) + nBytesStreamed == blobSize)
+  {
+    // the masked band's block stream came with its terms (tile_fast.hip: fusedFlush); what is left to read is what lies in front of it
+    ProfScope ps(ctx, "fletcher_enc");
+    launchFletcher(dBandOut + 14, (u32)(dPayload - dBandOut) - 14, dFl, st);
+    launchFletcherPatchWith(dFl, streamSums, blobSize - 14, dBandOut + 10, st);
+  }
+  else
   { ProfScope ps(ctx, "fletcher_enc"); launchFletcher(dBandOut + 14, blobSize - 14, dFl, st); launchFletcherPatch(dFl, blobSize - 14, dBandOut + 10, st); }
   hipMemcpyAsync(&hr.status, dStatus, sizeof(DeviceStatus), hipMemcpyDeviceToHost, st);
   if (!sync.wait()) return kFailed;

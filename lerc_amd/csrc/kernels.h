@@ -83,6 +83,7 @@ void launchExclusiveScan(const u32* in, u32* out, u32 n, u32* scratch, hipStream
 // closed form in DESIGN.md).  acc must be zeroed by the caller.
 void launchFletcher(const u8* bytes, u32 len, u64* partials /* kFletcherPartials words */, hipStream_t stream);
 void launchFletcherPatch(const u64* partials, u32 len, u8* dst /* 4 bytes, little endian */, hipStream_t stream);
+void launchFletcherPatchWith(const u64* partials, u32 sums, u32 len, u8* dst, hipStream_t stream);    // partials: the front part; sums: the rest's terms
 u32 fletcherFinish(u64 sumWords, u64 sumWeighted, u32 len);
 
 // byte mask (1 = valid) [+ NaN test on float data] -> bit mask, numValid; nValidBlk per block position

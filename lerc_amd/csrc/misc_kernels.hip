@@ -147,12 +147,13 @@ void launchFletcher(const u8* blob, u32 len, u64* acc, hipStream_t stream)
 
 // folds launchFletcher's partials and writes the finished checksum (four bytes, any alignment) -- so that an encoder need
 // not bring the sums to the host and send the header field back
-__global__ void __launch_bounds__(64) k_fletcher_patch(const u64* __restrict__ partials, u32 len, u8* __restrict__ dst)
+__global__ void __launch_bounds__(64) k_fletcher_patch(const u64* __restrict__ partials, u32 len, u8* __restrict__ dst, u32 moreA, u32 moreB)
 {
   u64 A = 0, B = 0;
   for (int i = laneId(); i < kFletcherPartials / 2; i += 64) { A += partials[2 * i]; B += partials[2 * i + 1]; }
   A = waveSum(A); B = waveSum(B);
   if (laneId() != 0) return;
+  A += moreA; B += moreB;
   const u64 N = ((u64)len + 1) / 2;
   A %= 65535u; B %= 65535u;
   u64 s1 = A;
@@ -165,7 +166,14 @@ __global__ void __launch_bounds__(64) k_fletcher_patch(const u64* __restrict__ p
 
 void launchFletcherPatch(const u64* partials, u32 len, u8* dst, hipStream_t stream)
 {
-  hipLaunchKernelGGL(k_fletcher_patch, dim3(1), dim3(64), 0, stream, partials, len, dst);
+  hipLaunchKernelGGL(k_fletcher_patch, dim3(1), dim3(64), 0, stream, partials, len, dst, 0u, 0u);
+}
+
+// the same where the partials cover the front part of the `len` bytes only and the terms of the rest are known already
+// (sums = sum of words mod 65535 | (sum of word index * word mod 65535) << 16, indices counted from the front)
+void launchFletcherPatchWith(const u64* partials, u32 sums, u32 len, u8* dst, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_fletcher_patch, dim3(1), dim3(64), 0, stream, partials, len, dst, sums & 0xFFFFu, sums >> 16);
 }
 
 u32 fletcherFinish(u64 A, u64 B, u32 len)

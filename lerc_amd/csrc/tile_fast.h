@@ -20,7 +20,8 @@ struct FastEncodeResult
   u32 prefixLen;       // bytes before the first block
   u32 checksum;
   u32 stuck;           // != 0: a workgroup gave up waiting for another one (never seen; the host then takes the general path)
-  u32 pad;
+  u32 streamSums;      // Fletcher terms of the block stream's bytes at their place in the band: sum of the 16-bit words mod 65535 |
+                       // (sum of word index * word mod 65535) << 16 -- a masked band's host adds header and mask to them
 };
 
 #ifdef LERC_SMALL_GROUPS                   // (emulator builds: small rasters then take the multi-group hand-offs too)

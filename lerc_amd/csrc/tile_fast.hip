@@ -1357,6 +1357,7 @@ fusedFinish(u32 nBytesTiling, u32 prefixLen, u8* __restrict__ out, u64 outCapaci
   __syncthreads();
   if (threadIdx.x == 0)
   {
+    res->streamSums = (u32)((s_A[0] + s_A[1] + s_A[2] + s_A[3]) % 65535u) | ((u32)((s_B[0] + s_B[1] + s_B[2] + s_B[3]) % 65535u) << 16);
     u64 a = 0, bInv = 0;
     u32 fl = 0;
     for (int i = 0; i < 4; i++) { a = s_kmax[i] > a ? s_kmax[i] : a; bInv = s_kmin[i] > bInv ? s_kmin[i] : bInv; fl |= s_flg[i]; }
