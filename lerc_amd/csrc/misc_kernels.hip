@@ -679,7 +679,10 @@ void launchBandStats(int dt, const void* data, const u8* maskBits, int nRows, in
   if (nDepth == 1 && dt > DT_Byte && nElem >= 4096 && ((uintptr_t)data & 15) == 0 && (nElem * dtSize(dt)) % 16 == 0)
   {
     const i64 nVec = nElem * dtSize(dt) / 16;
-    const dim3 gv((unsigned)std::min<i64>((nVec + 256 * 8 - 1) / (256 * 8), 4096));
+    // (small inputs -- the one row TryRaiseMaxZError's candidates are pruned on: a vector per thread, or a single workgroup
+    // tests nine candidates on every element of the row by itself: 45 us for 8192 floats)
+    const i64 perWG = nVec < (1 << 16) ? 256 : 256 * 8;
+    const dim3 gv((unsigned)std::min<i64>((nVec + perWG - 1) / perWG, 4096));
     switch (dt)
     {
       case DT_Short:  hipLaunchKernelGGL(k_band_stats_vec<short>, gv, block, 0, stream, (const short*)data, maskBits, nVec, raiseMask, mins, maxs, stats); break;

@@ -82,6 +82,17 @@ __device__ __forceinline__ Win16 loadWin16Words(const u32* words, u32 pos, u32 e
   return funnel16(d, (pos & 3u) * 8u, end > pos ? min(16u, end - pos) : 0u);
 }
 
+// ... where the array is known to reach 20 bytes beyond `pos` (what lies behind `end` is blanked all the same): five loads
+// without a condition, which the compiler can issue together
+__device__ __forceinline__ Win16 loadWin16WordsRoomy(const u32* words, u32 pos, u32 end)
+{
+  const u32 w0 = pos >> 2;
+  u32 d[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) d[k] = words[w0 + k];
+  return funnel16(d, (pos & 3u) * 8u, end > pos ? min(16u, end - pos) : 0u);
+}
+
 // 0 = ok, 1 = not a valid block here, 2 = raw block whose valid count is not known to the caller.
 // Mirrors the checks of Lerc2::ReadTile and BitStuffer2::Decode; additionally refuses element counts
 // that differ from the block's valid pixel count (the reference would read past its buffer there).
@@ -717,6 +728,8 @@ __global__ void __launch_bounds__(256) k_rank_chunks(BandParams p, WalkPlan wp, 
   // The column signature has to go on from block to block (sigFollows); checked on the links inside the chunk.
   u32 nc[E];    // (a thread's own positions stay in registers; LDS holds what the others look up)
   const u32 offPack = offsetBytesPack(p);
+  const bool sigChecked = p.mb == 8 || p.mb == 16 || p.mb == 32;
+  const u32 sigStep = (p.mb == 8 && pattern == 14u) ? 2u : (u32)p.mb >> 3;
 #pragma unroll
   for (u32 q = 0; q < E; q++)
   {
@@ -724,7 +737,7 @@ __global__ void __launch_bounds__(256) k_rank_chunks(BandParams p, WalkPlan wp, 
     u32 nx = kDead;
     if (r < len)
     {
-      const Win16 h = loadWin16Words(s_words, r + shift, endRel + shift);
+      const Win16 h = loadWin16WordsRoomy(s_words, r + shift, endRel + shift);    // (r + shift < 4112, the array holds 5244 bytes)
       const u32 bl = blockLength<TBYTES>(h, r + shift, endRel + shift, p, offPack, wp.uniformN > 0 ? wp.uniformN : -1, maxCount);
 #ifdef HIPSIM
       {
@@ -737,7 +750,9 @@ __global__ void __launch_bounds__(256) k_rank_chunks(BandParams p, WalkPlan wp, 
       if (bl != 0u && bl < 4094u)    // (no block of a chunk this size is that long; a raw block of unknown length: no successor)
       {
         nx = r + bl;
-        if (nx < len && !sigFollows(((u32)h.lo >> 2) & pattern, ((u32)s_bytes[nx + shift] >> 2) & pattern, p.mb, pattern)) nx = kDead;
+        const u32 sgA = ((u32)h.lo >> 2) & pattern, sgB = ((u32)s_bytes[min(nx, len - 1u) + shift] >> 2) & pattern;
+        const bool follows = !sigChecked | (sgB == sgA) | (sgB == ((sgA + sigStep) & pattern)) | (sgB == 0u);    // sigFollows, its constants taken out of the loop
+        nx = (nx < len && !follows) ? kDead : nx;
       }
     }
     nc[q] = nx | (1u << 16);
