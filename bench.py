@@ -149,19 +149,36 @@ def cpu_baseline_tiles(tiles_np, max_z_err, seconds=8.0):
                       f"one process per core on {len(res)} cores, lerc_computeCompressedSize+lerc_encode+lerc_decode each"}
 
 
-def other_config(torch, api, codec, name, x, max_z_err, n_depth, steps=5, warmup=2, reference=True):
+def other_config(torch, api, codec, name, x, max_z_err, n_depth, steps=5, warmup=2, reference=True, mask=None):
     """BASELINE configs[2] / configs[3] on this GPU, device resident: `steps` round trips (lerc_amd_encode_device +
-    lerc_amd_decode_device, the host waits for each call), per-kernel HIP-event times, the blob compared with the reference's."""
+    lerc_amd_decode_device, the host waits for each call), per-kernel HIP-event times, the blob compared with the reference's.
+    mask: a uint8 validity mask on the device (the configuration of SURVEY.md section 8 "next" row 1)"""
     import hashlib
     L = codec.lib
     out = torch.empty(x.numel() * x.element_size() + (1 << 20), dtype=torch.uint8, device=x.device)
     dec = torch.empty_like(x)
+    dec_mask = torch.empty_like(mask) if mask is not None else None
     n_pix = int(x.shape[0]) * int(x.shape[1])
     raw = x.numel() * x.element_size()
+    dt = api._torch_dt_code(x)
+    n_rows, n_cols = int(x.shape[0]), int(x.shape[1])
+    enc_s = dec_s = 0.0
 
     def one():
-        rc, nb = api.encode_device(codec, x, max_z_err, out, n_depth)
-        rc2 = api.decode_device(codec, out, nb, dec, n_depth)
+        nonlocal enc_s, dec_s
+        t0 = time.perf_counter()
+        if mask is None:
+            rc, nb = api.encode_device(codec, x, max_z_err, out, n_depth)
+        else:
+            rc, nb = codec.encode(x.data_ptr(), dt, n_depth, n_cols, n_rows, 1, max_z_err, out.data_ptr(), out.numel(), mask.data_ptr(), 1)
+        t1 = time.perf_counter()
+        if mask is None:
+            rc2 = api.decode_device(codec, out, nb, dec, n_depth)
+        else:
+            rc2 = codec.decode(out.data_ptr(), nb, dt, n_depth, n_cols, n_rows, 1, dec.data_ptr(), dec_mask.data_ptr(), 1)
+        t2 = time.perf_counter()
+        enc_s += t1 - t0
+        dec_s += t2 - t1
         if rc != 0 or rc2 != 0:
             raise RuntimeError(f"{name}: encode / decode failed: status {rc} / {rc2}: {codec.last_error()}")
         return nb
@@ -170,6 +187,7 @@ def other_config(torch, api, codec, name, x, max_z_err, n_depth, steps=5, warmup
         nb = one()
     torch.cuda.synchronize()
     L.lerc_amd_profile_enable(codec.h, 1)
+    enc_s = dec_s = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
         nb = one()
@@ -185,8 +203,11 @@ def other_config(torch, api, codec, name, x, max_z_err, n_depth, steps=5, warmup
     ms = el / steps * 1e3
     kms = sum(v["avg_ms"] * v["launches"] for v in kern.values()) / steps
     b_rt = 2 * (raw + nb)
-    same = bool(torch.equal(dec.view(torch.uint8), x.view(torch.uint8))) if max_z_err == 0 else None
+    same = bool(torch.equal(dec.view(torch.uint8), x.view(torch.uint8))) if (max_z_err == 0 and mask is None) else None
+    if mask is not None:
+        same = bool(torch.equal(dec_mask, mask)) and float(((dec.double() - x.double()).abs() * mask).max().item()) <= max_z_err + 6.2e-5
     res = {"workload": name, "value": round(n_pix * steps / el / 1e6, 2), "unit": "MPix/s", "steps": steps, "ms_per_step": round(ms, 4),
+           "encode_ms": round(enc_s / steps * 1e3, 4), "decode_ms": round(dec_s / steps * 1e3, 4),
            "kernel_ms_per_step": round(kms, 4), "blob_bytes": int(nb), "compression_ratio": round(raw / max(nb, 1), 3),
            "algorithmic_bytes": b_rt, "frac_of_hbm_peak_wall": round(b_rt / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
            "frac_of_hbm_peak_kernels": round(b_rt / (max(kms, 1e-9) / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -200,11 +221,14 @@ def other_config(torch, api, codec, name, x, max_z_err, n_depth, steps=5, warmup
         if lib is not None:
             xn = x.cpu().numpy()
             t0 = time.perf_counter()
-            rc, blob = lib.encode(xn, max_z_err, n_depth=n_depth)
+            kw = {"mask": mask.cpu().numpy()} if mask is not None else {}
+            rc, blob = lib.encode(xn, max_z_err, n_depth=n_depth, **kw)
             t1 = time.perf_counter()
             res["blob_matches_reference"] = bool(rc == 0 and len(blob) == nb and hashlib.sha256(bytes(blob)).hexdigest() == sha)
             res["reference_encode_s"] = round(t1 - t0, 3)
     res["verified"] = bool((same is not False) and res.get("blob_matches_reference", True))
+    if mask is not None:
+        res["mask_and_error_bound_hold"] = res.pop("lossless_round_trip")
     del out, dec
     return res
 
@@ -594,6 +618,18 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:    # noqa: BLE001 -- a sub-object must not take the line with it
                 others[key] = {"error": repr(e)[:200]}
+        # ... and the C2 raster with a validity mask (SURVEY.md section 8 "next" row 1): rectangles of invalid pixels, 10 % of the raster
+        try:
+            xo = synth.c2_float32(n, n, device=dev)
+            ii = torch.arange(n, device=dev).view(-1, 1)
+            jj = torch.arange(n, device=dev).view(1, -1)
+            mk = (((ii // 97) + (jj // 131)) % 10 != 0).to(torch.uint8).contiguous()
+            others["c2_masked"] = other_config(torch, api, codec, "8192x8192 float32 DEM, MaxZError=0.01, 10 % of the pixels invalid (general path)",
+                                               xo, args.max_z_err, 1, reference=not args.no_cpu_baseline, mask=mk)
+            del xo, mk
+            torch.cuda.empty_cache()
+        except Exception as e:    # noqa: BLE001
+            others["c2_masked"] = {"error": repr(e)[:200]}
 
     if rank == 0:
         blob_bytes = timed_blob_bytes
