@@ -21,4 +21,5 @@ timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_c4 -o kt -- python $RO
 DB=$(find /tmp/prof_c4 -name '*.db' | head -1)
 python "$ROOT/tools/rocpd_summary.py" "$DB" lerc > "$OUT/${TAG}_kernel_trace_c4.txt" 2>&1
 cd $ROOT
+bash tools/gpu_trace_config.sh general ${TAG}_masked > /dev/null 2>&1    # kernel trace of the masked raster (general path)
 ls -la "$OUT" | grep $TAG | wc -l
