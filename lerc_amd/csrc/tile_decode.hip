@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(256) k_rank_chunks(BandParams p, WalkPlan wp, 
 {
   __shared__ __align__(16) u8 s_bytes[kMemoChunk + kMemoWindowMax + 48];
   __shared__ u32 s_nc[kMemoChunk];    // successor relative to the chunk's start (16 bits; >= the chunk's length: outside; kDead) | blocks from here to there << 16
-  __shared__ u32 s_changed, s_lo, s_hi;
+  __shared__ u32 s_flag[2], s_lo, s_hi;
   constexpr u32 E = kMemoChunk / 256u;
   const u32 kDead = 0xFFFFu;
   const u32 c = blockIdx.x;
@@ -718,7 +718,7 @@ __global__ void __launch_bounds__(256) k_rank_chunks(BandParams p, WalkPlan wp, 
     else for (u32 k2 = 0; k2 < 16u && g + k2 < blobEnd; k2++) (&x.x)[k2 >> 2] |= (u32)blob[g + k2] << (8u * (k2 & 3u));
     *reinterpret_cast<uint4*>(&s_bytes[16u * v]) = x;
   }
-  if (threadIdx.x == 0) { s_lo = kNone; s_hi = 0u; }
+  if (threadIdx.x == 0) { s_lo = kNone; s_hi = 0u; s_flag[0] = 0u; s_flag[1] = 0u; }
   __syncthreads();
   const u32* s_words = reinterpret_cast<const u32*>(s_bytes);
   const u32 endRel = stageEnd - chunkStart;    // (what is staged of the stream, as seen from the chunk's start)
@@ -726,66 +726,116 @@ __global__ void __launch_bounds__(256) k_rank_chunks(BandParams p, WalkPlan wp, 
   // ---- every position's block, if it is one.  A raw block of a masked / ragged band (rc 2) has the length of its valid
   // pixel count, which takes the block index: no successor (the sweep, D3, walks such a chunk with the index in hand).
   // The column signature has to go on from block to block (sigFollows); checked on the links inside the chunk.
+  // Most positions fall to a look at their first byte: a difference flag where there is one slice only, a raw block of unknown
+  // length -- no block; a constant block or (every block full) a raw one -- its length is known.  Only a bit-stuffed block
+  // (mode 1: an eighth of all byte values, nearly all true blocks) needs its header, and those positions are collected in a
+  // queue per wave and parsed 64 at a time, every lane busy, instead of one lane in eight of a wave that parses all 64.
+  __shared__ u16 s_queue[4][128];
   u32 nc[E];    // (a thread's own positions stay in registers; LDS holds what the others look up)
   const u32 offPack = offsetBytesPack(p);
   const bool sigChecked = p.mb == 8 || p.mb == 16 || p.mb == 32;
   const u32 sigStep = (p.mb == 8 && pattern == 14u) ? 2u : (u32)p.mb >> 3;
-#pragma unroll
+  const int nValidAll = wp.uniformN > 0 ? wp.uniformN : -1;
+  const int wv = waveId();
+  const u64 lt = laneMaskLt();
+  // successor of position r whose block is bl bytes long (0: none) and whose flag byte is `flag`, as a packed word
+  auto linked = [&](u32 r, u32 bl, u32 flag) -> u32
+  {
+    u32 nx = kDead;
+    if (bl != 0u && bl < 4094u)    // (no block of a chunk this size is that long; a raw block of unknown length: no successor)
+    {
+      nx = r + bl;
+      const u32 sgA = (flag >> 2) & pattern, sgB = ((u32)s_bytes[min(nx, len - 1u) + shift] >> 2) & pattern;
+      const bool follows = !sigChecked | (sgB == sgA) | (sgB == ((sgA + sigStep) & pattern)) | (sgB == 0u);    // sigFollows, its constants taken out of the loop
+      nx = (nx < len && !follows) ? kDead : nx;
+    }
+    return nx | (1u << 16);
+  };
+  auto parsed = [&](u32 r) -> u32
+  {
+    const Win16 h = loadWin16WordsRoomy(s_words, r + shift, endRel + shift);    // (r + shift < 4112, the array holds 5244 bytes)
+    const u32 bl = blockLength<TBYTES>(h, r + shift, endRel + shift, p, offPack, nValidAll, maxCount);
+    return linked(r, bl == kLenRawUnknown ? 0u : bl, (u32)h.lo & 255u);
+  };
+  u32 nQueued = 0;    // (the same in all lanes of the wave)
+#pragma unroll 1
   for (u32 q = 0; q < E; q++)
   {
     const u32 r = q * 256u + threadIdx.x;
-    u32 nx = kDead;
-    if (r < len)
+    const u32 flag = s_bytes[min(r, len - 1u) + shift];
+    const u32 mode = flag & 3u, tc = flag >> 6;
+    const u32 diff = (p.version >= 5) ? ((flag >> 2) & 1u) : 0u;
+    const bool in = r < len && !(diff && p.nDepth == 1);
+    const bool toQueue = in && mode == 1u;
+    if (!toQueue)
     {
-      const Win16 h = loadWin16WordsRoomy(s_words, r + shift, endRel + shift);    // (r + shift < 4112, the array holds 5244 bytes)
-      const u32 bl = blockLength<TBYTES>(h, r + shift, endRel + shift, p, offPack, wp.uniformN > 0 ? wp.uniformN : -1, maxCount);
-#ifdef HIPSIM
-      {
-        BlkInfo b;
-        const int rc = parseWindow<TBYTES>(h, r + shift, endRel + shift, p, wp.uniformN > 0 ? wp.uniformN : -1, maxCount, b);
-        const u32 want = rc == 0 ? b.len : rc == 2 ? kLenRawUnknown : 0u;
-        if (want != bl) { fprintf(stderr, "blockLength %u != parseWindow %u (rc %d) at chunk %u + %u\n", bl, want, rc, c, r); abort(); }
-      }
-#endif
-      if (bl != 0u && bl < 4094u)    // (no block of a chunk this size is that long; a raw block of unknown length: no successor)
-      {
-        nx = r + bl;
-        const u32 sgA = ((u32)h.lo >> 2) & pattern, sgB = ((u32)s_bytes[min(nx, len - 1u) + shift] >> 2) & pattern;
-        const bool follows = !sigChecked | (sgB == sgA) | (sgB == ((sgA + sigStep) & pattern)) | (sgB == 0u);    // sigFollows, its constants taken out of the loop
-        nx = (nx < len && !follows) ? kDead : nx;
-      }
+      const u32 offB = (offPack >> ((tc * 2u + diff) * 4u)) & 15u;
+      u32 bl = (mode == 2u) ? 1u : (mode == 3u) ? (offB ? 1u + offB : 0u) : ((diff || nValidAll < 0) ? 0u : 1u + (u32)nValidAll * (u32)TBYTES);
+      if (!in || r + bl > endRel) bl = 0u;
+      s_nc[r] = linked(r, bl, flag);
     }
-    nc[q] = nx | (1u << 16);
-    s_nc[r] = nc[q];
+    const u64 bal = __ballot(toQueue);
+    if (toQueue) s_queue[wv][nQueued + (u32)__popcll(bal & lt)] = (u16)r;
+    nQueued += (u32)__popcll(bal);
+    waveSync();
+    if (nQueued >= 64u)
+    {
+      nQueued -= 64u;
+      const u32 r2 = s_queue[wv][nQueued + (u32)laneId()];
+      s_nc[r2] = parsed(r2);
+      waveSync();
+    }
+  }
+  if ((u32)laneId() < nQueued)
+  {
+    const u32 r2 = s_queue[wv][laneId()];
+    s_nc[r2] = parsed(r2);
   }
   __syncthreads();
-  // ---- doubling, synchronous rounds: a hop that ends inside the chunk is extended by the hop that starts where it ends.
-  // Most positions are no block start or end in one after a hop or two; they cost nothing from then on.
-  for (;;)
+#pragma unroll
+  for (u32 q = 0; q < E; q++) nc[q] = s_nc[q * 256u + threadIdx.x];
+#ifdef HIPSIM
+  for (u32 q = 0; q < E; q++)    // (emulator builds: the ordinary parser's verdict on every position)
   {
-    if (threadIdx.x == 0) s_changed = 0u;
+    const u32 r = q * 256u + threadIdx.x;
+    u32 want = kDead | (1u << 16);
+    if (r < len)
+    {
+      const Win16 h = loadWin16Words(s_words, r + shift, endRel + shift);
+      BlkInfo b;
+      const int rc = parseWindow<TBYTES>(h, r + shift, endRel + shift, p, nValidAll, maxCount, b);
+      want = linked(r, rc == 0 ? b.len : 0u, (u32)h.lo & 255u);
+    }
+    if (want != nc[q]) { fprintf(stderr, "k_rank_chunks: position %u of chunk %u: %08x, the ordinary parser says %08x\n", r, c, nc[q], want); abort(); }
+  }
+#endif
+  // ---- doubling, synchronous rounds: a hop that ends inside the chunk is extended by the hop that starts where it ends.
+  // Most positions are no block start or end in one after a hop or two; `live` says which of a thread's sixteen still go on.
+  u32 live = 0u;
+#pragma unroll
+  for (u32 q = 0; q < E; q++) live |= ((nc[q] & 0xFFFFu) < len ? 1u : 0u) << q;
+  for (u32 k = 0; ; k++)
+  {
     u32 ch = 0u;
 #pragma unroll
     for (u32 q = 0; q < E; q++)
-    {
-      const u32 nx = nc[q] & 0xFFFFu;
-      if (nx < len)
+      if ((live >> q) & 1u)
       {
-        const u32 v = s_nc[nx];
+        const u32 v = s_nc[nc[q] & 0xFFFFu];
         nc[q] = (v & 0xFFFFu) | ((nc[q] & 0xFFFF0000u) + (v & 0xFFFF0000u));
         ch |= 1u << q;
+        if ((v & 0xFFFFu) >= len) live &= ~(1u << q);
       }
-    }
-    __syncthreads();
+    __syncthreads();    // (everybody has read what it wanted of the old table)
     if (ch)
     {
-      s_changed = 1u;
+      s_flag[k & 1u] = 1u;
 #pragma unroll
       for (u32 q = 0; q < E; q++) if ((ch >> q) & 1u) s_nc[q * 256u + threadIdx.x] = nc[q];
     }
+    if (threadIdx.x == 0) s_flag[(k + 1u) & 1u] = 0u;    // (the next round's; whoever read it last did so before this round's first barrier)
     __syncthreads();
-    if (!s_changed) break;
-    __syncthreads();
+    if (!s_flag[k & 1u]) break;
   }
   // ---- the candidates: every byte up to one raw block + 1 behind the chunk's start (the stream's first block starts at
   // dataBegin).  Encoders never write a longer block (they fall back to raw); should a blob hold one, the exits agreed on
