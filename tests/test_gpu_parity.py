@@ -608,6 +608,20 @@ def test_device_mask_rle():
         assert rc == 0 and out[:size.value].cpu().numpy().tobytes() == want, (k, n, rc, size.value, len(want))
 
 
+def test_try_raise_with_a_mask(P, O):
+    """the emulator suite's cases -- TryRaiseMaxZError with a mask, first rows that promise more than the band keeps, NaNs under
+    and beside the mask -- byte for byte against the oracle"""
+    import test_sim_kernels as tsk
+    rng = np.random.default_rng(33)
+    for name, x, e, m in tsk.mask_and_stats_cases(rng):
+        r1, b1 = O.encode(x, e, mask=m)
+        r2, b2 = P.encode(x, e, mask=m)
+        assert r1 == r2 and b1 == b2, name
+        if r1 == 0:
+            d1, d2 = O.decode(b1), P.decode(b1)
+            assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1]) and _same(d1[2], d2[2]), name
+
+
 def test_device_mask_rle_decode():
     """the way back (rle_kernels.hip: hops by pointer doubling, a chain over the pieces, a wave per 256 bytes of stream) against
     RLE::decompress said plainly: the cases of the emulator suite incl. the damaged streams, on device memory"""

@@ -715,6 +715,49 @@ def test_sim_device_mask_rle(libs):
         L.lerc_amd_destroy(h)
 
 
+def mask_and_stats_cases(rng):
+    """float rasters with a mask whose values lie on a grid of 0.1 / 0.01 / 0.5 / whole numbers -- TryRaiseMaxZError raises the
+    error bound, or a first row promises it (the candidates are pruned on it, codec_encode.cpp) and a later row does not --,
+    NaNs under and beside the mask"""
+    out = []
+    for dt in (np.float32, np.float64):
+        for k, (digits, e) in enumerate(((1, 0.01), (2, 0.001), (0, 0.3), (1, 0.04), (None, 0.01))):
+            r, c = 64 + 16 * k, 128
+            x = 1000 + 50 * np.sin(np.arange(c)[None, :] / 30.0) + rng.standard_normal((r, c))
+            x = np.round(x * 2) / 2 if digits is None else np.round(x, digits)
+            x = x.astype(dt)
+            m = (rng.random((r, c)) > 0.15).astype(np.uint8)
+            m[r // 3:r // 3 + 9, 20:90] = 0
+            out.append((f"{np.dtype(dt).name} grid {digits} e {e}", x, e, m))
+            y = x.copy()
+            y[1:, :] += dt(0.013) * (rng.random((r - 1, c)) > 0.5)        # the first row keeps its promise, the others do not
+            out.append((f"{np.dtype(dt).name} grid {digits} e {e}, rows 1.. off the grid", y, e, m))
+            z = x.copy()
+            z[m == 0] = np.nan                                           # NaN under the mask: nothing changes
+            z[5, 7] = np.nan
+            m2 = m.copy()
+            m2[5, 7] = 1                                                 # ... and one at a valid pixel: it leaves the mask
+            out.append((f"{np.dtype(dt).name} grid {digits} e {e}, NaNs", z, e, m2))
+    return out
+
+
+def test_sim_try_raise_with_a_mask(libs):
+    """same blobs as the oracle's, whose TryRaiseMaxZError and mask filter are the reference's (a mask's statistics and the first
+    row's errors come out of one wait)"""
+    O, S = libs
+    rng = np.random.default_rng(33)
+    raised = 0
+    for name, x, e, m in mask_and_stats_cases(rng):
+        r1, b1 = O.encode(x, e, mask=m)
+        r2, b2 = S.encode(x, e, mask=m)
+        assert r1 == r2 and b1 == b2, name
+        if r1 == 0:
+            d1, d2 = O.decode(b1), S.decode(b1)
+            assert d1[0] == d2[0] == 0 and _same(d1[2], d2[2]), name
+            raised += int(O.blob_info(b1)[2][2] > e * 1.5)    # (dataRangeArray[2]: the error bound the blob was coded with)
+    assert raised >= 4, raised
+
+
 def test_sim_bit_plane_mode(libs):
     """maxZErr == 777: Lerc2::TryBitPlaneCompression picks the error bound from neighbour XOR statistics
     (Lerc2.cpp:1071-1229) -- all integer types, with a mask, with nDepth > 1, too few pixels, float (refused)."""
