@@ -768,7 +768,9 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
 
         if (hd.tryHuffmanInt())
         {
+          TL("before the Huffman plan");
           if (!planHuffman(ctx, dt, dData, dBits, nRows, nCols, nD, hd.version, huff, spec.on ? spec.histo : nullptr)) return kFailed;
+          TL("Huffman plan made");
           nBytesHuffman = huff.ok ? huff.nBytes : 0;
           if (huff.ok && nBytesHuffman < nBytesTiling) { payload = P_HUFFMAN; imageMode = huff.imageMode; nBytesData = nBytesHuffman; }
           else huff.ok = false;
@@ -877,6 +879,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   else if (payload == P_HUFFMAN)
   {
     if (!emitHuffman(ctx, dt, dData, dBits, nRows, nCols, nD, huff, dPayload, dStatus)) return kFailed;
+    TL("Huffman stream enqueued");
   }
 
   // ---- 5. checksum over blob[14 ..) (Lerc2.cpp:1012-1030), patched into the header (codec 2 has none)
