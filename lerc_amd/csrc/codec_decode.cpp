@@ -312,7 +312,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
   {
     size_t cand = 0;    // (k_rank_chunks' table: a word per candidate -- one raw block + 1 of them, 1100 at most, to a chunk of 4 KiB)
     for (int i = 0; i < rq.nBands; i++) cand = std::max(cand, std::min<size_t>(1100, 2 + (size_t)bands[i].hd.mbSize * bands[i].hd.mbSize * tb));
-    need += (maxChunks + 2) * cand * 4;
+    need += (maxChunks + 2) * (cand + 3) * 4;
   }
   need += fastBandWorkspace(nRows, nCols, rq.blobSize) + 4096;    // streaming path tables
   for (int i = 0; i < rq.nBands; i++)
@@ -613,7 +613,8 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     DecodeArgs da;
     da.blob = dBand; da.dataBegin = (u32)(at - bd.offset); da.blobEnd = blobEnd;
     da.maskBits = dMask; da.zMaxVec = dZMax; da.out = dOutBand; da.blockOff = nullptr; da.nValidBlk = nullptr;
-    const WalkPlan wp = makeWalkPlan(bp, da.dataBegin, da.blobEnd, nv);
+    WalkPlan wp = makeWalkPlan(bp, da.dataBegin, da.blobEnd, nv);
+    wp.test = fastTestGiveUp() & 24u;
     WalkBuffers wb;
     wb.chunkExit = ctx.allocT<u32>(wp.nChunks + 4);
     wb.chunkEntry = ctx.allocT<u32>(wp.nChunks + 4);
@@ -622,7 +623,8 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     wb.blockOff = ctx.allocT<u32>((size_t)wp.nSub + 4);
     wb.scratch = ctx.allocT<u32>(wp.nChunks / 1024 + 8);
     wb.candTab = wp.tabled ? ctx.allocT<u32>((size_t)wp.nChunks * wp.candWindow + 4) : nullptr;
-    if (wp.tabled && !wb.candTab) return kFailed;
+    wb.chunkSub = wp.tabled ? ctx.allocT<u32>(3 * (size_t)wp.nChunks + 4) : nullptr;
+    if (wp.tabled && (!wb.candTab || !wb.chunkSub)) return kFailed;
     u16* nValidBlk = nullptr;
     if (wp.uniformN == 0)
     {

@@ -38,6 +38,7 @@ struct WalkPlan
   int uniformN;          // > 0: every block has exactly this many valid pixels; 0: varies (mask / edges)
   u32 candWindow;        // a chunk's candidates: every byte of its first candWindow (one raw block + 1)
   u32 tabled;            // 1: chunks small enough for the kernel that ranks every position (candTab is filled)
+  u32 test;              // test knobs (LERC_AMD_TEST_GIVEUP): 8 = D4's first lane distrusts the landings; 16 = the landings are off by a byte
 };
 struct WalkBuffers
 {
@@ -48,6 +49,7 @@ struct WalkBuffers
   u32* blockOff;         // [nSub]
   const u16* nValidBlk;  // [nTV*nTH]   valid pixels per block position (nullptr when uniformN > 0)
   u32* scratch;          // scan scratch, >= nChunks/1024 + 2 words
+  u32* chunkSub;         // [3 * nChunks] where the lowest candidate's chain enters KiB 1, 2, 3 of the chunk (16 bits) | blocks from there to the chunk's exit << 16; ~0u: nowhere
   u32* candTab;          // [nChunks * candWindow] per candidate: where it leaves the chunk (relative, 16 bits) | blocks on the way << 16; 0 = not a block start
 };
 // ---- legacy Lerc1 z part (lerc1_kernels.hip)

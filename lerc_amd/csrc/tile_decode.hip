@@ -609,6 +609,7 @@ WalkPlan makeWalkPlan(const BandParams& p, u32 dataBegin, u32 blobEnd, int numVa
   wp.uniformN = uniform ? (int)n : 0;
   wp.candWindow = std::min(wp.window, 2u + n * tb);
   wp.tabled = (wp.chunkBytes <= 4096u && wp.window <= 1100u) ? 1u : 0u;    // (kMemoChunk, kMemoWindowMax below)
+  wp.test = 0u;
   return wp;
 }
 
@@ -691,14 +692,15 @@ __global__ void __launch_bounds__(64) k_walk_chunks(BandParams p, WalkPlan wp, c
 // Per candidate the table goes to candTab (8192^2 float with a 10 % mask: walks 0.98 ms, four sub-chunk walks joined by
 // look-ups 0.55 ms, this R ms, and D2's 0.09 ms become a look-up).
 static const u32 kMemoChunk = 4096, kMemoWindowMax = 1100;
+static const u32 kRankSub = 1024;    // the KiB of a chunk that D4 gives a lane each
 
 template<int TBYTES>
 __global__ void __launch_bounds__(256) k_rank_chunks(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin,
-                                                    u32 blobEnd, u32* __restrict__ chunkExit, u32* __restrict__ candTab)
+                                                    u32 blobEnd, u32* __restrict__ chunkExit, u32* __restrict__ candTab, u32* __restrict__ chunkSub)
 {
   __shared__ __align__(16) u8 s_bytes[kMemoChunk + kMemoWindowMax + 48];
   __shared__ u32 s_nc[kMemoChunk];    // successor relative to the chunk's start (16 bits; >= the chunk's length: outside; kDead) | blocks from here to there << 16
-  __shared__ u32 s_flag[2], s_lo, s_hi;
+  __shared__ u32 s_flag[2], s_lo, s_hi, s_lowR;
   constexpr u32 E = kMemoChunk / 256u;
   const u32 kDead = 0xFFFFu;
   const u32 c = blockIdx.x;
@@ -718,7 +720,7 @@ __global__ void __launch_bounds__(256) k_rank_chunks(BandParams p, WalkPlan wp, 
     else for (u32 k2 = 0; k2 < 16u && g + k2 < blobEnd; k2++) (&x.x)[k2 >> 2] |= (u32)blob[g + k2] << (8u * (k2 & 3u));
     *reinterpret_cast<uint4*>(&s_bytes[16u * v]) = x;
   }
-  if (threadIdx.x == 0) { s_lo = kNone; s_hi = 0u; s_flag[0] = 0u; s_flag[1] = 0u; }
+  if (threadIdx.x == 0) { s_lo = kNone; s_hi = 0u; s_lowR = kNone; s_flag[0] = 0u; s_flag[1] = 0u; }
   __syncthreads();
   const u32* s_words = reinterpret_cast<const u32*>(s_bytes);
   const u32 endRel = stageEnd - chunkStart;    // (what is staged of the stream, as seen from the chunk's start)
@@ -809,11 +811,13 @@ __global__ void __launch_bounds__(256) k_rank_chunks(BandParams p, WalkPlan wp, 
     if (want != nc[q]) { fprintf(stderr, "k_rank_chunks: position %u of chunk %u: %08x, the ordinary parser says %08x\n", r, c, nc[q], want); abort(); }
   }
 #endif
-  // ---- doubling, synchronous rounds: a hop that ends inside the chunk is extended by the hop that starts where it ends.
+  // ---- doubling, synchronous rounds: a hop that ends inside its KiB of the chunk is extended by the hop that starts where it
+  // ends -- up to the KiB's end, not the chunk's: the few positions that have to know how the chunk is left (its candidates)
+  // get there in four look-ups, and where the stream enters every KiB is what lets D4 walk the KiBs side by side.
   // Most positions are no block start or end in one after a hop or two; `live` says which of a thread's sixteen still go on.
   u32 live = 0u;
 #pragma unroll
-  for (u32 q = 0; q < E; q++) live |= ((nc[q] & 0xFFFFu) < len ? 1u : 0u) << q;
+  for (u32 q = 0; q < E; q++) live |= ((nc[q] & 0xFFFFu) < min(len, ((q >> 2) + 1u) * kRankSub) ? 1u : 0u) << q;    // (position q * 256 + tid lies in KiB q / 4)
   for (u32 k = 0; ; k++)
   {
     u32 ch = 0u;
@@ -824,7 +828,7 @@ __global__ void __launch_bounds__(256) k_rank_chunks(BandParams p, WalkPlan wp, 
         const u32 v = s_nc[nc[q] & 0xFFFFu];
         nc[q] = (v & 0xFFFFu) | ((nc[q] & 0xFFFF0000u) + (v & 0xFFFF0000u));
         ch |= 1u << q;
-        if ((v & 0xFFFFu) >= len) live &= ~(1u << q);
+        if ((v & 0xFFFFu) >= min(len, ((q >> 2) + 1u) * kRankSub)) live &= ~(1u << q);
       }
     __syncthreads();    // (everybody has read what it wanted of the old table)
     if (ch)
@@ -843,16 +847,51 @@ __global__ void __launch_bounds__(256) k_rank_chunks(BandParams p, WalkPlan wp, 
   // with its own walk.
   const u32 nCand = (c == 0) ? 1u : min(wp.candWindow, len);
   u32 lo = kNone, hi = 0u;
+  u32 myR = kNone, mySub[3] = { kNone, kNone, kNone };    // (a thread holds two candidates at most; the lower one that gets out is kept)
   for (u32 r = threadIdx.x; r < wp.candWindow; r += 256u)
   {
     u32 e = 0u;
-    if (r < nCand && (s_nc[r] & 0xFFFFu) != kDead) { e = s_nc[r]; const u32 x = e & 0xFFFFu; lo = min(lo, x); hi = max(hi, x); }
+    if (r < nCand)
+    {
+      // from KiB to KiB: where the chain enters each (landing | blocks before it << 16), where it leaves the chunk
+      u32 at = r, cnt = 0u, land[3] = { kNone, kNone, kNone };
+      bool out = false;
+      for (u32 hop = 0; hop < kMemoChunk / kRankSub && !out; hop++)
+      {
+        const u32 v = s_nc[at];
+        const u32 nx = v & 0xFFFFu;
+        if (nx == kDead) break;
+        cnt += v >> 16;
+        if (nx >= len) { e = nx | (cnt << 16); out = true; }
+        else { land[(nx / kRankSub) - 1u] = nx | (cnt << 16); at = nx; }    // (nx lies in a later KiB than `at`: 1 ... 3)
+      }
+      if (out)
+      {
+        const u32 x = e & 0xFFFFu;
+        lo = min(lo, x); hi = max(hi, x);
+        if (myR == kNone)
+        {
+          myR = r;
+#pragma unroll
+          for (int k = 0; k < 3; k++) mySub[k] = land[k] == kNone ? kNone : ((land[k] & 0xFFFFu) | (((e >> 16) - (land[k] >> 16)) << 16));    // landing | blocks from it to the exit << 16
+        }
+      }
+    }
     candTab[(size_t)c * wp.candWindow + r] = e;    // (a block is a byte at least: x >= 1, e != 0)
   }
   lo = waveMin(lo); hi = waveMax(hi);
-  if (laneId() == 0 && lo != kNone) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+  const u32 lowR = waveMin(myR);
+  if (laneId() == 0 && lo != kNone) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); atomicMin(&s_lowR, lowR); }
   __syncthreads();
-  if (threadIdx.x == 0) chunkExit[c] = (s_lo != kNone && s_lo == s_hi) ? chunkStart + s_lo : kNone;
+  const bool agreed = s_lo != kNone && s_lo == s_hi;
+  if (threadIdx.x == 0) chunkExit[c] = agreed ? chunkStart + s_lo : kNone;
+  // what D4's four lanes per chunk start from: the lowest candidate's landings (every candidate that gets out runs into the
+  // same chain sooner or later; D4's first lane checks that it arrives where this one did)
+  if (agreed ? (myR != kNone && myR == s_lowR) : threadIdx.x == 0)
+  {
+#pragma unroll
+    for (int k = 0; k < 3; k++) chunkSub[3u * c + k] = agreed ? mySub[k] : kNone;
+  }
 }
 
 // D2 for chunks that k_rank_chunks has tabled: the entry is a candidate, its count and exit are in the table
@@ -1130,14 +1169,86 @@ __global__ void __launch_bounds__(256) k_walk_emit(BandParams p, WalkPlan wp, co
   }
 }
 
+// D4 for chunks that k_rank_chunks has tabled: four lanes a chunk, a KiB each.  Lane 0 starts at the chunk's entry, the
+// others where the lowest candidate's chain entered their KiB, with the block index counted back from the chunk's end
+// (chunkSub: landing | blocks from there to the exit << 16) -- the entry's chain is that chain from wherever the two meet.
+// Whether they have met by the first landing is what lane 0 finds out first: it walks its KiB, and only if it arrives at
+// that landing with that block index do the other lanes walk theirs (side by side: a chain of two KiB instead of four);
+// if not (a candidate that joins the true chain late: never seen), lane 0 walks on to the chunk's end alone.
+template<int TBYTES>
+__global__ void __launch_bounds__(256) k_walk_emit_sub(BandParams p, WalkPlan wp, const u8* __restrict__ blob, u32 dataBegin, u32 blobEnd,
+                                                       const u32* __restrict__ chunkEntry, const u32* __restrict__ chunkBase,
+                                                       const u32* __restrict__ chunkSub, const u16* __restrict__ nValidBlk,
+                                                       u32* __restrict__ blockOff, DeviceStatus* st)
+{
+  if (st->error) return;    // raised by the sweep: the entries cannot be trusted
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  const u32 c = min(t >> 2, wp.nChunks - 1u), k = t & 3u;
+  const bool mine = (t >> 2) < wp.nChunks;
+  const u32 chunkStart = dataBegin + c * wp.chunkBytes;
+  const u32 chunkEnd = min(chunkStart + wp.chunkBytes, blobEnd);
+  const u32 maxCount = (u32)p.mb * (u32)p.mb;
+  const u32 nPos = (u32)p.nTV * (u32)p.nTH;
+  const u32 posBegin = chunkBase[c], posEnd = chunkBase[c + 1];
+  const u32 total = posEnd - posBegin;
+  u32 sub[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+  {
+    sub[i] = chunkSub[3u * c + i];
+    if (sub[i] != kNone && (wp.test & 16u)) sub[i] += 1u;    // (test: a landing that is none)
+    if (sub[i] != kNone && ((sub[i] & 0xFFFFu) >= chunkEnd - chunkStart || (sub[i] >> 16) >= total)) sub[i] = kNone;    // (never: an entry that cannot be; a block lies in front of a landing)
+  }
+  const bool table = wp.uniformN <= 0 && nValidBlk != nullptr;
+  // the stretch from `cur` (block index `pos`) to `stop` (block index `posStop`); false: something on the way is no block
+  auto walk = [&](u32& cur, u32& pos, u32 stop, u32 posStop) -> bool
+  {
+    while (cur < stop && pos < posStop)
+    {
+      const u32 blk = pos / (u32)p.nDepth;
+      const int nValid = wp.uniformN > 0 ? wp.uniformN : ((table && blk < nPos) ? (int)nValidBlk[blk] : -1);
+      BlkInfo b;
+      if (parseBlock<TBYTES>(blob, cur, blobEnd, p, nValid, maxCount, b) != 0) return false;
+      if (pos < wp.nSub) blockOff[pos] = cur;
+      pos++;
+      cur += b.len;
+    }
+    return true;
+  };
+  // the first landing there is: lane 0's first stop
+  u32 firstStop = chunkEnd, firstPos = posEnd;
+#pragma unroll
+  for (int i = 2; i >= 0; i--) if (sub[i] != kNone) { firstStop = chunkStart + (sub[i] & 0xFFFFu); firstPos = posEnd - (sub[i] >> 16); }
+  u32 cur0 = chunkEntry[c], pos0 = posBegin;
+  u32 verdict = 0u;    // 0: lane 0 goes on alone; 1: the landings hold, the other lanes walk; 2: the chunk is done; 3: no block on the way
+  if (mine && k == 0u)
+  {
+    if (!walk(cur0, pos0, firstStop, firstPos)) { raiseError(st, kFailed, 0x80000000u | c); verdict = 3u; }
+    else verdict = (firstStop == chunkEnd) ? 2u : ((cur0 == firstStop && pos0 == firstPos && !(wp.test & 8u)) ? 1u : 0u);
+  }
+  verdict = (u32)__shfl((int)verdict, laneId() & ~3);
+  if (!mine) return;
+  if (k == 0u)
+  {
+    if (verdict == 0u && !walk(cur0, pos0, chunkEnd, posEnd)) raiseError(st, kFailed, 0x80000000u | c);
+    return;
+  }
+  if (verdict != 1u || sub[k - 1u] == kNone) return;
+  u32 cur = chunkStart + (sub[k - 1u] & 0xFFFFu), pos = posEnd - (sub[k - 1u] >> 16), stop = chunkEnd, posStop = posEnd;
+#pragma unroll
+  for (int i = 2; i >= 0; i--)
+    if ((u32)i + 1u > k && sub[i] != kNone) { stop = chunkStart + (sub[i] & 0xFFFFu); posStop = posEnd - (sub[i] >> 16); }
+  if (!walk(cur, pos, stop, posStop)) raiseError(st, kFailed, 0x80000000u | c);    // (on the entry's own chain: what is no block here is none)
+}
+
 // candidates per chunk -> exits the candidates agree on -> counts where the entry is known -> one sweep that closes
 // the gaps (and sizes the raw blocks of masked / ragged bands, whose length hangs on the block index) -> offsets.
 // The first step needs neither the mask nor the blocks' valid counts and is launched on its own.
 template<int TBYTES>
 static void launchWalkChunksT(const BandParams& p, const WalkPlan& wp, const DecodeArgs& a, const WalkBuffers& wb, hipStream_t stream)
 {
-  if (wp.tabled && wb.candTab)
-    hipLaunchKernelGGL(k_rank_chunks<TBYTES>, dim3(wp.nChunks), dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit, wb.candTab);
+  if (wp.tabled && wb.candTab && wb.chunkSub)
+    hipLaunchKernelGGL(k_rank_chunks<TBYTES>, dim3(wp.nChunks), dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit, wb.candTab, wb.chunkSub);
   else
     hipLaunchKernelGGL(k_walk_chunks<TBYTES>, dim3(wp.nChunks), dim3(64), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, wb.chunkExit);
 }
@@ -1174,7 +1285,10 @@ static void launchWalkRestT(const BandParams& p, const WalkPlan& wp, const Decod
     fprintf(stderr, "walk debug: %u chunks, %u without agreed exit, %u without count\n", wp.nChunks, noExit, noCount);
   }
 #endif
-  if (lds)
+  if (wp.tabled && wb.candTab)
+    hipLaunchKernelGGL(k_walk_emit_sub<TBYTES>, dim3((4u * wp.nChunks + 255u) / 256u), dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd,
+                       (const u32*)wb.chunkEntry, (const u32*)wb.chunkBase, (const u32*)wb.chunkSub, wb.nValidBlk, wb.blockOff, st);
+  else if (lds)
     hipLaunchKernelGGL(k_walk_emit_lds<TBYTES>, gridL, dim3(256), 0, stream, p, wp, a.blob, a.dataBegin, a.blobEnd, (const u32*)wb.chunkEntry,
                        (const u32*)wb.chunkBase, wb.nValidBlk, wb.blockOff, st);
   else

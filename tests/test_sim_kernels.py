@@ -758,6 +758,49 @@ def test_sim_try_raise_with_a_mask(libs):
     assert raised >= 4, raised
 
 
+@pytest.mark.parametrize("knob", ["0", "8", "16", "24"])
+def test_sim_block_offsets_by_four_lanes_a_chunk(libs, knob):
+    """k_walk_emit_sub: a chunk's block offsets are written by four lanes, three of which start where k_rank_chunks saw a
+    candidate's chain enter their KiB.  The first lane checks that it arrives at the same place with the same block index; the
+    knobs make it distrust the landings (8), make the landings wrong by a byte (16), or both: same pixels every time.  Masked
+    and ragged rasters of every type that takes this path (8 x 8 blocks, one value per pixel), several chunks long."""
+    import sys
+    code = r"""
+import sys, os
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, capi, cases
+S, O = capi.sim(), capi.oracle()
+rng = np.random.default_rng(12)
+n = 0
+for dt, e in ((np.float32, 0.01), (np.uint16, 0), (np.int32, 1), (np.float64, 0.001), (np.uint8, 0), (np.int16, 2)):
+    for r, c in ((96, 512), (131, 397)):
+        x = cases._cast(cases.terrain(r, c, rng, amp=300, base=1000, sigma=1.5) / (8 if np.dtype(dt).itemsize == 1 else 1), dt)
+        for style in range(3):
+            m = np.ones((r, c), np.uint8)
+            if style == 0:
+                i = np.arange(r).reshape(-1, 1); j = np.arange(c).reshape(1, -1)
+                m = (((i // 13) + (j // 37)) %% 5 != 0).astype(np.uint8)
+            elif style == 1:
+                m = (rng.random((r, c)) > 0.1).astype(np.uint8)
+            elif (r %% 8 == 0 and c %% 8 == 0):
+                continue    # (no mask, whole blocks: the streaming kernels' raster)
+            r1, b1 = O.encode(x, e, mask=m)
+            assert r1 == 0
+            d1, d2 = O.decode(b1), S.decode(b1)
+            assert d1[0] == d2[0] == 0 and np.array_equal(d1[2], d2[2]), (np.dtype(dt).name, r, c, style)
+            v = d1[2].reshape(r, c) != 0 if d1[2] is not None else np.ones((r, c), bool)
+            assert np.array_equal(np.where(v, d1[1].reshape(r, c), 0), np.where(v, d2[1].reshape(r, c), 0)), (np.dtype(dt).name, r, c, style)
+            n += 1
+            if style == 0 and len(b1) > 9000:    # a damaged copy: the same verdict
+                bad = bytearray(b1); bad[len(bad) * 2 // 3] ^= 0x21
+                assert (O.decode(bytes(bad))[0] == 0) == (S.decode(bytes(bad))[0] == 0)
+print("offsets ok", n)
+""" % (capi.ROOT,)
+    env = dict(os.environ, LERC_AMD_TEST_GIVEUP=knob)
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    assert out.returncode == 0 and b"offsets ok" in out.stdout, out.stdout.decode()[-2000:]
+
+
 def test_sim_bit_plane_mode(libs):
     """maxZErr == 777: Lerc2::TryBitPlaneCompression picks the error bound from neighbour XOR statistics
     (Lerc2.cpp:1071-1229) -- all integer types, with a mask, with nDepth > 1, too few pixels, float (refused)."""
