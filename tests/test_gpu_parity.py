@@ -622,6 +622,17 @@ def test_try_raise_with_a_mask(P, O):
             assert d1[0] == d2[0] == 0 and _same(d1[1], d2[1]) and _same(d1[2], d2[2]), name
 
 
+@pytest.mark.parametrize("knob", ["0", "8", "16"])
+def test_block_offsets_by_four_lanes_a_chunk(knob):
+    """k_walk_emit_sub on the device: the emulator suite's rasters (masked and ragged, every data type) with the landings
+    trusted, distrusted (8) and made wrong by a byte (16) -- same pixels, same verdict on a damaged copy"""
+    import sys
+    import test_sim_kernels as tsk
+    env = dict(os.environ, LERC_AMD_TEST_GIVEUP=knob)
+    out = subprocess.run([sys.executable, "-c", tsk.four_lanes_code("product")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert out.returncode == 0 and b"offsets ok" in out.stdout, out.stdout.decode()[-2000:]
+
+
 def test_device_mask_rle_decode():
     """the way back (rle_kernels.hip: hops by pointer doubling, a chain over the pieces, a wave per 256 bytes of stream) against
     RLE::decompress said plainly: the cases of the emulator suite incl. the damaged streams, on device memory"""

@@ -765,11 +765,19 @@ def test_sim_block_offsets_by_four_lanes_a_chunk(libs, knob):
     knobs make it distrust the landings (8), make the landings wrong by a byte (16), or both: same pixels every time.  Masked
     and ragged rasters of every type that takes this path (8 x 8 blocks, one value per pixel), several chunks long."""
     import sys
-    code = r"""
+    env = dict(os.environ, LERC_AMD_TEST_GIVEUP=knob)
+    out = subprocess.run([sys.executable, "-c", four_lanes_code("sim")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    assert out.returncode == 0 and b"offsets ok" in out.stdout, out.stdout.decode()[-2000:]
+
+
+def four_lanes_code(which):
+    """the script of test_sim_block_offsets_by_four_lanes_a_chunk (a process of its own: the knob is read once); which: "sim" or
+    "product" (the GPU suite runs it on the device)"""
+    return r"""
 import sys, os
 sys.path.insert(0, os.path.join(%r, "tests"))
 import numpy as np, capi, cases
-S, O = capi.sim(), capi.oracle()
+S, O = capi.%s(), capi.oracle()
 rng = np.random.default_rng(12)
 n = 0
 for dt, e in ((np.float32, 0.01), (np.uint16, 0), (np.int32, 1), (np.float64, 0.001), (np.uint8, 0), (np.int16, 2)):
@@ -795,10 +803,7 @@ for dt, e in ((np.float32, 0.01), (np.uint16, 0), (np.int32, 1), (np.float64, 0.
                 bad = bytearray(b1); bad[len(bad) * 2 // 3] ^= 0x21
                 assert (O.decode(bytes(bad))[0] == 0) == (S.decode(bytes(bad))[0] == 0)
 print("offsets ok", n)
-""" % (capi.ROOT,)
-    env = dict(os.environ, LERC_AMD_TEST_GIVEUP=knob)
-    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
-    assert out.returncode == 0 and b"offsets ok" in out.stdout, out.stdout.decode()[-2000:]
+""" % (capi.ROOT, which)
 
 
 def test_sim_bit_plane_mode(libs):
