@@ -18,6 +18,9 @@
 //
 // FP parity: the quantiser is evaluated in double precision in the reference's
 // expression order; this file must be compiled with -ffp-contract=off.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 #include "kernels.h"
 #include "wave_utils.h"
 #include "block_plan.h"
@@ -526,11 +529,90 @@ static void launchWriteT(int mb, const void* data, const u8* maskBits, const Ban
     default: break;                                                   \
   }
 
+// Float types at maxZErr 0 (the lossless float mode's rival, Lerc2.cpp:1418-1452): a block is one byte (no valid pixel, or all
+// of them zero), raw if two of its values differ, else a constant (Lerc2::NumBytesTile, Lerc2.h:416-431) -- all a block's size
+// takes is its valid count and its range.  A LANE per block position and nothing else, instead of k_encode_tiles' wave per
+// block with its quantiser, LUT candidates and LDS staging (8192^2 float32: 337 -> R us).
+template<class T>
+__global__ void __launch_bounds__(256) k_tile_sizes_lossless_flt(const T* __restrict__ data, const u8* __restrict__ maskBits, BandParams p, u32* __restrict__ sizes)
+{
+  const int pos = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (pos >= p.nTV * p.nTH) return;
+  const int it = pos / p.nTH, jt = pos - it * p.nTH;
+  const int i0 = it * p.mb, j0 = jt * p.mb;
+  const int i1 = min(p.nRows, i0 + p.mb), j1 = min(p.nCols, j0 + p.mb);
+  int n = 0;
+  T mn = T(0), mx = T(0);
+  // whole blocks of 8 x 8 values, every pixel valid, rows of whole 16-byte units: a row of the block in 16-byte loads
+  constexpr int PV = 16 / (int)sizeof(T);
+  if (p.mb == 8 && p.allValid && i1 - i0 == 8 && j1 - j0 == 8 && (p.nCols % PV) == 0 && ((uintptr_t)data & 15) == 0)
+  {
+    struct alignas(16) Vec { T v[PV]; };
+    bool first = true;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+      const Vec* src = reinterpret_cast<const Vec*>(data + (i64)(i0 + r) * p.nCols + j0);
+#pragma unroll
+      for (int u = 0; u < 8 / PV; u++)
+      {
+        const Vec x = src[u];
+#pragma unroll
+        for (int q = 0; q < PV; q++)
+        {
+          const T v = x.v[q];
+          if (first) { mn = v; mx = v; first = false; }
+          else { mn = (v < mn) ? v : mn; mx = (v > mx) ? v : mx; }
+        }
+      }
+    }
+    n = 64;
+  }
+  else
+  for (int i = i0; i < i1; i++)
+  {
+    const i64 row = (i64)i * p.nCols;
+    for (int j = j0; j < j1; j++)
+    {
+      if (!p.allValid && !maskBit(maskBits, row + j)) continue;
+      const T v = data[row + j];
+      if (n == 0) { mn = v; mx = v; }
+      else { mn = (v < mn) ? v : mn; mx = (v > mx) ? v : mx; }
+      n++;
+    }
+  }
+  const Plan pl = planBlock<T>(p, n, mn, mx, p.dt, false, 0.0, 0u, 0u);
+  sizes[pos] = (u32)pl.nBytes;
+}
+
 void launchTileSizes(int dt, int mb, const void* data, const u8* maskBits, const BandParams& p, u32* sizes,
                      DeviceStatus* st, hipStream_t stream)
 {
   if (dt == DT_Char && launchSizesBytes<signed char>(mb, data, maskBits, p, sizes, stream)) return;
   if (dt == DT_Byte && launchSizesBytes<unsigned char>(mb, data, maskBits, p, sizes, stream)) return;
+  if ((dt == DT_Float || dt == DT_Double) && p.maxZErr == 0 && p.nDepth == 1 && !p.tryDiff && p.mb == mb)
+  {
+    const int nPos = p.nTV * p.nTH;
+    const dim3 grid((nPos + 255) / 256), block(256);
+    if (dt == DT_Float) hipLaunchKernelGGL(k_tile_sizes_lossless_flt<float>, grid, block, 0, stream, (const float*)data, maskBits, p, sizes);
+    else hipLaunchKernelGGL(k_tile_sizes_lossless_flt<double>, grid, block, 0, stream, (const double*)data, maskBits, p, sizes);
+#ifdef HIPSIM
+    {   // (emulator builds: the general kernel's sizes, block by block)
+      hipStreamSynchronize(stream);
+      std::vector<u32> want((size_t)nPos);
+      u32* tmp = nullptr;
+      if (hipMalloc(&tmp, (size_t)nPos * 4) == hipSuccess)
+      {
+        LERC_DT_SWITCH(dt, launchSizesT<TT>(mb, data, maskBits, p, tmp, st, stream))
+        hipStreamSynchronize(stream);
+        for (int i = 0; i < nPos; i++)
+          if (tmp[i] != sizes[i]) { fprintf(stderr, "k_tile_sizes_lossless_flt: block %d: %u bytes, the general kernel says %u\n", i, sizes[i], tmp[i]); abort(); }
+        hipFree(tmp);
+      }
+    }
+#endif
+    return;
+  }
   LERC_DT_SWITCH(dt, launchSizesT<TT>(mb, data, maskBits, p, sizes, st, stream))
 }
 
