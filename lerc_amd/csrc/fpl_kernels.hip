@@ -826,9 +826,81 @@ bool launchPackBitsDecode(const u8* in, u32 n, u32 expected, u8* scratch, u32* r
   return true;
 }
 
+// Running sums of bytes (restoreSequence's inner loop, fpl_Lerc2Ext.cpp:128-165) over a plane of 67 MB: the general scan
+// above takes four BYTES a thread (65 000 workgroups of 1 KiB, byte loads and stores: 205 us a pass on an 8192^2 band).  Here a
+// thread takes the 16 bytes of one aligned unit -- the plane starts anywhere, so the first and the last unit are partly
+// someone else's and go byte by byte -- and the second pass adds the carry to four bytes at a time.
+static const u32 kByteSumChunk = 4096;
+
+__device__ __forceinline__ u32 addBytes(u32 x, u32 c4)    // four byte-wise sums mod 256
+{
+  return ((x & 0x7F7F7F7Fu) + (c4 & 0x7F7F7F7Fu)) ^ ((x ^ c4) & 0x80808080u);
+}
+
+// unit u (16 bytes at base + 16 u, base 16-byte aligned) holds plane bytes 16 u - head ... ; valid: those in [0, n)
+__global__ void __launch_bounds__(256) k_bytesum_local(u8* __restrict__ base, u32 head, u32 n, u8* __restrict__ partial)
+{
+  __shared__ u32 s_wave[4];
+  const ScanSum op;
+  const u32 u = blockIdx.x * 256u + threadIdx.x;
+  const i64 first = (i64)16 * u - head;    // plane index of the unit's first byte
+  const bool any = first < (i64)n && first + 16 > 0;
+  const bool whole = first >= 0 && first + 16 <= (i64)n;
+  u32 w[4] = { 0, 0, 0, 0 };
+  if (whole) { const uint4 x = reinterpret_cast<const uint4*>(base)[u]; w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w; }
+  else if (any)
+    for (int k = 0; k < 16; k++) if (first + k >= 0 && first + k < (i64)n) w[k >> 2] |= (u32)base[16ull * u + k] << (8 * (k & 3));
+  // running sums inside the unit: byte k += byte k - 1, ..., as three doubling steps per word and the words' totals
+  u32 run = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+  {
+    u32 x = w[q];
+    x = addBytes(x, x << 8);
+    x = addBytes(x, x << 16);
+    x = addBytes(x, run * 0x01010101u);
+    w[q] = x;
+    run = x >> 24;
+  }
+  u32 total;
+  const u32 before = workgroupExclusive<u32, ScanSum>(run, op, s_wave, total) & 0xFFu;
+  const u32 c4 = before * 0x01010101u;
+#pragma unroll
+  for (int q = 0; q < 4; q++) w[q] = addBytes(w[q], c4);
+  if (whole) reinterpret_cast<uint4*>(base)[u] = make_uint4(w[0], w[1], w[2], w[3]);
+  else if (any)
+    for (int k = 0; k < 16; k++) if (first + k >= 0 && first + k < (i64)n) base[16ull * u + k] = (u8)(w[k >> 2] >> (8 * (k & 3)));
+  if (threadIdx.x == 0) partial[blockIdx.x] = (u8)total;
+}
+
+__global__ void __launch_bounds__(256) k_bytesum_add(u8* __restrict__ base, u32 head, u32 n, const u8* __restrict__ partial)
+{
+  const u32 u = blockIdx.x * 256u + threadIdx.x;
+  const u32 c = partial[blockIdx.x];
+  if (c == 0u) return;    // (the same for the whole workgroup)
+  const i64 first = (i64)16 * u - head;
+  if (first >= 0 && first + 16 <= (i64)n)
+  {
+    const u32 c4 = c * 0x01010101u;
+    uint4 x = reinterpret_cast<const uint4*>(base)[u];
+    x.x = addBytes(x.x, c4); x.y = addBytes(x.y, c4); x.z = addBytes(x.z, c4); x.w = addBytes(x.w, c4);
+    reinterpret_cast<uint4*>(base)[u] = x;
+  }
+  else if (first < (i64)n && first + 16 > 0)
+    for (int k = 0; k < 16; k++) if (first + k >= 0 && first + k < (i64)n) base[16ull * u + k] = (u8)(base[16ull * u + k] + c);
+}
+
 void launchBytePrefixSum(u8* p, u32 n, u32* scratch, hipStream_t st)
 {
-  inclusiveScan<u8, ScanSum>(p, n, (u8*)scratch, st);
+  if (n == 0) return;
+  const u32 head = (u32)((uintptr_t)p & 15u);
+  u8* base = p - head;
+  const u32 nUnits = (head + n + 15u) / 16u;
+  const u32 nPart = (nUnits + 255u) / 256u;
+  hipLaunchKernelGGL(k_bytesum_local, dim3(nPart), dim3(256), 0, st, base, head, n, (u8*)scratch);
+  if (nPart == 1) return;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gscan_partials<u8, ScanSum>), dim3(1), dim3(256), 0, st, (u8*)scratch, nPart);
+  hipLaunchKernelGGL(k_bytesum_add, dim3(nPart), dim3(256), 0, st, base, head, n, (const u8*)scratch);
 }
 
 void launchFplGather(const u8* planes, const int* byteIndex, const FplGeom& g, bool finish, void* out, hipStream_t st)
