@@ -1059,16 +1059,23 @@ __global__ void __launch_bounds__(kSweepThreads) k_walk_sweep(BandParams p, Walk
   if (threadIdx.x == 0) { s_cur = dataBegin; s_pos = 0; s_bad = 0; }
   if (wp.chunkBytes > kSweepChunkMax || wp.window > kSweepWindowMax) { if (threadIdx.x == 0) raiseError(st, kFailed, 0x20000000u); return; }
   __syncthreads();
+  // (a step's three loads are asked for one step ahead: a step is a handful of barriers, and the loads' way from memory was
+  // as long as all of them together)
+  u32 nextFrom = kNone, nextCnt = kNone, nextExit = kNone;
+  auto ask = [&](u32 base)
+  {
+    const u32 c = base + threadIdx.x;
+    const bool in = c < wp.nChunks;
+    nextFrom = !in ? kNone : (c == 0 ? dataBegin : chunkExit[c - 1]);
+    nextCnt = in ? chunkCount[c] : kNone;
+    nextExit = in ? entryExit[c] : kNone;    // (D2's exits; this kernel writes the entries of chunks it has placed only)
+  };
+  ask(0u);
   for (u32 base = 0; base < wp.nChunks; base += kSweepThreads)
   {
     const u32 batchEnd = min(base + kSweepThreads, wp.nChunks);
-    {
-      const u32 c = base + threadIdx.x;
-      const bool in = c < wp.nChunks;
-      s_from[threadIdx.x] = !in ? kNone : (c == 0 ? dataBegin : chunkExit[c - 1]);
-      s_cnt[threadIdx.x] = in ? chunkCount[c] : kNone;
-      s_exit[threadIdx.x] = in ? entryExit[c] : kNone;
-    }
+    s_from[threadIdx.x] = nextFrom; s_cnt[threadIdx.x] = nextCnt; s_exit[threadIdx.x] = nextExit;
+    if (base + kSweepThreads < wp.nChunks) ask(base + kSweepThreads);
     __syncthreads();
     u32 c = base;    // first chunk of the batch that is not placed yet (same in every thread)
     for (;;)

@@ -143,12 +143,13 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
   const u32 blobEnd = hl.blobEnd;
   const u32 nSub = (blobEnd + CH - 1u) >> SH;      // sub-chunk c = blob bytes [c * CH, (c + 1) * CH)
   const u32 cs = wg * (NCH - 1u);                  // first staged sub-chunk; own: cs + 1 ... cs + NCH - 1 (workgroup 0: cs too)
-  if (wg == 0u && !hl.ok && threadIdx.x == 0)      // (not a band of ours: say so)
+  const bool ours = hl.ok && headLiteEligible<DT>(blob, hl.version, nRows, nCols);
+  if (wg == 0u && !ours && threadIdx.x == 0)      // (not a band of ours: say so)
   {
     const FastDecodeParams hp0 = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
     storeParams<true>(b.params, hp0); if (b.hostParams) *b.hostParams = hp0;
   }
-  if (!hl.ok || (wg != 0u && cs + 1u >= nSub)) return;    // (the grid is sized for the largest stream the blob could hold)
+  if (!ours || (wg != 0u && cs + 1u >= nSub)) return;    // (the grid is sized for the largest stream the blob could hold)
   TRACEO(0);
   const u32 nWG = fastOneNumWG(blobEnd, (int)sizeof(T));
   const u32 r0 = cs << SH;                         // blob offset of LDS byte 0
