@@ -408,14 +408,16 @@ u8* Context::persistentState(int area, size_t bytes)
     if (hipMalloc((void**)&m_state[area], want) != hipSuccess) { lastError = "lerc_amd: hipMalloc failed"; return nullptr; }
     m_stateCap[area] = want;
   }
-  if (hipMemset(m_state[area], 0, m_stateCap[area]) != hipSuccess) return nullptr;
+  // (ON the context's stream: it is a non-blocking one, which a hipMemset on the default stream is not ordered with)
+  if (hipMemsetAsync(m_state[area], 0, m_stateCap[area], activeStream()) != hipSuccess || hipStreamSynchronize(activeStream()) != hipSuccess) return nullptr;
   return m_state[area];
 }
 
 void Context::wipePersistentState()
 {
   hipStreamSynchronize(activeStream());
-  for (int a = 0; a < 2; a++) if (m_state[a]) hipMemset(m_state[a], 0, m_stateCap[a]);
+  for (int a = 0; a < 2; a++) if (m_state[a]) hipMemsetAsync(m_state[a], 0, m_stateCap[a], activeStream());    // (see persistentState)
+  hipStreamSynchronize(activeStream());
 }
 
 u8* Context::asyncSlot(unsigned ticket)

@@ -1080,6 +1080,12 @@ void encodeStreamingVerdict(Context& ctx, const EncodeRequest& rq, const u8* slo
     numBytesWritten = rq.dOut ? hres.blobSize : 0;
     return;
   }
+  {
+    char msg[160];
+    snprintf(msg, sizeof(msg), "streaming encode handed the band to the general kernels (redo %u, reason bits 0x%x, stuck %u, blob %u bytes)",
+             hres.redo, hres.redoReason, hres.stuck, hres.blobSize);
+    ctx.lastNote = msg;
+  }
   if (hres.stuck) ctx.wipePersistentState();
   if (rq.dOut && hres.redoReason == 64u && hres.blobSize > rq.outCapacity) { status = kBufferTooSmall; return; }
   redo = true;

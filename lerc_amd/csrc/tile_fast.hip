@@ -1352,8 +1352,14 @@ fusedFinish(u32 nBytesTiling, u32 prefixLen, u8* __restrict__ out, u64 outCapaci
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) flg |= __shfl_xor(flg, m);
     if (lane == 0) { s_A[w] = fA; s_B[w] = fB; s_kmax[w] = kMaxAll; s_kmin[w] = kMinInv; s_flg[w] = flg; }
-    if (threadIdx.x < 9) s_raise[threadIdx.x] = observe64(f.raise + threadIdx.x);    // (aggregator 0 has arrived)
   }
+  // Aggregator 0's first-row errors may be read once ITS arrival has been seen -- by whichever wave holds the thread that
+  // watches its counter (thread nPackGroups % 256), which is this wave only if nPackGroups % 256 < 64: hence the barrier
+  // (without it a raster of one residency round -- 2048 x 4096: the last workgroup and aggregator 0 run side by side -- read
+  // the cells before they were written a few times in a hundred: zeros in a fresh context, "every candidate fits", and the
+  // band went to the general kernels for nothing; in a context that had seen another raster, that raster's errors).
+  __syncthreads();
+  if (threadIdx.x < 9) s_raise[threadIdx.x] = observe64(f.raise + threadIdx.x);
   __syncthreads();
   if (threadIdx.x == 0)
   {
