@@ -480,6 +480,34 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
       return true;
     };
 
+    // The one-sweep and the Huffman kernels take the mask's word for which pixels the stream holds, and how many: before they
+    // run, the mask has to be what the header says -- numValid set bits, out of a run-length stream that was intact (on the
+    // device that verdict would otherwise come with the call's last wait, after kernels had gone by a mask that may be
+    // anything: a rank divided by a valid count of zero, reads behind the band).  One wait, for masked bands in those modes only.
+    // (The block kernels of the tiling mode check every block against its valid count themselves.)
+    auto maskIsWhatTheHeaderSays = [&]() -> bool
+    {
+      if (maskAllValid || !dMask) return true;
+      if (!finishMask()) return false;
+      const i64 nGroups = (nPix + 31) >> 5;
+      const size_t mark = ctx.used();
+      u32* dCounts = ctx.allocT<u32>((size_t)nGroups + 4);
+      u32* dBase = ctx.allocT<u32>((size_t)nGroups + 4);
+      u32* dScr = ctx.allocT<u32>((size_t)nGroups / 1024 + 8);
+      u32* pinV = (u32*)ctx.pinned(64);
+      if (!dCounts || !dBase || !dScr || !pinV) return false;
+      launchMaskGroupCounts(dMask, nPix, dCounts, st);
+      launchExclusiveScan(dCounts, dBase, (u32)nGroups, dScr, st);
+      hipMemcpyAsync(pinV, dBase + nGroups, 4, hipMemcpyDeviceToHost, st);
+      hipMemcpyAsync(pinV + 4, dStatus, sizeof(DeviceStatus), hipMemcpyDeviceToHost, st);
+      if (!ctx.sync()) return false;
+      ctx.rewind(mark);
+      const DeviceStatus* hsNow = reinterpret_cast<const DeviceStatus*>(pinV + 4);
+      if (hsNow->error) { ctx.lastError = "device kernel reported an error"; return false; }
+      if ((i64)pinV[0] != (i64)hd.numValid) { ctx.lastError = "the band's mask does not hold the number of valid pixels its header names"; return false; }
+      return true;
+    };
+
     // noData value of this band: handed out, and the remapped value in the decoded pixels turned back into the
     // caller's original one (Lerc.cpp:488-510) -- enqueued when the iteration is left, behind the band's kernels
     struct BandEpilogue
@@ -540,6 +568,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
       if (maskAllValid) hipMemcpyAsync(dOutBand, src, (size_t)nPix * nD * tb, hipMemcpyDeviceToDevice, st);
       else
       {
+        if (!maskIsWhatTheHeaderSays()) return kFailed;
         const i64 nGroups = (nPix + 31) >> 5;
         u32* dCounts = ctx.allocT<u32>((size_t)nGroups + 4);
         u32* dBase = ctx.allocT<u32>((size_t)nGroups + 4);
@@ -573,6 +602,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
         continue;
       }
       if (!(imageMode == IEM_DeltaHuffman || (hd.version >= 4 && imageMode == IEM_Huffman))) return kFailed;
+      if (!maskIsWhatTheHeaderSays()) return kFailed;
       const u32 rc = decodeHuffman(ctx, dt, rq.hBlob ? rq.hBlob + bd.offset : nullptr, dBand, (u32)(at - bd.offset), blobEnd,
                                    imageMode, dMask, nRows, nCols, nD, hd.version, dOutBand, dStatus, bd.head, bd.headLen);
       if (rc != kOk) return rc;

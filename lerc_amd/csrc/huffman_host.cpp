@@ -463,6 +463,7 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
     hipMemcpyAsync(pin, dBase + nGroups, 4, hipMemcpyDeviceToHost, st);
     if (!ctx.sync()) { delete hTab; return kFailed; }
     numValid = pin[0];
+    if (numValid == 0) { delete hTab; return kFailed; }    // (a band without a valid pixel has no stream; the caller checks the count against the header)
     dValidIdx = ctx.allocT<u32>((size_t)numValid + 4);
     if (!dValidIdx) { delete hTab; return kFailed; }
     launchValidIndex(dMaskBits, dBase, nPix, dValidIdx, st);

@@ -715,6 +715,45 @@ def test_sim_device_mask_rle(libs):
         L.lerc_amd_destroy(h)
 
 
+def test_sim_damaged_mask_streams_in_front_of_the_huffman_and_one_sweep_kernels(libs):
+    """A mask whose run-length stream is damaged, in a band coded by the 8-bit Huffman mode or in one sweep: those kernels take the
+    mask's word for which pixels the stream holds.  With the mask decoded on the device the verdict on its stream used to come with
+    the call's last wait -- after k_huff_emit had divided a rank by a valid count of zero (found by tools/fuzz_sim_masked.py: SIGFPE
+    under the emulator).  The mask is checked against the header's count in front of those kernels now; same verdicts as the oracle's
+    on every flipped bit of the mask section, on the host's decoder and (LERC_AMD_DEVICE_RLE=16) the device's."""
+    import sys
+    code = r"""
+import sys, os, struct
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, capi, cases
+S, O = capi.sim(), capi.oracle()
+rng = np.random.default_rng(87)
+n = 0
+for dt, e, shape in ((np.int8, 0, (65, 186)), (np.uint8, 0, (40, 96)), (np.float32, 1e-7, (33, 70))):
+    r, c = shape
+    x = cases.terrain(r, c, rng, amp=50, base=100, sigma=3.0 if dt == np.float32 else 0.3)
+    x = cases._cast(x / 8 if np.dtype(dt).itemsize == 1 else x * 1000.123, dt)    # (float: noise no block can quantise -> one sweep)
+    m = np.ones((r, c), np.uint8); m[:, : c // 2] = 0; m[r // 2, 3] = 1; m[3:9, c // 2 + 5: c // 2 + 30] = 0
+    r1, b1 = O.encode(x, e, mask=m)
+    assert r1 == 0
+    n_mask = struct.unpack_from("<I", b1, 90)[0]
+    assert n_mask > 8
+    d1, d2 = O.decode(b1), S.decode(b1)
+    assert d1[0] == d2[0] == 0 and np.array_equal(d1[2], d2[2])
+    for k in range(60):
+        bb = bytearray(b1)
+        bb[94 + int(rng.integers(0, n_mask))] ^= 1 << int(rng.integers(0, 8))
+        a, b = O.decode(bytes(bb)), S.decode(bytes(bb))
+        assert (a[0] == 0) == (b[0] == 0), (np.dtype(dt).name, k, a[0], b[0])
+        n += 1
+print("masks ok", n)
+""" % (capi.ROOT,)
+    for knob in ("0", "16"):
+        env = dict(os.environ, LERC_AMD_DEVICE_RLE=knob)
+        out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+        assert out.returncode == 0 and b"masks ok" in out.stdout, out.stdout.decode()[-2000:]
+
+
 def mask_and_stats_cases(rng):
     """float rasters with a mask whose values lie on a grid of 0.1 / 0.01 / 0.5 / whole numbers -- TryRaiseMaxZError raises the
     error bound, or a first row promises it (the candidates are pruned on it, codec_encode.cpp) and a later row does not --,

@@ -33,6 +33,8 @@ while time.time() - t0 < budget:
         if not m.any(): m[0, 0] = 1
         kw["mask"] = m
     tag = f"{np.dtype(dt).name} {r}x{c} e={e} style={style} mask={mk}"
+    if "-v" in sys.argv: print(n, tag, flush=True)
+    if "-dump" in sys.argv: np.savez("/tmp/fuzz_last.npz", x=x, e=e, m=kw.get("mask", np.zeros(0, np.uint8)))
     r1, b1 = O.encode(x, e, **kw); r2, b2 = S.encode(x, e, **kw)
     n += 1
     if r1 != r2 or b1 != b2:
