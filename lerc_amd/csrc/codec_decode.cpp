@@ -366,8 +366,15 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
   struct FastBand { bool used = false; u32 epoch = 0; };
   std::vector<FastBand> fast(rq.nBands);
 
+  // what a band's kernels take from the workspace (mask tables, chunk tables, block offsets ...) is sized for ONE band: every band
+  // starts where the first one did.  The bands' kernels run in the order they are enqueued on the call's stream, and the side
+  // stream a mask is decoded on is forked behind everything the band in front enqueued, so a band's tables are dead when the
+  // next band's kernels write theirs.
+  const size_t bandMark = ctx.used();
+  bool maskFromDevice = false;    // this band's mask bits come out of launchMaskRleDecode (the verdict on its stream is still out)
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
+    ctx.rewind(bandMark);
     const BandDesc& bd = bands[iBand];
     const Header& hd = bd.hd;
     if (hd.nDepth != nD || hd.nCols != nCols || hd.nRows != nRows) return kFailed;
@@ -419,13 +426,14 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
       // and sent to the device by finishMask() -- in tiling mode behind the launch of the chunk walk, which needs no mask
       if (at + (u64)bd.numBytesMask > bd.offset + (u64)blobEnd) return kFailed;
       const size_t extra = std::min<size_t>((size_t)2 * nD * tb + 2, (size_t)(bd.offset + (u64)blobEnd - (at + (u64)bd.numBytesMask)));
-      const bool onDevice = maskBytes >= kDeviceRleFrom && bd.numBytesMask >= 2 && (size_t)bd.numBytesMask <= kDeviceRleMax;
+      bool onDevice = maskBytes >= kDeviceRleFrom && bd.numBytesMask >= 2 && (size_t)bd.numBytesMask <= kDeviceRleMax;
+      u8* scratch = onDevice ? ctx.allocT<u8>(maskRleDecodeScratchBytes((size_t)bd.numBytesMask)) : nullptr;
+      if (!scratch) onDevice = false;    // (no room for the tables: the host decodes the stream)
+      maskFromDevice = onDevice;
       if (onDevice)
       {
         // decoded on the device, in front of the band's kernels; a damaged stream raises Failed in the status the call ends on.
         // The host fetches the header bytes behind the mask only.
-        u8* scratch = ctx.allocT<u8>(maskRleDecodeScratchBytes((size_t)bd.numBytesMask));
-        if (!scratch) return kFailed;
         maskRle.resize(extra);    // (read first: the copy waits for what the stream holds)
         if (extra && !rd.read(at + (u64)bd.numBytesMask, extra, maskRle.data())) return kFailed;
         rd.cache = maskRle.data(); rd.cacheOff = at + (u64)bd.numBytesMask; rd.cacheLen = maskRle.size();
@@ -489,6 +497,8 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     {
       if (maskAllValid || !dMask) return true;
       if (!finishMask()) return false;
+      // (a mask the host decoded: rleDecode has vouched for the stream, and Lerc2::ReadMask, Lerc2.cpp:961-1008, asks no more)
+      if (!maskFromDevice) return true;
       const i64 nGroups = (nPix + 31) >> 5;
       const size_t mark = ctx.used();
       u32* dCounts = ctx.allocT<u32>((size_t)nGroups + 4);
@@ -743,6 +753,7 @@ u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
     if (src != kOk) return src;
     if (handled) { ctx.pathCount[2]++; return kOk; }
     if (!tried) break;    // (not a request the streaming kernels take blind: decodeImpl looks at every band)
+    if (bits == 0x200u) return kFailed;    // (decoded by the streaming kernels, and the checksum is wrong: no other tier would say anything else)
     if (bits & 0x100u) break;    // (the header says it is no band for the streaming kernels -- a mask, another mode: the other form would say the same)
     level--;
   }

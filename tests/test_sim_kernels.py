@@ -535,6 +535,35 @@ print("pieces ok")
     assert out.returncode == 0 and b"pieces ok" in out.stdout, out.stdout.decode()[-2000:]
 
 
+def test_sim_several_bands_with_a_mask_each_decoded_on_the_device(libs):
+    """Four bands, each with its own noisy mask, the masks' run-length streams decoded on the device (LERC_AMD_DEVICE_RLE=16): a
+    band's tables in the workspace are sized for one band and every band starts where the first one did (codec_decode.cpp) --
+    they used to pile up until a band found no room and the call failed on a blob the library's own encoder had written."""
+    import sys
+    code = r"""
+import sys, os
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, capi, cases
+S, O = capi.sim(), capi.oracle()
+rng = np.random.default_rng(77)
+for (nb, r, c, dt, e) in ((16, 256, 400, np.float32, 0.01), (3, 200, 264, np.uint16, 0), (5, 96, 520, np.uint8, 0)):    # (the first one failed)
+    x = np.stack([cases._cast(cases.terrain(r, c, rng, amp=300, base=1000, sigma=2.0) + 7 * k, dt) for k in range(nb)])
+    m = (rng.random((nb, r, c)) > 0.5).astype(np.uint8)
+    r1, b1 = O.encode(x, e, n_bands=nb, mask=m); r2, b2 = S.encode(x, e, n_bands=nb, mask=m)
+    assert r1 == r2 == 0 and b1 == b2, (nb, r, c)
+    d1, d2 = O.decode(b1, want_masks=nb, n_bands=nb), S.decode(b1, want_masks=nb, n_bands=nb)
+    assert d1[0] == d2[0] == 0, (d1[0], d2[0], nb, r, c)
+    assert np.array_equal(d1[2], d2[2]), (nb, r, c)
+    v = d1[2].reshape(nb, r, c) != 0
+    assert np.array_equal(d1[1].reshape(nb, r, c)[v], d2[1].reshape(nb, r, c)[v]), (nb, r, c)
+print("bands ok")
+""" % (capi.ROOT,)
+    for knob in ("16", "0"):
+        env = dict(os.environ, LERC_AMD_DEVICE_RLE=knob)
+        out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert out.returncode == 0 and b"bands ok" in out.stdout, out.stdout.decode()[-2000:]
+
+
 def _rle_restated(b):
     """RLE::compress (RLE.cpp:123-254) said plainly: in a literal stretch a run opens where five equal bytes start and one more
     byte follows; it takes every byte equal to its first; stretches and runs are cut at 32767; -32768 ends the stream"""
