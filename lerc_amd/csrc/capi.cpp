@@ -24,6 +24,7 @@ struct AsyncOp
   EncodeRequest er;
   DecodeRequest dr;
   bool streamed = false;    // its streaming kernels and the copy of their verdict are on the stream
+  int form = 0;             // a decode: which streaming form (DecodeRequest::maxForm)
   u32 epoch = 0;
   bool done = false;
   u32 status = kOk, bytes = 0;
@@ -221,7 +222,8 @@ lerc_status decodeHost(const unsigned char* blob, unsigned blobSize, int nMasks,
       }
     }
   }
-  rq.skipOne = triedOne;    // (the one-launch streaming decoder has just refused this blob)
+  if (triedOne) rq.maxForm = ctx.lastStreamForm - 1;    // (that streaming form has just refused this blob)
+  if (rq.maxForm <= 0) rq.noStreaming = true;
   const u32 rc = decodeDevice(ctx, rq);
   if (rc != kOk) return rc;
   if (widen)
@@ -488,7 +490,7 @@ void completeAll(lerc_amd_context* h)
         op.bytes = op.er.dOut ? written : needed;
         rerun = redo;
       }
-      else rerun = !decodeStreamingVerdict(ctx, slot, op.epoch);
+      else rerun = !decodeStreamingVerdict(ctx, slot, op.epoch, nullptr, op.form);
       if (!rerun) { if (!op.isEncode) ctx.pathCount[2]++; op.done = true; continue; }
     }
     rerun = true;
@@ -511,7 +513,7 @@ void completeAll(lerc_amd_context* h)
           if (getBlobInfo(head, sizeof(head), info) == kOk && info.blobSize >= 70 && info.blobSize <= op.dr.blobSize) op.dr.blobSize = info.blobSize;
         }
       }
-      op.dr.skipOne = op.streamed;    // (the one-launch streaming decoder has just refused this blob)
+      if (op.streamed) { op.dr.maxForm = op.form - 1; op.dr.noStreaming = op.dr.maxForm <= 0; }    // (that streaming form has just refused this blob)
       op.status = decodeDevice(ctx, op.dr);
     }
     op.done = true;
@@ -568,6 +570,7 @@ lerc_status lerc_amd_decode_device_async(lerc_amd_context* h, const unsigned cha
   const unsigned t = pushOp(h, op);
   AsyncOp& q = h->ops.back();
   q.streamed = decodeEnqueueStreaming(h->ctx, q.dr, h->ctx.asyncSlot(t), q.epoch);
+  q.form = h->ctx.lastStreamForm;
   if (!q.streamed) completeAll(h);
   *ticket = t;
   return kOk;
@@ -668,6 +671,12 @@ void lerc_amd_path_counters(lerc_amd_context* h, unsigned long long out[4])
 {
   if (!h) h = threadHandle();    // the context behind the stock host-pointer entry points of this thread
   for (int i = 0; i < 4; i++) out[i] = h ? h->ctx.pathCount[i] : 0;
+}
+
+void lerc_amd_decode_forms(lerc_amd_context* h, unsigned long long out[4])
+{
+  if (!h) h = threadHandle();
+  for (int i = 0; i < 4; i++) out[i] = h ? h->ctx.formCount[i] : 0;
 }
 
 unsigned int lerc_amd_mask_rle_device(lerc_amd_context* h, const unsigned char* dBits, unsigned int nBytes, unsigned char* dOut,

@@ -85,6 +85,9 @@ public:
   // which kernels served the calls so far: [0] encode streaming, [1] encode general, [2] decode streaming, [3] decode general
   unsigned long long pathCount[4] = { 0, 0, 0, 0 };
   bool lastDecodeStreamed = false;
+  unsigned long long formCount[4] = { 0, 0, 0, 0 };    // bands / tiles decoded by streaming form 1, 2, 3 (lerc_amd_decode_forms)
+  int lastStreamForm = 0;              // the form decodeEnqueueStreaming last enqueued (DecodeRequest::maxForm)
+  u32 scanSkip = 0;                    // decodes that keep off the scanning decoder: it has just handed a band on (a stream with blocks it cannot see)
 
   // optional per-kernel timing with HIP events on the active stream (bench.py: roofline of the dominant kernel)
   void profEnable(bool on) { m_prof = on; }
@@ -177,7 +180,8 @@ struct DecodeRequest
   void* dOut = nullptr;               // device: decoded pixels
   u8* dValidBytes = nullptr;          // device: nMasks byte masks, or nullptr
   bool noStreaming = false;            // go straight to the general kernels (a batch has already tried the streaming ones)
-  bool skipOne = false;                // the one-launch streaming decoder has just been tried on this blob: start with the two-launch form
+  int maxForm = 3;                     // the first streaming form to try: 3 the scanning decoder, 2 the walking one-launch decoder, 1 discovery + decode in
+                                       // two launches (a form that has just refused this blob hands it on with its own number less one)
   u8* hUsesNoData = nullptr;           // host [nBands] out (lerc_decode_4D), or nullptr
   double* hNoDataValues = nullptr;
 };
@@ -191,7 +195,7 @@ bool encodeEnqueueStreaming(Context& ctx, const EncodeRequest& rq, u8* slot);
 // redo: the general path has to repeat the request; else status / sizes are final
 void encodeStreamingVerdict(Context& ctx, const EncodeRequest& rq, const u8* slot, bool& redo, u32& status, u32& numBytesNeeded, u32& numBytesWritten);
 bool decodeEnqueueStreaming(Context& ctx, const DecodeRequest& rq, u8* slot, u32& epoch);
-bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits = nullptr);    // true: decoded, checksum good (bits: why not)
+bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits = nullptr, int form = -1);    // true: decoded, checksum good (bits: why not; form: the one that was enqueued, default the last)
 // host-pointer calls: streaming kernels + the results' way back to the host enqueued together, one wait (rq holds a device copy of the blob)
 u32 decodeSpeculativeToHost(Context& ctx, const DecodeRequest& rq, void* hOut, size_t outBytes, u8* hMask, size_t maskBytes, bool& handled);
 u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed);

@@ -76,7 +76,9 @@ bool readBandHeader(const BlobReader& rd, u64 off, BandDesc& b)
 static const size_t kCellParams = 0, kCellFallback = 128, kCellBytes = 192;
 static_assert(sizeof(FastDecodeParams) <= 128, "cell layout");
 
-static bool fastDecodeOneLaunch();    // the one-launch decoder (tile_fast_decode_one.hip); LERC_AMD_DECODE_LAUNCHES=2: discovery + decode as two launches
+static bool fastDecodeOneLaunch();    // the one-launch decoders (tile_fast_decode_scan.hip, tile_fast_decode_one.hip); LERC_AMD_DECODE_LAUNCHES=2: discovery + decode as two launches
+static int pickForm(Context& ctx, int maxForm, int nRows, int nCols);
+static int lowerForm(Context& ctx, int form, int nRows, int nCols) { return form > 1 ? pickForm(ctx, form - 1, nRows, nCols) : 0; }
 
 static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven, u32 nTiles = 1)
 {
@@ -89,9 +91,10 @@ static size_t fastBandWorkspace(int nRows, int nCols, u32 sizeGiven, u32 nTiles 
 // Enqueues header check, discovery and decode of nTiles blobs (one band: nTiles == 1, dTileOffset == nullptr);
 // nothing is read back here.  dParams [nTiles] and dFallback [4 * nTiles] receive the verdicts; the flags in dFallback
 // are raised by writing `epoch` (tile_fast.h), so the cells need no clearing.
-// (one: the one-launch decoder -- short walks over sub-chunks of 1 KiB; else discovery + decode as two launches over chunks of
-// 2 KiB, which follow streams the first cannot: more tiny blocks in a row, longer stretches without a bit-stuffed block)
-static bool launchFastBands(Context& ctx, bool one, int dt, int nRows, int nCols, const u8* dBlobs, u32 sizeBound, u32 nTiles, const u64* dTileOffset,
+// (form 3: the scanning decoder -- one launch, no walks, streams of bit-stuffed blocks; 2: the walking one-launch decoder -- short
+// walks over sub-chunks of 1 KiB; 1: discovery + decode as two launches over chunks of 2 KiB, which follow streams the others
+// cannot: more tiny blocks in a row, longer stretches without a bit-stuffed block)
+static bool launchFastBands(Context& ctx, int form, int dt, int nRows, int nCols, const u8* dBlobs, u32 sizeBound, u32 nTiles, const u64* dTileOffset,
                             const u32* dTileSize, void* dOut, FastDecodeParams* dParams, u32* dFallback, u32 epoch, u8* hCell = nullptr)
 {
   hipStream_t st = ctx.activeStream();
@@ -113,17 +116,23 @@ static bool launchFastBands(Context& ctx, bool one, int dt, int nRows, int nCols
   fbuf.wgCell = fbuf.wgGroupCell = fbuf.wgAcc = nullptr;
   fbuf.wgStride = fbuf.wgGroupStride = 0;
   // (epoch-tagged cells, never cleared: they live as long as the context and share its area with the encoder's)
-  if (one)
+  if (form >= 2)
   {
     // everything in one launch: a cell per workgroup and per group of workgroups, and the groups' checksum accumulators
     // (counters: left zero by the launch's last workgroup)
-    const size_t sWg = fastOneWgStride(sizeBound, dtSize(dt)), sGrp = fastOneGroupStride(sizeBound, dtSize(dt));
+    const size_t sWg = fastAnyWgStride(sizeBound, dtSize(dt)), sGrp = fastAnyGroupStride(sizeBound, dtSize(dt));
     fbuf.wgStride = (u32)sWg; fbuf.wgGroupStride = (u32)sGrp;
     fbuf.wgCell = (u64*)ctx.persistentState(1, (nT * (sWg + sGrp) + 8) * 8);
     fbuf.wgGroupCell = fbuf.wgCell ? fbuf.wgCell + nT * sWg : nullptr;
     fbuf.wgAcc = (u64*)ctx.persistentState(0, (nT * sGrp + 8) * 8);
     if (!fbuf.wgCell || !fbuf.wgAcc) return false;
     fbuf.recs = nullptr; fbuf.lists = nullptr; fbuf.chunkCell = fbuf.groupCell = fbuf.waveFletcher = nullptr;
+    if (form == 3)
+    {
+      ProfScope ps(ctx, "fast_decode_scan");
+      launchFastDecodeScan(dt, nRows, nCols, tb, dBlobs, sizeBound, fbuf, dOut, st);
+      return true;
+    }
     ProfScope ps(ctx, "fast_decode_one");
     launchFastDecodeOne(dt, nRows, nCols, tb, dBlobs, sizeBound, fbuf, dOut, st);
     return true;
@@ -145,10 +154,10 @@ static bool launchFastBands(Context& ctx, bool one, int dt, int nRows, int nCols
   return true;
 }
 
-static bool launchFastBand(Context& ctx, bool one, int dt, int nRows, int nCols, const u8* dBand, u32 sizeGiven, void* dOutBand, u8* dCell, u32 epoch,
+static bool launchFastBand(Context& ctx, int form, int dt, int nRows, int nCols, const u8* dBand, u32 sizeGiven, void* dOutBand, u8* dCell, u32 epoch,
                            u8* hCell = nullptr)
 {
-  return launchFastBands(ctx, one, dt, nRows, nCols, dBand, sizeGiven, 1, nullptr, nullptr, dOutBand,
+  return launchFastBands(ctx, form, dt, nRows, nCols, dBand, sizeGiven, 1, nullptr, nullptr, dOutBand,
                          reinterpret_cast<FastDecodeParams*>(dCell + kCellParams), reinterpret_cast<u32*>(dCell + kCellFallback), epoch, hCell);
 }
 
@@ -156,6 +165,26 @@ static bool fastDecodeOneLaunch()
 {
   static const bool one = []() { const char* e = getenv("LERC_AMD_DECODE_LAUNCHES"); return !e || atoi(e) != 2; }();
   return one;
+}
+
+// The streaming form a request starts with: the highest one at most maxForm that is switched on (LERC_AMD_DECODE_LAUNCHES=2: the
+// two-launch form only; LERC_AMD_DECODE_SCAN=0: not the scanning decoder), takes the raster (the scanning decoder: whole 8 x 8
+// blocks) and has not just handed a band of this context on: a stream the scanning decoder cannot follow -- many blocks that are not
+// bit-stuffed -- costs a launch before the next tier gets it, and the bands of one job are alike, so the next kScanSkip decodes
+// start one tier down.
+static const u32 kScanSkip = 16;
+static int pickForm(Context& ctx, int maxForm, int nRows, int nCols)
+{
+  static const bool scanOn = []() { const char* e = getenv("LERC_AMD_DECODE_SCAN"); return !e || atoi(e) != 0; }();
+  int f = maxForm > 3 ? 3 : maxForm;
+  if (f <= 0) return 0;
+  if (!fastDecodeOneLaunch()) return 1;
+  if (f == 3)
+  {
+    if (!scanOn || !fastDecodeScanEligible(nRows, nCols)) f = 2;
+    else if (ctx.scanSkip > 0) { ctx.scanSkip--; f = 2; }
+  }
+  return f;
 }
 
 // reason bits of a tile's / band's four epoch tagged flag cells
@@ -201,25 +230,31 @@ bool decodeEnqueueStreaming(Context& ctx, const DecodeRequest& rq, u8* slot, u32
   // first: if a launch fails, what the operation that had the slot before left there must not read as this one's "ok")
   memset(slot + 64, 0, kCellBytes);
   (void)hipGetLastError();
-  if (!launchFastBand(ctx, fastDecodeOneLaunch() && !rq.skipOne, dt, nRows, nCols, rq.dBlob, rq.blobSize, rq.dOut, dCells + 64, epoch, slot + 64)) return false;
+  const int form = pickForm(ctx, rq.maxForm, nRows, nCols);
+  if (form <= 0) return false;
+  ctx.lastStreamForm = form;
+  if (!launchFastBand(ctx, form, dt, nRows, nCols, rq.dBlob, rq.blobSize, rq.dOut, dCells + 64, epoch, slot + 64)) return false;
   if (hipGetLastError() != hipSuccess) { ctx.lastError = "lerc_amd: a streaming decode kernel could not be launched"; return false; }
   if (rq.nMasks > 0 && rq.dValidBytes) hipMemsetAsync(rq.dValidBytes, 1, (size_t)nRows * nCols, st);    // numValid == nPix or no verdict
   return true;
 }
 
-bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits)
+bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits, int form)
 {
   if (ctx.profOn()) ctx.profCollect();
+  if (form < 0) form = ctx.lastStreamForm;
   const u32 verdict = fastBandVerdict(slot + 64, epoch);
   if (bits) *bits = verdict;
   if (verdict & 0x8u) ctx.wipePersistentState();    // (a workgroup gave up waiting: the checksum accumulators may hold residue)
+  if (form == 3 && (verdict & 0x7u) && !(verdict & 0x300u)) ctx.scanSkip = kScanSkip;    // (a stream the scanning decoder does not follow)
   if (verdict)
   {
-    char msg[112];
-    snprintf(msg, sizeof(msg), "streaming decode handed the blob to the general path (reason bits 0x%x)", verdict);
+    char msg[128];
+    snprintf(msg, sizeof(msg), "streaming decode (form %d) handed the blob on (reason bits 0x%x)", form, verdict);
     ctx.lastNote = msg;
     return false;
   }
+  if (form >= 1 && form <= 3) ctx.formCount[form]++;
   return true;
 }
 
@@ -238,7 +273,8 @@ static u32 decodeSpeculative(Context& ctx, const DecodeRequest& rq, bool& handle
   return kOk;
 }
 
-// (fastLevel: 2 the one-launch streaming decoder where a band qualifies, 1 the two-launch form, 0 the general kernels only)
+// (fastLevel: the streaming form where a band qualifies -- 3 the scanning decoder, 2 the walking one-launch decoder, 1 the two-launch form -- or
+// 0: the general kernels only)
 static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool& fellBack)
 {
   const bool allowFast = fastLevel > 0;
@@ -635,7 +671,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     {
       FastBand& f = fast[iBand];
       f.epoch = ctx.nextEpoch();
-      if (!launchFastBand(ctx, fastLevel == 2, dt, nRows, nCols, dBand, blobEnd, dOutBand, dCells + 64 + (size_t)iBand * kCellBytes, f.epoch)) return kFailed;
+      if (!launchFastBand(ctx, fastLevel, dt, nRows, nCols, dBand, blobEnd, dOutBand, dCells + 64 + (size_t)iBand * kCellBytes, f.epoch)) return kFailed;
       ctx.lastDecodeStreamed = true;
       f.used = true;
       if (!finishMask()) return kFailed;    // all valid: the caller's mask bytes become 1s (Lerc.cpp:464-488 always writes them)
@@ -700,6 +736,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     const u32 verdict = fastBandVerdict(pin + 64 + (size_t)iBand * kCellBytes, fast[iBand].epoch);
     if (verdict & 0x8u) ctx.wipePersistentState();    // (a workgroup gave up waiting: the checksum accumulators may hold residue)
     if (verdict & 0x200u) return kFailed;    // decoded, but the checksum is wrong
+    if (fastLevel == 3 && (verdict & 0x7u) && !(verdict & 0x300u)) ctx.scanSkip = kScanSkip;
     if (verdict)                             // caller repeats with the general kernels
     {
       char msg[96];
@@ -708,6 +745,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
       fellBack = true;
       return kOk;
     }
+    if (fastLevel >= 1 && fastLevel <= 3) ctx.formCount[fastLevel]++;
   }
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
@@ -741,13 +779,14 @@ u32 decodeSpeculativeToHost(Context& ctx, const DecodeRequest& rq, void* hOut, s
 
 u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
 {
-  // tiers: the one-launch streaming decoder, the two-launch form (which follows streams the first cannot), the general kernels
-  int level = rq.noStreaming ? 0 : ((fastDecodeOneLaunch() && !rq.skipOne) ? 2 : 1);
+  // tiers: the scanning decoder, the walking one-launch decoder, the two-launch form (each follows streams the one in front cannot), the general kernels
+  int level = rq.noStreaming ? 0 : pickForm(ctx, rq.maxForm, rq.nRows, rq.nCols);
   while (level > 0)
   {
     bool handled = false, tried = false;
     DecodeRequest r = rq;
-    r.skipOne = level < 2;
+    r.maxForm = level;
+    if (level == 3) ctx.scanSkip = 0;    // (pickForm has just said 3: the request below must get the same answer)
     u32 bits = 0;
     const u32 src = decodeSpeculative(ctx, r, handled, tried, &bits);
     if (src != kOk) return src;
@@ -755,14 +794,15 @@ u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
     if (!tried) break;    // (not a request the streaming kernels take blind: decodeImpl looks at every band)
     if (bits == 0x200u) return kFailed;    // (decoded by the streaming kernels, and the checksum is wrong: no other tier would say anything else)
     if (bits & 0x100u) break;    // (the header says it is no band for the streaming kernels -- a mask, another mode: the other form would say the same)
-    level--;
+    level = lowerForm(ctx, level, rq.nRows, rq.nCols);
   }
   bool fellBack = false;
   u32 rc = decodeImpl(ctx, rq, level, fellBack);
   bool repeated = false;
   while (rc == kOk && fellBack && level > 0)
   {
-    repeated = --level == 0;
+    level = lowerForm(ctx, level, rq.nRows, rq.nCols);
+    repeated = level == 0;
     rc = decodeImpl(ctx, rq, level, fellBack);
   }
   if (rc == kOk) ctx.pathCount[(repeated || !ctx.lastDecodeStreamed) ? 3 : 2]++;
@@ -780,14 +820,15 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
     return kWrongParam;
   const int tbytes = dtSize(rq.dt);
   const u64 tileElems = (u64)rq.nRows * (u64)rq.nCols;
+  int batchForm = 0;
   auto decodeOne = [&](int t) -> u32
   {
     DecodeRequest one;
     one.dBlob = rq.dArena + rq.hOffsets[t]; one.blobSize = rq.hSizes[t]; one.dt = rq.dt; one.nDepth = 1; one.nCols = rq.nCols;
     one.nRows = rq.nRows; one.nBands = 1; one.nMasks = 0; one.dValidBytes = nullptr;
     one.dOut = (u8*)rq.dOut + (size_t)t * tileElems * tbytes;
-    one.noStreaming = !fastDecodeOneLaunch();    // the batch's kernels have just been tried: the two-launch form next (or, if the batch was that, the general kernels)
-    one.skipOne = true;
+    one.maxForm = batchForm - 1;                  // the batch's kernels have just been tried: the next form (or, if the batch was the two-launch form, the general kernels)
+    one.noStreaming = one.maxForm <= 0;
     return decodeDevice(ctx, one);
   };
   bool fastOk = fastDecodeEligible(rq.dt, 6, 8, rq.nRows, rq.nCols, 1, true) && ((uintptr_t)rq.dArena & 15) == 0
@@ -830,7 +871,8 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
     FastDecodeParams* dParams = reinterpret_cast<FastDecodeParams*>(dCells + 64);
     u32* dFallback = reinterpret_cast<u32*>(dCells + 64 + (size_t)n * sizeof(FastDecodeParams));
     const u32 epoch = ctx.nextEpoch();
-    if (!launchFastBands(ctx, fastDecodeOneLaunch(), rq.dt, rq.nRows, rq.nCols, rq.dArena, maxSize, (u32)n, dOff, dSize,
+    batchForm = pickForm(ctx, 3, rq.nRows, rq.nCols);
+    if (!launchFastBands(ctx, batchForm, rq.dt, rq.nRows, rq.nCols, rq.dArena, maxSize, (u32)n, dOff, dSize,
                          (u8*)rq.dOut + (size_t)t0 * tileElems * tbytes, dParams, dFallback, epoch))
       return kFailed;
     hipMemcpyAsync(pin, dCells, cellsBytes, hipMemcpyDeviceToHost, st);
@@ -846,7 +888,7 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
     {
       const u32 bits = fastFlagBits(hfb + 4 * i, epoch);
       const bool good = hp[i].ok && !bits && hp[i].checksumOk;
-      if (good) ctx.pathCount[2]++;
+      if (good) { ctx.pathCount[2]++; ctx.formCount[batchForm]++; }
       else
       {
         if (redo.empty())
@@ -859,6 +901,7 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
         redo.push_back(t0 + i);
       }
     }
+    if (batchForm == 3 && redo.size() > (size_t)n / 8) ctx.scanSkip = kScanSkip;    // (tiles the scanning decoder does not follow: the next batches start one tier down)
     for (int t : redo) { const u32 rc = decodeOne(t); if (rc != kOk) return rc; }    // (reuses the workspace: the batch is done with it)
   }
   return kOk;

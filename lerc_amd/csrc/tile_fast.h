@@ -266,12 +266,42 @@ LERC_HD u32 fastOneNumWG(u32 blobBytes, int typeBytes)
 LERC_HD u32 fastOneGroups(u32 nWG) { return (nWG + kOneGroup - 1u) / kOneGroup; }
 LERC_HD u32 fastOneWgStride(u32 bytesBound, int typeBytes) { return (fastOneNumWG(bytesBound, typeBytes) + 3u) & ~1u; }        // cells per tile
 LERC_HD u32 fastOneGroupStride(u32 bytesBound, int typeBytes) { return (fastOneGroups(fastOneNumWG(bytesBound, typeBytes)) + 3u) & ~1u; }    // group cells / accumulators per tile
+// The scanning decoder (tile_fast_decode_scan.hip), the first tier: a workgroup takes a PIECE of kScanPiece bytes of the blob, with
+// one block's length in front of it (the block that ends at the piece's first block begins there) and one behind it (the piece's
+// last block ends there).  No walks: every byte is looked at for the count byte of a bit-stuffed block header, and a block start
+// is where one candidate begins and another one ends.  The hand-offs are the one-launch decoder's (a cell per workgroup and per
+// group of kOneGroup workgroups, the groups' checksum accumulators).
+#ifndef LERC_SCAN_PIECE
+#ifdef LERC_SMALL_GROUPS
+#define LERC_SCAN_PIECE 8192               // (emulator builds: small streams then take several pieces)
+#else
+#define LERC_SCAN_PIECE 32768
+#endif
+#endif
+static const u32 kScanPiece = LERC_SCAN_PIECE;               // 32 KiB: three workgroups to a CU (51 KB of LDS each)
+static const u32 kScanThreads = kScanPiece / 64u;            // 64 bytes a thread
+LERC_HD u32 fastScanNumWG(u32 blobBytes) { return blobBytes ? (blobBytes + kScanPiece - 1u) / kScanPiece : 1u; }
+// cells per tile for either of the two one-launch decoders
+LERC_HD u32 fastAnyWgStride(u32 bytesBound, int typeBytes)
+{
+  const u32 a = fastOneNumWG(bytesBound, typeBytes), b = fastScanNumWG(bytesBound);
+  return ((a > b ? a : b) + 3u) & ~1u;
+}
+LERC_HD u32 fastAnyGroupStride(u32 bytesBound, int typeBytes)
+{
+  const u32 a = fastOneNumWG(bytesBound, typeBytes), b = fastScanNumWG(bytesBound);
+  return (fastOneGroups(a > b ? a : b) + 3u) & ~1u;
+}
 #ifndef LERC_DECODE_CHUNKS
 #define LERC_DECODE_CHUNKS 4
 #endif
 static const u32 kDecodeChunks = LERC_DECODE_CHUNKS;        // chunks whose blocks a workgroup of k_fast_decode decodes (divides kResolveWG)
 // longest block the streaming walk accepts: the raw form (the reference encoder never emits a longer one)
 constexpr u32 kFastWindow(int typeBytes) { return 2u + 64u * (u32)typeBytes; }
+
+// bytes staged in front of a piece of the scanning decoder and behind it (multiples of 32 / 16: bitmap words, 16-byte units)
+constexpr LERC_HD u32 scanPre(int typeBytes) { return (kFastWindow(typeBytes) + 31u) & ~31u; }
+constexpr LERC_HD u32 scanPost(int typeBytes) { return (kFastWindow(typeBytes) + 16u + 15u) & ~15u; }
 
 // sizes the host can bound without reading the blob (grids and buffers); the true values are in FastDecodeParams
 struct FastWalkPlan { u32 nChunks, nBlocks, nWaves, discChunks; };    // discChunks: chunks per discovery workgroup of this launch
@@ -351,5 +381,9 @@ void launchFastDecodeOne(int dt, int nRows, int nCols, const FastDecodeBatch& t,
                          const FastDecodeBuffers& b, void* out, hipStream_t st);
 void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
                       const FastDecodeBuffers& b, void* out, hipStream_t st);
+// the scanning decoder: rasters of whole 8 x 8 blocks
+bool fastDecodeScanEligible(int nRows, int nCols);
+void launchFastDecodeScan(int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
+                          const FastDecodeBuffers& b, void* out, hipStream_t st);
 
 }    // namespace lerc

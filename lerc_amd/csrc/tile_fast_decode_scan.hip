@@ -1,0 +1,769 @@
+// tile_fast_decode_scan.hip -- the streaming decoder's first tier: ONE launch, and no walk at all.
+//
+// The block stream stores no offsets (block k + 1 starts where block k ends; Lerc2::ReadTiles, Lerc2.cpp:1672-1713).  The two tiers
+// behind this one (tile_fast_decode_one.hip, tile_fast_decode.hip) find the block starts by letting block headers found in a few
+// windows WALK the stream -- chains of dependent steps, a dozen barriers, lists to settle which walk is the path.  Here every byte
+// of the stream is looked at once, in the registers it arrives in, and the chain is never followed:
+//   1. a workgroup of 512 threads takes a PIECE of 32 KiB of the blob (+ one block's length in front of it and behind it), every
+//      lane four or five 16-byte units; on the way to LDS the Fletcher32 terms of the piece, and the SCAN: "a byte 64 behind a byte
+//      10?nnnnn" -- the count byte of a bit-stuffed block of 64 values behind its bits byte (BitStuffer2.cpp:35-77) -- by exact
+//      byte-parallel arithmetic, 13 instructions a dword; units with a hit go to a queue (a ballot and one LDS atomic a wave);
+//   2. CANDIDATES, lane = unit with hits: the flag byte 2 + (bytes of the offset) in front of the count byte has to read "bit
+//      stuffed, that offset type" (Lerc2.cpp:1961-2021); the block's length follows from the bits byte (and the table size).  A
+//      candidate sets two bits: START[where it begins], END[where it ends];
+//   3. SURVIVORS = START & END: a block that begins where another one ends.  Every block of the path is one (its predecessor
+//      ends there: hence the block's length of bytes in front of the piece); of what the scan finds that is no block -- offset
+//      bytes that look like a flag byte in front of the same header, payload bytes: 15 to 30 a piece -- almost nothing is (it
+//      would have to begin where another false candidate ends: one piece in 60 of the uint16 raster, none of the float one);
+//      popcounts and one scan turn the bitmap into the list of the piece's block starts;
+//   4. CHECK, lane = block: the header in full (parseCode: ReadTile's and BitStuffer2::Decode's checks), and "this block ends
+//      where the next one of the list begins" -- the last one behind the piece.  A list that TILES its stretch of the stream and
+//      begins where the piece in front says its last block ends is the path, whatever the bitmaps looked like: the piece in
+//      front is right by the same argument, the first piece begins with the stream's first block, the last one has to end
+//      with the blob, and the blocks have to be as many as the raster has;
+//   5. where the list does not tile (a false survivor; blocks that are not bit-stuffed -- constant, all zero, raw -- which the
+//      scan does not see, and the block behind each of them, which has no END) ONE thread mends it: survivors inside a good
+//      block's extent are struck, gaps are walked block by block and what is found there entered, and if the list's first entry
+//      is the false one the mending starts from the second.  A piece that needs more than a few such steps gives up; the host
+//      then takes the band to the next tier (and keeps to it for a while: codec_decode.cpp);
+//   6. count out (an epoch-tagged cell: blocks of the piece, where its last block ends), the cells of the pieces in front added
+//      up -- the only wait --, then the pixels as in tile_fast_decode_one.hip: lane = V pixels of one block row.
+// Rasters whose rows / columns are no multiples of 8 keep to the next tier (their edge blocks have other counts).
+// Reference: Lerc2.cpp:1672-1713, :2025-2230; BitStuffer2.cpp:159-258, :476-540; Lerc2.cpp:1037-1064 (checksum).
+#include "tile_fast_decode_dev.h"
+#include <cstddef>
+
+namespace lerc {
+
+#if defined(LERC_PROBE) && !defined(HIPSIM)
+// tuning: per-workgroup time lines (constant-rate counter), read by tools/trace_decode_one.py
+static __device__ unsigned long long g_traceS[16 * 8192];
+extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_decode_scan(unsigned long long* out, int n)
+{ hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_traceS), sizeof(unsigned long long) * (size_t)n); }
+#define TRACES(slot) do { if (threadIdx.x == 0 && wg < 8192u) g_traceS[16 * wg + (slot)] = wall_clock64(); } while (0)
+#else
+#define TRACES(slot)
+#endif
+
+static const u32 kScanBadCap = 16, kScanFalseCap = 32, kScanInsCap = 64;
+
+template<class T> struct ScanGeom
+{
+  static constexpr int DT = DtOf<T>::v;
+  static constexpr u32 TB = (u32)sizeof(T), W = kFastWindow((int)sizeof(T));
+  static constexpr u32 P = kScanPiece, NT = kScanThreads;
+  static constexpr u32 PRE = scanPre((int)sizeof(T)), POST = scanPost((int)sizeof(T));
+  static constexpr u32 kBytes = PRE + P + POST, kUnits = kBytes / 16u;
+  static constexpr int kRounds = (int)((kUnits + NT - 1u) / NT);
+  static constexpr u32 kScanUnits = (PRE + P) / 16u + 1u;        // units the count byte of a block that begins in front of the piece's end can lie in
+  static constexpr u32 kMapWords = (kBytes + 31u) / 32u;
+  static constexpr u32 kOwnWord0 = PRE / 32u;
+  static constexpr u32 R = NT;                                    // blocks per decode round: one header per thread
+  static constexpr u32 kListCap = P / 16u, kQueueCap = P / 32u;
+  static_assert(PRE % 32u == 0u && POST % 16u == 0u && P % 2048u == 0u && NT % 64u == 0u, "units, bitmap words, waves");
+  static_assert(kBytes + 64u < 65535u, "16-bit positions");
+  static_assert(kUnits < 65536u && kScanUnits <= kUnits, "queue entries");
+};
+
+template<class T> struct ScanShared
+{
+  typedef ScanGeom<T> G;
+  alignas(16) u32 inAll[4 + G::kBytes / 4 + 4];      // [4 ...): the staged bytes; the word in front of them reads 0
+  alignas(16) u32 sb[G::kMapWords + 3];              // START; from step 3 on: START & END of the piece's own bytes
+  union U
+  {
+    alignas(16) u32 end[G::kMapWords + 3];           // steps 2 - 3
+    struct X                                         // the pixels, one round
+    {
+      double offs[G::R];
+      u32 code[G::R];                                // what the pixel loop wants to know of the block, 0 = bad
+      u32 at[G::R];                                  // raster offset (pixels) of the block's first pixel
+    } x;
+  } u;
+  union L
+  {
+    u32 queue[G::kQueueCap];                         // steps 1 - 2: unit | hits << 16
+    u16 list[G::kListCap + 8];                       // from step 3 on: the block starts, relative to the staged bytes
+  } l;
+  u16 badIdx[kScanBadCap], falseIdx[kScanFalseCap], insPos[kScanInsCap];
+  u32 wsum[G::NT / 64];
+  u64 fa[G::NT / 64], fb[G::NT / 64];
+  u64 part;                                          // sum of the cells: this group's in the low half, the groups' in front in the high half
+  u32 nQueue, nEnt, nBad[2], nFalse, nIns, over, bad, lost, exitRel, prevExit, mended;    // nBad: broken links found by the first / the second check
+  FastDecodeParams hp;                               // the band header, parsed in full by the first wave
+};
+
+// 0x80 in every byte of cur4 that reads 64 behind a byte 10?nnnnn, n != 0 (prev4: the dword in front of cur4)
+__device__ __forceinline__ u32 countByteHits(u32 cur4, u32 prev4)
+{
+  const u32 hdr4 = __builtin_amdgcn_alignbit(cur4, prev4, 24);                   // the bytes in front of cur4's
+  const u32 t = (cur4 ^ 0x40404040u) | ((hdr4 & 0xC0C0C0C0u) ^ 0x80808080u);      // a zero byte: 64 behind 10......
+  const u32 z = ((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu;               // 0x80 clear in the zero bytes, and only there
+  const u32 nz = ((hdr4 & 0x1F1F1F1Fu) + 0x1F1F1F1Fu) << 2;                         // 0x80 set where n != 0
+  return ~z & nz;
+}
+
+template<class T>
+__device__ __forceinline__ void
+fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols,
+             T* __restrict__ outPix, u32 wg)
+{
+  typedef ScanGeom<T> G;
+  constexpr int DT = G::DT;
+  constexpr u32 W = G::W, P = G::P, NT = G::NT, PRE = G::PRE, kUnits = G::kUnits, kMapWords = G::kMapWords;
+  constexpr u32 kWaves = NT / 64, kListCap = G::kListCap, kQueueCap = G::kQueueCap, R = G::R;
+  constexpr u32 RAW = 1u + 64u * G::TB;
+  u32* const s_in = S.inAll + 4;
+  auto& s_sb = S.sb; auto& s_end = S.u.end; auto& s_queue = S.l.queue; auto& s_list = S.l.list;
+  const int lane = laneId(), w = waveId();
+
+  // ---- the band header: every wave reads what the front part needs of it; the first wave reads it in full (Lerc2::ReadHeader's
+  // checks) while the staged bytes are on their way, and leaves the result in LDS (workgroup 0: also where the host wants it)
+  const HeadLite hl = parseHeadLite<DT>(blob, sizeGiven);
+  const u32 blobEnd = hl.blobEnd;
+  const bool ours = hl.ok && headLiteEligible<DT>(blob, hl.version, nRows, nCols);
+  if (wg == 0u && !ours && threadIdx.x == 0)      // (not a band of ours: say so)
+  {
+    const FastDecodeParams hp0 = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
+    storeParams<true>(b.params, hp0); if (b.hostParams) *b.hostParams = hp0;
+  }
+  const u32 nWG = fastScanNumWG(blobEnd);
+  if (!ours || wg >= nWG) return;                  // (the grid is sized for the largest stream the blob could hold)
+  TRACES(0);
+  const u32 pieceStart = wg * P;                   // blob offset of the piece's first own byte = of LDS byte PRE
+  const int version = (int)hl.version;
+  const bool v5 = version >= 5;
+  const u32 pattern = v5 ? 14u : 15u;
+  const u32 epoch = b.epoch;
+  const u64 tag = (u64)b.publishEpoch << 32;
+  const bool lastPiece = wg == nWG - 1u;
+  // positions are relative to the staged bytes: LDS byte r is blob byte pieceStart + r - PRE
+  const u32 blobRel = blobEnd - pieceStart + PRE;                                                    // the blob's end
+  const u32 dataRel = hl.dataBegin + PRE > pieceStart ? hl.dataBegin + PRE - pieceStart : 0u;        // the stream's first block (or 0: in front of all this)
+  const u32 pieceEndRel = PRE + P;
+
+  // ---- the staged bytes, all loads in flight at once (clipped to what the caller says is readable); a wave's first lane also
+  // asks for the dword in front of its unit (the other lanes get theirs from the lane in front)
+  constexpr int kRounds = G::kRounds;
+  uint4 x[kRounds];
+  u32 pvFirst[kRounds];
+#pragma unroll
+  for (int k = 0; k < kRounds; k++)
+  {
+    const u32 i = (u32)k * NT + threadIdx.x;
+    const i64 a = (i64)pieceStart - (i64)PRE + 16ll * (i64)i;
+    x[k] = make_uint4(0, 0, 0, 0);
+    pvFirst[k] = 0u;
+    if (i < kUnits && a >= 0)
+    {
+      if ((u64)a + 16ull <= sizeGiven) x[k] = *reinterpret_cast<const uint4*>(blob + a);
+      else if ((u64)a < sizeGiven)    // never read past the blob
+      {
+        u32 t4[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (u32 q = 0; q < 16; q++) if ((u64)a + q < sizeGiven) t4[q >> 2] |= (u32)blob[a + q] << (8 * (q & 3));
+        x[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+      }
+      if (lane == 0 && a >= 4 && (u64)a <= sizeGiven) pvFirst[k] = *reinterpret_cast<const u32*>(blob + a - 4);
+    }
+  }
+  if (w == 0)
+  {
+    const FastDecodeParams hpFull = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
+    if (lane == 0)
+    {
+      S.hp = hpFull;
+      if (wg == 0u)
+      {
+        // (the verdict on the checksum comes from the launch's last workgroup, microseconds later for a small blob: one writer
+        // per byte -- the host's copy, which travels over PCIe, gets everything BUT that word here (the host has zeroed it))
+        storeParams<true>(b.params, hpFull);
+        if (b.hostParams)
+        {
+          u64 wds[8];
+          memcpy(wds, &hpFull, 64);
+          static_assert(offsetof(FastDecodeParams, checksumOk) == 40 && sizeof(FastDecodeParams) == 64, "word 5 holds the verdict");
+#pragma unroll
+          for (int i = 0; i < 8; i++) if (i != 5) reinterpret_cast<volatile u64*>(b.hostParams)[i] = wds[i];
+        }
+      }
+    }
+  }
+  for (u32 i = threadIdx.x; i < kMapWords + 3u; i += NT) { s_sb[i] = 0u; s_end[i] = 0u; }
+  if (threadIdx.x < 4u) S.inAll[threadIdx.x] = 0u;
+  if (threadIdx.x == 0)
+  {
+    S.nQueue = 0u; S.nEnt = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
+    S.prevExit = kNoOffset; S.mended = 0u; S.part = 0ull;
+  }
+  __syncthreads();
+  if (!S.hp.ok) return;    // (not a band the streaming kernels take: the header says so in full only)
+
+  // ---- stage; Fletcher terms of the piece's own units (bytes 14 ... blobEnd - 1 of the blob are checksummed); scan
+  u32 fA = 0;
+  u64 fB = 0;
+  constexpr u32 ownUnit0 = PRE / 16u, ownUnit1 = (PRE + P) / 16u;
+  const bool inner = pieceStart != 0u && (u64)pieceStart + P <= blobEnd;    // no unit of this piece needs blanking
+#pragma unroll
+  for (int k = 0; k < kRounds; k++)
+  {
+    const u32 i = (u32)k * NT + threadIdx.x;
+    if (i < kUnits) *reinterpret_cast<uint4*>(&s_in[i * 4]) = x[k];
+    const u32 a = pieceStart + 16u * i - PRE;                                 // (own units: >= 0 and < 2^32)
+    if (inner)
+    {
+      if (i >= ownUnit0 && i < ownUnit1) fletcherUnit(x[k], (a - 14u) / 2u, fA, fB);    // unit at blob offset a holds words (a - 14) / 2 ...
+    }
+    else if (i >= ownUnit0 && i < ownUnit1 && a < blobEnd)
+    {
+      uint4 y = x[k];
+      if (a == 0 || a + 16 > blobEnd)    // blank what is not checksummed: the first 14 bytes, whatever lies behind the blob
+      {
+        u32 wd[4] = { y.x, y.y, y.z, y.w };
+#pragma unroll
+        for (u32 q = 0; q < 16; q++)
+          if (a + q < 14u || a + q >= blobEnd) wd[q >> 2] &= ~(0xFFu << (8 * (q & 3)));
+        y = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+      }
+      fletcherUnit(y, a ? (a - 14u) / 2u : 65528ull, fA, fB);             // (the first unit's index -7 as its residue mod 65535)
+    }
+    // the scan: count bytes of bit-stuffed block headers in this unit, a bit per byte -- bit k: byte 4 (k & 3) + (k >> 2)
+    {
+      u32 pv = dppMov<kDppWaveShr1>(x[k].w);
+      if (lane == 0) pv = pvFirst[k];
+      const u32 m0 = countByteHits(x[k].x, pv), m1 = countByteHits(x[k].y, x[k].x);
+      const u32 m2 = countByteHits(x[k].z, x[k].y), m3 = countByteHits(x[k].w, x[k].z);
+      const u32 z = (m0 >> 7) | ((m1 >> 7) << 1) | ((m2 >> 7) << 2) | ((m3 >> 7) << 3);
+      const u32 t = z | (z >> 4);
+      const u32 hits = (t & 0xFFu) | ((t >> 8) & 0xFF00u);
+      const bool has = hits != 0u && i < G::kScanUnits;
+      const u64 bal = __builtin_amdgcn_ballot_w64(has);
+      if (bal != 0ull)    // (wave-uniform)
+      {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&S.nQueue, (u32)__popcll(bal));
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        const u32 slot = base + (u32)__popcll(bal & laneMaskLt());
+        if (has)
+        {
+          if (slot < kQueueCap) s_queue[slot] = i | (hits << 16);
+          else S.over = 1u;
+        }
+      }
+    }
+  }
+  {
+    // (no reduction mod 65535 before the sums: a lane holds 5 units, A < 2^23 and B < 2^54 per lane)
+    const u64 A = waveSum(fA), B = waveSum(fB);
+    if (lane == 0) { S.fa[w] = A; S.fb[w] = B; }
+  }
+  __syncthreads();
+  TRACES(1);
+  if (threadIdx.x == 0)
+  {
+    // this workgroup's checksum terms: one atomic nobody waits for (the launch's last workgroup folds the accumulators)
+    u64 A = 0, B = 0;
+#pragma unroll
+    for (u32 k = 0; k < kWaves; k++) { A += S.fa[k]; B += S.fb[k]; }
+    A %= 65535u; B %= 65535u;
+    if (wg == 0u) drainVmem();    // (the band's parameters have arrived)
+    __hip_atomic_fetch_add(b.wgAcc + wg / kOneGroup, A | (B << 24) | (1ull << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  // ---- candidates: lane = unit with hits.  A bit-stuffed block reads: flag byte (bits 0-1 == 1, bits 6-7 the type of the
+  // offset, bit 2 clear from codec 5 on), the offset in that type, the bits byte 10?nnnnn (bit 5: look-up table), the count 64,
+  // [table size + 1, table,] payload (Lerc2.cpp:1961-2021, BitStuffer2.cpp:35-153).  The count byte stands 2 + (bytes of the
+  // offset) behind the flag byte: each offset type is tried.  The twelve bytes in front of the count byte's successor come out
+  // of four LDS words, shifted so that the byte 10 in front of the count byte is byte 0.
+  {
+    const u32 nQ = min(S.nQueue, kQueueCap);
+    for (u32 h = threadIdx.x; h < nQ; h += NT)
+    {
+      const u32 ent = s_queue[h], unit = ent & 0xFFFFu;
+      u32 hits = ent >> 16;
+      while (hits)
+      {
+        const u32 k = (u32)__ffs((int)hits) - 1u;
+        hits &= hits - 1u;
+        const u32 q = 16u * unit + 4u * (k & 3u) + (k >> 2);                // the count byte
+        const u32 wi = (q + 6u) >> 2, sh = 8u * ((q + 6u) & 3u);             // (word index into inAll: 16 bytes of zeros in front)
+        const u32 w0 = S.inAll[wi], w1 = S.inAll[wi + 1], w2 = S.inAll[wi + 2], w3 = S.inAll[wi + 3];
+        const u32 a0 = __builtin_amdgcn_alignbit(w1, w0, sh), a1 = __builtin_amdgcn_alignbit(w2, w1, sh), a2 = __builtin_amdgcn_alignbit(w3, w2, sh);
+        const u32 tB = (a2 >> 8) & 0xFFu, nb = tB & 31u, lut = (tB >> 5) & 1u;
+        const u32 nLut = ((a2 >> 24) - 1u) & 0xFFu;                          // valid: 1 ... 254
+        const bool okLut = (lut == 0u) | ((nLut - 1u) < 254u);
+        const u32 payload = lut ? 1u + ((nLut * nb + 7u) >> 3) + 8u * (u32)bitLen(nLut) : 8u * nb;
+#pragma unroll
+        for (u32 tc = 0; tc < 4; tc++)
+        {
+          const u32 offB = (offBytesTable<DT>() >> (4u * tc)) & 15u;
+          if (offB == 0u) continue;
+          const u32 m = 8u - offB;                                           // the flag byte is byte m of the twelve
+          const u32 flag = ((m < 4u ? a0 : m < 8u ? a1 : a2) >> (8u * (m & 3u))) & 0xFFu;
+          const u32 len = 3u + offB + payload;
+          const bool ok = (flag & 3u) == 1u && (flag >> 6) == tc && !(v5 && (flag & 4u)) && okLut && len <= RAW && q >= 2u + offB;
+          const u32 p = q - 2u - offB, e = p + len;
+          if (ok && p >= dataRel && p < pieceEndRel && e <= blobRel)
+          {
+            atomicOr(&s_sb[p >> 5], 1u << (p & 31u));
+            atomicOr(&s_end[e >> 5], 1u << (e & 31u));                      // (e < pieceEndRel + W: inside the bitmap)
+          }
+        }
+      }
+    }
+    if (threadIdx.x == 0 && dataRel >= PRE && dataRel < pieceEndRel)    // the stream's first block, whatever it is
+    {
+      atomicOr(&s_sb[dataRel >> 5], 1u << (dataRel & 31u));
+      atomicOr(&s_end[dataRel >> 5], 1u << (dataRel & 31u));
+    }
+  }
+  __syncthreads();
+  TRACES(2);
+
+  // ---- survivors of the piece's own bytes: a thread's two bitmap words; their list by popcounts and one scan
+  const u32 myWord = G::kOwnWord0 + 2u * threadIdx.x;
+  { s_sb[myWord] &= s_end[myWord]; s_sb[myWord + 1u] &= s_end[myWord + 1u]; }
+  auto buildList = [&]()
+  {
+    const u32 s0 = s_sb[myWord], s1 = s_sb[myWord + 1u];
+    const u32 c = (u32)__popc(s0) + (u32)__popc(s1);
+    const u32 inc = waveInclusiveScan(c);
+    __syncthreads();                                  // (the queue, which the list lies on, has been read by everybody)
+    if (lane == 63) S.wsum[w] = inc;
+    __syncthreads();
+    u32 idx = inc - c;
+    for (int k = 0; k < w; k++) idx += S.wsum[k];
+    const u32 pos0 = PRE + 64u * threadIdx.x;
+    u32 m = s0;
+    while (m) { const u32 bt = (u32)__ffs((int)m) - 1u; m &= m - 1u; if (idx < kListCap) s_list[idx] = (u16)(pos0 + bt); idx++; }
+    m = s1;
+    while (m) { const u32 bt = (u32)__ffs((int)m) - 1u; m &= m - 1u; if (idx < kListCap) s_list[idx] = (u16)(pos0 + 32u + bt); idx++; }
+    if (threadIdx.x == NT - 1u) { S.nEnt = min(idx, kListCap); if (idx > kListCap) S.over = 1u; }
+    __syncthreads();
+  };
+  buildList();
+  TRACES(3);
+
+  // ---- every block's header in full, lane = block: length, mode, bits, offset (ReadTile's and BitStuffer2::Decode's checks), and
+  // "the blocks tile the stream": a block ends where the next one of the list begins, the last one behind the piece (the
+  // blob's last piece: with the blob).  What the pixel loop wants to know of the first R blocks is kept.
+  const FastDecodeParams hp = S.hp;
+  const struct { int nCols, version; double invScale, zMaxHdr; } p = { (int)hp.nCols, (int)hp.version, hp.invScale, hp.zMaxHdr };
+  typedef DCfg<T> C;
+  constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
+  auto& s_offs = S.u.x.offs; auto& s_code = S.u.x.code; auto& s_at = S.u.x.at;
+  // the block at list entry f: its length, or 0 if it is none; keep: what the pixel loop needs goes to slot t
+  auto parseBlock = [&](u32 pos, bool keep, u32 t) -> u32
+  {
+    u32 h0, h1, h2;
+    ldsHeader<DT>(s_in, pos, h0, h1, h2);
+    u32 code = parseCode<DT>(h0, h1, h2, p.version);
+    if (pos + codeLen(code) > blobRel) code = 0u;
+    const u32 len = codeLen(code);
+    if (keep)
+    {
+      double offset = 0;
+      const u32 mode = codeMode(code);
+      if (code && (mode == 1 || mode == 3))
+      {
+        const u32 offB = codeOffBytes(code);
+        u64 bits = (((u64)h1 << 32) | h0) >> 8;
+        if (DT == DT_Double) bits |= (u64)h2 << 56;
+        if (offB < 8) bits &= (1ull << (8 * offB)) - 1;
+        offset = typedFromBits(bits, typeUsed(DT, (int)((h0 >> 6) & 3u)));
+      }
+      // in one word: where the payload begins (16: byte among the staged ones; the first raw value of a raw block), bits per
+      // value (5) << 16, mode (2) << 21, look-up table << 23, "plain" << 24 -- bit-stuffed without a table, a lane's V values
+      // inside 64 bits, and not even the largest value nb bits can hold reaches the header's zMax, so the pixels need no clamp
+      // -- and bit 31 (0: no such block)
+      u32 word = 0u;
+      if (code)
+      {
+        const u32 nb = codeBits(code), lutB = codeLut(code);
+        bool plainB = false;
+        if (mode == 1)
+        {
+          const u32 qTop = nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+          const bool below = (DT >= DT_Float) ? (offset + (double)qTop * p.invScale < p.zMaxHdr)
+                                              : ((i64)offset + (i64)qTop * (i64)p.invScale < (i64)p.zMaxHdr);
+          plainB = below && !lutB && (u32)V * nb <= 64u;
+        }
+        const u32 pay = pos + ((mode == 1u) ? 3u + codeOffBytes(code) + lutB : 1u);
+        word = (pay & 0xFFFFu) | (nb << 16) | (mode << 21) | (lutB << 23) | ((plainB ? 1u : 0u) << 24) | 0x80000000u;
+      }
+      s_offs[t] = offset;
+      s_code[t] = word;
+      s_at[t] = (h0 >> 2) & pattern;     // (the signature, until the block's place is known)
+    }
+    return len;
+  };
+  auto tilePass = [&](u32 pass)
+  {
+    const u32 nEnt = S.nEnt;
+    for (u32 f = threadIdx.x; f < nEnt; f += NT)
+    {
+      const u32 pos = (u32)s_list[f];
+      const u32 len = parseBlock(pos, f < R, f);
+      const u32 ext = pos + len;
+      const bool last = f + 1u == nEnt;
+      const u32 nxt = last ? 0u : (u32)s_list[f + 1u];
+      const bool ok = len != 0u && (last ? (lastPiece ? ext == blobRel : ext >= pieceEndRel) : ext == nxt);
+      if (!ok) { const u32 at = atomicAdd(&S.nBad[pass], 1u); if (at < kScanBadCap) S.badIdx[at] = (u16)f; }
+      if (last) S.exitRel = ext;
+    }
+    __syncthreads();
+  };
+  __syncthreads();    // (the bitmap of ENDs, which the round's arrays lie on, has been read by everybody)
+  tilePass(0u);
+  TRACES(4);
+
+  // ---- a list that does not tile is mended by one thread (see the head of the file): false survivors struck, gaps walked.
+  // Nothing is written until the whole list has been gone through; then the survivors' bitmap is corrected and the list built
+  // again from it.
+  if (S.nBad[0] != 0u)
+  {
+    if (threadIdx.x == 0)
+    {
+      const u32 n = S.nEnt, nBad = S.nBad[0];
+      bool good = false;
+      // (the stream's first block is what it is; any other piece's first survivor may be the false one -- and the second)
+      const u32 tries = (S.over || nBad > kScanBadCap || n == 0u) ? 0u : ((dataRel >= PRE && dataRel < pieceEndRel) ? 1u : 3u);
+      for (u32 start = 0; start < tries && start < n && !good; start++)
+      {
+        u32 nFalse = start, nIns = 0u, cur = start, exitRel = S.exitRel;
+        bool fail = start > kScanFalseCap;
+        while (!fail)
+        {
+          u32 a = 0xFFFFu;    // the first entry from cur on whose link to the next one is broken
+          for (u32 j = 0; j < nBad; j++) { const u32 f = (u32)S.badIdx[j]; if (f >= cur && f < a) a = f; }
+          if (a == 0xFFFFu) { good = true; break; }
+          const u32 pa = (u32)s_list[a], la = parseBlock(pa, false, 0u);
+          if (la == 0u) { fail = true; break; }
+          const u32 ea = pa + la;
+          u32 k = a + 1u;
+          while (k < n && (u32)s_list[k] < ea && !fail)    // survivors inside this block: none of them is one
+          {
+            if (nFalse < kScanFalseCap) S.falseIdx[nFalse] = (u16)k; else fail = true;
+            nFalse++; k++;
+          }
+          if (fail) break;
+          // what lies between this block's end and the next survivor (or the piece's end): blocks the scan cannot see
+          const u32 target = k < n ? (u32)s_list[k] : (lastPiece ? blobRel : pieceEndRel);
+          u32 xx = ea;
+          while (xx < target && !fail)
+          {
+            const u32 lx = xx < pieceEndRel ? parseBlock(xx, false, 0u) : 0u;
+            if (lx == 0u || nIns >= kScanInsCap) { fail = true; break; }
+            S.insPos[nIns++] = (u16)xx;
+            xx += lx;
+          }
+          if (fail) break;
+          if (k < n) { if (xx != target) { fail = true; break; } cur = k; }
+          else
+          {
+            if (lastPiece ? xx != blobRel : xx < pieceEndRel) { fail = true; break; }
+            exitRel = xx; good = true; break;
+          }
+        }
+        if (good)
+        {
+          for (u32 j = 0; j < start; j++) S.falseIdx[j] = (u16)j;
+          for (u32 j = 0; j < nFalse; j++) { const u32 pos = (u32)s_list[S.falseIdx[j]]; s_sb[pos >> 5] &= ~(1u << (pos & 31u)); }
+          for (u32 j = 0; j < nIns; j++) { const u32 pos = (u32)S.insPos[j]; s_sb[pos >> 5] |= 1u << (pos & 31u); }
+          (void)exitRel;
+        }
+      }
+      if (!good) S.bad = 1u;
+      S.mended = good ? 1u : 0u;
+    }
+    __syncthreads();
+    if (S.mended)
+    {
+      buildList();
+      tilePass(1u);
+      if (S.nBad[1] != 0u) S.bad = 1u;    // (mended once; a list that still does not tile goes the long way)
+    }
+  }
+
+  // ---- count out: blocks of this piece, and where its last block ends (relative to the piece's end)
+  const u32 total = S.bad ? 0u : S.nEnt;
+  if (threadIdx.x == 0)
+  {
+    const u32 ex = S.exitRel >= pieceEndRel ? min(S.exitRel - pieceEndRel, 0xFFFFu) : 0xFFFFu;
+    publish64(b.wgCell + wg, tag | ((u64)ex << 16) | (u64)min(total, 0xFFFFu));
+  }
+  // the first round's block places need the cells of the pieces in front -- those of this group, and one per group in front; the
+  // piece right in front also says where its last block ends: this piece's first block has to begin there
+  const u32 grp = wg / kOneGroup, g0 = grp * kOneGroup, nIn = wg - g0;
+  {
+    u64 part = 0;
+    bool lost = false;
+    const u32 nCells = nIn + grp + ((nIn == 0u && wg != 0u) ? 1u : 0u);
+    for (u32 i = threadIdx.x; i < nCells; i += NT)
+    {
+      const u64* pc = i < nIn ? b.wgCell + g0 + i : i < nIn + grp ? b.wgGroupCell + (i - nIn) : b.wgCell + (wg - 1u);
+      u64 c = observe64(pc);
+      for (u32 spin = 0; (u32)(c >> 32) != epoch && spin < b.spinLimit; spin++)
+      {
+        __builtin_amdgcn_s_sleep(4);
+        c = observe64(pc);
+      }
+      if ((u32)(c >> 32) != epoch) { lost = true; c = 0; }
+      else if (i == nIn - 1u || i == nIn + grp) S.prevExit = ((u32)c >> 16) & 0xFFFFu;    // (the piece right in front)
+      if (i < nIn + grp) part += i < nIn ? (u64)((u32)c & 0xFFFFu) : ((u64)(u32)c << 32);    // (a piece's cell: exit (16) | blocks (16))
+    }
+    if (__any(lost) && lane == 0) S.lost = 1u;
+    if (nCells != 0u)
+    {
+      part = waveSum(part);
+      if (lane == 0 && part) atomicAdd((unsigned long long*)&S.part, (unsigned long long)part);
+    }
+  }
+  __syncthreads();
+  TRACES(5);
+  if (S.lost)    // gave up waiting (never seen; the general path takes the band)
+  {
+    if (threadIdx.x == 0) raiseFlag(b, 3);
+    return;
+  }
+  const u32 inGroup = (u32)S.part, base = (u32)(S.part >> 32) + inGroup;
+  if (threadIdx.x == 0)
+  {
+    if (wg == g0 + kOneGroup - 1u) publish64(b.wgGroupCell + grp, tag | (u64)(inGroup + total));    // this group's total, for the groups behind
+    if (S.over) raiseFlag(b, 0);
+    bool bad = S.bad != 0u;
+    // where this piece's blocks begin: with the stream (the first piece), else where the piece in front says its last block ends
+    const u32 first = total ? (u32)s_list[0] : S.exitRel;
+    if (wg == 0u) bad = bad || first != dataRel;
+    else bad = bad || S.prevExit == 0xFFFFu || first != PRE + S.prevExit;
+    if (total == 0u && !lastPiece) bad = true;    // (a piece is longer than any block)
+    if (bad) raiseFlag(b, 1);
+    // the pieces hold all the raster's blocks, or the band goes the long way
+    if (lastPiece && (base + total != hp.nBlocks || S.exitRel != blobRel)) raiseFlag(b, 2);
+  }
+
+  // ---- rounds of at most R blocks (cut on multiples of BPW blocks of the RASTER, like the wave tiles below)
+  const bool pow2 = (hp.nTH & (hp.nTH - 1u)) == 0u;
+  const u32 thShift = 31u - (u32)__clz((int)hp.nTH);
+  const int r = lane >> 3, c = lane & 7, bb = c / LPR, h = c % LPR;
+  const i64 invI = (i64)p.invScale, zMaxI = (i64)p.zMaxHdr;
+  bool bad = false;
+  for (u32 fLo = 0; fLo < total; )
+  {
+    const u32 fHi = min(total, ((base + fLo + R) / (u32)BPW) * (u32)BPW - base);
+    // ---- the blocks' places: lane = block (the first round's headers are parsed already)
+    {
+      const u32 f = fLo + threadIdx.x;
+      if (f < fHi)
+      {
+        const u32 t = threadIdx.x;
+        if (fLo != 0u) (void)parseBlock((u32)s_list[f], true, t);
+        u32 code = s_code[t];
+        const u32 sigHdr = s_at[t];
+        const u32 blk = base + f;          // index of the block in the raster
+        const u32 it = pow2 ? (blk >> thShift) : blk / hp.nTH, jt = blk - it * hp.nTH;
+        if (sigHdr != (jt & pattern) || blk >= hp.nBlocks) code = 0;    // signature = (j0 >> 3) & pattern, j0 = 8 jt
+        if (code == 0u) { s_code[t] = 0u; bad = true; }
+        s_at[t] = code ? (it * 8u) * (u32)p.nCols + jt * 8u : kNoOffset;
+      }
+    }
+    __syncthreads();
+    // ---- pixels: a wave takes BPW blocks at a time, a lane V consecutive pixels of one raster row of one block.  Wave tiles
+    // lie on multiples of BPW blocks of the raster: a tile row is then a whole 128-byte line of the output
+    const u32 blkLo = base + fLo, blkHi = base + fHi;
+    const u32 g1 = (blkHi + BPW - 1) / BPW;
+    for (u32 g = blkLo / BPW + (u32)w; g < g1; g += kWaves)
+    {
+      const u32 blk = g * BPW + (u32)bb;
+      const bool have = blk >= blkLo && blk < blkHi;
+      const u32 t = have ? blk - blkLo : 0u;         // (the tile's blocks outside the round: lanes that do nothing)
+      const u32 code = have ? s_code[t] : 0u;        // (parseBlock's word)
+      const double offset = s_offs[t];
+      const u32 at0 = s_at[t];
+      const u32 nbC = (code >> 16) & 31u, mode = (code >> 21) & 3u, lut = (code >> 23) & 1u;
+      const u32 pbit = 8u * (code & 0xFFFFu);        // payload / first raw value
+      const int e0 = r * 8 + h * V;
+      T v[V];
+#pragma unroll
+      for (int k = 0; k < V; k++) v[k] = T(0);
+      // the common case, all blocks of the wave alike: bit-stuffed without a table, the lane's V values inside 64 bits, no
+      // clamp -- three words of the stream, one funnel shift each way, V shifts
+      const bool plain = ((code >> 24) & 1u) != 0u;
+      if (__all(plain || !code))
+      {
+        if (code)
+        {
+          const u32 nb = nbC;
+          const u32 bit0 = pbit + (u32)e0 * nb, wi = bit0 >> 5;
+          const u32 x0 = s_in[wi], x1 = s_in[wi + 1], x2 = s_in[wi + 2];
+          const u64 all = ((u64)__builtin_amdgcn_alignbit(x2, x1, bit0) << 32) | __builtin_amdgcn_alignbit(x1, x0, bit0);
+          const u32 mask = nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+          const i64 offI = (i64)offset;
+#pragma unroll
+          for (int k = 0; k < V; k++)
+          {
+            const u32 q = (u32)(all >> ((u32)k * nb)) & mask;
+            if (DT >= DT_Float) v[k] = (T)(offset + (double)q * p.invScale);    // Lerc2.cpp:2159-2160, no contraction
+            else v[k] = (T)(offI + (i64)q * invI);
+          }
+          struct alignas(sizeof(T) * V) Vec { T e[V]; };
+          Vec o;
+#pragma unroll
+          for (int k = 0; k < V; k++) o.e[k] = v[k];
+          DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
+        }
+      }
+      else if (code)
+      {
+        if (mode == 0)
+        {
+#pragma unroll
+          for (int k = 0; k < V; k++)
+          {
+            const u32 bp = pbit + (u32)(e0 + k) * 8u * (u32)sizeof(T);
+            u64 bits = ldsBits(s_in, bp, 32);
+            if (sizeof(T) == 8) bits |= (u64)ldsBits(s_in, bp + 32, 32) << 32;
+            else if (sizeof(T) < 4) bits &= (1ull << (8 * sizeof(T))) - 1;
+            memcpy(&v[k], &bits, sizeof(T));
+          }
+        }
+        else if (mode == 3)
+        {
+#pragma unroll
+          for (int k = 0; k < V; k++) v[k] = (T)offset;
+        }
+        else if (mode == 1)
+        {
+          const int nb = (int)nbC;
+          const i64 offI = (i64)offset;
+          if (!lut)
+          {
+#pragma unroll
+            for (int k = 0; k < V; k++)
+              v[k] = dequant<T>(offset, ldsBits(s_in, pbit + (u32)(e0 + k) * (u32)nb, nb), p.invScale, p.zMaxHdr, offI, invI, zMaxI);
+          }
+          else
+          {
+            const u32 nLut = (ldsBits(s_in, pbit - 8u, 8) - 1u) & 0xFFu;    // (the byte in front of the table: its size + 1)
+            const int nbIdx = bitLen(nLut);
+            const u32 idxBit = pbit + 8u * ((nLut * (u32)nb + 7) >> 3);
+#pragma unroll
+            for (int k = 0; k < V; k++)
+            {
+              u32 ix = ldsBits(s_in, idxBit + (u32)(e0 + k) * (u32)nbIdx, nbIdx);
+              if (ix > nLut) { ix = 0; bad = true; }    // the reference would read outside its table here
+              const u32 q = ix ? ldsBits(s_in, pbit + (ix - 1) * (u32)nb, nb) : 0u;
+              v[k] = dequant<T>(offset, q, p.invScale, p.zMaxHdr, offI, invI, zMaxI);
+            }
+          }
+        }
+        struct alignas(sizeof(T) * V) Vec { T e[V]; };
+        Vec o;
+#pragma unroll
+        for (int k = 0; k < V; k++) o.e[k] = v[k];
+        DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
+      }
+    }
+    fLo = fHi;
+    if (fLo < total) __syncthreads();    // (the round's arrays are taken again)
+  }
+  TRACES(6);
+  if (__any(bad) && lane == 0) raiseFlag(b, 3);
+
+  // ---- checksum: the launch's last workgroup waits for everybody's terms (they were sent off microseconds after each
+  // workgroup started), folds them and clears the accumulators for the next call (Lerc2.cpp:1037-1064)
+  if (!lastPiece) return;
+  __syncthreads();    // (S.fa / S.fb are free)
+  {
+    const u32 nGroups = fastOneGroups(nWG);
+    u64 A = 0, B = 0;
+    bool lostF = false;
+    for (u32 i = threadIdx.x; i < nGroups; i += NT)
+    {
+      const u64 want = (u64)min(kOneGroup, nWG - i * kOneGroup);
+      u64 v = observe64(b.wgAcc + i);
+      for (u32 spin = 0; (v >> 48) != want && spin < (1u << 22); spin++)
+      {
+        __builtin_amdgcn_s_sleep(8);
+        v = observe64(b.wgAcc + i);
+      }
+      if ((v >> 48) != want) lostF = true;
+      publish64(b.wgAcc + i, 0ull);
+      A += v & 0xFFFFFFull; B += (v >> 24) & 0xFFFFFFull;
+    }
+    A = waveSum(A % 65535u); B = waveSum(B % 65535u);
+    if (lane == 0) { S.fa[w] = A; S.fb[w] = B; }
+    if (__any(lostF) && lane == 0) raiseFlag(b, 3);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    A = 0; B = 0;
+    for (u32 i = 0; i < kWaves; i++) { A += S.fa[i]; B += S.fb[i]; }
+    A %= 65535u; B %= 65535u;
+    const u64 N = ((u64)(blobEnd - 14u) + 1) / 2;
+    u64 s1 = A, s2 = ((N % 65535u) * A + 65535u - B) % 65535u;
+    if (s1 == 0) s1 = 0xffff;
+    if (s2 == 0) s2 = 0xffff;
+    const u32 good = ((u32)((s2 << 16) | s1) == S.hp.expectChecksum) ? 1u : 0u;
+    publish32(&b.params->checksumOk, good);
+    if (b.hostParams) b.hostParams->checksumOk = good;
+  }
+}
+
+// blockIdx.y = tile of a batch (one raster: a batch of 1); each tile has its own slice of every buffer
+#ifdef HIPSIM
+#define LERC_SCAN_SGPR_CAP
+#else
+#define LERC_SCAN_SGPR_CAP __attribute__((amdgpu_num_sgpr(80)))
+#endif
+template<class T>
+__global__ void __launch_bounds__(kScanThreads) LERC_SCAN_SGPR_CAP
+k_fast_decode_scan(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 sizeGiven, int nRows, int nCols, T* __restrict__ outPix)
+{
+  const size_t tile = blockIdx.y;
+  b.params += tile; b.fallback += 4 * tile;
+  b.wgCell += tile * b.wgStride;
+  b.wgGroupCell += tile * b.wgGroupStride;
+  b.wgAcc += tile * b.wgGroupStride;
+  if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
+  __shared__ ScanShared<T> sm;
+  fastScanBody<T>(sm, b, blob, sizeGiven, nRows, nCols, outPix + tile * t.tileElems, blockIdx.x);
+}
+
+template<class T>
+static void launchFastDecodeScanT(int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven, const FastDecodeBuffers& b, void* out,
+                                  hipStream_t st)
+{
+  const dim3 grid(fastScanNumWG(sizeGiven), t.nTiles), block(kScanThreads);    // (sizeGiven: the largest blob of the batch)
+  hipLaunchKernelGGL((k_fast_decode_scan<T>), grid, block, 0, st, b, t, blob, sizeGiven, nRows, nCols, (T*)out);
+}
+
+// diagnostic: workgroups of the float kernel a CU holds, by the runtime's count
+extern "C" __attribute__((visibility("default"))) int lerc_amd_probe_decode_scan_residency()
+{
+#ifdef HIPSIM
+  return 0;
+#else
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fast_decode_scan<float>, (int)kScanThreads, 0) != hipSuccess) return -1;
+  return n;
+#endif
+}
+
+bool fastDecodeScanEligible(int nRows, int nCols) { return nRows % 8 == 0 && nCols % 8 == 0; }
+
+void launchFastDecodeScan(int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
+                          const FastDecodeBuffers& b, void* out, hipStream_t st)
+{
+  switch (dt)
+  {
+    case DT_Short:  launchFastDecodeScanT<short>(nRows, nCols, t, blob, sizeGiven, b, out, st); break;
+    case DT_UShort: launchFastDecodeScanT<unsigned short>(nRows, nCols, t, blob, sizeGiven, b, out, st); break;
+    case DT_Int:    launchFastDecodeScanT<int>(nRows, nCols, t, blob, sizeGiven, b, out, st); break;
+    case DT_UInt:   launchFastDecodeScanT<unsigned int>(nRows, nCols, t, blob, sizeGiven, b, out, st); break;
+    case DT_Float:  launchFastDecodeScanT<float>(nRows, nCols, t, blob, sizeGiven, b, out, st); break;
+    case DT_Double: launchFastDecodeScanT<double>(nRows, nCols, t, blob, sizeGiven, b, out, st); break;
+    default: break;
+  }
+}
+
+}    // namespace lerc

@@ -62,6 +62,14 @@ class LercLib:
         self.lib.lerc_amd_path_counters(None, out)
         return tuple(int(v) for v in out)
 
+    def decode_forms(self):
+        """lerc_amd only: bands / tiles decoded by (unused, the two-launch form, the walking one-launch decoder, the scanning decoder)"""
+        out = (ct.c_ulonglong * 4)()
+        self.lib.lerc_amd_decode_forms.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+        self.lib.lerc_amd_decode_forms.restype = None
+        self.lib.lerc_amd_decode_forms(None, out)
+        return tuple(int(v) for v in out)
+
     def last_note(self):
         self.lib.lerc_amd_last_note.argtypes = [ct.c_void_p]
         self.lib.lerc_amd_last_note.restype = ct.c_char_p
