@@ -114,6 +114,7 @@ static bool launchFastBands(Context& ctx, int form, int dt, int nRows, int nCols
   fbuf.discCell = nullptr;
   fbuf.testRewalk = (fastTestGiveUp() & 4u) ? 1u : 0u;
   fbuf.wgCell = fbuf.wgGroupCell = fbuf.wgAcc = nullptr;
+  fbuf.scanTicket = nullptr;
   fbuf.wgStride = fbuf.wgGroupStride = 0;
   // (epoch-tagged cells, never cleared: they live as long as the context and share its area with the encoder's)
   if (form >= 2)
@@ -124,8 +125,9 @@ static bool launchFastBands(Context& ctx, int form, int dt, int nRows, int nCols
     fbuf.wgStride = (u32)sWg; fbuf.wgGroupStride = (u32)sGrp;
     fbuf.wgCell = (u64*)ctx.persistentState(1, (nT * (sWg + sGrp) + 8) * 8);
     fbuf.wgGroupCell = fbuf.wgCell ? fbuf.wgCell + nT * sWg : nullptr;
-    fbuf.wgAcc = (u64*)ctx.persistentState(0, (nT * sGrp + 8) * 8);
+    fbuf.wgAcc = (u64*)ctx.persistentState(0, (nT * sGrp + 16) * 8);
     if (!fbuf.wgCell || !fbuf.wgAcc) return false;
+    fbuf.scanTicket = reinterpret_cast<u32*>(fbuf.wgAcc + nT * sGrp + 8);
     fbuf.recs = nullptr; fbuf.lists = nullptr; fbuf.chunkCell = fbuf.groupCell = fbuf.waveFletcher = nullptr;
     if (form == 3)
     {

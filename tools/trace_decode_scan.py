@@ -32,7 +32,7 @@ n_wg = (n + piece - 1) // piece
 tt = t[:min(n_wg, rows)]
 tt = tt[tt[:, 0] > 0]
 t0 = tt[:, 0].min()
-us = (tt[:, :7] - t0) / 100.0
+us = (tt[:, :7] - t0) / 100.0  # (items in ticket order)
 names = ["start -> staged, Fletcher, scan", "candidates", "survivors -> list", "headers + tiling check (+ mending)", "cells of the pieces in front", "places + pixels"]
 print(f"decode_scan: {len(tt)} workgroups traced, span {us[:, 6].max():.1f} us, mean life {(us[:, 6] - us[:, 0]).mean():.2f} us")
 for k, nm in enumerate(names):
