@@ -89,7 +89,7 @@ template<class T> struct ScanShared
   u32 wsum[G::NT / 64];
   u64 fa[G::NT / 64], fb[G::NT / 64];
   u64 part;                                          // sum of the cells: this group's in the low half, the groups' in front in the high half
-  u32 tk[3];                                         // tickets: this item, the next one, the one behind that
+  u32 tk[2];                                         // the ticket drawn during an item, by turns
   u32 nQueue, nEnt, nBad[2], nFalse, nIns, over, bad, lost, exitRel, prevExit, mended;    // nBad: broken links found by the first / the second check
   FastDecodeParams hp;                               // the band header, parsed in full by the first wave
 };
@@ -140,18 +140,20 @@ k_fast_decode_scan(FastDecodeBuffers b0, FastDecodeBatch t, ScanLaunch sl, const
   const int lane = laneId(), w = waveId();
   const u32 ppt = sl.piecesPerTile;
 
-  // ---- tickets: a workgroup holds the item it works on and the next one (whose bytes it asks for a whole item ahead), and draws
-  // the one behind that while it works; every workgroup ends up with two tickets it cannot use
-  const u32 nDraws = sl.nItems + 2u * gridDim.x;
+  // ---- tickets: a workgroup's first item is its index in the grid (the workgroups in front of it were dispatched before it); the
+  // others are drawn from a counter, each an item ahead (while one item is worked on, the bytes of the next are on their way and
+  // the ticket of the one behind that is being drawn).  Every workgroup draws one ticket it cannot use.
+  const u32 nDraws = sl.nItems + gridDim.x;
   auto draw = [&]() -> u32    // (one thread)
   {
     const u32 v = __hip_atomic_fetch_add(sl.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v == nDraws - 1u) publish32(sl.ticket, 0u);    // the launch's last ticket: the counter reads zero again
-    return v;
+    return gridDim.x + v;
   };
-  if (threadIdx.x == 0) { S.tk[0] = draw(); S.tk[1] = draw(); }
+  if (threadIdx.x == 0) S.tk[1] = draw();
+  if (threadIdx.x < 4u) S.inAll[threadIdx.x] = 0u;    // (the word in front of the staged bytes)
   __syncthreads();
-  u32 item = S.tk[0], next = S.tk[1];
+  u32 item = blockIdx.x, next = S.tk[1], iter = 0, curTile = 0xFFFFFFFFu;
 
   // ---- an item's bytes: all loads in flight at once (clipped to what the caller says is readable); a wave's first lane also asks
   // for the dword in front of its unit (the other lanes get theirs from the lane in front).  They stay in registers until the LDS
@@ -202,8 +204,25 @@ k_fast_decode_scan(FastDecodeBuffers b0, FastDecodeBatch t, ScanLaunch sl, const
       hits[k] = i < G::kScanUnits ? ((tt & 0xFFu) | ((tt >> 8) & 0xFF00u)) : 0u;
     }
   };
+  // the band header of a tile: read in full by the first wave (Lerc2::ReadHeader's checks); valid behind the next barrier
+  auto readHeader = [&](u32 tile)
+  {
+    if (w != 0) return;
+    const u8* __restrict__ blob = blob0;
+    u32 sizeGiven = sizeGiven0;
+    if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
+    const FastDecodeParams hpFull = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
+    if (lane == 0) S.hp = hpFull;
+  };
   bool scanned = false;
-  if (item < sl.nItems) { issueLoads(item); scanRegs(); scanned = true; }
+  if (item < sl.nItems)
+  {
+    // (the first item's header before its bytes: a band the streaming kernels do not take -- a mask, another mode -- is left alone)
+    curTile = item / ppt;
+    readHeader(curTile);
+    __syncthreads();
+    if (S.hp.ok) { issueLoads(item); scanRegs(); scanned = true; }
+  }
 
   while (item < sl.nItems)    // (the same for every thread)
   {
@@ -231,66 +250,47 @@ k_fast_decode_scan(FastDecodeBuffers b0, FastDecodeBatch t, ScanLaunch sl, const
 #define TRACEI(slot)
 #endif
 
-    // ---- the band header: every wave reads what the front part needs of it; the first wave reads it in full (Lerc2::ReadHeader's
-    // checks) and leaves the result in LDS (the tile's first piece: also where the host wants it)
-    const HeadLite hl = parseHeadLite<DT>(blob, sizeGiven);
-    const u32 blobEnd = hl.blobEnd;
-    const bool ours = hl.ok && headLiteEligible<DT>(blob, hl.version, nRows, nCols);
-    if (wg == 0u && !ours && threadIdx.x == 0)      // (not a band of ours: say so)
-    {
-      const FastDecodeParams hp0 = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
-      storeParams<true>(b.params, hp0); if (b.hostParams) *b.hostParams = hp0;
-    }
-    const u32 nWG = fastScanNumWG(blobEnd);
-    bool live = ours && wg < nWG;                    // (the items are as many as the largest stream the blobs could hold)
+    // ---- the band header: read in full by the first wave (Lerc2::ReadHeader's checks) when the workgroup comes to another tile; the
+    // result stays in LDS (the tile's first piece: also where the host wants it)
     TRACEI(0);
+    if (curTile != tile) { curTile = tile; readHeader(tile); }
+    if (threadIdx.x == 0)
+    {
+      S.nQueue = 0u; S.nEnt = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
+      S.prevExit = kNoOffset; S.mended = 0u; S.part = 0ull;
+      S.tk[iter & 1u] = draw();    // (read when this item is done)
+    }
+    __syncthreads();
+    const u32 blobEnd = S.hp.blobEnd;
+    const u32 nWG = fastScanNumWG(blobEnd);
+    const bool live = S.hp.ok != 0u && wg < nWG;     // (the items are as many as the largest stream the blobs could hold)
     const u32 pieceStart = wg * P;                   // blob offset of the piece's first own byte = of LDS byte PRE
-    const int version = (int)hl.version;
-    const bool v5 = version >= 5;
+    const bool v5 = S.hp.version >= 5u;
     const u32 pattern = v5 ? 14u : 15u;
     const u32 epoch = b.epoch;
     const u64 tag = (u64)b.publishEpoch << 32;
     const bool lastPiece = wg == nWG - 1u;
     // positions are relative to the staged bytes: LDS byte r is blob byte pieceStart + r - PRE
-    const u32 blobRel = blobEnd - pieceStart + PRE;                                                    // the blob's end
-    const u32 dataRel = hl.dataBegin + PRE > pieceStart ? hl.dataBegin + PRE - pieceStart : 0u;        // the stream's first block (or 0: in front of all this)
+    const u32 blobRel = blobEnd - pieceStart + PRE;                                                          // the blob's end
+    const u32 dataRel = S.hp.dataBegin + PRE > pieceStart ? S.hp.dataBegin + PRE - pieceStart : 0u;        // the stream's first block (or 0: in front of all this)
     const u32 pieceEndRel = PRE + P;
-    if (live)
+    if (live) for (u32 i = threadIdx.x; i < kMapWords + 3u; i += NT) { s_sb[i] = 0u; s_end[i] = 0u; }
+    if (wg == 0u && threadIdx.x == 0)
     {
-      if (w == 0)
+      // the tile's first piece leaves the header where the host wants it.  (The verdict on the checksum comes from the workgroup of the
+      // last piece, microseconds later for a small blob: one writer per byte -- the host's copy, which travels over PCIe, gets
+      // everything BUT that word here (the host has zeroed it).)
+      const FastDecodeParams hpFull = S.hp;
+      storeParams<true>(b.params, hpFull);
+      if (b.hostParams)
       {
-        const FastDecodeParams hpFull = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
-        if (lane == 0)
-        {
-          S.hp = hpFull;
-          if (wg == 0u)
-          {
-            // (the verdict on the checksum comes from the workgroup of the last piece, microseconds later for a small blob: one writer
-            // per byte -- the host's copy, which travels over PCIe, gets everything BUT that word here (the host has zeroed it))
-            storeParams<true>(b.params, hpFull);
-            if (b.hostParams)
-            {
-              u64 wds[8];
-              memcpy(wds, &hpFull, 64);
-              static_assert(offsetof(FastDecodeParams, checksumOk) == 40 && sizeof(FastDecodeParams) == 64, "word 5 holds the verdict");
+        u64 wds[8];
+        memcpy(wds, &hpFull, 64);
+        static_assert(offsetof(FastDecodeParams, checksumOk) == 40 && sizeof(FastDecodeParams) == 64, "word 5 holds the verdict");
 #pragma unroll
-              for (int i = 0; i < 8; i++) if (i != 5) reinterpret_cast<volatile u64*>(b.hostParams)[i] = wds[i];
-            }
-          }
-        }
-      }
-      for (u32 i = threadIdx.x; i < kMapWords + 3u; i += NT) { s_sb[i] = 0u; s_end[i] = 0u; }
-      if (threadIdx.x < 4u) S.inAll[threadIdx.x] = 0u;
-      if (threadIdx.x == 0)
-      {
-        S.nQueue = 0u; S.nEnt = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
-        S.prevExit = kNoOffset; S.mended = 0u; S.part = 0ull;
+        for (int i = 0; i < 8; i++) if (i != 5) reinterpret_cast<volatile u64*>(b.hostParams)[i] = wds[i];
       }
     }
-    if (threadIdx.x == 0) S.tk[2] = draw();
-    __syncthreads();
-    const u32 next2 = S.tk[2];
-    live = live && S.hp.ok;    // (not a band the streaming kernels take: the header says so in full only)
 
     if (live)
     {
@@ -323,7 +323,7 @@ k_fast_decode_scan(FastDecodeBuffers b0, FastDecodeBatch t, ScanLaunch sl, const
           }
           fletcherUnit(y, a ? (a - 14u) / 2u : 65528ull, fA, fB);             // (the first unit's index -7 as its residue mod 65535)
         }
-        const bool has = hits[k] != 0u;
+        const bool has = hits[k] != 0u && 16u * i < blobRel;    // (what lies behind the blob in the caller's buffer is not looked at)
         const u64 bal = __builtin_amdgcn_ballot_w64(has);
         if (bal != 0ull)    // (wave-uniform)
         {
@@ -346,7 +346,8 @@ k_fast_decode_scan(FastDecodeBuffers b0, FastDecodeBatch t, ScanLaunch sl, const
     }
     // the registers are free: the next item's bytes are asked for now, a whole item before they are looked at
     scanned = false;
-    if (next < sl.nItems) issueLoads(next);
+    const bool nextWanted = next < sl.nItems && (next / ppt != tile || S.hp.ok != 0u);    // (not another piece of a band that is none of ours)
+    if (nextWanted) issueLoads(next);
     __syncthreads();
     TRACEI(1);
     if (live)
@@ -605,7 +606,7 @@ k_fast_decode_scan(FastDecodeBuffers b0, FastDecodeBatch t, ScanLaunch sl, const
     u64 cell0 = 0;
     if (threadIdx.x < nCells) cell0 = observe64(cellOf(threadIdx.x));
 #ifndef LERC_SCAN_NO_SHADOW    // (tuning knob: the scan at the top of the next item instead)
-    if (!scanned && next < sl.nItems) { scanRegs(); scanned = true; }
+    if (!scanned && nextWanted) { scanRegs(); scanned = true; }
 #endif
     {
       u64 part = 0;
@@ -827,8 +828,8 @@ k_fast_decode_scan(FastDecodeBuffers b0, FastDecodeBatch t, ScanLaunch sl, const
     }    // (live)
     // ---- the next item: its bytes are in the registers (scanned, if this item had cells to wait for)
     __syncthreads();    // (the LDS is free)
-    if (!scanned && next < sl.nItems) { scanRegs(); scanned = true; }
-    item = next; next = next2;
+    if (!scanned && nextWanted) { scanRegs(); scanned = true; }
+    item = next; next = S.tk[iter & 1u]; iter++;
 #undef TRACEI
   }
 }
@@ -849,7 +850,7 @@ static void launchFastDecodeScanT(int nRows, int nCols, const FastDecodeBatch& t
                                   hipStream_t st)
 {
 #ifdef HIPSIM
-  const u32 slots = 2;       // (the emulator runs workgroup after workgroup: the first one takes every item, the second draws its two tickets and leaves)
+  const u32 slots = 1;       // (the emulator runs workgroup after workgroup, each to its end: one workgroup takes every item)
 #else
   static const int computeUnits = []() { hipDeviceProp_t pr; int dev = 0; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
   const u32 slots = (u32)computeUnits * (u32)scanResidency<T>();    // workgroups the chip holds at a time
