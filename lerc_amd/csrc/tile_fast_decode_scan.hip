@@ -56,7 +56,7 @@ template<class T> struct ScanGeom
   static constexpr u32 kBytes = PRE + P + POST, kUnits = kBytes / 16u;
   static constexpr int kRounds = (int)((kUnits + NT - 1u) / NT);
   static constexpr u32 kScanUnits = (PRE + P) / 16u + 1u;        // units the count byte of a block that begins in front of the piece's end can lie in
-  static constexpr u32 kMapWords = (kBytes + 31u) / 32u;
+  static constexpr u32 kMapWords = (kBytes + 31u) / 32u, kMapVecs = (kMapWords + 3u + 3u) / 4u;    // bitmap words; 16-byte vectors that hold them (+ 3 of slack)
   static constexpr u32 kOwnWord0 = PRE / 32u;
   static constexpr u32 R = NT;                                    // blocks per decode round: one header per thread
   static constexpr u32 kListCap = P / 16u, kQueueCap = P / 32u;
@@ -69,10 +69,10 @@ template<class T> struct ScanShared
 {
   typedef ScanGeom<T> G;
   alignas(16) u32 inAll[4 + G::kBytes / 4 + 4];      // [4 ...): the staged bytes; the word in front of them reads 0
-  alignas(16) u32 sb[G::kMapWords + 3];              // START; from step 3 on: START & END of the piece's own bytes
+  alignas(16) u32 sb[4 * G::kMapVecs];              // START; from step 3 on: START & END of the piece's own bytes
   union U
   {
-    alignas(16) u32 end[G::kMapWords + 3];           // steps 2 - 3
+    alignas(16) u32 end[4 * G::kMapVecs];           // steps 2 - 3
     struct X                                         // the pixels, one round
     {
       double offs[G::R];
@@ -82,14 +82,13 @@ template<class T> struct ScanShared
   } u;
   union L
   {
-    u32 queue[G::kQueueCap];                         // steps 1 - 2: unit | hits << 16
+    u16 queue[G::kQueueCap];                         // steps 1 - 2: units that may hold a count byte
     u16 list[G::kListCap + 8];                       // from step 3 on: the block starts, relative to the staged bytes
   } l;
   u16 badIdx[kScanBadCap], falseIdx[kScanFalseCap], insPos[kScanInsCap];
   u32 wsum[G::NT / 64];
   u64 fa[G::NT / 64], fb[G::NT / 64];
   u64 part;                                          // sum of the cells: this group's in the low half, the groups' in front in the high half
-  u32 tk[2];                                         // the ticket drawn during an item, by turns
   u32 nQueue, nEnt, nBad[2], nFalse, nIns, over, bad, lost, exitRel, prevExit, mended;    // nBad: broken links found by the first / the second check
   FastDecodeParams hp;                               // the band header, parsed in full by the first wave
 };
@@ -104,673 +103,526 @@ __device__ __forceinline__ u32 countByteHits(u32 cur4, u32 prev4)
   return ~z & nz;
 }
 
-// What the persistent workgroups of a launch share: ITEMS -- a piece of a tile -- are handed out in order by a ticket counter, so
-// that whatever a workgroup waits for (the cells of the pieces in front of its own) belongs to a workgroup that is running or
-// through, however many the chip holds at a time.
-struct ScanLaunch
+// bit 7 of a byte of the result is CLEAR where cur4 reads 64 behind a byte 10...... (and possibly set elsewhere: a filter)
+__device__ __forceinline__ u32 countByteMaybe(u32 cur4, u32 prev4)
 {
-  u32* ticket;          // the next item; zero between launches (the workgroup that draws the launch's last ticket clears it)
-  u32 nItems;           // tiles x piecesPerTile
-  u32 piecesPerTile;    // pieces the largest blob of the batch could hold
-};
+  const u32 hdr4 = __builtin_amdgcn_alignbit(cur4, prev4, 24);
+  const u32 t = (cur4 ^ 0x40404040u) | ((hdr4 & 0xC0C0C0C0u) ^ 0x80808080u);
+  return ((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t;
+}
 
-// blockIdx.y is not used: a batch of tiles is so many more items.  (80 scalar registers would let a SIMD hold eight waves; six
-// are resident -- three workgroups to a CU, LDS -- so the compiler may take what it likes.)
-#ifdef HIPSIM
-#define LERC_SCAN_REGS
-#else
-#ifndef LERC_SCAN_WAVES
-#define LERC_SCAN_WAVES 6
-#endif
-#define LERC_SCAN_REGS __attribute__((amdgpu_waves_per_eu(LERC_SCAN_WAVES, LERC_SCAN_WAVES)))
-#endif
 template<class T>
-__global__ void __launch_bounds__(kScanThreads) LERC_SCAN_REGS
-k_fast_decode_scan(FastDecodeBuffers b0, FastDecodeBatch t, ScanLaunch sl, const u8* blob0, u32 sizeGiven0, int nRows, int nCols, T* __restrict__ outPix0)
+__device__ __forceinline__ void
+fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols,
+             T* __restrict__ outPix, u32 wg)
 {
   typedef ScanGeom<T> G;
   constexpr int DT = G::DT;
-  constexpr u32 P = G::P, NT = G::NT, PRE = G::PRE, kUnits = G::kUnits, kMapWords = G::kMapWords;
+  constexpr u32 W = G::W, P = G::P, NT = G::NT, PRE = G::PRE, kUnits = G::kUnits;
   constexpr u32 kWaves = NT / 64, kListCap = G::kListCap, kQueueCap = G::kQueueCap, R = G::R;
   constexpr u32 RAW = 1u + 64u * G::TB;
-  constexpr int kRounds = G::kRounds;
-  __shared__ ScanShared<T> S;
   u32* const s_in = S.inAll + 4;
   auto& s_sb = S.sb; auto& s_end = S.u.end; auto& s_queue = S.l.queue; auto& s_list = S.l.list;
   const int lane = laneId(), w = waveId();
-  const u32 ppt = sl.piecesPerTile;
 
-  // ---- tickets: a workgroup's first item is its index in the grid (the workgroups in front of it were dispatched before it); the
-  // others are drawn from a counter, each an item ahead (while one item is worked on, the bytes of the next are on their way and
-  // the ticket of the one behind that is being drawn).  Every workgroup draws one ticket it cannot use.
-  const u32 nDraws = sl.nItems + gridDim.x;
-  auto draw = [&]() -> u32    // (one thread)
+  // ---- the band header: every wave reads what the front part needs of it; the first wave reads it in full (Lerc2::ReadHeader's
+  // checks) while the staged bytes are on their way, and leaves the result in LDS (workgroup 0: also where the host wants it)
+  const HeadLite hl = parseHeadLite<DT>(blob, sizeGiven);
+  const u32 blobEnd = hl.blobEnd;
+  const bool ours = hl.ok && headLiteEligible<DT>(blob, hl.version, nRows, nCols);
+  if (wg == 0u && !ours && threadIdx.x == 0)      // (not a band of ours: say so)
   {
-    const u32 v = __hip_atomic_fetch_add(sl.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v == nDraws - 1u) publish32(sl.ticket, 0u);    // the launch's last ticket: the counter reads zero again
-    return gridDim.x + v;
-  };
-  if (threadIdx.x == 0) S.tk[1] = draw();
-  if (threadIdx.x < 4u) S.inAll[threadIdx.x] = 0u;    // (the word in front of the staged bytes)
-  __syncthreads();
-  u32 item = blockIdx.x, next = S.tk[1], iter = 0, curTile = 0xFFFFFFFFu;
+    const FastDecodeParams hp0 = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
+    storeParams<true>(b.params, hp0); if (b.hostParams) *b.hostParams = hp0;
+  }
+  const u32 nWG = fastScanNumWG(blobEnd);
+  if (!ours || wg >= nWG) return;                  // (the grid is sized for the largest stream the blob could hold)
+  TRACES(0);
+  const u32 pieceStart = wg * P;                   // blob offset of the piece's first own byte = of LDS byte PRE
+  const int version = (int)hl.version;
+  const bool v5 = version >= 5;
+  const u32 pattern = v5 ? 14u : 15u;
+  const u32 epoch = b.epoch;
+  const u64 tag = (u64)b.publishEpoch << 32;
+  const bool lastPiece = wg == nWG - 1u;
+  // positions are relative to the staged bytes: LDS byte r is blob byte pieceStart + r - PRE
+  const u32 blobRel = blobEnd - pieceStart + PRE;                                                    // the blob's end
+  const u32 dataRel = hl.dataBegin + PRE > pieceStart ? hl.dataBegin + PRE - pieceStart : 0u;        // the stream's first block (or 0: in front of all this)
+  const u32 pieceEndRel = PRE + P;
 
-  // ---- an item's bytes: all loads in flight at once (clipped to what the caller says is readable); a wave's first lane also asks
-  // for the dword in front of its unit (the other lanes get theirs from the lane in front).  They stay in registers until the LDS
-  // is free for them -- the item in front may still be decoding out of it.
+  // ---- the staged bytes, all loads in flight at once (clipped to what the caller says is readable; 32-bit offsets from the blob's
+  // first byte: a blob is less than 4 GB; the bytes in front of the first piece do not exist).  A round in which a wave has no
+  // unit -- the last one, for all waves but the first -- is skipped by that wave, here and below.
+  constexpr int kRounds = G::kRounds;
   uint4 x[kRounds];
-  u32 hits[kRounds];
-  auto issueLoads = [&](u32 it)
+  const u32 aMine = pieceStart + 16u * threadIdx.x - PRE;    // (wraps for the first piece's units in front of the blob: not loaded)
+#pragma unroll
+  for (int k = 0; k < kRounds; k++)
   {
-    const u32 tile = it / ppt, wg = it - tile * ppt;
-    const u8* __restrict__ blob = blob0;
-    u32 sizeGiven = sizeGiven0;
-    if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
-    // (32-bit offsets from the blob's first byte: a blob is less than 4 GB; the bytes in front of the first piece do not exist)
-    const u32 a0 = wg * P + 16u * threadIdx.x - PRE;    // (wraps for the first piece's units in front of the blob: not loaded)
-#pragma unroll
-    for (int k = 0; k < kRounds; k++)
+    x[k] = make_uint4(0, 0, 0, 0);
+    if ((u32)k * NT + 64u * (u32)w >= kUnits) continue;
+    const u32 i = (u32)k * NT + threadIdx.x;
+    const u32 a = aMine + (u32)k * NT * 16u;
+    if (i < kUnits && (wg != 0u || i >= PRE / 16u))
     {
-      const u32 i = (u32)k * NT + threadIdx.x;
-      const u32 a = a0 + (u32)k * NT * 16u;
-      x[k] = make_uint4(0, 0, 0, 0);
-      if (i < kUnits && (wg != 0u || i >= PRE / 16u))
+      if (a <= sizeGiven && sizeGiven - a >= 16u) x[k] = *reinterpret_cast<const uint4*>(blob + a);
+      else if (a < sizeGiven)    // never read past the blob
       {
-        if (a <= sizeGiven && sizeGiven - a >= 16u) x[k] = *reinterpret_cast<const uint4*>(blob + a);
-        else if (a < sizeGiven)    // never read past the blob
-        {
-          u32 t4[4] = { 0, 0, 0, 0 };
+        u32 t4[4] = { 0, 0, 0, 0 };
 #pragma unroll
-          for (u32 q = 0; q < 16; q++) if (q < sizeGiven - a) t4[q >> 2] |= (u32)blob[a + q] << (8 * (q & 3));
-          x[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+        for (u32 q = 0; q < 16; q++) if (q < sizeGiven - a) t4[q >> 2] |= (u32)blob[a + q] << (8 * (q & 3));
+        x[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+      }
+    }
+  }
+  if (w == 0)
+  {
+    const FastDecodeParams hpFull = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
+    if (lane == 0)
+    {
+      S.hp = hpFull;
+      if (wg == 0u)
+      {
+        // (the verdict on the checksum comes from the launch's last workgroup, microseconds later for a small blob: one writer
+        // per byte -- the host's copy, which travels over PCIe, gets everything BUT that word here (the host has zeroed it))
+        storeParams<true>(b.params, hpFull);
+        if (b.hostParams)
+        {
+          u64 wds[8];
+          memcpy(wds, &hpFull, 64);
+          static_assert(offsetof(FastDecodeParams, checksumOk) == 40 && sizeof(FastDecodeParams) == 64, "word 5 holds the verdict");
+#pragma unroll
+          for (int i = 0; i < 8; i++) if (i != 5) reinterpret_cast<volatile u64*>(b.hostParams)[i] = wds[i];
         }
       }
     }
-  };
-  // the scan: count bytes of bit-stuffed block headers in each unit, a bit per byte -- bit k: byte 4 (k & 3) + (k >> 2).  Needs
-  // nothing but the bytes: it runs while the cells of the pieces in front are on their way.
-  auto scanRegs = [&]()
+  }
+  for (u32 i = threadIdx.x; i < G::kMapVecs; i += NT)
   {
+    reinterpret_cast<uint4*>(s_sb)[i] = make_uint4(0, 0, 0, 0);
+    reinterpret_cast<uint4*>(s_end)[i] = make_uint4(0, 0, 0, 0);
+  }
+  if (threadIdx.x < 4u) S.inAll[threadIdx.x] = 0u;
+  if (threadIdx.x == 0)
+  {
+    S.nQueue = 0u; S.nEnt = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
+    S.prevExit = kNoOffset; S.mended = 0u; S.part = 0ull;
+  }
+  __syncthreads();
+  if (!S.hp.ok) return;    // (not a band the streaming kernels take: the header says so in full only)
+
+  // ---- stage; Fletcher terms of the piece's own units (bytes 14 ... blobEnd - 1 of the blob are checksummed); scan
+  u32 fA = 0;
+  u64 fB = 0;
+  constexpr u32 ownUnit0 = PRE / 16u, ownUnit1 = (PRE + P) / 16u;
+  const bool inner = pieceStart != 0u && (u64)pieceStart + P <= blobEnd;    // no unit of this piece needs blanking
 #pragma unroll
-    for (int k = 0; k < kRounds; k++)
+  for (int k = 0; k < kRounds; k++)
+  {
+    if ((u32)k * NT + 64u * (u32)w >= kUnits) continue;    // (the same for all lanes of the wave)
+    const u32 i = (u32)k * NT + threadIdx.x;
+    if (i < kUnits) *reinterpret_cast<uint4*>(&s_in[i * 4]) = x[k];
+    const u32 a = pieceStart + 16u * i - PRE;                                 // (own units: >= 0 and < 2^32)
+    if (inner)
     {
-      const u32 i = (u32)k * NT + threadIdx.x;
-      u32 pv = dppMov<kDppWaveShr1>(x[k].w);
-      if (lane == 0) pv = 0u;    // (the byte in front belongs to another wave: the candidates step looks at these unit boundaries)
-      const u32 m0 = countByteHits(x[k].x, pv), m1 = countByteHits(x[k].y, x[k].x);
-      const u32 m2 = countByteHits(x[k].z, x[k].y), m3 = countByteHits(x[k].w, x[k].z);
-      const u32 z = (m0 >> 7) | ((m1 >> 7) << 1) | ((m2 >> 7) << 2) | ((m3 >> 7) << 3);
-      const u32 tt = z | (z >> 4);
-      hits[k] = i < G::kScanUnits ? ((tt & 0xFFu) | ((tt >> 8) & 0xFF00u)) : 0u;
+      if (i >= ownUnit0 && i < ownUnit1) fletcherUnit(x[k], (a - 14u) / 2u, fA, fB);    // unit at blob offset a holds words (a - 14) / 2 ...
     }
-  };
-  // the band header of a tile: read in full by the first wave (Lerc2::ReadHeader's checks); valid behind the next barrier
-  auto readHeader = [&](u32 tile)
+    else if (i >= ownUnit0 && i < ownUnit1 && a < blobEnd)
+    {
+      uint4 y = x[k];
+      if (a == 0 || a + 16 > blobEnd)    // blank what is not checksummed: the first 14 bytes, whatever lies behind the blob
+      {
+        u32 wd[4] = { y.x, y.y, y.z, y.w };
+#pragma unroll
+        for (u32 q = 0; q < 16; q++)
+          if (a + q < 14u || a + q >= blobEnd) wd[q >> 2] &= ~(0xFFu << (8 * (q & 3)));
+        y = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+      }
+      fletcherUnit(y, a ? (a - 14u) / 2u : 65528ull, fA, fB);             // (the first unit's index -7 as its residue mod 65535)
+    }
+    // the scan, first half: does the unit hold "a byte 64 behind a byte 10......" at all?  One unit in six does; those go to
+    // the queue (a ballot and one LDS atomic a wave), and the step below looks at them byte by byte.  (The byte in front of a
+    // wave's first unit belongs to another wave: taken for 10......, it lets the unit through if its first byte is 64.)
+    {
+      u32 pv = dppMov<kDppWaveShr1>(x[k].w);
+      if (lane == 0) pv = 0x80000000u;
+      const u32 z = countByteMaybe(x[k].x, pv) & countByteMaybe(x[k].y, x[k].x) & countByteMaybe(x[k].z, x[k].y) & countByteMaybe(x[k].w, x[k].z);
+      const bool has = (z & 0x80808080u) != 0x80808080u && i < G::kScanUnits && 16u * i < blobRel;    // (what lies behind the blob in the caller's buffer is not looked at)
+      const u64 bal = __builtin_amdgcn_ballot_w64(has);
+      if (bal != 0ull)    // (wave-uniform)
+      {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&S.nQueue, (u32)__popcll(bal));
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        const u32 slot = base + (u32)__popcll(bal & laneMaskLt());
+        if (has)
+        {
+          if (slot < kQueueCap) s_queue[slot] = (u16)i;
+          else S.over = 1u;
+        }
+      }
+    }
+  }
   {
-    if (w != 0) return;
-    const u8* __restrict__ blob = blob0;
-    u32 sizeGiven = sizeGiven0;
-    if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
-    const FastDecodeParams hpFull = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
-    if (lane == 0) S.hp = hpFull;
-  };
-  bool scanned = false;
-  if (item < sl.nItems)
+    // (no reduction mod 65535 before the sums: a lane holds 5 units, A < 2^23 and B < 2^54 per lane)
+    const u64 A = waveSum(fA), B = waveSum(fB);
+    if (lane == 0) { S.fa[w] = A; S.fb[w] = B; }
+  }
+  __syncthreads();
+  TRACES(1);
+  if (threadIdx.x == 0)
   {
-    // (the first item's header before its bytes: a band the streaming kernels do not take -- a mask, another mode -- is left alone)
-    curTile = item / ppt;
-    readHeader(curTile);
-    __syncthreads();
-    if (S.hp.ok) { issueLoads(item); scanRegs(); scanned = true; }
+    // this workgroup's checksum terms: one atomic nobody waits for (the launch's last workgroup folds the accumulators)
+    u64 A = 0, B = 0;
+#pragma unroll
+    for (u32 k = 0; k < kWaves; k++) { A += S.fa[k]; B += S.fb[k]; }
+    A %= 65535u; B %= 65535u;
+    if (wg == 0u) drainVmem();    // (the band's parameters have arrived)
+    __hip_atomic_fetch_add(b.wgAcc + wg / kOneGroup, A | (B << 24) | (1ull << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 
-  while (item < sl.nItems)    // (the same for every thread)
+  // ---- candidates: lane = unit with hits.  A bit-stuffed block reads: flag byte (bits 0-1 == 1, bits 6-7 the type of the
+  // offset, bit 2 clear from codec 5 on), the offset in that type, the bits byte 10?nnnnn (bit 5: look-up table), the count 64,
+  // [table size + 1, table,] payload (Lerc2.cpp:1961-2021, BitStuffer2.cpp:35-153).  The count byte stands 2 + (bytes of the
+  // offset) behind the flag byte: each offset type is tried.  The twelve bytes in front of the count byte's successor come out
+  // of four LDS words, shifted so that the byte 10 in front of the count byte is byte 0.
   {
-    const u32 tile = item / ppt, wg = item - tile * ppt;
-    // this tile's slice of every buffer
-    struct { FastDecodeParams* params; FastDecodeParams* hostParams; u64* wgCell; u64* wgGroupCell; u64* wgAcc; u32 epoch, publishEpoch, spinLimit; } b;
-    b.params = b0.params + tile; b.hostParams = b0.hostParams;
-    b.wgCell = b0.wgCell + (size_t)tile * b0.wgStride;
-    b.wgGroupCell = b0.wgGroupCell + (size_t)tile * b0.wgGroupStride;
-    b.wgAcc = b0.wgAcc + (size_t)tile * b0.wgGroupStride;
-    b.epoch = b0.epoch; b.publishEpoch = b0.publishEpoch; b.spinLimit = b0.spinLimit;
-    auto raise = [&](int k)    // raiseFlag() for this tile
+    const u32 nQ = min(S.nQueue, kQueueCap);
+    for (u32 h = threadIdx.x; h < nQ; h += NT)
     {
-      b0.fallback[4 * (size_t)tile + (size_t)k] = b0.epoch;
-      if (b0.hostFallback) b0.hostFallback[k] = b0.epoch;
-    };
-    const u8* __restrict__ blob = blob0;
-    u32 sizeGiven = sizeGiven0;
-    if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
-    T* __restrict__ outPix = outPix0 + (size_t)tile * t.tileElems;
-#if defined(LERC_PROBE) && !defined(HIPSIM)
-    const u32 traceRow = item;
-#define TRACEI(slot) do { if (threadIdx.x == 0 && traceRow < 8192u) g_traceS[16 * traceRow + (slot)] = wall_clock64(); } while (0)
-#else
-#define TRACEI(slot)
-#endif
-
-    // ---- the band header: read in full by the first wave (Lerc2::ReadHeader's checks) when the workgroup comes to another tile; the
-    // result stays in LDS (the tile's first piece: also where the host wants it)
-    TRACEI(0);
-    if (curTile != tile) { curTile = tile; readHeader(tile); }
-    if (threadIdx.x == 0)
-    {
-      S.nQueue = 0u; S.nEnt = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
-      S.prevExit = kNoOffset; S.mended = 0u; S.part = 0ull;
-      S.tk[iter & 1u] = draw();    // (read when this item is done)
-    }
-    __syncthreads();
-    const u32 blobEnd = S.hp.blobEnd;
-    const u32 nWG = fastScanNumWG(blobEnd);
-    const bool live = S.hp.ok != 0u && wg < nWG;     // (the items are as many as the largest stream the blobs could hold)
-    const u32 pieceStart = wg * P;                   // blob offset of the piece's first own byte = of LDS byte PRE
-    const bool v5 = S.hp.version >= 5u;
-    const u32 pattern = v5 ? 14u : 15u;
-    const u32 epoch = b.epoch;
-    const u64 tag = (u64)b.publishEpoch << 32;
-    const bool lastPiece = wg == nWG - 1u;
-    // positions are relative to the staged bytes: LDS byte r is blob byte pieceStart + r - PRE
-    const u32 blobRel = blobEnd - pieceStart + PRE;                                                          // the blob's end
-    const u32 dataRel = S.hp.dataBegin + PRE > pieceStart ? S.hp.dataBegin + PRE - pieceStart : 0u;        // the stream's first block (or 0: in front of all this)
-    const u32 pieceEndRel = PRE + P;
-    if (live) for (u32 i = threadIdx.x; i < kMapWords + 3u; i += NT) { s_sb[i] = 0u; s_end[i] = 0u; }
-    if (wg == 0u && threadIdx.x == 0)
-    {
-      // the tile's first piece leaves the header where the host wants it.  (The verdict on the checksum comes from the workgroup of the
-      // last piece, microseconds later for a small blob: one writer per byte -- the host's copy, which travels over PCIe, gets
-      // everything BUT that word here (the host has zeroed it).)
-      const FastDecodeParams hpFull = S.hp;
-      storeParams<true>(b.params, hpFull);
-      if (b.hostParams)
+      // the scan, second half: which bytes of the unit -- exactly: 64 behind 10?nnnnn, n != 0; a bit per byte, bit k: byte
+      // 4 (k & 3) + (k >> 2)
+      const u32 unit = (u32)s_queue[h];
+      const uint4 xu = *reinterpret_cast<const uint4*>(&s_in[4u * unit]);
+      const u32 pvu = S.inAll[4u * unit + 3u];                               // (the dword in front of the unit; in front of the staged bytes: 0)
+      const u32 m0 = countByteHits(xu.x, pvu), m1 = countByteHits(xu.y, xu.x), m2 = countByteHits(xu.z, xu.y), m3 = countByteHits(xu.w, xu.z);
+      const u32 zb = (m0 >> 7) | ((m1 >> 7) << 1) | ((m2 >> 7) << 2) | ((m3 >> 7) << 3);
+      const u32 tb = zb | (zb >> 4);
+      u32 hits = (tb & 0xFFu) | ((tb >> 8) & 0xFF00u);
+      while (hits)
       {
-        u64 wds[8];
-        memcpy(wds, &hpFull, 64);
-        static_assert(offsetof(FastDecodeParams, checksumOk) == 40 && sizeof(FastDecodeParams) == 64, "word 5 holds the verdict");
+        const u32 k = (u32)__ffs((int)hits) - 1u;
+        hits &= hits - 1u;
+        const u32 q = 16u * unit + 4u * (k & 3u) + (k >> 2);                // the count byte
+        const u32 wi = (q + 6u) >> 2, sh = 8u * ((q + 6u) & 3u);             // (word index into inAll: 16 bytes of zeros in front)
+        const u32 w0 = S.inAll[wi], w1 = S.inAll[wi + 1], w2 = S.inAll[wi + 2], w3 = S.inAll[wi + 3];
+        const u32 a0 = __builtin_amdgcn_alignbit(w1, w0, sh), a1 = __builtin_amdgcn_alignbit(w2, w1, sh), a2 = __builtin_amdgcn_alignbit(w3, w2, sh);
+        const u32 tB = (a2 >> 8) & 0xFFu, nb = tB & 31u, lut = (tB >> 5) & 1u;
+        const u32 nLut = ((a2 >> 24) - 1u) & 0xFFu;                          // valid: 1 ... 254
+        const bool okLut = (lut == 0u) | ((nLut - 1u) < 254u);
+        const u32 payload = lut ? 1u + ((nLut * nb + 7u) >> 3) + 8u * (u32)bitLen(nLut) : 8u * nb;
 #pragma unroll
-        for (int i = 0; i < 8; i++) if (i != 5) reinterpret_cast<volatile u64*>(b.hostParams)[i] = wds[i];
-      }
-    }
-
-    if (live)
-    {
-      // ---- the bytes into LDS; Fletcher terms of the piece's own units (bytes 14 ... blobEnd - 1 of the blob are checksummed);
-      // the units with hits into the queue (a ballot and one LDS atomic a wave)
-      u32 fA = 0;
-      u64 fB = 0;
-      constexpr u32 ownUnit0 = PRE / 16u, ownUnit1 = (PRE + P) / 16u;
-      const bool inner = pieceStart != 0u && (u64)pieceStart + P <= blobEnd;    // no unit of this piece needs blanking
-#pragma unroll
-      for (int k = 0; k < kRounds; k++)
-      {
-        const u32 i = (u32)k * NT + threadIdx.x;
-        if (i < kUnits) *reinterpret_cast<uint4*>(&s_in[i * 4]) = x[k];
-        const u32 a = pieceStart + 16u * i - PRE;                                 // (own units: >= 0 and < 2^32)
-        if (inner)
+        for (u32 tc = 0; tc < 4; tc++)
         {
-          if (i >= ownUnit0 && i < ownUnit1) fletcherUnit(x[k], (a - 14u) / 2u, fA, fB);    // unit at blob offset a holds words (a - 14) / 2 ...
-        }
-        else if (i >= ownUnit0 && i < ownUnit1 && a < blobEnd)
-        {
-          uint4 y = x[k];
-          if (a == 0 || a + 16 > blobEnd)    // blank what is not checksummed: the first 14 bytes, whatever lies behind the blob
+          const u32 offB = (offBytesTable<DT>() >> (4u * tc)) & 15u;
+          if (offB == 0u) continue;
+          const u32 m = 8u - offB;                                           // the flag byte is byte m of the twelve
+          const u32 flag = ((m < 4u ? a0 : m < 8u ? a1 : a2) >> (8u * (m & 3u))) & 0xFFu;
+          const u32 len = 3u + offB + payload;
+          const bool ok = (flag & 3u) == 1u && (flag >> 6) == tc && !(v5 && (flag & 4u)) && okLut && len <= RAW && q >= 2u + offB;
+          const u32 p = q - 2u - offB, e = p + len;
+          if (ok && p >= dataRel && p < pieceEndRel && e <= blobRel)
           {
-            u32 wd[4] = { y.x, y.y, y.z, y.w };
-#pragma unroll
-            for (u32 q = 0; q < 16; q++)
-              if (a + q < 14u || a + q >= blobEnd) wd[q >> 2] &= ~(0xFFu << (8 * (q & 3)));
-            y = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-          }
-          fletcherUnit(y, a ? (a - 14u) / 2u : 65528ull, fA, fB);             // (the first unit's index -7 as its residue mod 65535)
-        }
-        const bool has = hits[k] != 0u && 16u * i < blobRel;    // (what lies behind the blob in the caller's buffer is not looked at)
-        const u64 bal = __builtin_amdgcn_ballot_w64(has);
-        if (bal != 0ull)    // (wave-uniform)
-        {
-          u32 base = 0;
-          if (lane == 0) base = atomicAdd(&S.nQueue, (u32)__popcll(bal));
-          base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-          const u32 slot = base + (u32)__popcll(bal & laneMaskLt());
-          if (has)
-          {
-            if (slot < kQueueCap) s_queue[slot] = i | (hits[k] << 16);
-            else S.over = 1u;
+            atomicOr(&s_sb[p >> 5], 1u << (p & 31u));
+            atomicOr(&s_end[e >> 5], 1u << (e & 31u));                      // (e < pieceEndRel + W: inside the bitmap)
           }
         }
       }
-      {
-        // (no reduction mod 65535 before the sums: a lane holds 5 units, A < 2^23 and B < 2^54 per lane)
-        const u64 A = waveSum(fA), B = waveSum(fB);
-        if (lane == 0) { S.fa[w] = A; S.fb[w] = B; }
-      }
     }
-    // the registers are free: the next item's bytes are asked for now, a whole item before they are looked at
-    scanned = false;
-    const bool nextWanted = next < sl.nItems && (next / ppt != tile || S.hp.ok != 0u);    // (not another piece of a band that is none of ours)
-    if (nextWanted) issueLoads(next);
-    __syncthreads();
-    TRACEI(1);
-    if (live)
+    if (threadIdx.x == 0 && dataRel >= PRE && dataRel < pieceEndRel)    // the stream's first block, whatever it is
     {
+      atomicOr(&s_sb[dataRel >> 5], 1u << (dataRel & 31u));
+      atomicOr(&s_end[dataRel >> 5], 1u << (dataRel & 31u));
+    }
+  }
+  __syncthreads();
+  TRACES(2);
+
+  // ---- survivors of the piece's own bytes: a thread's two bitmap words; their list by popcounts and one scan
+  const u32 myWord = G::kOwnWord0 + 2u * threadIdx.x;
+  { s_sb[myWord] &= s_end[myWord]; s_sb[myWord + 1u] &= s_end[myWord + 1u]; }
+  auto buildList = [&]()
+  {
+    const u32 s0 = s_sb[myWord], s1 = s_sb[myWord + 1u];
+    const u32 c = (u32)__popc(s0) + (u32)__popc(s1);
+    const u32 inc = waveInclusiveScan(c);
+    __syncthreads();                                  // (the queue, which the list lies on, has been read by everybody)
+    if (lane == 63) S.wsum[w] = inc;
+    __syncthreads();
+    u32 idx = inc - c;
+    for (int k = 0; k < w; k++) idx += S.wsum[k];
+    const u32 pos0 = PRE + 64u * threadIdx.x;
+    u32 m = s0;
+    while (m) { const u32 bt = (u32)__ffs((int)m) - 1u; m &= m - 1u; if (idx < kListCap) s_list[idx] = (u16)(pos0 + bt); idx++; }
+    m = s1;
+    while (m) { const u32 bt = (u32)__ffs((int)m) - 1u; m &= m - 1u; if (idx < kListCap) s_list[idx] = (u16)(pos0 + 32u + bt); idx++; }
+    if (threadIdx.x == NT - 1u) { S.nEnt = min(idx, kListCap); if (idx > kListCap) S.over = 1u; }
+    __syncthreads();
+  };
+  buildList();
+  TRACES(3);
+
+  // ---- every block's header in full, lane = block: length, mode, bits, offset (ReadTile's and BitStuffer2::Decode's checks), and
+  // "the blocks tile the stream": a block ends where the next one of the list begins, the last one behind the piece (the
+  // blob's last piece: with the blob).  What the pixel loop wants to know of the first R blocks is kept.
+  const FastDecodeParams hp = S.hp;
+  const struct { int nCols, version; double invScale, zMaxHdr; } p = { (int)hp.nCols, (int)hp.version, hp.invScale, hp.zMaxHdr };
+  typedef DCfg<T> C;
+  constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
+  auto& s_offs = S.u.x.offs; auto& s_code = S.u.x.code; auto& s_at = S.u.x.at;
+  // the block at list entry f: its length, or 0 if it is none; keep: what the pixel loop needs goes to slot t
+  auto parseBlock = [&](u32 pos, bool keep, u32 t) -> u32
+  {
+    u32 h0, h1, h2;
+    ldsHeader<DT>(s_in, pos, h0, h1, h2);
+    u32 code = parseCode<DT>(h0, h1, h2, p.version);
+    if (pos + codeLen(code) > blobRel) code = 0u;
+    const u32 len = codeLen(code);
+    if (keep)
+    {
+      double offset = 0;
+      const u32 mode = codeMode(code);
+      if (code && (mode == 1 || mode == 3))
+      {
+        const u32 offB = codeOffBytes(code);
+        u64 bits = (((u64)h1 << 32) | h0) >> 8;
+        if (DT == DT_Double) bits |= (u64)h2 << 56;
+        if (offB < 8) bits &= (1ull << (8 * offB)) - 1;
+        offset = typedFromBits(bits, typeUsed(DT, (int)((h0 >> 6) & 3u)));
+      }
+      // in one word: where the payload begins (16: byte among the staged ones; the first raw value of a raw block), bits per
+      // value (5) << 16, mode (2) << 21, look-up table << 23, "plain" << 24 -- bit-stuffed without a table, a lane's V values
+      // inside 64 bits, and not even the largest value nb bits can hold reaches the header's zMax, so the pixels need no clamp
+      // -- and bit 31 (0: no such block)
+      u32 word = 0u;
+      if (code)
+      {
+        const u32 nb = codeBits(code), lutB = codeLut(code);
+        bool plainB = false;
+        if (mode == 1)
+        {
+          const u32 qTop = nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+          const bool below = (DT >= DT_Float) ? (offset + (double)qTop * p.invScale < p.zMaxHdr)
+                                              : ((i64)offset + (i64)qTop * (i64)p.invScale < (i64)p.zMaxHdr);
+          plainB = below && !lutB && (u32)V * nb <= 64u;
+        }
+        const u32 pay = pos + ((mode == 1u) ? 3u + codeOffBytes(code) + lutB : 1u);
+        word = (pay & 0xFFFFu) | (nb << 16) | (mode << 21) | (lutB << 23) | ((plainB ? 1u : 0u) << 24) | 0x80000000u;
+      }
+      s_offs[t] = offset;
+      s_code[t] = word;
+      s_at[t] = (h0 >> 2) & pattern;     // (the signature, until the block's place is known)
+    }
+    return len;
+  };
+  auto tilePass = [&](u32 pass)
+  {
+    const u32 nEnt = S.nEnt;
+    for (u32 f = threadIdx.x; f < nEnt; f += NT)
+    {
+      const u32 pos = (u32)s_list[f];
+      const u32 len = parseBlock(pos, f < R, f);
+      const u32 ext = pos + len;
+      const bool last = f + 1u == nEnt;
+      const u32 nxt = last ? 0u : (u32)s_list[f + 1u];
+      const bool ok = len != 0u && (last ? (lastPiece ? ext == blobRel : ext >= pieceEndRel) : ext == nxt);
+      if (!ok) { const u32 at = atomicAdd(&S.nBad[pass], 1u); if (at < kScanBadCap) S.badIdx[at] = (u16)f; }
+      if (last) S.exitRel = ext;
+    }
+    __syncthreads();
+  };
+  __syncthreads();    // (the bitmap of ENDs, which the round's arrays lie on, has been read by everybody)
+  tilePass(0u);
+  TRACES(4);
+
+  // ---- a list that does not tile is mended by one thread (see the head of the file): false survivors struck, gaps walked.
+  // Nothing is written until the whole list has been gone through; then the survivors' bitmap is corrected and the list built
+  // again from it.
+  if (S.nBad[0] != 0u)
+  {
     if (threadIdx.x == 0)
     {
-      // this workgroup's checksum terms: one atomic nobody waits for (the workgroup of the tile's last piece folds the accumulators)
-      u64 A = 0, B = 0;
-#pragma unroll
-      for (u32 k = 0; k < kWaves; k++) { A += S.fa[k]; B += S.fb[k]; }
-      A %= 65535u; B %= 65535u;
-      if (wg == 0u) drainVmem();    // (the band's parameters have arrived)
-      __hip_atomic_fetch_add(b.wgAcc + wg / kOneGroup, A | (B << 24) | (1ull << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u32 n = S.nEnt, nBad = S.nBad[0];
+      bool good = false;
+      // (the stream's first block is what it is; any other piece's first survivor may be the false one -- and the second)
+      const u32 tries = (S.over || nBad > kScanBadCap || n == 0u) ? 0u : ((dataRel >= PRE && dataRel < pieceEndRel) ? 1u : 3u);
+      for (u32 start = 0; start < tries && start < n && !good; start++)
+      {
+        u32 nFalse = start, nIns = 0u, cur = start, exitRel = S.exitRel;
+        bool fail = start > kScanFalseCap;
+        while (!fail)
+        {
+          u32 a = 0xFFFFu;    // the first entry from cur on whose link to the next one is broken
+          for (u32 j = 0; j < nBad; j++) { const u32 f = (u32)S.badIdx[j]; if (f >= cur && f < a) a = f; }
+          if (a == 0xFFFFu) { good = true; break; }
+          const u32 pa = (u32)s_list[a], la = parseBlock(pa, false, 0u);
+          if (la == 0u) { fail = true; break; }
+          const u32 ea = pa + la;
+          u32 k = a + 1u;
+          while (k < n && (u32)s_list[k] < ea && !fail)    // survivors inside this block: none of them is one
+          {
+            if (nFalse < kScanFalseCap) S.falseIdx[nFalse] = (u16)k; else fail = true;
+            nFalse++; k++;
+          }
+          if (fail) break;
+          // what lies between this block's end and the next survivor (or the piece's end): blocks the scan cannot see
+          const u32 target = k < n ? (u32)s_list[k] : (lastPiece ? blobRel : pieceEndRel);
+          u32 xx = ea;
+          while (xx < target && !fail)
+          {
+            const u32 lx = xx < pieceEndRel ? parseBlock(xx, false, 0u) : 0u;
+            if (lx == 0u || nIns >= kScanInsCap) { fail = true; break; }
+            S.insPos[nIns++] = (u16)xx;
+            xx += lx;
+          }
+          if (fail) break;
+          if (k < n) { if (xx != target) { fail = true; break; } cur = k; }
+          else
+          {
+            if (lastPiece ? xx != blobRel : xx < pieceEndRel) { fail = true; break; }
+            exitRel = xx; good = true; break;
+          }
+        }
+        if (good)
+        {
+          for (u32 j = 0; j < start; j++) S.falseIdx[j] = (u16)j;
+          for (u32 j = 0; j < nFalse; j++) { const u32 pos = (u32)s_list[S.falseIdx[j]]; s_sb[pos >> 5] &= ~(1u << (pos & 31u)); }
+          for (u32 j = 0; j < nIns; j++) { const u32 pos = (u32)S.insPos[j]; s_sb[pos >> 5] |= 1u << (pos & 31u); }
+          (void)exitRel;
+        }
+      }
+      if (!good) S.bad = 1u;
+      S.mended = good ? 1u : 0u;
     }
+    __syncthreads();
+    if (S.mended)
+    {
+      buildList();
+      tilePass(1u);
+      if (S.nBad[1] != 0u) S.bad = 1u;    // (mended once; a list that still does not tile goes the long way)
+    }
+  }
 
-    // ---- candidates: lane = unit with hits.  A bit-stuffed block reads: flag byte (bits 0-1 == 1, bits 6-7 the type of the
-    // offset, bit 2 clear from codec 5 on), the offset in that type, the bits byte 10?nnnnn (bit 5: look-up table), the count 64,
-    // [table size + 1, table,] payload (Lerc2.cpp:1961-2021, BitStuffer2.cpp:35-153).  The count byte stands 2 + (bytes of the
-    // offset) behind the flag byte: each offset type is tried.  The twelve bytes in front of the count byte's successor come out
-    // of four LDS words, shifted so that the byte 10 in front of the count byte is byte 0.
-    auto candidate = [&](u32 q)    // q: a count byte
+  // ---- count out: blocks of this piece, and where its last block ends (relative to the piece's end)
+  const u32 total = S.bad ? 0u : S.nEnt;
+  if (threadIdx.x == 0)
+  {
+    const u32 ex = S.exitRel >= pieceEndRel ? min(S.exitRel - pieceEndRel, 0xFFFFu) : 0xFFFFu;
+    publish64(b.wgCell + wg, tag | ((u64)ex << 16) | (u64)min(total, 0xFFFFu));
+  }
+  // the first round's block places need the cells of the pieces in front -- those of this group, and one per group in front; the
+  // piece right in front also says where its last block ends: this piece's first block has to begin there
+  const u32 grp = wg / kOneGroup, g0 = grp * kOneGroup, nIn = wg - g0;
+  {
+    u64 part = 0;
+    bool lost = false;
+    const u32 nCells = nIn + grp + ((nIn == 0u && wg != 0u) ? 1u : 0u);
+    for (u32 i = threadIdx.x; i < nCells; i += NT)
     {
-    const u32 wi = (q + 6u) >> 2, sh = 8u * ((q + 6u) & 3u);             // (word index into inAll: 16 bytes of zeros in front)
-    const u32 w0 = S.inAll[wi], w1 = S.inAll[wi + 1], w2 = S.inAll[wi + 2], w3 = S.inAll[wi + 3];
-    const u32 a0 = __builtin_amdgcn_alignbit(w1, w0, sh), a1 = __builtin_amdgcn_alignbit(w2, w1, sh), a2 = __builtin_amdgcn_alignbit(w3, w2, sh);
-    const u32 tB = (a2 >> 8) & 0xFFu, nb = tB & 31u, lut = (tB >> 5) & 1u;
-    const u32 nLut = ((a2 >> 24) - 1u) & 0xFFu;                          // valid: 1 ... 254
-    const bool okLut = (lut == 0u) | ((nLut - 1u) < 254u);
-    const u32 payload = lut ? 1u + ((nLut * nb + 7u) >> 3) + 8u * (u32)bitLen(nLut) : 8u * nb;
-#pragma unroll
-    for (u32 tc = 0; tc < 4; tc++)
-    {
-      const u32 offB = (offBytesTable<DT>() >> (4u * tc)) & 15u;
-      if (offB == 0u) continue;
-      const u32 m = 8u - offB;                                           // the flag byte is byte m of the twelve
-      const u32 flag = ((m < 4u ? a0 : m < 8u ? a1 : a2) >> (8u * (m & 3u))) & 0xFFu;
-      const u32 len = 3u + offB + payload;
-      const bool ok = (flag & 3u) == 1u && (flag >> 6) == tc && !(v5 && (flag & 4u)) && okLut && len <= RAW && q >= 2u + offB;
-      const u32 p = q - 2u - offB, e = p + len;
-      if (ok && p >= dataRel && p < pieceEndRel && e <= blobRel)
+      const u64* pc = i < nIn ? b.wgCell + g0 + i : i < nIn + grp ? b.wgGroupCell + (i - nIn) : b.wgCell + (wg - 1u);
+      u64 c = observe64(pc);
+      for (u32 spin = 0; (u32)(c >> 32) != epoch && spin < b.spinLimit; spin++)
       {
-        atomicOr(&s_sb[p >> 5], 1u << (p & 31u));
-        atomicOr(&s_end[e >> 5], 1u << (e & 31u));                      // (e < pieceEndRel + W: inside the bitmap)
+        __builtin_amdgcn_s_sleep(4);
+        c = observe64(pc);
       }
+      if ((u32)(c >> 32) != epoch) { lost = true; c = 0; }
+      else if (i == nIn - 1u || i == nIn + grp) S.prevExit = ((u32)c >> 16) & 0xFFFFu;    // (the piece right in front)
+      if (i < nIn + grp) part += i < nIn ? (u64)((u32)c & 0xFFFFu) : ((u64)(u32)c << 32);    // (a piece's cell: exit (16) | blocks (16))
     }
-    };
+    if (__any(lost) && lane == 0) S.lost = 1u;
+    if (nCells != 0u)
     {
-      const u32 nQ = min(S.nQueue, kQueueCap);
-      for (u32 h = threadIdx.x; h < nQ; h += NT)
+      part = waveSum(part);
+      if (lane == 0 && part) atomicAdd((unsigned long long*)&S.part, (unsigned long long)part);
+    }
+  }
+  __syncthreads();
+  TRACES(5);
+  if (S.lost)    // gave up waiting (never seen; the general path takes the band)
+  {
+    if (threadIdx.x == 0) raiseFlag(b, 3);
+    return;
+  }
+  const u32 inGroup = (u32)S.part, base = (u32)(S.part >> 32) + inGroup;
+  if (threadIdx.x == 0)
+  {
+    if (wg == g0 + kOneGroup - 1u) publish64(b.wgGroupCell + grp, tag | (u64)(inGroup + total));    // this group's total, for the groups behind
+    if (S.over) raiseFlag(b, 0);
+    bool bad = S.bad != 0u;
+    // where this piece's blocks begin: with the stream (the first piece), else where the piece in front says its last block ends
+    const u32 first = total ? (u32)s_list[0] : S.exitRel;
+    if (wg == 0u) bad = bad || first != dataRel;
+    else bad = bad || S.prevExit == 0xFFFFu || first != PRE + S.prevExit;
+    if (total == 0u && !lastPiece) bad = true;    // (a piece is longer than any block)
+    if (bad) raiseFlag(b, 1);
+    // the pieces hold all the raster's blocks, or the band goes the long way
+    if (lastPiece && (base + total != hp.nBlocks || S.exitRel != blobRel)) raiseFlag(b, 2);
+  }
+
+  // ---- rounds of at most R blocks (cut on multiples of BPW blocks of the RASTER, like the wave tiles below)
+  const bool pow2 = (hp.nTH & (hp.nTH - 1u)) == 0u;
+  const u32 thShift = 31u - (u32)__clz((int)hp.nTH);
+  const int r = lane >> 3, c = lane & 7, bb = c / LPR, h = c % LPR;
+  const i64 invI = (i64)p.invScale, zMaxI = (i64)p.zMaxHdr;
+  bool bad = false;
+  for (u32 fLo = 0; fLo < total; )
+  {
+    const u32 fHi = min(total, ((base + fLo + R) / (u32)BPW) * (u32)BPW - base);
+    // ---- the blocks' places: lane = block (the first round's headers are parsed already)
+    {
+      const u32 f = fLo + threadIdx.x;
+      if (f < fHi)
       {
-        const u32 ent = s_queue[h], unit = ent & 0xFFFFu;
-        u32 hh = ent >> 16;
-        while (hh)
-        {
-          const u32 k = (u32)__ffs((int)hh) - 1u;
-          hh &= hh - 1u;
-          candidate(16u * unit + 4u * (k & 3u) + (k >> 2));
-        }
-      }
-      // (a count byte in the first byte of a wave's first unit: the scan did not see the byte in front of it)
-      if (threadIdx.x >= NT - (u32)kRounds * kWaves)
-      {
-        const u32 j = threadIdx.x - (NT - (u32)kRounds * kWaves);
-        const u32 unit = (j / kWaves) * NT + 64u * (j % kWaves);
-        const u32 q = 16u * unit;
-        if (unit != 0u && unit < G::kScanUnits)
-        {
-          const u32 two = __builtin_amdgcn_alignbit(s_in[q >> 2], s_in[(q >> 2) - 1u], 24);    // the byte in front, then the unit's first
-          if ((two & 0xFFC0u) == 0x4080u && (two & 31u) != 0u) candidate(q);
-        }
-      }
-      if (threadIdx.x == 0 && dataRel >= PRE && dataRel < pieceEndRel)    // the stream's first block, whatever it is
-      {
-        atomicOr(&s_sb[dataRel >> 5], 1u << (dataRel & 31u));
-        atomicOr(&s_end[dataRel >> 5], 1u << (dataRel & 31u));
+        const u32 t = threadIdx.x;
+        if (fLo != 0u) (void)parseBlock((u32)s_list[f], true, t);
+        u32 code = s_code[t];
+        const u32 sigHdr = s_at[t];
+        const u32 blk = base + f;          // index of the block in the raster
+        const u32 it = pow2 ? (blk >> thShift) : blk / hp.nTH, jt = blk - it * hp.nTH;
+        if (sigHdr != (jt & pattern) || blk >= hp.nBlocks) code = 0;    // signature = (j0 >> 3) & pattern, j0 = 8 jt
+        if (code == 0u) { s_code[t] = 0u; bad = true; }
+        s_at[t] = code ? (it * 8u) * (u32)p.nCols + jt * 8u : kNoOffset;
       }
     }
     __syncthreads();
-    TRACEI(2);
-
-    // ---- survivors of the piece's own bytes: a thread's two bitmap words; their list by popcounts and one scan
-    const u32 myWord = G::kOwnWord0 + 2u * threadIdx.x;
-    { s_sb[myWord] &= s_end[myWord]; s_sb[myWord + 1u] &= s_end[myWord + 1u]; }
-    auto buildList = [&]()
+    // ---- pixels: a wave takes BPW blocks at a time, a lane V consecutive pixels of one raster row of one block.  Wave tiles
+    // lie on multiples of BPW blocks of the raster: a tile row is then a whole 128-byte line of the output
+    const u32 blkLo = base + fLo, blkHi = base + fHi;
+    const u32 g1 = (blkHi + BPW - 1) / BPW;
+    for (u32 g = blkLo / BPW + (u32)w; g < g1; g += kWaves)
     {
-      const u32 s0 = s_sb[myWord], s1 = s_sb[myWord + 1u];
-      const u32 c = (u32)__popc(s0) + (u32)__popc(s1);
-      const u32 inc = waveInclusiveScan(c);
-      if (lane == 63) S.wsum[w] = inc;
-      __syncthreads();                                  // (and: the queue, which the list lies on, has been read by everybody)
-      u32 idx = inc - c;
-      for (int k = 0; k < w; k++) idx += S.wsum[k];
-      const u32 pos0 = PRE + 64u * threadIdx.x;
-      u32 m = s0;
-      while (m) { const u32 bt = (u32)__ffs((int)m) - 1u; m &= m - 1u; if (idx < kListCap) s_list[idx] = (u16)(pos0 + bt); idx++; }
-      m = s1;
-      while (m) { const u32 bt = (u32)__ffs((int)m) - 1u; m &= m - 1u; if (idx < kListCap) s_list[idx] = (u16)(pos0 + 32u + bt); idx++; }
-      if (threadIdx.x == NT - 1u) { S.nEnt = min(idx, kListCap); if (idx > kListCap) S.over = 1u; }
-      __syncthreads();
-    };
-    buildList();
-    TRACEI(3);
-
-    // ---- every block's header in full, lane = block: length, mode, bits, offset (ReadTile's and BitStuffer2::Decode's checks), and
-    // "the blocks tile the stream": a block ends where the next one of the list begins, the last one behind the piece (the
-    // blob's last piece: with the blob).  What the pixel loop wants to know of the first R blocks is kept.
-    const FastDecodeParams hp = S.hp;
-    const struct { int nCols, version; double invScale, zMaxHdr; } p = { (int)hp.nCols, (int)hp.version, hp.invScale, hp.zMaxHdr };
-    typedef DCfg<T> C;
-    constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
-    auto& s_offs = S.u.x.offs; auto& s_code = S.u.x.code; auto& s_at = S.u.x.at;
-    // the block at staged byte pos: its length, or 0 if it is none; keep: what the pixel loop needs goes to slot t
-    auto parseBlock = [&](u32 pos, bool keep, u32 tSlot) -> u32
-    {
-      u32 h0, h1, h2;
-      ldsHeader<DT>(s_in, pos, h0, h1, h2);
-      u32 code = parseCode<DT>(h0, h1, h2, p.version);
-      if (pos + codeLen(code) > blobRel) code = 0u;
-      const u32 len = codeLen(code);
-      if (keep)
+      const u32 blk = g * BPW + (u32)bb;
+      const bool have = blk >= blkLo && blk < blkHi;
+      const u32 t = have ? blk - blkLo : 0u;         // (the tile's blocks outside the round: lanes that do nothing)
+      const u32 code = have ? s_code[t] : 0u;        // (parseBlock's word)
+      const double offset = s_offs[t];
+      const u32 at0 = s_at[t];
+      const u32 nbC = (code >> 16) & 31u, mode = (code >> 21) & 3u, lut = (code >> 23) & 1u;
+      const u32 pbit = 8u * (code & 0xFFFFu);        // payload / first raw value
+      const int e0 = r * 8 + h * V;
+      T v[V];
+#pragma unroll
+      for (int k = 0; k < V; k++) v[k] = T(0);
+      // the common case, all blocks of the wave alike: bit-stuffed without a table, the lane's V values inside 64 bits, no
+      // clamp -- three words of the stream, one funnel shift each way, V shifts
+      const bool plain = ((code >> 24) & 1u) != 0u;
+      if (__all(plain || !code))
       {
-        double offset = 0;
-        const u32 mode = codeMode(code);
-        if (code && (mode == 1 || mode == 3))
-        {
-          const u32 offB = codeOffBytes(code);
-          u64 bits = (((u64)h1 << 32) | h0) >> 8;
-          if (DT == DT_Double) bits |= (u64)h2 << 56;
-          if (offB < 8) bits &= (1ull << (8 * offB)) - 1;
-          offset = typedFromBits(bits, typeUsed(DT, (int)((h0 >> 6) & 3u)));
-        }
-        // in one word: where the payload begins (16: byte among the staged ones; the first raw value of a raw block), bits per
-        // value (5) << 16, mode (2) << 21, look-up table << 23, "plain" << 24 -- bit-stuffed without a table, a lane's V values
-        // inside 64 bits, and not even the largest value nb bits can hold reaches the header's zMax, so the pixels need no clamp
-        // -- and bit 31 (0: no such block)
-        u32 word = 0u;
         if (code)
         {
-          const u32 nb = codeBits(code), lutB = codeLut(code);
-          bool plainB = false;
-          if (mode == 1)
-          {
-            const u32 qTop = nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
-            const bool below = (DT >= DT_Float) ? (offset + (double)qTop * p.invScale < p.zMaxHdr)
-                                                : ((i64)offset + (i64)qTop * (i64)p.invScale < (i64)p.zMaxHdr);
-            plainB = below && !lutB && (u32)V * nb <= 64u;
-          }
-          const u32 pay = pos + ((mode == 1u) ? 3u + codeOffBytes(code) + lutB : 1u);
-          word = (pay & 0xFFFFu) | (nb << 16) | (mode << 21) | (lutB << 23) | ((plainB ? 1u : 0u) << 24) | 0x80000000u;
-        }
-        s_offs[tSlot] = offset;
-        s_code[tSlot] = word;
-        s_at[tSlot] = (h0 >> 2) & pattern;     // (the signature, until the block's place is known)
-      }
-      return len;
-    };
-    auto tilePass = [&](u32 pass)
-    {
-      const u32 nEnt = S.nEnt;
-      for (u32 f = threadIdx.x; f < nEnt; f += NT)
-      {
-        const u32 pos = (u32)s_list[f];
-        const u32 len = parseBlock(pos, f < R, f);
-        const u32 ext = pos + len;
-        const bool last = f + 1u == nEnt;
-        const u32 nxt = last ? 0u : (u32)s_list[f + 1u];
-        const bool ok = len != 0u && (last ? (lastPiece ? ext == blobRel : ext >= pieceEndRel) : ext == nxt);
-        if (!ok) { const u32 at = atomicAdd(&S.nBad[pass], 1u); if (at < kScanBadCap) S.badIdx[at] = (u16)f; }
-        if (last) S.exitRel = ext;
-      }
-      __syncthreads();
-    };
-    tilePass(0u);
-    TRACEI(4);
-
-    // ---- a list that does not tile is mended by one thread (see the head of the file): false survivors struck, gaps walked.
-    // Nothing is written until the whole list has been gone through; then the survivors' bitmap is corrected and the list built
-    // again from it.
-    if (S.nBad[0] != 0u)
-    {
-      if (threadIdx.x == 0)
-      {
-        const u32 n = S.nEnt, nBad = S.nBad[0];
-        bool good = false;
-        // (the stream's first block is what it is; any other piece's first survivor may be the false one -- and the second)
-        const u32 tries = (S.over || nBad > kScanBadCap || n == 0u) ? 0u : ((dataRel >= PRE && dataRel < pieceEndRel) ? 1u : 3u);
-        for (u32 start = 0; start < tries && start < n && !good; start++)
-        {
-          u32 nFalse = start, nIns = 0u, cur = start;
-          bool fail = false;
-          while (!fail)
-          {
-            u32 a = 0xFFFFu;    // the first entry from cur on whose link to the next one is broken
-            for (u32 j = 0; j < nBad; j++) { const u32 f = (u32)S.badIdx[j]; if (f >= cur && f < a) a = f; }
-            if (a == 0xFFFFu) { good = true; break; }
-            const u32 pa = (u32)s_list[a], la = parseBlock(pa, false, 0u);
-            if (la == 0u) { fail = true; break; }
-            const u32 ea = pa + la;
-            u32 k = a + 1u;
-            while (k < n && (u32)s_list[k] < ea && !fail)    // survivors inside this block: none of them is one
-            {
-              if (nFalse < kScanFalseCap) S.falseIdx[nFalse] = (u16)k; else fail = true;
-              nFalse++; k++;
-            }
-            if (fail) break;
-            // what lies between this block's end and the next survivor (or the piece's end): blocks the scan cannot see
-            const u32 target = k < n ? (u32)s_list[k] : (lastPiece ? blobRel : pieceEndRel);
-            u32 xx = ea;
-            while (xx < target && !fail)
-            {
-              const u32 lx = xx < pieceEndRel ? parseBlock(xx, false, 0u) : 0u;
-              if (lx == 0u || nIns >= kScanInsCap) { fail = true; break; }
-              S.insPos[nIns++] = (u16)xx;
-              xx += lx;
-            }
-            if (fail) break;
-            if (k < n) { if (xx != target) { fail = true; break; } cur = k; }
-            else
-            {
-              if (lastPiece ? xx != blobRel : xx < pieceEndRel) { fail = true; break; }
-              good = true; break;
-            }
-          }
-          if (good)
-          {
-            for (u32 j = 0; j < start; j++) S.falseIdx[j] = (u16)j;
-            for (u32 j = 0; j < nFalse; j++) { const u32 pos = (u32)s_list[S.falseIdx[j]]; s_sb[pos >> 5] &= ~(1u << (pos & 31u)); }
-            for (u32 j = 0; j < nIns; j++) { const u32 pos = (u32)S.insPos[j]; s_sb[pos >> 5] |= 1u << (pos & 31u); }
-          }
-        }
-        if (!good) S.bad = 1u;
-        S.mended = good ? 1u : 0u;
-      }
-      __syncthreads();
-      if (S.mended)
-      {
-        buildList();
-        tilePass(1u);
-        if (S.nBad[1] != 0u) S.bad = 1u;    // (mended once; a list that still does not tile goes the long way)
-      }
-    }
-
-    // ---- count out: blocks of this piece, and where its last block ends (relative to the piece's end)
-    const u32 total = S.bad ? 0u : S.nEnt;
-    if (threadIdx.x == 0)
-    {
-      const u32 ex = S.exitRel >= pieceEndRel ? min(S.exitRel - pieceEndRel, 0xFFFFu) : 0xFFFFu;
-      publish64(b.wgCell + wg, tag | ((u64)ex << 16) | (u64)min(total, 0xFFFFu));
-    }
-    // the blocks' places need the cells of the pieces in front -- those of this group, and one per group in front; the piece right in
-    // front also says where its last block ends: this piece's first block has to begin there.  They are asked for now; the next
-    // item's bytes are scanned while they travel.
-    const u32 grp = wg / kOneGroup, g0 = grp * kOneGroup, nIn = wg - g0;
-    const u32 nCells = nIn + grp + ((nIn == 0u && wg != 0u) ? 1u : 0u);
-    auto cellOf = [&](u32 i) -> const u64* { return i < nIn ? b.wgCell + g0 + i : i < nIn + grp ? b.wgGroupCell + (i - nIn) : b.wgCell + (wg - 1u); };
-    u64 cell0 = 0;
-    if (threadIdx.x < nCells) cell0 = observe64(cellOf(threadIdx.x));
-#ifndef LERC_SCAN_NO_SHADOW    // (tuning knob: the scan at the top of the next item instead)
-    if (!scanned && nextWanted) { scanRegs(); scanned = true; }
-#endif
-    {
-      u64 part = 0;
-      bool lost = false;
-      for (u32 i = threadIdx.x; i < nCells; i += NT)
-      {
-        const u64* pc = cellOf(i);
-        u64 c = i == threadIdx.x ? cell0 : observe64(pc);
-        for (u32 spin = 0; (u32)(c >> 32) != epoch && spin < b.spinLimit; spin++)
-        {
-          __builtin_amdgcn_s_sleep(4);
-          c = observe64(pc);
-        }
-        if ((u32)(c >> 32) != epoch) { lost = true; c = 0; }
-        else if (i == nIn - 1u || i == nIn + grp) S.prevExit = ((u32)c >> 16) & 0xFFFFu;    // (the piece right in front)
-        if (i < nIn + grp) part += i < nIn ? (u64)((u32)c & 0xFFFFu) : ((u64)(u32)c << 32);    // (a piece's cell: exit (16) | blocks (16))
-      }
-      if (__any(lost) && lane == 0) S.lost = 1u;
-      if (nCells != 0u)
-      {
-        part = waveSum(part);
-        if (lane == 0 && part) atomicAdd((unsigned long long*)&S.part, (unsigned long long)part);
-      }
-    }
-    __syncthreads();
-    TRACEI(5);
-    if (S.lost)    // gave up waiting (never seen; the general path takes the band)
-    {
-      if (threadIdx.x == 0) raise(3);
-    }
-    else
-    {
-    const u32 inGroup = (u32)S.part, base = (u32)(S.part >> 32) + inGroup;
-    if (threadIdx.x == 0)
-    {
-      if (wg == g0 + kOneGroup - 1u) publish64(b.wgGroupCell + grp, tag | (u64)(inGroup + total));    // this group's total, for the groups behind
-      if (S.over) raise(0);
-      bool bad = S.bad != 0u;
-      // where this piece's blocks begin: with the stream (the first piece), else where the piece in front says its last block ends
-      u32 exitRel = S.exitRel;
-      if (total == 0u && lastPiece && wg != 0u && S.prevExit != 0xFFFFu) exitRel = PRE + S.prevExit;    // (the last block began in the piece in front)
-      const u32 first = total ? (u32)s_list[0] : exitRel;
-      if (wg == 0u) bad = bad || first != dataRel;
-      else bad = bad || S.prevExit == 0xFFFFu || first != PRE + S.prevExit;
-      if (total == 0u && !lastPiece) bad = true;    // (a piece is longer than any block)
-      if (bad) raise(1);
-      // the pieces hold all the raster's blocks, or the band goes the long way
-      if (lastPiece && (base + total != hp.nBlocks || exitRel != blobRel)) raise(2);
-    }
-
-    // ---- rounds of at most R blocks (cut on multiples of BPW blocks of the RASTER, like the wave tiles below)
-    const bool pow2 = (hp.nTH & (hp.nTH - 1u)) == 0u;
-    const u32 thShift = 31u - (u32)__clz((int)hp.nTH);
-    const int r = lane >> 3, c = lane & 7, bb = c / LPR, h = c % LPR;
-    const i64 invI = (i64)p.invScale, zMaxI = (i64)p.zMaxHdr;
-    bool bad = false;
-    for (u32 fLo = 0; fLo < total; )
-    {
-      const u32 fHi = min(total, ((base + fLo + R) / (u32)BPW) * (u32)BPW - base);
-      // ---- the blocks' places: lane = block (the first round's headers are parsed already)
-      {
-        const u32 f = fLo + threadIdx.x;
-        if (f < fHi)
-        {
-          const u32 tSlot = threadIdx.x;
-          if (fLo != 0u) (void)parseBlock((u32)s_list[f], true, tSlot);
-          u32 code = s_code[tSlot];
-          const u32 sigHdr = s_at[tSlot];
-          const u32 blk = base + f;          // index of the block in the raster
-          const u32 it = pow2 ? (blk >> thShift) : blk / hp.nTH, jt = blk - it * hp.nTH;
-          if (sigHdr != (jt & pattern) || blk >= hp.nBlocks) code = 0;    // signature = (j0 >> 3) & pattern, j0 = 8 jt
-          if (code == 0u) { s_code[tSlot] = 0u; bad = true; }
-          s_at[tSlot] = code ? (it * 8u) * (u32)p.nCols + jt * 8u : kNoOffset;
-        }
-      }
-      __syncthreads();
-      // ---- pixels: a wave takes BPW blocks at a time, a lane V consecutive pixels of one raster row of one block.  Wave tiles
-      // lie on multiples of BPW blocks of the raster: a tile row is then a whole 128-byte line of the output
-      const u32 blkLo = base + fLo, blkHi = base + fHi;
-      const u32 g1 = (blkHi + BPW - 1) / BPW;
-      for (u32 g = blkLo / BPW + (u32)w; g < g1; g += kWaves)
-      {
-        const u32 blk = g * BPW + (u32)bb;
-        const bool have = blk >= blkLo && blk < blkHi;
-        const u32 tSlot = have ? blk - blkLo : 0u;     // (the tile's blocks outside the round: lanes that do nothing)
-        const u32 code = have ? s_code[tSlot] : 0u;    // (parseBlock's word)
-        const double offset = s_offs[tSlot];
-        const u32 at0 = s_at[tSlot];
-        const u32 nbC = (code >> 16) & 31u, mode = (code >> 21) & 3u, lut = (code >> 23) & 1u;
-        const u32 pbit = 8u * (code & 0xFFFFu);        // payload / first raw value
-        const int e0 = r * 8 + h * V;
-        T v[V];
+          const u32 nb = nbC;
+          const u32 bit0 = pbit + (u32)e0 * nb, wi = bit0 >> 5;
+          const u32 x0 = s_in[wi], x1 = s_in[wi + 1], x2 = s_in[wi + 2];
+          const u64 all = ((u64)__builtin_amdgcn_alignbit(x2, x1, bit0) << 32) | __builtin_amdgcn_alignbit(x1, x0, bit0);
+          const u32 mask = nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+          const i64 offI = (i64)offset;
 #pragma unroll
-        for (int k = 0; k < V; k++) v[k] = T(0);
-        // the common case, all blocks of the wave alike: bit-stuffed without a table, the lane's V values inside 64 bits, no
-        // clamp -- three words of the stream, one funnel shift each way, V shifts
-        const bool plain = ((code >> 24) & 1u) != 0u;
-        if (__all(plain || !code))
-        {
-          if (code)
+          for (int k = 0; k < V; k++)
           {
-            const u32 nb = nbC;
-            const u32 bit0 = pbit + (u32)e0 * nb, wi = bit0 >> 5;
-            const u32 x0 = s_in[wi], x1 = s_in[wi + 1], x2 = s_in[wi + 2];
-            const u64 all = ((u64)__builtin_amdgcn_alignbit(x2, x1, bit0) << 32) | __builtin_amdgcn_alignbit(x1, x0, bit0);
-            const u32 mask = nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
-            const i64 offI = (i64)offset;
-#pragma unroll
-            for (int k = 0; k < V; k++)
-            {
-              const u32 q = (u32)(all >> ((u32)k * nb)) & mask;
-              if (DT >= DT_Float) v[k] = (T)(offset + (double)q * p.invScale);    // Lerc2.cpp:2159-2160, no contraction
-              else v[k] = (T)(offI + (i64)q * invI);
-            }
-            struct alignas(sizeof(T) * V) Vec { T e[V]; };
-            Vec o;
-#pragma unroll
-            for (int k = 0; k < V; k++) o.e[k] = v[k];
-            DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
-          }
-        }
-        else if (code)
-        {
-          if (mode == 0)
-          {
-#pragma unroll
-            for (int k = 0; k < V; k++)
-            {
-              const u32 bp = pbit + (u32)(e0 + k) * 8u * (u32)sizeof(T);
-              u64 bits = ldsBits(s_in, bp, 32);
-              if (sizeof(T) == 8) bits |= (u64)ldsBits(s_in, bp + 32, 32) << 32;
-              else if (sizeof(T) < 4) bits &= (1ull << (8 * sizeof(T))) - 1;
-              memcpy(&v[k], &bits, sizeof(T));
-            }
-          }
-          else if (mode == 3)
-          {
-#pragma unroll
-            for (int k = 0; k < V; k++) v[k] = (T)offset;
-          }
-          else if (mode == 1)
-          {
-            const int nb = (int)nbC;
-            const i64 offI = (i64)offset;
-            if (!lut)
-            {
-#pragma unroll
-              for (int k = 0; k < V; k++)
-                v[k] = dequant<T>(offset, ldsBits(s_in, pbit + (u32)(e0 + k) * (u32)nb, nb), p.invScale, p.zMaxHdr, offI, invI, zMaxI);
-            }
-            else
-            {
-              const u32 nLut = (ldsBits(s_in, pbit - 8u, 8) - 1u) & 0xFFu;    // (the byte in front of the table: its size + 1)
-              const int nbIdx = bitLen(nLut);
-              const u32 idxBit = pbit + 8u * ((nLut * (u32)nb + 7) >> 3);
-#pragma unroll
-              for (int k = 0; k < V; k++)
-              {
-                u32 ix = ldsBits(s_in, idxBit + (u32)(e0 + k) * (u32)nbIdx, nbIdx);
-                if (ix > nLut) { ix = 0; bad = true; }    // the reference would read outside its table here
-                const u32 q = ix ? ldsBits(s_in, pbit + (ix - 1) * (u32)nb, nb) : 0u;
-                v[k] = dequant<T>(offset, q, p.invScale, p.zMaxHdr, offI, invI, zMaxI);
-              }
-            }
+            const u32 q = (u32)(all >> ((u32)k * nb)) & mask;
+            if (DT >= DT_Float) v[k] = (T)(offset + (double)q * p.invScale);    // Lerc2.cpp:2159-2160, no contraction
+            else v[k] = (T)(offI + (i64)q * invI);
           }
           struct alignas(sizeof(T) * V) Vec { T e[V]; };
           Vec o;
@@ -779,88 +631,128 @@ k_fast_decode_scan(FastDecodeBuffers b0, FastDecodeBatch t, ScanLaunch sl, const
           DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
         }
       }
-      fLo = fHi;
-      if (fLo < total) __syncthreads();    // (the round's arrays are taken again)
-    }
-    TRACEI(6);
-    if (__any(bad) && lane == 0) raise(3);
-
-    // ---- checksum: the workgroup of the tile's last piece waits for everybody's terms (they were sent off microseconds after each
-    // piece was taken up), folds them and clears the accumulators for the next call (Lerc2.cpp:1037-1064)
-    if (lastPiece)
-    {
-      __syncthreads();    // (S.fa / S.fb are free)
-      const u32 nGroups = fastOneGroups(nWG);
-      u64 A = 0, B = 0;
-      bool lostF = false;
-      for (u32 i = threadIdx.x; i < nGroups; i += NT)
+      else if (code)
       {
-        const u64 want = (u64)min(kOneGroup, nWG - i * kOneGroup);
-        u64 v = observe64(b.wgAcc + i);
-        for (u32 spin = 0; (v >> 48) != want && spin < (1u << 22); spin++)
+        if (mode == 0)
         {
-          __builtin_amdgcn_s_sleep(8);
-          v = observe64(b.wgAcc + i);
+#pragma unroll
+          for (int k = 0; k < V; k++)
+          {
+            const u32 bp = pbit + (u32)(e0 + k) * 8u * (u32)sizeof(T);
+            u64 bits = ldsBits(s_in, bp, 32);
+            if (sizeof(T) == 8) bits |= (u64)ldsBits(s_in, bp + 32, 32) << 32;
+            else if (sizeof(T) < 4) bits &= (1ull << (8 * sizeof(T))) - 1;
+            memcpy(&v[k], &bits, sizeof(T));
+          }
         }
-        if ((v >> 48) != want) lostF = true;
-        publish64(b.wgAcc + i, 0ull);
-        A += v & 0xFFFFFFull; B += (v >> 24) & 0xFFFFFFull;
-      }
-      A = waveSum(A % 65535u); B = waveSum(B % 65535u);
-      if (lane == 0) { S.fa[w] = A; S.fb[w] = B; }
-      if (__any(lostF) && lane == 0) raise(3);
-      __syncthreads();
-      if (threadIdx.x == 0)
-      {
-        A = 0; B = 0;
-        for (u32 i = 0; i < kWaves; i++) { A += S.fa[i]; B += S.fb[i]; }
-        A %= 65535u; B %= 65535u;
-        const u64 N = ((u64)(blobEnd - 14u) + 1) / 2;
-        u64 s1 = A, s2 = ((N % 65535u) * A + 65535u - B) % 65535u;
-        if (s1 == 0) s1 = 0xffff;
-        if (s2 == 0) s2 = 0xffff;
-        const u32 good = ((u32)((s2 << 16) | s1) == S.hp.expectChecksum) ? 1u : 0u;
-        publish32(&b.params->checksumOk, good);
-        if (b.hostParams) b.hostParams->checksumOk = good;
+        else if (mode == 3)
+        {
+#pragma unroll
+          for (int k = 0; k < V; k++) v[k] = (T)offset;
+        }
+        else if (mode == 1)
+        {
+          const int nb = (int)nbC;
+          const i64 offI = (i64)offset;
+          if (!lut)
+          {
+#pragma unroll
+            for (int k = 0; k < V; k++)
+              v[k] = dequant<T>(offset, ldsBits(s_in, pbit + (u32)(e0 + k) * (u32)nb, nb), p.invScale, p.zMaxHdr, offI, invI, zMaxI);
+          }
+          else
+          {
+            const u32 nLut = (ldsBits(s_in, pbit - 8u, 8) - 1u) & 0xFFu;    // (the byte in front of the table: its size + 1)
+            const int nbIdx = bitLen(nLut);
+            const u32 idxBit = pbit + 8u * ((nLut * (u32)nb + 7) >> 3);
+#pragma unroll
+            for (int k = 0; k < V; k++)
+            {
+              u32 ix = ldsBits(s_in, idxBit + (u32)(e0 + k) * (u32)nbIdx, nbIdx);
+              if (ix > nLut) { ix = 0; bad = true; }    // the reference would read outside its table here
+              const u32 q = ix ? ldsBits(s_in, pbit + (ix - 1) * (u32)nb, nb) : 0u;
+              v[k] = dequant<T>(offset, q, p.invScale, p.zMaxHdr, offI, invI, zMaxI);
+            }
+          }
+        }
+        struct alignas(sizeof(T) * V) Vec { T e[V]; };
+        Vec o;
+#pragma unroll
+        for (int k = 0; k < V; k++) o.e[k] = v[k];
+        DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
       }
     }
-    }    // (not lost)
-    }    // (live)
-    // ---- the next item: its bytes are in the registers (scanned, if this item had cells to wait for)
-    __syncthreads();    // (the LDS is free)
-    if (!scanned && nextWanted) { scanRegs(); scanned = true; }
-    item = next; next = S.tk[iter & 1u]; iter++;
-#undef TRACEI
+    fLo = fHi;
+    if (fLo < total) __syncthreads();    // (the round's arrays are taken again)
+  }
+  TRACES(6);
+  if (__any(bad) && lane == 0) raiseFlag(b, 3);
+
+  // ---- checksum: the launch's last workgroup waits for everybody's terms (they were sent off microseconds after each
+  // workgroup started), folds them and clears the accumulators for the next call (Lerc2.cpp:1037-1064)
+  if (!lastPiece) return;
+  __syncthreads();    // (S.fa / S.fb are free)
+  {
+    const u32 nGroups = fastOneGroups(nWG);
+    u64 A = 0, B = 0;
+    bool lostF = false;
+    for (u32 i = threadIdx.x; i < nGroups; i += NT)
+    {
+      const u64 want = (u64)min(kOneGroup, nWG - i * kOneGroup);
+      u64 v = observe64(b.wgAcc + i);
+      for (u32 spin = 0; (v >> 48) != want && spin < (1u << 22); spin++)
+      {
+        __builtin_amdgcn_s_sleep(8);
+        v = observe64(b.wgAcc + i);
+      }
+      if ((v >> 48) != want) lostF = true;
+      publish64(b.wgAcc + i, 0ull);
+      A += v & 0xFFFFFFull; B += (v >> 24) & 0xFFFFFFull;
+    }
+    A = waveSum(A % 65535u); B = waveSum(B % 65535u);
+    if (lane == 0) { S.fa[w] = A; S.fb[w] = B; }
+    if (__any(lostF) && lane == 0) raiseFlag(b, 3);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    A = 0; B = 0;
+    for (u32 i = 0; i < kWaves; i++) { A += S.fa[i]; B += S.fb[i]; }
+    A %= 65535u; B %= 65535u;
+    const u64 N = ((u64)(blobEnd - 14u) + 1) / 2;
+    u64 s1 = A, s2 = ((N % 65535u) * A + 65535u - B) % 65535u;
+    if (s1 == 0) s1 = 0xffff;
+    if (s2 == 0) s2 = 0xffff;
+    const u32 good = ((u32)((s2 << 16) | s1) == S.hp.expectChecksum) ? 1u : 0u;
+    publish32(&b.params->checksumOk, good);
+    if (b.hostParams) b.hostParams->checksumOk = good;
   }
 }
 
-template<class T>
-static int scanResidency()
-{
+// blockIdx.y = tile of a batch (one raster: a batch of 1); each tile has its own slice of every buffer
 #ifdef HIPSIM
-  return 1;
+#define LERC_SCAN_SGPR_CAP
 #else
-  static const int n = []() { int v = 0; return (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_fast_decode_scan<T>, (int)kScanThreads, 0) == hipSuccess && v > 0) ? v : 1; }();
-  return n;
+#define LERC_SCAN_SGPR_CAP __attribute__((amdgpu_num_sgpr(80)))
 #endif
+template<class T>
+__global__ void __launch_bounds__(kScanThreads) LERC_SCAN_SGPR_CAP
+k_fast_decode_scan(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 sizeGiven, int nRows, int nCols, T* __restrict__ outPix)
+{
+  const size_t tile = blockIdx.y;
+  b.params += tile; b.fallback += 4 * tile;
+  b.wgCell += tile * b.wgStride;
+  b.wgGroupCell += tile * b.wgGroupStride;
+  b.wgAcc += tile * b.wgGroupStride;
+  if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
+  __shared__ ScanShared<T> sm;
+  fastScanBody<T>(sm, b, blob, sizeGiven, nRows, nCols, outPix + tile * t.tileElems, blockIdx.x);
 }
 
 template<class T>
 static void launchFastDecodeScanT(int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven, const FastDecodeBuffers& b, void* out,
                                   hipStream_t st)
 {
-#ifdef HIPSIM
-  const u32 slots = 1;       // (the emulator runs workgroup after workgroup, each to its end: one workgroup takes every item)
-#else
-  static const int computeUnits = []() { hipDeviceProp_t pr; int dev = 0; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
-  const u32 slots = (u32)computeUnits * (u32)scanResidency<T>();    // workgroups the chip holds at a time
-#endif
-  ScanLaunch sl;
-  sl.ticket = b.scanTicket;
-  sl.piecesPerTile = fastScanNumWG(sizeGiven);    // (sizeGiven: the largest blob of the batch)
-  sl.nItems = sl.piecesPerTile * t.nTiles;
-  const dim3 grid(sl.nItems < slots ? sl.nItems : slots), block(kScanThreads);
-  hipLaunchKernelGGL((k_fast_decode_scan<T>), grid, block, 0, st, b, t, sl, blob, sizeGiven, nRows, nCols, (T*)out);
+  const dim3 grid(fastScanNumWG(sizeGiven), t.nTiles), block(kScanThreads);    // (sizeGiven: the largest blob of the batch)
+  hipLaunchKernelGGL((k_fast_decode_scan<T>), grid, block, 0, st, b, t, blob, sizeGiven, nRows, nCols, (T*)out);
 }
 
 // diagnostic: workgroups of the float kernel a CU holds, by the runtime's count
@@ -869,7 +761,9 @@ extern "C" __attribute__((visibility("default"))) int lerc_amd_probe_decode_scan
 #ifdef HIPSIM
   return 0;
 #else
-  return scanResidency<float>();
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fast_decode_scan<float>, (int)kScanThreads, 0) != hipSuccess) return -1;
+  return n;
 #endif
 }
 

@@ -1183,6 +1183,41 @@ def test_sim_async_device_api(libs):
         L.lerc_amd_destroy(h)
 
 
+def test_sim_decode_given_a_buffer_full_of_stale_bytes_behind_the_blob(libs):
+    """A queued decode is given the buffer's capacity as its size bound, and what lies behind the blob there is whatever the buffer
+    held before -- here the worst for the scanning decoder: nothing but bytes that read like block headers (0x8C 0x40 over and over).
+    They must not count (they once filled the queue of the blob's last piece: every queued decode went down a tier, silently);
+    the scanning decoder serves the call."""
+    import ctypes as ct
+    O, S = libs
+    L = _async_lib(S)
+    h = L.lerc_amd_create(None)
+    assert h
+    L.lerc_amd_decode_forms.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+    rng = np.random.default_rng(18)
+    try:
+        for arr, e in ((cases.terrain(64, 1024, rng, amp=300, base=1000, sigma=1.5).astype(np.float32), 0.01),
+                       (cases._cast(cases.terrain(40, 328, rng, amp=300, base=1000, sigma=1.5), np.uint16), 0)):
+            r0, b0 = O.encode(arr, e)
+            assert r0 == 0
+            blob = _aligned(len(b0) + 70000)
+            blob[:] = np.tile(np.array([0x8C, 0x40], np.uint8), blob.size // 2 + 1)[:blob.size]
+            blob[:len(b0)] = np.frombuffer(b0, np.uint8)
+            out = _aligned(arr.nbytes).view(arr.dtype).reshape(arr.shape)
+            f0 = (ct.c_ulonglong * 4)(); f1 = (ct.c_ulonglong * 4)()
+            L.lerc_amd_decode_forms(h, f0)
+            t2 = ct.c_uint(0)
+            rc = L.lerc_amd_decode_device_async(h, blob.ctypes.data, blob.size, 0, None, 1, arr.shape[1], arr.shape[0], 1, capi.dt_code(arr.dtype),
+                                                out.ctypes.data, ct.byref(t2))
+            assert rc == 0 and t2.value
+            assert L.lerc_amd_finish(h, t2.value, None) == 0
+            assert _same(O.decode(b0)[1].reshape(arr.shape), out)
+            L.lerc_amd_decode_forms(h, f1)
+            assert f1[3] == f0[3] + 1, ("the scanning decoder did not serve the call", list(f0), list(f1))
+    finally:
+        L.lerc_amd_destroy(h)
+
+
 def test_sim_workgroups_that_give_up_waiting(libs):
     """LERC_AMD_TEST_GIVEUP: every hand-off inside the one-launch encoder and the streaming decoder arrives with a tag nobody
     waits for; the waiters run into their poll limit, say so, and the host repeats the call on the general kernels --
