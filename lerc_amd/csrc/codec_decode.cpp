@@ -114,7 +114,23 @@ static bool launchFastBands(Context& ctx, int form, int dt, int nRows, int nCols
   fbuf.discCell = nullptr;
   fbuf.testRewalk = (fastTestGiveUp() & 4u) ? 1u : 0u;
   fbuf.wgCell = fbuf.wgGroupCell = fbuf.wgAcc = nullptr;
-  fbuf.scanTicket = nullptr;
+  // The scanning decoder asks for a piece's bytes without waiting for the band header where the blob is expected to reach that far:
+  // a batch's sizes are exact; a single band comes with its size (the synchronous calls) or with its buffer's capacity (a decode
+  // queued behind the encode that writes the blob) -- then what the context's last band of this shape had, plus an eighth (the
+  // bands of one job are alike), else half the raster's raw size.  A guess that is too large costs loads nobody looks at, one
+  // that is too small the header's latency in the pieces behind it.
+  {
+    const u64 raw = (u64)nRows * (u64)nCols * (u64)dtSize(dt);
+    u32 spec = sizeBound;
+    if (!dTileOffset && (u64)sizeBound * 10u >= raw * 9u)    // (as large as the raster itself: a capacity, not a size)
+    {
+      const bool alike = ctx.scanHint.dt == dt && ctx.scanHint.nRows == nRows && ctx.scanHint.nCols == nCols && ctx.scanHint.end != 0u;
+      const u64 guess = alike ? (u64)ctx.scanHint.end + ctx.scanHint.end / 8u + 65536u : raw / 2u;
+      spec = (u32)std::min<u64>(guess, sizeBound);
+    }
+    fbuf.scanSpecEnd = dTileOffset ? 0xFFFFFFFFu : spec;
+    ctx.lastStreamShape[0] = dt; ctx.lastStreamShape[1] = nRows; ctx.lastStreamShape[2] = nCols;
+  }
   fbuf.wgStride = fbuf.wgGroupStride = 0;
   // (epoch-tagged cells, never cleared: they live as long as the context and share its area with the encoder's)
   if (form >= 2)
@@ -125,9 +141,8 @@ static bool launchFastBands(Context& ctx, int form, int dt, int nRows, int nCols
     fbuf.wgStride = (u32)sWg; fbuf.wgGroupStride = (u32)sGrp;
     fbuf.wgCell = (u64*)ctx.persistentState(1, (nT * (sWg + sGrp) + 8) * 8);
     fbuf.wgGroupCell = fbuf.wgCell ? fbuf.wgCell + nT * sWg : nullptr;
-    fbuf.wgAcc = (u64*)ctx.persistentState(0, (nT * sGrp + 16) * 8);
+    fbuf.wgAcc = (u64*)ctx.persistentState(0, (nT * sGrp + 8) * 8);
     if (!fbuf.wgCell || !fbuf.wgAcc) return false;
-    fbuf.scanTicket = reinterpret_cast<u32*>(fbuf.wgAcc + nT * sGrp + 8);
     fbuf.recs = nullptr; fbuf.lists = nullptr; fbuf.chunkCell = fbuf.groupCell = fbuf.waveFletcher = nullptr;
     if (form == 3)
     {
@@ -210,6 +225,15 @@ static u32 fastBandVerdict(const u8* hCell, u32 epoch)
   return fb;
 }
 
+// a band the streaming kernels decoded: its size is the guess for the next band of that shape (launchFastBands)
+static void noteBandSize(Context& ctx, const u8* hCell)
+{
+  FastDecodeParams hp;
+  memcpy(&hp, hCell + kCellParams, sizeof(hp));
+  ctx.scanHint.dt = ctx.lastStreamShape[0]; ctx.scanHint.nRows = ctx.lastStreamShape[1]; ctx.scanHint.nCols = ctx.lastStreamShape[2];
+  ctx.scanHint.end = hp.blobEnd;
+}
+
 // Device-resident single-band blobs: everything is enqueued before a single byte of the blob has been seen by the
 // host (the header is checked by k_fast_header); one synchronisation.  handled == false: nothing was decided,
 // the caller goes the long way (header read, general kernels, exact status codes).
@@ -257,6 +281,7 @@ bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits, 
     return false;
   }
   if (form >= 1 && form <= 3) ctx.formCount[form]++;
+  noteBandSize(ctx, slot + 64);
   return true;
 }
 
@@ -748,6 +773,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
       return kOk;
     }
     if (fastLevel >= 1 && fastLevel <= 3) ctx.formCount[fastLevel]++;
+    noteBandSize(ctx, pin + 64 + (size_t)iBand * kCellBytes);
   }
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {

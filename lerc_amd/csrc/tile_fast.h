@@ -353,7 +353,7 @@ struct FastDecodeBuffers
   u32 epoch;
   u32 publishEpoch;    // == epoch; a test knob makes it differ, so that nobody ever sees a cell arrive and every waiter gives up
   u32 spinLimit;       // polls before a waiter gives up (2^22; the test knob: a few)
-  u32* scanTicket;     // the scanning decoder's item counter (tile_fast_decode_scan.hip: ScanLaunch), zero between launches
+  u32 scanSpecEnd;     // the scanning decoder: blob bytes the host expects the band to have -- pieces in front of that are asked for without waiting for the header
   u32 testRewalk;      // test knob (LERC_AMD_TEST_GIVEUP bit 2): the one-launch decoder walks every chunk's path again, as it does
                        // for the rare chunk whose path is not its walk 0
 };

@@ -343,6 +343,44 @@ template<bool THROUGH> __device__ __forceinline__ void storeParams(FastDecodePar
 // the same address in all lanes).  The full check is done once, by parseBandHeader in workgroup 0: if that one says
 // "not ours" nobody looks at what the others did.
 struct HeadLite { u32 ok, version, dataBegin, blobEnd; };
+// the band's first 64 bytes (a band is 70 bytes at least), asked for in one go: what parseHeadLite / headLiteEligible look at
+struct Head64 { uint4 a, c, d, e; };
+__device__ __forceinline__ Head64 loadHead64(const u8* __restrict__ blob, u32 sizeGiven)
+{
+  Head64 h;
+  h.a = h.c = h.d = h.e = make_uint4(0, 0, 0, 0);
+  if (sizeGiven < 70u) return h;
+  const uint4* src = reinterpret_cast<const uint4*>(blob);
+  h.a = src[0]; h.c = src[1]; h.d = src[2]; h.e = src[3];
+  return h;
+}
+template<int DT>
+__device__ __forceinline__ HeadLite parseHeadLite(const Head64& hd, u32 sizeGiven)
+{
+  constexpr u32 TB = (DT <= DT_UShort) ? 2 : (DT <= DT_Float) ? 4 : 8;
+  HeadLite h = { 0u, 0u, 0u, 0u };
+  if (sizeGiven < 70u) return h;
+  const uint4 a = hd.a, c = hd.c, d = hd.d;
+  const u32 version = (a.y >> 16) | (a.z << 16);                    // bytes 6 .. 9
+  const u32 size3 = (c.w >> 16) | (d.x << 16), size4 = (d.x >> 16) | (d.y << 16);
+  h.version = version;
+  const u32 hdr = (version >= 6u) ? 90u : (version >= 4u) ? 66u : 62u;
+  h.dataBegin = hdr + 4u + ((version >= 4u) ? 2u * TB : 0u) + 1u;   // mask byte count, ranges, one-sweep flag
+  h.blobEnd = min((version >= 4u) ? size4 : size3, sizeGiven);
+  h.ok = (version >= 3u && version <= 6u && h.blobEnd > h.dataBegin) ? 1u : 0u;
+  return h;
+}
+template<int DT>
+__device__ __forceinline__ bool headLiteEligible(const Head64& hd, u32 version, int nRows, int nCols)
+{
+  const uint4 c = hd.c, d = hd.d, e = hd.e;    // bytes 16 .. 63
+  const u32 numValid = (version >= 4u) ? ((c.z >> 16) | (c.w << 16)) : ((c.y >> 16) | (c.z << 16));    // bytes 26 .. 29 / 22 .. 25
+  const u64 z6 = ((u64)(e.x >> 16)) | ((u64)e.y << 16) | ((u64)(e.z & 0xFFFFu) << 48);
+  const u64 z4 = ((u64)(d.z >> 16)) | ((u64)d.w << 16) | ((u64)(e.x & 0xFFFFu) << 48);
+  const u64 z3 = ((u64)(d.y >> 16)) | ((u64)d.z << 16) | ((u64)(d.w & 0xFFFFu) << 48);
+  const u64 z = (version >= 6u) ? z6 : (version >= 4u) ? z4 : z3;
+  return numValid == (u32)nRows * (u32)nCols && z != 0ull && (z >> 63) == 0ull;
+}
 template<int DT>
 __device__ __forceinline__ HeadLite parseHeadLite(const u8* __restrict__ blob, u32 sizeGiven)
 {

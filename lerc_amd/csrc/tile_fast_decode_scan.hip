@@ -45,6 +45,17 @@ extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_deco
 #define TRACES(slot)
 #endif
 
+// 16-byte vectors of pixels a lane takes out of the stream while the cells of the pieces in front travel: as many as leave the
+// kernel at 80 vector registers (six waves a SIMD: three workgroups a CU)
+#ifndef LERC_SCAN_HELD
+#define LERC_SCAN_HELD 6
+#endif
+#ifndef LERC_SCAN_HELD32
+#define LERC_SCAN_HELD32 4
+#endif
+#ifndef LERC_SCAN_HELD16
+#define LERC_SCAN_HELD16 2
+#endif
 static const u32 kScanBadCap = 16, kScanFalseCap = 32, kScanInsCap = 64;
 
 template<class T> struct ScanGeom
@@ -113,7 +124,7 @@ __device__ __forceinline__ u32 countByteMaybe(u32 cur4, u32 prev4)
 
 template<class T>
 __device__ __forceinline__ void
-fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict__ blob, u32 sizeGiven, int nRows, int nCols,
+fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict__ blob, u32 sizeGiven, u32 specEnd, int nRows, int nCols,
              T* __restrict__ outPix, u32 wg)
 {
   typedef ScanGeom<T> G;
@@ -125,11 +136,46 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   auto& s_sb = S.sb; auto& s_end = S.u.end; auto& s_queue = S.l.queue; auto& s_list = S.l.list;
   const int lane = laneId(), w = waveId();
 
-  // ---- the band header: every wave reads what the front part needs of it; the first wave reads it in full (Lerc2::ReadHeader's
-  // checks) while the staged bytes are on their way, and leaves the result in LDS (workgroup 0: also where the host wants it)
-  const HeadLite hl = parseHeadLite<DT>(blob, sizeGiven);
+  // ---- the band header: every wave asks for its first 64 bytes; the first wave reads it in full (Lerc2::ReadHeader's checks)
+  // while the staged bytes are on their way, and leaves the result in LDS (workgroup 0: also where the host wants it).
+  // The piece's own bytes are asked for BEHIND the header's, without waiting for it, where the host expects the blob to reach
+  // that far (specEnd: the blob's size where it is known, else what the context's last band of this shape had -- the bands
+  // of one job are alike): the header's two microseconds are off the workgroup's critical path.  Pieces beyond that wait.
+  const u32 pieceStart = wg * P;                   // blob offset of the piece's first own byte = of LDS byte PRE
+  const Head64 h64 = loadHead64(blob, sizeGiven);
+  constexpr int kRounds = G::kRounds;
+  uint4 x[kRounds];
+  const u32 aMine = pieceStart + 16u * threadIdx.x - PRE;    // (wraps for the first piece's units in front of the blob: not loaded)
+  // all loads in flight at once (clipped to what the caller says is readable; 32-bit offsets from the blob's first byte: a blob
+  // is less than 4 GB; the bytes in front of the first piece do not exist).  A round in which a wave has no unit -- the last
+  // one, for all waves but the first -- is skipped by that wave, here and below.
+  auto issueLoads = [&]()
+  {
+#pragma unroll
+    for (int k = 0; k < kRounds; k++)
+    {
+      x[k] = make_uint4(0, 0, 0, 0);
+      if ((u32)k * NT + 64u * (u32)w >= kUnits) continue;
+      const u32 i = (u32)k * NT + threadIdx.x;
+      const u32 a = aMine + (u32)k * NT * 16u;
+      if (i < kUnits && (wg != 0u || i >= PRE / 16u))
+      {
+        if (a <= sizeGiven && sizeGiven - a >= 16u) x[k] = *reinterpret_cast<const uint4*>(blob + a);
+        else if (a < sizeGiven)    // never read past the blob
+        {
+          u32 t4[4] = { 0, 0, 0, 0 };
+#pragma unroll
+          for (u32 q = 0; q < 16; q++) if (q < sizeGiven - a) t4[q >> 2] |= (u32)blob[a + q] << (8 * (q & 3));
+          x[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+        }
+      }
+    }
+  };
+  const bool early = pieceStart < specEnd && pieceStart < sizeGiven;
+  if (early) issueLoads();
+  const HeadLite hl = parseHeadLite<DT>(h64, sizeGiven);
   const u32 blobEnd = hl.blobEnd;
-  const bool ours = hl.ok && headLiteEligible<DT>(blob, hl.version, nRows, nCols);
+  const bool ours = hl.ok && headLiteEligible<DT>(h64, hl.version, nRows, nCols);
   if (wg == 0u && !ours && threadIdx.x == 0)      // (not a band of ours: say so)
   {
     const FastDecodeParams hp0 = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
@@ -138,7 +184,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   const u32 nWG = fastScanNumWG(blobEnd);
   if (!ours || wg >= nWG) return;                  // (the grid is sized for the largest stream the blob could hold)
   TRACES(0);
-  const u32 pieceStart = wg * P;                   // blob offset of the piece's first own byte = of LDS byte PRE
+  if (!early) issueLoads();
   const int version = (int)hl.version;
   const bool v5 = version >= 5;
   const u32 pattern = v5 ? 14u : 15u;
@@ -150,31 +196,6 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   const u32 dataRel = hl.dataBegin + PRE > pieceStart ? hl.dataBegin + PRE - pieceStart : 0u;        // the stream's first block (or 0: in front of all this)
   const u32 pieceEndRel = PRE + P;
 
-  // ---- the staged bytes, all loads in flight at once (clipped to what the caller says is readable; 32-bit offsets from the blob's
-  // first byte: a blob is less than 4 GB; the bytes in front of the first piece do not exist).  A round in which a wave has no
-  // unit -- the last one, for all waves but the first -- is skipped by that wave, here and below.
-  constexpr int kRounds = G::kRounds;
-  uint4 x[kRounds];
-  const u32 aMine = pieceStart + 16u * threadIdx.x - PRE;    // (wraps for the first piece's units in front of the blob: not loaded)
-#pragma unroll
-  for (int k = 0; k < kRounds; k++)
-  {
-    x[k] = make_uint4(0, 0, 0, 0);
-    if ((u32)k * NT + 64u * (u32)w >= kUnits) continue;
-    const u32 i = (u32)k * NT + threadIdx.x;
-    const u32 a = aMine + (u32)k * NT * 16u;
-    if (i < kUnits && (wg != 0u || i >= PRE / 16u))
-    {
-      if (a <= sizeGiven && sizeGiven - a >= 16u) x[k] = *reinterpret_cast<const uint4*>(blob + a);
-      else if (a < sizeGiven)    // never read past the blob
-      {
-        u32 t4[4] = { 0, 0, 0, 0 };
-#pragma unroll
-        for (u32 q = 0; q < 16; q++) if (q < sizeGiven - a) t4[q >> 2] |= (u32)blob[a + q] << (8 * (q & 3));
-        x[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-      }
-    }
-  }
   if (w == 0)
   {
     const FastDecodeParams hpFull = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
@@ -510,17 +531,117 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     const u32 ex = S.exitRel >= pieceEndRel ? min(S.exitRel - pieceEndRel, 0xFFFFu) : 0xFFFFu;
     publish64(b.wgCell + wg, tag | ((u64)ex << 16) | (u64)min(total, 0xFFFFu));
   }
-  // the first round's block places need the cells of the pieces in front -- those of this group, and one per group in front; the
-  // piece right in front also says where its last block ends: this piece's first block has to begin there
+  // The blocks' places need the cells of the pieces in front -- those of this group, and one per group in front; the piece right in
+  // front also says where its last block ends: this piece's first block has to begin there.  The cells are asked for now;
+  // while they travel (the pieces in front publish when this one does, and a cell takes a few microseconds to be seen) the
+  // PIXELS are taken out of the stream: what a block's pixels ARE does not hang on where the block lies -- only where they go
+  // does.  A wave takes BPW blocks of the list at a time, a lane V consecutive pixels of one row of one block, and keeps up to
+  // kHeld such 16-byte vectors in registers; they are stored when the places are known.
+  struct alignas(sizeof(T) * V) Vec { T e[V]; };
+  constexpr u32 kHeld = sizeof(T) == 2 ? LERC_SCAN_HELD16 : (DT == DT_Float || DT == DT_Double) ? LERC_SCAN_HELD : LERC_SCAN_HELD32;
+  const int r = lane >> 3, c = lane & 7, bb = c / LPR, h = c % LPR;
+  const i64 invI = (i64)p.invScale, zMaxI = (i64)p.zMaxHdr;
+  bool bad = false;
+  // the lane's V pixels of the block in round slot tSlot (parseBlock's word and offset); a wave-uniform fast path for the common
+  // case, all blocks of the wave alike: bit-stuffed without a table, the lane's V values inside 64 bits, no clamp -- three words
+  // of the stream, one funnel shift each way, V shifts
+  auto blockRow = [&](u32 tSlot, bool have) -> Vec
+  {
+    const u32 code = have ? s_code[tSlot] : 0u;
+    const double offset = s_offs[tSlot];
+    const u32 nbC = (code >> 16) & 31u, mode = (code >> 21) & 3u, lut = (code >> 23) & 1u;
+    const u32 pbit = 8u * (code & 0xFFFFu);        // payload / first raw value
+    const int e0 = r * 8 + h * V;
+    Vec o;
+#pragma unroll
+    for (int k = 0; k < V; k++) o.e[k] = T(0);
+    const bool plain = ((code >> 24) & 1u) != 0u;
+    if (__all(plain || !code))
+    {
+      if (code)
+      {
+        const u32 nb = nbC;
+        const u32 bit0 = pbit + (u32)e0 * nb, wi = bit0 >> 5;
+        const u32 x0 = s_in[wi], x1 = s_in[wi + 1], x2 = s_in[wi + 2];
+        const u64 all = ((u64)__builtin_amdgcn_alignbit(x2, x1, bit0) << 32) | __builtin_amdgcn_alignbit(x1, x0, bit0);
+        const u32 mask = nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+        const i64 offI = (i64)offset;
+#pragma unroll
+        for (int k = 0; k < V; k++)
+        {
+          const u32 q = (u32)(all >> ((u32)k * nb)) & mask;
+          if (DT >= DT_Float) o.e[k] = (T)(offset + (double)q * p.invScale);    // Lerc2.cpp:2159-2160, no contraction
+          else o.e[k] = (T)(offI + (i64)q * invI);
+        }
+      }
+    }
+    else if (code)
+    {
+      if (mode == 0)
+      {
+#pragma unroll
+        for (int k = 0; k < V; k++)
+        {
+          const u32 bp = pbit + (u32)(e0 + k) * 8u * (u32)sizeof(T);
+          u64 bits = ldsBits(s_in, bp, 32);
+          if (sizeof(T) == 8) bits |= (u64)ldsBits(s_in, bp + 32, 32) << 32;
+          else if (sizeof(T) < 4) bits &= (1ull << (8 * sizeof(T))) - 1;
+          memcpy(&o.e[k], &bits, sizeof(T));
+        }
+      }
+      else if (mode == 3)
+      {
+#pragma unroll
+        for (int k = 0; k < V; k++) o.e[k] = (T)offset;
+      }
+      else if (mode == 1)
+      {
+        const int nb = (int)nbC;
+        const i64 offI = (i64)offset;
+        if (!lut)
+        {
+#pragma unroll
+          for (int k = 0; k < V; k++)
+            o.e[k] = dequant<T>(offset, ldsBits(s_in, pbit + (u32)(e0 + k) * (u32)nb, nb), p.invScale, p.zMaxHdr, offI, invI, zMaxI);
+        }
+        else
+        {
+          const u32 nLut = (ldsBits(s_in, pbit - 8u, 8) - 1u) & 0xFFu;    // (the byte in front of the table: its size + 1)
+          const int nbIdx = bitLen(nLut);
+          const u32 idxBit = pbit + 8u * ((nLut * (u32)nb + 7) >> 3);
+#pragma unroll
+          for (int k = 0; k < V; k++)
+          {
+            u32 ix = ldsBits(s_in, idxBit + (u32)(e0 + k) * (u32)nbIdx, nbIdx);
+            if (ix > nLut) { ix = 0; bad = true; }    // the reference would read outside its table here
+            const u32 q = ix ? ldsBits(s_in, pbit + (ix - 1) * (u32)nb, nb) : 0u;
+            o.e[k] = dequant<T>(offset, q, p.invScale, p.zMaxHdr, offI, invI, zMaxI);
+          }
+        }
+      }
+    }
+    return o;
+  };
   const u32 grp = wg / kOneGroup, g0 = grp * kOneGroup, nIn = wg - g0;
+  const u32 nCells = nIn + grp + ((nIn == 0u && wg != 0u) ? 1u : 0u);
+  auto cellOf = [&](u32 i) -> const u64* { return i < nIn ? b.wgCell + g0 + i : i < nIn + grp ? b.wgGroupCell + (i - nIn) : b.wgCell + (wg - 1u); };
+  u64 cell0 = 0;
+  if (threadIdx.x < nCells) cell0 = observe64(cellOf(threadIdx.x));
+  const u32 nFirst = min(total, R);                 // blocks of the first round: their headers are parsed
+  Vec held[kHeld];
+#pragma unroll
+  for (u32 j = 0; j < kHeld; j++)
+  {
+    const u32 f = (u32)BPW * ((u32)w + kWaves * j) + (u32)bb;
+    if ((u32)BPW * ((u32)w + kWaves * j) < nFirst) held[j] = blockRow(f, f < nFirst);    // (the same for all lanes of the wave)
+  }
   {
     u64 part = 0;
     bool lost = false;
-    const u32 nCells = nIn + grp + ((nIn == 0u && wg != 0u) ? 1u : 0u);
     for (u32 i = threadIdx.x; i < nCells; i += NT)
     {
-      const u64* pc = i < nIn ? b.wgCell + g0 + i : i < nIn + grp ? b.wgGroupCell + (i - nIn) : b.wgCell + (wg - 1u);
-      u64 c = observe64(pc);
+      const u64* pc = cellOf(i);
+      u64 c = i == threadIdx.x ? cell0 : observe64(pc);
       for (u32 spin = 0; (u32)(c >> 32) != epoch && spin < b.spinLimit; spin++)
       {
         __builtin_amdgcn_s_sleep(4);
@@ -551,25 +672,23 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     if (S.over) raiseFlag(b, 0);
     bool bad = S.bad != 0u;
     // where this piece's blocks begin: with the stream (the first piece), else where the piece in front says its last block ends
-    const u32 first = total ? (u32)s_list[0] : S.exitRel;
+    u32 exitRel = S.exitRel;
+    if (total == 0u && lastPiece && wg != 0u && S.prevExit != 0xFFFFu) exitRel = PRE + S.prevExit;    // (the stream's last block began in the piece in front)
+    const u32 first = total ? (u32)s_list[0] : exitRel;
     if (wg == 0u) bad = bad || first != dataRel;
     else bad = bad || S.prevExit == 0xFFFFu || first != PRE + S.prevExit;
     if (total == 0u && !lastPiece) bad = true;    // (a piece is longer than any block)
     if (bad) raiseFlag(b, 1);
     // the pieces hold all the raster's blocks, or the band goes the long way
-    if (lastPiece && (base + total != hp.nBlocks || S.exitRel != blobRel)) raiseFlag(b, 2);
+    if (lastPiece && (base + total != hp.nBlocks || exitRel != blobRel)) raiseFlag(b, 2);
   }
 
-  // ---- rounds of at most R blocks (cut on multiples of BPW blocks of the RASTER, like the wave tiles below)
+  // ---- rounds of at most R blocks: the blocks' places (lane = block), then the pixels' way out
   const bool pow2 = (hp.nTH & (hp.nTH - 1u)) == 0u;
   const u32 thShift = 31u - (u32)__clz((int)hp.nTH);
-  const int r = lane >> 3, c = lane & 7, bb = c / LPR, h = c % LPR;
-  const i64 invI = (i64)p.invScale, zMaxI = (i64)p.zMaxHdr;
-  bool bad = false;
   for (u32 fLo = 0; fLo < total; )
   {
-    const u32 fHi = min(total, ((base + fLo + R) / (u32)BPW) * (u32)BPW - base);
-    // ---- the blocks' places: lane = block (the first round's headers are parsed already)
+    const u32 fHi = min(total, fLo + R);
     {
       const u32 f = fLo + threadIdx.x;
       if (f < fHi)
@@ -586,101 +705,28 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       }
     }
     __syncthreads();
-    // ---- pixels: a wave takes BPW blocks at a time, a lane V consecutive pixels of one raster row of one block.  Wave tiles
-    // lie on multiples of BPW blocks of the raster: a tile row is then a whole 128-byte line of the output
-    const u32 blkLo = base + fLo, blkHi = base + fHi;
-    const u32 g1 = (blkHi + BPW - 1) / BPW;
-    for (u32 g = blkLo / BPW + (u32)w; g < g1; g += kWaves)
+    const u32 nRound = fHi - fLo;
+    auto store = [&](u32 tSlot, const Vec& o)
     {
-      const u32 blk = g * BPW + (u32)bb;
-      const bool have = blk >= blkLo && blk < blkHi;
-      const u32 t = have ? blk - blkLo : 0u;         // (the tile's blocks outside the round: lanes that do nothing)
-      const u32 code = have ? s_code[t] : 0u;        // (parseBlock's word)
-      const double offset = s_offs[t];
-      const u32 at0 = s_at[t];
-      const u32 nbC = (code >> 16) & 31u, mode = (code >> 21) & 3u, lut = (code >> 23) & 1u;
-      const u32 pbit = 8u * (code & 0xFFFFu);        // payload / first raw value
-      const int e0 = r * 8 + h * V;
-      T v[V];
+      const u32 at0 = s_at[tSlot];
+      if (at0 != kNoOffset) DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
+    };
+    u32 jFrom = 0;
+    if (fLo == 0u)
+    {
 #pragma unroll
-      for (int k = 0; k < V; k++) v[k] = T(0);
-      // the common case, all blocks of the wave alike: bit-stuffed without a table, the lane's V values inside 64 bits, no
-      // clamp -- three words of the stream, one funnel shift each way, V shifts
-      const bool plain = ((code >> 24) & 1u) != 0u;
-      if (__all(plain || !code))
+      for (u32 j = 0; j < kHeld; j++)
       {
-        if (code)
-        {
-          const u32 nb = nbC;
-          const u32 bit0 = pbit + (u32)e0 * nb, wi = bit0 >> 5;
-          const u32 x0 = s_in[wi], x1 = s_in[wi + 1], x2 = s_in[wi + 2];
-          const u64 all = ((u64)__builtin_amdgcn_alignbit(x2, x1, bit0) << 32) | __builtin_amdgcn_alignbit(x1, x0, bit0);
-          const u32 mask = nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
-          const i64 offI = (i64)offset;
-#pragma unroll
-          for (int k = 0; k < V; k++)
-          {
-            const u32 q = (u32)(all >> ((u32)k * nb)) & mask;
-            if (DT >= DT_Float) v[k] = (T)(offset + (double)q * p.invScale);    // Lerc2.cpp:2159-2160, no contraction
-            else v[k] = (T)(offI + (i64)q * invI);
-          }
-          struct alignas(sizeof(T) * V) Vec { T e[V]; };
-          Vec o;
-#pragma unroll
-          for (int k = 0; k < V; k++) o.e[k] = v[k];
-          DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
-        }
+        const u32 tSlot = (u32)BPW * ((u32)w + kWaves * j) + (u32)bb;
+        if (tSlot < nRound) store(tSlot, held[j]);
       }
-      else if (code)
-      {
-        if (mode == 0)
-        {
-#pragma unroll
-          for (int k = 0; k < V; k++)
-          {
-            const u32 bp = pbit + (u32)(e0 + k) * 8u * (u32)sizeof(T);
-            u64 bits = ldsBits(s_in, bp, 32);
-            if (sizeof(T) == 8) bits |= (u64)ldsBits(s_in, bp + 32, 32) << 32;
-            else if (sizeof(T) < 4) bits &= (1ull << (8 * sizeof(T))) - 1;
-            memcpy(&v[k], &bits, sizeof(T));
-          }
-        }
-        else if (mode == 3)
-        {
-#pragma unroll
-          for (int k = 0; k < V; k++) v[k] = (T)offset;
-        }
-        else if (mode == 1)
-        {
-          const int nb = (int)nbC;
-          const i64 offI = (i64)offset;
-          if (!lut)
-          {
-#pragma unroll
-            for (int k = 0; k < V; k++)
-              v[k] = dequant<T>(offset, ldsBits(s_in, pbit + (u32)(e0 + k) * (u32)nb, nb), p.invScale, p.zMaxHdr, offI, invI, zMaxI);
-          }
-          else
-          {
-            const u32 nLut = (ldsBits(s_in, pbit - 8u, 8) - 1u) & 0xFFu;    // (the byte in front of the table: its size + 1)
-            const int nbIdx = bitLen(nLut);
-            const u32 idxBit = pbit + 8u * ((nLut * (u32)nb + 7) >> 3);
-#pragma unroll
-            for (int k = 0; k < V; k++)
-            {
-              u32 ix = ldsBits(s_in, idxBit + (u32)(e0 + k) * (u32)nbIdx, nbIdx);
-              if (ix > nLut) { ix = 0; bad = true; }    // the reference would read outside its table here
-              const u32 q = ix ? ldsBits(s_in, pbit + (ix - 1) * (u32)nb, nb) : 0u;
-              v[k] = dequant<T>(offset, q, p.invScale, p.zMaxHdr, offI, invI, zMaxI);
-            }
-          }
-        }
-        struct alignas(sizeof(T) * V) Vec { T e[V]; };
-        Vec o;
-#pragma unroll
-        for (int k = 0; k < V; k++) o.e[k] = v[k];
-        DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
-      }
+      jFrom = kHeld;
+    }
+    for (u32 g = (u32)w + kWaves * jFrom; g * (u32)BPW < nRound; g += kWaves)
+    {
+      const u32 tSlot = g * (u32)BPW + (u32)bb;
+      const Vec o = blockRow(tSlot, tSlot < nRound);
+      if (tSlot < nRound) store(tSlot, o);
     }
     fLo = fHi;
     if (fLo < total) __syncthreads();    // (the round's arrays are taken again)
@@ -735,7 +781,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
 #endif
 template<class T>
 __global__ void __launch_bounds__(kScanThreads) LERC_SCAN_SGPR_CAP
-k_fast_decode_scan(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 sizeGiven, int nRows, int nCols, T* __restrict__ outPix)
+k_fast_decode_scan(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 sizeGiven, u32 specEnd, int nRows, int nCols, T* __restrict__ outPix)
 {
   const size_t tile = blockIdx.y;
   b.params += tile; b.fallback += 4 * tile;
@@ -744,7 +790,7 @@ k_fast_decode_scan(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 s
   b.wgAcc += tile * b.wgGroupStride;
   if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
   __shared__ ScanShared<T> sm;
-  fastScanBody<T>(sm, b, blob, sizeGiven, nRows, nCols, outPix + tile * t.tileElems, blockIdx.x);
+  fastScanBody<T>(sm, b, blob, sizeGiven, specEnd, nRows, nCols, outPix + tile * t.tileElems, blockIdx.x);
 }
 
 template<class T>
@@ -752,7 +798,7 @@ static void launchFastDecodeScanT(int nRows, int nCols, const FastDecodeBatch& t
                                   hipStream_t st)
 {
   const dim3 grid(fastScanNumWG(sizeGiven), t.nTiles), block(kScanThreads);    // (sizeGiven: the largest blob of the batch)
-  hipLaunchKernelGGL((k_fast_decode_scan<T>), grid, block, 0, st, b, t, blob, sizeGiven, nRows, nCols, (T*)out);
+  hipLaunchKernelGGL((k_fast_decode_scan<T>), grid, block, 0, st, b, t, blob, sizeGiven, b.scanSpecEnd, nRows, nCols, (T*)out);
 }
 
 // diagnostic: workgroups of the float kernel a CU holds, by the runtime's count
