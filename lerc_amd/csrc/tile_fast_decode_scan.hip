@@ -628,7 +628,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   u64 cell0 = 0;
   if (threadIdx.x < nCells) cell0 = observe64(cellOf(threadIdx.x));
   const u32 nFirst = min(total, R);                 // blocks of the first round: their headers are parsed
-  Vec held[kHeld];
+  Vec held[kHeld ? kHeld : 1u];
 #pragma unroll
   for (u32 j = 0; j < kHeld; j++)
   {
@@ -688,7 +688,8 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   const u32 thShift = 31u - (u32)__clz((int)hp.nTH);
   for (u32 fLo = 0; fLo < total; )
   {
-    const u32 fHi = min(total, fLo + R);
+    // (no vectors held: the rounds are cut on multiples of BPW blocks of the RASTER, like the wave tiles below)
+    const u32 fHi = kHeld ? min(total, fLo + R) : min(total, ((base + fLo + R) / (u32)BPW) * (u32)BPW - base);
     {
       const u32 f = fLo + threadIdx.x;
       if (f < fHi)
@@ -711,6 +712,23 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       const u32 at0 = s_at[tSlot];
       if (at0 != kNoOffset) DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
     };
+    if (kHeld == 0u)
+    {
+      // wave tiles on multiples of BPW blocks of the raster: a tile row is a whole 128-byte line of the output
+      const u32 blkLo = base + fLo, blkHi = base + fHi;
+      const u32 g1 = (blkHi + BPW - 1) / BPW;
+      for (u32 g = blkLo / BPW + (u32)w; g < g1; g += kWaves)
+      {
+        const u32 blk = g * BPW + (u32)bb;
+        const bool have = blk >= blkLo && blk < blkHi;
+        const u32 tSlot = have ? blk - blkLo : 0u;     // (the tile's blocks outside the round: lanes that do nothing)
+        const Vec o = blockRow(tSlot, have);
+        if (have) store(tSlot, o);
+      }
+      fLo = fHi;
+      if (fLo < total) __syncthreads();
+      continue;
+    }
     u32 jFrom = 0;
     if (fLo == 0u)
     {
