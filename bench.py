@@ -454,7 +454,7 @@ def main():
                 # the exchange step: all ranks' blobs on rank 0.  The transfers are enqueued here and run beside what this rank
                 # does next -- the decode of its own tiles does not hang on them (timed inside the step: start to arrival, and
                 # what of it was still to wait for behind the decode)
-                flight = shard.gather_arenas_start(out, used, offs, sizes, root=0)
+                flight = shard.gather_arenas_start(out, used, offs, sizes, root=0, after=torch.cuda.current_stream())    # (the codec's stream)
             tg0 = time.perf_counter()
             rc = api.decode_tiles_device(codec, out, offs, sizes, y)
             if rc != 0:

@@ -74,9 +74,12 @@ LERC_AMD_API lerc_status lerc_getDataRanges(const unsigned char* pLercBlob, unsi
 
 /* reference Lerc_c_api.h:238-252 -- pData / pValidBytes pre-allocated by the caller.  Lerc2 codec 2..6 and Lerc1 blobs
  * (Lerc1: pixels that are not valid keep what pData held, Lerc.cpp:2063-2107).
- * When the call returns anything but Ok the contents of pData / pValidBytes are unspecified: the streaming kernels write
- * pixels while the blob's checksum is still being summed and hand a bad blob to the general path afterwards (the
- * reference, too, leaves a partly written image behind when a block fails to parse behind a good checksum). */
+ * One difference to the reference when the call returns Failed: the reference checks a blob's checksum before it writes a pixel
+ * (Lerc2.cpp:592-601) and leaves pData / pValidBytes as they were; here the streaming kernels write pixels while the checksum is
+ * still being summed, so after a Failed decode of a blob they had taken up pData / pValidBytes hold ZEROS -- never pixels of a
+ * blob that did not pass (the device-pointer calls of lerc_amd_device.h do the same to their device buffers).  Other statuses
+ * (WrongParam, BufferTooSmall ...) are decided before anything is written.  (Behind a good checksum the reference, too, leaves a
+ * partly written image when a block fails to parse.) */
 LERC_AMD_API lerc_status lerc_decode(const unsigned char* pLercBlob, unsigned int blobSize, int nMasks,
     unsigned char* pValidBytes, int nDepth, int nCols, int nRows, int nBands, unsigned int dataType, void* pData);
 

@@ -207,6 +207,20 @@ class DeviceCodec:
         self.lib.lerc_amd_path_counters(self.h, out)
         return list(out)
 
+    def decode_forms(self):
+        """bands / tiles of this context decoded by [-, discovery + decode in two launches, the walking one-launch decoder, the scanning decoder]"""
+        out = (ct.c_ulonglong * 4)()
+        self.lib.lerc_amd_decode_forms.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+        self.lib.lerc_amd_decode_forms.restype = None
+        self.lib.lerc_amd_decode_forms(self.h, out)
+        return list(out)
+
+    def last_note(self):
+        """why the last call that left the streaming kernels (or went down a streaming tier) did so; "" if none did"""
+        self.lib.lerc_amd_last_note.argtypes = [ct.c_void_p]
+        self.lib.lerc_amd_last_note.restype = ct.c_char_p
+        return self.lib.lerc_amd_last_note(self.h).decode()
+
     def last_error(self):
         return self.lib.lerc_amd_last_error(self.h).decode()
 

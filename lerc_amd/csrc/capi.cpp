@@ -30,6 +30,17 @@ struct AsyncOp
   u32 status = kOk, bytes = 0;
 };
 
+// A decode that ends in Failed leaves zeros in the caller's device buffers: the streaming kernels write pixels while the blob's
+// checksum is still being summed (the reference checks first, Lerc2.cpp:592-601, and leaves the buffer alone).
+static void wipeDecodeOutputs(Context& ctx, const DecodeRequest& rq)
+{
+  hipStream_t st = ctx.activeStream();
+  const size_t nPix = (size_t)rq.nRows * rq.nCols;
+  if (rq.dOut) hipMemsetAsync(rq.dOut, 0, nPix * rq.nDepth * rq.nBands * (size_t)dtSize(rq.dt), st);
+  if (rq.dValidBytes && rq.nMasks > 0) hipMemsetAsync(rq.dValidBytes, 0, nPix * (size_t)rq.nMasks, st);
+  hipStreamSynchronize(st);
+}
+
 struct lerc_amd_context
 {
   Context ctx;
@@ -225,7 +236,18 @@ lerc_status decodeHost(const unsigned char* blob, unsigned blobSize, int nMasks,
   if (triedOne) rq.maxForm = ctx.lastStreamForm - 1;    // (that streaming form has just refused this blob)
   if (rq.maxForm <= 0) rq.noStreaming = true;
   const u32 rc = decodeDevice(ctx, rq);
-  if (rc != kOk) return rc;
+  if (rc != kOk)
+  {
+    // (the reference checks the checksum before it writes a pixel, Lerc2.cpp:592-601; here the streaming kernels' pixels were on
+    // their way into the caller's buffers while the checksum was being summed: what did not pass is wiped -- a failed decode
+    // leaves zeros, never pixels of a blob that is damaged)
+    if (triedOne)
+    {
+      memset(pData, 0, toDouble ? nVals * sizeof(double) : outBytes);
+      if (nMasks && pValidBytes) memset(pValidBytes, 0, maskBytes);
+    }
+    return rc;
+  }
   if (widen)
   {
     double* dWide = (double*)(dOut + ((outBytes + 255) / 256) * 256);
@@ -459,7 +481,9 @@ lerc_status lerc_amd_decode_device(lerc_amd_context* h, const unsigned char* dLe
   DecodeRequest rq;
   rq.dBlob = dLercBlob; rq.blobSize = blobSize; rq.dt = (int)dataType; rq.nDepth = nDepth; rq.nCols = nCols; rq.nRows = nRows;
   rq.nBands = nBands; rq.nMasks = nMasks; rq.dOut = dData; rq.dValidBytes = dValidBytes;
-  return decodeDevice(h->ctx, rq);
+  const u32 rc = decodeDevice(h->ctx, rq);
+  if (rc == kFailed) wipeDecodeOutputs(h->ctx, rq);
+  return rc;
 }
 
 // ---- asynchronous device API: operations queue up on the context's stream, the host runs ahead -------------------------
@@ -515,6 +539,7 @@ void completeAll(lerc_amd_context* h)
       }
       if (op.streamed) { op.dr.maxForm = op.form - 1; op.dr.noStreaming = op.dr.maxForm <= 0; }    // (that streaming form has just refused this blob)
       op.status = decodeDevice(ctx, op.dr);
+      if (op.status == kFailed) wipeDecodeOutputs(ctx, op.dr);
     }
     op.done = true;
   }

@@ -74,18 +74,24 @@ class GatherInFlight:
         return self._result
 
 
-def gather_arenas(arena, used, offsets, sizes, root=0):
+def gather_arenas(arena, used, offsets, sizes, root=0, after=None, force_collective=False):
     """The exchange step of a mosaic job in one call: gather_arenas_start(...).finish()."""
-    return gather_arenas_start(arena, used, offsets, sizes, root).finish()
+    return gather_arenas_start(arena, used, offsets, sizes, root, after, force_collective).finish()
 
 
-def gather_arenas_start(arena, used, offsets, sizes, root=0):
+def gather_arenas_start(arena, used, offsets, sizes, root=0, after=None, force_collective=False):
     """The exchange step of a mosaic job: the blobs of all ranks' tiles end up on `root`, in rank (= tile) order.
 
     arena    this rank's blob arena (uint8 tensor on the job's device: HBM under RCCL, host memory under gloo)
     used     bytes of it in use
     offsets  int64 / uint64 array-like [nLocalTiles]: where each local tile's blob starts in `arena`
     sizes    array-like [nLocalTiles]: its length
+
+    after    the stream the codec wrote `arena` on (a torch.cuda.Stream), or an event recorded there behind the encode: the
+             collective's stream is ordered behind it explicitly (RCCL's transfers run on a stream of their own, which torch
+             orders behind the CURRENT stream only -- the codec's need not be that one)
+    force_collective  run the collective steps in a process group of ONE rank too (tests: the lengths' all-gather on RCCL with
+             device tensors, the root's own copy between HBM slices; there is nobody to send to)
 
     offsets need not be monotonic (tiles a batch handed back to the general path sit behind the batch's own), a rank may
     hold no tile at all.
@@ -103,15 +109,22 @@ def gather_arenas_start(arena, used, offsets, sizes, root=0):
     sizes = torch.as_tensor(np.asarray(sizes).astype(np.int64), dtype=torch.int64)
     n_local = int(offsets.numel())
     used = int(used)
-    if world == 1:
+    grouped = dist.is_available() and dist.is_initialized()
+    if world == 1 and not (force_collective and grouped):
         return GatherInFlight((arena[:used], offsets.clone(), sizes.clone(), [0]))
+    if after is not None and dev.type == "cuda":
+        cur = torch.cuda.current_stream(dev)
+        if isinstance(after, torch.cuda.Event):
+            cur.wait_event(after)
+        else:
+            cur.wait_stream(after)
 
     # 1. how much everybody has: [bytes in use, tiles] (on the device under RCCL; gloo moves host memory)
     tdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
     mine = torch.tensor([used, n_local], dtype=torch.int64, device=tdev)
     table = torch.empty(2 * world, dtype=torch.int64, device=tdev)
     dist.all_gather_into_tensor(table, mine)
-    table = table.cpu().view(world, 2)
+    table = table.cpu().view(world, 2)    # (16 bytes a rank: the root cannot size its buffer, nor anybody post a transfer, without them)
     lens = [int(v) for v in table[:, 0]]
     tiles = [int(v) for v in table[:, 1]]
     bases, at = [], 0

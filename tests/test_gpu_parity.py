@@ -161,7 +161,9 @@ def test_against_real_reference_fuzz(P):
 
 
 # ---- full BASELINE sizes, device-pointer API ------------------------------------------------------
-def _device_roundtrip(x, max_z_err):
+def _device_roundtrip(x, max_z_err, streamed=False):
+    """streamed: the call must have been served by the streaming kernels alone -- the one-launch encoder, the scanning decoder
+    (a silent detour through the general kernels would keep every byte right and show on the bench only)"""
     import torch
     from lerc_amd import api
     codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)    # same stream as the tensor producers
@@ -172,6 +174,9 @@ def _device_roundtrip(x, max_z_err):
     rc = api.decode_device(codec, out, nb, y)
     assert rc == 0, (rc, codec.last_error())
     torch.cuda.synchronize()
+    if streamed:
+        assert codec.path_counters() == [1, 0, 1, 0], (codec.path_counters(), codec.last_note())
+        assert codec.decode_forms()[3] == 1, (codec.decode_forms(), codec.last_note())
     return out[:nb].cpu().numpy().tobytes(), y
 
 
@@ -180,7 +185,7 @@ def test_c2_full_size_8192_float32(P, O):
     import torch
     from lerc_amd import synth
     x = synth.c2_float32(8192, 8192, device="cuda:0")
-    blob, y = _device_roundtrip(x, 0.01)
+    blob, y = _device_roundtrip(x, 0.01, streamed=True)
     err = float((y.double() - x.double()).abs().max().item())
     assert err <= 0.01 + 6.2e-5
     xh = x.cpu().numpy()
@@ -199,7 +204,7 @@ def test_c3_full_size_16384_uint16_lossless(P, O):
     import torch
     from lerc_amd import synth
     x = synth.c3_uint16(16384, 16384, device="cuda:0")
-    blob, y = _device_roundtrip(x, 0.0)
+    blob, y = _device_roundtrip(x, 0.0, streamed=True)
     assert torch.equal(x.view(torch.int16), y.view(torch.int16))
     xh = x.cpu().numpy()
     rc, b2 = O.encode(xh, 0)
@@ -524,6 +529,7 @@ def test_first_row_errors_are_read_after_they_are_written(P, O):
     blob = torch.empty(x.numel() * 4 + 4096, dtype=torch.uint8, device=dev)
     y = torch.empty_like(x)
     fell = 0
+    notes = []
     for i in range(200):
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
@@ -531,12 +537,14 @@ def test_first_row_errors_are_read_after_they_are_written(P, O):
             rc, nb = api.encode_device(codec, x, 0.01, blob)
             rc2 = api.decode_device(codec, blob, nb, y)
             c = codec.path_counters()
+            f = codec.decode_forms()
+            if c[1] != 0 or c[3] != 0 or f[3] != 1: notes.append((i, list(c), list(f), codec.last_note(), codec.last_error()))
             codec.close()
         assert rc == 0 and rc2 == 0, (i, rc, rc2, list(c))
-        fell += int(c[1] != 0 or c[3] != 0)
-    # (before the barrier: 6 of 200 on average.  None since -- but a hand-off that times out while other processes keep the GPU
-    # busy sends a call the same way, by design, and was seen once with four test processes side by side: two are let pass)
-    assert fell <= 2, fell
+        fell += int(c[1] != 0 or c[3] != 0 or f[3] != 1)
+    # (before the barrier: 6 of 200 on average.  None since.  A hand-off that times out while other processes keep the GPU busy
+    # sends a call the same way, by design: LERC_AMD_TEST_SHARED_GPU=1 lets two pass -- the driver's run owns its GPU)
+    assert fell <= (2 if os.environ.get("LERC_AMD_TEST_SHARED_GPU") else 0), (fell, notes[:4])
     rng = np.random.default_rng(77)
     off = cases.terrain(1024, 2048, rng, amp=300, base=1000, sigma=2.0).astype(np.float32)          # nothing to raise
     on = np.round(cases.terrain(1024, 2048, rng, amp=300, base=1000, sigma=2.0), 1).astype(np.float32)    # every value on the 0.1 grid
@@ -939,3 +947,156 @@ def test_queued_device_calls(O):
             assert _same(O.decode(b0)[1].reshape(arr.shape), y.cpu().numpy()), arr.shape
     finally:
         codec.close()
+
+
+def test_random_sizes_stay_on_the_streaming_kernels():
+    """tools/fallback_hunt.py in the suite: a few thousand round trips of rasters of random sizes (rows / columns multiples of 8 and
+    not; float32 and int32) on a fresh context and on a warm one.  Synthetic terrain has nothing that sends a band elsewhere: every
+    call is served by the streaming kernels -- the hand-offs inside the launches (block counts, span sizes, checksum terms, first-row
+    errors) arrive every time, or the note of the call that went another way is printed.  (LERC_AMD_TEST_SHARED_GPU=1: two such
+    calls are let pass -- a hand-off that times out under other processes' load falls back by design.)"""
+    import time
+    import torch
+    from lerc_amd import api, synth
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(20260928)
+    big = synth.c2_float32(2048, 2304, device=dev)
+    warm = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
+    n = 0
+    odd = []
+    t0 = time.time()
+    while n < 3000 and time.time() - t0 < 150:
+        r, c = int(rng.integers(32, 2048)), int(rng.integers(64, 2304))
+        if rng.random() < 0.6:
+            r -= r % 8
+            c -= c % 8
+        x = big[:r, :c].contiguous()
+        e = 0.01
+        if rng.random() < 0.35:
+            x = (x * 8).to(torch.int32).contiguous()
+            e = 0
+        blob = torch.empty(x.numel() * x.element_size() + 8192, dtype=torch.uint8, device=dev)
+        y = torch.empty_like(x)
+        for fresh in (True, False):
+            codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream) if fresh else warm
+            c0, f0 = codec.path_counters(), codec.decode_forms()
+            rc, nb = api.encode_device(codec, x, e, blob)
+            rc2 = api.decode_device(codec, blob, nb, y)
+            c1, f1 = codec.path_counters(), codec.decode_forms()
+            n += 1
+            assert rc == 0 and rc2 == 0, (tuple(x.shape), x.dtype, rc, rc2, codec.last_error())
+            whole = r % 8 == 0 and c % 8 == 0
+            if c1[1] != c0[1] or c1[3] != c0[3] or (whole and f1[3] != f0[3] + 1):
+                odd.append((tuple(x.shape), str(x.dtype), "fresh" if fresh else "warm", [int(b - a) for a, b in zip(c0, c1)],
+                            [int(b - a) for a, b in zip(f0, f1)], codec.last_note(), codec.last_error()))
+            if fresh:
+                codec.close()
+        if n % 64 == 0:    # (the pixels, now and then: the counters say who served the call, not what it wrote)
+            d = (y.double() - x.double()).abs().max().item()
+            assert d <= e * (1 + 1e-6) + (6.2e-5 if e else 0), (tuple(x.shape), d)
+    assert len(odd) <= (2 if os.environ.get("LERC_AMD_TEST_SHARED_GPU") else 0), (n, odd[:6])
+
+
+def test_damaged_mask_in_front_of_the_huffman_kernels(P, O):
+    """A byte raster with a mask, coded in the 8-bit Huffman mode, with damaged mask sections: the Huffman kernels take the mask's word
+    for the number of valid pixels, so a mask that is not what the header says is refused before they run (it once divided a rank by a
+    valid count of zero -- found on the emulator; this is the same on hardware, the mask decoded on the host and on the device)."""
+    rng = np.random.default_rng(31)
+    r, c = 600, 1000
+    x = cases._cast(cases.terrain(r, c, rng, amp=40, base=100, sigma=1.0), np.uint8)
+    m = np.ones((r, c), np.uint8)
+    m[100:300, 200:900] = 0
+    m[rng.random((r, c)) < 0.02] = 0
+    rc, blob = O.encode(x, 0, mask=m)
+    assert rc == 0
+    info = O.blob_info(blob)
+    assert info[0] == 0
+    d0 = O.decode(blob)
+    assert d0[0] == 0
+    code = r"""
+import sys, os
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, capi
+P, O = capi.product(), capi.oracle()
+blob = open(sys.argv[1], "rb").read()
+rng = np.random.default_rng(5)
+hdr = 90 + 4
+n_mask = int.from_bytes(blob[90:94], "little")
+assert n_mask > 16
+bad = 0
+for t in range(48):
+    x = bytearray(blob)
+    k = hdr + int(rng.integers(0, n_mask))
+    x[k] ^= 1 << int(rng.integers(0, 8))
+    if t %% 6 == 0: x[k:k + 2] = b"\x00\x80"      # an end marker in the middle of the stream
+    x = bytes(x)
+    g1, g2 = O.decode(x), P.decode(x)
+    assert (g1[0] == 0) == (g2[0] == 0), (t, k, g1[0], g2[0])
+    bad += int(g1[0] != 0)
+g1, g2 = O.decode(blob), P.decode(blob)
+assert g1[0] == g2[0] == 0 and np.array_equal(g1[2], g2[2]) and np.array_equal(g1[1][g1[2] != 0], g2[1][g2[2] != 0])
+print("masks ok", bad)
+""" % (capi.ROOT,)
+    import subprocess
+    import sys
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".lerc2", delete=False) as f:
+        f.write(blob)
+        path = f.name
+    try:
+        for knob in ("16", "0"):
+            env = dict(os.environ, LERC_AMD_DEVICE_RLE=knob)
+            out = subprocess.run([sys.executable, "-c", code, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+            assert out.returncode == 0 and b"masks ok" in out.stdout, out.stdout.decode()[-2000:]
+    finally:
+        os.unlink(path)
+
+
+def test_blob_gather_over_rccl_in_a_group_of_one(O):
+    """The mosaic job's exchange step (lerc_amd/shard.py: gather_arenas_start) on the GPU box: a process group of ONE rank over
+    "nccl" -- RCCL -- with the collective steps forced (there is nobody to send to, but the lengths' all-gather runs on RCCL with
+    device tensors, the collective's stream is ordered behind the codec's by an event, and the root's own copy and the tables move
+    between HBM slices).  What several ranks do differently -- the grouped send / receive batch -- is covered by the gloo tests
+    (tests/test_shard_gloo.py); this one shows that RCCL loads and runs here and that the device-side half is in order: the
+    mosaic it leaves decodes to the tiles.  (A process of its own: the process group is global state.)"""
+    import sys
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from lerc_amd import api, shard, synth
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):                         # the codec on a stream of its own: the gather has to be told
+    codec = api.DeviceCodec(side.cuda_stream)
+    tiles = torch.stack([synth.c5_tile(3, k, device=dev) for k in range(24)])
+    arena = torch.empty(tiles.numel() * 4 + (1 << 16), dtype=torch.uint8, device=dev)
+    rc, offs, sizes, used = api.encode_tiles_device(codec, tiles, 0.01, arena)
+    assert rc == 0
+    done = torch.cuda.Event()
+    done.record(side)
+flight = shard.gather_arenas_start(arena, used, offs, sizes, root=0, after=done, force_collective=True)
+mosaic, t_off, t_size, bases = flight.finish()
+torch.cuda.synchronize()
+assert bases == [0] and int(mosaic.numel()) >= int(used)
+assert torch.equal(mosaic[:int(used)], arena[:int(used)])
+assert [int(v) for v in t_off] == [int(v) for v in offs] and [int(v) for v in t_size] == [int(v) for v in sizes]
+out = torch.empty_like(tiles)
+with torch.cuda.stream(side):
+    side.wait_stream(torch.cuda.current_stream())
+    rc = api.decode_tiles_device(codec, mosaic, t_off.numpy().astype(np.uint64), t_size.numpy().astype(np.uint32), out)
+    assert rc == 0
+torch.cuda.synchronize()
+assert float((out.double() - tiles.double()).abs().max().item()) <= 0.01 + 6.2e-5
+t = shard.max_over_ranks(1.25, device=dev)
+assert t == 1.25
+dist.destroy_process_group()
+print("rccl ok")
+""" % (capi.ROOT,)
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and b"rccl ok" in out.stdout, out.stdout.decode()[-3000:]

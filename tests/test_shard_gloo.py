@@ -155,3 +155,28 @@ def test_single_process_gather_is_the_arena_itself():
     arena = torch.arange(64, dtype=torch.uint8)
     mosaic, off, size, bases = shard.gather_arenas(arena, 40, [0, 16], [10, 24])
     assert mosaic.tolist() == list(range(40)) and off.tolist() == [0, 16] and size.tolist() == [10, 24] and bases == [0]
+
+
+def _group_of_one(port, path):
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        arena = torch.arange(64, dtype=torch.uint8)
+        mosaic, off, size, bases = shard.gather_arenas(arena, 40, [16, 0], [24, 10], force_collective=True)
+        # (the collective steps ran: the lengths' all-gather, the root's own copy into a buffer of its own, the tables)
+        ok = (mosaic.tolist() == list(range(40)) + [v for v in mosaic.tolist()[40:]] and mosaic.data_ptr() != arena.data_ptr()
+              and int(mosaic.numel()) == 48 and off.tolist() == [16, 0] and size.tolist() == [24, 10] and bases == [0])
+        open(path, "w").write("ok" if ok else repr((mosaic.tolist(), off.tolist(), size.tolist(), bases)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collective_steps_in_a_group_of_one(tmp_path):
+    """force_collective: a process group of ONE rank goes through the lengths' all-gather, the root's own copy and the tables -- what
+    the GPU suite runs over RCCL (tests/test_gpu_parity.py: test_blob_gather_over_rccl_in_a_group_of_one), here over gloo."""
+    import multiprocessing as mp
+    port = 29600 + os.getpid() % 200
+    path = str(tmp_path / "one.txt")
+    p = mp.get_context("spawn").Process(target=_group_of_one, args=(port, path))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0 and open(path).read() == "ok", open(path).read() if os.path.exists(path) else p.exitcode

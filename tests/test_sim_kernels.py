@@ -76,6 +76,18 @@ def test_sim_rejects_corruption(libs):
     blob[len(blob) // 2] ^= 0x40
     assert S.decode(bytes(blob))[0] == 1
     assert S.decode(bytes(blob[:300]))[0] != 0
+    # a blob the streaming kernels take up, with one flipped payload bit: Failed, and the caller's buffer holds zeros, not the
+    # pixels of a blob that did not pass its checksum (include/lerc_amd.h: lerc_decode; the harness pre-fills 0xCD)
+    rng = np.random.default_rng(12)
+    x = cases.terrain(64, 1024, rng, amp=300, base=1000, sigma=1.5).astype(np.float32)
+    rc, good = O.encode(x, 0.01)
+    assert rc == 0
+    bad = bytearray(good)
+    bad[len(bad) // 2] ^= 0x10
+    rc, dec, _ = S.decode(bytes(bad))
+    assert rc == 1 and dec is not None and not dec.view(np.uint8).any()
+    rc, dec, _ = S.decode(good)
+    assert rc == 0 and _same(dec, O.decode(good)[1])
 
 
 def _fast_cases():
