@@ -367,9 +367,8 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     const u32 s0 = s_sb[myWord], s1 = s_sb[myWord + 1u];
     const u32 c = (u32)__popc(s0) + (u32)__popc(s1);
     const u32 inc = waveInclusiveScan(c);
-    __syncthreads();                                  // (the queue, which the list lies on, has been read by everybody)
     if (lane == 63) S.wsum[w] = inc;
-    __syncthreads();
+    __syncthreads();                                  // (and: the queue, which the list lies on, has been read by everybody)
     u32 idx = inc - c;
     for (int k = 0; k < w; k++) idx += S.wsum[k];
     const u32 pos0 = PRE + 64u * threadIdx.x;
@@ -452,7 +451,6 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     }
     __syncthreads();
   };
-  __syncthreads();    // (the bitmap of ENDs, which the round's arrays lie on, has been read by everybody)
   tilePass(0u);
   TRACES(4);
 
