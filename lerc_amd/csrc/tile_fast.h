@@ -256,7 +256,10 @@ constexpr LERC_HD u32 fastOneSub(int typeBytes) { return (typeBytes == 8 && LERC
 #ifdef LERC_SMALL_GROUPS
 static const u32 kOneGroup = 2;
 #else
-static const u32 kOneGroup = 64;
+#ifndef LERC_ONE_GROUP
+#define LERC_ONE_GROUP 64
+#endif
+static const u32 kOneGroup = LERC_ONE_GROUP;
 #endif
 LERC_HD u32 fastOneNumWG(u32 blobBytes, int typeBytes)
 {

@@ -47,6 +47,9 @@ extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_deco
 
 // 16-byte vectors of pixels a lane takes out of the stream while the cells of the pieces in front travel: as many as leave the
 // kernel at 80 vector registers (six waves a SIMD: three workgroups a CU)
+#ifndef LERC_SCAN_SLEEP
+#define LERC_SCAN_SLEEP 4
+#endif
 #ifndef LERC_SCAN_HELD
 #define LERC_SCAN_HELD 6
 #endif
@@ -97,10 +100,10 @@ template<class T> struct ScanShared
     u16 list[G::kListCap + 8];                       // from step 3 on: the block starts, relative to the staged bytes
   } l;
   u16 badIdx[kScanBadCap], falseIdx[kScanFalseCap], insPos[kScanInsCap];
-  u32 wsum[G::NT / 64];
+  u32 wsum[G::NT / 64], qn[G::NT / 64];               // a wave's survivors; units a wave queued
   u64 fa[G::NT / 64], fb[G::NT / 64];
   u64 part;                                          // sum of the cells: this group's in the low half, the groups' in front in the high half
-  u32 nQueue, nEnt, nBad[2], nFalse, nIns, over, bad, lost, exitRel, prevExit, mended;    // nBad: broken links found by the first / the second check
+  u32 nEnt, nBad[2], nFalse, nIns, over, bad, lost, exitRel, prevExit, mended;    // nBad: broken links found by the first / the second check
   FastDecodeParams hp;                               // the band header, parsed in full by the first wave
 };
 
@@ -196,7 +199,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   const u32 dataRel = hl.dataBegin + PRE > pieceStart ? hl.dataBegin + PRE - pieceStart : 0u;        // the stream's first block (or 0: in front of all this)
   const u32 pieceEndRel = PRE + P;
 
-  if (w == 0)
+  if (w == (int)kWaves - 1)    // (the last wave: the first one has a round of staging more)
   {
     const FastDecodeParams hpFull = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
     if (lane == 0)
@@ -226,15 +229,16 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   if (threadIdx.x < 4u) S.inAll[threadIdx.x] = 0u;
   if (threadIdx.x == 0)
   {
-    S.nQueue = 0u; S.nEnt = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
+    S.nEnt = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
     S.prevExit = kNoOffset; S.mended = 0u; S.part = 0ull;
   }
-  __syncthreads();
-  if (!S.hp.ok) return;    // (not a band the streaming kernels take: the header says so in full only)
+  // (no barrier here: nothing below reads what was written above before the barrier behind the staging -- the queue is a
+  // wave's own, the bitmaps and the counters are for the steps behind that barrier)
 
   // ---- stage; Fletcher terms of the piece's own units (bytes 14 ... blobEnd - 1 of the blob are checksummed); scan
-  u32 fA = 0;
+  u32 fA = 0, nMine = 0;
   u64 fB = 0;
+  constexpr u32 kQueueSeg = kQueueCap / kWaves;    // a wave's stretch of the queue
   constexpr u32 ownUnit0 = PRE / 16u, ownUnit1 = (PRE + P) / 16u;
   const bool inner = pieceStart != 0u && (u64)pieceStart + P <= blobEnd;    // no unit of this piece needs blanking
 #pragma unroll
@@ -262,7 +266,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       fletcherUnit(y, a ? (a - 14u) / 2u : 65528ull, fA, fB);             // (the first unit's index -7 as its residue mod 65535)
     }
     // the scan, first half: does the unit hold "a byte 64 behind a byte 10......" at all?  One unit in six does; those go to
-    // the queue (a ballot and one LDS atomic a wave), and the step below looks at them byte by byte.  (The byte in front of a
+    // the wave's own stretch of the queue (a ballot, no atomic), and the step below looks at them byte by byte.  (The byte in front of a
     // wave's first unit belongs to another wave: taken for 10......, it lets the unit through if its first byte is 64.)
     {
       u32 pv = dppMov<kDppWaveShr1>(x[k].w);
@@ -270,27 +274,19 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       const u32 z = countByteMaybe(x[k].x, pv) & countByteMaybe(x[k].y, x[k].x) & countByteMaybe(x[k].z, x[k].y) & countByteMaybe(x[k].w, x[k].z);
       const bool has = (z & 0x80808080u) != 0x80808080u && i < G::kScanUnits && 16u * i < blobRel;    // (what lies behind the blob in the caller's buffer is not looked at)
       const u64 bal = __builtin_amdgcn_ballot_w64(has);
-      if (bal != 0ull)    // (wave-uniform)
-      {
-        u32 base = 0;
-        if (lane == 0) base = atomicAdd(&S.nQueue, (u32)__popcll(bal));
-        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-        const u32 slot = base + (u32)__popcll(bal & laneMaskLt());
-        if (has)
-        {
-          if (slot < kQueueCap) s_queue[slot] = (u16)i;
-          else S.over = 1u;
-        }
-      }
+      const u32 slot = nMine + (u32)__popcll(bal & laneMaskLt());
+      if (has && slot < kQueueSeg) s_queue[(u32)w * kQueueSeg + slot] = (u16)i;
+      nMine += (u32)__popcll(bal);
     }
   }
   {
     // (no reduction mod 65535 before the sums: a lane holds 5 units, A < 2^23 and B < 2^54 per lane)
     const u64 A = waveSum(fA), B = waveSum(fB);
-    if (lane == 0) { S.fa[w] = A; S.fb[w] = B; }
+    if (lane == 0) { S.fa[w] = A; S.fb[w] = B; S.qn[w] = nMine; }
   }
   __syncthreads();
   TRACES(1);
+  if (!S.hp.ok) return;    // (not a band the streaming kernels take: the header says so in full only)
   if (threadIdx.x == 0)
   {
     // this workgroup's checksum terms: one atomic nobody waits for (the launch's last workgroup folds the accumulators)
@@ -308,9 +304,12 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   // offset) behind the flag byte: each offset type is tried.  The twelve bytes in front of the count byte's successor come out
   // of four LDS words, shifted so that the byte 10 in front of the count byte is byte 0.
   {
-    const u32 nQ = min(S.nQueue, kQueueCap);
-    for (u32 h = threadIdx.x; h < nQ; h += NT)
+    // (a wave takes the units it queued itself: no counter to share -- but the bytes around them are other waves')
+    const u32 nQ = S.qn[w];
+    if (nQ > kQueueSeg && lane == 0) S.over = 1u;
+    for (u32 hq = (u32)lane; hq < min(nQ, kQueueSeg); hq += 64u)
     {
+      const u32 h = (u32)w * kQueueSeg + hq;
       // the scan, second half: which bytes of the unit -- exactly: 64 behind 10?nnnnn, n != 0; a bit per byte, bit k: byte
       // 4 (k & 3) + (k >> 2)
       const u32 unit = (u32)s_queue[h];
@@ -642,7 +641,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       u64 c = i == threadIdx.x ? cell0 : observe64(pc);
       for (u32 spin = 0; (u32)(c >> 32) != epoch && spin < b.spinLimit; spin++)
       {
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(LERC_SCAN_SLEEP);
         c = observe64(pc);
       }
       if ((u32)(c >> 32) != epoch) { lost = true; c = 0; }
