@@ -825,7 +825,9 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   // ---- 4. emit: small sections from the host, pixel payload by kernels
   // (put together in pinned memory -- the mask's RLE can be megabytes, and a pageable source is staged at ~1 GB/s with the
   // stream waiting; the area held the mask bits, which codeMask() has consumed by now)
-  const size_t prefixCap = headerBytes(hd.version) + 4 + rle.size() + (writeRanges ? 2 * (size_t)nD * tb : 0) + 2;
+  const size_t prefixLen = headerBytes(hd.version) + 4 + rle.size() + (writeRanges ? 2 * (size_t)nD * tb : 0) + 2;
+  const size_t huffPinAt = (prefixLen + 63) & ~(size_t)63;    // (the Huffman mode's code words and table: emitHuffman)
+  const size_t prefixCap = huffPinAt + (payload == P_HUFFMAN ? 2048 + huff.table.size() + 64 : 0);
   u8* prefix = (u8*)ctx.pinnedAux(prefixCap);
   if (!prefix) return kFailed;
   size_t at = 0;
@@ -878,7 +880,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   }
   else if (payload == P_HUFFMAN)
   {
-    if (!emitHuffman(ctx, dt, dData, dBits, nRows, nCols, nD, huff, dPayload, dStatus)) return kFailed;
+    if (!emitHuffman(ctx, dt, dData, dBits, nRows, nCols, nD, huff, dPayload, dStatus, prefix + huffPinAt)) return kFailed;
     TL("Huffman stream enqueued");
   }
 

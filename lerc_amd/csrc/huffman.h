@@ -32,7 +32,7 @@ bool planHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
 bool enqueueHuffmanHisto(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth, u32* hHisto);
 // writes table + pixel stream + padding at dOut; enqueues only -- `plan` must outlive the caller's next synchronisation
 bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth,
-                 const HuffmanPlan& plan, u8* dOut, DeviceStatus* dStatus);
+                 const HuffmanPlan& plan, u8* dOut, DeviceStatus* dStatus, u8* pin = nullptr);    // pin: pinned host memory, 2048 + plan.table.size() bytes, the caller's until its next synchronisation (or none)
 // decodes a Huffman payload starting at blob + dataBegin; returns an ErrCode
 u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 dataBegin, u32 blobEnd, int imageMode,
                   const u8* dMaskBits, int nRows, int nCols, int nDepth, int version, void* dOut, DeviceStatus* dStatus,

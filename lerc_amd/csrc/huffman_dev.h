@@ -35,17 +35,17 @@ void launchHuffRunBits(int dt, const void* data, const u8* maskBits, const HuffG
 // runBase: bit offset of every run (launchHuffRunBits + launchScan64) -- or, every pixel valid, nullptr and `cells` (one
 // zeroed u64 per 256 runs, huffPackCells): the packer finds its offsets itself, in one pass
 void launchHuffPack(int dt, const void* data, const u8* maskBits, const HuffGeom& g, int mode, const u64* codes, const u64* runBase,
-                    u32* stream /* zeroed */, u64* cells, DeviceStatus* status, hipStream_t st);
+                    u32* stream /* zeroed; the stream's first byte lies `mis` bytes into stream[0] */, u32 mis, u64* cells, DeviceStatus* status, hipStream_t st);
 inline size_t huffPackCells(i64 nElem) { return (size_t)(((nElem + kHuffSelfRun - 1) / kHuffSelfRun + 255) / 256); }
 void launchScan64(const u32* in, u64* out /* n + 1 */, u32 n, u64* scratch /* n/256 + 2 */, hipStream_t st);
 
 u32 huffSubWords(u64 streamBits, u32 slots);
 void launchHuffInitStarts(u64* starts, u64* prevStarts, u32 nSub, u32 subWords, hipStream_t st);
-void launchHuffSync(const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u32 subWords, u64* starts,
+void launchHuffSync(const u32* stream, u32 mis, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u32 subWords, u64* starts,
                     u64* prevStarts, u64* exits, u32* counts, u32* bad, bool firstRound, hipStream_t st);
 void launchHuffChain(u32 nSub, u64* starts, const u64* exits, u32* changed, hipStream_t st);
 void launchValidIndex(const u8* maskBits, const u32* groupBase, i64 nPix, u32* validIdx, hipStream_t st);
-void launchHuffEmit(int dt, const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u32 subWords, const u64* starts,
+void launchHuffEmit(int dt, const u32* stream, u32 mis, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u32 subWords, const u64* starts,
                     const u64* symBase, const HuffGeom& g, int mode, u64 nSymbols, u32 numValid, const u32* validIdx, bool planar,
                     void* out, hipStream_t st);
 // delta mode without a mask and a few values per pixel: symbols decoded plane by plane (planar = [nDepth][nPix] scratch),

@@ -365,7 +365,7 @@ bool planHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
 }
 
 bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth,
-                 const HuffmanPlan& plan, u8* dOut, DeviceStatus* dStatus)
+                 const HuffmanPlan& plan, u8* dOut, DeviceStatus* dStatus, u8* pin)
 {
   hipStream_t st = ctx.activeStream();
   const HuffGeom g{ nRows, nCols, nDepth };
@@ -373,18 +373,28 @@ bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
   const u32 nRuns = (u32)((nElem + kHuffRun - 1) / kHuffRun);
   const u64 nWords = ((plan.nBits + 31) >> 5) + 1;    // one extra word: the decoder's LUT may read ahead (Lerc2.cpp:2464)
 
-  plan.deviceCodes.resize(256);
-  u64* hCodes = plan.deviceCodes.data();
+  // the code words and the code table travel through pinned memory (`pin`, the caller's, 2 KB + the table's size: a pageable source
+  // is staged by the runtime while the stream waits); the stream is written where the blob has it, behind the table -- `mis` bytes
+  // into an aligned word, the packer shifts -- so nothing is copied afterwards
+  // (no pinned area handed in -- the lossless float mode's byte planes, several streams a band: the plan's own vectors, which
+  // live until the caller's next synchronisation)
+  if (!pin) plan.deviceCodes.resize(256);
+  u64* hCodes = pin ? reinterpret_cast<u64*>(pin) : plan.deviceCodes.data();
   for (int i = 0; i < 256; i++) hCodes[i] = ((u64)plan.codes[i].first << 32) | plan.codes[i].second;
+  const u8* hTable = plan.table.data();
+  if (pin) { memcpy(pin + 2048, plan.table.data(), plan.table.size()); hTable = pin + 2048; }
   u64* dCodes = ctx.allocT<u64>(256);
   u32* dRunBits = ctx.allocT<u32>((size_t)nRuns + 4);
   u64* dRunBase = ctx.allocT<u64>((size_t)nRuns + 4);
   u64* dScr = ctx.allocT<u64>((size_t)nRuns / 256 + 8);
-  u32* dStream = ctx.allocT<u32>((size_t)nWords + 4);
-  if (!dCodes || !dRunBits || !dRunBase || !dScr || !dStream) return false;
+  if (!dCodes || !dRunBits || !dRunBase || !dScr) return false;
+  u8* dStreamBytes = dOut + plan.table.size();
+  const u32 mis = (u32)((uintptr_t)dStreamBytes & 3u);
+  u32* dStream = reinterpret_cast<u32*>(dStreamBytes - mis);
   hipMemcpyAsync(dCodes, hCodes, 256 * sizeof(u64), hipMemcpyHostToDevice, st);
-  hipMemcpyAsync(dOut, plan.table.data(), plan.table.size(), hipMemcpyHostToDevice, st);
-  hipMemsetAsync(dStream, 0, (size_t)nWords * 4, st);
+  // (zeros first -- from the aligned word the stream begins in, which holds the table's last bytes too -- then the table)
+  hipMemsetAsync(dStream, 0, (size_t)mis + (size_t)nWords * 4, st);
+  hipMemcpyAsync(dOut, hTable, plan.table.size(), hipMemcpyHostToDevice, st);
   if (!dMaskBits && dStatus)
   {
     // every pixel valid: one pass (the packer's workgroups chain their bit counts themselves)
@@ -393,15 +403,15 @@ bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
     if (!dCells) return false;
     hipMemsetAsync(dCells, 0, nCells * 8, st);
     ProfScope ps(ctx, "huff_pack");
-    launchHuffPack(dt, dData, nullptr, g, plan.imageMode, dCodes, nullptr, dStream, dCells, dStatus, st);
+    launchHuffPack(dt, dData, nullptr, g, plan.imageMode, dCodes, nullptr, dStream, mis, dCells, dStatus, st);
   }
   else
   {
     { ProfScope ps(ctx, "huff_runbits"); launchHuffRunBits(dt, dData, dMaskBits, g, plan.imageMode, dCodes, dRunBits, st); }
     { ProfScope ps(ctx, "huff_scan"); launchScan64(dRunBits, dRunBase, nRuns, dScr, st); }
-    { ProfScope ps(ctx, "huff_pack"); launchHuffPack(dt, dData, dMaskBits, g, plan.imageMode, dCodes, dRunBase, dStream, nullptr, nullptr, st); }
+    { ProfScope ps(ctx, "huff_pack"); launchHuffPack(dt, dData, dMaskBits, g, plan.imageMode, dCodes, dRunBase, dStream, mis, nullptr, nullptr, st); }
   }
-  return hipMemcpyAsync(dOut + plan.table.size(), dStream, (size_t)nWords * 4, hipMemcpyDeviceToDevice, st) == hipSuccess;
+  return hipGetLastError() == hipSuccess;
 }
 
 u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 dataBegin, u32 blobEnd, int imageMode,
@@ -432,11 +442,14 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
     table.clear(); used = 0;
     if (!parseTable(head.data(), head.size(), version, table, used)) return kFailed;
   }
-  HuffDecodeTable* hTab = new HuffDecodeTable();
-  if (!buildDecodeTable(table, *hTab)) { delete hTab; return kFailed; }
+  // (in pinned memory, behind the call's 64 result bytes: a pageable source is staged by the runtime while the stream waits)
+  u8* pinAll = (u8*)ctx.pinned(64 + sizeof(HuffDecodeTable) + 64);
+  if (!pinAll) return kFailed;
+  HuffDecodeTable* hTab = reinterpret_cast<HuffDecodeTable*>(pinAll + 64);
+  if (!buildDecodeTable(table, *hTab)) return kFailed;
 
   const u32 streamBegin = dataBegin + (u32)used;
-  if (streamBegin + 4 > blobEnd) { delete hTab; return kFailed; }
+  if (streamBegin + 4 > blobEnd) return kFailed;
   const u64 streamBytes = blobEnd - streamBegin;
   const u64 nWords = streamBytes / 4;
   const u64 streamBits = nWords * 32;
@@ -455,23 +468,25 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
     u32* dCounts = ctx.allocT<u32>((size_t)nGroups + 4);
     u32* dBase = ctx.allocT<u32>((size_t)nGroups + 4);
     u32* dScr = ctx.allocT<u32>((size_t)nGroups / 1024 + 8);
-    if (!dCounts || !dBase || !dScr) { delete hTab; return kFailed; }
+    if (!dCounts || !dBase || !dScr) return kFailed;
     launchMaskGroupCounts(dMaskBits, nPix, dCounts, st);
     launchExclusiveScan(dCounts, dBase, (u32)nGroups, dScr, st);
     u32* pin = (u32*)ctx.pinned(64);
-    if (!pin) { delete hTab; return kFailed; }
+    if (!pin) return kFailed;
     hipMemcpyAsync(pin, dBase + nGroups, 4, hipMemcpyDeviceToHost, st);
-    if (!ctx.sync()) { delete hTab; return kFailed; }
+    if (!ctx.sync()) return kFailed;
     numValid = pin[0];
-    if (numValid == 0) { delete hTab; return kFailed; }    // (a band without a valid pixel has no stream; the caller checks the count against the header)
+    if (numValid == 0) return kFailed;    // (a band without a valid pixel has no stream; the caller checks the count against the header)
     dValidIdx = ctx.allocT<u32>((size_t)numValid + 4);
-    if (!dValidIdx) { delete hTab; return kFailed; }
+    if (!dValidIdx) return kFailed;
     launchValidIndex(dMaskBits, dBase, nPix, dValidIdx, st);
   }
   const u64 nSymbols = (u64)numValid * (u64)nDepth;
 
   HuffDecodeTable* dTab = ctx.allocT<HuffDecodeTable>(1);
-  u32* dStream = ctx.allocT<u32>((size_t)nWords + 4);
+  // the stream is read where the blob has it: `mis` bytes into an aligned word (the kernels put its words together)
+  const u32 mis = (u32)((uintptr_t)(dBlob + streamBegin) & 3u);
+  const u32* dStream = reinterpret_cast<const u32*>(dBlob + streamBegin - mis);
   u64* dStarts = ctx.allocT<u64>((size_t)nSub + 4);
   u64* dPrev = ctx.allocT<u64>((size_t)nSub + 4);
   u64* dExits = ctx.allocT<u64>((size_t)nSub + 4);
@@ -479,9 +494,8 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
   u64* dSymBase = ctx.allocT<u64>((size_t)nSub + 4);
   u64* dScr64 = ctx.allocT<u64>((size_t)nSub / 256 + 8);
   u32* dFlags = ctx.allocT<u32>(4);
-  if (!dTab || !dStream || !dStarts || !dPrev || !dExits || !dCounts || !dSymBase || !dScr64 || !dFlags) { delete hTab; return kFailed; }
+  if (!dTab || !dStarts || !dPrev || !dExits || !dCounts || !dSymBase || !dScr64 || !dFlags) return kFailed;
   hipMemcpyAsync(dTab, hTab, sizeof(HuffDecodeTable), hipMemcpyHostToDevice, st);
-  hipMemcpyAsync(dStream, dBlob + streamBegin, (size_t)nWords * 4, hipMemcpyDeviceToDevice, st);    // word aligned copy
   hipMemsetAsync(dFlags, 0, 16, st);
   launchHuffInitStarts(dStarts, dPrev, nSub, subWords, st);
 
@@ -490,24 +504,24 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
   // pixels, predictor undone -- is enqueued behind the first round without waiting for its verdict and repeated in the
   // rare case that the chain had to be corrected: one wait, no idle stream in between.
   u32* pin = (u32*)ctx.pinned(64);    // [0] chain changed, [1] bad code seen, [2..3] symbols in the stream
-  if (!pin) { delete hTab; return kFailed; }
+  if (!pin) return kFailed;
   u8* dPlanar = nullptr;
   const bool planar = huffPlanarDecode(imageMode, dMaskBits, nDepth);
   if (planar)
   {
     dPlanar = ctx.allocT<u8>((size_t)nSymbols + 16);
-    if (!dPlanar) { delete hTab; return kFailed; }
+    if (!dPlanar) return kFailed;
   }
   auto secondPass = [&]()
   {
     if (dMaskBits) hipMemsetAsync(dOut, 0, (size_t)nPix * nDepth, st);    // invalid pixels stay 0
     if (planar)
     {
-      { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, nWords, streamBits, dTab, nSub, subWords, dStarts, dSymBase, g, imageMode, nSymbols, numValid, nullptr, true, dPlanar, st); }
+      { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, mis, nWords, streamBits, dTab, nSub, subWords, dStarts, dSymBase, g, imageMode, nSymbols, numValid, nullptr, true, dPlanar, st); }
       { ProfScope ps(ctx, "huff_undelta"); launchHuffUndeltaPlanar(dPlanar, dOut, g, st); }
       return;
     }
-    { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, nWords, streamBits, dTab, nSub, subWords, dStarts, dSymBase, g, imageMode, nSymbols, numValid, dValidIdx, false, dOut, st); }
+    { ProfScope ps(ctx, "huff_emit"); launchHuffEmit(dt, dStream, mis, nWords, streamBits, dTab, nSub, subWords, dStarts, dSymBase, g, imageMode, nSymbols, numValid, dValidIdx, false, dOut, st); }
     if (imageMode == IEM_DeltaHuffman) { ProfScope ps(ctx, "huff_undelta"); launchHuffUndelta(dt, dOut, dMaskBits, g, st); }
   };
   const int kMaxRounds = 4096;
@@ -517,14 +531,13 @@ u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 da
   {
     { ProfScope ps(ctx, "huff_sync");
       hipMemsetAsync(dFlags, 0, 4, st);
-      launchHuffSync(dStream, nWords, streamBits, dTab, nSub, subWords, dStarts, dPrev, dExits, dCounts, dFlags + 1, round == 0, st);
+      launchHuffSync(dStream, mis, nWords, streamBits, dTab, nSub, subWords, dStarts, dPrev, dExits, dCounts, dFlags + 1, round == 0, st);
       launchHuffChain(nSub, dStarts, dExits, dFlags, st); }
     { ProfScope ps(ctx, "huff_scan"); launchScan64(dCounts, dSymBase, nSub, dScr64, st); }
     hipMemcpyAsync(pin, dFlags, 8, hipMemcpyDeviceToHost, st);
     hipMemcpyAsync(pin + 2, dSymBase + nSub, 8, hipMemcpyDeviceToHost, st);
     if (round == 0) secondPass();
     const bool ok = ctx.sync();
-    if (hTab) { delete hTab; hTab = nullptr; }    // (the table's upload has certainly happened now)
     if (!ok) return kFailed;
     memcpy(&total, pin + 2, 8);
     if (!pin[0]) break;

@@ -235,10 +235,19 @@ extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_huff
 #define TRACEH(slot)
 #endif
 
+// ORs a word of the bit stream into memory: the stream begins `mis` bytes into the aligned word stream[0]
+__device__ __forceinline__ void orStreamWord(u32* __restrict__ stream, u32 mis, u64 w, u32 v)
+{
+  if (mis == 0u) { atomicOr(&stream[w], v); return; }
+  const u32 sh = 8u * mis;
+  if (v << sh) atomicOr(&stream[w], v << sh);
+  if (v >> (32u - sh)) atomicOr(&stream[w + 1], v >> (32u - sh));
+}
+
 template<class T, bool PACK, int RUN>
 __global__ void __launch_bounds__(256)
 k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffGeom g, int mode, const u64* __restrict__ codes,
-              u32* __restrict__ runBits, const u64* __restrict__ runBase, u32* __restrict__ stream, u64* __restrict__ cells, DeviceStatus* status)
+              u32* __restrict__ runBits, const u64* __restrict__ runBase, u32* __restrict__ stream, u32 mis, u64* __restrict__ cells, DeviceStatus* status)
 {
   __shared__ u64 s_codes[256];
   __shared__ u8 s_sym[RUN * 260];
@@ -454,7 +463,7 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
       if (have >= 32)
       {
         if (inLds) atomicOr(&s_span[(u32)(w - spanWord0)], (u32)(acc >> 32));
-        else atomicOr(&stream[w], (u32)(acc >> 32));
+        else orStreamWord(stream, mis, w, (u32)(acc >> 32));
         acc <<= 32;
         have -= 32;
         w++;
@@ -463,17 +472,23 @@ k_huff_encode(const T* __restrict__ data, const u8* __restrict__ maskBits, HuffG
     if (have > 0 && (u32)(acc >> 32) != 0u)
     {
       if (inLds) atomicOr(&s_span[(u32)(w - spanWord0)], (u32)(acc >> 32));
-      else atomicOr(&stream[w], (u32)(acc >> 32));
+      else orStreamWord(stream, mis, w, (u32)(acc >> 32));
     }
   }
   if (!inLds) return;    // (uniform over the workgroup)
   __syncthreads();
   TRACEH(4);
-  for (u32 x = threadIdx.x; x < spanWords; x += 256)
+  // The stream lies where the blob has it, `mis` bytes into the aligned word stream[0]: aligned word m holds the last bytes of stream
+  // word m - 1 and the first ones of word m.  Whole aligned words are stored where both belong to this workgroup alone; the span's
+  // first and last word are shared with the neighbours, and what holds bits of them goes out with an atomic OR.
+  const u32 sh = 8u * mis;
+  for (u32 x = threadIdx.x; x < spanWords + (mis ? 1u : 0u); x += 256)
   {
-    const u32 word = s_span[x];
-    if (x == 0u || x + 1u == spanWords) { if (word) atomicOr(&stream[spanWord0 + x], word); }
-    else stream[spanWord0 + x] = word;
+    const u32 hi = x < spanWords ? s_span[x] : 0u, lo = (mis && x > 0u) ? s_span[x - 1u] : 0u;
+    const u32 word = mis ? ((hi << sh) | (lo >> (32u - sh))) : hi;
+    const bool own = mis ? (x >= 2u && x + 1u < spanWords) : (x >= 1u && x + 1u < spanWords);
+    if (own) stream[spanWord0 + x] = word;
+    else if (word) atomicOr(&stream[spanWord0 + x], word);
   }
   TRACEH(5);
 }
@@ -484,25 +499,25 @@ void launchHuffRunBits(int dt, const void* data, const u8* maskBits, const HuffG
   const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
   const i64 nRuns = (n + kHuffRun - 1) / kHuffRun;
   const dim3 grid((unsigned)((nRuns + 255) / 256)), block(256);
-  if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, false, kHuffRun>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, runBits, (const u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (DeviceStatus*)nullptr);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, false, kHuffRun>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, runBits, (const u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (DeviceStatus*)nullptr);
+  if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, false, kHuffRun>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, runBits, (const u64*)nullptr, (u32*)nullptr, 0u, (u64*)nullptr, (DeviceStatus*)nullptr);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, false, kHuffRun>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, runBits, (const u64*)nullptr, (u32*)nullptr, 0u, (u64*)nullptr, (DeviceStatus*)nullptr);
 }
 
 void launchHuffPack(int dt, const void* data, const u8* maskBits, const HuffGeom& g, int mode, const u64* codes, const u64* runBase,
-                    u32* stream, u64* cells, DeviceStatus* status, hipStream_t st)
+                    u32* stream, u32 mis, u64* cells, DeviceStatus* status, hipStream_t st)
 {
   const i64 n = (i64)g.nRows * g.nCols * g.nDepth;
   if (cells)    // one pass: no table of runs, so a thread takes kHuffSelfRun elements -- half the LDS, twice the workgroups per CU
   {
     const dim3 grid((unsigned)huffPackCells(n)), block(256);
-    if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, true, kHuffSelfRun>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, cells, status);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, true, kHuffSelfRun>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, cells, status);
+    if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, true, kHuffSelfRun>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, mis, cells, status);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, true, kHuffSelfRun>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, mis, cells, status);
     return;
   }
   const i64 nRuns = (n + kHuffRun - 1) / kHuffRun;
   const dim3 grid((unsigned)((nRuns + 255) / 256)), block(256);
-  if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, true, kHuffRun>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, cells, status);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, true, kHuffRun>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, cells, status);
+  if (dt == DT_Char) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<signed char, true, kHuffRun>), grid, block, 0, st, (const signed char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, mis, cells, status);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_huff_encode<unsigned char, true, kHuffRun>), grid, block, 0, st, (const unsigned char*)data, maskBits, g, mode, codes, (u32*)nullptr, runBase, stream, mis, cells, status);
 }
 
 // u32 -> u64 exclusive scan (bit offsets can exceed 2^32); out[n] = total
@@ -587,13 +602,27 @@ static const int kHuffStageWords = kHuffDecThreads * kHuffSubWordsMax + kHuffWar
 
 __device__ __forceinline__ i64 stageOriginWord(u32 subWords) { return (i64)blockIdx.x * kHuffDecThreads * subWords - kHuffWarmWords; }
 
-__device__ __forceinline__ void stageStream(const u32* __restrict__ stream, u64 nWords, u32 subWords, u32* s_str)
+// (the stream begins `mis` bytes into the aligned word stream[0] -- it lies where the blob has it, behind a code table of any
+// length: a word of the stream is put together from two aligned ones; the stream's last word from its bytes, so that nothing
+// behind the blob is read)
+__device__ __forceinline__ void stageStream(const u32* __restrict__ stream, u32 mis, u64 nWords, u32 subWords, u32* s_str)
 {
   const i64 o = stageOriginWord(subWords);
   for (u32 l = threadIdx.x; l < (u32)kHuffDecThreads * subWords + (u32)(kHuffWarmWords + kHuffTailWords); l += kHuffDecThreads)
   {
     const i64 w = o + l;
-    s_str[l] = (w >= 0 && (u64)w < nWords) ? stream[w] : 0u;
+    u32 v = 0u;
+    if (w >= 0 && (u64)w < nWords)
+    {
+      if (mis == 0u) v = stream[w];
+      else if ((u64)w + 1u < nWords) v = __builtin_amdgcn_alignbit(stream[w + 1], stream[w], 8u * mis);
+      else
+      {
+        const u8* bytes = reinterpret_cast<const u8*>(stream) + 4u * (size_t)w + mis;
+        v = (u32)bytes[0] | ((u32)bytes[1] << 8) | ((u32)bytes[2] << 16) | ((u32)bytes[3] << 24);
+      }
+    }
+    s_str[l] = v;
   }
 }
 
@@ -667,7 +696,7 @@ __device__ __forceinline__ int decodeOne(const HuffLdsTable& s, u32 top, int& sy
 // such threads start over from their predecessor's exit until its sub-sequences fit together.  If the chain of exits
 // (k_huff_chain) then fits across the workgroups as well, which is the normal case, that was the only round.
 __global__ void __launch_bounds__(kHuffDecThreads)
-k_huff_sync(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const HuffDecodeTable* __restrict__ table, u32 nSub, u32 subWords,
+k_huff_sync(const u32* __restrict__ stream, u32 mis, u64 nWords, u64 streamBits, const HuffDecodeTable* __restrict__ table, u32 nSub, u32 subWords,
             u64* __restrict__ starts, u64* __restrict__ prevStarts, u64* __restrict__ exits, u32* __restrict__ counts,
             u32* __restrict__ bad, int warm)
 {
@@ -684,7 +713,7 @@ k_huff_sync(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const Hu
   __syncthreads();
   if (!s_any) return;    // (after the first round most workgroups have nothing to redo)
   stageLut(table, s_tab);
-  stageStream(stream, nWords, subWords, s_str);
+  stageStream(stream, mis, nWords, subWords, s_str);
   __syncthreads();
   const u64 origin = (u64)(stageOriginWord(subWords) + kHuffWarmWords) * 32u;    // bit position of the slice's first sub-sequence
   const u64 subBits = (u64)subWords * 32u;
@@ -774,14 +803,14 @@ void launchValidIndex(const u8* maskBits, const u32* groupBase, i64 nPix, u32* v
 // second pass: write symbol r of the stream to its pixel (raw deltas in delta mode)
 template<class T>
 __global__ void __launch_bounds__(kHuffDecThreads)
-k_huff_emit(const u32* __restrict__ stream, u64 nWords, u64 streamBits, const HuffDecodeTable* __restrict__ table, u32 nSub, u32 subWords,
+k_huff_emit(const u32* __restrict__ stream, u32 mis, u64 nWords, u64 streamBits, const HuffDecodeTable* __restrict__ table, u32 nSub, u32 subWords,
             const u64* __restrict__ starts, const u64* __restrict__ symBase, HuffGeom g, int mode, u64 nSymbols, u32 numValid,
             const u32* __restrict__ validIdx, int rankOrder, T* __restrict__ out)
 {
   __shared__ HuffLdsTable s_tab;
   __shared__ u32 s_str[kHuffStageWords];
   stageLut(table, s_tab);
-  stageStream(stream, nWords, subWords, s_str);
+  stageStream(stream, mis, nWords, subWords, s_str);
   __syncthreads();
   const u32 t = blockIdx.x * (u32)kHuffDecThreads + threadIdx.x;
   if (t >= nSub) return;
@@ -1025,10 +1054,10 @@ void launchHuffUndelta(int dt, void* data, const u8* maskBits, const HuffGeom& g
   else hipLaunchKernelGGL(k_huff_undelta<unsigned char>, dim3(g.nDepth), dim3(64), 0, st, (unsigned char*)data, maskBits, g);
 }
 
-void launchHuffSync(const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u32 subWords, u64* starts,
+void launchHuffSync(const u32* stream, u32 mis, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u32 subWords, u64* starts,
                     u64* prevStarts, u64* exits, u32* counts, u32* bad, bool firstRound, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_huff_sync, dim3((nSub + kHuffDecThreads - 1) / kHuffDecThreads), dim3(kHuffDecThreads), 0, st, stream, nWords, streamBits, table, nSub, subWords,
+  hipLaunchKernelGGL(k_huff_sync, dim3((nSub + kHuffDecThreads - 1) / kHuffDecThreads), dim3(kHuffDecThreads), 0, st, stream, mis, nWords, streamBits, table, nSub, subWords,
                      starts, prevStarts, exits, counts, bad, firstRound ? 1 : 0);
 }
 
@@ -1054,15 +1083,15 @@ void launchHuffChain(u32 nSub, u64* starts, const u64* exits, u32* changed, hipS
   hipLaunchKernelGGL(k_huff_chain, dim3((nSub + 255) / 256), dim3(256), 0, st, nSub, starts, exits, changed);
 }
 
-void launchHuffEmit(int dt, const u32* stream, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u32 subWords, const u64* starts,
+void launchHuffEmit(int dt, const u32* stream, u32 mis, u64 nWords, u64 streamBits, const HuffDecodeTable* table, u32 nSub, u32 subWords, const u64* starts,
                     const u64* symBase, const HuffGeom& g, int mode, u64 nSymbols, u32 numValid, const u32* validIdx, bool planar,
                     void* out, hipStream_t st)
 {
   const dim3 grid((nSub + kHuffDecThreads - 1) / kHuffDecThreads), block(kHuffDecThreads);
   // symbol r goes to byte r: one value per pixel, or pixel-interleaved symbols (not delta mode), or planes wanted
   const int rankOrder = (!validIdx && (g.nDepth == 1 || mode == IEM_Huffman || planar)) ? 1 : 0;
-  if (dt == DT_Char) hipLaunchKernelGGL(k_huff_emit<signed char>, grid, block, 0, st, stream, nWords, streamBits, table, nSub, subWords, starts, symBase, g, mode, nSymbols, numValid, validIdx, rankOrder, (signed char*)out);
-  else hipLaunchKernelGGL(k_huff_emit<unsigned char>, grid, block, 0, st, stream, nWords, streamBits, table, nSub, subWords, starts, symBase, g, mode, nSymbols, numValid, validIdx, rankOrder, (unsigned char*)out);
+  if (dt == DT_Char) hipLaunchKernelGGL(k_huff_emit<signed char>, grid, block, 0, st, stream, mis, nWords, streamBits, table, nSub, subWords, starts, symBase, g, mode, nSymbols, numValid, validIdx, rankOrder, (signed char*)out);
+  else hipLaunchKernelGGL(k_huff_emit<unsigned char>, grid, block, 0, st, stream, mis, nWords, streamBits, table, nSub, subWords, starts, symBase, g, mode, nSymbols, numValid, validIdx, rankOrder, (unsigned char*)out);
 }
 
 __global__ void __launch_bounds__(256) k_init_starts(u64* __restrict__ starts, u64* __restrict__ prevStarts, u32 nSub, u32 subWords)
