@@ -384,6 +384,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   {
     bool on = false, sizesFresh = false;
     u32* dSizes = nullptr; u32* dOffsets = nullptr; u32* dScratch = nullptr;
+    u32* dHisto = nullptr; const u32* dTotal = nullptr;
     u32 total = 0;
     u32 histo[512];
     BandParams bp;
@@ -408,23 +409,34 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     b.mb = 8; b.nTV = (nRows + 7) / 8; b.nTH = (nCols + 7) / 8;
     { ProfScope ps(ctx, "tile_sizes"); launchTileSizes(dt, 8, dData, nullptr, b, spec.dSizes, dStatus, st); }
     { ProfScope ps(ctx, "scan_block_sizes"); launchExclusiveScan(spec.dSizes, spec.dOffsets, (u32)nPos8, spec.dScratch, st); }
-    if (!enqueueHuffmanHisto(ctx, dt, dData, nullptr, nRows, nCols, nD, spec.histo)) return;
-    hipMemcpyAsync(&spec.total, spec.dOffsets + nPos8, 4, hipMemcpyDeviceToHost, st);    // (copies behind all the kernels, see runStats)
+    enqueueHuffmanHistoDevice(ctx, dt, dData, nullptr, nRows, nCols, nD, spec.dHisto);    // (zeroed by runStats; the counts and the total come home with the statistics)
+    spec.dTotal = spec.dOffsets + nPos8;
     spec.on = spec.sizesFresh = true;
   };
+  // One kernel sets the statistics kernels' inputs, one gathers their results -- and what was enqueued ahead of the decisions: the
+  // two histograms, the blocks' total size -- in pinned memory the host reads after its wait: between the kernels of a band no
+  // copy command of a few bytes, and none into pageable memory (each keeps this thread until the stream has reached it).
   auto runStats = [&](int rows, u32 mask) -> bool
   {
-    for (int m = 0; m < nD; m++) { hMins[m] = statKeyInitMin(); hMaxs[m] = statKeyInitMax(); }
-    hipMemcpyAsync(dMins, hMins.data(), nD * 8, hipMemcpyHostToDevice, st);
-    hipMemcpyAsync(dMaxs, hMaxs.data(), nD * 8, hipMemcpyHostToDevice, st);
-    hipMemsetAsync(dStats, 0, sizeof(BandStats), st);
+    const bool specNow = specWanted && rows == nRows && !spec.on && !haveBits;
+    if (specNow && !spec.dHisto) spec.dHisto = ctx.allocT<u32>(512);
+    static_assert(sizeof(BandStats) % 4 == 0, "words");
+    const u32 wStats = (u32)(sizeof(BandStats) / 4), wKeys = 2u * (u32)nD;
+    u32* pin = (u32*)ctx.pinned(((size_t)wStats + 2u * wKeys + 512u + 16u) * 4u);
+    if (!pin) return false;
+    launchStatsInit(dMins, dMaxs, nD, reinterpret_cast<u32*>(dStats), wStats, (specNow && spec.dHisto) ? spec.dHisto : nullptr, (specNow && spec.dHisto) ? 512u : 0u, st);
     { ProfScope ps(ctx, rows == nRows ? "band_stats" : "band_stats_row0"); launchBandStats(dt, dData, (haveBits && !bandAllValid) ? dNewBits : nullptr, rows, nCols, nD, mask, dMins, dMaxs, dStats, st); }
-    // (in front of the copies: a copy into pageable memory keeps the host until everything enqueued so far is through)
-    if (specWanted && rows == nRows && !spec.on && !haveBits) speculate();
-    hipMemcpyAsync(&hr.stats, dStats, sizeof(BandStats), hipMemcpyDeviceToHost, st);
-    hipMemcpyAsync(hMins.data(), dMins, nD * 8, hipMemcpyDeviceToHost, st);
-    hipMemcpyAsync(hMaxs.data(), dMaxs, nD * 8, hipMemcpyDeviceToHost, st);
-    return sync.wait();
+    if (specNow && spec.dHisto) speculate();
+    const u32* const src[5] = { reinterpret_cast<const u32*>(dStats), reinterpret_cast<const u32*>(dMins), reinterpret_cast<const u32*>(dMaxs),
+                                spec.on && specNow ? spec.dHisto : nullptr, spec.on && specNow ? spec.dTotal : nullptr };
+    const u32 nw[5] = { wStats, wKeys, wKeys, spec.on && specNow ? 512u : 0u, spec.on && specNow ? 1u : 0u };
+    launchWordsGather(src, nw, pin, st);
+    if (!sync.wait()) return false;
+    memcpy(&hr.stats, pin, sizeof(BandStats));
+    memcpy(hMins.data(), pin + wStats, (size_t)nD * 8);
+    memcpy(hMaxs.data(), pin + wStats + wKeys, (size_t)nD * 8);
+    if (spec.on && specNow) { memcpy(spec.histo, pin + wStats + 2u * wKeys, 512 * 4); spec.total = pin[wStats + 2u * wKeys + 512u]; }
+    return true;
   };
   if (isFlt && maxZErr > 0)
   {
@@ -847,7 +859,8 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
     if (payload != P_ONESWEEP && (hd.tryHuffmanInt() || hd.tryHuffmanFlt())) prefix[at++] = (u8)imageMode;
   }
   TL("prefix assembled");
-  hipMemcpyAsync(dBandOut, prefix, at, hipMemcpyHostToDevice, st);
+  const bool prefixByKernel = payload == P_HUFFMAN && at <= 4096;    // (the Huffman mode's kernel takes a short prefix along: emitHuffman)
+  if (!prefixByKernel) hipMemcpyAsync(dBandOut, prefix, at, hipMemcpyHostToDevice, st);
   u8* dPayload = dBandOut + at;
 
   if (payload == P_TILING && dStreamed && hd.mbSize == 8)    // (in place since streamMasked)
@@ -880,7 +893,7 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   }
   else if (payload == P_HUFFMAN)
   {
-    if (!emitHuffman(ctx, dt, dData, dBits, nRows, nCols, nD, huff, dPayload, dStatus, prefix + huffPinAt)) return kFailed;
+    if (!emitHuffman(ctx, dt, dData, dBits, nRows, nCols, nD, huff, dPayload, dStatus, prefix + huffPinAt, prefixByKernel ? dBandOut : nullptr, prefix, (u32)at)) return kFailed;
     TL("Huffman stream enqueued");
   }
 

@@ -30,9 +30,10 @@ bool planHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
                  int version, HuffmanPlan& plan, const u32* readyHisto = nullptr);
 // the histograms only: counts into hHisto[512] once the stream has been waited for (hHisto must live until then)
 bool enqueueHuffmanHisto(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth, u32* hHisto);
+void enqueueHuffmanHistoDevice(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth, u32* dHisto);    // dHisto: 512 zeroed words, left on the device
 // writes table + pixel stream + padding at dOut; enqueues only -- `plan` must outlive the caller's next synchronisation
 bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth,
-                 const HuffmanPlan& plan, u8* dOut, DeviceStatus* dStatus, u8* pin = nullptr);    // pin: pinned host memory, 2048 + plan.table.size() bytes, the caller's until its next synchronisation (or none)
+                 const HuffmanPlan& plan, u8* dOut, DeviceStatus* dStatus, u8* pin = nullptr, u8* dAlso = nullptr, const u8* pinAlso = nullptr, u32 nAlso = 0);    // pin: pinned host memory, 2048 + plan.table.size() bytes, the caller's until its next synchronisation (or none); dAlso / pinAlso / nAlso: bytes of the caller's that travel with them (the band's header and ranges)
 // decodes a Huffman payload starting at blob + dataBegin; returns an ErrCode
 u32 decodeHuffman(Context& ctx, int dt, const u8* hBlob, const u8* dBlob, u32 dataBegin, u32 blobEnd, int imageMode,
                   const u8* dMaskBits, int nRows, int nCols, int nDepth, int version, void* dOut, DeviceStatus* dStatus,

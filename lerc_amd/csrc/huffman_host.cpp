@@ -322,6 +322,14 @@ bool enqueueHuffmanHisto(Context& ctx, int dt, const void* dData, const u8* dMas
   return hipMemcpyAsync(hHisto, dHisto, 512 * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
 }
 
+// the same without the way home: the counts stay in dHisto (512 words, zeroed by the caller), the caller gathers them
+void enqueueHuffmanHistoDevice(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth, u32* dHisto)
+{
+  const HuffGeom g{ nRows, nCols, nDepth };
+  ProfScope ps(ctx, "huff_histo");
+  launchHuffHisto(dt, dData, dMaskBits, g, dHisto, ctx.activeStream());
+}
+
 bool planHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth, int version,
                  HuffmanPlan& plan, const u32* readyHisto)
 {
@@ -365,7 +373,7 @@ bool planHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
 }
 
 bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, int nRows, int nCols, int nDepth,
-                 const HuffmanPlan& plan, u8* dOut, DeviceStatus* dStatus, u8* pin)
+                 const HuffmanPlan& plan, u8* dOut, DeviceStatus* dStatus, u8* pin, u8* dAlso, const u8* pinAlso, u32 nAlso)
 {
   hipStream_t st = ctx.activeStream();
   const HuffGeom g{ nRows, nCols, nDepth };
@@ -391,10 +399,20 @@ bool emitHuffman(Context& ctx, int dt, const void* dData, const u8* dMaskBits, i
   u8* dStreamBytes = dOut + plan.table.size();
   const u32 mis = (u32)((uintptr_t)dStreamBytes & 3u);
   u32* dStream = reinterpret_cast<u32*>(dStreamBytes - mis);
-  hipMemcpyAsync(dCodes, hCodes, 256 * sizeof(u64), hipMemcpyHostToDevice, st);
   // (zeros first -- from the aligned word the stream begins in, which holds the table's last bytes too -- then the table)
   hipMemsetAsync(dStream, 0, (size_t)mis + (size_t)nWords * 4, st);
-  hipMemcpyAsync(dOut, hTable, plan.table.size(), hipMemcpyHostToDevice, st);
+  if (pin)    // (one kernel that reads the pinned bytes instead of two copy commands)
+  {
+    u8* const dst[4] = { reinterpret_cast<u8*>(dCodes), dOut, dAlso, nullptr };
+    const u8* const src[4] = { reinterpret_cast<const u8*>(hCodes), hTable, pinAlso, nullptr };
+    const u32 n[4] = { 256u * (u32)sizeof(u64), (u32)plan.table.size(), dAlso ? nAlso : 0u, 0u };
+    launchBytesScatter(dst, src, n, st);
+  }
+  else
+  {
+    hipMemcpyAsync(dCodes, hCodes, 256 * sizeof(u64), hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(dOut, hTable, plan.table.size(), hipMemcpyHostToDevice, st);
+  }
   if (!dMaskBits && dStatus)
   {
     // every pixel valid: one pass (the packer's workgroups chain their bit counts themselves)

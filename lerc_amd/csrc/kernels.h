@@ -125,5 +125,10 @@ void launchOneSweep(bool encode, const void* src, void* dst, const u8* maskBits,
                     int pixelBytes, hipStream_t stream);
 void launchFill(void* dst, const void* pixel, int pixelBytes, const u8* maskBits, i64 nPix, hipStream_t stream);
 void launchWidenToDouble(int dt, const void* src, double* dst, i64 n, hipStream_t stream);
+// small moves by kernels instead of copy commands (misc_kernels.hip): the statistics kernels' inputs set, their results gathered
+// in pinned host memory (words of up to five sources back to back), short byte strings out of pinned host memory to their places
+void launchStatsInit(u64* mins, u64* maxs, int nDepth, u32* zeroA, u32 nWordsA, u32* zeroB, u32 nWordsB, hipStream_t stream);
+void launchWordsGather(const u32* const src[5], const u32 nWords[5], u32* dstPinned, hipStream_t stream);
+void launchBytesScatter(u8* const dst[4], const u8* const srcPinned[4], const u32 n[4], hipStream_t stream);
 
 }    // namespace lerc

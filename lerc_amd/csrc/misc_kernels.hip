@@ -952,4 +952,52 @@ void launchWidenToDouble(int dt, const void* src, double* dst, i64 n, hipStream_
   }
 }
 
+// ---- small moves by kernels instead of copy commands ---------------------------------------------------------------------
+// Between two kernels of a stream a hipMemcpyAsync / hipMemsetAsync of a few bytes is a command of its own -- for host memory
+// one of the copy engine's, with a hand-over either way -- and a copy into PAGEABLE host memory keeps the calling thread until
+// it is through: a band's statistics used to come home in five of them.  Here a kernel sets the inputs of the statistics
+// kernels (k_stats_init), and one gathers their results in a block of pinned host memory that the host reads after its wait
+// (k_words_gather); k_bytes_scatter moves up to four short byte strings out of pinned host memory to where the band wants
+// them (header and ranges, the Huffman mode's code table and code words).
+struct WordsGather { const u32* src[5]; u32 n[5]; };    // words of each source, written one behind the other
+__global__ void __launch_bounds__(256) k_words_gather(WordsGather g, u32* __restrict__ dst)
+{
+  u32 at = 0;
+  for (int k = 0; k < 5; k++)
+  {
+    if (g.src[k]) for (u32 i = threadIdx.x; i < g.n[k]; i += 256u) dst[at + i] = g.src[k][i];
+    at += g.n[k];
+  }
+}
+__global__ void __launch_bounds__(256) k_stats_init(u64* __restrict__ mins, u64* __restrict__ maxs, u32 nDepth, u64 initMin, u64 initMax,
+                                                    u32* __restrict__ zeroA, u32 nA, u32* __restrict__ zeroB, u32 nB)
+{
+  for (u32 i = threadIdx.x; i < nDepth; i += 256u) { mins[i] = initMin; maxs[i] = initMax; }
+  for (u32 i = threadIdx.x; i < nA; i += 256u) zeroA[i] = 0u;
+  for (u32 i = threadIdx.x; i < nB; i += 256u) zeroB[i] = 0u;
+}
+struct BytesScatter { u8* dst[4]; const u8* src[4]; u32 n[4]; };
+__global__ void __launch_bounds__(256) k_bytes_scatter(BytesScatter g)
+{
+  for (int k = 0; k < 4; k++)
+    if (g.dst[k]) for (u32 i = threadIdx.x; i < g.n[k]; i += 256u) g.dst[k][i] = g.src[k][i];
+}
+
+void launchStatsInit(u64* mins, u64* maxs, int nDepth, u32* zeroA, u32 nWordsA, u32* zeroB, u32 nWordsB, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(256), 0, stream, mins, maxs, (u32)nDepth, statKeyInitMin(), statKeyInitMax(), zeroA, nWordsA, zeroB, nWordsB);
+}
+void launchWordsGather(const u32* const src[5], const u32 nWords[5], u32* dstPinned, hipStream_t stream)
+{
+  WordsGather g;
+  for (int k = 0; k < 5; k++) { g.src[k] = src[k]; g.n[k] = nWords[k]; }
+  hipLaunchKernelGGL(k_words_gather, dim3(1), dim3(256), 0, stream, g, dstPinned);
+}
+void launchBytesScatter(u8* const dst[4], const u8* const srcPinned[4], const u32 n[4], hipStream_t stream)
+{
+  BytesScatter g;
+  for (int k = 0; k < 4; k++) { g.dst[k] = dst[k]; g.src[k] = srcPinned[k]; g.n[k] = n[k]; }
+  hipLaunchKernelGGL(k_bytes_scatter, dim3(1), dim3(256), 0, stream, g);
+}
+
 }    // namespace lerc
