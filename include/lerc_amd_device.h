@@ -83,7 +83,8 @@ LERC_AMD_API int lerc_amd_profile_read(lerc_amd_context* ctx, char* buf, int cap
  * behind lerc_encode / lerc_decode.  Diagnostics only (tests assert that the streaming path really ran). */
 LERC_AMD_API void lerc_amd_path_counters(lerc_amd_context* ctx, unsigned long long out[4]);
 /* Which of the streaming decoders served the bands / tiles counted in out[2] above: out[3] the scanning decoder (one launch, no
- * walks), out[2] the walking one-launch decoder, out[1] discovery + decode in two launches; out[0] is unused.  Same ctx convention. */
+ * walks), out[2] the walking one-launch decoder, out[1] discovery + decode in two launches; out[0] counts bands WITH a mask whose blocks the scanning decoder's first half found
+ * (the general kernels decode their pixels).  Same ctx convention. */
 LERC_AMD_API void lerc_amd_decode_forms(lerc_amd_context* ctx, unsigned long long out[4]);
 /* why the last call that left the streaming kernels did so ("" if none did); same ctx convention */
 LERC_AMD_API const char* lerc_amd_last_note(lerc_amd_context* ctx);

@@ -190,6 +190,11 @@ static bool fastDecodeOneLaunch()
 // bit-stuffed -- costs a launch before the next tier gets it, and the bands of one job are alike, so the next kScanSkip decodes
 // start one tier down.
 static const u32 kScanSkip = 16;
+static bool scanOffsetsOn()    // (LERC_AMD_SCAN_OFFSETS=0: masked bands keep to the general discovery)
+{
+  static const bool on = []() { const char* e = getenv("LERC_AMD_SCAN_OFFSETS"); return !e || atoi(e) != 0; }();
+  return on;
+}
 static int pickForm(Context& ctx, int maxForm, int nRows, int nCols)
 {
   static const bool scanOn = []() { const char* e = getenv("LERC_AMD_DECODE_SCAN"); return !e || atoi(e) != 0; }();
@@ -426,7 +431,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
   // bands decoded by the streaming kernels: their checksum comes out of the decode kernel itself
   // (a band of its own epoch each: the bands share the context's epoch-tagged cells, and cells left by the band before must
   // not look like this band's)
-  struct FastBand { bool used = false; u32 epoch = 0; };
+  struct FastBand { bool used = false; bool offsetsOnly = false; u32 epoch = 0; };    // offsetsOnly: a masked band whose block offsets the scanning decoder's first half found (its flags count, nothing else of the cell)
   std::vector<FastBand> fast(rq.nBands);
 
   // what a band's kernels take from the workspace (mask tables, chunk tables, block offsets ...) is sized for ONE band: every band
@@ -736,12 +741,46 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     }
     wb.nValidBlk = nValidBlk;
     if (!wb.chunkExit || !wb.chunkEntry || !wb.chunkCount || !wb.chunkBase || !wb.blockOff || !wb.scratch) return kFailed;
+    // A band with a mask, 8 x 8 blocks, one value a pixel: the scanning decoder's first half cuts the stream into blocks (tile_fast_decode_scan.hip,
+    // MODE 1: count bytes of 1 ... 64) instead of the general discovery below, which looks at every byte position (0.5 ms for the
+    // 96 MB of the masked 8192^2 raster).  It hands a stream it does not follow on: the caller repeats the band with level 0.
+    const bool scanOffsets = allowFast && !ctx.scanOffsetsBan && nValidBlk && dMask && bp.mb == 8 && nD == 1 && tb >= 2 && hd.version >= 3 && scanOffsetsOn();
+    if (scanOffsets)
+    {
+      const u32 nPos = (u32)bp.nTV * (u32)bp.nTH;
+      FastDecodeBuffers fbuf;
+      memset(&fbuf, 0, sizeof(fbuf));
+      const size_t sWg = fastAnyWgStride(blobEnd, tb), sGrp = fastAnyGroupStride(blobEnd, tb);
+      fbuf.wgStride = (u32)sWg; fbuf.wgGroupStride = (u32)sGrp;
+      fbuf.wgCell = (u64*)ctx.persistentState(1, (sWg + sGrp + 8) * 8);
+      fbuf.wgGroupCell = fbuf.wgCell ? fbuf.wgCell + sWg : nullptr;
+      fbuf.wgAcc = (u64*)ctx.persistentState(0, (sGrp + 8) * 8);
+      if (!fbuf.wgCell || !fbuf.wgAcc) return kFailed;
+      FastBand& f = fast[iBand];
+      f.epoch = ctx.nextEpoch();
+      f.offsetsOnly = true;
+      u8* cell = dCells + 64 + (size_t)iBand * kCellBytes;
+      fbuf.params = reinterpret_cast<FastDecodeParams*>(cell + kCellParams);
+      fbuf.fallback = reinterpret_cast<u32*>(cell + kCellFallback);
+      fbuf.epoch = f.epoch;
+      fbuf.publishEpoch = (fastTestGiveUp() & 2u) ? f.epoch ^ 0x5A5A5A5Au : f.epoch;
+      fbuf.spinLimit = (fastTestGiveUp() & 2u) ? 8u : (1u << 22);
+      // (the scan needs no mask: it runs while the host decodes the mask's RLE and sends the bits)
+      { ProfScope ps(ctx, "scan_offsets");
+        launchFastScanOffsets(dt, nRows, nCols, dBand, (u32)hd.version, da.dataBegin, blobEnd, wb.blockOff, nPos, fbuf, st); }
+      if (!finishMask(false)) return kFailed;
+      launchBlockValidCounts(dMask, bp, nValidBlk, maskSide ? maskSide : st);
+      if (!finishMask()) return kFailed;    // (joins the side stream, if the mask went that way)
+    }
+    else
+    {
     // the chunk candidates need no mask: they run while the host decodes the mask's RLE and sends the bits
     { ProfScope ps(ctx, "walk_chunks"); launchWalkChunks(bp, wp, da, wb, st); }
     if (!finishMask(false)) return kFailed;
     if (nValidBlk) launchBlockValidCounts(dMask, bp, nValidBlk, maskSide ? maskSide : st);
     if (!finishMask()) return kFailed;    // (joins the side stream, if the mask went that way)
     { ProfScope ps(ctx, "walk_offsets"); launchWalkRest(bp, wp, da, wb, dStatus, st); }
+    }
     da.blockOff = wb.blockOff;
     da.nValidBlk = nValidBlk;
     { ProfScope ps(ctx, "tile_decode"); launchTileDecode(dt, bp, da, dStatus, st); }
@@ -759,6 +798,24 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
   const DeviceStatus hs = *reinterpret_cast<const DeviceStatus*>(pin);
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
+    if (fast[iBand].offsetsOnly)
+    {
+      u32 cells[4];
+      memcpy(cells, pin + 64 + (size_t)iBand * kCellBytes + kCellFallback, 16);
+      const u32 bits = fastFlagBits(cells, fast[iBand].epoch);
+      if (bits & 0x8u) ctx.wipePersistentState();
+      if (bits)    // the caller repeats with the general kernels' own discovery
+      {
+        char msg[112];
+        snprintf(msg, sizeof(msg), "the scan did not find band %d's blocks (reason bits 0x%x): the general discovery takes it", iBand, bits);
+        ctx.lastNote = msg;
+        ctx.scanOffsetsBan = true;    // (for the rest of this call)
+        fellBack = true;
+        return kOk;
+      }
+      ctx.formCount[0]++;    // (lerc_amd_decode_forms: out[0] counts masked bands whose blocks the scan found)
+      continue;
+    }
     if (!fast[iBand].used) continue;
     const u32 verdict = fastBandVerdict(pin + 64 + (size_t)iBand * kCellBytes, fast[iBand].epoch);
     if (verdict & 0x8u) ctx.wipePersistentState();    // (a workgroup gave up waiting: the checksum accumulators may hold residue)
@@ -808,6 +865,7 @@ u32 decodeSpeculativeToHost(Context& ctx, const DecodeRequest& rq, void* hOut, s
 u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
 {
   // tiers: the scanning decoder, the walking one-launch decoder, the two-launch form (each follows streams the one in front cannot), the general kernels
+  ctx.scanOffsetsBan = false;
   int level = rq.noStreaming ? 0 : pickForm(ctx, rq.maxForm, rq.nRows, rq.nCols);
   while (level > 0)
   {

@@ -304,7 +304,9 @@ constexpr u32 kFastWindow(int typeBytes) { return 2u + 64u * (u32)typeBytes; }
 
 // bytes staged in front of a piece of the scanning decoder and behind it (multiples of 32 / 16: bitmap words, 16-byte units)
 constexpr LERC_HD u32 scanPre(int typeBytes) { return (kFastWindow(typeBytes) + 31u) & ~31u; }
-constexpr LERC_HD u32 scanPost(int typeBytes) { return (kFastWindow(typeBytes) + 16u + 15u) & ~15u; }
+// (behind it: the block that begins with the piece's last byte, and -- a masked band -- one more block's length: blocks that are not
+// bit-stuffed behind the piece's end, and the bit-stuffed one behind them, go to the piece in front)
+constexpr LERC_HD u32 scanPost(int typeBytes) { return (2u * kFastWindow(typeBytes) + 64u + 15u) & ~15u; }
 
 // sizes the host can bound without reading the blob (grids and buffers); the true values are in FastDecodeParams
 struct FastWalkPlan { u32 nChunks, nBlocks, nWaves, discChunks; };    // discChunks: chunks per discovery workgroup of this launch
@@ -385,6 +387,9 @@ void launchFastDecodeOne(int dt, int nRows, int nCols, const FastDecodeBatch& t,
                          const FastDecodeBuffers& b, void* out, hipStream_t st);
 void launchFastDecode(int stage, int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
                       const FastDecodeBuffers& b, void* out, hipStream_t st);
+// a masked band's block offsets (tile_fast_decode_scan.hip, MODE 1)
+void launchFastScanOffsets(int dt, int nRows, int nCols, const u8* band, u32 version, u32 dataBegin, u32 blobEnd, u32* blockOff, u32 nPos,
+                           const FastDecodeBuffers& b, hipStream_t st);
 // the scanning decoder: rasters of whole 8 x 8 blocks
 bool fastDecodeScanEligible(int nRows, int nCols);
 void launchFastDecodeScan(int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,

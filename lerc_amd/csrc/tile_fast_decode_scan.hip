@@ -73,7 +73,8 @@ template<class T> struct ScanGeom
   static constexpr u32 kMapWords = (kBytes + 31u) / 32u, kMapVecs = (kMapWords + 3u + 3u) / 4u;    // bitmap words; 16-byte vectors that hold them (+ 3 of slack)
   static constexpr u32 kOwnWord0 = PRE / 32u;
   static constexpr u32 R = NT;                                    // blocks per decode round: one header per thread
-  static constexpr u32 kListCap = P / 16u, kQueueCap = P / 32u;
+  static constexpr u32 kListCap = P / 16u;
+  static constexpr u32 kQueueSeg = (u32)kRounds * 64u, kQueueCap = (NT / 64u) * kQueueSeg;    // a wave's stretch of the queue holds all its units (a masked band: two units in three have a candidate)
   static_assert(PRE % 32u == 0u && POST % 16u == 0u && P % 2048u == 0u && NT % 64u == 0u, "units, bitmap words, waves");
   static_assert(kBytes + 64u < 65535u, "16-bit positions");
   static_assert(kUnits < 65536u && kScanUnits <= kUnits, "queue entries");
@@ -107,29 +108,47 @@ template<class T> struct ScanShared
   FastDecodeParams hp;                               // the band header, parsed in full by the first wave
 };
 
-// 0x80 in every byte of cur4 that reads 64 behind a byte 10?nnnnn, n != 0 (prev4: the dword in front of cur4)
-__device__ __forceinline__ u32 countByteHits(u32 cur4, u32 prev4)
+// ANYCOUNT: the count byte of a bit-stuffed block of a MASKED band -- any number of valid pixels, 1 ... 64 -- instead of 64.
+// 0x80 clear in every byte of the result where cur4's byte is such a count byte (and set elsewhere)
+template<bool ANYCOUNT> __device__ __forceinline__ u32 countByteTest(u32 cur4)
+{
+  if (!ANYCOUNT) return cur4 ^ 0x40404040u;                                     // a zero byte: 64
+  // 1 ... 64: bit 7 clear, and the low seven bits + 63 come to 01......
+  return ((((cur4 & 0x7F7F7F7Fu) + 0x3F3F3F3Fu) ^ 0x40404040u) & 0xC0C0C0C0u) | (cur4 & 0x80808080u);
+}
+// 0x80 in every byte of cur4 that is such a count byte behind a byte 10?nnnnn, n != 0 (prev4: the dword in front of cur4)
+template<bool ANYCOUNT> __device__ __forceinline__ u32 countByteHits(u32 cur4, u32 prev4)
 {
   const u32 hdr4 = __builtin_amdgcn_alignbit(cur4, prev4, 24);                   // the bytes in front of cur4's
-  const u32 t = (cur4 ^ 0x40404040u) | ((hdr4 & 0xC0C0C0C0u) ^ 0x80808080u);      // a zero byte: 64 behind 10......
+  const u32 t = countByteTest<ANYCOUNT>(cur4) | ((hdr4 & 0xC0C0C0C0u) ^ 0x80808080u);      // a zero byte: a count byte behind 10......
   const u32 z = ((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu;               // 0x80 clear in the zero bytes, and only there
   const u32 nz = ((hdr4 & 0x1F1F1F1Fu) + 0x1F1F1F1Fu) << 2;                         // 0x80 set where n != 0
   return ~z & nz;
 }
-
-// bit 7 of a byte of the result is CLEAR where cur4 reads 64 behind a byte 10...... (and possibly set elsewhere: a filter)
-__device__ __forceinline__ u32 countByteMaybe(u32 cur4, u32 prev4)
+// bit 7 of a byte of the result is CLEAR where cur4 reads such a count byte behind a byte 10...... (a filter: n is not looked at)
+template<bool ANYCOUNT> __device__ __forceinline__ u32 countByteMaybe(u32 cur4, u32 prev4)
 {
   const u32 hdr4 = __builtin_amdgcn_alignbit(cur4, prev4, 24);
-  const u32 t = (cur4 ^ 0x40404040u) | ((hdr4 & 0xC0C0C0C0u) ^ 0x80808080u);
+  const u32 t = countByteTest<ANYCOUNT>(cur4) | ((hdr4 & 0xC0C0C0C0u) ^ 0x80808080u);
   return ((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t;
 }
 
-template<class T>
+// MODE 1 (tile_decode.hip's kernels decode the pixels): the block stream of a band with a MASK -- a block holds 1 ... 64 pixels and its
+// count byte says how many; a block without a valid pixel is one byte, "all zero" (Lerc2.h:422) -- is only cut into blocks: where
+// block k of the stream begins goes to blockOff[k].
+struct ScanOffsetsJob
+{
+  u32 version, dataBegin, blobEnd;    // of the band (the host has read its header and mask)
+  u32* blockOff;                       // [nPos] out: offset of every block of the raster, in raster order
+  u32 nPos;
+};
+
+template<class T, int MODE>
 __device__ __forceinline__ void
 fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict__ blob, u32 sizeGiven, u32 specEnd, int nRows, int nCols,
-             T* __restrict__ outPix, u32 wg)
+             T* __restrict__ outPix, u32 wg, const ScanOffsetsJob& job)
 {
+  constexpr bool OFFS = MODE == 1;
   typedef ScanGeom<T> G;
   constexpr int DT = G::DT;
   constexpr u32 W = G::W, P = G::P, NT = G::NT, PRE = G::PRE, kUnits = G::kUnits;
@@ -176,10 +195,11 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   };
   const bool early = pieceStart < specEnd && pieceStart < sizeGiven;
   if (early) issueLoads();
-  const HeadLite hl = parseHeadLite<DT>(h64, sizeGiven);
+  HeadLite hl = parseHeadLite<DT>(h64, sizeGiven);
+  if (OFFS) { hl.ok = 1u; hl.version = job.version; hl.dataBegin = job.dataBegin; hl.blobEnd = job.blobEnd; }    // (the host has read the header)
   const u32 blobEnd = hl.blobEnd;
-  const bool ours = hl.ok && headLiteEligible<DT>(h64, hl.version, nRows, nCols);
-  if (wg == 0u && !ours && threadIdx.x == 0)      // (not a band of ours: say so)
+  const bool ours = OFFS || (hl.ok && headLiteEligible<DT>(h64, hl.version, nRows, nCols));
+  if (!OFFS && wg == 0u && !ours && threadIdx.x == 0)      // (not a band of ours: say so)
   {
     const FastDecodeParams hp0 = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
     storeParams<true>(b.params, hp0); if (b.hostParams) *b.hostParams = hp0;
@@ -199,7 +219,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   const u32 dataRel = hl.dataBegin + PRE > pieceStart ? hl.dataBegin + PRE - pieceStart : 0u;        // the stream's first block (or 0: in front of all this)
   const u32 pieceEndRel = PRE + P;
 
-  if (w == (int)kWaves - 1)    // (the last wave: the first one has a round of staging more)
+  if (!OFFS && w == (int)kWaves - 1)    // (the last wave: the first one has a round of staging more)
   {
     const FastDecodeParams hpFull = parseBandHeader<DT>(blob, sizeGiven, nRows, nCols);
     if (lane == 0)
@@ -238,7 +258,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   // ---- stage; Fletcher terms of the piece's own units (bytes 14 ... blobEnd - 1 of the blob are checksummed); scan
   u32 fA = 0, nMine = 0;
   u64 fB = 0;
-  constexpr u32 kQueueSeg = kQueueCap / kWaves;    // a wave's stretch of the queue
+  constexpr u32 kQueueSeg = G::kQueueSeg;          // a wave's stretch of the queue
   constexpr u32 ownUnit0 = PRE / 16u, ownUnit1 = (PRE + P) / 16u;
   const bool inner = pieceStart != 0u && (u64)pieceStart + P <= blobEnd;    // no unit of this piece needs blanking
 #pragma unroll
@@ -248,7 +268,8 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     const u32 i = (u32)k * NT + threadIdx.x;
     if (i < kUnits) *reinterpret_cast<uint4*>(&s_in[i * 4]) = x[k];
     const u32 a = pieceStart + 16u * i - PRE;                                 // (own units: >= 0 and < 2^32)
-    if (inner)
+    if (OFFS) { }    // (the general path sums the band's checksum in a kernel of its own)
+    else if (inner)
     {
       if (i >= ownUnit0 && i < ownUnit1) fletcherUnit(x[k], (a - 14u) / 2u, fA, fB);    // unit at blob offset a holds words (a - 14) / 2 ...
     }
@@ -271,7 +292,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     {
       u32 pv = dppMov<kDppWaveShr1>(x[k].w);
       if (lane == 0) pv = 0x80000000u;
-      const u32 z = countByteMaybe(x[k].x, pv) & countByteMaybe(x[k].y, x[k].x) & countByteMaybe(x[k].z, x[k].y) & countByteMaybe(x[k].w, x[k].z);
+      const u32 z = countByteMaybe<OFFS>(x[k].x, pv) & countByteMaybe<OFFS>(x[k].y, x[k].x) & countByteMaybe<OFFS>(x[k].z, x[k].y) & countByteMaybe<OFFS>(x[k].w, x[k].z);
       const bool has = (z & 0x80808080u) != 0x80808080u && i < G::kScanUnits && 16u * i < blobRel;    // (what lies behind the blob in the caller's buffer is not looked at)
       const u64 bal = __builtin_amdgcn_ballot_w64(has);
       const u32 slot = nMine + (u32)__popcll(bal & laneMaskLt());
@@ -286,8 +307,8 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   }
   __syncthreads();
   TRACES(1);
-  if (!S.hp.ok) return;    // (not a band the streaming kernels take: the header says so in full only)
-  if (threadIdx.x == 0)
+  if (!OFFS && !S.hp.ok) return;    // (not a band the streaming kernels take: the header says so in full only)
+  if (!OFFS && threadIdx.x == 0)
   {
     // this workgroup's checksum terms: one atomic nobody waits for (the launch's last workgroup folds the accumulators)
     u64 A = 0, B = 0;
@@ -315,7 +336,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       const u32 unit = (u32)s_queue[h];
       const uint4 xu = *reinterpret_cast<const uint4*>(&s_in[4u * unit]);
       const u32 pvu = S.inAll[4u * unit + 3u];                               // (the dword in front of the unit; in front of the staged bytes: 0)
-      const u32 m0 = countByteHits(xu.x, pvu), m1 = countByteHits(xu.y, xu.x), m2 = countByteHits(xu.z, xu.y), m3 = countByteHits(xu.w, xu.z);
+      const u32 m0 = countByteHits<OFFS>(xu.x, pvu), m1 = countByteHits<OFFS>(xu.y, xu.x), m2 = countByteHits<OFFS>(xu.z, xu.y), m3 = countByteHits<OFFS>(xu.w, xu.z);
       const u32 zb = (m0 >> 7) | ((m1 >> 7) << 1) | ((m2 >> 7) << 2) | ((m3 >> 7) << 3);
       const u32 tb = zb | (zb >> 4);
       u32 hits = (tb & 0xFFu) | ((tb >> 8) & 0xFF00u);
@@ -330,7 +351,8 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
         const u32 tB = (a2 >> 8) & 0xFFu, nb = tB & 31u, lut = (tB >> 5) & 1u;
         const u32 nLut = ((a2 >> 24) - 1u) & 0xFFu;                          // valid: 1 ... 254
         const bool okLut = (lut == 0u) | ((nLut - 1u) < 254u);
-        const u32 payload = lut ? 1u + ((nLut * nb + 7u) >> 3) + 8u * (u32)bitLen(nLut) : 8u * nb;
+        const u32 cnt = OFFS ? ((a2 >> 16) & 0xFFu) : 64u;                       // elements of the block: the count byte
+        const u32 payload = lut ? 1u + ((nLut * nb + 7u) >> 3) + ((cnt * (u32)bitLen(nLut) + 7u) >> 3) : ((cnt * nb + 7u) >> 3);
 #pragma unroll
         for (u32 tc = 0; tc < 4; tc++)
         {
@@ -384,7 +406,8 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   // ---- every block's header in full, lane = block: length, mode, bits, offset (ReadTile's and BitStuffer2::Decode's checks), and
   // "the blocks tile the stream": a block ends where the next one of the list begins, the last one behind the piece (the
   // blob's last piece: with the blob).  What the pixel loop wants to know of the first R blocks is kept.
-  const FastDecodeParams hp = S.hp;
+  FastDecodeParams hp = S.hp;
+  if (OFFS) { memset(&hp, 0, sizeof(hp)); hp.version = job.version; hp.nCols = (u32)nCols; }
   const struct { int nCols, version; double invScale, zMaxHdr; } p = { (int)hp.nCols, (int)hp.version, hp.invScale, hp.zMaxHdr };
   typedef DCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
@@ -394,10 +417,22 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   {
     u32 h0, h1, h2;
     ldsHeader<DT>(s_in, pos, h0, h1, h2);
-    u32 code = parseCode<DT>(h0, h1, h2, p.version);
+    u32 nEl = 64u;
+    if (OFFS)
+    {
+      // a masked band's block holds 1 ... 64 pixels, and its count byte says how many (the decode kernel, which knows the block's
+      // place, checks the number); a raw block's length hangs on it without saying it: such a stream goes the long way
+      const u32 offB = (offBytesTable<DT>() >> ((h0 >> 4) & 12u)) & 15u;
+      u32 tt = (u32)((((u64)h1 << 32) | h0) >> ((8u + 8u * offB) & 63u));
+      if (DT == DT_Double && offB == 8u) tt = h2 >> 8;
+      const u32 mode = h0 & 3u;
+      nEl = mode == 1u ? ((tt >> 8) & 0xFFu) : 64u;       // (constant blocks have no count, and their length does not hang on it)
+      if (mode == 0u || (nEl - 1u) >= 64u) nEl = 0u;
+    }
+    u32 code = (OFFS && nEl == 0u) ? 0u : parseCode<DT>(h0, h1, h2, p.version, nEl);
     if (pos + codeLen(code) > blobRel) code = 0u;
     const u32 len = codeLen(code);
-    if (keep)
+    if (!OFFS && keep)
     {
       double offset = 0;
       const u32 mode = codeMode(code);
@@ -521,6 +556,33 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     }
   }
 
+  // ---- A masked band: where this piece ends.  A piece's first block is the first one in its bytes that is bit-stuffed AND stands
+  // behind a bit-stuffed one (START & END: the scan knows no other blocks, and the mending only walks BETWEEN survivors), so what
+  // begins behind this piece's end in front of such a block -- a run of one-byte blocks of pixels that are all invalid, a
+  // constant block, the bit-stuffed block behind them, whose END nobody sets -- is this piece's: one thread walks them (they
+  // are staged: a block's length more than the unmasked bands need).
+  if (OFFS)
+  {
+    if (threadIdx.x == 0 && !S.bad && S.nEnt != 0u && !lastPiece)
+    {
+      u32 n = S.nEnt, xx = S.exitRel;
+      bool prevStuffed = ((s_in[(u32)s_list[n - 1u] >> 2] >> (8u * ((u32)s_list[n - 1u] & 3u))) & 3u) == 1u;
+      while (xx < blobRel)    // (at the stream's end the pieces behind hold nothing)
+      {
+        if (xx + 24u > G::kBytes) { S.bad = 1u; break; }
+        const bool curStuffed = ((s_in[xx >> 2] >> (8u * (xx & 3u))) & 3u) == 1u;
+        if (prevStuffed && curStuffed) break;    // a block the piece behind sees: bit-stuffed behind a bit-stuffed one
+        const u32 lx = parseBlock(xx, false, 0u);
+        if (lx == 0u || n >= kListCap || xx + lx + 24u > G::kBytes) { S.bad = 1u; break; }
+        s_list[n++] = (u16)xx;
+        prevStuffed = curStuffed;
+        xx += lx;
+      }
+      S.nEnt = n; S.exitRel = xx;
+    }
+    __syncthreads();
+  }
+
   // ---- count out: blocks of this piece, and where its last block ends (relative to the piece's end)
   const u32 total = S.bad ? 0u : S.nEnt;
   if (threadIdx.x == 0)
@@ -624,7 +686,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   auto cellOf = [&](u32 i) -> const u64* { return i < nIn ? b.wgCell + g0 + i : i < nIn + grp ? b.wgGroupCell + (i - nIn) : b.wgCell + (wg - 1u); };
   u64 cell0 = 0;
   if (threadIdx.x < nCells) cell0 = observe64(cellOf(threadIdx.x));
-  const u32 nFirst = min(total, R);                 // blocks of the first round: their headers are parsed
+  const u32 nFirst = OFFS ? 0u : min(total, R);     // blocks of the first round: their headers are parsed
   Vec held[kHeld ? kHeld : 1u];
 #pragma unroll
   for (u32 j = 0; j < kHeld; j++)
@@ -672,12 +734,22 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     u32 exitRel = S.exitRel;
     if (total == 0u && lastPiece && wg != 0u && S.prevExit != 0xFFFFu) exitRel = PRE + S.prevExit;    // (the stream's last block began in the piece in front)
     const u32 first = total ? (u32)s_list[0] : exitRel;
-    if (wg == 0u) bad = bad || first != dataRel;
+    const u32 firstPiece = hl.dataBegin / P;    // (a masked band: the mask's bytes may fill pieces of their own in front of the stream)
+    if (wg < firstPiece) bad = bad || total != 0u;
+    else if (wg == firstPiece) bad = bad || first != dataRel;
     else bad = bad || S.prevExit == 0xFFFFu || first != PRE + S.prevExit;
-    if (total == 0u && !lastPiece) bad = true;    // (a piece is longer than any block)
+    if (total == 0u && !lastPiece && wg >= firstPiece) bad = true;    // (a piece is longer than any block)
     if (bad) raiseFlag(b, 1);
     // the pieces hold all the raster's blocks, or the band goes the long way
-    if (lastPiece && (base + total != hp.nBlocks || exitRel != blobRel)) raiseFlag(b, 2);
+    const u32 nBlocksWanted = OFFS ? job.nPos : hp.nBlocks;
+    if (lastPiece && (base + total != nBlocksWanted || exitRel != blobRel)) raiseFlag(b, 2);
+  }
+  if (OFFS)
+  {
+    // where block k of the stream begins
+    for (u32 f = threadIdx.x; f < total; f += NT)
+      if (base + f < job.nPos) job.blockOff[base + f] = pieceStart + (u32)s_list[f] - PRE;
+    return;
   }
 
   // ---- rounds of at most R blocks: the blocks' places (lane = block), then the pixels' way out
@@ -805,7 +877,16 @@ k_fast_decode_scan(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 s
   b.wgAcc += tile * b.wgGroupStride;
   if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
   __shared__ ScanShared<T> sm;
-  fastScanBody<T>(sm, b, blob, sizeGiven, specEnd, nRows, nCols, outPix + tile * t.tileElems, blockIdx.x);
+  fastScanBody<T, 0>(sm, b, blob, sizeGiven, specEnd, nRows, nCols, outPix + tile * t.tileElems, blockIdx.x, ScanOffsetsJob());
+}
+
+// MODE 1: a masked band's block stream cut into blocks (see ScanOffsetsJob); no pixels, no checksum
+template<class T>
+__global__ void __launch_bounds__(kScanThreads) LERC_SCAN_SGPR_CAP
+k_fast_scan_offsets(FastDecodeBuffers b, ScanOffsetsJob job, const u8* blob, int nRows, int nCols)
+{
+  __shared__ ScanShared<T> sm;
+  fastScanBody<T, 1>(sm, b, blob, job.blobEnd, job.blobEnd, nRows, nCols, (T*)nullptr, blockIdx.x, job);
 }
 
 template<class T>
@@ -829,6 +910,25 @@ extern "C" __attribute__((visibility("default"))) int lerc_amd_probe_decode_scan
 }
 
 bool fastDecodeScanEligible(int nRows, int nCols) { return nRows % 8 == 0 && nCols % 8 == 0; }
+
+// a masked band's block offsets by the scanning decoder's first half (8 x 8 blocks, one value per pixel, 16-bit and wider types)
+void launchFastScanOffsets(int dt, int nRows, int nCols, const u8* band, u32 version, u32 dataBegin, u32 blobEnd, u32* blockOff, u32 nPos,
+                           const FastDecodeBuffers& b, hipStream_t st)
+{
+  ScanOffsetsJob job;
+  job.version = version; job.dataBegin = dataBegin; job.blobEnd = blobEnd; job.blockOff = blockOff; job.nPos = nPos;
+  const dim3 grid(fastScanNumWG(blobEnd)), block(kScanThreads);
+  switch (dt)
+  {
+    case DT_Short:  hipLaunchKernelGGL((k_fast_scan_offsets<short>), grid, block, 0, st, b, job, band, nRows, nCols); break;
+    case DT_UShort: hipLaunchKernelGGL((k_fast_scan_offsets<unsigned short>), grid, block, 0, st, b, job, band, nRows, nCols); break;
+    case DT_Int:    hipLaunchKernelGGL((k_fast_scan_offsets<int>), grid, block, 0, st, b, job, band, nRows, nCols); break;
+    case DT_UInt:   hipLaunchKernelGGL((k_fast_scan_offsets<unsigned int>), grid, block, 0, st, b, job, band, nRows, nCols); break;
+    case DT_Float:  hipLaunchKernelGGL((k_fast_scan_offsets<float>), grid, block, 0, st, b, job, band, nRows, nCols); break;
+    case DT_Double: hipLaunchKernelGGL((k_fast_scan_offsets<double>), grid, block, 0, st, b, job, band, nRows, nCols); break;
+    default: break;
+  }
+}
 
 void launchFastDecodeScan(int dt, int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven,
                           const FastDecodeBuffers& b, void* out, hipStream_t st)

@@ -1230,6 +1230,44 @@ def test_sim_decode_given_a_buffer_full_of_stale_bytes_behind_the_blob(libs):
         L.lerc_amd_destroy(h)
 
 
+def test_sim_masked_bands_are_cut_into_blocks_by_the_scan(libs):
+    """A band with a mask (8 x 8 blocks, one value a pixel, 16-bit and wider types): the scanning decoder's first half finds the block
+    offsets (tile_fast_decode_scan.hip, MODE 1 -- count bytes of 1 ... 64, one-byte blocks of pixels that are all invalid walked by the
+    mending, the blocks behind a piece's end up to the next bit-stuffed pair handed to the piece in front), the general kernels decode
+    the pixels.  lerc_amd_decode_forms()[0] counts such bands; damaged copies get the oracle's verdict (the scan hands what it cannot
+    follow to the general discovery)."""
+    O, S = libs
+    rng = np.random.default_rng(25)
+    served = 0
+    for it, (r, c, dt, e) in enumerate(((256, 400, np.float32, 0.01), (200, 264, np.uint16, 0), (512, 1024, np.float32, 0.01), (300, 300, np.int32, 0),
+                                        (128, 2048, np.float64, 0.001), (333, 517, np.float32, 0.1), (96, 4096, np.int16, 1))):
+        x = cases._cast(cases.terrain(r, c, rng, amp=300, base=1000, sigma=2.0), dt)
+        m = np.ones((r, c), np.uint8)
+        if it % 3 == 0:
+            for _ in range(8):
+                i0, j0 = int(rng.integers(0, r)), int(rng.integers(0, c))
+                m[i0:i0 + int(rng.integers(1, 60)), j0:j0 + int(rng.integers(1, 200))] = 0
+        elif it % 3 == 1:
+            m = (rng.random((r, c)) > 0.3).astype(np.uint8)
+        else:
+            m[((np.arange(r)[:, None] // 97) + (np.arange(c)[None, :] // 131)) % 10 == 0] = 0
+        rc, blob = O.encode(x, e, mask=m)
+        assert rc == 0
+        f0 = S.decode_forms()
+        d1, d2 = O.decode(blob), S.decode(blob)
+        f1 = S.decode_forms()
+        v = d1[2].reshape(r, c) != 0
+        assert d1[0] == d2[0] == 0 and np.array_equal(d1[2], d2[2]) and np.array_equal(d1[1].reshape(r, c)[v], d2[1].reshape(r, c)[v]), (it, r, c)
+        served += f1[0] - f0[0]
+        for t in range(6):
+            bad = bytearray(blob)
+            k = int(rng.integers(100, len(bad)))
+            bad[k] ^= 1 << int(rng.integers(0, 8))
+            g1, g2 = O.decode(bytes(bad)), S.decode(bytes(bad))
+            assert (g1[0] == 0) == (g2[0] == 0), (it, t, k, g1[0], g2[0])
+    assert served == 7, ("the scan did not serve every masked band", served, S.last_note())
+
+
 def test_sim_workgroups_that_give_up_waiting(libs):
     """LERC_AMD_TEST_GIVEUP: every hand-off inside the one-launch encoder and the streaming decoder arrives with a tag nobody
     waits for; the waiters run into their poll limit, say so, and the host repeats the call on the general kernels --
