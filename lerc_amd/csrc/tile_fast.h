@@ -303,7 +303,9 @@ static const u32 kDecodeChunks = LERC_DECODE_CHUNKS;        // chunks whose bloc
 constexpr u32 kFastWindow(int typeBytes) { return 2u + 64u * (u32)typeBytes; }
 
 // bytes staged in front of a piece of the scanning decoder and behind it (multiples of 32 / 16: bitmap words, 16-byte units)
-constexpr LERC_HD u32 scanPre(int typeBytes) { return (kFastWindow(typeBytes) + 31u) & ~31u; }
+// (in front of it: TWO blocks' lengths -- the block that ends where the piece's first block begins, and the one in front of that:
+// a block of the stream is one that begins where another one ends, and the piece's first block should be told by such a one)
+constexpr LERC_HD u32 scanPre(int typeBytes) { return (2u * kFastWindow(typeBytes) + 31u) & ~31u; }
 // (behind it: the block that begins with the piece's last byte, and -- a masked band -- one more block's length: blocks that are not
 // bit-stuffed behind the piece's end, and the bit-stuffed one behind them, go to the piece in front)
 constexpr LERC_HD u32 scanPost(int typeBytes) { return (2u * kFastWindow(typeBytes) + 64u + 15u) & ~15u; }

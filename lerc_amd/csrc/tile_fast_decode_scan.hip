@@ -41,8 +41,10 @@ static __device__ unsigned long long g_traceS[16 * 8192];
 extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_decode_scan(unsigned long long* out, int n)
 { hipDeviceSynchronize(); hipMemcpyFromSymbol(out, HIP_SYMBOL(g_traceS), sizeof(unsigned long long) * (size_t)n); }
 #define TRACES(slot) do { if (threadIdx.x == 0 && wg < 8192u) g_traceS[16 * wg + (slot)] = wall_clock64(); } while (0)
+#define TRACEV(slot, v) do { if (wg < 8192u) g_traceS[16 * wg + (slot)] = (unsigned long long)(v); } while (0)    // (one thread's)
 #else
 #define TRACES(slot)
+#define TRACEV(slot, v)
 #endif
 
 // 16-byte vectors of pixels a lane takes out of the stream while the cells of the pieces in front travel: as many as leave the
@@ -59,7 +61,7 @@ extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_deco
 #ifndef LERC_SCAN_HELD16
 #define LERC_SCAN_HELD16 2
 #endif
-static const u32 kScanBadCap = 16, kScanFalseCap = 32, kScanInsCap = 64;
+static const u32 kScanBadCap = 64, kScanFalseCap = 64, kScanInsCap = 128;    // (a masked band's pieces: three false survivors and a run or two of one-byte blocks each)
 
 template<class T> struct ScanGeom
 {
@@ -104,6 +106,7 @@ template<class T> struct ScanShared
   u32 wsum[G::NT / 64], qn[G::NT / 64];               // a wave's survivors; units a wave queued
   u64 fa[G::NT / 64], fb[G::NT / 64];
   u64 part;                                          // sum of the cells: this group's in the low half, the groups' in front in the high half
+  u32 anchor, frontBad;                              // the last survivor in front of the own bytes (0xFFFF: none); the list's first entries lie in front of where it ends
   u32 nEnt, nBad[2], nFalse, nIns, over, bad, lost, exitRel, prevExit, mended;    // nBad: broken links found by the first / the second check
   FastDecodeParams hp;                               // the band header, parsed in full by the first wave
 };
@@ -249,7 +252,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   if (threadIdx.x < 4u) S.inAll[threadIdx.x] = 0u;
   if (threadIdx.x == 0)
   {
-    S.nEnt = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
+    S.nEnt = 0u; S.frontBad = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
     S.prevExit = kNoOffset; S.mended = 0u; S.part = 0ull;
   }
   // (no barrier here: nothing below reads what was written above before the barrier behind the staging -- the queue is a
@@ -383,6 +386,16 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   // ---- survivors of the piece's own bytes: a thread's two bitmap words; their list by popcounts and one scan
   const u32 myWord = G::kOwnWord0 + 2u * threadIdx.x;
   { s_sb[myWord] &= s_end[myWord]; s_sb[myWord + 1u] &= s_end[myWord + 1u]; }
+  // the ANCHOR: the last survivor in front of the piece's own bytes.  Where it ends the piece's first block begins -- whatever
+  // else the own bytes' first survivors say (a false one there may tile with the true ones behind it: nothing in the piece
+  // would tell)
+  static_assert(G::kOwnWord0 <= 64u, "a lane of the first wave per bitmap word in front of the own bytes");
+  if (w == 0)
+  {
+    const u32 v = (u32)lane < G::kOwnWord0 ? (s_sb[lane] & s_end[lane]) : 0u;
+    const u32 last = waveMax(v ? 32u * (u32)lane + (31u - (u32)__clz((int)v)) + 1u : 0u);
+    if (lane == 0) S.anchor = last ? last - 1u : 0xFFFFu;
+  }
   auto buildList = [&]()
   {
     const u32 s0 = s_sb[myWord], s1 = s_sb[myWord + 1u];
@@ -482,6 +495,11 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       const bool ok = len != 0u && (last ? (lastPiece ? ext == blobRel : ext >= pieceEndRel) : ext == nxt);
       if (!ok) { const u32 at = atomicAdd(&S.nBad[pass], 1u); if (at < kScanBadCap) S.badIdx[at] = (u16)f; }
       if (last) S.exitRel = ext;
+      if (f == 0u && S.anchor != 0xFFFFu)    // (entries in front of where the anchor ends are none)
+      {
+        const u32 la = parseBlock(S.anchor, false, 0u);
+        if (la != 0u && S.anchor + la > pos) { if (pass == 0u) S.frontBad = 1u; else atomicAdd(&S.nBad[1], 1u); }
+      }
     }
     __syncthreads();
   };
@@ -491,18 +509,28 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   // ---- a list that does not tile is mended by one thread (see the head of the file): false survivors struck, gaps walked.
   // Nothing is written until the whole list has been gone through; then the survivors' bitmap is corrected and the list built
   // again from it.
-  if (S.nBad[0] != 0u)
+  if (S.nBad[0] != 0u || S.frontBad != 0u)
   {
     if (threadIdx.x == 0)
     {
       const u32 n = S.nEnt, nBad = S.nBad[0];
       bool good = false;
-      // (the stream's first block is what it is; any other piece's first survivor may be the false one -- and the second)
-      const u32 tries = (S.over || nBad > kScanBadCap || n == 0u) ? 0u : ((dataRel >= PRE && dataRel < pieceEndRel) ? 1u : 3u);
-      for (u32 start = 0; start < tries && start < n && !good; start++)
+      // where the piece's first block begins, if the bytes in front of it say so: where the anchor ends
+      u32 t0 = 0u;
+      if (S.anchor != 0xFFFFu) { const u32 la = parseBlock(S.anchor, false, 0u); if (la) t0 = S.anchor + la; }
+      u32 start0 = 0u;
+      while (start0 < n && (u32)s_list[start0] < t0) start0++;
+      // (the stream's first block is what it is, and so is what the anchor points at; else the piece's first survivor may be a
+      // false one -- and the second)
+      const bool sure = t0 != 0u || (dataRel >= PRE && dataRel < pieceEndRel);
+      const u32 tries = (S.over || nBad > kScanBadCap || n == 0u) ? 0u : (sure ? 1u : 3u);
+      const u32 endTarget = lastPiece ? blobRel : pieceEndRel;
+      for (u32 tr = 0; tr < tries && start0 + tr < n && !good; tr++)
       {
-        u32 nFalse = start, nIns = 0u, cur = start, exitRel = S.exitRel;
+        const u32 start = start0 + tr;
+        u32 nFalse = 0u, nIns = 0u, cur = start;
         bool fail = start > kScanFalseCap;
+        for (u32 j = 0; j < start && !fail; j++) S.falseIdx[nFalse++] = (u16)j;
         while (!fail)
         {
           u32 a = 0xFFFFu;    // the first entry from cur on whose link to the next one is broken
@@ -510,38 +538,34 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
           if (a == 0xFFFFu) { good = true; break; }
           const u32 pa = (u32)s_list[a], la = parseBlock(pa, false, 0u);
           if (la == 0u) { fail = true; break; }
-          const u32 ea = pa + la;
-          u32 k = a + 1u;
-          while (k < n && (u32)s_list[k] < ea && !fail)    // survivors inside this block: none of them is one
+          // from this block's end to the next survivor that begins where a block ends: survivors inside what is walked over are
+          // struck, blocks the scan did not see -- not bit-stuffed, or bit-stuffed behind one that is not -- are entered
+          u32 xx = pa + la, k = a + 1u;
+          for (;;)
           {
-            if (nFalse < kScanFalseCap) S.falseIdx[nFalse] = (u16)k; else fail = true;
-            nFalse++; k++;
-          }
-          if (fail) break;
-          // what lies between this block's end and the next survivor (or the piece's end): blocks the scan cannot see
-          const u32 target = k < n ? (u32)s_list[k] : (lastPiece ? blobRel : pieceEndRel);
-          u32 xx = ea;
-          while (xx < target && !fail)
-          {
-            const u32 lx = xx < pieceEndRel ? parseBlock(xx, false, 0u) : 0u;
-            if (lx == 0u || nIns >= kScanInsCap) { fail = true; break; }
+            while (k < n && (u32)s_list[k] < xx && !fail)
+            {
+              if (nFalse < kScanFalseCap) S.falseIdx[nFalse++] = (u16)k; else fail = true;
+              k++;
+            }
+            if (fail) break;
+            if (k < n ? xx == (u32)s_list[k] : (lastPiece ? xx == blobRel : xx >= pieceEndRel)) break;
+            if (xx >= endTarget || nIns >= kScanInsCap) { fail = true; break; }
+            const u32 b0 = (s_in[xx >> 2] >> (8u * (xx & 3u))) & 0xFFu;
+            // (a block of pixels that are all zero, or all invalid: one byte -- a masked band has runs of them)
+            const u32 lx = ((b0 & 3u) == 2u && !(v5 && (b0 & 4u))) ? 1u : parseBlock(xx, false, 0u);
+            if (lx == 0u) { fail = true; break; }
             S.insPos[nIns++] = (u16)xx;
             xx += lx;
           }
           if (fail) break;
-          if (k < n) { if (xx != target) { fail = true; break; } cur = k; }
-          else
-          {
-            if (lastPiece ? xx != blobRel : xx < pieceEndRel) { fail = true; break; }
-            exitRel = xx; good = true; break;
-          }
+          if (k < n) cur = k; else { good = true; break; }
         }
         if (good)
         {
-          for (u32 j = 0; j < start; j++) S.falseIdx[j] = (u16)j;
           for (u32 j = 0; j < nFalse; j++) { const u32 pos = (u32)s_list[S.falseIdx[j]]; s_sb[pos >> 5] &= ~(1u << (pos & 31u)); }
           for (u32 j = 0; j < nIns; j++) { const u32 pos = (u32)S.insPos[j]; s_sb[pos >> 5] |= 1u << (pos & 31u); }
-          (void)exitRel;
+          S.nIns = nIns; S.nFalse = nFalse;
         }
       }
       if (!good) S.bad = 1u;
@@ -739,6 +763,8 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     else if (wg == firstPiece) bad = bad || first != dataRel;
     else bad = bad || S.prevExit == 0xFFFFu || first != PRE + S.prevExit;
     if (total == 0u && !lastPiece && wg >= firstPiece) bad = true;    // (a piece is longer than any block)
+    TRACEV(8, total); TRACEV(9, S.nBad[0]); TRACEV(10, S.nBad[1]); TRACEV(11, (S.over ? 1u : 0u) | (S.bad ? 2u : 0u) | (bad ? 4u : 0u) | (S.mended ? 8u : 0u));
+    TRACEV(12, first); TRACEV(13, PRE + S.prevExit); TRACEV(14, S.nIns); TRACEV(15, S.nFalse);
     if (bad) raiseFlag(b, 1);
     // the pieces hold all the raster's blocks, or the band goes the long way
     const u32 nBlocksWanted = OFFS ? job.nPos : hp.nBlocks;
