@@ -89,6 +89,8 @@ public:
   int lastStreamForm = 0;              // the form decodeEnqueueStreaming last enqueued (DecodeRequest::maxForm)
   struct { int dt = -1, nRows = 0, nCols = 0; u32 end = 0; } scanHint;    // size of the last band the streaming kernels decoded, and its shape (see launchFastBands)
   int lastStreamShape[3] = { -1, 0, 0 };                                 // dt, nRows, nCols of the band decodeEnqueueStreaming / decodeImpl last enqueued
+  u32 blindSkip = 0;                   // decodes of blindShape that go to the header-reading path at once (the last blind attempt was refused by the header)
+  int blindShape[3] = { -1, 0, 0 };
   bool scanOffsetsBan = false;         // this call: a masked band's scan for block offsets has failed, the general discovery takes the bands
   u32 scanSkip = 0;                    // decodes that keep off the scanning decoder: it has just handed a band on (a stream with blocks it cannot see)
 

@@ -867,7 +867,13 @@ u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
   // tiers: the scanning decoder, the walking one-launch decoder, the two-launch form (each follows streams the one in front cannot), the general kernels
   ctx.scanOffsetsBan = false;
   int level = rq.noStreaming ? 0 : pickForm(ctx, rq.maxForm, rq.nRows, rq.nCols);
-  while (level > 0)
+  // A band whose header says "not for the streaming kernels" (a mask, another mode) costs the blind attempt a launch and a wait before
+  // the host reads the header itself.  The bands of one job are alike: after such a refusal the next few requests of that shape go
+  // to the header-reading path at once (which still hands an unmasked band to the streaming kernels, a header read later).
+  const bool sameShape = ctx.blindShape[0] == rq.dt && ctx.blindShape[1] == rq.nRows && ctx.blindShape[2] == rq.nCols;
+  bool blind = true;
+  if (ctx.blindSkip > 0 && sameShape) { ctx.blindSkip--; blind = false; }
+  while (blind && level > 0)
   {
     bool handled = false, tried = false;
     DecodeRequest r = rq;
@@ -879,7 +885,11 @@ u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
     if (handled) { ctx.pathCount[2]++; return kOk; }
     if (!tried) break;    // (not a request the streaming kernels take blind: decodeImpl looks at every band)
     if (bits == 0x200u) return kFailed;    // (decoded by the streaming kernels, and the checksum is wrong: no other tier would say anything else)
-    if (bits & 0x100u) break;    // (the header says it is no band for the streaming kernels -- a mask, another mode: the other form would say the same)
+    if (bits & 0x100u)           // (the header says it is no band for the streaming kernels -- a mask, another mode: the other form would say the same)
+    {
+      ctx.blindSkip = 8; ctx.blindShape[0] = rq.dt; ctx.blindShape[1] = rq.nRows; ctx.blindShape[2] = rq.nCols;
+      break;
+    }
     level = lowerForm(ctx, level, rq.nRows, rq.nCols);
   }
   bool fellBack = false;

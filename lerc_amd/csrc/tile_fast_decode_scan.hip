@@ -106,7 +106,7 @@ template<class T> struct ScanShared
   u32 wsum[G::NT / 64], qn[G::NT / 64];               // a wave's survivors; units a wave queued
   u64 fa[G::NT / 64], fb[G::NT / 64];
   u64 part;                                          // sum of the cells: this group's in the low half, the groups' in front in the high half
-  u32 anchor, frontBad;                              // the last survivor in front of the own bytes (0xFFFF: none); the list's first entries lie in front of where it ends
+  u32 t0, frontBad;                                  // where the anchor ends (0: no anchor); the list's first entries lie in front of that
   u32 nEnt, nBad[2], nFalse, nIns, over, bad, lost, exitRel, prevExit, mended;    // nBad: broken links found by the first / the second check
   FastDecodeParams hp;                               // the band header, parsed in full by the first wave
 };
@@ -252,7 +252,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   if (threadIdx.x < 4u) S.inAll[threadIdx.x] = 0u;
   if (threadIdx.x == 0)
   {
-    S.nEnt = 0u; S.frontBad = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
+    S.nEnt = 0u; S.frontBad = 0u; S.t0 = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
     S.prevExit = kNoOffset; S.mended = 0u; S.part = 0ull;
   }
   // (no barrier here: nothing below reads what was written above before the barrier behind the staging -- the queue is a
@@ -364,7 +364,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
           const u32 m = 8u - offB;                                           // the flag byte is byte m of the twelve
           const u32 flag = ((m < 4u ? a0 : m < 8u ? a1 : a2) >> (8u * (m & 3u))) & 0xFFu;
           const u32 len = 3u + offB + payload;
-          const bool ok = (flag & 3u) == 1u && (flag >> 6) == tc && !(v5 && (flag & 4u)) && okLut && len <= RAW && q >= 2u + offB;
+          const bool ok = (flag & 3u) == 1u && (flag >> 6) == tc && !(v5 && (flag & 4u)) && okLut && len <= (OFFS ? 1u + cnt * G::TB : RAW) && q >= 2u + offB;    // (no longer than the raw form of so many values)
           const u32 p = q - 2u - offB, e = p + len;
           if (ok && p >= dataRel && p < pieceEndRel && e <= blobRel)
           {
@@ -386,16 +386,9 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   // ---- survivors of the piece's own bytes: a thread's two bitmap words; their list by popcounts and one scan
   const u32 myWord = G::kOwnWord0 + 2u * threadIdx.x;
   { s_sb[myWord] &= s_end[myWord]; s_sb[myWord + 1u] &= s_end[myWord + 1u]; }
-  // the ANCHOR: the last survivor in front of the piece's own bytes.  Where it ends the piece's first block begins -- whatever
-  // else the own bytes' first survivors say (a false one there may tile with the true ones behind it: nothing in the piece
-  // would tell)
-  static_assert(G::kOwnWord0 <= 64u, "a lane of the first wave per bitmap word in front of the own bytes");
-  if (w == 0)
-  {
-    const u32 v = (u32)lane < G::kOwnWord0 ? (s_sb[lane] & s_end[lane]) : 0u;
-    const u32 last = waveMax(v ? 32u * (u32)lane + (31u - (u32)__clz((int)v)) + 1u : 0u);
-    if (lane == 0) S.anchor = last ? last - 1u : 0xFFFFu;
-  }
+  // (the bytes in front of the piece's own: their survivors say where the piece's first block begins -- the ANCHOR, below)
+  static_assert(G::kOwnWord0 <= NT, "a thread per bitmap word in front of the own bytes");
+  if (threadIdx.x < G::kOwnWord0) s_sb[threadIdx.x] &= s_end[threadIdx.x];
   auto buildList = [&]()
   {
     const u32 s0 = s_sb[myWord], s1 = s_sb[myWord + 1u];
@@ -482,6 +475,34 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     }
     return len;
   };
+  // The ANCHOR: where the piece's first block begins, told by the survivors in front of the piece's own bytes -- whatever the own bytes'
+  // first survivors say (a false one there may tile with the true ones behind it: nothing in the piece would tell).  The last
+  // two survivors in front: if the one ends where the other begins they are blocks, as good as certainly, and the piece's first
+  // block begins where the last one ends; if the last one lies inside the other, where that one ends.  0: nothing to go by.
+  auto anchorEnd = [&]() -> u32
+  {
+    u32 a1 = 0xFFFFu, a2 = 0xFFFFu;
+    for (u32 wd = G::kOwnWord0; wd-- > 0u && a2 == 0xFFFFu; )
+    {
+      u32 v = s_sb[wd];
+      while (v && a2 == 0xFFFFu)
+      {
+        const u32 bit = 31u - (u32)__clz((int)v);
+        v &= ~(1u << bit);
+        if (a1 == 0xFFFFu) a1 = 32u * wd + bit; else a2 = 32u * wd + bit;
+      }
+    }
+    if (a1 == 0xFFFFu) return 0u;
+    const u32 l1 = parseBlock(a1, false, 0u);
+    u32 t0 = l1 ? a1 + l1 : 0u;
+    if (a2 != 0xFFFFu)
+    {
+      const u32 l2 = parseBlock(a2, false, 0u);
+      if (l2 == 0u || a2 + l2 < a1) t0 = 0u;          // (not one behind the other: one of them is no block)
+      else if (a2 + l2 > a1) t0 = a2 + l2;            // (the last one lies inside the one in front)
+    }
+    return t0 >= PRE ? t0 : 0u;
+  };
   auto tilePass = [&](u32 pass)
   {
     const u32 nEnt = S.nEnt;
@@ -495,10 +516,10 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       const bool ok = len != 0u && (last ? (lastPiece ? ext == blobRel : ext >= pieceEndRel) : ext == nxt);
       if (!ok) { const u32 at = atomicAdd(&S.nBad[pass], 1u); if (at < kScanBadCap) S.badIdx[at] = (u16)f; }
       if (last) S.exitRel = ext;
-      if (f == 0u && S.anchor != 0xFFFFu)    // (entries in front of where the anchor ends are none)
+      if (f == 0u)    // (entries in front of where the anchor ends are none)
       {
-        const u32 la = parseBlock(S.anchor, false, 0u);
-        if (la != 0u && S.anchor + la > pos) { if (pass == 0u) S.frontBad = 1u; else atomicAdd(&S.nBad[1], 1u); }
+        if (pass == 0u) S.t0 = anchorEnd();
+        if (S.t0 > pos) { if (pass == 0u) S.frontBad = 1u; else atomicAdd(&S.nBad[1], 1u); }
       }
     }
     __syncthreads();
@@ -516,8 +537,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       const u32 n = S.nEnt, nBad = S.nBad[0];
       bool good = false;
       // where the piece's first block begins, if the bytes in front of it say so: where the anchor ends
-      u32 t0 = 0u;
-      if (S.anchor != 0xFFFFu) { const u32 la = parseBlock(S.anchor, false, 0u); if (la) t0 = S.anchor + la; }
+      const u32 t0 = S.t0;
       u32 start0 = 0u;
       while (start0 < n && (u32)s_list[start0] < t0) start0++;
       // (the stream's first block is what it is, and so is what the anchor points at; else the piece's first survivor may be a
