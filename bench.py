@@ -227,6 +227,38 @@ def other_config(torch, api, codec, name, x, max_z_err, n_depth, steps=5, warmup
             res["blob_matches_reference"] = bool(rc == 0 and len(blob) == nb and hashlib.sha256(bytes(blob)).hexdigest() == sha)
             res["reference_encode_s"] = round(t1 - t0, 3)
     res["verified"] = bool((same is not False) and res.get("blob_matches_reference", True))
+    # The same round trips QUEUED, like the headline's: encode and decode enqueued back to back on the stream (the decode is given
+    # the buffer's capacity and reads the blob's size from its header on the device), one wait behind all of them -- for the
+    # configurations the streaming kernels take blind (one value a pixel, no mask, 16-bit and wider types).
+    if mask is None and n_depth == 1 and x.element_size() >= 2:
+        def pair():
+            rc, t1 = api.encode_device_async(codec, x, max_z_err, out)
+            rc2, t2 = api.decode_device_async(codec, out, out.numel(), dec)
+            if rc != 0 or rc2 != 0:
+                raise RuntimeError(f"{name}: enqueue failed: status {rc} / {rc2}")
+            return t1, t2
+        for _ in range(warmup):
+            t1, t2 = pair()
+        codec.finish(t1); codec.finish(t2)
+        torch.cuda.synchronize()
+        dec.zero_()
+        L.lerc_amd_profile_enable(codec.h, 1)
+        tq0 = time.perf_counter()
+        tickets = [pair() for _ in range(steps)]
+        bad = [codec.finish(t)[0] for pr in tickets for t in pr]
+        torch.cuda.synchronize()
+        elq = time.perf_counter() - tq0
+        L.lerc_amd_profile_enable(codec.h, 0)
+        L.lerc_amd_profile_read(codec.h, buf, len(buf), 1)
+        kq = {}
+        for line in buf.value.decode().splitlines():
+            k, ms_, cnt = line.split()
+            kq[k] = {"avg_ms": round(float(ms_) / max(int(cnt), 1), 5), "launches": int(cnt)}
+        msq = elq / steps * 1e3
+        okq = not any(bad) and (bool(torch.equal(dec.view(torch.uint8), x.view(torch.uint8))) if max_z_err == 0 else True)
+        res["queued"] = {"value": round(n_pix * steps / elq / 1e6, 2), "ms_per_step": round(msq, 4),
+                         "frac_of_hbm_peak_wall": round(b_rt / (msq / 1e3) / 1e9 / HBM_PEAK_GBS, 5), "kernels": kq, "verified": bool(okq),
+                         "host": "steps enqueued on the stream, one wait at the end (lerc_amd_encode_device_async / lerc_amd_decode_device_async)"}
     if mask is not None:
         res["mask_and_error_bound_hold"] = res.pop("lossless_round_trip")
     del out, dec

@@ -349,21 +349,27 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   bool row0Measured = false;
   auto buildMask = [&]() -> bool
   {
-    hipMemsetAsync(dStats, 0, sizeof(BandStats), st);
+    // (inputs set and results gathered by kernels, through pinned memory: see runStats)
+    static_assert(sizeof(BandStats) % 4 == 0, "words");
+    const u32 wStats = (u32)(sizeof(BandStats) / 4);
+    u32* pin = (u32*)ctx.pinned((size_t)(2u * wStats + 16u) * 4u);
+    if (!pin) return false;
+    launchStatsInit(dMins, dMaxs, nD, reinterpret_cast<u32*>(dStats), wStats, candAll ? reinterpret_cast<u32*>(dStatsRow0) : nullptr, candAll ? wStats : 0u, st);
     { ProfScope ps(ctx, "build_mask"); launchBuildMask(dt, dData, dByteMask, nRows, nCols, nD, dNewBits, dStats, st); }
-    hipMemcpyAsync(&hr.stats, dStats, sizeof(BandStats), hipMemcpyDeviceToHost, st);
     row0Measured = false;
     if (candAll)
     {
-      for (int m = 0; m < nD; m++) { hMins[m] = statKeyInitMin(); hMaxs[m] = statKeyInitMax(); }
-      hipMemcpyAsync(dMins, hMins.data(), nD * 8, hipMemcpyHostToDevice, st);
-      hipMemcpyAsync(dMaxs, hMaxs.data(), nD * 8, hipMemcpyHostToDevice, st);
-      hipMemsetAsync(dStatsRow0, 0, sizeof(BandStats), st);
       { ProfScope ps(ctx, "band_stats_row0"); launchBandStats(dt, dData, dNewBits, 1, nCols, nD, candAll, dMins, dMaxs, dStatsRow0, st); }    // (with the bits just made: all ones if nothing is invalid)
-      hipMemcpyAsync(&hr.row0, dStatsRow0, sizeof(BandStats), hipMemcpyDeviceToHost, st);
       row0Measured = true;
     }
+    {
+      const u32* const src[5] = { reinterpret_cast<const u32*>(dStats), candAll ? reinterpret_cast<const u32*>(dStatsRow0) : nullptr, nullptr, nullptr, nullptr };
+      const u32 nw[5] = { wStats, candAll ? wStats : 0u, 0u, 0u, 0u };
+      launchWordsGather(src, nw, pin, st);
+    }
     if (!sync.wait()) return false;
+    memcpy(&hr.stats, pin, sizeof(BandStats));
+    if (candAll) memcpy(&hr.row0, pin + wStats, sizeof(BandStats));
     bandNumValid = (int)hr.stats.numValid;
     bandAllValid = (bandNumValid == (int)nPix);
     haveBits = true;
