@@ -796,6 +796,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
   if (anyGeneric) hipMemcpyAsync(hFl.data(), dFl, hFl.size() * 8, hipMemcpyDeviceToHost, st);
   if (!ctx.sync()) return kFailed;
   const DeviceStatus hs = *reinterpret_cast<const DeviceStatus*>(pin);
+  u32 nScanned = 0;
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
     if (fast[iBand].offsetsOnly)
@@ -813,7 +814,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
         fellBack = true;
         return kOk;
       }
-      ctx.formCount[0]++;    // (lerc_amd_decode_forms: out[0] counts masked bands whose blocks the scan found)
+      nScanned++;
       continue;
     }
     if (!fast[iBand].used) continue;
@@ -840,7 +841,17 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     for (int i = 0; i < kFletcherPartials; i += 2) { A += hFl[(size_t)iBand * kFletcherPartials + i]; B += hFl[(size_t)iBand * kFletcherPartials + i + 1]; }
     if (fletcherFinish(A, B, checksumLen[iBand]) != expectChecksum[iBand]) return kFailed;
   }
+  if (hs.error && nScanned != 0u)
+  {
+    // The scan's cut of a masked band is a proposal: where it had to guess (a raw block's length is in the mask, not in the stream) the
+    // decode kernel, which checks every block against the mask, may refuse it.  The general discovery has the last word.
+    ctx.lastNote = "the decode kernels refused the scan's block offsets: the general discovery takes the band";
+    ctx.scanOffsetsBan = true;
+    fellBack = true;
+    return kOk;
+  }
   if (hs.error) { ctx.lastError = "device kernel reported an error"; return hs.error; }
+  ctx.formCount[0] += nScanned;    // (lerc_amd_decode_forms: out[0] counts masked bands whose blocks the scan found)
   return kOk;
 }
 

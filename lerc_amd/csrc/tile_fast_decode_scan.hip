@@ -75,7 +75,7 @@ template<class T> struct ScanGeom
   static constexpr u32 kMapWords = (kBytes + 31u) / 32u, kMapVecs = (kMapWords + 3u + 3u) / 4u;    // bitmap words; 16-byte vectors that hold them (+ 3 of slack)
   static constexpr u32 kOwnWord0 = PRE / 32u;
   static constexpr u32 R = NT;                                    // blocks per decode round: one header per thread
-  static constexpr u32 kListCap = P / 16u;
+  static constexpr u32 kListCap = P / (P < 32768u ? 4u : 16u);    // (the emulator's small pieces hold runs as long as the full-size ones)
   static constexpr u32 kQueueSeg = (u32)kRounds * 64u, kQueueCap = (NT / 64u) * kQueueSeg;    // a wave's stretch of the queue holds all its units (a masked band: two units in three have a candidate)
   static_assert(PRE % 32u == 0u && POST % 16u == 0u && P % 2048u == 0u && NT % 64u == 0u, "units, bitmap words, waves");
   static_assert(kBytes + 64u < 65535u, "16-bit positions");
@@ -107,7 +107,12 @@ template<class T> struct ScanShared
   u64 fa[G::NT / 64], fb[G::NT / 64];
   u64 part;                                          // sum of the cells: this group's in the low half, the groups' in front in the high half
   u32 t0, frontBad;                                  // where the anchor ends (0: no anchor); the list's first entries lie in front of that
-  u32 nEnt, nBad[2], nFalse, nIns, over, bad, lost, exitRel, prevExit, mended;    // nBad: broken links found by the first / the second check
+  u32 nEnt, nBad[3], nFalse, nIns, over, bad, lost, exitRel, prevExit, mended;    // nBad: broken links found by the first / the second / the third check
+  u32 mendExit;                                      // MODE 1: where the piece's last block ends, if the mending had to find out (a raw block: see there)
+#ifdef LERC_PROBE
+  u32 dbg[4];
+#endif
+  u32 preCarry, fco[G::NT / 64];                     // MODE 1, the flood of one-byte blocks: a run goes on from the bytes in front into the piece's own; a wave's carry out (bit 0: without, bit 1: with a carry in)
   FastDecodeParams hp;                               // the band header, parsed in full by the first wave
 };
 
@@ -134,6 +139,15 @@ template<bool ANYCOUNT> __device__ __forceinline__ u32 countByteMaybe(u32 cur4, 
   const u32 hdr4 = __builtin_amdgcn_alignbit(cur4, prev4, 24);
   const u32 t = countByteTest<ANYCOUNT>(cur4) | ((hdr4 & 0xC0C0C0C0u) ^ 0x80808080u);
   return ((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t;
+}
+
+// bits of a bitmap word (positions base ... base + 31) for the positions [lo, hi)
+__device__ __forceinline__ u32 scanRangeMask(u32 base, u32 lo, u32 hi)
+{
+  const u32 nLo = lo > base ? lo - base : 0u, nHi = hi > base ? hi - base : 0u;
+  const u32 under = nLo >= 32u ? 0xFFFFFFFFu : ((1u << nLo) - 1u);
+  const u32 below = nHi >= 32u ? 0xFFFFFFFFu : ((1u << nHi) - 1u);
+  return below & ~under;
 }
 
 // MODE 1 (tile_decode.hip's kernels decode the pixels): the block stream of a band with a MASK -- a block holds 1 ... 64 pixels and its
@@ -252,7 +266,10 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   if (threadIdx.x < 4u) S.inAll[threadIdx.x] = 0u;
   if (threadIdx.x == 0)
   {
-    S.nEnt = 0u; S.frontBad = 0u; S.t0 = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
+    S.nEnt = 0u; S.frontBad = 0u; S.t0 = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nBad[2] = 0u; S.preCarry = 0u; S.mendExit = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
+#ifdef LERC_PROBE
+    S.dbg[0] = S.dbg[1] = S.dbg[2] = S.dbg[3] = 0u;
+#endif
     S.prevExit = kNoOffset; S.mended = 0u; S.part = 0ull;
   }
   // (no barrier here: nothing below reads what was written above before the barrier behind the staging -- the queue is a
@@ -366,7 +383,15 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
           const u32 len = 3u + offB + payload;
           const bool ok = (flag & 3u) == 1u && (flag >> 6) == tc && !(v5 && (flag & 4u)) && okLut && len <= (OFFS ? 1u + cnt * G::TB : RAW) && q >= 2u + offB;    // (no longer than the raw form of so many values)
           const u32 p = q - 2u - offB, e = p + len;
-          if (ok && p >= dataRel && p < pieceEndRel && e <= blobRel)
+          // (what stands where the candidate ends has to read like the flag byte of the block behind it: the column signature goes
+          // on, by a step or none, or begins again with a block row -- four bytes in five of anything else do not)
+          bool follows = true;
+          if (ok && e < blobRel && e < G::kBytes)
+          {
+            const u32 nf = (s_in[e >> 2] >> (8u * (e & 3u))) & 0xFFu;
+            follows = sigOk((flag >> 2) & pattern, (nf >> 2) & pattern, pattern) && !(v5 && (nf & 4u));
+          }
+          if (ok && follows && p >= dataRel && p < pieceEndRel && e <= blobRel)
           {
             atomicOr(&s_sb[p >> 5], 1u << (p & 31u));
             atomicOr(&s_end[e >> 5], 1u << (e & 31u));                      // (e < pieceEndRel + W: inside the bitmap)
@@ -389,6 +414,15 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   // (the bytes in front of the piece's own: their survivors say where the piece's first block begins -- the ANCHOR, below)
   static_assert(G::kOwnWord0 <= NT, "a thread per bitmap word in front of the own bytes");
   if (threadIdx.x < G::kOwnWord0) s_sb[threadIdx.x] &= s_end[threadIdx.x];
+  if (OFFS)
+  {
+    // (a masked band: END is done with; the bitmap takes where the SURVIVORS end -- the seeds of the flood below.  A thread clears
+    // the words it alone has read, and those behind the piece's own, which nobody has)
+    s_end[myWord] = 0u; s_end[myWord + 1u] = 0u;
+    if (threadIdx.x < G::kOwnWord0) s_end[threadIdx.x] = 0u;
+    constexpr u32 kBehind = G::kOwnWord0 + 2u * NT;
+    if (kBehind + threadIdx.x < 4u * G::kMapVecs) s_end[kBehind + threadIdx.x] = 0u;
+  }
   auto buildList = [&]()
   {
     const u32 s0 = s_sb[myWord], s1 = s_sb[myWord + 1u];
@@ -481,150 +515,445 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   // block begins where the last one ends; if the last one lies inside the other, where that one ends.  0: nothing to go by.
   auto anchorEnd = [&]() -> u32
   {
-    u32 a1 = 0xFFFFu, a2 = 0xFFFFu;
-    for (u32 wd = G::kOwnWord0; wd-- > 0u && a2 == 0xFFFFu; )
+    if (!OFFS)
     {
-      u32 v = s_sb[wd];
-      while (v && a2 == 0xFFFFu)
+      // (the unmasked bands' kernel: the last two survivors in front)
+      u32 a1 = 0xFFFFu, a2 = 0xFFFFu;
+      for (u32 wd = G::kOwnWord0; wd-- > 0u && a2 == 0xFFFFu; )
       {
-        const u32 bit = 31u - (u32)__clz((int)v);
-        v &= ~(1u << bit);
-        if (a1 == 0xFFFFu) a1 = 32u * wd + bit; else a2 = 32u * wd + bit;
+        u32 v = s_sb[wd];
+        while (v && a2 == 0xFFFFu)
+        {
+          const u32 bit = 31u - (u32)__clz((int)v);
+          v &= ~(1u << bit);
+          if (a1 == 0xFFFFu) a1 = 32u * wd + bit; else a2 = 32u * wd + bit;
+        }
       }
+      if (a1 == 0xFFFFu) return 0u;
+      const u32 l1 = parseBlock(a1, false, 0u);
+      u32 t0 = l1 ? a1 + l1 : 0u;
+      if (a2 != 0xFFFFu)
+      {
+        const u32 l2 = parseBlock(a2, false, 0u);
+        if (l2 == 0u || a2 + l2 < a1) t0 = 0u;          // (not one behind the other: one of them is no block)
+        else if (a2 + l2 > a1) t0 = a2 + l2;            // (the last one lies inside the one in front)
+      }
+      return t0 >= PRE ? t0 : 0u;
     }
-    if (a1 == 0xFFFFu) return 0u;
-    const u32 l1 = parseBlock(a1, false, 0u);
-    u32 t0 = l1 ? a1 + l1 : 0u;
-    if (a2 != 0xFFFFu)
+    else
     {
-      const u32 l2 = parseBlock(a2, false, 0u);
-      if (l2 == 0u || a2 + l2 < a1) t0 = 0u;          // (not one behind the other: one of them is no block)
-      else if (a2 + l2 > a1) t0 = a2 + l2;            // (the last one lies inside the one in front)
+      u32 a1 = 0xFFFFu, a2 = 0xFFFFu, a3 = 0xFFFFu;    // the last survivors in front of the own bytes, the last one first
+      u32 nA = 0u;
+      for (u32 wd = G::kOwnWord0; wd-- > 0u && nA < 3u; )
+      {
+        u32 v = s_sb[wd];
+        while (v && nA < 3u)
+        {
+          const u32 bit = 31u - (u32)__clz((int)v);
+          v &= ~(1u << bit);
+          const u32 pos = 32u * wd + bit;
+          if (nA == 0u) a1 = pos; else if (nA == 1u) a2 = pos; else a3 = pos;
+          nA++;
+        }
+      }
+      if (nA == 0u) return 0u;
+      const u32 l1 = parseBlock(a1, false, 0u);
+      u32 t0 = l1 ? a1 + l1 : 0u;
+      if (nA >= 2u)
+      {
+        const u32 l2 = parseBlock(a2, false, 0u);
+        if (l2 == 0u || a2 + l2 < a1) t0 = 0u;          // (not one behind the other: one of them is no block)
+        else if (a2 + l2 > a1)
+        {
+          // the two overlap: one of them is no block.  The survivor in front of both says which -- the one that begins where IT ends
+          t0 = 0u;
+          if (nA >= 3u)
+          {
+            const u32 l3 = parseBlock(a3, false, 0u);
+            if (l3 != 0u && a3 + l3 == a1) t0 = l1 ? a1 + l1 : 0u;
+            else if (l3 != 0u && a3 + l3 == a2) t0 = a2 + l2;
+          }
+        }
+      }
+      // (a masked band: blocks the scan does not see may lie between there and the piece's own bytes -- the mending walks them)
+      return (OFFS || t0 >= PRE) ? t0 : 0u;
     }
-    return t0 >= PRE ? t0 : 0u;
   };
-  auto tilePass = [&](u32 pass)
+  auto tilePass = [&](u32 pass, bool final)
   {
     const u32 nEnt = S.nEnt;
     for (u32 f = threadIdx.x; f < nEnt; f += NT)
     {
       const u32 pos = (u32)s_list[f];
-      const u32 len = parseBlock(pos, f < R, f);
-      const u32 ext = pos + len;
+      u32 len = parseBlock(pos, f < R, f);
       const bool last = f + 1u == nEnt;
       const u32 nxt = last ? 0u : (u32)s_list[f + 1u];
+      if (OFFS && final && len == 0u)
+      {
+        // (a raw block of a masked band, whose length the stream does not say: the mending has found where the next block begins)
+        const u32 b0 = (s_in[pos >> 2] >> (8u * (pos & 3u))) & 0xFFu;
+        const u32 e = last ? S.mendExit : nxt;
+        if ((b0 & 3u) == 0u && !(v5 && (b0 & 4u)) && e > pos + 1u && (e - pos - 1u) % G::TB == 0u && (e - pos - 1u) / G::TB <= 64u && e <= blobRel) len = e - pos;
+      }
+      const u32 ext = pos + len;
       const bool ok = len != 0u && (last ? (lastPiece ? ext == blobRel : ext >= pieceEndRel) : ext == nxt);
       if (!ok) { const u32 at = atomicAdd(&S.nBad[pass], 1u); if (at < kScanBadCap) S.badIdx[at] = (u16)f; }
+      if (OFFS && pass == 0u && len != 0u && ext < G::kBytes) atomicOr(&s_end[ext >> 5], 1u << (ext & 31u));    // (a seed of the flood)
       if (last) S.exitRel = ext;
-      if (f == 0u)    // (entries in front of where the anchor ends are none)
+      if (f == 0u)    // (entries in front of where the anchor ends are none; a masked band: blocks between there and the first entry are missing)
       {
-        if (pass == 0u) S.t0 = anchorEnd();
-        if (S.t0 > pos) { if (pass == 0u) S.frontBad = 1u; else atomicAdd(&S.nBad[1], 1u); }
+        if (!final) S.t0 = anchorEnd();
+        const u32 t0 = S.t0;
+        if (t0 > pos || (OFFS && t0 != 0u && t0 < pos)) { if (!final) S.frontBad = 1u; else atomicAdd(&S.nBad[pass], 1u); }
+      }
+    }
+    if (OFFS && nEnt == 0u && threadIdx.x == 0)    // (no entry: all of the piece is missing, if the bytes in front say where it begins)
+    {
+      if (!final) S.t0 = anchorEnd();
+      if (S.t0 != 0u && S.t0 < pieceEndRel && S.t0 < blobRel) { if (!final) S.frontBad = 1u; else atomicAdd(&S.nBad[pass], 1u); }
+    }
+    if (OFFS && pass == 0u && threadIdx.x < G::kOwnWord0)
+    {
+      // the survivors in front of the piece's own bytes: where they end (a run of one-byte blocks that begins there may reach the own bytes)
+      u32 v = s_sb[threadIdx.x];
+      while (v)
+      {
+        const u32 bit = (u32)__ffs((int)v) - 1u; v &= v - 1u;
+        const u32 pos = 32u * threadIdx.x + bit, len = parseBlock(pos, false, 0u), ext = pos + len;
+        if (len != 0u && ext < G::kBytes) atomicOr(&s_end[ext >> 5], 1u << (ext & 31u));
       }
     }
     __syncthreads();
   };
-  tilePass(0u);
+  tilePass(0u, false);
   TRACES(4);
+
+  // ---- A masked band has RUNS of one-byte blocks (pixels all invalid, Lerc2.h:422) which the scan cannot see, and behind each run a
+  // block without an END.  They are found by a FLOOD over the bitmaps: a byte that reads like such a block (mode 2; bit 2 clear from
+  // codec 5 on) IS one if a block ends in front of it -- a survivor (the seeds: tilePass has left the survivors' ends in END's
+  // place) or the one-byte block in front of it, as long as the column signature goes on from byte to byte -- and what begins behind
+  // the run's last byte is a block as well.  "Goes on while the bytes allow" is the carry chain of an addition: a thread adds
+  // its 64 positions' seeds to their go-on bits, the carries between threads and waves come from two ballots (generate /
+  // propagate), and the bits a carry went INTO are the run (a & the go-on bits) and the block behind it (the one bit where it stopped).
+  u32 cp = 0u;    // the pass whose broken links stand
+  if (OFFS && dataRel < pieceEndRel &&
+      (S.nBad[0] != 0u || S.frontBad != 0u || S.nEnt == 0u || (S.t0 == 0u && !(dataRel >= PRE))))
+  {
+    auto rangeMask = [&](u32 base, u32 lo, u32 hi) -> u32 { return scanRangeMask(base, lo, hi); };
+    // bitmap word wd: which of its 32 bytes read like a one-byte block (m2w), and which of those go on from the byte in front (contw)
+#ifdef LERC_PROBE
+    u32 dbgBoth = 0, dbgAny = 0, dbgC = 0, dbgCont = 0;
+#endif
+    auto wordMasks = [&](u32 wd, u32& m2w, u32& contw)
+    {
+      const u32 mBits = v5 ? 0x07070707u : 0x03030303u, pat4 = pattern * 0x01010101u, step4 = v5 ? 0x02020202u : 0x01010101u;
+      u32 prev = S.inAll[3u + 8u * wd];    // (the word in front; in front of the staged bytes: 0)
+      m2w = 0u; contw = 0u;
+#pragma unroll
+      for (u32 j = 0; j < 8u; j++)
+      {
+        const u32 x = s_in[8u * wd + j];
+        const u32 px = __builtin_amdgcn_alignbit(x, prev, 24);                    // the bytes in front of x's
+        // (0x80 in the bytes of y that are zero; y's bytes are below 0x80)
+        auto zeroBytes = [](u32 y) { return ~(y + 0x7F7F7F7Fu) & 0x80808080u; };
+        const u32 a = zeroBytes((x ^ 0x02020202u) & mBits), ap = zeroBytes((px ^ 0x02020202u) & mBits);
+        const u32 sg = (x >> 2) & pat4, sp = (px >> 2) & pat4;
+        const u32 any = zeroBytes(sg ^ sp) | zeroBytes(sg ^ ((sp + step4) & pat4)) | zeroBytes(sg);    // sigOk, four bytes at a time
+        const u32 c = a & ap & any;
+        m2w |= ((((a >> 7) * 0x01020408u) >> 24) & 15u) << (4u * j);
+        contw |= ((((c >> 7) * 0x01020408u) >> 24) & 15u) << (4u * j);
+#ifdef LERC_PROBE
+        dbgBoth += (u32)__popc(a & ap); dbgAny += (u32)__popc(any & 0x80808080u); dbgC += (u32)__popc(c);
+#endif
+        prev = x;
+      }
+#ifdef LERC_PROBE
+      dbgCont += (u32)__popc(contw);
+#endif
+      m2w &= rangeMask(32u * wd, dataRel, blobRel);
+      contw &= m2w;    // (in range; the stream's first block goes on from nothing)
+      if (dataRel >= 32u * wd && dataRel < 32u * wd + 32u) contw &= ~(1u << (dataRel - 32u * wd));
+    };
+    u32 m2a, ca, m2b, cb;
+    wordMasks(myWord, m2a, ca); wordMasks(myWord + 1u, m2b, cb);
+    const u64 X = (u64)ca | ((u64)cb << 32), M2 = (u64)m2a | ((u64)m2b << 32);
+    const u64 seed = ((u64)s_end[myWord] | ((u64)s_end[myWord + 1u] << 32)) & M2;
+    const u64 a = X | seed;
+    const u64 s0 = a + seed;
+    const bool gen = s0 < a, prop = !gen && s0 == ~0ull;
+    if (w == 0)
+    {
+      // the bytes in front of the piece's own, a bitmap word a lane.  If ALL of them read like a run and no block is known to end among
+      // them, the run began further in front: its first byte here is taken for a block (the piece in front, which says where its
+      // last block ends, will confirm or refute it)
+      u32 pm2 = 0u, pc = 0u, pseed = 0u;
+      const bool mine = (u32)lane < G::kOwnWord0;
+      if (mine) { wordMasks((u32)lane, pm2, pc); pseed = s_end[lane] & pm2; }
+      const bool likeRun = !mine || (pseed == 0u && (pc | (lane == 0 ? 1u : 0u)) == 0xFFFFFFFFu && (pm2 & 1u) != 0u);
+      if (__all(likeRun) && dataRel == 0u && lane == 0) pseed |= 1u;
+      const u32 a32 = pc | pseed;
+      const u64 s32 = (u64)a32 + (u64)pseed;
+      const bool g32 = mine && (s32 >> 32) != 0u, p32 = mine && !g32 && (u32)s32 == 0xFFFFFFFFu;
+      const u64 Gm = __builtin_amdgcn_ballot_w64(g32), Am = __builtin_amdgcn_ballot_w64(p32) | Gm;
+      const u64 into = (Am + Gm) ^ Am ^ Gm;                                        // lanes a carry goes into
+      const u32 cin = (u32)(into >> lane) & 1u;
+      const u32 cinb = (u32)((u64)a32 + (u64)pseed + cin) ^ a32 ^ pseed;           // bits a carry goes into
+      const u32 F = pseed | (cinb & pc), behind = cinb & ~F & rangeMask(32u * (u32)lane, dataRel, blobRel);
+      if (mine) s_sb[lane] |= F | behind;
+      if (lane == 0) S.preCarry = (u32)(into >> G::kOwnWord0) & 1u;
+    }
+    const u64 Gm = __builtin_amdgcn_ballot_w64(gen), Am = __builtin_amdgcn_ballot_w64(prop) | Gm;
+    {
+      const u64 t = Am + Gm;
+      const u32 co0 = t < Am ? 1u : 0u, co1 = (co0 || t + 1ull == 0ull) ? 1u : 0u;    // the wave's carry out without / with a carry in
+      if (lane == 0) S.fco[w] = co0 | (co1 << 1);
+    }
+    __syncthreads();
+    u32 cw = S.preCarry;
+    for (int k = 0; k < w; k++) cw = (S.fco[k] >> cw) & 1u;
+    const u64 into = (Am + Gm + (u64)cw) ^ Am ^ Gm;
+    const u64 cin = (into >> lane) & 1ull;
+    const u64 cinb = (a + seed + cin) ^ a ^ seed;
+    const u64 F = seed | (cinb & X);
+    const u64 lim = (u64)rangeMask(32u * myWord, dataRel, blobRel) | ((u64)rangeMask(32u * (myWord + 1u), dataRel, blobRel) << 32);
+    const u64 FT = F | (cinb & ~F & lim);
+    s_sb[myWord] |= (u32)FT; s_sb[myWord + 1u] |= (u32)(FT >> 32);
+#ifdef LERC_PROBE
+    atomicAdd(&S.dbg[0], dbgBoth); atomicAdd(&S.dbg[1], (u32)__popcll(X)); atomicAdd(&S.dbg[2], dbgC); atomicAdd(&S.dbg[3], dbgCont);
+#endif
+    if (threadIdx.x == 0) S.frontBad = 0u;    // (everybody has read it; the check below says it again)
+    __syncthreads();
+    buildList();
+    cp = 1u;
+    tilePass(1u, false);
+  }
 
   // ---- a list that does not tile is mended by one thread (see the head of the file): false survivors struck, gaps walked.
   // Nothing is written until the whole list has been gone through; then the survivors' bitmap is corrected and the list built
   // again from it.
-  if (S.nBad[0] != 0u || S.frontBad != 0u)
+  TRACEV(7, cp | (S.frontBad << 4) | (S.nBad[cp] << 8) | (S.nEnt << 16));
+#ifdef LERC_PROBE
+  TRACEV(6, (u64)S.dbg[0] | ((u64)S.dbg[1] << 16) | ((u64)S.dbg[2] << 32) | ((u64)S.dbg[3] << 48));
+#endif
+  if (S.nBad[cp] != 0u || S.frontBad != 0u)
   {
     if (threadIdx.x == 0)
     {
-      const u32 n = S.nEnt, nBad = S.nBad[0];
-      bool good = false;
-      // where the piece's first block begins, if the bytes in front of it say so: where the anchor ends
-      const u32 t0 = S.t0;
-      u32 start0 = 0u;
-      while (start0 < n && (u32)s_list[start0] < t0) start0++;
-      // (the stream's first block is what it is, and so is what the anchor points at; else the piece's first survivor may be a
-      // false one -- and the second)
-      const bool sure = t0 != 0u || (dataRel >= PRE && dataRel < pieceEndRel);
-      const u32 tries = (S.over || nBad > kScanBadCap || n == 0u) ? 0u : (sure ? 1u : 3u);
-      const u32 endTarget = lastPiece ? blobRel : pieceEndRel;
-      for (u32 tr = 0; tr < tries && start0 + tr < n && !good; tr++)
+      if (!OFFS)
       {
-        const u32 start = start0 + tr;
-        u32 nFalse = 0u, nIns = 0u, cur = start;
-        bool fail = start > kScanFalseCap;
-        for (u32 j = 0; j < start && !fail; j++) S.falseIdx[nFalse++] = (u16)j;
-        while (!fail)
+        // (the unmasked bands' kernel: no runs to speak of, no raw blocks of unknown length, no anchor in front of the staged bytes -- the lean
+        // form keeps the kernel at 80 vector registers, three workgroups a CU)
+        const u32 n = S.nEnt, nBad = S.nBad[cp];
+        bool good = false;
+        // where the piece's first block begins, if the bytes in front of it say so: where the anchor ends
+        const u32 t0 = S.t0;
+        u32 start0 = 0u;
+        while (start0 < n && (u32)s_list[start0] < t0) start0++;
+        // (the stream's first block is what it is, and so is what the anchor points at; else the piece's first survivor may be a
+        // false one -- and the second)
+        const bool sure = t0 != 0u || (dataRel >= PRE && dataRel < pieceEndRel);
+        const u32 tries = (S.over || nBad > kScanBadCap || n == 0u) ? 0u : (sure ? 1u : 3u);
+        const u32 endTarget = lastPiece ? blobRel : pieceEndRel;
+        for (u32 tr = 0; tr < tries && start0 + tr < n && !good; tr++)
         {
-          u32 a = 0xFFFFu;    // the first entry from cur on whose link to the next one is broken
-          for (u32 j = 0; j < nBad; j++) { const u32 f = (u32)S.badIdx[j]; if (f >= cur && f < a) a = f; }
-          if (a == 0xFFFFu) { good = true; break; }
-          const u32 pa = (u32)s_list[a], la = parseBlock(pa, false, 0u);
-          if (la == 0u) { fail = true; break; }
-          // from this block's end to the next survivor that begins where a block ends: survivors inside what is walked over are
-          // struck, blocks the scan did not see -- not bit-stuffed, or bit-stuffed behind one that is not -- are entered
-          u32 xx = pa + la, k = a + 1u;
-          for (;;)
+          const u32 start = start0 + tr;
+          u32 nFalse = 0u, nIns = 0u, cur = start;
+          bool fail = start > kScanFalseCap;
+          for (u32 j = 0; j < start && !fail; j++) S.falseIdx[nFalse++] = (u16)j;
+          while (!fail)
           {
-            while (k < n && (u32)s_list[k] < xx && !fail)
+            u32 a = 0xFFFFu;    // the first entry from cur on whose link to the next one is broken
+            for (u32 j = 0; j < nBad; j++) { const u32 f = (u32)S.badIdx[j]; if (f >= cur && f < a) a = f; }
+            if (a == 0xFFFFu) { good = true; break; }
+            const u32 pa = (u32)s_list[a], la = parseBlock(pa, false, 0u);
+            if (la == 0u) { fail = true; break; }
+            // from this block's end to the next survivor that begins where a block ends: survivors inside what is walked over are
+            // struck, blocks the scan did not see -- not bit-stuffed, or bit-stuffed behind one that is not -- are entered
+            u32 xx = pa + la, k = a + 1u;
+            for (;;)
             {
-              if (nFalse < kScanFalseCap) S.falseIdx[nFalse++] = (u16)k; else fail = true;
-              k++;
+              while (k < n && (u32)s_list[k] < xx && !fail)
+              {
+                if (nFalse < kScanFalseCap) S.falseIdx[nFalse++] = (u16)k; else fail = true;
+                k++;
+              }
+              if (fail) break;
+              if (k < n ? xx == (u32)s_list[k] : (lastPiece ? xx == blobRel : xx >= pieceEndRel)) break;
+              if (xx >= endTarget || nIns >= kScanInsCap) { fail = true; break; }
+              const u32 b0 = (s_in[xx >> 2] >> (8u * (xx & 3u))) & 0xFFu;
+              // (a block of pixels that are all zero, or all invalid: one byte -- a masked band has runs of them)
+              const u32 lx = ((b0 & 3u) == 2u && !(v5 && (b0 & 4u))) ? 1u : parseBlock(xx, false, 0u);
+              if (lx == 0u) { fail = true; break; }
+              S.insPos[nIns++] = (u16)xx;
+              xx += lx;
             }
             if (fail) break;
-            if (k < n ? xx == (u32)s_list[k] : (lastPiece ? xx == blobRel : xx >= pieceEndRel)) break;
-            if (xx >= endTarget || nIns >= kScanInsCap) { fail = true; break; }
-            const u32 b0 = (s_in[xx >> 2] >> (8u * (xx & 3u))) & 0xFFu;
-            // (a block of pixels that are all zero, or all invalid: one byte -- a masked band has runs of them)
-            const u32 lx = ((b0 & 3u) == 2u && !(v5 && (b0 & 4u))) ? 1u : parseBlock(xx, false, 0u);
-            if (lx == 0u) { fail = true; break; }
-            S.insPos[nIns++] = (u16)xx;
-            xx += lx;
+            if (k < n) cur = k; else { good = true; break; }
           }
-          if (fail) break;
-          if (k < n) cur = k; else { good = true; break; }
+          if (good)
+          {
+            for (u32 j = 0; j < nFalse; j++) { const u32 pos = (u32)s_list[S.falseIdx[j]]; s_sb[pos >> 5] &= ~(1u << (pos & 31u)); }
+            for (u32 j = 0; j < nIns; j++) { const u32 pos = (u32)S.insPos[j]; s_sb[pos >> 5] |= 1u << (pos & 31u); }
+            S.nIns = nIns; S.nFalse = nFalse;
+          }
         }
-        if (good)
-        {
-          for (u32 j = 0; j < nFalse; j++) { const u32 pos = (u32)s_list[S.falseIdx[j]]; s_sb[pos >> 5] &= ~(1u << (pos & 31u)); }
-          for (u32 j = 0; j < nIns; j++) { const u32 pos = (u32)S.insPos[j]; s_sb[pos >> 5] |= 1u << (pos & 31u); }
-          S.nIns = nIns; S.nFalse = nFalse;
-        }
+        if (!good) S.bad = 1u;
+        S.mended = good ? 1u : 0u;
       }
-      if (!good) S.bad = 1u;
-      S.mended = good ? 1u : 0u;
+      else
+      {
+        const u32 n = S.nEnt, nBad = S.nBad[cp];
+        bool good = false;
+        // where the piece's first block begins, if the bytes in front of it say so: where the anchor ends
+        const u32 t0 = S.t0;
+        u32 start0 = 0u;
+        while (start0 < n && (u32)s_list[start0] < t0) start0++;
+        // (the stream's first block is what it is, and so is what the anchor points at; else the piece's first survivor may be a
+        // false one -- and the second)
+        const bool sure = t0 != 0u || (dataRel >= PRE && dataRel < pieceEndRel);
+        const u32 tries = (S.over || nBad > kScanBadCap) ? 0u : (sure ? 1u : 3u);
+        const u32 endTarget = lastPiece ? blobRel : pieceEndRel;
+        // the length of the block at xx (k: the first list entry behind it), seen by the scan or not
+        auto lenAt = [&](u32 xx, u32 k) -> u32
+        {
+          const u32 b0 = (s_in[xx >> 2] >> (8u * (xx & 3u))) & 0xFFu;
+          // (a block of pixels that are all zero, or all invalid: one byte -- a masked band has runs of them)
+          u32 lx = 0u;
+          if ((b0 & 3u) == 2u && !(v5 && (b0 & 4u))) lx = 1u;
+          else if (OFFS && (b0 & 3u) == 0u && !(v5 && (b0 & 4u)))
+          {
+            // A RAW block of a masked band: the flag byte and its valid pixels' values -- how many, the stream does not say (the
+            // mask does, to who knows the block's place).  Few, where raw beats bit-stuffing (one or two pixels at a mask's edge):
+            // the first count behind which a known block begins, or blocks that parse, one behind the other, up to a known one
+            // (the decode kernel checks every block's length against the mask; a wrong guess here sends the band the long way)
+            // (a known block begins at p, or the piece / the stream ends there)
+            auto known = [&](u32 p) -> bool
+            {
+              u32 lo = k, hi = n;
+              while (lo < hi) { const u32 mid = (lo + hi) >> 1; if ((u32)s_list[mid] < p) lo = mid + 1u; else hi = mid; }
+              return (lo < n && (u32)s_list[lo] == p) || (lastPiece ? p == blobRel : p >= pieceEndRel);
+            };
+            // blocks that parse from p2 on, the signature going on, all the way to a known one (a run of one-byte blocks may lie
+            // between, and one more raw block: a mask's edge, the invalid blocks up to the edge in the next block row, its raw block)
+            // (The signature: block jt of a block row carries jt & pattern -- from codec 5 on two blocks share a value, before that none do;
+            // 0 begins a block row.  Two tilings of the same bytes can agree on everything else: ... raw block of TWO values ... read as a
+            // raw block of one value and a constant block costs the run behind it one byte, and the count comes out the same.)
+            auto chain = [&](auto& self, u32 p2, u32 sgPrev, u32 same, bool sure, u32 depth) -> bool
+            {
+              const u32 maxSame = v5 ? 2u : 1u, step = v5 ? 2u : 1u;
+              for (u32 stp = 0; stp < 160u; stp++)
+              {
+                if (known(p2)) return true;
+                if (p2 + 24u > G::kBytes || p2 >= blobRel) return false;
+                const u32 fq = (s_in[p2 >> 2] >> (8u * (p2 & 3u))) & 0xFFu, sg = (fq >> 2) & pattern;
+                if (v5 && (fq & 4u)) return false;
+                if (sg == 0u) { same = sgPrev == 0u ? same + 1u : 1u; sure = sure || sgPrev != 0u; }
+                else if (sg == sgPrev) { if (++same > maxSame) return false; }
+                else if (sg == ((sgPrev + step) & pattern) && (!sure || same == maxSame)) { same = 1u; sure = true; }
+                else return false;
+                if ((fq & 3u) == 0u)
+                {
+                  if (depth == 0u) return false;
+                  for (u32 nv2 = 1u; nv2 <= 8u; nv2++) if (self(self, p2 + 1u + nv2 * G::TB, sg, same, sure, depth - 1u)) return true;
+                  return false;
+                }
+                const u32 lq = (fq & 3u) == 2u ? 1u : parseBlock(p2, false, 0u);
+                if (lq == 0u) return false;
+                sgPrev = sg; p2 += lq;
+              }
+              return false;
+            };
+            for (u32 nv = 1u; nv <= 8u && lx == 0u; nv++)
+            {
+              const u32 q = xx + 1u + nv * G::TB;
+              if (q > endTarget && lastPiece) break;
+              if (chain(chain, q, (b0 >> 2) & pattern, 1u, false, 1u)) lx = 1u + nv * G::TB;
+  #ifdef HIPSIM
+              if (lx && getenv("LERC_SIM_SCAN_DIAG")) printf("raw block at blob offset %u: %u values\n", pieceStart + xx - PRE, nv);
+  #endif
+            }
+          }
+          else lx = parseBlock(xx, false, 0u);
+          return lx;
+        };
+        // (a masked band: the first attempt walks from the anchor's end, if that lies in front of the first entry; an anchor that leads
+        // nowhere is forgotten -- the piece in front has the last word on where this one's first block begins)
+        const bool frontGap = OFFS && t0 != 0u && (start0 >= n || t0 < (u32)s_list[start0]) && t0 < endTarget;
+        for (u32 att = frontGap ? 0u : 1u; tries != 0u && att <= tries && !good; att++)
+        {
+          const u32 tr = att == 0u ? 0u : att - 1u;
+          if (att != 0u && start0 + tr >= n) break;
+          const u32 start = start0 + tr;
+          u32 nFalse = 0u, nIns = 0u, cur = start, mendExit = 0u, firstOwn = 0u;
+          bool fail = start > kScanFalseCap;
+          for (u32 j = 0; j < start && !fail; j++) S.falseIdx[nFalse++] = (u16)j;
+          // (a masked band: blocks between the anchor's end and the first entry are walked like those behind a broken link)
+          bool wasFront = false;
+          bool front = att == 0u;
+          while (!fail)
+          {
+            u32 xx, k;
+            if (front) { xx = t0; k = start; front = false; wasFront = true; }
+            else
+            {
+              u32 a = 0xFFFFu;    // the first entry from cur on whose link to the next one is broken
+              for (u32 j = 0; j < nBad; j++) { const u32 f = (u32)S.badIdx[j]; if (f >= cur && f < a) a = f; }
+              if (a == 0xFFFFu) { good = true; break; }
+              const u32 pa = (u32)s_list[a], la = lenAt(pa, a + 1u);
+              if (la == 0u) { fail = true; break; }
+              xx = pa + la; k = a + 1u;
+            }
+            // from this block's end to the next survivor that begins where a block ends: survivors inside what is walked over are
+            // struck, blocks the scan did not see -- not bit-stuffed, or bit-stuffed behind one that is not -- are entered
+            for (;;)
+            {
+              while (k < n && (u32)s_list[k] < xx && !fail)
+              {
+                if (nFalse < kScanFalseCap) S.falseIdx[nFalse++] = (u16)k; else fail = true;
+                k++;
+              }
+              if (fail) break;
+              if (OFFS && xx >= PRE && firstOwn == 0u) firstOwn = xx;
+              if (k < n ? xx == (u32)s_list[k] : (lastPiece ? xx == blobRel : xx >= pieceEndRel)) break;
+              if (xx >= endTarget || nIns >= kScanInsCap) { fail = true; break; }
+              const u32 lx = lenAt(xx, k);
+              if (lx == 0u) { fail = true; break; }
+              if (!OFFS || xx >= PRE) S.insPos[nIns++] = (u16)xx;    // (blocks in front of the piece's own bytes are the piece's in front)
+              xx += lx;
+            }
+            if (fail) break;
+            if (k < n) cur = k; else { good = true; if (OFFS) mendExit = xx; break; }
+          }
+          if (good)
+          {
+            for (u32 j = 0; j < nFalse; j++) { const u32 pos = (u32)s_list[S.falseIdx[j]]; s_sb[pos >> 5] &= ~(1u << (pos & 31u)); }
+            for (u32 j = 0; j < nIns; j++) { const u32 pos = (u32)S.insPos[j]; s_sb[pos >> 5] |= 1u << (pos & 31u); }
+            S.nIns = nIns; S.nFalse = nFalse;
+            if (OFFS) { S.mendExit = mendExit; if (wasFront) S.t0 = firstOwn; else if (frontGap) S.t0 = 0u; }    // (where the piece's first block begins, now that the walk from the anchor's end has been there)
+          }
+        }
+  #ifdef HIPSIM
+        if (OFFS && getenv("LERC_SIM_SCAN_DIAG") && !good)
+        {
+          printf("piece %u: mending failed: n %u nBad %u t0 %u start0 %u tries %u; bad entries:", wg, n, nBad, t0, start0, tries);
+          for (u32 j = 0; j < nBad && j < 8u; j++) { const u32 f = S.badIdx[j]; const u32 pos = s_list[f]; printf(" [%u] at %u len %u flag %02x next %u;", f, pos, parseBlock(pos, false, 0u), (s_in[pos >> 2] >> (8u * (pos & 3u))) & 0xFFu, f + 1u < n ? (u32)s_list[f + 1u] : 0u); }
+          printf("\n   survivors in front:");
+          for (u32 wd = 0; wd < G::kOwnWord0; wd++) for (u32 bt = 0; bt < 32u; bt++) if (s_sb[wd] >> bt & 1u) printf(" %u(+%u)", 32u * wd + bt, parseBlock(32u * wd + bt, false, 0u));
+          printf("\n");
+          { const u32 f = S.badIdx[0]; const u32 pos = s_list[f]; const u32 e = nBad ? pos + parseBlock(pos, false, 0u) : t0 - 40u; printf("   bytes from %u:", e); for (u32 j = 0; j < 160u; j++) printf(" %02x", (s_in[(e + j) >> 2] >> (8u * ((e + j) & 3u))) & 0xFFu); printf("\n"); }
+        }
+  #endif
+        if (!good) S.bad = 1u;
+        S.mended = good ? 1u : 0u;
+      }
     }
     __syncthreads();
     if (S.mended)
     {
       buildList();
-      tilePass(1u);
-      if (S.nBad[1] != 0u) S.bad = 1u;    // (mended once; a list that still does not tile goes the long way)
+      tilePass(cp + 1u, true);
+      if (S.nBad[cp + 1u] != 0u) S.bad = 1u;    // (mended once; a list that still does not tile goes the long way)
     }
-  }
-
-  // ---- A masked band: where this piece ends.  A piece's first block is the first one in its bytes that is bit-stuffed AND stands
-  // behind a bit-stuffed one (START & END: the scan knows no other blocks, and the mending only walks BETWEEN survivors), so what
-  // begins behind this piece's end in front of such a block -- a run of one-byte blocks of pixels that are all invalid, a
-  // constant block, the bit-stuffed block behind them, whose END nobody sets -- is this piece's: one thread walks them (they
-  // are staged: a block's length more than the unmasked bands need).
-  if (OFFS)
-  {
-    if (threadIdx.x == 0 && !S.bad && S.nEnt != 0u && !lastPiece)
-    {
-      u32 n = S.nEnt, xx = S.exitRel;
-      bool prevStuffed = ((s_in[(u32)s_list[n - 1u] >> 2] >> (8u * ((u32)s_list[n - 1u] & 3u))) & 3u) == 1u;
-      while (xx < blobRel)    // (at the stream's end the pieces behind hold nothing)
-      {
-        if (xx + 24u > G::kBytes) { S.bad = 1u; break; }
-        const bool curStuffed = ((s_in[xx >> 2] >> (8u * (xx & 3u))) & 3u) == 1u;
-        if (prevStuffed && curStuffed) break;    // a block the piece behind sees: bit-stuffed behind a bit-stuffed one
-        const u32 lx = parseBlock(xx, false, 0u);
-        if (lx == 0u || n >= kListCap || xx + lx + 24u > G::kBytes) { S.bad = 1u; break; }
-        s_list[n++] = (u16)xx;
-        prevStuffed = curStuffed;
-        xx += lx;
-      }
-      S.nEnt = n; S.exitRel = xx;
-    }
-    __syncthreads();
   }
 
   // ---- count out: blocks of this piece, and where its last block ends (relative to the piece's end)
@@ -783,8 +1112,13 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     else if (wg == firstPiece) bad = bad || first != dataRel;
     else bad = bad || S.prevExit == 0xFFFFu || first != PRE + S.prevExit;
     if (total == 0u && !lastPiece && wg >= firstPiece) bad = true;    // (a piece is longer than any block)
-    TRACEV(8, total); TRACEV(9, S.nBad[0]); TRACEV(10, S.nBad[1]); TRACEV(11, (S.over ? 1u : 0u) | (S.bad ? 2u : 0u) | (bad ? 4u : 0u) | (S.mended ? 8u : 0u));
+    TRACEV(8, total); TRACEV(9, S.nBad[0]); TRACEV(10, S.nBad[1] | (S.nBad[2] << 16)); TRACEV(11, (S.over ? 1u : 0u) | (S.bad ? 2u : 0u) | (bad ? 4u : 0u) | (S.mended ? 8u : 0u));
     TRACEV(12, first); TRACEV(13, PRE + S.prevExit); TRACEV(14, S.nIns); TRACEV(15, S.nFalse);
+#ifdef HIPSIM
+    if (OFFS && getenv("LERC_SIM_SCAN_DIAG") && (bad || S.over || getenv("LERC_SIM_SCAN_DIAG")[0] == '2'))
+      printf("piece %u: total %u first %u expected %u t0 %u nBad %u %u %u frontBad %u over %u S.bad %u mended %u nIns %u nFalse %u exit %u pieceEnd %u blobRel %u dataRel %u\n", wg, total, first, PRE + S.prevExit, S.t0,
+             S.nBad[0], S.nBad[1], S.nBad[2], S.frontBad, S.over, S.bad, S.mended, S.nIns, S.nFalse, S.exitRel, pieceEndRel, blobRel, dataRel);
+#endif
     if (bad) raiseFlag(b, 1);
     // the pieces hold all the raster's blocks, or the band goes the long way
     const u32 nBlocksWanted = OFFS ? job.nPos : hp.nBlocks;

@@ -1268,6 +1268,47 @@ def test_sim_masked_bands_are_cut_into_blocks_by_the_scan(libs):
     assert served == 7, ("the scan did not serve every masked band", served, S.last_note())
 
 
+def test_sim_masked_bands_with_runs_and_raw_blocks(libs):
+    """What a mask's shape does to a band's block stream, and the scan (MODE 1) has to follow: RUNS of one-byte blocks (blocks without
+    a valid pixel) -- found by the flood from the survivors' ends, also where a run is longer than the bytes a piece stages in front of
+    its own (the run's first byte there is taken for a block; the piece in front confirms it) or crosses block rows; RAW blocks of one or
+    two valid pixels at curved and slanted edges, whose length only the mask knows (the mending tries the counts and wants the blocks
+    behind to parse up to a known one, the column signature going on in pairs); a raw block, the run to the next block row's edge, its
+    raw block.  Every band here is served by the scan, pixels and masks as the oracle has them."""
+    O, S = libs
+    rng = np.random.default_rng(7)
+    def ellipse(r, c):
+        ii, jj = np.mgrid[0:r, 0:c]
+        return ((ii - r / 2) ** 2 / (0.45 * r) ** 2 + (jj - c / 2) ** 2 / (0.44 * c) ** 2 < 1).astype(np.uint8)
+    def diagonal(r, c):
+        ii, jj = np.mgrid[0:r, 0:c]
+        return ((ii + jj) % 300 < 200).astype(np.uint8)
+    def cols(r, c, j0, j1, rows=None):
+        m = np.ones((r, c), np.uint8); m[:, j0:j1] = 0
+        if rows: m[rows[0]:rows[1]] = rows[2]
+        return m
+    todo = (("a third of every row", 64, 4096, np.float32, 0.01, cols(64, 4096, 0, 1365)),
+            ("the right half and the left quarter", 64, 4096, np.float32, 0.01, cols(64, 4096, 2048, 4096) & cols(64, 4096, 0, 1024)),
+            ("block rows without a pixel", 160, 1024, np.float32, 0.01, cols(160, 1024, 0, 0, (40, 80, 0))),
+            ("runs of 350", 32, 8192, np.uint16, 0, cols(32, 8192, 1000, 3800)),
+            ("runs of 400, a block row without", 32, 8192, np.uint16, 0, cols(32, 8192, 3000, 6200, (8, 16, 1))),
+            ("runs of 650: longer than what a piece stages in front", 32, 8192, np.float32, 0.01, cols(32, 8192, 500, 5700)),
+            ("an ellipse", 200, 1600, np.float32, 0.01, ellipse(200, 1600)),
+            ("an ellipse, 16 bit", 200, 1600, np.int16, 0, ellipse(200, 1600)),
+            ("slanted bands", 200, 1600, np.float32, 0.01, diagonal(200, 1600)),
+            ("slanted bands, 32 bit", 200, 1600, np.int32, 0, diagonal(200, 1600)))
+    for name, r, c, dt, e, m in todo:
+        x = cases._cast(cases.terrain(r, c, rng, amp=300, base=1000, sigma=2.0), dt)
+        rc, blob = O.encode(x, e, mask=m)
+        assert rc == 0
+        f0 = S.decode_forms()
+        d1, d2 = O.decode(blob), S.decode(blob)
+        f1 = S.decode_forms()
+        v = d1[2].reshape(r, c) != 0
+        assert d1[0] == d2[0] == 0 and np.array_equal(d1[2], d2[2]) and np.array_equal(d1[1].reshape(r, c)[v], d2[1].reshape(r, c)[v]), name
+        assert f1[0] - f0[0] == 1, ("the scan did not serve the band", name, S.last_note())
+
+
 def test_sim_workgroups_that_give_up_waiting(libs):
     """LERC_AMD_TEST_GIVEUP: every hand-off inside the one-launch encoder and the streaming decoder arrives with a tag nobody
     waits for; the waiters run into their poll limit, say so, and the host repeats the call on the general kernels --

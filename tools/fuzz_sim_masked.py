@@ -23,7 +23,7 @@ while time.time() - t0 < budget:
     x = cases._cast(x, dt)
     e = float(rng.choice([0, 0.001, 0.01, 0.5, 1, 3])) if kind == "f" else float(rng.choice([0, 0, 1, 4]))
     kw = {"n_depth": nd} if nd > 1 else {}
-    mk = int(rng.integers(0, 5))
+    mk = int(rng.integers(0, 8))
     if mk:
         m = np.ones((r, c), np.uint8)
         if mk == 1:
@@ -31,7 +31,13 @@ while time.time() - t0 < budget:
                 i0, j0 = int(rng.integers(0, r)), int(rng.integers(0, c)); m[i0:i0 + int(rng.integers(1, 40)), j0:j0 + int(rng.integers(1, 90))] = 0
         elif mk == 2: m = (rng.random((r, c)) > rng.random() * 0.7).astype(np.uint8)
         elif mk == 3: m[:, : c // 2] = 0; m[r // 2, 3] = 1
-        else: m = (((np.arange(r)[:, None] // 7) + (np.arange(c)[None, :] // 19)) % 3 != 0).astype(np.uint8)
+        elif mk == 4: m = (((np.arange(r)[:, None] // 7) + (np.arange(c)[None, :] // 19)) % 3 != 0).astype(np.uint8)
+        elif mk == 5:    # an ellipse: curved edges (blocks of one or two valid pixels: raw blocks), the rest of each row invalid
+            ii, jj = np.mgrid[0:r, 0:c]; m = (((ii - r / 2) / (r * rng.uniform(0.2, 0.6))) ** 2 + ((jj - c / 2) / (c * rng.uniform(0.2, 0.6))) ** 2 < 1).astype(np.uint8)
+        elif mk == 6:    # diagonal bands
+            ii, jj = np.mgrid[0:r, 0:c]; w = int(rng.integers(20, 400)); m = ((ii * int(rng.integers(1, 4)) + jj) % w < w * rng.uniform(0.2, 0.9)).astype(np.uint8)
+        else:            # long runs: columns and rows without a valid pixel
+            j0 = int(rng.integers(0, c)); m[:, j0:j0 + int(rng.integers(c // 4, c))] = 0; i0 = int(rng.integers(0, r)); m[i0:i0 + int(rng.integers(1, 60))] = int(rng.integers(0, 2))
         if not m.any(): m[0, 0] = 1
         kw["mask"] = m
     tag = f"{np.dtype(dt).name} {r}x{c}x{nd} e={e} style={style} mask={mk}"
@@ -56,4 +62,5 @@ while time.time() - t0 < budget:
         bb = bytearray(b1); bb[int(rng.integers(100, len(bb)))] ^= 1 << int(rng.integers(0, 8))
         if (O.decode(bytes(bb))[0] == 0) != (S.decode(bytes(bb))[0] == 0):
             bad += 1; print("VERDICT MISMATCH on a damaged copy", tag)
-print("cases", n, "mismatches", bad)
+f = S.decode_forms()
+print("cases", n, "mismatches", bad, "; masked bands cut into blocks by the scan:", f[0])

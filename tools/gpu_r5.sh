@@ -6,7 +6,7 @@ set -u
 OUT=$PWD/gpurun_out; mkdir -p "$OUT"
 run() {  # name, then env assignments
   local name=$1; shift
-  env "$@" python bench.py --steps ${STEPS:-20} --warmup 5 --no-cpu-baseline --no-c5-anchor --no-other-configs --rotate 0 2>"$OUT/r5_$name.err" | python -c "
+  timeout 120 env "$@" python bench.py --steps ${STEPS:-20} --warmup 5 --no-cpu-baseline --no-c5-anchor --no-other-configs --rotate 0 2>"$OUT/r5_$name.err" | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('$name', 'ms_per_step', d['ms_per_step'], 'frac', d['roundtrip']['frac_of_hbm_peak_wall'], 'verified', d['config']['verified'], ' '.join(f\"{k}={v['avg_ms']*1000:.1f}\" for k,v in d['kernels'].items()))

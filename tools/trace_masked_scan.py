@@ -47,6 +47,10 @@ for k, nm in enumerate(names):
 
 v = tt[:, 8:16]
 odd = np.nonzero((v[:, 3] & 7) != 0)[0]
+w7 = tt[:, 7]
+print("at the mending's door: flooded", int(((w7 & 15) == 1).sum()), "front mismatch", int((((w7 >> 4) & 15) != 0).sum()), "broken links left: mean %.2f" % ((w7 >> 8) & 255).mean(), "pieces with any", int((((w7 >> 8) & 255) != 0).sum()))
+w6 = tt[:, 6]
+print("flood, mean per piece: both %.1f, X %.1f, c %.1f, contw before the range mask %.1f" % ((w6 & 0xFFFF).mean(), ((w6 >> 16) & 0xFFFF).mean(), ((w6 >> 32) & 0xFFFF).mean(), ((w6 >> 48) & 0xFFFF).mean()))
 print("pieces with a flag:", len(odd), "of", len(tt), "; mended:", int(((v[:, 3] & 8) != 0).sum()))
 print("   first broken links: mean %.1f max %d; entries struck: mean %.1f max %d; blocks entered: mean %.1f max %d" %
       (v[:, 1].mean(), v[:, 1].max(), v[:, 7].mean(), v[:, 7].max(), v[:, 6].mean(), v[:, 6].max()))
