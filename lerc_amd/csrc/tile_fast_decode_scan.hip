@@ -107,7 +107,7 @@ template<class T> struct ScanShared
   u64 fa[G::NT / 64], fb[G::NT / 64];
   u64 part;                                          // sum of the cells: this group's in the low half, the groups' in front in the high half
   u32 t0, frontBad;                                  // where the anchor ends (0: no anchor); the list's first entries lie in front of that
-  u32 nEnt, nBad[3], nFalse, nIns, over, bad, lost, exitRel, prevExit, mended;    // nBad: broken links found by the first / the second / the third check
+  u32 nEnt, nBad[4], nStruck[4], nFalse, nIns, over, bad, lost, exitRel, prevExit, mended;    // nBad: broken links found by the first / the second / the third check
   u32 mendExit;                                      // MODE 1: where the piece's last block ends, if the mending had to find out (a raw block: see there)
 #ifdef LERC_PROBE
   u32 dbg[4];
@@ -266,7 +266,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   if (threadIdx.x < 4u) S.inAll[threadIdx.x] = 0u;
   if (threadIdx.x == 0)
   {
-    S.nEnt = 0u; S.frontBad = 0u; S.t0 = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nBad[2] = 0u; S.preCarry = 0u; S.mendExit = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
+    S.nEnt = 0u; S.frontBad = 0u; S.t0 = 0u; S.nBad[0] = 0u; S.nBad[1] = 0u; S.nBad[2] = 0u; S.nBad[3] = 0u; S.nStruck[0] = 0u; S.nStruck[1] = 0u; S.nStruck[2] = 0u; S.nStruck[3] = 0u; S.preCarry = 0u; S.mendExit = 0u; S.nFalse = 0u; S.nIns = 0u; S.over = 0u; S.bad = 0u; S.lost = 0u; S.exitRel = 0u;
 #ifdef LERC_PROBE
     S.dbg[0] = S.dbg[1] = S.dbg[2] = S.dbg[3] = 0u;
 #endif
@@ -348,56 +348,111 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     // (a wave takes the units it queued itself: no counter to share -- but the bytes around them are other waves')
     const u32 nQ = S.qn[w];
     if (nQ > kQueueSeg && lane == 0) S.over = 1u;
-    for (u32 hq = (u32)lane; hq < min(nQ, kQueueSeg); hq += 64u)
+    // what stands around the count byte at q: every offset type's flag byte, the block's length, the flag byte behind it -- and its START / END bits
+    auto candidate = [&](u32 q)
     {
-      const u32 h = (u32)w * kQueueSeg + hq;
-      // the scan, second half: which bytes of the unit -- exactly: 64 behind 10?nnnnn, n != 0; a bit per byte, bit k: byte
-      // 4 (k & 3) + (k >> 2)
-      const u32 unit = (u32)s_queue[h];
+      const u32 wi = (q + 6u) >> 2, sh = 8u * ((q + 6u) & 3u);             // (word index into inAll: 16 bytes of zeros in front)
+      const u32 w0 = S.inAll[wi], w1 = S.inAll[wi + 1], w2 = S.inAll[wi + 2], w3 = S.inAll[wi + 3];
+      const u32 a0 = __builtin_amdgcn_alignbit(w1, w0, sh), a1 = __builtin_amdgcn_alignbit(w2, w1, sh), a2 = __builtin_amdgcn_alignbit(w3, w2, sh);
+      const u32 tB = (a2 >> 8) & 0xFFu, nb = tB & 31u, lut = (tB >> 5) & 1u;
+      const u32 nLut = ((a2 >> 24) - 1u) & 0xFFu;                          // valid: 1 ... 254
+      const bool okLut = (lut == 0u) | ((nLut - 1u) < 254u);
+      const u32 cnt = OFFS ? ((a2 >> 16) & 0xFFu) : 64u;                       // elements of the block: the count byte
+      const u32 payload = lut ? 1u + ((nLut * nb + 7u) >> 3) + ((cnt * (u32)bitLen(nLut) + 7u) >> 3) : ((cnt * nb + 7u) >> 3);
+#pragma unroll
+      for (u32 tc = 0; tc < 4; tc++)
+      {
+        const u32 offB = (offBytesTable<DT>() >> (4u * tc)) & 15u;
+        if (offB == 0u) continue;
+        const u32 m = 8u - offB;                                           // the flag byte is byte m of the twelve
+        const u32 flag = ((m < 4u ? a0 : m < 8u ? a1 : a2) >> (8u * (m & 3u))) & 0xFFu;
+        const u32 len = 3u + offB + payload;
+        const bool ok = (flag & 3u) == 1u && (flag >> 6) == tc && !(v5 && (flag & 4u)) && okLut && len <= (OFFS ? 1u + cnt * G::TB : RAW) && q >= 2u + offB;    // (no longer than the raw form of so many values)
+        const u32 p = q - 2u - offB, e = p + len;
+        // (what stands where the candidate ends has to read like the flag byte of the block behind it: the column signature goes
+        // on, by a step or none, or begins again with a block row -- four bytes in five of anything else do not)
+        bool follows = true;
+        if (ok && e < blobRel && e < G::kBytes)
+        {
+          const u32 nf = (s_in[e >> 2] >> (8u * (e & 3u))) & 0xFFu;
+          follows = sigOk((flag >> 2) & pattern, (nf >> 2) & pattern, pattern) && !(v5 && (nf & 4u));
+        }
+        if (ok && follows && p >= dataRel && p < pieceEndRel && e <= blobRel)
+        {
+          atomicOr(&s_sb[p >> 5], 1u << (p & 31u));
+          atomicOr(&s_end[e >> 5], 1u << (e & 31u));                      // (e < pieceEndRel + W: inside the bitmap)
+        }
+      }
+    };
+    // the scan, second half: which bytes of a unit -- exactly: 64 (a masked band: 1 ... 64) behind 10?nnnnn, n != 0; a bit per byte,
+    // bit k: byte 4 (k & 3) + (k >> 2)
+    auto unitHits = [&](u32 unit) -> u32
+    {
       const uint4 xu = *reinterpret_cast<const uint4*>(&s_in[4u * unit]);
       const u32 pvu = S.inAll[4u * unit + 3u];                               // (the dword in front of the unit; in front of the staged bytes: 0)
       const u32 m0 = countByteHits<OFFS>(xu.x, pvu), m1 = countByteHits<OFFS>(xu.y, xu.x), m2 = countByteHits<OFFS>(xu.z, xu.y), m3 = countByteHits<OFFS>(xu.w, xu.z);
       const u32 zb = (m0 >> 7) | ((m1 >> 7) << 1) | ((m2 >> 7) << 2) | ((m3 >> 7) << 3);
       const u32 tb = zb | (zb >> 4);
-      u32 hits = (tb & 0xFFu) | ((tb >> 8) & 0xFF00u);
-      while (hits)
+      return (tb & 0xFFu) | ((tb >> 8) & 0xFF00u);
+    };
+    if (!OFFS)
+    {
+      // (a unit with a hit has one, as good as always: lane = unit)
+      for (u32 hq = (u32)lane; hq < min(nQ, kQueueSeg); hq += 64u)
       {
-        const u32 k = (u32)__ffs((int)hits) - 1u;
-        hits &= hits - 1u;
-        const u32 q = 16u * unit + 4u * (k & 3u) + (k >> 2);                // the count byte
-        const u32 wi = (q + 6u) >> 2, sh = 8u * ((q + 6u) & 3u);             // (word index into inAll: 16 bytes of zeros in front)
-        const u32 w0 = S.inAll[wi], w1 = S.inAll[wi + 1], w2 = S.inAll[wi + 2], w3 = S.inAll[wi + 3];
-        const u32 a0 = __builtin_amdgcn_alignbit(w1, w0, sh), a1 = __builtin_amdgcn_alignbit(w2, w1, sh), a2 = __builtin_amdgcn_alignbit(w3, w2, sh);
-        const u32 tB = (a2 >> 8) & 0xFFu, nb = tB & 31u, lut = (tB >> 5) & 1u;
-        const u32 nLut = ((a2 >> 24) - 1u) & 0xFFu;                          // valid: 1 ... 254
-        const bool okLut = (lut == 0u) | ((nLut - 1u) < 254u);
-        const u32 cnt = OFFS ? ((a2 >> 16) & 0xFFu) : 64u;                       // elements of the block: the count byte
-        const u32 payload = lut ? 1u + ((nLut * nb + 7u) >> 3) + ((cnt * (u32)bitLen(nLut) + 7u) >> 3) : ((cnt * nb + 7u) >> 3);
-#pragma unroll
-        for (u32 tc = 0; tc < 4; tc++)
+        const u32 unit = (u32)s_queue[(u32)w * kQueueSeg + hq];
+        u32 hits = unitHits(unit);
+        while (hits)
         {
-          const u32 offB = (offBytesTable<DT>() >> (4u * tc)) & 15u;
-          if (offB == 0u) continue;
-          const u32 m = 8u - offB;                                           // the flag byte is byte m of the twelve
-          const u32 flag = ((m < 4u ? a0 : m < 8u ? a1 : a2) >> (8u * (m & 3u))) & 0xFFu;
-          const u32 len = 3u + offB + payload;
-          const bool ok = (flag & 3u) == 1u && (flag >> 6) == tc && !(v5 && (flag & 4u)) && okLut && len <= (OFFS ? 1u + cnt * G::TB : RAW) && q >= 2u + offB;    // (no longer than the raw form of so many values)
-          const u32 p = q - 2u - offB, e = p + len;
-          // (what stands where the candidate ends has to read like the flag byte of the block behind it: the column signature goes
-          // on, by a step or none, or begins again with a block row -- four bytes in five of anything else do not)
-          bool follows = true;
-          if (ok && e < blobRel && e < G::kBytes)
+          const u32 k = (u32)__ffs((int)hits) - 1u;
+          hits &= hits - 1u;
+          candidate(16u * unit + 4u * (k & 3u) + (k >> 2));
+        }
+      }
+    }
+    else
+    {
+      // A masked band: any byte 1 ... 64 behind 10?nnnnn is a hit -- two thousand a piece, two in three of them no block, a unit holds up
+      // to eight.  Lane = unit would have the wave go round as often as its busiest lane has hits: the hits are laid out first, one
+      // behind the other (the wave's stretch of the queue, read by then, holds them), and taken 64 at a time, lane = hit.
+      u32 hm[kRounds], un[kRounds];
+#pragma unroll
+      for (int j = 0; j < kRounds; j++)
+      {
+        const u32 hq = (u32)lane + 64u * (u32)j;
+        hm[j] = 0u; un[j] = 0u;
+        if (hq < min(nQ, kQueueSeg)) { un[j] = (u32)s_queue[(u32)w * kQueueSeg + hq]; hm[j] = unitHits(un[j]); }
+      }
+      __builtin_amdgcn_wave_barrier();    // (every lane has read its queue entries: the stretch is free)
+      u16* const buf = &s_queue[(u32)w * kQueueSeg];
+      static_assert(kQueueSeg >= 128u, "room for a wave's worth of hits and what is left of the last");
+      u32 fill = 0u;
+#pragma unroll
+      for (int j = 0; j < kRounds; j++)
+      {
+        u32 m = hm[j];
+        while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull)
+        {
+          const bool has = m != 0u;
+          u32 q = 0u;
+          if (has) { const u32 k = (u32)__ffs((int)m) - 1u; m &= m - 1u; q = 16u * un[j] + 4u * (k & 3u) + (k >> 2); }
+          const u64 bal = __builtin_amdgcn_ballot_w64(has);
+          if (has) buf[fill + (u32)__popcll(bal & laneMaskLt())] = (u16)q;
+          fill += (u32)__popcll(bal);
+          __builtin_amdgcn_wave_barrier();
+          if (fill >= 64u)
           {
-            const u32 nf = (s_in[e >> 2] >> (8u * (e & 3u))) & 0xFFu;
-            follows = sigOk((flag >> 2) & pattern, (nf >> 2) & pattern, pattern) && !(v5 && (nf & 4u));
-          }
-          if (ok && follows && p >= dataRel && p < pieceEndRel && e <= blobRel)
-          {
-            atomicOr(&s_sb[p >> 5], 1u << (p & 31u));
-            atomicOr(&s_end[e >> 5], 1u << (e & 31u));                      // (e < pieceEndRel + W: inside the bitmap)
+            candidate((u32)buf[lane]);
+            const u32 rest = fill - 64u;
+            const u32 mv = (u32)lane < rest ? (u32)buf[64u + (u32)lane] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            if ((u32)lane < rest) buf[lane] = (u16)mv;
+            __builtin_amdgcn_wave_barrier();
+            fill = rest;
           }
         }
       }
+      if ((u32)lane < fill) candidate((u32)buf[lane]);
     }
     if (threadIdx.x == 0 && dataRel >= PRE && dataRel < pieceEndRel)    // the stream's first block, whatever it is
     {
@@ -598,6 +653,18 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       const u32 ext = pos + len;
       const bool ok = len != 0u && (last ? (lastPiece ? ext == blobRel : ext >= pieceEndRel) : ext == nxt);
       if (!ok) { const u32 at = atomicAdd(&S.nBad[pass], 1u); if (at < kScanBadCap) S.badIdx[at] = (u16)f; }
+      if (OFFS && !final && !ok && len != 0u)
+      {
+        // a block that ends where the entry after next begins (or the one after that): what lies between is no block -- false
+        // survivors, struck here by the lane that sees it (the list is built again before anybody trusts it)
+        for (u32 d = 2u; d <= 3u && f + d < nEnt; d++)
+          if ((u32)s_list[f + d] == ext)
+          {
+            for (u32 j = 1u; j < d; j++) { const u32 q = (u32)s_list[f + j]; atomicAnd(&s_sb[q >> 5], ~(1u << (q & 31u))); }
+            atomicAdd(&S.nStruck[pass], 1u);
+            break;
+          }
+      }
       if (OFFS && pass == 0u && len != 0u && ext < G::kBytes) atomicOr(&s_end[ext >> 5], 1u << (ext & 31u));    // (a seed of the flood)
       if (last) S.exitRel = ext;
       if (f == 0u)    // (entries in front of where the anchor ends are none; a masked band: blocks between there and the first entry are missing)
@@ -726,6 +793,14 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     buildList();
     cp = 1u;
     tilePass(1u, false);
+  }
+
+  // (a masked band: the lanes have struck false survivors, and links are still broken -- maybe theirs: look again)
+  if (OFFS && S.nBad[cp] != 0u && S.nStruck[cp] != 0u)
+  {
+    buildList();
+    cp++;
+    tilePass(cp, false);
   }
 
   // ---- a list that does not tile is mended by one thread (see the head of the file): false survivors struck, gaps walked.
