@@ -28,6 +28,19 @@
 //      then takes the band to the next tier (and keeps to it for a while: codec_decode.cpp);
 //   6. count out (an epoch-tagged cell: blocks of the piece, where its last block ends), the cells of the pieces in front added
 //      up -- the only wait --, then the pixels as in tile_fast_decode_one.hip: lane = V pixels of one block row.
+// Two more rules keep false candidates rare: a candidate is no longer than its raw form would be, and the byte where it ends has
+// to read like the flag byte of the next block -- the column signature going on, by a step or none, or beginning again with a
+// block row (four in five of anything else do not).  The ANCHOR -- where the piece's first block begins -- comes from the last
+// survivors in FRONT of the piece's own bytes, not from the own bytes' first survivor (a false one there may tile with what follows).
+//
+// MODE 1 cuts the block stream of a band WITH A MASK into blocks (k_fast_scan_offsets; the general kernels decode the pixels,
+// which need the mask): count bytes of 1 ... 64; RUNS of one-byte blocks (no valid pixel) found by a FLOOD over the bitmaps, seeded
+// where the survivors end, its carries between threads and waves by two ballots; false survivors struck by the lane that sees a
+// block end at the entry after next; the hits laid out one behind the other and taken lane = hit (a unit holds up to eight);
+// the one thread's mending left with RAW blocks, whose length only the mask knows (counts are tried against a chain of blocks
+// that parse, the signature going on in pairs, up to a known block -- a guess the decode kernels, which have the mask, may refuse:
+// the general discovery then takes the band).  A piece owns the blocks that begin in its bytes.  Limits: 2048 blocks a piece (streams
+// of mostly one-byte blocks go to the general discovery), 8 x 8 blocks, one value a pixel, 16-bit and wider types.
 // Rasters whose rows / columns are no multiples of 8 keep to the next tier (their edge blocks have other counts).
 // Reference: Lerc2.cpp:1672-1713, :2025-2230; BitStuffer2.cpp:159-258, :476-540; Lerc2.cpp:1037-1064 (checksum).
 #include "tile_fast_decode_dev.h"
@@ -61,7 +74,7 @@ extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_deco
 #ifndef LERC_SCAN_HELD16
 #define LERC_SCAN_HELD16 2
 #endif
-static const u32 kScanBadCap = 64, kScanFalseCap = 64, kScanInsCap = 128;    // (a masked band's pieces: three false survivors and a run or two of one-byte blocks each)
+static const u32 kScanBadCap = 64, kScanFalseCap = 64, kScanInsCap = 128;    // (the one thread's mending: broken links, entries struck, blocks entered -- a masked band enters into END's bitmap, 2048)
 
 template<class T> struct ScanGeom
 {
@@ -152,7 +165,8 @@ __device__ __forceinline__ u32 scanRangeMask(u32 base, u32 lo, u32 hi)
 
 // MODE 1 (tile_decode.hip's kernels decode the pixels): the block stream of a band with a MASK -- a block holds 1 ... 64 pixels and its
 // count byte says how many; a block without a valid pixel is one byte, "all zero" (Lerc2.h:422) -- is only cut into blocks: where
-// block k of the stream begins goes to blockOff[k].
+// block k of the stream begins goes to blockOff[k].  A piece's blocks are those that begin in its own bytes; the piece in front says
+// where its last block ends, and this piece's first block has to begin there.
 struct ScanOffsetsJob
 {
   u32 version, dataBegin, blobEnd;    // of the band (the host has read its header and mask)
@@ -708,9 +722,6 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   {
     auto rangeMask = [&](u32 base, u32 lo, u32 hi) -> u32 { return scanRangeMask(base, lo, hi); };
     // bitmap word wd: which of its 32 bytes read like a one-byte block (m2w), and which of those go on from the byte in front (contw)
-#ifdef LERC_PROBE
-    u32 dbgBoth = 0, dbgAny = 0, dbgC = 0, dbgCont = 0;
-#endif
     auto wordMasks = [&](u32 wd, u32& m2w, u32& contw)
     {
       const u32 mBits = v5 ? 0x07070707u : 0x03030303u, pat4 = pattern * 0x01010101u, step4 = v5 ? 0x02020202u : 0x01010101u;
@@ -729,14 +740,8 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
         const u32 c = a & ap & any;
         m2w |= ((((a >> 7) * 0x01020408u) >> 24) & 15u) << (4u * j);
         contw |= ((((c >> 7) * 0x01020408u) >> 24) & 15u) << (4u * j);
-#ifdef LERC_PROBE
-        dbgBoth += (u32)__popc(a & ap); dbgAny += (u32)__popc(any & 0x80808080u); dbgC += (u32)__popc(c);
-#endif
         prev = x;
       }
-#ifdef LERC_PROBE
-      dbgCont += (u32)__popc(contw);
-#endif
       m2w &= rangeMask(32u * wd, dataRel, blobRel);
       contw &= m2w;    // (in range; the stream's first block goes on from nothing)
       if (dataRel >= 32u * wd && dataRel < 32u * wd + 32u) contw &= ~(1u << (dataRel - 32u * wd));
@@ -786,7 +791,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     const u64 FT = F | (cinb & ~F & lim);
     s_sb[myWord] |= (u32)FT; s_sb[myWord + 1u] |= (u32)(FT >> 32);
 #ifdef LERC_PROBE
-    atomicAdd(&S.dbg[0], dbgBoth); atomicAdd(&S.dbg[1], (u32)__popcll(X)); atomicAdd(&S.dbg[2], dbgC); atomicAdd(&S.dbg[3], dbgCont);
+    atomicAdd(&S.dbg[0], (u32)__popcll(M2)); atomicAdd(&S.dbg[1], (u32)__popcll(X)); atomicAdd(&S.dbg[2], (u32)__popcll(seed)); atomicAdd(&S.dbg[3], (u32)__popcll(FT));
 #endif
     if (threadIdx.x == 0) S.frontBad = 0u;    // (everybody has read it; the check below says it again)
     __syncthreads();
@@ -888,6 +893,9 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
         const bool sure = t0 != 0u || (dataRel >= PRE && dataRel < pieceEndRel);
         const u32 tries = (S.over || nBad > kScanBadCap) ? 0u : (sure ? 1u : 3u);
         const u32 endTarget = lastPiece ? blobRel : pieceEndRel;
+        // (blocks entered: END's bitmap is done with in a masked band -- room for the run behind a raw block, which no flood reaches)
+        u16* const insWide = reinterpret_cast<u16*>(&s_end[0]);
+        constexpr u32 kInsWide = 8u * G::kMapVecs < 2048u ? 8u * G::kMapVecs : 2048u;    // (16-bit entries in the bitmap's bytes)
         // the length of the block at xx (k: the first list entry behind it), seen by the scan or not
         auto lenAt = [&](u32 xx, u32 k) -> u32
         {
@@ -916,7 +924,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
             auto chain = [&](auto& self, u32 p2, u32 sgPrev, u32 same, bool sure, u32 depth) -> bool
             {
               const u32 maxSame = v5 ? 2u : 1u, step = v5 ? 2u : 1u;
-              for (u32 stp = 0; stp < 160u; stp++)
+              for (u32 stp = 0, parses = 0; stp < 4096u && parses < 96u; stp++)
               {
                 if (known(p2)) return true;
                 if (p2 + 24u > G::kBytes || p2 >= blobRel) return false;
@@ -933,6 +941,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
                   return false;
                 }
                 const u32 lq = (fq & 3u) == 2u ? 1u : parseBlock(p2, false, 0u);
+                if ((fq & 3u) != 2u) parses++;
                 if (lq == 0u) return false;
                 sgPrev = sg; p2 += lq;
               }
@@ -990,10 +999,10 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
               if (fail) break;
               if (OFFS && xx >= PRE && firstOwn == 0u) firstOwn = xx;
               if (k < n ? xx == (u32)s_list[k] : (lastPiece ? xx == blobRel : xx >= pieceEndRel)) break;
-              if (xx >= endTarget || nIns >= kScanInsCap) { fail = true; break; }
+              if (xx >= endTarget || nIns >= kInsWide) { fail = true; break; }
               const u32 lx = lenAt(xx, k);
               if (lx == 0u) { fail = true; break; }
-              if (!OFFS || xx >= PRE) S.insPos[nIns++] = (u16)xx;    // (blocks in front of the piece's own bytes are the piece's in front)
+              if (xx >= PRE) insWide[nIns++] = (u16)xx;    // (blocks in front of the piece's own bytes are the piece's in front)
               xx += lx;
             }
             if (fail) break;
@@ -1002,7 +1011,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
           if (good)
           {
             for (u32 j = 0; j < nFalse; j++) { const u32 pos = (u32)s_list[S.falseIdx[j]]; s_sb[pos >> 5] &= ~(1u << (pos & 31u)); }
-            for (u32 j = 0; j < nIns; j++) { const u32 pos = (u32)S.insPos[j]; s_sb[pos >> 5] |= 1u << (pos & 31u); }
+            for (u32 j = 0; j < nIns; j++) { const u32 pos = (u32)insWide[j]; s_sb[pos >> 5] |= 1u << (pos & 31u); }
             S.nIns = nIns; S.nFalse = nFalse;
             if (OFFS) { S.mendExit = mendExit; if (wasFront) S.t0 = firstOwn; else if (frontGap) S.t0 = 0u; }    // (where the piece's first block begins, now that the walk from the anchor's end has been there)
           }

@@ -22,4 +22,10 @@ DB=$(find /tmp/prof_c4 -name '*.db' | head -1)
 python "$ROOT/tools/rocpd_summary.py" "$DB" lerc > "$OUT/${TAG}_kernel_trace_c4.txt" 2>&1
 cd $ROOT
 bash tools/gpu_trace_config.sh general ${TAG}_masked > /dev/null 2>&1    # kernel trace of the masked raster (general path)
+# per-workgroup time lines of the scanning decoder (unmasked: the headline band; masked: the block offsets) from the probe build, if it travelled
+if [ -f lerc_amd/csrc/_var/trace.so ]; then
+  PROBE_LIB=$PWD/lerc_amd/csrc/_var/trace.so timeout 200 python tools/trace_decode_scan.py > "$OUT/${TAG}_trace_decode_scan.txt" 2>&1
+  PROBE_LIB=$PWD/lerc_amd/csrc/_var/trace.so timeout 200 python tools/trace_masked_scan.py > "$OUT/${TAG}_trace_masked_scan.txt" 2>&1
+fi
+timeout 200 python tools/fuzz_against_oracle.py 5701 100 > "$OUT/${TAG}_fuzz.txt" 2>&1; tail -n 2 "$OUT/${TAG}_fuzz.txt"
 ls -la "$OUT" | grep $TAG | wc -l

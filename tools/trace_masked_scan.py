@@ -39,18 +39,18 @@ tt = t[:min(n_wg, rows)]
 tt = tt[tt[:, 0] > 0]
 t0 = tt[:, 0].min()
 us = (tt[:, :6] - t0) / 100.0
-names = ["start -> staged, scan", "candidates", "survivors -> list", "headers + tiling check + mending", "tail walk, cells of the pieces in front"]
+names = ["start -> staged, scan", "candidates", "survivors -> list", "headers + tiling check", "flood, second look, mending; cells of the pieces in front"]
 print(f"scan_offsets: {len(tt)} workgroups traced, span {us[:, 5].max():.1f} us, mean life {(us[:, 5] - us[:, 0]).mean():.2f} us")
 for k, nm in enumerate(names):
     d = us[:, k + 1] - us[:, k]
-    print("   %-44s mean %6.2f  p50 %6.2f  p90 %6.2f  max %7.2f" % (nm, d.mean(), np.median(d), np.percentile(d, 90), d.max()))
+    print("   %-58s mean %6.2f  p50 %6.2f  p90 %6.2f  max %7.2f" % (nm, d.mean(), np.median(d), np.percentile(d, 90), d.max()))
 
 v = tt[:, 8:16]
 odd = np.nonzero((v[:, 3] & 7) != 0)[0]
 w7 = tt[:, 7]
-print("at the mending's door: flooded", int(((w7 & 15) == 1).sum()), "front mismatch", int((((w7 >> 4) & 15) != 0).sum()), "broken links left: mean %.2f" % ((w7 >> 8) & 255).mean(), "pieces with any", int((((w7 >> 8) & 255) != 0).sum()))
+print("at the mending's door: flooded", int(((w7 & 15) >= 1).sum()), "front mismatch", int((((w7 >> 4) & 15) != 0).sum()), "broken links left: mean %.2f" % ((w7 >> 8) & 255).mean(), "pieces with any", int((((w7 >> 8) & 255) != 0).sum()))
 w6 = tt[:, 6]
-print("flood, mean per piece: both %.1f, X %.1f, c %.1f, contw before the range mask %.1f" % ((w6 & 0xFFFF).mean(), ((w6 >> 16) & 0xFFFF).mean(), ((w6 >> 32) & 0xFFFF).mean(), ((w6 >> 48) & 0xFFFF).mean()))
+print("flood, mean per piece: bytes that read like a one-byte block %.1f, of them going on from the byte in front %.1f, seeds (a survivor ends there) %.1f, blocks found %.1f" % ((w6 & 0xFFFF).mean(), ((w6 >> 16) & 0xFFFF).mean(), ((w6 >> 32) & 0xFFFF).mean(), ((w6 >> 48) & 0xFFFF).mean()))
 print("pieces with a flag:", len(odd), "of", len(tt), "; mended:", int(((v[:, 3] & 8) != 0).sum()))
 print("   first broken links: mean %.1f max %d; entries struck: mean %.1f max %d; blocks entered: mean %.1f max %d" %
       (v[:, 1].mean(), v[:, 1].max(), v[:, 7].mean(), v[:, 7].max(), v[:, 6].mean(), v[:, 6].max()))
