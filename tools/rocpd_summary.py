@@ -46,7 +46,7 @@ def traffic_json(fetch_db, write_db, size, out_path):
     """bytes per launch per bench kernel group from two PMC passes (FETCH_SIZE and WRITE_SIZE, both in KiB).
     gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes -> doubled (MI355X_MICROARCH.md, HBM section)."""
     import json
-    groups = {"k_fast_encode1": "fast_encode1", "k_fast_stats": "fast_stats_sizes", "k_fast_pack": "fast_pack", "k_fast_decode": "fast_decode", "k_fast_decode_one": "fast_decode_one",
+    groups = {"k_fast_encode1": "fast_encode1", "k_fast_stats": "fast_stats_sizes", "k_fast_pack": "fast_pack", "k_fast_decode": "fast_decode", "k_fast_decode_one": "fast_decode_one", "k_fast_decode_scan": "fast_decode_scan",
               "k_fast_discover": "fast_discover", "k_fast_scan_decide": "fast_scan_decide"}
 
     def per_kernel(db, counter):
