@@ -571,6 +571,10 @@ def test_first_row_errors_are_read_after_they_are_written(P, O):
     x = synth.c2_float32(2048, 4096, device=dev)
     blob = torch.empty(x.numel() * 4 + 4096, dtype=torch.uint8, device=dev)
     y = torch.empty_like(x)
+    # (the codecs below run on streams of their own, which are not ordered behind the stream that is still WRITING x: without this wait
+    # the first encode once read a raster that was not there yet -- leftovers of another test's blob: NaN, absurd sizes, reason bits
+    # 0x61 -- and "fell back" once in six runs of the suite.  The test's race, not the library's.)
+    torch.cuda.synchronize()
     fell = 0
     notes = []
     for i in range(200):
@@ -585,12 +589,9 @@ def test_first_row_errors_are_read_after_they_are_written(P, O):
             codec.close()
         assert rc == 0 and rc2 == 0, (i, rc, rc2, list(c))
         fell += int(c[1] != 0 or c[3] != 0 or f[3] != 1)
-    # (before the barrier: 6 of 200 on average.  Since: none in 15 runs of this test by itself, three of them with LERC_AMD_POISON (3 000
-    # fresh contexts); one -- the FIRST call, reason bits 0x61: statistics with residue -- in six runs of the whole suite, not reproduced
-    # and not explained (profiles/r05_notes.md).  The band goes to the general kernels and comes out right, which the suite's byte
-    # comparisons check.  One in 200 passes.  A hand-off that times out while other processes keep the GPU busy sends a call the same way,
-    # by design: LERC_AMD_TEST_SHARED_GPU=1 lets two pass -- the driver's run owns its GPU)
-    assert fell <= (2 if os.environ.get("LERC_AMD_TEST_SHARED_GPU") else 1), (fell, notes[:4])
+    # (before the barrier: 6 of 200 on average.  None since.  A hand-off that times out while other processes keep the GPU busy
+    # sends a call the same way, by design: LERC_AMD_TEST_SHARED_GPU=1 lets two pass -- the driver's run owns its GPU)
+    assert fell <= (2 if os.environ.get("LERC_AMD_TEST_SHARED_GPU") else 0), (fell, notes[:4])
     rng = np.random.default_rng(77)
     off = cases.terrain(1024, 2048, rng, amp=300, base=1000, sigma=2.0).astype(np.float32)          # nothing to raise
     on = np.round(cases.terrain(1024, 2048, rng, amp=300, base=1000, sigma=2.0), 1).astype(np.float32)    # every value on the 0.1 grid
