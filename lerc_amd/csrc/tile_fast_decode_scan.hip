@@ -662,7 +662,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
         // (a raw block of a masked band, whose length the stream does not say: the mending has found where the next block begins)
         const u32 b0 = (s_in[pos >> 2] >> (8u * (pos & 3u))) & 0xFFu;
         const u32 e = last ? S.mendExit : nxt;
-        if ((b0 & 3u) == 0u && !(v5 && (b0 & 4u)) && e > pos + 1u && (e - pos - 1u) % G::TB == 0u && (e - pos - 1u) / G::TB <= 64u && e <= blobRel) len = e - pos;
+        if ((b0 & 3u) == 0u && (b0 >> 6) == 0u && !(v5 && (b0 & 4u)) && e > pos + 1u && (e - pos - 1u) % G::TB == 0u && (e - pos - 1u) / G::TB <= 64u && e <= blobRel) len = e - pos;
       }
       const u32 ext = pos + len;
       const bool ok = len != 0u && (last ? (lastPiece ? ext == blobRel : ext >= pieceEndRel) : ext == nxt);
@@ -724,7 +724,9 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     // bitmap word wd: which of its 32 bytes read like a one-byte block (m2w), and which of those go on from the byte in front (contw)
     auto wordMasks = [&](u32 wd, u32& m2w, u32& contw)
     {
-      const u32 mBits = v5 ? 0x07070707u : 0x03030303u, pat4 = pattern * 0x01010101u, step4 = v5 ? 0x02020202u : 0x01010101u;
+      // (a one-byte block as the reference writes it: mode 2, the signature, nothing in bits 6 - 7, Lerc2.cpp:1955-1962; a writer that
+      // leaves something there is followed by the mending, or the general discovery)
+      const u32 mBits = v5 ? 0xC7C7C7C7u : 0xC3C3C3C3u, pat4 = pattern * 0x01010101u, step4 = v5 ? 0x02020202u : 0x01010101u;
       u32 prev = S.inAll[3u + 8u * wd];    // (the word in front; in front of the staged bytes: 0)
       m2w = 0u; contw = 0u;
 #pragma unroll
@@ -734,7 +736,9 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
         const u32 px = __builtin_amdgcn_alignbit(x, prev, 24);                    // the bytes in front of x's
         // (0x80 in the bytes of y that are zero; y's bytes are below 0x80)
         auto zeroBytes = [](u32 y) { return ~(y + 0x7F7F7F7Fu) & 0x80808080u; };
-        const u32 a = zeroBytes((x ^ 0x02020202u) & mBits), ap = zeroBytes((px ^ 0x02020202u) & mBits);
+        // (0x80 in the bytes of y that are zero, any y)
+        auto zeroBytesAny = [](u32 y) { return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u; };
+        const u32 a = zeroBytesAny((x ^ 0x02020202u) & mBits), ap = zeroBytesAny((px ^ 0x02020202u) & mBits);
         const u32 sg = (x >> 2) & pat4, sp = (px >> 2) & pat4;
         const u32 any = zeroBytes(sg ^ sp) | zeroBytes(sg ^ ((sp + step4) & pat4)) | zeroBytes(sg);    // sigOk, four bytes at a time
         const u32 c = a & ap & any;
@@ -903,7 +907,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
           // (a block of pixels that are all zero, or all invalid: one byte -- a masked band has runs of them)
           u32 lx = 0u;
           if ((b0 & 3u) == 2u && !(v5 && (b0 & 4u))) lx = 1u;
-          else if (OFFS && (b0 & 3u) == 0u && !(v5 && (b0 & 4u)))
+          else if (OFFS && (b0 & 3u) == 0u && (b0 >> 6) == 0u && !(v5 && (b0 & 4u)))    // (a raw block as the reference writes it: nothing in bits 6 - 7, Lerc2.cpp:1973)
           {
             // A RAW block of a masked band: the flag byte and its valid pixels' values -- how many, the stream does not say (the
             // mask does, to who knows the block's place).  Few, where raw beats bit-stuffing (one or two pixels at a mask's edge):
@@ -934,6 +938,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
                 else if (sg == sgPrev) { if (++same > maxSame) return false; }
                 else if (sg == ((sgPrev + step) & pattern) && (!sure || same == maxSame)) { same = 1u; sure = true; }
                 else return false;
+                if ((fq & 3u) != 1u && (fq & 3u) != 3u && (fq >> 6) != 0u) return false;    // (raw and all-zero blocks carry no offset type)
                 if ((fq & 3u) == 0u)
                 {
                   if (depth == 0u) return false;

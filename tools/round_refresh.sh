@@ -7,8 +7,10 @@ OUT=$PWD/gpurun_out; mkdir -p "$OUT"
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q > "$OUT/${TAG}_pytest_gpu.txt" 2>&1; tail -3 "$OUT/${TAG}_pytest_gpu.txt"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/${TAG}_smoke.txt" 2>&1; tail -2 "$OUT/${TAG}_smoke.txt"
-timeout 600 python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"; cut -c1-400 "$OUT/${TAG}_bench.json"
 bash tools/profile_run.sh $TAG
+# (the bench line quotes the traffic of the counter passes just made: it looks for them under profiles/, stamped with these sources' digest)
+cp "$OUT/${TAG}_hbm_traffic.json" profiles/ 2>/dev/null
+timeout 600 python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"; cut -c1-400 "$OUT/${TAG}_bench.json"
 timeout 300 python tools/time_configs.py c3 c4 general c2lossless > "$OUT/${TAG}_time_configs.txt" 2>&1
 timeout 200 python tools/time_tiles.py > "$OUT/${TAG}_time_tiles.txt" 2>&1
 timeout 200 python tools/time_small.py > "$OUT/${TAG}_time_small.txt" 2>&1
