@@ -440,6 +440,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
   // next band's kernels write theirs.
   const size_t bandMark = ctx.used();
   bool maskFromDevice = false;    // this band's mask bits come out of launchMaskRleDecode (the verdict on its stream is still out)
+  i64 hostMaskCount = -1;         // set bits among the nPix of a mask the HOST decoded (finishMask), for maskIsSound
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
     ctx.rewind(bandMark);
@@ -543,6 +544,17 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
         size_t written = 0;
         if (!rleDecode(maskRle.data(), (size_t)bd.numBytesMask, hostBits, maskBytes, &written)) return false;
         if (pinnedBits && written < maskBytes) memset(hostBits + written, 0, maskBytes - written);
+        {
+          // the valid pixels this mask names (BitMask::CountValidBits over the raster's nPix bits, most significant bit first): what the
+          // one-sweep kernel is bounded by -- Lerc2::ReadDataOneSweep asks the mask, not the header (Lerc2.cpp:1379-1385)
+          i64 cnt = 0;
+          const size_t whole = (size_t)(nPix >> 3);
+          size_t i = 0;
+          for (; i + 8 <= whole; i += 8) { u64 w8; memcpy(&w8, hostBits + i, 8); cnt += __builtin_popcountll(w8); }
+          for (; i < whole; i++) cnt += __builtin_popcount((unsigned)hostBits[i]);
+          if (nPix & 7) cnt += __builtin_popcount((unsigned)hostBits[whole] & (0xFF00u >> (nPix & 7)) & 0xFFu);
+          hostMaskCount = cnt;
+        }
         hipMemcpyAsync(dBits, hostBits, maskBytes, hipMemcpyHostToDevice, st);
         if (pinnedBits) { hipEventRecord(ctx.auxEvent(), st); auxInFlight = true; }
       }
@@ -557,16 +569,19 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     };
 
     // The one-sweep and the Huffman kernels take the mask's word for which pixels the stream holds, and how many: before they
-    // run, the mask has to be what the header says -- numValid set bits, out of a run-length stream that was intact (on the
-    // device that verdict would otherwise come with the call's last wait, after kernels had gone by a mask that may be
-    // anything: a rank divided by a valid count of zero, reads behind the band).  One wait, for masked bands in those modes only.
-    // (The block kernels of the tiling mode check every block against its valid count themselves.)
-    auto maskIsWhatTheHeaderSays = [&]() -> bool
+    // run, the mask has to be sound -- out of a run-length stream that was intact (on the device that verdict would otherwise come
+    // with the call's last wait, after kernels had gone by a mask that may be anything) -- and its OWN count of valid pixels is what
+    // bounds the one-sweep reader (m_bitMask.CountValidBits(), Lerc2.cpp:1379-1385; the header's count is not asked, there or in
+    // Lerc2::ReadMask, Lerc2.cpp:961-1008: a blob whose header names another number than its mask holds decodes like the
+    // reference's, or fails like it).  A mask the host decoded has been counted by finishMask; one the device decoded costs one
+    // wait, for masked bands in those modes only.  (The block kernels of the tiling mode check every block against its valid
+    // count themselves.)
+    auto maskIsSound = [&](i64& count) -> bool
     {
+      count = (i64)nPix;
       if (maskAllValid || !dMask) return true;
       if (!finishMask()) return false;
-      // (a mask the host decoded: rleDecode has vouched for the stream, and Lerc2::ReadMask, Lerc2.cpp:961-1008, asks no more)
-      if (!maskFromDevice) return true;
+      if (!maskFromDevice) { count = hostMaskCount >= 0 ? hostMaskCount : (i64)hd.numValid; return true; }
       const i64 nGroups = (nPix + 31) >> 5;
       const size_t mark = ctx.used();
       u32* dCounts = ctx.allocT<u32>((size_t)nGroups + 4);
@@ -582,7 +597,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
       ctx.rewind(mark);
       const DeviceStatus* hsNow = reinterpret_cast<const DeviceStatus*>(pinV + 4);
       if (hsNow->error) { ctx.lastError = "device kernel reported an error"; return false; }
-      if ((i64)pinV[0] != (i64)hd.numValid) { ctx.lastError = "the band's mask does not hold the number of valid pixels its header names"; return false; }
+      count = (i64)pinV[0];
       return true;
     };
 
@@ -640,13 +655,16 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     if (flags[0])
     {
       if (!finishMask()) return kFailed;
-      // one sweep: valid pixels stored raw in order (Lerc2.cpp:1368-1400)
-      if ((u64)(at - bd.offset) + (u64)nv * nD * tb > blobEnd) return kFailed;
+      // one sweep: valid pixels stored raw in order (Lerc2.cpp:1368-1400) -- as many as the MASK names, not as many as the header
+      // says: k_one_sweep reads the stream by the mask's ranks, so a header that names fewer pixels than its mask holds in front of a
+      // stream cut to match must not get past this bound
+      i64 nSweep = 0;
+      if (!maskIsSound(nSweep)) return kFailed;
+      if ((u64)(at - bd.offset) + (u64)nSweep * nD * tb > blobEnd) return kFailed;
       const u8* src = dBlob + at;
       if (maskAllValid) hipMemcpyAsync(dOutBand, src, (size_t)nPix * nD * tb, hipMemcpyDeviceToDevice, st);
       else
       {
-        if (!maskIsWhatTheHeaderSays()) return kFailed;
         const i64 nGroups = (nPix + 31) >> 5;
         u32* dCounts = ctx.allocT<u32>((size_t)nGroups + 4);
         u32* dBase = ctx.allocT<u32>((size_t)nGroups + 4);
@@ -680,7 +698,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
         continue;
       }
       if (!(imageMode == IEM_DeltaHuffman || (hd.version >= 4 && imageMode == IEM_Huffman))) return kFailed;
-      if (!maskIsWhatTheHeaderSays()) return kFailed;
+      { i64 unused = 0; if (!maskIsSound(unused)) return kFailed; }
       const u32 rc = decodeHuffman(ctx, dt, rq.hBlob ? rq.hBlob + bd.offset : nullptr, dBand, (u32)(at - bd.offset), blobEnd,
                                    imageMode, dMask, nRows, nCols, nD, hd.version, dOutBand, dStatus, bd.head, bd.headLen);
       if (rc != kOk) return rc;

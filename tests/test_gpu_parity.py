@@ -1099,6 +1099,19 @@ print("masks ok", bad)
         os.unlink(path)
 
 
+def test_header_and_mask_disagree_on_the_valid_count(P, O):
+    """Crafted blobs with a valid checksum whose header names another number of valid pixels than the mask holds, the one-sweep stream cut
+    to the header's count among them (round-5 review: the kernel, which reads by the mask's ranks, read past the blob through the
+    device-pointer API).  Verdicts and pixels are the oracle's and the real reference's; the same script runs under the emulator in
+    tests/test_sim_kernels.py.  Mask decoded on the host and (LERC_AMD_DEVICE_RLE=16) on the device."""
+    import sys
+    from test_sim_kernels import COUNT_MISMATCH_CODE
+    for knob in ("0", "16"):
+        env = dict(os.environ, LERC_AMD_DEVICE_RLE=knob)
+        out = subprocess.run([sys.executable, "-c", COUNT_MISMATCH_CODE % (capi.ROOT, "product")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert out.returncode == 0 and b"counts ok" in out.stdout, out.stdout.decode()[-2000:]
+
+
 def test_blob_gather_over_rccl_in_a_group_of_one(O):
     """The mosaic job's exchange step (lerc_amd/shard.py: gather_arenas_start) on the GPU box: a process group of ONE rank over
     "nccl" -- RCCL -- with the collective steps forced (there is nobody to send to, but the lengths' all-gather runs on RCCL with

@@ -795,6 +795,78 @@ print("masks ok", n)
         assert out.returncode == 0 and b"masks ok" in out.stdout, out.stdout.decode()[-2000:]
 
 
+COUNT_MISMATCH_CODE = r"""
+import sys, os, struct
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, capi, cases
+P, O, R = getattr(capi, %r)(), capi.oracle(), capi.ref()
+checkers = [O] + ([R] if R is not None else [])
+
+def fletcher32(b):
+    # Lerc2::ComputeChecksumFletcher32 (Lerc2.cpp:1037-1064) on the bytes behind the checksum field
+    a = np.frombuffer(b[: len(b) & ~1], np.uint8).astype(np.uint64)
+    w = (a[0::2] << 8) | a[1::2]
+    n = len(w)
+    s1 = 0xffff + int(w.sum())
+    s2 = 0xffff * (n + 1) + int((w * np.arange(n, 0, -1, dtype=np.uint64)).sum())
+    if len(b) & 1:
+        s1 += b[-1] << 8; s2 += s1
+    return ((s2 %% 65535 or 65535) << 16) | (s1 %% 65535 or 65535)
+
+def reseal(bb):
+    bb = bytearray(bb)
+    struct.pack_into("<I", bb, 10, fletcher32(bytes(bb[14:])))
+    return bytes(bb)
+
+rng = np.random.default_rng(87)
+n = 0
+for dt, e, shape in ((np.int8, 0, (65, 186)), (np.uint8, 0, (40, 96)), (np.float32, 1e-7, (33, 70)), (np.float64, 1e-12, (24, 40))):
+    r, c = shape
+    x = cases.terrain(r, c, rng, amp=50, base=100, sigma=3.0 if np.dtype(dt).kind == "f" else 0.3)
+    x = cases._cast(x / 8 if np.dtype(dt).itemsize == 1 else x * 1000.123, dt)    # (floats: noise no block can quantise -> one sweep)
+    m = np.ones((r, c), np.uint8); m[:, : c // 2] = 0; m[r // 2, 3] = 1; m[3:9, c // 2 + 5: c // 2 + 30] = 0
+    r1, b1 = O.encode(x, e, mask=m)
+    assert r1 == 0 and reseal(b1) == b1, "the test's checksum is not the codec's"
+    nv = struct.unpack_from("<i", b1, 26)[0]
+    assert nv == int(m.sum())
+    tb = np.dtype(dt).itemsize
+    n_mask = struct.unpack_from("<I", b1, 90)[0]
+    one_sweep = b1[94 + n_mask + 2 * tb] == 1
+    assert one_sweep == (np.dtype(dt).kind == "f")
+    crafted = []
+    for delta in (-1, 1, 1 - nv, 5, -20):    # the header names another count than the mask holds, the stream is whole
+        bb = bytearray(b1); struct.pack_into("<i", bb, 26, nv + delta); crafted.append(reseal(bb))
+    if one_sweep:
+        # the header says ONE valid pixel, the mask holds hundreds, the stream is cut to one pixel: by the header's count it is long
+        # enough, by the mask's (Lerc2::ReadDataOneSweep, Lerc2.cpp:1379-1385) it is not -- and the kernel reads by the mask's ranks
+        pay = 94 + n_mask + 2 * tb + 1
+        bb = bytearray(b1[:pay + tb]); struct.pack_into("<i", bb, 26, 1); struct.pack_into("<i", bb, 34, len(bb)); crafted.append(reseal(bb))
+        bb = bytearray(b1[:pay + tb * (nv - 1)]); struct.pack_into("<i", bb, 26, nv - 1); struct.pack_into("<i", bb, 34, len(bb)); crafted.append(reseal(bb))
+    for k, bb in enumerate(crafted):
+        got = P.decode(bb)
+        for L in checkers:
+            want = L.decode(bb)
+            assert (want[0] == 0) == (got[0] == 0), (np.dtype(dt).name, k, want[0], got[0])
+            if want[0] == 0:
+                assert np.array_equal(want[1].view(np.uint8), got[1].view(np.uint8)) and np.array_equal(want[2], got[2]), (np.dtype(dt).name, k)
+        if one_sweep and k >= 5: assert got[0] != 0
+        n += 1
+print("counts ok", n)
+"""
+
+
+def test_sim_header_and_mask_disagree_on_the_valid_count(libs):
+    """Behind a VALID checksum the header names another number of valid pixels than the mask holds (a crafted blob; round-5 review: with
+    the stream cut to the header's count the one-sweep kernel, which reads by the mask's ranks, read past the blob).  The reference asks
+    the mask, never the header (Lerc2::ReadDataOneSweep, Lerc2.cpp:1379-1385; DecodeHuffman goes by the mask's bits): same verdicts and
+    same pixels as the oracle and the real reference, with the mask decoded by the host and (LERC_AMD_DEVICE_RLE=16) by the device."""
+    import sys
+    for knob in ("0", "16"):
+        env = dict(os.environ, LERC_AMD_DEVICE_RLE=knob)
+        out = subprocess.run([sys.executable, "-c", COUNT_MISMATCH_CODE % (capi.ROOT, "sim")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+        assert out.returncode == 0 and b"counts ok" in out.stdout, out.stdout.decode()[-2000:]
+
+
 def mask_and_stats_cases(rng):
     """float rasters with a mask whose values lie on a grid of 0.1 / 0.01 / 0.5 / whole numbers -- TryRaiseMaxZError raises the
     error bound, or a first row promises it (the candidates are pruned on it, codec_encode.cpp) and a later row does not --,
