@@ -49,6 +49,12 @@ extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace(unsi
 #define TRACE_ID()
 #endif
 
+// tuning: LERC_ENC_EXIT=n builds an encoder that leaves at mark n (profiles/r06_notes.md: instruction counts per phase); results are invalid
+#ifndef LERC_ENC_EXIT
+#define LERC_ENC_EXIT 99
+#endif
+#define ENC_EXIT(n) do { if (LERC_ENC_EXIT == (n)) return; } while (0)
+
 enum FastRedo : u32
 {
   kRedoNaN = 1, kRedoAllInt = 2, kRedoRaise = 4, kRedoConst = 8, kRedoMb16 = 16, kRedoOneSweep = 32, kRedoCapacity = 64,
@@ -1276,17 +1282,20 @@ fusedFlush(const u32* s_out, u32 kLead, u32 g0, u32 spanLen, u8* __restrict__ ou
     const u32 lo = 16u * u;
     if (fits && lo >= ldsShift && lo + 16u <= spanEnd) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;    // (k_fast_discover reads them next: no streaming hint)
   }
-  // the span's two ragged ends (units shared with the neighbouring spans), byte by byte: two lanes of one wave, outside the
-  // loop -- inside it every wave that holds such a unit paid for sixteen predicated byte stores
-  if (threadIdx.x < 2u && fits && nUnits != 0u)
+  // the span's two ragged ends (units shared with the neighbouring spans): lane = byte, sixteen lanes an end, outside the loop --
+  // inside it every wave that holds such a unit paid for sixteen predicated byte stores, and two lanes going through their bytes
+  // one after the other were a chain of sixteen LDS reads on the first wave's way out
+  if (threadIdx.x < 32u && fits && nUnits != 0u)
   {
-    const u32 u = threadIdx.x ? nUnits - 1u : 0u;
+    const u32 end = threadIdx.x >> 4, i16 = threadIdx.x & 15u;
+    const u32 u = end ? nUnits - 1u : 0u;
     const u32 lo = 16u * u, first = lo < ldsShift ? ldsShift : lo, last = min(lo + 16u, spanEnd);    // owned bytes of the unit
-    const bool partial = !(first == lo && last == lo + 16u) && !(threadIdx.x == 1u && nUnits == 1u);    // (one unit in all: lane 0 takes it)
-    if (partial)
+    const bool partial = !(first == lo && last == lo + 16u) && !(end == 1u && nUnits == 1u);    // (one unit in all: the first sixteen lanes take it)
+    const u32 i = lo + i16;
+    if (partial && i >= first && i < last)
     {
       const u8* img = reinterpret_cast<const u8*>(s_out) + kLead - ldsShift;    // image byte of blob byte gAligned
-      for (u32 i = first; i < last; i++) out[gAligned + i] = img[i];
+      out[gAligned + i] = img[i];
     }
   }
 }
@@ -1298,12 +1307,14 @@ __device__ __forceinline__ void
 fusedArrive(u32 A, u64 B, u64* s_fa, u64* s_fb, const u32* s_fl, u32 wg, int wPlan, const FastFused& f)
 {
   const int w = waveId(), lane = laneId();
-  const u64 a = waveSum((u64)A), b2 = waveSum(B);
+  // (the sums are wanted mod 65535: folded to 32 bits first -- a wave's sum of 64 folds stays below 2^24 -- the reduction is DPP adds)
+  const u32 a = waveSum(fold65535(A)), b2 = waveSum(fold65535(B));
   if (lane == 0) { s_fa[w] = a; s_fb[w] = b2; }
   __syncthreads();
   if (w == wPlan && lane == 0)
   {
-    const u64 a4 = (s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3]) % 65535u, b4 = (s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]) % 65535u;
+    // (congruent to the sums and below 2^17: sixteen workgroups' terms fit the accumulator's 24-bit fields)
+    const u64 a4 = fold65535((u32)(s_fa[0] + s_fa[1] + s_fa[2] + s_fa[3])), b4 = fold65535((u32)(s_fb[0] + s_fb[1] + s_fb[2] + s_fb[3]));
     const u32 fl = s_fl[0] | s_fl[1] | s_fl[2] | s_fl[3];
     drainVmem();
     __hip_atomic_fetch_add(f.packPart + wg / kFastPackGroup, a4 | (b4 << 24) | (1ull << 48) | ((u64)(fl & 1u) << 53) | ((u64)((fl >> 1) & 1u) << 58),
@@ -1530,9 +1541,20 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
     }
   for (u32 i = threadIdx.x; i < (u32)kSpanWords / 4u; i += 256u) reinterpret_cast<uint4*>(s_out)[i] = make_uint4(0, 0, 0, 0);
   if (threadIdx.x == 0) { s_base = 0u; s_retry = 0u; }
+  if (LERC_ENC_EXIT == 1)    // (the loads are kept alive)
+  {
+#pragma unroll
+    for (int a = 0; a < U; a++)
+#pragma unroll
+      for (int t = 0; t < IT; t++)
+#pragma unroll
+        for (int k = 0; k < V; k++) { const u32 bits32 = (u32)rawBits<T>(v[a][t][k]); asm volatile("" :: "v"(bits32)); }
+    return;
+  }
 
   // ---- statistics per block (Lerc2::GetValidDataAndStats for an all-valid block + the tryLut count, Lerc2.cpp:1717-1799)
-  u32 flags = 0;
+  // (the two flags as per-lane booleans: the compiler keeps them as lane masks in scalar registers, an s_or a tile)
+  bool sawNaN = false, sawFrac = false;
 #pragma unroll
   for (int a = 0; a < U; a++)
   {
@@ -1546,11 +1568,11 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       if (DT >= DT_Float)
       {
 #pragma unroll
-        for (int k = 0; k < V; k++) if ((!MASKED || ((vm >> k) & 1u)) && isNaNv(x[k])) flags |= 1u;
-        if (!(flags & 2u))    // one fractional value settles "not all integers" for good
+        for (int k = 0; k < V; k++) sawNaN = sawNaN | ((!MASKED || ((vm >> k) & 1u)) & isNaNv(x[k]));
+        if (!sawFrac)    // one fractional value settles "not all integers" for good
         {
 #pragma unroll
-          for (int k = 0; k < V; k++) if ((!MASKED || ((vm >> k) & 1u)) && notIntegral(x[k])) flags |= 2u;
+          for (int k = 0; k < V; k++) sawFrac = sawFrac | ((!MASKED || ((vm >> k) & 1u)) & notIntegral(x[k]));
         }
       }
       T mn, mx;
@@ -1563,9 +1585,13 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       }
       else if constexpr (!PART)
       {
-        mn = x[0]; mx = x[0];
+        if constexpr (std::is_same<T, float>::value) laneMinMax4(x[0], x[1], x[2], x[3], mn, mx);
+        else
+        {
+          mn = x[0]; mx = x[0];
 #pragma unroll
-        for (int k = 1; k < V; k++) { mn = OpMin()(mn, x[k]); mx = OpMax()(mx, x[k]); }
+          for (int k = 1; k < V; k++) { mn = OpMin()(mn, x[k]); mx = OpMax()(mx, x[k]); }
+        }
       }
       else
       {
@@ -1582,6 +1608,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       }
       // "same as previous" in row-major block order, prevVal starts at 0 (Lerc2.cpp:1729-1758)
       int same, nElem = 64;
+      bool lutCand = true;    // a block of the wave may have more than half of its pixels equal to their predecessor (PART, MASKED: looked at below)
       if constexpr (MASKED)
       {
         // the valid pixel in front of this lane's first valid one: the last valid pixel of the nearest lane before it in
@@ -1603,11 +1630,33 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       }
       else if constexpr (!PART)
       {
-        T prev = (T)dppMovT<kDppWaveShr1>((ST)x[V - 1]);    // the previous pixel vector of the block lives in the previous lane
-        if (leader) prev = T(0);
-        same = (x[0] == prev) ? 1 : 0;
+        // Only "more than half of the 64 equal their predecessor" matters (tryLut), and that takes a lane whose count lies above the
+        // average of 32 / LB -- of which all but one are comparisons INSIDE the lane.  Those come first (noise: no lane gets there, and
+        // the pixel of the lane in front is never fetched); 32-bit types: "two of the three" as scalar logic on the comparisons' lane masks
+        bool maybe;
+        if constexpr (V == 4)
+        {
+          const u64 e1 = __ballot(x[1] == x[0]), e2 = __ballot(x[2] == x[1]), e3 = __ballot(x[3] == x[2]);
+          maybe = ((e1 & e2) | (e2 & e3) | (e1 & e3)) != 0ull;
+          same = 0;
+        }
+        else
+        {
+          same = 0;
 #pragma unroll
-        for (int k = 1; k < V; k++) same += (x[k] == x[k - 1]) ? 1 : 0;
+          for (int k = 1; k < V; k++) same += (x[k] == x[k - 1]) ? 1 : 0;
+          maybe = __any(same >= 32 / LB);
+        }
+        lutCand = false;
+        if (maybe)
+        {
+          T prev = (T)dppMovT<kDppWaveShr1>((ST)x[V - 1]);    // the previous pixel vector of the block lives in the previous lane
+          if (leader) prev = T(0);
+          same = (x[0] == prev) ? 1 : 0;
+#pragma unroll
+          for (int k = 1; k < V; k++) same += (x[k] == x[k - 1]) ? 1 : 0;
+          lutCand = __any(same > 32 / LB);
+        }
       }
       else
       {
@@ -1626,7 +1675,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         nElem = groupReduce<LB>(vc, OpSum());
       }
       u32 nd = 0;
-      if (PART || MASKED || __any(same > 32 / LB))
+      if (lutCand)
       {
         same = groupReduce<LB>(same, OpSum());
         const bool tryLut = (nElem > 4) && (2 * same > nElem) && ((double)mx > (double)mn + 3 * p.maxZErr);
@@ -1657,10 +1706,11 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       }
     }
   }
-  const bool f1 = __any(flags & 1u), f2 = __any(flags & 2u);
+  const bool f1 = __any(sawNaN), f2 = __any(sawFrac);
   if (lane == 0) s_fl[w] = (f1 ? 1u : 0u) | (f2 ? 2u : 0u);
   __syncthreads();
   TRACE(5);
+  ENC_EXIT(2);
 
   // ---- lane = block, a wave per unit (they rotate over the SIMDs from workgroup to workgroup): the per-block decisions of
   // Lerc2::NumBytesTile once per block and where each block starts in its unit's span
@@ -1689,7 +1739,9 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
     u32 inc = sz;
 #pragma unroll
     for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(inc, (unsigned)dd); if (lane >= dd) inc += o; }
-    s_w1[a][lane] = packDesc(pl, nb); s_bit[a][lane] = 8u * (kLead + inc - sz);
+    // (where the block begins in the span image -- a bit-stuffed block without a table: where its PAYLOAD begins, behind flag byte, offset,
+    // bits byte and count: the pixel owners then need nothing of the header's layout)
+    s_w1[a][lane] = packDesc(pl, nb); s_bit[a][lane] = 8u * (kLead + inc - sz + (pl.kind == 3 ? 3u + (u32)dtSize3((u32)pl.dtRed) : 0u));
     const u32 total = (u32)__shfl((int)inc, 63);
     // (blocks behind the raster's end repeat the last block's range: they change nothing)
     u64 kMin, kMax;
@@ -1715,6 +1767,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
     __hip_atomic_fetch_max(f.keyPart + 2 * (size_t)(wg / kFastPackGroup) + 1, ~kMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   TRACE(1);
+  ENC_EXIT(3);
   const bool sizeOnly = out == nullptr;    // (a size query of a ragged raster: everything but payloads and stores)
 
   // ---- where the spans go: the cells of the workgroups from the start of the group in front of this one's up to this
@@ -1759,7 +1812,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       const int kind = (int)((w1 >> 16) & 7u), tc = (int)((w1 >> 19) & 3u), dtRed = (int)((w1 >> 21) & 7u), nb = (int)(w1 >> 24);
       const int j0 = (int)fastSpanCol(span[a], (u32)lane) * 8;
       u32 flag = (u32)(((j0 >> 3) & 15) << 2) & 0x38u;    // version 6, no slice difference
-      const u32 at0 = s_bit[a][lane] + bitBase;
+      const u32 at0 = s_bit[a][lane] + bitBase - (kind == 3 ? 8u * (3u + (u32)dtSize3((u32)dtRed)) : 0u);    // (the block's first byte)
       if (kind == 7) { }
       else if (kind == 0) orBits(s_out, at0, flag | 2u, 8);
       else if (kind == 1) orBits(s_out, at0, flag, 8);
@@ -1794,7 +1847,6 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       if (kind == 3)
       {
         const int nb = (int)(w1 >> 24);
-        const int offBytes = dtSize3((w1 >> 21) & 7u);
         const T mn = s_mnT[a][blk];
         u32 q[V];
         quantizeLane<T, V>(p.intLossless, p.scale, v[a][t], mn, q);
@@ -1803,7 +1855,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
 #pragma unroll
           for (int k = 0; k < V; k++) if (k >= vc) q[k] = 0u;    // (no such pixel: no bits)
         }
-        const u32 at = at0 + 8u * (3u + (u32)offBytes);
+        const u32 at = at0;    // (the plan wave has left the payload's place)
         if constexpr (MASKED)
         {
           // the lane's valid values, closed up
@@ -1935,6 +1987,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       if (threadIdx.x == 0 && grp >= 2u) cb = observe64(f.baseCell + (grp - 1u));
     }
     if (together && a < U - 1) continue;    // (more units go into this image)
+    if (LERC_ENC_EXIT == 4) { __syncthreads(); return; }
     if (!resolved)
     {
       resolved = true;
@@ -1981,6 +2034,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
     fusedFlush(s_out, kLead, (MASKED ? f.payloadAt : prefixLen) + spanBase + flushed, segLen, out, outCapacity, fA, fB);    // (MASKED: behind the band's real sections, which the host writes)
     flushed += segLen;
   }
+  if (LERC_ENC_EXIT == 5) { if (fA == 0x12345678u && fB == 77ull) s_base = 1u; return; }
   fusedArrive(fA, fB, s_fa, s_fb, s_fl, wg, wPlan, f);
   TRACE(4);
   if (wg != nWG - 1u) return;

@@ -74,6 +74,11 @@ extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_deco
 #ifndef LERC_SCAN_HELD16
 #define LERC_SCAN_HELD16 2
 #endif
+// tuning: LERC_DEC_EXIT=n builds a decoder that leaves at mark n (profiles/r06_notes.md: instruction counts per phase); results are invalid
+#ifndef LERC_DEC_EXIT
+#define LERC_DEC_EXIT 99
+#endif
+#define DEC_EXIT(n) do { if (LERC_DEC_EXIT == (n)) return; } while (0)
 static const u32 kScanBadCap = 64, kScanFalseCap = 64, kScanInsCap = 128;    // (the one thread's mending: broken links, entries struck, blocks entered -- a masked band enters into END's bitmap, 2048)
 
 template<class T> struct ScanGeom
@@ -237,6 +242,13 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   }
   const u32 nWG = fastScanNumWG(blobEnd);
   if (!ours || wg >= nWG) return;                  // (the grid is sized for the largest stream the blob could hold)
+  if (LERC_DEC_EXIT == 0)    // a workgroup of the same shape (threads, LDS) that loads the header and stores one vector
+  {
+    S.inAll[threadIdx.x] = blobEnd + threadIdx.x;
+    __syncthreads();
+    if (!OFFS && threadIdx.x < 4u) outPix[(size_t)wg * 1024u + threadIdx.x] = (T)S.inAll[(threadIdx.x + 1u) & 511u];
+    return;
+  }
   TRACES(0);
   if (!early) issueLoads();
   const int version = (int)hl.version;
@@ -320,14 +332,31 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       }
       fletcherUnit(y, a ? (a - 14u) / 2u : 65528ull, fA, fB);             // (the first unit's index -7 as its residue mod 65535)
     }
-    // the scan, first half: does the unit hold "a byte 64 behind a byte 10......" at all?  One unit in six does; those go to
-    // the wave's own stretch of the queue (a ballot, no atomic), and the step below looks at them byte by byte.  (The byte in front of a
-    // wave's first unit belongs to another wave: taken for 10......, it lets the unit through if its first byte is 64.)
+    // the scan, first half: may the unit hold a count byte at all?  Those that may go to the wave's own stretch of the queue (a ballot,
+    // no atomic), and the step below looks at them byte by byte.  An unmasked band: "holds a byte 64" -- three instructions a dword
+    // (x ^ 0x40..., the zero byte test (t - 0x01...) & ~t, which may also flag the byte above a zero byte: a filter), one unit in five
+    // passes, a wave's queued units still fit one round of lanes as good as always; that the byte in front reads 10...... is left
+    // to the exact test (in the filter it cost three times as much as it saved).  A masked band: a byte 1 ... 64 behind a byte
+    // 10...... (the byte in front of a wave's first unit belongs to another wave: taken for 10......).
     {
-      u32 pv = dppMov<kDppWaveShr1>(x[k].w);
-      if (lane == 0) pv = 0x80000000u;
-      const u32 z = countByteMaybe<OFFS>(x[k].x, pv) & countByteMaybe<OFFS>(x[k].y, x[k].x) & countByteMaybe<OFFS>(x[k].z, x[k].y) & countByteMaybe<OFFS>(x[k].w, x[k].z);
-      const bool has = (z & 0x80808080u) != 0x80808080u && i < G::kScanUnits && 16u * i < blobRel;    // (what lies behind the blob in the caller's buffer is not looked at)
+      bool has;
+      if (!OFFS)
+      {
+        u32 acc = 0u;
+        { const u32 t = x[k].x ^ 0x40404040u; acc |= (t - 0x01010101u) & ~t; }
+        { const u32 t = x[k].y ^ 0x40404040u; acc |= (t - 0x01010101u) & ~t; }
+        { const u32 t = x[k].z ^ 0x40404040u; acc |= (t - 0x01010101u) & ~t; }
+        { const u32 t = x[k].w ^ 0x40404040u; acc |= (t - 0x01010101u) & ~t; }
+        has = (acc & 0x80808080u) != 0u;
+      }
+      else
+      {
+        u32 pv = dppMov<kDppWaveShr1>(x[k].w);
+        if (lane == 0) pv = 0x80000000u;
+        const u32 z = countByteMaybe<OFFS>(x[k].x, pv) & countByteMaybe<OFFS>(x[k].y, x[k].x) & countByteMaybe<OFFS>(x[k].z, x[k].y) & countByteMaybe<OFFS>(x[k].w, x[k].z);
+        has = (z & 0x80808080u) != 0x80808080u;
+      }
+      has = has && i < G::kScanUnits && 16u * i < blobRel;    // (what lies behind the blob in the caller's buffer is not looked at)
       const u64 bal = __builtin_amdgcn_ballot_w64(has);
       const u32 slot = nMine + (u32)__popcll(bal & laneMaskLt());
       if (has && slot < kQueueSeg) s_queue[(u32)w * kQueueSeg + slot] = (u16)i;
@@ -335,20 +364,22 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     }
   }
   {
-    // (no reduction mod 65535 before the sums: a lane holds 5 units, A < 2^23 and B < 2^54 per lane)
-    const u64 A = waveSum(fA), B = waveSum(fB);
+    // (a lane holds 5 units, A < 2^23 and B < 2^54 per lane; the sums are wanted mod 65535 and 2^16 = 1 there: folded to 32 bits
+    // first -- a wave's sum of the folds stays below 2^24 -- the reductions are DPP adds, and nobody divides)
+    const u32 A = waveSum(fold65535(fA)), B = waveSum(fold65535(fB));
     if (lane == 0) { S.fa[w] = A; S.fb[w] = B; S.qn[w] = nMine; }
   }
   __syncthreads();
   TRACES(1);
+  DEC_EXIT(1);
   if (!OFFS && !S.hp.ok) return;    // (not a band the streaming kernels take: the header says so in full only)
   if (!OFFS && threadIdx.x == 0)
   {
     // this workgroup's checksum terms: one atomic nobody waits for (the launch's last workgroup folds the accumulators)
-    u64 A = 0, B = 0;
+    u32 A32 = 0, B32 = 0;
 #pragma unroll
-    for (u32 k = 0; k < kWaves; k++) { A += S.fa[k]; B += S.fb[k]; }
-    A %= 65535u; B %= 65535u;
+    for (u32 k = 0; k < kWaves; k++) { A32 += (u32)S.fa[k]; B32 += (u32)S.fb[k]; }
+    const u64 A = fold65535(A32), B = fold65535(B32);    // (congruent, below 2^17: a group's 64 terms fit the accumulator's 24-bit fields)
     if (wg == 0u) drainVmem();    // (the band's parameters have arrived)
     __hip_atomic_fetch_add(b.wgAcc + wg / kOneGroup, A | (B << 24) | (1ull << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -476,6 +507,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   }
   __syncthreads();
   TRACES(2);
+  DEC_EXIT(2);
 
   // ---- survivors of the piece's own bytes: a thread's two bitmap words; their list by popcounts and one scan
   const u32 myWord = G::kOwnWord0 + 2u * threadIdx.x;
@@ -511,6 +543,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   };
   buildList();
   TRACES(3);
+  DEC_EXIT(3);
 
   // ---- every block's header in full, lane = block: length, mode, bits, offset (ReadTile's and BitStuffer2::Decode's checks), and
   // "the blocks tile the stream": a block ends where the next one of the list begins, the last one behind the piece (the
@@ -708,6 +741,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   };
   tilePass(0u, false);
   TRACES(4);
+  DEC_EXIT(4);
 
   // ---- A masked band has RUNS of one-byte blocks (pixels all invalid, Lerc2.h:422) which the scan cannot see, and behind each run a
   // block without an END.  They are found by a FLOOD over the bitmaps: a byte that reads like such a block (mode 2; bit 2 clear from
@@ -1181,6 +1215,18 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   }
   __syncthreads();
   TRACES(5);
+  if (LERC_DEC_EXIT == 5)    // (the held vectors are kept alive)
+  {
+#pragma unroll
+    for (u32 j = 0; j < kHeld; j++)
+    {
+      u32 w4[sizeof(Vec) / 4];
+      memcpy(w4, &held[j], sizeof(Vec));
+#pragma unroll
+      for (u32 q = 0; q < sizeof(Vec) / 4; q++) asm volatile("" :: "v"(w4[q]));
+    }
+    return;
+  }
   if (S.lost)    // gave up waiting (never seen; the general path takes the band)
   {
     if (threadIdx.x == 0) raiseFlag(b, 3);

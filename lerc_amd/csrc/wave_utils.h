@@ -219,6 +219,21 @@ __device__ __forceinline__ void rowMinMax(float& mn, float& mx)
 #endif
 }
 
+// minimum and maximum of a lane's four float values: v_min3 / v_max3 + one step, four instructions (through fminf / fmaxf hipcc puts a
+// v_max x, x in front of the first two operands to quiet signalling NaNs: six); results as OpMin / OpMax give them
+__device__ __forceinline__ void laneMinMax4(float a, float b, float c, float d, float& mn, float& mx)
+{
+#ifdef HIPSIM
+  mn = __builtin_fminf(__builtin_fminf(a, b), __builtin_fminf(c, d)); mx = __builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(c, d));
+#else
+  float t, u;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(a), "v"(b), "v"(c));
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u) : "v"(a), "v"(b), "v"(c));
+  asm("v_min_f32 %0, %1, %2" : "=v"(mn) : "v"(t), "v"(d));
+  asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(u), "v"(d));
+#endif
+}
+
 // whole-wave all-reduces (32- and 64-bit payloads)
 template<class T> __device__ __forceinline__ T waveMin(T v) { return groupReduce<64>(v, OpMin()); }
 template<class T> __device__ __forceinline__ T waveMax(T v) { return groupReduce<64>(v, OpMax()); }
@@ -304,6 +319,11 @@ __device__ __forceinline__ u32 dot2u16(u32 a, u32 b, u32 c)
   return __builtin_amdgcn_udot2(x, y, c, false);
 #endif
 }
+// Fletcher sums are wanted mod 65535 only, and 2^16 = 1 (mod 65535): a sum's 16-bit digits added up are congruent to it.  64 bits
+// come down to less than 2^18, 32 bits to less than 2^17 -- small enough for a wave's (a workgroup's) sums to stay in 32 bits, where a
+// reduction step is one DPP add, and no division anywhere.
+__device__ __forceinline__ u32 fold65535(u32 x) { return (x & 0xFFFFu) + (x >> 16); }
+__device__ __forceinline__ u32 fold65535(u64 x) { const u32 lo = (u32)x, hi = (u32)(x >> 32); return (lo & 0xFFFFu) + (lo >> 16) + (hi & 0xFFFFu) + (hi >> 16); }
 __device__ __forceinline__ void fletcherUnit(const uint4& x, u64 k0, u32& A, u64& B)
 {
   const u32 w0 = __builtin_amdgcn_perm(x.x, x.x, 0x02030001u), w1 = __builtin_amdgcn_perm(x.y, x.y, 0x02030001u);
