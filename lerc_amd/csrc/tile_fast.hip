@@ -1280,7 +1280,11 @@ fusedFlush(const u32* s_out, u32 kLead, u32 g0, u32 spanLen, u8* __restrict__ ou
     // (gAligned + 16 u >= 16 > 14 always holds here because spans start behind the >= 95-byte prefix)
     fletcherUnit(x, (u64)((gAligned + 16u * u - 14u) >> 1), A, B);
     const u32 lo = 16u * u;
+#ifdef LERC_TUNE_WRAP_STORES    // (tuning: the blob written into its first 4 MB over and over -- what the kernel takes without HBM writes; results invalid)
+    if (fits && lo >= ldsShift && lo + 16u <= spanEnd) *reinterpret_cast<uint4*>(out + ((gAligned + lo) & ((1u << 22) - 16u))) = x;
+#else
     if (fits && lo >= ldsShift && lo + 16u <= spanEnd) *reinterpret_cast<uint4*>(out + gAligned + lo) = x;    // (k_fast_discover reads them next: no streaming hint)
+#endif
   }
   // the span's two ragged ends (units shared with the neighbouring spans): lane = byte, sixteen lanes an end, outside the loop --
   // inside it every wave that holds such a unit paid for sixteen predicated byte stores, and two lanes going through their bytes
@@ -1497,7 +1501,11 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       {
         vcA[a][t] = V; bwA[a][t] = 8;
         const i64 at = laneOrigin<WIDE, BPW, V>(span[a], t * 4 + w, r, c, p.nCols);
+#ifdef LERC_TUNE_WRAP_LOADS    // (tuning: every pixel read out of the raster's first 4 MB -- what the kernel takes without HBM reads; results invalid)
+        loadLane<T, V>(data + (at & (i64)((1 << 20) - 1)), v[a][t], true);
+#else
         loadLane<T, V>(data + at, v[a][t], true);
+#endif
         if constexpr (MASKED)
         {
           // (columns are multiples of 8 and a lane's first column one of V: its V bits lie in one byte, most significant first)
@@ -1736,13 +1744,15 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
     if (!haveUnit || !fastSpanHas(span[a], (u32)lane)) { pl.nBytes = 0; pl.kind = 7; }    // behind the raster's last block: nothing to write
     const int nb = bitLen(qMax);
     const u32 sz = (u32)pl.nBytes;
-    u32 inc = sz;
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(inc, (unsigned)dd); if (lane >= dd) inc += o; }
+    const u32 inc = waveInclusiveScan(sz);
     // (where the block begins in the span image -- a bit-stuffed block without a table: where its PAYLOAD begins, behind flag byte, offset,
     // bits byte and count: the pixel owners then need nothing of the header's layout)
     s_w1[a][lane] = packDesc(pl, nb); s_bit[a][lane] = 8u * (kLead + inc - sz + (pl.kind == 3 ? 3u + (u32)dtSize3((u32)pl.dtRed) : 0u));
+#ifdef HIPSIM
     const u32 total = (u32)__shfl((int)inc, 63);
+#else
+    const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, 63);    // (the last lane's: into a scalar register, no LDS permute)
+#endif
     // (blocks behind the raster's end repeat the last block's range: they change nothing)
     u64 kMin, kMax;
     if (sizeof(T) <= 4)    // (the keys of these types have 34 bits at most: reduce the value, order-preserving in 32 bits, encode once)

@@ -22,7 +22,11 @@ __device__ __forceinline__ void raiseFlag(const FastDecodeBuffers& b, int k)
 // way they sit dirty in L2 / the Infinity Cache until the NEXT kernel's traffic pushes them out (measured on C2: this
 // kernel 79 -> 71 us, the statistics pass of the following encode 77 -> 53 us).  The same hint on the blob loads here or in
 // k_fast_discover costs 5-8 us: those bytes were just written by the kernel in front and are still on the die.
+#ifdef LERC_DECODE_PLAIN_STORES    // (tuning: the pixels written the ordinary way)
+#define DECODE_STORE(ptr, val) (*(ptr) = (val))
+#else
 #define DECODE_STORE(ptr, val) storeStreaming(ptr, val)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // block header parsing, branch free

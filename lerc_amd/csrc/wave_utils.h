@@ -257,12 +257,26 @@ __device__ __forceinline__ void orBits(u32* words, u32 bitPos, u32 value, int nb
   if (sh + (u32)nbits > 32) atomicOr(&words[w + 1], value >> (32 - sh));
 }
 
+// Inclusive sum scan over the wave.  In the VALU: four shifts inside a row of 16 lanes and two row broadcasts (lane 15 of a row into
+// the next row, lane 31 into the upper half), six v_add_u32_dpp -- through __shfl_up every step is an LDS permute with its round
+// trip, a select and an add, and the scan sits on the critical path of the encoder's plan wave and the decoder's list.
 __device__ __forceinline__ u32 waveInclusiveScan(u32 v)
 {
+#ifdef HIPSIM
   const int lane = laneId();
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { u32 t = __shfl_up(v, (unsigned)d); if (lane >= d) v += t; }
   return v;
+#else
+  // (a lane without a source adds the "old" operand, 0)
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);    // row_shr:1
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);    // row_shr:2
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);    // row_shr:4
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);    // row_shr:8
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);    // row_bcast:15 into rows 1 and 3
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);    // row_bcast:31 into rows 2 and 3
+  return v;
+#endif
 }
 
 // Exclusive scan of in[0 .. n) into out[0 .. n], out[n] = total, by ONE workgroup of 1024 threads: thread t owns a
