@@ -65,8 +65,11 @@ extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_deco
 #ifndef LERC_SCAN_SLEEP
 #define LERC_SCAN_SLEEP 4
 #endif
+#ifndef LERC_SCAN_WIDE
+#define LERC_SCAN_WIDE 1
+#endif
 #ifndef LERC_SCAN_HELD
-#define LERC_SCAN_HELD 6
+#define LERC_SCAN_HELD (LERC_SCAN_WIDE ? 4 : 6)    // (a lane of eight pixels has more in flight while it decodes: two wide vectors are what 80 registers hold)
 #endif
 #ifndef LERC_SCAN_HELD32
 #define LERC_SCAN_HELD32 4
@@ -1101,9 +1104,18 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   // PIXELS are taken out of the stream: what a block's pixels ARE does not hang on where the block lies -- only where they go
   // does.  A wave takes BPW blocks of the list at a time, a lane V consecutive pixels of one row of one block, and keeps up to
   // kHeld such 16-byte vectors in registers; they are stored when the places are known.
-  struct alignas(sizeof(T) * V) Vec { T e[V]; };
-  constexpr u32 kHeld = sizeof(T) == 2 ? LERC_SCAN_HELD16 : (DT == DT_Float || DT == DT_Double) ? LERC_SCAN_HELD : LERC_SCAN_HELD32;
-  const int r = lane >> 3, c = lane & 7, bb = c / LPR, h = c % LPR;
+  // float: a lane takes TWO vectors of its block -- the same four columns of row r and of row r + 4 -- so that what a lane does per block
+  // (the block's word, offset and place out of LDS, bit width, mask, payload position, the address) is done once for eight pixels instead
+  // of once for four; a wave tile is 8 blocks, a store instruction 4 raster rows of 256 bytes on end.  (The two vectors of one block ROW
+  // in a lane were tried first: every store instruction then writes every other 16 bytes, and the kernel took 125 us instead of 100.)
+  constexpr int NV = (LERC_SCAN_WIDE && DT == DT_Float) ? 2 : 1;       // vectors a lane (32-bit integers: their 64-bit dequantiser leaves no registers for it)
+  constexpr int PXL = V * NV, BPWL = BPW * NV;                          // pixels a lane, blocks a wave tile
+  constexpr int RSTEP = 8 / NV;                                         // rows between a lane's vectors
+  struct alignas(sizeof(T) * V) Vec1 { T e[V]; };
+  struct alignas(sizeof(T) * V) Vec { T e[PXL]; };
+  constexpr u32 kHeldV = sizeof(T) == 2 ? LERC_SCAN_HELD16 : (DT == DT_Float || DT == DT_Double) ? LERC_SCAN_HELD : LERC_SCAN_HELD32;
+  constexpr u32 kHeld = kHeldV / (u32)NV;                               // (as many registers)
+  const int r = lane / (8 * NV), c = lane % (8 * NV), bb = c / LPR, h = c % LPR;    // row (of the lane's first vector), block of the wave tile, vector of the block row
   const i64 invI = (i64)p.invScale, zMaxI = (i64)p.zMaxHdr;
   bool bad = false;
   // the lane's V pixels of the block in round slot tSlot (parseBlock's word and offset); a wave-uniform fast path for the common
@@ -1118,24 +1130,28 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     const int e0 = r * 8 + h * V;
     Vec o;
 #pragma unroll
-    for (int k = 0; k < V; k++) o.e[k] = T(0);
+    for (int k = 0; k < PXL; k++) o.e[k] = T(0);
     const bool plain = ((code >> 24) & 1u) != 0u;
     if (__all(plain || !code))
     {
       if (code)
       {
         const u32 nb = nbC;
-        const u32 bit0 = pbit + (u32)e0 * nb, wi = bit0 >> 5;
-        const u32 x0 = s_in[wi], x1 = s_in[wi + 1], x2 = s_in[wi + 2];
-        const u64 all = ((u64)__builtin_amdgcn_alignbit(x2, x1, bit0) << 32) | __builtin_amdgcn_alignbit(x1, x0, bit0);
         const u32 mask = nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
         const i64 offI = (i64)offset;
 #pragma unroll
-        for (int k = 0; k < V; k++)
+        for (int hv = 0; hv < NV; hv++)    // (a vector's V values lie inside 64 bits: three words of the stream, a funnel shift each way)
         {
-          const u32 q = (u32)(all >> ((u32)k * nb)) & mask;
-          if (DT >= DT_Float) o.e[k] = (T)(offset + (double)q * p.invScale);    // Lerc2.cpp:2159-2160, no contraction
-          else o.e[k] = (T)(offI + (i64)q * invI);
+          const u32 bit0 = pbit + (u32)(e0 + hv * 8 * RSTEP) * nb, wi = bit0 >> 5;
+          const u32 x0 = s_in[wi], x1 = s_in[wi + 1], x2 = s_in[wi + 2];
+          const u64 all = ((u64)__builtin_amdgcn_alignbit(x2, x1, bit0) << 32) | __builtin_amdgcn_alignbit(x1, x0, bit0);
+#pragma unroll
+          for (int k = 0; k < V; k++)
+          {
+            const u32 q = (u32)(all >> ((u32)k * nb)) & mask;
+            if (DT >= DT_Float) o.e[hv * V + k] = (T)(offset + (double)q * p.invScale);    // Lerc2.cpp:2159-2160, no contraction
+            else o.e[hv * V + k] = (T)(offI + (i64)q * invI);
+          }
         }
       }
     }
@@ -1144,9 +1160,9 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       if (mode == 0)
       {
 #pragma unroll
-        for (int k = 0; k < V; k++)
+        for (int k = 0; k < PXL; k++)
         {
-          const u32 bp = pbit + (u32)(e0 + k) * 8u * (u32)sizeof(T);
+          const u32 bp = pbit + (u32)(e0 + (k / V) * 8 * RSTEP + k % V) * 8u * (u32)sizeof(T);
           u64 bits = ldsBits(s_in, bp, 32);
           if (sizeof(T) == 8) bits |= (u64)ldsBits(s_in, bp + 32, 32) << 32;
           else if (sizeof(T) < 4) bits &= (1ull << (8 * sizeof(T))) - 1;
@@ -1156,7 +1172,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       else if (mode == 3)
       {
 #pragma unroll
-        for (int k = 0; k < V; k++) o.e[k] = (T)offset;
+        for (int k = 0; k < PXL; k++) o.e[k] = (T)offset;
       }
       else if (mode == 1)
       {
@@ -1165,8 +1181,8 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
         if (!lut)
         {
 #pragma unroll
-          for (int k = 0; k < V; k++)
-            o.e[k] = dequant<T>(offset, ldsBits(s_in, pbit + (u32)(e0 + k) * (u32)nb, nb), p.invScale, p.zMaxHdr, offI, invI, zMaxI);
+          for (int k = 0; k < PXL; k++)
+            o.e[k] = dequant<T>(offset, ldsBits(s_in, pbit + (u32)(e0 + (k / V) * 8 * RSTEP + k % V) * (u32)nb, nb), p.invScale, p.zMaxHdr, offI, invI, zMaxI);
         }
         else
         {
@@ -1174,9 +1190,9 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
           const int nbIdx = bitLen(nLut);
           const u32 idxBit = pbit + 8u * ((nLut * (u32)nb + 7) >> 3);
 #pragma unroll
-          for (int k = 0; k < V; k++)
+          for (int k = 0; k < PXL; k++)
           {
-            u32 ix = ldsBits(s_in, idxBit + (u32)(e0 + k) * (u32)nbIdx, nbIdx);
+            u32 ix = ldsBits(s_in, idxBit + (u32)(e0 + (k / V) * 8 * RSTEP + k % V) * (u32)nbIdx, nbIdx);
             if (ix > nLut) { ix = 0; bad = true; }    // the reference would read outside its table here
             const u32 q = ix ? ldsBits(s_in, pbit + (ix - 1) * (u32)nb, nb) : 0u;
             o.e[k] = dequant<T>(offset, q, p.invScale, p.zMaxHdr, offI, invI, zMaxI);
@@ -1196,8 +1212,8 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
 #pragma unroll
   for (u32 j = 0; j < kHeld; j++)
   {
-    const u32 f = (u32)BPW * ((u32)w + kWaves * j) + (u32)bb;
-    if ((u32)BPW * ((u32)w + kWaves * j) < nFirst) held[j] = blockRow(f, f < nFirst);    // (the same for all lanes of the wave)
+    const u32 f = (u32)BPWL * ((u32)w + kWaves * j) + (u32)bb;
+    if ((u32)BPWL * ((u32)w + kWaves * j) < nFirst) held[j] = blockRow(f, f < nFirst);    // (the same for all lanes of the wave)
   }
   {
     u64 part = 0;
@@ -1282,7 +1298,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   for (u32 fLo = 0; fLo < total; )
   {
     // (no vectors held: the rounds are cut on multiples of BPW blocks of the RASTER, like the wave tiles below)
-    const u32 fHi = kHeld ? min(total, fLo + R) : min(total, ((base + fLo + R) / (u32)BPW) * (u32)BPW - base);
+    const u32 fHi = kHeld ? min(total, fLo + R) : min(total, ((base + fLo + R) / (u32)BPWL) * (u32)BPWL - base);
     {
       const u32 f = fLo + threadIdx.x;
       if (f < fHi)
@@ -1304,19 +1320,32 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     {
       const u32 at0 = s_at[tSlot];
 #ifdef LERC_TUNE_WRAP_STORES    // (tuning: the pixels written into the raster's first 4 MB over and over -- what the kernel takes without HBM writes; results invalid)
-      if (at0 != kNoOffset) *reinterpret_cast<Vec*>(outPix + (((size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)) & (size_t)((1u << 20) - 1u))) = o;
+      if (at0 != kNoOffset)
+      {
+#pragma unroll
+        for (int hv = 0; hv < NV; hv++)
+        {
+          T* dst = outPix + (((size_t)at0 + (size_t)(r + hv * RSTEP) * (size_t)p.nCols + (size_t)(h * V)) & (size_t)((1u << 20) - 1u));
+          Vec1 v1; memcpy(&v1, &o.e[hv * V], sizeof(Vec1)); *reinterpret_cast<Vec1*>(dst) = v1;
+        }
+      }
 #else
-      if (at0 != kNoOffset) DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
+      if (at0 != kNoOffset)
+      {
+        T* dst = outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V);
+#pragma unroll
+        for (int hv = 0; hv < NV; hv++) { Vec1 v1; memcpy(&v1, &o.e[hv * V], sizeof(Vec1)); DECODE_STORE(reinterpret_cast<Vec1*>(dst + (size_t)(hv * RSTEP) * (size_t)p.nCols), v1); }
+      }
 #endif
     };
     if (kHeld == 0u)
     {
       // wave tiles on multiples of BPW blocks of the raster: a tile row is a whole 128-byte line of the output
       const u32 blkLo = base + fLo, blkHi = base + fHi;
-      const u32 g1 = (blkHi + BPW - 1) / BPW;
-      for (u32 g = blkLo / BPW + (u32)w; g < g1; g += kWaves)
+      const u32 g1 = (blkHi + BPWL - 1) / BPWL;
+      for (u32 g = blkLo / BPWL + (u32)w; g < g1; g += kWaves)
       {
-        const u32 blk = g * BPW + (u32)bb;
+        const u32 blk = g * BPWL + (u32)bb;
         const bool have = blk >= blkLo && blk < blkHi;
         const u32 tSlot = have ? blk - blkLo : 0u;     // (the tile's blocks outside the round: lanes that do nothing)
         const Vec o = blockRow(tSlot, have);
@@ -1332,14 +1361,14 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
 #pragma unroll
       for (u32 j = 0; j < kHeld; j++)
       {
-        const u32 tSlot = (u32)BPW * ((u32)w + kWaves * j) + (u32)bb;
+        const u32 tSlot = (u32)BPWL * ((u32)w + kWaves * j) + (u32)bb;
         if (tSlot < nRound) store(tSlot, held[j]);
       }
       jFrom = kHeld;
     }
-    for (u32 g = (u32)w + kWaves * jFrom; g * (u32)BPW < nRound; g += kWaves)
+    for (u32 g = (u32)w + kWaves * jFrom; g * (u32)BPWL < nRound; g += kWaves)
     {
-      const u32 tSlot = g * (u32)BPW + (u32)bb;
+      const u32 tSlot = g * (u32)BPWL + (u32)bb;
       const Vec o = blockRow(tSlot, tSlot < nRound);
       if (tSlot < nRound) store(tSlot, o);
     }
