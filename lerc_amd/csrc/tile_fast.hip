@@ -49,6 +49,9 @@ extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace(unsi
 #define TRACE_ID()
 #endif
 
+#ifndef LERC_ENC_WIDE
+#define LERC_ENC_WIDE 0    // (tuning: two vectors a lane in the one-launch encoder -- 8 % fewer vector instructions, but the float kernel no longer fits 64 registers: a pixel vector goes to scratch right behind its load, 90 -> 108 us)
+#endif
 // tuning: LERC_ENC_EXIT=n builds an encoder that leaves at mark n (profiles/r06_notes.md: instruction counts per phase); results are invalid
 #ifndef LERC_ENC_EXIT
 #define LERC_ENC_EXIT 99
@@ -1439,8 +1442,14 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
                 FastFused f, double requestedMaxZErr, u32 raiseCandidates, u64 outCapacity)
 {
   typedef FastCfg<T> C;
-  constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW, IT = C::IT;
-  constexpr int LB = 8 * LPR;                // lanes of a block: lane = b * LB + r * LPR + h (block of the wave tile, row, lane of the row)
+  constexpr int V = C::V, LPR = C::LPR;
+  // float rasters without a mask whose sides are multiples of 8: a lane holds TWO vectors of its block -- the same columns of row r and of
+  // row r + 4 -- so that what is done per lane and block (the reduction steps across the block's lanes, the block's words out of LDS, the
+  // place of its payload) is done once for eight pixels; a block is 8 lanes, a wave tile 8 blocks
+  constexpr int NV = (LERC_ENC_WIDE && !PART && !MASKED && std::is_same<T, float>::value) ? 2 : 1;
+  constexpr int VX = V * NV, RSTEP = 8 / NV;   // pixels of a lane; raster rows between its vectors
+  constexpr int LB = 8 * LPR / NV;             // lanes of a block: lane = b * LB + r * LPR + h (block of the wave tile, row of the lane's first vector, lane of the row)
+  constexpr int BPW = 64 / LB, IT = kFastBlocksPerWG / (4 * BPW);
   constexpr int DT = DtOf<T>::v;
   typedef typename ShflT<T>::type ST;
   static_assert(U >= 1 && U <= 4, "a plan wave per unit");
@@ -1486,7 +1495,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
 
   // ---- the pixels of all units: every load of the wave in flight first (non-temporal: nothing reads them again), the span
   // image is zeroed while they travel
-  T v[U][IT][V];
+  T v[U][IT][VX];
   // PART: pixels of this lane that exist (a prefix of its V: 0 .. V) and the width of its block, per wave tile
   int vcA[U][IT], bwA[U][IT];
   u32 vmA[U][IT];    // MASKED: bit k = pixel k of the lane is valid
@@ -1496,16 +1505,21 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
 #pragma unroll
     for (int t = 0; t < IT; t++)
     {
-      vmA[a][t] = (1u << V) - 1u;
+      vmA[a][t] = (1u << VX) - 1u;
       if constexpr (!PART)
       {
-        vcA[a][t] = V; bwA[a][t] = 8;
+        vcA[a][t] = VX; bwA[a][t] = 8;
         const i64 at = laneOrigin<WIDE, BPW, V>(span[a], t * 4 + w, r, c, p.nCols);
+#pragma unroll
+        for (int hv = 0; hv < NV; hv++)
+        {
+          const i64 atv = at + (i64)(hv * RSTEP) * p.nCols;
 #ifdef LERC_TUNE_WRAP_LOADS    // (tuning: every pixel read out of the raster's first 4 MB -- what the kernel takes without HBM reads; results invalid)
-        loadLane<T, V>(data + (at & (i64)((1 << 20) - 1)), v[a][t], true);
+          loadLane<T, V>(data + (atv & (i64)((1 << 20) - 1)), reinterpret_cast<T (&)[V]>(v[a][t][hv * V]), true);
 #else
-        loadLane<T, V>(data + at, v[a][t], true);
+          loadLane<T, V>(data + atv, reinterpret_cast<T (&)[V]>(v[a][t][hv * V]), true);
 #endif
+        }
         if constexpr (MASKED)
         {
           // (columns are multiples of 8 and a lane's first column one of V: its V bits lie in one byte, most significant first)
@@ -1556,7 +1570,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
 #pragma unroll
       for (int t = 0; t < IT; t++)
 #pragma unroll
-        for (int k = 0; k < V; k++) { const u32 bits32 = (u32)rawBits<T>(v[a][t][k]); asm volatile("" :: "v"(bits32)); }
+        for (int k = 0; k < VX; k++) { const u32 bits32 = (u32)rawBits<T>(v[a][t][k]); asm volatile("" :: "v"(bits32)); }
     return;
   }
 
@@ -1570,17 +1584,17 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
     for (int t = 0; t < IT; t++)
     {
       const int tile = t * 4 + w;
-      const T (&x)[V] = v[a][t];
+      const T (&x)[VX] = v[a][t];
       const int vc = vcA[a][t];    // (V unless PART; pixels that do not exist were loaded as 0: neither NaN nor fractional)
       const u32 vm = vmA[a][t];    // (all ones unless MASKED)
       if (DT >= DT_Float)
       {
 #pragma unroll
-        for (int k = 0; k < V; k++) sawNaN = sawNaN | ((!MASKED || ((vm >> k) & 1u)) & isNaNv(x[k]));
+        for (int k = 0; k < VX; k++) sawNaN = sawNaN | ((!MASKED || ((vm >> k) & 1u)) & isNaNv(x[k]));
         if (!sawFrac)    // one fractional value settles "not all integers" for good
         {
 #pragma unroll
-          for (int k = 0; k < V; k++) sawFrac = sawFrac | ((!MASKED || ((vm >> k) & 1u)) & notIntegral(x[k]));
+          for (int k = 0; k < VX; k++) sawFrac = sawFrac | ((!MASKED || ((vm >> k) & 1u)) & notIntegral(x[k]));
         }
       }
       T mn, mx;
@@ -1593,7 +1607,8 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       }
       else if constexpr (!PART)
       {
-        if constexpr (std::is_same<T, float>::value) laneMinMax4(x[0], x[1], x[2], x[3], mn, mx);
+        if constexpr (std::is_same<T, float>::value && NV == 2) laneMinMax8(x, mn, mx);
+        else if constexpr (std::is_same<T, float>::value) laneMinMax4(x[0], x[1], x[2], x[3], mn, mx);
         else
         {
           mn = x[0]; mx = x[0];
@@ -1608,7 +1623,8 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
 #pragma unroll
         for (int k = 0; k < V; k++) if (k < vc) { mn = OpMin()(mn, x[k]); mx = OpMax()(mx, x[k]); }
       }
-      if constexpr (std::is_same<T, float>::value) rowMinMax(mn, mx);    // (LB == 16)
+      if constexpr (std::is_same<T, float>::value && LB == 8) halfRowMinMax(mn, mx);
+      else if constexpr (std::is_same<T, float>::value) rowMinMax(mn, mx);    // (LB == 16)
       else
       {
         mn = (T)groupReduce<LB>((ST)mn, OpMin());
@@ -1644,8 +1660,14 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         bool maybe;
         if constexpr (V == 4)
         {
-          const u64 e1 = __ballot(x[1] == x[0]), e2 = __ballot(x[2] == x[1]), e3 = __ballot(x[3] == x[2]);
-          maybe = ((e1 & e2) | (e2 & e3) | (e1 & e3)) != 0ull;
+          u64 two = 0ull;    // lanes with two of the three comparisons inside a vector equal
+#pragma unroll
+          for (int hv = 0; hv < NV; hv++)
+          {
+            const u64 e1 = __ballot(x[hv * V + 1] == x[hv * V]), e2 = __ballot(x[hv * V + 2] == x[hv * V + 1]), e3 = __ballot(x[hv * V + 3] == x[hv * V + 2]);
+            two |= (e1 & e2) | (e2 & e3) | (e1 & e3);
+          }
+          maybe = two != 0ull;    // (two vectors a lane: above the average takes five of eight, of which two look at another lane -- three of six, so two of one vector's three)
           same = 0;
         }
         else
@@ -1658,11 +1680,22 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         lutCand = false;
         if (maybe)
         {
-          T prev = (T)dppMovT<kDppWaveShr1>((ST)x[V - 1]);    // the previous pixel vector of the block lives in the previous lane
-          if (leader) prev = T(0);
-          same = (x[0] == prev) ? 1 : 0;
+          same = 0;
 #pragma unroll
-          for (int k = 1; k < V; k++) same += (x[k] == x[k - 1]) ? 1 : 0;
+          for (int hv = 0; hv < NV; hv++)
+          {
+            T prev = (T)dppMovT<kDppWaveShr1>((ST)x[hv * V + V - 1]);    // the previous pixel vector of the block row lives in the previous lane
+            if constexpr (NV == 2)
+            {
+              // (the block's first lane: nothing in front of row 0; in front of row RSTEP the last pixel of row RSTEP - 1, the block's last lane's)
+              const T wrap = shflT<T>(x[V - 1], (lane + LB - 1) & 63);
+              if (leader) prev = hv == 0 ? T(0) : wrap;
+            }
+            else if (leader) prev = T(0);
+            same += (x[hv * V] == prev) ? 1 : 0;
+#pragma unroll
+            for (int k = 1; k < V; k++) same += (x[hv * V + k] == x[hv * V + k - 1]) ? 1 : 0;
+          }
           lutCand = __any(same > 32 / LB);
         }
       }
@@ -1691,8 +1724,8 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         {
           const double mv = ((double)mx - (double)mn) * p.scale;
           const bool need = tryLut && !(mv > (double)p.maxQ || (u32)(mv + 0.5) == 0);
-          u32 q[V];
-          quantizeLane<T, V>(p.intLossless, p.scale, x, mn, q);
+          u32 q[VX];
+          quantizeLane<T, VX>(p.intLossless, p.scale, x, mn, q);
           if constexpr (PART)
           {
 #pragma unroll
@@ -1703,7 +1736,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
 #pragma unroll
             for (int k = 0; k < V; k++) if (!((vm >> k) & 1u)) q[k] = 0xFFFFFFFFu;
           }
-          nd = groupDistinct<LB, V>(q, need);
+          nd = groupDistinct<LB, VX>(q, need);
         }
       }
       else same = 0;
@@ -1858,8 +1891,8 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       {
         const int nb = (int)(w1 >> 24);
         const T mn = s_mnT[a][blk];
-        u32 q[V];
-        quantizeLane<T, V>(p.intLossless, p.scale, v[a][t], mn, q);
+        u32 q[VX];
+        if constexpr (NV == 1) quantizeLane<T, VX>(p.intLossless, p.scale, v[a][t], mn, q);
         if constexpr (PART)
         {
 #pragma unroll
@@ -1886,25 +1919,37 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         else if (V * nb <= 64)
         {
           // (nb <= 16 here for V >= 4: pairs fit a 32-bit word, one 64-bit shift in all instead of one per value)
-          u64 s = 0;
-          if (V == 4) s = (u64)(q[0] | (q[1] << nb)) | ((u64)(q[2] | (q[3] << nb)) << (2 * nb));
-          else if (V == 8)
-          {
-            const u32 p0 = q[0] | (q[1] << nb), p1 = q[2] | (q[3] << nb), p2 = q[4] | (q[5] << nb), p3 = q[6] | (q[7] << nb);    // nb <= 8
-            s = (u64)(p0 | (p1 << (2 * nb))) | ((u64)(p2 | (p3 << (2 * nb))) << (4 * nb));
-          }
-          else
-          {
 #pragma unroll
-            for (int k = 0; k < V; k++) s |= (u64)q[k] << (k * nb);
+          for (int hv = 0; hv < NV; hv++)
+          {
+            // (two vectors a lane: one after the other -- quantised, packed and gone before the next one's values take registers)
+            if constexpr (NV == 2) quantizeLane<T, V>(p.intLossless, p.scale, reinterpret_cast<const T (&)[V]>(v[a][t][hv * V]), mn, reinterpret_cast<u32 (&)[V]>(q[hv * V]));
+            const u32* qv = &q[hv * V];
+            u64 s = 0;
+            if (V == 4) s = (u64)(qv[0] | (qv[1] << nb)) | ((u64)(qv[2] | (qv[3] << nb)) << (2 * nb));
+            else if (V == 8)
+            {
+              const u32 p0 = qv[0] | (qv[1] << nb), p1 = qv[2] | (qv[3] << nb), p2 = qv[4] | (qv[5] << nb), p3 = qv[6] | (qv[7] << nb);    // nb <= 8
+              s = (u64)(p0 | (p1 << (2 * nb))) | ((u64)(p2 | (p3 << (2 * nb))) << (4 * nb));
+            }
+            else
+            {
+#pragma unroll
+              for (int k = 0; k < V; k++) s |= (u64)qv[k] << (k * nb);
+            }
+            orBits64(s_out, at + (u32)(e0 + hv * 8 * RSTEP) * (u32)nb, s, V * nb);
           }
-          orBits64(s_out, at + (u32)e0 * (u32)nb, s, V * nb);
         }
         else
         {
 #pragma unroll
-          for (int k = 0; k < V; k += 2)
-            orBits64(s_out, at + (u32)(e0 + k) * (u32)nb, (u64)q[k] | ((u64)q[k + 1] << nb), 2 * nb);
+          for (int hv = 0; hv < NV; hv++)
+          {
+            if constexpr (NV == 2) quantizeLane<T, V>(p.intLossless, p.scale, reinterpret_cast<const T (&)[V]>(v[a][t][hv * V]), mn, reinterpret_cast<u32 (&)[V]>(q[hv * V]));
+#pragma unroll
+            for (int k = 0; k < V; k += 2)
+              orBits64(s_out, at + (u32)(e0 + hv * 8 * RSTEP + k) * (u32)nb, (u64)q[hv * V + k] | ((u64)q[hv * V + k + 1] << nb), 2 * nb);
+          }
         }
       }
       else if (kind == 1)
@@ -1919,8 +1964,8 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         else
         {
 #pragma unroll
-          for (int k = 0; k < V; k++)
-            if (!PART || k < vc) orBits64(s_out, at0 + 8u + (u32)(e0 + k) * 8u * (u32)sizeof(T), rawBits<T>(v[a][t][k]), 8 * (int)sizeof(T));
+          for (int k = 0; k < VX; k++)
+            if (!PART || k < vc) orBits64(s_out, at0 + 8u + (u32)(e0 + (k / V) * 8 * RSTEP + k % V) * 8u * (u32)sizeof(T), rawBits<T>(v[a][t][k]), 8 * (int)sizeof(T));
         }
       }
       // LUT blocks (kind 4): all blocks of the wave take part in the group reductions
@@ -1928,10 +1973,10 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       {
         const bool mine = (kind == 4);
         const T mn = s_mnT[a][blk];
-        u32 q[V], idx[V];
-        quantizeLane<T, V>(p.intLossless, p.scale, v[a][t], mn, q);
+        u32 q[VX], idx[VX];
+        quantizeLane<T, VX>(p.intLossless, p.scale, v[a][t], mn, q);
 #pragma unroll
-        for (int k = 0; k < V; k++) idx[k] = 0;
+        for (int k = 0; k < VX; k++) idx[k] = 0;
         if constexpr (PART)
         {
 #pragma unroll
@@ -1953,7 +1998,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         {
           u32 m = 0xFFFFFFFFu;
 #pragma unroll
-          for (int k = 0; k < V; k++)
+          for (int k = 0; k < VX; k++)
             if ((count == 0 || q[k] > last) && q[k] < m) m = q[k];
           m = groupReduce<LB>(m, OpMin());
           if (m == 0xFFFFFFFFu) active = false;
@@ -1961,7 +2006,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
           if (active)
           {
 #pragma unroll
-            for (int k = 0; k < V; k++) if (q[k] == m) idx[k] = count;
+            for (int k = 0; k < VX; k++) if (q[k] == m) idx[k] = count;
             if (leader && count > 0) orBits(s_out, lutAt + (count - 1) * (u32)nb, m, nb);
             last = m; count++;
           }
@@ -1972,9 +2017,9 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
           const int nbIdx = bitLen(nLut);
           if (leader) orBits(s_out, hdr, (u32)nb | (2u << 6) | 32u | (nElemB << 8) | ((nLut + 1) << 16), 24);
           const u32 idxAt = lutAt + 8u * ((nLut * (u32)nb + 7) >> 3);
-          u64 s = 0;
           if constexpr (MASKED)
           {
+            u64 s = 0;
             int rk = 0;
 #pragma unroll
             for (int k = 0; k < V; k++) if ((vm >> k) & 1u) { s |= (u64)idx[k] << (rk * nbIdx); rk++; }
@@ -1983,8 +2028,13 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
           else
           {
 #pragma unroll
-            for (int k = 0; k < V; k++) s |= (u64)idx[k] << (k * nbIdx);    // nbIdx <= 6
-            orBits64(s_out, idxAt + (u32)e0 * (u32)nbIdx, s, V * nbIdx);
+            for (int hv = 0; hv < NV; hv++)
+            {
+              u64 s = 0;
+#pragma unroll
+              for (int k = 0; k < V; k++) s |= (u64)idx[hv * V + k] << (k * nbIdx);    // nbIdx <= 6
+              orBits64(s_out, idxAt + (u32)(e0 + hv * 8 * RSTEP) * (u32)nbIdx, s, V * nbIdx);
+            }
           }
         }
       }

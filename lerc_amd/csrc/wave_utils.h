@@ -234,6 +234,37 @@ __device__ __forceinline__ void laneMinMax4(float a, float b, float c, float d, 
 #endif
 }
 
+// ... of a lane's eight values: a chain of v_min3 / v_max3, eight instructions
+__device__ __forceinline__ void laneMinMax8(const float (&x)[8], float& mn, float& mx)
+{
+#ifdef HIPSIM
+  mn = x[0]; mx = x[0];
+  for (int k = 1; k < 8; k++) { mn = __builtin_fminf(mn, x[k]); mx = __builtin_fmaxf(mx, x[k]); }
+#else
+  float t, u;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(x[0]), "v"(x[1]), "v"(x[2]));
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u) : "v"(x[0]), "v"(x[1]), "v"(x[2]));
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(t), "v"(x[3]), "v"(x[4]));
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u) : "v"(u), "v"(x[3]), "v"(x[4]));
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(t), "v"(x[5]), "v"(x[6]));
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u) : "v"(u), "v"(x[5]), "v"(x[6]));
+  asm("v_min_f32 %0, %1, %2" : "=v"(mn) : "v"(t), "v"(x[7]));
+  asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(u), "v"(x[7]));
+#endif
+}
+// minimum and maximum over groups of 8 lanes (half a DPP row): neighbour, neighbouring pair, the mirrored half -- three steps of two
+__device__ __forceinline__ void halfRowMinMax(float& mn, float& mx)
+{
+#ifdef HIPSIM
+  mn = groupReduce<8>(mn, OpMin()); mx = groupReduce<8>(mx, OpMax());
+#else
+  asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\tv_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\tv_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf"
+      : "+v"(mn), "+v"(mx));
+#endif
+}
+
 // whole-wave all-reduces (32- and 64-bit payloads)
 template<class T> __device__ __forceinline__ T waveMin(T v) { return groupReduce<64>(v, OpMin()); }
 template<class T> __device__ __forceinline__ T waveMax(T v) { return groupReduce<64>(v, OpMax()); }
