@@ -1552,8 +1552,16 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
         const int vc = r < bh ? max(0, min(V, bw - h * V)) : 0;
         vcA[a][t] = vc; bwA[a][t] = bw;
         const T* src = data + laneOrigin<WIDE, BPW, V>(span[a], t * 4 + w, r, c, p.nCols);
-        // (whole vectors where the raster's rows start on 16-byte boundaries; else, and at the ragged ends, pixel by pixel)
+        // (whole vectors where the raster's rows start on 16-byte boundaries -- or on 4-byte ones: the same instruction at dword
+        // alignment; else, and at the ragged ends, pixel by pixel)
         if (vc == V && (((size_t)p.nCols * sizeof(T)) & 15u) == 0u) loadLane<T, V>(src, v[a][t], true);
+        else if (sizeof(T) * V == 16 && vc == V && (((size_t)p.nCols * sizeof(T)) & 3u) == 0u)
+        {
+          struct Vec16 { T e[16 / sizeof(T)]; };
+          const Vec16 x16 = loadStreamingA4<Vec16>(src);
+#pragma unroll
+          for (int k = 0; k < V; k++) v[a][t][k] = x16.e[k];
+        }
         else
         {
 #pragma unroll

@@ -831,14 +831,15 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
         bw = (int)(dims & 15u);
         vc = r < (int)(dims >> 4) ? max(0, min(V, bw - h * V)) : 0;
       }
-      const bool rowsAligned = !RAG || (((size_t)p.nCols * sizeof(T)) & 15u) == 0u;    // (else: no 16-byte stores)
+      const bool rowsAligned = !RAG || (((size_t)p.nCols * sizeof(T)) & 15u) == 0u;    // (else: no 16-byte ALIGNED stores)
+      const bool rowsDword = sizeof(T) * V == 16 && (((size_t)p.nCols * sizeof(T)) & 3u) == 0u;    // (... but dwordx4 stores at dword alignment)
       const int e0 = r * bw + h * V;
       T v[V];
 #pragma unroll
       for (int k = 0; k < V; k++) v[k] = T(0);
       // the common case, all blocks of the wave alike: bit-stuffed without a table, the lane's V values inside 64 bits, no
       // clamp -- three words of the stream, one funnel shift each way, V shifts
-      const bool plain = ((code >> 24) & 1u) != 0u && (!RAG || (vc == V && bw == 8 && rowsAligned));
+      const bool plain = ((code >> 24) & 1u) != 0u && (!RAG || (vc == V && bw == 8 && (rowsAligned || rowsDword)));
       if (__all(plain || !code))
       {
         if (code)
@@ -860,7 +861,11 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
           Vec o;
 #pragma unroll
           for (int k = 0; k < V; k++) o.e[k] = v[k];
-          DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
+          if (RAG && !rowsAligned)
+          {
+            if constexpr (sizeof(Vec) == 16) storeStreamingA4(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V), o);
+          }
+          else DECODE_STORE(reinterpret_cast<Vec*>(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V)), o);
         }
       }
       else if (code)
@@ -907,7 +912,15 @@ fastOneBody(OneShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __restri
             }
           }
         }
-        if (RAG && !(vc == V && rowsAligned))
+        if (RAG && vc == V && !rowsAligned && rowsDword)
+        {
+          struct Vec16 { T e[V]; };
+          Vec16 o;
+#pragma unroll
+          for (int k = 0; k < V; k++) o.e[k] = v[k];
+          if constexpr (sizeof(Vec16) == 16) storeStreamingA4(outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V), o);
+        }
+        else if (RAG && !(vc == V && rowsAligned))
         {
           T* dst = outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V);
 #pragma unroll

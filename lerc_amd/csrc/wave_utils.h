@@ -91,6 +91,30 @@ template<class Vec> __device__ __forceinline__ Vec loadStreaming(const Vec* src)
 #endif
 }
 
+// The same 16 bytes at an address that is a multiple of 4 only (rasters whose row pitch is no multiple of 16 bytes: 8190 floats): one
+// dwordx4 instruction all the same -- the hardware takes vector accesses at dword alignment, they may touch two lines
+typedef u32x4_t u32x4_a4_t __attribute__((aligned(4)));
+template<class Vec> __device__ __forceinline__ void storeStreamingA4(void* dst, const Vec& v)
+{
+  static_assert(sizeof(Vec) == 16, "vector store");
+#ifdef HIPSIM
+  memcpy(dst, &v, 16);
+#else
+  u32x4_t x; memcpy(&x, &v, 16); __builtin_nontemporal_store(x, reinterpret_cast<u32x4_a4_t*>(dst));
+#endif
+}
+template<class Vec> __device__ __forceinline__ Vec loadStreamingA4(const void* src)
+{
+  static_assert(sizeof(Vec) == 16, "vector load");
+  Vec v;
+#ifdef HIPSIM
+  memcpy(&v, src, 16);
+#else
+  const u32x4_t x = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4_t*>(src)); memcpy(&v, &x, 16);
+#endif
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Cross-lane moves that stay in the VALU (no LDS traffic, unlike ds_bpermute behind __shfl*):
 // DPP (data parallel primitives) inside a row of 16 lanes, v_permlane{16,32}_swap across rows (gfx950).

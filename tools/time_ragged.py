@@ -14,7 +14,7 @@ import capi  # noqa: E402
 dev = torch.device("cuda:0")
 codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
 O = capi.oracle()
-for rows, cols in ((8190, 8190), (257, 257), (1000, 1201)):
+for rows, cols in ((8190, 8190), (8188, 8188), (8191, 8191), (4300, 4600), (3612, 3612), (3601, 3601), (257, 257), (1000, 1201)):
     x = synth.c2_float32(rows + 8, cols + 8, device=dev)[:rows, :cols].contiguous()
     blob = torch.empty(x.numel() * 4 + 4096, dtype=torch.uint8, device=dev)
     y = torch.empty_like(x)
@@ -31,7 +31,8 @@ for rows, cols in ((8190, 8190), (257, 257), (1000, 1201)):
         best_e, best_d = min(best_e, t1 - t0), min(best_d, t2 - t1)
     err = float((y.double() - x.double()).abs().max())
     same = None
-    if rows * cols <= 2000 * 2000:
+    if rows * cols <= 9000 * 9000:
         r, b = O.encode(x.cpu().numpy(), 0.01)
         same = bytes(blob[:n].cpu().numpy().tobytes()) == b
-    print(f"{rows} x {cols} f32: blob {n} B, encode {best_e*1e3:.3f} ms, decode {best_d*1e3:.3f} ms, round trip {rows*cols/(best_e+best_d)/1e6:.0f} MPix/s, max err {err:.5f}, blob == oracle: {same}")
+    forms = codec.decode_forms() if hasattr(codec, "decode_forms") else None
+    print(f"{rows} x {cols} f32: forms {forms} blob {n} B, encode {best_e*1e3:.3f} ms, decode {best_d*1e3:.3f} ms, round trip {rows*cols/(best_e+best_d)/1e6:.0f} MPix/s, max err {err:.5f}, blob == oracle: {same}")
