@@ -86,6 +86,11 @@ LERC_AMD_API void lerc_amd_path_counters(lerc_amd_context* ctx, unsigned long lo
  * walks), out[2] the walking one-launch decoder, out[1] discovery + decode in two launches; out[0] counts bands WITH a mask whose blocks the scanning decoder's first half found
  * (the general kernels decode their pixels).  Same ctx convention. */
 LERC_AMD_API void lerc_amd_decode_forms(lerc_amd_context* ctx, unsigned long long out[4]);
+/* Attempts that were thrown away on the way down the tiers -- each is a launch (or several) whose result nobody used: out[0] the decode
+ * kernels refused the block offsets the scan had proposed for a band with a mask (a raw block's length is a guess there; the general
+ * discovery then takes the band), out[1] that scan handed a masked band on by itself, out[2] a streaming decode tier (scan, walk, two
+ * launches) handed a band to the next one; out[3] unused.  Same ctx convention. */
+LERC_AMD_API void lerc_amd_decode_refusals(lerc_amd_context* ctx, unsigned long long out[4]);
 /* why the last call that left the streaming kernels did so ("" if none did); same ctx convention */
 LERC_AMD_API const char* lerc_amd_last_note(lerc_amd_context* ctx);
 

@@ -215,6 +215,15 @@ class DeviceCodec:
         self.lib.lerc_amd_decode_forms(self.h, out)
         return list(out)
 
+    def decode_refusals(self):
+        """attempts thrown away on the way down the tiers: [the decode kernels refused the masked scan's block offsets, the masked scan handed
+        a band on, a streaming decode tier handed a band on, -]"""
+        out = (ct.c_ulonglong * 4)()
+        self.lib.lerc_amd_decode_refusals.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+        self.lib.lerc_amd_decode_refusals.restype = None
+        self.lib.lerc_amd_decode_refusals(self.h, out)
+        return list(out)
+
     def last_note(self):
         """why the last call that left the streaming kernels (or went down a streaming tier) did so; "" if none did"""
         self.lib.lerc_amd_last_note.argtypes = [ct.c_void_p]

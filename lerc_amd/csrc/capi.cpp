@@ -704,6 +704,12 @@ void lerc_amd_decode_forms(lerc_amd_context* h, unsigned long long out[4])
   for (int i = 0; i < 4; i++) out[i] = h ? h->ctx.formCount[i] : 0;
 }
 
+void lerc_amd_decode_refusals(lerc_amd_context* h, unsigned long long out[4])
+{
+  if (!h) h = threadHandle();
+  for (int i = 0; i < 4; i++) out[i] = h ? h->ctx.refusalCount[i] : 0;
+}
+
 unsigned int lerc_amd_mask_rle_device(lerc_amd_context* h, const unsigned char* dBits, unsigned int nBytes, unsigned char* dOut,
                                       unsigned int cap, unsigned int* size)
 {

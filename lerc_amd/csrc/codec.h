@@ -86,6 +86,7 @@ public:
   unsigned long long pathCount[4] = { 0, 0, 0, 0 };
   bool lastDecodeStreamed = false;
   unsigned long long formCount[4] = { 0, 0, 0, 0 };    // bands / tiles decoded by streaming form 1, 2, 3 (lerc_amd_decode_forms)
+  unsigned long long refusalCount[4] = { 0, 0, 0, 0 };    // attempts thrown away (lerc_amd_decode_refusals): [0] the decode kernels refused the masked scan's block offsets, [1] the masked scan handed a band on, [2] a streaming decode tier handed a band on, [3] unused
   int lastStreamForm = 0;              // the form decodeEnqueueStreaming last enqueued (DecodeRequest::maxForm)
   struct { int dt = -1, nRows = 0, nCols = 0; u32 end = 0; } scanHint;    // size of the last band the streaming kernels decoded, and its shape (see launchFastBands)
   int lastStreamShape[3] = { -1, 0, 0 };                                 // dt, nRows, nCols of the band decodeEnqueueStreaming / decodeImpl last enqueued

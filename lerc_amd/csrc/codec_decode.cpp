@@ -283,6 +283,7 @@ bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits, 
     char msg[128];
     snprintf(msg, sizeof(msg), "streaming decode (form %d) handed the blob on (reason bits 0x%x)", form, verdict);
     ctx.lastNote = msg;
+    if (!(verdict & 0x300u)) ctx.refusalCount[2]++;    // (a tier's launch thrown away; 0x100 / 0x200: the header said "not ours" / the checksum is wrong)
     return false;
   }
   if (form >= 1 && form <= 3) ctx.formCount[form]++;
@@ -829,6 +830,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
         snprintf(msg, sizeof(msg), "the scan did not find band %d's blocks (reason bits 0x%x): the general discovery takes it", iBand, bits);
         ctx.lastNote = msg;
         ctx.scanOffsetsBan = true;    // (for the rest of this call)
+        ctx.refusalCount[1]++;
         fellBack = true;
         return kOk;
       }
@@ -845,6 +847,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
       char msg[96];
       snprintf(msg, sizeof(msg), "streaming decode handed band %d to the general kernels (reason bits 0x%x)", iBand, verdict);
       ctx.lastNote = msg;
+      ctx.refusalCount[2]++;
       fellBack = true;
       return kOk;
     }
@@ -864,6 +867,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     // The scan's cut of a masked band is a proposal: where it had to guess (a raw block's length is in the mask, not in the stream) the
     // decode kernel, which checks every block against the mask, may refuse it.  The general discovery has the last word.
     ctx.lastNote = "the decode kernels refused the scan's block offsets: the general discovery takes the band";
+    ctx.refusalCount[0]++;
     ctx.scanOffsetsBan = true;
     fellBack = true;
     return kOk;

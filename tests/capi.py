@@ -70,6 +70,15 @@ class LercLib:
         self.lib.lerc_amd_decode_forms(None, out)
         return tuple(int(v) for v in out)
 
+    def decode_refusals(self):
+        """lerc_amd only: attempts thrown away on the way down the tiers: (the decode kernels refused the masked scan's offsets, the masked
+        scan handed a band on, a streaming decode tier handed a band on, unused)"""
+        out = (ct.c_ulonglong * 4)()
+        self.lib.lerc_amd_decode_refusals.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+        self.lib.lerc_amd_decode_refusals.restype = None
+        self.lib.lerc_amd_decode_refusals(None, out)
+        return tuple(int(v) for v in out)
+
     def last_note(self):
         self.lib.lerc_amd_last_note.argtypes = [ct.c_void_p]
         self.lib.lerc_amd_last_note.restype = ct.c_char_p
