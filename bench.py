@@ -447,13 +447,18 @@ def main():
             big = synth.c2_float32(256 * rows_of_tiles, 65536, row0=256 * r0, col0=0, virt_cols=65536, device=dev)
             x = big.reshape(rows_of_tiles, 256, 256, 256).permute(0, 2, 1, 3).contiguous().reshape(rows_of_tiles * 256, 256, 256)[:count].contiguous()
             del big
-            out = torch.empty(x.numel() * 4 + count * 256, dtype=torch.uint8, device=dev)
+            # (room for the rank's table in front of the arena: its message to the root leaves as it lies, lerc_amd/shard.py)
+            room = (16 + 16 * count + 255) & ~255
+            front = torch.empty(room + x.numel() * 4 + count * 256, dtype=torch.uint8, device=dev)
+            out = front[room:]
+            fronts[k] = front
         else:
             # every rank compresses its own window of one large virtual raster (independent blobs)
             x = synth.c2_float32(n, n, row0=k * n, col0=rank * n, virt_cols=max(world, 1) * n, device=dev)
             out = torch.empty(n * n * 4 + (1 << 20), dtype=torch.uint8, device=dev)
         return x, out, torch.empty_like(x)
 
+    fronts = {}
     sets = [make_set(0)]
     n_pix = sets[0][0].numel()
     torch.cuda.synchronize()
@@ -486,7 +491,7 @@ def main():
                 # the exchange step: all ranks' blobs on rank 0.  The transfers are enqueued here and run beside what this rank
                 # does next -- the decode of its own tiles does not hang on them (timed inside the step: start to arrival, and
                 # what of it was still to wait for behind the decode)
-                flight = shard.gather_arenas_start(out, used, offs, sizes, root=0, after=torch.cuda.current_stream())    # (the codec's stream)
+                flight = shard.gather_arenas_start(out, used, offs, sizes, root=0, after=torch.cuda.current_stream(), codec=codec, front=fronts.get(k))    # (after: the codec's stream)
             tg0 = time.perf_counter()
             rc = api.decode_tiles_device(codec, out, offs, sizes, y)
             if rc != 0:

@@ -86,6 +86,23 @@ LERC_AMD_API void lerc_amd_path_counters(lerc_amd_context* ctx, unsigned long lo
  * walks), out[2] the walking one-launch decoder, out[1] discovery + decode in two launches; out[0] counts bands WITH a mask whose blocks the scanning decoder's first half found
  * (the general kernels decode their pixels).  Same ctx convention. */
 LERC_AMD_API void lerc_amd_decode_forms(lerc_amd_context* ctx, unsigned long long out[4]);
+/* The mosaic job's ONE exchange step (the reference has no counterpart: whoever tiles a mosaic moves the blobs
+ * himself): the gather of the ranks' compressed blobs on the rank that writes the container, over RCCL -- xGMI inside a node.
+ *   ncclComm      an ncclComm_t of the caller's (ncclCommInitRank; librccl is opened with dlopen when this is first called, inside a
+ *                 PyTorch process that is the RCCL torch.distributed uses); rank and size are the communicator's
+ *   dMessage      this rank's message, nBytes of device memory: its arena as lerc_amd_encode_tiles_device left it -- with the per-tile
+ *                 (offset, size) table in front, if the caller laid it out so: one message a rank
+ *   dRootBuffer   on the root: where the messages land, rank r's at hOffsets[r] (16-byte aligned, back to back); ignored elsewhere
+ *   hLengths      out, host, one word a rank: every rank's message length (all ranks get them); may be NULL
+ *   hOffsets      out, host, ranks + 1 words; may be NULL
+ *   stream        the HIP stream everything is enqueued on: one ncclAllGather of the lengths, then a sender's ncclSend at once (it needs
+ *                 nobody's length but its own), on the root one group of ncclRecv behind the only host wait there is (the lengths, 8 bytes
+ *                 a rank through pinned memory) and a copy of its own message.  The call returns when the transfers are POSTED; wait
+ *                 for the stream before the bytes are read.  Order it behind the encodes' stream with an event.
+ * Returns 0, 2 (WrongParam), 3 (BufferTooSmall: rootCapacity), 1 (Failed: lerc_amd_last_error says which RCCL call). */
+LERC_AMD_API unsigned int lerc_amd_gather_blobs(lerc_amd_context* ctx, void* ncclComm, int root, const void* dMessage, unsigned long long nBytes,
+                                                void* dRootBuffer, unsigned long long rootCapacity, unsigned long long* hLengths,
+                                                unsigned long long* hOffsets, void* stream);
 /* Attempts that were thrown away on the way down the tiers -- each is a launch (or several) whose result nobody used: out[0] the decode
  * kernels refused the block offsets the scan had proposed for a band with a mask (a raw block's length is a guess there; the general
  * discovery then takes the band), out[1] that scan handed a masked band on by itself, out[2] a streaming decode tier (scan, walk, two

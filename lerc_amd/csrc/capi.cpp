@@ -704,6 +704,17 @@ void lerc_amd_decode_forms(lerc_amd_context* h, unsigned long long out[4])
   for (int i = 0; i < 4; i++) out[i] = h ? h->ctx.formCount[i] : 0;
 }
 
+unsigned int lerc_amd_gather_blobs(lerc_amd_context* h, void* ncclComm, int root, const void* dMessage, unsigned long long nBytes,
+                                   void* dRootBuffer, unsigned long long rootCapacity, unsigned long long* hLengths, unsigned long long* hOffsets,
+                                   void* stream)
+{
+  if (!h || !ncclComm) return kWrongParam;
+  std::string err;
+  const u32 rc = gatherBlobsRccl(ncclComm, root, dMessage, nBytes, dRootBuffer, rootCapacity, (u64*)hLengths, (u64*)hOffsets, (hipStream_t)stream, err);
+  if (rc != kOk) h->ctx.lastError = err;
+  return rc;
+}
+
 void lerc_amd_decode_refusals(lerc_amd_context* h, unsigned long long out[4])
 {
   if (!h) h = threadHandle();

@@ -140,6 +140,10 @@ struct ProfScope
   ~ProfScope() { if (c.profOn()) c.profEnd(); }
 };
 
+// the mosaic job's exchange step over RCCL (gather_rccl.cpp)
+u32 gatherBlobsRccl(void* comm, int root, const void* dMessage, u64 nBytes, void* dRootBuffer, u64 rootCapacity, u64* hLengths, u64* hOffsets,
+                    hipStream_t st, std::string& err);
+
 // ---- whole-call entry points on DEVICE-resident pixel data -------------------------------------
 struct EncodeRequest
 {

@@ -1196,12 +1196,42 @@ with torch.cuda.stream(side):                         # the codec on a stream of
     assert rc == 0
     done = torch.cuda.Event()
     done.record(side)
+# the torch.distributed form (what the gloo tests run), then the exchange BELOW Python: lerc_amd_gather_blobs on a communicator made
+# with ncclGetUniqueId / ncclCommInitRank through the same librccl -- a message a rank, the per-tile table in front of the arena
+os.environ["LERC_AMD_GATHER"] = "torch"
 flight = shard.gather_arenas_start(arena, used, offs, sizes, root=0, after=done, force_collective=True)
 mosaic, t_off, t_size, bases = flight.finish()
 torch.cuda.synchronize()
 assert bases == [0] and int(mosaic.numel()) >= int(used)
 assert torch.equal(mosaic[:int(used)], arena[:int(used)])
 assert [int(v) for v in t_off] == [int(v) for v in offs] and [int(v) for v in t_size] == [int(v) for v in sizes]
+os.environ["LERC_AMD_GATHER"] = "c"
+need = 16 + 16 * 24
+for with_room in (False, True):
+    if with_room:      # the arena with room in front of it: the message leaves as it lies
+        with torch.cuda.stream(side):
+            buf = torch.empty(need + arena.numel(), dtype=torch.uint8, device=dev)
+            arena2 = buf[need:]
+            rc, offs2, sizes2, used2 = api.encode_tiles_device(codec, tiles, 0.01, arena2)
+            assert rc == 0 and used2 == used
+            done.record(side)
+        flight = shard.gather_arenas_start(arena2, used2, offs2, sizes2, root=0, after=done, force_collective=True, codec=codec, front=buf)
+    else:
+        flight = shard.gather_arenas_start(arena, used, offs, sizes, root=0, after=done, force_collective=True)
+    mosaic, t_off, t_size, bases = flight.finish()
+    assert bases == [need] and int(mosaic.numel()) == ((need + int(used) + 15) & ~15), (bases, mosaic.numel(), used)
+    assert torch.equal(mosaic[need:need + int(used)], arena[:int(used)])
+    assert [int(v) - need for v in t_off] == [int(v) for v in offs] and [int(v) for v in t_size] == [int(v) for v in sizes]
+import ctypes as ct
+R = shard.rccl_comm(dev)
+n_ranks = ct.c_int(0)
+assert R.lib.ncclCommCount(R.comm, ct.byref(n_ranks)) == 0 and n_ranks.value == 1
+# a root buffer that is too small is refused with BufferTooSmall (3), a communicator that is none with WrongParam (2)
+fn = codec.lib.lerc_amd_gather_blobs
+small = torch.empty(64, dtype=torch.uint8, device=dev)
+assert fn(codec.h, R.comm, 0, arena.data_ptr(), int(used), small.data_ptr(), 64, None, None, R.stream.cuda_stream) == 3
+assert fn(codec.h, None, 0, arena.data_ptr(), int(used), small.data_ptr(), 64, None, None, R.stream.cuda_stream) == 2
+torch.cuda.synchronize()
 out = torch.empty_like(tiles)
 with torch.cuda.stream(side):
     side.wait_stream(torch.cuda.current_stream())

@@ -9,7 +9,7 @@ FLAGS="-O3 -std=c++17 -fPIC -pthread -ffp-contract=off -fvisibility=hidden -Wno-
 build() {  # file macro n name
   /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS -D$2=$3 -c $1.hip -o _var/obj_exit/$4.o 2>/dev/null
   OTHERS=$(ls *.o | grep -v "^$1.o$")
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o _var/$4.so _var/obj_exit/$4.o $OTHERS
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o _var/$4.so _var/obj_exit/$4.o $OTHERS -ldl
   echo built _var/$4.so
 }
 N=0
