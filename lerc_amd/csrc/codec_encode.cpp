@@ -1284,13 +1284,27 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
     const u64 slotBytes = slotted ? rq.slotBytes : ((tileElems * tb / 2 + 4096) + 15) & ~15ull;
     const bool isFlt = rq.dt >= DT_Float;
     // one launch for tiles [t0, t0 + n), every blob in a slot of slotBytes; redoOut: the tiles it hands back, with the reason bits
+    // An arena is filled WITHOUT slots and without a pass that moves the blobs: a tile's last workgroup claims the tile's room with an
+    // atomic add on the batch's cursor (tile_fast.h: FastFused::arenaCursor), the tiles lie in the order of their claims.
+    // LERC_AMD_TILE_ARENA=copy keeps the slots + k_fast_tile_copy form (a knob for A/B runs and tests).
+    // (The emulator runs workgroups one after the other: a workgroup that waits for one BEHIND it waits for ever there.  Emulator builds keep
+    // the copy form unless asked, and then give up after a few polls -- which is the hand-back path's test.)
+#ifdef HIPSIM
+    static const bool cursorMode = []() { const char* e = getenv("LERC_AMD_TILE_ARENA"); return e && strcmp(e, "cursor") == 0; }();
+#else
+    static const bool cursorMode = []() { const char* e = getenv("LERC_AMD_TILE_ARENA"); return !(e && strcmp(e, "copy") == 0); }();
+#endif
+    const bool direct = !slotted && cursorMode;
     auto runBatch = [&](int t0, int n, u64 slotBytes, std::vector<std::pair<int, u32> >& redoOut) -> u32
     {
-      if (!ctx.reserve((size_t)n * ((slotted ? 0 : slotBytes) + sizeof(FastEncodeResult) + 8) + (1u << 16))) return kFailed;
-      u8* cells = ctx.persistentState(1, (size_t)n * cellWords * 8 + 256);
+      if (!ctx.reserve((size_t)n * (((slotted || direct) ? 0 : slotBytes) + sizeof(FastEncodeResult) + 8) + (1u << 16))) return kFailed;
+      u8* cells = ctx.persistentState(1, (size_t)n * (cellWords + (direct ? 1 : 0)) * 8 + 256);
       u8* counters = ctx.persistentState(0, (size_t)n * counterWords * 8 + 256);
-      u8* slots = slotted ? rq.dArena + (size_t)t0 * slotBytes : ctx.allocT<u8>((size_t)n * slotBytes);
-      FastEncodeResult* dRes = ctx.allocT<FastEncodeResult>(n);
+      u8* slots = slotted ? rq.dArena + (size_t)t0 * slotBytes : direct ? rq.dArena : ctx.allocT<u8>((size_t)n * slotBytes);
+      // (the results and, behind them, the batch's cursor: cleared by one memset)
+      FastEncodeResult* dRes = (FastEncodeResult*)ctx.alloc((size_t)n * sizeof(FastEncodeResult) + 16);
+      u64* dCursor = dRes ? reinterpret_cast<u64*>(reinterpret_cast<u8*>(dRes) + (size_t)n * sizeof(FastEncodeResult)) : nullptr;
+      static_assert(sizeof(FastEncodeResult) % 8 == 0, "the cursor behind the results is 8-byte aligned");
       u64* dOff = ctx.allocT<u64>((size_t)n + 1);
       if (!cells || !counters || !slots || !dRes || !dOff) return kFailed;
       FastEncodeLaunch fl;
@@ -1301,9 +1315,21 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
       f.packPart = (u64*)counters; f.keyPart = f.packPart + nPG + 1;
       f.nWG = nWGt; f.nTiles = (u32)n; f.cellStride = (u32)cellWords; f.counterStride = (u32)counterWords;
       f.tileElems = tileElems; f.outStride = slotBytes;
+      end = (end + 15) & ~15ull;
+      if (direct)
+      {
+        f.outStride = 0;
+        f.arenaCursor = dCursor;
+        f.tileCell = (u64*)cells + (size_t)n * cellWords;    // (epoch-tagged, behind the tiles' own cells)
+        f.tileOffset = dOff;
+        f.arenaBase = end; f.arenaCapacity = rq.arenaCapacity;
+      }
       f.epoch = ctx.nextEpoch();
       f.publishEpoch = (fastTestGiveUp() & 1u) ? f.epoch ^ 0x5A5A5A5Au : f.epoch;
       f.spinLimit = (fastTestGiveUp() & 1u) ? 8u : (1u << 22);
+#ifdef HIPSIM
+      if (direct) f.spinLimit = 64u;
+#endif
       fl.fb.result = dRes;
       fl.batch.nTiles = (u32)n; fl.batch.nWG = nWGt; fl.batch.tileElems = tileElems; fl.batch.nBlobsMore = 0;
       fl.cand = 0;
@@ -1323,20 +1349,19 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
       bp.invScale = 2 * bp.maxZErr;
       bp.intLossless = (!isFlt && bp.maxZErr == 0.5) ? 1 : 0;
       fl.maxZErr = rq.maxZErr;
-      end = (end + 15) & ~15ull;
       (void)hipGetLastError();
-      hipMemsetAsync(dRes, 0, (size_t)n * sizeof(FastEncodeResult), st);    // (the kernels raise `stuck`, nobody else clears it)
+      hipMemsetAsync(dRes, 0, (size_t)n * sizeof(FastEncodeResult) + 16, st);    // (the kernels raise `stuck`, nobody else clears it; the cursor)
       {
         ProfScope ps(ctx, "fast_encode1");
-        launchFastEncode(0, fl.bp, fl.maxZErr, fl.cand, (const u8*)rq.dData + (size_t)t0 * tileElems * tb, slots, slotBytes, 0, fl.fb, fl.batch, st);
+        launchFastEncode(0, fl.bp, fl.maxZErr, fl.cand, (const u8*)rq.dData + (size_t)t0 * tileElems * tb, slots, direct ? rq.arenaCapacity : slotBytes, 0, fl.fb, fl.batch, st);
       }
-      if (!slotted)
+      if (!slotted && !direct)
       {
         ProfScope ps(ctx, "fast_tile_move");
         launchFastTileCopy(dRes, dOff, slots, slotBytes, slotBytes, rq.dArena, (u32)n, end, rq.arenaCapacity, st);
       }
       if (hipGetLastError() != hipSuccess) { ctx.lastError = "lerc_amd: a streaming encode kernel could not be launched"; return kFailed; }
-      const size_t resBytes = (size_t)n * sizeof(FastEncodeResult), offBytes = ((size_t)n + 1) * 8;
+      const size_t resBytes = (size_t)n * sizeof(FastEncodeResult) + 16, offBytes = ((size_t)n + 1) * 8;    // (+ the cursor)
       u8* pin = (u8*)ctx.pinned(resBytes + offBytes);
       if (!pin) return kFailed;
       hipMemcpyAsync(pin, dRes, resBytes, hipMemcpyDeviceToHost, st);
@@ -1361,7 +1386,8 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
         ctx.pathCount[0]++;
       }
       if (anyStuck) ctx.wipePersistentState();
-      if (!slotted) end = off[n];
+      if (direct) { u64 claimed; memcpy(&claimed, pin + (size_t)n * sizeof(FastEncodeResult), 8); end += claimed; }    // (incl. the room of tiles that were handed back: holes)
+      else if (!slotted) end = off[n];
       return kOk;
     };
     // (a tile that compresses to more than half its raw size -- lossless noise, a small error bound -- does not fit the batch's
@@ -1381,7 +1407,7 @@ u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed
       if (rc != kOk) return rc;
       size_t tooBig = 0;
       for (const auto& r : back) if (r.second == 64u) tooBig++;    // (kRedoCapacity and nothing else)
-      if (!slotted && tooBig > (size_t)std::max(8, n / 32))
+      if (!slotted && !direct && tooBig > (size_t)std::max(8, n / 32))
       {
         end = end0; ctx.pathCount[0] = count0;
         for (int s0 = t0; s0 < t0 + n; s0 += maxBig)

@@ -104,6 +104,14 @@ struct FastFused
   u32 payloadAt;           // MASKED: where the block stream begins in `out` (header, mask, ranges and the sweep flag in front of it are the host's)
   u32 nTiles, cellStride, counterStride;
   u64 tileElems, outStride;
+  // a batch whose blobs go STRAIGHT into the arena (no slot a tile, no pass that moves them): a tile's last workgroup -- the one that
+  // knows the tile's size once its own spans are placed -- claims the tile's room with one atomic add on the batch's cursor and says
+  // where in an epoch-tagged cell, the tile's other workgroups wait for that cell before they flush.  Tiles lie in the arena in the
+  // order of their claims, 16-byte aligned; `out` is the arena.  nullptr: not this mode
+  u64* arenaCursor;        // bytes claimed by the batch so far (zero at launch)
+  u64* tileCell;           // [nTiles] epoch (32) | (the tile's offset in the arena) >> 4, 0xFFFFFFFF: the arena is full
+  u64* tileOffset;         // [nTiles] out: the tile's offset in the arena, for the host
+  u64 arenaBase, arenaCapacity;    // where the batch's first byte goes; the arena's size
 };
 LERC_HD u32 fastFusedGroups(u32 nWG) { return (nWG + kFusedGroup - 1u) / kFusedGroup; }
 // words of a tile's cells (sizes, group bases, group totals, first-row errors) and counters (pack accumulators + aggregator 0, key cells)

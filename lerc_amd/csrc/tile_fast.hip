@@ -1387,6 +1387,7 @@ fusedFinish(u32 nBytesTiling, u32 prefixLen, u8* __restrict__ out, u64 outCapaci
     for (int i = 0; i < 4; i++) { a = s_kmax[i] > a ? s_kmax[i] : a; bInv = s_kmin[i] > bInv ? s_kmin[i] : bInv; fl |= s_flg[i]; }
     const bool doRaise = DtOf<T>::v >= DT_Float && raiseCandidates != 0u;
     s_redo = fastDecide(p, requestedMaxZErr, raiseCandidates, nBytesTiling, ~bInv, a, fl, doRaise ? s_raise : nullptr, nBlobsMore, s_prefix, outCapacity, res, false);
+    if (f.arenaCursor && outCapacity == 0ull) res->redoReason |= kRedoArena;    // (the ARENA of a batch is full, not a tile's own room)
   }
   __syncthreads();
   if (s_redo) return;
@@ -1468,7 +1469,7 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   __shared__ u32 s_bit[U][kFastBlocksPerWG]; // bit position of each block inside s_out
   __shared__ u32 s_fl[4];
   __shared__ u64 s_fa[4], s_fb[4], s_kmx[U], s_kmn[U];
-  __shared__ u32 s_len[U], s_base, s_retry;
+  __shared__ u32 s_len[U], s_base, s_retry, s_tile;
   static_assert(!(PART && WIDE), "ragged rasters take the per-block mapping");
   static_assert(!(MASKED && WIDE), "masked bands take the per-block mapping");
 
@@ -1477,7 +1478,8 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
   {
     const size_t tile = blockIdx.y;
     data += tile * f.tileElems; res += tile;
-    if (out) out += tile * f.outStride;
+    if (out && !f.arenaCursor) out += tile * f.outStride;
+    if (f.arenaCursor) { f.tileCell += tile; f.tileOffset += tile; }
     f.sizeCell += tile * f.cellStride; f.baseCell += tile * f.cellStride; f.totalCell += tile * f.cellStride; f.raise += tile * f.cellStride;
     f.packPart += tile * f.counterStride; f.keyPart += tile * f.counterStride;
   }
@@ -2096,6 +2098,42 @@ k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, F
       }
       TRACE(3);
       spanBase = s_base;
+      if (f.arenaCursor && !sizeOnly)
+      {
+        // ---- a batch straight into the arena: where does this TILE go?  Its last workgroup knows the tile's size now (the spans in
+        // front of its own are placed), claims that much of the arena and says where; the others have published their sizes long
+        // ago and pick the answer up.  (They wait for a workgroup dispatched behind them -- but right behind them: a tile's
+        // workgroups are consecutive in dispatch order, and whatever else is resident belongs to tiles in front, which need nobody
+        // behind them to finish.  A waiter that gives up says so like everybody else: the host repeats the tile.)
+        if (threadIdx.x == 0)
+        {
+          u32 off16 = 0xFFFFFFFFu;
+          if (wg == nWG - 1u)
+          {
+            const u64 size16 = ((u64)prefixLen + spanBase + lenAll + 15ull) & ~15ull;
+            const u64 at = f.arenaBase + __hip_atomic_fetch_add(f.arenaCursor, size16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (at + size16 <= f.arenaCapacity && (at >> 4) < 0xFFFFFFFFull) off16 = (u32)(at >> 4);
+            *f.tileOffset = at;
+            publish64(f.tileCell, ((u64)f.publishEpoch << 32) | (u64)off16);
+          }
+          else
+          {
+            u64 cell = observe64(f.tileCell);
+            for (u32 spin = 0; (u32)(cell >> 32) != f.epoch && spin < f.spinLimit; spin++)
+            {
+              __builtin_amdgcn_s_sleep(4);
+              cell = observe64(f.tileCell);
+            }
+            if ((u32)(cell >> 32) == f.epoch) off16 = (u32)cell;
+            else __hip_atomic_store(&res->stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          s_tile = off16;
+        }
+        __syncthreads();
+        const u32 off16 = s_tile;
+        if (off16 == 0xFFFFFFFFu) outCapacity = 0ull;    // (no room, or no answer: nothing is stored; the last workgroup's verdict says "capacity")
+        else { out += (u64)off16 << 4; outCapacity = f.arenaCapacity - ((u64)off16 << 4); }
+      }
     }
     else __syncthreads();    // (the image is complete)
     const u32 segLen = together ? lenAll : len[a];

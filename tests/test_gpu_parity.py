@@ -1220,8 +1220,11 @@ for with_room in (False, True):
         flight = shard.gather_arenas_start(arena, used, offs, sizes, root=0, after=done, force_collective=True)
     mosaic, t_off, t_size, bases = flight.finish()
     assert bases == [need] and int(mosaic.numel()) == ((need + int(used) + 15) & ~15), (bases, mosaic.numel(), used)
-    assert torch.equal(mosaic[need:need + int(used)], arena[:int(used)])
-    assert [int(v) - need for v in t_off] == [int(v) for v in offs] and [int(v) for v in t_size] == [int(v) for v in sizes]
+    # (a batch's tiles lie in the arena in the order of their claims: another encode, another order -- compare with the arena that travelled)
+    src_arena, src_offs, src_sizes = (arena2, offs2, sizes2) if with_room else (arena, offs, sizes)
+    assert torch.equal(mosaic[need:need + int(used)], src_arena[:int(used)])
+    assert [int(v) - need for v in t_off] == [int(v) for v in src_offs] and [int(v) for v in t_size] == [int(v) for v in src_sizes]
+    assert sorted(int(v) for v in src_sizes) == sorted(int(v) for v in sizes)
 import ctypes as ct
 R = shard.rccl_comm(dev)
 n_ranks = ct.c_int(0)

@@ -340,6 +340,17 @@ def test_sim_tile_batches(libs):
         L.lerc_amd_destroy(h)
 
 
+def test_sim_tile_batches_when_the_arena_claim_is_never_answered():
+    """Batches straight into the arena (FastFused::arenaCursor: a tile's last workgroup claims the tile's room, the others wait for its
+    word) under the emulator, which runs workgroups one after the other: nobody in front of a tile's last workgroup ever gets an answer,
+    every such workgroup gives up, says so, and the host encodes those tiles by themselves -- the hand-back path; same blobs."""
+    import sys
+    env = dict(os.environ, LERC_AMD_TILE_ARENA="cursor")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "test_sim_tile_batches and not badly and not never_answered"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200, cwd=capi.ROOT)
+    assert out.returncode == 0 and b" passed" in out.stdout and b"failed" not in out.stdout, out.stdout.decode()[-2000:]
+
+
 def test_sim_tile_batches_that_compress_badly(libs):
     """A batch whose tiles compress to more than half their raw size (lossless noise; a tiny error bound) does not fit the
     one-launch encoder's first slots: the batch is then encoded once more with slots that hold raw blocks -- one launch again,
