@@ -93,6 +93,8 @@ public:
   u32 blindSkip = 0;                   // decodes of blindShape that go to the header-reading path at once (the last blind attempt was refused by the header)
   int blindShape[3] = { -1, 0, 0 };
   bool scanOffsetsBan = false;         // this call: a masked band's scan for block offsets has failed, the general discovery takes the bands
+  u32 scanLate = 0;                    // decodes whose scanning decoder counts late: an early count has just turned out wrong (a stream with blocks the scan does not see: the mending found them)
+  u32 lastScanGridBytes = 0;           // blob bytes the scanning decoder's last launch held pieces for (launchFastBands)
   u32 scanSkip = 0;                    // decodes that keep off the scanning decoder: it has just handed a band on (a stream with blocks it cannot see)
 
   // optional per-kernel timing with HIP events on the active stream (bench.py: roofline of the dominant kernel)
@@ -190,7 +192,7 @@ struct DecodeRequest
   void* dOut = nullptr;               // device: decoded pixels
   u8* dValidBytes = nullptr;          // device: nMasks byte masks, or nullptr
   bool noStreaming = false;            // go straight to the general kernels (a batch has already tried the streaming ones)
-  int maxForm = 3;                     // the first streaming form to try: 3 the scanning decoder, 2 the walking one-launch decoder, 1 discovery + decode in
+  int maxForm = 4;                     // the first streaming form to try: 4 the scanning decoder with early counts, 3 the scanning decoder, 2 the walking one-launch decoder, 1 discovery + decode in
                                        // two launches (a form that has just refused this blob hands it on with its own number less one)
   u8* hUsesNoData = nullptr;           // host [nBands] out (lerc_decode_4D), or nullptr
   double* hNoDataValues = nullptr;

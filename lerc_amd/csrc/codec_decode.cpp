@@ -122,13 +122,20 @@ static bool launchFastBands(Context& ctx, int form, int dt, int nRows, int nCols
   {
     const u64 raw = (u64)nRows * (u64)nCols * (u64)dtSize(dt);
     u32 spec = sizeBound;
+    bool fromHint = false;
     if (!dTileOffset && (u64)sizeBound * 10u >= raw * 9u)    // (as large as the raster itself: a capacity, not a size)
     {
       const bool alike = ctx.scanHint.dt == dt && ctx.scanHint.nRows == nRows && ctx.scanHint.nCols == nCols && ctx.scanHint.end != 0u;
+      fromHint = alike;
       const u64 guess = alike ? (u64)ctx.scanHint.end + ctx.scanHint.end / 8u + 65536u : raw / 2u;
       spec = (u32)std::min<u64>(guess, sizeBound);
     }
     fbuf.scanSpecEnd = dTileOffset ? 0xFFFFFFFFu : spec;
+    // (... and the launch itself is sized by a guess that comes from a band of this shape: LERC_AMD_SCAN_GRID=0 sizes it by what was given)
+    static const bool gridByGuess = []() { const char* e = getenv("LERC_AMD_SCAN_GRID"); return !e || atoi(e) != 0; }();
+    fbuf.scanEarly = form == 4 ? 1u : 0u;
+    fbuf.scanGridBytes = (gridByGuess && fromHint && spec < sizeBound) ? spec : 0u;
+    ctx.lastScanGridBytes = form >= 3 ? (fbuf.scanGridBytes ? fbuf.scanGridBytes : sizeBound) : 0u;
     ctx.lastStreamShape[0] = dt; ctx.lastStreamShape[1] = nRows; ctx.lastStreamShape[2] = nCols;
   }
   fbuf.wgStride = fbuf.wgGroupStride = 0;
@@ -144,7 +151,7 @@ static bool launchFastBands(Context& ctx, int form, int dt, int nRows, int nCols
     fbuf.wgAcc = (u64*)ctx.persistentState(0, (nT * sGrp + 8) * 8);
     if (!fbuf.wgCell || !fbuf.wgAcc) return false;
     fbuf.recs = nullptr; fbuf.lists = nullptr; fbuf.chunkCell = fbuf.groupCell = fbuf.waveFletcher = nullptr;
-    if (form == 3)
+    if (form >= 3)
     {
       ProfScope ps(ctx, "fast_decode_scan");
       launchFastDecodeScan(dt, nRows, nCols, tb, dBlobs, sizeBound, fbuf, dOut, st);
@@ -190,6 +197,11 @@ static bool fastDecodeOneLaunch()
 // bit-stuffed -- costs a launch before the next tier gets it, and the bands of one job are alike, so the next kScanSkip decodes
 // start one tier down.
 static const u32 kScanSkip = 16;
+// Form 4 is form 3 with EARLY counts (tile_fast_decode_scan.hip): a piece says how many blocks it holds as soon as the survivors are
+// counted.  A piece whose check or mending comes to another count -- a stream with blocks the scan does not see: constant, all zero,
+// raw -- raises a flag, and the band is decoded once more by form 3, which counts late and mends; the bands of one job are alike, so
+// the next kScanLate decodes start there.
+static const u32 kScanLate = 64;
 static bool scanOffsetsOn()    // (LERC_AMD_SCAN_OFFSETS=0: masked bands keep to the general discovery)
 {
   static const bool on = []() { const char* e = getenv("LERC_AMD_SCAN_OFFSETS"); return !e || atoi(e) != 0; }();
@@ -198,13 +210,16 @@ static bool scanOffsetsOn()    // (LERC_AMD_SCAN_OFFSETS=0: masked bands keep to
 static int pickForm(Context& ctx, int maxForm, int nRows, int nCols)
 {
   static const bool scanOn = []() { const char* e = getenv("LERC_AMD_DECODE_SCAN"); return !e || atoi(e) != 0; }();
-  int f = maxForm > 3 ? 3 : maxForm;
+  static const bool earlyOn = []() { const char* e = getenv("LERC_AMD_SCAN_EARLY"); return !e || atoi(e) != 0; }();
+  int f = maxForm > 4 ? 4 : maxForm;
   if (f <= 0) return 0;
   if (!fastDecodeOneLaunch()) return 1;
-  if (f == 3)
+  if (f >= 3)
   {
     if (!scanOn || !fastDecodeScanEligible(nRows, nCols)) f = 2;
     else if (ctx.scanSkip > 0) { ctx.scanSkip--; f = 2; }
+    else if (f == 4 && !earlyOn) f = 3;
+    else if (f == 4 && ctx.scanLate > 0) { ctx.scanLate--; f = 3; }
   }
   return f;
 }
@@ -277,7 +292,17 @@ bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits, 
   const u32 verdict = fastBandVerdict(slot + 64, epoch);
   if (bits) *bits = verdict;
   if (verdict & 0x8u) ctx.wipePersistentState();    // (a workgroup gave up waiting: the checksum accumulators may hold residue)
-  if (form == 3 && (verdict & 0x7u) && !(verdict & 0x300u)) ctx.scanSkip = kScanSkip;    // (a stream the scanning decoder does not follow)
+  bool gridTooSmall = false;
+  if (form >= 3 && (verdict & 0x4u) && !(verdict & 0x300u))
+  {
+    // (the launch was sized by the last band of this shape and this one is larger: not the stream's fault -- the guess is forgotten)
+    FastDecodeParams hp;
+    memcpy(&hp, slot + 64 + kCellParams, sizeof(hp));
+    gridTooSmall = ctx.lastScanGridBytes != 0u && fastScanNumWG(hp.blobEnd) > fastScanNumWG(ctx.lastScanGridBytes);
+    if (gridTooSmall) ctx.scanHint.end = 0u;
+  }
+  if (form == 3 && (verdict & 0x7u) && !(verdict & 0x300u) && !gridTooSmall) ctx.scanSkip = kScanSkip;    // (a stream the scanning decoder does not follow)
+  if (form == 4 && (verdict & 0x7u) && !(verdict & 0x300u) && !gridTooSmall) ctx.scanLate = kScanLate;    // (an early count was wrong: the late form mends)
   if (verdict)
   {
     char msg[128];
@@ -286,7 +311,7 @@ bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits, 
     if (!(verdict & 0x300u)) ctx.refusalCount[2]++;    // (a tier's launch thrown away; 0x100 / 0x200: the header said "not ours" / the checksum is wrong)
     return false;
   }
-  if (form >= 1 && form <= 3) ctx.formCount[form]++;
+  if (form >= 1 && form <= 4) ctx.formCount[std::min(form, 3)]++;
   noteBandSize(ctx, slot + 64);
   return true;
 }
@@ -842,6 +867,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     if (verdict & 0x8u) ctx.wipePersistentState();    // (a workgroup gave up waiting: the checksum accumulators may hold residue)
     if (verdict & 0x200u) return kFailed;    // decoded, but the checksum is wrong
     if (fastLevel == 3 && (verdict & 0x7u) && !(verdict & 0x300u)) ctx.scanSkip = kScanSkip;
+    if (fastLevel == 4 && (verdict & 0x7u) && !(verdict & 0x300u)) ctx.scanLate = kScanLate;
     if (verdict)                             // caller repeats with the general kernels
     {
       char msg[96];
@@ -851,7 +877,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
       fellBack = true;
       return kOk;
     }
-    if (fastLevel >= 1 && fastLevel <= 3) ctx.formCount[fastLevel]++;
+    if (fastLevel >= 1 && fastLevel <= 4) ctx.formCount[std::min(fastLevel, 3)]++;
     noteBandSize(ctx, pin + 64 + (size_t)iBand * kCellBytes);
   }
   for (int iBand = 0; iBand < rq.nBands; iBand++)
@@ -911,7 +937,7 @@ u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
     bool handled = false, tried = false;
     DecodeRequest r = rq;
     r.maxForm = level;
-    if (level == 3) ctx.scanSkip = 0;    // (pickForm has just said 3: the request below must get the same answer)
+    if (level >= 3) ctx.scanSkip = 0;    // (pickForm has just said so: the request below must get the same answer)
     u32 bits = 0;
     const u32 src = decodeSpeculative(ctx, r, handled, tried, &bits);
     if (src != kOk) return src;
@@ -1000,7 +1026,7 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
     FastDecodeParams* dParams = reinterpret_cast<FastDecodeParams*>(dCells + 64);
     u32* dFallback = reinterpret_cast<u32*>(dCells + 64 + (size_t)n * sizeof(FastDecodeParams));
     const u32 epoch = ctx.nextEpoch();
-    batchForm = pickForm(ctx, 3, rq.nRows, rq.nCols);
+    batchForm = pickForm(ctx, 4, rq.nRows, rq.nCols);
     if (!launchFastBands(ctx, batchForm, rq.dt, rq.nRows, rq.nCols, rq.dArena, maxSize, (u32)n, dOff, dSize,
                          (u8*)rq.dOut + (size_t)t0 * tileElems * tbytes, dParams, dFallback, epoch))
       return kFailed;
@@ -1017,7 +1043,7 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
     {
       const u32 bits = fastFlagBits(hfb + 4 * i, epoch);
       const bool good = hp[i].ok && !bits && hp[i].checksumOk;
-      if (good) { ctx.pathCount[2]++; ctx.formCount[batchForm]++; }
+      if (good) { ctx.pathCount[2]++; ctx.formCount[std::min(batchForm, 3)]++; }
       else
       {
         if (redo.empty())
@@ -1031,6 +1057,7 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
       }
     }
     if (batchForm == 3 && redo.size() > (size_t)n / 8) ctx.scanSkip = kScanSkip;    // (tiles the scanning decoder does not follow: the next batches start one tier down)
+    if (batchForm == 4 && redo.size() > (size_t)n / 8) ctx.scanLate = kScanLate;    // (early counts that were wrong: the next batches count late)
     for (int t : redo) { const u32 rc = decodeOne(t); if (rc != kOk) return rc; }    // (reuses the workspace: the batch is done with it)
   }
   return kOk;

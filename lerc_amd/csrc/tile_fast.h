@@ -369,6 +369,11 @@ struct FastDecodeBuffers
   u32 publishEpoch;    // == epoch; a test knob makes it differ, so that nobody ever sees a cell arrive and every waiter gives up
   u32 spinLimit;       // polls before a waiter gives up (2^22; the test knob: a few)
   u32 scanSpecEnd;     // the scanning decoder: blob bytes the host expects the band to have -- pieces in front of that are asked for without waiting for the header
+  u32 scanEarly;       // the scanning decoder: a piece says how many blocks it holds before it has checked them (tile_fast_decode_scan.hip: EARLY)
+  u32 scanGridBytes;   // the scanning decoder's launch holds pieces for a blob of so many bytes (0: of the size given).  A decode queued behind
+                       // the encode that writes its blob is given a CAPACITY -- as large as the raster -- and a launch sized for that has more
+                       // workgroups that find nothing to do than workgroups with a piece; the host sizes the launch like its early loads, by
+                       // what the context's last band of this shape had, and a band that turns out larger says so (flag 2) and goes on
   u32 testRewalk;      // test knob (LERC_AMD_TEST_GIVEUP bit 2): the one-launch decoder walks every chunk's path again, as it does
                        // for the rare chunk whose path is not its walk 0
 };

@@ -78,6 +78,9 @@ extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_deco
 #define LERC_SCAN_HELD16 2
 #endif
 // tuning: LERC_DEC_EXIT=n builds a decoder that leaves at mark n (profiles/r06_notes.md: instruction counts per phase); results are invalid
+#ifndef LERC_SCAN_EARLY
+#define LERC_SCAN_EARLY 1
+#endif
 #ifndef LERC_DEC_EXIT
 #define LERC_DEC_EXIT 99
 #endif
@@ -102,6 +105,9 @@ template<class T> struct ScanGeom
   static_assert(kBytes + 64u < 65535u, "16-bit positions");
   static_assert(kUnits < 65536u && kScanUnits <= kUnits, "queue entries");
 };
+
+// what a piece's verdict is made of (see fastScanBody: verdict)
+struct ScanVerdictIn { u32 total, base, dataRel, blobRel, dataBegin, nWanted; };
 
 template<class T> struct ScanShared
 {
@@ -129,6 +135,8 @@ template<class T> struct ScanShared
   u64 part;                                          // sum of the cells: this group's in the low half, the groups' in front in the high half
   u32 t0, frontBad;                                  // where the anchor ends (0: no anchor); the list's first entries lie in front of that
   u32 nEnt, nBad[4], nStruck[4], nFalse, nIns, over, bad, lost, exitRel, prevExit, mended;    // nBad: broken links found by the first / the second / the third check
+  u32 earlyCount, vDefer;                            // EARLY: what the piece said it holds before the check; the verdict is given behind the pixels
+  ScanVerdictIn vIn;
   u32 mendExit;                                      // MODE 1: where the piece's last block ends, if the mending had to find out (a raw block: see there)
 #ifdef LERC_PROBE
   u32 dbg[4];
@@ -232,8 +240,8 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       }
     }
   };
-  const bool early = pieceStart < specEnd && pieceStart < sizeGiven;
-  if (early) issueLoads();
+  const bool earlyLoads = pieceStart < specEnd && pieceStart < sizeGiven;
+  if (earlyLoads) issueLoads();
   HeadLite hl = parseHeadLite<DT>(h64, sizeGiven);
   if (OFFS) { hl.ok = 1u; hl.version = job.version; hl.dataBegin = job.dataBegin; hl.blobEnd = job.blobEnd; }    // (the host has read the header)
   const u32 blobEnd = hl.blobEnd;
@@ -244,7 +252,10 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     storeParams<true>(b.params, hp0); if (b.hostParams) *b.hostParams = hp0;
   }
   const u32 nWG = fastScanNumWG(blobEnd);
-  if (!ours || wg >= nWG) return;                  // (the grid is sized for the largest stream the blob could hold)
+  // (the grid is sized for the largest stream the blob could hold, or by the host's guess.  A guess that was too small: nobody decodes, the
+  // first workgroup hands the band on with its header -- flag 2, below)
+  const bool gridShort = !OFFS && nWG > gridDim.x;
+  if (!ours || wg >= nWG || (gridShort && wg != 0u)) return;
   if (LERC_DEC_EXIT == 0)    // a workgroup of the same shape (threads, LDS) that loads the header and stores one vector
   {
     S.inAll[threadIdx.x] = blobEnd + threadIdx.x;
@@ -253,7 +264,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     return;
   }
   TRACES(0);
-  if (!early) issueLoads();
+  if (!earlyLoads) issueLoads();
   const int version = (int)hl.version;
   const bool v5 = version >= 5;
   const u32 pattern = v5 ? 14u : 15u;
@@ -299,7 +310,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
 #ifdef LERC_PROBE
     S.dbg[0] = S.dbg[1] = S.dbg[2] = S.dbg[3] = 0u;
 #endif
-    S.prevExit = kNoOffset; S.mended = 0u; S.part = 0ull;
+    S.prevExit = kNoOffset; S.mended = 0u; S.part = 0ull; S.vDefer = 0u;
   }
   // (no barrier here: nothing below reads what was written above before the barrier behind the staging -- the queue is a
   // wave's own, the bitmaps and the counters are for the steps behind that barrier)
@@ -376,6 +387,11 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   TRACES(1);
   DEC_EXIT(1);
   if (!OFFS && !S.hp.ok) return;    // (not a band the streaming kernels take: the header says so in full only)
+  if (gridShort)
+  {
+    if (threadIdx.x == 0) raiseFlag(b, 2);
+    return;
+  }
   if (!OFFS && threadIdx.x == 0)
   {
     // this workgroup's checksum terms: one atomic nobody waits for (the launch's last workgroup folds the accumulators)
@@ -527,7 +543,14 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     constexpr u32 kBehind = G::kOwnWord0 + 2u * NT;
     if (kBehind + threadIdx.x < 4u * G::kMapVecs) s_end[kBehind + threadIdx.x] = 0u;
   }
-  auto buildList = [&]()
+  // EARLY: the piece's count leaves as soon as the survivors are counted -- before the list is written, before anybody has looked at a
+  // header: the pieces behind need it for their blocks' places and wait for the slowest of up to 63 pieces in front; what the list
+  // and the check below cost a piece is what every piece behind it waits less.  Where the piece's last block ends is not known
+  // yet (0xFFFE; only the piece right behind wants it, and only for its verdict: it looks again at the very end).  A piece whose
+  // check or mending comes to ANOTHER count has told the pieces behind a wrong one: it says so (flag 1) and the band is decoded
+  // once more without early counts.
+  const bool early = !OFFS && LERC_SCAN_EARLY != 0 && b.scanEarly != 0u;
+  auto buildList = [&](bool first)
   {
     const u32 s0 = s_sb[myWord], s1 = s_sb[myWord + 1u];
     const u32 c = (u32)__popc(s0) + (u32)__popc(s1);
@@ -536,6 +559,12 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     __syncthreads();                                  // (and: the queue, which the list lies on, has been read by everybody)
     u32 idx = inc - c;
     for (int k = 0; k < w; k++) idx += S.wsum[k];
+    if (first && early && threadIdx.x == NT - 1u)
+    {
+      const u32 n = min(min(idx + c, kListCap), 0xFFFFu);
+      S.earlyCount = n;
+      publish64(b.wgCell + wg, tag | (0xFFFEull << 16) | (u64)n);
+    }
     const u32 pos0 = PRE + 64u * threadIdx.x;
     u32 m = s0;
     while (m) { const u32 bt = (u32)__ffs((int)m) - 1u; m &= m - 1u; if (idx < kListCap) s_list[idx] = (u16)(pos0 + bt); idx++; }
@@ -544,7 +573,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     if (threadIdx.x == NT - 1u) { S.nEnt = min(idx, kListCap); if (idx > kListCap) S.over = 1u; }
     __syncthreads();
   };
-  buildList();
+  buildList(true);
   TRACES(3);
   DEC_EXIT(3);
 
@@ -845,7 +874,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
 #endif
     if (threadIdx.x == 0) S.frontBad = 0u;    // (everybody has read it; the check below says it again)
     __syncthreads();
-    buildList();
+    buildList(false);
     cp = 1u;
     tilePass(1u, false);
   }
@@ -853,7 +882,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   // (a masked band: the lanes have struck false survivors, and links are still broken -- maybe theirs: look again)
   if (OFFS && S.nBad[cp] != 0u && S.nStruck[cp] != 0u)
   {
-    buildList();
+    buildList(false);
     cp++;
     tilePass(cp, false);
   }
@@ -1085,7 +1114,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     __syncthreads();
     if (S.mended)
     {
-      buildList();
+      buildList(false);
       tilePass(cp + 1u, true);
       if (S.nBad[cp + 1u] != 0u) S.bad = 1u;    // (mended once; a list that still does not tile goes the long way)
     }
@@ -1095,8 +1124,10 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   const u32 total = S.bad ? 0u : S.nEnt;
   if (threadIdx.x == 0)
   {
-    const u32 ex = S.exitRel >= pieceEndRel ? min(S.exitRel - pieceEndRel, 0xFFFFu) : 0xFFFFu;
-    publish64(b.wgCell + wg, tag | ((u64)ex << 16) | (u64)min(total, 0xFFFFu));
+    const u32 ex = S.exitRel >= pieceEndRel ? min(S.exitRel - pieceEndRel, 0xFFFDu) : 0xFFFFu;
+    const u32 earlyCount = early ? S.earlyCount : 0u;
+    if (early && min(total, 0xFFFFu) != earlyCount) raiseFlag(b, 1);    // (the pieces behind have been told another count)
+    publish64(b.wgCell + wg, tag | ((u64)ex << 16) | (u64)(early ? earlyCount : min(total, 0xFFFFu)));
   }
   // The blocks' places need the cells of the pieces in front -- those of this group, and one per group in front; the piece right in
   // front also says where its last block ends: this piece's first block has to begin there.  The cells are asked for now;
@@ -1262,27 +1293,39 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   {
     if (wg == g0 + kOneGroup - 1u) publish64(b.wgGroupCell + grp, tag | (u64)(inGroup + total));    // this group's total, for the groups behind
     if (S.over) raiseFlag(b, 0);
+  }
+  // the piece's verdict (one thread).  EARLY: where the piece in front ends may not be known yet (0xFFFE) -- then what the verdict needs is put
+  // aside (LDS: nothing of it stays in registers over the pixel loop) and it is given behind the pixels, when that piece has long said
+  auto verdict = [&](const ScanVerdictIn& v, u32 prevExit)
+  {
+    const bool lastP = v.blobRel <= PRE + P;          // (the blob ends in this piece's own bytes)
     bool bad = S.bad != 0u;
     // where this piece's blocks begin: with the stream (the first piece), else where the piece in front says its last block ends
     u32 exitRel = S.exitRel;
-    if (total == 0u && lastPiece && wg != 0u && S.prevExit != 0xFFFFu) exitRel = PRE + S.prevExit;    // (the stream's last block began in the piece in front)
-    const u32 first = total ? (u32)s_list[0] : exitRel;
-    const u32 firstPiece = hl.dataBegin / P;    // (a masked band: the mask's bytes may fill pieces of their own in front of the stream)
-    if (wg < firstPiece) bad = bad || total != 0u;
-    else if (wg == firstPiece) bad = bad || first != dataRel;
-    else bad = bad || S.prevExit == 0xFFFFu || first != PRE + S.prevExit;
-    if (total == 0u && !lastPiece && wg >= firstPiece) bad = true;    // (a piece is longer than any block)
-    TRACEV(8, total); TRACEV(9, S.nBad[0]); TRACEV(10, S.nBad[1] | (S.nBad[2] << 16)); TRACEV(11, (S.over ? 1u : 0u) | (S.bad ? 2u : 0u) | (bad ? 4u : 0u) | (S.mended ? 8u : 0u));
-    TRACEV(12, first); TRACEV(13, PRE + S.prevExit); TRACEV(14, S.nIns); TRACEV(15, S.nFalse);
+    if (v.total == 0u && lastP && wg != 0u && prevExit != 0xFFFFu) exitRel = PRE + prevExit;    // (the stream's last block began in the piece in front)
+    const u32 first = v.total ? (u32)s_list[0] : exitRel;
+    const u32 firstPiece = v.dataBegin / P;    // (a masked band: the mask's bytes may fill pieces of their own in front of the stream)
+    if (wg < firstPiece) bad = bad || v.total != 0u;
+    else if (wg == firstPiece) bad = bad || first != v.dataRel;
+    else bad = bad || prevExit == 0xFFFFu || first != PRE + prevExit;
+    if (v.total == 0u && !lastP && wg >= firstPiece) bad = true;    // (a piece is longer than any block)
+    TRACEV(8, v.total); TRACEV(9, S.nBad[0]); TRACEV(10, S.nBad[1] | (S.nBad[2] << 16)); TRACEV(11, (S.over ? 1u : 0u) | (S.bad ? 2u : 0u) | (bad ? 4u : 0u) | (S.mended ? 8u : 0u));
+    TRACEV(12, first); TRACEV(13, PRE + prevExit); TRACEV(14, S.nIns); TRACEV(15, S.nFalse);
 #ifdef HIPSIM
     if (OFFS && getenv("LERC_SIM_SCAN_DIAG") && (bad || S.over || getenv("LERC_SIM_SCAN_DIAG")[0] == '2'))
-      printf("piece %u: total %u first %u expected %u t0 %u nBad %u %u %u frontBad %u over %u S.bad %u mended %u nIns %u nFalse %u exit %u pieceEnd %u blobRel %u dataRel %u\n", wg, total, first, PRE + S.prevExit, S.t0,
-             S.nBad[0], S.nBad[1], S.nBad[2], S.frontBad, S.over, S.bad, S.mended, S.nIns, S.nFalse, S.exitRel, pieceEndRel, blobRel, dataRel);
+      printf("piece %u: total %u first %u expected %u t0 %u nBad %u %u %u frontBad %u over %u S.bad %u mended %u nIns %u nFalse %u exit %u pieceEnd %u blobRel %u dataRel %u\n", wg, v.total, first, PRE + prevExit, S.t0,
+             S.nBad[0], S.nBad[1], S.nBad[2], S.frontBad, S.over, S.bad, S.mended, S.nIns, S.nFalse, S.exitRel, pieceEndRel, v.blobRel, v.dataRel);
 #endif
     if (bad) raiseFlag(b, 1);
     // the pieces hold all the raster's blocks, or the band goes the long way
-    const u32 nBlocksWanted = OFFS ? job.nPos : hp.nBlocks;
-    if (lastPiece && (base + total != nBlocksWanted || exitRel != blobRel)) raiseFlag(b, 2);
+    if (lastP && (v.base + v.total != v.nWanted || exitRel != v.blobRel)) raiseFlag(b, 2);
+  };
+  if (threadIdx.x == 0)
+  {
+    ScanVerdictIn v;
+    v.total = total; v.base = base; v.dataRel = dataRel; v.blobRel = blobRel; v.dataBegin = hl.dataBegin; v.nWanted = OFFS ? job.nPos : hp.nBlocks;
+    if (early && S.prevExit == 0xFFFEu) { S.vIn = v; S.vDefer = 1u; }
+    else verdict(v, S.prevExit);
   }
   if (OFFS)
   {
@@ -1377,6 +1420,17 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   }
   TRACES(6);
   if (__any(bad) && lane == 0) raiseFlag(b, 3);
+  if (early && threadIdx.x == 0 && S.vDefer)
+  {
+    u64 c = observe64(b.wgCell + (wg - 1u));
+    for (u32 spin = 0; ((u32)(c >> 32) != epoch || (((u32)c >> 16) & 0xFFFFu) == 0xFFFEu) && spin < b.spinLimit; spin++)
+    {
+      __builtin_amdgcn_s_sleep(LERC_SCAN_SLEEP);
+      c = observe64(b.wgCell + (wg - 1u));
+    }
+    const bool seen = (u32)(c >> 32) == epoch && (((u32)c >> 16) & 0xFFFFu) != 0xFFFEu;
+    verdict(S.vIn, seen ? (((u32)c >> 16) & 0xFFFFu) : 0xFFFFu);
+  }
 
   // ---- checksum: the launch's last workgroup waits for everybody's terms (they were sent off microseconds after each
   // workgroup started), folds them and clears the accumulators for the next call (Lerc2.cpp:1037-1064)
@@ -1450,7 +1504,7 @@ template<class T>
 static void launchFastDecodeScanT(int nRows, int nCols, const FastDecodeBatch& t, const u8* blob, u32 sizeGiven, const FastDecodeBuffers& b, void* out,
                                   hipStream_t st)
 {
-  const dim3 grid(fastScanNumWG(sizeGiven), t.nTiles), block(kScanThreads);    // (sizeGiven: the largest blob of the batch)
+  const dim3 grid(fastScanNumWG(b.scanGridBytes ? min(b.scanGridBytes, sizeGiven) : sizeGiven), t.nTiles), block(kScanThreads);    // (sizeGiven: the largest blob of the batch)
   hipLaunchKernelGGL((k_fast_decode_scan<T>), grid, block, 0, st, b, t, blob, sizeGiven, b.scanSpecEnd, nRows, nCols, (T*)out);
 }
 

@@ -1313,6 +1313,94 @@ def test_sim_decode_given_a_buffer_full_of_stale_bytes_behind_the_blob(libs):
         L.lerc_amd_destroy(h)
 
 
+def test_sim_queued_decode_whose_launch_was_sized_by_a_smaller_band(libs):
+    """A queued decode is given a capacity, and the scanning decoder's launch is sized by what the context's last band of that shape
+    had (+ an eighth, + 64 KiB) instead of by the capacity.  A band that turns out LARGER than that finds too few workgroups: it says so
+    (flag 2, nothing decoded), the host forgets the guess and the scanning decoder's other form serves the call with a launch sized by
+    the capacity: one launch thrown away, counted -- and nothing keeps the bands behind it off the first form (no early count was
+    wrong, no stream was refused): the same large band once more costs no second launch, its launch sized by the large one."""
+    import ctypes as ct
+    O, S = libs
+    L = _async_lib(S)
+    h = L.lerc_amd_create(None)
+    assert h
+    L.lerc_amd_decode_forms.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+    L.lerc_amd_decode_refusals.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+    rng = np.random.default_rng(31)
+    try:
+        smooth = cases.terrain(256, 1024, rng, amp=300, base=1000, sigma=0.01).astype(np.float32)
+        noisy = (cases.terrain(256, 1024, rng, amp=300, base=1000, sigma=1.5) + rng.normal(0, 40, (256, 1024))).astype(np.float32)
+        forms = []
+        for arr, e in ((smooth, 0.05), (noisy, 0.0005), (noisy, 0.0005), (smooth, 0.05)):
+            r0, b0 = O.encode(arr, e)
+            assert r0 == 0
+            blob = _aligned(arr.nbytes + 4096)
+            blob[:] = 0
+            blob[:len(b0)] = np.frombuffer(b0, np.uint8)
+            out = _aligned(arr.nbytes).view(arr.dtype).reshape(arr.shape)
+            f0 = (ct.c_ulonglong * 4)(); f1 = (ct.c_ulonglong * 4)(); r0_ = (ct.c_ulonglong * 4)(); r1_ = (ct.c_ulonglong * 4)()
+            L.lerc_amd_decode_forms(h, f0)
+            L.lerc_amd_decode_refusals(h, r0_)
+            t2 = ct.c_uint(0)
+            rc = L.lerc_amd_decode_device_async(h, blob.ctypes.data, blob.size, 0, None, 1, arr.shape[1], arr.shape[0], 1, capi.dt_code(arr.dtype),
+                                                out.ctypes.data, ct.byref(t2))
+            assert rc == 0 and t2.value
+            assert L.lerc_amd_finish(h, t2.value, None) == 0
+            assert _same(O.decode(b0)[1].reshape(arr.shape), out)
+            L.lerc_amd_decode_forms(h, f1)
+            L.lerc_amd_decode_refusals(h, r1_)
+            forms.append(([int(f1[k] - f0[k]) for k in range(4)], len(b0), int(r1_[2] - r0_[2])))
+        sizes = [f[1] for f in forms]
+        assert sizes[1] > sizes[0] + sizes[0] // 8 + 65536 + 4096, sizes           # (else the test shows nothing)
+        assert [f[0] for f in forms] == [[0, 0, 0, 1]] * 4, forms                  # the scanning decoder every time ...
+        assert [f[2] for f in forms] == [0, 1, 0, 0], forms                        # ... and one launch thrown away, for the larger band
+    finally:
+        L.lerc_amd_destroy(h)
+
+
+def test_sim_early_counts_that_the_mending_changes(libs):
+    """The scanning decoder's pieces say how many blocks they hold as soon as the survivors are counted (form 4, EARLY).  A raster with
+    flat stretches has constant blocks, which the scan does not see and the mending enters: the piece's count changes after it has
+    left -- the piece says so, the band is decoded once more by the late form (one launch thrown away, counted), and the next bands
+    of the context start with the late form: no more launches thrown away.  Noise keeps to the early form."""
+    import ctypes as ct
+    O, S = libs
+    L = _async_lib(S)
+    h = L.lerc_amd_create(None)
+    assert h
+    L.lerc_amd_decode_forms.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+    L.lerc_amd_decode_refusals.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+    L.lerc_amd_decode_device.restype = ct.c_uint
+    L.lerc_amd_decode_device.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_uint, ct.c_void_p]
+    rng = np.random.default_rng(41)
+    try:
+        noise = cases.terrain(128, 1024, rng, amp=300, base=1000, sigma=1.5).astype(np.float32)
+        flat = noise.copy()
+        flat[40:72, 200:264] = 1234.5          # 4 x 8 blocks of one value
+        flat[96:104, 512:520] = 777.25
+        seen = []
+        for arr in (noise, flat, flat, flat, noise):
+            r0, b0 = O.encode(arr, 0.01)
+            assert r0 == 0
+            blob = _aligned(len(b0) + 4096)
+            blob[:] = 0
+            blob[:len(b0)] = np.frombuffer(b0, np.uint8)
+            out = _aligned(arr.nbytes).view(arr.dtype).reshape(arr.shape)
+            f0 = (ct.c_ulonglong * 4)(); f1 = (ct.c_ulonglong * 4)(); q0 = (ct.c_ulonglong * 4)(); q1 = (ct.c_ulonglong * 4)()
+            L.lerc_amd_decode_forms(h, f0)
+            L.lerc_amd_decode_refusals(h, q0)
+            rc = L.lerc_amd_decode_device(h, blob.ctypes.data, len(b0), 0, None, 1, arr.shape[1], arr.shape[0], 1, capi.dt_code(arr.dtype), out.ctypes.data)
+            assert rc == 0
+            assert _same(O.decode(b0)[1].reshape(arr.shape), out)
+            L.lerc_amd_decode_forms(h, f1)
+            L.lerc_amd_decode_refusals(h, q1)
+            seen.append(([int(f1[k] - f0[k]) for k in range(4)], int(q1[2] - q0[2])))
+        assert [f for f, _ in seen] == [[0, 0, 0, 1]] * 5, seen          # the scanning decoder every time
+        assert [q for _, q in seen] == [0, 1, 0, 0, 0], seen             # the early count was wrong once; the context counts late from there on
+    finally:
+        L.lerc_amd_destroy(h)
+
+
 def test_sim_masked_bands_are_cut_into_blocks_by_the_scan(libs):
     """A band with a mask (8 x 8 blocks, one value a pixel, 16-bit and wider types): the scanning decoder's first half finds the block
     offsets (tile_fast_decode_scan.hip, MODE 1 -- count bytes of 1 ... 64, one-byte blocks of pixels that are all invalid walked by the
