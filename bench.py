@@ -188,12 +188,14 @@ def other_config(torch, api, codec, name, x, max_z_err, n_depth, steps=5, warmup
     torch.cuda.synchronize()
     L.lerc_amd_profile_enable(codec.h, 1)
     enc_s = dec_s = 0.0
+    forms0, refus0, paths0 = codec.decode_forms(), codec.decode_refusals(), codec.path_counters()
     t0 = time.perf_counter()
     for _ in range(steps):
         nb = one()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     L.lerc_amd_profile_enable(codec.h, 0)
+    forms1, refus1, paths1 = codec.decode_forms(), codec.decode_refusals(), codec.path_counters()
     buf = ct.create_string_buffer(1 << 16)
     L.lerc_amd_profile_read(codec.h, buf, len(buf), 1)
     kern = {}
@@ -211,7 +213,14 @@ def other_config(torch, api, codec, name, x, max_z_err, n_depth, steps=5, warmup
            "kernel_ms_per_step": round(kms, 4), "blob_bytes": int(nb), "compression_ratio": round(raw / max(nb, 1), 3),
            "algorithmic_bytes": b_rt, "frac_of_hbm_peak_wall": round(b_rt / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
            "frac_of_hbm_peak_kernels": round(b_rt / (max(kms, 1e-9) / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
-           "host": "every call waits for its own result", "lossless_round_trip": same, "kernels": kern}
+           "host": "every call waits for its own result", "lossless_round_trip": same, "kernels": kern,
+           # which tier served the timed decodes, and what was thrown away on the way (a fall to a lower tier is a number here)
+           "decode_forms": {"masked_scan": forms1[0] - forms0[0], "two_launches": forms1[1] - forms0[1], "walking": forms1[2] - forms0[2],
+                            "scanning": forms1[3] - forms0[3]},
+           "decode_refusals": {"masked_offsets_refused": refus1[0] - refus0[0], "masked_scan_handed_on": refus1[1] - refus0[1],
+                               "tier_handed_on": refus1[2] - refus0[2]},
+           "path_counters": {"encode_streaming": paths1[0] - paths0[0], "encode_general": paths1[1] - paths0[1],
+                             "decode_streaming": paths1[2] - paths0[2], "decode_general": paths1[3] - paths0[3]}}
     sha = hashlib.sha256(out[:nb].cpu().numpy().tobytes()).hexdigest()
     res["blob_sha256"] = sha
     if reference:
@@ -667,6 +676,28 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:    # noqa: BLE001
             others["c2_masked"] = {"error": repr(e)[:200]}
+        # ... and two rasters shaped like the ones the reference was benchmarked on (none of them has sides that are
+        # multiples of 8, DEMs have lakes and sea): a ragged one, 8190 x 8190, and the C2 raster with 15 % of its area flat (a few
+        # rectangles of one value: runs of constant blocks).  decode_forms says which tier served them.
+        try:
+            xo = synth.c2_float32(8190, 8190, device=dev)
+            others["c2_ragged"] = other_config(torch, api, codec, "8190x8190 float32 DEM, MaxZError=0.01 (rows / columns no multiples of 8: edge blocks)",
+                                               xo, args.max_z_err, 1, steps=8, reference=not args.no_cpu_baseline)
+            del xo
+            torch.cuda.empty_cache()
+        except Exception as e:    # noqa: BLE001
+            others["c2_ragged"] = {"error": repr(e)[:200]}
+        try:
+            xo = synth.c2_float32(n, n, device=dev)
+            for (r0, r1, c0, c1, val) in ((512, 2560, 1024, 3584, 1017.25), (3000, 5048, 4096, 7168, 733.5), (6000, 7024, 256, 2304, 1500.0),
+                                          (5120, 5632, 0, 2048, 0.0)):
+                xo[r0:r1, c0:c1] = val          # 5.2 + 6.3 + 2.1 + 1.0 M pixels of 67.1 M: 15 %
+            others["c2_flat"] = other_config(torch, api, codec, "8192x8192 float32 DEM, MaxZError=0.01, 15 % of the area flat (rectangles of one value: runs of constant blocks)",
+                                             xo, args.max_z_err, 1, steps=8, reference=not args.no_cpu_baseline)
+            del xo
+            torch.cuda.empty_cache()
+        except Exception as e:    # noqa: BLE001
+            others["c2_flat"] = {"error": repr(e)[:200]}
 
     if rank == 0:
         blob_bytes = timed_blob_bytes

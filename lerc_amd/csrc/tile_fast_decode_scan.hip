@@ -85,7 +85,7 @@ extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_deco
 #define LERC_DEC_EXIT 99
 #endif
 #define DEC_EXIT(n) do { if (LERC_DEC_EXIT == (n)) return; } while (0)
-static const u32 kScanBadCap = 64, kScanFalseCap = 64, kScanInsCap = 128;    // (the one thread's mending: broken links, entries struck, blocks entered -- a masked band enters into END's bitmap, 2048)
+static const u32 kScanBadCap = 64, kScanFalseCap = 64, kScanInsCap = 128, kScanRunCap = 64;    // (the one thread's mending: broken links, entries struck, blocks entered -- a masked band enters into END's bitmap, 2048)
 
 template<class T> struct ScanGeom
 {
@@ -130,6 +130,7 @@ template<class T> struct ScanShared
     u16 list[G::kListCap + 8];                       // from step 3 on: the block starts, relative to the staged bytes
   } l;
   u16 badIdx[kScanBadCap], falseIdx[kScanFalseCap], insPos[kScanInsCap];
+  u16 runPos[kScanRunCap], runLen[kScanRunCap], runCnt[kScanRunCap];    // an unmasked band's mending: blocks entered, run by run (where, a block's bytes, how many)
   u32 wsum[G::NT / 64], qn[G::NT / 64];               // a wave's survivors; units a wave queued
   u64 fa[G::NT / 64], fb[G::NT / 64];
   u64 part;                                          // sum of the cells: this group's in the low half, the groups' in front in the high half
@@ -750,7 +751,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       {
         if (!final) S.t0 = anchorEnd();
         const u32 t0 = S.t0;
-        if (t0 > pos || (OFFS && t0 != 0u && t0 < pos)) { if (!final) S.frontBad = 1u; else atomicAdd(&S.nBad[pass], 1u); }
+        if (t0 > pos || ((OFFS || final) && t0 != 0u && t0 < pos)) { if (!final) S.frontBad = 1u; else atomicAdd(&S.nBad[pass], 1u); }
       }
     }
     // An unmasked band's first check: the anchor -- one thread going backwards through the survivors in front of the piece's own bytes, two
@@ -894,72 +895,128 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
 #ifdef LERC_PROBE
   TRACEV(6, (u64)S.dbg[0] | ((u64)S.dbg[1] << 16) | ((u64)S.dbg[2] << 32) | ((u64)S.dbg[3] << 48));
 #endif
-  if (S.nBad[cp] != 0u || S.frontBad != 0u)
+  // An unmasked band's piece is mended by its first WAVE: the walk through a gap takes RUNS of constant / all-zero blocks -- a flat stretch
+  // of the raster: a lake, the sea, a fill value; blocks of 1 ... 9 bytes the scan does not see, hundreds on end -- 64 blocks a step
+  // (lane i looks at the byte i block lengths on: the same flag byte but for the column signature is the same block again), and where
+  // the bytes in front hold no anchor (they lie in such a run) the piece's first block begins where the piece in front says its last
+  // one ends: that piece has said so before it waits for anybody (a chain only through pieces that begin inside a run).
+  const bool firstOfStream = dataRel >= PRE && dataRel < pieceEndRel;
+  bool mendIt = S.nBad[cp] != 0u || S.frontBad != 0u;
+  if (!OFFS && !firstOfStream && dataRel < PRE) mendIt = mendIt || S.t0 == 0u || S.nEnt == 0u || S.t0 < (u32)s_list[0];    // (no anchor; blocks missing in front of the first survivor)
+  if (mendIt)
   {
-    if (threadIdx.x == 0)
+    if (!OFFS)
     {
-      if (!OFFS)
+      if (w == 0)
       {
-        // (the unmasked bands' kernel: no runs to speak of, no raw blocks of unknown length, no anchor in front of the staged bytes -- the lean
-        // form keeps the kernel at 80 vector registers, three workgroups a CU)
         const u32 n = S.nEnt, nBad = S.nBad[cp];
-        bool good = false;
-        // where the piece's first block begins, if the bytes in front of it say so: where the anchor ends
-        const u32 t0 = S.t0;
-        u32 start0 = 0u;
-        while (start0 < n && (u32)s_list[start0] < t0) start0++;
-        // (the stream's first block is what it is, and so is what the anchor points at; else the piece's first survivor may be a
-        // false one -- and the second)
-        const bool sure = t0 != 0u || (dataRel >= PRE && dataRel < pieceEndRel);
-        const u32 tries = (S.over || nBad > kScanBadCap || n == 0u) ? 0u : (sure ? 1u : 3u);
         const u32 endTarget = lastPiece ? blobRel : pieceEndRel;
-        for (u32 tr = 0; tr < tries && start0 + tr < n && !good; tr++)
+        u32 t0 = firstOfStream ? dataRel : S.t0;
+        if (t0 == 0u && n == 0u && !firstOfStream) t0 = anchorEnd();    // (nobody has looked: the check looks for an anchor beside its first entry)
+        if (t0 == 0u && !firstOfStream && wg != 0u)
         {
-          const u32 start = start0 + tr;
-          u32 nFalse = 0u, nIns = 0u, cur = start;
-          bool fail = start > kScanFalseCap;
-          for (u32 j = 0; j < start && !fail; j++) S.falseIdx[nFalse++] = (u16)j;
-          while (!fail)
+          // no anchor: the piece in front knows (its cell's upper half, once its own list is checked and mended)
+          const u64* pc = b.wgCell + (wg - 1u);
+          u64 c = observe64(pc);
+          for (u32 spin = 0; ((u32)(c >> 32) != epoch || (((u32)c >> 16) & 0xFFFFu) == 0xFFFEu) && spin < b.spinLimit; spin++)
           {
-            u32 a = 0xFFFFu;    // the first entry from cur on whose link to the next one is broken
-            for (u32 j = 0; j < nBad; j++) { const u32 f = (u32)S.badIdx[j]; if (f >= cur && f < a) a = f; }
-            if (a == 0xFFFFu) { good = true; break; }
-            const u32 pa = (u32)s_list[a], la = parseBlock(pa, false, 0u);
-            if (la == 0u) { fail = true; break; }
-            // from this block's end to the next survivor that begins where a block ends: survivors inside what is walked over are
-            // struck, blocks the scan did not see -- not bit-stuffed, or bit-stuffed behind one that is not -- are entered
-            u32 xx = pa + la, k = a + 1u;
-            for (;;)
-            {
-              while (k < n && (u32)s_list[k] < xx && !fail)
-              {
-                if (nFalse < kScanFalseCap) S.falseIdx[nFalse++] = (u16)k; else fail = true;
-                k++;
-              }
-              if (fail) break;
-              if (k < n ? xx == (u32)s_list[k] : (lastPiece ? xx == blobRel : xx >= pieceEndRel)) break;
-              if (xx >= endTarget || nIns >= kScanInsCap) { fail = true; break; }
-              const u32 b0 = (s_in[xx >> 2] >> (8u * (xx & 3u))) & 0xFFu;
-              // (a block of pixels that are all zero, or all invalid: one byte -- a masked band has runs of them)
-              const u32 lx = ((b0 & 3u) == 2u && !(v5 && (b0 & 4u))) ? 1u : parseBlock(xx, false, 0u);
-              if (lx == 0u) { fail = true; break; }
-              S.insPos[nIns++] = (u16)xx;
-              xx += lx;
-            }
-            if (fail) break;
-            if (k < n) cur = k; else { good = true; break; }
+            __builtin_amdgcn_s_sleep(LERC_SCAN_SLEEP);
+            c = observe64(pc);
           }
-          if (good)
+          const u32 pe = ((u32)c >> 16) & 0xFFFFu;
+          if ((u32)(c >> 32) == epoch && pe < 0xFFFEu) t0 = PRE + pe;
+        }
+        bool fail = t0 == 0u || S.over != 0u || nBad > kScanBadCap;
+        bool good = false;
+        u32 nFalse = 0u, nRuns = 0u;
+        u32 start = 0u;
+        while (start < n && (u32)s_list[start] < t0) start++;
+        if (start > kScanFalseCap) fail = true;
+        for (u32 j = 0; j < start && !fail; j++) S.falseIdx[nFalse++] = (u16)j;
+        // from xx to the next survivor that begins where a block ends (k: the first list entry not passed yet): survivors inside what is
+        // walked over are struck, blocks the scan did not see are entered -- run by run.  false: no way through
+        auto walk = [&](u32 xx, u32& k) -> bool
+        {
+          for (;;)
           {
-            for (u32 j = 0; j < nFalse; j++) { const u32 pos = (u32)s_list[S.falseIdx[j]]; s_sb[pos >> 5] &= ~(1u << (pos & 31u)); }
-            for (u32 j = 0; j < nIns; j++) { const u32 pos = (u32)S.insPos[j]; s_sb[pos >> 5] |= 1u << (pos & 31u); }
-            S.nIns = nIns; S.nFalse = nFalse;
+            while (k < n && (u32)s_list[k] < xx)
+            {
+              if (nFalse >= kScanFalseCap) return false;
+              S.falseIdx[nFalse++] = (u16)k;
+              k++;
+            }
+            if (k < n ? xx == (u32)s_list[k] : (lastPiece ? xx == blobRel : xx >= pieceEndRel)) return true;
+            if (xx >= endTarget || nRuns >= kScanRunCap) return false;
+            const u32 lx = parseBlock(xx, false, 0u);
+            if (lx == 0u) return false;
+            const u32 b0 = (s_in[xx >> 2] >> (8u * (xx & 3u))) & 0xFFu;
+            u32 cnt = 1u;
+            if ((b0 & 2u) != 0u && lx <= 9u)    // (all zero, or one value: the same block may follow, again and again)
+            {
+              const u32 pos = xx + (u32)lane * lx;
+              bool go = false;
+              if (pos + lx <= G::kBytes && pos < endTarget && pos + lx <= blobRel)
+              {
+                const u32 bi = (s_in[pos >> 2] >> (8u * (pos & 3u))) & 0xFFu;
+                const bool same = ((bi ^ b0) & ~(pattern << 2) & 0xFFu) == 0u;
+                const bool known = lane != 0 && ((s_sb[pos >> 5] >> (pos & 31u)) & 1u) != 0u;    // (a survivor begins here: the run's end, mended or not)
+                go = same && !known;
+              }
+              const u64 stop = ~__builtin_amdgcn_ballot_w64(go);
+              cnt = stop ? (u32)__ffsll((long long)stop) - 1u : 64u;
+              if (cnt == 0u) return false;    // (cannot be: lane 0's block has just parsed)
+            }
+            if (lane == 0) { S.runPos[nRuns] = (u16)xx; S.runLen[nRuns] = (u16)lx; S.runCnt[nRuns] = (u16)cnt; }
+            nRuns++;
+            xx += cnt * lx;
+          }
+        };
+        u32 cur = start;
+        if (!fail && (start >= n || (u32)s_list[start] > t0))    // blocks in front of the first survivor
+        {
+          u32 k = start;
+          if (!walk(t0, k)) fail = true;
+          else if (k < n) cur = k;
+          else good = true;
+        }
+        while (!fail && !good)
+        {
+          u32 a = 0xFFFFu;    // the first entry from cur on whose link to the next one is broken
+          for (u32 j = 0; j < nBad; j++) { const u32 f = (u32)S.badIdx[j]; if (f >= cur && f < a) a = f; }
+          if (a == 0xFFFFu) { good = true; break; }
+          const u32 pa = (u32)s_list[a], la = parseBlock(pa, false, 0u);
+          if (la == 0u) { fail = true; break; }
+          u32 k = a + 1u;
+          if (!walk(pa + la, k)) { fail = true; break; }
+          if (k < n) cur = k; else good = true;
+        }
+        good = good && !fail;
+        __builtin_amdgcn_wave_barrier();
+        if (good)
+        {
+          for (u32 j = (u32)lane; j < nFalse; j += 64u) { const u32 pos = (u32)s_list[S.falseIdx[j]]; atomicAnd(&s_sb[pos >> 5], ~(1u << (pos & 31u))); }
+          __builtin_amdgcn_wave_barrier();
+          for (u32 r = 0; r < nRuns; r++)
+          {
+            const u32 rp = S.runPos[r], rl = S.runLen[r], rc = S.runCnt[r];
+            if ((u32)lane < rc) { const u32 pos = rp + (u32)lane * rl; atomicOr(&s_sb[pos >> 5], 1u << (pos & 31u)); }
           }
         }
-        if (!good) S.bad = 1u;
-        S.mended = good ? 1u : 0u;
+#ifdef HIPSIM
+        if (lane == 0 && getenv("LERC_SIM_SCAN_DIAG"))
+          printf("piece %u: mending by the first wave: %s; t0 %u (check's: %u) entries %u broken links %u -> runs %u struck %u\n", wg, good ? "good" : "FAILED", t0, S.t0, n, nBad, nRuns, nFalse);
+#endif
+        if (lane == 0)
+        {
+          S.nIns = nRuns; S.nFalse = nFalse;
+          if (good) S.t0 = t0;
+          else S.bad = 1u;
+          S.mended = good ? 1u : 0u;
+        }
       }
-      else
+    }
+    else if (threadIdx.x == 0)
+    {
       {
         const u32 n = S.nEnt, nBad = S.nBad[cp];
         bool good = false;

@@ -1401,6 +1401,62 @@ def test_sim_early_counts_that_the_mending_changes(libs):
         L.lerc_amd_destroy(h)
 
 
+def test_sim_flat_stretches_stay_on_the_scanning_decoder(libs):
+    """Rasters with flat stretches -- a lake, the sea, a fill value: runs of constant (2 ... 5 bytes) and all-zero (1 byte) blocks, hundreds
+    on end, which the scan does not see -- are the scanning decoder's: the piece's first wave walks a gap run by run, 64 blocks a step,
+    and a piece that begins inside a run (no anchor in the bytes in front of it) takes its first block's place from the piece in
+    front.  Runs longer than a piece's staged bytes in front, runs that end with the raster's block row, several values (= block lengths),
+    the stream's first and last blocks inside a run; 16- and 32-bit integers as well.  One launch is thrown away for the first such band
+    of a context (the early count is wrong: the late form mends), none after that."""
+    import ctypes as ct
+    O, S = libs
+    L = _async_lib(S)
+    L.lerc_amd_decode_forms.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+    L.lerc_amd_decode_refusals.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+    L.lerc_amd_decode_device.restype = ct.c_uint
+    L.lerc_amd_decode_device.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_uint, ct.c_void_p]
+    rng = np.random.default_rng(43)
+
+    def flats(dt, e):
+        x = cases.terrain(96, 2048, rng, amp=300, base=1000, sigma=1.5)
+        out = []
+        a = x.copy(); a[16:48, 256:1280] = 1017.25; a[64:72, 1536:2048] = 0.0; a[72:80, 0:512] = 1500.0          # 5-byte, 1-byte and short blocks; a run up to the row's end, one from its start
+        out.append(a)
+        b = x.copy(); b[0:24, 0:1024] = 733.5; b[88:96, 1024:2048] = 12.0                                      # the stream's first and last blocks lie in runs
+        out.append(b)
+        c = x.copy(); c[8:88, 64:1984] = 250.0                                                                 # mostly flat: runs of 240 blocks, a few noise blocks between
+        out.append(c)
+        d = x.copy(); d[40:48, :] = 900.0; d[48:56, :] = 0.0                                                   # whole block rows flat: 256 + 256 blocks on end, two values
+        out.append(d)
+        return [(cases._cast(v, dt), e) for v in out]
+
+    for dt, e in ((np.float32, 0.01), (np.uint16, 0), (np.int32, 0)):
+        h = L.lerc_amd_create(None)
+        assert h
+        try:
+            seen = []
+            for arr, err in flats(dt, e):
+                r0, b0 = O.encode(arr, err)
+                assert r0 == 0
+                blob = _aligned(len(b0) + 4096)
+                blob[:] = 0
+                blob[:len(b0)] = np.frombuffer(b0, np.uint8)
+                out = _aligned(arr.nbytes).view(arr.dtype).reshape(arr.shape)
+                f0 = (ct.c_ulonglong * 4)(); f1 = (ct.c_ulonglong * 4)(); q0 = (ct.c_ulonglong * 4)(); q1 = (ct.c_ulonglong * 4)()
+                L.lerc_amd_decode_forms(h, f0)
+                L.lerc_amd_decode_refusals(h, q0)
+                rc = L.lerc_amd_decode_device(h, blob.ctypes.data, len(b0), 0, None, 1, arr.shape[1], arr.shape[0], 1, capi.dt_code(arr.dtype), out.ctypes.data)
+                assert rc == 0
+                assert _same(O.decode(b0)[1].reshape(arr.shape), out), (dt, len(seen))
+                L.lerc_amd_decode_forms(h, f1)
+                L.lerc_amd_decode_refusals(h, q1)
+                seen.append(([int(f1[k] - f0[k]) for k in range(4)], int(q1[2] - q0[2])))
+            assert [f for f, _ in seen] == [[0, 0, 0, 1]] * 4, (dt, seen)      # the scanning decoder every time
+            assert [q for _, q in seen] == [1, 0, 0, 0], (dt, seen)            # the early count was wrong once
+        finally:
+            L.lerc_amd_destroy(h)
+
+
 def test_sim_masked_bands_are_cut_into_blocks_by_the_scan(libs):
     """A band with a mask (8 x 8 blocks, one value a pixel, 16-bit and wider types): the scanning decoder's first half finds the block
     offsets (tile_fast_decode_scan.hip, MODE 1 -- count bytes of 1 ... 64, one-byte blocks of pixels that are all invalid walked by the
