@@ -863,7 +863,8 @@ fastDecodeBody(DecodeShared<T, RAG>& S, const FastDecodeBuffers& b, const u8* __
         {
           const u32 q = (u32)(all >> ((u32)k * nb)) & mask;
           if (DT >= DT_Float) v[k] = (T)(offset + (double)q * p.invScale);    // Lerc2.cpp:2159-2160, no contraction
-          else v[k] = (T)(offI + (i64)q * invI);
+          else if (sizeof(T) <= 4) v[k] = (T)((u32)offI + q * (u32)invI);    // (the low 32 bits of the sum are the pixel: no 64-bit product)
+            else v[k] = (T)(offI + (i64)q * invI);
         }
         struct alignas(sizeof(T) * V) Vec { T e[V]; };
         Vec o;

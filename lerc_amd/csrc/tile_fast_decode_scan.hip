@@ -78,6 +78,9 @@ extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_deco
 #define LERC_SCAN_HELD16 2
 #endif
 // tuning: LERC_DEC_EXIT=n builds a decoder that leaves at mark n (profiles/r06_notes.md: instruction counts per phase); results are invalid
+#ifndef LERC_SCAN_STAGGER
+#define LERC_SCAN_STAGGER 0
+#endif
 #ifndef LERC_SCAN_EARLY
 #define LERC_SCAN_EARLY 1
 #endif
@@ -212,6 +215,8 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   // that far (specEnd: the blob's size where it is known, else what the context's last band of this shape had -- the bands
   // of one job are alike): the header's two microseconds are off the workgroup's critical path.  Pieces beyond that wait.
   const u32 pieceStart = wg * P;                   // blob offset of the piece's first own byte = of LDS byte PRE
+  if (LERC_SCAN_STAGGER != 0 && !OFFS && wg < 768u)    // (tuning: the launch's first pieces -- all resident at once -- start one after the other instead of together)
+    for (u32 i = 0; i < wg * (u32)LERC_SCAN_STAGGER / 16u; i++) __builtin_amdgcn_s_sleep(1);
   const Head64 h64 = loadHead64(blob, sizeGiven);
   constexpr int kRounds = G::kRounds;
   uint4 x[kRounds];
@@ -1238,6 +1243,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
           {
             const u32 q = (u32)(all >> ((u32)k * nb)) & mask;
             if (DT >= DT_Float) o.e[hv * V + k] = (T)(offset + (double)q * p.invScale);    // Lerc2.cpp:2159-2160, no contraction
+            else if (sizeof(T) <= 4) o.e[hv * V + k] = (T)((u32)offI + q * (u32)invI);    // (the low 32 bits of the sum are the pixel: no 64-bit product)
             else o.e[hv * V + k] = (T)(offI + (i64)q * invI);
           }
         }

@@ -40,3 +40,12 @@ for k, nm in enumerate(names):
     print("   %-44s mean %6.2f  p50 %6.2f  p90 %6.2f" % (nm, d.mean(), np.median(d), np.percentile(d, 90)))
 st = np.sort(us[:, 0])
 print("   start times: p10 %.1f p50 %.1f p90 %.1f max %.1f us" % (np.percentile(st, 10), np.median(st), np.percentile(st, 90), st.max()))
+# the wait for the cells by position in the stream (a chain through the groups would make it grow), and by position in the group of 64
+wait = us[:, 5] - us[:, 4]
+n_t = len(wait)
+dec = [wait[i * n_t // 10:(i + 1) * n_t // 10].mean() for i in range(10)]
+print("   wait for the cells by tenth of the stream: " + " ".join("%.2f" % v for v in dec))
+pos = np.arange(n_t) % 64
+print("   wait by position in the group (0, 1, 8, 32, 62, 63): " + " ".join("%.2f" % wait[pos == q].mean() for q in (0, 1, 8, 32, 62, 63)))
+life = us[:, 6] - us[:, 0]
+print("   life by tenth of the stream: " + " ".join("%.1f" % life[i * n_t // 10:(i + 1) * n_t // 10].mean() for i in range(10)))
