@@ -347,15 +347,19 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
   if (isFlt && rq.maxZErr > 0)
     for (int c = 0; c < 9; c++) if (errCand[c] / 2 > rq.maxZErr) candAll |= 1u << c;
   bool row0Measured = false;
+  bool maskStats = false;    // the mask's kernel has made the band's statistics as well (launchMaskStats)
   auto buildMask = [&]() -> bool
   {
     // (inputs set and results gathered by kernels, through pinned memory: see runStats)
     static_assert(sizeof(BandStats) % 4 == 0, "words");
     const u32 wStats = (u32)(sizeof(BandStats) / 4);
-    u32* pin = (u32*)ctx.pinned((size_t)(2u * wStats + 16u) * 4u);
+    u32* pin = (u32*)ctx.pinned((size_t)(2u * wStats + 4u + 16u) * 4u);
     if (!pin) return false;
     launchStatsInit(dMins, dMaxs, nD, reinterpret_cast<u32*>(dStats), wStats, candAll ? reinterpret_cast<u32*>(dStatsRow0) : nullptr, candAll ? wStats : 0u, st);
-    { ProfScope ps(ctx, "build_mask"); launchBuildMask(dt, dData, dByteMask, nRows, nCols, nD, dNewBits, dStats, st); }
+    // (the band's statistics in the same read, where the band qualifies: they stand if no TryRaiseMaxZError candidate survives the first row)
+    maskStats = false;
+    if (dByteMask && !nd.active) { ProfScope ps(ctx, "mask_stats"); maskStats = launchMaskStats(dt, dData, dByteMask, nRows, nCols, nD, dNewBits, dMins, dMaxs, dStats, st); }
+    if (!maskStats) { ProfScope ps(ctx, "build_mask"); launchBuildMask(dt, dData, dByteMask, nRows, nCols, nD, dNewBits, dStats, st); }
     row0Measured = false;
     if (candAll)
     {
@@ -363,13 +367,15 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
       row0Measured = true;
     }
     {
-      const u32* const src[5] = { reinterpret_cast<const u32*>(dStats), candAll ? reinterpret_cast<const u32*>(dStatsRow0) : nullptr, nullptr, nullptr, nullptr };
-      const u32 nw[5] = { wStats, candAll ? wStats : 0u, 0u, 0u, 0u };
+      const u32* const src[5] = { reinterpret_cast<const u32*>(dStats), candAll ? reinterpret_cast<const u32*>(dStatsRow0) : nullptr,
+                                  maskStats ? reinterpret_cast<const u32*>(dMins) : nullptr, maskStats ? reinterpret_cast<const u32*>(dMaxs) : nullptr, nullptr };
+      const u32 nw[5] = { wStats, candAll ? wStats : 0u, maskStats ? 2u : 0u, maskStats ? 2u : 0u, 0u };
       launchWordsGather(src, nw, pin, st);
     }
     if (!sync.wait()) return false;
     memcpy(&hr.stats, pin, sizeof(BandStats));
     if (candAll) memcpy(&hr.row0, pin + wStats, sizeof(BandStats));
+    if (maskStats) { memcpy(hMins.data(), pin + wStats + (candAll ? wStats : 0u), 8); memcpy(hMaxs.data(), pin + wStats + (candAll ? wStats : 0u) + 2u, 8); }
     bandNumValid = (int)hr.stats.numValid;
     bandAllValid = (bandNumValid == (int)nPix);
     haveBits = true;
@@ -461,7 +467,11 @@ static u32 encodeBand(Context& ctx, const EncodeRequest& rq, int iBand, MaskStat
       raiseMask = cand;
     }
   }
-  if (bandNumValid > 0)
+  if (bandNumValid > 0 && maskStats && raiseMask == 0u && haveBits)
+  {
+    // (the statistics came with the mask: range, "not all integers", NaN -- and no candidate asks for more)
+  }
+  else if (bandNumValid > 0)
   {
     if (!runStats(nRows, raiseMask)) return kFailed;
     if (isFlt && hr.stats.hasNaN && !haveBits)

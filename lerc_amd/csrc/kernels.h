@@ -91,6 +91,10 @@ u32 fletcherFinish(u64 sumWords, u64 sumWeighted, u32 len);
 // byte mask (1 = valid) [+ NaN test on float data] -> bit mask, numValid; nValidBlk per block position
 void launchBuildMask(int dt, const void* data, const u8* byteMask, int nRows, int nCols, int nDepth, u8* maskBits,
                      BandStats* stats, hipStream_t stream);
+// the two in one read of the band, where no TryRaiseMaxZError candidate is wanted (one value a pixel, 16- and 32-bit types, whole words of
+// the bit mask): false = not enqueued, the band does not qualify
+bool launchMaskStats(int dt, const void* data, const u8* byteMask, int nRows, int nCols, int nDepth, u8* maskBits,
+                     u64* mins, u64* maxs, BandStats* stats, hipStream_t stream);
 void launchBlockValidCounts(const u8* maskBits, const BandParams& p, u16* nValidBlk, hipStream_t stream);
 void launchBitsToBytes(const u8* maskBits, u8* byteMask, i64 nPix, hipStream_t stream);
 

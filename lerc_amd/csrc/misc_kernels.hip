@@ -6,6 +6,7 @@
 // (Lerc2.cpp:1404-1470), Lerc2::TryRaiseMaxZError (:1233-1318), Write/ReadDataOneSweep (:1343-1400),
 // FillConstImage (:2681-2721), Lerc::Convert byte<->bit mask (Lerc.cpp:959-995).
 #include "kernels.h"
+#include <limits>
 #include <algorithm>
 #include "wave_utils.h"
 
@@ -706,6 +707,132 @@ void launchBandStats(int dt, const void* data, const u8* maskBits, int nRows, in
     case DT_Double: hipLaunchKernelGGL(k_band_stats<double>, grid, block, 0, stream, (const double*)data, maskBits, nPix, nDepth, maxZErr, raiseMask, mins, maxs, stats); break;
     default: break;
   }
+}
+
+// ================================================================================================
+// Mask AND statistics in one read of the band (a band with a byte mask, one value a pixel, 16- and 32-bit types): what k_build_mask16
+// and k_band_stats_vec make in a read of the band each -- the bit mask (minus pixels that are NaN), the count of valid pixels, the
+// range of the valid pixels, "not all integers" -- for the case that no TryRaiseMaxZError candidate survives the first row (then
+// the statistics need nothing else, Lerc2.cpp:1233-1318; else launchBandStats runs as before).  A wave takes 1024 / 2048 pixels a
+// round: every load instruction reads the band (16 bytes a lane) and the byte mask (the same pixels' bytes) on end, the lanes
+// whose bits share a 32-bit word of the bit mask (pixel 8 j + i is bit 0x80 >> i of byte j) OR theirs together and one of them stores.
+// The range in the pixels' own type (float: v_min / v_max; NaN never gets there), keys at the very end.
+// ================================================================================================
+template<class T>
+__global__ void __launch_bounds__(1024)
+k_mask_stats(const T* __restrict__ data, const u8* __restrict__ byteMask, i64 nVec, u32* __restrict__ maskWords,
+             u64* __restrict__ mins, u64* __restrict__ maxs, BandStats* stats)
+{
+  constexpr int V = 16 / (int)sizeof(T);           // 4 or 8 pixels a vector
+  constexpr int L = 32 / V;                        // lanes a word of the bit mask
+  constexpr bool isFlt = (DtOf<T>::v >= DT_Float);
+  static_assert(V == 4 || V == 8, "16- and 32-bit types");
+  struct alignas(16) Vec { T v[V]; };
+  struct alignas(V) MaskBytes { u8 b[V]; };
+  __shared__ u64 s_min, s_max;
+  __shared__ u32 s_cnt, s_flags;
+  if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0u; s_flags = 0u; }
+  __syncthreads();
+  const int lane = laneId();
+  const Vec* vec = reinterpret_cast<const Vec*>(data);
+  const MaskBytes* mb = reinterpret_cast<const MaskBytes*>(byteMask);
+  T mn = std::numeric_limits<T>::max(), mx = std::numeric_limits<T>::lowest();
+  if (isFlt) { mn = (T)__builtin_huge_valf(); mx = (T)(-__builtin_huge_valf()); }
+  bool sawNaN = false, sawFrac = false;
+  u32 cnt = 0;
+  // (workgroups of sixteen waves, two to a CU: the chip is full of waves -- a wave has a round's loads in flight, no more -- and the
+  // workgroups' atomics on the statistics' addresses, 40 ns each across the XCDs, are five hundred instead of four thousand)
+  const i64 nWaves = blockDim.x / 64;
+  const i64 waveStride = (i64)gridDim.x * nWaves * 256;    // vectors: a wave takes 4 x 64 a round
+  for (i64 base = ((i64)blockIdx.x * nWaves + waveId()) * 256; base < nVec; base += waveStride)
+  {
+    Vec x[4];
+    MaskBytes m[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)    // (all loads of the round in flight together)
+    {
+      const i64 t = base + j * 64 + lane;
+      if (t < nVec) { m[j] = mb[t]; x[j] = vec[t]; }
+      else { for (int q = 0; q < V; q++) { m[j].b[q] = 0; x[j].v[q] = T(0); } }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+      const i64 t = base + j * 64 + lane;
+      u32 bits = 0;    // pixel q of the vector: bit 7 - q (V == 8), bit 3 - q (V == 4)
+#pragma unroll
+      for (int q = 0; q < V; q++)
+      {
+        bool valid = m[j].b[q] != 0;
+        const T v = x[j].v[q];
+        if (isFlt && valid && isNaNT(v)) { sawNaN = true; valid = false; }    // (one value a pixel: NaN is "not valid", Lerc.cpp:959-975)
+        if (valid)
+        {
+          bits |= 1u << (V - 1 - q);
+          mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+          if (isFlt) sawFrac = sawFrac || !(v == (T)__builtin_truncf((float)v));    // Lerc.h:271 IsInt: (T)floor(x + 0.5) == x, i.e. x is a whole number
+        }
+      }
+      cnt += (u32)__popc(bits);
+      // the word's other lanes: lane i of L holds byte i (V == 8) or a nibble of byte i / 2, the high one first (V == 4)
+      const int i = lane & (L - 1);
+      u32 word = V == 8 ? bits << (8 * i) : bits << (8 * (i >> 1) + ((i & 1) ? 0 : 4));
+      word |= __shfl_xor(word, 1);
+      word |= __shfl_xor(word, 2);
+      if (L == 8) word |= __shfl_xor(word, 4);
+      if (i == 0 && t < nVec) maskWords[t / L] = word;
+    }
+  }
+  {
+    u64 kMin = waveMin(Key<T>::enc(mn)), kMax = waveMax(Key<T>::enc(mx));
+    cnt = waveSum(cnt);
+    const bool anyNaN = __any(sawNaN), anyFrac = __any(sawFrac);
+    if (lane == 0)
+    {
+      atomicMin(&s_min, kMin); atomicMax(&s_max, kMax);
+      if (cnt) atomicAdd(&s_cnt, cnt);
+      if (anyNaN || anyFrac) atomicOr(&s_flags, (anyNaN ? 1u : 0u) | (anyFrac ? 2u : 0u));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)    // (one addition a workgroup: sixteen thousand waves adding to one address take longer than reading the band)
+  {
+    if (s_cnt)
+    {
+      atomicAdd(&stats->numValid, s_cnt);
+      // (a workgroup without a valid pixel has no range; one whose range lies inside what stands already adds nothing -- atomics of
+      // all workgroups on one address, across the XCDs, are what such a kernel's time is made of)
+      if (s_min < __hip_atomic_load(&mins[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mins[0], s_min);
+      if (s_max > __hip_atomic_load(&maxs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&maxs[0], s_max);
+    }
+    if ((s_flags & 1u) && !__hip_atomic_load(&stats->hasNaN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&stats->hasNaN, 1u);
+    if ((s_flags & 2u) && !__hip_atomic_load(&stats->notAllInt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&stats->notAllInt, 1u);
+  }
+}
+
+// true: enqueued (the band qualifies).  maskBits, mins / maxs (initialised: launchStatsInit), stats (zeroed) as for the two kernels it stands for
+bool launchMaskStats(int dt, const void* data, const u8* byteMask, int nRows, int nCols, int nDepth, u8* maskBits,
+                     u64* mins, u64* maxs, BandStats* stats, hipStream_t stream)
+{
+  static const bool on = []() { const char* e = getenv("LERC_AMD_MASK_STATS"); return !e || atoi(e) != 0; }();
+  const i64 nPix = (i64)nRows * nCols;
+  const int tb = dtSize(dt);
+  if (!on || !byteMask || nDepth != 1 || (tb != 2 && tb != 4) || (nPix & 31) != 0 || nPix < 4096 || ((uintptr_t)data & 15) != 0 || ((uintptr_t)byteMask & 15) != 0
+      || ((uintptr_t)maskBits & 3) != 0)
+    return false;
+  const i64 nVec = nPix * tb / 16;
+  static const int maxWG = []() { const char* e = getenv("LERC_AMD_MASK_STATS_WG"); return e ? std::max(1, atoi(e)) : 512; }();
+  const dim3 grid((unsigned)std::min<i64>((nVec + 4095) / 4096, maxWG)), block(1024);
+  switch (dt)
+  {
+    case DT_Short:  hipLaunchKernelGGL(k_mask_stats<short>, grid, block, 0, stream, (const short*)data, byteMask, nVec, (u32*)maskBits, mins, maxs, stats); break;
+    case DT_UShort: hipLaunchKernelGGL(k_mask_stats<unsigned short>, grid, block, 0, stream, (const unsigned short*)data, byteMask, nVec, (u32*)maskBits, mins, maxs, stats); break;
+    case DT_Int:    hipLaunchKernelGGL(k_mask_stats<int>, grid, block, 0, stream, (const int*)data, byteMask, nVec, (u32*)maskBits, mins, maxs, stats); break;
+    case DT_UInt:   hipLaunchKernelGGL(k_mask_stats<unsigned int>, grid, block, 0, stream, (const unsigned int*)data, byteMask, nVec, (u32*)maskBits, mins, maxs, stats); break;
+    case DT_Float:  hipLaunchKernelGGL(k_mask_stats<float>, grid, block, 0, stream, (const float*)data, byteMask, nVec, (u32*)maskBits, mins, maxs, stats); break;
+    default: return false;
+  }
+  return true;
 }
 
 // ================================================================================================

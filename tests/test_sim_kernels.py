@@ -1457,6 +1457,58 @@ def test_sim_flat_stretches_stay_on_the_scanning_decoder(libs):
             L.lerc_amd_destroy(h)
 
 
+def test_sim_mask_and_statistics_in_one_read(libs):
+    """A band with a byte mask (one value a pixel, 16- / 32-bit types, whole words of the bit mask): k_mask_stats makes the bit mask, the
+    count of valid pixels and the band's statistics in ONE read of the band (misc_kernels.hip) where no TryRaiseMaxZError candidate
+    survives the first row -- the profile names the kernel, the blob is the oracle's.  NaNs under the mask and outside it, rasters
+    of whole numbers (the all-integer promotion), candidates that survive (then launchBandStats runs as before)."""
+    import ctypes as ct
+    O, S = libs
+    L = _async_lib(S)
+    enc = [ct.c_void_p, ct.c_uint, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p, ct.c_double]
+    L.lerc_amd_encode_device.restype = ct.c_uint
+    L.lerc_amd_encode_device.argtypes = [ct.c_void_p] + enc + [ct.c_void_p, ct.c_uint, ct.POINTER(ct.c_uint)]
+    L.lerc_amd_profile_enable.argtypes = [ct.c_void_p, ct.c_int]
+    L.lerc_amd_profile_read.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_int, ct.c_int]
+    rng = np.random.default_rng(51)
+    h = L.lerc_amd_create(None)
+    assert h
+    try:
+        cases_ = []
+        for dt, e in ((np.float32, 0.01), (np.uint16, 0), (np.int32, 0), (np.int16, 1), (np.uint32, 2)):
+            for (r, c) in ((64, 128), (40, 104), (128, 256)):
+                x = cases._cast(cases.terrain(r, c, rng, amp=300, base=1000, sigma=2.0), dt)
+                m = (rng.random((r, c)) > 0.2).astype(np.uint8)
+                m[:8, :16] = 0
+                if dt == np.float32:
+                    x[5, 7] = np.nan; x[20, 33] = np.nan; x[2, 3] = np.nan      # (under the mask, and not)
+                cases_.append((x, m, e, True))
+        whole = np.floor(cases.terrain(64, 128, rng, amp=300, base=1000, sigma=2.0)).astype(np.float32)
+        cases_.append((whole, (rng.random((64, 128)) > 0.3).astype(np.uint8), 0.5, True))       # all integers
+        tenths = (np.round(cases.terrain(64, 128, rng, amp=30, base=100, sigma=2.0) * 10) / 10).astype(np.float32)
+        cases_.append((tenths, (rng.random((64, 128)) > 0.3).astype(np.uint8), 0.001, False))   # a candidate may survive the first row: the statistics' own kernel
+        for x, m, e, fused in cases_:
+            src = _aligned(x.nbytes).view(x.dtype).reshape(x.shape); src[...] = x
+            msk = _aligned(m.nbytes).reshape(m.shape); msk[...] = m
+            blob = _aligned(x.nbytes + 65536)
+            n = ct.c_uint(0)
+            L.lerc_amd_profile_enable(h, 1)
+            rc = L.lerc_amd_encode_device(h, src.ctypes.data, capi.dt_code(x.dtype), 1, x.shape[1], x.shape[0], 1, 1, msk.ctypes.data, float(e),
+                                          blob.ctypes.data, blob.size, ct.byref(n))
+            L.lerc_amd_profile_enable(h, 0)
+            buf = ct.create_string_buffer(1 << 16)
+            L.lerc_amd_profile_read(h, buf, len(buf), 1)
+            names = [ln.split()[0] for ln in buf.value.decode().splitlines()]
+            r0, b0 = O.encode(x, e, mask=m)
+            assert rc == r0 == 0 and blob[:n.value].tobytes() == bytes(b0), (x.dtype, x.shape, e)
+            if fused:
+                assert "mask_stats" in names and "build_mask" not in names and "band_stats" not in names, (x.dtype, x.shape, names)
+            else:
+                assert "mask_stats" in names, names
+    finally:
+        L.lerc_amd_destroy(h)
+
+
 def test_sim_masked_bands_are_cut_into_blocks_by_the_scan(libs):
     """A band with a mask (8 x 8 blocks, one value a pixel, 16-bit and wider types): the scanning decoder's first half finds the block
     offsets (tile_fast_decode_scan.hip, MODE 1 -- count bytes of 1 ... 64, one-byte blocks of pixels that are all invalid walked by the
