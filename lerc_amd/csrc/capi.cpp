@@ -225,11 +225,11 @@ lerc_status decodeHost(const unsigned char* blob, unsigned blobSize, int nMasks,
       {
         DecodeRequest rs = rq;
         rs.hBlob = nullptr; rs.dBlob = dBlob;
-        bool handled = false;
-        const u32 src = decodeSpeculativeToHost(ctx, rs, pData, outBytes, nMasks ? pValidBytes : nullptr, maskBytes, handled);
+        bool handled = false, tried = false;
+        const u32 src = decodeSpeculativeToHost(ctx, rs, pData, outBytes, nMasks ? pValidBytes : nullptr, maskBytes, handled, tried);
         if (src != kOk) return src;
         if (handled) return kOk;
-        triedOne = true;
+        triedOne = tried;    // (nothing enqueued: no form has refused the blob, nothing was written)
       }
     }
   }
@@ -514,7 +514,7 @@ void completeAll(lerc_amd_context* h)
         op.bytes = op.er.dOut ? written : needed;
         rerun = redo;
       }
-      else rerun = !decodeStreamingVerdict(ctx, slot, op.epoch, nullptr, op.form);
+      else rerun = !decodeStreamingVerdict(ctx, slot, op.epoch, nullptr, op.form, op.dr.dt);
       if (!rerun) { if (!op.isEncode) ctx.pathCount[2]++; op.done = true; continue; }
     }
     rerun = true;

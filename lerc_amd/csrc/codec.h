@@ -207,9 +207,9 @@ bool encodeEnqueueStreaming(Context& ctx, const EncodeRequest& rq, u8* slot);
 // redo: the general path has to repeat the request; else status / sizes are final
 void encodeStreamingVerdict(Context& ctx, const EncodeRequest& rq, const u8* slot, bool& redo, u32& status, u32& numBytesNeeded, u32& numBytesWritten);
 bool decodeEnqueueStreaming(Context& ctx, const DecodeRequest& rq, u8* slot, u32& epoch);
-bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits = nullptr, int form = -1);    // true: decoded, checksum good (bits: why not; form: the one that was enqueued, default the last)
+bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits = nullptr, int form = -1, int dt = -1);    // true: decoded, checksum good (bits: why not; form: the one that was enqueued, default the last)
 // host-pointer calls: streaming kernels + the results' way back to the host enqueued together, one wait (rq holds a device copy of the blob)
-u32 decodeSpeculativeToHost(Context& ctx, const DecodeRequest& rq, void* hOut, size_t outBytes, u8* hMask, size_t maskBytes, bool& handled);
+u32 decodeSpeculativeToHost(Context& ctx, const DecodeRequest& rq, void* hOut, size_t outBytes, u8* hMask, size_t maskBytes, bool& handled, bool& tried);    // tried: the streaming kernels were enqueued (and may have written pixels)
 u32 encodeTilesDevice(Context& ctx, const TilesEncodeRequest& rq, u64& arenaUsed);
 u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq);
 

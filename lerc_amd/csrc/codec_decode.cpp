@@ -246,11 +246,13 @@ static u32 fastBandVerdict(const u8* hCell, u32 epoch)
 }
 
 // a band the streaming kernels decoded: its size is the guess for the next band of that shape (launchFastBands)
-static void noteBandSize(Context& ctx, const u8* hCell)
+static void noteBandSize(Context& ctx, const u8* hCell, int dt = -1)
 {
+  // (the shape from the band's own cell, the type from the request that is being answered: with several decodes of different shapes in
+  // flight, the shape the context enqueued LAST is another band's)
   FastDecodeParams hp;
   memcpy(&hp, hCell + kCellParams, sizeof(hp));
-  ctx.scanHint.dt = ctx.lastStreamShape[0]; ctx.scanHint.nRows = ctx.lastStreamShape[1]; ctx.scanHint.nCols = ctx.lastStreamShape[2];
+  ctx.scanHint.dt = dt >= 0 ? dt : ctx.lastStreamShape[0]; ctx.scanHint.nRows = (int)hp.nRows; ctx.scanHint.nCols = (int)hp.nCols;
   ctx.scanHint.end = hp.blobEnd;
 }
 
@@ -285,7 +287,7 @@ bool decodeEnqueueStreaming(Context& ctx, const DecodeRequest& rq, u8* slot, u32
   return true;
 }
 
-bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits, int form)
+bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits, int form, int dt)
 {
   if (ctx.profOn()) ctx.profCollect();
   if (form < 0) form = ctx.lastStreamForm;
@@ -312,7 +314,7 @@ bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits, 
     return false;
   }
   if (form >= 1 && form <= 4) ctx.formCount[std::min(form, 3)]++;
-  noteBandSize(ctx, slot + 64);
+  noteBandSize(ctx, slot + 64, dt);
   return true;
 }
 
@@ -327,7 +329,7 @@ static u32 decodeSpeculative(Context& ctx, const DecodeRequest& rq, bool& handle
   if (!pin || !decodeEnqueueStreaming(ctx, rq, pin, epoch)) return kOk;
   tried = true;
   if (!ctx.sync()) return kFailed;
-  handled = decodeStreamingVerdict(ctx, pin, epoch, bits);
+  handled = decodeStreamingVerdict(ctx, pin, epoch, bits, -1, rq.dt);
   return kOk;
 }
 
@@ -878,7 +880,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
       return kOk;
     }
     if (fastLevel >= 1 && fastLevel <= 4) ctx.formCount[std::min(fastLevel, 3)]++;
-    noteBandSize(ctx, pin + 64 + (size_t)iBand * kCellBytes);
+    noteBandSize(ctx, pin + 64 + (size_t)iBand * kCellBytes, dt);
   }
   for (int iBand = 0; iBand < rq.nBands; iBand++)
   {
@@ -906,17 +908,18 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
 // Host-pointer calls on a device copy of the blob: the same, with the pixels' (and the mask bytes') way back to the host
 // enqueued behind the kernels, so that the calling thread waits once.  handled == false: the device did not vouch for
 // what it wrote (the caller goes the long way and overwrites it).
-u32 decodeSpeculativeToHost(Context& ctx, const DecodeRequest& rq, void* hOut, size_t outBytes, u8* hMask, size_t maskBytes, bool& handled)
+u32 decodeSpeculativeToHost(Context& ctx, const DecodeRequest& rq, void* hOut, size_t outBytes, u8* hMask, size_t maskBytes, bool& handled, bool& tried)
 {
-  handled = false;
+  handled = false; tried = false;
   u8* pin = (u8*)ctx.pinned(64 + kCellBytes);
   u32 epoch = 0;
   if (!pin || !decodeEnqueueStreaming(ctx, rq, pin, epoch)) return kOk;
+  tried = true;
   hipStream_t st = ctx.activeStream();
   hipMemcpyAsync(hOut, rq.dOut, outBytes, hipMemcpyDeviceToHost, st);
   if (hMask && rq.dValidBytes) hipMemcpyAsync(hMask, rq.dValidBytes, maskBytes, hipMemcpyDeviceToHost, st);
   if (!ctx.sync()) return kFailed;
-  handled = decodeStreamingVerdict(ctx, pin, epoch);
+  handled = decodeStreamingVerdict(ctx, pin, epoch, nullptr, -1, rq.dt);
   if (handled) { ctx.pathCount[2]++; ctx.lastDecodeStreamed = true; }
   return kOk;
 }
@@ -982,9 +985,15 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
     one.dBlob = rq.dArena + rq.hOffsets[t]; one.blobSize = rq.hSizes[t]; one.dt = rq.dt; one.nDepth = 1; one.nCols = rq.nCols;
     one.nRows = rq.nRows; one.nBands = 1; one.nMasks = 0; one.dValidBytes = nullptr;
     one.dOut = (u8*)rq.dOut + (size_t)t * tileElems * tbytes;
-    one.maxForm = batchForm - 1;                  // the batch's kernels have just been tried: the next form (or, if the batch was the two-launch form, the general kernels)
+    one.maxForm = batchForm > 0 ? batchForm - 1 : 4;    // the batch's kernels have just been tried: the next form (or, if the batch was the two-launch form, the general kernels); no batch launch: every form
     one.noStreaming = one.maxForm <= 0;
-    return decodeDevice(ctx, one);
+    const u32 rc = decodeDevice(ctx, one);
+    if (rc == kFailed)    // (a failed decode leaves zeros, include/lerc_amd.h: the streaming kernels may have written pixels of a damaged blob)
+    {
+      hipMemsetAsync(one.dOut, 0, (size_t)tileElems * tbytes, ctx.activeStream());
+      hipStreamSynchronize(ctx.activeStream());
+    }
+    return rc;
   };
   bool fastOk = fastDecodeEligible(rq.dt, 6, 8, rq.nRows, rq.nCols, 1, true) && ((uintptr_t)rq.dArena & 15) == 0
     && ((uintptr_t)rq.dOut & 15) == 0 && ((tileElems * tbytes) % 16 == 0 || rq.nRows % 8 != 0 || rq.nCols % 8 != 0);    // (ragged tiles: pixel-wise stores)

@@ -608,8 +608,8 @@ k_band_stats_vec(const T* __restrict__ data, const u8* __restrict__ maskBits, i6
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    if (s_min != ~0ull) atomicMin(&mins[0], s_min);
-    if (s_max != 0ull) atomicMax(&maxs[0], s_max);
+    if (s_min != ~0ull && s_min < __hip_atomic_load(&mins[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mins[0], s_min);
+    if (s_max != 0ull && s_max > __hip_atomic_load(&maxs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&maxs[0], s_max);
     if ((s_flags & 1u) && !__hip_atomic_load(&stats->hasNaN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&stats->hasNaN, 1u);
     if ((s_flags & 2u) && !__hip_atomic_load(&stats->notAllInt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&stats->notAllInt, 1u);
   }
@@ -649,10 +649,22 @@ k_band_stats_bytes(const T* __restrict__ data, i64 nVec, int nDepth, u64* __rest
   const int phase = (int)((first * 16) % nDepth);
 #pragma unroll
   for (int b = 0; b < 16; b++)
-    if (mn[b] <= mx[b]) { const int m = (phase + b) % nDepth; atomicMin(&s_min[m], mn[b]); atomicMax(&s_max[m], mx[b]); }
+    if (mn[b] <= mx[b])
+    {
+      // (an atomic only where it changes something: sixteen of them a thread on nDepth addresses, and the workgroups' on the band's,
+      // are otherwise what this kernel's time is made of)
+      const int m = (phase + b) % nDepth;
+      if (mn[b] < *(volatile int*)&s_min[m]) atomicMin(&s_min[m], mn[b]);
+      if (mx[b] > *(volatile int*)&s_max[m]) atomicMax(&s_max[m], mx[b]);
+    }
   __syncthreads();
   for (int i = threadIdx.x; i < nDepth; i += 256)
-    if (s_min[i] <= s_max[i]) { atomicMin(&mins[i], Key<T>::enc((T)s_min[i])); atomicMax(&maxs[i], Key<T>::enc((T)s_max[i])); }
+    if (s_min[i] <= s_max[i])
+    {
+      const u64 kMin = Key<T>::enc((T)s_min[i]), kMax = Key<T>::enc((T)s_max[i]);
+      if (kMin < __hip_atomic_load(&mins[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mins[i], kMin);
+      if (kMax > __hip_atomic_load(&maxs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&maxs[i], kMax);
+    }
 }
 
 void launchBandStats(int dt, const void* data, const u8* maskBits, int nRows, int nCols, int nDepth, u32 raiseMask,

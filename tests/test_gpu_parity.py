@@ -199,6 +199,74 @@ def test_c2_full_size_8192_float32(P, O):
     assert float((y2.double() - y.double()).abs().max().item()) <= 0.01 + 6.2e-5
 
 
+def test_flat_stretches_stay_on_the_scanning_decoder_at_full_size(P, O):
+    """The C2 raster with 15 % of its area flat (rectangles of one value: runs of constant and all-zero blocks, 256 ... 384 on end, in
+    every piece of the stream): the scanning decoder's first wave walks the runs, pieces that begin inside one take their first block's
+    place from the piece in front.  Blob = the oracle's, pixels = the oracle's decode; the first such band of a context costs one
+    launch (its early counts are wrong), the bands behind it none; the same with uint16 (two vectors of blocks a lane less)."""
+    import torch
+    from lerc_amd import api, synth
+    for make, e, n in ((lambda: synth.c2_float32(8192, 8192, device="cuda:0"), 0.01, 8192),
+                       (lambda: synth.c3_uint16(4096, 8192, device="cuda:0"), 0, 4096)):
+        x = make()
+        xv = x if x.dtype == torch.float32 else x.view(torch.int16)    # (the same bits: values below 2^15)
+        for (r0, r1, c0, c1, val) in ((512, 2560, 1024, 3584, 1017), (3000, 4096, 4096, 7168, 733), (1000, 2024, 256, 2304, 1500), (3072, 3584, 0, 2048, 0)):
+            xv[r0:min(r1, n), c0:c1] = val
+        if x.dtype == torch.float32:
+            x[512:2560, 1024:3584] += 0.25
+        codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
+        out = torch.empty(x.numel() * x.element_size() + (1 << 20), dtype=torch.uint8, device=x.device)
+        y = torch.empty_like(x)
+        rc, nb = api.encode_device(codec, x, e, out)
+        assert rc == 0
+        xh = x.cpu().numpy()
+        rc, b2 = O.encode(xh, e)
+        blob = out[:nb].cpu().numpy().tobytes()
+        assert rc == 0 and len(b2) == nb and sha(b2) == sha(blob)
+        seen = []
+        for _ in range(3):
+            f0, q0 = codec.decode_forms(), codec.decode_refusals()
+            y.zero_()
+            rc = api.decode_device(codec, out, nb, y)
+            assert rc == 0, codec.last_error()
+            torch.cuda.synchronize()
+            f1, q1 = codec.decode_forms(), codec.decode_refusals()
+            seen.append((f1[3] - f0[3], q1[2] - q0[2]))
+            rc, dec, _ = O.decode(blob)
+            assert rc == 0 and np.array_equal(dec.reshape(xh.shape), y.cpu().numpy())
+        assert seen == [(1, 1), (1, 0), (1, 0)], (seen, codec.last_note())
+
+
+def test_mask_and_statistics_in_one_read_at_full_size(P, O):
+    """A masked 8192 x 4096 float32 band (and a uint16 one): the bit mask and the band's statistics come out of one kernel (the profile
+    says which), the blob is the oracle's -- NaNs under the mask and beside it."""
+    import ctypes as ct
+    import torch
+    from lerc_amd import api, synth
+    for make, e in ((lambda: synth.c2_float32(4096, 8192, device="cuda:0"), 0.01), (lambda: synth.c3_uint16(2048, 8192, device="cuda:0"), 0)):
+        x = make()
+        r, c = x.shape
+        ii = torch.arange(r, device=x.device).view(-1, 1); jj = torch.arange(c, device=x.device).view(1, -1)
+        mk = (((ii // 97) + (jj // 131)) % 10 != 0).to(torch.uint8).contiguous()
+        if x.dtype == torch.float32:
+            x[5, 7] = float("nan"); x[1000, 4000] = float("nan"); x[0, 0] = float("nan")
+        codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
+        L = codec.lib
+        L.lerc_amd_profile_enable.argtypes = [ct.c_void_p, ct.c_int]
+        L.lerc_amd_profile_read.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_int, ct.c_int]
+        out = torch.empty(x.numel() * x.element_size() + (1 << 20), dtype=torch.uint8, device=x.device)
+        L.lerc_amd_profile_enable(codec.h, 1)
+        rc, nb = codec.encode(x.data_ptr(), api._torch_dt_code(x), 1, c, r, 1, e, out.data_ptr(), out.numel(), mk.data_ptr(), 1)
+        assert rc == 0, codec.last_error()
+        L.lerc_amd_profile_enable(codec.h, 0)
+        buf = ct.create_string_buffer(1 << 16)
+        L.lerc_amd_profile_read(codec.h, buf, len(buf), 1)
+        names = [ln.split()[0] for ln in buf.value.decode().splitlines()]
+        assert "mask_stats" in names and "build_mask" not in names and "band_stats" not in names, names
+        rc, b2 = O.encode(x.cpu().numpy(), e, mask=mk.cpu().numpy())
+        assert rc == 0 and len(b2) == nb and sha(b2) == sha(out[:nb].cpu().numpy().tobytes())
+
+
 def test_c3_full_size_16384_uint16_lossless(P, O):
     """BASELINE configs[2]: lossless integer path, bit exact round trip, identical to the oracle."""
     import torch
