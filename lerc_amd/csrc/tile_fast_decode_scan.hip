@@ -1238,6 +1238,29 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
           const u32 bit0 = pbit + (u32)(e0 + hv * 8 * RSTEP) * nb, wi = bit0 >> 5;
           const u32 x0 = s_in[wi], x1 = s_in[wi + 1], x2 = s_in[wi + 2];
           const u64 all = ((u64)__builtin_amdgcn_alignbit(x2, x1, bit0) << 32) | __builtin_amdgcn_alignbit(x1, x0, bit0);
+#ifndef HIPSIM
+          if constexpr (sizeof(T) == 2 && V == 8 && DT < DT_Float)
+          {
+            // 16-bit pixels: eight values of at most eight bits -- the first four lie in the low word, the other four in the word that begins
+            // 4 nb bits on: a bit-field extract a value (no 64-bit shifts), and without a scale (lossless: 1) an addition
+            const u32 lo = (u32)all, mid = (u32)(all >> (4u * nb));
+            const u32 off32 = (u32)offI, inv32 = (u32)invI;
+            u32 q8[8];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { q8[k] = __builtin_amdgcn_ubfe(lo, (u32)k * nb, nb); q8[4 + k] = __builtin_amdgcn_ubfe(mid, (u32)k * nb, nb); }
+            if (inv32 == 1u)
+            {
+#pragma unroll
+              for (int k = 0; k < 8; k++) o.e[hv * V + k] = (T)(off32 + q8[k]);
+            }
+            else
+            {
+#pragma unroll
+              for (int k = 0; k < 8; k++) o.e[hv * V + k] = (T)(off32 + q8[k] * inv32);
+            }
+            continue;
+          }
+#endif
 #pragma unroll
           for (int k = 0; k < V; k++)
           {
