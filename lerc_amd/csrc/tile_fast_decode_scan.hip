@@ -643,7 +643,9 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
         const u32 pay = pos + ((mode == 1u) ? 3u + codeOffBytes(code) + lutB : 1u);
         word = (pay & 0xFFFFu) | (nb << 16) | (mode << 21) | (lutB << 23) | ((plainB ? 1u : 0u) << 24) | 0x80000000u;
       }
-      s_offs[t] = offset;
+      // (integer types: the offset as the integer the pixel loop adds to -- converted here, once a block, not once a lane and block row)
+      if (DT < DT_Float) { const i64 oi = (i64)offset; double od; memcpy(&od, &oi, 8); s_offs[t] = od; }
+      else s_offs[t] = offset;
       s_code[t] = word;
       s_at[t] = (h0 >> 2) & pattern;     // (the signature, until the block's place is known)
     }
@@ -1217,7 +1219,9 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   auto blockRow = [&](u32 tSlot, bool have) -> Vec
   {
     const u32 code = have ? s_code[tSlot] : 0u;
-    const double offset = s_offs[tSlot];
+    const double offRaw = s_offs[tSlot];
+    i64 offBits; memcpy(&offBits, &offRaw, 8);
+    const double offset = DT < DT_Float ? (double)offBits : offRaw;    // (integer types keep the integer: see parseBlock)
     const u32 nbC = (code >> 16) & 31u, mode = (code >> 21) & 3u, lut = (code >> 23) & 1u;
     const u32 pbit = 8u * (code & 0xFFFFu);        // payload / first raw value
     const int e0 = r * 8 + h * V;
@@ -1231,7 +1235,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       {
         const u32 nb = nbC;
         const u32 mask = nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
-        const i64 offI = (i64)offset;
+        const i64 offI = DT < DT_Float ? offBits : (i64)offset;
 #pragma unroll
         for (int hv = 0; hv < NV; hv++)    // (a vector's V values lie inside 64 bits: three words of the stream, a funnel shift each way)
         {
@@ -1294,7 +1298,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       else if (mode == 1)
       {
         const int nb = (int)nbC;
-        const i64 offI = (i64)offset;
+        const i64 offI = DT < DT_Float ? offBits : (i64)offset;
         if (!lut)
         {
 #pragma unroll
