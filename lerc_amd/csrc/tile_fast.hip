@@ -1441,7 +1441,13 @@ template<class T, bool WIDE, int U, bool PART, bool MASKED = false>
 #ifndef LERC_PART_WAVES
 #define LERC_PART_WAVES 6    // (ragged rasters: at 64 registers the float kernel spills 60 bytes a lane and takes 185 us for 8190^2 instead of 142)
 #endif
-__global__ void __launch_bounds__(256, (sizeof(T) <= 4 ? (MASKED ? LERC_MASKED_WAVES : PART ? LERC_PART_WAVES : 8) : 1)) LERC_SGPR_CAP    // (MASKED at 64 registers: 208 bytes of scratch a lane)
+#ifndef LERC_W32_WAVES
+#define LERC_W32_WAVES 7    // (32-bit types: 68 registers and no scratch; at eight waves -- 64 registers -- the float kernel spills three and takes 91 us instead of 85)
+#endif
+#ifndef LERC_U16_WAVES
+#define LERC_U16_WAVES 8
+#endif
+__global__ void __launch_bounds__(256, (sizeof(T) <= 4 ? (MASKED ? LERC_MASKED_WAVES : PART ? LERC_PART_WAVES : sizeof(T) == 2 ? LERC_U16_WAVES : LERC_W32_WAVES) : 1)) LERC_SGPR_CAP    // (MASKED at 64 registers: 208 bytes of scratch a lane)
 k_fast_encode1(const T* __restrict__ data, BandParams p, u8* __restrict__ out, FastEncodeResult* __restrict__ res, u32 nWG, u32 nBlobsMore,
                 FastFused f, double requestedMaxZErr, u32 raiseCandidates, u64 outCapacity)
 {
