@@ -78,6 +78,9 @@ extern "C" __attribute__((visibility("default"))) void lerc_amd_probe_trace_deco
 #define LERC_SCAN_HELD16 2
 #endif
 // tuning: LERC_DEC_EXIT=n builds a decoder that leaves at mark n (profiles/r06_notes.md: instruction counts per phase); results are invalid
+#ifndef LERC_SCAN_DIRECT
+#define LERC_SCAN_DIRECT 0
+#endif
 #ifndef LERC_SCAN_STAGGER
 #define LERC_SCAN_STAGGER 0
 #endif
@@ -125,6 +128,7 @@ template<class T> struct ScanShared
       double offs[G::R];
       u32 code[G::R];                                // what the pixel loop wants to know of the block, 0 = bad
       u32 at[G::R];                                  // raster offset (pixels) of the block's first pixel
+      u8 dims[G::R];                                 // RAG: the block's columns | rows << 4 (the raster's last blocks are smaller)
     } x;
   } u;
   union L
@@ -166,6 +170,15 @@ template<bool ANYCOUNT> __device__ __forceinline__ u32 countByteHits(u32 cur4, u
   const u32 nz = ((hdr4 & 0x1F1F1F1Fu) + 0x1F1F1F1Fu) << 2;                         // 0x80 set where n != 0
   return ~z & nz;
 }
+// the same for ONE count value v (v4 = v in every byte): 0x80 in every byte of cur4 that is v behind a byte 10?nnnnn, n != 0
+__device__ __forceinline__ u32 countByteHitsOf(u32 cur4, u32 prev4, u32 v4)
+{
+  const u32 hdr4 = __builtin_amdgcn_alignbit(cur4, prev4, 24);
+  const u32 t = (cur4 ^ v4) | ((hdr4 & 0xC0C0C0C0u) ^ 0x80808080u);
+  const u32 z = ((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu;
+  const u32 nz = ((hdr4 & 0x1F1F1F1Fu) + 0x1F1F1F1Fu) << 2;
+  return ~z & nz;
+}
 // bit 7 of a byte of the result is CLEAR where cur4 reads such a count byte behind a byte 10...... (a filter: n is not looked at)
 template<bool ANYCOUNT> __device__ __forceinline__ u32 countByteMaybe(u32 cur4, u32 prev4)
 {
@@ -194,12 +207,27 @@ struct ScanOffsetsJob
   u32 nPos;
 };
 
-template<class T, int MODE>
+template<class T, int MODE, bool RAG = false>
 __device__ __forceinline__ void
 fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict__ blob, u32 sizeGiven, u32 specEnd, int nRows, int nCols,
              T* __restrict__ outPix, u32 wg, const ScanOffsetsJob& job)
 {
   constexpr bool OFFS = MODE == 1;
+  static_assert(!(RAG && OFFS), "ragged rasters with a mask keep to the general discovery");
+  // RAG: a raster whose rows / columns are no multiples of 8 -- the last block of a block row holds 8 x wl pixels, the blocks of the last
+  // block row hl x 8 (the corner wl x hl), and their count bytes say so (Lerc2.cpp:1504-1519).  The filter also takes the count byte of the
+  // LAST BLOCK ROW's blocks (a whole block row of them on end); the one edge block a block row comes in through the mending.
+  const u32 ragWl = RAG ? (u32)nCols & 7u : 0u, ragHl = RAG ? (u32)nRows & 7u : 0u;
+  const u32 ragC2 = ragHl * 8u;                      // count byte of the last block row's blocks (0: no such row)
+  const u32 ragC3 = (ragWl != ragHl) ? ragWl * 8u : 0u;    // ... and of a block row's last block (0: no such column, or the same value): one block in nTH -- left to the mending it is a gap every few blocks of a narrow raster
+  // a RAW block's length is 1 + n sizeof(T), n the pixels of the block -- which the stream does not say: a whole block's 64 or an edge
+  // block's; where the next block begins says which (the mending looks, the last check takes it from the list)
+  auto ragRawOk = [&](u32 bytes) -> bool
+  {
+    if (bytes < 1u + (u32)sizeof(T) || (bytes - 1u) % (u32)sizeof(T) != 0u) return false;
+    const u32 n = (bytes - 1u) / (u32)sizeof(T);
+    return n == 64u || (ragWl != 0u && n == 8u * ragWl) || (ragHl != 0u && n == 8u * ragHl) || (ragWl != 0u && ragHl != 0u && n == ragWl * ragHl);
+  };
   typedef ScanGeom<T> G;
   constexpr int DT = G::DT;
   constexpr u32 W = G::W, P = G::P, NT = G::NT, PRE = G::PRE, kUnits = G::kUnits;
@@ -367,6 +395,22 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
         { const u32 t = x[k].y ^ 0x40404040u; acc |= (t - 0x01010101u) & ~t; }
         { const u32 t = x[k].z ^ 0x40404040u; acc |= (t - 0x01010101u) & ~t; }
         { const u32 t = x[k].w ^ 0x40404040u; acc |= (t - 0x01010101u) & ~t; }
+        if (RAG && ragC2 != 0u)
+        {
+          const u32 c4 = ragC2 * 0x01010101u;
+          { const u32 t = x[k].x ^ c4; acc |= (t - 0x01010101u) & ~t; }
+          { const u32 t = x[k].y ^ c4; acc |= (t - 0x01010101u) & ~t; }
+          { const u32 t = x[k].z ^ c4; acc |= (t - 0x01010101u) & ~t; }
+          { const u32 t = x[k].w ^ c4; acc |= (t - 0x01010101u) & ~t; }
+        }
+        if (RAG && ragC3 != 0u)
+        {
+          const u32 c4 = ragC3 * 0x01010101u;
+          { const u32 t = x[k].x ^ c4; acc |= (t - 0x01010101u) & ~t; }
+          { const u32 t = x[k].y ^ c4; acc |= (t - 0x01010101u) & ~t; }
+          { const u32 t = x[k].z ^ c4; acc |= (t - 0x01010101u) & ~t; }
+          { const u32 t = x[k].w ^ c4; acc |= (t - 0x01010101u) & ~t; }
+        }
         has = (acc & 0x80808080u) != 0u;
       }
       else
@@ -427,7 +471,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       const u32 tB = (a2 >> 8) & 0xFFu, nb = tB & 31u, lut = (tB >> 5) & 1u;
       const u32 nLut = ((a2 >> 24) - 1u) & 0xFFu;                          // valid: 1 ... 254
       const bool okLut = (lut == 0u) | ((nLut - 1u) < 254u);
-      const u32 cnt = OFFS ? ((a2 >> 16) & 0xFFu) : 64u;                       // elements of the block: the count byte
+      const u32 cnt = (OFFS || RAG) ? ((a2 >> 16) & 0xFFu) : 64u;              // elements of the block: the count byte (RAG: 64, or the last block row's)
       const u32 payload = lut ? 1u + ((nLut * nb + 7u) >> 3) + ((cnt * (u32)bitLen(nLut) + 7u) >> 3) : ((cnt * nb + 7u) >> 3);
 #pragma unroll
       for (u32 tc = 0; tc < 4; tc++)
@@ -437,7 +481,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
         const u32 m = 8u - offB;                                           // the flag byte is byte m of the twelve
         const u32 flag = ((m < 4u ? a0 : m < 8u ? a1 : a2) >> (8u * (m & 3u))) & 0xFFu;
         const u32 len = 3u + offB + payload;
-        const bool ok = (flag & 3u) == 1u && (flag >> 6) == tc && !(v5 && (flag & 4u)) && okLut && len <= (OFFS ? 1u + cnt * G::TB : RAW) && q >= 2u + offB;    // (no longer than the raw form of so many values)
+        const bool ok = (flag & 3u) == 1u && (flag >> 6) == tc && !(v5 && (flag & 4u)) && okLut && len <= ((OFFS || RAG) ? 1u + cnt * G::TB : RAW) && q >= 2u + offB;    // (no longer than the raw form of so many values)
         const u32 p = q - 2u - offB, e = p + len;
         // (what stands where the candidate ends has to read like the flag byte of the block behind it: the column signature goes
         // on, by a step or none, or begins again with a block row -- four bytes in five of anything else do not)
@@ -460,7 +504,17 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     {
       const uint4 xu = *reinterpret_cast<const uint4*>(&s_in[4u * unit]);
       const u32 pvu = S.inAll[4u * unit + 3u];                               // (the dword in front of the unit; in front of the staged bytes: 0)
-      const u32 m0 = countByteHits<OFFS>(xu.x, pvu), m1 = countByteHits<OFFS>(xu.y, xu.x), m2 = countByteHits<OFFS>(xu.z, xu.y), m3 = countByteHits<OFFS>(xu.w, xu.z);
+      u32 m0 = countByteHits<OFFS>(xu.x, pvu), m1 = countByteHits<OFFS>(xu.y, xu.x), m2 = countByteHits<OFFS>(xu.z, xu.y), m3 = countByteHits<OFFS>(xu.w, xu.z);
+      if (RAG && ragC2 != 0u)
+      {
+        const u32 c4 = ragC2 * 0x01010101u;
+        m0 |= countByteHitsOf(xu.x, pvu, c4); m1 |= countByteHitsOf(xu.y, xu.x, c4); m2 |= countByteHitsOf(xu.z, xu.y, c4); m3 |= countByteHitsOf(xu.w, xu.z, c4);
+      }
+      if (RAG && ragC3 != 0u)
+      {
+        const u32 c4 = ragC3 * 0x01010101u;
+        m0 |= countByteHitsOf(xu.x, pvu, c4); m1 |= countByteHitsOf(xu.y, xu.x, c4); m2 |= countByteHitsOf(xu.z, xu.y, c4); m3 |= countByteHitsOf(xu.w, xu.z, c4);
+      }
       const u32 zb = (m0 >> 7) | ((m1 >> 7) << 1) | ((m2 >> 7) << 2) | ((m3 >> 7) << 3);
       const u32 tb = zb | (zb >> 4);
       return (tb & 0xFFu) | ((tb >> 8) & 0xFF00u);
@@ -591,7 +645,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   const struct { int nCols, version; double invScale, zMaxHdr; } p = { (int)hp.nCols, (int)hp.version, hp.invScale, hp.zMaxHdr };
   typedef DCfg<T> C;
   constexpr int V = C::V, LPR = C::LPR, BPW = C::BPW;
-  auto& s_offs = S.u.x.offs; auto& s_code = S.u.x.code; auto& s_at = S.u.x.at;
+  auto& s_offs = S.u.x.offs; auto& s_code = S.u.x.code; auto& s_at = S.u.x.at; auto& s_dims = S.u.x.dims;
   // the block at list entry f: its length, or 0 if it is none; keep: what the pixel loop needs goes to slot t
   auto parseBlock = [&](u32 pos, bool keep, u32 t) -> u32
   {
@@ -609,7 +663,21 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       nEl = mode == 1u ? ((tt >> 8) & 0xFFu) : 64u;       // (constant blocks have no count, and their length does not hang on it)
       if (mode == 0u || (nEl - 1u) >= 64u) nEl = 0u;
     }
-    u32 code = (OFFS && nEl == 0u) ? 0u : parseCode<DT>(h0, h1, h2, p.version, nEl);
+    if (RAG)
+    {
+      // the count byte of a bit-stuffed block says how many pixels it holds: a whole block's 64, or what an edge block may hold (which of
+      // them it has to be is checked when the block's place is known); raw blocks are taken for whole ones (a raw EDGE block is
+      // shorter: such a stream does not tile and goes down a tier), constant blocks have no count
+      const u32 offB = (offBytesTable<DT>() >> ((h0 >> 4) & 12u)) & 15u;
+      u32 tt = (u32)((((u64)h1 << 32) | h0) >> ((8u + 8u * offB) & 63u));
+      if (DT == DT_Double && offB == 8u) tt = h2 >> 8;
+      if ((h0 & 3u) == 1u)
+      {
+        const u32 c = (tt >> 8) & 0xFFu;
+        nEl = (c == 64u || (ragWl != 0u && c == 8u * ragWl) || (ragHl != 0u && c == 8u * ragHl) || (ragWl != 0u && ragHl != 0u && c == ragWl * ragHl)) ? c : 0u;
+      }
+    }
+    u32 code = ((OFFS || RAG) && nEl == 0u) ? 0u : parseCode<DT>(h0, h1, h2, p.version, nEl);
     if (pos + codeLen(code) > blobRel) code = 0u;
     const u32 len = codeLen(code);
     if (!OFFS && keep)
@@ -638,10 +706,11 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
           const u32 qTop = nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
           const bool below = (DT >= DT_Float) ? (offset + (double)qTop * p.invScale < p.zMaxHdr)
                                               : ((i64)offset + (i64)qTop * (i64)p.invScale < (i64)p.zMaxHdr);
-          plainB = below && !lutB && (u32)V * nb <= 64u;
+          plainB = below && !lutB && (u32)V * nb <= 64u && (!RAG || nEl == 64u);
         }
         const u32 pay = pos + ((mode == 1u) ? 3u + codeOffBytes(code) + lutB : 1u);
         word = (pay & 0xFFFFu) | (nb << 16) | (mode << 21) | (lutB << 23) | ((plainB ? 1u : 0u) << 24) | 0x80000000u;
+        if (RAG) word |= ((nEl - 1u) & 63u) << 25;    // (how many pixels the block says it holds, until its place is known)
       }
       // (integer types: the offset as the integer the pixel loop adds to -- converted here, once a block, not once a lane and block row)
       if (DT < DT_Float) { const i64 oi = (i64)offset; double od; memcpy(&od, &oi, 8); s_offs[t] = od; }
@@ -736,6 +805,13 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
         const u32 b0 = (s_in[pos >> 2] >> (8u * (pos & 3u))) & 0xFFu;
         const u32 e = last ? S.mendExit : nxt;
         if ((b0 & 3u) == 0u && (b0 >> 6) == 0u && !(v5 && (b0 & 4u)) && e > pos + 1u && (e - pos - 1u) % G::TB == 0u && (e - pos - 1u) / G::TB <= 64u && e <= blobRel) len = e - pos;
+      }
+      if (RAG && final)
+      {
+        // (a raw EDGE block is shorter than parseBlock takes it to be: it ends where the next entry begins -- the mending has looked)
+        const u32 b0 = (s_in[pos >> 2] >> (8u * (pos & 3u))) & 0xFFu;
+        const u32 e = last ? S.mendExit : nxt;
+        if ((b0 & 3u) == 0u && (b0 >> 6) == 0u && !(v5 && (b0 & 4u)) && e > pos && e != pos + len && e <= blobRel && ragRawOk(e - pos)) len = e - pos;
       }
       const u32 ext = pos + len;
       const bool ok = len != 0u && (last ? (lastPiece ? ext == blobRel : ext >= pieceEndRel) : ext == nxt);
@@ -952,9 +1028,37 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
               S.falseIdx[nFalse++] = (u16)k;
               k++;
             }
-            if (k < n ? xx == (u32)s_list[k] : (lastPiece ? xx == blobRel : xx >= pieceEndRel)) return true;
+            if (k < n ? xx == (u32)s_list[k] : (lastPiece ? xx == blobRel : xx >= pieceEndRel)) { if (RAG && k >= n && lane == 0) S.mendExit = xx; return true; }
             if (xx >= endTarget || nRuns >= kScanRunCap) return false;
-            const u32 lx = parseBlock(xx, false, 0u);
+            u32 lx = parseBlock(xx, false, 0u);
+            if (RAG)
+            {
+              // a raw block: whole (what parseBlock says) or an edge block's few pixels -- the first length behind which a known block
+              // begins (the next entry, the blob's end) or a block parses
+              const u32 bq = (s_in[xx >> 2] >> (8u * (xx & 3u))) & 0xFFu;
+              if ((bq & 3u) == 0u && (bq >> 6) == 0u && !(v5 && (bq & 4u)))
+              {
+                const u32 cand[4] = { 64u, 8u * ragWl, 8u * ragHl, ragWl * ragHl };
+                u32 pick = 0u;
+                for (u32 ci = 0; ci < 4u && pick == 0u; ci++)
+                {
+                  if (cand[ci] == 0u) continue;
+                  const u32 e = xx + 1u + cand[ci] * G::TB;
+                  if (e > blobRel || e + 16u > G::kBytes) continue;
+                  const bool known = (k < n && e == (u32)s_list[k]) || (lastPiece && e == blobRel);
+                  if (known || (e < blobRel && parseBlock(e, false, 0u) != 0u)) pick = e - xx;
+                }
+                lx = pick;
+              }
+            }
+#ifdef HIPSIM
+            if (lx == 0u && lane == 0 && getenv("LERC_SIM_SCAN_DIAG"))
+            {
+              printf("piece %u: the walk stops at %u (blob offset %u; end target %u, blob end %u): no block there; bytes:", wg, xx, pieceStart + xx - PRE, endTarget, blobRel);
+              for (u32 j = 0; j < 24u; j++) printf(" %02x", (s_in[(xx + j) >> 2] >> (8u * ((xx + j) & 3u))) & 0xFFu);
+              printf("\n");
+            }
+#endif
             if (lx == 0u) return false;
             const u32 b0 = (s_in[xx >> 2] >> (8u * (xx & 3u))) & 0xFFu;
             u32 cnt = 1u;
@@ -1203,13 +1307,13 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   // (the block's word, offset and place out of LDS, bit width, mask, payload position, the address) is done once for eight pixels instead
   // of once for four; a wave tile is 8 blocks, a store instruction 4 raster rows of 256 bytes on end.  (The two vectors of one block ROW
   // in a lane were tried first: every store instruction then writes every other 16 bytes, and the kernel took 125 us instead of 100.)
-  constexpr int NV = (LERC_SCAN_WIDE && DT == DT_Float) ? 2 : 1;       // vectors a lane (32-bit integers: their 64-bit dequantiser leaves no registers for it)
+  constexpr int NV = (!RAG && LERC_SCAN_WIDE && DT == DT_Float) ? 2 : 1;       // vectors a lane (32-bit integers: their 64-bit dequantiser leaves no registers for it)
   constexpr int PXL = V * NV, BPWL = BPW * NV;                          // pixels a lane, blocks a wave tile
   constexpr int RSTEP = 8 / NV;                                         // rows between a lane's vectors
   struct alignas(sizeof(T) * V) Vec1 { T e[V]; };
   struct alignas(sizeof(T) * V) Vec { T e[PXL]; };
   constexpr u32 kHeldV = sizeof(T) == 2 ? LERC_SCAN_HELD16 : (DT == DT_Float || DT == DT_Double) ? LERC_SCAN_HELD : LERC_SCAN_HELD32;
-  constexpr u32 kHeld = kHeldV / (u32)NV;                               // (as many registers)
+  constexpr u32 kHeld = RAG ? 0u : kHeldV / (u32)NV;                    // (as many registers; RAG: none -- wave tiles on multiples of BPW blocks of the raster, as in the walking decoder)
   const int r = lane / (8 * NV), c = lane % (8 * NV), bb = c / LPR, h = c % LPR;    // row (of the lane's first vector), block of the wave tile, vector of the block row
   const i64 invI = (i64)p.invScale, zMaxI = (i64)p.zMaxHdr;
   bool bad = false;
@@ -1224,7 +1328,14 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     const double offset = DT < DT_Float ? (double)offBits : offRaw;    // (integer types keep the integer: see parseBlock)
     const u32 nbC = (code >> 16) & 31u, mode = (code >> 21) & 3u, lut = (code >> 23) & 1u;
     const u32 pbit = 8u * (code & 0xFFFFu);        // payload / first raw value
-    const int e0 = r * 8 + h * V;
+    int e0 = r * 8 + h * V, vc = V;                // the lane's first element of the block, and how many of its V pixels exist
+    if (RAG)
+    {
+      const u32 dims = have ? (u32)s_dims[tSlot] : 0x88u;
+      const int bw = (int)(dims & 15u), bh = (int)(dims >> 4);
+      e0 = r * bw + h * V;
+      vc = r < bh ? max(0, min(V, bw - h * V)) : 0;
+    }
     Vec o;
 #pragma unroll
     for (int k = 0; k < PXL; k++) o.e[k] = T(0);
@@ -1314,7 +1425,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
           for (int k = 0; k < PXL; k++)
           {
             u32 ix = ldsBits(s_in, idxBit + (u32)(e0 + (k / V) * 8 * RSTEP + k % V) * (u32)nbIdx, nbIdx);
-            if (ix > nLut) { ix = 0; bad = true; }    // the reference would read outside its table here
+            if (ix > nLut) { ix = 0; bad = bad || !RAG || (k % V) < vc; }    // the reference would read outside its table here (RAG: pixels that do not exist have no index)
             const u32 q = ix ? ldsBits(s_in, pbit + (ix - 1) * (u32)nb, nb) : 0u;
             o.e[k] = dequant<T>(offset, q, p.invScale, p.zMaxHdr, offI, invI, zMaxI);
           }
@@ -1324,8 +1435,11 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     return o;
   };
   const u32 grp = wg / kOneGroup, g0 = grp * kOneGroup, nIn = wg - g0;
-  const u32 nCells = nIn + grp + ((nIn == 0u && wg != 0u) ? 1u : 0u);
-  auto cellOf = [&](u32 i) -> const u64* { return i < nIn ? b.wgCell + g0 + i : i < nIn + grp ? b.wgGroupCell + (i - nIn) : b.wgCell + (wg - 1u); };
+  // (tuning, LERC_SCAN_DIRECT=n: the launch's first n pieces -- resident together -- add up the cells of ALL the pieces in front of them instead of
+  // their group's and the groups' totals: no chain through the groups' last pieces while everybody starts at once)
+  const bool direct = LERC_SCAN_DIRECT != 0 && !OFFS && wg < (u32)LERC_SCAN_DIRECT;
+  const u32 nCells = direct ? wg : nIn + grp + ((nIn == 0u && wg != 0u) ? 1u : 0u);
+  auto cellOf = [&](u32 i) -> const u64* { return direct ? b.wgCell + i : i < nIn ? b.wgCell + g0 + i : i < nIn + grp ? b.wgGroupCell + (i - nIn) : b.wgCell + (wg - 1u); };
   u64 cell0 = 0;
   if (threadIdx.x < nCells) cell0 = observe64(cellOf(threadIdx.x));
   const u32 nFirst = OFFS ? 0u : min(total, R);     // blocks of the first round: their headers are parsed
@@ -1349,8 +1463,9 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
         c = observe64(pc);
       }
       if ((u32)(c >> 32) != epoch) { lost = true; c = 0; }
-      else if (i == nIn - 1u || i == nIn + grp) S.prevExit = ((u32)c >> 16) & 0xFFFFu;    // (the piece right in front)
-      if (i < nIn + grp) part += i < nIn ? (u64)((u32)c & 0xFFFFu) : ((u64)(u32)c << 32);    // (a piece's cell: exit (16) | blocks (16))
+      else if (direct ? i == wg - 1u : (i == nIn - 1u || i == nIn + grp)) S.prevExit = ((u32)c >> 16) & 0xFFFFu;    // (the piece right in front)
+      if (direct) part += i >= g0 ? (u64)((u32)c & 0xFFFFu) : ((u64)((u32)c & 0xFFFFu) << 32);
+      else if (i < nIn + grp) part += i < nIn ? (u64)((u32)c & 0xFFFFu) : ((u64)(u32)c << 32);    // (a piece's cell: exit (16) | blocks (16))
     }
     if (__any(lost) && lane == 0) S.lost = 1u;
     if (nCells != 0u)
@@ -1443,6 +1558,28 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
         const u32 blk = base + f;          // index of the block in the raster
         const u32 it = pow2 ? (blk >> thShift) : blk / hp.nTH, jt = blk - it * hp.nTH;
         if (sigHdr != (jt & pattern) || blk >= hp.nBlocks) code = 0;    // signature = (j0 >> 3) & pattern, j0 = 8 jt
+        if (RAG)
+        {
+          // the block's size by its place; a bit-stuffed or raw block has to hold as many pixels as that (Lerc2.cpp:1504-1519)
+          const u32 nTV = ((u32)nRows + 7u) >> 3;
+          const u32 bw = (ragWl != 0u && jt == hp.nTH - 1u) ? ragWl : 8u, bh = (ragHl != 0u && it == nTV - 1u) ? ragHl : 8u;
+          {
+            // (a raw block says nothing of its size: it reaches to where the next block begins -- the list knows; parseBlock took it for a whole one)
+            const u32 posB = (u32)s_list[f], nextB = f + 1u < total ? (u32)s_list[f + 1u] : S.exitRel;
+            const u32 bq = (s_in[posB >> 2] >> (8u * (posB & 3u))) & 0xFFu;
+            if ((bq & 3u) == 0u && (bq >> 6) == 0u && !(v5 && (bq & 4u)) && nextB > posB && ragRawOk(nextB - posB) && sigHdr == (jt & pattern) && blk < hp.nBlocks)
+              code = ((posB + 1u) & 0xFFFFu) | 0x80000000u | ((((nextB - posB - 1u) / G::TB - 1u) & 63u) << 25);
+          }
+          const u32 modeB = (code >> 21) & 3u;
+          if (code && (modeB == 0u || modeB == 1u) && ((code >> 25) & 63u) + 1u != bw * bh) code = 0;
+          if (code) { code &= ~(63u << 25); s_code[t] = code; }
+          s_dims[t] = (u8)(bw | (bh << 4));
+        }
+#ifdef HIPSIM
+        if (code == 0u && getenv("LERC_SIM_SCAN_DIAG"))
+          printf("piece %u: block %u of the piece (raster block %u = row %u column %u of %u) does not belong there: word %08x, signature %u, at %u, next %u\n", wg, f, blk, it, jt, hp.nTH, s_code[t], sigHdr,
+                 (u32)s_list[f], f + 1u < total ? (u32)s_list[f + 1u] : S.exitRel);
+#endif
         if (code == 0u) { s_code[t] = 0u; bad = true; }
         s_at[t] = code ? (it * 8u) * (u32)p.nCols + jt * 8u : kNoOffset;
       }
@@ -1463,7 +1600,26 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
         }
       }
 #else
-      if (at0 != kNoOffset)
+      if (RAG)
+      {
+        if (at0 != kNoOffset)
+        {
+          const u32 dims = (u32)s_dims[tSlot];
+          const int bw = (int)(dims & 15u), bh = (int)(dims >> 4);
+          const int vc = r < bh ? max(0, min(V, bw - h * V)) : 0;
+          T* dst = outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V);
+          const size_t pitch = (size_t)p.nCols * sizeof(T);
+          Vec1 v1; memcpy(&v1, &o.e[0], sizeof(Vec1));
+          if (vc == V && (pitch & 15u) == 0u) DECODE_STORE(reinterpret_cast<Vec1*>(dst), v1);
+          else if (vc == V && sizeof(Vec1) == 16 && (pitch & 3u) == 0u) { if constexpr (sizeof(Vec1) == 16) storeStreamingA4(dst, v1); }    // (16 bytes at dword alignment)
+          else
+          {
+#pragma unroll
+            for (int k = 0; k < V; k++) if (k < vc) dst[k] = o.e[k];
+          }
+        }
+      }
+      else if (at0 != kNoOffset)
       {
         T* dst = outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V);
 #pragma unroll
@@ -1567,7 +1723,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
 #else
 #define LERC_SCAN_SGPR_CAP __attribute__((amdgpu_num_sgpr(80)))
 #endif
-template<class T>
+template<class T, bool RAG = false>
 __global__ void __launch_bounds__(kScanThreads) LERC_SCAN_SGPR_CAP
 k_fast_decode_scan(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 sizeGiven, u32 specEnd, int nRows, int nCols, T* __restrict__ outPix)
 {
@@ -1578,7 +1734,7 @@ k_fast_decode_scan(FastDecodeBuffers b, FastDecodeBatch t, const u8* blob, u32 s
   b.wgAcc += tile * b.wgGroupStride;
   if (t.tileOffset) { blob += t.tileOffset[tile]; sizeGiven = t.tileSize[tile]; }
   __shared__ ScanShared<T> sm;
-  fastScanBody<T, 0>(sm, b, blob, sizeGiven, specEnd, nRows, nCols, outPix + tile * t.tileElems, blockIdx.x, ScanOffsetsJob());
+  fastScanBody<T, 0, RAG>(sm, b, blob, sizeGiven, specEnd, nRows, nCols, outPix + tile * t.tileElems, blockIdx.x, ScanOffsetsJob());
 }
 
 // MODE 1: a masked band's block stream cut into blocks (see ScanOffsetsJob); no pixels, no checksum
@@ -1595,7 +1751,9 @@ static void launchFastDecodeScanT(int nRows, int nCols, const FastDecodeBatch& t
                                   hipStream_t st)
 {
   const dim3 grid(fastScanNumWG(b.scanGridBytes ? min(b.scanGridBytes, sizeGiven) : sizeGiven), t.nTiles), block(kScanThreads);    // (sizeGiven: the largest blob of the batch)
-  hipLaunchKernelGGL((k_fast_decode_scan<T>), grid, block, 0, st, b, t, blob, sizeGiven, b.scanSpecEnd, nRows, nCols, (T*)out);
+  // (rows / columns no multiples of 8: the instantiation that knows edge blocks)
+  if (nRows % 8 != 0 || nCols % 8 != 0) hipLaunchKernelGGL((k_fast_decode_scan<T, true>), grid, block, 0, st, b, t, blob, sizeGiven, b.scanSpecEnd, nRows, nCols, (T*)out);
+  else hipLaunchKernelGGL((k_fast_decode_scan<T, false>), grid, block, 0, st, b, t, blob, sizeGiven, b.scanSpecEnd, nRows, nCols, (T*)out);
 }
 
 // diagnostic: workgroups of the float kernel a CU holds, by the runtime's count
@@ -1610,7 +1768,11 @@ extern "C" __attribute__((visibility("default"))) int lerc_amd_probe_decode_scan
 #endif
 }
 
-bool fastDecodeScanEligible(int nRows, int nCols) { return nRows % 8 == 0 && nCols % 8 == 0; }
+bool fastDecodeScanEligible(int nRows, int nCols)
+{
+  static const bool ragOn = []() { const char* e = getenv("LERC_AMD_SCAN_RAGGED"); return !e || atoi(e) != 0; }();    // (0: ragged rasters keep to the walking tier)
+  return (nRows % 8 == 0 && nCols % 8 == 0) || (ragOn && nRows >= 8 && nCols >= 8);
+}
 
 // a masked band's block offsets by the scanning decoder's first half (8 x 8 blocks, one value per pixel, 16-bit and wider types)
 void launchFastScanOffsets(int dt, int nRows, int nCols, const u8* band, u32 version, u32 dataBegin, u32 blobEnd, u32* blockOff, u32 nPos,

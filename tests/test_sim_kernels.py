@@ -1509,6 +1509,53 @@ def test_sim_mask_and_statistics_in_one_read(libs):
         L.lerc_amd_destroy(h)
 
 
+def test_sim_ragged_rasters_on_the_scanning_decoder(libs):
+    """Rasters whose rows / columns are no multiples of 8 (the reference's own benchmark rasters: 4600 x 4300, 3612^2, 1201^2 ...): the scanning
+    decoder's RAG instantiation -- the filter also takes the count byte of the last block row's blocks (8 x rows mod 8), the one edge block a
+    block row comes in through the mending, a block's size is checked against its place, partial rows are stored pixel by pixel.  Pixels
+    = the oracle's, every band served by the scanning decoder (late counts: no launch thrown away); flat stretches and look-up tables
+    at the edges; all types."""
+    import ctypes as ct
+    O, S = libs
+    L = _async_lib(S)
+    L.lerc_amd_decode_forms.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+    L.lerc_amd_decode_refusals.argtypes = [ct.c_void_p, ct.POINTER(ct.c_ulonglong)]
+    L.lerc_amd_decode_device.restype = ct.c_uint
+    L.lerc_amd_decode_device.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_uint, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_uint, ct.c_void_p]
+    rng = np.random.default_rng(61)
+    h = L.lerc_amd_create(None)
+    assert h
+    try:
+        n_scan = 0
+        for dt, e, (r, c) in ((np.float32, 0.01, (257, 257)), (np.float32, 0.01, (100, 1027)), (np.uint16, 0, (129, 2050)), (np.int32, 0, (64, 1001)),
+                              (np.float32, 0.01, (203, 1024)), (np.float64, 0.001, (75, 515)), (np.int16, 1, (333, 517)), (np.uint32, 2, (90, 999)),
+                              (np.float32, 0.01, (1001, 131)), (np.uint16, 0, (8, 4099)), (np.float32, 0.1, (15, 3000))):
+            x = cases.terrain(r, c, rng, amp=300, base=1000, sigma=1.5)
+            if r > 64:
+                x[40:56, c - 40:] = 123.0          # flat up to the edge column
+                x[r - 12:, 16:200] = 77.0          # and in the last block row
+            x[:, 200:232] = np.floor(x[:, 200:232] / 32) * 32       # few distinct values: look-up tables
+            x = cases._cast(x, dt)
+            r0, b0 = O.encode(x, e)
+            assert r0 == 0
+            blob = _aligned(len(b0) + 4096)
+            blob[:] = 0
+            blob[:len(b0)] = np.frombuffer(b0, np.uint8)
+            out = _aligned(x.nbytes).view(x.dtype).reshape(x.shape)
+            f0 = (ct.c_ulonglong * 4)(); f1 = (ct.c_ulonglong * 4)(); q0 = (ct.c_ulonglong * 4)(); q1 = (ct.c_ulonglong * 4)()
+            L.lerc_amd_decode_forms(h, f0); L.lerc_amd_decode_refusals(h, q0)
+            rc = L.lerc_amd_decode_device(h, blob.ctypes.data, len(b0), 0, None, 1, c, r, 1, capi.dt_code(x.dtype), out.ctypes.data)
+            assert rc == 0
+            assert _same(O.decode(b0)[1].reshape(x.shape), out), (np.dtype(dt).name, r, c)
+            L.lerc_amd_decode_forms(h, f1); L.lerc_amd_decode_refusals(h, q1)
+            served = int(f1[3] - f0[3]) == 1 and int(q1[2] - q0[2]) == 0
+            n_scan += served
+            assert served or r < 16, (np.dtype(dt).name, r, c, [int(f1[k] - f0[k]) for k in range(4)], int(q1[2] - q0[2]))
+        assert n_scan >= 9, n_scan
+    finally:
+        L.lerc_amd_destroy(h)
+
+
 def test_sim_masked_bands_are_cut_into_blocks_by_the_scan(libs):
     """A band with a mask (8 x 8 blocks, one value a pixel, 16-bit and wider types): the scanning decoder's first half finds the block
     offsets (tile_fast_decode_scan.hip, MODE 1 -- count bytes of 1 ... 64, one-byte blocks of pixels that are all invalid walked by the
