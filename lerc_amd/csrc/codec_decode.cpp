@@ -218,7 +218,7 @@ static int pickForm(Context& ctx, int maxForm, int nRows, int nCols)
   {
     if (!scanOn || !fastDecodeScanEligible(nRows, nCols)) f = 2;
     else if (ctx.scanSkip > 0) { ctx.scanSkip--; f = 2; }
-    else if (f == 4 && (!earlyOn || nRows % 8 != 0 || nCols % 8 != 0)) f = 3;    // (ragged rasters: the edge blocks come in through the mending, every piece's count changes)
+    else if (f == 4 && !earlyOn) f = 3;
     else if (f == 4 && ctx.scanLate > 0) { ctx.scanLate--; f = 3; }
   }
   return f;

@@ -1294,7 +1294,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   {
     const u32 ex = S.exitRel >= pieceEndRel ? min(S.exitRel - pieceEndRel, 0xFFFDu) : 0xFFFFu;
     const u32 earlyCount = early ? S.earlyCount : 0u;
-    if (early && min(total, 0xFFFFu) != earlyCount) raiseFlag(b, 1);    // (the pieces behind have been told another count)
+    if (early && !lastPiece && min(total, 0xFFFFu) != earlyCount) raiseFlag(b, 1);    // (the pieces behind have been told another count; nobody is behind the last piece -- a ragged raster's corner block, a few pixels the scan does not see, is found there by the mending)
     publish64(b.wgCell + wg, tag | ((u64)ex << 16) | (u64)(early ? earlyCount : min(total, 0xFFFFu)));
   }
   // The blocks' places need the cells of the pieces in front -- those of this group, and one per group in front; the piece right in
@@ -1313,14 +1313,15 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   struct alignas(sizeof(T) * V) Vec1 { T e[V]; };
   struct alignas(sizeof(T) * V) Vec { T e[PXL]; };
   constexpr u32 kHeldV = sizeof(T) == 2 ? LERC_SCAN_HELD16 : (DT == DT_Float || DT == DT_Double) ? LERC_SCAN_HELD : LERC_SCAN_HELD32;
-  constexpr u32 kHeld = RAG ? 0u : kHeldV / (u32)NV;                    // (as many registers; RAG: none -- wave tiles on multiples of BPW blocks of the raster, as in the walking decoder)
+  constexpr u32 kHeld = RAG ? (kHeldV >= 2u ? kHeldV / 2u : kHeldV) / 1u : kHeldV / (u32)NV;                               // (as many registers; RAG: only wave tiles of whole, plain blocks are held -- an edge block's shape hangs on its place)
   const int r = lane / (8 * NV), c = lane % (8 * NV), bb = c / LPR, h = c % LPR;    // row (of the lane's first vector), block of the wave tile, vector of the block row
   const i64 invI = (i64)p.invScale, zMaxI = (i64)p.zMaxHdr;
   bool bad = false;
   // the lane's V pixels of the block in round slot tSlot (parseBlock's word and offset); a wave-uniform fast path for the common
   // case, all blocks of the wave alike: bit-stuffed without a table, the lane's V values inside 64 bits, no clamp -- three words
   // of the stream, one funnel shift each way, V shifts
-  auto blockRow = [&](u32 tSlot, bool have) -> Vec
+  bool tilePlain = false;    // RAG: the wave tile blockRow has just decoded holds whole, plain blocks only
+  auto blockRow = [&](u32 tSlot, bool have, bool dimsKnown = true) -> Vec
   {
     const u32 code = have ? s_code[tSlot] : 0u;
     const double offRaw = s_offs[tSlot];
@@ -1329,18 +1330,23 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     const u32 nbC = (code >> 16) & 31u, mode = (code >> 21) & 3u, lut = (code >> 23) & 1u;
     const u32 pbit = 8u * (code & 0xFFFFu);        // payload / first raw value
     int e0 = r * 8 + h * V, vc = V;                // the lane's first element of the block, and how many of its V pixels exist
-    if (RAG)
-    {
-      const u32 dims = have ? (u32)s_dims[tSlot] : 0x88u;
-      const int bw = (int)(dims & 15u), bh = (int)(dims >> 4);
-      e0 = r * bw + h * V;
-      vc = r < bh ? max(0, min(V, bw - h * V)) : 0;
-    }
     Vec o;
 #pragma unroll
     for (int k = 0; k < PXL; k++) o.e[k] = T(0);
     const bool plain = ((code >> 24) & 1u) != 0u;
-    if (__all(plain || !code))
+    const bool plainTile = __all(plain || !code);
+    if (RAG)
+    {
+      tilePlain = plainTile;                       // (a plain block is a whole one: the stores need no shapes either)
+      if (!plainTile)
+      {
+        const u32 dims = (have && dimsKnown) ? (u32)s_dims[tSlot] : 0x88u;
+        const int bw = (int)(dims & 15u), bh = (int)(dims >> 4);
+        e0 = r * bw + h * V;
+        vc = r < bh ? max(0, min(V, bw - h * V)) : 0;
+      }
+    }
+    if (plainTile)
     {
       if (code)
       {
@@ -1444,11 +1450,22 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
   if (threadIdx.x < nCells) cell0 = observe64(cellOf(threadIdx.x));
   const u32 nFirst = OFFS ? 0u : min(total, R);     // blocks of the first round: their headers are parsed
   Vec held[kHeld ? kHeld : 1u];
+  u32 heldMask = 0u;                               // RAG: wave tiles that are held (all their blocks whole and plain)
 #pragma unroll
   for (u32 j = 0; j < kHeld; j++)
   {
     const u32 f = (u32)BPWL * ((u32)w + kWaves * j) + (u32)bb;
-    if ((u32)BPWL * ((u32)w + kWaves * j) < nFirst) held[j] = blockRow(f, f < nFirst);    // (the same for all lanes of the wave)
+    if ((u32)BPWL * ((u32)w + kWaves * j) < nFirst)    // (the same for all lanes of the wave)
+    {
+      if (RAG)
+      {
+        const u32 cd = f < nFirst ? s_code[f] : 0u;
+        // (every block of the tile parsed, whole and plain: a block without a word yet -- a raw edge block gets its own when its place
+        // is known -- must not be held as zeros)
+        if (__all(f >= nFirst || ((cd >> 24) & 1u) != 0u)) { heldMask |= 1u << j; held[j] = blockRow(f, f < nFirst, false); }
+      }
+      else held[j] = blockRow(f, f < nFirst);
+    }
   }
   {
     u64 part = 0;
@@ -1586,7 +1603,8 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     }
     __syncthreads();
     const u32 nRound = fHi - fLo;
-    auto store = [&](u32 tSlot, const Vec& o)
+    const bool rowsAligned = (((size_t)p.nCols * sizeof(T)) & 15u) == 0u, rowsDword = sizeof(T) * V == 16 && (((size_t)p.nCols * sizeof(T)) & 3u) == 0u;
+    auto store = [&](u32 tSlot, const Vec& o, bool wholeTile = false)
     {
       const u32 at0 = s_at[tSlot];
 #ifdef LERC_TUNE_WRAP_STORES    // (tuning: the pixels written into the raster's first 4 MB over and over -- what the kernel takes without HBM writes; results invalid)
@@ -1600,7 +1618,23 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
         }
       }
 #else
-      if (RAG)
+      if (RAG && wholeTile)
+      {
+        // (whole blocks: a vector a lane -- aligned where the rows are, else 16 bytes at dword alignment, else pixel by pixel)
+        if (at0 != kNoOffset)
+        {
+          T* dst = outPix + (size_t)at0 + (size_t)r * (size_t)p.nCols + (size_t)(h * V);
+          Vec1 v1; memcpy(&v1, &o.e[0], sizeof(Vec1));
+          if (rowsAligned) DECODE_STORE(reinterpret_cast<Vec1*>(dst), v1);
+          else if (rowsDword) { if constexpr (sizeof(Vec1) == 16) storeStreamingA4(dst, v1); }
+          else
+          {
+#pragma unroll
+            for (int k = 0; k < V; k++) dst[k] = o.e[k];
+          }
+        }
+      }
+      else if (RAG)
       {
         if (at0 != kNoOffset)
         {
@@ -1651,7 +1685,12 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
       for (u32 j = 0; j < kHeld; j++)
       {
         const u32 tSlot = (u32)BPWL * ((u32)w + kWaves * j) + (u32)bb;
-        if (tSlot < nRound) store(tSlot, held[j]);
+        if (RAG && !((heldMask >> j) & 1u) && (u32)BPWL * ((u32)w + kWaves * j) < nRound)
+        {
+          const Vec o = blockRow(tSlot, tSlot < nRound);    // (not held: an edge block among the tile's, or a block that is not plain)
+          if (tSlot < nRound) store(tSlot, o, tilePlain);
+        }
+        else if (tSlot < nRound) store(tSlot, held[j], RAG);
       }
       jFrom = kHeld;
     }
@@ -1659,7 +1698,7 @@ fastScanBody(ScanShared<T>& S, const FastDecodeBuffers& b, const u8* __restrict_
     {
       const u32 tSlot = g * (u32)BPWL + (u32)bb;
       const Vec o = blockRow(tSlot, tSlot < nRound);
-      if (tSlot < nRound) store(tSlot, o);
+      if (tSlot < nRound) store(tSlot, o, RAG && tilePlain);
     }
     fLo = fHi;
     if (fLo < total) __syncthreads();    // (the round's arrays are taken again)

@@ -237,6 +237,40 @@ def test_flat_stretches_stay_on_the_scanning_decoder_at_full_size(P, O):
         assert seen == [(1, 1), (1, 0), (1, 0)], (seen, codec.last_note())
 
 
+def test_ragged_rasters_on_the_scanning_decoder_at_full_size(P, O):
+    """Rasters whose sides are no multiples of 8 -- the shapes the reference was benchmarked on -- decode on the scanning decoder (its RAG
+    instantiation: the edge blocks' count bytes in the filter, a block's size checked against its place, raw corner blocks, partial rows stored
+    pixel by pixel): pixels = the oracle's decode of the same blob, the blob = the oracle's, `decode_forms()[3]` counts the band.  8190 x 8190
+    float32 (rows at 8-byte alignment), 2049 x 4097 uint16 (odd pitch: pixel stores), 257 x 257 (a one-pixel raw corner), 1201 x 1001 int32."""
+    import torch
+    from lerc_amd import api, synth
+    for shape, dt, e in (((8190, 8190), torch.float32, 0.01), ((2049, 4097), "u16", 0), ((257, 257), torch.float32, 0.01), ((1201, 1001), torch.int32, 0),
+                         ((4300, 4600), torch.float32, 0.01)):
+        r, c = shape
+        x = synth.c2_float32(r + 8, c + 8, device="cuda:0")[:r, :c].contiguous()
+        if dt == "u16":
+            x = (x * 8).to(torch.int32).to(torch.uint16).contiguous()
+        elif dt == torch.int32:
+            x = (x * 8).to(torch.int32).contiguous()
+        codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
+        out = torch.empty(x.numel() * x.element_size() + (1 << 20), dtype=torch.uint8, device=x.device)
+        y = torch.zeros_like(x)
+        rc, nb = api.encode_device(codec, x, e, out)
+        assert rc == 0, codec.last_error()
+        f0 = codec.decode_forms()
+        rc = api.decode_device(codec, out, nb, y)
+        assert rc == 0, codec.last_error()
+        torch.cuda.synchronize()
+        f1 = codec.decode_forms()
+        assert f1[3] == f0[3] + 1, (shape, f0, f1, codec.last_note())
+        blob = out[:nb].cpu().numpy().tobytes()
+        xh = x.cpu().numpy()
+        rc, b2 = O.encode(xh, e)
+        assert rc == 0 and len(b2) == nb and sha(b2) == sha(blob), shape
+        rc, dec, _ = O.decode(blob)
+        assert rc == 0 and np.array_equal(dec.reshape(xh.shape), y.cpu().numpy()), shape
+
+
 def test_mask_and_statistics_in_one_read_at_full_size(P, O):
     """A masked 8192 x 4096 float32 band (and a uint16 one): the bit mask and the band's statistics come out of one kernel (the profile
     says which), the blob is the oracle's -- NaNs under the mask and beside it."""

@@ -15,7 +15,8 @@ lib = api.load_library()
 dev = torch.device("cuda:0")
 c3 = len(sys.argv) > 1 and sys.argv[1] == "c3"
 piece = int(os.environ.get("SCAN_PIECE", "32768"))
-x = synth.c3_uint16().to(dev) if c3 else synth.c2_float32(8192, 8192, device=dev)
+rag = len(sys.argv) > 1 and sys.argv[1] == "ragged"
+x = synth.c3_uint16().to(dev) if c3 else synth.c2_float32(8190, 8190, device=dev) if rag else synth.c2_float32(8192, 8192, device=dev)
 codec = api.DeviceCodec(torch.cuda.current_stream().cuda_stream)
 blob = torch.empty(x.numel() * x.element_size() + 4096, dtype=torch.uint8, device=dev)
 y = torch.empty_like(x)
