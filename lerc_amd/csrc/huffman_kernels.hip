@@ -969,19 +969,34 @@ __global__ void __launch_bounds__(256) k_huff_undelta_rows(T* __restrict__ data,
 // the row of every plane and writes the interleaved pixels out of LDS in whole words.
 static const int kHuffInterleaveMax = 16;
 
-__global__ void __launch_bounds__(256) k_huff_undelta_col0_planar(u8* __restrict__ planar, HuffGeom g)
+// (a workgroup of 1024 threads per plane, a thread takes a stretch of consecutive rows: all its loads -- one byte a row, a row apart: a
+// cache line each -- are in flight together, and ONE scan over the threads' sums follows; 256 rows a round with a scan each took sixteen
+// dependent rounds for 4096 rows, most of the predictor's 58 us)
+__global__ void __launch_bounds__(1024) k_huff_undelta_col0_planar(u8* __restrict__ planar, HuffGeom g)
 {
-  __shared__ u32 s_wave[4];
+  __shared__ u32 s_wave[16];
+  constexpr int kPer = 8;                            // rows a thread and round
   u8* plane = planar + (i64)blockIdx.x * g.nRows * g.nCols;
+  const int lane = laneId(), w = waveId();
   u32 carry = 0;
-  for (int i0 = 0; i0 < g.nRows; i0 += 256)
+  for (int i0 = 0; i0 < g.nRows; i0 += 1024 * kPer)
   {
-    const int i = i0 + (int)threadIdx.x;
-    const i64 at = (i64)i * g.nCols;
-    const u32 d = (i < g.nRows) ? (u32)plane[at] : 0u;
-    u32 total;
-    const u32 before = undeltaWorkgroupScan(d, s_wave, total);
-    if (i < g.nRows) plane[at] = (u8)(carry + before + d);
+    const int iMine = i0 + (int)threadIdx.x * kPer;
+    u32 d[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; k++) d[k] = (iMine + k < g.nRows) ? (u32)plane[(i64)(iMine + k) * g.nCols] : 0u;
+#pragma unroll
+    for (int k = 1; k < kPer; k++) d[k] += d[k - 1];
+    u32 inc = d[kPer - 1];
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) { const u32 t = __shfl_up(inc, (unsigned)s); if (lane >= s) inc += t; }
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    u32 before = carry + inc - d[kPer - 1], total = 0;
+    for (int i = 0; i < 16; i++) { const u32 t = s_wave[i]; if (i < w) before += t; total += t; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPer; k++) if (iMine + k < g.nRows) plane[(i64)(iMine + k) * g.nCols] = (u8)(before + d[k]);
     carry += total;
   }
 }
@@ -1030,7 +1045,7 @@ bool huffPlanarDecode(int imageMode, const u8* maskBits, int nDepth)
 
 void launchHuffUndeltaPlanar(u8* planar, void* out, const HuffGeom& g, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_huff_undelta_col0_planar, dim3(g.nDepth), dim3(256), 0, st, planar, g);
+  hipLaunchKernelGGL(k_huff_undelta_col0_planar, dim3(g.nDepth), dim3(1024), 0, st, planar, g);
   hipLaunchKernelGGL(k_huff_undelta_rows_interleave, dim3(g.nRows), dim3(256), 0, st, (const u8*)planar, (u8*)out, g);
 }
 
