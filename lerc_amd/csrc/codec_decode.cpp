@@ -218,7 +218,7 @@ static int pickForm(Context& ctx, int maxForm, int nRows, int nCols)
   {
     if (!scanOn || !fastDecodeScanEligible(nRows, nCols)) f = 2;
     else if (ctx.scanSkip > 0) { ctx.scanSkip--; f = 2; }
-    else if (f == 4 && !earlyOn) f = 3;
+    else if (f == 4 && (!earlyOn || nRows % 8 != 0 || nCols % 8 != 0)) f = 3;    // (ragged rasters count late: three count values in their filter make false survivors -- which the mending strikes, changing a count -- likelier: one piece in 3 244 of the 8190^2 raster, enough to throw every early launch away)
     else if (f == 4 && ctx.scanLate > 0) { ctx.scanLate--; f = 3; }
   }
   return f;

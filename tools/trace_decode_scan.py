@@ -50,3 +50,8 @@ pos = np.arange(n_t) % 64
 print("   wait by position in the group (0, 1, 8, 32, 62, 63): " + " ".join("%.2f" % wait[pos == q].mean() for q in (0, 1, 8, 32, 62, 63)))
 life = us[:, 6] - us[:, 0]
 print("   life by tenth of the stream: " + " ".join("%.1f" % life[i * n_t // 10:(i + 1) * n_t // 10].mean() for i in range(10)))
+# pieces that were mended (TRACEV slots: 7 = pass | frontBad << 4 | broken links << 8 | entries << 16; 11 = over | bad << 1 | verdict bad << 2 | mended << 3; 14 / 15 = runs entered / entries struck)
+flags = tt[:, 11]
+mended = np.nonzero(flags & 8)[0]
+print("   pieces mended: %d of %d; first: %s" % (len(mended), len(tt), [(int(i), int(tt[i, 7]) >> 8 & 0xFF, int(tt[i, 7]) >> 4 & 1, int(tt[i, 14]), int(tt[i, 15])) for i in mended[:8]]), "(piece, broken links, front gap, runs, struck)")
+print("   pieces flagged bad: %d" % int(np.count_nonzero(flags & 6)))
