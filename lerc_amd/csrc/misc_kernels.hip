@@ -97,33 +97,46 @@ void launchExclusiveScan(const u32* in, u32* out, u32 n, u32* scratch, hipStream
 // ================================================================================================
 static const int kFletcherBlocks = 512;
 
-__global__ void __launch_bounds__(256) k_fletcher(const u8* __restrict__ bytes, u32 len, u64* __restrict__ partials)
+// (1024 threads a workgroup: 512 workgroups of 256 threads were two waves a SIMD, and a wave that asks for one vector at a time is
+// latency; a unit that begins at an even byte -- every band's checksummed bytes do: they begin 14 bytes into a 16-byte aligned blob -- is
+// summed by two byte permutes and 16-bit dot products (wave_utils.h: fletcherUnit) instead of sixteen byte extractions)
+__global__ void __launch_bounds__(1024) k_fletcher(const u8* __restrict__ bytes, u32 len, u64* __restrict__ partials)
 {
-  __shared__ u64 s_a[4], s_b[4];
+  __shared__ u64 s_a[16], s_b[16];
   u64 A = 0, B = 0;
-  const u32 stride = gridDim.x * 256u;
+  const u32 stride = gridDim.x * blockDim.x;
   // 16 bytes per load from the first 16-byte aligned address on; byte p counts as (byte << 8) when p is even, with
   // weight p >> 1 -- inside a vector the weights are (q >> 1) + small constants, so the 64-bit product is paid once
   const u32 head = min(len, (u32)((16u - ((u32)(uintptr_t)bytes & 15u)) & 15u));
   const u32 nVec = (len - head) >> 4;
   const uint4* vec = reinterpret_cast<const uint4*>(bytes + head);
-  for (u32 i = blockIdx.x * 256u + threadIdx.x; i < nVec; i += stride)
+  if ((head & 1u) == 0u)
   {
-    const u32 q = head + (i << 4), odd = q & 1u;
-    const uint4 x = vec[i];
-    const u32 w[4] = { x.x, x.y, x.z, x.w };
-    u32 sumC = 0, inner = 0;
-#pragma unroll
-    for (u32 j = 0; j < 16u; j++)
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nVec; i += stride)
     {
-      const u32 byte = (w[j >> 2] >> (8u * (j & 3u))) & 255u;
-      const u32 c = byte << (((odd + j) & 1u) ? 0u : 8u);
-      sumC += c;
-      inner += ((odd + j) >> 1) * c;
+      u32 a32 = 0;
+      fletcherUnit(vec[i], (u64)((head + (i << 4)) >> 1), a32, B);
+      A += a32;
     }
-    A += sumC;
-    B += (u64)(q >> 1) * sumC + inner;
   }
+  else
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nVec; i += stride)
+    {
+      const u32 q = head + (i << 4), odd = q & 1u;
+      const uint4 x = vec[i];
+      const u32 w[4] = { x.x, x.y, x.z, x.w };
+      u32 sumC = 0, inner = 0;
+#pragma unroll
+      for (u32 j = 0; j < 16u; j++)
+      {
+        const u32 byte = (w[j >> 2] >> (8u * (j & 3u))) & 255u;
+        const u32 c = byte << (((odd + j) & 1u) ? 0u : 8u);
+        sumC += c;
+        inner += ((odd + j) >> 1) * c;
+      }
+      A += sumC;
+      B += (u64)(q >> 1) * sumC + inner;
+    }
   if (blockIdx.x == 0 && threadIdx.x == 0)
   {
     for (u32 p = 0; p < head; p++) { const u32 c = (u32)bytes[p] << ((p & 1u) ? 0 : 8); A += c; B += (u64)(p >> 1) * c; }
@@ -135,15 +148,17 @@ __global__ void __launch_bounds__(256) k_fletcher(const u8* __restrict__ bytes, 
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    partials[2 * blockIdx.x] = (s_a[0] + s_a[1] + s_a[2] + s_a[3]) % 65535u;
-    partials[2 * blockIdx.x + 1] = (s_b[0] + s_b[1] + s_b[2] + s_b[3]) % 65535u;
+    u64 a = 0, b = 0;
+    for (u32 k = 0; k < blockDim.x / 64u; k++) { a += s_a[k]; b += s_b[k]; }
+    partials[2 * blockIdx.x] = a % 65535u;
+    partials[2 * blockIdx.x + 1] = b % 65535u;
   }
 }
 
 // acc: 2 * kFletcherBlocks u64 words
 void launchFletcher(const u8* blob, u32 len, u64* acc, hipStream_t stream)
 {
-  hipLaunchKernelGGL(k_fletcher, dim3(kFletcherBlocks), dim3(256), 0, stream, blob, len, acc);
+  hipLaunchKernelGGL(k_fletcher, dim3(kFletcherBlocks), dim3(len >= (1u << 22) ? 1024 : 256), 0, stream, blob, len, acc);    // (small blobs: no more threads than vectors)
 }
 
 // folds launchFletcher's partials and writes the finished checksum (four bytes, any alignment) -- so that an encoder need
