@@ -201,7 +201,7 @@ static const u32 kScanSkip = 16;
 // counted.  A piece whose check or mending comes to another count -- a stream with blocks the scan does not see: constant, all zero,
 // raw -- raises a flag, and the band is decoded once more by form 3, which counts late and mends; the bands of one job are alike, so
 // the next kScanLate decodes start there.
-static const u32 kScanLate = 64;
+static const u32 kScanLate = 64;    // (the first time; four times as many after every further one, up to 4 096: Context::scanLateSpan)
 static bool scanOffsetsOn()    // (LERC_AMD_SCAN_OFFSETS=0: masked bands keep to the general discovery)
 {
   static const bool on = []() { const char* e = getenv("LERC_AMD_SCAN_OFFSETS"); return !e || atoi(e) != 0; }();
@@ -304,7 +304,7 @@ bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits, 
     if (gridTooSmall) ctx.scanHint.end = 0u;
   }
   if (form == 3 && (verdict & 0x7u) && !(verdict & 0x300u) && !gridTooSmall) ctx.scanSkip = kScanSkip;    // (a stream the scanning decoder does not follow)
-  if (form == 4 && (verdict & 0x7u) && !(verdict & 0x300u) && !gridTooSmall) ctx.scanLate = kScanLate;    // (an early count was wrong: the late form mends)
+  if (form == 4 && (verdict & 0x7u) && !(verdict & 0x300u) && !gridTooSmall) { ctx.scanLate = ctx.scanLateSpan; ctx.scanLateSpan = std::min<u32>(ctx.scanLateSpan * 4u, 4096u); }    // (an early count was wrong: the late form mends)
   if (verdict)
   {
     char msg[128];
@@ -869,7 +869,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     if (verdict & 0x8u) ctx.wipePersistentState();    // (a workgroup gave up waiting: the checksum accumulators may hold residue)
     if (verdict & 0x200u) return kFailed;    // decoded, but the checksum is wrong
     if (fastLevel == 3 && (verdict & 0x7u) && !(verdict & 0x300u)) ctx.scanSkip = kScanSkip;
-    if (fastLevel == 4 && (verdict & 0x7u) && !(verdict & 0x300u)) ctx.scanLate = kScanLate;
+    if (fastLevel == 4 && (verdict & 0x7u) && !(verdict & 0x300u)) { ctx.scanLate = ctx.scanLateSpan; ctx.scanLateSpan = std::min<u32>(ctx.scanLateSpan * 4u, 4096u); }
     if (verdict)                             // caller repeats with the general kernels
     {
       char msg[96];
@@ -1069,7 +1069,7 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
       }
     }
     if (batchForm == 3 && redo.size() > (size_t)n / 8) ctx.scanSkip = kScanSkip;    // (tiles the scanning decoder does not follow: the next batches start one tier down)
-    if (batchForm == 4 && redo.size() > (size_t)n / 8) ctx.scanLate = kScanLate;    // (early counts that were wrong: the next batches count late)
+    if (batchForm == 4 && redo.size() > (size_t)n / 8) { ctx.scanLate = ctx.scanLateSpan; ctx.scanLateSpan = std::min<u32>(ctx.scanLateSpan * 4u, 4096u); }    // (early counts that were wrong: the next batches count late)
     for (int t : redo) { const u32 rc = decodeOne(t); if (rc != kOk) return rc; }    // (reuses the workspace: the batch is done with it)
   }
   return kOk;
