@@ -252,6 +252,7 @@ def other_config(torch, api, codec, name, x, max_z_err, n_depth, steps=5, warmup
         torch.cuda.synchronize()
         dec.zero_()
         L.lerc_amd_profile_enable(codec.h, 1)
+        refq0 = codec.decode_refusals()
         tq0 = time.perf_counter()
         tickets = [pair() for _ in range(steps)]
         bad = [codec.finish(t)[0] for pr in tickets for t in pr]
@@ -267,6 +268,8 @@ def other_config(torch, api, codec, name, x, max_z_err, n_depth, steps=5, warmup
         okq = not any(bad) and (bool(torch.equal(dec.view(torch.uint8), x.view(torch.uint8))) if max_z_err == 0 else True)
         res["queued"] = {"value": round(n_pix * steps / elq / 1e6, 2), "ms_per_step": round(msq, 4),
                          "frac_of_hbm_peak_wall": round(b_rt / (msq / 1e3) / 1e9 / HBM_PEAK_GBS, 5), "kernels": kq, "verified": bool(okq),
+                         # (a decode whose streaming form hands the band on is repeated at finish time, and so is everything enqueued behind it)
+                         "tier_handed_on": codec.decode_refusals()[2] - refq0[2], "last_note": codec.last_note(),
                          "host": "steps enqueued on the stream, one wait at the end (lerc_amd_encode_device_async / lerc_amd_decode_device_async)"}
     if mask is not None:
         res["mask_and_error_bound_hold"] = res.pop("lossless_round_trip")

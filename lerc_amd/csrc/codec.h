@@ -94,6 +94,7 @@ public:
   int blindShape[3] = { -1, 0, 0 };
   bool scanOffsetsBan = false;         // this call: a masked band's scan for block offsets has failed, the general discovery takes the bands
   u32 scanLateSpan = 64;               // how many decodes the next wrong early count keeps the context on late counts (grows: 64, 256, ... 4096)
+  int scanLateRows = 0, scanLateCols = 0;    // ... and the shape of the band whose early count was wrong: the window is for bands of that shape
   u32 scanLate = 0;                    // decodes whose scanning decoder counts late: an early count has just turned out wrong (a stream with blocks the scan does not see: the mending found them)
   u32 lastScanGridBytes = 0;           // blob bytes the scanning decoder's last launch held pieces for (launchFastBands)
   u32 scanSkip = 0;                    // decodes that keep off the scanning decoder: it has just handed a band on (a stream with blocks it cannot see)

@@ -219,7 +219,7 @@ static int pickForm(Context& ctx, int maxForm, int nRows, int nCols)
     if (!scanOn || !fastDecodeScanEligible(nRows, nCols)) f = 2;
     else if (ctx.scanSkip > 0) { ctx.scanSkip--; f = 2; }
     else if (f == 4 && (!earlyOn || nRows % 8 != 0 || nCols % 8 != 0)) f = 3;    // (ragged rasters count late: three count values in their filter make false survivors -- which the mending strikes, changing a count -- likelier: one piece in 3 244 of the 8190^2 raster, enough to throw every early launch away)
-    else if (f == 4 && ctx.scanLate > 0) { ctx.scanLate--; f = 3; }
+    else if (f == 4 && ctx.scanLate > 0 && ctx.scanLateRows == nRows && ctx.scanLateCols == nCols) { ctx.scanLate--; f = 3; }    // (the bands of that shape: another job's rasters have streams of their own)
   }
   return f;
 }
@@ -304,7 +304,12 @@ bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits, 
     if (gridTooSmall) ctx.scanHint.end = 0u;
   }
   if (form == 3 && (verdict & 0x7u) && !(verdict & 0x300u) && !gridTooSmall) ctx.scanSkip = kScanSkip;    // (a stream the scanning decoder does not follow)
-  if (form == 4 && (verdict & 0x7u) && !(verdict & 0x300u) && !gridTooSmall) { ctx.scanLate = ctx.scanLateSpan; ctx.scanLateSpan = std::min<u32>(ctx.scanLateSpan * 4u, 4096u); }    // (an early count was wrong: the late form mends)
+  if (form == 4 && (verdict & 0x7u) && !(verdict & 0x300u) && !gridTooSmall) {
+    FastDecodeParams hpL;
+    memcpy(&hpL, slot + 64 + kCellParams, sizeof(hpL));
+    ctx.scanLate = ctx.scanLateSpan; ctx.scanLateSpan = std::min<u32>(ctx.scanLateSpan * 4u, 4096u);
+    ctx.scanLateRows = (int)hpL.nRows; ctx.scanLateCols = (int)hpL.nCols;
+  }    // (an early count was wrong: the late form mends)
   if (verdict)
   {
     char msg[128];
@@ -869,7 +874,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     if (verdict & 0x8u) ctx.wipePersistentState();    // (a workgroup gave up waiting: the checksum accumulators may hold residue)
     if (verdict & 0x200u) return kFailed;    // decoded, but the checksum is wrong
     if (fastLevel == 3 && (verdict & 0x7u) && !(verdict & 0x300u)) ctx.scanSkip = kScanSkip;
-    if (fastLevel == 4 && (verdict & 0x7u) && !(verdict & 0x300u)) { ctx.scanLate = ctx.scanLateSpan; ctx.scanLateSpan = std::min<u32>(ctx.scanLateSpan * 4u, 4096u); }
+    if (fastLevel == 4 && (verdict & 0x7u) && !(verdict & 0x300u)) { ctx.scanLate = ctx.scanLateSpan; ctx.scanLateSpan = std::min<u32>(ctx.scanLateSpan * 4u, 4096u); ctx.scanLateRows = nRows; ctx.scanLateCols = nCols; }
     if (verdict)                             // caller repeats with the general kernels
     {
       char msg[96];
@@ -1069,7 +1074,7 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
       }
     }
     if (batchForm == 3 && redo.size() > (size_t)n / 8) ctx.scanSkip = kScanSkip;    // (tiles the scanning decoder does not follow: the next batches start one tier down)
-    if (batchForm == 4 && redo.size() > (size_t)n / 8) { ctx.scanLate = ctx.scanLateSpan; ctx.scanLateSpan = std::min<u32>(ctx.scanLateSpan * 4u, 4096u); }    // (early counts that were wrong: the next batches count late)
+    if (batchForm == 4 && redo.size() > (size_t)n / 8) { ctx.scanLate = ctx.scanLateSpan; ctx.scanLateSpan = std::min<u32>(ctx.scanLateSpan * 4u, 4096u); ctx.scanLateRows = rq.nRows; ctx.scanLateCols = rq.nCols; }    // (early counts that were wrong: the next batches count late)
     for (int t : redo) { const u32 rc = decodeOne(t); if (rc != kOk) return rc; }    // (reuses the workspace: the batch is done with it)
   }
   return kOk;
