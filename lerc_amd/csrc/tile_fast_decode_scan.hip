@@ -22,12 +22,16 @@
 //      front is right by the same argument, the first piece begins with the stream's first block, the last one has to end
 //      with the blob, and the blocks have to be as many as the raster has;
 //   5. where the list does not tile (a false survivor; blocks that are not bit-stuffed -- constant, all zero, raw -- which the
-//      scan does not see, and the block behind each of them, which has no END) ONE thread mends it: survivors inside a good
-//      block's extent are struck, gaps are walked block by block and what is found there entered, and if the list's first entry
-//      is the false one the mending starts from the second.  A piece that needs more than a few such steps gives up; the host
-//      then takes the band to the next tier (and keeps to it for a while: codec_decode.cpp);
-//   6. count out (an epoch-tagged cell: blocks of the piece, where its last block ends), the cells of the pieces in front added
-//      up -- the only wait --, then the pixels as in tile_fast_decode_one.hip: lane = V pixels of one block row.
+//      scan does not see, and the block behind each of them, which has no END) the piece's first WAVE mends it (a masked band: one
+//      thread): survivors inside a good block's extent are struck, gaps are walked and what is found there entered -- a RUN of
+//      constant / all-zero blocks (a flat stretch of the raster: hundreds on end) 64 blocks a step, lane i looking i block lengths
+//      on --, and a piece that begins inside such a run (no anchor in the bytes in front of it) takes its first block's place from
+//      the piece in front.  A piece that needs more than its tables hold gives up; the host then takes the band to the next tier
+//      (and keeps to it for a while: codec_decode.cpp);
+//   6. count out (an epoch-tagged cell: blocks of the piece, where its last block ends -- EARLY, form 4: the count leaves as soon as
+//      the survivors are counted, before steps 4 - 5; a piece whose final count differs says so and the band is decoded once more with
+//      late counts), the cells of the pieces in front added up -- the only wait --, then the pixels as in tile_fast_decode_one.hip:
+//      lane = V pixels of one block row (float: of two).
 // Two more rules keep false candidates rare: a candidate is no longer than its raw form would be, and the byte where it ends has
 // to read like the flag byte of the next block -- the column signature going on, by a step or none, or beginning again with a
 // block row (four in five of anything else do not).  The ANCHOR -- where the piece's first block begins -- comes from the last
@@ -41,7 +45,9 @@
 // that parse, the signature going on in pairs, up to a known block -- a guess the decode kernels, which have the mask, may refuse:
 // the general discovery then takes the band).  A piece owns the blocks that begin in its bytes.  Limits: 2048 blocks a piece (streams
 // of mostly one-byte blocks go to the general discovery), 8 x 8 blocks, one value a pixel, 16-bit and wider types.
-// Rasters whose rows / columns are no multiples of 8 keep to the next tier (their edge blocks have other counts).
+// Rasters whose rows / columns are no multiples of 8 take the RAG instantiation: the edge blocks' count bytes (8 x rows mod 8, 8 x columns
+// mod 8) in the filter beside 64, a block's size checked against its place, raw edge blocks sized by where the next block begins,
+// partial rows stored pixel by pixel (Lerc2.cpp:1504-1519).
 // Reference: Lerc2.cpp:1672-1713, :2025-2230; BitStuffer2.cpp:159-258, :476-540; Lerc2.cpp:1037-1064 (checksum).
 #include "tile_fast_decode_dev.h"
 #include <cstddef>
