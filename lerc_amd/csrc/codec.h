@@ -97,6 +97,7 @@ public:
   int scanLateRows = 0, scanLateCols = 0;    // ... and the shape of the band whose early count was wrong: the window is for bands of that shape
   u32 scanLate = 0;                    // decodes whose scanning decoder counts late: an early count has just turned out wrong (a stream with blocks the scan does not see: the mending found them)
   u32 lastScanGridBytes = 0;           // blob bytes the scanning decoder's last launch held pieces for (launchFastBands)
+  int scanSkipRows = 0, scanSkipCols = 0;    // ... of that shape
   u32 scanSkip = 0;                    // decodes that keep off the scanning decoder: it has just handed a band on (a stream with blocks it cannot see)
 
   // optional per-kernel timing with HIP events on the active stream (bench.py: roofline of the dominant kernel)

@@ -217,7 +217,7 @@ static int pickForm(Context& ctx, int maxForm, int nRows, int nCols)
   if (f >= 3)
   {
     if (!scanOn || !fastDecodeScanEligible(nRows, nCols)) f = 2;
-    else if (ctx.scanSkip > 0) { ctx.scanSkip--; f = 2; }
+    else if (ctx.scanSkip > 0 && ctx.scanSkipRows == nRows && ctx.scanSkipCols == nCols) { ctx.scanSkip--; f = 2; }    // (bands of the shape that was handed on: the bands of one job are alike, another job's are not)
     else if (f == 4 && (!earlyOn || nRows % 8 != 0 || nCols % 8 != 0)) f = 3;    // (ragged rasters count late: three count values in their filter make false survivors -- which the mending strikes, changing a count -- likelier: one piece in 3 244 of the 8190^2 raster, enough to throw every early launch away)
     else if (f == 4 && ctx.scanLate > 0 && ctx.scanLateRows == nRows && ctx.scanLateCols == nCols) { ctx.scanLate--; f = 3; }    // (the bands of that shape: another job's rasters have streams of their own)
   }
@@ -303,7 +303,12 @@ bool decodeStreamingVerdict(Context& ctx, const u8* slot, u32 epoch, u32* bits, 
     gridTooSmall = ctx.lastScanGridBytes != 0u && fastScanNumWG(hp.blobEnd) > fastScanNumWG(ctx.lastScanGridBytes);
     if (gridTooSmall) ctx.scanHint.end = 0u;
   }
-  if (form == 3 && (verdict & 0x7u) && !(verdict & 0x300u) && !gridTooSmall) ctx.scanSkip = kScanSkip;    // (a stream the scanning decoder does not follow)
+  if (form == 3 && (verdict & 0x7u) && !(verdict & 0x300u) && !gridTooSmall)    // (a stream the scanning decoder does not follow)
+  {
+    FastDecodeParams hpS;
+    memcpy(&hpS, slot + 64 + kCellParams, sizeof(hpS));
+    ctx.scanSkip = kScanSkip; ctx.scanSkipRows = (int)hpS.nRows; ctx.scanSkipCols = (int)hpS.nCols;
+  }
   if (form == 4 && (verdict & 0x7u) && !(verdict & 0x300u) && !gridTooSmall) {
     FastDecodeParams hpL;
     memcpy(&hpL, slot + 64 + kCellParams, sizeof(hpL));
@@ -873,7 +878,7 @@ static u32 decodeImpl(Context& ctx, const DecodeRequest& rq, int fastLevel, bool
     const u32 verdict = fastBandVerdict(pin + 64 + (size_t)iBand * kCellBytes, fast[iBand].epoch);
     if (verdict & 0x8u) ctx.wipePersistentState();    // (a workgroup gave up waiting: the checksum accumulators may hold residue)
     if (verdict & 0x200u) return kFailed;    // decoded, but the checksum is wrong
-    if (fastLevel == 3 && (verdict & 0x7u) && !(verdict & 0x300u)) ctx.scanSkip = kScanSkip;
+    if (fastLevel == 3 && (verdict & 0x7u) && !(verdict & 0x300u)) { ctx.scanSkip = kScanSkip; ctx.scanSkipRows = nRows; ctx.scanSkipCols = nCols; }
     if (fastLevel == 4 && (verdict & 0x7u) && !(verdict & 0x300u)) { ctx.scanLate = ctx.scanLateSpan; ctx.scanLateSpan = std::min<u32>(ctx.scanLateSpan * 4u, 4096u); ctx.scanLateRows = nRows; ctx.scanLateCols = nCols; }
     if (verdict)                             // caller repeats with the general kernels
     {
@@ -945,7 +950,6 @@ u32 decodeDevice(Context& ctx, const DecodeRequest& rq)
     bool handled = false, tried = false;
     DecodeRequest r = rq;
     r.maxForm = level;
-    if (level >= 3) ctx.scanSkip = 0;    // (pickForm has just said so: the request below must get the same answer)
     u32 bits = 0;
     const u32 src = decodeSpeculative(ctx, r, handled, tried, &bits);
     if (src != kOk) return src;
@@ -1073,7 +1077,7 @@ u32 decodeTilesDevice(Context& ctx, const TilesDecodeRequest& rq)
         redo.push_back(t0 + i);
       }
     }
-    if (batchForm == 3 && redo.size() > (size_t)n / 8) ctx.scanSkip = kScanSkip;    // (tiles the scanning decoder does not follow: the next batches start one tier down)
+    if (batchForm == 3 && redo.size() > (size_t)n / 8) { ctx.scanSkip = kScanSkip; ctx.scanSkipRows = rq.nRows; ctx.scanSkipCols = rq.nCols; }    // (tiles the scanning decoder does not follow: the next batches start one tier down)
     if (batchForm == 4 && redo.size() > (size_t)n / 8) { ctx.scanLate = ctx.scanLateSpan; ctx.scanLateSpan = std::min<u32>(ctx.scanLateSpan * 4u, 4096u); ctx.scanLateRows = rq.nRows; ctx.scanLateCols = rq.nCols; }    // (early counts that were wrong: the next batches count late)
     for (int t : redo) { const u32 rc = decodeOne(t); if (rc != kOk) return rc; }    // (reuses the workspace: the batch is done with it)
   }
